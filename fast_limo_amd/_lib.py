@@ -1,0 +1,276 @@
+"""ctypes loader for the in-tree native libraries.
+
+``libflimo_hip.so``  -- HIP kernels + C ABI declared in ``include/flimo_c.h`` (the drop-in boundary)
+``libfast_limo.so``  -- host C++ mirror of the reference's Localizer / Mapper / esekf on top of it
+
+There is no Python or CPU fallback: if a library is missing or no gfx950 device is present the
+calls raise (``FlimoError``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_PKG)
+
+f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+
+
+class FlimoError(RuntimeError):
+    pass
+
+
+class MapCfg(C.Structure):
+    _fields_ = [("min_extent", C.c_float), ("bucket_size", C.c_int), ("downsample", C.c_int),
+                ("cell_size", C.c_float)]
+
+
+class MatchCfg(C.Structure):
+    _fields_ = [("NUM_MATCH_POINTS", C.c_int), ("MAX_NUM_MATCHES", C.c_int), ("MAX_NUM_PC2MATCH", C.c_int),
+                ("MAX_DIST_PLANE", C.c_double), ("PLANE_THRESHOLD", C.c_double), ("estimate_extrinsics", C.c_int)]
+
+
+class Frame(C.Structure):
+    _fields_ = [("p", C.c_float * 3), ("q", C.c_float * 4), ("v", C.c_float * 3), ("g", C.c_float * 3),
+                ("w", C.c_float * 3), ("a", C.c_float * 3), ("bg", C.c_float * 3), ("ba", C.c_float * 3),
+                ("time", C.c_double)]
+
+
+MATCH_REC_DTYPE = np.dtype([
+    ("H", np.float32, 12), ("h", np.float32), ("valid", np.float32), ("n", np.float32, 4),
+    ("p_global", np.float32, 3), ("sqd", np.float32, 5), ("nbr", np.int32, 5), ("n_nbr", np.int32)])
+
+FRAME_DTYPE = np.dtype([
+    ("p", np.float32, 3), ("q", np.float32, 4), ("v", np.float32, 3), ("g", np.float32, 3), ("w", np.float32, 3),
+    ("a", np.float32, 3), ("bg", np.float32, 3), ("ba", np.float32, 3), ("_pad", np.float32), ("time", np.float64)])
+
+# every symbol include/flimo_c.h declares (tests check the .so exports each one)
+HIP_SYMBOLS = [
+    "flimo_ctx_create", "flimo_ctx_destroy", "flimo_last_error", "flimo_version",
+    "flimo_map_config", "flimo_map_add", "flimo_map_clear", "flimo_map_size", "flimo_map_last_time",
+    "flimo_map_points", "flimo_knn", "flimo_scan_set", "flimo_scan_size", "flimo_scan_get",
+    "flimo_raw_scan_set", "flimo_deskew_resident", "flimo_deskew",
+    "flimo_match_reduce", "flimo_match_fetch", "flimo_match_fetch_H",
+    "flimo_scan_to_world", "flimo_map_add_scan",
+    "flimo_set_timing", "flimo_set_debug_records", "flimo_set_lanes_per_query", "flimo_last_kernel_ms",
+    "flimo_last_candidates_per_query",
+]
+
+_hip = None
+
+
+def hip_lib_path() -> str:
+    return os.path.join(_PKG, "libflimo_hip.so")
+
+
+def load_hip():
+    """Load libflimo_hip.so and declare the C ABI.  Raises FlimoError when the library is absent."""
+    global _hip
+    if _hip is not None:
+        return _hip
+    path = hip_lib_path()
+    if not os.path.exists(path):
+        raise FlimoError(f"{path} not found: run `python -c 'import __graft_entry__ as g; g.build()'` first")
+    L = C.CDLL(path)
+    vp = C.c_void_p
+    L.flimo_ctx_create.restype = C.c_int
+    L.flimo_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.flimo_ctx_destroy.restype = None
+    L.flimo_ctx_destroy.argtypes = [vp]
+    L.flimo_last_error.restype = C.c_char_p
+    L.flimo_last_error.argtypes = [vp]
+    L.flimo_version.restype = C.c_char_p
+    L.flimo_map_config.argtypes = [vp, C.POINTER(MapCfg)]
+    L.flimo_map_add.argtypes = [vp, f32p, C.c_size_t, C.c_size_t, C.c_double]
+    L.flimo_map_clear.argtypes = [vp]
+    L.flimo_map_size.restype = C.c_size_t
+    L.flimo_map_size.argtypes = [vp]
+    L.flimo_map_last_time.restype = C.c_double
+    L.flimo_map_last_time.argtypes = [vp]
+    L.flimo_map_points.argtypes = [vp, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.flimo_knn.argtypes = [vp, f32p, C.c_size_t, C.c_int, i32p, f32p, i32p]
+    L.flimo_scan_set.argtypes = [vp, f32p, C.c_size_t, C.c_size_t]
+    L.flimo_scan_size.restype = C.c_size_t
+    L.flimo_scan_size.argtypes = [vp]
+    L.flimo_scan_get.argtypes = [vp, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.flimo_raw_scan_set.argtypes = [vp, f32p, C.c_size_t, C.c_size_t, f64p]
+    L.flimo_deskew_resident.argtypes = [vp, C.c_void_p, C.c_size_t, f32p, f64p]
+    L.flimo_deskew.argtypes = [vp, f32p, C.c_size_t, C.c_size_t, f64p, C.c_void_p, C.c_size_t, f32p, f64p]
+    L.flimo_match_reduce.argtypes = [vp, f64p, C.POINTER(MatchCfg), f64p, f64p, C.POINTER(C.c_int)]
+    L.flimo_match_fetch.argtypes = [vp, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.flimo_match_fetch_H.argtypes = [vp, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.flimo_scan_to_world.argtypes = [vp, f64p, C.c_void_p, C.c_size_t]
+    L.flimo_map_add_scan.argtypes = [vp, f64p, C.c_double]
+    L.flimo_set_timing.argtypes = [vp, C.c_int]
+    L.flimo_set_debug_records.argtypes = [vp, C.c_int]
+    L.flimo_set_lanes_per_query.argtypes = [vp, C.c_int]
+    L.flimo_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.flimo_last_candidates_per_query.restype = C.c_double
+    L.flimo_last_candidates_per_query.argtypes = [vp]
+    for name in HIP_SYMBOLS:
+        fn = getattr(L, name)
+        if fn.restype is C.c_int and name not in ("flimo_ctx_create",):
+            pass
+    _hip = L
+    return L
+
+
+_ERRS = {-1: "no gfx950 device", -2: "invalid argument", -3: "HIP error", -4: "no map", -5: "too large",
+         -6: "unsupported"}
+
+
+class HipCtx:
+    """Thin OO wrapper over one ``flimo_ctx`` (one GPU, one map, one stream)."""
+
+    def __init__(self, device: int = 0):
+        L = load_hip()
+        h = C.c_void_p()
+        rc = L.flimo_ctx_create(device, C.byref(h))
+        if rc != 0:
+            raise FlimoError(f"flimo_ctx_create({device}) failed: {_ERRS.get(rc, rc)}")
+        self._h = h
+        self._L = L
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.flimo_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise FlimoError(f"{_ERRS.get(rc, rc)}: {self._L.flimo_last_error(self._h).decode()}")
+
+    # ---- map ----
+    def map_config(self, min_extent=0.2, bucket_size=2, downsample=True, cell_size=0.0):
+        cfg = MapCfg(min_extent, bucket_size, int(downsample), cell_size)
+        self._chk(self._L.flimo_map_config(self._h, C.byref(cfg)))
+
+    def map_add(self, xyz, stamp=0.0):
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        n = xyz.shape[0]
+        stride = xyz.strides[0] if xyz.ndim == 2 else 12
+        self._chk(self._L.flimo_map_add(self._h, xyz.reshape(-1), n, stride, float(stamp)))
+
+    def map_clear(self):
+        self._chk(self._L.flimo_map_clear(self._h))
+
+    def map_size(self) -> int:
+        return int(self._L.flimo_map_size(self._h))
+
+    def map_points(self) -> np.ndarray:
+        n = C.c_size_t(0)
+        self._chk(self._L.flimo_map_points(self._h, None, 0, C.byref(n)))
+        out = np.empty((max(n.value, 1), 3), dtype=np.float32)
+        self._chk(self._L.flimo_map_points(self._h, out.ctypes.data, n.value, C.byref(n)))
+        return out[:n.value]
+
+    def knn(self, q, k=5):
+        q = np.ascontiguousarray(q, dtype=np.float32).reshape(-1, 3)
+        nq = q.shape[0]
+        idx = np.empty((nq, k), np.int32)
+        sqd = np.empty((nq, k), np.float32)
+        cnt = np.empty((nq,), np.int32)
+        self._chk(self._L.flimo_knn(self._h, q.reshape(-1), nq, k, idx.reshape(-1), sqd.reshape(-1), cnt))
+        return idx, sqd, cnt
+
+    # ---- scan ----
+    def scan_set(self, xyz):
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        n = xyz.shape[0]
+        stride = xyz.strides[0] if xyz.ndim == 2 else 12
+        self._chk(self._L.flimo_scan_set(self._h, xyz.reshape(-1), n, stride))
+
+    def scan_size(self) -> int:
+        return int(self._L.flimo_scan_size(self._h))
+
+    def scan_get(self) -> np.ndarray:
+        n = self.scan_size()
+        out = np.empty((max(n, 1), 3), dtype=np.float32)
+        m = C.c_size_t(0)
+        self._chk(self._L.flimo_scan_get(self._h, out.ctypes.data, n, C.byref(m)))
+        return out[:n]
+
+    def raw_scan_set(self, xyz, t):
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        t = np.ascontiguousarray(t, dtype=np.float64)
+        n = xyz.shape[0]
+        stride = xyz.strides[0] if xyz.ndim == 2 else 12
+        self._chk(self._L.flimo_raw_scan_set(self._h, xyz.reshape(-1), n, stride, t))
+
+    def deskew_resident(self, frames: np.ndarray, L2B, last_x26):
+        assert frames.dtype == FRAME_DTYPE
+        frames = np.ascontiguousarray(frames)
+        self._chk(self._L.flimo_deskew_resident(self._h, frames.ctypes.data, frames.shape[0],
+                                                np.ascontiguousarray(L2B, dtype=np.float32).reshape(-1),
+                                                np.ascontiguousarray(last_x26, dtype=np.float64)))
+
+    # ---- measurement pass ----
+    def match_reduce(self, x26, cfg: MatchCfg):
+        HTH = np.zeros(144, np.float64)
+        HTh = np.zeros(12, np.float64)
+        M = C.c_int(0)
+        self._chk(self._L.flimo_match_reduce(self._h, np.ascontiguousarray(x26, dtype=np.float64), C.byref(cfg), HTH,
+                                             HTh, C.byref(M)))
+        return HTH.reshape(12, 12), HTh, M.value
+
+    def match_fetch(self) -> np.ndarray:
+        n = C.c_size_t(0)
+        self._chk(self._L.flimo_match_fetch(self._h, None, 0, C.byref(n)))
+        out = np.zeros(max(n.value, 1), dtype=MATCH_REC_DTYPE)
+        self._chk(self._L.flimo_match_fetch(self._h, out.ctypes.data, n.value, C.byref(n)))
+        return out[:n.value]
+
+    def match_fetch_H(self):
+        n = C.c_size_t(0)
+        self._chk(self._L.flimo_match_fetch_H(self._h, None, None, 0, C.byref(n)))
+        H = np.zeros((max(n.value, 1), 12), np.float64)
+        h = np.zeros(max(n.value, 1), np.float64)
+        self._chk(self._L.flimo_match_fetch_H(self._h, H.ctypes.data, h.ctypes.data, n.value, C.byref(n)))
+        return H[:n.value], h[:n.value]
+
+    def scan_to_world(self, x26) -> np.ndarray:
+        n = self.scan_size()
+        out = np.empty((max(n, 1), 3), dtype=np.float32)
+        self._chk(self._L.flimo_scan_to_world(self._h, np.ascontiguousarray(x26, dtype=np.float64), out.ctypes.data, n))
+        return out[:n]
+
+    def map_add_scan(self, x26, stamp=0.0):
+        self._chk(self._L.flimo_map_add_scan(self._h, np.ascontiguousarray(x26, dtype=np.float64), float(stamp)))
+
+    # ---- instrumentation ----
+    def set_timing(self, on=True):
+        self._chk(self._L.flimo_set_timing(self._h, int(on)))
+
+    def set_debug_records(self, on=True):
+        self._chk(self._L.flimo_set_debug_records(self._h, int(on)))
+
+    def set_lanes_per_query(self, l: int):
+        self._chk(self._L.flimo_set_lanes_per_query(self._h, int(l)))
+
+    def last_kernel_ms(self):
+        a = C.c_float(0)
+        b = C.c_float(0)
+        self._chk(self._L.flimo_last_kernel_ms(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def last_candidates_per_query(self) -> float:
+        return float(self._L.flimo_last_candidates_per_query(self._h))
+
+
+def default_match_cfg(**kw) -> MatchCfg:
+    c = MatchCfg(5, 2000, 10000, 2.0, 5.0e-2, 1)
+    for k, v in kw.items():
+        if not hasattr(c, k):
+            raise AttributeError(k)
+        setattr(c, k, v)
+    return c

@@ -1,0 +1,694 @@
+// fast_limo_amd/csrc/hip/flimo_capi.hip -- C ABI (include/flimo_c.h) over the gfx950 kernels.
+//
+// Host-side glue only: context / buffer management, the float32 pose matrices the reference builds
+// per pass (Objects/State.cpp:38-55,136-172; Modules/Localizer.cpp:549-555), launch sequencing and
+// the decode of the MFMA accumulator layout.  No compute fallback lives here: without a HIP
+// device every entry point fails with FLIMO_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+#include <string>
+#include <vector>
+#include <algorithm>
+#include "../../../include/flimo_c.h"
+#include "flimo_types.h"
+#include "flimo_kernels.h"
+#include "flimo_insert.h"
+
+#pragma clang fp contract(off)
+
+using namespace flimo;
+
+struct flimo_ctx {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  std::string err;
+  // config
+  flimo_map_cfg map_cfg{0.2f, 2, 1, 0.5f};
+  int lanes_per_query = 4;
+  bool timing = false;
+  bool debug_recs = false;
+  // map
+  float4* d_map_raw = nullptr;     // insertion order
+  float4* d_map_sorted = nullptr;  // cell order
+  size_t map_n = 0, map_cap = 0;
+  uint32_t* d_cell_start = nullptr;
+  size_t cell_cap = 0;
+  GridView grid{};
+  bool grid_valid = false;
+  double map_last_time = -1.0;
+  MapBuildScratch scratch;
+  InsertBook* book = nullptr;      // reference insert rule (flimo_insert.h)
+  // scan
+  float4* d_scan = nullptr;        // pc2match (body frame)
+  float4* d_scan_raw = nullptr;    // raw lidar-frame points for deskew
+  float4* d_scan_world = nullptr;
+  double* d_scan_t = nullptr;
+  size_t scan_n = 0, scan_cap = 0, raw_n = 0;
+  void* d_frames = nullptr;
+  size_t frames_cap = 0;
+  // per pass
+  Rec16* d_recs = nullptr;
+  RecDbg* d_dbg = nullptr;
+  size_t rec_cap = 0;
+  int last_nq = 0;
+  int reduce_waves = 256;
+  double* d_partials = nullptr;
+  double* d_out256 = nullptr;
+  double* h_out256 = nullptr;      // pinned
+  unsigned long long* d_cand = nullptr;
+  unsigned long long* h_cand = nullptr;  // pinned
+  double last_cand_per_query = 0.0;
+  int mfma_idx[16][16];            // (i,j) -> raw index
+  // staging
+  void* h_stage = nullptr;         // pinned
+  size_t stage_cap = 0;
+  // timing
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  float last_match_ms = 0.f, last_reduce_ms = 0.f;
+  flimo_match_cfg last_cfg{};
+};
+
+static int fail(flimo_ctx* c, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf;
+  return code;
+}
+#define HIPCHK(c, call)                                                                          \
+  do {                                                                                           \
+    hipError_t e_ = (call);                                                                      \
+    if (e_ != hipSuccess) return fail(c, FLIMO_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+  } while (0)
+
+static int ensure_stage(flimo_ctx* c, size_t bytes) {
+  if (bytes <= c->stage_cap) return FLIMO_OK;
+  if (c->h_stage) (void)hipHostFree(c->h_stage);
+  c->h_stage = nullptr;
+  c->stage_cap = 0;
+  size_t cap = bytes + bytes / 4 + 4096;
+  HIPCHK(c, hipHostMalloc(&c->h_stage, cap, hipHostMallocDefault));
+  c->stage_cap = cap;
+  return FLIMO_OK;
+}
+
+template <typename T>
+static int ensure_dev(flimo_ctx* c, T*& p, size_t& cap, size_t need, bool keep, size_t keep_n) {
+  if (need <= cap) return FLIMO_OK;
+  size_t ncap = need + need / 4 + 1024;
+  T* np = nullptr;
+  HIPCHK(c, hipMalloc(&np, ncap * sizeof(T)));
+  if (keep && p && keep_n) {
+    HIPCHK(c, hipMemcpyAsync(np, p, keep_n * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  if (p) (void)hipFree(p);
+  p = np;
+  cap = ncap;
+  return FLIMO_OK;
+}
+
+// ---- host float32 pose algebra (reference evaluation order, no FMA) --------------------------
+static inline float hsum3(float a, float b, float c) { return a + (b + c); }
+static void quat_to_rot_f(const float q[4] /*x y z w*/, float R[9]) {   // Eigen toRotationMatrix
+  const float tx = 2.f * q[0], ty = 2.f * q[1], tz = 2.f * q[2];
+  const float twx = tx * q[3], twy = ty * q[3], twz = tz * q[3];
+  const float txx = tx * q[0], txy = ty * q[0], txz = tz * q[0];
+  const float tyy = ty * q[1], tyz = tz * q[1], tzz = tz * q[2];
+  R[0] = 1.f - (tyy + tzz); R[1] = txy - twz;         R[2] = txz + twy;
+  R[3] = txy + twz;         R[4] = 1.f - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy;         R[7] = tyz + twx;         R[8] = 1.f - (txx + tyy);
+}
+static void quat_to_rot_d(const double q[4], double R[9]) {
+  const double tx = 2.0 * q[0], ty = 2.0 * q[1], tz = 2.0 * q[2];
+  const double twx = tx * q[3], twy = ty * q[3], twz = tz * q[3];
+  const double txx = tx * q[0], txy = ty * q[0], txz = tz * q[0];
+  const double tyy = ty * q[1], tyz = tz * q[1], tzz = tz * q[2];
+  R[0] = 1.0 - (tyy + tzz); R[1] = txy - twz;         R[2] = txz + twy;
+  R[3] = txy + twz;         R[4] = 1.0 - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy;         R[7] = tyz + twx;         R[8] = 1.0 - (txx + tyy);
+}
+static void se3_from(const float q[4], const float p[3], float T[16]) {      // State::get_RT / get_extr_RT
+  float R[9];
+  quat_to_rot_f(q, R);
+  T[0] = R[0]; T[1] = R[1]; T[2] = R[2];  T[3] = p[0];
+  T[4] = R[3]; T[5] = R[4]; T[6] = R[5];  T[7] = p[1];
+  T[8] = R[6]; T[9] = R[7]; T[10] = R[8]; T[11] = p[2];
+  T[12] = 0.f; T[13] = 0.f; T[14] = 0.f;  T[15] = 1.f;
+}
+static void se3_inv_from(const float q[4], const float p[3], float T[16]) {  // State::get_RT_inv / get_extr_RT_inv
+  float R[9];
+  quat_to_rot_f(q, R);
+  // rot^T and -rot^T * p, coefficient products reduced as c0 + (c1 + c2)
+  float Rt[9] = {R[0], R[3], R[6], R[1], R[4], R[7], R[2], R[5], R[8]};
+  float t[3];
+  for (int i = 0; i < 3; i++) t[i] = hsum3((-Rt[i * 3 + 0]) * p[0], (-Rt[i * 3 + 1]) * p[1], (-Rt[i * 3 + 2]) * p[2]);
+  T[0] = Rt[0]; T[1] = Rt[1]; T[2] = Rt[2];  T[3] = t[0];
+  T[4] = Rt[3]; T[5] = Rt[4]; T[6] = Rt[5];  T[7] = t[1];
+  T[8] = Rt[6]; T[9] = Rt[7]; T[10] = Rt[8]; T[11] = t[2];
+  T[12] = 0.f; T[13] = 0.f; T[14] = 0.f;     T[15] = 1.f;
+}
+static void pose_from_x26(const double x[26], PoseMats& P) {
+  // State(state_ikfom): casts (State.cpp:38-55)
+  const float p[3] = {(float)x[0], (float)x[1], (float)x[2]};
+  const float q[4] = {(float)x[3], (float)x[4], (float)x[5], (float)x[6]};
+  const float qLI[4] = {(float)x[7], (float)x[8], (float)x[9], (float)x[10]};
+  const float pLI[3] = {(float)x[11], (float)x[12], (float)x[13]};
+  se3_from(q, p, P.RT);
+  se3_inv_from(q, p, P.RT_inv);
+  se3_inv_from(qLI, pLI, P.TLI_inv);
+  // s.rot.conjugate().toRotationMatrix().cast<float>()  (Localizer.cpp:554-555)
+  const double qc[4] = {-x[3], -x[4], -x[5], x[6]};
+  const double lc[4] = {-x[7], -x[8], -x[9], x[10]};
+  double Rd[9], Ld[9];
+  quat_to_rot_d(qc, Rd);
+  quat_to_rot_d(lc, Ld);
+  for (int i = 0; i < 9; i++) { P.R_inv[i] = (float)Rd[i]; P.RLI_inv[i] = (float)Ld[i]; }
+}
+
+// ---- context ----------------------------------------------------------------------------------
+extern "C" const char* flimo_version(void) { return "fast_limo_amd 0.1.0 (gfx950)"; }
+
+extern "C" const char* flimo_last_error(const flimo_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+extern "C" int flimo_ctx_create(int device, flimo_ctx** out) {
+  if (!out) return FLIMO_ERR_INVALID;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FLIMO_ERR_NO_DEVICE;
+  if (device < 0 || device >= ndev) return FLIMO_ERR_INVALID;
+  if (hipSetDevice(device) != hipSuccess) return FLIMO_ERR_NO_DEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return FLIMO_ERR_NO_DEVICE;
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return FLIMO_ERR_NO_DEVICE;   // kernels are gfx950 only
+  flimo_ctx* c = new flimo_ctx();
+  c->device = device;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return FLIMO_ERR_HIP; }
+  for (int i = 0; i < 3; i++) (void)hipEventCreate(&c->ev[i]);
+  bool ok = hipMalloc(&c->d_partials, (size_t)c->reduce_waves * 256 * sizeof(double)) == hipSuccess &&
+            hipMalloc(&c->d_out256, 256 * sizeof(double)) == hipSuccess &&
+            hipHostMalloc((void**)&c->h_out256, 256 * sizeof(double), hipHostMallocDefault) == hipSuccess &&
+            hipMalloc(&c->d_cand, sizeof(unsigned long long)) == hipSuccess &&
+            hipHostMalloc((void**)&c->h_cand, sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess;
+  if (!ok) { flimo_ctx_destroy(c); return FLIMO_ERR_HIP; }
+  // calibrate the v_mfma_f64_16x16x4_f64 accumulator layout: D[i][j] = j + 16 i
+  launch_mfma_layout(c->stream, c->d_out256);
+  if (hipMemcpyAsync(c->h_out256, c->d_out256, 256 * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+      hipStreamSynchronize(c->stream) != hipSuccess) { flimo_ctx_destroy(c); return FLIMO_ERR_HIP; }
+  bool seen[256] = {false};
+  for (int r = 0; r < 256; r++) {
+    const double v = c->h_out256[r];
+    const int code = (int)llround(v);
+    if (code < 0 || code > 255 || fabs(v - code) > 1e-9 || seen[code]) { flimo_ctx_destroy(c); return FLIMO_ERR_HIP; }
+    seen[code] = true;
+    c->mfma_idx[code / 16][code % 16] = r;
+  }
+  const char* e = getenv("FLIMO_LPQ");
+  if (e) { int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) c->lanes_per_query = v; }
+  c->book = insert_book_create();
+  *out = c;
+  return FLIMO_OK;
+}
+
+extern "C" void flimo_ctx_destroy(flimo_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  (void)hipFree(c->d_map_raw); (void)hipFree(c->d_map_sorted); (void)hipFree(c->d_cell_start);
+  (void)hipFree(c->d_scan); (void)hipFree(c->d_scan_raw); (void)hipFree(c->d_scan_world); (void)hipFree(c->d_scan_t);
+  (void)hipFree(c->d_frames); (void)hipFree(c->d_recs); (void)hipFree(c->d_dbg);
+  (void)hipFree(c->d_partials); (void)hipFree(c->d_out256); (void)hipFree(c->d_cand);
+  if (c->h_out256) (void)hipHostFree(c->h_out256);
+  if (c->h_cand) (void)hipHostFree(c->h_cand);
+  if (c->h_stage) (void)hipHostFree(c->h_stage);
+  map_scratch_free(c->scratch);
+  for (int i = 0; i < 3; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->book) insert_book_destroy(c->book);
+  delete c;
+}
+
+// ---- map --------------------------------------------------------------------------------------
+extern "C" int flimo_map_config(flimo_ctx* c, const flimo_map_cfg* cfg) {
+  if (!c || !cfg) return FLIMO_ERR_INVALID;
+  if (!(cfg->min_extent > 0.f)) return fail(c, FLIMO_ERR_INVALID, "min_extent must be > 0");
+  c->map_cfg = *cfg;
+  if (!(c->map_cfg.cell_size > 0.f)) c->map_cfg.cell_size = 0.5f;
+  insert_book_config(c->book, cfg->min_extent, cfg->downsample != 0);
+  return FLIMO_OK;
+}
+
+extern "C" int flimo_map_clear(flimo_ctx* c) {
+  if (!c) return FLIMO_ERR_INVALID;
+  c->map_n = 0;
+  c->grid_valid = false;
+  c->map_last_time = -1.0;
+  insert_book_clear(c->book);
+  return FLIMO_OK;
+}
+
+extern "C" size_t flimo_map_size(const flimo_ctx* c) { return c ? c->map_n : 0; }
+extern "C" double flimo_map_last_time(const flimo_ctx* c) { return c ? c->map_last_time : -1.0; }
+
+static int rebuild_grid(flimo_ctx* c) {
+  (void)hipSetDevice(c->device);
+  c->grid_valid = false;
+  if (c->map_n == 0) return FLIMO_OK;
+  float bb[6];
+  HIPCHK(c, map_bbox(c->stream, c->d_map_raw, c->map_n, c->scratch, bb));
+  float cell = c->map_cfg.cell_size > 0.f ? c->map_cfg.cell_size : 0.5f;
+  int nx, ny, nz;
+  float ox, oy, oz, inv;
+  for (;;) {
+    inv = 1.0f / cell;
+    ox = bb[0] - 0.5f * cell; oy = bb[1] - 0.5f * cell; oz = bb[2] - 0.5f * cell;
+    // same float expression as the kernels: floor((p - o) * inv)
+    nx = (int)floorf((bb[3] - ox) * inv) + 2;
+    ny = (int)floorf((bb[4] - oy) * inv) + 2;
+    nz = (int)floorf((bb[5] - oz) * inv) + 2;
+    const double ncells = (double)nx * ny * nz;
+    if (ncells < 1.9e9) break;
+    cell *= 2.0f;   // keep the dense index addressable with 32 bits
+  }
+  const size_t ncells = (size_t)nx * ny * nz;
+  size_t dummy = 0;
+  if (c->map_cap > 0) {
+    // sorted buffer mirrors the raw capacity
+  }
+  {
+    size_t sorted_cap = c->d_map_sorted ? c->map_cap : 0;
+    if (!c->d_map_sorted || sorted_cap < c->map_n) {
+      if (c->d_map_sorted) (void)hipFree(c->d_map_sorted);
+      c->d_map_sorted = nullptr;
+      HIPCHK(c, hipMalloc(&c->d_map_sorted, c->map_cap * sizeof(float4)));
+    }
+  }
+  (void)dummy;
+  if (ncells + 1 > c->cell_cap) {
+    if (c->d_cell_start) (void)hipFree(c->d_cell_start);
+    c->d_cell_start = nullptr;
+    size_t cap = ncells + 1 + ncells / 8;
+    HIPCHK(c, hipMalloc(&c->d_cell_start, cap * sizeof(uint32_t)));
+    c->cell_cap = cap;
+  }
+  HIPCHK(c, map_build_grid(c->stream, c->d_map_raw, c->map_n, c->d_map_sorted, c->d_cell_start, ncells, ox, oy, oz, inv,
+                           nx, ny, nz, c->scratch));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->grid.pts = c->d_map_sorted;
+  c->grid.cell_start = c->d_cell_start;
+  c->grid.ox = ox; c->grid.oy = oy; c->grid.oz = oz;
+  c->grid.inv_cell = inv;
+  c->grid.cell = cell;
+  c->grid.nx = nx; c->grid.ny = ny; c->grid.nz = nz;
+  c->grid.n_pts = (uint32_t)c->map_n;
+  c->grid_valid = true;
+  return FLIMO_OK;
+}
+
+// append `n` packed float4 points (host, NaN-free, already filtered by the insert rule)
+static int map_append_host(flimo_ctx* c, const float4* pts, size_t n) {
+  if (n == 0) return FLIMO_OK;
+  if (c->map_n + n > 0x7fff0000ull) return fail(c, FLIMO_ERR_TOO_LARGE, "map would exceed 2^31 points");
+  const size_t old_cap = c->map_cap;
+  int rc = ensure_dev(c, c->d_map_raw, c->map_cap, c->map_n + n, true, c->map_n);
+  if (rc) return rc;
+  if (c->map_cap != old_cap && c->d_map_sorted) { (void)hipFree(c->d_map_sorted); c->d_map_sorted = nullptr; }
+  HIPCHK(c, hipMemcpyAsync(c->d_map_raw + c->map_n, pts, n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->map_n += n;
+  return FLIMO_OK;
+}
+
+extern "C" int flimo_map_add(flimo_ctx* c, const float* xyz, size_t n, size_t stride_bytes, double stamp) {
+  if (!c) return FLIMO_ERR_INVALID;
+  if (n < 1) return FLIMO_OK;                         // Mapper::add: `if(pc->points.size() < 1) return;`
+  if (!xyz || stride_bytes < 12) return fail(c, FLIMO_ERR_INVALID, "bad xyz/stride");
+  (void)hipSetDevice(c->device);
+  int rc = ensure_stage(c, n * sizeof(float4));
+  if (rc) return rc;
+  float4* st = (float4*)c->h_stage;
+  // Octree::processPoints: drop NaNs (Octree.hpp:243-244); then the reference's insert rule decides
+  // which points are stored (first batch: all; later batches: Octree::updateOctant semantics).
+  std::vector<float> packed;
+  packed.reserve(n * 3);
+  const unsigned char* b = (const unsigned char*)xyz;
+  for (size_t i = 0; i < n; i++) {
+    const float* p = (const float*)(b + i * stride_bytes);
+    if (std::isnan(p[0]) || std::isnan(p[1]) || std::isnan(p[2])) continue;
+    packed.push_back(p[0]); packed.push_back(p[1]); packed.push_back(p[2]);
+  }
+  const size_t m = packed.size() / 3;
+  std::vector<unsigned char> keep(m, 1);
+  insert_book_update(c->book, packed.data(), m, keep.data());
+  size_t k = 0;
+  for (size_t i = 0; i < m; i++) {
+    if (!keep[i]) continue;
+    st[k].x = packed[3 * i]; st[k].y = packed[3 * i + 1]; st[k].z = packed[3 * i + 2];
+    const uint32_t id = (uint32_t)(c->map_n + k);
+    memcpy(&st[k].w, &id, 4);
+    k++;
+  }
+  rc = map_append_host(c, st, k);
+  if (rc) return rc;
+  rc = rebuild_grid(c);
+  if (rc) return rc;
+  c->map_last_time = stamp;
+  return FLIMO_OK;
+}
+
+extern "C" int flimo_map_points(flimo_ctx* c, float* out, size_t cap, size_t* n) {
+  if (!c || !n) return FLIMO_ERR_INVALID;
+  *n = c->map_n;
+  if (!out || cap == 0 || c->map_n == 0) return FLIMO_OK;
+  if (!c->grid_valid) return fail(c, FLIMO_ERR_NOMAP, "map index not built");
+  (void)hipSetDevice(c->device);
+  const size_t m = std::min(cap, c->map_n);
+  int rc = ensure_stage(c, m * sizeof(float4));
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->h_stage, c->d_map_sorted, m * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const float4* s = (const float4*)c->h_stage;
+  for (size_t i = 0; i < m; i++) { out[3 * i] = s[i].x; out[3 * i + 1] = s[i].y; out[3 * i + 2] = s[i].z; }
+  return FLIMO_OK;
+}
+
+// ---- kNN --------------------------------------------------------------------------------------
+extern "C" int flimo_knn(flimo_ctx* c, const float* q, size_t nq, int k, int32_t* idx, float* sqd, int32_t* cnt) {
+  if (!c || !q || !idx || !sqd || !cnt) return FLIMO_ERR_INVALID;
+  if (k < 1 || k > 5) return fail(c, FLIMO_ERR_UNSUPPORTED, "k must be in 1..5");
+  if (nq == 0) return FLIMO_OK;
+  if (!c->grid_valid) {                       // Octree::knn with root_ == nullptr returns nothing
+    for (size_t i = 0; i < nq; i++) cnt[i] = 0;
+    for (size_t i = 0; i < nq * (size_t)k; i++) { idx[i] = -1; sqd[i] = 0.f; }
+    return FLIMO_OK;
+  }
+  (void)hipSetDevice(c->device);
+  float* d_q = nullptr; int32_t* d_idx = nullptr; float* d_sqd = nullptr; int32_t* d_cnt = nullptr;
+  HIPCHK(c, hipMalloc(&d_q, nq * 3 * sizeof(float)));
+  HIPCHK(c, hipMalloc(&d_idx, nq * k * sizeof(int32_t)));
+  HIPCHK(c, hipMalloc(&d_sqd, nq * k * sizeof(float)));
+  HIPCHK(c, hipMalloc(&d_cnt, nq * sizeof(int32_t)));
+  HIPCHK(c, hipMemcpyAsync(d_q, q, nq * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  launch_knn(c->stream, c->grid, d_q, (int)nq, k, 1 << 29, d_idx, d_sqd, d_cnt);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(idx, d_idx, nq * k * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(sqd, d_sqd, nq * k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(cnt, d_cnt, nq * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(d_q); (void)hipFree(d_idx); (void)hipFree(d_sqd); (void)hipFree(d_cnt);
+  return FLIMO_OK;
+}
+
+// ---- scan -------------------------------------------------------------------------------------
+static int ensure_scan(flimo_ctx* c, size_t n) {
+  if (n <= c->scan_cap) return FLIMO_OK;
+  const size_t cap = n + n / 4 + 1024;
+  float4 *a = nullptr, *b = nullptr, *w = nullptr;
+  double* t = nullptr;
+  HIPCHK(c, hipMalloc(&a, cap * sizeof(float4)));
+  HIPCHK(c, hipMalloc(&b, cap * sizeof(float4)));
+  HIPCHK(c, hipMalloc(&w, cap * sizeof(float4)));
+  HIPCHK(c, hipMalloc(&t, cap * sizeof(double)));
+  (void)hipFree(c->d_scan); (void)hipFree(c->d_scan_raw); (void)hipFree(c->d_scan_world); (void)hipFree(c->d_scan_t);
+  c->d_scan = a; c->d_scan_raw = b; c->d_scan_world = w; c->d_scan_t = t;
+  c->scan_cap = cap;
+  c->scan_n = 0; c->raw_n = 0;
+  return FLIMO_OK;
+}
+
+static int ensure_recs(flimo_ctx* c, size_t n) {
+  if (n <= c->rec_cap) return FLIMO_OK;
+  const size_t cap = n + n / 4 + 1024;
+  (void)hipFree(c->d_recs); (void)hipFree(c->d_dbg);
+  c->d_recs = nullptr; c->d_dbg = nullptr; c->rec_cap = 0;
+  HIPCHK(c, hipMalloc(&c->d_recs, cap * sizeof(Rec16)));
+  HIPCHK(c, hipMalloc(&c->d_dbg, cap * sizeof(RecDbg)));
+  c->rec_cap = cap;
+  return FLIMO_OK;
+}
+
+static int upload_points(flimo_ctx* c, const float* xyz, size_t n, size_t stride_bytes, float4* dst) {
+  int rc = ensure_stage(c, n * sizeof(float4));
+  if (rc) return rc;
+  float4* st = (float4*)c->h_stage;
+  const unsigned char* b = (const unsigned char*)xyz;
+  for (size_t i = 0; i < n; i++) {
+    const float* p = (const float*)(b + i * stride_bytes);
+    st[i].x = p[0]; st[i].y = p[1]; st[i].z = p[2]; st[i].w = (stride_bytes >= 16) ? p[3] : 0.f;
+  }
+  HIPCHK(c, hipMemcpyAsync(dst, st, n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return FLIMO_OK;
+}
+
+extern "C" int flimo_scan_set(flimo_ctx* c, const float* xyz, size_t n, size_t stride_bytes) {
+  if (!c) return FLIMO_ERR_INVALID;
+  if (n > 0 && (!xyz || stride_bytes < 12)) return fail(c, FLIMO_ERR_INVALID, "bad xyz/stride");
+  if (n > 0x7fff0000ull) return fail(c, FLIMO_ERR_TOO_LARGE, "scan too large");
+  (void)hipSetDevice(c->device);
+  int rc = ensure_scan(c, n);
+  if (rc) return rc;
+  if (n) { rc = upload_points(c, xyz, n, stride_bytes, c->d_scan); if (rc) return rc; }
+  c->scan_n = n;
+  return FLIMO_OK;
+}
+
+extern "C" size_t flimo_scan_size(const flimo_ctx* c) { return c ? c->scan_n : 0; }
+
+static int download_xyz(flimo_ctx* c, const float4* src, size_t m, float* out) {
+  int rc = ensure_stage(c, m * sizeof(float4));
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->h_stage, src, m * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const float4* s = (const float4*)c->h_stage;
+  for (size_t i = 0; i < m; i++) { out[3 * i] = s[i].x; out[3 * i + 1] = s[i].y; out[3 * i + 2] = s[i].z; }
+  return FLIMO_OK;
+}
+
+extern "C" int flimo_scan_get(flimo_ctx* c, float* out, size_t cap, size_t* n) {
+  if (!c || !n) return FLIMO_ERR_INVALID;
+  *n = c->scan_n;
+  if (!out || cap == 0 || c->scan_n == 0) return FLIMO_OK;
+  (void)hipSetDevice(c->device);
+  return download_xyz(c, c->d_scan, std::min(cap, c->scan_n), out);
+}
+
+// ---- deskew -----------------------------------------------------------------------------------
+extern "C" int flimo_raw_scan_set(flimo_ctx* c, const float* xyz, size_t n, size_t stride_bytes, const double* t) {
+  if (!c) return FLIMO_ERR_INVALID;
+  if (n > 0 && (!xyz || !t || stride_bytes < 12)) return fail(c, FLIMO_ERR_INVALID, "bad xyz/t/stride");
+  (void)hipSetDevice(c->device);
+  int rc = ensure_scan(c, n);
+  if (rc) return rc;
+  if (n) {
+    rc = upload_points(c, xyz, n, stride_bytes, c->d_scan_raw);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_scan_t, t, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  c->raw_n = n;
+  return FLIMO_OK;
+}
+
+extern "C" int flimo_deskew_resident(flimo_ctx* c, const flimo_frame* frames, size_t nf, const float L2B[16],
+                                     const double last_x26[26]) {
+  if (!c || !frames || nf == 0 || !L2B || !last_x26) return FLIMO_ERR_INVALID;
+  (void)hipSetDevice(c->device);
+  static_assert(sizeof(flimo_frame) == 112, "flimo_frame layout");
+  if (dev_frame_size() != sizeof(flimo_frame)) return fail(c, FLIMO_ERR_INVALID, "frame layout mismatch");
+  const size_t n = c->raw_n;
+  if (n == 0) { c->scan_n = 0; return FLIMO_OK; }
+  // frames + the two 4x4 matrices go through one pinned staging copy
+  const size_t fbytes = nf * sizeof(flimo_frame);
+  const size_t total = fbytes + 32 * sizeof(float);
+  if (total > c->frames_cap) {
+    (void)hipFree(c->d_frames);
+    c->d_frames = nullptr;
+    HIPCHK(c, hipMalloc(&c->d_frames, total * 2));
+    c->frames_cap = total * 2;
+  }
+  int rc = ensure_stage(c, total);
+  if (rc) return rc;
+  memcpy(c->h_stage, frames, fbytes);
+  float* m = (float*)((char*)c->h_stage + fbytes);
+  memcpy(m, L2B, 16 * sizeof(float));
+  {
+    const float p[3] = {(float)last_x26[0], (float)last_x26[1], (float)last_x26[2]};
+    const float q[4] = {(float)last_x26[3], (float)last_x26[4], (float)last_x26[5], (float)last_x26[6]};
+    se3_inv_from(q, p, m + 16);                       // last_state.get_RT_inv()
+  }
+  HIPCHK(c, hipMemcpyAsync(c->d_frames, c->h_stage, total, hipMemcpyHostToDevice, c->stream));
+  launch_deskew(c->stream, c->d_scan_raw, c->d_scan_t, (int)n, c->d_frames, (int)nf,
+                (const float*)((const char*)c->d_frames + fbytes), c->d_scan);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->scan_n = n;
+  return FLIMO_OK;
+}
+
+extern "C" int flimo_deskew(flimo_ctx* c, const float* xyz, size_t n, size_t stride_bytes, const double* t,
+                            const flimo_frame* frames, size_t nf, const float L2B[16], const double last_x26[26]) {
+  int rc = flimo_raw_scan_set(c, xyz, n, stride_bytes, t);
+  if (rc) return rc;
+  return flimo_deskew_resident(c, frames, nf, L2B, last_x26);
+}
+
+// ---- measurement pass -------------------------------------------------------------------------
+extern "C" int flimo_set_timing(flimo_ctx* c, int on) { if (!c) return FLIMO_ERR_INVALID; c->timing = on != 0; return FLIMO_OK; }
+extern "C" int flimo_set_debug_records(flimo_ctx* c, int on) { if (!c) return FLIMO_ERR_INVALID; c->debug_recs = on != 0; return FLIMO_OK; }
+extern "C" int flimo_set_lanes_per_query(flimo_ctx* c, int l) {
+  if (!c) return FLIMO_ERR_INVALID;
+  if (!(l == 1 || l == 2 || l == 4 || l == 8 || l == 16)) return fail(c, FLIMO_ERR_INVALID, "lanes per query must be 1,2,4,8,16");
+  c->lanes_per_query = l;
+  return FLIMO_OK;
+}
+extern "C" int flimo_last_kernel_ms(const flimo_ctx* c, float* match_ms, float* reduce_ms) {
+  if (!c) return FLIMO_ERR_INVALID;
+  if (match_ms) *match_ms = c->last_match_ms;
+  if (reduce_ms) *reduce_ms = c->last_reduce_ms;
+  return FLIMO_OK;
+}
+extern "C" double flimo_last_candidates_per_query(const flimo_ctx* c) { return c ? c->last_cand_per_query : 0.0; }
+
+static int gate_rings(const flimo_ctx* c, double max_dist_plane) {
+  // smallest ring r with ((r - margin) * cell)^2 >= MAX_DIST_PLANE: beyond it close_enough() fails anyway
+  const double cell = c->grid.cell;
+  const int maxdim = std::max(c->grid.nx, std::max(c->grid.ny, c->grid.nz));
+  const double margin = 1.0e-3 + 4.0e-7 * maxdim;
+  const double need = sqrt(std::max(max_dist_plane, 0.0)) * (1.0 + 1e-5) / cell + margin;
+  int r = (int)ceil(need);
+  return std::max(r, 1);
+}
+
+extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flimo_match_cfg* cfg, double HTH[144],
+                                  double HTh[12], int* M) {
+  if (!c || !x26 || !cfg || !HTH || !HTh || !M) return FLIMO_ERR_INVALID;
+  if (cfg->NUM_MATCH_POINTS != 5) return fail(c, FLIMO_ERR_UNSUPPORTED, "only NUM_MATCH_POINTS == 5 is supported");
+  for (int i = 0; i < 144; i++) HTH[i] = 0.0;
+  for (int i = 0; i < 12; i++) HTh[i] = 0.0;
+  *M = 0;
+  c->last_nq = 0;
+  c->last_cfg = *cfg;
+  if (!c->grid_valid || c->map_n == 0) return FLIMO_OK;      // Mapper::match: `if(not this->exists()) return matches;`
+  size_t nq = c->scan_n;
+  if (cfg->MAX_NUM_PC2MATCH >= 0 && nq > (size_t)cfg->MAX_NUM_PC2MATCH) nq = (size_t)cfg->MAX_NUM_PC2MATCH;
+  if (nq == 0) return FLIMO_OK;
+  (void)hipSetDevice(c->device);
+  int rc = ensure_recs(c, nq);
+  if (rc) return rc;
+
+  PoseMats P;
+  pose_from_x26(x26, P);
+  MatchParams mp;
+  mp.max_dist_plane = (float)cfg->MAX_DIST_PLANE;     // the gate compares float sq. distance with the double
+                                                      // threshold; identical unless MAX_DIST_PLANE is not a float
+  mp.plane_threshold = (float)cfg->PLANE_THRESHOLD;
+  mp.estimate_extrinsics = cfg->estimate_extrinsics ? 1 : 0;
+  mp.n_queries = (int)nq;
+  mp.max_ring = gate_rings(c, cfg->MAX_DIST_PLANE);
+
+  if (c->debug_recs) HIPCHK(c, hipMemsetAsync(c->d_cand, 0, sizeof(unsigned long long), c->stream));
+  if (c->timing) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  launch_match(c->stream, c->lanes_per_query, c->grid, c->d_scan, P, mp, c->d_recs, c->debug_recs ? c->d_dbg : nullptr,
+               c->d_cand);
+  if (cfg->MAX_NUM_MATCHES >= 0 && (size_t)cfg->MAX_NUM_MATCHES < nq) launch_cap(c->stream, c->d_recs, (int)nq, cfg->MAX_NUM_MATCHES);
+  if (c->timing) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+  launch_reduce(c->stream, c->d_recs, (int)nq, c->reduce_waves, c->d_partials, c->d_out256);
+  if (c->timing) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(c->h_out256, c->d_out256, 256 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (c->debug_recs) HIPCHK(c, hipMemcpyAsync(c->h_cand, c->d_cand, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->timing) {
+    (void)hipEventElapsedTime(&c->last_match_ms, c->ev[0], c->ev[1]);
+    (void)hipEventElapsedTime(&c->last_reduce_ms, c->ev[1], c->ev[2]);
+  }
+  if (c->debug_recs) c->last_cand_per_query = (double)(*c->h_cand) / (double)nq;
+  for (int i = 0; i < 12; i++) {
+    for (int j = 0; j < 12; j++) HTH[i * 12 + j] = c->h_out256[c->mfma_idx[i][j]];
+    HTh[i] = c->h_out256[c->mfma_idx[i][12]];
+  }
+  *M = (int)llround(c->h_out256[c->mfma_idx[13][13]]);
+  c->last_nq = (int)nq;
+  return FLIMO_OK;
+}
+
+extern "C" int flimo_match_fetch(flimo_ctx* c, flimo_match_rec* out, size_t cap, size_t* n) {
+  if (!c || !n) return FLIMO_ERR_INVALID;
+  *n = (size_t)c->last_nq;
+  if (!out || cap == 0 || c->last_nq == 0) return FLIMO_OK;
+  (void)hipSetDevice(c->device);
+  const size_t m = std::min(cap, (size_t)c->last_nq);
+  std::vector<Rec16> r(m);
+  std::vector<RecDbg> d(m);
+  HIPCHK(c, hipMemcpyAsync(r.data(), c->d_recs, m * sizeof(Rec16), hipMemcpyDeviceToHost, c->stream));
+  if (c->debug_recs) HIPCHK(c, hipMemcpyAsync(d.data(), c->d_dbg, m * sizeof(RecDbg), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (size_t i = 0; i < m; i++) {
+    flimo_match_rec& o = out[i];
+    memset(&o, 0, sizeof(o));
+    for (int k = 0; k < 12; k++) o.H[k] = r[i].v[k];
+    o.h = r[i].v[12];
+    o.valid = r[i].v[13];
+    if (c->debug_recs) {
+      for (int k = 0; k < 4; k++) o.n[k] = d[i].n[k];
+      for (int k = 0; k < 3; k++) o.p_global[k] = d[i].p_global[k];
+      for (int k = 0; k < 5; k++) { o.sqd[k] = d[i].sqd[k]; o.nbr[k] = d[i].nbr[k]; }
+      o.n_nbr = d[i].n_nbr;
+    } else {
+      for (int k = 0; k < 5; k++) o.nbr[k] = -1;
+      o.n_nbr = 0;
+    }
+  }
+  return FLIMO_OK;
+}
+
+extern "C" int flimo_match_fetch_H(flimo_ctx* c, double* H, double* h, size_t cap_rows, size_t* M) {
+  if (!c || !M) return FLIMO_ERR_INVALID;
+  *M = 0;
+  if (c->last_nq == 0) return FLIMO_OK;
+  (void)hipSetDevice(c->device);
+  const size_t m = (size_t)c->last_nq;
+  std::vector<Rec16> r(m);
+  HIPCHK(c, hipMemcpyAsync(r.data(), c->d_recs, m * sizeof(Rec16), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  size_t k = 0;
+  for (size_t i = 0; i < m; i++) {
+    if (r[i].v[13] == 0.f) continue;
+    if (H && h && k < cap_rows) {
+      for (int j = 0; j < 12; j++) H[k * 12 + j] = (double)r[i].v[j];
+      h[k] = (double)r[i].v[12];
+    }
+    k++;
+  }
+  *M = k;
+  return FLIMO_OK;
+}
+
+// ---- path exit --------------------------------------------------------------------------------
+extern "C" int flimo_scan_to_world(flimo_ctx* c, const double x26[26], float* out, size_t cap) {
+  if (!c || !x26) return FLIMO_ERR_INVALID;
+  if (c->scan_n == 0) return FLIMO_OK;
+  (void)hipSetDevice(c->device);
+  PoseMats P;
+  pose_from_x26(x26, P);
+  launch_transform(c->stream, c->d_scan, (int)c->scan_n, P, c->d_scan_world);
+  HIPCHK(c, hipGetLastError());
+  if (out && cap) return download_xyz(c, c->d_scan_world, std::min(cap, c->scan_n), out);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return FLIMO_OK;
+}
+
+extern "C" int flimo_map_add_scan(flimo_ctx* c, const double x26[26], double stamp) {
+  if (!c || !x26) return FLIMO_ERR_INVALID;
+  if (c->scan_n == 0) return FLIMO_OK;
+  std::vector<float> w(c->scan_n * 3);
+  int rc = flimo_scan_to_world(c, x26, w.data(), c->scan_n);
+  if (rc) return rc;
+  return flimo_map_add(c, w.data(), c->scan_n, 12, stamp);
+}

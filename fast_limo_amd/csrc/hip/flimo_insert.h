@@ -1,0 +1,29 @@
+// fast_limo_amd/csrc/hip/flimo_insert.h
+// Host-side bookkeeping of WHICH points the map stores.  The k-NN index on the GPU is a uniform
+// grid, but the reference decides what is stored through its incremental octree
+// (Objects/Octree.hpp:282-432): the first batch is stored completely, later batches are routed to
+// octree leaves where a leaf either splits (everything kept), appends, or -- when down-sampling is
+// on, the leaf is at minimum extent and already holds more than bucket/8 = 4 points -- drops the
+// whole incoming batch for that leaf.  Map contents therefore depend on this lattice, so the
+// product mirrors it: an index-based node pool that keeps leaf coordinates (needed to re-split)
+// and answers, per incoming point, "stored or dropped".  Effective bucket size is 32 because the
+// reference's setter is a no-op (Octree.hpp:155,178-180).
+//
+// Round-1 status: this runs on the host (O(batch * depth)); SURVEY.md section 8 row f-1 moves it
+// to the GPU.  It is not a fallback of any GPU kernel: no GPU version exists yet.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+namespace flimo {
+
+struct InsertBook;
+InsertBook* insert_book_create();
+void insert_book_destroy(InsertBook* b);
+void insert_book_config(InsertBook* b, float min_extent, bool downsample);
+void insert_book_clear(InsertBook* b);
+size_t insert_book_size(const InsertBook* b);
+// xyz: n packed NaN-free points.  keep[i] := 1 if point i is stored, 0 if dropped.
+void insert_book_update(InsertBook* b, const float* xyz, size_t n, unsigned char* keep);
+
+}  // namespace flimo

@@ -1,0 +1,41 @@
+// fast_limo_amd/csrc/hip/flimo_kernels.h -- host-callable launchers of the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "flimo_types.h"
+
+namespace flimo {
+
+// flimo_kernels.hip
+void launch_match(hipStream_t st, int lanes_per_query, const GridView& G, const float4* scan, const PoseMats& P,
+                  const MatchParams& mp, Rec16* recs, RecDbg* dbg, unsigned long long* cand);
+void launch_knn(hipStream_t st, const GridView& G, const float* qxyz, int nq, int k, int max_ring, int32_t* idx,
+                float* sqd, int32_t* cnt);
+void launch_cap(hipStream_t st, Rec16* recs, int n, int cap);
+void launch_reduce(hipStream_t st, const Rec16* recs, int n, int nwaves, double* partials, double* out256);
+void launch_mfma_layout(hipStream_t st, double* raw256);
+void launch_deskew(hipStream_t st, const float4* in, const double* t, int n, const void* frames, int nf,
+                   const float* mats32, float4* out);
+void launch_transform(hipStream_t st, const float4* in, int n, const PoseMats& P, float4* out);
+size_t dev_frame_size();
+
+// flimo_map.hip
+struct MapBuildScratch {
+  void* cub_tmp = nullptr;
+  size_t cub_tmp_bytes = 0;
+  uint32_t* keys_in = nullptr;
+  uint32_t* keys_out = nullptr;
+  uint32_t* vals_in = nullptr;
+  uint32_t* vals_out = nullptr;
+  size_t cap_pts = 0;
+  float* bbox = nullptr;   // 6 floats on device (min xyz, max xyz) as ordered ints
+};
+
+// min/max of n float4 points (NaN-free) -> host bbox[6]
+hipError_t map_bbox(hipStream_t st, const float4* pts, size_t n, MapBuildScratch& S, float bbox_host[6]);
+// Sorts `pts_in` by grid cell into `pts_out`, fills cell_start[ncells+1].
+hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4* pts_out, uint32_t* cell_start,
+                          size_t ncells, float ox, float oy, float oz, float inv_cell, int nx, int ny, int nz,
+                          MapBuildScratch& S);
+void map_scratch_free(MapBuildScratch& S);
+
+}  // namespace flimo

@@ -1,0 +1,653 @@
+// fast_limo_amd/csrc/hip/flimo_kernels.hip  -- gfx950 (MI355X) only.
+//
+// Hand-written HIP kernels of the fast_LIMO registration hot path:
+//   match_kernel<L>   Mapper::match + match_plane + Plane + Match + calculate_H for one scan
+//                     point per group of L lanes (reference Modules/Mapper.cpp:59-114,
+//                     Objects/Octree.hpp:526-599, Objects/Plane.cpp:23-114, Objects/Match.cpp:23-28,
+//                     Modules/Localizer.cpp:537-577)
+//   knn_kernel<L>     octree::Octree::knn for a batch of world-frame queries (Octree.hpp:526-555)
+//   reduce_kernel     h_x^T h_x, h_x^T h and the match count with v_mfma_f64_16x16x4_f64
+//                     (esekfom.hpp:1723,1727)
+//   cap_kernel        MAX_NUM_MATCHES "first M matches" rule (Localizer.cpp:539)
+//   deskew_kernel     Localizer::deskewPointCloud loop (Localizer.cpp:822-843)
+//   transform_kernel  pcl::transformPointCloud(pc2match, state.get_RT()) (Localizer.cpp:361)
+//
+// The map is a uniform grid (flimo_types.h: GridView).  A query visits the 3x3x3 block of cells
+// around it as 9 contiguous point ranges (x-adjacent cells are adjacent in memory), keeps a
+// register-resident sorted best-5, and proves exactness with a conservative "ball inside the
+// visited block" test; otherwise it widens ring by ring (shell only, pruned by box distance).
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <limits.h>
+#include "flimo_types.h"
+#include "flimo_math.h"
+#include "flimo_kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace flimo {
+
+// ------------------------------------------------------------------------------------------
+// best-5 list: ascending by (squared distance, map index).  Empty slots: (FLT_MAX, INT_MAX).
+// ------------------------------------------------------------------------------------------
+FLIMO_DEV bool pair_less(float d0, int i0, float d1, int i1) { return (d0 < d1) || (d0 == d1 && i0 < i1); }
+
+FLIMO_DEV void top5_insert(float (&bd)[5], int (&bi)[5], float d, int id) {
+  if (!pair_less(d, id, bd[4], bi[4])) return;
+  bd[4] = d;
+  bi[4] = id;
+#pragma unroll
+  for (int s = 4; s > 0; s--) {
+    const bool sw = pair_less(bd[s], bi[s], bd[s - 1], bi[s - 1]);
+    const float td = bd[s - 1];
+    const int ti = bi[s - 1];
+    bd[s - 1] = sw ? bd[s] : td;
+    bi[s - 1] = sw ? bi[s] : ti;
+    bd[s] = sw ? td : bd[s];
+    bi[s] = sw ? ti : bi[s];
+  }
+}
+
+// examine the points of one contiguous range with the L lanes of the query group
+template <int L>
+FLIMO_DEV void scan_range(const float4* __restrict__ pts, uint32_t lo, uint32_t hi, int sub, float gx, float gy,
+                          float gz, float (&bd)[5], int (&bi)[5], int& cand) {
+  uint32_t j = lo + (uint32_t)sub;
+  // two loads in flight per lane
+  for (; j + L < hi; j += 2 * L) {
+    const float4 p0 = pts[j];
+    const float4 p1 = pts[j + L];
+    const float d0 = sqdist3(gx, gy, gz, p0.x, p0.y, p0.z);
+    const float d1 = sqdist3(gx, gy, gz, p1.x, p1.y, p1.z);
+    top5_insert(bd, bi, d0, (int)j);
+    top5_insert(bd, bi, d1, (int)(j + L));
+    cand += 2;
+  }
+  if (j < hi) {
+    const float4 p0 = pts[j];
+    const float d0 = sqdist3(gx, gy, gz, p0.x, p0.y, p0.z);
+    top5_insert(bd, bi, d0, (int)j);
+    cand += 1;
+  }
+}
+
+// merge the private lists of the L lanes of a group; afterwards every lane holds the merged list
+template <int L>
+FLIMO_DEV void merge_group(float (&bd)[5], int (&bi)[5]) {
+#pragma unroll
+  for (int off = 1; off < L; off <<= 1) {
+    float od[5];
+    int oi[5];
+#pragma unroll
+    for (int s = 0; s < 5; s++) {
+      od[s] = __shfl_xor(bd[s], off, 64);
+      oi[s] = __shfl_xor(bi[s], off, 64);
+    }
+#pragma unroll
+    for (int s = 0; s < 5; s++) top5_insert(bd, bi, od[s], oi[s]);
+  }
+}
+
+// distance (in cell units) from the query to the slab of cells at offset d along one axis;
+// r = fractional position of the query inside its own cell, in [0,1]
+FLIMO_DEV float slab_dist(int d, float r) {
+  return d == 0 ? 0.f : (d > 0 ? ((float)d - r) : (r + (float)(-d - 1)));
+}
+
+struct KnnResult {
+  float bd[5];
+  int bi[5];
+  int cand;      // candidates examined by this lane
+  bool exact;    // the 5 entries are provably the exact 5-NN
+};
+
+// visit one row (fixed dy,dz) of the shell (r_prev, r] around cell (cx,cy,cz)
+template <int L>
+FLIMO_DEV void visit_row(const GridView& G, int cx, int cy, int cz, int dy, int dz, int r_prev, int r, float rx,
+                         float ry, float rz, float margin, float cell2, float bound, int sub, float gx, float gy,
+                         float gz, KnnResult& R) {
+  const float a = fmaxf(slab_dist(dy, ry) - margin, 0.f), b = fmaxf(slab_dist(dz, rz) - margin, 0.f);
+  const float yz2 = a * a + b * b;
+  if (yz2 * cell2 >= fminf(bound, R.bd[4])) return;   // the whole row is farther than the current 5th best
+  const size_t rowbase = ((size_t)(cz + dz) * (size_t)G.ny + (size_t)(cy + dy)) * (size_t)G.nx;
+  if (max(abs(dy), abs(dz)) > r_prev) {
+    const int x0 = max(cx - r, 0), x1 = min(cx + r, G.nx - 1);
+    if (x0 <= x1) {
+      const uint32_t lo = G.cell_start[rowbase + x0], hi = G.cell_start[rowbase + x1 + 1];
+      scan_range<L>(G.pts, lo, hi, sub, gx, gy, gz, R.bd, R.bi, R.cand);
+    }
+  } else {
+    // only the cells beyond the block already visited: [cx-r, cx-r_prev-1] and [cx+r_prev+1, cx+r]
+    {
+      const int x0 = max(cx - r, 0), x1 = min(cx - r_prev - 1, G.nx - 1);
+      const float sx = fmaxf(slab_dist(-(r_prev + 1), rx) - margin, 0.f);
+      if (x0 <= x1 && (sx * sx + yz2) * cell2 < fminf(bound, R.bd[4])) {
+        const uint32_t lo = G.cell_start[rowbase + x0], hi = G.cell_start[rowbase + x1 + 1];
+        scan_range<L>(G.pts, lo, hi, sub, gx, gy, gz, R.bd, R.bi, R.cand);
+      }
+    }
+    {
+      const int x0 = max(cx + r_prev + 1, 0), x1 = min(cx + r, G.nx - 1);
+      const float sx = fmaxf(slab_dist(r_prev + 1, rx) - margin, 0.f);
+      if (x0 <= x1 && (sx * sx + yz2) * cell2 < fminf(bound, R.bd[4])) {
+        const uint32_t lo = G.cell_start[rowbase + x0], hi = G.cell_start[rowbase + x1 + 1];
+        scan_range<L>(G.pts, lo, hi, sub, gx, gy, gz, R.bd, R.bi, R.cand);
+      }
+    }
+  }
+}
+
+// Exact 5-NN of (gx,gy,gz) over the grid; the L lanes of a group cooperate (sub = lane % L).
+// max_ring bounds the widening: if the search stops at max_ring without `exact`, then the true
+// 5th squared distance is >= ((max_ring + edge - margin) * cell)^2 >= (max_ring*cell - margin*cell)^2.
+template <int L>
+FLIMO_DEV void knn_search(const GridView& G, float gx, float gy, float gz, int sub, int max_ring, KnnResult& R) {
+#pragma unroll
+  for (int s = 0; s < 5; s++) { R.bd[s] = FLT_MAX; R.bi[s] = INT_MAX; }
+  R.cand = 0;
+  R.exact = false;
+
+  // query cell (same float expression as the map build: floor((p - o) * inv_cell))
+  const float fx = (gx - G.ox) * G.inv_cell, fy = (gy - G.oy) * G.inv_cell, fz = (gz - G.oz) * G.inv_cell;
+  if (!(fx == fx) || !(fy == fy) || !(fz == fz)) return;   // NaN query: no neighbours
+  const float lim = 1.0e9f;
+  const float flx = floorf(fminf(fmaxf(fx, -lim), lim));
+  const float fly = floorf(fminf(fmaxf(fy, -lim), lim));
+  const float flz = floorf(fminf(fmaxf(fz, -lim), lim));
+  const int cx = (int)flx, cy = (int)fly, cz = (int)flz;
+  const float rx = fminf(fmaxf(fx - flx, 0.f), 1.f), ry = fminf(fmaxf(fy - fly, 0.f), 1.f),
+              rz = fminf(fmaxf(fz - flz, 0.f), 1.f);
+
+  const int maxdim = max(G.nx, max(G.ny, G.nz));
+  const float margin = 1.0e-3f + 4.0e-7f * (float)maxdim;   // cell units; covers the rounding of the cell map
+  const float cell2 = G.cell * G.cell;
+  const float edge = fminf(fminf(fminf(rx, 1.f - rx), fminf(ry, 1.f - ry)), fminf(rz, 1.f - rz));
+
+  // first ring that can reach the grid at all
+  int r0;
+  {
+    const int ox_ = cx < 0 ? -cx : (cx >= G.nx ? cx - G.nx + 1 : 0);
+    const int oy_ = cy < 0 ? -cy : (cy >= G.ny ? cy - G.ny + 1 : 0);
+    const int oz_ = cz < 0 ? -cz : (cz >= G.nz ? cz - G.nz + 1 : 0);
+    r0 = max(1, max(ox_, max(oy_, oz_)));
+  }
+  if (r0 > max_ring) return;   // nothing within the gate distance
+
+  int r_prev = -1;
+  int r = r0;
+  float bound = FLT_MAX;       // merged 5th-best of the group so far (valid pruning bound)
+  for (;;) {
+    if (r == 1) {
+      // ---- common case: the 3x3x3 block as 9 contiguous ranges.  All 18 range bounds are loaded
+      //      before any point so their latencies overlap. ----
+      uint32_t lo[9], hi[9];
+      const int x0 = max(cx - 1, 0), x1 = min(cx + 1, G.nx - 1);
+#pragma unroll
+      for (int t = 0; t < 9; t++) {
+        const int dy = (t % 3 == 0) ? 0 : ((t % 3 == 1) ? -1 : 1);
+        const int dz = (t / 3 == 0) ? 0 : ((t / 3 == 1) ? -1 : 1);
+        const int yy = cy + dy, zz = cz + dz;
+        const bool in = (yy >= 0) && (yy < G.ny) && (zz >= 0) && (zz < G.nz) && (x0 <= x1);
+        const size_t rowbase = ((size_t)(in ? zz : 0) * (size_t)G.ny + (size_t)(in ? yy : 0)) * (size_t)G.nx;
+        lo[t] = in ? G.cell_start[rowbase + x0] : 0u;
+        hi[t] = in ? G.cell_start[rowbase + x1 + 1] : 0u;
+      }
+#pragma unroll
+      for (int t = 0; t < 9; t++) {
+        const int dy = (t % 3 == 0) ? 0 : ((t % 3 == 1) ? -1 : 1);
+        const int dz = (t / 3 == 0) ? 0 : ((t / 3 == 1) ? -1 : 1);
+        const float a = fmaxf(slab_dist(dy, ry) - margin, 0.f), b = fmaxf(slab_dist(dz, rz) - margin, 0.f);
+        if ((a * a + b * b) * cell2 >= R.bd[4]) continue;
+        scan_range<L>(G.pts, lo[t], hi[t], sub, gx, gy, gz, R.bd, R.bi, R.cand);
+      }
+    } else {
+      // ---- shell (r_prev, r] (rare): rows in ascending order, clipped to the grid ----
+      const int dz0 = max(-r, -cz), dz1 = min(r, G.nz - 1 - cz);
+      const int dy0 = max(-r, -cy), dy1 = min(r, G.ny - 1 - cy);
+      for (int dz = dz0; dz <= dz1; dz++)
+        for (int dy = dy0; dy <= dy1; dy++)
+          visit_row<L>(G, cx, cy, cz, dy, dz, r_prev, r, rx, ry, rz, margin, cell2, bound, sub, gx, gy, gz, R);
+    }
+    // ---- merge the group, test exactness ----
+    if (L > 1) merge_group<L>(R.bd, R.bi);
+    const float rg = ((float)r + edge - margin) * G.cell;   // every unvisited point is >= rg away
+    const bool have5 = R.bi[4] != INT_MAX;
+    const bool covers = (cx - r <= 0) && (cx + r >= G.nx - 1) && (cy - r <= 0) && (cy + r >= G.ny - 1) &&
+                        (cz - r <= 0) && (cz + r >= G.nz - 1);
+    if (covers || (have5 && R.bd[4] <= rg * rg * (1.f - 1.0e-6f))) { R.exact = true; break; }
+    if (r >= max_ring) break;
+    // next ring: straight to the radius that proves exactness once 5 candidates are known, else double
+    int rn = 2 * r;
+    if (have5) {
+      bound = R.bd[4];
+      const float need = __fsqrt_rn(R.bd[4]) * G.inv_cell * (1.f + 4.0e-6f) - edge + margin;
+      rn = max(r + 1, (int)ceilf(fminf(need, 1.0e9f)));
+    }
+    rn = min(rn, max_ring);
+    // keep the merged list on lane 0 of the group only (no duplicates at the next merge)
+    if (L > 1 && sub != 0) {
+#pragma unroll
+      for (int s = 0; s < 5; s++) { R.bd[s] = FLT_MAX; R.bi[s] = INT_MAX; }
+    }
+    r_prev = r;
+    r = rn;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// match kernel
+// ------------------------------------------------------------------------------------------
+template <int L, bool DBG>
+__global__ __launch_bounds__(256) void match_kernel(GridView G, const float4* __restrict__ scan, PoseMats P,
+                                                    MatchParams mp, Rec16* __restrict__ recs,
+                                                    RecDbg* __restrict__ dbg, unsigned long long* __restrict__ cand_total) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int q = tid / L;
+  const int sub = tid % L;
+  if (q >= mp.n_queries) return;   // whole groups exit together (n_queries groups of L lanes)
+
+  const float4 sp = scan[q];
+  float gx, gy, gz;
+  xform4(P.RT, sp.x, sp.y, sp.z, gx, gy, gz);   // global_point = s.get_RT() * bl4_point
+
+  KnnResult R;
+  knn_search<L>(G, gx, gy, gz, sub, mp.max_ring, R);
+
+  const bool have5 = R.bi[4] != INT_MAX;
+  // Plane gates (Plane.cpp:23-31): enough_points, close_enough (5th SQUARED distance < MAX_DIST_PLANE).
+  // If the search stopped inexact at max_ring the true 5th distance already fails close_enough.
+  bool valid = have5 && R.exact && (R.bd[4] < mp.max_dist_plane);
+
+  float n[4] = {0.f, 0.f, 0.f, 0.f};
+  float dist = 0.f;
+  float H[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) H[i] = 0.f;
+
+  if (valid) {
+    float px[5], py[5], pz[5];
+#pragma unroll
+    for (int s = 0; s < 5; s++) {
+      const float4 p = G.pts[R.bi[s]];
+      px[s] = p.x; py[s] = p.y; pz[s] = p.z;
+    }
+    plane_fit5(px, py, pz, n);
+    valid = plane_eval5(n, px, py, pz, mp.plane_threshold);
+    if (valid) {
+      // Match::Match: dist = n . p_global + d   (Plane.cpp:50-52)
+      dist = n[0] * gx + n[1] * gy + n[2] * gz + n[3];
+      // calculate_H (Localizer.cpp:549-569)
+      float ix, iy, iz, lx, ly, lz;
+      xform4(P.RT_inv, gx, gy, gz, ix, iy, iz);        // p_imu
+      xform4(P.TLI_inv, ix, iy, iz, lx, ly, lz);       // p_lidar
+      float Cx, Cy, Cz;
+      mul3(P.R_inv, n[0], n[1], n[2], Cx, Cy, Cz);     // C = R_inv * n
+      float Dx, Dy, Dz;
+      mul3(P.RLI_inv, Cx, Cy, Cz, Dx, Dy, Dz);         // I_R_L_inv * C
+      float Bx, By, Bz, Ax, Ay, Az;
+      cross3(lx, ly, lz, Dx, Dy, Dz, Bx, By, Bz);      // B = p_lidar x (I_R_L_inv*C)
+      cross3(ix, iy, iz, Cx, Cy, Cz, Ax, Ay, Az);      // A = p_imu x C
+      H[0] = n[0]; H[1] = n[1]; H[2] = n[2]; H[3] = Ax; H[4] = Ay; H[5] = Az;
+      if (mp.estimate_extrinsics) { H[6] = Bx; H[7] = By; H[8] = Bz; H[9] = Cx; H[10] = Cy; H[11] = Cz; }
+    }
+  }
+
+  if (DBG) {
+    // per-group candidate count
+    int c = R.cand;
+#pragma unroll
+    for (int off = 1; off < L; off <<= 1) c += __shfl_xor(c, off, 64);
+    if (sub == 0) {
+      RecDbg d;
+#pragma unroll
+      for (int i = 0; i < 4; i++) d.n[i] = valid ? n[i] : 0.f;
+      d.p_global[0] = gx; d.p_global[1] = gy; d.p_global[2] = gz;
+      int cnt = 0;
+#pragma unroll
+      for (int s = 0; s < 5; s++) {
+        const bool has = R.bi[s] != INT_MAX;
+        cnt += has ? 1 : 0;
+        d.sqd[s] = has ? R.bd[s] : 0.f;
+        d.nbr[s] = has ? R.bi[s] : -1;
+      }
+      d.n_nbr = R.exact ? cnt : -cnt - 1;   // negative: search stopped at the gate radius (not exact)
+      d.cand = c;
+      d.pad = 0;
+      dbg[q] = d;
+      atomicAdd(cand_total, (unsigned long long)c);
+    }
+  }
+
+  if (sub == 0) {
+    float4* out = reinterpret_cast<float4*>(&recs[q]);
+    if (valid) {
+      out[0] = make_float4(H[0], H[1], H[2], H[3]);
+      out[1] = make_float4(H[4], H[5], H[6], H[7]);
+      out[2] = make_float4(H[8], H[9], H[10], H[11]);
+      out[3] = make_float4(-dist, 1.f, 0.f, 0.f);
+    } else {
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      out[0] = z; out[1] = z; out[2] = z; out[3] = z;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// standalone exact kNN (Octree::knn boundary)
+// ------------------------------------------------------------------------------------------
+template <int L>
+__global__ __launch_bounds__(256) void knn_kernel(GridView G, const float* __restrict__ qxyz, int nq, int k,
+                                                  int max_ring, int32_t* __restrict__ idx, float* __restrict__ sqd,
+                                                  int32_t* __restrict__ cnt) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int q = tid / L;
+  const int sub = tid % L;
+  if (q >= nq) return;
+  KnnResult R;
+  knn_search<L>(G, qxyz[3 * q], qxyz[3 * q + 1], qxyz[3 * q + 2], sub, max_ring, R);
+  if (sub == 0) {
+    int c = 0;
+    for (int s = 0; s < k; s++) {
+      const bool has = R.bi[s] != INT_MAX;
+      c += has ? 1 : 0;
+      idx[(size_t)q * k + s] = has ? R.bi[s] : -1;
+      sqd[(size_t)q * k + s] = has ? R.bd[s] : 0.f;
+    }
+    cnt[q] = R.exact ? c : -c - 1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// MAX_NUM_MATCHES: keep only the first `cap` valid records in scan order (single block)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void cap_kernel(Rec16* __restrict__ recs, int n, int cap) {
+  __shared__ int s_cnt[1024];
+  const int t = threadIdx.x;
+  const int per = (n + 1023) / 1024;
+  const int b = t * per, e = min(n, b + per);
+  int c = 0;
+  for (int i = b; i < e; i++) c += (recs[i].v[13] != 0.f) ? 1 : 0;
+  s_cnt[t] = c;
+  __syncthreads();
+  // inclusive scan (Hillis-Steele)
+  for (int off = 1; off < 1024; off <<= 1) {
+    int v = (t >= off) ? s_cnt[t - off] : 0;
+    __syncthreads();
+    s_cnt[t] += v;
+    __syncthreads();
+  }
+  int rank = s_cnt[t] - c;   // exclusive prefix
+  for (int i = b; i < e; i++) {
+    if (recs[i].v[13] != 0.f) {
+      if (rank >= cap) {
+        float4* o = reinterpret_cast<float4*>(&recs[i]);
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        o[0] = z; o[1] = z; o[2] = z; o[3] = z;
+      }
+      rank++;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// HTH / HTh / M reduction with the f64 matrix core: D += X^T X where the 16 columns of X are
+// [H(12) | h | valid | 0 | 0]; so D[0:12,0:12] = H^T H, D[0:12,12] = H^T h, D[13,13] = M.
+// One wave accumulates a strided set of 4-record groups; raw accumulators (4 doubles per lane)
+// go to partials[wave][lane*4 + r]; reduce_final sums them in a fixed order.
+// ------------------------------------------------------------------------------------------
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(64) void reduce_kernel(const Rec16* __restrict__ recs, int n, double* __restrict__ partials) {
+  const int lane = threadIdx.x;
+  const int w = blockIdx.x;
+  const int nw = gridDim.x;
+  const int col = lane & 15, sub = lane >> 4;
+  const int groups = (n + 3) >> 2;
+  double4_t acc = {0.0, 0.0, 0.0, 0.0};
+  const float* base = reinterpret_cast<const float*>(recs);
+  for (int g = w; g < groups; g += nw) {
+    const int q = 4 * g + sub;
+    const float v = (q < n) ? base[(size_t)q * 16 + col] : 0.f;
+    const double a = (double)v;
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc, 0, 0, 0);
+  }
+  double* o = partials + (size_t)w * 256 + lane * 4;
+  o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3];
+}
+
+__global__ __launch_bounds__(256) void reduce_final_kernel(const double* __restrict__ partials, int nw,
+                                                           double* __restrict__ out) {
+  const int t = threadIdx.x;
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  int w = 0;
+  for (; w + 3 < nw; w += 4) {
+    s0 += partials[(size_t)(w + 0) * 256 + t];
+    s1 += partials[(size_t)(w + 1) * 256 + t];
+    s2 += partials[(size_t)(w + 2) * 256 + t];
+    s3 += partials[(size_t)(w + 3) * 256 + t];
+  }
+  for (; w < nw; w++) s0 += partials[(size_t)w * 256 + t];
+  out[t] = (s0 + s1) + (s2 + s3);
+}
+
+// calibration of the MFMA operand/result layout: D = A*B with A[i][0]=1, A[i][1]=i, B[0][j]=j,
+// B[1][j]=16  =>  D[i][j] = j + 16*i.  Operands are placed under the assumed layout
+// (lane -> row/col = lane%16, k = lane/16); the host decodes raw[lane*4+r] -> (i,j).
+__global__ void mfma_layout_kernel(double* __restrict__ raw) {
+  const int lane = threadIdx.x;
+  const int rc = lane & 15, k = lane >> 4;
+  const double a = (k == 0) ? 1.0 : (k == 1 ? (double)rc : 0.0);
+  const double b = (k == 0) ? (double)rc : (k == 1 ? 16.0 : 0.0);
+  double4_t acc = {0.0, 0.0, 0.0, 0.0};
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  raw[lane * 4 + 0] = acc[0]; raw[lane * 4 + 1] = acc[1]; raw[lane * 4 + 2] = acc[2]; raw[lane * 4 + 3] = acc[3];
+}
+
+// ------------------------------------------------------------------------------------------
+// deskew (Localizer.cpp:822-843) with State::update (State.cpp:76-119)
+// ------------------------------------------------------------------------------------------
+struct DevFrame {
+  float p[3], q[4], v[3], g[3], w[3], a[3], bg[3], ba[3];
+  float pad;
+  double time;
+};
+
+// Eigen::Quaternionf::toRotationMatrix
+FLIMO_DEV void quat_to_rot(float qx, float qy, float qz, float qw, float (&R)[9]) {
+  const float tx = 2.f * qx, ty = 2.f * qy, tz = 2.f * qz;
+  const float twx = tx * qw, twy = ty * qw, twz = tz * qw;
+  const float txx = tx * qx, txy = ty * qx, txz = tz * qx;
+  const float tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+  R[0] = 1.f - (tyy + tzz); R[1] = txy - twz;         R[2] = txz + twy;
+  R[3] = txy + twz;         R[4] = 1.f - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy;         R[7] = tyz + twx;         R[8] = 1.f - (txx + tyy);
+}
+
+__global__ __launch_bounds__(256) void deskew_kernel(const float4* __restrict__ in, const double* __restrict__ t,
+                                                     int n, const DevFrame* __restrict__ frames, int nf,
+                                                     const float* __restrict__ mats /* [0..15] lidar2baselink_T,
+                                                     [16..31] last_state.get_RT_inv() */,
+                                                     float4* __restrict__ out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const double tk = t[k];
+  // binary_search_tailored (Algorithms.hpp:25-38)
+  int low = 0, high = nf - 1;
+  while (high >= low) {
+    const int mid = (low + high) / 2;
+    if (frames[mid].time > tk) high = mid - 1; else low = mid + 1;
+  }
+  const int i_f = high < 0 ? 0 : high;
+  const DevFrame F = frames[i_f];
+  // State::update(tk)
+  const double dt = tk - F.time;
+  const float wx = F.w[0] - F.bg[0], wy = F.w[1] - F.bg[1], wz = F.w[2] - F.bg[2];
+  const float w_norm = __fsqrt_rn(sum3(wx * wx, wy * wy, wz * wz));
+  float Rm[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
+  if ((double)w_norm > 1.e-7) {
+    const float r0 = __fdiv_rn(wx, w_norm), r1 = __fdiv_rn(wy, w_norm), r2 = __fdiv_rn(wz, w_norm);
+    const float K[9] = {0.f, -r2, r1, r2, 0.f, -r0, -r1, r0, 0.f};
+    const float r_ang = (float)((double)w_norm * dt);
+    const float s = sinf(r_ang);
+    const float c = (float)(1.0 - (double)cosf(r_ang));
+    float cK[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) cK[i] = c * K[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        const float kk = sum3(cK[i * 3 + 0] * K[0 * 3 + j], cK[i * 3 + 1] * K[1 * 3 + j], cK[i * 3 + 2] * K[2 * 3 + j]);
+        Rm[i * 3 + j] = Rm[i * 3 + j] + (s * K[i * 3 + j] + kk);
+      }
+  }
+  // a0 = q._transformVector(a - ba) + g   (only needed for p)
+  const float qx = F.q[0], qy = F.q[1], qz = F.q[2], qw = F.q[3];
+  const float ax = F.a[0] - F.ba[0], ay = F.a[1] - F.ba[1], az = F.a[2] - F.ba[2];
+  float ux, uy, uz;
+  cross3(qx, qy, qz, ax, ay, az, ux, uy, uz);
+  ux = ux + ux; uy = uy + uy; uz = uz + uz;
+  float cx_, cy_, cz_;
+  cross3(qx, qy, qz, ux, uy, uz, cx_, cy_, cz_);
+  float a0x = (ax + qw * ux) + cx_, a0y = (ay + qw * uy) + cy_, a0z = (az + qw * uz) + cz_;
+  a0x = a0x + F.g[0]; a0y = a0y + F.g[1]; a0z = a0z + F.g[2];
+  // q *= Quaternionf(R)
+  float ux_, uy_, uz_, uw_;
+  {
+    float tr = Rm[0] + Rm[4] + Rm[8];
+    if (tr > 0.f) {
+      tr = __fsqrt_rn(tr + 1.0f);
+      uw_ = 0.5f * tr;
+      tr = __fdiv_rn(0.5f, tr);
+      ux_ = (Rm[7] - Rm[5]) * tr;
+      uy_ = (Rm[2] - Rm[6]) * tr;
+      uz_ = (Rm[3] - Rm[1]) * tr;
+    } else {
+      int i = 0;
+      if (Rm[4] > Rm[0]) i = 1;
+      if (Rm[8] > Rm[i * 4]) i = 2;
+      const int j = (i + 1) % 3, kq = (j + 1) % 3;
+      float tq = __fsqrt_rn(Rm[i * 4] - Rm[j * 4] - Rm[kq * 4] + 1.0f);
+      float cc[3];
+      cc[i] = 0.5f * tq;
+      tq = __fdiv_rn(0.5f, tq);
+      uw_ = (Rm[kq * 3 + j] - Rm[j * 3 + kq]) * tq;
+      cc[j] = (Rm[j * 3 + i] + Rm[i * 3 + j]) * tq;
+      cc[kq] = (Rm[kq * 3 + i] + Rm[i * 3 + kq]) * tq;
+      ux_ = cc[0]; uy_ = cc[1]; uz_ = cc[2];
+    }
+  }
+  const float nqw = qw * uw_ - qx * ux_ - qy * uy_ - qz * uz_;
+  const float nqx = qw * ux_ + qx * uw_ + qy * uz_ - qz * uy_;
+  const float nqy = qw * uy_ + qy * uw_ + qz * ux_ - qx * uz_;
+  const float nqz = qw * uz_ + qz * uw_ + qx * uy_ - qy * ux_;
+  // p += v*dt + 0.5*a0*dt*dt
+  const float fdt = (float)dt;
+  const float px = F.p[0] + (fdt * F.v[0] + fdt * (fdt * (0.5f * a0x)));
+  const float py = F.p[1] + (fdt * F.v[1] + fdt * (fdt * (0.5f * a0y)));
+  const float pz = F.p[2] + (fdt * F.v[2] + fdt * (fdt * (0.5f * a0z)));
+  // T = X0.get_RT() * lidar2baselink_T  (4x4 * 4x4, columns accumulated left to right)
+  float R0[9];
+  quat_to_rot(nqx, nqy, nqz, nqw, R0);
+  const float X[16] = {R0[0], R0[1], R0[2], px, R0[3], R0[4], R0[5], py, R0[6], R0[7], R0[8], pz, 0.f, 0.f, 0.f, 1.f};
+  float T[16];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      float acc = X[i * 4 + 0] * mats[0 * 4 + j];
+      acc = acc + X[i * 4 + 1] * mats[1 * 4 + j];
+      acc = acc + X[i * 4 + 2] * mats[2 * 4 + j];
+      acc = acc + X[i * 4 + 3] * mats[3 * 4 + j];
+      T[i * 4 + j] = acc;
+    }
+  const float4 p = in[k];
+  // world = T * [p,1]; the 4th component (T row 3) is carried like the reference does
+  float wx_ = ((T[0] * p.x + T[1] * p.y) + T[2] * p.z) + T[3] * 1.f;
+  float wy_ = ((T[4] * p.x + T[5] * p.y) + T[6] * p.z) + T[7] * 1.f;
+  float wz_ = ((T[8] * p.x + T[9] * p.y) + T[10] * p.z) + T[11] * 1.f;
+  float ww_ = ((T[12] * p.x + T[13] * p.y) + T[14] * p.z) + T[15] * 1.f;
+  const float* Li = mats + 16;
+  const float ox_ = ((Li[0] * wx_ + Li[1] * wy_) + Li[2] * wz_) + Li[3] * ww_;
+  const float oy_ = ((Li[4] * wx_ + Li[5] * wy_) + Li[6] * wz_) + Li[7] * ww_;
+  const float oz_ = ((Li[8] * wx_ + Li[9] * wy_) + Li[10] * wz_) + Li[11] * ww_;
+  out[k] = make_float4(ox_, oy_, oz_, p.w);
+}
+
+// pcl::transformPointCloud (PCL 1.10 SSE2 Transformer::se3): c0*x + (c1*y + (c2*z + c3))
+__global__ __launch_bounds__(256) void transform_kernel(const float4* __restrict__ in, int n, PoseMats P,
+                                                        float4* __restrict__ out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const float4 p = in[k];
+  const float* M = P.RT;
+  const float x = M[0] * p.x + (M[1] * p.y + (M[2] * p.z + M[3]));
+  const float y = M[4] * p.x + (M[5] * p.y + (M[6] * p.z + M[7]));
+  const float z = M[8] * p.x + (M[9] * p.y + (M[10] * p.z + M[11]));
+  out[k] = make_float4(x, y, z, p.w);
+}
+
+// ------------------------------------------------------------------------------------------
+// host-callable launchers
+// ------------------------------------------------------------------------------------------
+template <int L>
+static void launch_match_L(hipStream_t st, const GridView& G, const float4* scan, const PoseMats& P,
+                           const MatchParams& mp, Rec16* recs, RecDbg* dbg, unsigned long long* cand) {
+  const long long threads = (long long)mp.n_queries * L;
+  const int blocks = (int)((threads + 255) / 256);
+  if (blocks == 0) return;
+  if (dbg)
+    hipLaunchKernelGGL((match_kernel<L, true>), dim3(blocks), dim3(256), 0, st, G, scan, P, mp, recs, dbg, cand);
+  else
+    hipLaunchKernelGGL((match_kernel<L, false>), dim3(blocks), dim3(256), 0, st, G, scan, P, mp, recs, dbg, cand);
+}
+
+void launch_match(hipStream_t st, int lanes_per_query, const GridView& G, const float4* scan, const PoseMats& P,
+                  const MatchParams& mp, Rec16* recs, RecDbg* dbg, unsigned long long* cand) {
+  switch (lanes_per_query) {
+    case 1: launch_match_L<1>(st, G, scan, P, mp, recs, dbg, cand); break;
+    case 2: launch_match_L<2>(st, G, scan, P, mp, recs, dbg, cand); break;
+    case 4: launch_match_L<4>(st, G, scan, P, mp, recs, dbg, cand); break;
+    case 8: launch_match_L<8>(st, G, scan, P, mp, recs, dbg, cand); break;
+    default: launch_match_L<16>(st, G, scan, P, mp, recs, dbg, cand); break;
+  }
+}
+
+void launch_knn(hipStream_t st, const GridView& G, const float* qxyz, int nq, int k, int max_ring, int32_t* idx,
+                float* sqd, int32_t* cnt) {
+  const int L = 4;
+  const long long threads = (long long)nq * L;
+  const int blocks = (int)((threads + 255) / 256);
+  if (blocks == 0) return;
+  hipLaunchKernelGGL((knn_kernel<4>), dim3(blocks), dim3(256), 0, st, G, qxyz, nq, k, max_ring, idx, sqd, cnt);
+}
+
+void launch_cap(hipStream_t st, Rec16* recs, int n, int cap) {
+  hipLaunchKernelGGL(cap_kernel, dim3(1), dim3(1024), 0, st, recs, n, cap);
+}
+
+void launch_reduce(hipStream_t st, const Rec16* recs, int n, int nwaves, double* partials, double* out256) {
+  hipLaunchKernelGGL(reduce_kernel, dim3(nwaves), dim3(64), 0, st, recs, n, partials);
+  hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, st, partials, nwaves, out256);
+}
+
+void launch_mfma_layout(hipStream_t st, double* raw256) {
+  hipLaunchKernelGGL(mfma_layout_kernel, dim3(1), dim3(64), 0, st, raw256);
+}
+
+void launch_deskew(hipStream_t st, const float4* in, const double* t, int n, const void* frames, int nf,
+                   const float* mats32, float4* out) {
+  const int blocks = (n + 255) / 256;
+  if (blocks == 0) return;
+  hipLaunchKernelGGL(deskew_kernel, dim3(blocks), dim3(256), 0, st, in, t, n, (const DevFrame*)frames, nf, mats32, out);
+}
+
+void launch_transform(hipStream_t st, const float4* in, int n, const PoseMats& P, float4* out) {
+  const int blocks = (n + 255) / 256;
+  if (blocks == 0) return;
+  hipLaunchKernelGGL(transform_kernel, dim3(blocks), dim3(256), 0, st, in, n, P, out);
+}
+
+size_t dev_frame_size() { return sizeof(DevFrame); }
+
+}  // namespace flimo

@@ -1,0 +1,172 @@
+// fast_limo_amd/csrc/hip/flimo_map.hip  -- gfx950 (MI355X) only.
+//
+// Build of the GPU-resident map index: a uniform grid over the bounding box of the stored points.
+// Replaces the pointer octree of the reference as the k-NN acceleration structure
+// (Objects/Octree.hpp:282-338 createOctant); which points are STORED is decided by the caller
+// (flimo_capi.cpp implements the reference's insert rule).  Steps, all on the context stream:
+//   1. bbox      : min/max reduction (wave shuffles + one atomic per wave)
+//   2. cell keys : key = floor((p - o) * inv_cell) linearised with x fastest
+//   3. sort      : stable LSD radix sort of (key, index) pairs (rocPRIM through hipCUB) -- keeps
+//                  insertion order inside a cell, so the device order is deterministic
+//   4. gather    : points re-ordered into cell order (float4, w keeps the insertion index)
+//   5. cell_start: lower-bound of every cell id in the sorted keys
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <float.h>
+#include "flimo_types.h"
+#include "flimo_kernels.h"
+
+namespace flimo {
+
+// order-preserving float <-> uint mapping for atomic min/max
+__device__ __forceinline__ unsigned f2o(float f) {
+  unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+static inline float o2f_host(unsigned o) {
+  unsigned u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+__global__ __launch_bounds__(256) void bbox_kernel(const float4* __restrict__ pts, size_t n, unsigned* __restrict__ box) {
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 p = pts[i];
+    mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
+    mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      mn[a] = fminf(mn[a], __shfl_xor(mn[a], off, 64));
+      mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off, 64));
+    }
+  }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      atomicMin(&box[a], f2o(mn[a]));
+      atomicMax(&box[3 + a], f2o(mx[a]));
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void cellkey_kernel(const float4* __restrict__ pts, size_t n, float ox, float oy,
+                                                      float oz, float inv_cell, int nx, int ny, int nz,
+                                                      uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = pts[i];
+  // identical float expression to the query side (flimo_kernels.hip: knn_search)
+  int cx = (int)floorf((p.x - ox) * inv_cell);
+  int cy = (int)floorf((p.y - oy) * inv_cell);
+  int cz = (int)floorf((p.z - oz) * inv_cell);
+  cx = min(max(cx, 0), nx - 1);
+  cy = min(max(cy, 0), ny - 1);
+  cz = min(max(cz, 0), nz - 1);
+  keys[i] = (uint32_t)(((size_t)cz * ny + cy) * nx + cx);
+  vals[i] = (uint32_t)i;
+}
+
+__global__ __launch_bounds__(256) void gather_kernel(const float4* __restrict__ in, const uint32_t* __restrict__ perm,
+                                                     size_t n, float4* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[i] = in[perm[i]];
+}
+
+// cell_start = inclusive max-scan of E, where E[key+1] = (index of the last element of that key's
+// run) + 1 and 0 elsewhere; so cell_start[c] = number of sorted keys < c.
+__global__ __launch_bounds__(256) void tails_kernel(const uint32_t* __restrict__ keys, size_t n,
+                                                    uint32_t* __restrict__ E) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t k = keys[i];
+  if (i + 1 == n || keys[i + 1] != k) E[(size_t)k + 1] = (uint32_t)(i + 1);
+}
+
+static hipError_t ensure_scratch(MapBuildScratch& S, size_t n) {
+  hipError_t e;
+  if (!S.bbox) {
+    if ((e = hipMalloc(&S.bbox, 6 * sizeof(unsigned))) != hipSuccess) return e;
+  }
+  if (n > S.cap_pts) {
+    if (S.keys_in) { hipFree(S.keys_in); hipFree(S.keys_out); hipFree(S.vals_in); hipFree(S.vals_out); }
+    const size_t cap = n + n / 4 + 1024;
+    if ((e = hipMalloc(&S.keys_in, cap * 4)) != hipSuccess) return e;
+    if ((e = hipMalloc(&S.keys_out, cap * 4)) != hipSuccess) return e;
+    if ((e = hipMalloc(&S.vals_in, cap * 4)) != hipSuccess) return e;
+    if ((e = hipMalloc(&S.vals_out, cap * 4)) != hipSuccess) return e;
+    S.cap_pts = cap;
+  }
+  return hipSuccess;
+}
+
+hipError_t map_bbox(hipStream_t st, const float4* pts, size_t n, MapBuildScratch& S, float bbox_host[6]) {
+  hipError_t e = ensure_scratch(S, 0);
+  if (e != hipSuccess) return e;
+  unsigned init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+  if ((e = hipMemcpyAsync(S.bbox, init, sizeof(init), hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+  const int blocks = (int)std::min<size_t>((n + 255) / 256, 2048);
+  if (blocks > 0) hipLaunchKernelGGL(bbox_kernel, dim3(blocks), dim3(256), 0, st, pts, n, (unsigned*)S.bbox);
+  unsigned out[6];
+  if ((e = hipMemcpyAsync(out, S.bbox, sizeof(out), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+  if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+  for (int i = 0; i < 6; i++) bbox_host[i] = o2f_host(out[i]);
+  return hipSuccess;
+}
+
+hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4* pts_out, uint32_t* cell_start,
+                          size_t ncells, float ox, float oy, float oz, float inv_cell, int nx, int ny, int nz,
+                          MapBuildScratch& S) {
+  hipError_t e = ensure_scratch(S, n);
+  if (e != hipSuccess) return e;
+  const int blocks = (int)((n + 255) / 256);
+  if (blocks > 0)
+    hipLaunchKernelGGL(cellkey_kernel, dim3(blocks), dim3(256), 0, st, pts_in, n, ox, oy, oz, inv_cell, nx, ny, nz,
+                       S.keys_in, S.vals_in);
+  // number of key bits actually used
+  int bits = 1;
+  while (bits < 32 && ((size_t)1 << bits) < ncells) bits++;
+  size_t tmp_bytes = 0;
+  e = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, S.keys_in, S.keys_out, S.vals_in, S.vals_out, (int)n, 0,
+                                         bits, st);
+  if (e != hipSuccess) return e;
+  if (tmp_bytes > S.cub_tmp_bytes) {
+    if (S.cub_tmp) hipFree(S.cub_tmp);
+    if ((e = hipMalloc(&S.cub_tmp, tmp_bytes + 1024)) != hipSuccess) return e;
+    S.cub_tmp_bytes = tmp_bytes + 1024;
+  }
+  if (n > 0) {
+    e = hipcub::DeviceRadixSort::SortPairs(S.cub_tmp, tmp_bytes, S.keys_in, S.keys_out, S.vals_in, S.vals_out, (int)n,
+                                           0, bits, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(256), 0, st, pts_in, S.vals_out, n, pts_out);
+  }
+  if ((e = hipMemsetAsync(cell_start, 0, (ncells + 1) * sizeof(uint32_t), st)) != hipSuccess) return e;
+  if (n > 0) hipLaunchKernelGGL(tails_kernel, dim3(blocks), dim3(256), 0, st, S.keys_out, n, cell_start);
+  size_t scan_bytes = 0;
+  e = hipcub::DeviceScan::InclusiveScan(nullptr, scan_bytes, cell_start, cell_start, hipcub::Max(), (int)(ncells + 1), st);
+  if (e != hipSuccess) return e;
+  if (scan_bytes > S.cub_tmp_bytes) {
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;   // the sort may still be using cub_tmp
+    if (S.cub_tmp) hipFree(S.cub_tmp);
+    if ((e = hipMalloc(&S.cub_tmp, scan_bytes + 1024)) != hipSuccess) return e;
+    S.cub_tmp_bytes = scan_bytes + 1024;
+  }
+  e = hipcub::DeviceScan::InclusiveScan(S.cub_tmp, scan_bytes, cell_start, cell_start, hipcub::Max(), (int)(ncells + 1), st);
+  if (e != hipSuccess) return e;
+  return hipGetLastError();
+}
+
+void map_scratch_free(MapBuildScratch& S) {
+  if (S.cub_tmp) hipFree(S.cub_tmp);
+  if (S.keys_in) { hipFree(S.keys_in); hipFree(S.keys_out); hipFree(S.vals_in); hipFree(S.vals_out); }
+  if (S.bbox) hipFree(S.bbox);
+  S = MapBuildScratch();
+}
+
+}  // namespace flimo

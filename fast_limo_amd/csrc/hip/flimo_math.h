@@ -1,0 +1,216 @@
+// fast_limo_amd/csrc/hip/flimo_math.h
+// Device-side float32 geometry of the registration hot path, written for gfx950.
+//
+// Every function here must produce results that are BIT-IDENTICAL to the reference's float32
+// arithmetic (x86-64 SSE2, no FMA: CMakeLists.txt:4-5,17-21), so
+//   * this header is compiled with -ffp-contract=off and the pragma below,
+//   * sqrt and divide are the correctly rounded forms (hipcc default; we call __fsqrt_rn /
+//     __fdiv_rn explicitly),
+//   * evaluation order follows Eigen's expression evaluation as documented per function.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "flimo_types.h"
+
+#pragma clang fp contract(off)
+
+namespace flimo {
+
+#define FLIMO_DEV __device__ __forceinline__
+
+// 3-coefficient Eigen reduction: c0 + (c1 + c2)
+FLIMO_DEV float sum3(float a, float b, float c) { return a + (b + c); }
+
+// (q - p).squaredNorm()  -- reference Objects/Octree.hpp:572
+FLIMO_DEV float sqdist3(float qx, float qy, float qz, float px, float py, float pz) {
+  float dx = qx - px, dy = qy - py, dz = qz - pz;
+  return sum3(dx * dx, dy * dy, dz * dz);
+}
+
+// Matrix4f * Vector4f(x,y,z,1): ((c0*x + c1*y) + c2*z) + c3*1   (Mapper.cpp:71-72, Localizer.cpp:549-550)
+FLIMO_DEV void xform4(const float* M, float x, float y, float z, float& ox, float& oy, float& oz) {
+  ox = ((M[0] * x + M[1] * y) + M[2] * z) + M[3];
+  oy = ((M[4] * x + M[5] * y) + M[6] * z) + M[7];
+  oz = ((M[8] * x + M[9] * y) + M[10] * z) + M[11];
+}
+
+// Matrix3f * Vector3f, coefficient-based: row . v = r0*v0 + (r1*v1 + r2*v2)   (Localizer.cpp:564-565)
+FLIMO_DEV void mul3(const float* R, float x, float y, float z, float& ox, float& oy, float& oz) {
+  ox = sum3(R[0] * x, R[1] * y, R[2] * z);
+  oy = sum3(R[3] * x, R[4] * y, R[5] * z);
+  oz = sum3(R[6] * x, R[7] * y, R[8] * z);
+}
+
+FLIMO_DEV void cross3(float ax, float ay, float az, float bx, float by, float bz, float& ox, float& oy, float& oz) {
+  ox = ay * bz - az * by;
+  oy = az * bx - ax * bz;
+  oz = ax * by - ay * bx;
+}
+
+// ------------------------------------------------------------------------------------------
+// Plane::estimate_plane (Objects/Plane.cpp:80-105): least squares A x = -1 on the 5 neighbours by
+// column-pivoted Householder QR (Eigen::ColPivHouseholderQR::compute + solve), then
+// n = x/|x|, d = 1/|x|.  Fully unrolled 5x3, registers only.  px/py/pz: the 5 neighbours in
+// ascending-distance order.  Returns n_ABCD in n[4].
+// ------------------------------------------------------------------------------------------
+FLIMO_DEV void plane_fit5(const float (&px)[5], const float (&py)[5], const float (&pz)[5], float (&n)[4]) {
+  float a[3][5];  // a[col][row]
+#pragma unroll
+  for (int i = 0; i < 5; i++) { a[0][i] = px[i]; a[1][i] = py[i]; a[2][i] = pz[i]; }
+  float nU[3], nD[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 5; i++) s = s + a[k][i] * a[k][i];
+    nD[k] = __fsqrt_rn(s);
+    nU[k] = nD[k];
+  }
+  const float eps = 1.1920929e-07f;
+  float maxn = nU[0];
+  if (nU[1] > maxn) maxn = nU[1];
+  if (nU[2] > maxn) maxn = nU[2];
+  const float th = maxn * eps;
+  const float threshold_helper = __fdiv_rn(th * th, 5.0f);
+  const float downdate_thr = __fsqrt_rn(eps);
+  int nzp = 3;
+  int perm0 = 0, perm1 = 1, perm2 = 2;
+  float hC[3];
+
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    // pivot: first column of largest updated norm among k..2
+    int big = k;
+    float bign = nU[k];
+#pragma unroll
+    for (int j = k + 1; j < 3; j++)
+      if (nU[j] > bign) { bign = nU[j]; big = j; }
+    const float big_sq = bign * bign;
+    if (nzp == 3 && big_sq < threshold_helper * float(5 - k)) nzp = k;
+    // column swap k <-> big (register selects, no dynamic indexing)
+#pragma unroll
+    for (int j = k + 1; j < 3; j++) {
+      const bool sw = (big == j);
+#pragma unroll
+      for (int i = 0; i < 5; i++) { float t0 = a[k][i], t1 = a[j][i]; a[k][i] = sw ? t1 : t0; a[j][i] = sw ? t0 : t1; }
+      { float t0 = nU[k], t1 = nU[j]; nU[k] = sw ? t1 : t0; nU[j] = sw ? t0 : t1; }
+      { float t0 = nD[k], t1 = nD[j]; nD[k] = sw ? t1 : t0; nD[j] = sw ? t0 : t1; }
+      // perm: swap(perm[k], perm[big])
+      if (k == 0) {
+        if (j == 1) { int t0 = perm0, t1 = perm1; perm0 = sw ? t1 : t0; perm1 = sw ? t0 : t1; }
+        if (j == 2) { int t0 = perm0, t1 = perm2; perm0 = sw ? t1 : t0; perm2 = sw ? t0 : t1; }
+      } else if (k == 1) {
+        if (j == 2) { int t0 = perm1, t1 = perm2; perm1 = sw ? t1 : t0; perm2 = sw ? t0 : t1; }
+      }
+    }
+    // Householder vector of a[k][k..4]
+    float tailSq = 0.f;
+#pragma unroll
+    for (int i = k + 1; i < 5; i++) tailSq = tailSq + a[k][i] * a[k][i];
+    const float c0 = a[k][k];
+    float tau, beta;
+    const float tol = 1.17549435e-38f;
+    if (tailSq <= tol) {
+      tau = 0.f;
+      beta = c0;
+#pragma unroll
+      for (int i = k + 1; i < 5; i++) a[k][i] = 0.f;
+    } else {
+      beta = __fsqrt_rn(c0 * c0 + tailSq);
+      if (c0 >= 0.f) beta = -beta;
+      const float denom = c0 - beta;
+#pragma unroll
+      for (int i = k + 1; i < 5; i++) a[k][i] = __fdiv_rn(a[k][i], denom);
+      tau = __fdiv_rn(beta - c0, beta);
+    }
+    hC[k] = tau;
+    a[k][k] = beta;
+    // apply H_k to the remaining columns
+    if (tau != 0.f) {
+#pragma unroll
+      for (int j = k + 1; j < 3; j++) {
+        float tmp = 0.f;
+#pragma unroll
+        for (int i = k + 1; i < 5; i++) tmp = tmp + a[k][i] * a[j][i];
+        tmp = tmp + a[j][k];
+        a[j][k] = a[j][k] - tau * tmp;
+#pragma unroll
+        for (int i = k + 1; i < 5; i++) a[j][i] = a[j][i] - (tau * a[k][i]) * tmp;
+      }
+    }
+    // column-norm downdate (LAPACK xGEQPF style)
+#pragma unroll
+    for (int j = k + 1; j < 3; j++) {
+      if (nU[j] != 0.f) {
+        float temp = __fdiv_rn(fabsf(a[j][k]), nU[j]);
+        temp = (1.f + temp) * (1.f - temp);
+        temp = temp < 0.f ? 0.f : temp;
+        const float ratio = __fdiv_rn(nU[j], nD[j]);
+        const float temp2 = temp * (ratio * ratio);
+        if (temp2 <= downdate_thr) {
+          float s = 0.f;
+#pragma unroll
+          for (int i = k + 1; i < 5; i++) s = s + a[j][i] * a[j][i];
+          nD[j] = __fsqrt_rn(s);
+          nU[j] = nD[j];
+        } else {
+          nU[j] = nU[j] * __fsqrt_rn(temp);
+        }
+      }
+    }
+  }
+
+  // ---- solve  min |A x - b|, b = -1 ----
+  float c[5] = {-1.f, -1.f, -1.f, -1.f, -1.f};
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const float tau = hC[k];
+    if (k < nzp && tau != 0.f) {
+      float tmp = 0.f;
+#pragma unroll
+      for (int i = k + 1; i < 5; i++) tmp = tmp + a[k][i] * c[i];
+      tmp = tmp + c[k];
+      c[k] = c[k] - tau * tmp;
+#pragma unroll
+      for (int i = k + 1; i < 5; i++) c[i] = c[i] - (tau * a[k][i]) * tmp;
+    }
+  }
+  // back substitution on the leading nzp x nzp upper triangle: R[i][j] = a[j][i]
+#pragma unroll
+  for (int i = 2; i >= 0; i--) {
+    if (i < nzp) {
+      float s = c[i];
+#pragma unroll
+      for (int j = i + 1; j < 3; j++)
+        if (j < nzp) s = s - a[j][i] * c[j];
+      c[i] = __fdiv_rn(s, a[i][i]);
+    }
+  }
+  const float y0 = (0 < nzp) ? c[0] : 0.f;
+  const float y1 = (1 < nzp) ? c[1] : 0.f;
+  const float y2 = (2 < nzp) ? c[2] : 0.f;
+  // x[perm[i]] = y[i]
+  float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+  x0 = (perm0 == 0) ? y0 : x0; x1 = (perm0 == 1) ? y0 : x1; x2 = (perm0 == 2) ? y0 : x2;
+  x0 = (perm1 == 0) ? y1 : x0; x1 = (perm1 == 1) ? y1 : x1; x2 = (perm1 == 2) ? y1 : x2;
+  x0 = (perm2 == 0) ? y2 : x0; x1 = (perm2 == 1) ? y2 : x1; x2 = (perm2 == 2) ? y2 : x2;
+
+  const float nn = __fsqrt_rn(sum3(x0 * x0, x1 * x1, x2 * x2));   // normvec.norm()
+  n[0] = __fdiv_rn(x0, nn);
+  n[1] = __fdiv_rn(x1, nn);
+  n[2] = __fdiv_rn(x2, nn);
+  n[3] = __fdiv_rn(1.0f, nn);   // (float)(1.0 / n): double rounding is innocuous for division
+}
+
+// Plane::plane_eval (Objects/Plane.cpp:107-114)
+FLIMO_DEV bool plane_eval5(const float (&n)[4], const float (&px)[5], const float (&py)[5], const float (&pz)[5],
+                           float thres) {
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < 5; j++) {
+    const float res = n[0] * px[j] + n[1] * py[j] + n[2] * pz[j] + n[3];
+    ok = ok && !(fabsf(res) > thres);
+  }
+  return ok;
+}
+
+}  // namespace flimo

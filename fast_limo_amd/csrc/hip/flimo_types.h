@@ -1,0 +1,57 @@
+// fast_limo_amd/csrc/hip/flimo_types.h
+// Plain structs shared by the HIP translation units of libflimo_hip.so (gfx950 only).
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+namespace flimo {
+
+// GPU-resident map = uniform grid over the map's bounding box.  Points are stored as float4
+// (xyz + original insertion index bits in w), sorted by linear cell id with x fastest, so the
+// three x-adjacent cells of a row are ONE contiguous range of `pts`.
+struct GridView {
+  const float4* pts;           // [n_pts]  sorted by cell id
+  const uint32_t* cell_start;  // [nx*ny*nz + 1]  exclusive prefix of per-cell counts
+  float ox, oy, oz;            // min corner of cell (0,0,0)
+  float inv_cell;              // 1 / cell edge
+  float cell;                  // cell edge [m]
+  int nx, ny, nz;
+  uint32_t n_pts;
+};
+
+// Per-pass pose constants, computed on the host exactly as the reference does
+// (State(x).get_RT() etc., reference Objects/State.cpp:38-55,136-172 and
+// Modules/Localizer.cpp:549-555) and passed by value as a kernel argument.
+struct PoseMats {
+  float RT[16];       // body -> world            (Mapper.cpp:71-72)
+  float RT_inv[16];   // world -> body (IMU)      (Localizer.cpp:549)
+  float TLI_inv[16];  // body -> lidar            (Localizer.cpp:550)
+  float R_inv[9];     // s.rot^-1 as float        (Localizer.cpp:554)
+  float RLI_inv[9];   // s.offset_R_L_I^-1        (Localizer.cpp:555)
+};
+
+struct MatchParams {
+  float max_dist_plane;    // compared with the 5th SQUARED distance (Plane.cpp:47)
+  float plane_threshold;   // Plane.cpp:110
+  int estimate_extrinsics;
+  int n_queries;           // min(N, MAX_NUM_PC2MATCH)
+  int max_ring;            // search rings needed to honour the MAX_DIST_PLANE gate exactly
+};
+
+// 64-byte per-query record consumed by the HTH reducer: H row, h, valid flag.
+struct alignas(16) Rec16 {
+  float v[16];   // [0..11] H row, [12] h = -dist, [13] valid (1/0), [14..15] 0
+};
+
+// Debug side-record (only written when the context has debug records enabled).
+struct alignas(16) RecDbg {
+  float n[4];
+  float p_global[3];
+  int32_t n_nbr;
+  float sqd[5];
+  int32_t nbr[5];
+  int32_t cand;      // candidates examined
+  int32_t pad;
+};
+
+}  // namespace flimo

@@ -1,0 +1,152 @@
+/* include/flimo_c.h -- C ABI of the MI355X-native fast_LIMO registration hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.  Each entry point
+ * names the reference interface it replaces (paths relative to the fast_LIMO tree,
+ * include/fast_limo/... unless stated).  INTEGRATION.md shows how the reference's
+ * Mapper / Localizer / h_share_model call these.
+ *
+ * Conventions
+ *   - every function returns FLIMO_OK (0) or a negative error code; flimo_last_error() gives text.
+ *     Nothing throws or exits across this boundary (the reference prints and returns,
+ *     Modules/Localizer.cpp:249-260,379-380).
+ *   - one flimo_ctx owns one GPU's map, scan scratch and HIP stream; it is not re-entrant (the
+ *     reference serialises the update under mtx_ikfom, Modules/Localizer.cpp:326-353).
+ *   - the library fails loudly (FLIMO_ERR_NO_DEVICE) when no gfx950 device is present: there is
+ *     no CPU fallback.
+ *   - x26 = flat state_ikfom (IKFoM/use-ikfom.hpp:12-21):
+ *       pos[3] rot(x,y,z,w) offset_R_L_I(x,y,z,w) offset_T_L_I[3] vel[3] bg[3] ba[3] grav[3]
+ */
+#ifndef FLIMO_C_H
+#define FLIMO_C_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FLIMO_OK 0
+#define FLIMO_ERR_NO_DEVICE (-1)
+#define FLIMO_ERR_INVALID (-2)
+#define FLIMO_ERR_HIP (-3)
+#define FLIMO_ERR_NOMAP (-4)
+#define FLIMO_ERR_TOO_LARGE (-5)
+#define FLIMO_ERR_UNSUPPORTED (-6)
+
+typedef struct flimo_ctx flimo_ctx;
+
+/* Config::iKFoM::Mapping::Octree (Utils/Config.hpp:64-68) + the GPU grid knob. */
+typedef struct flimo_map_cfg {
+  float min_extent;  /* Octree/min_extent (default 0.2) */
+  int bucket_size;   /* accepted and ignored: the reference setter is a no-op, effective 32
+                        (Objects/Octree.hpp:155,178-180) */
+  int downsample;    /* Octree/downsampling */
+  float cell_size;   /* GPU hash-grid cell edge [m]; <= 0 selects the default (0.5 m) */
+} flimo_map_cfg;
+
+/* Config::iKFoM::Mapping (Utils/Config.hpp:58-63) + ikfom.estimate_extrinsics */
+typedef struct flimo_match_cfg {
+  int NUM_MATCH_POINTS;    /* k; only 5 is supported by the fused kernels */
+  int MAX_NUM_MATCHES;     /* Modules/Localizer.cpp:539 */
+  int MAX_NUM_PC2MATCH;    /* Modules/Mapper.cpp:63 */
+  double MAX_DIST_PLANE;   /* Objects/Plane.cpp:47 (compared with a SQUARED distance) */
+  double PLANE_THRESHOLD;  /* Objects/Plane.cpp:73,110 */
+  int estimate_extrinsics; /* Modules/Localizer.cpp:569 */
+} flimo_match_cfg;
+
+/* One per scan point: what Mapper::match_plane produced (debug / parity surface; replaces
+ * Localizer::get_matches(), Modules/Localizer.cpp:139-141,575-576). */
+typedef struct flimo_match_rec {
+  float H[12];       /* calculate_H row [n, A, B, C] (B, C zero unless estimate_extrinsics) */
+  float h;           /* -dist */
+  float valid;       /* 1.0f if the plane passed all gates (Match::lisanAlGaib) else 0.0f */
+  float n[4];        /* plane n_ABCD */
+  float p_global[3]; /* scan point in the world frame */
+  float sqd[5];      /* ascending squared distances of the 5 neighbours */
+  int32_t nbr[5];    /* indices into the device map order (see flimo_map_points) or -1 */
+  int32_t n_nbr;
+} flimo_match_rec;
+
+/* IMU frame handed to the deskew kernel: fast_limo::State (Objects/State.hpp:22-48) */
+typedef struct flimo_frame {
+  float p[3], q[4] /* x,y,z,w */, v[3], g[3], w[3], a[3], bg[3], ba[3];
+  double time;
+} flimo_frame;
+
+/* ---- context ---- */
+int flimo_ctx_create(int device, flimo_ctx** out);
+void flimo_ctx_destroy(flimo_ctx* ctx);
+const char* flimo_last_error(const flimo_ctx* ctx);
+const char* flimo_version(void);
+
+/* ---- map: replaces fast_limo::Mapper::{set_config,add,exists,size} (Modules/Mapper.cpp:38-57,88-96)
+ *      and octree::Octree::{initialize,update} (Objects/Octree.hpp:282-432) ---- */
+int flimo_map_config(flimo_ctx* ctx, const flimo_map_cfg* cfg);
+/* xyz: n points, stride_bytes between consecutive points (>= 12), host memory.  NaN points are
+ * dropped (Octree::processPoints, Objects/Octree.hpp:243-244). */
+int flimo_map_add(flimo_ctx* ctx, const float* xyz, size_t n, size_t stride_bytes, double stamp);
+int flimo_map_clear(flimo_ctx* ctx);
+size_t flimo_map_size(const flimo_ctx* ctx);
+double flimo_map_last_time(const flimo_ctx* ctx);
+/* copies the stored points (device order) as packed xyz; *n receives the total count
+ * (Octree::getData, Objects/Octree.hpp:198-215) */
+int flimo_map_points(flimo_ctx* ctx, float* xyz_out, size_t cap, size_t* n);
+
+/* ---- exact k-NN: replaces octree::Octree::knn (Objects/Octree.hpp:526-555) for a batch ----
+ * q_xyz packed [nq][3] host; outputs host: idx [nq][k] (device map order, -1 padded),
+ * sqd [nq][k] ascending squared distances (0 padded), cnt [nq].  k <= 5. */
+int flimo_knn(flimo_ctx* ctx, const float* q_xyz, size_t nq, int k, int32_t* idx, float* sqd, int32_t* cnt);
+
+/* ---- scan: pc2match of the reference (Modules/Localizer.hpp:36) ---- */
+int flimo_scan_set(flimo_ctx* ctx, const float* xyz, size_t n, size_t stride_bytes);
+size_t flimo_scan_size(const flimo_ctx* ctx);
+/* copy the resident scan back (packed xyz) */
+int flimo_scan_get(flimo_ctx* ctx, float* xyz_out, size_t cap, size_t* n);
+
+/* ---- deskew: replaces the OpenMP loop of Localizer::deskewPointCloud
+ *      (Modules/Localizer.cpp:820-843) incl. State::update (Objects/State.cpp:76-119) and
+ *      binary_search_tailored (Utils/Algorithms.hpp:25-38).  Input: time-sorted LiDAR-frame points
+ *      (xyz, stride) with per-point absolute times t[i] (= extract_point_time + offset, double);
+ *      frames sorted by time; lidar2baselink_T row-major 4x4; last_x26 = _iKFoM.get_x().
+ *      The result (body frame at scan end) becomes the resident scan (pc2match). ---- */
+int flimo_deskew(flimo_ctx* ctx, const float* xyz, size_t n, size_t stride_bytes, const double* t,
+                 const flimo_frame* frames, size_t n_frames, const float lidar2baselink_T[16],
+                 const double last_x26[26]);
+/* the same in two steps, so that the raw scan can be made resident in HBM ahead of time */
+int flimo_raw_scan_set(flimo_ctx* ctx, const float* xyz, size_t n, size_t stride_bytes, const double* t);
+int flimo_deskew_resident(flimo_ctx* ctx, const flimo_frame* frames, size_t n_frames,
+                          const float lidar2baselink_T[16], const double last_x26[26]);
+
+/* ---- one measurement pass: replaces IKFoM::h_share_model (IKFoM/use-ikfom.cpp:10-31) =
+ *      Mapper::match (Modules/Mapper.cpp:59-86) + Localizer::calculate_H
+ *      (Modules/Localizer.cpp:537-577) + the h_x^T h_x / h_x^T h products of
+ *      esekf::update_iterated_dyn_share_modified (esekfom.hpp:1723,1727).
+ *      HTH row-major 12x12, HTh 12, *M = number of matches used (after both caps). ---- */
+int flimo_match_reduce(flimo_ctx* ctx, const double x26[26], const flimo_match_cfg* cfg, double HTH[144],
+                       double HTh[12], int* M);
+/* per-point records of the last flimo_match_reduce (first min(N, MAX_NUM_PC2MATCH) points) */
+int flimo_match_fetch(flimo_ctx* ctx, flimo_match_rec* out, size_t cap, size_t* n);
+/* dense H (M x 12 row-major, compacted in scan order, capped) and h of the last pass: needed by the
+ * M < 23 branch of the update (esekfom.hpp:1701-1709) */
+int flimo_match_fetch_H(flimo_ctx* ctx, double* H, double* h, size_t cap_rows, size_t* M);
+
+/* ---- path exit: pcl::transformPointCloud(pc2match, state.get_RT()) + Mapper::add
+ *      (Modules/Localizer.cpp:361-377).  world_xyz_out may be NULL. ---- */
+int flimo_scan_to_world(flimo_ctx* ctx, const double x26[26], float* world_xyz_out, size_t cap);
+int flimo_map_add_scan(flimo_ctx* ctx, const double x26[26], double stamp);
+
+/* ---- instrumentation ---- */
+/* GPU time [ms] of the kernels of the last flimo_match_reduce: match, reduce (HIP events on the
+ * ctx stream); enable with flimo_set_timing(ctx, 1). */
+int flimo_set_timing(flimo_ctx* ctx, int on);
+/* also write the per-point debug part of flimo_match_rec (plane, neighbours, candidate counts) */
+int flimo_set_debug_records(flimo_ctx* ctx, int on);
+/* lanes of a wavefront that cooperate on one scan point in the match kernel: 1, 2, 4, 8 or 16 */
+int flimo_set_lanes_per_query(flimo_ctx* ctx, int lanes);
+int flimo_last_kernel_ms(const flimo_ctx* ctx, float* match_ms, float* reduce_ms);
+/* mean number of candidate map points examined per query in the last pass */
+double flimo_last_candidates_per_query(const flimo_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLIMO_C_H */

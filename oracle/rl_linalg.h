@@ -171,7 +171,7 @@ inline M3f quat_to_M3f(const Quatf& q) {
 template <typename T>
 inline QuatT<T> rot_to_quat(const T m[3][3]) {
   QuatT<T> q;
-  T t = m[0][0] + m[1][1] + m[2][2];
+  T t = m[0][0] + (m[1][1] + m[2][2]);   // trace() = diagonal().sum(): 3-coefficient redux
   if (t > T(0)) {
     t = std::sqrt(t + T(1.0));
     q.w = T(0.5) * t;
