@@ -57,7 +57,7 @@ HIP_SYMBOLS = [
     "flimo_match_reduce", "flimo_match_fetch", "flimo_match_fetch_H",
     "flimo_scan_to_world", "flimo_map_add_scan",
     "flimo_set_timing", "flimo_set_debug_records", "flimo_set_lanes_per_query", "flimo_last_kernel_ms",
-    "flimo_last_candidates_per_query",
+    "flimo_last_candidates_per_query", "flimo_last_widen_count",
 ]
 
 _hip = None
@@ -108,7 +108,9 @@ def load_hip():
     L.flimo_set_timing.argtypes = [vp, C.c_int]
     L.flimo_set_debug_records.argtypes = [vp, C.c_int]
     L.flimo_set_lanes_per_query.argtypes = [vp, C.c_int]
-    L.flimo_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.flimo_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.flimo_last_widen_count.restype = C.c_int
+    L.flimo_last_widen_count.argtypes = [vp]
     L.flimo_last_candidates_per_query.restype = C.c_double
     L.flimo_last_candidates_per_query.argtypes = [vp]
     for name in HIP_SYMBOLS:
@@ -260,8 +262,12 @@ class HipCtx:
     def last_kernel_ms(self):
         a = C.c_float(0)
         b = C.c_float(0)
-        self._chk(self._L.flimo_last_kernel_ms(self._h, C.byref(a), C.byref(b)))
-        return a.value, b.value
+        d = C.c_float(0)
+        self._chk(self._L.flimo_last_kernel_ms(self._h, C.byref(a), C.byref(b), C.byref(d)))
+        return a.value, b.value, d.value
+
+    def last_widen_count(self) -> int:
+        return int(self._L.flimo_last_widen_count(self._h))
 
     def last_candidates_per_query(self) -> float:
         return float(self._L.flimo_last_candidates_per_query(self._h))

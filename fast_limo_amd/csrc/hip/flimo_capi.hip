@@ -27,7 +27,7 @@ struct flimo_ctx {
   std::string err;
   // config
   flimo_map_cfg map_cfg{0.2f, 2, 1, 0.5f};
-  int lanes_per_query = 4;
+  int lanes_per_query = 16;
   bool timing = false;
   bool debug_recs = false;
   // map
@@ -42,7 +42,11 @@ struct flimo_ctx {
   MapBuildScratch scratch;
   InsertBook* book = nullptr;      // reference insert rule (flimo_insert.h)
   // scan
-  float4* d_scan = nullptr;        // pc2match (body frame)
+  float4* d_scan = nullptr;        // pc2match (body frame), caller order
+  float4* d_scan_sorted = nullptr; // the same points in Morton order, w = original index
+  void* d_nbr = nullptr;           // per-query neighbour records (sorted order)
+  int* d_wl = nullptr;             // worklist of queries that need the general ring search
+  int* d_wl_count = nullptr;
   float4* d_scan_raw = nullptr;    // raw lidar-frame points for deskew
   float4* d_scan_world = nullptr;
   double* d_scan_t = nullptr;
@@ -55,7 +59,9 @@ struct flimo_ctx {
   size_t rec_cap = 0;
   int last_nq = 0;
   int reduce_waves = 256;
-  double* d_partials = nullptr;
+  double* d_partials = nullptr;    // records-mode reduction partials [reduce_waves][256]
+  double* d_fit_partials = nullptr;  // per fit-block partials [fit_blocks][256]
+  size_t fit_partials_cap = 0;
   double* d_out256 = nullptr;
   double* h_out256 = nullptr;      // pinned
   unsigned long long* d_cand = nullptr;
@@ -66,8 +72,10 @@ struct flimo_ctx {
   void* h_stage = nullptr;         // pinned
   size_t stage_cap = 0;
   // timing
-  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
-  float last_match_ms = 0.f, last_reduce_ms = 0.f;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  float last_knn_ms = 0.f, last_widen_ms = 0.f, last_fit_ms = 0.f;
+  int* h_wl_count = nullptr;   // pinned
+  int last_widen_count = 0;
   flimo_match_cfg last_cfg{};
 };
 
@@ -189,11 +197,13 @@ extern "C" int flimo_ctx_create(int device, flimo_ctx** out) {
   flimo_ctx* c = new flimo_ctx();
   c->device = device;
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return FLIMO_ERR_HIP; }
-  for (int i = 0; i < 3; i++) (void)hipEventCreate(&c->ev[i]);
+  for (int i = 0; i < 4; i++) (void)hipEventCreate(&c->ev[i]);
   bool ok = hipMalloc(&c->d_partials, (size_t)c->reduce_waves * 256 * sizeof(double)) == hipSuccess &&
             hipMalloc(&c->d_out256, 256 * sizeof(double)) == hipSuccess &&
             hipHostMalloc((void**)&c->h_out256, 256 * sizeof(double), hipHostMallocDefault) == hipSuccess &&
             hipMalloc(&c->d_cand, sizeof(unsigned long long)) == hipSuccess &&
+            hipMalloc(&c->d_wl_count, sizeof(int)) == hipSuccess &&
+            hipHostMalloc((void**)&c->h_wl_count, sizeof(int), hipHostMallocDefault) == hipSuccess &&
             hipHostMalloc((void**)&c->h_cand, sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess;
   if (!ok) { flimo_ctx_destroy(c); return FLIMO_ERR_HIP; }
   // calibrate the v_mfma_f64_16x16x4_f64 accumulator layout: D[i][j] = j + 16 i
@@ -209,7 +219,7 @@ extern "C" int flimo_ctx_create(int device, flimo_ctx** out) {
     c->mfma_idx[code / 16][code % 16] = r;
   }
   const char* e = getenv("FLIMO_LPQ");
-  if (e) { int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) c->lanes_per_query = v; }
+  if (e) { int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) c->lanes_per_query = v; }
   c->book = insert_book_create();
   *out = c;
   return FLIMO_OK;
@@ -220,6 +230,8 @@ extern "C" void flimo_ctx_destroy(flimo_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   (void)hipFree(c->d_map_raw); (void)hipFree(c->d_map_sorted); (void)hipFree(c->d_cell_start);
+  (void)hipFree(c->d_scan_sorted); (void)hipFree(c->d_nbr); (void)hipFree(c->d_wl); (void)hipFree(c->d_wl_count);
+  (void)hipFree(c->d_fit_partials);
   (void)hipFree(c->d_scan); (void)hipFree(c->d_scan_raw); (void)hipFree(c->d_scan_world); (void)hipFree(c->d_scan_t);
   (void)hipFree(c->d_frames); (void)hipFree(c->d_recs); (void)hipFree(c->d_dbg);
   (void)hipFree(c->d_partials); (void)hipFree(c->d_out256); (void)hipFree(c->d_cand);
@@ -227,7 +239,8 @@ extern "C" void flimo_ctx_destroy(flimo_ctx* c) {
   if (c->h_cand) (void)hipHostFree(c->h_cand);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   map_scratch_free(c->scratch);
-  for (int i = 0; i < 3; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  for (int i = 0; i < 4; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  if (c->h_wl_count) (void)hipHostFree(c->h_wl_count);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->book) insert_book_destroy(c->book);
   delete c;
@@ -408,8 +421,18 @@ extern "C" int flimo_knn(flimo_ctx* c, const float* q, size_t nq, int k, int32_t
 static int ensure_scan(flimo_ctx* c, size_t n) {
   if (n <= c->scan_cap) return FLIMO_OK;
   const size_t cap = n + n / 4 + 1024;
-  float4 *a = nullptr, *b = nullptr, *w = nullptr;
+  float4 *a = nullptr, *b = nullptr, *w = nullptr, *so = nullptr;
   double* t = nullptr;
+  void* nb = nullptr;
+  int* wl = nullptr;
+  double* fp = nullptr;
+  const size_t fpn = (size_t)fit_blocks((int)cap) * 256;
+  HIPCHK(c, hipMalloc(&so, cap * sizeof(float4)));
+  HIPCHK(c, hipMalloc(&nb, cap * nbr_rec_size()));
+  HIPCHK(c, hipMalloc(&wl, cap * sizeof(int)));
+  HIPCHK(c, hipMalloc(&fp, fpn * sizeof(double)));
+  (void)hipFree(c->d_scan_sorted); (void)hipFree(c->d_nbr); (void)hipFree(c->d_wl); (void)hipFree(c->d_fit_partials);
+  c->d_scan_sorted = so; c->d_nbr = nb; c->d_wl = wl; c->d_fit_partials = fp; c->fit_partials_cap = fpn;
   HIPCHK(c, hipMalloc(&a, cap * sizeof(float4)));
   HIPCHK(c, hipMalloc(&b, cap * sizeof(float4)));
   HIPCHK(c, hipMalloc(&w, cap * sizeof(float4)));
@@ -453,7 +476,12 @@ extern "C" int flimo_scan_set(flimo_ctx* c, const float* xyz, size_t n, size_t s
   (void)hipSetDevice(c->device);
   int rc = ensure_scan(c, n);
   if (rc) return rc;
-  if (n) { rc = upload_points(c, xyz, n, stride_bytes, c->d_scan); if (rc) return rc; }
+  if (n) {
+    rc = upload_points(c, xyz, n, stride_bytes, c->d_scan);
+    if (rc) return rc;
+    HIPCHK(c, sort_scan(c->stream, c->d_scan, n, c->d_scan_sorted, c->scratch));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
   c->scan_n = n;
   return FLIMO_OK;
 }
@@ -526,6 +554,7 @@ extern "C" int flimo_deskew_resident(flimo_ctx* c, const flimo_frame* frames, si
   launch_deskew(c->stream, c->d_scan_raw, c->d_scan_t, (int)n, c->d_frames, (int)nf,
                 (const float*)((const char*)c->d_frames + fbytes), c->d_scan);
   HIPCHK(c, hipGetLastError());
+  HIPCHK(c, sort_scan(c->stream, c->d_scan, n, c->d_scan_sorted, c->scratch));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->scan_n = n;
   return FLIMO_OK;
@@ -543,16 +572,18 @@ extern "C" int flimo_set_timing(flimo_ctx* c, int on) { if (!c) return FLIMO_ERR
 extern "C" int flimo_set_debug_records(flimo_ctx* c, int on) { if (!c) return FLIMO_ERR_INVALID; c->debug_recs = on != 0; return FLIMO_OK; }
 extern "C" int flimo_set_lanes_per_query(flimo_ctx* c, int l) {
   if (!c) return FLIMO_ERR_INVALID;
-  if (!(l == 1 || l == 2 || l == 4 || l == 8 || l == 16)) return fail(c, FLIMO_ERR_INVALID, "lanes per query must be 1,2,4,8,16");
+  if (!(l == 1 || l == 2 || l == 4 || l == 8 || l == 16 || l == 32)) return fail(c, FLIMO_ERR_INVALID, "lanes per query must be 1,2,4,8,16,32");
   c->lanes_per_query = l;
   return FLIMO_OK;
 }
-extern "C" int flimo_last_kernel_ms(const flimo_ctx* c, float* match_ms, float* reduce_ms) {
+extern "C" int flimo_last_kernel_ms(const flimo_ctx* c, float* knn_ms, float* widen_ms, float* fit_ms) {
   if (!c) return FLIMO_ERR_INVALID;
-  if (match_ms) *match_ms = c->last_match_ms;
-  if (reduce_ms) *reduce_ms = c->last_reduce_ms;
+  if (knn_ms) *knn_ms = c->last_knn_ms;
+  if (widen_ms) *widen_ms = c->last_widen_ms;
+  if (fit_ms) *fit_ms = c->last_fit_ms;
   return FLIMO_OK;
 }
+extern "C" int flimo_last_widen_count(const flimo_ctx* c) { return c ? c->last_widen_count : 0; }
 extern "C" double flimo_last_candidates_per_query(const flimo_ctx* c) { return c ? c->last_cand_per_query : 0.0; }
 
 static int gate_rings(const flimo_ctx* c, double max_dist_plane) {
@@ -592,22 +623,39 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   mp.n_queries = (int)nq;
   mp.max_ring = gate_rings(c, cfg->MAX_DIST_PLANE);
 
+  const int n_all = (int)c->scan_n;                   // every resident point is searched; points beyond the
+                                                      // MAX_NUM_PC2MATCH prefix are masked by original index
+  const bool cap_binds = cfg->MAX_NUM_MATCHES >= 0 && (size_t)cfg->MAX_NUM_MATCHES < nq;
+  const bool want_recs = c->debug_recs || cap_binds;
   if (c->debug_recs) HIPCHK(c, hipMemsetAsync(c->d_cand, 0, sizeof(unsigned long long), c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_wl_count, 0, sizeof(int), c->stream));
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-  launch_match(c->stream, c->lanes_per_query, c->grid, c->d_scan, P, mp, c->d_recs, c->debug_recs ? c->d_dbg : nullptr,
-               c->d_cand);
-  if (cfg->MAX_NUM_MATCHES >= 0 && (size_t)cfg->MAX_NUM_MATCHES < nq) launch_cap(c->stream, c->d_recs, (int)nq, cfg->MAX_NUM_MATCHES);
+  launch_knn5(c->stream, c->lanes_per_query, c->grid, c->d_scan_sorted, n_all, P, mp.max_ring, c->d_nbr, c->d_wl,
+              c->d_wl_count, c->debug_recs ? c->d_cand : nullptr);
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-  launch_reduce(c->stream, c->d_recs, (int)nq, c->reduce_waves, c->d_partials, c->d_out256);
+  launch_widen(c->stream, c->grid, c->d_scan_sorted, P, mp.max_ring, c->d_nbr, c->d_wl, c->d_wl_count,
+               c->debug_recs ? c->d_cand : nullptr);
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+  launch_fit(c->stream, c->grid, c->d_scan_sorted, n_all, c->d_nbr, P, mp, c->d_fit_partials, want_recs ? c->d_recs : nullptr,
+             c->debug_recs ? c->d_dbg : nullptr);
+  if (cap_binds) {
+    launch_cap(c->stream, c->d_recs, (int)nq, cfg->MAX_NUM_MATCHES);
+    launch_reduce(c->stream, c->d_recs, (int)nq, c->reduce_waves, c->d_partials, c->d_out256);
+  } else {
+    launch_reduce_final(c->stream, c->d_fit_partials, fit_blocks(n_all), c->d_out256);
+  }
+  if (c->timing) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpyAsync(c->h_out256, c->d_out256, 256 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   if (c->debug_recs) HIPCHK(c, hipMemcpyAsync(c->h_cand, c->d_cand, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+  if (c->debug_recs || c->timing) HIPCHK(c, hipMemcpyAsync(c->h_wl_count, c->d_wl_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (c->timing) {
-    (void)hipEventElapsedTime(&c->last_match_ms, c->ev[0], c->ev[1]);
-    (void)hipEventElapsedTime(&c->last_reduce_ms, c->ev[1], c->ev[2]);
+    (void)hipEventElapsedTime(&c->last_knn_ms, c->ev[0], c->ev[1]);
+    (void)hipEventElapsedTime(&c->last_widen_ms, c->ev[1], c->ev[2]);
+    (void)hipEventElapsedTime(&c->last_fit_ms, c->ev[2], c->ev[3]);
   }
+  if (c->debug_recs || c->timing) c->last_widen_count = *c->h_wl_count;
   if (c->debug_recs) c->last_cand_per_query = (double)(*c->h_cand) / (double)nq;
   for (int i = 0; i < 12; i++) {
     for (int j = 0; j < 12; j++) HTH[i * 12 + j] = c->h_out256[c->mfma_idx[i][j]];

@@ -6,8 +6,16 @@
 namespace flimo {
 
 // flimo_kernels.hip
-void launch_match(hipStream_t st, int lanes_per_query, const GridView& G, const float4* scan, const PoseMats& P,
-                  const MatchParams& mp, Rec16* recs, RecDbg* dbg, unsigned long long* cand);
+// per pass: k-NN (fast path + worklist widening), then fit + in-block reduction, then the final sum
+void launch_knn5(hipStream_t st, int lanes_per_query, const GridView& G, const float4* scan_sorted, int n,
+                 const PoseMats& P, int max_ring, void* nbr, int* wl, int* wl_count, unsigned long long* cand);
+void launch_widen(hipStream_t st, const GridView& G, const float4* scan_sorted, const PoseMats& P, int max_ring, void* nbr,
+                  int* wl, int* wl_count, unsigned long long* cand);
+int fit_blocks(int n);
+void launch_fit(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const void* nbr, const PoseMats& P,
+                const MatchParams& mp, double* partials, Rec16* recs, RecDbg* dbg);
+void launch_reduce_final(hipStream_t st, const double* partials, int nparts, double* out256);
+size_t nbr_rec_size();
 void launch_knn(hipStream_t st, const GridView& G, const float* qxyz, int nq, int k, int max_ring, int32_t* idx,
                 float* sqd, int32_t* cnt);
 void launch_cap(hipStream_t st, Rec16* recs, int n, int cap);
@@ -33,6 +41,8 @@ struct MapBuildScratch {
 // min/max of n float4 points (NaN-free) -> host bbox[6]
 hipError_t map_bbox(hipStream_t st, const float4* pts, size_t n, MapBuildScratch& S, float bbox_host[6]);
 // Sorts `pts_in` by grid cell into `pts_out`, fills cell_start[ncells+1].
+// Spatial (Morton) sort of the scan: out[i] = (xyz of in[perm[i]], w = bit pattern of perm[i]).
+hipError_t sort_scan(hipStream_t st, const float4* in, size_t n, float4* out, MapBuildScratch& S);
 hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4* pts_out, uint32_t* cell_start,
                           size_t ncells, float ox, float oy, float oz, float inv_cell, int nx, int ny, int nz,
                           MapBuildScratch& S);

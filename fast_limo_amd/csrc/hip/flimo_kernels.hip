@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <float.h>
 #include <limits.h>
+#include <stdlib.h>
 #include "flimo_types.h"
 #include "flimo_math.h"
 #include "flimo_kernels.h"
@@ -220,7 +221,7 @@ FLIMO_DEV void knn_search(const GridView& G, float gx, float gy, float gz, int s
     int rn = 2 * r;
     if (have5) {
       bound = R.bd[4];
-      const float need = __fsqrt_rn(R.bd[4]) * G.inv_cell * (1.f + 4.0e-6f) - edge + margin;
+      const float need = fl_sqrt(R.bd[4]) * G.inv_cell * (1.f + 4.0e-6f) - edge + margin;
       rn = max(r + 1, (int)ceilf(fminf(need, 1.0e9f)));
     }
     rn = min(rn, max_ring);
@@ -235,100 +236,424 @@ FLIMO_DEV void knn_search(const GridView& G, float gx, float gy, float gz, int s
 }
 
 // ------------------------------------------------------------------------------------------
-// match kernel
+// Fast path of the per-pass k-NN: L lanes per scan point, 3x3x3 block only.
+//   * the 18 range bounds of the 9 rows are loaded first, then ALL candidate points of the block
+//     are addressed through one flattened index space (slot s -> row t, offset), so every lane
+//     issues its loads back to back (up to SLOTS in flight) regardless of how the candidates are
+//     spread over the rows;
+//   * each lane keeps a sorted private best-5 of 64-bit keys (float bits of d2 << 32 | map index:
+//     the same total order as (d2, index)); the group result is extracted with five rounds of a
+//     shuffle min-reduction;
+//   * a query whose 5-ball is not provably inside the block goes to a worklist that
+//     widen_kernel finishes with the general ring search.
+// Queries are processed in the spatial (Morton) order of `scan_sorted`; w of each scan point holds
+// its original index.  Block b works on chunk (b % 8) * (nblocks / 8) + b / 8 so that each XCD
+// (observed dispatch: block b -> XCD b % 8) sees one contiguous spatial range and its L2 keeps
+// that part of the map.
 // ------------------------------------------------------------------------------------------
-template <int L, bool DBG>
-__global__ __launch_bounds__(256) void match_kernel(GridView G, const float4* __restrict__ scan, PoseMats P,
-                                                    MatchParams mp, Rec16* __restrict__ recs,
-                                                    RecDbg* __restrict__ dbg, unsigned long long* __restrict__ cand_total) {
-  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int q = tid / L;
-  const int sub = tid % L;
-  if (q >= mp.n_queries) return;   // whole groups exit together (n_queries groups of L lanes)
+typedef unsigned long long u64;
+#define KEY_EMPTY 0xffffffffffffffffull
 
-  const float4 sp = scan[q];
+FLIMO_DEV u64 make_key(float d, uint32_t idx) { return ((u64)__float_as_uint(d) << 32) | (u64)idx; }
+
+FLIMO_DEV void key5_insert(u64 (&k)[5], u64 key) {
+  if (key >= k[4]) return;
+  k[4] = key;
+#pragma unroll
+  for (int s = 4; s > 0; s--) {
+    const u64 a = k[s - 1], b = k[s];
+    const bool sw = b < a;
+    k[s - 1] = sw ? b : a;
+    k[s] = sw ? a : b;
+  }
+}
+
+__device__ __forceinline__ int xcd_chunk(int b, int nb) {
+  // nb is a multiple of 8
+  return (b & 7) * (nb >> 3) + (b >> 3);
+}
+
+struct NbrRec {      // 32 bytes per query (sorted order)
+  int32_t idx[5];
+  int32_t flag;      // 1: exact 5-NN present, 0: no valid neighbourhood, 2: pending (worklist)
+  int32_t pad[2];
+};
+
+template <int L, int SLOTS>
+__global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __restrict__ scan_sorted, int n,
+                                                   PoseMats P, int max_ring, NbrRec* __restrict__ nbr,
+                                                   int* __restrict__ wl, int* __restrict__ wl_count,
+                                                   unsigned long long* __restrict__ cand_total) {
+  constexpr int QPB = 256 / L;          // queries per block; SLOTS = candidate loads in flight per lane
+  const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
+  const int p = chunk * QPB + threadIdx.x / L;
+  const int sub = threadIdx.x % L;
+  if (p >= n) return;
+
+  const float4 sp = scan_sorted[p];
   float gx, gy, gz;
-  xform4(P.RT, sp.x, sp.y, sp.z, gx, gy, gz);   // global_point = s.get_RT() * bl4_point
+  xform4(P.RT, sp.x, sp.y, sp.z, gx, gy, gz);
 
-  KnnResult R;
-  knn_search<L>(G, gx, gy, gz, sub, mp.max_ring, R);
-
-  const bool have5 = R.bi[4] != INT_MAX;
-  // Plane gates (Plane.cpp:23-31): enough_points, close_enough (5th SQUARED distance < MAX_DIST_PLANE).
-  // If the search stopped inexact at max_ring the true 5th distance already fails close_enough.
-  bool valid = have5 && R.exact && (R.bd[4] < mp.max_dist_plane);
-
-  float n[4] = {0.f, 0.f, 0.f, 0.f};
-  float dist = 0.f;
-  float H[12];
+  const float fx = (gx - G.ox) * G.inv_cell, fy = (gy - G.oy) * G.inv_cell, fz = (gz - G.oz) * G.inv_cell;
+  int flag = 0;
+  u64 best[5] = {KEY_EMPTY, KEY_EMPTY, KEY_EMPTY, KEY_EMPTY, KEY_EMPTY};
+  int cand = 0;
+  if ((fx == fx) && (fy == fy) && (fz == fz)) {
+    const float lim = 1.0e9f;
+    const float flx = floorf(fminf(fmaxf(fx, -lim), lim)), fly = floorf(fminf(fmaxf(fy, -lim), lim)),
+                flz = floorf(fminf(fmaxf(fz, -lim), lim));
+    const int cx = (int)flx, cy = (int)fly, cz = (int)flz;
+    const int ox_ = cx < 0 ? -cx : (cx >= G.nx ? cx - G.nx + 1 : 0);
+    const int oy_ = cy < 0 ? -cy : (cy >= G.ny ? cy - G.ny + 1 : 0);
+    const int oz_ = cz < 0 ? -cz : (cz >= G.nz ? cz - G.nz + 1 : 0);
+    const int r0 = max(1, max(ox_, max(oy_, oz_)));
+    if (r0 > max_ring) {
+      flag = 0;                       // nothing within the gate distance
+    } else if (r0 > 1) {
+      flag = 2;                       // outside the grid but within reach: general search
+    } else {
+      // ---- range bounds of the 9 rows ----
+      const int x0 = max(cx - 1, 0), x1 = min(cx + 1, G.nx - 1);
+      uint32_t lo[9], off[10];
+      off[0] = 0;
 #pragma unroll
-  for (int i = 0; i < 12; i++) H[i] = 0.f;
-
-  if (valid) {
-    float px[5], py[5], pz[5];
+      for (int t = 0; t < 9; t++) {
+        const int yy = cy + (t % 3) - 1, zz = cz + (t / 3) - 1;
+        const bool in = (yy >= 0) && (yy < G.ny) && (zz >= 0) && (zz < G.nz);
+        const size_t rowbase = ((size_t)(in ? zz : 0) * (size_t)G.ny + (size_t)(in ? yy : 0)) * (size_t)G.nx;
+        const uint32_t a = G.cell_start[rowbase + x0];
+        const uint32_t b = G.cell_start[rowbase + x1 + 1];
+        lo[t] = a;
+        off[t + 1] = in ? (b - a) : 0u;
+      }
 #pragma unroll
-    for (int s = 0; s < 5; s++) {
-      const float4 p = G.pts[R.bi[s]];
-      px[s] = p.x; py[s] = p.y; pz[s] = p.z;
-    }
-    plane_fit5(px, py, pz, n);
-    valid = plane_eval5(n, px, py, pz, mp.plane_threshold);
-    if (valid) {
-      // Match::Match: dist = n . p_global + d   (Plane.cpp:50-52)
-      dist = n[0] * gx + n[1] * gy + n[2] * gz + n[3];
-      // calculate_H (Localizer.cpp:549-569)
-      float ix, iy, iz, lx, ly, lz;
-      xform4(P.RT_inv, gx, gy, gz, ix, iy, iz);        // p_imu
-      xform4(P.TLI_inv, ix, iy, iz, lx, ly, lz);       // p_lidar
-      float Cx, Cy, Cz;
-      mul3(P.R_inv, n[0], n[1], n[2], Cx, Cy, Cz);     // C = R_inv * n
-      float Dx, Dy, Dz;
-      mul3(P.RLI_inv, Cx, Cy, Cz, Dx, Dy, Dz);         // I_R_L_inv * C
-      float Bx, By, Bz, Ax, Ay, Az;
-      cross3(lx, ly, lz, Dx, Dy, Dz, Bx, By, Bz);      // B = p_lidar x (I_R_L_inv*C)
-      cross3(ix, iy, iz, Cx, Cy, Cz, Ax, Ay, Az);      // A = p_imu x C
-      H[0] = n[0]; H[1] = n[1]; H[2] = n[2]; H[3] = Ax; H[4] = Ay; H[5] = Az;
-      if (mp.estimate_extrinsics) { H[6] = Bx; H[7] = By; H[8] = Bz; H[9] = Cx; H[10] = Cy; H[11] = Cz; }
+      for (int t = 0; t < 9; t++) off[t + 1] += off[t];
+      const uint32_t total = off[9];
+      // ---- flattened candidate stream ----
+      for (uint32_t s0 = (uint32_t)sub; s0 < total; s0 += SLOTS * L) {
+        float4 pt[SLOTS];
+        uint32_t id[SLOTS];
+#pragma unroll
+        for (int u = 0; u < SLOTS; u++) {
+          const uint32_t s = s0 + u * L;
+          uint32_t delta = lo[0];
+#pragma unroll
+          for (int t = 1; t < 9; t++) delta = (s >= off[t]) ? (lo[t] - off[t]) : delta;
+          id[u] = s + delta;
+          if (s < total) pt[u] = G.pts[id[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < SLOTS; u++) {
+          const uint32_t s = s0 + u * L;
+          if (s < total) {
+            const float d = sqdist3(gx, gy, gz, pt[u].x, pt[u].y, pt[u].z);
+            key5_insert(best, make_key(d, id[u]));
+            cand++;
+          }
+        }
+      }
+      // ---- group result: five rounds of min-extraction ----
+      if (L > 1) {
+        u64 mine[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++) mine[i] = best[i];
+#pragma unroll
+        for (int r = 0; r < 5; r++) {
+          u64 m = mine[0];
+#pragma unroll
+          for (int o = 1; o < L; o <<= 1) {
+            const u64 v = __shfl_xor(m, o, 64);
+            m = v < m ? v : m;
+          }
+          best[r] = m;
+          if (mine[0] == m) { mine[0] = mine[1]; mine[1] = mine[2]; mine[2] = mine[3]; mine[3] = mine[4]; mine[4] = KEY_EMPTY; }
+        }
+      }
+      // ---- exactness: the 5-ball must lie inside the visited block ----
+      const float rx = fminf(fmaxf(fx - flx, 0.f), 1.f), ry = fminf(fmaxf(fy - fly, 0.f), 1.f),
+                  rz = fminf(fmaxf(fz - flz, 0.f), 1.f);
+      const int maxdim = max(G.nx, max(G.ny, G.nz));
+      const float margin = 1.0e-3f + 4.0e-7f * (float)maxdim;
+      const float edge = fminf(fminf(fminf(rx, 1.f - rx), fminf(ry, 1.f - ry)), fminf(rz, 1.f - rz));
+      const float rg = (1.f + edge - margin) * G.cell;
+      const bool have5 = best[4] != KEY_EMPTY;
+      const float d5 = __uint_as_float((uint32_t)(best[4] >> 32));
+      const bool covers = (cx - 1 <= 0) && (cx + 1 >= G.nx - 1) && (cy - 1 <= 0) && (cy + 1 >= G.ny - 1) &&
+                          (cz - 1 <= 0) && (cz + 1 >= G.nz - 1);
+      if (have5 && (covers || d5 <= rg * rg * (1.f - 1.0e-6f))) flag = 1;
+      else if (covers) flag = 0;                 // the whole map holds fewer than 5 points
+      else flag = (max_ring > 1) ? 2 : 0;
     }
   }
+  if (cand_total) {
+    int c = cand;
+#pragma unroll
+    for (int o = 1; o < L; o <<= 1) c += __shfl_xor(c, o, 64);
+    if (sub == 0) atomicAdd(cand_total, (unsigned long long)c);
+  }
+  if (sub == 0) {
+    int4 a, b;
+    a.x = (int)(uint32_t)best[0]; a.y = (int)(uint32_t)best[1]; a.z = (int)(uint32_t)best[2]; a.w = (int)(uint32_t)best[3];
+    b.x = (int)(uint32_t)best[4]; b.y = flag; b.z = 0; b.w = 0;
+    int4* o = reinterpret_cast<int4*>(&nbr[p]);
+    o[0] = a;
+    o[1] = b;
+    if (flag == 2) wl[atomicAdd(wl_count, 1)] = p;
+  }
+}
 
-  if (DBG) {
-    // per-group candidate count
-    int c = R.cand;
+// Widening for the worklist (rare): ONE WAVE per query.  The (2r+1)^2 <= 49 rows of the ring-r block
+// are owned by one lane each (range bounds fetched in a single round trip), a wave prefix sum
+// flattens their candidates, every lane scans a strided share and the best 5 are extracted with
+// wave-wide min reductions.  r starts at 2 and jumps to the ring that proves exactness, never
+// beyond max_ring (<= 3 here; the host falls back to the general kernel for larger gates).
+__global__ __launch_bounds__(256) void widen_kernel(GridView G, const float4* __restrict__ scan_sorted, PoseMats P,
+                                                    int max_ring, NbrRec* __restrict__ nbr, const int* __restrict__ wl,
+                                                    const int* __restrict__ wl_count,
+                                                    unsigned long long* __restrict__ cand_total) {
+  __shared__ uint32_t s_off[4][65];
+  __shared__ uint32_t s_lo[4][64];
+  const int count = *wl_count;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int maxdim = max(G.nx, max(G.ny, G.nz));
+  const float margin = 1.0e-3f + 4.0e-7f * (float)maxdim;
+  for (int w = blockIdx.x * 4 + wave; w < count; w += gridDim.x * 4) {
+    const int p = wl[w];
+    const float4 sp = scan_sorted[p];
+    float gx, gy, gz;
+    xform4(P.RT, sp.x, sp.y, sp.z, gx, gy, gz);
+    const float fx = (gx - G.ox) * G.inv_cell, fy = (gy - G.oy) * G.inv_cell, fz = (gz - G.oz) * G.inv_cell;
+    const float flx = floorf(fminf(fmaxf(fx, -1.0e9f), 1.0e9f)), fly = floorf(fminf(fmaxf(fy, -1.0e9f), 1.0e9f)),
+                flz = floorf(fminf(fmaxf(fz, -1.0e9f), 1.0e9f));
+    const int cx = (int)flx, cy = (int)fly, cz = (int)flz;
+    const float rx = fminf(fmaxf(fx - flx, 0.f), 1.f), ry = fminf(fmaxf(fy - fly, 0.f), 1.f),
+                rz = fminf(fmaxf(fz - flz, 0.f), 1.f);
+    const float edge = fminf(fminf(fminf(rx, 1.f - rx), fminf(ry, 1.f - ry)), fminf(rz, 1.f - rz));
+    u64 best[5] = {KEY_EMPTY, KEY_EMPTY, KEY_EMPTY, KEY_EMPTY, KEY_EMPTY};
+    int flag = 0;
+    int cand = 0;
+    int r = min(2, max_ring);
+    for (;;) {
+      const int side = 2 * r + 1;
+      // one row per lane
+      uint32_t lo = 0, len = 0;
+      if (lane < side * side) {
+        const int yy = cy + (lane % side) - r, zz = cz + (lane / side) - r;
+        const int x0 = max(cx - r, 0), x1 = min(cx + r, G.nx - 1);
+        if (yy >= 0 && yy < G.ny && zz >= 0 && zz < G.nz && x0 <= x1) {
+          const size_t rowbase = ((size_t)zz * (size_t)G.ny + (size_t)yy) * (size_t)G.nx;
+          lo = G.cell_start[rowbase + x0];
+          len = G.cell_start[rowbase + x1 + 1] - lo;
+        }
+      }
+      // inclusive prefix sum over the wave
+      uint32_t inc = len;
 #pragma unroll
-    for (int off = 1; off < L; off <<= 1) c += __shfl_xor(c, off, 64);
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += v;
+      }
+      const uint32_t total = __shfl(inc, 63, 64);
+      s_off[wave][lane + 1] = inc;
+      if (lane == 0) s_off[wave][0] = 0;
+      s_lo[wave][lane] = lo;
+      __builtin_amdgcn_wave_barrier();
+      u64 mine[5] = {KEY_EMPTY, KEY_EMPTY, KEY_EMPTY, KEY_EMPTY, KEY_EMPTY};
+      for (uint32_t s = (uint32_t)lane; s < total; s += 64) {
+        // row t with off[t] <= s < off[t+1]
+        int a = 0, b = 63;
+        while (a < b) {
+          const int m = (a + b + 1) >> 1;
+          if (s_off[wave][m] <= s) a = m; else b = m - 1;
+        }
+        const uint32_t id = s_lo[wave][a] + (s - s_off[wave][a]);
+        const float4 q = G.pts[id];
+        key5_insert(mine, make_key(sqdist3(gx, gy, gz, q.x, q.y, q.z), id));
+        cand++;
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int k = 0; k < 5; k++) {
+        u64 m = mine[0];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const u64 v = __shfl_xor(m, o, 64);
+          m = v < m ? v : m;
+        }
+        best[k] = m;
+        if (mine[0] == m) { mine[0] = mine[1]; mine[1] = mine[2]; mine[2] = mine[3]; mine[3] = mine[4]; mine[4] = KEY_EMPTY; }
+      }
+      const float rg = ((float)r + edge - margin) * G.cell;
+      const bool have5 = best[4] != KEY_EMPTY;
+      const float d5 = __uint_as_float((uint32_t)(best[4] >> 32));
+      const bool covers = (cx - r <= 0) && (cx + r >= G.nx - 1) && (cy - r <= 0) && (cy + r >= G.ny - 1) &&
+                          (cz - r <= 0) && (cz + r >= G.nz - 1);
+      if (have5 && (covers || d5 <= rg * rg * (1.f - 1.0e-6f))) { flag = 1; break; }
+      if (covers || r >= max_ring) { flag = 0; break; }
+      int rn = r + 1;
+      if (have5) {
+        const float need = fl_sqrt(d5) * G.inv_cell * (1.f + 4.0e-6f) - edge + margin;
+        rn = max(r + 1, (int)ceilf(fminf(need, 1.0e9f)));
+      }
+      r = min(rn, max_ring);
+    }
+    if (cand_total) {
+      int c = cand;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) c += __shfl_xor(c, o, 64);
+      if (lane == 0) atomicAdd(cand_total, (unsigned long long)c);
+    }
+    if (lane == 0) {
+      int4 a, b;
+      a.x = (int)(uint32_t)best[0]; a.y = (int)(uint32_t)best[1]; a.z = (int)(uint32_t)best[2]; a.w = (int)(uint32_t)best[3];
+      b.x = (int)(uint32_t)best[4]; b.y = flag; b.z = 0; b.w = 0;
+      int4* o = reinterpret_cast<int4*>(&nbr[p]);
+      o[0] = a;
+      o[1] = b;
+    }
+  }
+}
+
+// general ring search for the worklist when the gate needs more than 3 rings (unusual configs)
+__global__ __launch_bounds__(256) void widen_general_kernel(GridView G, const float4* __restrict__ scan_sorted,
+                                                            PoseMats P, int max_ring, NbrRec* __restrict__ nbr,
+                                                            const int* __restrict__ wl, const int* __restrict__ wl_count) {
+  constexpr int L = 16;
+  const int count = *wl_count;
+  const int sub = threadIdx.x % L;
+  for (int w = blockIdx.x * (256 / L) + threadIdx.x / L; w < count; w += gridDim.x * (256 / L)) {
+    const int p = wl[w];
+    const float4 sp = scan_sorted[p];
+    float gx, gy, gz;
+    xform4(P.RT, sp.x, sp.y, sp.z, gx, gy, gz);
+    KnnResult R;
+    knn_search<L>(G, gx, gy, gz, sub, max_ring, R);
     if (sub == 0) {
-      RecDbg d;
+      const bool ok = R.exact && (R.bi[4] != INT_MAX);
+      int4 a, b;
+      a.x = R.bi[0]; a.y = R.bi[1]; a.z = R.bi[2]; a.w = R.bi[3];
+      b.x = R.bi[4]; b.y = ok ? 1 : 0; b.z = 0; b.w = 0;
+      int4* o = reinterpret_cast<int4*>(&nbr[p]);
+      o[0] = a;
+      o[1] = b;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// fit kernel: one lane per scan point (sorted order).  Plane gates + 5x3 QR + plane_eval + Match +
+// calculate_H row, then H^T H / H^T h / count of the block with the f64 matrix core.
+//   RECS: also write the 64-byte record at the point's ORIGINAL index (debug / MAX_NUM_MATCHES path)
+//   DBG : also write the debug side record
+// ------------------------------------------------------------------------------------------
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+template <bool RECS, bool DBG>
+__global__ __launch_bounds__(256) void fit_kernel(GridView G, const float4* __restrict__ scan_sorted, int n,
+                                                  const NbrRec* __restrict__ nbr, PoseMats P, MatchParams mp,
+                                                  double* __restrict__ partials, Rec16* __restrict__ recs,
+                                                  RecDbg* __restrict__ dbg) {
+  __shared__ float s_rec[4][16 * 65];       // per wave: [col][row] with stride 65
+  __shared__ double s_acc[4][256];
+  const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
+  const int p = chunk * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+  float v[16];
 #pragma unroll
-      for (int i = 0; i < 4; i++) d.n[i] = valid ? n[i] : 0.f;
-      d.p_global[0] = gx; d.p_global[1] = gy; d.p_global[2] = gz;
-      int cnt = 0;
+  for (int i = 0; i < 16; i++) v[i] = 0.f;
+  float n4[4] = {0.f, 0.f, 0.f, 0.f};
+  float gx = 0.f, gy = 0.f, gz = 0.f;
+  float sq[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  int ids[5] = {-1, -1, -1, -1, -1};
+  int flag = 0;
+  uint32_t orig = 0;
+  bool valid = false;
+  if (p < n) {
+    const float4 sp = scan_sorted[p];
+    orig = __float_as_uint(sp.w);
+    xform4(P.RT, sp.x, sp.y, sp.z, gx, gy, gz);
+    const int4* nb = reinterpret_cast<const int4*>(&nbr[p]);
+    const int4 a = nb[0], b = nb[1];
+    ids[0] = a.x; ids[1] = a.y; ids[2] = a.z; ids[3] = a.w; ids[4] = b.x;
+    flag = b.y;
+    valid = (flag == 1) && (orig < (uint32_t)mp.n_queries);
+    if (valid) {
+      float px[5], py[5], pz[5];
 #pragma unroll
       for (int s = 0; s < 5; s++) {
-        const bool has = R.bi[s] != INT_MAX;
-        cnt += has ? 1 : 0;
-        d.sqd[s] = has ? R.bd[s] : 0.f;
-        d.nbr[s] = has ? R.bi[s] : -1;
+        const float4 q = G.pts[ids[s]];
+        px[s] = q.x; py[s] = q.y; pz[s] = q.z;
+        sq[s] = sqdist3(gx, gy, gz, q.x, q.y, q.z);
       }
-      d.n_nbr = R.exact ? cnt : -cnt - 1;   // negative: search stopped at the gate radius (not exact)
-      d.cand = c;
-      d.pad = 0;
-      dbg[q] = d;
-      atomicAdd(cand_total, (unsigned long long)c);
+      // Plane gates (Plane.cpp:23-31): 5 neighbours, 5th SQUARED distance < MAX_DIST_PLANE
+      valid = sq[4] < mp.max_dist_plane;
+      if (valid) {
+        plane_fit5(px, py, pz, n4);
+        valid = plane_eval5(n4, px, py, pz, mp.plane_threshold);
+      }
+      if (valid) {
+        const float dist = n4[0] * gx + n4[1] * gy + n4[2] * gz + n4[3];   // Match::Match (Plane.cpp:50-52)
+        float ix, iy, iz, lx, ly, lz;
+        xform4(P.RT_inv, gx, gy, gz, ix, iy, iz);       // p_imu    (Localizer.cpp:549)
+        xform4(P.TLI_inv, ix, iy, iz, lx, ly, lz);      // p_lidar  (Localizer.cpp:550)
+        float Cx, Cy, Cz, Dx, Dy, Dz, Bx, By, Bz, Ax, Ay, Az;
+        mul3(P.R_inv, n4[0], n4[1], n4[2], Cx, Cy, Cz); // C = R_inv * n
+        mul3(P.RLI_inv, Cx, Cy, Cz, Dx, Dy, Dz);        // I_R_L_inv * C
+        cross3(lx, ly, lz, Dx, Dy, Dz, Bx, By, Bz);     // B
+        cross3(ix, iy, iz, Cx, Cy, Cz, Ax, Ay, Az);     // A
+        v[0] = n4[0]; v[1] = n4[1]; v[2] = n4[2]; v[3] = Ax; v[4] = Ay; v[5] = Az;
+        if (mp.estimate_extrinsics) { v[6] = Bx; v[7] = By; v[8] = Bz; v[9] = Cx; v[10] = Cy; v[11] = Cz; }
+        v[12] = -dist;
+        v[13] = 1.f;
+      }
+    }
+    if (RECS && orig < (uint32_t)mp.n_queries) {
+      float4* out = reinterpret_cast<float4*>(&recs[orig]);
+      out[0] = make_float4(v[0], v[1], v[2], v[3]);
+      out[1] = make_float4(v[4], v[5], v[6], v[7]);
+      out[2] = make_float4(v[8], v[9], v[10], v[11]);
+      out[3] = make_float4(v[12], v[13], 0.f, 0.f);
+      if (DBG) {
+        RecDbg d;
+#pragma unroll
+        for (int i = 0; i < 4; i++) d.n[i] = valid ? n4[i] : 0.f;
+        d.p_global[0] = gx; d.p_global[1] = gy; d.p_global[2] = gz;
+        int cnt = 0;
+#pragma unroll
+        for (int s = 0; s < 5; s++) {
+          const bool has = (flag == 1);
+          cnt += has ? 1 : 0;
+          d.sqd[s] = has ? sq[s] : 0.f;
+          d.nbr[s] = has ? ids[s] : -1;
+        }
+        d.n_nbr = cnt;
+        d.cand = 0;
+        d.pad = 0;
+        dbg[orig] = d;
+      }
     }
   }
-
-  if (sub == 0) {
-    float4* out = reinterpret_cast<float4*>(&recs[q]);
-    if (valid) {
-      out[0] = make_float4(H[0], H[1], H[2], H[3]);
-      out[1] = make_float4(H[4], H[5], H[6], H[7]);
-      out[2] = make_float4(H[8], H[9], H[10], H[11]);
-      out[3] = make_float4(-dist, 1.f, 0.f, 0.f);
-    } else {
-      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-      out[0] = z; out[1] = z; out[2] = z; out[3] = z;
-    }
+  // ---- block reduction: D += X^T X with X = the 64 rows of this wave, 4 rows per MFMA ----
+  float* sr = s_rec[wave];
+#pragma unroll
+  for (int c = 0; c < 16; c++) sr[c * 65 + lane] = v[c];
+  __builtin_amdgcn_wave_barrier();
+  __syncthreads();
+  double4_t acc = {0.0, 0.0, 0.0, 0.0};
+  const int col = lane & 15, sub4 = lane >> 4;
+#pragma unroll
+  for (int s = 0; s < 16; s++) {
+    const double a = (double)sr[col * 65 + 4 * s + sub4];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc, 0, 0, 0);
+  }
+  double* sa = s_acc[wave];
+  sa[lane * 4 + 0] = acc[0]; sa[lane * 4 + 1] = acc[1]; sa[lane * 4 + 2] = acc[2]; sa[lane * 4 + 3] = acc[3];
+  __syncthreads();
+  {
+    const int t = threadIdx.x;
+    const double r = (s_acc[0][t] + s_acc[1][t]) + (s_acc[2][t] + s_acc[3][t]);
+    partials[(size_t)blockIdx.x * 256 + t] = r;
   }
 }
 
@@ -395,8 +720,6 @@ __global__ __launch_bounds__(1024) void cap_kernel(Rec16* __restrict__ recs, int
 // One wave accumulates a strided set of 4-record groups; raw accumulators (4 doubles per lane)
 // go to partials[wave][lane*4 + r]; reduce_final sums them in a fixed order.
 // ------------------------------------------------------------------------------------------
-typedef double double4_t __attribute__((ext_vector_type(4)));
-
 __global__ __launch_bounds__(64) void reduce_kernel(const Rec16* __restrict__ recs, int n, double* __restrict__ partials) {
   const int lane = threadIdx.x;
   const int w = blockIdx.x;
@@ -405,29 +728,45 @@ __global__ __launch_bounds__(64) void reduce_kernel(const Rec16* __restrict__ re
   const int groups = (n + 3) >> 2;
   double4_t acc = {0.0, 0.0, 0.0, 0.0};
   const float* base = reinterpret_cast<const float*>(recs);
-  for (int g = w; g < groups; g += nw) {
-    const int q = 4 * g + sub;
-    const float v = (q < n) ? base[(size_t)q * 16 + col] : 0.f;
-    const double a = (double)v;
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc, 0, 0, 0);
+  constexpr int U = 8;   // loads in flight
+  for (int g0 = w; g0 < groups; g0 += nw * U) {
+    float v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int g = g0 + u * nw;
+      const int q = 4 * g + sub;
+      v[u] = (g < groups && q < n) ? base[(size_t)q * 16 + col] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const double a = (double)v[u];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc, 0, 0, 0);
+    }
   }
   double* o = partials + (size_t)w * 256 + lane * 4;
   o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3];
 }
 
-__global__ __launch_bounds__(256) void reduce_final_kernel(const double* __restrict__ partials, int nw,
-                                                           double* __restrict__ out) {
-  const int t = threadIdx.x;
+__global__ __launch_bounds__(1024) void reduce_final_kernel(const double* __restrict__ partials, int nw,
+                                                            double* __restrict__ out) {
+  // 256 accumulator slots x 4 slices of the partial list; fixed summation order
+  __shared__ double s[4][256];
+  const int t = threadIdx.x & 255, part = threadIdx.x >> 8;
+  const int per = (nw + 3) >> 2;
+  const int b = part * per, e = min(nw, b + per);
   double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-  int w = 0;
-  for (; w + 3 < nw; w += 4) {
-    s0 += partials[(size_t)(w + 0) * 256 + t];
-    s1 += partials[(size_t)(w + 1) * 256 + t];
-    s2 += partials[(size_t)(w + 2) * 256 + t];
-    s3 += partials[(size_t)(w + 3) * 256 + t];
+  int w = b;
+  for (; w + 15 < e; w += 16) {
+    double v[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) v[u] = partials[(size_t)(w + u) * 256 + t];
+#pragma unroll
+    for (int u = 0; u < 16; u += 4) { s0 += v[u]; s1 += v[u + 1]; s2 += v[u + 2]; s3 += v[u + 3]; }
   }
-  for (; w < nw; w++) s0 += partials[(size_t)w * 256 + t];
-  out[t] = (s0 + s1) + (s2 + s3);
+  for (; w < e; w++) s0 += partials[(size_t)w * 256 + t];
+  s[part][t] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (part == 0) out[t] = (s[0][t] + s[1][t]) + (s[2][t] + s[3][t]);
 }
 
 // calibration of the MFMA operand/result layout: D = A*B with A[i][0]=1, A[i][1]=i, B[0][j]=j,
@@ -482,10 +821,10 @@ __global__ __launch_bounds__(256) void deskew_kernel(const float4* __restrict__ 
   // State::update(tk)
   const double dt = tk - F.time;
   const float wx = F.w[0] - F.bg[0], wy = F.w[1] - F.bg[1], wz = F.w[2] - F.bg[2];
-  const float w_norm = __fsqrt_rn(sum3(wx * wx, wy * wy, wz * wz));
+  const float w_norm = fl_sqrt(sum3(wx * wx, wy * wy, wz * wz));
   float Rm[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
   if ((double)w_norm > 1.e-7) {
-    const float r0 = __fdiv_rn(wx, w_norm), r1 = __fdiv_rn(wy, w_norm), r2 = __fdiv_rn(wz, w_norm);
+    const float r0 = fl_div(wx, w_norm), r1 = fl_div(wy, w_norm), r2 = fl_div(wz, w_norm);
     const float K[9] = {0.f, -r2, r1, r2, 0.f, -r0, -r1, r0, 0.f};
     const float r_ang = (float)((double)w_norm * dt);
     const float s = sinf(r_ang);
@@ -516,9 +855,9 @@ __global__ __launch_bounds__(256) void deskew_kernel(const float4* __restrict__ 
   {
     float tr = Rm[0] + Rm[4] + Rm[8];
     if (tr > 0.f) {
-      tr = __fsqrt_rn(tr + 1.0f);
+      tr = fl_sqrt(tr + 1.0f);
       uw_ = 0.5f * tr;
-      tr = __fdiv_rn(0.5f, tr);
+      tr = fl_div(0.5f, tr);
       ux_ = (Rm[7] - Rm[5]) * tr;
       uy_ = (Rm[2] - Rm[6]) * tr;
       uz_ = (Rm[3] - Rm[1]) * tr;
@@ -527,10 +866,10 @@ __global__ __launch_bounds__(256) void deskew_kernel(const float4* __restrict__ 
       if (Rm[4] > Rm[0]) i = 1;
       if (Rm[8] > Rm[i * 4]) i = 2;
       const int j = (i + 1) % 3, kq = (j + 1) % 3;
-      float tq = __fsqrt_rn(Rm[i * 4] - Rm[j * 4] - Rm[kq * 4] + 1.0f);
+      float tq = fl_sqrt(Rm[i * 4] - Rm[j * 4] - Rm[kq * 4] + 1.0f);
       float cc[3];
       cc[i] = 0.5f * tq;
-      tq = __fdiv_rn(0.5f, tq);
+      tq = fl_div(0.5f, tq);
       uw_ = (Rm[kq * 3 + j] - Rm[j * 3 + kq]) * tq;
       cc[j] = (Rm[j * 3 + i] + Rm[i * 3 + j]) * tq;
       cc[kq] = (Rm[kq * 3 + i] + Rm[i * 3 + kq]) * tq;
@@ -590,28 +929,65 @@ __global__ __launch_bounds__(256) void transform_kernel(const float4* __restrict
 // ------------------------------------------------------------------------------------------
 // host-callable launchers
 // ------------------------------------------------------------------------------------------
+static inline int round_up8(int x) { return (x + 7) & ~7; }
+
+static int g_slots = 0;   // 0: default per L; developer override through FLIMO_SLOTS
 template <int L>
-static void launch_match_L(hipStream_t st, const GridView& G, const float4* scan, const PoseMats& P,
-                           const MatchParams& mp, Rec16* recs, RecDbg* dbg, unsigned long long* cand) {
-  const long long threads = (long long)mp.n_queries * L;
-  const int blocks = (int)((threads + 255) / 256);
-  if (blocks == 0) return;
-  if (dbg)
-    hipLaunchKernelGGL((match_kernel<L, true>), dim3(blocks), dim3(256), 0, st, G, scan, P, mp, recs, dbg, cand);
+static void launch_knn5_L(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const PoseMats& P,
+                          int max_ring, void* nbr, int* wl, int* wl_count, unsigned long long* cand) {
+  const int qpb = 256 / L;
+  const int blocks = round_up8((n + qpb - 1) / qpb);
+  if (g_slots == 0) { const char* e = getenv("FLIMO_SLOTS"); g_slots = e ? atoi(e) : -1; }
+  const int slots = g_slots > 0 ? g_slots : (L <= 4 ? 8 : 4);
+  if (slots >= 8)
+    hipLaunchKernelGGL((knn5_kernel<L, 8>), dim3(blocks), dim3(256), 0, st, G, scan_sorted, n, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand);
+  else if (slots >= 4)
+    hipLaunchKernelGGL((knn5_kernel<L, 4>), dim3(blocks), dim3(256), 0, st, G, scan_sorted, n, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand);
   else
-    hipLaunchKernelGGL((match_kernel<L, false>), dim3(blocks), dim3(256), 0, st, G, scan, P, mp, recs, dbg, cand);
+    hipLaunchKernelGGL((knn5_kernel<L, 2>), dim3(blocks), dim3(256), 0, st, G, scan_sorted, n, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand);
 }
 
-void launch_match(hipStream_t st, int lanes_per_query, const GridView& G, const float4* scan, const PoseMats& P,
-                  const MatchParams& mp, Rec16* recs, RecDbg* dbg, unsigned long long* cand) {
+void launch_knn5(hipStream_t st, int lanes_per_query, const GridView& G, const float4* scan_sorted, int n,
+                 const PoseMats& P, int max_ring, void* nbr, int* wl, int* wl_count, unsigned long long* cand) {
+  if (n <= 0) return;
   switch (lanes_per_query) {
-    case 1: launch_match_L<1>(st, G, scan, P, mp, recs, dbg, cand); break;
-    case 2: launch_match_L<2>(st, G, scan, P, mp, recs, dbg, cand); break;
-    case 4: launch_match_L<4>(st, G, scan, P, mp, recs, dbg, cand); break;
-    case 8: launch_match_L<8>(st, G, scan, P, mp, recs, dbg, cand); break;
-    default: launch_match_L<16>(st, G, scan, P, mp, recs, dbg, cand); break;
+    case 1: launch_knn5_L<1>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand); break;
+    case 2: launch_knn5_L<2>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand); break;
+    case 4: launch_knn5_L<4>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand); break;
+    case 8: launch_knn5_L<8>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand); break;
+    case 32: launch_knn5_L<32>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand); break;
+    default: launch_knn5_L<16>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand); break;
   }
 }
+
+void launch_widen(hipStream_t st, const GridView& G, const float4* scan_sorted, const PoseMats& P, int max_ring, void* nbr,
+                  int* wl, int* wl_count, unsigned long long* cand) {
+  if (max_ring <= 1) return;
+  if (max_ring <= 3)
+    hipLaunchKernelGGL(widen_kernel, dim3(4096), dim3(256), 0, st, G, scan_sorted, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand);
+  else
+    hipLaunchKernelGGL(widen_general_kernel, dim3(256), dim3(256), 0, st, G, scan_sorted, P, max_ring, (NbrRec*)nbr, wl, wl_count);
+}
+
+int fit_blocks(int n) { return round_up8((n + 255) / 256); }
+
+void launch_fit(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const void* nbr, const PoseMats& P,
+                const MatchParams& mp, double* partials, Rec16* recs, RecDbg* dbg) {
+  if (n <= 0) return;
+  const int blocks = fit_blocks(n);
+  if (recs && dbg)
+    hipLaunchKernelGGL((fit_kernel<true, true>), dim3(blocks), dim3(256), 0, st, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, partials, recs, dbg);
+  else if (recs)
+    hipLaunchKernelGGL((fit_kernel<true, false>), dim3(blocks), dim3(256), 0, st, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, partials, recs, dbg);
+  else
+    hipLaunchKernelGGL((fit_kernel<false, false>), dim3(blocks), dim3(256), 0, st, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, partials, recs, dbg);
+}
+
+void launch_reduce_final(hipStream_t st, const double* partials, int nparts, double* out256) {
+  hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(1024), 0, st, partials, nparts, out256);
+}
+
+size_t nbr_rec_size() { return sizeof(NbrRec); }
 
 void launch_knn(hipStream_t st, const GridView& G, const float* qxyz, int nq, int k, int max_ring, int32_t* idx,
                 float* sqd, int32_t* cnt) {
@@ -628,7 +1004,7 @@ void launch_cap(hipStream_t st, Rec16* recs, int n, int cap) {
 
 void launch_reduce(hipStream_t st, const Rec16* recs, int n, int nwaves, double* partials, double* out256) {
   hipLaunchKernelGGL(reduce_kernel, dim3(nwaves), dim3(64), 0, st, recs, n, partials);
-  hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, st, partials, nwaves, out256);
+  hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(1024), 0, st, partials, nwaves, out256);
 }
 
 void launch_mfma_layout(hipStream_t st, double* raw256) {

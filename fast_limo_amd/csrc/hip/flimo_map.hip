@@ -162,6 +162,60 @@ hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4
   return hipGetLastError();
 }
 
+// ---- spatial ordering of the scan ----------------------------------------------------------
+__device__ __forceinline__ uint32_t spread10(uint32_t v) {   // 10 bits -> every third bit
+  v &= 0x3ffu;
+  v = (v | (v << 16)) & 0x030000ffu;
+  v = (v | (v << 8)) & 0x0300f00fu;
+  v = (v | (v << 4)) & 0x030c30c3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+__global__ __launch_bounds__(256) void mortonkey_kernel(const float4* __restrict__ pts, size_t n,
+                                                        uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = pts[i];
+  // body-frame coordinates quantised to 0.5 m, +-256 m range (clamped); NaNs go to the end
+  const float qx = fminf(fmaxf(p.x * 2.0f + 512.f, 0.f), 1023.f);
+  const float qy = fminf(fmaxf(p.y * 2.0f + 512.f, 0.f), 1023.f);
+  const float qz = fminf(fmaxf(p.z * 2.0f + 512.f, 0.f), 1023.f);
+  const bool nan = !(p.x == p.x) || !(p.y == p.y) || !(p.z == p.z);
+  const uint32_t k = spread10((uint32_t)qx) | (spread10((uint32_t)qy) << 1) | (spread10((uint32_t)qz) << 2);
+  keys[i] = nan ? 0x3fffffffu : k;
+  vals[i] = (uint32_t)i;
+}
+__global__ __launch_bounds__(256) void gather_scan_kernel(const float4* __restrict__ in, const uint32_t* __restrict__ perm,
+                                                          size_t n, float4* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t src = perm[i];
+  float4 p = in[src];
+  p.w = __uint_as_float(src);
+  out[i] = p;
+}
+
+hipError_t sort_scan(hipStream_t st, const float4* in, size_t n, float4* out, MapBuildScratch& S) {
+  if (n == 0) return hipSuccess;
+  hipError_t e = ensure_scratch(S, n);
+  if (e != hipSuccess) return e;
+  const int blocks = (int)((n + 255) / 256);
+  hipLaunchKernelGGL(mortonkey_kernel, dim3(blocks), dim3(256), 0, st, in, n, S.keys_in, S.vals_in);
+  size_t tmp_bytes = 0;
+  e = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, S.keys_in, S.keys_out, S.vals_in, S.vals_out, (int)n, 0, 30, st);
+  if (e != hipSuccess) return e;
+  if (tmp_bytes > S.cub_tmp_bytes) {
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+    if (S.cub_tmp) (void)hipFree(S.cub_tmp);
+    if ((e = hipMalloc(&S.cub_tmp, tmp_bytes + 1024)) != hipSuccess) return e;
+    S.cub_tmp_bytes = tmp_bytes + 1024;
+  }
+  e = hipcub::DeviceRadixSort::SortPairs(S.cub_tmp, tmp_bytes, S.keys_in, S.keys_out, S.vals_in, S.vals_out, (int)n, 0, 30, st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(gather_scan_kernel, dim3(blocks), dim3(256), 0, st, in, S.vals_out, n, out);
+  return hipGetLastError();
+}
+
 void map_scratch_free(MapBuildScratch& S) {
   if (S.cub_tmp) hipFree(S.cub_tmp);
   if (S.keys_in) { hipFree(S.keys_in); hipFree(S.keys_out); hipFree(S.vals_in); hipFree(S.vals_out); }

@@ -4,8 +4,7 @@
 // Every function here must produce results that are BIT-IDENTICAL to the reference's float32
 // arithmetic (x86-64 SSE2, no FMA: CMakeLists.txt:4-5,17-21), so
 //   * this header is compiled with -ffp-contract=off and the pragma below,
-//   * sqrt and divide are the correctly rounded forms (hipcc default; we call __fsqrt_rn /
-//     __fdiv_rn explicitly),
+//   * sqrt and divide are the correctly rounded forms (fl_sqrt / fl_div below),
 //   * evaluation order follows Eigen's expression evaluation as documented per function.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -15,7 +14,14 @@
 
 namespace flimo {
 
-#define FLIMO_DEV __device__ __forceinline__
+#define FLIMO_DEV __host__ __device__ __forceinline__
+
+// Correctly rounded sqrt / divide.  NOTE: HIP's __fsqrt_rn maps to __ocml_native_sqrt_f32 (1 ulp,
+// measured 16 % mismatches against IEEE on gfx950), so it must NOT be used here; __builtin_sqrtf
+// and operator/ are lowered to the correctly rounded sequences (hipcc default
+// -fhip-fp32-correctly-rounded-divide-sqrt) -- verified bit-exact on the GPU by tools/devmath_check.
+FLIMO_DEV float fl_sqrt(float x) { return __builtin_sqrtf(x); }
+FLIMO_DEV float fl_div(float a, float b) { return a / b; }
 
 // 3-coefficient Eigen reduction: c0 + (c1 + c2)
 FLIMO_DEV float sum3(float a, float b, float c) { return a + (b + c); }
@@ -62,7 +68,7 @@ FLIMO_DEV void plane_fit5(const float (&px)[5], const float (&py)[5], const floa
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 5; i++) s = s + a[k][i] * a[k][i];
-    nD[k] = __fsqrt_rn(s);
+    nD[k] = fl_sqrt(s);
     nU[k] = nD[k];
   }
   const float eps = 1.1920929e-07f;
@@ -70,8 +76,8 @@ FLIMO_DEV void plane_fit5(const float (&px)[5], const float (&py)[5], const floa
   if (nU[1] > maxn) maxn = nU[1];
   if (nU[2] > maxn) maxn = nU[2];
   const float th = maxn * eps;
-  const float threshold_helper = __fdiv_rn(th * th, 5.0f);
-  const float downdate_thr = __fsqrt_rn(eps);
+  const float threshold_helper = fl_div(th * th, 5.0f);
+  const float downdate_thr = fl_sqrt(eps);
   int nzp = 3;
   int perm0 = 0, perm1 = 1, perm2 = 2;
   float hC[3];
@@ -115,12 +121,12 @@ FLIMO_DEV void plane_fit5(const float (&px)[5], const float (&py)[5], const floa
 #pragma unroll
       for (int i = k + 1; i < 5; i++) a[k][i] = 0.f;
     } else {
-      beta = __fsqrt_rn(c0 * c0 + tailSq);
+      beta = fl_sqrt(c0 * c0 + tailSq);
       if (c0 >= 0.f) beta = -beta;
       const float denom = c0 - beta;
 #pragma unroll
-      for (int i = k + 1; i < 5; i++) a[k][i] = __fdiv_rn(a[k][i], denom);
-      tau = __fdiv_rn(beta - c0, beta);
+      for (int i = k + 1; i < 5; i++) a[k][i] = fl_div(a[k][i], denom);
+      tau = fl_div(beta - c0, beta);
     }
     hC[k] = tau;
     a[k][k] = beta;
@@ -141,19 +147,19 @@ FLIMO_DEV void plane_fit5(const float (&px)[5], const float (&py)[5], const floa
 #pragma unroll
     for (int j = k + 1; j < 3; j++) {
       if (nU[j] != 0.f) {
-        float temp = __fdiv_rn(fabsf(a[j][k]), nU[j]);
+        float temp = fl_div(fabsf(a[j][k]), nU[j]);
         temp = (1.f + temp) * (1.f - temp);
         temp = temp < 0.f ? 0.f : temp;
-        const float ratio = __fdiv_rn(nU[j], nD[j]);
+        const float ratio = fl_div(nU[j], nD[j]);
         const float temp2 = temp * (ratio * ratio);
         if (temp2 <= downdate_thr) {
           float s = 0.f;
 #pragma unroll
           for (int i = k + 1; i < 5; i++) s = s + a[j][i] * a[j][i];
-          nD[j] = __fsqrt_rn(s);
+          nD[j] = fl_sqrt(s);
           nU[j] = nD[j];
         } else {
-          nU[j] = nU[j] * __fsqrt_rn(temp);
+          nU[j] = nU[j] * fl_sqrt(temp);
         }
       }
     }
@@ -182,7 +188,7 @@ FLIMO_DEV void plane_fit5(const float (&px)[5], const float (&py)[5], const floa
 #pragma unroll
       for (int j = i + 1; j < 3; j++)
         if (j < nzp) s = s - a[j][i] * c[j];
-      c[i] = __fdiv_rn(s, a[i][i]);
+      c[i] = fl_div(s, a[i][i]);
     }
   }
   const float y0 = (0 < nzp) ? c[0] : 0.f;
@@ -194,11 +200,11 @@ FLIMO_DEV void plane_fit5(const float (&px)[5], const float (&py)[5], const floa
   x0 = (perm1 == 0) ? y1 : x0; x1 = (perm1 == 1) ? y1 : x1; x2 = (perm1 == 2) ? y1 : x2;
   x0 = (perm2 == 0) ? y2 : x0; x1 = (perm2 == 1) ? y2 : x1; x2 = (perm2 == 2) ? y2 : x2;
 
-  const float nn = __fsqrt_rn(sum3(x0 * x0, x1 * x1, x2 * x2));   // normvec.norm()
-  n[0] = __fdiv_rn(x0, nn);
-  n[1] = __fdiv_rn(x1, nn);
-  n[2] = __fdiv_rn(x2, nn);
-  n[3] = __fdiv_rn(1.0f, nn);   // (float)(1.0 / n): double rounding is innocuous for division
+  const float nn = fl_sqrt(sum3(x0 * x0, x1 * x1, x2 * x2));   // normvec.norm()
+  n[0] = fl_div(x0, nn);
+  n[1] = fl_div(x1, nn);
+  n[2] = fl_div(x2, nn);
+  n[3] = fl_div(1.0f, nn);   // (float)(1.0 / n): double rounding is innocuous for division
 }
 
 // Plane::plane_eval (Objects/Plane.cpp:107-114)

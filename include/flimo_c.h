@@ -135,14 +135,17 @@ int flimo_scan_to_world(flimo_ctx* ctx, const double x26[26], float* world_xyz_o
 int flimo_map_add_scan(flimo_ctx* ctx, const double x26[26], double stamp);
 
 /* ---- instrumentation ---- */
-/* GPU time [ms] of the kernels of the last flimo_match_reduce: match, reduce (HIP events on the
- * ctx stream); enable with flimo_set_timing(ctx, 1). */
+/* GPU time [ms] of the stages of the last flimo_match_reduce, from HIP events on the ctx stream:
+ * k-NN fast path, ring widening of the worklist, fit + reductions.  Enable with
+ * flimo_set_timing(ctx, 1). */
 int flimo_set_timing(flimo_ctx* ctx, int on);
+int flimo_last_kernel_ms(const flimo_ctx* ctx, float* knn_ms, float* widen_ms, float* fit_ms);
+/* number of scan points of the last pass that needed more than the 3x3x3 cell block */
+int flimo_last_widen_count(const flimo_ctx* ctx);
 /* also write the per-point debug part of flimo_match_rec (plane, neighbours, candidate counts) */
 int flimo_set_debug_records(flimo_ctx* ctx, int on);
-/* lanes of a wavefront that cooperate on one scan point in the match kernel: 1, 2, 4, 8 or 16 */
+/* lanes of a wavefront that cooperate on one scan point in the k-NN kernel: 1, 2, 4, 8, 16 or 32 */
 int flimo_set_lanes_per_query(flimo_ctx* ctx, int lanes);
-int flimo_last_kernel_ms(const flimo_ctx* ctx, float* match_ms, float* reduce_ms);
 /* mean number of candidate map points examined per query in the last pass */
 double flimo_last_candidates_per_query(const flimo_ctx* ctx);
 

@@ -1,0 +1,60 @@
+// Developer check (GPU box): the float32 device math of flimo_math.h is bit-identical to the same
+// source compiled for the host (x86-64, no FMA).  Build: hipcc --offload-arch=gfx950 -O3
+// -ffp-contract=off -I fast_limo_amd/csrc/hip tools/devmath_check.hip -o /tmp/devmath_check
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "flimo_math.h"
+using namespace flimo;
+
+struct In { float px[5], py[5], pz[5]; float a, b; };
+struct Out { float n[4]; int ok; float s, d, sq; };
+
+__host__ __device__ void eval(const In& in, Out& o) {
+  plane_fit5(in.px, in.py, in.pz, o.n);
+  o.ok = plane_eval5(o.n, in.px, in.py, in.pz, 0.05f) ? 1 : 0;
+  o.s = fl_sqrt(fabsf(in.a));
+  o.d = fl_div(in.a, in.b);
+  o.sq = sqdist3(in.a, in.b, in.px[0], in.py[0], in.pz[0], in.px[1]);
+}
+__global__ void k(const In* in, Out* out, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) eval(in[i], out[i]);
+}
+int main() {
+  const int N = 1 << 20;
+  std::vector<In> in(N);
+  std::vector<Out> ho(N), go(N);
+  srand(7);
+  auto rf = []() { return (rand() % 200001 - 100000) * 1e-5f; };
+  for (int t = 0; t < N; t++) {
+    int mode = t % 4;
+    float ox = rf() * 100.f, oy = rf() * 100.f, oz = rf() * 10.f;
+    for (int i = 0; i < 5; i++) {
+      float a = rf() * 0.5f, b = rf() * 0.5f, c = rf() * (mode == 0 ? 0.01f : (mode == 1 ? 0.5f : 0.f));
+      if (mode == 2) { in[t].px[i] = ox + a; in[t].py[i] = oy + c; in[t].pz[i] = oz + b; }
+      else if (mode == 3) { in[t].px[i] = ox + a; in[t].py[i] = oy + a * 0.5f + c; in[t].pz[i] = oz + rf() * 1e-3f; }
+      else { in[t].px[i] = ox + a; in[t].py[i] = oy + b; in[t].pz[i] = oz + c; }
+    }
+    in[t].a = rf() * (t % 7 == 0 ? 1e-30f : 3.f);
+    in[t].b = rf() * (t % 11 == 0 ? 1e-25f : 7.f) + 1e-9f;
+  }
+  for (int t = 0; t < N; t++) eval(in[t], ho[t]);
+  In* din; Out* dout;
+  hipMalloc(&din, N * sizeof(In)); hipMalloc(&dout, N * sizeof(Out));
+  hipMemcpy(din, in.data(), N * sizeof(In), hipMemcpyHostToDevice);
+  hipLaunchKernelGGL(k, dim3(N / 256), dim3(256), 0, 0, din, dout, N);
+  hipMemcpy(go.data(), dout, N * sizeof(Out), hipMemcpyDeviceToHost);
+  int bn = 0, bok = 0, bs = 0, bd = 0, bq = 0;
+  for (int t = 0; t < N; t++) {
+    if (memcmp(ho[t].n, go[t].n, 16)) { if (bn < 5) printf("n mismatch t=%d mode=%d: %.9g %.9g %.9g %.9g | %.9g %.9g %.9g %.9g\n", t, t % 4, ho[t].n[0], ho[t].n[1], ho[t].n[2], ho[t].n[3], go[t].n[0], go[t].n[1], go[t].n[2], go[t].n[3]); bn++; }
+    if (ho[t].ok != go[t].ok) bok++;
+    if (memcmp(&ho[t].s, &go[t].s, 4)) { if (bs < 3) printf("sqrt mismatch a=%.9g: %.9g %.9g\n", in[t].a, ho[t].s, go[t].s); bs++; }
+    if (memcmp(&ho[t].d, &go[t].d, 4)) { if (bd < 3) printf("div mismatch %.9g/%.9g: %.9g %.9g\n", in[t].a, in[t].b, ho[t].d, go[t].d); bd++; }
+    if (memcmp(&ho[t].sq, &go[t].sq, 4)) bq++;
+  }
+  printf("DEVMATH mismatches: plane_n=%d plane_ok=%d sqrt=%d div=%d sqdist=%d of %d\n", bn, bok, bs, bd, bq, N);
+  return (bn || bok || bs || bd || bq) ? 1 : 0;
+}

@@ -73,21 +73,22 @@ out.update(valid_mismatch=int((valid_g != valid_o).sum()), M_gpu=int(M), M_oracl
 # ---- variant sweep ----
 ctx.set_debug_records(False)
 res = []
-for cell in [float(c) for c in os.environ.get("CELLS", "0.5,0.75,1.0,0.35").split(",")]:
+for cell in [float(c) for c in os.environ.get("CELLS", "0.5,0.6").split(",")]:
     ctx.map_clear(); ctx.map_config(cell_size=cell); ctx.map_add(mp)
     ctx.set_debug_records(True); ctx.match_reduce(x0, mcfg); cq = ctx.last_candidates_per_query(); ctx.set_debug_records(False)
-    for lpq in (1, 2, 4, 8, 16):
+    for lpq in [int(v) for v in os.environ.get('LPQS', '2,4,8,16').split(',')]:
         ctx.set_lanes_per_query(lpq)
         for _ in range(3): ctx.match_reduce(x0, mcfg)
-        ms = []; rs_ = []
+        ms = []; ws_ = []; rs_ = []
         t0 = time.time()
         for _ in range(20):
-            _, _, M2 = ctx.match_reduce(x0, mcfg); a, b = ctx.last_kernel_ms(); ms.append(a); rs_.append(b)
+            _, _, M2 = ctx.match_reduce(x0, mcfg); a, wd, b = ctx.last_kernel_ms(); ms.append(a); ws_.append(wd); rs_.append(b)
         wall = (time.time() - t0) / 20
         assert M2 == M, (M2, M)
-        r = dict(cell=cell, lpq=lpq, match_us=float(np.median(ms) * 1e3), reduce_us=float(np.median(rs_) * 1e3), wall_us=wall * 1e6, cand_per_q=cq)
+        r = dict(cell=cell, lpq=lpq, knn_us=float(np.median(ms) * 1e3), widen_us=float(np.median(ws_) * 1e3), widen_n=ctx.last_widen_count(), fit_us=float(np.median(rs_) * 1e3), wall_us=wall * 1e6, cand_per_q=cq)
         res.append(r); print(r, flush=True)
 out["sweep"] = res
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "probe.json"), "w"), indent=1)
+ctx.close()
 print("PROBE DONE")
