@@ -1,0 +1,252 @@
+"""Python view of the host C++ library (``libfast_limo.so``): ``Localizer`` with the reference's
+call pattern (``init`` -> ``updateIMU`` / ``updatePointCloud`` -> getters, reference
+``src/main.cpp:14-95``).  Everything here forwards to C++ through ``include/flimo_localizer_c.h``;
+there is no Python compute path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import numpy as np
+
+from . import _lib
+from ._lib import FlimoError, f32p, f64p
+
+_host = None
+
+
+class LocCfg(C.Structure):
+    _fields_ = [
+        ("NUM_MATCH_POINTS", C.c_int), ("MAX_NUM_MATCHES", C.c_int), ("MAX_NUM_PC2MATCH", C.c_int),
+        ("bucket_size", C.c_int),
+        ("MAX_DIST_PLANE", C.c_double), ("PLANE_THRESHOLD", C.c_double),
+        ("min_extent", C.c_float), ("downsampling", C.c_int),
+        ("MAX_NUM_ITERS", C.c_int), ("estimate_extrinsics", C.c_int),
+        ("LIMITS", C.c_double * 23),
+        ("cov_gyro", C.c_double), ("cov_acc", C.c_double), ("cov_bias_gyro", C.c_double), ("cov_bias_acc", C.c_double),
+        ("time_offset", C.c_int), ("end_of_sweep", C.c_int), ("num_threads", C.c_int),
+        ("imu2baselink_t", C.c_float * 3), ("imu2baselink_R", C.c_float * 9),
+        ("lidar2baselink_t", C.c_float * 3), ("lidar2baselink_R", C.c_float * 9),
+        ("accel_bias", C.c_float * 3), ("gyro_bias", C.c_float * 3), ("imu_sm", C.c_float * 9),
+        ("crop_active", C.c_int), ("cropBoxMin", C.c_float * 3), ("cropBoxMax", C.c_float * 3),
+        ("dist_active", C.c_int), ("min_dist", C.c_double),
+        ("rate_active", C.c_int), ("rate_value", C.c_int),
+        ("fov_active", C.c_int), ("fov_angle", C.c_float),
+        ("sensor_type", C.c_int),
+        ("gpu_device", C.c_int), ("gpu_cell_size", C.c_float),
+    ]
+
+
+HOST_SYMBOLS = [
+    "flimo_loc_create", "flimo_loc_destroy", "flimo_loc_ctx", "flimo_loc_update_imu", "flimo_loc_update_pointcloud",
+    "flimo_loc_map_add", "flimo_loc_map_size", "flimo_loc_get_x", "flimo_loc_set_x", "flimo_loc_get_P",
+    "flimo_loc_set_P", "flimo_loc_set_flags", "flimo_loc_num_passes", "flimo_loc_get_pass", "flimo_loc_get_pc2match",
+    "flimo_loc_get_final_scan", "flimo_loc_get_stage_times", "flimo_loc_get_pose_cov", "flimo_loc_register_resident",
+    "flimo_eskf_update_fixed", "flimo_eskf_predict",
+]
+
+
+def default_cfg(**kw) -> LocCfg:
+    """Defaults of reference ``src/main.cpp:101-168`` with the synthetic-benchmark deltas of
+    SURVEY.md section 8 d: identity extrinsics / sm, calibration and filters off, Velodyne time."""
+    c = LocCfg()
+    c.NUM_MATCH_POINTS, c.MAX_NUM_MATCHES, c.MAX_NUM_PC2MATCH = 5, 2000, 10000
+    c.bucket_size = 2
+    c.MAX_DIST_PLANE, c.PLANE_THRESHOLD = 2.0, 5.0e-2
+    c.min_extent, c.downsampling = 0.2, 1
+    c.MAX_NUM_ITERS, c.estimate_extrinsics = 3, 1
+    for i in range(23):
+        c.LIMITS[i] = 1e-3
+    c.cov_gyro, c.cov_acc, c.cov_bias_gyro, c.cov_bias_acc = 6e-4, 1e-2, 1e-5, 3e-4
+    c.time_offset, c.end_of_sweep, c.num_threads = 1, 0, 10
+    eye = [1, 0, 0, 0, 1, 0, 0, 0, 1]
+    for i in range(9):
+        c.imu2baselink_R[i] = eye[i]
+        c.lidar2baselink_R[i] = eye[i]
+        c.imu_sm[i] = eye[i]
+    c.crop_active = 0
+    for i in range(3):
+        c.cropBoxMin[i], c.cropBoxMax[i] = -1.0, 1.0
+    c.dist_active, c.min_dist = 0, 4.0
+    c.rate_active, c.rate_value = 0, 4
+    c.fov_active, c.fov_angle = 0, float(np.pi)
+    c.sensor_type = 1
+    c.gpu_device, c.gpu_cell_size = 0, 0.0
+    for k, v in kw.items():
+        if not hasattr(c, k):
+            raise AttributeError(k)
+        setattr(c, k, v)
+    return c
+
+
+def host_lib_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libfast_limo.so")
+
+
+def load_host():
+    global _host
+    if _host is not None:
+        return _host
+    _lib.load_hip()                     # resolve libflimo_hip.so first (same directory, rpath $ORIGIN)
+    path = host_lib_path()
+    if not os.path.exists(path):
+        raise FlimoError(f"{path} not found: build first")
+    L = C.CDLL(path)
+    vp = C.c_void_p
+    L.flimo_loc_create.argtypes = [C.POINTER(LocCfg), C.POINTER(vp)]
+    L.flimo_loc_destroy.restype = None
+    L.flimo_loc_destroy.argtypes = [vp]
+    L.flimo_loc_ctx.restype = vp
+    L.flimo_loc_ctx.argtypes = [vp]
+    L.flimo_loc_update_imu.argtypes = [vp, C.c_double, f32p, f32p]
+    L.flimo_loc_update_pointcloud.argtypes = [vp, f32p, C.c_size_t, C.c_double]
+    L.flimo_loc_map_add.argtypes = [vp, f32p, C.c_size_t, C.c_double]
+    L.flimo_loc_map_size.restype = C.c_size_t
+    L.flimo_loc_map_size.argtypes = [vp]
+    L.flimo_loc_get_x.restype = None
+    L.flimo_loc_get_x.argtypes = [vp, f64p]
+    L.flimo_loc_set_x.restype = None
+    L.flimo_loc_set_x.argtypes = [vp, f64p]
+    L.flimo_loc_get_P.restype = None
+    L.flimo_loc_get_P.argtypes = [vp, f64p]
+    L.flimo_loc_set_P.restype = None
+    L.flimo_loc_set_P.argtypes = [vp, f64p]
+    L.flimo_loc_set_flags.restype = None
+    L.flimo_loc_set_flags.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    L.flimo_loc_num_passes.argtypes = [vp]
+    L.flimo_loc_get_pass.restype = None
+    L.flimo_loc_get_pass.argtypes = [vp, C.c_int, C.POINTER(C.c_int), f64p, f64p, f64p, f64p]
+    L.flimo_loc_get_pc2match.restype = C.c_size_t
+    L.flimo_loc_get_pc2match.argtypes = [vp, C.c_void_p, C.c_size_t]
+    L.flimo_loc_get_final_scan.restype = C.c_size_t
+    L.flimo_loc_get_final_scan.argtypes = [vp, C.c_void_p, C.c_size_t]
+    L.flimo_loc_get_stage_times.restype = None
+    L.flimo_loc_get_stage_times.argtypes = [vp, f64p]
+    L.flimo_loc_get_pose_cov.restype = None
+    L.flimo_loc_get_pose_cov.argtypes = [vp, f64p]
+    L.flimo_loc_register_resident.argtypes = [vp, f64p, f64p]
+    L.flimo_eskf_update_fixed.argtypes = [f64p, f64p, f64p, f64p, C.c_int, C.c_int, f64p, C.c_double, C.c_double,
+                                          C.POINTER(C.c_int)]
+    L.flimo_eskf_predict.argtypes = [f64p, f64p, C.c_double, f64p, f64p, f64p]
+    _host = L
+    return L
+
+
+class Localizer:
+    """fast_limo::Localizer (one instance per GPU)."""
+
+    def __init__(self, cfg: LocCfg):
+        L = load_host()
+        h = C.c_void_p()
+        rc = L.flimo_loc_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise FlimoError(f"flimo_loc_create failed ({rc}): no gfx950 device or HIP error -- there is no CPU fallback")
+        self._h, self._L, self.cfg = h, L, cfg
+        self.hip = _lib.HipCtx.__new__(_lib.HipCtx)      # non-owning view of the Mapper's context
+        self.hip._h = C.c_void_p(L.flimo_loc_ctx(h))
+        self.hip._L = _lib.load_hip()
+        self.hip.close = lambda: None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.flimo_loc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def update_imu(self, stamp, ang_vel, lin_accel):
+        self._L.flimo_loc_update_imu(self._h, float(stamp), np.ascontiguousarray(ang_vel, dtype=np.float32),
+                                     np.ascontiguousarray(lin_accel, dtype=np.float32))
+
+    def update_pointcloud(self, pts5, stamp) -> int:
+        p = np.ascontiguousarray(pts5, dtype=np.float32).reshape(-1, 5)
+        return int(self._L.flimo_loc_update_pointcloud(self._h, p.reshape(-1), p.shape[0], float(stamp)))
+
+    def map_add(self, xyz, stamp=0.0):
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        rc = self._L.flimo_loc_map_add(self._h, xyz.reshape(-1), xyz.shape[0], float(stamp))
+        if rc != 0:
+            raise FlimoError(f"map_add failed ({rc})")
+
+    def map_size(self) -> int:
+        return int(self._L.flimo_loc_map_size(self._h))
+
+    def get_x(self):
+        x = np.empty(26, np.float64)
+        self._L.flimo_loc_get_x(self._h, x)
+        return x
+
+    def set_x(self, x):
+        self._L.flimo_loc_set_x(self._h, np.ascontiguousarray(x, dtype=np.float64))
+
+    def get_P(self):
+        P = np.empty(529, np.float64)
+        self._L.flimo_loc_get_P(self._h, P)
+        return P.reshape(23, 23)
+
+    def set_P(self, P):
+        self._L.flimo_loc_set_P(self._h, np.ascontiguousarray(P, dtype=np.float64).reshape(-1))
+
+    def set_flags(self, add_to_map=True, download_clouds=True, keep_log=False):
+        self._L.flimo_loc_set_flags(self._h, int(add_to_map), int(download_clouds), int(keep_log))
+
+    def passes(self):
+        out = []
+        for i in range(self._L.flimo_loc_num_passes(self._h)):
+            M = C.c_int(0)
+            HTH = np.empty(144); HTh = np.empty(12); dx = np.empty(23); xa = np.empty(26)
+            self._L.flimo_loc_get_pass(self._h, i, C.byref(M), HTH, HTh, dx, xa)
+            out.append(dict(M=M.value, HTH=HTH.reshape(12, 12), HTh=HTh, dx=dx, x_after=xa))
+        return out
+
+    def pc2match(self):
+        n = int(self._L.flimo_loc_get_pc2match(self._h, None, 0))
+        out = np.empty((max(n, 1), 3), np.float32)
+        self._L.flimo_loc_get_pc2match(self._h, out.ctypes.data, n)
+        return out[:n]
+
+    def final_scan(self):
+        n = int(self._L.flimo_loc_get_final_scan(self._h, None, 0))
+        out = np.empty((max(n, 1), 3), np.float32)
+        self._L.flimo_loc_get_final_scan(self._h, out.ctypes.data, n)
+        return out[:n]
+
+    def stage_times(self):
+        t = np.zeros(4)
+        self._L.flimo_loc_get_stage_times(self._h, t)
+        return dict(host_prep=t[0], deskew=t[1], update=t[2], map_insert=t[3])
+
+    def pose_cov(self):
+        c = np.zeros(36)
+        self._L.flimo_loc_get_pose_cov(self._h, c)
+        return c.reshape(6, 6).T       # returned column-major like the reference
+
+    def register_resident(self, x26_prior, P_prior) -> int:
+        return int(self._L.flimo_loc_register_resident(self._h, np.ascontiguousarray(x26_prior, dtype=np.float64),
+                                                       np.ascontiguousarray(P_prior, dtype=np.float64).reshape(-1)))
+
+
+def eskf_update_fixed(x26, P, H, h, max_iters=3, limits=None, R=0.001, D=5.0):
+    L = load_host()
+    x = np.ascontiguousarray(x26, dtype=np.float64).copy()
+    Pm = np.ascontiguousarray(P, dtype=np.float64).reshape(-1).copy()
+    H = np.ascontiguousarray(H, dtype=np.float64).reshape(-1, 12)
+    h = np.ascontiguousarray(h, dtype=np.float64).reshape(-1)
+    lim = np.full(23, 1e-3) if limits is None else np.ascontiguousarray(limits, dtype=np.float64)
+    n = C.c_int(0)
+    L.flimo_eskf_update_fixed(x, Pm, H.reshape(-1) if H.size else np.zeros(1), h if h.size else np.zeros(1), H.shape[0],
+                              max_iters, lim, R, D, C.byref(n))
+    return x, Pm.reshape(23, 23), n.value
+
+
+def eskf_predict(x26, P, dt, Qdiag, acc, gyro):
+    L = load_host()
+    x = np.ascontiguousarray(x26, dtype=np.float64).copy()
+    Pm = np.ascontiguousarray(P, dtype=np.float64).reshape(-1).copy()
+    L.flimo_eskf_predict(x, Pm, float(dt), np.ascontiguousarray(Qdiag, dtype=np.float64),
+                         np.ascontiguousarray(acc, dtype=np.float64), np.ascontiguousarray(gyro, dtype=np.float64))
+    return x, Pm.reshape(23, 23)

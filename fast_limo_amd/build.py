@@ -1,0 +1,38 @@
+"""Build driver: compiles the in-tree native libraries with hipcc / g++ through csrc/Makefile.
+
+``build_all()`` is what ``__graft_entry__.build()`` calls.  hipcc cross-compiles gfx950 code objects
+without a GPU, so this works in the CPU-only container; the resulting ``.so`` files stay in-tree
+(``fast_limo_amd/lib*.so``) and travel to the GPU box with the repository snapshot.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_PKG)
+
+
+def build_native(jobs: int = 4, force: bool = False) -> None:
+    cmd = ["make", "-C", os.path.join(_PKG, "csrc"), f"-j{jobs}"]
+    if force:
+        cmd.append("-B")
+    subprocess.check_call(cmd)
+    for so in ("libflimo_hip.so", "libfast_limo.so"):
+        if not os.path.exists(os.path.join(_PKG, so)):
+            raise RuntimeError(f"{so} was not produced")
+
+
+def build_tools() -> None:
+    """GPU-side checker binaries (device float math vs host IEEE)."""
+    src = os.path.join(ROOT, "tools", "devmath_check.hip")
+    out = os.path.join(ROOT, "tools", "devmath_check")
+    if (not os.path.exists(out)) or os.path.getmtime(out) < max(
+            os.path.getmtime(src), os.path.getmtime(os.path.join(_PKG, "csrc", "hip", "flimo_math.h"))):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+                               "-I", os.path.join(_PKG, "csrc", "hip"), src, "-o", out])
+
+
+def build_all(jobs: int = 4) -> None:
+    build_native(jobs)
+    build_tools()

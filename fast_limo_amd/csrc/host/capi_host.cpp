@@ -1,0 +1,191 @@
+// fast_limo_amd/csrc/host/capi_host.cpp -- C wrapper (include/flimo_localizer_c.h) over the host
+// C++ Localizer / Mapper.
+#include <cstring>
+#include <memory>
+#include "../../../include/flimo_localizer_c.h"
+#include "fast_limo/Modules/Localizer.hpp"
+#include "flimo_ikfom.hpp"
+
+using namespace fast_limo;
+
+struct flimo_loc {
+  std::unique_ptr<Mapper> map;
+  std::unique_ptr<Localizer> loc;
+};
+
+static Config to_config(const flimo_loc_cfg* c) {
+  Config cfg = Config::defaults();
+  cfg.ikfom.mapping.NUM_MATCH_POINTS = c->NUM_MATCH_POINTS;
+  cfg.ikfom.mapping.MAX_NUM_MATCHES = c->MAX_NUM_MATCHES;
+  cfg.ikfom.mapping.MAX_NUM_PC2MATCH = c->MAX_NUM_PC2MATCH;
+  cfg.ikfom.mapping.MAX_DIST_PLANE = c->MAX_DIST_PLANE;
+  cfg.ikfom.mapping.PLANE_THRESHOLD = c->PLANE_THRESHOLD;
+  cfg.ikfom.mapping.octree.bucket_size = c->bucket_size;
+  cfg.ikfom.mapping.octree.min_extent = c->min_extent;
+  cfg.ikfom.mapping.octree.downsampling = c->downsampling != 0;
+  cfg.ikfom.MAX_NUM_ITERS = c->MAX_NUM_ITERS;
+  cfg.ikfom.estimate_extrinsics = c->estimate_extrinsics != 0;
+  cfg.ikfom.LIMITS.assign(c->LIMITS, c->LIMITS + 23);
+  cfg.ikfom.cov_gyro = c->cov_gyro; cfg.ikfom.cov_acc = c->cov_acc;
+  cfg.ikfom.cov_bias_gyro = c->cov_bias_gyro; cfg.ikfom.cov_bias_acc = c->cov_bias_acc;
+  cfg.time_offset = c->time_offset != 0;
+  cfg.end_of_sweep = c->end_of_sweep != 0;
+  cfg.num_threads = c->num_threads;
+  cfg.extrinsics.imu2baselink_t.assign(c->imu2baselink_t, c->imu2baselink_t + 3);
+  cfg.extrinsics.imu2baselink_R.assign(c->imu2baselink_R, c->imu2baselink_R + 9);
+  cfg.extrinsics.lidar2baselink_t.assign(c->lidar2baselink_t, c->lidar2baselink_t + 3);
+  cfg.extrinsics.lidar2baselink_R.assign(c->lidar2baselink_R, c->lidar2baselink_R + 9);
+  cfg.intrinsics.accel_bias.assign(c->accel_bias, c->accel_bias + 3);
+  cfg.intrinsics.gyro_bias.assign(c->gyro_bias, c->gyro_bias + 3);
+  cfg.intrinsics.imu_sm.assign(c->imu_sm, c->imu_sm + 9);
+  cfg.filters.crop_active = c->crop_active != 0;
+  cfg.filters.cropBoxMin.assign(c->cropBoxMin, c->cropBoxMin + 3);
+  cfg.filters.cropBoxMax.assign(c->cropBoxMax, c->cropBoxMax + 3);
+  cfg.filters.voxel_active = false;
+  cfg.filters.dist_active = c->dist_active != 0;
+  cfg.filters.min_dist = c->min_dist;
+  cfg.filters.rate_active = c->rate_active != 0;
+  cfg.filters.rate_value = c->rate_value;
+  cfg.filters.fov_active = c->fov_active != 0;
+  cfg.filters.fov_angle = c->fov_angle;
+  cfg.sensor_type = c->sensor_type;
+  cfg.gravity_align = cfg.calibrate_accel = cfg.calibrate_gyro = false;
+  cfg.debug = false;
+  cfg.verbose = false;
+  cfg.gpu_device = c->gpu_device;
+  cfg.gpu_cell_size = c->gpu_cell_size;
+  return cfg;
+}
+
+extern "C" {
+
+int flimo_loc_create(const flimo_loc_cfg* cfg, flimo_loc** out) {
+  if (!cfg || !out) return FLIMO_ERR_INVALID;
+  *out = nullptr;
+  std::unique_ptr<flimo_loc> L(new flimo_loc());
+  L->map.reset(new Mapper(cfg->gpu_device));
+  L->loc.reset(new Localizer(L->map.get()));
+  Config c = to_config(cfg);
+  L->loc->init(c);
+  if (!L->map->ctx()) return FLIMO_ERR_NO_DEVICE;      // loud failure: no CPU fallback
+  *out = L.release();
+  return FLIMO_OK;
+}
+void flimo_loc_destroy(flimo_loc* L) { delete L; }
+flimo_ctx* flimo_loc_ctx(flimo_loc* L) { return L ? L->map->ctx() : nullptr; }
+
+int flimo_loc_update_imu(flimo_loc* L, double stamp, const float w[3], const float a[3]) {
+  if (!L) return FLIMO_ERR_INVALID;
+  IMUmeas m;
+  m.stamp = stamp;
+  m.dt = 0.0;
+  m.ang_vel = Eigen::Vector3f(w[0], w[1], w[2]);
+  m.lin_accel = Eigen::Vector3f(a[0], a[1], a[2]);
+  L->loc->updateIMU(m);
+  return FLIMO_OK;
+}
+int flimo_loc_update_pointcloud(flimo_loc* L, const float* pts5, size_t n, double stamp) {
+  if (!L) return FLIMO_ERR_INVALID;
+  auto pc = std::make_shared<pcl::PointCloud<PointType>>();
+  pc->points.resize(n);
+  for (size_t i = 0; i < n; i++) {
+    PointType& p = pc->points[i];
+    p.x = pts5[5 * i]; p.y = pts5[5 * i + 1]; p.z = pts5[5 * i + 2]; p.intensity = pts5[5 * i + 3];
+    p.timestamp = 0.0;
+    p.time = pts5[5 * i + 4];
+  }
+  L->loc->updatePointCloud(pc, stamp);
+  return L->loc->last_status();
+}
+int flimo_loc_map_add(flimo_loc* L, const float* xyz, size_t n, double stamp) {
+  if (!L) return FLIMO_ERR_INVALID;
+  if (!L->map->ctx()) return FLIMO_ERR_NO_DEVICE;
+  return flimo_map_add(L->map->ctx(), xyz, n, 12, stamp);
+}
+size_t flimo_loc_map_size(flimo_loc* L) { return L ? (size_t)L->map->size() : 0; }
+void flimo_loc_get_x(flimo_loc* L, double x26[26]) { L->loc->filter().get_x().to_flat(x26); }
+void flimo_loc_set_x(flimo_loc* L, const double x26[26]) { flimo_host::StateIkfom s; s.from_flat(x26); L->loc->filter().change_x(s); }
+void flimo_loc_get_P(flimo_loc* L, double P[529]) { std::memcpy(P, &L->loc->filter().get_P().a[0][0], sizeof(double) * 529); }
+void flimo_loc_set_P(flimo_loc* L, const double P[529]) {
+  flimo_host::Esekf::Cov C;
+  std::memcpy(&C.a[0][0], P, sizeof(double) * 529);
+  L->loc->filter().change_P(C);
+}
+void flimo_loc_set_flags(flimo_loc* L, int add_to_map, int download_clouds, int keep_log) {
+  L->loc->add_to_map = add_to_map != 0;
+  L->loc->download_clouds = download_clouds != 0;
+  L->loc->filter().keep_log = keep_log != 0;
+}
+int flimo_loc_num_passes(flimo_loc* L) { return (int)L->loc->filter().log.size(); }
+void flimo_loc_get_pass(flimo_loc* L, int i, int* M, double* HTH, double* HTh, double* dx, double* x_after) {
+  const flimo_host::PassLog& g = L->loc->filter().log[i];
+  *M = g.M;
+  std::memcpy(HTH, g.HTH, sizeof(g.HTH));
+  std::memcpy(HTh, g.HTh, sizeof(g.HTh));
+  std::memcpy(dx, g.dx, sizeof(g.dx));
+  std::memcpy(x_after, g.x_after, sizeof(g.x_after));
+}
+static size_t copy_cloud(const pcl::PointCloud<PointType>& pc, float* out, size_t cap) {
+  const size_t n = pc.points.size() < cap ? pc.points.size() : cap;
+  for (size_t i = 0; i < n; i++) { out[3 * i] = pc.points[i].x; out[3 * i + 1] = pc.points[i].y; out[3 * i + 2] = pc.points[i].z; }
+  return pc.points.size();
+}
+size_t flimo_loc_get_pc2match(flimo_loc* L, float* out, size_t cap) { return copy_cloud(*L->loc->get_pc2match_pointcloud(), out, cap); }
+size_t flimo_loc_get_final_scan(flimo_loc* L, float* out, size_t cap) { return copy_cloud(*L->loc->get_pointcloud(), out, cap); }
+void flimo_loc_get_stage_times(flimo_loc* L, double t[4]) { L->loc->get_stage_times(t); }
+void flimo_loc_get_pose_cov(flimo_loc* L, double cov36[36]) {
+  std::vector<double> c = L->loc->getPoseCovariance();
+  std::memcpy(cov36, c.data(), sizeof(double) * 36);
+}
+int flimo_loc_register_resident(flimo_loc* L, const double x26_prior[26], const double P_prior[529]) {
+  if (!L) return FLIMO_ERR_INVALID;
+  return L->loc->registerResident(x26_prior, P_prior);
+}
+
+int flimo_eskf_update_fixed(double x26[26], double P[529], const double* H, const double* h, int M, int max_iters,
+                            const double limits[23], double R, double D, int* n_passes) {
+  flimo_host::Esekf f;
+  flimo_host::StateIkfom s;
+  s.from_flat(x26);
+  f.change_x(s);
+  flimo_host::Esekf::Cov C;
+  std::memcpy(&C.a[0][0], P, sizeof(double) * 529);
+  f.change_P(C);
+  f.init(max_iters, limits);
+  f.keep_log = true;
+  f.h_reduced = [&](const flimo_host::StateIkfom&, flimo_host::ReducedMeas& out) {
+    out.M = M;
+    for (int i = 0; i < 144; i++) out.HTH[i] = 0.0;
+    for (int i = 0; i < 12; i++) out.HTh[i] = 0.0;
+    for (int m = 0; m < M; m++)
+      for (int i = 0; i < 12; i++) {
+        for (int j = 0; j < 12; j++) out.HTH[i * 12 + j] += H[(size_t)m * 12 + i] * H[(size_t)m * 12 + j];
+        out.HTh[i] += H[(size_t)m * 12 + i] * h[m];
+      }
+  };
+  f.h_dense = [&](flimo_host::DenseMeas& dm) { dm.H.assign(H, H + (size_t)M * 12); dm.h.assign(h, h + M); };
+  f.update_iterated_dyn_share_modified(R, D);
+  f.get_x().to_flat(x26);
+  std::memcpy(P, &f.get_P().a[0][0], sizeof(double) * 529);
+  if (n_passes) *n_passes = (int)f.log.size();
+  return FLIMO_OK;
+}
+int flimo_eskf_predict(double x26[26], double P[529], double dt, const double Qd[12], const double acc[3], const double gyro[3]) {
+  flimo_host::Esekf f;
+  flimo_host::StateIkfom s;
+  s.from_flat(x26);
+  f.change_x(s);
+  flimo_host::Esekf::Cov C;
+  std::memcpy(&C.a[0][0], P, sizeof(double) * 529);
+  f.change_P(C);
+  flimo_host::Mat<12, 12> Q = flimo_host::Mat<12, 12>::zero();
+  for (int i = 0; i < 12; i++) Q(i, i) = Qd[i];
+  flimo_host::InputIkfom in;
+  for (int i = 0; i < 3; i++) { in.acc(i, 0) = acc[i]; in.gyro(i, 0) = gyro[i]; }
+  f.predict(dt, Q, in);
+  f.get_x().to_flat(x26);
+  std::memcpy(P, &f.get_P().a[0][0], sizeof(double) * 529);
+  return FLIMO_OK;
+}
+
+}  // extern "C"

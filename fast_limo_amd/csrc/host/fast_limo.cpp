@@ -1,0 +1,698 @@
+// fast_limo_amd/csrc/host/fast_limo.cpp
+// Host side of the MI355X-native fast_limo library: State, Mapper and Localizer with the
+// reference's public API, driving the HIP hot path through the C ABI of include/flimo_c.h.
+// Reference files mirrored: include/fast_limo/Objects/State.cpp, Modules/Mapper.cpp,
+// Modules/Localizer.cpp (file:line cited per function).  Compile with -ffp-contract=off: the
+// float32 pose algebra must round like the reference (no FMA).
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <iostream>
+
+#include "../../../include/flimo_c.h"
+#include "fast_limo/Modules/Localizer.hpp"
+#include "fast_limo/Modules/Mapper.hpp"
+#include "flimo_ikfom.hpp"
+
+using namespace fast_limo;
+using flimo_host::Esekf;
+using flimo_host::StateIkfom;
+
+// ---------------------------------------------------------------------------------------------
+// float32 helpers (Eigen evaluation order: 3-term reductions are c0 + (c1 + c2))
+// ---------------------------------------------------------------------------------------------
+namespace {
+inline float s3(float a, float b, float c) { return a + (b + c); }
+
+void quat_to_R(const Eigen::Quaternionf& q, float R[9]) {   // Eigen::Quaternionf::toRotationMatrix
+  const float tx = 2.f * q.x(), ty = 2.f * q.y(), tz = 2.f * q.z();
+  const float twx = tx * q.w(), twy = ty * q.w(), twz = tz * q.w();
+  const float txx = tx * q.x(), txy = ty * q.x(), txz = tz * q.x();
+  const float tyy = ty * q.y(), tyz = tz * q.y(), tzz = tz * q.z();
+  R[0] = 1.f - (tyy + tzz); R[1] = txy - twz;         R[2] = txz + twy;
+  R[3] = txy + twz;         R[4] = 1.f - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy;         R[7] = tyz + twx;         R[8] = 1.f - (txx + tyy);
+}
+Eigen::Matrix4f se3(const Eigen::Quaternionf& q, const Eigen::Vector3f& p) {
+  float R[9];
+  quat_to_R(q, R);
+  Eigen::Matrix4f T = Eigen::Matrix4f::Identity();
+  for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) T(i, j) = R[i * 3 + j]; T(i, 3) = p(i); }
+  return T;
+}
+Eigen::Matrix4f se3_inv(const Eigen::Quaternionf& q, const Eigen::Vector3f& p) {
+  float R[9];
+  quat_to_R(q, R);
+  Eigen::Matrix4f T = Eigen::Matrix4f::Identity();
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) T(i, j) = R[j * 3 + i];
+    T(i, 3) = s3((-R[0 * 3 + i]) * p(0), (-R[1 * 3 + i]) * p(1), (-R[2 * 3 + i]) * p(2));
+  }
+  return T;
+}
+Eigen::Vector3f mat3_mul(const Eigen::Matrix3f& A, const Eigen::Vector3f& v) {
+  return Eigen::Vector3f(s3(A(0, 0) * v(0), A(0, 1) * v(1), A(0, 2) * v(2)), s3(A(1, 0) * v(0), A(1, 1) * v(1), A(1, 2) * v(2)),
+                         s3(A(2, 0) * v(0), A(2, 1) * v(1), A(2, 2) * v(2)));
+}
+Eigen::Vector3f cross(const Eigen::Vector3f& a, const Eigen::Vector3f& b) {
+  return Eigen::Vector3f(a(1) * b(2) - a(2) * b(1), a(2) * b(0) - a(0) * b(2), a(0) * b(1) - a(1) * b(0));
+}
+Eigen::Quaternionf quat_from_R(const Eigen::Matrix3f& m) {   // Eigen Quaternion(Matrix3f)
+  float t = m(0, 0) + (m(1, 1) + m(2, 2));
+  float x, y, z, w;
+  if (t > 0.f) {
+    t = std::sqrt(t + 1.0f);
+    w = 0.5f * t;
+    t = 0.5f / t;
+    x = (m(2, 1) - m(1, 2)) * t;
+    y = (m(0, 2) - m(2, 0)) * t;
+    z = (m(1, 0) - m(0, 1)) * t;
+  } else {
+    int i = 0;
+    if (m(1, 1) > m(0, 0)) i = 1;
+    if (m(2, 2) > m(i, i)) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = std::sqrt(m(i, i) - m(j, j) - m(k, k) + 1.0f);
+    float c[3];
+    c[i] = 0.5f * t;
+    t = 0.5f / t;
+    w = (m(k, j) - m(j, k)) * t;
+    c[j] = (m(j, i) + m(i, j)) * t;
+    c[k] = (m(k, i) + m(i, k)) * t;
+    x = c[0]; y = c[1]; z = c[2];
+  }
+  return Eigen::Quaternionf(w, x, y, z);
+}
+Eigen::Quaternionf quat_mul(const Eigen::Quaternionf& a, const Eigen::Quaternionf& b) {
+  return Eigen::Quaternionf(a.w() * b.w() - a.x() * b.x() - a.y() * b.y() - a.z() * b.z(),
+                            a.w() * b.x() + a.x() * b.w() + a.y() * b.z() - a.z() * b.y(),
+                            a.w() * b.y() + a.y() * b.w() + a.z() * b.x() - a.x() * b.z(),
+                            a.w() * b.z() + a.z() * b.w() + a.x() * b.y() - a.y() * b.x());
+}
+double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// Config defaults (reference src/main.cpp:101-168)
+// ---------------------------------------------------------------------------------------------
+Config Config::defaults() {
+  Config c;
+  c.topics.lidar = "/velodyne_points";
+  c.topics.imu = "/EL/Sensors/vectornav/IMU";
+  c.num_threads = 10;
+  c.sensor_type = 1;
+  c.debug = true;
+  c.verbose = true;
+  c.ikfom.estimate_extrinsics = true;
+  c.time_offset = true;
+  c.end_of_sweep = false;
+  c.gravity_align = true;
+  c.calibrate_accel = true;
+  c.calibrate_gyro = true;
+  c.imu_calib_time = 3.0;
+  c.extrinsics.imu2baselink_t = {0.f, 0.f, 0.f};
+  c.extrinsics.imu2baselink_R = std::vector<float>(9, 0.f);
+  c.extrinsics.lidar2baselink_t = {0.f, 0.f, 0.f};
+  c.extrinsics.lidar2baselink_R = std::vector<float>(9, 0.f);
+  c.intrinsics.accel_bias = {0.f, 0.f, 0.f};
+  c.intrinsics.gyro_bias = {0.f, 0.f, 0.f};
+  c.intrinsics.imu_sm = std::vector<float>(9, 0.f);
+  c.filters.crop_active = true;
+  c.filters.cropBoxMin = {-1.f, -1.f, -1.f};
+  c.filters.cropBoxMax = {1.f, 1.f, 1.f};
+  c.filters.voxel_active = true;
+  c.filters.leafSize = {0.25f, 0.25f, 0.25f};
+  c.filters.dist_active = false;
+  c.filters.min_dist = 4.0;
+  c.filters.rate_active = false;
+  c.filters.rate_value = 4;
+  c.filters.fov_active = false;
+  c.filters.fov_angle = (float)(360.0f * M_PI / 360.0);
+  c.ikfom.mapping.NUM_MATCH_POINTS = 5;
+  c.ikfom.mapping.MAX_NUM_MATCHES = 2000;
+  c.ikfom.mapping.MAX_NUM_PC2MATCH = 10000;
+  c.ikfom.mapping.MAX_DIST_PLANE = 2.0;
+  c.ikfom.mapping.PLANE_THRESHOLD = 5.e-2;
+  c.ikfom.mapping.octree.bucket_size = 2;
+  c.ikfom.mapping.octree.min_extent = 0.2f;
+  c.ikfom.mapping.octree.downsampling = true;
+  c.ikfom.MAX_NUM_ITERS = 3;
+  c.ikfom.cov_gyro = 6.e-4;
+  c.ikfom.cov_acc = 1.e-2;
+  c.ikfom.cov_bias_gyro = 1.e-5;
+  c.ikfom.cov_bias_acc = 3.e-4;
+  c.ikfom.LIMITS = std::vector<double>(23, 1.e-3);
+  return c;
+}
+
+// ---------------------------------------------------------------------------------------------
+// State
+// ---------------------------------------------------------------------------------------------
+State::State() : time(0.0) {}
+State::State(const StateIkfom& s) : time(0.0) {                    // State.cpp:38-55
+  q = Eigen::Quaternionf((float)s.rot.w, (float)s.rot.x, (float)s.rot.y, (float)s.rot.z);
+  p = Eigen::Vector3f((float)s.pos(0, 0), (float)s.pos(1, 0), (float)s.pos(2, 0));
+  v = Eigen::Vector3f((float)s.vel(0, 0), (float)s.vel(1, 0), (float)s.vel(2, 0));
+  g = Eigen::Vector3f((float)s.grav.vec(0, 0), (float)s.grav.vec(1, 0), (float)s.grav.vec(2, 0));
+  b.gyro = Eigen::Vector3f((float)s.bg(0, 0), (float)s.bg(1, 0), (float)s.bg(2, 0));
+  b.accel = Eigen::Vector3f((float)s.ba(0, 0), (float)s.ba(1, 0), (float)s.ba(2, 0));
+  qLI = Eigen::Quaternionf((float)s.offset_R_L_I.w, (float)s.offset_R_L_I.x, (float)s.offset_R_L_I.y, (float)s.offset_R_L_I.z);
+  pLI = Eigen::Vector3f((float)s.offset_T_L_I(0, 0), (float)s.offset_T_L_I(1, 0), (float)s.offset_T_L_I(2, 0));
+}
+State::State(const StateIkfom& s, double t) : State(s) { time = t; }
+State::State(const StateIkfom& s, double t, Eigen::Vector3f a_, Eigen::Vector3f w_) : State(s, t) { a = a_; w = w_; }
+Eigen::Matrix4f State::get_RT() const { return se3(q, p); }
+Eigen::Matrix4f State::get_RT_inv() const { return se3_inv(q, p); }
+Eigen::Matrix4f State::get_extr_RT() const { return se3(qLI, pLI); }
+Eigen::Matrix4f State::get_extr_RT_inv() const { return se3_inv(qLI, pLI); }
+
+// ---------------------------------------------------------------------------------------------
+// Mapper
+// ---------------------------------------------------------------------------------------------
+Mapper::Mapper() : num_threads_(1), ctx_(nullptr), device_(0), cell_size_(0.f) {
+  config.NUM_MATCH_POINTS = 5;                                    // Mapper.cpp:23-31
+  config.MAX_NUM_MATCHES = 2000;
+  config.MAX_NUM_PC2MATCH = 10000;
+  config.MAX_DIST_PLANE = 2.0;
+  config.PLANE_THRESHOLD = 5.e-2;
+  config.octree.bucket_size = 2;
+  config.octree.min_extent = 0.2f;
+  config.octree.downsampling = true;
+}
+Mapper::Mapper(int device) : Mapper() { device_ = device; }
+Mapper::~Mapper() { if (ctx_) flimo_ctx_destroy(ctx_); }
+
+bool Mapper::attach(int device, float cell_size) {
+  if (ctx_) return true;
+  device_ = device;
+  cell_size_ = cell_size;
+  const int rc = flimo_ctx_create(device, &ctx_);
+  if (rc != FLIMO_OK) {
+    ctx_ = nullptr;
+    err_ = "flimo_ctx_create failed (" + std::to_string(rc) + "): no gfx950 device or HIP error";
+    std::cout << "FAST_LIMO::FATAL ERROR: " << err_ << "\n";
+    return false;
+  }
+  flimo_map_cfg mc{config.octree.min_extent, config.octree.bucket_size, config.octree.downsampling ? 1 : 0, cell_size_};
+  flimo_map_config(ctx_, &mc);
+  return true;
+}
+void Mapper::set_num_threads(int n) { if (n >= 1) num_threads_ = n; }
+void Mapper::set_config(const Config::iKFoM::Mapping& cfg) {       // Mapper.cpp:38-45
+  config = cfg;
+  if (ctx_) {
+    flimo_map_cfg mc{config.octree.min_extent, config.octree.bucket_size, config.octree.downsampling ? 1 : 0, cell_size_};
+    flimo_map_config(ctx_, &mc);
+  }
+}
+bool Mapper::exists() { return ctx_ && flimo_map_size(ctx_) > 0; }
+int Mapper::size() { return ctx_ ? (int)flimo_map_size(ctx_) : 0; }
+double Mapper::last_time() { return ctx_ ? flimo_map_last_time(ctx_) : -1.0; }
+
+void Mapper::add(pcl::PointCloud<PointType>::Ptr& pc, double time) {   // Mapper.cpp:88-96
+  if (!pc || pc->points.size() < 1) return;
+  if (!ctx_ && !attach(device_, cell_size_)) return;
+  const int rc = flimo_map_add(ctx_, &pc->points[0].x, pc->points.size(), sizeof(PointType), time);
+  if (rc != FLIMO_OK) std::cout << "FAST_LIMO::Mapper::add failed: " << flimo_last_error(ctx_) << "\n";
+}
+
+Matches Mapper::match(State s, pcl::PointCloud<PointType>::Ptr& pc) {   // Mapper.cpp:59-86
+  Matches chosen;
+  if (!exists() || !pc) return matches;
+  // make `pc` the resident scan, run one pass at `s`, and read the per-point records back
+  flimo_scan_set(ctx_, &pc->points[0].x, pc->points.size(), sizeof(PointType));
+  double x26[26] = {0};
+  x26[0] = s.p(0); x26[1] = s.p(1); x26[2] = s.p(2);
+  x26[3] = s.q.x(); x26[4] = s.q.y(); x26[5] = s.q.z(); x26[6] = s.q.w();
+  x26[7] = s.qLI.x(); x26[8] = s.qLI.y(); x26[9] = s.qLI.z(); x26[10] = s.qLI.w();
+  x26[11] = s.pLI(0); x26[12] = s.pLI(1); x26[13] = s.pLI(2);
+  flimo_match_cfg mc{config.NUM_MATCH_POINTS, (int)pc->points.size(), config.MAX_NUM_PC2MATCH, config.MAX_DIST_PLANE,
+                     config.PLANE_THRESHOLD, 1};
+  double HTH[144], HTh[12];
+  int M = 0;
+  flimo_set_debug_records(ctx_, 1);
+  const int rc = flimo_match_reduce(ctx_, x26, &mc, HTH, HTh, &M);
+  if (rc == FLIMO_OK) {
+    size_t n = 0;
+    flimo_match_fetch(ctx_, nullptr, 0, &n);
+    std::vector<flimo_match_rec> recs(n);
+    flimo_match_fetch(ctx_, recs.data(), n, &n);
+    for (size_t i = 0; i < n; i++) {
+      if (recs[i].valid == 0.f) continue;
+      Match m;
+      m.good_fit = true;
+      m.dist = -recs[i].h;
+      m.n_ABCD = Eigen::Vector4f(recs[i].n[0], recs[i].n[1], recs[i].n[2], recs[i].n[3]);
+      m.p_global = Eigen::Vector3f(recs[i].p_global[0], recs[i].p_global[1], recs[i].p_global[2]);
+      m.p_local = Eigen::Vector3f(pc->points[i].x, pc->points[i].y, pc->points[i].z);
+      chosen.push_back(m);
+    }
+  }
+  flimo_set_debug_records(ctx_, 0);
+  matches = chosen;
+  return chosen;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Localizer
+// ---------------------------------------------------------------------------------------------
+Localizer::Localizer() : Localizer(&Mapper::getInstance()) { own_map_ = false; }
+Localizer::Localizer(Mapper* map)
+    : map_(map), own_map_(false), ikfom_(new Esekf()), sensor(SensorType::UNKNOWN), scan_stamp(0.0),
+      prev_scan_stamp(0.0), imu_stamp(0.0), prev_imu_stamp(0.0), first_imu_stamp(0.0), last_propagate_time_(-1.0),
+      imu_calib_time_(3.0), gravity_(9.81f), imu_calibrated_(false), num_threads_(1), have_prev_ang_(false),
+      last_status_(0), cpu_time(0.f), cpu_max_time(0.f), cpu_mean_time(0.f), scans_timed_(0) {
+  original_scan = std::make_shared<pcl::PointCloud<PointType>>();
+  deskewed_scan = std::make_shared<pcl::PointCloud<PointType>>();
+  pc2match = std::make_shared<pcl::PointCloud<PointType>>();
+  final_raw_scan = std::make_shared<pcl::PointCloud<PointType>>();
+  final_scan = std::make_shared<pcl::PointCloud<PointType>>();
+  for (int i = 0; i < 4; i++) stage_t_[i] = 0.0;
+  last_imu.stamp = 0; last_imu.dt = 0;
+}
+Localizer::~Localizer() { delete ikfom_; }
+
+void Localizer::init(Config& cfg) {                                // Localizer.cpp:35-117
+  config = cfg;
+  num_threads_ = config.num_threads < 1 ? 1 : config.num_threads;
+  map_->set_num_threads(num_threads_);
+  map_->set_config(config.ikfom.mapping);
+  map_->attach(config.gpu_device, config.gpu_cell_size);
+  init_iKFoM();
+  set_sensor_type((uint8_t)config.sensor_type);
+  // intrinsics (:67-69): Eigen::Map<Matrix3f> over the flat list is COLUMN-major
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) imu_accel_sm_(i, j) = config.intrinsics.imu_sm[j * 3 + i];
+  state.b.accel = Eigen::Vector3f(config.intrinsics.accel_bias[0], config.intrinsics.accel_bias[1], config.intrinsics.accel_bias[2]);
+  state.b.gyro = Eigen::Vector3f(config.intrinsics.gyro_bias[0], config.intrinsics.gyro_bias[1], config.intrinsics.gyro_bias[2]);
+  // extrinsics (:72-86): column-major map then transposed => the YAML list read row-major
+  extr.imu2baselink.t = Eigen::Vector3f(config.extrinsics.imu2baselink_t[0], config.extrinsics.imu2baselink_t[1], config.extrinsics.imu2baselink_t[2]);
+  extr.lidar2baselink.t = Eigen::Vector3f(config.extrinsics.lidar2baselink_t[0], config.extrinsics.lidar2baselink_t[1], config.extrinsics.lidar2baselink_t[2]);
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+    extr.imu2baselink.R(i, j) = config.extrinsics.imu2baselink_R[i * 3 + j];
+    extr.lidar2baselink.R(i, j) = config.extrinsics.lidar2baselink_R[i * 3 + j];
+  }
+  extr.imu2baselink_T = Eigen::Matrix4f::Identity();
+  extr.lidar2baselink_T = Eigen::Matrix4f::Identity();
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) { extr.imu2baselink_T(i, j) = extr.imu2baselink.R(i, j); extr.lidar2baselink_T(i, j) = extr.lidar2baselink.R(i, j); }
+    extr.imu2baselink_T(i, 3) = extr.imu2baselink.t(i);
+    extr.lidar2baselink_T(i, 3) = extr.lidar2baselink.t(i);
+  }
+  if (!(config.gravity_align || config.calibrate_accel || config.calibrate_gyro)) {   // :92-95
+    imu_calibrated_ = true;
+    init_iKFoM_state();
+  } else {
+    // the stand-still IMU calibration (Localizer.cpp:411-509) is not part of this
+    // round; a config that asks for it is reported instead of silently mis-initialised.
+    std::cout << "FAST_LIMO::WARNING: automatic IMU calibration is not implemented in the MI355X build; "
+                 "set calibration/{gravity_align,accel,gyro} to false\n";
+  }
+  imu_calib_time_ = config.imu_calib_time;
+}
+
+void Localizer::init_iKFoM() {                                     // Localizer.cpp:660-670
+  ikfom_->init(config.ikfom.MAX_NUM_ITERS, config.ikfom.LIMITS.data());
+  // IKFoM::h_share_model (use-ikfom.cpp:10-31) with the reduced seam
+  ikfom_->h_reduced = [this](const StateIkfom& x, flimo_host::ReducedMeas& out) {
+    double x26[26];
+    x.to_flat(x26);
+    const Config::iKFoM::Mapping& m = config.ikfom.mapping;
+    flimo_match_cfg mc{m.NUM_MATCH_POINTS, m.MAX_NUM_MATCHES, m.MAX_NUM_PC2MATCH, m.MAX_DIST_PLANE, m.PLANE_THRESHOLD,
+                       config.ikfom.estimate_extrinsics ? 1 : 0};
+    out.M = 0;
+    for (int i = 0; i < 144; i++) out.HTH[i] = 0.0;
+    for (int i = 0; i < 12; i++) out.HTh[i] = 0.0;
+    flimo_ctx* c = map_->ctx();
+    if (!c) return;
+    const int rc = flimo_match_reduce(c, x26, &mc, out.HTH, out.HTh, &out.M);
+    if (rc != FLIMO_OK) { std::cout << "FAST_LIMO::match_reduce failed: " << flimo_last_error(c) << "\n"; out.M = 0; }
+  };
+  ikfom_->h_dense = [this](flimo_host::DenseMeas& dm) {
+    flimo_ctx* c = map_->ctx();
+    size_t M = 0;
+    dm.H.clear(); dm.h.clear();
+    if (!c) return;
+    flimo_match_fetch_H(c, nullptr, nullptr, 0, &M);
+    dm.H.assign(M * 12, 0.0);
+    dm.h.assign(M, 0.0);
+    if (M) flimo_match_fetch_H(c, dm.H.data(), dm.h.data(), M, &M);
+  };
+}
+
+void Localizer::init_iKFoM_state() {                               // Localizer.cpp:672-694
+  StateIkfom s = ikfom_->get_x();
+  s.rot.x = state.q.x(); s.rot.y = state.q.y(); s.rot.z = state.q.z(); s.rot.w = state.q.w();
+  for (int i = 0; i < 3; i++) { s.pos(i, 0) = state.p(i); s.bg(i, 0) = state.b.gyro(i); s.ba(i, 0) = state.b.accel(i); }
+  s.grav = flimo_host::S2(0., 0., -(double)gravity_);
+  flimo_host::Mat3 Rd;
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Rd(i, j) = (double)extr.lidar2baselink.R(i, j);
+  s.offset_R_L_I = flimo_host::rot_to_quat(Rd);
+  for (int i = 0; i < 3; i++) s.offset_T_L_I(i, 0) = extr.lidar2baselink.t(i);
+  ikfom_->change_x(s);
+  Esekf::Cov P = Esekf::Cov::identity();
+  for (int i = 6; i < 12; i++) P(i, i) = 0.000001;
+  for (int i = 15; i < 18; i++) P(i, i) = 0.00001;
+  for (int i = 18; i < 21; i++) P(i, i) = 0.0001;
+  P(21, 21) = P(22, 22) = 0.000001;
+  ikfom_->change_P(P);
+}
+
+pcl::PointCloud<PointType>::Ptr Localizer::get_pointcloud() { return final_scan; }
+pcl::PointCloud<PointType>::Ptr Localizer::get_finalraw_pointcloud() { return final_raw_scan; }
+pcl::PointCloud<PointType>::ConstPtr Localizer::get_orig_pointcloud() { return original_scan; }
+pcl::PointCloud<PointType>::ConstPtr Localizer::get_deskewed_pointcloud() { return deskewed_scan; }
+pcl::PointCloud<PointType>::Ptr Localizer::get_pc2match_pointcloud() { return pc2match; }
+Matches& Localizer::get_matches() { return matches; }
+bool Localizer::is_calibrated() { return imu_calibrated_; }
+void Localizer::set_sensor_type(uint8_t type) { sensor = type < 5 ? static_cast<SensorType>(type) : SensorType::UNKNOWN; }
+SensorType Localizer::get_sensor_type() { return sensor; }
+double Localizer::get_propagate_time() { return last_propagate_time_; }
+
+State Localizer::getWorldState() {                                 // Localizer.cpp:176-190
+  if (!is_calibrated()) return State();
+  State out(ikfom_->get_x());
+  out.w = last_imu.ang_vel;
+  out.a = last_imu.lin_accel;
+  out.time = imu_stamp;
+  float R[9];
+  quat_to_R(out.q, R);
+  out.v = Eigen::Vector3f(s3(R[0] * out.v(0), R[3] * out.v(1), R[6] * out.v(2)), s3(R[1] * out.v(0), R[4] * out.v(1), R[7] * out.v(2)),
+                          s3(R[2] * out.v(0), R[5] * out.v(1), R[8] * out.v(2)));
+  return out;
+}
+State Localizer::getBodyState() {                                  // Localizer.cpp:158-174
+  if (!is_calibrated()) return State();
+  State out(ikfom_->get_x());
+  out.w = last_imu.ang_vel;
+  out.a = last_imu.lin_accel;
+  out.time = imu_stamp;
+  out.p = Eigen::Vector3f(out.p(0) + out.pLI(0), out.p(1) + out.pLI(1), out.p(2) + out.pLI(2));
+  out.q = quat_mul(out.q, out.qLI);
+  float R[9];
+  quat_to_R(out.q, R);
+  out.v = Eigen::Vector3f(s3(R[0] * out.v(0), R[3] * out.v(1), R[6] * out.v(2)), s3(R[1] * out.v(0), R[4] * out.v(1), R[7] * out.v(2)),
+                          s3(R[2] * out.v(0), R[5] * out.v(1), R[8] * out.v(2)));
+  return out;
+}
+std::vector<double> Localizer::getPoseCovariance() {               // Localizer.cpp:209-224 (column-major 6x6)
+  std::vector<double> cov(36, 0.0);
+  if (!is_calibrated()) return cov;
+  const Esekf::Cov& P = ikfom_->get_P();
+  double Pp[6][6];
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+    Pp[i][j] = P(3 + i, 3 + j); Pp[i][3 + j] = P(3 + i, j); Pp[3 + i][j] = P(i, 3 + j); Pp[3 + i][3 + j] = P(i, j);
+  }
+  for (int c = 0; c < 6; c++) for (int r = 0; r < 6; r++) cov[c * 6 + r] = Pp[r][c];
+  return cov;
+}
+std::vector<double> Localizer::getTwistCovariance() {              // Localizer.cpp:226-239
+  std::vector<double> cov(36, 0.0);
+  if (!is_calibrated()) return cov;
+  const Esekf::Cov& P = ikfom_->get_P();
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) cov[j * 6 + i] = P(6 + i, 6 + j);
+  for (int i = 3; i < 6; i++) cov[i * 6 + i] = config.ikfom.cov_gyro;
+  return cov;
+}
+void Localizer::get_cpu_stats(float& comput_time, float& max_comput_time, float& mean_comput_time, float& cpu_cores,
+                              float& cpu_load, float& cpu_max_load, float& ram_usage) {
+  comput_time = cpu_time; max_comput_time = cpu_max_time; mean_comput_time = cpu_mean_time;
+  cpu_cores = 0.f; cpu_load = 0.f; cpu_max_load = 0.f; ram_usage = 0.f;   // debug board is out of scope
+}
+
+IMUmeas Localizer::imu2baselink(IMUmeas& imu) {                    // Localizer.cpp:696-731
+  IMUmeas o;
+  double dt = imu.stamp - prev_imu_stamp;
+  if ((dt == 0.) || (dt > 0.1)) dt = 1.0 / 200.0;
+  const Eigen::Vector3f ang = mat3_mul(extr.imu2baselink.R, imu.ang_vel);
+  if (!have_prev_ang_) { ang_vel_cg_prev_ = ang; have_prev_ang_ = true; }
+  Eigen::Vector3f acc = mat3_mul(extr.imu2baselink.R, imu.lin_accel);
+  const Eigen::Vector3f nt(-extr.imu2baselink.t(0), -extr.imu2baselink.t(1), -extr.imu2baselink.t(2));
+  const float fdt = (float)dt;
+  const Eigen::Vector3f dw((ang(0) - ang_vel_cg_prev_(0)) / fdt, (ang(1) - ang_vel_cg_prev_(1)) / fdt, (ang(2) - ang_vel_cg_prev_(2)) / fdt);
+  const Eigen::Vector3f c1 = cross(dw, nt), c2 = cross(ang, cross(ang, nt));
+  acc = Eigen::Vector3f((acc(0) + c1(0)) + c2(0), (acc(1) + c1(1)) + c2(1), (acc(2) + c1(2)) + c2(2));
+  ang_vel_cg_prev_ = ang;
+  o.ang_vel = ang;
+  o.lin_accel = acc;
+  o.dt = dt;
+  o.stamp = imu.stamp;
+  Eigen::Quaternionf q = quat_from_R(extr.imu2baselink.R);
+  const float qn = std::sqrt(q.x() * q.x() + q.y() * q.y() + q.z() * q.z() + q.w() * q.w());
+  q = Eigen::Quaternionf(q.w() / qn, q.x() / qn, q.y() / qn, q.z() / qn);
+  o.q = quat_mul(q, imu.q);
+  prev_imu_stamp = imu.stamp;
+  return o;
+}
+
+void Localizer::propagateImu(const IMUmeas& imu) {                 // Localizer.cpp:583-608
+  flimo_host::InputIkfom in;
+  for (int i = 0; i < 3; i++) { in.acc(i, 0) = (double)imu.lin_accel(i); in.gyro(i, 0) = (double)imu.ang_vel(i); }
+  flimo_host::Mat<12, 12> Q = flimo_host::Mat<12, 12>::identity();
+  for (int i = 0; i < 3; i++) {
+    Q(i, i) = config.ikfom.cov_gyro; Q(3 + i, 3 + i) = config.ikfom.cov_acc;
+    Q(6 + i, 6 + i) = config.ikfom.cov_bias_gyro; Q(9 + i, 9 + i) = config.ikfom.cov_bias_acc;
+  }
+  mtx_ikfom.lock();
+  ikfom_->predict(imu.dt, Q, in);
+  const StateIkfom xs = ikfom_->get_x();
+  mtx_ikfom.unlock();
+  mtx_prop.lock();
+  propagated_buffer.push_front(State(xs, imu.stamp, imu.lin_accel, imu.ang_vel));
+  if (propagated_buffer.size() > 2000) propagated_buffer.pop_back();
+  mtx_prop.unlock();
+  last_propagate_time_ = imu.stamp;
+}
+
+void Localizer::updateIMU(IMUmeas& raw_imu) {                      // Localizer.cpp:401-531
+  imu_stamp = raw_imu.stamp;
+  IMUmeas imu = imu2baselink(raw_imu);
+  if (first_imu_stamp == 0.0) first_imu_stamp = imu.stamp;
+  if (!imu_calibrated_) return;        // stand-still calibration: SURVEY.md 8 f-3, not in this round
+  const Eigen::Vector3f sm = mat3_mul(imu_accel_sm_, imu.lin_accel);
+  imu.lin_accel = Eigen::Vector3f(sm(0) - state.b.accel(0), sm(1) - state.b.accel(1), sm(2) - state.b.accel(2));
+  imu.ang_vel = Eigen::Vector3f(imu.ang_vel(0) - state.b.gyro(0), imu.ang_vel(1) - state.b.gyro(1), imu.ang_vel(2) - state.b.gyro(2));
+  last_imu = imu;
+  imu_buffer.push_front(imu);
+  if (imu_buffer.size() > 2000) imu_buffer.pop_back();
+  propagateImu(imu);
+  cv_prop_stamp.notify_one();
+}
+
+bool Localizer::isInRange(const PointType& p) {                    // Localizer.cpp:873-876
+  if (!config.filters.fov_active) return true;
+  return std::fabs(std::atan2(p.y, p.x)) < config.filters.fov_angle;
+}
+
+// Localizer::propagatedFromTimeRange + integrateImu (Localizer.cpp:855-915).  The reference waits on
+// cv_prop_stamp without bound; here the wait is bounded (1 s) so a missing IMU stream cannot hang.
+bool Localizer::propagatedFromTimeRange(double start_time, double end_time, States& frames) {
+  frames.clear();
+  std::unique_lock<std::mutex> lock(mtx_prop);
+  if (propagated_buffer.empty() || propagated_buffer.front().time < end_time) {
+    cv_prop_stamp.wait_for(lock, std::chrono::seconds(1),
+                           [this, &end_time] { return !propagated_buffer.empty() && propagated_buffer.front().time >= end_time; });
+    if (propagated_buffer.empty() || propagated_buffer.front().time < end_time) return false;
+  }
+  const size_t n = propagated_buffer.size();
+  size_t it = 0, last = 0;
+  it++;
+  while (it != n && propagated_buffer[it].time >= end_time) { last = it; it++; }
+  while (it != n && propagated_buffer[it].time >= start_time) it++;
+  if (it == n) return false;
+  it++;
+  for (size_t k = it; k-- > last;) frames.push_back(propagated_buffer[k]);   // oldest -> newest
+  return true;
+}
+
+bool Localizer::deskewPointCloud(pcl::PointCloud<PointType>::Ptr& pc, double& start_time) {   // Localizer.cpp:733-853
+  if (pc->points.size() < 1) return false;
+  const double sweep_ref_time = start_time;
+  const bool eos = config.end_of_sweep;
+  std::function<bool(const PointType&, const PointType&)> cmp;
+  std::function<double(const PointType&)> extract;
+  if (sensor == SensorType::OUSTER) {
+    cmp = [eos](const PointType& a, const PointType& b) { return eos ? a.t > b.t : a.t < b.t; };
+    extract = [sweep_ref_time, eos](const PointType& p) { return eos ? sweep_ref_time - p.t * 1e-9f : sweep_ref_time + p.t * 1e-9f; };
+  } else if (sensor == SensorType::VELODYNE) {
+    cmp = [eos](const PointType& a, const PointType& b) { return eos ? a.time > b.time : a.time < b.time; };
+    extract = [sweep_ref_time, eos](const PointType& p) { return eos ? sweep_ref_time - p.time : sweep_ref_time + p.time; };
+  } else if (sensor == SensorType::HESAI) {
+    cmp = [](const PointType& a, const PointType& b) { return a.timestamp < b.timestamp; };
+    extract = [](const PointType& p) { return p.timestamp; };
+  } else if (sensor == SensorType::LIVOX) {
+    cmp = [](const PointType& a, const PointType& b) { return a.timestamp < b.timestamp; };
+    extract = [](const PointType& p) { return p.timestamp * 1e-9f; };
+  } else {
+    std::cout << "FAST_LIMO::FATAL ERROR: LiDAR sensor type unknown or not specified!\n";
+    return false;
+  }
+  // time order with the same library call as the reference (:789-790) so that ties land identically
+  auto sorted = std::make_shared<pcl::PointCloud<PointType>>();
+  sorted->points.resize(pc->points.size());
+  std::partial_sort_copy(pc->points.begin(), pc->points.end(), sorted->points.begin(), sorted->points.end(), cmp);
+  double offset = 0.0;
+  if (config.time_offset) {
+    offset = imu_stamp - extract(sorted->points.back()) - 1.e-4;
+    if (offset > 0.0) offset = 0.0;
+  }
+  scan_stamp = extract(sorted->points.back()) + offset;
+  States frames;
+  if (!propagatedFromTimeRange(prev_scan_stamp, scan_stamp, frames) || frames.empty()) {
+    std::cout << "FAST_LIMO::propagatedFromTimeRange(): not enough propagated states!\n";
+    return false;
+  }
+  mtx_ikfom.lock();
+  const StateIkfom xs = ikfom_->get_x();
+  mtx_ikfom.unlock();
+  last_state = State(xs);
+  // hand over to the GPU: per-point absolute times + the IMU frames
+  const size_t n = sorted->points.size();
+  std::vector<double> t(n);
+  for (size_t k = 0; k < n; k++) t[k] = extract(sorted->points[k]) + offset;
+  std::vector<flimo_frame> fr(frames.size());
+  for (size_t i = 0; i < frames.size(); i++) {
+    const State& F = frames[i];
+    flimo_frame& o = fr[i];
+    for (int a = 0; a < 3; a++) { o.p[a] = F.p(a); o.v[a] = F.v(a); o.g[a] = F.g(a); o.w[a] = F.w(a); o.a[a] = F.a(a); o.bg[a] = F.b.gyro(a); o.ba[a] = F.b.accel(a); }
+    o.q[0] = F.q.x(); o.q[1] = F.q.y(); o.q[2] = F.q.z(); o.q[3] = F.q.w();
+    o.time = F.time;
+  }
+  double x26[26];
+  xs.to_flat(x26);
+  flimo_ctx* c = map_->ctx();
+  if (!c) return false;
+  // raw scan + times become resident; frames are kept for registerResident()
+  int rc = flimo_raw_scan_set(c, &sorted->points[0].x, n, sizeof(PointType), t.data());
+  if (rc != FLIMO_OK) { std::cout << "FAST_LIMO::raw scan upload failed: " << flimo_last_error(c) << "\n"; return false; }
+  rs_frames_.assign(fr.begin(), fr.end());
+  std::memcpy(rs_l2b_, extr.lidar2baselink_T.m, sizeof(rs_l2b_));
+  rc = flimo_deskew_resident(c, rs_frames_.data(), rs_frames_.size(), rs_l2b_, x26);
+  if (rc != FLIMO_OK) { std::cout << "FAST_LIMO::deskew failed: " << flimo_last_error(c) << "\n"; return false; }
+  if (download_clouds) {
+    std::vector<float> xyz(n * 3);
+    size_t m = 0;
+    flimo_scan_get(c, xyz.data(), n, &m);
+    pc2match = sorted;     // keeps intensity / time of the time-sorted points
+    for (size_t k = 0; k < n; k++) { pc2match->points[k].x = xyz[3 * k]; pc2match->points[k].y = xyz[3 * k + 1]; pc2match->points[k].z = xyz[3 * k + 2]; }
+  } else {
+    pc2match = sorted;
+  }
+  return true;
+}
+
+// Benchmark entry (inputs resident in HBM): restores the given prior, then GPU deskew of the
+// resident raw scan + the iterated update.  No host filters, no PCIe upload, no map insert.
+int Localizer::registerResident(const double x26_prior[26], const double* P_prior) {
+  flimo_ctx* c = map_->ctx();
+  if (!c || rs_frames_.empty()) return -1;
+  StateIkfom xs;
+  xs.from_flat(x26_prior);
+  Esekf::Cov P;
+  std::memcpy(&P.a[0][0], P_prior, sizeof(double) * 23 * 23);
+  mtx_ikfom.lock();
+  ikfom_->change_x(xs);
+  ikfom_->change_P(P);
+  int rc = flimo_deskew_resident(c, rs_frames_.data(), rs_frames_.size(), rs_l2b_, x26_prior);
+  if (rc == FLIMO_OK && flimo_scan_size(c) > 1) ikfom_->update_iterated_dyn_share_modified(0.001, 5.0);
+  mtx_ikfom.unlock();
+  return rc;
+}
+
+void Localizer::updatePointCloud(pcl::PointCloud<PointType>::Ptr& raw_pc, double time_stamp) {   // Localizer.cpp:245-399
+  const double t0 = now_s();
+  last_status_ = 0;
+  if (!raw_pc || raw_pc->points.size() < 1) { std::cout << "FAST_LIMO::Raw PointCloud is empty!\n"; last_status_ = -1; return; }
+  if (!imu_calibrated_) { last_status_ = -2; return; }
+  if (imu_buffer.empty()) { std::cout << "FAST_LIMO::IMU buffer is empty!\n"; last_status_ = -3; return; }
+  if (config.filters.voxel_active) {
+    // the PCL VoxelGrid stage is not part of this round
+    std::cout << "FAST_LIMO::ERROR: filters/voxelGrid is not implemented in the MI355X build (set it to false)\n";
+    last_status_ = -4;
+    return;
+  }
+  // removeNaNFromPointCloud (:263-265) -- in place, as the reference mutates *raw_pc
+  {
+    std::vector<PointType>& P = raw_pc->points;
+    size_t k = 0;
+    for (size_t i = 0; i < P.size(); i++)
+      if (std::isfinite(P[i].x) && std::isfinite(P[i].y) && std::isfinite(P[i].z)) P[k++] = P[i];
+    P.resize(k);
+    raw_pc->is_dense = true;
+  }
+  // negative CropBox (:268-271): drop points strictly inside the box
+  if (config.filters.crop_active) {
+    std::vector<PointType>& P = raw_pc->points;
+    const std::vector<float>& mn = config.filters.cropBoxMin;
+    const std::vector<float>& mx = config.filters.cropBoxMax;
+    size_t k = 0;
+    for (size_t i = 0; i < P.size(); i++) {
+      const bool inside = !(P[i].x < mn[0] || P[i].y < mn[1] || P[i].z < mn[2] || P[i].x > mx[0] || P[i].y > mx[1] || P[i].z > mx[2]);
+      if (!inside) P[k++] = P[i];
+    }
+    P.resize(k);
+  }
+  // distance / rate / FoV filters (:274-302)
+  auto input_pc = std::make_shared<pcl::PointCloud<PointType>>();
+  {
+    const float min_dist = (float)config.filters.min_dist;
+    const int rate = config.filters.rate_value;
+    const std::vector<PointType>& P = raw_pc->points;
+    input_pc->points.reserve(P.size());
+    for (size_t i = 0; i < P.size(); i++) {
+      bool keep = isInRange(P[i]);
+      if (config.filters.dist_active) keep = keep && (std::sqrt(s3(P[i].x * P[i].x, P[i].y * P[i].y, P[i].z * P[i].z)) > min_dist);
+      if (config.filters.rate_active) keep = keep && ((long)i % rate == 0);
+      if (keep) input_pc->points.push_back(P[i]);
+    }
+  }
+  if (config.debug) original_scan = std::make_shared<pcl::PointCloud<PointType>>(*input_pc);
+  const double t1 = now_s();
+  const bool ok = deskewPointCloud(input_pc, time_stamp);
+  if (!ok) pc2match = std::make_shared<pcl::PointCloud<PointType>>();
+  const double t2 = now_s();
+  double t3 = t2, t4 = t2;
+  flimo_ctx* c = map_->ctx();
+  if (ok && c && flimo_scan_size(c) > 1) {
+    mtx_ikfom.lock();
+    ikfom_->update_iterated_dyn_share_modified(0.001 /*LiDAR noise*/, 5.0 /*degeneracy threshold*/);   // :333
+    map_->matches.clear();
+    State corrected(ikfom_->get_x());
+    if (config.calibrate_gyro) corrected.b.gyro = state.b.gyro;
+    if (config.calibrate_accel) corrected.b.accel = state.b.accel;
+    if (config.gravity_align) corrected.g = state.g;
+    state = corrected;
+    state.w = last_imu.ang_vel;
+    state.a = last_imu.lin_accel;
+    double x26[26];
+    ikfom_->get_x().to_flat(x26);
+    mtx_ikfom.unlock();
+    t3 = now_s();
+    extr.lidar2baselink_T = state.get_extr_RT();                   // :356
+    // transformPointCloud(pc2match -> final_scan) (:361-371) + Mapper::add (:377)
+    if (download_clouds) {
+      const size_t n = flimo_scan_size(c);
+      std::vector<float> w(n * 3);
+      flimo_scan_to_world(c, x26, w.data(), n);
+      final_scan = std::make_shared<pcl::PointCloud<PointType>>(*pc2match);
+      for (size_t k = 0; k < n && k < final_scan->points.size(); k++) { final_scan->points[k].x = w[3 * k]; final_scan->points[k].y = w[3 * k + 1]; final_scan->points[k].z = w[3 * k + 2]; }
+    }
+    if (add_to_map) {
+      const int rc = flimo_map_add_scan(c, x26, scan_stamp);
+      if (rc != FLIMO_OK) std::cout << "FAST_LIMO::map insert failed: " << flimo_last_error(c) << "\n";
+    }
+    t4 = now_s();
+  } else {
+    std::cout << "-------------- FAST_LIMO::NULL ITERATION --------------\n";
+    last_status_ = 1;
+  }
+  stage_t_[0] = t1 - t0; stage_t_[1] = t2 - t1; stage_t_[2] = t3 - t2; stage_t_[3] = t4 - t3;
+  cpu_time = (float)(t4 - t0);
+  if (cpu_time > cpu_max_time) cpu_max_time = cpu_time;
+  scans_timed_++;
+  cpu_mean_time += (cpu_time - cpu_mean_time) / (float)scans_timed_;
+  prev_scan_stamp = scan_stamp;
+}

@@ -1,0 +1,109 @@
+// fast_limo/Modules/Localizer.hpp -- the reference's Localizer API (Modules/Localizer.hpp:138-209)
+// on top of the MI355X hot path.  updatePointCloud = filters -> time sort -> GPU deskew ->
+// host IESKF with the GPU measurement seam -> GPU transform -> map insert.
+#ifndef __FASTLIMO_LOCALIZER_HPP__
+#define __FASTLIMO_LOCALIZER_HPP__
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include "fast_limo/Common.hpp"
+#include "flimo_c.h"
+#include "fast_limo/Modules/Mapper.hpp"
+#include "fast_limo/Objects/Match.hpp"
+#include "fast_limo/Objects/State.hpp"
+#include "fast_limo/Utils/Config.hpp"
+
+namespace flimo_host { class Esekf; struct StateIkfom; }
+
+class fast_limo::Localizer {
+ public:
+  pcl::PointCloud<PointType>::Ptr pc2match;   // body frame at scan end (Localizer.hpp:36)
+
+  Localizer();
+  ~Localizer();
+  void init(Config& cfg);
+
+  // callbacks
+  void updateIMU(IMUmeas& raw_imu);
+  void updatePointCloud(pcl::PointCloud<PointType>::Ptr& raw_pc, double time_stamp);
+
+  // outputs
+  pcl::PointCloud<PointType>::Ptr get_pointcloud();
+  pcl::PointCloud<PointType>::Ptr get_finalraw_pointcloud();
+  pcl::PointCloud<PointType>::ConstPtr get_orig_pointcloud();
+  pcl::PointCloud<PointType>::ConstPtr get_deskewed_pointcloud();
+  pcl::PointCloud<PointType>::Ptr get_pc2match_pointcloud();
+  Matches& get_matches();
+  State getWorldState();
+  State getBodyState();
+  std::vector<double> getPoseCovariance();
+  std::vector<double> getTwistCovariance();
+  double get_propagate_time();
+  void get_cpu_stats(float& comput_time, float& max_comput_time, float& mean_comput_time, float& cpu_cores,
+                     float& cpu_load, float& cpu_max_load, float& ram_usage);
+  bool is_calibrated();
+  void set_sensor_type(uint8_t type);
+  fast_limo::SensorType get_sensor_type();
+  void propagateImu(const IMUmeas& imu);
+
+  // --- MI355X additions -----------------------------------------------------------------------
+  explicit Localizer(Mapper* map);      // non-singleton instances (one per GPU, SURVEY.md 8 e)
+  Mapper& mapper() { return *map_; }
+  flimo_host::Esekf& filter() { return *ikfom_; }
+  int last_status() const { return last_status_; }    // 0 ok, 1 null iteration, <0 early return
+  double last_scan_stamp() const { return scan_stamp; }
+  // timings of the last updatePointCloud [s]: host prep (filters+sort), deskew, update, map insert
+  void get_stage_times(double t[4]) const { for (int i = 0; i < 4; i++) t[i] = stage_t_[i]; }
+  // benchmark entry: re-register the scan made resident by the last updatePointCloud from a given
+  // prior (x26, P 23x23 row-major); GPU deskew + iterated update only
+  int registerResident(const double x26_prior[26], const double* P_prior);
+  bool add_to_map = true;               // benchmarks may freeze the map
+  bool download_clouds = true;          // keep pc2match / final_scan host copies up to date
+
+  static Localizer& getInstance() {
+    static Localizer* loc = new Localizer();
+    return *loc;
+  }
+
+ private:
+  void init_iKFoM();
+  void init_iKFoM_state();
+  IMUmeas imu2baselink(IMUmeas& imu);
+  bool deskewPointCloud(pcl::PointCloud<PointType>::Ptr& pc, double& start_time);
+  bool propagatedFromTimeRange(double start_time, double end_time, States& frames);
+  bool isInRange(const PointType& p);
+
+  Mapper* map_;
+  bool own_map_;
+  flimo_host::Esekf* ikfom_;
+  std::mutex mtx_ikfom, mtx_prop;
+  std::condition_variable cv_prop_stamp;
+  State state, last_state;
+  Extrinsics extr;
+  SensorType sensor;
+  IMUmeas last_imu;
+  std::deque<IMUmeas> imu_buffer;         // front = newest, capacity 2000
+  std::deque<State> propagated_buffer;
+  Config config;
+  Eigen::Matrix3f imu_accel_sm_;
+  pcl::PointCloud<PointType>::ConstPtr original_scan, deskewed_scan;
+  pcl::PointCloud<PointType>::Ptr final_raw_scan, final_scan;
+  Matches matches;
+  double scan_stamp, prev_scan_stamp, imu_stamp, prev_imu_stamp, first_imu_stamp, last_propagate_time_;
+  double imu_calib_time_;
+  float gravity_;
+  bool imu_calibrated_;
+  int num_threads_;
+  bool have_prev_ang_;
+  Eigen::Vector3f ang_vel_cg_prev_;
+  std::vector<flimo_frame> rs_frames_;  // frames of the resident raw scan
+  float rs_l2b_[16];
+  int last_status_;
+  double stage_t_[4];
+  float cpu_time, cpu_max_time, cpu_mean_time;
+  long scans_timed_;
+
+  Localizer(const Localizer&) = delete;
+  Localizer& operator=(const Localizer&) = delete;
+};
+#endif

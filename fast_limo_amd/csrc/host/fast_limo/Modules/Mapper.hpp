@@ -1,0 +1,53 @@
+// fast_limo/Modules/Mapper.hpp -- GPU-resident map behind the reference's Mapper API
+// (reference Modules/Mapper.hpp:48-71, Modules/Mapper.cpp:38-96).  The octree is replaced by the
+// uniform-grid index of libflimo_hip; `match` keeps its signature for API compatibility, the
+// filter itself uses the reduced seam (match_reduce) instead of materialising Matches.
+#ifndef __FASTLIMO_MAPPER_HPP__
+#define __FASTLIMO_MAPPER_HPP__
+#include "fast_limo/Common.hpp"
+#include "fast_limo/Objects/Match.hpp"
+#include "fast_limo/Objects/State.hpp"
+#include "fast_limo/Utils/Config.hpp"
+
+struct flimo_ctx;
+
+class fast_limo::Mapper {
+ public:
+  Matches matches;
+
+  Mapper();
+  ~Mapper();
+  void set_num_threads(int n);
+  void set_config(const Config::iKFoM::Mapping& cfg);
+  bool exists();
+  int size();
+  double last_time();
+  // Mapper::match (Mapper.cpp:59-86): matches of the RESIDENT scan (pc must be the cloud last
+  // handed to the Localizer / set with set_scan) at state s.
+  Matches match(State s, pcl::PointCloud<PointType>::Ptr& pc);
+  void add(pcl::PointCloud<PointType>::Ptr& pc, double time);
+
+  // --- MI355X additions -----------------------------------------------------------------------
+  // one Mapper per GPU; getInstance() keeps the reference's process-wide singleton on device 0
+  explicit Mapper(int device);
+  bool attach(int device, float cell_size);     // creates the flimo_ctx; false + message on failure
+  flimo_ctx* ctx() { return ctx_; }
+  const Config::iKFoM::Mapping& config_ref() const { return config; }
+  const std::string& last_error() const { return err_; }
+
+  static Mapper& getInstance() {
+    static Mapper* mapper = new Mapper();
+    return *mapper;
+  }
+
+ private:
+  Config::iKFoM::Mapping config;
+  int num_threads_;
+  flimo_ctx* ctx_;
+  int device_;
+  float cell_size_;
+  std::string err_;
+  Mapper(const Mapper&) = delete;
+  Mapper& operator=(const Mapper&) = delete;
+};
+#endif

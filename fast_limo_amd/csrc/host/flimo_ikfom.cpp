@@ -1,0 +1,561 @@
+// fast_limo_amd/csrc/host/flimo_ikfom.cpp -- see flimo_ikfom.hpp.
+#include "flimo_ikfom.hpp"
+#include <algorithm>
+
+namespace flimo_host {
+
+// ---------------------------------------------------------------------------------------------
+bool inverse_lu(int n, const double* A, double* Ainv) {
+  std::vector<double> lu(A, A + (size_t)n * n);
+  std::vector<int> piv(n);
+  for (int i = 0; i < n; i++) piv[i] = i;
+  for (int k = 0; k < n; k++) {
+    int p = k;
+    double best = std::fabs(lu[(size_t)k * n + k]);
+    for (int i = k + 1; i < n; i++) {
+      const double v = std::fabs(lu[(size_t)i * n + k]);
+      if (v > best) { best = v; p = i; }
+    }
+    if (best == 0.0) return false;
+    if (p != k) {
+      for (int j = 0; j < n; j++) std::swap(lu[(size_t)k * n + j], lu[(size_t)p * n + j]);
+      std::swap(piv[k], piv[p]);
+    }
+    const double d = lu[(size_t)k * n + k];
+    for (int i = k + 1; i < n; i++) {
+      const double f = lu[(size_t)i * n + k] / d;
+      lu[(size_t)i * n + k] = f;
+      for (int j = k + 1; j < n; j++) lu[(size_t)i * n + j] -= f * lu[(size_t)k * n + j];
+    }
+  }
+  std::vector<double> y(n);
+  for (int col = 0; col < n; col++) {
+    for (int i = 0; i < n; i++) {
+      double s = (piv[i] == col) ? 1.0 : 0.0;
+      for (int j = 0; j < i; j++) s -= lu[(size_t)i * n + j] * y[j];
+      y[i] = s;
+    }
+    for (int i = n - 1; i >= 0; i--) {
+      double s = y[i];
+      for (int j = i + 1; j < n; j++) s -= lu[(size_t)i * n + j] * y[j];
+      y[i] = s / lu[(size_t)i * n + i];
+    }
+    for (int i = 0; i < n; i++) Ainv[(size_t)i * n + col] = y[i];
+  }
+  return true;
+}
+
+void sym_eig6(const Mat<6, 6>& S, double w[6], Mat<6, 6>& V) {
+  Mat<6, 6> A;
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j < 6; j++) A(i, j) = 0.5 * (S(i, j) + S(j, i));
+  V = Mat<6, 6>::identity();
+  for (int sweep = 0; sweep < 64; sweep++) {
+    double off = 0.0;
+    for (int i = 0; i < 6; i++)
+      for (int j = i + 1; j < 6; j++) off += A(i, j) * A(i, j);
+    if (off < 1e-300) break;
+    for (int p = 0; p < 6; p++)
+      for (int q = p + 1; q < 6; q++) {
+        if (A(p, q) == 0.0) continue;
+        const double theta = (A(q, q) - A(p, p)) / (2.0 * A(p, q));
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < 6; k++) { const double kp = A(k, p), kq = A(k, q); A(k, p) = c * kp - s * kq; A(k, q) = s * kp + c * kq; }
+        for (int k = 0; k < 6; k++) { const double pk = A(p, k), qk = A(q, k); A(p, k) = c * pk - s * qk; A(q, k) = s * pk + c * qk; }
+        for (int k = 0; k < 6; k++) { const double kp = V(k, p), kq = V(k, q); V(k, p) = c * kp - s * kq; V(k, q) = s * kp + c * kq; }
+      }
+  }
+  for (int i = 0; i < 6; i++) w[i] = A(i, i);
+}
+
+// ---------------------------------------------------------------------------------------------
+static const double kTol = 1e-11;   // MTK::tolerance<double>()
+
+Quat quat_mul(const Quat& a, const Quat& b) {
+  Quat r;
+  r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+  r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+  r.y = a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z;
+  r.z = a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x;
+  return r;
+}
+Mat3 quat_to_rot(const Quat& q) {
+  const double tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z;
+  const double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
+  const double txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
+  const double tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+  Mat3 R;
+  R(0, 0) = 1 - (tyy + tzz); R(0, 1) = txy - twz;       R(0, 2) = txz + twy;
+  R(1, 0) = txy + twz;       R(1, 1) = 1 - (txx + tzz); R(1, 2) = tyz - twx;
+  R(2, 0) = txz - twy;       R(2, 1) = tyz + twx;       R(2, 2) = 1 - (txx + tyy);
+  return R;
+}
+Quat rot_to_quat(const Mat3& m) {
+  Quat q;
+  double t = m(0, 0) + (m(1, 1) + m(2, 2));
+  if (t > 0) {
+    t = std::sqrt(t + 1.0);
+    q.w = 0.5 * t;
+    t = 0.5 / t;
+    q.x = (m(2, 1) - m(1, 2)) * t;
+    q.y = (m(0, 2) - m(2, 0)) * t;
+    q.z = (m(1, 0) - m(0, 1)) * t;
+  } else {
+    int i = 0;
+    if (m(1, 1) > m(0, 0)) i = 1;
+    if (m(2, 2) > m(i, i)) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = std::sqrt(m(i, i) - m(j, j) - m(k, k) + 1.0);
+    double c[3];
+    c[i] = 0.5 * t;
+    t = 0.5 / t;
+    q.w = (m(k, j) - m(j, k)) * t;
+    c[j] = (m(j, i) + m(i, j)) * t;
+    c[k] = (m(k, i) + m(i, k)) * t;
+    q.x = c[0]; q.y = c[1]; q.z = c[2];
+  }
+  return q;
+}
+Vec3 quat_rotate(const Quat& q, const Vec3& v) {
+  double uv[3] = {q.y * v(2, 0) - q.z * v(1, 0), q.z * v(0, 0) - q.x * v(2, 0), q.x * v(1, 0) - q.y * v(0, 0)};
+  for (int i = 0; i < 3; i++) uv[i] += uv[i];
+  const double c[3] = {q.y * uv[2] - q.z * uv[1], q.z * uv[0] - q.x * uv[2], q.x * uv[1] - q.y * uv[0]};
+  Vec3 o;
+  for (int i = 0; i < 3; i++) o(i, 0) = v(i, 0) + q.w * uv[i] + c[i];
+  return o;
+}
+Mat3 hat(const Vec3& v) {
+  Mat3 H = Mat3::zero();
+  H(0, 1) = -v(2, 0); H(0, 2) = v(1, 0);
+  H(1, 0) = v(2, 0);  H(1, 2) = -v(0, 0);
+  H(2, 0) = -v(1, 0); H(2, 1) = v(0, 0);
+  return H;
+}
+Mat3 A_matrix(const Vec3& v) {
+  const double sq = v(0, 0) * v(0, 0) + v(1, 0) * v(1, 0) + v(2, 0) * v(2, 0);
+  const double norm = std::sqrt(sq);
+  if (norm < kTol) return Mat3::identity();
+  const Mat3 H = hat(v);
+  return Mat3::identity() + ((1 - std::cos(norm)) / sq) * H + ((1 - std::sin(norm) / norm) / sq) * (H * H);
+}
+
+// MTK::cos_sinc_sqrt (mtkmath.hpp:143-174)
+static void cos_sinc_sqrt(double x2, double& c, double& s) {
+  static const double b0 = 2.220446049250313e-16;
+  static const double b2 = std::sqrt(b0);
+  static const double bn = std::sqrt(b2);
+  if (x2 >= bn) {
+    const double x = std::sqrt(x2);
+    c = std::cos(x);
+    s = std::sin(x) / x;
+    return;
+  }
+  static const double inv[] = {1 / 3., 1 / 4., 1 / 5., 1 / 6., 1 / 7., 1 / 8., 1 / 9.};
+  double cosi = 1., sinc = 1;
+  double term = -1 / 2. * x2;
+  for (int i = 0; i < 3; ++i) {
+    cosi += term;
+    term *= inv[2 * i];
+    sinc += term;
+    term *= -inv[2 * i + 1] * x2;
+  }
+  c = cosi;
+  s = sinc;
+}
+// MTK::exp<scalar,3>: q = (cos(scale|v|), sinc(scale|v|) * scale * v)
+static Quat exp_quat(const Vec3& v, double scale) {
+  const double n2 = v(0, 0) * v(0, 0) + v(1, 0) * v(1, 0) + v(2, 0) * v(2, 0);
+  double c, s;
+  cos_sinc_sqrt(scale * scale * n2, c, s);
+  const double mult = s * scale;
+  Quat q;
+  q.w = c; q.x = mult * v(0, 0); q.y = mult * v(1, 0); q.z = mult * v(2, 0);
+  return q;
+}
+Quat so3_exp(const Vec3& v, double scale) { return exp_quat(v, scale / 2); }
+Vec3 so3_log(const Quat& q) {
+  double nv = std::sqrt(q.x * q.x + q.y * q.y + q.z * q.z);
+  if (nv < kTol) nv = kTol;
+  const double s = 2.0 / nv * std::atan(nv / q.w);
+  Vec3 o;
+  o(0, 0) = s * q.x; o(1, 0) = s * q.y; o(2, 0) = s * q.z;
+  return o;
+}
+
+// ---- S2 -------------------------------------------------------------------------------------
+S2::S2() { vec = Vec3::zero(); vec(0, 0) = kS2Length; }
+S2::S2(double x, double y, double z) {
+  const double n = std::sqrt(x * x + y * y + z * z);
+  vec(0, 0) = x / n * kS2Length; vec(1, 0) = y / n * kS2Length; vec(2, 0) = z / n * kS2Length;
+}
+Mat<3, 2> S2::Bx() const {
+  const double L = kS2Length, v0 = vec(0, 0), v1 = vec(1, 0), v2 = vec(2, 0);
+  Mat<3, 2> B = Mat<3, 2>::zero();
+  if (v0 + L > kTol) {
+    B(0, 0) = -v1;                    B(0, 1) = -v2;
+    B(1, 0) = L - v1 * v1 / (L + v0); B(1, 1) = -v2 * v1 / (L + v0);
+    B(2, 0) = -v2 * v1 / (L + v0);    B(2, 1) = L - v2 * v2 / (L + v0);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 2; j++) B(i, j) /= L;
+  } else {
+    B(1, 1) = -1; B(2, 0) = 1;
+  }
+  return B;
+}
+void S2::boxplus(const double d[2], double scale) {
+  const Mat<3, 2> B = Bx();
+  Vec3 Bu;
+  for (int i = 0; i < 3; i++) Bu(i, 0) = B(i, 0) * d[0] + B(i, 1) * d[1];
+  vec = quat_to_rot(exp_quat(Bu, scale / 2)) * vec;
+}
+void S2::oplus(const Vec3& d, double scale) { vec = quat_to_rot(exp_quat(d, scale / 2)) * vec; }
+void S2::boxminus(double out[2], const S2& other) const {
+  const Vec3 hv = hat(vec) * other.vec;
+  const double v_sin = std::sqrt(hv(0, 0) * hv(0, 0) + hv(1, 0) * hv(1, 0) + hv(2, 0) * hv(2, 0));
+  const double v_cos = vec(0, 0) * other.vec(0, 0) + vec(1, 0) * other.vec(1, 0) + vec(2, 0) * other.vec(2, 0);
+  const double theta = std::atan2(v_sin, v_cos);
+  if (v_sin < kTol) {
+    if (std::fabs(theta) > kTol) { out[0] = 3.1415926; out[1] = 0; }
+    else { out[0] = 0; out[1] = 0; }
+    return;
+  }
+  const Mat<3, 2> B = other.Bx();
+  const Vec3 t = hat(other.vec) * vec;
+  const double f = theta / v_sin;
+  for (int j = 0; j < 2; j++) out[j] = f * (B(0, j) * t(0, 0) + B(1, j) * t(1, 0) + B(2, j) * t(2, 0));
+}
+Mat<2, 3> S2::Nx_yy() const { return (1 / kS2Length / kS2Length) * (Bx().T() * hat(vec)); }
+Mat<3, 2> S2::Mx(const double delta[2]) const {
+  const Mat<3, 2> B = Bx();
+  const double dn = std::sqrt(delta[0] * delta[0] + delta[1] * delta[1]);
+  if (dn < kTol) return -1.0 * (hat(vec) * B);
+  Vec3 Bu;
+  for (int i = 0; i < 3; i++) Bu(i, 0) = B(i, 0) * delta[0] + B(i, 1) * delta[1];
+  // reference: exp(Bu, scalar(1/2)) with integer 1/2 == 0  =>  identity rotation (S2.hpp:277)
+  const Mat3 E = quat_to_rot(exp_quat(Bu, double(1 / 2)));
+  return -1.0 * (E * hat(vec) * A_matrix(Bu).T() * B);
+}
+
+// ---- state ----------------------------------------------------------------------------------
+StateIkfom::StateIkfom() {
+  pos = offset_T_L_I = vel = bg = ba = Vec3::zero();
+}
+void StateIkfom::boxplus(const double d[kDof]) {
+  Vec3 r, o;
+  for (int i = 0; i < 3; i++) { pos(i, 0) += d[i]; r(i, 0) = d[3 + i]; o(i, 0) = d[6 + i]; }
+  rot = quat_mul(rot, so3_exp(r));
+  offset_R_L_I = quat_mul(offset_R_L_I, so3_exp(o));
+  for (int i = 0; i < 3; i++) { offset_T_L_I(i, 0) += d[9 + i]; vel(i, 0) += d[12 + i]; bg(i, 0) += d[15 + i]; ba(i, 0) += d[18 + i]; }
+  grav.boxplus(d + 21);
+}
+void StateIkfom::oplus(const double f[kDim], double dt) {
+  Vec3 r, o, g;
+  for (int i = 0; i < 3; i++) { pos(i, 0) += dt * f[i]; r(i, 0) = f[3 + i]; o(i, 0) = f[6 + i]; g(i, 0) = f[21 + i]; }
+  rot = quat_mul(rot, so3_exp(r, dt));
+  offset_R_L_I = quat_mul(offset_R_L_I, so3_exp(o, dt));
+  for (int i = 0; i < 3; i++) { offset_T_L_I(i, 0) += dt * f[9 + i]; vel(i, 0) += dt * f[12 + i]; bg(i, 0) += dt * f[15 + i]; ba(i, 0) += dt * f[18 + i]; }
+  grav.oplus(g, dt);
+}
+void StateIkfom::boxminus(double out[kDof], const StateIkfom& o) const {
+  const Vec3 r = so3_log(quat_mul(quat_conj(o.rot), rot));
+  const Vec3 l = so3_log(quat_mul(quat_conj(o.offset_R_L_I), offset_R_L_I));
+  for (int i = 0; i < 3; i++) {
+    out[i] = pos(i, 0) - o.pos(i, 0);
+    out[3 + i] = r(i, 0);
+    out[6 + i] = l(i, 0);
+    out[9 + i] = offset_T_L_I(i, 0) - o.offset_T_L_I(i, 0);
+    out[12 + i] = vel(i, 0) - o.vel(i, 0);
+    out[15 + i] = bg(i, 0) - o.bg(i, 0);
+    out[18 + i] = ba(i, 0) - o.ba(i, 0);
+  }
+  grav.boxminus(out + 21, o.grav);
+}
+void StateIkfom::to_flat(double x[26]) const {
+  int k = 0;
+  for (int i = 0; i < 3; i++) x[k++] = pos(i, 0);
+  x[k++] = rot.x; x[k++] = rot.y; x[k++] = rot.z; x[k++] = rot.w;
+  x[k++] = offset_R_L_I.x; x[k++] = offset_R_L_I.y; x[k++] = offset_R_L_I.z; x[k++] = offset_R_L_I.w;
+  for (int i = 0; i < 3; i++) x[k++] = offset_T_L_I(i, 0);
+  for (int i = 0; i < 3; i++) x[k++] = vel(i, 0);
+  for (int i = 0; i < 3; i++) x[k++] = bg(i, 0);
+  for (int i = 0; i < 3; i++) x[k++] = ba(i, 0);
+  for (int i = 0; i < 3; i++) x[k++] = grav.vec(i, 0);
+}
+void StateIkfom::from_flat(const double x[26]) {
+  int k = 0;
+  for (int i = 0; i < 3; i++) pos(i, 0) = x[k++];
+  rot.x = x[k++]; rot.y = x[k++]; rot.z = x[k++]; rot.w = x[k++];
+  offset_R_L_I.x = x[k++]; offset_R_L_I.y = x[k++]; offset_R_L_I.z = x[k++]; offset_R_L_I.w = x[k++];
+  for (int i = 0; i < 3; i++) offset_T_L_I(i, 0) = x[k++];
+  for (int i = 0; i < 3; i++) vel(i, 0) = x[k++];
+  for (int i = 0; i < 3; i++) bg(i, 0) = x[k++];
+  for (int i = 0; i < 3; i++) ba(i, 0) = x[k++];
+  for (int i = 0; i < 3; i++) grav.vec(i, 0) = x[k++];
+}
+
+// ---- process model (use-ikfom.cpp:43-84) ----------------------------------------------------
+static void model_f(const StateIkfom& s, const InputIkfom& in, double f[kDim]) {
+  for (int i = 0; i < kDim; i++) f[i] = 0.0;
+  const Vec3 a_in = quat_rotate(s.rot, in.acc - s.ba);
+  for (int i = 0; i < 3; i++) {
+    f[i] = s.vel(i, 0);
+    f[3 + i] = in.gyro(i, 0) - s.bg(i, 0);
+    f[12 + i] = a_in(i, 0) + s.grav.vec(i, 0);
+  }
+}
+static Mat<kDim, kDof> model_df_dx(const StateIkfom& s, const InputIkfom& in) {
+  Mat<kDim, kDof> F = Mat<kDim, kDof>::zero();
+  for (int i = 0; i < 3; i++) F(i, 12 + i) = 1.0;
+  const Mat3 R = quat_to_rot(s.rot);
+  const Mat3 RH = R * hat(in.acc - s.ba);
+  const double z2[2] = {0, 0};
+  const Mat<3, 2> gm = s.grav.Mx(z2);
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) { F(12 + i, 3 + j) = -RH(i, j); F(12 + i, 18 + j) = -R(i, j); }
+    for (int j = 0; j < 2; j++) F(12 + i, 21 + j) = gm(i, j);
+    F(3 + i, 15 + i) = -1.0;
+  }
+  return F;
+}
+static Mat<kDim, 12> model_df_dw(const StateIkfom& s) {
+  Mat<kDim, 12> G = Mat<kDim, 12>::zero();
+  const Mat3 R = quat_to_rot(s.rot);
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) G(12 + i, 3 + j) = -R(i, j);
+    G(3 + i, i) = -1.0; G(15 + i, 6 + i) = 1.0; G(18 + i, 9 + i) = 1.0;
+  }
+  return G;
+}
+
+// ---- filter ---------------------------------------------------------------------------------
+Esekf::Esekf() {
+  P_ = Cov::identity();
+  for (int i = 0; i < kDof; i++) limit_[i] = 1e-3;
+}
+void Esekf::init(int maximum_iteration, const double* limits) {
+  maximum_iter_ = maximum_iteration;
+  for (int i = 0; i < kDof; i++) limit_[i] = limits[i];
+}
+
+// rows idx..idx+B of M <- J * rows ; applied to the first ncols columns
+template <int B, int N>
+static void left_block(Mat<N, N>& M, int idx, const Mat<B, B>& J, int ncols) {
+  for (int c = 0; c < ncols; c++) {
+    double t[B];
+    for (int r = 0; r < B; r++) { double s = 0; for (int k = 0; k < B; k++) s += J(r, k) * M(idx + k, c); t[r] = s; }
+    for (int r = 0; r < B; r++) M(idx + r, c) = t[r];
+  }
+}
+// cols idx..idx+B of M <- cols * J^T
+template <int B, int N>
+static void right_block_T(Mat<N, N>& M, int idx, const Mat<B, B>& J) {
+  for (int r = 0; r < N; r++) {
+    double t[B];
+    for (int c = 0; c < B; c++) { double s = 0; for (int k = 0; k < B; k++) s += M(r, idx + k) * J(c, k); t[c] = s; }
+    for (int c = 0; c < B; c++) M(r, idx + c) = t[c];
+  }
+}
+
+void Esekf::predict(double dt, const Mat<12, 12>& Q, const InputIkfom& in) {
+  double f[kDim];
+  model_f(x_, in, f);
+  const Mat<kDim, kDof> fx = model_df_dx(x_, in);
+  const Mat<kDim, 12> fw = model_df_dw(x_);
+  const StateIkfom x_before = x_;
+  x_.oplus(f, dt);
+
+  Cov F1 = Cov::identity();
+  Cov fxf = Cov::zero();
+  Mat<kDof, 12> fwf = Mat<kDof, 12>::zero();
+  // vector blocks: rows copied (DOF index == DIM index up to the S2 block)
+  static const int vect_idx[5] = {0, 9, 12, 15, 18};
+  for (int v = 0; v < 5; v++)
+    for (int j = 0; j < 3; j++) {
+      for (int c = 0; c < kDof; c++) fxf(vect_idx[v] + j, c) = fx(vect_idx[v] + j, c);
+      for (int c = 0; c < 12; c++) fwf(vect_idx[v] + j, c) = fw(vect_idx[v] + j, c);
+    }
+  // SO3 blocks
+  static const int so3_idx[2] = {3, 6};
+  for (int s = 0; s < 2; s++) {
+    const int idx = so3_idx[s];
+    Vec3 seg;
+    for (int i = 0; i < 3; i++) seg(i, 0) = -1 * f[idx + i] * dt;
+    // F_x1 block = exp(seg, scalar(1/2)) with 1/2 == 0: identity (esekfom.hpp:312)
+    const Mat3 E = quat_to_rot(exp_quat(seg, double(1 / 2)));
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) F1(idx + i, idx + j) = E(i, j);
+    const Mat3 A = A_matrix(seg);
+    for (int c = 0; c < kDof; c++)
+      for (int r = 0; r < 3; r++) fxf(idx + r, c) = A(r, 0) * fx(idx, c) + A(r, 1) * fx(idx + 1, c) + A(r, 2) * fx(idx + 2, c);
+    for (int c = 0; c < 12; c++)
+      for (int r = 0; r < 3; r++) fwf(idx + r, c) = A(r, 0) * fw(idx, c) + A(r, 1) * fw(idx + 1, c) + A(r, 2) * fw(idx + 2, c);
+  }
+  // S2 block (DOF 21..22, DIM 21..23)
+  {
+    const int idx = 21;
+    Vec3 seg;
+    for (int i = 0; i < 3; i++) seg(i, 0) = f[idx + i] * dt;
+    const double z2[2] = {0, 0};
+    const Mat3 E = quat_to_rot(exp_quat(seg, double(1 / 2)));      // identity (esekfom.hpp:344)
+    const Mat<2, 3> Nx = x_.grav.Nx_yy();
+    const Mat<3, 2> Mx = x_before.grav.Mx(z2);
+    const Mat<2, 3> NE = Nx * E;
+    const Mat<2, 2> blk = NE * Mx;
+    for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) F1(idx + i, idx + j) = blk(i, j);
+    const Mat<2, 3> T = -1.0 * (NE * hat(x_before.grav.vec) * A_matrix(seg).T());
+    for (int c = 0; c < kDof; c++)
+      for (int r = 0; r < 2; r++) fxf(idx + r, c) = T(r, 0) * fx(idx, c) + T(r, 1) * fx(idx + 1, c) + T(r, 2) * fx(idx + 2, c);
+    for (int c = 0; c < 12; c++)
+      for (int r = 0; r < 2; r++) fwf(idx + r, c) = T(r, 0) * fw(idx, c) + T(r, 1) * fw(idx + 1, c) + T(r, 2) * fw(idx + 2, c);
+  }
+  F1 = F1 + dt * fxf;
+  const Mat<kDof, 12> G = dt * fwf;
+  P_ = F1 * P_ * F1.T() + G * Q * G.T();
+}
+
+void Esekf::update_iterated_dyn_share_modified(double R, double D) {
+  const int n = kDof;
+  log.clear();
+  int t = 0;
+  const StateIkfom x_prop = x_;
+  const Cov P_prop = P_;
+  double K_h[kDof];
+  Cov K_x = Cov::zero();
+  double dx_new[kDof];
+  ReducedMeas meas;
+  static const int so3_idx[2] = {3, 6};
+
+  for (int it = -1; it < maximum_iter_; it++) {
+    h_reduced(x_, meas);                                       // esekfom.hpp:1637
+    const int M = meas.M;
+    double dx[kDof];
+    x_.boxminus(dx, x_prop);                                   // :1652
+    for (int i = 0; i < n; i++) dx_new[i] = dx[i];
+    P_ = P_prop;                                               // :1655
+
+    for (int s = 0; s < 2; s++) {                              // :1659-1674
+      const int idx = so3_idx[s];
+      Vec3 seg;
+      for (int i = 0; i < 3; i++) seg(i, 0) = dx[idx + i];
+      const Mat3 J = A_matrix(seg).T();
+      double tv[3];
+      for (int r = 0; r < 3; r++) tv[r] = J(r, 0) * dx_new[idx] + J(r, 1) * dx_new[idx + 1] + J(r, 2) * dx_new[idx + 2];
+      for (int r = 0; r < 3; r++) dx_new[idx + r] = tv[r];
+      left_block<3, kDof>(P_, idx, J, n);
+      right_block_T<3, kDof>(P_, idx, J);
+    }
+    {                                                          // :1676-1697
+      const int idx = 21;
+      const Mat<2, 2> J = x_.grav.Nx_yy() * x_prop.grav.Mx(dx + idx);
+      double tv[2];
+      for (int r = 0; r < 2; r++) tv[r] = J(r, 0) * dx_new[idx] + J(r, 1) * dx_new[idx + 1];
+      for (int r = 0; r < 2; r++) dx_new[idx + r] = tv[r];
+      left_block<2, kDof>(P_, idx, J, n);
+      right_block_T<2, kDof>(P_, idx, J);
+    }
+
+    Mat<12, 12> HTH = Mat<12, 12>::zero();                      // defined as 0 when M < 23 (a-note 5)
+    double HTh[12];
+    for (int i = 0; i < 12; i++) HTh[i] = 0.0;
+
+    if (n > M) {                                               // :1701-1709
+      DenseMeas dm;
+      if (M > 0 && h_dense) h_dense(dm);
+      const double* H = dm.H.data();
+      std::vector<double> PHt((size_t)n * M), S((size_t)M * M), Sinv((size_t)M * M), K((size_t)n * M);
+      for (int i = 0; i < n; i++) for (int j = 0; j < M; j++) { double s = 0; for (int k = 0; k < 12; k++) s += P_(i, k) * H[(size_t)j * 12 + k]; PHt[(size_t)i * M + j] = s; }
+      for (int i = 0; i < M; i++) for (int j = 0; j < M; j++) { double s = 0; for (int k = 0; k < 12; k++) s += H[(size_t)i * 12 + k] * PHt[(size_t)k * M + j]; S[(size_t)i * M + j] = s / R + (i == j ? 1.0 : 0.0); }
+      if (M > 0) inverse_lu(M, S.data(), Sinv.data());
+      for (int i = 0; i < n; i++) for (int j = 0; j < M; j++) { double s = 0; for (int k = 0; k < M; k++) s += PHt[(size_t)i * M + k] * Sinv[(size_t)k * M + j]; K[(size_t)i * M + j] = s / R; }
+      for (int i = 0; i < n; i++) { double s = 0; for (int k = 0; k < M; k++) s += K[(size_t)i * M + k] * dm.h[k]; K_h[i] = s; }
+      K_x = Cov::zero();
+      for (int i = 0; i < n; i++) for (int j = 0; j < 12; j++) { double s = 0; for (int k = 0; k < M; k++) s += K[(size_t)i * M + k] * H[(size_t)k * 12 + j]; K_x(i, j) = s; }
+    } else {                                                   // :1722-1729
+      for (int i = 0; i < 12; i++) { HTh[i] = meas.HTh[i]; for (int j = 0; j < 12; j++) HTH(i, j) = meas.HTH[i * 12 + j]; }
+      Cov P_temp, P_inv;
+      {
+        Cov PR;
+        for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) PR(i, j) = P_(i, j) / R;
+        inverse<kDof>(PR, P_temp);
+      }
+      for (int i = 0; i < 12; i++) for (int j = 0; j < 12; j++) P_temp(i, j) += HTH(i, j);
+      inverse<kDof>(P_temp, P_inv);
+      for (int i = 0; i < n; i++) { double s = 0; for (int k = 0; k < 12; k++) s += P_inv(i, k) * HTh[k]; K_h[i] = s; }
+      K_x = Cov::zero();
+      for (int i = 0; i < n; i++) for (int j = 0; j < 12; j++) { double s = 0; for (int k = 0; k < 12; k++) s += P_inv(i, k) * HTH(k, j); K_x(i, j) = s; }
+    }
+
+    double dx_[kDof];                                          // :1733
+    for (int i = 0; i < n; i++) {
+      double s = 0;
+      for (int k = 0; k < n; k++) s += (K_x(i, k) - (i == k ? 1.0 : 0.0)) * dx_new[k];
+      dx_[i] = K_h[i] + s;
+    }
+
+    // degeneracy handling :1736-1744 (row-zeroing "projector" kept as in the reference)
+    Mat<6, 6> S6, V, Vinv, sel;
+    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) S6(i, j) = HTH(i, j);
+    double w[6];
+    sym_eig6(S6, w, V);
+    double prod = 1.0;
+    for (int i = 0; i < 6; i++) prod *= w[i];
+    if (prod < 1e-20) V = Mat<6, 6>::identity();
+    sel = V;
+    for (int v = 0; v < 6; v++) if (w[v] < D) for (int j = 0; j < 6; j++) sel(v, j) *= 0;
+    inverse<6>(V, Vinv);
+    double dx_nd[kDof];
+    for (int i = 0; i < n; i++) dx_nd[i] = dx_[i];
+    {
+      const Mat<6, 6> Pm = Vinv * sel;
+      for (int i = 0; i < 6; i++) { double s = 0; for (int k = 0; k < 6; k++) s += Pm(i, k) * dx_[k]; dx_nd[i] = s; }
+    }
+
+    x_.boxplus(dx_nd);                                         // :1747
+    bool converge = true;
+    for (int i = 0; i < n; i++) if (std::fabs(dx_[i]) > limit_[i]) { converge = false; break; }
+    if (converge) t++;
+
+    if (keep_log) {
+      PassLog lg;
+      lg.M = M;
+      for (int i = 0; i < 12; i++) { lg.HTh[i] = HTh[i]; for (int j = 0; j < 12; j++) lg.HTH[i * 12 + j] = HTH(i, j); }
+      for (int i = 0; i < n; i++) lg.dx[i] = dx_[i];
+      x_.to_flat(lg.x_after);
+      log.push_back(lg);
+    }
+
+    if (t > 1 || it == maximum_iter_ - 1) {                    // :1764-1820
+      Cov L = P_;
+      for (int s = 0; s < 2; s++) {
+        const int idx = so3_idx[s];
+        Vec3 seg;
+        for (int i = 0; i < 3; i++) seg(i, 0) = dx_[idx + i];
+        const Mat3 J = A_matrix(seg).T();
+        for (int c = 0; c < n; c++)
+          for (int r = 0; r < 3; r++) L(idx + r, c) = J(r, 0) * P_(idx, c) + J(r, 1) * P_(idx + 1, c) + J(r, 2) * P_(idx + 2, c);
+        left_block<3, kDof>(K_x, idx, J, 12);
+        right_block_T<3, kDof>(L, idx, J);
+        right_block_T<3, kDof>(P_, idx, J);
+      }
+      {
+        const int idx = 21;
+        const Mat<2, 2> J = x_.grav.Nx_yy() * x_prop.grav.Mx(dx_ + idx);
+        for (int c = 0; c < n; c++)
+          for (int r = 0; r < 2; r++) L(idx + r, c) = J(r, 0) * P_(idx, c) + J(r, 1) * P_(idx + 1, c);
+        left_block<2, kDof>(K_x, idx, J, 12);
+        right_block_T<2, kDof>(L, idx, J);
+        right_block_T<2, kDof>(P_, idx, J);
+      }
+      Cov Pn;
+      for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) {
+          double s = 0;
+          for (int k = 0; k < 12; k++) s += K_x(i, k) * P_(k, j);
+          Pn(i, j) = L(i, j) - s;
+        }
+      P_ = Pn;
+      return;
+    }
+  }
+}
+
+}  // namespace flimo_host

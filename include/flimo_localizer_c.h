@@ -1,0 +1,74 @@
+/* include/flimo_localizer_c.h -- C wrapper over the host C++ library (libfast_limo.so), i.e. over
+ * fast_limo::Localizer / fast_limo::Mapper with the reference's API (Modules/Localizer.hpp:138-209,
+ * Modules/Mapper.hpp:48-71).  It exists so that non-C++ callers (the Python tests and bench.py, or a
+ * ROS-free replay tool) can drive the same objects the ROS wrapper would (src/main.cpp:14-95).
+ * The hot-path boundary itself is include/flimo_c.h. */
+#ifndef FLIMO_LOCALIZER_C_H
+#define FLIMO_LOCALIZER_C_H
+#include <stddef.h>
+#include "flimo_c.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct flimo_loc flimo_loc;
+
+/* hot-path subset of fast_limo::Config (Utils/Config.hpp:23-95); defaults: src/main.cpp:101-168 */
+typedef struct flimo_loc_cfg {
+  int NUM_MATCH_POINTS, MAX_NUM_MATCHES, MAX_NUM_PC2MATCH;
+  int bucket_size;
+  double MAX_DIST_PLANE, PLANE_THRESHOLD;
+  float min_extent;
+  int downsampling;
+  int MAX_NUM_ITERS;
+  int estimate_extrinsics;
+  double LIMITS[23];
+  double cov_gyro, cov_acc, cov_bias_gyro, cov_bias_acc;
+  int time_offset, end_of_sweep, num_threads;
+  float imu2baselink_t[3], imu2baselink_R[9];
+  float lidar2baselink_t[3], lidar2baselink_R[9];
+  float accel_bias[3], gyro_bias[3], imu_sm[9];
+  /* filters (Config::Filters); voxel grid is not available in this build */
+  int crop_active; float cropBoxMin[3], cropBoxMax[3];
+  int dist_active; double min_dist;
+  int rate_active; int rate_value;
+  int fov_active; float fov_angle;
+  int sensor_type;
+  /* MI355X additions */
+  int gpu_device;
+  float gpu_cell_size;
+} flimo_loc_cfg;
+
+int    flimo_loc_create(const flimo_loc_cfg* cfg, flimo_loc** out);   /* Localizer::init */
+void   flimo_loc_destroy(flimo_loc* L);
+flimo_ctx* flimo_loc_ctx(flimo_loc* L);                               /* the Mapper's GPU context */
+int    flimo_loc_update_imu(flimo_loc* L, double stamp, const float ang_vel[3], const float lin_accel[3]);
+/* pts5: n x (x y z intensity time[s since sweep reference]).  Returns Localizer status:
+ * 0 ok, 1 null iteration, <0 early return */
+int    flimo_loc_update_pointcloud(flimo_loc* L, const float* pts5, size_t n, double stamp);
+int    flimo_loc_map_add(flimo_loc* L, const float* xyz, size_t n, double stamp);   /* Mapper::add */
+size_t flimo_loc_map_size(flimo_loc* L);
+void   flimo_loc_get_x(flimo_loc* L, double x26[26]);
+void   flimo_loc_set_x(flimo_loc* L, const double x26[26]);
+void   flimo_loc_get_P(flimo_loc* L, double P[529]);
+void   flimo_loc_set_P(flimo_loc* L, const double P[529]);
+void   flimo_loc_set_flags(flimo_loc* L, int add_to_map, int download_clouds, int keep_log);
+int    flimo_loc_num_passes(flimo_loc* L);
+void   flimo_loc_get_pass(flimo_loc* L, int i, int* M, double* HTH, double* HTh, double* dx, double* x_after);
+size_t flimo_loc_get_pc2match(flimo_loc* L, float* xyz_out, size_t cap);
+size_t flimo_loc_get_final_scan(flimo_loc* L, float* xyz_out, size_t cap);
+void   flimo_loc_get_stage_times(flimo_loc* L, double t[4]);
+void   flimo_loc_get_pose_cov(flimo_loc* L, double cov36[36]);       /* getPoseCovariance */
+/* benchmark step: restore the prior (x26, P) and re-register the resident raw scan
+ * (GPU deskew + iterated update) */
+int    flimo_loc_register_resident(flimo_loc* L, const double x26_prior[26], const double P_prior[529]);
+/* IESKF algebra in isolation with a fixed measurement (H [M][12], h [M]) -- for unit tests */
+int    flimo_eskf_update_fixed(double x26[26], double P[529], const double* H, const double* h, int M, int max_iters,
+                               const double limits[23], double R, double D, int* n_passes);
+int    flimo_eskf_predict(double x26[26], double P[529], double dt, const double Qdiag[12], const double acc[3],
+                          const double gyro[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
