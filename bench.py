@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native fast_LIMO registration hot path.
+
+A "step" is ONE scan registration of BASELINE.json's config 2: GPU deskew of a resident 64k-point
+Velodyne-like scan + the iterated ESKF update (<= MAX_NUM_ITERS+1 passes of
+k-NN -> plane fit -> point-to-plane residual/Jacobian -> H^T H reduction on the GPU, 23x23 solve on
+the host) against a resident 1M-point map.  Inputs are resident in HBM before the timed region
+(host filters / time sort / PCIe upload and the map insert are outside it: SURVEY.md section 8 rows
+f-1/f-2).  Every step restarts from the same predicted prior, so all steps do the
+same work and produce the same pose.
+
+  python bench.py --gpus N --steps K --warmup W
+For N > 1 the driver launches it under torch.distributed.run (one rank per GPU).  The path shards
+by independent scan streams (config 5): no data-path collective, weak scaling; torch.distributed is
+used only for the barrier and the max-over-ranks time.
+
+Rank 0 prints ONE JSON line (see the contract in the task description) with two extra objects:
+  roofline      dominant kernel (k-NN): algorithmic bytes per launch / mean launch time from HIP
+                events recorded on the library's stream during the timed region, vs 8 TB/s HBM
+  cpu_baseline  the CPU oracle (a restatement of the reference algorithm, "port") timed on this box's
+                host cores on the same scan / map, N = 1 only
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+E_FALLBACK = 46.64              # oracle leaf-point distance evaluations per query on cfg 2
+NBR_BYTES = 32                  # bytes the k-NN kernel writes per query (5 indices + flag, padded)
+
+
+def workload(rank: int, rings: int, az: int, nmap: int, L: float):
+    from fast_limo_amd import synth
+    mp = synth.box_world_map(nmap, L, 1)
+    scan_seed = 2 if rank == 0 else 10 + rank        # cfg 2 on rank 0, cfg 5 seeds on the others
+    scan = synth.velodyne_scan(rings, az, L, scan_seed)
+    imu = synth.stationary_imu(0.0, 0.35)
+    return mp, scan, imu
+
+
+def drive_to_prior(loc, mp, scan, imu):
+    """Prime the map, run the null first scan (reference a-note 8) and stop right before scan 2."""
+    st, w, a = imu
+    loc.map_add(mp)
+    i = 0
+    while i < len(st) and st[i] <= 0.105:
+        loc.update_imu(st[i], w[i], a[i]); i += 1
+    rc1 = loc.update_pointcloud(scan, 0.0)
+    while i < len(st) and st[i] <= 0.205:
+        loc.update_imu(st[i], w[i], a[i]); i += 1
+    return rc1
+
+
+def cpu_baseline(mp, scan, imu, caps, max_threads):
+    """Oracle Localizer timed on the host: deskew + iterated update of the same scan (no map insert)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as O
+    best = None
+    E = None
+    x_o = None
+    tried = sorted(set([1, max(1, min(max_threads, os.cpu_count() or 1))]))
+    for nt in tried:
+        L = O.Localizer(O.default_cfg(num_threads=nt, **caps))
+        drive_to_prior(_OracleNoInsert(L), mp, scan, imu)
+        x_prior, P_prior = L.get_x(), L.get_P()
+        times = []
+        budget_t0 = time.time()
+        for rep in range(5):
+            L.set_x(x_prior); L.set_P(P_prior)
+            t0 = time.perf_counter()
+            rc = L.update_pointcloud(scan, 0.1, add_to_map=False) if rep == 0 else _rerun(L, scan)
+            dt = time.perf_counter() - t0
+            st = L.stats()
+            times.append(st["t_deskew"] - st["t_sort"] + st["t_update"])   # the time sort is outside the GPU step too
+            if rep == 0:
+                x_o = L.get_x()
+                E = st["evals"] / max(st["queries"], 1)
+            if time.time() - budget_t0 > 12.0:
+                break
+        t = float(np.median(times))
+        if best is None or t < best[0]:
+            best = (t, nt, len(times))
+    t, nt, reps = best
+    return dict(value=1.0 / t, unit="scans/s", cores=nt, kind="port",
+                sample=f"median of {reps} registrations (deskew + iterated update, no map insert) of the same "
+                       f"{scan.shape[0]}-pt scan vs {mp.shape[0]}-pt map by the CPU oracle (restatement of the "
+                       f"reference; the reference itself cannot be built without Eigen/PCL/Boost); "
+                       f"threads tried {tried}, best shown"), E, x_o
+
+
+class _OracleNoInsert:
+    def __init__(self, L):
+        self.L = L
+
+    def map_add(self, mp):
+        self.L.map_add(mp)
+
+    def update_imu(self, *a):
+        self.L.update_imu(*a)
+
+    def update_pointcloud(self, pts, stamp):
+        return self.L.update_pointcloud(pts, stamp, add_to_map=False)
+
+
+def _rerun(L, scan):
+    # the oracle's prev_scan_stamp advanced after the first call; the deskew frames for the same stamp
+    # are still in its buffer, so re-running the same call is equivalent
+    return L.update_pointcloud(scan, 0.1, add_to_map=False)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--rings", type=int, default=64)
+    ap.add_argument("--azimuths", type=int, default=1024)
+    ap.add_argument("--map-points", type=int, default=1000000)
+    ap.add_argument("--box", type=float, default=100.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    n_gpus = args.gpus
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist_mod.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist = dist_mod
+
+    from fast_limo_amd import api
+    caps = dict(MAX_NUM_PC2MATCH=10**7, MAX_NUM_MATCHES=10**7)
+    mp, scan, imu = workload(rank, args.rings, args.azimuths, args.map_points, args.box)
+    loc = api.Localizer(api.default_cfg(gpu_device=local_rank, num_threads=os.cpu_count() or 1, **caps))
+    loc.set_flags(add_to_map=False, download_clouds=False, keep_log=False)
+    rc1 = drive_to_prior(loc, mp, scan, imu)
+    x_prior, P_prior = loc.get_x(), loc.get_P()
+    rc2 = loc.update_pointcloud(scan, 0.1)          # makes the raw scan + IMU frames resident
+    assert rc1 == 1 and rc2 == 0, (rc1, rc2)
+    x_ref = loc.get_x()
+
+    def step():
+        rc = loc.register_resident(x_prior, P_prior)
+        assert rc == 0, rc
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    loc.hip.set_timing(True)
+    loc.hip.timing_totals(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    tot = loc.hip.timing_totals()
+    loc.hip.set_timing(False)
+    x_end = loc.get_x()
+    assert np.array_equal(x_end, x_ref), "registration is not reproducible across steps"
+
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        out = {
+            "metric": "scans/sec (64k-pt scan, 1M-pt map) + kNN HBM GB/s vs roofline; ATE vs CPU ref",
+            "value": world * args.steps / elapsed,
+            "unit": "scans/s",
+            "n_gpus": n_gpus,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: %d-pt Velodyne-like scan (%d rings x %d azimuths), "
+                                   "%d-pt box-world map, k=5, MAX_NUM_ITERS=3, GPU deskew + iterated ESKF update per step"
+                                   % (scan.shape[0], args.rings, args.azimuths, mp.shape[0]),
+                       "parallelism": "replicas x%d (independent scan streams, no collective)" % world,
+                       "passes_per_step": tot["passes"] / max(args.steps, 1)},
+        }
+        cb, E, x_o = (None, None, None)
+        if world == 1 and not args.no_cpu_baseline:
+            cb, E, x_o = cpu_baseline(mp, scan, imu, caps, max_threads=32)
+            out["cpu_baseline"] = cb
+            dpos = float(np.abs(x_ref[0:3] - x_o[0:3]).max())
+            drot = float(2.0 * np.abs(x_ref[3:6] - x_o[3:6]).max())
+            out["pose_err_vs_cpu"] = {"pos_m": dpos, "rot_rad": drot, "tolerance": 1e-4}
+        Eq = E if E else E_FALLBACK
+        bytes_per_query = 16.0 + 16.0 * Eq + NBR_BYTES
+        qpl = tot["queries"] / max(tot["passes"], 1)               # queries per k-NN launch
+        knn_s = 1e-3 * tot["knn_ms"] / max(tot["passes"], 1)        # mean launch duration (HIP events)
+        achieved = bytes_per_query * qpl / knn_s / 1e9 if knn_s > 0 else 0.0
+        out["roofline"] = {"bound": "hbm", "kernel": "knn5_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                           "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                           "bytes_per_query": bytes_per_query, "E_evals_per_query": Eq,
+                           "queries_per_launch": qpl, "mean_launch_us": knn_s * 1e6,
+                           "stage_us_per_pass": {"knn": 1e3 * tot["knn_ms"] / max(tot["passes"], 1),
+                                                 "widen": 1e3 * tot["widen_ms"] / max(tot["passes"], 1),
+                                                 "fit_reduce": 1e3 * tot["fit_ms"] / max(tot["passes"], 1)}}
+        print(json.dumps(out))
+    loc.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -57,7 +57,7 @@ HIP_SYMBOLS = [
     "flimo_match_reduce", "flimo_match_fetch", "flimo_match_fetch_H",
     "flimo_scan_to_world", "flimo_map_add_scan",
     "flimo_set_timing", "flimo_set_debug_records", "flimo_set_lanes_per_query", "flimo_last_kernel_ms",
-    "flimo_last_candidates_per_query", "flimo_last_widen_count",
+    "flimo_last_candidates_per_query", "flimo_last_widen_count", "flimo_timing_totals",
 ]
 
 _hip = None
@@ -109,6 +109,8 @@ def load_hip():
     L.flimo_set_debug_records.argtypes = [vp, C.c_int]
     L.flimo_set_lanes_per_query.argtypes = [vp, C.c_int]
     L.flimo_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.flimo_timing_totals.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                      C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.c_int]
     L.flimo_last_widen_count.restype = C.c_int
     L.flimo_last_widen_count.argtypes = [vp]
     L.flimo_last_candidates_per_query.restype = C.c_double
@@ -265,6 +267,11 @@ class HipCtx:
         d = C.c_float(0)
         self._chk(self._L.flimo_last_kernel_ms(self._h, C.byref(a), C.byref(b), C.byref(d)))
         return a.value, b.value, d.value
+
+    def timing_totals(self, reset=False):
+        a = C.c_double(0); b = C.c_double(0); d = C.c_double(0); n = C.c_longlong(0); q = C.c_longlong(0)
+        self._chk(self._L.flimo_timing_totals(self._h, C.byref(a), C.byref(b), C.byref(d), C.byref(n), C.byref(q), int(reset)))
+        return dict(knn_ms=a.value, widen_ms=b.value, fit_ms=d.value, passes=n.value, queries=q.value)
 
     def last_widen_count(self) -> int:
         return int(self._L.flimo_last_widen_count(self._h))

@@ -76,6 +76,8 @@ struct flimo_ctx {
   float last_knn_ms = 0.f, last_widen_ms = 0.f, last_fit_ms = 0.f;
   int* h_wl_count = nullptr;   // pinned
   int last_widen_count = 0;
+  double tot_knn_ms = 0, tot_widen_ms = 0, tot_fit_ms = 0;
+  long long tot_passes = 0, tot_queries = 0;
   flimo_match_cfg last_cfg{};
 };
 
@@ -584,6 +586,17 @@ extern "C" int flimo_last_kernel_ms(const flimo_ctx* c, float* knn_ms, float* wi
   return FLIMO_OK;
 }
 extern "C" int flimo_last_widen_count(const flimo_ctx* c) { return c ? c->last_widen_count : 0; }
+extern "C" int flimo_timing_totals(flimo_ctx* c, double* knn_ms, double* widen_ms, double* fit_ms, long long* passes,
+                                   long long* queries, int reset) {
+  if (!c) return FLIMO_ERR_INVALID;
+  if (knn_ms) *knn_ms = c->tot_knn_ms;
+  if (widen_ms) *widen_ms = c->tot_widen_ms;
+  if (fit_ms) *fit_ms = c->tot_fit_ms;
+  if (passes) *passes = c->tot_passes;
+  if (queries) *queries = c->tot_queries;
+  if (reset) { c->tot_knn_ms = c->tot_widen_ms = c->tot_fit_ms = 0.0; c->tot_passes = 0; c->tot_queries = 0; }
+  return FLIMO_OK;
+}
 extern "C" double flimo_last_candidates_per_query(const flimo_ctx* c) { return c ? c->last_cand_per_query : 0.0; }
 
 static int gate_rings(const flimo_ctx* c, double max_dist_plane) {
@@ -654,6 +667,8 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
     (void)hipEventElapsedTime(&c->last_knn_ms, c->ev[0], c->ev[1]);
     (void)hipEventElapsedTime(&c->last_widen_ms, c->ev[1], c->ev[2]);
     (void)hipEventElapsedTime(&c->last_fit_ms, c->ev[2], c->ev[3]);
+    c->tot_knn_ms += c->last_knn_ms; c->tot_widen_ms += c->last_widen_ms; c->tot_fit_ms += c->last_fit_ms;
+    c->tot_passes++; c->tot_queries += n_all;
   }
   if (c->debug_recs || c->timing) c->last_widen_count = *c->h_wl_count;
   if (c->debug_recs) c->last_cand_per_query = (double)(*c->h_cand) / (double)nq;

@@ -140,6 +140,9 @@ int flimo_map_add_scan(flimo_ctx* ctx, const double x26[26], double stamp);
  * flimo_set_timing(ctx, 1). */
 int flimo_set_timing(flimo_ctx* ctx, int on);
 int flimo_last_kernel_ms(const flimo_ctx* ctx, float* knn_ms, float* widen_ms, float* fit_ms);
+/* sums over every pass since the last reset (timing must be on): per-stage GPU ms, passes, k-NN queries */
+int flimo_timing_totals(flimo_ctx* ctx, double* knn_ms, double* widen_ms, double* fit_ms, long long* passes,
+                        long long* queries, int reset);
 /* number of scan points of the last pass that needed more than the 3x3x3 cell block */
 int flimo_last_widen_count(const flimo_ctx* ctx);
 /* also write the per-point debug part of flimo_match_rec (plane, neighbours, candidate counts) */

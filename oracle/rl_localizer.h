@@ -322,7 +322,7 @@ struct Localizer {
   V3f ang_vel_cg_prev;
   // instrumentation
   int last_null_iteration = 0;
-  double t_deskew = 0, t_update = 0, t_mapadd = 0;
+  double t_deskew = 0, t_update = 0, t_mapadd = 0, t_sort = 0;
 
   void init(const LocCfg& cfg) {                                 // Localizer.cpp:35-117
     config = cfg;
@@ -460,7 +460,9 @@ struct Localizer {
     auto cmp = [eos](const Pt& a, const Pt& b) { return eos ? a.time > b.time : a.time < b.time; };
     auto extract = [sweep_ref_time, eos](const Pt& p) { return eos ? sweep_ref_time - p.time : sweep_ref_time + p.time; };
     std::vector<Pt> sorted(pc.size());
+    const double ts0 = omp_get_wtime();
     std::partial_sort_copy(pc.begin(), pc.end(), sorted.begin(), sorted.end(), cmp);   // :789-790
+    t_sort = omp_get_wtime() - ts0;
     double offset = 0.0;
     if (config.time_offset) {
       offset = imu_stamp - extract(sorted.back()) - 1.e-4;
