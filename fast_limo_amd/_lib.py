@@ -57,7 +57,7 @@ HIP_SYMBOLS = [
     "flimo_match_reduce", "flimo_match_fetch", "flimo_match_fetch_H",
     "flimo_scan_to_world", "flimo_map_add_scan",
     "flimo_set_timing", "flimo_set_debug_records", "flimo_set_lanes_per_query", "flimo_last_kernel_ms",
-    "flimo_last_candidates_per_query", "flimo_last_widen_count", "flimo_timing_totals",
+    "flimo_last_candidates_per_query", "flimo_last_widen_count", "flimo_timing_totals", "flimo_insert_rule_replay",
 ]
 
 _hip = None
@@ -111,6 +111,7 @@ def load_hip():
     L.flimo_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.flimo_timing_totals.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                       C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.c_int]
+    L.flimo_insert_rule_replay.argtypes = [C.c_float, C.c_int, f32p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t)]
     L.flimo_last_widen_count.restype = C.c_int
     L.flimo_last_widen_count.argtypes = [vp]
     L.flimo_last_candidates_per_query.restype = C.c_double
@@ -287,3 +288,21 @@ def default_match_cfg(**kw) -> MatchCfg:
             raise AttributeError(k)
         setattr(c, k, v)
     return c
+
+
+def insert_rule_replay(batches, min_extent=0.2, downsample=True):
+    """Host-only replay of the reference's octree insert rule; returns (keep flags per batch, stored count)."""
+    L = load_hip()
+    sizes = np.array([b.shape[0] for b in batches], dtype=np.uint64)
+    xyz = np.ascontiguousarray(np.concatenate([np.asarray(b, dtype=np.float32).reshape(-1, 3) for b in batches]))
+    keep = np.zeros(xyz.shape[0], dtype=np.uint8)
+    stored = C.c_size_t(0)
+    rc = L.flimo_insert_rule_replay(float(min_extent), int(downsample), xyz.reshape(-1), sizes.ctypes.data, len(batches),
+                                    keep.ctypes.data, C.byref(stored))
+    if rc != 0:
+        raise FlimoError(f"flimo_insert_rule_replay failed ({rc})")
+    out, off = [], 0
+    for b in batches:
+        out.append(keep[off:off + b.shape[0]].astype(bool))
+        off += b.shape[0]
+    return out, int(stored.value)

@@ -79,6 +79,10 @@ struct flimo_ctx {
   double tot_knn_ms = 0, tot_widen_ms = 0, tot_fit_ms = 0;
   long long tot_passes = 0, tot_queries = 0;
   flimo_match_cfg last_cfg{};
+  PoseMats last_P{};
+  MatchParams last_mp{};
+  int last_n_all = 0;
+  bool recs_valid = false, dbg_valid = false;
 };
 
 static int fail(flimo_ctx* c, int code, const char* fmt, ...) {
@@ -618,6 +622,7 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   *M = 0;
   c->last_nq = 0;
   c->last_cfg = *cfg;
+  c->recs_valid = c->dbg_valid = false;
   if (!c->grid_valid || c->map_n == 0) return FLIMO_OK;      // Mapper::match: `if(not this->exists()) return matches;`
   size_t nq = c->scan_n;
   if (cfg->MAX_NUM_PC2MATCH >= 0 && nq > (size_t)cfg->MAX_NUM_PC2MATCH) nq = (size_t)cfg->MAX_NUM_PC2MATCH;
@@ -678,6 +683,24 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   }
   *M = (int)llround(c->h_out256[c->mfma_idx[13][13]]);
   c->last_nq = (int)nq;
+  c->last_P = P; c->last_mp = mp; c->last_n_all = n_all;
+  c->recs_valid = want_recs; c->dbg_valid = c->debug_recs;
+  return FLIMO_OK;
+}
+
+// The fast pass keeps the per-point records on chip; the fetch entry points re-run the fit kernel in
+// record mode for the same pass when somebody asks for them (debug, or the M < 23 branch).
+static int materialize_recs(flimo_ctx* c, bool need_dbg) {
+  if (c->last_nq == 0) return FLIMO_OK;
+  if (c->recs_valid && (!need_dbg || c->dbg_valid)) return FLIMO_OK;
+  launch_fit(c->stream, c->grid, c->d_scan_sorted, c->last_n_all, c->d_nbr, c->last_P, c->last_mp, c->d_fit_partials,
+             c->d_recs, need_dbg ? c->d_dbg : nullptr);
+  const flimo_match_cfg& cfg = c->last_cfg;
+  if (cfg.MAX_NUM_MATCHES >= 0 && cfg.MAX_NUM_MATCHES < c->last_nq) launch_cap(c->stream, c->d_recs, c->last_nq, cfg.MAX_NUM_MATCHES);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->recs_valid = true;
+  c->dbg_valid = c->dbg_valid || need_dbg;
   return FLIMO_OK;
 }
 
@@ -686,11 +709,12 @@ extern "C" int flimo_match_fetch(flimo_ctx* c, flimo_match_rec* out, size_t cap,
   *n = (size_t)c->last_nq;
   if (!out || cap == 0 || c->last_nq == 0) return FLIMO_OK;
   (void)hipSetDevice(c->device);
+  { int rc = materialize_recs(c, true); if (rc) return rc; }
   const size_t m = std::min(cap, (size_t)c->last_nq);
   std::vector<Rec16> r(m);
   std::vector<RecDbg> d(m);
   HIPCHK(c, hipMemcpyAsync(r.data(), c->d_recs, m * sizeof(Rec16), hipMemcpyDeviceToHost, c->stream));
-  if (c->debug_recs) HIPCHK(c, hipMemcpyAsync(d.data(), c->d_dbg, m * sizeof(RecDbg), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d.data(), c->d_dbg, m * sizeof(RecDbg), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   for (size_t i = 0; i < m; i++) {
     flimo_match_rec& o = out[i];
@@ -698,14 +722,11 @@ extern "C" int flimo_match_fetch(flimo_ctx* c, flimo_match_rec* out, size_t cap,
     for (int k = 0; k < 12; k++) o.H[k] = r[i].v[k];
     o.h = r[i].v[12];
     o.valid = r[i].v[13];
-    if (c->debug_recs) {
+    {
       for (int k = 0; k < 4; k++) o.n[k] = d[i].n[k];
       for (int k = 0; k < 3; k++) o.p_global[k] = d[i].p_global[k];
       for (int k = 0; k < 5; k++) { o.sqd[k] = d[i].sqd[k]; o.nbr[k] = d[i].nbr[k]; }
       o.n_nbr = d[i].n_nbr;
-    } else {
-      for (int k = 0; k < 5; k++) o.nbr[k] = -1;
-      o.n_nbr = 0;
     }
   }
   return FLIMO_OK;
@@ -716,6 +737,7 @@ extern "C" int flimo_match_fetch_H(flimo_ctx* c, double* H, double* h, size_t ca
   *M = 0;
   if (c->last_nq == 0) return FLIMO_OK;
   (void)hipSetDevice(c->device);
+  { int rc = materialize_recs(c, false); if (rc) return rc; }
   const size_t m = (size_t)c->last_nq;
   std::vector<Rec16> r(m);
   HIPCHK(c, hipMemcpyAsync(r.data(), c->d_recs, m * sizeof(Rec16), hipMemcpyDeviceToHost, c->stream));
@@ -754,4 +776,20 @@ extern "C" int flimo_map_add_scan(flimo_ctx* c, const double x26[26], double sta
   int rc = flimo_scan_to_world(c, x26, w.data(), c->scan_n);
   if (rc) return rc;
   return flimo_map_add(c, w.data(), c->scan_n, 12, stamp);
+}
+
+// ---- host-only replay of the reference's insert rule (no GPU needed) --------------------------
+extern "C" int flimo_insert_rule_replay(float min_extent, int downsample, const float* xyz, const size_t* batch_sizes,
+                                        size_t n_batches, unsigned char* keep, size_t* stored) {
+  if (!xyz || !batch_sizes || !keep) return FLIMO_ERR_INVALID;
+  InsertBook* b = insert_book_create();
+  insert_book_config(b, min_extent, downsample != 0);
+  size_t off = 0;
+  for (size_t k = 0; k < n_batches; k++) {
+    insert_book_update(b, xyz + 3 * off, batch_sizes[k], keep + off);
+    off += batch_sizes[k];
+  }
+  if (stored) *stored = insert_book_size(b);
+  insert_book_destroy(b);
+  return FLIMO_OK;
 }

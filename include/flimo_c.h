@@ -152,6 +152,12 @@ int flimo_set_lanes_per_query(flimo_ctx* ctx, int lanes);
 /* mean number of candidate map points examined per query in the last pass */
 double flimo_last_candidates_per_query(const flimo_ctx* ctx);
 
+/* ---- diagnostics without a GPU ----
+ * Replays the map's insert rule (Octree::initialize / update, Objects/Octree.hpp:282-432) over a
+ * sequence of batches of packed NaN-free points: keep[i] = 1 if point i is stored.  Host only. */
+int flimo_insert_rule_replay(float min_extent, int downsample, const float* xyz, const size_t* batch_sizes,
+                             size_t n_batches, unsigned char* keep, size_t* stored);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,152 @@
+"""CPU suite, part 2: the product's host-side logic (no GPU compute is called here).
+  * libflimo_hip.so / libfast_limo.so load and export every symbol the headers declare
+  * context creation fails loudly without a gfx950 device (no CPU fallback)
+  * host IESKF (csrc/host/flimo_ikfom.cpp) == oracle on fixed measurements, both update branches
+  * map insert rule (csrc/hip/flimo_insert.cpp) == oracle octree stored set
+  * the N>1 bench plumbing (barrier + max over ranks) with world_size 2 on gloo
+"""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from common import sort_rows
+from fast_limo_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(flimo_[A-Za-z0-9_]+)\s*\(", txt)))
+
+
+def test_c_abi_exports_every_declared_symbol(built):
+    from fast_limo_amd import _lib, api
+    L = _lib.load_hip()
+    hip_decl = _declared("flimo_c.h")
+    assert len(hip_decl) >= 25
+    for name in hip_decl:
+        assert hasattr(L, name), name
+    assert sorted(_lib.HIP_SYMBOLS) == hip_decl
+    H = api.load_host()
+    host_decl = [n for n in _declared("flimo_localizer_c.h") if n not in hip_decl]
+    for name in host_decl:
+        assert hasattr(H, name), name
+    assert sorted(api.HOST_SYMBOLS) == sorted(host_decl)
+    assert b"gfx950" in L.flimo_version()
+
+
+def test_no_device_fails_loudly(built):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from fast_limo_amd import _lib, api
+    with pytest.raises(_lib.FlimoError):
+        _lib.HipCtx(0)
+    with pytest.raises(_lib.FlimoError):
+        api.Localizer(api.default_cfg())
+
+
+def test_host_ieskf_equals_oracle(built, oracle):
+    from fast_limo_amd import api
+    rs = np.random.RandomState(3)
+    x0 = oracle.identity_x26(pos=(1, 2, 3))
+    x0[3:7] = [0.01, -0.02, 0.03, 1.0]; x0[3:7] /= np.linalg.norm(x0[3:7])
+    x0[7:11] = [0.0, 0.01, 0.0, 1.0]; x0[7:11] /= np.linalg.norm(x0[7:11])
+    x0[14:17] = [0.1, 0.2, -0.1]
+    P = np.eye(23); P[6:12, 6:12] *= 1e-6; P[21:, 21:] *= 1e-6
+    for M in (500, 23, 22, 10, 1, 0):
+        n = rs.normal(size=(M, 3))
+        if M:
+            n /= np.linalg.norm(n, axis=1, keepdims=True)
+        H = np.hstack([n, rs.normal(size=(M, 3)) * 5, rs.normal(size=(M, 3)), n]) if M else np.zeros((0, 12))
+        h = rs.normal(size=M) * 0.05
+        xo, Po, no = oracle.eskf_update_fixed(x0, P, H, h)
+        xp, Pp, npp = api.eskf_update_fixed(x0, P, H, h)
+        assert no == npp
+        np.testing.assert_allclose(xp, xo, rtol=0, atol=1e-13)
+        np.testing.assert_allclose(Pp, Po, rtol=0, atol=1e-13)
+    Q = [6e-4] * 3 + [1e-2] * 3 + [1e-5] * 3 + [3e-4] * 3
+    xo, Po = oracle.eskf_predict(x0, P, 0.005, Q, [0.1, 0.2, 9.8], [0.01, -0.02, 0.03])
+    xp, Pp = api.eskf_predict(x0, P, 0.005, Q, [0.1, 0.2, 9.8], [0.01, -0.02, 0.03])
+    np.testing.assert_allclose(xp, xo, rtol=0, atol=1e-14)
+    np.testing.assert_allclose(Pp, Po, rtol=0, atol=1e-14)
+    assert np.abs(xo - x0).max() > 1e-4
+
+
+def test_insert_rule_equals_oracle_octree(built, oracle):
+    from fast_limo_amd import _lib
+    b0 = synth.box_world_map(30000, 12.0, 1)
+    batches = [b0, b0 + np.float32(0.003)]
+    batches += [synth.box_world_map(6000, 12.0 + 4 * k, 10 + k) + np.float32([k * 2.5, -k, 0]) for k in range(3)]
+    batches.append(np.array([[400.0, 3, 1], [-300.0, 2, 1]], np.float32))          # forces root growth
+    for ds in (True, False):
+        keep, stored = _lib.insert_rule_replay(batches, 0.2, ds)
+        oc = oracle.Octree(0.2, ds)
+        for b in batches:
+            oc.update(b)
+        assert stored == oc.size()
+        kept = np.concatenate([b[k] for b, k in zip(batches, keep)])
+        np.testing.assert_array_equal(sort_rows(kept), sort_rows(oc.points()))
+        if ds:
+            assert (~keep[1]).sum() > 1000           # the duplicate batch is largely dropped
+        else:
+            assert all(k.all() for k in keep)
+
+
+_WORKER = r'''
+import os, sys, time, json
+sys.path.insert(0, os.environ["FLIMO_ROOT"])
+import torch, torch.distributed as dist
+rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+# the bench's N>1 protocol: barrier, time K steps, barrier, MAX over ranks, rank 0 aggregates
+dist.barrier(); t0 = time.perf_counter()
+time.sleep(0.05 * (rank + 1))            # rank 1 is the slow one
+dist.barrier(); el = time.perf_counter() - t0
+t = torch.tensor([0.05 * (rank + 1)], dtype=torch.float64)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+if rank == 0:
+    steps = 10
+    print(json.dumps({"value": world * steps / float(t.item()), "max_t": float(t.item()), "el": el}))
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_gloo_aggregation(tmp_path):
+    """world_size-2 run of the bench's timing protocol on CPU (gloo): the slowest rank sets the time and
+    the throughput is the sum over ranks / that time (weak scaling, no data-path collective)."""
+    script = tmp_path / "w.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, FLIMO_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    r = json.loads(line)
+    assert abs(r["max_t"] - 0.10) < 1e-9
+    assert abs(r["value"] - 2 * 10 / 0.10) < 1e-6
+    assert r["el"] >= 0.099
+
+
+def test_bench_cli_contract():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for flag in ("--gpus", "--steps", "--warmup"):
+        assert flag in src
+    for key in ('"metric"', '"value"', '"unit"', '"n_gpus"', '"ms_per_step"', '"higher_is_better"', '"scaling"',
+                '"vs_baseline"', '"dtype"', '"data"', '"config"', '"roofline"', '"cpu_baseline"'):
+        assert key in src, key
+    # the product path never imports the oracle: only the cpu_baseline leg does
+    prod = ""
+    for dp, _, fs in os.walk(os.path.join(ROOT, "fast_limo_amd")):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h")):
+                prod += open(os.path.join(dp, f)).read()
+    assert "oracle_py" not in prod and "rl_octree" not in prod and "liboracle" not in prod
