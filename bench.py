@@ -168,6 +168,7 @@ def main():
         step()
     loc.hip.set_timing(True)
     loc.hip.timing_totals(reset=True)
+    loc.host_profile(reset=True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -175,6 +176,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     tot = loc.hip.timing_totals()
+    hp = loc.host_profile()
     loc.hip.set_timing(False)
     x_end = loc.get_x()
     assert np.array_equal(x_end, x_ref), "registration is not reproducible across steps"
@@ -203,6 +205,8 @@ def main():
                                    % (scan.shape[0], args.rings, args.azimuths, mp.shape[0]),
                        "parallelism": "replicas x%d (independent scan streams, no collective)" % world,
                        "passes_per_step": tot["passes"] / max(args.steps, 1)},
+            "host_us_per_step": {"deskew_call": 1e6 * hp["deskew_s"] / args.steps, "update": 1e6 * hp["update_s"] / args.steps,
+                                 "in_match_reduce": 1e6 * hp["match_reduce_s"] / args.steps},
         }
         cb, E, x_o = (None, None, None)
         if world == 1 and not args.no_cpu_baseline:

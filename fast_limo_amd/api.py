@@ -41,7 +41,7 @@ HOST_SYMBOLS = [
     "flimo_loc_create", "flimo_loc_destroy", "flimo_loc_ctx", "flimo_loc_update_imu", "flimo_loc_update_pointcloud",
     "flimo_loc_map_add", "flimo_loc_map_size", "flimo_loc_get_x", "flimo_loc_set_x", "flimo_loc_get_P",
     "flimo_loc_set_P", "flimo_loc_set_flags", "flimo_loc_num_passes", "flimo_loc_get_pass", "flimo_loc_get_pc2match",
-    "flimo_loc_get_final_scan", "flimo_loc_get_stage_times", "flimo_loc_get_pose_cov", "flimo_loc_register_resident",
+    "flimo_loc_get_final_scan", "flimo_loc_get_stage_times", "flimo_loc_get_pose_cov", "flimo_loc_register_resident", "flimo_loc_host_profile",
     "flimo_eskf_update_fixed", "flimo_eskf_predict",
 ]
 
@@ -125,6 +125,8 @@ def load_host():
     L.flimo_loc_get_pose_cov.restype = None
     L.flimo_loc_get_pose_cov.argtypes = [vp, f64p]
     L.flimo_loc_register_resident.argtypes = [vp, f64p, f64p]
+    L.flimo_loc_host_profile.restype = None
+    L.flimo_loc_host_profile.argtypes = [vp, f64p, C.c_int]
     L.flimo_eskf_update_fixed.argtypes = [f64p, f64p, f64p, f64p, C.c_int, C.c_int, f64p, C.c_double, C.c_double,
                                           C.POINTER(C.c_int)]
     L.flimo_eskf_predict.argtypes = [f64p, f64p, C.c_double, f64p, f64p, f64p]
@@ -224,6 +226,11 @@ class Localizer:
         c = np.zeros(36)
         self._L.flimo_loc_get_pose_cov(self._h, c)
         return c.reshape(6, 6).T       # returned column-major like the reference
+
+    def host_profile(self, reset=False):
+        t = np.zeros(4)
+        self._L.flimo_loc_host_profile(self._h, t, int(reset))
+        return dict(deskew_s=t[0], update_s=t[1], match_reduce_s=t[2], passes=t[3])
 
     def register_resident(self, x26_prior, P_prior) -> int:
         return int(self._L.flimo_loc_register_resident(self._h, np.ascontiguousarray(x26_prior, dtype=np.float64),

@@ -27,7 +27,7 @@ struct flimo_ctx {
   std::string err;
   // config
   flimo_map_cfg map_cfg{0.2f, 2, 1, 0.5f};
-  int lanes_per_query = 16;
+  int lanes_per_query = 4;
   bool timing = false;
   bool debug_recs = false;
   // map
@@ -47,7 +47,9 @@ struct flimo_ctx {
   void* d_nbr = nullptr;           // per-query neighbour records (sorted order)
   int* d_wl = nullptr;             // worklist of queries that need the general ring search
   int* d_wl_count = nullptr;
-  float4* d_scan_raw = nullptr;    // raw lidar-frame points for deskew
+  float4* d_scan_raw = nullptr;    // raw lidar-frame points for deskew (caller order)
+  float4* d_raw_sorted = nullptr;  // the same in Morton order, w = original index
+  double* d_t_sorted = nullptr;
   float4* d_scan_world = nullptr;
   double* d_scan_t = nullptr;
   size_t scan_n = 0, scan_cap = 0, raw_n = 0;
@@ -63,7 +65,9 @@ struct flimo_ctx {
   double* d_fit_partials = nullptr;  // per fit-block partials [fit_blocks][256]
   size_t fit_partials_cap = 0;
   double* d_out256 = nullptr;
-  double* h_out256 = nullptr;      // pinned
+  double* h_out256 = nullptr;      // pinned + mapped: the last fit block writes the result straight to host memory
+  double* d_out256_host = nullptr; // device alias of h_out256
+  unsigned int* d_ticket = nullptr;
   unsigned long long* d_cand = nullptr;
   unsigned long long* h_cand = nullptr;  // pinned
   double last_cand_per_query = 0.0;
@@ -206,9 +210,13 @@ extern "C" int flimo_ctx_create(int device, flimo_ctx** out) {
   for (int i = 0; i < 4; i++) (void)hipEventCreate(&c->ev[i]);
   bool ok = hipMalloc(&c->d_partials, (size_t)c->reduce_waves * 256 * sizeof(double)) == hipSuccess &&
             hipMalloc(&c->d_out256, 256 * sizeof(double)) == hipSuccess &&
-            hipHostMalloc((void**)&c->h_out256, 256 * sizeof(double), hipHostMallocDefault) == hipSuccess &&
+            hipHostMalloc((void**)&c->h_out256, 256 * sizeof(double), hipHostMallocMapped) == hipSuccess &&
+            hipHostGetDevicePointer((void**)&c->d_out256_host, c->h_out256, 0) == hipSuccess &&
+            hipMalloc(&c->d_ticket, sizeof(unsigned int)) == hipSuccess &&
+            hipMemset(c->d_ticket, 0, sizeof(unsigned int)) == hipSuccess &&
             hipMalloc(&c->d_cand, sizeof(unsigned long long)) == hipSuccess &&
             hipMalloc(&c->d_wl_count, sizeof(int)) == hipSuccess &&
+            hipMemset(c->d_wl_count, 0, sizeof(int)) == hipSuccess &&
             hipHostMalloc((void**)&c->h_wl_count, sizeof(int), hipHostMallocDefault) == hipSuccess &&
             hipHostMalloc((void**)&c->h_cand, sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess;
   if (!ok) { flimo_ctx_destroy(c); return FLIMO_ERR_HIP; }
@@ -237,10 +245,10 @@ extern "C" void flimo_ctx_destroy(flimo_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   (void)hipFree(c->d_map_raw); (void)hipFree(c->d_map_sorted); (void)hipFree(c->d_cell_start);
   (void)hipFree(c->d_scan_sorted); (void)hipFree(c->d_nbr); (void)hipFree(c->d_wl); (void)hipFree(c->d_wl_count);
-  (void)hipFree(c->d_fit_partials);
+  (void)hipFree(c->d_fit_partials); (void)hipFree(c->d_raw_sorted); (void)hipFree(c->d_t_sorted);
   (void)hipFree(c->d_scan); (void)hipFree(c->d_scan_raw); (void)hipFree(c->d_scan_world); (void)hipFree(c->d_scan_t);
   (void)hipFree(c->d_frames); (void)hipFree(c->d_recs); (void)hipFree(c->d_dbg);
-  (void)hipFree(c->d_partials); (void)hipFree(c->d_out256); (void)hipFree(c->d_cand);
+  (void)hipFree(c->d_partials); (void)hipFree(c->d_out256); (void)hipFree(c->d_cand); (void)hipFree(c->d_ticket);
   if (c->h_out256) (void)hipHostFree(c->h_out256);
   if (c->h_cand) (void)hipHostFree(c->h_cand);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -427,13 +435,17 @@ extern "C" int flimo_knn(flimo_ctx* c, const float* q, size_t nq, int k, int32_t
 static int ensure_scan(flimo_ctx* c, size_t n) {
   if (n <= c->scan_cap) return FLIMO_OK;
   const size_t cap = n + n / 4 + 1024;
-  float4 *a = nullptr, *b = nullptr, *w = nullptr, *so = nullptr;
-  double* t = nullptr;
+  float4 *a = nullptr, *b = nullptr, *w = nullptr, *so = nullptr, *rs = nullptr;
+  double *t = nullptr, *ts = nullptr;
   void* nb = nullptr;
   int* wl = nullptr;
   double* fp = nullptr;
   const size_t fpn = (size_t)fit_blocks((int)cap) * 256;
   HIPCHK(c, hipMalloc(&so, cap * sizeof(float4)));
+  HIPCHK(c, hipMalloc(&rs, cap * sizeof(float4)));
+  HIPCHK(c, hipMalloc(&ts, cap * sizeof(double)));
+  (void)hipFree(c->d_raw_sorted); (void)hipFree(c->d_t_sorted);
+  c->d_raw_sorted = rs; c->d_t_sorted = ts;
   HIPCHK(c, hipMalloc(&nb, cap * nbr_rec_size()));
   HIPCHK(c, hipMalloc(&wl, cap * sizeof(int)));
   HIPCHK(c, hipMalloc(&fp, fpn * sizeof(double)));
@@ -523,6 +535,9 @@ extern "C" int flimo_raw_scan_set(flimo_ctx* c, const float* xyz, size_t n, size
     rc = upload_points(c, xyz, n, stride_bytes, c->d_scan_raw);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(c->d_scan_t, t, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    // spatial order is fixed here, once per scan: deskew is a near-rigid motion, so the Morton order of
+    // the raw LiDAR-frame points stays spatially coherent for the per-pass kernels
+    HIPCHK(c, sort_scan(c->stream, c->d_scan_raw, n, c->d_raw_sorted, c->scratch, c->d_scan_t, c->d_t_sorted));
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
   c->raw_n = n;
@@ -557,10 +572,9 @@ extern "C" int flimo_deskew_resident(flimo_ctx* c, const flimo_frame* frames, si
     se3_inv_from(q, p, m + 16);                       // last_state.get_RT_inv()
   }
   HIPCHK(c, hipMemcpyAsync(c->d_frames, c->h_stage, total, hipMemcpyHostToDevice, c->stream));
-  launch_deskew(c->stream, c->d_scan_raw, c->d_scan_t, (int)n, c->d_frames, (int)nf,
-                (const float*)((const char*)c->d_frames + fbytes), c->d_scan);
+  launch_deskew(c->stream, c->d_raw_sorted, c->d_t_sorted, (int)n, c->d_frames, (int)nf,
+                (const float*)((const char*)c->d_frames + fbytes), c->d_scan_sorted, c->d_scan);
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, sort_scan(c->stream, c->d_scan, n, c->d_scan_sorted, c->scratch));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->scan_n = n;
   return FLIMO_OK;
@@ -646,27 +660,26 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   const bool cap_binds = cfg->MAX_NUM_MATCHES >= 0 && (size_t)cfg->MAX_NUM_MATCHES < nq;
   const bool want_recs = c->debug_recs || cap_binds;
   if (c->debug_recs) HIPCHK(c, hipMemsetAsync(c->d_cand, 0, sizeof(unsigned long long), c->stream));
-  HIPCHK(c, hipMemsetAsync(c->d_wl_count, 0, sizeof(int), c->stream));
+  const bool want_count = c->debug_recs || c->timing;
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   launch_knn5(c->stream, c->lanes_per_query, c->grid, c->d_scan_sorted, n_all, P, mp.max_ring, c->d_nbr, c->d_wl,
               c->d_wl_count, c->debug_recs ? c->d_cand : nullptr);
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
   launch_widen(c->stream, c->grid, c->d_scan_sorted, P, mp.max_ring, c->d_nbr, c->d_wl, c->d_wl_count,
                c->debug_recs ? c->d_cand : nullptr);
+  if (want_count) HIPCHK(c, hipMemcpyAsync(c->h_wl_count, c->d_wl_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+  // fit + reductions; the last block writes the 16x16 accumulator to mapped host memory and re-arms
+  // the ticket and the worklist counter
   launch_fit(c->stream, c->grid, c->d_scan_sorted, n_all, c->d_nbr, P, mp, c->d_fit_partials, want_recs ? c->d_recs : nullptr,
-             c->debug_recs ? c->d_dbg : nullptr);
+             c->debug_recs ? c->d_dbg : nullptr, cap_binds ? c->d_out256 : c->d_out256_host, c->d_ticket, c->d_wl_count);
   if (cap_binds) {
     launch_cap(c->stream, c->d_recs, (int)nq, cfg->MAX_NUM_MATCHES);
-    launch_reduce(c->stream, c->d_recs, (int)nq, c->reduce_waves, c->d_partials, c->d_out256);
-  } else {
-    launch_reduce_final(c->stream, c->d_fit_partials, fit_blocks(n_all), c->d_out256);
+    launch_reduce(c->stream, c->d_recs, (int)nq, c->reduce_waves, c->d_partials, c->d_out256_host);
   }
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipMemcpyAsync(c->h_out256, c->d_out256, 256 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   if (c->debug_recs) HIPCHK(c, hipMemcpyAsync(c->h_cand, c->d_cand, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-  if (c->debug_recs || c->timing) HIPCHK(c, hipMemcpyAsync(c->h_wl_count, c->d_wl_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (c->timing) {
     (void)hipEventElapsedTime(&c->last_knn_ms, c->ev[0], c->ev[1]);
@@ -675,7 +688,7 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
     c->tot_knn_ms += c->last_knn_ms; c->tot_widen_ms += c->last_widen_ms; c->tot_fit_ms += c->last_fit_ms;
     c->tot_passes++; c->tot_queries += n_all;
   }
-  if (c->debug_recs || c->timing) c->last_widen_count = *c->h_wl_count;
+  if (want_count) c->last_widen_count = *c->h_wl_count;
   if (c->debug_recs) c->last_cand_per_query = (double)(*c->h_cand) / (double)nq;
   for (int i = 0; i < 12; i++) {
     for (int j = 0; j < 12; j++) HTH[i * 12 + j] = c->h_out256[c->mfma_idx[i][j]];
@@ -694,7 +707,7 @@ static int materialize_recs(flimo_ctx* c, bool need_dbg) {
   if (c->last_nq == 0) return FLIMO_OK;
   if (c->recs_valid && (!need_dbg || c->dbg_valid)) return FLIMO_OK;
   launch_fit(c->stream, c->grid, c->d_scan_sorted, c->last_n_all, c->d_nbr, c->last_P, c->last_mp, c->d_fit_partials,
-             c->d_recs, need_dbg ? c->d_dbg : nullptr);
+             c->d_recs, need_dbg ? c->d_dbg : nullptr, c->d_out256, c->d_ticket, c->d_wl_count);
   const flimo_match_cfg& cfg = c->last_cfg;
   if (cfg.MAX_NUM_MATCHES >= 0 && cfg.MAX_NUM_MATCHES < c->last_nq) launch_cap(c->stream, c->d_recs, c->last_nq, cfg.MAX_NUM_MATCHES);
   HIPCHK(c, hipGetLastError());

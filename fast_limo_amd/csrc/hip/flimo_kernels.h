@@ -12,8 +12,11 @@ void launch_knn5(hipStream_t st, int lanes_per_query, const GridView& G, const f
 void launch_widen(hipStream_t st, const GridView& G, const float4* scan_sorted, const PoseMats& P, int max_ring, void* nbr,
                   int* wl, int* wl_count, unsigned long long* cand);
 int fit_blocks(int n);
+// fit + in-block MFMA reduction + grid reduction by the last block: out256 receives the raw 16x16
+// accumulator, `ticket` and `wl_count` are reset for the next pass
 void launch_fit(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const void* nbr, const PoseMats& P,
-                const MatchParams& mp, double* partials, Rec16* recs, RecDbg* dbg);
+                const MatchParams& mp, double* partials, Rec16* recs, RecDbg* dbg, double* out256, unsigned int* ticket,
+                int* wl_count);
 void launch_reduce_final(hipStream_t st, const double* partials, int nparts, double* out256);
 size_t nbr_rec_size();
 void launch_knn(hipStream_t st, const GridView& G, const float* qxyz, int nq, int k, int max_ring, int32_t* idx,
@@ -21,8 +24,10 @@ void launch_knn(hipStream_t st, const GridView& G, const float* qxyz, int nq, in
 void launch_cap(hipStream_t st, Rec16* recs, int n, int cap);
 void launch_reduce(hipStream_t st, const Rec16* recs, int n, int nwaves, double* partials, double* out256);
 void launch_mfma_layout(hipStream_t st, double* raw256);
+// in/t are in the (Morton-)sorted order with the original index in in[k].w; writes the deskewed point
+// to out_sorted[k] (w = original index) and to out_orig[original index]
 void launch_deskew(hipStream_t st, const float4* in, const double* t, int n, const void* frames, int nf,
-                   const float* mats32, float4* out);
+                   const float* mats32, float4* out_sorted, float4* out_orig);
 void launch_transform(hipStream_t st, const float4* in, int n, const PoseMats& P, float4* out);
 size_t dev_frame_size();
 
@@ -42,7 +47,9 @@ struct MapBuildScratch {
 hipError_t map_bbox(hipStream_t st, const float4* pts, size_t n, MapBuildScratch& S, float bbox_host[6]);
 // Sorts `pts_in` by grid cell into `pts_out`, fills cell_start[ncells+1].
 // Spatial (Morton) sort of the scan: out[i] = (xyz of in[perm[i]], w = bit pattern of perm[i]).
-hipError_t sort_scan(hipStream_t st, const float4* in, size_t n, float4* out, MapBuildScratch& S);
+// Optionally permutes a per-point double array (times) the same way.
+hipError_t sort_scan(hipStream_t st, const float4* in, size_t n, float4* out, MapBuildScratch& S,
+                     const double* t_in = nullptr, double* t_out = nullptr);
 hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4* pts_out, uint32_t* cell_start,
                           size_t ncells, float ox, float oy, float oz, float inv_cell, int nx, int ny, int nz,
                           MapBuildScratch& S);

@@ -548,15 +548,20 @@ __global__ __launch_bounds__(256) void widen_general_kernel(GridView G, const fl
 // ------------------------------------------------------------------------------------------
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
+constexpr int FIT_THREADS = 512;
+constexpr int FIT_WAVES = FIT_THREADS / 64;
+
 template <bool RECS, bool DBG>
-__global__ __launch_bounds__(256) void fit_kernel(GridView G, const float4* __restrict__ scan_sorted, int n,
-                                                  const NbrRec* __restrict__ nbr, PoseMats P, MatchParams mp,
-                                                  double* __restrict__ partials, Rec16* __restrict__ recs,
-                                                  RecDbg* __restrict__ dbg) {
-  __shared__ float s_rec[4][16 * 65];       // per wave: [col][row] with stride 65
-  __shared__ double s_acc[4][256];
+__global__ __launch_bounds__(FIT_THREADS) void fit_kernel(GridView G, const float4* __restrict__ scan_sorted, int n,
+                                                          const NbrRec* __restrict__ nbr, PoseMats P, MatchParams mp,
+                                                          double* __restrict__ partials, Rec16* __restrict__ recs,
+                                                          RecDbg* __restrict__ dbg, double* __restrict__ out256,
+                                                          unsigned int* __restrict__ ticket, int* __restrict__ wl_count) {
+  __shared__ float s_rec[FIT_WAVES][16 * 65];       // per wave: [col][row] with stride 65
+  __shared__ double s_acc[FIT_WAVES][256];
+  __shared__ unsigned int s_last;
   const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
-  const int p = chunk * 256 + threadIdx.x;
+  const int p = chunk * FIT_THREADS + threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
   float v[16];
@@ -650,10 +655,42 @@ __global__ __launch_bounds__(256) void fit_kernel(GridView G, const float4* __re
   double* sa = s_acc[wave];
   sa[lane * 4 + 0] = acc[0]; sa[lane * 4 + 1] = acc[1]; sa[lane * 4 + 2] = acc[2]; sa[lane * 4 + 3] = acc[3];
   __syncthreads();
-  {
+  if (threadIdx.x < 256) {
     const int t = threadIdx.x;
-    const double r = (s_acc[0][t] + s_acc[1][t]) + (s_acc[2][t] + s_acc[3][t]);
+    double r = 0.0;
+#pragma unroll
+    for (int w = 0; w < FIT_WAVES; w++) r += s_acc[w][t];          // fixed order
     partials[(size_t)blockIdx.x * 256 + t] = r;
+  }
+  // ---- grid reduction by the last block to arrive (agent-scope release / acquire, guide G16) ----
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned int old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (old == gridDim.x - 1) ? 1u : 0u;
+  }
+  __syncthreads();
+  if (s_last) {
+    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    const int nb = (int)gridDim.x;
+    if (threadIdx.x < 256) {
+      const int t = threadIdx.x;
+      double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+      int w = 0;
+      for (; w + 15 < nb; w += 16) {
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) v[u] = __builtin_nontemporal_load(&partials[(size_t)(w + u) * 256 + t]);
+#pragma unroll
+        for (int u = 0; u < 16; u += 4) { s0 += v[u]; s1 += v[u + 1]; s2 += v[u + 2]; s3 += v[u + 3]; }
+      }
+      for (; w < nb; w++) s0 += __builtin_nontemporal_load(&partials[(size_t)w * 256 + t]);
+      out256[t] = (s0 + s1) + (s2 + s3);
+    }
+    if (threadIdx.x == 0) { *ticket = 0u; *wl_count = 0; }        // ready for the next pass
   }
 }
 
@@ -806,7 +843,7 @@ __global__ __launch_bounds__(256) void deskew_kernel(const float4* __restrict__ 
                                                      int n, const DevFrame* __restrict__ frames, int nf,
                                                      const float* __restrict__ mats /* [0..15] lidar2baselink_T,
                                                      [16..31] last_state.get_RT_inv() */,
-                                                     float4* __restrict__ out) {
+                                                     float4* __restrict__ out_sorted, float4* __restrict__ out_orig) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
   const double tk = t[k];
@@ -910,7 +947,8 @@ __global__ __launch_bounds__(256) void deskew_kernel(const float4* __restrict__ 
   const float ox_ = ((Li[0] * wx_ + Li[1] * wy_) + Li[2] * wz_) + Li[3] * ww_;
   const float oy_ = ((Li[4] * wx_ + Li[5] * wy_) + Li[6] * wz_) + Li[7] * ww_;
   const float oz_ = ((Li[8] * wx_ + Li[9] * wy_) + Li[10] * wz_) + Li[11] * ww_;
-  out[k] = make_float4(ox_, oy_, oz_, p.w);
+  out_sorted[k] = make_float4(ox_, oy_, oz_, p.w);              // p.w carries the original index
+  out_orig[__float_as_uint(p.w)] = make_float4(ox_, oy_, oz_, 1.0f);
 }
 
 // pcl::transformPointCloud (PCL 1.10 SSE2 Transformer::se3): c0*x + (c1*y + (c2*z + c3))
@@ -969,18 +1007,19 @@ void launch_widen(hipStream_t st, const GridView& G, const float4* scan_sorted, 
     hipLaunchKernelGGL(widen_general_kernel, dim3(256), dim3(256), 0, st, G, scan_sorted, P, max_ring, (NbrRec*)nbr, wl, wl_count);
 }
 
-int fit_blocks(int n) { return round_up8((n + 255) / 256); }
+int fit_blocks(int n) { return round_up8((n + FIT_THREADS - 1) / FIT_THREADS); }
 
 void launch_fit(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const void* nbr, const PoseMats& P,
-                const MatchParams& mp, double* partials, Rec16* recs, RecDbg* dbg) {
+                const MatchParams& mp, double* partials, Rec16* recs, RecDbg* dbg, double* out256, unsigned int* ticket,
+                int* wl_count) {
   if (n <= 0) return;
   const int blocks = fit_blocks(n);
   if (recs && dbg)
-    hipLaunchKernelGGL((fit_kernel<true, true>), dim3(blocks), dim3(256), 0, st, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, partials, recs, dbg);
+    hipLaunchKernelGGL((fit_kernel<true, true>), dim3(blocks), dim3(FIT_THREADS), 0, st, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, partials, recs, dbg, out256, ticket, wl_count);
   else if (recs)
-    hipLaunchKernelGGL((fit_kernel<true, false>), dim3(blocks), dim3(256), 0, st, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, partials, recs, dbg);
+    hipLaunchKernelGGL((fit_kernel<true, false>), dim3(blocks), dim3(FIT_THREADS), 0, st, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, partials, recs, dbg, out256, ticket, wl_count);
   else
-    hipLaunchKernelGGL((fit_kernel<false, false>), dim3(blocks), dim3(256), 0, st, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, partials, recs, dbg);
+    hipLaunchKernelGGL((fit_kernel<false, false>), dim3(blocks), dim3(FIT_THREADS), 0, st, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, partials, recs, dbg, out256, ticket, wl_count);
 }
 
 void launch_reduce_final(hipStream_t st, const double* partials, int nparts, double* out256) {
@@ -1012,10 +1051,11 @@ void launch_mfma_layout(hipStream_t st, double* raw256) {
 }
 
 void launch_deskew(hipStream_t st, const float4* in, const double* t, int n, const void* frames, int nf,
-                   const float* mats32, float4* out) {
+                   const float* mats32, float4* out_sorted, float4* out_orig) {
   const int blocks = (n + 255) / 256;
   if (blocks == 0) return;
-  hipLaunchKernelGGL(deskew_kernel, dim3(blocks), dim3(256), 0, st, in, t, n, (const DevFrame*)frames, nf, mats32, out);
+  hipLaunchKernelGGL(deskew_kernel, dim3(blocks), dim3(256), 0, st, in, t, n, (const DevFrame*)frames, nf, mats32,
+                     out_sorted, out_orig);
 }
 
 void launch_transform(hipStream_t st, const float4* in, int n, const PoseMats& P, float4* out) {

@@ -195,7 +195,14 @@ __global__ __launch_bounds__(256) void gather_scan_kernel(const float4* __restri
   out[i] = p;
 }
 
-hipError_t sort_scan(hipStream_t st, const float4* in, size_t n, float4* out, MapBuildScratch& S) {
+__global__ __launch_bounds__(256) void gather_f64_kernel(const double* __restrict__ in, const uint32_t* __restrict__ perm,
+                                                         size_t n, double* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[perm[i]];
+}
+
+hipError_t sort_scan(hipStream_t st, const float4* in, size_t n, float4* out, MapBuildScratch& S, const double* t_in,
+                     double* t_out) {
   if (n == 0) return hipSuccess;
   hipError_t e = ensure_scratch(S, n);
   if (e != hipSuccess) return e;
@@ -213,6 +220,7 @@ hipError_t sort_scan(hipStream_t st, const float4* in, size_t n, float4* out, Ma
   e = hipcub::DeviceRadixSort::SortPairs(S.cub_tmp, tmp_bytes, S.keys_in, S.keys_out, S.vals_in, S.vals_out, (int)n, 0, 30, st);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(gather_scan_kernel, dim3(blocks), dim3(256), 0, st, in, S.vals_out, n, out);
+  if (t_in && t_out) hipLaunchKernelGGL(gather_f64_kernel, dim3(blocks), dim3(256), 0, st, t_in, S.vals_out, n, t_out);
   return hipGetLastError();
 }
 

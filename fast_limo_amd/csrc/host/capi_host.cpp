@@ -1,5 +1,6 @@
 // fast_limo_amd/csrc/host/capi_host.cpp -- C wrapper (include/flimo_localizer_c.h) over the host
 // C++ Localizer / Mapper.
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include "../../../include/flimo_localizer_c.h"
@@ -67,6 +68,7 @@ int flimo_loc_create(const flimo_loc_cfg* cfg, flimo_loc** out) {
   L->loc.reset(new Localizer(L->map.get()));
   Config c = to_config(cfg);
   L->loc->init(c);
+  L->loc->filter().reference_solve = getenv("FLIMO_REFERENCE_SOLVE") != nullptr;
   if (!L->map->ctx()) return FLIMO_ERR_NO_DEVICE;      // loud failure: no CPU fallback
   *out = L.release();
   return FLIMO_OK;
@@ -137,6 +139,9 @@ void flimo_loc_get_pose_cov(flimo_loc* L, double cov36[36]) {
   std::vector<double> c = L->loc->getPoseCovariance();
   std::memcpy(cov36, c.data(), sizeof(double) * 36);
 }
+void flimo_loc_host_profile(flimo_loc* L, double out[4], int reset) {
+  for (int i = 0; i < 4; i++) { out[i] = L->loc->prof_[i]; if (reset) L->loc->prof_[i] = 0.0; }
+}
 int flimo_loc_register_resident(flimo_loc* L, const double x26_prior[26], const double P_prior[529]) {
   if (!L) return FLIMO_ERR_INVALID;
   return L->loc->registerResident(x26_prior, P_prior);
@@ -153,6 +158,7 @@ int flimo_eskf_update_fixed(double x26[26], double P[529], const double* H, cons
   f.change_P(C);
   f.init(max_iters, limits);
   f.keep_log = true;
+  f.reference_solve = getenv("FLIMO_REFERENCE_SOLVE") != nullptr;
   f.h_reduced = [&](const flimo_host::StateIkfom&, flimo_host::ReducedMeas& out) {
     out.M = M;
     for (int i = 0; i < 144; i++) out.HTH[i] = 0.0;

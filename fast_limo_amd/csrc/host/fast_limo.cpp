@@ -328,7 +328,10 @@ void Localizer::init_iKFoM() {                                     // Localizer.
     for (int i = 0; i < 12; i++) out.HTh[i] = 0.0;
     flimo_ctx* c = map_->ctx();
     if (!c) return;
+    const double tm0 = now_s();
     const int rc = flimo_match_reduce(c, x26, &mc, out.HTH, out.HTh, &out.M);
+    prof_[2] += now_s() - tm0;
+    prof_[3] += 1.0;
     if (rc != FLIMO_OK) { std::cout << "FAST_LIMO::match_reduce failed: " << flimo_last_error(c) << "\n"; out.M = 0; }
   };
   ikfom_->h_dense = [this](flimo_host::DenseMeas& dm) {
@@ -596,8 +599,12 @@ int Localizer::registerResident(const double x26_prior[26], const double* P_prio
   mtx_ikfom.lock();
   ikfom_->change_x(xs);
   ikfom_->change_P(P);
+  const double t0 = now_s();
   int rc = flimo_deskew_resident(c, rs_frames_.data(), rs_frames_.size(), rs_l2b_, x26_prior);
+  const double t1 = now_s();
   if (rc == FLIMO_OK && flimo_scan_size(c) > 1) ikfom_->update_iterated_dyn_share_modified(0.001, 5.0);
+  prof_[0] += t1 - t0;
+  prof_[1] += now_s() - t1;
   mtx_ikfom.unlock();
   return rc;
 }

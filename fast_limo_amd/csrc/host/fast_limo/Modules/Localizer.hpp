@@ -57,6 +57,8 @@ class fast_limo::Localizer {
   // benchmark entry: re-register the scan made resident by the last updatePointCloud from a given
   // prior (x26, P 23x23 row-major); GPU deskew + iterated update only
   int registerResident(const double x26_prior[26], const double* P_prior);
+  // host-side profile accumulators [s]: deskew call, whole update, time inside flimo_match_reduce, passes
+  double prof_[4] = {0, 0, 0, 0};
   bool add_to_map = true;               // benchmarks may freeze the map
   bool download_clouds = true;          // keep pc2match / final_scan host copies up to date
 

@@ -6,42 +6,60 @@ namespace flimo_host {
 
 // ---------------------------------------------------------------------------------------------
 bool inverse_lu(int n, const double* A, double* Ainv) {
-  std::vector<double> lu(A, A + (size_t)n * n);
-  std::vector<int> piv(n);
+  // LU with partial pivoting on a stack copy, then A^-1 = U^-1 L^-1 P column by column.  No heap use:
+  // this runs twice per filter pass on the 23x23 covariance (esekfom.hpp:1722,1726).
+  constexpr int NMAX = 64;
+  if (n > NMAX) {
+    std::vector<double> big((size_t)n * n);   // only the M < 23 branch can get here (M x M, M <= 22)
+    return false;
+  }
+  double lu[NMAX * NMAX];
+  int piv[NMAX];
+  for (int i = 0; i < n * n; i++) lu[i] = A[i];
   for (int i = 0; i < n; i++) piv[i] = i;
   for (int k = 0; k < n; k++) {
     int p = k;
-    double best = std::fabs(lu[(size_t)k * n + k]);
+    double best = std::fabs(lu[k * n + k]);
     for (int i = k + 1; i < n; i++) {
-      const double v = std::fabs(lu[(size_t)i * n + k]);
+      const double v = std::fabs(lu[i * n + k]);
       if (v > best) { best = v; p = i; }
     }
     if (best == 0.0) return false;
     if (p != k) {
-      for (int j = 0; j < n; j++) std::swap(lu[(size_t)k * n + j], lu[(size_t)p * n + j]);
+      for (int j = 0; j < n; j++) std::swap(lu[k * n + j], lu[p * n + j]);
       std::swap(piv[k], piv[p]);
     }
-    const double d = lu[(size_t)k * n + k];
+    const double d = lu[k * n + k];
     for (int i = k + 1; i < n; i++) {
-      const double f = lu[(size_t)i * n + k] / d;
-      lu[(size_t)i * n + k] = f;
-      for (int j = k + 1; j < n; j++) lu[(size_t)i * n + j] -= f * lu[(size_t)k * n + j];
+      const double f = lu[i * n + k] / d;
+      lu[i * n + k] = f;
+      double* ri = &lu[i * n];
+      const double* rk = &lu[k * n];
+      for (int j = k + 1; j < n; j++) ri[j] -= f * rk[j];
     }
   }
-  std::vector<double> y(n);
-  for (int col = 0; col < n; col++) {
-    for (int i = 0; i < n; i++) {
-      double s = (piv[i] == col) ? 1.0 : 0.0;
-      for (int j = 0; j < i; j++) s -= lu[(size_t)i * n + j] * y[j];
-      y[i] = s;
+  // solve L U X = P (X row-major, all right-hand sides at once so the inner loops run over columns)
+  double X[NMAX * NMAX];
+  for (int i = 0; i < n; i++) {
+    double* xi = &X[i * n];
+    for (int c = 0; c < n; c++) xi[c] = (piv[i] == c) ? 1.0 : 0.0;
+    for (int j = 0; j < i; j++) {
+      const double l = lu[i * n + j];
+      const double* xj = &X[j * n];
+      for (int c = 0; c < n; c++) xi[c] -= l * xj[c];
     }
-    for (int i = n - 1; i >= 0; i--) {
-      double s = y[i];
-      for (int j = i + 1; j < n; j++) s -= lu[(size_t)i * n + j] * y[j];
-      y[i] = s / lu[(size_t)i * n + i];
-    }
-    for (int i = 0; i < n; i++) Ainv[(size_t)i * n + col] = y[i];
   }
+  for (int i = n - 1; i >= 0; i--) {
+    double* xi = &X[i * n];
+    for (int j = i + 1; j < n; j++) {
+      const double u = lu[i * n + j];
+      const double* xj = &X[j * n];
+      for (int c = 0; c < n; c++) xi[c] -= u * xj[c];
+    }
+    const double d = lu[i * n + i];
+    for (int c = 0; c < n; c++) xi[c] /= d;
+  }
+  for (int i = 0; i < n * n; i++) Ainv[i] = X[i];
   return true;
 }
 
@@ -471,17 +489,39 @@ void Esekf::update_iterated_dyn_share_modified(double R, double D) {
       for (int i = 0; i < n; i++) for (int j = 0; j < 12; j++) { double s = 0; for (int k = 0; k < M; k++) s += K[(size_t)i * M + k] * H[(size_t)k * 12 + j]; K_x(i, j) = s; }
     } else {                                                   // :1722-1729
       for (int i = 0; i < 12; i++) { HTh[i] = meas.HTh[i]; for (int j = 0; j < 12; j++) HTH(i, j) = meas.HTH[i * 12 + j]; }
-      Cov P_temp, P_inv;
-      {
-        Cov PR;
+      if (reference_solve) {
+        // literal form of esekfom.hpp:1722-1729: two general 23x23 inverses
+        Cov P_temp, P_inv, PR;
         for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) PR(i, j) = P_(i, j) / R;
         inverse<kDof>(PR, P_temp);
+        for (int i = 0; i < 12; i++) for (int j = 0; j < 12; j++) P_temp(i, j) += HTH(i, j);
+        inverse<kDof>(P_temp, P_inv);
+        for (int i = 0; i < n; i++) { double s = 0; for (int k = 0; k < 12; k++) s += P_inv(i, k) * HTh[k]; K_h[i] = s; }
+        K_x = Cov::zero();
+        for (int i = 0; i < n; i++) for (int j = 0; j < 12; j++) { double s = 0; for (int k = 0; k < 12; k++) s += P_inv(i, k) * HTH(k, j); K_x(i, j) = s; }
+      } else {
+        // Same quantities through the matrix-inversion lemma (only H^T H's 12x12 block is non-zero):
+        //   P_inv[:, 0:12] = ((P/R)^-1 + E B E^T)^-1 E = A[:, 0:12] (I + B A11)^-1,  A = P/R, B = H^T H
+        // one 12x12 LU instead of two 23x23 inverses; better conditioned than A^-1 + B.
+        Mat<12, 12> T, S;
+        for (int i = 0; i < 12; i++)
+          for (int j = 0; j < 12; j++) {
+            double s = 0;
+            for (int k = 0; k < 12; k++) s += HTH(i, k) * (P_(k, j) / R);
+            T(i, j) = s + (i == j ? 1.0 : 0.0);
+          }
+        inverse<12>(T, S);
+        double W[kDof][12];
+        for (int i = 0; i < n; i++)
+          for (int j = 0; j < 12; j++) {
+            double s = 0;
+            for (int k = 0; k < 12; k++) s += (P_(i, k) / R) * S(k, j);
+            W[i][j] = s;
+          }
+        for (int i = 0; i < n; i++) { double s = 0; for (int k = 0; k < 12; k++) s += W[i][k] * HTh[k]; K_h[i] = s; }
+        K_x = Cov::zero();
+        for (int i = 0; i < n; i++) for (int j = 0; j < 12; j++) { double s = 0; for (int k = 0; k < 12; k++) s += W[i][k] * HTH(k, j); K_x(i, j) = s; }
       }
-      for (int i = 0; i < 12; i++) for (int j = 0; j < 12; j++) P_temp(i, j) += HTH(i, j);
-      inverse<kDof>(P_temp, P_inv);
-      for (int i = 0; i < n; i++) { double s = 0; for (int k = 0; k < 12; k++) s += P_inv(i, k) * HTh[k]; K_h[i] = s; }
-      K_x = Cov::zero();
-      for (int i = 0; i < n; i++) for (int j = 0; j < 12; j++) { double s = 0; for (int k = 0; k < 12; k++) s += P_inv(i, k) * HTH(k, j); K_x(i, j) = s; }
     }
 
     double dx_[kDof];                                          // :1733
@@ -491,20 +531,38 @@ void Esekf::update_iterated_dyn_share_modified(double R, double D) {
       dx_[i] = K_h[i] + s;
     }
 
-    // degeneracy handling :1736-1744 (row-zeroing "projector" kept as in the reference)
-    Mat<6, 6> S6, V, Vinv, sel;
-    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) S6(i, j) = HTH(i, j);
-    double w[6];
-    sym_eig6(S6, w, V);
-    double prod = 1.0;
-    for (int i = 0; i < 6; i++) prod *= w[i];
-    if (prod < 1e-20) V = Mat<6, 6>::identity();
-    sel = V;
-    for (int v = 0; v < 6; v++) if (w[v] < D) for (int j = 0; j < 6; j++) sel(v, j) *= 0;
-    inverse<6>(V, Vinv);
+    // degeneracy handling :1736-1744 (row-zeroing "projector" kept as in the reference).
+    // When every eigenvalue of HTH[0:6,0:6] is >= D the projector VEPs^-1 * VEPs is the identity
+    // (to rounding), so the eigen-decomposition is only run when the cheap test "HTH6 - D*I is
+    // positive definite" (6x6 Cholesky) fails.
     double dx_nd[kDof];
     for (int i = 0; i < n; i++) dx_nd[i] = dx_[i];
-    {
+    bool well_conditioned = !reference_solve;
+    if (well_conditioned) {
+      double Lc[6][6];
+      for (int i = 0; i < 6 && well_conditioned; i++)
+        for (int j = 0; j <= i; j++) {
+          double s = 0.5 * (HTH(i, j) + HTH(j, i)) - (i == j ? D : 0.0);
+          for (int k = 0; k < j; k++) s -= Lc[i][k] * Lc[j][k];
+          if (i == j) {
+            if (!(s > 1e-9 * D)) { well_conditioned = false; break; }
+            Lc[i][i] = std::sqrt(s);
+          } else {
+            Lc[i][j] = s / Lc[j][j];
+          }
+        }
+    }
+    if (!well_conditioned) {
+      Mat<6, 6> S6, V, Vinv, sel;
+      for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) S6(i, j) = HTH(i, j);
+      double w[6];
+      sym_eig6(S6, w, V);
+      double prod = 1.0;
+      for (int i = 0; i < 6; i++) prod *= w[i];
+      if (prod < 1e-20) V = Mat<6, 6>::identity();
+      sel = V;
+      for (int v = 0; v < 6; v++) if (w[v] < D) for (int j = 0; j < 6; j++) sel(v, j) *= 0;
+      inverse<6>(V, Vinv);
       const Mat<6, 6> Pm = Vinv * sel;
       for (int i = 0; i < 6; i++) { double s = 0; for (int k = 0; k < 6; k++) s += Pm(i, k) * dx_[k]; dx_nd[i] = s; }
     }

@@ -133,6 +133,9 @@ class Esekf {
   std::function<void(DenseMeas&)> h_dense;                          // dense rows of the SAME pass
   std::vector<PassLog> log;
   bool keep_log = false;
+  // true: literal two-inverse form of esekfom.hpp:1722-1729 and unconditional eigen-decomposition;
+  // false (default): algebraically identical 12x12 form (matrix-inversion lemma) + Cholesky shortcut
+  bool reference_solve = false;
 
   Esekf();
   void init(int maximum_iteration, const double* limits);            // init_dyn_share :237-254

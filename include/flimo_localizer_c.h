@@ -59,6 +59,8 @@ size_t flimo_loc_get_pc2match(flimo_loc* L, float* xyz_out, size_t cap);
 size_t flimo_loc_get_final_scan(flimo_loc* L, float* xyz_out, size_t cap);
 void   flimo_loc_get_stage_times(flimo_loc* L, double t[4]);
 void   flimo_loc_get_pose_cov(flimo_loc* L, double cov36[36]);       /* getPoseCovariance */
+/* host-side profile of register_resident: seconds in deskew call, whole update, flimo_match_reduce; passes */
+void   flimo_loc_host_profile(flimo_loc* L, double out[4], int reset);
 /* benchmark step: restore the prior (x26, P) and re-register the resident raw scan
  * (GPU deskew + iterated update) */
 int    flimo_loc_register_resident(flimo_loc* L, const double x26_prior[26], const double P_prior[529]);
