@@ -166,7 +166,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    loc.hip.set_timing(True)
+    loc.hip.set_timing(int(os.environ.get('FLIMO_BENCH_TIMING', '1')))   # 1: HIP events around the k-NN kernel only
     loc.hip.timing_totals(reset=True)
     loc.host_profile(reset=True)
     barrier()
@@ -177,7 +177,7 @@ def main():
     elapsed = time.perf_counter() - t0
     tot = loc.hip.timing_totals()
     hp = loc.host_profile()
-    loc.hip.set_timing(False)
+    loc.hip.set_timing(0)
     x_end = loc.get_x()
     assert np.array_equal(x_end, x_ref), "registration is not reproducible across steps"
 

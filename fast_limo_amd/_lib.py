@@ -253,8 +253,9 @@ class HipCtx:
         self._chk(self._L.flimo_map_add_scan(self._h, np.ascontiguousarray(x26, dtype=np.float64), float(stamp)))
 
     # ---- instrumentation ----
-    def set_timing(self, on=True):
-        self._chk(self._L.flimo_set_timing(self._h, int(on)))
+    def set_timing(self, level=2):
+        """0 off, 1 k-NN kernel only, 2 every stage (True == 2)."""
+        self._chk(self._L.flimo_set_timing(self._h, 2 if level is True else int(level)))
 
     def set_debug_records(self, on=True):
         self._chk(self._L.flimo_set_debug_records(self._h, int(on)))

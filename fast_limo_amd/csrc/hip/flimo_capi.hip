@@ -12,6 +12,7 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#include <immintrin.h>
 #include "../../../include/flimo_c.h"
 #include "flimo_types.h"
 #include "flimo_kernels.h"
@@ -28,7 +29,7 @@ struct flimo_ctx {
   // config
   flimo_map_cfg map_cfg{0.2f, 2, 1, 0.5f};
   int lanes_per_query = 4;
-  bool timing = false;
+  int timing = 0;                  // 0 off, 1 k-NN kernel only (2 events per pass), 2 every stage
   bool debug_recs = false;
   // map
   float4* d_map_raw = nullptr;     // insertion order
@@ -68,6 +69,7 @@ struct flimo_ctx {
   double* h_out256 = nullptr;      // pinned + mapped: the last fit block writes the result straight to host memory
   double* d_out256_host = nullptr; // device alias of h_out256
   unsigned int* d_ticket = nullptr;
+  unsigned long long pass_seq = 0;  // last pass number published by the fit kernel
   unsigned long long* d_cand = nullptr;
   unsigned long long* h_cand = nullptr;  // pinned
   double last_cand_per_query = 0.0;
@@ -209,8 +211,8 @@ extern "C" int flimo_ctx_create(int device, flimo_ctx** out) {
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return FLIMO_ERR_HIP; }
   for (int i = 0; i < 4; i++) (void)hipEventCreate(&c->ev[i]);
   bool ok = hipMalloc(&c->d_partials, (size_t)c->reduce_waves * 256 * sizeof(double)) == hipSuccess &&
-            hipMalloc(&c->d_out256, 256 * sizeof(double)) == hipSuccess &&
-            hipHostMalloc((void**)&c->h_out256, 256 * sizeof(double), hipHostMallocMapped) == hipSuccess &&
+            hipMalloc(&c->d_out256, 264 * sizeof(double)) == hipSuccess &&
+            hipHostMalloc((void**)&c->h_out256, 264 * sizeof(double), hipHostMallocMapped) == hipSuccess &&
             hipHostGetDevicePointer((void**)&c->d_out256_host, c->h_out256, 0) == hipSuccess &&
             hipMalloc(&c->d_ticket, sizeof(unsigned int)) == hipSuccess &&
             hipMemset(c->d_ticket, 0, sizeof(unsigned int)) == hipSuccess &&
@@ -220,6 +222,7 @@ extern "C" int flimo_ctx_create(int device, flimo_ctx** out) {
             hipHostMalloc((void**)&c->h_wl_count, sizeof(int), hipHostMallocDefault) == hipSuccess &&
             hipHostMalloc((void**)&c->h_cand, sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess;
   if (!ok) { flimo_ctx_destroy(c); return FLIMO_ERR_HIP; }
+  memset(c->h_out256, 0, 264 * sizeof(double));
   // calibrate the v_mfma_f64_16x16x4_f64 accumulator layout: D[i][j] = j + 16 i
   launch_mfma_layout(c->stream, c->d_out256);
   if (hipMemcpyAsync(c->h_out256, c->d_out256, 256 * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
@@ -588,7 +591,7 @@ extern "C" int flimo_deskew(flimo_ctx* c, const float* xyz, size_t n, size_t str
 }
 
 // ---- measurement pass -------------------------------------------------------------------------
-extern "C" int flimo_set_timing(flimo_ctx* c, int on) { if (!c) return FLIMO_ERR_INVALID; c->timing = on != 0; return FLIMO_OK; }
+extern "C" int flimo_set_timing(flimo_ctx* c, int level) { if (!c) return FLIMO_ERR_INVALID; c->timing = level < 0 ? 0 : (level > 2 ? 2 : level); return FLIMO_OK; }
 extern "C" int flimo_set_debug_records(flimo_ctx* c, int on) { if (!c) return FLIMO_ERR_INVALID; c->debug_recs = on != 0; return FLIMO_OK; }
 extern "C" int flimo_set_lanes_per_query(flimo_ctx* c, int l) {
   if (!c) return FLIMO_ERR_INVALID;
@@ -660,7 +663,7 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   const bool cap_binds = cfg->MAX_NUM_MATCHES >= 0 && (size_t)cfg->MAX_NUM_MATCHES < nq;
   const bool want_recs = c->debug_recs || cap_binds;
   if (c->debug_recs) HIPCHK(c, hipMemsetAsync(c->d_cand, 0, sizeof(unsigned long long), c->stream));
-  const bool want_count = c->debug_recs || c->timing;
+  const bool want_count = c->debug_recs;
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   launch_knn5(c->stream, c->lanes_per_query, c->grid, c->d_scan_sorted, n_all, P, mp.max_ring, c->d_nbr, c->d_wl,
               c->d_wl_count, c->debug_recs ? c->d_cand : nullptr);
@@ -668,24 +671,40 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   launch_widen(c->stream, c->grid, c->d_scan_sorted, P, mp.max_ring, c->d_nbr, c->d_wl, c->d_wl_count,
                c->debug_recs ? c->d_cand : nullptr);
   if (want_count) HIPCHK(c, hipMemcpyAsync(c->h_wl_count, c->d_wl_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  if (c->timing) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-  // fit + reductions; the last block writes the 16x16 accumulator to mapped host memory and re-arms
-  // the ticket and the worklist counter
+  if (c->timing > 1) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+  // fit + reductions; the last block writes the 16x16 accumulator to mapped host memory, publishes the
+  // pass number and re-arms the ticket and the worklist counter
+  const unsigned long long seq = ++c->pass_seq;
   launch_fit(c->stream, c->grid, c->d_scan_sorted, n_all, c->d_nbr, P, mp, c->d_fit_partials, want_recs ? c->d_recs : nullptr,
-             c->debug_recs ? c->d_dbg : nullptr, cap_binds ? c->d_out256 : c->d_out256_host, c->d_ticket, c->d_wl_count);
+             c->debug_recs ? c->d_dbg : nullptr, cap_binds ? c->d_out256 : c->d_out256_host, c->d_ticket, c->d_wl_count, seq);
   if (cap_binds) {
     launch_cap(c->stream, c->d_recs, (int)nq, cfg->MAX_NUM_MATCHES);
     launch_reduce(c->stream, c->d_recs, (int)nq, c->reduce_waves, c->d_partials, c->d_out256_host);
   }
-  if (c->timing) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+  if (c->timing > 1) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
   HIPCHK(c, hipGetLastError());
   if (c->debug_recs) HIPCHK(c, hipMemcpyAsync(c->h_cand, c->d_cand, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (!cap_binds && !c->debug_recs && c->timing < 2) {
+    // low-latency completion: spin on the pass number the last fit block publishes to host memory
+    volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(c->h_out256 + 256);
+    unsigned long long spins = 0;
+    while (*flag != seq) {
+      _mm_pause();
+      if (++spins > 40000000ull) { HIPCHK(c, hipStreamSynchronize(c->stream)); break; }   // also surfaces launch errors
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    if (c->timing) HIPCHK(c, hipEventSynchronize(c->ev[1]));
+  } else {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
   if (c->timing) {
     (void)hipEventElapsedTime(&c->last_knn_ms, c->ev[0], c->ev[1]);
-    (void)hipEventElapsedTime(&c->last_widen_ms, c->ev[1], c->ev[2]);
-    (void)hipEventElapsedTime(&c->last_fit_ms, c->ev[2], c->ev[3]);
-    c->tot_knn_ms += c->last_knn_ms; c->tot_widen_ms += c->last_widen_ms; c->tot_fit_ms += c->last_fit_ms;
+    c->tot_knn_ms += c->last_knn_ms;
+    if (c->timing > 1) {
+      (void)hipEventElapsedTime(&c->last_widen_ms, c->ev[1], c->ev[2]);
+      (void)hipEventElapsedTime(&c->last_fit_ms, c->ev[2], c->ev[3]);
+      c->tot_widen_ms += c->last_widen_ms; c->tot_fit_ms += c->last_fit_ms;
+    }
     c->tot_passes++; c->tot_queries += n_all;
   }
   if (want_count) c->last_widen_count = *c->h_wl_count;
@@ -707,7 +726,7 @@ static int materialize_recs(flimo_ctx* c, bool need_dbg) {
   if (c->last_nq == 0) return FLIMO_OK;
   if (c->recs_valid && (!need_dbg || c->dbg_valid)) return FLIMO_OK;
   launch_fit(c->stream, c->grid, c->d_scan_sorted, c->last_n_all, c->d_nbr, c->last_P, c->last_mp, c->d_fit_partials,
-             c->d_recs, need_dbg ? c->d_dbg : nullptr, c->d_out256, c->d_ticket, c->d_wl_count);
+             c->d_recs, need_dbg ? c->d_dbg : nullptr, c->d_out256, c->d_ticket, c->d_wl_count, 0ull);
   const flimo_match_cfg& cfg = c->last_cfg;
   if (cfg.MAX_NUM_MATCHES >= 0 && cfg.MAX_NUM_MATCHES < c->last_nq) launch_cap(c->stream, c->d_recs, c->last_nq, cfg.MAX_NUM_MATCHES);
   HIPCHK(c, hipGetLastError());

@@ -12,11 +12,11 @@ void launch_knn5(hipStream_t st, int lanes_per_query, const GridView& G, const f
 void launch_widen(hipStream_t st, const GridView& G, const float4* scan_sorted, const PoseMats& P, int max_ring, void* nbr,
                   int* wl, int* wl_count, unsigned long long* cand);
 int fit_blocks(int n);
-// fit + in-block MFMA reduction + grid reduction by the last block: out256 receives the raw 16x16
-// accumulator, `ticket` and `wl_count` are reset for the next pass
+// fit + in-block MFMA reduction + grid reduction by the last block: out256[0..255] receives the raw
+// 16x16 accumulator and out256[256] (as u64) the pass number `seq` (system-scope release), `ticket` and `wl_count` are reset for the next pass
 void launch_fit(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const void* nbr, const PoseMats& P,
                 const MatchParams& mp, double* partials, Rec16* recs, RecDbg* dbg, double* out256, unsigned int* ticket,
-                int* wl_count);
+                int* wl_count, unsigned long long seq);
 void launch_reduce_final(hipStream_t st, const double* partials, int nparts, double* out256);
 size_t nbr_rec_size();
 void launch_knn(hipStream_t st, const GridView& G, const float* qxyz, int nq, int k, int max_ring, int32_t* idx,

@@ -548,7 +548,7 @@ __global__ __launch_bounds__(256) void widen_general_kernel(GridView G, const fl
 // ------------------------------------------------------------------------------------------
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-constexpr int FIT_THREADS = 512;
+constexpr int FIT_THREADS = 1024;
 constexpr int FIT_WAVES = FIT_THREADS / 64;
 
 template <bool RECS, bool DBG>
@@ -556,7 +556,8 @@ __global__ __launch_bounds__(FIT_THREADS) void fit_kernel(GridView G, const floa
                                                           const NbrRec* __restrict__ nbr, PoseMats P, MatchParams mp,
                                                           double* __restrict__ partials, Rec16* __restrict__ recs,
                                                           RecDbg* __restrict__ dbg, double* __restrict__ out256,
-                                                          unsigned int* __restrict__ ticket, int* __restrict__ wl_count) {
+                                                          unsigned int* __restrict__ ticket, int* __restrict__ wl_count,
+                                                          unsigned long long seq) {
   __shared__ float s_rec[FIT_WAVES][16 * 65];       // per wave: [col][row] with stride 65
   __shared__ double s_acc[FIT_WAVES][256];
   __shared__ unsigned int s_last;
@@ -676,21 +677,43 @@ __global__ __launch_bounds__(FIT_THREADS) void fit_kernel(GridView G, const floa
     if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     __syncthreads();
     const int nb = (int)gridDim.x;
-    if (threadIdx.x < 256) {
-      const int t = threadIdx.x;
-      double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-      int w = 0;
-      for (; w + 15 < nb; w += 16) {
-        double v[16];
+    // 256 accumulator slots x (FIT_THREADS / 256) slices of the block list; all loads of a slice are
+    // issued together (<= 16 per thread for up to 64 blocks); fixed summation order
+    constexpr int PARTS = FIT_THREADS / 256;
+    const int t = threadIdx.x & 255, part = threadIdx.x >> 8;
+    const int per = (nb + PARTS - 1) / PARTS;
+    const int b0 = part * per, b1 = min(nb, b0 + per);
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    int w = b0;
+    for (; w + 15 < b1; w += 16) {
+      double v[16];
 #pragma unroll
-        for (int u = 0; u < 16; u++) v[u] = __builtin_nontemporal_load(&partials[(size_t)(w + u) * 256 + t]);
+      for (int u = 0; u < 16; u++) v[u] = __builtin_nontemporal_load(&partials[(size_t)(w + u) * 256 + t]);
 #pragma unroll
-        for (int u = 0; u < 16; u += 4) { s0 += v[u]; s1 += v[u + 1]; s2 += v[u + 2]; s3 += v[u + 3]; }
-      }
-      for (; w < nb; w++) s0 += __builtin_nontemporal_load(&partials[(size_t)w * 256 + t]);
-      out256[t] = (s0 + s1) + (s2 + s3);
+      for (int u = 0; u < 16; u += 4) { s0 += v[u]; s1 += v[u + 1]; s2 += v[u + 2]; s3 += v[u + 3]; }
     }
-    if (threadIdx.x == 0) { *ticket = 0u; *wl_count = 0; }        // ready for the next pass
+    for (; w + 3 < b1; w += 4) {
+      double v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) v[u] = __builtin_nontemporal_load(&partials[(size_t)(w + u) * 256 + t]);
+      s0 += v[0]; s1 += v[1]; s2 += v[2]; s3 += v[3];
+    }
+    for (; w < b1; w++) s0 += __builtin_nontemporal_load(&partials[(size_t)w * 256 + t]);
+    s_acc[part][t] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (part == 0) {
+      double r = 0.0;
+#pragma unroll
+      for (int k = 0; k < PARTS; k++) r += s_acc[k][t];
+      out256[t] = r;
+    }
+    // publish: out256 may live in mapped host memory; the host spins on word 256 (the pass number)
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      *ticket = 0u; *wl_count = 0;                                // ready for the next pass
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(out256 + 256), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
@@ -1002,7 +1025,7 @@ void launch_widen(hipStream_t st, const GridView& G, const float4* scan_sorted, 
                   int* wl, int* wl_count, unsigned long long* cand) {
   if (max_ring <= 1) return;
   if (max_ring <= 3)
-    hipLaunchKernelGGL(widen_kernel, dim3(4096), dim3(256), 0, st, G, scan_sorted, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand);
+    hipLaunchKernelGGL(widen_kernel, dim3(1024), dim3(256), 0, st, G, scan_sorted, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand);
   else
     hipLaunchKernelGGL(widen_general_kernel, dim3(256), dim3(256), 0, st, G, scan_sorted, P, max_ring, (NbrRec*)nbr, wl, wl_count);
 }
@@ -1011,15 +1034,15 @@ int fit_blocks(int n) { return round_up8((n + FIT_THREADS - 1) / FIT_THREADS); }
 
 void launch_fit(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const void* nbr, const PoseMats& P,
                 const MatchParams& mp, double* partials, Rec16* recs, RecDbg* dbg, double* out256, unsigned int* ticket,
-                int* wl_count) {
+                int* wl_count, unsigned long long seq) {
   if (n <= 0) return;
   const int blocks = fit_blocks(n);
   if (recs && dbg)
-    hipLaunchKernelGGL((fit_kernel<true, true>), dim3(blocks), dim3(FIT_THREADS), 0, st, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, partials, recs, dbg, out256, ticket, wl_count);
+    hipLaunchKernelGGL((fit_kernel<true, true>), dim3(blocks), dim3(FIT_THREADS), 0, st, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, partials, recs, dbg, out256, ticket, wl_count, seq);
   else if (recs)
-    hipLaunchKernelGGL((fit_kernel<true, false>), dim3(blocks), dim3(FIT_THREADS), 0, st, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, partials, recs, dbg, out256, ticket, wl_count);
+    hipLaunchKernelGGL((fit_kernel<true, false>), dim3(blocks), dim3(FIT_THREADS), 0, st, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, partials, recs, dbg, out256, ticket, wl_count, seq);
   else
-    hipLaunchKernelGGL((fit_kernel<false, false>), dim3(blocks), dim3(FIT_THREADS), 0, st, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, partials, recs, dbg, out256, ticket, wl_count);
+    hipLaunchKernelGGL((fit_kernel<false, false>), dim3(blocks), dim3(FIT_THREADS), 0, st, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, partials, recs, dbg, out256, ticket, wl_count, seq);
 }
 
 void launch_reduce_final(hipStream_t st, const double* partials, int nparts, double* out256) {

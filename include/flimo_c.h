@@ -136,9 +136,9 @@ int flimo_map_add_scan(flimo_ctx* ctx, const double x26[26], double stamp);
 
 /* ---- instrumentation ---- */
 /* GPU time [ms] of the stages of the last flimo_match_reduce, from HIP events on the ctx stream:
- * k-NN fast path, ring widening of the worklist, fit + reductions.  Enable with
- * flimo_set_timing(ctx, 1). */
-int flimo_set_timing(flimo_ctx* ctx, int on);
+ * k-NN fast path, ring widening of the worklist, fit + reductions.  flimo_set_timing level:
+ * 0 off, 1 k-NN kernel only (two events per pass), 2 every stage. */
+int flimo_set_timing(flimo_ctx* ctx, int level);
 int flimo_last_kernel_ms(const flimo_ctx* ctx, float* knn_ms, float* widen_ms, float* fit_ms);
 /* sums over every pass since the last reset (timing must be on): per-stage GPU ms, passes, k-NN queries */
 int flimo_timing_totals(flimo_ctx* ctx, double* knn_ms, double* widen_ms, double* fit_ms, long long* passes,

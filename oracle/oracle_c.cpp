@@ -206,8 +206,8 @@ size_t oracle_loc_get_final_scan(void* Lp, float* out, size_t cap) { return copy
 void oracle_loc_get_stats(void* Lp, double t[4], long long* evals, long long* queries) {
   Localizer* L = (Localizer*)Lp;
   t[0] = L->t_deskew; t[1] = L->t_update; t[2] = L->t_mapadd; t[3] = L->t_sort;
-  *evals = L->map.last_evals;
-  *queries = L->map.last_queries;
+  *evals = L->map.sum_evals;       // over every pass of the last updatePointCloud
+  *queries = L->map.sum_queries;
 }
 long long oracle_loc_deskew(void* Lp, const float* pts5, size_t n, double stamp, float* out_xyz) {
   Localizer* L = (Localizer*)Lp;

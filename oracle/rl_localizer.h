@@ -191,6 +191,7 @@ struct Mapper {
   int num_threads_ = 1;
   long long last_evals = 0;        // instrumentation: distance evaluations in the last match()
   long long last_queries = 0;
+  long long sum_evals = 0, sum_queries = 0;   // since the last reset (Localizer::updatePointCloud entry)
 
   void set_config(const MappingCfg& c) {                          // Mapper.cpp:38-45
     config = c;
@@ -240,6 +241,8 @@ struct Mapper {
     }
     last_evals = evals_total;
     last_queries = (long long)cnt;
+    sum_evals += evals_total;          // accumulated over the passes of one update
+    sum_queries += (long long)cnt;
     for (size_t j = 0; j < init.size(); j++)
       if (init[j].is_plane) chosen.push_back(init[j]);
     if (all) *all = init;
@@ -498,6 +501,7 @@ struct Localizer {
   // <0 early return.
   int updatePointCloud(const std::vector<Pt>& raw, double time_stamp, bool add_to_map = true) {
     last_null_iteration = 0;
+    map.sum_evals = 0; map.sum_queries = 0;
     if (raw.empty()) return -1;
     if (!imu_calibrated_) return -2;
     if (imu_buffer.empty()) return -3;

@@ -1,0 +1,121 @@
+"""GPU suite at BASELINE.json's full sizes (config 2: 64k-pt scan vs 1M-pt map): size-independent
+properties instead of an element-wise oracle comparison of everything.
+  * exactness of the k-NN on a random subset against brute force in float32 (bit-exact distances)
+  * valid-match count == number of valid records; H^T H == sum over the fetched records
+  * run-to-run bit reproducibility (fixed summation order)
+  * invariance of H^T H to the lanes-per-query variant and to the grid cell size (the map index is
+    an implementation detail: exact k-NN must not depend on it)
+  * rigid-motion consistency: registering from the true pose leaves the pose (almost) unchanged
+  * full-size pose parity against the oracle (one registration, ~1 s of CPU)
+"""
+import numpy as np
+import pytest
+
+from common import CAPS, drive_two_scans, pose_delta
+from fast_limo_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def big(built):
+    from fast_limo_amd import _lib
+    mp = synth.box_world_map(1000000, 100.0, 1)
+    scan5 = synth.velodyne_scan(64, 1024, 100.0, 2)
+    ctx = _lib.HipCtx(0)
+    ctx.map_config()
+    ctx.map_add(mp)
+    ctx.scan_set(np.ascontiguousarray(scan5[:, :3]))
+    yield dict(ctx=ctx, mp=mp, scan5=scan5, scan=np.ascontiguousarray(scan5[:, :3]))
+    ctx.close()
+
+
+def _x0():
+    x = np.zeros(26); x[6] = 1; x[10] = 1; x[25] = -9.809
+    return x
+
+
+def test_knn_exact_on_subset(big):
+    ctx, mp = big["ctx"], big["mp"]
+    rs = np.random.RandomState(1)
+    q = big["scan"][rs.choice(65536, 400, replace=False)]
+    idx, sqd, cnt = ctx.knn(q, 5)
+    assert np.all(cnt == 5)
+    d = q[:, None, :] - mp[None, :, :]
+    d2 = (d[..., 0] * d[..., 0]).astype(np.float32) + ((d[..., 1] * d[..., 1]).astype(np.float32) + (d[..., 2] * d[..., 2]).astype(np.float32))
+    ref = np.sort(d2, axis=1)[:, :5]
+    np.testing.assert_array_equal(sqd, ref)
+    dev = ctx.map_points()
+    assert dev.shape[0] == 1000000
+    d2b = ((q[:, None, :] - dev[idx]) ** 2).sum(-1)
+    np.testing.assert_allclose(d2b, sqd, rtol=1e-5)
+
+
+def test_reduction_consistency_and_reproducibility(big):
+    from fast_limo_amd import _lib
+    ctx = big["ctx"]
+    cfg = _lib.default_match_cfg(**CAPS)
+    x0 = _x0()
+    HTH, HTh, M = ctx.match_reduce(x0, cfg)
+    HTH2, HTh2, M2 = ctx.match_reduce(x0, cfg)
+    assert M == M2 and M > 60000
+    np.testing.assert_array_equal(HTH, HTH2)            # bit-reproducible
+    np.testing.assert_array_equal(HTh, HTh2)
+    np.testing.assert_allclose(HTH, HTH.T, rtol=0, atol=0)
+    recs = ctx.match_fetch()
+    valid = recs["valid"] > 0
+    assert int(valid.sum()) == M
+    H = recs["H"][valid].astype(np.float64)
+    h = recs["h"][valid].astype(np.float64)
+    np.testing.assert_allclose(HTH, H.T @ H, rtol=1e-11, atol=1e-6)
+    np.testing.assert_allclose(HTh, H.T @ h, rtol=1e-11, atol=1e-6)
+    n = recs["n"][valid]
+    np.testing.assert_allclose(np.linalg.norm(n[:, :3], axis=1), 1.0, atol=1e-5)   # unit normals
+    assert np.all(recs["sqd"][valid][:, 4] < 2.0)                                   # close_enough gate
+    assert np.all(np.diff(recs["sqd"][valid], axis=1) >= 0)                         # ascending distances
+
+
+def test_invariance_to_kernel_variant_and_cell_size(big):
+    from fast_limo_amd import _lib
+    ctx = big["ctx"]
+    cfg = _lib.default_match_cfg(**CAPS)
+    x0 = _x0(); x0[0:3] = [0.1, -0.1, 0.02]
+    ref = None
+    for lpq in (1, 4, 16):
+        ctx.set_lanes_per_query(lpq)
+        HTH, HTh, M = ctx.match_reduce(x0, cfg)
+        if ref is None:
+            ref = (HTH, HTh, M)
+        else:
+            assert M == ref[2]
+            np.testing.assert_array_equal(HTH, ref[0])   # the k-NN result does not depend on L; same sums
+    ctx.set_lanes_per_query(4)
+    ctx2 = _lib.HipCtx(0)
+    ctx2.map_config(cell_size=0.8)
+    ctx2.map_add(big["mp"]); ctx2.scan_set(big["scan"])
+    HTH2, HTh2, M2 = ctx2.match_reduce(x0, cfg)
+    ctx2.close()
+    assert M2 == ref[2]
+    # a different grid reorders the map (tie-breaks, summation order): equal to rounding
+    np.testing.assert_allclose(HTH2, ref[0], rtol=1e-9, atol=1e-6)
+
+
+def test_fullsize_pose_parity_and_fixed_point(built, oracle, big):
+    from fast_limo_amd import api
+    mp, scan5 = big["mp"], big["scan5"]
+    imu = synth.stationary_imu(0.0, 0.35)
+    G = api.Localizer(api.default_cfg(num_threads=8, **CAPS)); G.set_flags(add_to_map=False, download_clouds=False)
+    assert drive_two_scans(G, mp, scan5, imu) == [1, 0]
+    xg = G.get_x()
+    Lo = oracle.Localizer(oracle.default_cfg(num_threads=8, **CAPS))
+
+    class W:
+        def map_add(self, m): Lo.map_add(m)
+        def update_imu(self, *a): Lo.update_imu(*a)
+        def update_pointcloud(self, p, s): return Lo.update_pointcloud(p, s, add_to_map=False)
+    assert drive_two_scans(W(), mp, scan5, imu) == [1, 0]
+    dpos, ang = pose_delta(xg, Lo.get_x())
+    assert dpos < 1e-4 and ang < 1e-4, (dpos, ang)
+    # close to the true offset T* (noise sigma 1 cm)
+    assert np.abs(xg[0:3] - np.array(synth.T_STAR_T)).max() < 5e-3
+    G.close()
