@@ -38,6 +38,21 @@ E_FALLBACK = 46.64              # oracle leaf-point distance evaluations per que
 NBR_BYTES = 32                  # bytes the k-NN kernel writes per query (5 indices + flag, padded)
 
 
+def pmc_traffic(queries_per_launch):
+    """HBM-side bytes per k-NN launch from the committed PMC profile (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+    in separate passes of this same command, FETCH_SIZE doubled per MI355X_MICROARCH.md): PMC counters
+    cannot be collected from inside the run, so the number is read from profiles/ and only reported when
+    it was taken on the same launch shape."""
+    f = os.path.join(ROOT, "profiles", "r01", "pmc_fetch_write_per_kernel.json")
+    try:
+        d = json.load(open(f))["knn5_kernel_traffic_bytes_per_launch"]
+        if abs(queries_per_launch - 65536) > 0.5:
+            return None
+        return d["total_corrected"]
+    except Exception:
+        return None
+
+
 def workload(rank: int, rings: int, az: int, nmap: int, L: float):
     from fast_limo_amd import synth
     mp = synth.box_world_map(nmap, L, 1)
@@ -221,7 +236,7 @@ def main():
         knn_s = 1e-3 * tot["knn_ms"] / max(tot["passes"], 1)        # mean launch duration (HIP events)
         achieved = bytes_per_query * qpl / knn_s / 1e9 if knn_s > 0 else 0.0
         out["roofline"] = {"bound": "hbm", "kernel": "knn5_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                           "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                           "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(qpl),
                            "bytes_per_query": bytes_per_query, "E_evals_per_query": Eq,
                            "queries_per_launch": qpl, "mean_launch_us": knn_s * 1e6,
                            "stage_us_per_pass": {"knn": 1e3 * tot["knn_ms"] / max(tot["passes"], 1),

@@ -124,3 +124,42 @@ def stationary_imu(t0: float, t1: float, rate_hz: float = 200.0):
     a = np.zeros((k, 3), dtype=np.float32)
     a[:, 2] = 9.809
     return stamps, w, a
+
+
+def corridor_scan(k: int, n: int, seed: int, speed: float = 10.0, sweep_s: float = 0.1, half_width: float = 6.0,
+                  sensor_height: float = 1.8, view: float = 30.0, sigma: float = 0.01) -> np.ndarray:
+    """Scan k of the config-3 stand-in (SURVEY.md section 8 d): a sensor driving at `speed` m/s along +x through a
+    corridor (ground, two side walls, transverse fins every 5 m that constrain x).  Every point is sampled
+    from the surfaces within `view` metres of the sensor position AT ITS OWN TIMESTAMP, so the sweep carries
+    real motion distortion.  Returns (n, 5) float32: x y z intensity time (time = i/n * sweep_s, sorted).
+    The sweep reference time of scan k is k * sweep_s."""
+    rs = np.random.RandomState(seed + 1000 * k)
+    t = np.arange(n, dtype=np.float64) / n * sweep_s
+    sx = speed * (k * sweep_s + t)                       # sensor x at each point's time
+    kind = rs.uniform(size=n)
+    gz = -sensor_height
+    pw = np.empty((n, 3), dtype=np.float64)
+    # ground
+    g = kind < 0.55
+    pw[g, 0] = sx[g] + rs.uniform(-view, view, g.sum())
+    pw[g, 1] = rs.uniform(-half_width, half_width, g.sum())
+    pw[g, 2] = gz + rs.normal(0, sigma, g.sum())
+    # side walls
+    w = (kind >= 0.55) & (kind < 0.85)
+    side = np.where(rs.uniform(size=w.sum()) < 0.5, -1.0, 1.0)
+    pw[w, 0] = sx[w] + rs.uniform(-view, view, w.sum())
+    pw[w, 1] = side * half_width + rs.normal(0, sigma, w.sum())
+    pw[w, 2] = gz + rs.uniform(0, 6.0, w.sum())
+    # fins: planes x = 5 m * j, 3 <= |y| <= half_width, facing x
+    f = kind >= 0.85
+    j = np.round((sx[f] + rs.uniform(-view, view, f.sum())) / 5.0)
+    pw[f, 0] = 5.0 * j + rs.normal(0, sigma, f.sum())
+    pw[f, 1] = np.where(rs.uniform(size=f.sum()) < 0.5, -1.0, 1.0) * rs.uniform(3.0, half_width, f.sum())
+    pw[f, 2] = gz + rs.uniform(0, 4.0, f.sum())
+    out = np.zeros((n, 5), dtype=np.float32)
+    out[:, 0] = (pw[:, 0] - sx).astype(np.float32)
+    out[:, 1] = pw[:, 1].astype(np.float32)
+    out[:, 2] = pw[:, 2].astype(np.float32)
+    out[:, 3] = 1.0
+    out[:, 4] = t.astype(np.float32)
+    return out
