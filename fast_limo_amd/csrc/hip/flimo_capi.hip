@@ -40,6 +40,7 @@ struct flimo_ctx {
   GridView grid{};
   bool grid_valid = false;
   double map_last_time = -1.0;
+  float bb[6] = {3.4e38f, 3.4e38f, 3.4e38f, -3.4e38f, -3.4e38f, -3.4e38f};   // bounding box of the stored points
   MapBuildScratch scratch;
   InsertBook* book = nullptr;      // reference insert rule (flimo_insert.h)
   // scan
@@ -278,6 +279,7 @@ extern "C" int flimo_map_clear(flimo_ctx* c) {
   c->map_n = 0;
   c->grid_valid = false;
   c->map_last_time = -1.0;
+  c->bb[0] = c->bb[1] = c->bb[2] = 3.4e38f; c->bb[3] = c->bb[4] = c->bb[5] = -3.4e38f;
   insert_book_clear(c->book);
   return FLIMO_OK;
 }
@@ -289,8 +291,7 @@ static int rebuild_grid(flimo_ctx* c) {
   (void)hipSetDevice(c->device);
   c->grid_valid = false;
   if (c->map_n == 0) return FLIMO_OK;
-  float bb[6];
-  HIPCHK(c, map_bbox(c->stream, c->d_map_raw, c->map_n, c->scratch, bb));
+  const float* bb = c->bb;    // tracked on the host while points are appended (no reduction kernel)
   float cell = c->map_cfg.cell_size > 0.f ? c->map_cfg.cell_size : 0.5f;
   int nx, ny, nz;
   float ox, oy, oz, inv;
@@ -379,6 +380,7 @@ extern "C" int flimo_map_add(flimo_ctx* c, const float* xyz, size_t n, size_t st
   for (size_t i = 0; i < m; i++) {
     if (!keep[i]) continue;
     st[k].x = packed[3 * i]; st[k].y = packed[3 * i + 1]; st[k].z = packed[3 * i + 2];
+    for (int a = 0; a < 3; a++) { const float v = packed[3 * i + a]; if (v < c->bb[a]) c->bb[a] = v; if (v > c->bb[3 + a]) c->bb[3 + a] = v; }
     const uint32_t id = (uint32_t)(c->map_n + k);
     memcpy(&st[k].w, &id, 4);
     k++;

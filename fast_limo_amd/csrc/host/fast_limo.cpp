@@ -533,10 +533,30 @@ bool Localizer::deskewPointCloud(pcl::PointCloud<PointType>::Ptr& pc, double& st
     std::cout << "FAST_LIMO::FATAL ERROR: LiDAR sensor type unknown or not specified!\n";
     return false;
   }
-  // time order with the same library call as the reference (:789-790) so that ties land identically
+  // Time order with the same library call as the reference (:789-790) so that ties land identically:
+  // std::partial_sort_copy is oblivious to the payload, so running it on 16-byte (key, index) records
+  // with a comparator that sees exactly what the reference's comparator sees yields the same
+  // permutation as sorting the 32-byte points through std::function, several times faster.
   auto sorted = std::make_shared<pcl::PointCloud<PointType>>();
-  sorted->points.resize(pc->points.size());
-  std::partial_sort_copy(pc->points.begin(), pc->points.end(), sorted->points.begin(), sorted->points.end(), cmp);
+  {
+    struct Rec { double key; uint32_t idx; uint32_t pad; };
+    const size_t n = pc->points.size();
+    std::vector<Rec> in(n), out(n);
+    const std::vector<PointType>& P = pc->points;
+    if (sensor == SensorType::OUSTER) {
+      for (size_t i = 0; i < n; i++) in[i] = Rec{(double)P[i].t, (uint32_t)i, 0};          // uint32 compare
+    } else if (sensor == SensorType::VELODYNE) {
+      for (size_t i = 0; i < n; i++) in[i] = Rec{(double)P[i].time, (uint32_t)i, 0};       // float compare (exact in double)
+    } else {
+      for (size_t i = 0; i < n; i++) in[i] = Rec{P[i].timestamp, (uint32_t)i, 0};          // double compare
+    }
+    const bool desc = eos && (sensor == SensorType::OUSTER || sensor == SensorType::VELODYNE);
+    if (desc) std::partial_sort_copy(in.begin(), in.end(), out.begin(), out.end(), [](const Rec& a, const Rec& b) { return a.key > b.key; });
+    else std::partial_sort_copy(in.begin(), in.end(), out.begin(), out.end(), [](const Rec& a, const Rec& b) { return a.key < b.key; });
+    sorted->points.resize(n);
+    for (size_t i = 0; i < n; i++) sorted->points[i] = P[out[i].idx];
+  }
+  (void)cmp;
   double offset = 0.0;
   if (config.time_offset) {
     offset = imu_stamp - extract(sorted->points.back()) - 1.e-4;

@@ -38,6 +38,7 @@ def test_corridor_replay_follows_cpu_oracle(built, oracle):
         worst = (max(worst[0], dpos), max(worst[1], ang))
         sizes.append(G.map_size())
         track.append(xg[0])
+    print("corridor replay: worst GPU-vs-CPU deviation", worst, "final x", track[-1], "map", sizes[-1])
     assert worst[0] <= 1e-4 and worst[1] <= 1e-4, worst
     assert sizes[0] == 0 and sizes[1] == n_pts and sizes[-1] > 3 * n_pts      # null scan, seed, then growth
     # sanity against the truth: x(t) = 10 t at the scan-end stamps (noise 1 cm, loose bound)

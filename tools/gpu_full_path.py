@@ -1,0 +1,28 @@
+"""Developer script: wall time of the FULL Localizer::updatePointCloud path (host filters + time sort + upload +
+GPU deskew + update + transform + map insert) on config 2, scan after scan, GPU vs oracle."""
+import sys, os, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np
+from fast_limo_amd import synth, api
+import oracle_py as O
+caps = dict(MAX_NUM_PC2MATCH=10**7, MAX_NUM_MATCHES=10**7)
+mp = synth.box_world_map(1000000, 100.0, 1)
+st, w, a = synth.stationary_imu(0.0, 1.0)
+G = api.Localizer(api.default_cfg(num_threads=32, **caps))
+Lo = O.Localizer(O.default_cfg(num_threads=32, **caps))
+G.map_add(mp); Lo.map_add(mp)
+i = 0
+for k in range(6):
+    until = 0.1 * (k + 1) + 0.005
+    while st[i] <= until:
+        G.update_imu(st[i], w[i], a[i]); Lo.update_imu(st[i], w[i], a[i]); i += 1
+    scan = synth.velodyne_scan(64, 1024, 100.0, 2 + k)
+    t0 = time.perf_counter(); rg = G.update_pointcloud(scan, 0.1 * k); tg = time.perf_counter() - t0
+    t0 = time.perf_counter(); ro = Lo.update_pointcloud(scan, 0.1 * k); to = time.perf_counter() - t0
+    sg = G.stage_times(); so = Lo.stats()
+    print("scan %d rc %d/%d  GPU total %.2f ms (prep %.2f deskew+upload %.2f update %.2f insert %.2f)  |  CPU total %.1f ms (deskew %.1f update %.1f insert %.1f)  map %d/%d  dpos %.2e"
+          % (k, rg, ro, tg * 1e3, sg['host_prep'] * 1e3, sg['deskew'] * 1e3, sg['update'] * 1e3, sg['map_insert'] * 1e3,
+             to * 1e3, so['t_deskew'] * 1e3, so['t_update'] * 1e3, so['t_mapadd'] * 1e3, G.map_size(), Lo.map_size(),
+             np.abs(G.get_x()[:3] - Lo.get_x()[:3]).max()), flush=True)
+G.close()
