@@ -53,7 +53,7 @@ HIP_SYMBOLS = [
     "flimo_ctx_create", "flimo_ctx_destroy", "flimo_last_error", "flimo_version",
     "flimo_map_config", "flimo_map_add", "flimo_map_clear", "flimo_map_size", "flimo_map_last_time",
     "flimo_map_points", "flimo_knn", "flimo_scan_set", "flimo_scan_size", "flimo_scan_get",
-    "flimo_raw_scan_set", "flimo_deskew_resident", "flimo_deskew",
+    "flimo_scan_voxel_filter", "flimo_raw_scan_set", "flimo_deskew_resident", "flimo_deskew",
     "flimo_match_reduce", "flimo_match_fetch", "flimo_match_fetch_H",
     "flimo_scan_to_world", "flimo_map_add_scan",
     "flimo_set_timing", "flimo_set_debug_records", "flimo_set_lanes_per_query", "flimo_last_kernel_ms",
@@ -97,6 +97,7 @@ def load_hip():
     L.flimo_scan_size.restype = C.c_size_t
     L.flimo_scan_size.argtypes = [vp]
     L.flimo_scan_get.argtypes = [vp, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.flimo_scan_voxel_filter.argtypes = [vp, C.c_float, C.POINTER(C.c_size_t)]
     L.flimo_raw_scan_set.argtypes = [vp, f32p, C.c_size_t, C.c_size_t, f64p]
     L.flimo_deskew_resident.argtypes = [vp, C.c_void_p, C.c_size_t, f32p, f64p]
     L.flimo_deskew.argtypes = [vp, f32p, C.c_size_t, C.c_size_t, f64p, C.c_void_p, C.c_size_t, f32p, f64p]
@@ -204,6 +205,11 @@ class HipCtx:
         m = C.c_size_t(0)
         self._chk(self._L.flimo_scan_get(self._h, out.ctypes.data, n, C.byref(m)))
         return out[:n]
+
+    def scan_voxel_filter(self, leaf: float) -> int:
+        n = C.c_size_t(0)
+        self._chk(self._L.flimo_scan_voxel_filter(self._h, float(leaf), C.byref(n)))
+        return int(n.value)
 
     def raw_scan_set(self, xyz, t):
         xyz = np.ascontiguousarray(xyz, dtype=np.float32)

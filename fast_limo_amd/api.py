@@ -28,11 +28,14 @@ class LocCfg(C.Structure):
         ("imu2baselink_t", C.c_float * 3), ("imu2baselink_R", C.c_float * 9),
         ("lidar2baselink_t", C.c_float * 3), ("lidar2baselink_R", C.c_float * 9),
         ("accel_bias", C.c_float * 3), ("gyro_bias", C.c_float * 3), ("imu_sm", C.c_float * 9),
+        ("voxel_active", C.c_int), ("leaf_size", C.c_float),
         ("crop_active", C.c_int), ("cropBoxMin", C.c_float * 3), ("cropBoxMax", C.c_float * 3),
         ("dist_active", C.c_int), ("min_dist", C.c_double),
         ("rate_active", C.c_int), ("rate_value", C.c_int),
         ("fov_active", C.c_int), ("fov_angle", C.c_float),
         ("sensor_type", C.c_int),
+        ("gravity_align", C.c_int), ("calibrate_accel", C.c_int), ("calibrate_gyro", C.c_int),
+        ("imu_calib_time", C.c_double),
         ("gpu_device", C.c_int), ("gpu_cell_size", C.c_float),
     ]
 
@@ -64,6 +67,7 @@ def default_cfg(**kw) -> LocCfg:
         c.imu2baselink_R[i] = eye[i]
         c.lidar2baselink_R[i] = eye[i]
         c.imu_sm[i] = eye[i]
+    c.voxel_active, c.leaf_size = 0, 0.25
     c.crop_active = 0
     for i in range(3):
         c.cropBoxMin[i], c.cropBoxMax[i] = -1.0, 1.0
@@ -71,6 +75,8 @@ def default_cfg(**kw) -> LocCfg:
     c.rate_active, c.rate_value = 0, 4
     c.fov_active, c.fov_angle = 0, float(np.pi)
     c.sensor_type = 1
+    c.gravity_align = c.calibrate_accel = c.calibrate_gyro = 0
+    c.imu_calib_time = 3.0
     c.gpu_device, c.gpu_cell_size = 0, 0.0
     for k, v in kw.items():
         if not hasattr(c, k):

@@ -529,6 +529,26 @@ extern "C" int flimo_scan_get(flimo_ctx* c, float* out, size_t cap, size_t* n) {
   return download_xyz(c, c->d_scan, std::min(cap, c->scan_n), out);
 }
 
+// ---- voxel filter on the resident scan (Localizer.cpp:313-321) ---------------------------------
+extern "C" int flimo_scan_voxel_filter(flimo_ctx* c, float leaf, size_t* n_out) {
+  if (!c || !(leaf > 0.f)) return FLIMO_ERR_INVALID;
+  if (n_out) *n_out = c->scan_n;
+  if (c->scan_n == 0) return FLIMO_OK;
+  (void)hipSetDevice(c->device);
+  size_t m = 0;
+  bool pass = false;
+  // d_scan_world is free scratch at this point of the scan life cycle
+  HIPCHK(c, voxel_grid(c->stream, c->d_scan, c->scan_n, leaf, c->d_scan_world, &m, &pass, c->scratch));
+  if (!pass) {
+    std::swap(c->d_scan, c->d_scan_world);
+    c->scan_n = m;
+  }
+  if (c->scan_n) HIPCHK(c, sort_scan(c->stream, c->d_scan, c->scan_n, c->d_scan_sorted, c->scratch));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (n_out) *n_out = c->scan_n;
+  return FLIMO_OK;
+}
+
 // ---- deskew -----------------------------------------------------------------------------------
 extern "C" int flimo_raw_scan_set(flimo_ctx* c, const float* xyz, size_t n, size_t stride_bytes, const double* t) {
   if (!c) return FLIMO_ERR_INVALID;

@@ -53,6 +53,9 @@ hipError_t sort_scan(hipStream_t st, const float4* in, size_t n, float4* out, Ma
 hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4* pts_out, uint32_t* cell_start,
                           size_t ncells, float ox, float oy, float oz, float inv_cell, int nx, int ny, int nz,
                           MapBuildScratch& S);
+// pcl::VoxelGrid on device points: out gets one centroid per occupied voxel in ascending voxel index
+hipError_t voxel_grid(hipStream_t st, const float4* in, size_t n, float leaf, float4* out, size_t* n_out, bool* passthrough,
+                      MapBuildScratch& S);
 void map_scratch_free(MapBuildScratch& S);
 
 }  // namespace flimo

@@ -224,6 +224,125 @@ hipError_t sort_scan(hipStream_t st, const float4* in, size_t n, float4* out, Ma
   return hipGetLastError();
 }
 
+// ---- voxel-grid down-sampling of the scan (pcl::VoxelGrid, reference Localizer.cpp:313-321) -----
+// One output point per occupied voxel = centroid of its points (float sums in ascending point order),
+// output in ascending linear voxel index  i + j*div_x + k*div_x*div_y  with
+// i = floor(x * inv_leaf) - floor(min_x * inv_leaf)  (PCL 1.10 filters/impl/voxel_grid.hpp).
+__global__ __launch_bounds__(256) void bbox_finite_kernel(const float4* __restrict__ pts, size_t n, unsigned* __restrict__ box) {
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 p = pts[i];
+    if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) continue;
+    mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
+    mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      mn[a] = fminf(mn[a], __shfl_xor(mn[a], off, 64));
+      mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off, 64));
+    }
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int a = 0; a < 3; a++) { atomicMin(&box[a], f2o(mn[a])); atomicMax(&box[3 + a], f2o(mx[a])); }
+}
+
+__global__ __launch_bounds__(256) void voxelkey_kernel(const float4* __restrict__ pts, size_t n, float inv, int mb0, int mb1,
+                                                       int mb2, int mul1, int mul2, uint32_t* __restrict__ keys,
+                                                       uint32_t* __restrict__ vals) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = pts[i];
+  uint32_t k = 0xffffffffu;                                 // non-finite points sort to the end and are skipped
+  if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
+    const int i0 = (int)(floorf(p.x * inv) - (float)mb0);
+    const int i1 = (int)(floorf(p.y * inv) - (float)mb1);
+    const int i2 = (int)(floorf(p.z * inv) - (float)mb2);
+    k = (uint32_t)(i0 + i1 * mul1 + i2 * mul2);
+  }
+  keys[i] = k;
+  vals[i] = (uint32_t)i;
+}
+
+__global__ __launch_bounds__(256) void voxelhead_kernel(const uint32_t* __restrict__ keys, size_t n, uint32_t* __restrict__ head) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t k = keys[i];
+  head[i] = (k != 0xffffffffu && (i == 0 || keys[i - 1] != k)) ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void voxelcentroid_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ keys,
+                                                            const uint32_t* __restrict__ perm, const uint32_t* __restrict__ head,
+                                                            const uint32_t* __restrict__ pos, size_t n, float4* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !head[i]) return;
+  const uint32_t k = keys[i];
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+  uint32_t cnt = 0;
+  for (size_t j = i; j < n && keys[j] == k; j++) {          // stable sort: ascending original index
+    const float4 p = pts[perm[j]];
+    sx += p.x; sy += p.y; sz += p.z;
+    cnt++;
+  }
+  const float nf = (float)cnt;
+  out[pos[i]] = make_float4(sx / nf, sy / nf, sz / nf, 1.0f);
+}
+
+// in -> out (may not alias).  *n_out receives the voxel count; returns hipErrorInvalidValue through
+// *passthrough = true when the voxel lattice would overflow an int (PCL then returns the input).
+hipError_t voxel_grid(hipStream_t st, const float4* in, size_t n, float leaf, float4* out, size_t* n_out, bool* passthrough,
+                      MapBuildScratch& S) {
+  *n_out = 0;
+  *passthrough = false;
+  if (n == 0) return hipSuccess;
+  hipError_t e = ensure_scratch(S, n);
+  if (e != hipSuccess) return e;
+  unsigned init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+  if ((e = hipMemcpyAsync(S.bbox, init, sizeof(init), hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+  const int blocks = (int)((n + 255) / 256);
+  hipLaunchKernelGGL(bbox_finite_kernel, dim3(std::min(blocks, 1024)), dim3(256), 0, st, in, n, (unsigned*)S.bbox);
+  unsigned ob[6];
+  if ((e = hipMemcpyAsync(ob, S.bbox, sizeof(ob), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+  if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+  if (ob[0] == 0xffffffffu) return hipSuccess;               // no finite point
+  const float inv = 1.0f / leaf;
+  int mb[3], db[3];
+  for (int a = 0; a < 3; a++) {
+    mb[a] = (int)floorf(o2f_host(ob[a]) * inv);
+    db[a] = (int)floorf(o2f_host(ob[3 + a]) * inv) - mb[a] + 1;
+  }
+  const long long cells = (long long)db[0] * db[1] * db[2];
+  if (cells > 2147483647ll) { *passthrough = true; return hipSuccess; }
+  hipLaunchKernelGGL(voxelkey_kernel, dim3(blocks), dim3(256), 0, st, in, n, inv, mb[0], mb[1], mb[2], db[0], db[0] * db[1],
+                     S.keys_in, S.vals_in);
+  size_t tmp_bytes = 0;
+  e = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, S.keys_in, S.keys_out, S.vals_in, S.vals_out, (int)n, 0, 32, st);
+  if (e != hipSuccess) return e;
+  size_t scan_bytes = 0;
+  e = hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, S.keys_in, S.vals_in, (int)n, st);
+  if (e != hipSuccess) return e;
+  const size_t need = std::max(tmp_bytes, scan_bytes);
+  if (need > S.cub_tmp_bytes) {
+    if (S.cub_tmp) (void)hipFree(S.cub_tmp);
+    if ((e = hipMalloc(&S.cub_tmp, need + 1024)) != hipSuccess) return e;
+    S.cub_tmp_bytes = need + 1024;
+  }
+  e = hipcub::DeviceRadixSort::SortPairs(S.cub_tmp, tmp_bytes, S.keys_in, S.keys_out, S.vals_in, S.vals_out, (int)n, 0, 32, st);
+  if (e != hipSuccess) return e;
+  // keys_in := head flags, vals_in := exclusive scan of the flags (output slot of each run)
+  hipLaunchKernelGGL(voxelhead_kernel, dim3(blocks), dim3(256), 0, st, S.keys_out, n, S.keys_in);
+  e = hipcub::DeviceScan::ExclusiveSum(S.cub_tmp, scan_bytes, S.keys_in, S.vals_in, (int)n, st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(voxelcentroid_kernel, dim3(blocks), dim3(256), 0, st, in, S.keys_out, S.vals_out, S.keys_in, S.vals_in, n, out);
+  uint32_t last_pos = 0, last_head = 0;
+  if ((e = hipMemcpyAsync(&last_pos, S.vals_in + (n - 1), 4, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+  if ((e = hipMemcpyAsync(&last_head, S.keys_in + (n - 1), 4, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+  if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+  *n_out = (size_t)last_pos + last_head;
+  return hipGetLastError();
+}
+
 void map_scratch_free(MapBuildScratch& S) {
   if (S.cub_tmp) hipFree(S.cub_tmp);
   if (S.keys_in) { hipFree(S.keys_in); hipFree(S.keys_out); hipFree(S.vals_in); hipFree(S.vals_out); }

@@ -42,7 +42,8 @@ static Config to_config(const flimo_loc_cfg* c) {
   cfg.filters.crop_active = c->crop_active != 0;
   cfg.filters.cropBoxMin.assign(c->cropBoxMin, c->cropBoxMin + 3);
   cfg.filters.cropBoxMax.assign(c->cropBoxMax, c->cropBoxMax + 3);
-  cfg.filters.voxel_active = false;
+  cfg.filters.voxel_active = c->voxel_active != 0;
+  cfg.filters.leafSize = {c->leaf_size, c->leaf_size, c->leaf_size};
   cfg.filters.dist_active = c->dist_active != 0;
   cfg.filters.min_dist = c->min_dist;
   cfg.filters.rate_active = c->rate_active != 0;
@@ -50,7 +51,10 @@ static Config to_config(const flimo_loc_cfg* c) {
   cfg.filters.fov_active = c->fov_active != 0;
   cfg.filters.fov_angle = c->fov_angle;
   cfg.sensor_type = c->sensor_type;
-  cfg.gravity_align = cfg.calibrate_accel = cfg.calibrate_gyro = false;
+  cfg.gravity_align = c->gravity_align != 0;
+  cfg.calibrate_accel = c->calibrate_accel != 0;
+  cfg.calibrate_gyro = c->calibrate_gyro != 0;
+  cfg.imu_calib_time = c->imu_calib_time;
   cfg.debug = false;
   cfg.verbose = false;
   cfg.gpu_device = c->gpu_device;

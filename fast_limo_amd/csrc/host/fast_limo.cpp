@@ -305,11 +305,6 @@ void Localizer::init(Config& cfg) {                                // Localizer.
   if (!(config.gravity_align || config.calibrate_accel || config.calibrate_gyro)) {   // :92-95
     imu_calibrated_ = true;
     init_iKFoM_state();
-  } else {
-    // the stand-still IMU calibration (Localizer.cpp:411-509) is not part of this
-    // round; a config that asks for it is reported instead of silently mis-initialised.
-    std::cout << "FAST_LIMO::WARNING: automatic IMU calibration is not implemented in the MI355X build; "
-                 "set calibration/{gravity_align,accel,gyro} to false\n";
   }
   imu_calib_time_ = config.imu_calib_time;
 }
@@ -470,11 +465,62 @@ void Localizer::propagateImu(const IMUmeas& imu) {                 // Localizer.
   last_propagate_time_ = imu.stamp;
 }
 
+// IMU calibration while the robot stands still (Localizer.cpp:411-493): average gyro / accel for
+// imu_calib_time_, then gravity-align the attitude (Quaternionf::FromTwoVectors), derive the biases and
+// seed the filter state.
+void Localizer::calibrateStandStill(const IMUmeas& imu) {
+  if ((imu.stamp - first_imu_stamp) < imu_calib_time_) {
+    calib_n_++;
+    for (int i = 0; i < 3; i++) { calib_gyro_(i) += imu.ang_vel(i); calib_accel_(i) += imu.lin_accel(i); }
+    return;
+  }
+  const float nf = (float)calib_n_;                      // `gyro_avg /= num_samples` (int -> float)
+  Eigen::Vector3f gyro_avg(calib_gyro_(0) / nf, calib_gyro_(1) / nf, calib_gyro_(2) / nf);
+  Eigen::Vector3f accel_avg(calib_accel_(0) / nf, calib_accel_(1) / nf, calib_accel_(2) / nf);
+  Eigen::Vector3f grav_vec(0.f, 0.f, gravity_);
+  state.q = imu.q;
+  if (config.gravity_align) {
+    // grav_vec = (accel_avg - b.accel).normalized() * |g|
+    Eigen::Vector3f d(accel_avg(0) - state.b.accel(0), accel_avg(1) - state.b.accel(1), accel_avg(2) - state.b.accel(2));
+    const float dn = std::sqrt(s3(d(0) * d(0), d(1) * d(1), d(2) * d(2)));
+    const float ag = std::fabs(gravity_);
+    grav_vec = Eigen::Vector3f(d(0) / dn * ag, d(1) / dn * ag, d(2) / dn * ag);
+    // Eigen::Quaternionf::FromTwoVectors(grav_vec, (0,0,g))  (Eigen/src/Geometry/Quaternion.h setFromTwoVectors)
+    const float gn = std::sqrt(s3(grav_vec(0) * grav_vec(0), grav_vec(1) * grav_vec(1), grav_vec(2) * grav_vec(2)));
+    const Eigen::Vector3f v0(grav_vec(0) / gn, grav_vec(1) / gn, grav_vec(2) / gn);
+    const float zn = std::sqrt(s3(0.f, 0.f, gravity_ * gravity_));
+    const Eigen::Vector3f v1(0.f / zn, 0.f / zn, gravity_ / zn);
+    const float c = s3(v1(0) * v0(0), v1(1) * v0(1), v1(2) * v0(2));
+    if (c < -1.0f + 1e-5f) {
+      // opposite vectors: Eigen falls back to an SVD to pick an axis; not reproduced (robot upside down)
+      std::cout << "FAST_LIMO::WARNING: gravity points opposite to +z, attitude left unaligned\n";
+    } else {
+      const Eigen::Vector3f axis = cross(v0, v1);
+      const float sq = std::sqrt((1.0f + c) * 2.0f);
+      const float invs = 1.0f / sq;
+      state.q = Eigen::Quaternionf(sq * 0.5f, axis(0) * invs, axis(1) * invs, axis(2) * invs);
+    }
+    state.g = grav_vec;
+  }
+  if (config.calibrate_accel)
+    state.b.accel = Eigen::Vector3f(accel_avg(0) - grav_vec(0), accel_avg(1) - grav_vec(1), accel_avg(2) - grav_vec(2));
+  if (config.calibrate_gyro) state.b.gyro = gyro_avg;
+  {
+    const float qn = std::sqrt(state.q.x() * state.q.x() + state.q.y() * state.q.y() + state.q.z() * state.q.z() + state.q.w() * state.q.w());
+    state.q = Eigen::Quaternionf(state.q.w() / qn, state.q.x() / qn, state.q.y() / qn, state.q.z() / qn);
+  }
+  init_iKFoM_state();
+  imu_calibrated_ = true;
+}
+
 void Localizer::updateIMU(IMUmeas& raw_imu) {                      // Localizer.cpp:401-531
   imu_stamp = raw_imu.stamp;
   IMUmeas imu = imu2baselink(raw_imu);
   if (first_imu_stamp == 0.0) first_imu_stamp = imu.stamp;
-  if (!imu_calibrated_) return;        // stand-still calibration: SURVEY.md 8 f-3, not in this round
+  if (!imu_calibrated_) {              // stand-still calibration (Localizer.cpp:411-509)
+    calibrateStandStill(imu);
+    return;
+  }
   const Eigen::Vector3f sm = mat3_mul(imu_accel_sm_, imu.lin_accel);
   imu.lin_accel = Eigen::Vector3f(sm(0) - state.b.accel(0), sm(1) - state.b.accel(1), sm(2) - state.b.accel(2));
   imu.ang_vel = Eigen::Vector3f(imu.ang_vel(0) - state.b.gyro(0), imu.ang_vel(1) - state.b.gyro(1), imu.ang_vel(2) - state.b.gyro(2));
@@ -635,12 +681,6 @@ void Localizer::updatePointCloud(pcl::PointCloud<PointType>::Ptr& raw_pc, double
   if (!raw_pc || raw_pc->points.size() < 1) { std::cout << "FAST_LIMO::Raw PointCloud is empty!\n"; last_status_ = -1; return; }
   if (!imu_calibrated_) { last_status_ = -2; return; }
   if (imu_buffer.empty()) { std::cout << "FAST_LIMO::IMU buffer is empty!\n"; last_status_ = -3; return; }
-  if (config.filters.voxel_active) {
-    // the PCL VoxelGrid stage is not part of this round
-    std::cout << "FAST_LIMO::ERROR: filters/voxelGrid is not implemented in the MI355X build (set it to false)\n";
-    last_status_ = -4;
-    return;
-  }
   // removeNaNFromPointCloud (:263-265) -- in place, as the reference mutates *raw_pc
   {
     std::vector<PointType>& P = raw_pc->points;
@@ -678,8 +718,22 @@ void Localizer::updatePointCloud(pcl::PointCloud<PointType>::Ptr& raw_pc, double
   }
   if (config.debug) original_scan = std::make_shared<pcl::PointCloud<PointType>>(*input_pc);
   const double t1 = now_s();
-  const bool ok = deskewPointCloud(input_pc, time_stamp);
+  bool ok = deskewPointCloud(input_pc, time_stamp);
   if (!ok) pc2match = std::make_shared<pcl::PointCloud<PointType>>();
+  if (ok && config.filters.voxel_active && map_->ctx()) {          // VoxelGrid (:313-321) on the GPU
+    size_t nv = 0;
+    const int rc = flimo_scan_voxel_filter(map_->ctx(), config.filters.leafSize[0], &nv);
+    if (rc != FLIMO_OK) { std::cout << "FAST_LIMO::voxel filter failed: " << flimo_last_error(map_->ctx()) << "\n"; ok = false; }
+    else if (download_clouds) {
+      std::vector<float> xyz(nv * 3);
+      size_t m = 0;
+      flimo_scan_get(map_->ctx(), xyz.data(), nv, &m);
+      auto vox = std::make_shared<pcl::PointCloud<PointType>>();
+      vox->points.resize(nv);
+      for (size_t k = 0; k < nv; k++) { vox->points[k].x = xyz[3 * k]; vox->points[k].y = xyz[3 * k + 1]; vox->points[k].z = xyz[3 * k + 2]; }
+      pc2match = vox;
+    }
+  }
   const double t2 = now_s();
   double t3 = t2, t4 = t2;
   flimo_ctx* c = map_->ctx();

@@ -71,6 +71,7 @@ class fast_limo::Localizer {
   void init_iKFoM();
   void init_iKFoM_state();
   IMUmeas imu2baselink(IMUmeas& imu);
+  void calibrateStandStill(const IMUmeas& imu);
   bool deskewPointCloud(pcl::PointCloud<PointType>::Ptr& pc, double& start_time);
   bool propagatedFromTimeRange(double start_time, double end_time, States& frames);
   bool isInRange(const PointType& p);
@@ -100,6 +101,8 @@ class fast_limo::Localizer {
   Eigen::Vector3f ang_vel_cg_prev_;
   std::vector<flimo_frame> rs_frames_;  // frames of the resident raw scan
   float rs_l2b_[16];
+  int calib_n_ = 0;
+  Eigen::Vector3f calib_gyro_, calib_accel_;
   int last_status_;
   double stage_t_[4];
   float cpu_time, cpu_max_time, cpu_mean_time;

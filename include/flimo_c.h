@@ -102,6 +102,10 @@ size_t flimo_scan_size(const flimo_ctx* ctx);
 /* copy the resident scan back (packed xyz) */
 int flimo_scan_get(flimo_ctx* ctx, float* xyz_out, size_t cap, size_t* n);
 
+/* ---- voxel-grid filter on the resident scan: replaces pcl::VoxelGrid in Localizer::updatePointCloud
+ *      (Modules/Localizer.cpp:313-321): centroid per occupied voxel, ascending voxel index ---- */
+int flimo_scan_voxel_filter(flimo_ctx* ctx, float leaf_size, size_t* n_out);
+
 /* ---- deskew: replaces the OpenMP loop of Localizer::deskewPointCloud
  *      (Modules/Localizer.cpp:820-843) incl. State::update (Objects/State.cpp:76-119) and
  *      binary_search_tailored (Utils/Algorithms.hpp:25-38).  Input: time-sorted LiDAR-frame points

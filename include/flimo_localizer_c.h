@@ -28,12 +28,16 @@ typedef struct flimo_loc_cfg {
   float imu2baselink_t[3], imu2baselink_R[9];
   float lidar2baselink_t[3], lidar2baselink_R[9];
   float accel_bias[3], gyro_bias[3], imu_sm[9];
-  /* filters (Config::Filters); voxel grid is not available in this build */
+  /* filters (Config::Filters) */
+  int voxel_active; float leaf_size;
   int crop_active; float cropBoxMin[3], cropBoxMax[3];
   int dist_active; double min_dist;
   int rate_active; int rate_value;
   int fov_active; float fov_angle;
   int sensor_type;
+  /* IMU stand-still calibration (Config flags, Modules/Localizer.cpp:411-509) */
+  int gravity_align, calibrate_accel, calibrate_gyro;
+  double imu_calib_time;
   /* MI355X additions */
   int gpu_device;
   float gpu_cell_size;

@@ -33,6 +33,12 @@ static LocCfg to_loc_cfg(const oracle_cfg* c) {
     L.lidar2baselink_R[i] = c->lidar2baselink_R[i];
     L.imu_sm[i] = c->imu_sm[i];
   }
+  L.gravity_align = c->gravity_align != 0;
+  L.calibrate_accel = c->calibrate_accel != 0;
+  L.calibrate_gyro = c->calibrate_gyro != 0;
+  L.imu_calib_time = c->imu_calib_time;
+  L.voxel_active = c->voxel_active != 0;
+  L.leaf_size = c->leaf_size;
   return L;
 }
 
@@ -99,6 +105,14 @@ void oracle_plane_fit(const float* nbr_xyz, const float* sqd, int n_nbr, int k, 
   bool ok = false;
   plane_from_neighbors(n_nbr, nb, sqd, cfg, n_out, ok);
   *is_plane = ok ? 1 : 0;
+}
+
+size_t oracle_voxel_grid(const float* xyz, size_t n, float leaf, float* out, size_t cap) {
+  std::vector<Pt> in(n);
+  for (size_t i = 0; i < n; i++) { in[i].x = xyz[3 * i]; in[i].y = xyz[3 * i + 1]; in[i].z = xyz[3 * i + 2]; in[i].intensity = 0; in[i].time = 0; }
+  std::vector<Pt> o = voxel_grid(in, leaf);
+  for (size_t i = 0; i < o.size() && i < cap; i++) { out[3 * i] = o[i].x; out[3 * i + 1] = o[i].y; out[3 * i + 2] = o[i].z; }
+  return o.size();
 }
 
 void oracle_pose_mats(const double x26[26], float RT[16], float RT_inv[16], float TLI_inv[16], float R_inv[9],

@@ -27,6 +27,10 @@ typedef struct oracle_cfg {
   float imu2baselink_t[3], imu2baselink_R[9];
   float lidar2baselink_t[3], lidar2baselink_R[9];
   float accel_bias[3], gyro_bias[3], imu_sm[9];
+  int gravity_align, calibrate_accel, calibrate_gyro;
+  double imu_calib_time;
+  int voxel_active;
+  float leaf_size;
 } oracle_cfg;
 
 /* per scan-point record of Mapper::match (before compaction) */
@@ -53,6 +57,9 @@ long long oracle_octree_knn(void* t, const float* q_xyz, size_t nq, int k, float
 /* ---- plane fit (reference Objects/Plane.cpp) ---- */
 void oracle_plane_fit(const float* nbr_xyz, const float* sqd, int n_nbr, int k, double max_dist_plane,
                       double plane_threshold, float n_out[4], int* is_plane);
+
+/* ---- pcl::VoxelGrid restatement: in n x 3, out cap x 3; returns the number of voxels ---- */
+size_t oracle_voxel_grid(const float* xyz, size_t n, float leaf, float* out, size_t cap);
 
 /* ---- state helpers ---- */
 /* x26 = pos3 rot(xyzw) offR(xyzw) offT3 vel3 bg3 ba3 grav3.  Outputs State(x).get_RT(), get_RT_inv(),

@@ -33,6 +33,9 @@ class OracleCfg(C.Structure):
         ("imu2baselink_t", C.c_float * 3), ("imu2baselink_R", C.c_float * 9),
         ("lidar2baselink_t", C.c_float * 3), ("lidar2baselink_R", C.c_float * 9),
         ("accel_bias", C.c_float * 3), ("gyro_bias", C.c_float * 3), ("imu_sm", C.c_float * 9),
+        ("gravity_align", C.c_int), ("calibrate_accel", C.c_int), ("calibrate_gyro", C.c_int),
+        ("imu_calib_time", C.c_double),
+        ("voxel_active", C.c_int), ("leaf_size", C.c_float),
     ]
 
 
@@ -59,6 +62,9 @@ def default_cfg(**kw) -> OracleCfg:
         c.LIMITS[i] = 1e-3
     c.cov_gyro, c.cov_acc, c.cov_bias_gyro, c.cov_bias_acc = 6e-4, 1e-2, 1e-5, 3e-4
     c.time_offset, c.end_of_sweep, c.num_threads = 1, 0, 10
+    c.gravity_align = c.calibrate_accel = c.calibrate_gyro = 0
+    c.imu_calib_time = 3.0
+    c.voxel_active, c.leaf_size = 0, 0.25
     eye = [1, 0, 0, 0, 1, 0, 0, 0, 1]
     for i in range(9):
         c.imu2baselink_R[i] = eye[i]
@@ -98,6 +104,8 @@ def lib():
     L.oracle_octree_points.argtypes = [vp, f32p, C.c_size_t]
     L.oracle_octree_knn.restype = C.c_longlong
     L.oracle_octree_knn.argtypes = [vp, f32p, C.c_size_t, C.c_int, f32p, f32p, i32p, C.c_int]
+    L.oracle_voxel_grid.restype = C.c_size_t
+    L.oracle_voxel_grid.argtypes = [f32p, C.c_size_t, C.c_float, f32p, C.c_size_t]
     L.oracle_plane_fit.argtypes = [f32p, f32p, C.c_int, C.c_int, C.c_double, C.c_double, f32p, C.POINTER(C.c_int)]
     L.oracle_pose_mats.argtypes = [f64p, f32p, f32p, f32p, f32p, f32p]
     L.oracle_state_boxplus.argtypes = [f64p, f64p]
@@ -173,6 +181,13 @@ class Octree:
         cnt = np.empty((nq,), dtype=np.int32)
         evals = lib().oracle_octree_knn(self._h, q, nq, k, nbr, sqd, cnt, num_threads)
         return nbr, sqd, cnt, int(evals)
+
+
+def voxel_grid(xyz, leaf):
+    xyz = _f32(xyz).reshape(-1, 3)
+    out = np.empty((max(xyz.shape[0], 1), 3), np.float32)
+    n = lib().oracle_voxel_grid(xyz, xyz.shape[0], float(leaf), out, xyz.shape[0])
+    return out[:n]
 
 
 def plane_fit(nbr, sqd, k=5, max_dist_plane=2.0, plane_threshold=0.05):

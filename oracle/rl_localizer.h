@@ -21,6 +21,8 @@
 #include <deque>
 #include <algorithm>
 #include <cstdio>
+#include <cfloat>
+#include <climits>
 #include <omp.h>
 #include "rl_linalg.h"
 #include "rl_octree.h"
@@ -58,6 +60,10 @@ struct LocCfg {                     // the subset of fast_limo::Config the hot p
   float accel_bias[3] = {0, 0, 0};
   float gyro_bias[3] = {0, 0, 0};
   float imu_sm[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  bool gravity_align = false, calibrate_accel = false, calibrate_gyro = false;
+  double imu_calib_time = 3.0;
+  bool voxel_active = false;
+  float leaf_size = 0.25f;
   LocCfg() { for (int i = 0; i < NDOF; i++) LIMITS[i] = 1e-3; }
 };
 
@@ -143,6 +149,56 @@ struct State {
   }
   M4f get_extr_RT_inv() const { return inv_from(qLI, pLI); }
 };
+
+// ---- pcl::VoxelGrid (Localizer.cpp:313-321; PCL 1.10 filters/impl/voxel_grid.hpp, restated from its
+// documented algorithm -- PCL is not available here): one output point per occupied voxel = centroid
+// of its points (float accumulation), output ordered by ascending linear voxel index
+// idx = i + j*div_x + k*div_x*div_y.  PCL sorts (idx, point) pairs with std::sort, which leaves the
+// order INSIDE a voxel unspecified; the restatement fixes it to ascending point index.
+inline std::vector<Pt> voxel_grid(const std::vector<Pt>& in, float leaf) {
+  std::vector<Pt> out;
+  if (in.empty()) return out;
+  const float inv = 1.0f / leaf;
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (const Pt& p : in) {
+    if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z)) continue;
+    mn[0] = std::min(mn[0], p.x); mn[1] = std::min(mn[1], p.y); mn[2] = std::min(mn[2], p.z);
+    mx[0] = std::max(mx[0], p.x); mx[1] = std::max(mx[1], p.y); mx[2] = std::max(mx[2], p.z);
+  }
+  int min_b[3], max_b[3], div_b[3];
+  for (int a = 0; a < 3; a++) {
+    min_b[a] = (int)std::floor(mn[a] * inv);
+    max_b[a] = (int)std::floor(mx[a] * inv);
+    div_b[a] = max_b[a] - min_b[a] + 1;
+  }
+  const long long cells = (long long)div_b[0] * div_b[1] * div_b[2];
+  if (cells > (long long)INT_MAX) return in;          // PCL warns and returns the input unchanged
+  const int mul1 = div_b[0], mul2 = div_b[0] * div_b[1];
+  std::vector<std::pair<int, int>> iv;
+  iv.reserve(in.size());
+  for (int i = 0; i < (int)in.size(); i++) {
+    const Pt& p = in[i];
+    if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z)) continue;
+    const int i0 = (int)(std::floor(p.x * inv) - (float)min_b[0]);
+    const int i1 = (int)(std::floor(p.y * inv) - (float)min_b[1]);
+    const int i2 = (int)(std::floor(p.z * inv) - (float)min_b[2]);
+    iv.push_back(std::make_pair(i0 + i1 * mul1 + i2 * mul2, i));
+  }
+  std::stable_sort(iv.begin(), iv.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first < b.first; });
+  size_t f = 0;
+  while (f < iv.size()) {
+    size_t l = f + 1;
+    while (l < iv.size() && iv[l].first == iv[f].first) l++;
+    float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
+    for (size_t k = f; k < l; k++) { const Pt& p = in[iv[k].second]; sx += p.x; sy += p.y; sz += p.z; si += p.intensity; }
+    const float n = (float)(l - f);
+    Pt o;
+    o.x = sx / n; o.y = sy / n; o.z = sz / n; o.intensity = si / n; o.time = 0.f;
+    out.push_back(o);
+    f = l;
+  }
+  return out;
+}
 
 // ---- Plane + Match ----------------------------------------------------------------------
 struct MatchRec {
@@ -321,6 +377,9 @@ struct Localizer {
   std::deque<State> propagated_buffer;
   std::vector<Pt> pc2match;                // body frame @ Xt2
   std::vector<Pt> final_scan;              // world frame
+  double first_imu_stamp = 0.0, imu_calib_time_ = 3.0;
+  int calib_n = 0;
+  V3f calib_gyro, calib_accel;
   bool have_prev_ang = false;
   V3f ang_vel_cg_prev;
   // instrumentation
@@ -356,9 +415,11 @@ struct Localizer {
     }
     imu2baselink_T.m[0][3] = imu2baselink_.t.x; imu2baselink_T.m[1][3] = imu2baselink_.t.y; imu2baselink_T.m[2][3] = imu2baselink_.t.z;
     lidar2baselink_T.m[0][3] = lidar2baselink_.t.x; lidar2baselink_T.m[1][3] = lidar2baselink_.t.y; lidar2baselink_T.m[2][3] = lidar2baselink_.t.z;
-    // no automatic calibration in the restatement (:92-95)
-    imu_calibrated_ = true;
-    init_iKFoM_state();
+    if (!(config.gravity_align || config.calibrate_accel || config.calibrate_gyro)) {   // :92-95
+      imu_calibrated_ = true;
+      init_iKFoM_state();
+    }
+    imu_calib_time_ = config.imu_calib_time;
   }
 
   void init_iKFoM_state() {                                      // Localizer.cpp:672-694
@@ -425,7 +486,41 @@ struct Localizer {
   void updateIMU(const IMUmeas& raw) {                           // Localizer.cpp:401-531 (calibrated branch)
     imu_stamp = raw.stamp;
     IMUmeas imu = imu2baselink(raw);
-    if (!imu_calibrated_) return;
+    if (first_imu_stamp == 0.0) first_imu_stamp = imu.stamp;
+    if (!imu_calibrated_) {                                        // Localizer.cpp:411-493
+      if ((imu.stamp - first_imu_stamp) < imu_calib_time_) {
+        calib_n++;
+        calib_gyro = calib_gyro + imu.ang_vel;
+        calib_accel = calib_accel + imu.lin_accel;
+        return;
+      }
+      V3f gyro_avg = calib_gyro / (float)calib_n, accel_avg = calib_accel / (float)calib_n;
+      V3f grav_vec(0.f, 0.f, (float)gravity_);
+      state.q = imu.q;
+      if (config.gravity_align) {
+        V3f d = accel_avg - state.baccel;
+        grav_vec = std::fabs((float)gravity_) * (d / norm3(d));          // normalized() * abs(g)
+        // Quaternionf::FromTwoVectors(grav_vec, (0,0,g))
+        V3f v0 = grav_vec / norm3(grav_vec);
+        V3f zz(0.f, 0.f, (float)gravity_);
+        V3f v1 = zz / norm3(zz);
+        float c = dot3(v1, v0);
+        if (!(c < -1.0f + 1e-5f)) {
+          V3f axis = cross3(v0, v1);
+          float sq = std::sqrt((1.0f + c) * 2.0f);
+          float invs = 1.0f / sq;
+          state.q = Quatf(sq * 0.5f, axis.x * invs, axis.y * invs, axis.z * invs);
+        }
+        state.g = grav_vec;
+      }
+      if (config.calibrate_accel) state.baccel = accel_avg - grav_vec;
+      if (config.calibrate_gyro) state.bgyro = gyro_avg;
+      float qn = std::sqrt(state.q.x * state.q.x + state.q.y * state.q.y + state.q.z * state.q.z + state.q.w * state.q.w);
+      state.q.x /= qn; state.q.y /= qn; state.q.z /= qn; state.q.w /= qn;
+      init_iKFoM_state();
+      imu_calibrated_ = true;
+      return;
+    }
     V3f sm_a = mul(imu_accel_sm_, imu.lin_accel);
     imu.lin_accel = sm_a - state.baccel;
     imu.ang_vel = imu.ang_vel - state.bgyro;
@@ -515,7 +610,8 @@ struct Localizer {
     deskew(input, time_stamp, deskewed);
     double t1 = omp_get_wtime();
     t_deskew = t1 - t0;
-    pc2match = deskewed;                                         // voxel filter off :313-321
+    if (config.voxel_active) pc2match = voxel_grid(deskewed, config.leaf_size);   // :313-321
+    else pc2match = deskewed;
     int rc = 0;
     if (pc2match.size() > 1) {
       ikfom.update_iterated_dyn_share_modified(0.001, 5.0);      // :333

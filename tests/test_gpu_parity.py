@@ -242,3 +242,65 @@ def test_sequence_with_map_insert_matches_oracle(built, oracle):
     assert G.map_size() > 3000
     np.testing.assert_allclose(sort_rows(G.final_scan()), sort_rows(Lo.final_scan()), atol=1e-6)
     G.close()
+
+
+def test_voxel_filter_bit_exact(hip, oracle):
+    """GPU voxel grid == oracle restatement of pcl::VoxelGrid (centroids and output order), incl. NaNs."""
+    scan = np.ascontiguousarray(synth.velodyne_scan(32, 512, 50.0, 9)[:, :3])
+    scan[5] = [np.nan, 1, 2]
+    for leaf in (0.25, 1.0, 0.1):
+        hip.scan_set(scan)
+        n = hip.scan_voxel_filter(leaf)
+        got = hip.scan_get()
+        ref = oracle.voxel_grid(scan, leaf)
+        assert n == ref.shape[0] == got.shape[0] and 0 < n < scan.shape[0]
+        np.testing.assert_array_equal(got, ref)
+
+
+def test_localizer_with_voxel_filter_matches_oracle(built, oracle):
+    from fast_limo_amd import api
+    mp, scan5, imu = cfg1_scene()
+    kw = dict(voxel_active=1, leaf_size=0.5, **CAPS)
+    G = api.Localizer(api.default_cfg(**kw)); G.set_flags(add_to_map=False)
+    Lo = oracle.Localizer(oracle.default_cfg(num_threads=1, **kw))
+
+    class W:
+        def map_add(self, m): Lo.map_add(m)
+        def update_imu(self, *a): Lo.update_imu(*a)
+        def update_pointcloud(self, p, s): return Lo.update_pointcloud(p, s, add_to_map=False)
+    assert drive_two_scans(G, mp, scan5, imu) == [1, 0]
+    assert drive_two_scans(W(), mp, scan5, imu) == [1, 0]
+    np.testing.assert_array_equal(G.pc2match(), Lo.pc2match())
+    assert G.pc2match().shape[0] < scan5.shape[0]
+    dpos, ang = pose_delta(G.get_x(), Lo.get_x())
+    assert dpos < 1e-4 and ang < 1e-4, (dpos, ang)
+    G.close()
+
+
+def test_imu_stand_still_calibration_matches_oracle(built, oracle):
+    """gravity alignment + bias estimation (Localizer.cpp:411-493), then a registration."""
+    from fast_limo_amd import api
+    import math
+    kw = dict(gravity_align=1, calibrate_accel=1, calibrate_gyro=1, imu_calib_time=0.2, **CAPS)
+    G = api.Localizer(api.default_cfg(**kw)); G.set_flags(add_to_map=False)
+    Lo = oracle.Localizer(oracle.default_cfg(num_threads=1, **kw))
+    R = synth.rpy_to_R(math.radians(2.0), math.radians(-1.5), 0.0)
+    acc = (R.T @ np.array([0, 0, 9.81])).astype(np.float32) + np.float32([0.02, -0.01, 0.03])
+    gyr = np.float32([0.001, -0.002, 0.0005])
+    rs = np.random.RandomState(3)
+    mp, scan5, _ = cfg1_scene(n_map=20000, n_scan=2048)
+    G.map_add(mp); Lo.map_add(mp)
+    t = 1.0
+    for k in range(120):
+        a = acc + rs.normal(0, 0.01, 3).astype(np.float32); w = gyr + rs.normal(0, 1e-4, 3).astype(np.float32)
+        G.update_imu(t, w, a); Lo.update_imu(t, w, a)
+        if k == 30:
+            assert G.update_pointcloud(scan5, t - 0.1) == -2          # not calibrated yet: early return
+        t += 0.005
+    xg, xo = G.get_x(), Lo.get_x()
+    np.testing.assert_allclose(xg, xo, rtol=0, atol=1e-12)             # same calibration result
+    assert np.abs(xg[17:20] - gyr).max() < 1e-4                        # gyro bias recovered
+    assert np.abs(xg[3:7] - [0, 0, 0, 1]).max() > 1e-3                 # attitude was gravity-aligned
+    rg = G.update_pointcloud(scan5, t - 0.105); ro = Lo.update_pointcloud(scan5, t - 0.105, add_to_map=False)
+    assert rg == ro
+    G.close()
