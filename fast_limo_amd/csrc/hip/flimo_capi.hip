@@ -17,6 +17,7 @@
 #include "flimo_types.h"
 #include "flimo_kernels.h"
 #include "flimo_insert.h"
+#include "flimo_gbook.h"
 
 #pragma clang fp contract(off)
 
@@ -42,7 +43,11 @@ struct flimo_ctx {
   double map_last_time = -1.0;
   float bb[6] = {3.4e38f, 3.4e38f, 3.4e38f, -3.4e38f, -3.4e38f, -3.4e38f};   // bounding box of the stored points
   MapBuildScratch scratch;
-  InsertBook* book = nullptr;      // reference insert rule (flimo_insert.h)
+  InsertBook* book = nullptr;      // reference insert rule, host build of the FIRST batch (flimo_insert.h)
+  GBook gbook;                     // the same tree on the device: every later batch is decided there
+  float4* d_batch = nullptr;       // staging for host-supplied later batches
+  size_t batch_cap = 0;
+  bool host_insert = false;        // FLIMO_HOST_INSERT=1: keep using the host book (A/B checks only)
   // scan
   float4* d_scan = nullptr;        // pc2match (body frame), caller order
   float4* d_scan_sorted = nullptr; // the same points in Morton order, w = original index
@@ -239,6 +244,8 @@ extern "C" int flimo_ctx_create(int device, flimo_ctx** out) {
   const char* e = getenv("FLIMO_LPQ");
   if (e) { int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) c->lanes_per_query = v; }
   c->book = insert_book_create();
+  e = getenv("FLIMO_HOST_INSERT");
+  c->host_insert = e && atoi(e) != 0;
   *out = c;
   return FLIMO_OK;
 }
@@ -261,6 +268,8 @@ extern "C" void flimo_ctx_destroy(flimo_ctx* c) {
   if (c->h_wl_count) (void)hipHostFree(c->h_wl_count);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->book) insert_book_destroy(c->book);
+  c->gbook.release();
+  (void)hipFree(c->d_batch);
   delete c;
 }
 
@@ -281,6 +290,7 @@ extern "C" int flimo_map_clear(flimo_ctx* c) {
   c->map_last_time = -1.0;
   c->bb[0] = c->bb[1] = c->bb[2] = 3.4e38f; c->bb[3] = c->bb[4] = c->bb[5] = -3.4e38f;
   insert_book_clear(c->book);
+  c->gbook.active = false;
   return FLIMO_OK;
 }
 
@@ -355,6 +365,46 @@ static int map_append_host(flimo_ctx* c, const float4* pts, size_t n) {
   return FLIMO_OK;
 }
 
+// Octree::update for a batch that already lives on the device (m points, NaNs allowed): the device
+// book decides keep / drop, the kept points are appended in batch order, the grid is rebuilt.
+static int map_add_device(flimo_ctx* c, const float4* d_pts, size_t m, double stamp) {
+  if (m == 0) return FLIMO_OK;
+  if (c->map_n + m > 0x7fff0000ull) return fail(c, FLIMO_ERR_TOO_LARGE, "map would exceed 2^31 points");
+  float bb[6];
+  bool any = false;
+  HIPCHK(c, batch_bbox(c->stream, d_pts, m, c->scratch, bb, &any));
+  if (any) {
+    const size_t old_cap = c->map_cap;
+    int rc = ensure_dev(c, c->d_map_raw, c->map_cap, c->map_n + m, true, c->map_n);
+    if (rc) return rc;
+    if (c->map_cap != old_cap && c->d_map_sorted) { (void)hipFree(c->d_map_sorted); c->d_map_sorted = nullptr; }
+    int kept = 0;
+    HIPCHK(c, c->gbook.update(c->stream, d_pts, (int)m, bb, c->d_map_raw, (int)c->map_n, &kept, c->scratch));
+    c->map_n += (size_t)kept;
+    if (kept > 0) {
+      // the kept points lie inside the batch box: a superset box only makes the dense grid a little larger
+      for (int a = 0; a < 3; a++) { if (bb[a] < c->bb[a]) c->bb[a] = bb[a]; if (bb[3 + a] > c->bb[3 + a]) c->bb[3 + a] = bb[3 + a]; }
+      rc = rebuild_grid(c);
+      if (rc) return rc;
+    }
+  }
+  c->map_last_time = stamp;
+  return FLIMO_OK;
+}
+
+// hand the host-built tree of the first batch to the device book
+static int gbook_import(flimo_ctx* c) {
+  std::vector<float> c4;
+  std::vector<int> child, cnt;
+  int root = -1;
+  insert_book_export(c->book, c4, child, cnt, &root);
+  if (root < 0) return FLIMO_OK;
+  HIPCHK(c, c->gbook.import_host(c->stream, c4, child, cnt, root, c->d_map_raw, (int)c->map_n, c->map_cfg.min_extent,
+                                 c->map_cfg.downsample != 0));
+  insert_book_clear(c->book);      // the device copy is the book from here on
+  return FLIMO_OK;
+}
+
 extern "C" int flimo_map_add(flimo_ctx* c, const float* xyz, size_t n, size_t stride_bytes, double stamp) {
   if (!c) return FLIMO_ERR_INVALID;
   if (n < 1) return FLIMO_OK;                         // Mapper::add: `if(pc->points.size() < 1) return;`
@@ -363,6 +413,18 @@ extern "C" int flimo_map_add(flimo_ctx* c, const float* xyz, size_t n, size_t st
   int rc = ensure_stage(c, n * sizeof(float4));
   if (rc) return rc;
   float4* st = (float4*)c->h_stage;
+  if (c->gbook.active) {
+    // later batches: Octree::update on the device (flimo_gbook.hip)
+    const unsigned char* b = (const unsigned char*)xyz;
+    for (size_t i = 0; i < n; i++) {
+      const float* p = (const float*)(b + i * stride_bytes);
+      st[i].x = p[0]; st[i].y = p[1]; st[i].z = p[2]; st[i].w = 0.f;
+    }
+    rc = ensure_dev(c, c->d_batch, c->batch_cap, n, false, 0);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_batch, st, n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    return map_add_device(c, c->d_batch, n, stamp);
+  }
   // Octree::processPoints: drop NaNs (Octree.hpp:243-244); then the reference's insert rule decides
   // which points are stored (first batch: all; later batches: Octree::updateOctant semantics).
   std::vector<float> packed;
@@ -390,6 +452,7 @@ extern "C" int flimo_map_add(flimo_ctx* c, const float* xyz, size_t n, size_t st
   rc = rebuild_grid(c);
   if (rc) return rc;
   c->map_last_time = stamp;
+  if (!c->host_insert && c->map_n > 0) return gbook_import(c);
   return FLIMO_OK;
 }
 
@@ -826,6 +889,11 @@ extern "C" int flimo_scan_to_world(flimo_ctx* c, const double x26[26], float* ou
 extern "C" int flimo_map_add_scan(flimo_ctx* c, const double x26[26], double stamp) {
   if (!c || !x26) return FLIMO_ERR_INVALID;
   if (c->scan_n == 0) return FLIMO_OK;
+  if (c->gbook.active) {           // resident path: transform, decide, append and re-index on the device
+    int rc = flimo_scan_to_world(c, x26, nullptr, 0);
+    if (rc) return rc;
+    return map_add_device(c, c->d_scan_world, c->scan_n, stamp);
+  }
   std::vector<float> w(c->scan_n * 3);
   int rc = flimo_scan_to_world(c, x26, w.data(), c->scan_n);
   if (rc) return rc;

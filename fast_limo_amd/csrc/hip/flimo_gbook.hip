@@ -1,0 +1,418 @@
+// fast_limo_amd/csrc/hip/flimo_gbook.hip  -- gfx950 (MI355X) only.
+//
+// GPU-resident bookkeeping of WHICH points the map stores = the reference's incremental octree insert
+// rule (Objects/Octree.hpp:341-432: update / updateOctant / createOctant), reproduced exactly, on the
+// device.  The k-NN index stays the uniform grid; this structure only
+// decides keep / drop and therefore needs, per octree node, its cube (centre, half edge in float32,
+// computed with the reference's arithmetic), its 8 child links and -- for leaves -- the point count;
+// every stored map point remembers its leaf (pt_leaf) so that a splitting leaf can be re-partitioned.
+//
+// One batch (Octree::update) on the device:
+//   route    every incoming point descends from the root to a leaf or to a missing child slot
+//   sort     stable radix sort of the batch by destination (rocPRIM)
+//   decide   one thread per destination group applies updateOctant's rule:
+//              leaf:  n + g > 32 and half > 2*min_extent  -> SPLIT (rebuild that subtree, keep all)
+//                     down-sampling and half <= 2*min_extent and n > 4 -> DROP the whole group
+//                     else APPEND
+//              missing child -> CREATE a subtree from the group (keep all)
+//   compact  kept points are appended to the map in batch order
+//   gather   points already stored in splitting leaves are collected (one pass over pt_leaf)
+//   build    one thread per SPLIT / CREATE item runs createOctant (split while count > 32 and
+//            half > 2*min_extent) on its index list, allocating nodes from the pool
+// The initial batch (Octree::initialize) is built on the host once (flimo_insert.cpp) and exported.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <float.h>
+#include <vector>
+#include "flimo_types.h"
+#include "flimo_kernels.h"
+#include "flimo_gbook.h"
+
+#pragma clang fp contract(off)
+
+namespace flimo {
+
+static const int kBucket = 32;     // effective bucket size of the reference (Octree.hpp:155,178-180)
+
+__device__ __forceinline__ int octant_of(float px, float py, float pz, const float4 c) {   // Octree.hpp:269-275
+  return (px > c.x ? 1 : 0) | (py > c.y ? 2 : 0) | (pz > c.z ? 4 : 0);
+}
+
+// ---- route ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gb_route_kernel(const float4* __restrict__ pts, int n, const float4* __restrict__ node_c,
+                                                       const int* __restrict__ node_child, const int* __restrict__ node_cnt,
+                                                       int root, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = pts[i];
+  int node = root;
+  uint32_t key;
+  if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) {     // Octree::processPoints drops NaNs (:243-244)
+    keys[i] = 0xffffffffu;
+    vals[i] = (uint32_t)i;
+    return;
+  }
+  for (;;) {
+    if (node_cnt[node] >= 0) { key = (uint32_t)node * 9u + 8u; break; }        // leaf
+    const int k = octant_of(p.x, p.y, p.z, node_c[node]);
+    const int ch = node_child[(size_t)node * 8 + k];
+    if (ch < 0) { key = (uint32_t)node * 9u + (uint32_t)k; break; }            // missing child
+    node = ch;
+  }
+  keys[i] = key;
+  vals[i] = (uint32_t)i;
+}
+
+// leaf of every stored point after the host-built tree was exported
+__global__ __launch_bounds__(256) void gb_leafof_kernel(const float4* __restrict__ pts, int n, const float4* __restrict__ node_c,
+                                                        const int* __restrict__ node_child, const int* __restrict__ node_cnt,
+                                                        int root, int* __restrict__ pt_leaf) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = pts[i];
+  int node = root;
+  while (node_cnt[node] < 0) {
+    const int ch = node_child[(size_t)node * 8 + octant_of(p.x, p.y, p.z, node_c[node])];
+    if (ch < 0) { node = -1; break; }       // cannot happen for points the tree was built from
+    node = ch;
+  }
+  pt_leaf[i] = node;
+}
+
+// ---- decide -----------------------------------------------------------------------------------
+struct GbItem {            // one subtree build
+  int node;                // SPLIT: the leaf to rebuild in place; CREATE: parent node
+  int slot;                // CREATE: child slot (0..7); SPLIT: 8
+  int g_begin, g_len;      // group range in the sorted batch
+  int n_old;               // SPLIT: points already in the leaf
+  int seg;                 // start of its index segment in the scratch lists
+};
+
+__global__ __launch_bounds__(256) void gb_decide_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ perm, int n,
+                                                        const float4* __restrict__ node_c, int* __restrict__ node_cnt,
+                                                        float min_half, int downsample, unsigned char* __restrict__ keep,
+                                                        int* __restrict__ assign /* per batch point: leaf or -1-item */,
+                                                        GbItem* __restrict__ items, int* __restrict__ counters /* [0] items, [1] seg cursor */,
+                                                        int* __restrict__ node_item) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t key = keys[i];
+  if (i > 0 && keys[i - 1] == key) return;            // not a group head
+  int g = 1;
+  while (i + g < n && keys[i + g] == key) g++;
+  if (key == 0xffffffffu) {                                  // non-finite points: never stored
+    for (int j = 0; j < g; j++) { keep[perm[i + j]] = 0; assign[perm[i + j]] = -1; }
+    return;
+  }
+  const int node = (int)(key / 9u), slot = (int)(key % 9u);
+  if (slot == 8) {
+    const int cnt = node_cnt[node];
+    const float half = node_c[node].w;
+    if (cnt + g > kBucket && half > 2 * min_half) {                      // SPLIT (Octree.hpp:385-395)
+      const int it = atomicAdd(&counters[0], 1);
+      const int seg = atomicAdd(&counters[1], cnt + g);
+      items[it] = GbItem{node, 8, i, g, cnt, seg};
+      node_item[node] = it;
+      for (int j = 0; j < g; j++) { keep[perm[i + j]] = 1; assign[perm[i + j]] = -1 - it; }
+    } else if (downsample && half <= 2 * min_half && cnt > kBucket / 8) {   // DROP (:399-401)
+      for (int j = 0; j < g; j++) { keep[perm[i + j]] = 0; assign[perm[i + j]] = node; }
+    } else {                                                             // APPEND (:403-404)
+      node_cnt[node] = cnt + g;
+      for (int j = 0; j < g; j++) { keep[perm[i + j]] = 1; assign[perm[i + j]] = node; }
+    }
+  } else {                                                               // CREATE (:418-426)
+    const int it = atomicAdd(&counters[0], 1);
+    const int seg = atomicAdd(&counters[1], g);
+    items[it] = GbItem{node, slot, i, g, 0, seg};
+    for (int j = 0; j < g; j++) { keep[perm[i + j]] = 1; assign[perm[i + j]] = -1 - it; }
+  }
+}
+
+// ---- compact: append the kept batch points to the map in batch order ---------------------------
+__global__ __launch_bounds__(256) void gb_flags_kernel(const unsigned char* __restrict__ keep, int n, uint32_t* __restrict__ f) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) f[i] = keep[i] ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void gb_append_kernel(const float4* __restrict__ batch, const unsigned char* __restrict__ keep,
+                                                        const uint32_t* __restrict__ rank, const int* __restrict__ assign, int n,
+                                                        int map_n, float4* __restrict__ map_raw, int* __restrict__ pt_leaf,
+                                                        int* __restrict__ new_index /* per batch point or -1 */) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (!keep[i]) { new_index[i] = -1; return; }
+  const int gi = map_n + (int)rank[i];
+  float4 p = batch[i];
+  p.w = __uint_as_float((uint32_t)gi);
+  map_raw[gi] = p;
+  pt_leaf[gi] = assign[i] >= 0 ? assign[i] : -1;      // SPLIT / CREATE members get their leaf from the build
+  new_index[i] = gi;
+}
+
+// ---- gather the members of every build item into its index segment -----------------------------
+__global__ __launch_bounds__(256) void gb_gather_old_kernel(const int* __restrict__ pt_leaf, int map_n_old, const int* __restrict__ node_item,
+                                                            const GbItem* __restrict__ items, int* __restrict__ cursor, int* __restrict__ lists) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= map_n_old) return;
+  const int leaf = pt_leaf[i];
+  if (leaf < 0) return;
+  const int it = node_item[leaf];
+  if (it < 0) return;
+  const int pos = atomicAdd(&cursor[it], 1);
+  lists[items[it].seg + pos] = i;
+}
+__global__ __launch_bounds__(256) void gb_gather_new_kernel(const uint32_t* __restrict__ perm, const int* __restrict__ new_index,
+                                                            const GbItem* __restrict__ items, int n_items, int* __restrict__ lists) {
+  const int it = blockIdx.x * blockDim.x + threadIdx.x;
+  if (it >= n_items) return;
+  const GbItem I = items[it];
+  for (int j = 0; j < I.g_len; j++) lists[I.seg + I.n_old + j] = new_index[perm[I.g_begin + j]];
+}
+
+// ---- build: createOctant (Octree.hpp:301-338) for one item per thread ----------------------------
+__global__ __launch_bounds__(64) void gb_build_kernel(const GbItem* __restrict__ items, int n_items, const float4* __restrict__ map_raw,
+                                                      int* __restrict__ lists, int* __restrict__ tmp, float4* __restrict__ node_c,
+                                                      int* __restrict__ node_child, int* __restrict__ node_cnt, int* __restrict__ node_n,
+                                                      int node_cap, float min_half, int* __restrict__ pt_leaf, int* __restrict__ node_item,
+                                                      int* __restrict__ overflow) {
+  const int it = blockIdx.x * blockDim.x + threadIdx.x;
+  if (it >= n_items) return;
+  const GbItem I = items[it];
+  const int total = I.n_old + I.g_len;
+  int root_node;
+  if (I.slot == 8) {
+    root_node = I.node;                       // rebuilt in place (`delete octant; octant = newOctant`)
+    node_item[I.node] = -1;
+  } else {
+    root_node = atomicAdd(node_n, 1);
+    if (root_node >= node_cap) { atomicExch(overflow, 1); return; }
+    const float4 pc = node_c[I.node];
+    const float f0 = (I.slot & 1) ? 0.5f : -0.5f, f1 = (I.slot & 2) ? 0.5f : -0.5f, f2 = (I.slot & 4) ? 0.5f : -0.5f;
+    node_c[root_node] = make_float4(pc.x + f0 * pc.w, pc.y + f1 * pc.w, pc.z + f2 * pc.w, pc.w * 0.5f);
+    for (int k = 0; k < 8; k++) node_child[(size_t)root_node * 8 + k] = -1;
+    node_child[(size_t)I.node * 8 + I.slot] = root_node;
+  }
+  // explicit stack of (node, begin, end) over the item's segment
+  int st_node[128], st_b[128], st_e[128];
+  int sp = 0;
+  st_node[0] = root_node; st_b[0] = I.seg; st_e[0] = I.seg + total; sp = 1;
+  while (sp > 0) {
+    sp--;
+    const int nd = st_node[sp], b = st_b[sp], e = st_e[sp];
+    const float4 c = node_c[nd];
+    const int cnt = e - b;
+    if (cnt > kBucket && c.w > 2 * min_half) {
+      node_cnt[nd] = -1;
+      int hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int j = b; j < e; j++) { const float4 p = map_raw[lists[j]]; hist[octant_of(p.x, p.y, p.z, c)]++; }
+      int start[8], cur[8];
+      int acc = b;
+      for (int k = 0; k < 8; k++) { start[k] = acc; cur[k] = acc; acc += hist[k]; }
+      for (int j = b; j < e; j++) { const int id = lists[j]; const float4 p = map_raw[id]; tmp[cur[octant_of(p.x, p.y, p.z, c)]++] = id; }
+      for (int j = b; j < e; j++) lists[j] = tmp[j];
+      for (int k = 0; k < 8; k++) node_child[(size_t)nd * 8 + k] = -1;
+      for (int k = 7; k >= 0; k--) {
+        if (hist[k] == 0) continue;
+        const int ch = atomicAdd(node_n, 1);
+        if (ch >= node_cap || sp >= 127) { atomicExch(overflow, 1); return; }
+        const float f0 = (k & 1) ? 0.5f : -0.5f, f1 = (k & 2) ? 0.5f : -0.5f, f2 = (k & 4) ? 0.5f : -0.5f;
+        node_c[ch] = make_float4(c.x + f0 * c.w, c.y + f1 * c.w, c.z + f2 * c.w, c.w * 0.5f);
+        node_child[(size_t)nd * 8 + k] = ch;
+        st_node[sp] = ch; st_b[sp] = start[k]; st_e[sp] = start[k] + hist[k]; sp++;
+      }
+    } else {
+      node_cnt[nd] = cnt;
+      for (int k = 0; k < 8; k++) node_child[(size_t)nd * 8 + k] = -1;
+      for (int j = b; j < e; j++) pt_leaf[lists[j]] = nd;
+    }
+  }
+}
+
+// ---- host side ----------------------------------------------------------------------------------
+#define GBCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return e_; } while (0)
+
+template <typename T>
+static hipError_t grow(T*& p, size_t& cap, size_t need, size_t keep_n, hipStream_t st) {
+  if (need <= cap) return hipSuccess;
+  const size_t ncap = need + need / 2 + 1024;
+  T* np = nullptr;
+  GBCHK(hipMalloc(&np, ncap * sizeof(T)));
+  if (p && keep_n) {
+    GBCHK(hipMemcpyAsync(np, p, keep_n * sizeof(T), hipMemcpyDeviceToDevice, st));
+    GBCHK(hipStreamSynchronize(st));
+  }
+  if (p) (void)hipFree(p);
+  p = np;
+  cap = ncap;
+  return hipSuccess;
+}
+
+void GBook::release() {
+  (void)hipFree(node_c); (void)hipFree(node_child); (void)hipFree(node_cnt); (void)hipFree(node_item); (void)hipFree(pt_leaf);
+  (void)hipFree(keep); (void)hipFree(assign); (void)hipFree(new_index); (void)hipFree(items); (void)hipFree(lists); (void)hipFree(tmp);
+  (void)hipFree(cursor); (void)hipFree(counters); (void)hipFree(flags); (void)hipFree(rank); (void)hipFree(node_n_dev);
+  *this = GBook();
+}
+
+hipError_t GBook::import_host(hipStream_t st, const std::vector<float>& c4, const std::vector<int>& child, const std::vector<int>& cnt,
+                              int root_id, const float4* map_raw, int map_n, float min_half_, bool downsample_) {
+  min_half = min_half_;
+  downsample = downsample_;
+  const size_t nn = cnt.size();
+  size_t cap_c = node_cap, cap_ch = node_cap * 8, cap_n = node_cap, cap_it = node_cap;
+  const size_t want = nn + nn / 2 + 4096;
+  GBCHK(grow(node_c, cap_c, want, 0, st));
+  GBCHK(grow(node_child, cap_ch, want * 8, 0, st));
+  GBCHK(grow(node_cnt, cap_n, want, 0, st));
+  GBCHK(grow(node_item, cap_it, want, 0, st));
+  node_cap = std::min(std::min(cap_c, cap_ch / 8), std::min(cap_n, cap_it));
+  GBCHK(hipMemcpyAsync(node_c, c4.data(), nn * sizeof(float4), hipMemcpyHostToDevice, st));
+  GBCHK(hipMemcpyAsync(node_child, child.data(), nn * 8 * sizeof(int), hipMemcpyHostToDevice, st));
+  GBCHK(hipMemcpyAsync(node_cnt, cnt.data(), nn * sizeof(int), hipMemcpyHostToDevice, st));
+  GBCHK(hipMemsetAsync(node_item, 0xff, node_cap * sizeof(int), st));
+  node_n = (int)nn;
+  root = root_id;
+  const float* r = &c4[(size_t)root_id * 4];
+  root_c[0] = r[0]; root_c[1] = r[1]; root_c[2] = r[2]; root_half = r[3];
+  GBCHK(grow(pt_leaf, pt_cap, (size_t)map_n + 1024, 0, st));
+  if (!node_n_dev) GBCHK(hipMalloc(&node_n_dev, sizeof(int)));
+  if (!counters) GBCHK(hipMalloc(&counters, 4 * sizeof(int)));
+  if (map_n > 0)
+    hipLaunchKernelGGL(gb_leafof_kernel, dim3((map_n + 255) / 256), dim3(256), 0, st, map_raw, map_n, node_c, node_child, node_cnt, root, pt_leaf);
+  GBCHK(hipStreamSynchronize(st));
+  active = true;
+  return hipGetLastError();
+}
+
+// batch: m NaN-free device points.  Appends the kept ones to *map_raw (capacity ensured by the caller:
+// map_cap >= map_n + m) and returns the number kept.
+hipError_t GBook::update(hipStream_t st, const float4* batch, int m, const float bb[6], float4* map_raw, int map_n, int* kept_out,
+                         MapBuildScratch& S) {
+  *kept_out = 0;
+  if (m <= 0) return hipSuccess;
+  // ---- root growth on the host mirror (Octree.hpp:354-374): max corner first, then min ----
+  {
+    std::vector<float> nc;   // new root nodes (c4) oldest first
+    std::vector<int> nchild;
+    const float corners[2][3] = {{bb[3], bb[4], bb[5]}, {bb[0], bb[1], bb[2]}};
+    for (int ci = 0; ci < 2; ci++) {
+      const float* b = corners[ci];
+      for (;;) {
+        float mm = fabsf(b[0] - root_c[0]);
+        const float my = fabsf(b[1] - root_c[1]), mz = fabsf(b[2] - root_c[2]);
+        if (my > mm) mm = my;
+        if (mz > mm) mm = mz;
+        if (!(mm > root_half)) break;
+        const float ph = 2 * root_half;
+        const float px = root_c[0] + (b[0] > root_c[0] ? 0.5f : -0.5f) * ph;
+        const float py = root_c[1] + (b[1] > root_c[1] ? 0.5f : -0.5f) * ph;
+        const float pz = root_c[2] + (b[2] > root_c[2] ? 0.5f : -0.5f) * ph;
+        const int slot = (root_c[0] > px ? 1 : 0) | (root_c[1] > py ? 2 : 0) | (root_c[2] > pz ? 4 : 0);
+        nc.push_back(px); nc.push_back(py); nc.push_back(pz); nc.push_back(ph);
+        for (int k = 0; k < 8; k++) nchild.push_back(k == slot ? root : -1);
+        root = node_n + (int)(nc.size() / 4) - 1;
+        root_c[0] = px; root_c[1] = py; root_c[2] = pz; root_half = ph;
+      }
+    }
+    const int add = (int)(nc.size() / 4);
+    if (add > 0) {
+      if ((size_t)node_n + add + 16 > node_cap) {
+        size_t cap_c = node_cap, cap_ch = node_cap * 8, cap_n = node_cap, cap_it = node_cap;
+        const size_t want = (size_t)node_n + add + 4096;
+        GBCHK(grow(node_c, cap_c, want, node_n, st));
+        GBCHK(grow(node_child, cap_ch, want * 8, (size_t)node_n * 8, st));
+        GBCHK(grow(node_cnt, cap_n, want, node_n, st));
+        GBCHK(grow(node_item, cap_it, want, 0, st));
+        node_cap = std::min(std::min(cap_c, cap_ch / 8), std::min(cap_n, cap_it));
+        GBCHK(hipMemsetAsync(node_item, 0xff, node_cap * sizeof(int), st));
+      }
+      std::vector<int> ncnt(add, -1);
+      GBCHK(hipMemcpyAsync(node_c + node_n, nc.data(), (size_t)add * sizeof(float4), hipMemcpyHostToDevice, st));
+      GBCHK(hipMemcpyAsync(node_child + (size_t)node_n * 8, nchild.data(), (size_t)add * 8 * sizeof(int), hipMemcpyHostToDevice, st));
+      GBCHK(hipMemcpyAsync(node_cnt + node_n, ncnt.data(), (size_t)add * sizeof(int), hipMemcpyHostToDevice, st));
+      GBCHK(hipStreamSynchronize(st));
+      node_n += add;
+    }
+  }
+  // ---- capacity for this batch: worst case every kept point creates a short chain of nodes ----
+  {
+    const size_t want = (size_t)node_n + (size_t)m * 16 + 4096;
+    if (want > node_cap) {
+      size_t cap_c = node_cap, cap_ch = node_cap * 8, cap_n = node_cap, cap_it = node_cap;
+      GBCHK(grow(node_c, cap_c, want, node_n, st));
+      GBCHK(grow(node_child, cap_ch, want * 8, (size_t)node_n * 8, st));
+      GBCHK(grow(node_cnt, cap_n, want, node_n, st));
+      GBCHK(grow(node_item, cap_it, want, 0, st));
+      node_cap = std::min(std::min(cap_c, cap_ch / 8), std::min(cap_n, cap_it));
+      GBCHK(hipMemsetAsync(node_item, 0xff, node_cap * sizeof(int), st));
+    }
+    GBCHK(grow(pt_leaf, pt_cap, (size_t)map_n + m + 1024, map_n, st));
+    size_t c1 = batch_cap, c2 = batch_cap, c3 = batch_cap, c4 = batch_cap, c5 = batch_cap, c6 = batch_cap, c7 = batch_cap;
+    GBCHK(grow(keep, c1, m, 0, st)); GBCHK(grow(assign, c2, m, 0, st)); GBCHK(grow(new_index, c3, m, 0, st));
+    GBCHK(grow(items, c4, m, 0, st)); GBCHK(grow(cursor, c5, m, 0, st)); GBCHK(grow(flags, c6, m, 0, st)); GBCHK(grow(rank, c7, m, 0, st));
+    batch_cap = std::min(std::min(std::min(c1, c2), std::min(c3, c4)), std::min(std::min(c5, c6), c7));
+    size_t l1 = lists_cap, l2 = lists_cap;
+    const size_t lw = (size_t)m * (kBucket + 1) + 1024;      // every group may pull in a full leaf
+    GBCHK(grow(lists, l1, lw, 0, st)); GBCHK(grow(tmp, l2, lw, 0, st));
+    lists_cap = std::min(l1, l2);
+  }
+  const int blocks = (m + 255) / 256;
+  // scratch for the sort: reuse the map builder's key / value buffers
+  {
+    size_t dummy = 0;
+    (void)dummy;
+    if (S.cap_pts < (size_t)m) {
+      if (S.keys_in) { (void)hipFree(S.keys_in); (void)hipFree(S.keys_out); (void)hipFree(S.vals_in); (void)hipFree(S.vals_out); }
+      const size_t cap = (size_t)m + m / 4 + 1024;
+      GBCHK(hipMalloc(&S.keys_in, cap * 4)); GBCHK(hipMalloc(&S.keys_out, cap * 4));
+      GBCHK(hipMalloc(&S.vals_in, cap * 4)); GBCHK(hipMalloc(&S.vals_out, cap * 4));
+      S.cap_pts = cap;
+    }
+  }
+  hipLaunchKernelGGL(gb_route_kernel, dim3(blocks), dim3(256), 0, st, batch, m, node_c, node_child, node_cnt, root, S.keys_in, S.vals_in);
+  size_t tmp_bytes = 0, scan_bytes = 0;
+  GBCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, S.keys_in, S.keys_out, S.vals_in, S.vals_out, m, 0, 32, st));
+  GBCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, flags, rank, m, st));
+  const size_t need = std::max(tmp_bytes, scan_bytes);
+  if (need > S.cub_tmp_bytes) {
+    GBCHK(hipStreamSynchronize(st));
+    if (S.cub_tmp) (void)hipFree(S.cub_tmp);
+    GBCHK(hipMalloc(&S.cub_tmp, need + 1024));
+    S.cub_tmp_bytes = need + 1024;
+  }
+  GBCHK(hipcub::DeviceRadixSort::SortPairs(S.cub_tmp, tmp_bytes, S.keys_in, S.keys_out, S.vals_in, S.vals_out, m, 0, 32, st));
+  GBCHK(hipMemsetAsync(counters, 0, 4 * sizeof(int), st));
+  hipLaunchKernelGGL(gb_decide_kernel, dim3(blocks), dim3(256), 0, st, S.keys_out, S.vals_out, m, node_c, node_cnt, min_half,
+                     downsample ? 1 : 0, keep, assign, items, counters, node_item);
+  hipLaunchKernelGGL(gb_flags_kernel, dim3(blocks), dim3(256), 0, st, keep, m, flags);
+  GBCHK(hipcub::DeviceScan::ExclusiveSum(S.cub_tmp, scan_bytes, flags, rank, m, st));
+  hipLaunchKernelGGL(gb_append_kernel, dim3(blocks), dim3(256), 0, st, batch, keep, rank, assign, m, map_n, map_raw, pt_leaf, new_index);
+  int h_cnt[4] = {0, 0, 0, 0};
+  uint32_t last_rank = 0, last_flag = 0;
+  GBCHK(hipMemcpyAsync(h_cnt, counters, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+  GBCHK(hipMemcpyAsync(&last_rank, rank + (m - 1), 4, hipMemcpyDeviceToHost, st));
+  GBCHK(hipMemcpyAsync(&last_flag, flags + (m - 1), 4, hipMemcpyDeviceToHost, st));
+  GBCHK(hipStreamSynchronize(st));
+  const int n_items = h_cnt[0];
+  const int kept = (int)(last_rank + last_flag);
+  if ((size_t)h_cnt[1] > lists_cap) return hipErrorOutOfMemory;
+  if (n_items > 0) {
+    GBCHK(hipMemsetAsync(cursor, 0, (size_t)n_items * sizeof(int), st));
+    if (map_n > 0)
+      hipLaunchKernelGGL(gb_gather_old_kernel, dim3((map_n + 255) / 256), dim3(256), 0, st, pt_leaf, map_n, node_item, items, cursor, lists);
+    hipLaunchKernelGGL(gb_gather_new_kernel, dim3((n_items + 255) / 256), dim3(256), 0, st, S.vals_out, new_index, items, n_items, lists);
+    GBCHK(hipMemcpyAsync(node_n_dev, &node_n, sizeof(int), hipMemcpyHostToDevice, st));
+    GBCHK(hipMemsetAsync(counters + 2, 0, sizeof(int), st));
+    hipLaunchKernelGGL(gb_build_kernel, dim3((n_items + 63) / 64), dim3(64), 0, st, items, n_items, map_raw, lists, tmp, node_c, node_child,
+                       node_cnt, node_n_dev, (int)node_cap, min_half, pt_leaf, node_item, counters + 2);
+    int ovf = 0;
+    GBCHK(hipMemcpyAsync(&node_n, node_n_dev, sizeof(int), hipMemcpyDeviceToHost, st));
+    GBCHK(hipMemcpyAsync(&ovf, counters + 2, sizeof(int), hipMemcpyDeviceToHost, st));
+    GBCHK(hipStreamSynchronize(st));
+    if (ovf) return hipErrorOutOfMemory;
+  }
+  *kept_out = kept;
+  last_items = n_items;
+  return hipGetLastError();
+}
+
+}  // namespace flimo

@@ -168,6 +168,30 @@ struct InsertBook {
   }
 };
 
+// flatten the live nodes (depth-first from the root) for the device-side book
+void insert_book_export(const InsertBook* b, std::vector<float>& c4, std::vector<int>& child, std::vector<int>& cnt, int* root_out) {
+  c4.clear(); child.clear(); cnt.clear();
+  *root_out = -1;
+  if (b->root < 0) return;
+  std::vector<int> stack, newid(b->pool.size(), -1), order;
+  stack.push_back(b->root);
+  while (!stack.empty()) {
+    const int id = stack.back();
+    stack.pop_back();
+    newid[id] = (int)order.size();
+    order.push_back(id);
+    for (int k = 0; k < 8; k++) if (b->pool[id].kid[k] >= 0) stack.push_back(b->pool[id].kid[k]);
+  }
+  c4.resize(order.size() * 4); child.assign(order.size() * 8, -1); cnt.resize(order.size());
+  for (size_t i = 0; i < order.size(); i++) {
+    const Cell& c = b->pool[order[i]];
+    c4[i * 4] = c.cx; c4[i * 4 + 1] = c.cy; c4[i * 4 + 2] = c.cz; c4[i * 4 + 3] = c.half;
+    for (int k = 0; k < 8; k++) if (c.kid[k] >= 0) child[i * 8 + k] = newid[c.kid[k]];
+    cnt[i] = c.split ? -1 : (int)c.pts.size();
+  }
+  *root_out = newid[b->root];
+}
+
 InsertBook* insert_book_create() { return new InsertBook(); }
 void insert_book_destroy(InsertBook* b) { delete b; }
 void insert_book_config(InsertBook* b, float min_extent, bool downsample) { b->min_half = min_extent; b->downsample = downsample; }

@@ -14,6 +14,7 @@
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
+#include <vector>
 
 namespace flimo {
 
@@ -25,5 +26,9 @@ void insert_book_clear(InsertBook* b);
 size_t insert_book_size(const InsertBook* b);
 // xyz: n packed NaN-free points.  keep[i] := 1 if point i is stored, 0 if dropped.
 void insert_book_update(InsertBook* b, const float* xyz, size_t n, unsigned char* keep);
+
+// flattened copy of the live tree: c4 = (cx, cy, cz, half) per node, child = 8 links per node (-1 absent),
+// cnt = leaf point count or -1 for internal nodes
+void insert_book_export(const InsertBook* b, std::vector<float>& c4, std::vector<int>& child, std::vector<int>& cnt, int* root_out);
 
 }  // namespace flimo

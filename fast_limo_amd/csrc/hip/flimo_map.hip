@@ -15,6 +15,7 @@
 #include <float.h>
 #include "flimo_types.h"
 #include "flimo_kernels.h"
+#include "flimo_gbook.h"
 
 namespace flimo {
 
@@ -287,6 +288,24 @@ __global__ __launch_bounds__(256) void voxelcentroid_kernel(const float4* __rest
   }
   const float nf = (float)cnt;
   out[pos[i]] = make_float4(sx / nf, sy / nf, sz / nf, 1.0f);
+}
+
+hipError_t batch_bbox(hipStream_t st, const float4* pts, size_t n, MapBuildScratch& S, float bb[6], bool* any) {
+  *any = false;
+  if (n == 0) return hipSuccess;
+  hipError_t e = ensure_scratch(S, 0);
+  if (e != hipSuccess) return e;
+  unsigned init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+  if ((e = hipMemcpyAsync(S.bbox, init, sizeof(init), hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+  const int blocks = (int)std::min<size_t>((n + 255) / 256, 1024);
+  hipLaunchKernelGGL(bbox_finite_kernel, dim3(blocks), dim3(256), 0, st, pts, n, (unsigned*)S.bbox);
+  unsigned ob[6];
+  if ((e = hipMemcpyAsync(ob, S.bbox, sizeof(ob), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+  if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+  if (ob[0] == 0xffffffffu) return hipSuccess;
+  for (int i = 0; i < 6; i++) bb[i] = o2f_host(ob[i]);
+  *any = true;
+  return hipSuccess;
 }
 
 // in -> out (may not alias).  *n_out receives the voxel count; returns hipErrorInvalidValue through

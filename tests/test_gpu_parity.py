@@ -304,3 +304,38 @@ def test_imu_stand_still_calibration_matches_oracle(built, oracle):
     rg = G.update_pointcloud(scan5, t - 0.105); ro = Lo.update_pointcloud(scan5, t - 0.105, add_to_map=False)
     assert rg == ro
     G.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("downsample", [True, False])
+def test_device_insert_rule_matches_octree(built, oracle, downsample):
+    """SURVEY section 8 row f-1: Octree::update / updateOctant / createOctant (reference Objects/Octree.hpp:341-432)
+    decided on the device.  The stored SET must equal the oracle octree's after every batch: dense re-inserts
+    (whole-leaf drops), leaf splits, child creation, root growth in both directions, NaN points, tiny batches."""
+    from fast_limo_amd import _lib
+    rng = np.random.default_rng(7)
+    base = synth.box_world_map(20000, 12.0, 3)
+    batches = [base, base[::2] + np.float32(0.01)]
+    batches += [synth.box_world_map(6000, 12.0 + 4 * k, 10 + k) + np.float32([k * 2.5, -k, 0]) for k in range(3)]
+    batches.append(np.array([[400.0, 3, 1], [-300.0, 2, 1]], np.float32))                      # root growth, both corners
+    with_nan = synth.box_world_map(3000, 14.0, 21)
+    with_nan[::17] = np.nan
+    batches.append(with_nan)
+    batches.append(rng.normal(0, 0.05, (5000, 3)).astype(np.float32) + np.float32([3, 3, 0.5]))  # one tight cluster: deep chain
+    batches.append(rng.uniform(-60, 60, (20000, 3)).astype(np.float32))                          # sparse: many child creations
+    batches.append(base[:1])
+    ctx = _lib.HipCtx(0)
+    try:
+        ctx.map_config(0.2, 2, downsample)
+        oc = oracle.Octree(0.2, downsample)
+        for k, b in enumerate(batches):
+            ctx.map_add(b)
+            oc.update(b)
+            assert ctx.map_size() == oc.size(), f"batch {k}"
+            np.testing.assert_array_equal(sort_rows(ctx.map_points()), sort_rows(oc.points()), err_msg=f"batch {k}")
+        # the index built over the device-decided map answers like the octree
+        q = rng.uniform(-15, 15, (2000, 3)).astype(np.float32)
+        idx, sqd, cnt = ctx.knn(q, 5)
+        np.testing.assert_array_equal(sqd, oc.knn(q, 5)[1])
+    finally:
+        ctx.close()
