@@ -64,7 +64,8 @@ _hip = None
 
 
 def hip_lib_path() -> str:
-    return os.path.join(_PKG, "libflimo_hip.so")
+    # FLIMO_HIP_LIB: developer override (e.g. the phase-stamp build libflimo_hip_trace.so)
+    return os.environ.get("FLIMO_HIP_LIB") or os.path.join(_PKG, "libflimo_hip.so")
 
 
 def load_hip():

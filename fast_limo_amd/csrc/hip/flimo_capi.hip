@@ -29,7 +29,7 @@ struct flimo_ctx {
   std::string err;
   // config
   flimo_map_cfg map_cfg{0.2f, 2, 1, 0.5f};
-  int lanes_per_query = 4;
+  int lanes_per_query = 2;
   int timing = 0;                  // 0 off, 1 k-NN kernel only (2 events per pass), 2 every stage
   bool debug_recs = false;
   // map
@@ -38,6 +38,8 @@ struct flimo_ctx {
   size_t map_n = 0, map_cap = 0;
   uint32_t* d_cell_start = nullptr;
   size_t cell_cap = 0;
+  uint32_t* d_row_table = nullptr;
+  size_t row_cap = 0;
   GridView grid{};
   bool grid_valid = false;
   double map_last_time = -1.0;
@@ -217,18 +219,18 @@ extern "C" int flimo_ctx_create(int device, flimo_ctx** out) {
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return FLIMO_ERR_HIP; }
   for (int i = 0; i < 4; i++) (void)hipEventCreate(&c->ev[i]);
   bool ok = hipMalloc(&c->d_partials, (size_t)c->reduce_waves * 256 * sizeof(double)) == hipSuccess &&
-            hipMalloc(&c->d_out256, 264 * sizeof(double)) == hipSuccess &&
-            hipHostMalloc((void**)&c->h_out256, 264 * sizeof(double), hipHostMallocMapped) == hipSuccess &&
+            hipMalloc(&c->d_out256, FIT_GROUPS * FIT_SLOT * sizeof(double)) == hipSuccess &&
+            hipHostMalloc((void**)&c->h_out256, FIT_GROUPS * FIT_SLOT * sizeof(double), hipHostMallocMapped) == hipSuccess &&
             hipHostGetDevicePointer((void**)&c->d_out256_host, c->h_out256, 0) == hipSuccess &&
-            hipMalloc(&c->d_ticket, sizeof(unsigned int)) == hipSuccess &&
-            hipMemset(c->d_ticket, 0, sizeof(unsigned int)) == hipSuccess &&
+            hipMalloc(&c->d_ticket, FIT_GROUPS * sizeof(unsigned int)) == hipSuccess &&
+            hipMemset(c->d_ticket, 0, FIT_GROUPS * sizeof(unsigned int)) == hipSuccess &&
             hipMalloc(&c->d_cand, sizeof(unsigned long long)) == hipSuccess &&
             hipMalloc(&c->d_wl_count, sizeof(int)) == hipSuccess &&
             hipMemset(c->d_wl_count, 0, sizeof(int)) == hipSuccess &&
             hipHostMalloc((void**)&c->h_wl_count, sizeof(int), hipHostMallocDefault) == hipSuccess &&
             hipHostMalloc((void**)&c->h_cand, sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess;
   if (!ok) { flimo_ctx_destroy(c); return FLIMO_ERR_HIP; }
-  memset(c->h_out256, 0, 264 * sizeof(double));
+  memset(c->h_out256, 0, FIT_GROUPS * FIT_SLOT * sizeof(double));
   // calibrate the v_mfma_f64_16x16x4_f64 accumulator layout: D[i][j] = j + 16 i
   launch_mfma_layout(c->stream, c->d_out256);
   if (hipMemcpyAsync(c->h_out256, c->d_out256, 256 * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
@@ -254,7 +256,7 @@ extern "C" void flimo_ctx_destroy(flimo_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  (void)hipFree(c->d_map_raw); (void)hipFree(c->d_map_sorted); (void)hipFree(c->d_cell_start);
+  (void)hipFree(c->d_map_raw); (void)hipFree(c->d_map_sorted); (void)hipFree(c->d_cell_start); (void)hipFree(c->d_row_table);
   (void)hipFree(c->d_scan_sorted); (void)hipFree(c->d_nbr); (void)hipFree(c->d_wl); (void)hipFree(c->d_wl_count);
   (void)hipFree(c->d_fit_partials); (void)hipFree(c->d_raw_sorted); (void)hipFree(c->d_t_sorted);
   (void)hipFree(c->d_scan); (void)hipFree(c->d_scan_raw); (void)hipFree(c->d_scan_world); (void)hipFree(c->d_scan_t);
@@ -339,9 +341,21 @@ static int rebuild_grid(flimo_ctx* c) {
   }
   HIPCHK(c, map_build_grid(c->stream, c->d_map_raw, c->map_n, c->d_map_sorted, c->d_cell_start, ncells, ox, oy, oz, inv,
                            nx, ny, nz, c->scratch));
+  {
+    const size_t rt = row_table_size(nx, ny, nz);
+    if (rt > c->row_cap) {
+      if (c->d_row_table) (void)hipFree(c->d_row_table);
+      c->d_row_table = nullptr;
+      const size_t cap = rt + rt / 8;
+      HIPCHK(c, hipMalloc(&c->d_row_table, cap * sizeof(uint32_t)));
+      c->row_cap = cap;
+    }
+    HIPCHK(c, map_build_row_table(c->stream, c->d_cell_start, nx, ny, nz, c->d_row_table));
+  }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->grid.pts = c->d_map_sorted;
   c->grid.cell_start = c->d_cell_start;
+  c->grid.row_table = c->d_row_table;
   c->grid.ox = ox; c->grid.oy = oy; c->grid.oz = oz;
   c->grid.inv_cell = inv;
   c->grid.cell = cell;
@@ -749,10 +763,12 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   const bool want_recs = c->debug_recs || cap_binds;
   if (c->debug_recs) HIPCHK(c, hipMemsetAsync(c->d_cand, 0, sizeof(unsigned long long), c->stream));
   const bool want_count = c->debug_recs;
-  if (c->timing) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  if (c->timing > 1) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  // level 1: the two events ride on the k-NN dispatch itself (kernel begin / end, no extra packets)
   launch_knn5(c->stream, c->lanes_per_query, c->grid, c->d_scan_sorted, n_all, P, mp.max_ring, c->d_nbr, c->d_wl,
-              c->d_wl_count, c->debug_recs ? c->d_cand : nullptr);
-  if (c->timing) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+              c->d_wl_count, c->debug_recs ? c->d_cand : nullptr, c->timing == 1 ? c->ev[0] : nullptr,
+              c->timing == 1 ? c->ev[1] : nullptr);
+  if (c->timing > 1) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
   launch_widen(c->stream, c->grid, c->d_scan_sorted, P, mp.max_ring, c->d_nbr, c->d_wl, c->d_wl_count,
                c->debug_recs ? c->d_cand : nullptr);
   if (want_count) HIPCHK(c, hipMemcpyAsync(c->h_wl_count, c->d_wl_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -770,12 +786,14 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   HIPCHK(c, hipGetLastError());
   if (c->debug_recs) HIPCHK(c, hipMemcpyAsync(c->h_cand, c->d_cand, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
   if (!cap_binds && !c->debug_recs && c->timing < 2) {
-    // low-latency completion: spin on the pass number the last fit block publishes to host memory
-    volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(c->h_out256 + 256);
+    // low-latency completion: spin on the pass number every reduction group publishes to host memory
     unsigned long long spins = 0;
-    while (*flag != seq) {
-      _mm_pause();
-      if (++spins > 40000000ull) { HIPCHK(c, hipStreamSynchronize(c->stream)); break; }   // also surfaces launch errors
+    for (int g = 0; g < FIT_GROUPS; g++) {
+      volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(c->h_out256 + (size_t)g * FIT_SLOT + 256);
+      while (*flag != seq) {
+        _mm_pause();
+        if (++spins > 40000000ull) { HIPCHK(c, hipStreamSynchronize(c->stream)); break; }   // also surfaces launch errors
+      }
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
     if (c->timing) HIPCHK(c, hipEventSynchronize(c->ev[1]));
@@ -794,11 +812,19 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   }
   if (want_count) c->last_widen_count = *c->h_wl_count;
   if (c->debug_recs) c->last_cand_per_query = (double)(*c->h_cand) / (double)nq;
-  for (int i = 0; i < 12; i++) {
-    for (int j = 0; j < 12; j++) HTH[i * 12 + j] = c->h_out256[c->mfma_idx[i][j]];
-    HTh[i] = c->h_out256[c->mfma_idx[i][12]];
+  // final sum over the reduction groups in slot order (the records path delivers one slot)
+  double acc[256];
+  const int slots = cap_binds ? 1 : FIT_GROUPS;
+  for (int t = 0; t < 256; t++) {
+    double r = c->h_out256[t];
+    for (int g = 1; g < slots; g++) r += c->h_out256[(size_t)g * FIT_SLOT + t];
+    acc[t] = r;
   }
-  *M = (int)llround(c->h_out256[c->mfma_idx[13][13]]);
+  for (int i = 0; i < 12; i++) {
+    for (int j = 0; j < 12; j++) HTH[i * 12 + j] = acc[c->mfma_idx[i][j]];
+    HTh[i] = acc[c->mfma_idx[i][12]];
+  }
+  *M = (int)llround(acc[c->mfma_idx[13][13]]);
   c->last_nq = (int)nq;
   c->last_P = P; c->last_mp = mp; c->last_n_all = n_all;
   c->recs_valid = want_recs; c->dbg_valid = c->debug_recs;

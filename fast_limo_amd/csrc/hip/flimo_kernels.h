@@ -8,10 +8,14 @@ namespace flimo {
 // flimo_kernels.hip
 // per pass: k-NN (fast path + worklist widening), then fit + in-block reduction, then the final sum
 void launch_knn5(hipStream_t st, int lanes_per_query, const GridView& G, const float4* scan_sorted, int n,
-                 const PoseMats& P, int max_ring, void* nbr, int* wl, int* wl_count, unsigned long long* cand);
+                 const PoseMats& P, int max_ring, void* nbr, int* wl, int* wl_count, unsigned long long* cand,
+                 hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 void launch_widen(hipStream_t st, const GridView& G, const float4* scan_sorted, const PoseMats& P, int max_ring, void* nbr,
                   int* wl, int* wl_count, unsigned long long* cand);
 int fit_blocks(int n);
+// the fit kernel reduces in FIT_GROUPS groups; slot g of its output = 256 sums + the pass number (FIT_SLOT doubles)
+constexpr int FIT_GROUPS = 8;
+constexpr int FIT_SLOT = 264;
 // fit + in-block MFMA reduction + grid reduction by the last block: out256[0..255] receives the raw
 // 16x16 accumulator and out256[256] (as u64) the pass number `seq` (system-scope release), `ticket` and `wl_count` are reset for the next pass
 void launch_fit(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const void* nbr, const PoseMats& P,
@@ -53,6 +57,8 @@ hipError_t sort_scan(hipStream_t st, const float4* in, size_t n, float4* out, Ma
 hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4* pts_out, uint32_t* cell_start,
                           size_t ncells, float ox, float oy, float oz, float inv_cell, int nx, int ny, int nz,
                           MapBuildScratch& S);
+size_t row_table_size(int nx, int ny, int nz);
+hipError_t map_build_row_table(hipStream_t st, const uint32_t* cell_start, int nx, int ny, int nz, uint32_t* out);
 // pcl::VoxelGrid on device points: out gets one centroid per occupied voxel in ascending voxel index
 hipError_t voxel_grid(hipStream_t st, const float4* in, size_t n, float leaf, float4* out, size_t* n_out, bool* passthrough,
                       MapBuildScratch& S);

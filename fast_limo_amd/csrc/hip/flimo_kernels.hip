@@ -17,6 +17,7 @@
 // register-resident sorted best-5, and proves exactness with a conservative "ball inside the
 // visited block" test; otherwise it widens ring by ring (shell only, pruned by box distance).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <float.h>
 #include <limits.h>
 #include <stdlib.h>
@@ -254,6 +255,23 @@ FLIMO_DEV void knn_search(const GridView& G, float gx, float gy, float gz, int s
 typedef unsigned long long u64;
 #define KEY_EMPTY 0xffffffffffffffffull
 
+// Developer-only phase stamps (built with -DFLIMO_TRACE into libflimo_hip_trace.so, never shipped):
+// thread 0 of every block stores the 100 MHz wall clock after draining its outstanding memory operations.
+#ifdef FLIMO_TRACE
+__device__ unsigned long long g_trace[2][16384 * 8];
+#define TRACE(k, slot)                                                                                  \
+  do {                                                                                                  \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                         \
+    if (threadIdx.x == 0 && blockIdx.x < 16384) g_trace[k][blockIdx.x * 8 + (slot)] = wall_clock64();  \
+  } while (0)
+extern "C" int flimo_trace_read(int k, unsigned long long* out, size_t n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), n * sizeof(unsigned long long), (size_t)k * 16384 * 8 * sizeof(unsigned long long),
+                                  hipMemcpyDeviceToHost);
+}
+#else
+#define TRACE(k, slot) do {} while (0)
+#endif
+
 FLIMO_DEV u64 make_key(float d, uint32_t idx) { return ((u64)__float_as_uint(d) << 32) | (u64)idx; }
 
 FLIMO_DEV void key5_insert(u64 (&k)[5], u64 key) {
@@ -279,6 +297,30 @@ struct NbrRec {      // 32 bytes per query (sorted order)
   int32_t pad[2];
 };
 
+// sorted private best-5 of one lane: distances as floats (+inf = empty), payload = position in the sorted map.
+// A lane meets its candidates in ascending map position, so on equal distance the earlier one stays in front:
+// the strict float compare orders exactly like the 64-bit (distance, position) key of the group merge.
+struct U3 { uint32_t a, b, c; };
+FLIMO_DEV void best5_insert(float (&kd)[5], uint32_t (&ki)[5], float x, uint32_t xi) {
+  const bool c0 = x < kd[0], c1 = x < kd[1], c2 = x < kd[2], c3 = x < kd[3], c4 = x < kd[4];
+  // flat two-level selects on the OLD values (nested ternaries would be lowered to branches)
+  const uint32_t t4 = c3 ? ki[3] : xi;
+  const uint32_t t3 = c2 ? ki[2] : xi;
+  const uint32_t t2 = c1 ? ki[1] : xi;
+  const uint32_t t1 = c0 ? ki[0] : xi;
+  ki[4] = c4 ? t4 : ki[4];
+  ki[3] = c3 ? t3 : ki[3];
+  ki[2] = c2 ? t2 : ki[2];
+  ki[1] = c1 ? t1 : ki[1];
+  ki[0] = c0 ? xi : ki[0];
+  kd[4] = __builtin_amdgcn_fmed3f(kd[3], x, kd[4]);      // kd[3] <= kd[4]: clamp x into [kd[3], kd[4]]
+  kd[3] = __builtin_amdgcn_fmed3f(kd[2], x, kd[3]);
+  kd[2] = __builtin_amdgcn_fmed3f(kd[1], x, kd[2]);
+  kd[1] = __builtin_amdgcn_fmed3f(kd[0], x, kd[1]);
+  kd[0] = c0 ? x : kd[0];
+}
+#define KEY_NONE 0x7f800000ffffffffull     // (+inf, -1): an empty slot of the merged list
+
 template <int L, int SLOTS>
 __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __restrict__ scan_sorted, int n,
                                                    PoseMats P, int max_ring, NbrRec* __restrict__ nbr,
@@ -289,14 +331,16 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
   const int p = chunk * QPB + threadIdx.x / L;
   const int sub = threadIdx.x % L;
   if (p >= n) return;
+  TRACE(0, 0);
 
   const float4 sp = scan_sorted[p];
   float gx, gy, gz;
   xform4(P.RT, sp.x, sp.y, sp.z, gx, gy, gz);
+  TRACE(0, 1);
 
   const float fx = (gx - G.ox) * G.inv_cell, fy = (gy - G.oy) * G.inv_cell, fz = (gz - G.oz) * G.inv_cell;
   int flag = 0;
-  u64 best[5] = {KEY_EMPTY, KEY_EMPTY, KEY_EMPTY, KEY_EMPTY, KEY_EMPTY};
+  u64 best[5] = {KEY_NONE, KEY_NONE, KEY_NONE, KEY_NONE, KEY_NONE};
   int cand = 0;
   if ((fx == fx) && (fy == fy) && (fz == fz)) {
     const float lim = 1.0e9f;
@@ -312,46 +356,73 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
     } else if (r0 > 1) {
       flag = 2;                       // outside the grid but within reach: general search
     } else {
-      // ---- range bounds of the 9 rows ----
+      // ---- range bounds of the 9 rows: six 12-byte loads from the y-fastest, padded row table ----
       const int x0 = max(cx - 1, 0), x1 = min(cx + 1, G.nx - 1);
-      uint32_t lo[9], off[10];
+      const size_t py = (size_t)G.ny + 4, pz = (size_t)G.nz + 4;
+      const uint32_t* Ta = G.row_table + ((size_t)x0 * pz + (size_t)(cz + 1)) * py + (size_t)(cy + 1);
+      const uint32_t* Tb = G.row_table + ((size_t)(x1 + 1) * pz + (size_t)(cz + 1)) * py + (size_t)(cy + 1);
+      U3 ra[3], rb[3];
+#pragma unroll
+      for (int dz = 0; dz < 3; dz++) {
+        ra[dz] = *reinterpret_cast<const U3*>(Ta + (size_t)dz * py);
+        rb[dz] = *reinterpret_cast<const U3*>(Tb + (size_t)dz * py);
+      }
+      uint32_t off[10], dl[9];          // dl[t] = lo[t] - off[t]: stream position -> map position
       off[0] = 0;
 #pragma unroll
-      for (int t = 0; t < 9; t++) {
-        const int yy = cy + (t % 3) - 1, zz = cz + (t / 3) - 1;
-        const bool in = (yy >= 0) && (yy < G.ny) && (zz >= 0) && (zz < G.nz);
-        const size_t rowbase = ((size_t)(in ? zz : 0) * (size_t)G.ny + (size_t)(in ? yy : 0)) * (size_t)G.nx;
-        const uint32_t a = G.cell_start[rowbase + x0];
-        const uint32_t b = G.cell_start[rowbase + x1 + 1];
-        lo[t] = a;
-        off[t + 1] = in ? (b - a) : 0u;
-      }
+      for (int dz = 0; dz < 3; dz++) {
+        const uint32_t a[3] = {ra[dz].a, ra[dz].b, ra[dz].c}, b[3] = {rb[dz].a, rb[dz].b, rb[dz].c};
 #pragma unroll
-      for (int t = 0; t < 9; t++) off[t + 1] += off[t];
+        for (int k = 0; k < 3; k++) {
+          const int t = 3 * dz + k;
+          dl[t] = a[k] - off[t];
+          off[t + 1] = off[t] + (b[k] - a[k]);
+        }
+      }
       const uint32_t total = off[9];
-      // ---- flattened candidate stream ----
+      TRACE(0, 2);
+      // ---- flattened candidate stream, branch-free body ----
+      float kd[5] = {INFINITY, INFINITY, INFINITY, INFINITY, INFINITY};
+      uint32_t ki[5] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+      const uint32_t last = total - 1u;
       for (uint32_t s0 = (uint32_t)sub; s0 < total; s0 += SLOTS * L) {
         float4 pt[SLOTS];
         uint32_t id[SLOTS];
 #pragma unroll
         for (int u = 0; u < SLOTS; u++) {
-          const uint32_t s = s0 + u * L;
-          uint32_t delta = lo[0];
+          const uint32_t s = min(s0 + u * L, last);
+          uint32_t delta = dl[0];
 #pragma unroll
-          for (int t = 1; t < 9; t++) delta = (s >= off[t]) ? (lo[t] - off[t]) : delta;
+          for (int t = 1; t < 9; t++) delta = (s >= off[t]) ? dl[t] : delta;
           id[u] = s + delta;
-          if (s < total) pt[u] = G.pts[id[u]];
+          pt[u] = G.pts[id[u]];
         }
+        // all SLOTS loads are issued back to back: the empty asm consumes every loaded value at once
+        if constexpr (SLOTS == 8)
+          asm volatile("" : "+v"(pt[0].x), "+v"(pt[0].y), "+v"(pt[0].z), "+v"(pt[1].x), "+v"(pt[1].y), "+v"(pt[1].z),
+                            "+v"(pt[2].x), "+v"(pt[2].y), "+v"(pt[2].z), "+v"(pt[3].x), "+v"(pt[3].y), "+v"(pt[3].z),
+                            "+v"(pt[4].x), "+v"(pt[4].y), "+v"(pt[4].z), "+v"(pt[5].x), "+v"(pt[5].y), "+v"(pt[5].z),
+                            "+v"(pt[6].x), "+v"(pt[6].y), "+v"(pt[6].z), "+v"(pt[7].x), "+v"(pt[7].y), "+v"(pt[7].z));
+        else if constexpr (SLOTS == 4)
+          asm volatile("" : "+v"(pt[0].x), "+v"(pt[0].y), "+v"(pt[0].z), "+v"(pt[1].x), "+v"(pt[1].y), "+v"(pt[1].z),
+                            "+v"(pt[2].x), "+v"(pt[2].y), "+v"(pt[2].z), "+v"(pt[3].x), "+v"(pt[3].y), "+v"(pt[3].z));
 #pragma unroll
         for (int u = 0; u < SLOTS; u++) {
-          const uint32_t s = s0 + u * L;
-          if (s < total) {
-            const float d = sqdist3(gx, gy, gz, pt[u].x, pt[u].y, pt[u].z);
-            key5_insert(best, make_key(d, id[u]));
-            cand++;
-          }
+          const bool live = s0 + u * L < total;
+          const float d = sqdist3(gx, gy, gz, pt[u].x, pt[u].y, pt[u].z);
+          best5_insert(kd, ki, live ? d : INFINITY, id[u]);
+          cand += live ? 1 : 0;
         }
       }
+#pragma unroll
+      for (int i = 0; i < 5; i++) best[i] = ((u64)__float_as_uint(kd[i]) << 32) | (u64)ki[i];
+      TRACE(0, 3);
+#ifdef FLIMO_TRACE
+      if (blockIdx.x < 16384) {   // developer statistics: accumulated block candidates (all passes), CU id
+        if (sub == 0) atomicAdd(&g_trace[0][blockIdx.x * 8 + 6], (unsigned long long)total);
+        if (threadIdx.x == 0) g_trace[0][blockIdx.x * 8 + 7] = __smid();
+      }
+#endif
       // ---- group result: five rounds of min-extraction ----
       if (L > 1) {
         u64 mine[5];
@@ -366,7 +437,7 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
             m = v < m ? v : m;
           }
           best[r] = m;
-          if (mine[0] == m) { mine[0] = mine[1]; mine[1] = mine[2]; mine[2] = mine[3]; mine[3] = mine[4]; mine[4] = KEY_EMPTY; }
+          if (mine[0] == m) { mine[0] = mine[1]; mine[1] = mine[2]; mine[2] = mine[3]; mine[3] = mine[4]; mine[4] = KEY_NONE; }
         }
       }
       // ---- exactness: the 5-ball must lie inside the visited block ----
@@ -376,8 +447,8 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
       const float margin = 1.0e-3f + 4.0e-7f * (float)maxdim;
       const float edge = fminf(fminf(fminf(rx, 1.f - rx), fminf(ry, 1.f - ry)), fminf(rz, 1.f - rz));
       const float rg = (1.f + edge - margin) * G.cell;
-      const bool have5 = best[4] != KEY_EMPTY;
       const float d5 = __uint_as_float((uint32_t)(best[4] >> 32));
+      const bool have5 = d5 < INFINITY;
       const bool covers = (cx - 1 <= 0) && (cx + 1 >= G.nx - 1) && (cy - 1 <= 0) && (cy + 1 >= G.ny - 1) &&
                           (cz - 1 <= 0) && (cz + 1 >= G.nz - 1);
       if (have5 && (covers || d5 <= rg * rg * (1.f - 1.0e-6f))) flag = 1;
@@ -391,6 +462,7 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
     for (int o = 1; o < L; o <<= 1) c += __shfl_xor(c, o, 64);
     if (sub == 0) atomicAdd(cand_total, (unsigned long long)c);
   }
+  TRACE(0, 4);
   if (sub == 0) {
     int4 a, b;
     a.x = (int)(uint32_t)best[0]; a.y = (int)(uint32_t)best[1]; a.z = (int)(uint32_t)best[2]; a.w = (int)(uint32_t)best[3];
@@ -400,6 +472,7 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
     o[1] = b;
     if (flag == 2) wl[atomicAdd(wl_count, 1)] = p;
   }
+  TRACE(0, 5);
 }
 
 // Widening for the worklist (rare): ONE WAVE per query.  The (2r+1)^2 <= 49 rows of the ring-r block
@@ -548,16 +621,16 @@ __global__ __launch_bounds__(256) void widen_general_kernel(GridView G, const fl
 // ------------------------------------------------------------------------------------------
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-constexpr int FIT_THREADS = 1024;
-constexpr int FIT_WAVES = FIT_THREADS / 64;
+static int g_fit_threads = 0;      // 256 / 512 / 1024 (FLIMO_FIT_THREADS)
 
-template <bool RECS, bool DBG>
+template <bool RECS, bool DBG, int FIT_THREADS>
 __global__ __launch_bounds__(FIT_THREADS) void fit_kernel(GridView G, const float4* __restrict__ scan_sorted, int n,
                                                           const NbrRec* __restrict__ nbr, PoseMats P, MatchParams mp,
                                                           double* __restrict__ partials, Rec16* __restrict__ recs,
                                                           RecDbg* __restrict__ dbg, double* __restrict__ out256,
                                                           unsigned int* __restrict__ ticket, int* __restrict__ wl_count,
                                                           unsigned long long seq) {
+  constexpr int FIT_WAVES = FIT_THREADS / 64;
   __shared__ float s_rec[FIT_WAVES][16 * 65];       // per wave: [col][row] with stride 65
   __shared__ double s_acc[FIT_WAVES][256];
   __shared__ unsigned int s_last;
@@ -575,6 +648,7 @@ __global__ __launch_bounds__(FIT_THREADS) void fit_kernel(GridView G, const floa
   int flag = 0;
   uint32_t orig = 0;
   bool valid = false;
+  TRACE(1, 0);
   if (p < n) {
     const float4 sp = scan_sorted[p];
     orig = __float_as_uint(sp.w);
@@ -584,6 +658,7 @@ __global__ __launch_bounds__(FIT_THREADS) void fit_kernel(GridView G, const floa
     ids[0] = a.x; ids[1] = a.y; ids[2] = a.z; ids[3] = a.w; ids[4] = b.x;
     flag = b.y;
     valid = (flag == 1) && (orig < (uint32_t)mp.n_queries);
+    TRACE(1, 1);
     if (valid) {
       float px[5], py[5], pz[5];
 #pragma unroll
@@ -592,6 +667,7 @@ __global__ __launch_bounds__(FIT_THREADS) void fit_kernel(GridView G, const floa
         px[s] = q.x; py[s] = q.y; pz[s] = q.z;
         sq[s] = sqdist3(gx, gy, gz, q.x, q.y, q.z);
       }
+      TRACE(1, 2);
       // Plane gates (Plane.cpp:23-31): 5 neighbours, 5th SQUARED distance < MAX_DIST_PLANE
       valid = sq[4] < mp.max_dist_plane;
       if (valid) {
@@ -640,6 +716,7 @@ __global__ __launch_bounds__(FIT_THREADS) void fit_kernel(GridView G, const floa
       }
     }
   }
+  TRACE(1, 3);
   // ---- block reduction: D += X^T X with X = the 64 rows of this wave, 4 rows per MFMA ----
   float* sr = s_rec[wave];
 #pragma unroll
@@ -663,57 +740,68 @@ __global__ __launch_bounds__(FIT_THREADS) void fit_kernel(GridView G, const floa
     for (int w = 0; w < FIT_WAVES; w++) r += s_acc[w][t];          // fixed order
     partials[(size_t)blockIdx.x * 256 + t] = r;
   }
-  // ---- grid reduction by the last block to arrive (agent-scope release / acquire, guide G16) ----
+  // ---- grid reduction in FIT_GROUPS independent groups (blocks b, b + 8, b + 16, ...): the last block of a
+  //      group to arrive sums the group's partials in block order and writes them, followed by the pass
+  //      number, to its 264-double slot of out256 (mapped host memory on the fast path); the host adds the
+  //      FIT_GROUPS slots in slot order.  Agent-scope release / acquire around the ticket (guide G16). ----
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  TRACE(1, 4);
+  const int group = blockIdx.x & (FIT_GROUPS - 1);
+  const int nb_g = (int)(gridDim.x / FIT_GROUPS);                  // gridDim.x is a multiple of 8
   if (threadIdx.x == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned int old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = (old == gridDim.x - 1) ? 1u : 0u;
+    const unsigned int old = __hip_atomic_fetch_add(ticket + group, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (old == (unsigned int)nb_g - 1u) ? 1u : 0u;
   }
   __syncthreads();
+  TRACE(1, 5);
   if (s_last) {
     if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     __syncthreads();
-    const int nb = (int)gridDim.x;
-    // 256 accumulator slots x (FIT_THREADS / 256) slices of the block list; all loads of a slice are
-    // issued together (<= 16 per thread for up to 64 blocks); fixed summation order
+    // 256 accumulator slots x (FIT_THREADS / 256) slices of the group's block list; up to 32 loads in flight
     constexpr int PARTS = FIT_THREADS / 256;
     const int t = threadIdx.x & 255, part = threadIdx.x >> 8;
-    const int per = (nb + PARTS - 1) / PARTS;
-    const int b0 = part * per, b1 = min(nb, b0 + per);
+    const int per = (nb_g + PARTS - 1) / PARTS;
+    const int k0 = part * per, k1 = min(nb_g, k0 + per);
+    const double* base = partials + (size_t)group * 256 + t;
+    const size_t stride = (size_t)FIT_GROUPS * 256;
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    int w = b0;
-    for (; w + 15 < b1; w += 16) {
-      double v[16];
+    int k = k0;
+    for (; k + 31 < k1; k += 32) {
+      double v[32];
 #pragma unroll
-      for (int u = 0; u < 16; u++) v[u] = __builtin_nontemporal_load(&partials[(size_t)(w + u) * 256 + t]);
+      for (int u = 0; u < 32; u++) v[u] = __builtin_nontemporal_load(base + (size_t)(k + u) * stride);
 #pragma unroll
-      for (int u = 0; u < 16; u += 4) { s0 += v[u]; s1 += v[u + 1]; s2 += v[u + 2]; s3 += v[u + 3]; }
+      for (int u = 0; u < 32; u += 4) { s0 += v[u]; s1 += v[u + 1]; s2 += v[u + 2]; s3 += v[u + 3]; }
     }
-    for (; w + 3 < b1; w += 4) {
+    for (; k + 3 < k1; k += 4) {
       double v[4];
 #pragma unroll
-      for (int u = 0; u < 4; u++) v[u] = __builtin_nontemporal_load(&partials[(size_t)(w + u) * 256 + t]);
+      for (int u = 0; u < 4; u++) v[u] = __builtin_nontemporal_load(base + (size_t)(k + u) * stride);
       s0 += v[0]; s1 += v[1]; s2 += v[2]; s3 += v[3];
     }
-    for (; w < b1; w++) s0 += __builtin_nontemporal_load(&partials[(size_t)w * 256 + t]);
+    for (; k < k1; k++) s0 += __builtin_nontemporal_load(base + (size_t)k * stride);
     s_acc[part][t] = (s0 + s1) + (s2 + s3);
     __syncthreads();
+    TRACE(1, 6);
+    double* out = out256 + (size_t)group * FIT_SLOT;
     if (part == 0) {
       double r = 0.0;
 #pragma unroll
-      for (int k = 0; k < PARTS; k++) r += s_acc[k][t];
-      out256[t] = r;
+      for (int q = 0; q < PARTS; q++) r += s_acc[q][t];
+      out[t] = r;
     }
-    // publish: out256 may live in mapped host memory; the host spins on word 256 (the pass number)
+    // publish: out256 may live in mapped host memory; the host spins on word 256 of every slot
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) {
-      *ticket = 0u; *wl_count = 0;                                // ready for the next pass
-      __hip_atomic_store(reinterpret_cast<unsigned long long*>(out256 + 256), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      ticket[group] = 0u;                                          // ready for the next pass
+      if (group == 0) *wl_count = 0;
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(out + 256), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    TRACE(1, 7);
   }
 }
 
@@ -995,29 +1083,32 @@ static inline int round_up8(int x) { return (x + 7) & ~7; }
 static int g_slots = 0;   // 0: default per L; developer override through FLIMO_SLOTS
 template <int L>
 static void launch_knn5_L(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const PoseMats& P,
-                          int max_ring, void* nbr, int* wl, int* wl_count, unsigned long long* cand) {
+                          int max_ring, void* nbr, int* wl, int* wl_count, unsigned long long* cand, hipEvent_t e0, hipEvent_t e1) {
   const int qpb = 256 / L;
   const int blocks = round_up8((n + qpb - 1) / qpb);
   if (g_slots == 0) { const char* e = getenv("FLIMO_SLOTS"); g_slots = e ? atoi(e) : -1; }
   const int slots = g_slots > 0 ? g_slots : (L <= 4 ? 8 : 4);
+  // e0 / e1 (optional) are attached to the dispatch itself: they read the kernel's own begin / end
+  // timestamps, without the extra barrier packets of hipEventRecord
   if (slots >= 8)
-    hipLaunchKernelGGL((knn5_kernel<L, 8>), dim3(blocks), dim3(256), 0, st, G, scan_sorted, n, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand);
+    hipExtLaunchKernelGGL((knn5_kernel<L, 8>), dim3(blocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand);
   else if (slots >= 4)
-    hipLaunchKernelGGL((knn5_kernel<L, 4>), dim3(blocks), dim3(256), 0, st, G, scan_sorted, n, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand);
+    hipExtLaunchKernelGGL((knn5_kernel<L, 4>), dim3(blocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand);
   else
-    hipLaunchKernelGGL((knn5_kernel<L, 2>), dim3(blocks), dim3(256), 0, st, G, scan_sorted, n, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand);
+    hipExtLaunchKernelGGL((knn5_kernel<L, 2>), dim3(blocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand);
 }
 
 void launch_knn5(hipStream_t st, int lanes_per_query, const GridView& G, const float4* scan_sorted, int n,
-                 const PoseMats& P, int max_ring, void* nbr, int* wl, int* wl_count, unsigned long long* cand) {
+                 const PoseMats& P, int max_ring, void* nbr, int* wl, int* wl_count, unsigned long long* cand,
+                 hipEvent_t e0, hipEvent_t e1) {
   if (n <= 0) return;
   switch (lanes_per_query) {
-    case 1: launch_knn5_L<1>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand); break;
-    case 2: launch_knn5_L<2>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand); break;
-    case 4: launch_knn5_L<4>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand); break;
-    case 8: launch_knn5_L<8>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand); break;
-    case 32: launch_knn5_L<32>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand); break;
-    default: launch_knn5_L<16>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand); break;
+    case 1: launch_knn5_L<1>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, e0, e1); break;
+    case 2: launch_knn5_L<2>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, e0, e1); break;
+    case 4: launch_knn5_L<4>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, e0, e1); break;
+    case 8: launch_knn5_L<8>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, e0, e1); break;
+    case 32: launch_knn5_L<32>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, e0, e1); break;
+    default: launch_knn5_L<16>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, e0, e1); break;
   }
 }
 
@@ -1030,19 +1121,38 @@ void launch_widen(hipStream_t st, const GridView& G, const float4* scan_sorted, 
     hipLaunchKernelGGL(widen_general_kernel, dim3(256), dim3(256), 0, st, G, scan_sorted, P, max_ring, (NbrRec*)nbr, wl, wl_count);
 }
 
-int fit_blocks(int n) { return round_up8((n + FIT_THREADS - 1) / FIT_THREADS); }
+static int fit_threads() {
+  if (g_fit_threads == 0) {
+    const char* e = getenv("FLIMO_FIT_THREADS");
+    const int v = e ? atoi(e) : 0;
+    g_fit_threads = (v == 256 || v == 512 || v == 1024) ? v : 256;
+  }
+  return g_fit_threads;
+}
+int fit_blocks(int n) { const int T = fit_threads(); return round_up8((n + T - 1) / T); }
+
+template <int T>
+static void launch_fit_T(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const void* nbr, const PoseMats& P,
+                         const MatchParams& mp, double* partials, Rec16* recs, RecDbg* dbg, double* out256, unsigned int* ticket,
+                         int* wl_count, unsigned long long seq) {
+  const int blocks = fit_blocks(n);
+  if (recs && dbg)
+    hipLaunchKernelGGL((fit_kernel<true, true, T>), dim3(blocks), dim3(T), 0, st, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, partials, recs, dbg, out256, ticket, wl_count, seq);
+  else if (recs)
+    hipLaunchKernelGGL((fit_kernel<true, false, T>), dim3(blocks), dim3(T), 0, st, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, partials, recs, dbg, out256, ticket, wl_count, seq);
+  else
+    hipLaunchKernelGGL((fit_kernel<false, false, T>), dim3(blocks), dim3(T), 0, st, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, partials, recs, dbg, out256, ticket, wl_count, seq);
+}
 
 void launch_fit(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const void* nbr, const PoseMats& P,
                 const MatchParams& mp, double* partials, Rec16* recs, RecDbg* dbg, double* out256, unsigned int* ticket,
                 int* wl_count, unsigned long long seq) {
   if (n <= 0) return;
-  const int blocks = fit_blocks(n);
-  if (recs && dbg)
-    hipLaunchKernelGGL((fit_kernel<true, true>), dim3(blocks), dim3(FIT_THREADS), 0, st, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, partials, recs, dbg, out256, ticket, wl_count, seq);
-  else if (recs)
-    hipLaunchKernelGGL((fit_kernel<true, false>), dim3(blocks), dim3(FIT_THREADS), 0, st, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, partials, recs, dbg, out256, ticket, wl_count, seq);
-  else
-    hipLaunchKernelGGL((fit_kernel<false, false>), dim3(blocks), dim3(FIT_THREADS), 0, st, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, partials, recs, dbg, out256, ticket, wl_count, seq);
+  switch (fit_threads()) {
+    case 1024: launch_fit_T<1024>(st, G, scan_sorted, n, nbr, P, mp, partials, recs, dbg, out256, ticket, wl_count, seq); break;
+    case 512: launch_fit_T<512>(st, G, scan_sorted, n, nbr, P, mp, partials, recs, dbg, out256, ticket, wl_count, seq); break;
+    default: launch_fit_T<256>(st, G, scan_sorted, n, nbr, P, mp, partials, recs, dbg, out256, ticket, wl_count, seq); break;
+  }
 }
 
 void launch_reduce_final(hipStream_t st, const double* partials, int nparts, double* out256) {

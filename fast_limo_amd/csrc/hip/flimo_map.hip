@@ -163,6 +163,25 @@ hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4
   return hipGetLastError();
 }
 
+// ---- y-fastest, padded copy of the row bounds (GridView::row_table) --------------------------
+__global__ __launch_bounds__(256) void rowtable_kernel(const uint32_t* __restrict__ cell_start, int nx, int ny, int nz,
+                                                       uint32_t* __restrict__ out, size_t total) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const size_t py = (size_t)ny + 4, pz = (size_t)nz + 4;
+  const int yp = (int)(i % py), zp = (int)((i / py) % pz), x = (int)(i / (py * pz));
+  const int y = yp - 2, z = zp - 2;
+  uint32_t v = 0u;
+  if (y >= 0 && y < ny && z >= 0 && z < nz) v = cell_start[((size_t)z * ny + y) * nx + x];   // x == nx: start of the next row
+  out[i] = v;
+}
+size_t row_table_size(int nx, int ny, int nz) { return ((size_t)nx + 1) * ((size_t)ny + 4) * ((size_t)nz + 4); }
+hipError_t map_build_row_table(hipStream_t st, const uint32_t* cell_start, int nx, int ny, int nz, uint32_t* out) {
+  const size_t total = row_table_size(nx, ny, nz);
+  hipLaunchKernelGGL(rowtable_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, cell_start, nx, ny, nz, out, total);
+  return hipGetLastError();
+}
+
 // ---- spatial ordering of the scan ----------------------------------------------------------
 __device__ __forceinline__ uint32_t spread10(uint32_t v) {   // 10 bits -> every third bit
   v &= 0x3ffu;

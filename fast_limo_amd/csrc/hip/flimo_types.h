@@ -12,6 +12,9 @@ namespace flimo {
 struct GridView {
   const float4* pts;           // [n_pts]  sorted by cell id
   const uint32_t* cell_start;  // [nx*ny*nz + 1]  exclusive prefix of per-cell counts
+  const uint32_t* row_table;   // [(nx+1)][nz+4][ny+4], y fastest, two empty cells of padding on both sides of y and z:
+                               // row_table[x][z+2][y+2] = cell_start of cell (x,y,z); plane x = nx holds the row ends.
+                               // The 3 y-neighbours of a row bound are 12 contiguous bytes (fast path of the k-NN).
   float ox, oy, oz;            // min corner of cell (0,0,0)
   float inv_cell;              // 1 / cell edge
   float cell;                  // cell edge [m]

@@ -1,0 +1,60 @@
+"""Developer tool (GPU box): in-kernel phase stamps of knn5_kernel / fit_kernel from the -DFLIMO_TRACE build.
+    make -C fast_limo_amd/csrc trace;  FLIMO_HIP_LIB=fast_limo_amd/libflimo_hip_trace.so python tools/gpu_trace.py
+Prints, per phase boundary, when (relative to the first block's start, in us) the median / first / last block passed it."""
+import os, sys, ctypes as C
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("FLIMO_HIP_LIB", os.path.join(ROOT, "fast_limo_amd", "libflimo_hip_trace.so"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np
+from fast_limo_amd import synth, _lib
+
+NMAP = int(os.environ.get("NMAP", 1000000)); L = float(os.environ.get("LBOX", 100.0))
+mp = synth.box_world_map(NMAP, L, 1)
+scan = np.ascontiguousarray(synth.velodyne_scan(64, 1024, L, 2)[:, :3])
+ctx = _lib.HipCtx(0)
+ctx.map_config(cell_size=0.5)
+ctx.map_add(mp)
+ctx.scan_set(scan)
+x0 = np.zeros(26); x0[6] = 1.0; x0[10] = 1.0; x0[25] = -9.809
+mcfg = _lib.default_match_cfg(MAX_NUM_PC2MATCH=10**7, MAX_NUM_MATCHES=10**7)
+lib = _lib.load_hip()
+lib.flimo_trace_read.argtypes = [C.c_int, C.c_void_p, C.c_size_t]
+for it in range(6):
+    ctx.match_reduce(x0, mcfg)
+names = {0: ["start", "query loaded", "row bounds loaded", "candidates done", "merged", "stored"],
+         1: ["start", "scan+nbr loaded", "5 points gathered", "row computed", "partial stored", "ticket taken",
+             "LAST: partials summed", "LAST: published"]}
+nblk = {0: (scan.shape[0] * int(os.environ.get("FLIMO_LPQ", 4)) + 255) // 256, 1: (scan.shape[0] + 255) // int(os.environ.get("FLIMO_FIT_THREADS", 256))}
+for k in (0, 1):
+    nb = nblk[k]
+    buf = np.zeros(nb * 8, np.uint64)
+    rc = lib.flimo_trace_read(k, buf.ctypes.data, buf.size)
+    assert rc == 0, rc
+    t = buf.reshape(nb, 8).astype(np.int64)
+    t0 = t[:, 0].min()
+    print("kernel", "knn5" if k == 0 else "fit", "blocks", nb, " (100 MHz clock: 0.01 us resolution)")
+    for s, nm in enumerate(names[k]):
+        col = t[:, s]
+        ok = col > 0
+        if not ok.any():
+            continue
+        v = (col[ok] - t0) / 100.0
+        print(f"  {nm:24s} n={int(ok.sum()):5d}  first {v.min():7.2f}  median {np.median(v):7.2f}  p90 {np.percentile(v, 90):7.2f}  last {v.max():7.2f} us")
+    if k == 0:
+        dur = (t[:, 5] - t[:, 0]) / 100.0
+        cph = (t[:, 3] - t[:, 2]) / 100.0
+        tot = t[:, 6] // 6          # accumulated over the 6 identical passes
+        order = np.argsort(-dur)
+        print("  slowest blocks: (block, xcd=b%8, dur us, cand-phase us, block candidates, smid)")
+        for b in order[:12]:
+            print(f"    {b:5d} {b % 8} {dur[b]:6.2f} {cph[b]:6.2f} {int(tot[b]):6d} {int(t[b, 7]):#x}")
+        print("  fastest nonzero:")
+        for b in order[-6:]:
+            print(f"    {b:5d} {b % 8} {dur[b]:6.2f} {cph[b]:6.2f} {int(tot[b]):6d} {int(t[b, 7]):#x}")
+        ok = tot > 0
+        print("  corr(dur, block candidates) =", np.corrcoef(dur[ok], tot[ok])[0, 1], " block candidates: median", np.median(tot[ok]), "max", tot.max())
+        end = (t[:, 5] - t0) / 100.0
+        for x in range(8):
+            m = (np.arange(nb) % 8) == x
+            print(f"  xcd {x}: median end {np.median(end[m]):6.2f}  last end {end[m].max():6.2f}  sum cand {int(tot[m].sum())}")
+ctx.close()
