@@ -56,7 +56,7 @@ HIP_SYMBOLS = [
     "flimo_scan_voxel_filter", "flimo_raw_scan_set", "flimo_deskew_resident", "flimo_deskew",
     "flimo_match_reduce", "flimo_match_fetch", "flimo_match_fetch_H",
     "flimo_scan_to_world", "flimo_map_add_scan",
-    "flimo_set_timing", "flimo_set_debug_records", "flimo_set_lanes_per_query", "flimo_last_kernel_ms",
+    "flimo_set_timing", "flimo_set_timing_stride", "flimo_pass_count", "flimo_set_debug_records", "flimo_set_lanes_per_query", "flimo_last_kernel_ms",
     "flimo_last_candidates_per_query", "flimo_last_widen_count", "flimo_timing_totals", "flimo_insert_rule_replay",
 ]
 
@@ -108,6 +108,9 @@ def load_hip():
     L.flimo_scan_to_world.argtypes = [vp, f64p, C.c_void_p, C.c_size_t]
     L.flimo_map_add_scan.argtypes = [vp, f64p, C.c_double]
     L.flimo_set_timing.argtypes = [vp, C.c_int]
+    L.flimo_set_timing_stride.argtypes = [vp, C.c_int]
+    L.flimo_pass_count.restype = C.c_ulonglong
+    L.flimo_pass_count.argtypes = [vp]
     L.flimo_set_debug_records.argtypes = [vp, C.c_int]
     L.flimo_set_lanes_per_query.argtypes = [vp, C.c_int]
     L.flimo_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
@@ -263,6 +266,13 @@ class HipCtx:
     def set_timing(self, level=2):
         """0 off, 1 k-NN kernel only, 2 every stage (True == 2)."""
         self._chk(self._L.flimo_set_timing(self._h, 2 if level is True else int(level)))
+
+    def set_timing_stride(self, every=1):
+        """Level 1 only: time every ``every``-th pass (sampling)."""
+        self._chk(self._L.flimo_set_timing_stride(self._h, int(every)))
+
+    def pass_count(self) -> int:
+        return int(self._L.flimo_pass_count(self._h))
 
     def set_debug_records(self, on=True):
         self._chk(self._L.flimo_set_debug_records(self._h, int(on)))

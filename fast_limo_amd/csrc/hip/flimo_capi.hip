@@ -30,7 +30,8 @@ struct flimo_ctx {
   // config
   flimo_map_cfg map_cfg{0.2f, 2, 1, 0.5f};
   int lanes_per_query = 2;
-  int timing = 0;                  // 0 off, 1 k-NN kernel only (2 events per pass), 2 every stage
+  int timing = 0;                  // 0 off, 1 k-NN kernel only (events ride on its dispatch), 2 every stage
+  int timing_stride = 1;           // level 1: time every n-th pass only (sampling keeps the perturbation small)
   bool debug_recs = false;
   // map
   float4* d_map_raw = nullptr;     // insertion order
@@ -691,6 +692,8 @@ extern "C" int flimo_deskew(flimo_ctx* c, const float* xyz, size_t n, size_t str
 
 // ---- measurement pass -------------------------------------------------------------------------
 extern "C" int flimo_set_timing(flimo_ctx* c, int level) { if (!c) return FLIMO_ERR_INVALID; c->timing = level < 0 ? 0 : (level > 2 ? 2 : level); return FLIMO_OK; }
+extern "C" unsigned long long flimo_pass_count(const flimo_ctx* c) { return c ? c->pass_seq : 0ull; }
+extern "C" int flimo_set_timing_stride(flimo_ctx* c, int every) { if (!c || every < 1) return FLIMO_ERR_INVALID; c->timing_stride = every; return FLIMO_OK; }
 extern "C" int flimo_set_debug_records(flimo_ctx* c, int on) { if (!c) return FLIMO_ERR_INVALID; c->debug_recs = on != 0; return FLIMO_OK; }
 extern "C" int flimo_set_lanes_per_query(flimo_ctx* c, int l) {
   if (!c) return FLIMO_ERR_INVALID;
@@ -763,16 +766,18 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   const bool want_recs = c->debug_recs || cap_binds;
   if (c->debug_recs) HIPCHK(c, hipMemsetAsync(c->d_cand, 0, sizeof(unsigned long long), c->stream));
   const bool want_count = c->debug_recs;
-  if (c->timing > 1) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  // effective level of THIS pass (level 1 may sample every timing_stride-th pass)
+  const int tlev = (c->timing == 1 && c->timing_stride > 1 && ((c->pass_seq + 1) % (unsigned long long)c->timing_stride) != 0) ? 0 : c->timing;
+  if (tlev > 1) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   // level 1: the two events ride on the k-NN dispatch itself (kernel begin / end, no extra packets)
   launch_knn5(c->stream, c->lanes_per_query, c->grid, c->d_scan_sorted, n_all, P, mp.max_ring, c->d_nbr, c->d_wl,
-              c->d_wl_count, c->debug_recs ? c->d_cand : nullptr, c->timing == 1 ? c->ev[0] : nullptr,
-              c->timing == 1 ? c->ev[1] : nullptr);
-  if (c->timing > 1) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+              c->d_wl_count, c->debug_recs ? c->d_cand : nullptr, tlev == 1 ? c->ev[0] : nullptr,
+              tlev == 1 ? c->ev[1] : nullptr);
+  if (tlev > 1) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
   launch_widen(c->stream, c->grid, c->d_scan_sorted, P, mp.max_ring, c->d_nbr, c->d_wl, c->d_wl_count,
                c->debug_recs ? c->d_cand : nullptr);
   if (want_count) HIPCHK(c, hipMemcpyAsync(c->h_wl_count, c->d_wl_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  if (c->timing > 1) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+  if (tlev > 1) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   // fit + reductions; the last block writes the 16x16 accumulator to mapped host memory, publishes the
   // pass number and re-arms the ticket and the worklist counter
   const unsigned long long seq = ++c->pass_seq;
@@ -782,10 +787,10 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
     launch_cap(c->stream, c->d_recs, (int)nq, cfg->MAX_NUM_MATCHES);
     launch_reduce(c->stream, c->d_recs, (int)nq, c->reduce_waves, c->d_partials, c->d_out256_host);
   }
-  if (c->timing > 1) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+  if (tlev > 1) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
   HIPCHK(c, hipGetLastError());
   if (c->debug_recs) HIPCHK(c, hipMemcpyAsync(c->h_cand, c->d_cand, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-  if (!cap_binds && !c->debug_recs && c->timing < 2) {
+  if (!cap_binds && !c->debug_recs && tlev < 2) {
     // low-latency completion: spin on the pass number every reduction group publishes to host memory
     unsigned long long spins = 0;
     for (int g = 0; g < FIT_GROUPS; g++) {
@@ -796,14 +801,14 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
       }
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    if (c->timing) HIPCHK(c, hipEventSynchronize(c->ev[1]));
+    if (tlev) HIPCHK(c, hipEventSynchronize(c->ev[1]));
   } else {
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
-  if (c->timing) {
+  if (tlev) {
     (void)hipEventElapsedTime(&c->last_knn_ms, c->ev[0], c->ev[1]);
     c->tot_knn_ms += c->last_knn_ms;
-    if (c->timing > 1) {
+    if (tlev > 1) {
       (void)hipEventElapsedTime(&c->last_widen_ms, c->ev[1], c->ev[2]);
       (void)hipEventElapsedTime(&c->last_fit_ms, c->ev[2], c->ev[3]);
       c->tot_widen_ms += c->last_widen_ms; c->tot_fit_ms += c->last_fit_ms;

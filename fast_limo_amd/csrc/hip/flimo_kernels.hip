@@ -1112,11 +1112,17 @@ void launch_knn5(hipStream_t st, int lanes_per_query, const GridView& G, const f
   }
 }
 
+static int g_widen_blocks = 0;
+static int widen_blocks() {
+  // default 2048 blocks = 8 waves per SIMD: the wave-per-query search is a latency chain
+  if (g_widen_blocks == 0) { const char* e = getenv("FLIMO_WIDEN_BLOCKS"); const int v = e ? atoi(e) : 0; g_widen_blocks = v > 0 ? v : 2048; }
+  return g_widen_blocks;
+}
 void launch_widen(hipStream_t st, const GridView& G, const float4* scan_sorted, const PoseMats& P, int max_ring, void* nbr,
                   int* wl, int* wl_count, unsigned long long* cand) {
   if (max_ring <= 1) return;
   if (max_ring <= 3)
-    hipLaunchKernelGGL(widen_kernel, dim3(1024), dim3(256), 0, st, G, scan_sorted, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand);
+    hipLaunchKernelGGL(widen_kernel, dim3(widen_blocks()), dim3(256), 0, st, G, scan_sorted, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand);
   else
     hipLaunchKernelGGL(widen_general_kernel, dim3(256), dim3(256), 0, st, G, scan_sorted, P, max_ring, (NbrRec*)nbr, wl, wl_count);
 }

@@ -143,6 +143,10 @@ int flimo_map_add_scan(flimo_ctx* ctx, const double x26[26], double stamp);
  * k-NN fast path, ring widening of the worklist, fit + reductions.  flimo_set_timing level:
  * 0 off, 1 k-NN kernel only (two events per pass), 2 every stage. */
 int flimo_set_timing(flimo_ctx* ctx, int level);
+/* level 1 only: time every `every`-th pass (default 1 = all); the totals count the timed passes only. */
+int flimo_set_timing_stride(flimo_ctx* ctx, int every);
+/* number of flimo_match_reduce passes launched on this context so far */
+unsigned long long flimo_pass_count(const flimo_ctx* ctx);
 int flimo_last_kernel_ms(const flimo_ctx* ctx, float* knn_ms, float* widen_ms, float* fit_ms);
 /* sums over every pass since the last reset (timing must be on): per-stage GPU ms, passes, k-NN queries */
 int flimo_timing_totals(flimo_ctx* ctx, double* knn_ms, double* widen_ms, double* fit_ms, long long* passes,
