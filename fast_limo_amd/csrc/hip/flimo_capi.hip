@@ -247,6 +247,8 @@ extern "C" int flimo_ctx_create(int device, flimo_ctx** out) {
   const char* e = getenv("FLIMO_LPQ");
   if (e) { int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) c->lanes_per_query = v; }
   c->book = insert_book_create();
+  e = getenv("FLIMO_XCD_STRIPE");
+  if (e) set_xcd_stripe(atoi(e));
   e = getenv("FLIMO_HOST_INSERT");
   c->host_insert = e && atoi(e) != 0;
   *out = c;

@@ -13,6 +13,7 @@ void launch_knn5(hipStream_t st, int lanes_per_query, const GridView& G, const f
 void launch_widen(hipStream_t st, const GridView& G, const float4* scan_sorted, const PoseMats& P, int max_ring, void* nbr,
                   int* wl, int* wl_count, unsigned long long* cand);
 int fit_blocks(int n);
+void set_xcd_stripe(int stripe);   // block -> scan chunk mapping of the per-pass kernels (see xcd_chunk)
 // the fit kernel reduces in FIT_GROUPS groups; slot g of its output = 256 sums + the pass number (FIT_SLOT doubles)
 constexpr int FIT_GROUPS = 8;
 constexpr int FIT_SLOT = 264;

@@ -286,9 +286,21 @@ FLIMO_DEV void key5_insert(u64 (&k)[5], u64 key) {
   }
 }
 
+// Block -> chunk of the Morton-sorted scan.  The dispatcher places block b on XCD b % 8 (observed); XCD x works on
+// stripes of c_stripe consecutive chunks, stripes dealt round-robin over the XCDs: neighbouring queries (same map
+// cells) stay on one XCD's L2 while every XCD gets its share of the cheap (outside the map) and the expensive
+// (far, cache-cold) parts of the scan.  c_stripe = 0: one contiguous eighth per XCD.
+__constant__ int c_stripe = 8;
+void set_xcd_stripe(int stripe) { (void)hipMemcpyToSymbol(HIP_SYMBOL(c_stripe), &stripe, sizeof(int)); }
+
 __device__ __forceinline__ int xcd_chunk(int b, int nb) {
   // nb is a multiple of 8
-  return (b & 7) * (nb >> 3) + (b >> 3);
+  const int x = b & 7, k = b >> 3, per = nb >> 3;
+  const int S = c_stripe;
+  if (S <= 0 || S >= per) return x * per + k;
+  const int full = (per / S) * S;                 // the last partial stripe of every XCD falls back to contiguous
+  if (k >= full) return 8 * full + x * (per - full) + (k - full);
+  return ((k / S) * 8 + x) * S + (k % S);
 }
 
 struct NbrRec {      // 32 bytes per query (sorted order)
@@ -320,6 +332,50 @@ FLIMO_DEV void best5_insert(float (&kd)[5], uint32_t (&ki)[5], float x, uint32_t
   kd[0] = c0 ? x : kd[0];
 }
 #define KEY_NONE 0x7f800000ffffffffull     // (+inf, -1): an empty slot of the merged list
+
+// N candidate slots of one lane: stream positions s0, s0 + L, ...; dead slots (>= total) re-read the last position and
+// insert +inf.  All N loads are issued back to back (the empty asm consumes every loaded value at once).
+template <int L, int N>
+__device__ __forceinline__ void knn5_body(const float4* __restrict__ pts, uint32_t s0, uint32_t total, uint32_t last,
+                                          const uint32_t (&off)[10], const uint32_t (&dl)[9], float gx, float gy, float gz,
+                                          float (&kd)[5], uint32_t (&ki)[5]) {
+  float4 pt[N];
+  uint32_t id[N];
+#pragma unroll
+  for (int u = 0; u < N; u++) {
+    const uint32_t s = min(s0 + u * L, last);
+    uint32_t delta = dl[0];
+#pragma unroll
+    for (int t = 1; t < 9; t++) delta = (s >= off[t]) ? dl[t] : delta;
+    id[u] = s + delta;
+    pt[u] = pts[id[u]];
+  }
+  if constexpr (N == 16) {
+    asm volatile("" : "+v"(pt[0].x), "+v"(pt[0].y), "+v"(pt[0].z), "+v"(pt[1].x), "+v"(pt[1].y), "+v"(pt[1].z),
+                      "+v"(pt[2].x), "+v"(pt[2].y), "+v"(pt[2].z), "+v"(pt[3].x), "+v"(pt[3].y), "+v"(pt[3].z),
+                      "+v"(pt[4].x), "+v"(pt[4].y), "+v"(pt[4].z), "+v"(pt[5].x), "+v"(pt[5].y), "+v"(pt[5].z),
+                      "+v"(pt[6].x), "+v"(pt[6].y), "+v"(pt[6].z), "+v"(pt[7].x), "+v"(pt[7].y), "+v"(pt[7].z),
+                      "+v"(pt[8].x), "+v"(pt[8].y), "+v"(pt[8].z), "+v"(pt[9].x), "+v"(pt[9].y), "+v"(pt[9].z));
+    asm volatile("" : "+v"(pt[10].x), "+v"(pt[10].y), "+v"(pt[10].z), "+v"(pt[11].x), "+v"(pt[11].y), "+v"(pt[11].z),
+                      "+v"(pt[12].x), "+v"(pt[12].y), "+v"(pt[12].z), "+v"(pt[13].x), "+v"(pt[13].y), "+v"(pt[13].z),
+                      "+v"(pt[14].x), "+v"(pt[14].y), "+v"(pt[14].z), "+v"(pt[15].x), "+v"(pt[15].y), "+v"(pt[15].z));
+  } else if constexpr (N == 8)
+    asm volatile("" : "+v"(pt[0].x), "+v"(pt[0].y), "+v"(pt[0].z), "+v"(pt[1].x), "+v"(pt[1].y), "+v"(pt[1].z),
+                      "+v"(pt[2].x), "+v"(pt[2].y), "+v"(pt[2].z), "+v"(pt[3].x), "+v"(pt[3].y), "+v"(pt[3].z),
+                      "+v"(pt[4].x), "+v"(pt[4].y), "+v"(pt[4].z), "+v"(pt[5].x), "+v"(pt[5].y), "+v"(pt[5].z),
+                      "+v"(pt[6].x), "+v"(pt[6].y), "+v"(pt[6].z), "+v"(pt[7].x), "+v"(pt[7].y), "+v"(pt[7].z));
+  else if constexpr (N == 4)
+    asm volatile("" : "+v"(pt[0].x), "+v"(pt[0].y), "+v"(pt[0].z), "+v"(pt[1].x), "+v"(pt[1].y), "+v"(pt[1].z),
+                      "+v"(pt[2].x), "+v"(pt[2].y), "+v"(pt[2].z), "+v"(pt[3].x), "+v"(pt[3].y), "+v"(pt[3].z));
+  else if constexpr (N == 2)
+    asm volatile("" : "+v"(pt[0].x), "+v"(pt[0].y), "+v"(pt[0].z), "+v"(pt[1].x), "+v"(pt[1].y), "+v"(pt[1].z));
+#pragma unroll
+  for (int u = 0; u < N; u++) {
+    const bool live = s0 + u * L < total;
+    const float d = sqdist3(gx, gy, gz, pt[u].x, pt[u].y, pt[u].z);
+    best5_insert(kd, ki, live ? d : INFINITY, id[u]);
+  }
+}
 
 template <int L, int SLOTS>
 __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __restrict__ scan_sorted, int n,
@@ -385,35 +441,12 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
       float kd[5] = {INFINITY, INFINITY, INFINITY, INFINITY, INFINITY};
       uint32_t ki[5] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
       const uint32_t last = total - 1u;
-      for (uint32_t s0 = (uint32_t)sub; s0 < total; s0 += SLOTS * L) {
-        float4 pt[SLOTS];
-        uint32_t id[SLOTS];
-#pragma unroll
-        for (int u = 0; u < SLOTS; u++) {
-          const uint32_t s = min(s0 + u * L, last);
-          uint32_t delta = dl[0];
-#pragma unroll
-          for (int t = 1; t < 9; t++) delta = (s >= off[t]) ? dl[t] : delta;
-          id[u] = s + delta;
-          pt[u] = G.pts[id[u]];
-        }
-        // all SLOTS loads are issued back to back: the empty asm consumes every loaded value at once
-        if constexpr (SLOTS == 8)
-          asm volatile("" : "+v"(pt[0].x), "+v"(pt[0].y), "+v"(pt[0].z), "+v"(pt[1].x), "+v"(pt[1].y), "+v"(pt[1].z),
-                            "+v"(pt[2].x), "+v"(pt[2].y), "+v"(pt[2].z), "+v"(pt[3].x), "+v"(pt[3].y), "+v"(pt[3].z),
-                            "+v"(pt[4].x), "+v"(pt[4].y), "+v"(pt[4].z), "+v"(pt[5].x), "+v"(pt[5].y), "+v"(pt[5].z),
-                            "+v"(pt[6].x), "+v"(pt[6].y), "+v"(pt[6].z), "+v"(pt[7].x), "+v"(pt[7].y), "+v"(pt[7].z));
-        else if constexpr (SLOTS == 4)
-          asm volatile("" : "+v"(pt[0].x), "+v"(pt[0].y), "+v"(pt[0].z), "+v"(pt[1].x), "+v"(pt[1].y), "+v"(pt[1].z),
-                            "+v"(pt[2].x), "+v"(pt[2].y), "+v"(pt[2].z), "+v"(pt[3].x), "+v"(pt[3].y), "+v"(pt[3].z));
-#pragma unroll
-        for (int u = 0; u < SLOTS; u++) {
-          const bool live = s0 + u * L < total;
-          const float d = sqdist3(gx, gy, gz, pt[u].x, pt[u].y, pt[u].z);
-          best5_insert(kd, ki, live ? d : INFINITY, id[u]);
-          cand += live ? 1 : 0;
-        }
-      }
+      // full bodies while more than half of a body's slots are live for this lane, then one half body
+      uint32_t s0 = (uint32_t)sub;
+      for (; s0 + (SLOTS / 2) * L < total; s0 += SLOTS * L)
+        knn5_body<L, SLOTS>(G.pts, s0, total, last, off, dl, gx, gy, gz, kd, ki);
+      if (s0 < total) knn5_body<L, (SLOTS >= 2 ? SLOTS / 2 : 1)>(G.pts, s0, total, last, off, dl, gx, gy, gz, kd, ki);
+      cand = total > (uint32_t)sub ? (int)((total - (uint32_t)sub + L - 1) / L) : 0;
 #pragma unroll
       for (int i = 0; i < 5; i++) best[i] = ((u64)__float_as_uint(kd[i]) << 32) | (u64)ki[i];
       TRACE(0, 3);
@@ -1090,7 +1123,9 @@ static void launch_knn5_L(hipStream_t st, const GridView& G, const float4* scan_
   const int slots = g_slots > 0 ? g_slots : (L <= 4 ? 8 : 4);
   // e0 / e1 (optional) are attached to the dispatch itself: they read the kernel's own begin / end
   // timestamps, without the extra barrier packets of hipEventRecord
-  if (slots >= 8)
+  if (slots >= 16 && L <= 2)
+    hipExtLaunchKernelGGL((knn5_kernel<L, 16>), dim3(blocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand);
+  else if (slots >= 8)
     hipExtLaunchKernelGGL((knn5_kernel<L, 8>), dim3(blocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand);
   else if (slots >= 4)
     hipExtLaunchKernelGGL((knn5_kernel<L, 4>), dim3(blocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand);
