@@ -771,7 +771,8 @@ __global__ __launch_bounds__(FIT_THREADS) void fit_kernel(GridView G, const floa
     double r = 0.0;
 #pragma unroll
     for (int w = 0; w < FIT_WAVES; w++) r += s_acc[w][t];          // fixed order
-    partials[(size_t)blockIdx.x * 256 + t] = r;
+    // written through to the agent-coherent level (no dirty L2 line is left behind for the ticket to flush)
+    __hip_atomic_store(&partials[(size_t)blockIdx.x * 256 + t], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   // ---- grid reduction in FIT_GROUPS independent groups (blocks b, b + 8, b + 16, ...): the last block of a
   //      group to arrive sums the group's partials in block order and writes them, followed by the pass
@@ -783,17 +784,15 @@ __global__ __launch_bounds__(FIT_THREADS) void fit_kernel(GridView G, const floa
   const int group = blockIdx.x & (FIT_GROUPS - 1);
   const int nb_g = (int)(gridDim.x / FIT_GROUPS);                  // gridDim.x is a multiple of 8
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // every partial of this block is already performed at agent scope (write-through stores, vmcnt(0), barrier)
     const unsigned int old = __hip_atomic_fetch_add(ticket + group, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = (old == (unsigned int)nb_g - 1u) ? 1u : 0u;
   }
   __syncthreads();
   TRACE(1, 5);
   if (s_last) {
-    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    __syncthreads();
-    // 256 accumulator slots x (FIT_THREADS / 256) slices of the group's block list; up to 32 loads in flight
+    // 256 accumulator slots x (FIT_THREADS / 256) slices of the group's block list; up to 32 loads in flight;
+    // agent-scope atomic loads read past this XCD's L2
     constexpr int PARTS = FIT_THREADS / 256;
     const int t = threadIdx.x & 255, part = threadIdx.x >> 8;
     const int per = (nb_g + PARTS - 1) / PARTS;
@@ -805,17 +804,17 @@ __global__ __launch_bounds__(FIT_THREADS) void fit_kernel(GridView G, const floa
     for (; k + 31 < k1; k += 32) {
       double v[32];
 #pragma unroll
-      for (int u = 0; u < 32; u++) v[u] = __builtin_nontemporal_load(base + (size_t)(k + u) * stride);
+      for (int u = 0; u < 32; u++) v[u] = __hip_atomic_load(base + (size_t)(k + u) * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
       for (int u = 0; u < 32; u += 4) { s0 += v[u]; s1 += v[u + 1]; s2 += v[u + 2]; s3 += v[u + 3]; }
     }
     for (; k + 3 < k1; k += 4) {
       double v[4];
 #pragma unroll
-      for (int u = 0; u < 4; u++) v[u] = __builtin_nontemporal_load(base + (size_t)(k + u) * stride);
+      for (int u = 0; u < 4; u++) v[u] = __hip_atomic_load(base + (size_t)(k + u) * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       s0 += v[0]; s1 += v[1]; s2 += v[2]; s3 += v[3];
     }
-    for (; k < k1; k++) s0 += __builtin_nontemporal_load(base + (size_t)k * stride);
+    for (; k < k1; k++) s0 += __hip_atomic_load(base + (size_t)k * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_acc[part][t] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     TRACE(1, 6);
@@ -824,15 +823,16 @@ __global__ __launch_bounds__(FIT_THREADS) void fit_kernel(GridView G, const floa
       double r = 0.0;
 #pragma unroll
       for (int q = 0; q < PARTS; q++) r += s_acc[q][t];
-      out[t] = r;
+      __hip_atomic_store(&out[t], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    // publish: out256 may live in mapped host memory; the host spins on word 256 of every slot
-    __threadfence_system();
+    // publish: out256 may live in mapped host memory; the host spins on word 256 of every slot.  The value
+    // stores are complete (vmcnt(0)) before the barrier, the pass number is stored after it.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-      ticket[group] = 0u;                                          // ready for the next pass
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(out + 256), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      ticket[group] = 0u;                                          // ready for the next pass (visible at kernel end)
       if (group == 0) *wl_count = 0;
-      __hip_atomic_store(reinterpret_cast<unsigned long long*>(out + 256), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     TRACE(1, 7);
   }
