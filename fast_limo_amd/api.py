@@ -41,7 +41,7 @@ class LocCfg(C.Structure):
 
 
 HOST_SYMBOLS = [
-    "flimo_loc_create", "flimo_loc_destroy", "flimo_loc_ctx", "flimo_loc_update_imu", "flimo_loc_update_pointcloud",
+    "flimo_loc_create", "flimo_loc_destroy", "flimo_loc_ctx", "flimo_loc_update_imu", "flimo_loc_update_pointcloud", "flimo_loc_update_pointcloud_points",
     "flimo_loc_map_add", "flimo_loc_map_size", "flimo_loc_get_x", "flimo_loc_set_x", "flimo_loc_get_P",
     "flimo_loc_set_P", "flimo_loc_set_flags", "flimo_loc_num_passes", "flimo_loc_get_pass", "flimo_loc_get_pc2match",
     "flimo_loc_get_final_scan", "flimo_loc_get_stage_times", "flimo_loc_get_pose_cov", "flimo_loc_register_resident", "flimo_loc_host_profile",
@@ -106,6 +106,7 @@ def load_host():
     L.flimo_loc_ctx.argtypes = [vp]
     L.flimo_loc_update_imu.argtypes = [vp, C.c_double, f32p, f32p]
     L.flimo_loc_update_pointcloud.argtypes = [vp, f32p, C.c_size_t, C.c_double]
+    L.flimo_loc_update_pointcloud_points.argtypes = [vp, C.c_void_p, C.c_size_t, C.c_double]
     L.flimo_loc_map_add.argtypes = [vp, f32p, C.c_size_t, C.c_double]
     L.flimo_loc_map_size.restype = C.c_size_t
     L.flimo_loc_map_size.argtypes = [vp]
@@ -173,6 +174,12 @@ class Localizer:
     def update_pointcloud(self, pts5, stamp) -> int:
         p = np.ascontiguousarray(pts5, dtype=np.float32).reshape(-1, 5)
         return int(self._L.flimo_loc_update_pointcloud(self._h, p.reshape(-1), p.shape[0], float(stamp)))
+
+    def update_pointcloud_points(self, pts32, stamp) -> int:
+        """pts32: structured array in the reference's 32-byte PointType layout (itemsize 32)."""
+        p = np.ascontiguousarray(pts32)
+        assert p.dtype.itemsize == 32
+        return int(self._L.flimo_loc_update_pointcloud_points(self._h, p.ctypes.data, p.shape[0], float(stamp)))
 
     def map_add(self, xyz, stamp=0.0):
         xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)

@@ -103,6 +103,15 @@ int flimo_loc_update_pointcloud(flimo_loc* L, const float* pts5, size_t n, doubl
   L->loc->updatePointCloud(pc, stamp);
   return L->loc->last_status();
 }
+int flimo_loc_update_pointcloud_points(flimo_loc* L, const void* pts32, size_t n, double stamp) {
+  if (!L || (!pts32 && n)) return FLIMO_ERR_INVALID;
+  static_assert(sizeof(PointType) == 32, "PointType must keep the reference's 32-byte layout");
+  auto pc = std::make_shared<pcl::PointCloud<PointType>>();
+  pc->points.resize(n);
+  if (n) std::memcpy(static_cast<void*>(&pc->points[0]), pts32, n * sizeof(PointType));
+  L->loc->updatePointCloud(pc, stamp);
+  return L->loc->last_status();
+}
 int flimo_loc_map_add(flimo_loc* L, const float* xyz, size_t n, double stamp) {
   if (!L) return FLIMO_ERR_INVALID;
   if (!L->map->ctx()) return FLIMO_ERR_NO_DEVICE;

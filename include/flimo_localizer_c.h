@@ -50,6 +50,10 @@ int    flimo_loc_update_imu(flimo_loc* L, double stamp, const float ang_vel[3], 
 /* pts5: n x (x y z intensity time[s since sweep reference]).  Returns Localizer status:
  * 0 ok, 1 null iteration, <0 early return */
 int    flimo_loc_update_pointcloud(flimo_loc* L, const float* pts5, size_t n, double stamp);
+/* The same with points in the reference's PointType layout (Common.hpp:100-113): float x, y, z, w; float intensity;
+ * 4 bytes of padding; 8-byte time union {uint32 t (OUSTER ns) | float time (VELODYNE s) | double timestamp
+ * (HESAI s, LIVOX ns)} -- the view that is read follows flimo_loc_cfg.sensor_type. */
+int    flimo_loc_update_pointcloud_points(flimo_loc* L, const void* points32, size_t n, double stamp);
 int    flimo_loc_map_add(flimo_loc* L, const float* xyz, size_t n, double stamp);   /* Mapper::add */
 size_t flimo_loc_map_size(flimo_loc* L);
 void   flimo_loc_get_x(flimo_loc* L, double x26[26]);

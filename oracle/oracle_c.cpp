@@ -1,5 +1,6 @@
 // oracle/oracle_c.cpp -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
 // C entry points over the restatement headers (rl_*.h).  See oracle_c.h.
+#include <cstring>
 #include "oracle_c.h"
 #include "rl_localizer.h"
 
@@ -39,6 +40,15 @@ static LocCfg to_loc_cfg(const oracle_cfg* c) {
   L.imu_calib_time = c->imu_calib_time;
   L.voxel_active = c->voxel_active != 0;
   L.leaf_size = c->leaf_size;
+  L.sensor_type = c->sensor_type;
+  L.crop_active = c->crop_active != 0;
+  for (int i = 0; i < 3; i++) { L.crop_min[i] = c->crop_min[i]; L.crop_max[i] = c->crop_max[i]; }
+  L.dist_active = c->dist_active != 0;
+  L.min_dist = c->min_dist;
+  L.rate_active = c->rate_active != 0;
+  L.rate_value = c->rate_value;
+  L.fov_active = c->fov_active != 0;
+  L.fov_angle = c->fov_angle;
   return L;
 }
 
@@ -190,6 +200,20 @@ static std::vector<Pt> to_pts5(const float* p, size_t n) {
   std::vector<Pt> v(n);
   for (size_t i = 0; i < n; i++) { v[i].x = p[5 * i]; v[i].y = p[5 * i + 1]; v[i].z = p[5 * i + 2]; v[i].intensity = p[5 * i + 3]; v[i].time = p[5 * i + 4]; }
   return v;
+}
+int oracle_loc_update_pointcloud_points(void* Lp, const void* pts32, size_t n, double stamp, int add_to_map) {
+  Localizer* L = (Localizer*)Lp;
+  std::vector<Pt> v(n);
+  const unsigned char* b = (const unsigned char*)pts32;
+  for (size_t i = 0; i < n; i++) {
+    const unsigned char* q = b + 32 * i;
+    std::memcpy(&v[i].x, q, 4); std::memcpy(&v[i].y, q + 4, 4); std::memcpy(&v[i].z, q + 8, 4);
+    std::memcpy(&v[i].intensity, q + 16, 4);
+    std::memcpy(&v[i].t, q + 24, 4);            // the three views of the union
+    std::memcpy(&v[i].time, q + 24, 4);
+    std::memcpy(&v[i].timestamp, q + 24, 8);
+  }
+  return L->updatePointCloud(v, stamp, add_to_map != 0);
 }
 int oracle_loc_update_pointcloud(void* Lp, const float* pts5, size_t n, double stamp, int add_to_map) {
   Localizer* L = (Localizer*)Lp;

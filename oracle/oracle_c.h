@@ -31,6 +31,14 @@ typedef struct oracle_cfg {
   double imu_calib_time;
   int voxel_active;
   float leaf_size;
+  int sensor_type;            /* 0 OUSTER, 1 VELODYNE, 2 HESAI, 3 LIVOX (Common.hpp:82) */
+  int crop_active;
+  float crop_min[3], crop_max[3];
+  int dist_active;
+  double min_dist;
+  int rate_active, rate_value;
+  int fov_active;
+  float fov_angle;
 } oracle_cfg;
 
 /* per scan-point record of Mapper::match (before compaction) */
@@ -81,6 +89,8 @@ void   oracle_loc_destroy(void* L);
 void   oracle_loc_update_imu(void* L, double stamp, const float ang_vel[3], const float lin_accel[3]);
 /* pts: n x 5 floats (x y z intensity time).  returns 0 ok / 1 null iteration / <0 early return */
 int    oracle_loc_update_pointcloud(void* L, const float* pts5, size_t n, double stamp, int add_to_map);
+/* points in the reference's 32-byte PointType layout: float x,y,z,w; float intensity; 4 bytes pad; 8-byte time union */
+int    oracle_loc_update_pointcloud_points(void* L, const void* pts32, size_t n, double stamp, int add_to_map);
 void   oracle_loc_map_add(void* L, const float* xyz, size_t n, double stamp);
 size_t oracle_loc_map_size(void* L);
 void   oracle_loc_get_x(void* L, double x26[26]);

@@ -36,7 +36,36 @@ class OracleCfg(C.Structure):
         ("gravity_align", C.c_int), ("calibrate_accel", C.c_int), ("calibrate_gyro", C.c_int),
         ("imu_calib_time", C.c_double),
         ("voxel_active", C.c_int), ("leaf_size", C.c_float),
+        ("sensor_type", C.c_int),
+        ("crop_active", C.c_int), ("crop_min", C.c_float * 3), ("crop_max", C.c_float * 3),
+        ("dist_active", C.c_int), ("min_dist", C.c_double),
+        ("rate_active", C.c_int), ("rate_value", C.c_int),
+        ("fov_active", C.c_int), ("fov_angle", C.c_float),
     ]
+
+
+# the reference's PointType (Common.hpp:100-113): xyz1, intensity, 4 bytes of padding, 8-byte time union
+POINT_DTYPE = np.dtype({"names": ["x", "y", "z", "w", "intensity", "tu"],
+                        "formats": [np.float32, np.float32, np.float32, np.float32, np.float32, np.uint64],
+                        "offsets": [0, 4, 8, 12, 16, 24], "itemsize": 32})
+
+
+def make_points(xyz, intensity=None, t_ns=None, time_s=None, timestamp=None):
+    """Build PointType records; exactly one of t_ns (uint32, OUSTER), time_s (float32, VELODYNE) and
+    timestamp (float64: HESAI seconds / LIVOX nanoseconds) selects the view of the time union."""
+    xyz = np.asarray(xyz, np.float32).reshape(-1, 3)
+    p = np.zeros(xyz.shape[0], POINT_DTYPE)
+    p["x"], p["y"], p["z"], p["w"] = xyz[:, 0], xyz[:, 1], xyz[:, 2], 1.0
+    if intensity is not None:
+        p["intensity"] = intensity
+    raw = p.view(np.uint8).reshape(-1, 32)
+    if t_ns is not None:
+        raw[:, 24:28] = np.asarray(t_ns, np.uint32).reshape(-1, 1).view(np.uint8)
+    elif time_s is not None:
+        raw[:, 24:28] = np.asarray(time_s, np.float32).reshape(-1, 1).view(np.uint8)
+    elif timestamp is not None:
+        raw[:, 24:32] = np.asarray(timestamp, np.float64).reshape(-1, 1).view(np.uint8)
+    return p
 
 
 MATCH_REC_DTYPE = np.dtype([
@@ -65,6 +94,11 @@ def default_cfg(**kw) -> OracleCfg:
     c.gravity_align = c.calibrate_accel = c.calibrate_gyro = 0
     c.imu_calib_time = 3.0
     c.voxel_active, c.leaf_size = 0, 0.25
+    c.sensor_type = 1                                   # VELODYNE
+    c.crop_active, c.dist_active, c.rate_active, c.fov_active = 0, 0, 0, 0
+    for i in range(3):
+        c.crop_min[i], c.crop_max[i] = -1.0, 1.0
+    c.min_dist, c.rate_value, c.fov_angle = 4.0, 4, 3.14159265
     eye = [1, 0, 0, 0, 1, 0, 0, 0, 1]
     for i in range(9):
         c.imu2baselink_R[i] = eye[i]
@@ -119,6 +153,8 @@ def lib():
     L.oracle_loc_update_imu.argtypes = [vp, C.c_double, f32p, f32p]
     L.oracle_loc_update_pointcloud.restype = C.c_int
     L.oracle_loc_update_pointcloud.argtypes = [vp, f32p, C.c_size_t, C.c_double, C.c_int]
+    L.oracle_loc_update_pointcloud_points.restype = C.c_int
+    L.oracle_loc_update_pointcloud_points.argtypes = [vp, C.c_void_p, C.c_size_t, C.c_double, C.c_int]
     L.oracle_loc_map_add.argtypes = [vp, f32p, C.c_size_t, C.c_double]
     L.oracle_loc_map_size.restype = C.c_size_t
     L.oracle_loc_map_size.argtypes = [vp]
@@ -246,6 +282,12 @@ class Localizer:
     def update_pointcloud(self, pts5, stamp, add_to_map=True) -> int:
         p = _f32(pts5).reshape(-1, 5)
         return int(lib().oracle_loc_update_pointcloud(self._h, p, p.shape[0], float(stamp), int(add_to_map)))
+
+    def update_pointcloud_points(self, pts32, stamp, add_to_map=True) -> int:
+        """pts32: structured array in the reference's 32-byte PointType layout (see POINT_DTYPE)."""
+        p = np.ascontiguousarray(pts32)
+        assert p.dtype.itemsize == 32
+        return int(lib().oracle_loc_update_pointcloud_points(self._h, p.ctypes.data, p.shape[0], float(stamp), int(add_to_map)))
 
     def map_add(self, xyz, stamp=0.0):
         xyz = _f32(xyz).reshape(-1, 3)

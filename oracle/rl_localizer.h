@@ -12,14 +12,16 @@
 //       propagatedFromTimeRange)
 //   fast_limo/Utils/Algorithms.hpp:25-38 (binary_search_tailored)
 //   IKFoM/use-ikfom.cpp:10-31 (h_share_model)
-// Out of scope here: IMU calibration, crop/voxel/min-dist/rate/FoV
-// filters (must be configured off), debug board.  Only SensorType::VELODYNE time decoding is
-// restated (float `time` since sweep reference).
+//   fast_limo/Modules/Localizer.cpp:262-302 (NaN removal, negative crop box, distance / rate / FoV filters),
+//       :873-876 (isInRange), :745-781 (per-sensor time decoding: OUSTER / VELODYNE / HESAI / LIVOX)
+// Out of scope here: debug board, ROS I/O.
 // PARITY UNPINNED: the reference has no tests and cannot be built here (Eigen/PCL/Boost absent).
 #pragma once
 #include <vector>
 #include <deque>
 #include <algorithm>
+#include <functional>
+#include <cstdint>
 #include <cstdio>
 #include <cfloat>
 #include <climits>
@@ -30,8 +32,15 @@
 
 namespace oracle {
 
-// PointType subset: xyz + intensity + float time (Common.hpp:100-113; 32-byte AoS in the reference)
-struct Pt { float x, y, z, intensity, time; };
+// PointType (Common.hpp:100-113; 32-byte AoS with a time UNION in the reference).  The three views of the union
+// are kept as separate members here; the C entry point fills the one the configured sensor reads.
+struct Pt {
+  float x, y, z, intensity;
+  float time = 0.f;          // VELODYNE: s since the sweep reference
+  uint32_t t = 0;            // OUSTER: ns since the sweep reference
+  double timestamp = 0.0;    // HESAI: absolute s; LIVOX: absolute ns
+};
+enum SensorType { OUSTER = 0, VELODYNE = 1, HESAI = 2, LIVOX = 3, UNKNOWN = 4 };   // Common.hpp:82
 
 struct MappingCfg {                 // Config::iKFoM::Mapping  (Utils/Config.hpp:58-69)
   int NUM_MATCH_POINTS = 5;
@@ -64,6 +73,15 @@ struct LocCfg {                     // the subset of fast_limo::Config the hot p
   double imu_calib_time = 3.0;
   bool voxel_active = false;
   float leaf_size = 0.25f;
+  int sensor_type = VELODYNE;
+  bool crop_active = false;                 // Config::filters (Utils/Config.hpp:40-56)
+  float crop_min[3] = {-1.f, -1.f, -1.f}, crop_max[3] = {1.f, 1.f, 1.f};
+  bool dist_active = false;
+  double min_dist = 4.0;
+  bool rate_active = false;
+  int rate_value = 4;
+  bool fov_active = false;
+  float fov_angle = 3.14159265f;
   LocCfg() { for (int i = 0; i < NDOF; i++) LIMITS[i] = 1e-3; }
 };
 
@@ -555,8 +573,25 @@ struct Localizer {
     if (pc.empty()) return false;
     double sweep_ref_time = start_time;
     const bool eos = config.end_of_sweep;
-    auto cmp = [eos](const Pt& a, const Pt& b) { return eos ? a.time > b.time : a.time < b.time; };
-    auto extract = [sweep_ref_time, eos](const Pt& p) { return eos ? sweep_ref_time - p.time : sweep_ref_time + p.time; };
+    // Localizer.cpp:745-781: comparator and time decoding per sensor.  `pt.t * 1e-9f` is a float product
+    // (uint32 converted to float), `pt.timestamp * 1e-9f` a double product.
+    std::function<bool(const Pt&, const Pt&)> cmp;
+    std::function<double(const Pt&)> extract;
+    if (config.sensor_type == OUSTER) {
+      cmp = [eos](const Pt& a, const Pt& b) { return eos ? a.t > b.t : a.t < b.t; };
+      extract = [sweep_ref_time, eos](const Pt& p) { return eos ? sweep_ref_time - p.t * 1e-9f : sweep_ref_time + p.t * 1e-9f; };
+    } else if (config.sensor_type == VELODYNE) {
+      cmp = [eos](const Pt& a, const Pt& b) { return eos ? a.time > b.time : a.time < b.time; };
+      extract = [sweep_ref_time, eos](const Pt& p) { return eos ? sweep_ref_time - p.time : sweep_ref_time + p.time; };
+    } else if (config.sensor_type == HESAI) {
+      cmp = [](const Pt& a, const Pt& b) { return a.timestamp < b.timestamp; };
+      extract = [](const Pt& p) { return p.timestamp; };
+    } else if (config.sensor_type == LIVOX) {
+      cmp = [](const Pt& a, const Pt& b) { return a.timestamp < b.timestamp; };
+      extract = [](const Pt& p) { return p.timestamp * 1e-9f; };
+    } else {
+      return false;                         // "LiDAR sensor type unknown or not specified" (:776-781)
+    }
     std::vector<Pt> sorted(pc.size());
     const double ts0 = omp_get_wtime();
     std::partial_sort_copy(pc.begin(), pc.end(), sorted.begin(), sorted.end(), cmp);   // :789-790
@@ -600,10 +635,34 @@ struct Localizer {
     if (raw.empty()) return -1;
     if (!imu_calibrated_) return -2;
     if (imu_buffer.empty()) return -3;
-    std::vector<Pt> input;
-    input.reserve(raw.size());
+    std::vector<Pt> finite;
+    finite.reserve(raw.size());
     for (const auto& p : raw) {                                  // removeNaNFromPointCloud :263-265
-      if (std::isfinite(p.x) && std::isfinite(p.y) && std::isfinite(p.z)) input.push_back(p);
+      if (std::isfinite(p.x) && std::isfinite(p.y) && std::isfinite(p.z)) finite.push_back(p);
+    }
+    if (config.crop_active) {                                    // pcl::CropBox, setNegative(true) (:57-59,268-271):
+      std::vector<Pt> kept;                                      // a point is "inside" unless it is beyond a face
+      kept.reserve(finite.size());
+      for (const auto& p : finite) {
+        const bool outside = p.x < config.crop_min[0] || p.y < config.crop_min[1] || p.z < config.crop_min[2] ||
+                             p.x > config.crop_max[0] || p.y > config.crop_max[1] || p.z > config.crop_max[2];
+        if (outside) kept.push_back(p);
+      }
+      finite.swap(kept);
+    }
+    // distance / rate / FoV filters over the INDEXED cloud (:274-302); the index is the position after the crop
+    std::vector<Pt> input;
+    input.reserve(finite.size());
+    {
+      const float min_dist = (float)config.min_dist;             // `static float min_dist = static_cast<float>(...)`
+      for (size_t i = 0; i < finite.size(); i++) {
+        const Pt& p = finite[i];
+        bool keep = true;
+        if (config.dist_active) keep = keep && (norm3(V3f(p.x, p.y, p.z)) > min_dist);
+        if (config.rate_active) keep = keep && ((long)i % config.rate_value == 0);
+        if (config.fov_active) keep = keep && (std::fabs(std::atan2(p.y, p.x)) < config.fov_angle);   // isInRange :873-876
+        if (keep) input.push_back(p);
+      }
     }
     double t0 = omp_get_wtime();
     std::vector<Pt> deskewed;

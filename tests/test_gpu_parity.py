@@ -339,3 +339,55 @@ def test_device_insert_rule_matches_octree(built, oracle, downsample):
         np.testing.assert_array_equal(sqd, oc.knn(q, 5)[1])
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sensor,eos", [("OUSTER", False), ("OUSTER", True), ("VELODYNE", True), ("HESAI", False), ("LIVOX", False)])
+def test_sensor_time_formats_and_input_filters_match_oracle(built, oracle, sensor, eos):
+    """Per-sensor time decoding (reference Localizer.cpp:745-781: uint32 ns / float s / absolute double s / absolute
+    double ns, start- or end-of-sweep reference) and the input filters (:262-302: NaN removal, negative crop box,
+    min-distance, every-n-th point, FoV) through the PointType-layout entry.  Time stamps are quantised so that many
+    points tie: the time order must still be the reference's (std::partial_sort_copy) order."""
+    from fast_limo_amd import api
+    code = {"OUSTER": 0, "VELODYNE": 1, "HESAI": 2, "LIVOX": 3}[sensor]
+    mp, scan5, imu = cfg1_scene(n_scan=6000)
+    st, w, a = imu
+    w = w + np.float32([0.0, 0.0, 0.3])                      # the body turns: the deskew depends on every point's time
+    rs = np.random.RandomState(3)
+    xyz = scan5[:, :3].copy()
+    xyz[::97] = np.nan                                       # removeNaNFromPointCloud
+    xyz[1::211] *= np.float32(0.01)                          # a few points inside the crop box / below min_dist
+    rel = np.round(rs.uniform(0.0, 0.1, xyz.shape[0]) * 2000.0) / 2000.0      # 200 distinct stamps -> ties
+    filt = dict(crop_active=1, dist_active=1, min_dist=1.5, rate_active=1, rate_value=3, fov_active=1, fov_angle=2.8)
+    gcfg = api.default_cfg(sensor_type=code, end_of_sweep=int(eos), cropBoxMin=(-0.5, -0.5, -0.5), cropBoxMax=(0.5, 0.5, 0.5),
+                           **filt, **CAPS)
+    ocfg = oracle.default_cfg(sensor_type=code, end_of_sweep=int(eos), crop_min=(-0.5, -0.5, -0.5), crop_max=(0.5, 0.5, 0.5),
+                              num_threads=1, **filt, **CAPS)
+    G = api.Localizer(gcfg)
+    Lo = oracle.Localizer(ocfg)
+    G.map_add(mp); Lo.map_add(mp)
+    i = 0
+    for until, start in ((0.105, 0.0), (0.205, 0.1)):
+        while i < len(st) and st[i] <= until:
+            G.update_imu(st[i], w[i], a[i]); Lo.update_imu(st[i], w[i], a[i]); i += 1
+        stamp = start + (0.1 if eos else 0.0)                # sweep reference: start or end of the sweep
+        if sensor == "OUSTER":
+            t = (0.1 - rel) if eos else rel
+            pts = oracle.make_points(xyz, 1.0, t_ns=np.round(t * 1e9).astype(np.uint32))
+        elif sensor == "VELODYNE":
+            t = (0.1 - rel) if eos else rel
+            pts = oracle.make_points(xyz, 1.0, time_s=t.astype(np.float32))
+        elif sensor == "HESAI":
+            pts = oracle.make_points(xyz, 1.0, timestamp=start + rel)
+        else:
+            pts = oracle.make_points(xyz, 1.0, timestamp=(start + rel) * 1e9)
+        rg = G.update_pointcloud_points(pts, stamp)
+        ro = Lo.update_pointcloud_points(pts, stamp)
+        assert rg == ro, (sensor, eos, rg, ro)
+    assert rg == 0
+    pg, po = G.pc2match(), Lo.pc2match()
+    assert pg.shape == po.shape and 800 < pg.shape[0] < 2500          # the filters removed most of the 6000 points
+    np.testing.assert_allclose(pg, po, rtol=0, atol=2e-6)             # same points in the same (time) order
+    dpos, ang = pose_delta(G.get_x(), Lo.get_x())
+    assert dpos < 1e-4 and ang < 1e-4, (sensor, eos, dpos, ang)
+    G.close()
