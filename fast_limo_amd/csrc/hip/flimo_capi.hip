@@ -98,6 +98,8 @@ struct flimo_ctx {
   MatchParams last_mp{};
   int last_n_all = 0;
   bool recs_valid = false, dbg_valid = false;
+  PrevPass prev{};                 // previous pass of the same resident scan (k-NN pruning bound); valid = 0 after any scan change
+  bool prune = true;               // FLIMO_PRUNE=0 disables the bound (A/B checks)
 };
 
 static int fail(flimo_ctx* c, int code, const char* fmt, ...) {
@@ -247,6 +249,8 @@ extern "C" int flimo_ctx_create(int device, flimo_ctx** out) {
   const char* e = getenv("FLIMO_LPQ");
   if (e) { int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) c->lanes_per_query = v; }
   c->book = insert_book_create();
+  e = getenv("FLIMO_PRUNE");
+  if (e) c->prune = atoi(e) != 0;
   e = getenv("FLIMO_XCD_STRIPE");
   if (e) set_xcd_stripe(atoi(e));
   e = getenv("FLIMO_HOST_INSERT");
@@ -543,7 +547,7 @@ static int ensure_scan(flimo_ctx* c, size_t n) {
   (void)hipFree(c->d_scan); (void)hipFree(c->d_scan_raw); (void)hipFree(c->d_scan_world); (void)hipFree(c->d_scan_t);
   c->d_scan = a; c->d_scan_raw = b; c->d_scan_world = w; c->d_scan_t = t;
   c->scan_cap = cap;
-  c->scan_n = 0; c->raw_n = 0;
+  c->scan_n = 0; c->raw_n = 0; c->prev.valid = 0;
   return FLIMO_OK;
 }
 
@@ -585,7 +589,7 @@ extern "C" int flimo_scan_set(flimo_ctx* c, const float* xyz, size_t n, size_t s
     HIPCHK(c, sort_scan(c->stream, c->d_scan, n, c->d_scan_sorted, c->scratch));
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
-  c->scan_n = n;
+  c->scan_n = n; c->prev.valid = 0;
   return FLIMO_OK;
 }
 
@@ -621,7 +625,7 @@ extern "C" int flimo_scan_voxel_filter(flimo_ctx* c, float leaf, size_t* n_out) 
   HIPCHK(c, voxel_grid(c->stream, c->d_scan, c->scan_n, leaf, c->d_scan_world, &m, &pass, c->scratch));
   if (!pass) {
     std::swap(c->d_scan, c->d_scan_world);
-    c->scan_n = m;
+    c->scan_n = m; c->prev.valid = 0;
   }
   if (c->scan_n) HIPCHK(c, sort_scan(c->stream, c->d_scan, c->scan_n, c->d_scan_sorted, c->scratch));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -656,7 +660,7 @@ extern "C" int flimo_deskew_resident(flimo_ctx* c, const flimo_frame* frames, si
   static_assert(sizeof(flimo_frame) == 112, "flimo_frame layout");
   if (dev_frame_size() != sizeof(flimo_frame)) return fail(c, FLIMO_ERR_INVALID, "frame layout mismatch");
   const size_t n = c->raw_n;
-  if (n == 0) { c->scan_n = 0; return FLIMO_OK; }
+  if (n == 0) { c->scan_n = 0; c->prev.valid = 0; return FLIMO_OK; }
   // frames + the two 4x4 matrices go through one pinned staging copy
   const size_t fbytes = nf * sizeof(flimo_frame);
   const size_t total = fbytes + 32 * sizeof(float);
@@ -681,7 +685,7 @@ extern "C" int flimo_deskew_resident(flimo_ctx* c, const flimo_frame* frames, si
                 (const float*)((const char*)c->d_frames + fbytes), c->d_scan_sorted, c->d_scan);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  c->scan_n = n;
+  c->scan_n = n; c->prev.valid = 0;
   return FLIMO_OK;
 }
 
@@ -773,8 +777,9 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   if (tlev > 1) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   // level 1: the two events ride on the k-NN dispatch itself (kernel begin / end, no extra packets)
   launch_knn5(c->stream, c->lanes_per_query, c->grid, c->d_scan_sorted, n_all, P, mp.max_ring, c->d_nbr, c->d_wl,
-              c->d_wl_count, c->debug_recs ? c->d_cand : nullptr, tlev == 1 ? c->ev[0] : nullptr,
+              c->d_wl_count, c->debug_recs ? c->d_cand : nullptr, c->prev, tlev == 1 ? c->ev[0] : nullptr,
               tlev == 1 ? c->ev[1] : nullptr);
+  if (c->prune) { memcpy(c->prev.RT, P.RT, sizeof(c->prev.RT)); c->prev.valid = 1; }   // the records now belong to this pose
   if (tlev > 1) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
   launch_widen(c->stream, c->grid, c->d_scan_sorted, P, mp.max_ring, c->d_nbr, c->d_wl, c->d_wl_count,
                c->debug_recs ? c->d_cand : nullptr);

@@ -9,7 +9,7 @@ namespace flimo {
 // per pass: k-NN (fast path + worklist widening), then fit + in-block reduction, then the final sum
 void launch_knn5(hipStream_t st, int lanes_per_query, const GridView& G, const float4* scan_sorted, int n,
                  const PoseMats& P, int max_ring, void* nbr, int* wl, int* wl_count, unsigned long long* cand,
-                 hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+                 const PrevPass& prev, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 void launch_widen(hipStream_t st, const GridView& G, const float4* scan_sorted, const PoseMats& P, int max_ring, void* nbr,
                   int* wl, int* wl_count, unsigned long long* cand);
 int fit_blocks(int n);

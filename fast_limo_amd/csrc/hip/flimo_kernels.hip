@@ -306,7 +306,8 @@ __device__ __forceinline__ int xcd_chunk(int b, int nb) {
 struct NbrRec {      // 32 bytes per query (sorted order)
   int32_t idx[5];
   int32_t flag;      // 1: exact 5-NN present, 0: no valid neighbourhood, 2: pending (worklist)
-  int32_t pad[2];
+  int32_t d5_bits;   // float bits of the 5th squared distance (bound for the next pass of the same scan)
+  int32_t d5_valid;  // 1 when flag == 1
 };
 
 // sorted private best-5 of one lane: distances as floats (+inf = empty), payload = position in the sorted map.
@@ -381,7 +382,7 @@ template <int L, int SLOTS>
 __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __restrict__ scan_sorted, int n,
                                                    PoseMats P, int max_ring, NbrRec* __restrict__ nbr,
                                                    int* __restrict__ wl, int* __restrict__ wl_count,
-                                                   unsigned long long* __restrict__ cand_total) {
+                                                   unsigned long long* __restrict__ cand_total, PrevPass prev) {
   constexpr int QPB = 256 / L;          // queries per block; SLOTS = candidate loads in flight per lane
   const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
   const int p = chunk * QPB + threadIdx.x / L;
@@ -395,6 +396,21 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
   TRACE(0, 1);
 
   const float fx = (gx - G.ox) * G.inv_cell, fy = (gy - G.oy) * G.inv_cell, fz = (gz - G.oz) * G.inv_cell;
+  // Upper bound of this pass's 5th-neighbour distance from the previous pass of the same scan: the five old
+  // neighbours are still in the map, and the query moved by |g - g_old|, so d5 <= sqrt(d5_old) + |g - g_old|.
+  // Cells farther than that cannot hold any of the five nearest points and are skipped (exactly, no heuristic).
+  float b2 = INFINITY;                               // bound, squared, in cell units
+  if (prev.valid) {
+    const int4 pb = reinterpret_cast<const int4*>(&nbr[p])[1];       // idx[4], flag, d5 bits, "d5 valid"
+    if (pb.y == 1 && pb.w == 1) {
+      float ox_, oy_, oz_;
+      xform4(prev.RT, sp.x, sp.y, sp.z, ox_, oy_, oz_);
+      const float ex = gx - ox_, ey = gy - oy_, ez = gz - oz_;
+      const float moved = fl_sqrt(sum3(ex * ex, ey * ey, ez * ez));
+      const float rc = ((fl_sqrt(__int_as_float(pb.z)) + moved) * (1.f + 1.0e-5f) + 1.0e-6f) * G.inv_cell;
+      b2 = rc * rc * (1.f + 1.0e-5f);
+    }
+  }
   int flag = 0;
   u64 best[5] = {KEY_NONE, KEY_NONE, KEY_NONE, KEY_NONE, KEY_NONE};
   int cand = 0;
@@ -412,27 +428,41 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
     } else if (r0 > 1) {
       flag = 2;                       // outside the grid but within reach: general search
     } else {
-      // ---- range bounds of the 9 rows: six 12-byte loads from the y-fastest, padded row table ----
-      const int x0 = max(cx - 1, 0), x1 = min(cx + 1, G.nx - 1);
+      // ---- range bounds of the 9 rows x 3 cells: twelve 12-byte loads from the y-fastest, padded row table
+      //      (x planes cx-1 .. cx+2, clamped: a plane index outside the grid yields an empty cell) ----
       const size_t py = (size_t)G.ny + 4, pz = (size_t)G.nz + 4;
-      const uint32_t* Ta = G.row_table + ((size_t)x0 * pz + (size_t)(cz + 1)) * py + (size_t)(cy + 1);
-      const uint32_t* Tb = G.row_table + ((size_t)(x1 + 1) * pz + (size_t)(cz + 1)) * py + (size_t)(cy + 1);
-      U3 ra[3], rb[3];
+      const size_t yz = (size_t)(cz + 1) * py + (size_t)(cy + 1);
+      U3 rb[4][3];
 #pragma unroll
-      for (int dz = 0; dz < 3; dz++) {
-        ra[dz] = *reinterpret_cast<const U3*>(Ta + (size_t)dz * py);
-        rb[dz] = *reinterpret_cast<const U3*>(Tb + (size_t)dz * py);
+      for (int k = 0; k < 4; k++) {
+        const int xp = min(max(cx - 1 + k, 0), G.nx);
+        const uint32_t* T = G.row_table + (size_t)xp * pz * py + yz;
+#pragma unroll
+        for (int dz = 0; dz < 3; dz++) rb[k][dz] = *reinterpret_cast<const U3*>(T + (size_t)dz * py);
       }
+      // position inside the cell and the conservative distances (cell units) to the neighbouring cells
+      const float rx = fminf(fmaxf(fx - flx, 0.f), 1.f), ry = fminf(fmaxf(fy - fly, 0.f), 1.f),
+                  rz = fminf(fmaxf(fz - flz, 0.f), 1.f);
+      const int maxdim = max(G.nx, max(G.ny, G.nz));
+      const float margin = 1.0e-3f + 4.0e-7f * (float)maxdim;
+      const float xl = fmaxf(rx - margin, 0.f), xr = fmaxf(1.f - rx - margin, 0.f);
+      const float yd[3] = {fmaxf(ry - margin, 0.f), 0.f, fmaxf(1.f - ry - margin, 0.f)};
+      const float zd[3] = {fmaxf(rz - margin, 0.f), 0.f, fmaxf(1.f - rz - margin, 0.f)};
       uint32_t off[10], dl[9];          // dl[t] = lo[t] - off[t]: stream position -> map position
       off[0] = 0;
 #pragma unroll
       for (int dz = 0; dz < 3; dz++) {
-        const uint32_t a[3] = {ra[dz].a, ra[dz].b, ra[dz].c}, b[3] = {rb[dz].a, rb[dz].b, rb[dz].c};
+        const uint32_t s0[3] = {rb[0][dz].a, rb[0][dz].b, rb[0][dz].c}, s1[3] = {rb[1][dz].a, rb[1][dz].b, rb[1][dz].c};
+        const uint32_t s2[3] = {rb[2][dz].a, rb[2][dz].b, rb[2][dz].c}, s3[3] = {rb[3][dz].a, rb[3][dz].b, rb[3][dz].c};
 #pragma unroll
         for (int k = 0; k < 3; k++) {
           const int t = 3 * dz + k;
-          dl[t] = a[k] - off[t];
-          off[t + 1] = off[t] + (b[k] - a[k]);
+          const float dyz2 = yd[k] * yd[k] + zd[dz] * zd[dz];
+          const bool row = dyz2 <= b2;
+          const bool left = dyz2 + xl * xl <= b2, right = dyz2 + xr * xr <= b2;
+          const uint32_t lo = left ? s0[k] : s1[k], hi = right ? s3[k] : s2[k];
+          dl[t] = lo - off[t];
+          off[t + 1] = off[t] + (row ? hi - lo : 0u);
         }
       }
       const uint32_t total = off[9];
@@ -473,11 +503,7 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
           if (mine[0] == m) { mine[0] = mine[1]; mine[1] = mine[2]; mine[2] = mine[3]; mine[3] = mine[4]; mine[4] = KEY_NONE; }
         }
       }
-      // ---- exactness: the 5-ball must lie inside the visited block ----
-      const float rx = fminf(fmaxf(fx - flx, 0.f), 1.f), ry = fminf(fmaxf(fy - fly, 0.f), 1.f),
-                  rz = fminf(fmaxf(fz - flz, 0.f), 1.f);
-      const int maxdim = max(G.nx, max(G.ny, G.nz));
-      const float margin = 1.0e-3f + 4.0e-7f * (float)maxdim;
+      // ---- exactness: the 5-ball must lie inside the 3x3x3 block ----
       const float edge = fminf(fminf(fminf(rx, 1.f - rx), fminf(ry, 1.f - ry)), fminf(rz, 1.f - rz));
       const float rg = (1.f + edge - margin) * G.cell;
       const float d5 = __uint_as_float((uint32_t)(best[4] >> 32));
@@ -499,7 +525,7 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
   if (sub == 0) {
     int4 a, b;
     a.x = (int)(uint32_t)best[0]; a.y = (int)(uint32_t)best[1]; a.z = (int)(uint32_t)best[2]; a.w = (int)(uint32_t)best[3];
-    b.x = (int)(uint32_t)best[4]; b.y = flag; b.z = 0; b.w = 0;
+    b.x = (int)(uint32_t)best[4]; b.y = flag; b.z = (int)(uint32_t)(best[4] >> 32); b.w = (flag == 1) ? 1 : 0;   // d5 for the next pass
     int4* o = reinterpret_cast<int4*>(&nbr[p]);
     o[0] = a;
     o[1] = b;
@@ -612,7 +638,7 @@ __global__ __launch_bounds__(256) void widen_kernel(GridView G, const float4* __
     if (lane == 0) {
       int4 a, b;
       a.x = (int)(uint32_t)best[0]; a.y = (int)(uint32_t)best[1]; a.z = (int)(uint32_t)best[2]; a.w = (int)(uint32_t)best[3];
-      b.x = (int)(uint32_t)best[4]; b.y = flag; b.z = 0; b.w = 0;
+      b.x = (int)(uint32_t)best[4]; b.y = flag; b.z = (int)(uint32_t)(best[4] >> 32); b.w = (flag == 1) ? 1 : 0;
       int4* o = reinterpret_cast<int4*>(&nbr[p]);
       o[0] = a;
       o[1] = b;
@@ -1116,7 +1142,8 @@ static inline int round_up8(int x) { return (x + 7) & ~7; }
 static int g_slots = 0;   // 0: default per L; developer override through FLIMO_SLOTS
 template <int L>
 static void launch_knn5_L(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const PoseMats& P,
-                          int max_ring, void* nbr, int* wl, int* wl_count, unsigned long long* cand, hipEvent_t e0, hipEvent_t e1) {
+                          int max_ring, void* nbr, int* wl, int* wl_count, unsigned long long* cand, const PrevPass& prev,
+                          hipEvent_t e0, hipEvent_t e1) {
   const int qpb = 256 / L;
   const int blocks = round_up8((n + qpb - 1) / qpb);
   if (g_slots == 0) { const char* e = getenv("FLIMO_SLOTS"); g_slots = e ? atoi(e) : -1; }
@@ -1124,26 +1151,26 @@ static void launch_knn5_L(hipStream_t st, const GridView& G, const float4* scan_
   // e0 / e1 (optional) are attached to the dispatch itself: they read the kernel's own begin / end
   // timestamps, without the extra barrier packets of hipEventRecord
   if (slots >= 16 && L <= 2)
-    hipExtLaunchKernelGGL((knn5_kernel<L, 16>), dim3(blocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand);
+    hipExtLaunchKernelGGL((knn5_kernel<L, 16>), dim3(blocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand, prev);
   else if (slots >= 8)
-    hipExtLaunchKernelGGL((knn5_kernel<L, 8>), dim3(blocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand);
+    hipExtLaunchKernelGGL((knn5_kernel<L, 8>), dim3(blocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand, prev);
   else if (slots >= 4)
-    hipExtLaunchKernelGGL((knn5_kernel<L, 4>), dim3(blocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand);
+    hipExtLaunchKernelGGL((knn5_kernel<L, 4>), dim3(blocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand, prev);
   else
-    hipExtLaunchKernelGGL((knn5_kernel<L, 2>), dim3(blocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand);
+    hipExtLaunchKernelGGL((knn5_kernel<L, 2>), dim3(blocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand, prev);
 }
 
 void launch_knn5(hipStream_t st, int lanes_per_query, const GridView& G, const float4* scan_sorted, int n,
                  const PoseMats& P, int max_ring, void* nbr, int* wl, int* wl_count, unsigned long long* cand,
-                 hipEvent_t e0, hipEvent_t e1) {
+                 const PrevPass& prev, hipEvent_t e0, hipEvent_t e1) {
   if (n <= 0) return;
   switch (lanes_per_query) {
-    case 1: launch_knn5_L<1>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, e0, e1); break;
-    case 2: launch_knn5_L<2>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, e0, e1); break;
-    case 4: launch_knn5_L<4>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, e0, e1); break;
-    case 8: launch_knn5_L<8>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, e0, e1); break;
-    case 32: launch_knn5_L<32>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, e0, e1); break;
-    default: launch_knn5_L<16>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, e0, e1); break;
+    case 1: launch_knn5_L<1>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, e0, e1); break;
+    case 2: launch_knn5_L<2>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, e0, e1); break;
+    case 4: launch_knn5_L<4>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, e0, e1); break;
+    case 8: launch_knn5_L<8>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, e0, e1); break;
+    case 32: launch_knn5_L<32>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, e0, e1); break;
+    default: launch_knn5_L<16>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, e0, e1); break;
   }
 }
 

@@ -22,6 +22,13 @@ struct GridView {
   uint32_t n_pts;
 };
 
+// Previous pass of the SAME scan (same sorted scan, same neighbour records): its body -> world matrix lets the k-NN
+// fast path bound how far every query moved; valid = 0 disables the pruning (first pass of a scan).
+struct PrevPass {
+  float RT[16];
+  int valid;
+};
+
 // Per-pass pose constants, computed on the host exactly as the reference does
 // (State(x).get_RT() etc., reference Objects/State.cpp:38-55,136-172 and
 // Modules/Localizer.cpp:549-555) and passed by value as a kernel argument.

@@ -391,3 +391,56 @@ def test_sensor_time_formats_and_input_filters_match_oracle(built, oracle, senso
     dpos, ang = pose_delta(G.get_x(), Lo.get_x())
     assert dpos < 1e-4 and ang < 1e-4, (sensor, eos, dpos, ang)
     G.close()
+
+
+@pytest.mark.gpu
+def test_previous_pass_bound_prunes_exactly(built, oracle):
+    """The k-NN fast path skips cells beyond (sqrt(d5 of the previous pass) + displacement); this must never change a
+    result.  A context with the bound on and one with it off (FLIMO_PRUNE=0) walk the same pose sequence -- tiny steps
+    (strong pruning), a 0.4 m / 2 degree jump (bound mostly void), back again -- and must agree bit for bit on every
+    per-point record, on the sums, and with the oracle at the last pose."""
+    from fast_limo_amd import _lib
+    mcfg = _lib.default_match_cfg(**CAPS)
+    mp = synth.box_world_map(400000, 15.0, 1)               # dense map: the 5-ball is much smaller than the 3x3x3 block
+    scan = np.ascontiguousarray(synth.box_world_scan_random(4096, 15.0, 2)[:, :3])
+    oc = oracle.Octree()
+    oc.update(mp)
+    os.environ["FLIMO_PRUNE"] = "0"
+    try:
+        plain = _lib.HipCtx(0)
+    finally:
+        del os.environ["FLIMO_PRUNE"]
+    pruned = _lib.HipCtx(0)
+    poses = []
+    x = oracle.identity_x26()
+    rs = np.random.RandomState(11)
+    def bump(x, dt, dr):
+        y = x.copy()
+        y[0:3] += rs.normal(0, dt, 3)
+        q = y[3:7] + np.concatenate([rs.normal(0, dr, 3), [0.0]])
+        y[3:7] = q / np.linalg.norm(q)
+        return y
+    for k in range(4):
+        x = bump(x, 2e-3, 1e-4); poses.append(x)
+    x = bump(x, 0.25, 0.015); poses.append(x)               # large jump
+    for k in range(3):
+        x = bump(x, 5e-4, 5e-5); poses.append(x)
+    try:
+        for c in (plain, pruned):
+            c.map_config(); c.map_add(mp); c.scan_set(scan); c.set_debug_records(True)
+        for k, xk in enumerate(poses):
+            a = plain.match_reduce(xk, mcfg); ra = plain.match_fetch()
+            b = pruned.match_reduce(xk, mcfg); rb = pruned.match_fetch()
+            assert a[2] == b[2], k
+            np.testing.assert_array_equal(a[0], b[0]); np.testing.assert_array_equal(a[1], b[1])
+            for f in ("valid", "n", "h", "sqd", "nbr", "H"):
+                np.testing.assert_array_equal(ra[f], rb[f], err_msg=f"pose {k} field {f}")
+            if k >= 1:                                          # fewer candidates were examined
+                assert pruned.last_candidates_per_query() <= plain.last_candidates_per_query() + 1e-9
+        assert pruned.last_candidates_per_query() < 0.6 * plain.last_candidates_per_query()
+        recs, H, h, ev = oracle.match_H(oc, oracle.default_cfg(num_threads=1, **CAPS), poses[-1], scan)
+        vg = rb["valid"] > 0
+        np.testing.assert_array_equal(vg, recs["is_plane"] > 0)
+        np.testing.assert_array_equal(rb["H"][vg].astype(np.float64), H)
+    finally:
+        plain.close(); pruned.close()
