@@ -227,7 +227,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: %d-pt Velodyne-like scan (%d rings x %d azimuths), "
+            "config": {"workload": ("BASELINE.json configs[1]: " if (args.rings, args.azimuths, args.map_points, args.box) == (64, 1024, 1000000, 100.0)
+                                    else "scaled variant of BASELINE.json configs[1]: ") +
+                                   "%d-pt Velodyne-like scan (%d rings x %d azimuths), "
                                    "%d-pt box-world map, k=5, MAX_NUM_ITERS=3, GPU deskew + iterated ESKF update per step"
                                    % (scan.shape[0], args.rings, args.azimuths, mp.shape[0]),
                        "parallelism": "replicas x%d (independent scan streams, no collective)" % world,

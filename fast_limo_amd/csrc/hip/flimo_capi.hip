@@ -300,6 +300,7 @@ extern "C" int flimo_map_clear(flimo_ctx* c) {
   c->bb[0] = c->bb[1] = c->bb[2] = 3.4e38f; c->bb[3] = c->bb[4] = c->bb[5] = -3.4e38f;
   insert_book_clear(c->book);
   c->gbook.active = false;
+  c->prev.valid = 0;               // the pruning bound only survives map ADDITIONS (distances can only shrink)
   return FLIMO_OK;
 }
 
