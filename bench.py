@@ -189,9 +189,9 @@ def main():
     for _ in range(args.warmup):
         step()
     # level 1: start/stop HIP events attached to the k-NN dispatch (on the context's own stream); sampled every
-    # 7th pass (coprime with the 4 passes of a step, so every pass position is covered) to keep the perturbation small
+    # 13th pass (coprime with the 4 passes of a step, so every pass position is covered) to keep the perturbation small
     loc.hip.set_timing(int(os.environ.get('FLIMO_BENCH_TIMING', '1')))
-    loc.hip.set_timing_stride(int(os.environ.get('FLIMO_BENCH_TIMING_STRIDE', '7')))
+    loc.hip.set_timing_stride(int(os.environ.get('FLIMO_BENCH_TIMING_STRIDE', '13')))
     loc.hip.timing_totals(reset=True)
     passes0 = loc.hip.pass_count()
     loc.host_profile(reset=True)

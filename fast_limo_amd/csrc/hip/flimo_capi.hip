@@ -65,6 +65,9 @@ struct flimo_ctx {
   size_t scan_n = 0, scan_cap = 0, raw_n = 0;
   void* d_frames = nullptr;
   size_t frames_cap = 0;
+  void* h_frames[2] = {nullptr, nullptr};   // pinned staging of the IMU frames, alternating: the deskew call does not wait
+  size_t h_frames_cap = 0;
+  int frames_slot = 0, async_deskews = 0;   // copies possibly still in flight since the stream was last known idle
   // per pass
   Rec16* d_recs = nullptr;
   RecDbg* d_dbg = nullptr;
@@ -272,6 +275,7 @@ extern "C" void flimo_ctx_destroy(flimo_ctx* c) {
   if (c->h_out256) (void)hipHostFree(c->h_out256);
   if (c->h_cand) (void)hipHostFree(c->h_cand);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
+  for (int k = 0; k < 2; k++) if (c->h_frames[k]) (void)hipHostFree(c->h_frames[k]);
   map_scratch_free(c->scratch);
   for (int i = 0; i < 4; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->h_wl_count) (void)hipHostFree(c->h_wl_count);
@@ -671,21 +675,34 @@ extern "C" int flimo_deskew_resident(flimo_ctx* c, const flimo_frame* frames, si
     HIPCHK(c, hipMalloc(&c->d_frames, total * 2));
     c->frames_cap = total * 2;
   }
-  int rc = ensure_stage(c, total);
-  if (rc) return rc;
-  memcpy(c->h_stage, frames, fbytes);
-  float* m = (float*)((char*)c->h_stage + fbytes);
+  if (total > c->h_frames_cap) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->async_deskews = 0;
+    for (int k = 0; k < 2; k++) { if (c->h_frames[k]) (void)hipHostFree(c->h_frames[k]); c->h_frames[k] = nullptr; }
+    c->h_frames_cap = 0;
+    for (int k = 0; k < 2; k++) HIPCHK(c, hipHostMalloc(&c->h_frames[k], total * 2, hipHostMallocDefault));
+    c->h_frames_cap = total * 2;
+  }
+  if (c->async_deskews >= 2) {                       // both staging slots may still be read by queued copies
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->async_deskews = 0;
+  }
+  char* hs = (char*)c->h_frames[c->frames_slot];
+  c->frames_slot ^= 1;
+  memcpy(hs, frames, fbytes);
+  float* m = (float*)(hs + fbytes);
   memcpy(m, L2B, 16 * sizeof(float));
   {
     const float p[3] = {(float)last_x26[0], (float)last_x26[1], (float)last_x26[2]};
     const float q[4] = {(float)last_x26[3], (float)last_x26[4], (float)last_x26[5], (float)last_x26[6]};
     se3_inv_from(q, p, m + 16);                       // last_state.get_RT_inv()
   }
-  HIPCHK(c, hipMemcpyAsync(c->d_frames, c->h_stage, total, hipMemcpyHostToDevice, c->stream));
+  // stream-ordered: everything that consumes the deskewed scan is queued behind this on the same stream
+  HIPCHK(c, hipMemcpyAsync(c->d_frames, hs, total, hipMemcpyHostToDevice, c->stream));
   launch_deskew(c->stream, c->d_raw_sorted, c->d_t_sorted, (int)n, c->d_frames, (int)nf,
                 (const float*)((const char*)c->d_frames + fbytes), c->d_scan_sorted, c->d_scan);
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->async_deskews++;
   c->scan_n = n; c->prev.valid = 0;
   return FLIMO_OK;
 }
@@ -823,6 +840,7 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
     }
     c->tot_passes++; c->tot_queries += n_all;
   }
+  c->async_deskews = 0;            // the pass completed: the stream is idle
   if (want_count) c->last_widen_count = *c->h_wl_count;
   if (c->debug_recs) c->last_cand_per_query = (double)(*c->h_cand) / (double)nq;
   // final sum over the reduction groups in slot order (the records path delivers one slot)

@@ -351,16 +351,7 @@ __device__ __forceinline__ void knn5_body(const float4* __restrict__ pts, uint32
     id[u] = s + delta;
     pt[u] = pts[id[u]];
   }
-  if constexpr (N == 16) {
-    asm volatile("" : "+v"(pt[0].x), "+v"(pt[0].y), "+v"(pt[0].z), "+v"(pt[1].x), "+v"(pt[1].y), "+v"(pt[1].z),
-                      "+v"(pt[2].x), "+v"(pt[2].y), "+v"(pt[2].z), "+v"(pt[3].x), "+v"(pt[3].y), "+v"(pt[3].z),
-                      "+v"(pt[4].x), "+v"(pt[4].y), "+v"(pt[4].z), "+v"(pt[5].x), "+v"(pt[5].y), "+v"(pt[5].z),
-                      "+v"(pt[6].x), "+v"(pt[6].y), "+v"(pt[6].z), "+v"(pt[7].x), "+v"(pt[7].y), "+v"(pt[7].z),
-                      "+v"(pt[8].x), "+v"(pt[8].y), "+v"(pt[8].z), "+v"(pt[9].x), "+v"(pt[9].y), "+v"(pt[9].z));
-    asm volatile("" : "+v"(pt[10].x), "+v"(pt[10].y), "+v"(pt[10].z), "+v"(pt[11].x), "+v"(pt[11].y), "+v"(pt[11].z),
-                      "+v"(pt[12].x), "+v"(pt[12].y), "+v"(pt[12].z), "+v"(pt[13].x), "+v"(pt[13].y), "+v"(pt[13].z),
-                      "+v"(pt[14].x), "+v"(pt[14].y), "+v"(pt[14].z), "+v"(pt[15].x), "+v"(pt[15].y), "+v"(pt[15].z));
-  } else if constexpr (N == 8)
+  if constexpr (N == 8)
     asm volatile("" : "+v"(pt[0].x), "+v"(pt[0].y), "+v"(pt[0].z), "+v"(pt[1].x), "+v"(pt[1].y), "+v"(pt[1].z),
                       "+v"(pt[2].x), "+v"(pt[2].y), "+v"(pt[2].z), "+v"(pt[3].x), "+v"(pt[3].y), "+v"(pt[3].z),
                       "+v"(pt[4].x), "+v"(pt[4].y), "+v"(pt[4].z), "+v"(pt[5].x), "+v"(pt[5].y), "+v"(pt[5].z),
@@ -1150,9 +1141,7 @@ static void launch_knn5_L(hipStream_t st, const GridView& G, const float4* scan_
   const int slots = g_slots > 0 ? g_slots : (L <= 4 ? 8 : 4);
   // e0 / e1 (optional) are attached to the dispatch itself: they read the kernel's own begin / end
   // timestamps, without the extra barrier packets of hipEventRecord
-  if (slots >= 16 && L <= 2)
-    hipExtLaunchKernelGGL((knn5_kernel<L, 16>), dim3(blocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand, prev);
-  else if (slots >= 8)
+  if (slots >= 8)
     hipExtLaunchKernelGGL((knn5_kernel<L, 8>), dim3(blocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand, prev);
   else if (slots >= 4)
     hipExtLaunchKernelGGL((knn5_kernel<L, 4>), dim3(blocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand, prev);
