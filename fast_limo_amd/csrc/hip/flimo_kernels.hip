@@ -527,9 +527,10 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
 
 // Widening for the worklist (rare): ONE WAVE per query.  The (2r+1)^2 <= 49 rows of the ring-r block
 // are owned by one lane each (range bounds fetched in a single round trip), a wave prefix sum
-// flattens their candidates, every lane scans a strided share and the best 5 are extracted with
-// wave-wide min reductions.  r starts at 2 and jumps to the ring that proves exactness, never
-// beyond max_ring (<= 3 here; the host falls back to the general kernel for larger gates).
+// flattens their candidates, every lane scans a strided share (four loads in flight) and the best 5 are
+// extracted with wave-wide min reductions.  r starts at the ring the fast path's own 5th distance asks for
+// (at least 2) and jumps to the ring that proves exactness, never beyond max_ring (<= 3 here; the host
+// falls back to the general kernel for larger gates).
 __global__ __launch_bounds__(256) void widen_kernel(GridView G, const float4* __restrict__ scan_sorted, PoseMats P,
                                                     int max_ring, NbrRec* __restrict__ nbr, const int* __restrict__ wl,
                                                     const int* __restrict__ wl_count,
@@ -543,6 +544,7 @@ __global__ __launch_bounds__(256) void widen_kernel(GridView G, const float4* __
   for (int w = blockIdx.x * 4 + wave; w < count; w += gridDim.x * 4) {
     const int p = wl[w];
     const float4 sp = scan_sorted[p];
+    const int hint_bits = reinterpret_cast<const int4*>(&nbr[p])[1].z;     // 5th squared distance inside the 3x3x3 block (+inf: none)
     float gx, gy, gz;
     xform4(P.RT, sp.x, sp.y, sp.z, gx, gy, gz);
     const float fx = (gx - G.ox) * G.inv_cell, fy = (gy - G.oy) * G.inv_cell, fz = (gz - G.oz) * G.inv_cell;
@@ -552,10 +554,18 @@ __global__ __launch_bounds__(256) void widen_kernel(GridView G, const float4* __
     const float rx = fminf(fmaxf(fx - flx, 0.f), 1.f), ry = fminf(fmaxf(fy - fly, 0.f), 1.f),
                 rz = fminf(fmaxf(fz - flz, 0.f), 1.f);
     const float edge = fminf(fminf(fminf(rx, 1.f - rx), fminf(ry, 1.f - ry)), fminf(rz, 1.f - rz));
-    u64 best[5] = {KEY_EMPTY, KEY_EMPTY, KEY_EMPTY, KEY_EMPTY, KEY_EMPTY};
+    u64 best[5] = {KEY_NONE, KEY_NONE, KEY_NONE, KEY_NONE, KEY_NONE};
     int flag = 0;
     int cand = 0;
-    int r = min(2, max_ring);
+    int r = 2;
+    {
+      const float hint = __int_as_float(hint_bits);
+      if (hint >= 0.f && hint < INFINITY) {            // an upper bound of the true 5th distance: go straight to its ring
+        const float need = fl_sqrt(hint) * G.inv_cell * (1.f + 4.0e-6f) - edge + margin;
+        r = max(2, (int)ceilf(fminf(need, 1.0e9f)));
+      }
+      r = min(r, max_ring);
+    }
     for (;;) {
       const int side = 2 * r + 1;
       // one row per lane
@@ -581,20 +591,36 @@ __global__ __launch_bounds__(256) void widen_kernel(GridView G, const float4* __
       if (lane == 0) s_off[wave][0] = 0;
       s_lo[wave][lane] = lo;
       __builtin_amdgcn_wave_barrier();
-      u64 mine[5] = {KEY_EMPTY, KEY_EMPTY, KEY_EMPTY, KEY_EMPTY, KEY_EMPTY};
-      for (uint32_t s = (uint32_t)lane; s < total; s += 64) {
-        // row t with off[t] <= s < off[t+1]
-        int a = 0, b = 63;
-        while (a < b) {
-          const int m = (a + b + 1) >> 1;
-          if (s_off[wave][m] <= s) a = m; else b = m - 1;
+      // strided share of the flattened candidates; rows ascend in memory, so a lane meets ascending map positions
+      float kd[5] = {INFINITY, INFINITY, INFINITY, INFINITY, INFINITY};
+      uint32_t ki[5] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+      const uint32_t last = total - 1u;
+      for (uint32_t s0 = (uint32_t)lane; s0 < total; s0 += 4 * 64) {
+        float4 q[4];
+        uint32_t id[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const uint32_t s = min(s0 + 64u * u, last);
+          int a = 0;                                   // row a with off[a] <= s < off[a + 1]
+#pragma unroll
+          for (int step = 32; step >= 1; step >>= 1) a = (s_off[wave][a + step] <= s) ? a + step : a;
+          id[u] = s_lo[wave][a] + (s - s_off[wave][a]);
+          q[u] = G.pts[id[u]];
         }
-        const uint32_t id = s_lo[wave][a] + (s - s_off[wave][a]);
-        const float4 q = G.pts[id];
-        key5_insert(mine, make_key(sqdist3(gx, gy, gz, q.x, q.y, q.z), id));
-        cand++;
+        asm volatile("" : "+v"(q[0].x), "+v"(q[0].y), "+v"(q[0].z), "+v"(q[1].x), "+v"(q[1].y), "+v"(q[1].z),
+                          "+v"(q[2].x), "+v"(q[2].y), "+v"(q[2].z), "+v"(q[3].x), "+v"(q[3].y), "+v"(q[3].z));
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const bool live = s0 + 64u * u < total;
+          const float d = sqdist3(gx, gy, gz, q[u].x, q[u].y, q[u].z);
+          best5_insert(kd, ki, live ? d : INFINITY, id[u]);
+        }
       }
+      cand += total > (uint32_t)lane ? (int)((total - (uint32_t)lane + 63u) / 64u) : 0;
       __builtin_amdgcn_wave_barrier();
+      u64 mine[5];
+#pragma unroll
+      for (int i = 0; i < 5; i++) mine[i] = ((u64)__float_as_uint(kd[i]) << 32) | (u64)ki[i];
 #pragma unroll
       for (int k = 0; k < 5; k++) {
         u64 m = mine[0];
@@ -604,11 +630,11 @@ __global__ __launch_bounds__(256) void widen_kernel(GridView G, const float4* __
           m = v < m ? v : m;
         }
         best[k] = m;
-        if (mine[0] == m) { mine[0] = mine[1]; mine[1] = mine[2]; mine[2] = mine[3]; mine[3] = mine[4]; mine[4] = KEY_EMPTY; }
+        if (mine[0] == m) { mine[0] = mine[1]; mine[1] = mine[2]; mine[2] = mine[3]; mine[3] = mine[4]; mine[4] = KEY_NONE; }
       }
       const float rg = ((float)r + edge - margin) * G.cell;
-      const bool have5 = best[4] != KEY_EMPTY;
       const float d5 = __uint_as_float((uint32_t)(best[4] >> 32));
+      const bool have5 = d5 < INFINITY;
       const bool covers = (cx - r <= 0) && (cx + r >= G.nx - 1) && (cy - r <= 0) && (cy + r >= G.ny - 1) &&
                           (cz - r <= 0) && (cz + r >= G.nz - 1);
       if (have5 && (covers || d5 <= rg * rg * (1.f - 1.0e-6f))) { flag = 1; break; }
