@@ -541,7 +541,7 @@ static int ensure_scan(flimo_ctx* c, size_t n) {
   (void)hipFree(c->d_raw_sorted); (void)hipFree(c->d_t_sorted);
   c->d_raw_sorted = rs; c->d_t_sorted = ts;
   HIPCHK(c, hipMalloc(&nb, cap * nbr_rec_size()));
-  HIPCHK(c, hipMalloc(&wl, cap * sizeof(int)));
+  HIPCHK(c, hipMalloc(&wl, (cap + 8192) * wl_entry_size()));   // + slack: every widening wave prefetches its first slot
   HIPCHK(c, hipMalloc(&fp, fpn * sizeof(double)));
   (void)hipFree(c->d_scan_sorted); (void)hipFree(c->d_nbr); (void)hipFree(c->d_wl); (void)hipFree(c->d_fit_partials);
   c->d_scan_sorted = so; c->d_nbr = nb; c->d_wl = wl; c->d_fit_partials = fp; c->fit_partials_cap = fpn;

@@ -24,6 +24,7 @@ void launch_fit(hipStream_t st, const GridView& G, const float4* scan_sorted, in
                 int* wl_count, unsigned long long seq);
 void launch_reduce_final(hipStream_t st, const double* partials, int nparts, double* out256);
 size_t nbr_rec_size();
+size_t wl_entry_size();   // bytes per worklist entry (query index, world position, 5th-distance hint)
 void launch_knn(hipStream_t st, const GridView& G, const float* qxyz, int nq, int k, int max_ring, int32_t* idx,
                 float* sqd, int32_t* cnt);
 void launch_cap(hipStream_t st, Rec16* recs, int n, int cap);

@@ -520,7 +520,14 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
     int4* o = reinterpret_cast<int4*>(&nbr[p]);
     o[0] = a;
     o[1] = b;
-    if (flag == 2) wl[atomicAdd(wl_count, 1)] = p;
+    if (flag == 2) {
+      // worklist entry = everything the widening wave needs to start (no dependent loads on its side):
+      // query index, world position, 5th squared distance found inside the 3x3x3 block (+inf: none)
+      const int slot = atomicAdd(wl_count, 1);
+      int4* e = reinterpret_cast<int4*>(wl) + 2 * (size_t)slot;
+      e[0] = make_int4(p, __float_as_int(gx), __float_as_int(gy), __float_as_int(gz));
+      e[1] = make_int4((int)(uint32_t)(best[4] >> 32), 0, 0, 0);
+    }
   }
   TRACE(0, 5);
 }
@@ -537,16 +544,20 @@ __global__ __launch_bounds__(256) void widen_kernel(GridView G, const float4* __
                                                     unsigned long long* __restrict__ cand_total) {
   __shared__ uint32_t s_off[4][65];
   __shared__ uint32_t s_lo[4][64];
-  const int count = *wl_count;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int maxdim = max(G.nx, max(G.ny, G.nz));
   const float margin = 1.0e-3f + 4.0e-7f * (float)maxdim;
-  for (int w = blockIdx.x * 4 + wave; w < count; w += gridDim.x * 4) {
-    const int p = wl[w];
-    const float4 sp = scan_sorted[p];
-    const int hint_bits = reinterpret_cast<const int4*>(&nbr[p])[1].z;     // 5th squared distance inside the 3x3x3 block (+inf: none)
-    float gx, gy, gz;
-    xform4(P.RT, sp.x, sp.y, sp.z, gx, gy, gz);
+  // the first entry of this wave is fetched together with the count (one round trip); slots beyond the count hold
+  // stale entries of earlier passes and are never used
+  int w = blockIdx.x * 4 + wave;
+  const int4* entries = reinterpret_cast<const int4*>(wl);
+  int4 e0 = entries[2 * (size_t)w], e1 = entries[2 * (size_t)w + 1];
+  const int count = *wl_count;
+  for (; w < count; w += gridDim.x * 4) {
+    if (w != (int)(blockIdx.x * 4 + wave)) { e0 = entries[2 * (size_t)w]; e1 = entries[2 * (size_t)w + 1]; }
+    const int p = e0.x;
+    const float gx = __int_as_float(e0.y), gy = __int_as_float(e0.z), gz = __int_as_float(e0.w);
+    const int hint_bits = e1.x;                        // 5th squared distance inside the 3x3x3 block (+inf: none)
     const float fx = (gx - G.ox) * G.inv_cell, fy = (gy - G.oy) * G.inv_cell, fz = (gz - G.oz) * G.inv_cell;
     const float flx = floorf(fminf(fmaxf(fx, -1.0e9f), 1.0e9f)), fly = floorf(fminf(fmaxf(fy, -1.0e9f), 1.0e9f)),
                 flz = floorf(fminf(fmaxf(fz, -1.0e9f), 1.0e9f));
@@ -671,7 +682,7 @@ __global__ __launch_bounds__(256) void widen_general_kernel(GridView G, const fl
   const int count = *wl_count;
   const int sub = threadIdx.x % L;
   for (int w = blockIdx.x * (256 / L) + threadIdx.x / L; w < count; w += gridDim.x * (256 / L)) {
-    const int p = wl[w];
+    const int p = reinterpret_cast<const int4*>(wl)[2 * (size_t)w].x;
     const float4 sp = scan_sorted[p];
     float gx, gy, gz;
     xform4(P.RT, sp.x, sp.y, sp.z, gx, gy, gz);
@@ -1192,7 +1203,7 @@ void launch_knn5(hipStream_t st, int lanes_per_query, const GridView& G, const f
 static int g_widen_blocks = 0;
 static int widen_blocks() {
   // default 2048 blocks = 8 waves per SIMD: the wave-per-query search is a latency chain
-  if (g_widen_blocks == 0) { const char* e = getenv("FLIMO_WIDEN_BLOCKS"); const int v = e ? atoi(e) : 0; g_widen_blocks = v > 0 ? v : 2048; }
+  if (g_widen_blocks == 0) { const char* e = getenv("FLIMO_WIDEN_BLOCKS"); const int v = e ? atoi(e) : 0; g_widen_blocks = (v > 0 && v <= 2048) ? v : 2048; }   // <= 2048: the worklist has 8192 slots of prefetch slack
   return g_widen_blocks;
 }
 void launch_widen(hipStream_t st, const GridView& G, const float4* scan_sorted, const PoseMats& P, int max_ring, void* nbr,
@@ -1243,6 +1254,7 @@ void launch_reduce_final(hipStream_t st, const double* partials, int nparts, dou
 }
 
 size_t nbr_rec_size() { return sizeof(NbrRec); }
+size_t wl_entry_size() { return 2 * sizeof(int4); }
 
 void launch_knn(hipStream_t st, const GridView& G, const float* qxyz, int nq, int k, int max_ring, int32_t* idx,
                 float* sqd, int32_t* cnt) {
