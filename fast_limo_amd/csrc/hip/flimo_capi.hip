@@ -10,6 +10,7 @@
 #include <string.h>
 #include <math.h>
 #include <string>
+#include <chrono>
 #include <vector>
 #include <algorithm>
 #include <immintrin.h>
@@ -396,9 +397,14 @@ static int map_append_host(flimo_ctx* c, const float4* pts, size_t n) {
 static int map_add_device(flimo_ctx* c, const float4* d_pts, size_t m, double stamp) {
   if (m == 0) return FLIMO_OK;
   if (c->map_n + m > 0x7fff0000ull) return fail(c, FLIMO_ERR_TOO_LARGE, "map would exceed 2^31 points");
+  static const bool prof = getenv("FLIMO_PROF_INSERT") != nullptr;     // developer timing of the insert stages
+  auto now = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = prof ? now() : 0.0;
   float bb[6];
   bool any = false;
   HIPCHK(c, batch_bbox(c->stream, d_pts, m, c->scratch, bb, &any));
+  const double t1 = prof ? now() : 0.0;
+  double t2 = t1, t3 = t1;
   if (any) {
     const size_t old_cap = c->map_cap;
     int rc = ensure_dev(c, c->d_map_raw, c->map_cap, c->map_n + m, true, c->map_n);
@@ -406,6 +412,7 @@ static int map_add_device(flimo_ctx* c, const float4* d_pts, size_t m, double st
     if (c->map_cap != old_cap && c->d_map_sorted) { (void)hipFree(c->d_map_sorted); c->d_map_sorted = nullptr; }
     int kept = 0;
     HIPCHK(c, c->gbook.update(c->stream, d_pts, (int)m, bb, c->d_map_raw, (int)c->map_n, &kept, c->scratch));
+    t2 = prof ? now() : 0.0;
     c->map_n += (size_t)kept;
     if (kept > 0) {
       // the kept points lie inside the batch box: a superset box only makes the dense grid a little larger
@@ -413,7 +420,9 @@ static int map_add_device(flimo_ctx* c, const float4* d_pts, size_t m, double st
       rc = rebuild_grid(c);
       if (rc) return rc;
     }
+    t3 = prof ? now() : 0.0;
   }
+  if (prof) fprintf(stderr, "[flimo insert] bbox %.0f us, book %.0f us, grid %.0f us (batch %zu, map %zu)\n", t1 - t0, t2 - t1, t3 - t2, m, c->map_n);
   c->map_last_time = stamp;
   return FLIMO_OK;
 }

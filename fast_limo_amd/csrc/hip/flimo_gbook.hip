@@ -168,61 +168,112 @@ __global__ __launch_bounds__(256) void gb_gather_new_kernel(const uint32_t* __re
   for (int j = 0; j < I.g_len; j++) lists[I.seg + I.n_old + j] = new_index[perm[I.g_begin + j]];
 }
 
-// ---- build: createOctant (Octree.hpp:301-338) for one item per thread ----------------------------
-__global__ __launch_bounds__(64) void gb_build_kernel(const GbItem* __restrict__ items, int n_items, const float4* __restrict__ map_raw,
-                                                      int* __restrict__ lists, int* __restrict__ tmp, float4* __restrict__ node_c,
-                                                      int* __restrict__ node_child, int* __restrict__ node_cnt, int* __restrict__ node_n,
-                                                      int node_cap, float min_half, int* __restrict__ pt_leaf, int* __restrict__ node_item,
-                                                      int* __restrict__ overflow) {
-  const int it = blockIdx.x * blockDim.x + threadIdx.x;
+// ---- build: createOctant (Octree.hpp:301-338), ONE WAVE per item ---------------------------------
+// The wave walks the item's subtree with an explicit stack (LDS); at every node that splits, the lanes load
+// the node's points in parallel, octant counts and stable ranks come from ballots, the index list is
+// partitioned through `tmp`, and lane 0 allocates the children with one atomic.
+constexpr int GB_STACK = 128;      // >= 7 * max depth + 1
+
+__global__ __launch_bounds__(256) void gb_build_kernel(const GbItem* __restrict__ items, int n_items, const float4* __restrict__ map_raw,
+                                                       int* __restrict__ lists, int* __restrict__ tmp, float4* __restrict__ node_c,
+                                                       int* __restrict__ node_child, int* __restrict__ node_cnt, int* __restrict__ node_n,
+                                                       int node_cap, float min_half, int* __restrict__ pt_leaf, int* __restrict__ node_item,
+                                                       int* __restrict__ overflow) {
+  __shared__ int s_node[4][GB_STACK], s_b[4][GB_STACK], s_e[4][GB_STACK];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int it = blockIdx.x * 4 + wave;
   if (it >= n_items) return;
   const GbItem I = items[it];
   const int total = I.n_old + I.g_len;
   int root_node;
   if (I.slot == 8) {
     root_node = I.node;                       // rebuilt in place (`delete octant; octant = newOctant`)
-    node_item[I.node] = -1;
+    if (lane == 0) node_item[I.node] = -1;
   } else {
-    root_node = atomicAdd(node_n, 1);
-    if (root_node >= node_cap) { atomicExch(overflow, 1); return; }
-    const float4 pc = node_c[I.node];
-    const float f0 = (I.slot & 1) ? 0.5f : -0.5f, f1 = (I.slot & 2) ? 0.5f : -0.5f, f2 = (I.slot & 4) ? 0.5f : -0.5f;
-    node_c[root_node] = make_float4(pc.x + f0 * pc.w, pc.y + f1 * pc.w, pc.z + f2 * pc.w, pc.w * 0.5f);
-    for (int k = 0; k < 8; k++) node_child[(size_t)root_node * 8 + k] = -1;
-    node_child[(size_t)I.node * 8 + I.slot] = root_node;
+    int rn = 0;
+    if (lane == 0) rn = atomicAdd(node_n, 1);
+    root_node = __shfl(rn, 0, 64);
+    if (root_node >= node_cap) { if (lane == 0) atomicExch(overflow, 1); return; }
+    if (lane == 0) {
+      const float4 pc = node_c[I.node];
+      const float f0 = (I.slot & 1) ? 0.5f : -0.5f, f1 = (I.slot & 2) ? 0.5f : -0.5f, f2 = (I.slot & 4) ? 0.5f : -0.5f;
+      node_c[root_node] = make_float4(pc.x + f0 * pc.w, pc.y + f1 * pc.w, pc.z + f2 * pc.w, pc.w * 0.5f);
+      node_child[(size_t)I.node * 8 + I.slot] = root_node;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   }
-  // explicit stack of (node, begin, end) over the item's segment
-  int st_node[128], st_b[128], st_e[128];
-  int sp = 0;
-  st_node[0] = root_node; st_b[0] = I.seg; st_e[0] = I.seg + total; sp = 1;
+  int sp = 1;
+  if (lane == 0) { s_node[wave][0] = root_node; s_b[wave][0] = I.seg; s_e[wave][0] = I.seg + total; }
+  __builtin_amdgcn_wave_barrier();
   while (sp > 0) {
     sp--;
-    const int nd = st_node[sp], b = st_b[sp], e = st_e[sp];
+    const int nd = s_node[wave][sp], b = s_b[wave][sp], e = s_e[wave][sp];
+    __builtin_amdgcn_wave_barrier();
     const float4 c = node_c[nd];
     const int cnt = e - b;
     if (cnt > kBucket && c.w > 2 * min_half) {
-      node_cnt[nd] = -1;
+      // ---- octant histogram (uniform across the wave) ----
       int hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      for (int j = b; j < e; j++) { const float4 p = map_raw[lists[j]]; hist[octant_of(p.x, p.y, p.z, c)]++; }
-      int start[8], cur[8];
-      int acc = b;
-      for (int k = 0; k < 8; k++) { start[k] = acc; cur[k] = acc; acc += hist[k]; }
-      for (int j = b; j < e; j++) { const int id = lists[j]; const float4 p = map_raw[id]; tmp[cur[octant_of(p.x, p.y, p.z, c)]++] = id; }
-      for (int j = b; j < e; j++) lists[j] = tmp[j];
-      for (int k = 0; k < 8; k++) node_child[(size_t)nd * 8 + k] = -1;
-      for (int k = 7; k >= 0; k--) {
-        if (hist[k] == 0) continue;
-        const int ch = atomicAdd(node_n, 1);
-        if (ch >= node_cap || sp >= 127) { atomicExch(overflow, 1); return; }
-        const float f0 = (k & 1) ? 0.5f : -0.5f, f1 = (k & 2) ? 0.5f : -0.5f, f2 = (k & 4) ? 0.5f : -0.5f;
-        node_c[ch] = make_float4(c.x + f0 * c.w, c.y + f1 * c.w, c.z + f2 * c.w, c.w * 0.5f);
-        node_child[(size_t)nd * 8 + k] = ch;
-        st_node[sp] = ch; st_b[sp] = start[k]; st_e[sp] = start[k] + hist[k]; sp++;
+      for (int j0 = b; j0 < e; j0 += 64) {
+        const int j = j0 + lane;
+        int oct = -1;
+        if (j < e) { const float4 p = map_raw[lists[j]]; oct = octant_of(p.x, p.y, p.z, c); }
+#pragma unroll
+        for (int k = 0; k < 8; k++) hist[k] += __popcll(__ballot(oct == k));
       }
+      int start[8], run[8];
+      int acc = b;
+#pragma unroll
+      for (int k = 0; k < 8; k++) { start[k] = acc; run[k] = acc; acc += hist[k]; }
+      // ---- stable partition through tmp ----
+      for (int j0 = b; j0 < e; j0 += 64) {
+        const int j = j0 + lane;
+        int oct = -1, id = 0;
+        if (j < e) { id = lists[j]; const float4 p = map_raw[id]; oct = octant_of(p.x, p.y, p.z, c); }
+        int dest = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const unsigned long long m = __ballot(oct == k);
+          if (oct == k) dest = run[k] + __popcll(m & ((1ull << lane) - 1ull));
+          run[k] += __popcll(m);
+        }
+        if (j < e) tmp[dest] = id;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      for (int j = b + lane; j < e; j += 64) lists[j] = tmp[j];
+      // ---- children ----
+      int nch = 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) nch += hist[k] > 0 ? 1 : 0;
+      int base = 0;
+      if (lane == 0) base = atomicAdd(node_n, nch);
+      base = __shfl(base, 0, 64);
+      if (base + nch > node_cap || sp + nch > GB_STACK) { if (lane == 0) atomicExch(overflow, 1); return; }
+      if (lane == 0) node_cnt[nd] = -1;
+      int ord = 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int ch = hist[k] > 0 ? base + ord : -1;
+        if (lane == 0) node_child[(size_t)nd * 8 + k] = ch;
+        if (hist[k] > 0) {
+          if (lane == 0) {
+            const float f0 = (k & 1) ? 0.5f : -0.5f, f1 = (k & 2) ? 0.5f : -0.5f, f2 = (k & 4) ? 0.5f : -0.5f;
+            node_c[ch] = make_float4(c.x + f0 * c.w, c.y + f1 * c.w, c.z + f2 * c.w, c.w * 0.5f);
+            s_node[wave][sp + ord] = ch; s_b[wave][sp + ord] = start[k]; s_e[wave][sp + ord] = start[k] + hist[k];
+          }
+          ord++;
+        }
+      }
+      sp += nch;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
     } else {
-      node_cnt[nd] = cnt;
-      for (int k = 0; k < 8; k++) node_child[(size_t)nd * 8 + k] = -1;
-      for (int j = b; j < e; j++) pt_leaf[lists[j]] = nd;
+      if (lane == 0) node_cnt[nd] = cnt;
+      if (lane < 8) node_child[(size_t)nd * 8 + lane] = -1;
+      for (int j = b + lane; j < e; j += 64) pt_leaf[lists[j]] = nd;
     }
   }
 }
@@ -402,7 +453,7 @@ hipError_t GBook::update(hipStream_t st, const float4* batch, int m, const float
     hipLaunchKernelGGL(gb_gather_new_kernel, dim3((n_items + 255) / 256), dim3(256), 0, st, S.vals_out, new_index, items, n_items, lists);
     GBCHK(hipMemcpyAsync(node_n_dev, &node_n, sizeof(int), hipMemcpyHostToDevice, st));
     GBCHK(hipMemsetAsync(counters + 2, 0, sizeof(int), st));
-    hipLaunchKernelGGL(gb_build_kernel, dim3((n_items + 63) / 64), dim3(64), 0, st, items, n_items, map_raw, lists, tmp, node_c, node_child,
+    hipLaunchKernelGGL(gb_build_kernel, dim3((n_items + 3) / 4), dim3(256), 0, st, items, n_items, map_raw, lists, tmp, node_c, node_child,
                        node_cnt, node_n_dev, (int)node_cap, min_half, pt_leaf, node_item, counters + 2);
     int ovf = 0;
     GBCHK(hipMemcpyAsync(&node_n, node_n_dev, sizeof(int), hipMemcpyDeviceToHost, st));

@@ -263,9 +263,20 @@ __global__ __launch_bounds__(256) void bbox_finite_kernel(const float4* __restri
       mn[a] = fminf(mn[a], __shfl_xor(mn[a], off, 64));
       mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off, 64));
     }
+  // one set of atomics per block (same-address atomics cost ~70 ns each on this part)
+  __shared__ float s_mn[4][3], s_mx[4][3];
+  const int wave = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0)
 #pragma unroll
-    for (int a = 0; a < 3; a++) { atomicMin(&box[a], f2o(mn[a])); atomicMax(&box[3 + a], f2o(mx[a])); }
+    for (int a = 0; a < 3; a++) { s_mn[wave][a] = mn[a]; s_mx[wave][a] = mx[a]; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int a = threadIdx.x;
+    const float lo = fminf(fminf(s_mn[0][a], s_mn[1][a]), fminf(s_mn[2][a], s_mn[3][a]));
+    const float hi = fmaxf(fmaxf(s_mx[0][a], s_mx[1][a]), fmaxf(s_mx[2][a], s_mx[3][a]));
+    atomicMin(&box[a], f2o(lo));
+    atomicMax(&box[3 + a], f2o(hi));
+  }
 }
 
 __global__ __launch_bounds__(256) void voxelkey_kernel(const float4* __restrict__ pts, size_t n, float inv, int mb0, int mb1,
@@ -316,7 +327,7 @@ hipError_t batch_bbox(hipStream_t st, const float4* pts, size_t n, MapBuildScrat
   if (e != hipSuccess) return e;
   unsigned init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
   if ((e = hipMemcpyAsync(S.bbox, init, sizeof(init), hipMemcpyHostToDevice, st)) != hipSuccess) return e;
-  const int blocks = (int)std::min<size_t>((n + 255) / 256, 1024);
+  const int blocks = (int)std::min<size_t>((n + 1023) / 1024, 128);
   hipLaunchKernelGGL(bbox_finite_kernel, dim3(blocks), dim3(256), 0, st, pts, n, (unsigned*)S.bbox);
   unsigned ob[6];
   if ((e = hipMemcpyAsync(ob, S.bbox, sizeof(ob), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
@@ -339,7 +350,7 @@ hipError_t voxel_grid(hipStream_t st, const float4* in, size_t n, float leaf, fl
   unsigned init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
   if ((e = hipMemcpyAsync(S.bbox, init, sizeof(init), hipMemcpyHostToDevice, st)) != hipSuccess) return e;
   const int blocks = (int)((n + 255) / 256);
-  hipLaunchKernelGGL(bbox_finite_kernel, dim3(std::min(blocks, 1024)), dim3(256), 0, st, in, n, (unsigned*)S.bbox);
+  hipLaunchKernelGGL(bbox_finite_kernel, dim3(std::max(1, std::min(blocks / 4, 128))), dim3(256), 0, st, in, n, (unsigned*)S.bbox);
   unsigned ob[6];
   if ((e = hipMemcpyAsync(ob, S.bbox, sizeof(ob), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
   if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;

@@ -7,17 +7,28 @@ import numpy as np
 from fast_limo_amd import synth, api
 import oracle_py as O
 caps = dict(MAX_NUM_PC2MATCH=10**7, MAX_NUM_MATCHES=10**7)
-mp = synth.box_world_map(1000000, 100.0, 1)
-st, w, a = synth.stationary_imu(0.0, 1.0)
+NMAP = int(os.environ.get("NMAP", 1000000)); LBOX = float(os.environ.get("LBOX", 100.0))
+RINGS = int(os.environ.get("RINGS", 64)); AZ = int(os.environ.get("AZ", 1024)); NSCANS = int(os.environ.get("NSCANS", 6))
+WITH_ORACLE = int(os.environ.get("ORACLE", 1)) != 0          # ORACLE=0: GPU only (large maps)
+mp = synth.box_world_map(NMAP, LBOX, 1)
+st, w, a = synth.stationary_imu(0.0, 0.1 * NSCANS + 0.4)
 G = api.Localizer(api.default_cfg(num_threads=32, **caps))
-Lo = O.Localizer(O.default_cfg(num_threads=32, **caps))
-G.map_add(mp); Lo.map_add(mp)
+class _NoOracle:
+    def map_add(self, *a): pass
+    def update_imu(self, *a): pass
+    def update_pointcloud(self, *a): return -9
+    def stats(self): return dict(t_deskew=0.0, t_update=0.0, t_mapadd=0.0)
+    def map_size(self): return 0
+    def get_x(self): return np.zeros(26)
+Lo = O.Localizer(O.default_cfg(num_threads=32, **caps)) if WITH_ORACLE else _NoOracle()
+t0 = time.perf_counter(); G.map_add(mp); print("GPU map prime %.1f ms (%d points)" % ((time.perf_counter() - t0) * 1e3, NMAP), flush=True)
+Lo.map_add(mp)
 i = 0
-for k in range(6):
+for k in range(NSCANS):
     until = 0.1 * (k + 1) + 0.005
     while st[i] <= until:
         G.update_imu(st[i], w[i], a[i]); Lo.update_imu(st[i], w[i], a[i]); i += 1
-    scan = synth.velodyne_scan(64, 1024, 100.0, 2 + k)
+    scan = synth.velodyne_scan(RINGS, AZ, LBOX, 2 + k)
     t0 = time.perf_counter(); rg = G.update_pointcloud(scan, 0.1 * k); tg = time.perf_counter() - t0
     t0 = time.perf_counter(); ro = Lo.update_pointcloud(scan, 0.1 * k); to = time.perf_counter() - t0
     sg = G.stage_times(); so = Lo.stats()
