@@ -195,3 +195,48 @@ def test_first_scan_is_null_and_unmapped_scan_does_not_move(oracle):
     assert L.update_pointcloud(scan, 0.1) == 0                        # no map yet: M = 0, pose untouched, map seeded
     np.testing.assert_allclose(L.get_x()[0:7], x_before[0:7], atol=1e-12)
     assert L.map_size() == 512
+
+
+@pytest.mark.parametrize("sensor", ["OUSTER", "VELODYNE", "HESAI", "LIVOX"])
+def test_input_filters_and_time_formats_against_numpy(oracle, sensor):
+    """Oracle restatement of Localizer.cpp:262-302 (NaN removal, negative crop box, min distance, every-n-th point of the
+    cropped cloud, FoV) and :745-781 (per-sensor time decoding) against a plain numpy statement of the same rules.  With
+    a motionless sensor and distinct time stamps, pc2match is the filtered cloud in time order."""
+    code = {"OUSTER": 0, "VELODYNE": 1, "HESAI": 2, "LIVOX": 3}[sensor]
+    mp, scan5, imu = cfg1_scene(n_scan=3000)
+    st, w, a = imu
+    rs = np.random.RandomState(4)
+    xyz = scan5[:, :3].copy()
+    xyz[::53] = np.nan
+    xyz[1::101] *= np.float32(0.02)
+    rel = (rs.permutation(xyz.shape[0]).astype(np.float64) + 0.25) / xyz.shape[0] * 0.1     # distinct, shuffled
+    filt = dict(crop_active=1, dist_active=1, min_dist=2.0, rate_active=1, rate_value=2, fov_active=1, fov_angle=2.5)
+    L = oracle.Localizer(oracle.default_cfg(sensor_type=code, crop_min=(-1, -1, -1), crop_max=(1, 1, 1), num_threads=1,
+                                            **filt, **CAPS))
+    L.map_add(mp)
+    i = 0
+    for until, start in ((0.105, 0.0), (0.205, 0.1)):
+        while i < len(st) and st[i] <= until:
+            L.update_imu(st[i], w[i], a[i]); i += 1
+        if sensor == "OUSTER":
+            pts = oracle.make_points(xyz, 1.0, t_ns=np.round(rel * 1e9).astype(np.uint32))
+        elif sensor == "VELODYNE":
+            pts = oracle.make_points(xyz, 1.0, time_s=rel.astype(np.float32))
+        elif sensor == "HESAI":
+            pts = oracle.make_points(xyz, 1.0, timestamp=start + rel)
+        else:
+            pts = oracle.make_points(xyz, 1.0, timestamp=(start + rel) * 1e9)
+        rc = L.update_pointcloud_points(pts, start, add_to_map=False)
+    assert rc == 0
+    # numpy statement of the filters
+    fin = np.isfinite(xyz).all(1)
+    p = xyz[fin]; t = rel[fin]
+    inside = np.all((p >= -1) & (p <= 1), axis=1)
+    p, t = p[~inside], t[~inside]
+    keep = (np.sqrt((p.astype(np.float32) ** 2).sum(1)) > np.float32(2.0)) & (np.arange(p.shape[0]) % 2 == 0) & \
+           (np.abs(np.arctan2(p[:, 1], p[:, 0])) < np.float32(2.5))
+    p, t = p[keep], t[keep]
+    order = np.argsort(t, kind="stable")
+    got = L.pc2match()
+    assert got.shape[0] == p.shape[0] and 300 < p.shape[0] < 1500
+    np.testing.assert_allclose(got, p[order], rtol=0, atol=2e-5)      # deskew of a motionless sensor: identity up to float32 rounding
