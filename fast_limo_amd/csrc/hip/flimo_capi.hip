@@ -332,19 +332,7 @@ static int rebuild_grid(flimo_ctx* c) {
     cell *= 2.0f;   // keep the dense index addressable with 32 bits
   }
   const size_t ncells = (size_t)nx * ny * nz;
-  size_t dummy = 0;
-  if (c->map_cap > 0) {
-    // sorted buffer mirrors the raw capacity
-  }
-  {
-    size_t sorted_cap = c->d_map_sorted ? c->map_cap : 0;
-    if (!c->d_map_sorted || sorted_cap < c->map_n) {
-      if (c->d_map_sorted) (void)hipFree(c->d_map_sorted);
-      c->d_map_sorted = nullptr;
-      HIPCHK(c, hipMalloc(&c->d_map_sorted, c->map_cap * sizeof(float4)));
-    }
-  }
-  (void)dummy;
+  if (!c->d_map_sorted) HIPCHK(c, hipMalloc(&c->d_map_sorted, c->map_cap * sizeof(float4)));   // mirrors the raw capacity (freed whenever that grows)
   if (ncells + 1 > c->cell_cap) {
     if (c->d_cell_start) (void)hipFree(c->d_cell_start);
     c->d_cell_start = nullptr;
@@ -518,19 +506,22 @@ extern "C" int flimo_knn(flimo_ctx* c, const float* q, size_t nq, int k, int32_t
     return FLIMO_OK;
   }
   (void)hipSetDevice(c->device);
-  float* d_q = nullptr; int32_t* d_idx = nullptr; float* d_sqd = nullptr; int32_t* d_cnt = nullptr;
-  HIPCHK(c, hipMalloc(&d_q, nq * 3 * sizeof(float)));
-  HIPCHK(c, hipMalloc(&d_idx, nq * k * sizeof(int32_t)));
-  HIPCHK(c, hipMalloc(&d_sqd, nq * k * sizeof(float)));
-  HIPCHK(c, hipMalloc(&d_cnt, nq * sizeof(int32_t)));
-  HIPCHK(c, hipMemcpyAsync(d_q, q, nq * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
-  launch_knn(c->stream, c->grid, d_q, (int)nq, k, 1 << 29, d_idx, d_sqd, d_cnt);
+  // scratch of this call, released on every exit path
+  struct Scratch {
+    float* q = nullptr; int32_t* idx = nullptr; float* sqd = nullptr; int32_t* cnt = nullptr;
+    ~Scratch() { (void)hipFree(q); (void)hipFree(idx); (void)hipFree(sqd); (void)hipFree(cnt); }
+  } d;
+  HIPCHK(c, hipMalloc(&d.q, nq * 3 * sizeof(float)));
+  HIPCHK(c, hipMalloc(&d.idx, nq * k * sizeof(int32_t)));
+  HIPCHK(c, hipMalloc(&d.sqd, nq * k * sizeof(float)));
+  HIPCHK(c, hipMalloc(&d.cnt, nq * sizeof(int32_t)));
+  HIPCHK(c, hipMemcpyAsync(d.q, q, nq * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  launch_knn(c->stream, c->grid, d.q, (int)nq, k, 1 << 29, d.idx, d.sqd, d.cnt);
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipMemcpyAsync(idx, d_idx, nq * k * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(sqd, d_sqd, nq * k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(cnt, d_cnt, nq * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(idx, d.idx, nq * k * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(sqd, d.sqd, nq * k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(cnt, d.cnt, nq * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  (void)hipFree(d_q); (void)hipFree(d_idx); (void)hipFree(d_sqd); (void)hipFree(d_cnt);
   return FLIMO_OK;
 }
 

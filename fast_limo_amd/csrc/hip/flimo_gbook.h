@@ -50,6 +50,7 @@ struct GBook {
   hipError_t update(hipStream_t st, const float4* batch, int m, const float bb[6], float4* map_raw, int map_n, int* kept_out,
                     MapBuildScratch& S);
   void release();
+  hipError_t reserve_nodes(hipStream_t st, size_t want);
 };
 
 // flimo_map.hip: bounding box of the finite points (host result); *any = false when there is none

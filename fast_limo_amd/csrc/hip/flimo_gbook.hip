@@ -297,6 +297,21 @@ static hipError_t grow(T*& p, size_t& cap, size_t need, size_t keep_n, hipStream
   return hipSuccess;
 }
 
+// node arrays grow together; the first node_n entries survive, node_item (per-batch scratch) is re-armed
+hipError_t GBook::reserve_nodes(hipStream_t st, size_t want) {
+  if (want <= node_cap) return hipSuccess;
+  const size_t keep_n = (size_t)node_n;
+  size_t c1 = node_cap, c2 = node_cap * 8, c3 = node_cap, c4 = 0;
+  const size_t ncap = want + want / 2 + 4096;
+  GBCHK(grow(node_c, c1, ncap, keep_n, st));
+  GBCHK(grow(node_child, c2, ncap * 8, keep_n * 8, st));
+  GBCHK(grow(node_cnt, c3, ncap, keep_n, st));
+  if (node_item) { (void)hipFree(node_item); node_item = nullptr; }
+  GBCHK(grow(node_item, c4, ncap, 0, st));
+  node_cap = std::min(std::min(c1, c2 / 8), std::min(c3, c4));
+  return hipMemsetAsync(node_item, 0xff, node_cap * sizeof(int), st);
+}
+
 void GBook::release() {
   (void)hipFree(node_c); (void)hipFree(node_child); (void)hipFree(node_cnt); (void)hipFree(node_item); (void)hipFree(pt_leaf);
   (void)hipFree(keep); (void)hipFree(assign); (void)hipFree(new_index); (void)hipFree(items); (void)hipFree(lists); (void)hipFree(tmp);
@@ -309,13 +324,8 @@ hipError_t GBook::import_host(hipStream_t st, const std::vector<float>& c4, cons
   min_half = min_half_;
   downsample = downsample_;
   const size_t nn = cnt.size();
-  size_t cap_c = node_cap, cap_ch = node_cap * 8, cap_n = node_cap, cap_it = node_cap;
-  const size_t want = nn + nn / 2 + 4096;
-  GBCHK(grow(node_c, cap_c, want, 0, st));
-  GBCHK(grow(node_child, cap_ch, want * 8, 0, st));
-  GBCHK(grow(node_cnt, cap_n, want, 0, st));
-  GBCHK(grow(node_item, cap_it, want, 0, st));
-  node_cap = std::min(std::min(cap_c, cap_ch / 8), std::min(cap_n, cap_it));
+  node_n = 0;                                           // nothing to carry over
+  GBCHK(reserve_nodes(st, nn + 4096));
   GBCHK(hipMemcpyAsync(node_c, c4.data(), nn * sizeof(float4), hipMemcpyHostToDevice, st));
   GBCHK(hipMemcpyAsync(node_child, child.data(), nn * 8 * sizeof(int), hipMemcpyHostToDevice, st));
   GBCHK(hipMemcpyAsync(node_cnt, cnt.data(), nn * sizeof(int), hipMemcpyHostToDevice, st));
@@ -366,16 +376,7 @@ hipError_t GBook::update(hipStream_t st, const float4* batch, int m, const float
     }
     const int add = (int)(nc.size() / 4);
     if (add > 0) {
-      if ((size_t)node_n + add + 16 > node_cap) {
-        size_t cap_c = node_cap, cap_ch = node_cap * 8, cap_n = node_cap, cap_it = node_cap;
-        const size_t want = (size_t)node_n + add + 4096;
-        GBCHK(grow(node_c, cap_c, want, node_n, st));
-        GBCHK(grow(node_child, cap_ch, want * 8, (size_t)node_n * 8, st));
-        GBCHK(grow(node_cnt, cap_n, want, node_n, st));
-        GBCHK(grow(node_item, cap_it, want, 0, st));
-        node_cap = std::min(std::min(cap_c, cap_ch / 8), std::min(cap_n, cap_it));
-        GBCHK(hipMemsetAsync(node_item, 0xff, node_cap * sizeof(int), st));
-      }
+      GBCHK(reserve_nodes(st, (size_t)node_n + add + 16));
       std::vector<int> ncnt(add, -1);
       GBCHK(hipMemcpyAsync(node_c + node_n, nc.data(), (size_t)add * sizeof(float4), hipMemcpyHostToDevice, st));
       GBCHK(hipMemcpyAsync(node_child + (size_t)node_n * 8, nchild.data(), (size_t)add * 8 * sizeof(int), hipMemcpyHostToDevice, st));
@@ -386,16 +387,7 @@ hipError_t GBook::update(hipStream_t st, const float4* batch, int m, const float
   }
   // ---- capacity for this batch: worst case every kept point creates a short chain of nodes ----
   {
-    const size_t want = (size_t)node_n + (size_t)m * 16 + 4096;
-    if (want > node_cap) {
-      size_t cap_c = node_cap, cap_ch = node_cap * 8, cap_n = node_cap, cap_it = node_cap;
-      GBCHK(grow(node_c, cap_c, want, node_n, st));
-      GBCHK(grow(node_child, cap_ch, want * 8, (size_t)node_n * 8, st));
-      GBCHK(grow(node_cnt, cap_n, want, node_n, st));
-      GBCHK(grow(node_item, cap_it, want, 0, st));
-      node_cap = std::min(std::min(cap_c, cap_ch / 8), std::min(cap_n, cap_it));
-      GBCHK(hipMemsetAsync(node_item, 0xff, node_cap * sizeof(int), st));
-    }
+    GBCHK(reserve_nodes(st, (size_t)node_n + (size_t)m * 16 + 4096));
     GBCHK(grow(pt_leaf, pt_cap, (size_t)map_n + m + 1024, map_n, st));
     size_t c1 = batch_cap, c2 = batch_cap, c3 = batch_cap, c4 = batch_cap, c5 = batch_cap, c6 = batch_cap, c7 = batch_cap;
     GBCHK(grow(keep, c1, m, 0, st)); GBCHK(grow(assign, c2, m, 0, st)); GBCHK(grow(new_index, c3, m, 0, st));
@@ -409,8 +401,6 @@ hipError_t GBook::update(hipStream_t st, const float4* batch, int m, const float
   const int blocks = (m + 255) / 256;
   // scratch for the sort: reuse the map builder's key / value buffers
   {
-    size_t dummy = 0;
-    (void)dummy;
     if (S.cap_pts < (size_t)m) {
       if (S.keys_in) { (void)hipFree(S.keys_in); (void)hipFree(S.keys_out); (void)hipFree(S.vals_in); (void)hipFree(S.vals_out); }
       const size_t cap = (size_t)m + m / 4 + 1024;
