@@ -774,6 +774,9 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   int rc = ensure_recs(c, nq);
   if (rc) return rc;
 
+  static const bool prof = getenv("FLIMO_PROF_PASS") != nullptr;        // developer timing of the host side of a pass
+  auto now_us = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double tp0 = prof ? now_us() : 0.0;
   PoseMats P;
   pose_from_x26(x26, P);
   MatchParams mp;
@@ -790,6 +793,7 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   const bool want_recs = c->debug_recs || cap_binds;
   if (c->debug_recs) HIPCHK(c, hipMemsetAsync(c->d_cand, 0, sizeof(unsigned long long), c->stream));
   const bool want_count = c->debug_recs;
+  const double tpa = prof ? now_us() : 0.0;
   // effective level of THIS pass (level 1 may sample every timing_stride-th pass)
   const int tlev = (c->timing == 1 && c->timing_stride > 1 && ((c->pass_seq + 1) % (unsigned long long)c->timing_stride) != 0) ? 0 : c->timing;
   if (tlev > 1) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
@@ -798,9 +802,11 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
               c->d_wl_count, c->debug_recs ? c->d_cand : nullptr, c->prev, tlev == 1 ? c->ev[0] : nullptr,
               tlev == 1 ? c->ev[1] : nullptr);
   if (c->prune) { memcpy(c->prev.RT, P.RT, sizeof(c->prev.RT)); c->prev.valid = 1; }   // the records now belong to this pose
+  const double tpb = prof ? now_us() : 0.0;
   if (tlev > 1) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
   launch_widen(c->stream, c->grid, c->d_scan_sorted, P, mp.max_ring, c->d_nbr, c->d_wl, c->d_wl_count,
                c->debug_recs ? c->d_cand : nullptr);
+  const double tpc = prof ? now_us() : 0.0;
   if (want_count) HIPCHK(c, hipMemcpyAsync(c->h_wl_count, c->d_wl_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   if (tlev > 1) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   // fit + reductions; the last block writes the 16x16 accumulator to mapped host memory, publishes the
@@ -814,6 +820,7 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   }
   if (tlev > 1) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
   HIPCHK(c, hipGetLastError());
+  const double tp1 = prof ? now_us() : 0.0;
   if (c->debug_recs) HIPCHK(c, hipMemcpyAsync(c->h_cand, c->d_cand, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
   if (!cap_binds && !c->debug_recs && tlev < 2) {
     // low-latency completion: spin on the pass number every reduction group publishes to host memory
@@ -839,6 +846,17 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
       c->tot_widen_ms += c->last_widen_ms; c->tot_fit_ms += c->last_fit_ms;
     }
     c->tot_passes++; c->tot_queries += n_all;
+  }
+  if (prof) {
+    static double acc_launch = 0, acc_wait = 0, a0 = 0, a1 = 0, a2 = 0, a3 = 0; static long cnt = 0;
+    const double tp2 = now_us();
+    acc_launch += tp1 - tp0; acc_wait += tp2 - tp1;
+    a0 += tpa - tp0; a1 += tpb - tpa; a2 += tpc - tpb; a3 += tp1 - tpc;
+    if (++cnt % 200 == 0) {
+      fprintf(stderr, "[flimo pass] host: pose+launches %.2f us (prep %.2f, knn launch %.2f, widen launch %.2f, fit launch %.2f), wait for result %.2f us (mean of 200)\n",
+              acc_launch / 200, a0 / 200, a1 / 200, a2 / 200, a3 / 200, acc_wait / 200);
+      acc_launch = acc_wait = a0 = a1 = a2 = a3 = 0;
+    }
   }
   c->async_deskews = 0;            // the pass completed: the stream is idle
   if (want_count) c->last_widen_count = *c->h_wl_count;
