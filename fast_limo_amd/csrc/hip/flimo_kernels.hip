@@ -836,7 +836,7 @@ __global__ __launch_bounds__(FIT_THREADS) void fit_kernel(GridView G, const floa
   __syncthreads();
   TRACE(1, 4);
   const int group = blockIdx.x & (FIT_GROUPS - 1);
-  const int nb_g = (int)(gridDim.x / FIT_GROUPS);                  // gridDim.x is a multiple of 8
+  const int nb_g = (int)(gridDim.x / FIT_GROUPS);                  // gridDim.x is a multiple of FIT_GROUPS
   if (threadIdx.x == 0) {
     // every partial of this block is already performed at agent scope (write-through stores, vmcnt(0), barrier)
     const unsigned int old = __hip_atomic_fetch_add(ticket + group, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1223,7 +1223,7 @@ static int fit_threads() {
   }
   return g_fit_threads;
 }
-int fit_blocks(int n) { const int T = fit_threads(); return round_up8((n + T - 1) / T); }
+int fit_blocks(int n) { const int T = fit_threads(); const int b = (n + T - 1) / T; return (b + FIT_GROUPS - 1) / FIT_GROUPS * FIT_GROUPS; }   // a multiple of FIT_GROUPS (and of 8)
 
 template <int T>
 static void launch_fit_T(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const void* nbr, const PoseMats& P,
