@@ -310,27 +310,25 @@ struct NbrRec {      // 32 bytes per query (sorted order)
   int32_t d5_valid;  // 1 when flag == 1
 };
 
-// sorted private best-5 of one lane: distances as floats (+inf = empty), payload = position in the sorted map.
-// A lane meets its candidates in ascending map position, so on equal distance the earlier one stays in front:
-// the strict float compare orders exactly like the 64-bit (distance, position) key of the group merge.
+// Sorted private best-5 of one lane.  A (distance, position) pair is the 64-bit key (float bits << 32 | position);
+// distances are non-negative finite floats (+inf = empty), so the key read as an IEEE double is a positive finite
+// double (the float's exponent field lands inside the double's 11-bit exponent, below 0x7ff) and doubles of one sign
+// order exactly like their bit patterns: v_min_f64 / v_max_f64 compare-and-select whole keys in ONE instruction each
+// (fp64 denormals are always preserved on gfx9, min/max return an operand unchanged).  Insertion into the sorted list is
+// a 9-instruction min/max ladder, no compares, no payload selects.
 struct U3 { uint32_t a, b, c; };
-FLIMO_DEV void best5_insert(float (&kd)[5], uint32_t (&ki)[5], float x, uint32_t xi) {
-  const bool c0 = x < kd[0], c1 = x < kd[1], c2 = x < kd[2], c3 = x < kd[3], c4 = x < kd[4];
-  // flat two-level selects on the OLD values (nested ternaries would be lowered to branches)
-  const uint32_t t4 = c3 ? ki[3] : xi;
-  const uint32_t t3 = c2 ? ki[2] : xi;
-  const uint32_t t2 = c1 ? ki[1] : xi;
-  const uint32_t t1 = c0 ? ki[0] : xi;
-  ki[4] = c4 ? t4 : ki[4];
-  ki[3] = c3 ? t3 : ki[3];
-  ki[2] = c2 ? t2 : ki[2];
-  ki[1] = c1 ? t1 : ki[1];
-  ki[0] = c0 ? xi : ki[0];
-  kd[4] = __builtin_amdgcn_fmed3f(kd[3], x, kd[4]);      // kd[3] <= kd[4]: clamp x into [kd[3], kd[4]]
-  kd[3] = __builtin_amdgcn_fmed3f(kd[2], x, kd[3]);
-  kd[2] = __builtin_amdgcn_fmed3f(kd[1], x, kd[2]);
-  kd[1] = __builtin_amdgcn_fmed3f(kd[0], x, kd[1]);
-  kd[0] = c0 ? x : kd[0];
+__device__ __forceinline__ double key_min(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double key_max(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double key_make(float d, uint32_t id) { return __hiloint2double((int)__float_as_uint(d), (int)id); }
+__device__ __forceinline__ void best5_insert(double (&k)[5], double x) {
+  double t = x;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const double lo = key_min(k[i], t);
+    t = key_max(k[i], t);
+    k[i] = lo;
+  }
+  k[4] = key_min(k[4], t);
 }
 #define KEY_NONE 0x7f800000ffffffffull     // (+inf, -1): an empty slot of the merged list
 
@@ -339,7 +337,7 @@ FLIMO_DEV void best5_insert(float (&kd)[5], uint32_t (&ki)[5], float x, uint32_t
 template <int L, int N>
 __device__ __forceinline__ void knn5_body(const float4* __restrict__ pts, uint32_t s0, uint32_t total, uint32_t last,
                                           const uint32_t (&off)[10], const uint32_t (&dl)[9], float gx, float gy, float gz,
-                                          float (&kd)[5], uint32_t (&ki)[5]) {
+                                          double (&k5)[5]) {
   float4 pt[N];
   uint32_t id[N];
 #pragma unroll
@@ -365,7 +363,7 @@ __device__ __forceinline__ void knn5_body(const float4* __restrict__ pts, uint32
   for (int u = 0; u < N; u++) {
     const bool live = s0 + u * L < total;
     const float d = sqdist3(gx, gy, gz, pt[u].x, pt[u].y, pt[u].z);
-    best5_insert(kd, ki, live ? d : INFINITY, id[u]);
+    best5_insert(k5, key_make(live ? d : INFINITY, live ? id[u] : 0xffffffffu));
   }
 }
 
@@ -459,17 +457,17 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
       const uint32_t total = off[9];
       TRACE(0, 2);
       // ---- flattened candidate stream, branch-free body ----
-      float kd[5] = {INFINITY, INFINITY, INFINITY, INFINITY, INFINITY};
-      uint32_t ki[5] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+      const double none = __longlong_as_double((long long)KEY_NONE);
+      double k5[5] = {none, none, none, none, none};
       const uint32_t last = total - 1u;
       // full bodies while more than half of a body's slots are live for this lane, then one half body
       uint32_t s0 = (uint32_t)sub;
       for (; s0 + (SLOTS / 2) * L < total; s0 += SLOTS * L)
-        knn5_body<L, SLOTS>(G.pts, s0, total, last, off, dl, gx, gy, gz, kd, ki);
-      if (s0 < total) knn5_body<L, (SLOTS >= 2 ? SLOTS / 2 : 1)>(G.pts, s0, total, last, off, dl, gx, gy, gz, kd, ki);
+        knn5_body<L, SLOTS>(G.pts, s0, total, last, off, dl, gx, gy, gz, k5);
+      if (s0 < total) knn5_body<L, (SLOTS >= 2 ? SLOTS / 2 : 1)>(G.pts, s0, total, last, off, dl, gx, gy, gz, k5);
       cand = total > (uint32_t)sub ? (int)((total - (uint32_t)sub + L - 1) / L) : 0;
 #pragma unroll
-      for (int i = 0; i < 5; i++) best[i] = ((u64)__float_as_uint(kd[i]) << 32) | (u64)ki[i];
+      for (int i = 0; i < 5; i++) best[i] = (u64)__double_as_longlong(k5[i]);
       TRACE(0, 3);
 #ifdef FLIMO_TRACE
       if (blockIdx.x < 16384) {   // developer statistics: accumulated block candidates (all passes), CU id
@@ -484,12 +482,10 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
         for (int i = 0; i < 5; i++) mine[i] = best[i];
 #pragma unroll
         for (int r = 0; r < 5; r++) {
-          u64 m = mine[0];
+          double md = __longlong_as_double((long long)mine[0]);
 #pragma unroll
-          for (int o = 1; o < L; o <<= 1) {
-            const u64 v = __shfl_xor(m, o, 64);
-            m = v < m ? v : m;
-          }
+          for (int o = 1; o < L; o <<= 1) md = key_min(md, __shfl_xor(md, o, 64));
+          const u64 m = (u64)__double_as_longlong(md);
           best[r] = m;
           if (mine[0] == m) { mine[0] = mine[1]; mine[1] = mine[2]; mine[2] = mine[3]; mine[3] = mine[4]; mine[4] = KEY_NONE; }
         }
@@ -603,8 +599,8 @@ __global__ __launch_bounds__(256) void widen_kernel(GridView G, const float4* __
       s_lo[wave][lane] = lo;
       __builtin_amdgcn_wave_barrier();
       // strided share of the flattened candidates; rows ascend in memory, so a lane meets ascending map positions
-      float kd[5] = {INFINITY, INFINITY, INFINITY, INFINITY, INFINITY};
-      uint32_t ki[5] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+      const double none = __longlong_as_double((long long)KEY_NONE);
+      double k5[5] = {none, none, none, none, none};
       const uint32_t last = total - 1u;
       for (uint32_t s0 = (uint32_t)lane; s0 < total; s0 += 4 * 64) {
         float4 q[4];
@@ -624,22 +620,20 @@ __global__ __launch_bounds__(256) void widen_kernel(GridView G, const float4* __
         for (int u = 0; u < 4; u++) {
           const bool live = s0 + 64u * u < total;
           const float d = sqdist3(gx, gy, gz, q[u].x, q[u].y, q[u].z);
-          best5_insert(kd, ki, live ? d : INFINITY, id[u]);
+          best5_insert(k5, key_make(live ? d : INFINITY, live ? id[u] : 0xffffffffu));
         }
       }
       cand += total > (uint32_t)lane ? (int)((total - (uint32_t)lane + 63u) / 64u) : 0;
       __builtin_amdgcn_wave_barrier();
       u64 mine[5];
 #pragma unroll
-      for (int i = 0; i < 5; i++) mine[i] = ((u64)__float_as_uint(kd[i]) << 32) | (u64)ki[i];
+      for (int i = 0; i < 5; i++) mine[i] = (u64)__double_as_longlong(k5[i]);
 #pragma unroll
       for (int k = 0; k < 5; k++) {
-        u64 m = mine[0];
+        double md = __longlong_as_double((long long)mine[0]);
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-          const u64 v = __shfl_xor(m, o, 64);
-          m = v < m ? v : m;
-        }
+        for (int o = 1; o < 64; o <<= 1) md = key_min(md, __shfl_xor(md, o, 64));
+        const u64 m = (u64)__double_as_longlong(md);
         best[k] = m;
         if (mine[0] == m) { mine[0] = mine[1]; mine[1] = mine[2]; mine[2] = mine[3]; mine[3] = mine[4]; mine[4] = KEY_NONE; }
       }
