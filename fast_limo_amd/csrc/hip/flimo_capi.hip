@@ -328,7 +328,7 @@ static int rebuild_grid(flimo_ctx* c) {
     ny = (int)floorf((bb[4] - oy) * inv) + 2;
     nz = (int)floorf((bb[5] - oz) * inv) + 2;
     const double ncells = (double)nx * ny * nz;
-    if (ncells < 1.9e9) break;
+    if (ncells < 1.9e9 && (double)row_table_size(nx, ny, nz) < 4.0e9) break;   // both indices stay 32-bit addressable
     cell *= 2.0f;   // keep the dense index addressable with 32 bits
   }
   const size_t ncells = (size_t)nx * ny * nz;

@@ -419,39 +419,56 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
     } else {
       // ---- range bounds of the 9 rows x 3 cells: twelve 12-byte loads from the y-fastest, padded row table
       //      (x planes cx-1 .. cx+2, clamped: a plane index outside the grid yields an empty cell) ----
-      const size_t py = (size_t)G.ny + 4, pz = (size_t)G.nz + 4;
-      const size_t yz = (size_t)(cz + 1) * py + (size_t)(cy + 1);
+      // (32-bit table indices: the host keeps the table below 2^32 entries)
+      const uint32_t py = (uint32_t)G.ny + 4u, plane = py * ((uint32_t)G.nz + 4u);
+      const uint32_t yz = (uint32_t)(cz + 1) * py + (uint32_t)(cy + 1);
       U3 rb[4][3];
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        const int xp = min(max(cx - 1 + k, 0), G.nx);
-        const uint32_t* T = G.row_table + (size_t)xp * pz * py + yz;
+        const uint32_t xp = (uint32_t)min(max(cx - 1 + k, 0), G.nx);
+        const uint32_t i0 = xp * plane + yz;
 #pragma unroll
-        for (int dz = 0; dz < 3; dz++) rb[k][dz] = *reinterpret_cast<const U3*>(T + (size_t)dz * py);
+        for (int dz = 0; dz < 3; dz++) rb[k][dz] = *reinterpret_cast<const U3*>(G.row_table + (i0 + (uint32_t)dz * py));
       }
       // position inside the cell and the conservative distances (cell units) to the neighbouring cells
       const float rx = fminf(fmaxf(fx - flx, 0.f), 1.f), ry = fminf(fmaxf(fy - fly, 0.f), 1.f),
                   rz = fminf(fmaxf(fz - flz, 0.f), 1.f);
       const int maxdim = max(G.nx, max(G.ny, G.nz));
       const float margin = 1.0e-3f + 4.0e-7f * (float)maxdim;
-      const float xl = fmaxf(rx - margin, 0.f), xr = fmaxf(1.f - rx - margin, 0.f);
-      const float yd[3] = {fmaxf(ry - margin, 0.f), 0.f, fmaxf(1.f - ry - margin, 0.f)};
-      const float zd[3] = {fmaxf(rz - margin, 0.f), 0.f, fmaxf(1.f - rz - margin, 0.f)};
       uint32_t off[10], dl[9];          // dl[t] = lo[t] - off[t]: stream position -> map position
       off[0] = 0;
+      if (!prev.valid) {
+        // first pass of a scan (kernel-uniform): no bound, every row is the full three cells
 #pragma unroll
-      for (int dz = 0; dz < 3; dz++) {
-        const uint32_t s0[3] = {rb[0][dz].a, rb[0][dz].b, rb[0][dz].c}, s1[3] = {rb[1][dz].a, rb[1][dz].b, rb[1][dz].c};
-        const uint32_t s2[3] = {rb[2][dz].a, rb[2][dz].b, rb[2][dz].c}, s3[3] = {rb[3][dz].a, rb[3][dz].b, rb[3][dz].c};
+        for (int dz = 0; dz < 3; dz++) {
+          const uint32_t s0[3] = {rb[0][dz].a, rb[0][dz].b, rb[0][dz].c}, s3[3] = {rb[3][dz].a, rb[3][dz].b, rb[3][dz].c};
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-          const int t = 3 * dz + k;
-          const float dyz2 = yd[k] * yd[k] + zd[dz] * zd[dz];
-          const bool row = dyz2 <= b2;
-          const bool left = dyz2 + xl * xl <= b2, right = dyz2 + xr * xr <= b2;
-          const uint32_t lo = left ? s0[k] : s1[k], hi = right ? s3[k] : s2[k];
-          dl[t] = lo - off[t];
-          off[t + 1] = off[t] + (row ? hi - lo : 0u);
+          for (int k = 0; k < 3; k++) {
+            const int t = 3 * dz + k;
+            dl[t] = s0[k] - off[t];
+            off[t + 1] = off[t] + (s3[k] - s0[k]);
+          }
+        }
+      } else {
+        const float xl = fmaxf(rx - margin, 0.f), xr = fmaxf(1.f - rx - margin, 0.f);
+        const float xl2 = xl * xl, xr2 = xr * xr;
+        const float yd[3] = {fmaxf(ry - margin, 0.f), 0.f, fmaxf(1.f - ry - margin, 0.f)};
+        const float zd[3] = {fmaxf(rz - margin, 0.f), 0.f, fmaxf(1.f - rz - margin, 0.f)};
+        const float yd2[3] = {yd[0] * yd[0], 0.f, yd[2] * yd[2]}, zd2[3] = {zd[0] * zd[0], 0.f, zd[2] * zd[2]};
+#pragma unroll
+        for (int dz = 0; dz < 3; dz++) {
+          const uint32_t s0[3] = {rb[0][dz].a, rb[0][dz].b, rb[0][dz].c}, s1[3] = {rb[1][dz].a, rb[1][dz].b, rb[1][dz].c};
+          const uint32_t s2[3] = {rb[2][dz].a, rb[2][dz].b, rb[2][dz].c}, s3[3] = {rb[3][dz].a, rb[3][dz].b, rb[3][dz].c};
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            const int t = 3 * dz + k;
+            const float dyz2 = yd2[k] + zd2[dz];
+            const bool row = dyz2 <= b2;
+            const bool left = dyz2 + xl2 <= b2, right = dyz2 + xr2 <= b2;
+            const uint32_t lo = left ? s0[k] : s1[k], hi = right ? s3[k] : s2[k];
+            dl[t] = lo - off[t];
+            off[t + 1] = off[t] + (row ? hi - lo : 0u);
+          }
         }
       }
       const uint32_t total = off[9];
