@@ -833,12 +833,16 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
       }
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    if (tlev) HIPCHK(c, hipEventSynchronize(c->ev[1]));
+    // the fit kernel has published, so the k-NN dispatch (earlier on the same stream) and its events are complete:
+    // no hipEventSynchronize (its blocking wait costs ~40 us per timed pass)
   } else {
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
   if (tlev) {
-    (void)hipEventElapsedTime(&c->last_knn_ms, c->ev[0], c->ev[1]);
+    if (hipEventElapsedTime(&c->last_knn_ms, c->ev[0], c->ev[1]) != hipSuccess) {      // not marked complete yet: wait for it
+      HIPCHK(c, hipEventSynchronize(c->ev[1]));
+      (void)hipEventElapsedTime(&c->last_knn_ms, c->ev[0], c->ev[1]);
+    }
     c->tot_knn_ms += c->last_knn_ms;
     if (tlev > 1) {
       (void)hipEventElapsedTime(&c->last_widen_ms, c->ev[1], c->ev[2]);
