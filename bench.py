@@ -208,6 +208,23 @@ def main():
     x_end = loc.get_x()
     assert np.array_equal(x_end, x_ref), "registration is not reproducible across steps"
 
+    # the same step WITH the path exit (transform + Mapper::add of the registered scan), reported
+    # beside `value`, never as `value`.  The first insertion stores the scan's new points; repeating the same scan is
+    # then mostly rejected by the reference's down-sampling rule, so both are shown.  Runs after the timed region.
+    with_insert = None
+    if rank == 0:
+        t_ins = []
+        sizes = [loc.map_size()]
+        for k in range(6):
+            t1 = time.perf_counter()
+            step()
+            loc.hip.map_add_scan(loc.get_x(), 0.2 + 0.1 * k)
+            t_ins.append(time.perf_counter() - t1)
+            sizes.append(loc.map_size())
+        with_insert = {"first_ms": 1e3 * t_ins[0], "points_stored_first": sizes[1] - sizes[0],
+                       "repeat_ms": 1e3 * float(np.median(t_ins[1:])), "points_stored_repeat": sizes[-1] - sizes[1],
+                       "scans_per_s_first": 1.0 / t_ins[0], "scans_per_s_repeat": 1.0 / float(np.median(t_ins[1:]))}
+
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -236,6 +253,7 @@ def main():
                        "passes_per_step": n_passes / max(args.steps, 1)},
             "host_us_per_step": {"deskew_call": 1e6 * hp["deskew_s"] / args.steps, "update": 1e6 * hp["update_s"] / args.steps,
                                  "in_match_reduce": 1e6 * hp["match_reduce_s"] / args.steps},
+            "with_map_insert": with_insert,
         }
         cb, E, x_o = (None, None, None)
         if world == 1 and not args.no_cpu_baseline:
