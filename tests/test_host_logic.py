@@ -150,3 +150,30 @@ def test_bench_cli_contract():
             if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h")):
                 prod += open(os.path.join(dp, f)).read()
     assert "oracle_py" not in prod and "rl_octree" not in prod and "liboracle" not in prod
+
+
+def test_pcd_and_imu_csv_round_trip(tmp_path):
+    """Replay harness formats: PCD ascii / binary with each per-point time field, IMU CSV."""
+    from fast_limo_amd import replay
+    rs = np.random.RandomState(0)
+    xyz = rs.uniform(-5, 5, (257, 3)).astype(np.float32)
+    inten = rs.uniform(0, 255, 257).astype(np.float32)
+    for field, vals in (("time", rs.uniform(0, 0.1, 257).astype(np.float32)), ("t", rs.randint(0, 10**8, 257).astype(np.uint32)),
+                        ("timestamp", 1.7e9 + rs.uniform(0, 0.1, 257))):
+        for binary in (True, False):
+            f = str(tmp_path / f"s_{field}_{int(binary)}.pcd")
+            replay.write_pcd(f, xyz, inten, field, vals, binary=binary)
+            p = replay.read_pcd(f)
+            assert p.dtype.itemsize == 32 and p.shape[0] == 257
+            np.testing.assert_array_equal(np.stack([p["x"], p["y"], p["z"]], 1), xyz)
+            np.testing.assert_array_equal(p["intensity"], inten)
+            raw = p.view(np.uint8).reshape(-1, 32)
+            width = {"time": 4, "t": 4, "timestamp": 8}[field]
+            got = raw[:, 24:24 + width].copy().view({"time": np.float32, "t": np.uint32, "timestamp": np.float64}[field]).ravel()
+            np.testing.assert_array_equal(got, vals)
+    st = np.arange(50) * 0.01
+    w = rs.normal(0, 0.1, (50, 3)).astype(np.float32); a = rs.normal(0, 1, (50, 3)).astype(np.float32)
+    f = str(tmp_path / "imu.csv")
+    replay.write_imu_csv(f, st, w, a)
+    st2, w2, a2 = replay.read_imu_csv(f)
+    np.testing.assert_allclose(st2, st, atol=1e-9); np.testing.assert_array_equal(w2, w); np.testing.assert_array_equal(a2, a)
