@@ -57,7 +57,7 @@ HIP_SYMBOLS = [
     "flimo_match_reduce", "flimo_match_fetch", "flimo_match_fetch_H",
     "flimo_scan_to_world", "flimo_map_add_scan",
     "flimo_set_timing", "flimo_set_timing_stride", "flimo_pass_count", "flimo_set_debug_records", "flimo_set_lanes_per_query", "flimo_last_kernel_ms",
-    "flimo_last_candidates_per_query", "flimo_last_widen_count", "flimo_timing_totals", "flimo_insert_rule_replay",
+    "flimo_last_candidates_per_query", "flimo_last_widen_count", "flimo_timing_totals", "flimo_insert_rule_replay", "flimo_plane_fit5_host", "flimo_plane_eval5_host",
 ]
 
 _hip = None

@@ -17,6 +17,7 @@
 #include "../../../include/flimo_c.h"
 #include "flimo_types.h"
 #include "flimo_kernels.h"
+#include "flimo_math.h"
 #include "flimo_insert.h"
 #include "flimo_gbook.h"
 
@@ -977,6 +978,22 @@ extern "C" int flimo_map_add_scan(flimo_ctx* c, const double x26[26], double sta
   int rc = flimo_scan_to_world(c, x26, w.data(), c->scan_n);
   if (rc) return rc;
   return flimo_map_add(c, w.data(), c->scan_n, 12, stamp);
+}
+
+// ---- host-side evaluation of the SAME plane routines the fit kernel runs (flimo_math.h is __host__ __device__):
+//      backs the fast_limo::Plane object of the host C++ mirror; not used on the hot path -----------------------
+extern "C" void flimo_plane_fit5_host(const float xyz[15], float n_out[4]) {
+  float px[5], py[5], pz[5];
+  for (int j = 0; j < 5; j++) { px[j] = xyz[3 * j]; py[j] = xyz[3 * j + 1]; pz[j] = xyz[3 * j + 2]; }
+  float n[4];
+  flimo::plane_fit5(px, py, pz, n);
+  for (int i = 0; i < 4; i++) n_out[i] = n[i];
+}
+extern "C" int flimo_plane_eval5_host(const float n_in[4], const float xyz[15], float threshold) {
+  float px[5], py[5], pz[5], n[4];
+  for (int j = 0; j < 5; j++) { px[j] = xyz[3 * j]; py[j] = xyz[3 * j + 1]; pz[j] = xyz[3 * j + 2]; }
+  for (int i = 0; i < 4; i++) n[i] = n_in[i];
+  return flimo::plane_eval5(n, px, py, pz, threshold) ? 1 : 0;
 }
 
 // ---- host-only replay of the reference's insert rule (no GPU needed) --------------------------

@@ -5,6 +5,7 @@
 #include <memory>
 #include "../../../include/flimo_localizer_c.h"
 #include "fast_limo/Modules/Localizer.hpp"
+#include "fast_limo/Objects/Plane.hpp"
 #include "flimo_ikfom.hpp"
 
 using namespace fast_limo;
@@ -111,6 +112,25 @@ int flimo_loc_update_pointcloud_points(flimo_loc* L, const void* pts32, size_t n
   if (n) std::memcpy(static_cast<void*>(&pc->points[0]), pts32, n * sizeof(PointType));
   L->loc->updatePointCloud(pc, stamp);
   return L->loc->last_status();
+}
+// fast_limo::Plane / Match object API (reference Objects/Plane.cpp:23-31, Match.cpp:23-28) for tests
+int flimo_host_plane(const float* xyz, const float* sqd, int n, int num_match_points, double max_dist_plane,
+                     double plane_threshold, const float p_global[3], float n_out[4], float* dist_out) {
+  Config::iKFoM::Mapping cfg;
+  cfg.NUM_MATCH_POINTS = num_match_points;
+  cfg.MAX_DIST_PLANE = max_dist_plane;
+  cfg.PLANE_THRESHOLD = plane_threshold;
+  MapPoints pts;
+  std::vector<float> d;
+  for (int i = 0; i < n; i++) { pts.push_back(pcl::PointXYZ(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2])); d.push_back(sqd[i]); }
+  Plane pl(pts, d, &cfg);
+  const Eigen::Vector4f nv = pl.get_normal();
+  for (int i = 0; i < 4; i++) n_out[i] = pl.good_fit() ? nv(i) : 0.f;
+  if (pl.good_fit() && p_global && dist_out) {
+    Match m(Eigen::Vector3f(p_global[0], p_global[1], p_global[2]), Eigen::Vector3f(0.f, 0.f, 0.f), pl);
+    *dist_out = m.dist;
+  }
+  return pl.good_fit() ? 1 : 0;
 }
 int flimo_loc_map_add(flimo_loc* L, const float* xyz, size_t n, double stamp) {
   if (!L) return FLIMO_ERR_INVALID;

@@ -243,12 +243,10 @@ Matches Mapper::match(State s, pcl::PointCloud<PointType>::Ptr& pc) {   // Mappe
     flimo_match_fetch(ctx_, recs.data(), n, &n);
     for (size_t i = 0; i < n; i++) {
       if (recs[i].valid == 0.f) continue;
-      Match m;
-      m.good_fit = true;
-      m.dist = -recs[i].h;
-      m.n_ABCD = Eigen::Vector4f(recs[i].n[0], recs[i].n[1], recs[i].n[2], recs[i].n[3]);
-      m.p_global = Eigen::Vector3f(recs[i].p_global[0], recs[i].p_global[1], recs[i].p_global[2]);
-      m.p_local = Eigen::Vector3f(pc->points[i].x, pc->points[i].y, pc->points[i].z);
+      const Plane plane(Eigen::Vector4f(recs[i].n[0], recs[i].n[1], recs[i].n[2], recs[i].n[3]), true, &config);
+      Match m(Eigen::Vector3f(recs[i].p_global[0], recs[i].p_global[1], recs[i].p_global[2]),
+              Eigen::Vector3f(pc->points[i].x, pc->points[i].y, pc->points[i].z), plane);
+      m.dist = -recs[i].h;       // the kernel's own value (identical expression, Match.cpp:27)
       chosen.push_back(m);
     }
   }

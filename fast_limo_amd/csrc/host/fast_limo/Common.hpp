@@ -91,6 +91,7 @@ enum class SensorType { OUSTER, VELODYNE, HESAI, LIVOX, UNKNOWN };
 class Localizer;
 class Mapper;
 class State;
+class Plane;
 class Match;
 struct Config;
 

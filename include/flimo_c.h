@@ -163,6 +163,12 @@ double flimo_last_candidates_per_query(const flimo_ctx* ctx);
 /* ---- diagnostics without a GPU ----
  * Replays the map's insert rule (Octree::initialize / update, Objects/Octree.hpp:282-432) over a
  * sequence of batches of packed NaN-free points: keep[i] = 1 if point i is stored.  Host only. */
+/* Host-side evaluation of the plane routines of the fit kernel (same source, compiled for the host): Plane::estimate_plane
+ * (Objects/Plane.cpp:80-105) for exactly 5 points (xyz packed) and Plane::plane_eval (:107-114).  They back the
+ * fast_limo::Plane object of the host C++ mirror; the registration path never calls them. */
+void flimo_plane_fit5_host(const float xyz[15], float n_out[4]);
+int  flimo_plane_eval5_host(const float n[4], const float xyz[15], float threshold);
+
 int flimo_insert_rule_replay(float min_extent, int downsample, const float* xyz, const size_t* batch_sizes,
                              size_t n_batches, unsigned char* keep, size_t* stored);
 

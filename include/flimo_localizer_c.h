@@ -72,6 +72,10 @@ void   flimo_loc_host_profile(flimo_loc* L, double out[4], int reset);
 /* benchmark step: restore the prior (x26, P) and re-register the resident raw scan
  * (GPU deskew + iterated update) */
 int    flimo_loc_register_resident(flimo_loc* L, const double x26_prior[26], const double P_prior[529]);
+/* fast_limo::Plane + Match object API in isolation (Plane.cpp:23-31, Match.cpp:23-28): returns good_fit(), the normal
+ * (zeros when not a plane) and Match(p_global, ., plane).dist -- for unit tests */
+int    flimo_host_plane(const float* xyz, const float* sqd, int n, int num_match_points, double max_dist_plane,
+                        double plane_threshold, const float p_global[3], float n_out[4], float* dist_out);
 /* IESKF algebra in isolation with a fixed measurement (H [M][12], h [M]) -- for unit tests */
 int    flimo_eskf_update_fixed(double x26[26], double P[529], const double* H, const double* h, int M, int max_iters,
                                const double limits[23], double R, double D, int* n_passes);

@@ -177,3 +177,41 @@ def test_pcd_and_imu_csv_round_trip(tmp_path):
     replay.write_imu_csv(f, st, w, a)
     st2, w2, a2 = replay.read_imu_csv(f)
     np.testing.assert_allclose(st2, st, atol=1e-9); np.testing.assert_array_equal(w2, w); np.testing.assert_array_equal(a2, a)
+
+
+def test_host_plane_object_equals_oracle(built, oracle):
+    """fast_limo::Plane / Match of the host C++ mirror (the object API of reference Objects/Plane.hpp, Match.hpp) evaluate
+    the fit kernel's own routines on the host: normals, gates and Match::dist must equal the oracle's bit for bit."""
+    import ctypes as C
+    from fast_limo_amd import api
+    L = api.load_host()
+    f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+    L.flimo_host_plane.restype = C.c_int
+    L.flimo_host_plane.argtypes = [f32p, f32p, C.c_int, C.c_int, C.c_double, C.c_double, f32p, f32p, C.POINTER(C.c_float)]
+    rs = np.random.RandomState(8)
+    n_good = 0
+    for trial in range(400):
+        nrm = rs.normal(size=3); nrm /= np.linalg.norm(nrm)
+        base = rs.uniform(-20, 20, 3)
+        u = np.cross(nrm, [1, 0, 0]); u /= np.linalg.norm(u); v = np.cross(nrm, u)
+        spread = rs.choice([0.2, 0.6, 1.5])
+        noise = rs.choice([0.0, 0.005, 0.08])
+        pts = (base + rs.uniform(-spread, spread, (5, 1)) * u + rs.uniform(-spread, spread, (5, 1)) * v
+               + rs.normal(0, noise, (5, 1)) * nrm).astype(np.float32)
+        q = (base + rs.normal(0, 0.05, 3)).astype(np.float32)
+        sqd = np.sort(((pts - q) ** 2).sum(1).astype(np.float32))
+        n_o, ok_o = oracle.plane_fit(pts, sqd)
+        n_h = np.zeros(4, np.float32); dist = C.c_float(0.0)
+        ok_h = L.flimo_host_plane(pts, sqd, 5, 5, 2.0, 0.05, q, n_h, C.byref(dist))
+        assert bool(ok_h) == bool(ok_o), trial
+        if ok_o:
+            n_good += 1
+            np.testing.assert_array_equal(n_h, n_o)
+            expect = np.float32(np.float32(np.float32(np.float32(n_o[0] * q[0]) + np.float32(n_o[1] * q[1])) + np.float32(n_o[2] * q[2])) + n_o[3])
+            assert dist.value == expect
+    assert 100 < n_good < 400                     # both outcomes of the gates were exercised
+    # fewer than NUM_MATCH_POINTS neighbours / 5th squared distance beyond MAX_DIST_PLANE: not a plane
+    n_h = np.zeros(4, np.float32)
+    assert L.flimo_host_plane(pts[:4].copy(), sqd[:4].copy(), 4, 5, 2.0, 0.05, q, n_h, None) == 0
+    far = sqd.copy(); far[4] = 2.5
+    assert L.flimo_host_plane(pts, far, 5, 5, 2.0, 0.05, q, n_h, None) == 0
