@@ -57,7 +57,7 @@ HIP_SYMBOLS = [
     "flimo_match_reduce", "flimo_match_fetch", "flimo_match_fetch_H",
     "flimo_scan_to_world", "flimo_map_add_scan",
     "flimo_set_timing", "flimo_set_timing_stride", "flimo_pass_count", "flimo_set_debug_records", "flimo_set_lanes_per_query", "flimo_last_kernel_ms",
-    "flimo_last_candidates_per_query", "flimo_last_widen_count", "flimo_timing_totals", "flimo_insert_rule_replay", "flimo_plane_fit5_host", "flimo_plane_eval5_host",
+    "flimo_last_candidates_per_query", "flimo_last_widen_count", "flimo_timing_totals", "flimo_insert_rule_replay", "flimo_plane_fit5_host", "flimo_plane_eval5_host", "flimo_calculate_H_host",
 ]
 
 _hip = None
@@ -117,6 +117,7 @@ def load_hip():
     L.flimo_timing_totals.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                       C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.c_int]
     L.flimo_insert_rule_replay.argtypes = [C.c_float, C.c_int, f32p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t)]
+    L.flimo_calculate_H_host.argtypes = [f64p, f32p, f32p, f32p, C.c_size_t, C.c_int, f64p, f64p]
     L.flimo_last_widen_count.restype = C.c_int
     L.flimo_last_widen_count.argtypes = [vp]
     L.flimo_last_candidates_per_query.restype = C.c_double

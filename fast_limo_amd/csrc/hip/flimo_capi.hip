@@ -996,6 +996,23 @@ extern "C" int flimo_plane_eval5_host(const float n_in[4], const float xyz[15], 
   return flimo::plane_eval5(n, px, py, pz, threshold) ? 1 : 0;
 }
 
+// Localizer::calculate_H (Localizer.cpp:537-577) on the host with the fit kernel's own row routine: H is M x 12
+// row-major float64 (the float32 row values, widened), h[i] = -dist[i].
+extern "C" int flimo_calculate_H_host(const double x26[26], const float* p_global, const float* n, const float* dist, size_t M,
+                                      int estimate_extrinsics, double* H, double* h) {
+  if (!x26 || (M && (!p_global || !n || !dist || !H || !h))) return FLIMO_ERR_INVALID;
+  PoseMats P;
+  pose_from_x26(x26, P);
+  for (size_t i = 0; i < M; i++) {
+    const float n4[4] = {n[4 * i], n[4 * i + 1], n[4 * i + 2], n[4 * i + 3]};
+    float row[12];
+    flimo::h_row(P, p_global[3 * i], p_global[3 * i + 1], p_global[3 * i + 2], n4, estimate_extrinsics, row);
+    for (int j = 0; j < 12; j++) H[i * 12 + j] = (double)row[j];
+    h[i] = (double)(-dist[i]);
+  }
+  return FLIMO_OK;
+}
+
 // ---- host-only replay of the reference's insert rule (no GPU needed) --------------------------
 extern "C" int flimo_insert_rule_replay(float min_extent, int downsample, const float* xyz, const size_t* batch_sizes,
                                         size_t n_batches, unsigned char* keep, size_t* stored) {

@@ -774,16 +774,10 @@ __global__ __launch_bounds__(FIT_THREADS) void fit_kernel(GridView G, const floa
       }
       if (valid) {
         const float dist = n4[0] * gx + n4[1] * gy + n4[2] * gz + n4[3];   // Match::Match (Plane.cpp:50-52)
-        float ix, iy, iz, lx, ly, lz;
-        xform4(P.RT_inv, gx, gy, gz, ix, iy, iz);       // p_imu    (Localizer.cpp:549)
-        xform4(P.TLI_inv, ix, iy, iz, lx, ly, lz);      // p_lidar  (Localizer.cpp:550)
-        float Cx, Cy, Cz, Dx, Dy, Dz, Bx, By, Bz, Ax, Ay, Az;
-        mul3(P.R_inv, n4[0], n4[1], n4[2], Cx, Cy, Cz); // C = R_inv * n
-        mul3(P.RLI_inv, Cx, Cy, Cz, Dx, Dy, Dz);        // I_R_L_inv * C
-        cross3(lx, ly, lz, Dx, Dy, Dz, Bx, By, Bz);     // B
-        cross3(ix, iy, iz, Cx, Cy, Cz, Ax, Ay, Az);     // A
-        v[0] = n4[0]; v[1] = n4[1]; v[2] = n4[2]; v[3] = Ax; v[4] = Ay; v[5] = Az;
-        if (mp.estimate_extrinsics) { v[6] = Bx; v[7] = By; v[8] = Bz; v[9] = Cx; v[10] = Cy; v[11] = Cz; }
+        float row[12];
+        h_row(P, gx, gy, gz, n4, mp.estimate_extrinsics, row);            // calculate_H (Localizer.cpp:546-572)
+#pragma unroll
+        for (int i = 0; i < 12; i++) v[i] = row[i];
         v[12] = -dist;
         v[13] = 1.f;
       }

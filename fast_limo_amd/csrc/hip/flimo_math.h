@@ -219,4 +219,22 @@ FLIMO_DEV bool plane_eval5(const float (&n)[4], const float (&px)[5], const floa
   return ok;
 }
 
+// One row of Localizer::calculate_H (Localizer.cpp:546-572) for a match with world point g and plane n:
+// v[0:3] = n, v[3:6] = p_imu x C, v[6:9] = p_lidar x (R_LI^-1 C), v[9:12] = C  (the last six only when the extrinsics
+// are estimated, else 0), with C = R^-1 n.  Shared by the fit kernel and the host-side Localizer::calculate_H.
+FLIMO_DEV void h_row(const PoseMats& P, float gx, float gy, float gz, const float (&n4)[4], int estimate_extrinsics,
+                     float (&v)[12]) {
+  float ix, iy, iz, lx, ly, lz;
+  xform4(P.RT_inv, gx, gy, gz, ix, iy, iz);       // p_imu    (Localizer.cpp:549)
+  xform4(P.TLI_inv, ix, iy, iz, lx, ly, lz);      // p_lidar  (Localizer.cpp:550)
+  float Cx, Cy, Cz, Dx, Dy, Dz, Bx, By, Bz, Ax, Ay, Az;
+  mul3(P.R_inv, n4[0], n4[1], n4[2], Cx, Cy, Cz); // C = R_inv * n
+  mul3(P.RLI_inv, Cx, Cy, Cz, Dx, Dy, Dz);        // I_R_L_inv * C
+  cross3(lx, ly, lz, Dx, Dy, Dz, Bx, By, Bz);     // B
+  cross3(ix, iy, iz, Cx, Cy, Cz, Ax, Ay, Az);     // A
+  v[0] = n4[0]; v[1] = n4[1]; v[2] = n4[2]; v[3] = Ax; v[4] = Ay; v[5] = Az;
+  if (estimate_extrinsics) { v[6] = Bx; v[7] = By; v[8] = Bz; v[9] = Cx; v[10] = Cy; v[11] = Cz; }
+  else { v[6] = v[7] = v[8] = v[9] = v[10] = v[11] = 0.f; }
+}
+
 }  // namespace flimo

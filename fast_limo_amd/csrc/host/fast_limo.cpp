@@ -463,6 +463,62 @@ void Localizer::propagateImu(const IMUmeas& imu) {                 // Localizer.
   last_propagate_time_ = imu.stamp;
 }
 
+// Localizer.cpp:917-949: the IMU samples between two stamps, oldest first (the reference hands out reverse iterators)
+bool Localizer::imuMeasFromTimeRange(double start_time, double end_time, std::vector<IMUmeas>& meas) {
+  meas.clear();
+  if (imu_buffer.empty() || imu_buffer.front().stamp < end_time) return false;
+  size_t it = 0, last = 0;
+  it++;
+  const size_t n = imu_buffer.size();
+  while (it != n && imu_buffer[it].stamp >= end_time) { last = it; it++; }
+  while (it != n && imu_buffer[it].stamp >= start_time) it++;
+  if (it == n) return false;
+  it++;
+  for (size_t k = it; k-- > last;) meas.push_back(imu_buffer[k]);         // reverse iteration it-1 ... last, as in the reference
+  imu_range_end_stamp_ = last > 0 ? imu_buffer[last - 1].stamp : imu_buffer[last].stamp;   // `end_imu_it->stamp`
+  return true;
+}
+
+void Localizer::propagateImu(double t1, double t2) {                 // Localizer.cpp:610-654
+  flimo_host::Mat<12, 12> Q = flimo_host::Mat<12, 12>::identity();
+  for (int i = 0; i < 3; i++) {
+    Q(i, i) = config.ikfom.cov_gyro; Q(3 + i, 3 + i) = config.ikfom.cov_acc;
+    Q(6 + i, 6 + i) = config.ikfom.cov_bias_gyro; Q(9 + i, 9 + i) = config.ikfom.cov_bias_acc;
+  }
+  std::vector<IMUmeas> meas;
+  if (!imuMeasFromTimeRange(t1, t2, meas)) { std::cout << "FAST_LIMO::propagateImu(): not enough IMU measurements\n"; return; }
+  mtx_ikfom.lock();
+  mtx_prop.lock();
+  for (const IMUmeas& imu : meas) {
+    flimo_host::InputIkfom in;
+    for (int i = 0; i < 3; i++) { in.acc(i, 0) = (double)imu.lin_accel(i); in.gyro(i, 0) = (double)imu.ang_vel(i); }
+    ikfom_->predict(imu.dt, Q, in);
+    propagated_buffer.push_front(State(ikfom_->get_x(), imu.stamp, imu.lin_accel, imu.ang_vel));
+    if (propagated_buffer.size() > 2000) propagated_buffer.pop_back();
+  }
+  mtx_ikfom.unlock();
+  mtx_prop.unlock();
+  last_propagate_time_ = imu_range_end_stamp_;                       // Localizer.cpp:653
+}
+
+void Localizer::calculate_H(const flimo_host::StateIkfom& s, const Matches& ms, std::vector<double>& H, std::vector<double>& h) {
+  const size_t N = ((int)ms.size() > config.ikfom.mapping.MAX_NUM_MATCHES) ? (size_t)config.ikfom.mapping.MAX_NUM_MATCHES : ms.size();
+  H.assign(N * 12, 0.0);
+  h.assign(N, 0.0);
+  std::vector<float> pg(N * 3), nn(N * 4), dd(N);
+  for (size_t i = 0; i < N; i++) {
+    const Eigen::Vector3f g = ms[i].get_global_point();
+    const Eigen::Vector4f nv = ms[i].plane.get_normal();
+    for (int a = 0; a < 3; a++) pg[3 * i + a] = g(a);
+    for (int a = 0; a < 4; a++) nn[4 * i + a] = nv(a);
+    dd[i] = ms[i].dist;
+  }
+  double x26[26];
+  s.to_flat(x26);
+  flimo_calculate_H_host(x26, pg.data(), nn.data(), dd.data(), N, config.ikfom.estimate_extrinsics ? 1 : 0, H.data(), h.data());
+  if (config.debug) matches = ms;
+}
+
 // IMU calibration while the robot stands still (Localizer.cpp:411-493): average gyro / accel for
 // imu_calib_time_, then gravity-align the attitude (Quaternionf::FromTwoVectors), derive the biases and
 // seed the filter state.

@@ -45,6 +45,10 @@ class fast_limo::Localizer {
   void set_sensor_type(uint8_t type);
   fast_limo::SensorType get_sensor_type();
   void propagateImu(const IMUmeas& imu);
+  void propagateImu(double t1, double t2);                 // Localizer.cpp:610-654 (unused by the reference's own callers)
+  // iKFoM measurement model (Localizer.cpp:537-577).  H is N x 12 row-major, N = min(matches, MAX_NUM_MATCHES); with
+  // FLIMO_USE_EIGEN_PCL map it onto an Eigen::MatrixXd.  The registration path builds the same rows on the GPU.
+  void calculate_H(const flimo_host::StateIkfom& s, const Matches& matches, std::vector<double>& H, std::vector<double>& h);
 
   // --- MI355X additions -----------------------------------------------------------------------
   explicit Localizer(Mapper* map);      // non-singleton instances (one per GPU, SURVEY.md 8 e)
@@ -74,6 +78,7 @@ class fast_limo::Localizer {
   void calibrateStandStill(const IMUmeas& imu);
   bool deskewPointCloud(pcl::PointCloud<PointType>::Ptr& pc, double& start_time);
   bool propagatedFromTimeRange(double start_time, double end_time, States& frames);
+  bool imuMeasFromTimeRange(double start_time, double end_time, std::vector<IMUmeas>& meas);   // Localizer.cpp:917-949, oldest first
   bool isInRange(const PointType& p);
 
   Mapper* map_;
@@ -86,6 +91,7 @@ class fast_limo::Localizer {
   SensorType sensor;
   IMUmeas last_imu;
   std::deque<IMUmeas> imu_buffer;         // front = newest, capacity 2000
+  double imu_range_end_stamp_ = 0.0;      // stamp of the sample right after the last imuMeasFromTimeRange range
   std::deque<State> propagated_buffer;
   Config config;
   Eigen::Matrix3f imu_accel_sm_;

@@ -169,6 +169,12 @@ double flimo_last_candidates_per_query(const flimo_ctx* ctx);
 void flimo_plane_fit5_host(const float xyz[15], float n_out[4]);
 int  flimo_plane_eval5_host(const float n[4], const float xyz[15], float threshold);
 
+/* Localizer::calculate_H (Localizer.cpp:537-577) for M given matches on the host, with the fit kernel's own row routine:
+ * p_global [M][3], n [M][4] (plane.get_normal()), dist [M] (Match::dist); H [M][12] row-major, h [M] = -dist.  Backs the
+ * Localizer::calculate_H method of the host C++ mirror; the registration path computes the same rows on the GPU. */
+int flimo_calculate_H_host(const double x26[26], const float* p_global, const float* n, const float* dist, size_t M,
+                           int estimate_extrinsics, double* H, double* h);
+
 int flimo_insert_rule_replay(float min_extent, int downsample, const float* xyz, const size_t* batch_sizes,
                              size_t n_batches, unsigned char* keep, size_t* stored);
 

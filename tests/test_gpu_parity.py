@@ -444,3 +444,35 @@ def test_previous_pass_bound_prunes_exactly(built, oracle):
         np.testing.assert_array_equal(rb["H"][vg].astype(np.float64), H)
     finally:
         plain.close(); pruned.close()
+
+
+@pytest.mark.gpu
+def test_host_calculate_H_equals_gpu_rows(hip, scene, oracle):
+    """Localizer::calculate_H of the host mirror (flimo_calculate_H_host: the fit kernel's own row routine compiled for
+    the host) reproduces the rows the GPU built, bit for bit, from the matches the GPU reports -- with and without the
+    extrinsic columns."""
+    from fast_limo_amd import _lib
+    L = _lib.load_hip()
+    x0 = oracle.identity_x26()
+    x0[0:3] = [0.04, -0.02, 0.01]
+    x0[3:7] = [0.002, -0.001, 0.004, 1.0]; x0[3:7] /= np.linalg.norm(x0[3:7])
+    x0[7:11] = [0.0, 0.002, 0.001, 1.0]; x0[7:11] /= np.linalg.norm(x0[7:11])
+    x0[11:14] = [0.02, -0.01, 0.03]
+    hip.set_lanes_per_query(2)
+    hip.scan_set(scene["scan"])
+    for est in (1, 0):
+        hip.set_debug_records(True)
+        hip.match_reduce(x0, _lib.default_match_cfg(estimate_extrinsics=est, **CAPS))
+        g = hip.match_fetch()
+        hip.set_debug_records(False)
+        v = g["valid"] > 0
+        M = int(v.sum())
+        assert M > 3000
+        pg = np.ascontiguousarray(g["p_global"][v]); n = np.ascontiguousarray(g["n"][v]); dist = np.ascontiguousarray(-g["h"][v])
+        H = np.zeros((M, 12)); h = np.zeros(M)
+        assert L.flimo_calculate_H_host(x0, pg, n, dist, M, est, H, h) == 0
+        np.testing.assert_array_equal(H, g["H"][v].astype(np.float64))
+        np.testing.assert_array_equal(h, g["h"][v].astype(np.float64))
+        if not est:
+            assert not H[:, 6:].any()
+    hip.set_lanes_per_query(16)
