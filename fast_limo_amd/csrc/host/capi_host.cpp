@@ -113,6 +113,22 @@ int flimo_loc_update_pointcloud_points(flimo_loc* L, const void* pts32, size_t n
   L->loc->updatePointCloud(pc, stamp);
   return L->loc->last_status();
 }
+// fast_limo::State::update (State.cpp:76-119) on a flat state, for unit tests: p3 q4(xyzw) v3 g3 w3 a3 bg3 ba3
+void flimo_host_state_update(float s[25], double time, double t) {
+  State X;
+  X.p = Eigen::Vector3f(s[0], s[1], s[2]);
+  X.q = Eigen::Quaternionf(s[6], s[3], s[4], s[5]);
+  X.v = Eigen::Vector3f(s[7], s[8], s[9]);
+  X.g = Eigen::Vector3f(s[10], s[11], s[12]);
+  X.w = Eigen::Vector3f(s[13], s[14], s[15]);
+  X.a = Eigen::Vector3f(s[16], s[17], s[18]);
+  X.b.gyro = Eigen::Vector3f(s[19], s[20], s[21]);
+  X.b.accel = Eigen::Vector3f(s[22], s[23], s[24]);
+  X.time = time;
+  X.update(t);
+  for (int i = 0; i < 3; i++) { s[i] = X.p(i); s[7 + i] = X.v(i); }
+  s[3] = X.q.x(); s[4] = X.q.y(); s[5] = X.q.z(); s[6] = X.q.w();
+}
 // fast_limo::Plane / Match object API (reference Objects/Plane.cpp:23-31, Match.cpp:23-28) for tests
 int flimo_host_plane(const float* xyz, const float* sqd, int n, int num_match_points, double max_dist_plane,
                      double plane_threshold, const float p_global[3], float n_out[4], float* dist_out) {

@@ -165,6 +165,57 @@ State::State(const StateIkfom& s) : time(0.0) {                    // State.cpp:
 }
 State::State(const StateIkfom& s, double t) : State(s) { time = t; }
 State::State(const StateIkfom& s, double t, Eigen::Vector3f a_, Eigen::Vector3f w_) : State(s, t) { a = a_; w = w_; }
+State::State(Eigen::Matrix4f& T) : State() {                          // State.cpp:68-74
+  Eigen::Matrix3f R;
+  for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) R(i, j) = T(i, j); p(i) = T(i, 3); }
+  q = quat_from_R(R);
+}
+
+void State::operator+=(const State& s) {                              // State.cpp:121-134
+  q = quat_mul(q, s.q);
+  for (int i = 0; i < 3; i++) { p(i) += s.p(i); v(i) += s.v(i); w(i) += s.w(i); }
+  b.gyro = s.b.gyro; b.accel = s.b.accel;
+  qLI = s.qLI; pLI = s.pLI;
+  g = s.g;
+}
+
+void State::update(double t) {                                        // State.cpp:76-119, float32 in the reference's order
+  const double dt = t - time;
+  const Eigen::Vector3f wv(w(0) - b.gyro(0), w(1) - b.gyro(1), w(2) - b.gyro(2));
+  const float w_norm = std::sqrt(s3(wv(0) * wv(0), wv(1) * wv(1), wv(2) * wv(2)));
+  Eigen::Matrix3f R = Eigen::Matrix3f::Identity();
+  if (w_norm > 1.e-7) {
+    const float r0 = wv(0) / w_norm, r1 = wv(1) / w_norm, r2 = wv(2) / w_norm;
+    const float K[9] = {0.f, -r2, r1, r2, 0.f, -r0, -r1, r0, 0.f};
+    const float r_ang = (float)(w_norm * dt);
+    const float sn = std::sin(r_ang);
+    const float cs = (float)(1.0 - std::cos(r_ang));                 // double scalar, converted to the float expression type
+    float cK[9];
+    for (int i = 0; i < 9; i++) cK[i] = cs * K[i];
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) {
+        const float kk = s3(cK[i * 3 + 0] * K[0 * 3 + j], cK[i * 3 + 1] * K[1 * 3 + j], cK[i * 3 + 2] * K[2 * 3 + j]);
+        R(i, j) = R(i, j) + (sn * K[i * 3 + j] + kk);
+      }
+  }
+  // a0 = q._transformVector(a - ba) + g  (Eigen: v + w*uv + q.vec x uv with uv = 2 q.vec x v)
+  const Eigen::Vector3f av(a(0) - b.accel(0), a(1) - b.accel(1), a(2) - b.accel(2));
+  const Eigen::Vector3f qv(q.x(), q.y(), q.z());
+  Eigen::Vector3f uv = cross(qv, av);
+  for (int i = 0; i < 3; i++) uv(i) = uv(i) + uv(i);
+  const Eigen::Vector3f c2 = cross(qv, uv);
+  Eigen::Vector3f a0;
+  for (int i = 0; i < 3; i++) a0(i) = (av(i) + q.w() * uv(i) + c2(i)) + g(i);
+  q = quat_mul(q, quat_from_R(R));
+  // p += v*dt + 0.5*a0*dt*dt, v += a0*dt: Eigen converts every double scalar to the float expression type first
+  const float fdt = (float)dt;
+  for (int i = 0; i < 3; i++) {
+    const float t3 = fdt * (fdt * (0.5f * a0(i)));
+    p(i) = p(i) + (fdt * v(i) + t3);
+    v(i) = v(i) + fdt * a0(i);
+  }
+}
+
 Eigen::Matrix4f State::get_RT() const { return se3(q, p); }
 Eigen::Matrix4f State::get_RT_inv() const { return se3_inv(q, p); }
 Eigen::Matrix4f State::get_extr_RT() const { return se3(qLI, pLI); }

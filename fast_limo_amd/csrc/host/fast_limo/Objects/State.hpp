@@ -20,11 +20,14 @@ class fast_limo::State {
   explicit State(const flimo_host::StateIkfom& s);                       // State.cpp:38-55
   State(const flimo_host::StateIkfom& s, double t);
   State(const flimo_host::StateIkfom& s, double t, Eigen::Vector3f a, Eigen::Vector3f w);
+  explicit State(Eigen::Matrix4f& T);                                      // State.cpp:68-74
+  void operator+=(const State& s);                                         // State.cpp:121-134
+  // State::update(t) (State.cpp:76-119): host form for callers; the deskew kernel runs the same steps per point on the GPU
+  void update(double t);
 
   Eigen::Matrix4f get_RT() const;            // State.cpp:136-143
   Eigen::Matrix4f get_RT_inv() const;        // :145-153
   Eigen::Matrix4f get_extr_RT() const;       // :155-162
   Eigen::Matrix4f get_extr_RT_inv() const;   // :164-172
-  // State::update(t) (State.cpp:76-119) runs on the GPU inside the deskew kernel.
 };
 #endif

@@ -72,6 +72,8 @@ void   flimo_loc_host_profile(flimo_loc* L, double out[4], int reset);
 /* benchmark step: restore the prior (x26, P) and re-register the resident raw scan
  * (GPU deskew + iterated update) */
 int    flimo_loc_register_resident(flimo_loc* L, const double x26_prior[26], const double P_prior[529]);
+/* fast_limo::State::update (State.cpp:76-119) on a flat state p3 q4(xyzw) v3 g3 w3 a3 bg3 ba3 -- for unit tests */
+void   flimo_host_state_update(float s[25], double time, double t);
 /* fast_limo::Plane + Match object API in isolation (Plane.cpp:23-31, Match.cpp:23-28): returns good_fit(), the normal
  * (zeros when not a plane) and Match(p_global, ., plane).dist -- for unit tests */
 int    flimo_host_plane(const float* xyz, const float* sqd, int n, int num_match_points, double max_dist_plane,

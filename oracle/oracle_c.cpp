@@ -66,6 +66,23 @@ static void fill_rec(const MatchRec& m, oracle_match_rec* r) {
 
 extern "C" {
 
+void oracle_state_update(float s[25], double time, double t) {
+  State X;
+  X.p = V3f(s[0], s[1], s[2]);
+  X.q = Quatf(s[6], s[3], s[4], s[5]);
+  X.v = V3f(s[7], s[8], s[9]);
+  X.g = V3f(s[10], s[11], s[12]);
+  X.w = V3f(s[13], s[14], s[15]);
+  X.a = V3f(s[16], s[17], s[18]);
+  X.bgyro = V3f(s[19], s[20], s[21]);
+  X.baccel = V3f(s[22], s[23], s[24]);
+  X.time = time;
+  X.update(t);
+  s[0] = X.p.x; s[1] = X.p.y; s[2] = X.p.z;
+  s[3] = X.q.x; s[4] = X.q.y; s[5] = X.q.z; s[6] = X.q.w;
+  s[7] = X.v.x; s[8] = X.v.y; s[9] = X.v.z;
+}
+
 void* oracle_octree_create(float min_extent, int downsample) {
   Octree* t = new Octree();
   t->setMinExtent(min_extent);

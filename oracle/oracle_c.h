@@ -52,6 +52,10 @@ typedef struct oracle_match_rec {
   float sqd[5];
 } oracle_match_rec;
 
+/* State::update (Objects/State.cpp:76-119): s = p[3] q[4](xyzw) v[3] g[3] w[3] a[3] bg[3] ba[3] (25 floats), propagated
+ * from `time` to `t`; writes p, q, v back */
+void   oracle_state_update(float s[25], double time, double t);
+
 /* ---- octree (reference Objects/Octree.hpp) ---- */
 void*  oracle_octree_create(float min_extent, int downsample);
 void   oracle_octree_destroy(void* t);

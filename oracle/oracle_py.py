@@ -226,6 +226,16 @@ def voxel_grid(xyz, leaf):
     return out[:n]
 
 
+def state_update(s25, time, t):
+    """State::update on a flat state (p3 q4(xyzw) v3 g3 w3 a3 bg3 ba3); returns the updated copy."""
+    s = np.ascontiguousarray(s25, dtype=np.float32).copy()
+    L = lib()
+    L.oracle_state_update.argtypes = [np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS"), C.c_double, C.c_double]
+    L.oracle_state_update.restype = None
+    L.oracle_state_update(s, float(time), float(t))
+    return s
+
+
 def plane_fit(nbr, sqd, k=5, max_dist_plane=2.0, plane_threshold=0.05):
     nbr = _f32(nbr).reshape(-1, 3)
     sqd = _f32(sqd).reshape(-1)

@@ -215,3 +215,31 @@ def test_host_plane_object_equals_oracle(built, oracle):
     assert L.flimo_host_plane(pts[:4].copy(), sqd[:4].copy(), 4, 5, 2.0, 0.05, q, n_h, None) == 0
     far = sqd.copy(); far[4] = 2.5
     assert L.flimo_host_plane(pts, far, 5, 5, 2.0, 0.05, q, n_h, None) == 0
+
+
+def test_host_state_update_equals_oracle(built, oracle):
+    """fast_limo::State::update of the host mirror (const-omega / const-accel propagation, State.cpp:76-119) against the
+    oracle restatement: bit-identical p, q, v over random states, including the |w| <= 1e-7 branch."""
+    import ctypes as C
+    from fast_limo_amd import api
+    L = api.load_host()
+    L.flimo_host_state_update.restype = None
+    L.flimo_host_state_update.argtypes = [np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS"), C.c_double, C.c_double]
+    rs = np.random.RandomState(12)
+    for k in range(300):
+        s = np.zeros(25, np.float32)
+        s[0:3] = rs.uniform(-50, 50, 3)
+        q = rs.normal(size=4); s[3:7] = q / np.linalg.norm(q)
+        s[7:10] = rs.uniform(-15, 15, 3)
+        s[10:13] = [0, 0, -9.809]
+        s[13:16] = rs.uniform(-2, 2, 3) if k % 7 else 0.0
+        s[16:19] = rs.uniform(-12, 12, 3)
+        s[19:22] = rs.normal(0, 0.01, 3); s[22:25] = rs.normal(0, 0.05, 3)
+        if k % 7 == 0:
+            s[19:22] = 0.0
+        t0 = rs.uniform(0, 100); t1 = t0 + rs.uniform(1e-4, 0.02)
+        a = s.copy()
+        L.flimo_host_state_update(a, t0, t1)
+        b = oracle.state_update(s, t0, t1)
+        np.testing.assert_array_equal(a, b, err_msg=str(k))
+        assert not np.array_equal(a[0:3], s[0:3])
