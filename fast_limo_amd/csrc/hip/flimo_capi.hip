@@ -65,6 +65,7 @@ struct flimo_ctx {
   float4* d_scan_world = nullptr;
   double* d_scan_t = nullptr;
   size_t scan_n = 0, scan_cap = 0, raw_n = 0;
+  size_t sorted_n = 0;             // points in d_scan_sorted: scan_n, or the MAX_NUM_PC2MATCH prefix once a pass asked for it
   void* d_frames = nullptr;
   size_t frames_cap = 0;
   void* h_frames[2] = {nullptr, nullptr};   // pinned staging of the IMU frames, alternating: the deskew call does not wait
@@ -553,7 +554,7 @@ static int ensure_scan(flimo_ctx* c, size_t n) {
   (void)hipFree(c->d_scan); (void)hipFree(c->d_scan_raw); (void)hipFree(c->d_scan_world); (void)hipFree(c->d_scan_t);
   c->d_scan = a; c->d_scan_raw = b; c->d_scan_world = w; c->d_scan_t = t;
   c->scan_cap = cap;
-  c->scan_n = 0; c->raw_n = 0; c->prev.valid = 0;
+  c->scan_n = 0; c->sorted_n = 0; c->raw_n = 0; c->prev.valid = 0;
   return FLIMO_OK;
 }
 
@@ -595,7 +596,7 @@ extern "C" int flimo_scan_set(flimo_ctx* c, const float* xyz, size_t n, size_t s
     HIPCHK(c, sort_scan(c->stream, c->d_scan, n, c->d_scan_sorted, c->scratch));
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
-  c->scan_n = n; c->prev.valid = 0;
+  c->scan_n = n; c->sorted_n = n; c->prev.valid = 0;
   return FLIMO_OK;
 }
 
@@ -631,7 +632,7 @@ extern "C" int flimo_scan_voxel_filter(flimo_ctx* c, float leaf, size_t* n_out) 
   HIPCHK(c, voxel_grid(c->stream, c->d_scan, c->scan_n, leaf, c->d_scan_world, &m, &pass, c->scratch));
   if (!pass) {
     std::swap(c->d_scan, c->d_scan_world);
-    c->scan_n = m; c->prev.valid = 0;
+    c->scan_n = m; c->sorted_n = m; c->prev.valid = 0;
   }
   if (c->scan_n) HIPCHK(c, sort_scan(c->stream, c->d_scan, c->scan_n, c->d_scan_sorted, c->scratch));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -666,7 +667,7 @@ extern "C" int flimo_deskew_resident(flimo_ctx* c, const flimo_frame* frames, si
   static_assert(sizeof(flimo_frame) == 112, "flimo_frame layout");
   if (dev_frame_size() != sizeof(flimo_frame)) return fail(c, FLIMO_ERR_INVALID, "frame layout mismatch");
   const size_t n = c->raw_n;
-  if (n == 0) { c->scan_n = 0; c->prev.valid = 0; return FLIMO_OK; }
+  if (n == 0) { c->scan_n = 0; c->sorted_n = 0; c->prev.valid = 0; return FLIMO_OK; }
   // frames + the two 4x4 matrices go through one pinned staging copy
   const size_t fbytes = nf * sizeof(flimo_frame);
   const size_t total = fbytes + 32 * sizeof(float);
@@ -704,7 +705,7 @@ extern "C" int flimo_deskew_resident(flimo_ctx* c, const flimo_frame* frames, si
                 (const float*)((const char*)c->d_frames + fbytes), c->d_scan_sorted, c->d_scan);
   HIPCHK(c, hipGetLastError());
   c->async_deskews++;
-  c->scan_n = n; c->prev.valid = 0;
+  c->scan_n = n; c->sorted_n = n; c->prev.valid = 0;
   return FLIMO_OK;
 }
 
@@ -788,8 +789,15 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   mp.n_queries = (int)nq;
   mp.max_ring = gate_rings(c, cfg->MAX_DIST_PLANE);
 
-  const int n_all = (int)c->scan_n;                   // every resident point is searched; points beyond the
-                                                      // MAX_NUM_PC2MATCH prefix are masked by original index
+  // Only the first MAX_NUM_PC2MATCH points (pc2match order) take part (Mapper.cpp:63-69): when that is a strict prefix,
+  // the Morton-sorted query set is rebuilt once per scan from that prefix alone.
+  if (nq < c->sorted_n || (c->sorted_n < c->scan_n && nq > c->sorted_n)) {
+    const size_t want = nq;
+    HIPCHK(c, sort_scan(c->stream, c->d_scan, want, c->d_scan_sorted, c->scratch));
+    c->sorted_n = want;
+    c->prev.valid = 0;
+  }
+  const int n_all = (int)c->sorted_n;                 // resident query set (== nq, or the whole scan when no cap binds)
   const bool cap_binds = cfg->MAX_NUM_MATCHES >= 0 && (size_t)cfg->MAX_NUM_MATCHES < nq;
   const bool want_recs = c->debug_recs || cap_binds;
   if (c->debug_recs) HIPCHK(c, hipMemsetAsync(c->d_cand, 0, sizeof(unsigned long long), c->stream));
@@ -813,9 +821,15 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   // fit + reductions; the last block writes the 16x16 accumulator to mapped host memory, publishes the
   // pass number and re-arms the ticket and the worklist counter
   const unsigned long long seq = ++c->pass_seq;
-  launch_fit(c->stream, c->grid, c->d_scan_sorted, n_all, c->d_nbr, P, mp, c->d_fit_partials, want_recs ? c->d_recs : nullptr,
-             c->debug_recs ? c->d_dbg : nullptr, cap_binds ? c->d_out256 : c->d_out256_host, c->d_ticket, c->d_wl_count, seq);
-  if (cap_binds) {
+  // MAX_NUM_MATCHES path: the fit kernel only writes the records (no reduction), one fused kernel ranks them in scan
+  // order, reduces the first MAX_NUM_MATCHES and publishes to slot 0
+  const bool fused_cap = cap_binds && !c->debug_recs;
+  launch_fit(c->stream, c->grid, c->d_scan_sorted, n_all, c->d_nbr, P, mp, fused_cap ? nullptr : c->d_fit_partials,
+             want_recs ? c->d_recs : nullptr, c->debug_recs ? c->d_dbg : nullptr, cap_binds ? c->d_out256 : c->d_out256_host,
+             c->d_ticket, c->d_wl_count, seq);
+  if (fused_cap) {
+    launch_capreduce(c->stream, c->d_recs, (int)nq, cfg->MAX_NUM_MATCHES, c->d_out256_host, c->d_wl_count, seq);
+  } else if (cap_binds) {
     launch_cap(c->stream, c->d_recs, (int)nq, cfg->MAX_NUM_MATCHES);
     launch_reduce(c->stream, c->d_recs, (int)nq, c->reduce_waves, c->d_partials, c->d_out256_host);
   }
@@ -823,10 +837,11 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   HIPCHK(c, hipGetLastError());
   const double tp1 = prof ? now_us() : 0.0;
   if (c->debug_recs) HIPCHK(c, hipMemcpyAsync(c->h_cand, c->d_cand, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-  if (!cap_binds && !c->debug_recs && tlev < 2) {
-    // low-latency completion: spin on the pass number every reduction group publishes to host memory
+  if (!c->debug_recs && tlev < 2) {
+    // low-latency completion: spin on the pass number every reduction group publishes to host memory (one slot on
+    // the MAX_NUM_MATCHES path)
     unsigned long long spins = 0;
-    for (int g = 0; g < FIT_GROUPS; g++) {
+    for (int g = 0; g < (cap_binds ? 1 : FIT_GROUPS); g++) {
       volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(c->h_out256 + (size_t)g * FIT_SLOT + 256);
       while (*flag != seq) {
         _mm_pause();
@@ -881,7 +896,8 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   *M = (int)llround(acc[c->mfma_idx[13][13]]);
   c->last_nq = (int)nq;
   c->last_P = P; c->last_mp = mp; c->last_n_all = n_all;
-  c->recs_valid = want_recs; c->dbg_valid = c->debug_recs;
+  c->recs_valid = want_recs && !fused_cap;      // the fused path leaves the records un-capped: a fetch re-materialises them
+  c->dbg_valid = c->debug_recs;
   return FLIMO_OK;
 }
 

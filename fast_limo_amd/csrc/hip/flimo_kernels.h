@@ -28,6 +28,8 @@ size_t wl_entry_size();   // bytes per worklist entry (query index, world positi
 void launch_knn(hipStream_t st, const GridView& G, const float* qxyz, int nq, int k, int max_ring, int32_t* idx,
                 float* sqd, int32_t* cnt);
 void launch_cap(hipStream_t st, Rec16* recs, int n, int cap);
+// MAX_NUM_MATCHES path in one launch: rank valid records in scan order, reduce the first `cap`, publish to slot 0 + pass number
+void launch_capreduce(hipStream_t st, const Rec16* recs, int n, int cap, double* out256, int* wl_count, unsigned long long seq);
 void launch_reduce(hipStream_t st, const Rec16* recs, int n, int nwaves, double* partials, double* out256);
 void launch_mfma_layout(hipStream_t st, double* raw256);
 // in/t are in the (Morton-)sorted order with the original index in in[k].w; writes the deskewed point

@@ -809,6 +809,7 @@ __global__ __launch_bounds__(FIT_THREADS) void fit_kernel(GridView G, const floa
     }
   }
   TRACE(1, 3);
+  if (partials == nullptr) return;      // records-only launch (MAX_NUM_MATCHES path): capreduce_kernel reduces the records
   // ---- block reduction: D += X^T X with X = the 64 rows of this wave, 4 rows per MFMA ----
   float* sr = s_rec[wave];
 #pragma unroll
@@ -1007,6 +1008,76 @@ __global__ __launch_bounds__(1024) void reduce_final_kernel(const double* __rest
   s[part][t] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (part == 0) out[t] = (s[0][t] + s[1][t]) + (s[2][t] + s[3][t]);
+}
+
+// ------------------------------------------------------------------------------------------
+// MAX_NUM_MATCHES path in ONE launch: rank the valid records in scan order (block-wide scan), reduce the first
+// `cap` of them with the f64 matrix core and publish sums + pass number to slot 0 of the (host-mapped) output.
+// One block: the cap only binds together with MAX_NUM_PC2MATCH-sized inputs (10^4 records, 640 KB).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void capreduce_kernel(const Rec16* __restrict__ recs, int n, int cap,
+                                                         double* __restrict__ out256, int* __restrict__ wl_count,
+                                                         unsigned long long seq) {
+  __shared__ int s_cnt[1024];
+  __shared__ float s_rec[16][16 * 65];
+  __shared__ double s_acc[16][256];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int per = (n + 1023) / 1024;
+  const int b = t * per, e = min(n, b + per);
+  const float* base = reinterpret_cast<const float*>(recs);
+  int c = 0;
+  for (int i = b; i < e; i++) c += (base[(size_t)i * 16 + 13] != 0.f) ? 1 : 0;
+  s_cnt[t] = c;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {              // inclusive scan (Hillis-Steele)
+    const int v = (t >= off) ? s_cnt[t - off] : 0;
+    __syncthreads();
+    s_cnt[t] += v;
+    __syncthreads();
+  }
+  int rank = s_cnt[t] - c;                                // valid records before this thread's chunk
+  double4_t acc = {0.0, 0.0, 0.0, 0.0};
+  const int col = lane & 15, sub4 = lane >> 4;
+  float* sr = s_rec[wave];
+  for (int k = 0; k < per; k++) {                         // `per` is block-uniform: every wave runs the same trip count
+    const int i = b + k;
+    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0;
+    if (i < e) {
+      const float4* rp = reinterpret_cast<const float4*>(&recs[i]);
+      const float4 q3 = rp[3];
+      if (q3.y != 0.f) {                                  // v[13]: valid
+        if (rank < cap) { r0 = rp[0]; r1 = rp[1]; r2 = rp[2]; r3 = q3; }
+        rank++;
+      }
+    }
+    const float v[16] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w};
+#pragma unroll
+    for (int cc = 0; cc < 16; cc++) sr[cc * 65 + lane] = v[cc];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+      const double a = (double)sr[col * 65 + 4 * q + sub4];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc, 0, 0, 0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  double* sa = s_acc[wave];
+  sa[lane * 4 + 0] = acc[0]; sa[lane * 4 + 1] = acc[1]; sa[lane * 4 + 2] = acc[2]; sa[lane * 4 + 3] = acc[3];
+  __syncthreads();
+  if (t < 256) {
+    double r = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) r += s_acc[w][t];        // fixed order
+    __hip_atomic_store(&out256[t], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (t == 0) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(out256 + 256), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    *wl_count = 0;                                        // ready for the next pass
+  }
 }
 
 // calibration of the MFMA operand/result layout: D = A*B with A[i][0]=1, A[i][1]=i, B[0][j]=j,
@@ -1272,6 +1343,10 @@ void launch_knn(hipStream_t st, const GridView& G, const float* qxyz, int nq, in
 
 void launch_cap(hipStream_t st, Rec16* recs, int n, int cap) {
   hipLaunchKernelGGL(cap_kernel, dim3(1), dim3(1024), 0, st, recs, n, cap);
+}
+
+void launch_capreduce(hipStream_t st, const Rec16* recs, int n, int cap, double* out256, int* wl_count, unsigned long long seq) {
+  hipLaunchKernelGGL(capreduce_kernel, dim3(1), dim3(1024), 0, st, recs, n, cap, out256, wl_count, seq);
 }
 
 void launch_reduce(hipStream_t st, const Rec16* recs, int n, int nwaves, double* partials, double* out256) {
