@@ -1050,6 +1050,7 @@ __global__ __launch_bounds__(1024) void capreduce_kernel(const Rec16* __restrict
         rank++;
       }
     }
+    if (__ballot(r3.y != 0.f) == 0ull) continue;           // no row of this wave is in: nothing to add (wave-uniform)
     const float v[16] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w};
 #pragma unroll
     for (int cc = 0; cc < 16; cc++) sr[cc * 65 + lane] = v[cc];
