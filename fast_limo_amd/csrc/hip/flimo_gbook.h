@@ -39,6 +39,8 @@ struct GBook {
   int* lists = nullptr;
   int* tmp = nullptr;
   size_t lists_cap = 0;
+  int* big_items = nullptr;      // item ids whose subtree build gets a whole block (at most batch / 2048 of them)
+  size_t big_cap = 0;
   int* counters = nullptr;       // [0] items, [1] list cursor, [2] overflow
   int last_items = 0;
 

@@ -33,6 +33,7 @@
 namespace flimo {
 
 static const int kBucket = 32;     // effective bucket size of the reference (Octree.hpp:155,178-180)
+static const int kBigItem = 2048;  // subtree builds with more points than this get a whole 1024-thread block
 
 __device__ __forceinline__ int octant_of(float px, float py, float pz, const float4 c) {   // Octree.hpp:269-275
   return (px > c.x ? 1 : 0) | (py > c.y ? 2 : 0) | (pz > c.z ? 4 : 0);
@@ -88,22 +89,39 @@ struct GbItem {            // one subtree build
   int seg;                 // start of its index segment in the scratch lists
 };
 
-__global__ __launch_bounds__(256) void gb_decide_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ perm, int n,
+// One thread per destination GROUP HEAD (the first sorted element of a run of equal keys): the group size comes from a
+// binary search for the end of the run, the decision is stored at the head's sorted position (dec_keep / dec_assign);
+// gb_apply_kernel hands it to every member.  No per-member loops: a scan entering fresh territory routes thousands of
+// points to one missing child.
+__device__ __forceinline__ int run_end(const uint32_t* __restrict__ keys, int i, int n, uint32_t key) {   // first j > i with keys[j] != key
+  int lo = i + 1, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (keys[mid] == key) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+__device__ __forceinline__ int run_begin(const uint32_t* __restrict__ keys, int i, uint32_t key) {        // first j <= i with keys[j] == key
+  int lo = 0, hi = i;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (keys[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void gb_decide_kernel(const uint32_t* __restrict__ keys, int n,
                                                         const float4* __restrict__ node_c, int* __restrict__ node_cnt,
-                                                        float min_half, int downsample, unsigned char* __restrict__ keep,
-                                                        int* __restrict__ assign /* per batch point: leaf or -1-item */,
-                                                        GbItem* __restrict__ items, int* __restrict__ counters /* [0] items, [1] seg cursor */,
-                                                        int* __restrict__ node_item) {
+                                                        float min_half, int downsample, uint32_t* __restrict__ dec_keep,
+                                                        int* __restrict__ dec_assign /* leaf, or -1-item */,
+                                                        GbItem* __restrict__ items, int* __restrict__ counters /* [0] items, [1] seg cursor, [3] big items */,
+                                                        int* __restrict__ node_item, int* __restrict__ big) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint32_t key = keys[i];
   if (i > 0 && keys[i - 1] == key) return;            // not a group head
-  int g = 1;
-  while (i + g < n && keys[i + g] == key) g++;
-  if (key == 0xffffffffu) {                                  // non-finite points: never stored
-    for (int j = 0; j < g; j++) { keep[perm[i + j]] = 0; assign[perm[i + j]] = -1; }
-    return;
-  }
+  const int g = run_end(keys, i, n, key) - i;
+  if (key == 0xffffffffu) { dec_keep[i] = 0u; dec_assign[i] = -1; return; }      // non-finite points: never stored
   const int node = (int)(key / 9u), slot = (int)(key % 9u);
   if (slot == 8) {
     const int cnt = node_cnt[node];
@@ -113,19 +131,33 @@ __global__ __launch_bounds__(256) void gb_decide_kernel(const uint32_t* __restri
       const int seg = atomicAdd(&counters[1], cnt + g);
       items[it] = GbItem{node, 8, i, g, cnt, seg};
       node_item[node] = it;
-      for (int j = 0; j < g; j++) { keep[perm[i + j]] = 1; assign[perm[i + j]] = -1 - it; }
+      if (cnt + g > kBigItem) big[atomicAdd(&counters[3], 1)] = it;
+      dec_keep[i] = 1u; dec_assign[i] = -1 - it;
     } else if (downsample && half <= 2 * min_half && cnt > kBucket / 8) {   // DROP (:399-401)
-      for (int j = 0; j < g; j++) { keep[perm[i + j]] = 0; assign[perm[i + j]] = node; }
+      dec_keep[i] = 0u; dec_assign[i] = node;
     } else {                                                             // APPEND (:403-404)
       node_cnt[node] = cnt + g;
-      for (int j = 0; j < g; j++) { keep[perm[i + j]] = 1; assign[perm[i + j]] = node; }
+      dec_keep[i] = 1u; dec_assign[i] = node;
     }
   } else {                                                               // CREATE (:418-426)
     const int it = atomicAdd(&counters[0], 1);
     const int seg = atomicAdd(&counters[1], g);
     items[it] = GbItem{node, slot, i, g, 0, seg};
-    for (int j = 0; j < g; j++) { keep[perm[i + j]] = 1; assign[perm[i + j]] = -1 - it; }
+    if (g > kBigItem) big[atomicAdd(&counters[3], 1)] = it;
+    dec_keep[i] = 1u; dec_assign[i] = -1 - it;
   }
+}
+
+// every sorted element copies its group's decision to its batch point
+__global__ __launch_bounds__(256) void gb_apply_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ perm, int n,
+                                                       const uint32_t* __restrict__ dec_keep, const int* __restrict__ dec_assign,
+                                                       unsigned char* __restrict__ keep, int* __restrict__ assign) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int h = run_begin(keys, i, keys[i]);
+  const uint32_t pt = perm[i];
+  keep[pt] = (unsigned char)dec_keep[h];
+  assign[pt] = dec_assign[h];
 }
 
 // ---- compact: append the kept batch points to the map in batch order ---------------------------
@@ -160,12 +192,16 @@ __global__ __launch_bounds__(256) void gb_gather_old_kernel(const int* __restric
   const int pos = atomicAdd(&cursor[it], 1);
   lists[items[it].seg + pos] = i;
 }
-__global__ __launch_bounds__(256) void gb_gather_new_kernel(const uint32_t* __restrict__ perm, const int* __restrict__ new_index,
-                                                            const GbItem* __restrict__ items, int n_items, int* __restrict__ lists) {
-  const int it = blockIdx.x * blockDim.x + threadIdx.x;
-  if (it >= n_items) return;
-  const GbItem I = items[it];
-  for (int j = 0; j < I.g_len; j++) lists[I.seg + I.n_old + j] = new_index[perm[I.g_begin + j]];
+__global__ __launch_bounds__(256) void gb_gather_new_kernel(const uint32_t* __restrict__ perm, const int* __restrict__ assign,
+                                                            const int* __restrict__ new_index, const GbItem* __restrict__ items, int n,
+                                                            int* __restrict__ lists) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;        // sorted position
+  if (i >= n) return;
+  const uint32_t pt = perm[i];
+  const int a = assign[pt];
+  if (a >= 0 || new_index[pt] < 0) return;                    // not a member of a build item (or dropped / non-finite)
+  const GbItem I = items[-1 - a];
+  lists[I.seg + I.n_old + (i - I.g_begin)] = new_index[pt];
 }
 
 // ---- build: createOctant (Octree.hpp:301-338), ONE WAVE per item ---------------------------------
@@ -174,7 +210,7 @@ __global__ __launch_bounds__(256) void gb_gather_new_kernel(const uint32_t* __re
 // partitioned through `tmp`, and lane 0 allocates the children with one atomic.
 constexpr int GB_STACK = 128;      // >= 7 * max depth + 1
 
-__global__ __launch_bounds__(256) void gb_build_kernel(const GbItem* __restrict__ items, int n_items, const float4* __restrict__ map_raw,
+__global__ __launch_bounds__(256) void gb_build_kernel(const GbItem* __restrict__ items, const int* __restrict__ n_items_dev, const float4* __restrict__ map_raw,
                                                        int* __restrict__ lists, int* __restrict__ tmp, float4* __restrict__ node_c,
                                                        int* __restrict__ node_child, int* __restrict__ node_cnt, int* __restrict__ node_n,
                                                        int node_cap, float min_half, int* __restrict__ pt_leaf, int* __restrict__ node_item,
@@ -182,9 +218,10 @@ __global__ __launch_bounds__(256) void gb_build_kernel(const GbItem* __restrict_
   __shared__ int s_node[4][GB_STACK], s_b[4][GB_STACK], s_e[4][GB_STACK];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int it = blockIdx.x * 4 + wave;
-  if (it >= n_items) return;
+  if (it >= *n_items_dev) return;             // the big-item kernel appends the small subtrees it cuts off
   const GbItem I = items[it];
   const int total = I.n_old + I.g_len;
+  if (total > kBigItem) return;               // gb_build_big_kernel
   int root_node;
   if (I.slot == 8) {
     root_node = I.node;                       // rebuilt in place (`delete octant; octant = newOctant`)
@@ -278,6 +315,134 @@ __global__ __launch_bounds__(256) void gb_build_kernel(const GbItem* __restrict_
   }
 }
 
+// ---- the same build for a BIG item (a scan entering fresh territory routes thousands of points to one missing
+//      child): one 1024-thread block per item, octant counts and partition slots through LDS atomics (the order of
+//      the points inside a leaf is irrelevant: leaves are sets) ----
+__global__ __launch_bounds__(1024) void gb_build_big_kernel(GbItem* __restrict__ items, int* __restrict__ n_items_dev, int items_cap,
+                                                            const int* __restrict__ big, int n_big,
+                                                            const float4* __restrict__ map_raw, int* __restrict__ lists,
+                                                            int* __restrict__ tmp, float4* __restrict__ node_c,
+                                                            int* __restrict__ node_child, int* __restrict__ node_cnt,
+                                                            int* __restrict__ node_n, int node_cap, float min_half,
+                                                            int* __restrict__ pt_leaf, int* __restrict__ node_item,
+                                                            int* __restrict__ overflow) {
+  __shared__ int s_node[GB_STACK], s_b[GB_STACK], s_e[GB_STACK];
+  __shared__ int s_hist[8], s_cur[8], s_base, s_root, s_fail;
+  if ((int)blockIdx.x >= n_big) return;
+  const int t = threadIdx.x, lane = t & 63;
+  const GbItem I = items[big[blockIdx.x]];
+  const int total = I.n_old + I.g_len;
+  if (t == 0) {
+    s_fail = 0;
+    int root_node;
+    if (I.slot == 8) {
+      root_node = I.node;
+      node_item[I.node] = -1;
+    } else {
+      root_node = atomicAdd(node_n, 1);
+      if (root_node >= node_cap) { atomicExch(overflow, 1); s_fail = 1; }
+      else {
+        const float4 pc = node_c[I.node];
+        const float f0 = (I.slot & 1) ? 0.5f : -0.5f, f1 = (I.slot & 2) ? 0.5f : -0.5f, f2 = (I.slot & 4) ? 0.5f : -0.5f;
+        node_c[root_node] = make_float4(pc.x + f0 * pc.w, pc.y + f1 * pc.w, pc.z + f2 * pc.w, pc.w * 0.5f);
+        node_child[(size_t)I.node * 8 + I.slot] = root_node;
+      }
+    }
+    s_root = root_node;
+    s_node[0] = root_node; s_b[0] = I.seg; s_e[0] = I.seg + total;
+  }
+  __threadfence_block();
+  __syncthreads();
+  if (s_fail) return;
+  int sp = 1;
+  while (sp > 0) {
+    sp--;
+    const int nd = s_node[sp], b = s_b[sp], e = s_e[sp];
+    __syncthreads();
+    const float4 c = node_c[nd];
+    const int cnt = e - b;
+    if (cnt > kBucket && c.w > 2 * min_half) {
+      if (t < 8) s_hist[t] = 0;
+      __syncthreads();
+      for (int j0 = b; j0 < e; j0 += 1024) {
+        const int j = j0 + t;
+        int oct = -1;
+        if (j < e) { const float4 p = map_raw[lists[j]]; oct = octant_of(p.x, p.y, p.z, c); }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const int w = __popcll(__ballot(oct == k));
+          if (lane == 0 && w) atomicAdd(&s_hist[k], w);
+        }
+      }
+      __syncthreads();
+      if (t == 0) {
+        int acc = b, nch = 0;
+        for (int k = 0; k < 8; k++) { s_cur[k] = acc; acc += s_hist[k]; nch += s_hist[k] > 0 ? 1 : 0; }
+        const int base = atomicAdd(node_n, nch);
+        if (base + nch > node_cap || sp + nch > GB_STACK) { atomicExch(overflow, 1); s_fail = 1; }
+        s_base = base;
+      }
+      __syncthreads();
+      if (s_fail) return;
+      int start[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) start[k] = s_cur[k];
+      __syncthreads();
+      for (int j0 = b; j0 < e; j0 += 1024) {
+        const int j = j0 + t;
+        int oct = -1, id = 0;
+        if (j < e) { id = lists[j]; const float4 p = map_raw[id]; oct = octant_of(p.x, p.y, p.z, c); }
+        int dest = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const unsigned long long m = __ballot(oct == k);
+          int wb = 0;
+          if (lane == 0 && m) wb = atomicAdd(&s_cur[k], __popcll(m));
+          wb = __shfl(wb, 0, 64);
+          if (oct == k) dest = wb + __popcll(m & ((1ull << lane) - 1ull));
+        }
+        if (j < e) tmp[dest] = id;
+      }
+      __threadfence_block();
+      __syncthreads();
+      for (int j = b + t; j < e; j += 1024) lists[j] = tmp[j];
+      if (t == 0) {
+        node_cnt[nd] = -1;
+        int ord = 0, cidx = 0;
+        for (int k = 0; k < 8; k++) {
+          const int h = s_hist[k];
+          const int ch = h > 0 ? s_base + cidx : -1;
+          node_child[(size_t)nd * 8 + k] = ch;
+          if (h > 0) {
+            cidx++;
+            const float f0 = (k & 1) ? 0.5f : -0.5f, f1 = (k & 2) ? 0.5f : -0.5f, f2 = (k & 4) ? 0.5f : -0.5f;
+            node_c[ch] = make_float4(c.x + f0 * c.w, c.y + f1 * c.w, c.z + f2 * c.w, c.w * 0.5f);
+            if (h > kBigItem) {                                   // still big: stays with this block
+              s_node[sp + ord] = ch; s_b[sp + ord] = start[k]; s_e[sp + ord] = start[k] + h;
+              ord++;
+            } else {                                              // small subtree: one wave of gb_build_kernel finishes it
+              const int slot = atomicAdd(n_items_dev, 1);
+              if (slot >= items_cap) { atomicExch(overflow, 1); s_fail = 1; }
+              else items[slot] = GbItem{ch, 8, 0, 0, h, start[k]};
+            }
+          }
+        }
+        s_base = ord;
+      }
+      __threadfence_block();
+      __syncthreads();
+      if (s_fail) return;
+      sp += s_base;
+      __syncthreads();
+    } else {
+      if (t == 0) node_cnt[nd] = cnt;
+      if (t < 8) node_child[(size_t)nd * 8 + t] = -1;
+      for (int j = b + t; j < e; j += 1024) pt_leaf[lists[j]] = nd;
+      __syncthreads();
+    }
+  }
+}
+
 // ---- host side ----------------------------------------------------------------------------------
 #define GBCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return e_; } while (0)
 
@@ -315,7 +480,7 @@ hipError_t GBook::reserve_nodes(hipStream_t st, size_t want) {
 void GBook::release() {
   (void)hipFree(node_c); (void)hipFree(node_child); (void)hipFree(node_cnt); (void)hipFree(node_item); (void)hipFree(pt_leaf);
   (void)hipFree(keep); (void)hipFree(assign); (void)hipFree(new_index); (void)hipFree(items); (void)hipFree(lists); (void)hipFree(tmp);
-  (void)hipFree(cursor); (void)hipFree(counters); (void)hipFree(flags); (void)hipFree(rank); (void)hipFree(node_n_dev);
+  (void)hipFree(cursor); (void)hipFree(counters); (void)hipFree(big_items); (void)hipFree(flags); (void)hipFree(rank); (void)hipFree(node_n_dev);
   *this = GBook();
 }
 
@@ -391,8 +556,11 @@ hipError_t GBook::update(hipStream_t st, const float4* batch, int m, const float
     GBCHK(grow(pt_leaf, pt_cap, (size_t)map_n + m + 1024, map_n, st));
     size_t c1 = batch_cap, c2 = batch_cap, c3 = batch_cap, c4 = batch_cap, c5 = batch_cap, c6 = batch_cap, c7 = batch_cap;
     GBCHK(grow(keep, c1, m, 0, st)); GBCHK(grow(assign, c2, m, 0, st)); GBCHK(grow(new_index, c3, m, 0, st));
-    GBCHK(grow(items, c4, m, 0, st)); GBCHK(grow(cursor, c5, m, 0, st)); GBCHK(grow(flags, c6, m, 0, st)); GBCHK(grow(rank, c7, m, 0, st));
+    // items: + room for the small subtrees the big-item kernel cuts off
+    GBCHK(grow(items, c4, (size_t)m + m / 16 + 64, 0, st));
+    GBCHK(grow(cursor, c5, m, 0, st)); GBCHK(grow(flags, c6, m, 0, st)); GBCHK(grow(rank, c7, m, 0, st));
     batch_cap = std::min(std::min(std::min(c1, c2), std::min(c3, c4)), std::min(std::min(c5, c6), c7));
+    GBCHK(grow(big_items, big_cap, (size_t)m / kBigItem + 16, 0, st));          // a batch of m points holds at most m / kBigItem big items
     size_t l1 = lists_cap, l2 = lists_cap;
     const size_t lw = (size_t)m * (kBucket + 1) + 1024;      // every group may pull in a full leaf
     GBCHK(grow(lists, l1, lw, 0, st)); GBCHK(grow(tmp, l2, lw, 0, st));
@@ -422,8 +590,10 @@ hipError_t GBook::update(hipStream_t st, const float4* batch, int m, const float
   }
   GBCHK(hipcub::DeviceRadixSort::SortPairs(S.cub_tmp, tmp_bytes, S.keys_in, S.keys_out, S.vals_in, S.vals_out, m, 0, 32, st));
   GBCHK(hipMemsetAsync(counters, 0, 4 * sizeof(int), st));
-  hipLaunchKernelGGL(gb_decide_kernel, dim3(blocks), dim3(256), 0, st, S.keys_out, S.vals_out, m, node_c, node_cnt, min_half,
-                     downsample ? 1 : 0, keep, assign, items, counters, node_item);
+  hipLaunchKernelGGL(gb_decide_kernel, dim3(blocks), dim3(256), 0, st, S.keys_out, m, node_c, node_cnt, min_half,
+                     downsample ? 1 : 0, flags /* dec_keep */, reinterpret_cast<int*>(rank) /* dec_assign */, items, counters, node_item, big_items);
+  hipLaunchKernelGGL(gb_apply_kernel, dim3(blocks), dim3(256), 0, st, S.keys_out, S.vals_out, m, flags, reinterpret_cast<const int*>(rank),
+                     keep, assign);
   hipLaunchKernelGGL(gb_flags_kernel, dim3(blocks), dim3(256), 0, st, keep, m, flags);
   GBCHK(hipcub::DeviceScan::ExclusiveSum(S.cub_tmp, scan_bytes, flags, rank, m, st));
   hipLaunchKernelGGL(gb_append_kernel, dim3(blocks), dim3(256), 0, st, batch, keep, rank, assign, m, map_n, map_raw, pt_leaf, new_index);
@@ -440,10 +610,18 @@ hipError_t GBook::update(hipStream_t st, const float4* batch, int m, const float
     GBCHK(hipMemsetAsync(cursor, 0, (size_t)n_items * sizeof(int), st));
     if (map_n > 0)
       hipLaunchKernelGGL(gb_gather_old_kernel, dim3((map_n + 255) / 256), dim3(256), 0, st, pt_leaf, map_n, node_item, items, cursor, lists);
-    hipLaunchKernelGGL(gb_gather_new_kernel, dim3((n_items + 255) / 256), dim3(256), 0, st, S.vals_out, new_index, items, n_items, lists);
+    hipLaunchKernelGGL(gb_gather_new_kernel, dim3(blocks), dim3(256), 0, st, S.vals_out, assign, new_index, items, m, lists);
     GBCHK(hipMemcpyAsync(node_n_dev, &node_n, sizeof(int), hipMemcpyHostToDevice, st));
     GBCHK(hipMemsetAsync(counters + 2, 0, sizeof(int), st));
-    hipLaunchKernelGGL(gb_build_kernel, dim3((n_items + 3) / 4), dim3(256), 0, st, items, n_items, map_raw, lists, tmp, node_c, node_child,
+    const int n_big = h_cnt[3];
+    const int items_cap = m + m / 16 + 64;
+    int bound = n_items;
+    if (n_big > 0) {
+      hipLaunchKernelGGL(gb_build_big_kernel, dim3(n_big), dim3(1024), 0, st, items, counters, items_cap, big_items, n_big, map_raw, lists,
+                         tmp, node_c, node_child, node_cnt, node_n_dev, (int)node_cap, min_half, pt_leaf, node_item, counters + 2);
+      bound = items_cap;                               // the final item count stays on the device (counters[0])
+    }
+    hipLaunchKernelGGL(gb_build_kernel, dim3((bound + 3) / 4), dim3(256), 0, st, items, counters, map_raw, lists, tmp, node_c, node_child,
                        node_cnt, node_n_dev, (int)node_cap, min_half, pt_leaf, node_item, counters + 2);
     int ovf = 0;
     GBCHK(hipMemcpyAsync(&node_n, node_n_dev, sizeof(int), hipMemcpyDeviceToHost, st));
