@@ -338,7 +338,7 @@ static int rebuild_grid(flimo_ctx* c) {
   if (ncells + 1 > c->cell_cap) {
     if (c->d_cell_start) (void)hipFree(c->d_cell_start);
     c->d_cell_start = nullptr;
-    size_t cap = ncells + 1 + ncells / 8;
+    size_t cap = ncells + 1 + ncells / 2;          // geometric growth: a map that keeps extending does not reallocate per scan
     HIPCHK(c, hipMalloc(&c->d_cell_start, cap * sizeof(uint32_t)));
     c->cell_cap = cap;
   }
@@ -349,7 +349,7 @@ static int rebuild_grid(flimo_ctx* c) {
     if (rt > c->row_cap) {
       if (c->d_row_table) (void)hipFree(c->d_row_table);
       c->d_row_table = nullptr;
-      const size_t cap = rt + rt / 8;
+      const size_t cap = rt + rt / 2;
       HIPCHK(c, hipMalloc(&c->d_row_table, cap * sizeof(uint32_t)));
       c->row_cap = cap;
     }
