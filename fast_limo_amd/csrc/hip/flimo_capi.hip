@@ -48,11 +48,11 @@ struct flimo_ctx {
   double map_last_time = -1.0;
   float bb[6] = {3.4e38f, 3.4e38f, 3.4e38f, -3.4e38f, -3.4e38f, -3.4e38f};   // bounding box of the stored points
   MapBuildScratch scratch;
-  InsertBook* book = nullptr;      // reference insert rule, host build of the FIRST batch (flimo_insert.h)
+  InsertBook* book = nullptr;      // host statement of the insert rule (flimo_insert.h): A/B checks and flimo_insert_rule_replay only
   GBook gbook;                     // the same tree on the device: every later batch is decided there
   float4* d_batch = nullptr;       // staging for host-supplied later batches
   size_t batch_cap = 0;
-  bool host_insert = false;        // FLIMO_HOST_INSERT=1: keep using the host book (A/B checks only)
+  bool host_insert = false;        // FLIMO_HOST_INSERT=1: first batch through the host book, then imported (A/B checks only)
   // scan
   float4* d_scan = nullptr;        // pc2match (body frame), caller order
   float4* d_scan_sorted = nullptr; // the same points in Morton order, w = original index
@@ -401,7 +401,11 @@ static int map_add_device(flimo_ctx* c, const float4* d_pts, size_t m, double st
     if (rc) return rc;
     if (c->map_cap != old_cap && c->d_map_sorted) { (void)hipFree(c->d_map_sorted); c->d_map_sorted = nullptr; }
     int kept = 0;
-    HIPCHK(c, c->gbook.update(c->stream, d_pts, (int)m, bb, c->d_map_raw, (int)c->map_n, &kept, c->scratch));
+    if (!c->gbook.active)        // first batch: Octree::initialize on the device
+      HIPCHK(c, c->gbook.init(c->stream, d_pts, (int)m, bb, c->d_map_raw, &kept, c->map_cfg.min_extent, c->map_cfg.downsample != 0,
+                              c->scratch));
+    else
+      HIPCHK(c, c->gbook.update(c->stream, d_pts, (int)m, bb, c->d_map_raw, (int)c->map_n, &kept, c->scratch));
     t2 = prof ? now() : 0.0;
     c->map_n += (size_t)kept;
     if (kept > 0) {
@@ -438,8 +442,8 @@ extern "C" int flimo_map_add(flimo_ctx* c, const float* xyz, size_t n, size_t st
   int rc = ensure_stage(c, n * sizeof(float4));
   if (rc) return rc;
   float4* st = (float4*)c->h_stage;
-  if (c->gbook.active) {
-    // later batches: Octree::update on the device (flimo_gbook.hip)
+  if (!c->host_insert) {
+    // Octree::initialize / Octree::update on the device (flimo_gbook.hip)
     const unsigned char* b = (const unsigned char*)xyz;
     for (size_t i = 0; i < n; i++) {
       const float* p = (const float*)(b + i * stride_bytes);
@@ -985,7 +989,7 @@ extern "C" int flimo_scan_to_world(flimo_ctx* c, const double x26[26], float* ou
 extern "C" int flimo_map_add_scan(flimo_ctx* c, const double x26[26], double stamp) {
   if (!c || !x26) return FLIMO_ERR_INVALID;
   if (c->scan_n == 0) return FLIMO_OK;
-  if (c->gbook.active) {           // resident path: transform, decide, append and re-index on the device
+  if (!c->host_insert) {           // resident path: transform, decide, append and re-index on the device
     int rc = flimo_scan_to_world(c, x26, nullptr, 0);
     if (rc) return rc;
     return map_add_device(c, c->d_scan_world, c->scan_n, stamp);

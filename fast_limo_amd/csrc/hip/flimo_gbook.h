@@ -47,6 +47,9 @@ struct GBook {
   // take over a tree built on the host for the first batch
   hipError_t import_host(hipStream_t st, const std::vector<float>& c4, const std::vector<int>& child, const std::vector<int>& cnt,
                          int root_id, const float4* map_raw, int map_n, float min_half, bool downsample);
+  // Octree::initialize for the first batch (m device points, NaNs ignored): stores every finite point in batch order
+  hipError_t init(hipStream_t st, const float4* batch, int m, const float bb[6], float4* map_raw, int* kept_out, float min_half,
+                  bool downsample, MapBuildScratch& S);
   // Octree::update for a batch of m device points (NaN points are ignored); bb = bounding box of the
   // finite points of the batch; appends the kept points to map_raw[map_n ...] and returns their count
   hipError_t update(hipStream_t st, const float4* batch, int m, const float bb[6], float4* map_raw, int map_n, int* kept_out,

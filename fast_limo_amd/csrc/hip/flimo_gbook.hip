@@ -509,6 +509,104 @@ hipError_t GBook::import_host(hipStream_t st, const std::vector<float>& c4, cons
   return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void gb_finite_kernel(const float4* __restrict__ pts, int n, unsigned char* __restrict__ keep,
+                                                        int* __restrict__ assign) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = pts[i];
+  keep[i] = (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) ? 1 : 0;     // Octree::processPoints (:243-244)
+  assign[i] = -1;
+}
+__global__ __launch_bounds__(256) void gb_iota_kernel(int* __restrict__ a, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] = i;
+}
+
+// Octree::initialize (Octree.hpp:282-298) on the device: the first batch is stored completely (finite points, batch
+// order); the root cube comes from its bounding box; the tree is ONE build item over all stored points.
+hipError_t GBook::init(hipStream_t st, const float4* batch, int m, const float bb[6], float4* map_raw, int* kept_out,
+                       float min_half_, bool downsample_, MapBuildScratch& S) {
+  *kept_out = 0;
+  active = false;
+  if (m <= 0) return hipSuccess;
+  min_half = min_half_;
+  downsample = downsample_;
+  node_n = 0;
+  GBCHK(reserve_nodes(st, (size_t)m + 4096));
+  GBCHK(grow(pt_leaf, pt_cap, (size_t)m + 1024, 0, st));
+  {
+    size_t c1 = batch_cap, c2 = batch_cap, c3 = batch_cap, c4 = batch_cap, c5 = batch_cap, c6 = batch_cap, c7 = batch_cap;
+    GBCHK(grow(keep, c1, m, 0, st)); GBCHK(grow(assign, c2, m, 0, st)); GBCHK(grow(new_index, c3, m, 0, st));
+    GBCHK(grow(items, c4, (size_t)m + m / 16 + 64, 0, st));
+    GBCHK(grow(cursor, c5, m, 0, st)); GBCHK(grow(flags, c6, m, 0, st)); GBCHK(grow(rank, c7, m, 0, st));
+    batch_cap = std::min(std::min(std::min(c1, c2), std::min(c3, c4)), std::min(std::min(c5, c6), c7));
+    GBCHK(grow(big_items, big_cap, (size_t)m / kBigItem + 16, 0, st));
+    size_t l1 = lists_cap, l2 = lists_cap;
+    GBCHK(grow(lists, l1, (size_t)m + 1024, 0, st)); GBCHK(grow(tmp, l2, (size_t)m + 1024, 0, st));
+    lists_cap = std::min(l1, l2);
+  }
+  if (!node_n_dev) GBCHK(hipMalloc(&node_n_dev, sizeof(int)));
+  if (!counters) GBCHK(hipMalloc(&counters, 4 * sizeof(int)));
+  const int blocks = (m + 255) / 256;
+  hipLaunchKernelGGL(gb_finite_kernel, dim3(blocks), dim3(256), 0, st, batch, m, keep, assign);
+  hipLaunchKernelGGL(gb_flags_kernel, dim3(blocks), dim3(256), 0, st, keep, m, flags);
+  size_t scan_bytes = 0;
+  GBCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, flags, rank, m, st));
+  if (scan_bytes > S.cub_tmp_bytes) {
+    GBCHK(hipStreamSynchronize(st));
+    if (S.cub_tmp) (void)hipFree(S.cub_tmp);
+    GBCHK(hipMalloc(&S.cub_tmp, scan_bytes + 1024));
+    S.cub_tmp_bytes = scan_bytes + 1024;
+  }
+  GBCHK(hipcub::DeviceScan::ExclusiveSum(S.cub_tmp, scan_bytes, flags, rank, m, st));
+  hipLaunchKernelGGL(gb_append_kernel, dim3(blocks), dim3(256), 0, st, batch, keep, rank, assign, m, 0, map_raw, pt_leaf, new_index);
+  uint32_t last_rank = 0, last_flag = 0;
+  GBCHK(hipMemcpyAsync(&last_rank, rank + (m - 1), 4, hipMemcpyDeviceToHost, st));
+  GBCHK(hipMemcpyAsync(&last_flag, flags + (m - 1), 4, hipMemcpyDeviceToHost, st));
+  GBCHK(hipStreamSynchronize(st));
+  const int kept = (int)(last_rank + last_flag);
+  if (kept == 0) return hipSuccess;
+  // root cube (Octree.hpp:287-296), float32 like the reference
+  const float ex = 0.5f * (bb[3] - bb[0]), ey = 0.5f * (bb[4] - bb[1]), ez = 0.5f * (bb[5] - bb[2]);
+  root_c[0] = bb[0] + ex; root_c[1] = bb[1] + ey; root_c[2] = bb[2] + ez;
+  root_half = ex;
+  if (ey > root_half) root_half = ey;
+  if (ez > root_half) root_half = ez;
+  root = 0;
+  const float4 rc = make_float4(root_c[0], root_c[1], root_c[2], root_half);
+  int child8[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+  const int zero = 0, one = 1;
+  GBCHK(hipMemcpyAsync(node_c, &rc, sizeof(float4), hipMemcpyHostToDevice, st));
+  GBCHK(hipMemcpyAsync(node_child, child8, sizeof(child8), hipMemcpyHostToDevice, st));
+  GBCHK(hipMemcpyAsync(node_cnt, &zero, sizeof(int), hipMemcpyHostToDevice, st));
+  GBCHK(hipMemsetAsync(node_item, 0xff, node_cap * sizeof(int), st));
+  GBCHK(hipMemcpyAsync(node_n_dev, &one, sizeof(int), hipMemcpyHostToDevice, st));
+  const GbItem I0{0, 8, 0, 0, kept, 0};
+  const int n_big = kept > kBigItem ? 1 : 0;
+  const int cnt4[4] = {1, kept, 0, n_big};
+  GBCHK(hipMemcpyAsync(items, &I0, sizeof(GbItem), hipMemcpyHostToDevice, st));
+  GBCHK(hipMemcpyAsync(counters, cnt4, sizeof(cnt4), hipMemcpyHostToDevice, st));
+  GBCHK(hipMemcpyAsync(big_items, &zero, sizeof(int), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(gb_iota_kernel, dim3((kept + 255) / 256), dim3(256), 0, st, lists, kept);
+  const int items_cap = m + m / 16 + 64;
+  int bound = 1;
+  if (n_big) {
+    hipLaunchKernelGGL(gb_build_big_kernel, dim3(1), dim3(1024), 0, st, items, counters, items_cap, big_items, 1, map_raw, lists, tmp, node_c,
+                       node_child, node_cnt, node_n_dev, (int)node_cap, min_half, pt_leaf, node_item, counters + 2);
+    bound = items_cap;
+  }
+  hipLaunchKernelGGL(gb_build_kernel, dim3((bound + 3) / 4), dim3(256), 0, st, items, counters, map_raw, lists, tmp, node_c, node_child,
+                     node_cnt, node_n_dev, (int)node_cap, min_half, pt_leaf, node_item, counters + 2);
+  int ovf = 0;
+  GBCHK(hipMemcpyAsync(&node_n, node_n_dev, sizeof(int), hipMemcpyDeviceToHost, st));
+  GBCHK(hipMemcpyAsync(&ovf, counters + 2, sizeof(int), hipMemcpyDeviceToHost, st));
+  GBCHK(hipStreamSynchronize(st));
+  if (ovf) return hipErrorOutOfMemory;
+  *kept_out = kept;
+  active = true;
+  return hipGetLastError();
+}
+
 // batch: m NaN-free device points.  Appends the kept ones to *map_raw (capacity ensured by the caller:
 // map_cap >= map_n + m) and returns the number kept.
 hipError_t GBook::update(hipStream_t st, const float4* batch, int m, const float bb[6], float4* map_raw, int map_n, int* kept_out,
