@@ -1,5 +1,5 @@
 // fast_limo_amd/csrc/hip/flimo_insert.h
-// Host-side bookkeeping of WHICH points the map stores.  The k-NN index on the GPU is a uniform
+// Host-side statement of WHICH points the map stores.  The k-NN index on the GPU is a uniform
 // grid, but the reference decides what is stored through its incremental octree
 // (Objects/Octree.hpp:282-432): the first batch is stored completely, later batches are routed to
 // octree leaves where a leaf either splits (everything kept), appends, or -- when down-sampling is
@@ -9,8 +9,9 @@
 // and answers, per incoming point, "stored or dropped".  Effective bucket size is 32 because the
 // reference's setter is a no-op (Octree.hpp:155,178-180).
 //
-// Round-1 status: this runs on the host (O(batch * depth)); SURVEY.md section 8 row f-1 moves it
-// to the GPU.  It is not a fallback of any GPU kernel: no GPU version exists yet.
+// The map itself is maintained by the device-resident book (flimo_gbook.hip), which reproduces the same rule on the
+// GPU.  This host statement backs flimo_insert_rule_replay (host-only API used by the CPU tests) and the
+// FLIMO_HOST_INSERT=1 A/B switch; it is not on the product's data path.
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
