@@ -688,6 +688,8 @@ bool Localizer::deskewPointCloud(pcl::PointCloud<PointType>::Ptr& pc, double& st
   // std::partial_sort_copy is oblivious to the payload, so running it on 16-byte (key, index) records
   // with a comparator that sees exactly what the reference's comparator sees yields the same
   // permutation as sorting the 32-byte points through std::function, several times faster.
+  static const bool prof = std::getenv("FLIMO_PROF_DESKEW") != nullptr;     // developer timing of the host stages
+  const double tp0 = prof ? now_s() : 0.0;
   auto sorted = std::make_shared<pcl::PointCloud<PointType>>();
   {
     struct Rec { double key; uint32_t idx; uint32_t pad; };
@@ -702,12 +704,48 @@ bool Localizer::deskewPointCloud(pcl::PointCloud<PointType>::Ptr& pc, double& st
       for (size_t i = 0; i < n; i++) in[i] = Rec{P[i].timestamp, (uint32_t)i, 0};          // double compare
     }
     const bool desc = eos && (sensor == SensorType::OUSTER || sensor == SensorType::VELODYNE);
-    if (desc) std::partial_sort_copy(in.begin(), in.end(), out.begin(), out.end(), [](const Rec& a, const Rec& b) { return a.key > b.key; });
-    else std::partial_sort_copy(in.begin(), in.end(), out.begin(), out.end(), [](const Rec& a, const Rec& b) { return a.key < b.key; });
+    // When no two points share a time stamp (and none is NaN) the sorted order is unique, so any sort gives what the
+    // reference's heap sort gives: identity / reversal for an already ordered cloud, std::sort otherwise.  Only clouds
+    // WITH ties need the exact library call (its tie order is what has to be reproduced).
+    bool unique = true, ascending = true, descending = true;
+    {
+      // open-addressing set over the key bits (load factor <= 1/2)
+      size_t cap = 1;
+      while (cap < 2 * n + 2) cap <<= 1;
+      std::vector<uint64_t> slot(cap, ~0ull);
+      for (size_t i = 0; i < n && unique; i++) {
+        const double k = in[i].key + 0.0;                     // -0.0 and +0.0 compare equal: hash them alike
+        if (k != k) { unique = false; break; }                // NaN: leave everything to the library call
+        uint64_t bits;
+        std::memcpy(&bits, &k, 8);
+        if (bits == ~0ull) { unique = false; break; }
+        size_t h = (size_t)((bits * 0x9E3779B97F4A7C15ull) >> 20) & (cap - 1);
+        while (slot[h] != ~0ull) {
+          if (slot[h] == bits) { unique = false; break; }
+          h = (h + 1) & (cap - 1);
+        }
+        if (unique) slot[h] = bits;
+        if (i > 0) { ascending = ascending && in[i - 1].key < in[i].key; descending = descending && in[i - 1].key > in[i].key; }
+      }
+    }
+    if (unique && ((!desc && ascending) || (desc && descending))) {
+      out = in;                                                // already in the requested order
+    } else if (unique && ((!desc && descending) || (desc && ascending))) {
+      for (size_t i = 0; i < n; i++) out[i] = in[n - 1 - i];
+    } else if (unique) {
+      out = in;
+      if (desc) std::sort(out.begin(), out.end(), [](const Rec& a, const Rec& b) { return a.key > b.key; });
+      else std::sort(out.begin(), out.end(), [](const Rec& a, const Rec& b) { return a.key < b.key; });
+    } else if (desc) {
+      std::partial_sort_copy(in.begin(), in.end(), out.begin(), out.end(), [](const Rec& a, const Rec& b) { return a.key > b.key; });
+    } else {
+      std::partial_sort_copy(in.begin(), in.end(), out.begin(), out.end(), [](const Rec& a, const Rec& b) { return a.key < b.key; });
+    }
     sorted->points.resize(n);
     for (size_t i = 0; i < n; i++) sorted->points[i] = P[out[i].idx];
   }
   (void)cmp;
+  const double tp1 = prof ? now_s() : 0.0;
   double offset = 0.0;
   if (config.time_offset) {
     offset = imu_stamp - extract(sorted->points.back()) - 1.e-4;
@@ -740,12 +778,18 @@ bool Localizer::deskewPointCloud(pcl::PointCloud<PointType>::Ptr& pc, double& st
   flimo_ctx* c = map_->ctx();
   if (!c) return false;
   // raw scan + times become resident; frames are kept for registerResident()
+  const double tp2 = prof ? now_s() : 0.0;
   int rc = flimo_raw_scan_set(c, &sorted->points[0].x, n, sizeof(PointType), t.data());
+  const double tp3 = prof ? now_s() : 0.0;
   if (rc != FLIMO_OK) { std::cout << "FAST_LIMO::raw scan upload failed: " << flimo_last_error(c) << "\n"; return false; }
   rs_frames_.assign(fr.begin(), fr.end());
   std::memcpy(rs_l2b_, extr.lidar2baselink_T.m, sizeof(rs_l2b_));
   rc = flimo_deskew_resident(c, rs_frames_.data(), rs_frames_.size(), rs_l2b_, x26);
   if (rc != FLIMO_OK) { std::cout << "FAST_LIMO::deskew failed: " << flimo_last_error(c) << "\n"; return false; }
+  const double tp4 = prof ? now_s() : 0.0;
+  if (prof)
+    fprintf(stderr, "[flimo deskew] time sort + gather %.0f us, frames/times %.0f us, upload + Morton sort %.0f us, deskew call %.0f us (n = %zu)\n",
+            (tp1 - tp0) * 1e6, (tp2 - tp1) * 1e6, (tp3 - tp2) * 1e6, (tp4 - tp3) * 1e6, n);
   if (download_clouds) {
     std::vector<float> xyz(n * 3);
     size_t m = 0;

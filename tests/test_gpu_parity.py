@@ -342,8 +342,11 @@ def test_device_insert_rule_matches_octree(built, oracle, downsample):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sensor,eos", [("OUSTER", False), ("OUSTER", True), ("VELODYNE", True), ("HESAI", False), ("LIVOX", False)])
-def test_sensor_time_formats_and_input_filters_match_oracle(built, oracle, sensor, eos):
+@pytest.mark.parametrize("sensor,eos,times", [("OUSTER", False, "ties"), ("OUSTER", True, "ties"), ("VELODYNE", True, "ties"),
+                                             ("HESAI", False, "ties"), ("LIVOX", False, "ties"),
+                                             ("VELODYNE", False, "unique-shuffled"), ("VELODYNE", True, "unique-shuffled"),
+                                             ("OUSTER", True, "unique-ordered"), ("HESAI", False, "unique-ordered")])
+def test_sensor_time_formats_and_input_filters_match_oracle(built, oracle, sensor, eos, times):
     """Per-sensor time decoding (reference Localizer.cpp:745-781: uint32 ns / float s / absolute double s / absolute
     double ns, start- or end-of-sweep reference) and the input filters (:262-302: NaN removal, negative crop box,
     min-distance, every-n-th point, FoV) through the PointType-layout entry.  Time stamps are quantised so that many
@@ -357,7 +360,12 @@ def test_sensor_time_formats_and_input_filters_match_oracle(built, oracle, senso
     xyz = scan5[:, :3].copy()
     xyz[::97] = np.nan                                       # removeNaNFromPointCloud
     xyz[1::211] *= np.float32(0.01)                          # a few points inside the crop box / below min_dist
-    rel = np.round(rs.uniform(0.0, 0.1, xyz.shape[0]) * 2000.0) / 2000.0      # 200 distinct stamps -> ties
+    if times == "ties":
+        rel = np.round(rs.uniform(0.0, 0.1, xyz.shape[0]) * 2000.0) / 2000.0  # 200 distinct stamps -> ties (the library call's order)
+    elif times == "unique-shuffled":                                          # unique stamps: any sort gives the reference's order
+        rel = (rs.permutation(xyz.shape[0]) + 0.5) / xyz.shape[0] * 0.0999
+    else:                                                                     # unique and already ordered (typical driver output)
+        rel = (np.arange(xyz.shape[0]) + 0.5) / xyz.shape[0] * 0.0999
     filt = dict(crop_active=1, dist_active=1, min_dist=1.5, rate_active=1, rate_value=3, fov_active=1, fov_angle=2.8)
     gcfg = api.default_cfg(sensor_type=code, end_of_sweep=int(eos), cropBoxMin=(-0.5, -0.5, -0.5), cropBoxMax=(0.5, 0.5, 0.5),
                            **filt, **CAPS)

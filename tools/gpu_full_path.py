@@ -29,6 +29,8 @@ for k in range(NSCANS):
     while st[i] <= until:
         G.update_imu(st[i], w[i], a[i]); Lo.update_imu(st[i], w[i], a[i]); i += 1
     scan = synth.velodyne_scan(RINGS, AZ, LBOX, 2 + k)
+    if int(os.environ.get("UNIQUE_TIMES", 0)):             # every point its own stamp (no ties: the time sort takes its fast path)
+        scan[:, 4] += (np.arange(scan.shape[0]) % RINGS).astype(np.float32) * np.float32(1.5e-6)
     t0 = time.perf_counter(); rg = G.update_pointcloud(scan, 0.1 * k); tg = time.perf_counter() - t0
     t0 = time.perf_counter(); ro = Lo.update_pointcloud(scan, 0.1 * k); to = time.perf_counter() - t0
     sg = G.stage_times(); so = Lo.stats()
