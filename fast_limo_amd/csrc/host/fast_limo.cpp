@@ -709,23 +709,36 @@ bool Localizer::deskewPointCloud(pcl::PointCloud<PointType>::Ptr& pc, double& st
     // WITH ties need the exact library call (its tie order is what has to be reproduced).
     bool unique = true, ascending = true, descending = true;
     {
-      // open-addressing set over the key bits (load factor <= 1/2)
-      size_t cap = 1;
-      while (cap < 2 * n + 2) cap <<= 1;
-      std::vector<uint64_t> slot(cap, ~0ull);
-      for (size_t i = 0; i < n && unique; i++) {
-        const double k = in[i].key + 0.0;                     // -0.0 and +0.0 compare equal: hash them alike
-        if (k != k) { unique = false; break; }                // NaN: leave everything to the library call
-        uint64_t bits;
-        std::memcpy(&bits, &k, 8);
-        if (bits == ~0ull) { unique = false; break; }
-        size_t h = (size_t)((bits * 0x9E3779B97F4A7C15ull) >> 20) & (cap - 1);
-        while (slot[h] != ~0ull) {
-          if (slot[h] == bits) { unique = false; break; }
-          h = (h + 1) & (cap - 1);
+      // one sequential pass: adjacent equal stamps (the usual way ties show up: the columns of a spinning sensor) send the
+      // cloud straight to the library call; a strictly monotone cloud is unique by construction
+      bool nan = false, adjacent_tie = false;
+      for (size_t i = 0; i < n; i++) {
+        nan = nan || (in[i].key != in[i].key);
+        if (i > 0) {
+          ascending = ascending && in[i - 1].key < in[i].key;
+          descending = descending && in[i - 1].key > in[i].key;
+          adjacent_tie = adjacent_tie || in[i - 1].key == in[i].key;
         }
-        if (unique) slot[h] = bits;
-        if (i > 0) { ascending = ascending && in[i - 1].key < in[i].key; descending = descending && in[i - 1].key > in[i].key; }
+      }
+      if (nan || adjacent_tie) {
+        unique = false;
+      } else if (!ascending && !descending) {
+        // unordered cloud: look for equal stamps anywhere with an open-addressing set over the key bits (load <= 1/2)
+        size_t cap = 1;
+        while (cap < 2 * n + 2) cap <<= 1;
+        std::vector<uint64_t> slot(cap, ~0ull);
+        for (size_t i = 0; i < n && unique; i++) {
+          const double k = in[i].key + 0.0;                   // -0.0 and +0.0 compare equal: hash them alike
+          uint64_t bits;
+          std::memcpy(&bits, &k, 8);
+          if (bits == ~0ull) { unique = false; break; }
+          size_t h = (size_t)((bits * 0x9E3779B97F4A7C15ull) >> 20) & (cap - 1);
+          while (slot[h] != ~0ull) {
+            if (slot[h] == bits) { unique = false; break; }
+            h = (h + 1) & (cap - 1);
+          }
+          if (unique) slot[h] = bits;
+        }
       }
     }
     if (unique && ((!desc && ascending) || (desc && descending))) {
