@@ -142,6 +142,9 @@ def main():
     ap.add_argument("--map-points", type=int, default=1000000)
     ap.add_argument("--box", type=float, default=100.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--with-insert", action="store_true",
+                    help="also time the step WITH the path exit (transform + map insert); off by default so that every "
+                         "k-NN launch of the run belongs to the benchmark workload (rocprofv3 averages stay comparable)")
     args = ap.parse_args()
 
     # stdout carries exactly ONE JSON line: the native library reports status lines the way the reference does
@@ -212,7 +215,7 @@ def main():
     # beside `value`, never as `value`.  The first insertion stores the scan's new points; repeating the same scan is
     # then mostly rejected by the reference's down-sampling rule, so both are shown.  Runs after the timed region.
     with_insert = None
-    if rank == 0:
+    if rank == 0 and args.with_insert:
         t_ins = []
         sizes = [loc.map_size()]
         for k in range(6):
