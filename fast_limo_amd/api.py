@@ -45,7 +45,7 @@ HOST_SYMBOLS = [
     "flimo_loc_map_add", "flimo_loc_map_size", "flimo_loc_get_x", "flimo_loc_set_x", "flimo_loc_get_P",
     "flimo_loc_set_P", "flimo_loc_set_flags", "flimo_loc_num_passes", "flimo_loc_get_pass", "flimo_loc_get_pc2match",
     "flimo_loc_get_final_scan", "flimo_loc_get_stage_times", "flimo_loc_get_pose_cov", "flimo_loc_register_resident", "flimo_loc_host_profile",
-    "flimo_eskf_update_fixed", "flimo_eskf_predict", "flimo_host_plane", "flimo_host_state_update",
+    "flimo_eskf_update_fixed", "flimo_eskf_predict", "flimo_host_plane", "flimo_host_state_update", "flimo_host_time_order",
 ]
 
 

@@ -129,6 +129,14 @@ void flimo_host_state_update(float s[25], double time, double t) {
   for (int i = 0; i < 3; i++) { s[i] = X.p(i); s[7 + i] = X.v(i); }
   s[3] = X.q.x(); s[4] = X.q.y(); s[5] = X.q.z(); s[6] = X.q.w();
 }
+// time order of a sweep (Localizer.cpp:789-790) for tests: use_library = 1 runs std::partial_sort_copy itself
+int flimo_host_time_order(const void* keys, int kind, size_t n, int descending, int use_library, uint32_t* order_out) {
+  if (!keys || !order_out || kind < 0 || kind > 2) return -1;
+  std::vector<uint32_t> order;
+  fast_limo::time_order(keys, kind, n, descending != 0, use_library != 0, order);
+  for (size_t i = 0; i < n; i++) order_out[i] = order[i];
+  return 0;
+}
 // fast_limo::Plane / Match object API (reference Objects/Plane.cpp:23-31, Match.cpp:23-28) for tests
 int flimo_host_plane(const float* xyz, const float* sqd, int n, int num_match_points, double max_dist_plane,
                      double plane_threshold, const float p_global[3], float n_out[4], float* dist_out) {

@@ -662,6 +662,142 @@ bool Localizer::propagatedFromTimeRange(double start_time, double end_time, Stat
   return true;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Time order of a sweep (reference Localizer.cpp:789-790: std::partial_sort_copy of the whole cloud with a "<" / ">"
+// comparator on the stamp).  For equal-size ranges the library call is copy + make_heap + sort_heap, so WHICH of two
+// points with equal stamps comes first is decided by the heap's moves and has to be reproduced move for move:
+//   * no two equal stamps (and no NaN): the order is unique -- identity / reversal / std::sort give it;
+//   * ties: heap_order() below restates libstdc++'s heap routines (bits/stl_heap.h: __make_heap, __adjust_heap,
+//     __push_heap, __pop_heap, __sort_heap; bits/stl_algo.h: __partial_sort_copy) on packed (key, index) records with a
+//     branch-free child choice -- the same comparisons in the same order, hence the same permutation (tests compare
+//     it with the library call on the host's libstdc++), at less than half the time of the library on 16-byte records;
+//   * NaN stamps: the comparator is no strict weak order; the library call itself runs (use_library).
+// Keys are mapped to unsigned integers that order like the stamps (-0.0 == +0.0 kept equal); descending = complement.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+struct HeapRec64 { uint64_t key; uint32_t idx; uint32_t pad; };
+inline bool hless(uint64_t a, uint64_t b) { return (a >> 32) < (b >> 32); }              // packed: key in the high half
+inline bool hless(const HeapRec64& a, const HeapRec64& b) { return a.key < b.key; }
+
+template <class R>
+inline void heap_adjust(R* f, ptrdiff_t hole, ptrdiff_t len, R v) {                      // __adjust_heap + __push_heap
+  const ptrdiff_t top = hole;
+  ptrdiff_t c = hole;
+  const ptrdiff_t lim = (len - 1) / 2;
+  while (c < lim) {
+    c = 2 * (c + 1);
+    {
+      // the walk always runs to the bottom and its lower levels miss L1: fetch the great-grandchildren of the current
+      // hole (8 consecutive records) while the two compares above them resolve
+      const ptrdiff_t g = 4 * c - 1;                                                     // first great-grandchild
+      if (g + 7 < len) { __builtin_prefetch(&f[g]); __builtin_prefetch(&f[g + 7]); }
+    }
+    c -= (ptrdiff_t)hless(f[c], f[c - 1]);                                               // the larger child; right one on ties
+    f[hole] = f[c];
+    hole = c;
+  }
+  if ((len & 1) == 0 && c == (len - 2) / 2) {
+    c = 2 * (c + 1);
+    f[hole] = f[c - 1];
+    hole = c - 1;
+  }
+  ptrdiff_t parent = (hole - 1) / 2;
+  while (hole > top && hless(f[parent], v)) {
+    f[hole] = f[parent];
+    hole = parent;
+    parent = (hole - 1) / 2;
+  }
+  f[hole] = v;
+}
+template <class R>
+void heap_order(R* f, ptrdiff_t len) {                                                   // make_heap + sort_heap
+  if (len < 2) return;
+  for (ptrdiff_t parent = (len - 2) / 2;; parent--) {
+    heap_adjust(f, parent, len, f[parent]);
+    if (parent == 0) break;
+  }
+  for (ptrdiff_t last = len - 1; last > 0; last--) {                                     // __pop_heap(first, last, last)
+    const R v = f[last];
+    f[last] = f[0];
+    heap_adjust(f, (ptrdiff_t)0, last, v);
+  }
+}
+inline uint32_t ord_u32(float x) {
+  x += 0.0f;                                                                             // -0.0 -> +0.0
+  uint32_t b;
+  std::memcpy(&b, &x, 4);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+inline uint64_t ord_u64(double x) {
+  x += 0.0;
+  uint64_t b;
+  std::memcpy(&b, &x, 8);
+  return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
+}
+template <class T>
+void library_order(const T* k, size_t n, bool desc, std::vector<uint32_t>& order) {
+  struct Rec { T key; uint32_t idx; };
+  std::vector<Rec> in(n), out(n);
+  for (size_t i = 0; i < n; i++) in[i] = Rec{k[i], (uint32_t)i};
+  if (desc) std::partial_sort_copy(in.begin(), in.end(), out.begin(), out.end(), [](const Rec& a, const Rec& b) { return a.key > b.key; });
+  else std::partial_sort_copy(in.begin(), in.end(), out.begin(), out.end(), [](const Rec& a, const Rec& b) { return a.key < b.key; });
+  for (size_t i = 0; i < n; i++) order[i] = out[i].idx;
+}
+template <class T>
+void time_order_t(const T* k, size_t n, bool desc, bool use_library, std::vector<uint32_t>& order) {
+  order.resize(n);
+  if (n == 0) return;
+  // one sequential pass: NaN, adjacent ties (the usual way ties show up: the columns of a spinning sensor), monotonicity
+  bool nan = false, tie = false, ascending = true, descending = true;
+  for (size_t i = 0; i < n; i++) {
+    nan = nan || (k[i] != k[i]);
+    if (i > 0) {
+      ascending = ascending && k[i - 1] < k[i];
+      descending = descending && k[i - 1] > k[i];
+      tie = tie || k[i - 1] == k[i];
+    }
+  }
+  if (nan || use_library) { library_order(k, n, desc, order); return; }
+  if (!tie && ((!desc && ascending) || (desc && descending))) {                          // strictly ordered already
+    for (size_t i = 0; i < n; i++) order[i] = (uint32_t)i;
+    return;
+  }
+  if (!tie && ((!desc && descending) || (desc && ascending))) {                          // strictly ordered, reversed
+    for (size_t i = 0; i < n; i++) order[i] = (uint32_t)(n - 1 - i);
+    return;
+  }
+  if (sizeof(T) == 4) {
+    std::vector<uint64_t> r(n);
+    for (size_t i = 0; i < n; i++) {
+      uint32_t u;
+      if (std::is_same<T, uint32_t>::value) { std::memcpy(&u, &k[i], 4); } else { float x; std::memcpy(&x, &k[i], 4); u = ord_u32(x); }
+      if (desc) u = ~u;
+      r[i] = ((uint64_t)u << 32) | (uint64_t)i;
+    }
+    heap_order(r.data(), (ptrdiff_t)n);
+    for (size_t i = 0; i < n; i++) order[i] = (uint32_t)(r[i] & 0xffffffffu);
+  } else {
+    std::vector<HeapRec64> r(n);
+    for (size_t i = 0; i < n; i++) {
+      double x;
+      std::memcpy(&x, &k[i], 8);
+      uint64_t u = ord_u64(x);
+      if (desc) u = ~u;
+      r[i] = HeapRec64{u, (uint32_t)i, 0};
+    }
+    heap_order(r.data(), (ptrdiff_t)n);
+    for (size_t i = 0; i < n; i++) order[i] = r[i].idx;
+  }
+}
+}  // namespace
+// kind: 0 = uint32 (OUSTER t), 1 = float (VELODYNE time), 2 = double (HESAI / LIVOX timestamp)
+void fast_limo::time_order(const void* keys, int kind, size_t n, bool desc, bool use_library, std::vector<uint32_t>& order) {
+  if (kind == 0) time_order_t(static_cast<const uint32_t*>(keys), n, desc, use_library, order);
+  else if (kind == 1) time_order_t(static_cast<const float*>(keys), n, desc, use_library, order);
+  else time_order_t(static_cast<const double*>(keys), n, desc, use_library, order);
+}
+
 bool Localizer::deskewPointCloud(pcl::PointCloud<PointType>::Ptr& pc, double& start_time) {   // Localizer.cpp:733-853
   if (pc->points.size() < 1) return false;
   const double sweep_ref_time = start_time;
@@ -692,70 +828,25 @@ bool Localizer::deskewPointCloud(pcl::PointCloud<PointType>::Ptr& pc, double& st
   const double tp0 = prof ? now_s() : 0.0;
   auto sorted = std::make_shared<pcl::PointCloud<PointType>>();
   {
-    struct Rec { double key; uint32_t idx; uint32_t pad; };
     const size_t n = pc->points.size();
-    std::vector<Rec> in(n), out(n);
     const std::vector<PointType>& P = pc->points;
-    if (sensor == SensorType::OUSTER) {
-      for (size_t i = 0; i < n; i++) in[i] = Rec{(double)P[i].t, (uint32_t)i, 0};          // uint32 compare
-    } else if (sensor == SensorType::VELODYNE) {
-      for (size_t i = 0; i < n; i++) in[i] = Rec{(double)P[i].time, (uint32_t)i, 0};       // float compare (exact in double)
-    } else {
-      for (size_t i = 0; i < n; i++) in[i] = Rec{P[i].timestamp, (uint32_t)i, 0};          // double compare
-    }
     const bool desc = eos && (sensor == SensorType::OUSTER || sensor == SensorType::VELODYNE);
-    // When no two points share a time stamp (and none is NaN) the sorted order is unique, so any sort gives what the
-    // reference's heap sort gives: identity / reversal for an already ordered cloud, std::sort otherwise.  Only clouds
-    // WITH ties need the exact library call (its tie order is what has to be reproduced).
-    bool unique = true, ascending = true, descending = true;
-    {
-      // one sequential pass: adjacent equal stamps (the usual way ties show up: the columns of a spinning sensor) send the
-      // cloud straight to the library call; a strictly monotone cloud is unique by construction
-      bool nan = false, adjacent_tie = false;
-      for (size_t i = 0; i < n; i++) {
-        nan = nan || (in[i].key != in[i].key);
-        if (i > 0) {
-          ascending = ascending && in[i - 1].key < in[i].key;
-          descending = descending && in[i - 1].key > in[i].key;
-          adjacent_tie = adjacent_tie || in[i - 1].key == in[i].key;
-        }
-      }
-      if (nan || adjacent_tie) {
-        unique = false;
-      } else if (!ascending && !descending) {
-        // unordered cloud: look for equal stamps anywhere with an open-addressing set over the key bits (load <= 1/2)
-        size_t cap = 1;
-        while (cap < 2 * n + 2) cap <<= 1;
-        std::vector<uint64_t> slot(cap, ~0ull);
-        for (size_t i = 0; i < n && unique; i++) {
-          const double k = in[i].key + 0.0;                   // -0.0 and +0.0 compare equal: hash them alike
-          uint64_t bits;
-          std::memcpy(&bits, &k, 8);
-          if (bits == ~0ull) { unique = false; break; }
-          size_t h = (size_t)((bits * 0x9E3779B97F4A7C15ull) >> 20) & (cap - 1);
-          while (slot[h] != ~0ull) {
-            if (slot[h] == bits) { unique = false; break; }
-            h = (h + 1) & (cap - 1);
-          }
-          if (unique) slot[h] = bits;
-        }
-      }
-    }
-    if (unique && ((!desc && ascending) || (desc && descending))) {
-      out = in;                                                // already in the requested order
-    } else if (unique && ((!desc && descending) || (desc && ascending))) {
-      for (size_t i = 0; i < n; i++) out[i] = in[n - 1 - i];
-    } else if (unique) {
-      out = in;
-      if (desc) std::sort(out.begin(), out.end(), [](const Rec& a, const Rec& b) { return a.key > b.key; });
-      else std::sort(out.begin(), out.end(), [](const Rec& a, const Rec& b) { return a.key < b.key; });
-    } else if (desc) {
-      std::partial_sort_copy(in.begin(), in.end(), out.begin(), out.end(), [](const Rec& a, const Rec& b) { return a.key > b.key; });
+    std::vector<uint32_t> order;
+    if (sensor == SensorType::OUSTER) {
+      std::vector<uint32_t> k(n);
+      for (size_t i = 0; i < n; i++) k[i] = P[i].t;
+      time_order(k.data(), 0, n, desc, false, order);
+    } else if (sensor == SensorType::VELODYNE) {
+      std::vector<float> k(n);
+      for (size_t i = 0; i < n; i++) k[i] = P[i].time;
+      time_order(k.data(), 1, n, desc, false, order);
     } else {
-      std::partial_sort_copy(in.begin(), in.end(), out.begin(), out.end(), [](const Rec& a, const Rec& b) { return a.key < b.key; });
+      std::vector<double> k(n);
+      for (size_t i = 0; i < n; i++) k[i] = P[i].timestamp;
+      time_order(k.data(), 2, n, desc, false, order);
     }
     sorted->points.resize(n);
-    for (size_t i = 0; i < n; i++) sorted->points[i] = P[out[i].idx];
+    for (size_t i = 0; i < n; i++) sorted->points[i] = P[order[i]];
   }
   (void)cmp;
   const double tp1 = prof ? now_s() : 0.0;

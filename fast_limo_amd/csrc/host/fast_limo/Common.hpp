@@ -132,6 +132,9 @@ template <typename T>
 using shared_ptr = std::shared_ptr<T>;
 template <typename T, typename... Args>
 std::shared_ptr<T> make_shared(Args&&... args) { return std::make_shared<T>(std::forward<Args>(args)...); }
+// Order of a sweep's points by time stamp exactly as the reference's std::partial_sort_copy leaves it (Localizer.cpp:789-790),
+// ties included.  kind: 0 = uint32 (OUSTER t), 1 = float (VELODYNE time), 2 = double (HESAI / LIVOX timestamp).
+void time_order(const void* keys, int kind, size_t n, bool descending, bool use_library, std::vector<uint32_t>& order);
 }  // namespace fast_limo
 
 typedef fast_limo::Point PointType;

@@ -76,6 +76,9 @@ int    flimo_loc_register_resident(flimo_loc* L, const double x26_prior[26], con
 void   flimo_host_state_update(float s[25], double time, double t);
 /* fast_limo::Plane + Match object API in isolation (Plane.cpp:23-31, Match.cpp:23-28): returns good_fit(), the normal
  * (zeros when not a plane) and Match(p_global, ., plane).dist -- for unit tests */
+/* Order in which Localizer::deskewPointCloud's std::partial_sort_copy (Localizer.cpp:789-790) leaves a sweep, ties included.
+ * kind: 0 uint32 (OUSTER), 1 float (VELODYNE), 2 double (HESAI/LIVOX); use_library=1 runs the library call itself (tests). */
+int    flimo_host_time_order(const void* keys, int kind, size_t n, int descending, int use_library, uint32_t* order_out);
 int    flimo_host_plane(const float* xyz, const float* sqd, int n, int num_match_points, double max_dist_plane,
                         double plane_threshold, const float p_global[3], float n_out[4], float* dist_out);
 /* IESKF algebra in isolation with a fixed measurement (H [M][12], h [M]) -- for unit tests */

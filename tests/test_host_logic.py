@@ -243,3 +243,56 @@ def test_host_state_update_equals_oracle(built, oracle):
         b = oracle.state_update(s, t0, t1)
         np.testing.assert_array_equal(a, b, err_msg=str(k))
         assert not np.array_equal(a[0:3], s[0:3])
+
+
+def test_time_order_equals_library_call(built):
+    """The host's heap-order restatement leaves a sweep in exactly the order std::partial_sort_copy does (reference
+    Localizer.cpp:789-790), ties included: every key type, both directions, odd and even sizes, heavy / adjacent /
+    scattered ties, signed zeros, already ordered and reversed input."""
+    import ctypes as C, time
+    from fast_limo_amd import api
+    L = api.load_host()
+    L.flimo_host_time_order.restype = C.c_int
+    L.flimo_host_time_order.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+
+    def order(keys, kind, desc, lib):
+        out = np.empty(keys.size, np.uint32)
+        assert L.flimo_host_time_order(keys.ctypes.data, kind, keys.size, desc, lib, out.ctypes.data) == 0
+        return out
+
+    rs = np.random.RandomState(5)
+    kinds = [(0, np.uint32), (1, np.float32), (2, np.float64)]
+    cases = 0
+    for n in [0, 1, 2, 3, 4, 5, 6, 7, 8, 15, 16, 17, 31, 32, 33, 100, 101, 1000, 1023, 1024, 1025, 4097, 20000]:
+        for kind, dt in kinds:
+            variants = []
+            variants.append(rs.randint(0, max(1, n // 8) + 1, n))                       # heavy scattered ties
+            variants.append(np.repeat(np.arange((n + 15) // 16), 16)[:n])               # columns: adjacent ties, ascending
+            variants.append(np.tile(np.arange((n + 15) // 16), 16)[:n])                 # ring-major: ties far apart
+            variants.append(np.arange(n))                                               # strictly ascending
+            variants.append(np.arange(n)[::-1].copy())                                  # strictly descending
+            variants.append(rs.permutation(n))                                          # unique, shuffled
+            variants.append(np.zeros(n))                                                # all equal
+            for v in variants:
+                if dt == np.uint32:
+                    keys = v.astype(np.uint32)
+                else:
+                    keys = (v.astype(np.float64) * 1e-3 - (0.004 if kind == 1 else 0.0)).astype(dt)   # some negative
+                    if n > 4:
+                        keys[rs.randint(n)] = -0.0; keys[rs.randint(n)] = 0.0
+                for desc in ([0, 1] if kind < 2 else [0]):
+                    a = order(keys, kind, desc, 0); b = order(keys, kind, desc, 1)
+                    np.testing.assert_array_equal(a, b, err_msg=f"n={n} kind={kind} desc={desc}")
+                    if n:
+                        k = keys[a].astype(np.float64)
+                        assert np.all(np.diff(k) <= 0) if desc else np.all(np.diff(k) >= 0)
+                    cases += 1
+    assert cases > 500
+    # NaN stamps: not a strict weak order, the library call itself runs -- same answer by construction, and no crash
+    keys = rs.uniform(0, 0.1, 1000).astype(np.float32); keys[::37] = np.nan
+    np.testing.assert_array_equal(order(keys, 1, 0, 0), order(keys, 1, 0, 1))
+    # and it is the faster of the two on a sweep-sized cloud with column ties
+    keys = np.repeat(np.arange(1024), 64).astype(np.float32) * 1e-4
+    t0 = time.perf_counter(); a = order(keys, 1, 0, 0); t1 = time.perf_counter(); b = order(keys, 1, 0, 1); t2 = time.perf_counter()
+    np.testing.assert_array_equal(a, b)
+    print(f"time order 64k with ties: restatement {1e3 * (t1 - t0):.2f} ms, library {1e3 * (t2 - t1):.2f} ms")
