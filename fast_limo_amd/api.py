@@ -41,7 +41,7 @@ class LocCfg(C.Structure):
 
 
 HOST_SYMBOLS = [
-    "flimo_loc_create", "flimo_loc_destroy", "flimo_loc_ctx", "flimo_loc_update_imu", "flimo_loc_update_pointcloud", "flimo_loc_update_pointcloud_points",
+    "flimo_loc_create", "flimo_loc_destroy", "flimo_loc_ctx", "flimo_loc_sync", "flimo_loc_set_async_insert", "flimo_loc_last_insert_seconds", "flimo_loc_update_imu", "flimo_loc_update_pointcloud", "flimo_loc_update_pointcloud_points",
     "flimo_loc_map_add", "flimo_loc_map_size", "flimo_loc_get_x", "flimo_loc_set_x", "flimo_loc_get_P",
     "flimo_loc_set_P", "flimo_loc_set_flags", "flimo_loc_num_passes", "flimo_loc_get_pass", "flimo_loc_get_pc2match",
     "flimo_loc_get_final_scan", "flimo_loc_get_stage_times", "flimo_loc_get_pose_cov", "flimo_loc_register_resident", "flimo_loc_host_profile",
@@ -104,6 +104,12 @@ def load_host():
     L.flimo_loc_destroy.argtypes = [vp]
     L.flimo_loc_ctx.restype = vp
     L.flimo_loc_ctx.argtypes = [vp]
+    L.flimo_loc_sync.restype = None
+    L.flimo_loc_sync.argtypes = [vp]
+    L.flimo_loc_set_async_insert.restype = None
+    L.flimo_loc_set_async_insert.argtypes = [vp, C.c_int]
+    L.flimo_loc_last_insert_seconds.restype = C.c_double
+    L.flimo_loc_last_insert_seconds.argtypes = [vp]
     L.flimo_loc_update_imu.argtypes = [vp, C.c_double, f32p, f32p]
     L.flimo_loc_update_pointcloud.argtypes = [vp, f32p, C.c_size_t, C.c_double]
     L.flimo_loc_update_pointcloud_points.argtypes = [vp, C.c_void_p, C.c_size_t, C.c_double]
@@ -141,6 +147,15 @@ def load_host():
     return L
 
 
+class _MapperCtxView(_lib.HipCtx):
+    """The Mapper's GPU context as seen from Python.  The handle is fetched through flimo_loc_ctx on every use, which
+    waits for a map insert still running on the Mapper's worker thread."""
+
+    @property
+    def _h(self):
+        return C.c_void_p(self._loc._L.flimo_loc_ctx(self._loc._h))
+
+
 class Localizer:
     """fast_limo::Localizer (one instance per GPU)."""
 
@@ -151,8 +166,8 @@ class Localizer:
         if rc != 0:
             raise FlimoError(f"flimo_loc_create failed ({rc}): no gfx950 device or HIP error -- there is no CPU fallback")
         self._h, self._L, self.cfg = h, L, cfg
-        self.hip = _lib.HipCtx.__new__(_lib.HipCtx)      # non-owning view of the Mapper's context
-        self.hip._h = C.c_void_p(L.flimo_loc_ctx(h))
+        self.hip = _MapperCtxView.__new__(_MapperCtxView)      # non-owning view of the Mapper's context
+        self.hip._loc = self
         self.hip._L = _lib.load_hip()
         self.hip.close = lambda: None
 
@@ -208,6 +223,16 @@ class Localizer:
 
     def set_flags(self, add_to_map=True, download_clouds=True, keep_log=False):
         self._L.flimo_loc_set_flags(self._h, int(add_to_map), int(download_clouds), int(keep_log))
+
+    def sync(self):
+        """Wait for the map insert of the last scan (it runs on the Mapper's worker thread)."""
+        self._L.flimo_loc_sync(self._h)
+
+    def set_async_insert(self, on=True):
+        self._L.flimo_loc_set_async_insert(self._h, int(on))
+
+    def last_insert_seconds(self):
+        return float(self._L.flimo_loc_last_insert_seconds(self._h))
 
     def passes(self):
         out = []

@@ -175,6 +175,10 @@ void flimo_loc_set_flags(flimo_loc* L, int add_to_map, int download_clouds, int 
   L->loc->download_clouds = download_clouds != 0;
   L->loc->filter().keep_log = keep_log != 0;
 }
+// the map insert that ends a scan runs on the Mapper's worker thread (Mapper::add_scan): wait for it / switch it off
+void flimo_loc_sync(flimo_loc* L) { if (L) L->map->sync(); }
+void flimo_loc_set_async_insert(flimo_loc* L, int on) { if (L) L->map->set_async(on != 0); }
+double flimo_loc_last_insert_seconds(flimo_loc* L) { return L ? L->map->last_insert_seconds() : 0.0; }
 int flimo_loc_num_passes(flimo_loc* L) { return (int)L->loc->filter().log.size(); }
 void flimo_loc_get_pass(flimo_loc* L, int i, int* M, double* HTH, double* HTh, double* dx, double* x_after) {
   const flimo_host::PassLog& g = L->loc->filter().log[i];

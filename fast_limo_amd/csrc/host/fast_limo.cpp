@@ -224,7 +224,7 @@ Eigen::Matrix4f State::get_extr_RT_inv() const { return se3_inv(qLI, pLI); }
 // ---------------------------------------------------------------------------------------------
 // Mapper
 // ---------------------------------------------------------------------------------------------
-Mapper::Mapper() : num_threads_(1), ctx_(nullptr), device_(0), cell_size_(0.f) {
+Mapper::Mapper() : num_threads_(1), ctx_(nullptr), device_(0), cell_size_(0.f), async_(std::getenv("FLIMO_SYNC_INSERT") == nullptr) {
   config.NUM_MATCH_POINTS = 5;                                    // Mapper.cpp:23-31
   config.MAX_NUM_MATCHES = 2000;
   config.MAX_NUM_PC2MATCH = 10000;
@@ -235,9 +235,55 @@ Mapper::Mapper() : num_threads_(1), ctx_(nullptr), device_(0), cell_size_(0.f) {
   config.octree.downsampling = true;
 }
 Mapper::Mapper(int device) : Mapper() { device_ = device; }
-Mapper::~Mapper() { if (ctx_) flimo_ctx_destroy(ctx_); }
+Mapper::~Mapper() {
+  sync();
+  if (worker_.joinable()) {
+    { std::lock_guard<std::mutex> lk(wm_); quit_ = true; }
+    wcv_.notify_all();
+    worker_.join();
+  }
+  if (ctx_) flimo_ctx_destroy(ctx_);
+}
+// ---- asynchronous path exit -------------------------------------------------------------------------------------------
+void Mapper::sync() {
+  if (!worker_.joinable()) return;
+  std::unique_lock<std::mutex> lk(wm_);
+  wcv_.wait(lk, [this] { return !busy_; });
+}
+void Mapper::run_insert(const double x26[26], double stamp) {
+  const double t0 = now_s();
+  const int rc = flimo_map_add_scan(ctx_, x26, stamp);
+  if (rc != FLIMO_OK) std::cout << "FAST_LIMO::map insert failed: " << flimo_last_error(ctx_) << "\n";
+  insert_seconds_ = now_s() - t0;
+}
+void Mapper::worker_main() {
+  std::unique_lock<std::mutex> lk(wm_);
+  for (;;) {
+    wcv_.wait(lk, [this] { return busy_ || quit_; });
+    if (quit_) return;
+    lk.unlock();
+    run_insert(job_x_, job_stamp_);                 // the only user of ctx_ while busy_ is set
+    lk.lock();
+    busy_ = false;
+    wcv_.notify_all();
+  }
+}
+void Mapper::add_scan(const double x26[26], double stamp) {
+  if (!ctx_) return;
+  sync();
+  if (!async_) { run_insert(x26, stamp); return; }
+  if (!worker_.joinable()) worker_ = std::thread(&Mapper::worker_main, this);
+  {
+    std::lock_guard<std::mutex> lk(wm_);
+    std::memcpy(job_x_, x26, sizeof(job_x_));
+    job_stamp_ = stamp;
+    busy_ = true;
+  }
+  wcv_.notify_all();
+}
 
 bool Mapper::attach(int device, float cell_size) {
+  sync();
   if (ctx_) return true;
   device_ = device;
   cell_size_ = cell_size;
@@ -255,17 +301,19 @@ bool Mapper::attach(int device, float cell_size) {
 void Mapper::set_num_threads(int n) { if (n >= 1) num_threads_ = n; }
 void Mapper::set_config(const Config::iKFoM::Mapping& cfg) {       // Mapper.cpp:38-45
   config = cfg;
+  sync();
   if (ctx_) {
     flimo_map_cfg mc{config.octree.min_extent, config.octree.bucket_size, config.octree.downsampling ? 1 : 0, cell_size_};
     flimo_map_config(ctx_, &mc);
   }
 }
-bool Mapper::exists() { return ctx_ && flimo_map_size(ctx_) > 0; }
-int Mapper::size() { return ctx_ ? (int)flimo_map_size(ctx_) : 0; }
-double Mapper::last_time() { return ctx_ ? flimo_map_last_time(ctx_) : -1.0; }
+bool Mapper::exists() { sync(); return ctx_ && flimo_map_size(ctx_) > 0; }
+int Mapper::size() { sync(); return ctx_ ? (int)flimo_map_size(ctx_) : 0; }
+double Mapper::last_time() { sync(); return ctx_ ? flimo_map_last_time(ctx_) : -1.0; }
 
 void Mapper::add(pcl::PointCloud<PointType>::Ptr& pc, double time) {   // Mapper.cpp:88-96
   if (!pc || pc->points.size() < 1) return;
+  sync();
   if (!ctx_ && !attach(device_, cell_size_)) return;
   const int rc = flimo_map_add(ctx_, &pc->points[0].x, pc->points.size(), sizeof(PointType), time);
   if (rc != FLIMO_OK) std::cout << "FAST_LIMO::Mapper::add failed: " << flimo_last_error(ctx_) << "\n";
@@ -1014,10 +1062,7 @@ void Localizer::updatePointCloud(pcl::PointCloud<PointType>::Ptr& raw_pc, double
       final_scan = std::make_shared<pcl::PointCloud<PointType>>(*pc2match);
       for (size_t k = 0; k < n && k < final_scan->points.size(); k++) { final_scan->points[k].x = w[3 * k]; final_scan->points[k].y = w[3 * k + 1]; final_scan->points[k].z = w[3 * k + 2]; }
     }
-    if (add_to_map) {
-      const int rc = flimo_map_add_scan(c, x26, scan_stamp);
-      if (rc != FLIMO_OK) std::cout << "FAST_LIMO::map insert failed: " << flimo_last_error(c) << "\n";
-    }
+    if (add_to_map) map_->add_scan(x26, scan_stamp);               // returns at once; the insert overlaps the next scan's host work
     t4 = now_s();
   } else {
     std::cout << "-------------- FAST_LIMO::NULL ITERATION --------------\n";

@@ -4,6 +4,9 @@
 // filter itself uses the reduced seam (match_reduce) instead of materialising Matches.
 #ifndef __FASTLIMO_MAPPER_HPP__
 #define __FASTLIMO_MAPPER_HPP__
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include "fast_limo/Common.hpp"
 #include "fast_limo/Objects/Match.hpp"
 #include "fast_limo/Objects/State.hpp"
@@ -31,7 +34,17 @@ class fast_limo::Mapper {
   // one Mapper per GPU; getInstance() keeps the reference's process-wide singleton on device 0
   explicit Mapper(int device);
   bool attach(int device, float cell_size);     // creates the flimo_ctx; false + message on failure
-  flimo_ctx* ctx() { return ctx_; }
+  // The handle of the GPU context.  A map insert started by add_scan() may still be running on the Mapper's worker
+  // thread: ctx() (like every other method of this class) waits for it first, so whoever holds the handle sees a
+  // quiescent context.  Re-fetch it after each Localizer::updatePointCloud instead of caching it across scans.
+  flimo_ctx* ctx() { sync(); return ctx_; }
+  // Path exit of a scan (reference Localizer.cpp:361-377: transformPointCloud + Mapper::add) for the scan RESIDENT on
+  // the GPU: returns at once, the insert runs on the worker thread and overlaps the host-side preparation (filters,
+  // time sort) of the next scan.  FLIMO_SYNC_INSERT=1 (or set_async(false)) makes it synchronous.
+  void add_scan(const double x26[26], double stamp);
+  void sync();                                  // wait for a running insert (no-op when idle)
+  void set_async(bool on) { sync(); async_ = on; }
+  double last_insert_seconds() { sync(); return insert_seconds_; }
   const Config::iKFoM::Mapping& config_ref() const { return config; }
   const std::string& last_error() const { return err_; }
 
@@ -47,6 +60,17 @@ class fast_limo::Mapper {
   int device_;
   float cell_size_;
   std::string err_;
+  // worker of add_scan()
+  bool async_;
+  std::thread worker_;
+  std::mutex wm_;
+  std::condition_variable wcv_;
+  bool busy_ = false, quit_ = false;
+  double job_x_[26];
+  double job_stamp_ = 0.0;
+  double insert_seconds_ = 0.0;
+  void run_insert(const double x26[26], double stamp);
+  void worker_main();
   Mapper(const Mapper&) = delete;
   Mapper& operator=(const Mapper&) = delete;
 };

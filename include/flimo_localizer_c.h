@@ -45,7 +45,13 @@ typedef struct flimo_loc_cfg {
 
 int    flimo_loc_create(const flimo_loc_cfg* cfg, flimo_loc** out);   /* Localizer::init */
 void   flimo_loc_destroy(flimo_loc* L);
-flimo_ctx* flimo_loc_ctx(flimo_loc* L);                               /* the Mapper's GPU context */
+/* The Mapper's GPU context.  The map insert that ends a scan (reference Localizer.cpp:361-377) runs on a worker thread
+ * and may still be in flight when flimo_loc_update_pointcloud* returns; this call (like every flimo_loc_* call that
+ * touches the map) waits for it first.  Fetch the handle again after each scan rather than caching it. */
+flimo_ctx* flimo_loc_ctx(flimo_loc* L);
+void   flimo_loc_sync(flimo_loc* L);                                  /* wait for a running map insert */
+void   flimo_loc_set_async_insert(flimo_loc* L, int on);              /* default on; FLIMO_SYNC_INSERT=1 turns it off */
+double flimo_loc_last_insert_seconds(flimo_loc* L);                   /* duration of the last insert (waits for it) */
 int    flimo_loc_update_imu(flimo_loc* L, double stamp, const float ang_vel[3], const float lin_accel[3]);
 /* pts5: n x (x y z intensity time[s since sweep reference]).  Returns Localizer status:
  * 0 ok, 1 null iteration, <0 early return */

@@ -80,3 +80,42 @@ def test_pcd_sequence_replay_ate(built, oracle, tmp_path):
         D.update_pointcloud(scans[k], 0.1 * k)
         np.testing.assert_array_equal(D.get_x(), pg[k])
     G.close(); D.close()
+
+
+def test_async_map_insert_is_invisible(built):
+    """The map insert that ends a scan runs on the Mapper's worker thread (Mapper::add_scan) and overlaps the host-side
+    preparation of the next scan.  Nothing observable may depend on it: the same drive with the insert synchronous gives
+    bit-identical states, covariances, map sizes and map contents, and queries made right after a scan (map size, the
+    raw context handle) see the finished insert."""
+    from fast_limo_amd import api
+    n_scans, n_pts, speed = 10, 6000, 10.0
+    st, w, a = synth.stationary_imu(0.0, 0.1 * n_scans + 0.06)
+
+    def drive(async_on):
+        G = api.Localizer(api.default_cfg(**CAPS))
+        G.set_async_insert(async_on)
+        x0 = G.get_x(); x0[14] = speed; G.set_x(x0)
+        i = 0
+        out = []
+        for k in range(n_scans):
+            until = 0.1 * (k + 1) + 0.005
+            while i < len(st) and st[i] <= until:
+                G.update_imu(st[i], w[i], a[i]); i += 1
+            rc = G.update_pointcloud(synth.corridor_scan(k, n_pts, 55, speed=speed), 0.1 * k)
+            if k % 3 == 0:
+                out.append((rc, G.get_x().copy(), G.get_P().copy(), G.map_size(), G.hip.map_size()))   # queried at once
+            else:
+                out.append((rc, G.get_x().copy(), G.get_P().copy(), None, None))                        # not queried: stays in flight
+        pts = G.hip.map_points()
+        G.close()
+        return out, pts
+
+    a_out, a_pts = drive(True)
+    s_out, s_pts = drive(False)
+    for k, (ra, rs) in enumerate(zip(a_out, s_out)):
+        assert ra[0] == rs[0], k
+        np.testing.assert_array_equal(ra[1], rs[1], err_msg=f"x scan {k}")
+        np.testing.assert_array_equal(ra[2], rs[2], err_msg=f"P scan {k}")
+        assert ra[3] == rs[3] and ra[4] == rs[4] and ra[3] == ra[4], k
+    assert a_pts.shape[0] > 3 * n_pts
+    np.testing.assert_array_equal(a_pts, s_pts)
