@@ -56,7 +56,7 @@ HIP_SYMBOLS = [
     "flimo_scan_voxel_filter", "flimo_raw_scan_set", "flimo_deskew_resident", "flimo_deskew",
     "flimo_match_reduce", "flimo_match_fetch", "flimo_match_fetch_H",
     "flimo_scan_to_world", "flimo_map_add_scan",
-    "flimo_set_timing", "flimo_set_timing_stride", "flimo_pass_count", "flimo_set_debug_records", "flimo_set_lanes_per_query", "flimo_last_kernel_ms",
+    "flimo_set_timing", "flimo_set_timing_stride", "flimo_pass_count", "flimo_map_grid_selfcheck", "flimo_set_debug_records", "flimo_set_lanes_per_query", "flimo_last_kernel_ms",
     "flimo_last_candidates_per_query", "flimo_last_widen_count", "flimo_timing_totals", "flimo_insert_rule_replay", "flimo_plane_fit5_host", "flimo_plane_eval5_host", "flimo_calculate_H_host",
 ]
 
@@ -111,6 +111,8 @@ def load_hip():
     L.flimo_set_timing_stride.argtypes = [vp, C.c_int]
     L.flimo_pass_count.restype = C.c_ulonglong
     L.flimo_pass_count.argtypes = [vp]
+    L.flimo_map_grid_selfcheck.restype = C.c_int
+    L.flimo_map_grid_selfcheck.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.flimo_set_debug_records.argtypes = [vp, C.c_int]
     L.flimo_set_lanes_per_query.argtypes = [vp, C.c_int]
     L.flimo_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
@@ -274,6 +276,13 @@ class HipCtx:
 
     def pass_count(self) -> int:
         return int(self._L.flimo_pass_count(self._h))
+
+    def grid_selfcheck(self):
+        """(mismatching words of the incrementally maintained index vs a from-scratch sort, merges, full builds)."""
+        mm = C.c_uint64(0)
+        st = (C.c_uint64 * 2)()
+        self._chk(self._L.flimo_map_grid_selfcheck(self._h, C.byref(mm), st))
+        return int(mm.value), int(st[0]), int(st[1])
 
     def set_debug_records(self, on=True):
         self._chk(self._L.flimo_set_debug_records(self._h, int(on)))

@@ -38,6 +38,13 @@ struct flimo_ctx {
   // map
   float4* d_map_raw = nullptr;     // insertion order
   float4* d_map_sorted = nullptr;  // cell order
+  float4* d_map_sorted2 = nullptr; // the other half of the double buffer of the incremental merge (lazy)
+  float gbox[6] = {0, 0, 0, 0, 0, 0};   // box the grid geometry was laid out for (the map box plus slack on the sides that grew)
+  bool have_gbox = false;
+  unsigned heavy_threshold = 0xffffffffu; // FLIMO_HEAVY=<n>: a query whose 3x3x3 block holds more than n candidates goes to the wave-per-query kernel (default: never)
+  bool force_full = false;         // the next index update lays the grid out afresh (cell size changed)
+  bool full_rebuild = false;       // FLIMO_FULL_REBUILD=1: sort the whole map on every insert (A/B of the merge)
+  uint64_t grid_merges = 0, grid_builds = 0;
   size_t map_n = 0, map_cap = 0;
   uint32_t* d_cell_start = nullptr;
   size_t cell_cap = 0;
@@ -261,6 +268,10 @@ extern "C" int flimo_ctx_create(int device, flimo_ctx** out) {
   if (e) set_xcd_stripe(atoi(e));
   e = getenv("FLIMO_HOST_INSERT");
   c->host_insert = e && atoi(e) != 0;
+  e = getenv("FLIMO_HEAVY");
+  if (e) { const long v = atol(e); c->heavy_threshold = v > 0 ? (unsigned)v : 0xffffffffu; }
+  e = getenv("FLIMO_FULL_REBUILD");
+  c->full_rebuild = e && atoi(e) != 0;
   *out = c;
   return FLIMO_OK;
 }
@@ -269,7 +280,7 @@ extern "C" void flimo_ctx_destroy(flimo_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  (void)hipFree(c->d_map_raw); (void)hipFree(c->d_map_sorted); (void)hipFree(c->d_cell_start); (void)hipFree(c->d_row_table);
+  (void)hipFree(c->d_map_raw); (void)hipFree(c->d_map_sorted); (void)hipFree(c->d_map_sorted2); (void)hipFree(c->d_cell_start); (void)hipFree(c->d_row_table);
   (void)hipFree(c->d_scan_sorted); (void)hipFree(c->d_nbr); (void)hipFree(c->d_wl); (void)hipFree(c->d_wl_count);
   (void)hipFree(c->d_fit_partials); (void)hipFree(c->d_raw_sorted); (void)hipFree(c->d_t_sorted);
   (void)hipFree(c->d_scan); (void)hipFree(c->d_scan_raw); (void)hipFree(c->d_scan_world); (void)hipFree(c->d_scan_t);
@@ -293,8 +304,10 @@ extern "C" void flimo_ctx_destroy(flimo_ctx* c) {
 extern "C" int flimo_map_config(flimo_ctx* c, const flimo_map_cfg* cfg) {
   if (!c || !cfg) return FLIMO_ERR_INVALID;
   if (!(cfg->min_extent > 0.f)) return fail(c, FLIMO_ERR_INVALID, "min_extent must be > 0");
+  const float cell_before = c->map_cfg.cell_size;
   c->map_cfg = *cfg;
   if (!(c->map_cfg.cell_size > 0.f)) c->map_cfg.cell_size = 0.5f;
+  if (c->map_cfg.cell_size != cell_before) { c->force_full = true; c->have_gbox = false; }   // takes effect at the next index update
   insert_book_config(c->book, cfg->min_extent, cfg->downsample != 0);
   return FLIMO_OK;
 }
@@ -303,6 +316,7 @@ extern "C" int flimo_map_clear(flimo_ctx* c) {
   if (!c) return FLIMO_ERR_INVALID;
   c->map_n = 0;
   c->grid_valid = false;
+  c->have_gbox = false;
   c->map_last_time = -1.0;
   c->bb[0] = c->bb[1] = c->bb[2] = 3.4e38f; c->bb[3] = c->bb[4] = c->bb[5] = -3.4e38f;
   insert_book_clear(c->book);
@@ -314,25 +328,91 @@ extern "C" int flimo_map_clear(flimo_ctx* c) {
 extern "C" size_t flimo_map_size(const flimo_ctx* c) { return c ? c->map_n : 0; }
 extern "C" double flimo_map_last_time(const flimo_ctx* c) { return c ? c->map_last_time : -1.0; }
 
+// Does the current grid geometry hold every point of box `bb` with the margins the kernels assume (lowest cell index
+// >= 0, highest <= n-2)?  Same float expressions as the kernels.
+static bool grid_covers(const GridView& g, const float* bb) {
+  const float o[3] = {g.ox, g.oy, g.oz};
+  const int n[3] = {g.nx, g.ny, g.nz};
+  for (int a = 0; a < 3; a++) {
+    if (!(o[a] <= bb[a] - 0.5f * g.cell)) return false;
+    if ((int)floorf((bb[a] - o[a]) * g.inv_cell) < 0) return false;
+    if ((int)floorf((bb[3 + a] - o[a]) * g.inv_cell) > n[a] - 2) return false;
+  }
+  return true;
+}
+static int publish_row_table(flimo_ctx* c, int nx, int ny, int nz, bool same_shape) {
+  const size_t rt = row_table_size(nx, ny, nz);
+  if (rt > c->row_cap) {
+    if (c->d_row_table) (void)hipFree(c->d_row_table);
+    c->d_row_table = nullptr;
+    const size_t cap = rt + rt / 2;
+    HIPCHK(c, hipMalloc(&c->d_row_table, cap * sizeof(uint32_t)));
+    c->row_cap = cap;
+  }
+  HIPCHK(c, map_build_row_table(c->stream, c->d_cell_start, nx, ny, nz, c->d_row_table, !same_shape));
+  return FLIMO_OK;
+}
+
+// Brings the cell-sorted copy of the map and its tables up to date with d_map_raw[0 .. map_n).
+//  * merge: the geometry still covers the map box and only points were appended since the last build -> the tail is merged
+//    into the sorted array (one streaming pass, map_merge_grid);
+//  * build: first build, or the map outgrew the geometry -> new geometry, laid out with slack on the sides that grew so
+//    that a sensor moving through new territory triggers it rarely, and a full sort.
 static int rebuild_grid(flimo_ctx* c) {
   (void)hipSetDevice(c->device);
-  c->grid_valid = false;
-  if (c->map_n == 0) return FLIMO_OK;
+  if (c->map_n == 0) { c->grid_valid = false; return FLIMO_OK; }
   const float* bb = c->bb;    // tracked on the host while points are appended (no reduction kernel)
-  float cell = c->map_cfg.cell_size > 0.f ? c->map_cfg.cell_size : 0.5f;
-  int nx, ny, nz;
-  float ox, oy, oz, inv;
-  for (;;) {
-    inv = 1.0f / cell;
-    ox = bb[0] - 0.5f * cell; oy = bb[1] - 0.5f * cell; oz = bb[2] - 0.5f * cell;
-    // same float expression as the kernels: floor((p - o) * inv)
-    nx = (int)floorf((bb[3] - ox) * inv) + 2;
-    ny = (int)floorf((bb[4] - oy) * inv) + 2;
-    nz = (int)floorf((bb[5] - oz) * inv) + 2;
-    const double ncells = (double)nx * ny * nz;
-    if (ncells < 1.9e9 && (double)row_table_size(nx, ny, nz) < 4.0e9) break;   // both indices stay 32-bit addressable
-    cell *= 2.0f;   // keep the dense index addressable with 32 bits
+  if (c->grid_valid && c->d_map_sorted && !c->full_rebuild && !c->force_full && c->grid.n_pts > 0 && c->map_n >= c->grid.n_pts &&
+      (c->map_n - c->grid.n_pts) <= c->grid.n_pts && grid_covers(c->grid, bb)) {
+    const size_t n_old = c->grid.n_pts, k = c->map_n - n_old;
+    if (k == 0) return FLIMO_OK;
+    c->grid_valid = false;
+    if (!c->d_map_sorted2) HIPCHK(c, hipMalloc(&c->d_map_sorted2, c->map_cap * sizeof(float4)));
+    const GridView& g = c->grid;
+    const size_t ncells = (size_t)g.nx * g.ny * g.nz;
+    HIPCHK(c, map_merge_grid(c->stream, c->d_map_sorted, n_old, c->d_map_raw + n_old, k, c->d_map_sorted2, c->d_cell_start, ncells,
+                             g.ox, g.oy, g.oz, g.inv_cell, g.nx, g.ny, g.nz, c->scratch));
+    int rc = publish_row_table(c, g.nx, g.ny, g.nz, true);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::swap(c->d_map_sorted, c->d_map_sorted2);
+    c->grid.pts = c->d_map_sorted;
+    c->grid.row_table = c->d_row_table;
+    c->grid.n_pts = (uint32_t)c->map_n;
+    c->grid_valid = true;
+    c->grid_merges++;
+    return FLIMO_OK;
   }
+  c->grid_valid = false;
+  float cell = c->map_cfg.cell_size > 0.f ? c->map_cfg.cell_size : 0.5f;
+  int nx = 0, ny = 0, nz = 0;
+  float ox = 0.f, oy = 0.f, oz = 0.f, inv = 1.f;
+  float W[6];
+  auto layout = [&](const float* box) {
+    inv = 1.0f / cell;
+    ox = box[0] - 0.5f * cell; oy = box[1] - 0.5f * cell; oz = box[2] - 0.5f * cell;
+    // same float expression as the kernels: floor((p - o) * inv)
+    nx = (int)floorf((box[3] - ox) * inv) + 2;
+    ny = (int)floorf((box[4] - oy) * inv) + 2;
+    nz = (int)floorf((box[5] - oz) * inv) + 2;
+    const double ncells = (double)nx * ny * nz;
+    return ncells < 1.9e9 && (double)row_table_size(nx, ny, nz) < 4.0e9;   // both indices stay 32-bit addressable
+  };
+  // slack: a side the map has grown beyond since the last layout moves out by max(8 cells, 1/8 of the extent)
+  for (int a = 0; a < 3; a++) { W[a] = bb[a]; W[3 + a] = bb[3 + a]; }
+  if (c->have_gbox) {
+    for (int a = 0; a < 3; a++) {
+      const float pad = std::max(8.0f * cell, 0.125f * (bb[3 + a] - bb[a]));
+      W[a] = (bb[a] < c->gbox[a]) ? bb[a] - pad : c->gbox[a];
+      W[3 + a] = (bb[3 + a] > c->gbox[3 + a]) ? bb[3 + a] + pad : c->gbox[3 + a];
+    }
+  }
+  if (!layout(W)) {
+    for (int a = 0; a < 6; a++) W[a] = bb[a];
+    while (!layout(W)) cell *= 2.0f;   // keep the dense index addressable with 32 bits
+  }
+  for (int a = 0; a < 6; a++) c->gbox[a] = W[a];
+  c->have_gbox = true;
   const size_t ncells = (size_t)nx * ny * nz;
   if (!c->d_map_sorted) HIPCHK(c, hipMalloc(&c->d_map_sorted, c->map_cap * sizeof(float4)));   // mirrors the raw capacity (freed whenever that grows)
   if (ncells + 1 > c->cell_cap) {
@@ -345,15 +425,8 @@ static int rebuild_grid(flimo_ctx* c) {
   HIPCHK(c, map_build_grid(c->stream, c->d_map_raw, c->map_n, c->d_map_sorted, c->d_cell_start, ncells, ox, oy, oz, inv,
                            nx, ny, nz, c->scratch));
   {
-    const size_t rt = row_table_size(nx, ny, nz);
-    if (rt > c->row_cap) {
-      if (c->d_row_table) (void)hipFree(c->d_row_table);
-      c->d_row_table = nullptr;
-      const size_t cap = rt + rt / 2;
-      HIPCHK(c, hipMalloc(&c->d_row_table, cap * sizeof(uint32_t)));
-      c->row_cap = cap;
-    }
-    HIPCHK(c, map_build_row_table(c->stream, c->d_cell_start, nx, ny, nz, c->d_row_table));
+    int rc = publish_row_table(c, nx, ny, nz, false);
+    if (rc) return rc;
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->grid.pts = c->d_map_sorted;
@@ -365,6 +438,43 @@ static int rebuild_grid(flimo_ctx* c) {
   c->grid.nx = nx; c->grid.ny = ny; c->grid.nz = nz;
   c->grid.n_pts = (uint32_t)c->map_n;
   c->grid_valid = true;
+  c->force_full = false;
+  c->grid_builds++;
+  return FLIMO_OK;
+}
+
+// Debug: sort the whole map again with the CURRENT geometry into temporary buffers and compare the result with the
+// incrementally maintained index (points, cell table, row table).  stats = {merges, full builds} so far.
+extern "C" int flimo_map_grid_selfcheck(flimo_ctx* c, uint64_t* mismatches, uint64_t stats[2]) {
+  if (!c || !mismatches) return FLIMO_ERR_INVALID;
+  if (stats) { stats[0] = c->grid_merges; stats[1] = c->grid_builds; }
+  *mismatches = 0;
+  if (!c->grid_valid) return FLIMO_OK;
+  (void)hipSetDevice(c->device);
+  const GridView& g = c->grid;
+  const size_t n = c->map_n, ncells = (size_t)g.nx * g.ny * g.nz, rt = row_table_size(g.nx, g.ny, g.nz);
+  if (g.n_pts != n) { *mismatches = 1; return FLIMO_OK; }
+  struct Tmp {
+    float4* pts = nullptr; uint32_t* cs = nullptr; uint32_t* row = nullptr;
+    ~Tmp() { (void)hipFree(pts); (void)hipFree(cs); (void)hipFree(row); }
+  } t;
+  HIPCHK(c, hipMalloc(&t.pts, n * sizeof(float4)));
+  HIPCHK(c, hipMalloc(&t.cs, (ncells + 1) * sizeof(uint32_t)));
+  HIPCHK(c, hipMalloc(&t.row, rt * sizeof(uint32_t)));
+  HIPCHK(c, map_build_grid(c->stream, c->d_map_raw, n, t.pts, t.cs, ncells, g.ox, g.oy, g.oz, g.inv_cell, g.nx, g.ny, g.nz, c->scratch));
+  HIPCHK(c, map_build_row_table(c->stream, t.cs, g.nx, g.ny, g.nz, t.row));
+  auto differ = [&](const void* a, const void* b, size_t bytes, uint64_t& out) -> int {
+    std::vector<unsigned char> ha(bytes), hb(bytes);
+    HIPCHK(c, hipMemcpyAsync(ha.data(), a, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(hb.data(), b, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i + 4 <= bytes; i += 4) out += memcmp(&ha[i], &hb[i], 4) != 0;
+    return FLIMO_OK;
+  };
+  int rc;
+  if ((rc = differ(t.pts, g.pts, n * sizeof(float4), *mismatches))) return rc;
+  if ((rc = differ(t.cs, g.cell_start, (ncells + 1) * sizeof(uint32_t), *mismatches))) return rc;
+  if ((rc = differ(t.row, g.row_table, rt * sizeof(uint32_t), *mismatches))) return rc;
   return FLIMO_OK;
 }
 
@@ -375,7 +485,7 @@ static int map_append_host(flimo_ctx* c, const float4* pts, size_t n) {
   const size_t old_cap = c->map_cap;
   int rc = ensure_dev(c, c->d_map_raw, c->map_cap, c->map_n + n, true, c->map_n);
   if (rc) return rc;
-  if (c->map_cap != old_cap && c->d_map_sorted) { (void)hipFree(c->d_map_sorted); c->d_map_sorted = nullptr; }
+  if (c->map_cap != old_cap && c->d_map_sorted) { (void)hipFree(c->d_map_sorted); (void)hipFree(c->d_map_sorted2); c->d_map_sorted = c->d_map_sorted2 = nullptr; c->grid_valid = false; }
   HIPCHK(c, hipMemcpyAsync(c->d_map_raw + c->map_n, pts, n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->map_n += n;
@@ -399,7 +509,7 @@ static int map_add_device(flimo_ctx* c, const float4* d_pts, size_t m, double st
     const size_t old_cap = c->map_cap;
     int rc = ensure_dev(c, c->d_map_raw, c->map_cap, c->map_n + m, true, c->map_n);
     if (rc) return rc;
-    if (c->map_cap != old_cap && c->d_map_sorted) { (void)hipFree(c->d_map_sorted); c->d_map_sorted = nullptr; }
+    if (c->map_cap != old_cap && c->d_map_sorted) { (void)hipFree(c->d_map_sorted); (void)hipFree(c->d_map_sorted2); c->d_map_sorted = c->d_map_sorted2 = nullptr; c->grid_valid = false; }
     int kept = 0;
     if (!c->gbook.active)        // first batch: Octree::initialize on the device
       HIPCHK(c, c->gbook.init(c->stream, d_pts, (int)m, bb, c->d_map_raw, &kept, c->map_cfg.min_extent, c->map_cfg.downsample != 0,
@@ -811,6 +921,7 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   const int tlev = (c->timing == 1 && c->timing_stride > 1 && ((c->pass_seq + 1) % (unsigned long long)c->timing_stride) != 0) ? 0 : c->timing;
   if (tlev > 1) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   // level 1: the two events ride on the k-NN dispatch itself (kernel begin / end, no extra packets)
+  c->prev.heavy = (mp.max_ring >= 2 && mp.max_ring <= 3) ? c->heavy_threshold : 0xffffffffu;   // only when the wave-per-query kernel follows
   launch_knn5(c->stream, c->lanes_per_query, c->grid, c->d_scan_sorted, n_all, P, mp.max_ring, c->d_nbr, c->d_wl,
               c->d_wl_count, c->debug_recs ? c->d_cand : nullptr, c->prev, tlev == 1 ? c->ev[0] : nullptr,
               tlev == 1 ? c->ev[1] : nullptr);

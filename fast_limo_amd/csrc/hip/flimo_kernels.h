@@ -61,8 +61,13 @@ hipError_t sort_scan(hipStream_t st, const float4* in, size_t n, float4* out, Ma
 hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4* pts_out, uint32_t* cell_start,
                           size_t ncells, float ox, float oy, float oz, float inv_cell, int nx, int ny, int nz,
                           MapBuildScratch& S);
+// Merges the k points appended since the last build into the cell-sorted array (same geometry): out_sorted and cell_start
+// become what map_build_grid gives for all n_old + k points.  cell_start is updated in place; out_sorted != old_sorted.
+hipError_t map_merge_grid(hipStream_t st, const float4* old_sorted, size_t n_old, const float4* new_pts, size_t k,
+                          float4* out_sorted, uint32_t* cell_start, size_t ncells, float ox, float oy, float oz,
+                          float inv_cell, int nx, int ny, int nz, MapBuildScratch& S);
 size_t row_table_size(int nx, int ny, int nz);
-hipError_t map_build_row_table(hipStream_t st, const uint32_t* cell_start, int nx, int ny, int nz, uint32_t* out);
+hipError_t map_build_row_table(hipStream_t st, const uint32_t* cell_start, int nx, int ny, int nz, uint32_t* out, bool zero_pads = true);
 // pcl::VoxelGrid on device points: out gets one centroid per occupied voxel in ascending voxel index
 hipError_t voxel_grid(hipStream_t st, const float4* in, size_t n, float leaf, float4* out, size_t* n_out, bool* passthrough,
                       MapBuildScratch& S);

@@ -471,7 +471,11 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
           }
         }
       }
-      const uint32_t total = off[9];
+      // A query whose block is crowded (a few cells right under the sensor hold hundreds of points once scans have been
+      // inserted) would keep its whole wave waiting while its two lanes walk the stream: it is handed to the wave-per-query
+      // kernel instead (same 3x3x3 block, 64 lanes), like the queries that need a wider block.
+      const bool heavy = off[9] > prev.heavy;
+      const uint32_t total = heavy ? 0u : off[9];
       TRACE(0, 2);
       // ---- flattened candidate stream, branch-free body ----
       const double none = __longlong_as_double((long long)KEY_NONE);
@@ -517,6 +521,7 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
       if (have5 && (covers || d5 <= rg * rg * (1.f - 1.0e-6f))) flag = 1;
       else if (covers) flag = 0;                 // the whole map holds fewer than 5 points
       else flag = (max_ring > 1) ? 2 : 0;
+      if (heavy) flag = 3;              // pending like 2, and the wider search starts at the 3x3x3 block itself
     }
   }
   if (cand_total) {
@@ -529,17 +534,18 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
   if (sub == 0) {
     int4 a, b;
     a.x = (int)(uint32_t)best[0]; a.y = (int)(uint32_t)best[1]; a.z = (int)(uint32_t)best[2]; a.w = (int)(uint32_t)best[3];
-    b.x = (int)(uint32_t)best[4]; b.y = flag; b.z = (int)(uint32_t)(best[4] >> 32); b.w = (flag == 1) ? 1 : 0;   // d5 for the next pass
+    b.x = (int)(uint32_t)best[4]; b.y = min(flag, 2); b.z = (int)(uint32_t)(best[4] >> 32); b.w = (flag == 1) ? 1 : 0;   // d5 for the next pass
     int4* o = reinterpret_cast<int4*>(&nbr[p]);
     o[0] = a;
     o[1] = b;
-    if (flag == 2) {
+    if (flag >= 2) {
       // worklist entry = everything the widening wave needs to start (no dependent loads on its side):
       // query index, world position, 5th squared distance found inside the 3x3x3 block (+inf: none)
       const int slot = atomicAdd(wl_count, 1);
       int4* e = reinterpret_cast<int4*>(wl) + 2 * (size_t)slot;
       e[0] = make_int4(p, __float_as_int(gx), __float_as_int(gy), __float_as_int(gz));
-      e[1] = make_int4((int)(uint32_t)(best[4] >> 32), 0, 0, 0);
+      // .y: first ring of the wave-per-query search; .z: this pass's pruning bound (cell units, squared; +inf: none)
+      e[1] = make_int4((int)(uint32_t)(best[4] >> 32), flag == 3 ? 1 : 2, __float_as_int(b2), 0);
     }
   }
   TRACE(0, 5);
@@ -581,7 +587,7 @@ __global__ __launch_bounds__(256) void widen_kernel(GridView G, const float4* __
     u64 best[5] = {KEY_NONE, KEY_NONE, KEY_NONE, KEY_NONE, KEY_NONE};
     int flag = 0;
     int cand = 0;
-    int r = 2;
+    int r = (e1.y == 1) ? 1 : 2;                       // 1: a crowded 3x3x3 block handed over unsearched
     {
       const float hint = __int_as_float(hint_bits);
       if (hint >= 0.f && hint < INFINITY) {            // an upper bound of the true 5th distance: go straight to its ring
@@ -596,7 +602,21 @@ __global__ __launch_bounds__(256) void widen_kernel(GridView G, const float4* __
       uint32_t lo = 0, len = 0;
       if (lane < side * side) {
         const int yy = cy + (lane % side) - r, zz = cz + (lane / side) - r;
-        const int x0 = max(cx - r, 0), x1 = min(cx + r, G.nx - 1);
+        int x0 = max(cx - r, 0), x1 = min(cx + r, G.nx - 1);
+        if (r == 1) {
+          // a crowded 3x3x3 block handed over by the fast path: the same exact pruning by the previous pass's bound
+          // (rows and end cells that cannot hold any of the five nearest points are skipped)
+          const float b2 = __int_as_float(e1.z);
+          const int ky = lane % 3, kz = lane / 3;
+          const float ydl = fmaxf(ry - margin, 0.f), ydr = fmaxf(1.f - ry - margin, 0.f);
+          const float zdl = fmaxf(rz - margin, 0.f), zdr = fmaxf(1.f - rz - margin, 0.f);
+          const float yd = ky == 0 ? ydl : (ky == 2 ? ydr : 0.f), zd = kz == 0 ? zdl : (kz == 2 ? zdr : 0.f);
+          const float dyz2 = yd * yd + zd * zd;
+          const float xl = fmaxf(rx - margin, 0.f), xr = fmaxf(1.f - rx - margin, 0.f);
+          if (!(dyz2 + xl * xl <= b2)) x0 = max(cx, 0);
+          if (!(dyz2 + xr * xr <= b2)) x1 = min(cx, G.nx - 1);
+          if (!(dyz2 <= b2)) x1 = x0 - 1;                 // empty row
+        }
         if (yy >= 0 && yy < G.ny && zz >= 0 && zz < G.nz && x0 <= x1) {
           const size_t rowbase = ((size_t)zz * (size_t)G.ny + (size_t)yy) * (size_t)G.nx;
           lo = G.cell_start[rowbase + x0];

@@ -163,22 +163,142 @@ hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4
   return hipGetLastError();
 }
 
+// ---- incremental update of the cell-sorted map ------------------------------------------------
+// The map only grows (the insert rule drops incoming points, never stored ones), so when the grid geometry still covers
+// the map the k points appended since the last build are MERGED into the sorted array instead of sorting everything
+// again: the new points are sorted by cell (k is a scan, not the map), every stored point moves up by the number of new
+// points in lower cells, every new point lands behind the stored points of its cell -- exactly the array a stable sort
+// of (stored points..., new points...) by cell gives, i.e. what map_build_grid produces for the same geometry.
+// One streaming pass over the points and one over the cell table; the binary searches over the k new keys are done
+// once per block (first / last element) and only blocks that straddle a new key search per element.
+__device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t* __restrict__ keys, uint32_t lo, uint32_t hi, uint32_t key) {
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (keys[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+// new point j (cell-sorted) -> behind the stored points of its cell: position = j + #stored points in cells <= key
+__global__ __launch_bounds__(256) void merge_new_kernel(const float4* __restrict__ new_pts, const uint32_t* __restrict__ nkeys,
+                                                        const uint32_t* __restrict__ nperm, uint32_t k,
+                                                        const uint32_t* __restrict__ cell_start_old, float4* __restrict__ out) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= k) return;
+  out[(size_t)cell_start_old[(size_t)nkeys[j] + 1] + j] = new_pts[nperm[j]];
+}
+// stored point i (cell-sorted) -> i + #new points in cells < its cell
+__global__ __launch_bounds__(256) void merge_old_kernel(const float4* __restrict__ old_pts, uint32_t n_old,
+                                                        const uint32_t* __restrict__ nkeys, uint32_t k, float ox, float oy, float oz,
+                                                        float inv_cell, int nx, int ny, int nz, float4* __restrict__ out) {
+  __shared__ uint32_t s_lo, s_hi;
+  const uint32_t base = blockIdx.x * blockDim.x;
+  const uint32_t i = base + threadIdx.x;
+  const uint32_t last = min(n_old, base + blockDim.x) - 1u;
+  float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+  uint32_t cid = 0;
+  if (i < n_old) {
+    p = old_pts[i];
+    int cx = (int)floorf((p.x - ox) * inv_cell);
+    int cy = (int)floorf((p.y - oy) * inv_cell);
+    int cz = (int)floorf((p.z - oz) * inv_cell);
+    cx = min(max(cx, 0), nx - 1);
+    cy = min(max(cy, 0), ny - 1);
+    cz = min(max(cz, 0), nz - 1);
+    cid = (uint32_t)(((size_t)cz * ny + cy) * nx + cx);
+    if (i == base) s_lo = lower_bound_u32(nkeys, 0u, k, cid);
+    if (i == last) s_hi = lower_bound_u32(nkeys, 0u, k, cid + 1u);
+  }
+  __syncthreads();
+  if (i >= n_old) return;
+  const uint32_t lo = s_lo, hi = s_hi;
+  const uint32_t shift = (lo == hi) ? lo : lower_bound_u32(nkeys, lo, hi, cid);
+  out[(size_t)i + shift] = p;
+}
+// cell_start[c] += #new points in cells < c   (c = 0 .. ncells; the last entry becomes the new point count)
+__global__ __launch_bounds__(256) void cellstart_shift_kernel(uint32_t* __restrict__ cell_start, size_t n_entries,
+                                                              const uint32_t* __restrict__ nkeys, uint32_t k) {
+  __shared__ uint32_t s_lo, s_hi;
+  constexpr int PER = 16;
+  const size_t base = (size_t)blockIdx.x * (blockDim.x * PER);
+  const size_t top = min(n_entries, base + (size_t)blockDim.x * PER) - 1;
+  if (threadIdx.x == 0) s_lo = lower_bound_u32(nkeys, 0u, k, (uint32_t)base);
+  if (threadIdx.x == 64) s_hi = lower_bound_u32(nkeys, 0u, k, (uint32_t)top);
+  __syncthreads();
+  const uint32_t lo = s_lo, hi = s_hi;
+  if (hi == 0u) return;                                  // nothing new below this chunk: entries unchanged
+#pragma unroll
+  for (int r = 0; r < PER; r++) {
+    const size_t cidx = base + (size_t)r * blockDim.x + threadIdx.x;
+    if (cidx < n_entries) {
+      const uint32_t add = (lo == hi) ? lo : lower_bound_u32(nkeys, lo, hi, (uint32_t)cidx);
+      cell_start[cidx] += add;
+    }
+  }
+}
+hipError_t map_merge_grid(hipStream_t st, const float4* old_sorted, size_t n_old, const float4* new_pts, size_t k,
+                          float4* out_sorted, uint32_t* cell_start, size_t ncells, float ox, float oy, float oz,
+                          float inv_cell, int nx, int ny, int nz, MapBuildScratch& S) {
+  if (k == 0) return hipSuccess;
+  hipError_t e = ensure_scratch(S, k);
+  if (e != hipSuccess) return e;
+  const int kb = (int)((k + 255) / 256);
+  hipLaunchKernelGGL(cellkey_kernel, dim3(kb), dim3(256), 0, st, new_pts, k, ox, oy, oz, inv_cell, nx, ny, nz, S.keys_in, S.vals_in);
+  int bits = 1;
+  while (bits < 32 && ((size_t)1 << bits) < ncells) bits++;
+  size_t tmp_bytes = 0;
+  e = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, S.keys_in, S.keys_out, S.vals_in, S.vals_out, (int)k, 0, bits, st);
+  if (e != hipSuccess) return e;
+  if (tmp_bytes > S.cub_tmp_bytes) {
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+    if (S.cub_tmp) hipFree(S.cub_tmp);
+    if ((e = hipMalloc(&S.cub_tmp, tmp_bytes + 1024)) != hipSuccess) return e;
+    S.cub_tmp_bytes = tmp_bytes + 1024;
+  }
+  e = hipcub::DeviceRadixSort::SortPairs(S.cub_tmp, tmp_bytes, S.keys_in, S.keys_out, S.vals_in, S.vals_out, (int)k, 0, bits, st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(merge_new_kernel, dim3(kb), dim3(256), 0, st, new_pts, S.keys_out, S.vals_out, (uint32_t)k, cell_start, out_sorted);
+  if (n_old > 0)
+    hipLaunchKernelGGL(merge_old_kernel, dim3((unsigned)((n_old + 255) / 256)), dim3(256), 0, st, old_sorted, (uint32_t)n_old,
+                       S.keys_out, (uint32_t)k, ox, oy, oz, inv_cell, nx, ny, nz, out_sorted);
+  hipLaunchKernelGGL(cellstart_shift_kernel, dim3((unsigned)((ncells + 1 + 4095) / 4096)), dim3(256), 0, st, cell_start, ncells + 1,
+                     S.keys_out, (uint32_t)k);
+  return hipGetLastError();
+}
+
 // ---- y-fastest, padded copy of the row bounds (GridView::row_table) --------------------------
+// A transposition per z slab (x-fastest cell table -> y-fastest row table) through a 32x33 LDS tile so that both the reads
+// (along x) and the writes (along y) are coalesced; the pad entries (y, z outside the grid) are zero and never written here.
 __global__ __launch_bounds__(256) void rowtable_kernel(const uint32_t* __restrict__ cell_start, int nx, int ny, int nz,
-                                                       uint32_t* __restrict__ out, size_t total) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
+                                                       uint32_t* __restrict__ out) {
+  __shared__ uint32_t tile[32][33];
+  // 1-D launch (any grid shape stays within the launch limits): tile index -> (x tile fastest, y tile, z)
+  const unsigned xt = (unsigned)(nx + 1 + 31) / 32u, yt = (unsigned)(ny + 31) / 32u;
+  const unsigned t = blockIdx.x;
+  const int z = (int)(t / (xt * yt));
+  const int x0 = (int)(t % xt) * 32, y0 = (int)((t / xt) % yt) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
   const size_t py = (size_t)ny + 4, pz = (size_t)nz + 4;
-  const int yp = (int)(i % py), zp = (int)((i / py) % pz), x = (int)(i / (py * pz));
-  const int y = yp - 2, z = zp - 2;
-  uint32_t v = 0u;
-  if (y >= 0 && y < ny && z >= 0 && z < nz) v = cell_start[((size_t)z * ny + y) * nx + x];   // x == nx: start of the next row
-  out[i] = v;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int y = y0 + ty + 8 * r, x = x0 + tx;
+    if (y < ny && x <= nx) tile[ty + 8 * r][tx] = cell_start[((size_t)z * ny + y) * nx + x];   // x == nx: start of the next row
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int x = x0 + ty + 8 * r, y = y0 + tx;
+    if (y < ny && x <= nx) out[((size_t)x * pz + (size_t)(z + 2)) * py + (size_t)(y + 2)] = tile[tx][ty + 8 * r];
+  }
 }
 size_t row_table_size(int nx, int ny, int nz) { return ((size_t)nx + 1) * ((size_t)ny + 4) * ((size_t)nz + 4); }
-hipError_t map_build_row_table(hipStream_t st, const uint32_t* cell_start, int nx, int ny, int nz, uint32_t* out) {
+// zero_pads: the table is new or its shape changed (the pads have to be cleared); false when the same table is refreshed
+hipError_t map_build_row_table(hipStream_t st, const uint32_t* cell_start, int nx, int ny, int nz, uint32_t* out, bool zero_pads) {
   const size_t total = row_table_size(nx, ny, nz);
-  hipLaunchKernelGGL(rowtable_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, cell_start, nx, ny, nz, out, total);
+  hipError_t e;
+  if (zero_pads && (e = hipMemsetAsync(out, 0, total * sizeof(uint32_t), st)) != hipSuccess) return e;
+  const size_t tiles = (size_t)((nx + 1 + 31) / 32) * (size_t)((ny + 31) / 32) * (size_t)nz;
+  if (tiles > 0x7fffffffull) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(rowtable_kernel, dim3((unsigned)tiles), dim3(256), 0, st, cell_start, nx, ny, nz, out);
   return hipGetLastError();
 }
 

@@ -27,6 +27,7 @@ struct GridView {
 struct PrevPass {
   float RT[16];
   int valid;
+  unsigned heavy;   // queries whose 3x3x3 block holds more candidates than this go to the wave-per-query kernel (0xffffffff: never)
 };
 
 // Per-pass pose constants, computed on the host exactly as the reference does

@@ -160,6 +160,12 @@ int flimo_set_lanes_per_query(flimo_ctx* ctx, int lanes);
 /* mean number of candidate map points examined per query in the last pass */
 double flimo_last_candidates_per_query(const flimo_ctx* ctx);
 
+/* The cell-sorted copy of the map is maintained incrementally: points appended by an insert are merged into it as long as
+ * the grid geometry covers the map box; otherwise the grid is laid out again (with slack on the sides that grew) and the whole
+ * map sorted.  Debug check: sorts the whole map again with the current geometry and counts the 32-bit words in which the
+ * maintained index (points, cell table, row table) differs -- 0 by construction.  stats = {merges, full builds} so far. */
+int flimo_map_grid_selfcheck(flimo_ctx* ctx, uint64_t* mismatches, uint64_t stats[2]);
+
 /* ---- diagnostics without a GPU ----
  * Replays the map's insert rule (Octree::initialize / update, Objects/Octree.hpp:282-432) over a
  * sequence of batches of packed NaN-free points: keep[i] = 1 if point i is stored.  Host only. */

@@ -333,6 +333,7 @@ def test_device_insert_rule_matches_octree(built, oracle, downsample):
             oc.update(b)
             assert ctx.map_size() == oc.size(), f"batch {k}"
             np.testing.assert_array_equal(sort_rows(ctx.map_points()), sort_rows(oc.points()), err_msg=f"batch {k}")
+            assert ctx.grid_selfcheck()[0] == 0, f"batch {k}"
         # the index built over the device-decided map answers like the octree
         q = rng.uniform(-15, 15, (2000, 3)).astype(np.float32)
         idx, sqd, cnt = ctx.knn(q, 5)
@@ -546,3 +547,84 @@ def test_cluttered_scene_parity(built, oracle):
     assert dpos < 1e-4 and ang < 1e-4, (dpos, ang)
     assert np.abs(G.get_x()[0:3] - t).max() < 0.05           # and it is the right answer
     G.close()
+
+
+@pytest.mark.gpu
+def test_incremental_index_equals_full_sort(built, oracle):
+    """The cell-sorted copy of the map is updated by MERGING the points an insert appended (one streaming pass) instead of
+    sorting the whole map again; when the map outgrows the grid the geometry is laid out afresh with slack on the sides
+    that grew.  After every insert of a drive through new territory the maintained index (points, cell table, row table)
+    is word for word what a from-scratch sort with the same geometry gives, merges dominate, and k-NN over it answers
+    like the oracle octree."""
+    from fast_limo_amd import _lib
+    rng = np.random.default_rng(11)
+    ctx = _lib.HipCtx(0)
+    try:
+        ctx.map_config(0.2, 2, True)
+        oc = oracle.Octree(0.2, True)
+        first = synth.box_world_map(150000, 30.0, 5)
+        ctx.map_add(first); oc.update(first)
+        for k in range(40):
+            # a window moving along +x (and slowly along -y): part of every batch lies beyond the map box so far
+            b = synth.box_world_map(4000, 20.0, 100 + k) + np.float32([2.0 * k, -0.7 * k, 0.0])
+            if k % 9 == 4:
+                b = np.concatenate([b, rng.uniform(-25, 25, (3, 3)).astype(np.float32) + np.float32([0, 0, 30 + k])])   # z grows
+            if k % 13 == 7:
+                b = b[:1]                                                                                          # one point
+            ctx.map_add(b); oc.update(b)
+            assert ctx.map_size() == oc.size(), k
+            mm, merges, builds = ctx.grid_selfcheck()
+            assert mm == 0, (k, mm, merges, builds)
+        mm, merges, builds = ctx.grid_selfcheck()
+        print("index updates: %d merges, %d full builds, map %d" % (merges, builds, ctx.map_size()))
+        assert merges >= 25 and builds <= 16, (merges, builds)      # slack = max(8 cells, 1/8 extent) per grown side
+        q = (rng.uniform(-30, 30, (4000, 3)) + [40, -14, 0]).astype(np.float32)
+        q[:, 2] = rng.uniform(0, 5, 4000)
+        idx, sqd, cnt = ctx.knn(q, 5)
+        np.testing.assert_array_equal(sqd, oc.knn(q, 5)[1])
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
+def test_crowded_block_handover_is_exact(built, oracle):
+    """Developer switch FLIMO_HEAVY=<n>: queries whose 3x3x3 block holds more than n candidates are handed to the
+    wave-per-query kernel (same block, same pruning bound) instead of being walked by their two lanes.  On a map with
+    crowded cells (and sparse ones) every record equals the default path's, over a pose sequence that exercises the
+    pruning bound, and the oracle's at the last pose."""
+    from fast_limo_amd import _lib
+    mcfg = _lib.default_match_cfg(**CAPS)
+    rs = np.random.RandomState(4)
+    mp = np.concatenate([synth.box_world_map(150000, 15.0, 1),                       # ~170 pts/m2: about 40 per cell
+                         synth.box_world_map(40000, 3.0, 2)])                        # a crowded patch: several hundred per cell
+    scan = np.ascontiguousarray(synth.box_world_scan_random(4096, 15.0, 2)[:, :3])
+    oc = oracle.Octree(); oc.update(mp)
+    os.environ["FLIMO_HEAVY"] = "96"
+    try:
+        handed = _lib.HipCtx(0)
+    finally:
+        del os.environ["FLIMO_HEAVY"]
+    plain = _lib.HipCtx(0)
+    x = oracle.identity_x26()
+    poses = []
+    for k in range(5):
+        x = x.copy(); x[0:3] += rs.normal(0, 0.02 if k != 3 else 0.3, 3); poses.append(x)
+    try:
+        for c in (plain, handed):
+            c.map_config(); c.map_add(mp); c.scan_set(scan); c.set_debug_records(True)
+        moved = 0
+        for k, xk in enumerate(poses):
+            a = plain.match_reduce(xk, mcfg); ra = plain.match_fetch()
+            b = handed.match_reduce(xk, mcfg); rb = handed.match_fetch()
+            assert a[2] == b[2], k
+            np.testing.assert_array_equal(a[0], b[0]); np.testing.assert_array_equal(a[1], b[1])
+            for f in ("valid", "n", "h", "sqd", "nbr", "H"):
+                np.testing.assert_array_equal(ra[f], rb[f], err_msg=f"pose {k} field {f}")
+            moved = max(moved, handed.last_widen_count() - plain.last_widen_count())
+        assert moved > 200, moved                                # the hand-over really happened
+        recs, H, h, ev = oracle.match_H(oc, oracle.default_cfg(num_threads=1, **CAPS), poses[-1], scan)
+        vg = rb["valid"] > 0
+        np.testing.assert_array_equal(vg, recs["is_plane"] > 0)
+        np.testing.assert_array_equal(rb["sqd"][vg], recs["sqd"][vg])
+    finally:
+        plain.close(); handed.close()

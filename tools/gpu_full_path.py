@@ -13,7 +13,7 @@ WITH_ORACLE = int(os.environ.get("ORACLE", 1)) != 0          # ORACLE=0: GPU onl
 mp = synth.box_world_map(NMAP, LBOX, 1)
 B2B = int(os.environ.get("B2B", 8))                          # scans per back-to-back run (two runs: async / sync insert)
 st, w, a = synth.stationary_imu(0.0, 0.1 * (NSCANS + 2 * B2B) + 0.4)
-G = api.Localizer(api.default_cfg(num_threads=32, **caps))
+G = api.Localizer(api.default_cfg(num_threads=32, gpu_cell_size=float(os.environ.get("CELL", 0)), **caps))
 class _NoOracle:
     def map_add(self, *a): pass
     def update_imu(self, *a): pass
