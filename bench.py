@@ -88,6 +88,7 @@ def cpu_baseline(mp, scan, imu, caps, max_threads):
         drive_to_prior(_OracleNoInsert(L), mp, scan, imu)
         x_prior, P_prior = L.get_x(), L.get_P()
         times = []
+        stages = []
         budget_t0 = time.time()
         for rep in range(5):
             L.set_x(x_prior); L.set_P(P_prior)
@@ -96,6 +97,7 @@ def cpu_baseline(mp, scan, imu, caps, max_threads):
             dt = time.perf_counter() - t0
             st = L.stats()
             times.append(st["t_deskew"] - st["t_sort"] + st["t_update"])   # the time sort is outside the GPU step too
+            stages.append((st["t_deskew"] - st["t_sort"], st["t_match"], st["t_hrows"], st["t_update"] - st["t_match"] - st["t_hrows"]))
             if rep == 0:
                 x_o = L.get_x()
                 E = st["evals"] / max(st["queries"], 1)
@@ -103,9 +105,10 @@ def cpu_baseline(mp, scan, imu, caps, max_threads):
                 break
         t = float(np.median(times))
         if best is None or t < best[0]:
-            best = (t, nt, len(times))
-    t, nt, reps = best
+            best = (t, nt, len(times), [float(v) * 1e3 for v in np.median(np.array(stages), axis=0)])
+    t, nt, reps, stg = best
     return dict(value=1.0 / t, unit="scans/s", cores=nt, kind="port",
+                stages_ms={"deskew": stg[0], "knn_plane_fit": stg[1], "H_rows": stg[2], "HtH_and_solve": stg[3]},
                 sample=f"median of {reps} registrations (deskew + iterated update, no map insert) of the same "
                        f"{scan.shape[0]}-pt scan vs {mp.shape[0]}-pt map by the CPU oracle (restatement of the "
                        f"reference; the reference itself cannot be built without Eigen/PCL/Boost); "

@@ -258,9 +258,9 @@ static size_t copy_xyz(const std::vector<Pt>& v, float* out, size_t cap) {
 }
 size_t oracle_loc_get_pc2match(void* Lp, float* out, size_t cap) { return copy_xyz(((Localizer*)Lp)->pc2match, out, cap); }
 size_t oracle_loc_get_final_scan(void* Lp, float* out, size_t cap) { return copy_xyz(((Localizer*)Lp)->final_scan, out, cap); }
-void oracle_loc_get_stats(void* Lp, double t[4], long long* evals, long long* queries) {
+void oracle_loc_get_stats(void* Lp, double t[6], long long* evals, long long* queries) {
   Localizer* L = (Localizer*)Lp;
-  t[0] = L->t_deskew; t[1] = L->t_update; t[2] = L->t_mapadd; t[3] = L->t_sort;
+  t[0] = L->t_deskew; t[1] = L->t_update; t[2] = L->t_mapadd; t[3] = L->t_sort; t[4] = L->t_match; t[5] = L->t_hrows;
   *evals = L->map.sum_evals;       // over every pass of the last updatePointCloud
   *queries = L->map.sum_queries;
 }

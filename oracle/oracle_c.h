@@ -108,7 +108,7 @@ size_t oracle_loc_get_pc2match(void* L, float* xyz_out, size_t cap);
 size_t oracle_loc_get_final_scan(void* L, float* xyz_out, size_t cap);
 /* timings of the last updatePointCloud: deskew (incl. sort), update, map add, time sort alone [s];
  * evals/queries of the last match */
-void   oracle_loc_get_stats(void* L, double t[4], long long* evals, long long* queries);
+void   oracle_loc_get_stats(void* L, double t[6], long long* evals, long long* queries);
 /* deskew only (Localizer.cpp:733-853); out n x 3 (body frame at scan end); returns count or -1 */
 long long oracle_loc_deskew(void* L, const float* pts5, size_t n, double stamp, float* out_xyz);
 /* run only the IESKF update (no deskew): pc2match := xyz (n x 3) */

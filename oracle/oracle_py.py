@@ -345,10 +345,11 @@ class Localizer:
         return out[:n]
 
     def stats(self):
-        t = np.zeros(4, np.float64)
+        t = np.zeros(6, np.float64)
         ev = C.c_longlong(0); q = C.c_longlong(0)
         lib().oracle_loc_get_stats(self._h, t, C.byref(ev), C.byref(q))
-        return dict(t_deskew=t[0], t_update=t[1], t_mapadd=t[2], t_sort=t[3], evals=ev.value, queries=q.value)
+        return dict(t_deskew=t[0], t_update=t[1], t_mapadd=t[2], t_sort=t[3], t_match=t[4], t_hrows=t[5],
+                    evals=ev.value, queries=q.value)
 
     def deskew(self, pts5, stamp):
         p = _f32(pts5).reshape(-1, 5)

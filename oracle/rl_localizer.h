@@ -403,6 +403,7 @@ struct Localizer {
   // instrumentation
   int last_null_iteration = 0;
   double t_deskew = 0, t_update = 0, t_mapadd = 0, t_sort = 0;
+  double t_match = 0, t_hrows = 0;   // inside t_update: Mapper::match (k-NN + plane fit) and calculate_H, summed over the passes
 
   void init(const LocCfg& cfg) {                                 // Localizer.cpp:35-117
     config = cfg;
@@ -461,8 +462,12 @@ struct Localizer {
 
   // IKFoM::h_share_model (use-ikfom.cpp:10-31)
   void h_share_model(const StateIkfom& x, MeasOut& out) {
+    const double ta = omp_get_wtime();
     std::vector<MatchRec> matches = map.match(State(x), pc2match);
+    const double tb = omp_get_wtime();
     calculate_H(x, matches, config, num_threads_ < 1 ? 1 : num_threads_, out);
+    t_match += tb - ta;
+    t_hrows += omp_get_wtime() - tb;
   }
 
   IMUmeas imu2baselink(const IMUmeas& imu) {                     // Localizer.cpp:696-731
@@ -673,6 +678,7 @@ struct Localizer {
     else pc2match = deskewed;
     int rc = 0;
     if (pc2match.size() > 1) {
+      t_match = t_hrows = 0.0;
       ikfom.update_iterated_dyn_share_modified(0.001, 5.0);      // :333
       double t2 = omp_get_wtime();
       t_update = t2 - t1;
