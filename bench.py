@@ -194,10 +194,13 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    # level 1: start/stop HIP events attached to the k-NN dispatch (on the context's own stream); sampled every
-    # 13th pass (coprime with the 4 passes of a step, so every pass position is covered) to keep the perturbation small
+    # level 1: start/stop HIP events attached to the k-NN dispatch (on the context's own stream).  A timed dispatch costs
+    # about 25 us of wall time, so the launches are SAMPLED: every (4k+1)-th pass -- the stride walks through the 4 pass
+    # positions of a step evenly -- at least 25 passes apart (8 samples over the default 50 steps, about 2 % of `value`),
+    # about 24 samples for long runs.  FLIMO_BENCH_TIMING_STRIDE=1 times every launch.
     loc.hip.set_timing(int(os.environ.get('FLIMO_BENCH_TIMING', '1')))
-    loc.hip.set_timing_stride(int(os.environ.get('FLIMO_BENCH_TIMING_STRIDE', '13')))
+    auto_stride = max(25, ((4 * args.steps // 24) // 4) * 4 + 1)
+    loc.hip.set_timing_stride(int(os.environ.get('FLIMO_BENCH_TIMING_STRIDE', str(auto_stride))))
     loc.hip.timing_totals(reset=True)
     passes0 = loc.hip.pass_count()
     loc.host_profile(reset=True)
