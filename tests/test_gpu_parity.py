@@ -628,3 +628,70 @@ def test_crowded_block_handover_is_exact(built, oracle):
         np.testing.assert_array_equal(rb["sqd"][vg], recs["sqd"][vg])
     finally:
         plain.close(); handed.close()
+
+
+@pytest.mark.gpu
+def test_randomised_configurations_match_oracle(built, oracle):
+    """Differential test over 16 random configurations: scene mix (box-world + tilted clutter at random densities), map
+    cell size, state (pose AND LiDAR-IMU extrinsics away from identity), gates (MAX_DIST_PLANE, PLANE_THRESHOLD), both caps
+    binding or not, extrinsics estimation on or off.  Per configuration: the same M, the H rows of the oracle bit for
+    bit and in its order, HtH within summation rounding, over two consecutive passes (the second one pruned by the first)."""
+    from fast_limo_amd import _lib
+    rs = np.random.RandomState(2024)
+    total_M, capped, widened = 0, 0, 0
+    for trial in range(16):
+        L = float(rs.choice([8.0, 15.0, 30.0]))
+        n_map = int(rs.choice([20000, 60000, 150000]))
+        mp = synth.box_world_map(n_map, L, 100 + trial)
+        if trial % 3 == 1:                                         # clutter: tilted plane patches
+            parts = [mp]
+            for k in range(4):
+                nrm = rs.normal(size=3); nrm /= np.linalg.norm(nrm)
+                u = np.cross(nrm, [0.2, 0.9, 0.4]); u /= np.linalg.norm(u); v = np.cross(nrm, u)
+                c0 = rs.uniform(-0.6 * L, 0.6 * L, 3); c0[2] = rs.uniform(0, 6)
+                m = 4000
+                parts.append((c0 + rs.uniform(-4, 4, (m, 1)) * u + rs.uniform(-4, 4, (m, 1)) * v
+                              + rs.normal(0, 0.01, (m, 1)) * nrm).astype(np.float32))
+            mp = np.concatenate(parts)
+        n_scan = int(rs.choice([257, 1000, 3000]))
+        scan = np.ascontiguousarray(synth.box_world_scan_random(n_scan, L, 200 + trial)[:, :3])
+        cell = float(rs.choice([0.0, 0.35, 0.5, 0.8]))
+        mdp = float(rs.choice([2.0, 1.0, 0.5]))
+        pth = float(rs.choice([0.05, 0.02, 0.1]))
+        pc2 = int(rs.choice([10**7, n_scan // 2, 100]))
+        mm = int(rs.choice([10**7, 10**7, 150, 40]))
+        est = int(rs.randint(0, 2))
+        x = oracle.identity_x26()
+        x[0:3] = rs.normal(0, 0.15, 3)
+        q = np.concatenate([rs.normal(0, 0.01, 3), [1.0]]); x[3:7] = q / np.linalg.norm(q)
+        if trial % 2:
+            q = np.concatenate([rs.normal(0, 0.02, 3), [1.0]]); x[7:11] = q / np.linalg.norm(q)     # offset_R_L_I
+            x[11:14] = rs.normal(0, 0.05, 3)                                                          # offset_T_L_I
+        x2 = x.copy(); x2[0:3] += rs.normal(0, 0.004, 3)
+        oc = oracle.Octree(); oc.update(mp)
+        ocfg = oracle.default_cfg(num_threads=1, MAX_NUM_PC2MATCH=pc2, MAX_NUM_MATCHES=mm, MAX_DIST_PLANE=mdp,
+                                  PLANE_THRESHOLD=pth, estimate_extrinsics=est)
+        gcfg = _lib.default_match_cfg(MAX_NUM_PC2MATCH=pc2, MAX_NUM_MATCHES=mm, MAX_DIST_PLANE=mdp, PLANE_THRESHOLD=pth,
+                                      estimate_extrinsics=est)
+        ctx = _lib.HipCtx(0)
+        try:
+            ctx.map_config(0.2, 2, True, cell) if cell > 0 else ctx.map_config()
+            ctx.map_add(mp); ctx.scan_set(scan)
+            ctx.set_debug_records(bool(trial % 2))                  # both record modes; the widening count is only read in debug mode
+            for k, xk in enumerate((x, x2)):
+                _, H, h, _ = oracle.match_H(oc, ocfg, xk, scan)
+                HTH, HTh, M = ctx.match_reduce(xk, gcfg)
+                tag = f"trial {trial} pass {k}: L={L} map={mp.shape[0]} scan={n_scan} cell={cell} mdp={mdp} pth={pth} caps=({pc2},{mm}) est={est}"
+                assert M == H.shape[0], tag
+                Hd, hd = ctx.match_fetch_H()
+                np.testing.assert_array_equal(Hd, H, err_msg=tag)
+                np.testing.assert_array_equal(hd, h, err_msg=tag)
+                np.testing.assert_allclose(HTH, H.T @ H if M else np.zeros((12, 12)), rtol=1e-11, atol=1e-9, err_msg=tag)
+                np.testing.assert_allclose(HTh, H.T @ h if M else np.zeros(12), rtol=1e-10, atol=1e-9, err_msg=tag)
+                total_M += M
+                capped += int(M == mm)
+                widened += int(ctx.last_widen_count() > 0)
+        finally:
+            ctx.close()
+    print(f"randomised configurations: {total_M} matches in total, {capped} passes with MAX_NUM_MATCHES binding, {widened} with widening")
+    assert total_M > 15000 and capped >= 4 and widened >= 4, (total_M, capped, widened)
