@@ -119,3 +119,44 @@ def test_async_map_insert_is_invisible(built):
         assert ra[3] == rs[3] and ra[4] == rs[4] and ra[3] == ra[4], k
     assert a_pts.shape[0] > 3 * n_pts
     np.testing.assert_array_equal(a_pts, s_pts)
+
+
+def test_reference_yaml_configuration_sequence(built, oracle):
+    """The reference's shipped configuration (config/kitti.yaml): crop box +-1 m, min distance 4 m, every 4th point, voxel
+    grid 1 m, MAX_NUM_PC2MATCH 1e4 / MAX_NUM_MATCHES 5000, LiDAR mounted off the IMU (the yaml's extrinsics), sensor biases,
+    time offset on -- the path a drop-in user actually runs (capped, voxelised scans, small matches per scan).  A 12-scan
+    drive with map inserts: same status codes, same pc2match sizes, same map sizes, pose within 1e-4 of the CPU oracle."""
+    from fast_limo_amd import api
+    n_scans, n_pts, speed = 12, 30000, 10.0
+    st, w, a = synth.stationary_imu(0.0, 0.1 * n_scans + 0.06)
+    lid_t = (8.086759e-01, -3.195559e-01, 7.997231e-01)
+    lid_R = (9.999976e-01, -7.854027e-04, 2.024406e-03, 7.553071e-04, 9.998898e-01, 1.482454e-02,
+             -2.035826e-03, -1.482298e-02, 9.998881e-01)
+    common = dict(MAX_NUM_PC2MATCH=10000, MAX_NUM_MATCHES=5000, voxel_active=1, leaf_size=1.0, crop_active=1,
+                  dist_active=1, min_dist=4.0, rate_active=1, rate_value=4, time_offset=1,
+                  lidar2baselink_t=lid_t, lidar2baselink_R=lid_R, accel_bias=(0.01, 0.01, 0.01), gyro_bias=(0.01, 0.01, 0.01),
+                  cov_gyro=6.01e-4, cov_acc=1.53e-2, cov_bias_gyro=1.54e-5, cov_bias_acc=3.38e-4)
+    G = api.Localizer(api.default_cfg(cropBoxMin=(-1.0, -1.0, -1.0), cropBoxMax=(1.0, 1.0, 1.0), **common))
+    Lo = oracle.Localizer(oracle.default_cfg(crop_min=(-1.0, -1.0, -1.0), crop_max=(1.0, 1.0, 1.0), num_threads=4, **common))
+    x0 = G.get_x(); x0[14] = speed
+    G.set_x(x0); Lo.set_x(x0)
+    i = 0
+    worst = (0.0, 0.0)
+    sizes = []
+    for k in range(n_scans):
+        until = 0.1 * (k + 1) + 0.005
+        while i < len(st) and st[i] <= until:
+            G.update_imu(st[i], w[i], a[i]); Lo.update_imu(st[i], w[i], a[i]); i += 1
+        scan = synth.corridor_scan(k, n_pts, 321, speed=speed)
+        rg = G.update_pointcloud(scan, 0.1 * k)
+        ro = Lo.update_pointcloud(scan, 0.1 * k)
+        assert rg == ro, (k, rg, ro)
+        assert G.pc2match().shape == Lo.pc2match().shape, (k, G.pc2match().shape, Lo.pc2match().shape)
+        assert G.map_size() == Lo.map_size(), (k, G.map_size(), Lo.map_size())
+        dpos, ang = pose_delta(G.get_x(), Lo.get_x())
+        worst = (max(worst[0], dpos), max(worst[1], ang))
+        sizes.append((G.pc2match().shape[0], G.map_size()))
+    print("kitti.yaml configuration: worst GPU-vs-CPU deviation", worst, "pc2match / map sizes", sizes[-1])
+    assert worst[0] <= 1e-4 and worst[1] <= 1e-4, worst
+    assert 200 < sizes[-1][0] < 10000 and sizes[-1][1] > 2 * sizes[-1][0]
+    G.close()
