@@ -160,3 +160,49 @@ def test_reference_yaml_configuration_sequence(built, oracle):
     assert worst[0] <= 1e-4 and worst[1] <= 1e-4, worst
     assert 200 < sizes[-1][0] < 10000 and sizes[-1][1] > 2 * sizes[-1][0]
     G.close()
+
+
+def test_per_scan_parity_along_a_drive_from_identical_state(built, oracle):
+    """The bar is per scan ON IDENTICAL INPUT (BASELINE.json north_star).  Free-running, two implementations of this filter
+    drift apart chaotically: the reference's covariance update cancels many digits, so a 1e-16 difference in the order of
+    the HtH sum becomes 1e-8 m one scan later and saturates near the estimator's own noise (~1e-3 m) once the maps differ by
+    their first point -- the same would happen between two builds of the reference (Eigen's blocked product order depends on
+    the SIMD width).  So this drive hands the oracle's state (x, P) to the product before every scan: on identical input
+    every one of 30 scans in the reference's shipped configuration lands within 1e-6 m / 1e-6 rad of the oracle, and the
+    maps keep the same size."""
+    from fast_limo_amd import api
+    n_scans, n_pts, speed = 30, 30000, 10.0
+    st, w, a = synth.stationary_imu(0.0, 0.1 * n_scans + 0.06)
+    common = dict(MAX_NUM_PC2MATCH=10000, MAX_NUM_MATCHES=5000, voxel_active=1, leaf_size=1.0, crop_active=1,
+                  dist_active=1, min_dist=4.0, rate_active=1, rate_value=4, time_offset=1,
+                  lidar2baselink_t=(8.086759e-01, -3.195559e-01, 7.997231e-01), accel_bias=(0.01, 0.01, 0.01),
+                  gyro_bias=(0.01, 0.01, 0.01))
+    G = api.Localizer(api.default_cfg(cropBoxMin=(-1.0, -1.0, -1.0), cropBoxMax=(1.0, 1.0, 1.0), **common))
+    Lo = oracle.Localizer(oracle.default_cfg(crop_min=(-1.0, -1.0, -1.0), crop_max=(1.0, 1.0, 1.0), num_threads=4, **common))
+    x0 = G.get_x(); x0[14] = speed
+    G.set_x(x0); Lo.set_x(x0)
+    i = 0
+    worst = (0.0, 0.0)
+    worst_P = worst_x = 0.0
+    free = []
+    for k in range(n_scans):
+        until = 0.1 * (k + 1) + 0.005
+        while i < len(st) and st[i] <= until:
+            G.update_imu(st[i], w[i], a[i]); Lo.update_imu(st[i], w[i], a[i]); i += 1
+        scan = synth.corridor_scan(k, n_pts, 654, speed=speed)
+        rg = G.update_pointcloud(scan, 0.1 * k)
+        ro = Lo.update_pointcloud(scan, 0.1 * k)
+        assert rg == ro, (k, rg, ro)
+        assert G.map_size() == Lo.map_size(), (k, G.map_size(), Lo.map_size())
+        dpos, ang = pose_delta(G.get_x(), Lo.get_x())
+        worst = (max(worst[0], dpos), max(worst[1], ang))
+        free.append(dpos)
+        Pg, Po = G.get_P(), Lo.get_P()
+        sc = np.sqrt(np.outer(np.abs(np.diag(Po)), np.abs(np.diag(Po)))) + 1e-300
+        worst_P = max(worst_P, float(np.abs((Pg - Po) / sc).max()))
+        worst_x = max(worst_x, float(np.abs(G.get_x() - Lo.get_x()).max()))
+        G.set_x(Lo.get_x()); G.set_P(Lo.get_P())            # identical input for the next scan
+    print("per-scan deviation from identical state over %d scans: worst %.2e m / %.2e rad; whole state %.2e; covariance (relative to sqrt(Pii Pjj)) %.2e"
+          % (n_scans, worst[0], worst[1], worst_x, worst_P))
+    assert worst[0] <= 1e-6 and worst[1] <= 1e-6, (worst, free)
+    G.close()

@@ -1,0 +1,37 @@
+"""Developer script: from IDENTICAL state every scan (the oracle's x, P handed to the product), how far apart do the two
+posteriors land?  Prints per scan the pose / state / covariance deviation and the condition number of P."""
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np
+import oracle_py as O
+from fast_limo_amd import synth, api
+n_scans, n_pts, speed = int(os.environ.get("NSCANS", 14)), 30000, 10.0
+st, w, a = synth.stationary_imu(0.0, 0.1 * n_scans + 0.06)
+common = dict(MAX_NUM_PC2MATCH=10000, MAX_NUM_MATCHES=5000, voxel_active=1, leaf_size=1.0, crop_active=1, dist_active=1, min_dist=4.0,
+              rate_active=1, rate_value=4, time_offset=1, lidar2baselink_t=(8.086759e-01, -3.195559e-01, 7.997231e-01),
+              accel_bias=(0.01, 0.01, 0.01), gyro_bias=(0.01, 0.01, 0.01))
+G = api.Localizer(api.default_cfg(cropBoxMin=(-1.0, -1.0, -1.0), cropBoxMax=(1.0, 1.0, 1.0), **common))
+G.set_flags(add_to_map=True, download_clouds=True, keep_log=True)
+Lo = O.Localizer(O.default_cfg(crop_min=(-1.0, -1.0, -1.0), crop_max=(1.0, 1.0, 1.0), num_threads=4, **common))
+x0 = G.get_x(); x0[14] = speed
+G.set_x(x0); Lo.set_x(x0)
+i = 0
+for k in range(n_scans):
+    until = 0.1 * (k + 1) + 0.005
+    while i < len(st) and st[i] <= until:
+        G.update_imu(st[i], w[i], a[i]); Lo.update_imu(st[i], w[i], a[i]); i += 1
+    Pprior = Lo.get_P()
+    scan = synth.corridor_scan(k, n_pts, 654, speed=speed)
+    rg = G.update_pointcloud(scan, 0.1 * k); ro = Lo.update_pointcloud(scan, 0.1 * k)
+    xg, xo, Pg, Po = G.get_x(), Lo.get_x(), G.get_P(), Lo.get_P()
+    sc = np.sqrt(np.outer(np.abs(np.diag(Po)), np.abs(np.diag(Po)))) + 1e-300
+    D = np.abs((Pg - Po) / sc)
+    ij = np.unravel_index(np.argmax(D), D.shape)
+    ps = G.passes()
+    lo_it = Lo.iters()
+    hth = max((np.abs(p["HTH"] - q["HTH"]).max() / (np.abs(q["HTH"]).max() + 1e-300)) for p, q in zip(ps, lo_it)) if ps and lo_it and len(ps) == len(lo_it) else float("nan")
+    print("scan %2d rc %d/%d  passes %d/%d  pos %.1e  state %.1e  P rel %.1e at %s  HTH rel %.1e  cond(P prior) %.1e  cond(P post) %.1e"
+          % (k, rg, ro, len(ps), len(lo_it), np.abs(xg[:3] - xo[:3]).max(), np.abs(xg - xo).max(), D.max(), ij, hth, np.linalg.cond(Pprior), np.linalg.cond(Po)))
+    G.set_x(xo); G.set_P(Po)
+G.close()
