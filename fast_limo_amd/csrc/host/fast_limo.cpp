@@ -982,40 +982,54 @@ void Localizer::updatePointCloud(pcl::PointCloud<PointType>::Ptr& raw_pc, double
   if (!raw_pc || raw_pc->points.size() < 1) { std::cout << "FAST_LIMO::Raw PointCloud is empty!\n"; last_status_ = -1; return; }
   if (!imu_calibrated_) { last_status_ = -2; return; }
   if (imu_buffer.empty()) { std::cout << "FAST_LIMO::IMU buffer is empty!\n"; last_status_ = -3; return; }
-  // removeNaNFromPointCloud (:263-265) -- in place, as the reference mutates *raw_pc
-  {
-    std::vector<PointType>& P = raw_pc->points;
-    size_t k = 0;
-    for (size_t i = 0; i < P.size(); i++)
-      if (std::isfinite(P[i].x) && std::isfinite(P[i].y) && std::isfinite(P[i].z)) P[k++] = P[i];
-    P.resize(k);
-    raw_pc->is_dense = true;
-  }
-  // negative CropBox (:268-271): drop points strictly inside the box
-  if (config.filters.crop_active) {
-    std::vector<PointType>& P = raw_pc->points;
-    const std::vector<float>& mn = config.filters.cropBoxMin;
-    const std::vector<float>& mx = config.filters.cropBoxMax;
-    size_t k = 0;
-    for (size_t i = 0; i < P.size(); i++) {
-      const bool inside = !(P[i].x < mn[0] || P[i].y < mn[1] || P[i].z < mn[2] || P[i].x > mx[0] || P[i].y > mx[1] || P[i].z > mx[2]);
-      if (!inside) P[k++] = P[i];
-    }
-    P.resize(k);
-  }
-  // distance / rate / FoV filters (:274-302)
+  // removeNaNFromPointCloud (:263-265), negative CropBox (:268-271) and the distance / rate / FoV filters (:274-302) in ONE
+  // pass over the raw cloud.  As in the reference, *raw_pc itself ends up NaN-free and cropped (both filters write back
+  // into it), and the rate filter counts positions in that cropped cloud.
   auto input_pc = std::make_shared<pcl::PointCloud<PointType>>();
   {
+    std::vector<PointType>& P = raw_pc->points;
+    const bool crop = config.filters.crop_active, dist = config.filters.dist_active;
+    const bool rate_on = config.filters.rate_active && config.filters.rate_value >= 1;   // (the reference divides by the value)
+    const bool fov = config.filters.fov_active;
+    const float mn0 = crop ? config.filters.cropBoxMin[0] : 0.f, mn1 = crop ? config.filters.cropBoxMin[1] : 0.f,
+                mn2 = crop ? config.filters.cropBoxMin[2] : 0.f;
+    const float mx0 = crop ? config.filters.cropBoxMax[0] : 0.f, mx1 = crop ? config.filters.cropBoxMax[1] : 0.f,
+                mx2 = crop ? config.filters.cropBoxMax[2] : 0.f;
     const float min_dist = (float)config.filters.min_dist;
-    const int rate = config.filters.rate_value;
-    const std::vector<PointType>& P = raw_pc->points;
-    input_pc->points.reserve(P.size());
-    for (size_t i = 0; i < P.size(); i++) {
-      bool keep = isInRange(P[i]);
-      if (config.filters.dist_active) keep = keep && (std::sqrt(s3(P[i].x * P[i].x, P[i].y * P[i].y, P[i].z * P[i].z)) > min_dist);
-      if (config.filters.rate_active) keep = keep && ((long)i % rate == 0);
-      if (keep) input_pc->points.push_back(P[i]);
+    const float fov_angle = config.filters.fov_angle;
+    const long rate = config.filters.rate_value;
+    const size_t n = P.size();
+    std::vector<PointType>& Q = input_pc->points;
+    static const bool prof_prep = std::getenv("FLIMO_PROF_PREP") != nullptr;
+    const double tq0 = prof_prep ? now_s() : 0.0;
+    Q.resize(n);                                   // upper bound; trimmed below (no per-point capacity checks)
+    const double tq1 = prof_prep ? now_s() : 0.0;
+    size_t k = 0, m = 0;
+    long phase = 0;                                // k % rate without a division per point
+    // Branches on the data itself (which side of the crop box, nearer than min_dist) mispredict on every other point of a
+    // real sweep; the tests are evaluated without short-circuit and only their rarely-true combination is branched on, the
+    // kept points are stored unconditionally and the output cursor advances by the verdict.
+    for (size_t i = 0; i < n; i++) {
+      const PointType p = P[i];
+      const bool finite = std::isfinite(p.x) & std::isfinite(p.y) & std::isfinite(p.z);
+      const bool outside = (p.x < mn0) | (p.y < mn1) | (p.z < mn2) | (p.x > mx0) | (p.y > mx1) | (p.z > mx2);   // not strictly inside the box
+      if (!(finite & (!crop | outside))) continue;
+      if (k != i) P[k] = p;
+      const bool pick = !rate_on || phase == 0;
+      if (rate_on && ++phase == rate) phase = 0;
+      k++;
+      if (!pick) continue;
+      bool keep = true;
+      if (fov) keep = std::fabs(std::atan2(p.y, p.x)) < fov_angle;                          // isInRange (:873-876)
+      if (dist) keep = keep & (std::sqrt(s3(p.x * p.x, p.y * p.y, p.z * p.z)) > min_dist);
+      Q[m] = p;
+      m += keep ? 1 : 0;
     }
+    const double tq2 = prof_prep ? now_s() : 0.0;
+    P.resize(k);
+    Q.resize(m);
+    raw_pc->is_dense = true;
+    if (prof_prep) fprintf(stderr, "[flimo prep] resize %.0f us, loop %.0f us, trim %.0f us (n = %zu -> %zu -> %zu)\n", (tq1 - tq0) * 1e6, (tq2 - tq1) * 1e6, (now_s() - tq2) * 1e6, n, k, m);
   }
   if (config.debug) original_scan = std::make_shared<pcl::PointCloud<PointType>>(*input_pc);
   const double t1 = now_s();
