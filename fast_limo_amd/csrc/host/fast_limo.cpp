@@ -916,7 +916,21 @@ bool Localizer::deskewPointCloud(pcl::PointCloud<PointType>::Ptr& pc, double& st
   // hand over to the GPU: per-point absolute times + the IMU frames
   const size_t n = sorted->points.size();
   std::vector<double> t(n);
-  for (size_t k = 0; k < n; k++) t[k] = extract(sorted->points[k]) + offset;
+  {
+    // the same expressions as `extract` above, without a std::function call per point
+    const std::vector<PointType>& S = sorted->points;
+    if (sensor == SensorType::OUSTER) {
+      if (eos) for (size_t k = 0; k < n; k++) t[k] = (sweep_ref_time - S[k].t * 1e-9f) + offset;
+      else for (size_t k = 0; k < n; k++) t[k] = (sweep_ref_time + S[k].t * 1e-9f) + offset;
+    } else if (sensor == SensorType::VELODYNE) {
+      if (eos) for (size_t k = 0; k < n; k++) t[k] = (sweep_ref_time - S[k].time) + offset;
+      else for (size_t k = 0; k < n; k++) t[k] = (sweep_ref_time + S[k].time) + offset;
+    } else if (sensor == SensorType::HESAI) {
+      for (size_t k = 0; k < n; k++) t[k] = S[k].timestamp + offset;
+    } else {
+      for (size_t k = 0; k < n; k++) t[k] = S[k].timestamp * 1e-9f + offset;
+    }
+  }
   std::vector<flimo_frame> fr(frames.size());
   for (size_t i = 0; i < frames.size(); i++) {
     const State& F = frames[i];
