@@ -182,8 +182,10 @@ def main():
     assert rc1 == 1 and rc2 == 0, (rc1, rc2)
     x_ref = loc.get_x()
 
+    reg = loc.register_resident_call(x_prior, P_prior)     # arguments and prototype bound once: the loop times the library
+
     def step():
-        rc = loc.register_resident(x_prior, P_prior)
+        rc = reg()
         assert rc == 0, rc
 
     def barrier():
