@@ -34,7 +34,8 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-E_FALLBACK = 46.64              # oracle leaf-point distance evaluations per query on cfg 2
+E_FALLBACK = 40.37              # oracle leaf-point distance evaluations per query on cfg 2, mean over the 4 passes of the
+                                # benchmark registration (what cpu_baseline measures at N = 1; used when it does not run: N > 1, --no-cpu-baseline)
 NBR_BYTES = 32                  # bytes the k-NN kernel writes per query (5 indices + flag, padded)
 
 
@@ -276,12 +277,14 @@ def main():
             drot = float(2.0 * np.abs(x_ref[3:6] - x_o[3:6]).max())
             out["pose_err_vs_cpu"] = {"pos_m": dpos, "rot_rad": drot, "tolerance": 1e-4}
         Eq = E if E else E_FALLBACK
-        bytes_per_query = 16.0 + 16.0 * Eq + NBR_BYTES
+        if not E and (args.rings, args.azimuths, args.map_points, args.box) != (64, 1024, 1000000, 100.0):
+            Eq = None                      # the constant only describes configs[1]
+        bytes_per_query = (16.0 + 16.0 * Eq + NBR_BYTES) if Eq else None
         qpl = tot["queries"] / max(tot["passes"], 1)               # queries per k-NN launch
         knn_s = 1e-3 * tot["knn_ms"] / max(tot["passes"], 1)        # mean launch duration (HIP events)
-        achieved = bytes_per_query * qpl / knn_s / 1e9 if knn_s > 0 else 0.0
+        achieved = bytes_per_query * qpl / knn_s / 1e9 if (knn_s > 0 and bytes_per_query) else None
         out["roofline"] = {"bound": "hbm", "kernel": "knn5_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                           "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(qpl),
+                           "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": pmc_traffic(qpl),
                            "bytes_per_query": bytes_per_query, "E_evals_per_query": Eq,
                            "queries_per_launch": qpl, "mean_launch_us": knn_s * 1e6, "timed_launches": tot["passes"],
                            "stage_us_per_pass": {"knn": 1e3 * tot["knn_ms"] / max(tot["passes"], 1),
