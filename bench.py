@@ -160,7 +160,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    n_gpus = args.gpus
+    n_gpus = world                      # one rank per GPU; `--gpus` documents the launch, WORLD_SIZE is what actually runs
+    if args.gpus != world and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1; reporting n_gpus={world}", file=sys.stderr)
 
     import torch
     dist = None
