@@ -201,10 +201,10 @@ def main():
         step()
     # level 1: start/stop HIP events attached to the k-NN dispatch (on the context's own stream).  A timed dispatch costs
     # about 25 us of wall time, so the launches are SAMPLED: every (4k+1)-th pass -- the stride walks through the 4 pass
-    # positions of a step evenly -- at least 25 passes apart (8 samples over the default 50 steps, about 2 % of `value`),
-    # about 24 samples for long runs.  FLIMO_BENCH_TIMING_STRIDE=1 times every launch.
+    # positions of a step evenly -- 8 samples over the timed region (every 25th pass of the default 50 steps, about 2 % of
+    # `value`; every launch of a very short run), more for long runs (one per 81 passes).  FLIMO_BENCH_TIMING_STRIDE=1 times all.
     loc.hip.set_timing(int(os.environ.get('FLIMO_BENCH_TIMING', '1')))
-    auto_stride = max(25, ((4 * args.steps // 24) // 4) * 4 + 1)
+    auto_stride = min(81, ((4 * args.steps // 8) // 4) * 4 + 1)        # 8 samples (short runs: every launch), one per 81 passes at most
     loc.hip.set_timing_stride(int(os.environ.get('FLIMO_BENCH_TIMING_STRIDE', str(auto_stride))))
     loc.hip.timing_totals(reset=True)
     passes0 = loc.hip.pass_count()
