@@ -1,7 +1,7 @@
 """Developer script: wall time of the FULL Localizer::updatePointCloud path (host filters + time sort + upload +
 GPU deskew + update + transform + map insert) on config 2, scan after scan, GPU vs oracle."""
 import sys, os, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 from fast_limo_amd import synth, api

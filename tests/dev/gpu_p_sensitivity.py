@@ -1,7 +1,7 @@
 """Developer script: from IDENTICAL state every scan (the oracle's x, P handed to the product), how far apart do the two
 posteriors land?  Prints per scan the pose / state / covariance deviation and the condition number of P."""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 import oracle_py as O

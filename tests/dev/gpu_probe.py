@@ -1,7 +1,7 @@
 """Developer probe (runs on the GPU box through gpurun): parity of the HIP path against the CPU
 oracle on cfg-2-like inputs and a sweep of kernel variants.  Not part of the product."""
 import sys, os, time, json
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 import oracle_py as O

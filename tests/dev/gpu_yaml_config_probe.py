@@ -1,7 +1,7 @@
 """Developer script: wall time per scan in the reference's shipped configuration (config/kitti.yaml: crop, min distance,
 every 4th point, 1 m voxel grid, caps 1e4 / 5000, LiDAR off the IMU) on KITTI-sized raw sweeps, GPU product vs CPU oracle."""
 import sys, os, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 from fast_limo_amd import synth, api

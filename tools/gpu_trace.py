@@ -4,7 +4,7 @@ Prints, per phase boundary, when (relative to the first block's start, in us) th
 import os, sys, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ.setdefault("FLIMO_HIP_LIB", os.path.join(ROOT, "fast_limo_amd", "libflimo_hip_trace.so"))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, ROOT)
 import numpy as np
 from fast_limo_amd import synth, _lib
 

@@ -1,10 +1,10 @@
 #!/bin/bash
-# usage (GPU box): tools/prof_full_path.sh <tag>   -- rocprofv3 kernel summary of tools/gpu_full_path.py (GPU only)
+# usage (GPU box): tools/prof_full_path.sh <tag>   -- rocprofv3 kernel summary of tests/dev/gpu_full_path.py (GPU only)
 tag=${1:-fp}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/prof_$tag
 cd /tmp && export TMPDIR=/tmp
-ORACLE=0 NSCANS=${NSCANS:-8} timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 $root/tools/gpu_full_path.py > $out.log 2>&1
+ORACLE=0 NSCANS=${NSCANS:-8} timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 $root/tests/dev/gpu_full_path.py > $out.log 2>&1
 cd $root
 f=$(find $out -name "*kernel_stats.csv" | head -1)
 python3 - "$f" <<'PY'
