@@ -577,7 +577,8 @@ def test_incremental_index_equals_full_sort(built, oracle):
             assert mm == 0, (k, mm, merges, builds)
         mm, merges, builds = ctx.grid_selfcheck()
         print("index updates: %d merges, %d full builds, map %d" % (merges, builds, ctx.map_size()))
-        assert merges >= 25 and builds <= 16, (merges, builds)      # slack = max(8 cells, 1/8 extent) per grown side
+        if not os.environ.get("FLIMO_FULL_REBUILD"):             # (the A/B switch sorts everything on every insert)
+            assert merges >= 25 and builds <= 16, (merges, builds)      # slack = max(8 cells, 1/8 extent) per grown side
         q = (rng.uniform(-30, 30, (4000, 3)) + [40, -14, 0]).astype(np.float32)
         q[:, 2] = rng.uniform(0, 5, 4000)
         idx, sqd, cnt = ctx.knn(q, 5)
