@@ -56,8 +56,8 @@ HIP_SYMBOLS = [
     "flimo_scan_voxel_filter", "flimo_raw_scan_set", "flimo_deskew_resident", "flimo_deskew",
     "flimo_match_reduce", "flimo_match_fetch", "flimo_match_fetch_H",
     "flimo_scan_to_world", "flimo_map_add_scan",
-    "flimo_set_timing", "flimo_set_timing_stride", "flimo_pass_count", "flimo_map_grid_selfcheck", "flimo_set_debug_records", "flimo_set_lanes_per_query", "flimo_last_kernel_ms",
-    "flimo_last_candidates_per_query", "flimo_last_widen_count", "flimo_timing_totals", "flimo_insert_rule_replay", "flimo_plane_fit5_host", "flimo_plane_eval5_host", "flimo_calculate_H_host",
+    "flimo_set_timing", "flimo_set_timing_stride", "flimo_pass_count", "flimo_fused_pass_count", "flimo_map_grid_selfcheck", "flimo_set_debug_records", "flimo_set_lanes_per_query", "flimo_last_kernel_ms",
+    "flimo_last_candidates_per_query", "flimo_last_widen_count", "flimo_last_stragglers", "flimo_timing_totals", "flimo_insert_rule_replay", "flimo_plane_fit5_host", "flimo_plane_eval5_host", "flimo_calculate_H_host",
 ]
 
 _hip = None
@@ -111,6 +111,8 @@ def load_hip():
     L.flimo_set_timing_stride.argtypes = [vp, C.c_int]
     L.flimo_pass_count.restype = C.c_ulonglong
     L.flimo_pass_count.argtypes = [vp]
+    L.flimo_fused_pass_count.restype = C.c_ulonglong
+    L.flimo_fused_pass_count.argtypes = [vp]
     L.flimo_map_grid_selfcheck.restype = C.c_int
     L.flimo_map_grid_selfcheck.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.flimo_set_debug_records.argtypes = [vp, C.c_int]
@@ -122,6 +124,8 @@ def load_hip():
     L.flimo_calculate_H_host.argtypes = [f64p, f32p, f32p, f32p, C.c_size_t, C.c_int, f64p, f64p]
     L.flimo_last_widen_count.restype = C.c_int
     L.flimo_last_widen_count.argtypes = [vp]
+    L.flimo_last_stragglers.restype = C.c_int
+    L.flimo_last_stragglers.argtypes = [vp]
     L.flimo_last_candidates_per_query.restype = C.c_double
     L.flimo_last_candidates_per_query.argtypes = [vp]
     for name in HIP_SYMBOLS:
@@ -277,6 +281,9 @@ class HipCtx:
     def pass_count(self) -> int:
         return int(self._L.flimo_pass_count(self._h))
 
+    def fused_pass_count(self) -> int:
+        return int(self._L.flimo_fused_pass_count(self._h))
+
     def grid_selfcheck(self):
         """(mismatching words of the incrementally maintained index vs a from-scratch sort, merges, full builds)."""
         mm = C.c_uint64(0)
@@ -304,6 +311,9 @@ class HipCtx:
 
     def last_widen_count(self) -> int:
         return int(self._L.flimo_last_widen_count(self._h))
+
+    def last_stragglers(self) -> int:
+        return int(self._L.flimo_last_stragglers(self._h))
 
     def last_candidates_per_query(self) -> float:
         return float(self._L.flimo_last_candidates_per_query(self._h))

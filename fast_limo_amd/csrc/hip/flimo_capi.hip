@@ -91,6 +91,15 @@ struct flimo_ctx {
   double* h_out256 = nullptr;      // pinned + mapped: the last fit block writes the result straight to host memory
   double* d_out256_host = nullptr; // device alias of h_out256
   unsigned int* d_ticket = nullptr;
+  // fit2 (per-pass fast path): per-block partials of the FIT_LIVE sums, granule slots in mapped host memory
+  double* d_fit2_partials = nullptr;
+  size_t fit2_partials_cap = 0;
+  double* h_granules = nullptr;    // pinned + mapped: [FIT_GROUPS][FIT_LIVE_PAD] x {sum, pass number}
+  double* d_granules_host = nullptr;
+  unsigned char live_idx[FIT_LIVE_PAD];   // live sum k -> raw MFMA accumulator index (from the calibrated layout)
+  bool fit2 = true;                // FLIMO_FIT2=0: the fast path uses fit_kernel (A/B checks)
+  bool fuse = true;                // FLIMO_FUSE=0: k-NN and fit stay separate dispatches in every pass (A/B checks)
+  unsigned long long fused_passes = 0;
   unsigned long long pass_seq = 0;  // last pass number published by the fit kernel
   unsigned long long* d_cand = nullptr;
   unsigned long long* h_cand = nullptr;  // pinned
@@ -113,6 +122,10 @@ struct flimo_ctx {
   bool recs_valid = false, dbg_valid = false;
   PrevPass prev{};                 // previous pass of the same resident scan (k-NN pruning bound); valid = 0 after any scan change
   bool prune = true;               // FLIMO_PRUNE=0 disables the bound (A/B checks)
+  int tail_pass1 = -1;             // FLIMO_TAIL_PASS1: 1 = the first pass of a scan always uses the in-kernel tail, 0 = never, default: by the straggler count of the last first pass
+  int stragglers_pass1 = 1 << 30;  // queries of the last first pass of a scan that needed more than their 3x3x3 block (unknown: many)
+  int last_stragglers = -1;        // the same of the last pass (-1: not reported by that pass's path)
+  bool tail = true;                // FLIMO_TAIL=0: pending queries go to the worklist + widen_kernel dispatch instead of being finished inside the k-NN launch (A/B checks)
 };
 
 static int fail(flimo_ctx* c, int code, const char* fmt, ...) {
@@ -238,6 +251,8 @@ extern "C" int flimo_ctx_create(int device, flimo_ctx** out) {
             hipMalloc(&c->d_out256, FIT_GROUPS * FIT_SLOT * sizeof(double)) == hipSuccess &&
             hipHostMalloc((void**)&c->h_out256, FIT_GROUPS * FIT_SLOT * sizeof(double), hipHostMallocMapped) == hipSuccess &&
             hipHostGetDevicePointer((void**)&c->d_out256_host, c->h_out256, 0) == hipSuccess &&
+            hipHostMalloc((void**)&c->h_granules, FIT_GROUPS * FIT_LIVE_PAD * 2 * sizeof(double), hipHostMallocMapped) == hipSuccess &&
+            hipHostGetDevicePointer((void**)&c->d_granules_host, c->h_granules, 0) == hipSuccess &&
             hipMalloc(&c->d_ticket, FIT_GROUPS * sizeof(unsigned int)) == hipSuccess &&
             hipMemset(c->d_ticket, 0, FIT_GROUPS * sizeof(unsigned int)) == hipSuccess &&
             hipMalloc(&c->d_cand, sizeof(unsigned long long)) == hipSuccess &&
@@ -247,6 +262,7 @@ extern "C" int flimo_ctx_create(int device, flimo_ctx** out) {
             hipHostMalloc((void**)&c->h_cand, sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess;
   if (!ok) { flimo_ctx_destroy(c); return FLIMO_ERR_HIP; }
   memset(c->h_out256, 0, FIT_GROUPS * FIT_SLOT * sizeof(double));
+  memset(c->h_granules, 0, FIT_GROUPS * FIT_LIVE_PAD * 2 * sizeof(double));
   // calibrate the v_mfma_f64_16x16x4_f64 accumulator layout: D[i][j] = j + 16 i
   launch_mfma_layout(c->stream, c->d_out256);
   if (hipMemcpyAsync(c->h_out256, c->d_out256, 256 * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
@@ -259,11 +275,27 @@ extern "C" int flimo_ctx_create(int device, flimo_ctx** out) {
     seen[code] = true;
     c->mfma_idx[code / 16][code % 16] = r;
   }
+  {
+    // the sums the filter reads: upper triangle of H^T H (78), H^T h (12), M (1)
+    int k = 0;
+    for (int i = 0; i < 12; i++) for (int j = i; j < 12; j++) c->live_idx[k++] = (unsigned char)c->mfma_idx[i][j];
+    for (int i = 0; i < 12; i++) c->live_idx[k++] = (unsigned char)c->mfma_idx[i][12];
+    c->live_idx[k++] = (unsigned char)c->mfma_idx[13][13];
+    for (; k < FIT_LIVE_PAD; k++) c->live_idx[k] = 0;
+  }
   const char* e = getenv("FLIMO_LPQ");
   if (e) { int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) c->lanes_per_query = v; }
   c->book = insert_book_create();
   e = getenv("FLIMO_PRUNE");
   if (e) c->prune = atoi(e) != 0;
+  e = getenv("FLIMO_TAIL_PASS1");
+  if (e) c->tail_pass1 = atoi(e) != 0;
+  e = getenv("FLIMO_FUSE");
+  if (e) c->fuse = atoi(e) != 0;
+  e = getenv("FLIMO_FIT2");
+  if (e) c->fit2 = atoi(e) != 0;
+  e = getenv("FLIMO_TAIL");
+  if (e) c->tail = atoi(e) != 0;
   e = getenv("FLIMO_XCD_STRIPE");
   if (e) set_xcd_stripe(atoi(e));
   e = getenv("FLIMO_HOST_INSERT");
@@ -287,6 +319,8 @@ extern "C" void flimo_ctx_destroy(flimo_ctx* c) {
   (void)hipFree(c->d_frames); (void)hipFree(c->d_recs); (void)hipFree(c->d_dbg);
   (void)hipFree(c->d_partials); (void)hipFree(c->d_out256); (void)hipFree(c->d_cand); (void)hipFree(c->d_ticket);
   if (c->h_out256) (void)hipHostFree(c->h_out256);
+  if (c->h_granules) (void)hipHostFree(c->h_granules);
+  (void)hipFree(c->d_fit2_partials);
   if (c->h_cand) (void)hipHostFree(c->h_cand);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   for (int k = 0; k < 2; k++) if (c->h_frames[k]) (void)hipHostFree(c->h_frames[k]);
@@ -651,6 +685,13 @@ static int ensure_scan(flimo_ctx* c, size_t n) {
   int* wl = nullptr;
   double* fp = nullptr;
   const size_t fpn = (size_t)fit_blocks((int)cap) * 256;
+  {
+    const size_t f2n = (size_t)std::max(fit2_blocks((int)cap), fused_blocks((int)cap)) * FIT_LIVE_PAD;
+    double* f2 = nullptr;
+    HIPCHK(c, hipMalloc(&f2, f2n * sizeof(double)));
+    (void)hipFree(c->d_fit2_partials);
+    c->d_fit2_partials = f2; c->fit2_partials_cap = f2n;
+  }
   HIPCHK(c, hipMalloc(&so, cap * sizeof(float4)));
   HIPCHK(c, hipMalloc(&rs, cap * sizeof(float4)));
   HIPCHK(c, hipMalloc(&ts, cap * sizeof(double)));
@@ -833,6 +874,7 @@ extern "C" int flimo_deskew(flimo_ctx* c, const float* xyz, size_t n, size_t str
 // ---- measurement pass -------------------------------------------------------------------------
 extern "C" int flimo_set_timing(flimo_ctx* c, int level) { if (!c) return FLIMO_ERR_INVALID; c->timing = level < 0 ? 0 : (level > 2 ? 2 : level); return FLIMO_OK; }
 extern "C" unsigned long long flimo_pass_count(const flimo_ctx* c) { return c ? c->pass_seq : 0ull; }
+extern "C" unsigned long long flimo_fused_pass_count(const flimo_ctx* c) { return c ? c->fused_passes : 0ull; }
 extern "C" int flimo_set_timing_stride(flimo_ctx* c, int every) { if (!c || every < 1) return FLIMO_ERR_INVALID; c->timing_stride = every; return FLIMO_OK; }
 extern "C" int flimo_set_debug_records(flimo_ctx* c, int on) { if (!c) return FLIMO_ERR_INVALID; c->debug_recs = on != 0; return FLIMO_OK; }
 extern "C" int flimo_set_lanes_per_query(flimo_ctx* c, int l) {
@@ -849,6 +891,7 @@ extern "C" int flimo_last_kernel_ms(const flimo_ctx* c, float* knn_ms, float* wi
   return FLIMO_OK;
 }
 extern "C" int flimo_last_widen_count(const flimo_ctx* c) { return c ? c->last_widen_count : 0; }
+extern "C" int flimo_last_stragglers(const flimo_ctx* c) { return c ? c->last_stragglers : -1; }
 extern "C" int flimo_timing_totals(flimo_ctx* c, double* knn_ms, double* widen_ms, double* fit_ms, long long* passes,
                                    long long* queries, int reset) {
   if (!c) return FLIMO_ERR_INVALID;
@@ -896,8 +939,7 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   PoseMats P;
   pose_from_x26(x26, P);
   MatchParams mp;
-  mp.max_dist_plane = (float)cfg->MAX_DIST_PLANE;     // the gate compares float sq. distance with the double
-                                                      // threshold; identical unless MAX_DIST_PLANE is not a float
+  mp.max_dist_plane_d = cfg->MAX_DIST_PLANE;          // the gate compares the float sq. distance with the DOUBLE threshold (Plane.cpp:47)
   mp.plane_threshold = (float)cfg->PLANE_THRESHOLD;
   mp.estimate_extrinsics = cfg->estimate_extrinsics ? 1 : 0;
   mp.n_queries = (int)nq;
@@ -921,24 +963,51 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   const int tlev = (c->timing == 1 && c->timing_stride > 1 && ((c->pass_seq + 1) % (unsigned long long)c->timing_stride) != 0) ? 0 : c->timing;
   if (tlev > 1) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   // level 1: the two events ride on the k-NN dispatch itself (kernel begin / end, no extra packets)
-  c->prev.heavy = (mp.max_ring >= 2 && mp.max_ring <= 3) ? c->heavy_threshold : 0xffffffffu;   // only when the wave-per-query kernel follows
+  // the k-NN launch finishes its own stragglers (in-kernel tail) for gates of up to 3 rings; the worklist + widening dispatch
+  // remains for wider gates and for the developer switches (FLIMO_TAIL=0, FLIMO_HEAVY)
+  const bool heavy_on = c->heavy_threshold != 0xffffffffu;
+  // First pass of a scan (no bound from a previous pass): with a poor prior whole waves of far-off points are pending at once,
+  // and a wave finishing 32 such queries two lanes each is one long chain -- those are better spread over the chip by the
+  // worklist dispatch.  With a good prior (the usual case in a sequence) the first pass has a handful of stragglers like any
+  // other: the count every pass publishes with its result decides for the next scan.
+  const bool first_pass = !c->prev.valid;
+  const bool tail_here = !first_pass || (c->tail_pass1 >= 0 ? c->tail_pass1 != 0 : c->stragglers_pass1 <= 1024);
+  const bool tail = c->tail && tail_here && !heavy_on && mp.max_ring >= 2 && mp.max_ring <= 3;
+  c->prev.heavy = (!tail && mp.max_ring >= 2 && mp.max_ring <= 3) ? c->heavy_threshold : 0xffffffffu;   // only when the wave-per-query kernel follows
+  // One launch for the whole pass (k-NN + tail + fit + reduction) whenever the tail applies, no records are wanted and the
+  // k-NN runs with its default two lanes per query
+  const bool fused = tail && c->fuse && c->fit2 && !want_recs && tlev < 2 && c->lanes_per_query == 2;
+  const unsigned long long seq = ++c->pass_seq;
+  if (fused) {
+    launch_match_fused(c->stream, c->grid, c->d_scan_sorted, n_all, P, mp, c->d_nbr, c->d_wl, c->d_wl_count, nullptr, c->prev,
+                       c->live_idx, c->d_fit2_partials, c->d_granules_host, c->d_ticket, seq, tlev == 1 ? c->ev[0] : nullptr,
+                       tlev == 1 ? c->ev[1] : nullptr);
+    c->fused_passes++;
+  } else
   launch_knn5(c->stream, c->lanes_per_query, c->grid, c->d_scan_sorted, n_all, P, mp.max_ring, c->d_nbr, c->d_wl,
-              c->d_wl_count, c->debug_recs ? c->d_cand : nullptr, c->prev, tlev == 1 ? c->ev[0] : nullptr,
+              c->d_wl_count, c->debug_recs ? c->d_cand : nullptr, c->prev, tail ? 1 : 0, tlev == 1 ? c->ev[0] : nullptr,
               tlev == 1 ? c->ev[1] : nullptr);
   if (c->prune) { memcpy(c->prev.RT, P.RT, sizeof(c->prev.RT)); c->prev.valid = 1; }   // the records now belong to this pose
   const double tpb = prof ? now_us() : 0.0;
   if (tlev > 1) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-  launch_widen(c->stream, c->grid, c->d_scan_sorted, P, mp.max_ring, c->d_nbr, c->d_wl, c->d_wl_count,
-               c->debug_recs ? c->d_cand : nullptr);
+  if (!tail)
+    launch_widen(c->stream, c->grid, c->d_scan_sorted, P, mp.max_ring, c->d_nbr, c->d_wl, c->d_wl_count,
+                 c->debug_recs ? c->d_cand : nullptr);
   const double tpc = prof ? now_us() : 0.0;
   if (want_count) HIPCHK(c, hipMemcpyAsync(c->h_wl_count, c->d_wl_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   if (tlev > 1) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   // fit + reductions; the last block writes the 16x16 accumulator to mapped host memory, publishes the
   // pass number and re-arms the ticket and the worklist counter
-  const unsigned long long seq = ++c->pass_seq;
   // MAX_NUM_MATCHES path: the fit kernel only writes the records (no reduction), one fused kernel ranks them in scan
   // order, reduces the first MAX_NUM_MATCHES and publishes to slot 0
   const bool fused_cap = cap_binds && !c->debug_recs;
+  const bool use_fit2 = c->fit2 && !want_recs && tlev < 2;      // the per-pass fast path (granule results)
+  if (fused) {
+    // the fit and the reduction ran inside the k-NN launch
+  } else if (use_fit2)
+    launch_fit2(c->stream, c->grid, c->d_scan_sorted, n_all, c->d_nbr, P, mp, c->live_idx, c->d_fit2_partials, c->d_granules_host,
+                c->d_ticket, c->d_wl_count, seq, tlev == 1 ? c->ev[2] : nullptr, tlev == 1 ? c->ev[3] : nullptr);
+  else
   launch_fit(c->stream, c->grid, c->d_scan_sorted, n_all, c->d_nbr, P, mp, fused_cap ? nullptr : c->d_fit_partials,
              want_recs ? c->d_recs : nullptr, c->debug_recs ? c->d_dbg : nullptr, cap_binds ? c->d_out256 : c->d_out256_host,
              c->d_ticket, c->d_wl_count, seq);
@@ -952,7 +1021,42 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   HIPCHK(c, hipGetLastError());
   const double tp1 = prof ? now_us() : 0.0;
   if (c->debug_recs) HIPCHK(c, hipMemcpyAsync(c->h_cand, c->d_cand, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-  if (!c->debug_recs && tlev < 2) {
+  double acc[256];
+  if (use_fit2) {
+    // low-latency completion: every sum arrives as a 16-byte granule {value, pass number}; a group's slot is complete when
+    // all of its FIT_LIVE tags carry this pass (the last granule is polled, then all are checked)
+    unsigned long long spins = 0;
+    bool synced = false;
+    for (int g = 0; g < FIT_GROUPS && !synced; g++) {
+      volatile unsigned long long* tags = reinterpret_cast<volatile unsigned long long*>(c->h_granules + (size_t)g * FIT_LIVE_PAD * 2);
+      for (;;) {
+        if (tags[2 * FIT_LIVE + 1] == seq) {                   // the last granule stored (straggler count), then every sum
+          bool all = true;
+          for (int k = 0; k < FIT_LIVE; k++) all = all && (tags[2 * k + 1] == seq);
+          if (all) break;
+        }
+        _mm_pause();
+        if (++spins > 40000000ull) { HIPCHK(c, hipStreamSynchronize(c->stream)); synced = true; break; }   // also surfaces launch errors
+      }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    // slot sums in slot order, then the full 16x16 raw layout the decode below reads
+    double live[FIT_LIVE];
+    for (int k = 0; k < FIT_LIVE; k++) {
+      double r = c->h_granules[2 * k];
+      for (int g = 1; g < FIT_GROUPS; g++) r += c->h_granules[((size_t)g * FIT_LIVE_PAD + k) * 2];
+      live[k] = r;
+    }
+    c->last_stragglers = (int)llround(c->h_granules[2 * FIT_LIVE]);
+    if (first_pass) c->stragglers_pass1 = c->last_stragglers;
+    for (int t = 0; t < 256; t++) acc[t] = 0.0;
+    {
+      int k = 0;
+      for (int i = 0; i < 12; i++) for (int j = i; j < 12; j++) { acc[c->mfma_idx[i][j]] = live[k]; acc[c->mfma_idx[j][i]] = live[k]; k++; }
+      for (int i = 0; i < 12; i++) acc[c->mfma_idx[i][12]] = live[k++];
+      acc[c->mfma_idx[13][13]] = live[k++];
+    }
+  } else if (!c->debug_recs && tlev < 2) {
     // low-latency completion: spin on the pass number every reduction group publishes to host memory (one slot on
     // the MAX_NUM_MATCHES path)
     unsigned long long spins = 0;
@@ -979,6 +1083,17 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
       (void)hipEventElapsedTime(&c->last_widen_ms, c->ev[1], c->ev[2]);
       (void)hipEventElapsedTime(&c->last_fit_ms, c->ev[2], c->ev[3]);
       c->tot_widen_ms += c->last_widen_ms; c->tot_fit_ms += c->last_fit_ms;
+    } else if (fused) {
+      c->last_fit_ms = 0.f; c->last_widen_ms = 0.f;            // one dispatch: everything is in the k-NN figure
+    } else if (use_fit2) {
+      // level 1: the fit dispatch carries its own pair of events (kernel begin / end); the host saw the granules, the
+      // kernel's end-of-dispatch signal may still be a moment away
+      if (hipEventElapsedTime(&c->last_fit_ms, c->ev[2], c->ev[3]) != hipSuccess) {
+        HIPCHK(c, hipEventSynchronize(c->ev[3]));
+        (void)hipEventElapsedTime(&c->last_fit_ms, c->ev[2], c->ev[3]);
+      }
+      c->tot_fit_ms += c->last_fit_ms;
+      c->last_widen_ms = 0.f;
     }
     c->tot_passes++; c->tot_queries += n_all;
   }
@@ -997,12 +1112,14 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   if (want_count) c->last_widen_count = *c->h_wl_count;
   if (c->debug_recs) c->last_cand_per_query = (double)(*c->h_cand) / (double)nq;
   // final sum over the reduction groups in slot order (the records path delivers one slot)
-  double acc[256];
-  const int slots = cap_binds ? 1 : FIT_GROUPS;
-  for (int t = 0; t < 256; t++) {
-    double r = c->h_out256[t];
-    for (int g = 1; g < slots; g++) r += c->h_out256[(size_t)g * FIT_SLOT + t];
-    acc[t] = r;
+  if (!use_fit2) {
+    c->last_stragglers = -1;
+    const int slots = cap_binds ? 1 : FIT_GROUPS;
+    for (int t = 0; t < 256; t++) {
+      double r = c->h_out256[t];
+      for (int g = 1; g < slots; g++) r += c->h_out256[(size_t)g * FIT_SLOT + t];
+      acc[t] = r;
+    }
   }
   for (int i = 0; i < 12; i++) {
     for (int j = 0; j < 12; j++) HTH[i * 12 + j] = acc[c->mfma_idx[i][j]];

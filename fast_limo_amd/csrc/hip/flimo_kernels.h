@@ -4,12 +4,15 @@
 #include "flimo_types.h"
 
 namespace flimo {
+struct FuseArgs;
 
 // flimo_kernels.hip
 // per pass: k-NN (fast path + worklist widening), then fit + in-block reduction, then the final sum
 void launch_knn5(hipStream_t st, int lanes_per_query, const GridView& G, const float4* scan_sorted, int n,
                  const PoseMats& P, int max_ring, void* nbr, int* wl, int* wl_count, unsigned long long* cand,
-                 const PrevPass& prev, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+                 const PrevPass& prev, int tail, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, const struct FuseArgs* fuse = nullptr);
+// tail != 0: queries that need more than the 3x3x3 block are finished inside the k-NN launch itself (gates of at most 3
+// rings; launch_knn5 clears the flag otherwise) and launch_widen has nothing to do
 void launch_widen(hipStream_t st, const GridView& G, const float4* scan_sorted, const PoseMats& P, int max_ring, void* nbr,
                   int* wl, int* wl_count, unsigned long long* cand);
 int fit_blocks(int n);
@@ -22,6 +25,22 @@ constexpr int FIT_SLOT = 264;
 void launch_fit(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const void* nbr, const PoseMats& P,
                 const MatchParams& mp, double* partials, Rec16* recs, RecDbg* dbg, double* out256, unsigned int* ticket,
                 int* wl_count, unsigned long long seq);
+// fit2: the per-pass fast path (no records, no caps).  Only the FIT_LIVE sums the filter reads leave a block (upper triangle
+// of H^T H, H^T h, M; live_idx[k] = index of sum k among the wave's 256 raw MFMA accumulators); the last block of each
+// group publishes FIT_LIVE_PAD 16-byte granules {sum, pass number as bits} to out_granules[group] (mapped host memory).
+constexpr int FIT_LIVE = 91;
+constexpr int FIT_LIVE_PAD = 96;
+int fit2_blocks(int n);
+void launch_fit2(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const void* nbr, const PoseMats& P,
+                 const MatchParams& mp, const unsigned char* live_idx, double* partials, void* out_granules, unsigned int* ticket,
+                 int* wl_count, unsigned long long seq, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+// The whole measurement pass in ONE launch (k-NN fast path + in-kernel tail + fit + reduction + publish; two lanes per query, gates of
+// 2..3 rings): partials needs fused_blocks(n) * FIT_LIVE_PAD doubles; results arrive as launch_fit2's granules.
+int fused_blocks(int n);
+void launch_match_fused(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const PoseMats& P, const MatchParams& mp,
+                        void* nbr, int* wl, int* wl_count, unsigned long long* cand, const PrevPass& prev,
+                        const unsigned char* live_idx, double* partials, void* out_granules, unsigned int* ticket,
+                        unsigned long long seq, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 void launch_reduce_final(hipStream_t st, const double* partials, int nparts, double* out256);
 size_t nbr_rec_size();
 size_t wl_entry_size();   // bytes per worklist entry (query index, world position, 5th-distance hint)

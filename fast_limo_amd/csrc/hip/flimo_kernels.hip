@@ -367,19 +367,257 @@ __device__ __forceinline__ void knn5_body(const float4* __restrict__ pts, uint32
   }
 }
 
-template <int L, int SLOTS>
+
+// ------------------------------------------------------------------------------------------
+// In-kernel widening ("tail") of the per-pass k-NN: the queries of a wave whose 5-ball is not provably inside their
+// 3x3x3 block are finished by the SAME wave right after its fast path -- no worklist, no second dispatch, no
+// cross-wave protocol.  The wave's F pending queries share its 64 lanes: Gl = 64 / pow2ceil(F) lanes per query
+// (64 lanes for a lone straggler of a converged pass, 2 lanes each when a whole wave of far-off points of the first pass is
+// pending), so the work of a wave is spread over all of its lanes whatever F is.  Per query and ring r (2 or 3):
+//   * the (2r+1)^2 rows of the ring-r block are dealt to the group's lanes; a row (and the cells at its two ends) that
+//     cannot hold one of the five nearest points -- farther than the bound known from the 3x3x3 block's own 5th
+//     distance and from the previous pass of the same scan -- is dropped (exact, same rule as the fast path);
+//   * row bounds -> LDS, group prefix sum, flattened candidate stream (four loads in flight per lane), private best-5,
+//     min-extraction across the group; the block is searched afresh (the bound, not the list, is what the 3x3x3 pass hands over);
+//   * exactness test as everywhere: the 5-ball inside the searched block, else the next ring, never beyond max_ring.
+// ------------------------------------------------------------------------------------------
+struct FitIdx { unsigned char raw[FIT_LIVE_PAD]; };   // live sum k -> index into the wave's 256 raw MFMA accumulators
+constexpr int TAIL_MAX_RING = 3;
+constexpr int TAIL_STRIDE = 52;                 // >= (2 * TAIL_MAX_RING + 1)^2 + 1
+struct __align__(16) WaveLds {                  // one per wave of the block
+  uint32_t off[32][TAIL_STRIDE];                // [group][row]: stream offset of the row; [rows] = total
+  uint32_t lo[32][TAIL_STRIDE];                 // map position of the row's first candidate
+  int src[64];                                  // lane of the wave's i-th pending query
+  int res[64][8];                               // fused pass: the tail hands a finished query back to its own lane (5 indices, flag)
+};
+// the fused pass reuses the tables after the tail: off -> the wave's 16 x 65 float row tile, lo -> its 256 raw f64 accumulators
+static_assert(sizeof(uint32_t) * 32 * TAIL_STRIDE >= sizeof(float) * 16 * 65, "row tile fits");
+static_assert(sizeof(uint32_t) * 32 * TAIL_STRIDE >= sizeof(double) * 256, "accumulators fit");
+
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ void knn5_tail(const GridView& G, int max_ring, NbrRec* __restrict__ nbr, bool pending, int p,
+                                          float gx, float gy, float gz, uint32_t hint_bits, float b2, WaveLds& S,
+                                          int* __restrict__ straggler_count, unsigned long long* __restrict__ cand_total,
+                                          bool keep_res) {
+  const int lane = threadIdx.x & 63;
+  const u64 B = __ballot(pending);
+  const int F = __popcll(B);
+  if (F == 0) return;                                         // wave-uniform
+  if (lane == 0) atomicAdd(straggler_count, F);               // statistics only (published with the pass result)
+  if (pending) S.src[__popcll(B & ((1ull << lane) - 1ull))] = lane;
+  wave_lds_sync();
+  int ngroups = 1;
+  while (ngroups < F && ngroups < 32) ngroups <<= 1;          // pow2ceil(F), at most 32 (>= 2 lanes per query)
+  const int Gl = 64 / ngroups;
+  const int lg = __ffs(Gl) - 1;
+  const int grp = lane >> lg, sub = lane & (Gl - 1);
+  const int maxdim = max(G.nx, max(G.ny, G.nz));
+  const float margin = 1.0e-3f + 4.0e-7f * (float)maxdim;
+  uint32_t* const t_off = S.off[grp];
+  uint32_t* const t_lo = S.lo[grp];
+  const double none = __longlong_as_double((long long)KEY_NONE);
+  int cand = 0;
+  for (int base = 0; base < F; base += ngroups) {
+    const int qi = base + grp;
+    bool active = qi < F;
+    const int src = S.src[active ? qi : 0];
+    const float qx = __shfl(gx, src, 64), qy = __shfl(gy, src, 64), qz = __shfl(gz, src, 64);
+    const int qp = __shfl(p, src, 64);
+    const float hint = __uint_as_float((uint32_t)__shfl((int)hint_bits, src, 64));   // 5th sq. distance inside the 3x3x3 block (+inf: none)
+    float bnd2 = __shfl(b2, src, 64);                          // pruning bound, cell units squared (+inf: none)
+    const float fx = (qx - G.ox) * G.inv_cell, fy = (qy - G.oy) * G.inv_cell, fz = (qz - G.oz) * G.inv_cell;
+    const float flx = floorf(fminf(fmaxf(fx, -1.0e9f), 1.0e9f)), fly = floorf(fminf(fmaxf(fy, -1.0e9f), 1.0e9f)),
+                flz = floorf(fminf(fmaxf(fz, -1.0e9f), 1.0e9f));
+    const int cx = (int)flx, cy = (int)fly, cz = (int)flz;
+    const float rx = fminf(fmaxf(fx - flx, 0.f), 1.f), ry = fminf(fmaxf(fy - fly, 0.f), 1.f),
+                rz = fminf(fmaxf(fz - flz, 0.f), 1.f);
+    const float edge = fminf(fminf(fminf(rx, 1.f - rx), fminf(ry, 1.f - ry)), fminf(rz, 1.f - rz));
+    int r = 2;
+    {
+      const int ox_ = cx < 0 ? -cx : (cx >= G.nx ? cx - G.nx + 1 : 0);
+      const int oy_ = cy < 0 ? -cy : (cy >= G.ny ? cy - G.ny + 1 : 0);
+      const int oz_ = cz < 0 ? -cz : (cz >= G.nz ? cz - G.nz + 1 : 0);
+      r = max(r, max(ox_, max(oy_, oz_)));                     // first ring that reaches the grid at all
+      if (hint >= 0.f && hint < INFINITY) {                    // an upper bound of the true 5th distance: its ring, its ball
+        const float need = fl_sqrt(hint) * G.inv_cell * (1.f + 4.0e-6f) - edge + margin;
+        r = max(r, (int)ceilf(fminf(need, 1.0e9f)));
+        const float rc = (fl_sqrt(hint) * (1.f + 1.0e-5f) + 1.0e-6f) * G.inv_cell;
+        bnd2 = fminf(bnd2, rc * rc * (1.f + 1.0e-5f));
+      }
+      r = min(r, max_ring);
+    }
+    u64 best[5] = {KEY_NONE, KEY_NONE, KEY_NONE, KEY_NONE, KEY_NONE};
+    int flag = 0;
+    for (;;) {
+      if (!__any(active)) break;
+      if (active) {
+        const int side = 2 * r + 1, rows = side * side;
+        const int rpl = (rows + Gl - 1) >> lg;                 // rows per lane (contiguous share)
+        const int j0 = sub * rpl, j1 = min(rows, j0 + rpl);
+        uint32_t mysum = 0;
+        for (int jb = 0; jb < rpl; jb += 8) {
+          uint32_t lo8[8], hi8[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            const int j = j0 + jb + u;
+            lo8[u] = 0u; hi8[u] = 0u;
+            if (jb + u < rpl && j < j1) {
+              const int jz = j / side, jy = j - jz * side;
+              const int dy = jy - r, dz = jz - r;
+              const int yy = cy + dy, zz = cz + dz;
+              const float a = fmaxf(slab_dist(dy, ry) - margin, 0.f), b = fmaxf(slab_dist(dz, rz) - margin, 0.f);
+              const float dyz2 = a * a + b * b;
+              if (dyz2 <= bnd2 && yy >= 0 && yy < G.ny && zz >= 0 && zz < G.nz) {
+                // cells of the row the bound's ball can reach: offset +d is (d - rx) away, offset -d is (rx + d - 1) away
+                const float xr = fl_sqrt(fmaxf(bnd2 - dyz2, 0.f)) * (1.f + 1.0e-6f) + margin + 1.0e-4f;
+                const int dr = (int)fminf(floorf(fminf(xr + rx, 1.0e6f)), (float)r);
+                const int dl = (int)fminf(floorf(fminf(xr + (1.f - rx), 1.0e6f)), (float)r);
+                const int x0 = max(cx - dl, 0), x1 = min(cx + dr, G.nx - 1);
+                if (x0 <= x1) {
+                  const size_t rowbase = ((size_t)zz * (size_t)G.ny + (size_t)yy) * (size_t)G.nx;
+                  lo8[u] = G.cell_start[rowbase + x0];
+                  hi8[u] = G.cell_start[rowbase + x1 + 1];
+                }
+              }
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            const int j = j0 + jb + u;
+            if (jb + u < rpl && j < j1) {
+              const uint32_t len = hi8[u] - lo8[u];
+              t_lo[j] = lo8[u];
+              t_off[j] = len;                                   // length for now, offset after the scan below
+              mysum += len;
+            }
+          }
+        }
+        // group prefix sum (the Gl lanes of a group are contiguous and aligned)
+        uint32_t inc = mysum;
+        for (int o = 1; o < Gl; o <<= 1) {
+          const uint32_t v = __shfl_up(inc, o, 64);
+          if (sub >= o) inc += v;
+        }
+        const uint32_t total = (uint32_t)__shfl((int)inc, (grp << lg) + Gl - 1, 64);
+        wave_lds_sync();
+        {
+          uint32_t run = inc - mysum;
+          for (int j = j0; j < j1; j++) { const uint32_t len = t_off[j]; t_off[j] = run; run += len; }
+          if (sub == Gl - 1) t_off[rows] = total;
+        }
+        wave_lds_sync();
+        double k5[5] = {none, none, none, none, none};
+        const uint32_t last = total - 1u;
+        for (uint32_t s0 = (uint32_t)sub; s0 < total; s0 += 4u * (uint32_t)Gl) {
+          float4 q[4];
+          uint32_t id[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const uint32_t s = min(s0 + (uint32_t)(u * Gl), last);
+            int a = 0;                                         // row a with off[a] <= s < off[a + 1]
+#pragma unroll
+            for (int step = 32; step >= 1; step >>= 1) { const int an = min(a + step, rows); a = (t_off[an] <= s) ? an : a; }
+            id[u] = t_lo[a] + (s - t_off[a]);
+            q[u] = G.pts[id[u]];
+          }
+          asm volatile("" : "+v"(q[0].x), "+v"(q[0].y), "+v"(q[0].z), "+v"(q[1].x), "+v"(q[1].y), "+v"(q[1].z),
+                            "+v"(q[2].x), "+v"(q[2].y), "+v"(q[2].z), "+v"(q[3].x), "+v"(q[3].y), "+v"(q[3].z));
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const bool live = s0 + (uint32_t)(u * Gl) < total;
+            const float d = sqdist3(qx, qy, qz, q[u].x, q[u].y, q[u].z);
+            best5_insert(k5, key_make(live ? d : INFINITY, live ? id[u] : 0xffffffffu));
+          }
+        }
+        cand += total > (uint32_t)sub ? (int)((total - (uint32_t)sub + (uint32_t)Gl - 1u) >> lg) : 0;
+        u64 mine[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++) mine[i] = (u64)__double_as_longlong(k5[i]);
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+          double md = __longlong_as_double((long long)mine[0]);
+          for (int o = 1; o < Gl; o <<= 1) md = key_min(md, __shfl_xor(md, o, 64));
+          const u64 m = (u64)__double_as_longlong(md);
+          best[k] = m;
+          if (mine[0] == m) { mine[0] = mine[1]; mine[1] = mine[2]; mine[2] = mine[3]; mine[3] = mine[4]; mine[4] = KEY_NONE; }
+        }
+        const float rg = ((float)r + edge - margin) * G.cell;
+        const float d5 = __uint_as_float((uint32_t)(best[4] >> 32));
+        const bool have5 = d5 < INFINITY;
+        const bool covers = (cx - r <= 0) && (cx + r >= G.nx - 1) && (cy - r <= 0) && (cy + r >= G.ny - 1) &&
+                            (cz - r <= 0) && (cz + r >= G.nz - 1);
+        if (have5 && (covers || d5 <= rg * rg * (1.f - 1.0e-6f))) { flag = 1; active = false; }
+        else if (covers || r >= max_ring) { flag = 0; active = false; }
+        else {
+          int rn = r + 1;
+          if (have5) {
+            const float need = fl_sqrt(d5) * G.inv_cell * (1.f + 4.0e-6f) - edge + margin;
+            rn = max(r + 1, (int)ceilf(fminf(need, 1.0e9f)));
+            const float rc = (fl_sqrt(d5) * (1.f + 1.0e-5f) + 1.0e-6f) * G.inv_cell;
+            bnd2 = fminf(bnd2, rc * rc * (1.f + 1.0e-5f));
+          }
+          r = min(rn, max_ring);
+        }
+        wave_lds_sync();                                        // the tables are rewritten by the next ring
+      }
+    }
+    if (qi < F && sub == 0) {
+      int4 a, b;
+      a.x = (int)(uint32_t)best[0]; a.y = (int)(uint32_t)best[1]; a.z = (int)(uint32_t)best[2]; a.w = (int)(uint32_t)best[3];
+      b.x = (int)(uint32_t)best[4]; b.y = flag; b.z = (int)(uint32_t)(best[4] >> 32); b.w = (flag == 1) ? 1 : 0;
+      int4* o = reinterpret_cast<int4*>(&nbr[qp]);
+      o[0] = a;
+      o[1] = b;
+      if (keep_res) {
+        int4* rr = reinterpret_cast<int4*>(S.res[src]);
+        rr[0] = a;
+        rr[1] = b;
+      }
+    }
+  }
+  if (cand_total && cand) atomicAdd(cand_total, (unsigned long long)cand);
+}
+
+// FUSE: the whole measurement pass in ONE launch (fast path of flimo_match_reduce): every wave goes on from its queries'
+// neighbours (fast path + tail) to their plane fit, residual and H row and to the H^T H reduction (fit_reduce_publish below).
+struct FuseArgs {
+  MatchParams mp;
+  FitIdx idx;
+  double* partials;
+  double2* granules;
+  unsigned int* ticket;
+  unsigned long long seq;
+};
+template <int ROWS>
+__device__ __forceinline__ void fit_reduce_publish(const float (&v)[16], bool owns_row, int row, float* sr, double* sa0, double* sa1,
+                                                   double* sa2, double* sa3, unsigned int* s_last, const FitIdx& idx,
+                                                   double* __restrict__ partials, double2* __restrict__ out_granules,
+                                                   unsigned int* __restrict__ ticket, int* __restrict__ wl_count,
+                                                   unsigned long long seq);
+FLIMO_DEV void fit_row(const GridView& G, const PoseMats& P, const MatchParams& mp, const int (&ids)[5], float gx, float gy, float gz,
+                       float (&v)[16]);
+
+template <int L, int SLOTS, bool FUSE>
 __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __restrict__ scan_sorted, int n,
                                                    PoseMats P, int max_ring, NbrRec* __restrict__ nbr,
                                                    int* __restrict__ wl, int* __restrict__ wl_count,
-                                                   unsigned long long* __restrict__ cand_total, PrevPass prev) {
+                                                   unsigned long long* __restrict__ cand_total, PrevPass prev, int tail,
+                                                   FuseArgs fa) {
   constexpr int QPB = 256 / L;          // queries per block; SLOTS = candidate loads in flight per lane
+  __shared__ WaveLds s_w[4];
+  __shared__ unsigned int s_last;
   const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
   const int p = chunk * QPB + threadIdx.x / L;
   const int sub = threadIdx.x % L;
-  if (p >= n) return;
+  const bool in_range = p < n;          // no early exit: the tail below is a wave-wide phase
   TRACE(0, 0);
 
-  const float4 sp = scan_sorted[p];
+  const float4 sp = scan_sorted[in_range ? p : 0];
   float gx, gy, gz;
   xform4(P.RT, sp.x, sp.y, sp.z, gx, gy, gz);
   TRACE(0, 1);
@@ -389,7 +627,7 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
   // neighbours are still in the map, and the query moved by |g - g_old|, so d5 <= sqrt(d5_old) + |g - g_old|.
   // Cells farther than that cannot hold any of the five nearest points and are skipped (exactly, no heuristic).
   float b2 = INFINITY;                               // bound, squared, in cell units
-  if (prev.valid) {
+  if (prev.valid && in_range) {
     const int4 pb = reinterpret_cast<const int4*>(&nbr[p])[1];       // idx[4], flag, d5 bits, "d5 valid"
     if (pb.y == 1 && pb.w == 1) {
       float ox_, oy_, oz_;
@@ -403,7 +641,7 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
   int flag = 0;
   u64 best[5] = {KEY_NONE, KEY_NONE, KEY_NONE, KEY_NONE, KEY_NONE};
   int cand = 0;
-  if ((fx == fx) && (fy == fy) && (fz == fz)) {
+  if (in_range && (fx == fx) && (fy == fy) && (fz == fz)) {
     const float lim = 1.0e9f;
     const float flx = floorf(fminf(fmaxf(fx, -lim), lim)), fly = floorf(fminf(fmaxf(fy, -lim), lim)),
                 flz = floorf(fminf(fmaxf(fz, -lim), lim));
@@ -528,10 +766,13 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
     int c = cand;
 #pragma unroll
     for (int o = 1; o < L; o <<= 1) c += __shfl_xor(c, o, 64);
-    if (sub == 0) atomicAdd(cand_total, (unsigned long long)c);
+    if (sub == 0 && in_range) atomicAdd(cand_total, (unsigned long long)c);
   }
   TRACE(0, 4);
-  if (sub == 0) {
+  // pending queries (flag 2) are finished right here by this wave when the gate needs at most TAIL_MAX_RING rings
+  // (`tail`); otherwise (wider gates, the developer's crowded-block hand-over) they go to the worklist kernels
+  const bool pend_tail = tail && in_range && flag == 2;
+  if (in_range && sub == 0 && !pend_tail) {
     int4 a, b;
     a.x = (int)(uint32_t)best[0]; a.y = (int)(uint32_t)best[1]; a.z = (int)(uint32_t)best[2]; a.w = (int)(uint32_t)best[3];
     b.x = (int)(uint32_t)best[4]; b.y = min(flag, 2); b.z = (int)(uint32_t)(best[4] >> 32); b.w = (flag == 1) ? 1 : 0;   // d5 for the next pass
@@ -548,7 +789,32 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
       e[1] = make_int4((int)(uint32_t)(best[4] >> 32), flag == 3 ? 1 : 2, __float_as_int(b2), 0);
     }
   }
+  WaveLds& W = s_w[threadIdx.x >> 6];
+  if (tail) knn5_tail(G, max_ring, nbr, pend_tail && sub == 0, p, gx, gy, gz, (uint32_t)(best[4] >> 32), b2, W, wl_count, cand_total, FUSE);
   TRACE(0, 5);
+  if constexpr (FUSE) {
+    // ---- fit + reduction of this wave's queries (one row per query, computed by the pair's first lane) ----
+    const int lane = threadIdx.x & 63;
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) v[i] = 0.f;
+    wave_lds_sync();                                           // the tail's hand-backs are visible; its tables are free
+    if (sub == 0 && in_range) {
+      int ids[5] = {(int)(uint32_t)best[0], (int)(uint32_t)best[1], (int)(uint32_t)best[2], (int)(uint32_t)best[3], (int)(uint32_t)best[4]};
+      int fl = flag;
+      if (pend_tail) {
+        const int4* rr = reinterpret_cast<const int4*>(W.res[lane]);
+        const int4 a = rr[0], b = rr[1];
+        ids[0] = a.x; ids[1] = a.y; ids[2] = a.z; ids[3] = a.w; ids[4] = b.x;
+        fl = b.y;
+      }
+      if (fl == 1 && __float_as_uint(sp.w) < (uint32_t)fa.mp.n_queries) fit_row(G, P, fa.mp, ids, gx, gy, gz, v);
+    }
+    wave_lds_sync();                                           // every lane is done with W.res before the tile overwrites the tables
+    fit_reduce_publish<64 / L>(v, sub == 0, lane / L, reinterpret_cast<float*>(W.off), reinterpret_cast<double*>(s_w[0].lo),
+                               reinterpret_cast<double*>(s_w[1].lo), reinterpret_cast<double*>(s_w[2].lo),
+                               reinterpret_cast<double*>(s_w[3].lo), &s_last, fa.idx, fa.partials, fa.granules, fa.ticket, wl_count, fa.seq);
+  }
 }
 
 // Widening for the worklist (rare): ONE WAVE per query.  The (2r+1)^2 <= 49 rows of the ring-r block
@@ -557,10 +823,11 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
 // extracted with wave-wide min reductions.  r starts at the ring the fast path's own 5th distance asks for
 // (at least 2) and jumps to the ring that proves exactness, never beyond max_ring (<= 3 here; the host
 // falls back to the general kernel for larger gates).
-__global__ __launch_bounds__(256) void widen_kernel(GridView G, const float4* __restrict__ scan_sorted, PoseMats P,
+template <int WPS>   // minimum waves per SIMD the register allocation must allow (8: every wave of the 2048-block launch is resident at once)
+__global__ __launch_bounds__(256, WPS) void widen_kernel(GridView G, const float4* __restrict__ scan_sorted, PoseMats P,
                                                     int max_ring, NbrRec* __restrict__ nbr, const int* __restrict__ wl,
                                                     const int* __restrict__ wl_count,
-                                                    unsigned long long* __restrict__ cand_total) {
+                                                    unsigned long long* __restrict__ cand_total, int first_ring) {
   __shared__ uint32_t s_off[4][65];
   __shared__ uint32_t s_lo[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -587,7 +854,7 @@ __global__ __launch_bounds__(256) void widen_kernel(GridView G, const float4* __
     u64 best[5] = {KEY_NONE, KEY_NONE, KEY_NONE, KEY_NONE, KEY_NONE};
     int flag = 0;
     int cand = 0;
-    int r = (e1.y == 1) ? 1 : 2;                       // 1: a crowded 3x3x3 block handed over unsearched
+    int r = (e1.y == 1) ? 1 : first_ring;              // 1: a crowded 3x3x3 block handed over unsearched; no hint: first_ring (2, or the gate's ring: one search instead of two)
     {
       const float hint = __int_as_float(hint_bits);
       if (hint >= 0.f && hint < INFINITY) {            // an upper bound of the true 5th distance: go straight to its ring
@@ -787,7 +1054,7 @@ __global__ __launch_bounds__(FIT_THREADS) void fit_kernel(GridView G, const floa
       }
       TRACE(1, 2);
       // Plane gates (Plane.cpp:23-31): 5 neighbours, 5th SQUARED distance < MAX_DIST_PLANE
-      valid = sq[4] < mp.max_dist_plane;
+      valid = (double)sq[4] < mp.max_dist_plane_d;            // float squared distance vs the double threshold (Plane.cpp:47)
       if (valid) {
         plane_fit5(px, py, pz, n4);
         valid = plane_eval5(n4, px, py, pz, mp.plane_threshold);
@@ -916,6 +1183,178 @@ __global__ __launch_bounds__(FIT_THREADS) void fit_kernel(GridView G, const floa
     }
     TRACE(1, 7);
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// fit2 kernel: the per-pass fast path of the fit stage (no records, no caps).  Same per-point routines as fit_kernel
+// (bit-identical rows); what differs is how the launch is laid out around the two things that bound it:
+//   * a point's chain (neighbour record -> 5 gathered map points -> gates -> 5x3 QR with its correctly rounded
+//     divisions and square roots -> plane test -> H row) is ~1700 DEPENDENT instructions: one full wave per SIMD has
+//     nothing to overlap them with.  PPW points per wave (32 by default: lanes PPW..63 idle in the point stage) put
+//     64 / PPW waves on every SIMD, which interleave their chains;
+//   * the grid reduction's hand-offs: only the 91 sums the filter reads (upper triangle of H^T H, H^T h, M) leave a block,
+//     the last block of each of the FIT_GROUPS groups adds its group's partials in block order (two halves, fixed
+//     order: bit-reproducible) and publishes 16-byte {sum, pass number} granules to mapped host memory -- data and
+//     "ready" travel together, so neither an acknowledged write nor a separate flag sits on the host's critical path.
+// X = [H | h | valid]: D = X^T X on the f64 matrix core gives H^T H, H^T h and M at once (4 rows per MFMA).
+// ------------------------------------------------------------------------------------------
+
+// Plane gates + 5x3 QR + plane test + Match + calculate_H row of one query with its five neighbours (ascending distance):
+// v = [H row (12) | h = -dist | 1] when every gate passes, untouched (zeros) otherwise.
+FLIMO_DEV void fit_row(const GridView& G, const PoseMats& P, const MatchParams& mp, const int (&ids)[5], float gx, float gy, float gz,
+                       float (&v)[16]) {
+  float px[5], py[5], pz[5], sq4 = 0.f;
+#pragma unroll
+  for (int s = 0; s < 5; s++) {
+    const float4 q = G.pts[ids[s]];
+    px[s] = q.x; py[s] = q.y; pz[s] = q.z;
+    if (s == 4) sq4 = sqdist3(gx, gy, gz, q.x, q.y, q.z);
+  }
+  // Plane gates (Plane.cpp:23-31,45-48): 5 neighbours, 5th SQUARED distance (float) < MAX_DIST_PLANE (double)
+  if (!((double)sq4 < mp.max_dist_plane_d)) return;
+  float n4[4];
+  plane_fit5(px, py, pz, n4);
+  if (!plane_eval5(n4, px, py, pz, mp.plane_threshold)) return;
+  const float dist = n4[0] * gx + n4[1] * gy + n4[2] * gz + n4[3];   // Match::Match (Plane.cpp:50-52)
+  float row[12];
+  h_row(P, gx, gy, gz, n4, mp.estimate_extrinsics, row);            // calculate_H (Localizer.cpp:546-572)
+#pragma unroll
+  for (int i = 0; i < 12; i++) v[i] = row[i];
+  v[12] = -dist;
+  v[13] = 1.f;
+}
+
+// Block-wide part of a pass: the wave's ROWS rows X = [H | h | valid] -> D = X^T X on the f64 matrix core (4 rows per MFMA),
+// the 91 sums the filter reads -> per-block partial (written through) -> ticket -> the last block of each of the FIT_GROUPS
+// groups adds its group's partials in block order (two halves, fixed order: bit-reproducible) and publishes 16-byte
+// {sum, pass number} granules to mapped host memory: data and "ready" travel together, so neither an acknowledged write
+// nor a separate flag sits on the host's critical path.  Must be reached by every thread of the block.
+template <int ROWS>
+__device__ __forceinline__ void fit_reduce_publish(const float (&v)[16], bool owns_row, int row, float* sr, double* sa0, double* sa1,
+                                                   double* sa2, double* sa3, unsigned int* s_last, const FitIdx& idx,
+                                                   double* __restrict__ partials, double2* __restrict__ out_granules,
+                                                   unsigned int* __restrict__ ticket, int* __restrict__ wl_count,
+                                                   unsigned long long seq) {
+  typedef double v2d_t __attribute__((ext_vector_type(2)));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (owns_row) {
+#pragma unroll
+    for (int c = 0; c < 16; c++) sr[c * 65 + row] = v[c];
+  }
+  wave_lds_sync();
+  double4_t acc = {0.0, 0.0, 0.0, 0.0};
+  const int col = lane & 15, sub4 = lane >> 4;
+#pragma unroll
+  for (int s = 0; s < ROWS / 4; s++) {
+    const double a = (double)sr[col * 65 + 4 * s + sub4];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc, 0, 0, 0);
+  }
+  double* sa = wave == 0 ? sa0 : (wave == 1 ? sa1 : (wave == 2 ? sa2 : sa3));
+  sa[lane * 4 + 0] = acc[0]; sa[lane * 4 + 1] = acc[1]; sa[lane * 4 + 2] = acc[2]; sa[lane * 4 + 3] = acc[3];
+  __syncthreads();
+  if (threadIdx.x < FIT_LIVE) {
+    const int t = idx.raw[threadIdx.x];
+    const double r = ((sa0[t] + sa1[t]) + sa2[t]) + sa3[t];          // fixed order
+    // written through to the agent-coherent level (no dirty L2 line is left behind for the ticket to flush)
+    __hip_atomic_store(&partials[(size_t)blockIdx.x * FIT_LIVE_PAD + threadIdx.x], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  TRACE(1, 4);
+  const int group = blockIdx.x & (FIT_GROUPS - 1);
+  const int nb_g = (int)(gridDim.x / FIT_GROUPS);                  // gridDim.x is a multiple of FIT_GROUPS
+  if (threadIdx.x == 0) {
+    // every partial of this block is already performed at agent scope (write-through stores, vmcnt(0), barrier)
+    const unsigned int old = __hip_atomic_fetch_add(ticket + group, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *s_last = (old == (unsigned int)nb_g - 1u) ? 1u : 0u;
+  }
+  __syncthreads();
+  TRACE(1, 5);
+  if (*s_last) {
+    // two halves of the group's block list x 128 columns (91 live); agent-scope loads read past this XCD's L2
+    const int t = threadIdx.x & 127, part = threadIdx.x >> 7;
+    const int per = (nb_g + 1) >> 1;
+    const int k0 = part * per, k1 = min(nb_g, k0 + per);
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    if (t < FIT_LIVE) {
+      const double* base = partials + (size_t)group * FIT_LIVE_PAD + t;
+      const size_t stride = (size_t)FIT_GROUPS * FIT_LIVE_PAD;
+      int k = k0;
+      for (; k + 31 < k1; k += 32) {
+        double w[32];
+#pragma unroll
+        for (int u = 0; u < 32; u++) w[u] = __hip_atomic_load(base + (size_t)(k + u) * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int u = 0; u < 32; u += 4) { s0 += w[u]; s1 += w[u + 1]; s2 += w[u + 2]; s3 += w[u + 3]; }
+      }
+      for (; k + 3 < k1; k += 4) {
+        double w[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) w[u] = __hip_atomic_load(base + (size_t)(k + u) * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s0 += w[0]; s1 += w[1]; s2 += w[2]; s3 += w[3];
+      }
+      for (; k < k1; k++) s0 += __hip_atomic_load(base + (size_t)k * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();                                               // sa0 / sa1 are free (every thread read its block sums above)
+    (part == 0 ? sa0 : sa1)[t] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    TRACE(1, 6);
+    if (threadIdx.x < FIT_LIVE) {
+      // one 16-byte store per sum: {value, pass number}; the host accepts a slot when all of its tags carry this pass
+      v2d_t g;
+      g.x = sa0[threadIdx.x] + sa1[threadIdx.x];
+      g.y = __longlong_as_double((long long)seq);
+      double2* o = out_granules + (size_t)group * FIT_LIVE_PAD + threadIdx.x;
+      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(o), "v"(g) : "memory");
+    }
+    if (threadIdx.x == 0) {
+      // granule FIT_LIVE: the number of queries of this pass that needed more than their 3x3x3 block (group 0; the k-NN
+      // phase of every block of the launch is complete: every block has taken its ticket), then the counter is re-armed
+      v2d_t g;
+      g.x = (group == 0) ? (double)__hip_atomic_load(wl_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+      g.y = __longlong_as_double((long long)seq);
+      double2* o = out_granules + (size_t)group * FIT_LIVE_PAD + FIT_LIVE;
+      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(o), "v"(g) : "memory");
+      ticket[group] = 0u;                                          // ready for the next pass (visible at kernel end)
+      if (group == 0) *wl_count = 0;
+    }
+    TRACE(1, 7);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// fit2 kernel: the fit stage as its own dispatch when the pass is not fused (first pass of a scan with a poor prior, other
+// lanes-per-query settings): neighbour records -> rows (fit_row) -> fit_reduce_publish.  PPW points per wave.
+// ------------------------------------------------------------------------------------------
+template <int PPW>
+__global__ __launch_bounds__(256) void fit2_kernel(GridView G, const float4* __restrict__ scan_sorted, int n,
+                                                   const NbrRec* __restrict__ nbr, PoseMats P, MatchParams mp, FitIdx idx,
+                                                   double* __restrict__ partials, double2* __restrict__ out_granules,
+                                                   unsigned int* __restrict__ ticket, int* __restrict__ wl_count,
+                                                   unsigned long long seq) {
+  __shared__ float s_rec[4][16 * 65];       // per wave: [col][row] with stride 65
+  __shared__ double s_acc[4][256];
+  __shared__ unsigned int s_last;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
+  const int p = (chunk * 4 + wave) * PPW + lane;
+  float v[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) v[i] = 0.f;
+  TRACE(1, 0);
+  if (lane < PPW && p < n) {
+    const float4 sp = scan_sorted[p];
+    const int4* nb = reinterpret_cast<const int4*>(&nbr[p]);
+    const int4 a = nb[0], b = nb[1];
+    float gx, gy, gz;
+    xform4(P.RT, sp.x, sp.y, sp.z, gx, gy, gz);
+    const int ids[5] = {a.x, a.y, a.z, a.w, b.x};
+    TRACE(1, 1);
+    if (b.y == 1 && __float_as_uint(sp.w) < (uint32_t)mp.n_queries) fit_row(G, P, mp, ids, gx, gy, gz, v);
+  }
+  TRACE(1, 3);
+  fit_reduce_publish<PPW>(v, lane < PPW, lane, s_rec[wave], s_acc[0], s_acc[1], s_acc[2], s_acc[3], &s_last, idx, partials,
+                          out_granules, ticket, wl_count, seq);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1268,32 +1707,40 @@ static int g_slots = 0;   // 0: default per L; developer override through FLIMO_
 template <int L>
 static void launch_knn5_L(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const PoseMats& P,
                           int max_ring, void* nbr, int* wl, int* wl_count, unsigned long long* cand, const PrevPass& prev,
-                          hipEvent_t e0, hipEvent_t e1) {
+                          int tail, hipEvent_t e0, hipEvent_t e1, const FuseArgs* fuse) {
   const int qpb = 256 / L;
   const int blocks = round_up8((n + qpb - 1) / qpb);
   if (g_slots == 0) { const char* e = getenv("FLIMO_SLOTS"); g_slots = e ? atoi(e) : -1; }
   const int slots = g_slots > 0 ? g_slots : (L <= 4 ? 8 : 4);
+  if constexpr (L == 2) {
+    if (fuse) {      // the whole pass in one launch (blocks is a multiple of 8 = FIT_GROUPS)
+      hipExtLaunchKernelGGL((knn5_kernel<2, 8, true>), dim3(blocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand, prev, 1, *fuse);
+      return;
+    }
+  }
+  FuseArgs nofuse{};
   // e0 / e1 (optional) are attached to the dispatch itself: they read the kernel's own begin / end
   // timestamps, without the extra barrier packets of hipEventRecord
   if (slots >= 8)
-    hipExtLaunchKernelGGL((knn5_kernel<L, 8>), dim3(blocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand, prev);
+    hipExtLaunchKernelGGL((knn5_kernel<L, 8, false>), dim3(blocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand, prev, tail, nofuse);
   else if (slots >= 4)
-    hipExtLaunchKernelGGL((knn5_kernel<L, 4>), dim3(blocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand, prev);
+    hipExtLaunchKernelGGL((knn5_kernel<L, 4, false>), dim3(blocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand, prev, tail, nofuse);
   else
-    hipExtLaunchKernelGGL((knn5_kernel<L, 2>), dim3(blocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand, prev);
+    hipExtLaunchKernelGGL((knn5_kernel<L, 2, false>), dim3(blocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand, prev, tail, nofuse);
 }
 
 void launch_knn5(hipStream_t st, int lanes_per_query, const GridView& G, const float4* scan_sorted, int n,
                  const PoseMats& P, int max_ring, void* nbr, int* wl, int* wl_count, unsigned long long* cand,
-                 const PrevPass& prev, hipEvent_t e0, hipEvent_t e1) {
+                 const PrevPass& prev, int tail, hipEvent_t e0, hipEvent_t e1, const FuseArgs* fuse) {
   if (n <= 0) return;
+  if (max_ring < 2 || max_ring > TAIL_MAX_RING) tail = 0;
   switch (lanes_per_query) {
-    case 1: launch_knn5_L<1>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, e0, e1); break;
-    case 2: launch_knn5_L<2>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, e0, e1); break;
-    case 4: launch_knn5_L<4>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, e0, e1); break;
-    case 8: launch_knn5_L<8>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, e0, e1); break;
-    case 32: launch_knn5_L<32>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, e0, e1); break;
-    default: launch_knn5_L<16>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, e0, e1); break;
+    case 1: launch_knn5_L<1>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse); break;
+    case 2: launch_knn5_L<2>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse); break;
+    case 4: launch_knn5_L<4>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse); break;
+    case 8: launch_knn5_L<8>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse); break;
+    case 32: launch_knn5_L<32>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse); break;
+    default: launch_knn5_L<16>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse); break;
   }
 }
 
@@ -1306,8 +1753,15 @@ static int widen_blocks() {
 void launch_widen(hipStream_t st, const GridView& G, const float4* scan_sorted, const PoseMats& P, int max_ring, void* nbr,
                   int* wl, int* wl_count, unsigned long long* cand) {
   if (max_ring <= 1) return;
-  if (max_ring <= 3)
-    hipLaunchKernelGGL(widen_kernel, dim3(widen_blocks()), dim3(256), 0, st, G, scan_sorted, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand);
+  static int tight = -1, r3 = -1;
+  if (tight < 0) { const char* e = getenv("FLIMO_WIDEN_TIGHT"); tight = e ? atoi(e) : 0; e = getenv("FLIMO_WIDEN_R3"); r3 = e ? atoi(e) : 1; }   // measured at 6.6 k pending queries: 19.3 -> 16.3 us
+  const int first_ring = r3 ? max_ring : 2;
+  if (max_ring <= 3) {
+    if (tight)
+      hipLaunchKernelGGL((widen_kernel<8>), dim3(widen_blocks()), dim3(256), 0, st, G, scan_sorted, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand, first_ring);
+    else
+      hipLaunchKernelGGL((widen_kernel<1>), dim3(widen_blocks()), dim3(256), 0, st, G, scan_sorted, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand, first_ring);
+  }
   else
     hipLaunchKernelGGL(widen_general_kernel, dim3(256), dim3(256), 0, st, G, scan_sorted, P, max_ring, (NbrRec*)nbr, wl, wl_count);
 }
@@ -1344,6 +1798,44 @@ void launch_fit(hipStream_t st, const GridView& G, const float4* scan_sorted, in
     case 512: launch_fit_T<512>(st, G, scan_sorted, n, nbr, P, mp, partials, recs, dbg, out256, ticket, wl_count, seq); break;
     default: launch_fit_T<256>(st, G, scan_sorted, n, nbr, P, mp, partials, recs, dbg, out256, ticket, wl_count, seq); break;
   }
+}
+
+static int g_fit_ppw = 0;          // points per wave of the fit2 kernel: 64 / 32 / 16 (FLIMO_FIT_PPW), default 64
+int fit2_ppw() {
+  if (g_fit_ppw == 0) {
+    const char* e = getenv("FLIMO_FIT_PPW");
+    const int v = e ? atoi(e) : 0;
+    g_fit_ppw = (v == 64 || v == 32 || v == 16) ? v : 64;    // measured: 64 -> 10.7 us, 32 -> 13.0, 16 -> 20.0 (the QR is VALU-issue bound, not latency bound)
+  }
+  return g_fit_ppw;
+}
+int fit2_blocks(int n) { const int per = 4 * fit2_ppw(); const int b = (n + per - 1) / per; return (b + FIT_GROUPS - 1) / FIT_GROUPS * FIT_GROUPS; }
+
+void launch_fit2(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const void* nbr, const PoseMats& P,
+                 const MatchParams& mp, const unsigned char* live_idx, double* partials, void* out_granules, unsigned int* ticket,
+                 int* wl_count, unsigned long long seq, hipEvent_t e0, hipEvent_t e1) {
+  if (n <= 0) return;
+  FitIdx idx;
+  for (int i = 0; i < FIT_LIVE_PAD; i++) idx.raw[i] = i < FIT_LIVE ? live_idx[i] : 0;
+  const int blocks = fit2_blocks(n);
+  switch (fit2_ppw()) {
+    case 64: hipExtLaunchKernelGGL((fit2_kernel<64>), dim3(blocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, idx, partials, (double2*)out_granules, ticket, wl_count, seq); break;
+    case 16: hipExtLaunchKernelGGL((fit2_kernel<16>), dim3(blocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, idx, partials, (double2*)out_granules, ticket, wl_count, seq); break;
+    default: hipExtLaunchKernelGGL((fit2_kernel<32>), dim3(blocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, idx, partials, (double2*)out_granules, ticket, wl_count, seq); break;
+  }
+}
+
+int fused_blocks(int n) { return round_up8((n + 127) / 128); }
+void launch_match_fused(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const PoseMats& P, const MatchParams& mp,
+                        void* nbr, int* wl, int* wl_count, unsigned long long* cand, const PrevPass& prev,
+                        const unsigned char* live_idx, double* partials, void* out_granules, unsigned int* ticket,
+                        unsigned long long seq, hipEvent_t e0, hipEvent_t e1) {
+  if (n <= 0) return;
+  FuseArgs fa;
+  fa.mp = mp;
+  for (int i = 0; i < FIT_LIVE_PAD; i++) fa.idx.raw[i] = i < FIT_LIVE ? live_idx[i] : 0;
+  fa.partials = partials; fa.granules = (double2*)out_granules; fa.ticket = ticket; fa.seq = seq;
+  launch_knn5_L<2>(st, G, scan_sorted, n, P, mp.max_ring, nbr, wl, wl_count, cand, prev, 1, e0, e1, &fa);
 }
 
 void launch_reduce_final(hipStream_t st, const double* partials, int nparts, double* out256) {

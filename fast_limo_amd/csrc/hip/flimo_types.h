@@ -42,7 +42,8 @@ struct PoseMats {
 };
 
 struct MatchParams {
-  float max_dist_plane;    // compared with the 5th SQUARED distance (Plane.cpp:47)
+  double max_dist_plane_d; // MAX_DIST_PLANE as configured: the gate compares the FLOAT 5th squared distance, widened, with
+                           // this double (Plane.cpp:45-48)
   float plane_threshold;   // Plane.cpp:110
   int estimate_extrinsics;
   int n_queries;           // min(N, MAX_NUM_PC2MATCH)

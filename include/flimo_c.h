@@ -147,12 +147,18 @@ int flimo_set_timing(flimo_ctx* ctx, int level);
 int flimo_set_timing_stride(flimo_ctx* ctx, int every);
 /* number of flimo_match_reduce passes launched on this context so far */
 unsigned long long flimo_pass_count(const flimo_ctx* ctx);
+/* ... of which ran as ONE launch (k-NN + in-kernel widening + fit + reduction); the others used separate dispatches (first pass
+ * of a scan with a poor prior, records / caps / debug, non-default lanes per query, gates wider than 3 rings) */
+unsigned long long flimo_fused_pass_count(const flimo_ctx* ctx);
 int flimo_last_kernel_ms(const flimo_ctx* ctx, float* knn_ms, float* widen_ms, float* fit_ms);
 /* sums over every pass since the last reset (timing must be on): per-stage GPU ms, passes, k-NN queries */
 int flimo_timing_totals(flimo_ctx* ctx, double* knn_ms, double* widen_ms, double* fit_ms, long long* passes,
                         long long* queries, int reset);
 /* number of scan points of the last pass that needed more than the 3x3x3 cell block */
 int flimo_last_widen_count(const flimo_ctx* ctx);
+/* the same count as published by the pass itself with its result (fast path), -1 when the last pass took a path that does
+ * not report it (records / caps / timing level 2) */
+int flimo_last_stragglers(const flimo_ctx* ctx);
 /* also write the per-point debug part of flimo_match_rec (plane, neighbours, candidate counts) */
 int flimo_set_debug_records(flimo_ctx* ctx, int on);
 /* lanes of a wavefront that cooperate on one scan point in the k-NN kernel: 1, 2, 4, 8, 16 or 32 */

@@ -16,26 +16,43 @@ ctx.map_config(cell_size=0.5)
 ctx.map_add(mp)
 ctx.scan_set(scan)
 x0 = np.zeros(26); x0[6] = 1.0; x0[10] = 1.0; x0[25] = -9.809
+if os.environ.get("X0") == "tstar":        # the converged pose: few stragglers, like passes 2..4 of a registration
+    x0[0:3] = synth.T_STAR_T
+    r, p_, y = [np.deg2rad(v) for v in synth.T_STAR_RPY_DEG]
+    cr, sr, cp, sp, cy, sy = np.cos(r / 2), np.sin(r / 2), np.cos(p_ / 2), np.sin(p_ / 2), np.cos(y / 2), np.sin(y / 2)
+    x0[3:7] = [sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy, cr * cp * cy + sr * sp * sy]
 mcfg = _lib.default_match_cfg(MAX_NUM_PC2MATCH=10**7, MAX_NUM_MATCHES=10**7)
 lib = _lib.load_hip()
 lib.flimo_trace_read.argtypes = [C.c_int, C.c_void_p, C.c_size_t]
 for it in range(6):
     ctx.match_reduce(x0, mcfg)
-names = {0: ["start", "query loaded", "row bounds loaded", "candidates done", "merged", "stored"],
+names = {0: ["start", "query loaded", "row bounds loaded", "candidates done", "merged", "stored (tail done)"],
          1: ["start", "scan+nbr loaded", "5 points gathered", "row computed", "partial stored", "ticket taken",
              "LAST: partials summed", "LAST: published"]}
-nblk = {0: (scan.shape[0] * int(os.environ.get("FLIMO_LPQ", 2)) + 255) // 256, 1: (scan.shape[0] + 255) // int(os.environ.get("FLIMO_FIT_THREADS", 256))}
+nblk = {0: (scan.shape[0] * int(os.environ.get("FLIMO_LPQ", 2)) + 255) // 256,
+        1: (scan.shape[0] + 255) // int(os.environ.get("FLIMO_FIT_THREADS", 256)) if os.environ.get("FLIMO_FIT2") == "0"
+           else (scan.shape[0] + 4 * int(os.environ.get("FLIMO_FIT_PPW", 32)) - 1) // (4 * int(os.environ.get("FLIMO_FIT_PPW", 32)))}
 for k in (0, 1):
     nb = nblk[k]
     buf = np.zeros(nb * 8, np.uint64)
     rc = lib.flimo_trace_read(k, buf.ctypes.data, buf.size)
     assert rc == 0, rc
     t = buf.reshape(nb, 8).astype(np.int64)
-    t0 = t[:, 0].min()
+    if k == 0:
+        t0_knn = t[:, 0].min()
+    fused = k == 1 and os.environ.get("FLIMO_FUSE", "1") != "0"
+    if fused:       # the fit / reduction stamps were written by the blocks of the fused k-NN launch: same block count, same time base
+        nb = nblk[0]
+        buf = np.zeros(nb * 8, np.uint64)
+        assert lib.flimo_trace_read(1, buf.ctypes.data, buf.size) == 0
+        t = buf.reshape(nb, 8).astype(np.int64)
+        t[:, 0:4] = 0
+    t0 = t0_knn if fused else t[:, 0].min()
     print("kernel", "knn5" if k == 0 else "fit", "blocks", nb, " (100 MHz clock: 0.01 us resolution)")
     for s, nm in enumerate(names[k]):
         col = t[:, s]
-        ok = col > 0
+        ok = col > t0 - 10**9 if fused else col > 0
+        ok = ok & (col > 0)
         if not ok.any():
             continue
         v = (col[ok] - t0) / 100.0
