@@ -332,6 +332,34 @@ __device__ __forceinline__ void best5_insert(double (&k)[5], double x) {
 }
 #define KEY_NONE 0x7f800000ffffffffull     // (+inf, -1): an empty slot of the merged list
 
+// Minimum of a key over an aligned group of Gl lanes (2, 4, ..., 64), result in every lane of the group.  Within a row of 16
+// lanes the exchange is DPP (quad permutes, half-row and row mirrors: a couple of cycles each, no LDS crossbar round trip as with
+// ds_bpermute); across rows the four row minima are read with v_readlane.  A 5-round extraction over 64 lanes costs ~0.3 us
+// this way instead of ~1.5 us of dependent ds_bpermute pairs.
+template <int CTRL>
+__device__ __forceinline__ double key_dpp(double x) {
+  const int lo = __double2loint(x), hi = __double2hiint(x);
+  const int l2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  const int h2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(h2, l2);
+}
+__device__ __forceinline__ double key_group_min(double md, int Gl, int lane) {
+  md = key_min(md, key_dpp<0xB1>(md));                        // quad_perm [1,0,3,2]
+  if (Gl >= 4) md = key_min(md, key_dpp<0x4E>(md));           // quad_perm [2,3,0,1]
+  if (Gl >= 8) md = key_min(md, key_dpp<0x141>(md));          // row_half_mirror
+  if (Gl >= 16) md = key_min(md, key_dpp<0x140>(md));         // row_mirror
+  if (Gl >= 32) {
+    const int lo = __double2loint(md), hi = __double2hiint(md);
+    const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+    const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+    const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+    const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+    const double a = key_min(r0, r1), b = key_min(r2, r3);
+    md = (Gl >= 64) ? key_min(a, b) : (lane < 32 ? a : b);
+  }
+  return md;
+}
+
 // N candidate slots of one lane: stream positions s0, s0 + L, ...; dead slots (>= total) re-read the last position and
 // insert +inf.  All N loads are issued back to back (the empty asm consumes every loaded value at once).
 template <int L, int N>
@@ -377,22 +405,19 @@ __device__ __forceinline__ void knn5_body(const float4* __restrict__ pts, uint32
 //   * the (2r+1)^2 rows of the ring-r block are dealt to the group's lanes; a row (and the cells at its two ends) that
 //     cannot hold one of the five nearest points -- farther than the bound known from the 3x3x3 block's own 5th
 //     distance and from the previous pass of the same scan -- is dropped (exact, same rule as the fast path);
-//   * row bounds -> LDS, group prefix sum, flattened candidate stream (four loads in flight per lane), private best-5,
-//     min-extraction across the group; the block is searched afresh (the bound, not the list, is what the 3x3x3 pass hands over);
+//   * every lane walks the candidates of its own rows (bounds of four rows per round trip, eight candidate loads in flight),
+//     private best-5, min-extraction across the group (DPP); the block is searched afresh (the bound, not the list, is what
+//     the 3x3x3 pass hands over);
 //   * exactness test as everywhere: the 5-ball inside the searched block, else the next ring, never beyond max_ring.
 // ------------------------------------------------------------------------------------------
 struct FitIdx { unsigned char raw[FIT_LIVE_PAD]; };   // live sum k -> index into the wave's 256 raw MFMA accumulators
 constexpr int TAIL_MAX_RING = 3;
-constexpr int TAIL_STRIDE = 52;                 // >= (2 * TAIL_MAX_RING + 1)^2 + 1
 struct __align__(16) WaveLds {                  // one per wave of the block
-  uint32_t off[32][TAIL_STRIDE];                // [group][row]: stream offset of the row; [rows] = total
-  uint32_t lo[32][TAIL_STRIDE];                 // map position of the row's first candidate
-  int src[64];                                  // lane of the wave's i-th pending query
+  float tile[16 * 65];                          // fused pass: the wave's rows, [col][row] with stride 65
+  double acc[256];                              // fused pass: the wave's raw f64 MFMA accumulators
+  int src[64];                                  // tail: lane of the wave's i-th pending query
   int res[64][8];                               // fused pass: the tail hands a finished query back to its own lane (5 indices, flag)
 };
-// the fused pass reuses the tables after the tail: off -> the wave's 16 x 65 float row tile, lo -> its 256 raw f64 accumulators
-static_assert(sizeof(uint32_t) * 32 * TAIL_STRIDE >= sizeof(float) * 16 * 65, "row tile fits");
-static_assert(sizeof(uint32_t) * 32 * TAIL_STRIDE >= sizeof(double) * 256, "accumulators fit");
 
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -418,8 +443,6 @@ __device__ __forceinline__ void knn5_tail(const GridView& G, int max_ring, NbrRe
   const int grp = lane >> lg, sub = lane & (Gl - 1);
   const int maxdim = max(G.nx, max(G.ny, G.nz));
   const float margin = 1.0e-3f + 4.0e-7f * (float)maxdim;
-  uint32_t* const t_off = S.off[grp];
-  uint32_t* const t_lo = S.lo[grp];
   const double none = __longlong_as_double((long long)KEY_NONE);
   int cand = 0;
   for (int base = 0; base < F; base += ngroups) {
@@ -456,17 +479,19 @@ __device__ __forceinline__ void knn5_tail(const GridView& G, int max_ring, NbrRe
     for (;;) {
       if (!__any(active)) break;
       if (active) {
+        // Every lane of the group owns rows of the ring-r block (row j of lane sub: j = sub + i * Gl) and walks its own rows'
+        // candidates: bounds of four rows in one round trip, then up to eight candidate loads in flight per row.  No
+        // flattening, no tables: with 64 lanes per query (the lone straggler of a converged pass) a lane owns at most one
+        // row and the chain is two round trips (bounds, candidates) and the extraction.
         const int side = 2 * r + 1, rows = side * side;
-        const int rpl = (rows + Gl - 1) >> lg;                 // rows per lane (contiguous share)
-        const int j0 = sub * rpl, j1 = min(rows, j0 + rpl);
-        uint32_t mysum = 0;
-        for (int jb = 0; jb < rpl; jb += 8) {
-          uint32_t lo8[8], hi8[8];
+        double k5[5] = {none, none, none, none, none};
+        for (int jb = sub; jb < rows; jb += 4 * Gl) {
+          uint32_t lo4[4], hi4[4];
 #pragma unroll
-          for (int u = 0; u < 8; u++) {
-            const int j = j0 + jb + u;
-            lo8[u] = 0u; hi8[u] = 0u;
-            if (jb + u < rpl && j < j1) {
+          for (int u = 0; u < 4; u++) {
+            const int j = jb + u * Gl;
+            lo4[u] = 0u; hi4[u] = 0u;
+            if (j < rows) {
               const int jz = j / side, jy = j - jz * side;
               const int dy = jy - r, dz = jz - r;
               const int yy = cy + dy, zz = cz + dz;
@@ -480,68 +505,39 @@ __device__ __forceinline__ void knn5_tail(const GridView& G, int max_ring, NbrRe
                 const int x0 = max(cx - dl, 0), x1 = min(cx + dr, G.nx - 1);
                 if (x0 <= x1) {
                   const size_t rowbase = ((size_t)zz * (size_t)G.ny + (size_t)yy) * (size_t)G.nx;
-                  lo8[u] = G.cell_start[rowbase + x0];
-                  hi8[u] = G.cell_start[rowbase + x1 + 1];
+                  lo4[u] = G.cell_start[rowbase + x0];
+                  hi4[u] = G.cell_start[rowbase + x1 + 1];
                 }
               }
             }
           }
 #pragma unroll
-          for (int u = 0; u < 8; u++) {
-            const int j = j0 + jb + u;
-            if (jb + u < rpl && j < j1) {
-              const uint32_t len = hi8[u] - lo8[u];
-              t_lo[j] = lo8[u];
-              t_off[j] = len;                                   // length for now, offset after the scan below
-              mysum += len;
+          for (int u = 0; u < 4; u++) {
+            const uint32_t hi = hi4[u];
+            for (uint32_t i0 = lo4[u]; i0 < hi; i0 += 8u) {
+              float4 q[8];
+#pragma unroll
+              for (int w = 0; w < 8; w++) q[w] = G.pts[min(i0 + (uint32_t)w, hi - 1u)];
+              asm volatile("" : "+v"(q[0].x), "+v"(q[0].y), "+v"(q[0].z), "+v"(q[1].x), "+v"(q[1].y), "+v"(q[1].z),
+                                "+v"(q[2].x), "+v"(q[2].y), "+v"(q[2].z), "+v"(q[3].x), "+v"(q[3].y), "+v"(q[3].z),
+                                "+v"(q[4].x), "+v"(q[4].y), "+v"(q[4].z), "+v"(q[5].x), "+v"(q[5].y), "+v"(q[5].z),
+                                "+v"(q[6].x), "+v"(q[6].y), "+v"(q[6].z), "+v"(q[7].x), "+v"(q[7].y), "+v"(q[7].z));
+#pragma unroll
+              for (int w = 0; w < 8; w++) {
+                const bool live = i0 + (uint32_t)w < hi;
+                const float d = sqdist3(qx, qy, qz, q[w].x, q[w].y, q[w].z);
+                best5_insert(k5, key_make(live ? d : INFINITY, live ? i0 + (uint32_t)w : 0xffffffffu));
+              }
             }
+            cand += (int)(hi - lo4[u]);
           }
         }
-        // group prefix sum (the Gl lanes of a group are contiguous and aligned)
-        uint32_t inc = mysum;
-        for (int o = 1; o < Gl; o <<= 1) {
-          const uint32_t v = __shfl_up(inc, o, 64);
-          if (sub >= o) inc += v;
-        }
-        const uint32_t total = (uint32_t)__shfl((int)inc, (grp << lg) + Gl - 1, 64);
-        wave_lds_sync();
-        {
-          uint32_t run = inc - mysum;
-          for (int j = j0; j < j1; j++) { const uint32_t len = t_off[j]; t_off[j] = run; run += len; }
-          if (sub == Gl - 1) t_off[rows] = total;
-        }
-        wave_lds_sync();
-        double k5[5] = {none, none, none, none, none};
-        const uint32_t last = total - 1u;
-        for (uint32_t s0 = (uint32_t)sub; s0 < total; s0 += 4u * (uint32_t)Gl) {
-          float4 q[4];
-          uint32_t id[4];
-#pragma unroll
-          for (int u = 0; u < 4; u++) {
-            const uint32_t s = min(s0 + (uint32_t)(u * Gl), last);
-            int a = 0;                                         // row a with off[a] <= s < off[a + 1]
-#pragma unroll
-            for (int step = 32; step >= 1; step >>= 1) { const int an = min(a + step, rows); a = (t_off[an] <= s) ? an : a; }
-            id[u] = t_lo[a] + (s - t_off[a]);
-            q[u] = G.pts[id[u]];
-          }
-          asm volatile("" : "+v"(q[0].x), "+v"(q[0].y), "+v"(q[0].z), "+v"(q[1].x), "+v"(q[1].y), "+v"(q[1].z),
-                            "+v"(q[2].x), "+v"(q[2].y), "+v"(q[2].z), "+v"(q[3].x), "+v"(q[3].y), "+v"(q[3].z));
-#pragma unroll
-          for (int u = 0; u < 4; u++) {
-            const bool live = s0 + (uint32_t)(u * Gl) < total;
-            const float d = sqdist3(qx, qy, qz, q[u].x, q[u].y, q[u].z);
-            best5_insert(k5, key_make(live ? d : INFINITY, live ? id[u] : 0xffffffffu));
-          }
-        }
-        cand += total > (uint32_t)sub ? (int)((total - (uint32_t)sub + (uint32_t)Gl - 1u) >> lg) : 0;
         u64 mine[5];
 #pragma unroll
         for (int i = 0; i < 5; i++) mine[i] = (u64)__double_as_longlong(k5[i]);
 #pragma unroll
         for (int k = 0; k < 5; k++) {
-          double md = __longlong_as_double((long long)mine[0]);
-          for (int o = 1; o < Gl; o <<= 1) md = key_min(md, __shfl_xor(md, o, 64));
+          const double md = key_group_min(__longlong_as_double((long long)mine[0]), Gl, lane);
           const u64 m = (u64)__double_as_longlong(md);
           best[k] = m;
           if (mine[0] == m) { mine[0] = mine[1]; mine[1] = mine[2]; mine[2] = mine[3]; mine[3] = mine[4]; mine[4] = KEY_NONE; }
@@ -563,7 +559,6 @@ __device__ __forceinline__ void knn5_tail(const GridView& G, int max_ring, NbrRe
           }
           r = min(rn, max_ring);
         }
-        wave_lds_sync();                                        // the tables are rewritten by the next ring
       }
     }
     if (qi < F && sub == 0) {
@@ -811,9 +806,8 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
       if (fl == 1 && __float_as_uint(sp.w) < (uint32_t)fa.mp.n_queries) fit_row(G, P, fa.mp, ids, gx, gy, gz, v);
     }
     wave_lds_sync();                                           // every lane is done with W.res before the tile overwrites the tables
-    fit_reduce_publish<64 / L>(v, sub == 0, lane / L, reinterpret_cast<float*>(W.off), reinterpret_cast<double*>(s_w[0].lo),
-                               reinterpret_cast<double*>(s_w[1].lo), reinterpret_cast<double*>(s_w[2].lo),
-                               reinterpret_cast<double*>(s_w[3].lo), &s_last, fa.idx, fa.partials, fa.granules, fa.ticket, wl_count, fa.seq);
+    fit_reduce_publish<64 / L>(v, sub == 0, lane / L, W.tile, s_w[0].acc, s_w[1].acc, s_w[2].acc, s_w[3].acc, &s_last, fa.idx,
+                               fa.partials, fa.granules, fa.ticket, wl_count, fa.seq);
   }
 }
 
@@ -934,9 +928,7 @@ __global__ __launch_bounds__(256, WPS) void widen_kernel(GridView G, const float
       for (int i = 0; i < 5; i++) mine[i] = (u64)__double_as_longlong(k5[i]);
 #pragma unroll
       for (int k = 0; k < 5; k++) {
-        double md = __longlong_as_double((long long)mine[0]);
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) md = key_min(md, __shfl_xor(md, o, 64));
+        const double md = key_group_min(__longlong_as_double((long long)mine[0]), 64, lane);
         const u64 m = (u64)__double_as_longlong(md);
         best[k] = m;
         if (mine[0] == m) { mine[0] = mine[1]; mine[1] = mine[2]; mine[2] = mine[3]; mine[3] = mine[4]; mine[4] = KEY_NONE; }

@@ -56,11 +56,26 @@ def test_reduction_consistency_and_reproducibility(big):
     ctx = big["ctx"]
     cfg = _lib.default_match_cfg(**CAPS)
     x0 = _x0()
+    # first pass of a scan (separate k-NN / widening / fit dispatches), then two passes that run as ONE launch each
+    ctx.scan_set(big["scan"])
+    HTH1, HTh1, M1 = ctx.match_reduce(x0, cfg)
+    n_fused = ctx.fused_pass_count()
     HTH, HTh, M = ctx.match_reduce(x0, cfg)
     HTH2, HTh2, M2 = ctx.match_reduce(x0, cfg)
-    assert M == M2 and M > 60000
-    np.testing.assert_array_equal(HTH, HTH2)            # bit-reproducible
+    assert ctx.fused_pass_count() == n_fused + 2        # the hot path is the one that ran
+    assert M == M2 == M1 and M > 60000
+    np.testing.assert_array_equal(HTH, HTH2)            # bit-reproducible (fixed summation order)
     np.testing.assert_array_equal(HTh, HTh2)
+    # the two paths partition the rows differently: same sums to rounding
+    np.testing.assert_allclose(HTH1, HTH, rtol=1e-13, atol=1e-7)
+    np.testing.assert_allclose(HTh1, HTh, rtol=1e-13, atol=1e-7)
+    # ... and a fresh first pass reproduces the first pass bit for bit
+    ctx.scan_set(big["scan"])
+    HTH1b, HTh1b, M1b = ctx.match_reduce(x0, cfg)
+    assert M1b == M1
+    np.testing.assert_array_equal(HTH1, HTH1b)
+    np.testing.assert_array_equal(HTh1, HTh1b)
+    HTH, HTh, M = ctx.match_reduce(x0, cfg)
     np.testing.assert_allclose(HTH, HTH.T, rtol=0, atol=0)
     recs = ctx.match_fetch()
     valid = recs["valid"] > 0
