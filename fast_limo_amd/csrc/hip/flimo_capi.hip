@@ -417,6 +417,11 @@ static int rebuild_grid(flimo_ctx* c) {
     c->grid_merges++;
     return FLIMO_OK;
   }
+  if (getenv("FLIMO_PROF_INSERT"))
+    fprintf(stderr, "[flimo index] full layout: valid %d sorted %p full_rebuild %d force %d n_pts %u map_n %zu covers %d  box [%g %g %g | %g %g %g] grid o (%g %g %g) n (%d %d %d)\n",
+            (int)c->grid_valid, (void*)c->d_map_sorted, (int)c->full_rebuild, (int)c->force_full, c->grid.n_pts, c->map_n,
+            c->grid_valid ? (int)grid_covers(c->grid, bb) : -1, bb[0], bb[1], bb[2], bb[3], bb[4], bb[5], c->grid.ox, c->grid.oy, c->grid.oz,
+            c->grid.nx, c->grid.ny, c->grid.nz);
   c->grid_valid = false;
   float cell = c->map_cfg.cell_size > 0.f ? c->map_cfg.cell_size : 0.5f;
   int nx = 0, ny = 0, nz = 0;
@@ -434,7 +439,11 @@ static int rebuild_grid(flimo_ctx* c) {
   };
   // slack: a side the map has grown beyond since the last layout moves out by max(8 cells, 1/8 of the extent)
   for (int a = 0; a < 3; a++) { W[a] = bb[a]; W[3 + a] = bb[3 + a]; }
-  if (c->have_gbox) {
+  if (!c->have_gbox) {
+    // first layout: a little room on every side (8 cells horizontally, 4 vertically), so that the first scans inserted into a
+    // pre-built map -- their noise alone pokes through an exact box -- are merged instead of re-sorting the whole map
+    for (int a = 0; a < 3; a++) { const float pad = (a < 2 ? 8.0f : 4.0f) * cell; W[a] = bb[a] - pad; W[3 + a] = bb[3 + a] + pad; }
+  } else {
     for (int a = 0; a < 3; a++) {
       const float pad = std::max(8.0f * cell, 0.125f * (bb[3 + a] - bb[a]));
       W[a] = (bb[a] < c->gbox[a]) ? bb[a] - pad : c->gbox[a];

@@ -12,7 +12,7 @@ import math
 import numpy as np
 
 __all__ = ["rpy_to_R", "box_world_map", "box_world_scan_random", "velodyne_scan", "stationary_imu",
-           "T_STAR_T", "T_STAR_RPY_DEG"]
+           "T_STAR_T", "T_STAR_RPY_DEG", "corridor_map"]
 
 # true pose offset T* used by every config (SURVEY.md section 8 d)
 T_STAR_T = (0.30, -0.20, 0.05)
@@ -163,3 +163,28 @@ def corridor_scan(k: int, n: int, seed: int, speed: float = 10.0, sweep_s: float
     out[:, 3] = 1.0
     out[:, 4] = t.astype(np.float32)
     return out
+
+
+def corridor_map(n: int, x0: float, x1: float, seed: int, half_width: float = 6.0, sensor_height: float = 1.8,
+                 sigma: float = 0.01) -> np.ndarray:
+    """World-frame map (n, 3) float32 of the corridor `corridor_scan` drives through, over x in [x0, x1]: the same ground,
+    side walls and fins (same proportions), used to prime a multi-million-point rolling map for the config-3 stand-in."""
+    rs = np.random.RandomState(seed)
+    kind = rs.uniform(size=n)
+    gz = -sensor_height
+    pw = np.empty((n, 3), dtype=np.float64)
+    g = kind < 0.55
+    pw[g, 0] = rs.uniform(x0, x1, g.sum())
+    pw[g, 1] = rs.uniform(-half_width, half_width, g.sum())
+    pw[g, 2] = gz + rs.normal(0, sigma, g.sum())
+    w = (kind >= 0.55) & (kind < 0.85)
+    side = np.where(rs.uniform(size=w.sum()) < 0.5, -1.0, 1.0)
+    pw[w, 0] = rs.uniform(x0, x1, w.sum())
+    pw[w, 1] = side * half_width + rs.normal(0, sigma, w.sum())
+    pw[w, 2] = gz + rs.uniform(0, 6.0, w.sum())
+    f = kind >= 0.85
+    j = np.round(rs.uniform(x0, x1, f.sum()) / 5.0)
+    pw[f, 0] = 5.0 * j + rs.normal(0, sigma, f.sum())
+    pw[f, 1] = np.where(rs.uniform(size=f.sum()) < 0.5, -1.0, 1.0) * rs.uniform(3.0, half_width, f.sum())
+    pw[f, 2] = gz + rs.uniform(0, 4.0, f.sum())
+    return pw.astype(np.float32)
