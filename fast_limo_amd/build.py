@@ -13,6 +13,38 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_PKG)
 
 
+_STAMP = os.path.join(_PKG, ".build_stamp")
+
+
+def sources_hash() -> str:
+    """Hash of every source the two libraries are built from (content, not mtime: a repository snapshot keeps neither order
+    nor times)."""
+    import hashlib
+    h = hashlib.sha256()
+    roots = [os.path.join(_PKG, "csrc"), os.path.join(ROOT, "include")]
+    files = []
+    for r in roots:
+        for d, dn, fn in os.walk(r):
+            dn[:] = [x for x in dn if x != "build"]
+            files += [os.path.join(d, f) for f in fn if f.endswith((".hip", ".h", ".hpp", ".cpp")) or f == "Makefile"]
+    for p in sorted(files):
+        h.update(os.path.relpath(p, ROOT).encode())
+        with open(p, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def is_stale() -> bool:
+    """True when a library is missing or was built from other sources than the ones in the tree."""
+    for so in ("libflimo_hip.so", "libfast_limo.so"):
+        if not os.path.exists(os.path.join(_PKG, so)):
+            return True
+    try:
+        return open(_STAMP).read().strip() != sources_hash()
+    except OSError:
+        return True
+
+
 def build_native(jobs: int = 4, force: bool = False) -> None:
     cmd = ["make", "-C", os.path.join(_PKG, "csrc"), f"-j{jobs}"]
     if force:
@@ -21,6 +53,8 @@ def build_native(jobs: int = 4, force: bool = False) -> None:
     for so in ("libflimo_hip.so", "libfast_limo.so"):
         if not os.path.exists(os.path.join(_PKG, so)):
             raise RuntimeError(f"{so} was not produced")
+    with open(_STAMP, "w") as fh:
+        fh.write(sources_hash() + "\n")
 
 
 def build_tools() -> None:

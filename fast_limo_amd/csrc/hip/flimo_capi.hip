@@ -564,6 +564,10 @@ static int map_add_device(flimo_ctx* c, const float4* d_pts, size_t m, double st
     if (kept > 0) {
       // the kept points lie inside the batch box: a superset box only makes the dense grid a little larger
       for (int a = 0; a < 3; a++) { if (bb[a] < c->bb[a]) c->bb[a] = bb[a]; if (bb[3 + a] > c->bb[3 + a]) c->bb[3 + a] = bb[3 + a]; }
+    }
+    // also when nothing was kept: a batch that made the raw buffer grow released the sorted copy, and a map without its
+    // index would answer every later pass with "no matches"
+    if (kept > 0 || (!c->grid_valid && c->map_n > 0)) {
       rc = rebuild_grid(c);
       if (rc) return rc;
     }
@@ -642,6 +646,7 @@ extern "C" int flimo_map_points(flimo_ctx* c, float* out, size_t cap, size_t* n)
   if (!c || !n) return FLIMO_ERR_INVALID;
   *n = c->map_n;
   if (!out || cap == 0 || c->map_n == 0) return FLIMO_OK;
+  if (!c->grid_valid) { int rc0 = rebuild_grid(c); if (rc0) return rc0; }
   if (!c->grid_valid) return fail(c, FLIMO_ERR_NOMAP, "map index not built");
   (void)hipSetDevice(c->device);
   const size_t m = std::min(cap, c->map_n);
@@ -659,6 +664,7 @@ extern "C" int flimo_knn(flimo_ctx* c, const float* q, size_t nq, int k, int32_t
   if (!c || !q || !idx || !sqd || !cnt) return FLIMO_ERR_INVALID;
   if (k < 1 || k > 5) return fail(c, FLIMO_ERR_UNSUPPORTED, "k must be in 1..5");
   if (nq == 0) return FLIMO_OK;
+  if (!c->grid_valid && c->map_n > 0) { int rc0 = rebuild_grid(c); if (rc0) return rc0; }
   if (!c->grid_valid) {                       // Octree::knn with root_ == nullptr returns nothing
     for (size_t i = 0; i < nq; i++) cnt[i] = 0;
     for (size_t i = 0; i < nq * (size_t)k; i++) { idx[i] = -1; sqd[i] = 0.f; }
@@ -934,6 +940,7 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   c->last_nq = 0;
   c->last_cfg = *cfg;
   c->recs_valid = c->dbg_valid = false;
+  if (!c->grid_valid && c->map_n > 0) { int rc0 = rebuild_grid(c); if (rc0) return rc0; }   // never a stored map without its index
   if (!c->grid_valid || c->map_n == 0) return FLIMO_OK;      // Mapper::match: `if(not this->exists()) return matches;`
   size_t nq = c->scan_n;
   if (cfg->MAX_NUM_PC2MATCH >= 0 && nq > (size_t)cfg->MAX_NUM_PC2MATCH) nq = (size_t)cfg->MAX_NUM_PC2MATCH;

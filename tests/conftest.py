@@ -24,7 +24,9 @@ def built():
     """Make sure the native libraries exist (hipcc cross-compiles without a GPU)."""
     from fast_limo_amd import build as b
     from fast_limo_amd import _lib
-    if not (os.path.exists(_lib.hip_lib_path()) and os.path.exists(os.path.join(os.path.dirname(_lib.hip_lib_path()), "libfast_limo.so"))):
+    # never a stale binary: the libraries carry the hash of the sources they were built from (fast_limo_amd/.build_stamp);
+    # after a source edit they are rebuilt here, otherwise this is a no-op
+    if b.is_stale():
         b.build_native()
     import oracle_py
     oracle_py.build()

@@ -696,3 +696,30 @@ def test_randomised_configurations_match_oracle(built, oracle):
             ctx.close()
     print(f"randomised configurations: {total_M} matches in total, {capped} passes with MAX_NUM_MATCHES binding, {widened} with widening")
     assert total_M > 15000 and capped >= 4 and widened >= 4, (total_M, capped, widened)
+
+
+@pytest.mark.gpu
+def test_fully_dropped_batch_that_grows_the_buffer_keeps_the_index(built):
+    """A later batch whose points are ALL rejected by the insert rule (saturated leaves) but that is large enough to make the
+    raw map buffer grow must leave a searchable map behind (the sorted copy is released with the old buffer)."""
+    from fast_limo_amd import _lib
+    rs = np.random.RandomState(12)
+    dense = rs.uniform(-0.5, 0.5, (20000, 3)).astype(np.float32)      # ~160 points per 0.2 m leaf: every leaf is saturated
+    ctx = _lib.HipCtx(0)
+    ctx.map_config()
+    ctx.map_add(dense)
+    assert ctx.map_size() == 20000
+    inner = rs.uniform(-0.3, 0.3, (20000, 3)).astype(np.float32)       # well inside: only saturated leaves
+    ctx.map_add(inner)                                                 # 20000 > capacity slack (n / 4 + 1024): the buffer grows
+    assert ctx.map_size() == 20000                                     # ... and nothing is kept
+    q = dense[:64]
+    idx, sqd, cnt = ctx.knn(q, 5)
+    assert np.all(cnt == 5)
+    assert np.all(sqd[:, 0] == 0.0)                                    # every query is a map point
+    ctx.scan_set(dense[:4096])
+    x0 = np.zeros(26); x0[6] = 1; x0[10] = 1; x0[25] = -9.809
+    HTH, HTh, M = ctx.match_reduce(x0, _lib.default_match_cfg(MAX_NUM_PC2MATCH=10**7, MAX_NUM_MATCHES=10**7, PLANE_THRESHOLD=10.0))
+    assert M > 0                                                       # not a silent "no map"
+    mm, merges, builds = ctx.grid_selfcheck()
+    assert mm == 0
+    ctx.close()
