@@ -14,9 +14,13 @@ For N > 1 the driver launches it under torch.distributed.run (one rank per GPU).
 by independent scan streams (config 5): no data-path collective, weak scaling; torch.distributed is
 used only for the barrier and the max-over-ranks time.
 
-Rank 0 prints ONE JSON line (see the contract in the task description) with two extra objects:
-  roofline      dominant kernel (k-NN): algorithmic bytes per launch / mean launch time from HIP
-                events recorded on the library's stream during the timed region, vs 8 TB/s HBM
+Rank 0 prints ONE JSON line (see the contract in the task description) with these extra objects:
+  roofline      dominant kernel = the one-launch measurement pass (k-NN fast path + in-kernel widening + plane fit +
+                residual / Jacobian + H^T H reduction, `knn5_kernel<2, 8, true>`): ALGORITHMIC bytes per launch / its mean
+                launch duration from HIP events attached to the dispatch during the timed region, vs 8 TB/s HBM; `stage`
+                gives every kind of pass (the first pass of the benchmark's poor prior runs k-NN / widening / fit as
+                separate dispatches); `traffic` = HBM-side bytes from the committed PMC profile of the same sources
+  end_to_end    the same scan from a host cloud: filters + time sort + upload + deskew + update + map insert
   cpu_baseline  the CPU oracle (a restatement of the reference algorithm, "port") timed on this box's
                 host cores on the same scan / map, N = 1 only
 """
@@ -40,18 +44,38 @@ NBR_BYTES = 32                  # bytes the k-NN kernel writes per query (5 indi
 
 
 def pmc_traffic(queries_per_launch):
-    """HBM-side bytes per k-NN launch from the committed PMC profile (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-    in separate passes of this same command, FETCH_SIZE doubled per MI355X_MICROARCH.md): PMC counters
-    cannot be collected from inside the run, so the number is read from profiles/ and only reported when
-    it was taken on the same launch shape."""
-    f = os.path.join(ROOT, "profiles", "r01", "pmc_fetch_write_per_kernel.json")
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC profile (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+    in separate passes of this same command, FETCH_SIZE doubled per MI355X_MICROARCH.md).  PMC counters cannot be collected
+    from inside the run; the profile carries the hash of the kernel sources it was taken with and is only reported when that is
+    the hash of the sources in the tree (and the launch shape is the benchmark's)."""
+    f = os.path.join(ROOT, "profiles", "r02", "pmc_fetch_write_per_kernel.json")
     try:
-        d = json.load(open(f))["knn5_kernel_traffic_bytes_per_launch"]
-        if abs(queries_per_launch - 65536) > 0.5:
+        from fast_limo_amd import build as b
+        d = json.load(open(f))
+        if d.get("sources_hash") != b.sources_hash() or abs(queries_per_launch - 65536) > 0.5:
             return None
-        return d["total_corrected"]
+        return d["dominant_kernel_traffic_bytes_per_launch"]["total_corrected"]
     except Exception:
         return None
+
+
+def cpu_info():
+    model, phys = None, None
+    try:
+        cores = set()
+        phys_id = core_id = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model is None:
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                phys_id = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core_id = line.split(":", 1)[1].strip()
+                cores.add((phys_id, core_id))
+        phys = len(cores) or None
+    except OSError:
+        pass
+    return model, phys, os.cpu_count()
 
 
 def workload(rank: int, rings: int, az: int, nmap: int, L: float):
@@ -59,7 +83,7 @@ def workload(rank: int, rings: int, az: int, nmap: int, L: float):
     mp = synth.box_world_map(nmap, L, 1)
     scan_seed = 2 if rank == 0 else 10 + rank        # cfg 2 on rank 0, cfg 5 seeds on the others
     scan = synth.velodyne_scan(rings, az, L, scan_seed)
-    imu = synth.stationary_imu(0.0, 0.35)
+    imu = synth.stationary_imu(0.0, 2.6)            # 0.35 s are used by the registration, the rest by the end-to-end sweeps
     return mp, scan, imu
 
 
@@ -73,16 +97,19 @@ def drive_to_prior(loc, mp, scan, imu):
     rc1 = loc.update_pointcloud(scan, 0.0)
     while i < len(st) and st[i] <= 0.205:
         loc.update_imu(st[i], w[i], a[i]); i += 1
+    loc._imu_cursor = i
     return rc1
 
 
 def cpu_baseline(mp, scan, imu, caps, max_threads):
-    """Oracle Localizer timed on the host: deskew + iterated update of the same scan (no map insert)."""
+    """Oracle Localizer timed on the host: deskew + iterated update of the same scan (no map insert).  3 warm-ups, then up to 20
+    registrations per thread count within a time budget (about 20 s in total)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py as O
     best = None
     E = None
     x_o = None
+    model, phys, logical = cpu_info()
     tried = sorted(set([1, max(1, min(max_threads, os.cpu_count() or 1))]))
     for nt in tried:
         L = O.Localizer(O.default_cfg(num_threads=nt, **caps))
@@ -91,32 +118,35 @@ def cpu_baseline(mp, scan, imu, caps, max_threads):
         times = []
         stages = []
         budget_t0 = time.time()
-        for rep in range(5):
+        budget = 6.0 if nt == 1 else 14.0
+        for rep in range(23):
             L.set_x(x_prior); L.set_P(P_prior)
-            t0 = time.perf_counter()
-            rc = L.update_pointcloud(scan, 0.1, add_to_map=False) if rep == 0 else _rerun(L, scan)
-            dt = time.perf_counter() - t0
+            rc = L.update_pointcloud(scan, 0.1, add_to_map=False)
             st = L.stats()
-            times.append(st["t_deskew"] - st["t_sort"] + st["t_update"])   # the time sort is outside the GPU step too
-            stages.append((st["t_deskew"] - st["t_sort"], st["t_match"], st["t_hrows"], st["t_update"] - st["t_match"] - st["t_hrows"]))
             if rep == 0:
                 x_o = L.get_x()
                 E = st["evals"] / max(st["queries"], 1)
-            if time.time() - budget_t0 > 12.0:
+            if rep >= 3 or (nt == 1 and rep >= 1):      # warm-ups dropped (one is enough for the slow single-thread run)
+                times.append(st["t_deskew"] - st["t_sort"] + st["t_update"])   # the time sort is outside the GPU step too
+                stages.append((st["t_deskew"] - st["t_sort"], st["t_match"], st["t_hrows"], st["t_update"] - st["t_match"] - st["t_hrows"]))
+            if time.time() - budget_t0 > budget and len(times) >= 3:
                 break
         t = float(np.median(times))
         if best is None or t < best[0]:
             best = (t, nt, len(times), [float(v) * 1e3 for v in np.median(np.array(stages), axis=0)])
     t, nt, reps, stg = best
-    return dict(value=1.0 / t, unit="scans/s", cores=nt, kind="port",
+    return dict(value=1.0 / t, unit="scans/s", cores=nt, kind="port", cpu_model=model, physical_cores=phys, logical_cpus=logical,
+                threads=nt, reps=reps,
                 stages_ms={"deskew": stg[0], "knn_plane_fit": stg[1], "H_rows": stg[2], "HtH_and_solve": stg[3]},
-                sample=f"median of {reps} registrations (deskew + iterated update, no map insert) of the same "
+                sample=f"median of {reps} registrations after warm-up (deskew + iterated update, no map insert) of the same "
                        f"{scan.shape[0]}-pt scan vs {mp.shape[0]}-pt map by the CPU oracle (restatement of the "
-                       f"reference; the reference itself cannot be built without Eigen/PCL/Boost); "
-                       f"threads tried {tried}, best shown"), E, x_o
+                       f"reference; the reference itself cannot be built without Eigen/PCL/Boost) on {model}, "
+                       f"{phys} physical cores, OpenMP threads tried {tried}, best ({nt}) shown"), E, x_o
 
 
 class _OracleNoInsert:
+    _imu_cursor = 0
+
     def __init__(self, L):
         self.L = L
 
@@ -130,10 +160,22 @@ class _OracleNoInsert:
         return self.L.update_pointcloud(pts, stamp, add_to_map=False)
 
 
-def _rerun(L, scan):
-    # the oracle's prev_scan_stamp advanced after the first call; the deskew frames for the same stamp
-    # are still in its buffer, so re-running the same call is equivalent
-    return L.update_pointcloud(scan, 0.1, add_to_map=False)
+def rank_barrier(dist, torch):
+    """Barrier over the ranks (if any) + device synchronisation: brackets the timed region on both sides."""
+    if dist is not None:
+        dist.barrier()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+
+
+def aggregate(dist, torch, elapsed: float, world: int, steps: int):
+    """(max over ranks of the timed region [s], whole-job scans/s): every rank registered `steps` scans of its own stream."""
+    if dist is not None:
+        dev = "cuda" if (torch.cuda.is_available() and dist.get_backend() == "nccl") else "cpu"
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    return elapsed, world * steps / elapsed
 
 
 def main():
@@ -146,6 +188,8 @@ def main():
     ap.add_argument("--map-points", type=int, default=1000000)
     ap.add_argument("--box", type=float, default=100.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--e2e-sweeps", type=int, default=8)
     ap.add_argument("--with-insert", action="store_true",
                     help="time the step WITH the path exit (transform + map insert) over six steps instead of the default two "
                          "(first insertion + one repeat), for a steadier 'repeat' figure")
@@ -169,8 +213,10 @@ def main():
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist_mod.init_process_group(backend="nccl", rank=rank, world_size=world)
+        backend = os.environ.get("FLIMO_BENCH_BACKEND", "nccl")      # "gloo": barrier and max over ranks on CPU tensors
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist_mod.init_process_group(backend=backend, rank=rank, world_size=world)
         dist = dist_mod
 
     from fast_limo_amd import api
@@ -192,10 +238,7 @@ def main():
         assert rc == 0, rc
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
-        if torch.cuda.is_available():
-            torch.cuda.synchronize()
+        rank_barrier(dist, torch)
 
     for _ in range(args.warmup):
         step()
@@ -207,7 +250,9 @@ def main():
     auto_stride = min(81, ((4 * args.steps // 8) // 4) * 4 + 1)        # 8 samples (short runs: every launch), one per 81 passes at most
     loc.hip.set_timing_stride(int(os.environ.get('FLIMO_BENCH_TIMING_STRIDE', str(auto_stride))))
     loc.hip.timing_totals(reset=True)
+    loc.hip.timing_split(reset=True)
     passes0 = loc.hip.pass_count()
+    fused0 = loc.hip.fused_pass_count()
     loc.host_profile(reset=True)
     barrier()
     t0 = time.perf_counter()
@@ -216,7 +261,9 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     tot = loc.hip.timing_totals()
+    split = loc.hip.timing_split()
     n_passes = loc.hip.pass_count() - passes0
+    n_fused_passes = loc.hip.fused_pass_count() - fused0
     hp = loc.host_profile()
     loc.hip.set_timing(0)
     x_end = loc.get_x()
@@ -241,15 +288,53 @@ def main():
                        "repeat_ms": 1e3 * float(np.median(t_ins[1:])), "points_stored_repeat": sizes[-1] - sizes[1],
                        "scans_per_s_first": 1.0 / t_ins[0], "scans_per_s_repeat": 1.0 / float(np.median(t_ins[1:]))}
 
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    # the whole Localizer::updatePointCloud from a HOST cloud (input filters, time sort, upload,
+    # deskew, update, device-resident map insert on the Mapper's worker thread), sweep after sweep, reported beside `value`.
+    # "tied": the stamps of a spinning sensor (all rings of a column share one stamp), "unique": every point its own stamp.
+    end_to_end = None
+    if rank == 0 and not args.no_end_to_end:
+        from fast_limo_amd import synth
+        st, w, a = imu
+        i = loc._imu_cursor
+        loc.set_flags(add_to_map=True, download_clouds=False, keep_log=False)
+        end_to_end = {"points_per_sweep": int(scan.shape[0])}
+        k = 2
+        for label in ("tied", "unique"):
+            sweeps = []
+            for j in range(args.e2e_sweeps):
+                sc = synth.velodyne_scan(args.rings, args.azimuths, args.box, 100 + j)
+                if label == "unique":
+                    sc[:, 4] += (np.arange(sc.shape[0]) % args.rings).astype(np.float32) * np.float32(1.5e-6)
+                sweeps.append(api.make_points_velodyne(sc))
+            lat = []
+            loc.sync()
+            T0 = time.perf_counter()
+            for j in range(args.e2e_sweeps):
+                until = 0.1 * (k + 1) + 0.005
+                while i < len(st) and st[i] <= until:
+                    loc.update_imu(st[i], w[i], a[i]); i += 1
+                t1 = time.perf_counter()
+                rc = loc.update_pointcloud_points(sweeps[j], 0.1 * k)
+                lat.append(time.perf_counter() - t1)
+                assert rc == 0, rc
+                k += 1
+            loc.sync()
+            T1 = time.perf_counter()
+            stg = loc.stage_times()
+            end_to_end[label + "_stamps"] = {"ms_per_sweep": 1e3 * (T1 - T0) / args.e2e_sweeps,
+                                             "call_returns_after_ms": 1e3 * float(np.median(lat)),
+                                             "sweeps": args.e2e_sweeps,
+                                             "last_sweep_stages_ms": {kk: 1e3 * float(v) for kk, v in stg.items()}}
+        end_to_end["ms"] = end_to_end["tied_stamps"]["ms_per_sweep"]
+        end_to_end["scans_per_s"] = 1e3 / end_to_end["ms"]
+        end_to_end["map_points_after"] = loc.map_size()
+
+    elapsed, value = aggregate(dist, torch, elapsed, world, args.steps)
 
     if rank == 0:
         out = {
             "metric": "scans/sec (64k-pt scan, 1M-pt map) + kNN HBM GB/s vs roofline; ATE vs CPU ref",
-            "value": world * args.steps / elapsed,
+            "value": value,
             "unit": "scans/s",
             "n_gpus": n_gpus,
             "steps": args.steps,
@@ -270,6 +355,7 @@ def main():
             "host_us_per_step": {"deskew_call": 1e6 * hp["deskew_s"] / args.steps, "update": 1e6 * hp["update_s"] / args.steps,
                                  "in_match_reduce": 1e6 * hp["match_reduce_s"] / args.steps},
             "with_map_insert": with_insert,
+            "end_to_end": end_to_end,
         }
         cb, E, x_o = (None, None, None)
         if world == 1 and not args.no_cpu_baseline:
@@ -282,16 +368,29 @@ def main():
         if not E and (args.rings, args.azimuths, args.map_points, args.box) != (64, 1024, 1000000, 100.0):
             Eq = None                      # the constant only describes configs[1]
         bytes_per_query = (16.0 + 16.0 * Eq + NBR_BYTES) if Eq else None
-        qpl = tot["queries"] / max(tot["passes"], 1)               # queries per k-NN launch
-        knn_s = 1e-3 * tot["knn_ms"] / max(tot["passes"], 1)        # mean launch duration (HIP events)
-        achieved = bytes_per_query * qpl / knn_s / 1e9 if (knn_s > 0 and bytes_per_query) else None
-        out["roofline"] = {"bound": "hbm", "kernel": "knn5_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                           "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": pmc_traffic(qpl),
+        qpl = tot["queries"] / max(tot["passes"], 1)               # queries per launch
+        us = lambda ms, n: (1e3 * ms / n) if n else None
+        one_us = us(split["fused_ms"], split["fused_n"])             # mean duration of the one-launch pass (HIP events on its dispatch)
+        sep = {"knn": us(split["knn_ms"], split["separate_n"]), "widen": us(split["widen_ms"], split["separate_n"]),
+               "fit_reduce": us(split["fit_ms"], split["separate_n"])} if split["separate_n"] else None
+        if one_us:
+            kernel, dur_us, n_timed = "knn5_kernel<2, 8, true>: the whole measurement pass in one launch (k-NN fast path + in-kernel widening + plane fit + residual/Jacobian + H^T H reduction)", one_us, split["fused_n"]
+        else:                              # developer switches (FLIMO_FUSE=0 ...): the k-NN dispatch alone
+            kernel, dur_us, n_timed = "knn5_kernel<2, 8, false>: k-NN dispatch (separate widening / fit dispatches)", us(tot["knn_ms"], tot["passes"]), tot["passes"]
+        achieved = bytes_per_query * qpl / (dur_us * 1e-6) / 1e9 if (dur_us and bytes_per_query) else None
+        traffic = pmc_traffic(qpl)
+        out["roofline"] = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                           "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
+                           "hbm_utilisation_measured": (traffic / (dur_us * 1e-6) / 1e9 / HBM_PEAK_GBPS) if (traffic and dur_us) else None,
                            "bytes_per_query": bytes_per_query, "E_evals_per_query": Eq,
-                           "queries_per_launch": qpl, "mean_launch_us": knn_s * 1e6, "timed_launches": tot["passes"],
-                           "stage_us_per_pass": {"knn": 1e3 * tot["knn_ms"] / max(tot["passes"], 1),
-                                                 "widen": 1e3 * tot["widen_ms"] / max(tot["passes"], 1),
-                                                 "fit_reduce": 1e3 * tot["fit_ms"] / max(tot["passes"], 1)}}
+                           "queries_per_launch": qpl, "mean_launch_us": dur_us, "timed_launches": n_timed,
+                           "note": "achieved = ALGORITHMIC k-NN bytes (16 B query + 16 B x E candidate points of the reference's own traversal + 32 B neighbour "
+                                   "record) per launch / launch duration; the launch also does the plane fit, the residual / Jacobian rows and the "
+                                   "reduction, which add no algorithmic bytes (the five neighbours were just read).  `traffic` / "
+                                   "`hbm_utilisation_measured` are the HBM-side bytes from PMC counters: the 1M-point map lives in L2 / Infinity Cache",
+                           "stage": {"one_launch_pass_us": one_us, "one_launch_passes_timed": split["fused_n"],
+                                     "separate_dispatch_pass_us": sep, "separate_dispatch_passes_timed": split["separate_n"],
+                                     "passes_in_one_launch": n_fused_passes, "passes_total": n_passes}}
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     loc.close()
     if dist is not None:

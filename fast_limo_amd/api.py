@@ -41,12 +41,28 @@ class LocCfg(C.Structure):
 
 
 HOST_SYMBOLS = [
-    "flimo_loc_create", "flimo_loc_destroy", "flimo_loc_ctx", "flimo_loc_sync", "flimo_loc_set_async_insert", "flimo_loc_last_insert_seconds", "flimo_loc_update_imu", "flimo_loc_update_pointcloud", "flimo_loc_update_pointcloud_points",
+    "flimo_loc_create", "flimo_loc_destroy", "flimo_loc_ctx", "flimo_loc_sync", "flimo_loc_set_async_insert", "flimo_loc_set_lazy_time_order", "flimo_loc_last_insert_seconds", "flimo_loc_update_imu", "flimo_loc_update_pointcloud", "flimo_loc_update_pointcloud_points",
     "flimo_loc_map_add", "flimo_loc_map_size", "flimo_loc_get_x", "flimo_loc_set_x", "flimo_loc_get_P",
     "flimo_loc_set_P", "flimo_loc_set_flags", "flimo_loc_num_passes", "flimo_loc_get_pass", "flimo_loc_get_pc2match",
     "flimo_loc_get_final_scan", "flimo_loc_get_stage_times", "flimo_loc_get_pose_cov", "flimo_loc_register_resident", "flimo_loc_host_profile",
     "flimo_eskf_update_fixed", "flimo_eskf_predict", "flimo_host_plane", "flimo_host_state_update", "flimo_host_time_order",
 ]
+
+
+# the reference's PointType (Common.hpp:100-113): xyz1, intensity, 4 bytes of padding, 8-byte time union
+POINT_DTYPE = np.dtype({"names": ["x", "y", "z", "w", "intensity", "tu"],
+                        "formats": [np.float32, np.float32, np.float32, np.float32, np.float32, np.uint64],
+                        "offsets": [0, 4, 8, 12, 16, 24], "itemsize": 32})
+
+
+def make_points_velodyne(pts5) -> np.ndarray:
+    """(n, 5) float32 x y z intensity time -> the reference's 32-byte PointType records (VELODYNE view of the time union),
+    what a ROS driver hands to Localizer::updatePointCloud."""
+    p5 = np.ascontiguousarray(pts5, dtype=np.float32).reshape(-1, 5)
+    p = np.zeros(p5.shape[0], POINT_DTYPE)
+    p["x"], p["y"], p["z"], p["w"], p["intensity"] = p5[:, 0], p5[:, 1], p5[:, 2], 1.0, p5[:, 3]
+    p.view(np.uint8).reshape(-1, 32)[:, 24:28] = p5[:, 4:5].copy().view(np.uint8)
+    return p
 
 
 def default_cfg(**kw) -> LocCfg:
@@ -108,6 +124,8 @@ def load_host():
     L.flimo_loc_sync.argtypes = [vp]
     L.flimo_loc_set_async_insert.restype = None
     L.flimo_loc_set_async_insert.argtypes = [vp, C.c_int]
+    L.flimo_loc_set_lazy_time_order.restype = None
+    L.flimo_loc_set_lazy_time_order.argtypes = [vp, C.c_int]
     L.flimo_loc_last_insert_seconds.restype = C.c_double
     L.flimo_loc_last_insert_seconds.argtypes = [vp]
     L.flimo_loc_update_imu.argtypes = [vp, C.c_double, f32p, f32p]
@@ -230,6 +248,10 @@ class Localizer:
 
     def set_async_insert(self, on=True):
         self._L.flimo_loc_set_async_insert(self._h, int(on))
+
+    def set_lazy_time_order(self, on=True):
+        """off: the sweep is always put into the reference's time order before the GPU sees it (A/B of the arrival-order path)."""
+        self._L.flimo_loc_set_lazy_time_order(self._h, int(on))
 
     def last_insert_seconds(self):
         return float(self._L.flimo_loc_last_insert_seconds(self._h))

@@ -109,12 +109,15 @@ struct flimo_ctx {
   void* h_stage = nullptr;         // pinned
   size_t stage_cap = 0;
   // timing
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [0,1] k-NN / fused dispatch, [2,3] fit, [4,5] widening
   float last_knn_ms = 0.f, last_widen_ms = 0.f, last_fit_ms = 0.f;
   int* h_wl_count = nullptr;   // pinned
   int last_widen_count = 0;
   double tot_knn_ms = 0, tot_widen_ms = 0, tot_fit_ms = 0;
   long long tot_passes = 0, tot_queries = 0;
+  // level-1 totals by kind of timed pass: [0] one-launch passes: total ms, count; [1] separate dispatches: k-NN ms, widening ms, fit ms, count
+  double split_fused_ms = 0, split_knn_ms = 0, split_widen_ms = 0, split_fit_ms = 0;
+  long long split_fused_n = 0, split_sep_n = 0;
   flimo_match_cfg last_cfg{};
   PoseMats last_P{};
   MatchParams last_mp{};
@@ -246,7 +249,7 @@ extern "C" int flimo_ctx_create(int device, flimo_ctx** out) {
   flimo_ctx* c = new flimo_ctx();
   c->device = device;
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return FLIMO_ERR_HIP; }
-  for (int i = 0; i < 4; i++) (void)hipEventCreate(&c->ev[i]);
+  for (int i = 0; i < 6; i++) (void)hipEventCreate(&c->ev[i]);
   bool ok = hipMalloc(&c->d_partials, (size_t)c->reduce_waves * 256 * sizeof(double)) == hipSuccess &&
             hipMalloc(&c->d_out256, FIT_GROUPS * FIT_SLOT * sizeof(double)) == hipSuccess &&
             hipHostMalloc((void**)&c->h_out256, FIT_GROUPS * FIT_SLOT * sizeof(double), hipHostMallocMapped) == hipSuccess &&
@@ -325,7 +328,7 @@ extern "C" void flimo_ctx_destroy(flimo_ctx* c) {
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   for (int k = 0; k < 2; k++) if (c->h_frames[k]) (void)hipHostFree(c->h_frames[k]);
   map_scratch_free(c->scratch);
-  for (int i = 0; i < 4; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  for (int i = 0; i < 6; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->h_wl_count) (void)hipHostFree(c->h_wl_count);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->book) insert_book_destroy(c->book);
@@ -918,6 +921,13 @@ extern "C" int flimo_timing_totals(flimo_ctx* c, double* knn_ms, double* widen_m
   if (reset) { c->tot_knn_ms = c->tot_widen_ms = c->tot_fit_ms = 0.0; c->tot_passes = 0; c->tot_queries = 0; }
   return FLIMO_OK;
 }
+extern "C" int flimo_timing_split(flimo_ctx* c, double out[6], int reset) {
+  if (!c || !out) return FLIMO_ERR_INVALID;
+  out[0] = c->split_fused_ms; out[1] = (double)c->split_fused_n;
+  out[2] = c->split_knn_ms; out[3] = c->split_widen_ms; out[4] = c->split_fit_ms; out[5] = (double)c->split_sep_n;
+  if (reset) { c->split_fused_ms = c->split_knn_ms = c->split_widen_ms = c->split_fit_ms = 0.0; c->split_fused_n = c->split_sep_n = 0; }
+  return FLIMO_OK;
+}
 extern "C" double flimo_last_candidates_per_query(const flimo_ctx* c) { return c ? c->last_cand_per_query : 0.0; }
 
 static int gate_rings(const flimo_ctx* c, double max_dist_plane) {
@@ -1006,9 +1016,10 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   if (c->prune) { memcpy(c->prev.RT, P.RT, sizeof(c->prev.RT)); c->prev.valid = 1; }   // the records now belong to this pose
   const double tpb = prof ? now_us() : 0.0;
   if (tlev > 1) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+  const bool widen_timed = !tail && tlev == 1 && mp.max_ring >= 2;
   if (!tail)
     launch_widen(c->stream, c->grid, c->d_scan_sorted, P, mp.max_ring, c->d_nbr, c->d_wl, c->d_wl_count,
-                 c->debug_recs ? c->d_cand : nullptr);
+                 c->debug_recs ? c->d_cand : nullptr, widen_timed ? c->ev[4] : nullptr, widen_timed ? c->ev[5] : nullptr);
   const double tpc = prof ? now_us() : 0.0;
   if (want_count) HIPCHK(c, hipMemcpyAsync(c->h_wl_count, c->d_wl_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   if (tlev > 1) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
@@ -1101,7 +1112,13 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
       c->tot_widen_ms += c->last_widen_ms; c->tot_fit_ms += c->last_fit_ms;
     } else if (fused) {
       c->last_fit_ms = 0.f; c->last_widen_ms = 0.f;            // one dispatch: everything is in the k-NN figure
+      c->split_fused_ms += c->last_knn_ms; c->split_fused_n++;
     } else if (use_fit2) {
+      c->last_widen_ms = 0.f;
+      if (widen_timed) {
+        if (hipEventElapsedTime(&c->last_widen_ms, c->ev[4], c->ev[5]) != hipSuccess) c->last_widen_ms = 0.f;
+        c->tot_widen_ms += c->last_widen_ms;
+      }
       // level 1: the fit dispatch carries its own pair of events (kernel begin / end); the host saw the granules, the
       // kernel's end-of-dispatch signal may still be a moment away
       if (hipEventElapsedTime(&c->last_fit_ms, c->ev[2], c->ev[3]) != hipSuccess) {
@@ -1109,7 +1126,7 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
         (void)hipEventElapsedTime(&c->last_fit_ms, c->ev[2], c->ev[3]);
       }
       c->tot_fit_ms += c->last_fit_ms;
-      c->last_widen_ms = 0.f;
+      c->split_knn_ms += c->last_knn_ms; c->split_widen_ms += c->last_widen_ms; c->split_fit_ms += c->last_fit_ms; c->split_sep_n++;
     }
     c->tot_passes++; c->tot_queries += n_all;
   }

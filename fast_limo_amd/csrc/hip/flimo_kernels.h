@@ -14,7 +14,7 @@ void launch_knn5(hipStream_t st, int lanes_per_query, const GridView& G, const f
 // tail != 0: queries that need more than the 3x3x3 block are finished inside the k-NN launch itself (gates of at most 3
 // rings; launch_knn5 clears the flag otherwise) and launch_widen has nothing to do
 void launch_widen(hipStream_t st, const GridView& G, const float4* scan_sorted, const PoseMats& P, int max_ring, void* nbr,
-                  int* wl, int* wl_count, unsigned long long* cand);
+                  int* wl, int* wl_count, unsigned long long* cand, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 int fit_blocks(int n);
 void set_xcd_stripe(int stripe);   // block -> scan chunk mapping of the per-pass kernels (see xcd_chunk)
 // the fit kernel reduces in FIT_GROUPS groups; slot g of its output = 256 sums + the pass number (FIT_SLOT doubles)

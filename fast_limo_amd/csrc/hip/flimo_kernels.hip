@@ -1743,16 +1743,16 @@ static int widen_blocks() {
   return g_widen_blocks;
 }
 void launch_widen(hipStream_t st, const GridView& G, const float4* scan_sorted, const PoseMats& P, int max_ring, void* nbr,
-                  int* wl, int* wl_count, unsigned long long* cand) {
+                  int* wl, int* wl_count, unsigned long long* cand, hipEvent_t e0, hipEvent_t e1) {
   if (max_ring <= 1) return;
   static int tight = -1, r3 = -1;
   if (tight < 0) { const char* e = getenv("FLIMO_WIDEN_TIGHT"); tight = e ? atoi(e) : 0; e = getenv("FLIMO_WIDEN_R3"); r3 = e ? atoi(e) : 1; }   // measured at 6.6 k pending queries: 19.3 -> 16.3 us
   const int first_ring = r3 ? max_ring : 2;
   if (max_ring <= 3) {
     if (tight)
-      hipLaunchKernelGGL((widen_kernel<8>), dim3(widen_blocks()), dim3(256), 0, st, G, scan_sorted, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand, first_ring);
+      hipExtLaunchKernelGGL((widen_kernel<8>), dim3(widen_blocks()), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand, first_ring);
     else
-      hipLaunchKernelGGL((widen_kernel<1>), dim3(widen_blocks()), dim3(256), 0, st, G, scan_sorted, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand, first_ring);
+      hipExtLaunchKernelGGL((widen_kernel<1>), dim3(widen_blocks()), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand, first_ring);
   }
   else
     hipLaunchKernelGGL(widen_general_kernel, dim3(256), dim3(256), 0, st, G, scan_sorted, P, max_ring, (NbrRec*)nbr, wl, wl_count);

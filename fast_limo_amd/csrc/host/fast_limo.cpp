@@ -896,10 +896,44 @@ bool Localizer::deskewPointCloud(pcl::PointCloud<PointType>::Ptr& pc, double& st
   static const bool prof = std::getenv("FLIMO_PROF_DESKEW") != nullptr;     // developer timing of the host stages
   const double tp0 = prof ? now_s() : 0.0;
   auto sorted = std::make_shared<pcl::PointCloud<PointType>>();
+  const bool desc = eos && (sensor == SensorType::OUSTER || sensor == SensorType::VELODYNE);
+  // WHO needs the exact permutation of that call?  The deskew itself works point by point (each point carries its stamp); the
+  // order of pc2match is visible (a) through MAX_NUM_PC2MATCH / MAX_NUM_MATCHES ("the first N in pc2match order"), (b) through
+  // the float32 centroid sums of the voxel grid, (c) in the clouds handed back to the caller.  When neither cap can bind and the
+  // voxel grid is off, the GPU gets the sweep in ARRIVAL order (registration and map insert do not wait for a 1.5 ms sequential
+  // heap sort of tied stamps); the permutation is then computed only if the caller wants the clouds, while the GPU works,
+  // and applied to the host copies (lazy_order_).  Pose and stored map are the same with and without the clouds.
+  lazy_order_.clear();
+  arrival_keys_pending_ = false;
   {
+    const size_t n0 = pc->points.size();
+    const auto& mc = config.ikfom.mapping;
+    const bool caps = (mc.MAX_NUM_PC2MATCH >= 0 && n0 > (size_t)mc.MAX_NUM_PC2MATCH) || (mc.MAX_NUM_MATCHES >= 0 && n0 > (size_t)mc.MAX_NUM_MATCHES);
+    bool arrival = lazy_time_order && !caps && !config.filters.voxel_active;
+    if (arrival) {
+      // the stamp of the point the sort would put last (largest key, smallest when sorting descending); NaN stamps: the library path
+      const std::vector<PointType>& P = pc->points;
+      size_t last = 0;
+      bool nan = false;
+      if (sensor == SensorType::OUSTER) {
+        for (size_t i = 1; i < n0; i++) if (desc ? P[i].t < P[last].t : P[i].t > P[last].t) last = i;
+      } else if (sensor == SensorType::VELODYNE) {
+        for (size_t i = 0; i < n0; i++) { nan = nan || (P[i].time != P[i].time); if (desc ? P[i].time < P[last].time : P[i].time > P[last].time) last = i; }
+      } else {
+        for (size_t i = 0; i < n0; i++) { nan = nan || (P[i].timestamp != P[i].timestamp); if (P[i].timestamp > P[last].timestamp) last = i; }
+      }
+      if (nan) arrival = false;
+      else {
+        sorted = pc;                                   // arrival order, no copy
+        arrival_last_ = last;
+        arrival_keys_pending_ = download_clouds;       // the permutation is wanted for the host clouds only
+      }
+    }
+    arrival_order_ = arrival;
+  }
+  if (!arrival_order_) {
     const size_t n = pc->points.size();
     const std::vector<PointType>& P = pc->points;
-    const bool desc = eos && (sensor == SensorType::OUSTER || sensor == SensorType::VELODYNE);
     std::vector<uint32_t> order;
     if (sensor == SensorType::OUSTER) {
       std::vector<uint32_t> k(n);
@@ -920,11 +954,12 @@ bool Localizer::deskewPointCloud(pcl::PointCloud<PointType>::Ptr& pc, double& st
   (void)cmp;
   const double tp1 = prof ? now_s() : 0.0;
   double offset = 0.0;
+  const PointType& last_pt = arrival_order_ ? sorted->points[arrival_last_] : sorted->points.back();
   if (config.time_offset) {
-    offset = imu_stamp - extract(sorted->points.back()) - 1.e-4;
+    offset = imu_stamp - extract(last_pt) - 1.e-4;
     if (offset > 0.0) offset = 0.0;
   }
-  scan_stamp = extract(sorted->points.back()) + offset;
+  scan_stamp = extract(last_pt) + offset;
   States frames;
   if (!propagatedFromTimeRange(prev_scan_stamp, scan_stamp, frames) || frames.empty()) {
     std::cout << "FAST_LIMO::propagatedFromTimeRange(): not enough propagated states!\n";
@@ -977,7 +1012,35 @@ bool Localizer::deskewPointCloud(pcl::PointCloud<PointType>::Ptr& pc, double& st
   if (prof)
     fprintf(stderr, "[flimo deskew] time sort + gather %.0f us, frames/times %.0f us, upload + Morton sort %.0f us, deskew call %.0f us (n = %zu)\n",
             (tp1 - tp0) * 1e6, (tp2 - tp1) * 1e6, (tp3 - tp2) * 1e6, (tp4 - tp3) * 1e6, n);
-  if (download_clouds) {
+  if (download_clouds && arrival_order_) {
+    // the GPU is busy with the deskew (and has the sweep): now the permutation of the reference's sort, for the host clouds
+    const std::vector<PointType>& P = sorted->points;
+    if (sensor == SensorType::OUSTER) {
+      std::vector<uint32_t> k(n);
+      for (size_t i = 0; i < n; i++) k[i] = P[i].t;
+      time_order(k.data(), 0, n, desc, false, lazy_order_);
+    } else if (sensor == SensorType::VELODYNE) {
+      std::vector<float> k(n);
+      for (size_t i = 0; i < n; i++) k[i] = P[i].time;
+      time_order(k.data(), 1, n, desc, false, lazy_order_);
+    } else {
+      std::vector<double> k(n);
+      for (size_t i = 0; i < n; i++) k[i] = P[i].timestamp;
+      time_order(k.data(), 2, n, desc, false, lazy_order_);
+    }
+    std::vector<float> xyz(n * 3);
+    size_t m = 0;
+    flimo_scan_get(c, xyz.data(), n, &m);
+    auto out = std::make_shared<pcl::PointCloud<PointType>>();
+    out->points.resize(n);
+    for (size_t k = 0; k < n; k++) {
+      const size_t j = lazy_order_[k];                 // position k of pc2match = arrival index j
+      PointType p = P[j];
+      p.x = xyz[3 * j]; p.y = xyz[3 * j + 1]; p.z = xyz[3 * j + 2];
+      out->points[k] = p;
+    }
+    pc2match = out;
+  } else if (download_clouds) {
     std::vector<float> xyz(n * 3);
     size_t m = 0;
     flimo_scan_get(c, xyz.data(), n, &m);
@@ -1109,7 +1172,11 @@ void Localizer::updatePointCloud(pcl::PointCloud<PointType>::Ptr& raw_pc, double
       std::vector<float> w(n * 3);
       flimo_scan_to_world(c, x26, w.data(), n);
       final_scan = std::make_shared<pcl::PointCloud<PointType>>(*pc2match);
-      for (size_t k = 0; k < n && k < final_scan->points.size(); k++) { final_scan->points[k].x = w[3 * k]; final_scan->points[k].y = w[3 * k + 1]; final_scan->points[k].z = w[3 * k + 2]; }
+      const bool perm = lazy_order_.size() == n;                    // the device holds the sweep in arrival order
+      for (size_t k = 0; k < n && k < final_scan->points.size(); k++) {
+        const size_t j = perm ? lazy_order_[k] : k;
+        final_scan->points[k].x = w[3 * j]; final_scan->points[k].y = w[3 * j + 1]; final_scan->points[k].z = w[3 * j + 2];
+      }
     }
     if (add_to_map) map_->add_scan(x26, scan_stamp);               // returns at once; the insert overlaps the next scan's host work
     t4 = now_s();

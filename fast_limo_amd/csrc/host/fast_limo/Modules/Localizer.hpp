@@ -65,6 +65,8 @@ class fast_limo::Localizer {
   double prof_[4] = {0, 0, 0, 0};
   bool add_to_map = true;               // benchmarks may freeze the map
   bool download_clouds = true;          // keep pc2match / final_scan host copies up to date
+  bool lazy_time_order = true;          // the GPU gets the sweep in arrival order whenever the time order is not observable through
+                                        // caps / voxel sums (deskewPointCloud); false: always the reference's permutation first
 
   static Localizer& getInstance() {
     static Localizer* loc = new Localizer();
@@ -106,6 +108,9 @@ class fast_limo::Localizer {
   bool have_prev_ang_;
   Eigen::Vector3f ang_vel_cg_prev_;
   std::vector<flimo_frame> rs_frames_;  // frames of the resident raw scan
+  std::vector<uint32_t> lazy_order_;    // arrival-order sweeps: pc2match position -> arrival index (empty: device order = pc2match order)
+  bool arrival_order_ = false, arrival_keys_pending_ = false;
+  size_t arrival_last_ = 0;             // index of the point the reference's sort would put last
   float rs_l2b_[16];
   int calib_n_ = 0;
   Eigen::Vector3f calib_gyro_, calib_accel_;

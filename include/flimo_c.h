@@ -154,6 +154,10 @@ int flimo_last_kernel_ms(const flimo_ctx* ctx, float* knn_ms, float* widen_ms, f
 /* sums over every pass since the last reset (timing must be on): per-stage GPU ms, passes, k-NN queries */
 int flimo_timing_totals(flimo_ctx* ctx, double* knn_ms, double* widen_ms, double* fit_ms, long long* passes,
                         long long* queries, int reset);
+/* level-1 totals by kind of timed pass since the last reset: out[0] ms of the one-launch passes (k-NN + in-kernel widening + fit +
+ * reduction), out[1] their count; out[2..4] ms of the k-NN, widening and fit dispatches of the passes that ran them separately,
+ * out[5] their count */
+int flimo_timing_split(flimo_ctx* ctx, double out[6], int reset);
 /* number of scan points of the last pass that needed more than the 3x3x3 cell block */
 int flimo_last_widen_count(const flimo_ctx* ctx);
 /* the same count as published by the pass itself with its result (fast path), -1 when the last pass took a path that does

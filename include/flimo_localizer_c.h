@@ -51,6 +51,10 @@ void   flimo_loc_destroy(flimo_loc* L);
 flimo_ctx* flimo_loc_ctx(flimo_loc* L);
 void   flimo_loc_sync(flimo_loc* L);                                  /* wait for a running map insert */
 void   flimo_loc_set_async_insert(flimo_loc* L, int on);              /* default on; FLIMO_SYNC_INSERT=1 turns it off */
+/* default on: when no cap can bind and the voxel grid is off, the order of std::partial_sort_copy (Localizer.cpp:789-790) is not
+ * observable by the registration; the GPU then gets the sweep in arrival order and the permutation is only computed for the
+ * clouds handed back to the caller (set_flags download_clouds), while the GPU works.  off: always sort first. */
+void   flimo_loc_set_lazy_time_order(flimo_loc* L, int on);
 double flimo_loc_last_insert_seconds(flimo_loc* L);                   /* duration of the last insert (waits for it) */
 int    flimo_loc_update_imu(flimo_loc* L, double stamp, const float ang_vel[3], const float lin_accel[3]);
 /* pts5: n x (x y z intensity time[s since sweep reference]).  Returns Localizer status:

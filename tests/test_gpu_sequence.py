@@ -212,3 +212,59 @@ def test_per_scan_parity_along_a_drive_from_identical_state(built, oracle):
           % (n_scans, worst[0], worst[1], worst_x, worst_P))
     assert worst[0] <= 1e-6 and worst[1] <= 1e-6, (worst, free)
     G.close()
+
+
+def test_arrival_order_path_equals_sorted_path(built):
+    """Tied stamps (all rings of a column share one): the reference's std::partial_sort_copy decides their order with a sequential
+    heap sort.  When no cap can bind and the voxel grid is off that order is not observable by the registration, so the GPU gets
+    the sweep in arrival order and the permutation is computed only for the clouds handed back.  Pose, covariance and the stored
+    map must not depend on whether the clouds are requested (bit for bit); against the always-sort-first path the clouds come back
+    in the same order with the same coordinates, and the pose agrees to the summation order of H^T H."""
+    from fast_limo_amd import api
+    n_scans, n_pts, speed = 8, 16384, 10.0
+    st, w, a = synth.stationary_imu(0.0, 0.1 * n_scans + 0.06)
+
+    def drive(lazy, clouds):
+        G = api.Localizer(api.default_cfg(**CAPS))
+        G.set_lazy_time_order(lazy)
+        G.set_flags(add_to_map=True, download_clouds=clouds)
+        x0 = G.get_x(); x0[14] = speed; G.set_x(x0)
+        i = 0
+        out = []
+        for k in range(n_scans):
+            until = 0.1 * (k + 1) + 0.005
+            while i < len(st) and st[i] <= until:
+                G.update_imu(st[i], w[i], a[i]); i += 1
+            scan = synth.corridor_scan(k, n_pts, 909, speed=speed)
+            scan[:, 4] = np.floor(scan[:, 4] * 2560.0) / np.float32(2560.0)         # 256 columns of 64 points with one stamp each
+            rc = G.update_pointcloud(scan, 0.1 * k)
+            out.append(dict(rc=rc, x=G.get_x(), P=G.get_P(), n=G.map_size(),
+                            pc=G.pc2match() if clouds else None, fs=G.final_scan() if (clouds and rc == 0) else None))
+        G.sync()
+        pts = sort_rows(G.hip.map_points())
+        G.close()
+        return out, pts
+
+    from common import sort_rows
+    sorted_first, m_a = drive(False, True)
+    lazy_clouds, m_b = drive(True, True)
+    lazy_plain, m_c = drive(True, False)
+    for k in range(n_scans):
+        a_, b_, c_ = sorted_first[k], lazy_clouds[k], lazy_plain[k]
+        assert a_["rc"] == b_["rc"] == c_["rc"]
+        # with / without the clouds: bit for bit
+        np.testing.assert_array_equal(b_["x"], c_["x"], err_msg=f"x scan {k}")
+        np.testing.assert_array_equal(b_["P"], c_["P"], err_msg=f"P scan {k}")
+        assert b_["n"] == c_["n"]
+        # against sort-first: same clouds in the same order, same pose up to the order of the H^T H sum
+        assert a_["n"] == b_["n"], (k, a_["n"], b_["n"])
+        np.testing.assert_allclose(a_["x"], b_["x"], rtol=0, atol=1e-9)
+        assert a_["pc"].shape == b_["pc"].shape
+        np.testing.assert_allclose(a_["pc"], b_["pc"], rtol=0, atol=2e-6)
+        if a_["fs"] is not None:
+            np.testing.assert_allclose(a_["fs"], b_["fs"], rtol=0, atol=2e-6)
+        if k <= 1:      # before any pose feeds back into the deskew: identical coordinates in identical order
+            np.testing.assert_array_equal(a_["pc"], b_["pc"])
+    np.testing.assert_array_equal(m_b, m_c)                    # the stored map, as a set
+    assert m_a.shape == m_b.shape
+    assert m_b.shape[0] > 2 * n_pts
