@@ -40,14 +40,19 @@ def main():
             if key in k:
                 return v
         return None
-    for kern in ("knn5_kernel", "widen_kernel", "fit_kernel"):
+    for kern, label in (("knn5_kernel<2, 8, true>", "dominant_kernel"), ("knn5_kernel<2, 8, false>", "knn5_separate"),
+                        ("widen_kernel", "widen_kernel"), ("fit2_kernel", "fit2_kernel"), ("fit_kernel", "fit_kernel")):
         f = find(res["FETCH_SIZE_KB_per_launch"], kern)
         w = find(res["WRITE_SIZE_KB_per_launch"], kern)
         if f and w:
-            res[kern + "_traffic_bytes_per_launch"] = {
-                "fetch_raw": f["mean"] * 1024.0, "fetch_corrected_x2": 2.0 * f["mean"] * 1024.0, "write_raw": w["mean"] * 1024.0,
+            res[label + "_traffic_bytes_per_launch"] = {
+                "kernel": kern, "fetch_raw": f["mean"] * 1024.0, "fetch_corrected_x2": 2.0 * f["mean"] * 1024.0, "write_raw": w["mean"] * 1024.0,
                 "total_corrected": 2.0 * f["mean"] * 1024.0 + w["mean"] * 1024.0, "launches": f["launches"],
                 "note": "FETCH_SIZE doubled (gfx950 rocprofv3 reports half of wide coalesced reads); WRITE_SIZE as reported"}
+    # the profile is only valid for the sources it was taken with (bench.py checks this hash)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from fast_limo_amd import build as b
+    res["sources_hash"] = b.sources_hash()
     json.dump(res, open(out, "w"), indent=1)
     for k, v in res.items():
         if k.endswith("_traffic_bytes_per_launch"):
