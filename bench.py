@@ -242,12 +242,13 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    # level 1: start/stop HIP events attached to the k-NN dispatch (on the context's own stream).  A timed dispatch costs
-    # about 25 us of wall time, so the launches are SAMPLED: every (4k+1)-th pass -- the stride walks through the 4 pass
-    # positions of a step evenly -- 8 samples over the timed region (every 25th pass of the default 50 steps, about 2 % of
-    # `value`; every launch of a very short run), more for long runs (one per 81 passes).  FLIMO_BENCH_TIMING_STRIDE=1 times all.
+    # level 1: start/stop HIP events attached to the dispatches of a pass (on the context's own stream): the kernels' own begin /
+    # end timestamps.  A timed pass costs tens of microseconds of wall time, so inside the timed region the passes are SAMPLED:
+    # every (4k+1)-th -- the stride walks through the 4 pass positions of a step evenly -- about 6 samples (every launch of a very
+    # short run), which keeps the perturbation of `value` near 1 %.  A dense series (every pass of 12 more steps) follows the
+    # timed region for the statistics (`stage.dense_after_timed_region`).  FLIMO_BENCH_TIMING_STRIDE=1 times all.
     loc.hip.set_timing(int(os.environ.get('FLIMO_BENCH_TIMING', '1')))
-    auto_stride = min(81, ((4 * args.steps // 8) // 4) * 4 + 1)        # 8 samples (short runs: every launch), one per 81 passes at most
+    auto_stride = max(5, ((4 * args.steps // 6) // 4) * 4 + 1)
     loc.hip.set_timing_stride(int(os.environ.get('FLIMO_BENCH_TIMING_STRIDE', str(auto_stride))))
     loc.hip.timing_totals(reset=True)
     loc.hip.timing_split(reset=True)
@@ -265,6 +266,17 @@ def main():
     n_passes = loc.hip.pass_count() - passes0
     n_fused_passes = loc.hip.fused_pass_count() - fused0
     hp = loc.host_profile()
+    dense = None
+    if int(os.environ.get('FLIMO_BENCH_TIMING', '1')) == 1:
+        loc.hip.set_timing_stride(1)
+        loc.hip.timing_split(reset=True)
+        for _ in range(12):
+            step()
+        d = loc.hip.timing_split(reset=True)
+        dense = {"one_launch_pass_us": (1e3 * d["fused_ms"] / d["fused_n"]) if d["fused_n"] else None, "one_launch_passes_timed": d["fused_n"],
+                 "separate_dispatch_pass_us": ({"knn": 1e3 * d["knn_ms"] / d["separate_n"], "widen": 1e3 * d["widen_ms"] / d["separate_n"],
+                                                "fit_reduce": 1e3 * d["fit_ms"] / d["separate_n"]} if d["separate_n"] else None),
+                 "separate_dispatch_passes_timed": d["separate_n"]}
     loc.hip.set_timing(0)
     x_end = loc.get_x()
     assert np.array_equal(x_end, x_ref), "registration is not reproducible across steps"
@@ -390,7 +402,8 @@ def main():
                                    "`hbm_utilisation_measured` are the HBM-side bytes from PMC counters: the 1M-point map lives in L2 / Infinity Cache",
                            "stage": {"one_launch_pass_us": one_us, "one_launch_passes_timed": split["fused_n"],
                                      "separate_dispatch_pass_us": sep, "separate_dispatch_passes_timed": split["separate_n"],
-                                     "passes_in_one_launch": n_fused_passes, "passes_total": n_passes}}
+                                     "passes_in_one_launch": n_fused_passes, "passes_total": n_passes,
+                                     "dense_after_timed_region": dense}}
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     loc.close()
     if dist is not None:

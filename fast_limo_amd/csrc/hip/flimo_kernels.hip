@@ -434,6 +434,10 @@ __device__ __forceinline__ void knn5_tail(const GridView& G, int max_ring, NbrRe
   const int F = __popcll(B);
   if (F == 0) return;                                         // wave-uniform
   if (lane == 0) atomicAdd(straggler_count, F);               // statistics only (published with the pass result)
+#ifdef FLIMO_TRACE
+  const unsigned long long tr_t0 = wall_clock64();
+  int tr_iters = 0;
+#endif
   if (pending) S.src[__popcll(B & ((1ull << lane) - 1ull))] = lane;
   wave_lds_sync();
   int ngroups = 1;
@@ -478,18 +482,24 @@ __device__ __forceinline__ void knn5_tail(const GridView& G, int max_ring, NbrRe
     int flag = 0;
     for (;;) {
       if (!__any(active)) break;
+#ifdef FLIMO_TRACE
+      tr_iters++;
+#endif
       if (active) {
         // Every lane of the group owns rows of the ring-r block (row j of lane sub: j = sub + i * Gl) and walks its own rows'
         // candidates: bounds of four rows in one round trip, then up to eight candidate loads in flight per row.  No
         // flattening, no tables: with 64 lanes per query (the lone straggler of a converged pass) a lane owns at most one
         // row and the chain is two round trips (bounds, candidates) and the extraction.
         const int side = 2 * r + 1, rows = side * side;
+        // lanes per row: a lone straggler has the whole wave -- two lanes share each of the 25 rows of a ring-2 block
+        const int lr = (Gl == 64 && rows <= 32) ? 2 : 1, nslots = Gl / lr;
+        const int slot = sub / lr, part = sub - slot * lr;
         double k5[5] = {none, none, none, none, none};
-        for (int jb = sub; jb < rows; jb += 4 * Gl) {
+        for (int jb = slot; jb < rows; jb += 4 * nslots) {
           uint32_t lo4[4], hi4[4];
 #pragma unroll
           for (int u = 0; u < 4; u++) {
-            const int j = jb + u * Gl;
+            const int j = jb + u * nslots;
             lo4[u] = 0u; hi4[u] = 0u;
             if (j < rows) {
               const int jz = j / side, jy = j - jz * side;
@@ -514,22 +524,23 @@ __device__ __forceinline__ void knn5_tail(const GridView& G, int max_ring, NbrRe
 #pragma unroll
           for (int u = 0; u < 4; u++) {
             const uint32_t hi = hi4[u];
-            for (uint32_t i0 = lo4[u]; i0 < hi; i0 += 8u) {
+            for (uint32_t i0 = lo4[u] + (uint32_t)part; i0 < hi; i0 += 8u * (uint32_t)lr) {
               float4 q[8];
 #pragma unroll
-              for (int w = 0; w < 8; w++) q[w] = G.pts[min(i0 + (uint32_t)w, hi - 1u)];
+              for (int w = 0; w < 8; w++) q[w] = G.pts[min(i0 + (uint32_t)(w * lr), hi - 1u)];
               asm volatile("" : "+v"(q[0].x), "+v"(q[0].y), "+v"(q[0].z), "+v"(q[1].x), "+v"(q[1].y), "+v"(q[1].z),
                                 "+v"(q[2].x), "+v"(q[2].y), "+v"(q[2].z), "+v"(q[3].x), "+v"(q[3].y), "+v"(q[3].z),
                                 "+v"(q[4].x), "+v"(q[4].y), "+v"(q[4].z), "+v"(q[5].x), "+v"(q[5].y), "+v"(q[5].z),
                                 "+v"(q[6].x), "+v"(q[6].y), "+v"(q[6].z), "+v"(q[7].x), "+v"(q[7].y), "+v"(q[7].z));
 #pragma unroll
               for (int w = 0; w < 8; w++) {
-                const bool live = i0 + (uint32_t)w < hi;
+                const uint32_t ii = i0 + (uint32_t)(w * lr);
+                const bool live = ii < hi;
                 const float d = sqdist3(qx, qy, qz, q[w].x, q[w].y, q[w].z);
-                best5_insert(k5, key_make(live ? d : INFINITY, live ? i0 + (uint32_t)w : 0xffffffffu));
+                best5_insert(k5, key_make(live ? d : INFINITY, live ? ii : 0xffffffffu));
               }
             }
-            cand += (int)(hi - lo4[u]);
+            if (part == 0) cand += (int)(hi - lo4[u]);
           }
         }
         u64 mine[5];
@@ -576,6 +587,11 @@ __device__ __forceinline__ void knn5_tail(const GridView& G, int max_ring, NbrRe
     }
   }
   if (cand_total && cand) atomicAdd(cand_total, (unsigned long long)cand);
+#ifdef FLIMO_TRACE
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  if (lane == 0 && blockIdx.x < 16384)      // developer statistics of the tail: duration (10 ns units), stragglers of the wave, ring iterations
+    g_trace[0][blockIdx.x * 8 + 7] = ((wall_clock64() - tr_t0) & 0xffffull) | ((unsigned long long)F << 16) | ((unsigned long long)tr_iters << 24) | (1ull << 40);
+#endif
 }
 
 // FUSE: the whole measurement pass in ONE launch (fast path of flimo_match_reduce): every wave goes on from its queries'

@@ -68,6 +68,15 @@ for k in (0, 1):
         print("  fastest nonzero:")
         for b in order[-6:]:
             print(f"    {b:5d} {b % 8} {dur[b]:6.2f} {cph[b]:6.2f} {int(tot[b]):6d} {int(t[b, 7]):#x}")
+        info = t[:, 7]
+        has = (info >> 40) & 1 == 1
+        if has.any():
+            d = (info[has] & 0xffff) / 100.0; F = (info[has] >> 16) & 0xff; it = (info[has] >> 24) & 0xff
+            print("  tail: blocks with stragglers %d; duration us median %.2f p90 %.2f max %.2f; F max %d; ring iterations max %d (mean %.2f)"
+                  % (int(has.sum()), np.median(d), np.percentile(d, 90), d.max(), int(F.max()), int(it.max()), it.mean()))
+            for Fv in sorted(set(F.tolist()))[:6]:
+                m = F == Fv
+                print("    F=%d: n=%d median %.2f us, iterations mean %.2f" % (Fv, int(m.sum()), np.median(d[m]), it[m].mean()))
         ok = tot > 0
         print("  corr(dur, block candidates) =", np.corrcoef(dur[ok], tot[ok])[0, 1], " block candidates: median", np.median(tot[ok]), "max", tot.max())
         end = (t[:, 5] - t0) / 100.0
