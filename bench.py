@@ -222,7 +222,8 @@ def main():
     from fast_limo_amd import api
     caps = dict(MAX_NUM_PC2MATCH=10**7, MAX_NUM_MATCHES=10**7)
     mp, scan, imu = workload(rank, args.rings, args.azimuths, args.map_points, args.box)
-    loc = api.Localizer(api.default_cfg(gpu_device=local_rank, num_threads=os.cpu_count() or 1,
+    n_dev = max(1, torch.cuda.device_count())        # one rank per GPU on a node; ranks wrap around on a smaller box (tests)
+    loc = api.Localizer(api.default_cfg(gpu_device=local_rank % n_dev, num_threads=os.cpu_count() or 1,
                                         gpu_cell_size=float(os.environ.get('FLIMO_BENCH_CELL', '0')), **caps))   # 0 = library default (0.5 m)
     loc.set_flags(add_to_map=False, download_clouds=False, keep_log=False)
     rc1 = drive_to_prior(loc, mp, scan, imu)

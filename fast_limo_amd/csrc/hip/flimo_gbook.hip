@@ -21,7 +21,7 @@
 //            half > 2*min_extent) on its index list, allocating nodes from the pool
 // The initial batch (Octree::initialize) is built on the host once (flimo_insert.cpp) and exported.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include "flimo_prims.h"
 #include <float.h>
 #include <vector>
 #include "flimo_types.h"
@@ -551,14 +551,14 @@ hipError_t GBook::init(hipStream_t st, const float4* batch, int m, const float b
   hipLaunchKernelGGL(gb_finite_kernel, dim3(blocks), dim3(256), 0, st, batch, m, keep, assign);
   hipLaunchKernelGGL(gb_flags_kernel, dim3(blocks), dim3(256), 0, st, keep, m, flags);
   size_t scan_bytes = 0;
-  GBCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, flags, rank, m, st));
+  GBCHK(exclusive_sum(nullptr, scan_bytes, flags, rank, m, st));
   if (scan_bytes > S.cub_tmp_bytes) {
     GBCHK(hipStreamSynchronize(st));
     if (S.cub_tmp) (void)hipFree(S.cub_tmp);
     GBCHK(hipMalloc(&S.cub_tmp, scan_bytes + 1024));
     S.cub_tmp_bytes = scan_bytes + 1024;
   }
-  GBCHK(hipcub::DeviceScan::ExclusiveSum(S.cub_tmp, scan_bytes, flags, rank, m, st));
+  GBCHK(exclusive_sum(S.cub_tmp, scan_bytes, flags, rank, m, st));
   hipLaunchKernelGGL(gb_append_kernel, dim3(blocks), dim3(256), 0, st, batch, keep, rank, assign, m, 0, map_raw, pt_leaf, new_index);
   uint32_t last_rank = 0, last_flag = 0;
   GBCHK(hipMemcpyAsync(&last_rank, rank + (m - 1), 4, hipMemcpyDeviceToHost, st));
@@ -677,8 +677,8 @@ hipError_t GBook::update(hipStream_t st, const float4* batch, int m, const float
   }
   hipLaunchKernelGGL(gb_route_kernel, dim3(blocks), dim3(256), 0, st, batch, m, node_c, node_child, node_cnt, root, S.keys_in, S.vals_in);
   size_t tmp_bytes = 0, scan_bytes = 0;
-  GBCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, S.keys_in, S.keys_out, S.vals_in, S.vals_out, m, 0, 32, st));
-  GBCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, flags, rank, m, st));
+  GBCHK(sort_pairs_u32(nullptr, tmp_bytes, S.keys_in, S.keys_out, S.vals_in, S.vals_out, m, 0, 32, st));
+  GBCHK(exclusive_sum(nullptr, scan_bytes, flags, rank, m, st));
   const size_t need = std::max(tmp_bytes, scan_bytes);
   if (need > S.cub_tmp_bytes) {
     GBCHK(hipStreamSynchronize(st));
@@ -686,14 +686,14 @@ hipError_t GBook::update(hipStream_t st, const float4* batch, int m, const float
     GBCHK(hipMalloc(&S.cub_tmp, need + 1024));
     S.cub_tmp_bytes = need + 1024;
   }
-  GBCHK(hipcub::DeviceRadixSort::SortPairs(S.cub_tmp, tmp_bytes, S.keys_in, S.keys_out, S.vals_in, S.vals_out, m, 0, 32, st));
+  GBCHK(sort_pairs_u32(S.cub_tmp, tmp_bytes, S.keys_in, S.keys_out, S.vals_in, S.vals_out, m, 0, 32, st));
   GBCHK(hipMemsetAsync(counters, 0, 4 * sizeof(int), st));
   hipLaunchKernelGGL(gb_decide_kernel, dim3(blocks), dim3(256), 0, st, S.keys_out, m, node_c, node_cnt, min_half,
                      downsample ? 1 : 0, flags /* dec_keep */, reinterpret_cast<int*>(rank) /* dec_assign */, items, counters, node_item, big_items);
   hipLaunchKernelGGL(gb_apply_kernel, dim3(blocks), dim3(256), 0, st, S.keys_out, S.vals_out, m, flags, reinterpret_cast<const int*>(rank),
                      keep, assign);
   hipLaunchKernelGGL(gb_flags_kernel, dim3(blocks), dim3(256), 0, st, keep, m, flags);
-  GBCHK(hipcub::DeviceScan::ExclusiveSum(S.cub_tmp, scan_bytes, flags, rank, m, st));
+  GBCHK(exclusive_sum(S.cub_tmp, scan_bytes, flags, rank, m, st));
   hipLaunchKernelGGL(gb_append_kernel, dim3(blocks), dim3(256), 0, st, batch, keep, rank, assign, m, map_n, map_raw, pt_leaf, new_index);
   int h_cnt[4] = {0, 0, 0, 0};
   uint32_t last_rank = 0, last_flag = 0;

@@ -11,7 +11,7 @@
 //   4. gather    : points re-ordered into cell order (float4, w keeps the insertion index)
 //   5. cell_start: lower-bound of every cell id in the sorted keys
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include "flimo_prims.h"
 #include <float.h>
 #include "flimo_types.h"
 #include "flimo_kernels.h"
@@ -133,7 +133,7 @@ hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4
   int bits = 1;
   while (bits < 32 && ((size_t)1 << bits) < ncells) bits++;
   size_t tmp_bytes = 0;
-  e = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, S.keys_in, S.keys_out, S.vals_in, S.vals_out, (int)n, 0,
+  e = sort_pairs_u32(nullptr, tmp_bytes, S.keys_in, S.keys_out, S.vals_in, S.vals_out, (int)n, 0,
                                          bits, st);
   if (e != hipSuccess) return e;
   if (tmp_bytes > S.cub_tmp_bytes) {
@@ -142,7 +142,7 @@ hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4
     S.cub_tmp_bytes = tmp_bytes + 1024;
   }
   if (n > 0) {
-    e = hipcub::DeviceRadixSort::SortPairs(S.cub_tmp, tmp_bytes, S.keys_in, S.keys_out, S.vals_in, S.vals_out, (int)n,
+    e = sort_pairs_u32(S.cub_tmp, tmp_bytes, S.keys_in, S.keys_out, S.vals_in, S.vals_out, (int)n,
                                            0, bits, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(256), 0, st, pts_in, S.vals_out, n, pts_out);
@@ -150,7 +150,7 @@ hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4
   if ((e = hipMemsetAsync(cell_start, 0, (ncells + 1) * sizeof(uint32_t), st)) != hipSuccess) return e;
   if (n > 0) hipLaunchKernelGGL(tails_kernel, dim3(blocks), dim3(256), 0, st, S.keys_out, n, cell_start);
   size_t scan_bytes = 0;
-  e = hipcub::DeviceScan::InclusiveScan(nullptr, scan_bytes, cell_start, cell_start, hipcub::Max(), (int)(ncells + 1), st);
+  e = inclusive_max_u32(nullptr, scan_bytes, cell_start, cell_start, (int)(ncells + 1), st);
   if (e != hipSuccess) return e;
   if (scan_bytes > S.cub_tmp_bytes) {
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;   // the sort may still be using cub_tmp
@@ -158,7 +158,7 @@ hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4
     if ((e = hipMalloc(&S.cub_tmp, scan_bytes + 1024)) != hipSuccess) return e;
     S.cub_tmp_bytes = scan_bytes + 1024;
   }
-  e = hipcub::DeviceScan::InclusiveScan(S.cub_tmp, scan_bytes, cell_start, cell_start, hipcub::Max(), (int)(ncells + 1), st);
+  e = inclusive_max_u32(S.cub_tmp, scan_bytes, cell_start, cell_start, (int)(ncells + 1), st);
   if (e != hipSuccess) return e;
   return hipGetLastError();
 }
@@ -246,7 +246,7 @@ hipError_t map_merge_grid(hipStream_t st, const float4* old_sorted, size_t n_old
   int bits = 1;
   while (bits < 32 && ((size_t)1 << bits) < ncells) bits++;
   size_t tmp_bytes = 0;
-  e = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, S.keys_in, S.keys_out, S.vals_in, S.vals_out, (int)k, 0, bits, st);
+  e = sort_pairs_u32(nullptr, tmp_bytes, S.keys_in, S.keys_out, S.vals_in, S.vals_out, (int)k, 0, bits, st);
   if (e != hipSuccess) return e;
   if (tmp_bytes > S.cub_tmp_bytes) {
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
@@ -254,7 +254,7 @@ hipError_t map_merge_grid(hipStream_t st, const float4* old_sorted, size_t n_old
     if ((e = hipMalloc(&S.cub_tmp, tmp_bytes + 1024)) != hipSuccess) return e;
     S.cub_tmp_bytes = tmp_bytes + 1024;
   }
-  e = hipcub::DeviceRadixSort::SortPairs(S.cub_tmp, tmp_bytes, S.keys_in, S.keys_out, S.vals_in, S.vals_out, (int)k, 0, bits, st);
+  e = sort_pairs_u32(S.cub_tmp, tmp_bytes, S.keys_in, S.keys_out, S.vals_in, S.vals_out, (int)k, 0, bits, st);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(merge_new_kernel, dim3(kb), dim3(256), 0, st, new_pts, S.keys_out, S.vals_out, (uint32_t)k, cell_start, out_sorted);
   if (n_old > 0)
@@ -349,7 +349,7 @@ hipError_t sort_scan(hipStream_t st, const float4* in, size_t n, float4* out, Ma
   const int blocks = (int)((n + 255) / 256);
   hipLaunchKernelGGL(mortonkey_kernel, dim3(blocks), dim3(256), 0, st, in, n, S.keys_in, S.vals_in);
   size_t tmp_bytes = 0;
-  e = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, S.keys_in, S.keys_out, S.vals_in, S.vals_out, (int)n, 0, 30, st);
+  e = sort_pairs_u32(nullptr, tmp_bytes, S.keys_in, S.keys_out, S.vals_in, S.vals_out, (int)n, 0, 30, st);
   if (e != hipSuccess) return e;
   if (tmp_bytes > S.cub_tmp_bytes) {
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
@@ -357,7 +357,7 @@ hipError_t sort_scan(hipStream_t st, const float4* in, size_t n, float4* out, Ma
     if ((e = hipMalloc(&S.cub_tmp, tmp_bytes + 1024)) != hipSuccess) return e;
     S.cub_tmp_bytes = tmp_bytes + 1024;
   }
-  e = hipcub::DeviceRadixSort::SortPairs(S.cub_tmp, tmp_bytes, S.keys_in, S.keys_out, S.vals_in, S.vals_out, (int)n, 0, 30, st);
+  e = sort_pairs_u32(S.cub_tmp, tmp_bytes, S.keys_in, S.keys_out, S.vals_in, S.vals_out, (int)n, 0, 30, st);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(gather_scan_kernel, dim3(blocks), dim3(256), 0, st, in, S.vals_out, n, out);
   if (t_in && t_out) hipLaunchKernelGGL(gather_f64_kernel, dim3(blocks), dim3(256), 0, st, t_in, S.vals_out, n, t_out);
@@ -486,10 +486,10 @@ hipError_t voxel_grid(hipStream_t st, const float4* in, size_t n, float leaf, fl
   hipLaunchKernelGGL(voxelkey_kernel, dim3(blocks), dim3(256), 0, st, in, n, inv, mb[0], mb[1], mb[2], db[0], db[0] * db[1],
                      S.keys_in, S.vals_in);
   size_t tmp_bytes = 0;
-  e = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, S.keys_in, S.keys_out, S.vals_in, S.vals_out, (int)n, 0, 32, st);
+  e = sort_pairs_u32(nullptr, tmp_bytes, S.keys_in, S.keys_out, S.vals_in, S.vals_out, (int)n, 0, 32, st);
   if (e != hipSuccess) return e;
   size_t scan_bytes = 0;
-  e = hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, S.keys_in, S.vals_in, (int)n, st);
+  e = exclusive_sum(nullptr, scan_bytes, S.keys_in, S.vals_in, (int)n, st);
   if (e != hipSuccess) return e;
   const size_t need = std::max(tmp_bytes, scan_bytes);
   if (need > S.cub_tmp_bytes) {
@@ -497,11 +497,11 @@ hipError_t voxel_grid(hipStream_t st, const float4* in, size_t n, float leaf, fl
     if ((e = hipMalloc(&S.cub_tmp, need + 1024)) != hipSuccess) return e;
     S.cub_tmp_bytes = need + 1024;
   }
-  e = hipcub::DeviceRadixSort::SortPairs(S.cub_tmp, tmp_bytes, S.keys_in, S.keys_out, S.vals_in, S.vals_out, (int)n, 0, 32, st);
+  e = sort_pairs_u32(S.cub_tmp, tmp_bytes, S.keys_in, S.keys_out, S.vals_in, S.vals_out, (int)n, 0, 32, st);
   if (e != hipSuccess) return e;
   // keys_in := head flags, vals_in := exclusive scan of the flags (output slot of each run)
   hipLaunchKernelGGL(voxelhead_kernel, dim3(blocks), dim3(256), 0, st, S.keys_out, n, S.keys_in);
-  e = hipcub::DeviceScan::ExclusiveSum(S.cub_tmp, scan_bytes, S.keys_in, S.vals_in, (int)n, st);
+  e = exclusive_sum(S.cub_tmp, scan_bytes, S.keys_in, S.vals_in, (int)n, st);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(voxelcentroid_kernel, dim3(blocks), dim3(256), 0, st, in, S.keys_out, S.vals_out, S.keys_in, S.vals_in, n, out);
   uint32_t last_pos = 0, last_head = 0;

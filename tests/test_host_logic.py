@@ -102,38 +102,74 @@ def test_insert_rule_equals_oracle_octree(built, oracle):
 _WORKER = r'''
 import os, sys, time, json
 sys.path.insert(0, os.environ["FLIMO_ROOT"])
+import numpy as np
 import torch, torch.distributed as dist
+import bench                                    # the benchmark's own barrier / aggregation code
+from fast_limo_amd import api                   # a real product call per "step": the host IESKF update (no GPU needed)
 rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
-dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-# the bench's N>1 protocol: barrier, time K steps, barrier, MAX over ranks, rank 0 aggregates
-dist.barrier(); t0 = time.perf_counter()
-time.sleep(0.05 * (rank + 1))            # rank 1 is the slow one
-dist.barrier(); el = time.perf_counter() - t0
-t = torch.tensor([0.05 * (rank + 1)], dtype=torch.float64)
-dist.all_reduce(t, op=dist.ReduceOp.MAX)
+dist.init_process_group(backend=os.environ.get("FLIMO_BENCH_BACKEND", "gloo"), rank=rank, world_size=world)
+rs = np.random.RandomState(rank)
+H = rs.normal(size=(200, 12)); h = rs.normal(size=200) * 1e-3
+x0 = np.zeros(26); x0[6] = 1; x0[10] = 1; x0[25] = -9.809
+steps = 10
+bench.rank_barrier(dist, torch)
+t0 = time.perf_counter()
+for _ in range(steps):
+    api.eskf_update_fixed(x0, np.eye(23) * 1e-3, H, h)
+time.sleep(0.05 * (rank + 1))                   # rank 1 is the slow one
+bench.rank_barrier(dist, torch)
+mine = time.perf_counter() - t0
+elapsed, value = bench.aggregate(dist, torch, mine, world, steps)
 if rank == 0:
-    steps = 10
-    print(json.dumps({"value": world * steps / float(t.item()), "max_t": float(t.item()), "el": el}))
+    print(json.dumps({"value": value, "elapsed": elapsed, "mine": mine, "steps": steps, "world": world}))
 dist.destroy_process_group()
 '''
 
 
-def test_two_rank_gloo_aggregation(tmp_path):
-    """world_size-2 run of the bench's timing protocol on CPU (gloo): the slowest rank sets the time and
-    the throughput is the sum over ranks / that time (weak scaling, no data-path collective)."""
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def test_two_rank_gloo_runs_the_bench_protocol(built, tmp_path):
+    """world_size-2 run on CPU (gloo) of bench.py's OWN barrier / max-over-ranks / aggregation helpers around real product calls:
+    the slowest rank sets the time, the throughput is the scans of all ranks over that time (weak scaling, no data-path
+    collective)."""
     script = tmp_path / "w.py"
     script.write_text(_WORKER)
-    env = dict(os.environ, FLIMO_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    port = str(_free_port())
+    env = dict(os.environ, FLIMO_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, FLIMO_BENCH_BACKEND="gloo")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
+                          "--master-addr", "127.0.0.1", "--master-port", port, str(script)],
                          env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     import json
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     r = json.loads(line)
-    assert abs(r["max_t"] - 0.10) < 1e-9
-    assert abs(r["value"] - 2 * 10 / 0.10) < 1e-6
-    assert r["el"] >= 0.099
+    assert r["elapsed"] >= 0.099 and r["elapsed"] >= r["mine"] - 1e-9          # the max over the ranks (rank 1 slept 0.1 s)
+    assert abs(r["value"] - r["world"] * r["steps"] / r["elapsed"]) < 1e-9
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu_through_gloo(built):
+    """The real bench.py under torch.distributed.run with two ranks (gloo for the barrier, both replicas on the one GPU of the box):
+    the N > 1 launch path end to end -- one JSON line from rank 0, n_gpus = 2, weak scaling, two independent streams."""
+    import json
+    port = str(_free_port())
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, FLIMO_BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", "2",
+                          "--steps", "4", "--warmup", "1", "--rings", "16", "--azimuths", "512", "--map-points", "100000",
+                          "--box", "40", "--no-cpu-baseline", "--no-end-to-end"],
+                         env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                        # rank 0 only
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["steps"] == 4
+    assert r["value"] > 0 and abs(r["value"] - 2 * 4 / (r["ms_per_step"] * 4e-3)) < 1e-6 * r["value"]
 
 
 def test_bench_cli_contract():
