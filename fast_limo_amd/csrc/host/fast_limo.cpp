@@ -363,11 +363,11 @@ Localizer::Localizer(Mapper* map)
       prev_scan_stamp(0.0), imu_stamp(0.0), prev_imu_stamp(0.0), first_imu_stamp(0.0), last_propagate_time_(-1.0),
       imu_calib_time_(3.0), gravity_(9.81f), imu_calibrated_(false), num_threads_(1), have_prev_ang_(false),
       last_status_(0), cpu_time(0.f), cpu_max_time(0.f), cpu_mean_time(0.f), scans_timed_(0) {
-  original_scan = std::make_shared<pcl::PointCloud<PointType>>();
-  deskewed_scan = std::make_shared<pcl::PointCloud<PointType>>();
-  pc2match = std::make_shared<pcl::PointCloud<PointType>>();
-  final_raw_scan = std::make_shared<pcl::PointCloud<PointType>>();
-  final_scan = std::make_shared<pcl::PointCloud<PointType>>();
+  original_scan = fast_limo::make_shared<pcl::PointCloud<PointType>>();
+  deskewed_scan = fast_limo::make_shared<pcl::PointCloud<PointType>>();
+  pc2match = fast_limo::make_shared<pcl::PointCloud<PointType>>();
+  final_raw_scan = fast_limo::make_shared<pcl::PointCloud<PointType>>();
+  final_scan = fast_limo::make_shared<pcl::PointCloud<PointType>>();
   for (int i = 0; i < 4; i++) stage_t_[i] = 0.0;
   last_imu.stamp = 0; last_imu.dt = 0;
 }
@@ -600,10 +600,11 @@ void Localizer::propagateImu(double t1, double t2) {                 // Localize
   last_propagate_time_ = imu_range_end_stamp_;                       // Localizer.cpp:653
 }
 
-void Localizer::calculate_H(const flimo_host::StateIkfom& s, const Matches& ms, std::vector<double>& H, std::vector<double>& h) {
+void Localizer::calculate_H(const state_ikfom& s, const Matches& ms, Eigen::MatrixXd& H, Eigen::VectorXd& h) {   // Localizer.hpp:176
   const size_t N = ((int)ms.size() > config.ikfom.mapping.MAX_NUM_MATCHES) ? (size_t)config.ikfom.mapping.MAX_NUM_MATCHES : ms.size();
-  H.assign(N * 12, 0.0);
-  h.assign(N, 0.0);
+  H = Eigen::MatrixXd::Zero((long)N, 12);
+  h = Eigen::VectorXd::Zero((long)N);
+  std::vector<double> Hf(N * 12, 0.0), hf(N, 0.0);
   std::vector<float> pg(N * 3), nn(N * 4), dd(N);
   for (size_t i = 0; i < N; i++) {
     const Eigen::Vector3f g = ms[i].get_global_point();
@@ -614,7 +615,11 @@ void Localizer::calculate_H(const flimo_host::StateIkfom& s, const Matches& ms, 
   }
   double x26[26];
   s.to_flat(x26);
-  flimo_calculate_H_host(x26, pg.data(), nn.data(), dd.data(), N, config.ikfom.estimate_extrinsics ? 1 : 0, H.data(), h.data());
+  flimo_calculate_H_host(x26, pg.data(), nn.data(), dd.data(), N, config.ikfom.estimate_extrinsics ? 1 : 0, Hf.data(), hf.data());
+  for (size_t i = 0; i < N; i++) {
+    for (int j = 0; j < 12; j++) H((long)i, j) = Hf[i * 12 + j];
+    h((long)i) = hf[i];
+  }
   if (config.debug) matches = ms;
 }
 
@@ -867,8 +872,9 @@ void fast_limo::time_order(const void* keys, int kind, size_t n, bool desc, bool
   else time_order_t(static_cast<const double*>(keys), n, desc, use_library, order);
 }
 
-bool Localizer::deskewPointCloud(pcl::PointCloud<PointType>::Ptr& pc, double& start_time) {   // Localizer.cpp:733-853
-  if (pc->points.size() < 1) return false;
+pcl::PointCloud<PointType>::Ptr Localizer::deskewPointCloud(pcl::PointCloud<PointType>::Ptr& pc, double& start_time) {
+  const pcl::PointCloud<PointType>::Ptr none;      // the reference returns the deskewed cloud; an early return hands back an empty pointer here   // Localizer.cpp:733-853
+  if (pc->points.size() < 1) return none;
   const double sweep_ref_time = start_time;
   const bool eos = config.end_of_sweep;
   std::function<bool(const PointType&, const PointType&)> cmp;
@@ -887,7 +893,7 @@ bool Localizer::deskewPointCloud(pcl::PointCloud<PointType>::Ptr& pc, double& st
     extract = [](const PointType& p) { return p.timestamp * 1e-9f; };
   } else {
     std::cout << "FAST_LIMO::FATAL ERROR: LiDAR sensor type unknown or not specified!\n";
-    return false;
+    return none;
   }
   // Time order with the same library call as the reference (:789-790) so that ties land identically:
   // std::partial_sort_copy is oblivious to the payload, so running it on 16-byte (key, index) records
@@ -895,7 +901,7 @@ bool Localizer::deskewPointCloud(pcl::PointCloud<PointType>::Ptr& pc, double& st
   // permutation as sorting the 32-byte points through std::function, several times faster.
   static const bool prof = std::getenv("FLIMO_PROF_DESKEW") != nullptr;     // developer timing of the host stages
   const double tp0 = prof ? now_s() : 0.0;
-  auto sorted = std::make_shared<pcl::PointCloud<PointType>>();
+  auto sorted = fast_limo::make_shared<pcl::PointCloud<PointType>>();
   const bool desc = eos && (sensor == SensorType::OUSTER || sensor == SensorType::VELODYNE);
   // WHO needs the exact permutation of that call?  The deskew itself works point by point (each point carries its stamp); the
   // order of pc2match is visible (a) through MAX_NUM_PC2MATCH / MAX_NUM_MATCHES ("the first N in pc2match order"), (b) through
@@ -963,7 +969,7 @@ bool Localizer::deskewPointCloud(pcl::PointCloud<PointType>::Ptr& pc, double& st
   States frames;
   if (!propagatedFromTimeRange(prev_scan_stamp, scan_stamp, frames) || frames.empty()) {
     std::cout << "FAST_LIMO::propagatedFromTimeRange(): not enough propagated states!\n";
-    return false;
+    return none;
   }
   mtx_ikfom.lock();
   const StateIkfom xs = ikfom_->get_x();
@@ -998,16 +1004,16 @@ bool Localizer::deskewPointCloud(pcl::PointCloud<PointType>::Ptr& pc, double& st
   double x26[26];
   xs.to_flat(x26);
   flimo_ctx* c = map_->ctx();
-  if (!c) return false;
+  if (!c) return none;
   // raw scan + times become resident; frames are kept for registerResident()
   const double tp2 = prof ? now_s() : 0.0;
   int rc = flimo_raw_scan_set(c, &sorted->points[0].x, n, sizeof(PointType), t.data());
   const double tp3 = prof ? now_s() : 0.0;
-  if (rc != FLIMO_OK) { std::cout << "FAST_LIMO::raw scan upload failed: " << flimo_last_error(c) << "\n"; return false; }
+  if (rc != FLIMO_OK) { std::cout << "FAST_LIMO::raw scan upload failed: " << flimo_last_error(c) << "\n"; return none; }
   rs_frames_.assign(fr.begin(), fr.end());
-  std::memcpy(rs_l2b_, extr.lidar2baselink_T.m, sizeof(rs_l2b_));
+  compat::to_row_major(extr.lidar2baselink_T, rs_l2b_);
   rc = flimo_deskew_resident(c, rs_frames_.data(), rs_frames_.size(), rs_l2b_, x26);
-  if (rc != FLIMO_OK) { std::cout << "FAST_LIMO::deskew failed: " << flimo_last_error(c) << "\n"; return false; }
+  if (rc != FLIMO_OK) { std::cout << "FAST_LIMO::deskew failed: " << flimo_last_error(c) << "\n"; return none; }
   const double tp4 = prof ? now_s() : 0.0;
   if (prof)
     fprintf(stderr, "[flimo deskew] time sort + gather %.0f us, frames/times %.0f us, upload + Morton sort %.0f us, deskew call %.0f us (n = %zu)\n",
@@ -1031,7 +1037,7 @@ bool Localizer::deskewPointCloud(pcl::PointCloud<PointType>::Ptr& pc, double& st
     std::vector<float> xyz(n * 3);
     size_t m = 0;
     flimo_scan_get(c, xyz.data(), n, &m);
-    auto out = std::make_shared<pcl::PointCloud<PointType>>();
+    auto out = fast_limo::make_shared<pcl::PointCloud<PointType>>();
     out->points.resize(n);
     for (size_t k = 0; k < n; k++) {
       const size_t j = lazy_order_[k];                 // position k of pc2match = arrival index j
@@ -1049,7 +1055,7 @@ bool Localizer::deskewPointCloud(pcl::PointCloud<PointType>::Ptr& pc, double& st
   } else {
     pc2match = sorted;
   }
-  return true;
+  return pc2match;
 }
 
 // Benchmark entry (inputs resident in HBM): restores the given prior, then GPU deskew of the
@@ -1083,7 +1089,7 @@ void Localizer::updatePointCloud(pcl::PointCloud<PointType>::Ptr& raw_pc, double
   // removeNaNFromPointCloud (:263-265), negative CropBox (:268-271) and the distance / rate / FoV filters (:274-302) in ONE
   // pass over the raw cloud.  As in the reference, *raw_pc itself ends up NaN-free and cropped (both filters write back
   // into it), and the rate filter counts positions in that cropped cloud.
-  auto input_pc = std::make_shared<pcl::PointCloud<PointType>>();
+  auto input_pc = fast_limo::make_shared<pcl::PointCloud<PointType>>();
   {
     std::vector<PointType>& P = raw_pc->points;
     const bool crop = config.filters.crop_active, dist = config.filters.dist_active;
@@ -1129,10 +1135,10 @@ void Localizer::updatePointCloud(pcl::PointCloud<PointType>::Ptr& raw_pc, double
     raw_pc->is_dense = true;
     if (prof_prep) fprintf(stderr, "[flimo prep] resize %.0f us, loop %.0f us, trim %.0f us (n = %zu -> %zu -> %zu)\n", (tq1 - tq0) * 1e6, (tq2 - tq1) * 1e6, (now_s() - tq2) * 1e6, n, k, m);
   }
-  if (config.debug) original_scan = std::make_shared<pcl::PointCloud<PointType>>(*input_pc);
+  if (config.debug) original_scan = fast_limo::make_shared<pcl::PointCloud<PointType>>(*input_pc);
   const double t1 = now_s();
-  bool ok = deskewPointCloud(input_pc, time_stamp);
-  if (!ok) pc2match = std::make_shared<pcl::PointCloud<PointType>>();
+  bool ok = (bool)deskewPointCloud(input_pc, time_stamp);       // sets pc2match (:307)
+  if (!ok) pc2match = fast_limo::make_shared<pcl::PointCloud<PointType>>();
   if (ok && config.filters.voxel_active && map_->ctx()) {          // VoxelGrid (:313-321) on the GPU
     size_t nv = 0;
     const int rc = flimo_scan_voxel_filter(map_->ctx(), config.filters.leafSize[0], &nv);
@@ -1141,7 +1147,7 @@ void Localizer::updatePointCloud(pcl::PointCloud<PointType>::Ptr& raw_pc, double
       std::vector<float> xyz(nv * 3);
       size_t m = 0;
       flimo_scan_get(map_->ctx(), xyz.data(), nv, &m);
-      auto vox = std::make_shared<pcl::PointCloud<PointType>>();
+      auto vox = fast_limo::make_shared<pcl::PointCloud<PointType>>();
       vox->points.resize(nv);
       for (size_t k = 0; k < nv; k++) { vox->points[k].x = xyz[3 * k]; vox->points[k].y = xyz[3 * k + 1]; vox->points[k].z = xyz[3 * k + 2]; }
       pc2match = vox;
@@ -1171,7 +1177,7 @@ void Localizer::updatePointCloud(pcl::PointCloud<PointType>::Ptr& raw_pc, double
       const size_t n = flimo_scan_size(c);
       std::vector<float> w(n * 3);
       flimo_scan_to_world(c, x26, w.data(), n);
-      final_scan = std::make_shared<pcl::PointCloud<PointType>>(*pc2match);
+      final_scan = fast_limo::make_shared<pcl::PointCloud<PointType>>(*pc2match);
       const bool perm = lazy_order_.size() == n;                    // the device holds the sweep in arrival order
       for (size_t k = 0; k < n && k < final_scan->points.size(); k++) {
         const size_t j = perm ? lazy_order_[k] : k;

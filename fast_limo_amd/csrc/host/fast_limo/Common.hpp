@@ -17,58 +17,98 @@
 
 #ifdef FLIMO_USE_EIGEN_PCL
 #include <Eigen/Dense>
+#include <pcl/pcl_config.h>
 #include <pcl/point_cloud.h>
 #include <pcl/point_types.h>
+#if PCL_VERSION_COMPARE(<, 1, 11, 0)
+#include <boost/make_shared.hpp>
+#include <boost/shared_ptr.hpp>
+#endif
 #else
+// Stand-ins: storage is PRIVATE, the only way in is the part of Eigen's / PCL's own interface the reference's callers use
+// (src/main.cpp, ROSutils.hpp, Localizer.hpp) -- so code that compiles against them compiles against the real headers as far
+// as these types go: no member spelling of the stand-ins can leak into the library (Eigen's matrices are column-major and
+// expose no such members).
 namespace Eigen {
-struct Vector3f {
-  float d[3];
-  Vector3f() : d{0.f, 0.f, 0.f} {}
-  Vector3f(float x, float y, float z) : d{x, y, z} {}
-  float& operator()(int i) { return d[i]; }
-  float operator()(int i) const { return d[i]; }
-  float& operator[](int i) { return d[i]; }
-  float operator[](int i) const { return d[i]; }
-  float x() const { return d[0]; }
-  float y() const { return d[1]; }
-  float z() const { return d[2]; }
+class Vector3f {
+  float d_[3];
+ public:
+  Vector3f() : d_{0.f, 0.f, 0.f} {}
+  Vector3f(float x, float y, float z) : d_{x, y, z} {}
+  float& operator()(int i) { return d_[i]; }
+  float operator()(int i) const { return d_[i]; }
+  float& operator[](int i) { return d_[i]; }
+  float operator[](int i) const { return d_[i]; }
+  float x() const { return d_[0]; }
+  float y() const { return d_[1]; }
+  float z() const { return d_[2]; }
   static Vector3f Zero() { return Vector3f(); }
 };
-struct Vector4f {
-  float d[4];
-  Vector4f() : d{0.f, 0.f, 0.f, 0.f} {}
-  Vector4f(float x, float y, float z, float w) : d{x, y, z, w} {}
-  float& operator()(int i) { return d[i]; }
-  float operator()(int i) const { return d[i]; }
+class Vector4f {
+  float d_[4];
+ public:
+  Vector4f() : d_{0.f, 0.f, 0.f, 0.f} {}
+  Vector4f(float x, float y, float z, float w) : d_{x, y, z, w} {}
+  float& operator()(int i) { return d_[i]; }
+  float operator()(int i) const { return d_[i]; }
 };
-struct Quaternionf {
-  float qx, qy, qz, qw;
-  Quaternionf() : qx(0.f), qy(0.f), qz(0.f), qw(1.f) {}
-  Quaternionf(float w, float x, float y, float z) : qx(x), qy(y), qz(z), qw(w) {}   // Eigen order (w,x,y,z)
-  float x() const { return qx; }
-  float y() const { return qy; }
-  float z() const { return qz; }
-  float w() const { return qw; }
+class Quaternionf {
+  float qx_, qy_, qz_, qw_;
+ public:
+  Quaternionf() : qx_(0.f), qy_(0.f), qz_(0.f), qw_(1.f) {}
+  Quaternionf(float w, float x, float y, float z) : qx_(x), qy_(y), qz_(z), qw_(w) {}   // Eigen order (w,x,y,z)
+  float x() const { return qx_; }
+  float y() const { return qy_; }
+  float z() const { return qz_; }
+  float w() const { return qw_; }
   static Quaternionf Identity() { return Quaternionf(); }
 };
-struct Matrix3f {
-  float m[9];   // row-major storage; access through (row, col)
-  Matrix3f() { for (int i = 0; i < 9; i++) m[i] = 0.f; }
-  float& operator()(int r, int c) { return m[r * 3 + c]; }
-  float operator()(int r, int c) const { return m[r * 3 + c]; }
-  static Matrix3f Identity() { Matrix3f o; o.m[0] = o.m[4] = o.m[8] = 1.f; return o; }
+class Matrix3f {
+  float m_[9];
+ public:
+  Matrix3f() { for (int i = 0; i < 9; i++) m_[i] = 0.f; }
+  float& operator()(int r, int c) { return m_[r * 3 + c]; }
+  float operator()(int r, int c) const { return m_[r * 3 + c]; }
+  static Matrix3f Identity() { Matrix3f o; o(0, 0) = o(1, 1) = o(2, 2) = 1.f; return o; }
 };
-struct Matrix4f {
-  float m[16];
-  Matrix4f() { for (int i = 0; i < 16; i++) m[i] = 0.f; }
-  float& operator()(int r, int c) { return m[r * 4 + c]; }
-  float operator()(int r, int c) const { return m[r * 4 + c]; }
-  static Matrix4f Identity() { Matrix4f o; o.m[0] = o.m[5] = o.m[10] = o.m[15] = 1.f; return o; }
+class Matrix4f {
+  float m_[16];
+ public:
+  Matrix4f() { for (int i = 0; i < 16; i++) m_[i] = 0.f; }
+  float& operator()(int r, int c) { return m_[r * 4 + c]; }
+  float operator()(int r, int c) const { return m_[r * 4 + c]; }
+  static Matrix4f Identity() { Matrix4f o; o(0, 0) = o(1, 1) = o(2, 2) = o(3, 3) = 1.f; return o; }
+};
+// dynamic double matrix / vector of the measurement seam (Localizer::calculate_H, Localizer.hpp:176)
+class MatrixXd {
+  std::vector<double> v_;
+  long r_, c_;
+ public:
+  MatrixXd() : r_(0), c_(0) {}
+  MatrixXd(long r, long c) : v_((size_t)(r * c), 0.0), r_(r), c_(c) {}
+  static MatrixXd Zero(long r, long c) { return MatrixXd(r, c); }
+  long rows() const { return r_; }
+  long cols() const { return c_; }
+  double& operator()(long r, long c) { return v_[(size_t)(r * c_ + c)]; }
+  double operator()(long r, long c) const { return v_[(size_t)(r * c_ + c)]; }
+};
+class VectorXd {
+  std::vector<double> v_;
+ public:
+  VectorXd() {}
+  explicit VectorXd(long n) : v_((size_t)n, 0.0) {}
+  static VectorXd Zero(long n) { return VectorXd(n); }
+  long size() const { return (long)v_.size(); }
+  double& operator()(long i) { return v_[(size_t)i]; }
+  double operator()(long i) const { return v_[(size_t)i]; }
 };
 }  // namespace Eigen
 namespace pcl {
 struct PointXYZ {
-  float x, y, z, pad_;
+  float x, y, z;
+ private:
+  float pad_;
+ public:
   PointXYZ() : x(0.f), y(0.f), z(0.f), pad_(1.f) {}
   PointXYZ(float x_, float y_, float z_) : x(x_), y(y_), z(z_), pad_(1.f) {}
 };
@@ -128,15 +168,44 @@ struct IMUmeas {
   Eigen::Quaternionf q;
 };
 
+// the smart pointer PCL's clouds use (reference Common.hpp:134-152): boost's before PCL 1.11, the standard one since
+#ifdef FLIMO_USE_EIGEN_PCL
+#if PCL_VERSION_COMPARE(<, 1, 11, 0)
+#define FLIMO_PCL_BOOST_PTR 1
+#endif
+#endif
+#ifdef FLIMO_PCL_BOOST_PTR
+template <typename T>
+using shared_ptr = boost::shared_ptr<T>;
+template <typename T, typename... Args>
+boost::shared_ptr<T> make_shared(Args&&... args) { return boost::make_shared<T>(std::forward<Args>(args)...); }
+#else
 template <typename T>
 using shared_ptr = std::shared_ptr<T>;
 template <typename T, typename... Args>
 std::shared_ptr<T> make_shared(Args&&... args) { return std::make_shared<T>(std::forward<Args>(args)...); }
+#endif
+
+// The library's own accessors for the few places where a matrix crosses the C ABI as a flat array: written against
+// operator()(row, col) only, so they read the same numbers from a stand-in and from a (column-major) Eigen matrix.
+namespace compat {
+inline void to_row_major(const Eigen::Matrix4f& M, float out[16]) {
+  for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) out[r * 4 + c] = M(r, c);
+}
+inline void to_row_major(const Eigen::Matrix3f& M, float out[9]) {
+  for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) out[r * 3 + c] = M(r, c);
+}
+}  // namespace compat
 // Order of a sweep's points by time stamp exactly as the reference's std::partial_sort_copy leaves it (Localizer.cpp:789-790),
 // ties included.  kind: 0 = uint32 (OUSTER t), 1 = float (VELODYNE time), 2 = double (HESAI / LIVOX timestamp).
 void time_order(const void* keys, int kind, size_t n, bool descending, bool use_library, std::vector<uint32_t>& order);
 }  // namespace fast_limo
 
+#ifdef FLIMO_USE_EIGEN_PCL
+POINT_CLOUD_REGISTER_POINT_STRUCT(fast_limo::Point,
+                                 (float, x, x)(float, y, y)(float, z, z)(float, intensity, intensity)
+                                 (std::uint32_t, t, t)(float, time, time)(double, timestamp, timestamp))
+#endif
 typedef fast_limo::Point PointType;
 typedef pcl::PointXYZ MapPoint;
 typedef std::vector<pcl::PointXYZ> MapPoints;

@@ -14,6 +14,7 @@
 #include "fast_limo/Utils/Config.hpp"
 
 namespace flimo_host { class Esekf; struct StateIkfom; }
+typedef flimo_host::StateIkfom state_ikfom;     // the reference's name of the filter state (IKFoM/use-ikfom.hpp:12-21)
 
 class fast_limo::Localizer {
  public:
@@ -46,9 +47,9 @@ class fast_limo::Localizer {
   fast_limo::SensorType get_sensor_type();
   void propagateImu(const IMUmeas& imu);
   void propagateImu(double t1, double t2);                 // Localizer.cpp:610-654 (unused by the reference's own callers)
-  // iKFoM measurement model (Localizer.cpp:537-577).  H is N x 12 row-major, N = min(matches, MAX_NUM_MATCHES); with
-  // FLIMO_USE_EIGEN_PCL map it onto an Eigen::MatrixXd.  The registration path builds the same rows on the GPU.
-  void calculate_H(const flimo_host::StateIkfom& s, const Matches& matches, std::vector<double>& H, std::vector<double>& h);
+  // iKFoM measurement model (Localizer.hpp:176, Localizer.cpp:537-577): H is N x 12, N = min(matches, MAX_NUM_MATCHES).  The
+  // registration path builds the same rows on the GPU.
+  void calculate_H(const state_ikfom&, const Matches&, Eigen::MatrixXd& H, Eigen::VectorXd& h);
 
   // --- MI355X additions -----------------------------------------------------------------------
   explicit Localizer(Mapper* map);      // non-singleton instances (one per GPU, SURVEY.md 8 e)
@@ -78,7 +79,7 @@ class fast_limo::Localizer {
   void init_iKFoM_state();
   IMUmeas imu2baselink(IMUmeas& imu);
   void calibrateStandStill(const IMUmeas& imu);
-  bool deskewPointCloud(pcl::PointCloud<PointType>::Ptr& pc, double& start_time);
+  pcl::PointCloud<PointType>::Ptr deskewPointCloud(pcl::PointCloud<PointType>::Ptr& pc, double& start_time);   // Localizer.hpp:191
   bool propagatedFromTimeRange(double start_time, double end_time, States& frames);
   bool imuMeasFromTimeRange(double start_time, double end_time, std::vector<IMUmeas>& meas);   // Localizer.cpp:917-949, oldest first
   bool isInRange(const PointType& p);
