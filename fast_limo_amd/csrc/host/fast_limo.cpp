@@ -917,16 +917,28 @@ pcl::PointCloud<PointType>::Ptr Localizer::deskewPointCloud(pcl::PointCloud<Poin
     const bool caps = (mc.MAX_NUM_PC2MATCH >= 0 && n0 > (size_t)mc.MAX_NUM_PC2MATCH) || (mc.MAX_NUM_MATCHES >= 0 && n0 > (size_t)mc.MAX_NUM_MATCHES);
     bool arrival = lazy_time_order && !caps && !config.filters.voxel_active;
     if (arrival) {
-      // the stamp of the point the sort would put last (largest key, smallest when sorting descending); NaN stamps: the library path
+      // the stamp of the point the sort would put last: the largest key (the smallest when sorting descending) -- only the KEY of
+      // that point is ever read (extract() below), so any point carrying it will do.  Two branch-free passes (the compiler
+      // vectorises them): the extreme key with a NaN check, then one index holding it.  NaN stamps: the library path.
       const std::vector<PointType>& P = pc->points;
       size_t last = 0;
       bool nan = false;
       if (sensor == SensorType::OUSTER) {
-        for (size_t i = 1; i < n0; i++) if (desc ? P[i].t < P[last].t : P[i].t > P[last].t) last = i;
+        uint32_t best = P[0].t;
+        if (desc) { for (size_t i = 1; i < n0; i++) best = P[i].t < best ? P[i].t : best; }
+        else { for (size_t i = 1; i < n0; i++) best = P[i].t > best ? P[i].t : best; }
+        for (size_t i = 0; i < n0; i++) if (P[i].t == best) { last = i; break; }
       } else if (sensor == SensorType::VELODYNE) {
-        for (size_t i = 0; i < n0; i++) { nan = nan || (P[i].time != P[i].time); if (desc ? P[i].time < P[last].time : P[i].time > P[last].time) last = i; }
+        float best = P[0].time, acc = 0.f;
+        if (desc) { for (size_t i = 0; i < n0; i++) { const float v = P[i].time; acc += v * 0.f; best = v < best ? v : best; } }
+        else { for (size_t i = 0; i < n0; i++) { const float v = P[i].time; acc += v * 0.f; best = v > best ? v : best; } }
+        nan = !(acc == 0.f) || best != best;                    // NaN or inf * 0 anywhere poisons the sum
+        for (size_t i = 0; i < n0 && !nan; i++) if (P[i].time == best) { last = i; break; }
       } else {
-        for (size_t i = 0; i < n0; i++) { nan = nan || (P[i].timestamp != P[i].timestamp); if (P[i].timestamp > P[last].timestamp) last = i; }
+        double best = P[0].timestamp, acc = 0.0;
+        for (size_t i = 0; i < n0; i++) { const double v = P[i].timestamp; acc += v * 0.0; best = v > best ? v : best; }
+        nan = !(acc == 0.0) || best != best;
+        for (size_t i = 0; i < n0 && !nan; i++) if (P[i].timestamp == best) { last = i; break; }
       }
       if (nan) arrival = false;
       else {
