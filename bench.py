@@ -278,9 +278,27 @@ def main():
                  "separate_dispatch_pass_us": ({"knn": 1e3 * d["knn_ms"] / d["separate_n"], "widen": 1e3 * d["widen_ms"] / d["separate_n"],
                                                 "fit_reduce": 1e3 * d["fit_ms"] / d["separate_n"]} if d["separate_n"] else None),
                  "separate_dispatch_passes_timed": d["separate_n"]}
-    loc.hip.set_timing(0)
     x_end = loc.get_x()
     assert np.array_equal(x_end, x_ref), "registration is not reproducible across steps"
+    # the k-NN STAGE on its own (fast path + widening, no fit): the same registration with the pass split into separate dispatches
+    # (A/B switch), every pass timed -- what the fused launch's k-NN part costs when rocprofv3 / HIP events can see it
+    knn_stage = None
+    if int(os.environ.get('FLIMO_BENCH_TIMING', '1')) == 1 and os.environ.get('FLIMO_FUSE', '1') != '0':
+        loc.hip.set_path_switches(fuse=0)
+        for _ in range(2):
+            step()
+        loc.hip.timing_split(reset=True)
+        for _ in range(12):
+            step()
+        d = loc.hip.timing_split(reset=True)
+        loc.hip.set_path_switches(fuse=1)
+        if d["separate_n"]:
+            knn_stage = {"knn_us": 1e3 * d["knn_ms"] / d["separate_n"], "widen_us": 1e3 * d["widen_ms"] / d["separate_n"],
+                         "fit_us": 1e3 * d["fit_ms"] / d["separate_n"], "passes_timed": d["separate_n"]}
+    loc.hip.set_timing(0)
+    if knn_stage:
+        step()          # back on the one-launch path: same state as at the end of the timed region
+        assert np.array_equal(loc.get_x(), x_ref)
 
     # the same step WITH the path exit (transform + Mapper::add of the registered scan), reported
     # beside `value`, never as `value`.  The first insertion stores the scan's new points; repeating the same scan is
@@ -405,6 +423,14 @@ def main():
                                      "separate_dispatch_pass_us": sep, "separate_dispatch_passes_timed": split["separate_n"],
                                      "passes_in_one_launch": n_fused_passes, "passes_total": n_passes,
                                      "dense_after_timed_region": dense}}
+        if knn_stage and bytes_per_query:
+            st_us = knn_stage["knn_us"] + knn_stage["widen_us"]
+            out["roofline"]["knn_stage_separate_dispatches"] = dict(
+                knn_stage, stage_us_per_pass=st_us, achieved=bytes_per_query * qpl / (st_us * 1e-6) / 1e9,
+                frac=bytes_per_query * qpl / (st_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                note="A/B series after the timed region with the pass split into dispatches: k-NN (fast path + in-kernel widening; the "
+                     "first pass of the poor prior hands its clustered stragglers to the widening dispatch) + widening, mean per pass "
+                     "over all 4 pass positions; same algorithmic bytes")
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     loc.close()
     if dist is not None:

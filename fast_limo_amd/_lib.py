@@ -57,7 +57,7 @@ HIP_SYMBOLS = [
     "flimo_match_reduce", "flimo_match_fetch", "flimo_match_fetch_H",
     "flimo_scan_to_world", "flimo_map_add_scan",
     "flimo_set_timing", "flimo_set_timing_stride", "flimo_pass_count", "flimo_fused_pass_count", "flimo_map_grid_selfcheck", "flimo_set_debug_records", "flimo_set_lanes_per_query", "flimo_last_kernel_ms",
-    "flimo_last_candidates_per_query", "flimo_last_widen_count", "flimo_last_stragglers", "flimo_timing_totals", "flimo_timing_split", "flimo_insert_rule_replay", "flimo_plane_fit5_host", "flimo_plane_eval5_host", "flimo_calculate_H_host",
+    "flimo_last_candidates_per_query", "flimo_last_widen_count", "flimo_last_stragglers", "flimo_timing_totals", "flimo_timing_split", "flimo_set_path_switches", "flimo_insert_rule_replay", "flimo_plane_fit5_host", "flimo_plane_eval5_host", "flimo_calculate_H_host",
 ]
 
 _hip = None
@@ -121,6 +121,7 @@ def load_hip():
     L.flimo_timing_totals.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                       C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.c_int]
     L.flimo_timing_split.argtypes = [vp, f64p, C.c_int]
+    L.flimo_set_path_switches.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     L.flimo_insert_rule_replay.argtypes = [C.c_float, C.c_int, f32p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t)]
     L.flimo_calculate_H_host.argtypes = [f64p, f32p, f32p, f32p, C.c_size_t, C.c_int, f64p, f64p]
     L.flimo_last_widen_count.restype = C.c_int
@@ -309,6 +310,9 @@ class HipCtx:
         a = C.c_double(0); b = C.c_double(0); d = C.c_double(0); n = C.c_longlong(0); q = C.c_longlong(0)
         self._chk(self._L.flimo_timing_totals(self._h, C.byref(a), C.byref(b), C.byref(d), C.byref(n), C.byref(q), int(reset)))
         return dict(knn_ms=a.value, widen_ms=b.value, fit_ms=d.value, passes=n.value, queries=q.value)
+
+    def set_path_switches(self, tail=-1, fuse=-1, fit2=-1):
+        self._chk(self._L.flimo_set_path_switches(self._h, int(tail), int(fuse), int(fit2)))
 
     def timing_split(self, reset=False):
         o = np.zeros(6)

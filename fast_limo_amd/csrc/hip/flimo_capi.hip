@@ -921,6 +921,14 @@ extern "C" int flimo_timing_totals(flimo_ctx* c, double* knn_ms, double* widen_m
   if (reset) { c->tot_knn_ms = c->tot_widen_ms = c->tot_fit_ms = 0.0; c->tot_passes = 0; c->tot_queries = 0; }
   return FLIMO_OK;
 }
+// developer / benchmark A/B: negative leaves a switch as it is
+extern "C" int flimo_set_path_switches(flimo_ctx* c, int tail, int fuse, int fit2) {
+  if (!c) return FLIMO_ERR_INVALID;
+  if (tail >= 0) c->tail = tail != 0;
+  if (fuse >= 0) c->fuse = fuse != 0;
+  if (fit2 >= 0) c->fit2 = fit2 != 0;
+  return FLIMO_OK;
+}
 extern "C" int flimo_timing_split(flimo_ctx* c, double out[6], int reset) {
   if (!c || !out) return FLIMO_ERR_INVALID;
   out[0] = c->split_fused_ms; out[1] = (double)c->split_fused_n;

@@ -158,6 +158,10 @@ int flimo_timing_totals(flimo_ctx* ctx, double* knn_ms, double* widen_ms, double
  * reduction), out[1] their count; out[2..4] ms of the k-NN, widening and fit dispatches of the passes that ran them separately,
  * out[5] their count */
 int flimo_timing_split(flimo_ctx* ctx, double out[6], int reset);
+/* A/B switches of the pass layout (each: 1 on, 0 off, negative = leave): `tail` finishes pending queries inside the k-NN launch,
+ * `fuse` runs the whole pass as one launch, `fit2` uses the granule-publishing fit dispatch.  All on by default; the benchmark
+ * switches `fuse` off for a short series to time the k-NN stage (fast path + widening) on its own. */
+int flimo_set_path_switches(flimo_ctx* ctx, int tail, int fuse, int fit2);
 /* number of scan points of the last pass that needed more than the 3x3x3 cell block */
 int flimo_last_widen_count(const flimo_ctx* ctx);
 /* the same count as published by the pass itself with its result (fast path), -1 when the last pass took a path that does
