@@ -54,7 +54,7 @@ void launch_mfma_layout(hipStream_t st, double* raw256);
 // in/t are in the (Morton-)sorted order with the original index in in[k].w; writes the deskewed point
 // to out_sorted[k] (w = original index) and to out_orig[original index]
 void launch_deskew(hipStream_t st, const float4* in, const double* t, int n, const void* frames, int nf,
-                   const float* mats32, float4* out_sorted, float4* out_orig);
+                   const float* mats32, float4* out_sorted, float4* out_orig, double t_offset = 0.0);   // stamp of point k = t[k] + t_offset
 void launch_transform(hipStream_t st, const float4* in, int n, const PoseMats& P, float4* out);
 size_t dev_frame_size();
 
@@ -85,6 +85,11 @@ hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4
 hipError_t map_merge_grid(hipStream_t st, const float4* old_sorted, size_t n_old, const float4* new_pts, size_t k,
                           float4* out_sorted, uint32_t* cell_start, size_t ncells, float ox, float oy, float oz,
                           float inv_cell, int nx, int ny, int nz, MapBuildScratch& S);
+// Input filters of a raw sweep (32-byte PointType records already on the device): NaN removal, crop box, every rate-th survivor,
+// min distance; order preserved.  out[k] = (xyz, w = k), t_out[k] = stamp without the sweep offset; ext_dev[3] = {extreme ordered
+// stamp key (complemented when the sweep is sorted descending), kept count, "a kept stamp is NaN"}.
+hipError_t filter_raw_scan(hipStream_t st, const void* raw32_dev, size_t n, const FilterParams& F, float4* out, double* t_out,
+                           unsigned long long* ext_dev, MapBuildScratch& S);
 size_t row_table_size(int nx, int ny, int nz);
 hipError_t map_build_row_table(hipStream_t st, const uint32_t* cell_start, int nx, int ny, int nz, uint32_t* out, bool zero_pads = true);
 // pcl::VoxelGrid on device points: out gets one centroid per occupied voxel in ascending voxel index

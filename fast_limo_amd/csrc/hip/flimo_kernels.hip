@@ -1585,10 +1585,10 @@ __global__ __launch_bounds__(256) void deskew_kernel(const float4* __restrict__ 
                                                      int n, const DevFrame* __restrict__ frames, int nf,
                                                      const float* __restrict__ mats /* [0..15] lidar2baselink_T,
                                                      [16..31] last_state.get_RT_inv() */,
-                                                     float4* __restrict__ out_sorted, float4* __restrict__ out_orig) {
+                                                     float4* __restrict__ out_sorted, float4* __restrict__ out_orig, double t_offset) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
-  const double tk = t[k];
+  const double tk = t[k] + t_offset;        // (sweep reference +- point time) + offset, as the host forms it (Localizer.cpp:741-805)
   // binary_search_tailored (Algorithms.hpp:25-38)
   int low = 0, high = nf - 1;
   while (high >= low) {
@@ -1880,11 +1880,11 @@ void launch_mfma_layout(hipStream_t st, double* raw256) {
 }
 
 void launch_deskew(hipStream_t st, const float4* in, const double* t, int n, const void* frames, int nf,
-                   const float* mats32, float4* out_sorted, float4* out_orig) {
+                   const float* mats32, float4* out_sorted, float4* out_orig, double t_offset) {
   const int blocks = (n + 255) / 256;
   if (blocks == 0) return;
   hipLaunchKernelGGL(deskew_kernel, dim3(blocks), dim3(256), 0, st, in, t, n, (const DevFrame*)frames, nf, mats32,
-                     out_sorted, out_orig);
+                     out_sorted, out_orig, t_offset);
 }
 
 void launch_transform(hipStream_t st, const float4* in, int n, const PoseMats& P, float4* out) {

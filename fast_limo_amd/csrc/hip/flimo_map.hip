@@ -364,6 +364,99 @@ hipError_t sort_scan(hipStream_t st, const float4* in, size_t n, float4* out, Ma
   return hipGetLastError();
 }
 
+// ---- input filters of a raw sweep on the device (Localizer.cpp:262-302): NaN removal -> crop box -> every rate-th survivor ->
+//      min distance, order preserved; per-point stamp (:741-805).  Records are the reference's 32-byte PointType. -----------------
+struct Raw32 { float x, y, z, w, intensity; uint32_t pad; uint32_t u0, u1; };   // u0/u1: the 8-byte time union
+__device__ __forceinline__ bool filt_alive(const Raw32& p, const FilterParams& F) {
+  const bool finite = isfinite(p.x) & isfinite(p.y) & isfinite(p.z);
+  const bool outside = (p.x < F.mn[0]) | (p.y < F.mn[1]) | (p.z < F.mn[2]) | (p.x > F.mx[0]) | (p.y > F.mx[1]) | (p.z > F.mx[2]);
+  return finite & (!F.crop | outside);
+}
+__global__ __launch_bounds__(256) void filt_alive_kernel(const Raw32* __restrict__ in, size_t n, FilterParams F, uint32_t* __restrict__ a) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] = filt_alive(in[i], F) ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void filt_keep_kernel(const Raw32* __restrict__ in, size_t n, FilterParams F, const uint32_t* __restrict__ a,
+                                                        const uint32_t* __restrict__ rank, uint32_t* __restrict__ keep) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  bool k = a[i] != 0u;
+  if (k && F.rate_on) k = (rank[i] % (uint32_t)F.rate) == 0u;
+  if (k && F.dist) {
+    const Raw32 p = in[i];
+    k = __builtin_sqrtf(p.x * p.x + (p.y * p.y + p.z * p.z)) > F.min_dist;
+  }
+  keep[i] = k ? 1u : 0u;
+}
+// out[pos] = (xyz, w = pos), t_out[pos] = the point's stamp without the sweep offset, ext[0] = extreme ordered key (max; min when
+// sorting descending, stored complemented), ext[1] = kept count, ext[2] = a kept stamp is NaN
+__global__ __launch_bounds__(256) void filt_compact_kernel(const Raw32* __restrict__ in, size_t n, FilterParams F, const uint32_t* __restrict__ keep,
+                                                           const uint32_t* __restrict__ pos, float4* __restrict__ out, double* __restrict__ t_out,
+                                                           unsigned long long* __restrict__ ext) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (i == n - 1) ext[1] = (unsigned long long)(pos[i] + keep[i]);
+  if (!keep[i]) return;
+  const Raw32 p = in[i];
+  const uint32_t o = pos[i];
+  out[o] = make_float4(p.x, p.y, p.z, __uint_as_float(o));
+  double t;
+  unsigned long long key;
+  bool nan = false;
+  const bool desc = F.eos && F.kind <= 1;
+  if (F.kind == 0) {
+    const float tf = (float)p.u0 * 1e-9f;
+    t = F.eos ? F.sweep_ref - (double)tf : F.sweep_ref + (double)tf;
+    key = (unsigned long long)p.u0;
+  } else if (F.kind == 1) {
+    float v = __uint_as_float(p.u0);
+    t = F.eos ? F.sweep_ref - (double)v : F.sweep_ref + (double)v;
+    nan = v != v;
+    v += 0.0f;
+    const uint32_t b = __float_as_uint(v);
+    key = (unsigned long long)((b & 0x80000000u) ? ~b : (b | 0x80000000u));
+  } else {
+    double v = __longlong_as_double((long long)(((unsigned long long)p.u1 << 32) | (unsigned long long)p.u0));
+    t = (F.kind == 2) ? v : v * (double)1e-9f;
+    nan = v != v;
+    v += 0.0;
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    key = (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
+  }
+  t_out[o] = t;
+  if (nan) atomicOr(&ext[2], 1ull);
+  else atomicMax(&ext[0], desc ? ~key : key);
+}
+
+hipError_t filter_raw_scan(hipStream_t st, const void* raw32_dev, size_t n, const FilterParams& F, float4* out, double* t_out,
+                           unsigned long long* ext_dev, MapBuildScratch& S) {
+  if (n == 0) return hipSuccess;
+  hipError_t e = ensure_scratch(S, n);
+  if (e != hipSuccess) return e;
+  const int blocks = (int)((n + 255) / 256);
+  const Raw32* in = static_cast<const Raw32*>(raw32_dev);
+  size_t scan_bytes = 0;
+  e = exclusive_sum(nullptr, scan_bytes, S.keys_in, S.vals_in, n, st);
+  if (e != hipSuccess) return e;
+  if (scan_bytes > S.cub_tmp_bytes) {
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+    if (S.cub_tmp) (void)hipFree(S.cub_tmp);
+    if ((e = hipMalloc(&S.cub_tmp, scan_bytes + 1024)) != hipSuccess) return e;
+    S.cub_tmp_bytes = scan_bytes + 1024;
+  }
+  if ((e = hipMemsetAsync(ext_dev, 0, 3 * sizeof(unsigned long long), st)) != hipSuccess) return e;
+  hipLaunchKernelGGL(filt_alive_kernel, dim3(blocks), dim3(256), 0, st, in, n, F, S.keys_in);
+  if (F.rate_on) {
+    e = exclusive_sum(S.cub_tmp, scan_bytes, S.keys_in, S.vals_in, n, st);               // rank among the survivors of NaN + crop
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(filt_keep_kernel, dim3(blocks), dim3(256), 0, st, in, n, F, S.keys_in, S.vals_in, S.keys_out);
+  e = exclusive_sum(S.cub_tmp, scan_bytes, S.keys_out, S.vals_out, n, st);                // output position
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(filt_compact_kernel, dim3(blocks), dim3(256), 0, st, in, n, F, S.keys_out, S.vals_out, out, t_out, ext_dev);
+  return hipGetLastError();
+}
+
 // ---- voxel-grid down-sampling of the scan (pcl::VoxelGrid, reference Localizer.cpp:313-321) -----
 // One output point per occupied voxel = centroid of its points (float sums in ascending point order),
 // output in ascending linear voxel index  i + j*div_x + k*div_x*div_y  with

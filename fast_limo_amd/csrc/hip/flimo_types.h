@@ -50,6 +50,18 @@ struct MatchParams {
   int max_ring;            // search rings needed to honour the MAX_DIST_PLANE gate exactly
 };
 
+// Input filters of Localizer::updatePointCloud (Localizer.cpp:262-302) + the per-point stamp of deskewPointCloud (:741-805)
+struct FilterParams {
+  int crop;                // CropBox, negative: points strictly inside the box are removed (:57-59,269-270)
+  float mn[3], mx[3];
+  int dist;                // min distance filter (:295-297)
+  float min_dist;          // compared with the float norm
+  int rate_on, rate;       // every rate-th of the points that survive NaN removal + crop box
+  int kind;                // time union view: 0 OUSTER u32 ns, 1 VELODYNE f32 s, 2 HESAI f64 s, 3 LIVOX f64 ns
+  int eos;                 // end_of_sweep
+  double sweep_ref;        // sweep reference time
+};
+
 // 64-byte per-query record consumed by the HTH reducer: H row, h, valid flag.
 struct alignas(16) Rec16 {
   float v[16];   // [0..11] H row, [12] h = -dist, [13] valid (1/0), [14..15] 0

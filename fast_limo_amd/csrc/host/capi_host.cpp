@@ -176,6 +176,7 @@ void flimo_loc_set_flags(flimo_loc* L, int add_to_map, int download_clouds, int 
   L->loc->filter().keep_log = keep_log != 0;
 }
 void flimo_loc_set_lazy_time_order(flimo_loc* L, int on) { if (L) L->loc->lazy_time_order = on != 0; }
+void flimo_loc_set_gpu_filters(flimo_loc* L, int on) { if (L) L->loc->gpu_filters = on != 0; }
 // the map insert that ends a scan runs on the Mapper's worker thread (Mapper::add_scan): wait for it / switch it off
 void flimo_loc_sync(flimo_loc* L) { if (L) L->map->sync(); }
 void flimo_loc_set_async_insert(flimo_loc* L, int on) { if (L) L->map->set_async(on != 0); }

@@ -1070,6 +1070,70 @@ pcl::PointCloud<PointType>::Ptr Localizer::deskewPointCloud(pcl::PointCloud<Poin
   return pc2match;
 }
 
+// The whole pre-update pipeline of a sweep on the GPU: NaN removal, crop box, rate and min-distance
+// filters, per-point stamps (flimo_raw_scan_filter_set), Morton order, deskew.  Taken when the sweep may reach the GPU in arrival
+// order (see deskewPointCloud) and nobody asked for host copies of the clouds; the FoV filter (host libm's atan2) and NaN stamps
+// stay on the host path.  Returns 0 = not applicable (take the host path), 1 = deskewed scan resident, -1 = sweep rejected
+// (the same early returns as deskewPointCloud).
+int Localizer::deskewOnDevice(pcl::PointCloud<PointType>::Ptr& raw_pc, double start_time) {
+  const auto& fl = config.filters;
+  const auto& mc = config.ikfom.mapping;
+  const size_t n = raw_pc->points.size();
+  const bool caps = (mc.MAX_NUM_PC2MATCH >= 0 && n > (size_t)mc.MAX_NUM_PC2MATCH) || (mc.MAX_NUM_MATCHES >= 0 && n > (size_t)mc.MAX_NUM_MATCHES);
+  if (!gpu_filters || !lazy_time_order || download_clouds || config.debug || fl.fov_active || fl.voxel_active || caps) return 0;
+  if (sensor != SensorType::OUSTER && sensor != SensorType::VELODYNE && sensor != SensorType::HESAI && sensor != SensorType::LIVOX) return 0;
+  flimo_ctx* c = map_->ctx();
+  if (!c) return 0;
+  flimo_filter_cfg fc;
+  std::memset(&fc, 0, sizeof(fc));
+  fc.crop_active = fl.crop_active ? 1 : 0;
+  for (int a = 0; a < 3; a++) { fc.crop_min[a] = fl.cropBoxMin[a]; fc.crop_max[a] = fl.cropBoxMax[a]; }
+  fc.dist_active = fl.dist_active ? 1 : 0; fc.min_dist = (float)fl.min_dist;
+  fc.rate_active = (fl.rate_active && fl.rate_value >= 1) ? 1 : 0; fc.rate_value = fl.rate_value;
+  fc.time_kind = sensor == SensorType::OUSTER ? 0 : (sensor == SensorType::VELODYNE ? 1 : (sensor == SensorType::HESAI ? 2 : 3));
+  fc.end_of_sweep = config.end_of_sweep ? 1 : 0;
+  fc.sweep_ref_time = start_time;
+  size_t kept = 0;
+  double last_stamp = 0.0;
+  int nan = 0;
+  static_assert(sizeof(PointType) == 32, "PointType layout");
+  if (flimo_raw_scan_filter_set(c, &raw_pc->points[0], n, &fc, &kept, &last_stamp, &nan) != FLIMO_OK || nan) return 0;
+  lazy_order_.clear();
+  arrival_order_ = true;
+  pc2match = fast_limo::make_shared<pcl::PointCloud<PointType>>();      // no host copy was asked for
+  if (kept < 1) return -1;
+  double offset = 0.0;
+  if (config.time_offset) {
+    offset = imu_stamp - last_stamp - 1.e-4;
+    if (offset > 0.0) offset = 0.0;
+  }
+  scan_stamp = last_stamp + offset;
+  States frames;
+  if (!propagatedFromTimeRange(prev_scan_stamp, scan_stamp, frames) || frames.empty()) {
+    std::cout << "FAST_LIMO::propagatedFromTimeRange(): not enough propagated states!\n";
+    return -1;
+  }
+  mtx_ikfom.lock();
+  const StateIkfom xs = ikfom_->get_x();
+  mtx_ikfom.unlock();
+  last_state = State(xs);
+  std::vector<flimo_frame> fr(frames.size());
+  for (size_t i = 0; i < frames.size(); i++) {
+    const State& F = frames[i];
+    flimo_frame& o = fr[i];
+    for (int a = 0; a < 3; a++) { o.p[a] = F.p(a); o.v[a] = F.v(a); o.g[a] = F.g(a); o.w[a] = F.w(a); o.a[a] = F.a(a); o.bg[a] = F.b.gyro(a); o.ba[a] = F.b.accel(a); }
+    o.q[0] = F.q.x(); o.q[1] = F.q.y(); o.q[2] = F.q.z(); o.q[3] = F.q.w();
+    o.time = F.time;
+  }
+  double x26[26];
+  xs.to_flat(x26);
+  rs_frames_.assign(fr.begin(), fr.end());
+  compat::to_row_major(extr.lidar2baselink_T, rs_l2b_);
+  const int rc = flimo_deskew_resident_offset(c, rs_frames_.data(), rs_frames_.size(), rs_l2b_, x26, offset);
+  if (rc != FLIMO_OK) { std::cout << "FAST_LIMO::deskew failed: " << flimo_last_error(c) << "\n"; return -1; }
+  return 1;
+}
+
 // Benchmark entry (inputs resident in HBM): restores the given prior, then GPU deskew of the
 // resident raw scan + the iterated update.  No host filters, no PCIe upload, no map insert.
 int Localizer::registerResident(const double x26_prior[26], const double* P_prior) {
@@ -1098,6 +1162,13 @@ void Localizer::updatePointCloud(pcl::PointCloud<PointType>::Ptr& raw_pc, double
   if (!raw_pc || raw_pc->points.size() < 1) { std::cout << "FAST_LIMO::Raw PointCloud is empty!\n"; last_status_ = -1; return; }
   if (!imu_calibrated_) { last_status_ = -2; return; }
   if (imu_buffer.empty()) { std::cout << "FAST_LIMO::IMU buffer is empty!\n"; last_status_ = -3; return; }
+  const double t0_dev = now_s();
+  const int on_device = deskewOnDevice(raw_pc, time_stamp);            // filters + stamps + deskew on the GPU when nothing needs host clouds
+  if (on_device != 0) {
+    const double t2d = now_s();
+    finishUpdate(on_device > 0, t0_dev, t0_dev, t2d);
+    return;
+  }
   // removeNaNFromPointCloud (:263-265), negative CropBox (:268-271) and the distance / rate / FoV filters (:274-302) in ONE
   // pass over the raw cloud.  As in the reference, *raw_pc itself ends up NaN-free and cropped (both filters write back
   // into it), and the rate filter counts positions in that cropped cloud.
@@ -1165,7 +1236,12 @@ void Localizer::updatePointCloud(pcl::PointCloud<PointType>::Ptr& raw_pc, double
       pc2match = vox;
     }
   }
-  const double t2 = now_s();
+  finishUpdate(ok, t0, t1, now_s());
+}
+
+// Second half of updatePointCloud (Localizer.cpp:323-399): iterated update on the resident scan, state hand-over, path exit
+// (transform + Mapper::add), bookkeeping.  t0 / t1 / t2: entry, end of the host preparation, end of the deskew stage.
+void Localizer::finishUpdate(bool ok, double t0, double t1, double t2) {
   double t3 = t2, t4 = t2;
   flimo_ctx* c = map_->ctx();
   if (ok && c && flimo_scan_size(c) > 1) {
@@ -1209,3 +1285,4 @@ void Localizer::updatePointCloud(pcl::PointCloud<PointType>::Ptr& raw_pc, double
   cpu_mean_time += (cpu_time - cpu_mean_time) / (float)scans_timed_;
   prev_scan_stamp = scan_stamp;
 }
+

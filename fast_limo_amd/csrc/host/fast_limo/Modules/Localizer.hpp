@@ -66,6 +66,7 @@ class fast_limo::Localizer {
   double prof_[4] = {0, 0, 0, 0};
   bool add_to_map = true;               // benchmarks may freeze the map
   bool download_clouds = true;          // keep pc2match / final_scan host copies up to date
+  bool gpu_filters = true;              // input filters + stamps on the GPU when the sweep may stay in arrival order and no host clouds are wanted
   bool lazy_time_order = true;          // the GPU gets the sweep in arrival order whenever the time order is not observable through
                                         // caps / voxel sums (deskewPointCloud); false: always the reference's permutation first
 
@@ -80,6 +81,8 @@ class fast_limo::Localizer {
   IMUmeas imu2baselink(IMUmeas& imu);
   void calibrateStandStill(const IMUmeas& imu);
   pcl::PointCloud<PointType>::Ptr deskewPointCloud(pcl::PointCloud<PointType>::Ptr& pc, double& start_time);   // Localizer.hpp:191
+  int deskewOnDevice(pcl::PointCloud<PointType>::Ptr& raw_pc, double start_time);       // filters + stamps + deskew on the GPU (f-2)
+  void finishUpdate(bool ok, double t0, double t1, double t2);
   bool propagatedFromTimeRange(double start_time, double end_time, States& frames);
   bool imuMeasFromTimeRange(double start_time, double end_time, std::vector<IMUmeas>& meas);   // Localizer.cpp:917-949, oldest first
   bool isInRange(const PointType& p);

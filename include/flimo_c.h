@@ -120,6 +120,27 @@ int flimo_raw_scan_set(flimo_ctx* ctx, const float* xyz, size_t n, size_t stride
 int flimo_deskew_resident(flimo_ctx* ctx, const flimo_frame* frames, size_t n_frames,
                           const float lidar2baselink_T[16], const double last_x26[26]);
 
+/* ---- input filters + stamps of a raw sweep on the GPU: replaces removeNaNFromPointCloud, the negative CropBox and the rate /
+ *      min-distance filters of Localizer::updatePointCloud (Modules/Localizer.cpp:262-302) and the per-point stamp of
+ *      deskewPointCloud (:741-805) for sweeps that may reach the GPU in arrival order.  points32: n records in the reference's
+ *      32-byte PointType layout (Common.hpp:100-113), host memory.  The kept points (order preserved) become the resident raw
+ *      scan; *n_kept their number; *last_stamp = stamp (without the sweep offset) of the point the reference's time sort puts
+ *      last; *nan_stamp = 1 when a kept stamp is NaN (the caller then takes the host path).  The FoV filter (atan2) is not
+ *      offered here: its rounding is the host libm's.  Follow with flimo_deskew_resident_offset. ---- */
+typedef struct flimo_filter_cfg {
+  int crop_active;  float crop_min[3], crop_max[3];
+  int dist_active;  float min_dist;
+  int rate_active;  int rate_value;
+  int time_kind;    /* 0 OUSTER (uint32 t, ns), 1 VELODYNE (float time, s), 2 HESAI (double timestamp, s), 3 LIVOX (double, ns) */
+  int end_of_sweep;
+  double sweep_ref_time;
+} flimo_filter_cfg;
+int flimo_raw_scan_filter_set(flimo_ctx* ctx, const void* points32, size_t n, const flimo_filter_cfg* cfg, size_t* n_kept,
+                              double* last_stamp, int* nan_stamp);
+/* flimo_deskew_resident with the sweep's time offset added to every resident stamp (Localizer.cpp:795-800) */
+int flimo_deskew_resident_offset(flimo_ctx* ctx, const flimo_frame* frames, size_t n_frames, const float lidar2baselink_T[16],
+                                 const double last_x26[26], double t_offset);
+
 /* ---- one measurement pass: replaces IKFoM::h_share_model (IKFoM/use-ikfom.cpp:10-31) =
  *      Mapper::match (Modules/Mapper.cpp:59-86) + Localizer::calculate_H
  *      (Modules/Localizer.cpp:537-577) + the h_x^T h_x / h_x^T h products of

@@ -55,6 +55,9 @@ void   flimo_loc_set_async_insert(flimo_loc* L, int on);              /* default
  * observable by the registration; the GPU then gets the sweep in arrival order and the permutation is only computed for the
  * clouds handed back to the caller (set_flags download_clouds), while the GPU works.  off: always sort first. */
 void   flimo_loc_set_lazy_time_order(flimo_loc* L, int on);
+/* default on: NaN removal, crop box, rate and min-distance filters and the per-point stamps run on the GPU
+ * (flimo_raw_scan_filter_set) whenever the arrival-order path applies and no host copies of the clouds are requested */
+void   flimo_loc_set_gpu_filters(flimo_loc* L, int on);
 double flimo_loc_last_insert_seconds(flimo_loc* L);                   /* duration of the last insert (waits for it) */
 int    flimo_loc_update_imu(flimo_loc* L, double stamp, const float ang_vel[3], const float lin_accel[3]);
 /* pts5: n x (x y z intensity time[s since sweep reference]).  Returns Localizer status:

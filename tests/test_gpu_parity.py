@@ -403,6 +403,72 @@ def test_sensor_time_formats_and_input_filters_match_oracle(built, oracle, senso
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("sensor,eos", [("OUSTER", False), ("OUSTER", True), ("VELODYNE", False), ("VELODYNE", True),
+                                        ("HESAI", False), ("LIVOX", False)])
+def test_gpu_input_filters_and_stamps_match_oracle(built, oracle, sensor, eos):
+    """The pre-update pipeline on the GPU (flimo_raw_scan_filter_set): NaN removal, negative crop box,
+    every-n-th survivor, min distance and the per-sensor point stamps, for a sweep that stays in arrival order (no host clouds
+    requested).  The deskewed resident scan must be the oracle's pc2match as a set of points (bit for bit where the body does
+    not turn, 2e-6 m with rotation: device sinf / cosf), with the same count; the host-filter path of the product must give the
+    identical resident scan and pose."""
+    from fast_limo_amd import api
+    code = {"OUSTER": 0, "VELODYNE": 1, "HESAI": 2, "LIVOX": 3}[sensor]
+    mp, scan5, imu = cfg1_scene(n_scan=6000)
+    st, w, a = imu
+    w = w + np.float32([0.0, 0.0, 0.3])
+    rs = np.random.RandomState(4)
+    xyz = scan5[:, :3].copy()
+    xyz[::89] = np.nan
+    xyz[1::173] *= np.float32(0.01)
+    rel = np.round(rs.uniform(0.0, 0.1, xyz.shape[0]) * 2000.0) / 2000.0          # ties
+    filt = dict(crop_active=1, dist_active=1, min_dist=1.5, rate_active=1, rate_value=3)
+    res = {}
+    ocfg = oracle.default_cfg(sensor_type=code, end_of_sweep=int(eos), crop_min=(-0.5, -0.5, -0.5), crop_max=(0.5, 0.5, 0.5),
+                              num_threads=1, **filt, **CAPS)
+    Lo = oracle.Localizer(ocfg)
+    Lo.map_add(mp)
+    for label, gpu_filters in (("device", True), ("host", False)):
+        G = api.Localizer(api.default_cfg(sensor_type=code, end_of_sweep=int(eos), cropBoxMin=(-0.5, -0.5, -0.5),
+                                          cropBoxMax=(0.5, 0.5, 0.5), **filt, **CAPS))
+        G.set_flags(add_to_map=True, download_clouds=False)
+        G.set_gpu_filters(gpu_filters)
+        G.map_add(mp)
+        i = 0
+        for until, start in ((0.105, 0.0), (0.205, 0.1)):
+            while i < len(st) and st[i] <= until:
+                G.update_imu(st[i], w[i], a[i])
+                if label == "device":
+                    Lo.update_imu(st[i], w[i], a[i])
+                i += 1
+            stamp = start + (0.1 if eos else 0.0)
+            if sensor == "OUSTER":
+                pts = oracle.make_points(xyz, 1.0, t_ns=np.round(((0.1 - rel) if eos else rel) * 1e9).astype(np.uint32))
+            elif sensor == "VELODYNE":
+                pts = oracle.make_points(xyz, 1.0, time_s=((0.1 - rel) if eos else rel).astype(np.float32))
+            elif sensor == "HESAI":
+                pts = oracle.make_points(xyz, 1.0, timestamp=start + rel)
+            else:
+                pts = oracle.make_points(xyz, 1.0, timestamp=(start + rel) * 1e9)
+            rg = G.update_pointcloud_points(pts, stamp)
+            if label == "device":
+                ro = Lo.update_pointcloud_points(pts, stamp)
+                assert rg == ro, (sensor, eos, rg, ro)
+        assert rg == 0
+        G.sync()
+        res[label] = (G.hip.scan_get(), G.get_x(), G.map_size())
+        G.close()
+    po = Lo.pc2match()
+    dev, hst = res["device"], res["host"]
+    assert dev[0].shape == po.shape and 800 < po.shape[0] < 2600
+    np.testing.assert_allclose(sort_rows(dev[0]), sort_rows(po), rtol=0, atol=2e-6)       # same kept points, same stamps
+    np.testing.assert_array_equal(dev[0], hst[0])                                        # device filters == host filters, same order
+    np.testing.assert_array_equal(dev[1], hst[1])
+    assert dev[2] == hst[2] == Lo.map_size()
+    dpos, ang = pose_delta(dev[1], Lo.get_x())
+    assert dpos < 1e-4 and ang < 1e-4, (sensor, eos, dpos, ang)
+
+
+@pytest.mark.gpu
 def test_previous_pass_bound_prunes_exactly(built, oracle):
     """The k-NN fast path skips cells beyond (sqrt(d5 of the previous pass) + displacement); this must never change a
     result.  A context with the bound on and one with it off (FLIMO_PRUNE=0) walk the same pose sequence -- tiny steps
