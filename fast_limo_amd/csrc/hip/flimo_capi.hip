@@ -133,6 +133,9 @@ struct flimo_ctx {
   int tail_pass1 = -1;             // FLIMO_TAIL_PASS1: 1 = the first pass of a scan always uses the in-kernel tail, 0 = never, default: by the straggler count of the last first pass
   int stragglers_pass1 = 1 << 30;  // queries of the last first pass of a scan that needed more than their 3x3x3 block (unknown: many)
   int last_stragglers = -1;        // the same of the last pass (-1: not reported by that pass's path)
+  bool force_general_k = false;    // FLIMO_GENERAL_K=1: NUM_MATCH_POINTS == 5 also takes the general (any-k) pass (A/B checks)
+  void* d_nbrk = nullptr;          // neighbour records of the general pass
+  size_t nbrk_cap = 0;
   bool tail = true;                // FLIMO_TAIL=0: pending queries go to the worklist + widen_kernel dispatch instead of being finished inside the k-NN launch (A/B checks)
 };
 
@@ -296,6 +299,8 @@ extern "C" int flimo_ctx_create(int device, flimo_ctx** out) {
   c->book = insert_book_create();
   e = getenv("FLIMO_PRUNE");
   if (e) c->prune = atoi(e) != 0;
+  e = getenv("FLIMO_GENERAL_K");
+  c->force_general_k = e && atoi(e) != 0;
   e = getenv("FLIMO_TAIL_PASS1");
   if (e) c->tail_pass1 = atoi(e) != 0;
   e = getenv("FLIMO_FUSE");
@@ -325,7 +330,7 @@ extern "C" void flimo_ctx_destroy(flimo_ctx* c) {
   (void)hipFree(c->d_fit_partials); (void)hipFree(c->d_raw_sorted); (void)hipFree(c->d_t_sorted);
   (void)hipFree(c->d_scan); (void)hipFree(c->d_scan_raw); (void)hipFree(c->d_scan_world); (void)hipFree(c->d_scan_t);
   (void)hipFree(c->d_frames); (void)hipFree(c->d_recs); (void)hipFree(c->d_dbg);
-  (void)hipFree(c->d_raw32); (void)hipFree(c->d_filt_ext);
+  (void)hipFree(c->d_raw32); (void)hipFree(c->d_filt_ext); (void)hipFree(c->d_nbrk);
   if (c->h_filt_ext) (void)hipHostFree(c->h_filt_ext);
   (void)hipFree(c->d_partials); (void)hipFree(c->d_out256); (void)hipFree(c->d_cand); (void)hipFree(c->d_ticket);
   if (c->h_out256) (void)hipHostFree(c->h_out256);
@@ -1032,7 +1037,9 @@ static int gate_rings(const flimo_ctx* c, double max_dist_plane) {
 extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flimo_match_cfg* cfg, double HTH[144],
                                   double HTh[12], int* M) {
   if (!c || !x26 || !cfg || !HTH || !HTh || !M) return FLIMO_ERR_INVALID;
-  if (cfg->NUM_MATCH_POINTS != 5) return fail(c, FLIMO_ERR_UNSUPPORTED, "only NUM_MATCH_POINTS == 5 is supported");
+  if (cfg->NUM_MATCH_POINTS < 3 || cfg->NUM_MATCH_POINTS > 8)
+    return fail(c, FLIMO_ERR_UNSUPPORTED, "NUM_MATCH_POINTS must be in 3..8 (a plane needs 3 points; the neighbour records hold 8)");
+  const bool general_k = cfg->NUM_MATCH_POINTS != 5 || c->force_general_k;
   for (int i = 0; i < 144; i++) HTH[i] = 0.0;
   for (int i = 0; i < 12; i++) HTh[i] = 0.0;
   *M = 0;
@@ -1070,6 +1077,35 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   }
   const int n_all = (int)c->sorted_n;                 // resident query set (== nq, or the whole scan when no cap binds)
   const bool cap_binds = cfg->MAX_NUM_MATCHES >= 0 && (size_t)cfg->MAX_NUM_MATCHES < nq;
+  if (general_k) {
+    // any NUM_MATCH_POINTS: exact k-NN by the ring search, M x 3 plane fit, records, record reduction (slow, general pass)
+    if ((size_t)n_all > c->nbrk_cap) {
+      (void)hipFree(c->d_nbrk);
+      c->d_nbrk = nullptr; c->nbrk_cap = 0;
+      const size_t cap = (size_t)n_all + (size_t)n_all / 4 + 1024;
+      HIPCHK(c, hipMalloc(&c->d_nbrk, cap * nbrk_rec_size()));
+      c->nbrk_cap = cap;
+    }
+    c->prev.valid = 0;                                 // the 5-NN records of this scan (pruning bound) are not maintained here
+    if (!launch_match_k(c->stream, cfg->NUM_MATCH_POINTS, c->grid, c->d_scan_sorted, n_all, P, mp, c->d_nbrk, c->d_recs, c->d_dbg))
+      return fail(c, FLIMO_ERR_UNSUPPORTED, "NUM_MATCH_POINTS out of range");
+    if (cap_binds) launch_cap(c->stream, c->d_recs, (int)nq, cfg->MAX_NUM_MATCHES);
+    launch_reduce(c->stream, c->d_recs, (int)nq, c->reduce_waves, c->d_partials, c->d_out256_host);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    ++c->pass_seq;
+    for (int i = 0; i < 12; i++) {
+      for (int j = 0; j < 12; j++) HTH[i * 12 + j] = c->h_out256[c->mfma_idx[i][j]];
+      HTh[i] = c->h_out256[c->mfma_idx[i][12]];
+    }
+    *M = (int)llround(c->h_out256[c->mfma_idx[13][13]]);
+    c->last_nq = (int)nq;
+    c->last_P = P; c->last_mp = mp; c->last_n_all = n_all;
+    c->recs_valid = true; c->dbg_valid = true;
+    c->last_stragglers = -1;
+    c->async_deskews = 0;
+    return FLIMO_OK;
+  }
   const bool want_recs = c->debug_recs || cap_binds;
   if (c->debug_recs) HIPCHK(c, hipMemsetAsync(c->d_cand, 0, sizeof(unsigned long long), c->stream));
   const bool want_count = c->debug_recs;

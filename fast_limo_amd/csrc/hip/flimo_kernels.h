@@ -41,6 +41,11 @@ void launch_match_fused(hipStream_t st, const GridView& G, const float4* scan_so
                         void* nbr, int* wl, int* wl_count, unsigned long long* cand, const PrevPass& prev,
                         const unsigned char* live_idx, double* partials, void* out_granules, unsigned int* ticket,
                         unsigned long long seq, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+// General NUM_MATCH_POINTS (3..8): exact k-NN by the ring search + M x 3 plane fit, records written at the original indices
+// (reduce them with launch_cap / launch_reduce).  nbrk: n * nbrk_rec_size() bytes of scratch.  false: k out of range.
+size_t nbrk_rec_size();
+bool launch_match_k(hipStream_t st, int k, const GridView& G, const float4* scan_sorted, int n, const PoseMats& P,
+                    const MatchParams& mp, void* nbrk, Rec16* recs, RecDbg* dbg);
 void launch_reduce_final(hipStream_t st, const double* partials, int nparts, double* out256);
 size_t nbr_rec_size();
 size_t wl_entry_size();   // bytes per worklist entry (query index, world position, 5th-distance hint)

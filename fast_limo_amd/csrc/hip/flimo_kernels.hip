@@ -34,12 +34,13 @@ namespace flimo {
 // ------------------------------------------------------------------------------------------
 FLIMO_DEV bool pair_less(float d0, int i0, float d1, int i1) { return (d0 < d1) || (d0 == d1 && i0 < i1); }
 
-FLIMO_DEV void top5_insert(float (&bd)[5], int (&bi)[5], float d, int id) {
-  if (!pair_less(d, id, bd[4], bi[4])) return;
-  bd[4] = d;
-  bi[4] = id;
+template <int K>
+FLIMO_DEV void topk_insert(float (&bd)[K], int (&bi)[K], float d, int id) {
+  if (!pair_less(d, id, bd[K - 1], bi[K - 1])) return;
+  bd[K - 1] = d;
+  bi[K - 1] = id;
 #pragma unroll
-  for (int s = 4; s > 0; s--) {
+  for (int s = K - 1; s > 0; s--) {
     const bool sw = pair_less(bd[s], bi[s], bd[s - 1], bi[s - 1]);
     const float td = bd[s - 1];
     const int ti = bi[s - 1];
@@ -51,9 +52,9 @@ FLIMO_DEV void top5_insert(float (&bd)[5], int (&bi)[5], float d, int id) {
 }
 
 // examine the points of one contiguous range with the L lanes of the query group
-template <int L>
+template <int L, int K>
 FLIMO_DEV void scan_range(const float4* __restrict__ pts, uint32_t lo, uint32_t hi, int sub, float gx, float gy,
-                          float gz, float (&bd)[5], int (&bi)[5], int& cand) {
+                          float gz, float (&bd)[K], int (&bi)[K], int& cand) {
   uint32_t j = lo + (uint32_t)sub;
   // two loads in flight per lane
   for (; j + L < hi; j += 2 * L) {
@@ -61,32 +62,32 @@ FLIMO_DEV void scan_range(const float4* __restrict__ pts, uint32_t lo, uint32_t 
     const float4 p1 = pts[j + L];
     const float d0 = sqdist3(gx, gy, gz, p0.x, p0.y, p0.z);
     const float d1 = sqdist3(gx, gy, gz, p1.x, p1.y, p1.z);
-    top5_insert(bd, bi, d0, (int)j);
-    top5_insert(bd, bi, d1, (int)(j + L));
+    topk_insert<K>(bd, bi, d0, (int)j);
+    topk_insert<K>(bd, bi, d1, (int)(j + L));
     cand += 2;
   }
   if (j < hi) {
     const float4 p0 = pts[j];
     const float d0 = sqdist3(gx, gy, gz, p0.x, p0.y, p0.z);
-    top5_insert(bd, bi, d0, (int)j);
+    topk_insert<K>(bd, bi, d0, (int)j);
     cand += 1;
   }
 }
 
 // merge the private lists of the L lanes of a group; afterwards every lane holds the merged list
-template <int L>
-FLIMO_DEV void merge_group(float (&bd)[5], int (&bi)[5]) {
+template <int L, int K>
+FLIMO_DEV void merge_group(float (&bd)[K], int (&bi)[K]) {
 #pragma unroll
   for (int off = 1; off < L; off <<= 1) {
-    float od[5];
-    int oi[5];
+    float od[K];
+    int oi[K];
 #pragma unroll
-    for (int s = 0; s < 5; s++) {
+    for (int s = 0; s < K; s++) {
       od[s] = __shfl_xor(bd[s], off, 64);
       oi[s] = __shfl_xor(bi[s], off, 64);
     }
 #pragma unroll
-    for (int s = 0; s < 5; s++) top5_insert(bd, bi, od[s], oi[s]);
+    for (int s = 0; s < K; s++) topk_insert<K>(bd, bi, od[s], oi[s]);
   }
 }
 
@@ -96,44 +97,46 @@ FLIMO_DEV float slab_dist(int d, float r) {
   return d == 0 ? 0.f : (d > 0 ? ((float)d - r) : (r + (float)(-d - 1)));
 }
 
-struct KnnResult {
-  float bd[5];
-  int bi[5];
+template <int K = 5>
+struct KnnResultK {
+  float bd[K];
+  int bi[K];
   int cand;      // candidates examined by this lane
-  bool exact;    // the 5 entries are provably the exact 5-NN
+  bool exact;    // the K entries are provably the exact K-NN
 };
+typedef KnnResultK<5> KnnResult;
 
 // visit one row (fixed dy,dz) of the shell (r_prev, r] around cell (cx,cy,cz)
-template <int L>
+template <int L, int K>
 FLIMO_DEV void visit_row(const GridView& G, int cx, int cy, int cz, int dy, int dz, int r_prev, int r, float rx,
                          float ry, float rz, float margin, float cell2, float bound, int sub, float gx, float gy,
-                         float gz, KnnResult& R) {
+                         float gz, KnnResultK<K>& R) {
   const float a = fmaxf(slab_dist(dy, ry) - margin, 0.f), b = fmaxf(slab_dist(dz, rz) - margin, 0.f);
   const float yz2 = a * a + b * b;
-  if (yz2 * cell2 >= fminf(bound, R.bd[4])) return;   // the whole row is farther than the current 5th best
+  if (yz2 * cell2 >= fminf(bound, R.bd[K - 1])) return;   // the whole row is farther than the current 5th best
   const size_t rowbase = ((size_t)(cz + dz) * (size_t)G.ny + (size_t)(cy + dy)) * (size_t)G.nx;
   if (max(abs(dy), abs(dz)) > r_prev) {
     const int x0 = max(cx - r, 0), x1 = min(cx + r, G.nx - 1);
     if (x0 <= x1) {
       const uint32_t lo = G.cell_start[rowbase + x0], hi = G.cell_start[rowbase + x1 + 1];
-      scan_range<L>(G.pts, lo, hi, sub, gx, gy, gz, R.bd, R.bi, R.cand);
+      scan_range<L, K>(G.pts, lo, hi, sub, gx, gy, gz, R.bd, R.bi, R.cand);
     }
   } else {
     // only the cells beyond the block already visited: [cx-r, cx-r_prev-1] and [cx+r_prev+1, cx+r]
     {
       const int x0 = max(cx - r, 0), x1 = min(cx - r_prev - 1, G.nx - 1);
       const float sx = fmaxf(slab_dist(-(r_prev + 1), rx) - margin, 0.f);
-      if (x0 <= x1 && (sx * sx + yz2) * cell2 < fminf(bound, R.bd[4])) {
+      if (x0 <= x1 && (sx * sx + yz2) * cell2 < fminf(bound, R.bd[K - 1])) {
         const uint32_t lo = G.cell_start[rowbase + x0], hi = G.cell_start[rowbase + x1 + 1];
-        scan_range<L>(G.pts, lo, hi, sub, gx, gy, gz, R.bd, R.bi, R.cand);
+        scan_range<L, K>(G.pts, lo, hi, sub, gx, gy, gz, R.bd, R.bi, R.cand);
       }
     }
     {
       const int x0 = max(cx + r_prev + 1, 0), x1 = min(cx + r, G.nx - 1);
       const float sx = fmaxf(slab_dist(r_prev + 1, rx) - margin, 0.f);
-      if (x0 <= x1 && (sx * sx + yz2) * cell2 < fminf(bound, R.bd[4])) {
+      if (x0 <= x1 && (sx * sx + yz2) * cell2 < fminf(bound, R.bd[K - 1])) {
         const uint32_t lo = G.cell_start[rowbase + x0], hi = G.cell_start[rowbase + x1 + 1];
-        scan_range<L>(G.pts, lo, hi, sub, gx, gy, gz, R.bd, R.bi, R.cand);
+        scan_range<L, K>(G.pts, lo, hi, sub, gx, gy, gz, R.bd, R.bi, R.cand);
       }
     }
   }
@@ -142,10 +145,10 @@ FLIMO_DEV void visit_row(const GridView& G, int cx, int cy, int cz, int dy, int 
 // Exact 5-NN of (gx,gy,gz) over the grid; the L lanes of a group cooperate (sub = lane % L).
 // max_ring bounds the widening: if the search stops at max_ring without `exact`, then the true
 // 5th squared distance is >= ((max_ring + edge - margin) * cell)^2 >= (max_ring*cell - margin*cell)^2.
-template <int L>
-FLIMO_DEV void knn_search(const GridView& G, float gx, float gy, float gz, int sub, int max_ring, KnnResult& R) {
+template <int L, int K = 5>
+FLIMO_DEV void knn_search(const GridView& G, float gx, float gy, float gz, int sub, int max_ring, KnnResultK<K>& R) {
 #pragma unroll
-  for (int s = 0; s < 5; s++) { R.bd[s] = FLT_MAX; R.bi[s] = INT_MAX; }
+  for (int s = 0; s < K; s++) { R.bd[s] = FLT_MAX; R.bi[s] = INT_MAX; }
   R.cand = 0;
   R.exact = false;
 
@@ -199,8 +202,8 @@ FLIMO_DEV void knn_search(const GridView& G, float gx, float gy, float gz, int s
         const int dy = (t % 3 == 0) ? 0 : ((t % 3 == 1) ? -1 : 1);
         const int dz = (t / 3 == 0) ? 0 : ((t / 3 == 1) ? -1 : 1);
         const float a = fmaxf(slab_dist(dy, ry) - margin, 0.f), b = fmaxf(slab_dist(dz, rz) - margin, 0.f);
-        if ((a * a + b * b) * cell2 >= R.bd[4]) continue;
-        scan_range<L>(G.pts, lo[t], hi[t], sub, gx, gy, gz, R.bd, R.bi, R.cand);
+        if ((a * a + b * b) * cell2 >= R.bd[K - 1]) continue;
+        scan_range<L, K>(G.pts, lo[t], hi[t], sub, gx, gy, gz, R.bd, R.bi, R.cand);
       }
     } else {
       // ---- shell (r_prev, r] (rare): rows in ascending order, clipped to the grid ----
@@ -208,28 +211,28 @@ FLIMO_DEV void knn_search(const GridView& G, float gx, float gy, float gz, int s
       const int dy0 = max(-r, -cy), dy1 = min(r, G.ny - 1 - cy);
       for (int dz = dz0; dz <= dz1; dz++)
         for (int dy = dy0; dy <= dy1; dy++)
-          visit_row<L>(G, cx, cy, cz, dy, dz, r_prev, r, rx, ry, rz, margin, cell2, bound, sub, gx, gy, gz, R);
+          visit_row<L, K>(G, cx, cy, cz, dy, dz, r_prev, r, rx, ry, rz, margin, cell2, bound, sub, gx, gy, gz, R);
     }
     // ---- merge the group, test exactness ----
-    if (L > 1) merge_group<L>(R.bd, R.bi);
+    if (L > 1) merge_group<L, K>(R.bd, R.bi);
     const float rg = ((float)r + edge - margin) * G.cell;   // every unvisited point is >= rg away
-    const bool have5 = R.bi[4] != INT_MAX;
+    const bool have5 = R.bi[K - 1] != INT_MAX;
     const bool covers = (cx - r <= 0) && (cx + r >= G.nx - 1) && (cy - r <= 0) && (cy + r >= G.ny - 1) &&
                         (cz - r <= 0) && (cz + r >= G.nz - 1);
-    if (covers || (have5 && R.bd[4] <= rg * rg * (1.f - 1.0e-6f))) { R.exact = true; break; }
+    if (covers || (have5 && R.bd[K - 1] <= rg * rg * (1.f - 1.0e-6f))) { R.exact = true; break; }
     if (r >= max_ring) break;
     // next ring: straight to the radius that proves exactness once 5 candidates are known, else double
     int rn = 2 * r;
     if (have5) {
-      bound = R.bd[4];
-      const float need = fl_sqrt(R.bd[4]) * G.inv_cell * (1.f + 4.0e-6f) - edge + margin;
+      bound = R.bd[K - 1];
+      const float need = fl_sqrt(R.bd[K - 1]) * G.inv_cell * (1.f + 4.0e-6f) - edge + margin;
       rn = max(r + 1, (int)ceilf(fminf(need, 1.0e9f)));
     }
     rn = min(rn, max_ring);
     // keep the merged list on lane 0 of the group only (no duplicates at the next merge)
     if (L > 1 && sub != 0) {
 #pragma unroll
-      for (int s = 0; s < 5; s++) { R.bd[s] = FLT_MAX; R.bi[s] = INT_MAX; }
+      for (int s = 0; s < K; s++) { R.bd[s] = FLT_MAX; R.bi[s] = INT_MAX; }
     }
     r_prev = r;
     r = rn;
@@ -1363,6 +1366,121 @@ __global__ __launch_bounds__(256) void fit2_kernel(GridView G, const float4* __r
   TRACE(1, 3);
   fit_reduce_publish<PPW>(v, lane < PPW, lane, s_rec[wave], s_acc[0], s_acc[1], s_acc[2], s_acc[3], &s_last, idx, partials,
                           out_granules, ticket, wl_count, seq);
+}
+
+// ------------------------------------------------------------------------------------------
+// General NUM_MATCH_POINTS (3..8, Mapper.cpp:106-109, Plane.cpp:41-43): the reference's plumbing accepts any k; every shipped
+// configuration uses 5, which the kernels above are specialised for.  Other values take this slower, general pass: exact k-NN
+// by the ring search (4 lanes per query), M x 3 plane fit (plane_fit_m), records at the points' original indices, then the
+// record reduction (cap_kernel / reduce_kernel).
+// ------------------------------------------------------------------------------------------
+struct NbrRecK { int32_t idx[8]; int32_t flag; int32_t pad[3]; };    // 48 bytes per query (sorted order)
+
+template <int K>
+__global__ __launch_bounds__(256) void knnk_kernel(GridView G, const float4* __restrict__ scan_sorted, int n, PoseMats P,
+                                                   int max_ring, NbrRecK* __restrict__ out) {
+  constexpr int L = 4;
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int p = tid / L, sub = tid % L;
+  if (p >= n) return;                       // the four lanes of a query leave together
+  const float4 sp = scan_sorted[p];
+  float gx, gy, gz;
+  xform4(P.RT, sp.x, sp.y, sp.z, gx, gy, gz);
+  KnnResultK<K> R;
+  knn_search<L, K>(G, gx, gy, gz, sub, max_ring, R);
+  if (sub == 0) {
+    NbrRecK o;
+#pragma unroll
+    for (int s = 0; s < 8; s++) o.idx[s] = s < K ? R.bi[s] : -1;
+    o.flag = (R.exact && R.bi[K - 1] != INT_MAX) ? 1 : 0;
+    o.pad[0] = o.pad[1] = o.pad[2] = 0;
+    out[p] = o;
+  }
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void fitk_kernel(GridView G, const float4* __restrict__ scan_sorted, int n,
+                                                   const NbrRecK* __restrict__ nbr, PoseMats P, MatchParams mp,
+                                                   Rec16* __restrict__ recs, RecDbg* __restrict__ dbg) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const float4 sp = scan_sorted[p];
+  const uint32_t orig = __float_as_uint(sp.w);
+  if (orig >= (uint32_t)mp.n_queries) return;
+  float gx, gy, gz;
+  xform4(P.RT, sp.x, sp.y, sp.z, gx, gy, gz);
+  const NbrRecK nb = nbr[p];
+  float v[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) v[i] = 0.f;
+  float n4[4] = {0.f, 0.f, 0.f, 0.f};
+  float px[K], py[K], pz[K], sq[K];
+  bool valid = nb.flag == 1;
+  if (valid) {
+#pragma unroll
+    for (int s = 0; s < K; s++) {
+      const float4 q = G.pts[nb.idx[s]];
+      px[s] = q.x; py[s] = q.y; pz[s] = q.z;
+      sq[s] = sqdist3(gx, gy, gz, q.x, q.y, q.z);
+    }
+    valid = (double)sq[K - 1] < mp.max_dist_plane_d;
+    if (valid) {
+      plane_fit_m<K>(px, py, pz, n4);
+      valid = plane_eval_m<K>(n4, px, py, pz, mp.plane_threshold);
+    }
+    if (valid) {
+      const float dist = n4[0] * gx + n4[1] * gy + n4[2] * gz + n4[3];
+      float row[12];
+      h_row(P, gx, gy, gz, n4, mp.estimate_extrinsics, row);
+#pragma unroll
+      for (int i = 0; i < 12; i++) v[i] = row[i];
+      v[12] = -dist;
+      v[13] = 1.f;
+    }
+  }
+  float4* o = reinterpret_cast<float4*>(&recs[orig]);
+  o[0] = make_float4(v[0], v[1], v[2], v[3]);
+  o[1] = make_float4(v[4], v[5], v[6], v[7]);
+  o[2] = make_float4(v[8], v[9], v[10], v[11]);
+  o[3] = make_float4(v[12], v[13], 0.f, 0.f);
+  if (dbg) {
+    RecDbg d;
+#pragma unroll
+    for (int i = 0; i < 4; i++) d.n[i] = valid ? n4[i] : 0.f;
+    d.p_global[0] = gx; d.p_global[1] = gy; d.p_global[2] = gz;
+    const bool has = nb.flag == 1;
+#pragma unroll
+    for (int s = 0; s < 5; s++) {            // the debug record shows the first five neighbours
+      d.sqd[s] = (has && s < K) ? sq[s < K ? s : 0] : 0.f;
+      d.nbr[s] = (has && s < K) ? nb.idx[s] : -1;
+    }
+    d.n_nbr = has ? K : 0;
+    d.cand = 0;
+    d.pad = 0;
+    dbg[orig] = d;
+  }
+}
+
+size_t nbrk_rec_size() { return sizeof(NbrRecK); }
+template <int K>
+static void launch_match_k_K(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const PoseMats& P,
+                             const MatchParams& mp, void* nbrk, Rec16* recs, RecDbg* dbg) {
+  const long long threads = (long long)n * 4;
+  hipLaunchKernelGGL((knnk_kernel<K>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, G, scan_sorted, n, P, mp.max_ring, (NbrRecK*)nbrk);
+  hipLaunchKernelGGL((fitk_kernel<K>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, G, scan_sorted, n, (const NbrRecK*)nbrk, P, mp, recs, dbg);
+}
+bool launch_match_k(hipStream_t st, int k, const GridView& G, const float4* scan_sorted, int n, const PoseMats& P,
+                    const MatchParams& mp, void* nbrk, Rec16* recs, RecDbg* dbg) {
+  if (n <= 0) return true;
+  switch (k) {
+    case 3: launch_match_k_K<3>(st, G, scan_sorted, n, P, mp, nbrk, recs, dbg); return true;
+    case 4: launch_match_k_K<4>(st, G, scan_sorted, n, P, mp, nbrk, recs, dbg); return true;
+    case 5: launch_match_k_K<5>(st, G, scan_sorted, n, P, mp, nbrk, recs, dbg); return true;
+    case 6: launch_match_k_K<6>(st, G, scan_sorted, n, P, mp, nbrk, recs, dbg); return true;
+    case 7: launch_match_k_K<7>(st, G, scan_sorted, n, P, mp, nbrk, recs, dbg); return true;
+    case 8: launch_match_k_K<8>(st, G, scan_sorted, n, P, mp, nbrk, recs, dbg); return true;
+    default: return false;
+  }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -207,6 +207,171 @@ FLIMO_DEV void plane_fit5(const float (&px)[5], const float (&py)[5], const floa
   n[3] = fl_div(1.0f, nn);   // (float)(1.0 / n): double rounding is innocuous for division
 }
 
+// The same for M neighbours (NUM_MATCH_POINTS 3..8, Mapper.cpp:106-109, Plane.cpp:41-43,80-105): Eigen's
+// ColPivHouseholderQR::computeInPlace + solve on an M x 3 matrix, including the 1-row block at the last step of M = 3
+// (makeHouseholder with an empty tail, applyHouseholderOnTheLeft on a single row).  The hot path keeps its unrolled 5 x 3 form.
+template <int M>
+FLIMO_DEV void plane_fit_m(const float (&px)[M], const float (&py)[M], const float (&pz)[M], float (&n)[4]) {
+  static_assert(M >= 3 && M <= 8, "3..8 neighbours");
+  float a[3][M];  // a[col][row]
+#pragma unroll
+  for (int i = 0; i < M; i++) { a[0][i] = px[i]; a[1][i] = py[i]; a[2][i] = pz[i]; }
+  float nU[3], nD[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < M; i++) s = s + a[k][i] * a[k][i];
+    nD[k] = fl_sqrt(s);
+    nU[k] = nD[k];
+  }
+  const float eps = 1.1920929e-07f;
+  float maxn = nU[0];
+  if (nU[1] > maxn) maxn = nU[1];
+  if (nU[2] > maxn) maxn = nU[2];
+  const float th = maxn * eps;
+  const float threshold_helper = fl_div(th * th, (float)M);
+  const float downdate_thr = fl_sqrt(eps);
+  int nzp = 3;
+  int perm0 = 0, perm1 = 1, perm2 = 2;
+  float hC[3];
+
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    int big = k;
+    float bign = nU[k];
+#pragma unroll
+    for (int j = k + 1; j < 3; j++)
+      if (nU[j] > bign) { bign = nU[j]; big = j; }
+    const float big_sq = bign * bign;
+    if (nzp == 3 && big_sq < threshold_helper * float(M - k)) nzp = k;
+#pragma unroll
+    for (int j = k + 1; j < 3; j++) {
+      const bool sw = (big == j);
+#pragma unroll
+      for (int i = 0; i < M; i++) { float t0 = a[k][i], t1 = a[j][i]; a[k][i] = sw ? t1 : t0; a[j][i] = sw ? t0 : t1; }
+      { float t0 = nU[k], t1 = nU[j]; nU[k] = sw ? t1 : t0; nU[j] = sw ? t0 : t1; }
+      { float t0 = nD[k], t1 = nD[j]; nD[k] = sw ? t1 : t0; nD[j] = sw ? t0 : t1; }
+      if (k == 0) {
+        if (j == 1) { int t0 = perm0, t1 = perm1; perm0 = sw ? t1 : t0; perm1 = sw ? t0 : t1; }
+        if (j == 2) { int t0 = perm0, t1 = perm2; perm0 = sw ? t1 : t0; perm2 = sw ? t0 : t1; }
+      } else if (k == 1) {
+        if (j == 2) { int t0 = perm1, t1 = perm2; perm1 = sw ? t1 : t0; perm2 = sw ? t0 : t1; }
+      }
+    }
+    float tailSq = 0.f;
+#pragma unroll
+    for (int i = k + 1; i < M; i++) tailSq = tailSq + a[k][i] * a[k][i];
+    const float c0 = a[k][k];
+    float tau, beta;
+    const float tol = 1.17549435e-38f;
+    const bool one_row = (M - k) == 1;
+    if (one_row || tailSq <= tol) {
+      tau = 0.f;
+      beta = c0;
+#pragma unroll
+      for (int i = k + 1; i < M; i++) a[k][i] = 0.f;
+    } else {
+      beta = fl_sqrt(c0 * c0 + tailSq);
+      if (c0 >= 0.f) beta = -beta;
+      const float denom = c0 - beta;
+#pragma unroll
+      for (int i = k + 1; i < M; i++) a[k][i] = fl_div(a[k][i], denom);
+      tau = fl_div(beta - c0, beta);
+    }
+    hC[k] = tau;
+    a[k][k] = beta;
+    if (one_row) {
+#pragma unroll
+      for (int j = k + 1; j < 3; j++) a[j][k] = a[j][k] * (1.f - tau);
+    } else if (tau != 0.f) {
+#pragma unroll
+      for (int j = k + 1; j < 3; j++) {
+        float tmp = 0.f;
+#pragma unroll
+        for (int i = k + 1; i < M; i++) tmp = tmp + a[k][i] * a[j][i];
+        tmp = tmp + a[j][k];
+        a[j][k] = a[j][k] - tau * tmp;
+#pragma unroll
+        for (int i = k + 1; i < M; i++) a[j][i] = a[j][i] - (tau * a[k][i]) * tmp;
+      }
+    }
+#pragma unroll
+    for (int j = k + 1; j < 3; j++) {
+      if (nU[j] != 0.f) {
+        float temp = fl_div(fabsf(a[j][k]), nU[j]);
+        temp = (1.f + temp) * (1.f - temp);
+        temp = temp < 0.f ? 0.f : temp;
+        const float ratio = fl_div(nU[j], nD[j]);
+        const float temp2 = temp * (ratio * ratio);
+        if (temp2 <= downdate_thr) {
+          float s = 0.f;
+#pragma unroll
+          for (int i = k + 1; i < M; i++) s = s + a[j][i] * a[j][i];
+          nD[j] = fl_sqrt(s);
+          nU[j] = nD[j];
+        } else {
+          nU[j] = nU[j] * fl_sqrt(temp);
+        }
+      }
+    }
+  }
+
+  float c[M];
+#pragma unroll
+  for (int i = 0; i < M; i++) c[i] = -1.f;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const float tau = hC[k];
+    if (k < nzp) {
+      if ((M - k) == 1) {
+        c[k] = c[k] * (1.f - tau);
+      } else if (tau != 0.f) {
+        float tmp = 0.f;
+#pragma unroll
+        for (int i = k + 1; i < M; i++) tmp = tmp + a[k][i] * c[i];
+        tmp = tmp + c[k];
+        c[k] = c[k] - tau * tmp;
+#pragma unroll
+        for (int i = k + 1; i < M; i++) c[i] = c[i] - (tau * a[k][i]) * tmp;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 2; i >= 0; i--) {
+    if (i < nzp) {
+      float s = c[i];
+#pragma unroll
+      for (int j = i + 1; j < 3; j++)
+        if (j < nzp) s = s - a[j][i] * c[j];
+      c[i] = fl_div(s, a[i][i]);
+    }
+  }
+  const float y0 = (0 < nzp) ? c[0] : 0.f;
+  const float y1 = (1 < nzp) ? c[1] : 0.f;
+  const float y2 = (2 < nzp) ? c[2] : 0.f;
+  float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+  x0 = (perm0 == 0) ? y0 : x0; x1 = (perm0 == 1) ? y0 : x1; x2 = (perm0 == 2) ? y0 : x2;
+  x0 = (perm1 == 0) ? y1 : x0; x1 = (perm1 == 1) ? y1 : x1; x2 = (perm1 == 2) ? y1 : x2;
+  x0 = (perm2 == 0) ? y2 : x0; x1 = (perm2 == 1) ? y2 : x1; x2 = (perm2 == 2) ? y2 : x2;
+  const float nn = fl_sqrt(sum3(x0 * x0, x1 * x1, x2 * x2));
+  n[0] = fl_div(x0, nn);
+  n[1] = fl_div(x1, nn);
+  n[2] = fl_div(x2, nn);
+  n[3] = fl_div(1.0f, nn);
+}
+
+template <int M>
+FLIMO_DEV bool plane_eval_m(const float (&n)[4], const float (&px)[M], const float (&py)[M], const float (&pz)[M], float thres) {
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < M; j++) {
+    const float res = n[0] * px[j] + n[1] * py[j] + n[2] * pz[j] + n[3];
+    ok = ok && !(fabsf(res) > thres);
+  }
+  return ok;
+}
+
 // Plane::plane_eval (Objects/Plane.cpp:107-114)
 FLIMO_DEV bool plane_eval5(const float (&n)[4], const float (&px)[5], const float (&py)[5], const float (&pz)[5],
                            float thres) {

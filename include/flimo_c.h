@@ -45,7 +45,7 @@ typedef struct flimo_map_cfg {
 
 /* Config::iKFoM::Mapping (Utils/Config.hpp:58-63) + ikfom.estimate_extrinsics */
 typedef struct flimo_match_cfg {
-  int NUM_MATCH_POINTS;    /* k; only 5 is supported by the fused kernels */
+  int NUM_MATCH_POINTS;    /* k in 3..8; 5 (every shipped configuration) runs the specialised kernels, other values a general pass */
   int MAX_NUM_MATCHES;     /* Modules/Localizer.cpp:539 */
   int MAX_NUM_PC2MATCH;    /* Modules/Mapper.cpp:63 */
   double MAX_DIST_PLANE;   /* Objects/Plane.cpp:47 (compared with a SQUARED distance) */

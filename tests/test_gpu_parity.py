@@ -128,6 +128,47 @@ def test_match_records_bit_exact(hip, scene, oracle, lpq):
     hip.set_lanes_per_query(16)
 
 
+@pytest.mark.parametrize("k", [3, 4, 6, 8])
+def test_general_num_match_points(hip, scene, oracle, k):
+    """NUM_MATCH_POINTS other than 5 (Mapper.cpp:106-109, Plane.cpp:41-43): the general pass (exact k-NN by the ring search,
+    k x 3 column-pivoted QR) against the oracle: same valid set, plane normals / residuals / H rows bit for bit."""
+    from fast_limo_amd import _lib
+    x0 = oracle.identity_x26()
+    x0[0:3] = [0.05, -0.03, 0.01]
+    x0[3:7] = [0.001, -0.002, 0.003, 1.0]; x0[3:7] /= np.linalg.norm(x0[3:7])
+    ocfg = oracle.default_cfg(num_threads=1, NUM_MATCH_POINTS=k, **CAPS)
+    recs, H, h, ev = oracle.match_H(scene["oc"], ocfg, x0, scene["scan"])
+    hip.scan_set(scene["scan"])
+    HTH, HTh, M = hip.match_reduce(x0, _lib.default_match_cfg(NUM_MATCH_POINTS=k, **CAPS))
+    g = hip.match_fetch()
+    vg, vo = g["valid"] > 0, recs["is_plane"] > 0
+    np.testing.assert_array_equal(vg, vo)
+    assert M == H.shape[0] == int(vg.sum()) and M > 2000
+    np.testing.assert_array_equal(g["n"][vg], recs["n"][vg])
+    np.testing.assert_array_equal(-g["h"][vg], recs["dist"][vg])
+    m = min(k, 5)
+    np.testing.assert_array_equal(g["sqd"][vg][:, :m], recs["sqd"][vg][:, :m])
+    np.testing.assert_array_equal(g["H"][vg].astype(np.float64), H)
+    np.testing.assert_allclose(HTH, H.T @ H, rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose(HTh, H.T @ h, rtol=1e-12, atol=1e-9)
+    # and a MAX_NUM_MATCHES cap on top of it (first `cap` valid matches in scan order)
+    cap = 500
+    ocfg2 = oracle.default_cfg(num_threads=1, NUM_MATCH_POINTS=k, MAX_NUM_PC2MATCH=10**7, MAX_NUM_MATCHES=cap)
+    _, H2, h2, _ = oracle.match_H(scene["oc"], ocfg2, x0, scene["scan"])
+    HTH2, HTh2, M2 = hip.match_reduce(x0, _lib.default_match_cfg(NUM_MATCH_POINTS=k, MAX_NUM_PC2MATCH=10**7, MAX_NUM_MATCHES=cap))
+    assert M2 == cap == H2.shape[0]
+    np.testing.assert_allclose(HTH2, H2.T @ H2, rtol=1e-12, atol=1e-9)
+
+
+def test_num_match_points_out_of_range_is_rejected(hip, scene):
+    from fast_limo_amd import _lib
+    hip.scan_set(scene["scan"])
+    x0 = np.zeros(26); x0[6] = 1; x0[10] = 1; x0[25] = -9.809
+    for k in (2, 9):
+        with pytest.raises(_lib.FlimoError):
+            hip.match_reduce(x0, _lib.default_match_cfg(NUM_MATCH_POINTS=k, **CAPS))
+
+
 def test_extrinsics_off_and_caps(hip, scene, oracle):
     from fast_limo_amd import _lib
     x0 = oracle.identity_x26()
