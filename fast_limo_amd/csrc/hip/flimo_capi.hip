@@ -133,6 +133,11 @@ struct flimo_ctx {
   int tail_pass1 = -1;             // FLIMO_TAIL_PASS1: 1 = the first pass of a scan always uses the in-kernel tail, 0 = never, default: by the straggler count of the last first pass
   int stragglers_pass1 = 1 << 30;  // queries of the last first pass of a scan that needed more than their 3x3x3 block (unknown: many)
   int last_stragglers = -1;        // the same of the last pass (-1: not reported by that pass's path)
+  int* d_tie_list = nullptr;       // queries of a pass whose five hinge on an exact distance tie (capacity = scan capacity)
+  unsigned int* d_tie_count = nullptr;   // [2]: alternating by pass number (the pass's reduction re-arms the next one's)
+  size_t tie_cap = 0;
+  bool ties = true;                // FLIMO_TIES=0: leave ties to the position rule (A/B checks)
+  unsigned long long tie_redos = 0, tie_queries = 0;
   bool force_general_k = false;    // FLIMO_GENERAL_K=1: NUM_MATCH_POINTS == 5 also takes the general (any-k) pass (A/B checks)
   void* d_nbrk = nullptr;          // neighbour records of the general pass
   size_t nbrk_cap = 0;
@@ -267,6 +272,8 @@ extern "C" int flimo_ctx_create(int device, flimo_ctx** out) {
             hipMalloc(&c->d_ticket, FIT_GROUPS * sizeof(unsigned int)) == hipSuccess &&
             hipMemset(c->d_ticket, 0, FIT_GROUPS * sizeof(unsigned int)) == hipSuccess &&
             hipMalloc(&c->d_cand, sizeof(unsigned long long)) == hipSuccess &&
+            hipMalloc(&c->d_tie_count, 2 * sizeof(unsigned int)) == hipSuccess &&
+            hipMemset(c->d_tie_count, 0, 2 * sizeof(unsigned int)) == hipSuccess &&
             hipMalloc(&c->d_wl_count, sizeof(int)) == hipSuccess &&
             hipMemset(c->d_wl_count, 0, sizeof(int)) == hipSuccess &&
             hipHostMalloc((void**)&c->h_wl_count, sizeof(int), hipHostMallocDefault) == hipSuccess &&
@@ -299,6 +306,8 @@ extern "C" int flimo_ctx_create(int device, flimo_ctx** out) {
   c->book = insert_book_create();
   e = getenv("FLIMO_PRUNE");
   if (e) c->prune = atoi(e) != 0;
+  e = getenv("FLIMO_TIES");
+  if (e) c->ties = atoi(e) != 0;
   e = getenv("FLIMO_GENERAL_K");
   c->force_general_k = e && atoi(e) != 0;
   e = getenv("FLIMO_TAIL_PASS1");
@@ -330,7 +339,7 @@ extern "C" void flimo_ctx_destroy(flimo_ctx* c) {
   (void)hipFree(c->d_fit_partials); (void)hipFree(c->d_raw_sorted); (void)hipFree(c->d_t_sorted);
   (void)hipFree(c->d_scan); (void)hipFree(c->d_scan_raw); (void)hipFree(c->d_scan_world); (void)hipFree(c->d_scan_t);
   (void)hipFree(c->d_frames); (void)hipFree(c->d_recs); (void)hipFree(c->d_dbg);
-  (void)hipFree(c->d_raw32); (void)hipFree(c->d_filt_ext); (void)hipFree(c->d_nbrk);
+  (void)hipFree(c->d_raw32); (void)hipFree(c->d_filt_ext); (void)hipFree(c->d_nbrk); (void)hipFree(c->d_tie_list); (void)hipFree(c->d_tie_count);
   if (c->h_filt_ext) (void)hipHostFree(c->h_filt_ext);
   (void)hipFree(c->d_partials); (void)hipFree(c->d_out256); (void)hipFree(c->d_cand); (void)hipFree(c->d_ticket);
   if (c->h_out256) (void)hipHostFree(c->h_out256);
@@ -697,6 +706,10 @@ extern "C" int flimo_knn(flimo_ctx* c, const float* q, size_t nq, int k, int32_t
   HIPCHK(c, hipMalloc(&d.cnt, nq * sizeof(int32_t)));
   HIPCHK(c, hipMemcpyAsync(d.q, q, nq * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
   launch_knn(c->stream, c->grid, d.q, (int)nq, k, 1 << 29, d.idx, d.sqd, d.cnt);
+  if (c->ties && c->gbook.active) {    // exactly tied distances: the reference's first-met choice (device copy of its octree)
+    const BookView book{c->gbook.node_c, c->gbook.node_child, c->gbook.node_cnt, c->gbook.root};
+    launch_knn_tie(c->stream, c->grid, book, d.q, (int)nq, k, d.idx, d.sqd, d.cnt);
+  }
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpyAsync(idx, d.idx, nq * k * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(sqd, d.sqd, nq * k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
@@ -715,6 +728,12 @@ static int ensure_scan(flimo_ctx* c, size_t n) {
   int* wl = nullptr;
   double* fp = nullptr;
   const size_t fpn = (size_t)fit_blocks((int)cap) * 256;
+  {
+    int* tlst = nullptr;
+    HIPCHK(c, hipMalloc(&tlst, cap * sizeof(int)));
+    (void)hipFree(c->d_tie_list);
+    c->d_tie_list = tlst; c->tie_cap = cap;
+  }
   {
     const size_t f2n = (size_t)std::max(fit2_blocks((int)cap), fused_blocks((int)cap)) * FIT_LIVE_PAD;
     double* f2 = nullptr;
@@ -979,6 +998,11 @@ extern "C" int flimo_deskew(flimo_ctx* c, const float* xyz, size_t n, size_t str
 extern "C" int flimo_set_timing(flimo_ctx* c, int level) { if (!c) return FLIMO_ERR_INVALID; c->timing = level < 0 ? 0 : (level > 2 ? 2 : level); return FLIMO_OK; }
 extern "C" unsigned long long flimo_pass_count(const flimo_ctx* c) { return c ? c->pass_seq : 0ull; }
 extern "C" unsigned long long flimo_fused_pass_count(const flimo_ctx* c) { return c ? c->fused_passes : 0ull; }
+extern "C" int flimo_tie_stats(const flimo_ctx* c, unsigned long long out[2]) {
+  if (!c || !out) return FLIMO_ERR_INVALID;
+  out[0] = c->tie_redos; out[1] = c->tie_queries;
+  return FLIMO_OK;
+}
 extern "C" int flimo_set_timing_stride(flimo_ctx* c, int every) { if (!c || every < 1) return FLIMO_ERR_INVALID; c->timing_stride = every; return FLIMO_OK; }
 extern "C" int flimo_set_debug_records(flimo_ctx* c, int on) { if (!c) return FLIMO_ERR_INVALID; c->debug_recs = on != 0; return FLIMO_OK; }
 extern "C" int flimo_set_lanes_per_query(flimo_ctx* c, int l) {
@@ -1129,22 +1153,28 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   // k-NN runs with its default two lanes per query
   const bool fused = tail && c->fuse && c->fit2 && !want_recs && tlev < 2 && c->lanes_per_query == 2;
   const unsigned long long seq = ++c->pass_seq;
+  // exact distance ties: the reference's choice needs the octree's visiting order, i.e. the device insert book
+  const bool ties_on = c->ties && c->gbook.active;
+  TieList tl{};
+  tl.count_next = c->d_tie_count + ((seq + 1) & 1);            // re-armed by this pass's reduction for the next pass
+  if (ties_on) { tl.list = c->d_tie_list; tl.count = c->d_tie_count + (seq & 1); tl.cap = (unsigned)c->tie_cap; }
+  const BookView book{c->gbook.node_c, c->gbook.node_child, c->gbook.node_cnt, c->gbook.root};
   if (fused) {
     launch_match_fused(c->stream, c->grid, c->d_scan_sorted, n_all, P, mp, c->d_nbr, c->d_wl, c->d_wl_count, nullptr, c->prev,
                        c->live_idx, c->d_fit2_partials, c->d_granules_host, c->d_ticket, seq, tlev == 1 ? c->ev[0] : nullptr,
-                       tlev == 1 ? c->ev[1] : nullptr);
+                       tlev == 1 ? c->ev[1] : nullptr, &tl);
     c->fused_passes++;
   } else
   launch_knn5(c->stream, c->lanes_per_query, c->grid, c->d_scan_sorted, n_all, P, mp.max_ring, c->d_nbr, c->d_wl,
               c->d_wl_count, c->debug_recs ? c->d_cand : nullptr, c->prev, tail ? 1 : 0, tlev == 1 ? c->ev[0] : nullptr,
-              tlev == 1 ? c->ev[1] : nullptr);
+              tlev == 1 ? c->ev[1] : nullptr, nullptr, &tl);
   if (c->prune) { memcpy(c->prev.RT, P.RT, sizeof(c->prev.RT)); c->prev.valid = 1; }   // the records now belong to this pose
   const double tpb = prof ? now_us() : 0.0;
   if (tlev > 1) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
   const bool widen_timed = !tail && tlev == 1 && mp.max_ring >= 2;
   if (!tail)
     launch_widen(c->stream, c->grid, c->d_scan_sorted, P, mp.max_ring, c->d_nbr, c->d_wl, c->d_wl_count,
-                 c->debug_recs ? c->d_cand : nullptr, widen_timed ? c->ev[4] : nullptr, widen_timed ? c->ev[5] : nullptr);
+                 c->debug_recs ? c->d_cand : nullptr, widen_timed ? c->ev[4] : nullptr, widen_timed ? c->ev[5] : nullptr, &tl);
   const double tpc = prof ? now_us() : 0.0;
   if (want_count) HIPCHK(c, hipMemcpyAsync(c->h_wl_count, c->d_wl_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   if (tlev > 1) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
@@ -1158,11 +1188,17 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
     // the fit and the reduction ran inside the k-NN launch
   } else if (use_fit2)
     launch_fit2(c->stream, c->grid, c->d_scan_sorted, n_all, c->d_nbr, P, mp, c->live_idx, c->d_fit2_partials, c->d_granules_host,
-                c->d_ticket, c->d_wl_count, seq, tlev == 1 ? c->ev[2] : nullptr, tlev == 1 ? c->ev[3] : nullptr);
-  else
+                c->d_ticket, c->d_wl_count, seq, tlev == 1 ? c->ev[2] : nullptr, tlev == 1 ? c->ev[3] : nullptr, &tl);
+  else {
+    // records / caps / debug / timing level 2 (synchronous): settle the ties before the rows are built, re-arm both counters after
+    HIPCHK(c, hipGetLastError());
+    if (ties_on) { launch_tie(c->stream, c->grid, book, c->d_scan_sorted, P, c->d_nbr, tl); HIPCHK(c, hipGetLastError()); }
   launch_fit(c->stream, c->grid, c->d_scan_sorted, n_all, c->d_nbr, P, mp, fused_cap ? nullptr : c->d_fit_partials,
              want_recs ? c->d_recs : nullptr, c->debug_recs ? c->d_dbg : nullptr, cap_binds ? c->d_out256 : c->d_out256_host,
              c->d_ticket, c->d_wl_count, seq);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemsetAsync(c->d_tie_count, 0, 2 * sizeof(unsigned int), c->stream));
+  }
   if (fused_cap) {
     launch_capreduce(c->stream, c->d_recs, (int)nq, cfg->MAX_NUM_MATCHES, c->d_out256_host, c->d_wl_count, seq);
   } else if (cap_binds) {
@@ -1176,22 +1212,42 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   double acc[256];
   if (use_fit2) {
     // low-latency completion: every sum arrives as a 16-byte granule {value, pass number}; a group's slot is complete when
-    // all of its FIT_LIVE tags carry this pass (the last granule is polled, then all are checked)
-    unsigned long long spins = 0;
-    bool synced = false;
-    for (int g = 0; g < FIT_GROUPS && !synced; g++) {
-      volatile unsigned long long* tags = reinterpret_cast<volatile unsigned long long*>(c->h_granules + (size_t)g * FIT_LIVE_PAD * 2);
-      for (;;) {
-        if (tags[2 * FIT_LIVE + 1] == seq) {                   // the last granule stored (straggler count), then every sum
-          bool all = true;
-          for (int k = 0; k < FIT_LIVE; k++) all = all && (tags[2 * k + 1] == seq);
-          if (all) break;
+    // all of its tags carry this pass (the last granule stored is polled, then all are checked)
+    auto wait_granules = [&](unsigned long long want) -> int {
+      unsigned long long spins = 0;
+      for (int g = 0; g < FIT_GROUPS; g++) {
+        volatile unsigned long long* tags = reinterpret_cast<volatile unsigned long long*>(c->h_granules + (size_t)g * FIT_LIVE_PAD * 2);
+        for (;;) {
+          if (tags[2 * (FIT_LIVE + 1) + 1] == want) {            // the last granule stored (tie count), then every other one
+            bool all = true;
+            for (int k = 0; k <= FIT_LIVE; k++) all = all && (tags[2 * k + 1] == want);
+            if (all) break;
+          }
+          _mm_pause();
+          if (++spins > 40000000ull) { HIPCHK(c, hipStreamSynchronize(c->stream)); return FLIMO_OK; }   // also surfaces launch errors
         }
-        _mm_pause();
-        if (++spins > 40000000ull) { HIPCHK(c, hipStreamSynchronize(c->stream)); synced = true; break; }   // also surfaces launch errors
       }
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+      return FLIMO_OK;
+    };
+    { const int rcw = wait_granules(seq); if (rcw) return rcw; }
+    c->last_stragglers = (int)llround(c->h_granules[2 * FIT_LIVE]);
+    if (first_pass) c->stragglers_pass1 = c->last_stragglers;
+    const long n_ties = (long)llround(c->h_granules[2 * (FIT_LIVE + 1)]);
+    if (n_ties > 0 && ties_on) {
+      // A few queries' five hinge on an exact float32 distance tie: settle them the reference's way (tie_kernel), then build the
+      // rows and the sums again (one more fit dispatch).  Roughly once per 65k-point scan on measured data.
+      c->tie_redos++; c->tie_queries += (unsigned long long)n_ties;
+      launch_tie(c->stream, c->grid, book, c->d_scan_sorted, P, c->d_nbr, tl);
+      const unsigned long long seq2 = ++c->pass_seq;
+      TieList tl2{};
+      tl2.count_next = c->d_tie_count + ((seq2 + 1) & 1);      // == this pass's counter: consumed by tie_kernel just above
+      launch_fit2(c->stream, c->grid, c->d_scan_sorted, n_all, c->d_nbr, P, mp, c->live_idx, c->d_fit2_partials, c->d_granules_host,
+                  c->d_ticket, c->d_wl_count, seq2, nullptr, nullptr, &tl2);
+      HIPCHK(c, hipGetLastError());
+      const int rcw = wait_granules(seq2);
+      if (rcw) return rcw;
     }
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);
     // slot sums in slot order, then the full 16x16 raw layout the decode below reads
     double live[FIT_LIVE];
     for (int k = 0; k < FIT_LIVE; k++) {
@@ -1199,8 +1255,6 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
       for (int g = 1; g < FIT_GROUPS; g++) r += c->h_granules[((size_t)g * FIT_LIVE_PAD + k) * 2];
       live[k] = r;
     }
-    c->last_stragglers = (int)llround(c->h_granules[2 * FIT_LIVE]);
-    if (first_pass) c->stragglers_pass1 = c->last_stragglers;
     for (int t = 0; t < 256; t++) acc[t] = 0.0;
     {
       int k = 0;

@@ -5,16 +5,20 @@
 
 namespace flimo {
 struct FuseArgs;
+struct TieList;
+struct BookView;
 
 // flimo_kernels.hip
 // per pass: k-NN (fast path + worklist widening), then fit + in-block reduction, then the final sum
 void launch_knn5(hipStream_t st, int lanes_per_query, const GridView& G, const float4* scan_sorted, int n,
                  const PoseMats& P, int max_ring, void* nbr, int* wl, int* wl_count, unsigned long long* cand,
-                 const PrevPass& prev, int tail, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, const struct FuseArgs* fuse = nullptr);
+                 const PrevPass& prev, int tail, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, const struct FuseArgs* fuse = nullptr,
+                 const TieList* ties = nullptr);
 // tail != 0: queries that need more than the 3x3x3 block are finished inside the k-NN launch itself (gates of at most 3
 // rings; launch_knn5 clears the flag otherwise) and launch_widen has nothing to do
 void launch_widen(hipStream_t st, const GridView& G, const float4* scan_sorted, const PoseMats& P, int max_ring, void* nbr,
-                  int* wl, int* wl_count, unsigned long long* cand, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+                  int* wl, int* wl_count, unsigned long long* cand, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr,
+                  const TieList* ties = nullptr);
 int fit_blocks(int n);
 void set_xcd_stripe(int stripe);   // block -> scan chunk mapping of the per-pass kernels (see xcd_chunk)
 // the fit kernel reduces in FIT_GROUPS groups; slot g of its output = 256 sums + the pass number (FIT_SLOT doubles)
@@ -33,14 +37,23 @@ constexpr int FIT_LIVE_PAD = 96;
 int fit2_blocks(int n);
 void launch_fit2(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const void* nbr, const PoseMats& P,
                  const MatchParams& mp, const unsigned char* live_idx, double* partials, void* out_granules, unsigned int* ticket,
-                 int* wl_count, unsigned long long seq, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+                 int* wl_count, unsigned long long seq, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, const TieList* ties = nullptr);
 // The whole measurement pass in ONE launch (k-NN fast path + in-kernel tail + fit + reduction + publish; two lanes per query, gates of
 // 2..3 rings): partials needs fused_blocks(n) * FIT_LIVE_PAD doubles; results arrive as launch_fit2's granules.
 int fused_blocks(int n);
 void launch_match_fused(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const PoseMats& P, const MatchParams& mp,
                         void* nbr, int* wl, int* wl_count, unsigned long long* cand, const PrevPass& prev,
                         const unsigned char* live_idx, double* partials, void* out_granules, unsigned int* ticket,
-                        unsigned long long seq, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+                        unsigned long long seq, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, const TieList* ties = nullptr);
+// The reference's choice among exactly tied distances (first met by Octree::knn's recursion): BookView = the device copy of the
+// octree (insert book), TieList = the queries a pass flagged.  launch_tie rewrites their neighbour records; launch_knn_tie does the
+// same for the output of launch_knn.
+struct BookView { const float4* node_c; const int* node_child; const int* node_cnt; int root; };
+struct TieList { int* list; unsigned int* count; unsigned int cap; unsigned int* count_next; };
+void launch_tie(hipStream_t st, const GridView& G, const BookView& B, const float4* scan_sorted, const PoseMats& P, void* nbr,
+                const TieList& tl);
+void launch_knn_tie(hipStream_t st, const GridView& G, const BookView& B, const float* qxyz, int nq, int k, int32_t* idx, float* sqd,
+                    const int32_t* cnt);
 // General NUM_MATCH_POINTS (3..8): exact k-NN by the ring search + M x 3 plane fit, records written at the original indices
 // (reduce them with launch_cap / launch_reduce).  nbrk: n * nbrk_rec_size() bytes of scratch.  false: k out of range.
 size_t nbrk_rec_size();

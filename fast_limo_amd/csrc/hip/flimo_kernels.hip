@@ -333,6 +333,19 @@ __device__ __forceinline__ void best5_insert(double (&k)[5], double x) {
   }
   k[4] = key_min(k[4], t);
 }
+// The same with a sixth entry: the best candidate that did NOT make the five.  Its distance tells whether the choice of the five
+// hinges on an exact float32 tie (d5 == d6) -- the one case in which the reference's answer depends on its octree's visiting
+// order (tie_kernel below restores that order).
+__device__ __forceinline__ void best6_insert(double (&k)[6], double x) {
+  double t = x;
+#pragma unroll
+  for (int i = 0; i < 5; i++) {
+    const double lo = key_min(k[i], t);
+    t = key_max(k[i], t);
+    k[i] = lo;
+  }
+  k[5] = key_min(k[5], t);
+}
 #define KEY_NONE 0x7f800000ffffffffull     // (+inf, -1): an empty slot of the merged list
 
 // Minimum of a key over an aligned group of Gl lanes (2, 4, ..., 64), result in every lane of the group.  Within a row of 16
@@ -368,7 +381,7 @@ __device__ __forceinline__ double key_group_min(double md, int Gl, int lane) {
 template <int L, int N>
 __device__ __forceinline__ void knn5_body(const float4* __restrict__ pts, uint32_t s0, uint32_t total, uint32_t last,
                                           const uint32_t (&off)[10], const uint32_t (&dl)[9], float gx, float gy, float gz,
-                                          double (&k5)[5]) {
+                                          double (&k5)[6]) {
   float4 pt[N];
   uint32_t id[N];
 #pragma unroll
@@ -394,7 +407,7 @@ __device__ __forceinline__ void knn5_body(const float4* __restrict__ pts, uint32
   for (int u = 0; u < N; u++) {
     const bool live = s0 + u * L < total;
     const float d = sqdist3(gx, gy, gz, pt[u].x, pt[u].y, pt[u].z);
-    best5_insert(k5, key_make(live ? d : INFINITY, live ? id[u] : 0xffffffffu));
+    best6_insert(k5, key_make(live ? d : INFINITY, live ? id[u] : 0xffffffffu));
   }
 }
 
@@ -414,6 +427,14 @@ __device__ __forceinline__ void knn5_body(const float4* __restrict__ pts, uint32
 //   * exactness test as everywhere: the 5-ball inside the searched block, else the next ring, never beyond max_ring.
 // ------------------------------------------------------------------------------------------
 struct FitIdx { unsigned char raw[FIT_LIVE_PAD]; };   // live sum k -> index into the wave's 256 raw MFMA accumulators
+// TieList (flimo_kernels.h): list + counter of THIS pass; the pass's last reduction block re-arms the counter the NEXT pass will
+// use (two counters, alternating: the host may still read this pass's count for tie_kernel)
+// exactly tied float32 distances among the five, or between the 5th and the best of the rest
+__device__ __forceinline__ bool key_has_tie(const u64 (&best)[5], u64 sixth) {
+  const uint32_t d0 = (uint32_t)(best[0] >> 32), d1 = (uint32_t)(best[1] >> 32), d2 = (uint32_t)(best[2] >> 32),
+                 d3 = (uint32_t)(best[3] >> 32), d4 = (uint32_t)(best[4] >> 32), d5 = (uint32_t)(sixth >> 32);
+  return (d0 == d1) | (d1 == d2) | (d2 == d3) | (d3 == d4) | (d4 == d5);
+}
 constexpr int TAIL_MAX_RING = 3;
 struct __align__(16) WaveLds {                  // one per wave of the block
   float tile[16 * 65];                          // fused pass: the wave's rows, [col][row] with stride 65
@@ -431,7 +452,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 __device__ __forceinline__ void knn5_tail(const GridView& G, int max_ring, NbrRec* __restrict__ nbr, bool pending, int p,
                                           float gx, float gy, float gz, uint32_t hint_bits, float b2, WaveLds& S,
                                           int* __restrict__ straggler_count, unsigned long long* __restrict__ cand_total,
-                                          bool keep_res) {
+                                          bool keep_res, const TieList& tl) {
   const int lane = threadIdx.x & 63;
   const u64 B = __ballot(pending);
   const int F = __popcll(B);
@@ -482,6 +503,7 @@ __device__ __forceinline__ void knn5_tail(const GridView& G, int max_ring, NbrRe
       r = min(r, max_ring);
     }
     u64 best[5] = {KEY_NONE, KEY_NONE, KEY_NONE, KEY_NONE, KEY_NONE};
+    u64 sixth = KEY_NONE;
     int flag = 0;
     for (;;) {
       if (!__any(active)) break;
@@ -497,7 +519,7 @@ __device__ __forceinline__ void knn5_tail(const GridView& G, int max_ring, NbrRe
         // lanes per row: a lone straggler has the whole wave -- two lanes share each of the 25 rows of a ring-2 block
         const int lr = (Gl == 64 && rows <= 32) ? 2 : 1, nslots = Gl / lr;
         const int slot = sub / lr, part = sub - slot * lr;
-        double k5[5] = {none, none, none, none, none};
+        double k5[6] = {none, none, none, none, none, none};
         for (int jb = slot; jb < rows; jb += 4 * nslots) {
           uint32_t lo4[4], hi4[4];
 #pragma unroll
@@ -540,21 +562,21 @@ __device__ __forceinline__ void knn5_tail(const GridView& G, int max_ring, NbrRe
                 const uint32_t ii = i0 + (uint32_t)(w * lr);
                 const bool live = ii < hi;
                 const float d = sqdist3(qx, qy, qz, q[w].x, q[w].y, q[w].z);
-                best5_insert(k5, key_make(live ? d : INFINITY, live ? ii : 0xffffffffu));
+                best6_insert(k5, key_make(live ? d : INFINITY, live ? ii : 0xffffffffu));
               }
             }
             if (part == 0) cand += (int)(hi - lo4[u]);
           }
         }
-        u64 mine[5];
+        u64 mine[6];
 #pragma unroll
-        for (int i = 0; i < 5; i++) mine[i] = (u64)__double_as_longlong(k5[i]);
+        for (int i = 0; i < 6; i++) mine[i] = (u64)__double_as_longlong(k5[i]);
 #pragma unroll
-        for (int k = 0; k < 5; k++) {
+        for (int k = 0; k < 6; k++) {
           const double md = key_group_min(__longlong_as_double((long long)mine[0]), Gl, lane);
           const u64 m = (u64)__double_as_longlong(md);
-          best[k] = m;
-          if (mine[0] == m) { mine[0] = mine[1]; mine[1] = mine[2]; mine[2] = mine[3]; mine[3] = mine[4]; mine[4] = KEY_NONE; }
+          if (k < 5) best[k] = m; else sixth = m;
+          if (mine[0] == m) { mine[0] = mine[1]; mine[1] = mine[2]; mine[2] = mine[3]; mine[3] = mine[4]; mine[4] = mine[5]; mine[5] = KEY_NONE; }
         }
         const float rg = ((float)r + edge - margin) * G.cell;
         const float d5 = __uint_as_float((uint32_t)(best[4] >> 32));
@@ -576,12 +598,14 @@ __device__ __forceinline__ void knn5_tail(const GridView& G, int max_ring, NbrRe
       }
     }
     if (qi < F && sub == 0) {
+      const bool tie = flag == 1 && key_has_tie(best, sixth);
       int4 a, b;
       a.x = (int)(uint32_t)best[0]; a.y = (int)(uint32_t)best[1]; a.z = (int)(uint32_t)best[2]; a.w = (int)(uint32_t)best[3];
-      b.x = (int)(uint32_t)best[4]; b.y = flag; b.z = (int)(uint32_t)(best[4] >> 32); b.w = (flag == 1) ? 1 : 0;
+      b.x = (int)(uint32_t)best[4]; b.y = flag; b.z = (int)(uint32_t)(best[4] >> 32); b.w = ((flag == 1) ? 1 : 0) | (tie ? 2 : 0);
       int4* o = reinterpret_cast<int4*>(&nbr[qp]);
       o[0] = a;
       o[1] = b;
+      if (tie && tl.list) { const unsigned slot = atomicAdd(tl.count, 1u); if (slot < tl.cap) tl.list[slot] = qp; }
       if (keep_res) {
         int4* rr = reinterpret_cast<int4*>(S.res[src]);
         rr[0] = a;
@@ -600,6 +624,7 @@ __device__ __forceinline__ void knn5_tail(const GridView& G, int max_ring, NbrRe
 // FUSE: the whole measurement pass in ONE launch (fast path of flimo_match_reduce): every wave goes on from its queries'
 // neighbours (fast path + tail) to their plane fit, residual and H row and to the H^T H reduction (fit_reduce_publish below).
 struct FuseArgs {
+  TieList tl;
   MatchParams mp;
   FitIdx idx;
   double* partials;
@@ -612,7 +637,7 @@ __device__ __forceinline__ void fit_reduce_publish(const float (&v)[16], bool ow
                                                    double* sa2, double* sa3, unsigned int* s_last, const FitIdx& idx,
                                                    double* __restrict__ partials, double2* __restrict__ out_granules,
                                                    unsigned int* __restrict__ ticket, int* __restrict__ wl_count,
-                                                   unsigned long long seq);
+                                                   unsigned long long seq, const TieList& tl);
 FLIMO_DEV void fit_row(const GridView& G, const PoseMats& P, const MatchParams& mp, const int (&ids)[5], float gx, float gy, float gz,
                        float (&v)[16]);
 
@@ -623,6 +648,7 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
                                                    unsigned long long* __restrict__ cand_total, PrevPass prev, int tail,
                                                    FuseArgs fa) {
   constexpr int QPB = 256 / L;          // queries per block; SLOTS = candidate loads in flight per lane
+  const TieList tl = fa.tl;
   __shared__ WaveLds s_w[4];
   __shared__ unsigned int s_last;
   const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
@@ -643,7 +669,7 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
   float b2 = INFINITY;                               // bound, squared, in cell units
   if (prev.valid && in_range) {
     const int4 pb = reinterpret_cast<const int4*>(&nbr[p])[1];       // idx[4], flag, d5 bits, "d5 valid"
-    if (pb.y == 1 && pb.w == 1) {
+    if (pb.y == 1 && (pb.w & 1)) {
       float ox_, oy_, oz_;
       xform4(prev.RT, sp.x, sp.y, sp.z, ox_, oy_, oz_);
       const float ex = gx - ox_, ey = gy - oy_, ez = gz - oz_;
@@ -654,6 +680,8 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
   }
   int flag = 0;
   u64 best[5] = {KEY_NONE, KEY_NONE, KEY_NONE, KEY_NONE, KEY_NONE};
+  u64 sixth = KEY_NONE;
+  bool tie = false;
   int cand = 0;
   if (in_range && (fx == fx) && (fy == fy) && (fz == fz)) {
     const float lim = 1.0e9f;
@@ -731,7 +759,7 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
       TRACE(0, 2);
       // ---- flattened candidate stream, branch-free body ----
       const double none = __longlong_as_double((long long)KEY_NONE);
-      double k5[5] = {none, none, none, none, none};
+      double k5[6] = {none, none, none, none, none, none};
       const uint32_t last = total - 1u;
       // full bodies while more than half of a body's slots are live for this lane, then one half body
       uint32_t s0 = (uint32_t)sub;
@@ -741,6 +769,7 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
       cand = total > (uint32_t)sub ? (int)((total - (uint32_t)sub + L - 1) / L) : 0;
 #pragma unroll
       for (int i = 0; i < 5; i++) best[i] = (u64)__double_as_longlong(k5[i]);
+      sixth = (u64)__double_as_longlong(k5[5]);
       TRACE(0, 3);
 #ifdef FLIMO_TRACE
       if (blockIdx.x < 16384) {   // developer statistics: accumulated block candidates (all passes), CU id
@@ -748,19 +777,20 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
         if (threadIdx.x == 0) g_trace[0][blockIdx.x * 8 + 7] = __smid();
       }
 #endif
-      // ---- group result: five rounds of min-extraction ----
+      // ---- group result: six rounds of min-extraction (the five, and the best of the rest) ----
       if (L > 1) {
-        u64 mine[5];
+        u64 mine[6];
 #pragma unroll
         for (int i = 0; i < 5; i++) mine[i] = best[i];
+        mine[5] = sixth;
 #pragma unroll
-        for (int r = 0; r < 5; r++) {
+        for (int r = 0; r < 6; r++) {
           double md = __longlong_as_double((long long)mine[0]);
 #pragma unroll
           for (int o = 1; o < L; o <<= 1) md = key_min(md, __shfl_xor(md, o, 64));
           const u64 m = (u64)__double_as_longlong(md);
-          best[r] = m;
-          if (mine[0] == m) { mine[0] = mine[1]; mine[1] = mine[2]; mine[2] = mine[3]; mine[3] = mine[4]; mine[4] = KEY_NONE; }
+          if (r < 5) best[r] = m; else sixth = m;
+          if (mine[0] == m) { mine[0] = mine[1]; mine[1] = mine[2]; mine[2] = mine[3]; mine[3] = mine[4]; mine[4] = mine[5]; mine[5] = KEY_NONE; }
         }
       }
       // ---- exactness: the 5-ball must lie inside the 3x3x3 block ----
@@ -770,7 +800,12 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
       const bool have5 = d5 < INFINITY;
       const bool covers = (cx - 1 <= 0) && (cx + 1 >= G.nx - 1) && (cy - 1 <= 0) && (cy + 1 >= G.ny - 1) &&
                           (cz - 1 <= 0) && (cz + 1 >= G.nz - 1);
-      if (have5 && (covers || d5 <= rg * rg * (1.f - 1.0e-6f))) flag = 1;
+      if (have5 && (covers || d5 <= rg * rg * (1.f - 1.0e-6f))) {
+        flag = 1;
+        // exactly tied float32 distances among the five or between the 5th and the 6th: the reference's choice / order follows
+        // its octree's visiting order (resolved by tie_kernel)
+        tie = key_has_tie(best, sixth);
+      }
       else if (covers) flag = 0;                 // the whole map holds fewer than 5 points
       else flag = (max_ring > 1) ? 2 : 0;
       if (heavy) flag = 3;              // pending like 2, and the wider search starts at the 3x3x3 block itself
@@ -789,7 +824,8 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
   if (in_range && sub == 0 && !pend_tail) {
     int4 a, b;
     a.x = (int)(uint32_t)best[0]; a.y = (int)(uint32_t)best[1]; a.z = (int)(uint32_t)best[2]; a.w = (int)(uint32_t)best[3];
-    b.x = (int)(uint32_t)best[4]; b.y = min(flag, 2); b.z = (int)(uint32_t)(best[4] >> 32); b.w = (flag == 1) ? 1 : 0;   // d5 for the next pass
+    b.x = (int)(uint32_t)best[4]; b.y = min(flag, 2); b.z = (int)(uint32_t)(best[4] >> 32); b.w = ((flag == 1) ? 1 : 0) | (tie ? 2 : 0);   // d5 for the next pass; bit 1: tie
+    if (tie && tl.list) { const unsigned slot = atomicAdd(tl.count, 1u); if (slot < tl.cap) tl.list[slot] = p; }
     int4* o = reinterpret_cast<int4*>(&nbr[p]);
     o[0] = a;
     o[1] = b;
@@ -804,7 +840,7 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
     }
   }
   WaveLds& W = s_w[threadIdx.x >> 6];
-  if (tail) knn5_tail(G, max_ring, nbr, pend_tail && sub == 0, p, gx, gy, gz, (uint32_t)(best[4] >> 32), b2, W, wl_count, cand_total, FUSE);
+  if (tail) knn5_tail(G, max_ring, nbr, pend_tail && sub == 0, p, gx, gy, gz, (uint32_t)(best[4] >> 32), b2, W, wl_count, cand_total, FUSE, tl);
   TRACE(0, 5);
   if constexpr (FUSE) {
     // ---- fit + reduction of this wave's queries (one row per query, computed by the pair's first lane) ----
@@ -826,7 +862,7 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
     }
     wave_lds_sync();                                           // every lane is done with W.res before the tile overwrites the tables
     fit_reduce_publish<64 / L>(v, sub == 0, lane / L, W.tile, s_w[0].acc, s_w[1].acc, s_w[2].acc, s_w[3].acc, &s_last, fa.idx,
-                               fa.partials, fa.granules, fa.ticket, wl_count, fa.seq);
+                               fa.partials, fa.granules, fa.ticket, wl_count, fa.seq, tl);
   }
 }
 
@@ -840,7 +876,7 @@ template <int WPS>   // minimum waves per SIMD the register allocation must allo
 __global__ __launch_bounds__(256, WPS) void widen_kernel(GridView G, const float4* __restrict__ scan_sorted, PoseMats P,
                                                     int max_ring, NbrRec* __restrict__ nbr, const int* __restrict__ wl,
                                                     const int* __restrict__ wl_count,
-                                                    unsigned long long* __restrict__ cand_total, int first_ring) {
+                                                    unsigned long long* __restrict__ cand_total, int first_ring, TieList tl) {
   __shared__ uint32_t s_off[4][65];
   __shared__ uint32_t s_lo[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -865,6 +901,7 @@ __global__ __launch_bounds__(256, WPS) void widen_kernel(GridView G, const float
                 rz = fminf(fmaxf(fz - flz, 0.f), 1.f);
     const float edge = fminf(fminf(fminf(rx, 1.f - rx), fminf(ry, 1.f - ry)), fminf(rz, 1.f - rz));
     u64 best[5] = {KEY_NONE, KEY_NONE, KEY_NONE, KEY_NONE, KEY_NONE};
+    u64 sixth = KEY_NONE;
     int flag = 0;
     int cand = 0;
     int r = (e1.y == 1) ? 1 : first_ring;              // 1: a crowded 3x3x3 block handed over unsearched; no hint: first_ring (2, or the gate's ring: one search instead of two)
@@ -917,7 +954,7 @@ __global__ __launch_bounds__(256, WPS) void widen_kernel(GridView G, const float
       __builtin_amdgcn_wave_barrier();
       // strided share of the flattened candidates; rows ascend in memory, so a lane meets ascending map positions
       const double none = __longlong_as_double((long long)KEY_NONE);
-      double k5[5] = {none, none, none, none, none};
+      double k5[6] = {none, none, none, none, none, none};
       const uint32_t last = total - 1u;
       for (uint32_t s0 = (uint32_t)lane; s0 < total; s0 += 4 * 64) {
         float4 q[4];
@@ -937,20 +974,20 @@ __global__ __launch_bounds__(256, WPS) void widen_kernel(GridView G, const float
         for (int u = 0; u < 4; u++) {
           const bool live = s0 + 64u * u < total;
           const float d = sqdist3(gx, gy, gz, q[u].x, q[u].y, q[u].z);
-          best5_insert(k5, key_make(live ? d : INFINITY, live ? id[u] : 0xffffffffu));
+          best6_insert(k5, key_make(live ? d : INFINITY, live ? id[u] : 0xffffffffu));
         }
       }
       cand += total > (uint32_t)lane ? (int)((total - (uint32_t)lane + 63u) / 64u) : 0;
       __builtin_amdgcn_wave_barrier();
-      u64 mine[5];
+      u64 mine[6];
 #pragma unroll
-      for (int i = 0; i < 5; i++) mine[i] = (u64)__double_as_longlong(k5[i]);
+      for (int i = 0; i < 6; i++) mine[i] = (u64)__double_as_longlong(k5[i]);
 #pragma unroll
-      for (int k = 0; k < 5; k++) {
+      for (int k = 0; k < 6; k++) {
         const double md = key_group_min(__longlong_as_double((long long)mine[0]), 64, lane);
         const u64 m = (u64)__double_as_longlong(md);
-        best[k] = m;
-        if (mine[0] == m) { mine[0] = mine[1]; mine[1] = mine[2]; mine[2] = mine[3]; mine[3] = mine[4]; mine[4] = KEY_NONE; }
+        if (k < 5) best[k] = m; else sixth = m;
+        if (mine[0] == m) { mine[0] = mine[1]; mine[1] = mine[2]; mine[2] = mine[3]; mine[3] = mine[4]; mine[4] = mine[5]; mine[5] = KEY_NONE; }
       }
       const float rg = ((float)r + edge - margin) * G.cell;
       const float d5 = __uint_as_float((uint32_t)(best[4] >> 32));
@@ -975,10 +1012,12 @@ __global__ __launch_bounds__(256, WPS) void widen_kernel(GridView G, const float
     if (lane == 0) {
       int4 a, b;
       a.x = (int)(uint32_t)best[0]; a.y = (int)(uint32_t)best[1]; a.z = (int)(uint32_t)best[2]; a.w = (int)(uint32_t)best[3];
-      b.x = (int)(uint32_t)best[4]; b.y = flag; b.z = (int)(uint32_t)(best[4] >> 32); b.w = (flag == 1) ? 1 : 0;
+      const bool tie = flag == 1 && key_has_tie(best, sixth);
+      b.x = (int)(uint32_t)best[4]; b.y = flag; b.z = (int)(uint32_t)(best[4] >> 32); b.w = ((flag == 1) ? 1 : 0) | (tie ? 2 : 0);
       int4* o = reinterpret_cast<int4*>(&nbr[p]);
       o[0] = a;
       o[1] = b;
+      if (tie && tl.list) { const unsigned slot = atomicAdd(tl.count, 1u); if (slot < tl.cap) tl.list[slot] = p; }
     }
   }
 }
@@ -1245,7 +1284,7 @@ __device__ __forceinline__ void fit_reduce_publish(const float (&v)[16], bool ow
                                                    double* sa2, double* sa3, unsigned int* s_last, const FitIdx& idx,
                                                    double* __restrict__ partials, double2* __restrict__ out_granules,
                                                    unsigned int* __restrict__ ticket, int* __restrict__ wl_count,
-                                                   unsigned long long seq) {
+                                                   unsigned long long seq, const TieList& tl) {
   typedef double v2d_t __attribute__((ext_vector_type(2)));
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (owns_row) {
@@ -1326,8 +1365,12 @@ __device__ __forceinline__ void fit_reduce_publish(const float (&v)[16], bool ow
       g.y = __longlong_as_double((long long)seq);
       double2* o = out_granules + (size_t)group * FIT_LIVE_PAD + FIT_LIVE;
       asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(o), "v"(g) : "memory");
+      // granule FIT_LIVE + 1: queries whose five hinge on an exact distance tie (the host then runs tie_kernel and the fit again)
+      g.x = (group == 0 && tl.count) ? (double)__hip_atomic_load(tl.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+      o = out_granules + (size_t)group * FIT_LIVE_PAD + FIT_LIVE + 1;
+      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(o), "v"(g) : "memory");
       ticket[group] = 0u;                                          // ready for the next pass (visible at kernel end)
-      if (group == 0) *wl_count = 0;
+      if (group == 0) { *wl_count = 0; if (tl.count_next) *tl.count_next = 0u; }
     }
     TRACE(1, 7);
   }
@@ -1342,7 +1385,7 @@ __global__ __launch_bounds__(256) void fit2_kernel(GridView G, const float4* __r
                                                    const NbrRec* __restrict__ nbr, PoseMats P, MatchParams mp, FitIdx idx,
                                                    double* __restrict__ partials, double2* __restrict__ out_granules,
                                                    unsigned int* __restrict__ ticket, int* __restrict__ wl_count,
-                                                   unsigned long long seq) {
+                                                   unsigned long long seq, TieList tl) {
   __shared__ float s_rec[4][16 * 65];       // per wave: [col][row] with stride 65
   __shared__ double s_acc[4][256];
   __shared__ unsigned int s_last;
@@ -1365,7 +1408,185 @@ __global__ __launch_bounds__(256) void fit2_kernel(GridView G, const float4* __r
   }
   TRACE(1, 3);
   fit_reduce_publish<PPW>(v, lane < PPW, lane, s_rec[wave], s_acc[0], s_acc[1], s_acc[2], s_acc[3], &s_last, idx, partials,
-                          out_granules, ticket, wl_count, seq);
+                          out_granules, ticket, wl_count, seq, tl);
+}
+
+// ------------------------------------------------------------------------------------------
+// The reference's order among EXACTLY tied distances.  Octree::knn (Objects/Octree.hpp:526-599) keeps, of two candidates at the
+// same float32 squared distance, the one its depth-first recursion meets first (Heap::addPoint rejects `dist >= worst`,
+// :72-87): at every octant it descends into the child holding the query first (mortonCode, :269-275), then into the others in
+// the order of `ordered_indices[morton]` (:144-153,585-596); inside a leaf the points are visited in insertion order
+// (createOctant / updateOctant append in batch order, :303-432).  So the reference's five = the first five of the candidates
+// sorted by (distance, visiting order).  The k-NN kernels above choose by (distance, position in the cell-sorted map) and flag
+// a query whose five -- or their order -- hinge on such a tie (key_has_tie); tie_kernel below re-derives the five of a flagged
+// query: every candidate with d <= d5 inside the proven block is collected, ties are ordered by walking the device copy of the
+// octree (the insert book: the reference's own cubes, flimo_gbook.hip) from the root to the node where the two candidates'
+// paths part.  A few queries per scan on measured data; every query of a lattice.
+// ------------------------------------------------------------------------------------------
+__constant__ unsigned char c_ordered_indices[8][7] = {
+    {1, 2, 4, 3, 5, 6, 7}, {0, 3, 5, 2, 4, 7, 6}, {0, 3, 6, 1, 4, 7, 5}, {1, 2, 7, 0, 5, 6, 4},
+    {0, 5, 6, 1, 2, 7, 3}, {1, 4, 7, 0, 3, 6, 2}, {2, 4, 7, 0, 3, 5, 1}, {3, 5, 6, 1, 2, 4, 0}};
+
+__device__ __forceinline__ int book_morton(float x, float y, float z, const float4& c) {
+  return (x > c.x ? 1 : 0) | (y > c.y ? 2 : 0) | (z > c.z ? 4 : 0);
+}
+__device__ __forceinline__ int visit_pos(int m, int c) {      // place of child c in the visiting order of a node whose query child is m
+  if (c == m) return 0;
+  int pos = 8;
+#pragma unroll
+  for (int i = 0; i < 7; i++) pos = (c_ordered_indices[m][i] == c) ? 1 + i : pos;
+  return pos;
+}
+// does Octree::knn meet stored point a (raw insertion index ra) before stored point b?
+__device__ bool visited_before(const BookView& B, float ax, float ay, float az, uint32_t ra, float bx, float by, float bz, uint32_t rb,
+                               float qx, float qy, float qz) {
+  int node = B.root;
+  for (int depth = 0; depth < 64 && node >= 0; depth++) {
+    if (B.node_cnt[node] >= 0) break;                         // same leaf: insertion order
+    const float4 c = B.node_c[node];
+    const int ca = book_morton(ax, ay, az, c), cb = book_morton(bx, by, bz, c);
+    if (ca != cb) {
+      const int m = book_morton(qx, qy, qz, c);
+      return visit_pos(m, ca) < visit_pos(m, cb);
+    }
+    node = B.node_child[(size_t)node * 8 + ca];
+  }
+  return ra < rb;
+}
+
+struct TieLds { float4 pt[64]; float d[64]; uint32_t pos[64]; unsigned int cnt; };
+
+// One wave: the first k of {candidates with d <= dk inside the ring-r block around q} in the reference's order -> out_pos / out_d
+// (lane 0).  Returns false when the block is wider than 3 rings or holds more than 64 such candidates (nothing is changed then).
+__device__ bool tie_select_wave(const GridView& G, const BookView& B, float qx, float qy, float qz, float dk, int k, TieLds& S,
+                                uint32_t (&out_pos)[8], float (&out_d)[8]) {
+  const int lane = threadIdx.x & 63;
+  const int maxdim = max(G.nx, max(G.ny, G.nz));
+  const float margin = 1.0e-3f + 4.0e-7f * (float)maxdim;
+  const float fx = (qx - G.ox) * G.inv_cell, fy = (qy - G.oy) * G.inv_cell, fz = (qz - G.oz) * G.inv_cell;
+  const float flx = floorf(fminf(fmaxf(fx, -1.0e9f), 1.0e9f)), fly = floorf(fminf(fmaxf(fy, -1.0e9f), 1.0e9f)),
+              flz = floorf(fminf(fmaxf(fz, -1.0e9f), 1.0e9f));
+  const int cx = (int)flx, cy = (int)fly, cz = (int)flz;
+  const float rx = fminf(fmaxf(fx - flx, 0.f), 1.f), ry = fminf(fmaxf(fy - fly, 0.f), 1.f), rz = fminf(fmaxf(fz - flz, 0.f), 1.f);
+  const float edge = fminf(fminf(fminf(rx, 1.f - rx), fminf(ry, 1.f - ry)), fminf(rz, 1.f - rz));
+  // smallest ring whose block provably holds the ball of radius sqrt(dk) (the same bound the searches use, turned around)
+  const float need = fl_sqrt(dk) * G.inv_cell * (1.f + 4.0e-6f) - edge + margin;
+  int r = max(1, (int)ceilf(fminf(need, 1.0e9f)));
+  {
+    const float rg = ((float)r + edge - margin) * G.cell;
+    if (!(dk <= rg * rg * (1.f - 1.0e-6f))) r++;
+  }
+  if (r > 3) return false;
+  if (lane == 0) S.cnt = 0u;
+  wave_lds_sync();
+  const int side = 2 * r + 1, rows = side * side;
+  const float rc = (fl_sqrt(dk) * (1.f + 1.0e-5f) + 1.0e-6f) * G.inv_cell;
+  const float bnd2 = rc * rc * (1.f + 1.0e-5f);
+  if (lane < rows) {
+    const int jz = lane / side, jy = lane - jz * side;
+    const int dy = jy - r, dz = jz - r;
+    const int yy = cy + dy, zz = cz + dz;
+    const float a = fmaxf(slab_dist(dy, ry) - margin, 0.f), b = fmaxf(slab_dist(dz, rz) - margin, 0.f);
+    const float dyz2 = a * a + b * b;
+    if (dyz2 <= bnd2 && yy >= 0 && yy < G.ny && zz >= 0 && zz < G.nz) {
+      const float xr = fl_sqrt(fmaxf(bnd2 - dyz2, 0.f)) * (1.f + 1.0e-6f) + margin + 1.0e-4f;
+      const int dr = (int)fminf(floorf(fminf(xr + rx, 1.0e6f)), (float)r);
+      const int dl = (int)fminf(floorf(fminf(xr + (1.f - rx), 1.0e6f)), (float)r);
+      const int x0 = max(cx - dl, 0), x1 = min(cx + dr, G.nx - 1);
+      if (x0 <= x1) {
+        const size_t rowbase = ((size_t)zz * (size_t)G.ny + (size_t)yy) * (size_t)G.nx;
+        const uint32_t lo = G.cell_start[rowbase + x0], hi = G.cell_start[rowbase + x1 + 1];
+        for (uint32_t i = lo; i < hi; i++) {
+          const float4 p = G.pts[i];
+          const float d = sqdist3(qx, qy, qz, p.x, p.y, p.z);
+          if (d <= dk) {
+            const unsigned slot = atomicAdd(&S.cnt, 1u);
+            if (slot < 64u) { S.pt[slot] = p; S.d[slot] = d; S.pos[slot] = i; }
+          }
+        }
+      }
+    }
+  }
+  wave_lds_sync();
+  const unsigned n = S.cnt;
+  if (n > 64u || (int)n < k) return false;
+  if (lane == 0) {
+    // selection sort of the first k by (distance, visiting order); n is a handful
+    for (int s = 0; s < k; s++) {
+      int best = s;
+      for (unsigned j = (unsigned)s + 1; j < n; j++) {
+        const float dj = S.d[j], db = S.d[best];
+        bool less = dj < db;
+        if (dj == db) {
+          const float4 a = S.pt[j], b = S.pt[best];
+          less = visited_before(B, a.x, a.y, a.z, __float_as_uint(a.w), b.x, b.y, b.z, __float_as_uint(b.w), qx, qy, qz);
+        }
+        if (less) best = (int)j;
+      }
+      const float4 tp = S.pt[s]; const float td = S.d[s]; const uint32_t tq = S.pos[s];
+      S.pt[s] = S.pt[best]; S.d[s] = S.d[best]; S.pos[s] = S.pos[best];
+      S.pt[best] = tp; S.d[best] = td; S.pos[best] = tq;
+      out_pos[s] = S.pos[s];
+      out_d[s] = S.d[s];
+    }
+  }
+  return true;
+}
+
+// per-pass form: the queries of the tie list (one wave each); rewrites their neighbour records
+__global__ __launch_bounds__(256) void tie_kernel(GridView G, BookView B, const float4* __restrict__ scan_sorted, PoseMats P,
+                                                  NbrRec* __restrict__ nbr, const int* __restrict__ list,
+                                                  const unsigned int* __restrict__ count, unsigned int cap) {
+  __shared__ TieLds s_t[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned n = min(*count, cap);
+  for (unsigned e = blockIdx.x * 4 + wave; e < n; e += gridDim.x * 4) {
+    const int p = list[e];
+    const float4 sp = scan_sorted[p];
+    float gx, gy, gz;
+    xform4(P.RT, sp.x, sp.y, sp.z, gx, gy, gz);
+    int4* rec = reinterpret_cast<int4*>(&nbr[p]);
+    const int4 b = rec[1];
+    uint32_t pos[8];
+    float d[8];
+    const bool ok = tie_select_wave(G, B, gx, gy, gz, __int_as_float(b.z), 5, s_t[wave], pos, d);
+    if (ok && lane == 0) {
+      rec[0] = make_int4((int)pos[0], (int)pos[1], (int)pos[2], (int)pos[3]);
+      rec[1] = make_int4((int)pos[4], b.y, b.z, 1);            // same 5th distance; the tie is settled
+    }
+    wave_lds_sync();
+  }
+}
+
+// standalone form (flimo_knn): every query, after knn_kernel
+__global__ __launch_bounds__(256) void knn_tie_kernel(GridView G, BookView B, const float* __restrict__ qxyz, int nq, int k,
+                                                      int32_t* __restrict__ idx, float* __restrict__ sqd, const int32_t* __restrict__ cnt) {
+  __shared__ TieLds s_t[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int q = blockIdx.x * 4 + wave; q < nq; q += gridDim.x * 4) {
+    if (cnt[q] != k) continue;                                 // fewer than k points in reach, or not proven exact
+    const float dk = sqd[(size_t)q * k + k - 1];
+    bool tied = false;                                         // cheap filter: a tie inside the k is visible; one at the boundary is not
+    uint32_t pos[8];
+    float d[8];
+    (void)tied;
+    const bool ok = tie_select_wave(G, B, qxyz[3 * q], qxyz[3 * q + 1], qxyz[3 * q + 2], dk, k, s_t[wave], pos, d);
+    if (ok && lane == 0) {
+      for (int s = 0; s < k; s++) { idx[(size_t)q * k + s] = (int32_t)pos[s]; sqd[(size_t)q * k + s] = d[s]; }
+    }
+    wave_lds_sync();
+  }
+}
+
+void launch_tie(hipStream_t st, const GridView& G, const BookView& B, const float4* scan_sorted, const PoseMats& P, void* nbr,
+                const TieList& tl) {
+  hipLaunchKernelGGL(tie_kernel, dim3(64), dim3(256), 0, st, G, B, scan_sorted, P, (NbrRec*)nbr, tl.list, tl.count, tl.cap);
+}
+void launch_knn_tie(hipStream_t st, const GridView& G, const BookView& B, const float* qxyz, int nq, int k, int32_t* idx, float* sqd,
+                    const int32_t* cnt) {
+  if (nq <= 0) return;
+  const int blocks = min(2048, (nq + 3) / 4);
+  hipLaunchKernelGGL(knn_tie_kernel, dim3(blocks), dim3(256), 0, st, G, B, qxyz, nq, k, idx, sqd, cnt);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1833,7 +2054,7 @@ static int g_slots = 0;   // 0: default per L; developer override through FLIMO_
 template <int L>
 static void launch_knn5_L(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const PoseMats& P,
                           int max_ring, void* nbr, int* wl, int* wl_count, unsigned long long* cand, const PrevPass& prev,
-                          int tail, hipEvent_t e0, hipEvent_t e1, const FuseArgs* fuse) {
+                          int tail, hipEvent_t e0, hipEvent_t e1, const FuseArgs* fuse, const TieList* tlp) {
   const int qpb = 256 / L;
   const int blocks = round_up8((n + qpb - 1) / qpb);
   if (g_slots == 0) { const char* e = getenv("FLIMO_SLOTS"); g_slots = e ? atoi(e) : -1; }
@@ -1845,6 +2066,7 @@ static void launch_knn5_L(hipStream_t st, const GridView& G, const float4* scan_
     }
   }
   FuseArgs nofuse{};
+  if (tlp) nofuse.tl = *tlp;
   // e0 / e1 (optional) are attached to the dispatch itself: they read the kernel's own begin / end
   // timestamps, without the extra barrier packets of hipEventRecord
   if (slots >= 8)
@@ -1857,16 +2079,16 @@ static void launch_knn5_L(hipStream_t st, const GridView& G, const float4* scan_
 
 void launch_knn5(hipStream_t st, int lanes_per_query, const GridView& G, const float4* scan_sorted, int n,
                  const PoseMats& P, int max_ring, void* nbr, int* wl, int* wl_count, unsigned long long* cand,
-                 const PrevPass& prev, int tail, hipEvent_t e0, hipEvent_t e1, const FuseArgs* fuse) {
+                 const PrevPass& prev, int tail, hipEvent_t e0, hipEvent_t e1, const FuseArgs* fuse, const TieList* tlp) {
   if (n <= 0) return;
   if (max_ring < 2 || max_ring > TAIL_MAX_RING) tail = 0;
   switch (lanes_per_query) {
-    case 1: launch_knn5_L<1>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse); break;
-    case 2: launch_knn5_L<2>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse); break;
-    case 4: launch_knn5_L<4>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse); break;
-    case 8: launch_knn5_L<8>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse); break;
-    case 32: launch_knn5_L<32>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse); break;
-    default: launch_knn5_L<16>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse); break;
+    case 1: launch_knn5_L<1>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp); break;
+    case 2: launch_knn5_L<2>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp); break;
+    case 4: launch_knn5_L<4>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp); break;
+    case 8: launch_knn5_L<8>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp); break;
+    case 32: launch_knn5_L<32>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp); break;
+    default: launch_knn5_L<16>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp); break;
   }
 }
 
@@ -1877,16 +2099,18 @@ static int widen_blocks() {
   return g_widen_blocks;
 }
 void launch_widen(hipStream_t st, const GridView& G, const float4* scan_sorted, const PoseMats& P, int max_ring, void* nbr,
-                  int* wl, int* wl_count, unsigned long long* cand, hipEvent_t e0, hipEvent_t e1) {
+                  int* wl, int* wl_count, unsigned long long* cand, hipEvent_t e0, hipEvent_t e1, const TieList* tlp) {
+  TieList tl{};
+  if (tlp) tl = *tlp;
   if (max_ring <= 1) return;
   static int tight = -1, r3 = -1;
   if (tight < 0) { const char* e = getenv("FLIMO_WIDEN_TIGHT"); tight = e ? atoi(e) : 0; e = getenv("FLIMO_WIDEN_R3"); r3 = e ? atoi(e) : 1; }   // measured at 6.6 k pending queries: 19.3 -> 16.3 us
   const int first_ring = r3 ? max_ring : 2;
   if (max_ring <= 3) {
     if (tight)
-      hipExtLaunchKernelGGL((widen_kernel<8>), dim3(widen_blocks()), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand, first_ring);
+      hipExtLaunchKernelGGL((widen_kernel<8>), dim3(widen_blocks()), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand, first_ring, tl);
     else
-      hipExtLaunchKernelGGL((widen_kernel<1>), dim3(widen_blocks()), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand, first_ring);
+      hipExtLaunchKernelGGL((widen_kernel<1>), dim3(widen_blocks()), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand, first_ring, tl);
   }
   else
     hipLaunchKernelGGL(widen_general_kernel, dim3(256), dim3(256), 0, st, G, scan_sorted, P, max_ring, (NbrRec*)nbr, wl, wl_count);
@@ -1939,15 +2163,17 @@ int fit2_blocks(int n) { const int per = 4 * fit2_ppw(); const int b = (n + per 
 
 void launch_fit2(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const void* nbr, const PoseMats& P,
                  const MatchParams& mp, const unsigned char* live_idx, double* partials, void* out_granules, unsigned int* ticket,
-                 int* wl_count, unsigned long long seq, hipEvent_t e0, hipEvent_t e1) {
+                 int* wl_count, unsigned long long seq, hipEvent_t e0, hipEvent_t e1, const TieList* tlp) {
   if (n <= 0) return;
+  TieList tl{};
+  if (tlp) tl = *tlp;
   FitIdx idx;
   for (int i = 0; i < FIT_LIVE_PAD; i++) idx.raw[i] = i < FIT_LIVE ? live_idx[i] : 0;
   const int blocks = fit2_blocks(n);
   switch (fit2_ppw()) {
-    case 64: hipExtLaunchKernelGGL((fit2_kernel<64>), dim3(blocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, idx, partials, (double2*)out_granules, ticket, wl_count, seq); break;
-    case 16: hipExtLaunchKernelGGL((fit2_kernel<16>), dim3(blocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, idx, partials, (double2*)out_granules, ticket, wl_count, seq); break;
-    default: hipExtLaunchKernelGGL((fit2_kernel<32>), dim3(blocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, idx, partials, (double2*)out_granules, ticket, wl_count, seq); break;
+    case 64: hipExtLaunchKernelGGL((fit2_kernel<64>), dim3(blocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, idx, partials, (double2*)out_granules, ticket, wl_count, seq, tl); break;
+    case 16: hipExtLaunchKernelGGL((fit2_kernel<16>), dim3(blocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, idx, partials, (double2*)out_granules, ticket, wl_count, seq, tl); break;
+    default: hipExtLaunchKernelGGL((fit2_kernel<32>), dim3(blocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, idx, partials, (double2*)out_granules, ticket, wl_count, seq, tl); break;
   }
 }
 
@@ -1955,13 +2181,15 @@ int fused_blocks(int n) { return round_up8((n + 127) / 128); }
 void launch_match_fused(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const PoseMats& P, const MatchParams& mp,
                         void* nbr, int* wl, int* wl_count, unsigned long long* cand, const PrevPass& prev,
                         const unsigned char* live_idx, double* partials, void* out_granules, unsigned int* ticket,
-                        unsigned long long seq, hipEvent_t e0, hipEvent_t e1) {
+                        unsigned long long seq, hipEvent_t e0, hipEvent_t e1, const TieList* tlp) {
   if (n <= 0) return;
   FuseArgs fa;
+  fa.tl = TieList{};
+  if (tlp) fa.tl = *tlp;
   fa.mp = mp;
   for (int i = 0; i < FIT_LIVE_PAD; i++) fa.idx.raw[i] = i < FIT_LIVE ? live_idx[i] : 0;
   fa.partials = partials; fa.granules = (double2*)out_granules; fa.ticket = ticket; fa.seq = seq;
-  launch_knn5_L<2>(st, G, scan_sorted, n, P, mp.max_ring, nbr, wl, wl_count, cand, prev, 1, e0, e1, &fa);
+  launch_knn5_L<2>(st, G, scan_sorted, n, P, mp.max_ring, nbr, wl, wl_count, cand, prev, 1, e0, e1, &fa, nullptr);
 }
 
 void launch_reduce_final(hipStream_t st, const double* partials, int nparts, double* out256) {

@@ -148,6 +148,9 @@ def test_config2_sequence_64_scans_65k_points_rolling_map(built, oracle):
           "%d index merges, %d full builds, %d of %d passes in one launch"
           % (n_scans, n_pts, prime.shape[0], G.map_size(), worst[0], worst[1], merges, builds,
              G.hip.fused_pass_count() - fused0, G.hip.pass_count()))
+    ts = G.hip.tie_stats()
+    print("exact distance ties settled the reference's way: %d queries in %d passes (of %d passes, %d queries each)"
+          % (ts["queries_settled"], ts["passes_redone"], G.hip.pass_count(), n_pts))
     devs = np.array(devs)
     print("per-scan |dpos|: median %.2e, scans above 1e-9: %d, above 1e-7: %d" % (np.median(devs), int((devs > 1e-9).sum()), int((devs > 1e-7).sum())))
     assert np.median(devs) <= 1e-7      # maps are built by each side from its own poses: 1e-13 differences reach the float32 map points
