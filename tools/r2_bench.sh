@@ -10,7 +10,7 @@ import json, sys
 try:
     d = json.load(open(sys.argv[1]))
     r = d["roofline"]; s = r.get("stage", {}); e = d.get("end_to_end") or {}
-    print(f"{sys.argv[2]:24s} value {d['value']:8.1f}  ms/step {d['ms_per_step']:.4f}  one-launch {s.get('one_launch_pass_us')}  separate {s.get('separate_dispatch_pass_us')}  frac {r.get('frac')}  e2e tied {e.get('tied_stamps',{}).get('ms_per_sweep')} unique {e.get('unique_stamps',{}).get('ms_per_sweep')}")
+    print(f"{sys.argv[2]:24s} value {d['value']:8.1f}  ms/step {d['ms_per_step']:.4f}  one-launch {r.get('mean_launch_us')}  separate {s.get('separate_dispatch_pass_us')}  frac {r.get('frac')}  e2e tied {e.get('tied_stamps',{}).get('ms_per_sweep')} unique {e.get('unique_stamps',{}).get('ms_per_sweep')}")
 except Exception as ex:
     print(sys.argv[2], "FAILED", ex); print(open(sys.argv[1].replace('.json', '.err')).read()[-1500:])
 PY

@@ -22,3 +22,17 @@ for r in rows[:7]:
     print(f'{name:40s} calls {r["Calls"]:>5s} avg {float(r["AverageNs"])/1e3:8.2f} us  min {float(r["MinNs"])/1e3:7.2f}  max {float(r["MaxNs"])/1e3:7.2f}  {r["Percentage"]:>6s}%')
 PY
 head -c 1500 gpurun_out/bench_$tag.json; echo
+# k-NN stage on its own: the same command with the pass split into dispatches (A/B switch)
+cd /tmp
+rm -rf $root/gpurun_out/prof_${tag}_nofuse
+FLIMO_FUSE=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/prof_${tag}_nofuse -- python3 $root/bench.py $args > /dev/null 2>&1
+cd $root
+f=$(find gpurun_out/prof_${tag}_nofuse -name "*kernel_stats.csv" | head -1)
+cp $f gpurun_out/bench_${tag}_nofuse_kernel_stats.csv
+python3 - "$f" <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+for r in rows[:6]:
+    name = r["Name"].replace("void ", "").replace("flimo::", "")[:40]
+    print(f'FUSE=0  {name:40s} calls {r["Calls"]:>5s} avg {float(r["AverageNs"])/1e3:8.2f} us  min {float(r["MinNs"])/1e3:7.2f}  max {float(r["MaxNs"])/1e3:7.2f}')
+PY
