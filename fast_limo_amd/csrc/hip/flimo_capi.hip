@@ -132,7 +132,12 @@ struct flimo_ctx {
   bool prune = true;               // FLIMO_PRUNE=0 disables the bound (A/B checks)
   int tail_pass1 = -1;             // FLIMO_TAIL_PASS1: 1 = the first pass of a scan always uses the in-kernel tail, 0 = never, default: by the straggler count of the last first pass
   int stragglers_pass1 = 1 << 30;  // queries of the last first pass of a scan that needed more than their 3x3x3 block (unknown: many)
+  int stragglers_hist[4] = {1 << 30, 0, 0, 0};   // the same per pass position within a scan (0 = first pass .. 3 = fourth and later), last scan that reported
+  int pass_in_scan = 0;
   int last_stragglers = -1;        // the same of the last pass (-1: not reported by that pass's path)
+  int xslabs = 1;                  // FLIMO_XSLABS: fine columns per cell along x (1, 2, 4, 8; power of two).  4 trims the candidate
+                                   // stream of a pruned pass by a quarter (-2 % pass time) and crowded cells by 25-30 %, but makes both
+                                   // tables and every index update 4x larger (+0.15 ms per 64k-point insert at 1M points): off by default
   int* d_tie_list = nullptr;       // queries of a pass whose five hinge on an exact distance tie (capacity = scan capacity)
   unsigned int* d_tie_count = nullptr;   // [2]: alternating by pass number (the pass's reduction re-arms the next one's)
   size_t tie_cap = 0;
@@ -306,6 +311,8 @@ extern "C" int flimo_ctx_create(int device, flimo_ctx** out) {
   c->book = insert_book_create();
   e = getenv("FLIMO_PRUNE");
   if (e) c->prune = atoi(e) != 0;
+  e = getenv("FLIMO_XSLABS");
+  if (e) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) c->xslabs = v; }
   e = getenv("FLIMO_TIES");
   if (e) c->ties = atoi(e) != 0;
   e = getenv("FLIMO_GENERAL_K");
@@ -427,10 +434,10 @@ static int rebuild_grid(flimo_ctx* c) {
     c->grid_valid = false;
     if (!c->d_map_sorted2) HIPCHK(c, hipMalloc(&c->d_map_sorted2, c->map_cap * sizeof(float4)));
     const GridView& g = c->grid;
-    const size_t ncells = (size_t)g.nx * g.ny * g.nz;
+    const size_t ncells = (size_t)g.nxf * g.ny * g.nz;
     HIPCHK(c, map_merge_grid(c->stream, c->d_map_sorted, n_old, c->d_map_raw + n_old, k, c->d_map_sorted2, c->d_cell_start, ncells,
-                             g.ox, g.oy, g.oz, g.inv_cell, g.nx, g.ny, g.nz, c->scratch));
-    int rc = publish_row_table(c, g.nx, g.ny, g.nz, true);
+                             g.ox, g.oy, g.oz, g.inv_cell, g.nx, g.ny, g.nz, g.xs, c->scratch));
+    int rc = publish_row_table(c, g.nxf, g.ny, g.nz, true);
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     std::swap(c->d_map_sorted, c->d_map_sorted2);
@@ -451,6 +458,7 @@ static int rebuild_grid(flimo_ctx* c) {
   int nx = 0, ny = 0, nz = 0;
   float ox = 0.f, oy = 0.f, oz = 0.f, inv = 1.f;
   float W[6];
+  int xs = c->xslabs;
   auto layout = [&](const float* box) {
     inv = 1.0f / cell;
     ox = box[0] - 0.5f * cell; oy = box[1] - 0.5f * cell; oz = box[2] - 0.5f * cell;
@@ -458,8 +466,13 @@ static int rebuild_grid(flimo_ctx* c) {
     nx = (int)floorf((box[3] - ox) * inv) + 2;
     ny = (int)floorf((box[4] - oy) * inv) + 2;
     nz = (int)floorf((box[5] - oz) * inv) + 2;
-    const double ncells = (double)nx * ny * nz;
-    return ncells < 1.9e9 && (double)row_table_size(nx, ny, nz) < 4.0e9;   // both indices stay 32-bit addressable
+    // both indices stay 32-bit addressable; the fine x columns are given up first (xs = preferred .. 1), then the cell grows
+    for (xs = c->xslabs; xs >= 1; xs >>= 1) {
+      const double ncols = (double)nx * xs * ny * nz;
+      if (ncols < 1.9e9 && (double)row_table_size(nx * xs, ny, nz) < 4.0e9) return true;
+    }
+    xs = 1;
+    return false;
   };
   // slack: a side the map has grown beyond since the last layout moves out by max(8 cells, 1/8 of the extent)
   for (int a = 0; a < 3; a++) { W[a] = bb[a]; W[3 + a] = bb[3 + a]; }
@@ -480,7 +493,7 @@ static int rebuild_grid(flimo_ctx* c) {
   }
   for (int a = 0; a < 6; a++) c->gbox[a] = W[a];
   c->have_gbox = true;
-  const size_t ncells = (size_t)nx * ny * nz;
+  const size_t ncells = (size_t)nx * xs * ny * nz;      // columns
   if (!c->d_map_sorted) HIPCHK(c, hipMalloc(&c->d_map_sorted, c->map_cap * sizeof(float4)));   // mirrors the raw capacity (freed whenever that grows)
   if (ncells + 1 > c->cell_cap) {
     if (c->d_cell_start) (void)hipFree(c->d_cell_start);
@@ -490,9 +503,9 @@ static int rebuild_grid(flimo_ctx* c) {
     c->cell_cap = cap;
   }
   HIPCHK(c, map_build_grid(c->stream, c->d_map_raw, c->map_n, c->d_map_sorted, c->d_cell_start, ncells, ox, oy, oz, inv,
-                           nx, ny, nz, c->scratch));
+                           nx, ny, nz, xs, c->scratch));
   {
-    int rc = publish_row_table(c, nx, ny, nz, false);
+    int rc = publish_row_table(c, nx * xs, ny, nz, false);
     if (rc) return rc;
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -503,6 +516,7 @@ static int rebuild_grid(flimo_ctx* c) {
   c->grid.inv_cell = inv;
   c->grid.cell = cell;
   c->grid.nx = nx; c->grid.ny = ny; c->grid.nz = nz;
+  c->grid.xs = xs; c->grid.nxf = nx * xs;
   c->grid.n_pts = (uint32_t)c->map_n;
   c->grid_valid = true;
   c->force_full = false;
@@ -519,7 +533,7 @@ extern "C" int flimo_map_grid_selfcheck(flimo_ctx* c, uint64_t* mismatches, uint
   if (!c->grid_valid) return FLIMO_OK;
   (void)hipSetDevice(c->device);
   const GridView& g = c->grid;
-  const size_t n = c->map_n, ncells = (size_t)g.nx * g.ny * g.nz, rt = row_table_size(g.nx, g.ny, g.nz);
+  const size_t n = c->map_n, ncells = (size_t)g.nxf * g.ny * g.nz, rt = row_table_size(g.nxf, g.ny, g.nz);
   if (g.n_pts != n) { *mismatches = 1; return FLIMO_OK; }
   struct Tmp {
     float4* pts = nullptr; uint32_t* cs = nullptr; uint32_t* row = nullptr;
@@ -528,8 +542,8 @@ extern "C" int flimo_map_grid_selfcheck(flimo_ctx* c, uint64_t* mismatches, uint
   HIPCHK(c, hipMalloc(&t.pts, n * sizeof(float4)));
   HIPCHK(c, hipMalloc(&t.cs, (ncells + 1) * sizeof(uint32_t)));
   HIPCHK(c, hipMalloc(&t.row, rt * sizeof(uint32_t)));
-  HIPCHK(c, map_build_grid(c->stream, c->d_map_raw, n, t.pts, t.cs, ncells, g.ox, g.oy, g.oz, g.inv_cell, g.nx, g.ny, g.nz, c->scratch));
-  HIPCHK(c, map_build_row_table(c->stream, t.cs, g.nx, g.ny, g.nz, t.row));
+  HIPCHK(c, map_build_grid(c->stream, c->d_map_raw, n, t.pts, t.cs, ncells, g.ox, g.oy, g.oz, g.inv_cell, g.nx, g.ny, g.nz, g.xs, c->scratch));
+  HIPCHK(c, map_build_row_table(c->stream, t.cs, g.nxf, g.ny, g.nz, t.row));
   auto differ = [&](const void* a, const void* b, size_t bytes, uint64_t& out) -> int {
     std::vector<unsigned char> ha(bytes), hb(bytes);
     HIPCHK(c, hipMemcpyAsync(ha.data(), a, bytes, hipMemcpyDeviceToHost, c->stream));
@@ -1146,7 +1160,11 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   // worklist dispatch.  With a good prior (the usual case in a sequence) the first pass has a handful of stragglers like any
   // other: the count every pass publishes with its result decides for the next scan.
   const bool first_pass = !c->prev.valid;
-  const bool tail_here = !first_pass || (c->tail_pass1 >= 0 ? c->tail_pass1 != 0 : c->stragglers_pass1 <= 1024);
+  c->pass_in_scan = first_pass ? 0 : std::min(c->pass_in_scan + 1, 3);
+  // later passes likewise, by the count the pass at the same position of the last scan published: a sparse far range (256k-point
+  // sweeps over a 900 m map) keeps thousands of points beyond their 3x3x3 block in every pass
+  const bool tail_here = first_pass ? (c->tail_pass1 >= 0 ? c->tail_pass1 != 0 : c->stragglers_hist[0] <= 1024)
+                                    : (c->stragglers_hist[c->pass_in_scan] <= 1024);
   const bool tail = c->tail && tail_here && !heavy_on && mp.max_ring >= 2 && mp.max_ring <= 3;
   c->prev.heavy = (!tail && mp.max_ring >= 2 && mp.max_ring <= 3) ? c->heavy_threshold : 0xffffffffu;   // only when the wave-per-query kernel follows
   // One launch for the whole pass (k-NN + tail + fit + reduction) whenever the tail applies, no records are wanted and the
@@ -1233,6 +1251,7 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
     { const int rcw = wait_granules(seq); if (rcw) return rcw; }
     c->last_stragglers = (int)llround(c->h_granules[2 * FIT_LIVE]);
     if (first_pass) c->stragglers_pass1 = c->last_stragglers;
+    c->stragglers_hist[c->pass_in_scan] = c->last_stragglers;
     const long n_ties = (long)llround(c->h_granules[2 * (FIT_LIVE + 1)]);
     if (n_ties > 0 && ties_on) {
       // A few queries' five hinge on an exact float32 distance tie: settle them the reference's way (tie_kernel), then build the

@@ -96,13 +96,13 @@ hipError_t map_bbox(hipStream_t st, const float4* pts, size_t n, MapBuildScratch
 hipError_t sort_scan(hipStream_t st, const float4* in, size_t n, float4* out, MapBuildScratch& S,
                      const double* t_in = nullptr, double* t_out = nullptr);
 hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4* pts_out, uint32_t* cell_start,
-                          size_t ncells, float ox, float oy, float oz, float inv_cell, int nx, int ny, int nz,
-                          MapBuildScratch& S);
+                          size_t ncells, float ox, float oy, float oz, float inv_cell, int nx, int ny, int nz, int xs,
+                          MapBuildScratch& S);    // ncells = nx * xs * ny * nz columns
 // Merges the k points appended since the last build into the cell-sorted array (same geometry): out_sorted and cell_start
 // become what map_build_grid gives for all n_old + k points.  cell_start is updated in place; out_sorted != old_sorted.
 hipError_t map_merge_grid(hipStream_t st, const float4* old_sorted, size_t n_old, const float4* new_pts, size_t k,
                           float4* out_sorted, uint32_t* cell_start, size_t ncells, float ox, float oy, float oz,
-                          float inv_cell, int nx, int ny, int nz, MapBuildScratch& S);
+                          float inv_cell, int nx, int ny, int nz, int xs, MapBuildScratch& S);
 // Input filters of a raw sweep (32-byte PointType records already on the device): NaN removal, crop box, every rate-th survivor,
 // min distance; order preserved.  out[k] = (xyz, w = k), t_out[k] = stamp without the sweep offset; ext_dev[3] = {extreme ordered
 // stamp key (complemented when the sweep is sorted descending), kept count, "a kept stamp is NaN"}.

@@ -114,11 +114,11 @@ FLIMO_DEV void visit_row(const GridView& G, int cx, int cy, int cz, int dy, int 
   const float a = fmaxf(slab_dist(dy, ry) - margin, 0.f), b = fmaxf(slab_dist(dz, rz) - margin, 0.f);
   const float yz2 = a * a + b * b;
   if (yz2 * cell2 >= fminf(bound, R.bd[K - 1])) return;   // the whole row is farther than the current 5th best
-  const size_t rowbase = ((size_t)(cz + dz) * (size_t)G.ny + (size_t)(cy + dy)) * (size_t)G.nx;
+  const size_t rowbase = ((size_t)(cz + dz) * (size_t)G.ny + (size_t)(cy + dy)) * (size_t)G.nxf;
   if (max(abs(dy), abs(dz)) > r_prev) {
     const int x0 = max(cx - r, 0), x1 = min(cx + r, G.nx - 1);
     if (x0 <= x1) {
-      const uint32_t lo = G.cell_start[rowbase + x0], hi = G.cell_start[rowbase + x1 + 1];
+      const uint32_t lo = G.cell_start[rowbase + (size_t)x0 * G.xs], hi = G.cell_start[rowbase + (size_t)(x1 + 1) * G.xs];
       scan_range<L, K>(G.pts, lo, hi, sub, gx, gy, gz, R.bd, R.bi, R.cand);
     }
   } else {
@@ -127,7 +127,7 @@ FLIMO_DEV void visit_row(const GridView& G, int cx, int cy, int cz, int dy, int 
       const int x0 = max(cx - r, 0), x1 = min(cx - r_prev - 1, G.nx - 1);
       const float sx = fmaxf(slab_dist(-(r_prev + 1), rx) - margin, 0.f);
       if (x0 <= x1 && (sx * sx + yz2) * cell2 < fminf(bound, R.bd[K - 1])) {
-        const uint32_t lo = G.cell_start[rowbase + x0], hi = G.cell_start[rowbase + x1 + 1];
+        const uint32_t lo = G.cell_start[rowbase + (size_t)x0 * G.xs], hi = G.cell_start[rowbase + (size_t)(x1 + 1) * G.xs];
         scan_range<L, K>(G.pts, lo, hi, sub, gx, gy, gz, R.bd, R.bi, R.cand);
       }
     }
@@ -135,7 +135,7 @@ FLIMO_DEV void visit_row(const GridView& G, int cx, int cy, int cz, int dy, int 
       const int x0 = max(cx + r_prev + 1, 0), x1 = min(cx + r, G.nx - 1);
       const float sx = fmaxf(slab_dist(r_prev + 1, rx) - margin, 0.f);
       if (x0 <= x1 && (sx * sx + yz2) * cell2 < fminf(bound, R.bd[K - 1])) {
-        const uint32_t lo = G.cell_start[rowbase + x0], hi = G.cell_start[rowbase + x1 + 1];
+        const uint32_t lo = G.cell_start[rowbase + (size_t)x0 * G.xs], hi = G.cell_start[rowbase + (size_t)(x1 + 1) * G.xs];
         scan_range<L, K>(G.pts, lo, hi, sub, gx, gy, gz, R.bd, R.bi, R.cand);
       }
     }
@@ -193,9 +193,9 @@ FLIMO_DEV void knn_search(const GridView& G, float gx, float gy, float gz, int s
         const int dz = (t / 3 == 0) ? 0 : ((t / 3 == 1) ? -1 : 1);
         const int yy = cy + dy, zz = cz + dz;
         const bool in = (yy >= 0) && (yy < G.ny) && (zz >= 0) && (zz < G.nz) && (x0 <= x1);
-        const size_t rowbase = ((size_t)(in ? zz : 0) * (size_t)G.ny + (size_t)(in ? yy : 0)) * (size_t)G.nx;
-        lo[t] = in ? G.cell_start[rowbase + x0] : 0u;
-        hi[t] = in ? G.cell_start[rowbase + x1 + 1] : 0u;
+        const size_t rowbase = ((size_t)(in ? zz : 0) * (size_t)G.ny + (size_t)(in ? yy : 0)) * (size_t)G.nxf;
+        lo[t] = in ? G.cell_start[rowbase + (size_t)x0 * G.xs] : 0u;
+        hi[t] = in ? G.cell_start[rowbase + (size_t)(x1 + 1) * G.xs] : 0u;
       }
 #pragma unroll
       for (int t = 0; t < 9; t++) {
@@ -539,9 +539,9 @@ __device__ __forceinline__ void knn5_tail(const GridView& G, int max_ring, NbrRe
                 const int dl = (int)fminf(floorf(fminf(xr + (1.f - rx), 1.0e6f)), (float)r);
                 const int x0 = max(cx - dl, 0), x1 = min(cx + dr, G.nx - 1);
                 if (x0 <= x1) {
-                  const size_t rowbase = ((size_t)zz * (size_t)G.ny + (size_t)yy) * (size_t)G.nx;
-                  lo4[u] = G.cell_start[rowbase + x0];
-                  hi4[u] = G.cell_start[rowbase + x1 + 1];
+                  const size_t rowbase = ((size_t)zz * (size_t)G.ny + (size_t)yy) * (size_t)G.nxf;
+                  lo4[u] = G.cell_start[rowbase + (size_t)x0 * G.xs];
+                  hi4[u] = G.cell_start[rowbase + (size_t)(x1 + 1) * G.xs];
                 }
               }
             }
@@ -697,57 +697,54 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
     } else if (r0 > 1) {
       flag = 2;                       // outside the grid but within reach: general search
     } else {
-      // ---- range bounds of the 9 rows x 3 cells: twelve 12-byte loads from the y-fastest, padded row table
-      //      (x planes cx-1 .. cx+2, clamped: a plane index outside the grid yields an empty cell) ----
+      // ---- range bounds of the 9 rows: six 12-byte loads from the y-fastest, padded row table -- two x planes (first column of
+      //      the rows' x range, one past its last) x three z, each load covering the three y neighbours.  The table is kept at
+      //      FINE column resolution along x (G.xs columns per cell): without a bound the range is the three cells (columns
+      //      (cx-1) xs .. (cx+2) xs), with the bound of the previous pass only the columns its ball can reach --
+      //      |x_point - x_query| <= sqrt(b2) in cell units, widened by the rounding margin -- clipped to the three cells (the
+      //      exactness proof below is about the 3x3x3 block).  The same columns for all nine rows; rows the ball cannot reach
+      //      at all are dropped as before. ----
       // (32-bit table indices: the host keeps the table below 2^32 entries)
-      const uint32_t py = (uint32_t)G.ny + 4u, plane = py * ((uint32_t)G.nz + 4u);
-      const uint32_t yz = (uint32_t)(cz + 1) * py + (uint32_t)(cy + 1);
-      U3 rb[4][3];
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const uint32_t xp = (uint32_t)min(max(cx - 1 + k, 0), G.nx);
-        const uint32_t i0 = xp * plane + yz;
-#pragma unroll
-        for (int dz = 0; dz < 3; dz++) rb[k][dz] = *reinterpret_cast<const U3*>(G.row_table + (i0 + (uint32_t)dz * py));
-      }
-      // position inside the cell and the conservative distances (cell units) to the neighbouring cells
       const float rx = fminf(fmaxf(fx - flx, 0.f), 1.f), ry = fminf(fmaxf(fy - fly, 0.f), 1.f),
                   rz = fminf(fmaxf(fz - flz, 0.f), 1.f);
       const int maxdim = max(G.nx, max(G.ny, G.nz));
       const float margin = 1.0e-3f + 4.0e-7f * (float)maxdim;
-      uint32_t off[10], dl[9];          // dl[t] = lo[t] - off[t]: stream position -> map position
-      off[0] = 0;
-      if (!prev.valid) {
-        // first pass of a scan (kernel-uniform): no bound, every row is the full three cells
+      int c0 = (cx - 1) * G.xs, c1 = (cx + 2) * G.xs;          // first column, one past the last
+      if (prev.valid && b2 < 1.0e6f) {
+        const float rb_ = fl_sqrt(b2) + margin;                 // reach along x in cell units (b2 is already inflated)
+        const float fxs = (float)G.xs;
+        c0 = max(c0, (int)floorf((fx - rb_) * fxs));
+        c1 = min(c1, (int)floorf((fx + rb_) * fxs) + 1);
+      }
+      c0 = min(max(c0, 0), G.nxf);
+      c1 = min(max(c1, c0), G.nxf);
+      const uint32_t py = (uint32_t)G.ny + 4u, plane = py * ((uint32_t)G.nz + 4u);
+      const uint32_t yz = (uint32_t)(cz + 1) * py + (uint32_t)(cy + 1);
+      U3 rbl[3], rbh[3];
+      {
+        const uint32_t iL = (uint32_t)c0 * plane + yz, iH = (uint32_t)c1 * plane + yz;
 #pragma unroll
         for (int dz = 0; dz < 3; dz++) {
-          const uint32_t s0[3] = {rb[0][dz].a, rb[0][dz].b, rb[0][dz].c}, s3[3] = {rb[3][dz].a, rb[3][dz].b, rb[3][dz].c};
-#pragma unroll
-          for (int k = 0; k < 3; k++) {
-            const int t = 3 * dz + k;
-            dl[t] = s0[k] - off[t];
-            off[t + 1] = off[t] + (s3[k] - s0[k]);
-          }
+          rbl[dz] = *reinterpret_cast<const U3*>(G.row_table + (iL + (uint32_t)dz * py));
+          rbh[dz] = *reinterpret_cast<const U3*>(G.row_table + (iH + (uint32_t)dz * py));
         }
-      } else {
-        const float xl = fmaxf(rx - margin, 0.f), xr = fmaxf(1.f - rx - margin, 0.f);
-        const float xl2 = xl * xl, xr2 = xr * xr;
+      }
+      uint32_t off[10], dl[9];          // dl[t] = lo[t] - off[t]: stream position -> map position
+      off[0] = 0;
+      {
+        // conservative distances (cell units) to the neighbouring rows; without a bound every row is in
         const float yd[3] = {fmaxf(ry - margin, 0.f), 0.f, fmaxf(1.f - ry - margin, 0.f)};
         const float zd[3] = {fmaxf(rz - margin, 0.f), 0.f, fmaxf(1.f - rz - margin, 0.f)};
         const float yd2[3] = {yd[0] * yd[0], 0.f, yd[2] * yd[2]}, zd2[3] = {zd[0] * zd[0], 0.f, zd[2] * zd[2]};
 #pragma unroll
         for (int dz = 0; dz < 3; dz++) {
-          const uint32_t s0[3] = {rb[0][dz].a, rb[0][dz].b, rb[0][dz].c}, s1[3] = {rb[1][dz].a, rb[1][dz].b, rb[1][dz].c};
-          const uint32_t s2[3] = {rb[2][dz].a, rb[2][dz].b, rb[2][dz].c}, s3[3] = {rb[3][dz].a, rb[3][dz].b, rb[3][dz].c};
+          const uint32_t sl[3] = {rbl[dz].a, rbl[dz].b, rbl[dz].c}, sh[3] = {rbh[dz].a, rbh[dz].b, rbh[dz].c};
 #pragma unroll
           for (int k = 0; k < 3; k++) {
             const int t = 3 * dz + k;
-            const float dyz2 = yd2[k] + zd2[dz];
-            const bool row = dyz2 <= b2;
-            const bool left = dyz2 + xl2 <= b2, right = dyz2 + xr2 <= b2;
-            const uint32_t lo = left ? s0[k] : s1[k], hi = right ? s3[k] : s2[k];
-            dl[t] = lo - off[t];
-            off[t + 1] = off[t] + (row ? hi - lo : 0u);
+            const bool row = !prev.valid || (yd2[k] + zd2[dz] <= b2);
+            dl[t] = sl[k] - off[t];
+            off[t + 1] = off[t] + (row ? sh[k] - sl[k] : 0u);
           }
         }
       }
@@ -935,9 +932,9 @@ __global__ __launch_bounds__(256, WPS) void widen_kernel(GridView G, const float
           if (!(dyz2 <= b2)) x1 = x0 - 1;                 // empty row
         }
         if (yy >= 0 && yy < G.ny && zz >= 0 && zz < G.nz && x0 <= x1) {
-          const size_t rowbase = ((size_t)zz * (size_t)G.ny + (size_t)yy) * (size_t)G.nx;
-          lo = G.cell_start[rowbase + x0];
-          len = G.cell_start[rowbase + x1 + 1] - lo;
+          const size_t rowbase = ((size_t)zz * (size_t)G.ny + (size_t)yy) * (size_t)G.nxf;
+          lo = G.cell_start[rowbase + (size_t)x0 * G.xs];
+          len = G.cell_start[rowbase + (size_t)(x1 + 1) * G.xs] - lo;
         }
       }
       // inclusive prefix sum over the wave
@@ -1494,8 +1491,8 @@ __device__ bool tie_select_wave(const GridView& G, const BookView& B, float qx, 
       const int dl = (int)fminf(floorf(fminf(xr + (1.f - rx), 1.0e6f)), (float)r);
       const int x0 = max(cx - dl, 0), x1 = min(cx + dr, G.nx - 1);
       if (x0 <= x1) {
-        const size_t rowbase = ((size_t)zz * (size_t)G.ny + (size_t)yy) * (size_t)G.nx;
-        const uint32_t lo = G.cell_start[rowbase + x0], hi = G.cell_start[rowbase + x1 + 1];
+        const size_t rowbase = ((size_t)zz * (size_t)G.ny + (size_t)yy) * (size_t)G.nxf;
+        const uint32_t lo = G.cell_start[rowbase + (size_t)x0 * G.xs], hi = G.cell_start[rowbase + (size_t)(x1 + 1) * G.xs];
         for (uint32_t i = lo; i < hi; i++) {
           const float4 p = G.pts[i];
           const float d = sqdist3(qx, qy, qz, p.x, p.y, p.z);

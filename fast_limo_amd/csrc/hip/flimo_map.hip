@@ -55,20 +55,24 @@ __global__ __launch_bounds__(256) void bbox_kernel(const float4* __restrict__ pt
   }
 }
 
+// column key of a point: (z, y, fine x column).  The fine column is floor(t * xs) of the SAME rounded t = (p.x - ox) * inv_cell whose
+// floor is the cell (xs is a power of two: the product is exact), so columns nest in cells exactly.
+__device__ __forceinline__ uint32_t column_key(const float4& p, float ox, float oy, float oz, float inv_cell, int nx, int ny, int nz, int xs) {
+  const float tx = (p.x - ox) * inv_cell;     // identical float expression to the query side (flimo_kernels.hip: knn_search)
+  int cx = (int)floorf(fminf(fmaxf(tx * (float)xs, -1.0e9f), 1.0e9f));
+  int cy = (int)floorf((p.y - oy) * inv_cell);
+  int cz = (int)floorf((p.z - oz) * inv_cell);
+  cx = min(max(cx, 0), nx * xs - 1);
+  cy = min(max(cy, 0), ny - 1);
+  cz = min(max(cz, 0), nz - 1);
+  return (uint32_t)(((size_t)cz * ny + cy) * ((size_t)nx * xs) + cx);
+}
 __global__ __launch_bounds__(256) void cellkey_kernel(const float4* __restrict__ pts, size_t n, float ox, float oy,
-                                                      float oz, float inv_cell, int nx, int ny, int nz,
+                                                      float oz, float inv_cell, int nx, int ny, int nz, int xs,
                                                       uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const float4 p = pts[i];
-  // identical float expression to the query side (flimo_kernels.hip: knn_search)
-  int cx = (int)floorf((p.x - ox) * inv_cell);
-  int cy = (int)floorf((p.y - oy) * inv_cell);
-  int cz = (int)floorf((p.z - oz) * inv_cell);
-  cx = min(max(cx, 0), nx - 1);
-  cy = min(max(cy, 0), ny - 1);
-  cz = min(max(cz, 0), nz - 1);
-  keys[i] = (uint32_t)(((size_t)cz * ny + cy) * nx + cx);
+  keys[i] = column_key(pts[i], ox, oy, oz, inv_cell, nx, ny, nz, xs);
   vals[i] = (uint32_t)i;
 }
 
@@ -121,13 +125,13 @@ hipError_t map_bbox(hipStream_t st, const float4* pts, size_t n, MapBuildScratch
 }
 
 hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4* pts_out, uint32_t* cell_start,
-                          size_t ncells, float ox, float oy, float oz, float inv_cell, int nx, int ny, int nz,
+                          size_t ncells, float ox, float oy, float oz, float inv_cell, int nx, int ny, int nz, int xs,
                           MapBuildScratch& S) {
   hipError_t e = ensure_scratch(S, n);
   if (e != hipSuccess) return e;
   const int blocks = (int)((n + 255) / 256);
   if (blocks > 0)
-    hipLaunchKernelGGL(cellkey_kernel, dim3(blocks), dim3(256), 0, st, pts_in, n, ox, oy, oz, inv_cell, nx, ny, nz,
+    hipLaunchKernelGGL(cellkey_kernel, dim3(blocks), dim3(256), 0, st, pts_in, n, ox, oy, oz, inv_cell, nx, ny, nz, xs,
                        S.keys_in, S.vals_in);
   // number of key bits actually used
   int bits = 1;
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(256) void merge_new_kernel(const float4* __restrict
 // stored point i (cell-sorted) -> i + #new points in cells < its cell
 __global__ __launch_bounds__(256) void merge_old_kernel(const float4* __restrict__ old_pts, uint32_t n_old,
                                                         const uint32_t* __restrict__ nkeys, uint32_t k, float ox, float oy, float oz,
-                                                        float inv_cell, int nx, int ny, int nz, float4* __restrict__ out) {
+                                                        float inv_cell, int nx, int ny, int nz, int xs, float4* __restrict__ out) {
   __shared__ uint32_t s_lo, s_hi;
   const uint32_t base = blockIdx.x * blockDim.x;
   const uint32_t i = base + threadIdx.x;
@@ -198,13 +202,7 @@ __global__ __launch_bounds__(256) void merge_old_kernel(const float4* __restrict
   uint32_t cid = 0;
   if (i < n_old) {
     p = old_pts[i];
-    int cx = (int)floorf((p.x - ox) * inv_cell);
-    int cy = (int)floorf((p.y - oy) * inv_cell);
-    int cz = (int)floorf((p.z - oz) * inv_cell);
-    cx = min(max(cx, 0), nx - 1);
-    cy = min(max(cy, 0), ny - 1);
-    cz = min(max(cz, 0), nz - 1);
-    cid = (uint32_t)(((size_t)cz * ny + cy) * nx + cx);
+    cid = column_key(p, ox, oy, oz, inv_cell, nx, ny, nz, xs);
     if (i == base) s_lo = lower_bound_u32(nkeys, 0u, k, cid);
     if (i == last) s_hi = lower_bound_u32(nkeys, 0u, k, cid + 1u);
   }
@@ -237,12 +235,12 @@ __global__ __launch_bounds__(256) void cellstart_shift_kernel(uint32_t* __restri
 }
 hipError_t map_merge_grid(hipStream_t st, const float4* old_sorted, size_t n_old, const float4* new_pts, size_t k,
                           float4* out_sorted, uint32_t* cell_start, size_t ncells, float ox, float oy, float oz,
-                          float inv_cell, int nx, int ny, int nz, MapBuildScratch& S) {
+                          float inv_cell, int nx, int ny, int nz, int xs, MapBuildScratch& S) {
   if (k == 0) return hipSuccess;
   hipError_t e = ensure_scratch(S, k);
   if (e != hipSuccess) return e;
   const int kb = (int)((k + 255) / 256);
-  hipLaunchKernelGGL(cellkey_kernel, dim3(kb), dim3(256), 0, st, new_pts, k, ox, oy, oz, inv_cell, nx, ny, nz, S.keys_in, S.vals_in);
+  hipLaunchKernelGGL(cellkey_kernel, dim3(kb), dim3(256), 0, st, new_pts, k, ox, oy, oz, inv_cell, nx, ny, nz, xs, S.keys_in, S.vals_in);
   int bits = 1;
   while (bits < 32 && ((size_t)1 << bits) < ncells) bits++;
   size_t tmp_bytes = 0;
@@ -259,7 +257,7 @@ hipError_t map_merge_grid(hipStream_t st, const float4* old_sorted, size_t n_old
   hipLaunchKernelGGL(merge_new_kernel, dim3(kb), dim3(256), 0, st, new_pts, S.keys_out, S.vals_out, (uint32_t)k, cell_start, out_sorted);
   if (n_old > 0)
     hipLaunchKernelGGL(merge_old_kernel, dim3((unsigned)((n_old + 255) / 256)), dim3(256), 0, st, old_sorted, (uint32_t)n_old,
-                       S.keys_out, (uint32_t)k, ox, oy, oz, inv_cell, nx, ny, nz, out_sorted);
+                       S.keys_out, (uint32_t)k, ox, oy, oz, inv_cell, nx, ny, nz, xs, out_sorted);
   hipLaunchKernelGGL(cellstart_shift_kernel, dim3((unsigned)((ncells + 1 + 4095) / 4096)), dim3(256), 0, st, cell_start, ncells + 1,
                      S.keys_out, (uint32_t)k);
   return hipGetLastError();

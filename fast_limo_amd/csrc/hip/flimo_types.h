@@ -11,15 +11,19 @@ namespace flimo {
 // three x-adjacent cells of a row are ONE contiguous range of `pts`.
 struct GridView {
   const float4* pts;           // [n_pts]  sorted by cell id
-  const uint32_t* cell_start;  // [nx*ny*nz + 1]  exclusive prefix of per-cell counts
-  const uint32_t* row_table;   // [(nx+1)][nz+4][ny+4], y fastest, two empty cells of padding on both sides of y and z:
-                               // row_table[x][z+2][y+2] = cell_start of cell (x,y,z); plane x = nx holds the row ends.
+  const uint32_t* cell_start;  // [nxf*ny*nz + 1]  exclusive prefix of per-column counts (column = cell / xs along x)
+  const uint32_t* row_table;   // [(nxf+1)][nz+4][ny+4], y fastest, two empty cells of padding on both sides of y and z:
+                               // row_table[xf][z+2][y+2] = cell_start of column (xf,y,z); plane xf = nxf holds the row ends.
                                // The 3 y-neighbours of a row bound are 12 contiguous bytes (fast path of the k-NN).
   float ox, oy, oz;            // min corner of cell (0,0,0)
   float inv_cell;              // 1 / cell edge
   float cell;                  // cell edge [m]
   int nx, ny, nz;
   uint32_t n_pts;
+  // x-slabs: both tables are kept at a FINER resolution along x (xs columns per cell, nxf = nx * xs columns per row; points are
+  // sorted by (z, y, fine column)): cell (x, y, z) starts at column x * xs.  Geometry (rings, exactness proofs) stays in whole
+  // cells; the fast path uses the fine columns to cut a row down to the columns its bound's ball can reach.
+  int xs, nxf;
 };
 
 // Previous pass of the SAME scan (same sorted scan, same neighbour records): its body -> world matrix lets the k-NN
