@@ -56,7 +56,7 @@ HIP_SYMBOLS = [
     "flimo_scan_voxel_filter", "flimo_raw_scan_set", "flimo_raw_scan_filter_set", "flimo_deskew_resident", "flimo_deskew_resident_offset", "flimo_deskew",
     "flimo_match_reduce", "flimo_match_fetch", "flimo_match_fetch_H",
     "flimo_scan_to_world", "flimo_map_add_scan",
-    "flimo_set_timing", "flimo_set_timing_stride", "flimo_pass_count", "flimo_fused_pass_count", "flimo_tie_stats", "flimo_map_grid_selfcheck", "flimo_set_debug_records", "flimo_set_lanes_per_query", "flimo_last_kernel_ms",
+    "flimo_set_timing", "flimo_set_timing_stride", "flimo_pass_count", "flimo_fused_pass_count", "flimo_tie_stats", "flimo_fine_stats", "flimo_map_grid_selfcheck", "flimo_set_debug_records", "flimo_set_lanes_per_query", "flimo_last_kernel_ms",
     "flimo_last_candidates_per_query", "flimo_last_widen_count", "flimo_last_stragglers", "flimo_timing_totals", "flimo_timing_split", "flimo_set_path_switches", "flimo_insert_rule_replay", "flimo_plane_fit5_host", "flimo_plane_eval5_host", "flimo_calculate_H_host",
 ]
 
@@ -112,6 +112,7 @@ def load_hip():
     L.flimo_pass_count.restype = C.c_ulonglong
     L.flimo_pass_count.argtypes = [vp]
     L.flimo_tie_stats.argtypes = [vp, C.POINTER(C.c_ulonglong)]
+    L.flimo_fine_stats.argtypes = [vp, C.POINTER(C.c_ulonglong)]
     L.flimo_fused_pass_count.restype = C.c_ulonglong
     L.flimo_fused_pass_count.argtypes = [vp]
     L.flimo_map_grid_selfcheck.restype = C.c_int
@@ -283,6 +284,11 @@ class HipCtx:
 
     def pass_count(self) -> int:
         return int(self._L.flimo_pass_count(self._h))
+
+    def fine_stats(self):
+        o = (C.c_ulonglong * 4)()
+        self._chk(self._L.flimo_fine_stats(self._h, o))
+        return dict(active=bool(o[0]), points=int(o[1]), builds=int(o[2]), passes=int(o[3]))
 
     def tie_stats(self):
         o = (C.c_ulonglong * 2)()

@@ -135,6 +135,20 @@ struct flimo_ctx {
   int stragglers_hist[4] = {1 << 30, 0, 0, 0};   // the same per pass position within a scan (0 = first pass .. 3 = fourth and later), last scan that reported
   int pass_in_scan = 0;
   int last_stragglers = -1;        // the same of the last pass (-1: not reported by that pass's path)
+  // second level over crowded regions (flimo_map.hip): a grid with a quarter of the cell edge over the box around the cells that
+  // hold more than fine_threshold points, with a copy of every map point inside it
+  bool fine_on = true;             // FLIMO_FINE=0 switches it off (A/B checks)
+  unsigned fine_threshold = 64;    // FLIMO_FINE_THRESHOLD
+  unsigned fine_min_points = 32768;// FLIMO_FINE_MIN_POINTS: smaller crowded regions are not worth the extra dispatch (measured: 1M map, 7k points: +4 us)
+  bool fine_valid = false;
+  GridView fine{};
+  int fine_qlo[3] = {0, 0, 0}, fine_qhi[3] = {-1, -1, -1};
+  float4 *d_fine_tmp = nullptr, *d_fine_pts = nullptr;
+  size_t fine_pts_cap = 0;
+  uint32_t *d_fine_cs = nullptr, *d_fine_rt = nullptr, *d_fine_count = nullptr;
+  size_t fine_cs_cap = 0, fine_rt_cap = 0;
+  int* d_crowd_box = nullptr;
+  uint64_t fine_builds = 0, fine_passes = 0;
   int xslabs = 1;                  // FLIMO_XSLABS: fine columns per cell along x (1, 2, 4, 8; power of two).  4 trims the candidate
                                    // stream of a pruned pass by a quarter (-2 % pass time) and crowded cells by 25-30 %, but makes both
                                    // tables and every index update 4x larger (+0.15 ms per 64k-point insert at 1M points): off by default
@@ -311,6 +325,12 @@ extern "C" int flimo_ctx_create(int device, flimo_ctx** out) {
   c->book = insert_book_create();
   e = getenv("FLIMO_PRUNE");
   if (e) c->prune = atoi(e) != 0;
+  e = getenv("FLIMO_FINE");
+  if (e) c->fine_on = atoi(e) != 0;
+  e = getenv("FLIMO_FINE_THRESHOLD");
+  if (e && atoi(e) > 0) c->fine_threshold = (unsigned)atoi(e);
+  e = getenv("FLIMO_FINE_MIN_POINTS");
+  if (e && atoi(e) >= 0) c->fine_min_points = (unsigned)atoi(e);
   e = getenv("FLIMO_XSLABS");
   if (e) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) c->xslabs = v; }
   e = getenv("FLIMO_TIES");
@@ -346,6 +366,8 @@ extern "C" void flimo_ctx_destroy(flimo_ctx* c) {
   (void)hipFree(c->d_fit_partials); (void)hipFree(c->d_raw_sorted); (void)hipFree(c->d_t_sorted);
   (void)hipFree(c->d_scan); (void)hipFree(c->d_scan_raw); (void)hipFree(c->d_scan_world); (void)hipFree(c->d_scan_t);
   (void)hipFree(c->d_frames); (void)hipFree(c->d_recs); (void)hipFree(c->d_dbg);
+  (void)hipFree(c->d_fine_tmp); (void)hipFree(c->d_fine_pts); (void)hipFree(c->d_fine_cs); (void)hipFree(c->d_fine_rt);
+  (void)hipFree(c->d_fine_count); (void)hipFree(c->d_crowd_box);
   (void)hipFree(c->d_raw32); (void)hipFree(c->d_filt_ext); (void)hipFree(c->d_nbrk); (void)hipFree(c->d_tie_list); (void)hipFree(c->d_tie_count);
   if (c->h_filt_ext) (void)hipHostFree(c->h_filt_ext);
   (void)hipFree(c->d_partials); (void)hipFree(c->d_out256); (void)hipFree(c->d_cand); (void)hipFree(c->d_ticket);
@@ -381,6 +403,7 @@ extern "C" int flimo_map_clear(flimo_ctx* c) {
   if (!c) return FLIMO_ERR_INVALID;
   c->map_n = 0;
   c->grid_valid = false;
+  c->fine_valid = false;
   c->have_gbox = false;
   c->map_last_time = -1.0;
   c->bb[0] = c->bb[1] = c->bb[2] = 3.4e38f; c->bb[3] = c->bb[4] = c->bb[5] = -3.4e38f;
@@ -418,6 +441,76 @@ static int publish_row_table(flimo_ctx* c, int nx, int ny, int nz, bool same_sha
   return FLIMO_OK;
 }
 
+// Second level: (re)built after every index update.  Cheap when no cell is crowded (one pass over the cell table).
+static int update_fine_grid(flimo_ctx* c) {
+  c->fine_valid = false;
+  if (!c->fine_on || !c->grid_valid || c->map_n == 0) return FLIMO_OK;
+  const GridView& g = c->grid;
+  if (!c->d_crowd_box) {
+    HIPCHK(c, hipMalloc(&c->d_crowd_box, 7 * sizeof(int)));
+    HIPCHK(c, hipMalloc(&c->d_fine_count, sizeof(uint32_t)));
+  }
+  int box[7];
+  HIPCHK(c, crowded_cells_box(c->stream, g.cell_start, g.nx, g.ny, g.nz, g.xs, c->fine_threshold, c->d_crowd_box, box));
+  if (box[6] <= 0) return FLIMO_OK;
+  // region copied completely: the crowded cells and one cell around them
+  float lo[3], hi[3];
+  const float o[3] = {g.ox, g.oy, g.oz};
+  for (int a = 0; a < 3; a++) { lo[a] = o[a] + (float)(box[a] - 1) * g.cell; hi[a] = o[a] + (float)(box[3 + a] + 2) * g.cell; }
+  const float cf = 0.25f * g.cell, inv_f = 1.0f / cf;
+  const float of[3] = {lo[0] - cf, lo[1] - cf, lo[2] - cf};             // one fine cell of margin below the region
+  int nf[3];
+  for (int a = 0; a < 3; a++) nf[a] = (int)floorf((hi[a] - of[a]) * inv_f) + 3;
+  const double ncf = (double)nf[0] * nf[1] * nf[2];
+  if (ncf > 6.4e7 || (double)row_table_size(nf[0], nf[1], nf[2]) > 2.0e8) return FLIMO_OK;      // crowded all over: not a region
+  // the copies
+  if (c->map_n > c->fine_pts_cap) {
+    (void)hipFree(c->d_fine_tmp); (void)hipFree(c->d_fine_pts);
+    c->d_fine_tmp = c->d_fine_pts = nullptr; c->fine_pts_cap = 0;
+    HIPCHK(c, hipMalloc(&c->d_fine_tmp, c->map_cap * sizeof(float4)));
+    HIPCHK(c, hipMalloc(&c->d_fine_pts, c->map_cap * sizeof(float4)));
+    c->fine_pts_cap = c->map_cap;
+  }
+  uint32_t m = 0;
+  HIPCHK(c, map_subset_in_box(c->stream, g.pts, c->map_n, lo, hi, c->d_fine_tmp, c->d_fine_count, &m, c->scratch));
+  if (m == 0 || m < c->fine_min_points) return FLIMO_OK;
+  const size_t ncells = (size_t)nf[0] * nf[1] * nf[2];
+  if (ncells + 1 > c->fine_cs_cap) {
+    (void)hipFree(c->d_fine_cs);
+    c->d_fine_cs = nullptr;
+    const size_t cap = ncells + 1 + ncells / 2;
+    HIPCHK(c, hipMalloc(&c->d_fine_cs, cap * sizeof(uint32_t)));
+    c->fine_cs_cap = cap;
+  }
+  const size_t rt = row_table_size(nf[0], nf[1], nf[2]);
+  if (rt > c->fine_rt_cap) {
+    (void)hipFree(c->d_fine_rt);
+    c->d_fine_rt = nullptr;
+    const size_t cap = rt + rt / 2;
+    HIPCHK(c, hipMalloc(&c->d_fine_rt, cap * sizeof(uint32_t)));
+    c->fine_rt_cap = cap;
+  }
+  HIPCHK(c, map_build_grid(c->stream, c->d_fine_tmp, m, c->d_fine_pts, c->d_fine_cs, ncells, of[0], of[1], of[2], inv_f, nf[0], nf[1], nf[2], 1,
+                           c->scratch));
+  HIPCHK(c, map_build_row_table(c->stream, c->d_fine_cs, nf[0], nf[1], nf[2], c->d_fine_rt, true));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  GridView& f = c->fine;
+  f.pts = c->d_fine_pts; f.cell_start = c->d_fine_cs; f.row_table = c->d_fine_rt;
+  f.ox = of[0]; f.oy = of[1]; f.oz = of[2];
+  f.inv_cell = inv_f; f.cell = cf;
+  f.nx = nf[0]; f.ny = nf[1]; f.nz = nf[2];
+  f.n_pts = m; f.xs = 1; f.nxf = nf[0];
+  // a query may be settled here when its fine 3x3x3 block lies inside [lo, hi): fine cell 1 starts at lo, so the query's own cell
+  // is >= 2; on the upper side one more cell of safety against the rounding of (hi - of) * inv_f
+  for (int a = 0; a < 3; a++) {
+    c->fine_qlo[a] = 2;
+    c->fine_qhi[a] = (int)floorf((hi[a] - of[a]) * inv_f) - 3;
+  }
+  c->fine_valid = c->fine_qhi[0] >= 2 && c->fine_qhi[1] >= 2 && c->fine_qhi[2] >= 2;
+  if (c->fine_valid) c->fine_builds++;
+  return FLIMO_OK;
+}
+
 // Brings the cell-sorted copy of the map and its tables up to date with d_map_raw[0 .. map_n).
 //  * merge: the geometry still covers the map box and only points were appended since the last build -> the tail is merged
 //    into the sorted array (one streaming pass, map_merge_grid);
@@ -446,7 +539,7 @@ static int rebuild_grid(flimo_ctx* c) {
     c->grid.n_pts = (uint32_t)c->map_n;
     c->grid_valid = true;
     c->grid_merges++;
-    return FLIMO_OK;
+    return update_fine_grid(c);
   }
   if (getenv("FLIMO_PROF_INSERT"))
     fprintf(stderr, "[flimo index] full layout: valid %d sorted %p full_rebuild %d force %d n_pts %u map_n %zu covers %d  box [%g %g %g | %g %g %g] grid o (%g %g %g) n (%d %d %d)\n",
@@ -521,7 +614,7 @@ static int rebuild_grid(flimo_ctx* c) {
   c->grid_valid = true;
   c->force_full = false;
   c->grid_builds++;
-  return FLIMO_OK;
+  return update_fine_grid(c);
 }
 
 // Debug: sort the whole map again with the CURRENT geometry into temporary buffers and compare the result with the
@@ -1012,6 +1105,11 @@ extern "C" int flimo_deskew(flimo_ctx* c, const float* xyz, size_t n, size_t str
 extern "C" int flimo_set_timing(flimo_ctx* c, int level) { if (!c) return FLIMO_ERR_INVALID; c->timing = level < 0 ? 0 : (level > 2 ? 2 : level); return FLIMO_OK; }
 extern "C" unsigned long long flimo_pass_count(const flimo_ctx* c) { return c ? c->pass_seq : 0ull; }
 extern "C" unsigned long long flimo_fused_pass_count(const flimo_ctx* c) { return c ? c->fused_passes : 0ull; }
+extern "C" int flimo_fine_stats(const flimo_ctx* c, unsigned long long out[4]) {
+  if (!c || !out) return FLIMO_ERR_INVALID;
+  out[0] = c->fine_valid ? 1 : 0; out[1] = c->fine_valid ? c->fine.n_pts : 0; out[2] = c->fine_builds; out[3] = c->fine_passes;
+  return FLIMO_OK;
+}
 extern "C" int flimo_tie_stats(const flimo_ctx* c, unsigned long long out[2]) {
   if (!c || !out) return FLIMO_ERR_INVALID;
   out[0] = c->tie_redos; out[1] = c->tie_queries;
@@ -1177,15 +1275,21 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   tl.count_next = c->d_tie_count + ((seq + 1) & 1);            // re-armed by this pass's reduction for the next pass
   if (ties_on) { tl.list = c->d_tie_list; tl.count = c->d_tie_count + (seq & 1); tl.cap = (unsigned)c->tie_cap; }
   const BookView book{c->gbook.node_c, c->gbook.node_child, c->gbook.node_cnt, c->gbook.root};
+  // crowded regions first: the fine pre-pass settles the queries whose five lie within centimetres (second-level grid)
+  const bool after_fine = c->fine_valid && c->lanes_per_query == 2 && mp.max_ring >= 1;
+  if (after_fine) {
+    launch_knn5_fine(c->stream, c->fine, c->d_scan_sorted, n_all, P, c->d_nbr, c->prev, c->fine_qlo, c->fine_qhi, &tl);
+    c->fine_passes++;
+  }
   if (fused) {
     launch_match_fused(c->stream, c->grid, c->d_scan_sorted, n_all, P, mp, c->d_nbr, c->d_wl, c->d_wl_count, nullptr, c->prev,
                        c->live_idx, c->d_fit2_partials, c->d_granules_host, c->d_ticket, seq, tlev == 1 ? c->ev[0] : nullptr,
-                       tlev == 1 ? c->ev[1] : nullptr, &tl);
+                       tlev == 1 ? c->ev[1] : nullptr, &tl, after_fine ? 1 : 0);
     c->fused_passes++;
   } else
   launch_knn5(c->stream, c->lanes_per_query, c->grid, c->d_scan_sorted, n_all, P, mp.max_ring, c->d_nbr, c->d_wl,
               c->d_wl_count, c->debug_recs ? c->d_cand : nullptr, c->prev, tail ? 1 : 0, tlev == 1 ? c->ev[0] : nullptr,
-              tlev == 1 ? c->ev[1] : nullptr, nullptr, &tl);
+              tlev == 1 ? c->ev[1] : nullptr, nullptr, &tl, after_fine ? 1 : 0);
   if (c->prune) { memcpy(c->prev.RT, P.RT, sizeof(c->prev.RT)); c->prev.valid = 1; }   // the records now belong to this pose
   const double tpb = prof ? now_us() : 0.0;
   if (tlev > 1) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));

@@ -13,7 +13,10 @@ struct BookView;
 void launch_knn5(hipStream_t st, int lanes_per_query, const GridView& G, const float4* scan_sorted, int n,
                  const PoseMats& P, int max_ring, void* nbr, int* wl, int* wl_count, unsigned long long* cand,
                  const PrevPass& prev, int tail, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, const struct FuseArgs* fuse = nullptr,
-                 const TieList* ties = nullptr);
+                 const TieList* ties = nullptr, int after_fine = 0);
+// fine pre-pass over the second-level grid of crowded regions (see flimo_map.hip); launches that follow it pass after_fine = 1
+void launch_knn5_fine(hipStream_t st, const GridView& Gf, const float4* scan_sorted, int n, const PoseMats& P, void* nbr,
+                      const PrevPass& prev, const int qlo[3], const int qhi[3], const TieList* ties);
 // tail != 0: queries that need more than the 3x3x3 block are finished inside the k-NN launch itself (gates of at most 3
 // rings; launch_knn5 clears the flag otherwise) and launch_widen has nothing to do
 void launch_widen(hipStream_t st, const GridView& G, const float4* scan_sorted, const PoseMats& P, int max_ring, void* nbr,
@@ -44,7 +47,8 @@ int fused_blocks(int n);
 void launch_match_fused(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const PoseMats& P, const MatchParams& mp,
                         void* nbr, int* wl, int* wl_count, unsigned long long* cand, const PrevPass& prev,
                         const unsigned char* live_idx, double* partials, void* out_granules, unsigned int* ticket,
-                        unsigned long long seq, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, const TieList* ties = nullptr);
+                        unsigned long long seq, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, const TieList* ties = nullptr,
+                        int after_fine = 0);
 // The reference's choice among exactly tied distances (first met by Octree::knn's recursion): BookView = the device copy of the
 // octree (insert book), TieList = the queries a pass flagged.  launch_tie rewrites their neighbour records; launch_knn_tie does the
 // same for the output of launch_knn.
@@ -108,6 +112,13 @@ hipError_t map_merge_grid(hipStream_t st, const float4* old_sorted, size_t n_old
 // stamp key (complemented when the sweep is sorted descending), kept count, "a kept stamp is NaN"}.
 hipError_t filter_raw_scan(hipStream_t st, const void* raw32_dev, size_t n, const FilterParams& F, float4* out, double* t_out,
                            unsigned long long* ext_dev, MapBuildScratch& S);
+// Second level over crowded regions: box (cell coordinates, inclusive) around the cells holding more than `threshold` points
+// (box_host[6] = their number; box_dev: 7 ints of device scratch), and the copy of the map points inside a box of metres
+// (w = position in the main sorted map).
+hipError_t crowded_cells_box(hipStream_t st, const uint32_t* cell_start, int nx, int ny, int nz, int xs, uint32_t threshold,
+                             int* box_dev, int box_host[7]);
+hipError_t map_subset_in_box(hipStream_t st, const float4* pts, size_t n, const float lo[3], const float hi[3], float4* out,
+                             uint32_t* count_dev, uint32_t* count_host, MapBuildScratch& S);
 size_t row_table_size(int nx, int ny, int nz);
 hipError_t map_build_row_table(hipStream_t st, const uint32_t* cell_start, int nx, int ny, int nz, uint32_t* out, bool zero_pads = true);
 // pcl::VoxelGrid on device points: out gets one centroid per occupied voxel in ascending voxel index

@@ -378,7 +378,9 @@ __device__ __forceinline__ double key_group_min(double md, int Gl, int lane) {
 
 // N candidate slots of one lane: stream positions s0, s0 + L, ...; dead slots (>= total) re-read the last position and
 // insert +inf.  All N loads are issued back to back (the empty asm consumes every loaded value at once).
-template <int L, int N>
+// PAYW: the key's payload is the point's w (the fine level's copies carry their position in the main map there) instead of the
+// position in `pts`
+template <int L, int N, bool PAYW = false>
 __device__ __forceinline__ void knn5_body(const float4* __restrict__ pts, uint32_t s0, uint32_t total, uint32_t last,
                                           const uint32_t (&off)[10], const uint32_t (&dl)[9], float gx, float gy, float gz,
                                           double (&k5)[6]) {
@@ -407,7 +409,7 @@ __device__ __forceinline__ void knn5_body(const float4* __restrict__ pts, uint32
   for (int u = 0; u < N; u++) {
     const bool live = s0 + u * L < total;
     const float d = sqdist3(gx, gy, gz, pt[u].x, pt[u].y, pt[u].z);
-    best6_insert(k5, key_make(live ? d : INFINITY, live ? id[u] : 0xffffffffu));
+    best6_insert(k5, key_make(live ? d : INFINITY, live ? (PAYW ? __float_as_uint(pt[u].w) : id[u]) : 0xffffffffu));
   }
 }
 
@@ -624,6 +626,11 @@ __device__ __forceinline__ void knn5_tail(const GridView& G, int max_ring, NbrRe
 // FUSE: the whole measurement pass in ONE launch (fast path of flimo_match_reduce): every wave goes on from its queries'
 // neighbours (fast path + tail) to their plane fit, residual and H row and to the H^T H reduction (fit_reduce_publish below).
 struct FuseArgs {
+  // second level (crowded regions): 0 = none; 1 = this launch follows a fine pre-pass and takes over the queries it settled
+  // (record flag 4); 2 = this launch IS the fine pre-pass (G = the fine grid; a query is settled when its five are proven
+  // inside its fine 3x3x3 block and that block lies inside the region the fine grid copies completely: cell in [qlo, qhi])
+  int fine_mode;
+  int qlo[3], qhi[3];
   TieList tl;
   MatchParams mp;
   FitIdx idx;
@@ -641,7 +648,7 @@ __device__ __forceinline__ void fit_reduce_publish(const float (&v)[16], bool ow
 FLIMO_DEV void fit_row(const GridView& G, const PoseMats& P, const MatchParams& mp, const int (&ids)[5], float gx, float gy, float gz,
                        float (&v)[16]);
 
-template <int L, int SLOTS, bool FUSE>
+template <int L, int SLOTS, bool FUSE, bool FINE = false>
 __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __restrict__ scan_sorted, int n,
                                                    PoseMats P, int max_ring, NbrRec* __restrict__ nbr,
                                                    int* __restrict__ wl, int* __restrict__ wl_count,
@@ -667,9 +674,15 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
   // neighbours are still in the map, and the query moved by |g - g_old|, so d5 <= sqrt(d5_old) + |g - g_old|.
   // Cells farther than that cannot hold any of the five nearest points and are skipped (exactly, no heuristic).
   float b2 = INFINITY;                               // bound, squared, in cell units
-  if (prev.valid && in_range) {
+  bool resolved = false;                             // settled by the fine pre-pass of this pass: nothing to search
+  int4 pa_res = make_int4(0, 0, 0, 0), pb_res = make_int4(0, 0, 0, 0);
+  if ((prev.valid || (!FINE && fa.fine_mode == 1)) && in_range) {
     const int4 pb = reinterpret_cast<const int4*>(&nbr[p])[1];       // idx[4], flag, d5 bits, "d5 valid"
-    if (pb.y == 1 && (pb.w & 1)) {
+    if (!FINE && fa.fine_mode == 1 && pb.y == 4) {
+      resolved = true;
+      pb_res = pb;
+      pa_res = reinterpret_cast<const int4*>(&nbr[p])[0];
+    } else if (prev.valid && pb.y == 1 && (pb.w & 1)) {
       float ox_, oy_, oz_;
       xform4(prev.RT, sp.x, sp.y, sp.z, ox_, oy_, oz_);
       const float ex = gx - ox_, ey = gy - oy_, ez = gz - oz_;
@@ -683,11 +696,21 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
   u64 sixth = KEY_NONE;
   bool tie = false;
   int cand = 0;
-  if (in_range && (fx == fx) && (fy == fy) && (fz == fz)) {
+  bool tie_listed = false;
+  int qcx = 0, qcy = 0, qcz = 0;
+  if (resolved) {
+    // the five (positions in the main map), their 5th distance and the tie bit as the pre-pass left them
+    best[0] = (u64)(uint32_t)pa_res.x; best[1] = (u64)(uint32_t)pa_res.y; best[2] = (u64)(uint32_t)pa_res.z; best[3] = (u64)(uint32_t)pa_res.w;
+    best[4] = ((u64)(uint32_t)pb_res.z << 32) | (u64)(uint32_t)pb_res.x;
+    flag = 1;
+    tie = (pb_res.w & 2) != 0;
+    tie_listed = true;
+  } else if (in_range && (fx == fx) && (fy == fy) && (fz == fz)) {
     const float lim = 1.0e9f;
     const float flx = floorf(fminf(fmaxf(fx, -lim), lim)), fly = floorf(fminf(fmaxf(fy, -lim), lim)),
                 flz = floorf(fminf(fmaxf(fz, -lim), lim));
     const int cx = (int)flx, cy = (int)fly, cz = (int)flz;
+    qcx = cx; qcy = cy; qcz = cz;
     const int ox_ = cx < 0 ? -cx : (cx >= G.nx ? cx - G.nx + 1 : 0);
     const int oy_ = cy < 0 ? -cy : (cy >= G.ny ? cy - G.ny + 1 : 0);
     const int oz_ = cz < 0 ? -cz : (cz >= G.nz ? cz - G.nz + 1 : 0);
@@ -761,8 +784,8 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
       // full bodies while more than half of a body's slots are live for this lane, then one half body
       uint32_t s0 = (uint32_t)sub;
       for (; s0 + (SLOTS / 2) * L < total; s0 += SLOTS * L)
-        knn5_body<L, SLOTS>(G.pts, s0, total, last, off, dl, gx, gy, gz, k5);
-      if (s0 < total) knn5_body<L, (SLOTS >= 2 ? SLOTS / 2 : 1)>(G.pts, s0, total, last, off, dl, gx, gy, gz, k5);
+        knn5_body<L, SLOTS, FINE>(G.pts, s0, total, last, off, dl, gx, gy, gz, k5);
+      if (s0 < total) knn5_body<L, (SLOTS >= 2 ? SLOTS / 2 : 1), FINE>(G.pts, s0, total, last, off, dl, gx, gy, gz, k5);
       cand = total > (uint32_t)sub ? (int)((total - (uint32_t)sub + L - 1) / L) : 0;
 #pragma unroll
       for (int i = 0; i < 5; i++) best[i] = (u64)__double_as_longlong(k5[i]);
@@ -814,6 +837,20 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
     for (int o = 1; o < L; o <<= 1) c += __shfl_xor(c, o, 64);
     if (sub == 0 && in_range) atomicAdd(cand_total, (unsigned long long)c);
   }
+  if constexpr (FINE) {
+    // fine pre-pass: settle what is proven inside the completely copied region, leave everything else to the main launch
+    const bool inside = qcx >= fa.qlo[0] && qcx <= fa.qhi[0] && qcy >= fa.qlo[1] && qcy <= fa.qhi[1] && qcz >= fa.qlo[2] && qcz <= fa.qhi[2];
+    if (in_range && sub == 0 && flag == 1 && inside) {
+      int4 a, b;
+      a.x = (int)(uint32_t)best[0]; a.y = (int)(uint32_t)best[1]; a.z = (int)(uint32_t)best[2]; a.w = (int)(uint32_t)best[3];
+      b.x = (int)(uint32_t)best[4]; b.y = 4; b.z = (int)(uint32_t)(best[4] >> 32); b.w = 1 | (tie ? 2 : 0);
+      int4* o = reinterpret_cast<int4*>(&nbr[p]);
+      o[0] = a;
+      o[1] = b;
+      if (tie && tl.list) { const unsigned slot = atomicAdd(tl.count, 1u); if (slot < tl.cap) tl.list[slot] = p; }
+    }
+    return;
+  }
   TRACE(0, 4);
   // pending queries (flag 2) are finished right here by this wave when the gate needs at most TAIL_MAX_RING rings
   // (`tail`); otherwise (wider gates, the developer's crowded-block hand-over) they go to the worklist kernels
@@ -822,7 +859,7 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
     int4 a, b;
     a.x = (int)(uint32_t)best[0]; a.y = (int)(uint32_t)best[1]; a.z = (int)(uint32_t)best[2]; a.w = (int)(uint32_t)best[3];
     b.x = (int)(uint32_t)best[4]; b.y = min(flag, 2); b.z = (int)(uint32_t)(best[4] >> 32); b.w = ((flag == 1) ? 1 : 0) | (tie ? 2 : 0);   // d5 for the next pass; bit 1: tie
-    if (tie && tl.list) { const unsigned slot = atomicAdd(tl.count, 1u); if (slot < tl.cap) tl.list[slot] = p; }
+    if (tie && !tie_listed && tl.list) { const unsigned slot = atomicAdd(tl.count, 1u); if (slot < tl.cap) tl.list[slot] = p; }
     int4* o = reinterpret_cast<int4*>(&nbr[p]);
     o[0] = a;
     o[1] = b;
@@ -2051,7 +2088,7 @@ static int g_slots = 0;   // 0: default per L; developer override through FLIMO_
 template <int L>
 static void launch_knn5_L(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const PoseMats& P,
                           int max_ring, void* nbr, int* wl, int* wl_count, unsigned long long* cand, const PrevPass& prev,
-                          int tail, hipEvent_t e0, hipEvent_t e1, const FuseArgs* fuse, const TieList* tlp) {
+                          int tail, hipEvent_t e0, hipEvent_t e1, const FuseArgs* fuse, const TieList* tlp, int after_fine = 0) {
   const int qpb = 256 / L;
   const int blocks = round_up8((n + qpb - 1) / qpb);
   if (g_slots == 0) { const char* e = getenv("FLIMO_SLOTS"); g_slots = e ? atoi(e) : -1; }
@@ -2064,6 +2101,7 @@ static void launch_knn5_L(hipStream_t st, const GridView& G, const float4* scan_
   }
   FuseArgs nofuse{};
   if (tlp) nofuse.tl = *tlp;
+  nofuse.fine_mode = after_fine ? 1 : 0;
   // e0 / e1 (optional) are attached to the dispatch itself: they read the kernel's own begin / end
   // timestamps, without the extra barrier packets of hipEventRecord
   if (slots >= 8)
@@ -2076,16 +2114,16 @@ static void launch_knn5_L(hipStream_t st, const GridView& G, const float4* scan_
 
 void launch_knn5(hipStream_t st, int lanes_per_query, const GridView& G, const float4* scan_sorted, int n,
                  const PoseMats& P, int max_ring, void* nbr, int* wl, int* wl_count, unsigned long long* cand,
-                 const PrevPass& prev, int tail, hipEvent_t e0, hipEvent_t e1, const FuseArgs* fuse, const TieList* tlp) {
+                 const PrevPass& prev, int tail, hipEvent_t e0, hipEvent_t e1, const FuseArgs* fuse, const TieList* tlp, int after_fine) {
   if (n <= 0) return;
   if (max_ring < 2 || max_ring > TAIL_MAX_RING) tail = 0;
   switch (lanes_per_query) {
-    case 1: launch_knn5_L<1>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp); break;
-    case 2: launch_knn5_L<2>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp); break;
-    case 4: launch_knn5_L<4>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp); break;
-    case 8: launch_knn5_L<8>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp); break;
-    case 32: launch_knn5_L<32>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp); break;
-    default: launch_knn5_L<16>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp); break;
+    case 1: launch_knn5_L<1>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine); break;
+    case 2: launch_knn5_L<2>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine); break;
+    case 4: launch_knn5_L<4>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine); break;
+    case 8: launch_knn5_L<8>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine); break;
+    case 32: launch_knn5_L<32>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine); break;
+    default: launch_knn5_L<16>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine); break;
   }
 }
 
@@ -2175,12 +2213,27 @@ void launch_fit2(hipStream_t st, const GridView& G, const float4* scan_sorted, i
 }
 
 int fused_blocks(int n) { return round_up8((n + 127) / 128); }
+// fine pre-pass over the second-level grid (crowded regions): settles the queries whose five are proven inside their fine 3x3x3
+// block; their records get flag 4, which the main launch of the same pass (fine_mode 1) takes over
+void launch_knn5_fine(hipStream_t st, const GridView& Gf, const float4* scan_sorted, int n, const PoseMats& P, void* nbr,
+                      const PrevPass& prev, const int qlo[3], const int qhi[3], const TieList* tlp) {
+  if (n <= 0) return;
+  FuseArgs fa{};
+  fa.fine_mode = 2;
+  for (int a = 0; a < 3; a++) { fa.qlo[a] = qlo[a]; fa.qhi[a] = qhi[a]; }
+  if (tlp) fa.tl = *tlp;
+  PrevPass pv = prev;
+  pv.heavy = 0xffffffffu;
+  hipLaunchKernelGGL((knn5_kernel<2, 8, false, true>), dim3(round_up8((n + 127) / 128)), dim3(256), 0, st, Gf, scan_sorted, n, P, 1,
+                     (NbrRec*)nbr, (int*)nullptr, (int*)nullptr, (unsigned long long*)nullptr, pv, 0, fa);
+}
 void launch_match_fused(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const PoseMats& P, const MatchParams& mp,
                         void* nbr, int* wl, int* wl_count, unsigned long long* cand, const PrevPass& prev,
                         const unsigned char* live_idx, double* partials, void* out_granules, unsigned int* ticket,
-                        unsigned long long seq, hipEvent_t e0, hipEvent_t e1, const TieList* tlp) {
+                        unsigned long long seq, hipEvent_t e0, hipEvent_t e1, const TieList* tlp, int after_fine) {
   if (n <= 0) return;
-  FuseArgs fa;
+  FuseArgs fa{};
+  fa.fine_mode = after_fine ? 1 : 0;
   fa.tl = TieList{};
   if (tlp) fa.tl = *tlp;
   fa.mp = mp;

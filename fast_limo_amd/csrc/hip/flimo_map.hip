@@ -263,6 +263,79 @@ hipError_t map_merge_grid(hipStream_t st, const float4* old_sorted, size_t n_old
   return hipGetLastError();
 }
 
+// ---- second level over crowded regions ----------------------------------------------------------------------------------
+// Raw sweeps inserted into the map leave cells right under the sensor with hundreds to thousands of points (the insert rule
+// keeps the whole first batch that lands in a leaf).  A query there has its five neighbours within centimetres but would walk
+// every point of its 3x3x3 cells.  The map therefore keeps a SECOND grid with a quarter of the cell edge over the box around the
+// crowded cells, holding a copy of every map point inside that box (w = position in the main sorted map, so that neighbour
+// ids and tie-breaks are the main map's); the pass asks it first (fine pre-pass, flimo_kernels.hip).
+__global__ __launch_bounds__(256) void crowded_kernel(const uint32_t* __restrict__ cell_start, int nx, int ny, int nz, int xs,
+                                                      uint32_t threshold, int* __restrict__ box /* min xyz, max xyz, count */) {
+  const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t ncells = (size_t)nx * ny * nz;
+  if (c >= ncells) return;
+  const int x = (int)(c % (size_t)nx);
+  const size_t row = c / (size_t)nx;
+  const size_t col0 = row * ((size_t)nx * xs) + (size_t)x * xs;
+  const uint32_t cnt = cell_start[col0 + xs] - cell_start[col0];
+  if (cnt <= threshold) return;
+  const int y = (int)(row % (size_t)ny), z = (int)(row / (size_t)ny);
+  atomicMin(&box[0], x); atomicMin(&box[1], y); atomicMin(&box[2], z);
+  atomicMax(&box[3], x); atomicMax(&box[4], y); atomicMax(&box[5], z);
+  atomicAdd(&box[6], 1);
+}
+hipError_t crowded_cells_box(hipStream_t st, const uint32_t* cell_start, int nx, int ny, int nz, int xs, uint32_t threshold,
+                             int* box_dev, int box_host[7]) {
+  const int init[7] = {INT_MAX, INT_MAX, INT_MAX, -1, -1, -1, 0};
+  hipError_t e;
+  if ((e = hipMemcpyAsync(box_dev, init, sizeof(init), hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+  const size_t ncells = (size_t)nx * ny * nz;
+  hipLaunchKernelGGL(crowded_kernel, dim3((unsigned)((ncells + 255) / 256)), dim3(256), 0, st, cell_start, nx, ny, nz, xs, threshold, box_dev);
+  if ((e = hipMemcpyAsync(box_host, box_dev, 7 * sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+  return hipStreamSynchronize(st);
+}
+// copy of the map points inside [lo, hi) (metres), w = position in the main sorted map; *count_dev receives their number
+__global__ __launch_bounds__(256) void inbox_flag_kernel(const float4* __restrict__ pts, size_t n, float lx, float ly, float lz, float hx,
+                                                         float hy, float hz, uint32_t* __restrict__ flag) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = pts[i];
+  flag[i] = (p.x >= lx && p.x < hx && p.y >= ly && p.y < hy && p.z >= lz && p.z < hz) ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void inbox_scatter_kernel(const float4* __restrict__ pts, size_t n, const uint32_t* __restrict__ flag,
+                                                            const uint32_t* __restrict__ pos, float4* __restrict__ out,
+                                                            uint32_t* __restrict__ count) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (i == n - 1) *count = pos[i] + flag[i];
+  if (!flag[i]) return;
+  const float4 p = pts[i];
+  out[pos[i]] = make_float4(p.x, p.y, p.z, __uint_as_float((uint32_t)i));
+}
+hipError_t map_subset_in_box(hipStream_t st, const float4* pts, size_t n, const float lo[3], const float hi[3], float4* out,
+                             uint32_t* count_dev, uint32_t* count_host, MapBuildScratch& S) {
+  *count_host = 0;
+  if (n == 0) return hipSuccess;
+  hipError_t e = ensure_scratch(S, n);
+  if (e != hipSuccess) return e;
+  const int blocks = (int)((n + 255) / 256);
+  size_t scan_bytes = 0;
+  e = exclusive_sum(nullptr, scan_bytes, S.keys_in, S.vals_in, n, st);
+  if (e != hipSuccess) return e;
+  if (scan_bytes > S.cub_tmp_bytes) {
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+    if (S.cub_tmp) (void)hipFree(S.cub_tmp);
+    if ((e = hipMalloc(&S.cub_tmp, scan_bytes + 1024)) != hipSuccess) return e;
+    S.cub_tmp_bytes = scan_bytes + 1024;
+  }
+  hipLaunchKernelGGL(inbox_flag_kernel, dim3(blocks), dim3(256), 0, st, pts, n, lo[0], lo[1], lo[2], hi[0], hi[1], hi[2], S.keys_in);
+  e = exclusive_sum(S.cub_tmp, scan_bytes, S.keys_in, S.vals_in, n, st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(inbox_scatter_kernel, dim3(blocks), dim3(256), 0, st, pts, n, S.keys_in, S.vals_in, out, count_dev);
+  if ((e = hipMemcpyAsync(count_host, count_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+  return hipStreamSynchronize(st);
+}
+
 // ---- y-fastest, padded copy of the row bounds (GridView::row_table) --------------------------
 // A transposition per z slab (x-fastest cell table -> y-fastest row table) through a 32x33 LDS tile so that both the reads
 // (along x) and the writes (along y) are coalesced; the pad entries (y, z outside the grid) are zero and never written here.

@@ -174,6 +174,9 @@ unsigned long long flimo_fused_pass_count(const flimo_ctx* ctx);
 /* exact float32 distance ties (Objects/Octree.hpp:72-87,558-599: the reference keeps the candidate its recursion meets first):
  * out[0] = passes whose rows were rebuilt after settling ties, out[1] = queries settled so far */
 int flimo_tie_stats(const flimo_ctx* ctx, unsigned long long out[2]);
+/* second level over crowded regions (cells holding > 64 points get a grid with a quarter of the cell edge and a pre-pass):
+ * out[0] = active now, out[1] = map points copied into it, out[2] = times it was (re)built, out[3] = passes that ran the pre-pass */
+int flimo_fine_stats(const flimo_ctx* ctx, unsigned long long out[4]);
 int flimo_last_kernel_ms(const flimo_ctx* ctx, float* knn_ms, float* widen_ms, float* fit_ms);
 /* sums over every pass since the last reset (timing must be on): per-stage GPU ms, passes, k-NN queries */
 int flimo_timing_totals(flimo_ctx* ctx, double* knn_ms, double* widen_ms, double* fit_ms, long long* passes,

@@ -903,3 +903,71 @@ def test_knn_on_a_lattice_ties_follow_the_reference(built, oracle):
         np.testing.assert_allclose(HTH2, H.T @ H, rtol=1e-12, atol=1e-9)
         np.testing.assert_allclose(HTH1, H.T @ H, rtol=1e-12, atol=1e-9)
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_crowded_cells_second_level_is_exact(built, oracle):
+    """Raw sweeps inserted into the map leave the cells under the sensor with hundreds of points (the insert rule keeps the whole
+    first batch that lands in a leaf).  Those regions get a second-level grid (a quarter of the cell edge, copies of every map
+    point inside) and a fine pre-pass that settles the queries whose five lie within centimetres.  Results must not change:
+    records equal the oracle's (which inserted the same world points) bit for bit, and H^T H equals the run with the second
+    level switched off bit for bit."""
+    import os
+    from fast_limo_amd import _lib
+    L = 40.0
+    mp = synth.box_world_map(150000, L, 5)
+    x_true = np.zeros(26); x_true[6] = 1; x_true[10] = 1; x_true[25] = -9.809
+    x_true[0:3] = synth.T_STAR_T
+    r, p_, y = [np.deg2rad(v) for v in synth.T_STAR_RPY_DEG]
+    cr, sr, cp, sp, cy, sy = np.cos(r / 2), np.sin(r / 2), np.cos(p_ / 2), np.sin(p_ / 2), np.cos(y / 2), np.sin(y / 2)
+    x_true[3:7] = [sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy, cr * cp * cy + sr * sp * sy]
+    sweeps = [np.ascontiguousarray(synth.velodyne_scan(64, 1024, L, 40 + j)[:, :3]) for j in range(6)]
+    query = np.ascontiguousarray(synth.velodyne_scan(64, 512, L, 77)[:, :3])
+    res = {}
+    oc = oracle.Octree()
+    oc.update(mp)
+    for label, fine in (("fine", "1"), ("plain", "0")):
+        os.environ["FLIMO_FINE"] = fine
+        os.environ["FLIMO_FINE_THRESHOLD"] = "32"
+        os.environ["FLIMO_FINE_MIN_POINTS"] = "0"
+        ctx = _lib.HipCtx(0)
+        os.environ.pop("FLIMO_FINE"); os.environ.pop("FLIMO_FINE_THRESHOLD"); os.environ.pop("FLIMO_FINE_MIN_POINTS")
+        ctx.map_config()
+        ctx.map_add(mp)
+        for j, sw in enumerate(sweeps):
+            ctx.scan_set(sw)
+            if label == "fine":
+                oc.update(ctx.scan_to_world(x_true))              # the same world points, the same insert rule
+            ctx.map_add_scan(x_true, 0.1 * (j + 1))
+        assert ctx.map_size() == oc.size()
+        fs = ctx.fine_stats()
+        assert fs["active"] == (label == "fine"), fs
+        if label == "fine":
+            assert fs["points"] > 5000
+        cfg = _lib.default_match_cfg(**CAPS)
+        ctx.scan_set(query)
+        p1 = ctx.match_reduce(x_true, cfg)                         # first pass (no bound)
+        p2 = ctx.match_reduce(x_true, cfg)                         # with the previous pass's bound
+        ctx.set_debug_records(True)
+        p3 = ctx.match_reduce(x_true, cfg)
+        g = ctx.match_fetch()
+        ctx.set_debug_records(False)
+        res[label] = (p1, p2, p3, g, ctx.map_points(), ctx.fine_stats())
+        mm, _, _ = ctx.grid_selfcheck()
+        assert mm == 0
+        ctx.close()
+    for k in range(3):
+        np.testing.assert_array_equal(res["fine"][k][0], res["plain"][k][0])          # H^T H: bit for bit
+        np.testing.assert_array_equal(res["fine"][k][1], res["plain"][k][1])
+        assert res["fine"][k][2] == res["plain"][k][2]
+    assert res["fine"][5]["passes"] >= 3
+    ocfg = oracle.default_cfg(num_threads=4, **CAPS)
+    recs, H, h, _ = oracle.match_H(oc, ocfg, x_true, query)
+    g, dev = res["fine"][3], res["fine"][4]
+    vg, vo = g["valid"] > 0, recs["is_plane"] > 0
+    np.testing.assert_array_equal(vg, vo)
+    assert vg.sum() > 20000
+    np.testing.assert_array_equal(g["sqd"][vg], recs["sqd"][vg])
+    np.testing.assert_array_equal(dev[g["nbr"]][vg], recs["nbr"][vg])
+    np.testing.assert_array_equal(g["n"][vg], recs["n"][vg])
+    np.testing.assert_array_equal(g["H"][vg].astype(np.float64), H)
