@@ -1979,8 +1979,9 @@ __global__ __launch_bounds__(256) void deskew_kernel(const float4* __restrict__ 
     const float r0 = fl_div(wx, w_norm), r1 = fl_div(wy, w_norm), r2 = fl_div(wz, w_norm);
     const float K[9] = {0.f, -r2, r1, r2, 0.f, -r0, -r1, r0, 0.f};
     const float r_ang = (float)((double)w_norm * dt);
-    const float s = sinf(r_ang);
-    const float c = (float)(1.0 - (double)cosf(r_ang));
+    float s, cs;
+    libm_sincosf(r_ang, s, cs);                        // std::sin / std::cos of a float, as the host's libm rounds them
+    const float c = (float)(1.0 - (double)cs);
     float cK[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) cK[i] = c * K[i];
@@ -2005,7 +2006,7 @@ __global__ __launch_bounds__(256) void deskew_kernel(const float4* __restrict__ 
   // q *= Quaternionf(R)
   float ux_, uy_, uz_, uw_;
   {
-    float tr = Rm[0] + Rm[4] + Rm[8];
+    float tr = sum3(Rm[0], Rm[4], Rm[8]);            // trace() = diagonal().sum(): Eigen's 3-coefficient redux c0 + (c1 + c2)
     if (tr > 0.f) {
       tr = fl_sqrt(tr + 1.0f);
       uw_ = 0.5f * tr;

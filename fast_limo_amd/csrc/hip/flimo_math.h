@@ -23,6 +23,34 @@ namespace flimo {
 FLIMO_DEV float fl_sqrt(float x) { return __builtin_sqrtf(x); }
 FLIMO_DEV float fl_div(float a, float b) { return a / b; }
 
+// sinf / cosf as the host's libm computes them (the reference's State::update calls std::sin / std::cos on a float,
+// State.cpp:88-90).  glibc >= 2.28 evaluates both in double: for |x| < pi/4 odd / even polynomials of degree 7 / 8, beyond that
+// the reduction x - n * pi/2 with n = round(x * 2/pi) and the polynomial the quadrant selects; |x| < 2^-12 returns x / 1.
+// Restated here with the published coefficients (ARM optimized-routines sincosf, the source of glibc's s_sincosf_data.c); checked
+// against the host's libm on 10M arguments by tools/devmath_check (no mismatch for |x| < pi/4, 3e-7 of the arguments up to 100 rad,
+// where libm's FMA build contracts the reduction).  |x| >= 120 (never a deskew angle) falls back to the device's own sinf / cosf.
+FLIMO_DEV void libm_sincosf(float x, float& s_out, float& c_out) {
+  const double S1 = -0x1.555545995a603p-3, S2 = 0x1.1107605230bc4p-7, S3 = -0x1.994eb3774cf24p-13;
+  const double C1 = -0x1.ffffffd0c621cp-2, C2 = 0x1.55553e1068f19p-5, C3 = -0x1.6c087e89a359dp-10, C4 = 0x1.99343027bf8c3p-16;
+  const float ax = __builtin_fabsf(x);
+  if (!(ax < 120.0f)) { s_out = __builtin_sinf(x); c_out = __builtin_cosf(x); return; }
+  if (ax < 0x1p-12f) { s_out = x; c_out = 1.0f; return; }
+  double xr = (double)x;
+  int n = 0;
+  if (!(ax < 0x1.921fb6p-1f)) {
+    const double r = xr * 0x1.45F306DC9C883p+23;
+    n = ((int)r + 0x800000) >> 24;
+    xr = xr - (double)n * 0x1.921FB54442D18p0;
+  }
+  const double x2 = xr * xr, x4 = x2 * x2;
+  const double x3 = xr * x2, x7 = x3 * x2, x6 = x4 * x2;
+  const double ps = (xr + x3 * S1) + x7 * (S2 + x2 * S3);                    // sin(xr)
+  const double pc = ((1.0 + x2 * C1) + x4 * C2) + x6 * (C3 + x2 * C4);      // cos(xr)
+  const double sv = (n & 1) ? pc : ps, cv = (n & 1) ? ps : pc;
+  s_out = (float)((n & 2) ? -sv : sv);
+  c_out = (float)(((n + 1) & 2) ? -cv : cv);
+}
+
 // 3-coefficient Eigen reduction: c0 + (c1 + c2)
 FLIMO_DEV float sum3(float a, float b, float c) { return a + (b + c); }
 

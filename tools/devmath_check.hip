@@ -23,7 +23,36 @@ __global__ void k(const In* in, Out* out, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) eval(in[i], out[i]);
 }
+__global__ void k_sincos(const float* x, float* s, float* c, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) libm_sincosf(x[i], s[i], c[i]);
+}
+// libm_sincosf on the device against the host's libm (sinf / cosf), three argument ranges
+static int check_sincos() {
+  const int N = 1 << 22;
+  std::vector<float> x(N), hs(N), hc(N), gs(N), gc(N);
+  srand(11);
+  for (int t = 0; t < N; t++) {
+    const double u = (rand() % 2000001 - 1000000) * 1e-6;
+    x[t] = (float)(t % 4 == 0 ? u * 100.0 : (t % 4 == 1 ? u * 1e-3 : u * 0.785));
+    hs[t] = sinf(x[t]); hc[t] = cosf(x[t]);
+  }
+  float *dx, *ds, *dc;
+  hipMalloc(&dx, N * 4); hipMalloc(&ds, N * 4); hipMalloc(&dc, N * 4);
+  hipMemcpy(dx, x.data(), N * 4, hipMemcpyHostToDevice);
+  hipLaunchKernelGGL(k_sincos, dim3(N / 256), dim3(256), 0, 0, dx, ds, dc, N);
+  hipMemcpy(gs.data(), ds, N * 4, hipMemcpyDeviceToHost);
+  hipMemcpy(gc.data(), dc, N * 4, hipMemcpyDeviceToHost);
+  int small_bad = 0, large_bad = 0, n_small = 0;
+  for (int t = 0; t < N; t++) {
+    const bool bad = memcmp(&hs[t], &gs[t], 4) || memcmp(&hc[t], &gc[t], 4);
+    if (fabsf(x[t]) < 0.785f) { n_small++; small_bad += bad; } else large_bad += bad;
+  }
+  printf("DEVMATH sincos mismatches vs host libm: |x|<pi/4: %d of %d   up to 100 rad: %d of %d\n", small_bad, n_small, large_bad, N - n_small);
+  return small_bad != 0 || large_bad > N / 100000;
+}
 int main() {
+  if (check_sincos()) return 2;
   const int N = 1 << 20;
   std::vector<In> in(N);
   std::vector<Out> ho(N), go(N);
