@@ -5,7 +5,11 @@ scan's last point, then the scan), and returns the trajectory.  No ROS, no datas
 
 PCD support: DATA ascii and DATA binary (not binary_compressed), fields x y z [intensity] and one per-point time field:
 `t` (uint32 ns, OUSTER), `time` (float32 s, VELODYNE), `timestamp` (float64: HESAI s / LIVOX ns).
-IMU CSV: `stamp,gx,gy,gz,ax,ay,az` per line (header line optional)."""
+IMU CSV: `stamp,gx,gy,gz,ax,ay,az` per line (header line optional).
+KITTI raw recordings (the layout of BASELINE.json's config 3, `<drive>_extract/velodyne_points/data/*.bin` + `timestamps*.txt` and
+`oxts/data/*.txt` + `timestamps.txt`): `read_kitti_bin`, `read_kitti_timestamps`, `read_kitti_oxts`; `replay` takes a directory of
+`.bin` sweeps and the IMU as arrays just as well.  A raw KITTI sweep has no per-point time: it is synthesised from the azimuth (the
+sensor spins at a constant rate), as the VELODYNE `time` field [s since the first point of the sweep]."""
 from __future__ import annotations
 
 import glob
@@ -90,6 +94,53 @@ def write_pcd(path: str, xyz, intensity=None, time_field: str = "time", time_val
                 f.write((" ".join(repr(v.item()) for v in r) + "\n").encode("ascii"))
 
 
+def read_kitti_bin(path: str, sweep_s: float = 0.1, clockwise: bool = True) -> np.ndarray:
+    """KITTI Velodyne sweep (`float32 x, y, z, reflectance` per point) -> the 32-byte PointType layout.  `time` = the fraction of
+    the revolution at the point's azimuth, counted from the first point's azimuth in the sensor's spin direction (KITTI's HDL-64E
+    spins clockwise seen from above), times `sweep_s`."""
+    a = np.fromfile(path, dtype=np.float32)
+    a = a[: (a.size // 4) * 4].reshape(-1, 4)
+    out = np.zeros(a.shape[0], POINT_DTYPE)
+    out["x"], out["y"], out["z"], out["w"], out["intensity"] = a[:, 0], a[:, 1], a[:, 2], 1.0, a[:, 3]
+    if a.shape[0]:
+        az = np.arctan2(a[:, 1].astype(np.float64), a[:, 0].astype(np.float64))
+        d = (az[0] - az) if clockwise else (az - az[0])
+        frac = np.mod(d, 2.0 * np.pi) / (2.0 * np.pi)
+        out["tu"] = (frac * sweep_s).astype(np.float32).view(np.uint32).astype(np.uint64)      # float32 seconds in the union's low word
+    return out
+
+
+def read_kitti_timestamps(path: str) -> np.ndarray:
+    """`YYYY-MM-DD hh:mm:ss.nnnnnnnnn` per line -> seconds since the first line (float64)."""
+    import calendar, time as _time
+    out = []
+    with open(path) as f:
+        for line in f:
+            line = line.strip()
+            if not line:
+                continue
+            date, _, clock = line.partition(" ")
+            hms, _, frac = clock.partition(".")
+            secs = calendar.timegm(_time.strptime(date + " " + hms, "%Y-%m-%d %H:%M:%S"))
+            out.append((secs, float("0." + (frac or "0"))))
+    if not out:
+        return np.zeros(0)
+    s0 = out[0][0]
+    t = np.array([(s - s0) + fr for s, fr in out], np.float64)
+    return t - t[0]
+
+
+def read_kitti_oxts(oxts_dir: str):
+    """KITTI OXTS packets (`oxts/data/%010d.txt`, 30 values per file; `oxts/timestamps.txt`) -> (stamps [s since the first
+    packet], gyro wx wy wz = values 17..19, accel ax ay az = values 11..13), the arrays `replay` takes as its IMU."""
+    files = sorted(glob.glob(os.path.join(oxts_dir, "data", "*.txt")))
+    st = read_kitti_timestamps(os.path.join(oxts_dir, "timestamps.txt"))
+    rows = [np.loadtxt(f, dtype=np.float64).reshape(-1)[:30] for f in files]
+    a = np.asarray(rows, np.float64).reshape(len(rows), -1)
+    n = min(len(st), a.shape[0])
+    return st[:n], a[:n, 17:20].astype(np.float32), a[:n, 11:14].astype(np.float32)
+
+
 def read_imu_csv(path: str):
     rows = []
     with open(path) as f:
@@ -112,13 +163,18 @@ def write_imu_csv(path: str, stamps, gyro, accel) -> None:
             f.write("%.9f,%s,%s\n" % (s, ",".join(repr(float(v)) for v in w), ",".join(repr(float(v)) for v in a)))
 
 
-def replay(loc, scan_dir: str, imu_csv: str, scan_stamps=None, sweep_s: float = 0.1, imu_lead_s: float = 0.005):
-    """Feed every PCD of `scan_dir` (sorted by name) to `loc` (anything with update_imu / update_pointcloud_points /
-    get_x: the product's api.Localizer or the oracle's Localizer).  `scan_stamps`: sweep reference time per scan
+def replay(loc, scan_dir: str, imu_csv, scan_stamps=None, sweep_s: float = 0.1, imu_lead_s: float = 0.005):
+    """Feed every sweep of `scan_dir` (`*.pcd`, or KITTI `*.bin`; sorted by name) to `loc` (anything with update_imu /
+    update_pointcloud_points / get_x: the product's api.Localizer or the oracle's Localizer).  `imu_csv`: path of an IMU CSV, or
+    the (stamps, gyro, accel) arrays themselves (read_kitti_oxts).  `scan_stamps`: sweep reference time per scan
     (default k * sweep_s).  IMU samples are delivered up to the end of each sweep (+ imu_lead_s) before the scan, the
     order the reference's two callbacks produce on a live system.  Returns (status codes, poses [n, 26])."""
     files = sorted(glob.glob(os.path.join(scan_dir, "*.pcd")))
-    st, w, a = read_imu_csv(imu_csv)
+    reader = read_pcd
+    if not files:
+        files = sorted(glob.glob(os.path.join(scan_dir, "*.bin")))
+        reader = lambda f: read_kitti_bin(f, sweep_s)
+    st, w, a = read_imu_csv(imu_csv) if isinstance(imu_csv, (str, os.PathLike)) else imu_csv
     if scan_stamps is None:
         scan_stamps = [k * sweep_s for k in range(len(files))]
     rcs, poses, i = [], [], 0
@@ -127,7 +183,7 @@ def replay(loc, scan_dir: str, imu_csv: str, scan_stamps=None, sweep_s: float = 
         while i < len(st) and st[i] <= until:
             loc.update_imu(st[i], w[i], a[i])
             i += 1
-        rcs.append(loc.update_pointcloud_points(read_pcd(f), stamp))
+        rcs.append(loc.update_pointcloud_points(reader(f), stamp))
         poses.append(np.array(loc.get_x()))
     return rcs, np.asarray(poses)
 

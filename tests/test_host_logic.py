@@ -332,3 +332,42 @@ def test_time_order_equals_library_call(built):
     t0 = time.perf_counter(); a = order(keys, 1, 0, 0); t1 = time.perf_counter(); b = order(keys, 1, 0, 1); t2 = time.perf_counter()
     np.testing.assert_array_equal(a, b)
     print(f"time order 64k with ties: restatement {1e3 * (t1 - t0):.2f} ms, library {1e3 * (t2 - t1):.2f} ms")
+
+
+def test_kitti_raw_readers(tmp_path):
+    """The replay harness reads the layout of a KITTI raw recording (BASELINE.json config 3): Velodyne `.bin` sweeps (per-point time
+    synthesised from the azimuth), `timestamps.txt`, OXTS packets -> the arrays `replay` feeds to a Localizer."""
+    from fast_limo_amd import replay
+    rs = np.random.RandomState(4)
+    vel = tmp_path / "velodyne_points" / "data"; vel.mkdir(parents=True)
+    n = 1000
+    az = -np.linspace(0.0, 2 * np.pi, n, endpoint=False) + 0.3          # clockwise from 0.3 rad
+    rng = rs.uniform(5, 40, n)
+    pts = np.stack([rng * np.cos(az), rng * np.sin(az), rs.uniform(-2, 1, n), rs.uniform(0, 1, n)], 1).astype(np.float32)
+    pts.tofile(str(vel / "0000000000.bin"))
+    p = replay.read_kitti_bin(str(vel / "0000000000.bin"), sweep_s=0.1)
+    assert p.dtype.itemsize == 32 and p.shape == (n,)
+    np.testing.assert_array_equal(np.stack([p["x"], p["y"], p["z"], p["intensity"]], 1), pts)
+    t = (p["tu"] & 0xffffffff).astype(np.uint32).view(np.float32)
+    assert t[0] == 0.0 and np.all(np.diff(t) > 0) and abs(t[-1] - 0.1 * (n - 1) / n) < 1e-6
+    ox = tmp_path / "oxts"; (ox / "data").mkdir(parents=True)
+    stamps = ["2011-09-26 13:02:25.964389445", "2011-09-26 13:02:25.974389445", "2011-09-26 13:02:26.004389445",
+              "2011-09-27 00:00:00.004389445"]
+    (ox / "timestamps.txt").write_text("\n".join(stamps) + "\n")
+    vals = rs.uniform(-1, 1, (4, 30))
+    for k in range(4):
+        (ox / "data" / ("%010d.txt" % k)).write_text(" ".join(repr(float(v)) for v in vals[k]) + "\n")
+    st, w, a = replay.read_kitti_oxts(str(ox))
+    np.testing.assert_allclose(st[:3], [0.0, 0.01, 0.04], atol=1e-9)
+    assert abs(st[3] - (10 * 3600 + 57 * 60 + 34.04)) < 1e-6                      # across midnight
+    np.testing.assert_array_equal(w, vals[:, 17:20].astype(np.float32))
+    np.testing.assert_array_equal(a, vals[:, 11:14].astype(np.float32))
+
+    class Rec:                                                                    # replay() drives anything Localizer-shaped
+        def __init__(self): self.imu, self.scans = [], []
+        def update_imu(self, s, w_, a_): self.imu.append(s)
+        def update_pointcloud_points(self, pts_, stamp): self.scans.append((len(pts_), stamp, len(self.imu))); return 0
+        def get_x(self): return np.zeros(26)
+    r = Rec()
+    rcs, poses = replay.replay(r, str(vel), (st, w, a), scan_stamps=[0.0])
+    assert rcs == [0] and r.scans == [(n, 0.0, 3)] and poses.shape == (1, 26)
