@@ -71,6 +71,7 @@ int flimo_loc_create(const flimo_loc_cfg* cfg, flimo_loc** out) {
   std::unique_ptr<flimo_loc> L(new flimo_loc());
   L->map.reset(new Mapper(cfg->gpu_device));
   L->loc.reset(new Localizer(L->map.get()));
+  L->loc->propagation_wait_s = 1.0;            // single-threaded callers (flimo_localizer_c.h); the C++ class itself waits like the reference
   Config c = to_config(cfg);
   L->loc->init(c);
   L->loc->filter().reference_solve = getenv("FLIMO_REFERENCE_SOLVE") != nullptr;
@@ -177,6 +178,7 @@ void flimo_loc_set_flags(flimo_loc* L, int add_to_map, int download_clouds, int 
 }
 void flimo_loc_set_lazy_time_order(flimo_loc* L, int on) { if (L) L->loc->lazy_time_order = on != 0; }
 void flimo_loc_set_gpu_filters(flimo_loc* L, int on) { if (L) L->loc->gpu_filters = on != 0; }
+void flimo_loc_set_propagation_wait(flimo_loc* L, double seconds) { if (L) L->loc->propagation_wait_s = seconds; }
 // the map insert that ends a scan runs on the Mapper's worker thread (Mapper::add_scan): wait for it / switch it off
 void flimo_loc_sync(flimo_loc* L) { if (L) L->map->sync(); }
 void flimo_loc_set_async_insert(flimo_loc* L, int on) { if (L) L->map->set_async(on != 0); }

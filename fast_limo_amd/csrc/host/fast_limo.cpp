@@ -695,13 +695,15 @@ bool Localizer::isInRange(const PointType& p) {                    // Localizer.
 }
 
 // Localizer::propagatedFromTimeRange + integrateImu (Localizer.cpp:855-915).  The reference waits on
-// cv_prop_stamp without bound; here the wait is bounded (1 s) so a missing IMU stream cannot hang.
+// cv_prop_stamp without bound and so does this class by default (propagation_wait_s < 0); the C handle bounds the wait
+// (flimo_loc_set_propagation_wait) because its callers usually feed IMU and sweeps from one thread.
 bool Localizer::propagatedFromTimeRange(double start_time, double end_time, States& frames) {
   frames.clear();
   std::unique_lock<std::mutex> lock(mtx_prop);
   if (propagated_buffer.empty() || propagated_buffer.front().time < end_time) {
-    cv_prop_stamp.wait_for(lock, std::chrono::seconds(1),
-                           [this, &end_time] { return !propagated_buffer.empty() && propagated_buffer.front().time >= end_time; });
+    auto reached = [this, &end_time] { return !propagated_buffer.empty() && propagated_buffer.front().time >= end_time; };
+    if (propagation_wait_s < 0.0) cv_prop_stamp.wait(lock, reached);
+    else cv_prop_stamp.wait_for(lock, std::chrono::duration<double>(propagation_wait_s), reached);
     if (propagated_buffer.empty() || propagated_buffer.front().time < end_time) return false;
   }
   const size_t n = propagated_buffer.size();

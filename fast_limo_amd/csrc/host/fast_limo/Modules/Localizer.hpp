@@ -67,6 +67,8 @@ class fast_limo::Localizer {
   bool add_to_map = true;               // benchmarks may freeze the map
   bool download_clouds = true;          // keep pc2match / final_scan host copies up to date
   bool gpu_filters = true;              // input filters + stamps on the GPU when the sweep may stay in arrival order and no host clouds are wanted
+  double propagation_wait_s = -1.0;     // propagatedFromTimeRange: < 0 waits for the IMU stream without bound (the reference,
+                                        // Localizer.cpp:859-863); >= 0 gives up after that many seconds (single-threaded drivers)
   bool lazy_time_order = true;          // the GPU gets the sweep in arrival order whenever the time order is not observable through
                                         // caps / voxel sums (deskewPointCloud); false: always the reference's permutation first
 

@@ -58,6 +58,11 @@ void   flimo_loc_set_lazy_time_order(flimo_loc* L, int on);
 /* default on: NaN removal, crop box, rate and min-distance filters and the per-point stamps run on the GPU
  * (flimo_raw_scan_filter_set) whenever the arrival-order path applies and no host copies of the clouds are requested */
 void   flimo_loc_set_gpu_filters(flimo_loc* L, int on);
+/* how long updatePointCloud waits for the IMU stream to reach the end of the sweep (Localizer::propagatedFromTimeRange,
+ * Localizer.cpp:855-871).  The reference waits on its condition variable without bound, and so does fast_limo::Localizer used
+ * through its C++ header (seconds < 0).  Handles made by flimo_loc_create start with 1 s, because their callers usually feed IMU
+ * and sweeps from ONE thread, where an unbounded wait could never be satisfied. */
+void   flimo_loc_set_propagation_wait(flimo_loc* L, double seconds);
 double flimo_loc_last_insert_seconds(flimo_loc* L);                   /* duration of the last insert (waits for it) */
 int    flimo_loc_update_imu(flimo_loc* L, double stamp, const float ang_vel[3], const float lin_accel[3]);
 /* pts5: n x (x y z intensity time[s since sweep reference]).  Returns Localizer status:

@@ -968,3 +968,38 @@ def test_crowded_cells_second_level_is_exact(built, oracle):
     np.testing.assert_array_equal(dev[g["nbr"]][vg], recs["nbr"][vg])
     np.testing.assert_array_equal(g["n"][vg], recs["n"][vg])
     np.testing.assert_array_equal(g["H"][vg].astype(np.float64), H)
+
+
+@pytest.mark.gpu
+def test_unbounded_imu_wait_like_the_reference(built, scene):
+    """Localizer::propagatedFromTimeRange (Localizer.cpp:855-871) waits on its condition variable until the IMU stream has
+    reached the end of the sweep -- without bound in the reference.  The C handle bounds the wait by default (one-thread
+    drivers); with the bound lifted a sweep that arrives before its IMU samples blocks until another thread delivers them,
+    and then registers exactly as in the one-thread order."""
+    import threading, time
+    from fast_limo_amd import api
+    st, w, a = synth.stationary_imu(0.0, 0.35)
+    scan5 = synth.velodyne_scan(16, 256, 25.0, 4)
+    cfg = dict(CAPS, time_offset=0)                   # with the offset on, a late IMU stream shifts the sweep instead of blocking it
+    ref = api.Localizer(api.default_cfg(**cfg)); ref.set_flags(add_to_map=False)
+    assert drive_two_scans(ref, scene["mp"], scan5, (st, w, a)) == [1, 0]
+    x_ref = ref.get_x(); ref.close()
+
+    G = api.Localizer(api.default_cfg(**cfg)); G.set_flags(add_to_map=False)
+    G.set_propagation_wait(-1.0)
+    G.map_add(scene["mp"])
+    i = 0
+    while st[i] <= 0.105:
+        G.update_imu(st[i], w[i], a[i]); i += 1
+    assert G.update_pointcloud(scan5, 0.0) == 1
+    out = {}
+    t = threading.Thread(target=lambda: out.setdefault("rc", G.update_pointcloud(scan5, 0.1)))
+    t.start()
+    time.sleep(1.3)                                   # longer than the C handle's default bound
+    assert t.is_alive() and "rc" not in out           # still waiting for the IMU stream
+    while i < len(st) and st[i] <= 0.205:
+        G.update_imu(st[i], w[i], a[i]); i += 1
+    t.join(20.0)
+    assert not t.is_alive() and out["rc"] == 0
+    np.testing.assert_array_equal(G.get_x(), x_ref)
+    G.close()
