@@ -798,7 +798,26 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
       }
 #endif
       // ---- group result: six rounds of min-extraction (the five, and the best of the rest) ----
-      if (L > 1) {
+      if constexpr (L == 2) {
+        // one exchange instead of six dependent rounds: both lanes hold ascending lists a (own) and b (partner's, one DPP quad
+        // permute per half key, all twelve independent); min(a[i], b[5 - i]) are the six smallest of the twelve (bitonic merge),
+        // a 12-exchange network (depth 5) sorts them -- keys are unique, so both lanes arrive at the same list
+        double a[6], c[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) a[i] = k5[i];
+#pragma unroll
+        for (int i = 0; i < 6; i++) c[i] = key_min(a[i], key_dpp<0xB1>(a[5 - i]));
+#define FLIMO_CE(i, j) { const double lo_ = key_min(c[i], c[j]); c[j] = key_max(c[i], c[j]); c[i] = lo_; }
+        FLIMO_CE(0, 5) FLIMO_CE(1, 3) FLIMO_CE(2, 4)
+        FLIMO_CE(1, 2) FLIMO_CE(3, 4)
+        FLIMO_CE(0, 3) FLIMO_CE(2, 5)
+        FLIMO_CE(0, 1) FLIMO_CE(2, 3) FLIMO_CE(4, 5)
+        FLIMO_CE(1, 2) FLIMO_CE(3, 4)
+#undef FLIMO_CE
+#pragma unroll
+        for (int i = 0; i < 5; i++) best[i] = (u64)__double_as_longlong(c[i]);
+        sixth = (u64)__double_as_longlong(c[5]);
+      } else if (L > 1) {
         u64 mine[6];
 #pragma unroll
         for (int i = 0; i < 5; i++) mine[i] = best[i];
