@@ -16,7 +16,7 @@ used only for the barrier and the max-over-ranks time.
 
 Rank 0 prints ONE JSON line (see the contract in the task description) with these extra objects:
   roofline      dominant kernel = the one-launch measurement pass (k-NN fast path + in-kernel widening + plane fit +
-                residual / Jacobian + H^T H reduction, `knn5_kernel<2, 8, true>`): ALGORITHMIC bytes per launch / its mean
+                residual / Jacobian + H^T H reduction, `knn5_kernel<2, 8, true, false>`): ALGORITHMIC bytes per launch / its mean
                 launch duration from HIP events attached to the dispatch during the timed region, vs 8 TB/s HBM; `stage`
                 gives every kind of pass (the first pass of the benchmark's poor prior runs k-NN / widening / fit as
                 separate dispatches); `traffic` = HBM-side bytes from the committed PMC profile of the same sources
@@ -408,9 +408,9 @@ def main():
         sep = {"knn": us(split["knn_ms"], split["separate_n"]), "widen": us(split["widen_ms"], split["separate_n"]),
                "fit_reduce": us(split["fit_ms"], split["separate_n"])} if split["separate_n"] else None
         if one_us:
-            kernel, dur_us, n_timed = "knn5_kernel<2, 8, true>: the whole measurement pass in one launch (k-NN fast path + in-kernel widening + plane fit + residual/Jacobian + H^T H reduction)", one_us, (dense["one_launch_passes_timed"] if (dense and dense.get("one_launch_pass_us")) else split["fused_n"])
+            kernel, dur_us, n_timed = "knn5_kernel<2, 8, true, false>: the whole measurement pass in one launch (k-NN fast path + in-kernel widening + plane fit + residual/Jacobian + H^T H reduction)", one_us, (dense["one_launch_passes_timed"] if (dense and dense.get("one_launch_pass_us")) else split["fused_n"])
         else:                              # developer switches (FLIMO_FUSE=0 ...): the k-NN dispatch alone
-            kernel, dur_us, n_timed = "knn5_kernel<2, 8, false>: k-NN dispatch (separate widening / fit dispatches)", us(tot["knn_ms"], tot["passes"]), tot["passes"]
+            kernel, dur_us, n_timed = "knn5_kernel<2, 8, false, false>: k-NN dispatch (separate widening / fit dispatches)", us(tot["knn_ms"], tot["passes"]), tot["passes"]
         achieved = bytes_per_query * qpl / (dur_us * 1e-6) / 1e9 if (dur_us and bytes_per_query) else None
         traffic = pmc_traffic(qpl)
         out["roofline"] = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS,

@@ -40,7 +40,7 @@ def main():
             if key in k:
                 return v
         return None
-    for kern, label in (("knn5_kernel<2, 8, true>", "dominant_kernel"), ("knn5_kernel<2, 8, false>", "knn5_separate"),
+    for kern, label in (("knn5_kernel<2, 8, true, false>", "dominant_kernel"), ("knn5_kernel<2, 8, false, false>", "knn5_separate"),
                         ("widen_kernel", "widen_kernel"), ("fit2_kernel", "fit2_kernel"), ("fit_kernel", "fit_kernel")):
         f = find(res["FETCH_SIZE_KB_per_launch"], kern)
         w = find(res["WRITE_SIZE_KB_per_launch"], kern)
