@@ -141,6 +141,7 @@ struct flimo_ctx {
   unsigned fine_threshold = 64;    // FLIMO_FINE_THRESHOLD
   unsigned fine_min_points = 32768;// FLIMO_FINE_MIN_POINTS: smaller crowded regions are not worth the extra dispatch (measured: 1M map, 7k points: +4 us)
   bool fine_valid = false;
+  bool crowd_box_valid = false;    // d_crowd_box holds the crowded cells' box of the current geometry
   GridView fine{};
   int fine_qlo[3] = {0, 0, 0}, fine_qhi[3] = {-1, -1, -1};
   float4 *d_fine_tmp = nullptr, *d_fine_pts = nullptr;
@@ -407,6 +408,7 @@ extern "C" int flimo_map_clear(flimo_ctx* c) {
   c->have_gbox = false;
   c->map_last_time = -1.0;
   c->bb[0] = c->bb[1] = c->bb[2] = 3.4e38f; c->bb[3] = c->bb[4] = c->bb[5] = -3.4e38f;
+  c->crowd_box_valid = false;
   insert_book_clear(c->book);
   c->gbook.active = false;
   c->prev.valid = 0;               // the pruning bound only survives map ADDITIONS (distances can only shrink)
@@ -442,7 +444,8 @@ static int publish_row_table(flimo_ctx* c, int nx, int ny, int nz, bool same_sha
 }
 
 // Second level: (re)built after every index update.  Cheap when no cell is crowded (one pass over the cell table).
-static int update_fine_grid(flimo_ctx* c) {
+// `relayout`: the geometry is new -> every cell is looked at; otherwise only the cells of the n_new points merged since the last look.
+static int update_fine_grid(flimo_ctx* c, bool relayout, const float4* new_pts = nullptr, size_t n_new = 0) {
   c->fine_valid = false;
   if (!c->fine_on || !c->grid_valid || c->map_n == 0) return FLIMO_OK;
   const GridView& g = c->grid;
@@ -450,8 +453,18 @@ static int update_fine_grid(flimo_ctx* c) {
     HIPCHK(c, hipMalloc(&c->d_crowd_box, 7 * sizeof(int)));
     HIPCHK(c, hipMalloc(&c->d_fine_count, sizeof(uint32_t)));
   }
+  static const bool prof = getenv("FLIMO_PROF_INSERT") != nullptr;     // developer timing of the stages (each ends synchronised)
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double tp0 = prof ? now() : 0.0;
   int box[7];
-  HIPCHK(c, crowded_cells_box(c->stream, g.cell_start, g.nx, g.ny, g.nz, g.xs, c->fine_threshold, c->d_crowd_box, box));
+  if (relayout || !c->crowd_box_valid || !new_pts) {
+    HIPCHK(c, crowded_cells_box(c->stream, g.cell_start, g.nx, g.ny, g.nz, g.xs, c->fine_threshold, c->d_crowd_box, box));
+    c->crowd_box_valid = true;
+  } else {
+    // same geometry as at the last look: only the cells of the points merged since can have become crowded
+    HIPCHK(c, crowded_cells_of_points(c->stream, new_pts, n_new, g.cell_start, g.ox, g.oy, g.oz, g.inv_cell, g.nx, g.ny, g.nz, g.xs,
+                                      c->fine_threshold, c->d_crowd_box, box));
+  }
   if (box[6] <= 0) return FLIMO_OK;
   // region copied completely: the crowded cells and one cell around them
   float lo[3], hi[3];
@@ -463,17 +476,23 @@ static int update_fine_grid(flimo_ctx* c) {
   for (int a = 0; a < 3; a++) nf[a] = (int)floorf((hi[a] - of[a]) * inv_f) + 3;
   const double ncf = (double)nf[0] * nf[1] * nf[2];
   if (ncf > 6.4e7 || (double)row_table_size(nf[0], nf[1], nf[2]) > 2.0e8) return FLIMO_OK;      // crowded all over: not a region
-  // the copies
-  if (c->map_n > c->fine_pts_cap) {
+  // the copies: the region's cells (clipped to the grid) are contiguous ranges of the cell-sorted map
+  const int gdim[3] = {g.nx, g.ny, g.nz};
+  int c0[3], c1[3];
+  for (int a = 0; a < 3; a++) { c0[a] = std::max(box[a] - 1, 0); c1[a] = std::min(box[3 + a] + 1, gdim[a] - 1); }
+  uint32_t m = 0;
+  HIPCHK(c, map_box_count(c->stream, g.cell_start, g.nx, g.ny, g.nz, g.xs, c0, c1, c->d_fine_count, &m, c->scratch));
+  if (m == 0 || m < c->fine_min_points) return FLIMO_OK;
+  const double tp1 = prof ? now() : 0.0;
+  if (m > c->fine_pts_cap) {
     (void)hipFree(c->d_fine_tmp); (void)hipFree(c->d_fine_pts);
     c->d_fine_tmp = c->d_fine_pts = nullptr; c->fine_pts_cap = 0;
-    HIPCHK(c, hipMalloc(&c->d_fine_tmp, c->map_cap * sizeof(float4)));
-    HIPCHK(c, hipMalloc(&c->d_fine_pts, c->map_cap * sizeof(float4)));
-    c->fine_pts_cap = c->map_cap;
+    const size_t cap = (size_t)m + m / 2 + 4096;
+    HIPCHK(c, hipMalloc(&c->d_fine_tmp, cap * sizeof(float4)));
+    HIPCHK(c, hipMalloc(&c->d_fine_pts, cap * sizeof(float4)));
+    c->fine_pts_cap = cap;
   }
-  uint32_t m = 0;
-  HIPCHK(c, map_subset_in_box(c->stream, g.pts, c->map_n, lo, hi, c->d_fine_tmp, c->d_fine_count, &m, c->scratch));
-  if (m == 0 || m < c->fine_min_points) return FLIMO_OK;
+  HIPCHK(c, map_box_copy(c->stream, g.pts, g.cell_start, g.nx, g.ny, g.nz, g.xs, c0, c1, c->d_fine_tmp, c->scratch));
   const size_t ncells = (size_t)nf[0] * nf[1] * nf[2];
   if (ncells + 1 > c->fine_cs_cap) {
     (void)hipFree(c->d_fine_cs);
@@ -492,8 +511,14 @@ static int update_fine_grid(flimo_ctx* c) {
   }
   HIPCHK(c, map_build_grid(c->stream, c->d_fine_tmp, m, c->d_fine_pts, c->d_fine_cs, ncells, of[0], of[1], of[2], inv_f, nf[0], nf[1], nf[2], 1,
                            c->scratch));
+  if (prof) HIPCHK(c, hipStreamSynchronize(c->stream));
+  const double tp2 = prof ? now() : 0.0;
   HIPCHK(c, map_build_row_table(c->stream, c->d_fine_cs, nf[0], nf[1], nf[2], c->d_fine_rt, true));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (prof) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    fprintf(stderr, "[flimo fine] crowded cells + count %.1f us, copy + sort into %d x %d x %d cells %.1f us, row table %.1f us (%u points)\n",
+            (tp1 - tp0) * 1e6, nf[0], nf[1], nf[2], (tp2 - tp1) * 1e6, (now() - tp2) * 1e6, m);
+  }
   GridView& f = c->fine;
   f.pts = c->d_fine_pts; f.cell_start = c->d_fine_cs; f.row_table = c->d_fine_rt;
   f.ox = of[0]; f.oy = of[1]; f.oz = of[2];
@@ -539,7 +564,7 @@ static int rebuild_grid(flimo_ctx* c) {
     c->grid.n_pts = (uint32_t)c->map_n;
     c->grid_valid = true;
     c->grid_merges++;
-    return update_fine_grid(c);
+    return update_fine_grid(c, false, c->d_map_raw + n_old, k);
   }
   if (getenv("FLIMO_PROF_INSERT"))
     fprintf(stderr, "[flimo index] full layout: valid %d sorted %p full_rebuild %d force %d n_pts %u map_n %zu covers %d  box [%g %g %g | %g %g %g] grid o (%g %g %g) n (%d %d %d)\n",
@@ -614,7 +639,7 @@ static int rebuild_grid(flimo_ctx* c) {
   c->grid_valid = true;
   c->force_full = false;
   c->grid_builds++;
-  return update_fine_grid(c);
+  return update_fine_grid(c, true);
 }
 
 // Debug: sort the whole map again with the CURRENT geometry into temporary buffers and compare the result with the

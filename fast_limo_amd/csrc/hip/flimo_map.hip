@@ -284,6 +284,33 @@ __global__ __launch_bounds__(256) void crowded_kernel(const uint32_t* __restrict
   atomicMax(&box[3], x); atomicMax(&box[4], y); atomicMax(&box[5], z);
   atomicAdd(&box[6], 1);
 }
+// the same test for the cells of k freshly merged points only (cells gain points nowhere else): O(k) instead of O(cells)
+__global__ __launch_bounds__(256) void crowded_points_kernel(const float4* __restrict__ pts, size_t k, const uint32_t* __restrict__ cell_start,
+                                                             float ox, float oy, float oz, float inv_cell, int nx, int ny, int nz, int xs,
+                                                             uint32_t threshold, int* __restrict__ box) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= k) return;
+  const uint32_t col = column_key(pts[i], ox, oy, oz, inv_cell, nx, ny, nz, xs);
+  const uint32_t col0 = col - col % (uint32_t)xs;
+  const uint32_t cnt = cell_start[col0 + xs] - cell_start[col0];
+  if (cnt <= threshold) return;
+  const uint32_t cell = col0 / (uint32_t)xs;
+  const int x = (int)(cell % (uint32_t)nx), y = (int)((cell / (uint32_t)nx) % (uint32_t)ny), z = (int)(cell / ((uint32_t)nx * (uint32_t)ny));
+  atomicMin(&box[0], x); atomicMin(&box[1], y); atomicMin(&box[2], z);
+  atomicMax(&box[3], x); atomicMax(&box[4], y); atomicMax(&box[5], z);
+  atomicAdd(&box[6], 1);
+}
+hipError_t crowded_cells_of_points(hipStream_t st, const float4* pts, size_t k, const uint32_t* cell_start, float ox, float oy, float oz,
+                                   float inv_cell, int nx, int ny, int nz, int xs, uint32_t threshold, int* box_dev, int box_host[7]) {
+  hipError_t e;
+  if (k > 0)
+    hipLaunchKernelGGL(crowded_points_kernel, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, st, pts, k, cell_start, ox, oy, oz, inv_cell, nx,
+                       ny, nz, xs, threshold, box_dev);
+  if ((e = hipMemcpyAsync(box_host, box_dev, 7 * sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+  return hipStreamSynchronize(st);
+}
+// Box of the cells that hold more than `threshold` points, from a look at every cell (new geometry); box_dev keeps it for
+// crowded_cells_of_points.  box_host[6] > 0: some cell is crowded.
 hipError_t crowded_cells_box(hipStream_t st, const uint32_t* cell_start, int nx, int ny, int nz, int xs, uint32_t threshold,
                              int* box_dev, int box_host[7]) {
   const int init[7] = {INT_MAX, INT_MAX, INT_MAX, -1, -1, -1, 0};
@@ -294,46 +321,65 @@ hipError_t crowded_cells_box(hipStream_t st, const uint32_t* cell_start, int nx,
   if ((e = hipMemcpyAsync(box_host, box_dev, 7 * sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
   return hipStreamSynchronize(st);
 }
-// copy of the map points inside [lo, hi) (metres), w = position in the main sorted map; *count_dev receives their number
-__global__ __launch_bounds__(256) void inbox_flag_kernel(const float4* __restrict__ pts, size_t n, float lx, float ly, float lz, float hx,
-                                                         float hy, float hz, uint32_t* __restrict__ flag) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float4 p = pts[i];
-  flag[i] = (p.x >= lx && p.x < hx && p.y >= ly && p.y < hy && p.z >= lz && p.z < hz) ? 1u : 0u;
+// Copy of the map points of a box of cells [c0, c1] (inclusive, already clipped to the grid), w = position in the main sorted
+// map.  The map is sorted by (z, y, x column), so the box is (y1-y0+1)(z1-z0+1) contiguous ranges read off the cell table:
+// counting and copying cost what the box holds, not what the map holds.  Two steps, so that the caller can size its
+// buffers (or give up) once it knows the count.
+__global__ __launch_bounds__(256) void boxrows_count_kernel(const uint32_t* __restrict__ cell_start, int ny, int nxf, int xs, int x0, int x1,
+                                                            int y0, int nyb, int z0, int nrows, uint32_t* __restrict__ cnt) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nrows) return;
+  const int y = y0 + r % nyb, z = z0 + r / nyb;
+  const size_t base = ((size_t)z * (size_t)ny + (size_t)y) * (size_t)nxf;
+  cnt[r] = cell_start[base + (size_t)(x1 + 1) * xs] - cell_start[base + (size_t)x0 * xs];
 }
-__global__ __launch_bounds__(256) void inbox_scatter_kernel(const float4* __restrict__ pts, size_t n, const uint32_t* __restrict__ flag,
-                                                            const uint32_t* __restrict__ pos, float4* __restrict__ out,
-                                                            uint32_t* __restrict__ count) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  if (i == n - 1) *count = pos[i] + flag[i];
-  if (!flag[i]) return;
-  const float4 p = pts[i];
-  out[pos[i]] = make_float4(p.x, p.y, p.z, __uint_as_float((uint32_t)i));
+__global__ __launch_bounds__(64) void boxrows_total_kernel(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off, int nrows,
+                                                           uint32_t* __restrict__ total) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *total = off[nrows - 1] + cnt[nrows - 1];
 }
-hipError_t map_subset_in_box(hipStream_t st, const float4* pts, size_t n, const float lo[3], const float hi[3], float4* out,
-                             uint32_t* count_dev, uint32_t* count_host, MapBuildScratch& S) {
+__global__ __launch_bounds__(64) void boxrows_copy_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ cell_start, int ny,
+                                                          int nxf, int xs, int x0, int y0, int nyb, int z0, const uint32_t* __restrict__ cnt,
+                                                          const uint32_t* __restrict__ off, float4* __restrict__ out) {
+  const int r = blockIdx.x;
+  const int y = y0 + r % nyb, z = z0 + r / nyb;
+  const size_t base = ((size_t)z * (size_t)ny + (size_t)y) * (size_t)nxf;
+  const uint32_t a = cell_start[base + (size_t)x0 * xs], n = cnt[r], o = off[r];
+  for (uint32_t i = threadIdx.x; i < n; i += 64) {
+    const float4 p = pts[a + i];
+    out[o + i] = make_float4(p.x, p.y, p.z, __uint_as_float(a + i));
+  }
+}
+hipError_t map_box_count(hipStream_t st, const uint32_t* cell_start, int nx, int ny, int nz, int xs, const int c0[3], const int c1[3],
+                         uint32_t* count_dev, uint32_t* count_host, MapBuildScratch& S) {
   *count_host = 0;
-  if (n == 0) return hipSuccess;
-  hipError_t e = ensure_scratch(S, n);
+  const int nyb = c1[1] - c0[1] + 1, nzb = c1[2] - c0[2] + 1;
+  if (nyb <= 0 || nzb <= 0 || c1[0] < c0[0]) return hipSuccess;
+  const int nrows = nyb * nzb;
+  hipError_t e = ensure_scratch(S, (size_t)nrows);
   if (e != hipSuccess) return e;
-  const int blocks = (int)((n + 255) / 256);
   size_t scan_bytes = 0;
-  e = exclusive_sum(nullptr, scan_bytes, S.keys_in, S.vals_in, n, st);
-  if (e != hipSuccess) return e;
+  if ((e = exclusive_sum(nullptr, scan_bytes, S.keys_in, S.vals_in, (size_t)nrows, st)) != hipSuccess) return e;
   if (scan_bytes > S.cub_tmp_bytes) {
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
     if (S.cub_tmp) (void)hipFree(S.cub_tmp);
     if ((e = hipMalloc(&S.cub_tmp, scan_bytes + 1024)) != hipSuccess) return e;
     S.cub_tmp_bytes = scan_bytes + 1024;
   }
-  hipLaunchKernelGGL(inbox_flag_kernel, dim3(blocks), dim3(256), 0, st, pts, n, lo[0], lo[1], lo[2], hi[0], hi[1], hi[2], S.keys_in);
-  e = exclusive_sum(S.cub_tmp, scan_bytes, S.keys_in, S.vals_in, n, st);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(inbox_scatter_kernel, dim3(blocks), dim3(256), 0, st, pts, n, S.keys_in, S.vals_in, out, count_dev);
+  hipLaunchKernelGGL(boxrows_count_kernel, dim3((nrows + 255) / 256), dim3(256), 0, st, cell_start, ny, nx * xs, xs, c0[0], c1[0], c0[1], nyb,
+                     c0[2], nrows, S.keys_in);
+  if ((e = exclusive_sum(S.cub_tmp, scan_bytes, S.keys_in, S.vals_in, (size_t)nrows, st)) != hipSuccess) return e;
+  hipLaunchKernelGGL(boxrows_total_kernel, dim3(1), dim3(64), 0, st, S.keys_in, S.vals_in, nrows, count_dev);
   if ((e = hipMemcpyAsync(count_host, count_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
   return hipStreamSynchronize(st);
+}
+// second step: the counts / offsets of map_box_count (same box, nothing else used the scratch in between) -> the copies
+hipError_t map_box_copy(hipStream_t st, const float4* pts, const uint32_t* cell_start, int nx, int ny, int nz, int xs, const int c0[3],
+                        const int c1[3], float4* out, MapBuildScratch& S) {
+  const int nyb = c1[1] - c0[1] + 1, nzb = c1[2] - c0[2] + 1;
+  if (nyb <= 0 || nzb <= 0 || c1[0] < c0[0]) return hipSuccess;
+  hipLaunchKernelGGL(boxrows_copy_kernel, dim3(nyb * nzb), dim3(64), 0, st, pts, cell_start, ny, nx * xs, xs, c0[0], c0[1], nyb, c0[2],
+                     S.keys_in, S.vals_in, out);
+  return hipGetLastError();
 }
 
 // ---- y-fastest, padded copy of the row bounds (GridView::row_table) --------------------------
