@@ -333,7 +333,8 @@ def main():
         for label in ("tied", "unique"):
             sweeps = []
             for j in range(args.e2e_sweeps):
-                sc = synth.velodyne_scan(args.rings, args.azimuths, args.box, 100 + j)
+                # different sweeps for the two runs: a sweep the map has already seen stores almost nothing
+                sc = synth.velodyne_scan(args.rings, args.azimuths, args.box, 100 + j + (args.e2e_sweeps if label == "unique" else 0))
                 if label == "unique":
                     sc[:, 4] += (np.arange(sc.shape[0]) % args.rings).astype(np.float32) * np.float32(1.5e-6)
                 sweeps.append(api.make_points_velodyne(sc))

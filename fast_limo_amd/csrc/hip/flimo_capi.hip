@@ -130,6 +130,7 @@ struct flimo_ctx {
   bool recs_valid = false, dbg_valid = false;
   PrevPass prev{};                 // previous pass of the same resident scan (k-NN pruning bound); valid = 0 after any scan change
   bool prune = true;               // FLIMO_PRUNE=0 disables the bound (A/B checks)
+  unsigned probe_min = 96;         // FLIMO_PROBE=<n>: first pass, a query with >= n candidates in its 3x3x3 block walks its own cell first for a bound (0: off)
   int tail_pass1 = -1;             // FLIMO_TAIL_PASS1: 1 = the first pass of a scan always uses the in-kernel tail, 0 = never, default: by the straggler count of the last first pass
   int stragglers_pass1 = 1 << 30;  // queries of the last first pass of a scan that needed more than their 3x3x3 block (unknown: many)
   int stragglers_hist[4] = {1 << 30, 0, 0, 0};   // the same per pass position within a scan (0 = first pass .. 3 = fourth and later), last scan that reported
@@ -139,6 +140,7 @@ struct flimo_ctx {
   // hold more than fine_threshold points, with a copy of every map point inside it
   bool fine_on = true;             // FLIMO_FINE=0 switches it off (A/B checks)
   unsigned fine_threshold = 64;    // FLIMO_FINE_THRESHOLD
+  int fine_div = 4;                // FLIMO_FINE_DIV: fine cells per cell edge (power of two)
   unsigned fine_min_points = 32768;// FLIMO_FINE_MIN_POINTS: smaller crowded regions are not worth the extra dispatch (measured: 1M map, 7k points: +4 us)
   bool fine_valid = false;
   bool crowd_box_valid = false;    // d_crowd_box holds the crowded cells' box of the current geometry
@@ -324,12 +326,16 @@ extern "C" int flimo_ctx_create(int device, flimo_ctx** out) {
   const char* e = getenv("FLIMO_LPQ");
   if (e) { int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) c->lanes_per_query = v; }
   c->book = insert_book_create();
+  e = getenv("FLIMO_PROBE");
+  if (e && atoi(e) >= 0) c->probe_min = (unsigned)atoi(e);
   e = getenv("FLIMO_PRUNE");
   if (e) c->prune = atoi(e) != 0;
   e = getenv("FLIMO_FINE");
   if (e) c->fine_on = atoi(e) != 0;
   e = getenv("FLIMO_FINE_THRESHOLD");
   if (e && atoi(e) > 0) c->fine_threshold = (unsigned)atoi(e);
+  e = getenv("FLIMO_FINE_DIV");
+  if (e && (atoi(e) == 2 || atoi(e) == 4 || atoi(e) == 8)) c->fine_div = atoi(e);
   e = getenv("FLIMO_FINE_MIN_POINTS");
   if (e && atoi(e) >= 0) c->fine_min_points = (unsigned)atoi(e);
   e = getenv("FLIMO_XSLABS");
@@ -470,7 +476,7 @@ static int update_fine_grid(flimo_ctx* c, bool relayout, const float4* new_pts =
   float lo[3], hi[3];
   const float o[3] = {g.ox, g.oy, g.oz};
   for (int a = 0; a < 3; a++) { lo[a] = o[a] + (float)(box[a] - 1) * g.cell; hi[a] = o[a] + (float)(box[3 + a] + 2) * g.cell; }
-  const float cf = 0.25f * g.cell, inv_f = 1.0f / cf;
+  const float cf = g.cell / (float)c->fine_div, inv_f = 1.0f / cf;
   const float of[3] = {lo[0] - cf, lo[1] - cf, lo[2] - cf};             // one fine cell of margin below the region
   int nf[3];
   for (int a = 0; a < 3; a++) nf[a] = (int)floorf((hi[a] - of[a]) * inv_f) + 3;
@@ -1289,6 +1295,7 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   const bool tail_here = first_pass ? (c->tail_pass1 >= 0 ? c->tail_pass1 != 0 : c->stragglers_hist[0] <= 1024)
                                     : (c->stragglers_hist[c->pass_in_scan] <= 1024);
   const bool tail = c->tail && tail_here && !heavy_on && mp.max_ring >= 2 && mp.max_ring <= 3;
+  c->prev.probe_min = c->probe_min;
   c->prev.heavy = (!tail && mp.max_ring >= 2 && mp.max_ring <= 3) ? c->heavy_threshold : 0xffffffffu;   // only when the wave-per-query kernel follows
   // One launch for the whole pass (k-NN + tail + fit + reduction) whenever the tail applies, no records are wanted and the
   // k-NN runs with its default two lanes per query

@@ -376,13 +376,35 @@ __device__ __forceinline__ double key_group_min(double md, int Gl, int lane) {
   return md;
 }
 
+// Two ascending 6-lists of unique keys -> the six smallest, ascending: min(a[i], b[5 - i]) are the six smallest of the twelve
+// (bitonic merge), a 12-exchange network (depth 5) sorts them.
+__device__ __forceinline__ void key_merge6(const double (&a)[6], const double (&b)[6], double (&c)[6]) {
+#pragma unroll
+  for (int i = 0; i < 6; i++) c[i] = key_min(a[i], b[5 - i]);
+#define FLIMO_CE(i, j) { const double lo_ = key_min(c[i], c[j]); c[j] = key_max(c[i], c[j]); c[i] = lo_; }
+  FLIMO_CE(0, 5) FLIMO_CE(1, 3) FLIMO_CE(2, 4)
+  FLIMO_CE(1, 2) FLIMO_CE(3, 4)
+  FLIMO_CE(0, 3) FLIMO_CE(2, 5)
+  FLIMO_CE(0, 1) FLIMO_CE(2, 3) FLIMO_CE(4, 5)
+  FLIMO_CE(1, 2) FLIMO_CE(3, 4)
+#undef FLIMO_CE
+}
+// the lists of the two lanes of a query (L = 2) -> the pair's list in both lanes: one DPP quad permute per half key (all twelve
+// independent) instead of six dependent extraction rounds; keys are unique, so both lanes arrive at the same list
+__device__ __forceinline__ void key_pair_merge6(const double (&a)[6], double (&c)[6]) {
+  double b[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) b[i] = key_dpp<0xB1>(a[i]);
+  key_merge6(a, b, c);
+}
+
 // N candidate slots of one lane: stream positions s0, s0 + L, ...; dead slots (>= total) re-read the last position and
 // insert +inf.  All N loads are issued back to back (the empty asm consumes every loaded value at once).
 // PAYW: the key's payload is the point's w (the fine level's copies carry their position in the main map there) instead of the
 // position in `pts`
-template <int L, int N, bool PAYW = false>
+template <int L, int N, bool PAYW = false, int NSEG = 9>
 __device__ __forceinline__ void knn5_body(const float4* __restrict__ pts, uint32_t s0, uint32_t total, uint32_t last,
-                                          const uint32_t (&off)[10], const uint32_t (&dl)[9], float gx, float gy, float gz,
+                                          const uint32_t (&off)[NSEG + 1], const uint32_t (&dl)[NSEG], float gx, float gy, float gz,
                                           double (&k5)[6]) {
   float4 pt[N];
   uint32_t id[N];
@@ -391,7 +413,7 @@ __device__ __forceinline__ void knn5_body(const float4* __restrict__ pts, uint32
     const uint32_t s = min(s0 + u * L, last);
     uint32_t delta = dl[0];
 #pragma unroll
-    for (int t = 1; t < 9; t++) delta = (s >= off[t]) ? dl[t] : delta;
+    for (int t = 1; t < NSEG; t++) delta = (s >= off[t]) ? dl[t] : delta;
     id[u] = s + delta;
     pt[u] = pts[id[u]];
   }
@@ -438,6 +460,7 @@ __device__ __forceinline__ bool key_has_tie(const u64 (&best)[5], u64 sixth) {
   return (d0 == d1) | (d1 == d2) | (d2 == d3) | (d3 == d4) | (d4 == d5);
 }
 constexpr int TAIL_MAX_RING = 3;
+constexpr uint32_t PROBE_MIN_OWN = 6;           // first pass: an own cell with fewer points gives no useful bound
 struct __align__(16) WaveLds {                  // one per wave of the block
   float tile[16 * 65];                          // fused pass: the wave's rows, [col][row] with stride 65
   double acc[256];                              // fused pass: the wave's raw f64 MFMA accumulators
@@ -743,6 +766,11 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
       c1 = min(max(c1, c0), G.nxf);
       const uint32_t py = (uint32_t)G.ny + 4u, plane = py * ((uint32_t)G.nz + 4u);
       const uint32_t yz = (uint32_t)(cz + 1) * py + (uint32_t)(cy + 1);
+      // First pass of a scan (no bound from a previous pass): a query whose OWN cell is crowded (raw sweeps inserted into the
+      // map leave cells with tens to hundreds of points) first walks that cell alone; its 5th distance there is an upper bound
+      // of the true one, and the other 26 cells are then walked only as far as that ball reaches (rows and end cells it cannot
+      // reach are dropped, exactly as with the bound of a previous pass).
+      const bool probe_on = L == 2 && !prev.valid && prev.heavy == 0xffffffffu && prev.probe_min != 0u;          // wave-uniform
       U3 rbl[3], rbh[3];
       {
         const uint32_t iL = (uint32_t)c0 * plane + yz, iH = (uint32_t)c1 * plane + yz;
@@ -752,24 +780,49 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
           rbh[dz] = *reinterpret_cast<const U3*>(G.row_table + (iH + (uint32_t)dz * py));
         }
       }
+      // the own cell's range: one 8-byte load from the x-fastest cell table, same round trip as the rows' bounds; the two inner x
+      // planes of the row table (needed to clip the second walk to cells) are fetched by the probing queries only, while they walk
+      uint32_t lo_own = 0u, n_own = 0u;
+      if (probe_on && cx >= 0 && cx < G.nx && cy >= 0 && cy < G.ny && cz >= 0 && cz < G.nz) {
+        const uint32_t* cs = G.cell_start + (((size_t)cz * (size_t)G.ny + (size_t)cy) * (size_t)G.nxf + (size_t)cx * (size_t)G.xs);
+        lo_own = cs[0];
+        n_own = cs[G.xs] - lo_own;
+      }
+      // conservative distances (cell units) to the neighbouring rows; without a bound every row is in
+      const float yd[3] = {fmaxf(ry - margin, 0.f), 0.f, fmaxf(1.f - ry - margin, 0.f)};
+      const float zd[3] = {fmaxf(rz - margin, 0.f), 0.f, fmaxf(1.f - rz - margin, 0.f)};
+      const float yd2[3] = {yd[0] * yd[0], 0.f, yd[2] * yd[2]}, zd2[3] = {zd[0] * zd[0], 0.f, zd[2] * zd[2]};
       uint32_t off[10], dl[9];          // dl[t] = lo[t] - off[t]: stream position -> map position
       off[0] = 0;
-      {
-        // conservative distances (cell units) to the neighbouring rows; without a bound every row is in
-        const float yd[3] = {fmaxf(ry - margin, 0.f), 0.f, fmaxf(1.f - ry - margin, 0.f)};
-        const float zd[3] = {fmaxf(rz - margin, 0.f), 0.f, fmaxf(1.f - rz - margin, 0.f)};
-        const float yd2[3] = {yd[0] * yd[0], 0.f, yd[2] * yd[2]}, zd2[3] = {zd[0] * zd[0], 0.f, zd[2] * zd[2]};
+#pragma unroll
+      for (int dz = 0; dz < 3; dz++) {
+        const uint32_t sl[3] = {rbl[dz].a, rbl[dz].b, rbl[dz].c}, sh[3] = {rbh[dz].a, rbh[dz].b, rbh[dz].c};
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          const int t = 3 * dz + k;
+          const bool row = !prev.valid || (yd2[k] + zd2[dz] <= b2);
+          dl[t] = sl[k] - off[t];
+          off[t + 1] = off[t] + (row ? sh[k] - sl[k] : 0u);
+        }
+      }
+      // probing pays when the block is heavy (crowded region: every lane of the wave probes, so nobody waits for a neighbour's
+      // full walk) and the own cell can give a bound at all
+      const bool two = probe_on && off[9] >= prev.probe_min && n_own >= PROBE_MIN_OWN;        // the same in both lanes of the pair
+      U3 rm1[3], rm2[3];
+#pragma unroll
+      for (int dz = 0; dz < 3; dz++) { rm1[dz] = rbl[dz]; rm2[dz] = rbh[dz]; }
+      if (two) {
+        const uint32_t iA = (uint32_t)(cx * G.xs) * plane + yz, iB = (uint32_t)((cx + 1) * G.xs) * plane + yz;
 #pragma unroll
         for (int dz = 0; dz < 3; dz++) {
-          const uint32_t sl[3] = {rbl[dz].a, rbl[dz].b, rbl[dz].c}, sh[3] = {rbh[dz].a, rbh[dz].b, rbh[dz].c};
-#pragma unroll
-          for (int k = 0; k < 3; k++) {
-            const int t = 3 * dz + k;
-            const bool row = !prev.valid || (yd2[k] + zd2[dz] <= b2);
-            dl[t] = sl[k] - off[t];
-            off[t + 1] = off[t] + (row ? sh[k] - sl[k] : 0u);
-          }
+          rm1[dz] = *reinterpret_cast<const U3*>(G.row_table + (iA + (uint32_t)dz * py));
+          rm2[dz] = *reinterpret_cast<const U3*>(G.row_table + (iB + (uint32_t)dz * py));
         }
+      }
+      if (two) {                        // first walk: the own cell only (one segment)
+        dl[0] = lo_own;
+#pragma unroll
+        for (int t = 1; t < 10; t++) off[t] = n_own;
       }
       // A query whose block is crowded (a few cells right under the sensor hold hundreds of points once scans have been
       // inserted) would keep its whole wave waiting while its two lanes walk the stream: it is handed to the wave-per-query
@@ -780,12 +833,14 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
       // ---- flattened candidate stream, branch-free body ----
       const double none = __longlong_as_double((long long)KEY_NONE);
       double k5[6] = {none, none, none, none, none, none};
-      const uint32_t last = total - 1u;
-      // full bodies while more than half of a body's slots are live for this lane, then one half body
-      uint32_t s0 = (uint32_t)sub;
-      for (; s0 + (SLOTS / 2) * L < total; s0 += SLOTS * L)
-        knn5_body<L, SLOTS, FINE>(G.pts, s0, total, last, off, dl, gx, gy, gz, k5);
-      if (s0 < total) knn5_body<L, (SLOTS >= 2 ? SLOTS / 2 : 1), FINE>(G.pts, s0, total, last, off, dl, gx, gy, gz, k5);
+      {
+        const uint32_t last = total - 1u;
+        // full bodies while more than half of a body's slots are live for this lane, then one half body
+        uint32_t s0 = (uint32_t)sub;
+        for (; s0 + (SLOTS / 2) * L < total; s0 += SLOTS * L)
+          knn5_body<L, SLOTS, FINE>(G.pts, s0, total, last, off, dl, gx, gy, gz, k5);
+        if (s0 < total) knn5_body<L, (SLOTS >= 2 ? SLOTS / 2 : 1), FINE>(G.pts, s0, total, last, off, dl, gx, gy, gz, k5);
+      }
       cand = total > (uint32_t)sub ? (int)((total - (uint32_t)sub + L - 1) / L) : 0;
 #pragma unroll
       for (int i = 0; i < 5; i++) best[i] = (u64)__double_as_longlong(k5[i]);
@@ -797,23 +852,65 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
         if (threadIdx.x == 0) g_trace[0][blockIdx.x * 8 + 7] = __smid();
       }
 #endif
-      // ---- group result: six rounds of min-extraction (the five, and the best of the rest) ----
+      // ---- group result: the five, and the best of the rest ----
       if constexpr (L == 2) {
-        // one exchange instead of six dependent rounds: both lanes hold ascending lists a (own) and b (partner's, one DPP quad
-        // permute per half key, all twelve independent); min(a[i], b[5 - i]) are the six smallest of the twelve (bitonic merge),
-        // a 12-exchange network (depth 5) sorts them -- keys are unique, so both lanes arrive at the same list
-        double a[6], c[6];
+        double c[6];
+        key_pair_merge6(k5, c);
+        if (__any(two)) {
+          // second walk of the queries that probed their own cell: the rest of the block within the probe's ball.  Ten segments:
+          // eight rows, and the centre row on both sides of the own cell (already walked).
+          uint32_t off2[11], dl2[10];
+          off2[0] = 0;
+          if (two) {
+            const float d5p = __uint_as_float((uint32_t)((u64)__double_as_longlong(c[4]) >> 32));      // n_own >= 5: finite
+            const float rc = (fl_sqrt(d5p) * (1.f + 1.0e-5f) + 1.0e-6f) * G.inv_cell;
+            const float bb = rc * rc * (1.f + 1.0e-5f);                                              // bound, cell units squared
 #pragma unroll
-        for (int i = 0; i < 6; i++) a[i] = k5[i];
+            for (int dz = 0; dz < 3; dz++) {
+              const uint32_t s0_[3] = {rbl[dz].a, rbl[dz].b, rbl[dz].c}, s1_[3] = {rm1[dz].a, rm1[dz].b, rm1[dz].c};
+              const uint32_t s2_[3] = {rm2[dz].a, rm2[dz].b, rm2[dz].c}, s3_[3] = {rbh[dz].a, rbh[dz].b, rbh[dz].c};
 #pragma unroll
-        for (int i = 0; i < 6; i++) c[i] = key_min(a[i], key_dpp<0xB1>(a[5 - i]));
-#define FLIMO_CE(i, j) { const double lo_ = key_min(c[i], c[j]); c[j] = key_max(c[i], c[j]); c[i] = lo_; }
-        FLIMO_CE(0, 5) FLIMO_CE(1, 3) FLIMO_CE(2, 4)
-        FLIMO_CE(1, 2) FLIMO_CE(3, 4)
-        FLIMO_CE(0, 3) FLIMO_CE(2, 5)
-        FLIMO_CE(0, 1) FLIMO_CE(2, 3) FLIMO_CE(4, 5)
-        FLIMO_CE(1, 2) FLIMO_CE(3, 4)
-#undef FLIMO_CE
+              for (int k = 0; k < 3; k++) {
+                const float dyz2 = yd2[k] + zd2[dz];
+                const bool row = dyz2 <= bb;
+                // reach along x within this row (cell units, widened by the rounding margin): the left cell is rx away, the right 1 - rx
+                const float xr = fl_sqrt(fmaxf(bb - dyz2, 0.f)) * (1.f + 1.0e-6f) + margin + 1.0e-4f;
+                const uint32_t lo_ = (rx <= xr) ? s0_[k] : s1_[k], hi_ = ((1.f - rx) <= xr) ? s3_[k] : s2_[k];
+                if (dz == 1 && k == 1) {
+                  // centre row: [lo_, own cell) and (own cell, hi_)
+                  dl2[4] = lo_ - off2[4];
+                  off2[5] = off2[4] + (s1_[k] - lo_);
+                  dl2[5] = s2_[k] - off2[5];
+                  off2[6] = off2[5] + (hi_ - s2_[k]);
+                } else {
+                  const int t = 3 * dz + k + ((3 * dz + k) > 4 ? 1 : 0);
+                  dl2[t] = lo_ - off2[t];
+                  off2[t + 1] = off2[t] + (row ? hi_ - lo_ : 0u);
+                }
+              }
+            }
+          } else {
+#pragma unroll
+            for (int t = 0; t < 10; t++) { off2[t + 1] = 0u; dl2[t] = 0u; }
+          }
+          const uint32_t total2 = off2[10];
+          double kb[6] = {none, none, none, none, none, none};
+          {
+            const uint32_t last = total2 - 1u;
+            uint32_t s0 = (uint32_t)sub;
+            for (; s0 + (SLOTS / 2) * L < total2; s0 += SLOTS * L)
+              knn5_body<L, SLOTS, FINE>(G.pts, s0, total2, last, off2, dl2, gx, gy, gz, kb);
+            if (s0 < total2) knn5_body<L, (SLOTS >= 2 ? SLOTS / 2 : 1), FINE>(G.pts, s0, total2, last, off2, dl2, gx, gy, gz, kb);
+          }
+          cand += total2 > (uint32_t)sub ? (int)((total2 - (uint32_t)sub + L - 1) / L) : 0;
+          double cb[6], cc[6];
+          key_pair_merge6(kb, cb);
+          key_merge6(c, cb, cc);                       // own cell + rest of the ball: disjoint point sets, unique keys
+          if (two) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) c[i] = cc[i];
+          }
+        }
 #pragma unroll
         for (int i = 0; i < 5; i++) best[i] = (u64)__double_as_longlong(c[i]);
         sixth = (u64)__double_as_longlong(c[5]);

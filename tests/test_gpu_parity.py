@@ -518,11 +518,11 @@ def test_previous_pass_bound_prunes_exactly(built, oracle):
     scan = np.ascontiguousarray(synth.box_world_scan_random(4096, 15.0, 2)[:, :3])
     oc = oracle.Octree()
     oc.update(mp)
-    os.environ["FLIMO_PRUNE"] = "0"
+    os.environ["FLIMO_PRUNE"] = "0"; os.environ["FLIMO_PROBE"] = "0"       # neither the previous pass's bound nor the own-cell probe
     try:
         plain = _lib.HipCtx(0)
     finally:
-        del os.environ["FLIMO_PRUNE"]
+        del os.environ["FLIMO_PRUNE"]; del os.environ["FLIMO_PROBE"]
     pruned = _lib.HipCtx(0)
     poses = []
     x = oracle.identity_x26()
@@ -906,7 +906,8 @@ def test_knn_on_a_lattice_ties_follow_the_reference(built, oracle):
 def test_crowded_cells_second_level_is_exact(built, oracle):
     """Raw sweeps inserted into the map leave the cells under the sensor with hundreds of points (the insert rule keeps the whole
     first batch that lands in a leaf).  Those regions get a second-level grid (a quarter of the cell edge, copies of every map
-    point inside) and a fine pre-pass that settles the queries whose five lie within centimetres.  Results must not change:
+    point inside) and a fine pre-pass that settles the queries whose five lie within centimetres; and in the first pass of a scan
+    the queries of heavy blocks walk their own cell first and the rest only within that bound.  Results must not change:
     records equal the oracle's (which inserted the same world points) bit for bit, and H^T H equals the run with the second
     level switched off bit for bit."""
     import os
@@ -923,12 +924,13 @@ def test_crowded_cells_second_level_is_exact(built, oracle):
     res = {}
     oc = oracle.Octree()
     oc.update(mp)
-    for label, fine in (("fine", "1"), ("plain", "0")):
+    for label, fine in (("fine", "1"), ("plain", "0"), ("noprobe", "0")):
         os.environ["FLIMO_FINE"] = fine
+        os.environ["FLIMO_PROBE"] = "0" if label == "noprobe" else "96"     # first pass: own-cell probe of the heavy blocks on / off
         os.environ["FLIMO_FINE_THRESHOLD"] = "32"
         os.environ["FLIMO_FINE_MIN_POINTS"] = "0"
         ctx = _lib.HipCtx(0)
-        os.environ.pop("FLIMO_FINE"); os.environ.pop("FLIMO_FINE_THRESHOLD"); os.environ.pop("FLIMO_FINE_MIN_POINTS")
+        os.environ.pop("FLIMO_FINE"); os.environ.pop("FLIMO_FINE_THRESHOLD"); os.environ.pop("FLIMO_FINE_MIN_POINTS"); os.environ.pop("FLIMO_PROBE")
         ctx.map_config()
         ctx.map_add(mp)
         for j, sw in enumerate(sweeps):
@@ -953,6 +955,11 @@ def test_crowded_cells_second_level_is_exact(built, oracle):
         mm, _, _ = ctx.grid_selfcheck()
         assert mm == 0
         ctx.close()
+    for k in range(3):
+        for other in ("plain", "noprobe"):
+            np.testing.assert_array_equal(res[other][k][0], res["fine"][k][0])
+            np.testing.assert_array_equal(res[other][k][1], res["fine"][k][1])
+            assert res[other][k][2] == res["fine"][k][2]
     for k in range(3):
         np.testing.assert_array_equal(res["fine"][k][0], res["plain"][k][0])          # H^T H: bit for bit
         np.testing.assert_array_equal(res["fine"][k][1], res["plain"][k][1])
