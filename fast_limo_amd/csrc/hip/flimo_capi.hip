@@ -11,6 +11,7 @@
 #include <math.h>
 #include <string>
 #include <chrono>
+#include <array>
 #include <vector>
 #include <algorithm>
 #include <immintrin.h>
@@ -150,7 +151,15 @@ struct flimo_ctx {
   size_t fine_pts_cap = 0;
   uint32_t *d_fine_cs = nullptr, *d_fine_rt = nullptr, *d_fine_count = nullptr;
   size_t fine_cs_cap = 0, fine_rt_cap = 0;
-  int* d_crowd_box = nullptr;
+  void* d_crowd_list = nullptr;        // int4 (x, y, z, -) of every crowded cell of the current geometry, listed once
+  uint32_t* d_crowd_count = nullptr;
+  uint32_t* d_crowd_bits = nullptr;    // one bit per cell: listed
+  size_t crowd_bits_cap = 0;
+  uint32_t crowd_listed = 0;           // entries of the device list the host has fetched
+  std::vector<std::array<int, 3>> crowd_cells;
+  float fine_center[3] = {0.f, 0.f, 0.f};   // sensor position of the last inserted scan (world)
+  bool have_fine_center = false;
+  float fine_radius = 24.f;            // FLIMO_FINE_RADIUS [m]: crowded cells farther from the sensor (xy) stay out of the region
   uint64_t fine_builds = 0, fine_passes = 0;
   int xslabs = 1;                  // FLIMO_XSLABS: fine columns per cell along x (1, 2, 4, 8; power of two).  4 trims the candidate
                                    // stream of a pruned pass by a quarter (-2 % pass time) and crowded cells by 25-30 %, but makes both
@@ -334,6 +343,8 @@ extern "C" int flimo_ctx_create(int device, flimo_ctx** out) {
   if (e) c->fine_on = atoi(e) != 0;
   e = getenv("FLIMO_FINE_THRESHOLD");
   if (e && atoi(e) > 0) c->fine_threshold = (unsigned)atoi(e);
+  e = getenv("FLIMO_FINE_RADIUS");
+  if (e && atof(e) > 0) c->fine_radius = (float)atof(e);
   e = getenv("FLIMO_FINE_DIV");
   if (e && (atoi(e) == 2 || atoi(e) == 4 || atoi(e) == 8)) c->fine_div = atoi(e);
   e = getenv("FLIMO_FINE_MIN_POINTS");
@@ -374,7 +385,7 @@ extern "C" void flimo_ctx_destroy(flimo_ctx* c) {
   (void)hipFree(c->d_scan); (void)hipFree(c->d_scan_raw); (void)hipFree(c->d_scan_world); (void)hipFree(c->d_scan_t);
   (void)hipFree(c->d_frames); (void)hipFree(c->d_recs); (void)hipFree(c->d_dbg);
   (void)hipFree(c->d_fine_tmp); (void)hipFree(c->d_fine_pts); (void)hipFree(c->d_fine_cs); (void)hipFree(c->d_fine_rt);
-  (void)hipFree(c->d_fine_count); (void)hipFree(c->d_crowd_box);
+  (void)hipFree(c->d_fine_count); (void)hipFree(c->d_crowd_list); (void)hipFree(c->d_crowd_count); (void)hipFree(c->d_crowd_bits);
   (void)hipFree(c->d_raw32); (void)hipFree(c->d_filt_ext); (void)hipFree(c->d_nbrk); (void)hipFree(c->d_tie_list); (void)hipFree(c->d_tie_count);
   if (c->h_filt_ext) (void)hipHostFree(c->h_filt_ext);
   (void)hipFree(c->d_partials); (void)hipFree(c->d_out256); (void)hipFree(c->d_cand); (void)hipFree(c->d_ticket);
@@ -415,6 +426,7 @@ extern "C" int flimo_map_clear(flimo_ctx* c) {
   c->map_last_time = -1.0;
   c->bb[0] = c->bb[1] = c->bb[2] = 3.4e38f; c->bb[3] = c->bb[4] = c->bb[5] = -3.4e38f;
   c->crowd_box_valid = false;
+  c->have_fine_center = false;
   insert_book_clear(c->book);
   c->gbook.active = false;
   c->prev.valid = 0;               // the pruning bound only survives map ADDITIONS (distances can only shrink)
@@ -455,21 +467,59 @@ static int update_fine_grid(flimo_ctx* c, bool relayout, const float4* new_pts =
   c->fine_valid = false;
   if (!c->fine_on || !c->grid_valid || c->map_n == 0) return FLIMO_OK;
   const GridView& g = c->grid;
-  if (!c->d_crowd_box) {
-    HIPCHK(c, hipMalloc(&c->d_crowd_box, 7 * sizeof(int)));
+  constexpr uint32_t CROWD_CAP = 1u << 20;
+  if (!c->d_crowd_list) {
+    HIPCHK(c, hipMalloc(&c->d_crowd_list, (size_t)CROWD_CAP * sizeof(int4)));
+    HIPCHK(c, hipMalloc(&c->d_crowd_count, sizeof(uint32_t)));
     HIPCHK(c, hipMalloc(&c->d_fine_count, sizeof(uint32_t)));
   }
   static const bool prof = getenv("FLIMO_PROF_INSERT") != nullptr;     // developer timing of the stages (each ends synchronised)
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double tp0 = prof ? now() : 0.0;
-  int box[7];
+  // 1. the list of crowded cells (device: a bit per cell + append list; host: their centres in world coordinates)
+  uint32_t listed = 0;
+  const size_t ncells_main = (size_t)g.nx * g.ny * g.nz;
   if (relayout || !c->crowd_box_valid || !new_pts) {
-    HIPCHK(c, crowded_cells_box(c->stream, g.cell_start, g.nx, g.ny, g.nz, g.xs, c->fine_threshold, c->d_crowd_box, box));
+    const size_t words = (ncells_main + 31) / 32;
+    if (words > c->crowd_bits_cap) {
+      (void)hipFree(c->d_crowd_bits);
+      c->d_crowd_bits = nullptr; c->crowd_bits_cap = 0;
+      HIPCHK(c, hipMalloc(&c->d_crowd_bits, (words + words / 4 + 64) * sizeof(uint32_t)));
+      c->crowd_bits_cap = words + words / 4 + 64;
+    }
+    c->crowd_cells.clear();
+    c->crowd_listed = 0;
+    HIPCHK(c, crowded_list_all(c->stream, g.cell_start, g.nx, g.ny, g.nz, g.xs, c->fine_threshold, c->d_crowd_bits, (int4*)c->d_crowd_list, CROWD_CAP,
+                               c->d_crowd_count, &listed));
     c->crowd_box_valid = true;
   } else {
     // same geometry as at the last look: only the cells of the points merged since can have become crowded
-    HIPCHK(c, crowded_cells_of_points(c->stream, new_pts, n_new, g.cell_start, g.ox, g.oy, g.oz, g.inv_cell, g.nx, g.ny, g.nz, g.xs,
-                                      c->fine_threshold, c->d_crowd_box, box));
+    HIPCHK(c, crowded_list_points(c->stream, new_pts, n_new, g.cell_start, g.ox, g.oy, g.oz, g.inv_cell, g.nx, g.ny, g.nz, g.xs,
+                                  c->fine_threshold, c->d_crowd_bits, (int4*)c->d_crowd_list, CROWD_CAP, c->d_crowd_count, &listed));
+  }
+  if (listed > CROWD_CAP) return FLIMO_OK;                      // crowded all over: no region to speak of
+  if (listed > c->crowd_listed) {
+    const size_t k = listed - c->crowd_listed;
+    std::vector<int> buf(4 * k);
+    HIPCHK(c, hipMemcpy(buf.data(), (const int4*)c->d_crowd_list + c->crowd_listed, k * sizeof(int4), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < k; i++) c->crowd_cells.push_back({buf[4 * i], buf[4 * i + 1], buf[4 * i + 2]});
+    c->crowd_listed = listed;
+  }
+  if (c->crowd_cells.empty()) return FLIMO_OK;
+  // 2. the box of the crowded cells around the sensor (the pose of the last inserted scan): that is where the next scans' dense
+  //    near-range queries land; crowded cells left behind along the path, or a lone one on a far wall, do not stretch it
+  int box[7] = {INT_MAX, INT_MAX, INT_MAX, -1, -1, -1, 0};
+  {
+    const float R = c->fine_radius * g.inv_cell;                // cells
+    const float scx = (c->fine_center[0] - g.ox) * g.inv_cell, scy = (c->fine_center[1] - g.oy) * g.inv_cell;
+    for (const auto& q : c->crowd_cells) {
+      if (c->have_fine_center) {
+        const float dx = (float)q[0] + 0.5f - scx, dy = (float)q[1] + 0.5f - scy;
+        if (dx * dx + dy * dy > R * R) continue;
+      }
+      for (int a = 0; a < 3; a++) { box[a] = std::min(box[a], q[a]); box[3 + a] = std::max(box[3 + a], q[a]); }
+      box[6]++;
+    }
   }
   if (box[6] <= 0) return FLIMO_OK;
   // region copied completely: the crowded cells and one cell around them
@@ -1584,6 +1634,8 @@ extern "C" int flimo_scan_to_world(flimo_ctx* c, const double x26[26], float* ou
 extern "C" int flimo_map_add_scan(flimo_ctx* c, const double x26[26], double stamp) {
   if (!c || !x26) return FLIMO_ERR_INVALID;
   if (c->scan_n == 0) return FLIMO_OK;
+  for (int a = 0; a < 3; a++) c->fine_center[a] = (float)x26[a];       // the second level follows the sensor (update_fine_grid)
+  c->have_fine_center = true;
   if (!c->host_insert) {           // resident path: transform, decide, append and re-index on the device
     int rc = flimo_scan_to_world(c, x26, nullptr, 0);
     if (rc) return rc;

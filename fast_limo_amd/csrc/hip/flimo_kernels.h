@@ -115,10 +115,11 @@ hipError_t filter_raw_scan(hipStream_t st, const void* raw32_dev, size_t n, cons
 // Second level over crowded regions: box (cell coordinates, inclusive) around the cells holding more than `threshold` points
 // (box_host[6] = their number; box_dev: 7 ints of device scratch), and the copy of the map points inside a box of metres
 // (w = position in the main sorted map).
-hipError_t crowded_cells_of_points(hipStream_t st, const float4* pts, size_t k, const uint32_t* cell_start, float ox, float oy, float oz,
-                                   float inv_cell, int nx, int ny, int nz, int xs, uint32_t threshold, int* box_dev, int box_host[7]);
-hipError_t crowded_cells_box(hipStream_t st, const uint32_t* cell_start, int nx, int ny, int nz, int xs, uint32_t threshold,
-                             int* box_dev, int box_host[7]);
+hipError_t crowded_list_all(hipStream_t st, const uint32_t* cell_start, int nx, int ny, int nz, int xs, uint32_t threshold, uint32_t* bits,
+                            int4* list, uint32_t cap, uint32_t* count_dev, uint32_t* count_host);
+hipError_t crowded_list_points(hipStream_t st, const float4* pts, size_t k, const uint32_t* cell_start, float ox, float oy, float oz,
+                               float inv_cell, int nx, int ny, int nz, int xs, uint32_t threshold, uint32_t* bits, int4* list, uint32_t cap,
+                               uint32_t* count_dev, uint32_t* count_host);
 hipError_t map_box_count(hipStream_t st, const uint32_t* cell_start, int nx, int ny, int nz, int xs, const int c0[3], const int c1[3],
                          uint32_t* count_dev, uint32_t* count_host, MapBuildScratch& S);
 hipError_t map_box_copy(hipStream_t st, const float4* pts, const uint32_t* cell_start, int nx, int ny, int nz, int xs, const int c0[3],

@@ -269,56 +269,61 @@ hipError_t map_merge_grid(hipStream_t st, const float4* old_sorted, size_t n_old
 // every point of its 3x3x3 cells.  The map therefore keeps a SECOND grid with a quarter of the cell edge over the box around the
 // crowded cells, holding a copy of every map point inside that box (w = position in the main sorted map, so that neighbour
 // ids and tie-breaks are the main map's); the pass asks it first (fine pre-pass, flimo_kernels.hip).
-__global__ __launch_bounds__(256) void crowded_kernel(const uint32_t* __restrict__ cell_start, int nx, int ny, int nz, int xs,
-                                                      uint32_t threshold, int* __restrict__ box /* min xyz, max xyz, count */) {
+// Crowded cells (more than `threshold` points) are LISTED once each (a bit per cell marks the listed ones); the host keeps the
+// list and boxes the part of it around the sensor.  crowded_list_all looks at every cell (new geometry: bits and list start
+// empty), crowded_list_points only at the cells of k freshly merged points (cells gain points nowhere else).
+__device__ __forceinline__ void crowded_append(uint32_t cell, int x, int y, int z, uint32_t* __restrict__ bits, int4* __restrict__ list,
+                                               uint32_t cap, uint32_t* __restrict__ count) {
+  const uint32_t m = 1u << (cell & 31u);
+  if (atomicOr(&bits[cell >> 5], m) & m) return;
+  const uint32_t slot = atomicAdd(count, 1u);
+  if (slot < cap) list[slot] = make_int4(x, y, z, 0);
+}
+__global__ __launch_bounds__(256) void crowded_all_kernel(const uint32_t* __restrict__ cell_start, int nx, int ny, int nz, int xs,
+                                                          uint32_t threshold, uint32_t* __restrict__ bits, int4* __restrict__ list,
+                                                          uint32_t cap, uint32_t* __restrict__ count) {
   const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t ncells = (size_t)nx * ny * nz;
   if (c >= ncells) return;
   const int x = (int)(c % (size_t)nx);
   const size_t row = c / (size_t)nx;
   const size_t col0 = row * ((size_t)nx * xs) + (size_t)x * xs;
-  const uint32_t cnt = cell_start[col0 + xs] - cell_start[col0];
-  if (cnt <= threshold) return;
-  const int y = (int)(row % (size_t)ny), z = (int)(row / (size_t)ny);
-  atomicMin(&box[0], x); atomicMin(&box[1], y); atomicMin(&box[2], z);
-  atomicMax(&box[3], x); atomicMax(&box[4], y); atomicMax(&box[5], z);
-  atomicAdd(&box[6], 1);
+  if (cell_start[col0 + xs] - cell_start[col0] <= threshold) return;
+  crowded_append((uint32_t)c, x, (int)(row % (size_t)ny), (int)(row / (size_t)ny), bits, list, cap, count);
 }
-// the same test for the cells of k freshly merged points only (cells gain points nowhere else): O(k) instead of O(cells)
 __global__ __launch_bounds__(256) void crowded_points_kernel(const float4* __restrict__ pts, size_t k, const uint32_t* __restrict__ cell_start,
                                                              float ox, float oy, float oz, float inv_cell, int nx, int ny, int nz, int xs,
-                                                             uint32_t threshold, int* __restrict__ box) {
+                                                             uint32_t threshold, uint32_t* __restrict__ bits, int4* __restrict__ list,
+                                                             uint32_t cap, uint32_t* __restrict__ count) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= k) return;
   const uint32_t col = column_key(pts[i], ox, oy, oz, inv_cell, nx, ny, nz, xs);
   const uint32_t col0 = col - col % (uint32_t)xs;
-  const uint32_t cnt = cell_start[col0 + xs] - cell_start[col0];
-  if (cnt <= threshold) return;
+  if (cell_start[col0 + xs] - cell_start[col0] <= threshold) return;
   const uint32_t cell = col0 / (uint32_t)xs;
-  const int x = (int)(cell % (uint32_t)nx), y = (int)((cell / (uint32_t)nx) % (uint32_t)ny), z = (int)(cell / ((uint32_t)nx * (uint32_t)ny));
-  atomicMin(&box[0], x); atomicMin(&box[1], y); atomicMin(&box[2], z);
-  atomicMax(&box[3], x); atomicMax(&box[4], y); atomicMax(&box[5], z);
-  atomicAdd(&box[6], 1);
+  crowded_append(cell, (int)(cell % (uint32_t)nx), (int)((cell / (uint32_t)nx) % (uint32_t)ny), (int)(cell / ((uint32_t)nx * (uint32_t)ny)), bits,
+                 list, cap, count);
 }
-hipError_t crowded_cells_of_points(hipStream_t st, const float4* pts, size_t k, const uint32_t* cell_start, float ox, float oy, float oz,
-                                   float inv_cell, int nx, int ny, int nz, int xs, uint32_t threshold, int* box_dev, int box_host[7]) {
+// *count_host = entries listed so far (may exceed cap: the list is then incomplete)
+hipError_t crowded_list_all(hipStream_t st, const uint32_t* cell_start, int nx, int ny, int nz, int xs, uint32_t threshold, uint32_t* bits,
+                            int4* list, uint32_t cap, uint32_t* count_dev, uint32_t* count_host) {
+  const size_t ncells = (size_t)nx * ny * nz;
+  hipError_t e;
+  if ((e = hipMemsetAsync(bits, 0, ((ncells + 31) / 32) * sizeof(uint32_t), st)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(count_dev, 0, sizeof(uint32_t), st)) != hipSuccess) return e;
+  hipLaunchKernelGGL(crowded_all_kernel, dim3((unsigned)((ncells + 255) / 256)), dim3(256), 0, st, cell_start, nx, ny, nz, xs, threshold, bits, list,
+                     cap, count_dev);
+  if ((e = hipMemcpyAsync(count_host, count_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+  return hipStreamSynchronize(st);
+}
+hipError_t crowded_list_points(hipStream_t st, const float4* pts, size_t k, const uint32_t* cell_start, float ox, float oy, float oz,
+                               float inv_cell, int nx, int ny, int nz, int xs, uint32_t threshold, uint32_t* bits, int4* list, uint32_t cap,
+                               uint32_t* count_dev, uint32_t* count_host) {
   hipError_t e;
   if (k > 0)
     hipLaunchKernelGGL(crowded_points_kernel, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, st, pts, k, cell_start, ox, oy, oz, inv_cell, nx,
-                       ny, nz, xs, threshold, box_dev);
-  if ((e = hipMemcpyAsync(box_host, box_dev, 7 * sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
-  return hipStreamSynchronize(st);
-}
-// Box of the cells that hold more than `threshold` points, from a look at every cell (new geometry); box_dev keeps it for
-// crowded_cells_of_points.  box_host[6] > 0: some cell is crowded.
-hipError_t crowded_cells_box(hipStream_t st, const uint32_t* cell_start, int nx, int ny, int nz, int xs, uint32_t threshold,
-                             int* box_dev, int box_host[7]) {
-  const int init[7] = {INT_MAX, INT_MAX, INT_MAX, -1, -1, -1, 0};
-  hipError_t e;
-  if ((e = hipMemcpyAsync(box_dev, init, sizeof(init), hipMemcpyHostToDevice, st)) != hipSuccess) return e;
-  const size_t ncells = (size_t)nx * ny * nz;
-  hipLaunchKernelGGL(crowded_kernel, dim3((unsigned)((ncells + 255) / 256)), dim3(256), 0, st, cell_start, nx, ny, nz, xs, threshold, box_dev);
-  if ((e = hipMemcpyAsync(box_host, box_dev, 7 * sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+                       ny, nz, xs, threshold, bits, list, cap, count_dev);
+  if ((e = hipMemcpyAsync(count_host, count_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
   return hipStreamSynchronize(st);
 }
 // Copy of the map points of a box of cells [c0, c1] (inclusive, already clipped to the grid), w = position in the main sorted
