@@ -1078,8 +1078,15 @@ extern "C" int flimo_raw_scan_filter_set(flimo_ctx* c, const void* points32, siz
   }
   rc = ensure_stage(c, n * 32);
   if (rc) return rc;
-  memcpy(c->h_stage, points32, n * 32);
-  HIPCHK(c, hipMemcpyAsync(c->d_raw32, c->h_stage, n * 32, hipMemcpyHostToDevice, c->stream));
+  {
+    // pageable caller memory -> pinned stage -> HBM in chunks: the DMA of a chunk runs while the next one is staged
+    const size_t total = n * 32, chunk = 512u << 10;
+    for (size_t o = 0; o < total; o += chunk) {
+      const size_t len = std::min(chunk, total - o);
+      memcpy((char*)c->h_stage + o, (const char*)points32 + o, len);
+      HIPCHK(c, hipMemcpyAsync((char*)c->d_raw32 + o, (const char*)c->h_stage + o, len, hipMemcpyHostToDevice, c->stream));
+    }
+  }
   FilterParams F;
   F.crop = cfg->crop_active ? 1 : 0;
   for (int a = 0; a < 3; a++) { F.mn[a] = cfg->crop_active ? cfg->crop_min[a] : 0.f; F.mx[a] = cfg->crop_active ? cfg->crop_max[a] : 0.f; }
