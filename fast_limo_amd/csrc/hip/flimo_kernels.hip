@@ -780,14 +780,6 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
           rbh[dz] = *reinterpret_cast<const U3*>(G.row_table + (iH + (uint32_t)dz * py));
         }
       }
-      // the own cell's range: one 8-byte load from the x-fastest cell table, same round trip as the rows' bounds; the two inner x
-      // planes of the row table (needed to clip the second walk to cells) are fetched by the probing queries only, while they walk
-      uint32_t lo_own = 0u, n_own = 0u;
-      if (probe_on && cx >= 0 && cx < G.nx && cy >= 0 && cy < G.ny && cz >= 0 && cz < G.nz) {
-        const uint32_t* cs = G.cell_start + (((size_t)cz * (size_t)G.ny + (size_t)cy) * (size_t)G.nxf + (size_t)cx * (size_t)G.xs);
-        lo_own = cs[0];
-        n_own = cs[G.xs] - lo_own;
-      }
       // conservative distances (cell units) to the neighbouring rows; without a bound every row is in
       const float yd[3] = {fmaxf(ry - margin, 0.f), 0.f, fmaxf(1.f - ry - margin, 0.f)};
       const float zd[3] = {fmaxf(rz - margin, 0.f), 0.f, fmaxf(1.f - rz - margin, 0.f)};
@@ -806,12 +798,13 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
         }
       }
       // probing pays when the block is heavy (crowded region: every lane of the wave probes, so nobody waits for a neighbour's
-      // full walk) and the own cell can give a bound at all
-      const bool two = probe_on && off[9] >= prev.probe_min && n_own >= PROBE_MIN_OWN;        // the same in both lanes of the pair
+      // full walk) and the own cell can give a bound at all.  Only those queries fetch the two inner x planes of the row table:
+      // they hold the own cell's range and let the second walk be clipped to cells.
+      const bool heavy_block = probe_on && off[9] >= prev.probe_min && cx >= 0 && cx < G.nx;
       U3 rm1[3], rm2[3];
 #pragma unroll
       for (int dz = 0; dz < 3; dz++) { rm1[dz] = rbl[dz]; rm2[dz] = rbh[dz]; }
-      if (two) {
+      if (heavy_block) {
         const uint32_t iA = (uint32_t)(cx * G.xs) * plane + yz, iB = (uint32_t)((cx + 1) * G.xs) * plane + yz;
 #pragma unroll
         for (int dz = 0; dz < 3; dz++) {
@@ -819,6 +812,8 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
           rm2[dz] = *reinterpret_cast<const U3*>(G.row_table + (iB + (uint32_t)dz * py));
         }
       }
+      const uint32_t lo_own = rm1[1].b, n_own = rm2[1].b - rm1[1].b;
+      const bool two = heavy_block && n_own >= PROBE_MIN_OWN;        // the same in both lanes of the pair
       if (two) {                        // first walk: the own cell only (one segment)
         dl[0] = lo_own;
 #pragma unroll
