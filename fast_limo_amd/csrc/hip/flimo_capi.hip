@@ -1644,8 +1644,11 @@ extern "C" int flimo_map_add_scan(flimo_ctx* c, const double x26[26], double sta
   for (int a = 0; a < 3; a++) c->fine_center[a] = (float)x26[a];       // the second level follows the sensor (update_fine_grid)
   c->have_fine_center = true;
   if (!c->host_insert) {           // resident path: transform, decide, append and re-index on the device
-    int rc = flimo_scan_to_world(c, x26, nullptr, 0);
-    if (rc) return rc;
+    (void)hipSetDevice(c->device);
+    PoseMats P;
+    pose_from_x26(x26, P);
+    launch_transform(c->stream, c->d_scan, (int)c->scan_n, P, c->d_scan_world);      // no host wait: the insert's first read-back follows
+    HIPCHK(c, hipGetLastError());
     return map_add_device(c, c->d_scan_world, c->scan_n, stamp);
   }
   std::vector<float> w(c->scan_n * 3);

@@ -42,14 +42,14 @@ __device__ __forceinline__ int octant_of(float px, float py, float pz, const flo
 // ---- route ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gb_route_kernel(const float4* __restrict__ pts, int n, const float4* __restrict__ node_c,
                                                        const int* __restrict__ node_child, const int* __restrict__ node_cnt,
-                                                       int root, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+                                                       int root, uint32_t nan_key, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float4 p = pts[i];
   int node = root;
   uint32_t key;
   if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) {     // Octree::processPoints drops NaNs (:243-244)
-    keys[i] = 0xffffffffu;
+    keys[i] = nan_key;                                          // above every (node, child) key: sorts last
     vals[i] = (uint32_t)i;
     return;
   }
@@ -115,13 +115,13 @@ __global__ __launch_bounds__(256) void gb_decide_kernel(const uint32_t* __restri
                                                         float min_half, int downsample, uint32_t* __restrict__ dec_keep,
                                                         int* __restrict__ dec_assign /* leaf, or -1-item */,
                                                         GbItem* __restrict__ items, int* __restrict__ counters /* [0] items, [1] seg cursor, [3] big items */,
-                                                        int* __restrict__ node_item, int* __restrict__ big) {
+                                                        int* __restrict__ node_item, int* __restrict__ big, uint32_t nan_key) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint32_t key = keys[i];
   if (i > 0 && keys[i - 1] == key) return;            // not a group head
   const int g = run_end(keys, i, n, key) - i;
-  if (key == 0xffffffffu) { dec_keep[i] = 0u; dec_assign[i] = -1; return; }      // non-finite points: never stored
+  if (key == nan_key) { dec_keep[i] = 0u; dec_assign[i] = -1; return; }      // non-finite points: never stored
   const int node = (int)(key / 9u), slot = (int)(key % 9u);
   if (slot == 8) {
     const int cnt = node_cnt[node];
@@ -675,9 +675,13 @@ hipError_t GBook::update(hipStream_t st, const float4* batch, int m, const float
       S.cap_pts = cap;
     }
   }
-  hipLaunchKernelGGL(gb_route_kernel, dim3(blocks), dim3(256), 0, st, batch, m, node_c, node_child, node_cnt, root, S.keys_in, S.vals_in);
+  // keys = node * 9 + slot; non-finite points get the key above all of them; only the bits in use are sorted
+  const uint32_t nan_key = (uint32_t)node_n * 9u + 9u;
+  int key_bits = 1;
+  while (key_bits < 32 && (1ull << key_bits) <= (unsigned long long)nan_key) key_bits++;
+  hipLaunchKernelGGL(gb_route_kernel, dim3(blocks), dim3(256), 0, st, batch, m, node_c, node_child, node_cnt, root, nan_key, S.keys_in, S.vals_in);
   size_t tmp_bytes = 0, scan_bytes = 0;
-  GBCHK(sort_pairs_u32(nullptr, tmp_bytes, S.keys_in, S.keys_out, S.vals_in, S.vals_out, m, 0, 32, st));
+  GBCHK(sort_pairs_u32(nullptr, tmp_bytes, S.keys_in, S.keys_out, S.vals_in, S.vals_out, m, 0, key_bits, st));
   GBCHK(exclusive_sum(nullptr, scan_bytes, flags, rank, m, st));
   const size_t need = std::max(tmp_bytes, scan_bytes);
   if (need > S.cub_tmp_bytes) {
@@ -686,10 +690,10 @@ hipError_t GBook::update(hipStream_t st, const float4* batch, int m, const float
     GBCHK(hipMalloc(&S.cub_tmp, need + 1024));
     S.cub_tmp_bytes = need + 1024;
   }
-  GBCHK(sort_pairs_u32(S.cub_tmp, tmp_bytes, S.keys_in, S.keys_out, S.vals_in, S.vals_out, m, 0, 32, st));
+  GBCHK(sort_pairs_u32(S.cub_tmp, tmp_bytes, S.keys_in, S.keys_out, S.vals_in, S.vals_out, m, 0, key_bits, st));
   GBCHK(hipMemsetAsync(counters, 0, 4 * sizeof(int), st));
   hipLaunchKernelGGL(gb_decide_kernel, dim3(blocks), dim3(256), 0, st, S.keys_out, m, node_c, node_cnt, min_half,
-                     downsample ? 1 : 0, flags /* dec_keep */, reinterpret_cast<int*>(rank) /* dec_assign */, items, counters, node_item, big_items);
+                     downsample ? 1 : 0, flags /* dec_keep */, reinterpret_cast<int*>(rank) /* dec_assign */, items, counters, node_item, big_items, nan_key);
   hipLaunchKernelGGL(gb_apply_kernel, dim3(blocks), dim3(256), 0, st, S.keys_out, S.vals_out, m, flags, reinterpret_cast<const int*>(rank),
                      keep, assign);
   hipLaunchKernelGGL(gb_flags_kernel, dim3(blocks), dim3(256), 0, st, keep, m, flags);
