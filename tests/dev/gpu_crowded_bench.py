@@ -21,6 +21,12 @@ for fine in os.environ.get("FINES", "1,0").split(","):
     os.environ["FLIMO_FINE"] = fine
     ctx = _lib.HipCtx(0)
     ctx.map_config(); ctx.map_add(mp)
+    def cands(ctx):
+        ctx.set_debug_records(True); ctx.scan_set(query); out = []
+        for k in range(2):
+            ctx.match_reduce(x, cfg); out.append("%.1f" % ctx.last_candidates_per_query())
+        ctx.set_debug_records(False)
+        return " / ".join(out)
     def timed(tag):
         ctx.scan_set(query)
         t = []
@@ -31,6 +37,16 @@ for fine in os.environ.get("FINES", "1,0").split(","):
             r3 = ctx.match_reduce(x, cfg); t3 = time.perf_counter()
             t.append((t1 - t0, t2 - t1, t3 - t2))
         t = np.median(np.array(t[1:]), axis=0) * 1e6
+        # kernel times of the same three passes (events on the dispatches)
+        ctx.set_timing(1); kt = []
+        for rep in range(4):
+            ctx.scan_set(query); row = []
+            for k in range(3):
+                ctx.match_reduce(x, cfg); a, w, f = ctx.last_kernel_ms(); row.append((a + w + f) * 1e3)
+            kt.append(row)
+        ctx.set_timing(0)
+        kt = np.median(np.array(kt[1:]), axis=0)
+        print("   kernels: first pass %.1f us, second %.1f us, third %.1f us;  candidates per query: %s" % (kt[0], kt[1], kt[2], cands(ctx)), flush=True)
         print("FINE=%s %s: map %d  first pass %.1f us, second %.1f us, third %.1f us  M %d  fine %s stragglers %d" % (
             fine, tag, ctx.map_size(), t[0], t[1], t[2], r3[2], ctx.fine_stats(), ctx.last_stragglers()), flush=True)
         return r3
