@@ -3,15 +3,19 @@
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 tag=${1:-final}
 cd $root; mkdir -p gpurun_out
-python bench.py 2>gpurun_out/bench_$tag.err > gpurun_out/bench_$tag.json
 args="--steps 50 --warmup 5 --no-cpu-baseline --no-end-to-end"
 cd /tmp && export TMPDIR=/tmp
 rm -rf $root/gpurun_out/prof_$tag $root/gpurun_out/pmc_fetch_$tag $root/gpurun_out/pmc_write_$tag
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/prof_$tag -- python3 $root/bench.py $args > $root/gpurun_out/prof_$tag.json 2>/dev/null
+# PMC passes first (counters in their own runs), so that the bench line below carries `traffic` for these very sources
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $root/gpurun_out/pmc_fetch_$tag -- python3 $root/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-end-to-end > /dev/null 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $root/gpurun_out/pmc_write_$tag -- python3 $root/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-end-to-end > /dev/null 2>&1
 cd $root
 python3 tools/pmc_summary.py gpurun_out/pmc_fetch_$tag gpurun_out/pmc_write_$tag gpurun_out/pmc_fetch_write_per_kernel_$tag.json | head -5
+cp gpurun_out/pmc_fetch_write_per_kernel_$tag.json profiles/r02/pmc_fetch_write_per_kernel.json      # (this box's copy; the caller commits the one merged back)
+python bench.py 2>gpurun_out/bench_$tag.err > gpurun_out/bench_$tag.json
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/prof_$tag -- python3 $root/bench.py $args > $root/gpurun_out/prof_$tag.json 2>/dev/null
+cd $root
 f=$(find gpurun_out/prof_$tag -name "*kernel_stats.csv" | head -1)
 cp $f gpurun_out/bench_${tag}_kernel_stats.csv
 python3 - "$f" <<'PY'
