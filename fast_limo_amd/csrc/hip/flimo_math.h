@@ -426,8 +426,10 @@ FLIMO_DEV void h_row(const PoseMats& P, float gx, float gy, float gz, const floa
   cross3(lx, ly, lz, Dx, Dy, Dz, Bx, By, Bz);     // B
   cross3(ix, iy, iz, Cx, Cy, Cz, Ax, Ay, Az);     // A
   v[0] = n4[0]; v[1] = n4[1]; v[2] = n4[2]; v[3] = Ax; v[4] = Ay; v[5] = Az;
-  if (estimate_extrinsics) { v[6] = Bx; v[7] = By; v[8] = Bz; v[9] = Cx; v[10] = Cy; v[11] = Cz; }
-  else { v[6] = v[7] = v[8] = v[9] = v[10] = v[11] = 0.f; }
+  // element-wise selects, not a branch around six stores (the compiler turned that into a private-memory round trip on the device)
+  const bool ee = estimate_extrinsics != 0;
+  v[6] = ee ? Bx : 0.f; v[7] = ee ? By : 0.f; v[8] = ee ? Bz : 0.f;
+  v[9] = ee ? Cx : 0.f; v[10] = ee ? Cy : 0.f; v[11] = ee ? Cz : 0.f;
 }
 
 }  // namespace flimo
