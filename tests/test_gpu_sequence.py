@@ -87,6 +87,39 @@ def test_pcd_sequence_replay_ate(built, oracle, tmp_path):
     G.close(); D.close()
 
 
+def test_kitti_layout_replay(built, oracle, tmp_path):
+    """The same harness over the layout of a KITTI raw recording (BASELINE.json config 3; the recording itself is not available
+    offline): Velodyne `.bin` sweeps without per-point times (synthesised from the azimuth by the reader), `timestamps.txt`,
+    OXTS packets as the IMU.  Product and oracle read the same files; same status codes, ATE below 1e-4 m."""
+    import datetime
+    from fast_limo_amd import api, replay
+    n_scans = 6
+    vel = tmp_path / "velodyne_points" / "data"; vel.mkdir(parents=True)
+    ox = tmp_path / "oxts"; (ox / "data").mkdir(parents=True)
+    mp = synth.box_world_map(60000, 25.0, 1)
+    for k in range(n_scans):
+        s5 = synth.velodyne_scan(16, 512, 25.0, 30 + k)
+        np.concatenate([s5[:, :3], s5[:, 3:4]], 1).astype(np.float32).tofile(str(vel / ("%010d.bin" % k)))
+    st, w, a = synth.stationary_imu(0.0, 0.1 * n_scans + 0.06)
+    t0 = datetime.datetime(2011, 9, 26, 13, 2, 25, 964389)
+    lines = []
+    for i in range(len(st)):
+        vals = np.zeros(30); vals[11:14] = a[i]; vals[17:20] = w[i]
+        (ox / "data" / ("%010d.txt" % i)).write_text(" ".join(repr(float(v)) for v in vals) + "\n")
+        ti = t0 + datetime.timedelta(seconds=float(st[i] - st[0]))
+        lines.append(ti.strftime("%Y-%m-%d %H:%M:%S.") + "%06d000" % ti.microsecond)
+    (ox / "timestamps.txt").write_text("\n".join(lines) + "\n")
+    imu = replay.read_kitti_oxts(str(ox))
+    assert len(imu[0]) == len(st) and abs(imu[0][-1] - (st[-1] - st[0])) < 1e-5
+    G = api.Localizer(api.default_cfg(**CAPS)); Lo = oracle.Localizer(oracle.default_cfg(num_threads=4, **CAPS))
+    G.map_add(mp); Lo.map_add(mp)
+    rg, pg = replay.replay(G, str(vel), imu)
+    ro, po = replay.replay(Lo, str(vel), imu)
+    assert rg == ro and rg[0] == 1 and rg[-1] == 0, (rg, ro)
+    assert replay.ate(pg, po) <= 1e-4, replay.ate(pg, po)
+    G.close()
+
+
 def test_async_map_insert_is_invisible(built):
     """The map insert that ends a scan runs on the Mapper's worker thread (Mapper::add_scan) and overlaps the host-side
     preparation of the next scan.  Nothing observable may depend on it: the same drive with the insert synchronous gives
