@@ -190,6 +190,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--e2e-sweeps", type=int, default=8)
+    ap.add_argument("--streams", type=int, default=3, help="informational leg: this many independent scan streams on ONE GPU at once (0: skip)")
     ap.add_argument("--with-insert", action="store_true",
                     help="time the step WITH the path exit (transform + map insert) over six steps instead of the default two "
                          "(first insertion + one repeat), for a steadier 'repeat' figure")
@@ -300,6 +301,43 @@ def main():
         step()          # back on the one-launch path: same state as at the end of the timed region
         assert np.array_equal(loc.get_x(), x_ref)
 
+    # Informational (never `value`): the same step from S independent scan streams on ONE GPU at once -- S Localizers, each with its
+    # own map and resident scan, each driven by its own host thread (SURVEY 8 e / BASELINE configs[4] on a single GPU).  One stream is
+    # a chain of dependent round trips that leaves most of the chip idle; streams overlap.
+    concurrent = None
+    if rank == 0 and world == 1 and args.streams > 1:
+        import threading
+        from fast_limo_amd import synth
+        S, K = args.streams, max(50, min(args.steps * 4, 300))
+        extra = [(None, reg)]                                # stream 0 = the Localizer of the timed region (an idle context would still
+        for sidx in range(1, S):                             # hold one of the GPU's few hardware queues)
+            sc = synth.velodyne_scan(args.rings, args.azimuths, args.box, 10 + sidx)     # the seeds of configs[4]
+            L = api.Localizer(api.default_cfg(gpu_device=local_rank % n_dev, num_threads=4, **caps))
+            L.set_flags(add_to_map=False, download_clouds=False, keep_log=False)
+            r1 = drive_to_prior(L, mp, sc, imu)
+            xs_, Ps_ = L.get_x(), L.get_P()
+            r2 = L.update_pointcloud(sc, 0.1)
+            assert r1 == 1 and r2 == 0, (r1, r2)
+            extra.append((L, L.register_resident_call(xs_, Ps_)))
+        gate = threading.Barrier(S + 1)
+        def stream_loop(reg_):
+            for _ in range(10):
+                assert reg_() == 0
+            gate.wait()
+            for _ in range(K):
+                reg_()
+        th = [threading.Thread(target=stream_loop, args=(e[1],)) for e in extra]
+        for t in th: t.start()
+        gate.wait(); tc0 = time.perf_counter()
+        for t in th: t.join()
+        tc = time.perf_counter() - tc0
+        concurrent = {"streams_on_one_gpu": S, "steps_per_stream": K, "scans_per_s_aggregate": S * K / tc,
+                      "scans_per_s_per_stream": K / tc,
+                      "note": "informational: S independent Localizer streams (own map, own resident scan, own host thread) on one GPU; "
+                              "`value` above is ONE stream"}
+        for e in extra[1:]:
+            e[0].close()
+
     # the same step WITH the path exit (transform + Mapper::add of the registered scan), reported
     # beside `value`, never as `value`.  The first insertion stores the scan's new points; repeating the same scan is
     # then mostly rejected by the reference's down-sampling rule, so both are shown.  Runs after the timed region.
@@ -388,6 +426,7 @@ def main():
                                  "in_match_reduce": 1e6 * hp["match_reduce_s"] / args.steps},
             "with_map_insert": with_insert,
             "end_to_end": end_to_end,
+            "concurrent_streams": concurrent,
         }
         cb, E, x_o = (None, None, None)
         if world == 1 and not args.no_cpu_baseline:
@@ -427,6 +466,12 @@ def main():
                                      "separate_dispatch_pass_us": sep, "separate_dispatch_passes_timed": split["separate_n"],
                                      "passes_in_one_launch": n_fused_passes, "passes_total": n_passes,
                                      "dense_after_timed_region": dense}}
+        if concurrent and bytes_per_query:
+            # the chip's aggregate k-NN rate with S streams in flight: algorithmic bytes of all their passes / wall time
+            ppstep = n_passes / max(args.steps, 1)
+            agg = concurrent["scans_per_s_aggregate"] * ppstep * bytes_per_query * qpl / 1e9
+            concurrent["knn_algorithmic_GBps_aggregate"] = agg
+            concurrent["knn_algorithmic_frac_of_hbm_peak"] = agg / HBM_PEAK_GBPS
         if knn_stage and bytes_per_query:
             st_us = knn_stage["knn_us"] + knn_stage["widen_us"]
             out["roofline"]["knn_stage_separate_dispatches"] = dict(
