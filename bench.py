@@ -334,7 +334,8 @@ def main():
         concurrent = {"streams_on_one_gpu": S, "steps_per_stream": K, "scans_per_s_aggregate": S * K / tc,
                       "scans_per_s_per_stream": K / tc,
                       "note": "informational: S independent Localizer streams (own map, own resident scan, own host thread) on one GPU; "
-                              "`value` above is ONE stream"}
+                              "`value` above is ONE stream.  Per-kernel profiles of this command are taken with --streams 0 (the overlapped "
+                              "launches of this leg would enter rocprofv3's per-kernel averages)"}
         for e in extra[1:]:
             e[0].close()
 

@@ -132,19 +132,18 @@ struct flimo_ctx {
   PrevPass prev{};                 // previous pass of the same resident scan (k-NN pruning bound); valid = 0 after any scan change
   bool prune = true;               // FLIMO_PRUNE=0 disables the bound (A/B checks)
   unsigned probe_min = 96;         // FLIMO_PROBE=<n>: first pass, a query with >= n candidates in its 3x3x3 block walks its own cell first for a bound (0: off)
-  int tail_pass1 = -1;             // FLIMO_TAIL_PASS1: 1 = the first pass of a scan always uses the in-kernel tail, 0 = never, default: by the straggler count of the last first pass
-  int stragglers_pass1 = 1 << 30;  // queries of the last first pass of a scan that needed more than their 3x3x3 block (unknown: many)
+  int tail_pass1 = -1;             // FLIMO_TAIL_PASS1: 1 = the first pass of a scan always uses the in-kernel tail, 0 = never, default: by the straggler count of the last scan's first pass (stragglers_hist[0])
   int stragglers_hist[4] = {1 << 30, 0, 0, 0};   // the same per pass position within a scan (0 = first pass .. 3 = fourth and later), last scan that reported
   int pass_in_scan = 0;
   int last_stragglers = -1;        // the same of the last pass (-1: not reported by that pass's path)
-  // second level over crowded regions (flimo_map.hip): a grid with a quarter of the cell edge over the box around the cells that
-  // hold more than fine_threshold points, with a copy of every map point inside it
+  // second level over crowded regions (flimo_map.hip): a grid with a quarter of the cell edge over the box around the cells near the
+  // sensor that hold more than fine_threshold points, with a copy of every map point inside it
   bool fine_on = true;             // FLIMO_FINE=0 switches it off (A/B checks)
   unsigned fine_threshold = 64;    // FLIMO_FINE_THRESHOLD
   int fine_div = 4;                // FLIMO_FINE_DIV: fine cells per cell edge (power of two)
   unsigned fine_min_points = 32768;// FLIMO_FINE_MIN_POINTS: smaller crowded regions are not worth the extra dispatch (measured: 1M map, 7k points: +4 us)
   bool fine_valid = false;
-  bool crowd_box_valid = false;    // d_crowd_box holds the crowded cells' box of the current geometry
+  bool crowd_box_valid = false;    // the crowded-cell list (device bits + list, host copy) belongs to the current geometry
   GridView fine{};
   int fine_qlo[3] = {0, 0, 0}, fine_qhi[3] = {-1, -1, -1};
   float4 *d_fine_tmp = nullptr, *d_fine_pts = nullptr;
@@ -1443,7 +1442,6 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
     };
     { const int rcw = wait_granules(seq); if (rcw) return rcw; }
     c->last_stragglers = (int)llround(c->h_granules[2 * FIT_LIVE]);
-    if (first_pass) c->stragglers_pass1 = c->last_stragglers;
     c->stragglers_hist[c->pass_in_scan] = c->last_stragglers;
     const long n_ties = (long)llround(c->h_granules[2 * (FIT_LIVE + 1)]);
     if (n_ties > 0 && ties_on) {

@@ -3,12 +3,13 @@
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 tag=${1:-final}
 cd $root; mkdir -p gpurun_out
-args="--steps 50 --warmup 5 --no-cpu-baseline --no-end-to-end"
+# --streams 0: without the informational concurrent-streams leg, whose overlapped launches would enter the per-kernel averages
+args="--steps 50 --warmup 5 --no-cpu-baseline --no-end-to-end --streams 0"
 cd /tmp && export TMPDIR=/tmp
 rm -rf $root/gpurun_out/prof_$tag $root/gpurun_out/pmc_fetch_$tag $root/gpurun_out/pmc_write_$tag
 # PMC passes first (counters in their own runs), so that the bench line below carries `traffic` for these very sources
-timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $root/gpurun_out/pmc_fetch_$tag -- python3 $root/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-end-to-end > /dev/null 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $root/gpurun_out/pmc_write_$tag -- python3 $root/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-end-to-end > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $root/gpurun_out/pmc_fetch_$tag -- python3 $root/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-end-to-end --streams 0 > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $root/gpurun_out/pmc_write_$tag -- python3 $root/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-end-to-end --streams 0 > /dev/null 2>&1
 cd $root
 python3 tools/pmc_summary.py gpurun_out/pmc_fetch_$tag gpurun_out/pmc_write_$tag gpurun_out/pmc_fetch_write_per_kernel_$tag.json | head -5
 cp gpurun_out/pmc_fetch_write_per_kernel_$tag.json profiles/r02/pmc_fetch_write_per_kernel.json      # (this box's copy; the caller commits the one merged back)
