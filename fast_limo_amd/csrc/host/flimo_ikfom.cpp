@@ -503,24 +503,32 @@ void Esekf::update_iterated_dyn_share_modified(double R, double D) {
         // Same quantities through the matrix-inversion lemma (only H^T H's 12x12 block is non-zero):
         //   P_inv[:, 0:12] = ((P/R)^-1 + E B E^T)^-1 E = A[:, 0:12] (I + B A11)^-1,  A = P/R, B = H^T H
         // one 12x12 LU instead of two 23x23 inverses; better conditioned than A^-1 + B.
+        // A[:, 0:12] = P[:, 0:12] / R once (the same quotients the two products below would form element by element)
+        double PR[kDof][12];
+        for (int i = 0; i < n; i++)
+          for (int k = 0; k < 12; k++) PR[i][k] = P_(i, k) / R;
+        // (the products below run i-k-j: every element is still summed over k in ascending order -- the same values bit for bit --
+        //  but the inner loop runs along a row, which the compiler vectorises)
         Mat<12, 12> T, S;
-        for (int i = 0; i < 12; i++)
-          for (int j = 0; j < 12; j++) {
-            double s = 0;
-            for (int k = 0; k < 12; k++) s += HTH(i, k) * (P_(k, j) / R);
-            T(i, j) = s + (i == j ? 1.0 : 0.0);
-          }
+        for (int i = 0; i < 12; i++) {
+          double acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+          for (int k = 0; k < 12; k++) { const double hk = HTH(i, k); for (int j = 0; j < 12; j++) acc[j] += hk * PR[k][j]; }
+          for (int j = 0; j < 12; j++) T(i, j) = acc[j] + (i == j ? 1.0 : 0.0);
+        }
         inverse<12>(T, S);
         double W[kDof][12];
-        for (int i = 0; i < n; i++)
-          for (int j = 0; j < 12; j++) {
-            double s = 0;
-            for (int k = 0; k < 12; k++) s += (P_(i, k) / R) * S(k, j);
-            W[i][j] = s;
-          }
+        for (int i = 0; i < n; i++) {
+          double acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+          for (int k = 0; k < 12; k++) { const double pk = PR[i][k]; for (int j = 0; j < 12; j++) acc[j] += pk * S(k, j); }
+          for (int j = 0; j < 12; j++) W[i][j] = acc[j];
+        }
         for (int i = 0; i < n; i++) { double s = 0; for (int k = 0; k < 12; k++) s += W[i][k] * HTh[k]; K_h[i] = s; }
         K_x = Cov::zero();
-        for (int i = 0; i < n; i++) for (int j = 0; j < 12; j++) { double s = 0; for (int k = 0; k < 12; k++) s += W[i][k] * HTH(k, j); K_x(i, j) = s; }
+        for (int i = 0; i < n; i++) {
+          double acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+          for (int k = 0; k < 12; k++) { const double wk = W[i][k]; for (int j = 0; j < 12; j++) acc[j] += wk * HTH(k, j); }
+          for (int j = 0; j < 12; j++) K_x(i, j) = acc[j];
+        }
       }
     }
 
@@ -604,12 +612,12 @@ void Esekf::update_iterated_dyn_share_modified(double R, double D) {
         right_block_T<2, kDof>(P_, idx, J);
       }
       Cov Pn;
-      for (int i = 0; i < n; i++)
-        for (int j = 0; j < n; j++) {
-          double s = 0;
-          for (int k = 0; k < 12; k++) s += K_x(i, k) * P_(k, j);
-          Pn(i, j) = L(i, j) - s;
-        }
+      for (int i = 0; i < n; i++) {
+        double acc[kDof];
+        for (int j = 0; j < n; j++) acc[j] = 0.0;
+        for (int k = 0; k < 12; k++) { const double kk = K_x(i, k); for (int j = 0; j < n; j++) acc[j] += kk * P_(k, j); }
+        for (int j = 0; j < n; j++) Pn(i, j) = L(i, j) - acc[j];
+      }
       P_ = Pn;
       return;
     }
