@@ -1010,3 +1010,16 @@ def test_unbounded_imu_wait_like_the_reference(built, scene):
     assert not t.is_alive() and out["rc"] == 0
     np.testing.assert_array_equal(G.get_x(), x_ref)
     G.close()
+
+
+@pytest.mark.gpu
+def test_differential_fuzz_with_crowded_maps(built, oracle):
+    """A short run of the developer soak (tests/dev/gpu_fuzz.py; 800 trials were run by hand this round): random scenes and scans,
+    maps crowded by raw sweeps inserted through the product and through the oracle's octree, poor and good priors, second level
+    and own-cell probe forced on in half of the trials -- per trial three passes whose M, H rows and residuals equal the oracle's
+    bit for bit, and an index that equals a fresh sort."""
+    import os, subprocess, sys
+    env = dict(os.environ, TRIALS="16", SEED="11")
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dev", "gpu_fuzz.py")
+    r = subprocess.run([sys.executable, script], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "FUZZ OK: 16 trials" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
