@@ -245,10 +245,24 @@ Mapper::~Mapper() {
   if (ctx_) flimo_ctx_destroy(ctx_);
 }
 // ---- asynchronous path exit -------------------------------------------------------------------------------------------
+// An insert takes a few hundred microseconds; waking a sleeping thread costs tens of them on either side of the hand-over.
+// Both sides therefore poll the flag for a bounded time before they fall back to the condition variable.
+static inline void spin_pause() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#endif
+}
 void Mapper::sync() {
   if (!worker_.joinable()) return;
-  std::unique_lock<std::mutex> lk(wm_);
-  wcv_.wait(lk, [this] { return !busy_; });
+  const double t0 = now_s();
+  while (busy_.load(std::memory_order_acquire)) {
+    if (now_s() - t0 > 2.0e-3) {
+      std::unique_lock<std::mutex> lk(wm_);
+      wcv_.wait(lk, [this] { return !busy_.load(); });
+      return;
+    }
+    spin_pause();
+  }
 }
 void Mapper::run_insert(const double x26[26], double stamp) {
   const double t0 = now_s();
@@ -259,7 +273,14 @@ void Mapper::run_insert(const double x26[26], double stamp) {
 void Mapper::worker_main() {
   std::unique_lock<std::mutex> lk(wm_);
   for (;;) {
-    wcv_.wait(lk, [this] { return busy_ || quit_; });
+    if (!busy_.load() && !quit_.load()) {
+      // the next job of a back-to-back sequence arrives within a millisecond: poll for it before going to sleep
+      lk.unlock();
+      const double t0 = now_s();
+      while (!busy_.load(std::memory_order_acquire) && !quit_.load(std::memory_order_acquire) && now_s() - t0 < 1.5e-3) spin_pause();
+      lk.lock();
+    }
+    wcv_.wait(lk, [this] { return busy_.load() || quit_.load(); });
     if (quit_) return;
     lk.unlock();
     run_insert(job_x_, job_stamp_);                 // the only user of ctx_ while busy_ is set

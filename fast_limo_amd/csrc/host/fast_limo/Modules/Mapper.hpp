@@ -4,6 +4,7 @@
 // filter itself uses the reduced seam (match_reduce) instead of materialising Matches.
 #ifndef __FASTLIMO_MAPPER_HPP__
 #define __FASTLIMO_MAPPER_HPP__
+#include <atomic>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -65,7 +66,7 @@ class fast_limo::Mapper {
   std::thread worker_;
   std::mutex wm_;
   std::condition_variable wcv_;
-  bool busy_ = false, quit_ = false;
+  std::atomic<bool> busy_{false}, quit_{false};   // written under wm_, also polled without it (short spins before the condition-variable waits)
   double job_x_[26];
   double job_stamp_ = 0.0;
   double insert_seconds_ = 0.0;
