@@ -10,7 +10,8 @@ f-1/f-2).  Every step restarts from the same predicted prior, so 
 same work and produce the same pose.
 
   python bench.py --gpus N --steps K --warmup W
-For N > 1 the driver launches it under torch.distributed.run (one rank per GPU).  The path shards
+For N > 1 the driver launches it under torch.distributed.run (one rank per GPU); a plain `python bench.py --gpus N` starts
+the N ranks itself (self_launch).  The path shards
 by independent scan streams (config 5): no data-path collective, weak scaling; torch.distributed is
 used only for the barrier and the max-over-ranks time.
 
@@ -160,6 +161,120 @@ class _OracleNoInsert:
         return self.L.update_pointcloud(pts, stamp, add_to_map=False)
 
 
+HBM_REGIME = dict(rings=128, azimuths=2048, map_points=20000000, box=447.0)      # BASELINE.json configs[3]: 256k-pt scan, 20M-pt map
+
+
+def pmc_traffic_hbm_regime():
+    """HBM-side bytes per launch of the pass kernel at 256k x 20M from the committed PMC profile (same rule as pmc_traffic)."""
+    f = os.path.join(ROOT, "profiles", "r03", "pmc_hbm_regime.json")
+    try:
+        from fast_limo_amd import build as b
+        d = json.load(open(f))
+        if d.get("sources_hash") != b.sources_hash():
+            return None
+        return d["dominant_kernel_traffic_bytes_per_launch"]["total_corrected"]
+    except Exception:
+        return None
+
+
+def hbm_regime_leg(device, steps, with_oracle, max_threads=32):
+    """"use config 4 (256k x 20M, 320 MB map) for the real HBM-roofline number" -- the one configuration
+    whose map (320 MB of points + two index tables) does not fit the 256 MB Infinity Cache.  Same step as the headline (GPU deskew
+    + iterated update of a resident scan against a resident map), its passes timed with HIP events on their dispatches; E from
+    the CPU oracle's own traversal on the identical registration."""
+    from fast_limo_amd import api, synth
+    caps = dict(MAX_NUM_PC2MATCH=10**7, MAX_NUM_MATCHES=10**7)
+    R = HBM_REGIME
+    mp = synth.box_world_map(R["map_points"], R["box"], 1)
+    scan = synth.velodyne_scan(R["rings"], R["azimuths"], R["box"], 2)
+    imu = synth.stationary_imu(0.0, 0.35)
+    loc = api.Localizer(api.default_cfg(gpu_device=device, num_threads=os.cpu_count() or 1, **caps))
+    loc.set_flags(add_to_map=False, download_clouds=False, keep_log=False)
+    rc1 = drive_to_prior(loc, mp, scan, imu)
+    x_prior, P_prior = loc.get_x(), loc.get_P()
+    rc2 = loc.update_pointcloud(scan, 0.1)
+    assert rc1 == 1 and rc2 == 0, (rc1, rc2)
+    x_ref = loc.get_x()
+    reg = loc.register_resident_call(x_prior, P_prior)
+    for _ in range(3):
+        assert reg() == 0
+    x_step = loc.get_x()
+    loc.hip.set_timing(0)
+    p0, f0 = loc.hip.pass_count(), loc.hip.fused_pass_count()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        reg()
+    elapsed = time.perf_counter() - t0
+    n_passes, n_fused = loc.hip.pass_count() - p0, loc.hip.fused_pass_count() - f0
+    assert np.allclose(loc.get_x(), x_step, rtol=0.0, atol=1e-9) and np.allclose(x_step, x_ref, rtol=0.0, atol=1e-6)
+    # every pass of 8 more steps timed by HIP events on its dispatch (the context's own stream)
+    loc.hip.set_timing(1); loc.hip.set_timing_stride(1)
+    loc.hip.timing_totals(reset=True); loc.hip.timing_split(reset=True)
+    for _ in range(8):
+        reg()
+    d, tot = loc.hip.timing_split(reset=True), loc.hip.timing_totals(reset=True)
+    qpl = tot["queries"] / max(tot["passes"], 1)
+    # the k-NN stage on its own (fast path + widening, no fit): the pass split into dispatches (A/B switch)
+    loc.hip.set_path_switches(fuse=0)
+    for _ in range(2):
+        reg()
+    loc.hip.timing_split(reset=True)
+    for _ in range(8):
+        reg()
+    ds = loc.hip.timing_split(reset=True)
+    loc.hip.set_path_switches(fuse=1)
+    loc.hip.set_timing(0)
+    stragglers = loc.hip.last_stragglers()
+    out = {"workload": "BASELINE.json configs[3] as a resident-input step: %d-pt scan (%d rings x %d azimuths) vs %d-pt box-world map (L = %.0f m), "
+                       "k=5, MAX_NUM_ITERS=3, GPU deskew + iterated ESKF update per step" % (scan.shape[0], R["rings"], R["azimuths"], mp.shape[0], R["box"]),
+           "map_bytes": int(mp.shape[0]) * 16, "steps": steps, "ms_per_step": 1e3 * elapsed / steps, "scans_per_s": steps / elapsed,
+           "passes_per_step": n_passes / steps, "passes_in_one_launch": n_fused, "passes_total": n_passes,
+           "stragglers_last_pass": stragglers,
+           "one_launch_pass_us": (1e3 * d["fused_ms"] / d["fused_n"]) if d["fused_n"] else None, "one_launch_passes_timed": d["fused_n"],
+           "separate_dispatch_pass_us": ({"knn": 1e3 * d["knn_ms"] / d["separate_n"], "widen": 1e3 * d["widen_ms"] / d["separate_n"],
+                                          "fit_reduce": 1e3 * d["fit_ms"] / d["separate_n"]} if d["separate_n"] else None),
+           "separate_dispatch_passes_timed": d["separate_n"], "queries_per_launch": qpl}
+    E = None
+    if with_oracle:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle_py as O
+        nt = max(1, min(max_threads, os.cpu_count() or 1))
+        L = O.Localizer(O.default_cfg(num_threads=nt, **caps))
+        drive_to_prior(_OracleNoInsert(L), mp, scan, imu)
+        rc = L.update_pointcloud(scan, 0.1, add_to_map=False)
+        st = L.stats()
+        E = st["evals"] / max(st["queries"], 1)
+        x_o = L.get_x()
+        out["pose_err_vs_cpu"] = {"pos_m": float(np.abs(x_ref[0:3] - x_o[0:3]).max()), "rot_rad": float(2.0 * np.abs(x_ref[3:6] - x_o[3:6]).max()),
+                                  "tolerance": 1e-4}
+        out["cpu_oracle_one_registration_s"] = float(st["t_deskew"] - st["t_sort"] + st["t_update"])
+        out["cpu_threads"] = nt
+        del L
+    out["E_evals_per_query"] = E
+    if E:
+        bpq = 16.0 + 16.0 * E + NBR_BYTES
+        out["bytes_per_query"] = bpq
+        alg = bpq * qpl
+        def rate(us):
+            return (alg / (us * 1e-6) / 1e9) if us else None
+        one = out["one_launch_pass_us"]
+        out["achieved"] = rate(one)
+        out["frac"] = (rate(one) / HBM_PEAK_GBPS) if one else None
+        if ds["separate_n"]:
+            knn_us, widen_us = 1e3 * ds["knn_ms"] / ds["separate_n"], 1e3 * ds["widen_ms"] / ds["separate_n"]
+            out["knn_stage_separate_dispatches"] = {"knn_us": knn_us, "widen_us": widen_us, "fit_us": 1e3 * ds["fit_ms"] / ds["separate_n"],
+                                                    "passes_timed": ds["separate_n"], "stage_us_per_pass": knn_us + widen_us,
+                                                    "achieved": rate(knn_us + widen_us), "frac": rate(knn_us + widen_us) / HBM_PEAK_GBPS,
+                                                    "knn_kernel_frac": rate(knn_us) / HBM_PEAK_GBPS}
+        traffic = pmc_traffic_hbm_regime()
+        out["traffic"] = traffic
+        out["traffic_over_algorithmic"] = (traffic / alg) if traffic else None
+        out["hbm_utilisation_measured"] = (traffic / (one * 1e-6) / 1e9 / HBM_PEAK_GBPS) if (traffic and one) else None
+        out["unit"], out["peak"], out["bound"] = "GB/s", HBM_PEAK_GBPS, "hbm"
+    loc.close()
+    return out
+
+
 def rank_barrier(dist, torch):
     """Barrier over the ranks (if any) + device synchronisation: brackets the timed region on both sides."""
     if dist is not None:
@@ -178,6 +293,39 @@ def aggregate(dist, torch, elapsed: float, world: int, steps: int):
     return elapsed, world * steps / elapsed
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* in their environment, the protocol torch.distributed.run uses) and wait for them.  This parent never touches the GPU
+    -- nothing that initialised HIP is ever re-executed -- and prints nothing itself: rank 0 inherits stdout and writes the one
+    JSON line.  On a box with fewer devices than ranks (tests: two ranks on one GPU) the ranks share devices and the barrier goes
+    through gloo, RCCL refusing two ranks on one device."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env0 = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if "FLIMO_BENCH_BACKEND" not in env0:
+        import torch                                   # device_count() enumerates without creating a HIP context
+        if torch.cuda.device_count() < n:
+            env0["FLIMO_BENCH_BACKEND"] = "gloo"
+    procs = []
+    for r in range(n):
+        env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        try:
+            p.wait(timeout=3600)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
+        rc = rc or p.returncode
+    return 1 if rc else 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -189,6 +337,9 @@ def main():
     ap.add_argument("--box", type=float, default=100.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-hbm-regime", action="store_true", help="skip the 256k x 20M leg (roofline.hbm_regime)")
+    ap.add_argument("--hbm-regime-only", action="store_true", help="run only the 256k x 20M leg and print it (profiling)")
+    ap.add_argument("--hbm-steps", type=int, default=20)
     ap.add_argument("--e2e-sweeps", type=int, default=8)
     ap.add_argument("--streams", type=int, default=3, help="informational leg: this many independent scan streams on ONE GPU at once (0: skip)")
     ap.add_argument("--with-insert", action="store_true",
@@ -196,18 +347,26 @@ def main():
                          "(first insertion + one repeat), for a steadier 'repeat' figure")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))            # plain `python bench.py --gpus N`: this process only starts the N ranks
+
     # stdout carries exactly ONE JSON line: the native library reports status lines the way the reference does
     # (std::cout), so fd 1 is pointed at stderr for the whole run and the result goes to the saved descriptor
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
+    if args.hbm_regime_only:
+        out = hbm_regime_leg(0, args.hbm_steps, with_oracle=not args.no_cpu_baseline)
+        os.write(json_fd, (json.dumps({"roofline": {"hbm_regime": out}}) + "\n").encode())
+        return
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    n_gpus = world                      # one rank per GPU; `--gpus` documents the launch, WORLD_SIZE is what actually runs
+    n_gpus = world                      # one rank per GPU; WORLD_SIZE is what actually runs
     if args.gpus != world and rank == 0:
-        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1; reporting n_gpus={world}", file=sys.stderr)
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: reporting n_gpus={world}", file=sys.stderr)
 
     import torch
     dist = None
@@ -491,8 +650,13 @@ def main():
                 note="A/B series after the timed region with the pass split into dispatches: k-NN (fast path + in-kernel widening; the "
                      "first pass of the poor prior hands its clustered stragglers to the widening dispatch) + widening, mean per pass "
                      "over all 4 pass positions; same algorithmic bytes")
+        loc.close()
+        loc = None
+        if world == 1 and not args.no_hbm_regime:
+            out["roofline"]["hbm_regime"] = hbm_regime_leg(local_rank % n_dev, args.hbm_steps, with_oracle=not args.no_cpu_baseline)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
-    loc.close()
+    if loc is not None:
+        loc.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -57,7 +57,7 @@ HIP_SYMBOLS = [
     "flimo_match_reduce", "flimo_match_fetch", "flimo_match_fetch_H",
     "flimo_scan_to_world", "flimo_map_add_scan",
     "flimo_set_timing", "flimo_set_timing_stride", "flimo_pass_count", "flimo_fused_pass_count", "flimo_tie_stats", "flimo_fine_stats", "flimo_map_grid_selfcheck", "flimo_set_debug_records", "flimo_set_lanes_per_query", "flimo_last_kernel_ms",
-    "flimo_last_candidates_per_query", "flimo_last_widen_count", "flimo_last_stragglers", "flimo_timing_totals", "flimo_timing_split", "flimo_set_path_switches", "flimo_insert_rule_replay", "flimo_plane_fit5_host", "flimo_plane_eval5_host", "flimo_calculate_H_host",
+    "flimo_last_candidates_per_query", "flimo_last_widen_count", "flimo_last_stragglers", "flimo_timing_totals", "flimo_timing_split", "flimo_set_path_switches", "flimo_set_wait_timeout_ms", "flimo_insert_rule_replay", "flimo_plane_fit5_host", "flimo_plane_eval5_host", "flimo_calculate_H_host",
 ]
 
 _hip = None
@@ -108,6 +108,7 @@ def load_hip():
     L.flimo_scan_to_world.argtypes = [vp, f64p, C.c_void_p, C.c_size_t]
     L.flimo_map_add_scan.argtypes = [vp, f64p, C.c_double]
     L.flimo_set_timing.argtypes = [vp, C.c_int]
+    L.flimo_set_wait_timeout_ms.argtypes = [vp, C.c_int]
     L.flimo_set_timing_stride.argtypes = [vp, C.c_int]
     L.flimo_pass_count.restype = C.c_ulonglong
     L.flimo_pass_count.argtypes = [vp]
@@ -333,6 +334,9 @@ class HipCtx:
 
     def last_widen_count(self) -> int:
         return int(self._L.flimo_last_widen_count(self._h))
+
+    def set_wait_timeout_ms(self, ms: int):
+        self._chk(self._L.flimo_set_wait_timeout_ms(self._h, int(ms)))
 
     def last_stragglers(self) -> int:
         return int(self._L.flimo_last_stragglers(self._h))

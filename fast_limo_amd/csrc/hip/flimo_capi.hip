@@ -133,6 +133,7 @@ struct flimo_ctx {
   bool prune = true;               // FLIMO_PRUNE=0 disables the bound (A/B checks)
   unsigned probe_min = 96;         // FLIMO_PROBE=<n>: first pass, a query with >= n candidates in its 3x3x3 block walks its own cell first for a bound (0: off)
   int tail_pass1 = -1;             // FLIMO_TAIL_PASS1: 1 = the first pass of a scan always uses the in-kernel tail, 0 = never, default: by the straggler count of the last scan's first pass (stragglers_hist[0])
+  int tail_max = 0;                // FLIMO_TAIL_MAX: most stragglers the last scan's pass at the same position may have published for this pass to finish its own in-kernel (0: max(1024, queries / 64))
   int stragglers_hist[4] = {1 << 30, 0, 0, 0};   // the same per pass position within a scan (0 = first pass .. 3 = fourth and later), last scan that reported
   int pass_in_scan = 0;
   int last_stragglers = -1;        // the same of the last pass (-1: not reported by that pass's path)
@@ -171,6 +172,7 @@ struct flimo_ctx {
   bool force_general_k = false;    // FLIMO_GENERAL_K=1: NUM_MATCH_POINTS == 5 also takes the general (any-k) pass (A/B checks)
   void* d_nbrk = nullptr;          // neighbour records of the general pass
   size_t nbrk_cap = 0;
+  int wait_timeout_ms = 2000;      // wall-clock bound of the wait for a pass's result (flimo_set_wait_timeout_ms)
   bool tail = true;                // FLIMO_TAIL=0: pending queries go to the worklist + widen_kernel dispatch instead of being finished inside the k-NN launch (A/B checks)
 };
 
@@ -299,8 +301,8 @@ extern "C" int flimo_ctx_create(int device, flimo_ctx** out) {
             hipHostGetDevicePointer((void**)&c->d_out256_host, c->h_out256, 0) == hipSuccess &&
             hipHostMalloc((void**)&c->h_granules, FIT_GROUPS * FIT_LIVE_PAD * 2 * sizeof(double), hipHostMallocMapped) == hipSuccess &&
             hipHostGetDevicePointer((void**)&c->d_granules_host, c->h_granules, 0) == hipSuccess &&
-            hipMalloc(&c->d_ticket, FIT_GROUPS * sizeof(unsigned int)) == hipSuccess &&
-            hipMemset(c->d_ticket, 0, FIT_GROUPS * sizeof(unsigned int)) == hipSuccess &&
+            hipMalloc(&c->d_ticket, (FIT_GROUPS + 1) * sizeof(unsigned int)) == hipSuccess &&      // one per group + one launch-wide
+            hipMemset(c->d_ticket, 0, (FIT_GROUPS + 1) * sizeof(unsigned int)) == hipSuccess &&
             hipMalloc(&c->d_cand, sizeof(unsigned long long)) == hipSuccess &&
             hipMalloc(&c->d_tie_count, 2 * sizeof(unsigned int)) == hipSuccess &&
             hipMemset(c->d_tie_count, 0, 2 * sizeof(unsigned int)) == hipSuccess &&
@@ -356,6 +358,8 @@ extern "C" int flimo_ctx_create(int device, flimo_ctx** out) {
   c->force_general_k = e && atoi(e) != 0;
   e = getenv("FLIMO_TAIL_PASS1");
   if (e) c->tail_pass1 = atoi(e) != 0;
+  e = getenv("FLIMO_TAIL_MAX");
+  if (e && atoi(e) > 0) c->tail_max = atoi(e);
   e = getenv("FLIMO_FUSE");
   if (e) c->fuse = atoi(e) != 0;
   e = getenv("FLIMO_FIT2");
@@ -934,6 +938,7 @@ static int ensure_scan(flimo_ctx* c, size_t n) {
   (void)hipFree(c->d_raw_sorted); (void)hipFree(c->d_t_sorted);
   c->d_raw_sorted = rs; c->d_t_sorted = ts;
   HIPCHK(c, hipMalloc(&nb, cap * nbr_rec_size()));
+  HIPCHK(c, hipMemsetAsync(nb, 0, cap * nbr_rec_size(), c->stream));      // flag 0 everywhere: no record is ever read uninitialised
   HIPCHK(c, hipMalloc(&wl, (cap + 8192) * wl_entry_size()));   // + slack: every widening wave prefetches its first slot
   HIPCHK(c, hipMalloc(&fp, fpn * sizeof(double)));
   (void)hipFree(c->d_scan_sorted); (void)hipFree(c->d_nbr); (void)hipFree(c->d_wl); (void)hipFree(c->d_fit_partials);
@@ -1257,6 +1262,53 @@ static int gate_rings(const flimo_ctx* c, double max_dist_plane) {
   return std::max(r, 1);
 }
 
+// Waits until every granule of the pass `want` has arrived in mapped host memory (spinning: a pass lasts tens of microseconds).
+// Bounded by wall clock (FLIMO_DEFAULT_WAIT_MS, flimo_set_wait_timeout_ms): a launch that never publishes -- a device fault, a
+// hung kernel -- ends the call with an error instead of hanging the caller, which holds the filter's mutex.
+static bool tags_complete(const flimo_ctx* c, unsigned long long want) {
+  const volatile unsigned long long* t0 = reinterpret_cast<const volatile unsigned long long*>(c->h_granules);
+  if (t0[2 * FIT_LIVE + 1] != want || t0[2 * (FIT_LIVE + 1) + 1] != want) return false;
+  for (int g = 0; g < FIT_GROUPS; g++) {
+    const volatile unsigned long long* tags = reinterpret_cast<const volatile unsigned long long*>(c->h_granules + (size_t)g * FIT_LIVE_PAD * 2);
+    for (int k = 0; k < FIT_LIVE; k++)
+      if (tags[2 * k + 1] != want) return false;
+  }
+  return true;
+}
+static int wait_tags(flimo_ctx* c, unsigned long long want) {
+  const volatile unsigned long long* t0 = reinterpret_cast<const volatile unsigned long long*>(c->h_granules);
+  unsigned long long spins = 0;
+  double deadline = 0.0;
+  auto now_s = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  for (;;) {
+    if (t0[2 * (FIT_LIVE + 1) + 1] == want && tags_complete(c, want)) return FLIMO_OK;
+    _mm_pause();
+    if ((++spins & 0x3fffull) != 0) continue;            // look at the clock every 16k polls (about 0.1 ms)
+    const double t = now_s();
+    if (deadline == 0.0) { deadline = t + 1e-3 * (double)c->wait_timeout_ms; continue; }
+    if (t < deadline) continue;
+    // out of time: what does the stream say?
+    const hipError_t q = hipStreamQuery(c->stream);
+    if (q == hipErrorNotReady)
+      return fail(c, FLIMO_ERR_TIMEOUT, "pass %llu did not publish its result within %d ms (kernel still running)", want, c->wait_timeout_ms);
+    if (q != hipSuccess) return fail(c, FLIMO_ERR_HIP, "pass %llu failed: %s", want, hipGetErrorString(q));
+    if (tags_complete(c, want)) return FLIMO_OK;          // arrived while we looked
+    // the stream is idle and the result never arrived: a ticket was left behind by an aborted launch.  Re-arm and report.
+    (void)hipMemsetAsync(c->d_ticket, 0, (FIT_GROUPS + 1) * sizeof(unsigned int), c->stream);
+    (void)hipMemsetAsync(c->d_wl_count, 0, sizeof(int), c->stream);
+    (void)hipMemsetAsync(c->d_tie_count, 0, 2 * sizeof(unsigned int), c->stream);
+    (void)hipStreamSynchronize(c->stream);
+    c->prev.valid = 0;
+    return fail(c, FLIMO_ERR_HIP, "pass %llu completed without publishing its result (reduction tickets re-armed)", want);
+  }
+}
+
+extern "C" int flimo_set_wait_timeout_ms(flimo_ctx* c, int ms) {
+  if (!c || ms < 1) return FLIMO_ERR_INVALID;
+  c->wait_timeout_ms = ms;
+  return FLIMO_OK;
+}
+
 extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flimo_match_cfg* cfg, double HTH[144],
                                   double HTh[12], int* M) {
   if (!c || !x26 || !cfg || !HTH || !HTh || !M) return FLIMO_ERR_INVALID;
@@ -1314,6 +1366,9 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
       return fail(c, FLIMO_ERR_UNSUPPORTED, "NUM_MATCH_POINTS out of range");
     if (cap_binds) launch_cap(c->stream, c->d_recs, (int)nq, cfg->MAX_NUM_MATCHES);
     launch_reduce(c->stream, c->d_recs, (int)nq, c->reduce_waves, c->d_partials, c->d_out256_host);
+    // the general pass leaves exact ties to the position rule and does not use the two alternating tie
+    // counters of the 5-NN passes; it keeps them armed for whichever 5-NN pass comes next
+    HIPCHK(c, hipMemsetAsync(c->d_tie_count, 0, 2 * sizeof(unsigned int), c->stream));
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     ++c->pass_seq;
@@ -1348,8 +1403,11 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   c->pass_in_scan = first_pass ? 0 : std::min(c->pass_in_scan + 1, 3);
   // later passes likewise, by the count the pass at the same position of the last scan published: a sparse far range (256k-point
   // sweeps over a 900 m map) keeps thousands of points beyond their 3x3x3 block in every pass
-  const bool tail_here = first_pass ? (c->tail_pass1 >= 0 ? c->tail_pass1 != 0 : c->stragglers_hist[0] <= 1024)
-                                    : (c->stragglers_hist[c->pass_in_scan] <= 1024);
+  // The bound grows with the scan: what hurts is a wave whose queries are ALL pending (one long chain), and a launch of n
+  // queries spreads 1/64 of them over its waves a handful at a time (FLIMO_TAIL_MAX overrides)
+  const int tail_max = c->tail_max > 0 ? c->tail_max : std::max(1024, n_all / 64);
+  const bool tail_here = first_pass ? (c->tail_pass1 >= 0 ? c->tail_pass1 != 0 : c->stragglers_hist[0] <= tail_max)
+                                    : (c->stragglers_hist[c->pass_in_scan] <= tail_max);
   const bool tail = c->tail && tail_here && !heavy_on && mp.max_ring >= 2 && mp.max_ring <= 3;
   c->prev.probe_min = c->probe_min;
   c->prev.heavy = (!tail && mp.max_ring >= 2 && mp.max_ring <= 3) ? c->heavy_threshold : 0xffffffffu;   // only when the wave-per-query kernel follows
@@ -1366,7 +1424,7 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   // crowded regions first: the fine pre-pass settles the queries whose five lie within centimetres (second-level grid)
   const bool after_fine = c->fine_valid && c->lanes_per_query == 2 && mp.max_ring >= 1;
   if (after_fine) {
-    launch_knn5_fine(c->stream, c->fine, c->d_scan_sorted, n_all, P, c->d_nbr, c->prev, c->fine_qlo, c->fine_qhi, &tl);
+    launch_knn5_fine(c->stream, c->fine, c->d_scan_sorted, n_all, P, c->d_nbr, c->prev, c->fine_qlo, c->fine_qhi, &tl, seq);
     c->fine_passes++;
   }
   if (fused) {
@@ -1377,7 +1435,7 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   } else
   launch_knn5(c->stream, c->lanes_per_query, c->grid, c->d_scan_sorted, n_all, P, mp.max_ring, c->d_nbr, c->d_wl,
               c->d_wl_count, c->debug_recs ? c->d_cand : nullptr, c->prev, tail ? 1 : 0, tlev == 1 ? c->ev[0] : nullptr,
-              tlev == 1 ? c->ev[1] : nullptr, nullptr, &tl, after_fine ? 1 : 0);
+              tlev == 1 ? c->ev[1] : nullptr, nullptr, &tl, after_fine ? 1 : 0, seq);
   if (c->prune) { memcpy(c->prev.RT, P.RT, sizeof(c->prev.RT)); c->prev.valid = 1; }   // the records now belong to this pose
   const double tpb = prof ? now_us() : 0.0;
   if (tlev > 1) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
@@ -1424,19 +1482,9 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
     // low-latency completion: every sum arrives as a 16-byte granule {value, pass number}; a group's slot is complete when
     // all of its tags carry this pass (the last granule stored is polled, then all are checked)
     auto wait_granules = [&](unsigned long long want) -> int {
-      unsigned long long spins = 0;
-      for (int g = 0; g < FIT_GROUPS; g++) {
-        volatile unsigned long long* tags = reinterpret_cast<volatile unsigned long long*>(c->h_granules + (size_t)g * FIT_LIVE_PAD * 2);
-        for (;;) {
-          if (tags[2 * (FIT_LIVE + 1) + 1] == want) {            // the last granule stored (tie count), then every other one
-            bool all = true;
-            for (int k = 0; k <= FIT_LIVE; k++) all = all && (tags[2 * k + 1] == want);
-            if (all) break;
-          }
-          _mm_pause();
-          if (++spins > 40000000ull) { HIPCHK(c, hipStreamSynchronize(c->stream)); return FLIMO_OK; }   // also surfaces launch errors
-        }
-      }
+      // slot 0 carries the launch's two counters (stored last, by the block that finishes the launch); then every group's sums
+      const int rcw = wait_tags(c, want);
+      if (rcw) return rcw;
       __atomic_thread_fence(__ATOMIC_ACQUIRE);
       return FLIMO_OK;
     };
@@ -1480,7 +1528,11 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
       volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(c->h_out256 + (size_t)g * FIT_SLOT + 256);
       while (*flag != seq) {
         _mm_pause();
-        if (++spins > 40000000ull) { HIPCHK(c, hipStreamSynchronize(c->stream)); break; }   // also surfaces launch errors
+        if (++spins > 40000000ull) {                             // also surfaces launch errors
+          HIPCHK(c, hipStreamSynchronize(c->stream));
+          if (*flag != seq) return fail(c, FLIMO_ERR_HIP, "pass %llu completed without publishing its result", seq);
+          break;
+        }
       }
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);

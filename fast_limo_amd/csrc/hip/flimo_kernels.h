@@ -13,10 +13,10 @@ struct BookView;
 void launch_knn5(hipStream_t st, int lanes_per_query, const GridView& G, const float4* scan_sorted, int n,
                  const PoseMats& P, int max_ring, void* nbr, int* wl, int* wl_count, unsigned long long* cand,
                  const PrevPass& prev, int tail, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, const struct FuseArgs* fuse = nullptr,
-                 const TieList* ties = nullptr, int after_fine = 0);
+                 const TieList* ties = nullptr, int after_fine = 0, unsigned long long seq = 0ull);
 // fine pre-pass over the second-level grid of crowded regions (see flimo_map.hip); launches that follow it pass after_fine = 1
 void launch_knn5_fine(hipStream_t st, const GridView& Gf, const float4* scan_sorted, int n, const PoseMats& P, void* nbr,
-                      const PrevPass& prev, const int qlo[3], const int qhi[3], const TieList* ties);
+                      const PrevPass& prev, const int qlo[3], const int qhi[3], const TieList* ties, unsigned long long seq);
 // tail != 0: queries that need more than the 3x3x3 block are finished inside the k-NN launch itself (gates of at most 3
 // rings; launch_knn5 clears the flag otherwise) and launch_widen has nothing to do
 void launch_widen(hipStream_t st, const GridView& G, const float4* scan_sorted, const PoseMats& P, int max_ring, void* nbr,
@@ -24,7 +24,8 @@ void launch_widen(hipStream_t st, const GridView& G, const float4* scan_sorted, 
                   const TieList* ties = nullptr);
 int fit_blocks(int n);
 void set_xcd_stripe(int stripe);   // block -> scan chunk mapping of the per-pass kernels (see xcd_chunk)
-// the fit kernel reduces in FIT_GROUPS groups; slot g of its output = 256 sums + the pass number (FIT_SLOT doubles)
+// the fit kernel reduces in FIT_GROUPS groups; slot g of its output = 256 sums + the pass number (FIT_SLOT doubles).
+// `ticket` arrays hold FIT_GROUPS + 1 counters: one per group and one launch-wide (fit_reduce_publish)
 constexpr int FIT_GROUPS = 8;
 constexpr int FIT_SLOT = 264;
 // fit + in-block MFMA reduction + grid reduction by the last block: out256[0..255] receives the raw

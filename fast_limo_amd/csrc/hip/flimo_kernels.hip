@@ -701,7 +701,9 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
   int4 pa_res = make_int4(0, 0, 0, 0), pb_res = make_int4(0, 0, 0, 0);
   if ((prev.valid || (!FINE && fa.fine_mode == 1)) && in_range) {
     const int4 pb = reinterpret_cast<const int4*>(&nbr[p])[1];       // idx[4], flag, d5 bits, "d5 valid"
-    if (!FINE && fa.fine_mode == 1 && pb.y == 4) {
+    // (a record settled by the fine pre-pass of THIS pass carries flag 4 and the pass number in the upper bits of w: a stale or
+    //  never-written record cannot be mistaken for one)
+    if (!FINE && fa.fine_mode == 1 && pb.y == 4 && ((uint32_t)pb.w >> 8) == (uint32_t)(fa.seq & 0xffffffull)) {
       resolved = true;
       pb_res = pb;
       pa_res = reinterpret_cast<const int4*>(&nbr[p])[0];
@@ -954,7 +956,8 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
     if (in_range && sub == 0 && flag == 1 && inside) {
       int4 a, b;
       a.x = (int)(uint32_t)best[0]; a.y = (int)(uint32_t)best[1]; a.z = (int)(uint32_t)best[2]; a.w = (int)(uint32_t)best[3];
-      b.x = (int)(uint32_t)best[4]; b.y = 4; b.z = (int)(uint32_t)(best[4] >> 32); b.w = 1 | (tie ? 2 : 0);
+      b.x = (int)(uint32_t)best[4]; b.y = 4; b.z = (int)(uint32_t)(best[4] >> 32);
+      b.w = (int)(1u | (tie ? 2u : 0u) | ((uint32_t)(fa.seq & 0xffffffull) << 8));
       int4* o = reinterpret_cast<int4*>(&nbr[p]);
       o[0] = a;
       o[1] = b;
@@ -1385,7 +1388,7 @@ __global__ __launch_bounds__(FIT_THREADS) void fit_kernel(GridView G, const floa
 // (bit-identical rows); what differs is how the launch is laid out around the two things that bound it:
 //   * a point's chain (neighbour record -> 5 gathered map points -> gates -> 5x3 QR with its correctly rounded
 //     divisions and square roots -> plane test -> H row) is ~1700 DEPENDENT instructions: one full wave per SIMD has
-//     nothing to overlap them with.  PPW points per wave (32 by default: lanes PPW..63 idle in the point stage) put
+//     nothing to overlap them with.  PPW points per wave (64 by default; with 32 or 16 lanes PPW..63 idle in the point stage) put
 //     64 / PPW waves on every SIMD, which interleave their chains;
 //   * the grid reduction's hand-offs: only the 91 sums the filter reads (upper triangle of H^T H, H^T h, M) leave a block,
 //     the last block of each of the FIT_GROUPS groups adds its group's partials in block order (two halves, fixed
@@ -1466,6 +1469,13 @@ __device__ __forceinline__ void fit_reduce_publish(const float (&v)[16], bool ow
   __syncthreads();
   TRACE(1, 5);
   if (*s_last) {
+    // Launch-wide ticket (slot FIT_GROUPS): the group whose last block arrives here LAST knows that every block of EVERY group has
+    // taken its group ticket, i.e. finished its k-NN / tail phase (in the one-launch pass the groups run concurrently: the last
+    // block of group 0 alone cannot know that).  Only that block reads the two counters of the pass and re-arms them.  Taken now,
+    // so that the round trip overlaps the loads of the group's partials.
+    bool launch_last = false;
+    if (threadIdx.x == 0)
+      launch_last = __hip_atomic_fetch_add(ticket + FIT_GROUPS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned int)FIT_GROUPS - 1u;
     // two halves of the group's block list x 128 columns (91 live); agent-scope loads read past this XCD's L2
     const int t = threadIdx.x & 127, part = threadIdx.x >> 7;
     const int per = (nb_g + 1) >> 1;
@@ -1503,19 +1513,23 @@ __device__ __forceinline__ void fit_reduce_publish(const float (&v)[16], bool ow
       asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(o), "v"(g) : "memory");
     }
     if (threadIdx.x == 0) {
-      // granule FIT_LIVE: the number of queries of this pass that needed more than their 3x3x3 block (group 0; the k-NN
-      // phase of every block of the launch is complete: every block has taken its ticket), then the counter is re-armed
-      v2d_t g;
-      g.x = (group == 0) ? (double)__hip_atomic_load(wl_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-      g.y = __longlong_as_double((long long)seq);
-      double2* o = out_granules + (size_t)group * FIT_LIVE_PAD + FIT_LIVE;
-      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(o), "v"(g) : "memory");
-      // granule FIT_LIVE + 1: queries whose five hinge on an exact distance tie (the host then runs tie_kernel and the fit again)
-      g.x = (group == 0 && tl.count) ? (double)__hip_atomic_load(tl.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-      o = out_granules + (size_t)group * FIT_LIVE_PAD + FIT_LIVE + 1;
-      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(o), "v"(g) : "memory");
-      ticket[group] = 0u;                                          // ready for the next pass (visible at kernel end)
-      if (group == 0) { *wl_count = 0; if (tl.count_next) *tl.count_next = 0u; }
+      __hip_atomic_store(ticket + group, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next pass
+      if (launch_last) {
+        // the launch's two counters, published in slot 0 whichever group this is (the host waits for these two granules first):
+        // granule FIT_LIVE = queries of this pass that needed more than their 3x3x3 block, granule FIT_LIVE + 1 = queries whose five
+        // hinge on an exact distance tie (the host then runs tie_kernel and the fit again).  Then everything is re-armed.
+        v2d_t g;
+        g.x = (double)__hip_atomic_load(wl_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        g.y = __longlong_as_double((long long)seq);
+        double2* o = out_granules + FIT_LIVE;
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(o), "v"(g) : "memory");
+        g.x = tl.count ? (double)__hip_atomic_load(tl.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        o = out_granules + FIT_LIVE + 1;
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(o), "v"(g) : "memory");
+        __hip_atomic_store(ticket + FIT_GROUPS, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(wl_count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tl.count_next) __hip_atomic_store(tl.count_next, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
     TRACE(1, 7);
   }
@@ -2200,7 +2214,8 @@ static int g_slots = 0;   // 0: default per L; developer override through FLIMO_
 template <int L>
 static void launch_knn5_L(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const PoseMats& P,
                           int max_ring, void* nbr, int* wl, int* wl_count, unsigned long long* cand, const PrevPass& prev,
-                          int tail, hipEvent_t e0, hipEvent_t e1, const FuseArgs* fuse, const TieList* tlp, int after_fine = 0) {
+                          int tail, hipEvent_t e0, hipEvent_t e1, const FuseArgs* fuse, const TieList* tlp, int after_fine = 0,
+                          unsigned long long seq = 0ull) {
   const int qpb = 256 / L;
   const int blocks = round_up8((n + qpb - 1) / qpb);
   if (g_slots == 0) { const char* e = getenv("FLIMO_SLOTS"); g_slots = e ? atoi(e) : -1; }
@@ -2214,6 +2229,7 @@ static void launch_knn5_L(hipStream_t st, const GridView& G, const float4* scan_
   FuseArgs nofuse{};
   if (tlp) nofuse.tl = *tlp;
   nofuse.fine_mode = after_fine ? 1 : 0;
+  nofuse.seq = seq;
   // e0 / e1 (optional) are attached to the dispatch itself: they read the kernel's own begin / end
   // timestamps, without the extra barrier packets of hipEventRecord
   if (slots >= 8)
@@ -2226,16 +2242,17 @@ static void launch_knn5_L(hipStream_t st, const GridView& G, const float4* scan_
 
 void launch_knn5(hipStream_t st, int lanes_per_query, const GridView& G, const float4* scan_sorted, int n,
                  const PoseMats& P, int max_ring, void* nbr, int* wl, int* wl_count, unsigned long long* cand,
-                 const PrevPass& prev, int tail, hipEvent_t e0, hipEvent_t e1, const FuseArgs* fuse, const TieList* tlp, int after_fine) {
+                 const PrevPass& prev, int tail, hipEvent_t e0, hipEvent_t e1, const FuseArgs* fuse, const TieList* tlp, int after_fine,
+                 unsigned long long seq) {
   if (n <= 0) return;
   if (max_ring < 2 || max_ring > TAIL_MAX_RING) tail = 0;
   switch (lanes_per_query) {
-    case 1: launch_knn5_L<1>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine); break;
-    case 2: launch_knn5_L<2>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine); break;
-    case 4: launch_knn5_L<4>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine); break;
-    case 8: launch_knn5_L<8>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine); break;
-    case 32: launch_knn5_L<32>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine); break;
-    default: launch_knn5_L<16>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine); break;
+    case 1: launch_knn5_L<1>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine, seq); break;
+    case 2: launch_knn5_L<2>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine, seq); break;
+    case 4: launch_knn5_L<4>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine, seq); break;
+    case 8: launch_knn5_L<8>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine, seq); break;
+    case 32: launch_knn5_L<32>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine, seq); break;
+    default: launch_knn5_L<16>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine, seq); break;
   }
 }
 
@@ -2328,10 +2345,11 @@ int fused_blocks(int n) { return round_up8((n + 127) / 128); }
 // fine pre-pass over the second-level grid (crowded regions): settles the queries whose five are proven inside their fine 3x3x3
 // block; their records get flag 4, which the main launch of the same pass (fine_mode 1) takes over
 void launch_knn5_fine(hipStream_t st, const GridView& Gf, const float4* scan_sorted, int n, const PoseMats& P, void* nbr,
-                      const PrevPass& prev, const int qlo[3], const int qhi[3], const TieList* tlp) {
+                      const PrevPass& prev, const int qlo[3], const int qhi[3], const TieList* tlp, unsigned long long seq) {
   if (n <= 0) return;
   FuseArgs fa{};
   fa.fine_mode = 2;
+  fa.seq = seq;
   for (int a = 0; a < 3; a++) { fa.qlo[a] = qlo[a]; fa.qhi[a] = qhi[a]; }
   if (tlp) fa.tl = *tlp;
   PrevPass pv = prev;

@@ -31,6 +31,7 @@ extern "C" {
 #define FLIMO_ERR_NOMAP (-4)
 #define FLIMO_ERR_TOO_LARGE (-5)
 #define FLIMO_ERR_UNSUPPORTED (-6)
+#define FLIMO_ERR_TIMEOUT (-7)      /* a pass did not publish its result within the wait bound (flimo_set_wait_timeout_ms) */
 
 typedef struct flimo_ctx flimo_ctx;
 
@@ -189,6 +190,11 @@ int flimo_timing_split(flimo_ctx* ctx, double out[6], int reset);
  * `fuse` runs the whole pass as one launch, `fit2` uses the granule-publishing fit dispatch.  All on by default; the benchmark
  * switches `fuse` off for a short series to time the k-NN stage (fast path + widening) on its own. */
 int flimo_set_path_switches(flimo_ctx* ctx, int tail, int fuse, int fit2);
+/* Wall-clock bound (milliseconds, default 2000) of the wait for a pass's result inside flimo_match_reduce: the reference's
+ * Mapper::match (Modules/Mapper.cpp:59-86) cannot hang, a GPU launch can -- when the bound expires the call returns
+ * FLIMO_ERR_TIMEOUT (kernel still running) or FLIMO_ERR_HIP (stream idle, nothing published) instead of blocking its caller,
+ * which holds the filter's mutex (Localizer.cpp:326-353). */
+int flimo_set_wait_timeout_ms(flimo_ctx* ctx, int ms);
 /* number of scan points of the last pass that needed more than the 3x3x3 cell block */
 int flimo_last_widen_count(const flimo_ctx* ctx);
 /* the same count as published by the pass itself with its result (fast path), -1 when the last pass took a path that does

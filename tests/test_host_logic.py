@@ -172,6 +172,38 @@ def test_bench_two_ranks_on_one_gpu_through_gloo(built):
     assert r["value"] > 0 and abs(r["value"] - 2 * 4 / (r["ms_per_step"] * 4e-3)) < 1e-6 * r["value"]
 
 
+@pytest.mark.gpu
+def test_bench_launches_its_own_ranks(built):
+    """A bare `python bench.py --gpus 2` (no torch.distributed.run, no WORLD_SIZE): bench.py starts the two ranks itself, before
+    anything touches the GPU in the parent, and rank 0 reports n_gpus = 2."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--rings", "16",
+                          "--azimuths", "512", "--map-points", "100000", "--box", "40", "--no-cpu-baseline", "--no-end-to-end"],
+                         env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["steps"] == 4
+    assert r["value"] > 0 and abs(r["value"] - 2 * 4 / (r["ms_per_step"] * 4e-3)) < 1e-6 * r["value"]
+
+
+def test_bench_self_launch_fails_loudly_without_a_gpu(built):
+    """CPU container: the same command starts its ranks, they meet through gloo, and the run ends with a non-zero status and no
+    JSON line because there is no gfx950 device (no CPU fallback anywhere on the product path)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by test_bench_launches_its_own_ranks")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--rings", "8",
+                          "--azimuths", "64", "--map-points", "2000", "--box", "10", "--no-cpu-baseline", "--no-end-to-end"],
+                         env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert "no gfx950 device" in out.stderr
+
+
 def test_bench_cli_contract():
     src = open(os.path.join(ROOT, "bench.py")).read()
     for flag in ("--gpus", "--steps", "--warmup"):
