@@ -45,7 +45,7 @@ HOST_SYMBOLS = [
     "flimo_loc_map_add", "flimo_loc_map_size", "flimo_loc_get_x", "flimo_loc_set_x", "flimo_loc_get_P",
     "flimo_loc_set_P", "flimo_loc_set_flags", "flimo_loc_num_passes", "flimo_loc_get_pass", "flimo_loc_get_pc2match",
     "flimo_loc_get_final_scan", "flimo_loc_get_stage_times", "flimo_loc_get_pose_cov", "flimo_loc_register_resident", "flimo_loc_host_profile",
-    "flimo_eskf_update_fixed", "flimo_eskf_predict", "flimo_host_plane", "flimo_host_state_update", "flimo_host_time_order",
+    "flimo_eskf_update_fixed", "flimo_eskf_predict", "flimo_host_eigen_solver6", "flimo_host_plane", "flimo_host_state_update", "flimo_host_time_order",
 ]
 
 
@@ -332,6 +332,17 @@ def eskf_update_fixed(x26, P, H, h, max_iters=3, limits=None, R=0.001, D=5.0):
     L.flimo_eskf_update_fixed(x, Pm, H.reshape(-1) if H.size else np.zeros(1), h if h.size else np.zeros(1), H.shape[0],
                               max_iters, lim, R, D, C.byref(n))
     return x, Pm.reshape(23, 23), n.value
+
+
+def eigen_solver6(A):
+    """The host filter's restatement of Eigen::EigenSolver<Matrix6d>: (eigenvalues real, imag, eigenvector real parts as columns)."""
+    L = load_host()
+    L.flimo_host_eigen_solver6.restype = None
+    L.flimo_host_eigen_solver6.argtypes = [f64p, f64p, f64p, f64p]
+    A = np.ascontiguousarray(A, dtype=np.float64).reshape(36)
+    wr = np.zeros(6); wi = np.zeros(6); V = np.zeros(36)
+    L.flimo_host_eigen_solver6(A, wr, wi, V)
+    return wr, wi, V.reshape(6, 6)
 
 
 def eskf_predict(x26, P, dt, Qdiag, acc, gyro):

@@ -1362,12 +1362,14 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
       c->nbrk_cap = cap;
     }
     c->prev.valid = 0;                                 // the 5-NN records of this scan (pruning bound) are not maintained here
-    if (!launch_match_k(c->stream, cfg->NUM_MATCH_POINTS, c->grid, c->d_scan_sorted, n_all, P, mp, c->d_nbrk, c->d_recs, c->d_dbg))
+    const BookView bookk{c->gbook.node_c, c->gbook.node_child, c->gbook.node_cnt, c->gbook.root};
+    if (!launch_match_k(c->stream, cfg->NUM_MATCH_POINTS, c->grid, c->d_scan_sorted, n_all, P, mp, c->d_nbrk, c->d_recs, c->d_dbg,
+                        (c->ties && c->gbook.active) ? &bookk : nullptr))
       return fail(c, FLIMO_ERR_UNSUPPORTED, "NUM_MATCH_POINTS out of range");
     if (cap_binds) launch_cap(c->stream, c->d_recs, (int)nq, cfg->MAX_NUM_MATCHES);
     launch_reduce(c->stream, c->d_recs, (int)nq, c->reduce_waves, c->d_partials, c->d_out256_host);
-    // the general pass leaves exact ties to the position rule and does not use the two alternating tie
-    // counters of the 5-NN passes; it keeps them armed for whichever 5-NN pass comes next
+    // the general pass settles ties for every query (tiek_kernel) and does not use the two alternating tie counters of the
+    // 5-NN passes; it keeps them armed for whichever 5-NN pass comes next
     HIPCHK(c, hipMemsetAsync(c->d_tie_count, 0, 2 * sizeof(unsigned int), c->stream));
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -21,6 +21,7 @@
 #include <float.h>
 #include <limits.h>
 #include <stdlib.h>
+#include <algorithm>
 #include "flimo_types.h"
 #include "flimo_math.h"
 #include "flimo_kernels.h"
@@ -1173,7 +1174,7 @@ __global__ __launch_bounds__(256, WPS) void widen_kernel(GridView G, const float
 // general ring search for the worklist when the gate needs more than 3 rings (unusual configs)
 __global__ __launch_bounds__(256) void widen_general_kernel(GridView G, const float4* __restrict__ scan_sorted,
                                                             PoseMats P, int max_ring, NbrRec* __restrict__ nbr,
-                                                            const int* __restrict__ wl, const int* __restrict__ wl_count) {
+                                                            const int* __restrict__ wl, const int* __restrict__ wl_count, TieList tl) {
   constexpr int L = 16;
   const int count = *wl_count;
   const int sub = threadIdx.x % L;
@@ -1188,10 +1189,13 @@ __global__ __launch_bounds__(256) void widen_general_kernel(GridView G, const fl
       const bool ok = R.exact && (R.bi[4] != INT_MAX);
       int4 a, b;
       a.x = R.bi[0]; a.y = R.bi[1]; a.z = R.bi[2]; a.w = R.bi[3];
-      b.x = R.bi[4]; b.y = ok ? 1 : 0; b.z = 0; b.w = 0;
+      // the ring search does not track the sixth candidate: every query it settles is listed for tie_kernel, which re-derives the
+      // five in the reference's visiting order (the same five when no distances are tied)
+      b.x = R.bi[4]; b.y = ok ? 1 : 0; b.z = ok ? __float_as_int(R.bd[4]) : 0; b.w = ok ? 3 : 0;
       int4* o = reinterpret_cast<int4*>(&nbr[p]);
       o[0] = a;
       o[1] = b;
+      if (ok && tl.list) { const unsigned slot = atomicAdd(tl.count, 1u); if (slot < tl.cap) tl.list[slot] = p; }
     }
   }
 }
@@ -1616,7 +1620,7 @@ __device__ bool visited_before(const BookView& B, float ax, float ay, float az, 
 struct TieLds { float4 pt[64]; float d[64]; uint32_t pos[64]; unsigned int cnt; };
 
 // One wave: the first k of {candidates with d <= dk inside the ring-r block around q} in the reference's order -> out_pos / out_d
-// (lane 0).  Returns false when the block is wider than 3 rings or holds more than 64 such candidates (nothing is changed then).
+// (lane 0).  Returns false when the ball holds more than 64 such candidates (nothing is changed then).
 __device__ bool tie_select_wave(const GridView& G, const BookView& B, float qx, float qy, float qz, float dk, int k, TieLds& S,
                                 uint32_t (&out_pos)[8], float (&out_d)[8]) {
   const int lane = threadIdx.x & 63;
@@ -1635,32 +1639,35 @@ __device__ bool tie_select_wave(const GridView& G, const BookView& B, float qx, 
     const float rg = ((float)r + edge - margin) * G.cell;
     if (!(dk <= rg * rg * (1.f - 1.0e-6f))) r++;
   }
-  if (r > 3) return false;
+  if (r > 64) return false;                                    // (a gate of more than 32 m at the default cell edge)
   if (lane == 0) S.cnt = 0u;
   wave_lds_sync();
   const int side = 2 * r + 1, rows = side * side;
   const float rc = (fl_sqrt(dk) * (1.f + 1.0e-5f) + 1.0e-6f) * G.inv_cell;
   const float bnd2 = rc * rc * (1.f + 1.0e-5f);
-  if (lane < rows) {
-    const int jz = lane / side, jy = lane - jz * side;
-    const int dy = jy - r, dz = jz - r;
-    const int yy = cy + dy, zz = cz + dz;
-    const float a = fmaxf(slab_dist(dy, ry) - margin, 0.f), b = fmaxf(slab_dist(dz, rz) - margin, 0.f);
-    const float dyz2 = a * a + b * b;
-    if (dyz2 <= bnd2 && yy >= 0 && yy < G.ny && zz >= 0 && zz < G.nz) {
-      const float xr = fl_sqrt(fmaxf(bnd2 - dyz2, 0.f)) * (1.f + 1.0e-6f) + margin + 1.0e-4f;
-      const int dr = (int)fminf(floorf(fminf(xr + rx, 1.0e6f)), (float)r);
-      const int dl = (int)fminf(floorf(fminf(xr + (1.f - rx), 1.0e6f)), (float)r);
-      const int x0 = max(cx - dl, 0), x1 = min(cx + dr, G.nx - 1);
-      if (x0 <= x1) {
-        const size_t rowbase = ((size_t)zz * (size_t)G.ny + (size_t)yy) * (size_t)G.nxf;
-        const uint32_t lo = G.cell_start[rowbase + (size_t)x0 * G.xs], hi = G.cell_start[rowbase + (size_t)(x1 + 1) * G.xs];
-        for (uint32_t i = lo; i < hi; i++) {
-          const float4 p = G.pts[i];
-          const float d = sqdist3(qx, qy, qz, p.x, p.y, p.z);
-          if (d <= dk) {
-            const unsigned slot = atomicAdd(&S.cnt, 1u);
-            if (slot < 64u) { S.pt[slot] = p; S.d[slot] = d; S.pos[slot] = i; }
+  for (int jb = 0; jb < rows; jb += 64) {                       // one row per lane, 64 rows per round (49 rows up to ring 3)
+    const int j = jb + lane;
+    if (j < rows) {
+      const int jz = j / side, jy = j - jz * side;
+      const int dy = jy - r, dz = jz - r;
+      const int yy = cy + dy, zz = cz + dz;
+      const float a = fmaxf(slab_dist(dy, ry) - margin, 0.f), b = fmaxf(slab_dist(dz, rz) - margin, 0.f);
+      const float dyz2 = a * a + b * b;
+      if (dyz2 <= bnd2 && yy >= 0 && yy < G.ny && zz >= 0 && zz < G.nz) {
+        const float xr = fl_sqrt(fmaxf(bnd2 - dyz2, 0.f)) * (1.f + 1.0e-6f) + margin + 1.0e-4f;
+        const int dr = (int)fminf(floorf(fminf(xr + rx, 1.0e6f)), (float)r);
+        const int dl = (int)fminf(floorf(fminf(xr + (1.f - rx), 1.0e6f)), (float)r);
+        const int x0 = max(cx - dl, 0), x1 = min(cx + dr, G.nx - 1);
+        if (x0 <= x1) {
+          const size_t rowbase = ((size_t)zz * (size_t)G.ny + (size_t)yy) * (size_t)G.nxf;
+          const uint32_t lo = G.cell_start[rowbase + (size_t)x0 * G.xs], hi = G.cell_start[rowbase + (size_t)(x1 + 1) * G.xs];
+          for (uint32_t i = lo; i < hi; i++) {
+            const float4 p = G.pts[i];
+            const float d = sqdist3(qx, qy, qz, p.x, p.y, p.z);
+            if (d <= dk) {
+              const unsigned slot = atomicAdd(&S.cnt, 1u);
+              if (slot < 64u) { S.pt[slot] = p; S.d[slot] = d; S.pos[slot] = i; }
+            }
           }
         }
       }
@@ -1841,24 +1848,50 @@ __global__ __launch_bounds__(256) void fitk_kernel(GridView G, const float4* __r
   }
 }
 
+// the general pass settles EVERY query's order the reference's way (it does not track the (K+1)-th candidate, so it cannot tell
+// which queries hinge on a tie): one wave per query, first K of the candidates within the K-th distance in visiting order
+template <int K>
+__global__ __launch_bounds__(256) void tiek_kernel(GridView G, BookView B, const float4* __restrict__ scan_sorted, int n, PoseMats P,
+                                                   NbrRecK* __restrict__ nbr) {
+  __shared__ TieLds s_t[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int p = blockIdx.x * 4 + wave; p < n; p += gridDim.x * 4) {
+    if (nbr[p].flag != 1) continue;                            // wave-uniform
+    const float4 sp = scan_sorted[p];
+    float gx, gy, gz;
+    xform4(P.RT, sp.x, sp.y, sp.z, gx, gy, gz);
+    const float4 far = G.pts[nbr[p].idx[K - 1]];
+    const float dk = sqdist3(gx, gy, gz, far.x, far.y, far.z);
+    uint32_t pos[8];
+    float d[8];
+    const bool ok = tie_select_wave(G, B, gx, gy, gz, dk, K, s_t[wave], pos, d);
+    if (ok && lane == 0) {
+#pragma unroll
+      for (int s2 = 0; s2 < K; s2++) nbr[p].idx[s2] = (int32_t)pos[s2];
+    }
+    wave_lds_sync();
+  }
+}
+
 size_t nbrk_rec_size() { return sizeof(NbrRecK); }
 template <int K>
 static void launch_match_k_K(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const PoseMats& P,
-                             const MatchParams& mp, void* nbrk, Rec16* recs, RecDbg* dbg) {
+                             const MatchParams& mp, void* nbrk, Rec16* recs, RecDbg* dbg, const BookView* book) {
   const long long threads = (long long)n * 4;
   hipLaunchKernelGGL((knnk_kernel<K>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, G, scan_sorted, n, P, mp.max_ring, (NbrRecK*)nbrk);
+  if (book) hipLaunchKernelGGL((tiek_kernel<K>), dim3((unsigned)std::min(8192, (n + 3) / 4)), dim3(256), 0, st, G, *book, scan_sorted, n, P, (NbrRecK*)nbrk);
   hipLaunchKernelGGL((fitk_kernel<K>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, G, scan_sorted, n, (const NbrRecK*)nbrk, P, mp, recs, dbg);
 }
 bool launch_match_k(hipStream_t st, int k, const GridView& G, const float4* scan_sorted, int n, const PoseMats& P,
-                    const MatchParams& mp, void* nbrk, Rec16* recs, RecDbg* dbg) {
+                    const MatchParams& mp, void* nbrk, Rec16* recs, RecDbg* dbg, const BookView* book) {
   if (n <= 0) return true;
   switch (k) {
-    case 3: launch_match_k_K<3>(st, G, scan_sorted, n, P, mp, nbrk, recs, dbg); return true;
-    case 4: launch_match_k_K<4>(st, G, scan_sorted, n, P, mp, nbrk, recs, dbg); return true;
-    case 5: launch_match_k_K<5>(st, G, scan_sorted, n, P, mp, nbrk, recs, dbg); return true;
-    case 6: launch_match_k_K<6>(st, G, scan_sorted, n, P, mp, nbrk, recs, dbg); return true;
-    case 7: launch_match_k_K<7>(st, G, scan_sorted, n, P, mp, nbrk, recs, dbg); return true;
-    case 8: launch_match_k_K<8>(st, G, scan_sorted, n, P, mp, nbrk, recs, dbg); return true;
+    case 3: launch_match_k_K<3>(st, G, scan_sorted, n, P, mp, nbrk, recs, dbg, book); return true;
+    case 4: launch_match_k_K<4>(st, G, scan_sorted, n, P, mp, nbrk, recs, dbg, book); return true;
+    case 5: launch_match_k_K<5>(st, G, scan_sorted, n, P, mp, nbrk, recs, dbg, book); return true;
+    case 6: launch_match_k_K<6>(st, G, scan_sorted, n, P, mp, nbrk, recs, dbg, book); return true;
+    case 7: launch_match_k_K<7>(st, G, scan_sorted, n, P, mp, nbrk, recs, dbg, book); return true;
+    case 8: launch_match_k_K<8>(st, G, scan_sorted, n, P, mp, nbrk, recs, dbg, book); return true;
     default: return false;
   }
 }
@@ -2277,7 +2310,7 @@ void launch_widen(hipStream_t st, const GridView& G, const float4* scan_sorted, 
       hipExtLaunchKernelGGL((widen_kernel<1>), dim3(widen_blocks()), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand, first_ring, tl);
   }
   else
-    hipLaunchKernelGGL(widen_general_kernel, dim3(256), dim3(256), 0, st, G, scan_sorted, P, max_ring, (NbrRec*)nbr, wl, wl_count);
+    hipLaunchKernelGGL(widen_general_kernel, dim3(256), dim3(256), 0, st, G, scan_sorted, P, max_ring, (NbrRec*)nbr, wl, wl_count, tl);
 }
 
 static int fit_threads() {

@@ -212,6 +212,13 @@ int flimo_loc_register_resident(flimo_loc* L, const double x26_prior[26], const 
   return L->loc->registerResident(x26_prior, P_prior);
 }
 
+void flimo_host_eigen_solver6(const double A[36], double wr[6], double wi[6], double V[36]) {
+  flimo_host::Mat<6, 6> a, v;
+  std::memcpy(&a.a[0][0], A, sizeof(double) * 36);
+  flimo_host::eigen_solver6(a, wr, wi, v);
+  std::memcpy(V, &v.a[0][0], sizeof(double) * 36);
+}
+
 int flimo_eskf_update_fixed(double x26[26], double P[529], const double* H, const double* h, int M, int max_iters,
                             const double limits[23], double R, double D, int* n_passes) {
   flimo_host::Esekf f;

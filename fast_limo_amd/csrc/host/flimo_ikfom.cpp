@@ -1,6 +1,7 @@
 // fast_limo_amd/csrc/host/flimo_ikfom.cpp -- see flimo_ikfom.hpp.
 #include "flimo_ikfom.hpp"
 #include <algorithm>
+#include <limits>
 
 namespace flimo_host {
 
@@ -63,28 +64,296 @@ bool inverse_lu(int n, const double* A, double* Ainv) {
   return true;
 }
 
-void sym_eig6(const Mat<6, 6>& S, double w[6], Mat<6, 6>& V) {
-  Mat<6, 6> A;
-  for (int i = 0; i < 6; i++)
-    for (int j = 0; j < 6; j++) A(i, j) = 0.5 * (S(i, j) + S(j, i));
-  V = Mat<6, 6>::identity();
-  for (int sweep = 0; sweep < 64; sweep++) {
-    double off = 0.0;
-    for (int i = 0; i < 6; i++)
-      for (int j = i + 1; j < 6; j++) off += A(i, j) * A(i, j);
-    if (off < 1e-300) break;
-    for (int p = 0; p < 6; p++)
-      for (int q = p + 1; q < 6; q++) {
-        if (A(p, q) == 0.0) continue;
-        const double theta = (A(q, q) - A(p, p)) / (2.0 * A(p, q));
-        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
-        const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
-        for (int k = 0; k < 6; k++) { const double kp = A(k, p), kq = A(k, q); A(k, p) = c * kp - s * kq; A(k, q) = s * kp + c * kq; }
-        for (int k = 0; k < 6; k++) { const double pk = A(p, k), qk = A(q, k); A(p, k) = c * pk - s * qk; A(q, k) = s * pk + c * qk; }
-        for (int k = 0; k < 6; k++) { const double kp = V(k, p), kq = V(k, q); V(k, p) = c * kp - s * kq; V(k, q) = s * kp + c * kq; }
-      }
+// ---------------------------------------------------------------------------------------------
+// Eigen::EigenSolver<Matrix<double,6,6>> as the reference calls it at esekfom.hpp:1736-1738.  Which ROW of the eigenvector matrix
+// the degeneracy projector zeroes is decided by the order (and the product it forms by the signs) in which Eigen hands out the
+// eigenpairs, so the solver's algorithm is followed step by step (Eigen 3.3.7: Householder/Householder.h, Jacobi/Jacobi.h,
+// Eigenvalues/HessenbergDecomposition.h, RealSchur.h, EigenSolver.h): scaling, Householder reduction to Hessenberg form with Q
+// accumulated from the last reflector, Francis double-shift QR with Eigen's deflation test and exceptional shifts, eigenvalues read
+// off the diagonal of T from the top, eigenvectors by back substitution and multiplication with Q, normalised columns, `.real()`.
+// Sums inside a step run left to right (Eigen's vectorised reductions may round the last bit differently).
+// ---------------------------------------------------------------------------------------------
+namespace {
+typedef Mat<6, 6> M6;
+struct Reflector { double tau, beta; };
+// x(0) <- beta, x(1..) <- essential part; stride: distance between consecutive coefficients
+Reflector reflector(double* x, int len, int stride) {
+  double tail = 0.0;
+  for (int i = 1; i < len; i++) tail += x[i * stride] * x[i * stride];
+  const double c0 = x[0];
+  if (tail <= std::numeric_limits<double>::min()) {
+    for (int i = 1; i < len; i++) x[i * stride] = 0.0;
+    return Reflector{0.0, c0};
   }
-  for (int i = 0; i < 6; i++) w[i] = A(i, i);
+  double beta = std::sqrt(c0 * c0 + tail);
+  if (c0 >= 0.0) beta = -beta;
+  for (int i = 1; i < len; i++) x[i * stride] = x[i * stride] / (c0 - beta);
+  return Reflector{(beta - c0) / beta, beta};
+}
+void reflect_left(M6& A, int r0, int c0, int nr, int nc, const double* ess, double tau) {
+  if (nr == 1) { for (int j = 0; j < nc; j++) A(r0, c0 + j) *= (1.0 - tau); return; }
+  if (tau == 0.0) return;
+  for (int j = 0; j < nc; j++) {
+    double t = 0.0;
+    for (int i = 1; i < nr; i++) t += ess[i - 1] * A(r0 + i, c0 + j);
+    t += A(r0, c0 + j);
+    A(r0, c0 + j) -= tau * t;
+    for (int i = 1; i < nr; i++) A(r0 + i, c0 + j) -= tau * ess[i - 1] * t;
+  }
+}
+void reflect_right(M6& A, int r0, int c0, int nr, int nc, const double* ess, double tau) {
+  if (nc == 1) { for (int i = 0; i < nr; i++) A(r0 + i, c0) *= (1.0 - tau); return; }
+  if (tau == 0.0) return;
+  for (int i = 0; i < nr; i++) {
+    double t = 0.0;
+    for (int j = 1; j < nc; j++) t += A(r0 + i, c0 + j) * ess[j - 1];
+    t += A(r0 + i, c0);
+    A(r0 + i, c0) -= tau * t;
+    for (int j = 1; j < nc; j++) A(r0 + i, c0 + j) -= tau * t * ess[j - 1];
+  }
+}
+// JacobiRotation::makeGivens, then the rotation J^T applied as the two-row / two-column update Eigen performs
+void givens(double p, double q, double& c, double& s) {
+  if (q == 0.0) { c = p < 0 ? -1.0 : 1.0; s = 0.0; return; }
+  if (p == 0.0) { c = 0.0; s = q < 0 ? 1.0 : -1.0; return; }
+  if (std::fabs(p) > std::fabs(q)) {
+    const double t = q / p;
+    double u = std::sqrt(1.0 + t * t);
+    if (p < 0) u = -u;
+    c = 1.0 / u; s = -t * c;
+  } else {
+    const double t = p / q;
+    double u = std::sqrt(1.0 + t * t);
+    if (q < 0) u = -u;
+    s = -1.0 / u; c = -t * s;
+  }
+}
+inline void plane_rot(double& x, double& y, double c, double s) { const double a = x, b = y; x = c * a - s * b; y = s * a + c * b; }
+}  // namespace
+
+void eigen_solver6(const Mat<6, 6>& A, double wr[6], double wi[6], Mat<6, 6>& V) {
+  const int N = 6;
+  const double eps = std::numeric_limits<double>::epsilon(), dmin = std::numeric_limits<double>::min();
+  M6 T = M6::zero(), U = M6::identity();
+  double scale = 0.0;
+  for (int i = 0; i < N; i++) for (int j = 0; j < N; j++) scale = std::max(scale, std::fabs(A(i, j)));
+  if (!(scale < dmin)) {
+    M6 H;
+    for (int i = 0; i < N; i++) for (int j = 0; j < N; j++) H(i, j) = A(i, j) / scale;
+    double tau[5];
+    for (int i = 0; i + 1 < N; i++) {                                // Hessenberg: A <- H_i A H_i'
+      const int rem = N - i - 1;
+      const Reflector h = reflector(&H(i + 1, i), rem, N);
+      H(i + 1, i) = h.beta;
+      tau[i] = h.tau;
+      double ess[6];
+      for (int k = 0; k + 1 < rem; k++) ess[k] = H(i + 2 + k, i);
+      reflect_left(H, i + 1, i + 1, rem, rem, ess, h.tau);
+      reflect_right(H, 0, i + 1, N, rem, ess, h.tau);
+    }
+    for (int k = N - 2; k >= 0; k--) {                               // Q = H_0 ... H_4 from the identity, last factor first
+      const int cs = N - k - 1;
+      double ess[6];
+      for (int t = 0; t + 1 < cs; t++) ess[t] = H(k + 2 + t, k);
+      reflect_left(U, N - cs, N - cs, cs, cs, ess, tau[k]);
+    }
+    for (int i = 0; i < N; i++) for (int j = 0; j < N; j++) T(i, j) = (i <= j + 1) ? H(i, j) : 0.0;
+    double norm = 0.0;
+    for (int j = 0; j < N; j++) for (int i = 0; i < std::min(N, j + 2); i++) norm += std::fabs(T(i, j));
+    const double as_zero = std::max(norm * eps * eps, dmin);
+    int iu = N - 1, iter = 0, total = 0;
+    double exshift = 0.0;
+    while (norm != 0.0 && iu >= 0) {
+      int il = iu;
+      for (; il > 0; il--) {
+        const double s = std::max((std::fabs(T(il - 1, il - 1)) + std::fabs(T(il, il))) * eps, as_zero);
+        if (std::fabs(T(il, il - 1)) <= s) break;
+      }
+      if (il == iu) {                                                // one root
+        T(iu, iu) = T(iu, iu) + exshift;
+        if (iu > 0) T(iu, iu - 1) = 0.0;
+        iu--; iter = 0;
+        continue;
+      }
+      if (il == iu - 1) {                                            // two roots
+        const double p = 0.5 * (T(iu - 1, iu - 1) - T(iu, iu));
+        const double q = p * p + T(iu, iu - 1) * T(iu - 1, iu);
+        T(iu, iu) += exshift;
+        T(iu - 1, iu - 1) += exshift;
+        if (q >= 0.0) {
+          const double z = std::sqrt(std::fabs(q));
+          double c, s;
+          givens(p >= 0.0 ? p + z : p - z, T(iu, iu - 1), c, s);
+          for (int j = iu - 1; j < N; j++) plane_rot(T(iu - 1, j), T(iu, j), c, s);
+          for (int i = 0; i <= iu; i++) plane_rot(T(i, iu - 1), T(i, iu), c, s);
+          T(iu, iu - 1) = 0.0;
+          for (int i = 0; i < N; i++) plane_rot(U(i, iu - 1), U(i, iu), c, s);
+        }
+        if (iu > 1) T(iu - 1, iu - 2) = 0.0;
+        iu -= 2; iter = 0;
+        continue;
+      }
+      double sh0 = T(iu, iu), sh1 = T(iu - 1, iu - 1), sh2 = T(iu, iu - 1) * T(iu - 1, iu);
+      if (iter == 10) {                                              // Wilkinson's ad hoc shift
+        exshift += sh0;
+        for (int i = 0; i <= iu; i++) T(i, i) -= sh0;
+        const double s = std::fabs(T(iu, iu - 1)) + std::fabs(T(iu - 1, iu - 2));
+        sh0 = 0.75 * s; sh1 = 0.75 * s; sh2 = -0.4375 * s * s;
+      }
+      if (iter == 30) {                                              // MATLAB's ad hoc shift
+        double s = (sh1 - sh0) / 2.0;
+        s = s * s + sh2;
+        if (s > 0.0) {
+          s = std::sqrt(s);
+          if (sh1 < sh0) s = -s;
+          s = s + (sh1 - sh0) / 2.0;
+          s = sh0 - sh2 / s;
+          exshift += s;
+          for (int i = 0; i <= iu; i++) T(i, i) -= s;
+          sh0 = sh1 = sh2 = 0.964;
+        }
+      }
+      iter++;
+      if (++total > 40 * N) break;
+      int im = iu - 2;
+      double v[3] = {0, 0, 0};
+      for (; im >= il; --im) {
+        const double Tmm = T(im, im), r = sh0 - Tmm, s = sh1 - Tmm;
+        v[0] = (r * s - sh2) / T(im + 1, im) + T(im, im + 1);
+        v[1] = T(im + 1, im + 1) - Tmm - r - s;
+        v[2] = T(im + 2, im + 1);
+        if (im == il) break;
+        const double lhs = T(im, im - 1) * (std::fabs(v[1]) + std::fabs(v[2]));
+        const double rhs = v[0] * (std::fabs(T(im - 1, im - 1)) + std::fabs(Tmm) + std::fabs(T(im + 1, im + 1)));
+        if (std::fabs(lhs) < eps * rhs) break;
+      }
+      for (int k = im; k <= iu - 2; ++k) {
+        double w[3];
+        if (k == im) { w[0] = v[0]; w[1] = v[1]; w[2] = v[2]; }
+        else { w[0] = T(k, k - 1); w[1] = T(k + 1, k - 1); w[2] = T(k + 2, k - 1); }
+        const Reflector h = reflector(w, 3, 1);
+        if (h.beta == 0.0) continue;
+        if (k == im && k > il) T(k, k - 1) = -T(k, k - 1);
+        else if (k != im) T(k, k - 1) = h.beta;
+        reflect_left(T, k, k, 3, N - k, &w[1], h.tau);
+        reflect_right(T, 0, k, std::min(iu, k + 3) + 1, 3, &w[1], h.tau);
+        reflect_right(U, 0, k, N, 3, &w[1], h.tau);
+      }
+      {
+        double w[2] = {T(iu - 1, iu - 2), T(iu, iu - 2)};
+        const Reflector h = reflector(w, 2, 1);
+        if (h.beta != 0.0) {
+          T(iu - 1, iu - 2) = h.beta;
+          reflect_left(T, iu - 1, iu - 1, 2, N - iu + 1, &w[1], h.tau);
+          reflect_right(T, 0, iu - 1, iu + 1, 2, &w[1], h.tau);
+          reflect_right(U, 0, iu - 1, N, 2, &w[1], h.tau);
+        }
+      }
+      for (int i = im + 2; i <= iu; ++i) { T(i, i - 2) = 0.0; if (i > im + 2) T(i, i - 3) = 0.0; }
+    }
+    for (int i = 0; i < N; i++) for (int j = 0; j < N; j++) T(i, j) *= scale;
+  }
+  for (int i = 0; i < N;) {                                          // eigenvalues, top to bottom
+    if (i == N - 1 || T(i + 1, i) == 0.0) { wr[i] = T(i, i); wi[i] = 0.0; i++; continue; }
+    const double p = 0.5 * (T(i, i) - T(i + 1, i + 1));
+    double t0 = T(i + 1, i), t1 = T(i, i + 1);
+    const double mx = std::max(std::fabs(p), std::max(std::fabs(t0), std::fabs(t1)));
+    t0 /= mx; t1 /= mx;
+    const double p0 = p / mx, z = mx * std::sqrt(std::fabs(p0 * p0 + t0 * t1));
+    wr[i] = wr[i + 1] = T(i + 1, i + 1) + p;
+    wi[i] = z; wi[i + 1] = -z;
+    i += 2;
+  }
+  double nrm = 0.0;
+  for (int j = 0; j < N; j++) for (int k = std::max(j - 1, 0); k < N; k++) nrm += std::fabs(T(j, k));
+  if (nrm != 0.0) {
+    for (int n = N - 1; n >= 0; n--) {
+      const double p = wr[n], q = wi[n];
+      if (q == 0.0) {
+        double lastr = 0.0, lastw = 0.0;
+        int l = n;
+        T(n, n) = 1.0;
+        for (int i = n - 1; i >= 0; i--) {
+          const double w = T(i, i) - p;
+          double r = 0.0;
+          for (int k = l; k <= n; k++) r += T(i, k) * T(k, n);
+          if (wi[i] < 0.0) { lastw = w; lastr = r; continue; }
+          l = i;
+          if (wi[i] == 0.0) T(i, n) = (w != 0.0) ? -r / w : -r / (eps * nrm);
+          else {
+            const double x = T(i, i + 1), y = T(i + 1, i);
+            const double den = (wr[i] - p) * (wr[i] - p) + wi[i] * wi[i];
+            const double t = (x * lastr - lastw * r) / den;
+            T(i, n) = t;
+            T(i + 1, n) = (std::fabs(x) > std::fabs(lastw)) ? (-r - w * t) / x : (-lastr - y * t) / lastw;
+          }
+          const double t = std::fabs(T(i, n));
+          if ((eps * t) * t > 1.0) for (int k = i; k < N; k++) T(k, n) /= t;
+        }
+      } else if (q < 0.0 && n > 0) {
+        // a conjugate pair (only rounding produces one from a symmetric matrix): complex back substitution
+        auto cdiv = [](double ar, double ai, double br, double bi, double& cr, double& ci) {
+          const double d = br * br + bi * bi;
+          cr = (ar * br + ai * bi) / d; ci = (ai * br - ar * bi) / d;
+        };
+        double lastra = 0.0, lastsa = 0.0, lastw = 0.0;
+        int l = n - 1;
+        if (std::fabs(T(n, n - 1)) > std::fabs(T(n - 1, n))) {
+          T(n - 1, n - 1) = q / T(n, n - 1);
+          T(n - 1, n) = -(T(n, n) - p) / T(n, n - 1);
+        } else {
+          double cr, ci;
+          cdiv(0.0, -T(n - 1, n), T(n - 1, n - 1) - p, q, cr, ci);
+          T(n - 1, n - 1) = cr; T(n - 1, n) = ci;
+        }
+        T(n, n - 1) = 0.0;
+        T(n, n) = 1.0;
+        for (int i = n - 2; i >= 0; i--) {
+          double ra = 0.0, sa = 0.0;
+          for (int k = l; k <= n; k++) { ra += T(i, k) * T(k, n - 1); sa += T(i, k) * T(k, n); }
+          const double w = T(i, i) - p;
+          if (wi[i] < 0.0) { lastw = w; lastra = ra; lastsa = sa; continue; }
+          l = i;
+          if (wi[i] == 0.0) {
+            double cr, ci;
+            cdiv(-ra, -sa, w, q, cr, ci);
+            T(i, n - 1) = cr; T(i, n) = ci;
+          } else {
+            const double x = T(i, i + 1), y = T(i + 1, i);
+            double vr = (wr[i] - p) * (wr[i] - p) + wi[i] * wi[i] - q * q;
+            const double vi = (wr[i] - p) * 2.0 * q;
+            if (vr == 0.0 && vi == 0.0) vr = eps * nrm * (std::fabs(w) + std::fabs(q) + std::fabs(x) + std::fabs(y) + std::fabs(lastw));
+            double cr, ci;
+            cdiv(x * lastra - lastw * ra + q * sa, x * lastsa - lastw * sa - q * ra, vr, vi, cr, ci);
+            T(i, n - 1) = cr; T(i, n) = ci;
+            if (std::fabs(x) > (std::fabs(lastw) + std::fabs(q))) {
+              T(i + 1, n - 1) = (-ra - w * T(i, n - 1) + q * T(i, n)) / x;
+              T(i + 1, n) = (-sa - w * T(i, n) - q * T(i, n - 1)) / x;
+            } else {
+              cdiv(-lastra - y * T(i, n - 1), -lastsa - y * T(i, n), lastw, q, cr, ci);
+              T(i + 1, n - 1) = cr; T(i + 1, n) = ci;
+            }
+          }
+          const double t = std::max(std::fabs(T(i, n - 1)), std::fabs(T(i, n)));
+          if ((eps * t) * t > 1.0) for (int k = i; k < N; k++) { T(k, n - 1) /= t; T(k, n) /= t; }
+        }
+        n--;
+      }
+    }
+    for (int j = N - 1; j >= 0; j--) {
+      double col[6];
+      for (int i = 0; i < N; i++) { double s = 0.0; for (int k = 0; k <= j; k++) s += U(i, k) * T(k, j); col[i] = s; }
+      for (int i = 0; i < N; i++) U(i, j) = col[i];
+    }
+  }
+  for (int j = 0; j < N; j++) {                                      // eigenvectors(): normalised; real part of a conjugate pair
+    const bool is_real = (std::fabs(wi[j]) <= std::fabs(wr[j]) * 2.0 * eps) || j + 1 == N;
+    double n2 = 0.0;
+    for (int i = 0; i < N; i++) n2 += U(i, j) * U(i, j) + (is_real ? 0.0 : U(i, j + 1) * U(i, j + 1));
+    const double nn = std::sqrt(n2);
+    for (int i = 0; i < N; i++) V(i, j) = n2 > 0.0 ? U(i, j) / nn : U(i, j);
+    if (!is_real) { for (int i = 0; i < N; i++) V(i, j + 1) = V(i, j); j++; }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -563,10 +832,10 @@ void Esekf::update_iterated_dyn_share_modified(double R, double D) {
     if (!well_conditioned) {
       Mat<6, 6> S6, V, Vinv, sel;
       for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) S6(i, j) = HTH(i, j);
-      double w[6];
-      sym_eig6(S6, w, V);
-      double prod = 1.0;
-      for (int i = 0; i < 6; i++) prod *= w[i];
+      double w[6], wim[6];
+      eigen_solver6(S6, w, wim, V);                              // eigenvalues().real(), eigenvectors().real() in Eigen's order
+      double prod = w[0];
+      for (int i = 1; i < 6; i++) prod *= w[i];
       if (prod < 1e-20) V = Mat<6, 6>::identity();
       sel = V;
       for (int v = 0; v < 6; v++) if (w[v] < D) for (int j = 0; j < 6; j++) sel(v, j) *= 0;

@@ -13,7 +13,8 @@
 // H^T H (12x12), H^T h (12) and M, which is all the M >= 23 branch uses (esekfom.hpp:1722-1729);
 // the dense H is requested through a second callback only when M < 23 (:1701-1709).
 // The reference's observable quirks are kept: `scalar(1/2)` == 0 in predict and S2_Mx, HTH := 0
-// when M < 23, row-zeroing degeneracy projector, convergence tested on the un-projected step.
+// when M < 23, row-zeroing degeneracy projector over Eigen::EigenSolver's eigenpair order (restated), convergence tested on the
+// un-projected step.
 // The 23x23 algebra is ~25 kflop per pass: it stays on the host (a GPU launch costs more).
 #pragma once
 #include <cmath>
@@ -59,8 +60,9 @@ typedef Mat<3, 3> Mat3;
 bool inverse_lu(int n, const double* A, double* Ainv);
 template <int N>
 inline bool inverse(const Mat<N, N>& A, Mat<N, N>& out) { return inverse_lu(N, &A.a[0][0], &out.a[0][0]); }
-// eigen-decomposition of a symmetric 6x6 (cyclic Jacobi): w eigenvalues, V eigenvectors as columns
-void sym_eig6(const Mat<6, 6>& S, double w[6], Mat<6, 6>& V);
+// Eigen::EigenSolver<Matrix<double,6,6>> as esekfom.hpp:1736-1738 uses it: eigenvalues (real, imaginary part) in the solver's order
+// -- the diagonal of the real Schur form from the top -- and the real parts of its normalised eigenvectors as columns of V
+void eigen_solver6(const Mat<6, 6>& A, double wr[6], double wi[6], Mat<6, 6>& V);
 
 // ---------------------------------------------------------------------------------------------
 // manifold pieces

@@ -104,6 +104,10 @@ int    flimo_eskf_update_fixed(double x26[26], double P[529], const double* H, c
                                const double limits[23], double R, double D, int* n_passes);
 int    flimo_eskf_predict(double x26[26], double P[529], double dt, const double Qdiag[12], const double acc[3],
                           const double gyro[3]);
+/* The filter's restatement of Eigen::EigenSolver<Matrix<double,6,6>> (IKFoM_toolkit/esekfom/esekfom.hpp:1736-1738, degeneracy
+ * handling): A row-major; eigenvalues in the solver's order (real, imaginary part), real parts of the normalised eigenvectors as
+ * the columns of V (row-major) -- for unit tests */
+void   flimo_host_eigen_solver6(const double A[36], double wr[6], double wi[6], double V[36]);
 
 #ifdef __cplusplus
 }

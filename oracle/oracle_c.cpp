@@ -297,6 +297,13 @@ void oracle_eskf_update_fixed(double x26[26], double P[529], const double* H, co
   std::memcpy(P, f.P_, sizeof(double) * 529);
   if (n_passes) *n_passes = (int)f.log.size();
 }
+// Eigen::EigenSolver<Matrix<double,6,6>> restated (rl_linalg.h): eigenvalues in the solver's order, real parts of the normalised
+// eigenvectors as columns (row-major V)
+void oracle_eigen_solver6(const double A[36], double wr[6], double wi[6], double V[36]) {
+  double Vm[6][6];
+  eigen_solver6(A, wr, wi, Vm);
+  for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) V[i * 6 + j] = Vm[i][j];
+}
 void oracle_eskf_predict(double x26[26], double P[529], double dt, const double Qd[12], const double acc[3], const double gyro[3]) {
   Esekf f;
   f.x_.from_flat(x26);

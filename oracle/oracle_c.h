@@ -118,6 +118,7 @@ int    oracle_loc_update_only(void* L, const float* xyz, size_t n);
  * measurement (H [M][12], h [M]) -- used to cross-check the manifold algebra against numpy. ---- */
 void oracle_eskf_update_fixed(double x26[26], double P[23 * 23], const double* H, const double* h, int M,
                               int max_iters, const double limits[23], double R, double D, int* n_passes);
+void oracle_eigen_solver6(const double A[36], double wr[6], double wi[6], double V[36]);
 void oracle_eskf_predict(double x26[26], double P[23 * 23], double dt, const double Qdiag[12], const double acc[3],
                          const double gyro[3]);
 

@@ -219,6 +219,17 @@ class Octree:
         return nbr, sqd, cnt, int(evals)
 
 
+def eigen_solver6(A):
+    """Eigen::EigenSolver<Matrix6d> restated: (eigenvalues real, imag, real parts of the normalised eigenvectors as columns)."""
+    A = np.ascontiguousarray(A, dtype=np.float64).reshape(36)
+    wr = np.zeros(6); wi = np.zeros(6); V = np.zeros(36)
+    L = lib()
+    L.oracle_eigen_solver6.argtypes = [f64p, f64p, f64p, f64p]
+    L.oracle_eigen_solver6.restype = None
+    L.oracle_eigen_solver6(A, wr, wi, V)
+    return wr, wi, V.reshape(6, 6)
+
+
 def voxel_grid(xyz, leaf):
     xyz = _f32(xyz).reshape(-1, 3)
     out = np.empty((max(xyz.shape[0], 1), 3), np.float32)

@@ -540,12 +540,14 @@ struct Esekf {
         dx_[i] = K_h[i] + s;
       }
 
-      // degeneracy :1736-1744
-      double S6[36], w[6], V[6][6];
+      // degeneracy :1736-1744: Eigen::EigenSolver of HTH[0:6,0:6] (restated in rl_linalg.h: the eigenpairs come in the order and
+      // with the signs of Eigen's Hessenberg + Francis QR + back substitution), `.real()` of values and vectors, the row-zeroing
+      // "projector" VEPs^-1 * selVEPs applied as Eigen evaluates the product: (VEPs^-1 * selVEPs) * dx_.head(6)
+      double S6[36], w[6], wim[6], V[6][6];
       for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) S6[i * 6 + j] = HTH[i][j];
-      jacobi_eig6(S6, w, V);
-      double prod = 1.0;
-      for (int i = 0; i < 6; i++) prod *= w[i];
+      eigen_solver6(S6, w, wim, V);
+      double prod = w[0];
+      for (int i = 1; i < 6; i++) prod *= w[i];
       if (prod < 1e-20) for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) V[i][j] = (i == j) ? 1.0 : 0.0;
       double sel[6][6];
       for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) sel[i][j] = V[i][j];
@@ -556,9 +558,9 @@ struct Esekf {
       double dx_nd[NDOF];
       for (int i = 0; i < n; i++) dx_nd[i] = dx_[i];
       {
-        double tmp[6];
-        for (int i = 0; i < 6; i++) { double s = 0; for (int k = 0; k < 6; k++) s += sel[i][k] * dx_[k]; tmp[i] = s; }
-        for (int i = 0; i < 6; i++) { double s = 0; for (int k = 0; k < 6; k++) s += Vinv[i * 6 + k] * tmp[k]; dx_nd[i] = s; }
+        double Pm[6][6];
+        for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) { double s = 0; for (int k = 0; k < 6; k++) s += Vinv[i * 6 + k] * sel[k][j]; Pm[i][j] = s; }
+        for (int i = 0; i < 6; i++) { double s = 0; for (int k = 0; k < 6; k++) s += Pm[i][k] * dx_[k]; dx_nd[i] = s; }
       }
 
       x_.boxplus(dx_nd);                                        // :1747

@@ -15,8 +15,8 @@
 //   * partial-pivot LU inverse in double
 //       (Eigen::Matrix<double,23,23>::inverse(); call sites
 //        include/IKFoM/IKFoM_toolkit/esekfom/esekfom.hpp:1706,1722,1726,1744)
-//   * symmetric 6x6 eigen-decomposition (stands in for Eigen::EigenSolver,
-//        esekfom.hpp:1736 -- see the note at jacobi_eig6)
+//   * Eigen::EigenSolver<Matrix<double,6,6>> (esekfom.hpp:1736): Householder Hessenberg reduction, Francis double-shift QR,
+//        eigenvectors by back substitution -- eigen_solver6 below
 //
 // PARITY UNPINNED: Eigen's expression templates fix an evaluation order that can
 // only be confirmed by compiling against Eigen.  Where the order is known from the
@@ -26,6 +26,8 @@
 // -ffp-contract=off (the reference is built without FMA: CMakeLists.txt:4-5,17-21).
 #pragma once
 #include <cmath>
+#include <limits>
+#include <algorithm>
 #include <cstring>
 #include <cstdint>
 #include <algorithm>
@@ -396,50 +398,355 @@ inline bool lu_inverse(int n, const double* A, double* Ainv) {
   return true;
 }
 
-// Cyclic Jacobi eigen-decomposition of a symmetric 6x6 (row-major).  Stands in for
-// Eigen::EigenSolver<Matrix<double,6,6>> at esekfom.hpp:1736.  HTH[0:6,0:6] is symmetric
-// PSD so its eigenpairs are real; Eigen's solver returns them in an order fixed by its
-// Hessenberg/QR iteration which is not reproduced here.  The order only matters when an
-// eigenvalue falls below the degeneracy threshold D (SURVEY.md section 8 a-note 6):
-// in the non-degenerate case VEPs^-1 * VEPs == I for any ordering.
-// Output: w[6] eigenvalues, V[6][6] eigenvectors as COLUMNS (V[r][c]).
-inline void jacobi_eig6(const double* S, double w[6], double V[6][6]) {
-  const int n = 6;
-  double a[6][6];
-  for (int i = 0; i < n; i++)
-    for (int j = 0; j < n; j++) {
-      a[i][j] = 0.5 * (S[i * n + j] + S[j * n + i]);
-      V[i][j] = (i == j) ? 1.0 : 0.0;
+// ---------------------------------------------------------------------------------------------------------------
+// Eigen::EigenSolver<Matrix<double,6,6>> restated (esekfom.hpp:1736-1738: `.eigenvalues().real()`, `.eigenvectors().real()`).
+//
+// Third-party arithmetic absent from /root/reference: Eigen3, version unpinned by the reference (find_package(Eigen3),
+// CMakeLists.txt:14); the reference's Docker base (osrf/ros:noetic) ships Eigen 3.3.7.  The degeneracy projector zeroes ROW i of
+// the eigenvector matrix when eigenVALUE i is below the threshold (esekfom.hpp:1741), so what reaches the state is decided by
+// the ORDER in which the solver returns the eigenpairs and by the SIGN of every eigenvector -- both are properties of the
+// algorithm, restated here from Eigen's published sources (Eigenvalues/HessenbergDecomposition.h, RealSchur.h, EigenSolver.h,
+// Householder/Householder.h, Jacobi/Jacobi.h of 3.3.7), step for step:
+//   1. scale by the largest |coefficient|, Householder reduction to Hessenberg form (makeHouseholder: beta = -sign(c0) |x|,
+//      essential = tail / (c0 - beta), tau = (beta - c0) / beta), Q accumulated backwards from the identity;
+//   2. Francis double-shift QR on the Hessenberg matrix (RealSchur::computeFromHessenberg): deflation test
+//      |T(i,i-1)| <= max(eps (|T(i-1,i-1)| + |T(i,i)|), considerAsZero), one root / two roots (splitOffTwoRows with a Jacobi
+//      rotation) / Francis step with the shift of the trailing 2x2 block and the exceptional shifts at iterations 10 and 30;
+//      eigenvalues are read off the diagonal of T from top to bottom -- THIS fixes their order;
+//   3. eigenvectors by back substitution on T (EigenSolver::doComputeEigenvectors), multiplied by Q, each column normalised.
+// Floating-point sums inside a step (Eigen vectorises dot products and norms; the order depends on alignment and packet size) are
+// taken left to right here, so the last bits may differ from a given Eigen build; order and signs do not depend on them.
+// Row-major 6x6 in, wr / wi eigenvalues, V = real parts of the normalised eigenvectors as COLUMNS (V[r][c]).
+// ---------------------------------------------------------------------------------------------------------------
+namespace eig6 {
+constexpr int N = 6;
+struct Hh { double tau, beta; };
+// Householder of x[0..m): x[0] becomes beta, x[1..m) the essential part (MatrixBase::makeHouseholderInPlace)
+inline Hh make_householder(double* x, int m, int stride) {
+  double tail2 = 0.0;
+  for (int i = 1; i < m; i++) tail2 += x[i * stride] * x[i * stride];
+  const double c0 = x[0];
+  Hh h;
+  if (tail2 <= std::numeric_limits<double>::min()) {
+    h.tau = 0.0; h.beta = c0;
+    for (int i = 1; i < m; i++) x[i * stride] = 0.0;
+  } else {
+    double beta = std::sqrt(c0 * c0 + tail2);
+    if (c0 >= 0.0) beta = -beta;
+    for (int i = 1; i < m; i++) x[i * stride] = x[i * stride] / (c0 - beta);
+    h.tau = (beta - c0) / beta;
+    h.beta = beta;
+  }
+  return h;
+}
+// M(r0.., c0..) of `rows` x `cols` <- (I - tau v v^T) M, v = [1; ess]      (applyHouseholderOnTheLeft)
+inline void apply_left(double M[N][N], int r0, int c0, int rows, int cols, const double* ess, double tau) {
+  if (rows == 1) { for (int j = 0; j < cols; j++) M[r0][c0 + j] *= (1.0 - tau); return; }
+  if (tau == 0.0) return;
+  for (int j = 0; j < cols; j++) {
+    double tmp = 0.0;
+    for (int i = 1; i < rows; i++) tmp += ess[i - 1] * M[r0 + i][c0 + j];
+    tmp += M[r0][c0 + j];
+    M[r0][c0 + j] -= tau * tmp;
+    for (int i = 1; i < rows; i++) M[r0 + i][c0 + j] -= tau * ess[i - 1] * tmp;
+  }
+}
+// M(r0.., c0..) <- M (I - tau v v^T)                                         (applyHouseholderOnTheRight)
+inline void apply_right(double M[N][N], int r0, int c0, int rows, int cols, const double* ess, double tau) {
+  if (cols == 1) { for (int i = 0; i < rows; i++) M[r0 + i][c0] *= (1.0 - tau); return; }
+  if (tau == 0.0) return;
+  for (int i = 0; i < rows; i++) {
+    double tmp = 0.0;
+    for (int j = 1; j < cols; j++) tmp += M[r0 + i][c0 + j] * ess[j - 1];
+    tmp += M[r0 + i][c0];
+    M[r0 + i][c0] -= tau * tmp;
+    for (int j = 1; j < cols; j++) M[r0 + i][c0 + j] -= tau * tmp * ess[j - 1];
+  }
+}
+struct Givens { double c, s; };
+inline Givens make_givens(double p, double q) {                             // JacobiRotation::makeGivens (real)
+  Givens g;
+  if (q == 0.0) { g.c = p < 0 ? -1.0 : 1.0; g.s = 0.0; }
+  else if (p == 0.0) { g.c = 0.0; g.s = q < 0 ? 1.0 : -1.0; }
+  else if (std::fabs(p) > std::fabs(q)) {
+    const double t = q / p;
+    double u = std::sqrt(1.0 + t * t);
+    if (p < 0) u = -u;
+    g.c = 1.0 / u; g.s = -t * g.c;
+  } else {
+    const double t = p / q;
+    double u = std::sqrt(1.0 + t * t);
+    if (q < 0) u = -u;
+    g.s = -1.0 / u; g.c = -t * g.s;
+  }
+  return g;
+}
+// x_i <- c x_i + s y_i, y_i <- -s x_i + c y_i                                (apply_rotation_in_the_plane)
+inline void rot(double& x, double& y, double c, double s) { const double xi = x, yi = y; x = c * xi + s * yi; y = -s * xi + c * yi; }
+}  // namespace eig6
+
+inline void eigen_solver6(const double* A, double wr[6], double wi[6], double V[6][6]) {
+  using namespace eig6;
+  const double eps = std::numeric_limits<double>::epsilon();
+  double T[N][N], U[N][N];
+  // ---- RealSchur::compute ----
+  double scale = 0.0;
+  for (int i = 0; i < N * N; i++) scale = std::fabs(A[i]) > scale ? std::fabs(A[i]) : scale;
+  for (int i = 0; i < N; i++) for (int j = 0; j < N; j++) { T[i][j] = 0.0; U[i][j] = (i == j) ? 1.0 : 0.0; }
+  bool converged = true;
+  if (!(scale < std::numeric_limits<double>::min())) {
+    double M[N][N];
+    for (int i = 0; i < N; i++) for (int j = 0; j < N; j++) M[i][j] = A[i * N + j] / scale;
+    // HessenbergDecomposition::_compute
+    double hco[N - 1];
+    for (int i = 0; i < N - 1; i++) {
+      const int rem = N - i - 1;
+      const Hh h = make_householder(&M[i + 1][i], rem, N);
+      M[i + 1][i] = h.beta;
+      hco[i] = h.tau;
+      double ess[N];
+      for (int k = 0; k < rem - 1; k++) ess[k] = M[i + 2 + k][i];
+      apply_left(M, i + 1, i + 1, rem, rem, ess, h.tau);          // A = H A H'
+      apply_right(M, 0, i + 1, N, rem, ess, h.tau);
     }
-  for (int sweep = 0; sweep < 64; sweep++) {
-    double off = 0.0;
-    for (int i = 0; i < n; i++)
-      for (int j = i + 1; j < n; j++) off += a[i][j] * a[i][j];
-    if (off < 1e-300) break;
-    for (int p = 0; p < n; p++)
-      for (int q = p + 1; q < n; q++) {
-        if (a[p][q] == 0.0) continue;
-        double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
-        double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
-        double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
-        for (int k = 0; k < n; k++) {
-          double akp = a[k][p], akq = a[k][q];
-          a[k][p] = c * akp - s * akq;
-          a[k][q] = s * akp + c * akq;
+    // matrixQ = H_0 H_1 ... H_{n-2}, accumulated from the last factor (HouseholderSequence::evalTo)
+    for (int k = N - 2; k >= 0; k--) {
+      const int corner = N - k - 1;
+      double ess[N];
+      for (int t = 0; t < corner - 1; t++) ess[t] = M[k + 2 + t][k];
+      apply_left(U, N - corner, N - corner, corner, corner, ess, hco[k]);
+    }
+    for (int i = 0; i < N; i++) for (int j = 0; j < N; j++) T[i][j] = (i <= j + 1) ? M[i][j] : 0.0;     // matrixH
+    // ---- RealSchur::computeFromHessenberg ----
+    const int max_iters = 40 * N;
+    int iu = N - 1, iter = 0, total_iter = 0;
+    double exshift = 0.0;
+    double norm = 0.0;                                               // computeNormOfT
+    for (int j = 0; j < N; j++) for (int i = 0; i < (j + 2 < N ? j + 2 : N); i++) norm += std::fabs(T[i][j]);
+    const double tiny = std::max(norm * eps * eps, std::numeric_limits<double>::min());
+    if (norm != 0.0) {
+      while (iu >= 0) {
+        int il = iu;                                                 // findSmallSubdiagEntry
+        while (il > 0) {
+          double sdiag = std::fabs(T[il - 1][il - 1]) + std::fabs(T[il][il]);
+          sdiag = std::max(sdiag * eps, tiny);
+          if (std::fabs(T[il][il - 1]) <= sdiag) break;
+          il--;
         }
-        for (int k = 0; k < n; k++) {
-          double apk = a[p][k], aqk = a[q][k];
-          a[p][k] = c * apk - s * aqk;
-          a[q][k] = s * apk + c * aqk;
-        }
-        for (int k = 0; k < n; k++) {
-          double vkp = V[k][p], vkq = V[k][q];
-          V[k][p] = c * vkp - s * vkq;
-          V[k][q] = s * vkp + c * vkq;
+        if (il == iu) {                                              // one root found
+          T[iu][iu] = T[iu][iu] + exshift;
+          if (iu > 0) T[iu][iu - 1] = 0.0;
+          iu--; iter = 0;
+        } else if (il == iu - 1) {                                   // two roots found: splitOffTwoRows
+          const double p = 0.5 * (T[iu - 1][iu - 1] - T[iu][iu]);
+          const double q = p * p + T[iu][iu - 1] * T[iu - 1][iu];
+          T[iu][iu] += exshift;
+          T[iu - 1][iu - 1] += exshift;
+          if (q >= 0.0) {                                            // two real eigenvalues
+            const double z = std::sqrt(std::fabs(q));
+            const Givens g = (p >= 0.0) ? make_givens(p + z, T[iu][iu - 1]) : make_givens(p - z, T[iu][iu - 1]);
+            for (int j = iu - 1; j < N; j++) rot(T[iu - 1][j], T[iu][j], g.c, -g.s);      // applyOnTheLeft(rot.adjoint())
+            for (int i = 0; i <= iu; i++) rot(T[i][iu - 1], T[i][iu], g.c, -g.s);          // applyOnTheRight(rot)
+            T[iu][iu - 1] = 0.0;
+            for (int i = 0; i < N; i++) rot(U[i][iu - 1], U[i][iu], g.c, -g.s);
+          }
+          if (iu > 1) T[iu - 1][iu - 2] = 0.0;
+          iu -= 2; iter = 0;
+        } else {                                                     // no convergence yet: one Francis QR step
+          double sh[3];                                              // computeShift
+          sh[0] = T[iu][iu]; sh[1] = T[iu - 1][iu - 1]; sh[2] = T[iu][iu - 1] * T[iu - 1][iu];
+          if (iter == 10) {                                          // Wilkinson's original ad hoc shift
+            exshift += sh[0];
+            for (int i = 0; i <= iu; i++) T[i][i] -= sh[0];
+            const double s = std::fabs(T[iu][iu - 1]) + std::fabs(T[iu - 1][iu - 2]);
+            sh[0] = 0.75 * s; sh[1] = 0.75 * s; sh[2] = -0.4375 * s * s;
+          }
+          if (iter == 30) {                                          // MATLAB's new ad hoc shift
+            double s = (sh[1] - sh[0]) / 2.0;
+            s = s * s + sh[2];
+            if (s > 0.0) {
+              s = std::sqrt(s);
+              if (sh[1] < sh[0]) s = -s;
+              s = s + (sh[1] - sh[0]) / 2.0;
+              s = sh[0] - sh[2] / s;
+              exshift += s;
+              for (int i = 0; i <= iu; i++) T[i][i] -= s;
+              sh[0] = sh[1] = sh[2] = 0.964;
+            }
+          }
+          iter++; total_iter++;
+          if (total_iter > max_iters) { converged = false; break; }
+          int im;                                                    // initFrancisQRStep
+          double v[3] = {0, 0, 0};
+          for (im = iu - 2; im >= il; --im) {
+            const double Tmm = T[im][im];
+            const double r = sh[0] - Tmm, s = sh[1] - Tmm;
+            v[0] = (r * s - sh[2]) / T[im + 1][im] + T[im][im + 1];
+            v[1] = T[im + 1][im + 1] - Tmm - r - s;
+            v[2] = T[im + 2][im + 1];
+            if (im == il) break;
+            const double lhs = T[im][im - 1] * (std::fabs(v[1]) + std::fabs(v[2]));
+            const double rhs = v[0] * (std::fabs(T[im - 1][im - 1]) + std::fabs(Tmm) + std::fabs(T[im + 1][im + 1]));
+            if (std::fabs(lhs) < eps * rhs) break;
+          }
+          for (int k = im; k <= iu - 2; ++k) {                       // performFrancisQRStep
+            const bool first = (k == im);
+            double w[3];
+            if (first) { w[0] = v[0]; w[1] = v[1]; w[2] = v[2]; }
+            else { w[0] = T[k][k - 1]; w[1] = T[k + 1][k - 1]; w[2] = T[k + 2][k - 1]; }
+            const Hh h = make_householder(w, 3, 1);
+            if (h.beta != 0.0) {
+              if (first && k > il) T[k][k - 1] = -T[k][k - 1];
+              else if (!first) T[k][k - 1] = h.beta;
+              apply_left(T, k, k, 3, N - k, &w[1], h.tau);
+              apply_right(T, 0, k, (iu < k + 3 ? iu : k + 3) + 1, 3, &w[1], h.tau);
+              apply_right(U, 0, k, N, 3, &w[1], h.tau);
+            }
+          }
+          {
+            double w[2] = {T[iu - 1][iu - 2], T[iu][iu - 2]};
+            const Hh h = make_householder(w, 2, 1);
+            if (h.beta != 0.0) {
+              T[iu - 1][iu - 2] = h.beta;
+              apply_left(T, iu - 1, iu - 1, 2, N - iu + 1, &w[1], h.tau);
+              apply_right(T, 0, iu - 1, iu + 1, 2, &w[1], h.tau);
+              apply_right(U, 0, iu - 1, N, 2, &w[1], h.tau);
+            }
+          }
+          for (int i = im + 2; i <= iu; ++i) {                       // clean up pollution due to round-off errors
+            T[i][i - 2] = 0.0;
+            if (i > im + 2) T[i][i - 3] = 0.0;
+          }
         }
       }
+    }
+    for (int i = 0; i < N; i++) for (int j = 0; j < N; j++) T[i][j] *= scale;
   }
-  for (int i = 0; i < n; i++) w[i] = a[i][i];
+  (void)converged;
+  // ---- EigenSolver::compute: eigenvalues from the (quasi-)triangular T, top to bottom ----
+  {
+    int i = 0;
+    while (i < N) {
+      if (i == N - 1 || T[i + 1][i] == 0.0) { wr[i] = T[i][i]; wi[i] = 0.0; ++i; }
+      else {
+        const double p = 0.5 * (T[i][i] - T[i + 1][i + 1]);
+        double t0 = T[i + 1][i], t1 = T[i][i + 1];
+        const double maxval = std::max(std::fabs(p), std::max(std::fabs(t0), std::fabs(t1)));
+        t0 /= maxval; t1 /= maxval;
+        const double p0 = p / maxval;
+        const double z = maxval * std::sqrt(std::fabs(p0 * p0 + t0 * t1));
+        wr[i] = T[i + 1][i + 1] + p; wi[i] = z;
+        wr[i + 1] = T[i + 1][i + 1] + p; wi[i + 1] = -z;
+        i += 2;
+      }
+    }
+  }
+  // ---- EigenSolver::doComputeEigenvectors: back substitution on T, then back transformation with U ----
+  double nrm = 0.0;
+  for (int j = 0; j < N; j++) for (int k = (j - 1 > 0 ? j - 1 : 0); k < N; k++) nrm += std::fabs(T[j][k]);
+  if (nrm != 0.0) {
+    for (int n = N - 1; n >= 0; n--) {
+      const double p = wr[n], q = wi[n];
+      if (q == 0.0) {                                                // real eigenvalue: real vector
+        double lastr = 0.0, lastw = 0.0;
+        int l = n;
+        T[n][n] = 1.0;
+        for (int i = n - 1; i >= 0; i--) {
+          const double w = T[i][i] - p;
+          double r = 0.0;
+          for (int k = l; k <= n; k++) r += T[i][k] * T[k][n];
+          if (wi[i] < 0.0) { lastw = w; lastr = r; }
+          else {
+            l = i;
+            if (wi[i] == 0.0) {
+              if (w != 0.0) T[i][n] = -r / w;
+              else T[i][n] = -r / (eps * nrm);
+            } else {                                                 // solve real equations
+              const double x = T[i][i + 1], y = T[i + 1][i];
+              const double denom = (wr[i] - p) * (wr[i] - p) + wi[i] * wi[i];
+              const double t = (x * lastr - lastw * r) / denom;
+              T[i][n] = t;
+              if (std::fabs(x) > std::fabs(lastw)) T[i + 1][n] = (-r - w * t) / x;
+              else T[i + 1][n] = (-lastr - y * t) / lastw;
+            }
+            const double t = std::fabs(T[i][n]);                     // overflow control
+            if ((eps * t) * t > 1.0) for (int k = i; k < N; k++) T[k][n] /= t;
+          }
+        }
+      } else if (q < 0.0 && n > 0) {                                 // complex pair (n-1, n): complex vector
+        double lastra = 0.0, lastsa = 0.0, lastw = 0.0;
+        int l = n - 1;
+        if (std::fabs(T[n][n - 1]) > std::fabs(T[n - 1][n])) {
+          T[n - 1][n - 1] = q / T[n][n - 1];
+          T[n - 1][n] = -(T[n][n] - p) / T[n][n - 1];
+        } else {
+          // cc = (0, -T(n-1,n)) / (T(n-1,n-1) - p, q)
+          const double ar = 0.0, ai = -T[n - 1][n], br = T[n - 1][n - 1] - p, bi = q;
+          const double d = br * br + bi * bi;
+          T[n - 1][n - 1] = (ar * br + ai * bi) / d;
+          T[n - 1][n] = (ai * br - ar * bi) / d;
+        }
+        T[n][n - 1] = 0.0;
+        T[n][n] = 1.0;
+        for (int i = n - 2; i >= 0; i--) {
+          double ra = 0.0, sa = 0.0;
+          for (int k = l; k <= n; k++) { ra += T[i][k] * T[k][n - 1]; sa += T[i][k] * T[k][n]; }
+          const double w = T[i][i] - p;
+          if (wi[i] < 0.0) { lastw = w; lastra = ra; lastsa = sa; }
+          else {
+            l = i;
+            if (wi[i] == 0.0) {
+              const double br = w, bi = q, d = br * br + bi * bi;    // cc = (-ra, -sa) / (w, q)
+              T[i][n - 1] = (-ra * br + -sa * bi) / d;
+              T[i][n] = (-sa * br - -ra * bi) / d;
+            } else {
+              const double x = T[i][i + 1], y = T[i + 1][i];
+              double vr = (wr[i] - p) * (wr[i] - p) + wi[i] * wi[i] - q * q;
+              const double vi = (wr[i] - p) * 2.0 * q;
+              if (vr == 0.0 && vi == 0.0) vr = eps * nrm * (std::fabs(w) + std::fabs(q) + std::fabs(x) + std::fabs(y) + std::fabs(lastw));
+              const double ar = x * lastra - lastw * ra + q * sa, ai = x * lastsa - lastw * sa - q * ra;
+              const double d = vr * vr + vi * vi;
+              T[i][n - 1] = (ar * vr + ai * vi) / d;
+              T[i][n] = (ai * vr - ar * vi) / d;
+              if (std::fabs(x) > (std::fabs(lastw) + std::fabs(q))) {
+                T[i + 1][n - 1] = (-ra - w * T[i][n - 1] + q * T[i][n]) / x;
+                T[i + 1][n] = (-sa - w * T[i][n] - q * T[i][n - 1]) / x;
+              } else {
+                const double cr = -lastra - y * T[i][n - 1], ci = -lastsa - y * T[i][n];       // / (lastw, q)
+                const double d2 = lastw * lastw + q * q;
+                T[i + 1][n - 1] = (cr * lastw + ci * q) / d2;
+                T[i + 1][n] = (ci * lastw - cr * q) / d2;
+              }
+            }
+            const double t = std::max(std::fabs(T[i][n - 1]), std::fabs(T[i][n]));             // overflow control
+            if ((eps * t) * t > 1.0) for (int k = i; k < N; k++) { T[k][n - 1] /= t; T[k][n] /= t; }
+          }
+        }
+        n--;                                                         // the pair's other eigenvalue is done too
+      }
+    }
+    for (int j = N - 1; j >= 0; j--) {                               // back transformation
+      double tmp[N];
+      for (int i = 0; i < N; i++) { double s = 0.0; for (int k = 0; k <= j; k++) s += U[i][k] * T[k][j]; tmp[i] = s; }
+      for (int i = 0; i < N; i++) U[i][j] = tmp[i];
+    }
+  }
+  // ---- EigenSolver::eigenvectors(): normalised columns; `.real()` of a conjugate pair is the pair's real part ----
+  for (int j = 0; j < N; j++) {
+    const bool real_ev = (std::fabs(wi[j]) <= std::fabs(wr[j]) * 2.0 * eps) || j + 1 == N;      // isMuchSmallerThan(imag, real, 2 eps)
+    if (real_ev) {
+      double n2 = 0.0;
+      for (int i = 0; i < N; i++) n2 += U[i][j] * U[i][j];
+      const double nn = std::sqrt(n2);
+      for (int i = 0; i < N; i++) V[i][j] = (n2 > 0.0) ? U[i][j] / nn : U[i][j];
+    } else {
+      double n2 = 0.0;
+      for (int i = 0; i < N; i++) n2 += U[i][j] * U[i][j] + U[i][j + 1] * U[i][j + 1];
+      const double nn = std::sqrt(n2);
+      for (int i = 0; i < N; i++) { V[i][j] = (n2 > 0.0) ? U[i][j] / nn : U[i][j]; V[i][j + 1] = V[i][j]; }
+      ++j;
+    }
+  }
 }
 
 }  // namespace oracle

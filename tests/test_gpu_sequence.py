@@ -52,6 +52,54 @@ def test_corridor_replay_follows_cpu_oracle(built, oracle):
     G.close()
 
 
+def test_lemma_solve_against_the_literal_two_inverse_form_over_30_scans(built):
+    """The filter's default solve is the matrix-inversion-lemma form of esekfom.hpp:1722-1729 (one 12x12 solve);
+    FLIMO_REFERENCE_SOLVE=1 selects the literal form (two 23x23 inverses, unconditional eigen-decomposition).  Thirty scans of a
+    drive, FREE-RUNNING (nothing is handed over between the two runs, map inserts on): what the algebraic form contributes to
+    the trajectory, accumulated, has to stay far below the 1e-4 bar of north_star."""
+    import os
+    from fast_limo_amd import api
+    n_scans, n_pts, speed = 30, 8000, 10.0
+    st, w, a = synth.stationary_imu(0.0, 0.1 * n_scans + 0.06)
+
+    def drive(literal):
+        old = os.environ.pop("FLIMO_REFERENCE_SOLVE", None)
+        if literal:
+            os.environ["FLIMO_REFERENCE_SOLVE"] = "1"
+        try:
+            G = api.Localizer(api.default_cfg(**CAPS))                 # the switch is read when the Localizer is created
+        finally:
+            os.environ.pop("FLIMO_REFERENCE_SOLVE", None)
+            if old is not None:
+                os.environ["FLIMO_REFERENCE_SOLVE"] = old
+        x0 = G.get_x(); x0[14] = speed; G.set_x(x0)
+        i = 0
+        xs, sizes = [], []
+        for k in range(n_scans):
+            until = 0.1 * (k + 1) + 0.005
+            while i < len(st) and st[i] <= until:
+                G.update_imu(st[i], w[i], a[i]); i += 1
+            assert G.update_pointcloud(synth.corridor_scan(k, n_pts, 555, speed=speed), 0.1 * k) == (1 if k == 0 else 0)
+            xs.append(G.get_x()); sizes.append(G.map_size())
+        P = G.get_P()
+        G.close()
+        return np.array(xs), np.array(sizes), P
+
+    xa, sa, Pa = drive(False)
+    xb, sb, Pb = drive(True)
+    dpos = np.abs(xa[:, 0:3] - xb[:, 0:3]).max(axis=1)
+    dq = np.abs(xa[:, 3:7] - xb[:, 3:7]).max(axis=1)
+    rel_P = np.abs(Pa - Pb).max() / np.abs(Pb).max()
+    print("lemma form vs literal two-inverse form over %d free-running scans: max |dpos| %.2e m (last scan %.2e), max |dq| %.2e, "
+          "covariance %.2e relative, map sizes differ by at most %d points"
+          % (n_scans, dpos.max(), dpos[-1], dq.max(), rel_P, int(np.abs(sa - sb).max())))
+    # measured: 3.7e-5 m / 8e-6 rad after 30 scans (the literal form inverts P / R, condition ~1e7: its own rounding is what moves)
+    assert dpos.max() <= 1e-4 and 2.0 * dq.max() <= 1e-4
+    assert np.abs(sa - sb).max() <= 8
+    assert rel_P <= 1e-3
+    assert abs(xa[-1, 0] - speed * 0.1 * n_scans) < 0.25
+
+
 def test_pcd_sequence_replay_ate(built, oracle, tmp_path):
     """The replay harness (fast_limo_amd/replay.py: PCD scans + IMU CSV, no ROS) drives the product and the oracle
     through the same files; ATE of the GPU trajectory w.r.t. the CPU trajectory stays below 1e-4 m and the harness

@@ -166,6 +166,83 @@ def test_ieskf_degenerate_scene_is_frozen(oracle):
     np.testing.assert_array_equal(x1[0:7], x0[0:7])
 
 
+def test_eigen_solver_restatement(oracle):
+    """Eigen::EigenSolver<Matrix6d> restated from its published algorithm (rl_linalg.h: Householder Hessenberg, Francis
+    double-shift QR, back substitution).  What can be checked without Eigen: eigenpairs against LAPACK (numpy), unit columns, and
+    the ORDER properties that follow from the algorithm -- a diagonal matrix keeps its diagonal order (no reflector acts), a
+    matrix that is already upper Hessenberg / tridiagonal is deflated from the bottom right, and the order is not sorted in general."""
+    rs = np.random.RandomState(0)
+    n_unsorted = 0
+    for trial in range(1500):
+        B = rs.randn(rs.randint(3, 40), 6) * rs.uniform(0.1, 30)
+        if trial % 5 == 0:
+            B[:, rs.choice(6, rs.randint(1, 6), replace=False)] *= 1e-4         # nearly degenerate directions
+        if trial % 7 == 0:
+            B = B[:rs.randint(1, 6)]                                           # rank deficient (corridor / open field)
+        A = B.T @ B
+        wr, wi, V = oracle.eigen_solver6(A)
+        ref = np.linalg.eigvalsh(A)
+        scale = max(np.abs(ref).max(), 1e-300)
+        assert np.abs(np.sort(wr) - ref).max() <= 1e-7 * scale
+        assert np.abs(wi).max() <= 1e-7 * scale                                # a symmetric matrix: pairs only by rounding
+        if not np.any(wi):
+            assert np.abs(np.sort(wr) - ref).max() <= 1e-12 * scale
+            assert np.abs(A @ V - V * wr[None, :]).max() <= 1e-10 * scale
+            np.testing.assert_allclose(np.linalg.norm(V, axis=0), 1.0, atol=1e-12)
+        n_unsorted += int(np.any(np.diff(wr) < 0) and np.any(np.diff(wr) > 0))
+    assert n_unsorted > 500                                                    # neither ascending nor descending: an order of its own
+    wr, wi, V = oracle.eigen_solver6(np.diag([3.0, 1.0, 2.0, 6.0, 5.0, 4.0]))
+    np.testing.assert_array_equal(wr, [3.0, 1.0, 2.0, 6.0, 5.0, 4.0])
+    np.testing.assert_array_equal(V, np.eye(6))
+    wr, wi, V = oracle.eigen_solver6(np.zeros((6, 6)))
+    np.testing.assert_array_equal(wr, 0.0); np.testing.assert_array_equal(V, np.eye(6))
+
+
+def _plane_rows(rs, normals, M, lever=5.0):
+    """H rows of points on planes with the given normals: [n, p x n, 0.., n] like calculate_H (Localizer.cpp:564-569)."""
+    H = np.zeros((M, 12)); h = rs.normal(size=M) * 0.02
+    for m in range(M):
+        n = np.asarray(normals[m % len(normals)], float)
+        p = rs.uniform(-lever, lever, 3)
+        H[m, 0:3] = n; H[m, 3:6] = np.cross(p, n); H[m, 9:12] = n
+    return H, h
+
+
+def test_ieskf_degenerate_projector_follows_the_solver_order(oracle):
+    """Corridor (two wall normals + floor, nothing along the axis) and single-plane scenes: eigenvalues of HTH[0:6,0:6] below D = 5.
+    The reference zeroes ROW i of the eigenvector matrix for eigenVALUE i (esekfom.hpp:1741) and applies VEPs^-1 * selVEPs: the
+    step that results is a function of the solver's eigenpair order.  Checked: (a) the oracle's first-pass step equals the dense
+    numpy evaluation of the same formula on the oracle's eigenpairs, (b) with a sorted order (what a Jacobi or LAPACK solver
+    gives) the step is DIFFERENT -- the order is observable, which is why the solver is restated."""
+    rs = np.random.RandomState(5)
+    scenes = {"corridor": [(0, 1, 0), (0, -1, 0), (0, 0, 1)], "single plane": [(0, 0, 1)], "two planes": [(0, 0, 1), (0, 1, 0)]}
+    differs = 0
+    for name, normals in scenes.items():
+        H, h = _plane_rows(rs, normals, 400)
+        x0 = oracle.identity_x26(pos=(0.5, -0.2, 0.1))
+        P = np.eye(23) * 1e-2
+        x1, P1, n_pass = oracle.eskf_update_fixed(x0, P, H, h, max_iters=0)          # ONE pass (it = -1)
+        HTH = H.T @ H
+        wr, wi, V = oracle.eigen_solver6(HTH[:6, :6])
+        assert (wr < 5.0).sum() >= 1, name                                            # degenerate indeed
+        # dense evaluation of the pass (Appendix A of SURVEY.md) with the projector built from (wr, V)
+        R = 0.001
+        Pinv = np.linalg.inv(np.linalg.inv(P / R) + np.pad(HTH, ((0, 11), (0, 11))))
+        dx = Pinv[:, :12] @ (H.T @ h)                                                 # dx_new = 0 at the first pass
+        def projected(w, Vm):
+            if np.prod(w) < 1e-20:
+                Vm = np.eye(6)
+            sel = Vm.copy(); sel[w < 5.0, :] = 0.0
+            return np.linalg.inv(Vm) @ sel @ dx[:6]
+        got = x1[0:3] - x0[0:3]
+        want = projected(wr, V)[0:3]
+        np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-9, err_msg=name)
+        ws, Vs = np.linalg.eigh(HTH[:6, :6])                                          # ascending order, LAPACK's signs
+        if np.abs(projected(ws, Vs)[0:3] - want).max() > 1e-6:
+            differs += 1
+    assert differs >= 1
+
+
 def test_known_answer_noise_free(oracle):
     """noise-free box world + known offset T*  =>  the filter converges to T* (SURVEY.md 8 c (3))."""
     mp, scan, imu = cfg1_scene(sigma=0.0)
