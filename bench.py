@@ -275,6 +275,71 @@ def hbm_regime_leg(device, steps, with_oracle, max_threads=32):
     return out
 
 
+def shipped_config_leg(device, with_oracle, n_sweeps=10, n_pts=120000):
+    """The reference's shipped configuration (config/kitti.yaml: crop box +-1 m, min distance 4 m, every 4th point, voxel grid 1 m,
+    MAX_NUM_PC2MATCH 1e4 / MAX_NUM_MATCHES 5000, the yaml's extrinsics and biases, debug on, clouds handed back) on raw 120k-point
+    sweeps of a drive, map inserts on: what a drop-in user behind the ROS wrapper runs.  ms per sweep (call + map insert), the
+    CPU oracle driven through the same sweeps beside it."""
+    from fast_limo_amd import api, synth
+    speed = 10.0
+    st, w, a = synth.stationary_imu(0.0, 0.1 * n_sweeps + 0.06)
+    lid_t = (8.086759e-01, -3.195559e-01, 7.997231e-01)
+    lid_R = (9.999976e-01, -7.854027e-04, 2.024406e-03, 7.553071e-04, 9.998898e-01, 1.482454e-02,
+             -2.035826e-03, -1.482298e-02, 9.998881e-01)
+    common = dict(MAX_NUM_PC2MATCH=10000, MAX_NUM_MATCHES=5000, voxel_active=1, leaf_size=1.0, crop_active=1,
+                  dist_active=1, min_dist=4.0, rate_active=1, rate_value=4, time_offset=1,
+                  lidar2baselink_t=lid_t, lidar2baselink_R=lid_R, accel_bias=(0.01, 0.01, 0.01), gyro_bias=(0.01, 0.01, 0.01),
+                  cov_gyro=6.01e-4, cov_acc=1.53e-2, cov_bias_gyro=1.54e-5, cov_bias_acc=3.38e-4)
+    sweeps5 = [synth.corridor_scan(k, n_pts, 4321, speed=speed) for k in range(n_sweeps)]
+    sweeps = [api.make_points_velodyne(s5) for s5 in sweeps5]
+
+    def drive(L, feed, sync):
+        x0 = L.get_x(); x0[14] = speed; L.set_x(x0)
+        i = 0
+        times = []
+        for k in range(n_sweeps):
+            until = 0.1 * (k + 1) + 0.005
+            while i < len(st) and st[i] <= until:
+                L.update_imu(st[i], w[i], a[i]); i += 1
+            t1 = time.perf_counter()
+            rc = feed(L, k)
+            sync(L)
+            times.append(time.perf_counter() - t1)
+            assert rc == (1 if k == 0 else 0), (k, rc)
+        return times
+
+    G = api.Localizer(api.default_cfg(gpu_device=device, cropBoxMin=(-1.0, -1.0, -1.0), cropBoxMax=(1.0, 1.0, 1.0), debug=1,
+                                      num_threads=os.cpu_count() or 1, **common))
+    G.set_flags(add_to_map=True, download_clouds=True, keep_log=False)
+
+    fresh = [s.copy() for s in sweeps]                                  # (the call filters its input cloud in place, like the reference)
+
+    def feed_gpu(L, k):
+        rc = L.update_pointcloud_points(fresh[k], 0.1 * k)
+        L.final_scan()
+        return rc
+    tg = drive(G, feed_gpu, lambda L: L.sync())
+    out = {"workload": "config/kitti.yaml filters / caps / voxel grid / extrinsics, debug on, clouds downloaded: %d raw sweeps of %d points, "
+                       "map inserts on" % (n_sweeps, n_pts),
+           "ms_per_sweep": 1e3 * float(np.median(tg[3:])), "pc2match_points": int(G.pc2match().shape[0]), "map_points": G.map_size(),
+           "last_sweep_stages_ms": {kk: 1e3 * float(v) for kk, v in G.stage_times().items()}}
+    xg = G.get_x()
+    G.close()
+    if with_oracle:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle_py as O
+        nt = max(1, min(32, os.cpu_count() or 1))
+        Lo = O.Localizer(O.default_cfg(crop_min=(-1.0, -1.0, -1.0), crop_max=(1.0, 1.0, 1.0), num_threads=nt, **common))
+        fresh_o = [s.copy() for s in sweeps]
+        to = drive(Lo, lambda L, k: L.update_pointcloud_points(fresh_o[k], 0.1 * k), lambda L: None)
+        out["cpu_oracle_ms_per_sweep"] = 1e3 * float(np.median(to[3:]))
+        out["cpu_threads"] = nt
+        out["speedup_vs_cpu_oracle"] = out["cpu_oracle_ms_per_sweep"] / out["ms_per_sweep"]
+        xo = Lo.get_x()
+        out["free_running_pose_difference_m"] = float(np.abs(xg[0:3] - xo[0:3]).max())
+    return out
+
+
 def rank_barrier(dist, torch):
     """Barrier over the ranks (if any) + device synchronisation: brackets the timed region on both sides."""
     if dist is not None:
@@ -567,7 +632,30 @@ def main():
                                              "last_sweep_stages_ms": {kk: 1e3 * float(v) for kk, v in stg.items()}}
         end_to_end["ms"] = end_to_end["tied_stamps"]["ms_per_sweep"]
         end_to_end["scans_per_s"] = 1e3 / end_to_end["ms"]
+        # the same sweeps with the clouds handed back to the caller (download_clouds = true is the class's default and what the
+        # reference's ROS wrapper needs: src/main.cpp:27-31 publishes get_pointcloud() after every sweep)
+        loc.set_flags(add_to_map=True, download_clouds=True, keep_log=False)
+        sweeps = [api.make_points_velodyne(synth.velodyne_scan(args.rings, args.azimuths, args.box, 300 + j)) for j in range(args.e2e_sweeps)]
+        lat, tot_sw = [], []
+        loc.sync()
+        for j in range(args.e2e_sweeps):
+            until = 0.1 * (k + 1) + 0.005
+            while i < len(st) and st[i] <= until:
+                loc.update_imu(st[i], w[i], a[i]); i += 1
+            t1 = time.perf_counter()
+            rc = loc.update_pointcloud_points(sweeps[j], 0.1 * k)
+            n_final = loc.final_scan().shape[0]                  # the caller takes the cloud (get_pointcloud)
+            t2 = time.perf_counter()
+            loc.sync()
+            t3 = time.perf_counter()
+            lat.append(t2 - t1); tot_sw.append(t3 - t1)
+            assert rc == 0 and n_final == sweeps[j].shape[0], (rc, n_final)
+            k += 1
+        end_to_end["with_clouds"] = {"ms": 1e3 * float(np.mean(tot_sw[1:])), "call_returns_after_ms": 1e3 * float(np.median(lat)),
+                                     "sweeps": args.e2e_sweeps,
+                                     "last_sweep_stages_ms": {kk: 1e3 * float(v) for kk, v in loc.stage_times().items()}}
         end_to_end["map_points_after"] = loc.map_size()
+        end_to_end["shipped_config"] = shipped_config_leg(local_rank % n_dev, not args.no_cpu_baseline)
 
     elapsed, value = aggregate(dist, torch, elapsed, world, args.steps)
 

@@ -53,7 +53,7 @@ HIP_SYMBOLS = [
     "flimo_ctx_create", "flimo_ctx_destroy", "flimo_last_error", "flimo_version",
     "flimo_map_config", "flimo_map_add", "flimo_map_clear", "flimo_map_size", "flimo_map_last_time",
     "flimo_map_points", "flimo_knn", "flimo_scan_set", "flimo_scan_size", "flimo_scan_get",
-    "flimo_scan_voxel_filter", "flimo_raw_scan_set", "flimo_raw_scan_filter_set", "flimo_deskew_resident", "flimo_deskew_resident_offset", "flimo_deskew",
+    "flimo_scan_voxel_filter", "flimo_raw_scan_set", "flimo_raw_scan_filter_set", "flimo_raw_scan_filter_order_set", "flimo_raw_scan_order", "flimo_deskew_resident", "flimo_deskew_resident_offset", "flimo_deskew",
     "flimo_match_reduce", "flimo_match_fetch", "flimo_match_fetch_H",
     "flimo_scan_to_world", "flimo_map_add_scan",
     "flimo_set_timing", "flimo_set_timing_stride", "flimo_pass_count", "flimo_fused_pass_count", "flimo_tie_stats", "flimo_fine_stats", "flimo_map_grid_selfcheck", "flimo_set_debug_records", "flimo_set_lanes_per_query", "flimo_last_kernel_ms",

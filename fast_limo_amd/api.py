@@ -36,7 +36,7 @@ class LocCfg(C.Structure):
         ("sensor_type", C.c_int),
         ("gravity_align", C.c_int), ("calibrate_accel", C.c_int), ("calibrate_gyro", C.c_int),
         ("imu_calib_time", C.c_double),
-        ("gpu_device", C.c_int), ("gpu_cell_size", C.c_float),
+        ("gpu_device", C.c_int), ("gpu_cell_size", C.c_float), ("debug", C.c_int),
     ]
 
 
@@ -94,6 +94,7 @@ def default_cfg(**kw) -> LocCfg:
     c.gravity_align = c.calibrate_accel = c.calibrate_gyro = 0
     c.imu_calib_time = 3.0
     c.gpu_device, c.gpu_cell_size = 0, 0.0
+    c.debug = 0
     for k, v in kw.items():
         if not hasattr(c, k):
             raise AttributeError(k)

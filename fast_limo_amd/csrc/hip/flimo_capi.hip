@@ -72,6 +72,11 @@ struct flimo_ctx {
   unsigned long long* d_filt_ext = nullptr;
   unsigned long long* h_filt_ext = nullptr;   // pinned
   double resident_t_offset = 0.0;  // sweep offset of the resident raw scan's stamps (0: already contained in them)
+  unsigned long long* d_tkey[2] = {nullptr, nullptr};   // ordered stamp keys of the kept points / the same sorted (device time order)
+  uint32_t* d_tperm = nullptr;     // time rank -> position among the kept points (arrival order)
+  double* d_t_tmp = nullptr;
+  size_t tkey_cap = 0;
+  bool raw_time_ordered = false;   // the resident raw scan is in the reference's time order (stamps pairwise different)
   float4* d_scan_raw = nullptr;    // raw lidar-frame points for deskew (caller order)
   float4* d_raw_sorted = nullptr;  // the same in Morton order, w = original index
   double* d_t_sorted = nullptr;
@@ -389,6 +394,7 @@ extern "C" void flimo_ctx_destroy(flimo_ctx* c) {
   (void)hipFree(c->d_frames); (void)hipFree(c->d_recs); (void)hipFree(c->d_dbg);
   (void)hipFree(c->d_fine_tmp); (void)hipFree(c->d_fine_pts); (void)hipFree(c->d_fine_cs); (void)hipFree(c->d_fine_rt);
   (void)hipFree(c->d_fine_count); (void)hipFree(c->d_crowd_list); (void)hipFree(c->d_crowd_count); (void)hipFree(c->d_crowd_bits);
+  (void)hipFree(c->d_tkey[0]); (void)hipFree(c->d_tkey[1]); (void)hipFree(c->d_tperm); (void)hipFree(c->d_t_tmp);
   (void)hipFree(c->d_raw32); (void)hipFree(c->d_filt_ext); (void)hipFree(c->d_nbrk); (void)hipFree(c->d_tie_list); (void)hipFree(c->d_tie_count);
   if (c->h_filt_ext) (void)hipHostFree(c->h_filt_ext);
   (void)hipFree(c->d_partials); (void)hipFree(c->d_out256); (void)hipFree(c->d_cand); (void)hipFree(c->d_ticket);
@@ -1059,15 +1065,21 @@ extern "C" int flimo_raw_scan_set(flimo_ctx* c, const float* xyz, size_t n, size
 
 extern "C" int flimo_raw_scan_filter_set(flimo_ctx* c, const void* points32, size_t n, const flimo_filter_cfg* cfg, size_t* n_kept,
                                          double* last_stamp, int* nan_stamp) {
-  if (!c || !cfg || !n_kept || !last_stamp || !nan_stamp || (n > 0 && !points32)) return FLIMO_ERR_INVALID;
+  int tied = 0;
+  return flimo_raw_scan_filter_order_set(c, points32, n, cfg, 0, n_kept, last_stamp, nan_stamp, &tied);
+}
+
+extern "C" int flimo_raw_scan_filter_order_set(flimo_ctx* c, const void* points32, size_t n, const flimo_filter_cfg* cfg, int time_order,
+                                               size_t* n_kept, double* last_stamp, int* nan_stamp, int* tied) {
+  if (!c || !cfg || !n_kept || !last_stamp || !nan_stamp || !tied || (n > 0 && !points32)) return FLIMO_ERR_INVALID;
   if (cfg->time_kind < 0 || cfg->time_kind > 3) return fail(c, FLIMO_ERR_INVALID, "time_kind must be 0..3");
   if (cfg->rate_active && cfg->rate_value < 1) return fail(c, FLIMO_ERR_INVALID, "rate_value must be >= 1");
   if (n > 0x7fff0000ull) return fail(c, FLIMO_ERR_TOO_LARGE, "scan too large");
-  *n_kept = 0; *last_stamp = 0.0; *nan_stamp = 0;
+  *n_kept = 0; *last_stamp = 0.0; *nan_stamp = 0; *tied = 0;
   (void)hipSetDevice(c->device);
   int rc = ensure_scan(c, n);
   if (rc) return rc;
-  c->raw_n = 0; c->resident_t_offset = 0.0;
+  c->raw_n = 0; c->resident_t_offset = 0.0; c->raw_time_ordered = false;
   if (n == 0) return FLIMO_OK;
   if (n > c->raw32_cap) {
     (void)hipFree(c->d_raw32);
@@ -1077,8 +1089,18 @@ extern "C" int flimo_raw_scan_filter_set(flimo_ctx* c, const void* points32, siz
     c->raw32_cap = cap;
   }
   if (!c->d_filt_ext) {
-    HIPCHK(c, hipMalloc(&c->d_filt_ext, 3 * sizeof(unsigned long long)));
-    HIPCHK(c, hipHostMalloc((void**)&c->h_filt_ext, 3 * sizeof(unsigned long long), hipHostMallocDefault));
+    HIPCHK(c, hipMalloc(&c->d_filt_ext, 4 * sizeof(unsigned long long)));
+    HIPCHK(c, hipHostMalloc((void**)&c->h_filt_ext, 4 * sizeof(unsigned long long), hipHostMallocDefault));
+  }
+  if (time_order && n > c->tkey_cap) {
+    (void)hipFree(c->d_tkey[0]); (void)hipFree(c->d_tkey[1]); (void)hipFree(c->d_tperm); (void)hipFree(c->d_t_tmp);
+    c->d_tkey[0] = c->d_tkey[1] = nullptr; c->d_tperm = nullptr; c->d_t_tmp = nullptr; c->tkey_cap = 0;
+    const size_t cap = c->scan_cap;                           // (>= n after ensure_scan)
+    HIPCHK(c, hipMalloc(&c->d_tkey[0], cap * sizeof(unsigned long long)));
+    HIPCHK(c, hipMalloc(&c->d_tkey[1], cap * sizeof(unsigned long long)));
+    HIPCHK(c, hipMalloc(&c->d_tperm, cap * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc(&c->d_t_tmp, cap * sizeof(double)));
+    c->tkey_cap = cap;
   }
   rc = ensure_stage(c, n * 32);
   if (rc) return rc;
@@ -1097,8 +1119,8 @@ extern "C" int flimo_raw_scan_filter_set(flimo_ctx* c, const void* points32, siz
   F.dist = cfg->dist_active ? 1 : 0; F.min_dist = cfg->min_dist;
   F.rate_on = cfg->rate_active ? 1 : 0; F.rate = cfg->rate_value;
   F.kind = cfg->time_kind; F.eos = cfg->end_of_sweep ? 1 : 0; F.sweep_ref = cfg->sweep_ref_time;
-  HIPCHK(c, filter_raw_scan(c->stream, c->d_raw32, n, F, c->d_scan_raw, c->d_scan_t, c->d_filt_ext, c->scratch));
-  HIPCHK(c, hipMemcpyAsync(c->h_filt_ext, c->d_filt_ext, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, filter_raw_scan(c->stream, c->d_raw32, n, F, c->d_scan_raw, c->d_scan_t, c->d_filt_ext, c->scratch, time_order ? c->d_tkey[0] : nullptr));
+  HIPCHK(c, hipMemcpyAsync(c->h_filt_ext, c->d_filt_ext, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const size_t m = (size_t)c->h_filt_ext[1];
   *n_kept = m;
@@ -1126,8 +1148,33 @@ extern "C" int flimo_raw_scan_filter_set(flimo_ctx* c, const void* points32, siz
     t = (cfg->time_kind == 2) ? v : v * (double)1e-9f;
   }
   *last_stamp = t;
+  if (time_order) {
+    // the kept points into the reference's time order (d_scan_world / d_t_tmp are free at this point of the scan's life)
+    HIPCHK(c, time_order_raw(c->stream, c->d_scan_raw, c->d_scan_t, m, c->d_tkey[0], c->d_tkey[1], c->d_scan_world, c->d_t_tmp, c->d_tperm,
+                             c->d_filt_ext, c->scratch));
+    HIPCHK(c, hipMemcpyAsync(c->h_filt_ext + 3, c->d_filt_ext + 3, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->h_filt_ext[3]) { *tied = 1; return FLIMO_OK; }      // equal stamps: only the host routine reproduces the library's order among them
+    std::swap(c->d_scan_raw, c->d_scan_world);
+    std::swap(c->d_scan_t, c->d_t_tmp);
+    c->raw_time_ordered = true;
+  }
   HIPCHK(c, sort_scan(c->stream, c->d_scan_raw, m, c->d_raw_sorted, c->scratch, c->d_scan_t, c->d_t_sorted));
   c->raw_n = m;
+  return FLIMO_OK;
+}
+
+// time rank -> position among the kept points of the last flimo_raw_scan_filter_order_set (identity when the sweep was left in
+// arrival order)
+extern "C" int flimo_raw_scan_order(flimo_ctx* c, uint32_t* order_out, size_t cap, size_t* n) {
+  if (!c || !n) return FLIMO_ERR_INVALID;
+  *n = c->raw_n;
+  if (!order_out || cap == 0 || c->raw_n == 0) return FLIMO_OK;
+  const size_t m = std::min(cap, c->raw_n);
+  if (!c->raw_time_ordered) { for (size_t i = 0; i < m; i++) order_out[i] = (uint32_t)i; return FLIMO_OK; }
+  (void)hipSetDevice(c->device);
+  HIPCHK(c, hipMemcpyAsync(order_out, c->d_tperm, m * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return FLIMO_OK;
 }
 

@@ -109,10 +109,16 @@ hipError_t map_merge_grid(hipStream_t st, const float4* old_sorted, size_t n_old
                           float4* out_sorted, uint32_t* cell_start, size_t ncells, float ox, float oy, float oz,
                           float inv_cell, int nx, int ny, int nz, int xs, MapBuildScratch& S);
 // Input filters of a raw sweep (32-byte PointType records already on the device): NaN removal, crop box, every rate-th survivor,
-// min distance; order preserved.  out[k] = (xyz, w = k), t_out[k] = stamp without the sweep offset; ext_dev[3] = {extreme ordered
-// stamp key (complemented when the sweep is sorted descending), kept count, "a kept stamp is NaN"}.
+// min distance; order preserved.  out[k] = (xyz, w = k), t_out[k] = stamp without the sweep offset; ext_dev[4] = {extreme ordered
+// stamp key (complemented when the sweep is sorted descending), kept count, "a kept stamp is NaN", "two kept stamps are equal"
+// (time_order_raw)}; key_out[k] (optional) = ordered stamp key, ascending = the order of the reference's time sort.
 hipError_t filter_raw_scan(hipStream_t st, const void* raw32_dev, size_t n, const FilterParams& F, float4* out, double* t_out,
-                           unsigned long long* ext_dev, MapBuildScratch& S);
+                           unsigned long long* ext_dev, MapBuildScratch& S, unsigned long long* key_out = nullptr);
+// The kept points in the reference's time order (unique when no two stamps are equal; ext_dev[3] = 1 reports equal stamps): stable
+// radix sort of the ordered stamp keys filter_raw_scan wrote, pts_out[i] = (xyz of pts[perm_out[i]], w = i), t_out likewise.
+hipError_t time_order_raw(hipStream_t st, const float4* pts, const double* t, size_t n, const unsigned long long* keys,
+                          unsigned long long* keys_sorted, float4* pts_out, double* t_out, uint32_t* perm_out,
+                          unsigned long long* ext_dev, MapBuildScratch& S);
 // Second level over crowded regions: box (cell coordinates, inclusive) around the cells holding more than `threshold` points
 // (box_host[6] = their number; box_dev: 7 ints of device scratch), and the copy of the map points inside a box of metres
 // (w = position in the main sorted map).

@@ -514,7 +514,7 @@ __global__ __launch_bounds__(256) void filt_keep_kernel(const Raw32* __restrict_
 // sorting descending, stored complemented), ext[1] = kept count, ext[2] = a kept stamp is NaN
 __global__ __launch_bounds__(256) void filt_compact_kernel(const Raw32* __restrict__ in, size_t n, FilterParams F, const uint32_t* __restrict__ keep,
                                                            const uint32_t* __restrict__ pos, float4* __restrict__ out, double* __restrict__ t_out,
-                                                           unsigned long long* __restrict__ ext) {
+                                                           unsigned long long* __restrict__ ext, unsigned long long* __restrict__ key_out) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   if (i == n - 1) ext[1] = (unsigned long long)(pos[i] + keep[i]);
@@ -546,12 +546,13 @@ __global__ __launch_bounds__(256) void filt_compact_kernel(const Raw32* __restri
     key = (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
   }
   t_out[o] = t;
+  if (key_out) key_out[o] = desc ? ~key : key;               // ascending in this key = the order of the reference's time sort
   if (nan) atomicOr(&ext[2], 1ull);
   else atomicMax(&ext[0], desc ? ~key : key);
 }
 
 hipError_t filter_raw_scan(hipStream_t st, const void* raw32_dev, size_t n, const FilterParams& F, float4* out, double* t_out,
-                           unsigned long long* ext_dev, MapBuildScratch& S) {
+                           unsigned long long* ext_dev, MapBuildScratch& S, unsigned long long* key_out) {
   if (n == 0) return hipSuccess;
   hipError_t e = ensure_scratch(S, n);
   if (e != hipSuccess) return e;
@@ -566,7 +567,7 @@ hipError_t filter_raw_scan(hipStream_t st, const void* raw32_dev, size_t n, cons
     if ((e = hipMalloc(&S.cub_tmp, scan_bytes + 1024)) != hipSuccess) return e;
     S.cub_tmp_bytes = scan_bytes + 1024;
   }
-  if ((e = hipMemsetAsync(ext_dev, 0, 3 * sizeof(unsigned long long), st)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(ext_dev, 0, 4 * sizeof(unsigned long long), st)) != hipSuccess) return e;
   hipLaunchKernelGGL(filt_alive_kernel, dim3(blocks), dim3(256), 0, st, in, n, F, S.keys_in);
   if (F.rate_on) {
     e = exclusive_sum(S.cub_tmp, scan_bytes, S.keys_in, S.vals_in, n, st);               // rank among the survivors of NaN + crop
@@ -575,7 +576,54 @@ hipError_t filter_raw_scan(hipStream_t st, const void* raw32_dev, size_t n, cons
   hipLaunchKernelGGL(filt_keep_kernel, dim3(blocks), dim3(256), 0, st, in, n, F, S.keys_in, S.vals_in, S.keys_out);
   e = exclusive_sum(S.cub_tmp, scan_bytes, S.keys_out, S.vals_out, n, st);                // output position
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(filt_compact_kernel, dim3(blocks), dim3(256), 0, st, in, n, F, S.keys_out, S.vals_out, out, t_out, ext_dev);
+  hipLaunchKernelGGL(filt_compact_kernel, dim3(blocks), dim3(256), 0, st, in, n, F, S.keys_out, S.vals_out, out, t_out, ext_dev, key_out);
+  return hipGetLastError();
+}
+
+// ---- the reference's time order of a sweep on the device (Localizer.cpp:789-790: std::partial_sort_copy of the whole cloud by
+//      stamp).  With pairwise different stamps the sorted order is unique, whatever algorithm produces it: a stable radix sort of
+//      (ordered stamp key, position) gives it; ext[3] reports whether two kept stamps are equal -- then the order among them is
+//      the library's heap moves' and only the host routine reproduces it (fast_limo.cpp: time_order). -----------------------------
+__global__ __launch_bounds__(256) void iota_kernel(uint32_t* __restrict__ v, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] = (uint32_t)i;
+}
+__global__ __launch_bounds__(256) void tied_keys_kernel(const unsigned long long* __restrict__ sorted, size_t n, unsigned long long* __restrict__ ext) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool tie = (i + 1 < n) && sorted[i] == sorted[i + 1];
+  if (__ballot(tie) && (threadIdx.x & 63) == 0) atomicOr(&ext[3], 1ull);
+}
+__global__ __launch_bounds__(256) void gather_time_order_kernel(const float4* __restrict__ in, const double* __restrict__ t_in,
+                                                                const uint32_t* __restrict__ perm, size_t n, float4* __restrict__ out,
+                                                                double* __restrict__ t_out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t j = perm[i];
+  const float4 p = in[j];
+  out[i] = make_float4(p.x, p.y, p.z, __uint_as_float((uint32_t)i));
+  t_out[i] = t_in[j];
+}
+hipError_t time_order_raw(hipStream_t st, const float4* pts, const double* t, size_t n, const unsigned long long* keys,
+                          unsigned long long* keys_sorted, float4* pts_out, double* t_out, uint32_t* perm_out,
+                          unsigned long long* ext_dev, MapBuildScratch& S) {
+  if (n == 0) return hipSuccess;
+  hipError_t e = ensure_scratch(S, n);
+  if (e != hipSuccess) return e;
+  const int blocks = (int)((n + 255) / 256);
+  hipLaunchKernelGGL(iota_kernel, dim3(blocks), dim3(256), 0, st, S.vals_in, n);
+  size_t tmp_bytes = 0;
+  e = sort_pairs_u64(nullptr, tmp_bytes, keys, keys_sorted, S.vals_in, perm_out, n, st);
+  if (e != hipSuccess) return e;
+  if (tmp_bytes > S.cub_tmp_bytes) {
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+    if (S.cub_tmp) (void)hipFree(S.cub_tmp);
+    if ((e = hipMalloc(&S.cub_tmp, tmp_bytes + 1024)) != hipSuccess) return e;
+    S.cub_tmp_bytes = tmp_bytes + 1024;
+  }
+  e = sort_pairs_u64(S.cub_tmp, tmp_bytes, keys, keys_sorted, S.vals_in, perm_out, n, st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(tied_keys_kernel, dim3(blocks), dim3(256), 0, st, keys_sorted, n, ext_dev);
+  hipLaunchKernelGGL(gather_time_order_kernel, dim3(blocks), dim3(256), 0, st, pts, t, perm_out, n, pts_out, t_out);
   return hipGetLastError();
 }
 

@@ -56,7 +56,7 @@ static Config to_config(const flimo_loc_cfg* c) {
   cfg.calibrate_accel = c->calibrate_accel != 0;
   cfg.calibrate_gyro = c->calibrate_gyro != 0;
   cfg.imu_calib_time = c->imu_calib_time;
-  cfg.debug = false;
+  cfg.debug = c->debug != 0;
   cfg.verbose = false;
   cfg.gpu_device = c->gpu_device;
   cfg.gpu_cell_size = c->gpu_cell_size;

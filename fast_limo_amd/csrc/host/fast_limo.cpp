@@ -858,9 +858,20 @@ void time_order_t(const T* k, size_t n, bool desc, bool use_library, std::vector
         if (desc) rank = (uint32_t)(runs - 1) - rank;
         r[i] = (rank << idx_bits) | (uint32_t)i;
       }
+      // The heap only ever compares ranks, so the permutation is a pure function of this (rank, index) array -- and a spinning
+      // sensor that delivers every point of every column repeats it sweep after sweep (same columns, same rings): the last
+      // array and its permutation are remembered (per thread: one sensor stream per thread), a repeat costs one comparison of
+      // 4 n bytes instead of the heap sort (64k points: 10 us instead of 1.5 ms).
+      thread_local std::vector<uint32_t> memo_in, memo_out;
+      if (memo_in.size() == n && std::memcmp(memo_in.data(), r.data(), n * sizeof(uint32_t)) == 0) {
+        std::memcpy(order.data(), memo_out.data(), n * sizeof(uint32_t));
+        return;
+      }
+      memo_in = r;
       heap_order(r.data(), (ptrdiff_t)n, LessPacked32{idx_bits});
       const uint32_t mask = ((uint32_t)1 << idx_bits) - 1u;
       for (size_t i = 0; i < n; i++) order[i] = r[i] & mask;
+      memo_out.assign(order.begin(), order.end());
       return;
     }
   }
@@ -1102,11 +1113,16 @@ int Localizer::deskewOnDevice(pcl::PointCloud<PointType>::Ptr& raw_pc, double st
   const auto& fl = config.filters;
   const auto& mc = config.ikfom.mapping;
   const size_t n = raw_pc->points.size();
-  const bool caps = (mc.MAX_NUM_PC2MATCH >= 0 && n > (size_t)mc.MAX_NUM_PC2MATCH) || (mc.MAX_NUM_MATCHES >= 0 && n > (size_t)mc.MAX_NUM_MATCHES);
-  if (!gpu_filters || !lazy_time_order || download_clouds || config.debug || fl.fov_active || fl.voxel_active || caps) return 0;
+  dev_front_end_ = false;
+  if (!gpu_filters || !lazy_time_order || fl.fov_active) return 0;
   if (sensor != SensorType::OUSTER && sensor != SensorType::VELODYNE && sensor != SensorType::HESAI && sensor != SensorType::LIVOX) return 0;
   flimo_ctx* c = map_->ctx();
   if (!c) return 0;
+  // WHO needs the reference's time order on the device?  "The first N of pc2match" (MAX_NUM_PC2MATCH / MAX_NUM_MATCHES) and the
+  // float sums of the voxel grid.  It is produced there when the stamps are pairwise different (a radix sort gives the unique
+  // sorted order); with equal stamps only the host routine reproduces the library's order: host path.
+  const bool caps = (mc.MAX_NUM_PC2MATCH >= 0 && n > (size_t)mc.MAX_NUM_PC2MATCH) || (mc.MAX_NUM_MATCHES >= 0 && n > (size_t)mc.MAX_NUM_MATCHES);
+  const bool need_order = caps || fl.voxel_active;
   flimo_filter_cfg fc;
   std::memset(&fc, 0, sizeof(fc));
   fc.crop_active = fl.crop_active ? 1 : 0;
@@ -1118,12 +1134,16 @@ int Localizer::deskewOnDevice(pcl::PointCloud<PointType>::Ptr& raw_pc, double st
   fc.sweep_ref_time = start_time;
   size_t kept = 0;
   double last_stamp = 0.0;
-  int nan = 0;
+  int nan = 0, tied = 0;
   static_assert(sizeof(PointType) == 32, "PointType layout");
-  if (flimo_raw_scan_filter_set(c, &raw_pc->points[0], n, &fc, &kept, &last_stamp, &nan) != FLIMO_OK || nan) return 0;
+  if (flimo_raw_scan_filter_order_set(c, &raw_pc->points[0], n, &fc, need_order ? 1 : 0, &kept, &last_stamp, &nan, &tied) != FLIMO_OK || nan || tied)
+    return 0;
   lazy_order_.clear();
-  arrival_order_ = true;
-  pc2match = fast_limo::make_shared<pcl::PointCloud<PointType>>();      // no host copy was asked for
+  arrival_order_ = !need_order;
+  dev_front_end_ = true;
+  dev_time_ordered_ = need_order;
+  dev_voxel_ = false;
+  pc2match = fast_limo::make_shared<pcl::PointCloud<PointType>>();      // put together after the update when somebody wants it
   if (kept < 1) return -1;
   double offset = 0.0;
   if (config.time_offset) {
@@ -1152,9 +1172,147 @@ int Localizer::deskewOnDevice(pcl::PointCloud<PointType>::Ptr& raw_pc, double st
   xs.to_flat(x26);
   rs_frames_.assign(fr.begin(), fr.end());
   compat::to_row_major(extr.lidar2baselink_T, rs_l2b_);
-  const int rc = flimo_deskew_resident_offset(c, rs_frames_.data(), rs_frames_.size(), rs_l2b_, x26, offset);
+  int rc = flimo_deskew_resident_offset(c, rs_frames_.data(), rs_frames_.size(), rs_l2b_, x26, offset);
   if (rc != FLIMO_OK) { std::cout << "FAST_LIMO::deskew failed: " << flimo_last_error(c) << "\n"; return -1; }
+  if (fl.voxel_active) {                                          // VoxelGrid (:313-321) on the resident scan, in time order
+    size_t nv = 0;
+    rc = flimo_scan_voxel_filter(c, fl.leafSize[0], &nv);
+    if (rc != FLIMO_OK) { std::cout << "FAST_LIMO::voxel filter failed: " << flimo_last_error(c) << "\n"; return -1; }
+    dev_voxel_ = true;
+  }
   return 1;
+}
+
+// Input filters of updatePointCloud in ONE pass over the raw cloud: removeNaNFromPointCloud (Localizer.cpp:263-265), negative
+// CropBox (:268-271), distance / rate / FoV filters (:274-302).  As in the reference, *raw_pc itself ends up NaN-free and cropped
+// (both filters write back into it), and the rate filter counts positions in that cropped cloud.
+void Localizer::filterInput(pcl::PointCloud<PointType>::Ptr& raw_pc, pcl::PointCloud<PointType>::Ptr& input_pc) {
+  std::vector<PointType>& P = raw_pc->points;
+  const bool crop = config.filters.crop_active, dist = config.filters.dist_active;
+  const bool rate_on = config.filters.rate_active && config.filters.rate_value >= 1;   // (the reference divides by the value)
+  const bool fov = config.filters.fov_active;
+  const float mn0 = crop ? config.filters.cropBoxMin[0] : 0.f, mn1 = crop ? config.filters.cropBoxMin[1] : 0.f,
+              mn2 = crop ? config.filters.cropBoxMin[2] : 0.f;
+  const float mx0 = crop ? config.filters.cropBoxMax[0] : 0.f, mx1 = crop ? config.filters.cropBoxMax[1] : 0.f,
+              mx2 = crop ? config.filters.cropBoxMax[2] : 0.f;
+  const float min_dist = (float)config.filters.min_dist;
+  const float fov_angle = config.filters.fov_angle;
+  const long rate = config.filters.rate_value;
+  const size_t n = P.size();
+  std::vector<PointType>& Q = input_pc->points;
+  Q.resize(n);                                   // upper bound; trimmed below (no per-point capacity checks)
+  size_t k = 0, m = 0;
+  long phase = 0;                                // k % rate without a division per point
+  // Branches on the data itself (which side of the crop box, nearer than min_dist) mispredict on every other point of a
+  // real sweep; the tests are evaluated without short-circuit and only their rarely-true combination is branched on, the
+  // kept points are stored unconditionally and the output cursor advances by the verdict.
+  for (size_t i = 0; i < n; i++) {
+    const PointType p = P[i];
+    const bool finite = std::isfinite(p.x) & std::isfinite(p.y) & std::isfinite(p.z);
+    const bool outside = (p.x < mn0) | (p.y < mn1) | (p.z < mn2) | (p.x > mx0) | (p.y > mx1) | (p.z > mx2);   // not strictly inside the box
+    if (!(finite & (!crop | outside))) continue;
+    if (k != i) P[k] = p;
+    const bool pick = !rate_on || phase == 0;
+    if (rate_on && ++phase == rate) phase = 0;
+    k++;
+    if (!pick) continue;
+    bool keep = true;
+    if (fov) keep = std::fabs(std::atan2(p.y, p.x)) < fov_angle;                          // isInRange (:873-876)
+    if (dist) keep = keep & (std::sqrt(s3(p.x * p.x, p.y * p.y, p.z * p.z)) > min_dist);
+    Q[m] = p;
+    m += keep ? 1 : 0;
+  }
+  P.resize(k);
+  Q.resize(m);
+  raw_pc->is_dense = true;
+}
+
+// Device front end: the clouds the caller may ask for (get_pointcloud(), get_pc2match_pointcloud(), with `debug` get_orig_pointcloud())
+// are put together AFTER the update -- the filter's mutex is free, the pose is out -- from the device's buffers and the host copy of
+// the sweep: the same input filters on the host copy (which also leaves *raw_pc filtered in place, as the reference does), the
+// order of the kept points from the device (its time order, or -- a sweep left in arrival order -- the host's time order routine).
+void Localizer::materializeClouds(pcl::PointCloud<PointType>::Ptr& raw_pc) {
+  flimo_ctx* c = map_->ctx();
+  if (!c) return;
+  static const bool prof = std::getenv("FLIMO_PROF_CLOUDS") != nullptr;     // developer timing of the stages
+  const double tp0 = prof ? now_s() : 0.0;
+  auto input_pc = fast_limo::make_shared<pcl::PointCloud<PointType>>();
+  filterInput(raw_pc, input_pc);
+  if (config.debug) original_scan = fast_limo::make_shared<pcl::PointCloud<PointType>>(*input_pc);
+  const size_t m = input_pc->points.size();
+  if (last_status_ != 0 || m == 0) { pc2match = fast_limo::make_shared<pcl::PointCloud<PointType>>(); return; }
+  const double tp1 = prof ? now_s() : 0.0;
+  // pc2match position -> index in input_pc
+  std::vector<uint32_t>& order = lazy_order_;
+  if (dev_time_ordered_) {
+    order.resize(m);
+    size_t got = 0;
+    flimo_raw_scan_order(c, order.data(), m, &got);
+    if (got != m) { std::cout << "FAST_LIMO::WARNING: device and host input filters disagree (" << got << " vs " << m << " points)\n"; return; }
+  } else {
+    const std::vector<PointType>& P = input_pc->points;
+    const bool desc = config.end_of_sweep && (sensor == SensorType::OUSTER || sensor == SensorType::VELODYNE);
+    if (sensor == SensorType::OUSTER) {
+      std::vector<uint32_t> k(m);
+      for (size_t i = 0; i < m; i++) k[i] = P[i].t;
+      time_order(k.data(), 0, m, desc, false, order);
+    } else if (sensor == SensorType::VELODYNE) {
+      std::vector<float> k(m);
+      for (size_t i = 0; i < m; i++) k[i] = P[i].time;
+      time_order(k.data(), 1, m, desc, false, order);
+    } else {
+      std::vector<double> k(m);
+      for (size_t i = 0; i < m; i++) k[i] = P[i].timestamp;
+      time_order(k.data(), 2, m, desc, false, order);
+    }
+  }
+  const double tp2 = prof ? now_s() : 0.0;
+  const size_t n_dev = flimo_scan_size(c);                       // resident pc2match: the deskewed points, or the voxel centroids
+  mat_body_.resize(n_dev * 3); mat_world_.resize(n_dev * 3);
+  size_t got = 0;
+  flimo_scan_get(c, mat_body_.data(), n_dev, &got);
+  double x26[26];
+  mtx_ikfom.lock();
+  ikfom_->get_x().to_flat(x26);
+  mtx_ikfom.unlock();
+  flimo_scan_to_world(c, x26, mat_world_.data(), n_dev);
+  const double tp3 = prof ? now_s() : 0.0;
+  const float* body = mat_body_.data();
+  const float* world = mat_world_.data();
+  // (the storage of the last sweep's clouds is taken over when the caller has let go of them: no fresh pages to fault in)
+  if (pc2match == mat_pm_) pc2match.reset();
+  if (final_scan == mat_fs_) final_scan.reset();
+  pcl::PointCloud<PointType>::Ptr pm = (mat_pm_ && mat_pm_.use_count() == 1) ? mat_pm_ : fast_limo::make_shared<pcl::PointCloud<PointType>>();
+  pcl::PointCloud<PointType>::Ptr fs = (mat_fs_ && mat_fs_.use_count() == 1) ? mat_fs_ : fast_limo::make_shared<pcl::PointCloud<PointType>>();
+  pm->points.resize(n_dev);
+  fs->points.resize(n_dev);
+  if (dev_voxel_) {
+    for (size_t k = 0; k < n_dev; k++) {
+      PointType p{};
+      p.x = body[3 * k]; p.y = body[3 * k + 1]; p.z = body[3 * k + 2];
+      pm->points[k] = p;
+      p.x = world[3 * k]; p.y = world[3 * k + 1]; p.z = world[3 * k + 2];
+      fs->points[k] = p;
+    }
+  } else {
+    // device order: its time order (position k = input_pc[order[k]]) or arrival order (position j = input_pc[j], shown at rank k)
+    for (size_t k = 0; k < n_dev && k < m; k++) {
+      const size_t src = order[k];
+      const size_t dev = dev_time_ordered_ ? k : src;
+      PointType p = input_pc->points[src];
+      p.x = body[3 * dev]; p.y = body[3 * dev + 1]; p.z = body[3 * dev + 2];
+      pm->points[k] = p;
+      p.x = world[3 * dev]; p.y = world[3 * dev + 1]; p.z = world[3 * dev + 2];
+      fs->points[k] = p;
+    }
+  }
+  mat_pm_.reset(); mat_fs_.reset();
+  pc2match = pm;
+  final_scan = fs;
+  mat_pm_ = pm; mat_fs_ = fs;
+  if (prof)
+    fprintf(stderr, "[flimo clouds] input filters %.0f us, order %.0f us, downloads %.0f us, assembly %.0f us (%zu -> %zu points, %zu resident)\n",
+            (tp1 - tp0) * 1e6, (tp2 - tp1) * 1e6, (tp3 - tp2) * 1e6, (now_s() - tp3) * 1e6, raw_pc->points.size(), m, n_dev);
 }
 
 // Benchmark entry (inputs resident in HBM): restores the given prior, then GPU deskew of the
@@ -1186,61 +1344,19 @@ void Localizer::updatePointCloud(pcl::PointCloud<PointType>::Ptr& raw_pc, double
   if (!imu_calibrated_) { last_status_ = -2; return; }
   if (imu_buffer.empty()) { std::cout << "FAST_LIMO::IMU buffer is empty!\n"; last_status_ = -3; return; }
   const double t0_dev = now_s();
-  const int on_device = deskewOnDevice(raw_pc, time_stamp);            // filters + stamps + deskew on the GPU when nothing needs host clouds
+  const int on_device = deskewOnDevice(raw_pc, time_stamp);            // filters + stamps (+ time order, voxel grid) + deskew on the GPU
   if (on_device != 0) {
     const double t2d = now_s();
     finishUpdate(on_device > 0, t0_dev, t0_dev, t2d);
+    if (download_clouds || config.debug) {
+      const double tm0 = now_s();
+      materializeClouds(raw_pc);
+      stage_t_[0] = now_s() - tm0;                                       // (host work of this path: the clouds, after the pose)
+    }
     return;
   }
-  // removeNaNFromPointCloud (:263-265), negative CropBox (:268-271) and the distance / rate / FoV filters (:274-302) in ONE
-  // pass over the raw cloud.  As in the reference, *raw_pc itself ends up NaN-free and cropped (both filters write back
-  // into it), and the rate filter counts positions in that cropped cloud.
   auto input_pc = fast_limo::make_shared<pcl::PointCloud<PointType>>();
-  {
-    std::vector<PointType>& P = raw_pc->points;
-    const bool crop = config.filters.crop_active, dist = config.filters.dist_active;
-    const bool rate_on = config.filters.rate_active && config.filters.rate_value >= 1;   // (the reference divides by the value)
-    const bool fov = config.filters.fov_active;
-    const float mn0 = crop ? config.filters.cropBoxMin[0] : 0.f, mn1 = crop ? config.filters.cropBoxMin[1] : 0.f,
-                mn2 = crop ? config.filters.cropBoxMin[2] : 0.f;
-    const float mx0 = crop ? config.filters.cropBoxMax[0] : 0.f, mx1 = crop ? config.filters.cropBoxMax[1] : 0.f,
-                mx2 = crop ? config.filters.cropBoxMax[2] : 0.f;
-    const float min_dist = (float)config.filters.min_dist;
-    const float fov_angle = config.filters.fov_angle;
-    const long rate = config.filters.rate_value;
-    const size_t n = P.size();
-    std::vector<PointType>& Q = input_pc->points;
-    static const bool prof_prep = std::getenv("FLIMO_PROF_PREP") != nullptr;
-    const double tq0 = prof_prep ? now_s() : 0.0;
-    Q.resize(n);                                   // upper bound; trimmed below (no per-point capacity checks)
-    const double tq1 = prof_prep ? now_s() : 0.0;
-    size_t k = 0, m = 0;
-    long phase = 0;                                // k % rate without a division per point
-    // Branches on the data itself (which side of the crop box, nearer than min_dist) mispredict on every other point of a
-    // real sweep; the tests are evaluated without short-circuit and only their rarely-true combination is branched on, the
-    // kept points are stored unconditionally and the output cursor advances by the verdict.
-    for (size_t i = 0; i < n; i++) {
-      const PointType p = P[i];
-      const bool finite = std::isfinite(p.x) & std::isfinite(p.y) & std::isfinite(p.z);
-      const bool outside = (p.x < mn0) | (p.y < mn1) | (p.z < mn2) | (p.x > mx0) | (p.y > mx1) | (p.z > mx2);   // not strictly inside the box
-      if (!(finite & (!crop | outside))) continue;
-      if (k != i) P[k] = p;
-      const bool pick = !rate_on || phase == 0;
-      if (rate_on && ++phase == rate) phase = 0;
-      k++;
-      if (!pick) continue;
-      bool keep = true;
-      if (fov) keep = std::fabs(std::atan2(p.y, p.x)) < fov_angle;                          // isInRange (:873-876)
-      if (dist) keep = keep & (std::sqrt(s3(p.x * p.x, p.y * p.y, p.z * p.z)) > min_dist);
-      Q[m] = p;
-      m += keep ? 1 : 0;
-    }
-    const double tq2 = prof_prep ? now_s() : 0.0;
-    P.resize(k);
-    Q.resize(m);
-    raw_pc->is_dense = true;
-    if (prof_prep) fprintf(stderr, "[flimo prep] resize %.0f us, loop %.0f us, trim %.0f us (n = %zu -> %zu -> %zu)\n", (tq1 - tq0) * 1e6, (tq2 - tq1) * 1e6, (now_s() - tq2) * 1e6, n, k, m);
-  }
+  filterInput(raw_pc, input_pc);
   if (config.debug) original_scan = fast_limo::make_shared<pcl::PointCloud<PointType>>(*input_pc);
   const double t1 = now_s();
   bool ok = (bool)deskewPointCloud(input_pc, time_stamp);       // sets pc2match (:307)
@@ -1284,7 +1400,7 @@ void Localizer::finishUpdate(bool ok, double t0, double t1, double t2) {
     t3 = now_s();
     extr.lidar2baselink_T = state.get_extr_RT();                   // :356
     // transformPointCloud(pc2match -> final_scan) (:361-371) + Mapper::add (:377)
-    if (download_clouds) {
+    if (download_clouds && !dev_front_end_) {                       // (device front end: materializeClouds, after this)
       const size_t n = flimo_scan_size(c);
       std::vector<float> w(n * 3);
       flimo_scan_to_world(c, x26, w.data(), n);

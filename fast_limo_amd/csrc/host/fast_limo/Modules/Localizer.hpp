@@ -66,7 +66,8 @@ class fast_limo::Localizer {
   double prof_[4] = {0, 0, 0, 0};
   bool add_to_map = true;               // benchmarks may freeze the map
   bool download_clouds = true;          // keep pc2match / final_scan host copies up to date
-  bool gpu_filters = true;              // input filters + stamps on the GPU when the sweep may stay in arrival order and no host clouds are wanted
+  bool gpu_filters = true;              // input filters + stamps (+ time order, when the stamps are pairwise different) on the GPU; the clouds
+                                        // the caller gets are then put together AFTER the update (materializeClouds)
   double propagation_wait_s = -1.0;     // propagatedFromTimeRange: < 0 waits for the IMU stream without bound (the reference,
                                         // Localizer.cpp:859-863); >= 0 gives up after that many seconds (single-threaded drivers)
   bool lazy_time_order = true;          // the GPU gets the sweep in arrival order whenever the time order is not observable through
@@ -85,6 +86,8 @@ class fast_limo::Localizer {
   pcl::PointCloud<PointType>::Ptr deskewPointCloud(pcl::PointCloud<PointType>::Ptr& pc, double& start_time);   // Localizer.hpp:191
   int deskewOnDevice(pcl::PointCloud<PointType>::Ptr& raw_pc, double start_time);       // filters + stamps + deskew on the GPU (f-2)
   void finishUpdate(bool ok, double t0, double t1, double t2);
+  void filterInput(pcl::PointCloud<PointType>::Ptr& raw_pc, pcl::PointCloud<PointType>::Ptr& input_pc);   // Localizer.cpp:262-302 in one pass
+  void materializeClouds(pcl::PointCloud<PointType>::Ptr& raw_pc);     // device front end: host clouds after the update
   bool propagatedFromTimeRange(double start_time, double end_time, States& frames);
   bool imuMeasFromTimeRange(double start_time, double end_time, std::vector<IMUmeas>& meas);   // Localizer.cpp:917-949, oldest first
   bool isInRange(const PointType& p);
@@ -116,6 +119,11 @@ class fast_limo::Localizer {
   std::vector<flimo_frame> rs_frames_;  // frames of the resident raw scan
   std::vector<uint32_t> lazy_order_;    // arrival-order sweeps: pc2match position -> arrival index (empty: device order = pc2match order)
   bool arrival_order_ = false, arrival_keys_pending_ = false;
+  bool dev_front_end_ = false;          // the last sweep went through the device front end (clouds materialized afterwards)
+  bool dev_time_ordered_ = false;       // ... and the device holds it in the reference's time order (stamps pairwise different)
+  bool dev_voxel_ = false;
+  std::vector<float> mat_body_, mat_world_;   // download staging of materializeClouds
+  pcl::PointCloud<PointType>::Ptr mat_pm_, mat_fs_;   // the clouds it handed out last (their storage is reused once the caller let go)
   size_t arrival_last_ = 0;             // index of the point the reference's sort would put last
   float rs_l2b_[16];
   int calib_n_ = 0;

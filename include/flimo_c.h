@@ -138,6 +138,14 @@ typedef struct flimo_filter_cfg {
 } flimo_filter_cfg;
 int flimo_raw_scan_filter_set(flimo_ctx* ctx, const void* points32, size_t n, const flimo_filter_cfg* cfg, size_t* n_kept,
                               double* last_stamp, int* nan_stamp);
+/* The same, and with time_order != 0 the kept points are put into the order of the reference's time sort (std::partial_sort_copy by
+ * stamp, Localizer.cpp:789-790) on the device: the order MAX_NUM_PC2MATCH / MAX_NUM_MATCHES ("the first N of pc2match") and the
+ * voxel grid's float sums are defined in.  That order is unique -- a stable radix sort gives it -- when no two kept stamps are
+ * equal; with equal stamps it is the library's heap moves', *tied = 1 is returned, nothing is made resident, and the caller takes
+ * the host routine.  flimo_raw_scan_order: time rank -> position among the kept points (for the clouds handed back to callers). */
+int flimo_raw_scan_filter_order_set(flimo_ctx* ctx, const void* points32, size_t n, const flimo_filter_cfg* cfg, int time_order,
+                                    size_t* n_kept, double* last_stamp, int* nan_stamp, int* tied);
+int flimo_raw_scan_order(flimo_ctx* ctx, uint32_t* order_out, size_t cap, size_t* n);
 /* flimo_deskew_resident with the sweep's time offset added to every resident stamp (Localizer.cpp:795-800) */
 int flimo_deskew_resident_offset(flimo_ctx* ctx, const flimo_frame* frames, size_t n_frames, const float lidar2baselink_T[16],
                                  const double last_x26[26], double t_offset);
