@@ -295,6 +295,59 @@ def test_per_scan_parity_along_a_drive_from_identical_state(built, oracle):
     G.close()
 
 
+def test_device_time_order_front_end_equals_host_front_end(built):
+    """The reference's shipped configuration needs the sweep in TIME order before the registration sees it: the voxel grid sums
+    floats in that order and MAX_NUM_PC2MATCH keeps "the first N".  With pairwise different stamps the device produces that order
+    itself (stable radix sort of the stamp keys: the sorted order is unique), so filters, stamps, time order, deskew, voxel grid and
+    caps all run on the GPU and the clouds are put together after the update; the host front end (one-pass filters, the library's
+    partial_sort_copy restated, upload) must give the SAME pose, covariance, map and clouds, bit for bit.  With equal stamps
+    (columns of a spinning sensor) the device declines and both runs take the host routine."""
+    from fast_limo_amd import api
+    from common import sort_rows
+    n_scans, n_pts, speed = 6, 40000, 10.0
+    st, w, a = synth.stationary_imu(0.0, 0.1 * n_scans + 0.06)
+    common = dict(MAX_NUM_PC2MATCH=3000, MAX_NUM_MATCHES=2000, voxel_active=1, leaf_size=0.5, crop_active=1, dist_active=1, min_dist=2.0,
+                  rate_active=1, rate_value=3, time_offset=1, cropBoxMin=(-1.0, -1.0, -1.0), cropBoxMax=(1.0, 1.0, 1.0))
+
+    def drive(gpu_front_end, tied, shuffle):
+        G = api.Localizer(api.default_cfg(**common))
+        G.set_gpu_filters(gpu_front_end)
+        G.set_flags(add_to_map=True, download_clouds=True)
+        x0 = G.get_x(); x0[14] = speed; G.set_x(x0)
+        i = 0
+        out = []
+        rs = np.random.RandomState(7)
+        for k in range(n_scans):
+            until = 0.1 * (k + 1) + 0.005
+            while i < len(st) and st[i] <= until:
+                G.update_imu(st[i], w[i], a[i]); i += 1
+            scan = synth.corridor_scan(k, n_pts, 1234, speed=speed)
+            if tied:
+                scan[:, 4] = np.floor(scan[:, 4] * 5120.0) / np.float32(5120.0)
+            if shuffle:
+                scan = scan[rs.permutation(n_pts)]                   # arrival order is NOT time order: the sort has work to do
+            rc = G.update_pointcloud(scan, 0.1 * k)
+            out.append(dict(rc=rc, x=G.get_x(), P=G.get_P(), n=G.map_size(), pc=G.pc2match(), fs=G.final_scan() if rc == 0 else None))
+        G.sync()
+        pts = sort_rows(G.hip.map_points())
+        G.close()
+        return out, pts
+
+    for tied, shuffle in ((False, False), (False, True), (True, False)):
+        dev, m_dev = drive(True, tied, shuffle)
+        host, m_host = drive(False, tied, shuffle)
+        for k in range(n_scans):
+            assert dev[k]["rc"] == host[k]["rc"], k
+            np.testing.assert_array_equal(dev[k]["x"], host[k]["x"], err_msg=f"x scan {k} tied {tied} shuffled {shuffle}")
+            np.testing.assert_array_equal(dev[k]["P"], host[k]["P"], err_msg=f"P scan {k}")
+            assert dev[k]["n"] == host[k]["n"]
+            np.testing.assert_array_equal(dev[k]["pc"], host[k]["pc"], err_msg=f"pc2match scan {k} tied {tied} shuffled {shuffle}")
+            if dev[k]["fs"] is not None:
+                np.testing.assert_array_equal(dev[k]["fs"], host[k]["fs"], err_msg=f"final scan {k}")
+        np.testing.assert_array_equal(m_dev, m_host)
+        assert dev[-1]["pc"].shape[0] > 3000 and dev[-1]["n"] > 3000         # the voxel grid's cloud is larger than MAX_NUM_PC2MATCH: the cap binds
+
+
 def test_arrival_order_path_equals_sorted_path(built):
     """Tied stamps (all rings of a column share one): the reference's std::partial_sort_copy decides their order with a sequential
     heap sort.  When no cap can bind and the voxel grid is off that order is not observable by the registration, so the GPU gets
