@@ -49,7 +49,7 @@ def pmc_traffic(queries_per_launch):
     in separate passes of this same command, FETCH_SIZE doubled per MI355X_MICROARCH.md).  PMC counters cannot be collected
     from inside the run; the profile carries the hash of the kernel sources it was taken with and is only reported when that is
     the hash of the sources in the tree (and the launch shape is the benchmark's)."""
-    f = os.path.join(ROOT, "profiles", "r02", "pmc_fetch_write_per_kernel.json")
+    f = os.path.join(ROOT, "profiles", "r03", "pmc_fetch_write_per_kernel.json")
     try:
         from fast_limo_amd import build as b
         d = json.load(open(f))
@@ -165,16 +165,19 @@ HBM_REGIME = dict(rings=128, azimuths=2048, map_points=20000000, box=447.0)     
 
 
 def pmc_traffic_hbm_regime():
-    """HBM-side bytes per launch of the pass kernel at 256k x 20M from the committed PMC profile (same rule as pmc_traffic)."""
+    """HBM-side bytes per launch at 256k x 20M from the committed PMC profile (same rule as pmc_traffic): the one-launch pass and
+    the k-NN kernel of the passes that run as separate dispatches."""
     f = os.path.join(ROOT, "profiles", "r03", "pmc_hbm_regime.json")
     try:
         from fast_limo_amd import build as b
         d = json.load(open(f))
         if d.get("sources_hash") != b.sources_hash():
-            return None
-        return d["dominant_kernel_traffic_bytes_per_launch"]["total_corrected"]
+            return None, None
+        one = d.get("dominant_kernel_traffic_bytes_per_launch", {}).get("total_corrected")
+        knn = d.get("knn5_separate_traffic_bytes_per_launch", {}).get("total_corrected")
+        return one, knn
     except Exception:
-        return None
+        return None, None
 
 
 def hbm_regime_leg(device, steps, with_oracle, max_threads=32):
@@ -266,10 +269,15 @@ def hbm_regime_leg(device, steps, with_oracle, max_threads=32):
                                                     "passes_timed": ds["separate_n"], "stage_us_per_pass": knn_us + widen_us,
                                                     "achieved": rate(knn_us + widen_us), "frac": rate(knn_us + widen_us) / HBM_PEAK_GBPS,
                                                     "knn_kernel_frac": rate(knn_us) / HBM_PEAK_GBPS}
-        traffic = pmc_traffic_hbm_regime()
+        traffic, traffic_knn = pmc_traffic_hbm_regime()
         out["traffic"] = traffic
         out["traffic_over_algorithmic"] = (traffic / alg) if traffic else None
         out["hbm_utilisation_measured"] = (traffic / (one * 1e-6) / 1e9 / HBM_PEAK_GBPS) if (traffic and one) else None
+        if ds["separate_n"] and traffic_knn:
+            ks = out["knn_stage_separate_dispatches"]
+            ks["knn_kernel_traffic"] = traffic_knn
+            ks["knn_kernel_traffic_over_algorithmic"] = traffic_knn / alg
+            ks["knn_kernel_hbm_utilisation_measured"] = traffic_knn / (ks["knn_us"] * 1e-6) / 1e9 / HBM_PEAK_GBPS
         out["unit"], out["peak"], out["bound"] = "GB/s", HBM_PEAK_GBPS, "hbm"
     loc.close()
     return out

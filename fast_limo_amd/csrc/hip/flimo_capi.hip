@@ -42,7 +42,6 @@ struct flimo_ctx {
   float4* d_map_sorted2 = nullptr; // the other half of the double buffer of the incremental merge (lazy)
   float gbox[6] = {0, 0, 0, 0, 0, 0};   // box the grid geometry was laid out for (the map box plus slack on the sides that grew)
   bool have_gbox = false;
-  unsigned heavy_threshold = 0xffffffffu; // FLIMO_HEAVY=<n>: a query whose 3x3x3 block holds more than n candidates goes to the wave-per-query kernel (default: never)
   bool force_full = false;         // the next index update lays the grid out afresh (cell size changed)
   bool full_rebuild = false;       // FLIMO_FULL_REBUILD=1: sort the whole map on every insert (A/B of the merge)
   uint64_t grid_merges = 0, grid_builds = 0;
@@ -108,7 +107,6 @@ struct flimo_ctx {
   double* h_granules = nullptr;    // pinned + mapped: [FIT_GROUPS][FIT_LIVE_PAD] x {sum, pass number}
   double* d_granules_host = nullptr;
   unsigned char live_idx[FIT_LIVE_PAD];   // live sum k -> raw MFMA accumulator index (from the calibrated layout)
-  bool fit2 = true;                // FLIMO_FIT2=0: the fast path uses fit_kernel (A/B checks)
   bool fuse = true;                // FLIMO_FUSE=0: k-NN and fit stay separate dispatches in every pass (A/B checks)
   unsigned long long fused_passes = 0;
   unsigned long long pass_seq = 0;  // last pass number published by the fit kernel
@@ -281,6 +279,51 @@ static void pose_from_x26(const double x[26], PoseMats& P) {
   for (int i = 0; i < 9; i++) { P.R_inv[i] = (float)Rd[i]; P.RLI_inv[i] = (float)Ld[i]; }
 }
 
+// ---- developer switches: every environment variable this library reads, in one place ------------------------------------------
+// None of them changes a result (the parity tests run under several of them); they exist for A/B measurements and fault isolation.
+//   FLIMO_LPQ=<1|2|4|8|16|32>     lanes of a wavefront per scan point in the k-NN kernel (2; other values run the separate-dispatch pass)
+//   FLIMO_FUSE=0                  k-NN and fit stay separate dispatches in every pass (default: the whole pass is one launch)
+//   FLIMO_TAIL=0                  pending queries always go to the worklist + widening dispatch instead of the in-kernel tail
+//   FLIMO_TAIL_PASS1=<0|1>        the first pass of a scan never / always uses the in-kernel tail (default: by the straggler count the
+//                                 last scan's first pass published)
+//   FLIMO_TAIL_MAX=<n>            most stragglers the pass at the same position of the last scan may have published for a pass to
+//                                 finish its own in-kernel (default max(1024, queries / 64))
+//   FLIMO_PRUNE=0                 no pruning by the previous pass's bound
+//   FLIMO_PROBE=<n>               first pass: a query with >= n candidates in its 3x3x3 block walks its own cell first (96; 0: off)
+//   FLIMO_TIES=0                  exact distance ties keep the position rule (default: the reference's first-met rule, tie_kernel)
+//   FLIMO_GENERAL_K=1             NUM_MATCH_POINTS == 5 also takes the general (any-k) pass
+//   FLIMO_FINE=0, FLIMO_FINE_THRESHOLD=<points per cell, 64>, FLIMO_FINE_DIV=<2|4|8, 4>, FLIMO_FINE_RADIUS=<m, 24>,
+//   FLIMO_FINE_MIN_POINTS=<32768>  second-level grid over crowded regions
+//   FLIMO_XSLABS=<1|2|4|8>        fine x columns per cell in the index tables (1)
+//   FLIMO_XCD_STRIPE=<chunks>     block -> scan chunk striping over the XCDs (8)
+//   FLIMO_FULL_REBUILD=1          the index is sorted from scratch on every insert (default: merged)
+//   FLIMO_HOST_INSERT=1           the first batch goes through the host statement of the insert rule, then is imported
+//   FLIMO_PROF_PASS / FLIMO_PROF_INSERT   host-side timing prints (stderr)
+// (csrc/host: FLIMO_REFERENCE_SOLVE=1 literal two-inverse gain, FLIMO_SYNC_INSERT=1 map inserts on the caller's thread,
+//  FLIMO_PROF_DESKEW / FLIMO_PROF_CLOUDS timing prints; bench.py: FLIMO_BENCH_*.)
+static void load_dev_switches(flimo_ctx* c) {
+  auto env_int = [](const char* name, int& out) { const char* e = getenv(name); if (!e) return false; out = atoi(e); return true; };
+  int v = 0;
+  if (env_int("FLIMO_LPQ", v) && (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32)) c->lanes_per_query = v;
+  if (env_int("FLIMO_FUSE", v)) c->fuse = v != 0;
+  if (env_int("FLIMO_TAIL", v)) c->tail = v != 0;
+  if (env_int("FLIMO_TAIL_PASS1", v)) c->tail_pass1 = v != 0;
+  if (env_int("FLIMO_TAIL_MAX", v) && v > 0) c->tail_max = v;
+  if (env_int("FLIMO_PRUNE", v)) c->prune = v != 0;
+  if (env_int("FLIMO_PROBE", v) && v >= 0) c->probe_min = (unsigned)v;
+  if (env_int("FLIMO_TIES", v)) c->ties = v != 0;
+  if (env_int("FLIMO_GENERAL_K", v)) c->force_general_k = v != 0;
+  if (env_int("FLIMO_FINE", v)) c->fine_on = v != 0;
+  if (env_int("FLIMO_FINE_THRESHOLD", v) && v > 0) c->fine_threshold = (unsigned)v;
+  if (env_int("FLIMO_FINE_DIV", v) && (v == 2 || v == 4 || v == 8)) c->fine_div = v;
+  if (env_int("FLIMO_FINE_MIN_POINTS", v) && v >= 0) c->fine_min_points = (unsigned)v;
+  { const char* e = getenv("FLIMO_FINE_RADIUS"); if (e && atof(e) > 0) c->fine_radius = (float)atof(e); }
+  if (env_int("FLIMO_XSLABS", v) && (v == 1 || v == 2 || v == 4 || v == 8)) c->xslabs = v;
+  if (env_int("FLIMO_XCD_STRIPE", v)) set_xcd_stripe(v);
+  if (env_int("FLIMO_FULL_REBUILD", v)) c->full_rebuild = v != 0;
+  if (env_int("FLIMO_HOST_INSERT", v)) c->host_insert = v != 0;
+}
+
 // ---- context ----------------------------------------------------------------------------------
 extern "C" const char* flimo_version(void) { return "fast_limo_amd 0.1.0 (gfx950)"; }
 
@@ -338,47 +381,8 @@ extern "C" int flimo_ctx_create(int device, flimo_ctx** out) {
     c->live_idx[k++] = (unsigned char)c->mfma_idx[13][13];
     for (; k < FIT_LIVE_PAD; k++) c->live_idx[k] = 0;
   }
-  const char* e = getenv("FLIMO_LPQ");
-  if (e) { int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) c->lanes_per_query = v; }
   c->book = insert_book_create();
-  e = getenv("FLIMO_PROBE");
-  if (e && atoi(e) >= 0) c->probe_min = (unsigned)atoi(e);
-  e = getenv("FLIMO_PRUNE");
-  if (e) c->prune = atoi(e) != 0;
-  e = getenv("FLIMO_FINE");
-  if (e) c->fine_on = atoi(e) != 0;
-  e = getenv("FLIMO_FINE_THRESHOLD");
-  if (e && atoi(e) > 0) c->fine_threshold = (unsigned)atoi(e);
-  e = getenv("FLIMO_FINE_RADIUS");
-  if (e && atof(e) > 0) c->fine_radius = (float)atof(e);
-  e = getenv("FLIMO_FINE_DIV");
-  if (e && (atoi(e) == 2 || atoi(e) == 4 || atoi(e) == 8)) c->fine_div = atoi(e);
-  e = getenv("FLIMO_FINE_MIN_POINTS");
-  if (e && atoi(e) >= 0) c->fine_min_points = (unsigned)atoi(e);
-  e = getenv("FLIMO_XSLABS");
-  if (e) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) c->xslabs = v; }
-  e = getenv("FLIMO_TIES");
-  if (e) c->ties = atoi(e) != 0;
-  e = getenv("FLIMO_GENERAL_K");
-  c->force_general_k = e && atoi(e) != 0;
-  e = getenv("FLIMO_TAIL_PASS1");
-  if (e) c->tail_pass1 = atoi(e) != 0;
-  e = getenv("FLIMO_TAIL_MAX");
-  if (e && atoi(e) > 0) c->tail_max = atoi(e);
-  e = getenv("FLIMO_FUSE");
-  if (e) c->fuse = atoi(e) != 0;
-  e = getenv("FLIMO_FIT2");
-  if (e) c->fit2 = atoi(e) != 0;
-  e = getenv("FLIMO_TAIL");
-  if (e) c->tail = atoi(e) != 0;
-  e = getenv("FLIMO_XCD_STRIPE");
-  if (e) set_xcd_stripe(atoi(e));
-  e = getenv("FLIMO_HOST_INSERT");
-  c->host_insert = e && atoi(e) != 0;
-  e = getenv("FLIMO_HEAVY");
-  if (e) { const long v = atol(e); c->heavy_threshold = v > 0 ? (unsigned)v : 0xffffffffu; }
-  e = getenv("FLIMO_FULL_REBUILD");
-  c->full_rebuild = e && atoi(e) != 0;
+  load_dev_switches(c);
   *out = c;
   return FLIMO_OK;
 }
@@ -1283,11 +1287,11 @@ extern "C" int flimo_timing_totals(flimo_ctx* c, double* knn_ms, double* widen_m
   return FLIMO_OK;
 }
 // developer / benchmark A/B: negative leaves a switch as it is
-extern "C" int flimo_set_path_switches(flimo_ctx* c, int tail, int fuse, int fit2) {
+extern "C" int flimo_set_path_switches(flimo_ctx* c, int tail, int fuse, int reserved) {
   if (!c) return FLIMO_ERR_INVALID;
+  (void)reserved;
   if (tail >= 0) c->tail = tail != 0;
   if (fuse >= 0) c->fuse = fuse != 0;
-  if (fit2 >= 0) c->fit2 = fit2 != 0;
   return FLIMO_OK;
 }
 extern "C" int flimo_timing_split(flimo_ctx* c, double out[6], int reset) {
@@ -1443,7 +1447,6 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   // level 1: the two events ride on the k-NN dispatch itself (kernel begin / end, no extra packets)
   // the k-NN launch finishes its own stragglers (in-kernel tail) for gates of up to 3 rings; the worklist + widening dispatch
   // remains for wider gates and for the developer switches (FLIMO_TAIL=0, FLIMO_HEAVY)
-  const bool heavy_on = c->heavy_threshold != 0xffffffffu;
   // First pass of a scan (no bound from a previous pass): with a poor prior whole waves of far-off points are pending at once,
   // and a wave finishing 32 such queries two lanes each is one long chain -- those are better spread over the chip by the
   // worklist dispatch.  With a good prior (the usual case in a sequence) the first pass has a handful of stragglers like any
@@ -1457,12 +1460,11 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   const int tail_max = c->tail_max > 0 ? c->tail_max : std::max(1024, n_all / 64);
   const bool tail_here = first_pass ? (c->tail_pass1 >= 0 ? c->tail_pass1 != 0 : c->stragglers_hist[0] <= tail_max)
                                     : (c->stragglers_hist[c->pass_in_scan] <= tail_max);
-  const bool tail = c->tail && tail_here && !heavy_on && mp.max_ring >= 2 && mp.max_ring <= 3;
+  const bool tail = c->tail && tail_here && mp.max_ring >= 2 && mp.max_ring <= 3;
   c->prev.probe_min = c->probe_min;
-  c->prev.heavy = (!tail && mp.max_ring >= 2 && mp.max_ring <= 3) ? c->heavy_threshold : 0xffffffffu;   // only when the wave-per-query kernel follows
   // One launch for the whole pass (k-NN + tail + fit + reduction) whenever the tail applies, no records are wanted and the
   // k-NN runs with its default two lanes per query
-  const bool fused = tail && c->fuse && c->fit2 && !want_recs && tlev < 2 && c->lanes_per_query == 2;
+  const bool fused = tail && c->fuse && !want_recs && tlev < 2 && c->lanes_per_query == 2;
   const unsigned long long seq = ++c->pass_seq;
   // exact distance ties: the reference's choice needs the octree's visiting order, i.e. the device insert book
   const bool ties_on = c->ties && c->gbook.active;
@@ -1500,7 +1502,7 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   // MAX_NUM_MATCHES path: the fit kernel only writes the records (no reduction), one fused kernel ranks them in scan
   // order, reduces the first MAX_NUM_MATCHES and publishes to slot 0
   const bool fused_cap = cap_binds && !c->debug_recs;
-  const bool use_fit2 = c->fit2 && !want_recs && tlev < 2;      // the per-pass fast path (granule results)
+  const bool use_fit2 = !want_recs && tlev < 2;                 // the per-pass fast path (granule results)
   if (fused) {
     // the fit and the reduction ran inside the k-NN launch
   } else if (use_fit2)

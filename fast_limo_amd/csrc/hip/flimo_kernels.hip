@@ -773,7 +773,7 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
       // map leave cells with tens to hundreds of points) first walks that cell alone; its 5th distance there is an upper bound
       // of the true one, and the other 26 cells are then walked only as far as that ball reaches (rows and end cells it cannot
       // reach are dropped, exactly as with the bound of a previous pass).
-      const bool probe_on = L == 2 && !prev.valid && prev.heavy == 0xffffffffu && prev.probe_min != 0u;          // wave-uniform
+      const bool probe_on = L == 2 && !prev.valid && prev.probe_min != 0u;          // wave-uniform
       U3 rbl[3], rbh[3];
       {
         const uint32_t iL = (uint32_t)c0 * plane + yz, iH = (uint32_t)c1 * plane + yz;
@@ -822,11 +822,7 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
 #pragma unroll
         for (int t = 1; t < 10; t++) off[t] = n_own;
       }
-      // A query whose block is crowded (a few cells right under the sensor hold hundreds of points once scans have been
-      // inserted) would keep its whole wave waiting while its two lanes walk the stream: it is handed to the wave-per-query
-      // kernel instead (same 3x3x3 block, 64 lanes), like the queries that need a wider block.
-      const bool heavy = off[9] > prev.heavy;
-      const uint32_t total = heavy ? 0u : off[9];
+      const uint32_t total = off[9];
       TRACE(0, 2);
       // ---- flattened candidate stream, branch-free body ----
       const double none = __longlong_as_double((long long)KEY_NONE);
@@ -942,7 +938,6 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
       }
       else if (covers) flag = 0;                 // the whole map holds fewer than 5 points
       else flag = (max_ring > 1) ? 2 : 0;
-      if (heavy) flag = 3;              // pending like 2, and the wider search starts at the 3x3x3 block itself
     }
   }
   if (cand_total) {
@@ -984,8 +979,7 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
       const int slot = atomicAdd(wl_count, 1);
       int4* e = reinterpret_cast<int4*>(wl) + 2 * (size_t)slot;
       e[0] = make_int4(p, __float_as_int(gx), __float_as_int(gy), __float_as_int(gz));
-      // .y: first ring of the wave-per-query search; .z: this pass's pruning bound (cell units, squared; +inf: none)
-      e[1] = make_int4((int)(uint32_t)(best[4] >> 32), flag == 3 ? 1 : 2, __float_as_int(b2), 0);
+      e[1] = make_int4((int)(uint32_t)(best[4] >> 32), 2, __float_as_int(b2), 0);
     }
   }
   WaveLds& W = s_w[threadIdx.x >> 6];
@@ -1021,8 +1015,7 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
 // extracted with wave-wide min reductions.  r starts at the ring the fast path's own 5th distance asks for
 // (at least 2) and jumps to the ring that proves exactness, never beyond max_ring (<= 3 here; the host
 // falls back to the general kernel for larger gates).
-template <int WPS>   // minimum waves per SIMD the register allocation must allow (8: every wave of the 2048-block launch is resident at once)
-__global__ __launch_bounds__(256, WPS) void widen_kernel(GridView G, const float4* __restrict__ scan_sorted, PoseMats P,
+__global__ __launch_bounds__(256) void widen_kernel(GridView G, const float4* __restrict__ scan_sorted, PoseMats P,
                                                     int max_ring, NbrRec* __restrict__ nbr, const int* __restrict__ wl,
                                                     const int* __restrict__ wl_count,
                                                     unsigned long long* __restrict__ cand_total, int first_ring, TieList tl) {
@@ -1053,7 +1046,7 @@ __global__ __launch_bounds__(256, WPS) void widen_kernel(GridView G, const float
     u64 sixth = KEY_NONE;
     int flag = 0;
     int cand = 0;
-    int r = (e1.y == 1) ? 1 : first_ring;              // 1: a crowded 3x3x3 block handed over unsearched; no hint: first_ring (2, or the gate's ring: one search instead of two)
+    int r = first_ring;                                // no hint: straight to the gate's ring (one search instead of two)
     {
       const float hint = __int_as_float(hint_bits);
       if (hint >= 0.f && hint < INFINITY) {            // an upper bound of the true 5th distance: go straight to its ring
@@ -1068,21 +1061,7 @@ __global__ __launch_bounds__(256, WPS) void widen_kernel(GridView G, const float
       uint32_t lo = 0, len = 0;
       if (lane < side * side) {
         const int yy = cy + (lane % side) - r, zz = cz + (lane / side) - r;
-        int x0 = max(cx - r, 0), x1 = min(cx + r, G.nx - 1);
-        if (r == 1) {
-          // a crowded 3x3x3 block handed over by the fast path: the same exact pruning by the previous pass's bound
-          // (rows and end cells that cannot hold any of the five nearest points are skipped)
-          const float b2 = __int_as_float(e1.z);
-          const int ky = lane % 3, kz = lane / 3;
-          const float ydl = fmaxf(ry - margin, 0.f), ydr = fmaxf(1.f - ry - margin, 0.f);
-          const float zdl = fmaxf(rz - margin, 0.f), zdr = fmaxf(1.f - rz - margin, 0.f);
-          const float yd = ky == 0 ? ydl : (ky == 2 ? ydr : 0.f), zd = kz == 0 ? zdl : (kz == 2 ? zdr : 0.f);
-          const float dyz2 = yd * yd + zd * zd;
-          const float xl = fmaxf(rx - margin, 0.f), xr = fmaxf(1.f - rx - margin, 0.f);
-          if (!(dyz2 + xl * xl <= b2)) x0 = max(cx, 0);
-          if (!(dyz2 + xr * xr <= b2)) x1 = min(cx, G.nx - 1);
-          if (!(dyz2 <= b2)) x1 = x0 - 1;                 // empty row
-        }
+        const int x0 = max(cx - r, 0), x1 = min(cx + r, G.nx - 1);
         if (yy >= 0 && yy < G.ny && zz >= 0 && zz < G.nz && x0 <= x1) {
           const size_t rowbase = ((size_t)zz * (size_t)G.ny + (size_t)yy) * (size_t)G.nxf;
           lo = G.cell_start[rowbase + (size_t)x0 * G.xs];
@@ -1208,7 +1187,6 @@ __global__ __launch_bounds__(256) void widen_general_kernel(GridView G, const fl
 // ------------------------------------------------------------------------------------------
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-static int g_fit_threads = 0;      // 256 / 512 / 1024 (FLIMO_FIT_THREADS)
 
 template <bool RECS, bool DBG, int FIT_THREADS>
 __global__ __launch_bounds__(FIT_THREADS) void fit_kernel(GridView G, const float4* __restrict__ scan_sorted, int n,
@@ -2243,7 +2221,6 @@ __global__ __launch_bounds__(256) void transform_kernel(const float4* __restrict
 // ------------------------------------------------------------------------------------------
 static inline int round_up8(int x) { return (x + 7) & ~7; }
 
-static int g_slots = 0;   // 0: default per L; developer override through FLIMO_SLOTS
 template <int L>
 static void launch_knn5_L(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const PoseMats& P,
                           int max_ring, void* nbr, int* wl, int* wl_count, unsigned long long* cand, const PrevPass& prev,
@@ -2251,8 +2228,7 @@ static void launch_knn5_L(hipStream_t st, const GridView& G, const float4* scan_
                           unsigned long long seq = 0ull) {
   const int qpb = 256 / L;
   const int blocks = round_up8((n + qpb - 1) / qpb);
-  if (g_slots == 0) { const char* e = getenv("FLIMO_SLOTS"); g_slots = e ? atoi(e) : -1; }
-  const int slots = g_slots > 0 ? g_slots : (L <= 4 ? 8 : 4);
+  constexpr int slots = (L <= 4 ? 8 : 4);          // candidate loads in flight per lane
   if constexpr (L == 2) {
     if (fuse) {      // the whole pass in one launch (blocks is a multiple of 8 = FIT_GROUPS)
       hipExtLaunchKernelGGL((knn5_kernel<2, 8, true>), dim3(blocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand, prev, 1, *fuse);
@@ -2265,12 +2241,7 @@ static void launch_knn5_L(hipStream_t st, const GridView& G, const float4* scan_
   nofuse.seq = seq;
   // e0 / e1 (optional) are attached to the dispatch itself: they read the kernel's own begin / end
   // timestamps, without the extra barrier packets of hipEventRecord
-  if (slots >= 8)
-    hipExtLaunchKernelGGL((knn5_kernel<L, 8, false>), dim3(blocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand, prev, tail, nofuse);
-  else if (slots >= 4)
-    hipExtLaunchKernelGGL((knn5_kernel<L, 4, false>), dim3(blocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand, prev, tail, nofuse);
-  else
-    hipExtLaunchKernelGGL((knn5_kernel<L, 2, false>), dim3(blocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand, prev, tail, nofuse);
+  hipExtLaunchKernelGGL((knn5_kernel<L, slots, false>), dim3(blocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand, prev, tail, nofuse);
 }
 
 void launch_knn5(hipStream_t st, int lanes_per_query, const GridView& G, const float4* scan_sorted, int n,
@@ -2289,74 +2260,36 @@ void launch_knn5(hipStream_t st, int lanes_per_query, const GridView& G, const f
   }
 }
 
-static int g_widen_blocks = 0;
-static int widen_blocks() {
-  // default 2048 blocks = 8 waves per SIMD: the wave-per-query search is a latency chain
-  if (g_widen_blocks == 0) { const char* e = getenv("FLIMO_WIDEN_BLOCKS"); const int v = e ? atoi(e) : 0; g_widen_blocks = (v > 0 && v <= 2048) ? v : 2048; }   // <= 2048: the worklist has 8192 slots of prefetch slack
-  return g_widen_blocks;
-}
 void launch_widen(hipStream_t st, const GridView& G, const float4* scan_sorted, const PoseMats& P, int max_ring, void* nbr,
                   int* wl, int* wl_count, unsigned long long* cand, hipEvent_t e0, hipEvent_t e1, const TieList* tlp) {
   TieList tl{};
   if (tlp) tl = *tlp;
   if (max_ring <= 1) return;
-  static int tight = -1, r3 = -1;
-  if (tight < 0) { const char* e = getenv("FLIMO_WIDEN_TIGHT"); tight = e ? atoi(e) : 0; e = getenv("FLIMO_WIDEN_R3"); r3 = e ? atoi(e) : 1; }   // measured at 6.6 k pending queries: 19.3 -> 16.3 us
-  const int first_ring = r3 ? max_ring : 2;
-  if (max_ring <= 3) {
-    if (tight)
-      hipExtLaunchKernelGGL((widen_kernel<8>), dim3(widen_blocks()), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand, first_ring, tl);
-    else
-      hipExtLaunchKernelGGL((widen_kernel<1>), dim3(widen_blocks()), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand, first_ring, tl);
-  }
+  // 2048 blocks = 8 waves per SIMD: the wave-per-query search is a latency chain (the worklist has 8192 slots of prefetch slack);
+  // entries without a hint go straight to the gate's ring (measured at 6.6 k pending queries: 19.3 -> 16.3 us)
+  if (max_ring <= 3)
+    hipExtLaunchKernelGGL(widen_kernel, dim3(2048), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand, max_ring, tl);
   else
     hipLaunchKernelGGL(widen_general_kernel, dim3(256), dim3(256), 0, st, G, scan_sorted, P, max_ring, (NbrRec*)nbr, wl, wl_count, tl);
 }
 
-static int fit_threads() {
-  if (g_fit_threads == 0) {
-    const char* e = getenv("FLIMO_FIT_THREADS");
-    const int v = e ? atoi(e) : 0;
-    g_fit_threads = (v == 256 || v == 512 || v == 1024) ? v : 256;
-  }
-  return g_fit_threads;
-}
-int fit_blocks(int n) { const int T = fit_threads(); const int b = (n + T - 1) / T; return (b + FIT_GROUPS - 1) / FIT_GROUPS * FIT_GROUPS; }   // a multiple of FIT_GROUPS (and of 8)
-
-template <int T>
-static void launch_fit_T(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const void* nbr, const PoseMats& P,
-                         const MatchParams& mp, double* partials, Rec16* recs, RecDbg* dbg, double* out256, unsigned int* ticket,
-                         int* wl_count, unsigned long long seq) {
-  const int blocks = fit_blocks(n);
-  if (recs && dbg)
-    hipLaunchKernelGGL((fit_kernel<true, true, T>), dim3(blocks), dim3(T), 0, st, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, partials, recs, dbg, out256, ticket, wl_count, seq);
-  else if (recs)
-    hipLaunchKernelGGL((fit_kernel<true, false, T>), dim3(blocks), dim3(T), 0, st, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, partials, recs, dbg, out256, ticket, wl_count, seq);
-  else
-    hipLaunchKernelGGL((fit_kernel<false, false, T>), dim3(blocks), dim3(T), 0, st, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, partials, recs, dbg, out256, ticket, wl_count, seq);
-}
+int fit_blocks(int n) { const int b = (n + 255) / 256; return (b + FIT_GROUPS - 1) / FIT_GROUPS * FIT_GROUPS; }   // a multiple of FIT_GROUPS (and of 8)
 
 void launch_fit(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const void* nbr, const PoseMats& P,
                 const MatchParams& mp, double* partials, Rec16* recs, RecDbg* dbg, double* out256, unsigned int* ticket,
                 int* wl_count, unsigned long long seq) {
   if (n <= 0) return;
-  switch (fit_threads()) {
-    case 1024: launch_fit_T<1024>(st, G, scan_sorted, n, nbr, P, mp, partials, recs, dbg, out256, ticket, wl_count, seq); break;
-    case 512: launch_fit_T<512>(st, G, scan_sorted, n, nbr, P, mp, partials, recs, dbg, out256, ticket, wl_count, seq); break;
-    default: launch_fit_T<256>(st, G, scan_sorted, n, nbr, P, mp, partials, recs, dbg, out256, ticket, wl_count, seq); break;
-  }
+  const int blocks = fit_blocks(n);
+  if (recs && dbg)
+    hipLaunchKernelGGL((fit_kernel<true, true, 256>), dim3(blocks), dim3(256), 0, st, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, partials, recs, dbg, out256, ticket, wl_count, seq);
+  else if (recs)
+    hipLaunchKernelGGL((fit_kernel<true, false, 256>), dim3(blocks), dim3(256), 0, st, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, partials, recs, dbg, out256, ticket, wl_count, seq);
+  else
+    hipLaunchKernelGGL((fit_kernel<false, false, 256>), dim3(blocks), dim3(256), 0, st, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, partials, recs, dbg, out256, ticket, wl_count, seq);
 }
 
-static int g_fit_ppw = 0;          // points per wave of the fit2 kernel: 64 / 32 / 16 (FLIMO_FIT_PPW), default 64
-int fit2_ppw() {
-  if (g_fit_ppw == 0) {
-    const char* e = getenv("FLIMO_FIT_PPW");
-    const int v = e ? atoi(e) : 0;
-    g_fit_ppw = (v == 64 || v == 32 || v == 16) ? v : 64;    // measured: 64 -> 10.7 us, 32 -> 13.0, 16 -> 20.0 (the QR is VALU-issue bound, not latency bound)
-  }
-  return g_fit_ppw;
-}
-int fit2_blocks(int n) { const int per = 4 * fit2_ppw(); const int b = (n + per - 1) / per; return (b + FIT_GROUPS - 1) / FIT_GROUPS * FIT_GROUPS; }
+// fit2: 64 points per wave (measured: 64 -> 10.7 us, 32 -> 13.0, 16 -> 20.0: the QR is VALU-issue bound, not latency bound)
+int fit2_blocks(int n) { const int b = (n + 255) / 256; return (b + FIT_GROUPS - 1) / FIT_GROUPS * FIT_GROUPS; }
 
 void launch_fit2(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const void* nbr, const PoseMats& P,
                  const MatchParams& mp, const unsigned char* live_idx, double* partials, void* out_granules, unsigned int* ticket,
@@ -2366,12 +2299,7 @@ void launch_fit2(hipStream_t st, const GridView& G, const float4* scan_sorted, i
   if (tlp) tl = *tlp;
   FitIdx idx;
   for (int i = 0; i < FIT_LIVE_PAD; i++) idx.raw[i] = i < FIT_LIVE ? live_idx[i] : 0;
-  const int blocks = fit2_blocks(n);
-  switch (fit2_ppw()) {
-    case 64: hipExtLaunchKernelGGL((fit2_kernel<64>), dim3(blocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, idx, partials, (double2*)out_granules, ticket, wl_count, seq, tl); break;
-    case 16: hipExtLaunchKernelGGL((fit2_kernel<16>), dim3(blocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, idx, partials, (double2*)out_granules, ticket, wl_count, seq, tl); break;
-    default: hipExtLaunchKernelGGL((fit2_kernel<32>), dim3(blocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, idx, partials, (double2*)out_granules, ticket, wl_count, seq, tl); break;
-  }
+  hipExtLaunchKernelGGL((fit2_kernel<64>), dim3(fit2_blocks(n)), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, idx, partials, (double2*)out_granules, ticket, wl_count, seq, tl);
 }
 
 int fused_blocks(int n) { return round_up8((n + 127) / 128); }
@@ -2386,7 +2314,6 @@ void launch_knn5_fine(hipStream_t st, const GridView& Gf, const float4* scan_sor
   for (int a = 0; a < 3; a++) { fa.qlo[a] = qlo[a]; fa.qhi[a] = qhi[a]; }
   if (tlp) fa.tl = *tlp;
   PrevPass pv = prev;
-  pv.heavy = 0xffffffffu;
   hipLaunchKernelGGL((knn5_kernel<2, 8, false, true>), dim3(round_up8((n + 127) / 128)), dim3(256), 0, st, Gf, scan_sorted, n, P, 1,
                      (NbrRec*)nbr, (int*)nullptr, (int*)nullptr, (unsigned long long*)nullptr, pv, 0, fa);
 }

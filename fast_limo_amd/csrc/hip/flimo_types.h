@@ -31,7 +31,6 @@ struct GridView {
 struct PrevPass {
   float RT[16];
   int valid;
-  unsigned heavy;   // queries whose 3x3x3 block holds more candidates than this go to the wave-per-query kernel (0xffffffff: never)
   unsigned probe_min;   // first pass: a query whose 3x3x3 block holds at least this many candidates walks its own cell first, for a bound (0: never)
 };
 

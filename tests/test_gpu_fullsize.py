@@ -63,7 +63,7 @@ def test_reduction_consistency_and_reproducibility(big):
     HTH, HTh, M = ctx.match_reduce(x0, cfg)
     HTH2, HTh2, M2 = ctx.match_reduce(x0, cfg)
     import os
-    if all(os.environ.get(k, "1") != "0" for k in ("FLIMO_TAIL", "FLIMO_FUSE", "FLIMO_FIT2")):      # not under a developer A/B switch
+    if all(os.environ.get(k, "1") != "0" for k in ("FLIMO_TAIL", "FLIMO_FUSE")):      # not under a developer A/B switch
         assert ctx.fused_pass_count() == n_fused + 2    # the hot path is the one that ran
     assert M == M2 == M1 and M > 60000
     np.testing.assert_array_equal(HTH, HTH2)            # bit-reproducible (fixed summation order)

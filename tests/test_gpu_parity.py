@@ -770,50 +770,6 @@ def test_incremental_index_equals_full_sort(built, oracle):
 
 
 @pytest.mark.gpu
-def test_crowded_block_handover_is_exact(built, oracle):
-    """Developer switch FLIMO_HEAVY=<n>: queries whose 3x3x3 block holds more than n candidates are handed to the
-    wave-per-query kernel (same block, same pruning bound) instead of being walked by their two lanes.  On a map with
-    crowded cells (and sparse ones) every record equals the default path's, over a pose sequence that exercises the
-    pruning bound, and the oracle's at the last pose."""
-    from fast_limo_amd import _lib
-    mcfg = _lib.default_match_cfg(**CAPS)
-    rs = np.random.RandomState(4)
-    mp = np.concatenate([synth.box_world_map(150000, 15.0, 1),                       # ~170 pts/m2: about 40 per cell
-                         synth.box_world_map(40000, 3.0, 2)])                        # a crowded patch: several hundred per cell
-    scan = np.ascontiguousarray(synth.box_world_scan_random(4096, 15.0, 2)[:, :3])
-    oc = oracle.Octree(); oc.update(mp)
-    os.environ["FLIMO_HEAVY"] = "96"
-    try:
-        handed = _lib.HipCtx(0)
-    finally:
-        del os.environ["FLIMO_HEAVY"]
-    plain = _lib.HipCtx(0)
-    x = oracle.identity_x26()
-    poses = []
-    for k in range(5):
-        x = x.copy(); x[0:3] += rs.normal(0, 0.02 if k != 3 else 0.3, 3); poses.append(x)
-    try:
-        for c in (plain, handed):
-            c.map_config(); c.map_add(mp); c.scan_set(scan); c.set_debug_records(True)
-        moved = 0
-        for k, xk in enumerate(poses):
-            a = plain.match_reduce(xk, mcfg); ra = plain.match_fetch()
-            b = handed.match_reduce(xk, mcfg); rb = handed.match_fetch()
-            assert a[2] == b[2], k
-            np.testing.assert_array_equal(a[0], b[0]); np.testing.assert_array_equal(a[1], b[1])
-            for f in ("valid", "n", "h", "sqd", "nbr", "H"):
-                np.testing.assert_array_equal(ra[f], rb[f], err_msg=f"pose {k} field {f}")
-            moved = max(moved, handed.last_widen_count() - plain.last_widen_count())
-        assert moved > 200, moved                                # the hand-over really happened
-        recs, H, h, ev = oracle.match_H(oc, oracle.default_cfg(num_threads=1, **CAPS), poses[-1], scan)
-        vg = rb["valid"] > 0
-        np.testing.assert_array_equal(vg, recs["is_plane"] > 0)
-        np.testing.assert_array_equal(rb["sqd"][vg], recs["sqd"][vg])
-    finally:
-        plain.close(); handed.close()
-
-
-@pytest.mark.gpu
 def test_randomised_configurations_match_oracle(built, oracle):
     """Differential test over 16 random configurations: scene mix (box-world + tilted clutter at random densities), map
     cell size, state (pose AND LiDAR-IMU extrinsics away from identity), gates (MAX_DIST_PLANE, PLANE_THRESHOLD), both caps

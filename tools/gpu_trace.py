@@ -30,8 +30,7 @@ names = {0: ["start", "query loaded", "row bounds loaded", "candidates done", "m
          1: ["start", "scan+nbr loaded", "5 points gathered", "row computed", "partial stored", "ticket taken",
              "LAST: partials summed", "LAST: published"]}
 nblk = {0: (scan.shape[0] * int(os.environ.get("FLIMO_LPQ", 2)) + 255) // 256,
-        1: (scan.shape[0] + 255) // int(os.environ.get("FLIMO_FIT_THREADS", 256)) if os.environ.get("FLIMO_FIT2") == "0"
-           else (scan.shape[0] + 4 * int(os.environ.get("FLIMO_FIT_PPW", 64)) - 1) // (4 * int(os.environ.get("FLIMO_FIT_PPW", 64)))}
+        1: (scan.shape[0] + 255) // 256}
 for k in (0, 1):
     nb = nblk[k]
     buf = np.zeros(nb * 8, np.uint64)

@@ -1,7 +1,9 @@
 #!/bin/bash
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $root
-for env in "FLIMO_DBG=0" "FLIMO_DBG=1" "FLIMO_DBG=2" "FLIMO_DBG=4" "FLIMO_DBG=7"; do
+for env in "X=1" "HIP_FORCE_DEV_KERNARG=0" "HIP_FORCE_DEV_KERNARG=1" "HSA_ENABLE_INTERRUPT=0" "GPU_MAX_HW_QUEUES=1" "DEBUG_CLR_LIMIT_BLIT_WG=1"; do
   echo "== $env"
-  env $env timeout 300 python tests/dev/gpu_pass_times.py 2>&1 | grep -E "level 1"
+  env $env timeout 300 python bench.py --steps 200 --warmup 10 --no-cpu-baseline --no-end-to-end --no-hbm-regime --streams 0 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print(round(d['value']), round(d['ms_per_step']*1e3,1), d['host_us_per_step'])"
 done
