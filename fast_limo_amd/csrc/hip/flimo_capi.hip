@@ -88,6 +88,12 @@ struct flimo_ctx {
   void* h_frames[2] = {nullptr, nullptr};   // pinned staging of the IMU frames, alternating: the deskew call does not wait
   size_t h_frames_cap = 0;
   int frames_slot = 0, async_deskews = 0;   // copies possibly still in flight since the stream was last known idle
+  // A deskew that has been set up (frames uploaded) but not run: the scan's first k-NN launch runs it on the way (DeskewArgs),
+  // anything else that reads d_scan / d_scan_sorted first runs the stand-alone kernel (flush_deskew)
+  DeskewArgs deskew_args{};
+  size_t deskew_n = 0;
+  bool deskew_pending = false;
+  bool lazy_deskew = true;         // FLIMO_LAZY_DESKEW=0: always the stand-alone kernel (developer A/B)
   // per pass
   Rec16* d_recs = nullptr;
   RecDbg* d_dbg = nullptr;
@@ -298,6 +304,7 @@ static void pose_from_x26(const double x[26], PoseMats& P) {
 //   FLIMO_XCD_STRIPE=<chunks>     block -> scan chunk striping over the XCDs (8)
 //   FLIMO_FULL_REBUILD=1          the index is sorted from scratch on every insert (default: merged)
 //   FLIMO_HOST_INSERT=1           the first batch goes through the host statement of the insert rule, then is imported
+//   FLIMO_LAZY_DESKEW=0           the deskew always runs as a dispatch of its own (default: on the scan's first k-NN launch)
 //   FLIMO_PROF_PASS / FLIMO_PROF_INSERT   host-side timing prints (stderr)
 // (csrc/host: FLIMO_REFERENCE_SOLVE=1 literal two-inverse gain, FLIMO_SYNC_INSERT=1 map inserts on the caller's thread,
 //  FLIMO_PROF_DESKEW / FLIMO_PROF_CLOUDS timing prints; bench.py: FLIMO_BENCH_*.)
@@ -322,6 +329,7 @@ static void load_dev_switches(flimo_ctx* c) {
   if (env_int("FLIMO_XCD_STRIPE", v)) set_xcd_stripe(v);
   if (env_int("FLIMO_FULL_REBUILD", v)) c->full_rebuild = v != 0;
   if (env_int("FLIMO_HOST_INSERT", v)) c->host_insert = v != 0;
+  if (env_int("FLIMO_LAZY_DESKEW", v)) c->lazy_deskew = v != 0;
 }
 
 // ---- context ----------------------------------------------------------------------------------
@@ -989,11 +997,22 @@ static int upload_points(flimo_ctx* c, const float* xyz, size_t n, size_t stride
   return FLIMO_OK;
 }
 
+// Runs a deskew that is still pending (see flimo_ctx::deskew_pending) as a dispatch of its own.
+static int flush_deskew(flimo_ctx* c) {
+  if (!c->deskew_pending) return FLIMO_OK;
+  c->deskew_pending = false;
+  const DeskewArgs& a = c->deskew_args;
+  launch_deskew(c->stream, a.raw, a.t, (int)c->deskew_n, a.frames, a.nf, a.mats, a.out_sorted, a.out_orig, a.t_offset);
+  HIPCHK(c, hipGetLastError());
+  return FLIMO_OK;
+}
+
 extern "C" int flimo_scan_set(flimo_ctx* c, const float* xyz, size_t n, size_t stride_bytes) {
   if (!c) return FLIMO_ERR_INVALID;
   if (n > 0 && (!xyz || stride_bytes < 12)) return fail(c, FLIMO_ERR_INVALID, "bad xyz/stride");
   if (n > 0x7fff0000ull) return fail(c, FLIMO_ERR_TOO_LARGE, "scan too large");
   (void)hipSetDevice(c->device);
+  c->deskew_pending = false;                 // the scan it belonged to is replaced
   int rc = ensure_scan(c, n);
   if (rc) return rc;
   if (n) {
@@ -1023,6 +1042,7 @@ extern "C" int flimo_scan_get(flimo_ctx* c, float* out, size_t cap, size_t* n) {
   *n = c->scan_n;
   if (!out || cap == 0 || c->scan_n == 0) return FLIMO_OK;
   (void)hipSetDevice(c->device);
+  { const int rcf = flush_deskew(c); if (rcf) return rcf; }
   return download_xyz(c, c->d_scan, std::min(cap, c->scan_n), out);
 }
 
@@ -1034,6 +1054,7 @@ extern "C" int flimo_scan_voxel_filter(flimo_ctx* c, float leaf, size_t* n_out) 
   (void)hipSetDevice(c->device);
   size_t m = 0;
   bool pass = false;
+  { const int rcf = flush_deskew(c); if (rcf) return rcf; }
   // d_scan_world is free scratch at this point of the scan life cycle
   HIPCHK(c, voxel_grid(c->stream, c->d_scan, c->scan_n, leaf, c->d_scan_world, &m, &pass, c->scratch));
   if (!pass) {
@@ -1051,6 +1072,7 @@ extern "C" int flimo_raw_scan_set(flimo_ctx* c, const float* xyz, size_t n, size
   if (!c) return FLIMO_ERR_INVALID;
   if (n > 0 && (!xyz || !t || stride_bytes < 12)) return fail(c, FLIMO_ERR_INVALID, "bad xyz/t/stride");
   (void)hipSetDevice(c->device);
+  c->deskew_pending = false;                 // a deskew never run belonged to the scan this one replaces
   int rc = ensure_scan(c, n);
   if (rc) return rc;
   if (n) {
@@ -1080,6 +1102,7 @@ extern "C" int flimo_raw_scan_filter_order_set(flimo_ctx* c, const void* points3
   if (cfg->rate_active && cfg->rate_value < 1) return fail(c, FLIMO_ERR_INVALID, "rate_value must be >= 1");
   if (n > 0x7fff0000ull) return fail(c, FLIMO_ERR_TOO_LARGE, "scan too large");
   *n_kept = 0; *last_stamp = 0.0; *nan_stamp = 0; *tied = 0;
+  c->deskew_pending = false;                 // a deskew never run belonged to the scan this one replaces
   (void)hipSetDevice(c->device);
   int rc = ensure_scan(c, n);
   if (rc) return rc;
@@ -1229,9 +1252,11 @@ extern "C" int flimo_deskew_resident_offset(flimo_ctx* c, const flimo_frame* fra
   }
   // stream-ordered: everything that consumes the deskewed scan is queued behind this on the same stream
   HIPCHK(c, hipMemcpyAsync(c->d_frames, hs, total, hipMemcpyHostToDevice, c->stream));
-  launch_deskew(c->stream, c->d_raw_sorted, c->d_t_sorted, (int)n, c->d_frames, (int)nf,
-                (const float*)((const char*)c->d_frames + fbytes), c->d_scan_sorted, c->d_scan, t_offset);
-  HIPCHK(c, hipGetLastError());
+  c->deskew_args = DeskewArgs{c->d_raw_sorted, c->d_t_sorted, c->d_frames, (int)nf, (const float*)((const char*)c->d_frames + fbytes),
+                              t_offset, c->d_scan_sorted, c->d_scan, 1};
+  c->deskew_n = n;
+  c->deskew_pending = true;
+  if (!c->lazy_deskew) { const int rcf = flush_deskew(c); if (rcf) return rcf; }
   c->async_deskews++;
   c->scan_n = n; c->sorted_n = n; c->prev.valid = 0;
   return FLIMO_OK;
@@ -1397,11 +1422,18 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   // the Morton-sorted query set is rebuilt once per scan from that prefix alone.
   if (nq < c->sorted_n || (c->sorted_n < c->scan_n && nq > c->sorted_n)) {
     const size_t want = nq;
+    { const int rcf = flush_deskew(c); if (rcf) return rcf; }
     HIPCHK(c, sort_scan(c->stream, c->d_scan, want, c->d_scan_sorted, c->scratch));
     c->sorted_n = want;
     c->prev.valid = 0;
   }
   const int n_all = (int)c->sorted_n;                 // resident query set (== nq, or the whole scan when no cap binds)
+  // A pending deskew rides on this pass's k-NN launch when that launch covers the whole scan and is the first to read it
+  const bool ride = c->deskew_pending && !general_k && c->deskew_n == (size_t)n_all &&
+                    !(c->fine_valid && c->lanes_per_query == 2 && mp.max_ring >= 1);     // (a fine pre-pass reads the scan first)
+  if (!ride) { const int rcf = flush_deskew(c); if (rcf) return rcf; }
+  const DeskewArgs* dkp = ride ? &c->deskew_args : nullptr;
+  c->deskew_pending = false;
   const bool cap_binds = cfg->MAX_NUM_MATCHES >= 0 && (size_t)cfg->MAX_NUM_MATCHES < nq;
   if (general_k) {
     // any NUM_MATCH_POINTS: exact k-NN by the ring search, M x 3 plane fit, records, record reduction (slow, general pass)
@@ -1481,12 +1513,12 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   if (fused) {
     launch_match_fused(c->stream, c->grid, c->d_scan_sorted, n_all, P, mp, c->d_nbr, c->d_wl, c->d_wl_count, nullptr, c->prev,
                        c->live_idx, c->d_fit2_partials, c->d_granules_host, c->d_ticket, seq, tlev == 1 ? c->ev[0] : nullptr,
-                       tlev == 1 ? c->ev[1] : nullptr, &tl, after_fine ? 1 : 0);
+                       tlev == 1 ? c->ev[1] : nullptr, &tl, after_fine ? 1 : 0, dkp);
     c->fused_passes++;
   } else
   launch_knn5(c->stream, c->lanes_per_query, c->grid, c->d_scan_sorted, n_all, P, mp.max_ring, c->d_nbr, c->d_wl,
               c->d_wl_count, c->debug_recs ? c->d_cand : nullptr, c->prev, tail ? 1 : 0, tlev == 1 ? c->ev[0] : nullptr,
-              tlev == 1 ? c->ev[1] : nullptr, nullptr, &tl, after_fine ? 1 : 0, seq);
+              tlev == 1 ? c->ev[1] : nullptr, nullptr, &tl, after_fine ? 1 : 0, seq, dkp);
   if (c->prune) { memcpy(c->prev.RT, P.RT, sizeof(c->prev.RT)); c->prev.valid = 1; }   // the records now belong to this pose
   const double tpb = prof ? now_us() : 0.0;
   if (tlev > 1) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
@@ -1732,6 +1764,7 @@ extern "C" int flimo_scan_to_world(flimo_ctx* c, const double x26[26], float* ou
   (void)hipSetDevice(c->device);
   PoseMats P;
   pose_from_x26(x26, P);
+  { const int rcf = flush_deskew(c); if (rcf) return rcf; }
   launch_transform(c->stream, c->d_scan, (int)c->scan_n, P, c->d_scan_world);
   HIPCHK(c, hipGetLastError());
   if (out && cap) return download_xyz(c, c->d_scan_world, std::min(cap, c->scan_n), out);
@@ -1748,6 +1781,7 @@ extern "C" int flimo_map_add_scan(flimo_ctx* c, const double x26[26], double sta
     (void)hipSetDevice(c->device);
     PoseMats P;
     pose_from_x26(x26, P);
+    { const int rcf = flush_deskew(c); if (rcf) return rcf; }
     launch_transform(c->stream, c->d_scan, (int)c->scan_n, P, c->d_scan_world);      // no host wait: the insert's first read-back follows
     HIPCHK(c, hipGetLastError());
     return map_add_device(c, c->d_scan_world, c->scan_n, stamp);

@@ -7,13 +7,19 @@ namespace flimo {
 struct FuseArgs;
 struct TieList;
 struct BookView;
+// The deskew of a scan's raw points riding on the first pass's k-NN launch (instead of a dispatch of its own): arguments of
+// launch_deskew, `on` = 1 when they are valid
+struct DeskewArgs {
+  const float4* raw; const double* t; const void* frames; int nf; const float* mats; double t_offset;
+  float4* out_sorted; float4* out_orig; int on;
+};
 
 // flimo_kernels.hip
 // per pass: k-NN (fast path + worklist widening), then fit + in-block reduction, then the final sum
 void launch_knn5(hipStream_t st, int lanes_per_query, const GridView& G, const float4* scan_sorted, int n,
                  const PoseMats& P, int max_ring, void* nbr, int* wl, int* wl_count, unsigned long long* cand,
                  const PrevPass& prev, int tail, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, const struct FuseArgs* fuse = nullptr,
-                 const TieList* ties = nullptr, int after_fine = 0, unsigned long long seq = 0ull);
+                 const TieList* ties = nullptr, int after_fine = 0, unsigned long long seq = 0ull, const DeskewArgs* deskew = nullptr);
 // fine pre-pass over the second-level grid of crowded regions (see flimo_map.hip); launches that follow it pass after_fine = 1
 void launch_knn5_fine(hipStream_t st, const GridView& Gf, const float4* scan_sorted, int n, const PoseMats& P, void* nbr,
                       const PrevPass& prev, const int qlo[3], const int qhi[3], const TieList* ties, unsigned long long seq);
@@ -49,7 +55,7 @@ void launch_match_fused(hipStream_t st, const GridView& G, const float4* scan_so
                         void* nbr, int* wl, int* wl_count, unsigned long long* cand, const PrevPass& prev,
                         const unsigned char* live_idx, double* partials, void* out_granules, unsigned int* ticket,
                         unsigned long long seq, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, const TieList* ties = nullptr,
-                        int after_fine = 0);
+                        int after_fine = 0, const DeskewArgs* deskew = nullptr);
 // The reference's choice among exactly tied distances (first met by Octree::knn's recursion): BookView = the device copy of the
 // octree (insert book), TieList = the queries a pass flagged.  launch_tie rewrites their neighbour records; launch_knn_tie does the
 // same for the output of launch_knn.

@@ -647,6 +647,160 @@ __device__ __forceinline__ void knn5_tail(const GridView& G, int max_ring, NbrRe
 #endif
 }
 
+// ------------------------------------------------------------------------------------------
+// deskew (Localizer.cpp:822-843) with State::update (State.cpp:76-119)
+// ------------------------------------------------------------------------------------------
+struct DevFrame {
+  float p[3], q[4], v[3], g[3], w[3], a[3], bg[3], ba[3];
+  float pad;
+  double time;
+};
+
+// Eigen::Quaternionf::toRotationMatrix
+FLIMO_DEV void quat_to_rot(float qx, float qy, float qz, float qw, float (&R)[9]) {
+  const float tx = 2.f * qx, ty = 2.f * qy, tz = 2.f * qz;
+  const float twx = tx * qw, twy = ty * qw, twz = tz * qw;
+  const float txx = tx * qx, txy = ty * qx, txz = tz * qx;
+  const float tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+  R[0] = 1.f - (tyy + tzz); R[1] = txy - twz;         R[2] = txz + twy;
+  R[3] = txy + twz;         R[4] = 1.f - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy;         R[7] = tyz + twx;         R[8] = 1.f - (txx + tyy);
+}
+
+// One point: p = raw LiDAR-frame point (w = original index), tk = its absolute stamp; returns the point in the body frame at the
+// scan's end (w unchanged).  The per-pass k-NN kernel of a scan's FIRST pass calls it too (the deskew rides on that launch).
+__device__ __forceinline__ float4 deskew_point(const float4 p, const double tk, const DevFrame* __restrict__ frames, int nf,
+                                               const float* __restrict__ mats /* [0..15] lidar2baselink_T, [16..31] last_state.get_RT_inv() */) {
+  // binary_search_tailored (Algorithms.hpp:25-38)
+  int low = 0, high = nf - 1;
+  while (high >= low) {
+    const int mid = (low + high) / 2;
+    if (frames[mid].time > tk) high = mid - 1; else low = mid + 1;
+  }
+  const int i_f = high < 0 ? 0 : high;
+  const DevFrame F = frames[i_f];
+  // State::update(tk)
+  const double dt = tk - F.time;
+  const float wx = F.w[0] - F.bg[0], wy = F.w[1] - F.bg[1], wz = F.w[2] - F.bg[2];
+  const float w_norm = fl_sqrt(sum3(wx * wx, wy * wy, wz * wz));
+  float Rm[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
+  if ((double)w_norm > 1.e-7) {
+    const float r0 = fl_div(wx, w_norm), r1 = fl_div(wy, w_norm), r2 = fl_div(wz, w_norm);
+    const float K[9] = {0.f, -r2, r1, r2, 0.f, -r0, -r1, r0, 0.f};
+    const float r_ang = (float)((double)w_norm * dt);
+    float s, cs;
+    libm_sincosf(r_ang, s, cs);                        // std::sin / std::cos of a float, as the host's libm rounds them
+    const float c = (float)(1.0 - (double)cs);
+    float cK[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) cK[i] = c * K[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        const float kk = sum3(cK[i * 3 + 0] * K[0 * 3 + j], cK[i * 3 + 1] * K[1 * 3 + j], cK[i * 3 + 2] * K[2 * 3 + j]);
+        Rm[i * 3 + j] = Rm[i * 3 + j] + (s * K[i * 3 + j] + kk);
+      }
+  }
+  // a0 = q._transformVector(a - ba) + g   (only needed for p)
+  const float qx = F.q[0], qy = F.q[1], qz = F.q[2], qw = F.q[3];
+  const float ax = F.a[0] - F.ba[0], ay = F.a[1] - F.ba[1], az = F.a[2] - F.ba[2];
+  float ux, uy, uz;
+  cross3(qx, qy, qz, ax, ay, az, ux, uy, uz);
+  ux = ux + ux; uy = uy + uy; uz = uz + uz;
+  float cx_, cy_, cz_;
+  cross3(qx, qy, qz, ux, uy, uz, cx_, cy_, cz_);
+  float a0x = (ax + qw * ux) + cx_, a0y = (ay + qw * uy) + cy_, a0z = (az + qw * uz) + cz_;
+  a0x = a0x + F.g[0]; a0y = a0y + F.g[1]; a0z = a0z + F.g[2];
+  // q *= Quaternionf(R)
+  float ux_, uy_, uz_, uw_;
+  {
+    float tr = sum3(Rm[0], Rm[4], Rm[8]);            // trace() = diagonal().sum(): Eigen's 3-coefficient redux c0 + (c1 + c2)
+    if (tr > 0.f) {
+      tr = fl_sqrt(tr + 1.0f);
+      uw_ = 0.5f * tr;
+      tr = fl_div(0.5f, tr);
+      ux_ = (Rm[7] - Rm[5]) * tr;
+      uy_ = (Rm[2] - Rm[6]) * tr;
+      uz_ = (Rm[3] - Rm[1]) * tr;
+    } else {
+      // i = the largest diagonal entry, j = (i+1)%3, k = (j+1)%3 (Eigen's quaternion-from-matrix); the three cases written out
+      // so that no matrix entry is addressed by a run-time index (registers, no scratch)
+      int i = 0;
+      if (Rm[4] > Rm[0]) i = 1;
+      if (Rm[8] > (i == 0 ? Rm[0] : Rm[4])) i = 2;
+      if (i == 0) {
+        float tq = fl_sqrt(Rm[0] - Rm[4] - Rm[8] + 1.0f);
+        ux_ = 0.5f * tq;
+        tq = fl_div(0.5f, tq);
+        uw_ = (Rm[7] - Rm[5]) * tq;
+        uy_ = (Rm[3] + Rm[1]) * tq;
+        uz_ = (Rm[6] + Rm[2]) * tq;
+      } else if (i == 1) {
+        float tq = fl_sqrt(Rm[4] - Rm[8] - Rm[0] + 1.0f);
+        uy_ = 0.5f * tq;
+        tq = fl_div(0.5f, tq);
+        uw_ = (Rm[2] - Rm[6]) * tq;
+        uz_ = (Rm[7] + Rm[5]) * tq;
+        ux_ = (Rm[1] + Rm[3]) * tq;
+      } else {
+        float tq = fl_sqrt(Rm[8] - Rm[0] - Rm[4] + 1.0f);
+        uz_ = 0.5f * tq;
+        tq = fl_div(0.5f, tq);
+        uw_ = (Rm[3] - Rm[1]) * tq;
+        ux_ = (Rm[2] + Rm[6]) * tq;
+        uy_ = (Rm[5] + Rm[7]) * tq;
+      }
+    }
+  }
+  const float nqw = qw * uw_ - qx * ux_ - qy * uy_ - qz * uz_;
+  const float nqx = qw * ux_ + qx * uw_ + qy * uz_ - qz * uy_;
+  const float nqy = qw * uy_ + qy * uw_ + qz * ux_ - qx * uz_;
+  const float nqz = qw * uz_ + qz * uw_ + qx * uy_ - qy * ux_;
+  // p += v*dt + 0.5*a0*dt*dt
+  const float fdt = (float)dt;
+  const float px = F.p[0] + (fdt * F.v[0] + fdt * (fdt * (0.5f * a0x)));
+  const float py = F.p[1] + (fdt * F.v[1] + fdt * (fdt * (0.5f * a0y)));
+  const float pz = F.p[2] + (fdt * F.v[2] + fdt * (fdt * (0.5f * a0z)));
+  // T = X0.get_RT() * lidar2baselink_T  (4x4 * 4x4, columns accumulated left to right)
+  float R0[9];
+  quat_to_rot(nqx, nqy, nqz, nqw, R0);
+  const float X[16] = {R0[0], R0[1], R0[2], px, R0[3], R0[4], R0[5], py, R0[6], R0[7], R0[8], pz, 0.f, 0.f, 0.f, 1.f};
+  float T[16];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      float acc = X[i * 4 + 0] * mats[0 * 4 + j];
+      acc = acc + X[i * 4 + 1] * mats[1 * 4 + j];
+      acc = acc + X[i * 4 + 2] * mats[2 * 4 + j];
+      acc = acc + X[i * 4 + 3] * mats[3 * 4 + j];
+      T[i * 4 + j] = acc;
+    }
+  // world = T * [p,1]; the 4th component (T row 3) is carried like the reference does
+  float wx_ = ((T[0] * p.x + T[1] * p.y) + T[2] * p.z) + T[3] * 1.f;
+  float wy_ = ((T[4] * p.x + T[5] * p.y) + T[6] * p.z) + T[7] * 1.f;
+  float wz_ = ((T[8] * p.x + T[9] * p.y) + T[10] * p.z) + T[11] * 1.f;
+  float ww_ = ((T[12] * p.x + T[13] * p.y) + T[14] * p.z) + T[15] * 1.f;
+  const float* Li = mats + 16;
+  const float ox_ = ((Li[0] * wx_ + Li[1] * wy_) + Li[2] * wz_) + Li[3] * ww_;
+  const float oy_ = ((Li[4] * wx_ + Li[5] * wy_) + Li[6] * wz_) + Li[7] * ww_;
+  const float oz_ = ((Li[8] * wx_ + Li[9] * wy_) + Li[10] * wz_) + Li[11] * ww_;
+  return make_float4(ox_, oy_, oz_, p.w);
+}
+
+__global__ __launch_bounds__(256) void deskew_kernel(const float4* __restrict__ in, const double* __restrict__ t,
+                                                     int n, const DevFrame* __restrict__ frames, int nf,
+                                                     const float* __restrict__ mats, float4* __restrict__ out_sorted,
+                                                     float4* __restrict__ out_orig, double t_offset) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  // (sweep reference +- point time) + offset, as the host forms it (Localizer.cpp:741-805)
+  const float4 o = deskew_point(in[k], t[k] + t_offset, frames, nf, mats);
+  out_sorted[k] = o;                                            // w carries the original index
+  out_orig[__float_as_uint(o.w)] = make_float4(o.x, o.y, o.z, 1.0f);
+}
+
 // FUSE: the whole measurement pass in ONE launch (fast path of flimo_match_reduce): every wave goes on from its queries'
 // neighbours (fast path + tail) to their plane fit, residual and H row and to the H^T H reduction (fit_reduce_publish below).
 struct FuseArgs {
@@ -662,6 +816,7 @@ struct FuseArgs {
   double2* granules;
   unsigned int* ticket;
   unsigned long long seq;
+  DeskewArgs dk;       // dk.on: first pass of a scan, the deskew rides on this launch
 };
 template <int ROWS>
 __device__ __forceinline__ void fit_reduce_publish(const float (&v)[16], bool owns_row, int row, float* sr, double* sa0, double* sa1,
@@ -688,7 +843,21 @@ __global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __r
   const bool in_range = p < n;          // no early exit: the tail below is a wave-wide phase
   TRACE(0, 0);
 
-  const float4 sp = scan_sorted[in_range ? p : 0];
+  float4 sp;
+  if (!FINE && fa.dk.on) {
+    // first pass of a scan: the deskew of this query's raw point (Localizer.cpp:822-843) instead of a dispatch of its own; the
+    // result is what deskew_kernel would have stored, and is stored for the later passes, the map insert and the clouds
+    sp = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (in_range) {
+      sp = deskew_point(fa.dk.raw[p], fa.dk.t[p] + fa.dk.t_offset, static_cast<const DevFrame*>(fa.dk.frames), fa.dk.nf, fa.dk.mats);
+      if (sub == 0) {
+        fa.dk.out_sorted[p] = sp;
+        fa.dk.out_orig[__float_as_uint(sp.w)] = make_float4(sp.x, sp.y, sp.z, 1.0f);
+      }
+    }
+  } else {
+    sp = scan_sorted[in_range ? p : 0];
+  }
   float gx, gy, gz;
   xform4(P.RT, sp.x, sp.y, sp.z, gx, gy, gz);
   TRACE(0, 1);
@@ -2070,139 +2239,6 @@ __global__ void mfma_layout_kernel(double* __restrict__ raw) {
   raw[lane * 4 + 0] = acc[0]; raw[lane * 4 + 1] = acc[1]; raw[lane * 4 + 2] = acc[2]; raw[lane * 4 + 3] = acc[3];
 }
 
-// ------------------------------------------------------------------------------------------
-// deskew (Localizer.cpp:822-843) with State::update (State.cpp:76-119)
-// ------------------------------------------------------------------------------------------
-struct DevFrame {
-  float p[3], q[4], v[3], g[3], w[3], a[3], bg[3], ba[3];
-  float pad;
-  double time;
-};
-
-// Eigen::Quaternionf::toRotationMatrix
-FLIMO_DEV void quat_to_rot(float qx, float qy, float qz, float qw, float (&R)[9]) {
-  const float tx = 2.f * qx, ty = 2.f * qy, tz = 2.f * qz;
-  const float twx = tx * qw, twy = ty * qw, twz = tz * qw;
-  const float txx = tx * qx, txy = ty * qx, txz = tz * qx;
-  const float tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
-  R[0] = 1.f - (tyy + tzz); R[1] = txy - twz;         R[2] = txz + twy;
-  R[3] = txy + twz;         R[4] = 1.f - (txx + tzz); R[5] = tyz - twx;
-  R[6] = txz - twy;         R[7] = tyz + twx;         R[8] = 1.f - (txx + tyy);
-}
-
-__global__ __launch_bounds__(256) void deskew_kernel(const float4* __restrict__ in, const double* __restrict__ t,
-                                                     int n, const DevFrame* __restrict__ frames, int nf,
-                                                     const float* __restrict__ mats /* [0..15] lidar2baselink_T,
-                                                     [16..31] last_state.get_RT_inv() */,
-                                                     float4* __restrict__ out_sorted, float4* __restrict__ out_orig, double t_offset) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= n) return;
-  const double tk = t[k] + t_offset;        // (sweep reference +- point time) + offset, as the host forms it (Localizer.cpp:741-805)
-  // binary_search_tailored (Algorithms.hpp:25-38)
-  int low = 0, high = nf - 1;
-  while (high >= low) {
-    const int mid = (low + high) / 2;
-    if (frames[mid].time > tk) high = mid - 1; else low = mid + 1;
-  }
-  const int i_f = high < 0 ? 0 : high;
-  const DevFrame F = frames[i_f];
-  // State::update(tk)
-  const double dt = tk - F.time;
-  const float wx = F.w[0] - F.bg[0], wy = F.w[1] - F.bg[1], wz = F.w[2] - F.bg[2];
-  const float w_norm = fl_sqrt(sum3(wx * wx, wy * wy, wz * wz));
-  float Rm[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
-  if ((double)w_norm > 1.e-7) {
-    const float r0 = fl_div(wx, w_norm), r1 = fl_div(wy, w_norm), r2 = fl_div(wz, w_norm);
-    const float K[9] = {0.f, -r2, r1, r2, 0.f, -r0, -r1, r0, 0.f};
-    const float r_ang = (float)((double)w_norm * dt);
-    float s, cs;
-    libm_sincosf(r_ang, s, cs);                        // std::sin / std::cos of a float, as the host's libm rounds them
-    const float c = (float)(1.0 - (double)cs);
-    float cK[9];
-#pragma unroll
-    for (int i = 0; i < 9; i++) cK[i] = c * K[i];
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-      for (int j = 0; j < 3; j++) {
-        const float kk = sum3(cK[i * 3 + 0] * K[0 * 3 + j], cK[i * 3 + 1] * K[1 * 3 + j], cK[i * 3 + 2] * K[2 * 3 + j]);
-        Rm[i * 3 + j] = Rm[i * 3 + j] + (s * K[i * 3 + j] + kk);
-      }
-  }
-  // a0 = q._transformVector(a - ba) + g   (only needed for p)
-  const float qx = F.q[0], qy = F.q[1], qz = F.q[2], qw = F.q[3];
-  const float ax = F.a[0] - F.ba[0], ay = F.a[1] - F.ba[1], az = F.a[2] - F.ba[2];
-  float ux, uy, uz;
-  cross3(qx, qy, qz, ax, ay, az, ux, uy, uz);
-  ux = ux + ux; uy = uy + uy; uz = uz + uz;
-  float cx_, cy_, cz_;
-  cross3(qx, qy, qz, ux, uy, uz, cx_, cy_, cz_);
-  float a0x = (ax + qw * ux) + cx_, a0y = (ay + qw * uy) + cy_, a0z = (az + qw * uz) + cz_;
-  a0x = a0x + F.g[0]; a0y = a0y + F.g[1]; a0z = a0z + F.g[2];
-  // q *= Quaternionf(R)
-  float ux_, uy_, uz_, uw_;
-  {
-    float tr = sum3(Rm[0], Rm[4], Rm[8]);            // trace() = diagonal().sum(): Eigen's 3-coefficient redux c0 + (c1 + c2)
-    if (tr > 0.f) {
-      tr = fl_sqrt(tr + 1.0f);
-      uw_ = 0.5f * tr;
-      tr = fl_div(0.5f, tr);
-      ux_ = (Rm[7] - Rm[5]) * tr;
-      uy_ = (Rm[2] - Rm[6]) * tr;
-      uz_ = (Rm[3] - Rm[1]) * tr;
-    } else {
-      int i = 0;
-      if (Rm[4] > Rm[0]) i = 1;
-      if (Rm[8] > Rm[i * 4]) i = 2;
-      const int j = (i + 1) % 3, kq = (j + 1) % 3;
-      float tq = fl_sqrt(Rm[i * 4] - Rm[j * 4] - Rm[kq * 4] + 1.0f);
-      float cc[3];
-      cc[i] = 0.5f * tq;
-      tq = fl_div(0.5f, tq);
-      uw_ = (Rm[kq * 3 + j] - Rm[j * 3 + kq]) * tq;
-      cc[j] = (Rm[j * 3 + i] + Rm[i * 3 + j]) * tq;
-      cc[kq] = (Rm[kq * 3 + i] + Rm[i * 3 + kq]) * tq;
-      ux_ = cc[0]; uy_ = cc[1]; uz_ = cc[2];
-    }
-  }
-  const float nqw = qw * uw_ - qx * ux_ - qy * uy_ - qz * uz_;
-  const float nqx = qw * ux_ + qx * uw_ + qy * uz_ - qz * uy_;
-  const float nqy = qw * uy_ + qy * uw_ + qz * ux_ - qx * uz_;
-  const float nqz = qw * uz_ + qz * uw_ + qx * uy_ - qy * ux_;
-  // p += v*dt + 0.5*a0*dt*dt
-  const float fdt = (float)dt;
-  const float px = F.p[0] + (fdt * F.v[0] + fdt * (fdt * (0.5f * a0x)));
-  const float py = F.p[1] + (fdt * F.v[1] + fdt * (fdt * (0.5f * a0y)));
-  const float pz = F.p[2] + (fdt * F.v[2] + fdt * (fdt * (0.5f * a0z)));
-  // T = X0.get_RT() * lidar2baselink_T  (4x4 * 4x4, columns accumulated left to right)
-  float R0[9];
-  quat_to_rot(nqx, nqy, nqz, nqw, R0);
-  const float X[16] = {R0[0], R0[1], R0[2], px, R0[3], R0[4], R0[5], py, R0[6], R0[7], R0[8], pz, 0.f, 0.f, 0.f, 1.f};
-  float T[16];
-#pragma unroll
-  for (int i = 0; i < 4; i++)
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      float acc = X[i * 4 + 0] * mats[0 * 4 + j];
-      acc = acc + X[i * 4 + 1] * mats[1 * 4 + j];
-      acc = acc + X[i * 4 + 2] * mats[2 * 4 + j];
-      acc = acc + X[i * 4 + 3] * mats[3 * 4 + j];
-      T[i * 4 + j] = acc;
-    }
-  const float4 p = in[k];
-  // world = T * [p,1]; the 4th component (T row 3) is carried like the reference does
-  float wx_ = ((T[0] * p.x + T[1] * p.y) + T[2] * p.z) + T[3] * 1.f;
-  float wy_ = ((T[4] * p.x + T[5] * p.y) + T[6] * p.z) + T[7] * 1.f;
-  float wz_ = ((T[8] * p.x + T[9] * p.y) + T[10] * p.z) + T[11] * 1.f;
-  float ww_ = ((T[12] * p.x + T[13] * p.y) + T[14] * p.z) + T[15] * 1.f;
-  const float* Li = mats + 16;
-  const float ox_ = ((Li[0] * wx_ + Li[1] * wy_) + Li[2] * wz_) + Li[3] * ww_;
-  const float oy_ = ((Li[4] * wx_ + Li[5] * wy_) + Li[6] * wz_) + Li[7] * ww_;
-  const float oz_ = ((Li[8] * wx_ + Li[9] * wy_) + Li[10] * wz_) + Li[11] * ww_;
-  out_sorted[k] = make_float4(ox_, oy_, oz_, p.w);              // p.w carries the original index
-  out_orig[__float_as_uint(p.w)] = make_float4(ox_, oy_, oz_, 1.0f);
-}
-
 // pcl::transformPointCloud (PCL 1.10 SSE2 Transformer::se3): c0*x + (c1*y + (c2*z + c3))
 __global__ __launch_bounds__(256) void transform_kernel(const float4* __restrict__ in, int n, PoseMats P,
                                                         float4* __restrict__ out) {
@@ -2225,7 +2261,7 @@ template <int L>
 static void launch_knn5_L(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const PoseMats& P,
                           int max_ring, void* nbr, int* wl, int* wl_count, unsigned long long* cand, const PrevPass& prev,
                           int tail, hipEvent_t e0, hipEvent_t e1, const FuseArgs* fuse, const TieList* tlp, int after_fine = 0,
-                          unsigned long long seq = 0ull) {
+                          unsigned long long seq = 0ull, const DeskewArgs* dk = nullptr) {
   const int qpb = 256 / L;
   const int blocks = round_up8((n + qpb - 1) / qpb);
   constexpr int slots = (L <= 4 ? 8 : 4);          // candidate loads in flight per lane
@@ -2239,6 +2275,7 @@ static void launch_knn5_L(hipStream_t st, const GridView& G, const float4* scan_
   if (tlp) nofuse.tl = *tlp;
   nofuse.fine_mode = after_fine ? 1 : 0;
   nofuse.seq = seq;
+  if (dk) nofuse.dk = *dk;
   // e0 / e1 (optional) are attached to the dispatch itself: they read the kernel's own begin / end
   // timestamps, without the extra barrier packets of hipEventRecord
   hipExtLaunchKernelGGL((knn5_kernel<L, slots, false>), dim3(blocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand, prev, tail, nofuse);
@@ -2247,16 +2284,16 @@ static void launch_knn5_L(hipStream_t st, const GridView& G, const float4* scan_
 void launch_knn5(hipStream_t st, int lanes_per_query, const GridView& G, const float4* scan_sorted, int n,
                  const PoseMats& P, int max_ring, void* nbr, int* wl, int* wl_count, unsigned long long* cand,
                  const PrevPass& prev, int tail, hipEvent_t e0, hipEvent_t e1, const FuseArgs* fuse, const TieList* tlp, int after_fine,
-                 unsigned long long seq) {
+                 unsigned long long seq, const DeskewArgs* dk) {
   if (n <= 0) return;
   if (max_ring < 2 || max_ring > TAIL_MAX_RING) tail = 0;
   switch (lanes_per_query) {
-    case 1: launch_knn5_L<1>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine, seq); break;
-    case 2: launch_knn5_L<2>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine, seq); break;
-    case 4: launch_knn5_L<4>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine, seq); break;
-    case 8: launch_knn5_L<8>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine, seq); break;
-    case 32: launch_knn5_L<32>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine, seq); break;
-    default: launch_knn5_L<16>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine, seq); break;
+    case 1: launch_knn5_L<1>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine, seq, dk); break;
+    case 2: launch_knn5_L<2>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine, seq, dk); break;
+    case 4: launch_knn5_L<4>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine, seq, dk); break;
+    case 8: launch_knn5_L<8>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine, seq, dk); break;
+    case 32: launch_knn5_L<32>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine, seq, dk); break;
+    default: launch_knn5_L<16>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine, seq, dk); break;
   }
 }
 
@@ -2320,9 +2357,10 @@ void launch_knn5_fine(hipStream_t st, const GridView& Gf, const float4* scan_sor
 void launch_match_fused(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const PoseMats& P, const MatchParams& mp,
                         void* nbr, int* wl, int* wl_count, unsigned long long* cand, const PrevPass& prev,
                         const unsigned char* live_idx, double* partials, void* out_granules, unsigned int* ticket,
-                        unsigned long long seq, hipEvent_t e0, hipEvent_t e1, const TieList* tlp, int after_fine) {
+                        unsigned long long seq, hipEvent_t e0, hipEvent_t e1, const TieList* tlp, int after_fine, const DeskewArgs* dk) {
   if (n <= 0) return;
   FuseArgs fa{};
+  if (dk) fa.dk = *dk;
   fa.fine_mode = after_fine ? 1 : 0;
   fa.tl = TieList{};
   if (tlp) fa.tl = *tlp;

@@ -41,7 +41,7 @@ typedef struct flimo_loc_cfg {
   /* MI355X additions */
   int gpu_device;
   float gpu_cell_size;
-  int debug;                   /* Config::debug (config/*.yaml `debug`): keep original_scan / deskewed / matches for the caller */
+  int debug;                   /* Config::debug (`debug` in the config yaml): keep original_scan / deskewed / matches for the caller */
 } flimo_loc_cfg;
 
 int    flimo_loc_create(const flimo_loc_cfg* cfg, flimo_loc** out);   /* Localizer::init */
