@@ -511,12 +511,12 @@ static int update_fine_grid(flimo_ctx* c, bool relayout, const float4* new_pts =
     c->crowd_cells.clear();
     c->crowd_listed = 0;
     HIPCHK(c, crowded_list_all(c->stream, g.cell_start, g.nx, g.ny, g.nz, g.xs, c->fine_threshold, c->d_crowd_bits, (int4*)c->d_crowd_list, CROWD_CAP,
-                               c->d_crowd_count, &listed));
+                               c->d_crowd_count, &listed, c->scratch));
     c->crowd_box_valid = true;
   } else {
     // same geometry as at the last look: only the cells of the points merged since can have become crowded
     HIPCHK(c, crowded_list_points(c->stream, new_pts, n_new, g.cell_start, g.ox, g.oy, g.oz, g.inv_cell, g.nx, g.ny, g.nz, g.xs,
-                                  c->fine_threshold, c->d_crowd_bits, (int4*)c->d_crowd_list, CROWD_CAP, c->d_crowd_count, &listed));
+                                  c->fine_threshold, c->d_crowd_bits, (int4*)c->d_crowd_list, CROWD_CAP, c->d_crowd_count, &listed, c->scratch));
   }
   if (listed > CROWD_CAP) return FLIMO_OK;                      // crowded all over: no region to speak of
   if (listed > c->crowd_listed) {
@@ -634,7 +634,7 @@ static int rebuild_grid(flimo_ctx* c) {
                              g.ox, g.oy, g.oz, g.inv_cell, g.nx, g.ny, g.nz, g.xs, c->scratch));
     int rc = publish_row_table(c, g.nxf, g.ny, g.nz, true);
     if (rc) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // (no wait here: everything that reads the index is queued behind this on the same stream; map_add_device ends synchronised)
     std::swap(c->d_map_sorted, c->d_map_sorted2);
     c->grid.pts = c->d_map_sorted;
     c->grid.row_table = c->d_row_table;
@@ -804,6 +804,8 @@ static int map_add_device(flimo_ctx* c, const float4* d_pts, size_t m, double st
       rc = rebuild_grid(c);
       if (rc) return rc;
     }
+    // ends synchronised: the book's node count (left in the mail words) is taken over behind the same wait
+    HIPCHK(c, c->gbook.finish(c->stream, c->scratch));
     t3 = prof ? now() : 0.0;
   }
   if (prof) fprintf(stderr, "[flimo insert] bbox %.0f us, book %.0f us, grid %.0f us (batch %zu, map %zu)\n", t1 - t0, t2 - t1, t3 - t2, m, c->map_n);

@@ -20,6 +20,8 @@ struct GBook {
   size_t node_cap = 0;
   int node_n = 0;
   int* node_n_dev = nullptr;
+  int node_n_on_dev = -1;        // the value *node_n_dev is known to hold (-1: unknown, upload before use)
+  bool finish_pending = false;   // update() left its node count in the mail words: finish() takes it over
   int root = -1;
   float root_c[3] = {0, 0, 0}, root_half = 0.f;   // host mirror of the root cube
   float min_half = 0.2f;
@@ -52,6 +54,9 @@ struct GBook {
                   bool downsample, MapBuildScratch& S);
   // Octree::update for a batch of m device points (NaN points are ignored); bb = bounding box of the
   // finite points of the batch; appends the kept points to map_raw[map_n ...] and returns their count
+  // (update() ends with its subtree builds still queued: finish() -- after any later wait on the stream, or with its own --
+  //  completes it; update() itself calls it first when the caller did not)
+  hipError_t finish(hipStream_t st, MapBuildScratch& S);
   hipError_t update(hipStream_t st, const float4* batch, int m, const float bb[6], float4* map_raw, int map_n, int* kept_out,
                     MapBuildScratch& S);
   void release();

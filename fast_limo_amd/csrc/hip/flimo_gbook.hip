@@ -496,6 +496,8 @@ hipError_t GBook::import_host(hipStream_t st, const std::vector<float>& c4, cons
   GBCHK(hipMemcpyAsync(node_cnt, cnt.data(), nn * sizeof(int), hipMemcpyHostToDevice, st));
   GBCHK(hipMemsetAsync(node_item, 0xff, node_cap * sizeof(int), st));
   node_n = (int)nn;
+  node_n_on_dev = -1;
+  finish_pending = false;
   root = root_id;
   const float* r = &c4[(size_t)root_id * 4];
   root_c[0] = r[0]; root_c[1] = r[1]; root_c[2] = r[2]; root_half = r[3];
@@ -602,6 +604,8 @@ hipError_t GBook::init(hipStream_t st, const float4* batch, int m, const float b
   GBCHK(hipMemcpyAsync(&ovf, counters + 2, sizeof(int), hipMemcpyDeviceToHost, st));
   GBCHK(hipStreamSynchronize(st));
   if (ovf) return hipErrorOutOfMemory;
+  node_n_on_dev = node_n;
+  finish_pending = false;
   *kept_out = kept;
   active = true;
   return hipGetLastError();
@@ -613,6 +617,7 @@ hipError_t GBook::update(hipStream_t st, const float4* batch, int m, const float
                          MapBuildScratch& S) {
   *kept_out = 0;
   if (m <= 0) return hipSuccess;
+  GBCHK(finish(st, S));
   // ---- root growth on the host mirror (Octree.hpp:354-374): max corner first, then min ----
   {
     std::vector<float> nc;   // new root nodes (c4) oldest first
@@ -699,12 +704,15 @@ hipError_t GBook::update(hipStream_t st, const float4* batch, int m, const float
   hipLaunchKernelGGL(gb_flags_kernel, dim3(blocks), dim3(256), 0, st, keep, m, flags);
   GBCHK(exclusive_sum(S.cub_tmp, scan_bytes, flags, rank, m, st));
   hipLaunchKernelGGL(gb_append_kernel, dim3(blocks), dim3(256), 0, st, batch, keep, rank, assign, m, map_n, map_raw, pt_leaf, new_index);
-  int h_cnt[4] = {0, 0, 0, 0};
-  uint32_t last_rank = 0, last_flag = 0;
-  GBCHK(hipMemcpyAsync(h_cnt, counters, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
-  GBCHK(hipMemcpyAsync(&last_rank, rank + (m - 1), 4, hipMemcpyDeviceToHost, st));
-  GBCHK(hipMemcpyAsync(&last_flag, flags + (m - 1), 4, hipMemcpyDeviceToHost, st));
+  // counts back through the mail words (one small kernel + one wait, no staged 4-byte copies)
+  {
+    const MailPart parts[3] = {{counters, 4, MAIL_BOOK}, {rank + (m - 1), 1, MAIL_BOOK + 4}, {flags + (m - 1), 1, MAIL_BOOK + 5}};
+    GBCHK(mail_words(st, S, parts, 3));
+  }
   GBCHK(hipStreamSynchronize(st));
+  int h_cnt[4];
+  for (int k = 0; k < 4; k++) h_cnt[k] = (int)S.mail_host[MAIL_BOOK + k];
+  const uint32_t last_rank = S.mail_host[MAIL_BOOK + 4], last_flag = S.mail_host[MAIL_BOOK + 5];
   const int n_items = h_cnt[0];
   const int kept = (int)(last_rank + last_flag);
   if ((size_t)h_cnt[1] > lists_cap) return hipErrorOutOfMemory;
@@ -713,7 +721,10 @@ hipError_t GBook::update(hipStream_t st, const float4* batch, int m, const float
     if (map_n > 0)
       hipLaunchKernelGGL(gb_gather_old_kernel, dim3((map_n + 255) / 256), dim3(256), 0, st, pt_leaf, map_n, node_item, items, cursor, lists);
     hipLaunchKernelGGL(gb_gather_new_kernel, dim3(blocks), dim3(256), 0, st, S.vals_out, assign, new_index, items, m, lists);
-    GBCHK(hipMemcpyAsync(node_n_dev, &node_n, sizeof(int), hipMemcpyHostToDevice, st));
+    if (node_n != node_n_on_dev) {                                  // (root growth on the host, or first use)
+      GBCHK(hipMemcpyAsync(node_n_dev, &node_n, sizeof(int), hipMemcpyHostToDevice, st));
+      node_n_on_dev = node_n;
+    }
     GBCHK(hipMemsetAsync(counters + 2, 0, sizeof(int), st));
     const int n_big = h_cnt[3];
     const int items_cap = m + m / 16 + 64;
@@ -725,15 +736,25 @@ hipError_t GBook::update(hipStream_t st, const float4* batch, int m, const float
     }
     hipLaunchKernelGGL(gb_build_kernel, dim3((bound + 3) / 4), dim3(256), 0, st, items, counters, map_raw, lists, tmp, node_c, node_child,
                        node_cnt, node_n_dev, (int)node_cap, min_half, pt_leaf, node_item, counters + 2);
-    int ovf = 0;
-    GBCHK(hipMemcpyAsync(&node_n, node_n_dev, sizeof(int), hipMemcpyDeviceToHost, st));
-    GBCHK(hipMemcpyAsync(&ovf, counters + 2, sizeof(int), hipMemcpyDeviceToHost, st));
-    GBCHK(hipStreamSynchronize(st));
-    if (ovf) return hipErrorOutOfMemory;
+    // the node count and the overflow mark travel by mail; the caller's next wait on the stream delivers them (finish)
+    const MailPart parts[2] = {{node_n_dev, 1, MAIL_BOOK_END}, {counters + 2, 1, MAIL_BOOK_END + 1}};
+    GBCHK(mail_words(st, S, parts, 2));
+    finish_pending = true;
   }
   *kept_out = kept;
   last_items = n_items;
   return hipGetLastError();
+}
+
+// Second half of update(): waits for the stream and takes over the node count the subtree builds left on the device.
+hipError_t GBook::finish(hipStream_t st, MapBuildScratch& S) {
+  if (!finish_pending) return hipSuccess;
+  finish_pending = false;
+  GBCHK(hipStreamSynchronize(st));
+  node_n = (int)S.mail_host[MAIL_BOOK_END];
+  node_n_on_dev = node_n;
+  if (S.mail_host[MAIL_BOOK_END + 1]) return hipErrorOutOfMemory;
+  return hipSuccess;
 }
 
 }  // namespace flimo

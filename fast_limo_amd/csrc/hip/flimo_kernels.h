@@ -96,8 +96,20 @@ struct MapBuildScratch {
   uint32_t* vals_in = nullptr;
   uint32_t* vals_out = nullptr;
   size_t cap_pts = 0;
-  float* bbox = nullptr;   // 6 floats on device (min xyz, max xyz) as ordered ints
+  float* bbox = nullptr;   // 6 floats on device (min xyz, max xyz) as ordered ints; armed (empty box) whenever no reduction is running
+  // "mail": 64 words of pinned host memory the device writes into (mail_words); the host reads them after synchronising the
+  // stream.  Replaces the 4-byte device-to-host copies (each a staged, blocking copy) of counts and boxes.
+  uint32_t* mail_host = nullptr;
+  uint32_t* mail_dev = nullptr;
 };
+// slots of the mail words
+enum MailSlot { MAIL_BOOK = 0 /* 6 */, MAIL_BOOK_END = 8 /* 2 */, MAIL_CROWD = 12, MAIL_BOXCOUNT = 13, MAIL_BBOX = 16 /* 6 */, MAIL_VOXEL = 24 /* 2 */,
+                MAIL_WORDS = 64 };
+struct MailPart { const void* src; int n; int dst; };
+// queues ONE small kernel that copies up to 6 runs of words into the mail slots; `rearm_bbox`: S.bbox is reset to the empty box
+// after it has been copied.  No synchronisation.
+hipError_t mail_words(hipStream_t st, MapBuildScratch& S, const MailPart* parts, int nparts, bool rearm_bbox = false);
+hipError_t ensure_mail(MapBuildScratch& S);
 
 // min/max of n float4 points (NaN-free) -> host bbox[6]
 hipError_t map_bbox(hipStream_t st, const float4* pts, size_t n, MapBuildScratch& S, float bbox_host[6]);
@@ -129,10 +141,10 @@ hipError_t time_order_raw(hipStream_t st, const float4* pts, const double* t, si
 // (box_host[6] = their number; box_dev: 7 ints of device scratch), and the copy of the map points inside a box of metres
 // (w = position in the main sorted map).
 hipError_t crowded_list_all(hipStream_t st, const uint32_t* cell_start, int nx, int ny, int nz, int xs, uint32_t threshold, uint32_t* bits,
-                            int4* list, uint32_t cap, uint32_t* count_dev, uint32_t* count_host);
+                            int4* list, uint32_t cap, uint32_t* count_dev, uint32_t* count_host, MapBuildScratch& S);
 hipError_t crowded_list_points(hipStream_t st, const float4* pts, size_t k, const uint32_t* cell_start, float ox, float oy, float oz,
                                float inv_cell, int nx, int ny, int nz, int xs, uint32_t threshold, uint32_t* bits, int4* list, uint32_t cap,
-                               uint32_t* count_dev, uint32_t* count_host);
+                               uint32_t* count_dev, uint32_t* count_host, MapBuildScratch& S);
 hipError_t map_box_count(hipStream_t st, const uint32_t* cell_start, int nx, int ny, int nz, int xs, const int c0[3], const int c1[3],
                          uint32_t* count_dev, uint32_t* count_host, MapBuildScratch& S);
 hipError_t map_box_copy(hipStream_t st, const float4* pts, const uint32_t* cell_start, int nx, int ny, int nz, int xs, const int c0[3],

@@ -827,8 +827,13 @@ __device__ __forceinline__ void fit_reduce_publish(const float (&v)[16], bool ow
 FLIMO_DEV void fit_row(const GridView& G, const PoseMats& P, const MatchParams& mp, const int (&ids)[5], float gx, float gy, float gz,
                        float (&v)[16]);
 
+#ifdef FLIMO_WPE
+#define KNN_WPE __attribute__((amdgpu_waves_per_eu(FLIMO_WPE, FLIMO_WPE)))
+#else
+#define KNN_WPE
+#endif
 template <int L, int SLOTS, bool FUSE, bool FINE = false>
-__global__ __launch_bounds__(256) void knn5_kernel(GridView G, const float4* __restrict__ scan_sorted, int n,
+__global__ __launch_bounds__(256) KNN_WPE void knn5_kernel(GridView G, const float4* __restrict__ scan_sorted, int n,
                                                    PoseMats P, int max_ring, NbrRec* __restrict__ nbr,
                                                    int* __restrict__ wl, int* __restrict__ wl_count,
                                                    unsigned long long* __restrict__ cand_total, PrevPass prev, int tail,

@@ -93,11 +93,52 @@ __global__ __launch_bounds__(256) void tails_kernel(const uint32_t* __restrict__
   if (i + 1 == n || keys[i + 1] != k) E[(size_t)k + 1] = (uint32_t)(i + 1);
 }
 
-static hipError_t ensure_scratch(MapBuildScratch& S, size_t n) {
+struct MailArgs { const uint32_t* src[6]; int n[6]; int dst[6]; int parts; unsigned* rearm; };
+__global__ __launch_bounds__(64) void mail_kernel(MailArgs a, uint32_t* __restrict__ mail) {
+  for (int k = 0; k < a.parts; k++)
+    if ((int)threadIdx.x < a.n[k]) mail[a.dst[k] + threadIdx.x] = a.src[k][threadIdx.x];
+  if (a.rearm && threadIdx.x < 6) {
+    __syncthreads();
+    a.rearm[threadIdx.x] = threadIdx.x < 3 ? 0xffffffffu : 0u;
+  }
+}
+hipError_t ensure_mail(MapBuildScratch& S) {
   hipError_t e;
   if (!S.bbox) {
     if ((e = hipMalloc(&S.bbox, 6 * sizeof(unsigned))) != hipSuccess) return e;
+    const unsigned init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+    if ((e = hipMemcpy(S.bbox, init, sizeof(init), hipMemcpyHostToDevice)) != hipSuccess) return e;
   }
+  if (!S.mail_host) {
+    if ((e = hipHostMalloc((void**)&S.mail_host, MAIL_WORDS * sizeof(uint32_t), hipHostMallocMapped)) != hipSuccess) return e;
+    memset(S.mail_host, 0, MAIL_WORDS * sizeof(uint32_t));
+    if ((e = hipHostGetDevicePointer((void**)&S.mail_dev, S.mail_host, 0)) != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+hipError_t mail_words(hipStream_t st, MapBuildScratch& S, const MailPart* parts, int nparts, bool rearm_bbox) {
+  hipError_t e = ensure_mail(S);
+  if (e != hipSuccess) return e;
+  MailArgs a{};
+  a.parts = nparts;
+  for (int k = 0; k < nparts && k < 6; k++) { a.src[k] = (const uint32_t*)parts[k].src; a.n[k] = parts[k].n; a.dst[k] = parts[k].dst; }
+  a.rearm = rearm_bbox ? (unsigned*)S.bbox : nullptr;
+  hipLaunchKernelGGL(mail_kernel, dim3(1), dim3(64), 0, st, a, S.mail_dev);
+  return hipGetLastError();
+}
+// the box the last bbox reduction left in S.bbox -> host (ordered-uint words), re-armed; ends synchronised
+static hipError_t fetch_bbox(hipStream_t st, MapBuildScratch& S, unsigned ob[6]) {
+  const MailPart part{S.bbox, 6, MAIL_BBOX};
+  hipError_t e = mail_words(st, S, &part, 1, true);
+  if (e != hipSuccess) return e;
+  if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+  for (int i = 0; i < 6; i++) ob[i] = S.mail_host[MAIL_BBOX + i];
+  return hipSuccess;
+}
+
+static hipError_t ensure_scratch(MapBuildScratch& S, size_t n) {
+  hipError_t e;
+  if ((e = ensure_mail(S)) != hipSuccess) return e;
   if (n > S.cap_pts) {
     if (S.keys_in) { hipFree(S.keys_in); hipFree(S.keys_out); hipFree(S.vals_in); hipFree(S.vals_out); }
     const size_t cap = n + n / 4 + 1024;
@@ -113,13 +154,10 @@ static hipError_t ensure_scratch(MapBuildScratch& S, size_t n) {
 hipError_t map_bbox(hipStream_t st, const float4* pts, size_t n, MapBuildScratch& S, float bbox_host[6]) {
   hipError_t e = ensure_scratch(S, 0);
   if (e != hipSuccess) return e;
-  unsigned init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
-  if ((e = hipMemcpyAsync(S.bbox, init, sizeof(init), hipMemcpyHostToDevice, st)) != hipSuccess) return e;
   const int blocks = (int)std::min<size_t>((n + 255) / 256, 2048);
   if (blocks > 0) hipLaunchKernelGGL(bbox_kernel, dim3(blocks), dim3(256), 0, st, pts, n, (unsigned*)S.bbox);
   unsigned out[6];
-  if ((e = hipMemcpyAsync(out, S.bbox, sizeof(out), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
-  if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+  if ((e = fetch_bbox(st, S, out)) != hipSuccess) return e;
   for (int i = 0; i < 6; i++) bbox_host[i] = o2f_host(out[i]);
   return hipSuccess;
 }
@@ -306,25 +344,31 @@ __global__ __launch_bounds__(256) void crowded_points_kernel(const float4* __res
 }
 // *count_host = entries listed so far (may exceed cap: the list is then incomplete)
 hipError_t crowded_list_all(hipStream_t st, const uint32_t* cell_start, int nx, int ny, int nz, int xs, uint32_t threshold, uint32_t* bits,
-                            int4* list, uint32_t cap, uint32_t* count_dev, uint32_t* count_host) {
+                            int4* list, uint32_t cap, uint32_t* count_dev, uint32_t* count_host, MapBuildScratch& S) {
   const size_t ncells = (size_t)nx * ny * nz;
   hipError_t e;
   if ((e = hipMemsetAsync(bits, 0, ((ncells + 31) / 32) * sizeof(uint32_t), st)) != hipSuccess) return e;
   if ((e = hipMemsetAsync(count_dev, 0, sizeof(uint32_t), st)) != hipSuccess) return e;
   hipLaunchKernelGGL(crowded_all_kernel, dim3((unsigned)((ncells + 255) / 256)), dim3(256), 0, st, cell_start, nx, ny, nz, xs, threshold, bits, list,
                      cap, count_dev);
-  if ((e = hipMemcpyAsync(count_host, count_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
-  return hipStreamSynchronize(st);
+  const MailPart part{count_dev, 1, MAIL_CROWD};
+  if ((e = mail_words(st, S, &part, 1)) != hipSuccess) return e;
+  if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+  *count_host = S.mail_host[MAIL_CROWD];
+  return hipSuccess;
 }
 hipError_t crowded_list_points(hipStream_t st, const float4* pts, size_t k, const uint32_t* cell_start, float ox, float oy, float oz,
                                float inv_cell, int nx, int ny, int nz, int xs, uint32_t threshold, uint32_t* bits, int4* list, uint32_t cap,
-                               uint32_t* count_dev, uint32_t* count_host) {
+                               uint32_t* count_dev, uint32_t* count_host, MapBuildScratch& S) {
   hipError_t e;
   if (k > 0)
     hipLaunchKernelGGL(crowded_points_kernel, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, st, pts, k, cell_start, ox, oy, oz, inv_cell, nx,
                        ny, nz, xs, threshold, bits, list, cap, count_dev);
-  if ((e = hipMemcpyAsync(count_host, count_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
-  return hipStreamSynchronize(st);
+  const MailPart part{count_dev, 1, MAIL_CROWD};
+  if ((e = mail_words(st, S, &part, 1)) != hipSuccess) return e;
+  if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+  *count_host = S.mail_host[MAIL_CROWD];
+  return hipSuccess;
 }
 // Copy of the map points of a box of cells [c0, c1] (inclusive, already clipped to the grid), w = position in the main sorted
 // map.  The map is sorted by (z, y, x column), so the box is (y1-y0+1)(z1-z0+1) contiguous ranges read off the cell table:
@@ -373,9 +417,11 @@ hipError_t map_box_count(hipStream_t st, const uint32_t* cell_start, int nx, int
   hipLaunchKernelGGL(boxrows_count_kernel, dim3((nrows + 255) / 256), dim3(256), 0, st, cell_start, ny, nx * xs, xs, c0[0], c1[0], c0[1], nyb,
                      c0[2], nrows, S.keys_in);
   if ((e = exclusive_sum(S.cub_tmp, scan_bytes, S.keys_in, S.vals_in, (size_t)nrows, st)) != hipSuccess) return e;
-  hipLaunchKernelGGL(boxrows_total_kernel, dim3(1), dim3(64), 0, st, S.keys_in, S.vals_in, nrows, count_dev);
-  if ((e = hipMemcpyAsync(count_host, count_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
-  return hipStreamSynchronize(st);
+  hipLaunchKernelGGL(boxrows_total_kernel, dim3(1), dim3(64), 0, st, S.keys_in, S.vals_in, nrows, S.mail_dev + MAIL_BOXCOUNT);
+  (void)count_dev;
+  if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+  *count_host = S.mail_host[MAIL_BOXCOUNT];
+  return hipSuccess;
 }
 // second step: the counts / offsets of map_box_count (same box, nothing else used the scratch in between) -> the copies
 hipError_t map_box_copy(hipStream_t st, const float4* pts, const uint32_t* cell_start, int nx, int ny, int nz, int xs, const int c0[3],
@@ -708,13 +754,10 @@ hipError_t batch_bbox(hipStream_t st, const float4* pts, size_t n, MapBuildScrat
   if (n == 0) return hipSuccess;
   hipError_t e = ensure_scratch(S, 0);
   if (e != hipSuccess) return e;
-  unsigned init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
-  if ((e = hipMemcpyAsync(S.bbox, init, sizeof(init), hipMemcpyHostToDevice, st)) != hipSuccess) return e;
   const int blocks = (int)std::min<size_t>((n + 1023) / 1024, 128);
   hipLaunchKernelGGL(bbox_finite_kernel, dim3(blocks), dim3(256), 0, st, pts, n, (unsigned*)S.bbox);
   unsigned ob[6];
-  if ((e = hipMemcpyAsync(ob, S.bbox, sizeof(ob), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
-  if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+  if ((e = fetch_bbox(st, S, ob)) != hipSuccess) return e;
   if (ob[0] == 0xffffffffu) return hipSuccess;
   for (int i = 0; i < 6; i++) bb[i] = o2f_host(ob[i]);
   *any = true;
@@ -730,13 +773,10 @@ hipError_t voxel_grid(hipStream_t st, const float4* in, size_t n, float leaf, fl
   if (n == 0) return hipSuccess;
   hipError_t e = ensure_scratch(S, n);
   if (e != hipSuccess) return e;
-  unsigned init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
-  if ((e = hipMemcpyAsync(S.bbox, init, sizeof(init), hipMemcpyHostToDevice, st)) != hipSuccess) return e;
   const int blocks = (int)((n + 255) / 256);
   hipLaunchKernelGGL(bbox_finite_kernel, dim3(std::max(1, std::min(blocks / 4, 128))), dim3(256), 0, st, in, n, (unsigned*)S.bbox);
   unsigned ob[6];
-  if ((e = hipMemcpyAsync(ob, S.bbox, sizeof(ob), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
-  if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+  if ((e = fetch_bbox(st, S, ob)) != hipSuccess) return e;
   if (ob[0] == 0xffffffffu) return hipSuccess;               // no finite point
   const float inv = 1.0f / leaf;
   int mb[3], db[3];
@@ -767,11 +807,10 @@ hipError_t voxel_grid(hipStream_t st, const float4* in, size_t n, float leaf, fl
   e = exclusive_sum(S.cub_tmp, scan_bytes, S.keys_in, S.vals_in, (int)n, st);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(voxelcentroid_kernel, dim3(blocks), dim3(256), 0, st, in, S.keys_out, S.vals_out, S.keys_in, S.vals_in, n, out);
-  uint32_t last_pos = 0, last_head = 0;
-  if ((e = hipMemcpyAsync(&last_pos, S.vals_in + (n - 1), 4, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
-  if ((e = hipMemcpyAsync(&last_head, S.keys_in + (n - 1), 4, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+  const MailPart parts[2] = {{S.vals_in + (n - 1), 1, MAIL_VOXEL}, {S.keys_in + (n - 1), 1, MAIL_VOXEL + 1}};
+  if ((e = mail_words(st, S, parts, 2)) != hipSuccess) return e;
   if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
-  *n_out = (size_t)last_pos + last_head;
+  *n_out = (size_t)S.mail_host[MAIL_VOXEL] + S.mail_host[MAIL_VOXEL + 1];
   return hipGetLastError();
 }
 
@@ -779,6 +818,7 @@ void map_scratch_free(MapBuildScratch& S) {
   if (S.cub_tmp) hipFree(S.cub_tmp);
   if (S.keys_in) { hipFree(S.keys_in); hipFree(S.keys_out); hipFree(S.vals_in); hipFree(S.vals_out); }
   if (S.bbox) hipFree(S.bbox);
+  if (S.mail_host) hipHostFree(S.mail_host);
   S = MapBuildScratch();
 }
 
