@@ -115,7 +115,8 @@ __global__ __launch_bounds__(256) void gb_decide_kernel(const uint32_t* __restri
                                                         float min_half, int downsample, uint32_t* __restrict__ dec_keep,
                                                         int* __restrict__ dec_assign /* leaf, or -1-item */,
                                                         GbItem* __restrict__ items, int* __restrict__ counters /* [0] items, [1] seg cursor, [3] big items */,
-                                                        int* __restrict__ node_item, int* __restrict__ big, uint32_t nan_key) {
+                                                        int* __restrict__ node_item, int* __restrict__ big, uint32_t nan_key,
+                                                        int* __restrict__ cursor /* per item: members gathered so far */) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint32_t key = keys[i];
@@ -130,6 +131,7 @@ __global__ __launch_bounds__(256) void gb_decide_kernel(const uint32_t* __restri
       const int it = atomicAdd(&counters[0], 1);
       const int seg = atomicAdd(&counters[1], cnt + g);
       items[it] = GbItem{node, 8, i, g, cnt, seg};
+      cursor[it] = 0;
       node_item[node] = it;
       if (cnt + g > kBigItem) big[atomicAdd(&counters[3], 1)] = it;
       dec_keep[i] = 1u; dec_assign[i] = -1 - it;
@@ -143,6 +145,7 @@ __global__ __launch_bounds__(256) void gb_decide_kernel(const uint32_t* __restri
     const int it = atomicAdd(&counters[0], 1);
     const int seg = atomicAdd(&counters[1], g);
     items[it] = GbItem{node, slot, i, g, 0, seg};
+    cursor[it] = 0;
     if (g > kBigItem) big[atomicAdd(&counters[3], 1)] = it;
     dec_keep[i] = 1u; dec_assign[i] = -1 - it;
   }
@@ -151,12 +154,15 @@ __global__ __launch_bounds__(256) void gb_decide_kernel(const uint32_t* __restri
 // every sorted element copies its group's decision to its batch point
 __global__ __launch_bounds__(256) void gb_apply_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ perm, int n,
                                                        const uint32_t* __restrict__ dec_keep, const int* __restrict__ dec_assign,
-                                                       unsigned char* __restrict__ keep, int* __restrict__ assign) {
+                                                       unsigned char* __restrict__ keep, int* __restrict__ assign,
+                                                       uint32_t* __restrict__ keep_word /* the same as a 0/1 word, for the rank scan */) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int h = run_begin(keys, i, keys[i]);
   const uint32_t pt = perm[i];
-  keep[pt] = (unsigned char)dec_keep[h];
+  const uint32_t k = dec_keep[h];
+  keep[pt] = (unsigned char)k;
+  keep_word[pt] = k ? 1u : 0u;
   assign[pt] = dec_assign[h];
 }
 
@@ -504,6 +510,7 @@ hipError_t GBook::import_host(hipStream_t st, const std::vector<float>& c4, cons
   GBCHK(grow(pt_leaf, pt_cap, (size_t)map_n + 1024, 0, st));
   if (!node_n_dev) GBCHK(hipMalloc(&node_n_dev, sizeof(int)));
   if (!counters) GBCHK(hipMalloc(&counters, 4 * sizeof(int)));
+  GBCHK(hipMemsetAsync(counters, 0, 4 * sizeof(int), st));
   if (map_n > 0)
     hipLaunchKernelGGL(gb_leafof_kernel, dim3((map_n + 255) / 256), dim3(256), 0, st, map_raw, map_n, node_c, node_child, node_cnt, root, pt_leaf);
   GBCHK(hipStreamSynchronize(st));
@@ -604,6 +611,7 @@ hipError_t GBook::init(hipStream_t st, const float4* batch, int m, const float b
   GBCHK(hipMemcpyAsync(&ovf, counters + 2, sizeof(int), hipMemcpyDeviceToHost, st));
   GBCHK(hipStreamSynchronize(st));
   if (ovf) return hipErrorOutOfMemory;
+  GBCHK(hipMemsetAsync(counters, 0, 4 * sizeof(int), st));      // update() expects them zero (its final mail re-zeroes them)
   node_n_on_dev = node_n;
   finish_pending = false;
   *kept_out = kept;
@@ -696,17 +704,18 @@ hipError_t GBook::update(hipStream_t st, const float4* batch, int m, const float
     S.cub_tmp_bytes = need + 1024;
   }
   GBCHK(sort_pairs_u32(S.cub_tmp, tmp_bytes, S.keys_in, S.keys_out, S.vals_in, S.vals_out, m, 0, key_bits, st));
-  GBCHK(hipMemsetAsync(counters, 0, 4 * sizeof(int), st));
+  // (counters: zero since the last batch's final mail, see below)
   hipLaunchKernelGGL(gb_decide_kernel, dim3(blocks), dim3(256), 0, st, S.keys_out, m, node_c, node_cnt, min_half,
-                     downsample ? 1 : 0, flags /* dec_keep */, reinterpret_cast<int*>(rank) /* dec_assign */, items, counters, node_item, big_items, nan_key);
+                     downsample ? 1 : 0, flags /* dec_keep */, reinterpret_cast<int*>(rank) /* dec_assign */, items, counters, node_item, big_items, nan_key,
+                     cursor);
+  // keep flags as words for the rank scan: into the sort's (now free) key input buffer
   hipLaunchKernelGGL(gb_apply_kernel, dim3(blocks), dim3(256), 0, st, S.keys_out, S.vals_out, m, flags, reinterpret_cast<const int*>(rank),
-                     keep, assign);
-  hipLaunchKernelGGL(gb_flags_kernel, dim3(blocks), dim3(256), 0, st, keep, m, flags);
-  GBCHK(exclusive_sum(S.cub_tmp, scan_bytes, flags, rank, m, st));
+                     keep, assign, S.keys_in);
+  GBCHK(exclusive_sum(S.cub_tmp, scan_bytes, S.keys_in, rank, m, st));
   hipLaunchKernelGGL(gb_append_kernel, dim3(blocks), dim3(256), 0, st, batch, keep, rank, assign, m, map_n, map_raw, pt_leaf, new_index);
   // counts back through the mail words (one small kernel + one wait, no staged 4-byte copies)
   {
-    const MailPart parts[3] = {{counters, 4, MAIL_BOOK}, {rank + (m - 1), 1, MAIL_BOOK + 4}, {flags + (m - 1), 1, MAIL_BOOK + 5}};
+    const MailPart parts[3] = {{counters, 4, MAIL_BOOK}, {rank + (m - 1), 1, MAIL_BOOK + 4}, {S.keys_in + (m - 1), 1, MAIL_BOOK + 5}};
     GBCHK(mail_words(st, S, parts, 3));
   }
   GBCHK(hipStreamSynchronize(st));
@@ -717,7 +726,6 @@ hipError_t GBook::update(hipStream_t st, const float4* batch, int m, const float
   const int kept = (int)(last_rank + last_flag);
   if ((size_t)h_cnt[1] > lists_cap) return hipErrorOutOfMemory;
   if (n_items > 0) {
-    GBCHK(hipMemsetAsync(cursor, 0, (size_t)n_items * sizeof(int), st));
     if (map_n > 0)
       hipLaunchKernelGGL(gb_gather_old_kernel, dim3((map_n + 255) / 256), dim3(256), 0, st, pt_leaf, map_n, node_item, items, cursor, lists);
     hipLaunchKernelGGL(gb_gather_new_kernel, dim3(blocks), dim3(256), 0, st, S.vals_out, assign, new_index, items, m, lists);
@@ -725,8 +733,7 @@ hipError_t GBook::update(hipStream_t st, const float4* batch, int m, const float
       GBCHK(hipMemcpyAsync(node_n_dev, &node_n, sizeof(int), hipMemcpyHostToDevice, st));
       node_n_on_dev = node_n;
     }
-    GBCHK(hipMemsetAsync(counters + 2, 0, sizeof(int), st));
-    const int n_big = h_cnt[3];
+    const int n_big = h_cnt[3];                      // (counters[2], the overflow mark, is zero like the others)
     const int items_cap = m + m / 16 + 64;
     int bound = n_items;
     if (n_big > 0) {
@@ -737,9 +744,12 @@ hipError_t GBook::update(hipStream_t st, const float4* batch, int m, const float
     hipLaunchKernelGGL(gb_build_kernel, dim3((bound + 3) / 4), dim3(256), 0, st, items, counters, map_raw, lists, tmp, node_c, node_child,
                        node_cnt, node_n_dev, (int)node_cap, min_half, pt_leaf, node_item, counters + 2);
     // the node count and the overflow mark travel by mail; the caller's next wait on the stream delivers them (finish)
+    // ... and the same small kernel zeroes the four counters for the next batch
     const MailPart parts[2] = {{node_n_dev, 1, MAIL_BOOK_END}, {counters + 2, 1, MAIL_BOOK_END + 1}};
-    GBCHK(mail_words(st, S, parts, 2));
+    GBCHK(mail_words(st, S, parts, 2, false, counters, 4));
     finish_pending = true;
+  } else {
+    GBCHK(hipMemsetAsync(counters, 0, 4 * sizeof(int), st));       // nothing to build: [1] / [3] may still be set
   }
   *kept_out = kept;
   last_items = n_items;

@@ -107,8 +107,9 @@ enum MailSlot { MAIL_BOOK = 0 /* 6 */, MAIL_BOOK_END = 8 /* 2 */, MAIL_CROWD = 1
                 MAIL_WORDS = 64 };
 struct MailPart { const void* src; int n; int dst; };
 // queues ONE small kernel that copies up to 6 runs of words into the mail slots; `rearm_bbox`: S.bbox is reset to the empty box
-// after it has been copied.  No synchronisation.
-hipError_t mail_words(hipStream_t st, MapBuildScratch& S, const MailPart* parts, int nparts, bool rearm_bbox = false);
+// after it has been copied; `zero` / `zero_n`: words set to 0 after the copy (counters for the next round).  No synchronisation.
+hipError_t mail_words(hipStream_t st, MapBuildScratch& S, const MailPart* parts, int nparts, bool rearm_bbox = false, void* zero = nullptr,
+                      int zero_n = 0);
 hipError_t ensure_mail(MapBuildScratch& S);
 
 // min/max of n float4 points (NaN-free) -> host bbox[6]

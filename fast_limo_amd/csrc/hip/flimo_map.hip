@@ -93,14 +93,13 @@ __global__ __launch_bounds__(256) void tails_kernel(const uint32_t* __restrict__
   if (i + 1 == n || keys[i + 1] != k) E[(size_t)k + 1] = (uint32_t)(i + 1);
 }
 
-struct MailArgs { const uint32_t* src[6]; int n[6]; int dst[6]; int parts; unsigned* rearm; };
+struct MailArgs { const uint32_t* src[6]; int n[6]; int dst[6]; int parts; unsigned* rearm; uint32_t* zero; int zero_n; };
 __global__ __launch_bounds__(64) void mail_kernel(MailArgs a, uint32_t* __restrict__ mail) {
   for (int k = 0; k < a.parts; k++)
     if ((int)threadIdx.x < a.n[k]) mail[a.dst[k] + threadIdx.x] = a.src[k][threadIdx.x];
-  if (a.rearm && threadIdx.x < 6) {
-    __syncthreads();
-    a.rearm[threadIdx.x] = threadIdx.x < 3 ? 0xffffffffu : 0u;
-  }
+  __syncthreads();                                   // (one wave: orders the copies before the resets below)
+  if (a.rearm && threadIdx.x < 6) a.rearm[threadIdx.x] = threadIdx.x < 3 ? 0xffffffffu : 0u;
+  if (a.zero && (int)threadIdx.x < a.zero_n) a.zero[threadIdx.x] = 0u;
 }
 hipError_t ensure_mail(MapBuildScratch& S) {
   hipError_t e;
@@ -116,13 +115,14 @@ hipError_t ensure_mail(MapBuildScratch& S) {
   }
   return hipSuccess;
 }
-hipError_t mail_words(hipStream_t st, MapBuildScratch& S, const MailPart* parts, int nparts, bool rearm_bbox) {
+hipError_t mail_words(hipStream_t st, MapBuildScratch& S, const MailPart* parts, int nparts, bool rearm_bbox, void* zero, int zero_n) {
   hipError_t e = ensure_mail(S);
   if (e != hipSuccess) return e;
   MailArgs a{};
   a.parts = nparts;
   for (int k = 0; k < nparts && k < 6; k++) { a.src[k] = (const uint32_t*)parts[k].src; a.n[k] = parts[k].n; a.dst[k] = parts[k].dst; }
   a.rearm = rearm_bbox ? (unsigned*)S.bbox : nullptr;
+  a.zero = (uint32_t*)zero; a.zero_n = zero_n;
   hipLaunchKernelGGL(mail_kernel, dim3(1), dim3(64), 0, st, a, S.mail_dev);
   return hipGetLastError();
 }
@@ -220,6 +220,24 @@ __device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t* __restrict__
   }
   return lo;
 }
+// The same by a whole wave (every lane gets the result): 64 probes per round instead of one -- 3 dependent loads for 64k keys
+// instead of 16.  The blocks below search once for their first and once for their last element before they stream.
+__device__ __forceinline__ uint32_t wave_lower_bound_u32(const uint32_t* __restrict__ keys, uint32_t k, uint32_t key) {
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t lo = 0u, hi = k;                            // the answer lies in [lo, hi]
+  while (hi - lo > 64u) {
+    const uint32_t step = (hi - lo + 63u) / 64u;
+    const uint32_t idx = lo + lane * step + (step - 1u);            // last element of this lane's segment
+    const bool below = idx < hi && keys[idx] < key;                  // monotone over the lanes (sorted keys)
+    const uint32_t c = (uint32_t)__popcll(__ballot(below));
+    const uint32_t nlo = min(lo + c * step, hi);
+    hi = min(nlo + (step - 1u), hi);
+    lo = nlo;
+  }
+  const uint32_t idx = lo + lane;
+  const bool below = idx < hi && keys[idx] < key;
+  return lo + (uint32_t)__popcll(__ballot(below));
+}
 // new point j (cell-sorted) -> behind the stored points of its cell: position = j + #stored points in cells <= key
 __global__ __launch_bounds__(256) void merge_new_kernel(const float4* __restrict__ new_pts, const uint32_t* __restrict__ nkeys,
                                                         const uint32_t* __restrict__ nperm, uint32_t k,
@@ -232,7 +250,7 @@ __global__ __launch_bounds__(256) void merge_new_kernel(const float4* __restrict
 __global__ __launch_bounds__(256) void merge_old_kernel(const float4* __restrict__ old_pts, uint32_t n_old,
                                                         const uint32_t* __restrict__ nkeys, uint32_t k, float ox, float oy, float oz,
                                                         float inv_cell, int nx, int ny, int nz, int xs, float4* __restrict__ out) {
-  __shared__ uint32_t s_lo, s_hi;
+  __shared__ uint32_t s_lo, s_hi, s_c0, s_c1;
   const uint32_t base = blockIdx.x * blockDim.x;
   const uint32_t i = base + threadIdx.x;
   const uint32_t last = min(n_old, base + blockDim.x) - 1u;
@@ -241,9 +259,12 @@ __global__ __launch_bounds__(256) void merge_old_kernel(const float4* __restrict
   if (i < n_old) {
     p = old_pts[i];
     cid = column_key(p, ox, oy, oz, inv_cell, nx, ny, nz, xs);
-    if (i == base) s_lo = lower_bound_u32(nkeys, 0u, k, cid);
-    if (i == last) s_hi = lower_bound_u32(nkeys, 0u, k, cid + 1u);
+    if (i == base) s_c0 = cid;
+    if (i == last) s_c1 = cid + 1u;
   }
+  __syncthreads();
+  if (threadIdx.x < 64) { const uint32_t r = wave_lower_bound_u32(nkeys, k, s_c0); if (threadIdx.x == 0) s_lo = r; }
+  else if (threadIdx.x < 128) { const uint32_t r = wave_lower_bound_u32(nkeys, k, s_c1); if (threadIdx.x == 64) s_hi = r; }
   __syncthreads();
   if (i >= n_old) return;
   const uint32_t lo = s_lo, hi = s_hi;
@@ -257,8 +278,8 @@ __global__ __launch_bounds__(256) void cellstart_shift_kernel(uint32_t* __restri
   constexpr int PER = 16;
   const size_t base = (size_t)blockIdx.x * (blockDim.x * PER);
   const size_t top = min(n_entries, base + (size_t)blockDim.x * PER) - 1;
-  if (threadIdx.x == 0) s_lo = lower_bound_u32(nkeys, 0u, k, (uint32_t)base);
-  if (threadIdx.x == 64) s_hi = lower_bound_u32(nkeys, 0u, k, (uint32_t)top);
+  if (threadIdx.x < 64) { const uint32_t r = wave_lower_bound_u32(nkeys, k, (uint32_t)base); if (threadIdx.x == 0) s_lo = r; }
+  else if (threadIdx.x < 128) { const uint32_t r = wave_lower_bound_u32(nkeys, k, (uint32_t)top); if (threadIdx.x == 64) s_hi = r; }
   __syncthreads();
   const uint32_t lo = s_lo, hi = s_hi;
   if (hi == 0u) return;                                  // nothing new below this chunk: entries unchanged
