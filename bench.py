@@ -322,9 +322,11 @@ def shipped_config_leg(device, with_oracle, n_sweeps=10, n_pts=120000):
 
     fresh = [s.copy() for s in sweeps]                                  # (the call filters its input cloud in place, like the reference)
 
+    cloud_buf = np.zeros((n_pts, 3), np.float32)
+
     def feed_gpu(L, k):
         rc = L.update_pointcloud_points(fresh[k], 0.1 * k)
-        L.final_scan()
+        L.final_scan(out=cloud_buf)
         return rc
     tg = drive(G, feed_gpu, lambda L: L.sync())
     out = {"workload": "config/kitti.yaml filters / caps / voxel grid / extrinsics, debug on, clouds downloaded: %d raw sweeps of %d points, "
@@ -645,6 +647,7 @@ def main():
         loc.set_flags(add_to_map=True, download_clouds=True, keep_log=False)
         sweeps = [api.make_points_velodyne(synth.velodyne_scan(args.rings, args.azimuths, args.box, 300 + j)) for j in range(args.e2e_sweeps)]
         lat, tot_sw = [], []
+        cloud_buf = np.zeros((max(s_.shape[0] for s_ in sweeps), 3), np.float32)
         loc.sync()
         for j in range(args.e2e_sweeps):
             until = 0.1 * (k + 1) + 0.005
@@ -652,7 +655,7 @@ def main():
                 loc.update_imu(st[i], w[i], a[i]); i += 1
             t1 = time.perf_counter()
             rc = loc.update_pointcloud_points(sweeps[j], 0.1 * k)
-            n_final = loc.final_scan().shape[0]                  # the caller takes the cloud (get_pointcloud)
+            n_final = loc.final_scan(out=cloud_buf).shape[0]     # the caller takes the cloud (get_pointcloud) into its own buffer
             t2 = time.perf_counter()
             loc.sync()
             t3 = time.perf_counter()

@@ -277,16 +277,20 @@ class Localizer:
             out.append(dict(M=M.value, HTH=HTH.reshape(12, 12), HTh=HTh, dx=dx, x_after=xa))
         return out
 
-    def pc2match(self):
-        n = int(self._L.flimo_loc_get_pc2match(self._h, None, 0))
-        out = np.empty((max(n, 1), 3), np.float32)
-        self._L.flimo_loc_get_pc2match(self._h, out.ctypes.data, n)
-        return out[:n]
+    def pc2match(self, out=None):
+        """xyz of get_pc2match_pointcloud(); `out`: a C-contiguous float32 (>= n, 3) array to fill instead of a fresh one."""
+        return self._cloud(self._L.flimo_loc_get_pc2match, out)
 
-    def final_scan(self):
-        n = int(self._L.flimo_loc_get_final_scan(self._h, None, 0))
-        out = np.empty((max(n, 1), 3), np.float32)
-        self._L.flimo_loc_get_final_scan(self._h, out.ctypes.data, n)
+    def final_scan(self, out=None):
+        """xyz of get_pointcloud() (world frame); `out` as for pc2match."""
+        return self._cloud(self._L.flimo_loc_get_final_scan, out)
+
+    def _cloud(self, getter, out):
+        n = int(getter(self._h, None, 0))
+        if out is None or out.shape[0] < n:
+            out = np.empty((max(n, 1), 3), np.float32)
+        assert out.dtype == np.float32 and out.flags["C_CONTIGUOUS"] and out.shape[1] == 3
+        getter(self._h, out.ctypes.data, n)
         return out[:n]
 
     def stage_times(self):

@@ -122,6 +122,8 @@ struct flimo_ctx {
   int mfma_idx[16][16];            // (i,j) -> raw index
   // staging
   void* h_stage = nullptr;         // pinned
+  void* h_clouds = nullptr;        // pinned: the two clouds of flimo_scan_clouds
+  size_t clouds_cap = 0;
   size_t stage_cap = 0;
   // timing
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [0,1] k-NN / fused dispatch, [2,3] fit, [4,5] widening
@@ -415,6 +417,7 @@ extern "C" void flimo_ctx_destroy(flimo_ctx* c) {
   (void)hipFree(c->d_fit2_partials);
   if (c->h_cand) (void)hipHostFree(c->h_cand);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
+  if (c->h_clouds) (void)hipHostFree(c->h_clouds);
   for (int k = 0; k < 2; k++) if (c->h_frames[k]) (void)hipHostFree(c->h_frames[k]);
   map_scratch_free(c->scratch);
   for (int i = 0; i < 6; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -1771,6 +1774,33 @@ extern "C" int flimo_scan_to_world(flimo_ctx* c, const double x26[26], float* ou
   HIPCHK(c, hipGetLastError());
   if (out && cap) return download_xyz(c, c->d_scan_world, std::min(cap, c->scan_n), out);
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  return FLIMO_OK;
+}
+
+extern "C" int flimo_scan_clouds(flimo_ctx* c, const double x26[26], const float** body, const float** world, size_t* n) {
+  if (!c || !x26 || !body || !world || !n) return FLIMO_ERR_INVALID;
+  *body = *world = nullptr;
+  *n = c->scan_n;
+  if (c->scan_n == 0) return FLIMO_OK;
+  (void)hipSetDevice(c->device);
+  const size_t bytes = c->scan_n * sizeof(float4);
+  if (2 * bytes > c->clouds_cap) {
+    if (c->h_clouds) (void)hipHostFree(c->h_clouds);
+    c->h_clouds = nullptr; c->clouds_cap = 0;
+    const size_t cap = 2 * bytes + bytes / 2 + 4096;
+    HIPCHK(c, hipHostMalloc(&c->h_clouds, cap, hipHostMallocDefault));
+    c->clouds_cap = cap;
+  }
+  PoseMats P;
+  pose_from_x26(x26, P);
+  { const int rcf = flush_deskew(c); if (rcf) return rcf; }
+  HIPCHK(c, hipMemcpyAsync(c->h_clouds, c->d_scan, bytes, hipMemcpyDeviceToHost, c->stream));
+  launch_transform(c->stream, c->d_scan, (int)c->scan_n, P, c->d_scan_world);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync((char*)c->h_clouds + bytes, c->d_scan_world, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *body = (const float*)c->h_clouds;
+  *world = (const float*)((const char*)c->h_clouds + bytes);
   return FLIMO_OK;
 }
 

@@ -13,6 +13,7 @@ using namespace fast_limo;
 struct flimo_loc {
   std::unique_ptr<Mapper> map;
   std::unique_ptr<Localizer> loc;
+  pcl::PointCloud<PointType>::Ptr in_pc;     // the cloud the last sweep came in with: its storage is reused when nobody kept it
 };
 
 static Config to_config(const flimo_loc_cfg* c) {
@@ -108,9 +109,12 @@ int flimo_loc_update_pointcloud(flimo_loc* L, const float* pts5, size_t n, doubl
 int flimo_loc_update_pointcloud_points(flimo_loc* L, const void* pts32, size_t n, double stamp) {
   if (!L || (!pts32 && n)) return FLIMO_ERR_INVALID;
   static_assert(sizeof(PointType) == 32, "PointType must keep the reference's 32-byte layout");
-  auto pc = std::make_shared<pcl::PointCloud<PointType>>();
+  // (a fresh cloud per sweep costs its pages' first touch -- about as much as the copy; the library filters the cloud in place
+  //  and keeps no pointer to it, so the last sweep's storage is free again unless the wrapper's user took it)
+  pcl::PointCloud<PointType>::Ptr pc = (L->in_pc && L->in_pc.use_count() == 1) ? L->in_pc : std::make_shared<pcl::PointCloud<PointType>>();
   pc->points.resize(n);
   if (n) std::memcpy(static_cast<void*>(&pc->points[0]), pts32, n * sizeof(PointType));
+  L->in_pc = pc;
   L->loc->updatePointCloud(pc, stamp);
   return L->loc->last_status();
 }

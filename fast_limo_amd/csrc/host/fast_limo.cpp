@@ -5,11 +5,16 @@
 // Modules/Localizer.cpp (file:line cited per function).  Compile with -ffp-contract=off: the
 // float32 pose algebra must round like the reference (no FMA).
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
 #include <functional>
 #include <iostream>
+#include <memory>
+#include <mutex>
+#include <thread>
 
 #include "../../../include/flimo_c.h"
 #include "fast_limo/Modules/Localizer.hpp"
@@ -376,6 +381,71 @@ Matches Mapper::match(State s, pcl::PointCloud<PointType>::Ptr& pc) {   // Mappe
 }
 
 // ---------------------------------------------------------------------------------------------
+// Helper threads of a Localizer: the host-only part of handing the clouds back (filters on the host copy, time order, assembling
+// two PCL clouds) runs beside the GPU work instead of after it.  Each worker has its own queue (a task can be pinned to a worker:
+// the time-order routine keeps a per-thread memo); wait() returns when everything queued has run.
+// ---------------------------------------------------------------------------------------------
+namespace flimo_host {
+class Helpers {
+ public:
+  explicit Helpers(int n) {
+    for (int i = 0; i < n; i++) w_.emplace_back(new Worker());
+    for (auto& w : w_) w->th = std::thread([this, p = w.get()] { loop(*p); });
+  }
+  ~Helpers() {
+    for (auto& w : w_) { { std::lock_guard<std::mutex> g(w->m); w->stop = true; } w->cv.notify_one(); }
+    for (auto& w : w_) w->th.join();
+  }
+  int size() const { return (int)w_.size(); }
+  void run(int worker, std::function<void()> f) {
+    Worker& w = *w_[(size_t)worker % w_.size()];
+    pending_.fetch_add(1, std::memory_order_relaxed);
+    { std::lock_guard<std::mutex> g(w.m); w.q.push_back(std::move(f)); w.queued.fetch_add(1, std::memory_order_release); }
+    w.cv.notify_one();
+  }
+  void wait() {
+    // short spin first: the tasks are tens to hundreds of microseconds, a sleeping waiter's wake-up costs as much again
+    for (int k = 0; k < 20000 && pending_.load(std::memory_order_acquire) != 0; k++) std::this_thread::yield();
+    std::unique_lock<std::mutex> g(dm_);
+    dcv_.wait(g, [this] { return pending_.load(std::memory_order_acquire) == 0; });
+  }
+ private:
+  struct Worker {
+    std::thread th; std::mutex m; std::condition_variable cv; std::deque<std::function<void()>> q; bool stop = false;
+    std::atomic<int> queued{0};
+  };
+  void loop(Worker& w) {
+    bool worked = false;
+    for (;;) {
+      std::function<void()> f;
+      if (worked) {
+        // the tasks of one sweep follow each other within a few hundred microseconds (filters ... assembly): poll that long
+        // before sleeping -- a sleeping thread's wake-up costs as much as the task
+        const auto t0 = std::chrono::steady_clock::now();
+        while (w.queued.load(std::memory_order_acquire) == 0 &&
+               std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(600)) {}
+      }
+      {
+        std::unique_lock<std::mutex> g(w.m);
+        w.cv.wait(g, [&] { return w.stop || !w.q.empty(); });
+        if (w.q.empty()) return;
+        f = std::move(w.q.front());
+        w.q.pop_front();
+        w.queued.fetch_sub(1, std::memory_order_relaxed);
+      }
+      f();
+      worked = true;
+      if (pending_.fetch_sub(1, std::memory_order_acq_rel) == 1) { std::lock_guard<std::mutex> g(dm_); dcv_.notify_all(); }
+    }
+  }
+  std::vector<std::unique_ptr<Worker>> w_;
+  std::atomic<int> pending_{0};
+  std::mutex dm_;
+  std::condition_variable dcv_;
+};
+}  // namespace flimo_host
+
+// ---------------------------------------------------------------------------------------------
 // Localizer
 // ---------------------------------------------------------------------------------------------
 Localizer::Localizer() : Localizer(&Mapper::getInstance()) { own_map_ = false; }
@@ -392,7 +462,7 @@ Localizer::Localizer(Mapper* map)
   for (int i = 0; i < 4; i++) stage_t_[i] = 0.0;
   last_imu.stamp = 0; last_imu.dt = 0;
 }
-Localizer::~Localizer() { delete ikfom_; }
+Localizer::~Localizer() { helpers_.reset(); delete ikfom_; }
 
 void Localizer::init(Config& cfg) {                                // Localizer.cpp:35-117
   config = cfg;
@@ -1231,26 +1301,21 @@ void Localizer::filterInput(pcl::PointCloud<PointType>::Ptr& raw_pc, pcl::PointC
 // are put together AFTER the update -- the filter's mutex is free, the pose is out -- from the device's buffers and the host copy of
 // the sweep: the same input filters on the host copy (which also leaves *raw_pc filtered in place, as the reference does), the
 // order of the kept points from the device (its time order, or -- a sweep left in arrival order -- the host's time order routine).
-void Localizer::materializeClouds(pcl::PointCloud<PointType>::Ptr& raw_pc) {
-  flimo_ctx* c = map_->ctx();
-  if (!c) return;
-  static const bool prof = std::getenv("FLIMO_PROF_CLOUDS") != nullptr;     // developer timing of the stages
-  const double tp0 = prof ? now_s() : 0.0;
-  auto input_pc = fast_limo::make_shared<pcl::PointCloud<PointType>>();
-  filterInput(raw_pc, input_pc);
-  if (config.debug) original_scan = fast_limo::make_shared<pcl::PointCloud<PointType>>(*input_pc);
-  const size_t m = input_pc->points.size();
-  if (last_status_ != 0 || m == 0) { pc2match = fast_limo::make_shared<pcl::PointCloud<PointType>>(); return; }
-  const double tp1 = prof ? now_s() : 0.0;
-  // pc2match position -> index in input_pc
-  std::vector<uint32_t>& order = lazy_order_;
-  if (dev_time_ordered_) {
-    order.resize(m);
-    size_t got = 0;
-    flimo_raw_scan_order(c, order.data(), m, &got);
-    if (got != m) { std::cout << "FAST_LIMO::WARNING: device and host input filters disagree (" << got << " vs " << m << " points)\n"; return; }
-  } else {
-    const std::vector<PointType>& P = input_pc->points;
+void Localizer::startCloudPrep(pcl::PointCloud<PointType>::Ptr& raw_pc) {
+  // host-only part, on helper 0 (always the same thread: time_order's memo is per thread) while the GPU runs the passes
+  if (!helpers_) helpers_.reset(new flimo_host::Helpers(3));
+  prep_input_ = fast_limo::make_shared<pcl::PointCloud<PointType>>();
+  prep_started_ = true;
+  pcl::PointCloud<PointType>::Ptr* raw = &raw_pc;                // (the caller's pointer outlives the task: materializeClouds waits)
+  if (raw_pc->points.size() >= 16384)                              // the helpers that will share the assembly: awake and polling by then
+    for (int w = 1; w < helpers_->size(); w++) helpers_->run(w, [] {});
+  helpers_->run(0, [this, raw] {
+    filterInput(*raw, prep_input_);
+    if (config.debug) original_scan = fast_limo::make_shared<pcl::PointCloud<PointType>>(*prep_input_);
+    if (dev_time_ordered_) return;                                 // the order comes from the device
+    const std::vector<PointType>& P = prep_input_->points;
+    const size_t m = P.size();
+    std::vector<uint32_t>& order = lazy_order_;
     const bool desc = config.end_of_sweep && (sensor == SensorType::OUSTER || sensor == SensorType::VELODYNE);
     if (sensor == SensorType::OUSTER) {
       std::vector<uint32_t> k(m);
@@ -1265,20 +1330,48 @@ void Localizer::materializeClouds(pcl::PointCloud<PointType>::Ptr& raw_pc) {
       for (size_t i = 0; i < m; i++) k[i] = P[i].timestamp;
       time_order(k.data(), 2, m, desc, false, order);
     }
+  });
+}
+
+// The device's side of the clouds: deskewed points (body frame), the same in the world frame, and -- a sweep the device put into
+// time order -- that order.  Called right after the last pass, before the map insert is handed to the Mapper's thread.
+void Localizer::downloadClouds(const double x26[26]) {
+  flimo_ctx* c = map_->ctx();
+  if (!c) return;
+  // resident pc2match (the deskewed points, or the voxel centroids) and its world-frame image: one round trip, no repacking
+  size_t n_dev = 0, got = 0;
+  if (flimo_scan_clouds(c, x26, &mat_body4_, &mat_world4_, &n_dev) != FLIMO_OK) return;
+  mat_n_dev_ = n_dev;
+  if (dev_time_ordered_) {
+    size_t m = 0;
+    flimo_raw_scan_order(c, nullptr, 0, &m);
+    lazy_order_.resize(m);
+    flimo_raw_scan_order(c, lazy_order_.data(), m, &got);
   }
-  const double tp2 = prof ? now_s() : 0.0;
-  const size_t n_dev = flimo_scan_size(c);                       // resident pc2match: the deskewed points, or the voxel centroids
-  mat_body_.resize(n_dev * 3); mat_world_.resize(n_dev * 3);
-  size_t got = 0;
-  flimo_scan_get(c, mat_body_.data(), n_dev, &got);
-  double x26[26];
-  mtx_ikfom.lock();
-  ikfom_->get_x().to_flat(x26);
-  mtx_ikfom.unlock();
-  flimo_scan_to_world(c, x26, mat_world_.data(), n_dev);
-  const double tp3 = prof ? now_s() : 0.0;
-  const float* body = mat_body_.data();
-  const float* world = mat_world_.data();
+  mat_downloaded_ = true;
+}
+
+void Localizer::materializeClouds(pcl::PointCloud<PointType>::Ptr& raw_pc) {
+  static const bool prof = std::getenv("FLIMO_PROF_CLOUDS") != nullptr;     // developer timing of the stages
+  const double tp0 = prof ? now_s() : 0.0;
+  if (!prep_started_) startCloudPrep(raw_pc);
+  helpers_->wait();
+  prep_started_ = false;
+  pcl::PointCloud<PointType>::Ptr input_pc = prep_input_;
+  prep_input_.reset();
+  const size_t m = input_pc->points.size();
+  if (last_status_ != 0 || m == 0 || !mat_downloaded_) { pc2match = fast_limo::make_shared<pcl::PointCloud<PointType>>(); return; }
+  mat_downloaded_ = false;
+  const double tp1 = prof ? now_s() : 0.0;
+  // pc2match position -> index in input_pc
+  const std::vector<uint32_t>& order = lazy_order_;
+  if (!dev_voxel_ && order.size() != m) {
+    std::cout << "FAST_LIMO::WARNING: device and host input filters disagree (" << order.size() << " vs " << m << " points)\n";
+    return;
+  }
+  const size_t n_dev = mat_n_dev_;
+  const float* body = mat_body4_;
+  const float* world = mat_world4_;
   // (the storage of the last sweep's clouds is taken over when the caller has let go of them: no fresh pages to fault in)
   if (pc2match == mat_pm_) pc2match.reset();
   if (final_scan == mat_fs_) final_scan.reset();
@@ -1286,33 +1379,46 @@ void Localizer::materializeClouds(pcl::PointCloud<PointType>::Ptr& raw_pc) {
   pcl::PointCloud<PointType>::Ptr fs = (mat_fs_ && mat_fs_.use_count() == 1) ? mat_fs_ : fast_limo::make_shared<pcl::PointCloud<PointType>>();
   pm->points.resize(n_dev);
   fs->points.resize(n_dev);
-  if (dev_voxel_) {
-    for (size_t k = 0; k < n_dev; k++) {
-      PointType p{};
-      p.x = body[3 * k]; p.y = body[3 * k + 1]; p.z = body[3 * k + 2];
-      pm->points[k] = p;
-      p.x = world[3 * k]; p.y = world[3 * k + 1]; p.z = world[3 * k + 2];
-      fs->points[k] = p;
+  PointType* pmp = pm->points.data();
+  PointType* fsp = fs->points.data();
+  const PointType* in = input_pc->points.data();
+  const bool vox = dev_voxel_, ordered = dev_time_ordered_;
+  const size_t n_out = vox ? n_dev : std::min(n_dev, m);
+  auto assemble = [=, &order](size_t k0, size_t k1) {
+    if (vox) {
+      for (size_t k = k0; k < k1; k++) {
+        PointType p{};
+        p.x = body[4 * k]; p.y = body[4 * k + 1]; p.z = body[4 * k + 2];
+        pmp[k] = p;
+        p.x = world[4 * k]; p.y = world[4 * k + 1]; p.z = world[4 * k + 2];
+        fsp[k] = p;
+      }
+      return;
     }
-  } else {
     // device order: its time order (position k = input_pc[order[k]]) or arrival order (position j = input_pc[j], shown at rank k)
-    for (size_t k = 0; k < n_dev && k < m; k++) {
+    for (size_t k = k0; k < k1; k++) {
       const size_t src = order[k];
-      const size_t dev = dev_time_ordered_ ? k : src;
-      PointType p = input_pc->points[src];
-      p.x = body[3 * dev]; p.y = body[3 * dev + 1]; p.z = body[3 * dev + 2];
-      pm->points[k] = p;
-      p.x = world[3 * dev]; p.y = world[3 * dev + 1]; p.z = world[3 * dev + 2];
-      fs->points[k] = p;
+      const size_t dev = ordered ? k : src;
+      PointType p = in[src];
+      p.x = body[4 * dev]; p.y = body[4 * dev + 1]; p.z = body[4 * dev + 2];
+      pmp[k] = p;
+      p.x = world[4 * dev]; p.y = world[4 * dev + 1]; p.z = world[4 * dev + 2];
+      fsp[k] = p;
     }
-  }
+  };
+  // four slices: three helpers and this thread (small clouds: not worth waking anybody)
+  const int parts = n_out >= 16384 ? helpers_->size() + 1 : 1;
+  const size_t per = (n_out + parts - 1) / parts;
+  for (int w = 1; w < parts; w++) helpers_->run(w - 1, [=] { assemble(std::min(n_out, w * per), std::min(n_out, (w + 1) * per)); });
+  assemble(0, std::min(n_out, per));
+  if (parts > 1) helpers_->wait();
   mat_pm_.reset(); mat_fs_.reset();
   pc2match = pm;
   final_scan = fs;
   mat_pm_ = pm; mat_fs_ = fs;
   if (prof)
-    fprintf(stderr, "[flimo clouds] input filters %.0f us, order %.0f us, downloads %.0f us, assembly %.0f us (%zu -> %zu points, %zu resident)\n",
-            (tp1 - tp0) * 1e6, (tp2 - tp1) * 1e6, (tp3 - tp2) * 1e6, (now_s() - tp3) * 1e6, raw_pc->points.size(), m, n_dev);
+    fprintf(stderr, "[flimo clouds] wait for the host filters / order %.0f us, assembly %.0f us (%zu -> %zu points, %zu resident)\n",
+            (tp1 - tp0) * 1e6, (now_s() - tp1) * 1e6, raw_pc->points.size(), m, n_dev);
 }
 
 // Benchmark entry (inputs resident in HBM): restores the given prior, then GPU deskew of the
@@ -1347,6 +1453,8 @@ void Localizer::updatePointCloud(pcl::PointCloud<PointType>::Ptr& raw_pc, double
   const int on_device = deskewOnDevice(raw_pc, time_stamp);            // filters + stamps (+ time order, voxel grid) + deskew on the GPU
   if (on_device != 0) {
     const double t2d = now_s();
+    mat_downloaded_ = false;
+    if (download_clouds || config.debug) startCloudPrep(raw_pc);        // host filters / order beside the GPU's passes
     finishUpdate(on_device > 0, t0_dev, t0_dev, t2d);
     if (download_clouds || config.debug) {
       const double tm0 = now_s();
@@ -1411,6 +1519,7 @@ void Localizer::finishUpdate(bool ok, double t0, double t1, double t2) {
         final_scan->points[k].x = w[3 * j]; final_scan->points[k].y = w[3 * j + 1]; final_scan->points[k].z = w[3 * j + 2];
       }
     }
+    if (dev_front_end_ && (download_clouds || config.debug)) downloadClouds(x26);   // before the insert takes the context
     if (add_to_map) map_->add_scan(x26, scan_stamp);               // returns at once; the insert overlaps the next scan's host work
     t4 = now_s();
   } else {

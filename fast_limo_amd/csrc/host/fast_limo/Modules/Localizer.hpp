@@ -5,6 +5,7 @@
 #define __FASTLIMO_LOCALIZER_HPP__
 #include <condition_variable>
 #include <deque>
+#include <memory>
 #include <mutex>
 #include "fast_limo/Common.hpp"
 #include "flimo_c.h"
@@ -13,7 +14,7 @@
 #include "fast_limo/Objects/State.hpp"
 #include "fast_limo/Utils/Config.hpp"
 
-namespace flimo_host { class Esekf; struct StateIkfom; }
+namespace flimo_host { class Esekf; struct StateIkfom; class Helpers; }
 typedef flimo_host::StateIkfom state_ikfom;     // the reference's name of the filter state (IKFoM/use-ikfom.hpp:12-21)
 
 class fast_limo::Localizer {
@@ -122,7 +123,17 @@ class fast_limo::Localizer {
   bool dev_front_end_ = false;          // the last sweep went through the device front end (clouds materialized afterwards)
   bool dev_time_ordered_ = false;       // ... and the device holds it in the reference's time order (stamps pairwise different)
   bool dev_voxel_ = false;
-  std::vector<float> mat_body_, mat_world_;   // download staging of materializeClouds
+  const float* mat_body4_ = nullptr;          // the downloaded clouds (float4 records in the context's pinned memory)
+  const float* mat_world4_ = nullptr;
+  // Materialization in three steps: the host-only part (input filters on the host copy, debug copy, host time order) runs on a
+  // helper thread beside the GPU's front end and passes; the downloads follow the last pass (before the map insert is handed to
+  // the Mapper's thread, which then owns the context); the two clouds are assembled by the helpers and the caller's thread.
+  std::unique_ptr<flimo_host::Helpers> helpers_;
+  pcl::PointCloud<PointType>::Ptr prep_input_;
+  size_t mat_n_dev_ = 0;
+  bool mat_downloaded_ = false, prep_started_ = false;
+  void startCloudPrep(pcl::PointCloud<PointType>::Ptr& raw_pc);
+  void downloadClouds(const double x26[26]);
   pcl::PointCloud<PointType>::Ptr mat_pm_, mat_fs_;   // the clouds it handed out last (their storage is reused once the caller let go)
   size_t arrival_last_ = 0;             // index of the point the reference's sort would put last
   float rs_l2b_[16];

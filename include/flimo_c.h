@@ -166,6 +166,10 @@ int flimo_match_fetch_H(flimo_ctx* ctx, double* H, double* h, size_t cap_rows, s
 /* ---- path exit: pcl::transformPointCloud(pc2match, state.get_RT()) + Mapper::add
  *      (Modules/Localizer.cpp:361-377).  world_xyz_out may be NULL. ---- */
 int flimo_scan_to_world(flimo_ctx* ctx, const double x26[26], float* world_xyz_out, size_t cap);
+/* Both clouds the caller of Localizer::updatePointCloud may ask for (pc2match: body frame; final_scan: world frame of pose x26,
+ * Localizer.cpp:361-371) in ONE round trip: packed float4 records (x, y, z, unused) in pinned memory owned by the context, valid
+ * until the next flimo_scan_clouds on it.  *n = points in each. */
+int flimo_scan_clouds(flimo_ctx* ctx, const double x26[26], const float** body_xyzw, const float** world_xyzw, size_t* n);
 int flimo_map_add_scan(flimo_ctx* ctx, const double x26[26], double stamp);
 
 /* ---- instrumentation ---- */

@@ -1000,7 +1000,10 @@ def test_crowded_cells_second_level_is_exact(built, oracle):
         for j, sw in enumerate(sweeps):
             ctx.scan_set(sw)
             if label == "fine":
-                oc.update(ctx.scan_to_world(x_true))              # the same world points, the same insert rule
+                world = ctx.scan_to_world(x_true)
+                both = ctx.scan_clouds(x_true)                    # the one-round-trip download hands out the same two clouds
+                assert np.array_equal(both[0], ctx.scan_get()) and np.array_equal(both[1], world)
+                oc.update(world)                                  # the same world points, the same insert rule
             ctx.map_add_scan(x_true, 0.1 * (j + 1))
         assert ctx.map_size() == oc.size()
         fs = ctx.fine_stats()
