@@ -423,7 +423,7 @@ class Helpers {
         // before sleeping -- a sleeping thread's wake-up costs as much as the task
         const auto t0 = std::chrono::steady_clock::now();
         while (w.queued.load(std::memory_order_acquire) == 0 &&
-               std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(600)) {}
+               std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(1000)) {}
       }
       {
         std::unique_lock<std::mutex> g(w.m);
@@ -1179,13 +1179,17 @@ pcl::PointCloud<PointType>::Ptr Localizer::deskewPointCloud(pcl::PointCloud<Poin
 // order (see deskewPointCloud) and nobody asked for host copies of the clouds; the FoV filter (host libm's atan2) and NaN stamps
 // stay on the host path.  Returns 0 = not applicable (take the host path), 1 = deskewed scan resident, -1 = sweep rejected
 // (the same early returns as deskewPointCloud).
+bool Localizer::deviceFrontEndEnabled() const {
+  if (!gpu_filters || !lazy_time_order || config.filters.fov_active) return false;
+  return sensor == SensorType::OUSTER || sensor == SensorType::VELODYNE || sensor == SensorType::HESAI || sensor == SensorType::LIVOX;
+}
+
 int Localizer::deskewOnDevice(pcl::PointCloud<PointType>::Ptr& raw_pc, double start_time) {
   const auto& fl = config.filters;
   const auto& mc = config.ikfom.mapping;
   const size_t n = raw_pc->points.size();
   dev_front_end_ = false;
-  if (!gpu_filters || !lazy_time_order || fl.fov_active) return 0;
-  if (sensor != SensorType::OUSTER && sensor != SensorType::VELODYNE && sensor != SensorType::HESAI && sensor != SensorType::LIVOX) return 0;
+  if (!deviceFrontEndEnabled()) return 0;
   flimo_ctx* c = map_->ctx();
   if (!c) return 0;
   // WHO needs the reference's time order on the device?  "The first N of pc2match" (MAX_NUM_PC2MATCH / MAX_NUM_MATCHES) and the
@@ -1213,6 +1217,7 @@ int Localizer::deskewOnDevice(pcl::PointCloud<PointType>::Ptr& raw_pc, double st
   dev_front_end_ = true;
   dev_time_ordered_ = need_order;
   dev_voxel_ = false;
+  if (prep_started_) prep_go_.store(need_order ? 1 : 2, std::memory_order_release);   // the raw cloud is uploaded: the helper may go on
   pc2match = fast_limo::make_shared<pcl::PointCloud<PointType>>();      // put together after the update when somebody wants it
   if (kept < 1) return -1;
   double offset = 0.0;
@@ -1256,7 +1261,7 @@ int Localizer::deskewOnDevice(pcl::PointCloud<PointType>::Ptr& raw_pc, double st
 // Input filters of updatePointCloud in ONE pass over the raw cloud: removeNaNFromPointCloud (Localizer.cpp:263-265), negative
 // CropBox (:268-271), distance / rate / FoV filters (:274-302).  As in the reference, *raw_pc itself ends up NaN-free and cropped
 // (both filters write back into it), and the rate filter counts positions in that cropped cloud.
-void Localizer::filterInput(pcl::PointCloud<PointType>::Ptr& raw_pc, pcl::PointCloud<PointType>::Ptr& input_pc) {
+void Localizer::filterInput(pcl::PointCloud<PointType>::Ptr& raw_pc, pcl::PointCloud<PointType>::Ptr& input_pc, bool compact_raw) {
   std::vector<PointType>& P = raw_pc->points;
   const bool crop = config.filters.crop_active, dist = config.filters.dist_active;
   const bool rate_on = config.filters.rate_active && config.filters.rate_value >= 1;   // (the reference divides by the value)
@@ -1281,7 +1286,7 @@ void Localizer::filterInput(pcl::PointCloud<PointType>::Ptr& raw_pc, pcl::PointC
     const bool finite = std::isfinite(p.x) & std::isfinite(p.y) & std::isfinite(p.z);
     const bool outside = (p.x < mn0) | (p.y < mn1) | (p.z < mn2) | (p.x > mx0) | (p.y > mx1) | (p.z > mx2);   // not strictly inside the box
     if (!(finite & (!crop | outside))) continue;
-    if (k != i) P[k] = p;
+    if (compact_raw && k != i) P[k] = p;
     const bool pick = !rate_on || phase == 0;
     if (rate_on && ++phase == rate) phase = 0;
     k++;
@@ -1292,8 +1297,32 @@ void Localizer::filterInput(pcl::PointCloud<PointType>::Ptr& raw_pc, pcl::PointC
     Q[m] = p;
     m += keep ? 1 : 0;
   }
-  P.resize(k);
   Q.resize(m);
+  if (!compact_raw) return;
+  P.resize(k);
+  raw_pc->is_dense = true;
+}
+
+// The part of filterInput that writes back into *raw_pc (NaN removal and crop box, Localizer.cpp:263-271), for a caller that ran
+// filterInput(..., false) while somebody else was still reading the raw cloud.
+void Localizer::compactRaw(pcl::PointCloud<PointType>::Ptr& raw_pc) {
+  std::vector<PointType>& P = raw_pc->points;
+  const bool crop = config.filters.crop_active;
+  const float mn0 = crop ? config.filters.cropBoxMin[0] : 0.f, mn1 = crop ? config.filters.cropBoxMin[1] : 0.f,
+              mn2 = crop ? config.filters.cropBoxMin[2] : 0.f;
+  const float mx0 = crop ? config.filters.cropBoxMax[0] : 0.f, mx1 = crop ? config.filters.cropBoxMax[1] : 0.f,
+              mx2 = crop ? config.filters.cropBoxMax[2] : 0.f;
+  const size_t n = P.size();
+  size_t k = 0;
+  for (size_t i = 0; i < n; i++) {
+    const PointType p = P[i];
+    const bool finite = std::isfinite(p.x) & std::isfinite(p.y) & std::isfinite(p.z);
+    const bool outside = (p.x < mn0) | (p.y < mn1) | (p.z < mn2) | (p.x > mx0) | (p.y > mx1) | (p.z > mx2);
+    if (!(finite & (!crop | outside))) continue;
+    if (k != i) P[k] = p;
+    k++;
+  }
+  P.resize(k);
   raw_pc->is_dense = true;
 }
 
@@ -1307,15 +1336,22 @@ void Localizer::startCloudPrep(pcl::PointCloud<PointType>::Ptr& raw_pc) {
   prep_input_ = fast_limo::make_shared<pcl::PointCloud<PointType>>();
   prep_started_ = true;
   pcl::PointCloud<PointType>::Ptr* raw = &raw_pc;                // (the caller's pointer outlives the task: materializeClouds waits)
-  if (raw_pc->points.size() >= 16384)                              // the helpers that will share the assembly: awake and polling by then
-    for (int w = 1; w < helpers_->size(); w++) helpers_->run(w, [] {});
-  helpers_->run(0, [this, raw] {
-    filterInput(*raw, prep_input_);
+  if (raw_pc->points.size() >= 16384) helpers_->run(2, [] {});      // (shares the assembly: awake and polling by then, like the other two)
+  prep_go_.store(0, std::memory_order_relaxed);
+  // which order will the device hold the sweep in?  (the same rule as deskewOnDevice; if it declines the sweep the host path does
+  // its own sort and the order computed here is not used)
+  const auto& mc = config.ikfom.mapping;
+  const size_t n_raw = raw_pc->points.size();
+  const bool caps = (mc.MAX_NUM_PC2MATCH >= 0 && n_raw > (size_t)mc.MAX_NUM_PC2MATCH) || (mc.MAX_NUM_MATCHES >= 0 && n_raw > (size_t)mc.MAX_NUM_MATCHES);
+  const bool host_order = !(caps || config.filters.voxel_active);
+  helpers_->run(0, [this, raw, host_order] {
+    // the device front end may still be reading the raw cloud (upload): filter WITHOUT writing back
+    filterInput(*raw, prep_input_, false);
     if (config.debug) original_scan = fast_limo::make_shared<pcl::PointCloud<PointType>>(*prep_input_);
-    if (dev_time_ordered_) return;                                 // the order comes from the device
+    if (!host_order) return;                                       // the order comes from the device
     const std::vector<PointType>& P = prep_input_->points;
     const size_t m = P.size();
-    std::vector<uint32_t>& order = lazy_order_;
+    std::vector<uint32_t>& order = prep_order_;
     const bool desc = config.end_of_sweep && (sensor == SensorType::OUSTER || sensor == SensorType::VELODYNE);
     if (sensor == SensorType::OUSTER) {
       std::vector<uint32_t> k(m);
@@ -1331,6 +1367,11 @@ void Localizer::startCloudPrep(pcl::PointCloud<PointType>::Ptr& raw_pc) {
       time_order(k.data(), 2, m, desc, false, order);
     }
   });
+  // once the caller's thread says the cloud is free, it is left filtered as the reference leaves it
+  helpers_->run(1, [this, raw] {
+    while (prep_go_.load(std::memory_order_acquire) == 0) std::this_thread::yield();
+    compactRaw(*raw);
+  });
 }
 
 // The device's side of the clouds: deskewed points (body frame), the same in the world frame, and -- a sweep the device put into
@@ -1345,8 +1386,8 @@ void Localizer::downloadClouds(const double x26[26]) {
   if (dev_time_ordered_) {
     size_t m = 0;
     flimo_raw_scan_order(c, nullptr, 0, &m);
-    lazy_order_.resize(m);
-    flimo_raw_scan_order(c, lazy_order_.data(), m, &got);
+    prep_order_.resize(m);
+    flimo_raw_scan_order(c, prep_order_.data(), m, &got);
   }
   mat_downloaded_ = true;
 }
@@ -1354,7 +1395,7 @@ void Localizer::downloadClouds(const double x26[26]) {
 void Localizer::materializeClouds(pcl::PointCloud<PointType>::Ptr& raw_pc) {
   static const bool prof = std::getenv("FLIMO_PROF_CLOUDS") != nullptr;     // developer timing of the stages
   const double tp0 = prof ? now_s() : 0.0;
-  if (!prep_started_) startCloudPrep(raw_pc);
+  if (!prep_started_) return;
   helpers_->wait();
   prep_started_ = false;
   pcl::PointCloud<PointType>::Ptr input_pc = prep_input_;
@@ -1364,7 +1405,7 @@ void Localizer::materializeClouds(pcl::PointCloud<PointType>::Ptr& raw_pc) {
   mat_downloaded_ = false;
   const double tp1 = prof ? now_s() : 0.0;
   // pc2match position -> index in input_pc
-  const std::vector<uint32_t>& order = lazy_order_;
+  const std::vector<uint32_t>& order = prep_order_;
   if (!dev_voxel_ && order.size() != m) {
     std::cout << "FAST_LIMO::WARNING: device and host input filters disagree (" << order.size() << " vs " << m << " points)\n";
     return;
@@ -1399,6 +1440,11 @@ void Localizer::materializeClouds(pcl::PointCloud<PointType>::Ptr& raw_pc) {
     for (size_t k = k0; k < k1; k++) {
       const size_t src = order[k];
       const size_t dev = ordered ? k : src;
+      if (k + 24 < k1) {                                           // the sweep's time order is a scattered walk over three arrays
+        const size_t nsrc = order[k + 24];
+        __builtin_prefetch(&in[nsrc]);
+        if (!ordered) { __builtin_prefetch(&body[4 * nsrc]); __builtin_prefetch(&world[4 * nsrc]); }
+      }
       PointType p = in[src];
       p.x = body[4 * dev]; p.y = body[4 * dev + 1]; p.z = body[4 * dev + 2];
       pmp[k] = p;
@@ -1450,11 +1496,16 @@ void Localizer::updatePointCloud(pcl::PointCloud<PointType>::Ptr& raw_pc, double
   if (!imu_calibrated_) { last_status_ = -2; return; }
   if (imu_buffer.empty()) { std::cout << "FAST_LIMO::IMU buffer is empty!\n"; last_status_ = -3; return; }
   const double t0_dev = now_s();
+  // the clouds the caller may ask for: their host-only part (filters on the host copy, time order) starts now, on a helper thread
+  const bool want_clouds = download_clouds || config.debug;
+  prep_started_ = false;
+  if (want_clouds && deviceFrontEndEnabled()) startCloudPrep(raw_pc);
   const int on_device = deskewOnDevice(raw_pc, time_stamp);            // filters + stamps (+ time order, voxel grid) + deskew on the GPU
+  if (prep_started_ && prep_go_.load(std::memory_order_relaxed) == 0)    // (deskewOnDevice says so itself as early as it can)
+    prep_go_.store(on_device != 0 ? (dev_time_ordered_ ? 1 : 2) : 3, std::memory_order_release);
   if (on_device != 0) {
     const double t2d = now_s();
     mat_downloaded_ = false;
-    if (download_clouds || config.debug) startCloudPrep(raw_pc);        // host filters / order beside the GPU's passes
     finishUpdate(on_device > 0, t0_dev, t0_dev, t2d);
     if (download_clouds || config.debug) {
       const double tm0 = now_s();
@@ -1463,9 +1514,17 @@ void Localizer::updatePointCloud(pcl::PointCloud<PointType>::Ptr& raw_pc, double
     }
     return;
   }
-  auto input_pc = fast_limo::make_shared<pcl::PointCloud<PointType>>();
-  filterInput(raw_pc, input_pc);
-  if (config.debug) original_scan = fast_limo::make_shared<pcl::PointCloud<PointType>>(*input_pc);
+  pcl::PointCloud<PointType>::Ptr input_pc;
+  if (prep_started_) {                                           // the device front end declined the sweep: the helper has filtered it
+    helpers_->wait();
+    prep_started_ = false;
+    input_pc = prep_input_;
+    prep_input_.reset();
+  } else {
+    input_pc = fast_limo::make_shared<pcl::PointCloud<PointType>>();
+    filterInput(raw_pc, input_pc);
+    if (config.debug) original_scan = fast_limo::make_shared<pcl::PointCloud<PointType>>(*input_pc);
+  }
   const double t1 = now_s();
   bool ok = (bool)deskewPointCloud(input_pc, time_stamp);       // sets pc2match (:307)
   if (!ok) pc2match = fast_limo::make_shared<pcl::PointCloud<PointType>>();

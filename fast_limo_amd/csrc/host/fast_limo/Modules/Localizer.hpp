@@ -3,6 +3,7 @@
 // host IESKF with the GPU measurement seam -> GPU transform -> map insert.
 #ifndef __FASTLIMO_LOCALIZER_HPP__
 #define __FASTLIMO_LOCALIZER_HPP__
+#include <atomic>
 #include <condition_variable>
 #include <deque>
 #include <memory>
@@ -87,7 +88,7 @@ class fast_limo::Localizer {
   pcl::PointCloud<PointType>::Ptr deskewPointCloud(pcl::PointCloud<PointType>::Ptr& pc, double& start_time);   // Localizer.hpp:191
   int deskewOnDevice(pcl::PointCloud<PointType>::Ptr& raw_pc, double start_time);       // filters + stamps + deskew on the GPU (f-2)
   void finishUpdate(bool ok, double t0, double t1, double t2);
-  void filterInput(pcl::PointCloud<PointType>::Ptr& raw_pc, pcl::PointCloud<PointType>::Ptr& input_pc);   // Localizer.cpp:262-302 in one pass
+  void filterInput(pcl::PointCloud<PointType>::Ptr& raw_pc, pcl::PointCloud<PointType>::Ptr& input_pc, bool compact_raw = true);   // Localizer.cpp:262-302 in one pass
   void materializeClouds(pcl::PointCloud<PointType>::Ptr& raw_pc);     // device front end: host clouds after the update
   bool propagatedFromTimeRange(double start_time, double end_time, States& frames);
   bool imuMeasFromTimeRange(double start_time, double end_time, std::vector<IMUmeas>& meas);   // Localizer.cpp:917-949, oldest first
@@ -130,8 +131,12 @@ class fast_limo::Localizer {
   // the Mapper's thread, which then owns the context); the two clouds are assembled by the helpers and the caller's thread.
   std::unique_ptr<flimo_host::Helpers> helpers_;
   pcl::PointCloud<PointType>::Ptr prep_input_;
+  std::vector<uint32_t> prep_order_;         // materialized pc2match position -> index among the host-filtered points
   size_t mat_n_dev_ = 0;
   bool mat_downloaded_ = false, prep_started_ = false;
+  std::atomic<int> prep_go_{0};              // 0: the raw cloud is still being read; 1 / 2 / 3: free -- order from the device / host order wanted / none
+  bool deviceFrontEndEnabled() const;
+  void compactRaw(pcl::PointCloud<PointType>::Ptr& raw_pc);
   void startCloudPrep(pcl::PointCloud<PointType>::Ptr& raw_pc);
   void downloadClouds(const double x26[26]);
   pcl::PointCloud<PointType>::Ptr mat_pm_, mat_fs_;   // the clouds it handed out last (their storage is reused once the caller let go)
