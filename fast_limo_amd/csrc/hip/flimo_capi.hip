@@ -1094,6 +1094,16 @@ extern "C" int flimo_raw_scan_set(flimo_ctx* c, const float* xyz, size_t n, size
   return FLIMO_OK;
 }
 
+extern "C" int flimo_upload_stage(flimo_ctx* c, size_t bytes, void** host_ptr) {
+  if (!c || !host_ptr) return FLIMO_ERR_INVALID;
+  *host_ptr = nullptr;
+  (void)hipSetDevice(c->device);
+  const int rc = ensure_stage(c, bytes);
+  if (rc) return rc;
+  *host_ptr = c->h_stage;
+  return FLIMO_OK;
+}
+
 extern "C" int flimo_raw_scan_filter_set(flimo_ctx* c, const void* points32, size_t n, const flimo_filter_cfg* cfg, size_t* n_kept,
                                          double* last_stamp, int* nan_stamp) {
   int tied = 0;
@@ -1134,9 +1144,14 @@ extern "C" int flimo_raw_scan_filter_order_set(flimo_ctx* c, const void* points3
     HIPCHK(c, hipMalloc(&c->d_t_tmp, cap * sizeof(double)));
     c->tkey_cap = cap;
   }
-  rc = ensure_stage(c, n * 32);
-  if (rc) return rc;
-  {
+  const bool staged = points32 == c->h_stage && n * 32 <= c->stage_cap;     // the caller filled flimo_upload_stage's buffer itself
+  if (!staged) {
+    rc = ensure_stage(c, n * 32);
+    if (rc) return rc;
+  }
+  if (staged) {
+    HIPCHK(c, hipMemcpyAsync(c->d_raw32, c->h_stage, n * 32, hipMemcpyHostToDevice, c->stream));
+  } else {
     // pageable caller memory -> pinned stage -> HBM in chunks: the DMA of a chunk runs while the next one is staged
     const size_t total = n * 32, chunk = 512u << 10;
     for (size_t o = 0; o < total; o += chunk) {

@@ -1210,14 +1210,43 @@ int Localizer::deskewOnDevice(pcl::PointCloud<PointType>::Ptr& raw_pc, double st
   double last_stamp = 0.0;
   int nan = 0, tied = 0;
   static_assert(sizeof(PointType) == 32, "PointType layout");
-  if (flimo_raw_scan_filter_order_set(c, &raw_pc->points[0], n, &fc, need_order ? 1 : 0, &kept, &last_stamp, &nan, &tied) != FLIMO_OK || nan || tied)
+  const void* src = &raw_pc->points[0];
+  if (n >= 32768) {
+    // pageable cloud -> the context's pinned upload buffer, shared with two helpers (chunks are taken from a common counter: a
+    // helper that wakes late finds nothing left and nobody waits for it)
+    void* stage = nullptr;
+    if (flimo_upload_stage(c, n * sizeof(PointType), &stage) == FLIMO_OK && stage) {
+      if (!helpers_) helpers_.reset(new flimo_host::Helpers(3));
+      struct CopyJob {
+        const char* src; char* dst; size_t total, chunk, nchunks;
+        std::atomic<size_t> next{0}, done{0};
+        void work() {
+          for (;;) {
+            const size_t i = next.fetch_add(1, std::memory_order_relaxed);
+            if (i >= nchunks) return;
+            const size_t o = i * chunk;
+            std::memcpy(dst + o, src + o, std::min(chunk, total - o));
+            done.fetch_add(1, std::memory_order_release);
+          }
+        }
+      };
+      auto job = std::make_shared<CopyJob>();
+      job->src = (const char*)src; job->dst = (char*)stage; job->total = n * sizeof(PointType); job->chunk = 128u << 10;
+      job->nchunks = (job->total + job->chunk - 1) / job->chunk;
+      for (int w = 1; w <= 2; w++) helpers_->run(w, [job] { job->work(); });
+      job->work();
+      while (job->done.load(std::memory_order_acquire) < job->nchunks) {}
+      src = stage;
+    }
+  }
+  if (flimo_raw_scan_filter_order_set(c, src, n, &fc, need_order ? 1 : 0, &kept, &last_stamp, &nan, &tied) != FLIMO_OK || nan || tied)
     return 0;
   lazy_order_.clear();
   arrival_order_ = !need_order;
   dev_front_end_ = true;
   dev_time_ordered_ = need_order;
   dev_voxel_ = false;
-  if (prep_started_) prep_go_.store(need_order ? 1 : 2, std::memory_order_release);   // the raw cloud is uploaded: the helper may go on
+  releaseRawCloud();                                                       // the raw cloud is uploaded
   pc2match = fast_limo::make_shared<pcl::PointCloud<PointType>>();      // put together after the update when somebody wants it
   if (kept < 1) return -1;
   double offset = 0.0;
@@ -1336,8 +1365,8 @@ void Localizer::startCloudPrep(pcl::PointCloud<PointType>::Ptr& raw_pc) {
   prep_input_ = fast_limo::make_shared<pcl::PointCloud<PointType>>();
   prep_started_ = true;
   pcl::PointCloud<PointType>::Ptr* raw = &raw_pc;                // (the caller's pointer outlives the task: materializeClouds waits)
-  if (raw_pc->points.size() >= 16384) helpers_->run(2, [] {});      // (shares the assembly: awake and polling by then, like the other two)
-  prep_go_.store(0, std::memory_order_relaxed);
+  if (raw_pc->points.size() >= 16384)                              // the helpers that will share the assembly: awake and polling by then
+    for (int w = 1; w < helpers_->size(); w++) helpers_->run(w, [] {});
   // which order will the device hold the sweep in?  (the same rule as deskewOnDevice; if it declines the sweep the host path does
   // its own sort and the order computed here is not used)
   const auto& mc = config.ikfom.mapping;
@@ -1367,11 +1396,16 @@ void Localizer::startCloudPrep(pcl::PointCloud<PointType>::Ptr& raw_pc) {
       time_order(k.data(), 2, m, desc, false, order);
     }
   });
-  // once the caller's thread says the cloud is free, it is left filtered as the reference leaves it
-  helpers_->run(1, [this, raw] {
-    while (prep_go_.load(std::memory_order_acquire) == 0) std::this_thread::yield();
-    compactRaw(*raw);
-  });
+  prep_raw_ = raw;
+}
+
+// The raw cloud is no longer read by anybody else (uploaded, or the device front end declined the sweep): it is left NaN-free and
+// cropped, as the reference leaves it -- on a helper, beside the passes.
+void Localizer::releaseRawCloud() {
+  if (!prep_started_ || !prep_raw_) return;
+  pcl::PointCloud<PointType>::Ptr* raw = prep_raw_;
+  prep_raw_ = nullptr;
+  helpers_->run(0, [this, raw] { compactRaw(*raw); });           // helper 0: behind its read-only filter pass over the same cloud
 }
 
 // The device's side of the clouds: deskewed points (body frame), the same in the world frame, and -- a sweep the device put into
@@ -1501,8 +1535,7 @@ void Localizer::updatePointCloud(pcl::PointCloud<PointType>::Ptr& raw_pc, double
   prep_started_ = false;
   if (want_clouds && deviceFrontEndEnabled()) startCloudPrep(raw_pc);
   const int on_device = deskewOnDevice(raw_pc, time_stamp);            // filters + stamps (+ time order, voxel grid) + deskew on the GPU
-  if (prep_started_ && prep_go_.load(std::memory_order_relaxed) == 0)    // (deskewOnDevice says so itself as early as it can)
-    prep_go_.store(on_device != 0 ? (dev_time_ordered_ ? 1 : 2) : 3, std::memory_order_release);
+  releaseRawCloud();                                                     // (deskewOnDevice does so itself as early as it can)
   if (on_device != 0) {
     const double t2d = now_s();
     mat_downloaded_ = false;

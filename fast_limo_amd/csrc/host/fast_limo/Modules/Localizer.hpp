@@ -134,7 +134,8 @@ class fast_limo::Localizer {
   std::vector<uint32_t> prep_order_;         // materialized pc2match position -> index among the host-filtered points
   size_t mat_n_dev_ = 0;
   bool mat_downloaded_ = false, prep_started_ = false;
-  std::atomic<int> prep_go_{0};              // 0: the raw cloud is still being read; 1 / 2 / 3: free -- order from the device / host order wanted / none
+  pcl::PointCloud<PointType>::Ptr* prep_raw_ = nullptr;   // the caller's cloud while its in-place filtering is still owed (releaseRawCloud)
+  void releaseRawCloud();
   bool deviceFrontEndEnabled() const;
   void compactRaw(pcl::PointCloud<PointType>::Ptr& raw_pc);
   void startCloudPrep(pcl::PointCloud<PointType>::Ptr& raw_pc);

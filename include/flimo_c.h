@@ -138,6 +138,10 @@ typedef struct flimo_filter_cfg {
 } flimo_filter_cfg;
 int flimo_raw_scan_filter_set(flimo_ctx* ctx, const void* points32, size_t n, const flimo_filter_cfg* cfg, size_t* n_kept,
                               double* last_stamp, int* nan_stamp);
+/* Optional: the context's pinned upload buffer (>= bytes).  A caller that copies the sweep's records into it -- from several threads
+ * if it likes -- and passes THAT pointer as points32 to the next flimo_raw_scan_filter_set / _order_set saves the call's own
+ * single-threaded staging copy (pcl clouds live in pageable memory).  Valid until the next call on the context that stages data. */
+int flimo_upload_stage(flimo_ctx* ctx, size_t bytes, void** host_ptr);
 /* The same, and with time_order != 0 the kept points are put into the order of the reference's time sort (std::partial_sort_copy by
  * stamp, Localizer.cpp:789-790) on the device: the order MAX_NUM_PC2MATCH / MAX_NUM_MATCHES ("the first N of pc2match") and the
  * voxel grid's float sums are defined in.  That order is unique -- a stable radix sort gives it -- when no two kept stamps are
