@@ -348,18 +348,23 @@ def test_device_time_order_front_end_equals_host_front_end(built):
         assert dev[-1]["pc"].shape[0] > 3000 and dev[-1]["n"] > 3000         # the voxel grid's cloud is larger than MAX_NUM_PC2MATCH: the cap binds
 
 
-def test_arrival_order_path_equals_sorted_path(built):
+@pytest.mark.parametrize("n_pts,filters", [(16384, False), (40000, True)])
+def test_arrival_order_path_equals_sorted_path(built, n_pts, filters):
     """Tied stamps (all rings of a column share one): the reference's std::partial_sort_copy decides their order with a sequential
     heap sort.  When no cap can bind and the voxel grid is off that order is not observable by the registration, so the GPU gets
     the sweep in arrival order and the permutation is computed only for the clouds handed back.  Pose, covariance and the stored
     map must not depend on whether the clouds are requested (bit for bit); against the always-sort-first path the clouds come back
     in the same order with the same coordinates, and the pose agrees to the summation order of H^T H."""
     from fast_limo_amd import api
-    n_scans, n_pts, speed = 8, 16384, 10.0
+    n_scans, speed = 8, 10.0
     st, w, a = synth.stationary_imu(0.0, 0.1 * n_scans + 0.06)
+    # second case: a sweep large enough for the shared upload staging, with the crop box / min distance / rate filters on (the clouds
+    # are then put together from the helper thread's filter pass over the host copy and the device's buffers)
+    extra = dict(crop_active=1, cropBoxMin=(-1.0, -1.0, -1.0), cropBoxMax=(1.0, 1.0, 1.0), dist_active=1, min_dist=2.0,
+                 rate_active=1, rate_value=2) if filters else {}
 
     def drive(lazy, clouds):
-        G = api.Localizer(api.default_cfg(**CAPS))
+        G = api.Localizer(api.default_cfg(**CAPS, **extra))
         G.set_lazy_time_order(lazy)
         G.set_flags(add_to_map=True, download_clouds=clouds)
         x0 = G.get_x(); x0[14] = speed; G.set_x(x0)
@@ -401,4 +406,4 @@ def test_arrival_order_path_equals_sorted_path(built):
             np.testing.assert_array_equal(a_["pc"], b_["pc"])
     np.testing.assert_array_equal(m_b, m_c)                    # the stored map, as a set
     assert m_a.shape == m_b.shape
-    assert m_b.shape[0] > 2 * n_pts
+    assert m_b.shape[0] > (n_pts // 2 if filters else 2 * n_pts)
