@@ -123,6 +123,8 @@ struct flimo_ctx {
   // staging
   void* h_stage = nullptr;         // pinned
   void* h_clouds = nullptr;        // pinned: the two clouds of flimo_scan_clouds
+  void (*overlap_fn)(void*) = nullptr;   // flimo_match_reduce_overlap: host work of the caller to run while the pass is in flight
+  void* overlap_arg = nullptr;
   size_t clouds_cap = 0;
   size_t stage_cap = 0;
   // timing
@@ -1405,6 +1407,24 @@ extern "C" int flimo_set_wait_timeout_ms(flimo_ctx* c, int ms) {
   return FLIMO_OK;
 }
 
+extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flimo_match_cfg* cfg, double HTH[144], double HTh[12], int* M);
+extern "C" int flimo_match_reduce_overlap(flimo_ctx* c, const double x26[26], const flimo_match_cfg* cfg, double HTH[144], double HTh[12],
+                                          int* M, void (*while_in_flight)(void*), void* arg) {
+  if (!c) return FLIMO_ERR_INVALID;
+  c->overlap_fn = while_in_flight;
+  c->overlap_arg = arg;
+  const int rc = flimo_match_reduce(c, x26, cfg, HTH, HTh, M);
+  c->overlap_fn = nullptr;                            // (not reached on this path: the caller runs it)
+  return rc;
+}
+
+static inline void run_overlap(flimo_ctx* c) {
+  if (!c->overlap_fn) return;
+  void (*fn)(void*) = c->overlap_fn;
+  c->overlap_fn = nullptr;
+  fn(c->overlap_arg);
+}
+
 extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flimo_match_cfg* cfg, double HTH[144],
                                   double HTh[12], int* M) {
   if (!c || !x26 || !cfg || !HTH || !HTh || !M) return FLIMO_ERR_INVALID;
@@ -1475,6 +1495,7 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
     // 5-NN passes; it keeps them armed for whichever 5-NN pass comes next
     HIPCHK(c, hipMemsetAsync(c->d_tie_count, 0, 2 * sizeof(unsigned int), c->stream));
     HIPCHK(c, hipGetLastError());
+    run_overlap(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     ++c->pass_seq;
     for (int i = 0; i < 12; i++) {
@@ -1591,6 +1612,7 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
       __atomic_thread_fence(__ATOMIC_ACQUIRE);
       return FLIMO_OK;
     };
+    run_overlap(c);                                    // the caller's own work, beside the launch
     { const int rcw = wait_granules(seq); if (rcw) return rcw; }
     c->last_stragglers = (int)llround(c->h_granules[2 * FIT_LIVE]);
     c->stragglers_hist[c->pass_in_scan] = c->last_stragglers;

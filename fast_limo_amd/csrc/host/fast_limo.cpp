@@ -500,7 +500,7 @@ void Localizer::init(Config& cfg) {                                // Localizer.
 void Localizer::init_iKFoM() {                                     // Localizer.cpp:660-670
   ikfom_->init(config.ikfom.MAX_NUM_ITERS, config.ikfom.LIMITS.data());
   // IKFoM::h_share_model (use-ikfom.cpp:10-31) with the reduced seam
-  ikfom_->h_reduced = [this](const StateIkfom& x, flimo_host::ReducedMeas& out) {
+  ikfom_->h_reduced_overlap = [this](const StateIkfom& x, flimo_host::ReducedMeas& out, const std::function<void()>& in_flight) {
     double x26[26];
     x.to_flat(x26);
     const Config::iKFoM::Mapping& m = config.ikfom.mapping;
@@ -512,7 +512,9 @@ void Localizer::init_iKFoM() {                                     // Localizer.
     flimo_ctx* c = map_->ctx();
     if (!c) return;
     const double tm0 = now_s();
-    const int rc = flimo_match_reduce(c, x26, &mc, out.HTH, out.HTh, &out.M);
+    const int rc = flimo_match_reduce_overlap(c, x26, &mc, out.HTH, out.HTh, &out.M,
+                                              [](void* f) { (*static_cast<const std::function<void()>*>(f))(); },
+                                              const_cast<std::function<void()>*>(&in_flight));
     prof_[2] += now_s() - tm0;
     prof_[3] += 1.0;
     if (rc != FLIMO_OK) { std::cout << "FAST_LIMO::match_reduce failed: " << flimo_last_error(c) << "\n"; out.M = 0; }

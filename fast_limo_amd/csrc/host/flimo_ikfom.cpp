@@ -712,9 +712,12 @@ void Esekf::update_iterated_dyn_share_modified(double R, double D) {
   static const int so3_idx[2] = {3, 6};
 
   for (int it = -1; it < maximum_iter_; it++) {
-    h_reduced(x_, meas);                                       // esekfom.hpp:1637
-    const int M = meas.M;
+    // The part of the iteration that does not depend on the measurement (:1652-1697: x boxminus x_propagated, P through the
+    // manifold Jacobians) runs while the pass is in flight on the GPU when the plug-in offers that; the values are the same.
     double dx[kDof];
+    bool pre_done = false;
+    auto pre = [&]() {
+    pre_done = true;
     x_.boxminus(dx, x_prop);                                   // :1652
     for (int i = 0; i < n; i++) dx_new[i] = dx[i];
     P_ = P_prop;                                               // :1655
@@ -739,6 +742,11 @@ void Esekf::update_iterated_dyn_share_modified(double R, double D) {
       left_block<2, kDof>(P_, idx, J, n);
       right_block_T<2, kDof>(P_, idx, J);
     }
+    };
+    if (h_reduced_overlap) h_reduced_overlap(x_, meas, pre);    // esekfom.hpp:1637
+    else h_reduced(x_, meas);
+    if (!pre_done) pre();
+    const int M = meas.M;
 
     Mat<12, 12> HTH = Mat<12, 12>::zero();                      // defined as 0 when M < 23 (a-note 5)
     double HTh[12];

@@ -132,6 +132,9 @@ class Esekf {
  public:
   typedef Mat<kDof, kDof> Cov;
   std::function<void(const StateIkfom&, ReducedMeas&)> h_reduced;   // replaces h_dyn_share (esekfom.hpp:128)
+  // the same with work of the filter to run while the measurement is in flight (called at most once; optional: when unset, or
+  // when the plug-in did not get to call it, the filter runs the work itself after h_reduced)
+  std::function<void(const StateIkfom&, ReducedMeas&, const std::function<void()>&)> h_reduced_overlap;
   std::function<void(DenseMeas&)> h_dense;                          // dense rows of the SAME pass
   std::vector<PassLog> log;
   bool keep_log = false;

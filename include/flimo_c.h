@@ -161,6 +161,13 @@ int flimo_deskew_resident_offset(flimo_ctx* ctx, const flimo_frame* frames, size
  *      HTH row-major 12x12, HTh 12, *M = number of matches used (after both caps). ---- */
 int flimo_match_reduce(flimo_ctx* ctx, const double x26[26], const flimo_match_cfg* cfg, double HTH[144],
                        double HTh[12], int* M);
+/* The same pass, with host work of the caller to do WHILE the GPU runs it: `while_in_flight(arg)` is called at most once, after
+ * the pass's launches are queued and before the call waits for their result.  In esekf::update_iterated_dyn_share_modified the
+ * part of an iteration that does not depend on the measurement (x boxminus x_propagated, the re-projection of P through the
+ * manifold Jacobians, esekfom.hpp:1652-1697) is such work.  On paths that do not wait (errors, an empty map) the function is not
+ * called: the caller checks and runs it itself. */
+int flimo_match_reduce_overlap(flimo_ctx* ctx, const double x26[26], const flimo_match_cfg* cfg, double HTH[144], double HTh[12], int* M,
+                               void (*while_in_flight)(void*), void* arg);
 /* per-point records of the last flimo_match_reduce (first min(N, MAX_NUM_PC2MATCH) points) */
 int flimo_match_fetch(flimo_ctx* ctx, flimo_match_rec* out, size_t cap, size_t* n);
 /* dense H (M x 12 row-major, compacted in scan order, capped) and h of the last pass: needed by the
