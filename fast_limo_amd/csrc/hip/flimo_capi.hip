@@ -174,9 +174,11 @@ struct flimo_ctx {
   bool have_fine_center = false;
   float fine_radius = 24.f;            // FLIMO_FINE_RADIUS [m]: crowded cells farther from the sensor (xy) stay out of the region
   uint64_t fine_builds = 0, fine_passes = 0;
-  int xslabs = 1;                  // FLIMO_XSLABS: fine columns per cell along x (1, 2, 4, 8; power of two).  4 trims the candidate
-                                   // stream of a pruned pass by a quarter (-2 % pass time) and crowded cells by 25-30 %, but makes both
-                                   // tables and every index update 4x larger (+0.15 ms per 64k-point insert at 1M points): off by default
+  int xslabs = 2;                  // FLIMO_XSLABS: fine columns per cell along x (1, 2, 4, 8; power of two): a pass that has the
+                                   // previous pass's bound walks only the half cells its ball reaches.  Measured (round 3, 1M map):
+                                   // clean map no change (21.8 -> 22.1 us), after 50 raw 64k sweeps the later passes 30.9 -> 23.2 us
+                                   // (1.05x the clean map's); inserts unchanged at 2 (0.28 ms), +14 % at 4; both tables twice the size
+                                   // (the layout falls back to fewer columns where 32-bit indices would not do)
   int* d_tie_list = nullptr;       // queries of a pass whose five hinge on an exact distance tie (capacity = scan capacity)
   unsigned int* d_tie_count = nullptr;   // [2]: alternating by pass number (the pass's reduction re-arms the next one's)
   size_t tie_cap = 0;
@@ -304,7 +306,7 @@ static void pose_from_x26(const double x[26], PoseMats& P) {
 //   FLIMO_GENERAL_K=1             NUM_MATCH_POINTS == 5 also takes the general (any-k) pass
 //   FLIMO_FINE=0, FLIMO_FINE_THRESHOLD=<points per cell, 64>, FLIMO_FINE_DIV=<2|4|8, 4>, FLIMO_FINE_RADIUS=<m, 24>,
 //   FLIMO_FINE_MIN_POINTS=<32768>  second-level grid over crowded regions
-//   FLIMO_XSLABS=<1|2|4|8>        fine x columns per cell in the index tables (1)
+//   FLIMO_XSLABS=<1|2|4|8>        fine x columns per cell in the index tables (2)
 //   FLIMO_XCD_STRIPE=<chunks>     block -> scan chunk striping over the XCDs (8)
 //   FLIMO_FULL_REBUILD=1          the index is sorted from scratch on every insert (default: merged)
 //   FLIMO_HOST_INSERT=1           the first batch goes through the host statement of the insert rule, then is imported

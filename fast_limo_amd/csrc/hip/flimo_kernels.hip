@@ -996,7 +996,12 @@ __global__ __launch_bounds__(256) KNN_WPE void knn5_kernel(GridView G, const flo
 #pragma unroll
         for (int t = 1; t < 10; t++) off[t] = n_own;
       }
-      const uint32_t total = off[9];
+      // A wave in which SOME queries probe walks twice (probe, then the rest of the ball) while the others would sit out the second
+      // walk after a full first one: those walk the first half of their stream now and the second half then -- both walks are about
+      // half as long for every lane of the wave (the two halves are disjoint point sets, merged like the probe's)
+      const bool split_walk = L == 2 && probe_on && __any(two) && !two;
+      const uint32_t half = split_walk ? (off[9] + 1u) / 2u : 0u;
+      const uint32_t total = split_walk ? half : off[9];
       TRACE(0, 2);
       // ---- flattened candidate stream, branch-free body ----
       const double none = __longlong_as_double((long long)KEY_NONE);
@@ -1057,6 +1062,11 @@ __global__ __launch_bounds__(256) KNN_WPE void knn5_kernel(GridView G, const flo
                 }
               }
             }
+          } else if (split_walk) {
+            // second half of this query's stream: positions [half, off[9]) of the nine segments, shifted down by `half`
+#pragma unroll
+            for (int t = 0; t < 9; t++) { off2[t + 1] = off[t + 1] > half ? off[t + 1] - half : 0u; dl2[t] = dl[t] + half; }
+            off2[10] = off2[9]; dl2[9] = 0u;
           } else {
 #pragma unroll
             for (int t = 0; t < 10; t++) { off2[t + 1] = 0u; dl2[t] = 0u; }
@@ -1073,8 +1083,8 @@ __global__ __launch_bounds__(256) KNN_WPE void knn5_kernel(GridView G, const flo
           cand += total2 > (uint32_t)sub ? (int)((total2 - (uint32_t)sub + L - 1) / L) : 0;
           double cb[6], cc[6];
           key_pair_merge6(kb, cb);
-          key_merge6(c, cb, cc);                       // own cell + rest of the ball: disjoint point sets, unique keys
-          if (two) {
+          key_merge6(c, cb, cc);                       // own cell + rest of the ball / the two halves: disjoint point sets, unique keys
+          if (two || split_walk) {
 #pragma unroll
             for (int i = 0; i < 6; i++) c[i] = cc[i];
           }

@@ -17,4 +17,5 @@ h=r.get('hbm_regime') or {}
 print('hbm', {k:h.get(k) for k in ('ms_per_step','passes_per_step','passes_in_one_launch','passes_total','stragglers_last_pass','one_launch_pass_us','separate_dispatch_pass_us','E_evals_per_query','frac','knn_stage_separate_dispatches','pose_err_vs_cpu')})
 print('e2e', (d.get('end_to_end') or {}).get('ms'), 'cpu', (d.get('cpu_baseline') or {}).get('value'), 'host_us', d['host_us_per_step'], 'pose', d.get('pose_err_vs_cpu'))
 print('streams', (d.get('concurrent_streams') or {}).get('scans_per_s_aggregate'), 'insert', d.get('with_map_insert'))
+cr=r.get('crowded') or {}; print('crowded', {k:cr.get(k) for k in ('clean_map_us','crowded_map_us','first_pass_ratio','later_passes_ratio','insert_ms_per_sweep')})
 PY

@@ -6,12 +6,12 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $root; mkdir -p gpurun_out/profiles_r03 profiles/r03
 out=$root/gpurun_out/profiles_r03
 # --streams 0: without the informational concurrent-streams leg, whose overlapped launches would enter the per-kernel averages
-args="--steps 100 --warmup 5 --no-cpu-baseline --no-end-to-end --no-hbm-regime --streams 0"
+args="--steps 100 --warmup 5 --no-cpu-baseline --no-end-to-end --no-hbm-regime --no-crowded --streams 0"
 cd /tmp && export TMPDIR=/tmp
 rm -rf $out/pmc_fetch $out/pmc_write $out/prof $out/prof_nofuse $out/pmc_fetch_hbm $out/pmc_write_hbm $out/prof_hbm
 # ---- PMC passes first (counters in their own runs), so that the bench line below carries `traffic` for these very sources ----
-timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -- python3 $root/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-end-to-end --no-hbm-regime --streams 0 > /dev/null 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -- python3 $root/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-end-to-end --no-hbm-regime --streams 0 > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -- python3 $root/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-end-to-end --no-hbm-regime --no-crowded --streams 0 > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -- python3 $root/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-end-to-end --no-hbm-regime --no-crowded --streams 0 > /dev/null 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch_hbm -- python3 $root/bench.py --hbm-regime-only --no-cpu-baseline --hbm-steps 6 > /dev/null 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write_hbm -- python3 $root/bench.py --hbm-regime-only --no-cpu-baseline --hbm-steps 6 > /dev/null 2>&1
 cd $root
