@@ -1521,7 +1521,7 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   if (tlev > 1) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   // level 1: the two events ride on the k-NN dispatch itself (kernel begin / end, no extra packets)
   // the k-NN launch finishes its own stragglers (in-kernel tail) for gates of up to 3 rings; the worklist + widening dispatch
-  // remains for wider gates and for the developer switches (FLIMO_TAIL=0, FLIMO_HEAVY)
+  // remains for wider gates and for the developer switch FLIMO_TAIL=0
   // First pass of a scan (no bound from a previous pass): with a poor prior whole waves of far-off points are pending at once,
   // and a wave finishing 32 such queries two lanes each is one long chain -- those are better spread over the chip by the
   // worklist dispatch.  With a good prior (the usual case in a sequence) the first pass has a handful of stragglers like any
