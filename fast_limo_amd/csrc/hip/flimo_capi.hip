@@ -1170,6 +1170,7 @@ extern "C" int flimo_raw_scan_filter_order_set(flimo_ctx* c, const void* points3
   F.dist = cfg->dist_active ? 1 : 0; F.min_dist = cfg->min_dist;
   F.rate_on = cfg->rate_active ? 1 : 0; F.rate = cfg->rate_value;
   F.kind = cfg->time_kind; F.eos = cfg->end_of_sweep ? 1 : 0; F.sweep_ref = cfg->sweep_ref_time;
+  F.fov = cfg->fov_active ? 1 : 0; F.fov_angle = cfg->fov_angle;
   HIPCHK(c, filter_raw_scan(c->stream, c->d_raw32, n, F, c->d_scan_raw, c->d_scan_t, c->d_filt_ext, c->scratch, time_order ? c->d_tkey[0] : nullptr));
   HIPCHK(c, hipMemcpyAsync(c->h_filt_ext, c->d_filt_ext, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));

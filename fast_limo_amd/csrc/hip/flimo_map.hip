@@ -14,6 +14,7 @@
 #include "flimo_prims.h"
 #include <float.h>
 #include "flimo_types.h"
+#include "flimo_math.h"
 #include "flimo_kernels.h"
 #include "flimo_gbook.h"
 
@@ -571,9 +572,10 @@ __global__ __launch_bounds__(256) void filt_keep_kernel(const Raw32* __restrict_
   if (i >= n) return;
   bool k = a[i] != 0u;
   if (k && F.rate_on) k = (rank[i] % (uint32_t)F.rate) == 0u;
-  if (k && F.dist) {
+  if (k && (F.dist || F.fov)) {
     const Raw32 p = in[i];
-    k = __builtin_sqrtf(p.x * p.x + (p.y * p.y + p.z * p.z)) > F.min_dist;
+    if (F.fov) k = __builtin_fabsf(libm_atan2f(p.y, p.x)) < F.fov_angle;       // std::atan2 of two floats, as the host's libm rounds it
+    if (k && F.dist) k = __builtin_sqrtf(p.x * p.x + (p.y * p.y + p.z * p.z)) > F.min_dist;
   }
   keep[i] = k ? 1u : 0u;
 }

@@ -51,6 +51,83 @@ FLIMO_DEV void libm_sincosf(float x, float& s_out, float& c_out) {
   c_out = (float)(((n + 1) & 2) ? -cv : cv);
 }
 
+// std::atan2 of two floats as the host's libm evaluates it (the reference's FoV filter: fabs(atan2(p.y, p.x)) < fov_angle,
+// Localizer.cpp:873-876).  glibc's atan2f up to 2.40 is the fdlibm routine in float arithmetic (e_atan2f.c over s_atanf.c:
+// argument reduction to [0, 7/16] by four breakpoints, odd/even split of an 11-term polynomial, hi/lo table of atan at the
+// breakpoints); restated here operation for operation (plain IEEE float ops, no contraction), checked against the host's libm on
+// 16M argument pairs by tools/devmath_check.
+FLIMO_DEV float libm_atanf(float x) {
+  const float atanhi[4] = {4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f};
+  const float atanlo[4] = {5.0121582440e-09f, 3.7748947079e-08f, 3.4473217170e-08f, 7.5497894159e-08f};
+  const float aT[11] = {3.3333334327e-01f, -2.0000000298e-01f, 1.4285714924e-01f, -1.1111110449e-01f, 9.0908870101e-02f, -7.6918758452e-02f,
+                        6.6610731184e-02f, -5.8335702866e-02f, 4.9768779427e-02f, -3.6531571299e-02f, 1.6285819933e-02f};
+  const unsigned int hxu = __builtin_bit_cast(unsigned int, x);
+  const int hx = (int)hxu;
+  const int ix = hx & 0x7fffffff;
+  int id;
+  if (ix >= 0x4c000000) {                       // |x| >= 2^25
+    if (ix > 0x7f800000) return x + x;          // NaN
+    return hx > 0 ? atanhi[3] + atanlo[3] : -atanhi[3] - atanlo[3];
+  }
+  if (ix < 0x3ee00000) {                        // |x| < 0.4375
+    if (ix < 0x31000000) return x;              // |x| < 2^-29
+    id = -1;
+  } else {
+    x = __builtin_fabsf(x);
+    if (ix < 0x3f980000) {                      // |x| < 1.1875
+      if (ix < 0x3f300000) { id = 0; x = fl_div(2.0f * x - 1.0f, 2.0f + x); }       // 7/16 <= |x| < 11/16
+      else { id = 1; x = fl_div(x - 1.0f, x + 1.0f); }                             // 11/16 <= |x| < 19/16
+    } else {
+      if (ix < 0x401c0000) { id = 2; x = fl_div(x - 1.5f, 1.0f + 1.5f * x); }       // |x| < 2.4375
+      else { id = 3; x = fl_div(-1.0f, x); }
+    }
+  }
+  const float z = x * x;
+  const float w = z * z;
+  const float s1 = z * (aT[0] + w * (aT[2] + w * (aT[4] + w * (aT[6] + w * (aT[8] + w * aT[10])))));
+  const float s2 = w * (aT[1] + w * (aT[3] + w * (aT[5] + w * (aT[7] + w * aT[9]))));
+  if (id < 0) return x - x * (s1 + s2);
+  const float hi = id == 0 ? atanhi[0] : (id == 1 ? atanhi[1] : (id == 2 ? atanhi[2] : atanhi[3]));
+  const float lo = id == 0 ? atanlo[0] : (id == 1 ? atanlo[1] : (id == 2 ? atanlo[2] : atanlo[3]));
+  const float r = hi - ((x * (s1 + s2) - lo) - x);
+  return hx < 0 ? -r : r;
+}
+FLIMO_DEV float libm_atan2f(float y, float x) {
+  const float tiny = 1.0e-30f, pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+  const int hx = (int)__builtin_bit_cast(unsigned int, x), hy = (int)__builtin_bit_cast(unsigned int, y);
+  const int ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
+  if (ix > 0x7f800000 || iy > 0x7f800000) return x + y;              // NaN
+  if (hx == 0x3f800000) return libm_atanf(y);                         // x = 1
+  const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);                 // 2 * sign(x) + sign(y)
+  if (iy == 0) {
+    if (m == 0 || m == 1) return y;
+    return m == 2 ? pi + tiny : -pi - tiny;
+  }
+  if (ix == 0) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+  if (ix == 0x7f800000) {
+    if (iy == 0x7f800000) {
+      if (m == 0) return pi_o_4 + tiny;
+      if (m == 1) return -pi_o_4 - tiny;
+      if (m == 2) return 3.0f * pi_o_4 + tiny;
+      return -3.0f * pi_o_4 - tiny;
+    }
+    if (m == 0) return 0.0f;
+    if (m == 1) return -0.0f;
+    if (m == 2) return pi + tiny;
+    return -pi - tiny;
+  }
+  if (iy == 0x7f800000) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+  const int k = (iy - ix) >> 23;
+  float z;
+  if (k > 60) z = pi_o_2 + 0.5f * pi_lo;                              // |y/x| > 2^60
+  else if (hx < 0 && k < -60) z = 0.0f;                               // |y|/x < -2^60
+  else z = libm_atanf(__builtin_fabsf(fl_div(y, x)));
+  if (m == 0) return z;
+  if (m == 1) return -z;
+  if (m == 2) return pi - (z - pi_lo);
+  return (z - pi_lo) - pi;
+}
+
 // 3-coefficient Eigen reduction: c0 + (c1 + c2)
 FLIMO_DEV float sum3(float a, float b, float c) { return a + (b + c); }
 

@@ -64,6 +64,8 @@ struct FilterParams {
   int kind;                // time union view: 0 OUSTER u32 ns, 1 VELODYNE f32 s, 2 HESAI f64 s, 3 LIVOX f64 ns
   int eos;                 // end_of_sweep
   double sweep_ref;        // sweep reference time
+  int fov;                 // FoV filter (:873-876): fabs(atan2(y, x)) < fov_angle on the rate filter's survivors
+  float fov_angle;
 };
 
 // 64-byte per-query record consumed by the HTH reducer: H row, h, valid flag.

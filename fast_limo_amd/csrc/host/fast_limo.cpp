@@ -1182,7 +1182,7 @@ pcl::PointCloud<PointType>::Ptr Localizer::deskewPointCloud(pcl::PointCloud<Poin
 // stay on the host path.  Returns 0 = not applicable (take the host path), 1 = deskewed scan resident, -1 = sweep rejected
 // (the same early returns as deskewPointCloud).
 bool Localizer::deviceFrontEndEnabled() const {
-  if (!gpu_filters || !lazy_time_order || config.filters.fov_active) return false;
+  if (!gpu_filters || !lazy_time_order) return false;
   return sensor == SensorType::OUSTER || sensor == SensorType::VELODYNE || sensor == SensorType::HESAI || sensor == SensorType::LIVOX;
 }
 
@@ -1208,6 +1208,7 @@ int Localizer::deskewOnDevice(pcl::PointCloud<PointType>::Ptr& raw_pc, double st
   fc.time_kind = sensor == SensorType::OUSTER ? 0 : (sensor == SensorType::VELODYNE ? 1 : (sensor == SensorType::HESAI ? 2 : 3));
   fc.end_of_sweep = config.end_of_sweep ? 1 : 0;
   fc.sweep_ref_time = start_time;
+  fc.fov_active = fl.fov_active ? 1 : 0; fc.fov_angle = fl.fov_angle;
   size_t kept = 0;
   double last_stamp = 0.0;
   int nan = 0, tied = 0;

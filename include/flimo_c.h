@@ -135,6 +135,7 @@ typedef struct flimo_filter_cfg {
   int time_kind;    /* 0 OUSTER (uint32 t, ns), 1 VELODYNE (float time, s), 2 HESAI (double timestamp, s), 3 LIVOX (double, ns) */
   int end_of_sweep;
   double sweep_ref_time;
+  int fov_active;   float fov_angle;   /* FoV filter (Localizer.cpp:873-876): fabs(atan2(y, x)) < fov_angle, atan2 as the host's libm rounds it */
 } flimo_filter_cfg;
 int flimo_raw_scan_filter_set(flimo_ctx* ctx, const void* points32, size_t n, const flimo_filter_cfg* cfg, size_t* n_kept,
                               double* last_stamp, int* nan_stamp);

@@ -459,7 +459,7 @@ def test_gpu_input_filters_and_stamps_match_oracle(built, oracle, sensor, eos):
     xyz[::89] = np.nan
     xyz[1::173] *= np.float32(0.01)
     rel = np.round(rs.uniform(0.0, 0.1, xyz.shape[0]) * 2000.0) / 2000.0          # ties
-    filt = dict(crop_active=1, dist_active=1, min_dist=1.5, rate_active=1, rate_value=3)
+    filt = dict(crop_active=1, dist_active=1, min_dist=1.5, rate_active=1, rate_value=3, fov_active=1, fov_angle=2.8)
     res = {}
     ocfg = oracle.default_cfg(sensor_type=code, end_of_sweep=int(eos), crop_min=(-0.5, -0.5, -0.5), crop_max=(0.5, 0.5, 0.5),
                               num_threads=1, **filt, **CAPS)

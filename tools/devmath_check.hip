@@ -2,6 +2,7 @@
 // source compiled for the host (x86-64, no FMA).  Build: hipcc --offload-arch=gfx950 -O3
 // -ffp-contract=off -I fast_limo_amd/csrc/hip tools/devmath_check.hip -o /tmp/devmath_check
 #include <hip/hip_runtime.h>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -51,8 +52,54 @@ static int check_sincos() {
   printf("DEVMATH sincos mismatches vs host libm: |x|<pi/4: %d of %d   up to 100 rad: %d of %d\n", small_bad, n_small, large_bad, N - n_small);
   return small_bad != 0 || large_bad > N / 100000;
 }
+__global__ void k_atan2(const float* y, const float* x, float* o, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) o[i] = libm_atan2f(y[i], x[i]);
+}
+// libm_atan2f on the device against the host's libm (atan2f): lidar-like points, every breakpoint region of the reduction, the
+// axes, tiny / huge ratios, signed zeros, infinities
+static int check_atan2() {
+  const int N = 1 << 24;
+  std::vector<float> y(N), x(N), h(N), g(N);
+  srand(23);
+  auto ru = []() { return (rand() % 2000001 - 1000000) * 1e-6; };
+  const float special[] = {0.0f, -0.0f, 1.0f, -1.0f, 1e-30f, -1e-30f, 1e30f, -1e30f, INFINITY, -INFINITY, 0.4375f, 0.6875f, 1.1875f, 2.4375f,
+                           3.0e-9f, 33554432.0f, 1.17549435e-38f, 1e-42f};
+  const int ns = (int)(sizeof(special) / sizeof(special[0]));
+  for (int t = 0; t < N; t++) {
+    const int mode = t % 8;
+    double a = ru(), b = ru();
+    if (mode == 0) { y[t] = (float)(a * 100.0); x[t] = (float)(b * 100.0); }
+    else if (mode == 1) { y[t] = (float)(a * 100.0); x[t] = (float)(b * 1e-3); }             // around +-pi/2
+    else if (mode == 2) { y[t] = (float)(a * 1e-3); x[t] = (float)(b * 100.0); }             // around 0 and +-pi
+    else if (mode == 3) { const double r = 0.3 + 2.5 * fabs(a); x[t] = (float)(b * 50.0); y[t] = (float)(r * x[t]); }   // ratios across the breakpoints
+    else if (mode == 4) { y[t] = (float)(a * pow(10.0, 30.0 * b)); x[t] = (float)(ru() * pow(10.0, 30.0 * ru())); }
+    else if (mode == 5) { y[t] = special[rand() % ns]; x[t] = special[rand() % ns]; }
+    else if (mode == 6) { y[t] = (float)a; x[t] = 1.0f; }
+    else { unsigned u = ((unsigned)rand() << 16) ^ (unsigned)rand(), v = ((unsigned)rand() << 16) ^ (unsigned)rand(); memcpy(&y[t], &u, 4); memcpy(&x[t], &v, 4); }
+    h[t] = atan2f(y[t], x[t]);
+  }
+  float *dy, *dx, *dout;
+  hipMalloc(&dy, (size_t)N * 4); hipMalloc(&dx, (size_t)N * 4); hipMalloc(&dout, (size_t)N * 4);
+  hipMemcpy(dy, y.data(), (size_t)N * 4, hipMemcpyHostToDevice);
+  hipMemcpy(dx, x.data(), (size_t)N * 4, hipMemcpyHostToDevice);
+  hipLaunchKernelGGL(k_atan2, dim3(N / 256), dim3(256), 0, 0, dy, dx, dout, N);
+  hipMemcpy(g.data(), dout, (size_t)N * 4, hipMemcpyDeviceToHost);
+  int bad = 0, shown = 0;
+  for (int t = 0; t < N; t++) {
+    const bool nan_both = (h[t] != h[t]) && (g[t] != g[t]);
+    if (!nan_both && memcmp(&h[t], &g[t], 4)) {
+      bad++;
+      if (shown++ < 8) printf("  atan2f(%a, %a): host %a device %a (mode %d)\n", y[t], x[t], h[t], g[t], t % 8);
+    }
+  }
+  printf("DEVMATH atan2f mismatches vs host libm: %d of %d\n", bad, N);
+  hipFree(dy); hipFree(dx); hipFree(dout);
+  return bad != 0;
+}
 int main() {
   if (check_sincos()) return 2;
+  if (check_atan2()) return 3;
   const int N = 1 << 20;
   std::vector<In> in(N);
   std::vector<Out> ho(N), go(N);
