@@ -699,6 +699,9 @@ void Esekf::predict(double dt, const Mat<12, 12>& Q, const InputIkfom& in) {
   P_ = F1 * P_ * F1.T() + G * Q * G.T();
 }
 
+// (AVX2 clone chosen at load time where the CPU has it: the 12- and 23-wide inner loops run four doubles at a time; no FMA in either
+//  clone -- the sums keep their order and rounding)
+__attribute__((target_clones("avx2", "default")))
 void Esekf::update_iterated_dyn_share_modified(double R, double D) {
   const int n = kDof;
   log.clear();
