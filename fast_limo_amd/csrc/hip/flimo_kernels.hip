@@ -978,20 +978,25 @@ __global__ __launch_bounds__(256) KNN_WPE void knn5_kernel(GridView G, const flo
       // full walk) and the own cell can give a bound at all.  Only those queries fetch the two inner x planes of the row table:
       // they hold the own cell's range and let the second walk be clipped to cells.
       const bool heavy_block = probe_on && off[9] >= prev.probe_min && cx >= 0 && cx < G.nx;
-      U3 rm1[3], rm2[3];
-#pragma unroll
-      for (int dz = 0; dz < 3; dz++) { rm1[dz] = rbl[dz]; rm2[dz] = rbh[dz]; }
+      const uint32_t centre = yz + py + 1u;                         // (z, y) = the query's own row within a padded x plane
+      uint32_t own_a = rbl[1].b, own_b = rbh[1].b;                  // the own cell's range (two 4-byte loads, heavy blocks only)
       if (heavy_block) {
-        const uint32_t iA = (uint32_t)(cx * G.xs) * plane + yz, iB = (uint32_t)((cx + 1) * G.xs) * plane + yz;
-#pragma unroll
-        for (int dz = 0; dz < 3; dz++) {
-          rm1[dz] = *reinterpret_cast<const U3*>(G.row_table + (iA + (uint32_t)dz * py));
-          rm2[dz] = *reinterpret_cast<const U3*>(G.row_table + (iB + (uint32_t)dz * py));
-        }
+        own_a = G.row_table[(uint32_t)(cx * G.xs) * plane + centre];
+        own_b = G.row_table[(uint32_t)((cx + 1) * G.xs) * plane + centre];
       }
-      const uint32_t lo_own = rm1[1].b, n_own = rm2[1].b - rm1[1].b;
+      // The probe walks the query's own COLUMN (the tables' x resolution: half a cell by default) when that alone can give a bound,
+      // its own cell otherwise: in a crowded cell the column holds a fraction of the points and its 5th distance is as good.  The
+      // column's two bounds in the centre row are at most two more 4-byte loads (one of them is a cell boundary already here).
+      uint32_t lo_own = own_a, hi_own = own_b;
+      if (heavy_block && G.xs > 1 && hi_own - lo_own >= 2u * PROBE_MIN_OWN) {
+        const int col = min(max((int)floorf(fx * (float)G.xs), cx * G.xs), (cx + 1) * G.xs - 1);
+        const uint32_t ca = (col == cx * G.xs) ? lo_own : G.row_table[(uint32_t)col * plane + centre];
+        const uint32_t cb = (col + 1 == (cx + 1) * G.xs) ? hi_own : G.row_table[(uint32_t)(col + 1) * plane + centre];
+        if (cb - ca >= PROBE_MIN_OWN) { lo_own = ca; hi_own = cb; }
+      }
+      const uint32_t n_own = hi_own - lo_own;
       const bool two = heavy_block && n_own >= PROBE_MIN_OWN;        // the same in both lanes of the pair
-      if (two) {                        // first walk: the own cell only (one segment)
+      if (two) {                        // first walk: the own column / cell only (one segment)
         dl[0] = lo_own;
 #pragma unroll
         for (int t = 1; t < 10; t++) off[t] = n_own;
@@ -1030,35 +1035,51 @@ __global__ __launch_bounds__(256) KNN_WPE void knn5_kernel(GridView G, const flo
         double c[6];
         key_pair_merge6(k5, c);
         if (__any(two)) {
-          // second walk of the queries that probed their own cell: the rest of the block within the probe's ball.  Ten segments:
-          // eight rows, and the centre row on both sides of the own cell (already walked).
+          // second walk of the queries that probed: the rest of the probe's ball, laid out exactly like a pass that HAS a bound
+          // (the rows the ball reaches, the columns it reaches -- one more round trip for the two x planes that bound them) minus
+          // the probed range.  Ten segments: eight rows, and the centre row on both sides of the probed range.
           uint32_t off2[11], dl2[10];
           off2[0] = 0;
           if (two) {
             const float d5p = __uint_as_float((uint32_t)((u64)__double_as_longlong(c[4]) >> 32));      // n_own >= 5: finite
             const float rc = (fl_sqrt(d5p) * (1.f + 1.0e-5f) + 1.0e-6f) * G.inv_cell;
             const float bb = rc * rc * (1.f + 1.0e-5f);                                              // bound, cell units squared
+            int h0 = (cx - 1) * G.xs, h1 = (cx + 2) * G.xs;
+            if (bb < 1.0e6f) {
+              const float rb_ = fl_sqrt(bb) + margin;
+              const float fxs = (float)G.xs;
+              h0 = max(h0, (int)floorf((fx - rb_) * fxs));
+              h1 = min(h1, (int)floorf((fx + rb_) * fxs) + 1);
+            }
+            h0 = min(max(h0, 0), G.nxf);
+            h1 = min(max(h1, h0), G.nxf);
+            U3 hl[3], hh[3];
+            {
+              const uint32_t iL = (uint32_t)h0 * plane + yz, iH = (uint32_t)h1 * plane + yz;
+#pragma unroll
+              for (int dz = 0; dz < 3; dz++) {
+                hl[dz] = *reinterpret_cast<const U3*>(G.row_table + (iL + (uint32_t)dz * py));
+                hh[dz] = *reinterpret_cast<const U3*>(G.row_table + (iH + (uint32_t)dz * py));
+              }
+            }
 #pragma unroll
             for (int dz = 0; dz < 3; dz++) {
-              const uint32_t s0_[3] = {rbl[dz].a, rbl[dz].b, rbl[dz].c}, s1_[3] = {rm1[dz].a, rm1[dz].b, rm1[dz].c};
-              const uint32_t s2_[3] = {rm2[dz].a, rm2[dz].b, rm2[dz].c}, s3_[3] = {rbh[dz].a, rbh[dz].b, rbh[dz].c};
+              const uint32_t sl_[3] = {hl[dz].a, hl[dz].b, hl[dz].c}, sh_[3] = {hh[dz].a, hh[dz].b, hh[dz].c};
 #pragma unroll
               for (int k = 0; k < 3; k++) {
-                const float dyz2 = yd2[k] + zd2[dz];
-                const bool row = dyz2 <= bb;
-                // reach along x within this row (cell units, widened by the rounding margin): the left cell is rx away, the right 1 - rx
-                const float xr = fl_sqrt(fmaxf(bb - dyz2, 0.f)) * (1.f + 1.0e-6f) + margin + 1.0e-4f;
-                const uint32_t lo_ = (rx <= xr) ? s0_[k] : s1_[k], hi_ = ((1.f - rx) <= xr) ? s3_[k] : s2_[k];
+                const bool row = yd2[k] + zd2[dz] <= bb;
                 if (dz == 1 && k == 1) {
-                  // centre row: [lo_, own cell) and (own cell, hi_)
-                  dl2[4] = lo_ - off2[4];
-                  off2[5] = off2[4] + (s1_[k] - lo_);
-                  dl2[5] = s2_[k] - off2[5];
-                  off2[6] = off2[5] + (hi_ - s2_[k]);
+                  // centre row: [sl, probed range) and (probed range, sh), each clipped to the ball's columns (a probed CELL may
+                  // stick out of them; what sticks out has been walked already)
+                  const uint32_t le = min(max(lo_own, sl_[k]), sh_[k]), rs = min(max(hi_own, sl_[k]), sh_[k]);
+                  dl2[4] = sl_[k] - off2[4];
+                  off2[5] = off2[4] + (le - sl_[k]);
+                  dl2[5] = rs - off2[5];
+                  off2[6] = off2[5] + (sh_[k] - rs);
                 } else {
                   const int t = 3 * dz + k + ((3 * dz + k) > 4 ? 1 : 0);
-                  dl2[t] = lo_ - off2[t];
-                  off2[t + 1] = off2[t] + (row ? hi_ - lo_ : 0u);
+                  dl2[t] = sl_[k] - off2[t];
+                  off2[t + 1] = off2[t] + (row ? sh_[k] - sl_[k] : 0u);
                 }
               }
             }

@@ -43,10 +43,12 @@ for fine in os.environ.get("FINES", "1,0").split(","):
             ctx.scan_set(query); row = []
             for k in range(3):
                 ctx.match_reduce(x, cfg); a, w, f = ctx.last_kernel_ms(); row.append((a + w + f) * 1e3)
+                if k == 0: parts = (a * 1e3, w * 1e3, f * 1e3)
             kt.append(row)
         ctx.set_timing(0)
         kt = np.median(np.array(kt[1:]), axis=0)
-        print("   kernels: first pass %.1f us, second %.1f us, third %.1f us;  candidates per query: %s" % (kt[0], kt[1], kt[2], cands(ctx)), flush=True)
+        print("   kernels: first pass %.1f us (k-NN %.1f + widening %.1f + fit %.1f in the last repetition), second %.1f us, third %.1f us;  candidates per query: %s" % (
+            kt[0], parts[0], parts[1], parts[2], kt[1], kt[2], cands(ctx)), flush=True)
         print("FINE=%s %s: map %d  first pass %.1f us, second %.1f us, third %.1f us  M %d  fine %s stragglers %d" % (
             fine, tag, ctx.map_size(), t[0], t[1], t[2], r3[2], ctx.fine_stats(), ctx.last_stragglers()), flush=True)
         return r3

@@ -24,7 +24,17 @@ if os.environ.get("X0") == "tstar":        # the converged pose: few stragglers,
 mcfg = _lib.default_match_cfg(MAX_NUM_PC2MATCH=10**7, MAX_NUM_MATCHES=10**7)
 lib = _lib.load_hip()
 lib.flimo_trace_read.argtypes = [C.c_int, C.c_void_p, C.c_size_t]
+# NINS=<n>: n raw sweeps inserted at the pose first (a map crowded under the sensor); FIRSTPASS=1: every traced pass is the
+# first pass of a scan (no bound from a previous pass)
+for j in range(int(os.environ.get("NINS", 0))):
+    ctx.scan_set(np.ascontiguousarray(synth.velodyne_scan(64, 1024, L, 100 + j)[:, :3]))
+    ctx.map_add_scan(x0, 0.0)
+if int(os.environ.get("NINS", 0)):
+    scan = np.ascontiguousarray(synth.velodyne_scan(64, 1024, L, 999)[:, :3])
+    ctx.scan_set(scan)
 for it in range(6):
+    if os.environ.get("FIRSTPASS") == "1":
+        ctx.scan_set(scan)
     ctx.match_reduce(x0, mcfg)
 names = {0: ["start", "query loaded", "row bounds loaded", "candidates done", "merged", "stored (tail done)"],
          1: ["start", "scan+nbr loaded", "5 points gathered", "row computed", "partial stored", "ticket taken",
