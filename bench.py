@@ -191,7 +191,8 @@ def hbm_regime_leg(device, steps, with_oracle, max_threads=32):
     mp = synth.box_world_map(R["map_points"], R["box"], 1)
     scan = synth.velodyne_scan(R["rings"], R["azimuths"], R["box"], 2)
     imu = synth.stationary_imu(0.0, 0.35)
-    loc = api.Localizer(api.default_cfg(gpu_device=device, num_threads=os.cpu_count() or 1, **caps))
+    loc = api.Localizer(api.default_cfg(gpu_device=device, num_threads=os.cpu_count() or 1,
+                                        gpu_cell_size=float(os.environ.get('FLIMO_BENCH_CELL', '0')), **caps))   # 0 = library default
     loc.set_flags(add_to_map=False, download_clouds=False, keep_log=False)
     rc1 = drive_to_prior(loc, mp, scan, imu)
     x_prior, P_prior = loc.get_x(), loc.get_P()
