@@ -1,0 +1,103 @@
+// Developer probe (GPU box): what would a PRE-LAUNCHED measurement pass save?  A pass kernel enqueued while its predecessor runs could
+// read its pose from mapped host memory instead of waiting for the host's launch.  This measures, for a 512-block launch like the
+// pass's:  (a) host launch -> first result word back in host memory (today's path: hipLaunchKernel after the pose is known),
+//          (b) host store of a "pose ready" word -> result word back, for a kernel that is already resident and polling that word
+//              (every block polls host memory / only block 0 polls and republishes through device memory).
+// Build: hipcc --offload-arch=gfx950 -O3 tools/prelaunch_probe.hip -o tools/prelaunch_probe
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include <algorithm>
+#include <immintrin.h>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+
+struct Args { float pose[48]; };
+
+// mode 0: no polling (pose in the kernel arguments); 1: every block polls the host word; 2: block 0 polls the host word and
+// republishes it in device memory, the others poll that
+__global__ __launch_bounds__(256) void pass_like(int mode, Args a, const unsigned long long* host_word, unsigned long long* dev_word,
+                                                 unsigned long long seq, unsigned int* ticket, unsigned long long* out_host,
+                                                 float* sink) {
+  __shared__ int s_abort;
+  if (threadIdx.x == 0) {
+    s_abort = 0;
+    if (mode != 0) {
+      const unsigned long long t0 = wall_clock64();
+      if (mode == 1 || blockIdx.x == 0) {
+        while (__hip_atomic_load(host_word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+          if (wall_clock64() - t0 > 5000000ull) { s_abort = 1; break; }          // 50 ms at 100 MHz
+          __builtin_amdgcn_s_sleep(2);
+        }
+        if (mode == 2) __hip_atomic_store(dev_word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        while (__hip_atomic_load(dev_word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != seq) {
+          if (wall_clock64() - t0 > 5000000ull) { s_abort = 1; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (s_abort) return;
+  // a little work that depends on the pose, so that nothing is optimised away
+  float v = a.pose[threadIdx.x % 48] * (float)(threadIdx.x + 1);
+  if (v == 123456.789f) sink[blockIdx.x] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == gridDim.x - 1) {
+      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(out_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+int main() {
+  hipStream_t st;
+  CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  unsigned long long *h_word, *d_hword, *h_out, *d_hout, *dev_word;
+  unsigned int* ticket; float* sink;
+  CHECK(hipHostMalloc((void**)&h_word, 64, hipHostMallocMapped)); CHECK(hipHostGetDevicePointer((void**)&d_hword, h_word, 0));
+  CHECK(hipHostMalloc((void**)&h_out, 64, hipHostMallocMapped)); CHECK(hipHostGetDevicePointer((void**)&d_hout, h_out, 0));
+  CHECK(hipMalloc(&dev_word, 64)); CHECK(hipMemset(dev_word, 0, 64));
+  CHECK(hipMalloc(&ticket, 4)); CHECK(hipMemset(ticket, 0, 4));
+  CHECK(hipMalloc(&sink, 4096 * 4));
+  *h_word = 0; *h_out = 0;
+  Args a; for (int i = 0; i < 48; i++) a.pose[i] = (float)i;
+  const int blocks = 512, reps = 400;
+  unsigned long long seq = 0;
+  for (int mode = 0; mode < 3; mode++) {
+    std::vector<double> lat;
+    for (int r = 0; r < reps; r++) {
+      ++seq;
+      volatile unsigned long long* out = h_out;
+      if (mode == 0) {
+        // today: the pose is known, launch, wait for the result word
+        const double t0 = now_us();
+        hipLaunchKernelGGL(pass_like, dim3(blocks), dim3(256), 0, st, 0, a, d_hword, dev_word, seq, ticket, d_hout, sink);
+        while (*out != seq) _mm_pause();
+        lat.push_back(now_us() - t0);
+      } else {
+        // pre-launched: the kernel is resident and polling; 30 us later (the predecessor's run time) the host stores the word
+        hipLaunchKernelGGL(pass_like, dim3(blocks), dim3(256), 0, st, mode, a, d_hword, dev_word, seq, ticket, d_hout, sink);
+        const double tw = now_us();
+        while (now_us() - tw < 30.0) _mm_pause();
+        const double t0 = now_us();
+        __atomic_store_n(h_word, seq, __ATOMIC_RELEASE);
+        while (*out != seq) _mm_pause();
+        lat.push_back(now_us() - t0);
+      }
+      CHECK(hipStreamSynchronize(st));
+    }
+    std::sort(lat.begin(), lat.end());
+    printf("PRELAUNCH mode %d (%s): median %.2f us  p10 %.2f  p90 %.2f\n", mode,
+           mode == 0 ? "launch after the pose is known" : (mode == 1 ? "resident, every block polls host memory" : "resident, block 0 polls host memory, the others device memory"),
+           lat[reps / 2], lat[reps / 10], lat[reps * 9 / 10]);
+  }
+  return 0;
+}
