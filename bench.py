@@ -133,12 +133,17 @@ def cpu_baseline(mp, scan, imu, caps, max_threads):
             if time.time() - budget_t0 > budget and len(times) >= 3:
                 break
         t = float(np.median(times))
+        # the path exit once (transform + Mapper::add of the registered scan into the map): reported as a stage, not part of `value`
+        L.set_x(x_prior); L.set_P(P_prior)
+        L.update_pointcloud(scan, 0.1, add_to_map=True)
+        t_add = float(L.stats()["t_mapadd"])
         if best is None or t < best[0]:
-            best = (t, nt, len(times), [float(v) * 1e3 for v in np.median(np.array(stages), axis=0)])
+            best = (t, nt, len(times), [float(v) * 1e3 for v in np.median(np.array(stages), axis=0)] + [t_add * 1e3])
     t, nt, reps, stg = best
     return dict(value=1.0 / t, unit="scans/s", cores=nt, kind="port", cpu_model=model, physical_cores=phys, logical_cpus=logical,
                 threads=nt, reps=reps,
-                stages_ms={"deskew": stg[0], "knn_plane_fit": stg[1], "H_rows": stg[2], "HtH_and_solve": stg[3]},
+                stages_ms={"deskew": stg[0], "knn_plane_fit": stg[1], "H_rows": stg[2], "HtH_and_solve": stg[3],
+                           "map_add_once_not_in_value": stg[4]},
                 sample=f"median of {reps} registrations after warm-up (deskew + iterated update, no map insert) of the same "
                        f"{scan.shape[0]}-pt scan vs {mp.shape[0]}-pt map by the CPU oracle (restatement of the "
                        f"reference; the reference itself cannot be built without Eigen/PCL/Boost) on {model}, "
