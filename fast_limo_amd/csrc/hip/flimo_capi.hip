@@ -123,6 +123,9 @@ struct flimo_ctx {
   // staging
   void* h_stage = nullptr;         // pinned
   void* h_clouds = nullptr;        // pinned: the two clouds of flimo_scan_clouds
+  bool widen_fit = true;           // FLIMO_WIDEN_FIT=0: widening and fit of a separate-dispatch pass as two launches
+  int* h_wf_err = nullptr;         // mapped: set by a fit block of widen_fit_kernel whose wait for a widening wave ran out
+  int* d_wf_err = nullptr;
   void (*overlap_fn)(void*) = nullptr;   // flimo_match_reduce_overlap: host work of the caller to run while the pass is in flight
   void* overlap_arg = nullptr;
   size_t clouds_cap = 0;
@@ -311,6 +314,7 @@ static void pose_from_x26(const double x[26], PoseMats& P) {
 //   FLIMO_FULL_REBUILD=1          the index is sorted from scratch on every insert (default: merged)
 //   FLIMO_HOST_INSERT=1           the first batch goes through the host statement of the insert rule, then is imported
 //   FLIMO_LAZY_DESKEW=0           the deskew always runs as a dispatch of its own (default: on the scan's first k-NN launch)
+//   FLIMO_WIDEN_FIT=0             widening and fit of a separate-dispatch pass as two launches (default: one, widen_fit_kernel)
 //   FLIMO_PROF_PASS / FLIMO_PROF_INSERT   host-side timing prints (stderr)
 // (csrc/host: FLIMO_REFERENCE_SOLVE=1 literal two-inverse gain, FLIMO_SYNC_INSERT=1 map inserts on the caller's thread,
 //  FLIMO_PROF_DESKEW / FLIMO_PROF_CLOUDS timing prints; bench.py: FLIMO_BENCH_*.)
@@ -336,6 +340,7 @@ static void load_dev_switches(flimo_ctx* c) {
   if (env_int("FLIMO_FULL_REBUILD", v)) c->full_rebuild = v != 0;
   if (env_int("FLIMO_HOST_INSERT", v)) c->host_insert = v != 0;
   if (env_int("FLIMO_LAZY_DESKEW", v)) c->lazy_deskew = v != 0;
+  if (env_int("FLIMO_WIDEN_FIT", v)) c->widen_fit = v != 0;
 }
 
 // ---- context ----------------------------------------------------------------------------------
@@ -368,11 +373,14 @@ extern "C" int flimo_ctx_create(int device, flimo_ctx** out) {
             hipMalloc(&c->d_cand, sizeof(unsigned long long)) == hipSuccess &&
             hipMalloc(&c->d_tie_count, 2 * sizeof(unsigned int)) == hipSuccess &&
             hipMemset(c->d_tie_count, 0, 2 * sizeof(unsigned int)) == hipSuccess &&
+            hipHostMalloc((void**)&c->h_wf_err, sizeof(int), hipHostMallocMapped) == hipSuccess &&
+            hipHostGetDevicePointer((void**)&c->d_wf_err, c->h_wf_err, 0) == hipSuccess &&
             hipMalloc(&c->d_wl_count, sizeof(int)) == hipSuccess &&
             hipMemset(c->d_wl_count, 0, sizeof(int)) == hipSuccess &&
             hipHostMalloc((void**)&c->h_wl_count, sizeof(int), hipHostMallocDefault) == hipSuccess &&
             hipHostMalloc((void**)&c->h_cand, sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess;
   if (!ok) { flimo_ctx_destroy(c); return FLIMO_ERR_HIP; }
+  *c->h_wf_err = 0;
   memset(c->h_out256, 0, FIT_GROUPS * FIT_SLOT * sizeof(double));
   memset(c->h_granules, 0, FIT_GROUPS * FIT_LIVE_PAD * 2 * sizeof(double));
   // calibrate the v_mfma_f64_16x16x4_f64 accumulator layout: D[i][j] = j + 16 i
@@ -420,6 +428,7 @@ extern "C" void flimo_ctx_destroy(flimo_ctx* c) {
   if (c->h_granules) (void)hipHostFree(c->h_granules);
   (void)hipFree(c->d_fit2_partials);
   if (c->h_cand) (void)hipHostFree(c->h_cand);
+  if (c->h_wf_err) (void)hipHostFree(c->h_wf_err);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->h_clouds) (void)hipHostFree(c->h_clouds);
   for (int k = 0; k < 2; k++) if (c->h_frames[k]) (void)hipHostFree(c->h_frames[k]);
@@ -1566,8 +1575,14 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   if (c->prune) { memcpy(c->prev.RT, P.RT, sizeof(c->prev.RT)); c->prev.valid = 1; }   // the records now belong to this pose
   const double tpb = prof ? now_us() : 0.0;
   if (tlev > 1) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-  const bool widen_timed = !tail && tlev == 1 && mp.max_ring >= 2;
-  if (!tail)
+  // widening + fit in one launch when both follow (the fit's settled rows do not wait for the widening's stragglers)
+  const bool combined = c->widen_fit && !tail && !fused && !want_recs && tlev < 2 && !want_count && mp.max_ring >= 2 && mp.max_ring <= 3;
+  const bool widen_timed = !tail && !combined && tlev == 1 && mp.max_ring >= 2;
+  if (combined)
+    launch_widen_fit(c->stream, c->grid, c->d_scan_sorted, n_all, P, mp, c->d_nbr, c->d_wl, c->d_wl_count, nullptr, c->live_idx,
+                     c->d_fit2_partials, c->d_granules_host, c->d_ticket, seq, tlev == 1 ? c->ev[2] : nullptr,
+                     tlev == 1 ? c->ev[3] : nullptr, &tl, &tl, c->d_wf_err);
+  else if (!tail)
     launch_widen(c->stream, c->grid, c->d_scan_sorted, P, mp.max_ring, c->d_nbr, c->d_wl, c->d_wl_count,
                  c->debug_recs ? c->d_cand : nullptr, widen_timed ? c->ev[4] : nullptr, widen_timed ? c->ev[5] : nullptr, &tl);
   const double tpc = prof ? now_us() : 0.0;
@@ -1579,8 +1594,8 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   // order, reduces the first MAX_NUM_MATCHES and publishes to slot 0
   const bool fused_cap = cap_binds && !c->debug_recs;
   const bool use_fit2 = !want_recs && tlev < 2;                 // the per-pass fast path (granule results)
-  if (fused) {
-    // the fit and the reduction ran inside the k-NN launch
+  if (fused || combined) {
+    // the fit and the reduction ran inside the k-NN launch / the widening launch
   } else if (use_fit2)
     launch_fit2(c->stream, c->grid, c->d_scan_sorted, n_all, c->d_nbr, P, mp, c->live_idx, c->d_fit2_partials, c->d_granules_host,
                 c->d_ticket, c->d_wl_count, seq, tlev == 1 ? c->ev[2] : nullptr, tlev == 1 ? c->ev[3] : nullptr, &tl);
@@ -1617,6 +1632,7 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
     };
     run_overlap(c);                                    // the caller's own work, beside the launch
     { const int rcw = wait_granules(seq); if (rcw) return rcw; }
+    if (combined && *(volatile int*)c->h_wf_err) { *c->h_wf_err = 0; return fail(c, FLIMO_ERR_HIP, "a fit block's wait for its widening wave ran out"); }
     c->last_stragglers = (int)llround(c->h_granules[2 * FIT_LIVE]);
     c->stragglers_hist[c->pass_in_scan] = c->last_stragglers;
     const long n_ties = (long)llround(c->h_granules[2 * (FIT_LIVE + 1)]);

@@ -823,7 +823,7 @@ __device__ __forceinline__ void fit_reduce_publish(const float (&v)[16], bool ow
                                                    double* sa2, double* sa3, unsigned int* s_last, const FitIdx& idx,
                                                    double* __restrict__ partials, double2* __restrict__ out_granules,
                                                    unsigned int* __restrict__ ticket, int* __restrict__ wl_count,
-                                                   unsigned long long seq, const TieList& tl);
+                                                   unsigned long long seq, const TieList& tl, int blk = -1, int nblk = -1);
 FLIMO_DEV void fit_row(const GridView& G, const PoseMats& P, const MatchParams& mp, const int (&ids)[5], float gx, float gy, float gz,
                        float (&v)[16]);
 
@@ -1220,23 +1220,24 @@ __global__ __launch_bounds__(256) KNN_WPE void knn5_kernel(GridView G, const flo
 // extracted with wave-wide min reductions.  r starts at the ring the fast path's own 5th distance asks for
 // (at least 2) and jumps to the ring that proves exactness, never beyond max_ring (<= 3 here; the host
 // falls back to the general kernel for larger gates).
-__global__ __launch_bounds__(256) void widen_kernel(GridView G, const float4* __restrict__ scan_sorted, PoseMats P,
-                                                    int max_ring, NbrRec* __restrict__ nbr, const int* __restrict__ wl,
-                                                    const int* __restrict__ wl_count,
-                                                    unsigned long long* __restrict__ cand_total, int first_ring, TieList tl) {
-  __shared__ uint32_t s_off[4][65];
-  __shared__ uint32_t s_lo[4][64];
+// (blk / nblk: this block's number among the launch's widening blocks; PUBLISH: the record is read by fit blocks of the SAME launch,
+//  possibly on another XCD -- written through, the word that carries the flag last)
+template <bool PUBLISH>
+__device__ __forceinline__ void widen_body(const GridView& G, int max_ring, NbrRec* __restrict__ nbr,
+                                           const int* __restrict__ wl, const int* __restrict__ wl_count,
+                                           unsigned long long* __restrict__ cand_total, int first_ring, const TieList& tl,
+                                           int blk, int nblk, uint32_t (*s_off)[65], uint32_t (*s_lo)[64]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int maxdim = max(G.nx, max(G.ny, G.nz));
   const float margin = 1.0e-3f + 4.0e-7f * (float)maxdim;
   // the first entry of this wave is fetched together with the count (one round trip); slots beyond the count hold
   // stale entries of earlier passes and are never used
-  int w = blockIdx.x * 4 + wave;
+  int w = blk * 4 + wave;
   const int4* entries = reinterpret_cast<const int4*>(wl);
   int4 e0 = entries[2 * (size_t)w], e1 = entries[2 * (size_t)w + 1];
   const int count = *wl_count;
-  for (; w < count; w += gridDim.x * 4) {
-    if (w != (int)(blockIdx.x * 4 + wave)) { e0 = entries[2 * (size_t)w]; e1 = entries[2 * (size_t)w + 1]; }
+  for (; w < count; w += nblk * 4) {
+    if (w != blk * 4 + wave) { e0 = entries[2 * (size_t)w]; e1 = entries[2 * (size_t)w + 1]; }
     const int p = e0.x;
     const float gx = __int_as_float(e0.y), gy = __int_as_float(e0.z), gz = __int_as_float(e0.w);
     const int hint_bits = e1.x;                        // 5th squared distance inside the 3x3x3 block (+inf: none)
@@ -1348,11 +1349,30 @@ __global__ __launch_bounds__(256) void widen_kernel(GridView G, const float4* __
       const bool tie = flag == 1 && key_has_tie(best, sixth);
       b.x = (int)(uint32_t)best[4]; b.y = flag; b.z = (int)(uint32_t)(best[4] >> 32); b.w = ((flag == 1) ? 1 : 0) | (tie ? 2 : 0);
       int4* o = reinterpret_cast<int4*>(&nbr[p]);
-      o[0] = a;
-      o[1] = b;
+      if constexpr (PUBLISH) {
+        unsigned long long* o8 = reinterpret_cast<unsigned long long*>(o);
+        __hip_atomic_store(o8 + 0, ((unsigned long long)(uint32_t)a.y << 32) | (uint32_t)a.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(o8 + 1, ((unsigned long long)(uint32_t)a.w << 32) | (uint32_t)a.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(o8 + 3, ((unsigned long long)(uint32_t)b.w << 32) | (uint32_t)b.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the flag's word last, once the three stores above are performed at the agent-coherent level.  No release FENCE: at agent
+        // scope it writes the whole L2 back (as an acquire invalidates it) -- these stores go through by themselves
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(o8 + 2, ((unsigned long long)(uint32_t)b.y << 32) | (uint32_t)b.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        o[0] = a;
+        o[1] = b;
+      }
       if (tie && tl.list) { const unsigned slot = atomicAdd(tl.count, 1u); if (slot < tl.cap) tl.list[slot] = p; }
     }
   }
+}
+__global__ __launch_bounds__(256) void widen_kernel(GridView G, const float4* __restrict__ scan_sorted, PoseMats P,
+                                                    int max_ring, NbrRec* __restrict__ nbr, const int* __restrict__ wl,
+                                                    const int* __restrict__ wl_count,
+                                                    unsigned long long* __restrict__ cand_total, int first_ring, TieList tl) {
+  __shared__ uint32_t s_off[4][65];
+  __shared__ uint32_t s_lo[4][64];
+  widen_body<false>(G, max_ring, nbr, wl, wl_count, cand_total, first_ring, tl, (int)blockIdx.x, (int)gridDim.x, s_off, s_lo);
 }
 
 // general ring search for the worklist when the gate needs more than 3 rings (unusual configs)
@@ -1619,8 +1639,10 @@ __device__ __forceinline__ void fit_reduce_publish(const float (&v)[16], bool ow
                                                    double* sa2, double* sa3, unsigned int* s_last, const FitIdx& idx,
                                                    double* __restrict__ partials, double2* __restrict__ out_granules,
                                                    unsigned int* __restrict__ ticket, int* __restrict__ wl_count,
-                                                   unsigned long long seq, const TieList& tl) {
+                                                   unsigned long long seq, const TieList& tl, int blk, int nblk) {
+  // blk / nblk: this block's number among the launch's nblk fit blocks (-1: the whole launch consists of them)
   typedef double v2d_t __attribute__((ext_vector_type(2)));
+  const int fb = blk < 0 ? (int)blockIdx.x : blk, fnb = nblk < 0 ? (int)gridDim.x : nblk;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (owns_row) {
 #pragma unroll
@@ -1641,13 +1663,13 @@ __device__ __forceinline__ void fit_reduce_publish(const float (&v)[16], bool ow
     const int t = idx.raw[threadIdx.x];
     const double r = ((sa0[t] + sa1[t]) + sa2[t]) + sa3[t];          // fixed order
     // written through to the agent-coherent level (no dirty L2 line is left behind for the ticket to flush)
-    __hip_atomic_store(&partials[(size_t)blockIdx.x * FIT_LIVE_PAD + threadIdx.x], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&partials[(size_t)fb * FIT_LIVE_PAD + threadIdx.x], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   TRACE(1, 4);
-  const int group = blockIdx.x & (FIT_GROUPS - 1);
-  const int nb_g = (int)(gridDim.x / FIT_GROUPS);                  // gridDim.x is a multiple of FIT_GROUPS
+  const int group = fb & (FIT_GROUPS - 1);
+  const int nb_g = fnb / FIT_GROUPS;                               // the number of fit blocks is a multiple of FIT_GROUPS
   if (threadIdx.x == 0) {
     // every partial of this block is already performed at agent scope (write-through stores, vmcnt(0), barrier)
     const unsigned int old = __hip_atomic_fetch_add(ticket + group, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1755,6 +1777,65 @@ __global__ __launch_bounds__(256) void fit2_kernel(GridView G, const float4* __r
   TRACE(1, 3);
   fit_reduce_publish<PPW>(v, lane < PPW, lane, s_rec[wave], s_acc[0], s_acc[1], s_acc[2], s_acc[3], &s_last, idx, partials,
                           out_granules, ticket, wl_count, seq, tl);
+}
+
+// Widening and fit of a pass that runs in separate dispatches (first pass of a poor prior) in ONE launch: the first `wblocks`
+// blocks are the widening's (one wave per worklist entry), the rest the fit's (64 rows per wave).  A fit block does the rows
+// the k-NN dispatch settled at once -- nine in ten -- and waits for the rows that are still on the worklist (record flag 2) until
+// their widening wave has written the record (through to the agent-coherent level, the flag's word last).  Every XCD dispatches
+// its workgroups in order, so wherever a fit block runs the widening blocks of every XCD are ahead of the fit blocks there: the
+// waves it waits for are running or done.  The wait is bounded by the wall clock all the same (then the row counts as "no
+// match" and *err is set: the host reports it).  Row order, partial slots and the reduction are the fit dispatch's own.
+__global__ __launch_bounds__(256) void widen_fit_kernel(GridView G, const float4* __restrict__ scan_sorted, int n, PoseMats P, int max_ring,
+                                                        NbrRec* __restrict__ nbr, const int* __restrict__ wl, int* __restrict__ wl_count,
+                                                        unsigned long long* __restrict__ cand_total, int wblocks, TieList tl_widen,
+                                                        MatchParams mp, FitIdx idx, double* __restrict__ partials,
+                                                        double2* __restrict__ out_granules, unsigned int* __restrict__ ticket,
+                                                        unsigned long long seq, TieList tl_fit, int* __restrict__ err) {
+  __shared__ float s_rec[4][16 * 65];
+  __shared__ double s_acc[4][256];
+  __shared__ unsigned int s_last;
+  if ((int)blockIdx.x < wblocks) {
+    uint32_t (*s_off)[65] = reinterpret_cast<uint32_t (*)[65]>(&s_rec[0][0]);
+    uint32_t (*s_lo)[64] = reinterpret_cast<uint32_t (*)[64]>(&s_rec[1][0]);
+    widen_body<true>(G, max_ring, nbr, wl, wl_count, cand_total, max_ring, tl_widen, (int)blockIdx.x, wblocks, s_off, s_lo);
+    return;
+  }
+  const int fb = (int)blockIdx.x - wblocks, fnb = (int)gridDim.x - wblocks;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int chunk = xcd_chunk(fb, fnb);
+  const int p = (chunk * 4 + wave) * 64 + lane;
+  float v[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) v[i] = 0.f;
+  if (p < n) {
+    const float4 sp = scan_sorted[p];
+    const int4* nb = reinterpret_cast<const int4*>(&nbr[p]);
+    int4 a = nb[0], b = nb[1];
+    float gx, gy, gz;
+    xform4(P.RT, sp.x, sp.y, sp.z, gx, gy, gz);
+    if (b.y == 2) {
+      // still on the worklist: its widening wave (this launch) publishes the record
+      const unsigned long long* o8 = reinterpret_cast<const unsigned long long*>(&nbr[p]);
+      const unsigned long long t0 = wall_clock64();
+      unsigned long long w2;
+      for (;;) {
+        w2 = __hip_atomic_load(o8 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (agent-scope loads read past this XCD's L2)
+        if ((int)(w2 >> 32) != 2) break;
+        if (wall_clock64() - t0 > 2000000ull) { w2 = (w2 & 0xffffffffull); atomicExch(err, 1); break; }     // 20 ms at 100 MHz: flag 0
+        __builtin_amdgcn_s_sleep(16);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the flag's word has been seen: the rest was performed before it
+      const unsigned long long w0 = __hip_atomic_load(o8 + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long w1 = __hip_atomic_load(o8 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      a.x = (int)(uint32_t)w0; a.y = (int)(uint32_t)(w0 >> 32); a.z = (int)(uint32_t)w1; a.w = (int)(uint32_t)(w1 >> 32);
+      b.x = (int)(uint32_t)w2; b.y = (int)(uint32_t)(w2 >> 32);
+    }
+    const int ids[5] = {a.x, a.y, a.z, a.w, b.x};
+    if (b.y == 1 && __float_as_uint(sp.w) < (uint32_t)mp.n_queries) fit_row(G, P, mp, ids, gx, gy, gz, v);
+  }
+  fit_reduce_publish<64>(v, true, lane, s_rec[wave], s_acc[0], s_acc[1], s_acc[2], s_acc[3], &s_last, idx, partials,
+                         out_granules, ticket, wl_count, seq, tl_fit, fb, fnb);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2373,6 +2454,21 @@ void launch_fit2(hipStream_t st, const GridView& G, const float4* scan_sorted, i
   FitIdx idx;
   for (int i = 0; i < FIT_LIVE_PAD; i++) idx.raw[i] = i < FIT_LIVE ? live_idx[i] : 0;
   hipExtLaunchKernelGGL((fit2_kernel<64>), dim3(fit2_blocks(n)), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, idx, partials, (double2*)out_granules, ticket, wl_count, seq, tl);
+}
+
+void launch_widen_fit(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const PoseMats& P, const MatchParams& mp,
+                      void* nbr, int* wl, int* wl_count, unsigned long long* cand, const unsigned char* live_idx, double* partials,
+                      void* out_granules, unsigned int* ticket, unsigned long long seq, hipEvent_t e0, hipEvent_t e1,
+                      const TieList* tl_widen, const TieList* tl_fit, int* err) {
+  if (n <= 0) return;
+  TieList tw{}, tf{};
+  if (tl_widen) tw = *tl_widen;
+  if (tl_fit) tf = *tl_fit;
+  FitIdx idx;
+  for (int i = 0; i < FIT_LIVE_PAD; i++) idx.raw[i] = i < FIT_LIVE ? live_idx[i] : 0;
+  const int wblocks = 2048, fblocks = fit2_blocks(n);
+  hipExtLaunchKernelGGL(widen_fit_kernel, dim3(wblocks + fblocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, P, mp.max_ring, (NbrRec*)nbr,
+                        wl, wl_count, cand, wblocks, tw, mp, idx, partials, (double2*)out_granules, ticket, seq, tf, err);
 }
 
 int fused_blocks(int n) { return round_up8((n + 127) / 128); }
