@@ -224,14 +224,14 @@ def hbm_regime_leg(device, steps, with_oracle, max_threads=32):
     d, tot = loc.hip.timing_split(reset=True), loc.hip.timing_totals(reset=True)
     qpl = tot["queries"] / max(tot["passes"], 1)
     # the k-NN stage on its own (fast path + widening, no fit): the pass split into dispatches (A/B switch)
-    loc.hip.set_path_switches(fuse=0)
+    loc.hip.set_path_switches(fuse=0, widen_fit=0)
     for _ in range(2):
         reg()
     loc.hip.timing_split(reset=True)
     for _ in range(8):
         reg()
     ds = loc.hip.timing_split(reset=True)
-    loc.hip.set_path_switches(fuse=1)
+    loc.hip.set_path_switches(fuse=1, widen_fit=1)
     loc.hip.set_timing(0)
     stragglers = loc.hip.last_stragglers()
     out = {"workload": "BASELINE.json configs[3] as a resident-input step: %d-pt scan (%d rings x %d azimuths) vs %d-pt box-world map (L = %.0f m), "
@@ -589,14 +589,14 @@ def main():
     # (A/B switch), every pass timed -- what the fused launch's k-NN part costs when rocprofv3 / HIP events can see it
     knn_stage = None
     if int(os.environ.get('FLIMO_BENCH_TIMING', '1')) == 1 and os.environ.get('FLIMO_FUSE', '1') != '0':
-        loc.hip.set_path_switches(fuse=0)
+        loc.hip.set_path_switches(fuse=0, widen_fit=0)
         for _ in range(2):
             step()
         loc.hip.timing_split(reset=True)
         for _ in range(12):
             step()
         d = loc.hip.timing_split(reset=True)
-        loc.hip.set_path_switches(fuse=1)
+        loc.hip.set_path_switches(fuse=1, widen_fit=1)
         if d["separate_n"]:
             knn_stage = {"knn_us": 1e3 * d["knn_ms"] / d["separate_n"], "widen_us": 1e3 * d["widen_ms"] / d["separate_n"],
                          "fit_us": 1e3 * d["fit_ms"] / d["separate_n"], "passes_timed": d["separate_n"]}
@@ -794,7 +794,9 @@ def main():
                            "stage": {"one_launch_pass_us_sampled_inside_timed_region": in_region_us, "one_launch_passes_timed": split["fused_n"],
                                      "separate_dispatch_pass_us": sep, "separate_dispatch_passes_timed": split["separate_n"],
                                      "passes_in_one_launch": n_fused_passes, "passes_total": n_passes,
-                                     "dense_after_timed_region": dense}}
+                                     "dense_after_timed_region": dense,
+                                     "note": "separate-dispatch passes (the first pass of the poor prior) are two launches: k-NN, then "
+                                             "widening + fit in one (widen_fit_kernel): its time is under fit_reduce, widen is 0"}}
         if concurrent and bytes_per_query:
             # the chip's aggregate k-NN rate with S streams in flight: algorithmic bytes of all their passes / wall time
             ppstep = n_passes / max(args.steps, 1)

@@ -335,8 +335,8 @@ class HipCtx:
         self._chk(self._L.flimo_timing_totals(self._h, C.byref(a), C.byref(b), C.byref(d), C.byref(n), C.byref(q), int(reset)))
         return dict(knn_ms=a.value, widen_ms=b.value, fit_ms=d.value, passes=n.value, queries=q.value)
 
-    def set_path_switches(self, tail=-1, fuse=-1):
-        self._chk(self._L.flimo_set_path_switches(self._h, int(tail), int(fuse), -1))
+    def set_path_switches(self, tail=-1, fuse=-1, widen_fit=-1):
+        self._chk(self._L.flimo_set_path_switches(self._h, int(tail), int(fuse), int(widen_fit)))
 
     def timing_split(self, reset=False):
         o = np.zeros(6)

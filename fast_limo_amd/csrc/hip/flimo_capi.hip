@@ -1346,9 +1346,9 @@ extern "C" int flimo_timing_totals(flimo_ctx* c, double* knn_ms, double* widen_m
   return FLIMO_OK;
 }
 // developer / benchmark A/B: negative leaves a switch as it is
-extern "C" int flimo_set_path_switches(flimo_ctx* c, int tail, int fuse, int reserved) {
+extern "C" int flimo_set_path_switches(flimo_ctx* c, int tail, int fuse, int widen_fit) {
   if (!c) return FLIMO_ERR_INVALID;
-  (void)reserved;
+  if (widen_fit >= 0) c->widen_fit = widen_fit != 0;
   if (tail >= 0) c->tail = tail != 0;
   if (fuse >= 0) c->fuse = fuse != 0;
   return FLIMO_OK;
