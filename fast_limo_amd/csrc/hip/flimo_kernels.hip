@@ -1174,6 +1174,7 @@ __global__ __launch_bounds__(256) KNN_WPE void knn5_kernel(GridView G, const flo
     int4 a, b;
     a.x = (int)(uint32_t)best[0]; a.y = (int)(uint32_t)best[1]; a.z = (int)(uint32_t)best[2]; a.w = (int)(uint32_t)best[3];
     b.x = (int)(uint32_t)best[4]; b.y = min(flag, 2); b.z = (int)(uint32_t)(best[4] >> 32); b.w = ((flag == 1) ? 1 : 0) | (tie ? 2 : 0);   // d5 for the next pass; bit 1: tie
+    if (flag >= 2) { a.x = a.y = a.z = a.w = -1; b.x = -1; }   // pending: no neighbour numbers -- widen_fit_kernel's readers tell a half-rewritten record by them
     if (tie && !tie_listed && tl.list) { const unsigned slot = atomicAdd(tl.count, 1u); if (slot < tl.cap) tl.list[slot] = p; }
     int4* o = reinterpret_cast<int4*>(&nbr[p]);
     o[0] = a;
@@ -1814,22 +1815,27 @@ __global__ __launch_bounds__(256) void widen_fit_kernel(GridView G, const float4
     int4 a = nb[0], b = nb[1];
     float gx, gy, gz;
     xform4(P.RT, sp.x, sp.y, sp.z, gx, gy, gz);
-    if (b.y == 2) {
-      // still on the worklist: its widening wave (this launch) publishes the record
+    // A record on the worklist (flag 2) carries no neighbour numbers (-1).  Its widening wave -- this launch, possibly another XCD --
+    // writes the four 8-byte words through one by one, the flag's word last; words of one record may still become visible out of
+    // order, so a "found" record counts only when all five numbers are map positions: a reader that meets the new flag with an
+    // old half looks again (agent-scope loads read past this XCD's L2; bounded by the wall clock).
+    auto incomplete = [&](const int4& ra, const int4& rb) {
+      return rb.y == 2 || (rb.y == 1 && ((uint32_t)ra.x >= G.n_pts || (uint32_t)ra.y >= G.n_pts || (uint32_t)ra.z >= G.n_pts ||
+                                          (uint32_t)ra.w >= G.n_pts || (uint32_t)rb.x >= G.n_pts));
+    };
+    if (incomplete(a, b)) {
       const unsigned long long* o8 = reinterpret_cast<const unsigned long long*>(&nbr[p]);
       const unsigned long long t0 = wall_clock64();
-      unsigned long long w2;
       for (;;) {
-        w2 = __hip_atomic_load(o8 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (agent-scope loads read past this XCD's L2)
-        if ((int)(w2 >> 32) != 2) break;
-        if (wall_clock64() - t0 > 2000000ull) { w2 = (w2 & 0xffffffffull); atomicExch(err, 1); break; }     // 20 ms at 100 MHz: flag 0
+        const unsigned long long w2 = __hip_atomic_load(o8 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long w0 = __hip_atomic_load(o8 + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long w1 = __hip_atomic_load(o8 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a.x = (int)(uint32_t)w0; a.y = (int)(uint32_t)(w0 >> 32); a.z = (int)(uint32_t)w1; a.w = (int)(uint32_t)(w1 >> 32);
+        b.x = (int)(uint32_t)w2; b.y = (int)(uint32_t)(w2 >> 32);
+        if (!incomplete(a, b)) break;
+        if (wall_clock64() - t0 > 2000000ull) { b.y = 0; atomicExch(err, 1); break; }     // 20 ms at 100 MHz: no match, reported
         __builtin_amdgcn_s_sleep(16);
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the flag's word has been seen: the rest was performed before it
-      const unsigned long long w0 = __hip_atomic_load(o8 + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned long long w1 = __hip_atomic_load(o8 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      a.x = (int)(uint32_t)w0; a.y = (int)(uint32_t)(w0 >> 32); a.z = (int)(uint32_t)w1; a.w = (int)(uint32_t)(w1 >> 32);
-      b.x = (int)(uint32_t)w2; b.y = (int)(uint32_t)(w2 >> 32);
     }
     const int ids[5] = {a.x, a.y, a.z, a.w, b.x};
     if (b.y == 1 && __float_as_uint(sp.w) < (uint32_t)mp.n_queries) fit_row(G, P, mp, ids, gx, gy, gz, v);
