@@ -554,7 +554,10 @@ def main():
     # short run), which keeps the perturbation of `value` near 1 %.  A dense series (every pass of 12 more steps) follows the
     # timed region for the statistics (`stage.dense_after_timed_region`).  FLIMO_BENCH_TIMING_STRIDE=1 times all.
     loc.hip.set_timing(int(os.environ.get('FLIMO_BENCH_TIMING', '1')))
-    auto_stride = max(5, ((4 * args.steps // (6 if args.steps >= 50 else 3)) // 4) * 4 + 1)      # (3 samples in a run of < 50 steps)
+    auto_stride = max(5, ((4 * args.steps // 6) // 4) * 4 + 1)
+    if args.steps < 50:
+        auto_stride = 1 << 30           # a short run (the driver's 20 steps last 3 ms) is not sampled at all: three timed passes would
+                                        # cost 3 % of it; the dense series below provides the kernel statistics
     loc.hip.set_timing_stride(int(os.environ.get('FLIMO_BENCH_TIMING_STRIDE', str(auto_stride))))
     loc.hip.timing_totals(reset=True)
     loc.hip.timing_split(reset=True)
@@ -777,7 +780,7 @@ def main():
         if not E and (args.rings, args.azimuths, args.map_points, args.box) != (64, 1024, 1000000, 100.0):
             Eq = None                      # the constant only describes configs[1]
         bytes_per_query = (16.0 + 16.0 * Eq + NBR_BYTES) if Eq else None
-        qpl = tot["queries"] / max(tot["passes"], 1)               # queries per launch
+        qpl = tot["queries"] / tot["passes"] if tot["passes"] else float(scan.shape[0])      # queries per launch (every point of the scan is a query here)
         us = lambda ms, n: (1e3 * ms / n) if n else None
         in_region_us = us(split["fused_ms"], split["fused_n"])      # sparse samples inside the timed region (each perturbs the wall time)
         one_us = dense["one_launch_pass_us"] if (dense and dense.get("one_launch_pass_us")) else in_region_us
