@@ -187,8 +187,22 @@ __global__ __launch_bounds__(256) void gb_append_kernel(const float4* __restrict
 }
 
 // ---- gather the members of every build item into its index segment -----------------------------
-__global__ __launch_bounds__(256) void gb_gather_old_kernel(const int* __restrict__ pt_leaf, int map_n_old, const int* __restrict__ node_item,
-                                                            const GbItem* __restrict__ items, int* __restrict__ cursor, int* __restrict__ lists) {
+// (one launch: the first `old_blocks` blocks look at the stored points, the rest at the batch -- the two halves do not depend on
+//  each other)
+__global__ __launch_bounds__(256) void gb_gather_kernel(const int* __restrict__ pt_leaf, int map_n_old, const int* __restrict__ node_item,
+                                                        const GbItem* __restrict__ items, int* __restrict__ cursor, int* __restrict__ lists,
+                                                        int old_blocks, const uint32_t* __restrict__ perm, const int* __restrict__ assign,
+                                                        const int* __restrict__ new_index, int n) {
+  if ((int)blockIdx.x >= old_blocks) {
+    const int i = ((int)blockIdx.x - old_blocks) * blockDim.x + threadIdx.x;        // sorted position
+    if (i >= n) return;
+    const uint32_t pt = perm[i];
+    const int a = assign[pt];
+    if (a >= 0 || new_index[pt] < 0) return;                    // not a member of a build item (or dropped / non-finite)
+    const GbItem I = items[-1 - a];
+    lists[I.seg + I.n_old + (i - I.g_begin)] = new_index[pt];
+    return;
+  }
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= map_n_old) return;
   const int leaf = pt_leaf[i];
@@ -197,17 +211,6 @@ __global__ __launch_bounds__(256) void gb_gather_old_kernel(const int* __restric
   if (it < 0) return;
   const int pos = atomicAdd(&cursor[it], 1);
   lists[items[it].seg + pos] = i;
-}
-__global__ __launch_bounds__(256) void gb_gather_new_kernel(const uint32_t* __restrict__ perm, const int* __restrict__ assign,
-                                                            const int* __restrict__ new_index, const GbItem* __restrict__ items, int n,
-                                                            int* __restrict__ lists) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;        // sorted position
-  if (i >= n) return;
-  const uint32_t pt = perm[i];
-  const int a = assign[pt];
-  if (a >= 0 || new_index[pt] < 0) return;                    // not a member of a build item (or dropped / non-finite)
-  const GbItem I = items[-1 - a];
-  lists[I.seg + I.n_old + (i - I.g_begin)] = new_index[pt];
 }
 
 // ---- build: createOctant (Octree.hpp:301-338), ONE WAVE per item ---------------------------------
@@ -726,9 +729,11 @@ hipError_t GBook::update(hipStream_t st, const float4* batch, int m, const float
   const int kept = (int)(last_rank + last_flag);
   if ((size_t)h_cnt[1] > lists_cap) return hipErrorOutOfMemory;
   if (n_items > 0) {
-    if (map_n > 0)
-      hipLaunchKernelGGL(gb_gather_old_kernel, dim3((map_n + 255) / 256), dim3(256), 0, st, pt_leaf, map_n, node_item, items, cursor, lists);
-    hipLaunchKernelGGL(gb_gather_new_kernel, dim3(blocks), dim3(256), 0, st, S.vals_out, assign, new_index, items, m, lists);
+    {
+      const int old_blocks = map_n > 0 ? (map_n + 255) / 256 : 0;
+      hipLaunchKernelGGL(gb_gather_kernel, dim3(old_blocks + blocks), dim3(256), 0, st, pt_leaf, map_n, node_item, items, cursor, lists,
+                         old_blocks, S.vals_out, assign, new_index, m);
+    }
     if (node_n != node_n_on_dev) {                                  // (root growth on the host, or first use)
       GBCHK(hipMemcpyAsync(node_n_dev, &node_n, sizeof(int), hipMemcpyHostToDevice, st));
       node_n_on_dev = node_n;

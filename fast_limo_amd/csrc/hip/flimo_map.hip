@@ -240,18 +240,21 @@ __device__ __forceinline__ uint32_t wave_lower_bound_u32(const uint32_t* __restr
   return lo + (uint32_t)__popcll(__ballot(below));
 }
 // new point j (cell-sorted) -> behind the stored points of its cell: position = j + #stored points in cells <= key
-__global__ __launch_bounds__(256) void merge_new_kernel(const float4* __restrict__ new_pts, const uint32_t* __restrict__ nkeys,
-                                                        const uint32_t* __restrict__ nperm, uint32_t k,
-                                                        const uint32_t* __restrict__ cell_start_old, float4* __restrict__ out) {
-  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= k) return;
-  out[(size_t)cell_start_old[(size_t)nkeys[j] + 1] + j] = new_pts[nperm[j]];
-}
 // stored point i (cell-sorted) -> i + #new points in cells < its cell
-__global__ __launch_bounds__(256) void merge_old_kernel(const float4* __restrict__ old_pts, uint32_t n_old,
-                                                        const uint32_t* __restrict__ nkeys, uint32_t k, float ox, float oy, float oz,
-                                                        float inv_cell, int nx, int ny, int nz, int xs, float4* __restrict__ out) {
+// (one launch for both: the first `old_blocks` blocks move the stored points, the rest place the new ones; they write disjoint
+//  positions and read only the old tables)
+__global__ __launch_bounds__(256) void merge_points_kernel(const float4* __restrict__ old_pts, uint32_t n_old,
+                                                           const uint32_t* __restrict__ nkeys, uint32_t k, float ox, float oy, float oz,
+                                                           float inv_cell, int nx, int ny, int nz, int xs, float4* __restrict__ out,
+                                                           uint32_t old_blocks, const float4* __restrict__ new_pts,
+                                                           const uint32_t* __restrict__ nperm, const uint32_t* __restrict__ cell_start_old) {
   __shared__ uint32_t s_lo, s_hi, s_c0, s_c1;
+  if (blockIdx.x >= old_blocks) {
+    const uint32_t j = (blockIdx.x - old_blocks) * blockDim.x + threadIdx.x;
+    if (j >= k) return;
+    out[(size_t)cell_start_old[(size_t)nkeys[j] + 1] + j] = new_pts[nperm[j]];
+    return;
+  }
   const uint32_t base = blockIdx.x * blockDim.x;
   const uint32_t i = base + threadIdx.x;
   const uint32_t last = min(n_old, base + blockDim.x) - 1u;
@@ -314,10 +317,11 @@ hipError_t map_merge_grid(hipStream_t st, const float4* old_sorted, size_t n_old
   }
   e = sort_pairs_u32(S.cub_tmp, tmp_bytes, S.keys_in, S.keys_out, S.vals_in, S.vals_out, (int)k, 0, bits, st);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(merge_new_kernel, dim3(kb), dim3(256), 0, st, new_pts, S.keys_out, S.vals_out, (uint32_t)k, cell_start, out_sorted);
-  if (n_old > 0)
-    hipLaunchKernelGGL(merge_old_kernel, dim3((unsigned)((n_old + 255) / 256)), dim3(256), 0, st, old_sorted, (uint32_t)n_old,
-                       S.keys_out, (uint32_t)k, ox, oy, oz, inv_cell, nx, ny, nz, xs, out_sorted);
+  {
+    const unsigned old_blocks = (unsigned)((n_old + 255) / 256);
+    hipLaunchKernelGGL(merge_points_kernel, dim3(old_blocks + (unsigned)kb), dim3(256), 0, st, old_sorted, (uint32_t)n_old, S.keys_out, (uint32_t)k,
+                       ox, oy, oz, inv_cell, nx, ny, nz, xs, out_sorted, old_blocks, new_pts, S.vals_out, cell_start);
+  }
   hipLaunchKernelGGL(cellstart_shift_kernel, dim3((unsigned)((ncells + 1 + 4095) / 4096)), dim3(256), 0, st, cell_start, ncells + 1,
                      S.keys_out, (uint32_t)k);
   return hipGetLastError();
