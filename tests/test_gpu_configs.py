@@ -118,7 +118,7 @@ def test_config2_sequence_64_scans_65k_points_rolling_map(built, oracle):
     st, w, a = synth.stationary_imu(0.0, 0.1 * n_scans + 0.06)
     G = api.Localizer(api.default_cfg(num_threads=8, **CAPS)); G.set_flags(add_to_map=True, download_clouds=False)
     Lo = oracle.Localizer(oracle.default_cfg(num_threads=8, **CAPS))
-    prime = synth.corridor_map(2600000, -40.0, 760.0, 99)      # the map the drive rolls through
+    prime = synth.corridor_map(5000000, -40.0, 760.0, 99)      # the map the drive rolls through (BASELINE configs[2]: "rolling 5M")
     G.map_add(prime); Lo.map_add(prime)
     assert G.map_size() == Lo.map_size() == prime.shape[0]
     x0 = G.get_x(); x0[14] = speed
@@ -156,7 +156,7 @@ def test_config2_sequence_64_scans_65k_points_rolling_map(built, oracle):
     print("per-scan |dpos|: median %.2e, scans above 1e-9: %d, above 1e-7: %d" % (np.median(devs), int((devs > 1e-9).sum()), int((devs > 1e-7).sum())))
     assert np.median(devs) <= 1e-7      # maps are built by each side from its own poses: 1e-13 differences reach the float32 map points
     assert mm == 0
-    assert G.map_size() > 2600000 + 1000        # a dense prior map: the down-sampling rule keeps a few dozen points per scan
+    assert G.map_size() > 5000000 + 1000        # a dense prior map: the down-sampling rule keeps a few dozen points per scan
     assert abs(G.get_x()[0] - speed * 0.1 * n_scans) < 0.25
     assert G.hip.fused_pass_count() - fused0 > n_scans            # the one-launch pass is what a sequence runs
     G.close()
