@@ -588,16 +588,20 @@ __global__ __launch_bounds__(256) void filt_keep_kernel(const Raw32* __restrict_
 __global__ __launch_bounds__(256) void filt_compact_kernel(const Raw32* __restrict__ in, size_t n, FilterParams F, const uint32_t* __restrict__ keep,
                                                            const uint32_t* __restrict__ pos, float4* __restrict__ out, double* __restrict__ t_out,
                                                            unsigned long long* __restrict__ ext, unsigned long long* __restrict__ key_out) {
+  // (no early exits: the block reduces its extreme key and NaN mark first -- one atomic per block instead of one per wave)
+  __shared__ unsigned long long s_max[4];
+  __shared__ int s_nan[4];
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  const bool live = i < n && keep[i] != 0u;
   if (i == n - 1) ext[1] = (unsigned long long)(pos[i] + keep[i]);
-  if (!keep[i]) return;
+  unsigned long long mine = 0ull;                              // ordered key of this point (0: none)
+  bool nan = false;
+  if (live) {
   const Raw32 p = in[i];
   const uint32_t o = pos[i];
   out[o] = make_float4(p.x, p.y, p.z, __uint_as_float(o));
   double t;
   unsigned long long key;
-  bool nan = false;
   const bool desc = F.eos && F.kind <= 1;
   if (F.kind == 0) {
     const float tf = (float)p.u0 * 1e-9f;
@@ -620,8 +624,21 @@ __global__ __launch_bounds__(256) void filt_compact_kernel(const Raw32* __restri
   }
   t_out[o] = t;
   if (key_out) key_out[o] = desc ? ~key : key;               // ascending in this key = the order of the reference's time sort
-  if (nan) atomicOr(&ext[2], 1ull);
-  else atomicMax(&ext[0], desc ? ~key : key);
+  if (!nan) mine = desc ? ~key : key;
+  }
+  // block maximum of the keys, block OR of the NaN marks
+  unsigned long long m = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const unsigned long long v = __shfl_xor(m, o, 64); m = v > m ? v : m; }
+  const int any_nan = __any(live && nan) ? 1 : 0;
+  if ((threadIdx.x & 63) == 0) { s_max[threadIdx.x >> 6] = m; s_nan[threadIdx.x >> 6] = any_nan; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long bm = s_max[0];
+    for (int w = 1; w < 4; w++) bm = s_max[w] > bm ? s_max[w] : bm;
+    if (bm) atomicMax(&ext[0], bm);
+    if (s_nan[0] | s_nan[1] | s_nan[2] | s_nan[3]) atomicOr(&ext[2], 1ull);
+  }
 }
 
 hipError_t filter_raw_scan(hipStream_t st, const void* raw32_dev, size_t n, const FilterParams& F, float4* out, double* t_out,
