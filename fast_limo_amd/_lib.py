@@ -40,6 +40,22 @@ class Frame(C.Structure):
                 ("time", C.c_double)]
 
 
+CHAIN_MAX_PASSES = 12
+
+
+class ChainPass(C.Structure):
+    _fields_ = [("M", C.c_int), ("stragglers", C.c_int), ("ties", C.c_int), ("HTH", C.c_double * 144), ("HTh", C.c_double * 12),
+                ("dx", C.c_double * 23), ("x_after", C.c_double * 26)]
+
+
+class ChainIO(C.Structure):
+    """flimo_chain_io (include/flimo_c.h): arguments and results of flimo_update_chain."""
+    _fields_ = [("x26", C.c_double * 26), ("P", C.c_double * 529), ("limits", C.c_double * 23), ("R", C.c_double), ("D", C.c_double),
+                ("max_iter", C.c_int), ("want_log", C.c_int),
+                ("status", C.c_int), ("reason", C.c_int), ("passes", C.c_int), ("it_next", C.c_int), ("t", C.c_int),
+                ("x26_out", C.c_double * 26), ("P_out", C.c_double * 529), ("log", ChainPass * CHAIN_MAX_PASSES)]
+
+
 MATCH_REC_DTYPE = np.dtype([
     ("H", np.float32, 12), ("h", np.float32), ("valid", np.float32), ("n", np.float32, 4),
     ("p_global", np.float32, 3), ("sqd", np.float32, 5), ("nbr", np.int32, 5), ("n_nbr", np.int32)])
@@ -58,6 +74,7 @@ HIP_SYMBOLS = [
     "flimo_scan_to_world", "flimo_scan_clouds", "flimo_upload_stage", "flimo_match_reduce_overlap", "flimo_map_add_scan",
     "flimo_set_timing", "flimo_set_timing_stride", "flimo_pass_count", "flimo_fused_pass_count", "flimo_tie_stats", "flimo_fine_stats", "flimo_map_grid_selfcheck", "flimo_set_debug_records", "flimo_set_lanes_per_query", "flimo_last_kernel_ms",
     "flimo_last_candidates_per_query", "flimo_last_widen_count", "flimo_last_stragglers", "flimo_timing_totals", "flimo_timing_split", "flimo_set_path_switches", "flimo_set_wait_timeout_ms", "flimo_insert_rule_replay", "flimo_plane_fit5_host", "flimo_plane_eval5_host", "flimo_calculate_H_host",
+    "flimo_update_chain", "flimo_chain_stats",
 ]
 
 _hip = None
@@ -129,6 +146,8 @@ def load_hip():
     L.flimo_set_path_switches.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     L.flimo_insert_rule_replay.argtypes = [C.c_float, C.c_int, f32p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t)]
     L.flimo_calculate_H_host.argtypes = [f64p, f32p, f32p, f32p, C.c_size_t, C.c_int, f64p, f64p]
+    L.flimo_update_chain.argtypes = [vp, C.POINTER(MatchCfg), C.POINTER(ChainIO)]
+    L.flimo_chain_stats.argtypes = [vp, f64p, C.c_int]
     L.flimo_last_widen_count.restype = C.c_int
     L.flimo_last_widen_count.argtypes = [vp]
     L.flimo_last_stragglers.restype = C.c_int
@@ -342,6 +361,27 @@ class HipCtx:
         o = np.zeros(6)
         self._chk(self._L.flimo_timing_split(self._h, o, int(reset)))
         return dict(fused_ms=o[0], fused_n=int(o[1]), knn_ms=o[2], widen_ms=o[3], fit_ms=o[4], separate_n=int(o[5]))
+
+    def update_chain(self, cfg: "MatchCfg", x26, P, limits, R=0.001, D=5.0, max_iter=3, want_log=True):
+        """The whole iterated update of the resident scan enqueued at once (flimo_update_chain).  Returns a dict: status (0 declined,
+        1 done, 2 handed back), reason, passes, it_next, t, x (26), P (23 x 23, status 1) and the per-pass log."""
+        io = ChainIO()
+        io.x26[:] = list(np.asarray(x26, dtype=np.float64))
+        io.P[:] = list(np.asarray(P, dtype=np.float64).reshape(-1))
+        io.limits[:] = list(np.asarray(limits, dtype=np.float64))
+        io.R, io.D, io.max_iter, io.want_log = float(R), float(D), int(max_iter), int(bool(want_log))
+        self._chk(self._L.flimo_update_chain(self._h, C.byref(cfg), C.byref(io)))
+        n_log = min(CHAIN_MAX_PASSES, io.passes + (1 if io.status == 2 else 0))
+        log = [dict(M=io.log[i].M, stragglers=io.log[i].stragglers, ties=io.log[i].ties,
+                    HTH=np.array(io.log[i].HTH).reshape(12, 12), HTh=np.array(io.log[i].HTh), dx=np.array(io.log[i].dx),
+                    x_after=np.array(io.log[i].x_after)) for i in range(n_log)]
+        return dict(status=io.status, reason=io.reason, passes=io.passes, it_next=io.it_next, t=io.t, x=np.array(io.x26_out),
+                    P=np.array(io.P_out).reshape(23, 23), log=log)
+
+    def chain_stats(self, reset=False):
+        o = np.zeros(5)
+        self._chk(self._L.flimo_chain_stats(self._h, o, int(reset)))
+        return dict(algebra_ms=o[0], algebra_n=int(o[1]), chains=int(o[2]), handed_back=int(o[3]), declined=int(o[4]))
 
     def last_widen_count(self) -> int:
         return int(self._L.flimo_last_widen_count(self._h))

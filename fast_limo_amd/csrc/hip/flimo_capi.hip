@@ -19,6 +19,8 @@
 #include "flimo_types.h"
 #include "flimo_kernels.h"
 #include "flimo_math.h"
+#include "flimo_pose.h"
+#include "flimo_chain.h"
 #include "flimo_insert.h"
 #include "flimo_gbook.h"
 
@@ -191,6 +193,23 @@ struct flimo_ctx {
   void* d_nbrk = nullptr;          // neighbour records of the general pass
   size_t nbrk_cap = 0;
   int wait_timeout_ms = 2000;      // wall-clock bound of the wait for a pass's result (flimo_set_wait_timeout_ms)
+  hipEvent_t timeout_ev = nullptr; // recorded behind the launches of a pass / chain whose wait ran out
+  bool timeout_pending = false;    // ... and not yet seen complete: no new pass is queued on top of it (check_abandoned)
+  // the whole iterated update enqueued at once (flimo_chain.h, flimo_update_chain)
+  ChainState* d_chain = nullptr;         // device filter state
+  void* d_chain_gran = nullptr;          // device copy of the granule slots: a chained pass publishes its sums here
+  ChainPrior* h_chain_prior = nullptr;   // mapped: the prior of the scan's update (read by the first algebra kernel)
+  ChainPrior* d_chain_prior = nullptr;   // its device alias
+  double* h_chain_res = nullptr;         // mapped: CH_RES result granules {value, tag}
+  void* d_chain_res = nullptr;
+  double* h_chain_log = nullptr;         // mapped: CH_MAX_PASSES x CH_LOGN log granules
+  void* d_chain_log = nullptr;
+  unsigned long long chain_tag = 0x4000000000000000ull;   // tag of the last chain (own number space)
+  bool host_update = false;              // FLIMO_HOST_UPDATE=1: flimo_update_chain always declines (the host loop runs the update; A/B)
+  hipEvent_t chain_ev[CH_MAX_PASSES][6]; // per pass: [0,1] first launch, [2,3] second launch, [4,5] algebra kernel (lazy)
+  bool chain_ev_made = false;
+  double chain_alg_ms = 0;
+  long long chain_alg_n = 0, chains_run = 0, chains_back = 0, chains_declined = 0;
   bool tail = true;                // FLIMO_TAIL=0: pending queries go to the worklist + widen_kernel dispatch instead of being finished inside the k-NN launch (A/B checks)
 };
 
@@ -236,63 +255,8 @@ static int ensure_dev(flimo_ctx* c, T*& p, size_t& cap, size_t need, bool keep, 
   return FLIMO_OK;
 }
 
-// ---- host float32 pose algebra (reference evaluation order, no FMA) --------------------------
-static inline float hsum3(float a, float b, float c) { return a + (b + c); }
-static void quat_to_rot_f(const float q[4] /*x y z w*/, float R[9]) {   // Eigen toRotationMatrix
-  const float tx = 2.f * q[0], ty = 2.f * q[1], tz = 2.f * q[2];
-  const float twx = tx * q[3], twy = ty * q[3], twz = tz * q[3];
-  const float txx = tx * q[0], txy = ty * q[0], txz = tz * q[0];
-  const float tyy = ty * q[1], tyz = tz * q[1], tzz = tz * q[2];
-  R[0] = 1.f - (tyy + tzz); R[1] = txy - twz;         R[2] = txz + twy;
-  R[3] = txy + twz;         R[4] = 1.f - (txx + tzz); R[5] = tyz - twx;
-  R[6] = txz - twy;         R[7] = tyz + twx;         R[8] = 1.f - (txx + tyy);
-}
-static void quat_to_rot_d(const double q[4], double R[9]) {
-  const double tx = 2.0 * q[0], ty = 2.0 * q[1], tz = 2.0 * q[2];
-  const double twx = tx * q[3], twy = ty * q[3], twz = tz * q[3];
-  const double txx = tx * q[0], txy = ty * q[0], txz = tz * q[0];
-  const double tyy = ty * q[1], tyz = tz * q[1], tzz = tz * q[2];
-  R[0] = 1.0 - (tyy + tzz); R[1] = txy - twz;         R[2] = txz + twy;
-  R[3] = txy + twz;         R[4] = 1.0 - (txx + tzz); R[5] = tyz - twx;
-  R[6] = txz - twy;         R[7] = tyz + twx;         R[8] = 1.0 - (txx + tyy);
-}
-static void se3_from(const float q[4], const float p[3], float T[16]) {      // State::get_RT / get_extr_RT
-  float R[9];
-  quat_to_rot_f(q, R);
-  T[0] = R[0]; T[1] = R[1]; T[2] = R[2];  T[3] = p[0];
-  T[4] = R[3]; T[5] = R[4]; T[6] = R[5];  T[7] = p[1];
-  T[8] = R[6]; T[9] = R[7]; T[10] = R[8]; T[11] = p[2];
-  T[12] = 0.f; T[13] = 0.f; T[14] = 0.f;  T[15] = 1.f;
-}
-static void se3_inv_from(const float q[4], const float p[3], float T[16]) {  // State::get_RT_inv / get_extr_RT_inv
-  float R[9];
-  quat_to_rot_f(q, R);
-  // rot^T and -rot^T * p, coefficient products reduced as c0 + (c1 + c2)
-  float Rt[9] = {R[0], R[3], R[6], R[1], R[4], R[7], R[2], R[5], R[8]};
-  float t[3];
-  for (int i = 0; i < 3; i++) t[i] = hsum3((-Rt[i * 3 + 0]) * p[0], (-Rt[i * 3 + 1]) * p[1], (-Rt[i * 3 + 2]) * p[2]);
-  T[0] = Rt[0]; T[1] = Rt[1]; T[2] = Rt[2];  T[3] = t[0];
-  T[4] = Rt[3]; T[5] = Rt[4]; T[6] = Rt[5];  T[7] = t[1];
-  T[8] = Rt[6]; T[9] = Rt[7]; T[10] = Rt[8]; T[11] = t[2];
-  T[12] = 0.f; T[13] = 0.f; T[14] = 0.f;     T[15] = 1.f;
-}
-static void pose_from_x26(const double x[26], PoseMats& P) {
-  // State(state_ikfom): casts (State.cpp:38-55)
-  const float p[3] = {(float)x[0], (float)x[1], (float)x[2]};
-  const float q[4] = {(float)x[3], (float)x[4], (float)x[5], (float)x[6]};
-  const float qLI[4] = {(float)x[7], (float)x[8], (float)x[9], (float)x[10]};
-  const float pLI[3] = {(float)x[11], (float)x[12], (float)x[13]};
-  se3_from(q, p, P.RT);
-  se3_inv_from(q, p, P.RT_inv);
-  se3_inv_from(qLI, pLI, P.TLI_inv);
-  // s.rot.conjugate().toRotationMatrix().cast<float>()  (Localizer.cpp:554-555)
-  const double qc[4] = {-x[3], -x[4], -x[5], x[6]};
-  const double lc[4] = {-x[7], -x[8], -x[9], x[10]};
-  double Rd[9], Ld[9];
-  quat_to_rot_d(qc, Rd);
-  quat_to_rot_d(lc, Ld);
-  for (int i = 0; i < 9; i++) { P.R_inv[i] = (float)Rd[i]; P.RLI_inv[i] = (float)Ld[i]; }
-}
+// (the float32 pose algebra of a pass -- State casts, get_RT / get_RT_inv / get_extr_RT_inv, the conjugate rotations of
+//  calculate_H -- lives in flimo_pose.h: the host and the device filter form the same constants from the same code)
 
 // ---- developer switches: every environment variable this library reads, in one place ------------------------------------------
 // None of them changes a result (the parity tests run under several of them); they exist for A/B measurements and fault isolation.
@@ -315,6 +279,8 @@ static void pose_from_x26(const double x[26], PoseMats& P) {
 //   FLIMO_HOST_INSERT=1           the first batch goes through the host statement of the insert rule, then is imported
 //   FLIMO_LAZY_DESKEW=0           the deskew always runs as a dispatch of its own (default: on the scan's first k-NN launch)
 //   FLIMO_WIDEN_FIT=0             widening and fit of a separate-dispatch pass as two launches (default: one, widen_fit_kernel)
+//   FLIMO_HOST_UPDATE=1           the iterated update runs as a host loop over single passes (default: the whole update is enqueued at
+//                                 once, flimo_update_chain)
 //   FLIMO_PROF_PASS / FLIMO_PROF_INSERT   host-side timing prints (stderr)
 // (csrc/host: FLIMO_REFERENCE_SOLVE=1 literal two-inverse gain, FLIMO_SYNC_INSERT=1 map inserts on the caller's thread,
 //  FLIMO_PROF_DESKEW / FLIMO_PROF_CLOUDS timing prints; bench.py: FLIMO_BENCH_*.)
@@ -341,6 +307,7 @@ static void load_dev_switches(flimo_ctx* c) {
   if (env_int("FLIMO_HOST_INSERT", v)) c->host_insert = v != 0;
   if (env_int("FLIMO_LAZY_DESKEW", v)) c->lazy_deskew = v != 0;
   if (env_int("FLIMO_WIDEN_FIT", v)) c->widen_fit = v != 0;
+  if (env_int("FLIMO_HOST_UPDATE", v)) c->host_update = v != 0;
 }
 
 // ---- context ----------------------------------------------------------------------------------
@@ -375,12 +342,24 @@ extern "C" int flimo_ctx_create(int device, flimo_ctx** out) {
             hipMemset(c->d_tie_count, 0, 2 * sizeof(unsigned int)) == hipSuccess &&
             hipHostMalloc((void**)&c->h_wf_err, sizeof(int), hipHostMallocMapped) == hipSuccess &&
             hipHostGetDevicePointer((void**)&c->d_wf_err, c->h_wf_err, 0) == hipSuccess &&
+            hipMalloc((void**)&c->d_chain, chain_state_size()) == hipSuccess &&
+            hipMemset(c->d_chain, 0, chain_state_size()) == hipSuccess &&
+            hipMalloc(&c->d_chain_gran, FIT_GROUPS * FIT_LIVE_PAD * 2 * sizeof(double)) == hipSuccess &&
+            hipMemset(c->d_chain_gran, 0, FIT_GROUPS * FIT_LIVE_PAD * 2 * sizeof(double)) == hipSuccess &&
+            hipHostMalloc((void**)&c->h_chain_prior, sizeof(ChainPrior), hipHostMallocMapped) == hipSuccess &&
+            hipHostGetDevicePointer((void**)&c->d_chain_prior, c->h_chain_prior, 0) == hipSuccess &&
+            hipHostMalloc((void**)&c->h_chain_res, (size_t)CH_RES * 2 * sizeof(double), hipHostMallocMapped) == hipSuccess &&
+            hipHostGetDevicePointer(&c->d_chain_res, c->h_chain_res, 0) == hipSuccess &&
+            hipHostMalloc((void**)&c->h_chain_log, (size_t)CH_MAX_PASSES * CH_LOGN * 2 * sizeof(double), hipHostMallocMapped) == hipSuccess &&
+            hipHostGetDevicePointer(&c->d_chain_log, c->h_chain_log, 0) == hipSuccess &&
             hipMalloc(&c->d_wl_count, sizeof(int)) == hipSuccess &&
             hipMemset(c->d_wl_count, 0, sizeof(int)) == hipSuccess &&
             hipHostMalloc((void**)&c->h_wl_count, sizeof(int), hipHostMallocDefault) == hipSuccess &&
             hipHostMalloc((void**)&c->h_cand, sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess;
   if (!ok) { flimo_ctx_destroy(c); return FLIMO_ERR_HIP; }
   *c->h_wf_err = 0;
+  memset(c->h_chain_res, 0, (size_t)CH_RES * 2 * sizeof(double));
+  memset(c->h_chain_log, 0, (size_t)CH_MAX_PASSES * CH_LOGN * 2 * sizeof(double));
   memset(c->h_out256, 0, FIT_GROUPS * FIT_SLOT * sizeof(double));
   memset(c->h_granules, 0, FIT_GROUPS * FIT_LIVE_PAD * 2 * sizeof(double));
   // calibrate the v_mfma_f64_16x16x4_f64 accumulator layout: D[i][j] = j + 16 i
@@ -429,11 +408,17 @@ extern "C" void flimo_ctx_destroy(flimo_ctx* c) {
   (void)hipFree(c->d_fit2_partials);
   if (c->h_cand) (void)hipHostFree(c->h_cand);
   if (c->h_wf_err) (void)hipHostFree(c->h_wf_err);
+  (void)hipFree(c->d_chain); (void)hipFree(c->d_chain_gran);
+  if (c->h_chain_prior) (void)hipHostFree(c->h_chain_prior);
+  if (c->h_chain_res) (void)hipHostFree(c->h_chain_res);
+  if (c->h_chain_log) (void)hipHostFree(c->h_chain_log);
+  if (c->chain_ev_made) for (int i = 0; i < CH_MAX_PASSES; i++) for (int k = 0; k < 6; k++) (void)hipEventDestroy(c->chain_ev[i][k]);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->h_clouds) (void)hipHostFree(c->h_clouds);
   for (int k = 0; k < 2; k++) if (c->h_frames[k]) (void)hipHostFree(c->h_frames[k]);
   map_scratch_free(c->scratch);
   for (int i = 0; i < 6; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  if (c->timeout_ev) (void)hipEventDestroy(c->timeout_ev);
   if (c->h_wl_count) (void)hipHostFree(c->h_wl_count);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->book) insert_book_destroy(c->book);
@@ -1375,6 +1360,22 @@ static int gate_rings(const flimo_ctx* c, double max_dist_plane) {
 // Waits until every granule of the pass `want` has arrived in mapped host memory (spinning: a pass lasts tens of microseconds).
 // Bounded by wall clock (FLIMO_DEFAULT_WAIT_MS, flimo_set_wait_timeout_ms): a launch that never publishes -- a device fault, a
 // hung kernel -- ends the call with an error instead of hanging the caller, which holds the filter's mutex.
+// A wait that ran out leaves its launches in flight: they still own the pass buffers (neighbour records, tickets, the chain's prior
+// in mapped memory).  An event behind them tells when they are gone; until then every new pass is refused with the same error.
+static int abandon_wait(flimo_ctx* c, const char* what, unsigned long long id) {
+  if (!c->timeout_ev) (void)hipEventCreateWithFlags(&c->timeout_ev, hipEventDisableTiming);
+  if (c->timeout_ev && hipEventRecord(c->timeout_ev, c->stream) == hipSuccess) c->timeout_pending = true;
+  c->prev.valid = 0;
+  return fail(c, FLIMO_ERR_TIMEOUT, "%s %llu did not publish its result within %d ms (kernels still running)", what, id, c->wait_timeout_ms);
+}
+static int check_abandoned(flimo_ctx* c) {
+  if (!c->timeout_pending) return FLIMO_OK;
+  const hipError_t q = hipEventQuery(c->timeout_ev);
+  if (q == hipErrorNotReady) return fail(c, FLIMO_ERR_TIMEOUT, "the launches of an earlier pass whose wait ran out are still running");
+  c->timeout_pending = false;
+  if (q != hipSuccess) return fail(c, FLIMO_ERR_HIP, "an abandoned pass failed: %s", hipGetErrorString(q));
+  return FLIMO_OK;
+}
 static bool tags_complete(const flimo_ctx* c, unsigned long long want) {
   const volatile unsigned long long* t0 = reinterpret_cast<const volatile unsigned long long*>(c->h_granules);
   if (t0[2 * FIT_LIVE + 1] != want || t0[2 * (FIT_LIVE + 1) + 1] != want) return false;
@@ -1390,6 +1391,7 @@ static int wait_tags(flimo_ctx* c, unsigned long long want) {
   unsigned long long spins = 0;
   double deadline = 0.0;
   auto now_s = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  if (c->wait_timeout_ms == 0) return abandon_wait(c, "pass", want);      // "do not wait at all" (the error path's test hook)
   for (;;) {
     if (t0[2 * (FIT_LIVE + 1) + 1] == want && tags_complete(c, want)) return FLIMO_OK;
     _mm_pause();
@@ -1399,8 +1401,7 @@ static int wait_tags(flimo_ctx* c, unsigned long long want) {
     if (t < deadline) continue;
     // out of time: what does the stream say?
     const hipError_t q = hipStreamQuery(c->stream);
-    if (q == hipErrorNotReady)
-      return fail(c, FLIMO_ERR_TIMEOUT, "pass %llu did not publish its result within %d ms (kernel still running)", want, c->wait_timeout_ms);
+    if (q == hipErrorNotReady) return abandon_wait(c, "pass", want);
     if (q != hipSuccess) return fail(c, FLIMO_ERR_HIP, "pass %llu failed: %s", want, hipGetErrorString(q));
     if (tags_complete(c, want)) return FLIMO_OK;          // arrived while we looked
     // the stream is idle and the result never arrived: a ticket was left behind by an aborted launch.  Re-arm and report.
@@ -1414,7 +1415,7 @@ static int wait_tags(flimo_ctx* c, unsigned long long want) {
 }
 
 extern "C" int flimo_set_wait_timeout_ms(flimo_ctx* c, int ms) {
-  if (!c || ms < 1) return FLIMO_ERR_INVALID;
+  if (!c || ms < 0) return FLIMO_ERR_INVALID;
   c->wait_timeout_ms = ms;
   return FLIMO_OK;
 }
@@ -1443,6 +1444,7 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   if (cfg->NUM_MATCH_POINTS < 3 || cfg->NUM_MATCH_POINTS > 8)
     return fail(c, FLIMO_ERR_UNSUPPORTED, "NUM_MATCH_POINTS must be in 3..8 (a plane needs 3 points; the neighbour records hold 8)");
   const bool general_k = cfg->NUM_MATCH_POINTS != 5 || c->force_general_k;
+  { const int rca = check_abandoned(c); if (rca) return rca; }
   for (int i = 0; i < 144; i++) HTH[i] = 0.0;
   for (int i = 0; i < 12; i++) HTh[i] = 0.0;
   *M = 0;
@@ -1748,6 +1750,238 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   c->last_P = P; c->last_mp = mp; c->last_n_all = n_all;
   c->recs_valid = want_recs && !fused_cap;      // the fused path leaves the records un-capped: a fetch re-materialises them
   c->dbg_valid = c->debug_recs;
+  return FLIMO_OK;
+}
+
+// ---- the whole iterated update enqueued at once (flimo_chain.h) ---------------------------------------------------------------
+// Layout of a pass inside the chain = the layout flimo_match_reduce gives the pass at the same position: one launch (k-NN + tail +
+// fit + reduction) when the last scan's pass at that position published few stragglers, else the k-NN launch followed by widening
+// + fit in one launch (or widening, then fit); a fine pre-pass before either when a crowded region is active.  Pass 0 gets its pose
+// constants as kernel arguments (the host knows x), later passes read them from the device filter.
+extern "C" int flimo_chain_stats(flimo_ctx* c, double out[5], int reset) {
+  if (!c || !out) return FLIMO_ERR_INVALID;
+  out[0] = c->chain_alg_ms; out[1] = (double)c->chain_alg_n; out[2] = (double)c->chains_run; out[3] = (double)c->chains_back;
+  out[4] = (double)c->chains_declined;
+  if (reset) { c->chain_alg_ms = 0; c->chain_alg_n = 0; c->chains_run = c->chains_back = c->chains_declined = 0; }
+  return FLIMO_OK;
+}
+
+extern "C" int flimo_update_chain(flimo_ctx* c, const flimo_match_cfg* cfg, flimo_chain_io* io) {
+  if (!c || !cfg || !io) return FLIMO_ERR_INVALID;
+  io->status = FLIMO_CHAIN_DECLINED; io->reason = 0; io->passes = 0; io->it_next = -1; io->t = 0;
+  auto decline = [&]() { c->chains_declined++; return FLIMO_OK; };
+  { const int rca = check_abandoned(c); if (rca) return rca; }
+  if (c->host_update) return decline();
+  if (cfg->NUM_MATCH_POINTS != 5 || c->force_general_k) return decline();
+  const int n_pass = io->max_iter + 1;
+  if (io->max_iter < 0 || n_pass > CH_MAX_PASSES) return decline();
+  if (c->debug_recs || c->timing > 1 || c->lanes_per_query != 2 || !c->tail || !c->fuse) return decline();
+  if (!c->grid_valid && c->map_n > 0) { int rc0 = rebuild_grid(c); if (rc0) return rc0; }
+  if (!c->grid_valid || c->map_n == 0) return decline();      // Mapper::match returns no matches: the host loop handles M = 0
+  size_t nq = c->scan_n;
+  if (cfg->MAX_NUM_PC2MATCH >= 0 && nq > (size_t)cfg->MAX_NUM_PC2MATCH) nq = (size_t)cfg->MAX_NUM_PC2MATCH;
+  if (nq == 0) return decline();
+  if (cfg->MAX_NUM_MATCHES >= 0 && (size_t)cfg->MAX_NUM_MATCHES < nq) return decline();      // caps need the records
+  (void)hipSetDevice(c->device);
+  { int rc = ensure_recs(c, nq); if (rc) return rc; }
+  MatchParams mp;
+  mp.max_dist_plane_d = cfg->MAX_DIST_PLANE;
+  mp.plane_threshold = (float)cfg->PLANE_THRESHOLD;
+  mp.estimate_extrinsics = cfg->estimate_extrinsics ? 1 : 0;
+  mp.n_queries = (int)nq;
+  mp.max_ring = gate_rings(c, cfg->MAX_DIST_PLANE);
+  if (mp.max_ring < 2 || mp.max_ring > 3) return decline();
+  c->last_nq = 0;
+  c->last_cfg = *cfg;
+  c->recs_valid = c->dbg_valid = false;
+  if (nq < c->sorted_n || (c->sorted_n < c->scan_n && nq > c->sorted_n)) {
+    { const int rcf = flush_deskew(c); if (rcf) return rcf; }
+    HIPCHK(c, sort_scan(c->stream, c->d_scan, nq, c->d_scan_sorted, c->scratch));
+    c->sorted_n = nq;
+    c->prev.valid = 0;
+  }
+  const int n_all = (int)c->sorted_n;
+  const bool after_fine = c->fine_valid && mp.max_ring >= 1;
+  const bool ride = c->deskew_pending && c->deskew_n == (size_t)n_all && !after_fine;
+  if (!ride) { const int rcf = flush_deskew(c); if (rcf) return rcf; }
+  const DeskewArgs* dkp = ride ? &c->deskew_args : nullptr;
+  c->deskew_pending = false;
+  if (c->timing == 1 && !c->chain_ev_made) {
+    for (int i = 0; i < CH_MAX_PASSES; i++) for (int k = 0; k < 6; k++) HIPCHK(c, hipEventCreate(&c->chain_ev[i][k]));
+    c->chain_ev_made = true;
+  }
+
+  // the prior, where the first algebra kernel reads it
+  PoseMats P0;
+  pose_from_x26(io->x26, P0);
+  ChainPrior& pr = *c->h_chain_prior;
+  memcpy(pr.x, io->x26, sizeof(pr.x));
+  memcpy(pr.P, io->P, sizeof(pr.P));
+  memcpy(pr.limit, io->limits, sizeof(pr.limit));
+  pr.R = io->R; pr.D = io->D; pr.max_iter = io->max_iter; pr.pad = 0;
+  memcpy(pr.RT0, P0.RT, sizeof(pr.RT0));
+  __atomic_thread_fence(__ATOMIC_RELEASE);
+
+  const unsigned long long tag = ++c->chain_tag;
+  const unsigned long long seq0 = c->pass_seq;
+  const bool ties_on = c->ties && c->gbook.active;
+  const ChainHead* head = reinterpret_cast<const ChainHead*>(c->d_chain);
+  const int tail_max = c->tail_max > 0 ? c->tail_max : std::max(1024, n_all / 64);
+  struct Plan { int pos; bool fused, combined, timed; };
+  Plan plan[CH_MAX_PASSES];
+  int pos = c->pass_in_scan;
+  bool prev_valid = c->prev.valid != 0;
+  c->prev.probe_min = c->probe_min;
+  for (int i = 0; i < n_pass; i++) {
+    const unsigned long long seq = seq0 + 1 + (unsigned long long)i;
+    const bool first_pass = !prev_valid;
+    pos = first_pass ? 0 : std::min(pos + 1, 3);
+    const bool tail_here = first_pass ? (c->tail_pass1 >= 0 ? c->tail_pass1 != 0 : c->stragglers_hist[0] <= tail_max)
+                                      : (c->stragglers_hist[pos] <= tail_max);
+    const bool fused = tail_here;
+    const bool combined = !fused && c->widen_fit;
+    const bool timed = c->timing == 1 && (c->timing_stride <= 1 || (seq % (unsigned long long)c->timing_stride) == 0);
+    plan[i] = Plan{pos, fused, combined, timed};
+    hipEvent_t* ev = timed ? c->chain_ev[i] : nullptr;
+    const ChainHead* ch = i == 0 ? nullptr : head;
+    PrevPass pv = c->prev;
+    pv.valid = prev_valid ? 1 : 0;            // (pass 0: the context's own bound, if any; later passes: RT comes from the device filter)
+    TieList tl{};
+    tl.count_next = c->d_tie_count + ((seq + 1) & 1);
+    if (ties_on) { tl.list = c->d_tie_list; tl.count = c->d_tie_count + (seq & 1); tl.cap = (unsigned)c->tie_cap; }
+    if (after_fine) {
+      launch_knn5_fine(c->stream, c->fine, c->d_scan_sorted, n_all, P0, c->d_nbr, pv, c->fine_qlo, c->fine_qhi, &tl, seq, ch);
+      c->fine_passes++;
+    }
+    const DeskewArgs* dk = i == 0 ? dkp : nullptr;
+    if (fused) {
+      launch_match_fused(c->stream, c->grid, c->d_scan_sorted, n_all, P0, mp, c->d_nbr, c->d_wl, c->d_wl_count, nullptr, pv, c->live_idx,
+                         c->d_fit2_partials, c->d_chain_gran, c->d_ticket, seq, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr, &tl,
+                         after_fine ? 1 : 0, dk, ch);
+    } else {
+      launch_knn5(c->stream, 2, c->grid, c->d_scan_sorted, n_all, P0, mp.max_ring, c->d_nbr, c->d_wl, c->d_wl_count, nullptr, pv, 0,
+                  ev ? ev[0] : nullptr, ev ? ev[1] : nullptr, nullptr, &tl, after_fine ? 1 : 0, seq, dk, ch);
+      if (combined) {
+        launch_widen_fit(c->stream, c->grid, c->d_scan_sorted, n_all, P0, mp, c->d_nbr, c->d_wl, c->d_wl_count, nullptr, c->live_idx,
+                         c->d_fit2_partials, c->d_chain_gran, c->d_ticket, seq, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr, &tl, &tl,
+                         c->d_wf_err, ch);
+      } else {
+        launch_widen(c->stream, c->grid, c->d_scan_sorted, P0, mp.max_ring, c->d_nbr, c->d_wl, c->d_wl_count, nullptr, nullptr, nullptr, &tl, ch);
+        launch_fit2(c->stream, c->grid, c->d_scan_sorted, n_all, c->d_nbr, P0, mp, c->live_idx, c->d_fit2_partials, c->d_chain_gran,
+                    c->d_ticket, c->d_wl_count, seq, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr, &tl, ch);
+      }
+    }
+    launch_ieskf(c->stream, c->d_chain, c->d_chain_gran, seq, i == 0 ? c->d_chain_prior : nullptr, c->d_chain_res,
+                 io->want_log ? c->d_chain_log : nullptr, tag, ev ? ev[4] : nullptr, ev ? ev[5] : nullptr);
+    prev_valid = c->prune;
+  }
+  HIPCHK(c, hipGetLastError());
+  c->chains_run++;
+
+  // ---- one wait: the head of the result (stored last), then every granule the status promises ----
+  const volatile unsigned long long* rt = reinterpret_cast<const volatile unsigned long long*>(c->h_chain_res);
+  auto tag_at = [&](int slot) { return rt[2 * slot + 1] == tag; };
+  auto val_at = [&](int slot) { return c->h_chain_res[2 * slot]; };
+  auto complete = [&]() {
+    if (!tag_at(CH_STATUS)) return false;
+    for (int k = 0; k < CH_P; k++) if (!tag_at(k)) return false;
+    if ((int)llround(val_at(CH_STATUS)) == 1)
+      for (int k = CH_P; k < CH_RES; k++) if (!tag_at(k)) return false;
+    return true;
+  };
+  {
+    unsigned long long spins = 0;
+    double deadline = 0.0;
+    auto now_s = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    // (whatever ends the wait early: the context's pass count stays consistent with the tie counters' parity only if every queued
+    //  pass is assumed to run; a chain that is abandoned or fails resets the pass buffers' bookkeeping instead)
+    if (c->wait_timeout_ms == 0) { c->pass_seq = seq0 + (unsigned long long)n_pass; return abandon_wait(c, "update chain", tag - 0x4000000000000000ull); }
+    for (;;) {
+      if (tag_at(CH_STATUS) && complete()) break;
+      _mm_pause();
+      if ((++spins & 0x3fffull) != 0) continue;
+      const double t = now_s();
+      if (deadline == 0.0) { deadline = t + 1e-3 * (double)c->wait_timeout_ms; continue; }
+      if (t < deadline) continue;
+      const hipError_t q = hipStreamQuery(c->stream);
+      c->prev.valid = 0;
+      if (q == hipErrorNotReady) { c->pass_seq = seq0 + (unsigned long long)n_pass; return abandon_wait(c, "update chain", tag - 0x4000000000000000ull); }
+      if (q != hipSuccess) return fail(c, FLIMO_ERR_HIP, "the update chain failed: %s", hipGetErrorString(q));
+      if (complete()) break;
+      (void)hipMemsetAsync(c->d_ticket, 0, (FIT_GROUPS + 1) * sizeof(unsigned int), c->stream);
+      (void)hipMemsetAsync(c->d_wl_count, 0, sizeof(int), c->stream);
+      (void)hipMemsetAsync(c->d_tie_count, 0, 2 * sizeof(unsigned int), c->stream);
+      (void)hipStreamSynchronize(c->stream);
+      return fail(c, FLIMO_ERR_HIP, "the update chain completed without publishing its result (reduction tickets re-armed)");
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  }
+  io->status = (int)llround(val_at(CH_STATUS));
+  io->reason = (int)llround(val_at(CH_BAIL));
+  io->passes = (int)llround(val_at(CH_PASSES));
+  io->it_next = (int)llround(val_at(CH_IT));
+  io->t = (int)llround(val_at(CH_T));
+  for (int k = 0; k < 26; k++) io->x26_out[k] = val_at(CH_X + k);
+  if (io->status == FLIMO_CHAIN_DONE) for (int k = 0; k < 529; k++) io->P_out[k] = val_at(CH_P + k);
+  // passes whose measurement ran: the completed iterations, and the one that was handed back
+  const int executed = std::min(n_pass, io->passes + (io->status == FLIMO_CHAIN_HANDED_BACK ? 1 : 0));
+  for (int i = 0; i < executed; i++) {
+    flimo_chain_pass& L = io->log[i];
+    L.M = (int)llround(val_at(CH_PASSINFO + 3 * i)); L.stragglers = (int)llround(val_at(CH_PASSINFO + 3 * i + 1));
+    L.ties = (int)llround(val_at(CH_PASSINFO + 3 * i + 2));
+    c->stragglers_hist[plan[i].pos] = L.stragglers;
+    c->last_stragglers = L.stragglers;
+    c->pass_in_scan = plan[i].pos;
+    if (plan[i].fused) c->fused_passes++;
+    if (io->want_log && i < io->passes) {
+      const volatile unsigned long long* lt = reinterpret_cast<const volatile unsigned long long*>(c->h_chain_log) + (size_t)i * CH_LOGN * 2;
+      const double* lv = c->h_chain_log + (size_t)i * CH_LOGN * 2;
+      unsigned long long spins = 0;
+      for (int k = 0; k < CH_LOGN; k++) {
+        while (lt[2 * k + 1] != tag) { _mm_pause(); if (++spins > 400000000ull) return fail(c, FLIMO_ERR_HIP, "the update chain's log did not arrive"); }
+      }
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+      for (int k = 0; k < 144; k++) L.HTH[k] = lv[2 * k];
+      for (int k = 0; k < 12; k++) L.HTh[k] = lv[2 * (144 + k)];
+      for (int k = 0; k < 23; k++) L.dx[k] = lv[2 * (156 + k)];
+      for (int k = 0; k < 26; k++) L.x_after[k] = lv[2 * (179 + k)];
+    }
+  }
+  if (io->status == FLIMO_CHAIN_HANDED_BACK) {
+    c->chains_back++;
+    if (io->reason == 4) { c->prev.valid = 0; return fail(c, FLIMO_ERR_HIP, "a pass of the update chain did not publish its sums"); }
+  }
+  // what the context knows about its last pass (fetches, the next pass's bound)
+  c->pass_seq = seq0 + (unsigned long long)executed;
+  double x_meas[26];
+  for (int k = 0; k < 26; k++) x_meas[k] = val_at(CH_XMEAS + k);
+  PoseMats Pl;
+  pose_from_x26(x_meas, Pl);
+  if (c->prune && executed > 0) { memcpy(c->prev.RT, Pl.RT, sizeof(c->prev.RT)); c->prev.valid = 1; }
+  c->last_nq = (int)nq;
+  c->last_P = Pl; c->last_mp = mp; c->last_n_all = n_all;
+  c->async_deskews = 0;
+  // timing (level 1): the launches' own begin / end stamps
+  for (int i = 0; i < executed; i++) {
+    if (!plan[i].timed) continue;
+    hipEvent_t* ev = c->chain_ev[i];
+    float ms = 0.f;
+    auto elapsed = [&](hipEvent_t a, hipEvent_t b) {
+      float m = 0.f;
+      if (hipEventElapsedTime(&m, a, b) != hipSuccess) { (void)hipEventSynchronize(b); (void)hipEventElapsedTime(&m, a, b); }
+      return m;
+    };
+    ms = elapsed(ev[0], ev[1]);
+    c->last_knn_ms = ms; c->tot_knn_ms += ms;
+    if (plan[i].fused) { c->split_fused_ms += ms; c->split_fused_n++; c->last_fit_ms = c->last_widen_ms = 0.f; }
+    else {
+      const float ms2 = elapsed(ev[2], ev[3]);
+      c->split_knn_ms += ms; c->split_fit_ms += ms2; c->split_sep_n++; c->tot_fit_ms += ms2;
+      c->last_fit_ms = ms2; c->last_widen_ms = 0.f;
+    }
+    if (i < io->passes) { c->chain_alg_ms += elapsed(ev[4], ev[5]); c->chain_alg_n++; }
+    c->tot_passes++; c->tot_queries += n_all;
+  }
   return FLIMO_OK;
 }
 

@@ -7,6 +7,7 @@ namespace flimo {
 struct FuseArgs;
 struct TieList;
 struct BookView;
+struct ChainHead;   // flimo_chain.h: a launch given one reads its pose constants from the device filter and leaves at once when the chain has ended
 // The deskew of a scan's raw points riding on the first pass's k-NN launch (instead of a dispatch of its own): arguments of
 // launch_deskew, `on` = 1 when they are valid
 struct DeskewArgs {
@@ -19,15 +20,17 @@ struct DeskewArgs {
 void launch_knn5(hipStream_t st, int lanes_per_query, const GridView& G, const float4* scan_sorted, int n,
                  const PoseMats& P, int max_ring, void* nbr, int* wl, int* wl_count, unsigned long long* cand,
                  const PrevPass& prev, int tail, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, const struct FuseArgs* fuse = nullptr,
-                 const TieList* ties = nullptr, int after_fine = 0, unsigned long long seq = 0ull, const DeskewArgs* deskew = nullptr);
+                 const TieList* ties = nullptr, int after_fine = 0, unsigned long long seq = 0ull, const DeskewArgs* deskew = nullptr,
+                 const ChainHead* chain = nullptr);
 // fine pre-pass over the second-level grid of crowded regions (see flimo_map.hip); launches that follow it pass after_fine = 1
 void launch_knn5_fine(hipStream_t st, const GridView& Gf, const float4* scan_sorted, int n, const PoseMats& P, void* nbr,
-                      const PrevPass& prev, const int qlo[3], const int qhi[3], const TieList* ties, unsigned long long seq);
+                      const PrevPass& prev, const int qlo[3], const int qhi[3], const TieList* ties, unsigned long long seq,
+                      const ChainHead* chain = nullptr);
 // tail != 0: queries that need more than the 3x3x3 block are finished inside the k-NN launch itself (gates of at most 3
 // rings; launch_knn5 clears the flag otherwise) and launch_widen has nothing to do
 void launch_widen(hipStream_t st, const GridView& G, const float4* scan_sorted, const PoseMats& P, int max_ring, void* nbr,
                   int* wl, int* wl_count, unsigned long long* cand, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr,
-                  const TieList* ties = nullptr);
+                  const TieList* ties = nullptr, const ChainHead* chain = nullptr);
 int fit_blocks(int n);
 void set_xcd_stripe(int stripe);   // block -> scan chunk mapping of the per-pass kernels (see xcd_chunk)
 // the fit kernel reduces in FIT_GROUPS groups; slot g of its output = 256 sums + the pass number (FIT_SLOT doubles).
@@ -47,12 +50,13 @@ constexpr int FIT_LIVE_PAD = 96;
 int fit2_blocks(int n);
 void launch_fit2(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const void* nbr, const PoseMats& P,
                  const MatchParams& mp, const unsigned char* live_idx, double* partials, void* out_granules, unsigned int* ticket,
-                 int* wl_count, unsigned long long seq, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, const TieList* ties = nullptr);
+                 int* wl_count, unsigned long long seq, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, const TieList* ties = nullptr,
+                 const ChainHead* chain = nullptr);
 // widening + fit of a separate-dispatch pass in one launch (max_ring 2..3): see widen_fit_kernel
 void launch_widen_fit(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const PoseMats& P, const MatchParams& mp,
                       void* nbr, int* wl, int* wl_count, unsigned long long* cand, const unsigned char* live_idx, double* partials,
                       void* out_granules, unsigned int* ticket, unsigned long long seq, hipEvent_t e0, hipEvent_t e1,
-                      const TieList* tl_widen, const TieList* tl_fit, int* err);
+                      const TieList* tl_widen, const TieList* tl_fit, int* err, const ChainHead* chain = nullptr);
 // The whole measurement pass in ONE launch (k-NN fast path + in-kernel tail + fit + reduction + publish; two lanes per query, gates of
 // 2..3 rings): partials needs fused_blocks(n) * FIT_LIVE_PAD doubles; results arrive as launch_fit2's granules.
 int fused_blocks(int n);
@@ -60,7 +64,7 @@ void launch_match_fused(hipStream_t st, const GridView& G, const float4* scan_so
                         void* nbr, int* wl, int* wl_count, unsigned long long* cand, const PrevPass& prev,
                         const unsigned char* live_idx, double* partials, void* out_granules, unsigned int* ticket,
                         unsigned long long seq, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, const TieList* ties = nullptr,
-                        int after_fine = 0, const DeskewArgs* deskew = nullptr);
+                        int after_fine = 0, const DeskewArgs* deskew = nullptr, const ChainHead* chain = nullptr);
 // The reference's choice among exactly tied distances (first met by Octree::knn's recursion): BookView = the device copy of the
 // octree (insert book), TieList = the queries a pass flagged.  launch_tie rewrites their neighbour records; launch_knn_tie does the
 // same for the output of launch_knn.

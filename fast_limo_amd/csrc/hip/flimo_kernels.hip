@@ -25,6 +25,7 @@
 #include "flimo_types.h"
 #include "flimo_math.h"
 #include "flimo_kernels.h"
+#include "flimo_chain.h"
 
 #pragma clang fp contract(off)
 
@@ -832,12 +833,14 @@ FLIMO_DEV void fit_row(const GridView& G, const PoseMats& P, const MatchParams& 
 #else
 #define KNN_WPE
 #endif
+// The pass's body, shared by the two kernels below: a host-driven pass gets its pose constants by value (kernel arguments), a
+// chained pass (flimo_chain.h) reads them from the device filter's head -- same code, the constants come from another address.
 template <int L, int SLOTS, bool FUSE, bool FINE = false>
-__global__ __launch_bounds__(256) KNN_WPE void knn5_kernel(GridView G, const float4* __restrict__ scan_sorted, int n,
-                                                   PoseMats P, int max_ring, NbrRec* __restrict__ nbr,
-                                                   int* __restrict__ wl, int* __restrict__ wl_count,
-                                                   unsigned long long* __restrict__ cand_total, PrevPass prev, int tail,
-                                                   FuseArgs fa) {
+__device__ __forceinline__ void knn5_pass(const GridView& G, const float4* __restrict__ scan_sorted, int n,
+                                          const PoseMats& P, int max_ring, NbrRec* __restrict__ nbr,
+                                          int* __restrict__ wl, int* __restrict__ wl_count,
+                                          unsigned long long* __restrict__ cand_total, const float* __restrict__ prev_RT, int prev_valid,
+                                          unsigned prev_probe_min, int tail, const FuseArgs& fa) {
   constexpr int QPB = 256 / L;          // queries per block; SLOTS = candidate loads in flight per lane
   const TieList tl = fa.tl;
   __shared__ WaveLds s_w[4];
@@ -874,7 +877,7 @@ __global__ __launch_bounds__(256) KNN_WPE void knn5_kernel(GridView G, const flo
   float b2 = INFINITY;                               // bound, squared, in cell units
   bool resolved = false;                             // settled by the fine pre-pass of this pass: nothing to search
   int4 pa_res = make_int4(0, 0, 0, 0), pb_res = make_int4(0, 0, 0, 0);
-  if ((prev.valid || (!FINE && fa.fine_mode == 1)) && in_range) {
+  if ((prev_valid || (!FINE && fa.fine_mode == 1)) && in_range) {
     const int4 pb = reinterpret_cast<const int4*>(&nbr[p])[1];       // idx[4], flag, d5 bits, "d5 valid"
     // (a record settled by the fine pre-pass of THIS pass carries flag 4 and the pass number in the upper bits of w: a stale or
     //  never-written record cannot be mistaken for one)
@@ -882,9 +885,9 @@ __global__ __launch_bounds__(256) KNN_WPE void knn5_kernel(GridView G, const flo
       resolved = true;
       pb_res = pb;
       pa_res = reinterpret_cast<const int4*>(&nbr[p])[0];
-    } else if (prev.valid && pb.y == 1 && (pb.w & 1)) {
+    } else if (prev_valid && pb.y == 1 && (pb.w & 1)) {
       float ox_, oy_, oz_;
-      xform4(prev.RT, sp.x, sp.y, sp.z, ox_, oy_, oz_);
+      xform4(prev_RT, sp.x, sp.y, sp.z, ox_, oy_, oz_);
       const float ex = gx - ox_, ey = gy - oy_, ez = gz - oz_;
       const float moved = fl_sqrt(sum3(ex * ex, ey * ey, ez * ez));
       const float rc = ((fl_sqrt(__int_as_float(pb.z)) + moved) * (1.f + 1.0e-5f) + 1.0e-6f) * G.inv_cell;
@@ -933,7 +936,7 @@ __global__ __launch_bounds__(256) KNN_WPE void knn5_kernel(GridView G, const flo
       const int maxdim = max(G.nx, max(G.ny, G.nz));
       const float margin = 1.0e-3f + 4.0e-7f * (float)maxdim;
       int c0 = (cx - 1) * G.xs, c1 = (cx + 2) * G.xs;          // first column, one past the last
-      if (prev.valid && b2 < 1.0e6f) {
+      if (prev_valid && b2 < 1.0e6f) {
         const float rb_ = fl_sqrt(b2) + margin;                 // reach along x in cell units (b2 is already inflated)
         const float fxs = (float)G.xs;
         c0 = max(c0, (int)floorf((fx - rb_) * fxs));
@@ -947,7 +950,7 @@ __global__ __launch_bounds__(256) KNN_WPE void knn5_kernel(GridView G, const flo
       // map leave cells with tens to hundreds of points) first walks that cell alone; its 5th distance there is an upper bound
       // of the true one, and the other 26 cells are then walked only as far as that ball reaches (rows and end cells it cannot
       // reach are dropped, exactly as with the bound of a previous pass).
-      const bool probe_on = L == 2 && !prev.valid && prev.probe_min != 0u;          // wave-uniform
+      const bool probe_on = L == 2 && !prev_valid && prev_probe_min != 0u;          // wave-uniform
       U3 rbl[3], rbh[3];
       {
         const uint32_t iL = (uint32_t)c0 * plane + yz, iH = (uint32_t)c1 * plane + yz;
@@ -969,7 +972,7 @@ __global__ __launch_bounds__(256) KNN_WPE void knn5_kernel(GridView G, const flo
 #pragma unroll
         for (int k = 0; k < 3; k++) {
           const int t = 3 * dz + k;
-          const bool row = !prev.valid || (yd2[k] + zd2[dz] <= b2);
+          const bool row = !prev_valid || (yd2[k] + zd2[dz] <= b2);
           dl[t] = sl[k] - off[t];
           off[t + 1] = off[t] + (row ? sh[k] - sl[k] : 0u);
         }
@@ -977,7 +980,7 @@ __global__ __launch_bounds__(256) KNN_WPE void knn5_kernel(GridView G, const flo
       // probing pays when the block is heavy (crowded region: every lane of the wave probes, so nobody waits for a neighbour's
       // full walk) and the own cell can give a bound at all.  Only those queries fetch the two inner x planes of the row table:
       // they hold the own cell's range and let the second walk be clipped to cells.
-      const bool heavy_block = probe_on && off[9] >= prev.probe_min && cx >= 0 && cx < G.nx;
+      const bool heavy_block = probe_on && off[9] >= prev_probe_min && cx >= 0 && cx < G.nx;
       const uint32_t centre = yz + py + 1u;                         // (z, y) = the query's own row within a padded x plane
       uint32_t own_a = rbl[1].b, own_b = rbh[1].b;                  // the own cell's range (two 4-byte loads, heavy blocks only)
       if (heavy_block) {
@@ -1215,6 +1218,26 @@ __global__ __launch_bounds__(256) KNN_WPE void knn5_kernel(GridView G, const flo
   }
 }
 
+template <int L, int SLOTS, bool FUSE, bool FINE = false>
+__global__ __launch_bounds__(256) KNN_WPE void knn5_kernel(GridView G, const float4* __restrict__ scan_sorted, int n,
+                                                   PoseMats P, int max_ring, NbrRec* __restrict__ nbr,
+                                                   int* __restrict__ wl, int* __restrict__ wl_count,
+                                                   unsigned long long* __restrict__ cand_total, PrevPass prev, int tail,
+                                                   FuseArgs fa) {
+  knn5_pass<L, SLOTS, FUSE, FINE>(G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand_total, prev.RT, prev.valid, prev.probe_min, tail, fa);
+}
+// The same pass inside a chain: pose constants and the bound's reference pose from the device filter (written by the algebra
+// kernel queued before this launch); nothing to do once the chain has ended.
+template <int L, int SLOTS, bool FUSE, bool FINE = false>
+__global__ __launch_bounds__(256) KNN_WPE void knn5_chain_kernel(GridView G, const float4* __restrict__ scan_sorted, int n,
+                                                   const ChainHead* __restrict__ H, int max_ring, NbrRec* __restrict__ nbr,
+                                                   int* __restrict__ wl, int* __restrict__ wl_count,
+                                                   unsigned long long* __restrict__ cand_total, int prev_valid, unsigned probe_min, int tail,
+                                                   FuseArgs fa) {
+  if (H->status != 0) return;
+  knn5_pass<L, SLOTS, FUSE, FINE>(G, scan_sorted, n, H->pose, max_ring, nbr, wl, wl_count, cand_total, H->prev_RT, prev_valid, probe_min, tail, fa);
+}
+
 // Widening for the worklist (rare): ONE WAVE per query.  The (2r+1)^2 <= 49 rows of the ring-r block
 // are owned by one lane each (range bounds fetched in a single round trip), a wave prefix sum
 // flattens their candidates, every lane scans a strided share (four loads in flight) and the best 5 are
@@ -1370,9 +1393,11 @@ __device__ __forceinline__ void widen_body(const GridView& G, int max_ring, NbrR
 __global__ __launch_bounds__(256) void widen_kernel(GridView G, const float4* __restrict__ scan_sorted, PoseMats P,
                                                     int max_ring, NbrRec* __restrict__ nbr, const int* __restrict__ wl,
                                                     const int* __restrict__ wl_count,
-                                                    unsigned long long* __restrict__ cand_total, int first_ring, TieList tl) {
+                                                    unsigned long long* __restrict__ cand_total, int first_ring, TieList tl,
+                                                    const ChainHead* __restrict__ H) {
   __shared__ uint32_t s_off[4][65];
   __shared__ uint32_t s_lo[4][64];
+  if (H && H->status != 0) return;                   // a chained pass after the chain has ended
   widen_body<false>(G, max_ring, nbr, wl, wl_count, cand_total, first_ring, tl, (int)blockIdx.x, (int)gridDim.x, s_off, s_lo);
 }
 
@@ -1716,11 +1741,13 @@ __device__ __forceinline__ void fit_reduce_publish(const float (&v)[16], bool ow
     TRACE(1, 6);
     if (threadIdx.x < FIT_LIVE) {
       // one 16-byte store per sum: {value, pass number}; the host accepts a slot when all of its tags carry this pass
+      // (s_nop 1 after every such store: the two wait states of the VMEM-store-data hazard on gfx940+, which the compiler cannot
+      //  insert for inline assembly -- the next VALU write of g's registers could otherwise reach the store)
       v2d_t g;
       g.x = sa0[threadIdx.x] + sa1[threadIdx.x];
       g.y = __longlong_as_double((long long)seq);
       double2* o = out_granules + (size_t)group * FIT_LIVE_PAD + threadIdx.x;
-      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(o), "v"(g) : "memory");
+      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(o), "v"(g) : "memory");
     }
     if (threadIdx.x == 0) {
       __hip_atomic_store(ticket + group, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next pass
@@ -1732,10 +1759,10 @@ __device__ __forceinline__ void fit_reduce_publish(const float (&v)[16], bool ow
         g.x = (double)__hip_atomic_load(wl_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         g.y = __longlong_as_double((long long)seq);
         double2* o = out_granules + FIT_LIVE;
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(o), "v"(g) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(o), "v"(g) : "memory");
         g.x = tl.count ? (double)__hip_atomic_load(tl.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
         o = out_granules + FIT_LIVE + 1;
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(o), "v"(g) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(o), "v"(g) : "memory");
         __hip_atomic_store(ticket + FIT_GROUPS, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(wl_count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tl.count_next) __hip_atomic_store(tl.count_next, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1750,11 +1777,11 @@ __device__ __forceinline__ void fit_reduce_publish(const float (&v)[16], bool ow
 // lanes-per-query settings): neighbour records -> rows (fit_row) -> fit_reduce_publish.  PPW points per wave.
 // ------------------------------------------------------------------------------------------
 template <int PPW>
-__global__ __launch_bounds__(256) void fit2_kernel(GridView G, const float4* __restrict__ scan_sorted, int n,
-                                                   const NbrRec* __restrict__ nbr, PoseMats P, MatchParams mp, FitIdx idx,
-                                                   double* __restrict__ partials, double2* __restrict__ out_granules,
-                                                   unsigned int* __restrict__ ticket, int* __restrict__ wl_count,
-                                                   unsigned long long seq, TieList tl) {
+__device__ __forceinline__ void fit2_pass(const GridView& G, const float4* __restrict__ scan_sorted, int n,
+                                          const NbrRec* __restrict__ nbr, const PoseMats& P, const MatchParams& mp, const FitIdx& idx,
+                                          double* __restrict__ partials, double2* __restrict__ out_granules,
+                                          unsigned int* __restrict__ ticket, int* __restrict__ wl_count,
+                                          unsigned long long seq, const TieList& tl) {
   __shared__ float s_rec[4][16 * 65];       // per wave: [col][row] with stride 65
   __shared__ double s_acc[4][256];
   __shared__ unsigned int s_last;
@@ -1780,6 +1807,24 @@ __global__ __launch_bounds__(256) void fit2_kernel(GridView G, const float4* __r
                           out_granules, ticket, wl_count, seq, tl);
 }
 
+template <int PPW>
+__global__ __launch_bounds__(256) void fit2_kernel(GridView G, const float4* __restrict__ scan_sorted, int n,
+                                                   const NbrRec* __restrict__ nbr, PoseMats P, MatchParams mp, FitIdx idx,
+                                                   double* __restrict__ partials, double2* __restrict__ out_granules,
+                                                   unsigned int* __restrict__ ticket, int* __restrict__ wl_count,
+                                                   unsigned long long seq, TieList tl) {
+  fit2_pass<PPW>(G, scan_sorted, n, nbr, P, mp, idx, partials, out_granules, ticket, wl_count, seq, tl);
+}
+template <int PPW>
+__global__ __launch_bounds__(256) void fit2_chain_kernel(GridView G, const float4* __restrict__ scan_sorted, int n,
+                                                   const NbrRec* __restrict__ nbr, const ChainHead* __restrict__ H, MatchParams mp, FitIdx idx,
+                                                   double* __restrict__ partials, double2* __restrict__ out_granules,
+                                                   unsigned int* __restrict__ ticket, int* __restrict__ wl_count,
+                                                   unsigned long long seq, TieList tl) {
+  if (H->status != 0) return;
+  fit2_pass<PPW>(G, scan_sorted, n, nbr, H->pose, mp, idx, partials, out_granules, ticket, wl_count, seq, tl);
+}
+
 // Widening and fit of a pass that runs in separate dispatches (first pass of a poor prior) in ONE launch: the first `wblocks`
 // blocks are the widening's (one wave per worklist entry), the rest the fit's (64 rows per wave).  A fit block does the rows
 // the k-NN dispatch settled at once -- nine in ten -- and waits for the rows that are still on the worklist (record flag 2) until
@@ -1787,12 +1832,12 @@ __global__ __launch_bounds__(256) void fit2_kernel(GridView G, const float4* __r
 // its workgroups in order, so wherever a fit block runs the widening blocks of every XCD are ahead of the fit blocks there: the
 // waves it waits for are running or done.  The wait is bounded by the wall clock all the same (then the row counts as "no
 // match" and *err is set: the host reports it).  Row order, partial slots and the reduction are the fit dispatch's own.
-__global__ __launch_bounds__(256) void widen_fit_kernel(GridView G, const float4* __restrict__ scan_sorted, int n, PoseMats P, int max_ring,
-                                                        NbrRec* __restrict__ nbr, const int* __restrict__ wl, int* __restrict__ wl_count,
-                                                        unsigned long long* __restrict__ cand_total, int wblocks, TieList tl_widen,
-                                                        MatchParams mp, FitIdx idx, double* __restrict__ partials,
-                                                        double2* __restrict__ out_granules, unsigned int* __restrict__ ticket,
-                                                        unsigned long long seq, TieList tl_fit, int* __restrict__ err) {
+__device__ __forceinline__ void widen_fit_pass(const GridView& G, const float4* __restrict__ scan_sorted, int n, const PoseMats& P, int max_ring,
+                                               NbrRec* __restrict__ nbr, const int* __restrict__ wl, int* __restrict__ wl_count,
+                                               unsigned long long* __restrict__ cand_total, int wblocks, const TieList& tl_widen,
+                                               const MatchParams& mp, const FitIdx& idx, double* __restrict__ partials,
+                                               double2* __restrict__ out_granules, unsigned int* __restrict__ ticket,
+                                               unsigned long long seq, const TieList& tl_fit, int* __restrict__ err) {
   __shared__ float s_rec[4][16 * 65];
   __shared__ double s_acc[4][256];
   __shared__ unsigned int s_last;
@@ -1842,6 +1887,24 @@ __global__ __launch_bounds__(256) void widen_fit_kernel(GridView G, const float4
   }
   fit_reduce_publish<64>(v, true, lane, s_rec[wave], s_acc[0], s_acc[1], s_acc[2], s_acc[3], &s_last, idx, partials,
                          out_granules, ticket, wl_count, seq, tl_fit, fb, fnb);
+}
+
+__global__ __launch_bounds__(256) void widen_fit_kernel(GridView G, const float4* __restrict__ scan_sorted, int n, PoseMats P, int max_ring,
+                                                        NbrRec* __restrict__ nbr, const int* __restrict__ wl, int* __restrict__ wl_count,
+                                                        unsigned long long* __restrict__ cand_total, int wblocks, TieList tl_widen,
+                                                        MatchParams mp, FitIdx idx, double* __restrict__ partials,
+                                                        double2* __restrict__ out_granules, unsigned int* __restrict__ ticket,
+                                                        unsigned long long seq, TieList tl_fit, int* __restrict__ err) {
+  widen_fit_pass(G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand_total, wblocks, tl_widen, mp, idx, partials, out_granules, ticket, seq, tl_fit, err);
+}
+__global__ __launch_bounds__(256) void widen_fit_chain_kernel(GridView G, const float4* __restrict__ scan_sorted, int n, const ChainHead* __restrict__ H,
+                                                        int max_ring, NbrRec* __restrict__ nbr, const int* __restrict__ wl, int* __restrict__ wl_count,
+                                                        unsigned long long* __restrict__ cand_total, int wblocks, TieList tl_widen,
+                                                        MatchParams mp, FitIdx idx, double* __restrict__ partials,
+                                                        double2* __restrict__ out_granules, unsigned int* __restrict__ ticket,
+                                                        unsigned long long seq, TieList tl_fit, int* __restrict__ err) {
+  if (H->status != 0) return;
+  widen_fit_pass(G, scan_sorted, n, H->pose, max_ring, nbr, wl, wl_count, cand_total, wblocks, tl_widen, mp, idx, partials, out_granules, ticket, seq, tl_fit, err);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2384,12 +2447,15 @@ template <int L>
 static void launch_knn5_L(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const PoseMats& P,
                           int max_ring, void* nbr, int* wl, int* wl_count, unsigned long long* cand, const PrevPass& prev,
                           int tail, hipEvent_t e0, hipEvent_t e1, const FuseArgs* fuse, const TieList* tlp, int after_fine = 0,
-                          unsigned long long seq = 0ull, const DeskewArgs* dk = nullptr) {
+                          unsigned long long seq = 0ull, const DeskewArgs* dk = nullptr, const ChainHead* chain = nullptr) {
   const int qpb = 256 / L;
   const int blocks = round_up8((n + qpb - 1) / qpb);
   constexpr int slots = (L <= 4 ? 8 : 4);          // candidate loads in flight per lane
   if constexpr (L == 2) {
     if (fuse) {      // the whole pass in one launch (blocks is a multiple of 8 = FIT_GROUPS)
+      if (chain)
+        hipExtLaunchKernelGGL((knn5_chain_kernel<2, 8, true>), dim3(blocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, chain, max_ring, (NbrRec*)nbr, wl, wl_count, cand, prev.valid, prev.probe_min, 1, *fuse);
+      else
       hipExtLaunchKernelGGL((knn5_kernel<2, 8, true>), dim3(blocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand, prev, 1, *fuse);
       return;
     }
@@ -2401,15 +2467,22 @@ static void launch_knn5_L(hipStream_t st, const GridView& G, const float4* scan_
   if (dk) nofuse.dk = *dk;
   // e0 / e1 (optional) are attached to the dispatch itself: they read the kernel's own begin / end
   // timestamps, without the extra barrier packets of hipEventRecord
+  if constexpr (L == 2) {
+    if (chain) {
+      hipExtLaunchKernelGGL((knn5_chain_kernel<2, 8, false>), dim3(blocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, chain, max_ring, (NbrRec*)nbr, wl, wl_count, cand, prev.valid, prev.probe_min, tail, nofuse);
+      return;
+    }
+  }
   hipExtLaunchKernelGGL((knn5_kernel<L, slots, false>), dim3(blocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand, prev, tail, nofuse);
 }
 
 void launch_knn5(hipStream_t st, int lanes_per_query, const GridView& G, const float4* scan_sorted, int n,
                  const PoseMats& P, int max_ring, void* nbr, int* wl, int* wl_count, unsigned long long* cand,
                  const PrevPass& prev, int tail, hipEvent_t e0, hipEvent_t e1, const FuseArgs* fuse, const TieList* tlp, int after_fine,
-                 unsigned long long seq, const DeskewArgs* dk) {
+                 unsigned long long seq, const DeskewArgs* dk, const ChainHead* chain) {
   if (n <= 0) return;
   if (max_ring < 2 || max_ring > TAIL_MAX_RING) tail = 0;
+  if (chain) { launch_knn5_L<2>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine, seq, dk, chain); return; }   // (two lanes per query only)
   switch (lanes_per_query) {
     case 1: launch_knn5_L<1>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine, seq, dk); break;
     case 2: launch_knn5_L<2>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine, seq, dk); break;
@@ -2421,14 +2494,14 @@ void launch_knn5(hipStream_t st, int lanes_per_query, const GridView& G, const f
 }
 
 void launch_widen(hipStream_t st, const GridView& G, const float4* scan_sorted, const PoseMats& P, int max_ring, void* nbr,
-                  int* wl, int* wl_count, unsigned long long* cand, hipEvent_t e0, hipEvent_t e1, const TieList* tlp) {
+                  int* wl, int* wl_count, unsigned long long* cand, hipEvent_t e0, hipEvent_t e1, const TieList* tlp, const ChainHead* chain) {
   TieList tl{};
   if (tlp) tl = *tlp;
   if (max_ring <= 1) return;
   // 2048 blocks = 8 waves per SIMD: the wave-per-query search is a latency chain (the worklist has 8192 slots of prefetch slack);
   // entries without a hint go straight to the gate's ring (measured at 6.6 k pending queries: 19.3 -> 16.3 us)
   if (max_ring <= 3)
-    hipExtLaunchKernelGGL(widen_kernel, dim3(2048), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand, max_ring, tl);
+    hipExtLaunchKernelGGL(widen_kernel, dim3(2048), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand, max_ring, tl, chain);
   else
     hipLaunchKernelGGL(widen_general_kernel, dim3(256), dim3(256), 0, st, G, scan_sorted, P, max_ring, (NbrRec*)nbr, wl, wl_count, tl);
 }
@@ -2453,19 +2526,23 @@ int fit2_blocks(int n) { const int b = (n + 255) / 256; return (b + FIT_GROUPS -
 
 void launch_fit2(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const void* nbr, const PoseMats& P,
                  const MatchParams& mp, const unsigned char* live_idx, double* partials, void* out_granules, unsigned int* ticket,
-                 int* wl_count, unsigned long long seq, hipEvent_t e0, hipEvent_t e1, const TieList* tlp) {
+                 int* wl_count, unsigned long long seq, hipEvent_t e0, hipEvent_t e1, const TieList* tlp, const ChainHead* chain) {
   if (n <= 0) return;
   TieList tl{};
   if (tlp) tl = *tlp;
   FitIdx idx;
   for (int i = 0; i < FIT_LIVE_PAD; i++) idx.raw[i] = i < FIT_LIVE ? live_idx[i] : 0;
+  if (chain) {
+    hipExtLaunchKernelGGL((fit2_chain_kernel<64>), dim3(fit2_blocks(n)), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, (const NbrRec*)nbr, chain, mp, idx, partials, (double2*)out_granules, ticket, wl_count, seq, tl);
+    return;
+  }
   hipExtLaunchKernelGGL((fit2_kernel<64>), dim3(fit2_blocks(n)), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, idx, partials, (double2*)out_granules, ticket, wl_count, seq, tl);
 }
 
 void launch_widen_fit(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const PoseMats& P, const MatchParams& mp,
                       void* nbr, int* wl, int* wl_count, unsigned long long* cand, const unsigned char* live_idx, double* partials,
                       void* out_granules, unsigned int* ticket, unsigned long long seq, hipEvent_t e0, hipEvent_t e1,
-                      const TieList* tl_widen, const TieList* tl_fit, int* err) {
+                      const TieList* tl_widen, const TieList* tl_fit, int* err, const ChainHead* chain) {
   if (n <= 0) return;
   TieList tw{}, tf{};
   if (tl_widen) tw = *tl_widen;
@@ -2473,6 +2550,11 @@ void launch_widen_fit(hipStream_t st, const GridView& G, const float4* scan_sort
   FitIdx idx;
   for (int i = 0; i < FIT_LIVE_PAD; i++) idx.raw[i] = i < FIT_LIVE ? live_idx[i] : 0;
   const int wblocks = 2048, fblocks = fit2_blocks(n);
+  if (chain) {
+    hipExtLaunchKernelGGL(widen_fit_chain_kernel, dim3(wblocks + fblocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, chain, mp.max_ring, (NbrRec*)nbr,
+                          wl, wl_count, cand, wblocks, tw, mp, idx, partials, (double2*)out_granules, ticket, seq, tf, err);
+    return;
+  }
   hipExtLaunchKernelGGL(widen_fit_kernel, dim3(wblocks + fblocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, P, mp.max_ring, (NbrRec*)nbr,
                         wl, wl_count, cand, wblocks, tw, mp, idx, partials, (double2*)out_granules, ticket, seq, tf, err);
 }
@@ -2481,7 +2563,7 @@ int fused_blocks(int n) { return round_up8((n + 127) / 128); }
 // fine pre-pass over the second-level grid (crowded regions): settles the queries whose five are proven inside their fine 3x3x3
 // block; their records get flag 4, which the main launch of the same pass (fine_mode 1) takes over
 void launch_knn5_fine(hipStream_t st, const GridView& Gf, const float4* scan_sorted, int n, const PoseMats& P, void* nbr,
-                      const PrevPass& prev, const int qlo[3], const int qhi[3], const TieList* tlp, unsigned long long seq) {
+                      const PrevPass& prev, const int qlo[3], const int qhi[3], const TieList* tlp, unsigned long long seq, const ChainHead* chain) {
   if (n <= 0) return;
   FuseArgs fa{};
   fa.fine_mode = 2;
@@ -2489,13 +2571,19 @@ void launch_knn5_fine(hipStream_t st, const GridView& Gf, const float4* scan_sor
   for (int a = 0; a < 3; a++) { fa.qlo[a] = qlo[a]; fa.qhi[a] = qhi[a]; }
   if (tlp) fa.tl = *tlp;
   PrevPass pv = prev;
+  if (chain) {
+    hipLaunchKernelGGL((knn5_chain_kernel<2, 8, false, true>), dim3(round_up8((n + 127) / 128)), dim3(256), 0, st, Gf, scan_sorted, n, chain, 1,
+                       (NbrRec*)nbr, (int*)nullptr, (int*)nullptr, (unsigned long long*)nullptr, pv.valid, pv.probe_min, 0, fa);
+    return;
+  }
   hipLaunchKernelGGL((knn5_kernel<2, 8, false, true>), dim3(round_up8((n + 127) / 128)), dim3(256), 0, st, Gf, scan_sorted, n, P, 1,
                      (NbrRec*)nbr, (int*)nullptr, (int*)nullptr, (unsigned long long*)nullptr, pv, 0, fa);
 }
 void launch_match_fused(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const PoseMats& P, const MatchParams& mp,
                         void* nbr, int* wl, int* wl_count, unsigned long long* cand, const PrevPass& prev,
                         const unsigned char* live_idx, double* partials, void* out_granules, unsigned int* ticket,
-                        unsigned long long seq, hipEvent_t e0, hipEvent_t e1, const TieList* tlp, int after_fine, const DeskewArgs* dk) {
+                        unsigned long long seq, hipEvent_t e0, hipEvent_t e1, const TieList* tlp, int after_fine, const DeskewArgs* dk,
+                        const ChainHead* chain) {
   if (n <= 0) return;
   FuseArgs fa{};
   if (dk) fa.dk = *dk;
@@ -2505,7 +2593,7 @@ void launch_match_fused(hipStream_t st, const GridView& G, const float4* scan_so
   fa.mp = mp;
   for (int i = 0; i < FIT_LIVE_PAD; i++) fa.idx.raw[i] = i < FIT_LIVE ? live_idx[i] : 0;
   fa.partials = partials; fa.granules = (double2*)out_granules; fa.ticket = ticket; fa.seq = seq;
-  launch_knn5_L<2>(st, G, scan_sorted, n, P, mp.max_ring, nbr, wl, wl_count, cand, prev, 1, e0, e1, &fa, nullptr);
+  launch_knn5_L<2>(st, G, scan_sorted, n, P, mp.max_ring, nbr, wl, wl_count, cand, prev, 1, e0, e1, &fa, nullptr, 0, 0ull, nullptr, chain);
 }
 
 void launch_reduce_final(hipStream_t st, const double* partials, int nparts, double* out256) {

@@ -517,7 +517,52 @@ void Localizer::init_iKFoM() {                                     // Localizer.
                                               const_cast<std::function<void()>*>(&in_flight));
     prof_[2] += now_s() - tm0;
     prof_[3] += 1.0;
-    if (rc != FLIMO_OK) { std::cout << "FAST_LIMO::match_reduce failed: " << flimo_last_error(c) << "\n"; out.M = 0; }
+    if (rc != FLIMO_OK) {
+      // the reference's plug-in cannot fail (Mapper.cpp:59-86); a GPU pass can (timeout, HIP error): the update is abandoned
+      std::cout << "FAST_LIMO::match_reduce failed: " << flimo_last_error(c) << "\n";
+      out.M = 0;
+      ikfom_->failed = true;
+    }
+  };
+  // the whole update enqueued at once (flimo_update_chain): esekfom.hpp:1620-1823 without a host round trip per iteration
+  ikfom_->device_chain = [this](const double x26[26], const Esekf::Cov& P, const double* limits, double R, double D, int max_iter,
+                                flimo_host::ChainResult& out) {
+    out.status = 0;
+    flimo_ctx* c = map_->ctx();
+    if (!c) return;
+    if (!chain_io_) chain_io_.reset(new flimo_chain_io);
+    flimo_chain_io& io = *chain_io_;
+    std::memcpy(io.x26, x26, sizeof(io.x26));
+    std::memcpy(io.P, &P.a[0][0], sizeof(io.P));
+    std::memcpy(io.limits, limits, sizeof(io.limits));
+    io.R = R; io.D = D; io.max_iter = max_iter;
+    io.want_log = ikfom_->keep_log ? 1 : 0;
+    const Config::iKFoM::Mapping& m = config.ikfom.mapping;
+    flimo_match_cfg mc{m.NUM_MATCH_POINTS, m.MAX_NUM_MATCHES, m.MAX_NUM_PC2MATCH, m.MAX_DIST_PLANE, m.PLANE_THRESHOLD,
+                       config.ikfom.estimate_extrinsics ? 1 : 0};
+    const double tm0 = now_s();
+    const int rc = flimo_update_chain(c, &mc, &io);
+    prof_[2] += now_s() - tm0;
+    if (rc != FLIMO_OK) {
+      std::cout << "FAST_LIMO::update_chain failed: " << flimo_last_error(c) << "\n";
+      ikfom_->failed = true;
+      return;
+    }
+    out.status = io.status; out.passes = io.passes; out.it_next = io.it_next; out.t = io.t;
+    if (io.status == FLIMO_CHAIN_DECLINED) return;
+    prof_[3] += (double)io.passes;
+    std::memcpy(out.x, io.x26_out, sizeof(out.x));
+    if (io.status == FLIMO_CHAIN_DONE) std::memcpy(out.P, io.P_out, sizeof(io.P_out));
+    if (ikfom_->keep_log)
+      for (int i = 0; i < io.passes; i++) {
+        flimo_host::PassLog lg;
+        lg.M = io.log[i].M;
+        std::memcpy(lg.HTH, io.log[i].HTH, sizeof(lg.HTH));
+        std::memcpy(lg.HTh, io.log[i].HTh, sizeof(lg.HTh));
+        std::memcpy(lg.dx, io.log[i].dx, sizeof(lg.dx));
+        std::memcpy(lg.x_after, io.log[i].x_after, sizeof(lg.x_after));
+        ikfom_->log.push_back(lg);
+      }
   };
   ikfom_->h_dense = [this](flimo_host::DenseMeas& dm) {
     flimo_ctx* c = map_->ctx();
@@ -1450,6 +1495,16 @@ void Localizer::materializeClouds(pcl::PointCloud<PointType>::Ptr& raw_pc) {
   const size_t n_dev = mat_n_dev_;
   const float* body = mat_body4_;
   const float* world = mat_world4_;
+  // Without the voxel grid the device's kept set must BE the host's: a different count (a filter decided differently at a boundary:
+  // atan2f of the FoV filter on another libm, a NaN rule) would pair every later point with the wrong device point -- and in the
+  // arrival-order layout index the pinned buffers beyond their n_dev valid records.  Refused, loudly, instead.
+  if (!dev_voxel_ && n_dev != m) {
+    std::cout << "FAST_LIMO::WARNING: device and host input filters kept different sets (" << n_dev << " vs " << m
+              << " points): no clouds for this sweep\n";
+    pc2match = fast_limo::make_shared<pcl::PointCloud<PointType>>();
+    final_scan = fast_limo::make_shared<pcl::PointCloud<PointType>>();
+    return;
+  }
   // (the storage of the last sweep's clouds is taken over when the caller has let go of them: no fresh pages to fault in)
   if (pc2match == mat_pm_) pc2match.reset();
   if (final_scan == mat_fs_) final_scan.reset();
@@ -1477,6 +1532,7 @@ void Localizer::materializeClouds(pcl::PointCloud<PointType>::Ptr& raw_pc) {
     for (size_t k = k0; k < k1; k++) {
       const size_t src = order[k];
       const size_t dev = ordered ? k : src;
+      if (src >= m || dev >= n_dev) continue;                       // (cannot happen after the count check above; never index past the buffers)
       if (k + 24 < k1) {                                           // the sweep's time order is a scattered walk over three arrays
         const size_t nsrc = order[k + 24];
         __builtin_prefetch(&in[nsrc]);
@@ -1519,7 +1575,10 @@ int Localizer::registerResident(const double x26_prior[26], const double* P_prio
   const double t0 = now_s();
   int rc = flimo_deskew_resident(c, rs_frames_.data(), rs_frames_.size(), rs_l2b_, x26_prior);
   const double t1 = now_s();
-  if (rc == FLIMO_OK && flimo_scan_size(c) > 1) ikfom_->update_iterated_dyn_share_modified(0.001, 5.0);
+  if (rc == FLIMO_OK && flimo_scan_size(c) > 1) {
+    ikfom_->update_iterated_dyn_share_modified(0.001, 5.0);
+    if (ikfom_->failed) rc = FLIMO_ERR_HIP;                        // a pass failed: state and covariance are the prior's again
+  }
   prof_[0] += t1 - t0;
   prof_[1] += now_s() - t1;
   mtx_ikfom.unlock();
@@ -1589,6 +1648,17 @@ void Localizer::finishUpdate(bool ok, double t0, double t1, double t2) {
   if (ok && c && flimo_scan_size(c) > 1) {
     mtx_ikfom.lock();
     ikfom_->update_iterated_dyn_share_modified(0.001 /*LiDAR noise*/, 5.0 /*degeneracy threshold*/);   // :333
+    if (ikfom_->failed) {
+      // A pass of the update failed on the GPU (the reference's Mapper::match cannot, Mapper.cpp:59-86).  The filter is back at the
+      // propagated state and covariance; the scan is not inserted into the map at an unmeasured pose; the caller sees status -4 and
+      // the reference's own line for a scan that produced no update (Localizer.cpp:379-380).  The next sweep registers normally.
+      mtx_ikfom.unlock();
+      std::cout << "-------------- FAST_LIMO::NULL ITERATION --------------\n";
+      last_status_ = -4;
+      stage_t_[0] = t1 - t0; stage_t_[1] = t2 - t1; stage_t_[2] = now_s() - t2; stage_t_[3] = 0.0;
+      prev_scan_stamp = scan_stamp;
+      return;
+    }
     map_->matches.clear();
     State corrected(ikfom_->get_x());
     if (config.calibrate_gyro) corrected.b.gyro = state.b.gyro;

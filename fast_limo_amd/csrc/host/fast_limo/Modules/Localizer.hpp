@@ -97,6 +97,7 @@ class fast_limo::Localizer {
   Mapper* map_;
   bool own_map_;
   flimo_host::Esekf* ikfom_;
+  std::unique_ptr<flimo_chain_io> chain_io_;          // arguments / results of flimo_update_chain (20 kB: kept, not on the stack)
   std::mutex mtx_ikfom, mtx_prop;
   std::condition_variable cv_prop_stamp;
   State state, last_state;

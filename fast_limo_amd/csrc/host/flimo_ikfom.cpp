@@ -64,6 +64,47 @@ bool inverse_lu(int n, const double* A, double* Ainv) {
   return true;
 }
 
+// Gauss-Jordan inverse with partial pivoting, without row exchanges (a pivot row is marked used instead): in step k every OTHER
+// row r gets  row_r -= (A[r][k] / A[p][k]) * row_p  on the columns right of k and on the accumulated right-hand side.  The
+// per-element operations of a step are independent of each other, so a parallel evaluation (the device filter's 12 x 12 solve,
+// csrc/hip/flimo_ieskf.h: ik_gj12_wave) gives the same bits; the chain of n dependent steps is half of LU + two substitutions.
+// Pivot: the largest |A[r][k]| among the rows not yet used, the lowest r among equals.
+bool inverse_gj(int n, const double* Ain, double* Ainv) {
+  constexpr int NMAX = 32;
+  if (n > NMAX) return false;
+  double A[NMAX * NMAX], X[NMAX * NMAX], dk[NMAX];
+  int prow[NMAX];
+  bool used[NMAX];
+  for (int i = 0; i < n * n; i++) { A[i] = Ain[i]; X[i] = 0.0; }
+  for (int i = 0; i < n; i++) { X[i * n + i] = 1.0; used[i] = false; }
+  for (int k = 0; k < n; k++) {
+    int p = -1;
+    double best = -1.0;
+    for (int r = 0; r < n; r++) {
+      if (used[r]) continue;
+      const double v = std::fabs(A[r * n + k]);
+      if (v > best) { best = v; p = r; }
+    }
+    if (p < 0 || !(best > 0.0)) return false;
+    const double d = A[p * n + k];
+    const double* ap = &A[p * n];
+    const double* xp = &X[p * n];
+    for (int r = 0; r < n; r++) {
+      if (r == p) continue;
+      const double f = A[r * n + k] / d;
+      double* ar = &A[r * n];
+      double* xr = &X[r * n];
+      for (int j = k + 1; j < n; j++) ar[j] = ar[j] - f * ap[j];
+      for (int c = 0; c < n; c++) xr[c] = xr[c] - f * xp[c];
+    }
+    used[p] = true; prow[k] = p; dk[k] = d;
+  }
+  // row prow[k] of the reduced left side is dk[k] e_k^T: row k of the inverse = X[prow[k]] / dk[k]
+  for (int k = 0; k < n; k++)
+    for (int c = 0; c < n; c++) Ainv[k * n + c] = X[prow[k] * n + c] / dk[k];
+  return true;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Eigen::EigenSolver<Matrix<double,6,6>> as the reference calls it at esekfom.hpp:1736-1738.  Which ROW of the eigenvector matrix
 // the degeneracy projector zeroes is decided by the order (and the product it forms by the signs) in which Eigen hands out the
@@ -713,8 +754,30 @@ void Esekf::update_iterated_dyn_share_modified(double R, double D) {
   double dx_new[kDof];
   ReducedMeas meas;
   static const int so3_idx[2] = {3, 6};
+  failed = false;
 
-  for (int it = -1; it < maximum_iter_; it++) {
+  // The whole loop on the measurement side, when it offers that: every iteration below (same arithmetic, flimo_ieskf.hip) enqueued
+  // at once.  It may hand the loop back at any iteration: the rare branches stay here.
+  int it0 = -1;
+  if (device_chain) {
+    ChainResult r;
+    double x26[26];
+    x_.to_flat(x26);
+    device_chain(x26, P_, limit_, R, D, maximum_iter_, r);
+    if (failed) return;                                        // (x_, P_ untouched: still the propagated values)
+    if (r.status == 1) {
+      x_.from_flat(r.x);
+      std::memcpy(&P_.a[0][0], r.P, sizeof(double) * kDof * kDof);
+      return;
+    }
+    if (r.status == 2) {
+      x_.from_flat(r.x);
+      it0 = r.it_next;
+      t = r.t;
+    }
+  }
+
+  for (int it = it0; it < maximum_iter_; it++) {
     // The part of the iteration that does not depend on the measurement (:1652-1697: x boxminus x_propagated, P through the
     // manifold Jacobians) runs while the pass is in flight on the GPU when the plug-in offers that; the values are the same.
     double dx[kDof];
@@ -748,6 +811,7 @@ void Esekf::update_iterated_dyn_share_modified(double R, double D) {
     };
     if (h_reduced_overlap) h_reduced_overlap(x_, meas, pre);    // esekfom.hpp:1637
     else h_reduced(x_, meas);
+    if (failed) { x_ = x_prop; P_ = P_prop; return; }          // the pass did not happen: nothing to update with
     if (!pre_done) pre();
     const int M = meas.M;
 
@@ -795,7 +859,7 @@ void Esekf::update_iterated_dyn_share_modified(double R, double D) {
           for (int k = 0; k < 12; k++) { const double hk = HTH(i, k); for (int j = 0; j < 12; j++) acc[j] += hk * PR[k][j]; }
           for (int j = 0; j < 12; j++) T(i, j) = acc[j] + (i == j ? 1.0 : 0.0);
         }
-        inverse<12>(T, S);
+        if (!inverse_gj(12, &T.a[0][0], &S.a[0][0])) inverse<12>(T, S);      // (same steps as the device filter's solve)
         double W[kDof][12];
         for (int i = 0; i < n; i++) {
           double acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};

@@ -1,0 +1,121 @@
+"""GPU parity: the whole iterated update enqueued at once (flimo_update_chain: pass -> one-block algebra kernel -> pass ...,
+flimo_chain.h / flimo_ieskf.hip) against the host loop over single passes (flimo_match_reduce + flimo_host::Esekf, the layout of
+rounds 1-3, kept behind FLIMO_HOST_UPDATE=1) and against the golden per-pass vectors.  Reference: esekf::
+update_iterated_dyn_share_modified, IKFoM_toolkit/esekfom/esekfom.hpp:1620-1823."""
+import os
+
+import numpy as np
+import pytest
+
+from common import CAPS, cfg1_scene, drive_two_scans, pose_delta
+from fast_limo_amd import synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg1_golden.npz")
+
+
+def _localizer(host_update, **kw):
+    """A Localizer whose context reads FLIMO_HOST_UPDATE at creation."""
+    from fast_limo_amd import api
+    old = os.environ.get("FLIMO_HOST_UPDATE")
+    os.environ["FLIMO_HOST_UPDATE"] = "1" if host_update else "0"
+    try:
+        L = api.Localizer(api.default_cfg(**CAPS, **kw))
+    finally:
+        if old is None:
+            del os.environ["FLIMO_HOST_UPDATE"]
+        else:
+            os.environ["FLIMO_HOST_UPDATE"] = old
+    return L
+
+
+def test_chain_equals_the_host_loop_pass_by_pass(built):
+    """Same scene through the chained update and through the host loop: every pass's M, sums, step and state, the final state and
+    covariance.  The two run the same arithmetic in the same order; what differs is libm (sin / cos / atan of doubles)."""
+    mp, scan5, imu = cfg1_scene()
+    D = _localizer(False); H = _localizer(True)
+    for L in (D, H):
+        L.set_flags(add_to_map=False, keep_log=True)
+        assert drive_two_scans(L, mp, scan5, imu) == [1, 0]
+    cs = D.hip.chain_stats()
+    assert cs["chains"] >= 1 and cs["handed_back"] == 0, cs
+    assert H.hip.chain_stats()["chains"] == 0
+    pd, ph = D.passes(), H.passes()
+    assert len(pd) == len(ph) >= 2
+    assert [p["M"] for p in pd] == [p["M"] for p in ph]
+    for a, b in zip(pd, ph):
+        np.testing.assert_allclose(a["HTH"], b["HTH"], rtol=1e-12, atol=1e-9)
+        np.testing.assert_allclose(a["HTh"], b["HTh"], rtol=1e-12, atol=1e-9)
+        np.testing.assert_allclose(a["dx"], b["dx"], rtol=0, atol=1e-13)
+        np.testing.assert_allclose(a["x_after"], b["x_after"], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(D.get_x(), H.get_x(), rtol=0, atol=1e-13)
+    # (P = L - K_x P cancels from 1 to 1e-6: the last bits of the libm calls show up at 1e-11 absolute in its small entries)
+    np.testing.assert_allclose(D.get_P(), H.get_P(), rtol=1e-9, atol=1e-10)
+    # and the golden vectors of the same scene
+    g = np.load(GOLD)
+    assert [p["M"] for p in pd] == list(g["M"])
+    for p, HTH, dx in zip(pd, g["HTH"], g["dx"]):
+        np.testing.assert_allclose(p["HTH"], HTH, rtol=1e-11, atol=1e-8)
+        np.testing.assert_allclose(p["dx"], dx, rtol=0, atol=1e-9)
+    D.close(); H.close()
+
+
+def test_chain_is_bit_reproducible_and_counts_its_passes(built):
+    mp, scan5, imu = cfg1_scene(n_map=200000, n_scan=16384, L=40.0)
+    xs = []
+    for _ in range(2):
+        D = _localizer(False)
+        D.set_flags(add_to_map=False, keep_log=True)
+        assert drive_two_scans(D, mp, scan5, imu) == [1, 0]
+        n0 = D.hip.pass_count()
+        xs.append((D.get_x().copy(), D.get_P().copy(), len(D.passes())))
+        assert n0 == len(D.passes())        # the context's pass count = passes whose measurement ran
+        D.close()
+    assert xs[0][2] == xs[1][2]
+    np.testing.assert_array_equal(xs[0][0], xs[1][0])
+    np.testing.assert_array_equal(xs[0][1], xs[1][1])
+
+
+def test_chain_hands_back_what_it_does_not_run(built, oracle):
+    """M < 23 (a scan with a handful of usable points) and a degenerate corridor: the device stops at that iteration and the host
+    filter finishes the update; the result equals the host loop's."""
+    mp = synth.box_world_map(30000, 15.0, 3)
+    imu = synth.stationary_imu(0.0, 0.35)
+    scan = synth.box_world_scan_random(2048, 15.0, 4)
+    few = scan.copy()
+    few[12:, :3] += 500.0                       # all but 12 points far off the map: M < 23
+    res = []
+    for host in (False, True):
+        L = _localizer(host)
+        L.set_flags(add_to_map=False, keep_log=True)
+        assert drive_two_scans(L, mp, scan, imu, second_scan=few) == [1, 0]
+        res.append((L.get_x().copy(), L.get_P().copy(), [p["M"] for p in L.passes()], L.hip.chain_stats()))
+        L.close()
+    (xd, Pd, Md, sd), (xh, Ph, Mh, sh) = res
+    assert sd["chains"] >= 1 and sd["handed_back"] >= 1, sd
+    assert Md == Mh and max(Md) < 23
+    np.testing.assert_allclose(xd, xh, rtol=0, atol=1e-13)
+    np.testing.assert_allclose(Pd, Ph, rtol=1e-9, atol=1e-10)
+
+
+def test_raw_chain_entry_point_declines_what_needs_records(built):
+    """C ABI directly: caps that bind need the per-point records -> FLIMO_CHAIN_DECLINED and nothing is changed."""
+    from fast_limo_amd import _lib
+    mp, scan5, _ = cfg1_scene()
+    h = _lib.HipCtx()
+    h.map_add(np.ascontiguousarray(mp[:, :3]))
+    h.scan_set(np.ascontiguousarray(scan5[:, :3]))
+    x = np.zeros(26); x[6] = 1.0; x[10] = 1.0; x[25] = -9.809
+    P = np.eye(23) * 1e-2
+    lim = np.full(23, 1e-3)
+    n0 = h.pass_count()
+    r = h.update_chain(_lib.default_match_cfg(MAX_NUM_MATCHES=100, MAX_NUM_PC2MATCH=10**7), x, P, lim)
+    assert r["status"] == 0 and h.pass_count() == n0
+    r = h.update_chain(_lib.default_match_cfg(MAX_NUM_MATCHES=10**7, MAX_NUM_PC2MATCH=10**7), x, P, lim, max_iter=3)
+    assert r["status"] == 1 and 1 <= r["passes"] <= 4 and h.pass_count() == n0 + r["passes"]
+    assert all(p["M"] > 1000 for p in r["log"])
+    # the same registration pass by pass through flimo_match_reduce: the first pass's sums are identical
+    HTH, HTh, M = h.match_reduce(x, _lib.default_match_cfg(MAX_NUM_MATCHES=10**7, MAX_NUM_PC2MATCH=10**7))
+    assert M == r["log"][0]["M"]
+    np.testing.assert_array_equal(HTH, r["log"][0]["HTH"])
+    h.close()
