@@ -53,7 +53,8 @@ class ChainIO(C.Structure):
     _fields_ = [("x26", C.c_double * 26), ("P", C.c_double * 529), ("limits", C.c_double * 23), ("R", C.c_double), ("D", C.c_double),
                 ("max_iter", C.c_int), ("want_log", C.c_int),
                 ("status", C.c_int), ("reason", C.c_int), ("passes", C.c_int), ("it_next", C.c_int), ("t", C.c_int),
-                ("x26_out", C.c_double * 26), ("P_out", C.c_double * 529), ("log", ChainPass * CHAIN_MAX_PASSES)]
+                ("x26_out", C.c_double * 26), ("meas_valid", C.c_int), ("meas_M", C.c_int), ("meas_HTH", C.c_double * 144),
+                ("meas_HTh", C.c_double * 12), ("log", ChainPass * CHAIN_MAX_PASSES)]
 
 
 MATCH_REC_DTYPE = np.dtype([
@@ -363,20 +364,22 @@ class HipCtx:
         return dict(fused_ms=o[0], fused_n=int(o[1]), knn_ms=o[2], widen_ms=o[3], fit_ms=o[4], separate_n=int(o[5]))
 
     def update_chain(self, cfg: "MatchCfg", x26, P, limits, R=0.001, D=5.0, max_iter=3, want_log=True):
-        """The whole iterated update of the resident scan enqueued at once (flimo_update_chain).  Returns a dict: status (0 declined,
-        1 done, 2 handed back), reason, passes, it_next, t, x (26), P (23 x 23, status 1) and the per-pass log."""
+        """The iterations of the update of the resident scan enqueued at once (flimo_update_chain).  Returns a dict: status (0 declined,
+        2 handed back), reason (1 M < 23, 2 ties, 3 degenerate, 5 the iteration that ends the loop), passes, it_next, t, x (26), the
+        handed-back iteration's sums (meas: M, HTH, HTh or None) and the per-pass log."""
         io = ChainIO()
         io.x26[:] = list(np.asarray(x26, dtype=np.float64))
         io.P[:] = list(np.asarray(P, dtype=np.float64).reshape(-1))
         io.limits[:] = list(np.asarray(limits, dtype=np.float64))
         io.R, io.D, io.max_iter, io.want_log = float(R), float(D), int(max_iter), int(bool(want_log))
         self._chk(self._L.flimo_update_chain(self._h, C.byref(cfg), C.byref(io)))
-        n_log = min(CHAIN_MAX_PASSES, io.passes + (1 if io.status == 2 else 0))
+        n_log = min(CHAIN_MAX_PASSES, io.passes + (1 if io.status == 2 else 0))   # + the handed-back iteration's counts
         log = [dict(M=io.log[i].M, stragglers=io.log[i].stragglers, ties=io.log[i].ties,
                     HTH=np.array(io.log[i].HTH).reshape(12, 12), HTh=np.array(io.log[i].HTh), dx=np.array(io.log[i].dx),
                     x_after=np.array(io.log[i].x_after)) for i in range(n_log)]
+        meas = dict(M=io.meas_M, HTH=np.array(io.meas_HTH).reshape(12, 12), HTh=np.array(io.meas_HTh)) if io.meas_valid else None
         return dict(status=io.status, reason=io.reason, passes=io.passes, it_next=io.it_next, t=io.t, x=np.array(io.x26_out),
-                    P=np.array(io.P_out).reshape(23, 23), log=log)
+                    meas=meas, log=log)
 
     def chain_stats(self, reset=False):
         o = np.zeros(5)

@@ -21,6 +21,7 @@
 #include "flimo_math.h"
 #include "flimo_pose.h"
 #include "flimo_chain.h"
+#include "flimo_ieskf.h"
 #include "flimo_insert.h"
 #include "flimo_gbook.h"
 
@@ -205,6 +206,8 @@ struct flimo_ctx {
   double* h_chain_log = nullptr;         // mapped: CH_MAX_PASSES x CH_LOGN log granules
   void* d_chain_log = nullptr;
   unsigned long long chain_tag = 0x4000000000000000ull;   // tag of the last chain (own number space)
+  bool chain_inline = true;              // FLIMO_CHAIN_INLINE=0: the measurement-dependent half of an iteration as a launch of its own behind the pass (A/B)
+  bool combined_err_check = true;
   bool host_update = false;              // FLIMO_HOST_UPDATE=1: flimo_update_chain always declines (the host loop runs the update; A/B)
   hipEvent_t chain_ev[CH_MAX_PASSES][6]; // per pass: [0,1] first launch, [2,3] second launch, [4,5] algebra kernel (lazy)
   bool chain_ev_made = false;
@@ -281,6 +284,8 @@ static int ensure_dev(flimo_ctx* c, T*& p, size_t& cap, size_t need, bool keep, 
 //   FLIMO_WIDEN_FIT=0             widening and fit of a separate-dispatch pass as two launches (default: one, widen_fit_kernel)
 //   FLIMO_HOST_UPDATE=1           the iterated update runs as a host loop over single passes (default: the whole update is enqueued at
 //                                 once, flimo_update_chain)
+//   FLIMO_CHAIN_INLINE=0          chained update: the filter's measurement-dependent half as a launch of its own behind each pass
+//                                 (default: inside the pass's reducing launch, run by the workgroup that completes it)
 //   FLIMO_PROF_PASS / FLIMO_PROF_INSERT   host-side timing prints (stderr)
 // (csrc/host: FLIMO_REFERENCE_SOLVE=1 literal two-inverse gain, FLIMO_SYNC_INSERT=1 map inserts on the caller's thread,
 //  FLIMO_PROF_DESKEW / FLIMO_PROF_CLOUDS timing prints; bench.py: FLIMO_BENCH_*.)
@@ -308,6 +313,7 @@ static void load_dev_switches(flimo_ctx* c) {
   if (env_int("FLIMO_LAZY_DESKEW", v)) c->lazy_deskew = v != 0;
   if (env_int("FLIMO_WIDEN_FIT", v)) c->widen_fit = v != 0;
   if (env_int("FLIMO_HOST_UPDATE", v)) c->host_update = v != 0;
+  if (env_int("FLIMO_CHAIN_INLINE", v)) c->chain_inline = v != 0;
 }
 
 // ---- context ----------------------------------------------------------------------------------
@@ -335,8 +341,8 @@ extern "C" int flimo_ctx_create(int device, flimo_ctx** out) {
             hipHostGetDevicePointer((void**)&c->d_out256_host, c->h_out256, 0) == hipSuccess &&
             hipHostMalloc((void**)&c->h_granules, FIT_GROUPS * FIT_LIVE_PAD * 2 * sizeof(double), hipHostMallocMapped) == hipSuccess &&
             hipHostGetDevicePointer((void**)&c->d_granules_host, c->h_granules, 0) == hipSuccess &&
-            hipMalloc(&c->d_ticket, (FIT_GROUPS + 1) * sizeof(unsigned int)) == hipSuccess &&      // one per group + one launch-wide
-            hipMemset(c->d_ticket, 0, (FIT_GROUPS + 1) * sizeof(unsigned int)) == hipSuccess &&
+            hipMalloc(&c->d_ticket, (FIT_GROUPS + 2) * sizeof(unsigned int)) == hipSuccess &&      // one per group + one launch-wide + the chained passes' third
+            hipMemset(c->d_ticket, 0, (FIT_GROUPS + 2) * sizeof(unsigned int)) == hipSuccess &&
             hipMalloc(&c->d_cand, sizeof(unsigned long long)) == hipSuccess &&
             hipMalloc(&c->d_tie_count, 2 * sizeof(unsigned int)) == hipSuccess &&
             hipMemset(c->d_tie_count, 0, 2 * sizeof(unsigned int)) == hipSuccess &&
@@ -1405,7 +1411,7 @@ static int wait_tags(flimo_ctx* c, unsigned long long want) {
     if (q != hipSuccess) return fail(c, FLIMO_ERR_HIP, "pass %llu failed: %s", want, hipGetErrorString(q));
     if (tags_complete(c, want)) return FLIMO_OK;          // arrived while we looked
     // the stream is idle and the result never arrived: a ticket was left behind by an aborted launch.  Re-arm and report.
-    (void)hipMemsetAsync(c->d_ticket, 0, (FIT_GROUPS + 1) * sizeof(unsigned int), c->stream);
+    (void)hipMemsetAsync(c->d_ticket, 0, (FIT_GROUPS + 2) * sizeof(unsigned int), c->stream);
     (void)hipMemsetAsync(c->d_wl_count, 0, sizeof(int), c->stream);
     (void)hipMemsetAsync(c->d_tie_count, 0, 2 * sizeof(unsigned int), c->stream);
     (void)hipStreamSynchronize(c->stream);
@@ -1768,7 +1774,7 @@ extern "C" int flimo_chain_stats(flimo_ctx* c, double out[5], int reset) {
 
 extern "C" int flimo_update_chain(flimo_ctx* c, const flimo_match_cfg* cfg, flimo_chain_io* io) {
   if (!c || !cfg || !io) return FLIMO_ERR_INVALID;
-  io->status = FLIMO_CHAIN_DECLINED; io->reason = 0; io->passes = 0; io->it_next = -1; io->t = 0;
+  io->status = FLIMO_CHAIN_DECLINED; io->reason = 0; io->passes = 0; io->it_next = -1; io->t = 0; io->meas_valid = 0; io->meas_M = 0;
   auto decline = [&]() { c->chains_declined++; return FLIMO_OK; };
   { const int rca = check_abandoned(c); if (rca) return rca; }
   if (c->host_update) return decline();
@@ -1811,7 +1817,8 @@ extern "C" int flimo_update_chain(flimo_ctx* c, const flimo_match_cfg* cfg, flim
     c->chain_ev_made = true;
   }
 
-  // the prior, where the first algebra kernel reads it
+  // the prior, where the first pass's extra workgroup reads it; the measurement-independent half of iteration -1 with it
+  // (x == x_prop: no transcendental function is evaluated, host and device agree bit for bit)
   PoseMats P0;
   pose_from_x26(io->x26, P0);
   ChainPrior& pr = *c->h_chain_prior;
@@ -1819,7 +1826,7 @@ extern "C" int flimo_update_chain(flimo_ctx* c, const flimo_match_cfg* cfg, flim
   memcpy(pr.P, io->P, sizeof(pr.P));
   memcpy(pr.limit, io->limits, sizeof(pr.limit));
   pr.R = io->R; pr.D = io->D; pr.max_iter = io->max_iter; pr.pad = 0;
-  memcpy(pr.RT0, P0.RT, sizeof(pr.RT0));
+  ik_pre_serial(io->x26, io->x26, io->P, io->R, pr.dxn, pr.PR);
   __atomic_thread_fence(__ATOMIC_RELEASE);
 
   const unsigned long long tag = ++c->chain_tag;
@@ -1832,6 +1839,14 @@ extern "C" int flimo_update_chain(flimo_ctx* c, const flimo_match_cfg* cfg, flim
   int pos = c->pass_in_scan;
   bool prev_valid = c->prev.valid != 0;
   c->prev.probe_min = c->probe_min;
+  ChainCtl ctl{};
+  ctl.S = c->d_chain;
+  ctl.gran = reinterpret_cast<double2*>(c->d_chain_gran);
+  ctl.res = reinterpret_cast<double2*>(c->d_chain_res);
+  ctl.log = io->want_log ? reinterpret_cast<double2*>(c->d_chain_log) : nullptr;
+  ctl.tag = tag;
+  ctl.ticket3 = c->d_ticket + FIT_GROUPS + 1;
+  ctl.inline_alg = c->chain_inline ? 1 : 0;
   for (int i = 0; i < n_pass; i++) {
     const unsigned long long seq = seq0 + 1 + (unsigned long long)i;
     const bool first_pass = !prev_valid;
@@ -1844,6 +1859,7 @@ extern "C" int flimo_update_chain(flimo_ctx* c, const flimo_match_cfg* cfg, flim
     plan[i] = Plan{pos, fused, combined, timed};
     hipEvent_t* ev = timed ? c->chain_ev[i] : nullptr;
     const ChainHead* ch = i == 0 ? nullptr : head;
+    ctl.prior = i == 0 ? c->d_chain_prior : nullptr;
     PrevPass pv = c->prev;
     pv.valid = prev_valid ? 1 : 0;            // (pass 0: the context's own bound, if any; later passes: RT comes from the device filter)
     TieList tl{};
@@ -1857,45 +1873,42 @@ extern "C" int flimo_update_chain(flimo_ctx* c, const flimo_match_cfg* cfg, flim
     if (fused) {
       launch_match_fused(c->stream, c->grid, c->d_scan_sorted, n_all, P0, mp, c->d_nbr, c->d_wl, c->d_wl_count, nullptr, pv, c->live_idx,
                          c->d_fit2_partials, c->d_chain_gran, c->d_ticket, seq, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr, &tl,
-                         after_fine ? 1 : 0, dk, ch);
+                         after_fine ? 1 : 0, dk, ch, &ctl);
     } else {
       launch_knn5(c->stream, 2, c->grid, c->d_scan_sorted, n_all, P0, mp.max_ring, c->d_nbr, c->d_wl, c->d_wl_count, nullptr, pv, 0,
                   ev ? ev[0] : nullptr, ev ? ev[1] : nullptr, nullptr, &tl, after_fine ? 1 : 0, seq, dk, ch);
       if (combined) {
         launch_widen_fit(c->stream, c->grid, c->d_scan_sorted, n_all, P0, mp, c->d_nbr, c->d_wl, c->d_wl_count, nullptr, c->live_idx,
                          c->d_fit2_partials, c->d_chain_gran, c->d_ticket, seq, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr, &tl, &tl,
-                         c->d_wf_err, ch);
+                         c->d_wf_err, ch, &ctl);
       } else {
         launch_widen(c->stream, c->grid, c->d_scan_sorted, P0, mp.max_ring, c->d_nbr, c->d_wl, c->d_wl_count, nullptr, nullptr, nullptr, &tl, ch);
         launch_fit2(c->stream, c->grid, c->d_scan_sorted, n_all, c->d_nbr, P0, mp, c->live_idx, c->d_fit2_partials, c->d_chain_gran,
-                    c->d_ticket, c->d_wl_count, seq, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr, &tl, ch);
+                    c->d_ticket, c->d_wl_count, seq, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr, &tl, ch, &ctl);
       }
     }
-    launch_ieskf(c->stream, c->d_chain, c->d_chain_gran, seq, i == 0 ? c->d_chain_prior : nullptr, c->d_chain_res,
-                 io->want_log ? c->d_chain_log : nullptr, tag, ev ? ev[4] : nullptr, ev ? ev[5] : nullptr);
+    if (!c->chain_inline)
+      launch_ieskf(c->stream, ctl, seq, i == 0 ? P0.RT : nullptr, ev ? ev[4] : nullptr, ev ? ev[5] : nullptr);
     prev_valid = c->prune;
   }
   HIPCHK(c, hipGetLastError());
   c->chains_run++;
 
-  // ---- one wait: the head of the result (stored last), then every granule the status promises ----
+  // ---- one wait: the head of the result (stored last), then every granule ----
   const volatile unsigned long long* rt = reinterpret_cast<const volatile unsigned long long*>(c->h_chain_res);
   auto tag_at = [&](int slot) { return rt[2 * slot + 1] == tag; };
   auto val_at = [&](int slot) { return c->h_chain_res[2 * slot]; };
   auto complete = [&]() {
-    if (!tag_at(CH_STATUS)) return false;
-    for (int k = 0; k < CH_P; k++) if (!tag_at(k)) return false;
-    if ((int)llround(val_at(CH_STATUS)) == 1)
-      for (int k = CH_P; k < CH_RES; k++) if (!tag_at(k)) return false;
+    for (int k = 0; k < CH_RES; k++) if (!tag_at(k)) return false;
     return true;
   };
   {
-    unsigned long long spins = 0;
-    double deadline = 0.0;
-    auto now_s = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     // (whatever ends the wait early: the context's pass count stays consistent with the tie counters' parity only if every queued
     //  pass is assumed to run; a chain that is abandoned or fails resets the pass buffers' bookkeeping instead)
     if (c->wait_timeout_ms == 0) { c->pass_seq = seq0 + (unsigned long long)n_pass; return abandon_wait(c, "update chain", tag - 0x4000000000000000ull); }
+    unsigned long long spins = 0;
+    double deadline = 0.0;
+    auto now_s = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     for (;;) {
       if (tag_at(CH_STATUS) && complete()) break;
       _mm_pause();
@@ -1908,7 +1921,7 @@ extern "C" int flimo_update_chain(flimo_ctx* c, const flimo_match_cfg* cfg, flim
       if (q == hipErrorNotReady) { c->pass_seq = seq0 + (unsigned long long)n_pass; return abandon_wait(c, "update chain", tag - 0x4000000000000000ull); }
       if (q != hipSuccess) return fail(c, FLIMO_ERR_HIP, "the update chain failed: %s", hipGetErrorString(q));
       if (complete()) break;
-      (void)hipMemsetAsync(c->d_ticket, 0, (FIT_GROUPS + 1) * sizeof(unsigned int), c->stream);
+      (void)hipMemsetAsync(c->d_ticket, 0, (FIT_GROUPS + 2) * sizeof(unsigned int), c->stream);
       (void)hipMemsetAsync(c->d_wl_count, 0, sizeof(int), c->stream);
       (void)hipMemsetAsync(c->d_tie_count, 0, 2 * sizeof(unsigned int), c->stream);
       (void)hipStreamSynchronize(c->stream);
@@ -1922,9 +1935,16 @@ extern "C" int flimo_update_chain(flimo_ctx* c, const flimo_match_cfg* cfg, flim
   io->it_next = (int)llround(val_at(CH_IT));
   io->t = (int)llround(val_at(CH_T));
   for (int k = 0; k < 26; k++) io->x26_out[k] = val_at(CH_X + k);
-  if (io->status == FLIMO_CHAIN_DONE) for (int k = 0; k < 529; k++) io->P_out[k] = val_at(CH_P + k);
+  if (io->reason == CH_R_FINAL || io->reason == CH_R_DEGENERATE) {
+    io->meas_valid = 1;
+    int k = 0;
+    for (int i = 0; i < 12; i++) for (int j = i; j < 12; j++) { const double v = val_at(CH_SUMS + k++); io->meas_HTH[i * 12 + j] = v; io->meas_HTH[j * 12 + i] = v; }
+    for (int i = 0; i < 12; i++) io->meas_HTh[i] = val_at(CH_SUMS + k++);
+    io->meas_M = (int)llround(val_at(CH_SUMS + k));
+  }
+  if (c->combined_err_check && *(volatile int*)c->h_wf_err) { *c->h_wf_err = 0; c->prev.valid = 0; return fail(c, FLIMO_ERR_HIP, "a fit block's wait for its widening wave ran out"); }
   // passes whose measurement ran: the completed iterations, and the one that was handed back
-  const int executed = std::min(n_pass, io->passes + (io->status == FLIMO_CHAIN_HANDED_BACK ? 1 : 0));
+  const int executed = std::min(n_pass, io->passes + 1);
   for (int i = 0; i < executed; i++) {
     flimo_chain_pass& L = io->log[i];
     L.M = (int)llround(val_at(CH_PASSINFO + 3 * i)); L.stragglers = (int)llround(val_at(CH_PASSINFO + 3 * i + 1));
@@ -1947,16 +1967,12 @@ extern "C" int flimo_update_chain(flimo_ctx* c, const flimo_match_cfg* cfg, flim
       for (int k = 0; k < 26; k++) L.x_after[k] = lv[2 * (179 + k)];
     }
   }
-  if (io->status == FLIMO_CHAIN_HANDED_BACK) {
-    c->chains_back++;
-    if (io->reason == 4) { c->prev.valid = 0; return fail(c, FLIMO_ERR_HIP, "a pass of the update chain did not publish its sums"); }
-  }
-  // what the context knows about its last pass (fetches, the next pass's bound)
+  if (io->reason != CH_R_FINAL) c->chains_back++;
+  // what the context knows about its last pass (fetches, the next pass's bound): the handed-back iteration's, at x26_out
   c->pass_seq = seq0 + (unsigned long long)executed;
-  double x_meas[26];
-  for (int k = 0; k < 26; k++) x_meas[k] = val_at(CH_XMEAS + k);
+  if (io->reason == CH_R_FAILED) { c->prev.valid = 0; return fail(c, FLIMO_ERR_HIP, "a pass of the update chain did not publish its sums"); }
   PoseMats Pl;
-  pose_from_x26(x_meas, Pl);
+  pose_from_x26(io->x26_out, Pl);
   if (c->prune && executed > 0) { memcpy(c->prev.RT, Pl.RT, sizeof(c->prev.RT)); c->prev.valid = 1; }
   c->last_nq = (int)nq;
   c->last_P = Pl; c->last_mp = mp; c->last_n_all = n_all;
@@ -1965,13 +1981,12 @@ extern "C" int flimo_update_chain(flimo_ctx* c, const flimo_match_cfg* cfg, flim
   for (int i = 0; i < executed; i++) {
     if (!plan[i].timed) continue;
     hipEvent_t* ev = c->chain_ev[i];
-    float ms = 0.f;
     auto elapsed = [&](hipEvent_t a, hipEvent_t b) {
       float m = 0.f;
       if (hipEventElapsedTime(&m, a, b) != hipSuccess) { (void)hipEventSynchronize(b); (void)hipEventElapsedTime(&m, a, b); }
       return m;
     };
-    ms = elapsed(ev[0], ev[1]);
+    const float ms = elapsed(ev[0], ev[1]);
     c->last_knn_ms = ms; c->tot_knn_ms += ms;
     if (plan[i].fused) { c->split_fused_ms += ms; c->split_fused_n++; c->last_fit_ms = c->last_widen_ms = 0.f; }
     else {
@@ -1979,7 +1994,7 @@ extern "C" int flimo_update_chain(flimo_ctx* c, const flimo_match_cfg* cfg, flim
       c->split_knn_ms += ms; c->split_fit_ms += ms2; c->split_sep_n++; c->tot_fit_ms += ms2;
       c->last_fit_ms = ms2; c->last_widen_ms = 0.f;
     }
-    if (i < io->passes) { c->chain_alg_ms += elapsed(ev[4], ev[5]); c->chain_alg_n++; }
+    if (!c->chain_inline) { c->chain_alg_ms += elapsed(ev[4], ev[5]); c->chain_alg_n++; }
     c->tot_passes++; c->tot_queries += n_all;
   }
   return FLIMO_OK;

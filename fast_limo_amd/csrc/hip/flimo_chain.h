@@ -1,11 +1,17 @@
 // fast_limo_amd/csrc/hip/flimo_chain.h
 // The whole iterated update of a scan enqueued at once ("chain"): esekf::update_iterated_dyn_share_modified
-// (IKFoM_toolkit/esekfom/esekfom.hpp:1620-1823) as  pass_1 -> algebra -> pass_2 -> algebra -> ...  on ONE HIP stream, no host
-// round trip between the passes.  A pass is the measurement plug-in (h_share_model, use-ikfom.cpp:10-31: the k-NN / fit /
-// reduction launches of flimo_kernels.hip); the algebra is the rest of one outer iteration (:1652-1760, and :1764-1820 on the
-// last one) run by a one-block kernel (flimo_ieskf.hip) that leaves the next pass's float32 pose constants in device memory.
-// Every launch of a later pass reads its pose from there and leaves at once when the chain has ended (converged, or handed back
-// to the host filter: M < 23, exact distance ties, a degenerate H^T H).
+// (IKFoM_toolkit/esekfom/esekfom.hpp:1620-1823) as  pass_1 -> pass_2 -> ...  on ONE HIP stream, no host round trip between the
+// passes and no launch of its own for the filter's algebra.  A pass is the measurement plug-in (h_share_model, use-ikfom.cpp:10-31:
+// the k-NN / fit / reduction launches of flimo_kernels.hip).  The rest of one outer iteration (:1652-1760) runs INSIDE the pass's
+// reducing launch (flimo_ieskf.h):
+//   * one extra workgroup computes the half that does not depend on the measurement (x boxminus x_prop, the covariance through the
+//     manifold blocks, :1652-1697) while the other workgroups search and fit;
+//   * the workgroup that completes the launch (the last one to arrive at a ticket) goes on from the pass's 91 sums to the gain,
+//     the step, boxplus and the convergence test (:1722-1764) and leaves the next pass's float32 pose constants in device memory.
+// Every launch of a later pass reads its pose from there and leaves at once when the chain has ended.  The chain ends by handing the
+// loop back to the host filter: at the iteration whose covariance update is due (:1764-1820: the host runs that one iteration from
+// the sums the device hands over -- no further pass), or earlier at a branch the device does not run (M < 23, exact distance ties,
+// a degenerate H^T H).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "flimo_types.h"
@@ -18,37 +24,68 @@ constexpr int CH_MAX_PASSES = 12;      // MAX_NUM_ITERS + 1 <= this, else the ho
 struct ChainHead {
   PoseMats pose;           // float32 constants of the NEXT pass (State casts, get_RT / get_RT_inv / get_extr_RT_inv, calculate_H's rotations)
   float prev_RT[16];       // body -> world of the pass just completed: the next pass's pruning bound is relative to it
-  int status;              // 0: the chain goes on; 1: finished (x, P final); 2: handed back to the host filter
+  int status;              // 0: the chain goes on; 2: handed back to the host filter
   int pad[3];
 };
 
-// The prior of a scan's update, written by the host into mapped memory before the chain is enqueued (read once, by the first
-// algebra kernel)
+// The prior of a scan's update, written by the host into mapped memory before the chain is enqueued (copied to the device filter
+// by the first pass's extra workgroup, beside the pass).  The measurement-independent half of iteration -1 (x == x_prop: no
+// transcendental function is evaluated) comes with it.
 struct ChainPrior {
   double x[26];            // flat state_ikfom (use-ikfom.hpp:12-21)
   double P[529];           // 23 x 23 row-major
   double limit[23];        // convergence limits (esekfom.hpp:1757-1763)
   double R, D;             // measurement noise, degeneracy threshold
-  int max_iter;            // MAX_NUM_ITERS: passes it = -1 .. max_iter - 1
+  int max_iter;            // MAX_NUM_ITERS: iterations it = -1 .. max_iter - 1
   int pad;
-  float RT0[16];           // body -> world the first pass ran with
+  double dxn[23];          // dx_new of iteration -1
+  double PR[276];          // (P_ through the blocks)[:, 0:12] / R of iteration -1
+};
+
+// Filter state of one scan's update in device memory.  flat state x26: pos3 rot4(xyzw) offR4 offT3 vel3 bg3 ba3 grav3.
+struct ChainState {
+  ChainHead head;          // what the pass kernels read
+  double x[26];
+  double x_prop[26];
+  double P_prop[529];
+  double limit[23];
+  double R, D;
+  int max_iter;            // MAX_NUM_ITERS: iterations it = -1 .. max_iter - 1
+  int it;                  // next iteration: it = -1 + iterations done
+  int t;                   // iterations that met the limits so far
+  int passes;              // iterations completed by the device
+  double info[3 * CH_MAX_PASSES];   // per pass: M, stragglers, ties
+  double pre_dxn[23];      // the measurement-independent half of the CURRENT iteration (extra workgroup of its pass)
+  double pre_PR[276];
+};
+
+// Arguments of the algebra inside a pass's reducing launch (S == nullptr: a host-driven pass)
+struct ChainCtl {
+  ChainState* S;
+  const ChainPrior* prior;     // first pass of the chain: mapped host memory; later passes: nullptr
+  double2* gran;               // DEVICE copy of the granule slots: [FIT_GROUPS][FIT_LIVE_PAD] x {sum, pass number}
+  double2* res;                // mapped host memory: CH_RES result granules {value, tag}
+  double2* log;                // mapped host memory: per-pass log (or nullptr)
+  unsigned long long tag;      // tag of this scan's chain
+  unsigned int* ticket3;       // "sums published / pre-part stored" ticket: FIT_GROUPS + 1 arrivals per launch
+  int inline_alg;              // 1: the completing workgroup runs the algebra; 0: a launch of its own does (flimo_ieskf.hip, A/B)
 };
 
 // Results: 16-byte granules {value, tag} in mapped host memory (data and "ready" travel together, like a pass's sums)
 constexpr int CH_STATUS = 0, CH_BAIL = 1, CH_PASSES = 2, CH_IT = 3, CH_T = 4;
-constexpr int CH_X = 5;                                   // x[26] after the last completed algebra
-constexpr int CH_XMEAS = CH_X + 26;                       // x[26] the last executed pass measured at
-constexpr int CH_PASSINFO = CH_XMEAS + 26;                // per pass: M, stragglers, ties
-constexpr int CH_P = CH_PASSINFO + 3 * CH_MAX_PASSES;     // P[529] (status 1)
-constexpr int CH_RES = CH_P + 529;
+constexpr int CH_X = 5;                                   // x[26]: the state the handed-back iteration measured at
+constexpr int CH_PASSINFO = CH_X + 26;                    // per pass: M, stragglers, ties
+constexpr int CH_SUMS = CH_PASSINFO + 3 * CH_MAX_PASSES;  // the handed-back iteration's 91 sums (upper triangle of H^T H, H^T h, M)
+constexpr int CH_RES = CH_SUMS + 91;
+// reasons (CH_BAIL)
+constexpr int CH_R_FEW = 1, CH_R_TIES = 2, CH_R_DEGENERATE = 3, CH_R_FAILED = 4, CH_R_FINAL = 5;
 // optional per-pass log (tests): HTH[144], HTh[12], dx[23], x_after[26]
 constexpr int CH_LOGN = 144 + 12 + 23 + 26;
 
-struct ChainState;                                        // flimo_ieskf.hip
 size_t chain_state_size();
-// One outer iteration's algebra after a pass: `gran` = the pass's granules in DEVICE memory ([FIT_GROUPS][FIT_LIVE_PAD] x {sum, seq});
-// prior != nullptr: first pass of the chain (the state is loaded from it).  res / log: mapped host memory.
-void launch_ieskf(hipStream_t st, ChainState* S, const void* gran, unsigned long long seq, const ChainPrior* prior, void* res, void* log,
-                  unsigned long long tag, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+// A/B: the algebra as a launch of its own behind the pass (inline_alg = 0).  gran: the pass's granules in device memory.
+void launch_ieskf(hipStream_t st, const ChainCtl& ch, unsigned long long seq, const float* used_RT_host_or_null,
+                  hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+void launch_ieskf_extra(hipStream_t st, const ChainCtl& ch, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);   // developer tool
 
 }  // namespace flimo

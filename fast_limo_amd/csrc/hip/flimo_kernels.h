@@ -7,6 +7,7 @@ namespace flimo {
 struct FuseArgs;
 struct TieList;
 struct BookView;
+struct ChainCtl;    // flimo_chain.h: the filter's algebra inside the pass's reducing launch
 struct ChainHead;   // flimo_chain.h: a launch given one reads its pose constants from the device filter and leaves at once when the chain has ended
 // The deskew of a scan's raw points riding on the first pass's k-NN launch (instead of a dispatch of its own): arguments of
 // launch_deskew, `on` = 1 when they are valid
@@ -51,12 +52,13 @@ int fit2_blocks(int n);
 void launch_fit2(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const void* nbr, const PoseMats& P,
                  const MatchParams& mp, const unsigned char* live_idx, double* partials, void* out_granules, unsigned int* ticket,
                  int* wl_count, unsigned long long seq, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, const TieList* ties = nullptr,
-                 const ChainHead* chain = nullptr);
+                 const ChainHead* chain = nullptr, const ChainCtl* ctl = nullptr);
 // widening + fit of a separate-dispatch pass in one launch (max_ring 2..3): see widen_fit_kernel
 void launch_widen_fit(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const PoseMats& P, const MatchParams& mp,
                       void* nbr, int* wl, int* wl_count, unsigned long long* cand, const unsigned char* live_idx, double* partials,
                       void* out_granules, unsigned int* ticket, unsigned long long seq, hipEvent_t e0, hipEvent_t e1,
-                      const TieList* tl_widen, const TieList* tl_fit, int* err, const ChainHead* chain = nullptr);
+                      const TieList* tl_widen, const TieList* tl_fit, int* err, const ChainHead* chain = nullptr,
+                      const ChainCtl* ctl = nullptr);
 // The whole measurement pass in ONE launch (k-NN fast path + in-kernel tail + fit + reduction + publish; two lanes per query, gates of
 // 2..3 rings): partials needs fused_blocks(n) * FIT_LIVE_PAD doubles; results arrive as launch_fit2's granules.
 int fused_blocks(int n);
@@ -64,7 +66,8 @@ void launch_match_fused(hipStream_t st, const GridView& G, const float4* scan_so
                         void* nbr, int* wl, int* wl_count, unsigned long long* cand, const PrevPass& prev,
                         const unsigned char* live_idx, double* partials, void* out_granules, unsigned int* ticket,
                         unsigned long long seq, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, const TieList* ties = nullptr,
-                        int after_fine = 0, const DeskewArgs* deskew = nullptr, const ChainHead* chain = nullptr);
+                        int after_fine = 0, const DeskewArgs* deskew = nullptr, const ChainHead* chain = nullptr,
+                        const ChainCtl* ctl = nullptr);
 // The reference's choice among exactly tied distances (first met by Octree::knn's recursion): BookView = the device copy of the
 // octree (insert book), TieList = the queries a pass flagged.  launch_tie rewrites their neighbour records; launch_knn_tie does the
 // same for the output of launch_knn.

@@ -26,6 +26,7 @@
 #include "flimo_math.h"
 #include "flimo_kernels.h"
 #include "flimo_chain.h"
+#include "flimo_ieskf.h"
 
 #pragma clang fp contract(off)
 
@@ -818,13 +819,32 @@ struct FuseArgs {
   unsigned int* ticket;
   unsigned long long seq;
   DeskewArgs dk;       // dk.on: first pass of a scan, the deskew rides on this launch
+  ChainCtl ch;         // ch.S: a pass of a chained update (flimo_chain.h): the launch has one extra workgroup, and the workgroup
+                       // that completes it goes on with the filter's algebra
 };
 template <int ROWS>
 __device__ __forceinline__ void fit_reduce_publish(const float (&v)[16], bool owns_row, int row, float* sr, double* sa0, double* sa1,
                                                    double* sa2, double* sa3, unsigned int* s_last, const FitIdx& idx,
                                                    double* __restrict__ partials, double2* __restrict__ out_granules,
                                                    unsigned int* __restrict__ ticket, int* __restrict__ wl_count,
-                                                   unsigned long long seq, const TieList& tl, int blk = -1, int nblk = -1);
+                                                   unsigned long long seq, const TieList& tl, int blk = -1, int nblk = -1,
+                                                   const ChainCtl* chp = nullptr, const float* used_RT = nullptr, double* big_lds = nullptr);
+// A workgroup of a chained pass has done its share of the launch (a reduction group's sums published / the measurement-independent
+// half stored; all written through, performed): FIT_GROUPS + 1 of them arrive here, the last one runs the filter's algebra.
+// Workgroup-wide; s_flag: a word of shared memory.
+__device__ __forceinline__ void chain_arrive(const ChainCtl& ch, unsigned long long seq, const float* used_RT, double* big_lds,
+                                             unsigned int* s_flag) {
+  if (!ch.inline_alg) return;                          // the algebra is a launch of its own (A/B)
+  if (threadIdx.x == 0) {
+    const unsigned int old = __hip_atomic_fetch_add(ch.ticket3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *s_flag = (old == (unsigned int)FIT_GROUPS) ? 1u : 0u;
+    if (old == (unsigned int)FIT_GROUPS) __hip_atomic_store(ch.ticket3, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch
+  }
+  __syncthreads();
+  if (*s_flag == 0u) return;
+  int* s_i = reinterpret_cast<int*>(big_lds + IKL_END);
+  ik_final_stage<false>(ch, seq, used_RT, big_lds, s_i, (int)threadIdx.x);
+}
 FLIMO_DEV void fit_row(const GridView& G, const PoseMats& P, const MatchParams& mp, const int (&ids)[5], float gx, float gy, float gz,
                        float (&v)[16]);
 
@@ -845,7 +865,21 @@ __device__ __forceinline__ void knn5_pass(const GridView& G, const float4* __res
   const TieList tl = fa.tl;
   __shared__ WaveLds s_w[4];
   __shared__ unsigned int s_last;
-  const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
+  static_assert(sizeof(WaveLds) * 4 >= (size_t)IESKF_LDS_BYTES, "the filter's algebra runs in this workgroup's shared memory");
+  // a chained pass's reducing launch has one workgroup more than the scan needs: it does the filter's measurement-independent half
+  int nb = (int)gridDim.x;
+  if constexpr (FUSE) {
+    if (fa.ch.S) {
+      nb -= 1;
+      if ((int)blockIdx.x == nb) {
+        double* big = reinterpret_cast<double*>(s_w);
+        ik_extra_block(fa.ch, big, (int)threadIdx.x);
+        chain_arrive(fa.ch, fa.seq, P.RT, big, &s_last);
+        return;
+      }
+    }
+  }
+  const int chunk = xcd_chunk(blockIdx.x, nb);
   const int p = chunk * QPB + threadIdx.x / L;
   const int sub = threadIdx.x % L;
   const bool in_range = p < n;          // no early exit: the tail below is a wave-wide phase
@@ -1214,7 +1248,8 @@ __device__ __forceinline__ void knn5_pass(const GridView& G, const float4* __res
     }
     wave_lds_sync();                                           // every lane is done with W.res before the tile overwrites the tables
     fit_reduce_publish<64 / L>(v, sub == 0, lane / L, W.tile, s_w[0].acc, s_w[1].acc, s_w[2].acc, s_w[3].acc, &s_last, fa.idx,
-                               fa.partials, fa.granules, fa.ticket, wl_count, fa.seq, tl);
+                               fa.partials, fa.granules, fa.ticket, wl_count, fa.seq, tl, (int)blockIdx.x, nb, &fa.ch, P.RT,
+                               reinterpret_cast<double*>(s_w));
   }
 }
 
@@ -1665,7 +1700,8 @@ __device__ __forceinline__ void fit_reduce_publish(const float (&v)[16], bool ow
                                                    double* sa2, double* sa3, unsigned int* s_last, const FitIdx& idx,
                                                    double* __restrict__ partials, double2* __restrict__ out_granules,
                                                    unsigned int* __restrict__ ticket, int* __restrict__ wl_count,
-                                                   unsigned long long seq, const TieList& tl, int blk, int nblk) {
+                                                   unsigned long long seq, const TieList& tl, int blk, int nblk,
+                                                   const ChainCtl* chp, const float* used_RT, double* big_lds) {
   // blk / nblk: this block's number among the launch's nblk fit blocks (-1: the whole launch consists of them)
   typedef double v2d_t __attribute__((ext_vector_type(2)));
   const int fb = blk < 0 ? (int)blockIdx.x : blk, fnb = nblk < 0 ? (int)gridDim.x : nblk;
@@ -1769,6 +1805,13 @@ __device__ __forceinline__ void fit_reduce_publish(const float (&v)[16], bool ow
       }
     }
     TRACE(1, 7);
+    if (chp && chp->S) {
+      // chained pass: this group's sums (and, from the launch's last arrival, the two counters) are on their way to the device copy
+      // of the granule slots; once they are performed the group arrives -- the last arrival of the launch goes on with the algebra
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      chain_arrive(*chp, seq, used_RT, big_lds, s_last);
+    }
   }
 }
 
@@ -1781,12 +1824,23 @@ __device__ __forceinline__ void fit2_pass(const GridView& G, const float4* __res
                                           const NbrRec* __restrict__ nbr, const PoseMats& P, const MatchParams& mp, const FitIdx& idx,
                                           double* __restrict__ partials, double2* __restrict__ out_granules,
                                           unsigned int* __restrict__ ticket, int* __restrict__ wl_count,
-                                          unsigned long long seq, const TieList& tl) {
-  __shared__ float s_rec[4][16 * 65];       // per wave: [col][row] with stride 65
+                                          unsigned long long seq, const TieList& tl, const ChainCtl& ch) {
+  __shared__ __align__(16) float s_rec[4][16 * 65];       // per wave: [col][row] with stride 65
   __shared__ double s_acc[4][256];
   __shared__ unsigned int s_last;
+  static_assert(sizeof(float) * 4 * 16 * 65 >= (size_t)IESKF_LDS_BYTES, "the filter's algebra runs in this workgroup's shared memory");
+  int nb = (int)gridDim.x;
+  if (ch.S) {
+    nb -= 1;
+    if ((int)blockIdx.x == nb) {
+      double* big = reinterpret_cast<double*>(&s_rec[0][0]);
+      ik_extra_block(ch, big, (int)threadIdx.x);
+      chain_arrive(ch, seq, P.RT, big, &s_last);
+      return;
+    }
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
+  const int chunk = xcd_chunk(blockIdx.x, nb);
   const int p = (chunk * 4 + wave) * PPW + lane;
   float v[16];
 #pragma unroll
@@ -1804,7 +1858,7 @@ __device__ __forceinline__ void fit2_pass(const GridView& G, const float4* __res
   }
   TRACE(1, 3);
   fit_reduce_publish<PPW>(v, lane < PPW, lane, s_rec[wave], s_acc[0], s_acc[1], s_acc[2], s_acc[3], &s_last, idx, partials,
-                          out_granules, ticket, wl_count, seq, tl);
+                          out_granules, ticket, wl_count, seq, tl, (int)blockIdx.x, nb, &ch, P.RT, reinterpret_cast<double*>(&s_rec[0][0]));
 }
 
 template <int PPW>
@@ -1812,17 +1866,17 @@ __global__ __launch_bounds__(256) void fit2_kernel(GridView G, const float4* __r
                                                    const NbrRec* __restrict__ nbr, PoseMats P, MatchParams mp, FitIdx idx,
                                                    double* __restrict__ partials, double2* __restrict__ out_granules,
                                                    unsigned int* __restrict__ ticket, int* __restrict__ wl_count,
-                                                   unsigned long long seq, TieList tl) {
-  fit2_pass<PPW>(G, scan_sorted, n, nbr, P, mp, idx, partials, out_granules, ticket, wl_count, seq, tl);
+                                                   unsigned long long seq, TieList tl, ChainCtl ch) {
+  fit2_pass<PPW>(G, scan_sorted, n, nbr, P, mp, idx, partials, out_granules, ticket, wl_count, seq, tl, ch);
 }
 template <int PPW>
 __global__ __launch_bounds__(256) void fit2_chain_kernel(GridView G, const float4* __restrict__ scan_sorted, int n,
                                                    const NbrRec* __restrict__ nbr, const ChainHead* __restrict__ H, MatchParams mp, FitIdx idx,
                                                    double* __restrict__ partials, double2* __restrict__ out_granules,
                                                    unsigned int* __restrict__ ticket, int* __restrict__ wl_count,
-                                                   unsigned long long seq, TieList tl) {
+                                                   unsigned long long seq, TieList tl, ChainCtl ch) {
   if (H->status != 0) return;
-  fit2_pass<PPW>(G, scan_sorted, n, nbr, H->pose, mp, idx, partials, out_granules, ticket, wl_count, seq, tl);
+  fit2_pass<PPW>(G, scan_sorted, n, nbr, H->pose, mp, idx, partials, out_granules, ticket, wl_count, seq, tl, ch);
 }
 
 // Widening and fit of a pass that runs in separate dispatches (first pass of a poor prior) in ONE launch: the first `wblocks`
@@ -1837,17 +1891,27 @@ __device__ __forceinline__ void widen_fit_pass(const GridView& G, const float4* 
                                                unsigned long long* __restrict__ cand_total, int wblocks, const TieList& tl_widen,
                                                const MatchParams& mp, const FitIdx& idx, double* __restrict__ partials,
                                                double2* __restrict__ out_granules, unsigned int* __restrict__ ticket,
-                                               unsigned long long seq, const TieList& tl_fit, int* __restrict__ err) {
-  __shared__ float s_rec[4][16 * 65];
+                                               unsigned long long seq, const TieList& tl_fit, int* __restrict__ err, const ChainCtl& ch) {
+  __shared__ __align__(16) float s_rec[4][16 * 65];
   __shared__ double s_acc[4][256];
   __shared__ unsigned int s_last;
+  int nball = (int)gridDim.x;
+  if (ch.S) {
+    nball -= 1;
+    if ((int)blockIdx.x == nball) {
+      double* big = reinterpret_cast<double*>(&s_rec[0][0]);
+      ik_extra_block(ch, big, (int)threadIdx.x);
+      chain_arrive(ch, seq, P.RT, big, &s_last);
+      return;
+    }
+  }
   if ((int)blockIdx.x < wblocks) {
     uint32_t (*s_off)[65] = reinterpret_cast<uint32_t (*)[65]>(&s_rec[0][0]);
     uint32_t (*s_lo)[64] = reinterpret_cast<uint32_t (*)[64]>(&s_rec[1][0]);
     widen_body<true>(G, max_ring, nbr, wl, wl_count, cand_total, max_ring, tl_widen, (int)blockIdx.x, wblocks, s_off, s_lo);
     return;
   }
-  const int fb = (int)blockIdx.x - wblocks, fnb = (int)gridDim.x - wblocks;
+  const int fb = (int)blockIdx.x - wblocks, fnb = nball - wblocks;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int chunk = xcd_chunk(fb, fnb);
   const int p = (chunk * 4 + wave) * 64 + lane;
@@ -1886,7 +1950,7 @@ __device__ __forceinline__ void widen_fit_pass(const GridView& G, const float4* 
     if (b.y == 1 && __float_as_uint(sp.w) < (uint32_t)mp.n_queries) fit_row(G, P, mp, ids, gx, gy, gz, v);
   }
   fit_reduce_publish<64>(v, true, lane, s_rec[wave], s_acc[0], s_acc[1], s_acc[2], s_acc[3], &s_last, idx, partials,
-                         out_granules, ticket, wl_count, seq, tl_fit, fb, fnb);
+                         out_granules, ticket, wl_count, seq, tl_fit, fb, fnb, &ch, P.RT, reinterpret_cast<double*>(&s_rec[0][0]));
 }
 
 __global__ __launch_bounds__(256) void widen_fit_kernel(GridView G, const float4* __restrict__ scan_sorted, int n, PoseMats P, int max_ring,
@@ -1894,17 +1958,17 @@ __global__ __launch_bounds__(256) void widen_fit_kernel(GridView G, const float4
                                                         unsigned long long* __restrict__ cand_total, int wblocks, TieList tl_widen,
                                                         MatchParams mp, FitIdx idx, double* __restrict__ partials,
                                                         double2* __restrict__ out_granules, unsigned int* __restrict__ ticket,
-                                                        unsigned long long seq, TieList tl_fit, int* __restrict__ err) {
-  widen_fit_pass(G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand_total, wblocks, tl_widen, mp, idx, partials, out_granules, ticket, seq, tl_fit, err);
+                                                        unsigned long long seq, TieList tl_fit, int* __restrict__ err, ChainCtl ch) {
+  widen_fit_pass(G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand_total, wblocks, tl_widen, mp, idx, partials, out_granules, ticket, seq, tl_fit, err, ch);
 }
 __global__ __launch_bounds__(256) void widen_fit_chain_kernel(GridView G, const float4* __restrict__ scan_sorted, int n, const ChainHead* __restrict__ H,
                                                         int max_ring, NbrRec* __restrict__ nbr, const int* __restrict__ wl, int* __restrict__ wl_count,
                                                         unsigned long long* __restrict__ cand_total, int wblocks, TieList tl_widen,
                                                         MatchParams mp, FitIdx idx, double* __restrict__ partials,
                                                         double2* __restrict__ out_granules, unsigned int* __restrict__ ticket,
-                                                        unsigned long long seq, TieList tl_fit, int* __restrict__ err) {
+                                                        unsigned long long seq, TieList tl_fit, int* __restrict__ err, ChainCtl ch) {
   if (H->status != 0) return;
-  widen_fit_pass(G, scan_sorted, n, H->pose, max_ring, nbr, wl, wl_count, cand_total, wblocks, tl_widen, mp, idx, partials, out_granules, ticket, seq, tl_fit, err);
+  widen_fit_pass(G, scan_sorted, n, H->pose, max_ring, nbr, wl, wl_count, cand_total, wblocks, tl_widen, mp, idx, partials, out_granules, ticket, seq, tl_fit, err, ch);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2452,11 +2516,12 @@ static void launch_knn5_L(hipStream_t st, const GridView& G, const float4* scan_
   const int blocks = round_up8((n + qpb - 1) / qpb);
   constexpr int slots = (L <= 4 ? 8 : 4);          // candidate loads in flight per lane
   if constexpr (L == 2) {
-    if (fuse) {      // the whole pass in one launch (blocks is a multiple of 8 = FIT_GROUPS)
+    if (fuse) {      // the whole pass in one launch (blocks is a multiple of 8 = FIT_GROUPS; a chained pass has one workgroup more)
+      const int grid = blocks + (fuse->ch.S ? 1 : 0);
       if (chain)
-        hipExtLaunchKernelGGL((knn5_chain_kernel<2, 8, true>), dim3(blocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, chain, max_ring, (NbrRec*)nbr, wl, wl_count, cand, prev.valid, prev.probe_min, 1, *fuse);
+        hipExtLaunchKernelGGL((knn5_chain_kernel<2, 8, true>), dim3(grid), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, chain, max_ring, (NbrRec*)nbr, wl, wl_count, cand, prev.valid, prev.probe_min, 1, *fuse);
       else
-      hipExtLaunchKernelGGL((knn5_kernel<2, 8, true>), dim3(blocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand, prev, 1, *fuse);
+      hipExtLaunchKernelGGL((knn5_kernel<2, 8, true>), dim3(grid), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand, prev, 1, *fuse);
       return;
     }
   }
@@ -2526,37 +2591,44 @@ int fit2_blocks(int n) { const int b = (n + 255) / 256; return (b + FIT_GROUPS -
 
 void launch_fit2(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const void* nbr, const PoseMats& P,
                  const MatchParams& mp, const unsigned char* live_idx, double* partials, void* out_granules, unsigned int* ticket,
-                 int* wl_count, unsigned long long seq, hipEvent_t e0, hipEvent_t e1, const TieList* tlp, const ChainHead* chain) {
+                 int* wl_count, unsigned long long seq, hipEvent_t e0, hipEvent_t e1, const TieList* tlp, const ChainHead* chain,
+                 const ChainCtl* ctl) {
   if (n <= 0) return;
   TieList tl{};
   if (tlp) tl = *tlp;
   FitIdx idx;
   for (int i = 0; i < FIT_LIVE_PAD; i++) idx.raw[i] = i < FIT_LIVE ? live_idx[i] : 0;
+  ChainCtl ch{};
+  if (ctl) ch = *ctl;
+  const int grid = fit2_blocks(n) + (ch.S ? 1 : 0);
   if (chain) {
-    hipExtLaunchKernelGGL((fit2_chain_kernel<64>), dim3(fit2_blocks(n)), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, (const NbrRec*)nbr, chain, mp, idx, partials, (double2*)out_granules, ticket, wl_count, seq, tl);
+    hipExtLaunchKernelGGL((fit2_chain_kernel<64>), dim3(grid), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, (const NbrRec*)nbr, chain, mp, idx, partials, (double2*)out_granules, ticket, wl_count, seq, tl, ch);
     return;
   }
-  hipExtLaunchKernelGGL((fit2_kernel<64>), dim3(fit2_blocks(n)), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, idx, partials, (double2*)out_granules, ticket, wl_count, seq, tl);
+  hipExtLaunchKernelGGL((fit2_kernel<64>), dim3(grid), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, idx, partials, (double2*)out_granules, ticket, wl_count, seq, tl, ch);
 }
 
 void launch_widen_fit(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const PoseMats& P, const MatchParams& mp,
                       void* nbr, int* wl, int* wl_count, unsigned long long* cand, const unsigned char* live_idx, double* partials,
                       void* out_granules, unsigned int* ticket, unsigned long long seq, hipEvent_t e0, hipEvent_t e1,
-                      const TieList* tl_widen, const TieList* tl_fit, int* err, const ChainHead* chain) {
+                      const TieList* tl_widen, const TieList* tl_fit, int* err, const ChainHead* chain, const ChainCtl* ctl) {
   if (n <= 0) return;
+  ChainCtl ch{};
+  if (ctl) ch = *ctl;
   TieList tw{}, tf{};
   if (tl_widen) tw = *tl_widen;
   if (tl_fit) tf = *tl_fit;
   FitIdx idx;
   for (int i = 0; i < FIT_LIVE_PAD; i++) idx.raw[i] = i < FIT_LIVE ? live_idx[i] : 0;
   const int wblocks = 2048, fblocks = fit2_blocks(n);
+  const int grid = wblocks + fblocks + (ch.S ? 1 : 0);
   if (chain) {
-    hipExtLaunchKernelGGL(widen_fit_chain_kernel, dim3(wblocks + fblocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, chain, mp.max_ring, (NbrRec*)nbr,
-                          wl, wl_count, cand, wblocks, tw, mp, idx, partials, (double2*)out_granules, ticket, seq, tf, err);
+    hipExtLaunchKernelGGL(widen_fit_chain_kernel, dim3(grid), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, chain, mp.max_ring, (NbrRec*)nbr,
+                          wl, wl_count, cand, wblocks, tw, mp, idx, partials, (double2*)out_granules, ticket, seq, tf, err, ch);
     return;
   }
-  hipExtLaunchKernelGGL(widen_fit_kernel, dim3(wblocks + fblocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, P, mp.max_ring, (NbrRec*)nbr,
-                        wl, wl_count, cand, wblocks, tw, mp, idx, partials, (double2*)out_granules, ticket, seq, tf, err);
+  hipExtLaunchKernelGGL(widen_fit_kernel, dim3(grid), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, P, mp.max_ring, (NbrRec*)nbr,
+                        wl, wl_count, cand, wblocks, tw, mp, idx, partials, (double2*)out_granules, ticket, seq, tf, err, ch);
 }
 
 int fused_blocks(int n) { return round_up8((n + 127) / 128); }
@@ -2583,9 +2655,10 @@ void launch_match_fused(hipStream_t st, const GridView& G, const float4* scan_so
                         void* nbr, int* wl, int* wl_count, unsigned long long* cand, const PrevPass& prev,
                         const unsigned char* live_idx, double* partials, void* out_granules, unsigned int* ticket,
                         unsigned long long seq, hipEvent_t e0, hipEvent_t e1, const TieList* tlp, int after_fine, const DeskewArgs* dk,
-                        const ChainHead* chain) {
+                        const ChainHead* chain, const ChainCtl* ctl) {
   if (n <= 0) return;
   FuseArgs fa{};
+  if (ctl) fa.ch = *ctl;
   if (dk) fa.dk = *dk;
   fa.fine_mode = after_fine ? 1 : 0;
   fa.tl = TieList{};

@@ -552,7 +552,13 @@ void Localizer::init_iKFoM() {                                     // Localizer.
     if (io.status == FLIMO_CHAIN_DECLINED) return;
     prof_[3] += (double)io.passes;
     std::memcpy(out.x, io.x26_out, sizeof(out.x));
-    if (io.status == FLIMO_CHAIN_DONE) std::memcpy(out.P, io.P_out, sizeof(io.P_out));
+    out.have_meas = io.meas_valid != 0;
+    if (out.have_meas) {
+      out.meas.M = io.meas_M;
+      std::memcpy(out.meas.HTH, io.meas_HTH, sizeof(out.meas.HTH));
+      std::memcpy(out.meas.HTh, io.meas_HTh, sizeof(out.meas.HTh));
+      prof_[3] += 1.0;                                                // (its pass ran on the device too)
+    }
     if (ikfom_->keep_log)
       for (int i = 0; i < io.passes; i++) {
         flimo_host::PassLog lg;

@@ -86,22 +86,56 @@ bool inverse_gj(int n, const double* Ain, double* Ainv) {
       if (v > best) { best = v; p = r; }
     }
     if (p < 0 || !(best > 0.0)) return false;
-    const double d = A[p * n + k];
+    const double rinv = 1.0 / A[p * n + k];
     const double* ap = &A[p * n];
     const double* xp = &X[p * n];
     for (int r = 0; r < n; r++) {
       if (r == p) continue;
-      const double f = A[r * n + k] / d;
+      const double f = A[r * n + k] * rinv;
       double* ar = &A[r * n];
       double* xr = &X[r * n];
       for (int j = k + 1; j < n; j++) ar[j] = ar[j] - f * ap[j];
       for (int c = 0; c < n; c++) xr[c] = xr[c] - f * xp[c];
     }
-    used[p] = true; prow[k] = p; dk[k] = d;
+    used[p] = true; prow[k] = p; dk[k] = rinv;
   }
-  // row prow[k] of the reduced left side is dk[k] e_k^T: row k of the inverse = X[prow[k]] / dk[k]
+  // row prow[k] of the reduced left side is A[p][k] e_k^T: row k of the inverse = X[prow[k]] * (1 / A[p][k])
   for (int k = 0; k < n; k++)
-    for (int c = 0; c < n; c++) Ainv[k * n + c] = X[prow[k] * n + c] / dk[k];
+    for (int c = 0; c < n; c++) Ainv[k * n + c] = X[prow[k] * n + c] * dk[k];
+  return true;
+}
+
+// A u = v by the same elimination, the right-hand side as one more column (csrc/hip/flimo_ieskf.h: ik_gj12_solve_wave)
+bool solve_gj(int n, const double* Ain, const double* v, double* u) {
+  constexpr int NMAX = 32;
+  if (n > NMAX) return false;
+  double A[NMAX * NMAX], b[NMAX], dk[NMAX];
+  int prow[NMAX];
+  bool used[NMAX];
+  for (int i = 0; i < n * n; i++) A[i] = Ain[i];
+  for (int i = 0; i < n; i++) { b[i] = v[i]; used[i] = false; }
+  for (int k = 0; k < n; k++) {
+    int p = -1;
+    double best = -1.0;
+    for (int r = 0; r < n; r++) {
+      if (used[r]) continue;
+      const double m = std::fabs(A[r * n + k]);
+      if (m > best) { best = m; p = r; }
+    }
+    if (p < 0 || !(best > 0.0)) return false;
+    const double rinv = 1.0 / A[p * n + k];
+    const double* ap = &A[p * n];
+    const double bp = b[p];
+    for (int r = 0; r < n; r++) {
+      if (r == p) continue;
+      const double f = A[r * n + k] * rinv;
+      double* ar = &A[r * n];
+      for (int j = k + 1; j < n; j++) ar[j] = ar[j] - f * ap[j];
+      b[r] = b[r] - f * bp;
+    }
+    used[p] = true; prow[k] = p; dk[k] = rinv;
+  }
+  for (int k = 0; k < n; k++) u[k] = b[prow[k]] * dk[k];
   return true;
 }
 
@@ -759,21 +793,18 @@ void Esekf::update_iterated_dyn_share_modified(double R, double D) {
   // The whole loop on the measurement side, when it offers that: every iteration below (same arithmetic, flimo_ieskf.hip) enqueued
   // at once.  It may hand the loop back at any iteration: the rare branches stay here.
   int it0 = -1;
+  bool inject = false;                                         // the first iteration of the loop below already has its pass's sums
   if (device_chain) {
     ChainResult r;
     double x26[26];
     x_.to_flat(x26);
     device_chain(x26, P_, limit_, R, D, maximum_iter_, r);
     if (failed) return;                                        // (x_, P_ untouched: still the propagated values)
-    if (r.status == 1) {
-      x_.from_flat(r.x);
-      std::memcpy(&P_.a[0][0], r.P, sizeof(double) * kDof * kDof);
-      return;
-    }
     if (r.status == 2) {
       x_.from_flat(r.x);
       it0 = r.it_next;
       t = r.t;
+      if (r.have_meas) { inject = true; meas = r.meas; }
     }
   }
 
@@ -809,12 +840,15 @@ void Esekf::update_iterated_dyn_share_modified(double R, double D) {
       right_block_T<2, kDof>(P_, idx, J);
     }
     };
-    if (h_reduced_overlap) h_reduced_overlap(x_, meas, pre);    // esekfom.hpp:1637
+    if (inject) inject = false;                                 // (the device's pass at this very state)
+    else if (h_reduced_overlap) h_reduced_overlap(x_, meas, pre);    // esekfom.hpp:1637
     else h_reduced(x_, meas);
     if (failed) { x_ = x_prop; P_ = P_prop; return; }          // the pass did not happen: nothing to update with
     if (!pre_done) pre();
     const int M = meas.M;
 
+    bool lemma_step = false;
+    double dx_lemma[kDof];
     Mat<12, 12> HTH = Mat<12, 12>::zero();                      // defined as 0 when M < 23 (a-note 5)
     double HTh[12];
     for (int i = 0; i < 12; i++) HTh[i] = 0.0;
@@ -866,18 +900,28 @@ void Esekf::update_iterated_dyn_share_modified(double R, double D) {
           for (int k = 0; k < 12; k++) { const double pk = PR[i][k]; for (int j = 0; j < 12; j++) acc[j] += pk * S(k, j); }
           for (int j = 0; j < 12; j++) W[i][j] = acc[j];
         }
-        for (int i = 0; i < n; i++) { double s = 0; for (int k = 0; k < 12; k++) s += W[i][k] * HTh[k]; K_h[i] = s; }
         K_x = Cov::zero();
         for (int i = 0; i < n; i++) {
           double acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
           for (int k = 0; k < 12; k++) { const double wk = W[i][k]; for (int j = 0; j < 12; j++) acc[j] += wk * HTH(k, j); }
           for (int j = 0; j < 12; j++) K_x(i, j) = acc[j];
         }
+        // The step of :1733, dx_ = K_h + (K_x - I) dx_new with K_h = W H^T h and K_x = W H^T H (W = P_inv[:, 0:12]), taken in the
+        // order  dx_ = PR (S (H^T h + H^T H dx_new[0:12])) - dx_new : two 12-vectors between the solve and the step instead of
+        // the two 23 x 12 products (which only the covariance of the last iteration needs) -- the order the device filter's
+        // critical path runs in (csrc/hip/flimo_ieskf.hip: ik_post_block)
+        lemma_step = true;
+        double v[12], u[12];
+        for (int i = 0; i < 12; i++) { double a = 0; for (int k = 0; k < 12; k++) a += HTH(i, k) * dx_new[k]; v[i] = HTh[i] + a; }
+        if (!solve_gj(12, &T.a[0][0], v, u))                     // T u = v directly (the device filter never forms S)
+          for (int m = 0; m < 12; m++) { double a = 0; for (int k = 0; k < 12; k++) a += S(m, k) * v[k]; u[m] = a; }
+        for (int i = 0; i < n; i++) { double a = 0; for (int m = 0; m < 12; m++) a += PR[i][m] * u[m]; dx_lemma[i] = a - dx_new[i]; }
       }
     }
 
     double dx_[kDof];                                          // :1733
     for (int i = 0; i < n; i++) {
+      if (lemma_step) { dx_[i] = dx_lemma[i]; continue; }
       double s = 0;
       for (int k = 0; k < n; k++) s += (K_x(i, k) - (i == k ? 1.0 : 0.0)) * dx_new[k];
       dx_[i] = K_h[i] + s;

@@ -60,6 +60,7 @@ typedef Mat<3, 3> Mat3;
 bool inverse_lu(int n, const double* A, double* Ainv);
 // Gauss-Jordan with partial pivoting, rows marked instead of exchanged (n <= 32): the order of operations of the device filter
 bool inverse_gj(int n, const double* A, double* Ainv);
+bool solve_gj(int n, const double* A, const double* v, double* u);   // A u = v by the same elimination
 template <int N>
 inline bool inverse(const Mat<N, N>& A, Mat<N, N>& out) { return inverse_lu(N, &A.a[0][0], &out.a[0][0]); }
 // Eigen::EigenSolver<Matrix<double,6,6>> as esekfom.hpp:1736-1738 uses it: eigenvalues (real, imaginary part) in the solver's order
@@ -116,11 +117,6 @@ struct InputIkfom { Vec3 acc, gyro; };
 // ---------------------------------------------------------------------------------------------
 // the filter
 // ---------------------------------------------------------------------------------------------
-struct ReducedMeas {      // what the measurement plug-in returns per pass
-  int M = 0;
-  double HTH[144];
-  double HTh[12];
-};
 struct DenseMeas {        // only for the M < 23 branch
   std::vector<double> H;  // M x 12 row-major
   std::vector<double> h;  // M
@@ -131,21 +127,27 @@ struct PassLog {
 };
 
 // The whole update run by the measurement side in one go (the GPU library's flimo_update_chain): what comes back
+struct ReducedMeas {      // what the measurement plug-in returns per pass
+  int M = 0;
+  double HTH[144];
+  double HTh[12];
+};
 struct ChainResult {
-  int status = 0;         // 0 declined (nothing ran), 1 done (x, P final), 2 handed back (resume the loop at it_next with t, from x)
+  int status = 0;         // 0 declined (nothing ran), 2 handed back (resume the loop at it_next with t, from x)
   int passes = 0;         // outer iterations completed
   int it_next = -1, t = 0;
   double x[26];
-  double P[kDof * kDof];  // status 1
+  bool have_meas = false; // the pass of iteration it_next has run: `meas` holds its sums (the loop does not repeat it)
+  ReducedMeas meas;
 };
 
 class Esekf {
  public:
   typedef Mat<kDof, kDof> Cov;
-  // Optional: the whole iterated update on the measurement side (device).  Called once at the start of
-  // update_iterated_dyn_share_modified with the propagated state; may decline or hand the loop back at any iteration (M < 23,
-  // distance ties, degenerate H^T H: esekfom.hpp:1701-1709,1736-1744 stay on the host).  Completed iterations are appended to `log`
-  // by the callee when keep_log is set.
+  // Optional: the iterations of the update on the measurement side (device).  Called once at the start of
+  // update_iterated_dyn_share_modified with the propagated state; may decline, and hands the loop back at the iteration whose
+  // covariance update is due (with that iteration's sums) or earlier (M < 23, distance ties, degenerate H^T H:
+  // esekfom.hpp:1701-1709,1736-1744 stay on the host).  Completed iterations are appended to `log` by the callee when keep_log is set.
   std::function<void(const double x26[26], const Cov& P, const double* limits, double R, double D, int max_iter, ChainResult& out)> device_chain;
   // Set by a measurement callback whose pass failed (a GPU error, a timeout): the update is abandoned -- x_ and P_ are restored to
   // the propagated values and update_iterated_dyn_share_modified returns (the reference's plug-in cannot fail, Mapper.cpp:59-86)

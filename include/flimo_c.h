@@ -169,25 +169,29 @@ int flimo_match_reduce(flimo_ctx* ctx, const double x26[26], const flimo_match_c
  * called: the caller checks and runs it itself. */
 int flimo_match_reduce_overlap(flimo_ctx* ctx, const double x26[26], const flimo_match_cfg* cfg, double HTH[144], double HTh[12], int* M,
                                void (*while_in_flight)(void*), void* arg);
-/* ---- the whole iterated update of the resident scan, enqueued at once: replaces esekf::update_iterated_dyn_share_modified
- *      (IKFoM_toolkit/esekfom/esekfom.hpp:1620-1823) for the M >= 23, well-conditioned case.  Every outer iteration = the pass above
- *      (h_share_model) + the 23-dof algebra of :1652-1760 (and the covariance :1764-1820 on the last one) run by a one-block kernel
- *      queued behind the pass's launches; the next pass reads its pose from device memory, passes after convergence leave at once.
- *      No host round trip between the passes: the caller gets x, P and the iteration count back once.
- *      io->status after the call:
- *        FLIMO_CHAIN_DONE         x26 / P hold the updated state (the reference function has returned);
- *        FLIMO_CHAIN_HANDED_BACK  an iteration met a branch the device does not run (reason 1: M < 23, :1701-1709; 2: exact float32
- *                                 distance ties to settle the reference's way; 3: H^T H needs the eigen-decomposition of :1736-1744;
- *                                 4: a pass did not publish): x26 = the state that iteration measured at, it_next / t the loop
- *                                 variables to resume esekfom.hpp:1634's loop with (the caller runs that iteration again, through
- *                                 flimo_match_reduce);
- *        FLIMO_CHAIN_DECLINED     nothing was run (records / caps / debug / timing level 2 / NUM_MATCH_POINTS != 5 / gates wider than
- *                                 3 rings / more than FLIMO_CHAIN_MAX_PASSES iterations / FLIMO_HOST_UPDATE=1): the caller runs its loop.
+/* ---- the iterated update of the resident scan, enqueued at once: replaces the loop of esekf::update_iterated_dyn_share_modified
+ *      (IKFoM_toolkit/esekfom/esekfom.hpp:1620-1823) up to the iteration whose covariance update is due.  Every outer iteration =
+ *      the pass above (h_share_model) + the 23-dof algebra of :1652-1760, run INSIDE the pass's reducing launch: one extra workgroup
+ *      does the half that does not depend on the measurement beside the pass, the workgroup that completes the launch goes on from
+ *      the sums to the gain, the step, boxplus and the convergence test and leaves the next pass's pose in device memory; passes
+ *      queued behind the end of the chain leave at once.  No host round trip and no launch between the passes.
+ *      The loop always comes back to the caller (status FLIMO_CHAIN_HANDED_BACK) at iteration it_next with counter t, state x26_out:
+ *        reason FLIMO_CHAIN_FINAL       that iteration ends the loop (:1764: converged twice, or the last one): its pass has run,
+ *                                       meas_* hold its sums -- the caller runs :1652-1820 for it without another pass;
+ *        reason FLIMO_CHAIN_DEGENERATE  H^T H needs the eigen-decomposition of :1736-1744 (or the solve met a zero pivot): meas_* valid;
+ *        reason FLIMO_CHAIN_FEW         M < 23 (:1701-1709 needs the dense rows): the caller runs the iteration through
+ *                                       flimo_match_reduce / flimo_match_fetch_H;
+ *        reason FLIMO_CHAIN_TIES        exact float32 distance ties to settle the reference's way: likewise;
+ *      or not at all: FLIMO_CHAIN_DECLINED, nothing was run (records / caps / debug / timing level 2 / NUM_MATCH_POINTS != 5 / gates
+ *      wider than 3 rings / more than FLIMO_CHAIN_MAX_PASSES iterations / FLIMO_HOST_UPDATE=1): the caller runs its loop.
  *      The gain is the matrix-inversion-lemma form of :1722-1729 (one 12x12 solve), as in csrc/host/flimo_ikfom.cpp. ---- */
 #define FLIMO_CHAIN_MAX_PASSES 12
 #define FLIMO_CHAIN_DECLINED 0
-#define FLIMO_CHAIN_DONE 1
 #define FLIMO_CHAIN_HANDED_BACK 2
+#define FLIMO_CHAIN_FEW 1
+#define FLIMO_CHAIN_TIES 2
+#define FLIMO_CHAIN_DEGENERATE 3
+#define FLIMO_CHAIN_FINAL 5
 typedef struct flimo_chain_pass {
   int M, stragglers, ties;       /* matches of the pass, queries that needed more than their 3x3x3 block, queries on an exact tie */
   double HTH[144], HTh[12];      /* want_log only: the pass's sums, */
@@ -204,13 +208,15 @@ typedef struct flimo_chain_io {
   /* out */
   int status, reason;
   int passes;                    /* outer iterations completed on the device */
-  int it_next, t;                /* loop variables after them (it_next = -1 + passes) */
-  double x26_out[26], P_out[529];/* P_out only with FLIMO_CHAIN_DONE */
+  int it_next, t;                /* loop variables to resume with (it_next = -1 + passes) */
+  double x26_out[26];            /* x_ at that iteration */
+  int meas_valid, meas_M;        /* that iteration's pass: usable sums (reasons FINAL, DEGENERATE) */
+  double meas_HTH[144], meas_HTh[12];
   flimo_chain_pass log[FLIMO_CHAIN_MAX_PASSES];   /* entries 0 .. passes - 1 (+ the handed-back iteration's M / stragglers / ties) */
 } flimo_chain_io;
 int flimo_update_chain(flimo_ctx* ctx, const flimo_match_cfg* cfg, flimo_chain_io* io);
-/* out[0] = GPU ms of the algebra kernels timed so far (timing level 1), out[1] = their number, out[2] = chains run,
- * out[3] = chains handed back to the host filter, out[4] = chains declined */
+/* out[0] = GPU ms of the algebra launches timed so far (timing level 1; only with FLIMO_CHAIN_INLINE=0), out[1] = their number,
+ * out[2] = chains run, out[3] = chains that came back before the final iteration, out[4] = chains declined */
 int flimo_chain_stats(flimo_ctx* ctx, double out[5], int reset);
 /* per-point records of the last flimo_match_reduce (first min(N, MAX_NUM_PC2MATCH) points) */
 int flimo_match_fetch(flimo_ctx* ctx, flimo_match_rec* out, size_t cap, size_t* n);

@@ -1,5 +1,5 @@
-"""GPU parity: the whole iterated update enqueued at once (flimo_update_chain: pass -> one-block algebra kernel -> pass ...,
-flimo_chain.h / flimo_ieskf.hip) against the host loop over single passes (flimo_match_reduce + flimo_host::Esekf, the layout of
+"""GPU parity: the iterations of the update enqueued at once (flimo_update_chain: the filter's algebra inside each pass's reducing
+launch, flimo_chain.h / flimo_ieskf.h) against the host loop over single passes (flimo_match_reduce + flimo_host::Esekf, the layout of
 rounds 1-3, kept behind FLIMO_HOST_UPDATE=1) and against the golden per-pass vectors.  Reference: esekf::
 update_iterated_dyn_share_modified, IKFoM_toolkit/esekfom/esekfom.hpp:1620-1823."""
 import os
@@ -98,8 +98,9 @@ def test_chain_hands_back_what_it_does_not_run(built, oracle):
     np.testing.assert_allclose(Pd, Ph, rtol=1e-9, atol=1e-10)
 
 
-def test_raw_chain_entry_point_declines_what_needs_records(built):
-    """C ABI directly: caps that bind need the per-point records -> FLIMO_CHAIN_DECLINED and nothing is changed."""
+def test_raw_chain_entry_point(built):
+    """C ABI directly: caps that bind need the per-point records -> FLIMO_CHAIN_DECLINED and nothing is changed; otherwise the loop comes
+    back at the iteration that ends it, with that iteration's sums."""
     from fast_limo_amd import _lib
     mp, scan5, _ = cfg1_scene()
     h = _lib.HipCtx()
@@ -111,11 +112,43 @@ def test_raw_chain_entry_point_declines_what_needs_records(built):
     n0 = h.pass_count()
     r = h.update_chain(_lib.default_match_cfg(MAX_NUM_MATCHES=100, MAX_NUM_PC2MATCH=10**7), x, P, lim)
     assert r["status"] == 0 and h.pass_count() == n0
-    r = h.update_chain(_lib.default_match_cfg(MAX_NUM_MATCHES=10**7, MAX_NUM_PC2MATCH=10**7), x, P, lim, max_iter=3)
-    assert r["status"] == 1 and 1 <= r["passes"] <= 4 and h.pass_count() == n0 + r["passes"]
+    cfg = _lib.default_match_cfg(MAX_NUM_MATCHES=10**7, MAX_NUM_PC2MATCH=10**7)
+    r = h.update_chain(cfg, x, P, lim, max_iter=3)
+    assert r["status"] == 2 and r["reason"] == 5 and 0 <= r["passes"] <= 3, r
+    assert h.pass_count() == n0 + r["passes"] + 1 and r["it_next"] == r["passes"] - 1
+    assert r["meas"] is not None and r["meas"]["M"] == r["log"][r["passes"]]["M"] > 1000
     assert all(p["M"] > 1000 for p in r["log"])
-    # the same registration pass by pass through flimo_match_reduce: the first pass's sums are identical
-    HTH, HTh, M = h.match_reduce(x, _lib.default_match_cfg(MAX_NUM_MATCHES=10**7, MAX_NUM_PC2MATCH=10**7))
-    assert M == r["log"][0]["M"]
-    np.testing.assert_array_equal(HTH, r["log"][0]["HTH"])
+    # the handed-back iteration's pass once more, through flimo_match_reduce at the handed-back state: the same matches; the sums
+    # agree to rounding (the two may split the scan into different partial sums)
+    HTH, HTh, M = h.match_reduce(r["x"], cfg)
+    assert M == r["meas"]["M"]
+    np.testing.assert_allclose(HTH, r["meas"]["HTH"], rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose(HTh, r["meas"]["HTh"], rtol=1e-11, atol=1e-9)
     h.close()
+
+
+def test_chain_with_the_algebra_as_its_own_launch_is_bit_equal(built):
+    """FLIMO_CHAIN_INLINE=0 (A/B): the measurement-dependent half of an iteration as a one-workgroup launch behind the pass -- same
+    routine, same bits as inside the pass's reducing launch."""
+    from fast_limo_amd import api
+    mp, scan5, imu = cfg1_scene(n_map=200000, n_scan=16384, L=40.0)
+    out = []
+    for inline in ("1", "0"):
+        old = os.environ.get("FLIMO_CHAIN_INLINE")
+        os.environ["FLIMO_CHAIN_INLINE"] = inline
+        try:
+            D = api.Localizer(api.default_cfg(**CAPS))
+        finally:
+            if old is None:
+                del os.environ["FLIMO_CHAIN_INLINE"]
+            else:
+                os.environ["FLIMO_CHAIN_INLINE"] = old
+        D.set_flags(add_to_map=False, keep_log=True)
+        assert drive_two_scans(D, mp, scan5, imu) == [1, 0]
+        assert D.hip.chain_stats()["chains"] >= 1
+        out.append((D.get_x().copy(), D.get_P().copy(), [p["dx"] for p in D.passes()]))
+        D.close()
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    for a, b in zip(out[0][2], out[1][2]):
+        np.testing.assert_array_equal(a, b)

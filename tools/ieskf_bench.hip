@@ -1,8 +1,7 @@
-// tools/ieskf_bench.hip -- developer tool (GPU box): the device filter's algebra kernel (fast_limo_amd/csrc/hip/flimo_ieskf.hip) on
-// its own: duration per launch (HIP events on the dispatch) and parity with the host filter (csrc/host/flimo_ikfom.cpp) on
-// synthetic sums -- the same H^T H / H^T h in every iteration, like flimo_eskf_update_fixed.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Ifast_limo_amd/csrc/hip -Ifast_limo_amd/csrc/host -Iinclude \
-//         tools/ieskf_bench.hip fast_limo_amd/csrc/host/flimo_ikfom.cpp -o tools/ieskf_bench
+// tools/ieskf_bench.hip -- developer tool (GPU box): the device filter's algebra (fast_limo_amd/csrc/hip/flimo_ieskf.h) on its own,
+// as the two one-workgroup launches of the A/B form (flimo_ieskf.hip): duration per launch (HIP events on the dispatch), phase
+// stamps, bit-reproducibility, and parity with the host filter (csrc/host/flimo_ikfom.cpp) on synthetic sums -- the same H^T H /
+// H^T h in every iteration, like flimo_eskf_update_fixed.   Build: tools/ieskf_bench.sh
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdio.h>
@@ -22,7 +21,6 @@ int main(int argc, char** argv) {
   const int max_iter = 3;
   std::mt19937_64 rng(7);
   std::normal_distribution<double> N01(0.0, 1.0);
-  // a plausible prior: attitude near identity, P = diag-dominant SPD
   double x[26] = {0};
   x[0] = 0.3; x[1] = -0.2; x[2] = 0.1;
   { const double a = 0.02; x[3] = 0; x[4] = 0; x[5] = sin(a / 2); x[6] = cos(a / 2); }
@@ -34,7 +32,6 @@ int main(int argc, char** argv) {
     for (int i = 0; i < 529; i++) A[i] = 0.02 * N01(rng);
     for (int i = 0; i < 23; i++) for (int j = 0; j < 23; j++) { double s = 0; for (int k = 0; k < 23; k++) s += A[i * 23 + k] * A[j * 23 + k]; P[i * 23 + j] = 1e-3 * s + (i == j ? 1e-4 : 0.0); }
   }
-  // sums of M random measurement rows
   const int M = 5000;
   double HTH[144] = {0}, HTh[12] = {0};
   for (int m = 0; m < M; m++) {
@@ -53,7 +50,6 @@ int main(int argc, char** argv) {
   f.init(max_iter, limits); f.keep_log = true;
   f.h_reduced = [&](const flimo_host::StateIkfom&, flimo_host::ReducedMeas& o) { o.M = M; memcpy(o.HTH, HTH, sizeof(HTH)); memcpy(o.HTh, HTh, sizeof(HTh)); };
   f.update_iterated_dyn_share_modified(0.001, 5.0);
-  double xh[26]; f.get_x().to_flat(xh);
   // ---- device ----
   ChainState* S; CK(hipMalloc(&S, sizeof(ChainState))); CK(hipMemset(S, 0, sizeof(ChainState)));
   double2* gran; CK(hipMalloc(&gran, FIT_GROUPS * FIT_LIVE_PAD * sizeof(double2)));
@@ -72,85 +68,82 @@ int main(int argc, char** argv) {
   ChainPrior* pr; CK(hipHostMalloc((void**)&pr, sizeof(ChainPrior), hipHostMallocMapped));
   memcpy(pr->x, x, sizeof(x)); memcpy(pr->P, P, sizeof(P)); memcpy(pr->limit, limits, sizeof(limits));
   pr->R = 0.001; pr->D = 5.0; pr->max_iter = max_iter; pr->pad = 0;
-  { PoseMats P0; pose_from_x26(x, P0); memcpy(pr->RT0, P0.RT, sizeof(pr->RT0)); }
+  ik_pre_serial(x, x, P, 0.001, pr->dxn, pr->PR);
+  PoseMats P0; pose_from_x26(x, P0);
   double* res; CK(hipHostMalloc((void**)&res, CH_RES * 2 * sizeof(double), hipHostMallocMapped)); memset(res, 0, CH_RES * 2 * sizeof(double));
   double* lg; CK(hipHostMalloc((void**)&lg, CH_MAX_PASSES * CH_LOGN * 2 * sizeof(double), hipHostMallocMapped));
+  unsigned int* t3; CK(hipMalloc(&t3, 4)); CK(hipMemset(t3, 0, 4));
   hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-  hipEvent_t e[8]; for (auto& v : e) CK(hipEventCreate(&v));
-  double tsum[4] = {0, 0, 0, 0}; int passes_dev = 0;
-  for (int r = 0; r < reps; r++) {
-    for (int i = 0; i <= max_iter; i++)
-      launch_ieskf(st, S, gran, seq, i == 0 ? pr : nullptr, res, r == 0 ? lg : nullptr, tag + r, e[2 * i], e[2 * i + 1]);
+  hipEvent_t e[16]; for (auto& v : e) CK(hipEventCreate(&v));
+  ChainCtl ctl{};
+  ctl.S = S; ctl.gran = gran; ctl.res = (double2*)res; ctl.log = (double2*)lg; ctl.tag = tag; ctl.ticket3 = t3; ctl.inline_alg = 0;
+  auto chain = [&](unsigned long long tg, bool log, bool ev) {
+    for (int i = 0; i <= max_iter; i++) {
+      ChainCtl c2 = ctl; c2.tag = tg; c2.log = log ? ctl.log : nullptr; c2.prior = i == 0 ? pr : nullptr;
+      launch_ieskf_extra(st, c2, ev ? e[4 * i] : nullptr, ev ? e[4 * i + 1] : nullptr);
+      launch_ieskf(st, c2, seq, i == 0 ? P0.RT : nullptr, ev ? e[4 * i + 2] : nullptr, ev ? e[4 * i + 3] : nullptr);
+    }
     CK(hipStreamSynchronize(st));
-    passes_dev = (int)llround(res[2 * CH_PASSES]);
-    for (int i = 0; i < passes_dev && i < 4; i++) { float ms = 0; CK(hipEventElapsedTime(&ms, e[2 * i], e[2 * i + 1])); if (r >= reps / 4) tsum[i] += ms; }
+  };
+  double tx[4] = {0, 0, 0, 0}, tf[4] = {0, 0, 0, 0};
+  for (int r = 0; r < reps; r++) {
+    chain(tag + r, r == 0, true);
+    for (int i = 0; i <= max_iter; i++) {
+      float a = 0, b = 0;
+      CK(hipEventElapsedTime(&a, e[4 * i], e[4 * i + 1])); CK(hipEventElapsedTime(&b, e[4 * i + 2], e[4 * i + 3]));
+      if (r >= reps / 4) { tx[i] += a; tf[i] += b; }
+    }
   }
-  // bit-reproducibility of the result granules, chain after chain (same inputs)
+  const int nt = reps - reps / 4;
+  const int passes_dev = (int)llround(res[2 * CH_PASSES]);
+  printf("device: status %d reason %d iterations completed %d, it_next %d t %d (host filter logged %zu passes)\n", (int)llround(res[2 * CH_STATUS]),
+         (int)llround(res[2 * CH_BAIL]), passes_dev, (int)llround(res[2 * CH_IT]), (int)llround(res[2 * CH_T]), f.log.size());
+  printf("extra workgroup (measurement-independent half) [us]: first (copies the prior) %.2f, then %.2f %.2f %.2f\n", 1e3 * tx[0] / nt, 1e3 * tx[1] / nt, 1e3 * tx[2] / nt, 1e3 * tx[3] / nt);
+  printf("final stage (sums -> next state) [us]: %.2f %.2f %.2f, handing back %.2f\n", 1e3 * tf[0] / nt, 1e3 * tf[1] / nt, 1e3 * tf[2] / nt, 1e3 * tf[3] / nt);
+  double dlog = 0, dxa = 0;
+  for (int p = 0; p < passes_dev && p < (int)f.log.size(); p++) {
+    for (int k = 0; k < 23; k++) dlog = fmax(dlog, fabs(lg[2 * (p * CH_LOGN + 156 + k)] - f.log[p].dx[k]));
+    for (int k = 0; k < 26; k++) dxa = fmax(dxa, fabs(lg[2 * (p * CH_LOGN + 179 + k)] - f.log[p].x_after[k]));
+  }
+  double dxm = 0;
+  if (passes_dev >= 1) for (int k = 0; k < 26; k++) dxm = fmax(dxm, fabs(res[2 * (CH_X + k)] - f.log[passes_dev - 1].x_after[k]));
+  printf("vs host filter: per-pass step %.3e, state after each pass %.3e, handed-back state %.3e; sums handed back: M %.0f HTH[0] %.17g (in %.17g)\n", dlog, dxa, dxm,
+         res[2 * (CH_SUMS + 90)], res[2 * CH_SUMS], HTH[0]);
   {
     std::vector<double> ref(CH_RES);
     for (int k = 0; k < CH_RES; k++) ref[k] = res[2 * k];
-#ifdef IESKF_STAMPS
-    static double dref[8][529], dcur[8][529];
-    CK(hipMemcpyFromSymbol(dref, HIP_SYMBOL(g_ik_dbg), sizeof(dref)));
-    int shown = 0;
-#endif
-    long bad_chains = 0, bad_vals = 0; int first_bad = -1;
-    const int nrep = reps * 20;
+    long bad = 0;
+    const int nrep = reps * 10;
     for (int r = 0; r < nrep; r++) {
-      for (int i = 0; i <= max_iter; i++) launch_ieskf(st, S, gran, seq, i == 0 ? pr : nullptr, res, nullptr, tag + 100000 + r);
-      CK(hipStreamSynchronize(st));
-      int nb = 0;
-      for (int k = 0; k < CH_RES; k++) if (memcmp(&ref[k], &res[2 * k], 8) != 0) { nb++; if (first_bad < 0) first_bad = k; }
-      if (nb) { bad_chains++; bad_vals += nb; }
-#ifdef IESKF_STAMPS
-      if (nb && shown < 4) {
-        shown++;
-        CK(hipMemcpyFromSymbol(dcur, HIP_SYMBOL(g_ik_dbg), sizeof(dcur)));
-        const char* nm[6] = {"L (end)", "P_ (end)", "K_x (end)", "J (end)", "P_ (cov start)", "J (cov start)"};
-        for (int a = 0; a < 6; a++) {
-          int cnt = 0, first = -1;
-          for (int k = 0; k < 529; k++) if (memcmp(&dref[a][k], &dcur[a][k], 8) != 0) { cnt++; if (first < 0) first = k; }
-          if (cnt) printf("  chain %d: %s differs in %d values, first %d (row %d col %d)\n", r, nm[a], cnt, first, first / 23, first % 23);
-        }
-      }
-#endif
+      chain(tag + 100000 + r, false, false);
+      for (int k = 0; k < CH_RES; k++) if (memcmp(&ref[k], &res[2 * k], 8) != 0) { bad++; break; }
     }
-    printf("reproducibility: %ld of %d chains differ from the first (%ld values; first differing slot %d, CH_P = %d)\n", bad_chains, nrep, bad_vals, first_bad, CH_P);
+    printf("reproducibility: %ld of %d chains differ from the first\n", bad, nrep);
   }
-  const int nt = reps - reps / 4;
-  printf("device: status %d bail %d passes %d (host %zu)\n", (int)llround(res[2 * CH_STATUS]), (int)llround(res[2 * CH_BAIL]), passes_dev, f.log.size());
-  printf("algebra kernel [us]: first (prior from mapped memory) %.2f, middle %.2f %.2f, last (covariance) %.2f\n", 1e3 * tsum[0] / nt, 1e3 * tsum[1] / nt,
-         1e3 * tsum[2] / nt, 1e3 * tsum[passes_dev - 1 < 4 ? passes_dev - 1 : 3] / nt);
-  double dxm = 0, dPm = 0, dPrel = 0;
-  for (int i = 0; i < 26; i++) dxm = fmax(dxm, fabs(res[2 * (CH_X + i)] - xh[i]));
-  for (int i = 0; i < 529; i++) { const double a = res[2 * (CH_P + i)], b = f.get_P().a[i / 23][i % 23]; dPm = fmax(dPm, fabs(a - b)); dPrel = fmax(dPrel, fabs(a - b) / (fabs(b) + 1e-30)); }
-  double dlog = 0;
-  for (size_t p = 0; p < f.log.size() && (int)p < passes_dev; p++)
-    for (int k = 0; k < 23; k++) dlog = fmax(dlog, fabs(lg[2 * (p * CH_LOGN + 156 + k)] - f.log[p].dx[k]));
-  printf("vs host filter: max |dx state| %.3e, per-pass step %.3e, |dP| %.3e (rel %.3e)\n", dxm, dlog, dPm, dPrel);
 #ifdef IESKF_STAMPS
   {
-    // phase stamps of a middle iteration and of the last one (10 ns resolution)
-    const char* names[12] = {"start", "loaded", "pre: chains done", "P re-projected", "T built", "LU done", "solved", "dx_", "boxplus", "cov: start", "END (middle)", "END (last)"};
+    const char* names[12] = {"start", "loaded", "", "", "T, v built", "GJ done", "", "u, dx_ (+ Cholesky test)", "boxplus + conv", "", "END (goes on)", "END (hands back)"};
     for (int which = 0; which < 2; which++) {
-      launch_ieskf(st, S, gran, seq, pr, res, nullptr, tag + 5000);
-      launch_ieskf(st, S, gran, seq, nullptr, res, nullptr, tag + 5000);
-      if (which) { launch_ieskf(st, S, gran, seq, nullptr, res, nullptr, tag + 5000); launch_ieskf(st, S, gran, seq, nullptr, res, nullptr, tag + 5000); }
+      const int upto = which ? max_iter : 1;
+      for (int i = 0; i <= upto; i++) {
+        ChainCtl c2 = ctl; c2.tag = tag + 5000; c2.log = nullptr; c2.prior = i == 0 ? pr : nullptr;
+        launch_ieskf_extra(st, c2);
+        launch_ieskf(st, c2, seq, i == 0 ? P0.RT : nullptr);
+      }
       CK(hipStreamSynchronize(st));
       unsigned long long t[32];
       CK(hipMemcpyFromSymbol(t, HIP_SYMBOL(g_ik_stamps), sizeof(t)));
-      printf("%s iteration:", which ? "last" : "middle");
-      for (int k = 1; k < 12; k++) if ((which ? k != 10 : k < 9 || k == 10)) printf("  %s +%.2f", names[k], 0.01 * (double)(long long)(t[k] - t[0]));
+      printf("%s iteration:", which ? "handing-back" : "middle");
+      for (int k = 1; k < 12; k++) if (names[k][0] && (which ? k != 10 : k != 11)) printf("  %s +%.2f", names[k], 0.01 * (double)(long long)(t[k] - t[0]));
       printf(" us\n");
     }
   }
 #endif
-  // back-to-back chain of 4 algebra kernels with nothing between: wall time per kernel incl. the dispatch boundary
   CK(hipEventRecord(e[0], st));
   for (int r = 0; r < reps; r++)
-    for (int i = 0; i <= max_iter; i++) launch_ieskf(st, S, gran, seq, i == 0 ? pr : nullptr, res, nullptr, tag + 1000 + r);
+    for (int i = 0; i <= max_iter; i++) { ChainCtl c2 = ctl; c2.tag = tag + 9000 + r; c2.log = nullptr; c2.prior = i == 0 ? pr : nullptr; launch_ieskf(st, c2, seq, i == 0 ? P0.RT : nullptr); }
   CK(hipEventRecord(e[1], st)); CK(hipStreamSynchronize(st));
   float ms = 0; CK(hipEventElapsedTime(&ms, e[0], e[1]));
-  printf("back to back: %.2f us per launch (kernel + boundary)\n", 1e3 * ms / (reps * (max_iter + 1)));
+  printf("back to back: %.2f us per final-stage launch (kernel + boundary)\n", 1e3 * ms / (reps * (max_iter + 1)));
   return 0;
 }
