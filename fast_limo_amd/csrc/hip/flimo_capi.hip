@@ -190,6 +190,7 @@ struct flimo_ctx {
   size_t tie_cap = 0;
   bool ties = true;                // FLIMO_TIES=0: leave ties to the position rule (A/B checks)
   unsigned long long tie_redos = 0, tie_queries = 0;
+  unsigned long long* d_tie_settled = nullptr;   // queries whose ties were settled inside a reducing launch (tie_repair_wave), counted on the device
   bool force_general_k = false;    // FLIMO_GENERAL_K=1: NUM_MATCH_POINTS == 5 also takes the general (any-k) pass (A/B checks)
   void* d_nbrk = nullptr;          // neighbour records of the general pass
   size_t nbrk_cap = 0;
@@ -206,7 +207,8 @@ struct flimo_ctx {
   double* h_chain_log = nullptr;         // mapped: CH_MAX_PASSES x CH_LOGN log granules
   void* d_chain_log = nullptr;
   unsigned long long chain_tag = 0x4000000000000000ull;   // tag of the last chain (own number space)
-  bool chain_inline = true;              // FLIMO_CHAIN_INLINE=0: the measurement-dependent half of an iteration as a launch of its own behind the pass (A/B)
+  bool chain_inline = false;             // FLIMO_CHAIN_INLINE=1: the measurement-dependent half of an iteration inside the pass's reducing launch (run by the
+                                         // workgroup that completes it) instead of a one-workgroup launch of its own behind the pass
   bool combined_err_check = true;
   bool host_update = false;              // FLIMO_HOST_UPDATE=1: flimo_update_chain always declines (the host loop runs the update; A/B)
   hipEvent_t chain_ev[CH_MAX_PASSES][6]; // per pass: [0,1] first launch, [2,3] second launch, [4,5] algebra kernel (lazy)
@@ -284,8 +286,9 @@ static int ensure_dev(flimo_ctx* c, T*& p, size_t& cap, size_t need, bool keep, 
 //   FLIMO_WIDEN_FIT=0             widening and fit of a separate-dispatch pass as two launches (default: one, widen_fit_kernel)
 //   FLIMO_HOST_UPDATE=1           the iterated update runs as a host loop over single passes (default: the whole update is enqueued at
 //                                 once, flimo_update_chain)
-//   FLIMO_CHAIN_INLINE=0          chained update: the filter's measurement-dependent half as a launch of its own behind each pass
-//                                 (default: inside the pass's reducing launch, run by the workgroup that completes it)
+//   FLIMO_CHAIN_INLINE=1          chained update: the filter's measurement-dependent half inside the pass's reducing launch, run by the
+//                                 workgroup that completes it (default: a one-workgroup launch of its own behind each pass -- the same
+//                                 step time within 1 %, and the pass kernel's duration stays the pass's)
 //   FLIMO_PROF_PASS / FLIMO_PROF_INSERT   host-side timing prints (stderr)
 // (csrc/host: FLIMO_REFERENCE_SOLVE=1 literal two-inverse gain, FLIMO_SYNC_INSERT=1 map inserts on the caller's thread,
 //  FLIMO_PROF_DESKEW / FLIMO_PROF_CLOUDS timing prints; bench.py: FLIMO_BENCH_*.)
@@ -358,6 +361,8 @@ extern "C" int flimo_ctx_create(int device, flimo_ctx** out) {
             hipHostGetDevicePointer(&c->d_chain_res, c->h_chain_res, 0) == hipSuccess &&
             hipHostMalloc((void**)&c->h_chain_log, (size_t)CH_MAX_PASSES * CH_LOGN * 2 * sizeof(double), hipHostMallocMapped) == hipSuccess &&
             hipHostGetDevicePointer(&c->d_chain_log, c->h_chain_log, 0) == hipSuccess &&
+            hipMalloc((void**)&c->d_tie_settled, sizeof(unsigned long long)) == hipSuccess &&
+            hipMemset(c->d_tie_settled, 0, sizeof(unsigned long long)) == hipSuccess &&
             hipMalloc(&c->d_wl_count, sizeof(int)) == hipSuccess &&
             hipMemset(c->d_wl_count, 0, sizeof(int)) == hipSuccess &&
             hipHostMalloc((void**)&c->h_wl_count, sizeof(int), hipHostMallocDefault) == hipSuccess &&
@@ -414,7 +419,7 @@ extern "C" void flimo_ctx_destroy(flimo_ctx* c) {
   (void)hipFree(c->d_fit2_partials);
   if (c->h_cand) (void)hipHostFree(c->h_cand);
   if (c->h_wf_err) (void)hipHostFree(c->h_wf_err);
-  (void)hipFree(c->d_chain); (void)hipFree(c->d_chain_gran);
+  (void)hipFree(c->d_chain); (void)hipFree(c->d_chain_gran); (void)hipFree(c->d_tie_settled);
   if (c->h_chain_prior) (void)hipHostFree(c->h_chain_prior);
   if (c->h_chain_res) (void)hipHostFree(c->h_chain_res);
   if (c->h_chain_log) (void)hipHostFree(c->h_chain_log);
@@ -925,7 +930,7 @@ extern "C" int flimo_knn(flimo_ctx* c, const float* q, size_t nq, int k, int32_t
   HIPCHK(c, hipMemcpyAsync(d.q, q, nq * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
   launch_knn(c->stream, c->grid, d.q, (int)nq, k, 1 << 29, d.idx, d.sqd, d.cnt);
   if (c->ties && c->gbook.active) {    // exactly tied distances: the reference's first-met choice (device copy of its octree)
-    const BookView book{c->gbook.node_c, c->gbook.node_child, c->gbook.node_cnt, c->gbook.root};
+    const BookView book{c->gbook.node_c, c->gbook.node_child, c->gbook.node_cnt, c->gbook.root, c->d_tie_settled};
     launch_knn_tie(c->stream, c->grid, book, d.q, (int)nq, k, d.idx, d.sqd, d.cnt);
   }
   HIPCHK(c, hipGetLastError());
@@ -1306,6 +1311,10 @@ extern "C" int flimo_fine_stats(const flimo_ctx* c, unsigned long long out[4]) {
 extern "C" int flimo_tie_stats(const flimo_ctx* c, unsigned long long out[2]) {
   if (!c || !out) return FLIMO_ERR_INVALID;
   out[0] = c->tie_redos; out[1] = c->tie_queries;
+  // + the queries settled inside the reducing launches (counted on the device; the stream is drained for the read)
+  unsigned long long dev = 0;
+  (void)hipSetDevice(c->device);
+  if (c->d_tie_settled && hipMemcpy(&dev, c->d_tie_settled, sizeof(dev), hipMemcpyDeviceToHost) == hipSuccess) out[1] += dev;
   return FLIMO_OK;
 }
 extern "C" int flimo_set_timing_stride(flimo_ctx* c, int every) { if (!c || every < 1) return FLIMO_ERR_INVALID; c->timing_stride = every; return FLIMO_OK; }
@@ -1505,7 +1514,7 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
       c->nbrk_cap = cap;
     }
     c->prev.valid = 0;                                 // the 5-NN records of this scan (pruning bound) are not maintained here
-    const BookView bookk{c->gbook.node_c, c->gbook.node_child, c->gbook.node_cnt, c->gbook.root};
+    const BookView bookk{c->gbook.node_c, c->gbook.node_child, c->gbook.node_cnt, c->gbook.root, nullptr};
     if (!launch_match_k(c->stream, cfg->NUM_MATCH_POINTS, c->grid, c->d_scan_sorted, n_all, P, mp, c->d_nbrk, c->d_recs, c->d_dbg,
                         (c->ties && c->gbook.active) ? &bookk : nullptr))
       return fail(c, FLIMO_ERR_UNSUPPORTED, "NUM_MATCH_POINTS out of range");
@@ -1563,8 +1572,12 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   const bool ties_on = c->ties && c->gbook.active;
   TieList tl{};
   tl.count_next = c->d_tie_count + ((seq + 1) & 1);            // re-armed by this pass's reduction for the next pass
-  if (ties_on) { tl.list = c->d_tie_list; tl.count = c->d_tie_count + (seq & 1); tl.cap = (unsigned)c->tie_cap; }
-  const BookView book{c->gbook.node_c, c->gbook.node_child, c->gbook.node_cnt, c->gbook.root};
+  // The per-pass fast paths (one launch / k-NN + widening + fit2) settle ties where they build the rows (tie_repair_wave): no list,
+  // the count they publish stays 0.  The records / caps / debug path lists them for tie_kernel as before.
+  const bool inline_ties = ties_on && !want_recs && tlev < 2;
+  if (ties_on && !inline_ties) { tl.list = c->d_tie_list; tl.count = c->d_tie_count + (seq & 1); tl.cap = (unsigned)c->tie_cap; }
+  const BookView book{c->gbook.node_c, c->gbook.node_child, c->gbook.node_cnt, c->gbook.root, c->d_tie_settled};
+  const BookView* bookp = inline_ties ? &book : nullptr;
   // crowded regions first: the fine pre-pass settles the queries whose five lie within centimetres (second-level grid)
   const bool after_fine = c->fine_valid && c->lanes_per_query == 2 && mp.max_ring >= 1;
   if (after_fine) {
@@ -1574,7 +1587,7 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   if (fused) {
     launch_match_fused(c->stream, c->grid, c->d_scan_sorted, n_all, P, mp, c->d_nbr, c->d_wl, c->d_wl_count, nullptr, c->prev,
                        c->live_idx, c->d_fit2_partials, c->d_granules_host, c->d_ticket, seq, tlev == 1 ? c->ev[0] : nullptr,
-                       tlev == 1 ? c->ev[1] : nullptr, &tl, after_fine ? 1 : 0, dkp);
+                       tlev == 1 ? c->ev[1] : nullptr, &tl, after_fine ? 1 : 0, dkp, nullptr, nullptr, bookp);
     c->fused_passes++;
   } else
   launch_knn5(c->stream, c->lanes_per_query, c->grid, c->d_scan_sorted, n_all, P, mp.max_ring, c->d_nbr, c->d_wl,
@@ -1589,7 +1602,7 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   if (combined)
     launch_widen_fit(c->stream, c->grid, c->d_scan_sorted, n_all, P, mp, c->d_nbr, c->d_wl, c->d_wl_count, nullptr, c->live_idx,
                      c->d_fit2_partials, c->d_granules_host, c->d_ticket, seq, tlev == 1 ? c->ev[2] : nullptr,
-                     tlev == 1 ? c->ev[3] : nullptr, &tl, &tl, c->d_wf_err);
+                     tlev == 1 ? c->ev[3] : nullptr, &tl, &tl, c->d_wf_err, nullptr, nullptr, bookp);
   else if (!tail)
     launch_widen(c->stream, c->grid, c->d_scan_sorted, P, mp.max_ring, c->d_nbr, c->d_wl, c->d_wl_count,
                  c->debug_recs ? c->d_cand : nullptr, widen_timed ? c->ev[4] : nullptr, widen_timed ? c->ev[5] : nullptr, &tl);
@@ -1606,7 +1619,7 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
     // the fit and the reduction ran inside the k-NN launch / the widening launch
   } else if (use_fit2)
     launch_fit2(c->stream, c->grid, c->d_scan_sorted, n_all, c->d_nbr, P, mp, c->live_idx, c->d_fit2_partials, c->d_granules_host,
-                c->d_ticket, c->d_wl_count, seq, tlev == 1 ? c->ev[2] : nullptr, tlev == 1 ? c->ev[3] : nullptr, &tl);
+                c->d_ticket, c->d_wl_count, seq, tlev == 1 ? c->ev[2] : nullptr, tlev == 1 ? c->ev[3] : nullptr, &tl, nullptr, nullptr, bookp);
   else {
     // records / caps / debug / timing level 2 (synchronous): settle the ties before the rows are built, re-arm both counters after
     HIPCHK(c, hipGetLastError());
@@ -1832,6 +1845,8 @@ extern "C" int flimo_update_chain(flimo_ctx* c, const flimo_match_cfg* cfg, flim
   const unsigned long long tag = ++c->chain_tag;
   const unsigned long long seq0 = c->pass_seq;
   const bool ties_on = c->ties && c->gbook.active;
+  const BookView book{c->gbook.node_c, c->gbook.node_child, c->gbook.node_cnt, c->gbook.root, c->d_tie_settled};
+  const BookView* bookp = ties_on ? &book : nullptr;
   const ChainHead* head = reinterpret_cast<const ChainHead*>(c->d_chain);
   const int tail_max = c->tail_max > 0 ? c->tail_max : std::max(1024, n_all / 64);
   struct Plan { int pos; bool fused, combined, timed; };
@@ -1862,9 +1877,8 @@ extern "C" int flimo_update_chain(flimo_ctx* c, const flimo_match_cfg* cfg, flim
     ctl.prior = i == 0 ? c->d_chain_prior : nullptr;
     PrevPass pv = c->prev;
     pv.valid = prev_valid ? 1 : 0;            // (pass 0: the context's own bound, if any; later passes: RT comes from the device filter)
-    TieList tl{};
+    TieList tl{};                                // (ties are settled inside the reducing launches: nothing is listed)
     tl.count_next = c->d_tie_count + ((seq + 1) & 1);
-    if (ties_on) { tl.list = c->d_tie_list; tl.count = c->d_tie_count + (seq & 1); tl.cap = (unsigned)c->tie_cap; }
     if (after_fine) {
       launch_knn5_fine(c->stream, c->fine, c->d_scan_sorted, n_all, P0, c->d_nbr, pv, c->fine_qlo, c->fine_qhi, &tl, seq, ch);
       c->fine_passes++;
@@ -1873,18 +1887,18 @@ extern "C" int flimo_update_chain(flimo_ctx* c, const flimo_match_cfg* cfg, flim
     if (fused) {
       launch_match_fused(c->stream, c->grid, c->d_scan_sorted, n_all, P0, mp, c->d_nbr, c->d_wl, c->d_wl_count, nullptr, pv, c->live_idx,
                          c->d_fit2_partials, c->d_chain_gran, c->d_ticket, seq, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr, &tl,
-                         after_fine ? 1 : 0, dk, ch, &ctl);
+                         after_fine ? 1 : 0, dk, ch, &ctl, bookp);
     } else {
       launch_knn5(c->stream, 2, c->grid, c->d_scan_sorted, n_all, P0, mp.max_ring, c->d_nbr, c->d_wl, c->d_wl_count, nullptr, pv, 0,
                   ev ? ev[0] : nullptr, ev ? ev[1] : nullptr, nullptr, &tl, after_fine ? 1 : 0, seq, dk, ch);
       if (combined) {
         launch_widen_fit(c->stream, c->grid, c->d_scan_sorted, n_all, P0, mp, c->d_nbr, c->d_wl, c->d_wl_count, nullptr, c->live_idx,
                          c->d_fit2_partials, c->d_chain_gran, c->d_ticket, seq, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr, &tl, &tl,
-                         c->d_wf_err, ch, &ctl);
+                         c->d_wf_err, ch, &ctl, bookp);
       } else {
         launch_widen(c->stream, c->grid, c->d_scan_sorted, P0, mp.max_ring, c->d_nbr, c->d_wl, c->d_wl_count, nullptr, nullptr, nullptr, &tl, ch);
         launch_fit2(c->stream, c->grid, c->d_scan_sorted, n_all, c->d_nbr, P0, mp, c->live_idx, c->d_fit2_partials, c->d_chain_gran,
-                    c->d_ticket, c->d_wl_count, seq, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr, &tl, ch, &ctl);
+                    c->d_ticket, c->d_wl_count, seq, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr, &tl, ch, &ctl, bookp);
       }
     }
     if (!c->chain_inline)

@@ -52,13 +52,13 @@ int fit2_blocks(int n);
 void launch_fit2(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const void* nbr, const PoseMats& P,
                  const MatchParams& mp, const unsigned char* live_idx, double* partials, void* out_granules, unsigned int* ticket,
                  int* wl_count, unsigned long long seq, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, const TieList* ties = nullptr,
-                 const ChainHead* chain = nullptr, const ChainCtl* ctl = nullptr);
+                 const ChainHead* chain = nullptr, const ChainCtl* ctl = nullptr, const BookView* book = nullptr);
 // widening + fit of a separate-dispatch pass in one launch (max_ring 2..3): see widen_fit_kernel
 void launch_widen_fit(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const PoseMats& P, const MatchParams& mp,
                       void* nbr, int* wl, int* wl_count, unsigned long long* cand, const unsigned char* live_idx, double* partials,
                       void* out_granules, unsigned int* ticket, unsigned long long seq, hipEvent_t e0, hipEvent_t e1,
                       const TieList* tl_widen, const TieList* tl_fit, int* err, const ChainHead* chain = nullptr,
-                      const ChainCtl* ctl = nullptr);
+                      const ChainCtl* ctl = nullptr, const BookView* book = nullptr);
 // The whole measurement pass in ONE launch (k-NN fast path + in-kernel tail + fit + reduction + publish; two lanes per query, gates of
 // 2..3 rings): partials needs fused_blocks(n) * FIT_LIVE_PAD doubles; results arrive as launch_fit2's granules.
 int fused_blocks(int n);
@@ -67,11 +67,11 @@ void launch_match_fused(hipStream_t st, const GridView& G, const float4* scan_so
                         const unsigned char* live_idx, double* partials, void* out_granules, unsigned int* ticket,
                         unsigned long long seq, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, const TieList* ties = nullptr,
                         int after_fine = 0, const DeskewArgs* deskew = nullptr, const ChainHead* chain = nullptr,
-                        const ChainCtl* ctl = nullptr);
+                        const ChainCtl* ctl = nullptr, const BookView* book = nullptr);
 // The reference's choice among exactly tied distances (first met by Octree::knn's recursion): BookView = the device copy of the
 // octree (insert book), TieList = the queries a pass flagged.  launch_tie rewrites their neighbour records; launch_knn_tie does the
 // same for the output of launch_knn.
-struct BookView { const float4* node_c; const int* node_child; const int* node_cnt; int root; };
+struct BookView { const float4* node_c; const int* node_child; const int* node_cnt; int root; unsigned long long* settled; };   // settled (optional): queries whose ties were settled inside a reducing launch
 struct TieList { int* list; unsigned int* count; unsigned int cap; unsigned int* count_next; };
 void launch_tie(hipStream_t st, const GridView& G, const BookView& B, const float4* scan_sorted, const PoseMats& P, void* nbr,
                 const TieList& tl);

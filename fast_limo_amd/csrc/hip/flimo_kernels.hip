@@ -819,6 +819,7 @@ struct FuseArgs {
   unsigned int* ticket;
   unsigned long long seq;
   DeskewArgs dk;       // dk.on: first pass of a scan, the deskew rides on this launch
+  BookView book;       // book.node_c: exact distance ties are settled inside this launch, the reference's way (tie_repair_wave)
   ChainCtl ch;         // ch.S: a pass of a chained update (flimo_chain.h): the launch has one extra workgroup, and the workgroup
                        // that completes it goes on with the filter's algebra
 };
@@ -847,6 +848,45 @@ __device__ __forceinline__ void chain_arrive(const ChainCtl& ch, unsigned long l
 }
 FLIMO_DEV void fit_row(const GridView& G, const PoseMats& P, const MatchParams& mp, const int (&ids)[5], float gx, float gy, float gz,
                        float (&v)[16]);
+
+// Exact float32 distance ties, settled where the rows are built (every reducing launch): the wave takes its tied queries one at a
+// time -- every candidate with d <= d5 inside the proven block, ordered the reference's way by walking the device copy of its
+// octree (tie_select_wave, further down) -- and the owner lane goes on with the reference's five; the record is rewritten, its tie
+// bit cleared.  No list, no second launch, no host round trip.  Wave-wide; TS: the wave's own shared memory.
+struct TieLds;
+__device__ bool tie_select_wave(const GridView& G, const BookView& B, float qx, float qy, float qz, float dk, int k, TieLds& S,
+                                uint32_t (&out_pos)[8], float (&out_d)[8]);
+__device__ __forceinline__ void tie_repair_wave(const GridView& G, const BookView& B, NbrRec* __restrict__ nbr, bool mine_tied, int p,
+                                                float gx, float gy, float gz, uint32_t d5bits, int (&ids)[5], TieLds& TS) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long tm = __ballot(mine_tied);
+  while (tm) {                                                 // wave-uniform
+    const int tlane = __ffsll((long long)tm) - 1;
+    tm &= tm - 1ull;
+    const float qx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gx), tlane));
+    const float qy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gy), tlane));
+    const float qz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gz), tlane));
+    const float dk = __int_as_float(__builtin_amdgcn_readlane((int)d5bits, tlane));
+    uint32_t pos[8];
+    float d[8];
+#pragma unroll
+    for (int s_ = 0; s_ < 8; s_++) { pos[s_] = 0u; d[s_] = 0.f; }
+    wave_lds_sync();
+    const bool ok = tie_select_wave(G, B, qx, qy, qz, dk, 5, TS, pos, d);      // (the result is lane 0's)
+    int got[5];
+#pragma unroll
+    for (int s_ = 0; s_ < 5; s_++) got[s_] = __builtin_amdgcn_readlane((int)pos[s_], 0);
+    if (ok && lane == tlane) {
+#pragma unroll
+      for (int s_ = 0; s_ < 5; s_++) ids[s_] = got[s_];
+      int4* rec = reinterpret_cast<int4*>(&nbr[p]);
+      rec[0] = make_int4(got[0], got[1], got[2], got[3]);
+      rec[1] = make_int4(got[4], 1, (int)d5bits, 1);           // same 5th distance; the tie is settled
+      if (B.settled) atomicAdd(B.settled, 1ull);               // (statistics)
+    }
+    wave_lds_sync();
+  }
+}
 
 #ifdef FLIMO_WPE
 #define KNN_WPE __attribute__((amdgpu_waves_per_eu(FLIMO_WPE, FLIMO_WPE)))
@@ -1235,15 +1275,21 @@ __device__ __forceinline__ void knn5_pass(const GridView& G, const float4* __res
 #pragma unroll
     for (int i = 0; i < 16; i++) v[i] = 0.f;
     wave_lds_sync();                                           // the tail's hand-backs are visible; its tables are free
+    int ids[5] = {(int)(uint32_t)best[0], (int)(uint32_t)best[1], (int)(uint32_t)best[2], (int)(uint32_t)best[3], (int)(uint32_t)best[4]};
+    int fl = flag;
+    bool tied = tie;
+    uint32_t d5b = (uint32_t)(best[4] >> 32);
+    if (sub == 0 && in_range && pend_tail) {
+      const int4* rr = reinterpret_cast<const int4*>(W.res[lane]);
+      const int4 a = rr[0], b = rr[1];
+      ids[0] = a.x; ids[1] = a.y; ids[2] = a.z; ids[3] = a.w; ids[4] = b.x;
+      fl = b.y;
+      tied = (b.w & 2) != 0;
+      d5b = (uint32_t)b.z;
+    }
+    if (fa.book.node_c)
+      tie_repair_wave(G, fa.book, nbr, sub == 0 && in_range && fl == 1 && tied, p, gx, gy, gz, d5b, ids, *reinterpret_cast<TieLds*>(W.tile));
     if (sub == 0 && in_range) {
-      int ids[5] = {(int)(uint32_t)best[0], (int)(uint32_t)best[1], (int)(uint32_t)best[2], (int)(uint32_t)best[3], (int)(uint32_t)best[4]};
-      int fl = flag;
-      if (pend_tail) {
-        const int4* rr = reinterpret_cast<const int4*>(W.res[lane]);
-        const int4 a = rr[0], b = rr[1];
-        ids[0] = a.x; ids[1] = a.y; ids[2] = a.z; ids[3] = a.w; ids[4] = b.x;
-        fl = b.y;
-      }
       if (fl == 1 && __float_as_uint(sp.w) < (uint32_t)fa.mp.n_queries) fit_row(G, P, fa.mp, ids, gx, gy, gz, v);
     }
     wave_lds_sync();                                           // every lane is done with W.res before the tile overwrites the tables
@@ -1824,7 +1870,7 @@ __device__ __forceinline__ void fit2_pass(const GridView& G, const float4* __res
                                           const NbrRec* __restrict__ nbr, const PoseMats& P, const MatchParams& mp, const FitIdx& idx,
                                           double* __restrict__ partials, double2* __restrict__ out_granules,
                                           unsigned int* __restrict__ ticket, int* __restrict__ wl_count,
-                                          unsigned long long seq, const TieList& tl, const ChainCtl& ch) {
+                                          unsigned long long seq, const TieList& tl, const ChainCtl& ch, const BookView& book) {
   __shared__ __align__(16) float s_rec[4][16 * 65];       // per wave: [col][row] with stride 65
   __shared__ double s_acc[4][256];
   __shared__ unsigned int s_last;
@@ -1846,15 +1892,19 @@ __device__ __forceinline__ void fit2_pass(const GridView& G, const float4* __res
 #pragma unroll
   for (int i = 0; i < 16; i++) v[i] = 0.f;
   TRACE(1, 0);
-  if (lane < PPW && p < n) {
-    const float4 sp = scan_sorted[p];
-    const int4* nb = reinterpret_cast<const int4*>(&nbr[p]);
+  {
+    const bool mine = lane < PPW && p < n;
+    const float4 sp = scan_sorted[mine ? p : 0];
+    const int4* nb = reinterpret_cast<const int4*>(&nbr[mine ? p : 0]);
     const int4 a = nb[0], b = nb[1];
     float gx, gy, gz;
     xform4(P.RT, sp.x, sp.y, sp.z, gx, gy, gz);
-    const int ids[5] = {a.x, a.y, a.z, a.w, b.x};
+    int ids[5] = {a.x, a.y, a.z, a.w, b.x};
     TRACE(1, 1);
-    if (b.y == 1 && __float_as_uint(sp.w) < (uint32_t)mp.n_queries) fit_row(G, P, mp, ids, gx, gy, gz, v);
+    if (book.node_c)
+      tie_repair_wave(G, book, const_cast<NbrRec*>(nbr), mine && b.y == 1 && (b.w & 2) != 0, p, gx, gy, gz, (uint32_t)b.z, ids,
+                      *reinterpret_cast<TieLds*>(&s_rec[wave][0]));
+    if (mine && b.y == 1 && __float_as_uint(sp.w) < (uint32_t)mp.n_queries) fit_row(G, P, mp, ids, gx, gy, gz, v);
   }
   TRACE(1, 3);
   fit_reduce_publish<PPW>(v, lane < PPW, lane, s_rec[wave], s_acc[0], s_acc[1], s_acc[2], s_acc[3], &s_last, idx, partials,
@@ -1866,17 +1916,17 @@ __global__ __launch_bounds__(256) void fit2_kernel(GridView G, const float4* __r
                                                    const NbrRec* __restrict__ nbr, PoseMats P, MatchParams mp, FitIdx idx,
                                                    double* __restrict__ partials, double2* __restrict__ out_granules,
                                                    unsigned int* __restrict__ ticket, int* __restrict__ wl_count,
-                                                   unsigned long long seq, TieList tl, ChainCtl ch) {
-  fit2_pass<PPW>(G, scan_sorted, n, nbr, P, mp, idx, partials, out_granules, ticket, wl_count, seq, tl, ch);
+                                                   unsigned long long seq, TieList tl, ChainCtl ch, BookView book) {
+  fit2_pass<PPW>(G, scan_sorted, n, nbr, P, mp, idx, partials, out_granules, ticket, wl_count, seq, tl, ch, book);
 }
 template <int PPW>
 __global__ __launch_bounds__(256) void fit2_chain_kernel(GridView G, const float4* __restrict__ scan_sorted, int n,
                                                    const NbrRec* __restrict__ nbr, const ChainHead* __restrict__ H, MatchParams mp, FitIdx idx,
                                                    double* __restrict__ partials, double2* __restrict__ out_granules,
                                                    unsigned int* __restrict__ ticket, int* __restrict__ wl_count,
-                                                   unsigned long long seq, TieList tl, ChainCtl ch) {
+                                                   unsigned long long seq, TieList tl, ChainCtl ch, BookView book) {
   if (H->status != 0) return;
-  fit2_pass<PPW>(G, scan_sorted, n, nbr, H->pose, mp, idx, partials, out_granules, ticket, wl_count, seq, tl, ch);
+  fit2_pass<PPW>(G, scan_sorted, n, nbr, H->pose, mp, idx, partials, out_granules, ticket, wl_count, seq, tl, ch, book);
 }
 
 // Widening and fit of a pass that runs in separate dispatches (first pass of a poor prior) in ONE launch: the first `wblocks`
@@ -1891,7 +1941,8 @@ __device__ __forceinline__ void widen_fit_pass(const GridView& G, const float4* 
                                                unsigned long long* __restrict__ cand_total, int wblocks, const TieList& tl_widen,
                                                const MatchParams& mp, const FitIdx& idx, double* __restrict__ partials,
                                                double2* __restrict__ out_granules, unsigned int* __restrict__ ticket,
-                                               unsigned long long seq, const TieList& tl_fit, int* __restrict__ err, const ChainCtl& ch) {
+                                               unsigned long long seq, const TieList& tl_fit, int* __restrict__ err, const ChainCtl& ch,
+                                               const BookView& book) {
   __shared__ __align__(16) float s_rec[4][16 * 65];
   __shared__ double s_acc[4][256];
   __shared__ unsigned int s_last;
@@ -1918,6 +1969,11 @@ __device__ __forceinline__ void widen_fit_pass(const GridView& G, const float4* 
   float v[16];
 #pragma unroll
   for (int i = 0; i < 16; i++) v[i] = 0.f;
+  int ids[5] = {0, 0, 0, 0, 0};
+  bool row_ok = false, tied = false;
+  uint32_t d5b = 0u;
+  float4 qsp = make_float4(0.f, 0.f, 0.f, 0.f);
+  float qx = 0.f, qy = 0.f, qz = 0.f;
   if (p < n) {
     const float4 sp = scan_sorted[p];
     const int4* nb = reinterpret_cast<const int4*>(&nbr[p]);
@@ -1946,9 +2002,14 @@ __device__ __forceinline__ void widen_fit_pass(const GridView& G, const float4* 
         __builtin_amdgcn_s_sleep(16);
       }
     }
-    const int ids[5] = {a.x, a.y, a.z, a.w, b.x};
-    if (b.y == 1 && __float_as_uint(sp.w) < (uint32_t)mp.n_queries) fit_row(G, P, mp, ids, gx, gy, gz, v);
+    ids[0] = a.x; ids[1] = a.y; ids[2] = a.z; ids[3] = a.w; ids[4] = b.x;
+    row_ok = b.y == 1;
+    tied = row_ok && (b.w & 2) != 0;
+    d5b = (uint32_t)b.z;
+    qsp = sp; qx = gx; qy = gy; qz = gz;
   }
+  if (book.node_c) tie_repair_wave(G, book, nbr, tied, p, qx, qy, qz, d5b, ids, *reinterpret_cast<TieLds*>(&s_rec[wave][0]));
+  if (p < n && row_ok && __float_as_uint(qsp.w) < (uint32_t)mp.n_queries) fit_row(G, P, mp, ids, qx, qy, qz, v);
   fit_reduce_publish<64>(v, true, lane, s_rec[wave], s_acc[0], s_acc[1], s_acc[2], s_acc[3], &s_last, idx, partials,
                          out_granules, ticket, wl_count, seq, tl_fit, fb, fnb, &ch, P.RT, reinterpret_cast<double*>(&s_rec[0][0]));
 }
@@ -1958,17 +2019,17 @@ __global__ __launch_bounds__(256) void widen_fit_kernel(GridView G, const float4
                                                         unsigned long long* __restrict__ cand_total, int wblocks, TieList tl_widen,
                                                         MatchParams mp, FitIdx idx, double* __restrict__ partials,
                                                         double2* __restrict__ out_granules, unsigned int* __restrict__ ticket,
-                                                        unsigned long long seq, TieList tl_fit, int* __restrict__ err, ChainCtl ch) {
-  widen_fit_pass(G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand_total, wblocks, tl_widen, mp, idx, partials, out_granules, ticket, seq, tl_fit, err, ch);
+                                                        unsigned long long seq, TieList tl_fit, int* __restrict__ err, ChainCtl ch, BookView book) {
+  widen_fit_pass(G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand_total, wblocks, tl_widen, mp, idx, partials, out_granules, ticket, seq, tl_fit, err, ch, book);
 }
 __global__ __launch_bounds__(256) void widen_fit_chain_kernel(GridView G, const float4* __restrict__ scan_sorted, int n, const ChainHead* __restrict__ H,
                                                         int max_ring, NbrRec* __restrict__ nbr, const int* __restrict__ wl, int* __restrict__ wl_count,
                                                         unsigned long long* __restrict__ cand_total, int wblocks, TieList tl_widen,
                                                         MatchParams mp, FitIdx idx, double* __restrict__ partials,
                                                         double2* __restrict__ out_granules, unsigned int* __restrict__ ticket,
-                                                        unsigned long long seq, TieList tl_fit, int* __restrict__ err, ChainCtl ch) {
+                                                        unsigned long long seq, TieList tl_fit, int* __restrict__ err, ChainCtl ch, BookView book) {
   if (H->status != 0) return;
-  widen_fit_pass(G, scan_sorted, n, H->pose, max_ring, nbr, wl, wl_count, cand_total, wblocks, tl_widen, mp, idx, partials, out_granules, ticket, seq, tl_fit, err, ch);
+  widen_fit_pass(G, scan_sorted, n, H->pose, max_ring, nbr, wl, wl_count, cand_total, wblocks, tl_widen, mp, idx, partials, out_granules, ticket, seq, tl_fit, err, ch, book);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2592,8 +2653,10 @@ int fit2_blocks(int n) { const int b = (n + 255) / 256; return (b + FIT_GROUPS -
 void launch_fit2(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const void* nbr, const PoseMats& P,
                  const MatchParams& mp, const unsigned char* live_idx, double* partials, void* out_granules, unsigned int* ticket,
                  int* wl_count, unsigned long long seq, hipEvent_t e0, hipEvent_t e1, const TieList* tlp, const ChainHead* chain,
-                 const ChainCtl* ctl) {
+                 const ChainCtl* ctl, const BookView* bookp) {
   if (n <= 0) return;
+  BookView book{};
+  if (bookp) book = *bookp;
   TieList tl{};
   if (tlp) tl = *tlp;
   FitIdx idx;
@@ -2602,17 +2665,20 @@ void launch_fit2(hipStream_t st, const GridView& G, const float4* scan_sorted, i
   if (ctl) ch = *ctl;
   const int grid = fit2_blocks(n) + (ch.S ? 1 : 0);
   if (chain) {
-    hipExtLaunchKernelGGL((fit2_chain_kernel<64>), dim3(grid), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, (const NbrRec*)nbr, chain, mp, idx, partials, (double2*)out_granules, ticket, wl_count, seq, tl, ch);
+    hipExtLaunchKernelGGL((fit2_chain_kernel<64>), dim3(grid), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, (const NbrRec*)nbr, chain, mp, idx, partials, (double2*)out_granules, ticket, wl_count, seq, tl, ch, book);
     return;
   }
-  hipExtLaunchKernelGGL((fit2_kernel<64>), dim3(grid), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, idx, partials, (double2*)out_granules, ticket, wl_count, seq, tl, ch);
+  hipExtLaunchKernelGGL((fit2_kernel<64>), dim3(grid), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, idx, partials, (double2*)out_granules, ticket, wl_count, seq, tl, ch, book);
 }
 
 void launch_widen_fit(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const PoseMats& P, const MatchParams& mp,
                       void* nbr, int* wl, int* wl_count, unsigned long long* cand, const unsigned char* live_idx, double* partials,
                       void* out_granules, unsigned int* ticket, unsigned long long seq, hipEvent_t e0, hipEvent_t e1,
-                      const TieList* tl_widen, const TieList* tl_fit, int* err, const ChainHead* chain, const ChainCtl* ctl) {
+                      const TieList* tl_widen, const TieList* tl_fit, int* err, const ChainHead* chain, const ChainCtl* ctl,
+                      const BookView* bookp) {
   if (n <= 0) return;
+  BookView book{};
+  if (bookp) book = *bookp;
   ChainCtl ch{};
   if (ctl) ch = *ctl;
   TieList tw{}, tf{};
@@ -2624,11 +2690,11 @@ void launch_widen_fit(hipStream_t st, const GridView& G, const float4* scan_sort
   const int grid = wblocks + fblocks + (ch.S ? 1 : 0);
   if (chain) {
     hipExtLaunchKernelGGL(widen_fit_chain_kernel, dim3(grid), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, chain, mp.max_ring, (NbrRec*)nbr,
-                          wl, wl_count, cand, wblocks, tw, mp, idx, partials, (double2*)out_granules, ticket, seq, tf, err, ch);
+                          wl, wl_count, cand, wblocks, tw, mp, idx, partials, (double2*)out_granules, ticket, seq, tf, err, ch, book);
     return;
   }
   hipExtLaunchKernelGGL(widen_fit_kernel, dim3(grid), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, P, mp.max_ring, (NbrRec*)nbr,
-                        wl, wl_count, cand, wblocks, tw, mp, idx, partials, (double2*)out_granules, ticket, seq, tf, err, ch);
+                        wl, wl_count, cand, wblocks, tw, mp, idx, partials, (double2*)out_granules, ticket, seq, tf, err, ch, book);
 }
 
 int fused_blocks(int n) { return round_up8((n + 127) / 128); }
@@ -2655,10 +2721,11 @@ void launch_match_fused(hipStream_t st, const GridView& G, const float4* scan_so
                         void* nbr, int* wl, int* wl_count, unsigned long long* cand, const PrevPass& prev,
                         const unsigned char* live_idx, double* partials, void* out_granules, unsigned int* ticket,
                         unsigned long long seq, hipEvent_t e0, hipEvent_t e1, const TieList* tlp, int after_fine, const DeskewArgs* dk,
-                        const ChainHead* chain, const ChainCtl* ctl) {
+                        const ChainHead* chain, const ChainCtl* ctl, const BookView* bookp) {
   if (n <= 0) return;
   FuseArgs fa{};
   if (ctl) fa.ch = *ctl;
+  if (bookp) fa.book = *bookp;
   if (dk) fa.dk = *dk;
   fa.fine_mode = after_fine ? 1 : 0;
   fa.tl = TieList{};

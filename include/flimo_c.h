@@ -246,7 +246,9 @@ unsigned long long flimo_pass_count(const flimo_ctx* ctx);
  * of a scan with a poor prior, records / caps / debug, non-default lanes per query, gates wider than 3 rings) */
 unsigned long long flimo_fused_pass_count(const flimo_ctx* ctx);
 /* exact float32 distance ties (Objects/Octree.hpp:72-87,558-599: the reference keeps the candidate its recursion meets first):
- * out[0] = passes whose rows were rebuilt after settling ties, out[1] = queries settled so far */
+ * out[0] = passes whose rows were rebuilt after settling ties in a launch of their own (records / caps / debug path), out[1] =
+ * queries settled so far -- there and inside the reducing launches of the per-pass fast paths, which settle a tied query where
+ * they build its row */
 int flimo_tie_stats(const flimo_ctx* ctx, unsigned long long out[2]);
 /* second level over crowded regions (cells holding > 64 points get a grid with a quarter of the cell edge and a pre-pass):
  * out[0] = active now, out[1] = map points copied into it, out[2] = times it was (re)built, out[3] = passes that ran the pre-pass */

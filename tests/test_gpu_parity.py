@@ -955,7 +955,7 @@ def test_knn_on_a_lattice_ties_follow_the_reference(built, oracle):
     vg, vo = g["valid"] > 0, recs["is_plane"] > 0
     np.testing.assert_array_equal(vg, vo)
     if os.environ.get("FLIMO_TIES", "1") != "0":
-        assert t1["passes_redone"] >= t0["passes_redone"] + 2 and t1["queries_settled"] >= t0["queries_settled"] + 500
+        assert t1["queries_settled"] >= t0["queries_settled"] + 500      # (inside the reducing launches: no pass is redone for them)
         np.testing.assert_array_equal(dev[g["nbr"]][vg], recs["nbr"][vg])          # the same five points in the same order
         np.testing.assert_array_equal(g["n"][vg], recs["n"][vg])
         np.testing.assert_array_equal(g["H"][vg].astype(np.float64), H)
