@@ -164,7 +164,7 @@ def load_hip():
 
 
 _ERRS = {-1: "no gfx950 device", -2: "invalid argument", -3: "HIP error", -4: "no map", -5: "too large",
-         -6: "unsupported"}
+         -6: "unsupported", -7: "TIMEOUT"}
 
 
 class HipCtx:

@@ -152,3 +152,65 @@ def test_chain_with_the_algebra_as_its_own_launch_is_bit_equal(built):
     np.testing.assert_array_equal(out[0][1], out[1][1])
     for a, b in zip(out[0][2], out[1][2]):
         np.testing.assert_array_equal(a, b)
+
+
+def test_a_pass_that_fails_is_surfaced(built):
+    """The reference's Mapper::match cannot fail (Modules/Mapper.cpp:59-86); a GPU pass can (timeout, HIP error).  C ABI: the wait
+    bound 0 ("do not wait") makes flimo_match_reduce and flimo_update_chain return FLIMO_ERR_TIMEOUT while their launches are
+    still queued; nothing new is queued on top of them until they are gone.  Localizer: the update is abandoned -- status -4, state
+    and covariance back at the propagated values, no map insert -- and the next sweep registers normally."""
+    import time
+    from fast_limo_amd import _lib, api
+    mp, scan5, imu = cfg1_scene()
+    h = _lib.HipCtx()
+    h.map_add(np.ascontiguousarray(mp[:, :3]))
+    h.scan_set(np.ascontiguousarray(scan5[:, :3]))
+    x = np.zeros(26); x[6] = 1.0; x[10] = 1.0; x[25] = -9.809
+    cfg = _lib.default_match_cfg(MAX_NUM_MATCHES=10**7, MAX_NUM_PC2MATCH=10**7)
+    ref = h.match_reduce(x, cfg)
+    h.set_wait_timeout_ms(0)
+    with pytest.raises(_lib.FlimoError, match="TIMEOUT"):
+        h.match_reduce(x, cfg)
+    with pytest.raises(_lib.FlimoError, match="TIMEOUT"):               # still running (refused), or gone: then this one times out
+        h.update_chain(cfg, x, np.eye(23) * 1e-2, np.full(23, 1e-3))
+    h.set_wait_timeout_ms(2000)
+    for _ in range(200):                                               # the abandoned launches drain within microseconds
+        try:
+            got = h.match_reduce(x, cfg)
+            break
+        except _lib.FlimoError:
+            time.sleep(0.001)
+    assert got[2] == ref[2]
+    np.testing.assert_allclose(got[0], ref[0], rtol=1e-12, atol=1e-9)
+    h.close()
+    # ---- through the Localizer ----
+    st, w, a = imu
+    L = _localizer(False)
+    L.set_flags(add_to_map=True, keep_log=False)
+    L.map_add(mp)
+    i = 0
+    def feed(until):
+        nonlocal i
+        while i < len(st) and st[i] <= until:
+            L.update_imu(st[i], w[i], a[i]); i += 1
+    feed(0.105); assert L.update_pointcloud(scan5, 0.0) == 1           # null iteration (reference a-note 8)
+    feed(0.205); assert L.update_pointcloud(scan5, 0.1) == 0
+    L.sync()
+    n_map, x_ok = L.map_size(), L.get_x().copy()
+    feed(0.305)
+    L.hip.set_wait_timeout_ms(0)
+    rc = L.update_pointcloud(scan5, 0.2)
+    assert rc == -4, rc                                                # the update was abandoned
+    L.sync()
+    assert L.map_size() == n_map                                       # no insert at an unmeasured pose
+    assert np.isfinite(L.get_x()).all() and np.abs(L.get_x()[0:3] - x_ok[0:3]).max() < 0.05      # the propagated state
+    L.hip.set_wait_timeout_ms(2000)
+    time.sleep(0.05)
+    feed(0.405)
+    rc = L.update_pointcloud(scan5, 0.3)
+    assert rc == 0, rc                                                 # the next sweep registers normally
+    L.sync()
+    assert L.map_size() >= n_map
+    dpos, ang = pose_delta(L.get_x(), x_ok)
+    assert dpos < 1e-2 and ang < 1e-2
+    L.close()
