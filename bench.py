@@ -110,7 +110,11 @@ def cpu_baseline(mp, scan, imu, caps, max_threads):
     best = None
     E = None
     x_o = None
+    per_threads = {}
     model, phys, logical = cpu_info()
+    # 1 thread, and the reference's own clamp: Config.num_threads is what the wrapper hands to omp_set_num_threads (Localizer.cpp:46-50)
+    # and its shipped configurations ask for at most the machine's cores; 32 is where the oracle stops scaling on these hosts (the
+    # k-NN loop is memory-latency bound), so more threads only add scheduling noise to a 20-second budget
     tried = sorted(set([1, max(1, min(max_threads, os.cpu_count() or 1))]))
     for nt in tried:
         L = O.Localizer(O.default_cfg(num_threads=nt, **caps))
@@ -133,6 +137,7 @@ def cpu_baseline(mp, scan, imu, caps, max_threads):
             if time.time() - budget_t0 > budget and len(times) >= 3:
                 break
         t = float(np.median(times))
+        per_threads[str(nt)] = {"scans_per_s": 1.0 / t, "ms": 1e3 * t, "reps": len(times)}
         # the path exit once (transform + Mapper::add of the registered scan into the map): reported as a stage, not part of `value`
         L.set_x(x_prior); L.set_P(P_prior)
         L.update_pointcloud(scan, 0.1, add_to_map=True)
@@ -141,7 +146,7 @@ def cpu_baseline(mp, scan, imu, caps, max_threads):
             best = (t, nt, len(times), [float(v) * 1e3 for v in np.median(np.array(stages), axis=0)] + [t_add * 1e3])
     t, nt, reps, stg = best
     return dict(value=1.0 / t, unit="scans/s", cores=nt, kind="port", cpu_model=model, physical_cores=phys, logical_cpus=logical,
-                threads=nt, reps=reps,
+                threads=nt, reps=reps, by_threads=per_threads,
                 stages_ms={"deskew": stg[0], "knn_plane_fit": stg[1], "H_rows": stg[2], "HtH_and_solve": stg[3],
                            "map_add_once_not_in_value": stg[4]},
                 sample=f"median of {reps} registrations after warm-up (deskew + iterated update, no map insert) of the same "
@@ -224,14 +229,14 @@ def hbm_regime_leg(device, steps, with_oracle, max_threads=32):
     d, tot = loc.hip.timing_split(reset=True), loc.hip.timing_totals(reset=True)
     qpl = tot["queries"] / max(tot["passes"], 1)
     # the k-NN stage on its own (fast path + widening, no fit): the pass split into dispatches (A/B switch)
-    loc.hip.set_path_switches(fuse=0, widen_fit=0)
+    loc.hip.set_path_switches(fuse=0)
     for _ in range(2):
         reg()
     loc.hip.timing_split(reset=True)
     for _ in range(8):
         reg()
     ds = loc.hip.timing_split(reset=True)
-    loc.hip.set_path_switches(fuse=1, widen_fit=1)
+    loc.hip.set_path_switches(fuse=1)
     loc.hip.set_timing(0)
     stragglers = loc.hip.last_stragglers()
     out = {"workload": "BASELINE.json configs[3] as a resident-input step: %d-pt scan (%d rings x %d azimuths) vs %d-pt box-world map (L = %.0f m), "
@@ -538,16 +543,6 @@ def main():
 
     step()
     x_step = loc.get_x()               # the state every later step must reproduce
-    # Setup, before the W warm-up steps: the step rate of a process keeps rising over its first thousand steps (clocks, first touches,
-    # the host's caches: 6 500 scans/s over the first 20 steps, 7 200 after 400), and 20 timed steps last 3 ms.  A quarter of a second of
-    # untimed steps first (reported as config.settle_steps_before_warmup): the timed region then shows the steady state.
-    settle_steps, t_settle0 = 0, time.perf_counter()
-    while time.perf_counter() - t_settle0 < 0.25:
-        for _ in range(50):
-            step()
-        settle_steps += 50
-    for _ in range(args.warmup - 1):
-        step()
     # level 1: start/stop HIP events attached to the dispatches of a pass (on the context's own stream): the kernels' own begin /
     # end timestamps.  A timed pass costs tens of microseconds of wall time, so inside the timed region the passes are SAMPLED:
     # every (4k+1)-th -- the stride walks through the 4 pass positions of a step evenly -- about 6 samples (every launch of a very
@@ -559,8 +554,12 @@ def main():
         auto_stride = 1 << 30           # a short run (the driver's 20 steps last 3 ms) is not sampled at all: three timed passes would
                                         # cost 3 % of it; the dense series below provides the kernel statistics
     loc.hip.set_timing_stride(int(os.environ.get('FLIMO_BENCH_TIMING_STRIDE', str(auto_stride))))
+    # W untimed warm-up steps, exactly (the registration above that made the scan resident and `step()` for x_step are setup)
+    for _ in range(args.warmup):
+        step()
     loc.hip.timing_totals(reset=True)
     loc.hip.timing_split(reset=True)
+    loc.hip.chain_stats(reset=True)
     passes0 = loc.hip.pass_count()
     fused0 = loc.hip.fused_pass_count()
     loc.host_profile(reset=True)
@@ -572,16 +571,40 @@ def main():
     elapsed = time.perf_counter() - t0
     tot = loc.hip.timing_totals()
     split = loc.hip.timing_split()
+    chain = loc.hip.chain_stats()
     n_passes = loc.hip.pass_count() - passes0
     n_fused_passes = loc.hip.fused_pass_count() - fused0
     hp = loc.host_profile()
+    # The spread of the timed region: the same K-step region nine more times, untimed by events (timing level 0), right after `value`'s
+    # (the driver's 20 steps last 3 ms; one region is a thin sample)
+    value_regions = None
+    if rank == 0:
+        loc.hip.set_timing(0)
+        regs = []
+        for _ in range(9):
+            tr0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            regs.append(args.steps / (time.perf_counter() - tr0))
+        regs = sorted(regs + [args.steps / elapsed])
+        value_regions = {"regions": len(regs), "steps_each": args.steps, "scans_per_s_min": regs[0], "scans_per_s_median": float(np.median(regs)),
+                         "scans_per_s_max": regs[-1], "note": "`value` is the FIRST region (the one between the barriers); the others follow it back to back"}
+        loc.hip.set_timing(int(os.environ.get('FLIMO_BENCH_TIMING', '1')))
     dense = None
+    kernel_us_per_step = None
     if int(os.environ.get('FLIMO_BENCH_TIMING', '1')) == 1:
         loc.hip.set_timing_stride(1)
         loc.hip.timing_split(reset=True)
+        loc.hip.chain_stats(reset=True)
         for _ in range(12):
             step()
         d = loc.hip.timing_split(reset=True)
+        cs = loc.hip.chain_stats(reset=True)
+        # GPU time of one step, every launch of it timed by events on its dispatch: passes (all their launches) + the filter's algebra
+        kernel_us_per_step = {"passes": 1e3 * (d["fused_ms"] + d["knn_ms"] + d["widen_ms"] + d["fit_ms"]) / 12.0,
+                              "filter_algebra": 1e3 * cs["algebra_ms"] / 12.0, "algebra_launches_per_step": cs["algebra_n"] / 12.0,
+                              "algebra_launch_us": (1e3 * cs["algebra_ms"] / cs["algebra_n"]) if cs["algebra_n"] else None}
+        kernel_us_per_step["total"] = kernel_us_per_step["passes"] + kernel_us_per_step["filter_algebra"]
         dense = {"one_launch_pass_us": (1e3 * d["fused_ms"] / d["fused_n"]) if d["fused_n"] else None, "one_launch_passes_timed": d["fused_n"],
                  "separate_dispatch_pass_us": ({"knn": 1e3 * d["knn_ms"] / d["separate_n"], "widen": 1e3 * d["widen_ms"] / d["separate_n"],
                                                 "fit_reduce": 1e3 * d["fit_ms"] / d["separate_n"]} if d["separate_n"] else None),
@@ -600,14 +623,14 @@ def main():
     # (A/B switch), every pass timed -- what the fused launch's k-NN part costs when rocprofv3 / HIP events can see it
     knn_stage = None
     if int(os.environ.get('FLIMO_BENCH_TIMING', '1')) == 1 and os.environ.get('FLIMO_FUSE', '1') != '0':
-        loc.hip.set_path_switches(fuse=0, widen_fit=0)
+        loc.hip.set_path_switches(fuse=0)
         for _ in range(2):
             step()
         loc.hip.timing_split(reset=True)
         for _ in range(12):
             step()
         d = loc.hip.timing_split(reset=True)
-        loc.hip.set_path_switches(fuse=1, widen_fit=1)
+        loc.hip.set_path_switches(fuse=1)
         if d["separate_n"]:
             knn_stage = {"knn_us": 1e3 * d["knn_ms"] / d["separate_n"], "widen_us": 1e3 * d["widen_ms"] / d["separate_n"],
                          "fit_us": 1e3 * d["fit_ms"] / d["separate_n"], "passes_timed": d["separate_n"]}
@@ -762,7 +785,12 @@ def main():
                                    % (scan.shape[0], args.rings, args.azimuths, mp.shape[0]),
                        "parallelism": "replicas x%d (independent scan streams, no collective)" % world,
                        "passes_per_step": n_passes / max(args.steps, 1), "steps_bit_reproducible": repro_bitwise,
-                       "settle_steps_before_warmup": settle_steps},
+                       "update": ("chained: every iteration's launches queued at once, the filter's algebra on the device (flimo_update_chain)"
+                                  if chain["chains"] else "host loop over single passes (FLIMO_HOST_UPDATE=1 or declined)"),
+                       "chains_run": chain["chains"], "chains_handed_back_early": chain["handed_back"], "chains_declined": chain["declined"]},
+            "value_regions": value_regions,
+            "kernel_us_per_step": kernel_us_per_step,
+            "step_minus_kernels_us": ((1e3 * 1e3 * elapsed / args.steps) - kernel_us_per_step["total"]) if kernel_us_per_step else None,
             "host_us_per_step": {"deskew_call": 1e6 * hp["deskew_s"] / args.steps, "update": 1e6 * hp["update_s"] / args.steps,
                                  "in_match_reduce": 1e6 * hp["match_reduce_s"] / args.steps},
             "with_map_insert": with_insert,
@@ -807,8 +835,8 @@ def main():
                                      "separate_dispatch_pass_us": sep, "separate_dispatch_passes_timed": split["separate_n"],
                                      "passes_in_one_launch": n_fused_passes, "passes_total": n_passes,
                                      "dense_after_timed_region": dense,
-                                     "note": "separate-dispatch passes (the first pass of the poor prior) are two launches: k-NN, then "
-                                             "widening + fit in one (widen_fit_kernel): its time is under fit_reduce, widen is 0"}}
+                                     "note": "separate-dispatch passes (the first pass of the poor prior) are three launches: k-NN, widening of the "
+                                             "worklist, fit + reduction"}}
         if concurrent and bytes_per_query:
             # the chip's aggregate k-NN rate with S streams in flight: algorithmic bytes of all their passes / wall time
             ppstep = n_passes / max(args.steps, 1)

@@ -126,9 +126,6 @@ struct flimo_ctx {
   // staging
   void* h_stage = nullptr;         // pinned
   void* h_clouds = nullptr;        // pinned: the two clouds of flimo_scan_clouds
-  bool widen_fit = true;           // FLIMO_WIDEN_FIT=0: widening and fit of a separate-dispatch pass as two launches
-  int* h_wf_err = nullptr;         // mapped: set by a fit block of widen_fit_kernel whose wait for a widening wave ran out
-  int* d_wf_err = nullptr;
   void (*overlap_fn)(void*) = nullptr;   // flimo_match_reduce_overlap: host work of the caller to run while the pass is in flight
   void* overlap_arg = nullptr;
   size_t clouds_cap = 0;
@@ -209,9 +206,8 @@ struct flimo_ctx {
   unsigned long long chain_tag = 0x4000000000000000ull;   // tag of the last chain (own number space)
   bool chain_inline = false;             // FLIMO_CHAIN_INLINE=1: the measurement-dependent half of an iteration inside the pass's reducing launch (run by the
                                          // workgroup that completes it) instead of a one-workgroup launch of its own behind the pass
-  bool combined_err_check = true;
   bool host_update = false;              // FLIMO_HOST_UPDATE=1: flimo_update_chain always declines (the host loop runs the update; A/B)
-  hipEvent_t chain_ev[CH_MAX_PASSES][6]; // per pass: [0,1] first launch, [2,3] second launch, [4,5] algebra kernel (lazy)
+  hipEvent_t chain_ev[CH_MAX_PASSES][8]; // per pass: [0,1] first launch, [2,3] fit launch, [4,5] algebra launch, [6,7] widening launch (lazy)
   bool chain_ev_made = false;
   double chain_alg_ms = 0;
   long long chain_alg_n = 0, chains_run = 0, chains_back = 0, chains_declined = 0;
@@ -283,7 +279,6 @@ static int ensure_dev(flimo_ctx* c, T*& p, size_t& cap, size_t need, bool keep, 
 //   FLIMO_FULL_REBUILD=1          the index is sorted from scratch on every insert (default: merged)
 //   FLIMO_HOST_INSERT=1           the first batch goes through the host statement of the insert rule, then is imported
 //   FLIMO_LAZY_DESKEW=0           the deskew always runs as a dispatch of its own (default: on the scan's first k-NN launch)
-//   FLIMO_WIDEN_FIT=0             widening and fit of a separate-dispatch pass as two launches (default: one, widen_fit_kernel)
 //   FLIMO_HOST_UPDATE=1           the iterated update runs as a host loop over single passes (default: the whole update is enqueued at
 //                                 once, flimo_update_chain)
 //   FLIMO_CHAIN_INLINE=1          chained update: the filter's measurement-dependent half inside the pass's reducing launch, run by the
@@ -314,7 +309,6 @@ static void load_dev_switches(flimo_ctx* c) {
   if (env_int("FLIMO_FULL_REBUILD", v)) c->full_rebuild = v != 0;
   if (env_int("FLIMO_HOST_INSERT", v)) c->host_insert = v != 0;
   if (env_int("FLIMO_LAZY_DESKEW", v)) c->lazy_deskew = v != 0;
-  if (env_int("FLIMO_WIDEN_FIT", v)) c->widen_fit = v != 0;
   if (env_int("FLIMO_HOST_UPDATE", v)) c->host_update = v != 0;
   if (env_int("FLIMO_CHAIN_INLINE", v)) c->chain_inline = v != 0;
 }
@@ -349,8 +343,6 @@ extern "C" int flimo_ctx_create(int device, flimo_ctx** out) {
             hipMalloc(&c->d_cand, sizeof(unsigned long long)) == hipSuccess &&
             hipMalloc(&c->d_tie_count, 2 * sizeof(unsigned int)) == hipSuccess &&
             hipMemset(c->d_tie_count, 0, 2 * sizeof(unsigned int)) == hipSuccess &&
-            hipHostMalloc((void**)&c->h_wf_err, sizeof(int), hipHostMallocMapped) == hipSuccess &&
-            hipHostGetDevicePointer((void**)&c->d_wf_err, c->h_wf_err, 0) == hipSuccess &&
             hipMalloc((void**)&c->d_chain, chain_state_size()) == hipSuccess &&
             hipMemset(c->d_chain, 0, chain_state_size()) == hipSuccess &&
             hipMalloc(&c->d_chain_gran, FIT_GROUPS * FIT_LIVE_PAD * 2 * sizeof(double)) == hipSuccess &&
@@ -368,7 +360,6 @@ extern "C" int flimo_ctx_create(int device, flimo_ctx** out) {
             hipHostMalloc((void**)&c->h_wl_count, sizeof(int), hipHostMallocDefault) == hipSuccess &&
             hipHostMalloc((void**)&c->h_cand, sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess;
   if (!ok) { flimo_ctx_destroy(c); return FLIMO_ERR_HIP; }
-  *c->h_wf_err = 0;
   memset(c->h_chain_res, 0, (size_t)CH_RES * 2 * sizeof(double));
   memset(c->h_chain_log, 0, (size_t)CH_MAX_PASSES * CH_LOGN * 2 * sizeof(double));
   memset(c->h_out256, 0, FIT_GROUPS * FIT_SLOT * sizeof(double));
@@ -418,12 +409,11 @@ extern "C" void flimo_ctx_destroy(flimo_ctx* c) {
   if (c->h_granules) (void)hipHostFree(c->h_granules);
   (void)hipFree(c->d_fit2_partials);
   if (c->h_cand) (void)hipHostFree(c->h_cand);
-  if (c->h_wf_err) (void)hipHostFree(c->h_wf_err);
   (void)hipFree(c->d_chain); (void)hipFree(c->d_chain_gran); (void)hipFree(c->d_tie_settled);
   if (c->h_chain_prior) (void)hipHostFree(c->h_chain_prior);
   if (c->h_chain_res) (void)hipHostFree(c->h_chain_res);
   if (c->h_chain_log) (void)hipHostFree(c->h_chain_log);
-  if (c->chain_ev_made) for (int i = 0; i < CH_MAX_PASSES; i++) for (int k = 0; k < 6; k++) (void)hipEventDestroy(c->chain_ev[i][k]);
+  if (c->chain_ev_made) for (int i = 0; i < CH_MAX_PASSES; i++) for (int k = 0; k < 8; k++) (void)hipEventDestroy(c->chain_ev[i][k]);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->h_clouds) (void)hipHostFree(c->h_clouds);
   for (int k = 0; k < 2; k++) if (c->h_frames[k]) (void)hipHostFree(c->h_frames[k]);
@@ -1300,7 +1290,16 @@ extern "C" int flimo_deskew(flimo_ctx* c, const float* xyz, size_t n, size_t str
 }
 
 // ---- measurement pass -------------------------------------------------------------------------
-extern "C" int flimo_set_timing(flimo_ctx* c, int level) { if (!c) return FLIMO_ERR_INVALID; c->timing = level < 0 ? 0 : (level > 2 ? 2 : level); return FLIMO_OK; }
+extern "C" int flimo_set_timing(flimo_ctx* c, int level) {
+  if (!c) return FLIMO_ERR_INVALID;
+  c->timing = level < 0 ? 0 : (level > 2 ? 2 : level);
+  if (c->timing == 1 && !c->chain_ev_made) {      // the chained update's per-pass events: made here, not inside a timed update
+    (void)hipSetDevice(c->device);
+    for (int i = 0; i < CH_MAX_PASSES; i++) for (int k = 0; k < 8; k++) HIPCHK(c, hipEventCreate(&c->chain_ev[i][k]));
+    c->chain_ev_made = true;
+  }
+  return FLIMO_OK;
+}
 extern "C" unsigned long long flimo_pass_count(const flimo_ctx* c) { return c ? c->pass_seq : 0ull; }
 extern "C" unsigned long long flimo_fused_pass_count(const flimo_ctx* c) { return c ? c->fused_passes : 0ull; }
 extern "C" int flimo_fine_stats(const flimo_ctx* c, unsigned long long out[4]) {
@@ -1348,7 +1347,7 @@ extern "C" int flimo_timing_totals(flimo_ctx* c, double* knn_ms, double* widen_m
 // developer / benchmark A/B: negative leaves a switch as it is
 extern "C" int flimo_set_path_switches(flimo_ctx* c, int tail, int fuse, int widen_fit) {
   if (!c) return FLIMO_ERR_INVALID;
-  if (widen_fit >= 0) c->widen_fit = widen_fit != 0;
+  (void)widen_fit;                 // (round 4: widening and fit are always two launches; the argument is accepted and ignored)
   if (tail >= 0) c->tail = tail != 0;
   if (fuse >= 0) c->fuse = fuse != 0;
   return FLIMO_OK;
@@ -1596,14 +1595,12 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   if (c->prune) { memcpy(c->prev.RT, P.RT, sizeof(c->prev.RT)); c->prev.valid = 1; }   // the records now belong to this pose
   const double tpb = prof ? now_us() : 0.0;
   if (tlev > 1) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-  // widening + fit in one launch when both follow (the fit's settled rows do not wait for the widening's stragglers)
-  const bool combined = c->widen_fit && !tail && !fused && !want_recs && tlev < 2 && !want_count && mp.max_ring >= 2 && mp.max_ring <= 3;
-  const bool widen_timed = !tail && !combined && tlev == 1 && mp.max_ring >= 2;
-  if (combined)
-    launch_widen_fit(c->stream, c->grid, c->d_scan_sorted, n_all, P, mp, c->d_nbr, c->d_wl, c->d_wl_count, nullptr, c->live_idx,
-                     c->d_fit2_partials, c->d_granules_host, c->d_ticket, seq, tlev == 1 ? c->ev[2] : nullptr,
-                     tlev == 1 ? c->ev[3] : nullptr, &tl, &tl, c->d_wf_err, nullptr, nullptr, bookp);
-  else if (!tail)
+  // A separate-dispatch pass is three launches: k-NN, widening of the worklist (one wave per pending query, dealt out over the whole
+  // chip), fit + reduction.  (Rounds 3's widen_fit_kernel ran the last two as one launch, its fit workgroups polling records its
+  // widening workgroups were still writing: 3 us per step bought with a forward-progress assumption and relaxed cross-XCD reads --
+  // retired in round 4 by design.)
+  const bool widen_timed = !tail && tlev == 1 && mp.max_ring >= 2;
+  if (!tail)
     launch_widen(c->stream, c->grid, c->d_scan_sorted, P, mp.max_ring, c->d_nbr, c->d_wl, c->d_wl_count,
                  c->debug_recs ? c->d_cand : nullptr, widen_timed ? c->ev[4] : nullptr, widen_timed ? c->ev[5] : nullptr, &tl);
   const double tpc = prof ? now_us() : 0.0;
@@ -1615,8 +1612,8 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   // order, reduces the first MAX_NUM_MATCHES and publishes to slot 0
   const bool fused_cap = cap_binds && !c->debug_recs;
   const bool use_fit2 = !want_recs && tlev < 2;                 // the per-pass fast path (granule results)
-  if (fused || combined) {
-    // the fit and the reduction ran inside the k-NN launch / the widening launch
+  if (fused) {
+    // the fit and the reduction ran inside the k-NN launch
   } else if (use_fit2)
     launch_fit2(c->stream, c->grid, c->d_scan_sorted, n_all, c->d_nbr, P, mp, c->live_idx, c->d_fit2_partials, c->d_granules_host,
                 c->d_ticket, c->d_wl_count, seq, tlev == 1 ? c->ev[2] : nullptr, tlev == 1 ? c->ev[3] : nullptr, &tl, nullptr, nullptr, bookp);
@@ -1653,7 +1650,6 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
     };
     run_overlap(c);                                    // the caller's own work, beside the launch
     { const int rcw = wait_granules(seq); if (rcw) return rcw; }
-    if (combined && *(volatile int*)c->h_wf_err) { *c->h_wf_err = 0; return fail(c, FLIMO_ERR_HIP, "a fit block's wait for its widening wave ran out"); }
     c->last_stragglers = (int)llround(c->h_granules[2 * FIT_LIVE]);
     c->stragglers_hist[c->pass_in_scan] = c->last_stragglers;
     const long n_ties = (long)llround(c->h_granules[2 * (FIT_LIVE + 1)]);
@@ -1825,10 +1821,6 @@ extern "C" int flimo_update_chain(flimo_ctx* c, const flimo_match_cfg* cfg, flim
   if (!ride) { const int rcf = flush_deskew(c); if (rcf) return rcf; }
   const DeskewArgs* dkp = ride ? &c->deskew_args : nullptr;
   c->deskew_pending = false;
-  if (c->timing == 1 && !c->chain_ev_made) {
-    for (int i = 0; i < CH_MAX_PASSES; i++) for (int k = 0; k < 6; k++) HIPCHK(c, hipEventCreate(&c->chain_ev[i][k]));
-    c->chain_ev_made = true;
-  }
 
   // the prior, where the first pass's extra workgroup reads it; the measurement-independent half of iteration -1 with it
   // (x == x_prop: no transcendental function is evaluated, host and device agree bit for bit)
@@ -1869,7 +1861,7 @@ extern "C" int flimo_update_chain(flimo_ctx* c, const flimo_match_cfg* cfg, flim
     const bool tail_here = first_pass ? (c->tail_pass1 >= 0 ? c->tail_pass1 != 0 : c->stragglers_hist[0] <= tail_max)
                                       : (c->stragglers_hist[pos] <= tail_max);
     const bool fused = tail_here;
-    const bool combined = !fused && c->widen_fit;
+    const bool combined = false;
     const bool timed = c->timing == 1 && (c->timing_stride <= 1 || (seq % (unsigned long long)c->timing_stride) == 0);
     plan[i] = Plan{pos, fused, combined, timed};
     hipEvent_t* ev = timed ? c->chain_ev[i] : nullptr;
@@ -1891,12 +1883,8 @@ extern "C" int flimo_update_chain(flimo_ctx* c, const flimo_match_cfg* cfg, flim
     } else {
       launch_knn5(c->stream, 2, c->grid, c->d_scan_sorted, n_all, P0, mp.max_ring, c->d_nbr, c->d_wl, c->d_wl_count, nullptr, pv, 0,
                   ev ? ev[0] : nullptr, ev ? ev[1] : nullptr, nullptr, &tl, after_fine ? 1 : 0, seq, dk, ch);
-      if (combined) {
-        launch_widen_fit(c->stream, c->grid, c->d_scan_sorted, n_all, P0, mp, c->d_nbr, c->d_wl, c->d_wl_count, nullptr, c->live_idx,
-                         c->d_fit2_partials, c->d_chain_gran, c->d_ticket, seq, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr, &tl, &tl,
-                         c->d_wf_err, ch, &ctl, bookp);
-      } else {
-        launch_widen(c->stream, c->grid, c->d_scan_sorted, P0, mp.max_ring, c->d_nbr, c->d_wl, c->d_wl_count, nullptr, nullptr, nullptr, &tl, ch);
+      {
+        launch_widen(c->stream, c->grid, c->d_scan_sorted, P0, mp.max_ring, c->d_nbr, c->d_wl, c->d_wl_count, nullptr, ev ? ev[6] : nullptr, ev ? ev[7] : nullptr, &tl, ch);
         launch_fit2(c->stream, c->grid, c->d_scan_sorted, n_all, c->d_nbr, P0, mp, c->live_idx, c->d_fit2_partials, c->d_chain_gran,
                     c->d_ticket, c->d_wl_count, seq, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr, &tl, ch, &ctl, bookp);
       }
@@ -1956,7 +1944,6 @@ extern "C" int flimo_update_chain(flimo_ctx* c, const flimo_match_cfg* cfg, flim
     for (int i = 0; i < 12; i++) io->meas_HTh[i] = val_at(CH_SUMS + k++);
     io->meas_M = (int)llround(val_at(CH_SUMS + k));
   }
-  if (c->combined_err_check && *(volatile int*)c->h_wf_err) { *c->h_wf_err = 0; c->prev.valid = 0; return fail(c, FLIMO_ERR_HIP, "a fit block's wait for its widening wave ran out"); }
   // passes whose measurement ran: the completed iterations, and the one that was handed back
   const int executed = std::min(n_pass, io->passes + 1);
   for (int i = 0; i < executed; i++) {
@@ -2004,9 +1991,9 @@ extern "C" int flimo_update_chain(flimo_ctx* c, const flimo_match_cfg* cfg, flim
     c->last_knn_ms = ms; c->tot_knn_ms += ms;
     if (plan[i].fused) { c->split_fused_ms += ms; c->split_fused_n++; c->last_fit_ms = c->last_widen_ms = 0.f; }
     else {
-      const float ms2 = elapsed(ev[2], ev[3]);
-      c->split_knn_ms += ms; c->split_fit_ms += ms2; c->split_sep_n++; c->tot_fit_ms += ms2;
-      c->last_fit_ms = ms2; c->last_widen_ms = 0.f;
+      const float ms2 = elapsed(ev[2], ev[3]), msw = elapsed(ev[6], ev[7]);
+      c->split_knn_ms += ms; c->split_fit_ms += ms2; c->split_widen_ms += msw; c->split_sep_n++; c->tot_fit_ms += ms2; c->tot_widen_ms += msw;
+      c->last_fit_ms = ms2; c->last_widen_ms = msw;
     }
     if (!c->chain_inline) { c->chain_alg_ms += elapsed(ev[4], ev[5]); c->chain_alg_n++; }
     c->tot_passes++; c->tot_queries += n_all;

@@ -53,12 +53,6 @@ void launch_fit2(hipStream_t st, const GridView& G, const float4* scan_sorted, i
                  const MatchParams& mp, const unsigned char* live_idx, double* partials, void* out_granules, unsigned int* ticket,
                  int* wl_count, unsigned long long seq, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, const TieList* ties = nullptr,
                  const ChainHead* chain = nullptr, const ChainCtl* ctl = nullptr, const BookView* book = nullptr);
-// widening + fit of a separate-dispatch pass in one launch (max_ring 2..3): see widen_fit_kernel
-void launch_widen_fit(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const PoseMats& P, const MatchParams& mp,
-                      void* nbr, int* wl, int* wl_count, unsigned long long* cand, const unsigned char* live_idx, double* partials,
-                      void* out_granules, unsigned int* ticket, unsigned long long seq, hipEvent_t e0, hipEvent_t e1,
-                      const TieList* tl_widen, const TieList* tl_fit, int* err, const ChainHead* chain = nullptr,
-                      const ChainCtl* ctl = nullptr, const BookView* book = nullptr);
 // The whole measurement pass in ONE launch (k-NN fast path + in-kernel tail + fit + reduction + publish; two lanes per query, gates of
 // 2..3 rings): partials needs fused_blocks(n) * FIT_LIVE_PAD doubles; results arrive as launch_fit2's granules.
 int fused_blocks(int n);

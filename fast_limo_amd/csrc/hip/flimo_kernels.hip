@@ -1251,7 +1251,6 @@ __device__ __forceinline__ void knn5_pass(const GridView& G, const float4* __res
     int4 a, b;
     a.x = (int)(uint32_t)best[0]; a.y = (int)(uint32_t)best[1]; a.z = (int)(uint32_t)best[2]; a.w = (int)(uint32_t)best[3];
     b.x = (int)(uint32_t)best[4]; b.y = min(flag, 2); b.z = (int)(uint32_t)(best[4] >> 32); b.w = ((flag == 1) ? 1 : 0) | (tie ? 2 : 0);   // d5 for the next pass; bit 1: tie
-    if (flag >= 2) { a.x = a.y = a.z = a.w = -1; b.x = -1; }   // pending: no neighbour numbers -- widen_fit_kernel's readers tell a half-rewritten record by them
     if (tie && !tie_listed && tl.list) { const unsigned slot = atomicAdd(tl.count, 1u); if (slot < tl.cap) tl.list[slot] = p; }
     int4* o = reinterpret_cast<int4*>(&nbr[p]);
     o[0] = a;
@@ -1325,9 +1324,7 @@ __global__ __launch_bounds__(256) KNN_WPE void knn5_chain_kernel(GridView G, con
 // extracted with wave-wide min reductions.  r starts at the ring the fast path's own 5th distance asks for
 // (at least 2) and jumps to the ring that proves exactness, never beyond max_ring (<= 3 here; the host
 // falls back to the general kernel for larger gates).
-// (blk / nblk: this block's number among the launch's widening blocks; PUBLISH: the record is read by fit blocks of the SAME launch,
-//  possibly on another XCD -- written through, the word that carries the flag last)
-template <bool PUBLISH>
+// (blk / nblk: this block's number among the launch's blocks)
 __device__ __forceinline__ void widen_body(const GridView& G, int max_ring, NbrRec* __restrict__ nbr,
                                            const int* __restrict__ wl, const int* __restrict__ wl_count,
                                            unsigned long long* __restrict__ cand_total, int first_ring, const TieList& tl,
@@ -1454,19 +1451,8 @@ __device__ __forceinline__ void widen_body(const GridView& G, int max_ring, NbrR
       const bool tie = flag == 1 && key_has_tie(best, sixth);
       b.x = (int)(uint32_t)best[4]; b.y = flag; b.z = (int)(uint32_t)(best[4] >> 32); b.w = ((flag == 1) ? 1 : 0) | (tie ? 2 : 0);
       int4* o = reinterpret_cast<int4*>(&nbr[p]);
-      if constexpr (PUBLISH) {
-        unsigned long long* o8 = reinterpret_cast<unsigned long long*>(o);
-        __hip_atomic_store(o8 + 0, ((unsigned long long)(uint32_t)a.y << 32) | (uint32_t)a.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(o8 + 1, ((unsigned long long)(uint32_t)a.w << 32) | (uint32_t)a.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(o8 + 3, ((unsigned long long)(uint32_t)b.w << 32) | (uint32_t)b.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // the flag's word last, once the three stores above are performed at the agent-coherent level.  No release FENCE: at agent
-        // scope it writes the whole L2 back (as an acquire invalidates it) -- these stores go through by themselves
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(o8 + 2, ((unsigned long long)(uint32_t)b.y << 32) | (uint32_t)b.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else {
-        o[0] = a;
-        o[1] = b;
-      }
+      o[0] = a;
+      o[1] = b;
       if (tie && tl.list) { const unsigned slot = atomicAdd(tl.count, 1u); if (slot < tl.cap) tl.list[slot] = p; }
     }
   }
@@ -1479,7 +1465,7 @@ __global__ __launch_bounds__(256) void widen_kernel(GridView G, const float4* __
   __shared__ uint32_t s_off[4][65];
   __shared__ uint32_t s_lo[4][64];
   if (H && H->status != 0) return;                   // a chained pass after the chain has ended
-  widen_body<false>(G, max_ring, nbr, wl, wl_count, cand_total, first_ring, tl, (int)blockIdx.x, (int)gridDim.x, s_off, s_lo);
+  widen_body(G, max_ring, nbr, wl, wl_count, cand_total, first_ring, tl, (int)blockIdx.x, (int)gridDim.x, s_off, s_lo);
 }
 
 // general ring search for the worklist when the gate needs more than 3 rings (unusual configs)
@@ -1927,109 +1913,6 @@ __global__ __launch_bounds__(256) void fit2_chain_kernel(GridView G, const float
                                                    unsigned long long seq, TieList tl, ChainCtl ch, BookView book) {
   if (H->status != 0) return;
   fit2_pass<PPW>(G, scan_sorted, n, nbr, H->pose, mp, idx, partials, out_granules, ticket, wl_count, seq, tl, ch, book);
-}
-
-// Widening and fit of a pass that runs in separate dispatches (first pass of a poor prior) in ONE launch: the first `wblocks`
-// blocks are the widening's (one wave per worklist entry), the rest the fit's (64 rows per wave).  A fit block does the rows
-// the k-NN dispatch settled at once -- nine in ten -- and waits for the rows that are still on the worklist (record flag 2) until
-// their widening wave has written the record (through to the agent-coherent level, the flag's word last).  Every XCD dispatches
-// its workgroups in order, so wherever a fit block runs the widening blocks of every XCD are ahead of the fit blocks there: the
-// waves it waits for are running or done.  The wait is bounded by the wall clock all the same (then the row counts as "no
-// match" and *err is set: the host reports it).  Row order, partial slots and the reduction are the fit dispatch's own.
-__device__ __forceinline__ void widen_fit_pass(const GridView& G, const float4* __restrict__ scan_sorted, int n, const PoseMats& P, int max_ring,
-                                               NbrRec* __restrict__ nbr, const int* __restrict__ wl, int* __restrict__ wl_count,
-                                               unsigned long long* __restrict__ cand_total, int wblocks, const TieList& tl_widen,
-                                               const MatchParams& mp, const FitIdx& idx, double* __restrict__ partials,
-                                               double2* __restrict__ out_granules, unsigned int* __restrict__ ticket,
-                                               unsigned long long seq, const TieList& tl_fit, int* __restrict__ err, const ChainCtl& ch,
-                                               const BookView& book) {
-  __shared__ __align__(16) float s_rec[4][16 * 65];
-  __shared__ double s_acc[4][256];
-  __shared__ unsigned int s_last;
-  int nball = (int)gridDim.x;
-  if (ch.S) {
-    nball -= 1;
-    if ((int)blockIdx.x == nball) {
-      double* big = reinterpret_cast<double*>(&s_rec[0][0]);
-      ik_extra_block(ch, big, (int)threadIdx.x);
-      chain_arrive(ch, seq, P.RT, big, &s_last);
-      return;
-    }
-  }
-  if ((int)blockIdx.x < wblocks) {
-    uint32_t (*s_off)[65] = reinterpret_cast<uint32_t (*)[65]>(&s_rec[0][0]);
-    uint32_t (*s_lo)[64] = reinterpret_cast<uint32_t (*)[64]>(&s_rec[1][0]);
-    widen_body<true>(G, max_ring, nbr, wl, wl_count, cand_total, max_ring, tl_widen, (int)blockIdx.x, wblocks, s_off, s_lo);
-    return;
-  }
-  const int fb = (int)blockIdx.x - wblocks, fnb = nball - wblocks;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int chunk = xcd_chunk(fb, fnb);
-  const int p = (chunk * 4 + wave) * 64 + lane;
-  float v[16];
-#pragma unroll
-  for (int i = 0; i < 16; i++) v[i] = 0.f;
-  int ids[5] = {0, 0, 0, 0, 0};
-  bool row_ok = false, tied = false;
-  uint32_t d5b = 0u;
-  float4 qsp = make_float4(0.f, 0.f, 0.f, 0.f);
-  float qx = 0.f, qy = 0.f, qz = 0.f;
-  if (p < n) {
-    const float4 sp = scan_sorted[p];
-    const int4* nb = reinterpret_cast<const int4*>(&nbr[p]);
-    int4 a = nb[0], b = nb[1];
-    float gx, gy, gz;
-    xform4(P.RT, sp.x, sp.y, sp.z, gx, gy, gz);
-    // A record on the worklist (flag 2) carries no neighbour numbers (-1).  Its widening wave -- this launch, possibly another XCD --
-    // writes the four 8-byte words through one by one, the flag's word last; words of one record may still become visible out of
-    // order, so a "found" record counts only when all five numbers are map positions: a reader that meets the new flag with an
-    // old half looks again (agent-scope loads read past this XCD's L2; bounded by the wall clock).
-    auto incomplete = [&](const int4& ra, const int4& rb) {
-      return rb.y == 2 || (rb.y == 1 && ((uint32_t)ra.x >= G.n_pts || (uint32_t)ra.y >= G.n_pts || (uint32_t)ra.z >= G.n_pts ||
-                                          (uint32_t)ra.w >= G.n_pts || (uint32_t)rb.x >= G.n_pts));
-    };
-    if (incomplete(a, b)) {
-      const unsigned long long* o8 = reinterpret_cast<const unsigned long long*>(&nbr[p]);
-      const unsigned long long t0 = wall_clock64();
-      for (;;) {
-        const unsigned long long w2 = __hip_atomic_load(o8 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long w0 = __hip_atomic_load(o8 + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long w1 = __hip_atomic_load(o8 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        a.x = (int)(uint32_t)w0; a.y = (int)(uint32_t)(w0 >> 32); a.z = (int)(uint32_t)w1; a.w = (int)(uint32_t)(w1 >> 32);
-        b.x = (int)(uint32_t)w2; b.y = (int)(uint32_t)(w2 >> 32);
-        if (!incomplete(a, b)) break;
-        if (wall_clock64() - t0 > 2000000ull) { b.y = 0; atomicExch(err, 1); break; }     // 20 ms at 100 MHz: no match, reported
-        __builtin_amdgcn_s_sleep(16);
-      }
-    }
-    ids[0] = a.x; ids[1] = a.y; ids[2] = a.z; ids[3] = a.w; ids[4] = b.x;
-    row_ok = b.y == 1;
-    tied = row_ok && (b.w & 2) != 0;
-    d5b = (uint32_t)b.z;
-    qsp = sp; qx = gx; qy = gy; qz = gz;
-  }
-  if (book.node_c) tie_repair_wave(G, book, nbr, tied, p, qx, qy, qz, d5b, ids, *reinterpret_cast<TieLds*>(&s_rec[wave][0]));
-  if (p < n && row_ok && __float_as_uint(qsp.w) < (uint32_t)mp.n_queries) fit_row(G, P, mp, ids, qx, qy, qz, v);
-  fit_reduce_publish<64>(v, true, lane, s_rec[wave], s_acc[0], s_acc[1], s_acc[2], s_acc[3], &s_last, idx, partials,
-                         out_granules, ticket, wl_count, seq, tl_fit, fb, fnb, &ch, P.RT, reinterpret_cast<double*>(&s_rec[0][0]));
-}
-
-__global__ __launch_bounds__(256) void widen_fit_kernel(GridView G, const float4* __restrict__ scan_sorted, int n, PoseMats P, int max_ring,
-                                                        NbrRec* __restrict__ nbr, const int* __restrict__ wl, int* __restrict__ wl_count,
-                                                        unsigned long long* __restrict__ cand_total, int wblocks, TieList tl_widen,
-                                                        MatchParams mp, FitIdx idx, double* __restrict__ partials,
-                                                        double2* __restrict__ out_granules, unsigned int* __restrict__ ticket,
-                                                        unsigned long long seq, TieList tl_fit, int* __restrict__ err, ChainCtl ch, BookView book) {
-  widen_fit_pass(G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand_total, wblocks, tl_widen, mp, idx, partials, out_granules, ticket, seq, tl_fit, err, ch, book);
-}
-__global__ __launch_bounds__(256) void widen_fit_chain_kernel(GridView G, const float4* __restrict__ scan_sorted, int n, const ChainHead* __restrict__ H,
-                                                        int max_ring, NbrRec* __restrict__ nbr, const int* __restrict__ wl, int* __restrict__ wl_count,
-                                                        unsigned long long* __restrict__ cand_total, int wblocks, TieList tl_widen,
-                                                        MatchParams mp, FitIdx idx, double* __restrict__ partials,
-                                                        double2* __restrict__ out_granules, unsigned int* __restrict__ ticket,
-                                                        unsigned long long seq, TieList tl_fit, int* __restrict__ err, ChainCtl ch, BookView book) {
-  if (H->status != 0) return;
-  widen_fit_pass(G, scan_sorted, n, H->pose, max_ring, nbr, wl, wl_count, cand_total, wblocks, tl_widen, mp, idx, partials, out_granules, ticket, seq, tl_fit, err, ch, book);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2669,32 +2552,6 @@ void launch_fit2(hipStream_t st, const GridView& G, const float4* scan_sorted, i
     return;
   }
   hipExtLaunchKernelGGL((fit2_kernel<64>), dim3(grid), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, idx, partials, (double2*)out_granules, ticket, wl_count, seq, tl, ch, book);
-}
-
-void launch_widen_fit(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const PoseMats& P, const MatchParams& mp,
-                      void* nbr, int* wl, int* wl_count, unsigned long long* cand, const unsigned char* live_idx, double* partials,
-                      void* out_granules, unsigned int* ticket, unsigned long long seq, hipEvent_t e0, hipEvent_t e1,
-                      const TieList* tl_widen, const TieList* tl_fit, int* err, const ChainHead* chain, const ChainCtl* ctl,
-                      const BookView* bookp) {
-  if (n <= 0) return;
-  BookView book{};
-  if (bookp) book = *bookp;
-  ChainCtl ch{};
-  if (ctl) ch = *ctl;
-  TieList tw{}, tf{};
-  if (tl_widen) tw = *tl_widen;
-  if (tl_fit) tf = *tl_fit;
-  FitIdx idx;
-  for (int i = 0; i < FIT_LIVE_PAD; i++) idx.raw[i] = i < FIT_LIVE ? live_idx[i] : 0;
-  const int wblocks = 2048, fblocks = fit2_blocks(n);
-  const int grid = wblocks + fblocks + (ch.S ? 1 : 0);
-  if (chain) {
-    hipExtLaunchKernelGGL(widen_fit_chain_kernel, dim3(grid), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, chain, mp.max_ring, (NbrRec*)nbr,
-                          wl, wl_count, cand, wblocks, tw, mp, idx, partials, (double2*)out_granules, ticket, seq, tf, err, ch, book);
-    return;
-  }
-  hipExtLaunchKernelGGL(widen_fit_kernel, dim3(grid), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, P, mp.max_ring, (NbrRec*)nbr,
-                        wl, wl_count, cand, wblocks, tw, mp, idx, partials, (double2*)out_granules, ticket, seq, tf, err, ch, book);
 }
 
 int fused_blocks(int n) { return round_up8((n + 127) / 128); }

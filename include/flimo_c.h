@@ -262,9 +262,9 @@ int flimo_timing_totals(flimo_ctx* ctx, double* knn_ms, double* widen_ms, double
  * out[5] their count */
 int flimo_timing_split(flimo_ctx* ctx, double out[6], int reset);
 /* A/B switches of the pass layout (each: 1 on, 0 off, negative = leave): `tail` finishes pending queries inside the k-NN launch,
- * `fuse` runs the whole pass as one launch, `widen_fit` runs widening and fit of a separate-dispatch pass as one launch.  All on by
- * default; the benchmark switches `fuse` and `widen_fit` off for a short series to time the k-NN stage (fast path + widening) on
- * its own. */
+ * `fuse` runs the whole pass as one launch.  Both on by default; the benchmark switches `fuse` off for a short series to time the
+ * k-NN stage (fast path + widening) on its own.  `widen_fit` is accepted and ignored (round 3 ran widening and fit of a
+ * separate-dispatch pass as one launch; they are two launches again). */
 int flimo_set_path_switches(flimo_ctx* ctx, int tail, int fuse, int widen_fit);
 /* Wall-clock bound (milliseconds, default 2000) of the wait for a pass's result inside flimo_match_reduce: the reference's
  * Mapper::match (Modules/Mapper.cpp:59-86) cannot hang, a GPU launch can -- when the bound expires the call returns
