@@ -590,6 +590,26 @@ def main():
         value_regions = {"regions": len(regs), "steps_each": args.steps, "scans_per_s_min": regs[0], "scans_per_s_median": float(np.median(regs)),
                          "scans_per_s_max": regs[-1], "note": "`value` is the FIRST region (the one between the barriers); the others follow it back to back"}
         loc.hip.set_timing(int(os.environ.get('FLIMO_BENCH_TIMING', '1')))
+    # The update's two layouts on THIS host, the same K steps each (informational; `value` above is the layout the library chose by
+    # its launch round-trip measurement): the chain queued at once and the host loop over single passes
+    modes = None
+    if rank == 0:
+        um = loc.hip.update_mode()
+        modes = {"chosen": "chain" if um["chained"] else "host_loop", "launch_round_trip_us": um["launch_rtt_us"]}
+        for name, mode in (("chain", 2), ("host_loop", 1)):
+            loc.hip.set_update_mode(mode)
+            for _ in range(3):
+                step()
+            rates = []
+            for _ in range(3):
+                tr0 = time.perf_counter()
+                for _ in range(args.steps):
+                    step()
+                rates.append(args.steps / (time.perf_counter() - tr0))
+            modes[name + "_scans_per_s"] = float(np.median(rates))
+        loc.hip.set_update_mode(0)
+        for _ in range(2):
+            step()
     dense = None
     kernel_us_per_step = None
     if int(os.environ.get('FLIMO_BENCH_TIMING', '1')) == 1:
@@ -786,9 +806,10 @@ def main():
                        "parallelism": "replicas x%d (independent scan streams, no collective)" % world,
                        "passes_per_step": n_passes / max(args.steps, 1), "steps_bit_reproducible": repro_bitwise,
                        "update": ("chained: every iteration's launches queued at once, the filter's algebra on the device (flimo_update_chain)"
-                                  if chain["chains"] else "host loop over single passes (FLIMO_HOST_UPDATE=1 or declined)"),
+                                  if chain["chains"] else "host loop over single passes (this host's launch round trip is short, or FLIMO_HOST_UPDATE=1)"),
                        "chains_run": chain["chains"], "chains_handed_back_early": chain["handed_back"], "chains_declined": chain["declined"]},
             "value_regions": value_regions,
+            "update_layouts": modes,
             "kernel_us_per_step": kernel_us_per_step,
             "step_minus_kernels_us": ((1e3 * 1e3 * elapsed / args.steps) - kernel_us_per_step["total"]) if kernel_us_per_step else None,
             "host_us_per_step": {"deskew_call": 1e6 * hp["deskew_s"] / args.steps, "update": 1e6 * hp["update_s"] / args.steps,

@@ -75,7 +75,7 @@ HIP_SYMBOLS = [
     "flimo_scan_to_world", "flimo_scan_clouds", "flimo_upload_stage", "flimo_match_reduce_overlap", "flimo_map_add_scan",
     "flimo_set_timing", "flimo_set_timing_stride", "flimo_pass_count", "flimo_fused_pass_count", "flimo_tie_stats", "flimo_fine_stats", "flimo_map_grid_selfcheck", "flimo_set_debug_records", "flimo_set_lanes_per_query", "flimo_last_kernel_ms",
     "flimo_last_candidates_per_query", "flimo_last_widen_count", "flimo_last_stragglers", "flimo_timing_totals", "flimo_timing_split", "flimo_set_path_switches", "flimo_set_wait_timeout_ms", "flimo_insert_rule_replay", "flimo_plane_fit5_host", "flimo_plane_eval5_host", "flimo_calculate_H_host",
-    "flimo_update_chain", "flimo_chain_stats",
+    "flimo_update_chain", "flimo_chain_stats", "flimo_set_update_mode", "flimo_update_mode",
 ]
 
 _hip = None
@@ -149,6 +149,8 @@ def load_hip():
     L.flimo_calculate_H_host.argtypes = [f64p, f32p, f32p, f32p, C.c_size_t, C.c_int, f64p, f64p]
     L.flimo_update_chain.argtypes = [vp, C.POINTER(MatchCfg), C.POINTER(ChainIO)]
     L.flimo_chain_stats.argtypes = [vp, f64p, C.c_int]
+    L.flimo_set_update_mode.argtypes = [vp, C.c_int]
+    L.flimo_update_mode.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_double)]
     L.flimo_last_widen_count.restype = C.c_int
     L.flimo_last_widen_count.argtypes = [vp]
     L.flimo_last_stragglers.restype = C.c_int
@@ -380,6 +382,15 @@ class HipCtx:
         meas = dict(M=io.meas_M, HTH=np.array(io.meas_HTH).reshape(12, 12), HTh=np.array(io.meas_HTh)) if io.meas_valid else None
         return dict(status=io.status, reason=io.reason, passes=io.passes, it_next=io.it_next, t=io.t, x=np.array(io.x26_out),
                     meas=meas, log=log)
+
+    def set_update_mode(self, mode: int):
+        """0: chain or host loop by this host's launch -> result round trip; 1: host loop; 2: chain."""
+        self._chk(self._L.flimo_set_update_mode(self._h, int(mode)))
+
+    def update_mode(self):
+        ch = C.c_int(0); rtt = C.c_double(0)
+        self._chk(self._L.flimo_update_mode(self._h, C.byref(ch), C.byref(rtt)))
+        return dict(chained=bool(ch.value), launch_rtt_us=rtt.value)
 
     def chain_stats(self, reset=False):
         o = np.zeros(5)

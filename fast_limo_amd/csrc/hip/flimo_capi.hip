@@ -206,7 +206,14 @@ struct flimo_ctx {
   unsigned long long chain_tag = 0x4000000000000000ull;   // tag of the last chain (own number space)
   bool chain_inline = false;             // FLIMO_CHAIN_INLINE=1: the measurement-dependent half of an iteration inside the pass's reducing launch (run by the
                                          // workgroup that completes it) instead of a one-workgroup launch of its own behind the pass
-  bool host_update = false;              // FLIMO_HOST_UPDATE=1: flimo_update_chain always declines (the host loop runs the update; A/B)
+  // Which way the iterated update runs: the chain costs about 11 us per pass on top of the pass's kernels whatever the host (the
+  // algebra launch and two dispatch boundaries); the host loop costs this host's launch -> result round trip + 2-3 us of algebra --
+  // 9 us on a fast host, 15-19 us on a slow one (BENCH_r03: 5 497 scans/s where the builder's box gave 7 102).  The round trip is
+  // measured once at context creation (launch_rtt_us); update_mode 0 = choose by it, 1 = host loop, 2 = chain.
+  int update_mode = 0;                   // FLIMO_HOST_UPDATE=1 -> 1, FLIMO_HOST_UPDATE=0 -> 2, unset -> 0 (flimo_set_update_mode)
+  double launch_rtt_us = 0.0;            // median launch -> granule seen of a one-thread kernel on this host
+  double rtt_threshold_us = 8.0;         // FLIMO_RTT_THRESHOLD_US: the chain is chosen when the round trip is longer
+  bool host_update = false;              // (the choice in force) flimo_update_chain always declines (the host loop runs the update; A/B)
   hipEvent_t chain_ev[CH_MAX_PASSES][8]; // per pass: [0,1] first launch, [2,3] fit launch, [4,5] algebra launch, [6,7] widening launch (lazy)
   bool chain_ev_made = false;
   double chain_alg_ms = 0;
@@ -279,8 +286,9 @@ static int ensure_dev(flimo_ctx* c, T*& p, size_t& cap, size_t need, bool keep, 
 //   FLIMO_FULL_REBUILD=1          the index is sorted from scratch on every insert (default: merged)
 //   FLIMO_HOST_INSERT=1           the first batch goes through the host statement of the insert rule, then is imported
 //   FLIMO_LAZY_DESKEW=0           the deskew always runs as a dispatch of its own (default: on the scan's first k-NN launch)
-//   FLIMO_HOST_UPDATE=1           the iterated update runs as a host loop over single passes (default: the whole update is enqueued at
-//                                 once, flimo_update_chain)
+//   FLIMO_HOST_UPDATE=<1|0>       the iterated update runs as a host loop over single passes / as a chain queued at once (flimo_update_chain),
+//                                 whatever the host (default: chosen by the launch -> result round trip measured at context creation)
+//   FLIMO_RTT_THRESHOLD_US=<us>   ... the round trip above which the chain is chosen (8)
 //   FLIMO_CHAIN_INLINE=1          chained update: the filter's measurement-dependent half inside the pass's reducing launch, run by the
 //                                 workgroup that completes it (default: a one-workgroup launch of its own behind each pass -- the same
 //                                 step time within 1 %, and the pass kernel's duration stays the pass's)
@@ -309,7 +317,8 @@ static void load_dev_switches(flimo_ctx* c) {
   if (env_int("FLIMO_FULL_REBUILD", v)) c->full_rebuild = v != 0;
   if (env_int("FLIMO_HOST_INSERT", v)) c->host_insert = v != 0;
   if (env_int("FLIMO_LAZY_DESKEW", v)) c->lazy_deskew = v != 0;
-  if (env_int("FLIMO_HOST_UPDATE", v)) c->host_update = v != 0;
+  if (env_int("FLIMO_HOST_UPDATE", v)) c->update_mode = v != 0 ? 1 : 2;
+  { const char* e = getenv("FLIMO_RTT_THRESHOLD_US"); if (e && atof(e) > 0) c->rtt_threshold_us = atof(e); }
   if (env_int("FLIMO_CHAIN_INLINE", v)) c->chain_inline = v != 0;
 }
 
@@ -386,6 +395,26 @@ extern "C" int flimo_ctx_create(int device, flimo_ctx** out) {
   }
   c->book = insert_book_create();
   load_dev_switches(c);
+  {
+    // launch -> result round trip of this host (median of 32 after 8 warm-ups): a one-thread kernel stores a granule to mapped
+    // memory, the host spins on its tag -- what every host-driven pass pays beyond its kernels
+    std::vector<double> rt;
+    volatile unsigned long long* tagp = reinterpret_cast<volatile unsigned long long*>(c->h_chain_res) + 1;
+    for (int i = 0; i < 40; i++) {
+      const unsigned long long tag = 0x7100000000000000ull + (unsigned long long)i;
+      const auto t0 = std::chrono::steady_clock::now();
+      launch_rtt_probe(c->stream, c->d_chain_res, tag);
+      unsigned long long spins = 0;
+      while (*tagp != tag && ++spins < 200000000ull) _mm_pause();
+      const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+      if (i >= 8) rt.push_back(us);
+    }
+    (void)hipStreamSynchronize(c->stream);
+    std::sort(rt.begin(), rt.end());
+    c->launch_rtt_us = rt[rt.size() / 2];
+    memset(c->h_chain_res, 0, 2 * sizeof(double));
+    c->host_update = c->update_mode == 1 || (c->update_mode == 0 && c->launch_rtt_us <= c->rtt_threshold_us);
+  }
   *out = c;
   return FLIMO_OK;
 }
@@ -1773,6 +1802,18 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
 // fit + reduction) when the last scan's pass at that position published few stragglers, else the k-NN launch followed by widening
 // + fit in one launch (or widening, then fit); a fine pre-pass before either when a crowded region is active.  Pass 0 gets its pose
 // constants as kernel arguments (the host knows x), later passes read them from the device filter.
+extern "C" int flimo_set_update_mode(flimo_ctx* c, int mode) {
+  if (!c || mode < 0 || mode > 2) return FLIMO_ERR_INVALID;
+  c->update_mode = mode;
+  c->host_update = mode == 1 || (mode == 0 && c->launch_rtt_us <= c->rtt_threshold_us);
+  return FLIMO_OK;
+}
+extern "C" int flimo_update_mode(const flimo_ctx* c, int* chained, double* launch_rtt_us) {
+  if (!c) return FLIMO_ERR_INVALID;
+  if (chained) *chained = c->host_update ? 0 : 1;
+  if (launch_rtt_us) *launch_rtt_us = c->launch_rtt_us;
+  return FLIMO_OK;
+}
 extern "C" int flimo_chain_stats(flimo_ctx* c, double out[5], int reset) {
   if (!c || !out) return FLIMO_ERR_INVALID;
   out[0] = c->chain_alg_ms; out[1] = (double)c->chain_alg_n; out[2] = (double)c->chains_run; out[3] = (double)c->chains_back;

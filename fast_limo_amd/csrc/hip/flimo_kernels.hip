@@ -2433,6 +2433,19 @@ __global__ void mfma_layout_kernel(double* __restrict__ raw) {
   raw[lane * 4 + 0] = acc[0]; raw[lane * 4 + 1] = acc[1]; raw[lane * 4 + 2] = acc[2]; raw[lane * 4 + 3] = acc[3];
 }
 
+// What a host-driven pass pays on THIS host beyond its kernels: a one-thread launch that stores a 16-byte {value, tag} granule to
+// mapped host memory the way a pass publishes its sums (flimo_ctx_create times launch -> granule seen, flimo_capi.hip)
+__global__ void rtt_probe_kernel(double2* __restrict__ out, unsigned long long tag) {
+  typedef double v2d_t __attribute__((ext_vector_type(2)));
+  v2d_t g;
+  g.x = 1.0;
+  g.y = __longlong_as_double((long long)tag);
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(out), "v"(g) : "memory");
+}
+void launch_rtt_probe(hipStream_t st, void* out_granule, unsigned long long tag) {
+  hipLaunchKernelGGL(rtt_probe_kernel, dim3(1), dim3(1), 0, st, (double2*)out_granule, tag);
+}
+
 // pcl::transformPointCloud (PCL 1.10 SSE2 Transformer::se3): c0*x + (c1*y + (c2*z + c3))
 __global__ __launch_bounds__(256) void transform_kernel(const float4* __restrict__ in, int n, PoseMats P,
                                                         float4* __restrict__ out) {

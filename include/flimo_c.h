@@ -215,6 +215,12 @@ typedef struct flimo_chain_io {
   flimo_chain_pass log[FLIMO_CHAIN_MAX_PASSES];   /* entries 0 .. passes - 1 (+ the handed-back iteration's M / stragglers / ties) */
 } flimo_chain_io;
 int flimo_update_chain(flimo_ctx* ctx, const flimo_match_cfg* cfg, flimo_chain_io* io);
+/* Which way a caller's update runs: 0 (default) = by this host's launch -> result round trip, measured once at context creation (a
+ * host-driven pass pays it every time, a chain never: flimo_update_chain declines on a fast host, where the host loop is the faster
+ * of the two, and runs on a slow one); 1 = always decline (host loop); 2 = always run the chain.  FLIMO_HOST_UPDATE=1 / 0 preset 1 / 2.
+ * flimo_update_mode: *chained = 1 when flimo_update_chain will run, *launch_rtt_us = the measured round trip. */
+int flimo_set_update_mode(flimo_ctx* ctx, int mode);
+int flimo_update_mode(const flimo_ctx* ctx, int* chained, double* launch_rtt_us);
 /* out[0] = GPU ms of the algebra launches timed so far (timing level 1; only with FLIMO_CHAIN_INLINE=0), out[1] = their number,
  * out[2] = chains run, out[3] = chains that came back before the final iteration, out[4] = chains declined */
 int flimo_chain_stats(flimo_ctx* ctx, double out[5], int reset);

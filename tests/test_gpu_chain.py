@@ -104,6 +104,9 @@ def test_raw_chain_entry_point(built):
     from fast_limo_amd import _lib
     mp, scan5, _ = cfg1_scene()
     h = _lib.HipCtx()
+    h.set_update_mode(2)                          # the chain, whatever this host's launch round trip
+    m = h.update_mode()
+    assert m["chained"] and 0.5 < m["launch_rtt_us"] < 1000.0, m
     h.map_add(np.ascontiguousarray(mp[:, :3]))
     h.scan_set(np.ascontiguousarray(scan5[:, :3]))
     x = np.zeros(26); x[6] = 1.0; x[10] = 1.0; x[25] = -9.809
@@ -137,7 +140,7 @@ def test_chain_with_the_algebra_as_its_own_launch_is_bit_equal(built):
         old = os.environ.get("FLIMO_CHAIN_INLINE")
         os.environ["FLIMO_CHAIN_INLINE"] = inline
         try:
-            D = api.Localizer(api.default_cfg(**CAPS))
+            D = _localizer(False)
         finally:
             if old is None:
                 del os.environ["FLIMO_CHAIN_INLINE"]
@@ -163,6 +166,7 @@ def test_a_pass_that_fails_is_surfaced(built):
     from fast_limo_amd import _lib, api
     mp, scan5, imu = cfg1_scene()
     h = _lib.HipCtx()
+    h.set_update_mode(2)
     h.map_add(np.ascontiguousarray(mp[:, :3]))
     h.scan_set(np.ascontiguousarray(scan5[:, :3]))
     x = np.zeros(26); x[6] = 1.0; x[10] = 1.0; x[25] = -9.809
