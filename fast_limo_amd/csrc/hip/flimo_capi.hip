@@ -1872,7 +1872,7 @@ extern "C" int flimo_update_chain(flimo_ctx* c, const flimo_match_cfg* cfg, flim
   memcpy(pr.P, io->P, sizeof(pr.P));
   memcpy(pr.limit, io->limits, sizeof(pr.limit));
   pr.R = io->R; pr.D = io->D; pr.max_iter = io->max_iter; pr.pad = 0;
-  ik_pre_serial(io->x26, io->x26, io->P, io->R, pr.dxn, pr.PR);
+  ik_pre_serial(io->x26, io->x26, io->P, io->R, pr.dxn, pr.AG, pr.AG + 144);
   __atomic_thread_fence(__ATOMIC_RELEASE);
 
   const unsigned long long tag = ++c->chain_tag;

@@ -39,7 +39,7 @@ struct ChainPrior {
   int max_iter;            // MAX_NUM_ITERS: iterations it = -1 .. max_iter - 1
   int pad;
   double dxn[23];          // dx_new of iteration -1
-  double PR[276];          // (P_ through the blocks)[:, 0:12] / R of iteration -1
+  double AG[276];          // of iteration -1: A11^-1 (144) and G2 = A21 A11^-1 (132) of A = (P_ through the blocks) / R
 };
 
 // Filter state of one scan's update in device memory.  flat state x26: pos3 rot4(xyzw) offR4 offT3 vel3 bg3 ba3 grav3.
@@ -55,8 +55,8 @@ struct ChainState {
   int t;                   // iterations that met the limits so far
   int passes;              // iterations completed by the device
   double info[3 * CH_MAX_PASSES];   // per pass: M, stragglers, ties
-  double pre_dxn[23];      // the measurement-independent half of the CURRENT iteration (extra workgroup of its pass)
-  double pre_PR[276];
+  double pre_dxn[23];      // the measurement-independent half of the CURRENT iteration (extra workgroup of its pass):
+  double pre_AG[276];      // dx_new; A11^-1 (144) and G2 = A21 A11^-1 (132) of A = P_ / R
 };
 
 // Arguments of the algebra inside a pass's reducing launch (S == nullptr: a host-driven pass)

@@ -30,8 +30,10 @@ constexpr int IK_LIVE = 91, IK_LIVE_PAD = 96, IK_GROUPS = 8;     // = FIT_LIVE, 
 
 // shared-memory layout (doubles)
 constexpr int IKL_P = 0;                 // P_ 23 x 23 (extra workgroup only)
-constexpr int IKL_PR = IKL_P + 529;      // P_[:, 0:12] / R   23 x 12
-constexpr int IKL_HTH = IKL_PR + 276;    // 12 x 12
+constexpr int IKL_PR = IKL_P + 529;      // P_[:, 0:12] / R   23 x 12 (extra workgroup only); rows 0..11 = A11
+constexpr int IKL_AI = IKL_PR + 276;     // A11^-1            12 x 12
+constexpr int IKL_G2 = IKL_AI + 144;     // PR[12:23] A11^-1  11 x 12
+constexpr int IKL_HTH = IKL_G2 + 132;    // 12 x 12
 constexpr int IKL_T = IKL_HTH + 144;     // 12 x 12
 constexpr int IKL_HTh = IKL_T + 144;     // 12
 constexpr int IKL_DX = IKL_HTh + 12;     // dx       23
@@ -313,6 +315,89 @@ __device__ inline bool ik_gj12_solve_wave(const double* __restrict__ T, const do
   return ok;
 }
 
+// The inverse itself (the measurement-independent half needs A11^-1): the same elimination on [T | I], the right-hand side's three
+// columns of this lane's column group riding along.  X row-major 12 x 12.
+__device__ inline bool ik_gj12_inverse_wave(const double* __restrict__ T, double* __restrict__ X, int lane) {
+  const int r = lane >> 2, cg = lane & 3;
+  const bool live_row = r < 12;
+  double a[3], x[3];
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    a[j] = live_row ? T[r * 12 + 3 * cg + j] : 0.0;
+    x[j] = (live_row && r == 3 * cg + j) ? 1.0 : 0.0;
+  }
+  bool used = !live_row;
+  int my_k = 0;
+  double my_d = 1.0;
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < 12; k++) {
+    const int kc = k / 3, kr = k % 3;
+    const double ak = a[kr];
+    double ark;
+    switch (kc) {
+      case 0: ark = ik_dpp<0x00>(ak); break;
+      case 1: ark = ik_dpp<0x55>(ak); break;
+      case 2: ark = ik_dpp<0xAA>(ak); break;
+      default: ark = ik_dpp<0xFF>(ak); break;
+    }
+    const double mag = used ? -1.0 : fabs(ark);
+    double rown = 1.0 / ark;
+    asm volatile("" : "+v"(rown));
+    double m = ik_max(mag, ik_dpp<0x124>(mag));
+    m = ik_max(m, ik_dpp<0x128>(m));
+    const double mx = ik_max(ik_max(ik_readlane(m, 0), ik_readlane(m, 16)), ik_readlane(m, 32));
+    ok = ok && (mx > 0.0);
+    const unsigned long long cand = __ballot(cg == 0 && !used && mag == mx);
+    const int p_lane = cand ? __ffsll((long long)cand) - 1 : 0;
+    const double rinv = ik_readlane(rown, p_lane);
+    const int src4 = (p_lane + cg) << 2;
+    double ap[3], xp[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) { ap[j] = ik_shfl(a[j], src4); xp[j] = ik_shfl(x[j], src4); }
+    const bool is_p = (lane >> 2) == (p_lane >> 2);
+    const double f = is_p ? 0.0 : ark * rinv;
+#pragma unroll
+    for (int j = 0; j < 3; j++) { a[j] = a[j] - f * ap[j]; x[j] = x[j] - f * xp[j]; }
+    if (is_p) { used = true; my_k = k; my_d = rinv; }
+  }
+  if (live_row) {
+#pragma unroll
+    for (int j = 0; j < 3; j++) X[my_k * 12 + 3 * cg + j] = x[j] * my_d;
+  }
+  return ok;
+}
+// ... and serially for the host (flimo_update_chain forms iteration -1's half itself): the steps of csrc/host/flimo_ikfom.cpp: inverse_gj
+__host__ inline bool ik_inverse_gj12_serial(const double* Ain, double* Ainv) {
+  const int n = 12;
+  double A[144], X[144], dk[12];
+  int prow[12];
+  bool used[12];
+  for (int i = 0; i < 144; i++) { A[i] = Ain[i]; X[i] = 0.0; }
+  for (int i = 0; i < n; i++) { X[i * n + i] = 1.0; used[i] = false; }
+  for (int k = 0; k < n; k++) {
+    int p = -1;
+    double best = -1.0;
+    for (int r = 0; r < n; r++) {
+      if (used[r]) continue;
+      const double m = fabs(A[r * n + k]);
+      if (m > best) { best = m; p = r; }
+    }
+    if (p < 0 || !(best > 0.0)) return false;
+    const double rinv = 1.0 / A[p * n + k];
+    for (int r = 0; r < n; r++) {
+      if (r == p) continue;
+      const double f = A[r * n + k] * rinv;
+      for (int j = k + 1; j < n; j++) A[r * n + j] = A[r * n + j] - f * A[p * n + j];
+      for (int c = 0; c < n; c++) X[r * n + c] = X[r * n + c] - f * X[p * n + c];
+    }
+    used[p] = true; prow[k] = p; dk[k] = rinv;
+  }
+  for (int k = 0; k < n; k++)
+    for (int c = 0; c < n; c++) Ainv[k * n + c] = X[prow[k] * n + c] * dk[k];
+  return true;
+}
+
 // ---- data handed between workgroups of ONE launch: written through / read past the XCD's L2 (agent scope, relaxed) -------------
 __device__ __forceinline__ void ik_st(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void ik_sti(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -437,13 +522,27 @@ __device__ __forceinline__ void ik_pre_block(double* lds, double R, int tid) {
   __syncthreads();
   for (int e = tid; e < n * 12; e += 256) PR[e] = P_[(e / 12) * n + (e % 12)] / R;
   __syncthreads();
+  // The gain of :1722-1729 is taken through the block-inverse identity (see ik_final_stage): A11^-1 and G2 = A21 A11^-1 of
+  // A = P_ / R do not depend on the measurement
+  double* AI = lds + IKL_AI;
+  double* G2 = lds + IKL_G2;
+  if (tid < 64) (void)ik_gj12_inverse_wave(PR, AI, tid);       // A11 = PR[0:12] (a zero pivot: the final stage's solve reports it)
+  __syncthreads();
+  if (tid < 132) {
+    const int i = tid / 12, j = tid % 12;
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < 12; k++) acc += PR[(12 + i) * 12 + k] * AI[k * 12 + j];
+    G2[tid] = acc;
+  }
+  __syncthreads();
 }
 
 // The same half, serially, for the host (flimo_update_chain computes iteration -1's with it: x == x_prop there, so no
 // transcendental function is evaluated and host and device agree bit for bit).  dxn[23], PR[276] out.
-__host__ inline void ik_pre_serial(const double xc[26], const double xp[26], const double* P_prop, double R, double* dxn, double* PR) {
+__host__ inline void ik_pre_serial(const double xc[26], const double xp[26], const double* P_prop, double R, double* dxn, double* AI, double* G2) {
   const int n = IK_N;
-  double dx[IK_N], Jb[22], P_[529];
+  double dx[IK_N], Jb[22], P_[529], PR[276];
   for (int s = 0; s < 2; s++) {
     const int o = s == 0 ? 3 : 7, idx = s == 0 ? 3 : 6;
     const Q4 a{xc[o], xc[o + 1], xc[o + 2], xc[o + 3]};
@@ -490,6 +589,13 @@ __host__ inline void ik_pre_serial(const double xc[26], const double xp[26], con
   };
   left(3, 3, Jb); right(3, 3, Jb); left(3, 6, Jb + 9); right(3, 6, Jb + 9); left(2, 21, Jb + 18); right(2, 21, Jb + 18);
   for (int e = 0; e < n * 12; e++) PR[e] = P_[(e / 12) * n + (e % 12)] / R;
+  if (!ik_inverse_gj12_serial(PR, AI)) for (int e = 0; e < 144; e++) AI[e] = 0.0;      // (singular A11: the solve's zero pivot hands the loop back)
+  for (int i = 0; i < 11; i++)
+    for (int j = 0; j < 12; j++) {
+      double acc = 0.0;
+      for (int k = 0; k < 12; k++) acc += PR[(12 + i) * 12 + k] * AI[k * 12 + j];
+      G2[i * 12 + j] = acc;
+    }
 }
 
 // ---- the extra workgroup of a pass's reducing launch: leaves the measurement-independent half of THIS iteration (and, in the
@@ -500,7 +606,7 @@ __device__ __forceinline__ void ik_extra_block(const ChainCtl& ch, double* lds, 
   if (ch.prior) {
     const ChainPrior* pr = ch.prior;
     for (int i = tid; i < 529; i += 256) ik_st(&S->P_prop[i], pr->P[i]);
-    for (int e = tid; e < n * 12; e += 256) ik_st(&S->pre_PR[e], pr->PR[e]);
+    for (int e = tid; e < 276; e += 256) ik_st(&S->pre_AG[e], pr->AG[e]);
     if (tid < 26) { const double v = pr->x[tid]; ik_st(&S->x[tid], v); ik_st(&S->x_prop[tid], v); }
     else if (tid >= 32 && tid < 32 + n) ik_st(&S->limit[tid - 32], pr->limit[tid - 32]);
     else if (tid >= 64 && tid < 64 + n) ik_st(&S->pre_dxn[tid - 64], pr->dxn[tid - 64]);
@@ -517,9 +623,9 @@ __device__ __forceinline__ void ik_extra_block(const ChainCtl& ch, double* lds, 
     const double R = S->R;
     __syncthreads();
     ik_pre_block(lds, R, tid);
-    const double* PR = lds + IKL_PR;
+    const double* AG = lds + IKL_AI;                             // A11^-1 (144) and G2 (132): contiguous
     const double* dxn = lds + IKL_DXN;
-    for (int e = tid; e < n * 12; e += 256) ik_st(&S->pre_PR[e], PR[e]);
+    for (int e = tid; e < 276; e += 256) ik_st(&S->pre_AG[e], AG[e]);
     if (tid >= 64 && tid < 64 + n) ik_st(&S->pre_dxn[tid - 64], dxn[tid - 64]);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -590,7 +696,8 @@ __device__ __forceinline__ void ik_final_stage(const ChainCtl& ch, unsigned long
                                                int* s_i, int tid) {
   ChainState* S = ch.S;
   const int n = IK_N;
-  double* PR = lds + IKL_PR;
+  double* AI = lds + IKL_AI;
+  double* G2 = lds + IKL_G2;
   double* HTH = lds + IKL_HTH;
   double* T = lds + IKL_T;
   double* HTh = lds + IKL_HTh;
@@ -643,7 +750,7 @@ __device__ __forceinline__ void ik_final_stage(const ChainCtl& ch, unsigned long
   } else if (tid == 224) {
     s_i[20] = ik_ldi(&S->it); s_i[21] = ik_ldi(&S->t); s_i[22] = ik_ldi(&S->passes); s_i[23] = ik_ldi(&S->max_iter);
   }
-  for (int e = tid; e < n * 12; e += 256) PR[e] = ik_ld(&S->pre_PR[e]);
+  for (int e = tid; e < 276; e += 256) AI[e] = ik_ld(&S->pre_AG[e]);            // A11^-1 and G2 (contiguous)
   const int all_ok = __syncthreads_and(pass_ok ? 1 : 0);
   IK_STAMP(1);
   const int M = (int)llrint(live[IK_LIVE - 1]);
@@ -654,13 +761,12 @@ __device__ __forceinline__ void ik_final_stage(const ChainCtl& ch, unsigned long
     ik_hand_back(ch, lds, !all_ok ? CH_R_FAILED : (M < n ? CH_R_FEW : CH_R_TIES), it, t_in, passes, M, n_strag, n_ties, tid);
     return;
   }
-  // ---- gain through the matrix-inversion lemma (:1722-1729): T = H^T H PR[0:12] + I;  v = H^T h + H^T H dx_new[0:12] ----
+  // ---- gain (:1722-1729).  With A = P_ / R and B = H^T H:  P_inv = (A^-1 + E B E^T)^-1, and by the block-inverse identity
+  //      P_inv E = [I; A21 A11^-1] (A11^-1 + B)^-1  -- the reference's formula without the two 23 x 23 inverses and without forming
+  //      I + B A11 (whose 1 drowns in B A11 ~ 1e7: three digits worse on the measured states, tests/test_host_logic.py).
+  //      N = A11^-1 + H^T H;  v = H^T h + H^T H dx_new[0:12];  N z = v;  dx_ = [z; G2 z] - dx_new ----
   if (tid < 144) {
-    const int i = tid / 12, j = tid % 12;
-    double acc = 0.0;
-#pragma unroll
-    for (int k = 0; k < 12; k++) acc += HTH[i * 12 + k] * PR[k * 12 + j];
-    T[tid] = acc + (i == j ? 1.0 : 0.0);
+    T[tid] = AI[tid] + HTH[tid];
   } else if (tid >= 192 && tid < 204) {
     const int i = tid - 192;
     double acc = 0.0;
@@ -670,8 +776,8 @@ __device__ __forceinline__ void ik_final_stage(const ChainCtl& ch, unsigned long
   }
   __syncthreads();
   IK_STAMP(4);
-  // Wave 0: T u = v by Gauss-Jordan in its registers, then dx_ = PR u - dx_new (the step of :1733 in the order the host filter
-  // also takes it; shared memory written and read by the same wave: in order, no workgroup barrier).  Beside it, one
+  // Wave 0: N z = v by Gauss-Jordan in its registers, then dx_ = [z; G2 z] - dx_new (the step of :1733 in the order the host
+  // filter also takes it; shared memory written and read by the same wave: in order, no workgroup barrier).  Beside it, one
   // lane of another wave: degeneracy (:1736-1744) -- when H^T H[0:6,0:6] - D I is positive definite every eigenvalue is >= D
   // and the projector is the identity (the host's shortcut); otherwise the host does the eigen-decomposition.
   if (tid < 64) {
@@ -680,10 +786,12 @@ __device__ __forceinline__ void ik_final_stage(const ChainCtl& ch, unsigned long
     IK_STAMP(5);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (tid < n) {
+    if (tid < 12) {
+      dxu[tid] = uu[tid] - dxn[tid];
+    } else if (tid < n) {
       double acc = 0.0;
 #pragma unroll
-      for (int m = 0; m < 12; m++) acc += PR[tid * 12 + m] * uu[m];
+      for (int m = 0; m < 12; m++) acc += G2[(tid - 12) * 12 + m] * uu[m];
       dxu[tid] = acc - dxn[tid];
     }
   } else if (tid == 192) {

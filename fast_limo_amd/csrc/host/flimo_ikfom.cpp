@@ -878,44 +878,48 @@ void Esekf::update_iterated_dyn_share_modified(double R, double D) {
         K_x = Cov::zero();
         for (int i = 0; i < n; i++) for (int j = 0; j < 12; j++) { double s = 0; for (int k = 0; k < 12; k++) s += P_inv(i, k) * HTH(k, j); K_x(i, j) = s; }
       } else {
-        // Same quantities through the matrix-inversion lemma (only H^T H's 12x12 block is non-zero):
-        //   P_inv[:, 0:12] = ((P/R)^-1 + E B E^T)^-1 E = A[:, 0:12] (I + B A11)^-1,  A = P/R, B = H^T H
-        // one 12x12 LU instead of two 23x23 inverses; better conditioned than A^-1 + B.
-        // A[:, 0:12] = P[:, 0:12] / R once (the same quotients the two products below would form element by element)
+        // The reference's formula,  P_inv = ((P/R)^-1 + E B E^T)^-1  with A = P/R and B = H^T H (only its 12x12 block is non-zero),
+        // through the block-inverse identity
+        //     P_inv E = [ I ; A21 A11^-1 ] (A11^-1 + B)^-1 :
+        // the Schur complement of A^-1's lower block IS A11^-1, so the 12 x 12 system N = A11^-1 + B is exactly what the two
+        // 23 x 23 inverses of :1722,1726 solve -- as accurate on the measured states as the literal form (1e-15 of a 3e-2 m step)
+        // where the round-3 form A[:, 0:12] (I + B A11)^-1 lost three digits to the 1 that drowns in B A11 ~ 1e7
+        // (tests/test_host_logic.py: ..._against_80_bit_arithmetic).  A11^-1 and G2 = A21 A11^-1 do not depend on the measurement:
+        // the device filter forms them beside the pass (csrc/hip/flimo_ieskf.h: ik_pre_block); N z = v is the only solve between the
+        // pass's sums and the step.  Same operations in the same order on both sides.
         double PR[kDof][12];
         for (int i = 0; i < n; i++)
           for (int k = 0; k < 12; k++) PR[i][k] = P_(i, k) / R;
-        // (the products below run i-k-j: every element is still summed over k in ascending order -- the same values bit for bit --
-        //  but the inner loop runs along a row, which the compiler vectorises)
-        Mat<12, 12> T, S;
-        for (int i = 0; i < 12; i++) {
-          double acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-          for (int k = 0; k < 12; k++) { const double hk = HTH(i, k); for (int j = 0; j < 12; j++) acc[j] += hk * PR[k][j]; }
-          for (int j = 0; j < 12; j++) T(i, j) = acc[j] + (i == j ? 1.0 : 0.0);
-        }
-        if (!inverse_gj(12, &T.a[0][0], &S.a[0][0])) inverse<12>(T, S);      // (same steps as the device filter's solve)
+        Mat<12, 12> A11, Ai, Nm, Ninv;
+        for (int i = 0; i < 12; i++) for (int j = 0; j < 12; j++) A11(i, j) = PR[i][j];
+        if (!inverse_gj(12, &A11.a[0][0], &Ai.a[0][0])) inverse<12>(A11, Ai);
+        double G2[kDof - 12][12];
+        for (int i = 0; i < n - 12; i++)
+          for (int j = 0; j < 12; j++) { double a = 0; for (int k = 0; k < 12; k++) a += PR[12 + i][k] * Ai(k, j); G2[i][j] = a; }
+        for (int i = 0; i < 12; i++) for (int j = 0; j < 12; j++) Nm(i, j) = Ai(i, j) + HTH(i, j);
+        // The step of :1733, dx_ = K_h + (K_x - I) dx_new with K_h = W H^T h, K_x = W H^T H (W = P_inv E), taken as
+        //   v = H^T h + H^T H dx_new[0:12];  N z = v;  dx_ = [z; G2 z] - dx_new
+        // (one 12-vector solve between the sums and the step: the device filter's critical path)
+        lemma_step = true;
+        double v[12], z[12];
+        for (int i = 0; i < 12; i++) { double a = 0; for (int k = 0; k < 12; k++) a += HTH(i, k) * dx_new[k]; v[i] = HTh[i] + a; }
+        const bool have_inv = inverse_gj(12, &Nm.a[0][0], &Ninv.a[0][0]) || inverse<12>(Nm, Ninv);
+        (void)have_inv;
+        if (!solve_gj(12, &Nm.a[0][0], v, z))
+          for (int m = 0; m < 12; m++) { double a = 0; for (int k = 0; k < 12; k++) a += Ninv(m, k) * v[k]; z[m] = a; }
+        for (int i = 0; i < 12; i++) dx_lemma[i] = z[i] - dx_new[i];
+        for (int i = 12; i < n; i++) { double a = 0; for (int m = 0; m < 12; m++) a += G2[i - 12][m] * z[m]; dx_lemma[i] = a - dx_new[i]; }
+        // K_x = P_inv E B = [Ninv; G2 Ninv] B  (the covariance update of the last iteration, :1766-1820)
         double W[kDof][12];
-        for (int i = 0; i < n; i++) {
-          double acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-          for (int k = 0; k < 12; k++) { const double pk = PR[i][k]; for (int j = 0; j < 12; j++) acc[j] += pk * S(k, j); }
-          for (int j = 0; j < 12; j++) W[i][j] = acc[j];
-        }
+        for (int i = 0; i < 12; i++) for (int j = 0; j < 12; j++) W[i][j] = Ninv(i, j);
+        for (int i = 12; i < n; i++)
+          for (int j = 0; j < 12; j++) { double a = 0; for (int k = 0; k < 12; k++) a += G2[i - 12][k] * Ninv(k, j); W[i][j] = a; }
         K_x = Cov::zero();
         for (int i = 0; i < n; i++) {
           double acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
           for (int k = 0; k < 12; k++) { const double wk = W[i][k]; for (int j = 0; j < 12; j++) acc[j] += wk * HTH(k, j); }
           for (int j = 0; j < 12; j++) K_x(i, j) = acc[j];
         }
-        // The step of :1733, dx_ = K_h + (K_x - I) dx_new with K_h = W H^T h and K_x = W H^T H (W = P_inv[:, 0:12]), taken in the
-        // order  dx_ = PR (S (H^T h + H^T H dx_new[0:12])) - dx_new : two 12-vectors between the solve and the step instead of
-        // the two 23 x 12 products (which only the covariance of the last iteration needs) -- the order the device filter's
-        // critical path runs in (csrc/hip/flimo_ieskf.hip: ik_post_block)
-        lemma_step = true;
-        double v[12], u[12];
-        for (int i = 0; i < 12; i++) { double a = 0; for (int k = 0; k < 12; k++) a += HTH(i, k) * dx_new[k]; v[i] = HTh[i] + a; }
-        if (!solve_gj(12, &T.a[0][0], v, u))                     // T u = v directly (the device filter never forms S)
-          for (int m = 0; m < 12; m++) { double a = 0; for (int k = 0; k < 12; k++) a += S(m, k) * v[k]; u[m] = a; }
-        for (int i = 0; i < n; i++) { double a = 0; for (int m = 0; m < 12; m++) a += PR[i][m] * u[m]; dx_lemma[i] = a - dx_new[i]; }
       }
     }
 

@@ -160,7 +160,8 @@ class Esekf {
   std::vector<PassLog> log;
   bool keep_log = false;
   // true: literal two-inverse form of esekfom.hpp:1722-1729 and unconditional eigen-decomposition;
-  // false (default): algebraically identical 12x12 form (matrix-inversion lemma) + Cholesky shortcut
+  // false (default): the same formula through the block-inverse identity -- one 12x12 system, as accurate as the literal form --
+  // + Cholesky shortcut
   bool reference_solve = false;
 
   Esekf();

@@ -68,7 +68,7 @@ int main(int argc, char** argv) {
   ChainPrior* pr; CK(hipHostMalloc((void**)&pr, sizeof(ChainPrior), hipHostMallocMapped));
   memcpy(pr->x, x, sizeof(x)); memcpy(pr->P, P, sizeof(P)); memcpy(pr->limit, limits, sizeof(limits));
   pr->R = 0.001; pr->D = 5.0; pr->max_iter = max_iter; pr->pad = 0;
-  ik_pre_serial(x, x, P, 0.001, pr->dxn, pr->PR);
+  ik_pre_serial(x, x, P, 0.001, pr->dxn, pr->AG, pr->AG + 144);
   PoseMats P0; pose_from_x26(x, P0);
   double* res; CK(hipHostMalloc((void**)&res, CH_RES * 2 * sizeof(double), hipHostMallocMapped)); memset(res, 0, CH_RES * 2 * sizeof(double));
   double* lg; CK(hipHostMalloc((void**)&lg, CH_MAX_PASSES * CH_LOGN * 2 * sizeof(double), hipHostMallocMapped));
