@@ -192,6 +192,7 @@ struct flimo_ctx {
   void* d_nbrk = nullptr;          // neighbour records of the general pass
   size_t nbrk_cap = 0;
   int wait_timeout_ms = 2000;      // wall-clock bound of the wait for a pass's result (flimo_set_wait_timeout_ms)
+  hipEvent_t adopt_ev = nullptr;   // flimo_scan_adopt: orders the two contexts' streams around the hand-over copies
   hipEvent_t timeout_ev = nullptr; // recorded behind the launches of a pass / chain whose wait ran out
   bool timeout_pending = false;    // ... and not yet seen complete: no new pass is queued on top of it (check_abandoned)
   // the whole iterated update enqueued at once (flimo_chain.h, flimo_update_chain)
@@ -218,6 +219,7 @@ struct flimo_ctx {
   bool chain_ev_made = false;
   double chain_alg_ms = 0;
   long long chain_alg_n = 0, chains_run = 0, chains_back = 0, chains_declined = 0;
+  int fov_check = 0, fov_check_bad = 0;   // device atan2f vs this host's libm: 0 not checked yet, 1 equal, -1 different (the FoV filter is then declined)
   bool tail = true;                // FLIMO_TAIL=0: pending queries go to the worklist + widen_kernel dispatch instead of being finished inside the k-NN launch (A/B checks)
 };
 
@@ -449,6 +451,7 @@ extern "C" void flimo_ctx_destroy(flimo_ctx* c) {
   map_scratch_free(c->scratch);
   for (int i = 0; i < 6; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->timeout_ev) (void)hipEventDestroy(c->timeout_ev);
+  if (c->adopt_ev) (void)hipEventDestroy(c->adopt_ev);
   if (c->h_wl_count) (void)hipHostFree(c->h_wl_count);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->book) insert_book_destroy(c->book);
@@ -1194,6 +1197,40 @@ extern "C" int flimo_raw_scan_filter_order_set(flimo_ctx* c, const void* points3
   F.dist = cfg->dist_active ? 1 : 0; F.min_dist = cfg->min_dist;
   F.rate_on = cfg->rate_active ? 1 : 0; F.rate = cfg->rate_value;
   F.kind = cfg->time_kind; F.eos = cfg->end_of_sweep ? 1 : 0; F.sweep_ref = cfg->sweep_ref_time;
+  if (cfg->fov_active) {
+    // The FoV verdict is |atan2f(y, x)| < angle with the HOST libm's rounding (Localizer.cpp:873-876).  The device restates glibc's
+    // fdlibm routine (up to 2.40); a libm that rounds atan2f differently (glibc >= 2.41: CORE-MATH) would keep another set at the
+    // FoV's edge than the host path and the reference on that host do.  Checked once per context: 8 192 argument pairs (signed
+    // zeros, denormals, huge ratios, the octant boundaries, random bit patterns); on any difference the device declines and the
+    // caller's host front end filters the sweep.
+    if (c->fov_check == 0) {
+      std::vector<float> yx, got;
+      auto push = [&](float y, float x) { yx.push_back(y); yx.push_back(x); };
+      const float sp[] = {0.f, -0.f, 1.f, -1.f, 1e-38f, -1e-38f, 1e-45f, 3.4e38f, -3.4e38f, 0.4375f, 0.6875f, 1.1875f, 2.4375f, 1e-10f, 1e10f, 0.5f, 2.f};
+      for (float y : sp) for (float x : sp) push(y, x);
+      uint64_t st = 0x9E3779B97F4A7C15ull;
+      auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (uint32_t)(st >> 16); };
+      while (yx.size() < 2 * 8192) {
+        uint32_t a = rnd(), b = rnd();
+        float y, x;
+        if (yx.size() < 2 * 4096) { y = ((int)(a % 200001u) - 100000) * 1e-3f; x = ((int)(b % 200001u) - 100000) * 1e-3f; }     // sensor-like coordinates
+        else { memcpy(&y, &a, 4); memcpy(&x, &b, 4); if (!(y == y) || !(x == x)) continue; }                                        // any finite or infinite pattern
+        push(y, x);
+      }
+      const int npair = (int)(yx.size() / 2);
+      got.resize(npair);
+      HIPCHK(c, atan2f_probe(c->stream, yx.data(), npair, got.data()));
+      int bad = 0;
+      for (int i = 0; i < npair; i++) {
+        const float ref = std::atan2(yx[2 * i], yx[2 * i + 1]);
+        if (memcmp(&ref, &got[i], 4) != 0 && !(ref != ref && got[i] != got[i])) bad++;
+      }
+      c->fov_check = bad == 0 ? 1 : -1;
+      c->fov_check_bad = bad;
+    }
+    if (c->fov_check < 0)
+      return fail(c, FLIMO_ERR_UNSUPPORTED, "this host's atan2f differs from the device's restatement on %d of 8192 argument pairs: the FoV filter stays on the host front end", c->fov_check_bad);
+  }
   F.fov = cfg->fov_active ? 1 : 0; F.fov_angle = cfg->fov_angle;
   HIPCHK(c, filter_raw_scan(c->stream, c->d_raw32, n, F, c->d_scan_raw, c->d_scan_t, c->d_filt_ext, c->scratch, time_order ? c->d_tkey[0] : nullptr));
   HIPCHK(c, hipMemcpyAsync(c->h_filt_ext, c->d_filt_ext, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
@@ -1237,6 +1274,35 @@ extern "C" int flimo_raw_scan_filter_order_set(flimo_ctx* c, const void* points3
   }
   HIPCHK(c, sort_scan(c->stream, c->d_scan_raw, m, c->d_raw_sorted, c->scratch, c->d_scan_t, c->d_t_sorted));
   c->raw_n = m;
+  return FLIMO_OK;
+}
+
+// The resident raw sweep of `src` becomes `dst`'s (both on one GPU): what flimo_raw_scan_filter_order_set left in src -- kept points,
+// stamps, their Morton-ordered copies -- is copied device to device on dst's stream behind src's queued work.  Lets a caller run
+// the input stage of sweep k + 1 on a context of its own while dst's stream still carries sweep k's map insert.
+extern "C" int flimo_scan_adopt(flimo_ctx* dst, flimo_ctx* src) {
+  if (!dst || !src || dst == src) return FLIMO_ERR_INVALID;
+  if (dst->device != src->device) return fail(dst, FLIMO_ERR_INVALID, "flimo_scan_adopt: the two contexts are on different devices");
+  (void)hipSetDevice(dst->device);
+  const size_t m = src->raw_n;
+  dst->deskew_pending = false;
+  { const int rc = ensure_scan(dst, m); if (rc) return rc; }
+  dst->raw_n = 0; dst->resident_t_offset = 0.0; dst->raw_time_ordered = false;
+  if (m == 0) return FLIMO_OK;
+  if (!src->adopt_ev) HIPCHK(dst, hipEventCreateWithFlags(&src->adopt_ev, hipEventDisableTiming));
+  HIPCHK(dst, hipEventRecord(src->adopt_ev, src->stream));
+  HIPCHK(dst, hipStreamWaitEvent(dst->stream, src->adopt_ev, 0));
+  HIPCHK(dst, hipMemcpyAsync(dst->d_scan_raw, src->d_scan_raw, m * sizeof(float4), hipMemcpyDeviceToDevice, dst->stream));
+  HIPCHK(dst, hipMemcpyAsync(dst->d_scan_t, src->d_scan_t, m * sizeof(double), hipMemcpyDeviceToDevice, dst->stream));
+  HIPCHK(dst, hipMemcpyAsync(dst->d_raw_sorted, src->d_raw_sorted, m * sizeof(float4), hipMemcpyDeviceToDevice, dst->stream));
+  HIPCHK(dst, hipMemcpyAsync(dst->d_t_sorted, src->d_t_sorted, m * sizeof(double), hipMemcpyDeviceToDevice, dst->stream));
+  // (src may start its next sweep at once: its buffers must outlive these copies)
+  if (!dst->adopt_ev) HIPCHK(dst, hipEventCreateWithFlags(&dst->adopt_ev, hipEventDisableTiming));
+  HIPCHK(dst, hipEventRecord(dst->adopt_ev, dst->stream));
+  HIPCHK(dst, hipStreamWaitEvent(src->stream, dst->adopt_ev, 0));
+  dst->raw_n = m;
+  dst->resident_t_offset = src->resident_t_offset;
+  dst->raw_time_ordered = src->raw_time_ordered;
   return FLIMO_OK;
 }
 

@@ -44,6 +44,7 @@ struct GBook {
   int* big_items = nullptr;      // item ids whose subtree build gets a whole block (at most batch / 2048 of them)
   size_t big_cap = 0;
   int* counters = nullptr;       // [0] items, [1] list cursor, [2] overflow
+  bool counters_dirty = false;   // an update() that did not reach its trailing mail (an error return) left them non-zero: the next one clears them
   int last_items = 0;
 
   // take over a tree built on the host for the first batch

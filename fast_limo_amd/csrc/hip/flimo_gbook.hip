@@ -707,7 +707,9 @@ hipError_t GBook::update(hipStream_t st, const float4* batch, int m, const float
     S.cub_tmp_bytes = need + 1024;
   }
   GBCHK(sort_pairs_u32(S.cub_tmp, tmp_bytes, S.keys_in, S.keys_out, S.vals_in, S.vals_out, m, 0, key_bits, st));
-  // (counters: zero since the last batch's final mail, see below)
+  // (counters: zero since the last batch's final mail, see below -- unless that batch left early on an error: cleared here then)
+  if (counters_dirty) GBCHK(hipMemsetAsync(counters, 0, 4 * sizeof(int), st));
+  counters_dirty = true;
   hipLaunchKernelGGL(gb_decide_kernel, dim3(blocks), dim3(256), 0, st, S.keys_out, m, node_c, node_cnt, min_half,
                      downsample ? 1 : 0, flags /* dec_keep */, reinterpret_cast<int*>(rank) /* dec_assign */, items, counters, node_item, big_items, nan_key,
                      cursor);
@@ -752,9 +754,11 @@ hipError_t GBook::update(hipStream_t st, const float4* batch, int m, const float
     // ... and the same small kernel zeroes the four counters for the next batch
     const MailPart parts[2] = {{node_n_dev, 1, MAIL_BOOK_END}, {counters + 2, 1, MAIL_BOOK_END + 1}};
     GBCHK(mail_words(st, S, parts, 2, false, counters, 4));
+    counters_dirty = false;
     finish_pending = true;
   } else {
     GBCHK(hipMemsetAsync(counters, 0, 4 * sizeof(int), st));       // nothing to build: [1] / [3] may still be set
+    counters_dirty = false;
   }
   *kept_out = kept;
   last_items = n_items;

@@ -157,6 +157,7 @@ hipError_t map_box_count(hipStream_t st, const uint32_t* cell_start, int nx, int
                          uint32_t* count_dev, uint32_t* count_host, MapBuildScratch& S);
 hipError_t map_box_copy(hipStream_t st, const float4* pts, const uint32_t* cell_start, int nx, int ny, int nz, int xs, const int c0[3],
                         const int c1[3], float4* out, MapBuildScratch& S);
+hipError_t atan2f_probe(hipStream_t st, const float* yx_host, int n, float* out_host);   // the device's atan2f on n (y, x) pairs
 size_t row_table_size(int nx, int ny, int nz);
 hipError_t map_build_row_table(hipStream_t st, const uint32_t* cell_start, int nx, int ny, int nz, uint32_t* out, bool zero_pads = true);
 // pcl::VoxelGrid on device points: out gets one centroid per occupied voxel in ascending voxel index

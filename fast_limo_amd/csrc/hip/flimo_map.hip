@@ -131,8 +131,13 @@ hipError_t mail_words(hipStream_t st, MapBuildScratch& S, const MailPart* parts,
 static hipError_t fetch_bbox(hipStream_t st, MapBuildScratch& S, unsigned ob[6]) {
   const MailPart part{S.bbox, 6, MAIL_BBOX};
   hipError_t e = mail_words(st, S, &part, 1, true);
-  if (e != hipSuccess) return e;
-  if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) {
+    // the re-arming rode on the mail kernel that did not run: put the empty box back by hand, so the next reduction starts from it
+    const unsigned init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+    (void)hipMemcpy(S.bbox, init, sizeof(init), hipMemcpyHostToDevice);
+    return e;
+  }
   for (int i = 0; i < 6; i++) ob[i] = S.mail_host[MAIL_BBOX + i];
   return hipSuccess;
 }
@@ -484,6 +489,25 @@ __global__ __launch_bounds__(256) void rowtable_kernel(const uint32_t* __restric
     if (y < ny && x <= nx) out[((size_t)x * pz + (size_t)(z + 2)) * py + (size_t)(y + 2)] = tile[tx][ty + 8 * r];
   }
 }
+// The device's atan2f (flimo_math.h: libm_atan2f, fdlibm's routine as glibc up to 2.40 evaluates it) on n argument pairs: the host
+// compares with ITS libm once per context before the FoV filter may run on the device (flimo_capi.hip: fov_selfcheck)
+__global__ void atan2f_probe_kernel(const float2* __restrict__ yx, int n, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = libm_atan2f(yx[i].x, yx[i].y);
+}
+hipError_t atan2f_probe(hipStream_t st, const float* yx_host, int n, float* out_host) {
+  float2* d_in = nullptr; float* d_out = nullptr;
+  hipError_t e;
+  if ((e = hipMalloc(&d_in, (size_t)n * sizeof(float2))) != hipSuccess) return e;
+  if ((e = hipMalloc(&d_out, (size_t)n * sizeof(float))) != hipSuccess) { (void)hipFree(d_in); return e; }
+  e = hipMemcpyAsync(d_in, yx_host, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) { hipLaunchKernelGGL(atan2f_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_in, n, d_out); e = hipGetLastError(); }
+  if (e == hipSuccess) e = hipMemcpyAsync(out_host, d_out, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(d_in); (void)hipFree(d_out);
+  return e;
+}
+
 size_t row_table_size(int nx, int ny, int nz) { return ((size_t)nx + 1) * ((size_t)ny + 4) * ((size_t)nz + 4); }
 // zero_pads: the table is new or its shape changed (the pads have to be cleared); false when the same table is refreshed
 hipError_t map_build_row_table(hipStream_t st, const uint32_t* cell_start, int nx, int ny, int nz, uint32_t* out, bool zero_pads) {

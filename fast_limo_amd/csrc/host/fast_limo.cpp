@@ -229,7 +229,7 @@ Eigen::Matrix4f State::get_extr_RT_inv() const { return se3_inv(qLI, pLI); }
 // ---------------------------------------------------------------------------------------------
 // Mapper
 // ---------------------------------------------------------------------------------------------
-Mapper::Mapper() : num_threads_(1), ctx_(nullptr), device_(0), cell_size_(0.f), async_(std::getenv("FLIMO_SYNC_INSERT") == nullptr) {
+Mapper::Mapper() : num_threads_(1), ctx_(nullptr), front_(nullptr), device_(0), cell_size_(0.f), async_(std::getenv("FLIMO_SYNC_INSERT") == nullptr) {
   config.NUM_MATCH_POINTS = 5;                                    // Mapper.cpp:23-31
   config.MAX_NUM_MATCHES = 2000;
   config.MAX_NUM_PC2MATCH = 10000;
@@ -247,6 +247,7 @@ Mapper::~Mapper() {
     wcv_.notify_all();
     worker_.join();
   }
+  if (front_) flimo_ctx_destroy(front_);
   if (ctx_) flimo_ctx_destroy(ctx_);
 }
 // ---- asynchronous path exit -------------------------------------------------------------------------------------------
@@ -322,8 +323,11 @@ bool Mapper::attach(int device, float cell_size) {
   }
   flimo_map_cfg mc{config.octree.min_extent, config.octree.bucket_size, config.octree.downsampling ? 1 : 0, cell_size_};
   flimo_map_config(ctx_, &mc);
+  // the input stage's own context (see front_ctx()); a sequential insert leaves nothing to overlap with
+  if (std::getenv("FLIMO_NO_FRONT_CTX") == nullptr && flimo_ctx_create(device, &front_) != FLIMO_OK) front_ = nullptr;
   return true;
 }
+flimo_ctx* Mapper::front_ctx() { return async_ ? front_ : nullptr; }
 void Mapper::set_num_threads(int n) { if (n >= 1) num_threads_ = n; }
 void Mapper::set_config(const Config::iKFoM::Mapping& cfg) {       // Mapper.cpp:38-45
   config = cfg;
@@ -1242,8 +1246,13 @@ int Localizer::deskewOnDevice(pcl::PointCloud<PointType>::Ptr& raw_pc, double st
   const auto& mc = config.ikfom.mapping;
   const size_t n = raw_pc->points.size();
   dev_front_end_ = false;
+  order_ctx_ = nullptr;
   if (!deviceFrontEndEnabled()) return 0;
-  flimo_ctx* c = map_->ctx();
+  // Upload, filters, stamps and the time order do not read the map: they run on the Mapper's second context while the main one
+  // still carries the previous sweep's insert (Mapper::add runs behind publish() there); the main context is waited for only
+  // when the sweep is handed over, right before the deskew.
+  flimo_ctx* const front = map_->front_ctx();
+  flimo_ctx* c = front ? front : map_->ctx();
   if (!c) return 0;
   // WHO needs the reference's time order on the device?  "The first N of pc2match" (MAX_NUM_PC2MATCH / MAX_NUM_MATCHES) and the
   // float sums of the voxel grid.  It is produced there when the stamps are pairwise different (a radix sort gives the unique
@@ -1295,6 +1304,15 @@ int Localizer::deskewOnDevice(pcl::PointCloud<PointType>::Ptr& raw_pc, double st
   }
   if (flimo_raw_scan_filter_order_set(c, src, n, &fc, need_order ? 1 : 0, &kept, &last_stamp, &nan, &tied) != FLIMO_OK || nan || tied)
     return 0;
+  order_ctx_ = c;
+  if (front) {
+    c = map_->ctx();                                                       // waits for the running insert
+    if (!c) return 0;
+    if (flimo_scan_adopt(c, front) != FLIMO_OK) {
+      std::cout << "FAST_LIMO::scan hand-over failed: " << flimo_last_error(c) << "\n";
+      return -1;
+    }
+  }
   lazy_order_.clear();
   arrival_order_ = !need_order;
   dev_front_end_ = true;
@@ -1473,9 +1491,10 @@ void Localizer::downloadClouds(const double x26[26]) {
   mat_n_dev_ = n_dev;
   if (dev_time_ordered_) {
     size_t m = 0;
-    flimo_raw_scan_order(c, nullptr, 0, &m);
+    flimo_ctx* oc = order_ctx_ ? order_ctx_ : c;                    // the context that ran the input stage keeps the time order
+    flimo_raw_scan_order(oc, nullptr, 0, &m);
     prep_order_.resize(m);
-    flimo_raw_scan_order(c, prep_order_.data(), m, &got);
+    flimo_raw_scan_order(oc, prep_order_.data(), m, &got);
   }
   mat_downloaded_ = true;
 }

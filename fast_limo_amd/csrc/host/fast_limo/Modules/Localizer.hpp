@@ -123,6 +123,7 @@ class fast_limo::Localizer {
   std::vector<uint32_t> lazy_order_;    // arrival-order sweeps: pc2match position -> arrival index (empty: device order = pc2match order)
   bool arrival_order_ = false, arrival_keys_pending_ = false;
   bool dev_front_end_ = false;          // the last sweep went through the device front end (clouds materialized afterwards)
+  flimo_ctx* order_ctx_ = nullptr;      // the context that ran this sweep's input stage (it keeps the time order)
   bool dev_time_ordered_ = false;       // ... and the device holds it in the reference's time order (stamps pairwise different)
   bool dev_voxel_ = false;
   const float* mat_body4_ = nullptr;          // the downloaded clouds (float4 records in the context's pinned memory)

@@ -39,6 +39,10 @@ class fast_limo::Mapper {
   // thread: ctx() (like every other method of this class) waits for it first, so whoever holds the handle sees a
   // quiescent context.  Re-fetch it after each Localizer::updatePointCloud instead of caching it across scans.
   flimo_ctx* ctx() { sync(); return ctx_; }
+  // A second context on the same GPU for the INPUT stage of a sweep (upload, filters, stamps, time order: nothing of it reads the
+  // map): handed out WITHOUT waiting for a running insert, so that stage overlaps the previous sweep's Mapper::add; the sweep is
+  // then handed over to ctx() with flimo_scan_adopt.  nullptr when it cannot be created (the caller uses ctx()).
+  flimo_ctx* front_ctx();
   // Path exit of a scan (reference Localizer.cpp:361-377: transformPointCloud + Mapper::add) for the scan RESIDENT on
   // the GPU: returns at once, the insert runs on the worker thread and overlaps the host-side preparation (filters,
   // time sort) of the next scan.  FLIMO_SYNC_INSERT=1 (or set_async(false)) makes it synchronous.
@@ -58,6 +62,7 @@ class fast_limo::Mapper {
   Config::iKFoM::Mapping config;
   int num_threads_;
   flimo_ctx* ctx_;
+  flimo_ctx* front_;            // the input stage's context (front_ctx())
   int device_;
   float cell_size_;
   std::string err_;

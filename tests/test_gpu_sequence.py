@@ -207,6 +207,60 @@ def test_async_map_insert_is_invisible(built):
     np.testing.assert_array_equal(a_pts, s_pts)
 
 
+@pytest.mark.parametrize("unique", [True, False])
+def test_input_stage_on_its_own_context_is_invisible(built, oracle, unique, monkeypatch):
+    """Upload, filters, stamps and time order of sweep k + 1 run on a second context while the main one still carries sweep k's map
+    insert; the sweep is handed over with flimo_scan_adopt right before the deskew.  Same drive with the second context switched
+    off (FLIMO_NO_FRONT_CTX): states, covariances, map sizes and the stored map bit for bit, with pairwise different stamps (the
+    device puts the sweep into time order and keeps that order on the second context) and with tied ones."""
+    from fast_limo_amd import api
+    n_scans, n_pts, speed = 8, 40000, 10.0
+    st, w, a = synth.stationary_imu(0.0, 0.1 * n_scans + 0.06)
+    filt = dict(crop_active=1, cropBoxMin=(-1.0, -1.0, -1.0), cropBoxMax=(1.0, 1.0, 1.0), dist_active=1, min_dist=2.0,
+                rate_active=1, rate_value=2, voxel_active=1, leaf_size=0.5)
+
+    def drive(front):
+        if front:
+            monkeypatch.delenv("FLIMO_NO_FRONT_CTX", raising=False)
+        else:
+            monkeypatch.setenv("FLIMO_NO_FRONT_CTX", "1")
+        G = api.Localizer(api.default_cfg(sensor_type=2, MAX_NUM_PC2MATCH=10000, MAX_NUM_MATCHES=5000, **filt))
+        G.set_flags(add_to_map=True, download_clouds=(not unique))
+        x0 = G.get_x(); x0[14] = speed; G.set_x(x0)
+        i = 0
+        out = []
+        for k in range(n_scans):
+            until = 0.1 * (k + 1) + 0.005
+            while i < len(st) and st[i] <= until:
+                G.update_imu(st[i], w[i], a[i]); i += 1
+            scan = synth.corridor_scan(k, n_pts, 77, speed=speed)
+            rel = scan[:, 4].astype(np.float64)
+            if unique:
+                rel = (np.argsort(np.argsort(rel, kind="stable"), kind="stable") + 0.5) * (0.1 / n_pts)
+            else:
+                rel = np.floor(rel * 2560.0) / 2560.0
+            pts = oracle.make_points(scan[:, :3], 1.0, timestamp=0.1 * k + rel)
+            rc = G.update_pointcloud_points(pts, 0.1 * k)
+            out.append((rc, G.get_x().copy(), G.get_P().copy(), G.map_size() if k % 3 == 0 else None,
+                        G.pc2match() if (not unique and rc == 0) else None))
+        G.sync()
+        pts = G.hip.map_points()
+        G.close()
+        return out, pts
+
+    f_out, f_pts = drive(True)
+    n_out, n_pts_ = drive(False)
+    for k, (rf, rn) in enumerate(zip(f_out, n_out)):
+        assert rf[0] == rn[0] == 0, (k, rf[0], rn[0])
+        np.testing.assert_array_equal(rf[1], rn[1], err_msg=f"x scan {k}")
+        np.testing.assert_array_equal(rf[2], rn[2], err_msg=f"P scan {k}")
+        assert rf[3] == rn[3], k
+        if rf[4] is not None:
+            np.testing.assert_array_equal(rf[4], rn[4], err_msg=f"pc2match scan {k}")
+    assert f_pts.shape[0] > 1000
+    np.testing.assert_array_equal(f_pts, n_pts_)
+
+
 def test_reference_yaml_configuration_sequence(built, oracle):
     """The reference's shipped configuration (config/kitti.yaml): crop box +-1 m, min distance 4 m, every 4th point, voxel
     grid 1 m, MAX_NUM_PC2MATCH 1e4 / MAX_NUM_MATCHES 5000, LiDAR mounted off the IMU (the yaml's extrinsics), sensor biases,
