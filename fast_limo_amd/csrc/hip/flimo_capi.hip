@@ -82,9 +82,11 @@ struct flimo_ctx {
   float4* d_scan_raw = nullptr;    // raw lidar-frame points for deskew (caller order)
   float4* d_raw_sorted = nullptr;  // the same in Morton order, w = original index
   double* d_t_sorted = nullptr;
+  size_t raw_sorted_cap = 0;       // capacity of the two above
   float4* d_scan_world = nullptr;
   double* d_scan_t = nullptr;
   size_t scan_n = 0, scan_cap = 0, raw_n = 0;
+  size_t order_n = 0;              // points of the last input stage run HERE (d_tperm; stays when the sweep is handed over)
   size_t sorted_n = 0;             // points in d_scan_sorted: scan_n, or the MAX_NUM_PC2MATCH prefix once a pass asked for it
   void* d_frames = nullptr;
   size_t frames_cap = 0;
@@ -212,7 +214,7 @@ struct flimo_ctx {
   // 9 us on a fast host, 15-19 us on a slow one (BENCH_r03: 5 497 scans/s where the builder's box gave 7 102).  The round trip is
   // measured once at context creation (launch_rtt_us); update_mode 0 = choose by it, 1 = host loop, 2 = chain.
   int update_mode = 0;                   // FLIMO_HOST_UPDATE=1 -> 1, FLIMO_HOST_UPDATE=0 -> 2, unset -> 0 (flimo_set_update_mode)
-  double launch_rtt_us = 0.0;            // median launch -> granule seen of a one-thread kernel on this host
+  double launch_rtt_us = 0.0;            // launch -> granule seen (lower quartile) of a one-thread kernel on this host
   double rtt_threshold_us = 8.0;         // FLIMO_RTT_THRESHOLD_US: the chain is chosen when the round trip is longer
   bool host_update = false;              // (the choice in force) flimo_update_chain always declines (the host loop runs the update; A/B)
   hipEvent_t chain_ev[CH_MAX_PASSES][8]; // per pass: [0,1] first launch, [2,3] fit launch, [4,5] algebra launch, [6,7] widening launch (lazy)
@@ -398,8 +400,9 @@ extern "C" int flimo_ctx_create(int device, flimo_ctx** out) {
   c->book = insert_book_create();
   load_dev_switches(c);
   {
-    // launch -> result round trip of this host (median of 32 after 8 warm-ups): a one-thread kernel stores a granule to mapped
-    // memory, the host spins on its tag -- what every host-driven pass pays beyond its kernels
+    // launch -> result round trip of this host (lower quartile of 32 after 8 warm-ups: a property of the host, not of what else
+    // runs at the moment): a one-thread kernel stores a granule to mapped memory, the host spins on its tag -- what every
+    // host-driven pass pays beyond its kernels
     std::vector<double> rt;
     volatile unsigned long long* tagp = reinterpret_cast<volatile unsigned long long*>(c->h_chain_res) + 1;
     for (int i = 0; i < 40; i++) {
@@ -413,7 +416,7 @@ extern "C" int flimo_ctx_create(int device, flimo_ctx** out) {
     }
     (void)hipStreamSynchronize(c->stream);
     std::sort(rt.begin(), rt.end());
-    c->launch_rtt_us = rt[rt.size() / 2];
+    c->launch_rtt_us = rt[rt.size() / 4];
     memset(c->h_chain_res, 0, 2 * sizeof(double));
     c->host_update = c->update_mode == 1 || (c->update_mode == 0 && c->launch_rtt_us <= c->rtt_threshold_us);
   }
@@ -964,11 +967,24 @@ extern "C" int flimo_knn(flimo_ctx* c, const float* q, size_t nq, int k, int32_t
 }
 
 // ---- scan -------------------------------------------------------------------------------------
+// the Morton-ordered raw sweep (deskew's input) has a capacity of its own: flimo_scan_adopt exchanges it between two contexts
+static int ensure_raw_sorted(flimo_ctx* c, size_t n) {
+  if (n <= c->raw_sorted_cap) return FLIMO_OK;
+  const size_t cap = n + n / 4 + 1024;
+  float4* rs = nullptr;
+  double* ts = nullptr;
+  HIPCHK(c, hipMalloc(&rs, cap * sizeof(float4)));
+  HIPCHK(c, hipMalloc(&ts, cap * sizeof(double)));
+  (void)hipFree(c->d_raw_sorted); (void)hipFree(c->d_t_sorted);
+  c->d_raw_sorted = rs; c->d_t_sorted = ts; c->raw_sorted_cap = cap;
+  return FLIMO_OK;
+}
 static int ensure_scan(flimo_ctx* c, size_t n) {
+  { const int rc = ensure_raw_sorted(c, n); if (rc) return rc; }
   if (n <= c->scan_cap) return FLIMO_OK;
   const size_t cap = n + n / 4 + 1024;
-  float4 *a = nullptr, *b = nullptr, *w = nullptr, *so = nullptr, *rs = nullptr;
-  double *t = nullptr, *ts = nullptr;
+  float4 *a = nullptr, *b = nullptr, *w = nullptr, *so = nullptr;
+  double* t = nullptr;
   void* nb = nullptr;
   int* wl = nullptr;
   double* fp = nullptr;
@@ -987,10 +1003,6 @@ static int ensure_scan(flimo_ctx* c, size_t n) {
     c->d_fit2_partials = f2; c->fit2_partials_cap = f2n;
   }
   HIPCHK(c, hipMalloc(&so, cap * sizeof(float4)));
-  HIPCHK(c, hipMalloc(&rs, cap * sizeof(float4)));
-  HIPCHK(c, hipMalloc(&ts, cap * sizeof(double)));
-  (void)hipFree(c->d_raw_sorted); (void)hipFree(c->d_t_sorted);
-  c->d_raw_sorted = rs; c->d_t_sorted = ts;
   HIPCHK(c, hipMalloc(&nb, cap * nbr_rec_size()));
   HIPCHK(c, hipMemsetAsync(nb, 0, cap * nbr_rec_size(), c->stream));      // flag 0 everywhere: no record is ever read uninitialised
   HIPCHK(c, hipMalloc(&wl, (cap + 8192) * wl_entry_size()));   // + slack: every widening wave prefetches its first slot
@@ -1120,7 +1132,7 @@ extern "C" int flimo_raw_scan_set(flimo_ctx* c, const float* xyz, size_t n, size
     HIPCHK(c, sort_scan(c->stream, c->d_scan_raw, n, c->d_raw_sorted, c->scratch, c->d_scan_t, c->d_t_sorted));
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
-  c->raw_n = n;
+  c->raw_n = n; c->order_n = n;
   c->resident_t_offset = 0.0;
   return FLIMO_OK;
 }
@@ -1152,7 +1164,7 @@ extern "C" int flimo_raw_scan_filter_order_set(flimo_ctx* c, const void* points3
   (void)hipSetDevice(c->device);
   int rc = ensure_scan(c, n);
   if (rc) return rc;
-  c->raw_n = 0; c->resident_t_offset = 0.0; c->raw_time_ordered = false;
+  c->raw_n = 0; c->order_n = 0; c->resident_t_offset = 0.0; c->raw_time_ordered = false;
   if (n == 0) return FLIMO_OK;
   if (n > c->raw32_cap) {
     (void)hipFree(c->d_raw32);
@@ -1273,12 +1285,13 @@ extern "C" int flimo_raw_scan_filter_order_set(flimo_ctx* c, const void* points3
     c->raw_time_ordered = true;
   }
   HIPCHK(c, sort_scan(c->stream, c->d_scan_raw, m, c->d_raw_sorted, c->scratch, c->d_scan_t, c->d_t_sorted));
-  c->raw_n = m;
+  c->raw_n = m; c->order_n = m;
   return FLIMO_OK;
 }
 
-// The resident raw sweep of `src` becomes `dst`'s (both on one GPU): what flimo_raw_scan_filter_order_set left in src -- kept points,
-// stamps, their Morton-ordered copies -- is copied device to device on dst's stream behind src's queued work.  Lets a caller run
+// The resident raw sweep of `src` becomes `dst`'s (both on one GPU): the Morton-ordered points and stamps that
+// flimo_raw_scan_filter_order_set left in src -- the deskew's input, the only part of a raw sweep read after the input stage --
+// change owner (the two contexts exchange the buffers: no copy), dst's stream is ordered behind src's queued work.  Lets a caller run
 // the input stage of sweep k + 1 on a context of its own while dst's stream still carries sweep k's map insert.
 extern "C" int flimo_scan_adopt(flimo_ctx* dst, flimo_ctx* src) {
   if (!dst || !src || dst == src) return FLIMO_ERR_INVALID;
@@ -1287,22 +1300,22 @@ extern "C" int flimo_scan_adopt(flimo_ctx* dst, flimo_ctx* src) {
   const size_t m = src->raw_n;
   dst->deskew_pending = false;
   { const int rc = ensure_scan(dst, m); if (rc) return rc; }
-  dst->raw_n = 0; dst->resident_t_offset = 0.0; dst->raw_time_ordered = false;
+  dst->raw_n = 0; dst->order_n = 0; dst->resident_t_offset = 0.0; dst->raw_time_ordered = false;
   if (m == 0) return FLIMO_OK;
   if (!src->adopt_ev) HIPCHK(dst, hipEventCreateWithFlags(&src->adopt_ev, hipEventDisableTiming));
+  if (!dst->adopt_ev) HIPCHK(dst, hipEventCreateWithFlags(&dst->adopt_ev, hipEventDisableTiming));
+  // dst reads what src's queued sort writes; src's next sweep writes what dst's queued work may still read
   HIPCHK(dst, hipEventRecord(src->adopt_ev, src->stream));
   HIPCHK(dst, hipStreamWaitEvent(dst->stream, src->adopt_ev, 0));
-  HIPCHK(dst, hipMemcpyAsync(dst->d_scan_raw, src->d_scan_raw, m * sizeof(float4), hipMemcpyDeviceToDevice, dst->stream));
-  HIPCHK(dst, hipMemcpyAsync(dst->d_scan_t, src->d_scan_t, m * sizeof(double), hipMemcpyDeviceToDevice, dst->stream));
-  HIPCHK(dst, hipMemcpyAsync(dst->d_raw_sorted, src->d_raw_sorted, m * sizeof(float4), hipMemcpyDeviceToDevice, dst->stream));
-  HIPCHK(dst, hipMemcpyAsync(dst->d_t_sorted, src->d_t_sorted, m * sizeof(double), hipMemcpyDeviceToDevice, dst->stream));
-  // (src may start its next sweep at once: its buffers must outlive these copies)
-  if (!dst->adopt_ev) HIPCHK(dst, hipEventCreateWithFlags(&dst->adopt_ev, hipEventDisableTiming));
   HIPCHK(dst, hipEventRecord(dst->adopt_ev, dst->stream));
   HIPCHK(dst, hipStreamWaitEvent(src->stream, dst->adopt_ev, 0));
+  std::swap(dst->d_raw_sorted, src->d_raw_sorted);
+  std::swap(dst->d_t_sorted, src->d_t_sorted);
+  std::swap(dst->raw_sorted_cap, src->raw_sorted_cap);
   dst->raw_n = m;
   dst->resident_t_offset = src->resident_t_offset;
   dst->raw_time_ordered = src->raw_time_ordered;
+  src->raw_n = 0;                                   // src keeps the time order (flimo_raw_scan_order), not the sweep
   return FLIMO_OK;
 }
 
@@ -1310,9 +1323,9 @@ extern "C" int flimo_scan_adopt(flimo_ctx* dst, flimo_ctx* src) {
 // arrival order)
 extern "C" int flimo_raw_scan_order(flimo_ctx* c, uint32_t* order_out, size_t cap, size_t* n) {
   if (!c || !n) return FLIMO_ERR_INVALID;
-  *n = c->raw_n;
-  if (!order_out || cap == 0 || c->raw_n == 0) return FLIMO_OK;
-  const size_t m = std::min(cap, c->raw_n);
+  *n = c->order_n;
+  if (!order_out || cap == 0 || c->order_n == 0) return FLIMO_OK;
+  const size_t m = std::min(cap, c->order_n);
   if (!c->raw_time_ordered) { for (size_t i = 0; i < m; i++) order_out[i] = (uint32_t)i; return FLIMO_OK; }
   (void)hipSetDevice(c->device);
   HIPCHK(c, hipMemcpyAsync(order_out, c->d_tperm, m * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));

@@ -151,10 +151,11 @@ int flimo_upload_stage(flimo_ctx* ctx, size_t bytes, void** host_ptr);
 int flimo_raw_scan_filter_order_set(flimo_ctx* ctx, const void* points32, size_t n, const flimo_filter_cfg* cfg, int time_order,
                                     size_t* n_kept, double* last_stamp, int* nan_stamp, int* tied);
 int flimo_raw_scan_order(flimo_ctx* ctx, uint32_t* order_out, size_t cap, size_t* n);
-/* The resident raw sweep of `src` (what flimo_raw_scan_filter_set / _order_set left there) becomes `dst`'s: device-to-device copies on
- * dst's stream, ordered behind src's queued work.  Both contexts on one GPU.  The input stage of a sweep -- upload, filters, stamps,
- * time order (Localizer.cpp:262-302,741-805) -- does not read the map: a caller runs it on a context of its own while dst's stream
- * still carries the previous sweep's Mapper::add, then hands the sweep over (flimo_raw_scan_order stays with src). */
+/* The resident raw sweep of `src` (what flimo_raw_scan_filter_set / _order_set left there) becomes `dst`'s: the two contexts exchange
+ * the buffers of the Morton-ordered points and stamps (no copy) and dst's stream is ordered behind src's queued work.  Both contexts
+ * on one GPU.  The input stage of a sweep -- upload, filters, stamps, time order (Localizer.cpp:262-302,741-805) -- does not read
+ * the map: a caller runs it on a context of its own while dst's stream still carries the previous sweep's Mapper::add, then hands
+ * the sweep over.  src keeps the time order (flimo_raw_scan_order) and no sweep. */
 int flimo_scan_adopt(flimo_ctx* dst, flimo_ctx* src);
 /* flimo_deskew_resident with the sweep's time offset added to every resident stamp (Localizer.cpp:795-800) */
 int flimo_deskew_resident_offset(flimo_ctx* ctx, const flimo_frame* frames, size_t n_frames, const float lidar2baselink_T[16],
