@@ -41,7 +41,7 @@ class LocCfg(C.Structure):
 
 
 HOST_SYMBOLS = [
-    "flimo_loc_create", "flimo_loc_destroy", "flimo_loc_ctx", "flimo_loc_sync", "flimo_loc_set_async_insert", "flimo_loc_set_lazy_time_order", "flimo_loc_set_gpu_filters", "flimo_loc_set_propagation_wait", "flimo_loc_last_insert_seconds", "flimo_loc_update_imu", "flimo_loc_update_pointcloud", "flimo_loc_update_pointcloud_points",
+    "flimo_loc_create", "flimo_loc_destroy", "flimo_loc_ctx", "flimo_loc_sync", "flimo_loc_set_async_insert", "flimo_loc_set_lazy_time_order", "flimo_loc_set_gpu_filters", "flimo_loc_set_propagation_wait", "flimo_loc_last_insert_seconds", "flimo_loc_update_imu", "flimo_loc_update_imu_n", "flimo_loc_replay", "flimo_loc_update_pointcloud", "flimo_loc_update_pointcloud_points",
     "flimo_loc_map_add", "flimo_loc_map_size", "flimo_loc_get_x", "flimo_loc_set_x", "flimo_loc_get_P",
     "flimo_loc_set_P", "flimo_loc_set_flags", "flimo_loc_num_passes", "flimo_loc_get_pass", "flimo_loc_get_pc2match",
     "flimo_loc_get_final_scan", "flimo_loc_get_stage_times", "flimo_loc_get_pose_cov", "flimo_loc_register_resident", "flimo_loc_host_profile",
@@ -134,6 +134,10 @@ def load_host():
     L.flimo_loc_last_insert_seconds.restype = C.c_double
     L.flimo_loc_last_insert_seconds.argtypes = [vp]
     L.flimo_loc_update_imu.argtypes = [vp, C.c_double, f32p, f32p]
+    L.flimo_loc_update_imu_n.argtypes = [vp, C.c_size_t, np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS"), f32p, f32p]
+    f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+    L.flimo_loc_replay.argtypes = [vp, C.c_size_t, C.POINTER(C.c_void_p), np.ctypeslib.ndpointer(np.uintp, flags="C_CONTIGUOUS"), f64p, f64p,
+                                   C.c_size_t, f64p, f32p, f32p, np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS"), f64p]
     L.flimo_loc_update_pointcloud.argtypes = [vp, f32p, C.c_size_t, C.c_double]
     L.flimo_loc_update_pointcloud_points.argtypes = [vp, C.c_void_p, C.c_size_t, C.c_double]
     L.flimo_loc_map_add.argtypes = [vp, f32p, C.c_size_t, C.c_double]
@@ -208,6 +212,34 @@ class Localizer:
     def update_imu(self, stamp, ang_vel, lin_accel):
         self._L.flimo_loc_update_imu(self._h, float(stamp), np.ascontiguousarray(ang_vel, dtype=np.float32),
                                      np.ascontiguousarray(lin_accel, dtype=np.float32))
+
+    def update_imu_n(self, stamps, ang_vel, lin_accel):
+        """Several samples in arrival order with one call across the binding (one updateIMU each)."""
+        t = np.ascontiguousarray(stamps, dtype=np.float64).reshape(-1)
+        w = np.ascontiguousarray(ang_vel, dtype=np.float32).reshape(-1)
+        a = np.ascontiguousarray(lin_accel, dtype=np.float32).reshape(-1)
+        assert w.size == 3 * t.size and a.size == 3 * t.size
+        rc = self._L.flimo_loc_update_imu_n(self._h, t.size, t, w, a)
+        if rc != 0:
+            raise RuntimeError("flimo_loc_update_imu_n failed (%d)" % rc)
+
+    def replay(self, sweeps, sweep_stamps, imu_until, imu_stamps, ang_vel, lin_accel):
+        """A recorded drive at full speed from native code (flimo_loc_replay): ``sweeps`` is a list of POINT_DTYPE arrays.
+        Returns (status per sweep, seconds since the start at which each call returned)."""
+        sweeps = [np.ascontiguousarray(p) for p in sweeps]
+        n = len(sweeps)
+        ptrs = (C.c_void_p * n)(*[p.ctypes.data for p in sweeps])
+        npts = np.array([p.shape[0] for p in sweeps], np.uintp)
+        t = np.ascontiguousarray(imu_stamps, dtype=np.float64).reshape(-1)
+        w = np.ascontiguousarray(ang_vel, dtype=np.float32).reshape(-1)
+        a = np.ascontiguousarray(lin_accel, dtype=np.float32).reshape(-1)
+        status = np.zeros(n, np.int32)
+        secs = np.zeros(n, np.float64)
+        rc = self._L.flimo_loc_replay(self._h, n, ptrs, npts, np.ascontiguousarray(sweep_stamps, dtype=np.float64),
+                                      np.ascontiguousarray(imu_until, dtype=np.float64), t.size, t, w, a, status, secs)
+        if rc != 0:
+            raise RuntimeError("flimo_loc_replay failed (%d)" % rc)
+        return status, secs
 
     def update_pointcloud(self, pts5, stamp) -> int:
         p = np.ascontiguousarray(pts5, dtype=np.float32).reshape(-1, 5)

@@ -1,6 +1,7 @@
 // fast_limo_amd/csrc/host/capi_host.cpp -- C wrapper (include/flimo_localizer_c.h) over the host
 // C++ Localizer / Mapper.
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <memory>
 #include "../../../include/flimo_localizer_c.h"
@@ -93,6 +94,14 @@ int flimo_loc_update_imu(flimo_loc* L, double stamp, const float w[3], const flo
   L->loc->updateIMU(m);
   return FLIMO_OK;
 }
+int flimo_loc_update_imu_n(flimo_loc* L, size_t n, const double* stamps, const float* w3, const float* a3) {
+  if (!L || (n && (!stamps || !w3 || !a3))) return FLIMO_ERR_INVALID;
+  for (size_t i = 0; i < n; i++) {
+    const int rc = flimo_loc_update_imu(L, stamps[i], w3 + 3 * i, a3 + 3 * i);
+    if (rc != FLIMO_OK) return rc;
+  }
+  return FLIMO_OK;
+}
 int flimo_loc_update_pointcloud(flimo_loc* L, const float* pts5, size_t n, double stamp) {
   if (!L) return FLIMO_ERR_INVALID;
   auto pc = std::make_shared<pcl::PointCloud<PointType>>();
@@ -109,6 +118,7 @@ int flimo_loc_update_pointcloud(flimo_loc* L, const float* pts5, size_t n, doubl
 int flimo_loc_update_pointcloud_points(flimo_loc* L, const void* pts32, size_t n, double stamp) {
   if (!L || (!pts32 && n)) return FLIMO_ERR_INVALID;
   static_assert(sizeof(PointType) == 32, "PointType must keep the reference's 32-byte layout");
+  if (L->loc->updatePointCloudView(static_cast<const PointType*>(pts32), n, stamp)) return L->loc->last_status();
   // (a fresh cloud per sweep costs its pages' first touch -- about as much as the copy; the library filters the cloud in place
   //  and keeps no pointer to it, so the last sweep's storage is free again unless the wrapper's user took it)
   pcl::PointCloud<PointType>::Ptr pc = (L->in_pc && L->in_pc.use_count() == 1) ? L->in_pc : std::make_shared<pcl::PointCloud<PointType>>();
@@ -117,6 +127,23 @@ int flimo_loc_update_pointcloud_points(flimo_loc* L, const void* pts32, size_t n
   L->in_pc = pc;
   L->loc->updatePointCloud(pc, stamp);
   return L->loc->last_status();
+}
+// A recorded drive replayed at full speed from native code: before sweep k every IMU sample with stamp <= imu_until[k] is handed to
+// updateIMU, then the sweep to updatePointCloud -- what a C++ driver replaying a bag does, without a binding's per-call cost
+// between the sweeps.  status_out[k]: the sweep's status; seconds_out[k] (optional): when its call returned, since the start.
+int flimo_loc_replay(flimo_loc* L, size_t n_sweeps, const void* const* sweeps32, const size_t* n_points, const double* sweep_stamps,
+                     const double* imu_until, size_t n_imu, const double* imu_stamps, const float* w3, const float* a3,
+                     int* status_out, double* seconds_out) {
+  if (!L || (n_sweeps && (!sweeps32 || !n_points || !sweep_stamps || !imu_until || !status_out))) return FLIMO_ERR_INVALID;
+  if (n_imu && (!imu_stamps || !w3 || !a3)) return FLIMO_ERR_INVALID;
+  const auto t0 = std::chrono::steady_clock::now();
+  size_t i = 0;
+  for (size_t k = 0; k < n_sweeps; k++) {
+    for (; i < n_imu && imu_stamps[i] <= imu_until[k]; i++) flimo_loc_update_imu(L, imu_stamps[i], w3 + 3 * i, a3 + 3 * i);
+    status_out[k] = flimo_loc_update_pointcloud_points(L, sweeps32[k], n_points[k], sweep_stamps[k]);
+    if (seconds_out) seconds_out[k] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  }
+  return FLIMO_OK;
 }
 // fast_limo::State::update (State.cpp:76-119) on a flat state, for unit tests: p3 q4(xyzw) v3 g3 w3 a3 bg3 ba3
 void flimo_host_state_update(float s[25], double time, double t) {

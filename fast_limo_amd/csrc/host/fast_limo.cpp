@@ -298,6 +298,7 @@ void Mapper::worker_main() {
 void Mapper::add_scan(const double x26[26], double stamp) {
   if (!ctx_) return;
   sync();
+  handoff_time_ = now_s();
   if (!async_) { run_insert(x26, stamp); return; }
   if (!worker_.joinable()) worker_ = std::thread(&Mapper::worker_main, this);
   {
@@ -1241,19 +1242,21 @@ bool Localizer::deviceFrontEndEnabled() const {
   return sensor == SensorType::OUSTER || sensor == SensorType::VELODYNE || sensor == SensorType::HESAI || sensor == SensorType::LIVOX;
 }
 
-int Localizer::deskewOnDevice(pcl::PointCloud<PointType>::Ptr& raw_pc, double start_time) {
+int Localizer::deskewOnDevice(const PointType* raw_points, size_t n, double start_time) {
   const auto& fl = config.filters;
   const auto& mc = config.ikfom.mapping;
-  const size_t n = raw_pc->points.size();
   dev_front_end_ = false;
   order_ctx_ = nullptr;
   if (!deviceFrontEndEnabled()) return 0;
   // Upload, filters, stamps and the time order do not read the map: they run on the Mapper's second context while the main one
   // still carries the previous sweep's insert (Mapper::add runs behind publish() there); the main context is waited for only
   // when the sweep is handed over, right before the deskew.
+  static const bool prof = std::getenv("FLIMO_PROF_FRONT") != nullptr;     // developer timing of this function's stages
+  const double tf0 = prof ? now_s() : 0.0;
   flimo_ctx* const front = map_->front_ctx();
   flimo_ctx* c = front ? front : map_->ctx();
   if (!c) return 0;
+  const double tf1 = prof ? now_s() : 0.0;
   // WHO needs the reference's time order on the device?  "The first N of pc2match" (MAX_NUM_PC2MATCH / MAX_NUM_MATCHES) and the
   // float sums of the voxel grid.  It is produced there when the stamps are pairwise different (a radix sort gives the unique
   // sorted order); with equal stamps only the host routine reproduces the library's order: host path.
@@ -1273,7 +1276,7 @@ int Localizer::deskewOnDevice(pcl::PointCloud<PointType>::Ptr& raw_pc, double st
   double last_stamp = 0.0;
   int nan = 0, tied = 0;
   static_assert(sizeof(PointType) == 32, "PointType layout");
-  const void* src = &raw_pc->points[0];
+  const void* src = raw_points;
   if (n >= 32768) {
     // pageable cloud -> the context's pinned upload buffer, shared with two helpers (chunks are taken from a common counter: a
     // helper that wakes late finds nothing left and nobody waits for it)
@@ -1302,17 +1305,25 @@ int Localizer::deskewOnDevice(pcl::PointCloud<PointType>::Ptr& raw_pc, double st
       src = stage;
     }
   }
+  const double tf2 = prof ? now_s() : 0.0;
   if (flimo_raw_scan_filter_order_set(c, src, n, &fc, need_order ? 1 : 0, &kept, &last_stamp, &nan, &tied) != FLIMO_OK || nan || tied)
     return 0;
+  const double tf3 = prof ? now_s() : 0.0;
+  double tf4 = tf3;
   order_ctx_ = c;
   if (front) {
     c = map_->ctx();                                                       // waits for the running insert
     if (!c) return 0;
+    tf4 = prof ? now_s() : 0.0;
     if (flimo_scan_adopt(c, front) != FLIMO_OK) {
       std::cout << "FAST_LIMO::scan hand-over failed: " << flimo_last_error(c) << "\n";
       return -1;
     }
   }
+  if (prof)
+    std::fprintf(stderr, "front: since last insert hand-off %.1f us | ctx %.1f  stage copy %.1f  filter %.1f  wait insert %.1f  adopt %.1f | last insert %.1f us\n",
+                 1e6 * (tf0 - map_->last_handoff_time()), 1e6 * (tf1 - tf0), 1e6 * (tf2 - tf1), 1e6 * (tf3 - tf2), 1e6 * (tf4 - tf3),
+                 1e6 * (now_s() - tf4), 1e6 * map_->last_insert_seconds());
   lazy_order_.clear();
   arrival_order_ = !need_order;
   dev_front_end_ = true;
@@ -1610,18 +1621,35 @@ int Localizer::registerResident(const double x26_prior[26], const double* P_prio
   return rc;
 }
 
+// updatePointCloud for a caller that holds the sweep as plain memory (a language binding): when the sweep takes the device's input
+// stage and nobody wants host clouds, the points go from the caller's memory straight into the upload buffer -- no cloud object is
+// built.  false: not applicable, nothing was done (the caller builds the cloud and calls updatePointCloud).
+bool Localizer::updatePointCloudView(const PointType* points, size_t n, double time_stamp) {
+  if (!points || n < 1 || !imu_calibrated_ || imu_buffer.empty()) return false;
+  if (download_clouds || config.debug || !deviceFrontEndEnabled()) return false;
+  last_status_ = 0;
+  const double t0_dev = now_s();
+  prep_started_ = false;
+  const int on_device = deskewOnDevice(points, n, time_stamp);
+  if (on_device == 0) { device_declined_ = true; return false; }     // (the updatePointCloud that follows does not ask again)
+  mat_downloaded_ = false;
+  finishUpdate(on_device > 0, t0_dev, t0_dev, now_s());
+  return true;
+}
+
 void Localizer::updatePointCloud(pcl::PointCloud<PointType>::Ptr& raw_pc, double time_stamp) {   // Localizer.cpp:245-399
   const double t0 = now_s();
   last_status_ = 0;
   if (!raw_pc || raw_pc->points.size() < 1) { std::cout << "FAST_LIMO::Raw PointCloud is empty!\n"; last_status_ = -1; return; }
   if (!imu_calibrated_) { last_status_ = -2; return; }
   if (imu_buffer.empty()) { std::cout << "FAST_LIMO::IMU buffer is empty!\n"; last_status_ = -3; return; }
+  struct Rearm { bool& f; ~Rearm() { f = false; } } rearm{device_declined_};
   const double t0_dev = now_s();
   // the clouds the caller may ask for: their host-only part (filters on the host copy, time order) starts now, on a helper thread
   const bool want_clouds = download_clouds || config.debug;
   prep_started_ = false;
   if (want_clouds && deviceFrontEndEnabled()) startCloudPrep(raw_pc);
-  const int on_device = deskewOnDevice(raw_pc, time_stamp);            // filters + stamps (+ time order, voxel grid) + deskew on the GPU
+  const int on_device = device_declined_ ? 0 : deskewOnDevice(&raw_pc->points[0], raw_pc->points.size(), time_stamp);   // filters + stamps (+ time order, voxel grid) + deskew on the GPU
   releaseRawCloud();                                                     // (deskewOnDevice does so itself as early as it can)
   if (on_device != 0) {
     const double t2d = now_s();

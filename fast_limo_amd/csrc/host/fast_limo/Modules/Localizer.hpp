@@ -29,6 +29,7 @@ class fast_limo::Localizer {
   // callbacks
   void updateIMU(IMUmeas& raw_imu);
   void updatePointCloud(pcl::PointCloud<PointType>::Ptr& raw_pc, double time_stamp);
+  bool updatePointCloudView(const PointType* points, size_t n, double time_stamp);   // bindings: see fast_limo.cpp
 
   // outputs
   pcl::PointCloud<PointType>::Ptr get_pointcloud();
@@ -86,7 +87,7 @@ class fast_limo::Localizer {
   IMUmeas imu2baselink(IMUmeas& imu);
   void calibrateStandStill(const IMUmeas& imu);
   pcl::PointCloud<PointType>::Ptr deskewPointCloud(pcl::PointCloud<PointType>::Ptr& pc, double& start_time);   // Localizer.hpp:191
-  int deskewOnDevice(pcl::PointCloud<PointType>::Ptr& raw_pc, double start_time);       // filters + stamps + deskew on the GPU (f-2)
+  int deskewOnDevice(const PointType* raw_points, size_t n, double start_time);       // filters + stamps + deskew on the GPU (f-2)
   void finishUpdate(bool ok, double t0, double t1, double t2);
   void filterInput(pcl::PointCloud<PointType>::Ptr& raw_pc, pcl::PointCloud<PointType>::Ptr& input_pc, bool compact_raw = true);   // Localizer.cpp:262-302 in one pass
   void materializeClouds(pcl::PointCloud<PointType>::Ptr& raw_pc);     // device front end: host clouds after the update
@@ -123,6 +124,7 @@ class fast_limo::Localizer {
   std::vector<uint32_t> lazy_order_;    // arrival-order sweeps: pc2match position -> arrival index (empty: device order = pc2match order)
   bool arrival_order_ = false, arrival_keys_pending_ = false;
   bool dev_front_end_ = false;          // the last sweep went through the device front end (clouds materialized afterwards)
+  bool device_declined_ = false;        // updatePointCloudView asked the device front end for this sweep and was turned down
   flimo_ctx* order_ctx_ = nullptr;      // the context that ran this sweep's input stage (it keeps the time order)
   bool dev_time_ordered_ = false;       // ... and the device holds it in the reference's time order (stamps pairwise different)
   bool dev_voxel_ = false;

@@ -50,6 +50,7 @@ class fast_limo::Mapper {
   void sync();                                  // wait for a running insert (no-op when idle)
   void set_async(bool on) { sync(); async_ = on; }
   double last_insert_seconds() { sync(); return insert_seconds_; }
+  double last_handoff_time() const { return handoff_time_; }      // developer timing
   const Config::iKFoM::Mapping& config_ref() const { return config; }
   const std::string& last_error() const { return err_; }
 
@@ -74,6 +75,7 @@ class fast_limo::Mapper {
   std::atomic<bool> busy_{false}, quit_{false};   // written under wm_, also polled without it (short spins before the condition-variable waits)
   double job_x_[26];
   double job_stamp_ = 0.0;
+  double handoff_time_ = 0.0;
   double insert_seconds_ = 0.0;
   void run_insert(const double x26[26], double stamp);
   void worker_main();

@@ -771,7 +771,42 @@ void Esekf::predict(double dt, const Mat<12, 12>& Q, const InputIkfom& in) {
   }
   F1 = F1 + dt * fxf;
   const Mat<kDof, 12> G = dt * fwf;
-  P_ = F1 * P_ * F1.T() + G * Q * G.T();
+  // P_ = F1 * P_ * F1.T() + G * Q * G.T(), the sums in the order the dense products take them (k ascending) with the terms whose
+  // factor of F1 / G is exactly zero left out -- adding 0 * p changes no partial sum (F1 is the identity plus a few 3 x 3 blocks,
+  // G has twelve rows): a sample's covariance propagation in 2 us instead of 9, twenty samples between two sweeps
+  int nzF[kDof][kDof], nF[kDof], nzG[kDof][12], nG[kDof];
+  for (int i = 0; i < kDof; i++) {
+    nF[i] = 0; nG[i] = 0;
+    for (int k = 0; k < kDof; k++) if (F1(i, k) != 0.0) nzF[i][nF[i]++] = k;
+    for (int k = 0; k < 12; k++) if (G(i, k) != 0.0) nzG[i][nG[i]++] = k;
+  }
+  Cov T;                                                      // F1 * P_
+  for (int i = 0; i < kDof; i++) {
+    double row[kDof];
+    for (int j = 0; j < kDof; j++) row[j] = 0.0;
+    for (int q = 0; q < nF[i]; q++) {
+      const int k = nzF[i][q];
+      const double fik = F1(i, k);
+      for (int j = 0; j < kDof; j++) row[j] += fik * P_(k, j);
+    }
+    for (int j = 0; j < kDof; j++) T(i, j) = row[j];
+  }
+  Mat<kDof, 12> GQ;                                           // G * Q
+  for (int i = 0; i < kDof; i++)
+    for (int j = 0; j < 12; j++) {
+      double sum = 0.0;
+      for (int q = 0; q < nG[i]; q++) sum += G(i, nzG[i][q]) * Q(nzG[i][q], j);
+      GQ(i, j) = sum;
+    }
+  Cov Pn;
+  for (int i = 0; i < kDof; i++)
+    for (int j = 0; j < kDof; j++) {
+      double a = 0.0, b = 0.0;
+      for (int q = 0; q < nF[j]; q++) a += T(i, nzF[j][q]) * F1(j, nzF[j][q]);        // (T * F1^T)(i, j)
+      for (int q = 0; q < nG[j]; q++) b += GQ(i, nzG[j][q]) * G(j, nzG[j][q]);        // (GQ * G^T)(i, j)
+      Pn(i, j) = a + b;
+    }
+  P_ = Pn;
 }
 
 // (AVX2 clone chosen at load time where the CPU has it: the 12- and 23-wide inner loops run four doubles at a time; no FMA in either

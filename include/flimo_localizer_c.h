@@ -66,6 +66,15 @@ void   flimo_loc_set_gpu_filters(flimo_loc* L, int on);
 void   flimo_loc_set_propagation_wait(flimo_loc* L, double seconds);
 double flimo_loc_last_insert_seconds(flimo_loc* L);                   /* duration of the last insert (waits for it) */
 int    flimo_loc_update_imu(flimo_loc* L, double stamp, const float ang_vel[3], const float lin_accel[3]);
+/* n samples in arrival order, one updateIMU each (a binding whose per-call cost matters -- ctypes: 25 us -- hands over the samples
+ * between two sweeps at once) */
+int    flimo_loc_update_imu_n(flimo_loc* L, size_t n, const double* stamps, const float* ang_vel3, const float* lin_accel3);
+/* A recorded drive replayed at full speed from native code: before sweep k every IMU sample with stamp <= imu_until[k] goes to
+ * updateIMU, then the sweep (PointType records, as flimo_loc_update_pointcloud_points takes them) to updatePointCloud.
+ * status_out[k]: that sweep's status; seconds_out[k] (or NULL): when its call returned, since the start of the replay. */
+int    flimo_loc_replay(flimo_loc* L, size_t n_sweeps, const void* const* sweeps32, const size_t* n_points, const double* sweep_stamps,
+                        const double* imu_until, size_t n_imu, const double* imu_stamps, const float* ang_vel3, const float* lin_accel3,
+                        int* status_out, double* seconds_out);
 /* pts5: n x (x y z intensity time[s since sweep reference]).  Returns Localizer status:
  * 0 ok, 1 null iteration, <0 early return */
 int    flimo_loc_update_pointcloud(flimo_loc* L, const float* pts5, size_t n, double stamp);
