@@ -1374,7 +1374,14 @@ int Localizer::deskewOnDevice(const PointType* raw_points, size_t n, double star
 // CropBox (:268-271), distance / rate / FoV filters (:274-302).  As in the reference, *raw_pc itself ends up NaN-free and cropped
 // (both filters write back into it), and the rate filter counts positions in that cropped cloud.
 void Localizer::filterInput(pcl::PointCloud<PointType>::Ptr& raw_pc, pcl::PointCloud<PointType>::Ptr& input_pc, bool compact_raw) {
-  std::vector<PointType>& P = raw_pc->points;
+  const size_t k = filterInput(raw_pc->points.data(), raw_pc->points.size(), input_pc, compact_raw);
+  if (!compact_raw) return;
+  raw_pc->points.resize(k);
+  raw_pc->is_dense = true;
+}
+// ... on plain memory; returns the number of points that pass NaN removal and the crop box (with compact_raw they are moved to the
+// front of P, which is otherwise only read)
+size_t Localizer::filterInput(PointType* P, size_t n, pcl::PointCloud<PointType>::Ptr& input_pc, bool compact_raw) {
   const bool crop = config.filters.crop_active, dist = config.filters.dist_active;
   const bool rate_on = config.filters.rate_active && config.filters.rate_value >= 1;   // (the reference divides by the value)
   const bool fov = config.filters.fov_active;
@@ -1385,7 +1392,6 @@ void Localizer::filterInput(pcl::PointCloud<PointType>::Ptr& raw_pc, pcl::PointC
   const float min_dist = (float)config.filters.min_dist;
   const float fov_angle = config.filters.fov_angle;
   const long rate = config.filters.rate_value;
-  const size_t n = P.size();
   std::vector<PointType>& Q = input_pc->points;
   Q.resize(n);                                   // upper bound; trimmed below (no per-point capacity checks)
   size_t k = 0, m = 0;
@@ -1410,9 +1416,7 @@ void Localizer::filterInput(pcl::PointCloud<PointType>::Ptr& raw_pc, pcl::PointC
     m += keep ? 1 : 0;
   }
   Q.resize(m);
-  if (!compact_raw) return;
-  P.resize(k);
-  raw_pc->is_dense = true;
+  return k;
 }
 
 // The part of filterInput that writes back into *raw_pc (NaN removal and crop box, Localizer.cpp:263-271), for a caller that ran
@@ -1443,22 +1447,24 @@ void Localizer::compactRaw(pcl::PointCloud<PointType>::Ptr& raw_pc) {
 // the sweep: the same input filters on the host copy (which also leaves *raw_pc filtered in place, as the reference does), the
 // order of the kept points from the device (its time order, or -- a sweep left in arrival order -- the host's time order routine).
 void Localizer::startCloudPrep(pcl::PointCloud<PointType>::Ptr& raw_pc) {
+  startCloudPrep(raw_pc->points.data(), raw_pc->points.size());
+  prep_raw_ = &raw_pc;                                             // (the caller's pointer outlives the task: materializeClouds waits)
+}
+void Localizer::startCloudPrep(PointType* raw_points, size_t n_raw) {
   // host-only part, on helper 0 (always the same thread: time_order's memo is per thread) while the GPU runs the passes
   if (!helpers_) helpers_.reset(new flimo_host::Helpers(3));
   prep_input_ = fast_limo::make_shared<pcl::PointCloud<PointType>>();
   prep_started_ = true;
-  pcl::PointCloud<PointType>::Ptr* raw = &raw_pc;                // (the caller's pointer outlives the task: materializeClouds waits)
-  if (raw_pc->points.size() >= 16384)                              // the helpers that will share the assembly: awake and polling by then
+  if (n_raw >= 16384)                                              // the helpers that will share the assembly: awake and polling by then
     for (int w = 1; w < helpers_->size(); w++) helpers_->run(w, [] {});
   // which order will the device hold the sweep in?  (the same rule as deskewOnDevice; if it declines the sweep the host path does
   // its own sort and the order computed here is not used)
   const auto& mc = config.ikfom.mapping;
-  const size_t n_raw = raw_pc->points.size();
   const bool caps = (mc.MAX_NUM_PC2MATCH >= 0 && n_raw > (size_t)mc.MAX_NUM_PC2MATCH) || (mc.MAX_NUM_MATCHES >= 0 && n_raw > (size_t)mc.MAX_NUM_MATCHES);
   const bool host_order = !(caps || config.filters.voxel_active);
-  helpers_->run(0, [this, raw, host_order] {
+  helpers_->run(0, [this, raw_points, n_raw, host_order] {
     // the device front end may still be reading the raw cloud (upload): filter WITHOUT writing back
-    filterInput(*raw, prep_input_, false);
+    filterInput(raw_points, n_raw, prep_input_, false);
     if (config.debug) original_scan = fast_limo::make_shared<pcl::PointCloud<PointType>>(*prep_input_);
     if (!host_order) return;                                       // the order comes from the device
     const std::vector<PointType>& P = prep_input_->points;
@@ -1479,7 +1485,7 @@ void Localizer::startCloudPrep(pcl::PointCloud<PointType>::Ptr& raw_pc) {
       time_order(k.data(), 2, m, desc, false, order);
     }
   });
-  prep_raw_ = raw;
+  prep_raw_ = nullptr;
 }
 
 // The raw cloud is no longer read by anybody else (uploaded, or the device front end declined the sweep): it is left NaN-free and
@@ -1510,7 +1516,7 @@ void Localizer::downloadClouds(const double x26[26]) {
   mat_downloaded_ = true;
 }
 
-void Localizer::materializeClouds(pcl::PointCloud<PointType>::Ptr& raw_pc) {
+void Localizer::materializeClouds(size_t n_raw) {
   static const bool prof = std::getenv("FLIMO_PROF_CLOUDS") != nullptr;     // developer timing of the stages
   const double tp0 = prof ? now_s() : 0.0;
   if (!prep_started_) return;
@@ -1593,7 +1599,7 @@ void Localizer::materializeClouds(pcl::PointCloud<PointType>::Ptr& raw_pc) {
   mat_pm_ = pm; mat_fs_ = fs;
   if (prof)
     fprintf(stderr, "[flimo clouds] wait for the host filters / order %.0f us, assembly %.0f us (%zu -> %zu points, %zu resident)\n",
-            (tp1 - tp0) * 1e6, (now_s() - tp1) * 1e6, raw_pc->points.size(), m, n_dev);
+            (tp1 - tp0) * 1e6, (now_s() - tp1) * 1e6, n_raw, m, n_dev);
 }
 
 // Benchmark entry (inputs resident in HBM): restores the given prior, then GPU deskew of the
@@ -1622,18 +1628,29 @@ int Localizer::registerResident(const double x26_prior[26], const double* P_prio
 }
 
 // updatePointCloud for a caller that holds the sweep as plain memory (a language binding): when the sweep takes the device's input
-// stage and nobody wants host clouds, the points go from the caller's memory straight into the upload buffer -- no cloud object is
-// built.  false: not applicable, nothing was done (the caller builds the cloud and calls updatePointCloud).
+// stage the points go from the caller's memory straight into the upload buffer (and, when host clouds are wanted, through the
+// helper thread's filter pass) -- no cloud object is built.  false: not applicable, nothing was done (the caller builds the cloud and calls updatePointCloud).
 bool Localizer::updatePointCloudView(const PointType* points, size_t n, double time_stamp) {
   if (!points || n < 1 || !imu_calibrated_ || imu_buffer.empty()) return false;
-  if (download_clouds || config.debug || !deviceFrontEndEnabled()) return false;
+  if (!deviceFrontEndEnabled()) return false;
   last_status_ = 0;
   const double t0_dev = now_s();
   prep_started_ = false;
+  // (the clouds' host-only part reads the caller's memory too, and leaves it as it is: there is no cloud object to filter in place)
+  if (download_clouds || config.debug) startCloudPrep(const_cast<PointType*>(points), n);
   const int on_device = deskewOnDevice(points, n, time_stamp);
-  if (on_device == 0) { device_declined_ = true; return false; }     // (the updatePointCloud that follows does not ask again)
+  if (on_device == 0) {                                               // (the updatePointCloud that follows does not ask again)
+    if (prep_started_) { helpers_->wait(); prep_started_ = false; prep_input_.reset(); }
+    device_declined_ = true;
+    return false;
+  }
   mat_downloaded_ = false;
   finishUpdate(on_device > 0, t0_dev, t0_dev, now_s());
+  if (download_clouds || config.debug) {
+    const double tm0 = now_s();
+    materializeClouds(n);
+    stage_t_[0] = now_s() - tm0;
+  }
   return true;
 }
 
@@ -1657,7 +1674,7 @@ void Localizer::updatePointCloud(pcl::PointCloud<PointType>::Ptr& raw_pc, double
     finishUpdate(on_device > 0, t0_dev, t0_dev, t2d);
     if (download_clouds || config.debug) {
       const double tm0 = now_s();
-      materializeClouds(raw_pc);
+      materializeClouds(raw_pc->points.size());
       stage_t_[0] = now_s() - tm0;                                       // (host work of this path: the clouds, after the pose)
     }
     return;

@@ -90,7 +90,8 @@ class fast_limo::Localizer {
   int deskewOnDevice(const PointType* raw_points, size_t n, double start_time);       // filters + stamps + deskew on the GPU (f-2)
   void finishUpdate(bool ok, double t0, double t1, double t2);
   void filterInput(pcl::PointCloud<PointType>::Ptr& raw_pc, pcl::PointCloud<PointType>::Ptr& input_pc, bool compact_raw = true);   // Localizer.cpp:262-302 in one pass
-  void materializeClouds(pcl::PointCloud<PointType>::Ptr& raw_pc);     // device front end: host clouds after the update
+  size_t filterInput(PointType* P, size_t n, pcl::PointCloud<PointType>::Ptr& input_pc, bool compact_raw);
+  void materializeClouds(size_t n_raw);     // device front end: host clouds after the update
   bool propagatedFromTimeRange(double start_time, double end_time, States& frames);
   bool imuMeasFromTimeRange(double start_time, double end_time, std::vector<IMUmeas>& meas);   // Localizer.cpp:917-949, oldest first
   bool isInRange(const PointType& p);
@@ -143,6 +144,7 @@ class fast_limo::Localizer {
   bool deviceFrontEndEnabled() const;
   void compactRaw(pcl::PointCloud<PointType>::Ptr& raw_pc);
   void startCloudPrep(pcl::PointCloud<PointType>::Ptr& raw_pc);
+  void startCloudPrep(PointType* raw_points, size_t n_raw);
   void downloadClouds(const double x26[26]);
   pcl::PointCloud<PointType>::Ptr mat_pm_, mat_fs_;   // the clouds it handed out last (their storage is reused once the caller let go)
   size_t arrival_last_ = 0;             // index of the point the reference's sort would put last

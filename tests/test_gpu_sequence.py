@@ -261,6 +261,58 @@ def test_input_stage_on_its_own_context_is_invisible(built, oracle, unique, monk
     np.testing.assert_array_equal(f_pts, n_pts_)
 
 
+def test_native_replay_and_batched_imu_equal_the_call_by_call_drive(built, oracle):
+    """flimo_loc_replay (a recorded drive fed from native code), flimo_loc_update_imu_n (the IMU samples between two sweeps in one
+    call) and the sweep taken straight from the caller's memory (updatePointCloudView: no clouds requested) against the plain
+    call-by-call drive with the clouds handed back: same status, state, covariance and stored map, bit for bit."""
+    from fast_limo_amd import api
+    n_scans, n_pts, speed = 6, 40000, 10.0
+    st, w, a = synth.stationary_imu(0.0, 0.1 * n_scans + 0.06)
+    sweeps = []
+    for k in range(n_scans):
+        scan = synth.corridor_scan(k, n_pts, 31, speed=speed)
+        rel = (np.argsort(np.argsort(scan[:, 4], kind="stable"), kind="stable") + 0.5) * (0.1 / n_pts)
+        sweeps.append(oracle.make_points(scan[:, :3], 1.0, timestamp=0.1 * k + rel))
+    until = 0.1 * (np.arange(n_scans) + 1) + 0.005
+
+    def make(clouds):
+        G = api.Localizer(api.default_cfg(sensor_type=2, **CAPS))
+        G.set_flags(add_to_map=True, download_clouds=clouds)
+        x0 = G.get_x(); x0[14] = speed; G.set_x(x0)
+        return G
+
+    def finish(G):
+        G.sync()
+        out = (G.get_x().copy(), G.get_P().copy(), G.map_size(), G.hip.map_points())
+        G.close()
+        return out
+
+    G = make(True)                                                      # call by call, clouds on: the cloud object path
+    i, rc_a = 0, []
+    for k in range(n_scans):
+        while i < len(st) and st[i] <= until[k]:
+            G.update_imu(st[i], w[i], a[i]); i += 1
+        rc_a.append(G.update_pointcloud_points(sweeps[k], 0.1 * k))
+    ref = finish(G)
+    G = make(False)                                                     # batched IMU, the sweep from the caller's memory
+    i, rc_b = 0, []
+    for k in range(n_scans):
+        i1 = int(np.searchsorted(st, until[k], side="right"))
+        G.update_imu_n(st[i:i1], w[i:i1], a[i:i1]); i = i1
+        rc_b.append(G.update_pointcloud_points(sweeps[k], 0.1 * k))
+    got_b = finish(G)
+    G = make(False)                                                     # the whole drive in one native call
+    rc_c, secs = G.replay(sweeps, 0.1 * np.arange(n_scans), until, st, w, a)
+    got_c = finish(G)
+    assert rc_a == rc_b == list(rc_c) == [1] + [0] * (n_scans - 1)
+    assert np.all(np.diff(secs) > 0)
+    for got in (got_b, got_c):
+        np.testing.assert_array_equal(got[0], ref[0])
+        np.testing.assert_array_equal(got[1], ref[1])
+        assert got[2] == ref[2] > n_pts
+        np.testing.assert_array_equal(got[3], ref[3])
+
+
 def test_reference_yaml_configuration_sequence(built, oracle):
     """The reference's shipped configuration (config/kitti.yaml): crop box +-1 m, min distance 4 m, every 4th point, voxel
     grid 1 m, MAX_NUM_PC2MATCH 1e4 / MAX_NUM_MATCHES 5000, LiDAR mounted off the IMU (the yaml's extrinsics), sensor biases,
