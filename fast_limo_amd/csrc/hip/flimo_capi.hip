@@ -996,7 +996,8 @@ static int ensure_scan(flimo_ctx* c, size_t n) {
     c->d_tie_list = tlst; c->tie_cap = cap;
   }
   {
-    const size_t f2n = (size_t)std::max(fit2_blocks((int)cap), fused_blocks((int)cap)) * FIT_LIVE_PAD;
+    // (a one-launch pass spreads a small scan over up to FUSED_SPREAD_SLOTS query slots)
+    const size_t f2n = (size_t)std::max(std::max(fit2_blocks((int)cap), fused_blocks((int)cap)), FUSED_SPREAD_SLOTS / 128 + 8) * FIT_LIVE_PAD;
     double* f2 = nullptr;
     HIPCHK(c, hipMalloc(&f2, f2n * sizeof(double)));
     (void)hipFree(c->d_fit2_partials);
@@ -1244,6 +1245,8 @@ extern "C" int flimo_raw_scan_filter_order_set(flimo_ctx* c, const void* points3
       return fail(c, FLIMO_ERR_UNSUPPORTED, "this host's atan2f differs from the device's restatement on %d of 8192 argument pairs: the FoV filter stays on the host front end", c->fov_check_bad);
   }
   F.fov = cfg->fov_active ? 1 : 0; F.fov_angle = cfg->fov_angle;
+  const bool keep_order = (time_order & 2) != 0;      // bit 1: no spatial order (a voxel filter follows and re-orders the scan)
+  time_order &= 1;
   HIPCHK(c, filter_raw_scan(c->stream, c->d_raw32, n, F, c->d_scan_raw, c->d_scan_t, c->d_filt_ext, c->scratch, time_order ? c->d_tkey[0] : nullptr));
   HIPCHK(c, hipMemcpyAsync(c->h_filt_ext, c->d_filt_ext, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1284,7 +1287,8 @@ extern "C" int flimo_raw_scan_filter_order_set(flimo_ctx* c, const void* points3
     std::swap(c->d_scan_t, c->d_t_tmp);
     c->raw_time_ordered = true;
   }
-  HIPCHK(c, sort_scan(c->stream, c->d_scan_raw, m, c->d_raw_sorted, c->scratch, c->d_scan_t, c->d_t_sorted));
+  if (keep_order) HIPCHK(c, index_scan(c->stream, c->d_scan_raw, m, c->d_raw_sorted, c->d_scan_t, c->d_t_sorted));
+  else HIPCHK(c, sort_scan(c->stream, c->d_scan_raw, m, c->d_raw_sorted, c->scratch, c->d_scan_t, c->d_t_sorted));
   c->raw_n = m; c->order_n = m;
   return FLIMO_OK;
 }

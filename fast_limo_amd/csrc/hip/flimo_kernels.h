@@ -55,6 +55,8 @@ void launch_fit2(hipStream_t st, const GridView& G, const float4* scan_sorted, i
                  const ChainHead* chain = nullptr, const ChainCtl* ctl = nullptr, const BookView* book = nullptr);
 // The whole measurement pass in ONE launch (k-NN fast path + in-kernel tail + fit + reduction + publish; two lanes per query, gates of
 // 2..3 rings): partials needs fused_blocks(n) * FIT_LIVE_PAD doubles; results arrive as launch_fit2's granules.
+constexpr int FUSED_SPREAD_SLOTS = 32768;     // scans below this many query slots are spread over more workgroups
+int fused_spread(int n);
 int fused_blocks(int n);
 void launch_match_fused(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const PoseMats& P, const MatchParams& mp,
                         void* nbr, int* wl, int* wl_count, unsigned long long* cand, const PrevPass& prev,
@@ -108,6 +110,10 @@ struct MapBuildScratch {
   // stream.  Replaces the 4-byte device-to-host copies (each a staged, blocking copy) of counts and boxes.
   uint32_t* mail_host = nullptr;
   uint32_t* mail_dev = nullptr;
+  // the one-launch input filter (filter_raw_scan): per tile {count, launch number} of two sums, then the tile ticket
+  unsigned long long* filt_desc = nullptr;
+  size_t filt_tiles_cap = 0;
+  unsigned int filt_epoch = 0, filt_ticket_base = 0;
 };
 // slots of the mail words
 enum MailSlot { MAIL_BOOK = 0 /* 6 */, MAIL_BOOK_END = 8 /* 2 */, MAIL_CROWD = 12, MAIL_BOXCOUNT = 13, MAIL_BBOX = 16 /* 6 */, MAIL_VOXEL = 24 /* 2 */,
@@ -126,6 +132,8 @@ hipError_t map_bbox(hipStream_t st, const float4* pts, size_t n, MapBuildScratch
 // Optionally permutes a per-point double array (times) the same way.
 hipError_t sort_scan(hipStream_t st, const float4* in, size_t n, float4* out, MapBuildScratch& S,
                      const double* t_in = nullptr, double* t_out = nullptr);
+// the same layout without re-ordering (out[i] = (xyz, w = i)): for a sweep a voxel filter re-orders anyway
+hipError_t index_scan(hipStream_t st, const float4* in, size_t n, float4* out, const double* t_in, double* t_out);
 hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4* pts_out, uint32_t* cell_start,
                           size_t ncells, float ox, float oy, float oz, float inv_cell, int nx, int ny, int nz, int xs,
                           MapBuildScratch& S);    // ncells = nx * xs * ny * nz columns

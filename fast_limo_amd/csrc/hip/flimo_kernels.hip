@@ -822,6 +822,7 @@ struct FuseArgs {
   BookView book;       // book.node_c: exact distance ties are settled inside this launch, the reference's way (tie_repair_wave)
   ChainCtl ch;         // ch.S: a pass of a chained update (flimo_chain.h): the launch has one extra workgroup, and the workgroup
                        // that completes it goes on with the filter's algebra
+  int spread;          // one-launch pass of a small scan: only every 2^spread-th query slot is taken (see knn5_pass)
 };
 template <int ROWS>
 __device__ __forceinline__ void fit_reduce_publish(const float (&v)[16], bool owns_row, int row, float* sr, double* sa0, double* sa1,
@@ -920,9 +921,14 @@ __device__ __forceinline__ void knn5_pass(const GridView& G, const float4* __res
     }
   }
   const int chunk = xcd_chunk(blockIdx.x, nb);
-  const int p = chunk * QPB + threadIdx.x / L;
+  // A small scan is spread over 2^spread times as many workgroups: only every 2^spread-th query slot of a wave is taken.  The fast
+  // path is a chain of dependent round trips whatever the wave holds, and the tail shares a wave's 64 lanes among its pending
+  // queries -- 2 lanes each in a full wave of 32, 16 each when the wave holds 4: a 2 000-point scan over a sparse map (every
+  // query needs the rings 2 and 3) takes a fifth of the time.
+  const int slot = chunk * QPB + threadIdx.x / L;
+  const int p = slot >> fa.spread;
   const int sub = threadIdx.x % L;
-  const bool in_range = p < n;          // no early exit: the tail below is a wave-wide phase
+  const bool in_range = p < n && (slot & ((1 << fa.spread) - 1)) == 0;          // no early exit: the tail below is a wave-wide phase
   TRACE(0, 0);
 
   float4 sp;
@@ -2474,7 +2480,7 @@ static void launch_knn5_L(hipStream_t st, const GridView& G, const float4* scan_
   constexpr int slots = (L <= 4 ? 8 : 4);          // candidate loads in flight per lane
   if constexpr (L == 2) {
     if (fuse) {      // the whole pass in one launch (blocks is a multiple of 8 = FIT_GROUPS; a chained pass has one workgroup more)
-      const int grid = blocks + (fuse->ch.S ? 1 : 0);
+      const int grid = fused_blocks(n) + (fuse->ch.S ? 1 : 0);
       if (chain)
         hipExtLaunchKernelGGL((knn5_chain_kernel<2, 8, true>), dim3(grid), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, chain, max_ring, (NbrRec*)nbr, wl, wl_count, cand, prev.valid, prev.probe_min, 1, *fuse);
       else
@@ -2567,7 +2573,9 @@ void launch_fit2(hipStream_t st, const GridView& G, const float4* scan_sorted, i
   hipExtLaunchKernelGGL((fit2_kernel<64>), dim3(grid), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, idx, partials, (double2*)out_granules, ticket, wl_count, seq, tl, ch, book);
 }
 
-int fused_blocks(int n) { return round_up8((n + 127) / 128); }
+// (a small scan is spread: see knn5_pass)
+int fused_spread(int n) { int sh = 0; while (sh < 3 && ((long long)n << (sh + 1)) <= FUSED_SPREAD_SLOTS) sh++; return sh; }
+int fused_blocks(int n) { return round_up8((int)((((long long)n << fused_spread(n)) + 127) / 128)); }
 // fine pre-pass over the second-level grid (crowded regions): settles the queries whose five are proven inside their fine 3x3x3
 // block; their records get flag 4, which the main launch of the same pass (fine_mode 1) takes over
 void launch_knn5_fine(hipStream_t st, const GridView& Gf, const float4* scan_sorted, int n, const PoseMats& P, void* nbr,
@@ -2603,6 +2611,7 @@ void launch_match_fused(hipStream_t st, const GridView& G, const float4* scan_so
   fa.mp = mp;
   for (int i = 0; i < FIT_LIVE_PAD; i++) fa.idx.raw[i] = i < FIT_LIVE ? live_idx[i] : 0;
   fa.partials = partials; fa.granules = (double2*)out_granules; fa.ticket = ticket; fa.seq = seq;
+  fa.spread = fused_spread(n);
   launch_knn5_L<2>(st, G, scan_sorted, n, P, mp.max_ring, nbr, wl, wl_count, cand, prev, 1, e0, e1, &fa, nullptr, 0, 0ull, nullptr, chain);
 }
 

@@ -582,6 +582,22 @@ hipError_t sort_scan(hipStream_t st, const float4* in, size_t n, float4* out, Ma
   return hipGetLastError();
 }
 
+// The sweep left in the order it has (a voxel filter follows and re-orders the scan anyway: the Morton order of the raw sweep would
+// serve nobody): out[i] = (xyz, w = i), the same layout sort_scan produces.
+__global__ __launch_bounds__(256) void index_scan_kernel(const float4* __restrict__ in, size_t n, float4* __restrict__ out,
+                                                         const double* __restrict__ t_in, double* __restrict__ t_out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = in[i];
+  out[i] = make_float4(p.x, p.y, p.z, __uint_as_float((uint32_t)i));
+  if (t_in) t_out[i] = t_in[i];
+}
+hipError_t index_scan(hipStream_t st, const float4* in, size_t n, float4* out, const double* t_in, double* t_out) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(index_scan_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, n, out, t_in, t_out);
+  return hipGetLastError();
+}
+
 // ---- input filters of a raw sweep on the device (Localizer.cpp:262-302): NaN removal -> crop box -> every rate-th survivor ->
 //      min distance, order preserved; per-point stamp (:741-805).  Records are the reference's 32-byte PointType. -----------------
 struct Raw32 { float x, y, z, w, intensity; uint32_t pad; uint32_t u0, u1; };   // u0/u1: the 8-byte time union
@@ -590,72 +606,147 @@ __device__ __forceinline__ bool filt_alive(const Raw32& p, const FilterParams& F
   const bool outside = (p.x < F.mn[0]) | (p.y < F.mn[1]) | (p.z < F.mn[2]) | (p.x > F.mx[0]) | (p.y > F.mx[1]) | (p.z > F.mx[2]);
   return finite & (!F.crop | outside);
 }
-__global__ __launch_bounds__(256) void filt_alive_kernel(const Raw32* __restrict__ in, size_t n, FilterParams F, uint32_t* __restrict__ a) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) a[i] = filt_alive(in[i], F) ? 1u : 0u;
-}
-__global__ __launch_bounds__(256) void filt_keep_kernel(const Raw32* __restrict__ in, size_t n, FilterParams F, const uint32_t* __restrict__ a,
-                                                        const uint32_t* __restrict__ rank, uint32_t* __restrict__ keep) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  bool k = a[i] != 0u;
-  if (k && F.rate_on) k = (rank[i] % (uint32_t)F.rate) == 0u;
-  if (k && (F.dist || F.fov)) {
-    const Raw32 p = in[i];
-    if (F.fov) k = __builtin_fabsf(libm_atan2f(p.y, p.x)) < F.fov_angle;       // std::atan2 of two floats, as the host's libm rounds it
-    if (k && F.dist) k = __builtin_sqrtf(p.x * p.x + (p.y * p.y + p.z * p.z)) > F.min_dist;
-  }
-  keep[i] = k ? 1u : 0u;
-}
+// The filters of a sweep in ONE launch.  A workgroup takes a tile of FILT_TILE consecutive points (tiles are handed out in order by
+// a ticket, so a tile's predecessors are always running or done); a point's rank among the survivors of NaN removal + crop box (the
+// rate filter's "every rate-th") and its output position are the tile's own counts (wave ballots; eight coalesced rows of 64 points
+// per wave) plus the sums over all earlier tiles, which every tile publishes the moment it knows its own count -- {count, launch
+// number} in one 64-bit word -- and reads from all its predecessors at once, 64 per round trip (two chained waits per tile, a few
+// microseconds for the whole sweep instead of eight dispatches).
 // out[pos] = (xyz, w = pos), t_out[pos] = the point's stamp without the sweep offset, ext[0] = extreme ordered key (max; min when
 // sorting descending, stored complemented), ext[1] = kept count, ext[2] = a kept stamp is NaN
-__global__ __launch_bounds__(256) void filt_compact_kernel(const Raw32* __restrict__ in, size_t n, FilterParams F, const uint32_t* __restrict__ keep,
-                                                           const uint32_t* __restrict__ pos, float4* __restrict__ out, double* __restrict__ t_out,
+constexpr int FILT_ROWS = 8;
+constexpr int FILT_TILE = 256 * FILT_ROWS;
+__device__ __forceinline__ unsigned int filt_lookback(const unsigned long long* __restrict__ desc, int tile, unsigned int epoch, unsigned int* s_sum) {
+  // exclusive sum of the earlier tiles' counts (first wave; the block picks it up from *s_sum)
+  if (threadIdx.x < 64) {
+    unsigned int sum = 0;
+    for (int base = 0; base < tile; base += 64) {
+      const int t = base + (int)threadIdx.x;
+      unsigned int c = 0;
+      if (t < tile) {
+        unsigned long long d;
+        do { d = __hip_atomic_load(&desc[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((unsigned int)(d >> 32) != epoch);
+        c = (unsigned int)d;
+      }
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) c += __shfl_xor(c, o, 64);
+      sum += c;
+    }
+    if (threadIdx.x == 0) *s_sum = sum;
+  }
+  __syncthreads();
+  return *s_sum;
+}
+__global__ __launch_bounds__(256) void filt_onepass_kernel(const Raw32* __restrict__ in, size_t n, FilterParams F, unsigned int* __restrict__ ticket,
+                                                           unsigned int ticket_base, unsigned long long* __restrict__ desc_alive,
+                                                           unsigned long long* __restrict__ desc_kept, unsigned int epoch,
+                                                           float4* __restrict__ out, double* __restrict__ t_out,
                                                            unsigned long long* __restrict__ ext, unsigned long long* __restrict__ key_out) {
-  // (no early exits: the block reduces its extreme key and NaN mark first -- one atomic per block instead of one per wave)
+  __shared__ unsigned int s_tile, s_sum[2], s_cnt[2][4];
   __shared__ unsigned long long s_max[4];
   __shared__ int s_nan[4];
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = i < n && keep[i] != 0u;
-  if (i == n - 1) ext[1] = (unsigned long long)(pos[i] + keep[i]);
-  unsigned long long mine = 0ull;                              // ordered key of this point (0: none)
-  bool nan = false;
-  if (live) {
-  const Raw32 p = in[i];
-  const uint32_t o = pos[i];
-  out[o] = make_float4(p.x, p.y, p.z, __uint_as_float(o));
-  double t;
-  unsigned long long key;
+  if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u) - ticket_base;
+  __syncthreads();
+  const int tile = (int)s_tile;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const size_t base = (size_t)tile * FILT_TILE + (size_t)wave * (64 * FILT_ROWS);
+  // ---- the tile's points (row r of this wave: points base + 64 r + lane), NaN removal + crop box ----
+  float px[FILT_ROWS], py[FILT_ROWS], pz[FILT_ROWS];
+  uint32_t u0[FILT_ROWS], u1[FILT_ROWS];
+  unsigned long long alive[FILT_ROWS];
+  unsigned int n_alive = 0;
+#pragma unroll
+  for (int r = 0; r < FILT_ROWS; r++) {
+    const size_t i = base + (size_t)r * 64 + lane;
+    Raw32 p;
+    p.x = p.y = p.z = 0.f; p.u0 = p.u1 = 0u;
+    const bool inb = i < n;
+    if (inb) {
+      const float4 a = reinterpret_cast<const float4*>(in + i)[0];
+      const uint4 b = reinterpret_cast<const uint4*>(in + i)[1];
+      p.x = a.x; p.y = a.y; p.z = a.z; p.u0 = b.z; p.u1 = b.w;
+    }
+    px[r] = p.x; py[r] = p.y; pz[r] = p.z; u0[r] = p.u0; u1[r] = p.u1;
+    alive[r] = __ballot(inb && filt_alive(p, F));
+    n_alive += (unsigned int)__popcll(alive[r]);
+  }
+  if (lane == 0) s_cnt[0][wave] = n_alive;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    __hip_atomic_store(&desc_alive[tile], ((unsigned long long)epoch << 32) | (unsigned long long)(s_cnt[0][0] + s_cnt[0][1] + s_cnt[0][2] + s_cnt[0][3]),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // ---- rank among the survivors -> every rate-th, then FoV and min distance ----
+  unsigned int rank0 = 0;
+  if (F.rate_on) {
+    rank0 = filt_lookback(desc_alive, tile, epoch, &s_sum[0]);
+    for (int w = 0; w < wave; w++) rank0 += s_cnt[0][w];
+  }
+  unsigned long long keep[FILT_ROWS];
+  unsigned int n_keep = 0;
+#pragma unroll
+  for (int r = 0; r < FILT_ROWS; r++) {
+    bool k = (alive[r] >> lane) & 1ull;
+    if (k && F.rate_on) k = ((rank0 + (unsigned int)__popcll(alive[r] & lt)) % (uint32_t)F.rate) == 0u;
+    if (k && F.fov) k = __builtin_fabsf(libm_atan2f(py[r], px[r])) < F.fov_angle;       // std::atan2 of two floats, as the host's libm rounds it
+    if (k && F.dist) k = __builtin_sqrtf(px[r] * px[r] + (py[r] * py[r] + pz[r] * pz[r])) > F.min_dist;
+    keep[r] = __ballot(k);
+    n_keep += (unsigned int)__popcll(keep[r]);
+    rank0 += (unsigned int)__popcll(alive[r]);
+  }
+  if (lane == 0) s_cnt[1][wave] = n_keep;
+  __syncthreads();
+  const unsigned int tile_keep = s_cnt[1][0] + s_cnt[1][1] + s_cnt[1][2] + s_cnt[1][3];
+  if (threadIdx.x == 0)
+    __hip_atomic_store(&desc_kept[tile], ((unsigned long long)epoch << 32) | (unsigned long long)tile_keep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned int pos0 = filt_lookback(desc_kept, tile, epoch, &s_sum[1]);
+  if ((size_t)(tile + 1) * FILT_TILE >= n && threadIdx.x == 0) ext[1] = (unsigned long long)(pos0 + tile_keep);      // the last tile: kept count
+  for (int w = 0; w < wave; w++) pos0 += s_cnt[1][w];
+  // ---- compaction: position, stamp, ordered key ----
+  unsigned long long mine = 0ull;                              // extreme ordered key of this lane's points (0: none)
+  bool any_nan = false;
   const bool desc = F.eos && F.kind <= 1;
-  if (F.kind == 0) {
-    const float tf = (float)p.u0 * 1e-9f;
-    t = F.eos ? F.sweep_ref - (double)tf : F.sweep_ref + (double)tf;
-    key = (unsigned long long)p.u0;
-  } else if (F.kind == 1) {
-    float v = __uint_as_float(p.u0);
-    t = F.eos ? F.sweep_ref - (double)v : F.sweep_ref + (double)v;
-    nan = v != v;
-    v += 0.0f;
-    const uint32_t b = __float_as_uint(v);
-    key = (unsigned long long)((b & 0x80000000u) ? ~b : (b | 0x80000000u));
-  } else {
-    double v = __longlong_as_double((long long)(((unsigned long long)p.u1 << 32) | (unsigned long long)p.u0));
-    t = (F.kind == 2) ? v : v * (double)1e-9f;
-    nan = v != v;
-    v += 0.0;
-    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-    key = (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
+#pragma unroll
+  for (int r = 0; r < FILT_ROWS; r++) {
+    if ((keep[r] >> lane) & 1ull) {
+      const uint32_t o = pos0 + (unsigned int)__popcll(keep[r] & lt);
+      out[o] = make_float4(px[r], py[r], pz[r], __uint_as_float(o));
+      double t;
+      unsigned long long key;
+      bool nan = false;
+      if (F.kind == 0) {
+        const float tf = (float)u0[r] * 1e-9f;
+        t = F.eos ? F.sweep_ref - (double)tf : F.sweep_ref + (double)tf;
+        key = (unsigned long long)u0[r];
+      } else if (F.kind == 1) {
+        float v = __uint_as_float(u0[r]);
+        t = F.eos ? F.sweep_ref - (double)v : F.sweep_ref + (double)v;
+        nan = v != v;
+        v += 0.0f;
+        const uint32_t b = __float_as_uint(v);
+        key = (unsigned long long)((b & 0x80000000u) ? ~b : (b | 0x80000000u));
+      } else {
+        double v = __longlong_as_double((long long)(((unsigned long long)u1[r] << 32) | (unsigned long long)u0[r]));
+        t = (F.kind == 2) ? v : v * (double)1e-9f;
+        nan = v != v;
+        v += 0.0;
+        const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+        key = (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
+      }
+      t_out[o] = t;
+      const unsigned long long ok = desc ? ~key : key;        // ascending in this key = the order of the reference's time sort
+      if (key_out) key_out[o] = ok;
+      if (!nan) mine = ok > mine ? ok : mine;
+      any_nan |= nan;
+    }
+    pos0 += (unsigned int)__popcll(keep[r]);
   }
-  t_out[o] = t;
-  if (key_out) key_out[o] = desc ? ~key : key;               // ascending in this key = the order of the reference's time sort
-  if (!nan) mine = desc ? ~key : key;
-  }
-  // block maximum of the keys, block OR of the NaN marks
+  // block maximum of the keys, block OR of the NaN marks: one atomic per block
   unsigned long long m = mine;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) { const unsigned long long v = __shfl_xor(m, o, 64); m = v > m ? v : m; }
-  const int any_nan = __any(live && nan) ? 1 : 0;
-  if ((threadIdx.x & 63) == 0) { s_max[threadIdx.x >> 6] = m; s_nan[threadIdx.x >> 6] = any_nan; }
+  const int wave_nan = __any(any_nan) ? 1 : 0;
+  if (lane == 0) { s_max[wave] = m; s_nan[wave] = wave_nan; }
   __syncthreads();
   if (threadIdx.x == 0) {
     unsigned long long bm = s_max[0];
@@ -668,29 +759,28 @@ __global__ __launch_bounds__(256) void filt_compact_kernel(const Raw32* __restri
 hipError_t filter_raw_scan(hipStream_t st, const void* raw32_dev, size_t n, const FilterParams& F, float4* out, double* t_out,
                            unsigned long long* ext_dev, MapBuildScratch& S, unsigned long long* key_out) {
   if (n == 0) return hipSuccess;
-  hipError_t e = ensure_scratch(S, n);
-  if (e != hipSuccess) return e;
-  const int blocks = (int)((n + 255) / 256);
-  const Raw32* in = static_cast<const Raw32*>(raw32_dev);
-  size_t scan_bytes = 0;
-  e = exclusive_sum(nullptr, scan_bytes, S.keys_in, S.vals_in, n, st);
-  if (e != hipSuccess) return e;
-  if (scan_bytes > S.cub_tmp_bytes) {
+  const size_t tiles = (n + FILT_TILE - 1) / FILT_TILE;
+  hipError_t e;
+  if (tiles > S.filt_tiles_cap) {
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
-    if (S.cub_tmp) (void)hipFree(S.cub_tmp);
-    if ((e = hipMalloc(&S.cub_tmp, scan_bytes + 1024)) != hipSuccess) return e;
-    S.cub_tmp_bytes = scan_bytes + 1024;
+    if (S.filt_desc) (void)hipFree(S.filt_desc);
+    S.filt_desc = nullptr;
+    const size_t cap = tiles + tiles / 2 + 64;
+    if ((e = hipMalloc(&S.filt_desc, (2 * cap + 1) * sizeof(unsigned long long))) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(S.filt_desc, 0, (2 * cap + 1) * sizeof(unsigned long long), st)) != hipSuccess) return e;   // launch number 0: never valid
+    S.filt_tiles_cap = cap;
+    S.filt_epoch = 0;
+    S.filt_ticket_base = 0;
   }
   if ((e = hipMemsetAsync(ext_dev, 0, 4 * sizeof(unsigned long long), st)) != hipSuccess) return e;
-  hipLaunchKernelGGL(filt_alive_kernel, dim3(blocks), dim3(256), 0, st, in, n, F, S.keys_in);
-  if (F.rate_on) {
-    e = exclusive_sum(S.cub_tmp, scan_bytes, S.keys_in, S.vals_in, n, st);               // rank among the survivors of NaN + crop
-    if (e != hipSuccess) return e;
-  }
-  hipLaunchKernelGGL(filt_keep_kernel, dim3(blocks), dim3(256), 0, st, in, n, F, S.keys_in, S.vals_in, S.keys_out);
-  e = exclusive_sum(S.cub_tmp, scan_bytes, S.keys_out, S.vals_out, n, st);                // output position
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(filt_compact_kernel, dim3(blocks), dim3(256), 0, st, in, n, F, S.keys_out, S.vals_out, out, t_out, ext_dev, key_out);
+  unsigned long long* desc_alive = S.filt_desc;
+  unsigned long long* desc_kept = S.filt_desc + S.filt_tiles_cap;
+  unsigned int* ticket = reinterpret_cast<unsigned int*>(S.filt_desc + 2 * S.filt_tiles_cap);
+  S.filt_epoch++;
+  if (S.filt_epoch == 0u) S.filt_epoch = 1u;                   // (after 2^32 launches the words are 2^32 launches stale: never equal)
+  hipLaunchKernelGGL(filt_onepass_kernel, dim3((unsigned)tiles), dim3(256), 0, st, static_cast<const Raw32*>(raw32_dev), n, F, ticket,
+                     S.filt_ticket_base, desc_alive, desc_kept, S.filt_epoch, out, t_out, ext_dev, key_out);
+  S.filt_ticket_base += (unsigned int)tiles;                   // (wraps with the counter)
   return hipGetLastError();
 }
 
@@ -886,6 +976,7 @@ void map_scratch_free(MapBuildScratch& S) {
   if (S.cub_tmp) hipFree(S.cub_tmp);
   if (S.keys_in) { hipFree(S.keys_in); hipFree(S.keys_out); hipFree(S.vals_in); hipFree(S.vals_out); }
   if (S.bbox) hipFree(S.bbox);
+  if (S.filt_desc) hipFree(S.filt_desc);
   if (S.mail_host) hipHostFree(S.mail_host);
   S = MapBuildScratch();
 }

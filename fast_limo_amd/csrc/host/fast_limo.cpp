@@ -1306,7 +1306,7 @@ int Localizer::deskewOnDevice(const PointType* raw_points, size_t n, double star
     }
   }
   const double tf2 = prof ? now_s() : 0.0;
-  if (flimo_raw_scan_filter_order_set(c, src, n, &fc, need_order ? 1 : 0, &kept, &last_stamp, &nan, &tied) != FLIMO_OK || nan || tied)
+  if (flimo_raw_scan_filter_order_set(c, src, n, &fc, (need_order ? 1 : 0) | (fl.voxel_active ? 2 : 0), &kept, &last_stamp, &nan, &tied) != FLIMO_OK || nan || tied)
     return 0;
   const double tf3 = prof ? now_s() : 0.0;
   double tf4 = tf3;

@@ -147,7 +147,9 @@ int flimo_upload_stage(flimo_ctx* ctx, size_t bytes, void** host_ptr);
  * stamp, Localizer.cpp:789-790) on the device: the order MAX_NUM_PC2MATCH / MAX_NUM_MATCHES ("the first N of pc2match") and the
  * voxel grid's float sums are defined in.  That order is unique -- a stable radix sort gives it -- when no two kept stamps are
  * equal; with equal stamps it is the library's heap moves', *tied = 1 is returned, nothing is made resident, and the caller takes
- * the host routine.  flimo_raw_scan_order: time rank -> position among the kept points (for the clouds handed back to callers). */
+ * the host routine.  flimo_raw_scan_order: time rank -> position among the kept points (for the clouds handed back to callers).
+ * time_order bit 1 (value 2): the sweep is NOT put into the spatial order the per-pass kernels like -- for a caller that runs
+ * flimo_scan_voxel_filter right after the deskew, which re-orders the scan anyway. */
 int flimo_raw_scan_filter_order_set(flimo_ctx* ctx, const void* points32, size_t n, const flimo_filter_cfg* cfg, int time_order,
                                     size_t* n_kept, double* last_stamp, int* nan_stamp, int* tied);
 int flimo_raw_scan_order(flimo_ctx* ctx, uint32_t* order_out, size_t cap, size_t* n);
