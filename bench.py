@@ -49,7 +49,7 @@ def pmc_traffic(queries_per_launch):
     in separate passes of this same command, FETCH_SIZE doubled per MI355X_MICROARCH.md).  PMC counters cannot be collected
     from inside the run; the profile carries the hash of the kernel sources it was taken with and is only reported when that is
     the hash of the sources in the tree (and the launch shape is the benchmark's)."""
-    f = os.path.join(ROOT, "profiles", "r03", "pmc_fetch_write_per_kernel.json")
+    f = os.path.join(ROOT, "profiles", "r04", "pmc_fetch_write_per_kernel.json")
     try:
         from fast_limo_amd import build as b
         d = json.load(open(f))
@@ -177,7 +177,7 @@ HBM_REGIME = dict(rings=128, azimuths=2048, map_points=20000000, box=447.0)     
 def pmc_traffic_hbm_regime():
     """HBM-side bytes per launch at 256k x 20M from the committed PMC profile (same rule as pmc_traffic): the one-launch pass and
     the k-NN kernel of the passes that run as separate dispatches."""
-    f = os.path.join(ROOT, "profiles", "r03", "pmc_hbm_regime.json")
+    f = os.path.join(ROOT, "profiles", "r04", "pmc_hbm_regime.json")
     try:
         from fast_limo_amd import build as b
         d = json.load(open(f))
@@ -584,11 +584,19 @@ def main():
     fused0 = loc.hip.fused_pass_count()
     loc.host_profile(reset=True)
     barrier()
+    step_marks = [] if os.environ.get("FLIMO_BENCH_STEP_TIMES") else None      # developer: the region's profile, step by step
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    if step_marks is None:
+        for _ in range(args.steps):
+            step()
+    else:
+        for _ in range(args.steps):
+            step()
+            step_marks.append(time.perf_counter())
     barrier()
     elapsed = time.perf_counter() - t0
+    if step_marks:
+        print("step times [us]: " + " ".join("%.0f" % (1e6 * d) for d in np.diff([t0] + step_marks)), file=sys.stderr)
     tot = loc.hip.timing_totals()
     split = loc.hip.timing_split()
     chain = loc.hip.chain_stats()

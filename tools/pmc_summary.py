@@ -36,10 +36,13 @@ def main():
         acc = per_kernel(d, counter)
         res[label] = {short(k): {"launches": len(v), "mean": sum(v) / len(v)} for k, v in acc.items() if "rocprim" not in k and "hipcub" not in k}
     def find(tbl, key):
-        for k, v in tbl.items():
-            if key in k:
-                return v
-        return None
+        # a pass of a chained update is the same kernel body under another name (knn5_chain_kernel / fit2_chain_kernel): the two are
+        # pooled, weighted by their launches
+        hits = [v for k, v in tbl.items() if key in k or key.replace("_kernel<", "_chain_kernel<") in k]
+        if not hits:
+            return None
+        n = sum(h["launches"] for h in hits)
+        return {"launches": n, "mean": sum(h["mean"] * h["launches"] for h in hits) / n}
     for kern, label in (("knn5_kernel<2, 8, true, false>", "dominant_kernel"), ("knn5_kernel<2, 8, false, false>", "knn5_separate"),
                         ("widen_kernel", "widen_kernel"), ("fit2_kernel", "fit2_kernel"), ("fit_kernel", "fit_kernel")):
         f = find(res["FETCH_SIZE_KB_per_launch"], kern)
