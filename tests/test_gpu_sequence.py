@@ -52,11 +52,11 @@ def test_corridor_replay_follows_cpu_oracle(built, oracle):
     G.close()
 
 
-def test_lemma_solve_against_the_literal_two_inverse_form_over_30_scans(built):
-    """The filter's default solve is the matrix-inversion-lemma form of esekfom.hpp:1722-1729 (one 12x12 solve);
-    FLIMO_REFERENCE_SOLVE=1 selects the literal form (two 23x23 inverses, unconditional eigen-decomposition).  Thirty scans of a
-    drive, FREE-RUNNING (nothing is handed over between the two runs, map inserts on): what the algebraic form contributes to
-    the trajectory, accumulated, has to stay far below the 1e-4 bar of north_star."""
+def test_default_gain_against_the_literal_two_inverse_form_over_30_scans(built):
+    """The filter's default gain takes esekfom.hpp:1722-1729 through the block-inverse identity (one 12x12 system, round 4; rounds
+    1-3: the matrix-inversion-lemma form); FLIMO_REFERENCE_SOLVE=1 selects the literal form (two 23x23 inverses, unconditional
+    eigen-decomposition).  Thirty scans of a drive, FREE-RUNNING (nothing is handed over between the two runs, map inserts on):
+    what the algebraic form contributes to the trajectory, accumulated, has to stay far below the 1e-4 bar of north_star."""
     import os
     from fast_limo_amd import api
     n_scans, n_pts, speed = 30, 8000, 10.0
@@ -90,10 +90,10 @@ def test_lemma_solve_against_the_literal_two_inverse_form_over_30_scans(built):
     dpos = np.abs(xa[:, 0:3] - xb[:, 0:3]).max(axis=1)
     dq = np.abs(xa[:, 3:7] - xb[:, 3:7]).max(axis=1)
     rel_P = np.abs(Pa - Pb).max() / np.abs(Pb).max()
-    print("lemma form vs literal two-inverse form over %d free-running scans: max |dpos| %.2e m (last scan %.2e), max |dq| %.2e, "
+    print("default gain vs literal two-inverse form over %d free-running scans: max |dpos| %.2e m (last scan %.2e), max |dq| %.2e, "
           "covariance %.2e relative, map sizes differ by at most %d points"
           % (n_scans, dpos.max(), dpos[-1], dq.max(), rel_P, int(np.abs(sa - sb).max())))
-    # measured: 3.7e-5 m / 8e-6 rad after 30 scans (the literal form inverts P / R, condition ~1e7: its own rounding is what moves)
+    # (rounds 1-3, lemma form: 3.7e-5 m / 8e-6 rad after 30 scans; the literal form inverts P / R, condition ~1e7: its own rounding moves too)
     assert dpos.max() <= 1e-4 and 2.0 * dq.max() <= 1e-4
     assert np.abs(sa - sb).max() <= 8
     assert rel_P <= 1e-3
