@@ -1,17 +1,18 @@
 // fast_limo_amd/csrc/hip/flimo_chain.h
 // The whole iterated update of a scan enqueued at once ("chain"): esekf::update_iterated_dyn_share_modified
-// (IKFoM_toolkit/esekfom/esekfom.hpp:1620-1823) as  pass_1 -> pass_2 -> ...  on ONE HIP stream, no host round trip between the
-// passes and no launch of its own for the filter's algebra.  A pass is the measurement plug-in (h_share_model, use-ikfom.cpp:10-31:
-// the k-NN / fit / reduction launches of flimo_kernels.hip).  The rest of one outer iteration (:1652-1760) runs INSIDE the pass's
-// reducing launch (flimo_ieskf.h):
-//   * one extra workgroup computes the half that does not depend on the measurement (x boxminus x_prop, the covariance through the
-//     manifold blocks, :1652-1697) while the other workgroups search and fit;
-//   * the workgroup that completes the launch (the last one to arrive at a ticket) goes on from the pass's 91 sums to the gain,
-//     the step, boxplus and the convergence test (:1722-1764) and leaves the next pass's float32 pose constants in device memory.
+// (IKFoM_toolkit/esekfom/esekfom.hpp:1620-1823) as  pass_1 -> algebra -> pass_2 -> algebra -> ...  on ONE HIP stream, no host round
+// trip between the passes.  A pass is the measurement plug-in (h_share_model, use-ikfom.cpp:10-31: the k-NN / fit / reduction launches
+// of flimo_kernels.hip).  The rest of one outer iteration (:1652-1760) is split where the loop allows it (flimo_ieskf.h):
+//   * one extra workgroup of the pass's reducing launch computes the half that does not depend on the measurement (x boxminus x_prop,
+//     the covariance through the manifold blocks, :1652-1697) while the other workgroups search and fit;
+//   * a one-workgroup launch behind the pass (ieskf_kernel, flimo_ieskf.hip) goes on from the pass's 91 sums to the gain, the step,
+//     boxplus and the convergence test (:1722-1764) and leaves the next pass's float32 pose constants in device memory.  With
+//     inline_alg the workgroup that completes the reducing launch (the last one to arrive at a ticket) does that itself: no dispatch
+//     in between, at the price of a longer pass kernel (FLIMO_CHAIN_INLINE=1; measured 1 us per step apart).
 // Every launch of a later pass reads its pose from there and leaves at once when the chain has ended.  The chain ends by handing the
 // loop back to the host filter: at the iteration whose covariance update is due (:1764-1820: the host runs that one iteration from
-// the sums the device hands over -- no further pass), or earlier at a branch the device does not run (M < 23, exact distance ties,
-// a degenerate H^T H).
+// the sums the device hands over -- no further pass), or earlier at a branch the device does not run (M < 23, a degenerate H^T H,
+// a failure).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "flimo_types.h"
@@ -68,7 +69,7 @@ struct ChainCtl {
   double2* log;                // mapped host memory: per-pass log (or nullptr)
   unsigned long long tag;      // tag of this scan's chain
   unsigned int* ticket3;       // "sums published / pre-part stored" ticket: FIT_GROUPS + 1 arrivals per launch
-  int inline_alg;              // 1: the completing workgroup runs the algebra; 0: a launch of its own does (flimo_ieskf.hip, A/B)
+  int inline_alg;              // 0 (default): the algebra is a launch of its own (flimo_ieskf.hip); 1: the completing workgroup runs it
 };
 
 // Results: 16-byte granules {value, tag} in mapped host memory (data and "ready" travel together, like a pass's sums)
@@ -77,13 +78,13 @@ constexpr int CH_X = 5;                                   // x[26]: the state th
 constexpr int CH_PASSINFO = CH_X + 26;                    // per pass: M, stragglers, ties
 constexpr int CH_SUMS = CH_PASSINFO + 3 * CH_MAX_PASSES;  // the handed-back iteration's 91 sums (upper triangle of H^T H, H^T h, M)
 constexpr int CH_RES = CH_SUMS + 91;
-// reasons (CH_BAIL)
+// reasons (CH_BAIL); TIES no longer occurs (exact ties are settled inside the reducing launch)
 constexpr int CH_R_FEW = 1, CH_R_TIES = 2, CH_R_DEGENERATE = 3, CH_R_FAILED = 4, CH_R_FINAL = 5;
 // optional per-pass log (tests): HTH[144], HTh[12], dx[23], x_after[26]
 constexpr int CH_LOGN = 144 + 12 + 23 + 26;
 
 size_t chain_state_size();
-// A/B: the algebra as a launch of its own behind the pass (inline_alg = 0).  gran: the pass's granules in device memory.
+// the algebra as a launch of its own behind the pass (inline_alg = 0).  gran: the pass's granules in device memory.
 void launch_ieskf(hipStream_t st, const ChainCtl& ch, unsigned long long seq, const float* used_RT_host_or_null,
                   hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 void launch_ieskf_extra(hipStream_t st, const ChainCtl& ch, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);   // developer tool

@@ -15,7 +15,11 @@
 // The reference's observable quirks are kept: `scalar(1/2)` == 0 in predict and S2_Mx, HTH := 0
 // when M < 23, row-zeroing degeneracy projector over Eigen::EigenSolver's eigenpair order (restated), convergence tested on the
 // un-projected step.
-// The 23x23 algebra is ~25 kflop per pass: it stays on the host (a GPU launch costs more).
+// The 23x23 algebra is ~25 kflop per pass.  Two layouts of the loop: this filter calls the measurement once per iteration (one
+// launch -> result round trip each), or the device runs the iterations back to back with the same algebra between them
+// (Esekf::device_chain -> flimo_update_chain, csrc/hip/flimo_ieskf.h) and this filter finishes the iteration whose covariance update
+// is due from the sums handed back.  inverse_gj / solve_gj below are the elimination the device's one-wave solver runs: the two
+// layouts take the same steps.
 #pragma once
 #include <cmath>
 #include <cstring>
