@@ -207,6 +207,9 @@ struct flimo_ctx {
   double* h_chain_log = nullptr;         // mapped: CH_MAX_PASSES x CH_LOGN log granules
   void* d_chain_log = nullptr;
   unsigned long long chain_tag = 0x4000000000000000ull;   // tag of the last chain (own number space)
+  bool chain_resident = false;           // FLIMO_CHAIN_RESIDENT=1: ONE resident workgroup runs every iteration's algebra beside the chain's passes (flimo_chain.h)
+  hipStream_t stream2 = nullptr;         // ... on this stream
+  hipEvent_t timeout_ev2 = nullptr;
   bool chain_inline = false;             // FLIMO_CHAIN_INLINE=1: the measurement-dependent half of an iteration inside the pass's reducing launch (run by the
                                          // workgroup that completes it) instead of a one-workgroup launch of its own behind the pass
   // Which way the iterated update runs: the chain costs about 11 us per pass on top of the pass's kernels whatever the host (the
@@ -296,6 +299,9 @@ static int ensure_dev(flimo_ctx* c, T*& p, size_t& cap, size_t need, bool keep, 
 //   FLIMO_CHAIN_INLINE=1          chained update: the filter's measurement-dependent half inside the pass's reducing launch, run by the
 //                                 workgroup that completes it (default: a one-workgroup launch of its own behind each pass -- the same
 //                                 step time within 1 %, and the pass kernel's duration stays the pass's)
+//   FLIMO_CHAIN_RESIDENT=1        chained update: one resident workgroup, launched beside the chain on a stream of its own, runs every
+//                                 iteration's algebra; the passes' workgroups wait for their constants in device memory (no dispatch
+//                                 boundary on either side of the algebra)
 //   FLIMO_PROF_PASS / FLIMO_PROF_INSERT   host-side timing prints (stderr)
 // (csrc/host: FLIMO_REFERENCE_SOLVE=1 literal two-inverse gain, FLIMO_SYNC_INSERT=1 map inserts on the caller's thread,
 //  FLIMO_PROF_DESKEW / FLIMO_PROF_CLOUDS timing prints; bench.py: FLIMO_BENCH_*.)
@@ -324,6 +330,7 @@ static void load_dev_switches(flimo_ctx* c) {
   if (env_int("FLIMO_HOST_UPDATE", v)) c->update_mode = v != 0 ? 1 : 2;
   { const char* e = getenv("FLIMO_RTT_THRESHOLD_US"); if (e && atof(e) > 0) c->rtt_threshold_us = atof(e); }
   if (env_int("FLIMO_CHAIN_INLINE", v)) c->chain_inline = v != 0;
+  if (env_int("FLIMO_CHAIN_RESIDENT", v)) c->chain_resident = v != 0;
 }
 
 // ---- context ----------------------------------------------------------------------------------
@@ -344,6 +351,7 @@ extern "C" int flimo_ctx_create(int device, flimo_ctx** out) {
   flimo_ctx* c = new flimo_ctx();
   c->device = device;
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return FLIMO_ERR_HIP; }
+  if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { (void)hipStreamDestroy(c->stream); c->stream = nullptr; delete c; return FLIMO_ERR_HIP; }
   for (int i = 0; i < 6; i++) (void)hipEventCreate(&c->ev[i]);
   bool ok = hipMalloc(&c->d_partials, (size_t)c->reduce_waves * 256 * sizeof(double)) == hipSuccess &&
             hipMalloc(&c->d_out256, FIT_GROUPS * FIT_SLOT * sizeof(double)) == hipSuccess &&
@@ -456,6 +464,8 @@ extern "C" void flimo_ctx_destroy(flimo_ctx* c) {
   if (c->timeout_ev) (void)hipEventDestroy(c->timeout_ev);
   if (c->adopt_ev) (void)hipEventDestroy(c->adopt_ev);
   if (c->h_wl_count) (void)hipHostFree(c->h_wl_count);
+  if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
+  if (c->timeout_ev2) (void)hipEventDestroy(c->timeout_ev2);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->book) insert_book_destroy(c->book);
   c->gbook.release();
@@ -1491,12 +1501,15 @@ static int gate_rings(const flimo_ctx* c, double max_dist_plane) {
 static int abandon_wait(flimo_ctx* c, const char* what, unsigned long long id) {
   if (!c->timeout_ev) (void)hipEventCreateWithFlags(&c->timeout_ev, hipEventDisableTiming);
   if (c->timeout_ev && hipEventRecord(c->timeout_ev, c->stream) == hipSuccess) c->timeout_pending = true;
+  if (!c->timeout_ev2) (void)hipEventCreateWithFlags(&c->timeout_ev2, hipEventDisableTiming);
+  if (c->timeout_ev2) (void)hipEventRecord(c->timeout_ev2, c->stream2);          // (a resident algebra workgroup may still be waiting)
   c->prev.valid = 0;
   return fail(c, FLIMO_ERR_TIMEOUT, "%s %llu did not publish its result within %d ms (kernels still running)", what, id, c->wait_timeout_ms);
 }
 static int check_abandoned(flimo_ctx* c) {
   if (!c->timeout_pending) return FLIMO_OK;
-  const hipError_t q = hipEventQuery(c->timeout_ev);
+  hipError_t q = hipEventQuery(c->timeout_ev);
+  if (q == hipSuccess && c->timeout_ev2) q = hipEventQuery(c->timeout_ev2);
   if (q == hipErrorNotReady) return fail(c, FLIMO_ERR_TIMEOUT, "the launches of an earlier pass whose wait ran out are still running");
   c->timeout_pending = false;
   if (q != hipSuccess) return fail(c, FLIMO_ERR_HIP, "an abandoned pass failed: %s", hipGetErrorString(q));
@@ -1891,6 +1904,14 @@ extern "C" int flimo_set_update_mode(flimo_ctx* c, int mode) {
   c->host_update = mode == 1 || (mode == 0 && c->launch_rtt_us <= c->rtt_threshold_us);
   return FLIMO_OK;
 }
+// developer timing of the resident form of the chain (flimo_chain.h: ChainState::stamps): CH_MAX_PASSES x 4 wall-clock ticks (100 MHz)
+extern "C" int flimo_chain_stamps(flimo_ctx* c, unsigned long long* out48) {
+  if (!c || !out48) return FLIMO_ERR_INVALID;
+  (void)hipSetDevice(c->device);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(out48, reinterpret_cast<const char*>(c->d_chain) + offsetof(ChainState, stamps), sizeof(unsigned long long) * CH_MAX_PASSES * 4, hipMemcpyDeviceToHost));
+  return FLIMO_OK;
+}
 extern "C" int flimo_update_mode(const flimo_ctx* c, int* chained, double* launch_rtt_us) {
   if (!c) return FLIMO_ERR_INVALID;
   if (chained) *chained = c->host_update ? 0 : 1;
@@ -1978,6 +1999,16 @@ extern "C" int flimo_update_chain(flimo_ctx* c, const flimo_match_cfg* cfg, flim
   ctl.tag = tag;
   ctl.ticket3 = c->d_ticket + FIT_GROUPS + 1;
   ctl.inline_alg = c->chain_inline ? 1 : 0;
+  const bool resident = c->chain_resident && !c->chain_inline;
+  ctl.resident = resident ? 1 : 0;
+  ctl.end_code = 0x80000000u | (unsigned int)(tag & 0x7fffffffull);
+  if (resident) {
+    // the algebra's workgroup first: it holds its place on the GPU while the passes run (ticket3 is zero: the last chain's hand-back
+    // re-armed it before it published its result)
+    ChainCtl rc = ctl;
+    rc.prior = nullptr;
+    launch_ieskf_resident(c->stream2, rc, seq0, n_pass, P0.RT, c->wait_timeout_ms > 0 ? c->wait_timeout_ms : 2000);
+  }
   for (int i = 0; i < n_pass; i++) {
     const unsigned long long seq = seq0 + 1 + (unsigned long long)i;
     const bool first_pass = !prev_valid;
@@ -1995,25 +2026,28 @@ extern "C" int flimo_update_chain(flimo_ctx* c, const flimo_match_cfg* cfg, flim
     pv.valid = prev_valid ? 1 : 0;            // (pass 0: the context's own bound, if any; later passes: RT comes from the device filter)
     TieList tl{};                                // (ties are settled inside the reducing launches: nothing is listed)
     tl.count_next = c->d_tie_count + ((seq + 1) & 1);
+    // resident algebra: the FIRST launch of a later pass waits (in device memory) for this pass's constants
+    unsigned int wait_epoch = (resident && i > 0) ? ch_epoch_of(seq) : 0u;
     if (after_fine) {
-      launch_knn5_fine(c->stream, c->fine, c->d_scan_sorted, n_all, P0, c->d_nbr, pv, c->fine_qlo, c->fine_qhi, &tl, seq, ch);
+      launch_knn5_fine(c->stream, c->fine, c->d_scan_sorted, n_all, P0, c->d_nbr, pv, c->fine_qlo, c->fine_qhi, &tl, seq, ch, wait_epoch, ctl.end_code);
+      wait_epoch = 0u;
       c->fine_passes++;
     }
     const DeskewArgs* dk = i == 0 ? dkp : nullptr;
     if (fused) {
       launch_match_fused(c->stream, c->grid, c->d_scan_sorted, n_all, P0, mp, c->d_nbr, c->d_wl, c->d_wl_count, nullptr, pv, c->live_idx,
                          c->d_fit2_partials, c->d_chain_gran, c->d_ticket, seq, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr, &tl,
-                         after_fine ? 1 : 0, dk, ch, &ctl, bookp);
+                         after_fine ? 1 : 0, dk, ch, &ctl, bookp, wait_epoch);
     } else {
       launch_knn5(c->stream, 2, c->grid, c->d_scan_sorted, n_all, P0, mp.max_ring, c->d_nbr, c->d_wl, c->d_wl_count, nullptr, pv, 0,
-                  ev ? ev[0] : nullptr, ev ? ev[1] : nullptr, nullptr, &tl, after_fine ? 1 : 0, seq, dk, ch);
+                  ev ? ev[0] : nullptr, ev ? ev[1] : nullptr, nullptr, &tl, after_fine ? 1 : 0, seq, dk, ch, wait_epoch, ctl.end_code);
       {
         launch_widen(c->stream, c->grid, c->d_scan_sorted, P0, mp.max_ring, c->d_nbr, c->d_wl, c->d_wl_count, nullptr, ev ? ev[6] : nullptr, ev ? ev[7] : nullptr, &tl, ch);
         launch_fit2(c->stream, c->grid, c->d_scan_sorted, n_all, c->d_nbr, P0, mp, c->live_idx, c->d_fit2_partials, c->d_chain_gran,
                     c->d_ticket, c->d_wl_count, seq, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr, &tl, ch, &ctl, bookp);
       }
     }
-    if (!c->chain_inline)
+    if (!c->chain_inline && !resident)
       launch_ieskf(c->stream, ctl, seq, i == 0 ? P0.RT : nullptr, ev ? ev[4] : nullptr, ev ? ev[5] : nullptr);
     prev_valid = c->prune;
   }
@@ -2095,7 +2129,14 @@ extern "C" int flimo_update_chain(flimo_ctx* c, const flimo_match_cfg* cfg, flim
   if (io->reason != CH_R_FINAL) c->chains_back++;
   // what the context knows about its last pass (fetches, the next pass's bound): the handed-back iteration's, at x26_out
   c->pass_seq = seq0 + (unsigned long long)executed;
-  if (io->reason == CH_R_FAILED) { c->prev.valid = 0; return fail(c, FLIMO_ERR_HIP, "a pass of the update chain did not publish its sums"); }
+  if (io->reason == CH_R_FAILED) {
+    c->prev.valid = 0;
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->stream2);
+    (void)hipMemsetAsync(c->d_ticket, 0, (FIT_GROUPS + 2) * sizeof(unsigned int), c->stream);
+    (void)hipStreamSynchronize(c->stream);
+    return fail(c, FLIMO_ERR_HIP, "a pass of the update chain did not publish its sums");
+  }
   PoseMats Pl;
   pose_from_x26(io->x26_out, Pl);
   if (c->prune && executed > 0) { memcpy(c->prev.RT, Pl.RT, sizeof(c->prev.RT)); c->prev.valid = 1; }
@@ -2119,7 +2160,7 @@ extern "C" int flimo_update_chain(flimo_ctx* c, const flimo_match_cfg* cfg, flim
       c->split_knn_ms += ms; c->split_fit_ms += ms2; c->split_widen_ms += msw; c->split_sep_n++; c->tot_fit_ms += ms2; c->tot_widen_ms += msw;
       c->last_fit_ms = ms2; c->last_widen_ms = msw;
     }
-    if (!c->chain_inline) { c->chain_alg_ms += elapsed(ev[4], ev[5]); c->chain_alg_n++; }
+    if (!c->chain_inline && !c->chain_resident) { c->chain_alg_ms += elapsed(ev[4], ev[5]); c->chain_alg_n++; }
     c->tot_passes++; c->tot_queries += n_all;
   }
   return FLIMO_OK;

@@ -26,8 +26,10 @@ struct ChainHead {
   PoseMats pose;           // float32 constants of the NEXT pass (State casts, get_RT / get_RT_inv / get_extr_RT_inv, calculate_H's rotations)
   float prev_RT[16];       // body -> world of the pass just completed: the next pass's pruning bound is relative to it
   int status;              // 0: the chain goes on; 2: handed back to the host filter
-  int pad[3];
+  unsigned int epoch;      // resident algebra: number (low 32 bits) of the pass these constants are FOR -- written last, behind them
+  int pad[2];
 };
+static_assert(sizeof(ChainHead) % 4 == 0 && sizeof(ChainHead) / 4 <= 128, "a pass workgroup reads the head with one load per thread");
 
 // The prior of a scan's update, written by the host into mapped memory before the chain is enqueued (copied to the device filter
 // by the first pass's extra workgroup, beside the pass).  The measurement-independent half of iteration -1 (x == x_prop: no
@@ -58,6 +60,9 @@ struct ChainState {
   double info[3 * CH_MAX_PASSES];   // per pass: M, stragglers, ties
   double pre_dxn[23];      // the measurement-independent half of the CURRENT iteration (extra workgroup of its pass):
   double pre_AG[276];      // dx_new; A11^-1 (144) and G2 = A21 A11^-1 (132) of A = P_ / R
+  // developer timing of the resident form (100 MHz wall clock; slot = pass number modulo CH_MAX_PASSES): [0] the pass's first
+  // workgroup starts waiting, [1] it has its constants, [2] the algebra has seen the pass's arrivals, [3] it has published
+  unsigned long long stamps[CH_MAX_PASSES][4];
 };
 
 // Arguments of the algebra inside a pass's reducing launch (S == nullptr: a host-driven pass)
@@ -70,6 +75,9 @@ struct ChainCtl {
   unsigned long long tag;      // tag of this scan's chain
   unsigned int* ticket3;       // "sums published / pre-part stored" ticket: FIT_GROUPS + 1 arrivals per launch
   int inline_alg;              // 0 (default): the algebra is a launch of its own (flimo_ieskf.hip); 1: the completing workgroup runs it
+  unsigned int end_code;       // resident algebra: head.epoch takes this value (top bit set, the chain's tag below) when the chain has ended
+  int resident;                // 1: ONE workgroup launched beside the chain runs every iteration's algebra (ieskf_resident_kernel): the
+                               // reducing launches only count their arrivals at ticket3, the next pass's workgroups wait for head.epoch
 };
 
 // Results: 16-byte granules {value, tag} in mapped host memory (data and "ready" travel together, like a pass's sums)
@@ -88,5 +96,13 @@ size_t chain_state_size();
 void launch_ieskf(hipStream_t st, const ChainCtl& ch, unsigned long long seq, const float* used_RT_host_or_null,
                   hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 void launch_ieskf_extra(hipStream_t st, const ChainCtl& ch, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);   // developer tool
+// The resident form: one workgroup for the whole chain, launched on a stream of its own BEFORE the chain's passes.  Iteration i waits
+// for the (FIT_GROUPS + 1) (i + 1) arrivals of pass i at ticket3 (zero when the chain starts; the kernel re-arms it when it leaves),
+// runs the algebra and publishes the next pass's constants under head.epoch = that pass's number (31 bits), or ch.end_code when the
+// loop goes back to the host; a pass's workgroups poll that word in device memory.  Every wait is bounded by the wall clock (wait_ms): a pass that never arrives ends the chain with reason FAILED.
+void launch_ieskf_resident(hipStream_t st, const ChainCtl& ch, unsigned long long seq0, int n_pass, const float* first_RT_host, int wait_ms);
+// head.epoch of the pass numbered seq: never zero (zero means "do not wait"), top bit clear (set: an end code)
+__host__ __device__ inline unsigned int ch_epoch_of(unsigned long long seq) { return (unsigned int)(seq & 0x3fffffffull) | 0x40000000u; }
+constexpr int CH_POLL_MS = 200;          // a pass's workgroups give up waiting for their constants after this long (status FAILED)
 
 }  // namespace flimo

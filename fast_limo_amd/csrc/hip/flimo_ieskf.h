@@ -619,7 +619,7 @@ __device__ __forceinline__ void ik_extra_block(const ChainCtl& ch, double* lds, 
     double* xc = lds + IKL_XC;
     double* xp = lds + IKL_XP;
     for (int i = tid; i < 529; i += 256) P_[i] = S->P_prop[i];                    // :1655
-    if (tid < 26) { xc[tid] = S->x[tid]; xp[tid] = S->x_prop[tid]; }
+    if (tid < 26) { xc[tid] = ik_ld(&S->x[tid]); xp[tid] = ik_ld(&S->x_prop[tid]); }   // (x: stored by the algebra of the last iteration, maybe microseconds ago)
     const double R = S->R;
     __syncthreads();
     ik_pre_block(lds, R, tid);
@@ -643,21 +643,32 @@ __device__ __forceinline__ void ik_hand_back(const ChainCtl& ch, double* lds, in
   if (tid >= 32 && tid < 32 + 3 * CH_MAX_PASSES) {
     const int k = tid - 32, p = k / 3;
     double v = 0.0;
-    if (p < passes) v = S->info[k];
+    if (p < passes) v = ik_ld(&S->info[k]);
     else if (p == passes) v = (k % 3 == 0) ? (double)M : (k % 3 == 1 ? (double)n_strag : (double)n_ties);
     ik_put(ch.res, CH_PASSINFO + k, v, ch.tag);
   }
   if (tid >= 96 && tid < 96 + IK_LIVE) ik_put(ch.res, CH_SUMS + tid - 96, live[tid - 96], ch.tag);
   if (tid == 224) {
+    if (ch.resident) {
+      // the arrival counter is re-armed BEFORE the result is out: the host may queue the next chain the moment it has it (every
+      // workgroup that will ever arrive for this chain has; passes queued behind the end leave without arriving)
+      __hip_atomic_store(ch.ticket3, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     ik_put(ch.res, CH_BAIL, (double)reason, ch.tag); ik_put(ch.res, CH_PASSES, (double)passes, ch.tag);
     ik_put(ch.res, CH_IT, (double)it, ch.tag); ik_put(ch.res, CH_T, (double)t, ch.tag);
     ik_put(ch.res, CH_STATUS, 2.0, ch.tag);
-    S->head.status = 2;
+    ik_sti(&S->head.status, 2);
+    if (ch.resident) {                                          // the queued passes' workgroups are polling this word: they leave
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(&S->head.epoch, ch.end_code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
 // The next pass's float32 constants from the new state (Objects/State.cpp:38-55,136-172, Localizer.cpp:554-555), three independent
 // pieces on three waves, written straight to the device filter's head
+__device__ __forceinline__ void ik_stf(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void ik_store_pose(const double* xn, ChainHead* H, int tid) {
   if (tid == 0) {
     const float p[3] = {(float)xn[0], (float)xn[1], (float)xn[2]};
@@ -665,7 +676,7 @@ __device__ __forceinline__ void ik_store_pose(const double* xn, ChainHead* H, in
     float T[16];
     se3_from(q, p, T);
 #pragma unroll
-    for (int i = 0; i < 16; i++) H->pose.RT[i] = T[i];
+    for (int i = 0; i < 16; i++) ik_stf(&H->pose.RT[i], T[i]);
   } else if (tid == 64 || tid == 65) {
     const int o = tid == 64 ? 3 : 7, po = tid == 64 ? 0 : 11;    // (rot, pos) / (offset_R_L_I, offset_T_L_I)
     const float p[3] = {(float)xn[po], (float)xn[po + 1], (float)xn[po + 2]};
@@ -674,7 +685,7 @@ __device__ __forceinline__ void ik_store_pose(const double* xn, ChainHead* H, in
     se3_inv_from(q, p, T);
     float* dst = tid == 64 ? H->pose.RT_inv : H->pose.TLI_inv;
 #pragma unroll
-    for (int i = 0; i < 16; i++) dst[i] = T[i];
+    for (int i = 0; i < 16; i++) ik_stf(&dst[i], T[i]);
   } else if (tid == 128 || tid == 129) {
     const int o = tid == 128 ? 3 : 7;
     const double qc[4] = {-xn[o], -xn[o + 1], -xn[o + 2], xn[o + 3]};
@@ -682,7 +693,7 @@ __device__ __forceinline__ void ik_store_pose(const double* xn, ChainHead* H, in
     quat_to_rot_d(qc, Rd);
     float* dst = tid == 128 ? H->pose.R_inv : H->pose.RLI_inv;
 #pragma unroll
-    for (int i = 0; i < 9; i++) dst[i] = (float)Rd[i];
+    for (int i = 0; i < 9; i++) ik_stf(&dst[i], (float)Rd[i]);
   }
 }
 
@@ -690,9 +701,10 @@ __device__ __forceinline__ void ik_store_pose(const double* xn, ChainHead* H, in
 //      gran / the device filter were written by other workgroups of this launch (or by earlier launches): read past the L2.
 //      used_RT: body -> world matrix this pass ran with (kernel argument of the first pass, the filter's head afterwards).
 //      CHECK_TAGS: the sums must carry `seq` (the algebra as a launch of its own: a pass that failed left older ones).
-//      Workgroup-wide, 256 threads; lds: IKL_END doubles, s_i: 32 ints. ----
+//      Workgroup-wide, 256 threads; lds: IKL_END doubles, s_i: 32 ints.
+//      Returns true when the chain goes on (the next pass's constants are stored), false when the loop went back to the host. ----
 template <bool CHECK_TAGS>
-__device__ __forceinline__ void ik_final_stage(const ChainCtl& ch, unsigned long long seq, const float* __restrict__ used_RT, double* lds,
+__device__ __forceinline__ bool ik_final_stage(const ChainCtl& ch, unsigned long long seq, const float* __restrict__ used_RT, double* lds,
                                                int* s_i, int tid) {
   ChainState* S = ch.S;
   const int n = IK_N;
@@ -759,7 +771,7 @@ __device__ __forceinline__ void ik_final_stage(const ChainCtl& ch, unsigned long
   // ---- branches the host filter takes over: a pass that did not publish, M < 23, exact distance ties ----
   if (!all_ok || M < n || n_ties > 0) {
     ik_hand_back(ch, lds, !all_ok ? CH_R_FAILED : (M < n ? CH_R_FEW : CH_R_TIES), it, t_in, passes, M, n_strag, n_ties, tid);
-    return;
+    return false;
   }
   // ---- gain (:1722-1729).  With A = P_ / R and B = H^T H:  P_inv = (A^-1 + E B E^T)^-1, and by the block-inverse identity
   //      P_inv E = [I; A21 A11^-1] (A11^-1 + B)^-1  -- the reference's formula without the two 23 x 23 inverses and without forming
@@ -818,7 +830,7 @@ __device__ __forceinline__ void ik_final_stage(const ChainCtl& ch, unsigned long
   IK_STAMP(7);
   if (s_i[17] != 0 || s_i[19] != 0) {
     ik_hand_back(ch, lds, CH_R_DEGENERATE, it, t_in, passes, M, n_strag, n_ties, tid);
-    return;
+    return false;
   }
   // ---- x boxplus dx_ (:1747), convergence (:1757-1764) ----
   if (tid < 2) {
@@ -854,11 +866,12 @@ __device__ __forceinline__ void ik_final_stage(const ChainCtl& ch, unsigned long
     // the iteration that ends the loop (:1764): the host filter runs it from these sums -- state, covariance, log -- without a pass
     ik_hand_back(ch, lds, CH_R_FINAL, it, t_in, passes, M, n_strag, n_ties, tid);
     IK_STAMP(11);
-    return;
+    return false;
   }
   const int t_out = s_i[21];
   // per-pass bookkeeping, the optional log, the next pass's constants and the bound's reference pose (the pose this pass ran with)
-  if (tid == 200 && passes < CH_MAX_PASSES) { S->info[3 * passes] = (double)M; S->info[3 * passes + 1] = (double)n_strag; S->info[3 * passes + 2] = (double)n_ties; }
+  // (everything another workgroup reads later is written through: the next pass may already be polling for it)
+  if (tid == 200 && passes < CH_MAX_PASSES) { ik_st(&S->info[3 * passes], (double)M); ik_st(&S->info[3 * passes + 1], (double)n_strag); ik_st(&S->info[3 * passes + 2], (double)n_ties); }
   if (ch.log && passes < CH_MAX_PASSES) {
     double2* lg = ch.log + (size_t)passes * CH_LOGN;
     if (tid < 144) ik_put(lg, tid, HTH[tid], ch.tag);
@@ -866,12 +879,19 @@ __device__ __forceinline__ void ik_final_stage(const ChainCtl& ch, unsigned long
     if (tid >= 160 && tid < 160 + n) ik_put(lg, 156 + tid - 160, dxu[tid - 160], ch.tag);
     if (tid >= 192 && tid < 192 + 26) ik_put(lg, 179 + tid - 192, xn[tid - 192], ch.tag);
   }
-  if (tid >= 224 && tid < 240) S->head.prev_RT[tid - 224] = used_RT[tid - 224];
+  if (tid >= 224 && tid < 240) ik_stf(&S->head.prev_RT[tid - 224], used_RT[tid - 224]);
   __syncthreads();                                              // (used_RT may BE head.pose.RT: read above before it is overwritten)
   ik_store_pose(xn, &S->head, tid);
-  if (tid == 32) { S->head.status = 0; S->it = it + 1; S->t = t_out; S->passes = passes + 1; }
-  if (tid >= 96 && tid < 96 + 26) S->x[tid - 96] = xn[tid - 96];
+  if (tid == 32) { ik_sti(&S->head.status, 0); ik_sti(&S->it, it + 1); ik_sti(&S->t, t_out); ik_sti(&S->passes, passes + 1); }
+  if (tid >= 96 && tid < 96 + 26) ik_st(&S->x[tid - 96], xn[tid - 96]);
+  if (ch.resident) {
+    // the next pass's workgroups are waiting for this word: everything above is performed first
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(&S->head.epoch, ch_epoch_of(seq + 1ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   IK_STAMP(10);
+  return true;
 }
 
 }  // namespace flimo

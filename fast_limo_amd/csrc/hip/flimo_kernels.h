@@ -22,11 +22,13 @@ void launch_knn5(hipStream_t st, int lanes_per_query, const GridView& G, const f
                  const PoseMats& P, int max_ring, void* nbr, int* wl, int* wl_count, unsigned long long* cand,
                  const PrevPass& prev, int tail, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, const struct FuseArgs* fuse = nullptr,
                  const TieList* ties = nullptr, int after_fine = 0, unsigned long long seq = 0ull, const DeskewArgs* deskew = nullptr,
-                 const ChainHead* chain = nullptr);
+                 const ChainHead* chain = nullptr, unsigned int wait_epoch = 0u, unsigned int end_code = 0u);
+// (wait_epoch != 0: the launch's workgroups wait for the resident algebra to publish the chain's head under that number -- the FIRST
+//  launch of a chained pass; end_code: the value that says the chain has ended; flimo_chain.h)
 // fine pre-pass over the second-level grid of crowded regions (see flimo_map.hip); launches that follow it pass after_fine = 1
 void launch_knn5_fine(hipStream_t st, const GridView& Gf, const float4* scan_sorted, int n, const PoseMats& P, void* nbr,
                       const PrevPass& prev, const int qlo[3], const int qhi[3], const TieList* ties, unsigned long long seq,
-                      const ChainHead* chain = nullptr);
+                      const ChainHead* chain = nullptr, unsigned int wait_epoch = 0u, unsigned int end_code = 0u);
 // tail != 0: queries that need more than the 3x3x3 block are finished inside the k-NN launch itself (gates of at most 3
 // rings; launch_knn5 clears the flag otherwise) and launch_widen has nothing to do
 void launch_widen(hipStream_t st, const GridView& G, const float4* scan_sorted, const PoseMats& P, int max_ring, void* nbr,
@@ -63,7 +65,7 @@ void launch_match_fused(hipStream_t st, const GridView& G, const float4* scan_so
                         const unsigned char* live_idx, double* partials, void* out_granules, unsigned int* ticket,
                         unsigned long long seq, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, const TieList* ties = nullptr,
                         int after_fine = 0, const DeskewArgs* deskew = nullptr, const ChainHead* chain = nullptr,
-                        const ChainCtl* ctl = nullptr, const BookView* book = nullptr);
+                        const ChainCtl* ctl = nullptr, const BookView* book = nullptr, unsigned int wait_epoch = 0u);
 // The reference's choice among exactly tied distances (first met by Octree::knn's recursion): BookView = the device copy of the
 // octree (insert book), TieList = the queries a pass flagged.  launch_tie rewrites their neighbour records; launch_knn_tie does the
 // same for the output of launch_knn.

@@ -836,7 +836,11 @@ __device__ __forceinline__ void fit_reduce_publish(const float (&v)[16], bool ow
 // Workgroup-wide; s_flag: a word of shared memory.
 __device__ __forceinline__ void chain_arrive(const ChainCtl& ch, unsigned long long seq, const float* used_RT, double* big_lds,
                                              unsigned int* s_flag) {
-  if (!ch.inline_alg) return;                          // the algebra is a launch of its own (A/B)
+  if (ch.resident) {                                   // a resident workgroup runs the algebra: it counts the arrivals
+    if (threadIdx.x == 0) (void)__hip_atomic_fetch_add(ch.ticket3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  if (!ch.inline_alg) return;                          // the algebra is a launch of its own
   if (threadIdx.x == 0) {
     const unsigned int old = __hip_atomic_fetch_add(ch.ticket3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     *s_flag = (old == (unsigned int)FIT_GROUPS) ? 1u : 0u;
@@ -1312,16 +1316,56 @@ __global__ __launch_bounds__(256) KNN_WPE void knn5_kernel(GridView G, const flo
                                                    FuseArgs fa) {
   knn5_pass<L, SLOTS, FUSE, FINE>(G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand_total, prev.RT, prev.valid, prev.probe_min, tail, fa);
 }
+// How a launch of a chained pass gets the filter's head: a copy in the workgroup's shared memory (one word per thread), which the pass
+// reads its constants from.  wait_epoch == 0: the head was stored by an earlier launch on this stream (the algebra as a launch of
+// its own; a later launch of a pass whose first one waited): plain loads.  Otherwise a resident workgroup publishes it while this
+// launch is already placed: one thread polls head.epoch in device memory (s_sleep between looks, bounded by the wall clock), then
+// the workgroup reads the head past the caches.  nullptr: the chain has ended (or the wait ran out): leave.
+__device__ __forceinline__ const ChainHead* chain_enter(const ChainHead* __restrict__ H, unsigned int wait_epoch, unsigned int end_code) {
+  constexpr int NW = (int)(sizeof(ChainHead) / 4);
+  __shared__ unsigned int s_head[NW];
+  __shared__ int s_go;
+  if (wait_epoch != 0u) {
+    if (threadIdx.x == 0) {
+      const unsigned long long t0 = wall_clock64();
+      ChainState* dbgS = blockIdx.x == 0 ? const_cast<ChainState*>(reinterpret_cast<const ChainState*>(H)) : nullptr;
+      if (dbgS) dbgS->stamps[wait_epoch % CH_MAX_PASSES][0] = t0;
+      int go = 0;
+      // (the algebra takes a few microseconds from the moment the last pass delivered: hundreds of workgroups looking at one word
+      //  every 60 ns would stand in its way -- a first look, a long nap, then a look every quarter of a microsecond)
+      for (int look = 0;; look++) {
+        const unsigned int e = __hip_atomic_load(&H->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (e == wait_epoch) { go = 1; break; }
+        if (e == end_code) break;
+        if (wall_clock64() - t0 > (unsigned long long)CH_POLL_MS * 100000ull) break;      // 100 MHz
+        if (look == 0) __builtin_amdgcn_s_sleep(96);
+        else __builtin_amdgcn_s_sleep(8);
+      }
+      if (dbgS) dbgS->stamps[wait_epoch % CH_MAX_PASSES][1] = wall_clock64();
+      s_go = go;
+    }
+    __syncthreads();
+    if (!s_go) return nullptr;
+    if ((int)threadIdx.x < NW)
+      s_head[threadIdx.x] = __hip_atomic_load(reinterpret_cast<const unsigned int*>(H) + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    if ((int)threadIdx.x < NW) s_head[threadIdx.x] = reinterpret_cast<const unsigned int*>(H)[threadIdx.x];
+  }
+  __syncthreads();
+  const ChainHead* Lh = reinterpret_cast<const ChainHead*>(s_head);
+  return Lh->status != 0 ? nullptr : Lh;
+}
 // The same pass inside a chain: pose constants and the bound's reference pose from the device filter (written by the algebra
-// kernel queued before this launch); nothing to do once the chain has ended.
+// queued before this launch, or by the resident one while this launch waits); nothing to do once the chain has ended.
 template <int L, int SLOTS, bool FUSE, bool FINE = false>
 __global__ __launch_bounds__(256) KNN_WPE void knn5_chain_kernel(GridView G, const float4* __restrict__ scan_sorted, int n,
                                                    const ChainHead* __restrict__ H, int max_ring, NbrRec* __restrict__ nbr,
                                                    int* __restrict__ wl, int* __restrict__ wl_count,
                                                    unsigned long long* __restrict__ cand_total, int prev_valid, unsigned probe_min, int tail,
-                                                   FuseArgs fa) {
-  if (H->status != 0) return;
-  knn5_pass<L, SLOTS, FUSE, FINE>(G, scan_sorted, n, H->pose, max_ring, nbr, wl, wl_count, cand_total, H->prev_RT, prev_valid, probe_min, tail, fa);
+                                                   FuseArgs fa, unsigned int wait_epoch) {
+  const ChainHead* Lh = chain_enter(H, wait_epoch, fa.ch.end_code);
+  if (!Lh) return;
+  knn5_pass<L, SLOTS, FUSE, FINE>(G, scan_sorted, n, Lh->pose, max_ring, nbr, wl, wl_count, cand_total, Lh->prev_RT, prev_valid, probe_min, tail, fa);
 }
 
 // Widening for the worklist (rare): ONE WAVE per query.  The (2r+1)^2 <= 49 rows of the ring-r block
@@ -2474,7 +2518,8 @@ template <int L>
 static void launch_knn5_L(hipStream_t st, const GridView& G, const float4* scan_sorted, int n, const PoseMats& P,
                           int max_ring, void* nbr, int* wl, int* wl_count, unsigned long long* cand, const PrevPass& prev,
                           int tail, hipEvent_t e0, hipEvent_t e1, const FuseArgs* fuse, const TieList* tlp, int after_fine = 0,
-                          unsigned long long seq = 0ull, const DeskewArgs* dk = nullptr, const ChainHead* chain = nullptr) {
+                          unsigned long long seq = 0ull, const DeskewArgs* dk = nullptr, const ChainHead* chain = nullptr,
+                          unsigned int wait_epoch = 0u, unsigned int end_code = 0u) {
   const int qpb = 256 / L;
   const int blocks = round_up8((n + qpb - 1) / qpb);
   constexpr int slots = (L <= 4 ? 8 : 4);          // candidate loads in flight per lane
@@ -2482,7 +2527,7 @@ static void launch_knn5_L(hipStream_t st, const GridView& G, const float4* scan_
     if (fuse) {      // the whole pass in one launch (blocks is a multiple of 8 = FIT_GROUPS; a chained pass has one workgroup more)
       const int grid = fused_blocks(n) + (fuse->ch.S ? 1 : 0);
       if (chain)
-        hipExtLaunchKernelGGL((knn5_chain_kernel<2, 8, true>), dim3(grid), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, chain, max_ring, (NbrRec*)nbr, wl, wl_count, cand, prev.valid, prev.probe_min, 1, *fuse);
+        hipExtLaunchKernelGGL((knn5_chain_kernel<2, 8, true>), dim3(grid), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, chain, max_ring, (NbrRec*)nbr, wl, wl_count, cand, prev.valid, prev.probe_min, 1, *fuse, wait_epoch);
       else
       hipExtLaunchKernelGGL((knn5_kernel<2, 8, true>), dim3(grid), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand, prev, 1, *fuse);
       return;
@@ -2493,11 +2538,12 @@ static void launch_knn5_L(hipStream_t st, const GridView& G, const float4* scan_
   nofuse.fine_mode = after_fine ? 1 : 0;
   nofuse.seq = seq;
   if (dk) nofuse.dk = *dk;
+  nofuse.ch.end_code = end_code;
   // e0 / e1 (optional) are attached to the dispatch itself: they read the kernel's own begin / end
   // timestamps, without the extra barrier packets of hipEventRecord
   if constexpr (L == 2) {
     if (chain) {
-      hipExtLaunchKernelGGL((knn5_chain_kernel<2, 8, false>), dim3(blocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, chain, max_ring, (NbrRec*)nbr, wl, wl_count, cand, prev.valid, prev.probe_min, tail, nofuse);
+      hipExtLaunchKernelGGL((knn5_chain_kernel<2, 8, false>), dim3(blocks), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, n, chain, max_ring, (NbrRec*)nbr, wl, wl_count, cand, prev.valid, prev.probe_min, tail, nofuse, wait_epoch);
       return;
     }
   }
@@ -2507,10 +2553,10 @@ static void launch_knn5_L(hipStream_t st, const GridView& G, const float4* scan_
 void launch_knn5(hipStream_t st, int lanes_per_query, const GridView& G, const float4* scan_sorted, int n,
                  const PoseMats& P, int max_ring, void* nbr, int* wl, int* wl_count, unsigned long long* cand,
                  const PrevPass& prev, int tail, hipEvent_t e0, hipEvent_t e1, const FuseArgs* fuse, const TieList* tlp, int after_fine,
-                 unsigned long long seq, const DeskewArgs* dk, const ChainHead* chain) {
+                 unsigned long long seq, const DeskewArgs* dk, const ChainHead* chain, unsigned int wait_epoch, unsigned int end_code) {
   if (n <= 0) return;
   if (max_ring < 2 || max_ring > TAIL_MAX_RING) tail = 0;
-  if (chain) { launch_knn5_L<2>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine, seq, dk, chain); return; }   // (two lanes per query only)
+  if (chain) { launch_knn5_L<2>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine, seq, dk, chain, wait_epoch, end_code); return; }   // (two lanes per query only)
   switch (lanes_per_query) {
     case 1: launch_knn5_L<1>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine, seq, dk); break;
     case 2: launch_knn5_L<2>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine, seq, dk); break;
@@ -2579,9 +2625,11 @@ int fused_blocks(int n) { return round_up8((int)((((long long)n << fused_spread(
 // fine pre-pass over the second-level grid (crowded regions): settles the queries whose five are proven inside their fine 3x3x3
 // block; their records get flag 4, which the main launch of the same pass (fine_mode 1) takes over
 void launch_knn5_fine(hipStream_t st, const GridView& Gf, const float4* scan_sorted, int n, const PoseMats& P, void* nbr,
-                      const PrevPass& prev, const int qlo[3], const int qhi[3], const TieList* tlp, unsigned long long seq, const ChainHead* chain) {
+                      const PrevPass& prev, const int qlo[3], const int qhi[3], const TieList* tlp, unsigned long long seq, const ChainHead* chain,
+                      unsigned int wait_epoch, unsigned int end_code) {
   if (n <= 0) return;
   FuseArgs fa{};
+  fa.ch.end_code = end_code;
   fa.fine_mode = 2;
   fa.seq = seq;
   for (int a = 0; a < 3; a++) { fa.qlo[a] = qlo[a]; fa.qhi[a] = qhi[a]; }
@@ -2589,7 +2637,7 @@ void launch_knn5_fine(hipStream_t st, const GridView& Gf, const float4* scan_sor
   PrevPass pv = prev;
   if (chain) {
     hipLaunchKernelGGL((knn5_chain_kernel<2, 8, false, true>), dim3(round_up8((n + 127) / 128)), dim3(256), 0, st, Gf, scan_sorted, n, chain, 1,
-                       (NbrRec*)nbr, (int*)nullptr, (int*)nullptr, (unsigned long long*)nullptr, pv.valid, pv.probe_min, 0, fa);
+                       (NbrRec*)nbr, (int*)nullptr, (int*)nullptr, (unsigned long long*)nullptr, pv.valid, pv.probe_min, 0, fa, wait_epoch);
     return;
   }
   hipLaunchKernelGGL((knn5_kernel<2, 8, false, true>), dim3(round_up8((n + 127) / 128)), dim3(256), 0, st, Gf, scan_sorted, n, P, 1,
@@ -2599,7 +2647,7 @@ void launch_match_fused(hipStream_t st, const GridView& G, const float4* scan_so
                         void* nbr, int* wl, int* wl_count, unsigned long long* cand, const PrevPass& prev,
                         const unsigned char* live_idx, double* partials, void* out_granules, unsigned int* ticket,
                         unsigned long long seq, hipEvent_t e0, hipEvent_t e1, const TieList* tlp, int after_fine, const DeskewArgs* dk,
-                        const ChainHead* chain, const ChainCtl* ctl, const BookView* bookp) {
+                        const ChainHead* chain, const ChainCtl* ctl, const BookView* bookp, unsigned int wait_epoch) {
   if (n <= 0) return;
   FuseArgs fa{};
   if (ctl) fa.ch = *ctl;
@@ -2612,7 +2660,7 @@ void launch_match_fused(hipStream_t st, const GridView& G, const float4* scan_so
   for (int i = 0; i < FIT_LIVE_PAD; i++) fa.idx.raw[i] = i < FIT_LIVE ? live_idx[i] : 0;
   fa.partials = partials; fa.granules = (double2*)out_granules; fa.ticket = ticket; fa.seq = seq;
   fa.spread = fused_spread(n);
-  launch_knn5_L<2>(st, G, scan_sorted, n, P, mp.max_ring, nbr, wl, wl_count, cand, prev, 1, e0, e1, &fa, nullptr, 0, 0ull, nullptr, chain);
+  launch_knn5_L<2>(st, G, scan_sorted, n, P, mp.max_ring, nbr, wl, wl_count, cand, prev, 1, e0, e1, &fa, nullptr, 0, 0ull, nullptr, chain, wait_epoch, fa.ch.end_code);
 }
 
 void launch_reduce_final(hipStream_t st, const double* partials, int nparts, double* out256) {

@@ -227,6 +227,10 @@ int flimo_update_chain(flimo_ctx* ctx, const flimo_match_cfg* cfg, flimo_chain_i
  * host-driven pass pays it every time, a chain never: flimo_update_chain declines on a fast host, where the host loop is the faster
  * of the two, and runs on a slow one); 1 = always decline (host loop); 2 = always run the chain.  FLIMO_HOST_UPDATE=1 / 0 preset 1 / 2.
  * flimo_update_mode: *chained = 1 when flimo_update_chain will run, *launch_rtt_us = the measured round trip. */
+/* developer timing of a chained update whose algebra is resident (FLIMO_CHAIN_RESIDENT=1): 12 x 4 wall-clock ticks (100 MHz), slot =
+ * pass number modulo 12: [0] the pass starts waiting for its constants, [1] it has them, [2] the algebra has seen the PREVIOUS pass's
+ * arrivals, [3] it has published */
+int flimo_chain_stamps(flimo_ctx* ctx, unsigned long long* out48);
 int flimo_set_update_mode(flimo_ctx* ctx, int mode);
 int flimo_update_mode(const flimo_ctx* ctx, int* chained, double* launch_rtt_us);
 /* out[0] = GPU ms of the algebra launches timed so far (timing level 1; only with FLIMO_CHAIN_INLINE=0), out[1] = their number,
