@@ -1198,16 +1198,19 @@ extern "C" int flimo_raw_scan_filter_order_set(flimo_ctx* c, const void* points3
     HIPCHK(c, hipMalloc(&c->d_t_tmp, cap * sizeof(double)));
     c->tkey_cap = cap;
   }
-  const bool staged = points32 == c->h_stage && n * 32 <= c->stage_cap;     // the caller filled flimo_upload_stage's buffer itself
+  // time_order bit 2: the records are 16 bytes -- x, y, z and the 32-bit time word (OUSTER's t, VELODYNE's time)
+  const size_t rec = (time_order & 4) ? 16 : 32;
+  if (rec == 16 && cfg->time_kind > 1) return fail(c, FLIMO_ERR_INVALID, "16-byte records carry a 32-bit time word: time_kind 0 or 1");
+  const bool staged = points32 == c->h_stage && n * rec <= c->stage_cap;     // the caller filled flimo_upload_stage's buffer itself
   if (!staged) {
-    rc = ensure_stage(c, n * 32);
+    rc = ensure_stage(c, n * rec);
     if (rc) return rc;
   }
   if (staged) {
-    HIPCHK(c, hipMemcpyAsync(c->d_raw32, c->h_stage, n * 32, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_raw32, c->h_stage, n * rec, hipMemcpyHostToDevice, c->stream));
   } else {
     // pageable caller memory -> pinned stage -> HBM in chunks: the DMA of a chunk runs while the next one is staged
-    const size_t total = n * 32, chunk = 512u << 10;
+    const size_t total = n * rec, chunk = 512u << 10;
     for (size_t o = 0; o < total; o += chunk) {
       const size_t len = std::min(chunk, total - o);
       memcpy((char*)c->h_stage + o, (const char*)points32 + o, len);
@@ -1257,7 +1260,7 @@ extern "C" int flimo_raw_scan_filter_order_set(flimo_ctx* c, const void* points3
   F.fov = cfg->fov_active ? 1 : 0; F.fov_angle = cfg->fov_angle;
   const bool keep_order = (time_order & 2) != 0;      // bit 1: no spatial order (a voxel filter follows and re-orders the scan)
   time_order &= 1;
-  HIPCHK(c, filter_raw_scan(c->stream, c->d_raw32, n, F, c->d_scan_raw, c->d_scan_t, c->d_filt_ext, c->scratch, time_order ? c->d_tkey[0] : nullptr));
+  HIPCHK(c, filter_raw_scan(c->stream, c->d_raw32, n, F, c->d_scan_raw, c->d_scan_t, c->d_filt_ext, c->scratch, time_order ? c->d_tkey[0] : nullptr, (int)rec));
   HIPCHK(c, hipMemcpyAsync(c->h_filt_ext, c->d_filt_ext, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const size_t m = (size_t)c->h_filt_ext[1];

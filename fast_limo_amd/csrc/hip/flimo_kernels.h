@@ -149,7 +149,8 @@ hipError_t map_merge_grid(hipStream_t st, const float4* old_sorted, size_t n_old
 // stamp key (complemented when the sweep is sorted descending), kept count, "a kept stamp is NaN", "two kept stamps are equal"
 // (time_order_raw)}; key_out[k] (optional) = ordered stamp key, ascending = the order of the reference's time sort.
 hipError_t filter_raw_scan(hipStream_t st, const void* raw32_dev, size_t n, const FilterParams& F, float4* out, double* t_out,
-                           unsigned long long* ext_dev, MapBuildScratch& S, unsigned long long* key_out = nullptr);
+                           unsigned long long* ext_dev, MapBuildScratch& S, unsigned long long* key_out = nullptr, int rec_bytes = 32);
+// (rec_bytes 16: records {x, y, z, 32-bit time word} instead of the reference's 32-byte PointType -- time kinds 0 and 1)
 // The kept points in the reference's time order (unique when no two stamps are equal; ext_dev[3] = 1 reports equal stamps): stable
 // radix sort of the ordered stamp keys filter_raw_scan wrote, pts_out[i] = (xyz of pts[perm_out[i]], w = i), t_out likewise.
 hipError_t time_order_raw(hipStream_t st, const float4* pts, const double* t, size_t n, const unsigned long long* keys,

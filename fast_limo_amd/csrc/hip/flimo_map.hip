@@ -637,7 +637,10 @@ __device__ __forceinline__ unsigned int filt_lookback(const unsigned long long* 
   __syncthreads();
   return *s_sum;
 }
-__global__ __launch_bounds__(256) void filt_onepass_kernel(const Raw32* __restrict__ in, size_t n, FilterParams F, unsigned int* __restrict__ ticket,
+// REC = 32: the reference's PointType records; REC = 16: {x, y, z, the 32-bit time word} (OUSTER / VELODYNE stamps), what a caller
+// that stages the upload itself may pack the sweep into -- half the bytes over PCIe
+template <int REC>
+__global__ __launch_bounds__(256) void filt_onepass_kernel(const void* __restrict__ in_, size_t n, FilterParams F, unsigned int* __restrict__ ticket,
                                                            unsigned int ticket_base, unsigned long long* __restrict__ desc_alive,
                                                            unsigned long long* __restrict__ desc_kept, unsigned int epoch,
                                                            float4* __restrict__ out, double* __restrict__ t_out,
@@ -663,9 +666,15 @@ __global__ __launch_bounds__(256) void filt_onepass_kernel(const Raw32* __restri
     p.x = p.y = p.z = 0.f; p.u0 = p.u1 = 0u;
     const bool inb = i < n;
     if (inb) {
-      const float4 a = reinterpret_cast<const float4*>(in + i)[0];
-      const uint4 b = reinterpret_cast<const uint4*>(in + i)[1];
-      p.x = a.x; p.y = a.y; p.z = a.z; p.u0 = b.z; p.u1 = b.w;
+      if constexpr (REC == 32) {
+        const Raw32* in = static_cast<const Raw32*>(in_);
+        const float4 a = reinterpret_cast<const float4*>(in + i)[0];
+        const uint4 b = reinterpret_cast<const uint4*>(in + i)[1];
+        p.x = a.x; p.y = a.y; p.z = a.z; p.u0 = b.z; p.u1 = b.w;
+      } else {
+        const float4 a = static_cast<const float4*>(in_)[i];
+        p.x = a.x; p.y = a.y; p.z = a.z; p.u0 = __float_as_uint(a.w);
+      }
     }
     px[r] = p.x; py[r] = p.y; pz[r] = p.z; u0[r] = p.u0; u1[r] = p.u1;
     alive[r] = __ballot(inb && filt_alive(p, F));
@@ -757,7 +766,7 @@ __global__ __launch_bounds__(256) void filt_onepass_kernel(const Raw32* __restri
 }
 
 hipError_t filter_raw_scan(hipStream_t st, const void* raw32_dev, size_t n, const FilterParams& F, float4* out, double* t_out,
-                           unsigned long long* ext_dev, MapBuildScratch& S, unsigned long long* key_out) {
+                           unsigned long long* ext_dev, MapBuildScratch& S, unsigned long long* key_out, int rec_bytes) {
   if (n == 0) return hipSuccess;
   const size_t tiles = (n + FILT_TILE - 1) / FILT_TILE;
   hipError_t e;
@@ -778,8 +787,12 @@ hipError_t filter_raw_scan(hipStream_t st, const void* raw32_dev, size_t n, cons
   unsigned int* ticket = reinterpret_cast<unsigned int*>(S.filt_desc + 2 * S.filt_tiles_cap);
   S.filt_epoch++;
   if (S.filt_epoch == 0u) S.filt_epoch = 1u;                   // (after 2^32 launches the words are 2^32 launches stale: never equal)
-  hipLaunchKernelGGL(filt_onepass_kernel, dim3((unsigned)tiles), dim3(256), 0, st, static_cast<const Raw32*>(raw32_dev), n, F, ticket,
-                     S.filt_ticket_base, desc_alive, desc_kept, S.filt_epoch, out, t_out, ext_dev, key_out);
+  if (rec_bytes == 16)
+    hipLaunchKernelGGL(filt_onepass_kernel<16>, dim3((unsigned)tiles), dim3(256), 0, st, raw32_dev, n, F, ticket,
+                       S.filt_ticket_base, desc_alive, desc_kept, S.filt_epoch, out, t_out, ext_dev, key_out);
+  else
+    hipLaunchKernelGGL(filt_onepass_kernel<32>, dim3((unsigned)tiles), dim3(256), 0, st, raw32_dev, n, F, ticket,
+                       S.filt_ticket_base, desc_alive, desc_kept, S.filt_epoch, out, t_out, ext_dev, key_out);
   S.filt_ticket_base += (unsigned int)tiles;                   // (wraps with the counter)
   return hipGetLastError();
 }

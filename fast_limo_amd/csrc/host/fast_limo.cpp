@@ -9,6 +9,9 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 #include <cstring>
 #include <functional>
 #include <iostream>
@@ -1277,36 +1280,61 @@ int Localizer::deskewOnDevice(const PointType* raw_points, size_t n, double star
   int nan = 0, tied = 0;
   static_assert(sizeof(PointType) == 32, "PointType layout");
   const void* src = raw_points;
+  bool rec16 = false;
   if (n >= 32768) {
     // pageable cloud -> the context's pinned upload buffer, shared with two helpers (chunks are taken from a common counter: a
     // helper that wakes late finds nothing left and nobody waits for it)
+    // A sensor whose stamp is a 32-bit word (OUSTER, VELODYNE) is packed into 16-byte records on the way -- x, y, z and that word
+    // are all the device reads of a point: half the bytes over PCIe.
+    static const bool no_pack = std::getenv("FLIMO_NO_PACK16") != nullptr;       // developer A/B
+    const bool pack = fc.time_kind <= 1 && !no_pack;
     void* stage = nullptr;
-    if (flimo_upload_stage(c, n * sizeof(PointType), &stage) == FLIMO_OK && stage) {
+    if (flimo_upload_stage(c, n * (pack ? 16 : sizeof(PointType)), &stage) == FLIMO_OK && stage) {
       if (!helpers_) helpers_.reset(new flimo_host::Helpers(3));
       struct CopyJob {
-        const char* src; char* dst; size_t total, chunk, nchunks;
+        const char* src; char* dst; size_t n_pts, chunk_pts, nchunks; bool pack;
         std::atomic<size_t> next{0}, done{0};
         void work() {
           for (;;) {
             const size_t i = next.fetch_add(1, std::memory_order_relaxed);
             if (i >= nchunks) return;
-            const size_t o = i * chunk;
-            std::memcpy(dst + o, src + o, std::min(chunk, total - o));
+            const size_t p0 = i * chunk_pts, p1 = std::min(n_pts, p0 + chunk_pts);
+            if (!pack) {
+              std::memcpy(dst + p0 * 32, src + p0 * 32, (p1 - p0) * 32);
+            } else {
+#if defined(__SSE2__)
+              // (x, y, z, w) and the time word -> (x, y, z, time): two loads, two shuffles, one store per point
+              for (size_t p = p0; p < p1; p++) {
+                const __m128 a = _mm_loadu_ps(reinterpret_cast<const float*>(src + p * 32));
+                const __m128 t = _mm_load_ss(reinterpret_cast<const float*>(src + p * 32 + 24));
+                const __m128 zt = _mm_shuffle_ps(a, t, _MM_SHUFFLE(0, 0, 2, 2));                    // (z, z, t, t)
+                _mm_storeu_ps(reinterpret_cast<float*>(dst + p * 16), _mm_shuffle_ps(a, zt, _MM_SHUFFLE(2, 0, 1, 0)));   // (x, y, z, t)
+              }
+#else
+              for (size_t p = p0; p < p1; p++) {
+                uint32_t rec[4];
+                std::memcpy(rec, src + p * 32, 12);
+                std::memcpy(rec + 3, src + p * 32 + 24, 4);
+                std::memcpy(dst + p * 16, rec, 16);
+              }
+#endif
+            }
             done.fetch_add(1, std::memory_order_release);
           }
         }
       };
       auto job = std::make_shared<CopyJob>();
-      job->src = (const char*)src; job->dst = (char*)stage; job->total = n * sizeof(PointType); job->chunk = 128u << 10;
-      job->nchunks = (job->total + job->chunk - 1) / job->chunk;
+      job->src = (const char*)src; job->dst = (char*)stage; job->n_pts = n; job->chunk_pts = 4096; job->pack = pack;
+      job->nchunks = (n + job->chunk_pts - 1) / job->chunk_pts;
       for (int w = 1; w <= 2; w++) helpers_->run(w, [job] { job->work(); });
       job->work();
       while (job->done.load(std::memory_order_acquire) < job->nchunks) {}
       src = stage;
+      if (pack) rec16 = true;
     }
   }
   const double tf2 = prof ? now_s() : 0.0;
-  if (flimo_raw_scan_filter_order_set(c, src, n, &fc, (need_order ? 1 : 0) | (fl.voxel_active ? 2 : 0), &kept, &last_stamp, &nan, &tied) != FLIMO_OK || nan || tied)
+  if (flimo_raw_scan_filter_order_set(c, src, n, &fc, (need_order ? 1 : 0) | (fl.voxel_active ? 2 : 0) | (rec16 ? 4 : 0), &kept, &last_stamp, &nan, &tied) != FLIMO_OK || nan || tied)
     return 0;
   const double tf3 = prof ? now_s() : 0.0;
   double tf4 = tf3;

@@ -149,7 +149,10 @@ int flimo_upload_stage(flimo_ctx* ctx, size_t bytes, void** host_ptr);
  * equal; with equal stamps it is the library's heap moves', *tied = 1 is returned, nothing is made resident, and the caller takes
  * the host routine.  flimo_raw_scan_order: time rank -> position among the kept points (for the clouds handed back to callers).
  * time_order bit 1 (value 2): the sweep is NOT put into the spatial order the per-pass kernels like -- for a caller that runs
- * flimo_scan_voxel_filter right after the deskew, which re-orders the scan anyway. */
+ * flimo_scan_voxel_filter right after the deskew, which re-orders the scan anyway.
+ * time_order bit 2 (value 4): points32 holds 16-byte records {float x, y, z; 32-bit time word (PointType offset 24: OUSTER's uint32 t,
+ * VELODYNE's float time)} instead of PointType records: time_kind 0 or 1 only.  A caller that stages the upload itself
+ * (flimo_upload_stage) packs the sweep while it copies it and halves the bytes over PCIe. */
 int flimo_raw_scan_filter_order_set(flimo_ctx* ctx, const void* points32, size_t n, const flimo_filter_cfg* cfg, int time_order,
                                     size_t* n_kept, double* last_stamp, int* nan_stamp, int* tied);
 int flimo_raw_scan_order(flimo_ctx* ctx, uint32_t* order_out, size_t cap, size_t* n);

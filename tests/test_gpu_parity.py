@@ -507,6 +507,54 @@ def test_gpu_input_filters_and_stamps_match_oracle(built, oracle, sensor, eos):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("sensor,eos", [("OUSTER", False), ("VELODYNE", True), ("HESAI", False)])
+def test_staged_upload_packs_32_bit_stamps_into_16_byte_records(built, oracle, sensor, eos):
+    """A sweep of 32 768 points or more is staged into pinned memory by the caller's helper threads; a sensor whose stamp is a 32-bit
+    word (OUSTER, VELODYNE) is packed into 16-byte records {x, y, z, time word} on the way (flimo_raw_scan_filter_order_set,
+    time_order bit 2), the others travel as the reference's 32-byte records.  Against the host front end (host filters, host stamps):
+    the same resident scan, state and map, bit for bit; NaN coordinates and the filters included."""
+    from fast_limo_amd import api
+    code = {"OUSTER": 0, "VELODYNE": 1, "HESAI": 2}[sensor]
+    mp, scan5, imu = cfg1_scene(n_scan=40000)
+    st, w, a = imu
+    rs = np.random.RandomState(11)
+    xyz = scan5[:, :3].copy()
+    xyz[::97] = np.nan
+    xyz[1::211] *= np.float32(0.01)
+    rel = (rs.permutation(xyz.shape[0]) + 0.5) * (0.1 / xyz.shape[0])                     # pairwise different stamps
+    filt = dict(crop_active=1, dist_active=1, min_dist=1.5, rate_active=1, rate_value=3)
+    res = {}
+    for label, gpu_filters in (("device", True), ("host", False)):
+        G = api.Localizer(api.default_cfg(sensor_type=code, end_of_sweep=int(eos), cropBoxMin=(-0.5, -0.5, -0.5),
+                                          cropBoxMax=(0.5, 0.5, 0.5), **filt, **CAPS))
+        G.set_flags(add_to_map=True, download_clouds=False)
+        G.set_gpu_filters(gpu_filters)
+        G.map_add(mp)
+        i = 0
+        for until, start in ((0.105, 0.0), (0.205, 0.1)):
+            while i < len(st) and st[i] <= until:
+                G.update_imu(st[i], w[i], a[i]); i += 1
+            stamp = start + (0.1 if eos else 0.0)
+            if sensor == "OUSTER":
+                pts = oracle.make_points(xyz, 1.0, t_ns=np.round(((0.1 - rel) if eos else rel) * 1e9).astype(np.uint32))
+            elif sensor == "VELODYNE":
+                pts = oracle.make_points(xyz, 1.0, time_s=((0.1 - rel) if eos else rel).astype(np.float32))
+            else:
+                pts = oracle.make_points(xyz, 1.0, timestamp=start + rel)
+            rc = G.update_pointcloud_points(pts, stamp)
+        assert rc == 0
+        G.sync()
+        res[label] = (G.hip.scan_get(), G.get_x(), G.get_P(), G.map_size())
+        G.close()
+    dev, hst = res["device"], res["host"]
+    assert dev[0].shape == hst[0].shape and dev[0].shape[0] > 8000
+    np.testing.assert_array_equal(dev[0], hst[0])
+    np.testing.assert_array_equal(dev[1], hst[1])
+    np.testing.assert_array_equal(dev[2], hst[2])
+    assert dev[3] == hst[3]
+
+
+@pytest.mark.gpu
 def test_separate_dispatch_pass_is_bit_reproducible(built):
     """A pass that runs in separate dispatches (the first registration of a context, a poor prior: thousands of queries on the
     worklist) is three launches since round 4 -- k-NN, widening, fit + reduction; the widening deals the worklist out dynamically
