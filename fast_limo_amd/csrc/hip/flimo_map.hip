@@ -25,6 +25,7 @@ __device__ __forceinline__ unsigned f2o(float f) {
   unsigned u = __float_as_uint(f);
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
+__device__ __forceinline__ float o2f(unsigned o) { return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o); }
 static inline float o2f_host(unsigned o) {
   unsigned u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
   float f;
@@ -879,14 +880,29 @@ __global__ __launch_bounds__(256) void bbox_finite_kernel(const float4* __restri
   }
 }
 
-__global__ __launch_bounds__(256) void voxelkey_kernel(const float4* __restrict__ pts, size_t n, float inv, int mb0, int mb1,
-                                                       int mb2, int mul1, int mul2, uint32_t* __restrict__ keys,
-                                                       uint32_t* __restrict__ vals) {
+// The lattice comes from the box the reduction before this launch left in device memory (ordered-uint words: no host round trip
+// for it): min_b = floor(min * inv), div_b = floor(max * inv) - min_b + 1, the host's expressions.  flags[0] = 1: no finite point;
+// flags[1] = 1: the lattice would overflow an int (PCL then returns its input) -- keys are not valid then, the host looks at the
+// flags when it reads the count.
+__global__ __launch_bounds__(256) void voxelkey_kernel(const float4* __restrict__ pts, size_t n, float inv, const unsigned* __restrict__ box,
+                                                       uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ flags) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned b0 = box[0];
+  int mb0 = 0, mb1 = 0, mb2 = 0, mul1 = 1, mul2 = 1;
+  bool bad = b0 == 0xffffffffu;
+  if (!bad) {
+    mb0 = (int)floorf(o2f(box[0]) * inv); mb1 = (int)floorf(o2f(box[1]) * inv); mb2 = (int)floorf(o2f(box[2]) * inv);
+    const int d0 = (int)floorf(o2f(box[3]) * inv) - mb0 + 1, d1 = (int)floorf(o2f(box[4]) * inv) - mb1 + 1, d2 = (int)floorf(o2f(box[5]) * inv) - mb2 + 1;
+    const long long cells = (long long)d0 * d1 * d2;
+    if (cells > 2147483647ll) { bad = true; if (i == 0) flags[1] = 1u; }
+    mul1 = d0; mul2 = d0 * d1;
+  } else if (i == 0) {
+    flags[0] = 1u;
+  }
   if (i >= n) return;
   const float4 p = pts[i];
   uint32_t k = 0xffffffffu;                                 // non-finite points sort to the end and are skipped
-  if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
+  if (!bad && isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
     const int i0 = (int)(floorf(p.x * inv) - (float)mb0);
     const int i1 = (int)(floorf(p.y * inv) - (float)mb1);
     const int i2 = (int)(floorf(p.z * inv) - (float)mb2);
@@ -911,10 +927,22 @@ __global__ __launch_bounds__(256) void voxelcentroid_kernel(const float4* __rest
   const uint32_t k = keys[i];
   float sx = 0.f, sy = 0.f, sz = 0.f;
   uint32_t cnt = 0;
-  for (size_t j = i; j < n && keys[j] == k; j++) {          // stable sort: ascending original index
-    const float4 p = pts[perm[j]];
-    sx += p.x; sy += p.y; sz += p.z;
-    cnt++;
+  // stable sort: ascending original index.  Eight keys / positions / points per round trip (a voxel of the reference's shipped
+  // configuration holds about sixteen); the sums keep their order
+  for (size_t j = i; j < n; j += 8) {
+    uint32_t kk[8], pp[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) { const size_t q = j + u < n ? j + u : n - 1; kk[u] = j + u < n ? keys[q] : ~k; pp[u] = perm[q]; }
+    float4 pt[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) pt[u] = pts[pp[u]];
+    bool more = true;
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      more = more && kk[u] == k;
+      if (more) { sx += pt[u].x; sy += pt[u].y; sz += pt[u].z; cnt++; }
+    }
+    if (!more) break;
   }
   const float nf = (float)cnt;
   out[pos[i]] = make_float4(sx / nf, sy / nf, sz / nf, 1.0f);
@@ -946,19 +974,12 @@ hipError_t voxel_grid(hipStream_t st, const float4* in, size_t n, float leaf, fl
   if (e != hipSuccess) return e;
   const int blocks = (int)((n + 255) / 256);
   hipLaunchKernelGGL(bbox_finite_kernel, dim3(std::max(1, std::min(blocks / 4, 128))), dim3(256), 0, st, in, n, (unsigned*)S.bbox);
-  unsigned ob[6];
-  if ((e = fetch_bbox(st, S, ob)) != hipSuccess) return e;
-  if (ob[0] == 0xffffffffu) return hipSuccess;               // no finite point
   const float inv = 1.0f / leaf;
-  int mb[3], db[3];
-  for (int a = 0; a < 3; a++) {
-    mb[a] = (int)floorf(o2f_host(ob[a]) * inv);
-    db[a] = (int)floorf(o2f_host(ob[3 + a]) * inv) - mb[a] + 1;
-  }
-  const long long cells = (long long)db[0] * db[1] * db[2];
-  if (cells > 2147483647ll) { *passthrough = true; return hipSuccess; }
-  hipLaunchKernelGGL(voxelkey_kernel, dim3(blocks), dim3(256), 0, st, in, n, inv, mb[0], mb[1], mb[2], db[0], db[0] * db[1],
-                     S.keys_in, S.vals_in);
+  // (the box stays on the device: the key kernel derives the lattice from it; two flag words ride home with the count)
+  uint32_t* flags = S.mail_dev + MAIL_VOXEL + 2;
+  S.mail_host[MAIL_VOXEL + 2] = S.mail_host[MAIL_VOXEL + 3] = 0u;      // (mapped memory; nothing in flight writes these words)
+  __atomic_thread_fence(__ATOMIC_RELEASE);
+  hipLaunchKernelGGL(voxelkey_kernel, dim3(blocks), dim3(256), 0, st, in, n, inv, (const unsigned*)S.bbox, S.keys_in, S.vals_in, flags);
   size_t tmp_bytes = 0;
   e = sort_pairs_u32(nullptr, tmp_bytes, S.keys_in, S.keys_out, S.vals_in, S.vals_out, (int)n, 0, 32, st);
   if (e != hipSuccess) return e;
@@ -979,8 +1000,14 @@ hipError_t voxel_grid(hipStream_t st, const float4* in, size_t n, float leaf, fl
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(voxelcentroid_kernel, dim3(blocks), dim3(256), 0, st, in, S.keys_out, S.vals_out, S.keys_in, S.vals_in, n, out);
   const MailPart parts[2] = {{S.vals_in + (n - 1), 1, MAIL_VOXEL}, {S.keys_in + (n - 1), 1, MAIL_VOXEL + 1}};
-  if ((e = mail_words(st, S, parts, 2)) != hipSuccess) return e;
-  if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+  if ((e = mail_words(st, S, parts, 2, true)) != hipSuccess) return e;              // (+ the box re-armed for the next reduction)
+  if ((e = hipStreamSynchronize(st)) != hipSuccess) {
+    const unsigned init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+    (void)hipMemcpy(S.bbox, init, sizeof(init), hipMemcpyHostToDevice);
+    return e;
+  }
+  if (S.mail_host[MAIL_VOXEL + 2]) return hipSuccess;        // no finite point
+  if (S.mail_host[MAIL_VOXEL + 3]) { *passthrough = true; return hipSuccess; }
   *n_out = (size_t)S.mail_host[MAIL_VOXEL] + S.mail_host[MAIL_VOXEL + 1];
   return hipGetLastError();
 }
