@@ -848,6 +848,10 @@ void Esekf::update_iterated_dyn_share_modified(double R, double D) {
     // manifold Jacobians) runs while the pass is in flight on the GPU when the plug-in offers that; the values are the same.
     double dx[kDof];
     bool pre_done = false;
+    // what the default gain needs of A = P_ / R (measurement-independent: formed in pre(), beside the pass): PR = A[:, 0:12],
+    // Ai = A11^-1, G2 = A21 A11^-1
+    double PR[kDof][12], G2[kDof - 12][12];
+    Mat<12, 12> Ai, Nm;
     auto pre = [&]() {
     pre_done = true;
     x_.boxminus(dx, x_prop);                                   // :1652
@@ -873,6 +877,15 @@ void Esekf::update_iterated_dyn_share_modified(double R, double D) {
       for (int r = 0; r < 2; r++) dx_new[idx + r] = tv[r];
       left_block<2, kDof>(P_, idx, J, n);
       right_block_T<2, kDof>(P_, idx, J);
+    }
+    if (!reference_solve) {
+      for (int i = 0; i < n; i++)
+        for (int k = 0; k < 12; k++) PR[i][k] = P_(i, k) / R;
+      Mat<12, 12> A11;
+      for (int i = 0; i < 12; i++) for (int j = 0; j < 12; j++) A11(i, j) = PR[i][j];
+      if (!inverse_gj(12, &A11.a[0][0], &Ai.a[0][0])) inverse<12>(A11, Ai);
+      for (int i = 0; i < n - 12; i++)
+        for (int j = 0; j < 12; j++) { double a = 0; for (int k = 0; k < 12; k++) a += PR[12 + i][k] * Ai(k, j); G2[i][j] = a; }
     }
     };
     if (inject) inject = false;                                 // (the device's pass at this very state)
@@ -922,15 +935,7 @@ void Esekf::update_iterated_dyn_share_modified(double R, double D) {
         // (tests/test_host_logic.py: ..._against_80_bit_arithmetic).  A11^-1 and G2 = A21 A11^-1 do not depend on the measurement:
         // the device filter forms them beside the pass (csrc/hip/flimo_ieskf.h: ik_pre_block); N z = v is the only solve between the
         // pass's sums and the step.  Same operations in the same order on both sides.
-        double PR[kDof][12];
-        for (int i = 0; i < n; i++)
-          for (int k = 0; k < 12; k++) PR[i][k] = P_(i, k) / R;
-        Mat<12, 12> A11, Ai, Nm, Ninv;
-        for (int i = 0; i < 12; i++) for (int j = 0; j < 12; j++) A11(i, j) = PR[i][j];
-        if (!inverse_gj(12, &A11.a[0][0], &Ai.a[0][0])) inverse<12>(A11, Ai);
-        double G2[kDof - 12][12];
-        for (int i = 0; i < n - 12; i++)
-          for (int j = 0; j < 12; j++) { double a = 0; for (int k = 0; k < 12; k++) a += PR[12 + i][k] * Ai(k, j); G2[i][j] = a; }
+        // (PR, Ai, G2: pre(), while the pass was in flight)
         for (int i = 0; i < 12; i++) for (int j = 0; j < 12; j++) Nm(i, j) = Ai(i, j) + HTH(i, j);
         // The step of :1733, dx_ = K_h + (K_x - I) dx_new with K_h = W H^T h, K_x = W H^T H (W = P_inv E), taken as
         //   v = H^T h + H^T H dx_new[0:12];  N z = v;  dx_ = [z; G2 z] - dx_new
@@ -938,23 +943,14 @@ void Esekf::update_iterated_dyn_share_modified(double R, double D) {
         lemma_step = true;
         double v[12], z[12];
         for (int i = 0; i < 12; i++) { double a = 0; for (int k = 0; k < 12; k++) a += HTH(i, k) * dx_new[k]; v[i] = HTh[i] + a; }
-        const bool have_inv = inverse_gj(12, &Nm.a[0][0], &Ninv.a[0][0]) || inverse<12>(Nm, Ninv);
-        (void)have_inv;
-        if (!solve_gj(12, &Nm.a[0][0], v, z))
+        if (!solve_gj(12, &Nm.a[0][0], v, z)) {
+          Mat<12, 12> Ninv;
+          (void)(inverse_gj(12, &Nm.a[0][0], &Ninv.a[0][0]) || inverse<12>(Nm, Ninv));
           for (int m = 0; m < 12; m++) { double a = 0; for (int k = 0; k < 12; k++) a += Ninv(m, k) * v[k]; z[m] = a; }
+        }
         for (int i = 0; i < 12; i++) dx_lemma[i] = z[i] - dx_new[i];
         for (int i = 12; i < n; i++) { double a = 0; for (int m = 0; m < 12; m++) a += G2[i - 12][m] * z[m]; dx_lemma[i] = a - dx_new[i]; }
-        // K_x = P_inv E B = [Ninv; G2 Ninv] B  (the covariance update of the last iteration, :1766-1820)
-        double W[kDof][12];
-        for (int i = 0; i < 12; i++) for (int j = 0; j < 12; j++) W[i][j] = Ninv(i, j);
-        for (int i = 12; i < n; i++)
-          for (int j = 0; j < 12; j++) { double a = 0; for (int k = 0; k < 12; k++) a += G2[i - 12][k] * Ninv(k, j); W[i][j] = a; }
-        K_x = Cov::zero();
-        for (int i = 0; i < n; i++) {
-          double acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-          for (int k = 0; k < 12; k++) { const double wk = W[i][k]; for (int j = 0; j < 12; j++) acc[j] += wk * HTH(k, j); }
-          for (int j = 0; j < 12; j++) K_x(i, j) = acc[j];
-        }
+        // (K_x is only read by the covariance update of the iteration that ends the loop: formed there)
       }
     }
 
@@ -1017,6 +1013,21 @@ void Esekf::update_iterated_dyn_share_modified(double R, double D) {
     }
 
     if (t > 1 || it == maximum_iter_ - 1) {                    // :1764-1820
+      if (lemma_step) {
+        // K_x = P_inv E B = [Ninv; G2 Ninv] B
+        Mat<12, 12> Ninv;
+        (void)(inverse_gj(12, &Nm.a[0][0], &Ninv.a[0][0]) || inverse<12>(Nm, Ninv));
+        double W[kDof][12];
+        for (int i = 0; i < 12; i++) for (int j = 0; j < 12; j++) W[i][j] = Ninv(i, j);
+        for (int i = 12; i < n; i++)
+          for (int j = 0; j < 12; j++) { double a = 0; for (int k = 0; k < 12; k++) a += G2[i - 12][k] * Ninv(k, j); W[i][j] = a; }
+        K_x = Cov::zero();
+        for (int i = 0; i < n; i++) {
+          double acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+          for (int k = 0; k < 12; k++) { const double wk = W[i][k]; for (int j = 0; j < 12; j++) acc[j] += wk * HTH(k, j); }
+          for (int j = 0; j < 12; j++) K_x(i, j) = acc[j];
+        }
+      }
       Cov L = P_;
       for (int s = 0; s < 2; s++) {
         const int idx = so3_idx[s];
