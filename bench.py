@@ -290,6 +290,16 @@ def hbm_regime_leg(device, steps, with_oracle, max_threads=32):
             ks["knn_kernel_traffic_over_algorithmic"] = traffic_knn / alg
             ks["knn_kernel_hbm_utilisation_measured"] = traffic_knn / (ks["knn_us"] * 1e-6) / 1e9 / HBM_PEAK_GBPS
         out["unit"], out["peak"], out["bound"] = "GB/s", HBM_PEAK_GBPS, "hbm"
+    # the path exit at this size (transform + Mapper::add of the registered 256k-point scan into the 20M-point map): the first insert
+    # stores the scan's new points, a repeat of the same scan is mostly rejected by the reference's down-sampling rule
+    ins = []
+    n0 = loc.map_size()
+    for k in range(3):
+        t1 = time.perf_counter()
+        loc.hip.map_add_scan(loc.get_x(), 0.2 + 0.1 * k)
+        ins.append(time.perf_counter() - t1)
+    out["map_insert_ms"] = {"first": 1e3 * ins[0], "repeat": 1e3 * float(np.median(ins[1:])), "points_stored": loc.map_size() - n0,
+                            "note": "flimo_map_add_scan of the resident scan, waited for; index merged incrementally"}
     loc.close()
     return out
 

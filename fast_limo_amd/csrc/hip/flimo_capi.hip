@@ -351,7 +351,6 @@ extern "C" int flimo_ctx_create(int device, flimo_ctx** out) {
   flimo_ctx* c = new flimo_ctx();
   c->device = device;
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return FLIMO_ERR_HIP; }
-  if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { (void)hipStreamDestroy(c->stream); c->stream = nullptr; delete c; return FLIMO_ERR_HIP; }
   for (int i = 0; i < 6; i++) (void)hipEventCreate(&c->ev[i]);
   bool ok = hipMalloc(&c->d_partials, (size_t)c->reduce_waves * 256 * sizeof(double)) == hipSuccess &&
             hipMalloc(&c->d_out256, FIT_GROUPS * FIT_SLOT * sizeof(double)) == hipSuccess &&
@@ -1505,14 +1504,14 @@ static int abandon_wait(flimo_ctx* c, const char* what, unsigned long long id) {
   if (!c->timeout_ev) (void)hipEventCreateWithFlags(&c->timeout_ev, hipEventDisableTiming);
   if (c->timeout_ev && hipEventRecord(c->timeout_ev, c->stream) == hipSuccess) c->timeout_pending = true;
   if (!c->timeout_ev2) (void)hipEventCreateWithFlags(&c->timeout_ev2, hipEventDisableTiming);
-  if (c->timeout_ev2) (void)hipEventRecord(c->timeout_ev2, c->stream2);          // (a resident algebra workgroup may still be waiting)
+  if (c->timeout_ev2 && c->stream2) (void)hipEventRecord(c->timeout_ev2, c->stream2);          // (a resident algebra workgroup may still be waiting)
   c->prev.valid = 0;
   return fail(c, FLIMO_ERR_TIMEOUT, "%s %llu did not publish its result within %d ms (kernels still running)", what, id, c->wait_timeout_ms);
 }
 static int check_abandoned(flimo_ctx* c) {
   if (!c->timeout_pending) return FLIMO_OK;
   hipError_t q = hipEventQuery(c->timeout_ev);
-  if (q == hipSuccess && c->timeout_ev2) q = hipEventQuery(c->timeout_ev2);
+  if (q == hipSuccess && c->timeout_ev2 && c->stream2) q = hipEventQuery(c->timeout_ev2);
   if (q == hipErrorNotReady) return fail(c, FLIMO_ERR_TIMEOUT, "the launches of an earlier pass whose wait ran out are still running");
   c->timeout_pending = false;
   if (q != hipSuccess) return fail(c, FLIMO_ERR_HIP, "an abandoned pass failed: %s", hipGetErrorString(q));
@@ -2005,6 +2004,7 @@ extern "C" int flimo_update_chain(flimo_ctx* c, const flimo_match_cfg* cfg, flim
   const bool resident = c->chain_resident && !c->chain_inline;
   ctl.resident = resident ? 1 : 0;
   ctl.end_code = 0x80000000u | (unsigned int)(tag & 0x7fffffffull);
+  if (resident && !c->stream2) HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));   // (made on first use: a process has few hardware queues)
   if (resident) {
     // the algebra's workgroup first: it holds its place on the GPU while the passes run (ticket3 is zero: the last chain's hand-back
     // re-armed it before it published its result)
@@ -2135,7 +2135,7 @@ extern "C" int flimo_update_chain(flimo_ctx* c, const flimo_match_cfg* cfg, flim
   if (io->reason == CH_R_FAILED) {
     c->prev.valid = 0;
     (void)hipStreamSynchronize(c->stream);
-    (void)hipStreamSynchronize(c->stream2);
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     (void)hipMemsetAsync(c->d_ticket, 0, (FIT_GROUPS + 2) * sizeof(unsigned int), c->stream);
     (void)hipStreamSynchronize(c->stream);
     return fail(c, FLIMO_ERR_HIP, "a pass of the update chain did not publish its sums");

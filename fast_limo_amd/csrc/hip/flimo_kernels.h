@@ -80,7 +80,6 @@ void launch_knn_tie(hipStream_t st, const GridView& G, const BookView& B, const 
 size_t nbrk_rec_size();
 bool launch_match_k(hipStream_t st, int k, const GridView& G, const float4* scan_sorted, int n, const PoseMats& P,
                     const MatchParams& mp, void* nbrk, Rec16* recs, RecDbg* dbg, const BookView* book = nullptr);   // book: ties the reference's way
-void launch_reduce_final(hipStream_t st, const double* partials, int nparts, double* out256);
 size_t nbr_rec_size();
 size_t wl_entry_size();   // bytes per worklist entry (query index, world position, 5th-distance hint)
 void launch_knn(hipStream_t st, const GridView& G, const float* qxyz, int nq, int k, int max_ring, int32_t* idx,

@@ -2663,10 +2663,6 @@ void launch_match_fused(hipStream_t st, const GridView& G, const float4* scan_so
   launch_knn5_L<2>(st, G, scan_sorted, n, P, mp.max_ring, nbr, wl, wl_count, cand, prev, 1, e0, e1, &fa, nullptr, 0, 0ull, nullptr, chain, wait_epoch, fa.ch.end_code);
 }
 
-void launch_reduce_final(hipStream_t st, const double* partials, int nparts, double* out256) {
-  hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(1024), 0, st, partials, nparts, out256);
-}
-
 size_t nbr_rec_size() { return sizeof(NbrRec); }
 size_t wl_entry_size() { return 2 * sizeof(int4); }
 
