@@ -1260,8 +1260,7 @@ extern "C" int flimo_raw_scan_filter_order_set(flimo_ctx* c, const void* points3
   const bool keep_order = (time_order & 2) != 0;      // bit 1: no spatial order (a voxel filter follows and re-orders the scan)
   time_order &= 1;
   HIPCHK(c, filter_raw_scan(c->stream, c->d_raw32, n, F, c->d_scan_raw, c->d_scan_t, c->d_filt_ext, c->scratch, time_order ? c->d_tkey[0] : nullptr, (int)rec));
-  HIPCHK(c, hipMemcpyAsync(c->h_filt_ext, c->d_filt_ext, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, filter_raw_scan_result(c->stream, c->scratch, c->d_filt_ext, c->wait_timeout_ms, c->h_filt_ext));
   const size_t m = (size_t)c->h_filt_ext[1];
   *n_kept = m;
   *nan_stamp = c->h_filt_ext[2] ? 1 : 0;
@@ -1292,9 +1291,9 @@ extern "C" int flimo_raw_scan_filter_order_set(flimo_ctx* c, const void* points3
     // the kept points into the reference's time order (d_scan_world / d_t_tmp are free at this point of the scan's life)
     HIPCHK(c, time_order_raw(c->stream, c->d_scan_raw, c->d_scan_t, m, c->d_tkey[0], c->d_tkey[1], c->d_scan_world, c->d_t_tmp, c->d_tperm,
                              c->d_filt_ext, c->scratch));
-    HIPCHK(c, hipMemcpyAsync(c->h_filt_ext + 3, c->d_filt_ext + 3, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->h_filt_ext[3]) { *tied = 1; return FLIMO_OK; }      // equal stamps: only the host routine reproduces the library's order among them
+    bool is_tied = false;
+    HIPCHK(c, time_order_raw_tied(c->stream, c->scratch, c->d_filt_ext, c->wait_timeout_ms, &is_tied));
+    if (is_tied) { *tied = 1; return FLIMO_OK; }      // equal stamps: only the host routine reproduces the library's order among them
     std::swap(c->d_scan_raw, c->d_scan_world);
     std::swap(c->d_scan_t, c->d_t_tmp);
     c->raw_time_ordered = true;

@@ -115,6 +115,8 @@ struct MapBuildScratch {
   unsigned long long* filt_desc = nullptr;
   size_t filt_tiles_cap = 0;
   unsigned int filt_epoch = 0, filt_ticket_base = 0;
+  unsigned long long* filt_mail_host = nullptr;   // mapped: four {value, launch number} granules (extreme key, kept count, NaN mark; tied stamps)
+  unsigned long long* filt_mail_dev = nullptr;
 };
 // slots of the mail words
 enum MailSlot { MAIL_BOOK = 0 /* 6 */, MAIL_BOOK_END = 8 /* 2 */, MAIL_CROWD = 12, MAIL_BOXCOUNT = 13, MAIL_BBOX = 16 /* 6 */, MAIL_VOXEL = 24 /* 2 */,
@@ -150,6 +152,9 @@ hipError_t map_merge_grid(hipStream_t st, const float4* old_sorted, size_t n_old
 hipError_t filter_raw_scan(hipStream_t st, const void* raw32_dev, size_t n, const FilterParams& F, float4* out, double* t_out,
                            unsigned long long* ext_dev, MapBuildScratch& S, unsigned long long* key_out = nullptr, int rec_bytes = 32);
 // (rec_bytes 16: records {x, y, z, 32-bit time word} instead of the reference's 32-byte PointType -- time kinds 0 and 1)
+// (the three host-side results of the last filter_raw_scan -- extreme key, kept count, NaN mark -- without a copy and a stream wait)
+hipError_t filter_raw_scan_result(hipStream_t st, MapBuildScratch& S, const unsigned long long* ext_dev, int timeout_ms, unsigned long long ext3[3]);
+hipError_t time_order_raw_tied(hipStream_t st, MapBuildScratch& S, const unsigned long long* ext_dev, int timeout_ms, bool* tied);
 // The kept points in the reference's time order (unique when no two stamps are equal; ext_dev[3] = 1 reports equal stamps): stable
 // radix sort of the ordered stamp keys filter_raw_scan wrote, pts_out[i] = (xyz of pts[perm_out[i]], w = i), t_out likewise.
 hipError_t time_order_raw(hipStream_t st, const float4* pts, const double* t, size_t n, const unsigned long long* keys,

@@ -11,6 +11,8 @@
 //   4. gather    : points re-ordered into cell order (float4, w keeps the insertion index)
 //   5. cell_start: lower-bound of every cell id in the sorted keys
 #include <hip/hip_runtime.h>
+#include <chrono>
+#include <immintrin.h>
 #include "flimo_prims.h"
 #include <float.h>
 #include "flimo_types.h"
@@ -645,13 +647,16 @@ __global__ __launch_bounds__(256) void filt_onepass_kernel(const void* __restric
                                                            unsigned int ticket_base, unsigned long long* __restrict__ desc_alive,
                                                            unsigned long long* __restrict__ desc_kept, unsigned int epoch,
                                                            float4* __restrict__ out, double* __restrict__ t_out,
-                                                           unsigned long long* __restrict__ ext, unsigned long long* __restrict__ key_out) {
+                                                           unsigned long long* __restrict__ ext, unsigned long long* __restrict__ key_out,
+                                                           unsigned int* __restrict__ done, unsigned int done_base,
+                                                           unsigned long long* __restrict__ mail) {
   __shared__ unsigned int s_tile, s_sum[2], s_cnt[2][4];
   __shared__ unsigned long long s_max[4];
   __shared__ int s_nan[4];
   if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u) - ticket_base;
   __syncthreads();
   const int tile = (int)s_tile;
+  if (tile < 0 || tile >= (int)gridDim.x) return;             // (a ticket out of step with the host's count -- an earlier launch that never ran: no tile of this launch; the caller sees a count that was never written)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const unsigned long long lt = (1ull << lane) - 1ull;
   const size_t base = (size_t)tile * FILT_TILE + (size_t)wave * (64 * FILT_ROWS);
@@ -710,7 +715,8 @@ __global__ __launch_bounds__(256) void filt_onepass_kernel(const void* __restric
   if (threadIdx.x == 0)
     __hip_atomic_store(&desc_kept[tile], ((unsigned long long)epoch << 32) | (unsigned long long)tile_keep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   unsigned int pos0 = filt_lookback(desc_kept, tile, epoch, &s_sum[1]);
-  if ((size_t)(tile + 1) * FILT_TILE >= n && threadIdx.x == 0) ext[1] = (unsigned long long)(pos0 + tile_keep);      // the last tile: kept count
+  if ((size_t)(tile + 1) * FILT_TILE >= n && threadIdx.x == 0)                                                        // the last tile: kept count
+    __hip_atomic_store(&ext[1], (unsigned long long)(pos0 + tile_keep), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   for (int w = 0; w < wave; w++) pos0 += s_cnt[1][w];
   // ---- compaction: position, stamp, ordered key ----
   unsigned long long mine = 0ull;                              // extreme ordered key of this lane's points (0: none)
@@ -763,6 +769,21 @@ __global__ __launch_bounds__(256) void filt_onepass_kernel(const void* __restric
     for (int w = 1; w < 4; w++) bm = s_max[w] > bm ? s_max[w] : bm;
     if (bm) atomicMax(&ext[0], bm);
     if (s_nan[0] | s_nan[1] | s_nan[2] | s_nan[3]) atomicOr(&ext[2], 1ull);
+    // The tile that finishes LAST hands the three results to the host: 16-byte {value, launch number} granules in mapped memory
+    // (data and "ready" in one store -- the host spins on the tags instead of paying a copy and a stream wait).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this tile's contributions are performed
+    const unsigned int arrived = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - done_base;
+    if (arrived == gridDim.x - 1u) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        typedef unsigned long long v2u_t __attribute__((ext_vector_type(2)));
+        v2u_t g;
+        g.x = __hip_atomic_load(&ext[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        g.y = (unsigned long long)epoch;
+        unsigned long long* o = mail + 2 * k;
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(o), "v"(g) : "memory");
+      }
+    }
   }
 }
 
@@ -782,20 +803,49 @@ hipError_t filter_raw_scan(hipStream_t st, const void* raw32_dev, size_t n, cons
     S.filt_epoch = 0;
     S.filt_ticket_base = 0;
   }
+  if (!S.filt_mail_host) {
+    if ((e = hipHostMalloc((void**)&S.filt_mail_host, 8 * sizeof(unsigned long long), hipHostMallocMapped)) != hipSuccess) return e;
+    memset(S.filt_mail_host, 0, 8 * sizeof(unsigned long long));
+    if ((e = hipHostGetDevicePointer((void**)&S.filt_mail_dev, S.filt_mail_host, 0)) != hipSuccess) return e;
+  }
   if ((e = hipMemsetAsync(ext_dev, 0, 4 * sizeof(unsigned long long), st)) != hipSuccess) return e;
   unsigned long long* desc_alive = S.filt_desc;
   unsigned long long* desc_kept = S.filt_desc + S.filt_tiles_cap;
   unsigned int* ticket = reinterpret_cast<unsigned int*>(S.filt_desc + 2 * S.filt_tiles_cap);
+  unsigned int* done = ticket + 1;                              // (the same 8-byte word: tiles started / tiles finished, both counted up for ever)
   S.filt_epoch++;
   if (S.filt_epoch == 0u) S.filt_epoch = 1u;                   // (after 2^32 launches the words are 2^32 launches stale: never equal)
   if (rec_bytes == 16)
     hipLaunchKernelGGL(filt_onepass_kernel<16>, dim3((unsigned)tiles), dim3(256), 0, st, raw32_dev, n, F, ticket,
-                       S.filt_ticket_base, desc_alive, desc_kept, S.filt_epoch, out, t_out, ext_dev, key_out);
+                       S.filt_ticket_base, desc_alive, desc_kept, S.filt_epoch, out, t_out, ext_dev, key_out, done, S.filt_ticket_base, S.filt_mail_dev);
   else
     hipLaunchKernelGGL(filt_onepass_kernel<32>, dim3((unsigned)tiles), dim3(256), 0, st, raw32_dev, n, F, ticket,
-                       S.filt_ticket_base, desc_alive, desc_kept, S.filt_epoch, out, t_out, ext_dev, key_out);
+                       S.filt_ticket_base, desc_alive, desc_kept, S.filt_epoch, out, t_out, ext_dev, key_out, done, S.filt_ticket_base, S.filt_mail_dev);
   S.filt_ticket_base += (unsigned int)tiles;                   // (wraps with the counter)
-  return hipGetLastError();
+  e = hipGetLastError();
+  if (e != hipSuccess) S.filt_tiles_cap = 0;                   // the launch did not happen: ticket and count are out of step -- start over next time
+  return e;
+}
+
+// The three results of the last filter_raw_scan on the host: spins on the granules' tags (the kernel's last tile stores them to
+// mapped memory); a wait that runs out falls back to a copy behind the stream.  ext3: extreme key, kept count, NaN mark.
+hipError_t filter_raw_scan_result(hipStream_t st, MapBuildScratch& S, const unsigned long long* ext_dev, int timeout_ms, unsigned long long ext3[3]) {
+  const volatile unsigned long long* m = S.filt_mail_host;
+  const unsigned long long tag = (unsigned long long)S.filt_epoch;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned long long spins = 0;; spins++) {
+    if (m[1] == tag && m[3] == tag && m[5] == tag) {
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+      ext3[0] = m[0]; ext3[1] = m[2]; ext3[2] = m[4];
+      return hipSuccess;
+    }
+    _mm_pause();
+    if ((spins & 0xfffull) == 0xfffull &&
+        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > (double)(timeout_ms > 0 ? timeout_ms : 2000)) break;
+  }
+  hipError_t e = hipStreamSynchronize(st);
+  if (e != hipSuccess) return e;
+  return hipMemcpy(ext3, ext_dev, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
 }
 
 // ---- the reference's time order of a sweep on the device (Localizer.cpp:789-790: std::partial_sort_copy of the whole cloud by
@@ -813,8 +863,18 @@ __global__ __launch_bounds__(256) void tied_keys_kernel(const unsigned long long
 }
 __global__ __launch_bounds__(256) void gather_time_order_kernel(const float4* __restrict__ in, const double* __restrict__ t_in,
                                                                 const uint32_t* __restrict__ perm, size_t n, float4* __restrict__ out,
-                                                                double* __restrict__ t_out) {
+                                                                double* __restrict__ t_out, const unsigned long long* __restrict__ ext,
+                                                                unsigned long long* __restrict__ mail, unsigned long long tag) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) {
+    // "two kept stamps are equal" (tied_keys_kernel, the launch before this one) goes to the host as a {value, tag} granule
+    typedef unsigned long long v2u_t __attribute__((ext_vector_type(2)));
+    v2u_t g;
+    g.x = ext[3];
+    g.y = tag;
+    unsigned long long* o = mail + 6;
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(o), "v"(g) : "memory");
+  }
   if (i >= n) return;
   const uint32_t j = perm[i];
   const float4 p = in[j];
@@ -841,8 +901,28 @@ hipError_t time_order_raw(hipStream_t st, const float4* pts, const double* t, si
   e = sort_pairs_u64(S.cub_tmp, tmp_bytes, keys, keys_sorted, S.vals_in, perm_out, n, st);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(tied_keys_kernel, dim3(blocks), dim3(256), 0, st, keys_sorted, n, ext_dev);
-  hipLaunchKernelGGL(gather_time_order_kernel, dim3(blocks), dim3(256), 0, st, pts, t, perm_out, n, pts_out, t_out);
+  hipLaunchKernelGGL(gather_time_order_kernel, dim3(blocks), dim3(256), 0, st, pts, t, perm_out, n, pts_out, t_out, ext_dev, S.filt_mail_dev,
+                     (unsigned long long)S.filt_epoch);
   return hipGetLastError();
+}
+
+// "two kept stamps are equal" of the last time_order_raw (same way home as filter_raw_scan_result)
+hipError_t time_order_raw_tied(hipStream_t st, MapBuildScratch& S, const unsigned long long* ext_dev, int timeout_ms, bool* tied) {
+  const volatile unsigned long long* m = S.filt_mail_host;
+  const unsigned long long tag = (unsigned long long)S.filt_epoch;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned long long spins = 0;; spins++) {
+    if (m[7] == tag) { __atomic_thread_fence(__ATOMIC_ACQUIRE); *tied = m[6] != 0ull; return hipSuccess; }
+    _mm_pause();
+    if ((spins & 0xfffull) == 0xfffull &&
+        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > (double)(timeout_ms > 0 ? timeout_ms : 2000)) break;
+  }
+  hipError_t e = hipStreamSynchronize(st);
+  if (e != hipSuccess) return e;
+  unsigned long long v = 0;
+  e = hipMemcpy(&v, ext_dev + 3, sizeof(v), hipMemcpyDeviceToHost);
+  *tied = v != 0ull;
+  return e;
 }
 
 // ---- voxel-grid down-sampling of the scan (pcl::VoxelGrid, reference Localizer.cpp:313-321) -----
@@ -1017,6 +1097,7 @@ void map_scratch_free(MapBuildScratch& S) {
   if (S.keys_in) { hipFree(S.keys_in); hipFree(S.keys_out); hipFree(S.vals_in); hipFree(S.vals_out); }
   if (S.bbox) hipFree(S.bbox);
   if (S.filt_desc) hipFree(S.filt_desc);
+  if (S.filt_mail_host) hipHostFree(S.filt_mail_host);
   if (S.mail_host) hipHostFree(S.mail_host);
   S = MapBuildScratch();
 }
