@@ -723,7 +723,7 @@ hipError_t GBook::update(hipStream_t st, const float4* batch, int m, const float
     const MailPart parts[3] = {{counters, 4, MAIL_BOOK}, {rank + (m - 1), 1, MAIL_BOOK + 4}, {S.keys_in + (m - 1), 1, MAIL_BOOK + 5}};
     GBCHK(mail_words(st, S, parts, 3));
   }
-  GBCHK(hipStreamSynchronize(st));
+  GBCHK(mail_wait(st, S));
   int h_cnt[4];
   for (int k = 0; k < 4; k++) h_cnt[k] = (int)S.mail_host[MAIL_BOOK + k];
   const uint32_t last_rank = S.mail_host[MAIL_BOOK + 4], last_flag = S.mail_host[MAIL_BOOK + 5];

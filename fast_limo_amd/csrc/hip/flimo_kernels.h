@@ -111,6 +111,7 @@ struct MapBuildScratch {
   // stream.  Replaces the 4-byte device-to-host copies (each a staged, blocking copy) of counts and boxes.
   uint32_t* mail_host = nullptr;
   uint32_t* mail_dev = nullptr;
+  uint32_t mail_seq = 0;
   // the one-launch input filter (filter_raw_scan): per tile {count, launch number} of two sums, then the tile ticket
   unsigned long long* filt_desc = nullptr;
   size_t filt_tiles_cap = 0;
@@ -120,13 +121,14 @@ struct MapBuildScratch {
 };
 // slots of the mail words
 enum MailSlot { MAIL_BOOK = 0 /* 6 */, MAIL_BOOK_END = 8 /* 2 */, MAIL_CROWD = 12, MAIL_BOXCOUNT = 13, MAIL_BBOX = 16 /* 6 */, MAIL_VOXEL = 24 /* 2 */,
-                MAIL_WORDS = 64 };
+                MAIL_TAG = 62 /* number of the last mail_words, written behind its words */, MAIL_WORDS = 64 };
 struct MailPart { const void* src; int n; int dst; };
 // queues ONE small kernel that copies up to 6 runs of words into the mail slots; `rearm_bbox`: S.bbox is reset to the empty box
 // after it has been copied; `zero` / `zero_n`: words set to 0 after the copy (counters for the next round).  No synchronisation.
 hipError_t mail_words(hipStream_t st, MapBuildScratch& S, const MailPart* parts, int nparts, bool rearm_bbox = false, void* zero = nullptr,
                       int zero_n = 0);
 hipError_t ensure_mail(MapBuildScratch& S);
+hipError_t mail_wait(hipStream_t st, MapBuildScratch& S);   // the words of the last mail_words are in S.mail_host (spins on their tag)
 
 // min/max of n float4 points (NaN-free) -> host bbox[6]
 hipError_t map_bbox(hipStream_t st, const float4* pts, size_t n, MapBuildScratch& S, float bbox_host[6]);

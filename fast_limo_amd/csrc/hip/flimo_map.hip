@@ -97,13 +97,16 @@ __global__ __launch_bounds__(256) void tails_kernel(const uint32_t* __restrict__
   if (i + 1 == n || keys[i + 1] != k) E[(size_t)k + 1] = (uint32_t)(i + 1);
 }
 
-struct MailArgs { const uint32_t* src[6]; int n[6]; int dst[6]; int parts; unsigned* rearm; uint32_t* zero; int zero_n; };
+struct MailArgs { const uint32_t* src[6]; int n[6]; int dst[6]; int parts; unsigned* rearm; uint32_t* zero; int zero_n; uint32_t tag; };
 __global__ __launch_bounds__(64) void mail_kernel(MailArgs a, uint32_t* __restrict__ mail) {
   for (int k = 0; k < a.parts; k++)
     if ((int)threadIdx.x < a.n[k]) mail[a.dst[k] + threadIdx.x] = a.src[k][threadIdx.x];
+  __threadfence_system();
   __syncthreads();                                   // (one wave: orders the copies before the resets below)
   if (a.rearm && threadIdx.x < 6) a.rearm[threadIdx.x] = threadIdx.x < 3 ? 0xffffffffu : 0u;
   if (a.zero && (int)threadIdx.x < a.zero_n) a.zero[threadIdx.x] = 0u;
+  // the words are on their way to host memory; the tag follows them (mail_wait spins on it: no stream wait for a few words)
+  if (threadIdx.x == 0) __hip_atomic_store(&mail[MAIL_TAG], a.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 hipError_t ensure_mail(MapBuildScratch& S) {
   hipError_t e;
@@ -127,14 +130,28 @@ hipError_t mail_words(hipStream_t st, MapBuildScratch& S, const MailPart* parts,
   for (int k = 0; k < nparts && k < 6; k++) { a.src[k] = (const uint32_t*)parts[k].src; a.n[k] = parts[k].n; a.dst[k] = parts[k].dst; }
   a.rearm = rearm_bbox ? (unsigned*)S.bbox : nullptr;
   a.zero = (uint32_t*)zero; a.zero_n = zero_n;
+  if (++S.mail_seq == 0u) S.mail_seq = 1u;
+  a.tag = S.mail_seq;
   hipLaunchKernelGGL(mail_kernel, dim3(1), dim3(64), 0, st, a, S.mail_dev);
   return hipGetLastError();
+}
+// Waits for the words of the last mail_words (every launch queued before it on the stream has completed by then): spins on the tag
+// in mapped memory; a wait that runs out (2 s) falls back to the stream.
+hipError_t mail_wait(hipStream_t st, MapBuildScratch& S) {
+  const volatile uint32_t* m = S.mail_host;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned long long spins = 0;; spins++) {
+    if (m[MAIL_TAG] == S.mail_seq) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return hipSuccess; }
+    _mm_pause();
+    if ((spins & 0xfffull) == 0xfffull && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) break;
+  }
+  return hipStreamSynchronize(st);
 }
 // the box the last bbox reduction left in S.bbox -> host (ordered-uint words), re-armed; ends synchronised
 static hipError_t fetch_bbox(hipStream_t st, MapBuildScratch& S, unsigned ob[6]) {
   const MailPart part{S.bbox, 6, MAIL_BBOX};
   hipError_t e = mail_words(st, S, &part, 1, true);
-  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e == hipSuccess) e = mail_wait(st, S);
   if (e != hipSuccess) {
     // the re-arming rode on the mail kernel that did not run: put the empty box back by hand, so the next reduction starts from it
     const unsigned init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
@@ -387,7 +404,7 @@ hipError_t crowded_list_all(hipStream_t st, const uint32_t* cell_start, int nx, 
                      cap, count_dev);
   const MailPart part{count_dev, 1, MAIL_CROWD};
   if ((e = mail_words(st, S, &part, 1)) != hipSuccess) return e;
-  if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+  if ((e = mail_wait(st, S)) != hipSuccess) return e;
   *count_host = S.mail_host[MAIL_CROWD];
   return hipSuccess;
 }
@@ -400,7 +417,7 @@ hipError_t crowded_list_points(hipStream_t st, const float4* pts, size_t k, cons
                        ny, nz, xs, threshold, bits, list, cap, count_dev);
   const MailPart part{count_dev, 1, MAIL_CROWD};
   if ((e = mail_words(st, S, &part, 1)) != hipSuccess) return e;
-  if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+  if ((e = mail_wait(st, S)) != hipSuccess) return e;
   *count_host = S.mail_host[MAIL_CROWD];
   return hipSuccess;
 }
@@ -1081,7 +1098,7 @@ hipError_t voxel_grid(hipStream_t st, const float4* in, size_t n, float leaf, fl
   hipLaunchKernelGGL(voxelcentroid_kernel, dim3(blocks), dim3(256), 0, st, in, S.keys_out, S.vals_out, S.keys_in, S.vals_in, n, out);
   const MailPart parts[2] = {{S.vals_in + (n - 1), 1, MAIL_VOXEL}, {S.keys_in + (n - 1), 1, MAIL_VOXEL + 1}};
   if ((e = mail_words(st, S, parts, 2, true)) != hipSuccess) return e;              // (+ the box re-armed for the next reduction)
-  if ((e = hipStreamSynchronize(st)) != hipSuccess) {
+  if ((e = mail_wait(st, S)) != hipSuccess) {
     const unsigned init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
     (void)hipMemcpy(S.bbox, init, sizeof(init), hipMemcpyHostToDevice);
     return e;
