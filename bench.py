@@ -590,6 +590,7 @@ def main():
     loc.hip.timing_totals(reset=True)
     loc.hip.timing_split(reset=True)
     loc.hip.chain_stats(reset=True)
+    pipe0 = loc.hip.pass_pipeline_stats()
     passes0 = loc.hip.pass_count()
     fused0 = loc.hip.fused_pass_count()
     loc.host_profile(reset=True)
@@ -610,6 +611,8 @@ def main():
     tot = loc.hip.timing_totals()
     split = loc.hip.timing_split()
     chain = loc.hip.chain_stats()
+    pipe1 = loc.hip.pass_pipeline_stats()
+    pipe_found, pipe_wasted = pipe1["published"] - pipe0["published"], pipe1["cancelled"] - pipe0["cancelled"]
     n_passes = loc.hip.pass_count() - passes0
     n_fused_passes = loc.hip.fused_pass_count() - fused0
     hp = loc.host_profile()
@@ -876,7 +879,8 @@ def main():
                        "passes_per_step": n_passes / max(args.steps, 1), "steps_bit_reproducible": repro_bitwise,
                        "update": ("chained: every iteration's launches queued at once, the filter's algebra on the device (flimo_update_chain)"
                                   if chain["chains"] else "host loop over single passes (this host's launch round trip is short, or FLIMO_HOST_UPDATE=1)"),
-                       "chains_run": chain["chains"], "chains_handed_back_early": chain["handed_back"], "chains_declined": chain["declined"]},
+                       "chains_run": chain["chains"], "chains_handed_back_early": chain["handed_back"], "chains_declined": chain["declined"],
+                       "host_loop_passes_found_waiting": pipe_found, "host_loop_passes_queued_for_nothing": pipe_wasted},
             "value_regions": value_regions,
             "update_layouts": modes,
             "kernel_us_per_step": kernel_us_per_step,

@@ -207,6 +207,26 @@ struct flimo_ctx {
   double* h_chain_log = nullptr;         // mapped: CH_MAX_PASSES x CH_LOGN log granules
   void* d_chain_log = nullptr;
   unsigned long long chain_tag = 0x4000000000000000ull;   // tag of the last chain (own number space)
+  // Host loop, pipelined (FLIMO_PIPELINE=0 switches it off): while a one-launch pass runs, the NEXT pass of the same update is already
+  // queued behind it -- a chained-pass kernel whose workgroups wait, placed on the GPU, for their constants in `d_pipe_head`
+  // (fine-grained device memory the host stores into through the PCIe BAR).  The next flimo_match_reduce then publishes the pose
+  // instead of launching: no doorbell -> dispatch -> kernel start on the iteration's critical path.  A pass nobody asks for (the
+  // update converged) is told to leave by the next call on the context (ctx_enter).
+  struct Prelaunch {
+    bool active = false;
+    unsigned long long seq = 0;      // the pass number it will publish under
+    size_t nq = 0;
+    int n_all = 0, pos = 0;
+    flimo_match_cfg cfg{};
+    uint64_t grid_version = 0;
+    unsigned int end_code = 0;
+    double t_launch = 0.0;
+  } pre;
+  bool pipeline = false;                 // flimo_set_pass_pipeline (FLIMO_PIPELINE=0/1 presets it and wins)
+  bool pipeline_env = false;
+  ChainHead* d_pipe_head = nullptr;      // fine-grained device memory (host-writable); nullptr: not available on this system
+  unsigned int pipe_tag = 0;
+  unsigned long long pipe_published = 0, pipe_cancelled = 0;   // statistics
   bool chain_resident = false;           // FLIMO_CHAIN_RESIDENT=1: ONE resident workgroup runs every iteration's algebra beside the chain's passes (flimo_chain.h)
   hipStream_t stream2 = nullptr;         // ... on this stream
   hipEvent_t timeout_ev2 = nullptr;
@@ -228,6 +248,7 @@ struct flimo_ctx {
   bool tail = true;                // FLIMO_TAIL=0: pending queries go to the worklist + widen_kernel dispatch instead of being finished inside the k-NN launch (A/B checks)
 };
 
+static inline void ctx_enter(flimo_ctx* c);       // hipSetDevice + a pass queued ahead of the filter's algebra is told to leave (see cancel_prelaunch)
 static int fail(flimo_ctx* c, int code, const char* fmt, ...) {
   char buf[512];
   va_list ap;
@@ -299,6 +320,8 @@ static int ensure_dev(flimo_ctx* c, T*& p, size_t& cap, size_t need, bool keep, 
 //   FLIMO_CHAIN_INLINE=1          chained update: the filter's measurement-dependent half inside the pass's reducing launch, run by the
 //                                 workgroup that completes it (default: a one-workgroup launch of its own behind each pass -- the same
 //                                 step time within 1 %, and the pass kernel's duration stays the pass's)
+//   FLIMO_PIPELINE=0              host loop: no pass is queued ahead of the filter's algebra (default: the next one-launch pass waits on the
+//                                 GPU for its pose, which the host stores into device memory)
 //   FLIMO_CHAIN_RESIDENT=1        chained update: one resident workgroup, launched beside the chain on a stream of its own, runs every
 //                                 iteration's algebra; the passes' workgroups wait for their constants in device memory (no dispatch
 //                                 boundary on either side of the algebra)
@@ -330,6 +353,7 @@ static void load_dev_switches(flimo_ctx* c) {
   if (env_int("FLIMO_HOST_UPDATE", v)) c->update_mode = v != 0 ? 1 : 2;
   { const char* e = getenv("FLIMO_RTT_THRESHOLD_US"); if (e && atof(e) > 0) c->rtt_threshold_us = atof(e); }
   if (env_int("FLIMO_CHAIN_INLINE", v)) c->chain_inline = v != 0;
+  if (env_int("FLIMO_PIPELINE", v)) { c->pipeline = v != 0; c->pipeline_env = true; }
   if (env_int("FLIMO_CHAIN_RESIDENT", v)) c->chain_resident = v != 0;
 }
 
@@ -407,6 +431,19 @@ extern "C" int flimo_ctx_create(int device, flimo_ctx** out) {
   c->book = insert_book_create();
   load_dev_switches(c);
   {
+    // the pipelined host loop's head: device memory the HOST stores into (fine-grained; reached through the PCIe BAR).  Not every
+    // system maps it: without it the host loop launches every pass when its pose is known, as before.
+    void* p = nullptr;
+    if (hipExtMallocWithFlags(&p, sizeof(ChainHead), hipDeviceMallocFinegrained) == hipSuccess && p &&
+        hipMemset(p, 0, sizeof(ChainHead)) == hipSuccess && hipDeviceSynchronize() == hipSuccess) {
+      c->d_pipe_head = static_cast<ChainHead*>(p);
+    } else {
+      if (p) (void)hipFree(p);
+      (void)hipGetLastError();
+      c->d_pipe_head = nullptr;
+    }
+  }
+  {
     // launch -> result round trip of this host (lower quartile of 32 after 8 warm-ups: a property of the host, not of what else
     // runs at the moment): a one-thread kernel stores a granule to mapped memory, the host spins on its tag -- what every
     // host-driven pass pays beyond its kernels
@@ -425,7 +462,7 @@ extern "C" int flimo_ctx_create(int device, flimo_ctx** out) {
     std::sort(rt.begin(), rt.end());
     c->launch_rtt_us = rt[rt.size() / 4];
     memset(c->h_chain_res, 0, 2 * sizeof(double));
-    c->host_update = c->update_mode == 1 || (c->update_mode == 0 && c->launch_rtt_us <= c->rtt_threshold_us);
+    c->host_update = c->update_mode == 1 || (c->update_mode == 0 && c->launch_rtt_us <= ((c->pipeline && c->d_pipe_head) ? 2.0 : 1.0) * c->rtt_threshold_us);
   }
   *out = c;
   return FLIMO_OK;
@@ -433,7 +470,7 @@ extern "C" int flimo_ctx_create(int device, flimo_ctx** out) {
 
 extern "C" void flimo_ctx_destroy(flimo_ctx* c) {
   if (!c) return;
-  (void)hipSetDevice(c->device);
+  ctx_enter(c);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   (void)hipFree(c->d_map_raw); (void)hipFree(c->d_map_sorted); (void)hipFree(c->d_map_sorted2); (void)hipFree(c->d_cell_start); (void)hipFree(c->d_row_table);
   (void)hipFree(c->d_scan_sorted); (void)hipFree(c->d_nbr); (void)hipFree(c->d_wl); (void)hipFree(c->d_wl_count);
@@ -463,6 +500,7 @@ extern "C" void flimo_ctx_destroy(flimo_ctx* c) {
   if (c->timeout_ev) (void)hipEventDestroy(c->timeout_ev);
   if (c->adopt_ev) (void)hipEventDestroy(c->adopt_ev);
   if (c->h_wl_count) (void)hipHostFree(c->h_wl_count);
+  if (c->d_pipe_head) (void)hipFree(c->d_pipe_head);
   if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
   if (c->timeout_ev2) (void)hipEventDestroy(c->timeout_ev2);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -665,7 +703,7 @@ static int update_fine_grid(flimo_ctx* c, bool relayout, const float4* new_pts =
 //  * build: first build, or the map outgrew the geometry -> new geometry, laid out with slack on the sides that grew so
 //    that a sensor moving through new territory triggers it rarely, and a full sort.
 static int rebuild_grid(flimo_ctx* c) {
-  (void)hipSetDevice(c->device);
+  ctx_enter(c);
   if (c->map_n == 0) { c->grid_valid = false; return FLIMO_OK; }
   const float* bb = c->bb;    // tracked on the host while points are appended (no reduction kernel)
   if (c->grid_valid && c->d_map_sorted && !c->full_rebuild && !c->force_full && c->grid.n_pts > 0 && c->map_n >= c->grid.n_pts &&
@@ -772,7 +810,7 @@ extern "C" int flimo_map_grid_selfcheck(flimo_ctx* c, uint64_t* mismatches, uint
   if (stats) { stats[0] = c->grid_merges; stats[1] = c->grid_builds; }
   *mismatches = 0;
   if (!c->grid_valid) return FLIMO_OK;
-  (void)hipSetDevice(c->device);
+  ctx_enter(c);
   const GridView& g = c->grid;
   const size_t n = c->map_n, ncells = (size_t)g.nxf * g.ny * g.nz, rt = row_table_size(g.nxf, g.ny, g.nz);
   if (g.n_pts != n) { *mismatches = 1; return FLIMO_OK; }
@@ -876,7 +914,7 @@ extern "C" int flimo_map_add(flimo_ctx* c, const float* xyz, size_t n, size_t st
   if (!c) return FLIMO_ERR_INVALID;
   if (n < 1) return FLIMO_OK;                         // Mapper::add: `if(pc->points.size() < 1) return;`
   if (!xyz || stride_bytes < 12) return fail(c, FLIMO_ERR_INVALID, "bad xyz/stride");
-  (void)hipSetDevice(c->device);
+  ctx_enter(c);
   int rc = ensure_stage(c, n * sizeof(float4));
   if (rc) return rc;
   float4* st = (float4*)c->h_stage;
@@ -929,7 +967,7 @@ extern "C" int flimo_map_points(flimo_ctx* c, float* out, size_t cap, size_t* n)
   if (!out || cap == 0 || c->map_n == 0) return FLIMO_OK;
   if (!c->grid_valid) { int rc0 = rebuild_grid(c); if (rc0) return rc0; }
   if (!c->grid_valid) return fail(c, FLIMO_ERR_NOMAP, "map index not built");
-  (void)hipSetDevice(c->device);
+  ctx_enter(c);
   const size_t m = std::min(cap, c->map_n);
   int rc = ensure_stage(c, m * sizeof(float4));
   if (rc) return rc;
@@ -951,7 +989,7 @@ extern "C" int flimo_knn(flimo_ctx* c, const float* q, size_t nq, int k, int32_t
     for (size_t i = 0; i < nq * (size_t)k; i++) { idx[i] = -1; sqd[i] = 0.f; }
     return FLIMO_OK;
   }
-  (void)hipSetDevice(c->device);
+  ctx_enter(c);
   // scratch of this call, released on every exit path
   struct Scratch {
     float* q = nullptr; int32_t* idx = nullptr; float* sqd = nullptr; int32_t* cnt = nullptr;
@@ -1069,7 +1107,7 @@ extern "C" int flimo_scan_set(flimo_ctx* c, const float* xyz, size_t n, size_t s
   if (!c) return FLIMO_ERR_INVALID;
   if (n > 0 && (!xyz || stride_bytes < 12)) return fail(c, FLIMO_ERR_INVALID, "bad xyz/stride");
   if (n > 0x7fff0000ull) return fail(c, FLIMO_ERR_TOO_LARGE, "scan too large");
-  (void)hipSetDevice(c->device);
+  ctx_enter(c);
   c->deskew_pending = false;                 // the scan it belonged to is replaced
   int rc = ensure_scan(c, n);
   if (rc) return rc;
@@ -1099,7 +1137,7 @@ extern "C" int flimo_scan_get(flimo_ctx* c, float* out, size_t cap, size_t* n) {
   if (!c || !n) return FLIMO_ERR_INVALID;
   *n = c->scan_n;
   if (!out || cap == 0 || c->scan_n == 0) return FLIMO_OK;
-  (void)hipSetDevice(c->device);
+  ctx_enter(c);
   { const int rcf = flush_deskew(c); if (rcf) return rcf; }
   return download_xyz(c, c->d_scan, std::min(cap, c->scan_n), out);
 }
@@ -1109,7 +1147,7 @@ extern "C" int flimo_scan_voxel_filter(flimo_ctx* c, float leaf, size_t* n_out) 
   if (!c || !(leaf > 0.f)) return FLIMO_ERR_INVALID;
   if (n_out) *n_out = c->scan_n;
   if (c->scan_n == 0) return FLIMO_OK;
-  (void)hipSetDevice(c->device);
+  ctx_enter(c);
   size_t m = 0;
   bool pass = false;
   { const int rcf = flush_deskew(c); if (rcf) return rcf; }
@@ -1129,7 +1167,7 @@ extern "C" int flimo_scan_voxel_filter(flimo_ctx* c, float leaf, size_t* n_out) 
 extern "C" int flimo_raw_scan_set(flimo_ctx* c, const float* xyz, size_t n, size_t stride_bytes, const double* t) {
   if (!c) return FLIMO_ERR_INVALID;
   if (n > 0 && (!xyz || !t || stride_bytes < 12)) return fail(c, FLIMO_ERR_INVALID, "bad xyz/t/stride");
-  (void)hipSetDevice(c->device);
+  ctx_enter(c);
   c->deskew_pending = false;                 // a deskew never run belonged to the scan this one replaces
   int rc = ensure_scan(c, n);
   if (rc) return rc;
@@ -1150,7 +1188,7 @@ extern "C" int flimo_raw_scan_set(flimo_ctx* c, const float* xyz, size_t n, size
 extern "C" int flimo_upload_stage(flimo_ctx* c, size_t bytes, void** host_ptr) {
   if (!c || !host_ptr) return FLIMO_ERR_INVALID;
   *host_ptr = nullptr;
-  (void)hipSetDevice(c->device);
+  ctx_enter(c);
   const int rc = ensure_stage(c, bytes);
   if (rc) return rc;
   *host_ptr = c->h_stage;
@@ -1171,7 +1209,7 @@ extern "C" int flimo_raw_scan_filter_order_set(flimo_ctx* c, const void* points3
   if (n > 0x7fff0000ull) return fail(c, FLIMO_ERR_TOO_LARGE, "scan too large");
   *n_kept = 0; *last_stamp = 0.0; *nan_stamp = 0; *tied = 0;
   c->deskew_pending = false;                 // a deskew never run belonged to the scan this one replaces
-  (void)hipSetDevice(c->device);
+  ctx_enter(c);
   int rc = ensure_scan(c, n);
   if (rc) return rc;
   c->raw_n = 0; c->order_n = 0; c->resident_t_offset = 0.0; c->raw_time_ordered = false;
@@ -1311,7 +1349,7 @@ extern "C" int flimo_raw_scan_filter_order_set(flimo_ctx* c, const void* points3
 extern "C" int flimo_scan_adopt(flimo_ctx* dst, flimo_ctx* src) {
   if (!dst || !src || dst == src) return FLIMO_ERR_INVALID;
   if (dst->device != src->device) return fail(dst, FLIMO_ERR_INVALID, "flimo_scan_adopt: the two contexts are on different devices");
-  (void)hipSetDevice(dst->device);
+  ctx_enter(dst);
   const size_t m = src->raw_n;
   dst->deskew_pending = false;
   { const int rc = ensure_scan(dst, m); if (rc) return rc; }
@@ -1342,7 +1380,7 @@ extern "C" int flimo_raw_scan_order(flimo_ctx* c, uint32_t* order_out, size_t ca
   if (!order_out || cap == 0 || c->order_n == 0) return FLIMO_OK;
   const size_t m = std::min(cap, c->order_n);
   if (!c->raw_time_ordered) { for (size_t i = 0; i < m; i++) order_out[i] = (uint32_t)i; return FLIMO_OK; }
-  (void)hipSetDevice(c->device);
+  ctx_enter(c);
   HIPCHK(c, hipMemcpyAsync(order_out, c->d_tperm, m * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return FLIMO_OK;
@@ -1357,7 +1395,7 @@ extern "C" int flimo_deskew_resident_offset(flimo_ctx* c, const flimo_frame* fra
                                             const double last_x26[26], double t_offset) {
   if (!c || !frames || nf == 0 || !L2B || !last_x26) return FLIMO_ERR_INVALID;
   c->resident_t_offset = t_offset;        // a later re-registration of the same resident sweep (benchmark) uses the same stamps
-  (void)hipSetDevice(c->device);
+  ctx_enter(c);
   static_assert(sizeof(flimo_frame) == 112, "flimo_frame layout");
   if (dev_frame_size() != sizeof(flimo_frame)) return fail(c, FLIMO_ERR_INVALID, "frame layout mismatch");
   const size_t n = c->raw_n;
@@ -1417,7 +1455,7 @@ extern "C" int flimo_set_timing(flimo_ctx* c, int level) {
   if (!c) return FLIMO_ERR_INVALID;
   c->timing = level < 0 ? 0 : (level > 2 ? 2 : level);
   if (c->timing == 1 && !c->chain_ev_made) {      // the chained update's per-pass events: made here, not inside a timed update
-    (void)hipSetDevice(c->device);
+    ctx_enter(c);
     for (int i = 0; i < CH_MAX_PASSES; i++) for (int k = 0; k < 8; k++) HIPCHK(c, hipEventCreate(&c->chain_ev[i][k]));
     c->chain_ev_made = true;
   }
@@ -1435,7 +1473,7 @@ extern "C" int flimo_tie_stats(const flimo_ctx* c, unsigned long long out[2]) {
   out[0] = c->tie_redos; out[1] = c->tie_queries;
   // + the queries settled inside the reducing launches (counted on the device; the stream is drained for the read)
   unsigned long long dev = 0;
-  (void)hipSetDevice(c->device);
+  ctx_enter(const_cast<flimo_ctx*>(c));
   if (c->d_tie_settled && hipMemcpy(&dev, c->d_tie_settled, sizeof(dev), hipMemcpyDeviceToHost) == hipSuccess) out[1] += dev;
   return FLIMO_OK;
 }
@@ -1507,6 +1545,54 @@ static int abandon_wait(flimo_ctx* c, const char* what, unsigned long long id) {
   c->prev.valid = 0;
   return fail(c, FLIMO_ERR_TIMEOUT, "%s %llu did not publish its result within %d ms (kernels still running)", what, id, c->wait_timeout_ms);
 }
+static inline bool same_match_cfg(const flimo_match_cfg& a, const flimo_match_cfg& b) {      // (field by field: the struct has padding)
+  return a.NUM_MATCH_POINTS == b.NUM_MATCH_POINTS && a.MAX_NUM_MATCHES == b.MAX_NUM_MATCHES && a.MAX_NUM_PC2MATCH == b.MAX_NUM_PC2MATCH &&
+         a.MAX_DIST_PLANE == b.MAX_DIST_PLANE && a.PLANE_THRESHOLD == b.PLANE_THRESHOLD && a.estimate_extrinsics == b.estimate_extrinsics;
+}
+// ---- pipelined host loop: the pass queued ahead of the algebra --------------------------------------------------------------
+static inline double wall_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+// the waiting pass is told to leave (its workgroups poll head.epoch); cheap: one posted store when there is one, nothing otherwise
+static inline void cancel_prelaunch(flimo_ctx* c) {
+  if (!c->pre.active) return;
+  c->pre.active = false;
+  c->pipe_cancelled++;
+  __atomic_store_n(&c->d_pipe_head->epoch, c->pre.end_code, __ATOMIC_RELEASE);
+  _mm_sfence();
+}
+// every entry point that queues work on the context's stream passes here first: nothing may line up behind a pass that waits
+static inline void ctx_enter(flimo_ctx* c) {
+  (void)hipSetDevice(c->device);
+  cancel_prelaunch(c);
+}
+// the constants of the waiting pass: pose, the last pass's pose (its pruning bound's reference), then -- behind a store fence --
+// the word its workgroups poll
+static inline void publish_prelaunch(flimo_ctx* c, const PoseMats& P, const float prev_RT[16], unsigned long long seq) {
+  ChainHead h;
+  memset(&h, 0, sizeof(h));
+  h.pose = P;
+  memcpy(h.prev_RT, prev_RT, sizeof(h.prev_RT));
+  h.status = 0;
+  // (everything but the epoch word, in 8-byte stores; then the epoch)
+  const size_t words8 = offsetof(ChainHead, status) / 8;
+  static_assert(offsetof(ChainHead, status) % 8 == 0 && offsetof(ChainHead, epoch) == offsetof(ChainHead, status) + 4, "ChainHead layout");
+  volatile unsigned long long* dst = reinterpret_cast<volatile unsigned long long*>(c->d_pipe_head);
+  const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&h);
+  for (size_t i = 0; i < words8; i++) dst[i] = src[i];
+  __atomic_store_n(&c->d_pipe_head->status, 0, __ATOMIC_RELAXED);
+  _mm_sfence();
+  __atomic_store_n(&c->d_pipe_head->epoch, ch_epoch_of(seq), __ATOMIC_RELEASE);
+  _mm_sfence();
+  c->pre.active = false;
+  c->pipe_published++;
+}
+
+// which layout the automatic mode takes: the host loop while this host's launch round trip is below the threshold -- twice the
+// threshold when the loop is pipelined (its iterations then pay a store into device memory instead of a launch)
+static inline bool auto_host_update(const flimo_ctx* c) {
+  const double thr = (c->pipeline && c->d_pipe_head) ? 2.0 * c->rtt_threshold_us : c->rtt_threshold_us;
+  return c->launch_rtt_us <= thr;
+}
+
 static int check_abandoned(flimo_ctx* c) {
   if (!c->timeout_pending) return FLIMO_OK;
   hipError_t q = hipEventQuery(c->timeout_ev);
@@ -1584,6 +1670,9 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   if (cfg->NUM_MATCH_POINTS < 3 || cfg->NUM_MATCH_POINTS > 8)
     return fail(c, FLIMO_ERR_UNSUPPORTED, "NUM_MATCH_POINTS must be in 3..8 (a plane needs 3 points; the neighbour records hold 8)");
   const bool general_k = cfg->NUM_MATCH_POINTS != 5 || c->force_general_k;
+  // (a pass queued ahead of this call -- pipelined host loop -- is either this call's, decided below before anything is queued, or
+  //  told to leave: every early way out of this function cancels it)
+  struct PreGuard { flimo_ctx* c; bool decided = false; ~PreGuard() { if (!decided) cancel_prelaunch(c); } } pre_guard{c};
   { const int rca = check_abandoned(c); if (rca) return rca; }
   for (int i = 0; i < 144; i++) HTH[i] = 0.0;
   for (int i = 0; i < 12; i++) HTh[i] = 0.0;
@@ -1596,9 +1685,19 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   size_t nq = c->scan_n;
   if (cfg->MAX_NUM_PC2MATCH >= 0 && nq > (size_t)cfg->MAX_NUM_PC2MATCH) nq = (size_t)cfg->MAX_NUM_PC2MATCH;
   if (nq == 0) return FLIMO_OK;
-  (void)hipSetDevice(c->device);
+  (void)hipSetDevice(c->device);            // (not ctx_enter: a waiting pass may be THIS call's)
+  // Is the pass that waits on the GPU this call's?  Same scan, same settings, same map index, the next pass number, nothing else
+  // to queue first (no re-sort, no pending deskew), and not so old that its workgroups may have given up (CH_POLL_MS).
+  const uint64_t grid_version = c->grid_builds * 0x100000000ull + c->grid_merges;
+  bool use_pre = c->pre.active && !general_k && c->prev.valid && c->pre.nq == nq && c->pre.seq == c->pass_seq + 1 &&
+                 same_match_cfg(c->pre.cfg, *cfg) && c->pre.grid_version == grid_version && !c->deskew_pending &&
+                 !(nq < c->sorted_n || (c->sorted_n < c->scan_n && nq > c->sorted_n)) && c->pre.n_all == (int)c->sorted_n &&
+                 !c->debug_recs && !(cfg->MAX_NUM_MATCHES >= 0 && (size_t)cfg->MAX_NUM_MATCHES < nq) &&
+                 wall_s() - c->pre.t_launch < 0.25e-3 * (double)CH_POLL_MS;
+  if (!use_pre) cancel_prelaunch(c);
+  pre_guard.decided = true;
   int rc = ensure_recs(c, nq);
-  if (rc) return rc;
+  if (rc) { cancel_prelaunch(c); return rc; }
 
   static const bool prof = getenv("FLIMO_PROF_PASS") != nullptr;        // developer timing of the host side of a pass
   auto now_us = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -1705,11 +1804,22 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   const BookView* bookp = inline_ties ? &book : nullptr;
   // crowded regions first: the fine pre-pass settles the queries whose five lie within centimetres (second-level grid)
   const bool after_fine = c->fine_valid && c->lanes_per_query == 2 && mp.max_ring >= 1;
-  if (after_fine) {
+  if (use_pre && !(fused && !after_fine && tlev == 0)) {
+    // (what was queued ahead is a one-launch pass without a fine pre-pass and without timing events: anything else -- a straggler
+    //  count that changed the layout, a sampled pass -- is launched the usual way)
+    cancel_prelaunch(c);
+    use_pre = false;
+  }
+  if (use_pre) {
+    publish_prelaunch(c, P, c->prev.RT, seq);
+    c->fused_passes++;
+  } else if (after_fine) {
     launch_knn5_fine(c->stream, c->fine, c->d_scan_sorted, n_all, P, c->d_nbr, c->prev, c->fine_qlo, c->fine_qhi, &tl, seq);
     c->fine_passes++;
   }
-  if (fused) {
+  if (use_pre) {
+    // its launch is on the GPU already
+  } else if (fused) {
     launch_match_fused(c->stream, c->grid, c->d_scan_sorted, n_all, P, mp, c->d_nbr, c->d_wl, c->d_wl_count, nullptr, c->prev,
                        c->live_idx, c->d_fit2_partials, c->d_granules_host, c->d_ticket, seq, tlev == 1 ? c->ev[0] : nullptr,
                        tlev == 1 ? c->ev[1] : nullptr, &tl, after_fine ? 1 : 0, dkp, nullptr, nullptr, bookp);
@@ -1763,6 +1873,30 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   HIPCHK(c, hipGetLastError());
   const double tp1 = prof ? now_us() : 0.0;
   if (c->debug_recs) HIPCHK(c, hipMemcpyAsync(c->h_cand, c->d_cand, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+  // ---- pipelined host loop: the NEXT pass of this update is queued now, behind this one.  Its workgroups are placed when this pass
+  //      ends and wait for their constants in device memory; the next call publishes them instead of launching (use_pre above).
+  //      Only the usual case is queued ahead: a one-launch pass (by the straggler count its position published in the last scan),
+  //      no fine pre-pass, no timing events, no records. ----
+  if (c->pipeline && c->d_pipe_head && c->prune && use_fit2 && !want_count && c->tail && c->fuse && c->lanes_per_query == 2 &&
+      mp.max_ring >= 2 && mp.max_ring <= 3 && !c->fine_valid && inline_ties == ties_on) {
+    const unsigned long long nseq = seq + 1;
+    const int ntlev = (c->timing == 1 && c->timing_stride > 1 && (nseq % (unsigned long long)c->timing_stride) != 0) ? 0 : c->timing;
+    const int npos = std::min(c->pass_in_scan + 1, 3);
+    if (ntlev == 0 && c->stragglers_hist[npos] <= tail_max) {
+      TieList tln{};
+      tln.count_next = c->d_tie_count + ((nseq + 1) & 1);
+      ChainCtl pc{};
+      pc.end_code = 0x80000000u | (++c->pipe_tag & 0x7fffffffu);
+      PrevPass pv = c->prev;
+      pv.valid = 1;                                            // (its reference pose comes from the head)
+      launch_match_fused(c->stream, c->grid, c->d_scan_sorted, n_all, P, mp, c->d_nbr, c->d_wl, c->d_wl_count, nullptr, pv,
+                         c->live_idx, c->d_fit2_partials, c->d_granules_host, c->d_ticket, nseq, nullptr, nullptr, &tln, 0, nullptr,
+                         c->d_pipe_head, &pc, bookp, ch_epoch_of(nseq));
+      HIPCHK(c, hipGetLastError());
+      c->pre.active = true; c->pre.seq = nseq; c->pre.nq = nq; c->pre.n_all = n_all; c->pre.pos = npos; c->pre.cfg = *cfg;
+      c->pre.grid_version = grid_version; c->pre.end_code = pc.end_code; c->pre.t_launch = wall_s();
+    }
+  }
   double acc[256];
   if (use_fit2) {
     // low-latency completion: every sum arrives as a 16-byte granule {value, pass number}; a group's slot is complete when
@@ -1902,15 +2036,32 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
 extern "C" int flimo_set_update_mode(flimo_ctx* c, int mode) {
   if (!c || mode < 0 || mode > 2) return FLIMO_ERR_INVALID;
   c->update_mode = mode;
-  c->host_update = mode == 1 || (mode == 0 && c->launch_rtt_us <= c->rtt_threshold_us);
+  c->host_update = mode == 1 || (mode == 0 && auto_host_update(c));
   return FLIMO_OK;
 }
 // developer timing of the resident form of the chain (flimo_chain.h: ChainState::stamps): CH_MAX_PASSES x 4 wall-clock ticks (100 MHz)
 extern "C" int flimo_chain_stamps(flimo_ctx* c, unsigned long long* out48) {
   if (!c || !out48) return FLIMO_ERR_INVALID;
-  (void)hipSetDevice(c->device);
+  ctx_enter(c);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpy(out48, reinterpret_cast<const char*>(c->d_chain) + offsetof(ChainState, stamps), sizeof(unsigned long long) * CH_MAX_PASSES * 4, hipMemcpyDeviceToHost));
+  return FLIMO_OK;
+}
+extern "C" int flimo_set_pass_pipeline(flimo_ctx* c, int on) {
+  if (!c) return FLIMO_ERR_INVALID;
+  cancel_prelaunch(c);
+  if (!c->pipeline_env) c->pipeline = on != 0;
+  if (c->update_mode == 0) c->host_update = auto_host_update(c);
+  return FLIMO_OK;
+}
+extern "C" int flimo_pass_pipeline_end(flimo_ctx* c) {
+  if (!c) return FLIMO_ERR_INVALID;
+  cancel_prelaunch(c);
+  return FLIMO_OK;
+}
+extern "C" int flimo_pass_pipeline_stats(const flimo_ctx* c, unsigned long long out[2]) {
+  if (!c || !out) return FLIMO_ERR_INVALID;
+  out[0] = c->pipe_published; out[1] = c->pipe_cancelled;
   return FLIMO_OK;
 }
 extern "C" int flimo_update_mode(const flimo_ctx* c, int* chained, double* launch_rtt_us) {
@@ -1943,7 +2094,7 @@ extern "C" int flimo_update_chain(flimo_ctx* c, const flimo_match_cfg* cfg, flim
   if (cfg->MAX_NUM_PC2MATCH >= 0 && nq > (size_t)cfg->MAX_NUM_PC2MATCH) nq = (size_t)cfg->MAX_NUM_PC2MATCH;
   if (nq == 0) return decline();
   if (cfg->MAX_NUM_MATCHES >= 0 && (size_t)cfg->MAX_NUM_MATCHES < nq) return decline();      // caps need the records
-  (void)hipSetDevice(c->device);
+  ctx_enter(c);
   { int rc = ensure_recs(c, nq); if (rc) return rc; }
   MatchParams mp;
   mp.max_dist_plane_d = cfg->MAX_DIST_PLANE;
@@ -2188,7 +2339,7 @@ extern "C" int flimo_match_fetch(flimo_ctx* c, flimo_match_rec* out, size_t cap,
   if (!c || !n) return FLIMO_ERR_INVALID;
   *n = (size_t)c->last_nq;
   if (!out || cap == 0 || c->last_nq == 0) return FLIMO_OK;
-  (void)hipSetDevice(c->device);
+  ctx_enter(c);
   { int rc = materialize_recs(c, true); if (rc) return rc; }
   const size_t m = std::min(cap, (size_t)c->last_nq);
   std::vector<Rec16> r(m);
@@ -2216,7 +2367,7 @@ extern "C" int flimo_match_fetch_H(flimo_ctx* c, double* H, double* h, size_t ca
   if (!c || !M) return FLIMO_ERR_INVALID;
   *M = 0;
   if (c->last_nq == 0) return FLIMO_OK;
-  (void)hipSetDevice(c->device);
+  ctx_enter(c);
   { int rc = materialize_recs(c, false); if (rc) return rc; }
   const size_t m = (size_t)c->last_nq;
   std::vector<Rec16> r(m);
@@ -2239,7 +2390,7 @@ extern "C" int flimo_match_fetch_H(flimo_ctx* c, double* H, double* h, size_t ca
 extern "C" int flimo_scan_to_world(flimo_ctx* c, const double x26[26], float* out, size_t cap) {
   if (!c || !x26) return FLIMO_ERR_INVALID;
   if (c->scan_n == 0) return FLIMO_OK;
-  (void)hipSetDevice(c->device);
+  ctx_enter(c);
   PoseMats P;
   pose_from_x26(x26, P);
   { const int rcf = flush_deskew(c); if (rcf) return rcf; }
@@ -2255,7 +2406,7 @@ extern "C" int flimo_scan_clouds(flimo_ctx* c, const double x26[26], const float
   *body = *world = nullptr;
   *n = c->scan_n;
   if (c->scan_n == 0) return FLIMO_OK;
-  (void)hipSetDevice(c->device);
+  ctx_enter(c);
   const size_t bytes = c->scan_n * sizeof(float4);
   if (2 * bytes > c->clouds_cap) {
     if (c->h_clouds) (void)hipHostFree(c->h_clouds);
@@ -2283,7 +2434,7 @@ extern "C" int flimo_map_add_scan(flimo_ctx* c, const double x26[26], double sta
   for (int a = 0; a < 3; a++) c->fine_center[a] = (float)x26[a];       // the second level follows the sensor (update_fine_grid)
   c->have_fine_center = true;
   if (!c->host_insert) {           // resident path: transform, decide, append and re-index on the device
-    (void)hipSetDevice(c->device);
+    ctx_enter(c);
     PoseMats P;
     pose_from_x26(x26, P);
     { const int rcf = flush_deskew(c); if (rcf) return rcf; }

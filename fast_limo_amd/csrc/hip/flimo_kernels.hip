@@ -1334,7 +1334,7 @@ __device__ __forceinline__ const ChainHead* chain_enter(const ChainHead* __restr
       // (the algebra takes a few microseconds from the moment the last pass delivered: hundreds of workgroups looking at one word
       //  every 60 ns would stand in its way -- a first look, a long nap, then a look every quarter of a microsecond)
       for (int look = 0;; look++) {
-        const unsigned int e = __hip_atomic_load(&H->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int e = __hip_atomic_load(&H->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (written by a resident workgroup, or by the HOST)
         if (e == wait_epoch) { go = 1; break; }
         if (e == end_code) break;
         if (wall_clock64() - t0 > (unsigned long long)CH_POLL_MS * 100000ull) break;      // 100 MHz
@@ -1347,7 +1347,7 @@ __device__ __forceinline__ const ChainHead* chain_enter(const ChainHead* __restr
     __syncthreads();
     if (!s_go) return nullptr;
     if ((int)threadIdx.x < NW)
-      s_head[threadIdx.x] = __hip_atomic_load(reinterpret_cast<const unsigned int*>(H) + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_head[threadIdx.x] = __hip_atomic_load(reinterpret_cast<const unsigned int*>(H) + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   } else {
     if ((int)threadIdx.x < NW) s_head[threadIdx.x] = reinterpret_cast<const unsigned int*>(H)[threadIdx.x];
   }

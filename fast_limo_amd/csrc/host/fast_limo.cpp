@@ -327,6 +327,9 @@ bool Mapper::attach(int device, float cell_size) {
   }
   flimo_map_cfg mc{config.octree.min_extent, config.octree.bucket_size, config.octree.downsampling ? 1 : 0, cell_size_};
   flimo_map_config(ctx_, &mc);
+  // The host loop of the iterated update queues the next pass ahead of the filter's algebra (flimo_set_pass_pipeline): this library
+  // tells the context when an update is over (Esekf::h_update_end), which is what the switch asks of its caller.
+  if (std::getenv("FLIMO_PIPELINE") == nullptr) (void)flimo_set_pass_pipeline(ctx_, 1);
   // the input stage's own context (see front_ctx()); a sequential insert leaves nothing to overlap with
   if (std::getenv("FLIMO_NO_FRONT_CTX") == nullptr && flimo_ctx_create(device, &front_) != FLIMO_OK) front_ = nullptr;
   return true;
@@ -577,6 +580,10 @@ void Localizer::init_iKFoM() {                                     // Localizer.
         std::memcpy(lg.x_after, io.log[i].x_after, sizeof(lg.x_after));
         ikfom_->log.push_back(lg);
       }
+  };
+  ikfom_->h_update_end = [this]() {
+    flimo_ctx* c = map_->ctx();
+    if (c) (void)flimo_pass_pipeline_end(c);
   };
   ikfom_->h_dense = [this](flimo_host::DenseMeas& dm) {
     flimo_ctx* c = map_->ctx();

@@ -824,6 +824,7 @@ void Esekf::update_iterated_dyn_share_modified(double R, double D) {
   ReducedMeas meas;
   static const int so3_idx[2] = {3, 6};
   failed = false;
+  struct AtExit { std::function<void()>& f; ~AtExit() { if (f) f(); } } at_exit{h_update_end};
 
   // The whole loop on the measurement side, when it offers that: every iteration below (same arithmetic, flimo_ieskf.hip) enqueued
   // at once.  It may hand the loop back at any iteration: the rare branches stay here.

@@ -161,6 +161,9 @@ class Esekf {
   // when the plug-in did not get to call it, the filter runs the work itself after h_reduced)
   std::function<void(const StateIkfom&, ReducedMeas&, const std::function<void()>&)> h_reduced_overlap;
   std::function<void(DenseMeas&)> h_dense;                          // dense rows of the SAME pass
+  // called once when update_iterated_dyn_share_modified leaves, whichever way: a plug-in that queued a pass ahead of the loop's
+  // next iteration (pipelined host loop, flimo_c.h: flimo_pass_pipeline_end) lets it go
+  std::function<void()> h_update_end;
   std::vector<PassLog> log;
   bool keep_log = false;
   // true: literal two-inverse form of esekfom.hpp:1722-1729 and unconditional eigen-decomposition;

@@ -230,6 +230,17 @@ int flimo_update_chain(flimo_ctx* ctx, const flimo_match_cfg* cfg, flimo_chain_i
  * host-driven pass pays it every time, a chain never: flimo_update_chain declines on a fast host, where the host loop is the faster
  * of the two, and runs on a slow one); 1 = always decline (host loop); 2 = always run the chain.  FLIMO_HOST_UPDATE=1 / 0 preset 1 / 2.
  * flimo_update_mode: *chained = 1 when flimo_update_chain will run, *launch_rtt_us = the measured round trip. */
+/* Host loop, pipelined.  With the switch on, a flimo_match_reduce that ran a one-launch pass queues the NEXT pass of the same update
+ * right behind it: a kernel whose workgroups are placed on the GPU when the current pass ends and wait there for their pose.  The next
+ * flimo_match_reduce (same scan, same settings) stores the pose into device memory instead of launching: the doorbell -> dispatch ->
+ * kernel start of a launch leave the iteration's critical path (4-5 us per pass).  What it asks of the caller: say when the update is
+ * over (flimo_pass_pipeline_end, right after the loop of esekfom.hpp:1652-1820) -- a pass nobody asks for is also told to leave by the
+ * next call on the context and gives up by itself after 0.2 s, but until then a device-wide synchronisation anywhere in the process
+ * waits for it.  Off by default for that reason; fast_limo::Localizer switches it on and makes the call.  FLIMO_PIPELINE=0/1 presets it.
+ * flimo_pass_pipeline_stats: {passes that found their launch waiting, queued passes nobody asked for}. */
+int flimo_set_pass_pipeline(flimo_ctx* ctx, int on);
+int flimo_pass_pipeline_end(flimo_ctx* ctx);
+int flimo_pass_pipeline_stats(const flimo_ctx* ctx, unsigned long long out[2]);
 /* developer timing of a chained update whose algebra is resident (FLIMO_CHAIN_RESIDENT=1): 12 x 4 wall-clock ticks (100 MHz), slot =
  * pass number modulo 12: [0] the pass starts waiting for its constants, [1] it has them, [2] the algebra has seen the PREVIOUS pass's
  * arrivals, [3] it has published */

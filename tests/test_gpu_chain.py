@@ -158,6 +158,74 @@ def test_the_three_places_of_the_algebra_are_bit_equal(built, monkeypatch):
             np.testing.assert_array_equal(a, b)
 
 
+def test_pipelined_host_loop_is_bit_equal_and_lets_its_last_pass_go(built, monkeypatch):
+    """Host loop, pipelined (flimo_set_pass_pipeline; fast_limo::Localizer switches it on): the next pass of an update waits on the GPU
+    for its pose, which the next flimo_match_reduce stores into device memory instead of launching.  Same kernels, same inputs: state,
+    covariance and every pass's dx bit-equal to the loop that launches each pass when its pose is known (FLIMO_PIPELINE=0), over a
+    drive with map inserts; passes are found waiting; the pass queued behind an update's last iteration is told to leave (the drive
+    would otherwise take 0.2 s per scan).  C ABI: the same two passes with and without the switch, then other work on the context."""
+    import time
+    from fast_limo_amd import _lib, api
+    n_scans, n_pts, speed = 6, 30000, 10.0
+    st, w, a = synth.stationary_imu(0.0, 0.1 * n_scans + 0.06)
+    out = {}
+    for label, env in (("pipelined", None), ("plain", "0")):
+        if env is None:
+            monkeypatch.delenv("FLIMO_PIPELINE", raising=False)
+        else:
+            monkeypatch.setenv("FLIMO_PIPELINE", env)
+        G = _localizer(True)
+        monkeypatch.delenv("FLIMO_PIPELINE", raising=False)
+        G.set_flags(add_to_map=True, keep_log=True)
+        x0 = G.get_x(); x0[14] = speed; G.set_x(x0)
+        i, res = 0, []
+        t0 = time.perf_counter()
+        for k in range(n_scans):
+            until = 0.1 * (k + 1) + 0.005
+            while i < len(st) and st[i] <= until:
+                G.update_imu(st[i], w[i], a[i]); i += 1
+            rc = G.update_pointcloud(synth.corridor_scan(k, n_pts, 77, speed=speed), 0.1 * k)
+            res.append((rc, G.get_x().copy(), G.get_P().copy(), [p["dx"].copy() for p in G.passes()], G.map_size()))
+        out[label] = (res, time.perf_counter() - t0, G.hip.pass_pipeline_stats())
+        G.close()
+    for ra, rb in zip(out["pipelined"][0], out["plain"][0]):
+        assert ra[0] == rb[0] and ra[4] == rb[4]
+        np.testing.assert_array_equal(ra[1], rb[1])
+        np.testing.assert_array_equal(ra[2], rb[2])
+        assert len(ra[3]) == len(rb[3])
+        for da, db in zip(ra[3], rb[3]):
+            np.testing.assert_array_equal(da, db)
+    sp = out["pipelined"][2]
+    assert sp["published"] >= n_scans - 2 and out["plain"][2]["published"] == 0, (sp, out["plain"][2])
+    assert sp["cancelled"] >= 1                                      # (a pass was queued behind an update's last iteration, and let go)
+    assert out["pipelined"][1] < 0.5, out["pipelined"][1]              # nothing waited for a pass to give up (0.2 s each)
+    # ---- C ABI ----
+    mp, scan5, imu = cfg1_scene()
+    cfg = _lib.default_match_cfg(MAX_NUM_MATCHES=10**7, MAX_NUM_PC2MATCH=10**7)
+    x = np.zeros(26); x[6] = 1.0; x[10] = 1.0; x[25] = -9.809
+    xs = [x.copy() for _ in range(3)]
+    xs[1][0] += 0.01; xs[2][0] += 0.015; xs[2][1] -= 0.004
+    got = {}
+    for on in (False, True):
+        h = _lib.HipCtx()
+        h.set_update_mode(1)
+        h.map_add(np.ascontiguousarray(mp[:, :3]))
+        h.scan_set(np.ascontiguousarray(scan5[:, :3]))
+        h.set_pass_pipeline(on)
+        got[on] = [h.match_reduce(xk, cfg) for xk in xs]
+        h.pass_pipeline_end()
+        s_ = h.pass_pipeline_stats()
+        assert (s_["published"] >= 1) == on, s_
+        t0 = time.perf_counter()
+        h.map_add(np.ascontiguousarray(mp[:1000, :3] + 0.01))         # other work on the context: nothing in its way
+        assert time.perf_counter() - t0 < 0.15
+        h.close()
+    for ra, rb in zip(got[False], got[True]):
+        assert ra[2] == rb[2]
+        np.testing.assert_array_equal(ra[0], rb[0])
+        np.testing.assert_array_equal(ra[1], rb[1])
+
+
 def test_a_pass_that_fails_is_surfaced(built):
     """The reference's Mapper::match cannot fail (Modules/Mapper.cpp:59-86); a GPU pass can (timeout, HIP error).  C ABI: the wait
     bound 0 ("do not wait") makes flimo_match_reduce and flimo_update_chain return FLIMO_ERR_TIMEOUT while their launches are

@@ -26,7 +26,12 @@ __global__ __launch_bounds__(256) void pass_like(int mode, Args a, const unsigne
     s_abort = 0;
     if (mode != 0) {
       const unsigned long long t0 = wall_clock64();
-      if (mode == 1 || blockIdx.x == 0) {
+      if (mode == 3) {
+        while (__hip_atomic_load(dev_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+          if (wall_clock64() - t0 > 5000000ull) { s_abort = 1; break; }
+          __builtin_amdgcn_s_sleep(8);
+        }
+      } else if (mode == 1 || blockIdx.x == 0) {
         while (__hip_atomic_load(host_word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
           if (wall_clock64() - t0 > 5000000ull) { s_abort = 1; break; }          // 50 ms at 100 MHz
           __builtin_amdgcn_s_sleep(2);
@@ -65,13 +70,18 @@ int main() {
   CHECK(hipHostMalloc((void**)&h_word, 64, hipHostMallocMapped)); CHECK(hipHostGetDevicePointer((void**)&d_hword, h_word, 0));
   CHECK(hipHostMalloc((void**)&h_out, 64, hipHostMallocMapped)); CHECK(hipHostGetDevicePointer((void**)&d_hout, h_out, 0));
   CHECK(hipMalloc(&dev_word, 64)); CHECK(hipMemset(dev_word, 0, 64));
+  // mode 3: a word of DEVICE memory the host can store into (fine-grained allocation, reached through the PCIe BAR)
+  unsigned long long* fg_word = nullptr;
+  const bool have_fg = hipExtMallocWithFlags((void**)&fg_word, 64, hipDeviceMallocFinegrained) == hipSuccess && fg_word;
+  if (have_fg) CHECK(hipMemset(fg_word, 0, 64));
+  printf("fine-grained device word: %s\n", have_fg ? "allocated" : "NOT available");
   CHECK(hipMalloc(&ticket, 4)); CHECK(hipMemset(ticket, 0, 4));
   CHECK(hipMalloc(&sink, 4096 * 4));
   *h_word = 0; *h_out = 0;
   Args a; for (int i = 0; i < 48; i++) a.pose[i] = (float)i;
   const int blocks = 512, reps = 400;
   unsigned long long seq = 0;
-  for (int mode = 0; mode < 3; mode++) {
+  for (int mode = 0; mode < (have_fg ? 4 : 3); mode++) {
     std::vector<double> lat;
     for (int r = 0; r < reps; r++) {
       ++seq;
@@ -84,11 +94,12 @@ int main() {
         lat.push_back(now_us() - t0);
       } else {
         // pre-launched: the kernel is resident and polling; 30 us later (the predecessor's run time) the host stores the word
-        hipLaunchKernelGGL(pass_like, dim3(blocks), dim3(256), 0, st, mode, a, d_hword, dev_word, seq, ticket, d_hout, sink);
+        hipLaunchKernelGGL(pass_like, dim3(blocks), dim3(256), 0, st, mode, a, d_hword, mode == 3 ? fg_word : dev_word, seq, ticket, d_hout, sink);
         const double tw = now_us();
         while (now_us() - tw < 30.0) _mm_pause();
         const double t0 = now_us();
-        __atomic_store_n(h_word, seq, __ATOMIC_RELEASE);
+        if (mode == 3) { __atomic_store_n(fg_word, seq, __ATOMIC_RELEASE); _mm_sfence(); }
+        else __atomic_store_n(h_word, seq, __ATOMIC_RELEASE);
         while (*out != seq) _mm_pause();
         lat.push_back(now_us() - t0);
       }
@@ -96,7 +107,7 @@ int main() {
     }
     std::sort(lat.begin(), lat.end());
     printf("PRELAUNCH mode %d (%s): median %.2f us  p10 %.2f  p90 %.2f\n", mode,
-           mode == 0 ? "launch after the pose is known" : (mode == 1 ? "resident, every block polls host memory" : "resident, block 0 polls host memory, the others device memory"),
+           mode == 0 ? "launch after the pose is known" : (mode == 1 ? "resident, every block polls host memory" : (mode == 2 ? "resident, block 0 polls host memory, the others device memory" : "resident, every block polls a DEVICE word the host stores into")),
            lat[reps / 2], lat[reps / 10], lat[reps * 9 / 10]);
   }
   return 0;
