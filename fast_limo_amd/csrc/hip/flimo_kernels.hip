@@ -1332,13 +1332,14 @@ __device__ __forceinline__ const ChainHead* chain_enter(const ChainHead* __restr
       if (dbgS) dbgS->stamps[wait_epoch % CH_MAX_PASSES][0] = t0;
       int go = 0;
       // (the algebra takes a few microseconds from the moment the last pass delivered: hundreds of workgroups looking at one word
-      //  every 60 ns would stand in its way -- a first look, a long nap, then a look every quarter of a microsecond)
+      //  every 60 ns would stand in its way -- a first look, a nap of 1.5 us (the host's algebra of a pipelined loop takes two),
+      //  then a look every quarter of a microsecond)
       for (int look = 0;; look++) {
         const unsigned int e = __hip_atomic_load(&H->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (written by a resident workgroup, or by the HOST)
         if (e == wait_epoch) { go = 1; break; }
         if (e == end_code) break;
         if (wall_clock64() - t0 > (unsigned long long)CH_POLL_MS * 100000ull) break;      // 100 MHz
-        if (look == 0) __builtin_amdgcn_s_sleep(96);
+        if (look == 0) __builtin_amdgcn_s_sleep(48);
         else __builtin_amdgcn_s_sleep(8);
       }
       if (dbgS) dbgS->stamps[wait_epoch % CH_MAX_PASSES][1] = wall_clock64();
