@@ -103,6 +103,6 @@ void launch_ieskf_extra(hipStream_t st, const ChainCtl& ch, hipEvent_t e0 = null
 void launch_ieskf_resident(hipStream_t st, const ChainCtl& ch, unsigned long long seq0, int n_pass, const float* first_RT_host, int wait_ms);
 // head.epoch of the pass numbered seq: never zero (zero means "do not wait"), top bit clear (set: an end code)
 __host__ __device__ inline unsigned int ch_epoch_of(unsigned long long seq) { return (unsigned int)(seq & 0x3fffffffull) | 0x40000000u; }
-constexpr int CH_POLL_MS = 200;          // a pass's workgroups give up waiting for their constants after this long (status FAILED)
+constexpr int CH_POLL_MS = 50;           // a pass's workgroups give up waiting for their constants after this long (status FAILED)
 
 }  // namespace flimo

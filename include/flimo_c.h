@@ -235,7 +235,7 @@ int flimo_update_chain(flimo_ctx* ctx, const flimo_match_cfg* cfg, flimo_chain_i
  * flimo_match_reduce (same scan, same settings) stores the pose into device memory instead of launching: the doorbell -> dispatch ->
  * kernel start of a launch leave the iteration's critical path (4-5 us per pass).  What it asks of the caller: say when the update is
  * over (flimo_pass_pipeline_end, right after the loop of esekfom.hpp:1652-1820) -- a pass nobody asks for is also told to leave by the
- * next call on the context and gives up by itself after 0.2 s, but until then a device-wide synchronisation anywhere in the process
+ * next call on the context and gives up by itself after 50 ms, but until then a device-wide synchronisation anywhere in the process
  * waits for it.  Off by default for that reason; fast_limo::Localizer switches it on and makes the call.  FLIMO_PIPELINE=0/1 presets it.
  * flimo_pass_pipeline_stats: {passes that found their launch waiting, queued passes nobody asked for}. */
 int flimo_set_pass_pipeline(flimo_ctx* ctx, int on);

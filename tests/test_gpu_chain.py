@@ -163,7 +163,7 @@ def test_pipelined_host_loop_is_bit_equal_and_lets_its_last_pass_go(built, monke
     for its pose, which the next flimo_match_reduce stores into device memory instead of launching.  Same kernels, same inputs: state,
     covariance and every pass's dx bit-equal to the loop that launches each pass when its pose is known (FLIMO_PIPELINE=0), over a
     drive with map inserts; passes are found waiting; the pass queued behind an update's last iteration is told to leave (the drive
-    would otherwise take 0.2 s per scan).  C ABI: the same two passes with and without the switch, then other work on the context."""
+    would otherwise take 50 ms per scan).  C ABI: the same two passes with and without the switch, then other work on the context."""
     import time
     from fast_limo_amd import _lib, api
     n_scans, n_pts, speed = 6, 30000, 10.0
@@ -198,7 +198,7 @@ def test_pipelined_host_loop_is_bit_equal_and_lets_its_last_pass_go(built, monke
     sp = out["pipelined"][2]
     assert sp["published"] >= n_scans - 2 and out["plain"][2]["published"] == 0, (sp, out["plain"][2])
     assert sp["cancelled"] >= 1                                      # (a pass was queued behind an update's last iteration, and let go)
-    assert out["pipelined"][1] < 0.5, out["pipelined"][1]              # nothing waited for a pass to give up (0.2 s each)
+    assert out["pipelined"][1] < out["plain"][1] + 0.04, (out["pipelined"][1], out["plain"][1])   # nothing waited for a pass to give up (50 ms each)
     # ---- C ABI ----
     mp, scan5, imu = cfg1_scene()
     cfg = _lib.default_match_cfg(MAX_NUM_MATCHES=10**7, MAX_NUM_PC2MATCH=10**7)
