@@ -8,12 +8,17 @@ out=$root/gpurun_out/profiles_r04
 # --streams 0: without the informational concurrent-streams leg, whose overlapped launches would enter the per-kernel averages
 args="--steps 100 --warmup 5 --no-cpu-baseline --no-end-to-end --no-hbm-regime --no-crowded --streams 0"
 cd /tmp && export TMPDIR=/tmp
-rm -rf $out/pmc_fetch $out/pmc_write $out/prof $out/prof_nofuse $out/pmc_fetch_hbm $out/pmc_write_hbm $out/prof_hbm
+rm -rf $out/pmc_fetch $out/pmc_write $out/prof $out/prof_nopipeline $out/prof_nofuse $out/pmc_fetch_hbm $out/pmc_write_hbm $out/prof_hbm
 # ---- PMC passes first (counters in their own runs), so that the bench line below carries `traffic` for these very sources ----
+# (FLIMO_PIPELINE=0 for the counter passes and for one of the kernel summaries: a pass queued ahead of the host's algebra is the same
+#  kernel under its chained name, its duration includes the wait for its pose and one per scan leaves without working -- per-kernel
+#  averages of traffic and time are taken from launches that start with their pose)
+export FLIMO_PIPELINE=0
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -- python3 $root/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-end-to-end --no-hbm-regime --no-crowded --streams 0 > /dev/null 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -- python3 $root/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-end-to-end --no-hbm-regime --no-crowded --streams 0 > /dev/null 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch_hbm -- python3 $root/bench.py --hbm-regime-only --no-cpu-baseline --hbm-steps 6 > /dev/null 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write_hbm -- python3 $root/bench.py --hbm-regime-only --no-cpu-baseline --hbm-steps 6 > /dev/null 2>&1
+unset FLIMO_PIPELINE
 cd $root
 python3 tools/pmc_summary.py $out/pmc_fetch $out/pmc_write $out/pmc_fetch_write_per_kernel.json | head -6
 python3 tools/pmc_summary.py $out/pmc_fetch_hbm $out/pmc_write_hbm $out/pmc_hbm_regime.json | head -6
@@ -22,16 +27,17 @@ cp $out/pmc_fetch_write_per_kernel.json $out/pmc_hbm_regime.json profiles/r04/  
 python bench.py --steps 100 --warmup 5 2>$out/bench_r04.err > $out/bench_r04.json
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python3 $root/bench.py $args > $out/bench_r04_under_rocprof.json 2>/dev/null
+FLIMO_PIPELINE=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_nopipeline -- python3 $root/bench.py $args > /dev/null 2>&1
 FLIMO_FUSE=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_nofuse -- python3 $root/bench.py $args > /dev/null 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_hbm -- python3 $root/bench.py --hbm-regime-only --no-cpu-baseline > $out/bench_r04_hbm_under_rocprof.json 2>/dev/null
 cd $root
-for t in prof prof_nofuse prof_hbm; do
+for t in prof prof_nopipeline prof_nofuse prof_hbm; do
   f=$(find $out/$t -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp $f $out/bench_r04_${t}_kernel_stats.csv
 done
 python3 - "$out" <<'PY'
 import csv, sys, glob, os
-for t in ("prof", "prof_nofuse", "prof_hbm"):
+for t in ("prof", "prof_nopipeline", "prof_nofuse", "prof_hbm"):
     f = os.path.join(sys.argv[1], "bench_r04_%s_kernel_stats.csv" % t)
     if not os.path.exists(f): continue
     print("==", t)
@@ -40,5 +46,5 @@ for t in ("prof", "prof_nofuse", "prof_hbm"):
         print(f'{name:44s} calls {r["Calls"]:>5s} avg {float(r["AverageNs"])/1e3:8.2f} us  min {float(r["MinNs"])/1e3:7.2f}  max {float(r["MaxNs"])/1e3:7.2f}  {r["Percentage"]:>6s}%')
 PY
 head -c 600 $out/bench_r04.json; echo
-rm -rf $out/pmc_fetch $out/pmc_write $out/prof $out/prof_nofuse $out/pmc_fetch_hbm $out/pmc_write_hbm $out/prof_hbm
+rm -rf $out/pmc_fetch $out/pmc_write $out/prof $out/prof_nopipeline $out/prof_nofuse $out/pmc_fetch_hbm $out/pmc_write_hbm $out/prof_hbm
 ls -la $out
