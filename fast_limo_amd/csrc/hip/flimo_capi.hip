@@ -434,7 +434,9 @@ extern "C" int flimo_ctx_create(int device, flimo_ctx** out) {
     // the pipelined host loop's head: device memory the HOST stores into (fine-grained; reached through the PCIe BAR).  Not every
     // system maps it: without it the host loop launches every pass when its pose is known, as before.
     void* p = nullptr;
-    if (hipExtMallocWithFlags(&p, sizeof(ChainHead), hipDeviceMallocFinegrained) == hipSuccess && p &&
+    int large_bar = 0;
+    (void)hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device);      // (host stores into device memory need the whole of it behind the BAR)
+    if (large_bar && hipExtMallocWithFlags(&p, sizeof(ChainHead), hipDeviceMallocFinegrained) == hipSuccess && p &&
         hipMemset(p, 0, sizeof(ChainHead)) == hipSuccess && hipDeviceSynchronize() == hipSuccess) {
       c->d_pipe_head = static_cast<ChainHead*>(p);
     } else {

@@ -228,7 +228,8 @@ typedef struct flimo_chain_io {
 int flimo_update_chain(flimo_ctx* ctx, const flimo_match_cfg* cfg, flimo_chain_io* io);
 /* Which way a caller's update runs: 0 (default) = by this host's launch -> result round trip, measured once at context creation (a
  * host-driven pass pays it every time, a chain never: flimo_update_chain declines on a fast host, where the host loop is the faster
- * of the two, and runs on a slow one); 1 = always decline (host loop); 2 = always run the chain.  FLIMO_HOST_UPDATE=1 / 0 preset 1 / 2.
+ * of the two, and runs on a slow one: from 8 us on, from 16 us when the host loop is pipelined, FLIMO_RTT_THRESHOLD_US); 1 = always
+ * decline (host loop); 2 = always run the chain.  FLIMO_HOST_UPDATE=1 / 0 preset 1 / 2.
  * flimo_update_mode: *chained = 1 when flimo_update_chain will run, *launch_rtt_us = the measured round trip. */
 /* Host loop, pipelined.  With the switch on, a flimo_match_reduce that ran a one-launch pass queues the NEXT pass of the same update
  * right behind it: a kernel whose workgroups are placed on the GPU when the current pass ends and wait there for their pose.  The next
