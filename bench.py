@@ -878,7 +878,8 @@ def main():
                        "parallelism": "replicas x%d (independent scan streams, no collective)" % world,
                        "passes_per_step": n_passes / max(args.steps, 1), "steps_bit_reproducible": repro_bitwise,
                        "update": ("chained: every iteration's launches queued at once, the filter's algebra on the device (flimo_update_chain)"
-                                  if chain["chains"] else "host loop over single passes (this host's launch round trip is short, or FLIMO_HOST_UPDATE=1)"),
+                                  if chain["chains"] else ("host loop, pipelined: the next pass waits on the GPU for the pose the host stores into device memory (flimo_set_pass_pipeline)"
+                                                           if pipe_found else "host loop over single passes (this host's launch round trip is short, or FLIMO_HOST_UPDATE=1)")),
                        "chains_run": chain["chains"], "chains_handed_back_early": chain["handed_back"], "chains_declined": chain["declined"],
                        "host_loop_passes_found_waiting": pipe_found, "host_loop_passes_queued_for_nothing": pipe_wasted},
             "value_regions": value_regions,
