@@ -90,6 +90,8 @@ struct flimo_ctx {
   size_t sorted_n = 0;             // points in d_scan_sorted: scan_n, or the MAX_NUM_PC2MATCH prefix once a pass asked for it
   void* d_frames = nullptr;
   size_t frames_cap = 0;
+  char* d_frames_fg = nullptr;              // two slots of FRAMES_FG_SLOT bytes in fine-grained device memory the host stores into (large-BAR devices):
+                                            // the IMU frames of a deskew without a copy launch (DeskewArgs::stage_words)
   void* h_frames[2] = {nullptr, nullptr};   // pinned staging of the IMU frames, alternating: the deskew call does not wait
   size_t h_frames_cap = 0;
   int frames_slot = 0, async_deskews = 0;   // copies possibly still in flight since the stream was last known idle
@@ -248,6 +250,7 @@ struct flimo_ctx {
   bool tail = true;                // FLIMO_TAIL=0: pending queries go to the worklist + widen_kernel dispatch instead of being finished inside the k-NN launch (A/B checks)
 };
 
+constexpr size_t FRAMES_FG_SLOT = 8192;             // bytes per slot of flimo_ctx::d_frames_fg (about 70 IMU frames)
 static inline void ctx_enter(flimo_ctx* c);       // hipSetDevice + a pass queued ahead of the filter's algebra is told to leave (see cancel_prelaunch)
 static int fail(flimo_ctx* c, int code, const char* fmt, ...) {
   char buf[512];
@@ -439,6 +442,10 @@ extern "C" int flimo_ctx_create(int device, flimo_ctx** out) {
     if (large_bar && hipExtMallocWithFlags(&p, sizeof(ChainHead), hipDeviceMallocFinegrained) == hipSuccess && p &&
         hipMemset(p, 0, sizeof(ChainHead)) == hipSuccess && hipDeviceSynchronize() == hipSuccess) {
       c->d_pipe_head = static_cast<ChainHead*>(p);
+      void* q = nullptr;
+      if (getenv("FLIMO_NO_FRAMES_BAR") == nullptr && hipExtMallocWithFlags(&q, 2 * FRAMES_FG_SLOT, hipDeviceMallocFinegrained) == hipSuccess && q)
+        c->d_frames_fg = static_cast<char*>(q);
+      else (void)hipGetLastError();
     } else {
       if (p) (void)hipFree(p);
       (void)hipGetLastError();
@@ -503,6 +510,7 @@ extern "C" void flimo_ctx_destroy(flimo_ctx* c) {
   if (c->adopt_ev) (void)hipEventDestroy(c->adopt_ev);
   if (c->h_wl_count) (void)hipHostFree(c->h_wl_count);
   if (c->d_pipe_head) (void)hipFree(c->d_pipe_head);
+  if (c->d_frames_fg) (void)hipFree(c->d_frames_fg);
   if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
   if (c->timeout_ev2) (void)hipEventDestroy(c->timeout_ev2);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1402,9 +1410,32 @@ extern "C" int flimo_deskew_resident_offset(flimo_ctx* c, const flimo_frame* fra
   if (dev_frame_size() != sizeof(flimo_frame)) return fail(c, FLIMO_ERR_INVALID, "frame layout mismatch");
   const size_t n = c->raw_n;
   if (n == 0) { c->scan_n = 0; c->sorted_n = 0; c->prev.valid = 0; return FLIMO_OK; }
-  // frames + the two 4x4 matrices go through one pinned staging copy
   const size_t fbytes = nf * sizeof(flimo_frame);
   const size_t total = fbytes + 32 * sizeof(float);
+  if (c->d_frames_fg && total <= FRAMES_FG_SLOT && c->lazy_deskew) {
+    // The host stores frames + matrices straight into (fine-grained) device memory: no copy launch and no dispatch boundary ahead of
+    // the pass the deskew rides on.  Two slots, alternating: a pass that still reads the last sweep's is not disturbed.
+    alignas(64) char buf[FRAMES_FG_SLOT];
+    memcpy(buf, frames, fbytes);
+    float* m = reinterpret_cast<float*>(buf + fbytes);
+    memcpy(m, L2B, 16 * sizeof(float));
+    {
+      const float p[3] = {(float)last_x26[0], (float)last_x26[1], (float)last_x26[2]};
+      const float q[4] = {(float)last_x26[3], (float)last_x26[4], (float)last_x26[5], (float)last_x26[6]};
+      se3_inv_from(q, p, m + 16);                     // last_state.get_RT_inv()
+    }
+    char* dst = c->d_frames_fg + (size_t)c->frames_slot * FRAMES_FG_SLOT;
+    c->frames_slot ^= 1;
+    memcpy(dst, buf, (total + 7) & ~(size_t)7);
+    _mm_sfence();
+    c->deskew_args = DeskewArgs{c->d_raw_sorted, c->d_t_sorted, dst, (int)nf, reinterpret_cast<const float*>(dst + fbytes),
+                                t_offset, c->d_scan_sorted, c->d_scan, 1, (int)(total / 4)};
+    c->deskew_n = n;
+    c->deskew_pending = true;
+    c->scan_n = n; c->sorted_n = n; c->prev.valid = 0;
+    return FLIMO_OK;
+  }
+  // frames + the two 4x4 matrices go through one pinned staging copy
   if (total > c->frames_cap) {
     (void)hipFree(c->d_frames);
     c->d_frames = nullptr;
@@ -1436,7 +1467,7 @@ extern "C" int flimo_deskew_resident_offset(flimo_ctx* c, const flimo_frame* fra
   // stream-ordered: everything that consumes the deskewed scan is queued behind this on the same stream
   HIPCHK(c, hipMemcpyAsync(c->d_frames, hs, total, hipMemcpyHostToDevice, c->stream));
   c->deskew_args = DeskewArgs{c->d_raw_sorted, c->d_t_sorted, c->d_frames, (int)nf, (const float*)((const char*)c->d_frames + fbytes),
-                              t_offset, c->d_scan_sorted, c->d_scan, 1};
+                              t_offset, c->d_scan_sorted, c->d_scan, 1, 0};
   c->deskew_n = n;
   c->deskew_pending = true;
   if (!c->lazy_deskew) { const int rcf = flush_deskew(c); if (rcf) return rcf; }

@@ -14,6 +14,8 @@ struct ChainHead;   // flimo_chain.h: a launch given one reads its pose constant
 struct DeskewArgs {
   const float4* raw; const double* t; const void* frames; int nf; const float* mats; double t_offset;
   float4* out_sorted; float4* out_orig; int on;
+  int stage_words;     // > 0: frames + matrices (this many 4-byte words from `frames`) were stored by the HOST into fine-grained device
+                       // memory -- no copy launch; the riding pass reads them once per workgroup, past the caches, into shared memory
 };
 
 // flimo_kernels.hip

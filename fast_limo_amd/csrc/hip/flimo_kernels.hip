@@ -939,14 +939,29 @@ __device__ __forceinline__ void knn5_pass(const GridView& G, const float4* __res
   if (!FINE && fa.dk.on) {
     // first pass of a scan: the deskew of this query's raw point (Localizer.cpp:822-843) instead of a dispatch of its own; the
     // result is what deskew_kernel would have stored, and is stored for the later passes, the map insert and the clouds
+    const DevFrame* dk_frames = static_cast<const DevFrame*>(fa.dk.frames);
+    const float* dk_mats = fa.dk.mats;
+    const bool staged = fa.dk.stage_words > 0;                 // (launch-uniform)
+    if (staged) {
+      // the IMU frames came straight from the host (stores into fine-grained device memory, no copy launch ahead of this pass):
+      // one look past the caches per workgroup, into shared memory nobody uses before the tail / the fit
+      unsigned int* dst = reinterpret_cast<unsigned int*>(s_w);
+      const unsigned int* src = reinterpret_cast<const unsigned int*>(fa.dk.frames);
+      for (int i = (int)threadIdx.x; i < fa.dk.stage_words; i += 256)
+        dst[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __syncthreads();
+      dk_frames = reinterpret_cast<const DevFrame*>(dst);
+      dk_mats = reinterpret_cast<const float*>(dst) + (fa.dk.mats - static_cast<const float*>(fa.dk.frames));
+    }
     sp = make_float4(0.f, 0.f, 0.f, 0.f);
     if (in_range) {
-      sp = deskew_point(fa.dk.raw[p], fa.dk.t[p] + fa.dk.t_offset, static_cast<const DevFrame*>(fa.dk.frames), fa.dk.nf, fa.dk.mats);
+      sp = deskew_point(fa.dk.raw[p], fa.dk.t[p] + fa.dk.t_offset, dk_frames, fa.dk.nf, dk_mats);
       if (sub == 0) {
         fa.dk.out_sorted[p] = sp;
         fa.dk.out_orig[__float_as_uint(sp.w)] = make_float4(sp.x, sp.y, sp.z, 1.0f);
       }
     }
+    if (staged) __syncthreads();                               // every wave is done with the frames before any of them reuses s_w
   } else {
     sp = scan_sorted[in_range ? p : 0];
   }
