@@ -43,6 +43,13 @@ class Frame(C.Structure):
 CHAIN_MAX_PASSES = 12
 
 
+class FilterCfg(C.Structure):
+    """flimo_filter_cfg (include/flimo_c.h)."""
+    _fields_ = [("crop_active", C.c_int), ("crop_min", C.c_float * 3), ("crop_max", C.c_float * 3), ("dist_active", C.c_int),
+                ("min_dist", C.c_float), ("rate_active", C.c_int), ("rate_value", C.c_int), ("time_kind", C.c_int),
+                ("end_of_sweep", C.c_int), ("sweep_ref_time", C.c_double), ("fov_active", C.c_int), ("fov_angle", C.c_float)]
+
+
 class ChainPass(C.Structure):
     _fields_ = [("M", C.c_int), ("stragglers", C.c_int), ("ties", C.c_int), ("HTH", C.c_double * 144), ("HTh", C.c_double * 12),
                 ("dx", C.c_double * 23), ("x_after", C.c_double * 26)]
@@ -151,6 +158,11 @@ def load_hip():
     L.flimo_chain_stats.argtypes = [vp, f64p, C.c_int]
     L.flimo_set_update_mode.argtypes = [vp, C.c_int]
     L.flimo_scan_adopt.argtypes = [vp, vp]
+    L.flimo_raw_scan_filter_order_set.argtypes = [vp, C.c_void_p, C.c_size_t, C.POINTER(FilterCfg), C.c_int, C.POINTER(C.c_size_t),
+                                                  C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.flimo_raw_scan_order.argtypes = [vp, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.flimo_deskew_resident_offset.argtypes = [vp, C.c_void_p, C.c_size_t, np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS"),
+                                               np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS"), C.c_double]
     L.flimo_chain_stamps.argtypes = [vp, C.POINTER(C.c_ulonglong)]
     L.flimo_set_pass_pipeline.argtypes = [vp, C.c_int]
     L.flimo_pass_pipeline_end.argtypes = [vp]
@@ -255,6 +267,37 @@ class HipCtx:
         n = C.c_size_t(0)
         self._chk(self._L.flimo_scan_voxel_filter(self._h, float(leaf), C.byref(n)))
         return int(n.value)
+
+    def raw_scan_filter_order_set(self, records, time_order=0, **cfg):
+        """flimo_raw_scan_filter_order_set: ``records`` = the sweep as 32-byte PointType records (itemsize 32) or, with bit 2 of
+        ``time_order`` set, as 16-byte {x, y, z, time word} records.  Returns (kept, last_stamp, nan_stamp, tied)."""
+        fc = FilterCfg()
+        for k, v in cfg.items():
+            if k in ("crop_min", "crop_max"):
+                setattr(fc, k, (C.c_float * 3)(*v))
+            else:
+                setattr(fc, k, v)
+        rec = np.ascontiguousarray(records)
+        n = rec.shape[0]
+        assert rec.dtype.itemsize * (rec.size // max(n, 1)) == (16 if (time_order & 4) else 32)
+        kept, last, nan, tied = C.c_size_t(0), C.c_double(0), C.c_int(0), C.c_int(0)
+        self._chk(self._L.flimo_raw_scan_filter_order_set(self._h, rec.ctypes.data, n, C.byref(fc), int(time_order), C.byref(kept),
+                                                          C.byref(last), C.byref(nan), C.byref(tied)))
+        return int(kept.value), float(last.value), int(nan.value), int(tied.value)
+
+    def raw_scan_order(self):
+        n = C.c_size_t(0)
+        self._chk(self._L.flimo_raw_scan_order(self._h, None, 0, C.byref(n)))
+        out = np.zeros(max(n.value, 1), np.uint32)
+        self._chk(self._L.flimo_raw_scan_order(self._h, out.ctypes.data, n.value, C.byref(n)))
+        return out[:n.value]
+
+    def deskew_resident_offset(self, frames, L2B, last_x26, t_offset):
+        assert frames.dtype == FRAME_DTYPE
+        frames = np.ascontiguousarray(frames)
+        self._chk(self._L.flimo_deskew_resident_offset(self._h, frames.ctypes.data, frames.shape[0],
+                                                       np.ascontiguousarray(L2B, dtype=np.float32).reshape(-1),
+                                                       np.ascontiguousarray(last_x26, dtype=np.float64), float(t_offset)))
 
     def scan_adopt(self, src: "HipCtx"):
         """The resident raw sweep of ``src`` becomes this context's (flimo_scan_adopt)."""

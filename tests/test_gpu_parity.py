@@ -555,6 +555,65 @@ def test_staged_upload_packs_32_bit_stamps_into_16_byte_records(built, oracle, s
 
 
 @pytest.mark.gpu
+def test_c_abi_input_stage_records_hand_over_and_time_order(built, oracle):
+    """The input stage through the C ABI itself (flimo_raw_scan_filter_order_set): PointType records against the same sweep packed
+    into 16-byte {x, y, z, time word} records (time_order bit 2) -- same kept count, same last stamp, same deskewed scan bit for bit;
+    the kept points against a numpy restatement of the filters (NaN removal, negative crop box, every 3rd survivor, min distance:
+    Localizer.cpp:262-302) and the time rank -> position table against a stable argsort of their stamps (:789-790, stamps pairwise
+    different); flimo_scan_adopt: a second context deskews the sweep the first one filtered, same bits."""
+    from fast_limo_amd import _lib
+    rs = np.random.RandomState(3)
+    n = 50000
+    xyz = (rs.uniform(-30, 30, (n, 3)) * [1, 1, 0.1]).astype(np.float32)
+    xyz[::101] = np.nan
+    rel = ((rs.permutation(n) + 0.25) * (0.1 / n)).astype(np.float32)                     # VELODYNE: float seconds, pairwise different
+    pts = oracle.make_points(xyz, 1.0, time_s=rel)
+    rec16 = np.zeros((n, 4), np.float32)
+    rec16[:, :3] = xyz
+    rec16[:, 3] = rel
+    cfg = dict(crop_active=1, crop_min=(-2.0, -2.0, -2.0), crop_max=(2.0, 2.0, 2.0), dist_active=1, min_dist=5.0, rate_active=1,
+               rate_value=3, time_kind=1, end_of_sweep=0, sweep_ref_time=10.0)
+    # numpy restatement of the filters
+    finite = np.isfinite(xyz).all(axis=1)
+    inside = ((xyz > -2.0) & (xyz < 2.0)).all(axis=1)
+    alive = finite & ~inside
+    rank = np.cumsum(alive) - 1
+    keep = alive & (rank % 3 == 0)
+    with np.errstate(invalid="ignore"):
+        keep &= np.sqrt(xyz[:, 0] * xyz[:, 0] + (xyz[:, 1] * xyz[:, 1] + xyz[:, 2] * xyz[:, 2])) > np.float32(5.0)
+    kept_xyz, kept_t = xyz[keep], rel[keep]
+    order_ref = np.argsort(kept_t, kind="stable")
+    frames = np.zeros(24, _lib.FRAME_DTYPE)
+    frames["q"][:, 3] = 1.0
+    frames["g"][:, 2] = -9.81
+    frames["a"][:, 2] = 9.81                                                              # at rest: the specific force cancels gravity exactly
+    frames["time"] = 10.0 + 0.005 * np.arange(24) - 0.005
+    L2B = np.eye(4, dtype=np.float32)
+    x26 = np.zeros(26); x26[6] = 1.0; x26[10] = 1.0; x26[25] = -9.81
+    scans = {}
+    for label, rec, bit in (("records32", pts, 0), ("records16", rec16, 4)):
+        h = _lib.HipCtx()
+        kept, last, nan, tied = h.raw_scan_filter_order_set(rec, 1 | bit, **cfg)
+        assert (kept, nan, tied) == (int(keep.sum()), 0, 0), (label, kept, nan, tied)
+        assert last == 10.0 + float(kept_t.max())
+        np.testing.assert_array_equal(h.raw_scan_order(), order_ref.astype(np.uint32))
+        h.deskew_resident_offset(frames, L2B, x26, 0.0)
+        scans[label] = h.scan_get()
+        h.close()
+    np.testing.assert_array_equal(scans["records32"], scans["records16"])
+    np.testing.assert_array_equal(scans["records32"], kept_xyz[order_ref])                    # a body at rest: the points themselves, in time order
+    a, b = _lib.HipCtx(), _lib.HipCtx()
+    kept, _, _, _ = a.raw_scan_filter_order_set(rec16, 1 | 4, **cfg)
+    b.scan_adopt(a)
+    b.deskew_resident_offset(frames, L2B, x26, 0.0)
+    np.testing.assert_array_equal(b.scan_get(), scans["records32"])
+    np.testing.assert_array_equal(a.raw_scan_order(), order_ref.astype(np.uint32))           # the time order stays with the context that made it
+    with pytest.raises(_lib.FlimoError):
+        a.raw_scan_filter_order_set(rec16, 4, **dict(cfg, time_kind=2))                       # 16-byte records carry a 32-bit time word
+    a.close(); b.close()
+
+
+@pytest.mark.gpu
 def test_separate_dispatch_pass_is_bit_reproducible(built):
     """A pass that runs in separate dispatches (the first registration of a context, a poor prior: thousands of queries on the
     worklist) is three launches since round 4 -- k-NN, widening, fit + reduction; the widening deals the worklist out dynamically
