@@ -1336,14 +1336,15 @@ __global__ __launch_bounds__(256) KNN_WPE void knn5_kernel(GridView G, const flo
 // its own; a later launch of a pass whose first one waited): plain loads.  Otherwise a resident workgroup publishes it while this
 // launch is already placed: one thread polls head.epoch in device memory (s_sleep between looks, bounded by the wall clock), then
 // the workgroup reads the head past the caches.  nullptr: the chain has ended (or the wait ran out): leave.
-__device__ __forceinline__ const ChainHead* chain_enter(const ChainHead* __restrict__ H, unsigned int wait_epoch, unsigned int end_code) {
+__device__ __forceinline__ const ChainHead* chain_enter(const ChainHead* __restrict__ H, unsigned int wait_epoch, unsigned int end_code,
+                                                        ChainState* stamps_of) {
   constexpr int NW = (int)(sizeof(ChainHead) / 4);
   __shared__ unsigned int s_head[NW];
   __shared__ int s_go;
   if (wait_epoch != 0u) {
     if (threadIdx.x == 0) {
       const unsigned long long t0 = wall_clock64();
-      ChainState* dbgS = blockIdx.x == 0 ? const_cast<ChainState*>(reinterpret_cast<const ChainState*>(H)) : nullptr;
+      ChainState* dbgS = blockIdx.x == 0 ? stamps_of : nullptr;      // (developer stamps: only a chain's head is part of a ChainState)
       if (dbgS) dbgS->stamps[wait_epoch % CH_MAX_PASSES][0] = t0;
       int go = 0;
       // (the algebra takes a few microseconds from the moment the last pass delivered: hundreds of workgroups looking at one word
@@ -1379,7 +1380,7 @@ __global__ __launch_bounds__(256) KNN_WPE void knn5_chain_kernel(GridView G, con
                                                    int* __restrict__ wl, int* __restrict__ wl_count,
                                                    unsigned long long* __restrict__ cand_total, int prev_valid, unsigned probe_min, int tail,
                                                    FuseArgs fa, unsigned int wait_epoch) {
-  const ChainHead* Lh = chain_enter(H, wait_epoch, fa.ch.end_code);
+  const ChainHead* Lh = chain_enter(H, wait_epoch, fa.ch.end_code, fa.ch.S);
   if (!Lh) return;
   knn5_pass<L, SLOTS, FUSE, FINE>(G, scan_sorted, n, Lh->pose, max_ring, nbr, wl, wl_count, cand_total, Lh->prev_RT, prev_valid, probe_min, tail, fa);
 }
