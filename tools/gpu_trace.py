@@ -37,7 +37,7 @@ for it in range(6):
         ctx.scan_set(scan)
     ctx.match_reduce(x0, mcfg)
 names = {0: ["start", "query loaded", "row bounds loaded", "candidates done", "merged", "stored (tail done)"],
-         1: ["start", "scan+nbr loaded", "5 points gathered", "row computed", "partial stored", "ticket taken",
+         1: ["start", "scan+nbr loaded / fused: fit starts", "5 points gathered", "row computed", "partial stored", "ticket taken",
              "LAST: partials summed", "LAST: published"]}
 nblk = {0: (scan.shape[0] * int(os.environ.get("FLIMO_LPQ", 2)) + 255) // 256,
         1: (scan.shape[0] + 255) // 256}
@@ -55,7 +55,7 @@ for k in (0, 1):
         buf = np.zeros(nb * 8, np.uint64)
         assert lib.flimo_trace_read(1, buf.ctypes.data, buf.size) == 0
         t = buf.reshape(nb, 8).astype(np.int64)
-        t[:, 0:4] = 0
+        t[:, 0] = 0; t[:, 2] = 0
     t0 = t0_knn if fused else t[:, 0].min()
     print("kernel", "knn5" if k == 0 else "fit", "blocks", nb, " (100 MHz clock: 0.01 us resolution)")
     for s, nm in enumerate(names[k]):
