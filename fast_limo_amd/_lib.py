@@ -82,7 +82,7 @@ HIP_SYMBOLS = [
     "flimo_scan_to_world", "flimo_scan_clouds", "flimo_upload_stage", "flimo_match_reduce_overlap", "flimo_map_add_scan",
     "flimo_set_timing", "flimo_set_timing_stride", "flimo_pass_count", "flimo_fused_pass_count", "flimo_tie_stats", "flimo_list_stats", "flimo_set_lists", "flimo_fine_stats", "flimo_map_grid_selfcheck", "flimo_set_debug_records", "flimo_set_lanes_per_query", "flimo_last_kernel_ms",
     "flimo_last_candidates_per_query", "flimo_last_widen_count", "flimo_last_stragglers", "flimo_timing_totals", "flimo_timing_split", "flimo_set_path_switches", "flimo_set_wait_timeout_ms", "flimo_insert_rule_replay", "flimo_plane_fit5_host", "flimo_plane_eval5_host", "flimo_calculate_H_host",
-    "flimo_update_chain", "flimo_chain_stats", "flimo_set_update_mode", "flimo_update_mode", "flimo_scan_adopt", "flimo_chain_stamps", "flimo_set_pass_pipeline", "flimo_pass_pipeline_end", "flimo_pass_pipeline_stats",
+    "flimo_update_chain", "flimo_chain_stats", "flimo_set_update_mode", "flimo_update_mode", "flimo_scan_adopt", "flimo_set_pass_pipeline", "flimo_pass_pipeline_end", "flimo_pass_pipeline_stats",
 ]
 
 _hip = None
@@ -165,7 +165,6 @@ def load_hip():
     L.flimo_raw_scan_order.argtypes = [vp, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.flimo_deskew_resident_offset.argtypes = [vp, C.c_void_p, C.c_size_t, np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS"),
                                                np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS"), C.c_double]
-    L.flimo_chain_stamps.argtypes = [vp, C.POINTER(C.c_ulonglong)]
     L.flimo_set_pass_pipeline.argtypes = [vp, C.c_int]
     L.flimo_pass_pipeline_end.argtypes = [vp]
     L.flimo_pass_pipeline_stats.argtypes = [vp, C.POINTER(C.c_ulonglong)]
@@ -465,11 +464,6 @@ class HipCtx:
         o = (C.c_ulonglong * 2)()
         self._chk(self._L.flimo_pass_pipeline_stats(self._h, o))
         return dict(published=int(o[0]), cancelled=int(o[1]))
-
-    def chain_stamps(self):
-        out = np.zeros(48, np.uint64)
-        self._chk(self._L.flimo_chain_stamps(self._h, out.ctypes.data_as(C.POINTER(C.c_ulonglong))))
-        return out.reshape(12, 4)
 
     def chain_stats(self, reset=False):
         o = np.zeros(5)

@@ -242,11 +242,6 @@ struct flimo_ctx {
   ChainHead* d_pipe_head = nullptr;      // fine-grained device memory (host-writable); nullptr: not available on this system
   unsigned int pipe_tag = 0;
   unsigned long long pipe_published = 0, pipe_cancelled = 0;   // statistics
-  bool chain_resident = false;           // FLIMO_CHAIN_RESIDENT=1: ONE resident workgroup runs every iteration's algebra beside the chain's passes (flimo_chain.h)
-  hipStream_t stream2 = nullptr;         // ... on this stream
-  hipEvent_t timeout_ev2 = nullptr;
-  bool chain_inline = false;             // FLIMO_CHAIN_INLINE=1: the measurement-dependent half of an iteration inside the pass's reducing launch (run by the
-                                         // workgroup that completes it) instead of a one-workgroup launch of its own behind the pass
   // Which way the iterated update runs: the chain costs about 11 us per pass on top of the pass's kernels whatever the host (the
   // algebra launch and two dispatch boundaries); the host loop costs this host's launch -> result round trip + 2-3 us of algebra --
   // 9 us on a fast host, 15-19 us on a slow one (BENCH_r03: 5 497 scans/s where the builder's box gave 7 102).  The round trip is
@@ -333,14 +328,8 @@ static int ensure_dev(flimo_ctx* c, T*& p, size_t& cap, size_t need, bool keep, 
 //   FLIMO_HOST_UPDATE=<1|0>       the iterated update runs as a host loop over single passes / as a chain queued at once (flimo_update_chain),
 //                                 whatever the host (default: chosen by the launch -> result round trip measured at context creation)
 //   FLIMO_RTT_THRESHOLD_US=<us>   ... the round trip above which the chain is chosen (8)
-//   FLIMO_CHAIN_INLINE=1          chained update: the filter's measurement-dependent half inside the pass's reducing launch, run by the
-//                                 workgroup that completes it (default: a one-workgroup launch of its own behind each pass -- the same
-//                                 step time within 1 %, and the pass kernel's duration stays the pass's)
 //   FLIMO_PIPELINE=0              host loop: no pass is queued ahead of the filter's algebra (default: the next one-launch pass waits on the
 //                                 GPU for its pose, which the host stores into device memory)
-//   FLIMO_CHAIN_RESIDENT=1        chained update: one resident workgroup, launched beside the chain on a stream of its own, runs every
-//                                 iteration's algebra; the passes' workgroups wait for their constants in device memory (no dispatch
-//                                 boundary on either side of the algebra)
 //   FLIMO_LISTS=0                 no neighbour lists handed from pass to pass (every pass searches for every query)
 //   FLIMO_LISTS_FIRST=1           the first pass of a scan leaves lists too;  FLIMO_LIST_MARGIN=<m, 0.10> slack a list-leaving search adds
 //   FLIMO_PROF_PASS / FLIMO_PROF_INSERT   host-side timing prints (stderr)
@@ -370,9 +359,7 @@ static void load_dev_switches(flimo_ctx* c) {
   if (env_int("FLIMO_LAZY_DESKEW", v)) c->lazy_deskew = v != 0;
   if (env_int("FLIMO_HOST_UPDATE", v)) c->update_mode = v != 0 ? 1 : 2;
   { const char* e = getenv("FLIMO_RTT_THRESHOLD_US"); if (e && atof(e) > 0) c->rtt_threshold_us = atof(e); }
-  if (env_int("FLIMO_CHAIN_INLINE", v)) c->chain_inline = v != 0;
   if (env_int("FLIMO_PIPELINE", v)) { c->pipeline = v != 0; c->pipeline_env = true; }
-  if (env_int("FLIMO_CHAIN_RESIDENT", v)) c->chain_resident = v != 0;
   if (env_int("FLIMO_LISTS", v)) c->lists_on = v != 0;
   if (env_int("FLIMO_LISTS_FIRST", v)) c->lists_first = v != 0;
   { const char* e = getenv("FLIMO_LIST_MARGIN"); if (e && atof(e) >= 0) c->list_margin = (float)atof(e); }
@@ -532,8 +519,6 @@ extern "C" void flimo_ctx_destroy(flimo_ctx* c) {
   if (c->h_wl_count) (void)hipHostFree(c->h_wl_count);
   if (c->d_pipe_head) (void)hipFree(c->d_pipe_head);
   if (c->d_frames_fg) (void)hipFree(c->d_frames_fg);
-  if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
-  if (c->timeout_ev2) (void)hipEventDestroy(c->timeout_ev2);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->book) insert_book_destroy(c->book);
   c->gbook.release();
@@ -1616,8 +1601,6 @@ static int gate_rings(const flimo_ctx* c, double max_dist_plane) {
 static int abandon_wait(flimo_ctx* c, const char* what, unsigned long long id) {
   if (!c->timeout_ev) (void)hipEventCreateWithFlags(&c->timeout_ev, hipEventDisableTiming);
   if (c->timeout_ev && hipEventRecord(c->timeout_ev, c->stream) == hipSuccess) c->timeout_pending = true;
-  if (!c->timeout_ev2) (void)hipEventCreateWithFlags(&c->timeout_ev2, hipEventDisableTiming);
-  if (c->timeout_ev2 && c->stream2) (void)hipEventRecord(c->timeout_ev2, c->stream2);          // (a resident algebra workgroup may still be waiting)
   c->prev.valid = 0;
   return fail(c, FLIMO_ERR_TIMEOUT, "%s %llu did not publish its result within %d ms (kernels still running)", what, id, c->wait_timeout_ms);
 }
@@ -1672,7 +1655,6 @@ static inline bool auto_host_update(const flimo_ctx* c) {
 static int check_abandoned(flimo_ctx* c) {
   if (!c->timeout_pending) return FLIMO_OK;
   hipError_t q = hipEventQuery(c->timeout_ev);
-  if (q == hipSuccess && c->timeout_ev2 && c->stream2) q = hipEventQuery(c->timeout_ev2);
   if (q == hipErrorNotReady) return fail(c, FLIMO_ERR_TIMEOUT, "the launches of an earlier pass whose wait ran out are still running");
   c->timeout_pending = false;
   if (q != hipSuccess) return fail(c, FLIMO_ERR_HIP, "an abandoned pass failed: %s", hipGetErrorString(q));
@@ -2143,14 +2125,6 @@ extern "C" int flimo_set_update_mode(flimo_ctx* c, int mode) {
   c->host_update = mode == 1 || (mode == 0 && auto_host_update(c));
   return FLIMO_OK;
 }
-// developer timing of the resident form of the chain (flimo_chain.h: ChainState::stamps): CH_MAX_PASSES x 4 wall-clock ticks (100 MHz)
-extern "C" int flimo_chain_stamps(flimo_ctx* c, unsigned long long* out48) {
-  if (!c || !out48) return FLIMO_ERR_INVALID;
-  ctx_enter(c);
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  HIPCHK(c, hipMemcpy(out48, reinterpret_cast<const char*>(c->d_chain) + offsetof(ChainState, stamps), sizeof(unsigned long long) * CH_MAX_PASSES * 4, hipMemcpyDeviceToHost));
-  return FLIMO_OK;
-}
 extern "C" int flimo_set_pass_pipeline(flimo_ctx* c, int on) {
   if (!c) return FLIMO_ERR_INVALID;
   cancel_prelaunch(c);
@@ -2257,19 +2231,7 @@ extern "C" int flimo_update_chain(flimo_ctx* c, const flimo_match_cfg* cfg, flim
   ctl.res = reinterpret_cast<double2*>(c->d_chain_res);
   ctl.log = io->want_log ? reinterpret_cast<double2*>(c->d_chain_log) : nullptr;
   ctl.tag = tag;
-  ctl.ticket3 = c->d_ticket + FIT_GROUPS + 1;
-  ctl.inline_alg = c->chain_inline ? 1 : 0;
-  const bool resident = c->chain_resident && !c->chain_inline;
-  ctl.resident = resident ? 1 : 0;
   ctl.end_code = 0x80000000u | (unsigned int)(tag & 0x7fffffffull);
-  if (resident && !c->stream2) HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));   // (made on first use: a process has few hardware queues)
-  if (resident) {
-    // the algebra's workgroup first: it holds its place on the GPU while the passes run (ticket3 is zero: the last chain's hand-back
-    // re-armed it before it published its result)
-    ChainCtl rc = ctl;
-    rc.prior = nullptr;
-    launch_ieskf_resident(c->stream2, rc, seq0, n_pass, P0.RT, c->wait_timeout_ms > 0 ? c->wait_timeout_ms : 2000);
-  }
   for (int i = 0; i < n_pass; i++) {
     const unsigned long long seq = seq0 + 1 + (unsigned long long)i;
     const bool first_pass = !prev_valid;
@@ -2298,8 +2260,7 @@ extern "C" int flimo_update_chain(flimo_ctx* c, const flimo_match_cfg* cfg, flim
       if (ls.build) { lists_now = true; if (lists_from < 0) lists_from = i; }
     }
     const ListCtl* lsp = ls.recs ? &ls : nullptr;
-    // resident algebra: the FIRST launch of a later pass waits (in device memory) for this pass's constants
-    unsigned int wait_epoch = (resident && i > 0) ? ch_epoch_of(seq) : 0u;
+    unsigned int wait_epoch = 0u;                 // (the algebra launch queued before this pass has stored its constants)
     if (after_fine) {
       launch_knn5_fine(c->stream, c->fine, c->d_scan_sorted, n_all, P0, c->d_nbr, pv, c->fine_qlo, c->fine_qhi, &tl, seq, ch, wait_epoch, ctl.end_code);
       wait_epoch = 0u;
@@ -2319,8 +2280,7 @@ extern "C" int flimo_update_chain(flimo_ctx* c, const flimo_match_cfg* cfg, flim
                     c->d_ticket, c->d_wl_count, seq, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr, &tl, ch, &ctl, bookp);
       }
     }
-    if (!c->chain_inline && !resident)
-      launch_ieskf(c->stream, ctl, seq, i == 0 ? P0.RT : nullptr, ev ? ev[4] : nullptr, ev ? ev[5] : nullptr);
+    launch_ieskf(c->stream, ctl, seq, i == 0 ? P0.RT : nullptr, ev ? ev[4] : nullptr, ev ? ev[5] : nullptr);
     prev_valid = c->prune;
   }
   HIPCHK(c, hipGetLastError());
@@ -2404,7 +2364,6 @@ extern "C" int flimo_update_chain(flimo_ctx* c, const flimo_match_cfg* cfg, flim
   if (io->reason == CH_R_FAILED) {
     c->prev.valid = 0;
     (void)hipStreamSynchronize(c->stream);
-    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     (void)hipMemsetAsync(c->d_ticket, 0, (FIT_GROUPS + 2) * sizeof(unsigned int), c->stream);
     (void)hipStreamSynchronize(c->stream);
     return fail(c, FLIMO_ERR_HIP, "a pass of the update chain did not publish its sums");
@@ -2435,7 +2394,7 @@ extern "C" int flimo_update_chain(flimo_ctx* c, const flimo_match_cfg* cfg, flim
       c->split_knn_ms += ms; c->split_fit_ms += ms2; c->split_widen_ms += msw; c->split_sep_n++; c->tot_fit_ms += ms2; c->tot_widen_ms += msw;
       c->last_fit_ms = ms2; c->last_widen_ms = msw;
     }
-    if (!c->chain_inline && !c->chain_resident) { c->chain_alg_ms += elapsed(ev[4], ev[5]); c->chain_alg_n++; }
+    c->chain_alg_ms += elapsed(ev[4], ev[5]); c->chain_alg_n++;
     c->tot_passes++; c->tot_queries += n_all;
   }
   return FLIMO_OK;

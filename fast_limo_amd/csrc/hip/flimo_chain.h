@@ -6,9 +6,9 @@
 //   * one extra workgroup of the pass's reducing launch computes the half that does not depend on the measurement (x boxminus x_prop,
 //     the covariance through the manifold blocks, :1652-1697) while the other workgroups search and fit;
 //   * a one-workgroup launch behind the pass (ieskf_kernel, flimo_ieskf.hip) goes on from the pass's 91 sums to the gain, the step,
-//     boxplus and the convergence test (:1722-1764) and leaves the next pass's float32 pose constants in device memory.  With
-//     inline_alg the workgroup that completes the reducing launch (the last one to arrive at a ticket) does that itself: no dispatch
-//     in between, at the price of a longer pass kernel (FLIMO_CHAIN_INLINE=1; measured 1 us per step apart).
+//     boxplus and the convergence test (:1722-1764) and leaves the next pass's float32 pose constants in device memory.  (Rounds 4
+//     also ran that half inside the reducing launch and in one resident workgroup beside the chain; neither beat the launch of its
+//     own by more than 1 %, profiles/r04/withdrawn_experiments.md, and both were removed in round 5.)
 // Every launch of a later pass reads its pose from there and leaves at once when the chain has ended.  The chain ends by handing the
 // loop back to the host filter: at the iteration whose covariance update is due (:1764-1820: the host runs that one iteration from
 // the sums the device hands over -- no further pass), or earlier at a branch the device does not run (M < 23, a degenerate H^T H,
@@ -26,7 +26,7 @@ struct ChainHead {
   PoseMats pose;           // float32 constants of the NEXT pass (State casts, get_RT / get_RT_inv / get_extr_RT_inv, calculate_H's rotations)
   float prev_RT[16];       // body -> world of the pass just completed: the next pass's pruning bound is relative to it
   int status;              // 0: the chain goes on; 2: handed back to the host filter
-  unsigned int epoch;      // resident algebra: number (low 32 bits) of the pass these constants are FOR -- written last, behind them
+  unsigned int epoch;      // pipelined host loop: number (low 32 bits) of the pass these constants are FOR -- written last, behind them
   int pad[2];
 };
 static_assert(sizeof(ChainHead) % 4 == 0 && sizeof(ChainHead) / 4 <= 128, "a pass workgroup reads the head with one load per thread");
@@ -60,9 +60,6 @@ struct ChainState {
   double info[3 * CH_MAX_PASSES];   // per pass: M, stragglers, ties
   double pre_dxn[23];      // the measurement-independent half of the CURRENT iteration (extra workgroup of its pass):
   double pre_AG[276];      // dx_new; A11^-1 (144) and G2 = A21 A11^-1 (132) of A = P_ / R
-  // developer timing of the resident form (100 MHz wall clock; slot = pass number modulo CH_MAX_PASSES): [0] the pass's first
-  // workgroup starts waiting, [1] it has its constants, [2] the algebra has seen the pass's arrivals, [3] it has published
-  unsigned long long stamps[CH_MAX_PASSES][4];
 };
 
 // Arguments of the algebra inside a pass's reducing launch (S == nullptr: a host-driven pass)
@@ -73,11 +70,7 @@ struct ChainCtl {
   double2* res;                // mapped host memory: CH_RES result granules {value, tag}
   double2* log;                // mapped host memory: per-pass log (or nullptr)
   unsigned long long tag;      // tag of this scan's chain
-  unsigned int* ticket3;       // "sums published / pre-part stored" ticket: FIT_GROUPS + 1 arrivals per launch
-  int inline_alg;              // 0 (default): the algebra is a launch of its own (flimo_ieskf.hip); 1: the completing workgroup runs it
-  unsigned int end_code;       // resident algebra: head.epoch takes this value (top bit set, the chain's tag below) when the chain has ended
-  int resident;                // 1: ONE workgroup launched beside the chain runs every iteration's algebra (ieskf_resident_kernel): the
-                               // reducing launches only count their arrivals at ticket3, the next pass's workgroups wait for head.epoch
+  unsigned int end_code;       // a pass queued ahead of its pose (pipelined host loop): head.epoch takes this value (top bit set) when it is told to leave
 };
 
 // Results: 16-byte granules {value, tag} in mapped host memory (data and "ready" travel together, like a pass's sums)
@@ -92,15 +85,10 @@ constexpr int CH_R_FEW = 1, CH_R_TIES = 2, CH_R_DEGENERATE = 3, CH_R_FAILED = 4,
 constexpr int CH_LOGN = 144 + 12 + 23 + 26;
 
 size_t chain_state_size();
-// the algebra as a launch of its own behind the pass (inline_alg = 0).  gran: the pass's granules in device memory.
+// the algebra as a launch of its own behind the pass.  gran: the pass's granules in device memory.
 void launch_ieskf(hipStream_t st, const ChainCtl& ch, unsigned long long seq, const float* used_RT_host_or_null,
                   hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 void launch_ieskf_extra(hipStream_t st, const ChainCtl& ch, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);   // developer tool
-// The resident form: one workgroup for the whole chain, launched on a stream of its own BEFORE the chain's passes.  Iteration i waits
-// for the (FIT_GROUPS + 1) (i + 1) arrivals of pass i at ticket3 (zero when the chain starts; the kernel re-arms it when it leaves),
-// runs the algebra and publishes the next pass's constants under head.epoch = that pass's number (31 bits), or ch.end_code when the
-// loop goes back to the host; a pass's workgroups poll that word in device memory.  Every wait is bounded by the wall clock (wait_ms): a pass that never arrives ends the chain with reason FAILED.
-void launch_ieskf_resident(hipStream_t st, const ChainCtl& ch, unsigned long long seq0, int n_pass, const float* first_RT_host, int wait_ms);
 // head.epoch of the pass numbered seq: never zero (zero means "do not wait"), top bit clear (set: an end code)
 __host__ __device__ inline unsigned int ch_epoch_of(unsigned long long seq) { return (unsigned int)(seq & 0x3fffffffull) | 0x40000000u; }
 constexpr int CH_POLL_MS = 50;           // a pass's workgroups give up waiting for their constants after this long (status FAILED)

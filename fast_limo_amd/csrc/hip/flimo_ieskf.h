@@ -649,20 +649,10 @@ __device__ __forceinline__ void ik_hand_back(const ChainCtl& ch, double* lds, in
   }
   if (tid >= 96 && tid < 96 + IK_LIVE) ik_put(ch.res, CH_SUMS + tid - 96, live[tid - 96], ch.tag);
   if (tid == 224) {
-    if (ch.resident) {
-      // the arrival counter is re-armed BEFORE the result is out: the host may queue the next chain the moment it has it (every
-      // workgroup that will ever arrive for this chain has; passes queued behind the end leave without arriving)
-      __hip_atomic_store(ch.ticket3, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
     ik_put(ch.res, CH_BAIL, (double)reason, ch.tag); ik_put(ch.res, CH_PASSES, (double)passes, ch.tag);
     ik_put(ch.res, CH_IT, (double)it, ch.tag); ik_put(ch.res, CH_T, (double)t, ch.tag);
     ik_put(ch.res, CH_STATUS, 2.0, ch.tag);
     ik_sti(&S->head.status, 2);
-    if (ch.resident) {                                          // the queued passes' workgroups are polling this word: they leave
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(&S->head.epoch, ch.end_code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
   }
 }
 
@@ -884,12 +874,6 @@ __device__ __forceinline__ bool ik_final_stage(const ChainCtl& ch, unsigned long
   ik_store_pose(xn, &S->head, tid);
   if (tid == 32) { ik_sti(&S->head.status, 0); ik_sti(&S->it, it + 1); ik_sti(&S->t, t_out); ik_sti(&S->passes, passes + 1); }
   if (tid >= 96 && tid < 96 + 26) ik_st(&S->x[tid - 96], xn[tid - 96]);
-  if (ch.resident) {
-    // the next pass's workgroups are waiting for this word: everything above is performed first
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) __hip_atomic_store(&S->head.epoch, ch_epoch_of(seq + 1ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
   IK_STAMP(10);
   return true;
 }

@@ -887,28 +887,7 @@ __device__ __forceinline__ void fit_reduce_publish(const float (&v)[16], bool ow
                                                    double* sa2, double* sa3, unsigned int* s_last, const FitIdx& idx,
                                                    double* __restrict__ partials, double2* __restrict__ out_granules,
                                                    unsigned int* __restrict__ ticket, int* __restrict__ wl_count,
-                                                   unsigned long long seq, const TieList& tl, int blk = -1, int nblk = -1,
-                                                   const ChainCtl* chp = nullptr, const float* used_RT = nullptr, double* big_lds = nullptr);
-// A workgroup of a chained pass has done its share of the launch (a reduction group's sums published / the measurement-independent
-// half stored; all written through, performed): FIT_GROUPS + 1 of them arrive here, the last one runs the filter's algebra.
-// Workgroup-wide; s_flag: a word of shared memory.
-__device__ __forceinline__ void chain_arrive(const ChainCtl& ch, unsigned long long seq, const float* used_RT, double* big_lds,
-                                             unsigned int* s_flag) {
-  if (ch.resident) {                                   // a resident workgroup runs the algebra: it counts the arrivals
-    if (threadIdx.x == 0) (void)__hip_atomic_fetch_add(ch.ticket3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return;
-  }
-  if (!ch.inline_alg) return;                          // the algebra is a launch of its own
-  if (threadIdx.x == 0) {
-    const unsigned int old = __hip_atomic_fetch_add(ch.ticket3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *s_flag = (old == (unsigned int)FIT_GROUPS) ? 1u : 0u;
-    if (old == (unsigned int)FIT_GROUPS) __hip_atomic_store(ch.ticket3, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch
-  }
-  __syncthreads();
-  if (*s_flag == 0u) return;
-  int* s_i = reinterpret_cast<int*>(big_lds + IKL_END);
-  ik_final_stage<false>(ch, seq, used_RT, big_lds, s_i, (int)threadIdx.x);
-}
+                                                   unsigned long long seq, const TieList& tl, int blk = -1, int nblk = -1);
 FLIMO_DEV void fit_row(const GridView& G, const PoseMats& P, const MatchParams& mp, const int (&ids)[5], float gx, float gy, float gz,
                        float (&v)[16]);
 
@@ -977,7 +956,6 @@ __device__ __forceinline__ void knn5_pass(const GridView& G, const float4* __res
       if ((int)blockIdx.x == nb) {
         double* big = reinterpret_cast<double*>(s_w);
         ik_extra_block(fa.ch, big, (int)threadIdx.x);
-        chain_arrive(fa.ch, fa.seq, P.RT, big, &s_last);
         return;
       }
     }
@@ -1477,8 +1455,7 @@ __device__ __forceinline__ void knn5_pass(const GridView& G, const float4* __res
     TRACE(1, 3);
     wave_lds_sync();                                           // every lane is done with W.res before the tile overwrites the tables
     fit_reduce_publish<64 / L>(v, sub == 0, lane / L, W.tile, s_w[0].acc, s_w[1].acc, s_w[2].acc, s_w[3].acc, &s_last, fa.idx,
-                               fa.partials, fa.granules, fa.ticket, wl_count, fa.seq, tl, (int)blockIdx.x, nb, &fa.ch, P.RT,
-                               reinterpret_cast<double*>(s_w));
+                               fa.partials, fa.granules, fa.ticket, wl_count, fa.seq, tl, (int)blockIdx.x, nb);
   }
 }
 
@@ -1495,16 +1472,13 @@ __global__ __launch_bounds__(256) KNN_WPE void knn5_kernel(GridView G, const flo
 // its own; a later launch of a pass whose first one waited): plain loads.  Otherwise a resident workgroup publishes it while this
 // launch is already placed: one thread polls head.epoch in device memory (s_sleep between looks, bounded by the wall clock), then
 // the workgroup reads the head past the caches.  nullptr: the chain has ended (or the wait ran out): leave.
-__device__ __forceinline__ const ChainHead* chain_enter(const ChainHead* __restrict__ H, unsigned int wait_epoch, unsigned int end_code,
-                                                        ChainState* stamps_of) {
+__device__ __forceinline__ const ChainHead* chain_enter(const ChainHead* __restrict__ H, unsigned int wait_epoch, unsigned int end_code) {
   constexpr int NW = (int)(sizeof(ChainHead) / 4);
   __shared__ unsigned int s_head[NW];
   __shared__ int s_go;
   if (wait_epoch != 0u) {
     if (threadIdx.x == 0) {
       const unsigned long long t0 = wall_clock64();
-      ChainState* dbgS = blockIdx.x == 0 ? stamps_of : nullptr;      // (developer stamps: only a chain's head is part of a ChainState)
-      if (dbgS) dbgS->stamps[wait_epoch % CH_MAX_PASSES][0] = t0;
       int go = 0;
       // (the algebra takes a few microseconds from the moment the last pass delivered: hundreds of workgroups looking at one word
       //  every 60 ns would stand in its way -- a first look, a nap of 1.5 us (the host's algebra of a pipelined loop takes two),
@@ -1517,7 +1491,6 @@ __device__ __forceinline__ const ChainHead* chain_enter(const ChainHead* __restr
         if (look == 0) __builtin_amdgcn_s_sleep(48);
         else __builtin_amdgcn_s_sleep(8);
       }
-      if (dbgS) dbgS->stamps[wait_epoch % CH_MAX_PASSES][1] = wall_clock64();
       s_go = go;
     }
     __syncthreads();
@@ -1539,7 +1512,7 @@ __global__ __launch_bounds__(256) KNN_WPE void knn5_chain_kernel(GridView G, con
                                                    int* __restrict__ wl, int* __restrict__ wl_count,
                                                    unsigned long long* __restrict__ cand_total, int prev_valid, unsigned probe_min, int tail,
                                                    FuseArgs fa, unsigned int wait_epoch) {
-  const ChainHead* Lh = chain_enter(H, wait_epoch, fa.ch.end_code, fa.ch.S);
+  const ChainHead* Lh = chain_enter(H, wait_epoch, fa.ch.end_code);
   if (!Lh) return;
   knn5_pass<L, SLOTS, FUSE, FINE>(G, scan_sorted, n, Lh->pose, max_ring, nbr, wl, wl_count, cand_total, Lh->prev_RT, prev_valid, probe_min, tail, fa);
 }
@@ -1991,8 +1964,7 @@ __device__ __forceinline__ void fit_reduce_publish(const float (&v)[16], bool ow
                                                    double* sa2, double* sa3, unsigned int* s_last, const FitIdx& idx,
                                                    double* __restrict__ partials, double2* __restrict__ out_granules,
                                                    unsigned int* __restrict__ ticket, int* __restrict__ wl_count,
-                                                   unsigned long long seq, const TieList& tl, int blk, int nblk,
-                                                   const ChainCtl* chp, const float* used_RT, double* big_lds) {
+                                                   unsigned long long seq, const TieList& tl, int blk, int nblk) {
   // blk / nblk: this block's number among the launch's nblk fit blocks (-1: the whole launch consists of them)
   typedef double v2d_t __attribute__((ext_vector_type(2)));
   const int fb = blk < 0 ? (int)blockIdx.x : blk, fnb = nblk < 0 ? (int)gridDim.x : nblk;
@@ -2102,13 +2074,6 @@ __device__ __forceinline__ void fit_reduce_publish(const float (&v)[16], bool ow
       }
     }
     TRACE(1, 7);
-    if (chp && chp->S) {
-      // chained pass: this group's sums (and, from the launch's last arrival, the two counters) are on their way to the device copy
-      // of the granule slots; once they are performed the group arrives -- the last arrival of the launch goes on with the algebra
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      chain_arrive(*chp, seq, used_RT, big_lds, s_last);
-    }
   }
 }
 
@@ -2132,7 +2097,6 @@ __device__ __forceinline__ void fit2_pass(const GridView& G, const float4* __res
     if ((int)blockIdx.x == nb) {
       double* big = reinterpret_cast<double*>(&s_rec[0][0]);
       ik_extra_block(ch, big, (int)threadIdx.x);
-      chain_arrive(ch, seq, P.RT, big, &s_last);
       return;
     }
   }
@@ -2159,7 +2123,7 @@ __device__ __forceinline__ void fit2_pass(const GridView& G, const float4* __res
   }
   TRACE(1, 3);
   fit_reduce_publish<PPW>(v, lane < PPW, lane, s_rec[wave], s_acc[0], s_acc[1], s_acc[2], s_acc[3], &s_last, idx, partials,
-                          out_granules, ticket, wl_count, seq, tl, (int)blockIdx.x, nb, &ch, P.RT, reinterpret_cast<double*>(&s_rec[0][0]));
+                          out_granules, ticket, wl_count, seq, tl, (int)blockIdx.x, nb);
 }
 
 template <int PPW>

@@ -242,13 +242,9 @@ int flimo_update_chain(flimo_ctx* ctx, const flimo_match_cfg* cfg, flimo_chain_i
 int flimo_set_pass_pipeline(flimo_ctx* ctx, int on);
 int flimo_pass_pipeline_end(flimo_ctx* ctx);
 int flimo_pass_pipeline_stats(const flimo_ctx* ctx, unsigned long long out[2]);
-/* developer timing of a chained update whose algebra is resident (FLIMO_CHAIN_RESIDENT=1): 12 x 4 wall-clock ticks (100 MHz), slot =
- * pass number modulo 12: [0] the pass starts waiting for its constants, [1] it has them, [2] the algebra has seen the PREVIOUS pass's
- * arrivals, [3] it has published */
-int flimo_chain_stamps(flimo_ctx* ctx, unsigned long long* out48);
 int flimo_set_update_mode(flimo_ctx* ctx, int mode);
 int flimo_update_mode(const flimo_ctx* ctx, int* chained, double* launch_rtt_us);
-/* out[0] = GPU ms of the algebra launches timed so far (timing level 1; only with FLIMO_CHAIN_INLINE=0), out[1] = their number,
+/* out[0] = GPU ms of the algebra launches timed so far (timing level 1), out[1] = their number,
  * out[2] = chains run, out[3] = chains that came back before the final iteration, out[4] = chains declined */
 int flimo_chain_stats(flimo_ctx* ctx, double out[5], int reset);
 /* per-point records of the last flimo_match_reduce (first min(N, MAX_NUM_PC2MATCH) points) */

@@ -44,14 +44,4 @@ print("timed: one-launch pass %.2f us x %d, separate knn %.2f + second %.2f us x
     1e3 * d["fit_ms"] / max(d["separate_n"], 1), d["separate_n"], 1e3 * cs["algebra_ms"] / max(cs["algebra_n"], 1), cs["algebra_n"],
     cs["chains"], cs["handed_back"], cs["declined"]))
 loc.hip.set_timing(0)
-if os.environ.get("FLIMO_CHAIN_RESIDENT") == "1":
-    for _ in range(3):
-        reg()
-        st_ = loc.hip.chain_stamps().astype(np.int64)
-        rows = st_[np.argsort(st_[:, 0])]
-        rows = rows[rows[:, 0] > 0][-3:]
-        base = rows[0, 2]
-        print("resident stamps [us from the first arrival seen]: " + " | ".join(
-            "arrivals seen %.2f published %.2f (algebra %.2f)  pass waits from %.2f has constants %.2f" %
-            ((r[2] - base) / 100.0, (r[3] - base) / 100.0, (r[3] - r[2]) / 100.0, (r[0] - base) / 100.0, (r[1] - base) / 100.0) for r in rows))
 loc.close()

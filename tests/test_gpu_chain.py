@@ -130,34 +130,6 @@ def test_raw_chain_entry_point(built):
     h.close()
 
 
-def test_the_three_places_of_the_algebra_are_bit_equal(built, monkeypatch):
-    """The measurement-dependent half of an iteration runs as a one-workgroup launch behind the pass (default), inside the pass's
-    reducing launch (FLIMO_CHAIN_INLINE=1), or in ONE resident workgroup beside the whole chain whose passes wait for their constants
-    in device memory (FLIMO_CHAIN_RESIDENT=1) -- the same routine: the same bits."""
-    from fast_limo_amd import api
-    mp, scan5, imu = cfg1_scene(n_map=200000, n_scan=16384, L=40.0)
-    out = []
-    for inline, resident in (("1", "0"), ("0", "0"), ("0", "1")):
-        monkeypatch.setenv("FLIMO_CHAIN_INLINE", inline)
-        monkeypatch.setenv("FLIMO_CHAIN_RESIDENT", resident)
-        try:
-            D = _localizer(False)
-        finally:
-            monkeypatch.delenv("FLIMO_CHAIN_INLINE")
-            monkeypatch.delenv("FLIMO_CHAIN_RESIDENT")
-        D.set_flags(add_to_map=False, keep_log=True)
-        assert drive_two_scans(D, mp, scan5, imu) == [1, 0]
-        assert D.hip.chain_stats()["chains"] >= 1
-        out.append((D.get_x().copy(), D.get_P().copy(), [p["dx"] for p in D.passes()]))
-        D.close()
-    for other in out[1:]:
-        np.testing.assert_array_equal(out[0][0], other[0])
-        np.testing.assert_array_equal(out[0][1], other[1])
-        assert len(out[0][2]) == len(other[2]) >= 2
-        for a, b in zip(out[0][2], other[2]):
-            np.testing.assert_array_equal(a, b)
-
-
 def test_pipelined_host_loop_is_bit_equal_and_lets_its_last_pass_go(built, monkeypatch):
     """Host loop, pipelined (flimo_set_pass_pipeline; fast_limo::Localizer switches it on): the next pass of an update waits on the GPU
     for its pose, which the next flimo_match_reduce stores into device memory instead of launching.  Same kernels, same inputs: state,

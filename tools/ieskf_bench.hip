@@ -72,11 +72,10 @@ int main(int argc, char** argv) {
   PoseMats P0; pose_from_x26(x, P0);
   double* res; CK(hipHostMalloc((void**)&res, CH_RES * 2 * sizeof(double), hipHostMallocMapped)); memset(res, 0, CH_RES * 2 * sizeof(double));
   double* lg; CK(hipHostMalloc((void**)&lg, CH_MAX_PASSES * CH_LOGN * 2 * sizeof(double), hipHostMallocMapped));
-  unsigned int* t3; CK(hipMalloc(&t3, 4)); CK(hipMemset(t3, 0, 4));
   hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   hipEvent_t e[16]; for (auto& v : e) CK(hipEventCreate(&v));
   ChainCtl ctl{};
-  ctl.S = S; ctl.gran = gran; ctl.res = (double2*)res; ctl.log = (double2*)lg; ctl.tag = tag; ctl.ticket3 = t3; ctl.inline_alg = 0;
+  ctl.S = S; ctl.gran = gran; ctl.res = (double2*)res; ctl.log = (double2*)lg; ctl.tag = tag;
   auto chain = [&](unsigned long long tg, bool log, bool ev) {
     for (int i = 0; i <= max_iter; i++) {
       ChainCtl c2 = ctl; c2.tag = tg; c2.log = log ? ctl.log : nullptr; c2.prior = i == 0 ? pr : nullptr;
