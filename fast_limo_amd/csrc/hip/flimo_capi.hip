@@ -67,18 +67,6 @@ struct flimo_ctx {
   float4* d_scan = nullptr;        // pc2match (body frame), caller order
   float4* d_scan_sorted = nullptr; // the same points in Morton order, w = original index
   void* d_nbr = nullptr;           // per-query neighbour records (sorted order)
-  // Neighbour lists handed from pass to pass of one scan (ListCtl, flimo_kernels.h): the second and later passes of an update take
-  // their five from the list the previous pass's search left, when the list proves them (FLIMO_LISTS=0 switches it off)
-  void* d_lists = nullptr;         // scan capacity x list_rec_size()
-  unsigned int* d_list_miss = nullptr;
-  bool lists_on = true;
-  int lists_first = 0;             // FLIMO_LISTS_FIRST=1: the first pass of a scan leaves lists too (pays when the prior is centimetres off)
-  float list_margin = 0.10f;       // FLIMO_LIST_MARGIN [m]: a search that leaves a list widens its pruning ball by this much
-  bool lists_built = false;        // the lists in d_lists belong to the resident scan ...
-  uint64_t lists_grid_version = 0; // ... and to this state of the map index (positions)
-  int lists_n = 0;
-  long last_list_miss = -1;        // queries the last pass searched for although it had lists (-1: the pass did not use lists)
-  unsigned long long list_passes = 0, list_queries = 0, list_misses = 0;
   int* d_wl = nullptr;             // worklist of queries that need the general ring search
   int* d_wl_count = nullptr;
   void* d_raw32 = nullptr;         // unfiltered sweep as 32-byte PointType records (flimo_raw_scan_filter_set)
@@ -235,7 +223,6 @@ struct flimo_ctx {
     uint64_t grid_version = 0;
     unsigned int end_code = 0;
     double t_launch = 0.0;
-    bool lists_use = false, lists_build = false;   // what its launch was told about the neighbour lists
   } pre;
   bool pipeline = false;                 // flimo_set_pass_pipeline (FLIMO_PIPELINE=0/1 presets it and wins)
   bool pipeline_env = false;
@@ -330,8 +317,6 @@ static int ensure_dev(flimo_ctx* c, T*& p, size_t& cap, size_t need, bool keep, 
 //   FLIMO_RTT_THRESHOLD_US=<us>   ... the round trip above which the chain is chosen (8)
 //   FLIMO_PIPELINE=0              host loop: no pass is queued ahead of the filter's algebra (default: the next one-launch pass waits on the
 //                                 GPU for its pose, which the host stores into device memory)
-//   FLIMO_LISTS=0                 no neighbour lists handed from pass to pass (every pass searches for every query)
-//   FLIMO_LISTS_FIRST=1           the first pass of a scan leaves lists too;  FLIMO_LIST_MARGIN=<m, 0.10> slack a list-leaving search adds
 //   FLIMO_PROF_PASS / FLIMO_PROF_INSERT   host-side timing prints (stderr)
 // (csrc/host: FLIMO_REFERENCE_SOLVE=1 literal two-inverse gain, FLIMO_SYNC_INSERT=1 map inserts on the caller's thread,
 //  FLIMO_PROF_DESKEW / FLIMO_PROF_CLOUDS timing prints; bench.py: FLIMO_BENCH_*.)
@@ -360,9 +345,6 @@ static void load_dev_switches(flimo_ctx* c) {
   if (env_int("FLIMO_HOST_UPDATE", v)) c->update_mode = v != 0 ? 1 : 2;
   { const char* e = getenv("FLIMO_RTT_THRESHOLD_US"); if (e && atof(e) > 0) c->rtt_threshold_us = atof(e); }
   if (env_int("FLIMO_PIPELINE", v)) { c->pipeline = v != 0; c->pipeline_env = true; }
-  if (env_int("FLIMO_LISTS", v)) c->lists_on = v != 0;
-  if (env_int("FLIMO_LISTS_FIRST", v)) c->lists_first = v != 0;
-  { const char* e = getenv("FLIMO_LIST_MARGIN"); if (e && atof(e) >= 0) c->list_margin = (float)atof(e); }
 }
 
 // ---- context ----------------------------------------------------------------------------------
@@ -409,8 +391,6 @@ extern "C" int flimo_ctx_create(int device, flimo_ctx** out) {
             hipMemset(c->d_tie_settled, 0, sizeof(unsigned long long)) == hipSuccess &&
             hipMalloc(&c->d_wl_count, sizeof(int)) == hipSuccess &&
             hipMemset(c->d_wl_count, 0, sizeof(int)) == hipSuccess &&
-            hipMalloc(&c->d_list_miss, sizeof(unsigned int)) == hipSuccess &&
-            hipMemset(c->d_list_miss, 0, sizeof(unsigned int)) == hipSuccess &&
             hipHostMalloc((void**)&c->h_wl_count, sizeof(int), hipHostMallocDefault) == hipSuccess &&
             hipHostMalloc((void**)&c->h_cand, sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess;
   if (!ok) { flimo_ctx_destroy(c); return FLIMO_ERR_HIP; }
@@ -490,7 +470,6 @@ extern "C" void flimo_ctx_destroy(flimo_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   (void)hipFree(c->d_map_raw); (void)hipFree(c->d_map_sorted); (void)hipFree(c->d_map_sorted2); (void)hipFree(c->d_cell_start); (void)hipFree(c->d_row_table);
   (void)hipFree(c->d_scan_sorted); (void)hipFree(c->d_nbr); (void)hipFree(c->d_wl); (void)hipFree(c->d_wl_count);
-  (void)hipFree(c->d_lists); (void)hipFree(c->d_list_miss);
   (void)hipFree(c->d_fit_partials); (void)hipFree(c->d_raw_sorted); (void)hipFree(c->d_t_sorted);
   (void)hipFree(c->d_scan); (void)hipFree(c->d_scan_raw); (void)hipFree(c->d_scan_world); (void)hipFree(c->d_scan_t);
   (void)hipFree(c->d_frames); (void)hipFree(c->d_recs); (void)hipFree(c->d_dbg);
@@ -1069,13 +1048,6 @@ static int ensure_scan(flimo_ctx* c, size_t n) {
   HIPCHK(c, hipMalloc(&so, cap * sizeof(float4)));
   HIPCHK(c, hipMalloc(&nb, cap * nbr_rec_size()));
   HIPCHK(c, hipMemsetAsync(nb, 0, cap * nbr_rec_size(), c->stream));      // flag 0 everywhere: no record is ever read uninitialised
-  {
-    void* ls = nullptr;
-    HIPCHK(c, hipMalloc(&ls, cap * list_rec_size()));
-    HIPCHK(c, hipMemsetAsync(ls, 0, cap * list_rec_size(), c->stream));     // R = 0 everywhere: empty lists
-    (void)hipFree(c->d_lists);
-    c->d_lists = ls; c->lists_built = false;
-  }
   HIPCHK(c, hipMalloc(&wl, (cap + 8192) * wl_entry_size()));   // + slack: every widening wave prefetches its first slot
   HIPCHK(c, hipMalloc(&fp, fpn * sizeof(double)));
   (void)hipFree(c->d_scan_sorted); (void)hipFree(c->d_nbr); (void)hipFree(c->d_wl); (void)hipFree(c->d_fit_partials);
@@ -1514,21 +1486,6 @@ extern "C" int flimo_fine_stats(const flimo_ctx* c, unsigned long long out[4]) {
   out[0] = c->fine_valid ? 1 : 0; out[1] = c->fine_valid ? c->fine.n_pts : 0; out[2] = c->fine_builds; out[3] = c->fine_passes;
   return FLIMO_OK;
 }
-extern "C" int flimo_list_stats(flimo_ctx* c, double out[4], int reset) {
-  if (!c || !out) return FLIMO_ERR_INVALID;
-  out[0] = (double)c->list_passes; out[1] = (double)c->list_queries; out[2] = (double)c->list_misses; out[3] = (double)c->last_list_miss;
-  if (reset) c->list_passes = c->list_queries = c->list_misses = 0;
-  return FLIMO_OK;
-}
-extern "C" int flimo_set_lists(flimo_ctx* c, int mode, float margin_m) {
-  if (!c || mode < 0 || mode > 2) return FLIMO_ERR_INVALID;
-  ctx_enter(c);                                       // (a pass queued ahead was told about the old setting)
-  c->lists_on = mode != 0;
-  c->lists_first = mode == 2;
-  c->lists_built = false;
-  if (margin_m >= 0.f) c->list_margin = margin_m;
-  return FLIMO_OK;
-}
 extern "C" int flimo_tie_stats(const flimo_ctx* c, unsigned long long out[2]) {
   if (!c || !out) return FLIMO_ERR_INVALID;
   out[0] = c->tie_redos; out[1] = c->tie_queries;
@@ -1862,20 +1819,6 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   const BookView* bookp = inline_ties ? &book : nullptr;
   // crowded regions first: the fine pre-pass settles the queries whose five lie within centimetres (second-level grid)
   const bool after_fine = c->fine_valid && c->lanes_per_query == 2 && mp.max_ring >= 1;
-  // neighbour lists (ListCtl): a pass that searches leaves them, the later passes of the same scan over the same index try them first
-  const bool use_fit2 = !want_recs && tlev < 2;                 // the per-pass fast path (granule results)
-  if (first_pass) c->lists_built = false;
-  ListCtl ls{};
-  if (c->lists_on && c->prune && c->d_lists && c->lanes_per_query == 2 && mp.max_ring >= 1 && mp.max_ring <= 3) {
-    ls.recs = c->d_lists;
-    ls.margin = c->list_margin;
-    ls.use = (c->lists_built && c->lists_grid_version == grid_version && c->lists_n == n_all) ? 1 : 0;
-    ls.build = (!first_pass || c->lists_first) ? 1 : 0;
-    ls.miss = (ls.use && use_fit2) ? c->d_list_miss : nullptr;
-    if (!ls.use && !ls.build) ls.recs = nullptr;
-  }
-  tl.aux = ls.miss;
-  const ListCtl* lsp = ls.recs ? &ls : nullptr;
   if (use_pre && !(fused && !after_fine && tlev == 0)) {
     // (what was queued ahead is a one-launch pass without a fine pre-pass and without timing events: anything else -- a straggler
     //  count that changed the layout, a sampled pass -- is launched the usual way)
@@ -1894,15 +1837,13 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   } else if (fused) {
     launch_match_fused(c->stream, c->grid, c->d_scan_sorted, n_all, P, mp, c->d_nbr, c->d_wl, c->d_wl_count, nullptr, c->prev,
                        c->live_idx, c->d_fit2_partials, c->d_granules_host, c->d_ticket, seq, tlev == 1 ? c->ev[0] : nullptr,
-                       tlev == 1 ? c->ev[1] : nullptr, &tl, after_fine ? 1 : 0, dkp, nullptr, nullptr, bookp, 0u, lsp);
+                       tlev == 1 ? c->ev[1] : nullptr, &tl, after_fine ? 1 : 0, dkp, nullptr, nullptr, bookp);
     c->fused_passes++;
   } else
   launch_knn5(c->stream, c->lanes_per_query, c->grid, c->d_scan_sorted, n_all, P, mp.max_ring, c->d_nbr, c->d_wl,
               c->d_wl_count, c->debug_recs ? c->d_cand : nullptr, c->prev, tail ? 1 : 0, tlev == 1 ? c->ev[0] : nullptr,
-              tlev == 1 ? c->ev[1] : nullptr, nullptr, &tl, after_fine ? 1 : 0, seq, dkp, nullptr, 0u, 0u, lsp);
+              tlev == 1 ? c->ev[1] : nullptr, nullptr, &tl, after_fine ? 1 : 0, seq, dkp);
   if (c->prune) { memcpy(c->prev.RT, P.RT, sizeof(c->prev.RT)); c->prev.valid = 1; }   // the records now belong to this pose
-  const bool ls_used = use_pre ? c->pre.lists_use : (ls.use != 0);
-  if (use_pre ? c->pre.lists_build : (ls.build != 0)) { c->lists_built = true; c->lists_grid_version = grid_version; c->lists_n = n_all; }
   const double tpb = prof ? now_us() : 0.0;
   if (tlev > 1) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
   // A separate-dispatch pass is three launches: k-NN, widening of the worklist (one wave per pending query, dealt out over the whole
@@ -1912,7 +1853,7 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   const bool widen_timed = !tail && tlev == 1 && mp.max_ring >= 2;
   if (!tail)
     launch_widen(c->stream, c->grid, c->d_scan_sorted, P, mp.max_ring, c->d_nbr, c->d_wl, c->d_wl_count,
-                 c->debug_recs ? c->d_cand : nullptr, widen_timed ? c->ev[4] : nullptr, widen_timed ? c->ev[5] : nullptr, &tl, nullptr, lsp);
+                 c->debug_recs ? c->d_cand : nullptr, widen_timed ? c->ev[4] : nullptr, widen_timed ? c->ev[5] : nullptr, &tl);
   const double tpc = prof ? now_us() : 0.0;
   if (want_count) HIPCHK(c, hipMemcpyAsync(c->h_wl_count, c->d_wl_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   if (tlev > 1) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
@@ -1921,6 +1862,7 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   // MAX_NUM_MATCHES path: the fit kernel only writes the records (no reduction), one fused kernel ranks them in scan
   // order, reduces the first MAX_NUM_MATCHES and publishes to slot 0
   const bool fused_cap = cap_binds && !c->debug_recs;
+  const bool use_fit2 = !want_recs && tlev < 2;                 // the per-pass fast path (granule results)
   if (fused) {
     // the fit and the reduction ran inside the k-NN launch
   } else if (use_fit2)
@@ -1958,22 +1900,14 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
     if (ntlev == 0 && c->stragglers_hist[npos] <= tail_max) {
       TieList tln{};
       tln.count_next = c->d_tie_count + ((nseq + 1) & 1);
-      ListCtl lsn{};                                           // (the lists this pass leaves or already found are the next one's)
-      if (c->lists_on && c->d_lists) {
-        lsn.recs = c->d_lists; lsn.margin = c->list_margin; lsn.build = 1;
-        lsn.use = c->lists_built ? 1 : 0;
-        lsn.miss = lsn.use ? c->d_list_miss : nullptr;
-      }
-      tln.aux = lsn.miss;
       ChainCtl pc{};
       pc.end_code = 0x80000000u | (++c->pipe_tag & 0x7fffffffu);
       PrevPass pv = c->prev;
       pv.valid = 1;                                            // (its reference pose comes from the head)
       launch_match_fused(c->stream, c->grid, c->d_scan_sorted, n_all, P, mp, c->d_nbr, c->d_wl, c->d_wl_count, nullptr, pv,
                          c->live_idx, c->d_fit2_partials, c->d_granules_host, c->d_ticket, nseq, nullptr, nullptr, &tln, 0, nullptr,
-                         c->d_pipe_head, &pc, bookp, ch_epoch_of(nseq), lsn.recs ? &lsn : nullptr);
+                         c->d_pipe_head, &pc, bookp, ch_epoch_of(nseq));
       HIPCHK(c, hipGetLastError());
-      c->pre.lists_use = lsn.recs && lsn.use; c->pre.lists_build = lsn.recs && lsn.build;
       c->pre.active = true; c->pre.seq = nseq; c->pre.nq = nq; c->pre.n_all = n_all; c->pre.pos = npos; c->pre.cfg = *cfg;
       c->pre.grid_version = grid_version; c->pre.end_code = pc.end_code; c->pre.t_launch = wall_s();
     }
@@ -1993,11 +1927,6 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
     { const int rcw = wait_granules(seq); if (rcw) return rcw; }
     c->last_stragglers = (int)llround(c->h_granules[2 * FIT_LIVE]);
     c->stragglers_hist[c->pass_in_scan] = c->last_stragglers;
-    c->last_list_miss = -1;
-    if (ls_used && reinterpret_cast<const volatile unsigned long long*>(c->h_granules)[2 * (FIT_LIVE + 2) + 1] == seq) {
-      c->last_list_miss = (long)llround(c->h_granules[2 * (FIT_LIVE + 2)]);
-      c->list_passes++; c->list_queries += (unsigned long long)n_all; c->list_misses += (unsigned long long)c->last_list_miss;
-    }
     const long n_ties = (long)llround(c->h_granules[2 * (FIT_LIVE + 1)]);
     if (n_ties > 0 && ties_on) {
       // A few queries' five hinge on an exact float32 distance tie: settle them the reference's way (tie_kernel), then build the
@@ -2220,10 +2149,6 @@ extern "C" int flimo_update_chain(flimo_ctx* c, const flimo_match_cfg* cfg, flim
   Plan plan[CH_MAX_PASSES];
   int pos = c->pass_in_scan;
   bool prev_valid = c->prev.valid != 0;
-  const uint64_t grid_version = c->grid_builds * 0x100000000ull + c->grid_merges;
-  if (!prev_valid) c->lists_built = false;   // another scan: its lists are not this one's
-  bool lists_now = c->lists_built && c->lists_grid_version == grid_version && c->lists_n == n_all;
-  int lists_from = -1;                       // first pass of this chain that leaves lists
   c->prev.probe_min = c->probe_min;
   ChainCtl ctl{};
   ctl.S = c->d_chain;
@@ -2249,17 +2174,6 @@ extern "C" int flimo_update_chain(flimo_ctx* c, const flimo_match_cfg* cfg, flim
     pv.valid = prev_valid ? 1 : 0;            // (pass 0: the context's own bound, if any; later passes: RT comes from the device filter)
     TieList tl{};                                // (ties are settled inside the reducing launches: nothing is listed)
     tl.count_next = c->d_tie_count + ((seq + 1) & 1);
-    // neighbour lists, as in flimo_match_reduce: a pass that is not the scan's first leaves them, the next ones try them first
-    ListCtl ls{};
-    if (first_pass) lists_now = false;
-    if (c->lists_on && c->prune && c->d_lists) {
-      ls.recs = c->d_lists; ls.margin = c->list_margin;
-      ls.use = lists_now ? 1 : 0;
-      ls.build = (!first_pass || c->lists_first) ? 1 : 0;
-      if (!ls.use && !ls.build) ls.recs = nullptr;
-      if (ls.build) { lists_now = true; if (lists_from < 0) lists_from = i; }
-    }
-    const ListCtl* lsp = ls.recs ? &ls : nullptr;
     unsigned int wait_epoch = 0u;                 // (the algebra launch queued before this pass has stored its constants)
     if (after_fine) {
       launch_knn5_fine(c->stream, c->fine, c->d_scan_sorted, n_all, P0, c->d_nbr, pv, c->fine_qlo, c->fine_qhi, &tl, seq, ch, wait_epoch, ctl.end_code);
@@ -2270,12 +2184,12 @@ extern "C" int flimo_update_chain(flimo_ctx* c, const flimo_match_cfg* cfg, flim
     if (fused) {
       launch_match_fused(c->stream, c->grid, c->d_scan_sorted, n_all, P0, mp, c->d_nbr, c->d_wl, c->d_wl_count, nullptr, pv, c->live_idx,
                          c->d_fit2_partials, c->d_chain_gran, c->d_ticket, seq, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr, &tl,
-                         after_fine ? 1 : 0, dk, ch, &ctl, bookp, wait_epoch, lsp);
+                         after_fine ? 1 : 0, dk, ch, &ctl, bookp, wait_epoch);
     } else {
       launch_knn5(c->stream, 2, c->grid, c->d_scan_sorted, n_all, P0, mp.max_ring, c->d_nbr, c->d_wl, c->d_wl_count, nullptr, pv, 0,
-                  ev ? ev[0] : nullptr, ev ? ev[1] : nullptr, nullptr, &tl, after_fine ? 1 : 0, seq, dk, ch, wait_epoch, ctl.end_code, lsp);
+                  ev ? ev[0] : nullptr, ev ? ev[1] : nullptr, nullptr, &tl, after_fine ? 1 : 0, seq, dk, ch, wait_epoch, ctl.end_code);
       {
-        launch_widen(c->stream, c->grid, c->d_scan_sorted, P0, mp.max_ring, c->d_nbr, c->d_wl, c->d_wl_count, nullptr, ev ? ev[6] : nullptr, ev ? ev[7] : nullptr, &tl, ch, lsp);
+        launch_widen(c->stream, c->grid, c->d_scan_sorted, P0, mp.max_ring, c->d_nbr, c->d_wl, c->d_wl_count, nullptr, ev ? ev[6] : nullptr, ev ? ev[7] : nullptr, &tl, ch);
         launch_fit2(c->stream, c->grid, c->d_scan_sorted, n_all, c->d_nbr, P0, mp, c->live_idx, c->d_fit2_partials, c->d_chain_gran,
                     c->d_ticket, c->d_wl_count, seq, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr, &tl, ch, &ctl, bookp);
       }
@@ -2371,9 +2285,6 @@ extern "C" int flimo_update_chain(flimo_ctx* c, const flimo_match_cfg* cfg, flim
   PoseMats Pl;
   pose_from_x26(io->x26_out, Pl);
   if (c->prune && executed > 0) { memcpy(c->prev.RT, Pl.RT, sizeof(c->prev.RT)); c->prev.valid = 1; }
-  // (a pass that ran left its lists; passes that found the chain ended left the lists alone)
-  if (lists_from >= 0 && lists_from < executed) { c->lists_built = true; c->lists_grid_version = grid_version; c->lists_n = n_all; }
-  else if (lists_from >= 0 && !(c->lists_built && c->lists_grid_version == grid_version && c->lists_n == n_all)) c->lists_built = false;
   c->last_nq = (int)nq;
   c->last_P = Pl; c->last_mp = mp; c->last_n_all = n_all;
   c->async_deskews = 0;

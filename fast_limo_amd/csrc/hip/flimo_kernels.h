@@ -6,7 +6,6 @@
 namespace flimo {
 struct FuseArgs;
 struct TieList;
-struct ListCtl;
 struct BookView;
 struct ChainCtl;    // flimo_chain.h: the filter's algebra inside the pass's reducing launch
 struct ChainHead;   // flimo_chain.h: a launch given one reads its pose constants from the device filter and leaves at once when the chain has ended
@@ -25,8 +24,7 @@ void launch_knn5(hipStream_t st, int lanes_per_query, const GridView& G, const f
                  const PoseMats& P, int max_ring, void* nbr, int* wl, int* wl_count, unsigned long long* cand,
                  const PrevPass& prev, int tail, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, const struct FuseArgs* fuse = nullptr,
                  const TieList* ties = nullptr, int after_fine = 0, unsigned long long seq = 0ull, const DeskewArgs* deskew = nullptr,
-                 const ChainHead* chain = nullptr, unsigned int wait_epoch = 0u, unsigned int end_code = 0u,
-                 const ListCtl* lists = nullptr);
+                 const ChainHead* chain = nullptr, unsigned int wait_epoch = 0u, unsigned int end_code = 0u);
 // (wait_epoch != 0: the launch's workgroups wait for the resident algebra to publish the chain's head under that number -- the FIRST
 //  launch of a chained pass; end_code: the value that says the chain has ended; flimo_chain.h)
 // fine pre-pass over the second-level grid of crowded regions (see flimo_map.hip); launches that follow it pass after_fine = 1
@@ -37,7 +35,7 @@ void launch_knn5_fine(hipStream_t st, const GridView& Gf, const float4* scan_sor
 // rings; launch_knn5 clears the flag otherwise) and launch_widen has nothing to do
 void launch_widen(hipStream_t st, const GridView& G, const float4* scan_sorted, const PoseMats& P, int max_ring, void* nbr,
                   int* wl, int* wl_count, unsigned long long* cand, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr,
-                  const TieList* ties = nullptr, const ChainHead* chain = nullptr, const ListCtl* lists = nullptr);
+                  const TieList* ties = nullptr, const ChainHead* chain = nullptr);
 int fit_blocks(int n);
 void set_xcd_stripe(int stripe);   // block -> scan chunk mapping of the per-pass kernels (see xcd_chunk)
 // the fit kernel reduces in FIT_GROUPS groups; slot g of its output = 256 sums + the pass number (FIT_SLOT doubles).
@@ -69,24 +67,12 @@ void launch_match_fused(hipStream_t st, const GridView& G, const float4* scan_so
                         const unsigned char* live_idx, double* partials, void* out_granules, unsigned int* ticket,
                         unsigned long long seq, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, const TieList* ties = nullptr,
                         int after_fine = 0, const DeskewArgs* deskew = nullptr, const ChainHead* chain = nullptr,
-                        const ChainCtl* ctl = nullptr, const BookView* book = nullptr, unsigned int wait_epoch = 0u,
-                        const ListCtl* lists = nullptr);
+                        const ChainCtl* ctl = nullptr, const BookView* book = nullptr, unsigned int wait_epoch = 0u);
 // The reference's choice among exactly tied distances (first met by Octree::knn's recursion): BookView = the device copy of the
 // octree (insert book), TieList = the queries a pass flagged.  launch_tie rewrites their neighbour records; launch_knn_tie does the
 // same for the output of launch_knn.
 struct BookView { const float4* node_c; const int* node_child; const int* node_cnt; int root; unsigned long long* settled; };   // settled (optional): queries whose ties were settled inside a reducing launch
-struct TieList { int* list; unsigned int* count; unsigned int cap; unsigned int* count_next;
-                 unsigned int* aux; };   // aux (optional): a third launch-wide counter, published as granule FIT_LIVE + 2 and re-armed (list misses)
-// Neighbour lists handed from pass to pass of ONE scan over ONE map index (verified reuse, see ListRec in flimo_kernels.hip): the
-// search that settles a query also stores every map point within a radius R of it that it can vouch for (up to 12 positions); a
-// later pass whose query moved by delta takes its five from that list when sqrt(d5') + delta < R proves that no other point can
-// be nearer -- the same five, the same order, the same bits as the full search.  recs: n x list_rec_size() bytes.
-//   use:   the launch tries the lists first (they were written by an earlier pass of this scan over this index)
-//   build: every query this launch settles by a search leaves its list (a query it cannot vouch for leaves an empty one)
-//   margin: metres a search may widen its pruning ball by so that the list it leaves has slack (0: none)
-//   miss:  (optional) counter of the queries a `use` launch had to search for; published as granule FIT_LIVE + 2 and re-armed
-struct ListCtl { void* recs; int use; int build; float margin; unsigned int* miss; };
-size_t list_rec_size();
+struct TieList { int* list; unsigned int* count; unsigned int cap; unsigned int* count_next; };
 void launch_tie(hipStream_t st, const GridView& G, const BookView& B, const float4* scan_sorted, const PoseMats& P, void* nbr,
                 const TieList& tl);
 void launch_knn_tie(hipStream_t st, const GridView& G, const BookView& B, const float* qxyz, int nq, int k, int32_t* idx, float* sqd,

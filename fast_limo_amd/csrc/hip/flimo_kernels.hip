@@ -316,29 +316,6 @@ struct NbrRec {      // 32 bytes per query (sorted order)
   int32_t d5_valid;  // 1 when flag == 1
 };
 
-// Neighbour list of one query, handed from pass to pass of the same scan over the same map index (ListCtl, flimo_kernels.h).
-// The reference searches its octree afresh in every pass of the iterated update (esekfom.hpp:1634-1637 -> Mapper.cpp:68-76);
-// between two passes a query moves by millimetres.  The search that settles a query therefore also leaves
-//   g, R  : the query's world position and a radius such that EVERY map point x with |x - g| < R is among idx[]
-//   idx[] : up to 12 map positions (0xffffffff: unused); [0..5] are read by the pair's first lane, [6..11] by its second
-// and a later pass at g' takes the five nearest of idx[] (5th distance d5') and accepts them when sqrt(d5') + |g' - g| < R: any map
-// point within sqrt(d5') of g' -- the true five and everything tied with the fifth -- is then within R of g, i.e. in the list, so
-// the list's five ARE the map's five, chosen by the same (distance, position) keys: the full search's bits.  A list that cannot
-// prove it (R == 0, too few entries, the query moved too far) costs nothing but the look: the query is searched for as before,
-// with the list's d5' as its pruning bound, and leaves a fresh list.
-struct __align__(16) ListRec {
-  float gx, gy, gz, R;
-  uint32_t idx[12];
-};
-static_assert(sizeof(ListRec) == 64, "one 64-byte line per query");
-__device__ __forceinline__ float key_dist(double k) { return __uint_as_float((uint32_t)__double2hiint(k)); }
-__device__ __forceinline__ uint32_t key_pos(double k) { return (uint32_t)__double2loint(k); }
-// header of a list: R2 = squared radius the search vouches for (metres^2; <= 0 or NaN: none)
-__device__ __forceinline__ void list_store_head(ListRec* __restrict__ r, float gx, float gy, float gz, float R2) {
-  const float R = (R2 > 0.f && R2 < INFINITY) ? fl_sqrt(R2) * (1.f - 1.0e-5f) : (R2 == INFINITY ? 3.0e38f : 0.f);
-  *reinterpret_cast<float4*>(r) = make_float4(gx, gy, gz, R);
-}
-
 // Sorted private best-5 of one lane.  A (distance, position) pair is the 64-bit key (float bits << 32 | position);
 // distances are non-negative finite floats (+inf = empty), so the key read as an IEEE double is a positive finite
 // double (the float's exponent field lands inside the double's 11-bit exponent, below 0x7ff) and doubles of one sign
@@ -503,8 +480,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 __device__ __forceinline__ void knn5_tail(const GridView& G, int max_ring, NbrRec* __restrict__ nbr, bool pending, int p,
                                           float gx, float gy, float gz, uint32_t hint_bits, float b2, WaveLds& S,
                                           int* __restrict__ straggler_count, unsigned long long* __restrict__ cand_total,
-                                          bool keep_res, const TieList& tl, ListRec* __restrict__ lrecs = nullptr, float lmargin = 0.f) {
-  // (lrecs: every query settled here leaves its neighbour list, see ListRec; lmargin: metres its ball is widened by for that)
+                                          bool keep_res, const TieList& tl) {
   const int lane = threadIdx.x & 63;
   const u64 B = __ballot(pending);
   const int F = __popcll(B);
@@ -549,7 +525,7 @@ __device__ __forceinline__ void knn5_tail(const GridView& G, int max_ring, NbrRe
       if (hint >= 0.f && hint < INFINITY) {                    // an upper bound of the true 5th distance: its ring, its ball
         const float need = fl_sqrt(hint) * G.inv_cell * (1.f + 4.0e-6f) - edge + margin;
         r = max(r, (int)ceilf(fminf(need, 1.0e9f)));
-        const float rc = (fl_sqrt(hint) * (1.f + 1.0e-5f) + 1.0e-6f + lmargin) * G.inv_cell;
+        const float rc = (fl_sqrt(hint) * (1.f + 1.0e-5f) + 1.0e-6f) * G.inv_cell;
         bnd2 = fminf(bnd2, rc * rc * (1.f + 1.0e-5f));
       }
       r = min(r, max_ring);
@@ -623,9 +599,6 @@ __device__ __forceinline__ void knn5_tail(const GridView& G, int max_ring, NbrRe
         u64 mine[6];
 #pragma unroll
         for (int i = 0; i < 6; i++) mine[i] = (u64)__double_as_longlong(k5[i]);
-        // (list: a lane dropped only candidates beyond its own sixth key -- the group vouches for everything nearer than the nearest
-        //  of those sixths)
-        const float dmin6 = lrecs ? key_dist(key_group_min(k5[5], Gl, lane)) : 0.f;
 #pragma unroll
         for (int k = 0; k < 6; k++) {
           const double md = key_group_min(__longlong_as_double((long long)mine[0]), Gl, lane);
@@ -638,44 +611,14 @@ __device__ __forceinline__ void knn5_tail(const GridView& G, int max_ring, NbrRe
         const bool have5 = d5 < INFINITY;
         const bool covers = (cx - r <= 0) && (cx + r >= G.nx - 1) && (cy - r <= 0) && (cy + r >= G.ny - 1) &&
                             (cz - r <= 0) && (cz + r >= G.nz - 1);
-        if (have5 && (covers || d5 <= rg * rg * (1.f - 1.0e-6f))) {
-          flag = 1; active = false;
-          if (lrecs) {
-            // the query's list: the six just extracted and the next six of the group's lists; everything nearer than the 13th, than the
-            // lanes' sixths, than the block's faces and than the pruning ball is among them (the condition is the same in every lane
-            // of the group: the extraction rounds below are group-wide)
-            uint32_t ext[6];
-            float d13 = INFINITY;
-#pragma unroll
-            for (int k = 0; k < 7; k++) {
-              const double md = key_group_min(__longlong_as_double((long long)mine[0]), Gl, lane);
-              const u64 m = (u64)__double_as_longlong(md);
-              if (k < 6) ext[k] = (uint32_t)m; else d13 = __uint_as_float((uint32_t)(m >> 32));
-              if (mine[0] == m) { mine[0] = mine[1]; mine[1] = mine[2]; mine[2] = mine[3]; mine[3] = mine[4]; mine[4] = mine[5]; mine[5] = KEY_NONE; }
-            }
-            if (sub == 0) {
-              float r2 = fminf(dmin6, d13);
-              if (!covers) r2 = fminf(r2, rg * rg * (1.f - 1.0e-6f));
-              if (bnd2 < 1.0e6f) r2 = fminf(r2, bnd2 * (G.cell * G.cell) * (1.f - 4.0e-5f));
-              ListRec* lr = lrecs + qp;
-              list_store_head(lr, qx, qy, qz, r2);
-              uint4* li = reinterpret_cast<uint4*>(lr->idx);
-              li[0] = make_uint4((uint32_t)best[0], (uint32_t)best[1], (uint32_t)best[2], (uint32_t)best[3]);
-              li[1] = make_uint4((uint32_t)best[4], (uint32_t)sixth, ext[0], ext[1]);
-              li[2] = make_uint4(ext[2], ext[3], ext[4], ext[5]);
-            }
-          }
-        }
-        else if (covers || r >= max_ring) {
-          flag = 0; active = false;
-          if (lrecs && sub == 0) list_store_head(lrecs + qp, qx, qy, qz, 0.f);
-        }
+        if (have5 && (covers || d5 <= rg * rg * (1.f - 1.0e-6f))) { flag = 1; active = false; }
+        else if (covers || r >= max_ring) { flag = 0; active = false; }
         else {
           int rn = r + 1;
           if (have5) {
             const float need = fl_sqrt(d5) * G.inv_cell * (1.f + 4.0e-6f) - edge + margin;
             rn = max(r + 1, (int)ceilf(fminf(need, 1.0e9f)));
-            const float rc = (fl_sqrt(d5) * (1.f + 1.0e-5f) + 1.0e-6f + lmargin) * G.inv_cell;
+            const float rc = (fl_sqrt(d5) * (1.f + 1.0e-5f) + 1.0e-6f) * G.inv_cell;
             bnd2 = fminf(bnd2, rc * rc * (1.f + 1.0e-5f));
           }
           r = min(rn, max_ring);
@@ -880,7 +823,6 @@ struct FuseArgs {
   ChainCtl ch;         // ch.S: a pass of a chained update (flimo_chain.h): the launch has one extra workgroup, and the workgroup
                        // that completes it goes on with the filter's algebra
   int spread;          // one-launch pass of a small scan: only every 2^spread-th query slot is taken (see knn5_pass)
-  ListCtl ls;          // ls.recs: neighbour lists handed from pass to pass (ListRec)
 };
 template <int ROWS>
 __device__ __forceinline__ void fit_reduce_publish(const float (&v)[16], bool owns_row, int row, float* sr, double* sa0, double* sa1,
@@ -1001,17 +943,6 @@ __device__ __forceinline__ void knn5_pass(const GridView& G, const float4* __res
   } else {
     sp = scan_sorted[in_range ? p : 0];
   }
-  // the query's neighbour list (ListRec), fetched with its scan point: header + this lane's six positions
-  const bool lists_use = L == 2 && !FINE && fa.ls.recs != nullptr && fa.ls.use != 0;          // launch-uniform
-  const bool lists_build = L == 2 && !FINE && fa.ls.recs != nullptr && fa.ls.build != 0;
-  ListRec* const lrec = static_cast<ListRec*>(fa.ls.recs) + (in_range ? p : 0);
-  float4 lhd = make_float4(0.f, 0.f, 0.f, 0.f);
-  uint2 li01 = make_uint2(0u, 0u), li23 = li01, li45 = li01;
-  if (lists_use) {
-    lhd = *reinterpret_cast<const float4*>(lrec);
-    const uint2* li = reinterpret_cast<const uint2*>(lrec->idx + 6 * sub);
-    li01 = li[0]; li23 = li[1]; li45 = li[2];
-  }
   float gx, gy, gz;
   xform4(P.RT, sp.x, sp.y, sp.z, gx, gy, gz);
   TRACE(0, 1);
@@ -1047,57 +978,6 @@ __device__ __forceinline__ void knn5_pass(const GridView& G, const float4* __res
   int cand = 0;
   bool tie_listed = false;
   int qcx = 0, qcy = 0, qcz = 0;
-  // ---- the list first: two dependent round trips (list, its points) instead of the search's five ----
-  bool list_hit = false;
-  float list_R2 = 0.f;                                // squared radius the search below vouches for (0: it leaves no list)
-  bool pv_on = prev_valid != 0;                       // a pruning bound may exist (launch-uniform)
-  if constexpr (L == 2 && !FINE) {
-    if (lists_use) {
-      const bool has = in_range && !resolved && lhd.w > 0.f;
-      if (__any(has)) {
-        const uint32_t id[6] = {li01.x, li01.y, li23.x, li23.y, li45.x, li45.y};
-        float4 pt[6];
-#pragma unroll
-        for (int u = 0; u < 6; u++) pt[u] = G.pts[(has && id[u] != 0xffffffffu) ? id[u] : 0u];
-        asm volatile("" : "+v"(pt[0].x), "+v"(pt[0].y), "+v"(pt[0].z), "+v"(pt[1].x), "+v"(pt[1].y), "+v"(pt[1].z),
-                          "+v"(pt[2].x), "+v"(pt[2].y), "+v"(pt[2].z), "+v"(pt[3].x), "+v"(pt[3].y), "+v"(pt[3].z),
-                          "+v"(pt[4].x), "+v"(pt[4].y), "+v"(pt[4].z), "+v"(pt[5].x), "+v"(pt[5].y), "+v"(pt[5].z));
-        const double none = __longlong_as_double((long long)KEY_NONE);
-        double k6[6] = {none, none, none, none, none, none};
-#pragma unroll
-        for (int u = 0; u < 6; u++) {
-          const bool live = has && id[u] != 0xffffffffu;
-          const float d = sqdist3(gx, gy, gz, pt[u].x, pt[u].y, pt[u].z);
-          best6_insert(k6, key_make(live ? d : INFINITY, live ? id[u] : 0xffffffffu));
-        }
-        double c[6];
-        key_pair_merge6(k6, c);
-        const float d5l = key_dist(c[4]);
-        const float ex = gx - lhd.x, ey = gy - lhd.y, ez = gz - lhd.z;
-        const float moved = fl_sqrt(sum3(ex * ex, ey * ey, ez * ez));
-        // every map point within sqrt(d5l) of g is within sqrt(d5l) + moved of the list's origin: inside R, i.e. listed
-        const bool ok = has && d5l < INFINITY && (fl_sqrt(d5l) + moved) * (1.f + 2.0e-5f) + 2.0e-6f < lhd.w;
-        if (ok) {
-#pragma unroll
-          for (int i = 0; i < 5; i++) best[i] = (u64)__double_as_longlong(c[i]);
-          sixth = (u64)__double_as_longlong(c[5]);
-          flag = 1;
-          tie = key_has_tie(best, sixth);
-          list_hit = true;
-        } else if (has && d5l < INFINITY) {
-          // the list's five are map points: their 5th distance bounds the true one (the search below walks that ball only)
-          const float rc = (fl_sqrt(d5l) * (1.f + 1.0e-5f) + 1.0e-6f) * G.inv_cell;
-          b2 = fminf(b2, rc * rc * (1.f + 1.0e-5f));
-        }
-      }
-      pv_on = true;
-      TRACE(0, 2);
-      if (fa.ls.miss) {
-        const u64 mb = __ballot(in_range && sub == 0 && !list_hit && !resolved);
-        if (mb != 0ull && (threadIdx.x & 63) == 0) atomicAdd(fa.ls.miss, (unsigned int)__popcll(mb));
-      }
-    }
-  }
   if (resolved) {
     // the five (positions in the main map), their 5th distance and the tie bit as the pre-pass left them
     best[0] = (u64)(uint32_t)pa_res.x; best[1] = (u64)(uint32_t)pa_res.y; best[2] = (u64)(uint32_t)pa_res.z; best[3] = (u64)(uint32_t)pa_res.w;
@@ -1105,12 +985,8 @@ __device__ __forceinline__ void knn5_pass(const GridView& G, const float4* __res
     flag = 1;
     tie = (pb_res.w & 2) != 0;
     tie_listed = true;
-  } else if (list_hit) {
-    // the five came from the list
   } else if (in_range && (fx == fx) && (fy == fy) && (fz == fz)) {
     const float lim = 1.0e9f;
-    // a search that leaves a list walks a slightly larger ball than it needs: the list's slack (any larger bound is still a bound)
-    if (lists_build && b2 < 1.0e6f) { const float rw = fl_sqrt(b2) + fa.ls.margin * G.inv_cell; b2 = rw * rw; }
     const float flx = floorf(fminf(fmaxf(fx, -lim), lim)), fly = floorf(fminf(fmaxf(fy, -lim), lim)),
                 flz = floorf(fminf(fmaxf(fz, -lim), lim));
     const int cx = (int)flx, cy = (int)fly, cz = (int)flz;
@@ -1137,7 +1013,7 @@ __device__ __forceinline__ void knn5_pass(const GridView& G, const float4* __res
       const int maxdim = max(G.nx, max(G.ny, G.nz));
       const float margin = 1.0e-3f + 4.0e-7f * (float)maxdim;
       int c0 = (cx - 1) * G.xs, c1 = (cx + 2) * G.xs;          // first column, one past the last
-      if (pv_on && b2 < 1.0e6f) {
+      if (prev_valid && b2 < 1.0e6f) {
         const float rb_ = fl_sqrt(b2) + margin;                 // reach along x in cell units (b2 is already inflated)
         const float fxs = (float)G.xs;
         c0 = max(c0, (int)floorf((fx - rb_) * fxs));
@@ -1151,7 +1027,7 @@ __device__ __forceinline__ void knn5_pass(const GridView& G, const float4* __res
       // map leave cells with tens to hundreds of points) first walks that cell alone; its 5th distance there is an upper bound
       // of the true one, and the other 26 cells are then walked only as far as that ball reaches (rows and end cells it cannot
       // reach are dropped, exactly as with the bound of a previous pass).
-      const bool probe_on = L == 2 && !pv_on && prev_probe_min != 0u;          // wave-uniform
+      const bool probe_on = L == 2 && !prev_valid && prev_probe_min != 0u;          // wave-uniform
       U3 rbl[3], rbh[3];
       {
         const uint32_t iL = (uint32_t)c0 * plane + yz, iH = (uint32_t)c1 * plane + yz;
@@ -1173,7 +1049,7 @@ __device__ __forceinline__ void knn5_pass(const GridView& G, const float4* __res
 #pragma unroll
         for (int k = 0; k < 3; k++) {
           const int t = 3 * dz + k;
-          const bool row = !pv_on || (yd2[k] + zd2[dz] <= b2);
+          const bool row = !prev_valid || (yd2[k] + zd2[dz] <= b2);
           dl[t] = sl[k] - off[t];
           off[t + 1] = off[t] + (row ? sh[k] - sl[k] : 0u);
         }
@@ -1227,20 +1103,6 @@ __device__ __forceinline__ void knn5_pass(const GridView& G, const float4* __res
 #pragma unroll
       for (int i = 0; i < 5; i++) best[i] = (u64)__double_as_longlong(k5[i]);
       sixth = (u64)__double_as_longlong(k5[5]);
-      // this lane's six nearest go into the query's list as they are; the lane vouches for everything nearer than its sixth (what it
-      // dropped was farther), the pair for the smaller of the two (the header follows once the query is known to be settled here)
-      float list_r2 = 0.f;
-      if constexpr (L == 2 && !FINE) {
-        if (lists_build && !two && !split_walk) {
-          uint2* lo_ = reinterpret_cast<uint2*>(lrec->idx + 6 * sub);
-          lo_[0] = make_uint2(key_pos(k5[0]), key_pos(k5[1]));
-          lo_[1] = make_uint2(key_pos(k5[2]), key_pos(k5[3]));
-          lo_[2] = make_uint2(key_pos(k5[4]), key_pos(k5[5]));
-          const float own6 = key_dist(k5[5]);
-          const float oth6 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(own6), 0xB1, 0xf, 0xf, false));
-          list_r2 = fminf(own6, oth6);
-        }
-      }
       TRACE(0, 3);
 #ifdef FLIMO_TRACE
       if (blockIdx.x < 16384) {   // developer statistics: accumulated block candidates (all passes), CU id
@@ -1361,19 +1223,6 @@ __device__ __forceinline__ void knn5_pass(const GridView& G, const float4* __res
       }
       else if (covers) flag = 0;                 // the whole map holds fewer than 5 points
       else flag = (max_ring > 1) ? 2 : 0;
-      if constexpr (L == 2 && !FINE) {
-        if (lists_build && sub == 0) {
-          // what the walk above saw: the 3x3x3 block (everything within rg of the query), cut down to the pruning ball when there was
-          // one (rows and columns farther than sqrt(b2) cells were dropped)
-          float r2 = 0.f;
-          if (flag == 1) {
-            r2 = list_r2;
-            if (!covers) r2 = fminf(r2, rg * rg * (1.f - 1.0e-6f));
-            if (pv_on && b2 < 1.0e6f) r2 = fminf(r2, b2 * (G.cell * G.cell) * (1.f - 4.0e-5f));
-          }
-          list_R2 = r2;
-        }
-      }
     }
   }
   if (cand_total) {
@@ -1381,11 +1230,6 @@ __device__ __forceinline__ void knn5_pass(const GridView& G, const float4* __res
 #pragma unroll
     for (int o = 1; o < L; o <<= 1) c += __shfl_xor(c, o, 64);
     if (sub == 0 && in_range) atomicAdd(cand_total, (unsigned long long)c);
-  }
-  if constexpr (L == 2 && !FINE) {
-    // every query that did not take its five from a list leaves a fresh header (an empty list where nothing can be vouched for:
-    // no stale one survives a building pass); a pending query's is written by whoever settles it (tail / widening)
-    if (lists_build && sub == 0 && in_range && !list_hit && flag != 2) list_store_head(lrec, gx, gy, gz, list_R2);
   }
   if constexpr (FINE) {
     // fine pre-pass: settle what is proven inside the completely copied region, leave everything else to the main launch
@@ -1424,8 +1268,7 @@ __device__ __forceinline__ void knn5_pass(const GridView& G, const float4* __res
     }
   }
   WaveLds& W = s_w[threadIdx.x >> 6];
-  if (tail) knn5_tail(G, max_ring, nbr, pend_tail && sub == 0, p, gx, gy, gz, (uint32_t)(best[4] >> 32), b2, W, wl_count, cand_total, FUSE, tl,
-                      lists_build ? static_cast<ListRec*>(fa.ls.recs) : nullptr, fa.ls.margin);
+  if (tail) knn5_tail(G, max_ring, nbr, pend_tail && sub == 0, p, gx, gy, gz, (uint32_t)(best[4] >> 32), b2, W, wl_count, cand_total, FUSE, tl);
   TRACE(0, 5);
   if constexpr (FUSE) {
     // ---- fit + reduction of this wave's queries (one row per query, computed by the pair's first lane) ----
@@ -1527,9 +1370,7 @@ __global__ __launch_bounds__(256) KNN_WPE void knn5_chain_kernel(GridView G, con
 __device__ __forceinline__ void widen_body(const GridView& G, int max_ring, NbrRec* __restrict__ nbr,
                                            const int* __restrict__ wl, const int* __restrict__ wl_count,
                                            unsigned long long* __restrict__ cand_total, int first_ring, const TieList& tl,
-                                           int blk, int nblk, uint32_t (*s_off)[65], uint32_t (*s_lo)[64],
-                                           ListRec* __restrict__ lrecs = nullptr) {
-  // (lrecs: every query settled here leaves its neighbour list, see ListRec)
+                                           int blk, int nblk, uint32_t (*s_off)[65], uint32_t (*s_lo)[64]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int maxdim = max(G.nx, max(G.ny, G.nz));
   const float margin = 1.0e-3f + 4.0e-7f * (float)maxdim;
@@ -1619,7 +1460,6 @@ __device__ __forceinline__ void widen_body(const GridView& G, int max_ring, NbrR
       u64 mine[6];
 #pragma unroll
       for (int i = 0; i < 6; i++) mine[i] = (u64)__double_as_longlong(k5[i]);
-      const float dmin6 = lrecs ? key_dist(key_group_min(k5[5], 64, lane)) : 0.f;      // (see knn5_tail)
 #pragma unroll
       for (int k = 0; k < 6; k++) {
         const double md = key_group_min(__longlong_as_double((long long)mine[0]), 64, lane);
@@ -1632,38 +1472,8 @@ __device__ __forceinline__ void widen_body(const GridView& G, int max_ring, NbrR
       const bool have5 = d5 < INFINITY;
       const bool covers = (cx - r <= 0) && (cx + r >= G.nx - 1) && (cy - r <= 0) && (cy + r >= G.ny - 1) &&
                           (cz - r <= 0) && (cz + r >= G.nz - 1);
-      if (have5 && (covers || d5 <= rg * rg * (1.f - 1.0e-6f))) {
-        flag = 1;
-        if (lrecs) {
-          // the query's list: the next six of the wave's lists behind the six just extracted; complete up to the 13th, the lanes'
-          // sixths and the block's faces (this search walks the whole ring-r block)
-          uint32_t ext[6];
-          float d13 = INFINITY;
-#pragma unroll
-          for (int k = 0; k < 7; k++) {
-            const double md = key_group_min(__longlong_as_double((long long)mine[0]), 64, lane);
-            const u64 m = (u64)__double_as_longlong(md);
-            if (k < 6) ext[k] = (uint32_t)m; else d13 = __uint_as_float((uint32_t)(m >> 32));
-            if (mine[0] == m) { mine[0] = mine[1]; mine[1] = mine[2]; mine[2] = mine[3]; mine[3] = mine[4]; mine[4] = mine[5]; mine[5] = KEY_NONE; }
-          }
-          if (lane == 0) {
-            float r2 = fminf(dmin6, d13);
-            if (!covers) r2 = fminf(r2, rg * rg * (1.f - 1.0e-6f));
-            ListRec* lr = lrecs + p;
-            list_store_head(lr, gx, gy, gz, r2);
-            uint4* li = reinterpret_cast<uint4*>(lr->idx);
-            li[0] = make_uint4((uint32_t)best[0], (uint32_t)best[1], (uint32_t)best[2], (uint32_t)best[3]);
-            li[1] = make_uint4((uint32_t)best[4], (uint32_t)sixth, ext[0], ext[1]);
-            li[2] = make_uint4(ext[2], ext[3], ext[4], ext[5]);
-          }
-        }
-        break;
-      }
-      if (covers || r >= max_ring) {
-        flag = 0;
-        if (lrecs && lane == 0) list_store_head(lrecs + p, gx, gy, gz, 0.f);
-        break;
-      }
+      if (have5 && (covers || d5 <= rg * rg * (1.f - 1.0e-6f))) { flag = 1; break; }
+      if (covers || r >= max_ring) { flag = 0; break; }
       int rn = r + 1;
       if (have5) {
         const float need = fl_sqrt(d5) * G.inv_cell * (1.f + 4.0e-6f) - edge + margin;
@@ -1693,11 +1503,11 @@ __global__ __launch_bounds__(256) void widen_kernel(GridView G, const float4* __
                                                     int max_ring, NbrRec* __restrict__ nbr, const int* __restrict__ wl,
                                                     const int* __restrict__ wl_count,
                                                     unsigned long long* __restrict__ cand_total, int first_ring, TieList tl,
-                                                    const ChainHead* __restrict__ H, ListRec* __restrict__ lrecs) {
+                                                    const ChainHead* __restrict__ H) {
   __shared__ uint32_t s_off[4][65];
   __shared__ uint32_t s_lo[4][64];
   if (H && H->status != 0) return;                   // a chained pass after the chain has ended
-  widen_body(G, max_ring, nbr, wl, wl_count, cand_total, first_ring, tl, (int)blockIdx.x, (int)gridDim.x, s_off, s_lo, lrecs);
+  widen_body(G, max_ring, nbr, wl, wl_count, cand_total, first_ring, tl, (int)blockIdx.x, (int)gridDim.x, s_off, s_lo);
 }
 
 // general ring search for the worklist when the gate needs more than 3 rings (unusual configs)
@@ -2055,15 +1865,9 @@ __device__ __forceinline__ void fit_reduce_publish(const float (&v)[16], bool ow
         // granule FIT_LIVE = queries of this pass that needed more than their 3x3x3 block, granule FIT_LIVE + 1 = queries whose five
         // hinge on an exact distance tie (the host then runs tie_kernel and the fit again).  Then everything is re-armed.
         v2d_t g;
-        g.y = __longlong_as_double((long long)seq);
-        double2* o = out_granules + FIT_LIVE + 2;
-        if (tl.aux) {                              // third counter (list misses): ahead of the two the host waits for
-          g.x = (double)__hip_atomic_load(tl.aux, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(o), "v"(g) : "memory");
-          __hip_atomic_store(tl.aux, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
         g.x = (double)__hip_atomic_load(wl_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        o = out_granules + FIT_LIVE;
+        g.y = __longlong_as_double((long long)seq);
+        double2* o = out_granules + FIT_LIVE;
         asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(o), "v"(g) : "memory");
         g.x = tl.count ? (double)__hip_atomic_load(tl.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
         o = out_granules + FIT_LIVE + 1;
@@ -2698,7 +2502,7 @@ static void launch_knn5_L(hipStream_t st, const GridView& G, const float4* scan_
                           int max_ring, void* nbr, int* wl, int* wl_count, unsigned long long* cand, const PrevPass& prev,
                           int tail, hipEvent_t e0, hipEvent_t e1, const FuseArgs* fuse, const TieList* tlp, int after_fine = 0,
                           unsigned long long seq = 0ull, const DeskewArgs* dk = nullptr, const ChainHead* chain = nullptr,
-                          unsigned int wait_epoch = 0u, unsigned int end_code = 0u, const ListCtl* lists = nullptr) {
+                          unsigned int wait_epoch = 0u, unsigned int end_code = 0u) {
   const int qpb = 256 / L;
   const int blocks = round_up8((n + qpb - 1) / qpb);
   constexpr int slots = (L <= 4 ? 8 : 4);          // candidate loads in flight per lane
@@ -2718,7 +2522,6 @@ static void launch_knn5_L(hipStream_t st, const GridView& G, const float4* scan_
   nofuse.seq = seq;
   if (dk) nofuse.dk = *dk;
   nofuse.ch.end_code = end_code;
-  if (lists && L == 2) nofuse.ls = *lists;
   // e0 / e1 (optional) are attached to the dispatch itself: they read the kernel's own begin / end
   // timestamps, without the extra barrier packets of hipEventRecord
   if constexpr (L == 2) {
@@ -2733,14 +2536,13 @@ static void launch_knn5_L(hipStream_t st, const GridView& G, const float4* scan_
 void launch_knn5(hipStream_t st, int lanes_per_query, const GridView& G, const float4* scan_sorted, int n,
                  const PoseMats& P, int max_ring, void* nbr, int* wl, int* wl_count, unsigned long long* cand,
                  const PrevPass& prev, int tail, hipEvent_t e0, hipEvent_t e1, const FuseArgs* fuse, const TieList* tlp, int after_fine,
-                 unsigned long long seq, const DeskewArgs* dk, const ChainHead* chain, unsigned int wait_epoch, unsigned int end_code,
-                 const ListCtl* lists) {
+                 unsigned long long seq, const DeskewArgs* dk, const ChainHead* chain, unsigned int wait_epoch, unsigned int end_code) {
   if (n <= 0) return;
   if (max_ring < 2 || max_ring > TAIL_MAX_RING) tail = 0;
-  if (chain) { launch_knn5_L<2>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine, seq, dk, chain, wait_epoch, end_code, lists); return; }   // (two lanes per query only)
+  if (chain) { launch_knn5_L<2>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine, seq, dk, chain, wait_epoch, end_code); return; }   // (two lanes per query only)
   switch (lanes_per_query) {
-    case 2: launch_knn5_L<2>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine, seq, dk, nullptr, 0u, 0u, lists); break;
     case 1: launch_knn5_L<1>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine, seq, dk); break;
+    case 2: launch_knn5_L<2>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine, seq, dk); break;
     case 4: launch_knn5_L<4>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine, seq, dk); break;
     case 8: launch_knn5_L<8>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine, seq, dk); break;
     case 32: launch_knn5_L<32>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine, seq, dk); break;
@@ -2749,16 +2551,14 @@ void launch_knn5(hipStream_t st, int lanes_per_query, const GridView& G, const f
 }
 
 void launch_widen(hipStream_t st, const GridView& G, const float4* scan_sorted, const PoseMats& P, int max_ring, void* nbr,
-                  int* wl, int* wl_count, unsigned long long* cand, hipEvent_t e0, hipEvent_t e1, const TieList* tlp, const ChainHead* chain,
-                  const ListCtl* lists) {
+                  int* wl, int* wl_count, unsigned long long* cand, hipEvent_t e0, hipEvent_t e1, const TieList* tlp, const ChainHead* chain) {
   TieList tl{};
   if (tlp) tl = *tlp;
   if (max_ring <= 1) return;
-  ListRec* lrecs = (lists && lists->recs && lists->build) ? static_cast<ListRec*>(lists->recs) : nullptr;
   // 2048 blocks = 8 waves per SIMD: the wave-per-query search is a latency chain (the worklist has 8192 slots of prefetch slack);
   // entries without a hint go straight to the gate's ring (measured at 6.6 k pending queries: 19.3 -> 16.3 us)
   if (max_ring <= 3)
-    hipExtLaunchKernelGGL(widen_kernel, dim3(2048), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand, max_ring, tl, chain, lrecs);
+    hipExtLaunchKernelGGL(widen_kernel, dim3(2048), dim3(256), 0, st, e0, e1, 0, G, scan_sorted, P, max_ring, (NbrRec*)nbr, wl, wl_count, cand, max_ring, tl, chain);
   else
     hipLaunchKernelGGL(widen_general_kernel, dim3(256), dim3(256), 0, st, G, scan_sorted, P, max_ring, (NbrRec*)nbr, wl, wl_count, tl);
 }
@@ -2830,10 +2630,9 @@ void launch_match_fused(hipStream_t st, const GridView& G, const float4* scan_so
                         void* nbr, int* wl, int* wl_count, unsigned long long* cand, const PrevPass& prev,
                         const unsigned char* live_idx, double* partials, void* out_granules, unsigned int* ticket,
                         unsigned long long seq, hipEvent_t e0, hipEvent_t e1, const TieList* tlp, int after_fine, const DeskewArgs* dk,
-                        const ChainHead* chain, const ChainCtl* ctl, const BookView* bookp, unsigned int wait_epoch, const ListCtl* lists) {
+                        const ChainHead* chain, const ChainCtl* ctl, const BookView* bookp, unsigned int wait_epoch) {
   if (n <= 0) return;
   FuseArgs fa{};
-  if (lists) fa.ls = *lists;
   if (ctl) fa.ch = *ctl;
   if (bookp) fa.book = *bookp;
   if (dk) fa.dk = *dk;
@@ -2848,7 +2647,6 @@ void launch_match_fused(hipStream_t st, const GridView& G, const float4* scan_so
 }
 
 size_t nbr_rec_size() { return sizeof(NbrRec); }
-size_t list_rec_size() { return sizeof(ListRec); }
 size_t wl_entry_size() { return 2 * sizeof(int4); }
 
 void launch_knn(hipStream_t st, const GridView& G, const float* qxyz, int nq, int k, int max_ring, int32_t* idx,

@@ -282,13 +282,6 @@ int flimo_tie_stats(const flimo_ctx* ctx, unsigned long long out[2]);
 /* second level over crowded regions (cells holding > 64 points get a grid with a quarter of the cell edge and a pre-pass):
  * out[0] = active now, out[1] = map points copied into it, out[2] = times it was (re)built, out[3] = passes that ran the pre-pass */
 int flimo_fine_stats(const flimo_ctx* ctx, unsigned long long out[4]);
-/* neighbour lists handed from pass to pass of one scan (the reference searches its octree afresh in every pass of the update,
- * esekfom.hpp:1634-1637 -> Mapper.cpp:68-76; here the second and later passes take a query's five from the list the previous pass's
- * search left whenever the list proves them -- same points, same order): out[0] = passes that tried lists, out[1] = queries of
- * those passes, out[2] = queries among them that had to be searched for, out[3] = the same of the last pass (-1: it had no lists).
- * flimo_set_lists: mode 0 off, 1 on (default), 2 on and the first pass of a scan leaves lists too; margin_m < 0 = leave. */
-int flimo_list_stats(flimo_ctx* ctx, double out[4], int reset);
-int flimo_set_lists(flimo_ctx* ctx, int mode, float margin_m);
 int flimo_last_kernel_ms(const flimo_ctx* ctx, float* knn_ms, float* widen_ms, float* fit_ms);
 /* sums over every pass since the last reset (timing must be on): per-stage GPU ms, passes, k-NN queries */
 int flimo_timing_totals(flimo_ctx* ctx, double* knn_ms, double* widen_ms, double* fit_ms, long long* passes,

@@ -690,85 +690,6 @@ def test_previous_pass_bound_prunes_exactly(built, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("records", [True, False])
-def test_neighbour_lists_prove_the_same_five(built, oracle, records):
-    """Passes 2.. of an update take a query's five from the list the previous pass's search left, when sqrt(d5') + displacement < R
-    proves that no other map point can be nearer (ListRec, flimo_kernels.hip; the reference searches afresh in every pass,
-    esekfom.hpp:1634-1637 -> Mapper.cpp:68-76).  Contexts with the lists off, on, on with no slack and the first pass leaving lists
-    too, and on with a very wide slack walk the same poses -- millimetre steps (the lists are hit), a 0.3 m jump (they cannot prove
-    anything: every query is searched for and leaves a fresh list), millimetres again, a map insert between two passes (the
-    positions a list holds are the old index's), the same scan set again (its lists belong to the scan before) -- and must agree
-    bit for bit: on every per-point record (separate dispatches) / on the sums (the one-launch pass), and with the oracle's rows."""
-    from fast_limo_amd import _lib
-    mcfg = _lib.default_match_cfg(**CAPS)
-    mp = synth.box_world_map(300000, 20.0, 1)
-    extra = synth.box_world_map(60000, 20.0, 7)
-    scan = np.ascontiguousarray(synth.box_world_scan_random(8192, 20.0, 2)[:, :3])
-    rs = np.random.RandomState(23)
-    def bump(x, dt, dr):
-        y = x.copy()
-        y[0:3] += rs.normal(0, dt, 3)
-        q = y[3:7] + np.concatenate([rs.normal(0, dr, 3), [0.0]])
-        y[3:7] = q / np.linalg.norm(q)
-        return y
-    x = oracle.identity_x26()
-    steps = []                                              # (what, pose)
-    steps.append(("pass", x))
-    for k in range(3):
-        x = bump(x, 1.5e-3, 1e-4); steps.append(("pass", x))
-    x = bump(x, 0.17, 0.01); steps.append(("pass", x))      # jump
-    for k in range(2):
-        x = bump(x, 4e-4, 3e-5); steps.append(("pass", x))
-    steps.append(("insert", None))
-    for k in range(2):
-        x = bump(x, 4e-4, 3e-5); steps.append(("pass", x))
-    steps.append(("rescan", None))
-    for k in range(3):
-        x = bump(x, 1e-3, 1e-4); steps.append(("pass", x))
-    settings = [("off", 0, -1.0), ("on", 1, -1.0), ("tight+first", 2, 0.0), ("wide", 1, 0.6)]
-    ctxs = []
-    try:
-        for name, mode, margin in settings:
-            c = _lib.HipCtx(0)
-            c.map_config(); c.map_add(mp); c.scan_set(scan); c.set_debug_records(records); c.set_lists(mode, margin)
-            ctxs.append(c)
-        n_pass = 0
-        for what, xk in steps:
-            if what == "insert":
-                for c in ctxs: c.map_add(extra)
-                continue
-            if what == "rescan":
-                for c in ctxs: c.scan_set(scan)
-                continue
-            outs = [c.match_reduce(xk, mcfg) for c in ctxs]
-            recs = [c.match_fetch() for c in ctxs] if records else None
-            for (name, _, _), o in zip(settings[1:], outs[1:]):
-                assert o[2] == outs[0][2], (name, n_pass)
-                np.testing.assert_array_equal(o[0], outs[0][0], err_msg=f"{name} pass {n_pass} HTH")
-                np.testing.assert_array_equal(o[1], outs[0][1], err_msg=f"{name} pass {n_pass} HTh")
-            if records:
-                for (name, _, _), r in zip(settings[1:], recs[1:]):
-                    for f in ("valid", "n", "h", "sqd", "nbr", "H"):
-                        np.testing.assert_array_equal(r[f], recs[0][f], err_msg=f"{name} pass {n_pass} field {f}")
-            n_pass += 1
-        if records:
-            oc = oracle.Octree()
-            oc.update(mp); oc.update(extra)
-            orecs, H, h, ev = oracle.match_H(oc, oracle.default_cfg(num_threads=1, **CAPS), xk, scan)
-            vg = recs[1]["valid"] > 0
-            np.testing.assert_array_equal(vg, orecs["is_plane"] > 0)
-            np.testing.assert_array_equal(recs[1]["H"][vg].astype(np.float64), H)
-        else:
-            # the one-launch passes report what the lists did: off = never tried; on = most queries of the small steps proven
-            st = [c.list_stats() for c in ctxs]
-            assert st[0]["passes"] == 0
-            assert st[1]["passes"] >= 6 and st[1]["misses"] < 0.5 * st[1]["queries"], st[1]
-            assert st[3]["passes"] >= 6
-    finally:
-        for c in ctxs: c.close()
-
-
-@pytest.mark.gpu
 def test_host_calculate_H_equals_gpu_rows(hip, scene, oracle):
     """Localizer::calculate_H of the host mirror (flimo_calculate_H_host: the fit kernel's own row routine compiled for
     the host) reproduces the rows the GPU built, bit for bit, from the matches the GPU reports -- with and without the
