@@ -450,9 +450,9 @@ class HipCtx:
         self._chk(self._L.flimo_pass_pipeline_end(self._h))
 
     def pass_pipeline_stats(self):
-        o = (C.c_ulonglong * 2)()
+        o = (C.c_ulonglong * 4)()
         self._chk(self._L.flimo_pass_pipeline_stats(self._h, o))
-        return dict(published=int(o[0]), cancelled=int(o[1]))
+        return dict(published=int(o[0]), cancelled=int(o[1]), aged=int(o[2]), left=int(o[3]))
 
     def chain_stats(self, reset=False):
         o = np.zeros(5)

@@ -11,6 +11,7 @@
 #include <math.h>
 #include <string>
 #include <chrono>
+#include <thread>
 #include <array>
 #include <vector>
 #include <algorithm>
@@ -229,13 +230,15 @@ struct flimo_ctx {
   ChainHead* d_pipe_head = nullptr;      // fine-grained device memory (host-writable); nullptr: not available on this system
   unsigned int pipe_tag = 0;
   unsigned long long pipe_published = 0, pipe_cancelled = 0;   // statistics
+  unsigned long long pipe_aged = 0, pipe_left = 0;             // passes found too old to be published to / that left before the publish reached them
+  int test_publish_delay_ms = 0;         // FLIMO_TEST_PUBLISH_DELAY_MS (tests): a sleep between the age check of a waiting pass and the publish
+  PrevPass prev_before{};                // `prev` as the pass in flight was given it (a pass that has to be launched a second time)
   // Which way the iterated update runs: the chain costs about 11 us per pass on top of the pass's kernels whatever the host (the
   // algebra launch and two dispatch boundaries); the host loop costs this host's launch -> result round trip + 2-3 us of algebra --
   // 9 us on a fast host, 15-19 us on a slow one (BENCH_r03: 5 497 scans/s where the builder's box gave 7 102).  The round trip is
-  // measured once at context creation (launch_rtt_us); update_mode 0 = choose by it, 1 = host loop, 2 = chain.
+  // measured once at context creation (launch_rtt_us) and REPORTED; update_mode 0 and 1 = host loop, 2 = chain (the caller's choice).
   int update_mode = 0;                   // FLIMO_HOST_UPDATE=1 -> 1, FLIMO_HOST_UPDATE=0 -> 2, unset -> 0 (flimo_set_update_mode)
   double launch_rtt_us = 0.0;            // launch -> granule seen (lower quartile) of a one-thread kernel on this host
-  double rtt_threshold_us = 8.0;         // FLIMO_RTT_THRESHOLD_US: the chain is chosen when the round trip is longer
   bool host_update = false;              // (the choice in force) flimo_update_chain always declines (the host loop runs the update; A/B)
   hipEvent_t chain_ev[CH_MAX_PASSES][8]; // per pass: [0,1] first launch, [2,3] fit launch, [4,5] algebra launch, [6,7] widening launch (lazy)
   bool chain_ev_made = false;
@@ -312,9 +315,8 @@ static int ensure_dev(flimo_ctx* c, T*& p, size_t& cap, size_t need, bool keep, 
 //   FLIMO_FULL_REBUILD=1          the index is sorted from scratch on every insert (default: merged)
 //   FLIMO_HOST_INSERT=1           the first batch goes through the host statement of the insert rule, then is imported
 //   FLIMO_LAZY_DESKEW=0           the deskew always runs as a dispatch of its own (default: on the scan's first k-NN launch)
-//   FLIMO_HOST_UPDATE=<1|0>       the iterated update runs as a host loop over single passes / as a chain queued at once (flimo_update_chain),
-//                                 whatever the host (default: chosen by the launch -> result round trip measured at context creation)
-//   FLIMO_RTT_THRESHOLD_US=<us>   ... the round trip above which the chain is chosen (8)
+//   FLIMO_HOST_UPDATE=<1|0>       the iterated update runs as a host loop over single passes (the default) / as a chain queued at once
+//                                 (flimo_update_chain)
 //   FLIMO_PIPELINE=0              host loop: no pass is queued ahead of the filter's algebra (default: the next one-launch pass waits on the
 //                                 GPU for its pose, which the host stores into device memory)
 //   FLIMO_PROF_PASS / FLIMO_PROF_INSERT   host-side timing prints (stderr)
@@ -343,8 +345,32 @@ static void load_dev_switches(flimo_ctx* c) {
   if (env_int("FLIMO_HOST_INSERT", v)) c->host_insert = v != 0;
   if (env_int("FLIMO_LAZY_DESKEW", v)) c->lazy_deskew = v != 0;
   if (env_int("FLIMO_HOST_UPDATE", v)) c->update_mode = v != 0 ? 1 : 2;
-  { const char* e = getenv("FLIMO_RTT_THRESHOLD_US"); if (e && atof(e) > 0) c->rtt_threshold_us = atof(e); }
   if (env_int("FLIMO_PIPELINE", v)) { c->pipeline = v != 0; c->pipeline_env = true; }
+  if (env_int("FLIMO_TEST_PUBLISH_DELAY_MS", v) && v > 0) c->test_publish_delay_ms = v;
+}
+
+// Does the GPU see what the HOST stores into this allocation?  The host writes a pattern into the head's epoch word (a plain store
+// through the BAR, as publish_prelaunch does), a one-thread kernel reads the word past the caches and hands it back in a granule
+// of mapped host memory; twice, with different patterns.  A mapping that is missing altogether would fault at the first store --
+// the large-BAR attribute is what stands for its presence (hipPointerGetAttributes reports such memory as plain device memory);
+// FLIMO_NO_BAR=1 switches the path off on a system where that is not enough.
+static bool host_store_probe(flimo_ctx* c, ChainHead* head) {
+  volatile unsigned long long* tagp = reinterpret_cast<volatile unsigned long long*>(c->h_chain_res) + 1;
+  for (unsigned int round = 0; round < 2; round++) {
+    const unsigned int pattern = 0x5a17c0deu ^ (round * 0x01010101u);
+    __atomic_store_n(&head->epoch, pattern, __ATOMIC_RELEASE);
+    _mm_sfence();
+    const unsigned long long tag = 0x7200000000000000ull + round;
+    launch_word_probe(c->stream, &head->epoch, c->d_chain_res, tag);
+    if (hipStreamSynchronize(c->stream) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (*tagp != tag) return false;
+    const double seen = c->h_chain_res[0];
+    if ((unsigned int)llround(seen) != pattern) return false;
+  }
+  __atomic_store_n(&head->epoch, 0u, __ATOMIC_RELEASE);
+  _mm_sfence();
+  memset(c->h_chain_res, 0, 2 * sizeof(double));
+  return true;
 }
 
 // ---- context ----------------------------------------------------------------------------------
@@ -426,8 +452,9 @@ extern "C" int flimo_ctx_create(int device, flimo_ctx** out) {
     void* p = nullptr;
     int large_bar = 0;
     (void)hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device);      // (host stores into device memory need the whole of it behind the BAR)
+    if (getenv("FLIMO_NO_BAR") != nullptr) large_bar = 0;      // (stands in for a system that does not map device memory for the host)
     if (large_bar && hipExtMallocWithFlags(&p, sizeof(ChainHead), hipDeviceMallocFinegrained) == hipSuccess && p &&
-        hipMemset(p, 0, sizeof(ChainHead)) == hipSuccess && hipDeviceSynchronize() == hipSuccess) {
+        hipMemset(p, 0, sizeof(ChainHead)) == hipSuccess && hipDeviceSynchronize() == hipSuccess && host_store_probe(c, static_cast<ChainHead*>(p))) {
       c->d_pipe_head = static_cast<ChainHead*>(p);
       void* q = nullptr;
       if (getenv("FLIMO_NO_FRAMES_BAR") == nullptr && hipExtMallocWithFlags(&q, 2 * FRAMES_FG_SLOT, hipDeviceMallocFinegrained) == hipSuccess && q)
@@ -458,7 +485,7 @@ extern "C" int flimo_ctx_create(int device, flimo_ctx** out) {
     std::sort(rt.begin(), rt.end());
     c->launch_rtt_us = rt[rt.size() / 4];
     memset(c->h_chain_res, 0, 2 * sizeof(double));
-    c->host_update = c->update_mode == 1 || (c->update_mode == 0 && c->launch_rtt_us <= ((c->pipeline && c->d_pipe_head) ? 2.0 : 1.0) * c->rtt_threshold_us);
+    c->host_update = c->update_mode != 2;          // (the round trip is reported, not acted on: see auto_host_update)
   }
   *out = c;
   return FLIMO_OK;
@@ -1486,12 +1513,13 @@ extern "C" int flimo_fine_stats(const flimo_ctx* c, unsigned long long out[4]) {
   out[0] = c->fine_valid ? 1 : 0; out[1] = c->fine_valid ? c->fine.n_pts : 0; out[2] = c->fine_builds; out[3] = c->fine_passes;
   return FLIMO_OK;
 }
-extern "C" int flimo_tie_stats(const flimo_ctx* c, unsigned long long out[2]) {
+extern "C" int flimo_tie_stats(flimo_ctx* c, unsigned long long out[2]) {
   if (!c || !out) return FLIMO_ERR_INVALID;
   out[0] = c->tie_redos; out[1] = c->tie_queries;
-  // + the queries settled inside the reducing launches (counted on the device; the stream is drained for the read)
+  // + the queries settled inside the reducing launches (counted on the device).  NOT a passive getter: the context is entered (a
+  // pass queued ahead of its pose is told to leave) and the stream drained for the read -- the owner's thread only.
   unsigned long long dev = 0;
-  ctx_enter(const_cast<flimo_ctx*>(c));
+  ctx_enter(c);
   if (c->d_tie_settled && hipMemcpy(&dev, c->d_tie_settled, sizeof(dev), hipMemcpyDeviceToHost) == hipSuccess) out[1] += dev;
   return FLIMO_OK;
 }
@@ -1602,12 +1630,12 @@ static inline void publish_prelaunch(flimo_ctx* c, const PoseMats& P, const floa
   c->pipe_published++;
 }
 
-// which layout the automatic mode takes: the host loop while this host's launch round trip is below the threshold -- twice the
-// threshold when the loop is pipelined (its iterations then pay a store into device memory instead of a launch)
-static inline bool auto_host_update(const flimo_ctx* c) {
-  const double thr = (c->pipeline && c->d_pipe_head) ? 2.0 * c->rtt_threshold_us : c->rtt_threshold_us;
-  return c->launch_rtt_us <= thr;
-}
+// Which layout runs is the caller's choice, never a measurement's: the two layouts agree to 1e-15 per pass, not bit for bit (libm
+// against the device's sin / cos / acos), so a choice made from a launch round trip measured at context creation -- as round 4
+// did, with a threshold inside the spread of the hosts it ran on -- made the filter's bits depend on timing noise.  Mode 0 is the
+// host loop (pipelined where the device maps fine-grained memory); the chain runs when it is asked for (flimo_set_update_mode(2),
+// FLIMO_HOST_UPDATE=0): a host whose launch round trip is beyond ~16 us is better off with it.
+static inline bool auto_host_update(const flimo_ctx*) { return true; }
 
 static int check_abandoned(flimo_ctx* c) {
   if (!c->timeout_pending) return FLIMO_OK;
@@ -1627,24 +1655,34 @@ static bool tags_complete(const flimo_ctx* c, unsigned long long want) {
   }
   return true;
 }
-static int wait_tags(flimo_ctx* c, unsigned long long want) {
+// left_ms >= 0: the pass was published to a launch that had been waiting for it (pipelined host loop).  Such a launch leaves as a whole
+// when its wait ran out before the publish reached it (chain_enter's decision word) -- nothing of the pass has run then, no ticket
+// was touched: FLIMO_PASS_LEFT tells the caller to launch the pass the usual way.  Its own bound is a little over the launch's.
+constexpr int FLIMO_PASS_LEFT = 1000;
+static int wait_tags(flimo_ctx* c, unsigned long long want, int left_ms = -1) {
   const volatile unsigned long long* t0 = reinterpret_cast<const volatile unsigned long long*>(c->h_granules);
   unsigned long long spins = 0;
   double deadline = 0.0;
   auto now_s = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   if (c->wait_timeout_ms == 0) return abandon_wait(c, "pass", want);      // "do not wait at all" (the error path's test hook)
+  const int bound_ms = left_ms >= 0 ? std::min(left_ms, c->wait_timeout_ms) : c->wait_timeout_ms;
   for (;;) {
     if (t0[2 * (FIT_LIVE + 1) + 1] == want && tags_complete(c, want)) return FLIMO_OK;
     _mm_pause();
     if ((++spins & 0x3fffull) != 0) continue;            // look at the clock every 16k polls (about 0.1 ms)
+    // (a pass published to a waiting launch: the launch's own verdict, read through the BAR -- "left" ends the wait at once)
+    if (left_ms >= 0 && c->d_pipe_head &&
+        __atomic_load_n(&c->d_pipe_head->decision, __ATOMIC_ACQUIRE) == (ch_epoch_of(want) | 0x80000000u)) return FLIMO_PASS_LEFT;
     const double t = now_s();
-    if (deadline == 0.0) { deadline = t + 1e-3 * (double)c->wait_timeout_ms; continue; }
+    if (deadline == 0.0) { deadline = t + 1e-3 * (double)bound_ms; continue; }
     if (t < deadline) continue;
     // out of time: what does the stream say?
     const hipError_t q = hipStreamQuery(c->stream);
+    if (q == hipErrorNotReady && left_ms >= 0 && bound_ms < c->wait_timeout_ms) { left_ms = -1; deadline = t + 1e-3 * (double)(c->wait_timeout_ms - bound_ms); continue; }   // (still running: the usual bound)
     if (q == hipErrorNotReady) return abandon_wait(c, "pass", want);
     if (q != hipSuccess) return fail(c, FLIMO_ERR_HIP, "pass %llu failed: %s", want, hipGetErrorString(q));
     if (tags_complete(c, want)) return FLIMO_OK;          // arrived while we looked
+    if (left_ms >= 0) return FLIMO_PASS_LEFT;
     // the stream is idle and the result never arrived: a ticket was left behind by an aborted launch.  Re-arm and report.
     (void)hipMemsetAsync(c->d_ticket, 0, (FIT_GROUPS + 2) * sizeof(unsigned int), c->stream);
     (void)hipMemsetAsync(c->d_wl_count, 0, sizeof(int), c->stream);
@@ -1707,8 +1745,8 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   bool use_pre = c->pre.active && !general_k && c->prev.valid && c->pre.nq == nq && c->pre.seq == c->pass_seq + 1 &&
                  same_match_cfg(c->pre.cfg, *cfg) && c->pre.grid_version == grid_version && !c->deskew_pending &&
                  !(nq < c->sorted_n || (c->sorted_n < c->scan_n && nq > c->sorted_n)) && c->pre.n_all == (int)c->sorted_n &&
-                 !c->debug_recs && !(cfg->MAX_NUM_MATCHES >= 0 && (size_t)cfg->MAX_NUM_MATCHES < nq) &&
-                 wall_s() - c->pre.t_launch < 0.25e-3 * (double)CH_POLL_MS;
+                 !c->debug_recs && !(cfg->MAX_NUM_MATCHES >= 0 && (size_t)cfg->MAX_NUM_MATCHES < nq);
+  if (use_pre && !(wall_s() - c->pre.t_launch < 0.25e-3 * (double)CH_POLL_MS)) { use_pre = false; c->pipe_aged++; }      // (this call's, but too old)
   if (!use_pre) cancel_prelaunch(c);
   pre_guard.decided = true;
   int rc = ensure_recs(c, nq);
@@ -1826,6 +1864,14 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
     use_pre = false;
   }
   if (use_pre) {
+    // (the clock once more, right before the store: the pose maths above, a page fault, a descheduled thread -- a pass whose
+    //  workgroups may be giving up is told to leave instead, and launched the usual way below)
+    const int test_delay_ms = c->test_publish_delay_ms;
+    if (wall_s() - c->pre.t_launch >= 0.25e-3 * (double)CH_POLL_MS) { cancel_prelaunch(c); use_pre = false; c->pipe_aged++; }
+    else if (test_delay_ms > 0) std::this_thread::sleep_for(std::chrono::milliseconds(test_delay_ms));      // (tests: the window the decision word closes)
+  }
+  const bool was_pre = use_pre;
+  if (use_pre) {
     publish_prelaunch(c, P, c->prev.RT, seq);
     c->fused_passes++;
   } else if (after_fine) {
@@ -1843,6 +1889,7 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   launch_knn5(c->stream, c->lanes_per_query, c->grid, c->d_scan_sorted, n_all, P, mp.max_ring, c->d_nbr, c->d_wl,
               c->d_wl_count, c->debug_recs ? c->d_cand : nullptr, c->prev, tail ? 1 : 0, tlev == 1 ? c->ev[0] : nullptr,
               tlev == 1 ? c->ev[1] : nullptr, nullptr, &tl, after_fine ? 1 : 0, seq, dkp);
+  c->prev_before = c->prev;
   if (c->prune) { memcpy(c->prev.RT, P.RT, sizeof(c->prev.RT)); c->prev.valid = 1; }   // the records now belong to this pose
   const double tpb = prof ? now_us() : 0.0;
   if (tlev > 1) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
@@ -1916,15 +1963,29 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   if (use_fit2) {
     // low-latency completion: every sum arrives as a 16-byte granule {value, pass number}; a group's slot is complete when
     // all of its tags carry this pass (the last granule stored is polled, then all are checked)
-    auto wait_granules = [&](unsigned long long want) -> int {
+    auto wait_granules = [&](unsigned long long want, int left_ms = -1) -> int {
       // slot 0 carries the launch's two counters (stored last, by the block that finishes the launch); then every group's sums
-      const int rcw = wait_tags(c, want);
+      const int rcw = wait_tags(c, want, left_ms);
       if (rcw) return rcw;
       __atomic_thread_fence(__ATOMIC_ACQUIRE);
       return FLIMO_OK;
     };
     run_overlap(c);                                    // the caller's own work, beside the launch
-    { const int rcw = wait_granules(seq); if (rcw) return rcw; }
+    {
+      int rcw = wait_granules(seq, was_pre ? CH_POLL_MS + 25 : -1);
+      if (rcw == FLIMO_PASS_LEFT) {
+        // the launch that waited for this pass left before the pose reached it, as a whole: nothing ran.  The pass queued behind it for
+        // the NEXT iteration is told to leave too, and this pass is launched the usual way (same number, same buffers).
+        cancel_prelaunch(c);
+        c->pipe_left++;
+        launch_match_fused(c->stream, c->grid, c->d_scan_sorted, n_all, P, mp, c->d_nbr, c->d_wl, c->d_wl_count, nullptr, c->prev_before,
+                           c->live_idx, c->d_fit2_partials, c->d_granules_host, c->d_ticket, seq, nullptr, nullptr, &tl, 0, nullptr, nullptr,
+                           nullptr, bookp);
+        HIPCHK(c, hipGetLastError());
+        rcw = wait_granules(seq);
+      }
+      if (rcw) return rcw;
+    }
     c->last_stragglers = (int)llround(c->h_granules[2 * FIT_LIVE]);
     c->stragglers_hist[c->pass_in_scan] = c->last_stragglers;
     const long n_ties = (long)llround(c->h_granules[2 * (FIT_LIVE + 1)]);
@@ -2066,9 +2127,9 @@ extern "C" int flimo_pass_pipeline_end(flimo_ctx* c) {
   cancel_prelaunch(c);
   return FLIMO_OK;
 }
-extern "C" int flimo_pass_pipeline_stats(const flimo_ctx* c, unsigned long long out[2]) {
+extern "C" int flimo_pass_pipeline_stats(const flimo_ctx* c, unsigned long long out[4]) {
   if (!c || !out) return FLIMO_ERR_INVALID;
-  out[0] = c->pipe_published; out[1] = c->pipe_cancelled;
+  out[0] = c->pipe_published; out[1] = c->pipe_cancelled; out[2] = c->pipe_aged; out[3] = c->pipe_left;
   return FLIMO_OK;
 }
 extern "C" int flimo_update_mode(const flimo_ctx* c, int* chained, double* launch_rtt_us) {

@@ -91,6 +91,7 @@ void launch_cap(hipStream_t st, Rec16* recs, int n, int cap);
 void launch_capreduce(hipStream_t st, const Rec16* recs, int n, int cap, double* out256, int* wl_count, unsigned long long seq);
 void launch_reduce(hipStream_t st, const Rec16* recs, int n, int nwaves, double* partials, double* out256);
 void launch_mfma_layout(hipStream_t st, double* raw256);
+void launch_word_probe(hipStream_t st, const unsigned int* src, void* out_granule, unsigned long long tag);   // the 32-bit word at src (read past the caches) as a granule
 void launch_rtt_probe(hipStream_t st, void* out_granule, unsigned long long tag);   // one 16-byte {1.0, tag} granule to mapped host memory
 // in/t are in the (Morton-)sorted order with the original index in in[k].w; writes the deskewed point
 // to out_sorted[k] (w = original index) and to out_orig[original index]

@@ -1326,11 +1326,26 @@ __device__ __forceinline__ const ChainHead* chain_enter(const ChainHead* __restr
       // (the algebra takes a few microseconds from the moment the last pass delivered: hundreds of workgroups looking at one word
       //  every 60 ns would stand in its way -- a first look, a nap of 1.5 us (the host's algebra of a pipelined loop takes two),
       //  then a look every quarter of a microsecond)
+      // Whether the launch runs or leaves is ONE decision for all of its workgroups: the first to see its constants published, to be
+      // told to leave, or to run out of time writes the verdict into the head's decision word (compare-and-swap: the first writer
+      // wins), and every workgroup follows the word -- a host thread descheduled around its publish can no longer leave half a
+      // launch running and half of it gone (tickets never completed, the host waiting for sums that cannot come).  The word holds
+      // the wait's own number (go) or that number with the top bit set (leave): older verdicts are other waits'.
+      unsigned int* dec = const_cast<unsigned int*>(&H->decision);
+      const unsigned int v_go = wait_epoch, v_no = wait_epoch | 0x80000000u;
       for (int look = 0;; look++) {
-        const unsigned int e = __hip_atomic_load(&H->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (written by a resident workgroup, or by the HOST)
-        if (e == wait_epoch) { go = 1; break; }
-        if (e == end_code) break;
-        if (wall_clock64() - t0 > (unsigned long long)CH_POLL_MS * 100000ull) break;      // 100 MHz
+        const unsigned int d = __hip_atomic_load(dec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned int e = __hip_atomic_load(&H->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (written by the HOST)
+        if (d == v_go) { go = 1; break; }
+        if (d == v_no) break;
+        unsigned int want = 0u;
+        if (e == wait_epoch) want = v_go;
+        else if (e == end_code || wall_clock64() - t0 > (unsigned long long)CH_POLL_MS * 100000ull) want = v_no;      // 100 MHz
+        if (want != 0u) {
+          unsigned int expected = d;
+          if (__hip_atomic_compare_exchange_strong(dec, &expected, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) { go = want == v_go ? 1 : 0; break; }      // (the host reads the verdict too)
+          continue;                                            // (somebody else decided first: look again)
+        }
         if (look == 0) __builtin_amdgcn_s_sleep(48);
         else __builtin_amdgcn_s_sleep(8);
       }
@@ -2468,6 +2483,15 @@ __global__ void mfma_layout_kernel(double* __restrict__ raw) {
 
 // What a host-driven pass pays on THIS host beyond its kernels: a one-thread launch that stores a 16-byte {value, tag} granule to
 // mapped host memory the way a pass publishes its sums (flimo_ctx_create times launch -> granule seen, flimo_capi.hip)
+// (flimo_capi.hip: host_store_probe) the word at `src`, read past the caches, as the value of a {value, tag} granule in host memory
+__global__ void word_probe_kernel(const unsigned int* __restrict__ src, double2* __restrict__ out, unsigned long long tag) {
+  const unsigned int w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  typedef double v2d_t __attribute__((ext_vector_type(2)));
+  v2d_t g;
+  g.x = (double)w;
+  g.y = __longlong_as_double((long long)tag);
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(out), "v"(g) : "memory");
+}
 __global__ void rtt_probe_kernel(double2* __restrict__ out, unsigned long long tag) {
   typedef double v2d_t __attribute__((ext_vector_type(2)));
   v2d_t g;
@@ -2671,6 +2695,9 @@ void launch_reduce(hipStream_t st, const Rec16* recs, int n, int nwaves, double*
   hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(1024), 0, st, partials, nwaves, out256);
 }
 
+void launch_word_probe(hipStream_t st, const unsigned int* src, void* out_granule, unsigned long long tag) {
+  hipLaunchKernelGGL(word_probe_kernel, dim3(1), dim3(1), 0, st, src, (double2*)out_granule, tag);
+}
 void launch_mfma_layout(hipStream_t st, double* raw256) {
   hipLaunchKernelGGL(mfma_layout_kernel, dim3(1), dim3(64), 0, st, raw256);
 }

@@ -30,20 +30,27 @@
 // as these types go: no member spelling of the stand-ins can leak into the library (Eigen's matrices are column-major and
 // expose no such members).
 namespace Eigen {
-class Vector3f {
-  float d_[3];
+// (templates on the scalar only so that `v.cast<double>()` -- what ROSutils.hpp does with a State's members -- has a type to
+//  return; Vector3f / Vector3d / Quaternionf / Quaterniond are the spellings the reference's callers use)
+template <typename S>
+class FlimoVector3 {
+  S d_[3];
  public:
-  Vector3f() : d_{0.f, 0.f, 0.f} {}
-  Vector3f(float x, float y, float z) : d_{x, y, z} {}
-  float& operator()(int i) { return d_[i]; }
-  float operator()(int i) const { return d_[i]; }
-  float& operator[](int i) { return d_[i]; }
-  float operator[](int i) const { return d_[i]; }
-  float x() const { return d_[0]; }
-  float y() const { return d_[1]; }
-  float z() const { return d_[2]; }
-  static Vector3f Zero() { return Vector3f(); }
+  FlimoVector3() : d_{S(0), S(0), S(0)} {}
+  FlimoVector3(S x, S y, S z) : d_{x, y, z} {}
+  S& operator()(int i) { return d_[i]; }
+  S operator()(int i) const { return d_[i]; }
+  S& operator[](int i) { return d_[i]; }
+  S operator[](int i) const { return d_[i]; }
+  S x() const { return d_[0]; }
+  S y() const { return d_[1]; }
+  S z() const { return d_[2]; }
+  static FlimoVector3 Zero() { return FlimoVector3(); }
+  template <typename T>
+  FlimoVector3<T> cast() const { return FlimoVector3<T>((T)d_[0], (T)d_[1], (T)d_[2]); }
 };
+typedef FlimoVector3<float> Vector3f;
+typedef FlimoVector3<double> Vector3d;
 class Vector4f {
   float d_[4];
  public:
@@ -52,17 +59,22 @@ class Vector4f {
   float& operator()(int i) { return d_[i]; }
   float operator()(int i) const { return d_[i]; }
 };
-class Quaternionf {
-  float qx_, qy_, qz_, qw_;
+template <typename S>
+class FlimoQuaternion {
+  S qx_, qy_, qz_, qw_;
  public:
-  Quaternionf() : qx_(0.f), qy_(0.f), qz_(0.f), qw_(1.f) {}
-  Quaternionf(float w, float x, float y, float z) : qx_(x), qy_(y), qz_(z), qw_(w) {}   // Eigen order (w,x,y,z)
-  float x() const { return qx_; }
-  float y() const { return qy_; }
-  float z() const { return qz_; }
-  float w() const { return qw_; }
-  static Quaternionf Identity() { return Quaternionf(); }
+  FlimoQuaternion() : qx_(S(0)), qy_(S(0)), qz_(S(0)), qw_(S(1)) {}
+  FlimoQuaternion(S w, S x, S y, S z) : qx_(x), qy_(y), qz_(z), qw_(w) {}   // Eigen order (w,x,y,z)
+  S x() const { return qx_; }
+  S y() const { return qy_; }
+  S z() const { return qz_; }
+  S w() const { return qw_; }
+  static FlimoQuaternion Identity() { return FlimoQuaternion(); }
+  template <typename T>
+  FlimoQuaternion<T> cast() const { return FlimoQuaternion<T>((T)qw_, (T)qx_, (T)qy_, (T)qz_); }
 };
+typedef FlimoQuaternion<float> Quaternionf;
+typedef FlimoQuaternion<double> Quaterniond;
 class Matrix3f {
   float m_[9];
  public:

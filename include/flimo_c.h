@@ -126,8 +126,10 @@ int flimo_deskew_resident(flimo_ctx* ctx, const flimo_frame* frames, size_t n_fr
  *      deskewPointCloud (:741-805) for sweeps that may reach the GPU in arrival order.  points32: n records in the reference's
  *      32-byte PointType layout (Common.hpp:100-113), host memory.  The kept points (order preserved) become the resident raw
  *      scan; *n_kept their number; *last_stamp = stamp (without the sweep offset) of the point the reference's time sort puts
- *      last; *nan_stamp = 1 when a kept stamp is NaN (the caller then takes the host path).  The FoV filter (atan2) is not
- *      offered here: its rounding is the host libm's.  Follow with flimo_deskew_resident_offset. ---- */
+ *      last; *nan_stamp = 1 when a kept stamp is NaN (the caller then takes the host path).  The FoV filter (:873-876) runs here
+ *      too (fov_active): atan2 of two floats as glibc's fdlibm routine evaluates it, checked once per context against THIS host's
+ *      libm on a set of argument pairs (a host whose atan2f rounds differently declines the filter: the call then reports
+ *      FLIMO_ERR_UNSUPPORTED and the caller filters on the host).  Follow with flimo_deskew_resident_offset. ---- */
 typedef struct flimo_filter_cfg {
   int crop_active;  float crop_min[3], crop_max[3];
   int dist_active;  float min_dist;
@@ -226,10 +228,11 @@ typedef struct flimo_chain_io {
   flimo_chain_pass log[FLIMO_CHAIN_MAX_PASSES];   /* entries 0 .. passes - 1 (+ the handed-back iteration's M / stragglers / ties) */
 } flimo_chain_io;
 int flimo_update_chain(flimo_ctx* ctx, const flimo_match_cfg* cfg, flimo_chain_io* io);
-/* Which way a caller's update runs: 0 (default) = by this host's launch -> result round trip, measured once at context creation (a
- * host-driven pass pays it every time, a chain never: flimo_update_chain declines on a fast host, where the host loop is the faster
- * of the two, and runs on a slow one: from 8 us on, from 16 us when the host loop is pipelined, FLIMO_RTT_THRESHOLD_US); 1 = always
- * decline (host loop); 2 = always run the chain.  FLIMO_HOST_UPDATE=1 / 0 preset 1 / 2.
+/* Which way a caller's update runs: 0 (default) and 1 = flimo_update_chain declines and the caller's host loop runs the update pass
+ * by pass; 2 = the chain runs.  The choice is the caller's, never a measurement's: the two layouts agree to 1e-15 per pass but not
+ * bit for bit, so a choice made from timing (round 4 chose by the launch round trip measured at context creation) made the
+ * filter's bits depend on the host.  A host whose launch -> result round trip (reported below) is beyond ~16 us gains from mode 2.
+ * FLIMO_HOST_UPDATE=1 / 0 preset 1 / 2.
  * flimo_update_mode: *chained = 1 when flimo_update_chain will run, *launch_rtt_us = the measured round trip. */
 /* Host loop, pipelined.  With the switch on, a flimo_match_reduce that ran a one-launch pass queues the NEXT pass of the same update
  * right behind it: a kernel whose workgroups are placed on the GPU when the current pass ends and wait there for their pose.  The next
@@ -238,10 +241,12 @@ int flimo_update_chain(flimo_ctx* ctx, const flimo_match_cfg* cfg, flimo_chain_i
  * over (flimo_pass_pipeline_end, right after the loop of esekfom.hpp:1652-1820) -- a pass nobody asks for is also told to leave by the
  * next call on the context and gives up by itself after 50 ms, but until then a device-wide synchronisation anywhere in the process
  * waits for it.  Off by default for that reason; fast_limo::Localizer switches it on and makes the call.  FLIMO_PIPELINE=0/1 presets it.
- * flimo_pass_pipeline_stats: {passes that found their launch waiting, queued passes nobody asked for}. */
+ * flimo_pass_pipeline_stats: {passes that found their launch waiting, queued passes nobody asked for, passes whose waiting launch was
+ * found too old to publish to (told to leave, launched the usual way), passes whose launch had left as a whole before the publish
+ * reached it (launched again)}. */
 int flimo_set_pass_pipeline(flimo_ctx* ctx, int on);
 int flimo_pass_pipeline_end(flimo_ctx* ctx);
-int flimo_pass_pipeline_stats(const flimo_ctx* ctx, unsigned long long out[2]);
+int flimo_pass_pipeline_stats(const flimo_ctx* ctx, unsigned long long out[4]);
 int flimo_set_update_mode(flimo_ctx* ctx, int mode);
 int flimo_update_mode(const flimo_ctx* ctx, int* chained, double* launch_rtt_us);
 /* out[0] = GPU ms of the algebra launches timed so far (timing level 1), out[1] = their number,
@@ -278,7 +283,7 @@ unsigned long long flimo_fused_pass_count(const flimo_ctx* ctx);
  * out[0] = passes whose rows were rebuilt after settling ties in a launch of their own (records / caps / debug path), out[1] =
  * queries settled so far -- there and inside the reducing launches of the per-pass fast paths, which settle a tied query where
  * they build its row */
-int flimo_tie_stats(const flimo_ctx* ctx, unsigned long long out[2]);
+int flimo_tie_stats(flimo_ctx* ctx, unsigned long long out[2]);   /* (enters the context and drains its stream: owner's thread only) */
 /* second level over crowded regions (cells holding > 64 points get a grid with a quarter of the cell edge and a pre-pass):
  * out[0] = active now, out[1] = map points copied into it, out[2] = times it was (re)built, out[3] = passes that ran the pre-pass */
 int flimo_fine_stats(const flimo_ctx* ctx, unsigned long long out[4]);

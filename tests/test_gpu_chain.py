@@ -198,7 +198,8 @@ def test_pipelined_host_loop_is_bit_equal_and_lets_its_last_pass_go(built, monke
         np.testing.assert_array_equal(ra[1], rb[1])
 
 
-def test_a_pass_that_fails_is_surfaced(built):
+@pytest.mark.parametrize("host_loop", [False, True])
+def test_a_pass_that_fails_is_surfaced(built, host_loop):
     """The reference's Mapper::match cannot fail (Modules/Mapper.cpp:59-86); a GPU pass can (timeout, HIP error).  C ABI: the wait
     bound 0 ("do not wait") makes flimo_match_reduce and flimo_update_chain return FLIMO_ERR_TIMEOUT while their launches are
     still queued; nothing new is queued on top of them until they are gone.  Localizer: the update is abandoned -- status -4, state
@@ -208,6 +209,7 @@ def test_a_pass_that_fails_is_surfaced(built):
     mp, scan5, imu = cfg1_scene()
     h = _lib.HipCtx()
     h.set_update_mode(2)
+    h.set_pass_pipeline(host_loop)                # (host loop: its passes are queued ahead of their poses, as the Localizer queues them)
     h.map_add(np.ascontiguousarray(mp[:, :3]))
     h.scan_set(np.ascontiguousarray(scan5[:, :3]))
     x = np.zeros(26); x[6] = 1.0; x[10] = 1.0; x[25] = -9.809
@@ -229,8 +231,11 @@ def test_a_pass_that_fails_is_surfaced(built):
     np.testing.assert_allclose(got[0], ref[0], rtol=1e-12, atol=1e-9)
     h.close()
     # ---- through the Localizer ----
+    # (both layouts of the update: the chain, and the pipelined host loop every measured host runs by default -- its abort path is
+    #  fast_limo.cpp's h_share_model failure -> Esekf::update leaves with the propagated state)
     st, w, a = imu
-    L = _localizer(False)
+    L = _localizer(host_loop)
+    assert L.hip.update_mode()["chained"] == (0 if host_loop else 1)
     L.set_flags(add_to_map=True, keep_log=False)
     L.map_add(mp)
     i = 0
@@ -259,3 +264,80 @@ def test_a_pass_that_fails_is_surfaced(built):
     dpos, ang = pose_delta(L.get_x(), x_ok)
     assert dpos < 1e-2 and ang < 1e-2
     L.close()
+
+
+def test_a_waiting_pass_that_ages_or_leaves_is_launched_again(built, monkeypatch):
+    """Pipelined host loop: the pass queued ahead of its pose gives up after CH_POLL_MS = 50 ms (flimo_chain.h).  (1) A caller that comes
+    back late (here: 30 ms between two passes, beyond the 12.5 ms age bound) finds the pass too old, tells it to leave and launches the
+    usual way.  (2) A host thread descheduled between its age check and its publish (FLIMO_TEST_PUBLISH_DELAY_MS = 70 > 50) publishes to
+    a launch that has left -- as a whole: the workgroups share one verdict (chain_enter's decision word), no ticket is touched -- and
+    the pass is launched again.  Either way the sums are the plain loop's, bit for bit, and nothing waits for seconds."""
+    import time
+    from fast_limo_amd import _lib
+    mp, scan5, imu = cfg1_scene()
+    cfg = _lib.default_match_cfg(MAX_NUM_MATCHES=10**7, MAX_NUM_PC2MATCH=10**7)
+    x = np.zeros(26); x[6] = 1.0; x[10] = 1.0; x[25] = -9.809
+    xs = [x.copy() for _ in range(4)]
+    xs[1][0] += 0.01; xs[2][0] += 0.015; xs[2][1] -= 0.004; xs[3][0] += 0.016
+    def run(pipeline, pause_s, delay_ms):
+        if delay_ms:
+            monkeypatch.setenv("FLIMO_TEST_PUBLISH_DELAY_MS", str(delay_ms))
+        h = _lib.HipCtx()
+        monkeypatch.delenv("FLIMO_TEST_PUBLISH_DELAY_MS", raising=False)
+        h.set_update_mode(1)
+        h.map_add(np.ascontiguousarray(mp[:, :3]))
+        h.scan_set(np.ascontiguousarray(scan5[:, :3]))
+        h.set_pass_pipeline(pipeline)
+        out, t0 = [], time.perf_counter()
+        for xk in xs:
+            out.append(h.match_reduce(xk, cfg))
+            if pause_s:
+                time.sleep(pause_s)
+        dt = time.perf_counter() - t0
+        h.pass_pipeline_end()
+        st = h.pass_pipeline_stats()
+        h.close()
+        return out, st, dt
+    plain, st0, _ = run(False, 0.0, 0)
+    aged, st1, dt1 = run(True, 0.030, 0)
+    if st1["published"] + st1["aged"] + st1["cancelled"] == 0:
+        pytest.skip("this device does not map fine-grained memory for the host: the plain loop runs")
+    assert st1["aged"] >= 2 and st1["left"] == 0, st1
+    left, st2, dt2 = run(True, 0.0, 70)
+    assert st2["left"] >= 2, st2                          # the launches had left as a whole; their passes were launched again
+    for got in (aged, left):
+        for ra, rb in zip(plain, got):
+            assert ra[2] == rb[2]
+            np.testing.assert_array_equal(ra[0], rb[0])
+            np.testing.assert_array_equal(ra[1], rb[1])
+    assert dt1 < 1.0 and dt2 < 1.5, (dt1, dt2)            # nobody sat out the 2 s wait bound
+
+
+def test_a_device_without_host_writable_memory_runs_the_plain_loop(built, monkeypatch):
+    """The pipelined host loop needs device memory the HOST stores into (fine-grained allocation behind a large BAR, found coherent by a
+    probe at context creation).  A context without it (FLIMO_NO_BAR=1 stands in for such a system) runs the plain loop: a pass is
+    launched when its pose is known -- same sums, bit for bit, nothing published."""
+    from fast_limo_amd import _lib
+    mp, scan5, imu = cfg1_scene()
+    cfg = _lib.default_match_cfg(MAX_NUM_MATCHES=10**7, MAX_NUM_PC2MATCH=10**7)
+    x = np.zeros(26); x[6] = 1.0; x[10] = 1.0; x[25] = -9.809
+    xs = [x.copy() for _ in range(3)]
+    xs[1][0] += 0.01; xs[2][0] += 0.015
+    got = {}
+    for nobar in (False, True):
+        if nobar:
+            monkeypatch.setenv("FLIMO_NO_BAR", "1")
+        h = _lib.HipCtx()
+        monkeypatch.delenv("FLIMO_NO_BAR", raising=False)
+        h.set_update_mode(1)
+        h.map_add(np.ascontiguousarray(mp[:, :3]))
+        h.scan_set(np.ascontiguousarray(scan5[:, :3]))
+        h.set_pass_pipeline(True)
+        got[nobar] = ([h.match_reduce(xk, cfg) for xk in xs], h.pass_pipeline_stats())
+        h.pass_pipeline_end()
+        h.close()
+    assert got[True][1]["published"] == 0 and got[True][1]["cancelled"] == 0, got[True][1]
+    for ra, rb in zip(got[False][0], got[True][0]):
+        assert ra[2] == rb[2]
+        np.testing.assert_array_equal(ra[0], rb[0])
+        np.testing.assert_array_equal(ra[1], rb[1])
