@@ -80,7 +80,7 @@ HIP_SYMBOLS = [
     "flimo_scan_voxel_filter", "flimo_raw_scan_set", "flimo_raw_scan_filter_set", "flimo_raw_scan_filter_order_set", "flimo_raw_scan_order", "flimo_deskew_resident", "flimo_deskew_resident_offset", "flimo_deskew",
     "flimo_match_reduce", "flimo_match_fetch", "flimo_match_fetch_H",
     "flimo_scan_to_world", "flimo_scan_clouds", "flimo_upload_stage", "flimo_match_reduce_overlap", "flimo_map_add_scan",
-    "flimo_set_timing", "flimo_set_timing_stride", "flimo_pass_count", "flimo_fused_pass_count", "flimo_tie_stats", "flimo_fine_stats", "flimo_map_grid_selfcheck", "flimo_set_debug_records", "flimo_set_lanes_per_query", "flimo_last_kernel_ms",
+    "flimo_set_timing", "flimo_set_timing_stride", "flimo_pass_count", "flimo_fused_pass_count", "flimo_tie_stats", "flimo_fine_stats", "flimo_map_grid_selfcheck", "flimo_set_debug_records", "flimo_last_kernel_ms",
     "flimo_last_candidates_per_query", "flimo_last_widen_count", "flimo_last_stragglers", "flimo_timing_totals", "flimo_timing_split", "flimo_set_path_switches", "flimo_set_wait_timeout_ms", "flimo_insert_rule_replay", "flimo_plane_fit5_host", "flimo_plane_eval5_host", "flimo_calculate_H_host",
     "flimo_update_chain", "flimo_chain_stats", "flimo_set_update_mode", "flimo_update_mode", "flimo_scan_adopt", "flimo_set_pass_pipeline", "flimo_pass_pipeline_end", "flimo_pass_pipeline_stats",
 ]
@@ -146,12 +146,11 @@ def load_hip():
     L.flimo_map_grid_selfcheck.restype = C.c_int
     L.flimo_map_grid_selfcheck.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.flimo_set_debug_records.argtypes = [vp, C.c_int]
-    L.flimo_set_lanes_per_query.argtypes = [vp, C.c_int]
     L.flimo_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.flimo_timing_totals.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                       C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.c_int]
     L.flimo_timing_split.argtypes = [vp, f64p, C.c_int]
-    L.flimo_set_path_switches.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    L.flimo_set_path_switches.argtypes = [vp, C.c_int, C.c_int]
     L.flimo_insert_rule_replay.argtypes = [C.c_float, C.c_int, f32p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t)]
     L.flimo_calculate_H_host.argtypes = [f64p, f32p, f32p, f32p, C.c_size_t, C.c_int, f64p, f64p]
     L.flimo_update_chain.argtypes = [vp, C.POINTER(MatchCfg), C.POINTER(ChainIO)]
@@ -393,9 +392,6 @@ class HipCtx:
     def set_debug_records(self, on=True):
         self._chk(self._L.flimo_set_debug_records(self._h, int(on)))
 
-    def set_lanes_per_query(self, l: int):
-        self._chk(self._L.flimo_set_lanes_per_query(self._h, int(l)))
-
     def last_kernel_ms(self):
         a = C.c_float(0)
         b = C.c_float(0)
@@ -408,8 +404,8 @@ class HipCtx:
         self._chk(self._L.flimo_timing_totals(self._h, C.byref(a), C.byref(b), C.byref(d), C.byref(n), C.byref(q), int(reset)))
         return dict(knn_ms=a.value, widen_ms=b.value, fit_ms=d.value, passes=n.value, queries=q.value)
 
-    def set_path_switches(self, tail=-1, fuse=-1, widen_fit=-1):
-        self._chk(self._L.flimo_set_path_switches(self._h, int(tail), int(fuse), int(widen_fit)))
+    def set_path_switches(self, tail=-1, fuse=-1):
+        self._chk(self._L.flimo_set_path_switches(self._h, int(tail), int(fuse)))
 
     def timing_split(self, reset=False):
         o = np.zeros(6)

@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <immintrin.h>
 #include "../../../include/flimo_c.h"
+#include "../../../include/flimo_dev.h"
 #include "flimo_types.h"
 #include "flimo_kernels.h"
 #include "flimo_math.h"
@@ -36,7 +37,6 @@ struct flimo_ctx {
   std::string err;
   // config
   flimo_map_cfg map_cfg{0.2f, 2, 1, 0.5f};
-  int lanes_per_query = 2;
   int timing = 0;                  // 0 off, 1 k-NN kernel only (events ride on its dispatch), 2 every stage
   int timing_stride = 1;           // level 1: time every n-th pass only (sampling keeps the perturbation small)
   bool debug_recs = false;
@@ -63,7 +63,6 @@ struct flimo_ctx {
   GBook gbook;                     // the same tree on the device: every later batch is decided there
   float4* d_batch = nullptr;       // staging for host-supplied later batches
   size_t batch_cap = 0;
-  bool host_insert = false;        // FLIMO_HOST_INSERT=1: first batch through the host book, then imported (A/B checks only)
   // scan
   float4* d_scan = nullptr;        // pc2match (body frame), caller order
   float4* d_scan_sorted = nullptr; // the same points in Morton order, w = original index
@@ -101,7 +100,6 @@ struct flimo_ctx {
   DeskewArgs deskew_args{};
   size_t deskew_n = 0;
   bool deskew_pending = false;
-  bool lazy_deskew = true;         // FLIMO_LAZY_DESKEW=0: always the stand-alone kernel (developer A/B)
   // per pass
   Rec16* d_recs = nullptr;
   RecDbg* d_dbg = nullptr;
@@ -153,8 +151,6 @@ struct flimo_ctx {
   PrevPass prev{};                 // previous pass of the same resident scan (k-NN pruning bound); valid = 0 after any scan change
   bool prune = true;               // FLIMO_PRUNE=0 disables the bound (A/B checks)
   unsigned probe_min = 96;         // FLIMO_PROBE=<n>: first pass, a query with >= n candidates in its 3x3x3 block walks its own cell first for a bound (0: off)
-  int tail_pass1 = -1;             // FLIMO_TAIL_PASS1: 1 = the first pass of a scan always uses the in-kernel tail, 0 = never, default: by the straggler count of the last scan's first pass (stragglers_hist[0])
-  int tail_max = 0;                // FLIMO_TAIL_MAX: most stragglers the last scan's pass at the same position may have published for this pass to finish its own in-kernel (0: max(1024, queries / 64))
   int stragglers_hist[4] = {1 << 30, 0, 0, 0};   // the same per pass position within a scan (0 = first pass .. 3 = fourth and later), last scan that reported
   int pass_in_scan = 0;
   int last_stragglers = -1;        // the same of the last pass (-1: not reported by that pass's path)
@@ -193,7 +189,6 @@ struct flimo_ctx {
   bool ties = true;                // FLIMO_TIES=0: leave ties to the position rule (A/B checks)
   unsigned long long tie_redos = 0, tie_queries = 0;
   unsigned long long* d_tie_settled = nullptr;   // queries whose ties were settled inside a reducing launch (tie_repair_wave), counted on the device
-  bool force_general_k = false;    // FLIMO_GENERAL_K=1: NUM_MATCH_POINTS == 5 also takes the general (any-k) pass (A/B checks)
   void* d_nbrk = nullptr;          // neighbour records of the general pass
   size_t nbrk_cap = 0;
   int wait_timeout_ms = 2000;      // wall-clock bound of the wait for a pass's result (flimo_set_wait_timeout_ms)
@@ -296,54 +291,37 @@ static int ensure_dev(flimo_ctx* c, T*& p, size_t& cap, size_t need, bool keep, 
 //  calculate_H -- lives in flimo_pose.h: the host and the device filter form the same constants from the same code)
 
 // ---- developer switches: every environment variable this library reads, in one place ------------------------------------------
-// None of them changes a result (the parity tests run under several of them); they exist for A/B measurements and fault isolation.
-//   FLIMO_LPQ=<1|2|4|8|16|32>     lanes of a wavefront per scan point in the k-NN kernel (2; other values run the separate-dispatch pass)
+// None of them changes a result (the parity tests run under them); they exist for A/B measurements, fault isolation and the tests
+// that need a path forced.  Round 5 removed the ones nothing exercised (lanes per query, forced tail / general-k, x columns, XCD
+// stripe, fine divisor / radius, host insert, eager deskew, the frames' BAR switch) together with the code paths they selected.
 //   FLIMO_FUSE=0                  k-NN and fit stay separate dispatches in every pass (default: the whole pass is one launch)
 //   FLIMO_TAIL=0                  pending queries always go to the worklist + widening dispatch instead of the in-kernel tail
-//   FLIMO_TAIL_PASS1=<0|1>        the first pass of a scan never / always uses the in-kernel tail (default: by the straggler count the
-//                                 last scan's first pass published)
-//   FLIMO_TAIL_MAX=<n>            most stragglers the pass at the same position of the last scan may have published for a pass to
-//                                 finish its own in-kernel (default max(1024, queries / 64))
 //   FLIMO_PRUNE=0                 no pruning by the previous pass's bound
 //   FLIMO_PROBE=<n>               first pass: a query with >= n candidates in its 3x3x3 block walks its own cell first (96; 0: off)
-//   FLIMO_TIES=0                  exact distance ties keep the position rule (default: the reference's first-met rule, tie_kernel)
-//   FLIMO_GENERAL_K=1             NUM_MATCH_POINTS == 5 also takes the general (any-k) pass
-//   FLIMO_FINE=0, FLIMO_FINE_THRESHOLD=<points per cell, 64>, FLIMO_FINE_DIV=<2|4|8, 4>, FLIMO_FINE_RADIUS=<m, 24>,
-//   FLIMO_FINE_MIN_POINTS=<32768>  second-level grid over crowded regions
-//   FLIMO_XSLABS=<1|2|4|8>        fine x columns per cell in the index tables (2)
-//   FLIMO_XCD_STRIPE=<chunks>     block -> scan chunk striping over the XCDs (8)
+//   FLIMO_TIES=0                  exact distance ties keep the position rule (default: the reference's first-met rule)
+//   FLIMO_FINE=0, FLIMO_FINE_THRESHOLD=<points per cell, 64>, FLIMO_FINE_MIN_POINTS=<32768>   second-level grid over crowded regions
 //   FLIMO_FULL_REBUILD=1          the index is sorted from scratch on every insert (default: merged)
-//   FLIMO_HOST_INSERT=1           the first batch goes through the host statement of the insert rule, then is imported
-//   FLIMO_LAZY_DESKEW=0           the deskew always runs as a dispatch of its own (default: on the scan's first k-NN launch)
 //   FLIMO_HOST_UPDATE=<1|0>       the iterated update runs as a host loop over single passes (the default) / as a chain queued at once
 //                                 (flimo_update_chain)
 //   FLIMO_PIPELINE=0              host loop: no pass is queued ahead of the filter's algebra (default: the next one-launch pass waits on the
 //                                 GPU for its pose, which the host stores into device memory)
+//   FLIMO_NO_BAR=1                behave like a system that does not map device memory for the host (no pipelined loop, staged IMU frames)
+//   FLIMO_TEST_PUBLISH_DELAY_MS   (tests) a sleep between the age check of a waiting pass and the publish of its pose
 //   FLIMO_PROF_PASS / FLIMO_PROF_INSERT   host-side timing prints (stderr)
-// (csrc/host: FLIMO_REFERENCE_SOLVE=1 literal two-inverse gain, FLIMO_SYNC_INSERT=1 map inserts on the caller's thread,
+// (csrc/host: FLIMO_REFERENCE_SOLVE=1 literal two-inverse gain, FLIMO_NO_FRONT_CTX=1 input stage on the main context,
 //  FLIMO_PROF_DESKEW / FLIMO_PROF_CLOUDS timing prints; bench.py: FLIMO_BENCH_*.)
 static void load_dev_switches(flimo_ctx* c) {
   auto env_int = [](const char* name, int& out) { const char* e = getenv(name); if (!e) return false; out = atoi(e); return true; };
   int v = 0;
-  if (env_int("FLIMO_LPQ", v) && (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32)) c->lanes_per_query = v;
   if (env_int("FLIMO_FUSE", v)) c->fuse = v != 0;
   if (env_int("FLIMO_TAIL", v)) c->tail = v != 0;
-  if (env_int("FLIMO_TAIL_PASS1", v)) c->tail_pass1 = v != 0;
-  if (env_int("FLIMO_TAIL_MAX", v) && v > 0) c->tail_max = v;
   if (env_int("FLIMO_PRUNE", v)) c->prune = v != 0;
   if (env_int("FLIMO_PROBE", v) && v >= 0) c->probe_min = (unsigned)v;
   if (env_int("FLIMO_TIES", v)) c->ties = v != 0;
-  if (env_int("FLIMO_GENERAL_K", v)) c->force_general_k = v != 0;
   if (env_int("FLIMO_FINE", v)) c->fine_on = v != 0;
   if (env_int("FLIMO_FINE_THRESHOLD", v) && v > 0) c->fine_threshold = (unsigned)v;
-  if (env_int("FLIMO_FINE_DIV", v) && (v == 2 || v == 4 || v == 8)) c->fine_div = v;
   if (env_int("FLIMO_FINE_MIN_POINTS", v) && v >= 0) c->fine_min_points = (unsigned)v;
-  { const char* e = getenv("FLIMO_FINE_RADIUS"); if (e && atof(e) > 0) c->fine_radius = (float)atof(e); }
-  if (env_int("FLIMO_XSLABS", v) && (v == 1 || v == 2 || v == 4 || v == 8)) c->xslabs = v;
-  if (env_int("FLIMO_XCD_STRIPE", v)) set_xcd_stripe(v);
   if (env_int("FLIMO_FULL_REBUILD", v)) c->full_rebuild = v != 0;
-  if (env_int("FLIMO_HOST_INSERT", v)) c->host_insert = v != 0;
-  if (env_int("FLIMO_LAZY_DESKEW", v)) c->lazy_deskew = v != 0;
   if (env_int("FLIMO_HOST_UPDATE", v)) c->update_mode = v != 0 ? 1 : 2;
   if (env_int("FLIMO_PIPELINE", v)) { c->pipeline = v != 0; c->pipeline_env = true; }
   if (env_int("FLIMO_TEST_PUBLISH_DELAY_MS", v) && v > 0) c->test_publish_delay_ms = v;
@@ -457,7 +435,7 @@ extern "C" int flimo_ctx_create(int device, flimo_ctx** out) {
         hipMemset(p, 0, sizeof(ChainHead)) == hipSuccess && hipDeviceSynchronize() == hipSuccess && host_store_probe(c, static_cast<ChainHead*>(p))) {
       c->d_pipe_head = static_cast<ChainHead*>(p);
       void* q = nullptr;
-      if (getenv("FLIMO_NO_FRAMES_BAR") == nullptr && hipExtMallocWithFlags(&q, 2 * FRAMES_FG_SLOT, hipDeviceMallocFinegrained) == hipSuccess && q)
+      if (hipExtMallocWithFlags(&q, 2 * FRAMES_FG_SLOT, hipDeviceMallocFinegrained) == hipSuccess && q)
         c->d_frames_fg = static_cast<char*>(q);
       else (void)hipGetLastError();
     } else {
@@ -940,47 +918,16 @@ extern "C" int flimo_map_add(flimo_ctx* c, const float* xyz, size_t n, size_t st
   int rc = ensure_stage(c, n * sizeof(float4));
   if (rc) return rc;
   float4* st = (float4*)c->h_stage;
-  if (!c->host_insert) {
-    // Octree::initialize / Octree::update on the device (flimo_gbook.hip)
-    const unsigned char* b = (const unsigned char*)xyz;
-    for (size_t i = 0; i < n; i++) {
-      const float* p = (const float*)(b + i * stride_bytes);
-      st[i].x = p[0]; st[i].y = p[1]; st[i].z = p[2]; st[i].w = 0.f;
-    }
-    rc = ensure_dev(c, c->d_batch, c->batch_cap, n, false, 0);
-    if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->d_batch, st, n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
-    return map_add_device(c, c->d_batch, n, stamp);
-  }
-  // Octree::processPoints: drop NaNs (Octree.hpp:243-244); then the reference's insert rule decides
-  // which points are stored (first batch: all; later batches: Octree::updateOctant semantics).
-  std::vector<float> packed;
-  packed.reserve(n * 3);
+  // Octree::initialize / Octree::update on the device (flimo_gbook.hip)
   const unsigned char* b = (const unsigned char*)xyz;
   for (size_t i = 0; i < n; i++) {
     const float* p = (const float*)(b + i * stride_bytes);
-    if (std::isnan(p[0]) || std::isnan(p[1]) || std::isnan(p[2])) continue;
-    packed.push_back(p[0]); packed.push_back(p[1]); packed.push_back(p[2]);
+    st[i].x = p[0]; st[i].y = p[1]; st[i].z = p[2]; st[i].w = 0.f;
   }
-  const size_t m = packed.size() / 3;
-  std::vector<unsigned char> keep(m, 1);
-  insert_book_update(c->book, packed.data(), m, keep.data());
-  size_t k = 0;
-  for (size_t i = 0; i < m; i++) {
-    if (!keep[i]) continue;
-    st[k].x = packed[3 * i]; st[k].y = packed[3 * i + 1]; st[k].z = packed[3 * i + 2];
-    for (int a = 0; a < 3; a++) { const float v = packed[3 * i + a]; if (v < c->bb[a]) c->bb[a] = v; if (v > c->bb[3 + a]) c->bb[3 + a] = v; }
-    const uint32_t id = (uint32_t)(c->map_n + k);
-    memcpy(&st[k].w, &id, 4);
-    k++;
-  }
-  rc = map_append_host(c, st, k);
+  rc = ensure_dev(c, c->d_batch, c->batch_cap, n, false, 0);
   if (rc) return rc;
-  rc = rebuild_grid(c);
-  if (rc) return rc;
-  c->map_last_time = stamp;
-  if (!c->host_insert && c->map_n > 0) return gbook_import(c);
-  return FLIMO_OK;
+  HIPCHK(c, hipMemcpyAsync(c->d_batch, st, n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+  return map_add_device(c, c->d_batch, n, stamp);
 }
 
 extern "C" int flimo_map_points(flimo_ctx* c, float* out, size_t cap, size_t* n) {
@@ -1424,7 +1371,7 @@ extern "C" int flimo_deskew_resident_offset(flimo_ctx* c, const flimo_frame* fra
   if (n == 0) { c->scan_n = 0; c->sorted_n = 0; c->prev.valid = 0; return FLIMO_OK; }
   const size_t fbytes = nf * sizeof(flimo_frame);
   const size_t total = fbytes + 32 * sizeof(float);
-  if (c->d_frames_fg && total <= FRAMES_FG_SLOT && c->lazy_deskew) {
+  if (c->d_frames_fg && total <= FRAMES_FG_SLOT) {
     // The host stores frames + matrices straight into (fine-grained) device memory: no copy launch and no dispatch boundary ahead of
     // the pass the deskew rides on.  Two slots, alternating: a pass that still reads the last sweep's is not disturbed.
     alignas(64) char buf[FRAMES_FG_SLOT];
@@ -1482,7 +1429,6 @@ extern "C" int flimo_deskew_resident_offset(flimo_ctx* c, const flimo_frame* fra
                               t_offset, c->d_scan_sorted, c->d_scan, 1, 0};
   c->deskew_n = n;
   c->deskew_pending = true;
-  if (!c->lazy_deskew) { const int rcf = flush_deskew(c); if (rcf) return rcf; }
   c->async_deskews++;
   c->scan_n = n; c->sorted_n = n; c->prev.valid = 0;
   return FLIMO_OK;
@@ -1498,7 +1444,7 @@ extern "C" int flimo_deskew(flimo_ctx* c, const float* xyz, size_t n, size_t str
 // ---- measurement pass -------------------------------------------------------------------------
 extern "C" int flimo_set_timing(flimo_ctx* c, int level) {
   if (!c) return FLIMO_ERR_INVALID;
-  c->timing = level < 0 ? 0 : (level > 2 ? 2 : level);
+  c->timing = level > 0 ? 1 : 0;          // (level 2 -- events around every stage, synchronous -- went with the A/B kernels it timed)
   if (c->timing == 1 && !c->chain_ev_made) {      // the chained update's per-pass events: made here, not inside a timed update
     ctx_enter(c);
     for (int i = 0; i < CH_MAX_PASSES; i++) for (int k = 0; k < 8; k++) HIPCHK(c, hipEventCreate(&c->chain_ev[i][k]));
@@ -1525,12 +1471,6 @@ extern "C" int flimo_tie_stats(flimo_ctx* c, unsigned long long out[2]) {
 }
 extern "C" int flimo_set_timing_stride(flimo_ctx* c, int every) { if (!c || every < 1) return FLIMO_ERR_INVALID; c->timing_stride = every; return FLIMO_OK; }
 extern "C" int flimo_set_debug_records(flimo_ctx* c, int on) { if (!c) return FLIMO_ERR_INVALID; c->debug_recs = on != 0; return FLIMO_OK; }
-extern "C" int flimo_set_lanes_per_query(flimo_ctx* c, int l) {
-  if (!c) return FLIMO_ERR_INVALID;
-  if (!(l == 1 || l == 2 || l == 4 || l == 8 || l == 16 || l == 32)) return fail(c, FLIMO_ERR_INVALID, "lanes per query must be 1,2,4,8,16,32");
-  c->lanes_per_query = l;
-  return FLIMO_OK;
-}
 extern "C" int flimo_last_kernel_ms(const flimo_ctx* c, float* knn_ms, float* widen_ms, float* fit_ms) {
   if (!c) return FLIMO_ERR_INVALID;
   if (knn_ms) *knn_ms = c->last_knn_ms;
@@ -1552,9 +1492,8 @@ extern "C" int flimo_timing_totals(flimo_ctx* c, double* knn_ms, double* widen_m
   return FLIMO_OK;
 }
 // developer / benchmark A/B: negative leaves a switch as it is
-extern "C" int flimo_set_path_switches(flimo_ctx* c, int tail, int fuse, int widen_fit) {
+extern "C" int flimo_set_path_switches(flimo_ctx* c, int tail, int fuse) {
   if (!c) return FLIMO_ERR_INVALID;
-  (void)widen_fit;                 // (round 4: widening and fit are always two launches; the argument is accepted and ignored)
   if (tail >= 0) c->tail = tail != 0;
   if (fuse >= 0) c->fuse = fuse != 0;
   return FLIMO_OK;
@@ -1722,7 +1661,7 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   if (!c || !x26 || !cfg || !HTH || !HTh || !M) return FLIMO_ERR_INVALID;
   if (cfg->NUM_MATCH_POINTS < 3 || cfg->NUM_MATCH_POINTS > 8)
     return fail(c, FLIMO_ERR_UNSUPPORTED, "NUM_MATCH_POINTS must be in 3..8 (a plane needs 3 points; the neighbour records hold 8)");
-  const bool general_k = cfg->NUM_MATCH_POINTS != 5 || c->force_general_k;
+  const bool general_k = cfg->NUM_MATCH_POINTS != 5;
   // (a pass queued ahead of this call -- pipelined host loop -- is either this call's, decided below before anything is queued, or
   //  told to leave: every early way out of this function cancels it)
   struct PreGuard { flimo_ctx* c; bool decided = false; ~PreGuard() { if (!decided) cancel_prelaunch(c); } } pre_guard{c};
@@ -1776,7 +1715,7 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   const int n_all = (int)c->sorted_n;                 // resident query set (== nq, or the whole scan when no cap binds)
   // A pending deskew rides on this pass's k-NN launch when that launch covers the whole scan and is the first to read it
   const bool ride = c->deskew_pending && !general_k && c->deskew_n == (size_t)n_all &&
-                    !(c->fine_valid && c->lanes_per_query == 2 && mp.max_ring >= 1);     // (a fine pre-pass reads the scan first)
+                    !(c->fine_valid && mp.max_ring >= 1);     // (a fine pre-pass reads the scan first)
   if (!ride) { const int rcf = flush_deskew(c); if (rcf) return rcf; }
   const DeskewArgs* dkp = ride ? &c->deskew_args : nullptr;
   c->deskew_pending = false;
@@ -1822,7 +1761,6 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   const double tpa = prof ? now_us() : 0.0;
   // effective level of THIS pass (level 1 may sample every timing_stride-th pass)
   const int tlev = (c->timing == 1 && c->timing_stride > 1 && ((c->pass_seq + 1) % (unsigned long long)c->timing_stride) != 0) ? 0 : c->timing;
-  if (tlev > 1) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   // level 1: the two events ride on the k-NN dispatch itself (kernel begin / end, no extra packets)
   // the k-NN launch finishes its own stragglers (in-kernel tail) for gates of up to 3 rings; the worklist + widening dispatch
   // remains for wider gates and for the developer switch FLIMO_TAIL=0
@@ -1836,14 +1774,14 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   // sweeps over a 900 m map) keeps thousands of points beyond their 3x3x3 block in every pass
   // The bound grows with the scan: what hurts is a wave whose queries are ALL pending (one long chain), and a launch of n
   // queries spreads 1/64 of them over its waves a handful at a time (FLIMO_TAIL_MAX overrides)
-  const int tail_max = c->tail_max > 0 ? c->tail_max : std::max(1024, n_all / 64);
-  const bool tail_here = first_pass ? (c->tail_pass1 >= 0 ? c->tail_pass1 != 0 : c->stragglers_hist[0] <= tail_max)
+  const int tail_max = std::max(1024, n_all / 64);
+  const bool tail_here = first_pass ? (c->stragglers_hist[0] <= tail_max)
                                     : (c->stragglers_hist[c->pass_in_scan] <= tail_max);
   const bool tail = c->tail && tail_here && mp.max_ring >= 2 && mp.max_ring <= 3;
   c->prev.probe_min = c->probe_min;
   // One launch for the whole pass (k-NN + tail + fit + reduction) whenever the tail applies, no records are wanted and the
   // k-NN runs with its default two lanes per query
-  const bool fused = tail && c->fuse && !want_recs && tlev < 2 && c->lanes_per_query == 2;
+  const bool fused = tail && c->fuse && !want_recs;
   const unsigned long long seq = ++c->pass_seq;
   // exact distance ties: the reference's choice needs the octree's visiting order, i.e. the device insert book
   const bool ties_on = c->ties && c->gbook.active;
@@ -1851,12 +1789,12 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   tl.count_next = c->d_tie_count + ((seq + 1) & 1);            // re-armed by this pass's reduction for the next pass
   // The per-pass fast paths (one launch / k-NN + widening + fit2) settle ties where they build the rows (tie_repair_wave): no list,
   // the count they publish stays 0.  The records / caps / debug path lists them for tie_kernel as before.
-  const bool inline_ties = ties_on && !want_recs && tlev < 2;
+  const bool inline_ties = ties_on && !want_recs;
   if (ties_on && !inline_ties) { tl.list = c->d_tie_list; tl.count = c->d_tie_count + (seq & 1); tl.cap = (unsigned)c->tie_cap; }
   const BookView book{c->gbook.node_c, c->gbook.node_child, c->gbook.node_cnt, c->gbook.root, c->d_tie_settled};
   const BookView* bookp = inline_ties ? &book : nullptr;
   // crowded regions first: the fine pre-pass settles the queries whose five lie within centimetres (second-level grid)
-  const bool after_fine = c->fine_valid && c->lanes_per_query == 2 && mp.max_ring >= 1;
+  const bool after_fine = c->fine_valid && mp.max_ring >= 1;
   if (use_pre && !(fused && !after_fine && tlev == 0)) {
     // (what was queued ahead is a one-launch pass without a fine pre-pass and without timing events: anything else -- a straggler
     //  count that changed the layout, a sampled pass -- is launched the usual way)
@@ -1886,13 +1824,12 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
                        tlev == 1 ? c->ev[1] : nullptr, &tl, after_fine ? 1 : 0, dkp, nullptr, nullptr, bookp);
     c->fused_passes++;
   } else
-  launch_knn5(c->stream, c->lanes_per_query, c->grid, c->d_scan_sorted, n_all, P, mp.max_ring, c->d_nbr, c->d_wl,
+  launch_knn5(c->stream, 2, c->grid, c->d_scan_sorted, n_all, P, mp.max_ring, c->d_nbr, c->d_wl,
               c->d_wl_count, c->debug_recs ? c->d_cand : nullptr, c->prev, tail ? 1 : 0, tlev == 1 ? c->ev[0] : nullptr,
               tlev == 1 ? c->ev[1] : nullptr, nullptr, &tl, after_fine ? 1 : 0, seq, dkp);
   c->prev_before = c->prev;
   if (c->prune) { memcpy(c->prev.RT, P.RT, sizeof(c->prev.RT)); c->prev.valid = 1; }   // the records now belong to this pose
   const double tpb = prof ? now_us() : 0.0;
-  if (tlev > 1) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
   // A separate-dispatch pass is three launches: k-NN, widening of the worklist (one wave per pending query, dealt out over the whole
   // chip), fit + reduction.  (Rounds 3's widen_fit_kernel ran the last two as one launch, its fit workgroups polling records its
   // widening workgroups were still writing: 3 us per step bought with a forward-progress assumption and relaxed cross-XCD reads --
@@ -1903,13 +1840,12 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
                  c->debug_recs ? c->d_cand : nullptr, widen_timed ? c->ev[4] : nullptr, widen_timed ? c->ev[5] : nullptr, &tl);
   const double tpc = prof ? now_us() : 0.0;
   if (want_count) HIPCHK(c, hipMemcpyAsync(c->h_wl_count, c->d_wl_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  if (tlev > 1) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   // fit + reductions; the last block writes the 16x16 accumulator to mapped host memory, publishes the
   // pass number and re-arms the ticket and the worklist counter
   // MAX_NUM_MATCHES path: the fit kernel only writes the records (no reduction), one fused kernel ranks them in scan
   // order, reduces the first MAX_NUM_MATCHES and publishes to slot 0
   const bool fused_cap = cap_binds && !c->debug_recs;
-  const bool use_fit2 = !want_recs && tlev < 2;                 // the per-pass fast path (granule results)
+  const bool use_fit2 = !want_recs;                             // the per-pass fast path (granule results)
   if (fused) {
     // the fit and the reduction ran inside the k-NN launch
   } else if (use_fit2)
@@ -1931,7 +1867,6 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
     launch_cap(c->stream, c->d_recs, (int)nq, cfg->MAX_NUM_MATCHES);
     launch_reduce(c->stream, c->d_recs, (int)nq, c->reduce_waves, c->d_partials, c->d_out256_host);
   }
-  if (tlev > 1) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
   HIPCHK(c, hipGetLastError());
   const double tp1 = prof ? now_us() : 0.0;
   if (c->debug_recs) HIPCHK(c, hipMemcpyAsync(c->h_cand, c->d_cand, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
@@ -1939,7 +1874,7 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   //      ends and wait for their constants in device memory; the next call publishes them instead of launching (use_pre above).
   //      Only the usual case is queued ahead: a one-launch pass (by the straggler count its position published in the last scan),
   //      no fine pre-pass, no timing events, no records. ----
-  if (c->pipeline && c->d_pipe_head && c->prune && use_fit2 && !want_count && c->tail && c->fuse && c->lanes_per_query == 2 &&
+  if (c->pipeline && c->d_pipe_head && c->prune && use_fit2 && !want_count && c->tail && c->fuse &&
       mp.max_ring >= 2 && mp.max_ring <= 3 && !c->fine_valid && inline_ties == ties_on) {
     const unsigned long long nseq = seq + 1;
     const int ntlev = (c->timing == 1 && c->timing_stride > 1 && (nseq % (unsigned long long)c->timing_stride) != 0) ? 0 : c->timing;
@@ -2017,7 +1952,7 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
       for (int i = 0; i < 12; i++) acc[c->mfma_idx[i][12]] = live[k++];
       acc[c->mfma_idx[13][13]] = live[k++];
     }
-  } else if (!c->debug_recs && tlev < 2) {
+  } else if (!c->debug_recs) {
     // low-latency completion: spin on the pass number every reduction group publishes to host memory (one slot on
     // the MAX_NUM_MATCHES path)
     unsigned long long spins = 0;
@@ -2044,11 +1979,7 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
       (void)hipEventElapsedTime(&c->last_knn_ms, c->ev[0], c->ev[1]);
     }
     c->tot_knn_ms += c->last_knn_ms;
-    if (tlev > 1) {
-      (void)hipEventElapsedTime(&c->last_widen_ms, c->ev[1], c->ev[2]);
-      (void)hipEventElapsedTime(&c->last_fit_ms, c->ev[2], c->ev[3]);
-      c->tot_widen_ms += c->last_widen_ms; c->tot_fit_ms += c->last_fit_ms;
-    } else if (fused) {
+    if (fused) {
       c->last_fit_ms = 0.f; c->last_widen_ms = 0.f;            // one dispatch: everything is in the k-NN figure
       c->split_fused_ms += c->last_knn_ms; c->split_fused_n++;
     } else if (use_fit2) {
@@ -2152,10 +2083,10 @@ extern "C" int flimo_update_chain(flimo_ctx* c, const flimo_match_cfg* cfg, flim
   auto decline = [&]() { c->chains_declined++; return FLIMO_OK; };
   { const int rca = check_abandoned(c); if (rca) return rca; }
   if (c->host_update) return decline();
-  if (cfg->NUM_MATCH_POINTS != 5 || c->force_general_k) return decline();
+  if (cfg->NUM_MATCH_POINTS != 5) return decline();
   const int n_pass = io->max_iter + 1;
   if (io->max_iter < 0 || n_pass > CH_MAX_PASSES) return decline();
-  if (c->debug_recs || c->timing > 1 || c->lanes_per_query != 2 || !c->tail || !c->fuse) return decline();
+  if (c->debug_recs || !c->tail || !c->fuse) return decline();
   if (!c->grid_valid && c->map_n > 0) { int rc0 = rebuild_grid(c); if (rc0) return rc0; }
   if (!c->grid_valid || c->map_n == 0) return decline();      // Mapper::match returns no matches: the host loop handles M = 0
   size_t nq = c->scan_n;
@@ -2205,7 +2136,7 @@ extern "C" int flimo_update_chain(flimo_ctx* c, const flimo_match_cfg* cfg, flim
   const BookView book{c->gbook.node_c, c->gbook.node_child, c->gbook.node_cnt, c->gbook.root, c->d_tie_settled};
   const BookView* bookp = ties_on ? &book : nullptr;
   const ChainHead* head = reinterpret_cast<const ChainHead*>(c->d_chain);
-  const int tail_max = c->tail_max > 0 ? c->tail_max : std::max(1024, n_all / 64);
+  const int tail_max = std::max(1024, n_all / 64);
   struct Plan { int pos; bool fused, combined, timed; };
   Plan plan[CH_MAX_PASSES];
   int pos = c->pass_in_scan;
@@ -2222,7 +2153,7 @@ extern "C" int flimo_update_chain(flimo_ctx* c, const flimo_match_cfg* cfg, flim
     const unsigned long long seq = seq0 + 1 + (unsigned long long)i;
     const bool first_pass = !prev_valid;
     pos = first_pass ? 0 : std::min(pos + 1, 3);
-    const bool tail_here = first_pass ? (c->tail_pass1 >= 0 ? c->tail_pass1 != 0 : c->stragglers_hist[0] <= tail_max)
+    const bool tail_here = first_pass ? (c->stragglers_hist[0] <= tail_max)
                                       : (c->stragglers_hist[pos] <= tail_max);
     const bool fused = tail_here;
     const bool combined = false;
@@ -2486,19 +2417,14 @@ extern "C" int flimo_map_add_scan(flimo_ctx* c, const double x26[26], double sta
   if (c->scan_n == 0) return FLIMO_OK;
   for (int a = 0; a < 3; a++) c->fine_center[a] = (float)x26[a];       // the second level follows the sensor (update_fine_grid)
   c->have_fine_center = true;
-  if (!c->host_insert) {           // resident path: transform, decide, append and re-index on the device
-    ctx_enter(c);
-    PoseMats P;
-    pose_from_x26(x26, P);
-    { const int rcf = flush_deskew(c); if (rcf) return rcf; }
-    launch_transform(c->stream, c->d_scan, (int)c->scan_n, P, c->d_scan_world);      // no host wait: the insert's first read-back follows
-    HIPCHK(c, hipGetLastError());
-    return map_add_device(c, c->d_scan_world, c->scan_n, stamp);
-  }
-  std::vector<float> w(c->scan_n * 3);
-  int rc = flimo_scan_to_world(c, x26, w.data(), c->scan_n);
-  if (rc) return rc;
-  return flimo_map_add(c, w.data(), c->scan_n, 12, stamp);
+  // resident path: transform, decide, append and re-index on the device
+  ctx_enter(c);
+  PoseMats P;
+  pose_from_x26(x26, P);
+  { const int rcf = flush_deskew(c); if (rcf) return rcf; }
+  launch_transform(c->stream, c->d_scan, (int)c->scan_n, P, c->d_scan_world);      // no host wait: the insert's first read-back follows
+  HIPCHK(c, hipGetLastError());
+  return map_add_device(c, c->d_scan_world, c->scan_n, stamp);
 }
 
 // ---- host-side evaluation of the SAME plane routines the fit kernel runs (flimo_math.h is __host__ __device__):

@@ -2529,7 +2529,7 @@ static void launch_knn5_L(hipStream_t st, const GridView& G, const float4* scan_
                           unsigned int wait_epoch = 0u, unsigned int end_code = 0u) {
   const int qpb = 256 / L;
   const int blocks = round_up8((n + qpb - 1) / qpb);
-  constexpr int slots = (L <= 4 ? 8 : 4);          // candidate loads in flight per lane
+  constexpr int slots = 8;          // candidate loads in flight per lane
   if constexpr (L == 2) {
     if (fuse) {      // the whole pass in one launch (blocks is a multiple of 8 = FIT_GROUPS; a chained pass has one workgroup more)
       const int grid = fused_blocks(n) + (fuse->ch.S ? 1 : 0);
@@ -2564,14 +2564,9 @@ void launch_knn5(hipStream_t st, int lanes_per_query, const GridView& G, const f
   if (n <= 0) return;
   if (max_ring < 2 || max_ring > TAIL_MAX_RING) tail = 0;
   if (chain) { launch_knn5_L<2>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine, seq, dk, chain, wait_epoch, end_code); return; }   // (two lanes per query only)
-  switch (lanes_per_query) {
-    case 1: launch_knn5_L<1>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine, seq, dk); break;
-    case 2: launch_knn5_L<2>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine, seq, dk); break;
-    case 4: launch_knn5_L<4>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine, seq, dk); break;
-    case 8: launch_knn5_L<8>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine, seq, dk); break;
-    case 32: launch_knn5_L<32>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine, seq, dk); break;
-    default: launch_knn5_L<16>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine, seq, dk); break;
-  }
+  // (two lanes per query: the other lane counts of rounds 1-4 were A/B variants nothing selected)
+  (void)lanes_per_query;
+  launch_knn5_L<2>(st, G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand, prev, tail, e0, e1, fuse, tlp, after_fine, seq, dk);
 }
 
 void launch_widen(hipStream_t st, const GridView& G, const float4* scan_sorted, const PoseMats& P, int max_ring, void* nbr,
@@ -2598,8 +2593,7 @@ void launch_fit(hipStream_t st, const GridView& G, const float4* scan_sorted, in
     hipLaunchKernelGGL((fit_kernel<true, true, 256>), dim3(blocks), dim3(256), 0, st, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, partials, recs, dbg, out256, ticket, wl_count, seq);
   else if (recs)
     hipLaunchKernelGGL((fit_kernel<true, false, 256>), dim3(blocks), dim3(256), 0, st, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, partials, recs, dbg, out256, ticket, wl_count, seq);
-  else
-    hipLaunchKernelGGL((fit_kernel<false, false, 256>), dim3(blocks), dim3(256), 0, st, G, scan_sorted, n, (const NbrRec*)nbr, P, mp, partials, recs, dbg, out256, ticket, wl_count, seq);
+  // (the records are what this path is for: the per-pass fast path is launch_fit2 / the one-launch pass)
 }
 
 // fit2: 64 points per wave (measured: 64 -> 10.7 us, 32 -> 13.0, 16 -> 20.0: the QR is VALU-issue bound, not latency bound)

@@ -241,18 +241,14 @@ int flimo_update_chain(flimo_ctx* ctx, const flimo_match_cfg* cfg, flimo_chain_i
  * over (flimo_pass_pipeline_end, right after the loop of esekfom.hpp:1652-1820) -- a pass nobody asks for is also told to leave by the
  * next call on the context and gives up by itself after 50 ms, but until then a device-wide synchronisation anywhere in the process
  * waits for it.  Off by default for that reason; fast_limo::Localizer switches it on and makes the call.  FLIMO_PIPELINE=0/1 presets it.
- * flimo_pass_pipeline_stats: {passes that found their launch waiting, queued passes nobody asked for, passes whose waiting launch was
- * found too old to publish to (told to leave, launched the usual way), passes whose launch had left as a whole before the publish
- * reached it (launched again)}. */
+ */
 int flimo_set_pass_pipeline(flimo_ctx* ctx, int on);
 int flimo_pass_pipeline_end(flimo_ctx* ctx);
-int flimo_pass_pipeline_stats(const flimo_ctx* ctx, unsigned long long out[4]);
 int flimo_set_update_mode(flimo_ctx* ctx, int mode);
 int flimo_update_mode(const flimo_ctx* ctx, int* chained, double* launch_rtt_us);
-/* out[0] = GPU ms of the algebra launches timed so far (timing level 1), out[1] = their number,
- * out[2] = chains run, out[3] = chains that came back before the final iteration, out[4] = chains declined */
-int flimo_chain_stats(flimo_ctx* ctx, double out[5], int reset);
 /* per-point records of the last flimo_match_reduce (first min(N, MAX_NUM_PC2MATCH) points) */
+/* also write the per-point debug part of flimo_match_rec (plane, neighbours, candidate counts) */
+int flimo_set_debug_records(flimo_ctx* ctx, int on);
 int flimo_match_fetch(flimo_ctx* ctx, flimo_match_rec* out, size_t cap, size_t* n);
 /* dense H (M x 12 row-major, compacted in scan order, capped) and h of the last pass: needed by the
  * M < 23 branch of the update (esekfom.hpp:1701-1709) */
@@ -267,61 +263,11 @@ int flimo_scan_to_world(flimo_ctx* ctx, const double x26[26], float* world_xyz_o
 int flimo_scan_clouds(flimo_ctx* ctx, const double x26[26], const float** body_xyzw, const float** world_xyzw, size_t* n);
 int flimo_map_add_scan(flimo_ctx* ctx, const double x26[26], double stamp);
 
-/* ---- instrumentation ---- */
-/* GPU time [ms] of the stages of the last flimo_match_reduce, from HIP events on the ctx stream:
- * k-NN fast path, ring widening of the worklist, fit + reductions.  flimo_set_timing level:
- * 0 off, 1 k-NN kernel only (two events per pass), 2 every stage. */
-int flimo_set_timing(flimo_ctx* ctx, int level);
-/* level 1 only: time every `every`-th pass (default 1 = all); the totals count the timed passes only. */
-int flimo_set_timing_stride(flimo_ctx* ctx, int every);
-/* number of flimo_match_reduce passes launched on this context so far */
-unsigned long long flimo_pass_count(const flimo_ctx* ctx);
-/* ... of which ran as ONE launch (k-NN + in-kernel widening + fit + reduction); the others used separate dispatches (first pass
- * of a scan with a poor prior, records / caps / debug, non-default lanes per query, gates wider than 3 rings) */
-unsigned long long flimo_fused_pass_count(const flimo_ctx* ctx);
-/* exact float32 distance ties (Objects/Octree.hpp:72-87,558-599: the reference keeps the candidate its recursion meets first):
- * out[0] = passes whose rows were rebuilt after settling ties in a launch of their own (records / caps / debug path), out[1] =
- * queries settled so far -- there and inside the reducing launches of the per-pass fast paths, which settle a tied query where
- * they build its row */
-int flimo_tie_stats(flimo_ctx* ctx, unsigned long long out[2]);   /* (enters the context and drains its stream: owner's thread only) */
-/* second level over crowded regions (cells holding > 64 points get a grid with a quarter of the cell edge and a pre-pass):
- * out[0] = active now, out[1] = map points copied into it, out[2] = times it was (re)built, out[3] = passes that ran the pre-pass */
-int flimo_fine_stats(const flimo_ctx* ctx, unsigned long long out[4]);
-int flimo_last_kernel_ms(const flimo_ctx* ctx, float* knn_ms, float* widen_ms, float* fit_ms);
-/* sums over every pass since the last reset (timing must be on): per-stage GPU ms, passes, k-NN queries */
-int flimo_timing_totals(flimo_ctx* ctx, double* knn_ms, double* widen_ms, double* fit_ms, long long* passes,
-                        long long* queries, int reset);
-/* level-1 totals by kind of timed pass since the last reset: out[0] ms of the one-launch passes (k-NN + in-kernel widening + fit +
- * reduction), out[1] their count; out[2..4] ms of the k-NN, widening and fit dispatches of the passes that ran them separately,
- * out[5] their count */
-int flimo_timing_split(flimo_ctx* ctx, double out[6], int reset);
-/* A/B switches of the pass layout (each: 1 on, 0 off, negative = leave): `tail` finishes pending queries inside the k-NN launch,
- * `fuse` runs the whole pass as one launch.  Both on by default; the benchmark switches `fuse` off for a short series to time the
- * k-NN stage (fast path + widening) on its own.  `widen_fit` is accepted and ignored (round 3 ran widening and fit of a
- * separate-dispatch pass as one launch; they are two launches again). */
-int flimo_set_path_switches(flimo_ctx* ctx, int tail, int fuse, int widen_fit);
 /* Wall-clock bound (milliseconds, default 2000) of the wait for a pass's result inside flimo_match_reduce: the reference's
  * Mapper::match (Modules/Mapper.cpp:59-86) cannot hang, a GPU launch can -- when the bound expires the call returns
  * FLIMO_ERR_TIMEOUT (kernel still running) or FLIMO_ERR_HIP (stream idle, nothing published) instead of blocking its caller,
  * which holds the filter's mutex (Localizer.cpp:326-353). */
 int flimo_set_wait_timeout_ms(flimo_ctx* ctx, int ms);
-/* number of scan points of the last pass that needed more than the 3x3x3 cell block */
-int flimo_last_widen_count(const flimo_ctx* ctx);
-/* the same count as published by the pass itself with its result (fast path), -1 when the last pass took a path that does
- * not report it (records / caps / timing level 2) */
-int flimo_last_stragglers(const flimo_ctx* ctx);
-/* also write the per-point debug part of flimo_match_rec (plane, neighbours, candidate counts) */
-int flimo_set_debug_records(flimo_ctx* ctx, int on);
-/* lanes of a wavefront that cooperate on one scan point in the k-NN kernel: 1, 2, 4, 8, 16 or 32 */
-int flimo_set_lanes_per_query(flimo_ctx* ctx, int lanes);
-/* mean number of candidate map points examined per query in the last pass */
-double flimo_last_candidates_per_query(const flimo_ctx* ctx);
-
-/* The cell-sorted copy of the map is maintained incrementally: points appended by an insert are merged into it as long as
- * the grid geometry covers the map box; otherwise the grid is laid out again (with slack on the sides that grew) and the whole
- * map sorted.  Debug check: sorts the whole map again with the current geometry and counts the 32-bit words in which the
- * maintained index (points, cell table, row table) differs -- 0 by construction.  stats = {merges, full builds} so far. */
-int flimo_map_grid_selfcheck(flimo_ctx* ctx, uint64_t* mismatches, uint64_t stats[2]);
 
 /* ---- diagnostics without a GPU ----
  * Replays the map's insert rule (Octree::initialize / update, Objects/Octree.hpp:282-432) over a

@@ -95,8 +95,7 @@ def test_knn_small_k_and_empty_map(built):
     c.close()
 
 
-@pytest.mark.parametrize("lpq", [1, 4, 16, 32])
-def test_match_records_bit_exact(hip, scene, oracle, lpq):
+def test_match_records_bit_exact(hip, scene, oracle):
     from fast_limo_amd import _lib
     x0 = oracle.identity_x26()
     x0[0:3] = [0.05, -0.03, 0.01]
@@ -105,7 +104,6 @@ def test_match_records_bit_exact(hip, scene, oracle, lpq):
     x0[11:14] = [0.01, 0.0, -0.02]
     ocfg = oracle.default_cfg(num_threads=1, **CAPS)
     recs, H, h, ev = oracle.match_H(scene["oc"], ocfg, x0, scene["scan"])
-    hip.set_lanes_per_query(lpq)
     hip.scan_set(scene["scan"])
     hip.set_debug_records(True)
     HTH, HTh, M = hip.match_reduce(x0, _lib.default_match_cfg(**CAPS))
@@ -125,7 +123,6 @@ def test_match_records_bit_exact(hip, scene, oracle, lpq):
     Hd, hd = hip.match_fetch_H()
     np.testing.assert_array_equal(Hd, H); np.testing.assert_array_equal(hd, h)
     assert has5.sum() >= vg.sum()
-    hip.set_lanes_per_query(16)
 
 
 @pytest.mark.parametrize("k", [3, 4, 6, 8])
@@ -701,7 +698,6 @@ def test_host_calculate_H_equals_gpu_rows(hip, scene, oracle):
     x0[3:7] = [0.002, -0.001, 0.004, 1.0]; x0[3:7] /= np.linalg.norm(x0[3:7])
     x0[7:11] = [0.0, 0.002, 0.001, 1.0]; x0[7:11] /= np.linalg.norm(x0[7:11])
     x0[11:14] = [0.02, -0.01, 0.03]
-    hip.set_lanes_per_query(2)
     hip.scan_set(scene["scan"])
     for est in (1, 0):
         hip.set_debug_records(True)
@@ -718,7 +714,6 @@ def test_host_calculate_H_equals_gpu_rows(hip, scene, oracle):
         np.testing.assert_array_equal(h, g["h"][v].astype(np.float64))
         if not est:
             assert not H[:, 6:].any()
-    hip.set_lanes_per_query(16)
 
 
 @pytest.mark.gpu
