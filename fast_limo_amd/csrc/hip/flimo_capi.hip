@@ -1611,7 +1611,7 @@ static int wait_tags(flimo_ctx* c, unsigned long long want, int left_ms = -1) {
     if ((++spins & 0x3fffull) != 0) continue;            // look at the clock every 16k polls (about 0.1 ms)
     // (a pass published to a waiting launch: the launch's own verdict, read through the BAR -- "left" ends the wait at once)
     if (left_ms >= 0 && c->d_pipe_head &&
-        __atomic_load_n(&c->d_pipe_head->decision, __ATOMIC_ACQUIRE) == (ch_epoch_of(want) | 0x80000000u)) return FLIMO_PASS_LEFT;
+        __atomic_load_n(&c->d_pipe_head->decision, __ATOMIC_ACQUIRE) == ((ch_epoch_of(want) & 0x3fffffffu) | 0x80000000u)) return FLIMO_PASS_LEFT;
     const double t = now_s();
     if (deadline == 0.0) { deadline = t + 1e-3 * (double)bound_ms; continue; }
     if (t < deadline) continue;

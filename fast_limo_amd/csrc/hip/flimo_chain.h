@@ -27,7 +27,7 @@ struct ChainHead {
   float prev_RT[16];       // body -> world of the pass just completed: the next pass's pruning bound is relative to it
   int status;              // 0: the chain goes on; 2: handed back to the host filter
   unsigned int epoch;      // pipelined host loop: number (low 32 bits) of the pass these constants are FOR -- written last, behind them
-  unsigned int decision;   // a launch that waits for `epoch`: its workgroups' common verdict (chain_enter, flimo_kernels.hip); written by the device only
+  unsigned int decision;   // a launch that waits for `epoch`: workgroup 0's verdict when the wait runs out (chain_enter, flimo_kernels.hip); written by the device only
   int pad;
 };
 static_assert(sizeof(ChainHead) % 4 == 0 && sizeof(ChainHead) / 4 <= 128, "a pass workgroup reads the head with one load per thread");

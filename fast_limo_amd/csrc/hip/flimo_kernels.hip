@@ -1326,26 +1326,34 @@ __device__ __forceinline__ const ChainHead* chain_enter(const ChainHead* __restr
       // (the algebra takes a few microseconds from the moment the last pass delivered: hundreds of workgroups looking at one word
       //  every 60 ns would stand in its way -- a first look, a nap of 1.5 us (the host's algebra of a pipelined loop takes two),
       //  then a look every quarter of a microsecond)
-      // Whether the launch runs or leaves is ONE decision for all of its workgroups: the first to see its constants published, to be
-      // told to leave, or to run out of time writes the verdict into the head's decision word (compare-and-swap: the first writer
-      // wins), and every workgroup follows the word -- a host thread descheduled around its publish can no longer leave half a
-      // launch running and half of it gone (tickets never completed, the host waiting for sums that cannot come).  The word holds
-      // the wait's own number (go) or that number with the top bit set (leave): older verdicts are other waits'.
+      // Whether the launch runs or leaves is ONE decision for all of its workgroups.  Every workgroup looks at the host's word and
+      // goes the moment it sees its constants published (no atomics, nothing between the publish and the start); only workgroup 0
+      // may declare the wait over, and it does so in two steps through the head's decision word: "pending", a grace period longer
+      // than a store takes to become visible, then -- after another look at the host's word -- "leave", or "go" when the publish
+      // arrived in between.  A workgroup that finds "pending" waits for the verdict; one that finds "leave" leaves even if it
+      // also sees the publish (the host reads the same word and launches the pass again).  So a host thread descheduled around its
+      // publish can no longer leave half a launch running and half of it gone (tickets never completed, sums that cannot come).
+      // The word holds the wait's own number: go = number, pending = number | bit 31, leave = number without bit 30 | bit 31.
       unsigned int* dec = const_cast<unsigned int*>(&H->decision);
-      const unsigned int v_go = wait_epoch, v_no = wait_epoch | 0x80000000u;
+      const unsigned int v_go = wait_epoch, v_pend = wait_epoch | 0x80000000u, v_no = (wait_epoch & 0x3fffffffu) | 0x80000000u;
       for (int look = 0;; look++) {
         const unsigned int d = __hip_atomic_load(dec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         const unsigned int e = __hip_atomic_load(&H->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (written by the HOST)
-        if (d == v_go) { go = 1; break; }
         if (d == v_no) break;
-        unsigned int want = 0u;
-        if (e == wait_epoch) want = v_go;
-        else if (e == end_code || wall_clock64() - t0 > (unsigned long long)CH_POLL_MS * 100000ull) want = v_no;      // 100 MHz
-        if (want != 0u) {
-          unsigned int expected = d;
-          if (__hip_atomic_compare_exchange_strong(dec, &expected, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) { go = want == v_go ? 1 : 0; break; }      // (the host reads the verdict too)
-          continue;                                            // (somebody else decided first: look again)
+        if (d == v_pend) { __builtin_amdgcn_s_sleep(8); continue; }
+        if (e == wait_epoch || d == v_go) { go = 1; break; }
+        if (e == end_code) break;                              // (told to leave by the host: every workgroup reads the same)
+        const unsigned long long waited = wall_clock64() - t0;                                                // 100 MHz
+        if (blockIdx.x == 0 && waited > (unsigned long long)CH_POLL_MS * 100000ull) {
+          __hip_atomic_store(dec, v_pend, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          for (int nap = 0; nap < 4; nap++) __builtin_amdgcn_s_sleep(127);                                   // >= 10 us
+          const unsigned int e2 = __hip_atomic_load(&H->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          go = e2 == wait_epoch ? 1 : 0;
+          __hip_atomic_store(dec, go ? v_go : v_no, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          break;
         }
+        if (waited > 4ull * (unsigned long long)CH_POLL_MS * 100000ull) break;      // (backstop: workgroup 0 decides long before)
         if (look == 0) __builtin_amdgcn_s_sleep(48);
         else __builtin_amdgcn_s_sleep(8);
       }
