@@ -49,7 +49,7 @@ def pmc_traffic(queries_per_launch):
     in separate passes of this same command, FETCH_SIZE doubled per MI355X_MICROARCH.md).  PMC counters cannot be collected
     from inside the run; the profile carries the hash of the kernel sources it was taken with and is only reported when that is
     the hash of the sources in the tree (and the launch shape is the benchmark's)."""
-    f = os.path.join(ROOT, "profiles", "r04", "pmc_fetch_write_per_kernel.json")
+    f = os.path.join(ROOT, "profiles", "r05", "pmc_fetch_write_per_kernel.json")
     try:
         from fast_limo_amd import build as b
         d = json.load(open(f))
@@ -112,10 +112,10 @@ def cpu_baseline(mp, scan, imu, caps, max_threads):
     x_o = None
     per_threads = {}
     model, phys, logical = cpu_info()
-    # 1 thread, and the reference's own clamp: Config.num_threads is what the wrapper hands to omp_set_num_threads (Localizer.cpp:46-50)
-    # and its shipped configurations ask for at most the machine's cores; 32 is where the oracle stops scaling on these hosts (the
-    # k-NN loop is memory-latency bound), so more threads only add scheduling noise to a 20-second budget
-    tried = sorted(set([1, max(1, min(max_threads, os.cpu_count() or 1))]))
+    # 1 thread and every power of two up to the machine's hardware threads (Config.num_threads is what the wrapper hands to
+    # omp_set_num_threads, Localizer.cpp:46-50): the best is shown, all are reported (`by_threads`); about 25 s in total
+    ncpu = os.cpu_count() or 1
+    tried = sorted(set([1] + [t for t in (8, 16, 32, 64, 128) if t <= min(ncpu, max_threads)]))
     for nt in tried:
         L = O.Localizer(O.default_cfg(num_threads=nt, **caps))
         drive_to_prior(_OracleNoInsert(L), mp, scan, imu)
@@ -123,7 +123,7 @@ def cpu_baseline(mp, scan, imu, caps, max_threads):
         times = []
         stages = []
         budget_t0 = time.time()
-        budget = 6.0 if nt == 1 else 14.0
+        budget = 4.0 if nt == 1 else 3.5
         for rep in range(23):
             L.set_x(x_prior); L.set_P(P_prior)
             rc = L.update_pointcloud(scan, 0.1, add_to_map=False)
@@ -177,7 +177,7 @@ HBM_REGIME = dict(rings=128, azimuths=2048, map_points=20000000, box=447.0)     
 def pmc_traffic_hbm_regime():
     """HBM-side bytes per launch at 256k x 20M from the committed PMC profile (same rule as pmc_traffic): the one-launch pass and
     the k-NN kernel of the passes that run as separate dispatches."""
-    f = os.path.join(ROOT, "profiles", "r04", "pmc_hbm_regime.json")
+    f = os.path.join(ROOT, "profiles", "r05", "pmc_hbm_regime.json")
     try:
         from fast_limo_amd import build as b
         d = json.load(open(f))
@@ -298,6 +298,8 @@ def hbm_regime_leg(device, steps, with_oracle, max_threads=32):
         t1 = time.perf_counter()
         loc.hip.map_add_scan(loc.get_x(), 0.2 + 0.1 * k)
         ins.append(time.perf_counter() - t1)
+    ib = loc.hip.map_index_bytes()
+    out["index_bytes"] = dict(ib, over_map_bytes=ib["index"] / max(ib["points"], 1))
     out["map_insert_ms"] = {"first": 1e3 * ins[0], "repeat": 1e3 * float(np.median(ins[1:])), "points_stored": loc.map_size() - n0,
                             "note": "flimo_map_add_scan of the resident scan, waited for; index merged incrementally"}
     loc.close()
@@ -425,8 +427,10 @@ def shipped_config_leg(device, with_oracle, n_sweeps=10, n_pts=120000):
         G2.update_imu_n(st[i:i1], w[i:i1], a[i:i1]); i = i1
         feed_gpu(G2, k)
     G2.sync()
+    # (`ms_per_sweep` keeps its round-1..3 meaning: the median sweep, each followed by a wait for its map insert; the back-to-back
+    #  rate is `ms_per_sweep_sustained`)
     out["ms_per_sweep_each_waited_for"] = out["ms_per_sweep"]
-    out["ms_per_sweep"] = 1e3 * (time.perf_counter() - t1) / (n_sweeps - 3)
+    out["ms_per_sweep_sustained"] = 1e3 * (time.perf_counter() - t1) / (n_sweeps - 3)
     assert np.array_equal(G2.get_x(), xg)                               # the same drive
     G2.close()
     if with_oracle:
@@ -436,9 +440,11 @@ def shipped_config_leg(device, with_oracle, n_sweeps=10, n_pts=120000):
         Lo = O.Localizer(O.default_cfg(crop_min=(-1.0, -1.0, -1.0), crop_max=(1.0, 1.0, 1.0), num_threads=nt, **common))
         fresh_o = [s.copy() for s in sweeps]
         to = drive(Lo, lambda L, k: L.update_pointcloud_points(fresh_o[k], 0.1 * k), lambda L: None)
-        out["cpu_oracle_ms_per_sweep"] = 1e3 * float(np.mean(to[3:]))
+        out["cpu_oracle_ms_per_sweep"] = 1e3 * float(np.median(to[3:]))          # the same statistic on both sides: median sweep
+        out["cpu_oracle_ms_per_sweep_mean"] = 1e3 * float(np.mean(to[3:]))
         out["cpu_threads"] = nt
         out["speedup_vs_cpu_oracle"] = out["cpu_oracle_ms_per_sweep"] / out["ms_per_sweep"]
+        out["speedup_vs_cpu_oracle_sustained"] = out["cpu_oracle_ms_per_sweep_mean"] / out["ms_per_sweep_sustained"]      # (sequential CPU mean vs back-to-back GPU)
         xo = Lo.get_x()
         out["free_running_pose_difference_m"] = float(np.abs(xg[0:3] - xo[0:3]).max())
     return out
@@ -805,16 +811,19 @@ def main():
             assert not status.any(), status
             i = i1
             k += args.e2e_sweeps
-            end_to_end[label + "_stamps"] = {"ms_per_sweep": 1e3 * back_to_back,
+            end_to_end[label + "_stamps"] = {"ms_per_sweep": 1e3 * float(np.median(tot_sw[1:])),
+                                             "ms_per_sweep_sustained": 1e3 * back_to_back,
                                              "ms_per_sweep_each_waited_for": 1e3 * float(np.mean(tot_sw[1:])),
                                              "call_returns_after_ms": 1e3 * float(np.median(lat)),
                                              "sweeps": args.e2e_sweeps,
-                                             "note": "ms_per_sweep: sweeps fed back to back from native code (flimo_loc_replay; IMU propagation "
-                                                     "between them included, one wait for the last insert at the end); each_waited_for: every call "
-                                                     "followed by a wait for its map insert (rounds 1-3 reported this one)",
+                                             "note": "ms_per_sweep: median sweep, every call followed by a wait for its map insert (the meaning of rounds "
+                                                     "1-3; each_waited_for = the mean of the same); ms_per_sweep_sustained: sweeps fed back to back from "
+                                                     "native code (flimo_loc_replay; IMU propagation between them included, one wait for the last "
+                                                     "insert at the end)",
                                              "last_sweep_stages_ms": {kk: 1e3 * float(v) for kk, v in stg.items()}}
         end_to_end["ms"] = end_to_end["tied_stamps"]["ms_per_sweep"]
         end_to_end["scans_per_s"] = 1e3 / end_to_end["ms"]
+        end_to_end["ms_sustained"] = end_to_end["tied_stamps"]["ms_per_sweep_sustained"]
         # the same sweeps with the clouds handed back to the caller (download_clouds = true is the class's default and what the
         # reference's ROS wrapper needs: src/main.cpp:27-31 publishes get_pointcloud() after every sweep)
         loc.set_flags(add_to_map=True, download_clouds=True, keep_log=False)
@@ -847,7 +856,8 @@ def main():
             k += 1
         loc.sync()
         back_to_back = (time.perf_counter() - t1) / args.e2e_sweeps
-        end_to_end["with_clouds"] = {"ms": 1e3 * back_to_back, "ms_each_waited_for": 1e3 * float(np.mean(tot_sw[1:])),
+        end_to_end["with_clouds"] = {"ms": 1e3 * float(np.median(tot_sw[1:])), "ms_sustained": 1e3 * back_to_back,
+                                     "ms_each_waited_for": 1e3 * float(np.mean(tot_sw[1:])),
                                      "call_returns_after_ms": 1e3 * float(np.median(lat)),
                                      "sweeps": args.e2e_sweeps,
                                      "last_sweep_stages_ms": {kk: 1e3 * float(v) for kk, v in stg.items()}}
@@ -882,10 +892,7 @@ def main():
                                                            if pipe_found else "host loop over single passes (this host's launch round trip is short, or FLIMO_HOST_UPDATE=1)")),
                        "chains_run": chain["chains"], "chains_handed_back_early": chain["handed_back"], "chains_declined": chain["declined"],
                        "host_loop_passes_found_waiting": pipe_found, "host_loop_passes_queued_for_nothing": pipe_wasted},
-            "value_regions": value_regions,
             "update_layouts": modes,
-            "kernel_us_per_step": kernel_us_per_step,
-            "step_minus_kernels_us": ((1e3 * 1e3 * elapsed / args.steps) - kernel_us_per_step["total"]) if kernel_us_per_step else None,
             "host_us_per_step": {"deskew_call": 1e6 * hp["deskew_s"] / args.steps, "update": 1e6 * hp["update_s"] / args.steps,
                                  "in_match_reduce": 1e6 * hp["match_reduce_s"] / args.steps},
             "with_map_insert": with_insert,
@@ -894,7 +901,7 @@ def main():
         }
         cb, E, x_o = (None, None, None)
         if world == 1 and not args.no_cpu_baseline:
-            cb, E, x_o = cpu_baseline(mp, scan, imu, caps, max_threads=32)
+            cb, E, x_o = cpu_baseline(mp, scan, imu, caps, max_threads=128)
             out["cpu_baseline"] = cb
             dpos = float(np.abs(x_ref[0:3] - x_o[0:3]).max())
             drot = float(2.0 * np.abs(x_ref[3:6] - x_o[3:6]).max())
@@ -922,6 +929,16 @@ def main():
                            "hbm_utilisation_measured": (traffic / (dur_us * 1e-6) / 1e9 / HBM_PEAK_GBPS) if (traffic and dur_us) else None,
                            "bytes_per_query": bytes_per_query, "E_evals_per_query": Eq,
                            "queries_per_launch": qpl, "mean_launch_us": dur_us, "timed_launches": n_timed,
+                           "kernel_in_timed_region": ("knn5_chain_kernel<2, 8, true, false>: the same device function queued AHEAD of its pose (pipelined host loop): its "
+                                                      "event duration includes the wait for the pose, so `mean_launch_us` is taken from the dense series right after the "
+                                                      "region, where every pass is launched when its pose is known (knn5_kernel<2, 8, true, false>)"
+                                                      if pipe_found else "knn5_kernel<2, 8, true, false> (passes launched when their pose is known)"),
+                           "reproduce": "rocprofv3 --kernel-trace --stats of `FLIMO_PIPELINE=0 python3 bench.py --streams 0`: profiles/r05/bench_r05_prof_nopipeline_kernel_stats.csv, "
+                                        "row knn5_kernel<2, 8, true, false>",
+                           "step": {"value_regions": value_regions, "kernel_us_per_step": kernel_us_per_step,
+                                    "step_minus_kernels_us": ((1e3 * 1e3 * elapsed / args.steps) - kernel_us_per_step["total"]) if kernel_us_per_step else None,
+                                    "note": "value_regions: the timed K-step region and nine more right behind it (min / median / max of scans/s); "
+                                            "kernel_us_per_step: every launch of 12 steps timed by HIP events on its dispatch"},
                            "note": "achieved = ALGORITHMIC k-NN bytes (16 B query + 16 B x E candidate points of the reference's own traversal + 32 B neighbour "
                                    "record) per launch / launch duration; the launch also does the plane fit, the residual / Jacobian rows and the "
                                    "reduction, which add no algorithmic bytes (the five neighbours were just read).  `traffic` / "

@@ -80,7 +80,7 @@ HIP_SYMBOLS = [
     "flimo_scan_voxel_filter", "flimo_raw_scan_set", "flimo_raw_scan_filter_set", "flimo_raw_scan_filter_order_set", "flimo_raw_scan_order", "flimo_deskew_resident", "flimo_deskew_resident_offset", "flimo_deskew",
     "flimo_match_reduce", "flimo_match_fetch", "flimo_match_fetch_H",
     "flimo_scan_to_world", "flimo_scan_clouds", "flimo_upload_stage", "flimo_match_reduce_overlap", "flimo_map_add_scan",
-    "flimo_set_timing", "flimo_set_timing_stride", "flimo_pass_count", "flimo_fused_pass_count", "flimo_tie_stats", "flimo_fine_stats", "flimo_map_grid_selfcheck", "flimo_set_debug_records", "flimo_last_kernel_ms",
+    "flimo_set_timing", "flimo_set_timing_stride", "flimo_pass_count", "flimo_fused_pass_count", "flimo_tie_stats", "flimo_map_index_bytes", "flimo_fine_stats", "flimo_map_grid_selfcheck", "flimo_set_debug_records", "flimo_last_kernel_ms",
     "flimo_last_candidates_per_query", "flimo_last_widen_count", "flimo_last_stragglers", "flimo_timing_totals", "flimo_timing_split", "flimo_set_path_switches", "flimo_set_wait_timeout_ms", "flimo_insert_rule_replay", "flimo_plane_fit5_host", "flimo_plane_eval5_host", "flimo_calculate_H_host",
     "flimo_update_chain", "flimo_chain_stats", "flimo_set_update_mode", "flimo_update_mode", "flimo_scan_adopt", "flimo_set_pass_pipeline", "flimo_pass_pipeline_end", "flimo_pass_pipeline_stats",
 ]
@@ -141,6 +141,7 @@ def load_hip():
     L.flimo_pass_count.argtypes = [vp]
     L.flimo_tie_stats.argtypes = [vp, C.POINTER(C.c_ulonglong)]
     L.flimo_fine_stats.argtypes = [vp, C.POINTER(C.c_ulonglong)]
+    L.flimo_map_index_bytes.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.flimo_fused_pass_count.restype = C.c_ulonglong
     L.flimo_fused_pass_count.argtypes = [vp]
     L.flimo_map_grid_selfcheck.restype = C.c_int
@@ -378,6 +379,11 @@ class HipCtx:
         o = (C.c_ulonglong * 2)()
         self._chk(self._L.flimo_tie_stats(self._h, o))
         return dict(passes_redone=int(o[0]), queries_settled=int(o[1]))
+
+    def map_index_bytes(self):
+        o = (C.c_uint64 * 3)()
+        self._chk(self._L.flimo_map_index_bytes(self._h, o))
+        return dict(points=int(o[0]), index=int(o[1]), second_level=int(o[2]))
 
     def fused_pass_count(self) -> int:
         return int(self._L.flimo_fused_pass_count(self._h))

@@ -54,6 +54,8 @@ struct flimo_ctx {
   size_t cell_cap = 0;
   uint32_t* d_row_table = nullptr;
   size_t row_cap = 0;
+  uint32_t *d_row_start = nullptr, *d_row_start_t = nullptr;   // the rows' absolute starts (x order / padded y-fastest copy): GridView
+  size_t rowstart_cap = 0, rowstart_t_cap = 0;
   GridView grid{};
   bool grid_valid = false;
   double map_last_time = -1.0;
@@ -166,8 +168,8 @@ struct flimo_ctx {
   int fine_qlo[3] = {0, 0, 0}, fine_qhi[3] = {-1, -1, -1};
   float4 *d_fine_tmp = nullptr, *d_fine_pts = nullptr;
   size_t fine_pts_cap = 0;
-  uint32_t *d_fine_cs = nullptr, *d_fine_rt = nullptr, *d_fine_count = nullptr;
-  size_t fine_cs_cap = 0, fine_rt_cap = 0;
+  uint32_t *d_fine_cs = nullptr, *d_fine_rt = nullptr, *d_fine_count = nullptr, *d_fine_rs = nullptr, *d_fine_rst = nullptr;
+  size_t fine_cs_cap = 0, fine_rt_cap = 0, fine_rs_cap = 0, fine_rst_cap = 0;
   void* d_crowd_list = nullptr;        // int4 (x, y, z, -) of every crowded cell of the current geometry, listed once
   uint32_t* d_crowd_count = nullptr;
   uint32_t* d_crowd_bits = nullptr;    // one bit per cell: listed
@@ -474,6 +476,7 @@ extern "C" void flimo_ctx_destroy(flimo_ctx* c) {
   ctx_enter(c);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   (void)hipFree(c->d_map_raw); (void)hipFree(c->d_map_sorted); (void)hipFree(c->d_map_sorted2); (void)hipFree(c->d_cell_start); (void)hipFree(c->d_row_table);
+  (void)hipFree(c->d_row_start); (void)hipFree(c->d_row_start_t); (void)hipFree(c->d_fine_rs); (void)hipFree(c->d_fine_rst);
   (void)hipFree(c->d_scan_sorted); (void)hipFree(c->d_nbr); (void)hipFree(c->d_wl); (void)hipFree(c->d_wl_count);
   (void)hipFree(c->d_fit_partials); (void)hipFree(c->d_raw_sorted); (void)hipFree(c->d_t_sorted);
   (void)hipFree(c->d_scan); (void)hipFree(c->d_scan_raw); (void)hipFree(c->d_scan_world); (void)hipFree(c->d_scan_t);
@@ -553,16 +556,17 @@ static bool grid_covers(const GridView& g, const float* bb) {
   }
   return true;
 }
-static int publish_row_table(flimo_ctx* c, int nx, int ny, int nz, bool same_shape) {
-  const size_t rt = row_table_size(nx, ny, nz);
-  if (rt > c->row_cap) {
-    if (c->d_row_table) (void)hipFree(c->d_row_table);
-    c->d_row_table = nullptr;
-    const size_t cap = rt + rt / 2;
-    HIPCHK(c, hipMalloc(&c->d_row_table, cap * sizeof(uint32_t)));
-    c->row_cap = cap;
-  }
-  HIPCHK(c, map_build_row_table(c->stream, c->d_cell_start, nx, ny, nz, c->d_row_table, !same_shape));
+// capacity of the four index tables of a grid of nxf x ny x nz columns (geometric growth: a map that keeps extending does not
+// reallocate per scan); *grew: a table was reallocated (its pads are not zero any more)
+template <typename T>
+static int ensure_table(flimo_ctx* c, T*& p, size_t& cap, size_t need, bool* grew) {
+  if (need <= cap) return FLIMO_OK;
+  if (p) (void)hipFree(p);
+  p = nullptr;
+  const size_t ncap = need + need / 2;
+  HIPCHK(c, hipMalloc(&p, ncap * sizeof(T)));
+  cap = ncap;
+  if (grew) *grew = true;
   return FLIMO_OK;
 }
 
@@ -653,39 +657,27 @@ static int update_fine_grid(flimo_ctx* c, bool relayout, const float4* new_pts =
     HIPCHK(c, hipMalloc(&c->d_fine_pts, cap * sizeof(float4)));
     c->fine_pts_cap = cap;
   }
-  HIPCHK(c, map_box_copy(c->stream, g.pts, g.cell_start, g.nx, g.ny, g.nz, g.xs, c0, c1, c->d_fine_tmp, c->scratch));
-  const size_t ncells = (size_t)nf[0] * nf[1] * nf[2];
-  if (ncells + 1 > c->fine_cs_cap) {
-    (void)hipFree(c->d_fine_cs);
-    c->d_fine_cs = nullptr;
-    const size_t cap = ncells + 1 + ncells / 2;
-    HIPCHK(c, hipMalloc(&c->d_fine_cs, cap * sizeof(uint32_t)));
-    c->fine_cs_cap = cap;
+  HIPCHK(c, map_box_copy(c->stream, g.pts, g.cell_start, g.row_start, g.nx, g.ny, g.nz, g.xs, c0, c1, c->d_fine_tmp, c->scratch));
+  {
+    int rc;
+    if ((rc = ensure_table(c, c->d_fine_cs, c->fine_cs_cap, cell_table_size(nf[0], nf[1], nf[2]), nullptr))) return rc;
+    if ((rc = ensure_table(c, c->d_fine_rt, c->fine_rt_cap, row_table_size(nf[0], nf[1], nf[2]), nullptr))) return rc;
+    if ((rc = ensure_table(c, c->d_fine_rs, c->fine_rs_cap, row_start_size(nf[1], nf[2]), nullptr))) return rc;
+    if ((rc = ensure_table(c, c->d_fine_rst, c->fine_rst_cap, row_start_t_size(nf[1], nf[2]), nullptr))) return rc;
   }
-  const size_t rt = row_table_size(nf[0], nf[1], nf[2]);
-  if (rt > c->fine_rt_cap) {
-    (void)hipFree(c->d_fine_rt);
-    c->d_fine_rt = nullptr;
-    const size_t cap = rt + rt / 2;
-    HIPCHK(c, hipMalloc(&c->d_fine_rt, cap * sizeof(uint32_t)));
-    c->fine_rt_cap = cap;
-  }
-  HIPCHK(c, map_build_grid(c->stream, c->d_fine_tmp, m, c->d_fine_pts, c->d_fine_cs, ncells, of[0], of[1], of[2], inv_f, nf[0], nf[1], nf[2], 1,
-                           c->scratch));
-  if (prof) HIPCHK(c, hipStreamSynchronize(c->stream));
-  const double tp2 = prof ? now() : 0.0;
-  HIPCHK(c, map_build_row_table(c->stream, c->d_fine_cs, nf[0], nf[1], nf[2], c->d_fine_rt, true));
+  const IndexTables Tf{c->d_fine_cs, c->d_fine_rs, c->d_fine_rt, c->d_fine_rst};
+  HIPCHK(c, map_build_grid(c->stream, c->d_fine_tmp, m, c->d_fine_pts, Tf, of[0], of[1], of[2], inv_f, nf[0], nf[1], nf[2], 1, c->scratch, true));
   if (prof) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    fprintf(stderr, "[flimo fine] crowded cells + count %.1f us, copy + sort into %d x %d x %d cells %.1f us, row table %.1f us (%u points)\n",
-            (tp1 - tp0) * 1e6, nf[0], nf[1], nf[2], (tp2 - tp1) * 1e6, (now() - tp2) * 1e6, m);
+    fprintf(stderr, "[flimo fine] crowded cells + count %.1f us, copy + sort + tables of %d x %d x %d cells %.1f us (%u points)\n",
+            (tp1 - tp0) * 1e6, nf[0], nf[1], nf[2], (now() - tp1) * 1e6, m);
   }
   GridView& f = c->fine;
-  f.pts = c->d_fine_pts; f.cell_start = c->d_fine_cs; f.row_table = c->d_fine_rt;
+  f.pts = c->d_fine_pts; f.cell_start = c->d_fine_cs; f.row_table = c->d_fine_rt; f.row_start = c->d_fine_rs; f.row_start_t = c->d_fine_rst;
   f.ox = of[0]; f.oy = of[1]; f.oz = of[2];
   f.inv_cell = inv_f; f.cell = cf;
   f.nx = nf[0]; f.ny = nf[1]; f.nz = nf[2];
-  f.n_pts = m; f.xs = 1; f.nxf = nf[0];
+  f.n_pts = m; f.xs = 1; f.nxf = nf[0]; f.nxs = nf[0] + 1;
   // a query may be settled here when its fine 3x3x3 block lies inside [lo, hi): fine cell 1 starts at lo, so the query's own cell
   // is >= 2; on the upper side one more cell of safety against the rounding of (hi - of) * inv_f
   for (int a = 0; a < 3; a++) {
@@ -713,11 +705,9 @@ static int rebuild_grid(flimo_ctx* c) {
     c->grid_valid = false;
     if (!c->d_map_sorted2) HIPCHK(c, hipMalloc(&c->d_map_sorted2, c->map_cap * sizeof(float4)));
     const GridView& g = c->grid;
-    const size_t ncells = (size_t)g.nxf * g.ny * g.nz;
-    HIPCHK(c, map_merge_grid(c->stream, c->d_map_sorted, n_old, c->d_map_raw + n_old, k, c->d_map_sorted2, c->d_cell_start, ncells,
+    const IndexTables T{c->d_cell_start, c->d_row_start, c->d_row_table, c->d_row_start_t};
+    HIPCHK(c, map_merge_grid(c->stream, c->d_map_sorted, n_old, c->d_map_raw + n_old, k, c->d_map_sorted2, T,
                              g.ox, g.oy, g.oz, g.inv_cell, g.nx, g.ny, g.nz, g.xs, c->scratch));
-    int rc = publish_row_table(c, g.nxf, g.ny, g.nz, true);
-    if (rc) return rc;
     // (no wait here: everything that reads the index is queued behind this on the same stream; map_add_device ends synchronised)
     std::swap(c->d_map_sorted, c->d_map_sorted2);
     c->grid.pts = c->d_map_sorted;
@@ -747,7 +737,7 @@ static int rebuild_grid(flimo_ctx* c) {
     nz = (int)floorf((box[5] - oz) * inv) + 2;
     // both indices stay 32-bit addressable; the fine x columns are given up first (xs = preferred .. 1), then the cell grows
     for (xs = c->xslabs; xs >= 1; xs >>= 1) {
-      const double ncols = (double)nx * xs * ny * nz;
+      const double ncols = (double)cell_table_size(nx * xs, ny, nz);
       if (ncols < 1.9e9 && (double)row_table_size(nx * xs, ny, nz) < 4.0e9) return true;
     }
     xs = 1;
@@ -772,30 +762,27 @@ static int rebuild_grid(flimo_ctx* c) {
   }
   for (int a = 0; a < 6; a++) c->gbox[a] = W[a];
   c->have_gbox = true;
-  const size_t ncells = (size_t)nx * xs * ny * nz;      // columns
   if (!c->d_map_sorted) HIPCHK(c, hipMalloc(&c->d_map_sorted, c->map_cap * sizeof(float4)));   // mirrors the raw capacity (freed whenever that grows)
-  if (ncells + 1 > c->cell_cap) {
-    if (c->d_cell_start) (void)hipFree(c->d_cell_start);
-    c->d_cell_start = nullptr;
-    size_t cap = ncells + 1 + ncells / 2;          // geometric growth: a map that keeps extending does not reallocate per scan
-    HIPCHK(c, hipMalloc(&c->d_cell_start, cap * sizeof(uint32_t)));
-    c->cell_cap = cap;
-  }
-  HIPCHK(c, map_build_grid(c->stream, c->d_map_raw, c->map_n, c->d_map_sorted, c->d_cell_start, ncells, ox, oy, oz, inv,
-                           nx, ny, nz, xs, c->scratch));
   {
-    int rc = publish_row_table(c, nx * xs, ny, nz, false);
-    if (rc) return rc;
+    int rc;
+    if ((rc = ensure_table(c, c->d_cell_start, c->cell_cap, cell_table_size(nx * xs, ny, nz), nullptr))) return rc;
+    if ((rc = ensure_table(c, c->d_row_table, c->row_cap, row_table_size(nx * xs, ny, nz), nullptr))) return rc;
+    if ((rc = ensure_table(c, c->d_row_start, c->rowstart_cap, row_start_size(ny, nz), nullptr))) return rc;
+    if ((rc = ensure_table(c, c->d_row_start_t, c->rowstart_t_cap, row_start_t_size(ny, nz), nullptr))) return rc;
   }
+  const IndexTables T{c->d_cell_start, c->d_row_start, c->d_row_table, c->d_row_start_t};
+  HIPCHK(c, map_build_grid(c->stream, c->d_map_raw, c->map_n, c->d_map_sorted, T, ox, oy, oz, inv, nx, ny, nz, xs, c->scratch, true));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->grid.pts = c->d_map_sorted;
   c->grid.cell_start = c->d_cell_start;
   c->grid.row_table = c->d_row_table;
+  c->grid.row_start = c->d_row_start;
+  c->grid.row_start_t = c->d_row_start_t;
   c->grid.ox = ox; c->grid.oy = oy; c->grid.oz = oz;
   c->grid.inv_cell = inv;
   c->grid.cell = cell;
   c->grid.nx = nx; c->grid.ny = ny; c->grid.nz = nz;
-  c->grid.xs = xs; c->grid.nxf = nx * xs;
+  c->grid.xs = xs; c->grid.nxf = nx * xs; c->grid.nxs = nx * xs + 1;
   c->grid.n_pts = (uint32_t)c->map_n;
   c->grid_valid = true;
   c->force_full = false;
@@ -812,17 +799,20 @@ extern "C" int flimo_map_grid_selfcheck(flimo_ctx* c, uint64_t* mismatches, uint
   if (!c->grid_valid) return FLIMO_OK;
   ctx_enter(c);
   const GridView& g = c->grid;
-  const size_t n = c->map_n, ncells = (size_t)g.nxf * g.ny * g.nz, rt = row_table_size(g.nxf, g.ny, g.nz);
+  const size_t n = c->map_n, ncs = cell_table_size(g.nxf, g.ny, g.nz), rt = row_table_size(g.nxf, g.ny, g.nz),
+               nrs = row_start_size(g.ny, g.nz), nrst = row_start_t_size(g.ny, g.nz);
   if (g.n_pts != n) { *mismatches = 1; return FLIMO_OK; }
   struct Tmp {
-    float4* pts = nullptr; uint32_t* cs = nullptr; uint32_t* row = nullptr;
-    ~Tmp() { (void)hipFree(pts); (void)hipFree(cs); (void)hipFree(row); }
+    float4* pts = nullptr; uint32_t* cs = nullptr; uint32_t* row = nullptr; uint32_t* rs = nullptr; uint32_t* rst = nullptr;
+    ~Tmp() { (void)hipFree(pts); (void)hipFree(cs); (void)hipFree(row); (void)hipFree(rs); (void)hipFree(rst); }
   } t;
   HIPCHK(c, hipMalloc(&t.pts, n * sizeof(float4)));
-  HIPCHK(c, hipMalloc(&t.cs, (ncells + 1) * sizeof(uint32_t)));
+  HIPCHK(c, hipMalloc(&t.cs, ncs * sizeof(uint32_t)));
   HIPCHK(c, hipMalloc(&t.row, rt * sizeof(uint32_t)));
-  HIPCHK(c, map_build_grid(c->stream, c->d_map_raw, n, t.pts, t.cs, ncells, g.ox, g.oy, g.oz, g.inv_cell, g.nx, g.ny, g.nz, g.xs, c->scratch));
-  HIPCHK(c, map_build_row_table(c->stream, t.cs, g.nxf, g.ny, g.nz, t.row));
+  HIPCHK(c, hipMalloc(&t.rs, nrs * sizeof(uint32_t)));
+  HIPCHK(c, hipMalloc(&t.rst, nrst * sizeof(uint32_t)));
+  const IndexTables Tt{t.cs, t.rs, t.row, t.rst};
+  HIPCHK(c, map_build_grid(c->stream, c->d_map_raw, n, t.pts, Tt, g.ox, g.oy, g.oz, g.inv_cell, g.nx, g.ny, g.nz, g.xs, c->scratch, true));
   auto differ = [&](const void* a, const void* b, size_t bytes, uint64_t& out) -> int {
     std::vector<unsigned char> ha(bytes), hb(bytes);
     HIPCHK(c, hipMemcpyAsync(ha.data(), a, bytes, hipMemcpyDeviceToHost, c->stream));
@@ -833,8 +823,10 @@ extern "C" int flimo_map_grid_selfcheck(flimo_ctx* c, uint64_t* mismatches, uint
   };
   int rc;
   if ((rc = differ(t.pts, g.pts, n * sizeof(float4), *mismatches))) return rc;
-  if ((rc = differ(t.cs, g.cell_start, (ncells + 1) * sizeof(uint32_t), *mismatches))) return rc;
+  if ((rc = differ(t.cs, g.cell_start, ncs * sizeof(uint32_t), *mismatches))) return rc;
   if ((rc = differ(t.row, g.row_table, rt * sizeof(uint32_t), *mismatches))) return rc;
+  if ((rc = differ(t.rs, g.row_start, nrs * sizeof(uint32_t), *mismatches))) return rc;
+  if ((rc = differ(t.rst, g.row_start_t, nrst * sizeof(uint32_t), *mismatches))) return rc;
   return FLIMO_OK;
 }
 
@@ -1457,6 +1449,16 @@ extern "C" unsigned long long flimo_fused_pass_count(const flimo_ctx* c) { retur
 extern "C" int flimo_fine_stats(const flimo_ctx* c, unsigned long long out[4]) {
   if (!c || !out) return FLIMO_ERR_INVALID;
   out[0] = c->fine_valid ? 1 : 0; out[1] = c->fine_valid ? c->fine.n_pts : 0; out[2] = c->fine_builds; out[3] = c->fine_passes;
+  return FLIMO_OK;
+}
+extern "C" int flimo_map_index_bytes(const flimo_ctx* c, uint64_t out[3]) {
+  if (!c || !out) return FLIMO_ERR_INVALID;
+  out[0] = (uint64_t)c->map_n * sizeof(float4);
+  auto tables = [](const GridView& g) {
+    return (uint64_t)(cell_table_size(g.nxf, g.ny, g.nz) + row_table_size(g.nxf, g.ny, g.nz) + row_start_size(g.ny, g.nz) + row_start_t_size(g.ny, g.nz)) * 4ull;
+  };
+  out[1] = c->grid_valid ? tables(c->grid) : 0ull;
+  out[2] = c->fine_valid ? (uint64_t)c->fine.n_pts * sizeof(float4) + tables(c->fine) : 0ull;
   return FLIMO_OK;
 }
 extern "C" int flimo_tie_stats(flimo_ctx* c, unsigned long long out[2]) {

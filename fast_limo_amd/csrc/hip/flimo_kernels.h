@@ -135,20 +135,28 @@ hipError_t mail_wait(hipStream_t st, MapBuildScratch& S);   // the words of the 
 
 // min/max of n float4 points (NaN-free) -> host bbox[6]
 hipError_t map_bbox(hipStream_t st, const float4* pts, size_t n, MapBuildScratch& S, float bbox_host[6]);
-// Sorts `pts_in` by grid cell into `pts_out`, fills cell_start[ncells+1].
 // Spatial (Morton) sort of the scan: out[i] = (xyz of in[perm[i]], w = bit pattern of perm[i]).
 // Optionally permutes a per-point double array (times) the same way.
 hipError_t sort_scan(hipStream_t st, const float4* in, size_t n, float4* out, MapBuildScratch& S,
                      const double* t_in = nullptr, double* t_out = nullptr);
 // the same layout without re-ordering (out[i] = (xyz, w = i)): for a sweep a voxel filter re-orders anyway
 hipError_t index_scan(hipStream_t st, const float4* in, size_t n, float4* out, const double* t_in, double* t_out);
-hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4* pts_out, uint32_t* cell_start,
-                          size_t ncells, float ox, float oy, float oz, float inv_cell, int nx, int ny, int nz, int xs,
-                          MapBuildScratch& S);    // ncells = nx * xs * ny * nz columns
-// Merges the k points appended since the last build into the cell-sorted array (same geometry): out_sorted and cell_start
-// become what map_build_grid gives for all n_old + k points.  cell_start is updated in place; out_sorted != old_sorted.
+// The four index tables of a grid (GridView, flimo_types.h): cell_start[cell_table_size], row_start[row_start_size],
+// row_table[row_table_size], row_start_t[row_start_t_size] (nxf = nx * xs columns per row).
+struct IndexTables { uint32_t* cell_start; uint32_t* row_start; uint32_t* row_table; uint32_t* row_start_t; };
+size_t cell_table_size(int nxf, int ny, int nz);
+size_t row_start_size(int ny, int nz);
+size_t row_start_t_size(int ny, int nz);
+// Sorts `pts_in` by (z, y, fine x column) into `pts_out` and fills the four tables.  zero_pads: the y-fastest tables are new or
+// their shape changed (their pads have to be cleared).
+hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4* pts_out, const IndexTables& T,
+                          float ox, float oy, float oz, float inv_cell, int nx, int ny, int nz, int xs,
+                          MapBuildScratch& S, bool zero_pads = true);
+// Merges the k points appended since the last build into the cell-sorted array (same geometry): out_sorted and the tables
+// become what map_build_grid gives for all n_old + k points.  The tables are updated in place -- the rows' starts, and the
+// relative entries of the rows that received points: O(rows + touched rows x row length), not O(cells); out_sorted != old_sorted.
 hipError_t map_merge_grid(hipStream_t st, const float4* old_sorted, size_t n_old, const float4* new_pts, size_t k,
-                          float4* out_sorted, uint32_t* cell_start, size_t ncells, float ox, float oy, float oz,
+                          float4* out_sorted, const IndexTables& T, float ox, float oy, float oz,
                           float inv_cell, int nx, int ny, int nz, int xs, MapBuildScratch& S);
 // Input filters of a raw sweep (32-byte PointType records already on the device): NaN removal, crop box, every rate-th survivor,
 // min distance; order preserved.  out[k] = (xyz, w = k), t_out[k] = stamp without the sweep offset; ext_dev[4] = {extreme ordered
@@ -175,8 +183,8 @@ hipError_t crowded_list_points(hipStream_t st, const float4* pts, size_t k, cons
                                uint32_t* count_dev, uint32_t* count_host, MapBuildScratch& S);
 hipError_t map_box_count(hipStream_t st, const uint32_t* cell_start, int nx, int ny, int nz, int xs, const int c0[3], const int c1[3],
                          uint32_t* count_dev, uint32_t* count_host, MapBuildScratch& S);
-hipError_t map_box_copy(hipStream_t st, const float4* pts, const uint32_t* cell_start, int nx, int ny, int nz, int xs, const int c0[3],
-                        const int c1[3], float4* out, MapBuildScratch& S);
+hipError_t map_box_copy(hipStream_t st, const float4* pts, const uint32_t* cell_start, const uint32_t* row_start, int nx, int ny, int nz, int xs,
+                        const int c0[3], const int c1[3], float4* out, MapBuildScratch& S);
 hipError_t atan2f_probe(hipStream_t st, const float* yx_host, int n, float* out_host);   // the device's atan2f on n (y, x) pairs
 size_t row_table_size(int nx, int ny, int nz);
 hipError_t map_build_row_table(hipStream_t st, const uint32_t* cell_start, int nx, int ny, int nz, uint32_t* out, bool zero_pads = true);

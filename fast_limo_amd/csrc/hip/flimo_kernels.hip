@@ -117,11 +117,14 @@ FLIMO_DEV void visit_row(const GridView& G, int cx, int cy, int cz, int dy, int 
   const float a = fmaxf(slab_dist(dy, ry) - margin, 0.f), b = fmaxf(slab_dist(dz, rz) - margin, 0.f);
   const float yz2 = a * a + b * b;
   if (yz2 * cell2 >= fminf(bound, R.bd[K - 1])) return;   // the whole row is farther than the current 5th best
-  const size_t rowbase = ((size_t)(cz + dz) * (size_t)G.ny + (size_t)(cy + dy)) * (size_t)G.nxf;
+  // (the tables hold positions relative to their row's start: GridView)
+  const size_t rowi = (size_t)(cz + dz) * (size_t)G.ny + (size_t)(cy + dy);
+  const size_t rowbase = rowi * (size_t)G.nxs;
+  const uint32_t rs = G.row_start[rowi];
   if (max(abs(dy), abs(dz)) > r_prev) {
     const int x0 = max(cx - r, 0), x1 = min(cx + r, G.nx - 1);
     if (x0 <= x1) {
-      const uint32_t lo = G.cell_start[rowbase + (size_t)x0 * G.xs], hi = G.cell_start[rowbase + (size_t)(x1 + 1) * G.xs];
+      const uint32_t lo = rs + G.cell_start[rowbase + (size_t)x0 * G.xs], hi = rs + G.cell_start[rowbase + (size_t)(x1 + 1) * G.xs];
       scan_range<L, K>(G.pts, lo, hi, sub, gx, gy, gz, R.bd, R.bi, R.cand);
     }
   } else {
@@ -130,7 +133,7 @@ FLIMO_DEV void visit_row(const GridView& G, int cx, int cy, int cz, int dy, int 
       const int x0 = max(cx - r, 0), x1 = min(cx - r_prev - 1, G.nx - 1);
       const float sx = fmaxf(slab_dist(-(r_prev + 1), rx) - margin, 0.f);
       if (x0 <= x1 && (sx * sx + yz2) * cell2 < fminf(bound, R.bd[K - 1])) {
-        const uint32_t lo = G.cell_start[rowbase + (size_t)x0 * G.xs], hi = G.cell_start[rowbase + (size_t)(x1 + 1) * G.xs];
+        const uint32_t lo = rs + G.cell_start[rowbase + (size_t)x0 * G.xs], hi = rs + G.cell_start[rowbase + (size_t)(x1 + 1) * G.xs];
         scan_range<L, K>(G.pts, lo, hi, sub, gx, gy, gz, R.bd, R.bi, R.cand);
       }
     }
@@ -138,7 +141,7 @@ FLIMO_DEV void visit_row(const GridView& G, int cx, int cy, int cz, int dy, int 
       const int x0 = max(cx + r_prev + 1, 0), x1 = min(cx + r, G.nx - 1);
       const float sx = fmaxf(slab_dist(r_prev + 1, rx) - margin, 0.f);
       if (x0 <= x1 && (sx * sx + yz2) * cell2 < fminf(bound, R.bd[K - 1])) {
-        const uint32_t lo = G.cell_start[rowbase + (size_t)x0 * G.xs], hi = G.cell_start[rowbase + (size_t)(x1 + 1) * G.xs];
+        const uint32_t lo = rs + G.cell_start[rowbase + (size_t)x0 * G.xs], hi = rs + G.cell_start[rowbase + (size_t)(x1 + 1) * G.xs];
         scan_range<L, K>(G.pts, lo, hi, sub, gx, gy, gz, R.bd, R.bi, R.cand);
       }
     }
@@ -196,9 +199,11 @@ FLIMO_DEV void knn_search(const GridView& G, float gx, float gy, float gz, int s
         const int dz = (t / 3 == 0) ? 0 : ((t / 3 == 1) ? -1 : 1);
         const int yy = cy + dy, zz = cz + dz;
         const bool in = (yy >= 0) && (yy < G.ny) && (zz >= 0) && (zz < G.nz) && (x0 <= x1);
-        const size_t rowbase = ((size_t)(in ? zz : 0) * (size_t)G.ny + (size_t)(in ? yy : 0)) * (size_t)G.nxf;
-        lo[t] = in ? G.cell_start[rowbase + (size_t)x0 * G.xs] : 0u;
-        hi[t] = in ? G.cell_start[rowbase + (size_t)(x1 + 1) * G.xs] : 0u;
+        const size_t rowi = (size_t)(in ? zz : 0) * (size_t)G.ny + (size_t)(in ? yy : 0);
+        const size_t rowbase = rowi * (size_t)G.nxs;
+        const uint32_t rs = in ? G.row_start[rowi] : 0u;
+        lo[t] = in ? rs + G.cell_start[rowbase + (size_t)x0 * G.xs] : 0u;
+        hi[t] = in ? rs + G.cell_start[rowbase + (size_t)(x1 + 1) * G.xs] : 0u;
       }
 #pragma unroll
       for (int t = 0; t < 9; t++) {
@@ -567,9 +572,11 @@ __device__ __forceinline__ void knn5_tail(const GridView& G, int max_ring, NbrRe
                 const int dl = (int)fminf(floorf(fminf(xr + (1.f - rx), 1.0e6f)), (float)r);
                 const int x0 = max(cx - dl, 0), x1 = min(cx + dr, G.nx - 1);
                 if (x0 <= x1) {
-                  const size_t rowbase = ((size_t)zz * (size_t)G.ny + (size_t)yy) * (size_t)G.nxf;
-                  lo4[u] = G.cell_start[rowbase + (size_t)x0 * G.xs];
-                  hi4[u] = G.cell_start[rowbase + (size_t)(x1 + 1) * G.xs];
+                  const size_t rowi = (size_t)zz * (size_t)G.ny + (size_t)yy;
+                  const size_t rowbase = rowi * (size_t)G.nxs;
+                  const uint32_t rs = G.row_start[rowi];      // (the tables hold positions relative to their row's start)
+                  lo4[u] = rs + G.cell_start[rowbase + (size_t)x0 * G.xs];
+                  hi4[u] = rs + G.cell_start[rowbase + (size_t)(x1 + 1) * G.xs];
                 }
               }
             }
@@ -1028,13 +1035,21 @@ __device__ __forceinline__ void knn5_pass(const GridView& G, const float4* __res
       // of the true one, and the other 26 cells are then walked only as far as that ball reaches (rows and end cells it cannot
       // reach are dropped, exactly as with the bound of a previous pass).
       const bool probe_on = L == 2 && !prev_valid && prev_probe_min != 0u;          // wave-uniform
-      U3 rbl[3], rbh[3];
+      // (the table holds positions relative to their row's start; the nine rows' starts are three more 12-byte loads from the
+      //  padded copy of the row starts, in the same round trip -- pads: 0 + 0, an empty range)
+      U3 rbl[3], rbh[3], rsb[3];
       {
         const uint32_t iL = (uint32_t)c0 * plane + yz, iH = (uint32_t)c1 * plane + yz;
 #pragma unroll
         for (int dz = 0; dz < 3; dz++) {
           rbl[dz] = *reinterpret_cast<const U3*>(G.row_table + (iL + (uint32_t)dz * py));
           rbh[dz] = *reinterpret_cast<const U3*>(G.row_table + (iH + (uint32_t)dz * py));
+          rsb[dz] = *reinterpret_cast<const U3*>(G.row_start_t + (yz + (uint32_t)dz * py));
+        }
+#pragma unroll
+        for (int dz = 0; dz < 3; dz++) {
+          rbl[dz].a += rsb[dz].a; rbl[dz].b += rsb[dz].b; rbl[dz].c += rsb[dz].c;
+          rbh[dz].a += rsb[dz].a; rbh[dz].b += rsb[dz].b; rbh[dz].c += rsb[dz].c;
         }
       }
       // conservative distances (cell units) to the neighbouring rows; without a bound every row is in
@@ -1061,8 +1076,8 @@ __device__ __forceinline__ void knn5_pass(const GridView& G, const float4* __res
       const uint32_t centre = yz + py + 1u;                         // (z, y) = the query's own row within a padded x plane
       uint32_t own_a = rbl[1].b, own_b = rbh[1].b;                  // the own cell's range (two 4-byte loads, heavy blocks only)
       if (heavy_block) {
-        own_a = G.row_table[(uint32_t)(cx * G.xs) * plane + centre];
-        own_b = G.row_table[(uint32_t)((cx + 1) * G.xs) * plane + centre];
+        own_a = rsb[1].b + G.row_table[(uint32_t)(cx * G.xs) * plane + centre];
+        own_b = rsb[1].b + G.row_table[(uint32_t)((cx + 1) * G.xs) * plane + centre];
       }
       // The probe walks the query's own COLUMN (the tables' x resolution: half a cell by default) when that alone can give a bound,
       // its own cell otherwise: in a crowded cell the column holds a fraction of the points and its 5th distance is as good.  The
@@ -1070,8 +1085,8 @@ __device__ __forceinline__ void knn5_pass(const GridView& G, const float4* __res
       uint32_t lo_own = own_a, hi_own = own_b;
       if (heavy_block && G.xs > 1 && hi_own - lo_own >= 2u * PROBE_MIN_OWN) {
         const int col = min(max((int)floorf(fx * (float)G.xs), cx * G.xs), (cx + 1) * G.xs - 1);
-        const uint32_t ca = (col == cx * G.xs) ? lo_own : G.row_table[(uint32_t)col * plane + centre];
-        const uint32_t cb = (col + 1 == (cx + 1) * G.xs) ? hi_own : G.row_table[(uint32_t)(col + 1) * plane + centre];
+        const uint32_t ca = (col == cx * G.xs) ? lo_own : rsb[1].b + G.row_table[(uint32_t)col * plane + centre];
+        const uint32_t cb = (col + 1 == (cx + 1) * G.xs) ? hi_own : rsb[1].b + G.row_table[(uint32_t)(col + 1) * plane + centre];
         if (cb - ca >= PROBE_MIN_OWN) { lo_own = ca; hi_own = cb; }
       }
       const uint32_t n_own = hi_own - lo_own;
@@ -1140,6 +1155,11 @@ __device__ __forceinline__ void knn5_pass(const GridView& G, const float4* __res
               for (int dz = 0; dz < 3; dz++) {
                 hl[dz] = *reinterpret_cast<const U3*>(G.row_table + (iL + (uint32_t)dz * py));
                 hh[dz] = *reinterpret_cast<const U3*>(G.row_table + (iH + (uint32_t)dz * py));
+              }
+#pragma unroll
+              for (int dz = 0; dz < 3; dz++) {
+                hl[dz].a += rsb[dz].a; hl[dz].b += rsb[dz].b; hl[dz].c += rsb[dz].c;
+                hh[dz].a += rsb[dz].a; hh[dz].b += rsb[dz].b; hh[dz].c += rsb[dz].c;
               }
             }
 #pragma unroll
@@ -1420,11 +1440,19 @@ __device__ __forceinline__ void widen_body(const GridView& G, int max_ring, NbrR
     int flag = 0;
     int cand = 0;
     int r = first_ring;                                // no hint: straight to the gate's ring (one search instead of two)
+    // The ball that must hold the five (cell units squared, +inf: none known): the bound of the previous pass of this scan that the
+    // k-NN launch handed over, and the 3x3x3 block's own 5th distance.  Rows the ball cannot reach are not walked and the others
+    // only over the cells it reaches -- exactly as the in-kernel tail does (round 4 walked whole ring-2/3 blocks here: 56-117 KB
+    // per query against 1 KB of candidates that can matter, profiles/r04/pmc_hbm_regime.json).
+    float bnd2 = __int_as_float(e1.z);
+    if (!(bnd2 >= 0.f)) bnd2 = INFINITY;
     {
       const float hint = __int_as_float(hint_bits);
       if (hint >= 0.f && hint < INFINITY) {            // an upper bound of the true 5th distance: go straight to its ring
         const float need = fl_sqrt(hint) * G.inv_cell * (1.f + 4.0e-6f) - edge + margin;
         r = max(2, (int)ceilf(fminf(need, 1.0e9f)));
+        const float rc = (fl_sqrt(hint) * (1.f + 1.0e-5f) + 1.0e-6f) * G.inv_cell;
+        bnd2 = fminf(bnd2, rc * rc * (1.f + 1.0e-5f));
       }
       r = min(r, max_ring);
     }
@@ -1433,12 +1461,24 @@ __device__ __forceinline__ void widen_body(const GridView& G, int max_ring, NbrR
       // one row per lane
       uint32_t lo = 0, len = 0;
       if (lane < side * side) {
-        const int yy = cy + (lane % side) - r, zz = cz + (lane / side) - r;
-        const int x0 = max(cx - r, 0), x1 = min(cx + r, G.nx - 1);
-        if (yy >= 0 && yy < G.ny && zz >= 0 && zz < G.nz && x0 <= x1) {
-          const size_t rowbase = ((size_t)zz * (size_t)G.ny + (size_t)yy) * (size_t)G.nxf;
-          lo = G.cell_start[rowbase + (size_t)x0 * G.xs];
-          len = G.cell_start[rowbase + (size_t)(x1 + 1) * G.xs] - lo;
+        const int dy = (lane % side) - r, dz = (lane / side) - r;
+        const int yy = cy + dy, zz = cz + dz;
+        const float a_ = fmaxf(slab_dist(dy, ry) - margin, 0.f), b_ = fmaxf(slab_dist(dz, rz) - margin, 0.f);
+        const float dyz2 = a_ * a_ + b_ * b_;
+        int x0 = max(cx - r, 0), x1 = min(cx + r, G.nx - 1);
+        if (bnd2 < 1.0e18f) {
+          // cells of the row the ball can reach: offset +d is (d - rx) away, offset -d is (rx + d - 1) away
+          const float xr = fl_sqrt(fmaxf(bnd2 - dyz2, 0.f)) * (1.f + 1.0e-6f) + margin + 1.0e-4f;
+          const int dr = (int)fminf(floorf(fminf(xr + rx, 1.0e6f)), (float)r);
+          const int dl = (int)fminf(floorf(fminf(xr + (1.f - rx), 1.0e6f)), (float)r);
+          x0 = max(cx - dl, 0); x1 = min(cx + dr, G.nx - 1);
+        }
+        if (dyz2 <= bnd2 && yy >= 0 && yy < G.ny && zz >= 0 && zz < G.nz && x0 <= x1) {
+          const size_t rowi = (size_t)zz * (size_t)G.ny + (size_t)yy;
+          const size_t rowbase = rowi * (size_t)G.nxs;
+          const uint32_t rl = G.cell_start[rowbase + (size_t)x0 * G.xs];
+          lo = G.row_start[rowi] + rl;                          // (relative to the row's start)
+          len = G.cell_start[rowbase + (size_t)(x1 + 1) * G.xs] - rl;
         }
       }
       // inclusive prefix sum over the wave
@@ -1501,6 +1541,8 @@ __device__ __forceinline__ void widen_body(const GridView& G, int max_ring, NbrR
       if (have5) {
         const float need = fl_sqrt(d5) * G.inv_cell * (1.f + 4.0e-6f) - edge + margin;
         rn = max(r + 1, (int)ceilf(fminf(need, 1.0e9f)));
+        const float rc = (fl_sqrt(d5) * (1.f + 1.0e-5f) + 1.0e-6f) * G.inv_cell;
+        bnd2 = fminf(bnd2, rc * rc * (1.f + 1.0e-5f));
       }
       r = min(rn, max_ring);
     }
@@ -2056,8 +2098,10 @@ __device__ bool tie_select_wave(const GridView& G, const BookView& B, float qx, 
         const int dl = (int)fminf(floorf(fminf(xr + (1.f - rx), 1.0e6f)), (float)r);
         const int x0 = max(cx - dl, 0), x1 = min(cx + dr, G.nx - 1);
         if (x0 <= x1) {
-          const size_t rowbase = ((size_t)zz * (size_t)G.ny + (size_t)yy) * (size_t)G.nxf;
-          const uint32_t lo = G.cell_start[rowbase + (size_t)x0 * G.xs], hi = G.cell_start[rowbase + (size_t)(x1 + 1) * G.xs];
+          const size_t rowi = (size_t)zz * (size_t)G.ny + (size_t)yy;
+          const size_t rowbase = rowi * (size_t)G.nxs;
+          const uint32_t rs = G.row_start[rowi];                // (the tables hold positions relative to their row's start)
+          const uint32_t lo = rs + G.cell_start[rowbase + (size_t)x0 * G.xs], hi = rs + G.cell_start[rowbase + (size_t)(x1 + 1) * G.xs];
           for (uint32_t i = lo; i < hi; i++) {
             const float4 p = G.pts[i];
             const float d = sqdist3(qx, qy, qz, p.x, p.y, p.z);

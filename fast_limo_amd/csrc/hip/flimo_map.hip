@@ -69,7 +69,7 @@ __device__ __forceinline__ uint32_t column_key(const float4& p, float ox, float 
   cx = min(max(cx, 0), nx * xs - 1);
   cy = min(max(cy, 0), ny - 1);
   cz = min(max(cz, 0), nz - 1);
-  return (uint32_t)(((size_t)cz * ny + cy) * ((size_t)nx * xs) + cx);
+  return (uint32_t)(((size_t)cz * ny + cy) * ((size_t)nx * xs + 1) + cx);      // (a row of the cell table: nxf columns + its end entry)
 }
 __global__ __launch_bounds__(256) void cellkey_kernel(const float4* __restrict__ pts, size_t n, float ox, float oy,
                                                       float oz, float inv_cell, int nx, int ny, int nz, int xs,
@@ -188,9 +188,39 @@ hipError_t map_bbox(hipStream_t st, const float4* pts, size_t n, MapBuildScratch
   return hipSuccess;
 }
 
-hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4* pts_out, uint32_t* cell_start,
-                          size_t ncells, float ox, float oy, float oz, float inv_cell, int nx, int ny, int nz, int xs,
-                          MapBuildScratch& S) {
+// absolute column starts (x fastest, rows of nxs entries) -> row_start[r] = the row's first entry, cell_start[] relative to it
+__global__ __launch_bounds__(256) void rows_relative_kernel(uint32_t* __restrict__ cell_start, uint32_t* __restrict__ row_start, size_t nrows, int nxs) {
+  const size_t r = blockIdx.x;
+  __shared__ uint32_t s_base;
+  if (threadIdx.x == 0) {
+    s_base = cell_start[r * (size_t)nxs];
+    row_start[r] = s_base;
+    if (r + 1 == nrows) row_start[nrows] = cell_start[nrows * (size_t)nxs];      // (the table's last entry: the point count)
+  }
+  __syncthreads();
+  const uint32_t base = s_base;
+  uint32_t* row = cell_start + r * (size_t)nxs;
+  __syncthreads();                                     // (thread 0 read entry 0 before anybody rewrites it)
+  for (int x = threadIdx.x; x < nxs; x += blockDim.x) row[x] -= base;
+}
+// row_start -> its padded, y-fastest copy (pads stay zero)
+__global__ __launch_bounds__(256) void rowstart_t_kernel(const uint32_t* __restrict__ row_start, int ny, int nz, uint32_t* __restrict__ out) {
+  const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= (size_t)ny * nz) return;
+  const int y = (int)(r % (size_t)ny), z = (int)(r / (size_t)ny);
+  out[(size_t)(z + 2) * ((size_t)ny + 4) + (size_t)(y + 2)] = row_start[r];
+}
+size_t cell_table_size(int nxf, int ny, int nz) { return (size_t)ny * nz * ((size_t)nxf + 1) + 1; }
+size_t row_start_size(int ny, int nz) { return (size_t)ny * nz + 1; }
+size_t row_start_t_size(int ny, int nz) { return ((size_t)ny + 4) * ((size_t)nz + 4); }
+
+hipError_t map_build_row_table(hipStream_t st, const uint32_t* cell_start, int nx, int ny, int nz, uint32_t* out, bool zero_pads);
+hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4* pts_out, const IndexTables& T,
+                          float ox, float oy, float oz, float inv_cell, int nx, int ny, int nz, int xs,
+                          MapBuildScratch& S, bool zero_pads) {
+  const int nxf = nx * xs, nxs = nxf + 1;
+  const size_t nrows = (size_t)ny * nz, ncells = nrows * (size_t)nxs;      // entries before the last one
+  uint32_t* cell_start = T.cell_start;
   hipError_t e = ensure_scratch(S, n);
   if (e != hipSuccess) return e;
   const int blocks = (int)((n + 255) / 256);
@@ -228,6 +258,11 @@ hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4
   }
   e = inclusive_max_u32(S.cub_tmp, scan_bytes, cell_start, cell_start, (int)(ncells + 1), st);
   if (e != hipSuccess) return e;
+  // absolute starts -> rows' starts + entries relative to them, then the two y-fastest copies the k-NN fast path reads
+  hipLaunchKernelGGL(rows_relative_kernel, dim3((unsigned)nrows), dim3(256), 0, st, cell_start, T.row_start, nrows, nxs);
+  if ((e = map_build_row_table(st, cell_start, nxf, ny, nz, T.row_table, zero_pads)) != hipSuccess) return e;
+  if (zero_pads && (e = hipMemsetAsync(T.row_start_t, 0, row_start_t_size(ny, nz) * sizeof(uint32_t), st)) != hipSuccess) return e;
+  hipLaunchKernelGGL(rowstart_t_kernel, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, st, T.row_start, ny, nz, T.row_start_t);
   return hipGetLastError();
 }
 
@@ -272,12 +307,16 @@ __global__ __launch_bounds__(256) void merge_points_kernel(const float4* __restr
                                                            const uint32_t* __restrict__ nkeys, uint32_t k, float ox, float oy, float oz,
                                                            float inv_cell, int nx, int ny, int nz, int xs, float4* __restrict__ out,
                                                            uint32_t old_blocks, const float4* __restrict__ new_pts,
-                                                           const uint32_t* __restrict__ nperm, const uint32_t* __restrict__ cell_start_old) {
+                                                           const uint32_t* __restrict__ nperm, const uint32_t* __restrict__ cell_start_old,
+                                                           const uint32_t* __restrict__ row_start_old, int nxs) {
   __shared__ uint32_t s_lo, s_hi, s_c0, s_c1;
   if (blockIdx.x >= old_blocks) {
     const uint32_t j = (blockIdx.x - old_blocks) * blockDim.x + threadIdx.x;
     if (j >= k) return;
-    out[(size_t)cell_start_old[(size_t)nkeys[j] + 1] + j] = new_pts[nperm[j]];
+    // (behind the stored points of its column: the next entry of the same row -- a column is never a row's end entry -- plus the
+    //  row's start)
+    const uint32_t key = nkeys[j];
+    out[(size_t)row_start_old[key / (uint32_t)nxs] + (size_t)cell_start_old[(size_t)key + 1] + j] = new_pts[nperm[j]];
     return;
   }
   const uint32_t base = blockIdx.x * blockDim.x;
@@ -300,31 +339,46 @@ __global__ __launch_bounds__(256) void merge_points_kernel(const float4* __restr
   const uint32_t shift = (lo == hi) ? lo : lower_bound_u32(nkeys, lo, hi, cid);
   out[(size_t)i + shift] = p;
 }
-// cell_start[c] += #new points in cells < c   (c = 0 .. ncells; the last entry becomes the new point count)
-__global__ __launch_bounds__(256) void cellstart_shift_kernel(uint32_t* __restrict__ cell_start, size_t n_entries,
-                                                              const uint32_t* __restrict__ nkeys, uint32_t k) {
+// The tables after a merge.  row_start[r] += #new points in rows < r (every row: a table of ny*nz + 1 entries).  Relative entries
+// change only inside the rows that received points: entry (r, xf) += #new points of row r in columns < xf -- one workgroup per
+// row looks whether its row has new keys at all (a wave-wide search over the sorted new keys) and leaves if not; a row that has
+// rewrites its nxs entries in both tables (x fastest here, y fastest in row_table).
+__global__ __launch_bounds__(256) void rows_merge_kernel(uint32_t* __restrict__ cell_start, uint32_t* __restrict__ row_start,
+                                                         uint32_t* __restrict__ row_table, uint32_t* __restrict__ row_start_t,
+                                                         const uint32_t* __restrict__ nkeys, uint32_t k, int nxs, int ny, int nz) {
   __shared__ uint32_t s_lo, s_hi;
-  constexpr int PER = 16;
-  const size_t base = (size_t)blockIdx.x * (blockDim.x * PER);
-  const size_t top = min(n_entries, base + (size_t)blockDim.x * PER) - 1;
-  if (threadIdx.x < 64) { const uint32_t r = wave_lower_bound_u32(nkeys, k, (uint32_t)base); if (threadIdx.x == 0) s_lo = r; }
-  else if (threadIdx.x < 128) { const uint32_t r = wave_lower_bound_u32(nkeys, k, (uint32_t)top); if (threadIdx.x == 64) s_hi = r; }
+  const size_t nrows = (size_t)ny * nz;
+  const size_t r = blockIdx.x;                                   // 0 .. nrows (the extra one: the point count at row_start[nrows])
+  const uint32_t first = (uint32_t)(r * (size_t)nxs);
+  if (threadIdx.x < 64) { const uint32_t v = wave_lower_bound_u32(nkeys, k, first); if (threadIdx.x == 0) s_lo = v; }
+  else if (threadIdx.x < 128) { const uint32_t v = r < nrows ? wave_lower_bound_u32(nkeys, k, first + (uint32_t)nxs) : k; if (threadIdx.x == 64) s_hi = v; }
   __syncthreads();
   const uint32_t lo = s_lo, hi = s_hi;
-  if (hi == 0u) return;                                  // nothing new below this chunk: entries unchanged
-#pragma unroll
-  for (int r = 0; r < PER; r++) {
-    const size_t cidx = base + (size_t)r * blockDim.x + threadIdx.x;
-    if (cidx < n_entries) {
-      const uint32_t add = (lo == hi) ? lo : lower_bound_u32(nkeys, lo, hi, (uint32_t)cidx);
-      cell_start[cidx] += add;
+  if (threadIdx.x == 0 && lo != 0u) {
+    const uint32_t v = row_start[r] + lo;
+    row_start[r] = v;
+    if (r < nrows) row_start_t[(size_t)(r / (size_t)ny + 2) * ((size_t)ny + 4) + (size_t)(r % (size_t)ny + 2)] = v;
+    else cell_start[nrows * (size_t)nxs] = v;                    // (the cell table's last entry: the point count, like row_start's)
+  }
+  if (r >= nrows || lo == hi) return;
+  const int y = (int)(r % (size_t)ny), z = (int)(r / (size_t)ny);
+  const size_t py = (size_t)ny + 4, pz = (size_t)nz + 4;
+  uint32_t* row = cell_start + r * (size_t)nxs;
+  for (int x = threadIdx.x; x < nxs; x += blockDim.x) {
+    const uint32_t add = lower_bound_u32(nkeys, lo, hi, first + (uint32_t)x) - lo;
+    if (add != 0u) {
+      const uint32_t v = row[x] + add;
+      row[x] = v;
+      row_table[((size_t)x * pz + (size_t)(z + 2)) * py + (size_t)(y + 2)] = v;
     }
   }
 }
 hipError_t map_merge_grid(hipStream_t st, const float4* old_sorted, size_t n_old, const float4* new_pts, size_t k,
-                          float4* out_sorted, uint32_t* cell_start, size_t ncells, float ox, float oy, float oz,
+                          float4* out_sorted, const IndexTables& T, float ox, float oy, float oz,
                           float inv_cell, int nx, int ny, int nz, int xs, MapBuildScratch& S) {
   if (k == 0) return hipSuccess;
+  const int nxs = nx * xs + 1;
+  const size_t nrows = (size_t)ny * nz, ncells = nrows * (size_t)nxs;
   hipError_t e = ensure_scratch(S, k);
   if (e != hipSuccess) return e;
   const int kb = (int)((k + 255) / 256);
@@ -345,10 +399,11 @@ hipError_t map_merge_grid(hipStream_t st, const float4* old_sorted, size_t n_old
   {
     const unsigned old_blocks = (unsigned)((n_old + 255) / 256);
     hipLaunchKernelGGL(merge_points_kernel, dim3(old_blocks + (unsigned)kb), dim3(256), 0, st, old_sorted, (uint32_t)n_old, S.keys_out, (uint32_t)k,
-                       ox, oy, oz, inv_cell, nx, ny, nz, xs, out_sorted, old_blocks, new_pts, S.vals_out, cell_start);
+                       ox, oy, oz, inv_cell, nx, ny, nz, xs, out_sorted, old_blocks, new_pts, S.vals_out, T.cell_start, T.row_start, nxs);
   }
-  hipLaunchKernelGGL(cellstart_shift_kernel, dim3((unsigned)((ncells + 1 + 4095) / 4096)), dim3(256), 0, st, cell_start, ncells + 1,
-                     S.keys_out, (uint32_t)k);
+  // (the points were placed with the OLD tables: the tables follow)
+  hipLaunchKernelGGL(rows_merge_kernel, dim3((unsigned)(nrows + 1)), dim3(256), 0, st, T.cell_start, T.row_start, T.row_table, T.row_start_t,
+                     S.keys_out, (uint32_t)k, nxs, ny, nz);
   return hipGetLastError();
 }
 
@@ -376,7 +431,7 @@ __global__ __launch_bounds__(256) void crowded_all_kernel(const uint32_t* __rest
   if (c >= ncells) return;
   const int x = (int)(c % (size_t)nx);
   const size_t row = c / (size_t)nx;
-  const size_t col0 = row * ((size_t)nx * xs) + (size_t)x * xs;
+  const size_t col0 = row * ((size_t)nx * xs + 1) + (size_t)x * xs;      // (entries of one row: relative to the same start)
   if (cell_start[col0 + xs] - cell_start[col0] <= threshold) return;
   crowded_append((uint32_t)c, x, (int)(row % (size_t)ny), (int)(row / (size_t)ny), bits, list, cap, count);
 }
@@ -387,11 +442,13 @@ __global__ __launch_bounds__(256) void crowded_points_kernel(const float4* __res
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= k) return;
   const uint32_t col = column_key(pts[i], ox, oy, oz, inv_cell, nx, ny, nz, xs);
-  const uint32_t col0 = col - col % (uint32_t)xs;
+  const uint32_t nxs = (uint32_t)(nx * xs + 1);
+  const uint32_t row = col / nxs, xf = col - row * nxs;
+  const uint32_t col0 = col - xf % (uint32_t)xs;
   if (cell_start[col0 + xs] - cell_start[col0] <= threshold) return;
-  const uint32_t cell = col0 / (uint32_t)xs;
-  crowded_append(cell, (int)(cell % (uint32_t)nx), (int)((cell / (uint32_t)nx) % (uint32_t)ny), (int)(cell / ((uint32_t)nx * (uint32_t)ny)), bits,
-                 list, cap, count);
+  const uint32_t x = xf / (uint32_t)xs;
+  const uint32_t cell = row * (uint32_t)nx + x;
+  crowded_append(cell, (int)x, (int)(row % (uint32_t)ny), (int)(row / (uint32_t)ny), bits, list, cap, count);
 }
 // *count_host = entries listed so far (may exceed cap: the list is then incomplete)
 hipError_t crowded_list_all(hipStream_t st, const uint32_t* cell_start, int nx, int ny, int nz, int xs, uint32_t threshold, uint32_t* bits,
@@ -430,20 +487,22 @@ __global__ __launch_bounds__(256) void boxrows_count_kernel(const uint32_t* __re
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= nrows) return;
   const int y = y0 + r % nyb, z = z0 + r / nyb;
-  const size_t base = ((size_t)z * (size_t)ny + (size_t)y) * (size_t)nxf;
+  const size_t base = ((size_t)z * (size_t)ny + (size_t)y) * ((size_t)nxf + 1);
   cnt[r] = cell_start[base + (size_t)(x1 + 1) * xs] - cell_start[base + (size_t)x0 * xs];
 }
 __global__ __launch_bounds__(64) void boxrows_total_kernel(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off, int nrows,
                                                            uint32_t* __restrict__ total) {
   if (threadIdx.x == 0 && blockIdx.x == 0) *total = off[nrows - 1] + cnt[nrows - 1];
 }
-__global__ __launch_bounds__(64) void boxrows_copy_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ cell_start, int ny,
+__global__ __launch_bounds__(64) void boxrows_copy_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ cell_start,
+                                                          const uint32_t* __restrict__ row_start, int ny,
                                                           int nxf, int xs, int x0, int y0, int nyb, int z0, const uint32_t* __restrict__ cnt,
                                                           const uint32_t* __restrict__ off, float4* __restrict__ out) {
   const int r = blockIdx.x;
   const int y = y0 + r % nyb, z = z0 + r / nyb;
-  const size_t base = ((size_t)z * (size_t)ny + (size_t)y) * (size_t)nxf;
-  const uint32_t a = cell_start[base + (size_t)x0 * xs], n = cnt[r], o = off[r];
+  const size_t rowi = (size_t)z * (size_t)ny + (size_t)y;
+  const size_t base = rowi * ((size_t)nxf + 1);
+  const uint32_t a = row_start[rowi] + cell_start[base + (size_t)x0 * xs], n = cnt[r], o = off[r];
   for (uint32_t i = threadIdx.x; i < n; i += 64) {
     const float4 p = pts[a + i];
     out[o + i] = make_float4(p.x, p.y, p.z, __uint_as_float(a + i));
@@ -475,11 +534,11 @@ hipError_t map_box_count(hipStream_t st, const uint32_t* cell_start, int nx, int
   return hipSuccess;
 }
 // second step: the counts / offsets of map_box_count (same box, nothing else used the scratch in between) -> the copies
-hipError_t map_box_copy(hipStream_t st, const float4* pts, const uint32_t* cell_start, int nx, int ny, int nz, int xs, const int c0[3],
-                        const int c1[3], float4* out, MapBuildScratch& S) {
+hipError_t map_box_copy(hipStream_t st, const float4* pts, const uint32_t* cell_start, const uint32_t* row_start, int nx, int ny, int nz, int xs,
+                        const int c0[3], const int c1[3], float4* out, MapBuildScratch& S) {
   const int nyb = c1[1] - c0[1] + 1, nzb = c1[2] - c0[2] + 1;
   if (nyb <= 0 || nzb <= 0 || c1[0] < c0[0]) return hipSuccess;
-  hipLaunchKernelGGL(boxrows_copy_kernel, dim3(nyb * nzb), dim3(64), 0, st, pts, cell_start, ny, nx * xs, xs, c0[0], c0[1], nyb, c0[2],
+  hipLaunchKernelGGL(boxrows_copy_kernel, dim3(nyb * nzb), dim3(64), 0, st, pts, cell_start, row_start, ny, nx * xs, xs, c0[0], c0[1], nyb, c0[2],
                      S.keys_in, S.vals_in, out);
   return hipGetLastError();
 }
@@ -500,7 +559,7 @@ __global__ __launch_bounds__(256) void rowtable_kernel(const uint32_t* __restric
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const int y = y0 + ty + 8 * r, x = x0 + tx;
-    if (y < ny && x <= nx) tile[ty + 8 * r][tx] = cell_start[((size_t)z * ny + y) * nx + x];   // x == nx: start of the next row
+    if (y < ny && x <= nx) tile[ty + 8 * r][tx] = cell_start[((size_t)z * ny + y) * ((size_t)nx + 1) + x];   // (rows of nx + 1 entries; x == nx: the row's length)
   }
   __syncthreads();
 #pragma unroll
