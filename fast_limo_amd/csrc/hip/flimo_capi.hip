@@ -180,7 +180,7 @@ struct flimo_ctx {
   bool have_fine_center = false;
   float fine_radius = 24.f;            // FLIMO_FINE_RADIUS [m]: crowded cells farther from the sensor (xy) stay out of the region
   uint64_t fine_builds = 0, fine_passes = 0;
-  int xslabs = 2;                  // FLIMO_XSLABS: fine columns per cell along x (1, 2, 4, 8; power of two): a pass that has the
+  int xslabs = 2;                  // fine columns per cell along x (1, 2, 4, 8; power of two): a pass that has the
                                    // previous pass's bound walks only the half cells its ball reaches.  Measured (round 3, 1M map):
                                    // clean map no change (21.8 -> 22.1 us), after 50 raw 64k sweeps the later passes 30.9 -> 23.2 us
                                    // (1.05x the clean map's); inserts unchanged at 2 (0.28 ms), +14 % at 4; both tables twice the size
@@ -1775,7 +1775,7 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   // later passes likewise, by the count the pass at the same position of the last scan published: a sparse far range (256k-point
   // sweeps over a 900 m map) keeps thousands of points beyond their 3x3x3 block in every pass
   // The bound grows with the scan: what hurts is a wave whose queries are ALL pending (one long chain), and a launch of n
-  // queries spreads 1/64 of them over its waves a handful at a time (FLIMO_TAIL_MAX overrides)
+  // queries spreads 1/64 of them over its waves a handful at a time
   const int tail_max = std::max(1024, n_all / 64);
   const bool tail_here = first_pass ? (c->stragglers_hist[0] <= tail_max)
                                     : (c->stragglers_hist[c->pass_in_scan] <= tail_max);

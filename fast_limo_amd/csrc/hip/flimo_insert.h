@@ -11,7 +11,7 @@
 //
 // The map itself is maintained by the device-resident book (flimo_gbook.hip), which reproduces the same rule on the
 // GPU.  This host statement backs flimo_insert_rule_replay (host-only API used by the CPU tests) and the
-// FLIMO_HOST_INSERT=1 A/B switch; it is not on the product's data path.
+// book's initial batch; it is not on the product's data path.
 #pragma once
 #include <stddef.h>
 #include <stdint.h>

@@ -76,8 +76,7 @@ res = []
 for cell in [float(c) for c in os.environ.get("CELLS", "0.5,0.6").split(",")]:
     ctx.map_clear(); ctx.map_config(cell_size=cell); ctx.map_add(mp)
     ctx.set_debug_records(True); ctx.match_reduce(x0, mcfg); cq = ctx.last_candidates_per_query(); ctx.set_debug_records(False)
-    for lpq in [int(v) for v in os.environ.get('LPQS', '2,4,8,16').split(',')]:
-        ctx.set_lanes_per_query(lpq)
+    for lpq in [2]:    # two lanes per query is the only layout since round 5
         for _ in range(3): ctx.match_reduce(x0, mcfg)
         ms = []; ws_ = []; rs_ = []
         t0 = time.time()

@@ -10,7 +10,6 @@ scan = np.ascontiguousarray(synth.velodyne_scan(int(os.environ.get("RINGS", 64))
 ctx = _lib.HipCtx(0)
 ctx.map_config(cell_size=float(os.environ.get("CELL", 0.5)))
 ctx.map_add(mp); ctx.scan_set(scan)
-ctx.set_lanes_per_query(int(os.environ.get("LPQ", 16)))
 x0 = np.zeros(26); x0[6] = 1; x0[10] = 1; x0[25] = -9.809
 cfg = _lib.default_match_cfg(MAX_NUM_PC2MATCH=10**7, MAX_NUM_MATCHES=10**7)
 for _ in range(int(os.environ.get("ITERS", 30))):

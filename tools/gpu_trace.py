@@ -39,7 +39,7 @@ for it in range(6):
 names = {0: ["start", "query loaded", "row bounds loaded", "candidates done", "merged", "stored (tail done)"],
          1: ["start", "scan+nbr loaded / fused: fit starts", "5 points gathered", "row computed", "partial stored", "ticket taken",
              "LAST: partials summed", "LAST: published"]}
-nblk = {0: (scan.shape[0] * int(os.environ.get("FLIMO_LPQ", 2)) + 255) // 256,
+nblk = {0: (scan.shape[0] * 2 + 255) // 256,
         1: (scan.shape[0] + 255) // 256}
 for k in (0, 1):
     nb = nblk[k]
