@@ -50,12 +50,10 @@ struct flimo_ctx {
   bool full_rebuild = false;       // FLIMO_FULL_REBUILD=1: sort the whole map on every insert (A/B of the merge)
   uint64_t grid_merges = 0, grid_builds = 0;
   size_t map_n = 0, map_cap = 0;
-  uint32_t* d_cell_start = nullptr;
-  size_t cell_cap = 0;
-  uint32_t* d_row_table = nullptr;
-  size_t row_cap = 0;
-  uint32_t *d_row_start = nullptr, *d_row_start_t = nullptr;   // the rows' absolute starts (x order / padded y-fastest copy): GridView
-  size_t rowstart_cap = 0, rowstart_t_cap = 0;
+  // the index of the main grid (GridView, flimo_types.h): segment table, escape pool (+ its fill count), the rows' starts
+  uint2* d_segs = nullptr;
+  uint32_t *d_ovf = nullptr, *d_ovf_count = nullptr, *d_row_start = nullptr;
+  size_t segs_cap = 0, ovf_cap = 0, rowstart_cap = 0;
   GridView grid{};
   bool grid_valid = false;
   double map_last_time = -1.0;
@@ -168,8 +166,9 @@ struct flimo_ctx {
   int fine_qlo[3] = {0, 0, 0}, fine_qhi[3] = {-1, -1, -1};
   float4 *d_fine_tmp = nullptr, *d_fine_pts = nullptr;
   size_t fine_pts_cap = 0;
-  uint32_t *d_fine_cs = nullptr, *d_fine_rt = nullptr, *d_fine_count = nullptr, *d_fine_rs = nullptr, *d_fine_rst = nullptr;
-  size_t fine_cs_cap = 0, fine_rt_cap = 0, fine_rs_cap = 0, fine_rst_cap = 0;
+  uint2* d_fine_segs = nullptr;
+  uint32_t *d_fine_ovf = nullptr, *d_fine_ovf_count = nullptr, *d_fine_count = nullptr, *d_fine_rs = nullptr;
+  size_t fine_segs_cap = 0, fine_ovf_cap = 0, fine_rs_cap = 0;
   void* d_crowd_list = nullptr;        // int4 (x, y, z, -) of every crowded cell of the current geometry, listed once
   uint32_t* d_crowd_count = nullptr;
   uint32_t* d_crowd_bits = nullptr;    // one bit per cell: listed
@@ -475,13 +474,13 @@ extern "C" void flimo_ctx_destroy(flimo_ctx* c) {
   if (!c) return;
   ctx_enter(c);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  (void)hipFree(c->d_map_raw); (void)hipFree(c->d_map_sorted); (void)hipFree(c->d_map_sorted2); (void)hipFree(c->d_cell_start); (void)hipFree(c->d_row_table);
-  (void)hipFree(c->d_row_start); (void)hipFree(c->d_row_start_t); (void)hipFree(c->d_fine_rs); (void)hipFree(c->d_fine_rst);
+  (void)hipFree(c->d_map_raw); (void)hipFree(c->d_map_sorted); (void)hipFree(c->d_map_sorted2); (void)hipFree(c->d_segs); (void)hipFree(c->d_ovf);
+  (void)hipFree(c->d_ovf_count); (void)hipFree(c->d_row_start); (void)hipFree(c->d_fine_rs); (void)hipFree(c->d_fine_ovf); (void)hipFree(c->d_fine_ovf_count);
   (void)hipFree(c->d_scan_sorted); (void)hipFree(c->d_nbr); (void)hipFree(c->d_wl); (void)hipFree(c->d_wl_count);
   (void)hipFree(c->d_fit_partials); (void)hipFree(c->d_raw_sorted); (void)hipFree(c->d_t_sorted);
   (void)hipFree(c->d_scan); (void)hipFree(c->d_scan_raw); (void)hipFree(c->d_scan_world); (void)hipFree(c->d_scan_t);
   (void)hipFree(c->d_frames); (void)hipFree(c->d_recs); (void)hipFree(c->d_dbg);
-  (void)hipFree(c->d_fine_tmp); (void)hipFree(c->d_fine_pts); (void)hipFree(c->d_fine_cs); (void)hipFree(c->d_fine_rt);
+  (void)hipFree(c->d_fine_tmp); (void)hipFree(c->d_fine_pts); (void)hipFree(c->d_fine_segs);
   (void)hipFree(c->d_fine_count); (void)hipFree(c->d_crowd_list); (void)hipFree(c->d_crowd_count); (void)hipFree(c->d_crowd_bits);
   (void)hipFree(c->d_tkey[0]); (void)hipFree(c->d_tkey[1]); (void)hipFree(c->d_tperm); (void)hipFree(c->d_t_tmp);
   (void)hipFree(c->d_raw32); (void)hipFree(c->d_filt_ext); (void)hipFree(c->d_nbrk); (void)hipFree(c->d_tie_list); (void)hipFree(c->d_tie_count);
@@ -556,8 +555,8 @@ static bool grid_covers(const GridView& g, const float* bb) {
   }
   return true;
 }
-// capacity of the four index tables of a grid of nxf x ny x nz columns (geometric growth: a map that keeps extending does not
-// reallocate per scan); *grew: a table was reallocated (its pads are not zero any more)
+// capacity of the index tables of a grid of nxf x ny x nz columns (geometric growth: a map that keeps extending does not
+// reallocate per scan); *grew: a table was reallocated
 template <typename T>
 static int ensure_table(flimo_ctx* c, T*& p, size_t& cap, size_t need, bool* grew) {
   if (need <= cap) return FLIMO_OK;
@@ -598,12 +597,12 @@ static int update_fine_grid(flimo_ctx* c, bool relayout, const float4* new_pts =
     }
     c->crowd_cells.clear();
     c->crowd_listed = 0;
-    HIPCHK(c, crowded_list_all(c->stream, g.cell_start, g.nx, g.ny, g.nz, g.xs, c->fine_threshold, c->d_crowd_bits, (int4*)c->d_crowd_list, CROWD_CAP,
+    HIPCHK(c, crowded_list_all(c->stream, g, c->fine_threshold, c->d_crowd_bits, (int4*)c->d_crowd_list, CROWD_CAP,
                                c->d_crowd_count, &listed, c->scratch));
     c->crowd_box_valid = true;
   } else {
     // same geometry as at the last look: only the cells of the points merged since can have become crowded
-    HIPCHK(c, crowded_list_points(c->stream, new_pts, n_new, g.cell_start, g.ox, g.oy, g.oz, g.inv_cell, g.nx, g.ny, g.nz, g.xs,
+    HIPCHK(c, crowded_list_points(c->stream, new_pts, n_new, g,
                                   c->fine_threshold, c->d_crowd_bits, (int4*)c->d_crowd_list, CROWD_CAP, c->d_crowd_count, &listed, c->scratch));
   }
   if (listed > CROWD_CAP) return FLIMO_OK;                      // crowded all over: no region to speak of
@@ -640,13 +639,13 @@ static int update_fine_grid(flimo_ctx* c, bool relayout, const float4* new_pts =
   int nf[3];
   for (int a = 0; a < 3; a++) nf[a] = (int)floorf((hi[a] - of[a]) * inv_f) + 3;
   const double ncf = (double)nf[0] * nf[1] * nf[2];
-  if (ncf > 6.4e7 || (double)row_table_size(nf[0], nf[1], nf[2]) > 2.0e8) return FLIMO_OK;      // crowded all over: not a region
+  if (ncf > 6.4e7) return FLIMO_OK;      // crowded all over: not a region
   // the copies: the region's cells (clipped to the grid) are contiguous ranges of the cell-sorted map
   const int gdim[3] = {g.nx, g.ny, g.nz};
   int c0[3], c1[3];
   for (int a = 0; a < 3; a++) { c0[a] = std::max(box[a] - 1, 0); c1[a] = std::min(box[3 + a] + 1, gdim[a] - 1); }
   uint32_t m = 0;
-  HIPCHK(c, map_box_count(c->stream, g.cell_start, g.nx, g.ny, g.nz, g.xs, c0, c1, c->d_fine_count, &m, c->scratch));
+  HIPCHK(c, map_box_count(c->stream, g, c0, c1, c->d_fine_count, &m, c->scratch));
   if (m == 0 || m < c->fine_min_points) return FLIMO_OK;
   const double tp1 = prof ? now() : 0.0;
   if (m > c->fine_pts_cap) {
@@ -657,27 +656,27 @@ static int update_fine_grid(flimo_ctx* c, bool relayout, const float4* new_pts =
     HIPCHK(c, hipMalloc(&c->d_fine_pts, cap * sizeof(float4)));
     c->fine_pts_cap = cap;
   }
-  HIPCHK(c, map_box_copy(c->stream, g.pts, g.cell_start, g.row_start, g.nx, g.ny, g.nz, g.xs, c0, c1, c->d_fine_tmp, c->scratch));
+  HIPCHK(c, map_box_copy(c->stream, g, c0, c1, c->d_fine_tmp, c->scratch));
   {
     int rc;
-    if ((rc = ensure_table(c, c->d_fine_cs, c->fine_cs_cap, cell_table_size(nf[0], nf[1], nf[2]), nullptr))) return rc;
-    if ((rc = ensure_table(c, c->d_fine_rt, c->fine_rt_cap, row_table_size(nf[0], nf[1], nf[2]), nullptr))) return rc;
+    if ((rc = ensure_table(c, c->d_fine_segs, c->fine_segs_cap, segs_size(nf[0], nf[1], nf[2]), nullptr))) return rc;
     if ((rc = ensure_table(c, c->d_fine_rs, c->fine_rs_cap, row_start_size(nf[1], nf[2]), nullptr))) return rc;
-    if ((rc = ensure_table(c, c->d_fine_rst, c->fine_rst_cap, row_start_t_size(nf[1], nf[2]), nullptr))) return rc;
+    if ((rc = ensure_table(c, c->d_fine_ovf, c->fine_ovf_cap, (c->fine_pts_cap / 16 + 64) * 8, nullptr))) return rc;
+    if (!c->d_fine_ovf_count) HIPCHK(c, hipMalloc(&c->d_fine_ovf_count, sizeof(uint32_t)));
   }
-  const IndexTables Tf{c->d_fine_cs, c->d_fine_rs, c->d_fine_rt, c->d_fine_rst};
-  HIPCHK(c, map_build_grid(c->stream, c->d_fine_tmp, m, c->d_fine_pts, Tf, of[0], of[1], of[2], inv_f, nf[0], nf[1], nf[2], 1, c->scratch, true));
+  const IndexTables Tf{c->d_fine_segs, c->d_fine_ovf, c->d_fine_ovf_count, (uint32_t)(c->fine_ovf_cap / 8), c->d_fine_rs};
+  HIPCHK(c, map_build_grid(c->stream, c->d_fine_tmp, m, c->d_fine_pts, Tf, of[0], of[1], of[2], inv_f, nf[0], nf[1], nf[2], 1, c->scratch));
   if (prof) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     fprintf(stderr, "[flimo fine] crowded cells + count %.1f us, copy + sort + tables of %d x %d x %d cells %.1f us (%u points)\n",
             (tp1 - tp0) * 1e6, nf[0], nf[1], nf[2], (now() - tp1) * 1e6, m);
   }
   GridView& f = c->fine;
-  f.pts = c->d_fine_pts; f.cell_start = c->d_fine_cs; f.row_table = c->d_fine_rt; f.row_start = c->d_fine_rs; f.row_start_t = c->d_fine_rst;
+  f.pts = c->d_fine_pts; f.segs = c->d_fine_segs; f.ovf = c->d_fine_ovf; f.row_start = c->d_fine_rs;
   f.ox = of[0]; f.oy = of[1]; f.oz = of[2];
   f.inv_cell = inv_f; f.cell = cf;
   f.nx = nf[0]; f.ny = nf[1]; f.nz = nf[2];
-  f.n_pts = m; f.xs = 1; f.nxf = nf[0]; f.nxs = nf[0] + 1;
+  f.n_pts = m; f.xs = 1; f.nxf = nf[0]; f.nxs = nf[0] + 1; f.nseg = (int)grid_nseg(nf[0]);
   // a query may be settled here when its fine 3x3x3 block lies inside [lo, hi): fine cell 1 starts at lo, so the query's own cell
   // is >= 2; on the upper side one more cell of safety against the rounding of (hi - of) * inv_f
   for (int a = 0; a < 3; a++) {
@@ -705,13 +704,12 @@ static int rebuild_grid(flimo_ctx* c) {
     c->grid_valid = false;
     if (!c->d_map_sorted2) HIPCHK(c, hipMalloc(&c->d_map_sorted2, c->map_cap * sizeof(float4)));
     const GridView& g = c->grid;
-    const IndexTables T{c->d_cell_start, c->d_row_start, c->d_row_table, c->d_row_start_t};
+    const IndexTables T{c->d_segs, c->d_ovf, c->d_ovf_count, (uint32_t)(c->ovf_cap / 8), c->d_row_start};
     HIPCHK(c, map_merge_grid(c->stream, c->d_map_sorted, n_old, c->d_map_raw + n_old, k, c->d_map_sorted2, T,
                              g.ox, g.oy, g.oz, g.inv_cell, g.nx, g.ny, g.nz, g.xs, c->scratch));
     // (no wait here: everything that reads the index is queued behind this on the same stream; map_add_device ends synchronised)
     std::swap(c->d_map_sorted, c->d_map_sorted2);
     c->grid.pts = c->d_map_sorted;
-    c->grid.row_table = c->d_row_table;
     c->grid.n_pts = (uint32_t)c->map_n;
     c->grid_valid = true;
     c->grid_merges++;
@@ -737,8 +735,8 @@ static int rebuild_grid(flimo_ctx* c) {
     nz = (int)floorf((box[5] - oz) * inv) + 2;
     // both indices stay 32-bit addressable; the fine x columns are given up first (xs = preferred .. 1), then the cell grows
     for (xs = c->xslabs; xs >= 1; xs >>= 1) {
-      const double ncols = (double)cell_table_size(nx * xs, ny, nz);
-      if (ncols < 1.9e9 && (double)row_table_size(nx * xs, ny, nz) < 4.0e9) return true;
+      const double ncols = (double)ny * (double)nz * ((double)nx * xs + 1.0);              // (32-bit column keys)
+      if (ncols < 1.9e9 && (double)segs_size(nx * xs, ny, nz) < 4.0e9) return true;
     }
     xs = 1;
     return false;
@@ -765,24 +763,24 @@ static int rebuild_grid(flimo_ctx* c) {
   if (!c->d_map_sorted) HIPCHK(c, hipMalloc(&c->d_map_sorted, c->map_cap * sizeof(float4)));   // mirrors the raw capacity (freed whenever that grows)
   {
     int rc;
-    if ((rc = ensure_table(c, c->d_cell_start, c->cell_cap, cell_table_size(nx * xs, ny, nz), nullptr))) return rc;
-    if ((rc = ensure_table(c, c->d_row_table, c->row_cap, row_table_size(nx * xs, ny, nz), nullptr))) return rc;
+    if ((rc = ensure_table(c, c->d_segs, c->segs_cap, segs_size(nx * xs, ny, nz), nullptr))) return rc;
     if ((rc = ensure_table(c, c->d_row_start, c->rowstart_cap, row_start_size(ny, nz), nullptr))) return rc;
-    if ((rc = ensure_table(c, c->d_row_start_t, c->rowstart_t_cap, row_start_t_size(ny, nz), nullptr))) return rc;
+    // (one escape slot per 16 points the point buffer can hold: a segment escapes when a column holds more than 15)
+    if ((rc = ensure_table(c, c->d_ovf, c->ovf_cap, (c->map_cap / 16 + 64) * 8, nullptr))) return rc;
+    if (!c->d_ovf_count) HIPCHK(c, hipMalloc(&c->d_ovf_count, sizeof(uint32_t)));
   }
-  const IndexTables T{c->d_cell_start, c->d_row_start, c->d_row_table, c->d_row_start_t};
-  HIPCHK(c, map_build_grid(c->stream, c->d_map_raw, c->map_n, c->d_map_sorted, T, ox, oy, oz, inv, nx, ny, nz, xs, c->scratch, true));
+  const IndexTables T{c->d_segs, c->d_ovf, c->d_ovf_count, (uint32_t)(c->ovf_cap / 8), c->d_row_start};
+  HIPCHK(c, map_build_grid(c->stream, c->d_map_raw, c->map_n, c->d_map_sorted, T, ox, oy, oz, inv, nx, ny, nz, xs, c->scratch));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->grid.pts = c->d_map_sorted;
-  c->grid.cell_start = c->d_cell_start;
-  c->grid.row_table = c->d_row_table;
+  c->grid.segs = c->d_segs;
+  c->grid.ovf = c->d_ovf;
   c->grid.row_start = c->d_row_start;
-  c->grid.row_start_t = c->d_row_start_t;
   c->grid.ox = ox; c->grid.oy = oy; c->grid.oz = oz;
   c->grid.inv_cell = inv;
   c->grid.cell = cell;
   c->grid.nx = nx; c->grid.ny = ny; c->grid.nz = nz;
-  c->grid.xs = xs; c->grid.nxf = nx * xs; c->grid.nxs = nx * xs + 1;
+  c->grid.xs = xs; c->grid.nxf = nx * xs; c->grid.nxs = nx * xs + 1; c->grid.nseg = (int)grid_nseg(nx * xs);
   c->grid.n_pts = (uint32_t)c->map_n;
   c->grid_valid = true;
   c->force_full = false;
@@ -799,34 +797,38 @@ extern "C" int flimo_map_grid_selfcheck(flimo_ctx* c, uint64_t* mismatches, uint
   if (!c->grid_valid) return FLIMO_OK;
   ctx_enter(c);
   const GridView& g = c->grid;
-  const size_t n = c->map_n, ncs = cell_table_size(g.nxf, g.ny, g.nz), rt = row_table_size(g.nxf, g.ny, g.nz),
-               nrs = row_start_size(g.ny, g.nz), nrst = row_start_t_size(g.ny, g.nz);
+  const size_t n = c->map_n;
   if (g.n_pts != n) { *mismatches = 1; return FLIMO_OK; }
   struct Tmp {
-    float4* pts = nullptr; uint32_t* cs = nullptr; uint32_t* row = nullptr; uint32_t* rs = nullptr; uint32_t* rst = nullptr;
-    ~Tmp() { (void)hipFree(pts); (void)hipFree(cs); (void)hipFree(row); (void)hipFree(rs); (void)hipFree(rst); }
+    float4* pts = nullptr; uint2* segs = nullptr; uint32_t* ovf = nullptr; uint32_t* cnt = nullptr; uint32_t* rs = nullptr; unsigned long long* diff = nullptr;
+    ~Tmp() { (void)hipFree(pts); (void)hipFree(segs); (void)hipFree(ovf); (void)hipFree(cnt); (void)hipFree(rs); (void)hipFree(diff); }
   } t;
+  const size_t ovf_slots = n / 16 + 64;
   HIPCHK(c, hipMalloc(&t.pts, n * sizeof(float4)));
-  HIPCHK(c, hipMalloc(&t.cs, ncs * sizeof(uint32_t)));
-  HIPCHK(c, hipMalloc(&t.row, rt * sizeof(uint32_t)));
-  HIPCHK(c, hipMalloc(&t.rs, nrs * sizeof(uint32_t)));
-  HIPCHK(c, hipMalloc(&t.rst, nrst * sizeof(uint32_t)));
-  const IndexTables Tt{t.cs, t.rs, t.row, t.rst};
-  HIPCHK(c, map_build_grid(c->stream, c->d_map_raw, n, t.pts, Tt, g.ox, g.oy, g.oz, g.inv_cell, g.nx, g.ny, g.nz, g.xs, c->scratch, true));
-  auto differ = [&](const void* a, const void* b, size_t bytes, uint64_t& out) -> int {
+  HIPCHK(c, hipMalloc(&t.segs, segs_size(g.nxf, g.ny, g.nz) * sizeof(uint2)));
+  HIPCHK(c, hipMalloc(&t.ovf, ovf_slots * 8 * sizeof(uint32_t)));
+  HIPCHK(c, hipMalloc(&t.cnt, sizeof(uint32_t)));
+  HIPCHK(c, hipMalloc(&t.rs, row_start_size(g.ny, g.nz) * sizeof(uint32_t)));
+  HIPCHK(c, hipMalloc(&t.diff, sizeof(unsigned long long)));
+  HIPCHK(c, hipMemsetAsync(t.diff, 0, sizeof(unsigned long long), c->stream));
+  const IndexTables Tt{t.segs, t.ovf, t.cnt, (uint32_t)ovf_slots, t.rs};
+  HIPCHK(c, map_build_grid(c->stream, c->d_map_raw, n, t.pts, Tt, g.ox, g.oy, g.oz, g.inv_cell, g.nx, g.ny, g.nz, g.xs, c->scratch));
+  // the points bit for bit; the index by meaning (every row's start, every column's count: escapes take their slots in arrival order)
+  {
+    const size_t bytes = n * sizeof(float4);
     std::vector<unsigned char> ha(bytes), hb(bytes);
-    HIPCHK(c, hipMemcpyAsync(ha.data(), a, bytes, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(hb.data(), b, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(ha.data(), t.pts, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(hb.data(), g.pts, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (size_t i = 0; i + 4 <= bytes; i += 4) out += memcmp(&ha[i], &hb[i], 4) != 0;
-    return FLIMO_OK;
-  };
-  int rc;
-  if ((rc = differ(t.pts, g.pts, n * sizeof(float4), *mismatches))) return rc;
-  if ((rc = differ(t.cs, g.cell_start, ncs * sizeof(uint32_t), *mismatches))) return rc;
-  if ((rc = differ(t.row, g.row_table, rt * sizeof(uint32_t), *mismatches))) return rc;
-  if ((rc = differ(t.rs, g.row_start, nrs * sizeof(uint32_t), *mismatches))) return rc;
-  if ((rc = differ(t.rst, g.row_start_t, nrst * sizeof(uint32_t), *mismatches))) return rc;
+    for (size_t i = 0; i + 4 <= bytes; i += 4) *mismatches += memcmp(&ha[i], &hb[i], 4) != 0;
+  }
+  GridView ref = g;
+  ref.pts = t.pts; ref.segs = t.segs; ref.ovf = t.ovf; ref.row_start = t.rs;
+  HIPCHK(c, index_compare(c->stream, ref, g, t.diff));
+  unsigned long long d = 0;
+  HIPCHK(c, hipMemcpyAsync(&d, t.diff, sizeof(d), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *mismatches += d;
   return FLIMO_OK;
 }
 
@@ -1454,11 +1456,12 @@ extern "C" int flimo_fine_stats(const flimo_ctx* c, unsigned long long out[4]) {
 extern "C" int flimo_map_index_bytes(const flimo_ctx* c, uint64_t out[3]) {
   if (!c || !out) return FLIMO_ERR_INVALID;
   out[0] = (uint64_t)c->map_n * sizeof(float4);
-  auto tables = [](const GridView& g) {
-    return (uint64_t)(cell_table_size(g.nxf, g.ny, g.nz) + row_table_size(g.nxf, g.ny, g.nz) + row_start_size(g.ny, g.nz) + row_start_t_size(g.ny, g.nz)) * 4ull;
+  // (segment table + rows' starts + the escape pool as allocated)
+  auto tables = [](const GridView& g, size_t ovf_words) {
+    return (uint64_t)segs_size(g.nxf, g.ny, g.nz) * 8ull + (uint64_t)(row_start_size(g.ny, g.nz) + ovf_words) * 4ull;
   };
-  out[1] = c->grid_valid ? tables(c->grid) : 0ull;
-  out[2] = c->fine_valid ? (uint64_t)c->fine.n_pts * sizeof(float4) + tables(c->fine) : 0ull;
+  out[1] = c->grid_valid ? tables(c->grid, c->ovf_cap) : 0ull;
+  out[2] = c->fine_valid ? (uint64_t)c->fine.n_pts * sizeof(float4) + tables(c->fine, c->fine_ovf_cap) : 0ull;
   return FLIMO_OK;
 }
 extern "C" int flimo_tie_stats(flimo_ctx* c, unsigned long long out[2]) {

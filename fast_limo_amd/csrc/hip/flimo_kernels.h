@@ -141,20 +141,20 @@ hipError_t sort_scan(hipStream_t st, const float4* in, size_t n, float4* out, Ma
                      const double* t_in = nullptr, double* t_out = nullptr);
 // the same layout without re-ordering (out[i] = (xyz, w = i)): for a sweep a voxel filter re-orders anyway
 hipError_t index_scan(hipStream_t st, const float4* in, size_t n, float4* out, const double* t_in, double* t_out);
-// The four index tables of a grid (GridView, flimo_types.h): cell_start[cell_table_size], row_start[row_start_size],
-// row_table[row_table_size], row_start_t[row_start_t_size] (nxf = nx * xs columns per row).
-struct IndexTables { uint32_t* cell_start; uint32_t* row_start; uint32_t* row_table; uint32_t* row_start_t; };
-size_t cell_table_size(int nxf, int ny, int nz);
+// The index of a grid (GridView, flimo_types.h): segs[segs_size], row_start[row_start_size], and the pool of escapes
+// (ovf[ovf_cap][8], *ovf_count slots taken: one slot per 16 points of the point buffer's capacity is always enough).
+struct IndexTables { uint2* segs; uint32_t* ovf; uint32_t* ovf_count; uint32_t ovf_cap; uint32_t* row_start; };
+size_t segs_size(int nxf, int ny, int nz);
 size_t row_start_size(int ny, int nz);
-size_t row_start_t_size(int ny, int nz);
-// Sorts `pts_in` by (z, y, fine x column) into `pts_out` and fills the four tables.  zero_pads: the y-fastest tables are new or
-// their shape changed (their pads have to be cleared).
+// Sorts `pts_in` by (z, y, fine x column) into `pts_out` and fills the index.
 hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4* pts_out, const IndexTables& T,
                           float ox, float oy, float oz, float inv_cell, int nx, int ny, int nz, int xs,
-                          MapBuildScratch& S, bool zero_pads = true);
+                          MapBuildScratch& S);
+// debug: *diff_dev += the number of (row, column) pairs at which two indices of the same geometry differ
+hipError_t index_compare(hipStream_t st, const GridView& A, const GridView& B, unsigned long long* diff_dev);
 // Merges the k points appended since the last build into the cell-sorted array (same geometry): out_sorted and the tables
-// become what map_build_grid gives for all n_old + k points.  The tables are updated in place -- the rows' starts, and the
-// relative entries of the rows that received points: O(rows + touched rows x row length), not O(cells); out_sorted != old_sorted.
+// become what map_build_grid gives for all n_old + k points.  The index is updated in place -- the rows' starts, and the
+// entries of the rows that received points: O(rows + touched rows x row length), not O(cells); out_sorted != old_sorted.
 hipError_t map_merge_grid(hipStream_t st, const float4* old_sorted, size_t n_old, const float4* new_pts, size_t k,
                           float4* out_sorted, const IndexTables& T, float ox, float oy, float oz,
                           float inv_cell, int nx, int ny, int nz, int xs, MapBuildScratch& S);
@@ -176,18 +176,14 @@ hipError_t time_order_raw(hipStream_t st, const float4* pts, const double* t, si
 // Second level over crowded regions: box (cell coordinates, inclusive) around the cells holding more than `threshold` points
 // (box_host[6] = their number; box_dev: 7 ints of device scratch), and the copy of the map points inside a box of metres
 // (w = position in the main sorted map).
-hipError_t crowded_list_all(hipStream_t st, const uint32_t* cell_start, int nx, int ny, int nz, int xs, uint32_t threshold, uint32_t* bits,
+hipError_t crowded_list_all(hipStream_t st, const GridView& G, uint32_t threshold, uint32_t* bits,
                             int4* list, uint32_t cap, uint32_t* count_dev, uint32_t* count_host, MapBuildScratch& S);
-hipError_t crowded_list_points(hipStream_t st, const float4* pts, size_t k, const uint32_t* cell_start, float ox, float oy, float oz,
-                               float inv_cell, int nx, int ny, int nz, int xs, uint32_t threshold, uint32_t* bits, int4* list, uint32_t cap,
-                               uint32_t* count_dev, uint32_t* count_host, MapBuildScratch& S);
-hipError_t map_box_count(hipStream_t st, const uint32_t* cell_start, int nx, int ny, int nz, int xs, const int c0[3], const int c1[3],
+hipError_t crowded_list_points(hipStream_t st, const float4* pts, size_t k, const GridView& G, uint32_t threshold, uint32_t* bits, int4* list,
+                               uint32_t cap, uint32_t* count_dev, uint32_t* count_host, MapBuildScratch& S);
+hipError_t map_box_count(hipStream_t st, const GridView& G, const int c0[3], const int c1[3],
                          uint32_t* count_dev, uint32_t* count_host, MapBuildScratch& S);
-hipError_t map_box_copy(hipStream_t st, const float4* pts, const uint32_t* cell_start, const uint32_t* row_start, int nx, int ny, int nz, int xs,
-                        const int c0[3], const int c1[3], float4* out, MapBuildScratch& S);
+hipError_t map_box_copy(hipStream_t st, const GridView& G, const int c0[3], const int c1[3], float4* out, MapBuildScratch& S);
 hipError_t atan2f_probe(hipStream_t st, const float* yx_host, int n, float* out_host);   // the device's atan2f on n (y, x) pairs
-size_t row_table_size(int nx, int ny, int nz);
-hipError_t map_build_row_table(hipStream_t st, const uint32_t* cell_start, int nx, int ny, int nz, uint32_t* out, bool zero_pads = true);
 // pcl::VoxelGrid on device points: out gets one centroid per occupied voxel in ascending voxel index
 hipError_t voxel_grid(hipStream_t st, const float4* in, size_t n, float leaf, float4* out, size_t* n_out, bool* passthrough,
                       MapBuildScratch& S);

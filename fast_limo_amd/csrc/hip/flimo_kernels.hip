@@ -117,14 +117,11 @@ FLIMO_DEV void visit_row(const GridView& G, int cx, int cy, int cz, int dy, int 
   const float a = fmaxf(slab_dist(dy, ry) - margin, 0.f), b = fmaxf(slab_dist(dz, rz) - margin, 0.f);
   const float yz2 = a * a + b * b;
   if (yz2 * cell2 >= fminf(bound, R.bd[K - 1])) return;   // the whole row is farther than the current 5th best
-  // (the tables hold positions relative to their row's start: GridView)
-  const size_t rowi = (size_t)(cz + dz) * (size_t)G.ny + (size_t)(cy + dy);
-  const size_t rowbase = rowi * (size_t)G.nxs;
-  const uint32_t rs = G.row_start[rowi];
   if (max(abs(dy), abs(dz)) > r_prev) {
     const int x0 = max(cx - r, 0), x1 = min(cx + r, G.nx - 1);
     if (x0 <= x1) {
-      const uint32_t lo = rs + G.cell_start[rowbase + (size_t)x0 * G.xs], hi = rs + G.cell_start[rowbase + (size_t)(x1 + 1) * G.xs];
+      uint32_t lo, hi;
+      grid_row_range(G, cy + dy, cz + dz, x0 * G.xs, (x1 + 1) * G.xs, lo, hi);
       scan_range<L, K>(G.pts, lo, hi, sub, gx, gy, gz, R.bd, R.bi, R.cand);
     }
   } else {
@@ -133,7 +130,8 @@ FLIMO_DEV void visit_row(const GridView& G, int cx, int cy, int cz, int dy, int 
       const int x0 = max(cx - r, 0), x1 = min(cx - r_prev - 1, G.nx - 1);
       const float sx = fmaxf(slab_dist(-(r_prev + 1), rx) - margin, 0.f);
       if (x0 <= x1 && (sx * sx + yz2) * cell2 < fminf(bound, R.bd[K - 1])) {
-        const uint32_t lo = rs + G.cell_start[rowbase + (size_t)x0 * G.xs], hi = rs + G.cell_start[rowbase + (size_t)(x1 + 1) * G.xs];
+        uint32_t lo, hi;
+        grid_row_range(G, cy + dy, cz + dz, x0 * G.xs, (x1 + 1) * G.xs, lo, hi);
         scan_range<L, K>(G.pts, lo, hi, sub, gx, gy, gz, R.bd, R.bi, R.cand);
       }
     }
@@ -141,7 +139,8 @@ FLIMO_DEV void visit_row(const GridView& G, int cx, int cy, int cz, int dy, int 
       const int x0 = max(cx + r_prev + 1, 0), x1 = min(cx + r, G.nx - 1);
       const float sx = fmaxf(slab_dist(r_prev + 1, rx) - margin, 0.f);
       if (x0 <= x1 && (sx * sx + yz2) * cell2 < fminf(bound, R.bd[K - 1])) {
-        const uint32_t lo = rs + G.cell_start[rowbase + (size_t)x0 * G.xs], hi = rs + G.cell_start[rowbase + (size_t)(x1 + 1) * G.xs];
+        uint32_t lo, hi;
+        grid_row_range(G, cy + dy, cz + dz, x0 * G.xs, (x1 + 1) * G.xs, lo, hi);
         scan_range<L, K>(G.pts, lo, hi, sub, gx, gy, gz, R.bd, R.bi, R.cand);
       }
     }
@@ -199,11 +198,8 @@ FLIMO_DEV void knn_search(const GridView& G, float gx, float gy, float gz, int s
         const int dz = (t / 3 == 0) ? 0 : ((t / 3 == 1) ? -1 : 1);
         const int yy = cy + dy, zz = cz + dz;
         const bool in = (yy >= 0) && (yy < G.ny) && (zz >= 0) && (zz < G.nz) && (x0 <= x1);
-        const size_t rowi = (size_t)(in ? zz : 0) * (size_t)G.ny + (size_t)(in ? yy : 0);
-        const size_t rowbase = rowi * (size_t)G.nxs;
-        const uint32_t rs = in ? G.row_start[rowi] : 0u;
-        lo[t] = in ? rs + G.cell_start[rowbase + (size_t)x0 * G.xs] : 0u;
-        hi[t] = in ? rs + G.cell_start[rowbase + (size_t)(x1 + 1) * G.xs] : 0u;
+        lo[t] = 0u; hi[t] = 0u;
+        if (in) grid_row_range(G, yy, zz, x0 * G.xs, (x1 + 1) * G.xs, lo[t], hi[t]);
       }
 #pragma unroll
       for (int t = 0; t < 9; t++) {
@@ -328,6 +324,7 @@ struct NbrRec {      // 32 bytes per query (sorted order)
 // (fp64 denormals are always preserved on gfx9, min/max return an operand unchanged).  Insertion into the sorted list is
 // a 9-instruction min/max ladder, no compares, no payload selects.
 struct U3 { uint32_t a, b, c; };
+struct __attribute__((aligned(8))) Seg2 { uint32_t x0, y0, x1, y1; };   // two neighbouring entries of a row of GridView::segs (one 16-byte load)
 __device__ __forceinline__ double key_min(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ double key_max(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ double key_make(float d, uint32_t id) { return __hiloint2double((int)__float_as_uint(d), (int)id); }
@@ -572,11 +569,7 @@ __device__ __forceinline__ void knn5_tail(const GridView& G, int max_ring, NbrRe
                 const int dl = (int)fminf(floorf(fminf(xr + (1.f - rx), 1.0e6f)), (float)r);
                 const int x0 = max(cx - dl, 0), x1 = min(cx + dr, G.nx - 1);
                 if (x0 <= x1) {
-                  const size_t rowi = (size_t)zz * (size_t)G.ny + (size_t)yy;
-                  const size_t rowbase = rowi * (size_t)G.nxs;
-                  const uint32_t rs = G.row_start[rowi];      // (the tables hold positions relative to their row's start)
-                  lo4[u] = rs + G.cell_start[rowbase + (size_t)x0 * G.xs];
-                  hi4[u] = rs + G.cell_start[rowbase + (size_t)(x1 + 1) * G.xs];
+                  grid_row_range(G, yy, zz, x0 * G.xs, (x1 + 1) * G.xs, lo4[u], hi4[u]);
                 }
               }
             }
@@ -1007,13 +1000,14 @@ __device__ __forceinline__ void knn5_pass(const GridView& G, const float4* __res
     } else if (r0 > 1) {
       flag = 2;                       // outside the grid but within reach: general search
     } else {
-      // ---- range bounds of the 9 rows: six 12-byte loads from the y-fastest, padded row table -- two x planes (first column of
-      //      the rows' x range, one past its last) x three z, each load covering the three y neighbours.  The table is kept at
+      // ---- range bounds of the 9 rows: nine 16-byte loads from the segment table (GridView) -- the two neighbouring entries that
+      //      hold the rows' x range -- and three 12-byte loads of the rows' starts, all in one round trip.  The table is kept at
       //      FINE column resolution along x (G.xs columns per cell): without a bound the range is the three cells (columns
       //      (cx-1) xs .. (cx+2) xs), with the bound of the previous pass only the columns its ball can reach --
       //      |x_point - x_query| <= sqrt(b2) in cell units, widened by the rounding margin -- clipped to the three cells (the
       //      exactness proof below is about the 3x3x3 block).  The same columns for all nine rows; rows the ball cannot reach
-      //      at all are dropped as before. ----
+      //      at all are dropped as before.  At most 3 xs <= 8 columns: the range's two ends lie in the entry of its first column
+      //      or in the next one. ----
       // (32-bit table indices: the host keeps the table below 2^32 entries)
       const float rx = fminf(fmaxf(fx - flx, 0.f), 1.f), ry = fminf(fmaxf(fy - fly, 0.f), 1.f),
                   rz = fminf(fmaxf(fz - flz, 0.f), 1.f);
@@ -1028,28 +1022,50 @@ __device__ __forceinline__ void knn5_pass(const GridView& G, const float4* __res
       }
       c0 = min(max(c0, 0), G.nxf);
       c1 = min(max(c1, c0), G.nxf);
-      const uint32_t py = (uint32_t)G.ny + 4u, plane = py * ((uint32_t)G.nz + 4u);
-      const uint32_t yz = (uint32_t)(cz + 1) * py + (uint32_t)(cy + 1);
+      const uint32_t py = (uint32_t)G.ny + 2u * GRID_PAD;
+      const uint32_t yz = (uint32_t)(cz + GRID_PAD - 1) * py + (uint32_t)(cy + GRID_PAD - 1);      // padded row (cy - 1, cz - 1)
+      const uint32_t sg0 = (uint32_t)c0 >> 3;                   // entry of the range's first column
       // First pass of a scan (no bound from a previous pass): a query whose OWN cell is crowded (raw sweeps inserted into the
       // map leave cells with tens to hundreds of points) first walks that cell alone; its 5th distance there is an upper bound
       // of the true one, and the other 26 cells are then walked only as far as that ball reaches (rows and end cells it cannot
       // reach are dropped, exactly as with the bound of a previous pass).
       const bool probe_on = L == 2 && !prev_valid && prev_probe_min != 0u;          // wave-uniform
-      // (the table holds positions relative to their row's start; the nine rows' starts are three more 12-byte loads from the
-      //  padded copy of the row starts, in the same round trip -- pads: 0 + 0, an empty range)
+      // (the entries count from their row's start; the nine rows' starts are three 12-byte loads in the same round trip --
+      //  pad rows: 0 + 0, an empty range)
       U3 rbl[3], rbh[3], rsb[3];
+      Seg2 own_e;                       // the centre row's two entries: the probe's own cell / column is read off them
       {
-        const uint32_t iL = (uint32_t)c0 * plane + yz, iH = (uint32_t)c1 * plane + yz;
+        Seg2 e[9];
 #pragma unroll
         for (int dz = 0; dz < 3; dz++) {
-          rbl[dz] = *reinterpret_cast<const U3*>(G.row_table + (iL + (uint32_t)dz * py));
-          rbh[dz] = *reinterpret_cast<const U3*>(G.row_table + (iH + (uint32_t)dz * py));
-          rsb[dz] = *reinterpret_cast<const U3*>(G.row_start_t + (yz + (uint32_t)dz * py));
+#pragma unroll
+          for (int k = 0; k < 3; k++)
+            e[3 * dz + k] = *reinterpret_cast<const Seg2*>(G.segs + ((size_t)(yz + (uint32_t)dz * py + (uint32_t)k) * (size_t)G.nseg + sg0));
+          rsb[dz] = *reinterpret_cast<const U3*>(G.row_start + (yz + (uint32_t)dz * py));
+        }
+        own_e = e[4];
+        const uint32_t k0 = (uint32_t)c0 & 7u, k1 = (uint32_t)c1 & 7u;
+        const bool next = ((uint32_t)c1 >> 3) != sg0;           // the range's end lies in the second entry
+        // (one test for all eighteen counts: escapes are segments of crowded cells)
+        uint32_t lo9[9], hi9[9], esc = 0u;
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+          const uint32_t hx = next ? e[t].x1 : e[t].x0, hy = next ? e[t].y1 : e[t].y0;
+          esc |= e[t].x0 | hx;
+          lo9[t] = seg_count_plain(e[t].x0, e[t].y0, k0);
+          hi9[t] = seg_count_plain(hx, hy, k1);
+        }
+        if (__builtin_expect((int)esc < 0, 0)) {
+#pragma unroll
+          for (int t = 0; t < 9; t++) {
+            lo9[t] = seg_count(e[t].x0, e[t].y0, k0, G.ovf);
+            hi9[t] = seg_count(next ? e[t].x1 : e[t].x0, next ? e[t].y1 : e[t].y0, k1, G.ovf);
+          }
         }
 #pragma unroll
         for (int dz = 0; dz < 3; dz++) {
-          rbl[dz].a += rsb[dz].a; rbl[dz].b += rsb[dz].b; rbl[dz].c += rsb[dz].c;
-          rbh[dz].a += rsb[dz].a; rbh[dz].b += rsb[dz].b; rbh[dz].c += rsb[dz].c;
+          rbl[dz].a = lo9[3 * dz] + rsb[dz].a; rbl[dz].b = lo9[3 * dz + 1] + rsb[dz].b; rbl[dz].c = lo9[3 * dz + 2] + rsb[dz].c;
+          rbh[dz].a = hi9[3 * dz] + rsb[dz].a; rbh[dz].b = hi9[3 * dz + 1] + rsb[dz].b; rbh[dz].c = hi9[3 * dz + 2] + rsb[dz].c;
         }
       }
       // conservative distances (cell units) to the neighbouring rows; without a bound every row is in
@@ -1073,20 +1089,23 @@ __device__ __forceinline__ void knn5_pass(const GridView& G, const float4* __res
       // full walk) and the own cell can give a bound at all.  Only those queries fetch the two inner x planes of the row table:
       // they hold the own cell's range and let the second walk be clipped to cells.
       const bool heavy_block = probe_on && off[9] >= prev_probe_min && cx >= 0 && cx < G.nx;
-      const uint32_t centre = yz + py + 1u;                         // (z, y) = the query's own row within a padded x plane
-      uint32_t own_a = rbl[1].b, own_b = rbh[1].b;                  // the own cell's range (two 4-byte loads, heavy blocks only)
+      // position of column `col` (within the loaded range's two entries) in the centre row
+      auto centre_pos = [&](int col) -> uint32_t {
+        const bool nx_ = ((uint32_t)col >> 3) != sg0;
+        return rsb[1].b + seg_count(nx_ ? own_e.x1 : own_e.x0, nx_ ? own_e.y1 : own_e.y0, (uint32_t)col & 7u, G.ovf);
+      };
+      uint32_t own_a = rbl[1].b, own_b = rbh[1].b;                  // the own cell's range (heavy blocks only; no load: the entries are here)
       if (heavy_block) {
-        own_a = rsb[1].b + G.row_table[(uint32_t)(cx * G.xs) * plane + centre];
-        own_b = rsb[1].b + G.row_table[(uint32_t)((cx + 1) * G.xs) * plane + centre];
+        own_a = centre_pos(cx * G.xs);
+        own_b = centre_pos((cx + 1) * G.xs);
       }
-      // The probe walks the query's own COLUMN (the tables' x resolution: half a cell by default) when that alone can give a bound,
-      // its own cell otherwise: in a crowded cell the column holds a fraction of the points and its 5th distance is as good.  The
-      // column's two bounds in the centre row are at most two more 4-byte loads (one of them is a cell boundary already here).
+      // The probe walks the query's own COLUMN (the table's x resolution: half a cell by default) when that alone can give a bound,
+      // its own cell otherwise: in a crowded cell the column holds a fraction of the points and its 5th distance is as good.
       uint32_t lo_own = own_a, hi_own = own_b;
       if (heavy_block && G.xs > 1 && hi_own - lo_own >= 2u * PROBE_MIN_OWN) {
         const int col = min(max((int)floorf(fx * (float)G.xs), cx * G.xs), (cx + 1) * G.xs - 1);
-        const uint32_t ca = (col == cx * G.xs) ? lo_own : rsb[1].b + G.row_table[(uint32_t)col * plane + centre];
-        const uint32_t cb = (col + 1 == (cx + 1) * G.xs) ? hi_own : rsb[1].b + G.row_table[(uint32_t)(col + 1) * plane + centre];
+        const uint32_t ca = (col == cx * G.xs) ? lo_own : centre_pos(col);
+        const uint32_t cb = (col + 1 == (cx + 1) * G.xs) ? hi_own : centre_pos(col + 1);
         if (cb - ca >= PROBE_MIN_OWN) { lo_own = ca; hi_own = cb; }
       }
       const uint32_t n_own = hi_own - lo_own;
@@ -1148,18 +1167,26 @@ __device__ __forceinline__ void knn5_pass(const GridView& G, const float4* __res
             }
             h0 = min(max(h0, 0), G.nxf);
             h1 = min(max(h1, h0), G.nxf);
+            // (h0 .. h1 lie inside the first walk's columns: the same two entries per row, read again -- they are not kept in
+            //  registers across the first walk)
             U3 hl[3], hh[3];
             {
-              const uint32_t iL = (uint32_t)h0 * plane + yz, iH = (uint32_t)h1 * plane + yz;
+              const uint32_t k0 = (uint32_t)h0 & 7u, k1 = (uint32_t)h1 & 7u;
+              const bool n0 = ((uint32_t)h0 >> 3) != sg0, n1 = ((uint32_t)h1 >> 3) != sg0;
+              Seg2 e[9];
 #pragma unroll
-              for (int dz = 0; dz < 3; dz++) {
-                hl[dz] = *reinterpret_cast<const U3*>(G.row_table + (iL + (uint32_t)dz * py));
-                hh[dz] = *reinterpret_cast<const U3*>(G.row_table + (iH + (uint32_t)dz * py));
+              for (int t = 0; t < 9; t++)
+                e[t] = *reinterpret_cast<const Seg2*>(G.segs + ((size_t)(yz + (uint32_t)(t / 3) * py + (uint32_t)(t % 3)) * (size_t)G.nseg + sg0));
+              uint32_t lo9[9], hi9[9];
+#pragma unroll
+              for (int t = 0; t < 9; t++) {
+                lo9[t] = seg_count(n0 ? e[t].x1 : e[t].x0, n0 ? e[t].y1 : e[t].y0, k0, G.ovf);
+                hi9[t] = seg_count(n1 ? e[t].x1 : e[t].x0, n1 ? e[t].y1 : e[t].y0, k1, G.ovf);
               }
 #pragma unroll
               for (int dz = 0; dz < 3; dz++) {
-                hl[dz].a += rsb[dz].a; hl[dz].b += rsb[dz].b; hl[dz].c += rsb[dz].c;
-                hh[dz].a += rsb[dz].a; hh[dz].b += rsb[dz].b; hh[dz].c += rsb[dz].c;
+                hl[dz].a = lo9[3 * dz] + rsb[dz].a; hl[dz].b = lo9[3 * dz + 1] + rsb[dz].b; hl[dz].c = lo9[3 * dz + 2] + rsb[dz].c;
+                hh[dz].a = hi9[3 * dz] + rsb[dz].a; hh[dz].b = hi9[3 * dz + 1] + rsb[dz].b; hh[dz].c = hi9[3 * dz + 2] + rsb[dz].c;
               }
             }
 #pragma unroll
@@ -1474,11 +1501,9 @@ __device__ __forceinline__ void widen_body(const GridView& G, int max_ring, NbrR
           x0 = max(cx - dl, 0); x1 = min(cx + dr, G.nx - 1);
         }
         if (dyz2 <= bnd2 && yy >= 0 && yy < G.ny && zz >= 0 && zz < G.nz && x0 <= x1) {
-          const size_t rowi = (size_t)zz * (size_t)G.ny + (size_t)yy;
-          const size_t rowbase = rowi * (size_t)G.nxs;
-          const uint32_t rl = G.cell_start[rowbase + (size_t)x0 * G.xs];
-          lo = G.row_start[rowi] + rl;                          // (relative to the row's start)
-          len = G.cell_start[rowbase + (size_t)(x1 + 1) * G.xs] - rl;
+          uint32_t hi_;
+          grid_row_range(G, yy, zz, x0 * G.xs, (x1 + 1) * G.xs, lo, hi_);
+          len = hi_ - lo;
         }
       }
       // inclusive prefix sum over the wave
@@ -2098,10 +2123,8 @@ __device__ bool tie_select_wave(const GridView& G, const BookView& B, float qx, 
         const int dl = (int)fminf(floorf(fminf(xr + (1.f - rx), 1.0e6f)), (float)r);
         const int x0 = max(cx - dl, 0), x1 = min(cx + dr, G.nx - 1);
         if (x0 <= x1) {
-          const size_t rowi = (size_t)zz * (size_t)G.ny + (size_t)yy;
-          const size_t rowbase = rowi * (size_t)G.nxs;
-          const uint32_t rs = G.row_start[rowi];                // (the tables hold positions relative to their row's start)
-          const uint32_t lo = rs + G.cell_start[rowbase + (size_t)x0 * G.xs], hi = rs + G.cell_start[rowbase + (size_t)(x1 + 1) * G.xs];
+          uint32_t lo, hi;
+          grid_row_range(G, yy, zz, x0 * G.xs, (x1 + 1) * G.xs, lo, hi);
           for (uint32_t i = lo; i < hi; i++) {
             const float4 p = G.pts[i];
             const float d = sqdist3(qx, qy, qz, p.x, p.y, p.z);

@@ -9,7 +9,7 @@
 //   3. sort      : stable LSD radix sort of (key, index) pairs (rocPRIM through hipCUB) -- keeps
 //                  insertion order inside a cell, so the device order is deterministic
 //   4. gather    : points re-ordered into cell order (float4, w keeps the insertion index)
-//   5. cell_start: lower-bound of every cell id in the sorted keys
+//   5. segment table: one workgroup per row turns the row's columns into its entries (GridView, flimo_types.h)
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <immintrin.h>
@@ -85,16 +85,6 @@ __global__ __launch_bounds__(256) void gather_kernel(const float4* __restrict__ 
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   out[i] = in[perm[i]];
-}
-
-// cell_start = inclusive max-scan of E, where E[key+1] = (index of the last element of that key's
-// run) + 1 and 0 elsewhere; so cell_start[c] = number of sorted keys < c.
-__global__ __launch_bounds__(256) void tails_kernel(const uint32_t* __restrict__ keys, size_t n,
-                                                    uint32_t* __restrict__ E) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t k = keys[i];
-  if (i + 1 == n || keys[i + 1] != k) E[(size_t)k + 1] = (uint32_t)(i + 1);
 }
 
 struct MailArgs { const uint32_t* src[6]; int n[6]; int dst[6]; int parts; unsigned* rearm; uint32_t* zero; int zero_n; uint32_t tag; };
@@ -188,92 +178,10 @@ hipError_t map_bbox(hipStream_t st, const float4* pts, size_t n, MapBuildScratch
   return hipSuccess;
 }
 
-// absolute column starts (x fastest, rows of nxs entries) -> row_start[r] = the row's first entry, cell_start[] relative to it
-__global__ __launch_bounds__(256) void rows_relative_kernel(uint32_t* __restrict__ cell_start, uint32_t* __restrict__ row_start, size_t nrows, int nxs) {
-  const size_t r = blockIdx.x;
-  __shared__ uint32_t s_base;
-  if (threadIdx.x == 0) {
-    s_base = cell_start[r * (size_t)nxs];
-    row_start[r] = s_base;
-    if (r + 1 == nrows) row_start[nrows] = cell_start[nrows * (size_t)nxs];      // (the table's last entry: the point count)
-  }
-  __syncthreads();
-  const uint32_t base = s_base;
-  uint32_t* row = cell_start + r * (size_t)nxs;
-  __syncthreads();                                     // (thread 0 read entry 0 before anybody rewrites it)
-  for (int x = threadIdx.x; x < nxs; x += blockDim.x) row[x] -= base;
-}
-// row_start -> its padded, y-fastest copy (pads stay zero)
-__global__ __launch_bounds__(256) void rowstart_t_kernel(const uint32_t* __restrict__ row_start, int ny, int nz, uint32_t* __restrict__ out) {
-  const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= (size_t)ny * nz) return;
-  const int y = (int)(r % (size_t)ny), z = (int)(r / (size_t)ny);
-  out[(size_t)(z + 2) * ((size_t)ny + 4) + (size_t)(y + 2)] = row_start[r];
-}
-size_t cell_table_size(int nxf, int ny, int nz) { return (size_t)ny * nz * ((size_t)nxf + 1) + 1; }
-size_t row_start_size(int ny, int nz) { return (size_t)ny * nz + 1; }
-size_t row_start_t_size(int ny, int nz) { return ((size_t)ny + 4) * ((size_t)nz + 4); }
+// ---- the segment table (GridView, flimo_types.h) ----------------------------------------------------------------------------
+size_t segs_size(int nxf, int ny, int nz) { return grid_prows(ny, nz) * grid_nseg(nxf); }
+size_t row_start_size(int ny, int nz) { return grid_prows(ny, nz); }
 
-hipError_t map_build_row_table(hipStream_t st, const uint32_t* cell_start, int nx, int ny, int nz, uint32_t* out, bool zero_pads);
-hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4* pts_out, const IndexTables& T,
-                          float ox, float oy, float oz, float inv_cell, int nx, int ny, int nz, int xs,
-                          MapBuildScratch& S, bool zero_pads) {
-  const int nxf = nx * xs, nxs = nxf + 1;
-  const size_t nrows = (size_t)ny * nz, ncells = nrows * (size_t)nxs;      // entries before the last one
-  uint32_t* cell_start = T.cell_start;
-  hipError_t e = ensure_scratch(S, n);
-  if (e != hipSuccess) return e;
-  const int blocks = (int)((n + 255) / 256);
-  if (blocks > 0)
-    hipLaunchKernelGGL(cellkey_kernel, dim3(blocks), dim3(256), 0, st, pts_in, n, ox, oy, oz, inv_cell, nx, ny, nz, xs,
-                       S.keys_in, S.vals_in);
-  // number of key bits actually used
-  int bits = 1;
-  while (bits < 32 && ((size_t)1 << bits) < ncells) bits++;
-  size_t tmp_bytes = 0;
-  e = sort_pairs_u32(nullptr, tmp_bytes, S.keys_in, S.keys_out, S.vals_in, S.vals_out, (int)n, 0,
-                                         bits, st);
-  if (e != hipSuccess) return e;
-  if (tmp_bytes > S.cub_tmp_bytes) {
-    if (S.cub_tmp) hipFree(S.cub_tmp);
-    if ((e = hipMalloc(&S.cub_tmp, tmp_bytes + 1024)) != hipSuccess) return e;
-    S.cub_tmp_bytes = tmp_bytes + 1024;
-  }
-  if (n > 0) {
-    e = sort_pairs_u32(S.cub_tmp, tmp_bytes, S.keys_in, S.keys_out, S.vals_in, S.vals_out, (int)n,
-                                           0, bits, st);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(256), 0, st, pts_in, S.vals_out, n, pts_out);
-  }
-  if ((e = hipMemsetAsync(cell_start, 0, (ncells + 1) * sizeof(uint32_t), st)) != hipSuccess) return e;
-  if (n > 0) hipLaunchKernelGGL(tails_kernel, dim3(blocks), dim3(256), 0, st, S.keys_out, n, cell_start);
-  size_t scan_bytes = 0;
-  e = inclusive_max_u32(nullptr, scan_bytes, cell_start, cell_start, (int)(ncells + 1), st);
-  if (e != hipSuccess) return e;
-  if (scan_bytes > S.cub_tmp_bytes) {
-    if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;   // the sort may still be using cub_tmp
-    if (S.cub_tmp) hipFree(S.cub_tmp);
-    if ((e = hipMalloc(&S.cub_tmp, scan_bytes + 1024)) != hipSuccess) return e;
-    S.cub_tmp_bytes = scan_bytes + 1024;
-  }
-  e = inclusive_max_u32(S.cub_tmp, scan_bytes, cell_start, cell_start, (int)(ncells + 1), st);
-  if (e != hipSuccess) return e;
-  // absolute starts -> rows' starts + entries relative to them, then the two y-fastest copies the k-NN fast path reads
-  hipLaunchKernelGGL(rows_relative_kernel, dim3((unsigned)nrows), dim3(256), 0, st, cell_start, T.row_start, nrows, nxs);
-  if ((e = map_build_row_table(st, cell_start, nxf, ny, nz, T.row_table, zero_pads)) != hipSuccess) return e;
-  if (zero_pads && (e = hipMemsetAsync(T.row_start_t, 0, row_start_t_size(ny, nz) * sizeof(uint32_t), st)) != hipSuccess) return e;
-  hipLaunchKernelGGL(rowstart_t_kernel, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, st, T.row_start, ny, nz, T.row_start_t);
-  return hipGetLastError();
-}
-
-// ---- incremental update of the cell-sorted map ------------------------------------------------
-// The map only grows (the insert rule drops incoming points, never stored ones), so when the grid geometry still covers
-// the map the k points appended since the last build are MERGED into the sorted array instead of sorting everything
-// again: the new points are sorted by cell (k is a scan, not the map), every stored point moves up by the number of new
-// points in lower cells, every new point lands behind the stored points of its cell -- exactly the array a stable sort
-// of (stored points..., new points...) by cell gives, i.e. what map_build_grid produces for the same geometry.
-// One streaming pass over the points and one over the cell table; the binary searches over the k new keys are done
-// once per block (first / last element) and only blocks that straddle a new key search per element.
 __device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t* __restrict__ keys, uint32_t lo, uint32_t hi, uint32_t key) {
   while (lo < hi) {
     const uint32_t mid = (lo + hi) >> 1;
@@ -282,7 +190,7 @@ __device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t* __restrict__
   return lo;
 }
 // The same by a whole wave (every lane gets the result): 64 probes per round instead of one -- 3 dependent loads for 64k keys
-// instead of 16.  The blocks below search once for their first and once for their last element before they stream.
+// instead of 16.
 __device__ __forceinline__ uint32_t wave_lower_bound_u32(const uint32_t* __restrict__ keys, uint32_t k, uint32_t key) {
   const uint32_t lane = threadIdx.x & 63u;
   uint32_t lo = 0u, hi = k;                            // the answer lies in [lo, hi]
@@ -299,6 +207,142 @@ __device__ __forceinline__ uint32_t wave_lower_bound_u32(const uint32_t* __restr
   const bool below = idx < hi && keys[idx] < key;
   return lo + (uint32_t)__popcll(__ballot(below));
 }
+
+// The entries of ONE row from its points' columns: a histogram of the row's columns in shared memory (windows of SEG_WIN
+// columns; a row's points are sorted by column), the segments' prefix sums by a scan over the workgroup, then one entry per
+// segment -- eight nibbles, or an escape (eight cumulative counts in `ovf`) when a column holds more than 15 points.  An escape
+// keeps the slot its entry already had (the map only grows: a segment that escaped stays one), a new one takes the next free slot.
+// cols(i) = column of the row's i-th point.
+constexpr int SEG_WIN = 4096;                                      // columns per window (a multiple of 8 * 256 / 1)
+struct SegTab { uint2* segs; uint32_t* ovf; uint32_t* ovf_count; uint32_t ovf_cap; int nseg; };
+template <typename ColOf>
+__device__ __forceinline__ void row_entries(const SegTab& T, uint32_t prow, uint32_t len, int nxf, ColOf cols, uint32_t* s_cnt /*[SEG_WIN]*/,
+                                            uint32_t* s_scan /*[256 + 1]*/) {
+  uint2* row = T.segs + (size_t)prow * (size_t)T.nseg;
+  const int t = (int)threadIdx.x;
+  uint32_t carry = 0u;                                             // points in the columns below the window
+  for (int w0 = 0; w0 < T.nseg * 8; w0 += SEG_WIN) {
+    for (int i = t; i < SEG_WIN; i += 256) s_cnt[i] = 0u;
+    __syncthreads();
+    for (uint32_t i = (uint32_t)t; i < len; i += 256u) {
+      const int c = cols(i) - w0;
+      if (c >= 0 && c < SEG_WIN) atomicAdd(&s_cnt[c], 1u);
+    }
+    __syncthreads();
+    // SEG_WIN / 8 = 512 segments per window: two per thread
+    uint32_t tot[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      uint32_t a = 0u;
+#pragma unroll
+      for (int k = 0; k < 8; k++) a += s_cnt[(2 * t + h) * 8 + k];
+      tot[h] = a;
+    }
+    s_scan[t] = tot[0] + tot[1];
+    __syncthreads();
+    // exclusive scan of 256 values (Hillis-Steele in place, double buffered through registers)
+    for (int o = 1; o < 256; o <<= 1) {
+      const uint32_t v = (t >= o) ? s_scan[t - o] : 0u;
+      __syncthreads();
+      s_scan[t] += v;
+      __syncthreads();
+    }
+    const uint32_t incl = s_scan[t], excl = incl - (tot[0] + tot[1]);
+    const uint32_t win_total = s_scan[255];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int sg = (w0 >> 3) + 2 * t + h;
+      if (sg < T.nseg) {
+        const uint32_t pre = carry + excl + (h ? tot[0] : 0u);
+        uint32_t nib = 0u;
+        bool big = false;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const uint32_t v = s_cnt[(2 * t + h) * 8 + k];
+          big = big || v > 15u;
+          nib |= (v & 15u) << (4 * k);
+        }
+        if (!big) {
+          row[sg] = make_uint2(pre, nib);
+        } else {
+          const uint2 old = row[sg];
+          uint32_t slot = ((int)old.x < 0) ? old.y : atomicAdd(T.ovf_count, 1u);
+          if (slot < T.ovf_cap) {
+            uint32_t a = 0u;
+#pragma unroll
+            for (int k = 0; k < 8; k++) { T.ovf[(size_t)slot * 8u + k] = a; a += s_cnt[(2 * t + h) * 8 + k]; }
+            row[sg] = make_uint2(pre | 0x80000000u, slot);
+          }
+          // (slot >= cap cannot happen: the pool holds one slot per 16 points of the point buffer's capacity)
+        }
+      }
+    }
+    carry += win_total;
+    __syncthreads();
+  }
+}
+// Full build: one workgroup per row of the grid.  keys: the sorted column keys of all n points (key = row * nxs + column).
+__global__ __launch_bounds__(256) void rows_build_kernel(SegTab T, uint32_t* __restrict__ row_start, const uint32_t* __restrict__ keys, uint32_t n,
+                                                         int nxs, int ny) {
+  __shared__ uint32_t s_cnt[SEG_WIN], s_scan[257], s_lo, s_hi;
+  const uint32_t r = blockIdx.x;
+  const uint32_t first = r * (uint32_t)nxs;
+  if (threadIdx.x < 64) { const uint32_t v = wave_lower_bound_u32(keys, n, first); if (threadIdx.x == 0) s_lo = v; }
+  else if (threadIdx.x < 128) { const uint32_t v = wave_lower_bound_u32(keys, n, first + (uint32_t)nxs); if (threadIdx.x == 64) s_hi = v; }
+  __syncthreads();
+  const uint32_t lo = s_lo, hi = s_hi;
+  const uint32_t prow = (r / (uint32_t)ny + GRID_PAD) * (uint32_t)(ny + 2 * GRID_PAD) + (r % (uint32_t)ny + GRID_PAD);
+  if (threadIdx.x == 0) row_start[prow] = lo;
+  if (lo == hi) return;                                            // (the table was cleared: an empty row is all zero)
+  const uint32_t* rk = keys + lo;
+  row_entries(T, prow, hi - lo, nxs - 1, [&](uint32_t i) { return (int)(rk[i] - first); }, s_cnt, s_scan);
+}
+static hipError_t sort_keys(hipStream_t st, size_t n, int bits, MapBuildScratch& S) {
+  size_t tmp_bytes = 0;
+  hipError_t e = sort_pairs_u32(nullptr, tmp_bytes, S.keys_in, S.keys_out, S.vals_in, S.vals_out, (int)n, 0, bits, st);
+  if (e != hipSuccess) return e;
+  if (tmp_bytes > S.cub_tmp_bytes) {
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;   // (an earlier launch may still be using cub_tmp)
+    if (S.cub_tmp) (void)hipFree(S.cub_tmp);
+    S.cub_tmp = nullptr; S.cub_tmp_bytes = 0;
+    if ((e = hipMalloc(&S.cub_tmp, tmp_bytes + 1024)) != hipSuccess) return e;
+    S.cub_tmp_bytes = tmp_bytes + 1024;
+  }
+  return sort_pairs_u32(S.cub_tmp, tmp_bytes, S.keys_in, S.keys_out, S.vals_in, S.vals_out, (int)n, 0, bits, st);
+}
+hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4* pts_out, const IndexTables& T,
+                          float ox, float oy, float oz, float inv_cell, int nx, int ny, int nz, int xs,
+                          MapBuildScratch& S) {
+  const int nxf = nx * xs, nxs = nxf + 1;
+  const size_t nrows = (size_t)ny * nz, ncols = nrows * (size_t)nxs;
+  hipError_t e = ensure_scratch(S, n);
+  if (e != hipSuccess) return e;
+  const int blocks = (int)((n + 255) / 256);
+  if (blocks > 0)
+    hipLaunchKernelGGL(cellkey_kernel, dim3(blocks), dim3(256), 0, st, pts_in, n, ox, oy, oz, inv_cell, nx, ny, nz, xs,
+                       S.keys_in, S.vals_in);
+  int bits = 1;                                                    // number of key bits actually used
+  while (bits < 32 && ((size_t)1 << bits) < ncols) bits++;
+  if (n > 0) {
+    if ((e = sort_keys(st, n, bits, S)) != hipSuccess) return e;
+    hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(256), 0, st, pts_in, S.vals_out, n, pts_out);
+  }
+  if ((e = hipMemsetAsync(T.segs, 0, segs_size(nxf, ny, nz) * sizeof(uint2), st)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(T.row_start, 0, row_start_size(ny, nz) * sizeof(uint32_t), st)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(T.ovf_count, 0, sizeof(uint32_t), st)) != hipSuccess) return e;
+  const SegTab tab{T.segs, T.ovf, T.ovf_count, T.ovf_cap, (int)grid_nseg(nxf)};
+  hipLaunchKernelGGL(rows_build_kernel, dim3((unsigned)nrows), dim3(256), 0, st, tab, T.row_start, S.keys_out, (uint32_t)n, nxs, ny);
+  return hipGetLastError();
+}
+
+// ---- incremental update of the cell-sorted map ------------------------------------------------
+// The map only grows (the insert rule drops incoming points, never stored ones), so when the grid geometry still covers
+// the map the k points appended since the last build are MERGED into the sorted array instead of sorting everything
+// again: the new points are sorted by cell (k is a scan, not the map), every stored point moves up by the number of new
+// points in lower cells, every new point lands behind the stored points of its cell -- exactly the array a stable sort
+// of (stored points..., new points...) by cell gives, i.e. what map_build_grid produces for the same geometry.
+// One streaming pass over the points and one over the cell table; the binary searches over the k new keys are done
+// once per block (first / last element) and only blocks that straddle a new key search per element.
 // new point j (cell-sorted) -> behind the stored points of its cell: position = j + #stored points in cells <= key
 // stored point i (cell-sorted) -> i + #new points in cells < its cell
 // (one launch for both: the first `old_blocks` blocks move the stored points, the rest place the new ones; they write disjoint
@@ -307,16 +351,19 @@ __global__ __launch_bounds__(256) void merge_points_kernel(const float4* __restr
                                                            const uint32_t* __restrict__ nkeys, uint32_t k, float ox, float oy, float oz,
                                                            float inv_cell, int nx, int ny, int nz, int xs, float4* __restrict__ out,
                                                            uint32_t old_blocks, const float4* __restrict__ new_pts,
-                                                           const uint32_t* __restrict__ nperm, const uint32_t* __restrict__ cell_start_old,
-                                                           const uint32_t* __restrict__ row_start_old, int nxs) {
+                                                           const uint32_t* __restrict__ nperm, const uint2* __restrict__ segs_old,
+                                                           const uint32_t* __restrict__ ovf, const uint32_t* __restrict__ row_start_old,
+                                                           int nxs, int nseg) {
   __shared__ uint32_t s_lo, s_hi, s_c0, s_c1;
   if (blockIdx.x >= old_blocks) {
     const uint32_t j = (blockIdx.x - old_blocks) * blockDim.x + threadIdx.x;
     if (j >= k) return;
-    // (behind the stored points of its column: the next entry of the same row -- a column is never a row's end entry -- plus the
-    //  row's start)
+    // (behind the stored points of its column: the row's start + the row's points in columns <= its own)
     const uint32_t key = nkeys[j];
-    out[(size_t)row_start_old[key / (uint32_t)nxs] + (size_t)cell_start_old[(size_t)key + 1] + j] = new_pts[nperm[j]];
+    const uint32_t r = key / (uint32_t)nxs, col = key - r * (uint32_t)nxs + 1u;
+    const uint32_t prow = (r / (uint32_t)ny + GRID_PAD) * (uint32_t)(ny + 2 * GRID_PAD) + (r % (uint32_t)ny + GRID_PAD);
+    const uint2 e = segs_old[(size_t)prow * (size_t)nseg + (col >> 3)];
+    out[(size_t)row_start_old[prow] + (size_t)seg_count(e.x, e.y, col & 7u, ovf) + j] = new_pts[nperm[j]];
     return;
   }
   const uint32_t base = blockIdx.x * blockDim.x;
@@ -339,71 +386,57 @@ __global__ __launch_bounds__(256) void merge_points_kernel(const float4* __restr
   const uint32_t shift = (lo == hi) ? lo : lower_bound_u32(nkeys, lo, hi, cid);
   out[(size_t)i + shift] = p;
 }
-// The tables after a merge.  row_start[r] += #new points in rows < r (every row: a table of ny*nz + 1 entries).  Relative entries
-// change only inside the rows that received points: entry (r, xf) += #new points of row r in columns < xf -- one workgroup per
-// row looks whether its row has new keys at all (a wave-wide search over the sorted new keys) and leaves if not; a row that has
-// rewrites its nxs entries in both tables (x fastest here, y fastest in row_table).
-__global__ __launch_bounds__(256) void rows_merge_kernel(uint32_t* __restrict__ cell_start, uint32_t* __restrict__ row_start,
-                                                         uint32_t* __restrict__ row_table, uint32_t* __restrict__ row_start_t,
-                                                         const uint32_t* __restrict__ nkeys, uint32_t k, int nxs, int ny, int nz) {
-  __shared__ uint32_t s_lo, s_hi;
-  const size_t nrows = (size_t)ny * nz;
-  const size_t r = blockIdx.x;                                   // 0 .. nrows (the extra one: the point count at row_start[nrows])
-  const uint32_t first = (uint32_t)(r * (size_t)nxs);
+// The table after a merge.  row_start[r] += #new points in rows < r (every row: the small table).  Entries change only inside the
+// rows that received points: one workgroup per row looks whether its row has new keys at all (a wave-wide search over the sorted
+// new keys) and leaves if not; a row that has rebuilds its entries from its points in the merged array (row_entries).
+__global__ __launch_bounds__(256) void rows_merge_kernel(SegTab T, uint32_t* __restrict__ row_start, const uint32_t* __restrict__ nkeys, uint32_t k,
+                                                         const float4* __restrict__ merged, float ox, float oy, float oz, float inv_cell,
+                                                         int nx, int ny, int nz, int xs) {
+  __shared__ uint32_t s_cnt[SEG_WIN], s_scan[257], s_lo, s_hi;
+  const int nxs = nx * xs + 1;
+  const uint32_t r = blockIdx.x;
+  const uint32_t first = r * (uint32_t)nxs;
   if (threadIdx.x < 64) { const uint32_t v = wave_lower_bound_u32(nkeys, k, first); if (threadIdx.x == 0) s_lo = v; }
-  else if (threadIdx.x < 128) { const uint32_t v = r < nrows ? wave_lower_bound_u32(nkeys, k, first + (uint32_t)nxs) : k; if (threadIdx.x == 64) s_hi = v; }
+  else if (threadIdx.x < 128) { const uint32_t v = wave_lower_bound_u32(nkeys, k, first + (uint32_t)nxs); if (threadIdx.x == 64) s_hi = v; }
   __syncthreads();
   const uint32_t lo = s_lo, hi = s_hi;
-  if (threadIdx.x == 0 && lo != 0u) {
-    const uint32_t v = row_start[r] + lo;
-    row_start[r] = v;
-    if (r < nrows) row_start_t[(size_t)(r / (size_t)ny + 2) * ((size_t)ny + 4) + (size_t)(r % (size_t)ny + 2)] = v;
-    else cell_start[nrows * (size_t)nxs] = v;                    // (the cell table's last entry: the point count, like row_start's)
+  const uint32_t prow = (r / (uint32_t)ny + GRID_PAD) * (uint32_t)(ny + 2 * GRID_PAD) + (r % (uint32_t)ny + GRID_PAD);
+  const uint32_t start = row_start[prow] + lo;
+  if (lo == hi) {
+    if (threadIdx.x == 0 && lo != 0u) row_start[prow] = start;
+    return;
   }
-  if (r >= nrows || lo == hi) return;
-  const int y = (int)(r % (size_t)ny), z = (int)(r / (size_t)ny);
-  const size_t py = (size_t)ny + 4, pz = (size_t)nz + 4;
-  uint32_t* row = cell_start + r * (size_t)nxs;
-  for (int x = threadIdx.x; x < nxs; x += blockDim.x) {
-    const uint32_t add = lower_bound_u32(nkeys, lo, hi, first + (uint32_t)x) - lo;
-    if (add != 0u) {
-      const uint32_t v = row[x] + add;
-      row[x] = v;
-      row_table[((size_t)x * pz + (size_t)(z + 2)) * py + (size_t)(y + 2)] = v;
-    }
-  }
+  // the row's length before the merge: its entry of column nxf
+  const uint2 e = T.segs[(size_t)prow * (size_t)T.nseg + (size_t)((nxs - 1) >> 3)];
+  const uint32_t len = seg_count(e.x, e.y, (uint32_t)(nxs - 1) & 7u, T.ovf) + (hi - lo);
+  __syncthreads();                                                 // (everybody has read the old entry)
+  if (threadIdx.x == 0) row_start[prow] = start;
+  const float4* rp = merged + start;
+  row_entries(T, prow, len, nxs - 1,
+              [&](uint32_t i) { return (int)(column_key(rp[i], ox, oy, oz, inv_cell, nx, ny, nz, xs) - first); }, s_cnt, s_scan);
 }
 hipError_t map_merge_grid(hipStream_t st, const float4* old_sorted, size_t n_old, const float4* new_pts, size_t k,
                           float4* out_sorted, const IndexTables& T, float ox, float oy, float oz,
                           float inv_cell, int nx, int ny, int nz, int xs, MapBuildScratch& S) {
   if (k == 0) return hipSuccess;
-  const int nxs = nx * xs + 1;
-  const size_t nrows = (size_t)ny * nz, ncells = nrows * (size_t)nxs;
+  const int nxs = nx * xs + 1, nseg = (int)grid_nseg(nx * xs);
+  const size_t nrows = (size_t)ny * nz, ncols = nrows * (size_t)nxs;
   hipError_t e = ensure_scratch(S, k);
   if (e != hipSuccess) return e;
   const int kb = (int)((k + 255) / 256);
   hipLaunchKernelGGL(cellkey_kernel, dim3(kb), dim3(256), 0, st, new_pts, k, ox, oy, oz, inv_cell, nx, ny, nz, xs, S.keys_in, S.vals_in);
   int bits = 1;
-  while (bits < 32 && ((size_t)1 << bits) < ncells) bits++;
-  size_t tmp_bytes = 0;
-  e = sort_pairs_u32(nullptr, tmp_bytes, S.keys_in, S.keys_out, S.vals_in, S.vals_out, (int)k, 0, bits, st);
-  if (e != hipSuccess) return e;
-  if (tmp_bytes > S.cub_tmp_bytes) {
-    if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
-    if (S.cub_tmp) hipFree(S.cub_tmp);
-    if ((e = hipMalloc(&S.cub_tmp, tmp_bytes + 1024)) != hipSuccess) return e;
-    S.cub_tmp_bytes = tmp_bytes + 1024;
-  }
-  e = sort_pairs_u32(S.cub_tmp, tmp_bytes, S.keys_in, S.keys_out, S.vals_in, S.vals_out, (int)k, 0, bits, st);
-  if (e != hipSuccess) return e;
+  while (bits < 32 && ((size_t)1 << bits) < ncols) bits++;
+  if ((e = sort_keys(st, k, bits, S)) != hipSuccess) return e;
   {
     const unsigned old_blocks = (unsigned)((n_old + 255) / 256);
     hipLaunchKernelGGL(merge_points_kernel, dim3(old_blocks + (unsigned)kb), dim3(256), 0, st, old_sorted, (uint32_t)n_old, S.keys_out, (uint32_t)k,
-                       ox, oy, oz, inv_cell, nx, ny, nz, xs, out_sorted, old_blocks, new_pts, S.vals_out, T.cell_start, T.row_start, nxs);
+                       ox, oy, oz, inv_cell, nx, ny, nz, xs, out_sorted, old_blocks, new_pts, S.vals_out, T.segs, T.ovf, T.row_start, nxs, nseg);
   }
-  // (the points were placed with the OLD tables: the tables follow)
-  hipLaunchKernelGGL(rows_merge_kernel, dim3((unsigned)(nrows + 1)), dim3(256), 0, st, T.cell_start, T.row_start, T.row_table, T.row_start_t,
-                     S.keys_out, (uint32_t)k, nxs, ny, nz);
+  // (the points were placed with the OLD table: the table follows)
+  const SegTab tab{T.segs, T.ovf, T.ovf_count, T.ovf_cap, nseg};
+  hipLaunchKernelGGL(rows_merge_kernel, dim3((unsigned)nrows), dim3(256), 0, st, tab, T.row_start, S.keys_out, (uint32_t)k, out_sorted,
+                     ox, oy, oz, inv_cell, nx, ny, nz, xs);
   return hipGetLastError();
 }
 
@@ -423,55 +456,51 @@ __device__ __forceinline__ void crowded_append(uint32_t cell, int x, int y, int 
   const uint32_t slot = atomicAdd(count, 1u);
   if (slot < cap) list[slot] = make_int4(x, y, z, 0);
 }
-__global__ __launch_bounds__(256) void crowded_all_kernel(const uint32_t* __restrict__ cell_start, int nx, int ny, int nz, int xs,
-                                                          uint32_t threshold, uint32_t* __restrict__ bits, int4* __restrict__ list,
+__global__ __launch_bounds__(256) void crowded_all_kernel(GridView G, uint32_t threshold, uint32_t* __restrict__ bits, int4* __restrict__ list,
                                                           uint32_t cap, uint32_t* __restrict__ count) {
   const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t ncells = (size_t)nx * ny * nz;
+  const size_t ncells = (size_t)G.nx * G.ny * G.nz;
   if (c >= ncells) return;
-  const int x = (int)(c % (size_t)nx);
-  const size_t row = c / (size_t)nx;
-  const size_t col0 = row * ((size_t)nx * xs + 1) + (size_t)x * xs;      // (entries of one row: relative to the same start)
-  if (cell_start[col0 + xs] - cell_start[col0] <= threshold) return;
-  crowded_append((uint32_t)c, x, (int)(row % (size_t)ny), (int)(row / (size_t)ny), bits, list, cap, count);
+  const int x = (int)(c % (size_t)G.nx);
+  const size_t row = c / (size_t)G.nx;
+  const int y = (int)(row % (size_t)G.ny), z = (int)(row / (size_t)G.ny);
+  uint32_t lo, hi;
+  grid_row_range(G, y, z, x * G.xs, (x + 1) * G.xs, lo, hi);
+  if (hi - lo <= threshold) return;
+  crowded_append((uint32_t)c, x, y, z, bits, list, cap, count);
 }
-__global__ __launch_bounds__(256) void crowded_points_kernel(const float4* __restrict__ pts, size_t k, const uint32_t* __restrict__ cell_start,
-                                                             float ox, float oy, float oz, float inv_cell, int nx, int ny, int nz, int xs,
+__global__ __launch_bounds__(256) void crowded_points_kernel(const float4* __restrict__ pts, size_t k, GridView G,
                                                              uint32_t threshold, uint32_t* __restrict__ bits, int4* __restrict__ list,
                                                              uint32_t cap, uint32_t* __restrict__ count) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= k) return;
-  const uint32_t col = column_key(pts[i], ox, oy, oz, inv_cell, nx, ny, nz, xs);
-  const uint32_t nxs = (uint32_t)(nx * xs + 1);
-  const uint32_t row = col / nxs, xf = col - row * nxs;
-  const uint32_t col0 = col - xf % (uint32_t)xs;
-  if (cell_start[col0 + xs] - cell_start[col0] <= threshold) return;
-  const uint32_t x = xf / (uint32_t)xs;
-  const uint32_t cell = row * (uint32_t)nx + x;
-  crowded_append(cell, (int)x, (int)(row % (uint32_t)ny), (int)(row / (uint32_t)ny), bits, list, cap, count);
+  const uint32_t col = column_key(pts[i], G.ox, G.oy, G.oz, G.inv_cell, G.nx, G.ny, G.nz, G.xs);
+  const uint32_t row = col / (uint32_t)G.nxs, xf = col - row * (uint32_t)G.nxs;
+  const int x = (int)(xf / (uint32_t)G.xs), y = (int)(row % (uint32_t)G.ny), z = (int)(row / (uint32_t)G.ny);
+  uint32_t lo, hi;
+  grid_row_range(G, y, z, x * G.xs, (x + 1) * G.xs, lo, hi);
+  if (hi - lo <= threshold) return;
+  crowded_append(row * (uint32_t)G.nx + (uint32_t)x, x, y, z, bits, list, cap, count);
 }
 // *count_host = entries listed so far (may exceed cap: the list is then incomplete)
-hipError_t crowded_list_all(hipStream_t st, const uint32_t* cell_start, int nx, int ny, int nz, int xs, uint32_t threshold, uint32_t* bits,
+hipError_t crowded_list_all(hipStream_t st, const GridView& G, uint32_t threshold, uint32_t* bits,
                             int4* list, uint32_t cap, uint32_t* count_dev, uint32_t* count_host, MapBuildScratch& S) {
-  const size_t ncells = (size_t)nx * ny * nz;
+  const size_t ncells = (size_t)G.nx * G.ny * G.nz;
   hipError_t e;
   if ((e = hipMemsetAsync(bits, 0, ((ncells + 31) / 32) * sizeof(uint32_t), st)) != hipSuccess) return e;
   if ((e = hipMemsetAsync(count_dev, 0, sizeof(uint32_t), st)) != hipSuccess) return e;
-  hipLaunchKernelGGL(crowded_all_kernel, dim3((unsigned)((ncells + 255) / 256)), dim3(256), 0, st, cell_start, nx, ny, nz, xs, threshold, bits, list,
-                     cap, count_dev);
+  hipLaunchKernelGGL(crowded_all_kernel, dim3((unsigned)((ncells + 255) / 256)), dim3(256), 0, st, G, threshold, bits, list, cap, count_dev);
   const MailPart part{count_dev, 1, MAIL_CROWD};
   if ((e = mail_words(st, S, &part, 1)) != hipSuccess) return e;
   if ((e = mail_wait(st, S)) != hipSuccess) return e;
   *count_host = S.mail_host[MAIL_CROWD];
   return hipSuccess;
 }
-hipError_t crowded_list_points(hipStream_t st, const float4* pts, size_t k, const uint32_t* cell_start, float ox, float oy, float oz,
-                               float inv_cell, int nx, int ny, int nz, int xs, uint32_t threshold, uint32_t* bits, int4* list, uint32_t cap,
-                               uint32_t* count_dev, uint32_t* count_host, MapBuildScratch& S) {
+hipError_t crowded_list_points(hipStream_t st, const float4* pts, size_t k, const GridView& G, uint32_t threshold, uint32_t* bits, int4* list,
+                               uint32_t cap, uint32_t* count_dev, uint32_t* count_host, MapBuildScratch& S) {
   hipError_t e;
   if (k > 0)
-    hipLaunchKernelGGL(crowded_points_kernel, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, st, pts, k, cell_start, ox, oy, oz, inv_cell, nx,
-                       ny, nz, xs, threshold, bits, list, cap, count_dev);
+    hipLaunchKernelGGL(crowded_points_kernel, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, st, pts, k, G, threshold, bits, list, cap, count_dev);
   const MailPart part{count_dev, 1, MAIL_CROWD};
   if ((e = mail_words(st, S, &part, 1)) != hipSuccess) return e;
   if ((e = mail_wait(st, S)) != hipSuccess) return e;
@@ -482,33 +511,30 @@ hipError_t crowded_list_points(hipStream_t st, const float4* pts, size_t k, cons
 // map.  The map is sorted by (z, y, x column), so the box is (y1-y0+1)(z1-z0+1) contiguous ranges read off the cell table:
 // counting and copying cost what the box holds, not what the map holds.  Two steps, so that the caller can size its
 // buffers (or give up) once it knows the count.
-__global__ __launch_bounds__(256) void boxrows_count_kernel(const uint32_t* __restrict__ cell_start, int ny, int nxf, int xs, int x0, int x1,
-                                                            int y0, int nyb, int z0, int nrows, uint32_t* __restrict__ cnt) {
+__global__ __launch_bounds__(256) void boxrows_count_kernel(GridView G, int x0, int x1, int y0, int nyb, int z0, int nrows,
+                                                            uint32_t* __restrict__ cnt) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= nrows) return;
-  const int y = y0 + r % nyb, z = z0 + r / nyb;
-  const size_t base = ((size_t)z * (size_t)ny + (size_t)y) * ((size_t)nxf + 1);
-  cnt[r] = cell_start[base + (size_t)(x1 + 1) * xs] - cell_start[base + (size_t)x0 * xs];
+  uint32_t lo, hi;
+  grid_row_range(G, y0 + r % nyb, z0 + r / nyb, x0 * G.xs, (x1 + 1) * G.xs, lo, hi);
+  cnt[r] = hi - lo;
 }
 __global__ __launch_bounds__(64) void boxrows_total_kernel(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off, int nrows,
                                                            uint32_t* __restrict__ total) {
   if (threadIdx.x == 0 && blockIdx.x == 0) *total = off[nrows - 1] + cnt[nrows - 1];
 }
-__global__ __launch_bounds__(64) void boxrows_copy_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ cell_start,
-                                                          const uint32_t* __restrict__ row_start, int ny,
-                                                          int nxf, int xs, int x0, int y0, int nyb, int z0, const uint32_t* __restrict__ cnt,
+__global__ __launch_bounds__(64) void boxrows_copy_kernel(GridView G, int x0, int x1, int y0, int nyb, int z0, const uint32_t* __restrict__ cnt,
                                                           const uint32_t* __restrict__ off, float4* __restrict__ out) {
   const int r = blockIdx.x;
-  const int y = y0 + r % nyb, z = z0 + r / nyb;
-  const size_t rowi = (size_t)z * (size_t)ny + (size_t)y;
-  const size_t base = rowi * ((size_t)nxf + 1);
-  const uint32_t a = row_start[rowi] + cell_start[base + (size_t)x0 * xs], n = cnt[r], o = off[r];
+  uint32_t a, hi;
+  grid_row_range(G, y0 + r % nyb, z0 + r / nyb, x0 * G.xs, (x1 + 1) * G.xs, a, hi);
+  const uint32_t n = cnt[r], o = off[r];
   for (uint32_t i = threadIdx.x; i < n; i += 64) {
-    const float4 p = pts[a + i];
+    const float4 p = G.pts[a + i];
     out[o + i] = make_float4(p.x, p.y, p.z, __uint_as_float(a + i));
   }
 }
-hipError_t map_box_count(hipStream_t st, const uint32_t* cell_start, int nx, int ny, int nz, int xs, const int c0[3], const int c1[3],
+hipError_t map_box_count(hipStream_t st, const GridView& G, const int c0[3], const int c1[3],
                          uint32_t* count_dev, uint32_t* count_host, MapBuildScratch& S) {
   *count_host = 0;
   const int nyb = c1[1] - c0[1] + 1, nzb = c1[2] - c0[2] + 1;
@@ -524,8 +550,7 @@ hipError_t map_box_count(hipStream_t st, const uint32_t* cell_start, int nx, int
     if ((e = hipMalloc(&S.cub_tmp, scan_bytes + 1024)) != hipSuccess) return e;
     S.cub_tmp_bytes = scan_bytes + 1024;
   }
-  hipLaunchKernelGGL(boxrows_count_kernel, dim3((nrows + 255) / 256), dim3(256), 0, st, cell_start, ny, nx * xs, xs, c0[0], c1[0], c0[1], nyb,
-                     c0[2], nrows, S.keys_in);
+  hipLaunchKernelGGL(boxrows_count_kernel, dim3((nrows + 255) / 256), dim3(256), 0, st, G, c0[0], c1[0], c0[1], nyb, c0[2], nrows, S.keys_in);
   if ((e = exclusive_sum(S.cub_tmp, scan_bytes, S.keys_in, S.vals_in, (size_t)nrows, st)) != hipSuccess) return e;
   hipLaunchKernelGGL(boxrows_total_kernel, dim3(1), dim3(64), 0, st, S.keys_in, S.vals_in, nrows, S.mail_dev + MAIL_BOXCOUNT);
   (void)count_dev;
@@ -534,40 +559,13 @@ hipError_t map_box_count(hipStream_t st, const uint32_t* cell_start, int nx, int
   return hipSuccess;
 }
 // second step: the counts / offsets of map_box_count (same box, nothing else used the scratch in between) -> the copies
-hipError_t map_box_copy(hipStream_t st, const float4* pts, const uint32_t* cell_start, const uint32_t* row_start, int nx, int ny, int nz, int xs,
-                        const int c0[3], const int c1[3], float4* out, MapBuildScratch& S) {
+hipError_t map_box_copy(hipStream_t st, const GridView& G, const int c0[3], const int c1[3], float4* out, MapBuildScratch& S) {
   const int nyb = c1[1] - c0[1] + 1, nzb = c1[2] - c0[2] + 1;
   if (nyb <= 0 || nzb <= 0 || c1[0] < c0[0]) return hipSuccess;
-  hipLaunchKernelGGL(boxrows_copy_kernel, dim3(nyb * nzb), dim3(64), 0, st, pts, cell_start, row_start, ny, nx * xs, xs, c0[0], c0[1], nyb, c0[2],
-                     S.keys_in, S.vals_in, out);
+  hipLaunchKernelGGL(boxrows_copy_kernel, dim3(nyb * nzb), dim3(64), 0, st, G, c0[0], c1[0], c0[1], nyb, c0[2], S.keys_in, S.vals_in, out);
   return hipGetLastError();
 }
 
-// ---- y-fastest, padded copy of the row bounds (GridView::row_table) --------------------------
-// A transposition per z slab (x-fastest cell table -> y-fastest row table) through a 32x33 LDS tile so that both the reads
-// (along x) and the writes (along y) are coalesced; the pad entries (y, z outside the grid) are zero and never written here.
-__global__ __launch_bounds__(256) void rowtable_kernel(const uint32_t* __restrict__ cell_start, int nx, int ny, int nz,
-                                                       uint32_t* __restrict__ out) {
-  __shared__ uint32_t tile[32][33];
-  // 1-D launch (any grid shape stays within the launch limits): tile index -> (x tile fastest, y tile, z)
-  const unsigned xt = (unsigned)(nx + 1 + 31) / 32u, yt = (unsigned)(ny + 31) / 32u;
-  const unsigned t = blockIdx.x;
-  const int z = (int)(t / (xt * yt));
-  const int x0 = (int)(t % xt) * 32, y0 = (int)((t / xt) % yt) * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
-  const size_t py = (size_t)ny + 4, pz = (size_t)nz + 4;
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const int y = y0 + ty + 8 * r, x = x0 + tx;
-    if (y < ny && x <= nx) tile[ty + 8 * r][tx] = cell_start[((size_t)z * ny + y) * ((size_t)nx + 1) + x];   // (rows of nx + 1 entries; x == nx: the row's length)
-  }
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const int x = x0 + ty + 8 * r, y = y0 + tx;
-    if (y < ny && x <= nx) out[((size_t)x * pz + (size_t)(z + 2)) * py + (size_t)(y + 2)] = tile[tx][ty + 8 * r];
-  }
-}
 // The device's atan2f (flimo_math.h: libm_atan2f, fdlibm's routine as glibc up to 2.40 evaluates it) on n argument pairs: the host
 // compares with ITS libm once per context before the FoV filter may run on the device (flimo_capi.hip: fov_selfcheck)
 __global__ void atan2f_probe_kernel(const float2* __restrict__ yx, int n, float* __restrict__ out) {
@@ -587,15 +585,21 @@ hipError_t atan2f_probe(hipStream_t st, const float* yx_host, int n, float* out_
   return e;
 }
 
-size_t row_table_size(int nx, int ny, int nz) { return ((size_t)nx + 1) * ((size_t)ny + 4) * ((size_t)nz + 4); }
-// zero_pads: the table is new or its shape changed (the pads have to be cleared); false when the same table is refreshed
-hipError_t map_build_row_table(hipStream_t st, const uint32_t* cell_start, int nx, int ny, int nz, uint32_t* out, bool zero_pads) {
-  const size_t total = row_table_size(nx, ny, nz);
-  hipError_t e;
-  if (zero_pads && (e = hipMemsetAsync(out, 0, total * sizeof(uint32_t), st)) != hipSuccess) return e;
-  const size_t tiles = (size_t)((nx + 1 + 31) / 32) * (size_t)((ny + 31) / 32) * (size_t)nz;
-  if (tiles > 0x7fffffffull) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(rowtable_kernel, dim3((unsigned)tiles), dim3(256), 0, st, cell_start, nx, ny, nz, out);
+// ---- debug: two indices of the same geometry say the same (flimo_map_grid_selfcheck) -- compared by MEANING, column by column:
+//      escapes take their slots in the order the workgroups arrive ----
+__global__ __launch_bounds__(256) void index_compare_kernel(GridView A, GridView B, unsigned long long* __restrict__ diff) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t per = (size_t)A.nxf + 1;
+  if (i >= grid_prows(A.ny, A.nz) * per) return;
+  const uint32_t prow = (uint32_t)(i / per);
+  const int col = (int)(i % per);
+  unsigned bad = grid_count(A, prow, col) != grid_count(B, prow, col);
+  if (col == 0) bad += A.row_start[prow] != B.row_start[prow];
+  if (bad) atomicAdd(diff, (unsigned long long)bad);
+}
+hipError_t index_compare(hipStream_t st, const GridView& A, const GridView& B, unsigned long long* diff_dev) {
+  const size_t n = grid_prows(A.ny, A.nz) * ((size_t)A.nxf + 1);
+  hipLaunchKernelGGL(index_compare_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, A, B, diff_dev);
   return hipGetLastError();
 }
 
