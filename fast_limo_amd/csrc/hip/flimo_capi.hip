@@ -48,12 +48,9 @@ struct flimo_ctx {
   bool have_gbox = false;
   bool force_full = false;         // the next index update lays the grid out afresh (cell size changed)
   bool full_rebuild = false;       // FLIMO_FULL_REBUILD=1: sort the whole map on every insert (A/B of the merge)
-  uint64_t grid_merges = 0, grid_builds = 0;
+  uint64_t grid_merges = 0, grid_builds = 0, index_overflows = 0;
   size_t map_n = 0, map_cap = 0;
-  // the index of the main grid (GridView, flimo_types.h): segment table, escape pool (+ its fill count), the rows' starts
-  uint2* d_segs = nullptr;
-  uint32_t *d_ovf = nullptr, *d_ovf_count = nullptr, *d_row_start = nullptr;
-  size_t segs_cap = 0, ovf_cap = 0, rowstart_cap = 0;
+  IndexTables idx;                 // the index of the main grid (GridView, flimo_types.h): tiles, directory, escapes, xstart
   GridView grid{};
   bool grid_valid = false;
   double map_last_time = -1.0;
@@ -166,9 +163,8 @@ struct flimo_ctx {
   int fine_qlo[3] = {0, 0, 0}, fine_qhi[3] = {-1, -1, -1};
   float4 *d_fine_tmp = nullptr, *d_fine_pts = nullptr;
   size_t fine_pts_cap = 0;
-  uint2* d_fine_segs = nullptr;
-  uint32_t *d_fine_ovf = nullptr, *d_fine_ovf_count = nullptr, *d_fine_count = nullptr, *d_fine_rs = nullptr;
-  size_t fine_segs_cap = 0, fine_ovf_cap = 0, fine_rs_cap = 0;
+  IndexTables fine_idx;
+  uint32_t* d_fine_count = nullptr;
   void* d_crowd_list = nullptr;        // int4 (x, y, z, -) of every crowded cell of the current geometry, listed once
   uint32_t* d_crowd_count = nullptr;
   uint32_t* d_crowd_bits = nullptr;    // one bit per cell: listed
@@ -474,13 +470,12 @@ extern "C" void flimo_ctx_destroy(flimo_ctx* c) {
   if (!c) return;
   ctx_enter(c);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  (void)hipFree(c->d_map_raw); (void)hipFree(c->d_map_sorted); (void)hipFree(c->d_map_sorted2); (void)hipFree(c->d_segs); (void)hipFree(c->d_ovf);
-  (void)hipFree(c->d_ovf_count); (void)hipFree(c->d_row_start); (void)hipFree(c->d_fine_rs); (void)hipFree(c->d_fine_ovf); (void)hipFree(c->d_fine_ovf_count);
+  (void)hipFree(c->d_map_raw); (void)hipFree(c->d_map_sorted); (void)hipFree(c->d_map_sorted2); index_free(c->idx); index_free(c->fine_idx);
   (void)hipFree(c->d_scan_sorted); (void)hipFree(c->d_nbr); (void)hipFree(c->d_wl); (void)hipFree(c->d_wl_count);
   (void)hipFree(c->d_fit_partials); (void)hipFree(c->d_raw_sorted); (void)hipFree(c->d_t_sorted);
   (void)hipFree(c->d_scan); (void)hipFree(c->d_scan_raw); (void)hipFree(c->d_scan_world); (void)hipFree(c->d_scan_t);
   (void)hipFree(c->d_frames); (void)hipFree(c->d_recs); (void)hipFree(c->d_dbg);
-  (void)hipFree(c->d_fine_tmp); (void)hipFree(c->d_fine_pts); (void)hipFree(c->d_fine_segs);
+  (void)hipFree(c->d_fine_tmp); (void)hipFree(c->d_fine_pts); 
   (void)hipFree(c->d_fine_count); (void)hipFree(c->d_crowd_list); (void)hipFree(c->d_crowd_count); (void)hipFree(c->d_crowd_bits);
   (void)hipFree(c->d_tkey[0]); (void)hipFree(c->d_tkey[1]); (void)hipFree(c->d_tperm); (void)hipFree(c->d_t_tmp);
   (void)hipFree(c->d_raw32); (void)hipFree(c->d_filt_ext); (void)hipFree(c->d_nbrk); (void)hipFree(c->d_tie_list); (void)hipFree(c->d_tie_count);
@@ -555,20 +550,6 @@ static bool grid_covers(const GridView& g, const float* bb) {
   }
   return true;
 }
-// capacity of the index tables of a grid of nxf x ny x nz columns (geometric growth: a map that keeps extending does not
-// reallocate per scan); *grew: a table was reallocated
-template <typename T>
-static int ensure_table(flimo_ctx* c, T*& p, size_t& cap, size_t need, bool* grew) {
-  if (need <= cap) return FLIMO_OK;
-  if (p) (void)hipFree(p);
-  p = nullptr;
-  const size_t ncap = need + need / 2;
-  HIPCHK(c, hipMalloc(&p, ncap * sizeof(T)));
-  cap = ncap;
-  if (grew) *grew = true;
-  return FLIMO_OK;
-}
-
 // Second level: (re)built after every index update.  Cheap when no cell is crowded (one pass over the cell table).
 // `relayout`: the geometry is new -> every cell is looked at; otherwise only the cells of the n_new points merged since the last look.
 static int update_fine_grid(flimo_ctx* c, bool relayout, const float4* new_pts = nullptr, size_t n_new = 0) {
@@ -657,26 +638,20 @@ static int update_fine_grid(flimo_ctx* c, bool relayout, const float4* new_pts =
     c->fine_pts_cap = cap;
   }
   HIPCHK(c, map_box_copy(c->stream, g, c0, c1, c->d_fine_tmp, c->scratch));
-  {
-    int rc;
-    if ((rc = ensure_table(c, c->d_fine_segs, c->fine_segs_cap, segs_size(nf[0], nf[1], nf[2]), nullptr))) return rc;
-    if ((rc = ensure_table(c, c->d_fine_rs, c->fine_rs_cap, row_start_size(nf[1], nf[2]), nullptr))) return rc;
-    if ((rc = ensure_table(c, c->d_fine_ovf, c->fine_ovf_cap, (c->fine_pts_cap / 16 + 64) * 8, nullptr))) return rc;
-    if (!c->d_fine_ovf_count) HIPCHK(c, hipMalloc(&c->d_fine_ovf_count, sizeof(uint32_t)));
-  }
-  const IndexTables Tf{c->d_fine_segs, c->d_fine_ovf, c->d_fine_ovf_count, (uint32_t)(c->fine_ovf_cap / 8), c->d_fine_rs};
-  HIPCHK(c, map_build_grid(c->stream, c->d_fine_tmp, m, c->d_fine_pts, Tf, of[0], of[1], of[2], inv_f, nf[0], nf[1], nf[2], 1, c->scratch));
+  HIPCHK(c, map_build_grid(c->stream, c->d_fine_tmp, m, c->d_fine_pts, c->fine_idx, c->fine_pts_cap, of[0], of[1], of[2], inv_f, nf[0], nf[1], nf[2], 1,
+                           c->scratch));
   if (prof) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     fprintf(stderr, "[flimo fine] crowded cells + count %.1f us, copy + sort + tables of %d x %d x %d cells %.1f us (%u points)\n",
             (tp1 - tp0) * 1e6, nf[0], nf[1], nf[2], (now() - tp1) * 1e6, m);
   }
   GridView& f = c->fine;
-  f.pts = c->d_fine_pts; f.segs = c->d_fine_segs; f.ovf = c->d_fine_ovf; f.row_start = c->d_fine_rs;
+  f.pts = c->d_fine_pts;
   f.ox = of[0]; f.oy = of[1]; f.oz = of[2];
   f.inv_cell = inv_f; f.cell = cf;
   f.nx = nf[0]; f.ny = nf[1]; f.nz = nf[2];
-  f.n_pts = m; f.xs = 1; f.nxf = nf[0]; f.nxs = nf[0] + 1; f.nseg = (int)grid_nseg(nf[0]);
+  f.n_pts = m; f.xs = 1; f.nxf = nf[0]; f.nxs = nf[0] + 1;
+  index_view(c->fine_idx, f);
   // a query may be settled here when its fine 3x3x3 block lies inside [lo, hi): fine cell 1 starts at lo, so the query's own cell
   // is >= 2; on the upper side one more cell of safety against the rounding of (hi - of) * inv_f
   for (int a = 0; a < 3; a++) {
@@ -704,8 +679,7 @@ static int rebuild_grid(flimo_ctx* c) {
     c->grid_valid = false;
     if (!c->d_map_sorted2) HIPCHK(c, hipMalloc(&c->d_map_sorted2, c->map_cap * sizeof(float4)));
     const GridView& g = c->grid;
-    const IndexTables T{c->d_segs, c->d_ovf, c->d_ovf_count, (uint32_t)(c->ovf_cap / 8), c->d_row_start};
-    HIPCHK(c, map_merge_grid(c->stream, c->d_map_sorted, n_old, c->d_map_raw + n_old, k, c->d_map_sorted2, T,
+    HIPCHK(c, map_merge_grid(c->stream, c->d_map_sorted, n_old, c->d_map_raw + n_old, k, c->d_map_sorted2, c->idx,
                              g.ox, g.oy, g.oz, g.inv_cell, g.nx, g.ny, g.nz, g.xs, c->scratch));
     // (no wait here: everything that reads the index is queued behind this on the same stream; map_add_device ends synchronised)
     std::swap(c->d_map_sorted, c->d_map_sorted2);
@@ -736,7 +710,7 @@ static int rebuild_grid(flimo_ctx* c) {
     // both indices stay 32-bit addressable; the fine x columns are given up first (xs = preferred .. 1), then the cell grows
     for (xs = c->xslabs; xs >= 1; xs >>= 1) {
       const double ncols = (double)ny * (double)nz * ((double)nx * xs + 1.0);              // (32-bit column keys)
-      if (ncols < 1.9e9 && (double)segs_size(nx * xs, ny, nz) < 4.0e9) return true;
+      if (ncols < 1.9e9) return true;
     }
     xs = 1;
     return false;
@@ -761,26 +735,16 @@ static int rebuild_grid(flimo_ctx* c) {
   for (int a = 0; a < 6; a++) c->gbox[a] = W[a];
   c->have_gbox = true;
   if (!c->d_map_sorted) HIPCHK(c, hipMalloc(&c->d_map_sorted, c->map_cap * sizeof(float4)));   // mirrors the raw capacity (freed whenever that grows)
-  {
-    int rc;
-    if ((rc = ensure_table(c, c->d_segs, c->segs_cap, segs_size(nx * xs, ny, nz), nullptr))) return rc;
-    if ((rc = ensure_table(c, c->d_row_start, c->rowstart_cap, row_start_size(ny, nz), nullptr))) return rc;
-    // (one escape slot per 16 points the point buffer can hold: a segment escapes when a column holds more than 15)
-    if ((rc = ensure_table(c, c->d_ovf, c->ovf_cap, (c->map_cap / 16 + 64) * 8, nullptr))) return rc;
-    if (!c->d_ovf_count) HIPCHK(c, hipMalloc(&c->d_ovf_count, sizeof(uint32_t)));
-  }
-  const IndexTables T{c->d_segs, c->d_ovf, c->d_ovf_count, (uint32_t)(c->ovf_cap / 8), c->d_row_start};
-  HIPCHK(c, map_build_grid(c->stream, c->d_map_raw, c->map_n, c->d_map_sorted, T, ox, oy, oz, inv, nx, ny, nz, xs, c->scratch));
+  HIPCHK(c, map_build_grid(c->stream, c->d_map_raw, c->map_n, c->d_map_sorted, c->idx, c->map_cap, ox, oy, oz, inv, nx, ny, nz, xs, c->scratch));
+  c->scratch.mail_host[MAIL_TILES + 2] = c->scratch.mail_host[MAIL_TILES + 3] = 0u;      // (the merges' words: tiles taken, "ran out")
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->grid.pts = c->d_map_sorted;
-  c->grid.segs = c->d_segs;
-  c->grid.ovf = c->d_ovf;
-  c->grid.row_start = c->d_row_start;
   c->grid.ox = ox; c->grid.oy = oy; c->grid.oz = oz;
   c->grid.inv_cell = inv;
   c->grid.cell = cell;
   c->grid.nx = nx; c->grid.ny = ny; c->grid.nz = nz;
-  c->grid.xs = xs; c->grid.nxf = nx * xs; c->grid.nxs = nx * xs + 1; c->grid.nseg = (int)grid_nseg(nx * xs);
+  c->grid.xs = xs; c->grid.nxf = nx * xs; c->grid.nxs = nx * xs + 1;
+  index_view(c->idx, c->grid);
   c->grid.n_pts = (uint32_t)c->map_n;
   c->grid_valid = true;
   c->force_full = false;
@@ -800,19 +764,13 @@ extern "C" int flimo_map_grid_selfcheck(flimo_ctx* c, uint64_t* mismatches, uint
   const size_t n = c->map_n;
   if (g.n_pts != n) { *mismatches = 1; return FLIMO_OK; }
   struct Tmp {
-    float4* pts = nullptr; uint2* segs = nullptr; uint32_t* ovf = nullptr; uint32_t* cnt = nullptr; uint32_t* rs = nullptr; unsigned long long* diff = nullptr;
-    ~Tmp() { (void)hipFree(pts); (void)hipFree(segs); (void)hipFree(ovf); (void)hipFree(cnt); (void)hipFree(rs); (void)hipFree(diff); }
+    float4* pts = nullptr; unsigned long long* diff = nullptr; IndexTables idx;
+    ~Tmp() { (void)hipFree(pts); (void)hipFree(diff); index_free(idx); }
   } t;
-  const size_t ovf_slots = n / 16 + 64;
   HIPCHK(c, hipMalloc(&t.pts, n * sizeof(float4)));
-  HIPCHK(c, hipMalloc(&t.segs, segs_size(g.nxf, g.ny, g.nz) * sizeof(uint2)));
-  HIPCHK(c, hipMalloc(&t.ovf, ovf_slots * 8 * sizeof(uint32_t)));
-  HIPCHK(c, hipMalloc(&t.cnt, sizeof(uint32_t)));
-  HIPCHK(c, hipMalloc(&t.rs, row_start_size(g.ny, g.nz) * sizeof(uint32_t)));
   HIPCHK(c, hipMalloc(&t.diff, sizeof(unsigned long long)));
   HIPCHK(c, hipMemsetAsync(t.diff, 0, sizeof(unsigned long long), c->stream));
-  const IndexTables Tt{t.segs, t.ovf, t.cnt, (uint32_t)ovf_slots, t.rs};
-  HIPCHK(c, map_build_grid(c->stream, c->d_map_raw, n, t.pts, Tt, g.ox, g.oy, g.oz, g.inv_cell, g.nx, g.ny, g.nz, g.xs, c->scratch));
+  HIPCHK(c, map_build_grid(c->stream, c->d_map_raw, n, t.pts, t.idx, n, g.ox, g.oy, g.oz, g.inv_cell, g.nx, g.ny, g.nz, g.xs, c->scratch));
   // the points bit for bit; the index by meaning (every row's start, every column's count: escapes take their slots in arrival order)
   {
     const size_t bytes = n * sizeof(float4);
@@ -823,7 +781,8 @@ extern "C" int flimo_map_grid_selfcheck(flimo_ctx* c, uint64_t* mismatches, uint
     for (size_t i = 0; i + 4 <= bytes; i += 4) *mismatches += memcmp(&ha[i], &hb[i], 4) != 0;
   }
   GridView ref = g;
-  ref.pts = t.pts; ref.segs = t.segs; ref.ovf = t.ovf; ref.row_start = t.rs;
+  ref.pts = t.pts;
+  index_view(t.idx, ref);
   HIPCHK(c, index_compare(c->stream, ref, g, t.diff));
   unsigned long long d = 0;
   HIPCHK(c, hipMemcpyAsync(&d, t.diff, sizeof(d), hipMemcpyDeviceToHost, c->stream));
@@ -884,6 +843,14 @@ static int map_add_device(flimo_ctx* c, const float4* d_pts, size_t m, double st
     }
     // ends synchronised: the book's node count (left in the mail words) is taken over behind the same wait
     HIPCHK(c, c->gbook.finish(c->stream, c->scratch));
+    if (c->grid_valid && index_merge_overflow(c->scratch)) {
+      // the merge needed more tiles than the pool had room for: lay the index out afresh (sized by what the map needs now)
+      c->force_full = true;
+      c->index_overflows++;
+      rc = rebuild_grid(c);
+      if (rc) return rc;
+    }
+    c->idx.tiles_used = std::max(c->idx.tiles_used, c->scratch.mail_host[MAIL_TILES + 2]);
     t3 = prof ? now() : 0.0;
   }
   if (prof) fprintf(stderr, "[flimo insert] bbox %.0f us, book %.0f us, grid %.0f us (batch %zu, map %zu)\n", t1 - t0, t2 - t1, t3 - t2, m, c->map_n);
@@ -1453,15 +1420,18 @@ extern "C" int flimo_fine_stats(const flimo_ctx* c, unsigned long long out[4]) {
   out[0] = c->fine_valid ? 1 : 0; out[1] = c->fine_valid ? c->fine.n_pts : 0; out[2] = c->fine_builds; out[3] = c->fine_passes;
   return FLIMO_OK;
 }
-extern "C" int flimo_map_index_bytes(const flimo_ctx* c, uint64_t out[3]) {
+extern "C" int flimo_map_index_bytes(const flimo_ctx* c, uint64_t out[5]) {
   if (!c || !out) return FLIMO_ERR_INVALID;
   out[0] = (uint64_t)c->map_n * sizeof(float4);
-  // (segment table + rows' starts + the escape pool as allocated)
-  auto tables = [](const GridView& g, size_t ovf_words) {
-    return (uint64_t)segs_size(g.nxf, g.ny, g.nz) * 8ull + (uint64_t)(row_start_size(g.ny, g.nz) + ovf_words) * 4ull;
+  // (the tiles that exist + the zero tile, the directory, xstart, the escape pool as allocated)
+  auto tables = [](const GridView& g, const IndexTables& T) {
+    return (uint64_t)T.tiles_used * grid_tile_entries(g.ts, g.ty, g.tz) * 8ull + (uint64_t)GRID_DIR_MAX * 2ull +
+           (uint64_t)(grid_xstart_size(g.ny, g.nz, g.ntx) + T.ovf_cap) * 4ull;
   };
-  out[1] = c->grid_valid ? tables(c->grid, c->ovf_cap) : 0ull;
-  out[2] = c->fine_valid ? (uint64_t)c->fine.n_pts * sizeof(float4) + tables(c->fine, c->fine_ovf_cap) : 0ull;
+  out[1] = c->grid_valid ? tables(c->grid, c->idx) : 0ull;
+  out[2] = c->fine_valid ? (uint64_t)c->fine.n_pts * sizeof(float4) + tables(c->fine, c->fine_idx) : 0ull;
+  out[3] = c->grid_valid ? c->idx.tiles_used : 0ull;
+  out[4] = c->index_overflows;
   return FLIMO_OK;
 }
 extern "C" int flimo_tie_stats(flimo_ctx* c, unsigned long long out[2]) {

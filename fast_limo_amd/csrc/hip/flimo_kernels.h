@@ -123,7 +123,7 @@ struct MapBuildScratch {
   unsigned long long* filt_mail_dev = nullptr;
 };
 // slots of the mail words
-enum MailSlot { MAIL_BOOK = 0 /* 6 */, MAIL_BOOK_END = 8 /* 2 */, MAIL_CROWD = 12, MAIL_BOXCOUNT = 13, MAIL_BBOX = 16 /* 6 */, MAIL_VOXEL = 24 /* 2 */,
+enum MailSlot { MAIL_BOOK = 0 /* 6 */, MAIL_BOOK_END = 8 /* 2 */, MAIL_CROWD = 12, MAIL_BOXCOUNT = 13, MAIL_BBOX = 16 /* 6 */, MAIL_VOXEL = 24 /* 4 */, MAIL_TILES = 28 /* build: tiles, overflow; merge: tiles, overflow */,
                 MAIL_TAG = 62 /* number of the last mail_words, written behind its words */, MAIL_WORDS = 64 };
 struct MailPart { const void* src; int n; int dst; };
 // queues ONE small kernel that copies up to 6 runs of words into the mail slots; `rearm_bbox`: S.bbox is reset to the empty box
@@ -141,22 +141,35 @@ hipError_t sort_scan(hipStream_t st, const float4* in, size_t n, float4* out, Ma
                      const double* t_in = nullptr, double* t_out = nullptr);
 // the same layout without re-ordering (out[i] = (xyz, w = i)): for a sweep a voxel filter re-orders anyway
 hipError_t index_scan(hipStream_t st, const float4* in, size_t n, float4* out, const double* t_in, double* t_out);
-// The index of a grid (GridView, flimo_types.h): segs[segs_size], row_start[row_start_size], and the pool of escapes
-// (ovf[ovf_cap][8], *ovf_count slots taken: one slot per 16 points of the point buffer's capacity is always enough).
-struct IndexTables { uint2* segs; uint32_t* ovf; uint32_t* ovf_count; uint32_t ovf_cap; uint32_t* row_start; };
-size_t segs_size(int nxf, int ny, int nz);
-size_t row_start_size(int ny, int nz);
-// Sorts `pts_in` by (z, y, fine x column) into `pts_out` and fills the index.
-hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4* pts_out, const IndexTables& T,
+// The index of a grid (GridView, flimo_types.h) as the host owns it: the pool of tiles (tile 0: all zero), the directory, the
+// escape pool (one slot per 16 points of the point buffer's capacity is always enough) and xstart.  map_build_grid sizes and
+// (re)allocates all of it; map_merge_grid takes tiles from the pool's room and reports when it ran out (index_merge_overflow).
+struct IndexTables {
+  uint2* tiles = nullptr; size_t tiles_cap_entries = 0;
+  uint32_t cap_tiles = 0, tiles_used = 0;                 // tiles of the current shape the pool holds / numbers taken at the last build
+  uint16_t* dir = nullptr;                                // GRID_DIR_MAX entries
+  uint32_t* need = nullptr;                               // GRID_DIR_MAX words: tiles a batch of new points needs
+  uint32_t* counters = nullptr;                           // [0] next free tile number, [1] a merge ran out of tiles, [2] escape slots taken
+  uint32_t* ovf = nullptr; size_t ovf_cap = 0;            // words (8 per slot)
+  uint32_t* xstart = nullptr; size_t xstart_cap = 0;
+};
+void index_free(IndexTables& T);
+// Sorts `pts_in` by (z, y, fine x column) into `pts_out` and builds the index (ends synchronised: the pool is sized by the number
+// of tiles the points need).  pts_cap: capacity of the point buffer the index is for.
+hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4* pts_out, IndexTables& T, size_t pts_cap,
                           float ox, float oy, float oz, float inv_cell, int nx, int ny, int nz, int xs,
                           MapBuildScratch& S);
+// fills the table pointers and the tile shape of a GridView whose geometry (nx, ny, nz, xs, nxf) is set
+void index_view(const IndexTables& T, GridView& G);
+// after the stream has been waited for: did a merge since the last build run out of tiles (the index is then incomplete)?
+bool index_merge_overflow(const MapBuildScratch& S);
 // debug: *diff_dev += the number of (row, column) pairs at which two indices of the same geometry differ
 hipError_t index_compare(hipStream_t st, const GridView& A, const GridView& B, unsigned long long* diff_dev);
 // Merges the k points appended since the last build into the cell-sorted array (same geometry): out_sorted and the tables
 // become what map_build_grid gives for all n_old + k points.  The index is updated in place -- the rows' starts, and the
 // entries of the rows that received points: O(rows + touched rows x row length), not O(cells); out_sorted != old_sorted.
 hipError_t map_merge_grid(hipStream_t st, const float4* old_sorted, size_t n_old, const float4* new_pts, size_t k,
-                          float4* out_sorted, const IndexTables& T, float ox, float oy, float oz,
+                          float4* out_sorted, IndexTables& T, float ox, float oy, float oz,
                           float inv_cell, int nx, int ny, int nz, int xs, MapBuildScratch& S);
 // Input filters of a raw sweep (32-byte PointType records already on the device): NaN removal, crop box, every rate-th survivor,
 // min distance; order preserved.  out[k] = (xyz, w = k), t_out[k] = stamp without the sweep offset; ext_dev[4] = {extreme ordered

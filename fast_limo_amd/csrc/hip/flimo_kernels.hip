@@ -121,7 +121,7 @@ FLIMO_DEV void visit_row(const GridView& G, int cx, int cy, int cz, int dy, int 
     const int x0 = max(cx - r, 0), x1 = min(cx + r, G.nx - 1);
     if (x0 <= x1) {
       uint32_t lo, hi;
-      grid_row_range(G, cy + dy, cz + dz, x0 * G.xs, (x1 + 1) * G.xs, lo, hi);
+      grid_row_range(G, G.dir, cy + dy, cz + dz, x0 * G.xs, (x1 + 1) * G.xs, lo, hi);
       scan_range<L, K>(G.pts, lo, hi, sub, gx, gy, gz, R.bd, R.bi, R.cand);
     }
   } else {
@@ -131,7 +131,7 @@ FLIMO_DEV void visit_row(const GridView& G, int cx, int cy, int cz, int dy, int 
       const float sx = fmaxf(slab_dist(-(r_prev + 1), rx) - margin, 0.f);
       if (x0 <= x1 && (sx * sx + yz2) * cell2 < fminf(bound, R.bd[K - 1])) {
         uint32_t lo, hi;
-        grid_row_range(G, cy + dy, cz + dz, x0 * G.xs, (x1 + 1) * G.xs, lo, hi);
+        grid_row_range(G, G.dir, cy + dy, cz + dz, x0 * G.xs, (x1 + 1) * G.xs, lo, hi);
         scan_range<L, K>(G.pts, lo, hi, sub, gx, gy, gz, R.bd, R.bi, R.cand);
       }
     }
@@ -140,7 +140,7 @@ FLIMO_DEV void visit_row(const GridView& G, int cx, int cy, int cz, int dy, int 
       const float sx = fmaxf(slab_dist(r_prev + 1, rx) - margin, 0.f);
       if (x0 <= x1 && (sx * sx + yz2) * cell2 < fminf(bound, R.bd[K - 1])) {
         uint32_t lo, hi;
-        grid_row_range(G, cy + dy, cz + dz, x0 * G.xs, (x1 + 1) * G.xs, lo, hi);
+        grid_row_range(G, G.dir, cy + dy, cz + dz, x0 * G.xs, (x1 + 1) * G.xs, lo, hi);
         scan_range<L, K>(G.pts, lo, hi, sub, gx, gy, gz, R.bd, R.bi, R.cand);
       }
     }
@@ -199,7 +199,7 @@ FLIMO_DEV void knn_search(const GridView& G, float gx, float gy, float gz, int s
         const int yy = cy + dy, zz = cz + dz;
         const bool in = (yy >= 0) && (yy < G.ny) && (zz >= 0) && (zz < G.nz) && (x0 <= x1);
         lo[t] = 0u; hi[t] = 0u;
-        if (in) grid_row_range(G, yy, zz, x0 * G.xs, (x1 + 1) * G.xs, lo[t], hi[t]);
+        if (in) grid_row_range(G, G.dir, yy, zz, x0 * G.xs, (x1 + 1) * G.xs, lo[t], hi[t]);
       }
 #pragma unroll
       for (int t = 0; t < 9; t++) {
@@ -479,7 +479,7 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ void knn5_tail(const GridView& G, int max_ring, NbrRec* __restrict__ nbr, bool pending, int p,
+__device__ __forceinline__ void knn5_tail(const GridView& G, const uint16_t* dir, int max_ring, NbrRec* __restrict__ nbr, bool pending, int p,
                                           float gx, float gy, float gz, uint32_t hint_bits, float b2, WaveLds& S,
                                           int* __restrict__ straggler_count, unsigned long long* __restrict__ cand_total,
                                           bool keep_res, const TieList& tl) {
@@ -569,7 +569,7 @@ __device__ __forceinline__ void knn5_tail(const GridView& G, int max_ring, NbrRe
                 const int dl = (int)fminf(floorf(fminf(xr + (1.f - rx), 1.0e6f)), (float)r);
                 const int x0 = max(cx - dl, 0), x1 = min(cx + dr, G.nx - 1);
                 if (x0 <= x1) {
-                  grid_row_range(G, yy, zz, x0 * G.xs, (x1 + 1) * G.xs, lo4[u], hi4[u]);
+                  grid_row_range(G, dir, yy, zz, x0 * G.xs, (x1 + 1) * G.xs, lo4[u], hi4[u]);
                 }
               }
             }
@@ -877,10 +877,28 @@ __device__ __forceinline__ void tie_repair_wave(const GridView& G, const BookVie
 #else
 #define KNN_WPE
 #endif
+// The directory of the index (GridView) in the workgroup's shared memory: at most GRID_DIR_MAX 16-bit entries = 512 x 16 bytes, two
+// 16-byte loads per thread (the host pads the directory to a multiple of 16 bytes).  Fetch and store are separate so that a launch
+// can have the loads in flight while it fetches its query; the store is followed by a barrier (every thread of the workgroup).
+struct DirRegs { uint4 a, b; };
+__device__ __forceinline__ DirRegs grid_dir_fetch(const GridView& G) {
+  const int n16 = (G.ntx * G.nty * G.ntz + 7) >> 3;
+  const uint4* src = reinterpret_cast<const uint4*>(G.dir);
+  DirRegs r;
+  r.a = (int)threadIdx.x < n16 ? src[threadIdx.x] : make_uint4(0u, 0u, 0u, 0u);
+  r.b = (int)threadIdx.x + 256 < n16 ? src[threadIdx.x + 256] : make_uint4(0u, 0u, 0u, 0u);
+  return r;
+}
+__device__ __forceinline__ void grid_dir_store(uint16_t* s_dir, const DirRegs& r) {
+  uint4* dst = reinterpret_cast<uint4*>(s_dir);
+  dst[threadIdx.x] = r.a;
+  dst[threadIdx.x + 256] = r.b;
+  __syncthreads();
+}
 // The pass's body, shared by the two kernels below: a host-driven pass gets its pose constants by value (kernel arguments), a
 // chained pass (flimo_chain.h) reads them from the device filter's head -- same code, the constants come from another address.
 template <int L, int SLOTS, bool FUSE, bool FINE = false>
-__device__ __forceinline__ void knn5_pass(const GridView& G, const float4* __restrict__ scan_sorted, int n,
+__device__ __forceinline__ void knn5_pass(const GridView& G, uint16_t* dir, const DirRegs* dir_pending, const float4* __restrict__ scan_sorted, int n,
                                           const PoseMats& P, int max_ring, NbrRec* __restrict__ nbr,
                                           int* __restrict__ wl, int* __restrict__ wl_count,
                                           unsigned long long* __restrict__ cand_total, const float* __restrict__ prev_RT, int prev_valid,
@@ -943,6 +961,8 @@ __device__ __forceinline__ void knn5_pass(const GridView& G, const float4* __res
   } else {
     sp = scan_sorted[in_range ? p : 0];
   }
+  // (the directory's loads were issued before the query's: into shared memory now, behind a barrier)
+  if (dir_pending) grid_dir_store(dir, *dir_pending);
   float gx, gy, gz;
   xform4(P.RT, sp.x, sp.y, sp.z, gx, gy, gz);
   TRACE(0, 1);
@@ -1022,16 +1042,27 @@ __device__ __forceinline__ void knn5_pass(const GridView& G, const float4* __res
       }
       c0 = min(max(c0, 0), G.nxf);
       c1 = min(max(c1, c0), G.nxf);
-      const uint32_t py = (uint32_t)G.ny + 2u * GRID_PAD;
-      const uint32_t yz = (uint32_t)(cz + GRID_PAD - 1) * py + (uint32_t)(cy + GRID_PAD - 1);      // padded row (cy - 1, cz - 1)
+      const uint32_t py0 = (uint32_t)(cy + GRID_PAD - 1), pz0 = (uint32_t)(cz + GRID_PAD - 1);      // padded row (cy - 1, cz - 1)
       const uint32_t sg0 = (uint32_t)c0 >> 3;                   // entry of the range's first column
+      const uint32_t tx0 = sg0 >> G.ts;
+      // the nine rows' entries: tile (directory in shared memory) -> the two neighbouring entries of the row inside the tile
+      uint32_t eidx[9];                  // (32-bit: the host keeps the pool below 2^32 entries)
+#pragma unroll
+      for (int t = 0; t < 9; t++) {
+        const uint32_t py_ = py0 + (uint32_t)(t % 3), pz_ = pz0 + (uint32_t)(t / 3);
+        eidx[t] = (uint32_t)grid_entry_index(G, (uint32_t)dir[grid_dir_index(G, py_, pz_, sg0)], py_, pz_, sg0);
+      }
       // First pass of a scan (no bound from a previous pass): a query whose OWN cell is crowded (raw sweeps inserted into the
       // map leave cells with tens to hundreds of points) first walks that cell alone; its 5th distance there is an upper bound
       // of the true one, and the other 26 cells are then walked only as far as that ball reaches (rows and end cells it cannot
       // reach are dropped, exactly as with the bound of a previous pass).
       const bool probe_on = L == 2 && !prev_valid && prev_probe_min != 0u;          // wave-uniform
-      // (the entries count from their row's start; the nine rows' starts are three 12-byte loads in the same round trip --
-      //  pad rows: 0 + 0, an empty range)
+      // (the entries count from their row's first point in the tile's x range; those positions are three 12-byte loads of
+      //  `xstart` in the same round trip -- pad rows and tiles that do not exist: an empty range)
+      // conservative distances (cell units) to the neighbouring rows; without a bound every row is in
+      const float yd[3] = {fmaxf(ry - margin, 0.f), 0.f, fmaxf(1.f - ry - margin, 0.f)};
+      const float zd[3] = {fmaxf(rz - margin, 0.f), 0.f, fmaxf(1.f - rz - margin, 0.f)};
+      const float yd2[3] = {yd[0] * yd[0], 0.f, yd[2] * yd[2]}, zd2[3] = {zd[0] * zd[0], 0.f, zd[2] * zd[2]};
       U3 rbl[3], rbh[3], rsb[3];
       Seg2 own_e;                       // the centre row's two entries: the probe's own cell / column is read off them
       {
@@ -1039,9 +1070,10 @@ __device__ __forceinline__ void knn5_pass(const GridView& G, const float4* __res
 #pragma unroll
         for (int dz = 0; dz < 3; dz++) {
 #pragma unroll
-          for (int k = 0; k < 3; k++)
-            e[3 * dz + k] = *reinterpret_cast<const Seg2*>(G.segs + ((size_t)(yz + (uint32_t)dz * py + (uint32_t)k) * (size_t)G.nseg + sg0));
-          rsb[dz] = *reinterpret_cast<const U3*>(G.row_start + (yz + (uint32_t)dz * py));
+          for (int k = 0; k < 3; k++) {
+            e[3 * dz + k] = *reinterpret_cast<const Seg2*>(G.tiles + eidx[3 * dz + k]);
+          }
+          rsb[dz] = *reinterpret_cast<const U3*>(G.xstart + grid_xstart_index(G, py0, pz0 + (uint32_t)dz, tx0));
         }
         own_e = e[4];
         const uint32_t k0 = (uint32_t)c0 & 7u, k1 = (uint32_t)c1 & 7u;
@@ -1068,10 +1100,6 @@ __device__ __forceinline__ void knn5_pass(const GridView& G, const float4* __res
           rbh[dz].a = hi9[3 * dz] + rsb[dz].a; rbh[dz].b = hi9[3 * dz + 1] + rsb[dz].b; rbh[dz].c = hi9[3 * dz + 2] + rsb[dz].c;
         }
       }
-      // conservative distances (cell units) to the neighbouring rows; without a bound every row is in
-      const float yd[3] = {fmaxf(ry - margin, 0.f), 0.f, fmaxf(1.f - ry - margin, 0.f)};
-      const float zd[3] = {fmaxf(rz - margin, 0.f), 0.f, fmaxf(1.f - rz - margin, 0.f)};
-      const float yd2[3] = {yd[0] * yd[0], 0.f, yd[2] * yd[2]}, zd2[3] = {zd[0] * zd[0], 0.f, zd[2] * zd[2]};
       uint32_t off[10], dl[9];          // dl[t] = lo[t] - off[t]: stream position -> map position
       off[0] = 0;
 #pragma unroll
@@ -1176,7 +1204,7 @@ __device__ __forceinline__ void knn5_pass(const GridView& G, const float4* __res
               Seg2 e[9];
 #pragma unroll
               for (int t = 0; t < 9; t++)
-                e[t] = *reinterpret_cast<const Seg2*>(G.segs + ((size_t)(yz + (uint32_t)(t / 3) * py + (uint32_t)(t % 3)) * (size_t)G.nseg + sg0));
+                e[t] = *reinterpret_cast<const Seg2*>(G.tiles + eidx[t]);
               uint32_t lo9[9], hi9[9];
 #pragma unroll
               for (int t = 0; t < 9; t++) {
@@ -1315,7 +1343,7 @@ __device__ __forceinline__ void knn5_pass(const GridView& G, const float4* __res
     }
   }
   WaveLds& W = s_w[threadIdx.x >> 6];
-  if (tail) knn5_tail(G, max_ring, nbr, pend_tail && sub == 0, p, gx, gy, gz, (uint32_t)(best[4] >> 32), b2, W, wl_count, cand_total, FUSE, tl);
+  if (tail) knn5_tail(G, dir, max_ring, nbr, pend_tail && sub == 0, p, gx, gy, gz, (uint32_t)(best[4] >> 32), b2, W, wl_count, cand_total, FUSE, tl);
   TRACE(0, 5);
   if constexpr (FUSE) {
     // ---- fit + reduction of this wave's queries (one row per query, computed by the pair's first lane) ----
@@ -1355,7 +1383,9 @@ __global__ __launch_bounds__(256) KNN_WPE void knn5_kernel(GridView G, const flo
                                                    int* __restrict__ wl, int* __restrict__ wl_count,
                                                    unsigned long long* __restrict__ cand_total, PrevPass prev, int tail,
                                                    FuseArgs fa) {
-  knn5_pass<L, SLOTS, FUSE, FINE>(G, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand_total, prev.RT, prev.valid, prev.probe_min, tail, fa);
+  __shared__ __align__(16) uint16_t s_dir[GRID_DIR_MAX];
+  const DirRegs dr = grid_dir_fetch(G);
+  knn5_pass<L, SLOTS, FUSE, FINE>(G, s_dir, &dr, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand_total, prev.RT, prev.valid, prev.probe_min, tail, fa);
 }
 // How a launch of a chained pass gets the filter's head: a copy in the workgroup's shared memory (one word per thread), which the pass
 // reads its constants from.  wait_epoch == 0: the head was stored by an earlier launch on this stream (the algebra as a launch of
@@ -1425,9 +1455,16 @@ __global__ __launch_bounds__(256) KNN_WPE void knn5_chain_kernel(GridView G, con
                                                    int* __restrict__ wl, int* __restrict__ wl_count,
                                                    unsigned long long* __restrict__ cand_total, int prev_valid, unsigned probe_min, int tail,
                                                    FuseArgs fa, unsigned int wait_epoch) {
+  // (the directory of the map's index is copied while the launch may still be waiting for its pose: the map does not change
+  //  between the passes of a scan)
+  __shared__ __align__(16) uint16_t s_dir[GRID_DIR_MAX];
+  {
+    const DirRegs dr = grid_dir_fetch(G);
+    grid_dir_store(s_dir, dr);
+  }
   const ChainHead* Lh = chain_enter(H, wait_epoch, fa.ch.end_code);
   if (!Lh) return;
-  knn5_pass<L, SLOTS, FUSE, FINE>(G, scan_sorted, n, Lh->pose, max_ring, nbr, wl, wl_count, cand_total, Lh->prev_RT, prev_valid, probe_min, tail, fa);
+  knn5_pass<L, SLOTS, FUSE, FINE>(G, s_dir, nullptr, scan_sorted, n, Lh->pose, max_ring, nbr, wl, wl_count, cand_total, Lh->prev_RT, prev_valid, probe_min, tail, fa);
 }
 
 // Widening for the worklist (rare): ONE WAVE per query.  The (2r+1)^2 <= 49 rows of the ring-r block
@@ -1502,7 +1539,7 @@ __device__ __forceinline__ void widen_body(const GridView& G, int max_ring, NbrR
         }
         if (dyz2 <= bnd2 && yy >= 0 && yy < G.ny && zz >= 0 && zz < G.nz && x0 <= x1) {
           uint32_t hi_;
-          grid_row_range(G, yy, zz, x0 * G.xs, (x1 + 1) * G.xs, lo, hi_);
+          grid_row_range(G, G.dir, yy, zz, x0 * G.xs, (x1 + 1) * G.xs, lo, hi_);
           len = hi_ - lo;
         }
       }
@@ -2124,7 +2161,7 @@ __device__ bool tie_select_wave(const GridView& G, const BookView& B, float qx, 
         const int x0 = max(cx - dl, 0), x1 = min(cx + dr, G.nx - 1);
         if (x0 <= x1) {
           uint32_t lo, hi;
-          grid_row_range(G, yy, zz, x0 * G.xs, (x1 + 1) * G.xs, lo, hi);
+          grid_row_range(G, G.dir, yy, zz, x0 * G.xs, (x1 + 1) * G.xs, lo, hi);
           for (uint32_t i = lo; i < hi; i++) {
             const float4 p = G.pts[i];
             const float d = sqdist3(qx, qy, qz, p.x, p.y, p.z);

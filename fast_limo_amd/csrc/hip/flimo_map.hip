@@ -178,10 +178,7 @@ hipError_t map_bbox(hipStream_t st, const float4* pts, size_t n, MapBuildScratch
   return hipSuccess;
 }
 
-// ---- the segment table (GridView, flimo_types.h) ----------------------------------------------------------------------------
-size_t segs_size(int nxf, int ny, int nz) { return grid_prows(ny, nz) * grid_nseg(nxf); }
-size_t row_start_size(int ny, int nz) { return grid_prows(ny, nz); }
-
+// ---- the index (GridView, flimo_types.h): directory, tiles of segment entries, xstart ----------------------------------------
 __device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t* __restrict__ keys, uint32_t lo, uint32_t hi, uint32_t key) {
   while (lo < hi) {
     const uint32_t mid = (lo + hi) >> 1;
@@ -208,28 +205,92 @@ __device__ __forceinline__ uint32_t wave_lower_bound_u32(const uint32_t* __restr
   return lo + (uint32_t)__popcll(__ballot(below));
 }
 
+// geometry of the index as the builders need it
+struct TabGeo { int nxs, ny, nz, ts, ty, tz, ntx, nty, ntz; };
+struct SegTab { uint2* tiles; const uint16_t* dir; uint32_t* ovf; uint32_t* ovf_count; uint32_t ovf_cap; uint32_t* xstart; TabGeo g; };
+__device__ __forceinline__ uint32_t tab_dir_index(const TabGeo& g, uint32_t py, uint32_t pz, uint32_t sg) {
+  return ((pz >> g.tz) * (uint32_t)g.nty + (py >> g.ty)) * (uint32_t)g.ntx + (sg >> g.ts);
+}
+// which tiles a batch of sorted column keys needs: the tile of each key's segment, and -- for a key in the FIRST segment of a
+// tile -- the tile to its left (whose last entry continues into that segment)
+__global__ __launch_bounds__(256) void tiles_mark_kernel(const uint32_t* __restrict__ keys, uint32_t n, TabGeo g, uint32_t* __restrict__ need) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t key = keys[i];
+  const uint32_t r = key / (uint32_t)g.nxs, sg = (key - r * (uint32_t)g.nxs) >> 3;
+  const uint32_t py = r % (uint32_t)g.ny + GRID_PAD, pz = r / (uint32_t)g.ny + GRID_PAD;
+  const uint32_t d = tab_dir_index(g, py, pz, sg);
+  need[d] = 1u;
+  if ((sg & ((1u << g.ts) - 1u)) == 0u && sg != 0u) need[d - 1u] = 1u;
+}
+// needed tiles that do not exist yet take the next numbers, in directory order (one workgroup: a scan over at most GRID_DIR_MAX
+// entries); counters[0] = next free number, counters[1] = 1 when the pool ran out (those tiles stay absent: the host lays the
+// index out afresh before anything reads it), mail[0..1] = the same two words for the host
+__global__ __launch_bounds__(256) void tiles_number_kernel(uint16_t* __restrict__ dir, uint32_t* __restrict__ need, int ndir, uint32_t cap_tiles,
+                                                           uint32_t* __restrict__ counters, uint32_t* __restrict__ mail, int fresh) {
+  __shared__ uint32_t s_scan[256];
+  const int t = (int)threadIdx.x;
+  constexpr int PER = GRID_DIR_MAX / 256;
+  uint32_t mine[PER], cnt = 0u;
+#pragma unroll
+  for (int k = 0; k < PER; k++) {
+    const int i = t * PER + k;
+    const bool want = i < ndir && need[i] != 0u && (fresh || dir[i] == 0);
+    mine[k] = want ? 1u : 0u;
+    cnt += mine[k];
+    if (i < ndir) { need[i] = 0u; if (fresh && !want) dir[i] = 0; }
+  }
+  s_scan[t] = cnt;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    const uint32_t v = (t >= o) ? s_scan[t - o] : 0u;
+    __syncthreads();
+    s_scan[t] += v;
+    __syncthreads();
+  }
+  const uint32_t first = fresh ? 1u : counters[0];
+  uint32_t num = first + s_scan[t] - cnt;
+  bool over = false;
+#pragma unroll
+  for (int k = 0; k < PER; k++) {
+    if (mine[k]) {
+      if (num < cap_tiles && num < 65536u) dir[t * PER + k] = (uint16_t)num; else over = true;
+      num++;
+    }
+  }
+  __syncthreads();
+  if (t == 255) { counters[0] = min(first + s_scan[255], cap_tiles); if (mail) mail[0] = first + s_scan[255]; }
+  if (over) { counters[1] = 1u; if (mail) mail[1] = 1u; }
+}
+
 // The entries of ONE row from its points' columns: a histogram of the row's columns in shared memory (windows of SEG_WIN
 // columns; a row's points are sorted by column), the segments' prefix sums by a scan over the workgroup, then one entry per
-// segment -- eight nibbles, or an escape (eight cumulative counts in `ovf`) when a column holds more than 15 points.  An escape
+// segment -- eight nibbles, or an escape (eight cumulative counts in `ovf`) when a column holds more than 15 points -- written
+// into the tiles that exist, counted from the row's first point in the tile; xstart gets the position of that point.  An escape
 // keeps the slot its entry already had (the map only grows: a segment that escaped stays one), a new one takes the next free slot.
-// cols(i) = column of the row's i-th point.
-constexpr int SEG_WIN = 4096;                                      // columns per window (a multiple of 8 * 256 / 1)
-struct SegTab { uint2* segs; uint32_t* ovf; uint32_t* ovf_count; uint32_t ovf_cap; int nseg; };
+// cols(i) = column of the row's i-th point; start = position of the row's first point in pts.
+constexpr int SEG_WIN = 4096;                                      // columns per window: 512 segments, two per thread
 template <typename ColOf>
-__device__ __forceinline__ void row_entries(const SegTab& T, uint32_t prow, uint32_t len, int nxf, ColOf cols, uint32_t* s_cnt /*[SEG_WIN]*/,
-                                            uint32_t* s_scan /*[256 + 1]*/) {
-  uint2* row = T.segs + (size_t)prow * (size_t)T.nseg;
+__device__ __forceinline__ void row_entries(const SegTab& T, uint32_t py, uint32_t pz, uint32_t start, uint32_t len, ColOf cols,
+                                            uint32_t* s_cnt /*[SEG_WIN + 8]*/, uint32_t* s_pre /*[513]*/, uint32_t* s_scan /*[256]*/) {
+  const TabGeo& g = T.g;
   const int t = (int)threadIdx.x;
+  const uint32_t TS = 1u << g.ts;
+  const int nseg = g.ntx << g.ts;                                  // segments of the directory's x extent
+  const uint32_t xrow = (pz * (uint32_t)g.ntx) * (uint32_t)(g.ny + 2 * GRID_PAD) + py;      // xstart index of x-tile 0
   uint32_t carry = 0u;                                             // points in the columns below the window
-  for (int w0 = 0; w0 < T.nseg * 8; w0 += SEG_WIN) {
-    for (int i = t; i < SEG_WIN; i += 256) s_cnt[i] = 0u;
+  uint32_t tbase = 0u;                                             // ... below the tile the window starts in (tiles longer than a window)
+  for (int w0 = 0; w0 < nseg * 8; w0 += SEG_WIN) {
+    if ((((uint32_t)w0 >> 3) & (TS - 1u)) == 0u) tbase = carry;
+    // (eight columns more than the window: the segment behind it, whose nibbles the closing entry of a tile that ends with the
+    //  window carries)
+    for (int i = t; i < SEG_WIN + 8; i += 256) s_cnt[i] = 0u;
     __syncthreads();
     for (uint32_t i = (uint32_t)t; i < len; i += 256u) {
       const int c = cols(i) - w0;
-      if (c >= 0 && c < SEG_WIN) atomicAdd(&s_cnt[c], 1u);
+      if (c >= 0 && c < SEG_WIN + 8) atomicAdd(&s_cnt[c], 1u);
     }
     __syncthreads();
-    // SEG_WIN / 8 = 512 segments per window: two per thread
     uint32_t tot[2];
 #pragma unroll
     for (int h = 0; h < 2; h++) {
@@ -240,40 +301,51 @@ __device__ __forceinline__ void row_entries(const SegTab& T, uint32_t prow, uint
     }
     s_scan[t] = tot[0] + tot[1];
     __syncthreads();
-    // exclusive scan of 256 values (Hillis-Steele in place, double buffered through registers)
     for (int o = 1; o < 256; o <<= 1) {
       const uint32_t v = (t >= o) ? s_scan[t - o] : 0u;
       __syncthreads();
       s_scan[t] += v;
       __syncthreads();
     }
-    const uint32_t incl = s_scan[t], excl = incl - (tot[0] + tot[1]);
+    const uint32_t excl = s_scan[t] - (tot[0] + tot[1]);
     const uint32_t win_total = s_scan[255];
+    s_pre[2 * t] = carry + excl;                                   // points of the row below segment (w0 / 8) + 2 t
+    s_pre[2 * t + 1] = carry + excl + tot[0];
+    if (t == 255) s_pre[512] = carry + win_total;
+    __syncthreads();
+    // entry of window segment i (0 .. 512) at `slot` of tile `tile`, counted from `base` points
+    auto put = [&](int i, uint32_t tile, uint32_t slot, uint32_t base) {
+      uint2* dst = T.tiles + ((((size_t)tile << (g.ty + g.tz)) + (size_t)(((pz & ((1u << g.tz) - 1u)) << g.ty) + (py & ((1u << g.ty) - 1u)))) * (TS + 1u) + slot);
+      const uint32_t pre = s_pre[i] - base;
+      uint32_t nib = 0u;
+      bool big = false;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const uint32_t v = s_cnt[i * 8 + k];
+        big = big || v > 15u;
+        nib |= (v & 15u) << (4 * k);
+      }
+      if (!big) { *dst = make_uint2(pre, nib); return; }
+      const uint2 old = *dst;
+      const uint32_t slot_o = ((int)old.x < 0) ? old.y : atomicAdd(T.ovf_count, 1u);
+      if (slot_o < T.ovf_cap) {            // (always: the pool holds one slot per 16 points of the point buffer's capacity)
+        uint32_t a = 0u;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { T.ovf[(size_t)slot_o * 8u + k] = a; a += s_cnt[i * 8 + k]; }
+        *dst = make_uint2(pre | 0x80000000u, slot_o);
+      }
+    };
 #pragma unroll
     for (int h = 0; h < 2; h++) {
-      const int sg = (w0 >> 3) + 2 * t + h;
-      if (sg < T.nseg) {
-        const uint32_t pre = carry + excl + (h ? tot[0] : 0u);
-        uint32_t nib = 0u;
-        bool big = false;
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-          const uint32_t v = s_cnt[(2 * t + h) * 8 + k];
-          big = big || v > 15u;
-          nib |= (v & 15u) << (4 * k);
-        }
-        if (!big) {
-          row[sg] = make_uint2(pre, nib);
-        } else {
-          const uint2 old = row[sg];
-          uint32_t slot = ((int)old.x < 0) ? old.y : atomicAdd(T.ovf_count, 1u);
-          if (slot < T.ovf_cap) {
-            uint32_t a = 0u;
-#pragma unroll
-            for (int k = 0; k < 8; k++) { T.ovf[(size_t)slot * 8u + k] = a; a += s_cnt[(2 * t + h) * 8 + k]; }
-            row[sg] = make_uint2(pre | 0x80000000u, slot);
-          }
-          // (slot >= cap cannot happen: the pool holds one slot per 16 points of the point buffer's capacity)
+      const int i = 2 * t + h, sg = (w0 >> 3) + i;
+      if (sg < nseg) {
+        const uint32_t sl = (uint32_t)sg & (TS - 1u);
+        if (sl == 0u) T.xstart[xrow + (uint32_t)(sg >> g.ts) * (uint32_t)(g.ny + 2 * GRID_PAD)] = start + s_pre[i];
+        const uint32_t tile = T.dir[tab_dir_index(g, py, pz, (uint32_t)sg)];
+        if (tile) {
+          const uint32_t base = (TS <= 512u) ? s_pre[i - (int)sl] : tbase;      // (a window is a whole number of tiles, or a part of one)
+          put(i, tile, sl, base);
+          if (sl == TS - 1u) put(i + 1, tile, TS, base);         // the closing entry: the segment behind the tile, same base
         }
       }
     }
@@ -282,20 +354,24 @@ __device__ __forceinline__ void row_entries(const SegTab& T, uint32_t prow, uint
   }
 }
 // Full build: one workgroup per row of the grid.  keys: the sorted column keys of all n points (key = row * nxs + column).
-__global__ __launch_bounds__(256) void rows_build_kernel(SegTab T, uint32_t* __restrict__ row_start, const uint32_t* __restrict__ keys, uint32_t n,
-                                                         int nxs, int ny) {
-  __shared__ uint32_t s_cnt[SEG_WIN], s_scan[257], s_lo, s_hi;
+__global__ __launch_bounds__(256) void rows_build_kernel(SegTab T, const uint32_t* __restrict__ keys, uint32_t n) {
+  __shared__ uint32_t s_cnt[SEG_WIN + 8], s_pre[513], s_scan[256], s_lo, s_hi;
+  const TabGeo& g = T.g;
   const uint32_t r = blockIdx.x;
-  const uint32_t first = r * (uint32_t)nxs;
+  const uint32_t first = r * (uint32_t)g.nxs;
   if (threadIdx.x < 64) { const uint32_t v = wave_lower_bound_u32(keys, n, first); if (threadIdx.x == 0) s_lo = v; }
-  else if (threadIdx.x < 128) { const uint32_t v = wave_lower_bound_u32(keys, n, first + (uint32_t)nxs); if (threadIdx.x == 64) s_hi = v; }
+  else if (threadIdx.x < 128) { const uint32_t v = wave_lower_bound_u32(keys, n, first + (uint32_t)g.nxs); if (threadIdx.x == 64) s_hi = v; }
   __syncthreads();
   const uint32_t lo = s_lo, hi = s_hi;
-  const uint32_t prow = (r / (uint32_t)ny + GRID_PAD) * (uint32_t)(ny + 2 * GRID_PAD) + (r % (uint32_t)ny + GRID_PAD);
-  if (threadIdx.x == 0) row_start[prow] = lo;
-  if (lo == hi) return;                                            // (the table was cleared: an empty row is all zero)
+  const uint32_t py = r % (uint32_t)g.ny + GRID_PAD, pz = r / (uint32_t)g.ny + GRID_PAD;
+  if (lo == hi) {
+    // an empty row: no entries (the pool was cleared), and every xstart = where its first point will go
+    const uint32_t xrow = (pz * (uint32_t)g.ntx) * (uint32_t)(g.ny + 2 * GRID_PAD) + py;
+    for (int tx = (int)threadIdx.x; tx < g.ntx; tx += 256) T.xstart[xrow + (uint32_t)tx * (uint32_t)(g.ny + 2 * GRID_PAD)] = lo;
+    return;
+  }
   const uint32_t* rk = keys + lo;
-  row_entries(T, prow, hi - lo, nxs - 1, [&](uint32_t i) { return (int)(rk[i] - first); }, s_cnt, s_scan);
+  row_entries(T, py, pz, lo, hi - lo, [&](uint32_t i) { return (int)(rk[i] - first); }, s_cnt, s_pre, s_scan);
 }
 static hipError_t sort_keys(hipStream_t st, size_t n, int bits, MapBuildScratch& S) {
   size_t tmp_bytes = 0;
@@ -310,13 +386,50 @@ static hipError_t sort_keys(hipStream_t st, size_t n, int bits, MapBuildScratch&
   }
   return sort_pairs_u32(S.cub_tmp, tmp_bytes, S.keys_in, S.keys_out, S.vals_in, S.vals_out, (int)n, 0, bits, st);
 }
-hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4* pts_out, const IndexTables& T,
+void index_view(const IndexTables& T, GridView& G) {
+  const TileShape t = grid_tile_shape(G.nxf, G.ny, G.nz);
+  G.tiles = T.tiles; G.dir = T.dir; G.ovf = T.ovf; G.xstart = T.xstart;
+  G.ts = t.ts; G.ty = t.ty; G.tz = t.tz; G.ntx = t.ntx; G.nty = t.nty; G.ntz = t.ntz;
+}
+bool index_merge_overflow(const MapBuildScratch& S) { return S.mail_host && S.mail_host[MAIL_TILES + 3] != 0u; }
+void index_free(IndexTables& T) {
+  (void)hipFree(T.tiles); (void)hipFree(T.dir); (void)hipFree(T.need); (void)hipFree(T.counters); (void)hipFree(T.ovf); (void)hipFree(T.xstart);
+  T = IndexTables{};
+}
+template <typename P>
+static hipError_t grow(P*& p, size_t& cap, size_t need, size_t slack) {
+  if (need <= cap) return hipSuccess;
+  if (p) (void)hipFree(p);
+  p = nullptr; cap = 0;
+  hipError_t e = hipMalloc(&p, (need + slack) * sizeof(P));
+  if (e == hipSuccess) cap = need + slack;
+  return e;
+}
+static TabGeo tab_geo(int nx, int ny, int nz, int xs, const TileShape& ts) {
+  return TabGeo{nx * xs + 1, ny, nz, ts.ts, ts.ty, ts.tz, ts.ntx, ts.nty, ts.ntz};
+}
+hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4* pts_out, IndexTables& T, size_t pts_cap,
                           float ox, float oy, float oz, float inv_cell, int nx, int ny, int nz, int xs,
                           MapBuildScratch& S) {
   const int nxf = nx * xs, nxs = nxf + 1;
   const size_t nrows = (size_t)ny * nz, ncols = nrows * (size_t)nxs;
+  const TileShape shape = grid_tile_shape(nxf, ny, nz);
+  const TabGeo g = tab_geo(nx, ny, nz, xs, shape);
+  const int ndir = shape.ntx * shape.nty * shape.ntz;
   hipError_t e = ensure_scratch(S, n);
   if (e != hipSuccess) return e;
+  if ((e = ensure_mail(S)) != hipSuccess) return e;
+  if (!T.dir) {
+    if ((e = hipMalloc(&T.dir, (GRID_DIR_MAX + 8) * sizeof(uint16_t))) != hipSuccess) return e;
+    if ((e = hipMalloc(&T.need, GRID_DIR_MAX * sizeof(uint32_t))) != hipSuccess) return e;
+    if ((e = hipMalloc(&T.counters, 4 * sizeof(uint32_t))) != hipSuccess) return e;
+  }
+  {
+    size_t slots = T.ovf_cap;
+    if ((e = grow(T.ovf, slots, (pts_cap / 16 + 64) * 8, 0)) != hipSuccess) return e;
+    T.ovf_cap = slots;
+    if ((e = grow(T.xstart, T.xstart_cap, grid_xstart_size(ny, nz, shape.ntx), grid_xstart_size(ny, nz, shape.ntx) / 2)) != hipSuccess) return e;
+  }
   const int blocks = (int)((n + 255) / 256);
   if (blocks > 0)
     hipLaunchKernelGGL(cellkey_kernel, dim3(blocks), dim3(256), 0, st, pts_in, n, ox, oy, oz, inv_cell, nx, ny, nz, xs,
@@ -327,11 +440,30 @@ hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4
     if ((e = sort_keys(st, n, bits, S)) != hipSuccess) return e;
     hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(256), 0, st, pts_in, S.vals_out, n, pts_out);
   }
-  if ((e = hipMemsetAsync(T.segs, 0, segs_size(nxf, ny, nz) * sizeof(uint2), st)) != hipSuccess) return e;
-  if ((e = hipMemsetAsync(T.row_start, 0, row_start_size(ny, nz) * sizeof(uint32_t), st)) != hipSuccess) return e;
-  if ((e = hipMemsetAsync(T.ovf_count, 0, sizeof(uint32_t), st)) != hipSuccess) return e;
-  const SegTab tab{T.segs, T.ovf, T.ovf_count, T.ovf_cap, (int)grid_nseg(nxf)};
-  hipLaunchKernelGGL(rows_build_kernel, dim3((unsigned)nrows), dim3(256), 0, st, tab, T.row_start, S.keys_out, (uint32_t)n, nxs, ny);
+  // which tiles exist, and their numbers (directory order); the host sizes the pool by their count
+  if ((e = hipMemsetAsync(T.need, 0, GRID_DIR_MAX * sizeof(uint32_t), st)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(T.dir, 0, (GRID_DIR_MAX + 8) * sizeof(uint16_t), st)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(T.counters, 0, 4 * sizeof(uint32_t), st)) != hipSuccess) return e;
+  if (n > 0) hipLaunchKernelGGL(tiles_mark_kernel, dim3(blocks), dim3(256), 0, st, S.keys_out, (uint32_t)n, g, T.need);
+  S.mail_host[MAIL_TILES] = 0u; S.mail_host[MAIL_TILES + 1] = 0u;
+  hipLaunchKernelGGL(tiles_number_kernel, dim3(1), dim3(256), 0, st, T.dir, T.need, ndir, 65536u, T.counters, S.mail_dev + MAIL_TILES, 1);
+  if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+  const size_t ntiles = S.mail_host[MAIL_TILES];                   // the zero tile + the tiles that exist
+  if (S.mail_host[MAIL_TILES + 1] || ntiles == 0) return hipErrorOutOfMemory;      // (more than 65535 tiles: the directory has at most 4096 entries)
+  const size_t te = grid_tile_entries(shape.ts, shape.ty, shape.tz);
+  {
+    // the pool in TILES of this shape; room for the map to grow into (a merge that runs out lays the index out afresh)
+    size_t cap_entries = T.tiles_cap_entries;
+    if ((e = grow(T.tiles, cap_entries, (ntiles + std::max<size_t>(8, ntiles / 4)) * te, 0)) != hipSuccess) return e;
+    T.tiles_cap_entries = cap_entries;
+  }
+  if ((ntiles + std::max<size_t>(8, ntiles / 4)) * te >= ((size_t)1 << 32)) return hipErrorOutOfMemory;      // (32-bit entry indices)
+  T.cap_tiles = (uint32_t)std::min<size_t>(std::min<size_t>(T.tiles_cap_entries, ((size_t)1 << 32) - 1) / te, 65536);
+  if ((e = hipMemsetAsync(T.tiles, 0, (size_t)T.cap_tiles * te * sizeof(uint2), st)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(T.xstart, 0, grid_xstart_size(ny, nz, shape.ntx) * sizeof(uint32_t), st)) != hipSuccess) return e;
+  const SegTab tab{T.tiles, T.dir, T.ovf, T.counters + 2, (uint32_t)(T.ovf_cap / 8), T.xstart, g};
+  hipLaunchKernelGGL(rows_build_kernel, dim3((unsigned)nrows), dim3(256), 0, st, tab, S.keys_out, (uint32_t)n);
+  T.tiles_used = (uint32_t)ntiles;
   return hipGetLastError();
 }
 
@@ -346,24 +478,29 @@ hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4
 // new point j (cell-sorted) -> behind the stored points of its cell: position = j + #stored points in cells <= key
 // stored point i (cell-sorted) -> i + #new points in cells < its cell
 // (one launch for both: the first `old_blocks` blocks move the stored points, the rest place the new ones; they write disjoint
-//  positions and read only the old tables)
+//  positions and read only the old index -- a tile that came into being for this batch is still all zero: "no stored point here")
 __global__ __launch_bounds__(256) void merge_points_kernel(const float4* __restrict__ old_pts, uint32_t n_old,
                                                            const uint32_t* __restrict__ nkeys, uint32_t k, float ox, float oy, float oz,
                                                            float inv_cell, int nx, int ny, int nz, int xs, float4* __restrict__ out,
                                                            uint32_t old_blocks, const float4* __restrict__ new_pts,
-                                                           const uint32_t* __restrict__ nperm, const uint2* __restrict__ segs_old,
-                                                           const uint32_t* __restrict__ ovf, const uint32_t* __restrict__ row_start_old,
-                                                           int nxs, int nseg) {
+                                                           const uint32_t* __restrict__ nperm, SegTab T) {
   __shared__ uint32_t s_lo, s_hi, s_c0, s_c1;
   if (blockIdx.x >= old_blocks) {
     const uint32_t j = (blockIdx.x - old_blocks) * blockDim.x + threadIdx.x;
     if (j >= k) return;
-    // (behind the stored points of its column: the row's start + the row's points in columns <= its own)
+    // (behind the stored points of its column: the row's points below the NEXT column)
+    const TabGeo& g = T.g;
     const uint32_t key = nkeys[j];
-    const uint32_t r = key / (uint32_t)nxs, col = key - r * (uint32_t)nxs + 1u;
-    const uint32_t prow = (r / (uint32_t)ny + GRID_PAD) * (uint32_t)(ny + 2 * GRID_PAD) + (r % (uint32_t)ny + GRID_PAD);
-    const uint2 e = segs_old[(size_t)prow * (size_t)nseg + (col >> 3)];
-    out[(size_t)row_start_old[prow] + (size_t)seg_count(e.x, e.y, col & 7u, ovf) + j] = new_pts[nperm[j]];
+    const uint32_t r = key / (uint32_t)g.nxs, col = key - r * (uint32_t)g.nxs + 1u, sg = col >> 3;
+    const uint32_t py = r % (uint32_t)g.ny + GRID_PAD, pz = r / (uint32_t)g.ny + GRID_PAD;
+    uint32_t pos = T.xstart[(pz * (uint32_t)g.ntx + (sg >> g.ts)) * (uint32_t)(g.ny + 2 * GRID_PAD) + py];
+    const uint32_t tile = T.dir[tab_dir_index(g, py, pz, sg)];
+    if (tile) {
+      const uint32_t TS = 1u << g.ts;
+      const uint2 e = T.tiles[(((size_t)tile << (g.ty + g.tz)) + (size_t)(((pz & ((1u << g.tz) - 1u)) << g.ty) + (py & ((1u << g.ty) - 1u)))) * (TS + 1u) + (sg & (TS - 1u))];
+      pos += seg_count(e.x, e.y, col & 7u, T.ovf);
+    }
+    out[(size_t)pos + j] = new_pts[nperm[j]];
     return;
   }
   const uint32_t base = blockIdx.x * blockDim.x;
@@ -386,41 +523,54 @@ __global__ __launch_bounds__(256) void merge_points_kernel(const float4* __restr
   const uint32_t shift = (lo == hi) ? lo : lower_bound_u32(nkeys, lo, hi, cid);
   out[(size_t)i + shift] = p;
 }
-// The table after a merge.  row_start[r] += #new points in rows < r (every row: the small table).  Entries change only inside the
+// The index after a merge.  Every xstart of row r += #new points in rows < r (the small table).  Entries change only inside the
 // rows that received points: one workgroup per row looks whether its row has new keys at all (a wave-wide search over the sorted
-// new keys) and leaves if not; a row that has rebuilds its entries from its points in the merged array (row_entries).
-__global__ __launch_bounds__(256) void rows_merge_kernel(SegTab T, uint32_t* __restrict__ row_start, const uint32_t* __restrict__ nkeys, uint32_t k,
+// new keys) and leaves if not; a row that has rebuilds its entries and its xstarts from its points in the merged array.
+__global__ __launch_bounds__(256) void rows_merge_kernel(SegTab T, const uint32_t* __restrict__ nkeys, uint32_t k,
                                                          const float4* __restrict__ merged, float ox, float oy, float oz, float inv_cell,
-                                                         int nx, int ny, int nz, int xs) {
-  __shared__ uint32_t s_cnt[SEG_WIN], s_scan[257], s_lo, s_hi;
-  const int nxs = nx * xs + 1;
+                                                         int nx, int xs) {
+  __shared__ uint32_t s_cnt[SEG_WIN + 8], s_pre[513], s_scan[256], s_lo, s_hi;
+  const TabGeo& g = T.g;
   const uint32_t r = blockIdx.x;
-  const uint32_t first = r * (uint32_t)nxs;
+  const uint32_t first = r * (uint32_t)g.nxs;
   if (threadIdx.x < 64) { const uint32_t v = wave_lower_bound_u32(nkeys, k, first); if (threadIdx.x == 0) s_lo = v; }
-  else if (threadIdx.x < 128) { const uint32_t v = wave_lower_bound_u32(nkeys, k, first + (uint32_t)nxs); if (threadIdx.x == 64) s_hi = v; }
+  else if (threadIdx.x < 128) { const uint32_t v = wave_lower_bound_u32(nkeys, k, first + (uint32_t)g.nxs); if (threadIdx.x == 64) s_hi = v; }
   __syncthreads();
   const uint32_t lo = s_lo, hi = s_hi;
-  const uint32_t prow = (r / (uint32_t)ny + GRID_PAD) * (uint32_t)(ny + 2 * GRID_PAD) + (r % (uint32_t)ny + GRID_PAD);
-  const uint32_t start = row_start[prow] + lo;
+  const uint32_t py = r % (uint32_t)g.ny + GRID_PAD, pz = r / (uint32_t)g.ny + GRID_PAD;
+  const uint32_t stride = (uint32_t)(g.ny + 2 * GRID_PAD);
+  const uint32_t xrow = (pz * (uint32_t)g.ntx) * stride + py;
   if (lo == hi) {
-    if (threadIdx.x == 0 && lo != 0u) row_start[prow] = start;
+    if (lo != 0u)
+      for (int tx = (int)threadIdx.x; tx < g.ntx; tx += 256) T.xstart[xrow + (uint32_t)tx * stride] += lo;
     return;
   }
-  // the row's length before the merge: its entry of column nxf
-  const uint2 e = T.segs[(size_t)prow * (size_t)T.nseg + (size_t)((nxs - 1) >> 3)];
-  const uint32_t len = seg_count(e.x, e.y, (uint32_t)(nxs - 1) & 7u, T.ovf) + (hi - lo);
-  __syncthreads();                                                 // (everybody has read the old entry)
-  if (threadIdx.x == 0) row_start[prow] = start;
+  // the row before the merge: its first point, and its length -- the last x-tile's xstart + the row's points in that tile
+  const uint32_t start_old = T.xstart[xrow];
+  uint32_t end_old = T.xstart[xrow + (uint32_t)(g.ntx - 1) * stride];
+  {
+    const uint32_t TS = 1u << g.ts;
+    const uint32_t sg = (uint32_t)(g.nxs - 1) >> 3;                  // (column nxf lies in the last x-tile)
+    const uint32_t tile = T.dir[tab_dir_index(g, py, pz, sg)];
+    if (tile) {
+      const uint2 e = T.tiles[(((size_t)tile << (g.ty + g.tz)) + (size_t)(((pz & ((1u << g.tz) - 1u)) << g.ty) + (py & ((1u << g.ty) - 1u)))) * (TS + 1u) + (sg & (TS - 1u))];
+      end_old += seg_count(e.x, e.y, (uint32_t)(g.nxs - 1) & 7u, T.ovf);
+    }
+  }
+  __syncthreads();                                                 // (everybody has read the old index of this row)
+  const uint32_t start = start_old + lo, len = (end_old - start_old) + (hi - lo);
   const float4* rp = merged + start;
-  row_entries(T, prow, len, nxs - 1,
-              [&](uint32_t i) { return (int)(column_key(rp[i], ox, oy, oz, inv_cell, nx, ny, nz, xs) - first); }, s_cnt, s_scan);
+  row_entries(T, py, pz, start, len,
+              [&](uint32_t i) { return (int)(column_key(rp[i], ox, oy, oz, inv_cell, nx, g.ny, g.nz, xs) - first); }, s_cnt, s_pre, s_scan);
 }
 hipError_t map_merge_grid(hipStream_t st, const float4* old_sorted, size_t n_old, const float4* new_pts, size_t k,
-                          float4* out_sorted, const IndexTables& T, float ox, float oy, float oz,
+                          float4* out_sorted, IndexTables& T, float ox, float oy, float oz,
                           float inv_cell, int nx, int ny, int nz, int xs, MapBuildScratch& S) {
   if (k == 0) return hipSuccess;
-  const int nxs = nx * xs + 1, nseg = (int)grid_nseg(nx * xs);
+  const int nxs = nx * xs + 1;
   const size_t nrows = (size_t)ny * nz, ncols = nrows * (size_t)nxs;
+  const TileShape shape = grid_tile_shape(nx * xs, ny, nz);
+  const TabGeo g = tab_geo(nx, ny, nz, xs, shape);
   hipError_t e = ensure_scratch(S, k);
   if (e != hipSuccess) return e;
   const int kb = (int)((k + 255) / 256);
@@ -428,15 +578,19 @@ hipError_t map_merge_grid(hipStream_t st, const float4* old_sorted, size_t n_old
   int bits = 1;
   while (bits < 32 && ((size_t)1 << bits) < ncols) bits++;
   if ((e = sort_keys(st, k, bits, S)) != hipSuccess) return e;
+  // tiles the new points need and the map did not have take the next numbers of the pool (cleared when it was laid out)
+  hipLaunchKernelGGL(tiles_mark_kernel, dim3(kb), dim3(256), 0, st, S.keys_out, (uint32_t)k, g, T.need);
+  hipLaunchKernelGGL(tiles_number_kernel, dim3(1), dim3(256), 0, st, T.dir, T.need, shape.ntx * shape.nty * shape.ntz, T.cap_tiles, T.counters,
+                     S.mail_dev + MAIL_TILES + 2, 0);
+  const SegTab tab{T.tiles, T.dir, T.ovf, T.counters + 2, (uint32_t)(T.ovf_cap / 8), T.xstart, g};
   {
     const unsigned old_blocks = (unsigned)((n_old + 255) / 256);
     hipLaunchKernelGGL(merge_points_kernel, dim3(old_blocks + (unsigned)kb), dim3(256), 0, st, old_sorted, (uint32_t)n_old, S.keys_out, (uint32_t)k,
-                       ox, oy, oz, inv_cell, nx, ny, nz, xs, out_sorted, old_blocks, new_pts, S.vals_out, T.segs, T.ovf, T.row_start, nxs, nseg);
+                       ox, oy, oz, inv_cell, nx, ny, nz, xs, out_sorted, old_blocks, new_pts, S.vals_out, tab);
   }
-  // (the points were placed with the OLD table: the table follows)
-  const SegTab tab{T.segs, T.ovf, T.ovf_count, T.ovf_cap, nseg};
-  hipLaunchKernelGGL(rows_merge_kernel, dim3((unsigned)nrows), dim3(256), 0, st, tab, T.row_start, S.keys_out, (uint32_t)k, out_sorted,
-                     ox, oy, oz, inv_cell, nx, ny, nz, xs);
+  // (the points were placed with the OLD index: the index follows)
+  hipLaunchKernelGGL(rows_merge_kernel, dim3((unsigned)nrows), dim3(256), 0, st, tab, S.keys_out, (uint32_t)k, out_sorted,
+                     ox, oy, oz, inv_cell, nx, xs);
   return hipGetLastError();
 }
 
@@ -465,7 +619,7 @@ __global__ __launch_bounds__(256) void crowded_all_kernel(GridView G, uint32_t t
   const size_t row = c / (size_t)G.nx;
   const int y = (int)(row % (size_t)G.ny), z = (int)(row / (size_t)G.ny);
   uint32_t lo, hi;
-  grid_row_range(G, y, z, x * G.xs, (x + 1) * G.xs, lo, hi);
+  grid_row_range(G, G.dir, y, z, x * G.xs, (x + 1) * G.xs, lo, hi);
   if (hi - lo <= threshold) return;
   crowded_append((uint32_t)c, x, y, z, bits, list, cap, count);
 }
@@ -478,7 +632,7 @@ __global__ __launch_bounds__(256) void crowded_points_kernel(const float4* __res
   const uint32_t row = col / (uint32_t)G.nxs, xf = col - row * (uint32_t)G.nxs;
   const int x = (int)(xf / (uint32_t)G.xs), y = (int)(row % (uint32_t)G.ny), z = (int)(row / (uint32_t)G.ny);
   uint32_t lo, hi;
-  grid_row_range(G, y, z, x * G.xs, (x + 1) * G.xs, lo, hi);
+  grid_row_range(G, G.dir, y, z, x * G.xs, (x + 1) * G.xs, lo, hi);
   if (hi - lo <= threshold) return;
   crowded_append(row * (uint32_t)G.nx + (uint32_t)x, x, y, z, bits, list, cap, count);
 }
@@ -516,7 +670,7 @@ __global__ __launch_bounds__(256) void boxrows_count_kernel(GridView G, int x0, 
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= nrows) return;
   uint32_t lo, hi;
-  grid_row_range(G, y0 + r % nyb, z0 + r / nyb, x0 * G.xs, (x1 + 1) * G.xs, lo, hi);
+  grid_row_range(G, G.dir, y0 + r % nyb, z0 + r / nyb, x0 * G.xs, (x1 + 1) * G.xs, lo, hi);
   cnt[r] = hi - lo;
 }
 __global__ __launch_bounds__(64) void boxrows_total_kernel(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off, int nrows,
@@ -527,7 +681,7 @@ __global__ __launch_bounds__(64) void boxrows_copy_kernel(GridView G, int x0, in
                                                           const uint32_t* __restrict__ off, float4* __restrict__ out) {
   const int r = blockIdx.x;
   uint32_t a, hi;
-  grid_row_range(G, y0 + r % nyb, z0 + r / nyb, x0 * G.xs, (x1 + 1) * G.xs, a, hi);
+  grid_row_range(G, G.dir, y0 + r % nyb, z0 + r / nyb, x0 * G.xs, (x1 + 1) * G.xs, a, hi);
   const uint32_t n = cnt[r], o = off[r];
   for (uint32_t i = threadIdx.x; i < n; i += 64) {
     const float4 p = G.pts[a + i];
@@ -590,15 +744,13 @@ hipError_t atan2f_probe(hipStream_t st, const float* yx_host, int n, float* out_
 __global__ __launch_bounds__(256) void index_compare_kernel(GridView A, GridView B, unsigned long long* __restrict__ diff) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t per = (size_t)A.nxf + 1;
-  if (i >= grid_prows(A.ny, A.nz) * per) return;
-  const uint32_t prow = (uint32_t)(i / per);
-  const int col = (int)(i % per);
-  unsigned bad = grid_count(A, prow, col) != grid_count(B, prow, col);
-  if (col == 0) bad += A.row_start[prow] != B.row_start[prow];
-  if (bad) atomicAdd(diff, (unsigned long long)bad);
+  if (i >= (size_t)A.ny * A.nz * per) return;
+  const int row = (int)(i / per), col = (int)(i % per);
+  const int y = row % A.ny, z = row / A.ny;
+  if (grid_pos(A, A.dir, y, z, col) != grid_pos(B, B.dir, y, z, col)) atomicAdd(diff, 1ull);
 }
 hipError_t index_compare(hipStream_t st, const GridView& A, const GridView& B, unsigned long long* diff_dev) {
-  const size_t n = grid_prows(A.ny, A.nz) * ((size_t)A.nxf + 1);
+  const size_t n = (size_t)A.ny * A.nz * ((size_t)A.nxf + 1);
   hipLaunchKernelGGL(index_compare_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, A, B, diff_dev);
   return hipGetLastError();
 }

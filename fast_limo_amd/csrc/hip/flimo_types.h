@@ -10,22 +10,30 @@ namespace flimo {
 // (xyz + original insertion index bits in w), sorted by linear cell id with x fastest, so the
 // three x-adjacent cells of a row are ONE contiguous range of `pts`.
 //
-// The index (round 5) is ONE table of 8-byte entries, one per SEGMENT of 8 fine x columns of a row (row = one (y, z) line of cells
-// along x; rows are padded by two empty rows on both sides of y and z, so that a 3x3 block of rows around any row of the grid is
-// addressable):
-//     entry.x = number of the row's points in columns below the segment's first         (bit 31: the entry is an escape, below)
-//     entry.y = eight 4-bit counts, one per column of the segment (column k in bits 4k .. 4k+3)
-// "points of row r in columns < c" is entry.x + the sum of the nibbles below c & 7: one v_bfe + one v_dot8_u32_u4.  A segment with
-// a column of more than 15 points (crowded maps: raw sweeps inserted under the sensor) is an ESCAPE: entry.y is the index of eight
-// cumulative 32-bit counts in `ovf` (one more dependent load, only there).  One byte of index per fine column instead of the
-// eight of rounds 3-5a (a row-major and a y-fastest table of 32-bit positions): 1.6x the map's bytes at 20 M points where
-// those were 12x.  Every count is RELATIVE TO THE ROW's first point; the rows' absolute starts are a table of their own (a point
-// merged into the map shifts every later row -- the small table -- and changes entries only inside its own row).
+// The index (round 5) has two levels.
+//  * SEGMENT ENTRIES, 8 bytes per segment of 8 fine x columns of a row (row = one (y, z) line of cells along x):
+//        entry.x = number of the row's points in the columns of its TILE below the segment's first   (bit 31: escape, below)
+//        entry.y = eight 4-bit counts, one per column of the segment (column k in bits 4k .. 4k+3)
+//    "points in columns < c" is entry.x + the sum of the nibbles below c & 7: one v_bfe + one v_dot8_u32_u4.  A segment with a
+//    column of more than 15 points (crowded maps: raw sweeps inserted under the sensor) is an ESCAPE: entry.y is the index of
+//    eight cumulative 32-bit counts in `ovf` (one more dependent load, only there).  One byte of index per fine column instead of
+//    the eight of rounds 3-5a (a row-major and a y-fastest table of 32-bit positions).
+//  * TILES: the entries live in tiles of 2^ts segments x 2^ty rows x 2^tz layers, and only tiles that hold a point exist; `dir`
+//    maps a tile's coordinates to its number in the pool (0: the shared all-zero tile: "no points here").  The directory is at most
+//    GRID_DIR_MAX 16-bit entries (the layout doubles the tile until it is): the k-NN pass keeps it in shared memory, so the way to an
+//    entry is still ONE round trip to memory.  A row of a tile has 2^ts + 1 entries: the last one continues into the first
+//    segment of the next tile along x (same prefix base), so that the 16-byte load of two neighbouring entries never leaves the
+//    tile -- a tile whose first segment holds a point makes its left neighbour exist.
+//  * `xstart[pz][tx][py]` (y fastest, rows padded by two on both sides of y and z): position in pts of the first point of row
+//    (y, z) that lies in x-tile tx or beyond.  A point merged into the map shifts every later row -- this small table -- and
+//    changes entries only inside its own row.
+// Padded coordinates everywhere below: py = y + GRID_PAD, pz = z + GRID_PAD.
 struct GridView {
   const float4* pts;           // [n_pts]  sorted by (z, y, fine x column)
-  const uint2* segs;           // [(nz+4) * (ny+4)][nseg]  padded row (y, z) -> row (z+2) * (ny+4) + (y+2); pad rows: all zero
+  const uint2* tiles;          // [1 + present tiles][2^tz][2^ty][2^ts + 1]
+  const uint16_t* dir;         // [ntz][nty][ntx]
   const uint32_t* ovf;         // [..][8]  escapes: points of the segment in columns below k, k = 0..7
-  const uint32_t* row_start;   // [(nz+4) * (ny+4)]  the padded row's first point in pts (pad rows: 0)
+  const uint32_t* xstart;      // [nz + 4][ntx][ny + 4]
   float ox, oy, oz;            // min corner of cell (0,0,0)
   float inv_cell;              // 1 / cell edge
   float cell;                  // cell edge [m]
@@ -36,12 +44,27 @@ struct GridView {
   // cells; the fast path uses the fine columns to cut a row down to the columns its bound's ball can reach.
   int xs, nxf;
   int nxs;                     // stride of the 32-bit sort key of a column: key = (z * ny + y) * nxs + column, nxs = nxf + 1
-  int nseg;                    // entries per row: (nxf >> 3) + 2 (column nxf -- the row's length -- has an entry, and one more
-                               // so that the 16-byte load of two neighbouring entries stays inside the row)
+  int ts, ty, tz;              // log2 of the tile's extent in segments / rows / layers
+  int ntx, nty, ntz;           // directory extent
 };
 constexpr int GRID_PAD = 2;    // empty rows around the grid in y and z
-constexpr size_t grid_nseg(int nxf) { return ((size_t)nxf >> 3) + 2; }
-constexpr size_t grid_prows(int ny, int nz) { return ((size_t)ny + 2 * GRID_PAD) * ((size_t)nz + 2 * GRID_PAD); }
+constexpr int GRID_DIR_MAX = 4096;
+struct TileShape { int ts, ty, tz, ntx, nty, ntz; };
+// tile shape of a grid of nxf columns x ny x nz rows: from 32 segments (256 columns) x 32 rows x 8 layers, doubled (z, y, x in
+// turn) until the directory fits
+inline TileShape grid_tile_shape(int nxf, int ny, int nz) {
+  TileShape t{5, 5, 3, 0, 0, 0};
+  for (int turn = 0;; turn++) {
+    const int nseg = (nxf >> 3) + 1;                       // segments 0 .. nxf >> 3 (column nxf -- a row's length -- has an entry)
+    t.ntx = (nseg + (1 << t.ts) - 1) >> t.ts;
+    t.nty = (ny + 2 * GRID_PAD + (1 << t.ty) - 1) >> t.ty;
+    t.ntz = (nz + 2 * GRID_PAD + (1 << t.tz) - 1) >> t.tz;
+    if ((long long)t.ntx * t.nty * t.ntz <= GRID_DIR_MAX) return t;
+    if (turn % 3 == 0) t.tz++; else if (turn % 3 == 1) t.ty++; else t.ts++;
+  }
+}
+constexpr size_t grid_tile_entries(int ts, int ty, int tz) { return (((size_t)1 << ts) + 1) << (ty + tz); }
+constexpr size_t grid_xstart_size(int ny, int nz, int ntx) { return ((size_t)ny + 2 * GRID_PAD) * ((size_t)nz + 2 * GRID_PAD) * (size_t)ntx; }
 
 #if defined(__HIPCC__)
 // points in the columns below column k (0..7) of a segment
@@ -53,22 +76,41 @@ __device__ __forceinline__ uint32_t seg_count(uint32_t ex, uint32_t ey, uint32_t
 __device__ __forceinline__ uint32_t seg_count_plain(uint32_t ex, uint32_t ey, uint32_t k) {
   return __builtin_amdgcn_udot8(ey, 0x11111111u & ((1u << (4u * k)) - 1u), ex, false);
 }
-__device__ __forceinline__ uint32_t grid_prow(const GridView& G, int y, int z) {
-  return (uint32_t)(z + GRID_PAD) * (uint32_t)(G.ny + 2 * GRID_PAD) + (uint32_t)(y + GRID_PAD);
+// index of the directory entry of the tile of padded row (py, pz), segment sg
+__device__ __forceinline__ uint32_t grid_dir_index(const GridView& G, uint32_t py, uint32_t pz, uint32_t sg) {
+  return __umul24(__umul24(pz >> G.tz, (uint32_t)G.nty) + (py >> G.ty), (uint32_t)G.ntx) + (sg >> G.ts);      // (24-bit multiplies: full rate)
 }
-// points of padded row `prow` in columns < col (col in 0 .. nxf)
-__device__ __forceinline__ uint32_t grid_count(const GridView& G, uint32_t prow, int col) {
-  const uint2 e = G.segs[(size_t)prow * (size_t)G.nseg + (size_t)(col >> 3)];
-  return seg_count(e.x, e.y, (uint32_t)col & 7u, G.ovf);
+// index in `tiles` of the entry of padded row (py, pz), segment sg, given its tile's number (a tile's row: 2^ts + 1 entries)
+// (32-bit: the host keeps the pool below 2^32 entries)
+__device__ __forceinline__ uint32_t grid_entry_index(const GridView& G, uint32_t tile, uint32_t py, uint32_t pz, uint32_t sg) {
+  const uint32_t zl = pz & ((1u << G.tz) - 1u), yl = py & ((1u << G.ty) - 1u), sl = sg & ((1u << G.ts) - 1u);
+  const uint32_t row = (tile << (G.ty + G.tz)) + (zl << G.ty) + yl;
+  return (row << G.ts) + row + sl;
+}
+__device__ __forceinline__ uint32_t grid_xstart_index(const GridView& G, uint32_t py, uint32_t pz, uint32_t tx) {
+  return (pz * (uint32_t)G.ntx + tx) * (uint32_t)(G.ny + 2 * GRID_PAD) + py;
+}
+// position in pts of the first point of row (y, z) in column col or beyond (col in 0 .. nxf); dir: G.dir or a copy of it
+__device__ __forceinline__ uint32_t grid_pos(const GridView& G, const uint16_t* dir, int y, int z, int col) {
+  const uint32_t py = (uint32_t)(y + GRID_PAD), pz = (uint32_t)(z + GRID_PAD), sg = (uint32_t)col >> 3;
+  // (no branch on "no tile": tile 0 is all zero -- no point of any row here -- so that the loads of two calls overlap)
+  const uint32_t tile = dir[grid_dir_index(G, py, pz, sg)];
+  const uint32_t base = G.xstart[grid_xstart_index(G, py, pz, sg >> G.ts)];
+  const uint2 e = G.tiles[grid_entry_index(G, tile, py, pz, sg)];
+  return base + seg_count(e.x, e.y, (uint32_t)col & 7u, G.ovf);
 }
 // [lo, hi) = positions in pts of the points of row (y, z) in columns [col0, col1)
-__device__ __forceinline__ void grid_row_range(const GridView& G, int y, int z, int col0, int col1, uint32_t& lo, uint32_t& hi) {
-  const uint32_t prow = grid_prow(G, y, z);
-  const uint32_t rs = G.row_start[prow];
-  const uint2* row = G.segs + (size_t)prow * (size_t)G.nseg;
-  const uint2 e0 = row[col0 >> 3], e1 = row[col1 >> 3];
-  lo = rs + seg_count(e0.x, e0.y, (uint32_t)col0 & 7u, G.ovf);
-  hi = rs + seg_count(e1.x, e1.y, (uint32_t)col1 & 7u, G.ovf);
+__device__ __forceinline__ void grid_row_range(const GridView& G, const uint16_t* dir, int y, int z, int col0, int col1, uint32_t& lo, uint32_t& hi) {
+  const uint32_t py = (uint32_t)(y + GRID_PAD), pz = (uint32_t)(z + GRID_PAD), s0 = (uint32_t)col0 >> 3, s1 = (uint32_t)col1 >> 3;
+  const uint32_t t0 = dir[grid_dir_index(G, py, pz, s0)], t1 = dir[grid_dir_index(G, py, pz, s1)];
+  const uint32_t b0 = G.xstart[grid_xstart_index(G, py, pz, s0 >> G.ts)], b1 = G.xstart[grid_xstart_index(G, py, pz, s1 >> G.ts)];
+  const uint2 e0 = G.tiles[grid_entry_index(G, t0, py, pz, s0)], e1 = G.tiles[grid_entry_index(G, t1, py, pz, s1)];
+  lo = b0 + seg_count_plain(e0.x, e0.y, (uint32_t)col0 & 7u);
+  hi = b1 + seg_count_plain(e1.x, e1.y, (uint32_t)col1 & 7u);
+  if (__builtin_expect((int)(e0.x | e1.x) < 0, 0)) {
+    lo = b0 + seg_count(e0.x, e0.y, (uint32_t)col0 & 7u, G.ovf);
+    hi = b1 + seg_count(e1.x, e1.y, (uint32_t)col1 & 7u, G.ovf);
+  }
 }
 #endif
 

@@ -899,6 +899,47 @@ def test_incremental_index_equals_full_sort(built, oracle):
 
 
 @pytest.mark.gpu
+def test_l_shaped_two_kilometre_drive_keeps_the_index_sparse(built, oracle):
+    """A 2 km drive, 1 km along +x and then 1 km along +y, inserting what the sensor sees every 10 m.  The map's bounding box is
+    a square kilometre of which the drive touches an L: the index holds tiles only where map points are (a table over the whole
+    box would be an order of magnitude larger), stays what a from-scratch build of the same map gives, and answers like the
+    oracle octree along the whole path -- also at the corner, at both ends and off the path."""
+    from fast_limo_amd import _lib
+    rng = np.random.default_rng(5)
+    ctx = _lib.HipCtx(0)
+    try:
+        ctx.map_config(0.2, 2, True)
+        oc = oracle.Octree(0.2, True)
+        pos = [np.float32([10.0 * k, 0.0, 0.0]) for k in range(101)] + [np.float32([1000.0, 10.0 * k, 0.0]) for k in range(1, 101)]
+        for k, c in enumerate(pos):
+            b = synth.box_world_map(6000, 50.0, 300 + k) + c          # (a 100 m box of structure around the sensor, 20 m high)
+            ctx.map_add(b); oc.update(b)
+            assert ctx.map_size() == oc.size(), k
+            if k % 40 == 39:
+                mm, merges, builds = ctx.grid_selfcheck()
+                assert mm == 0, (k, mm, merges, builds)
+        mm, merges, builds = ctx.grid_selfcheck()
+        assert mm == 0, (mm, merges, builds)
+        ib = ctx.map_index_bytes()
+        # what ONE table over the bounding box would take at a byte per fine column (1.1 km x 1.1 km x 20 m, 0.5 m cells,
+        # two columns per cell): the tiles that exist are a fraction of it
+        whole_box = 2 * (1100 / 0.5) * (1100 / 0.5) * (20 / 0.5)
+        print("L-shaped drive: map %d points (%.1f MB), index %.1f MB in %d tiles (a table over the box: %.0f MB), "
+              "%d merges, %d full builds, %d of them for a full tile pool"
+              % (ctx.map_size(), ib["points"] / 1e6, ib["index"] / 1e6, ib["tiles"], whole_box / 1e6, merges, builds, ib["tile_pool_relayouts"]))
+        assert ib["index"] < 0.4 * whole_box, (ib, whole_box)
+        assert merges >= 120, (merges, builds)
+        q = []
+        for c in (pos[0], pos[50], pos[100], pos[150], pos[200], np.float32([500.0, 500.0, 0.0]), np.float32([-30.0, -30.0, 0.0])):
+            q.append((rng.uniform(-40, 40, (600, 3)) * [1, 1, 0.1] + [0, 0, 2]).astype(np.float32) + c)
+        q = np.concatenate(q)
+        idx, sqd, cnt = ctx.knn(q, 5)
+        np.testing.assert_array_equal(sqd, oc.knn(q, 5)[1])
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
 def test_randomised_configurations_match_oracle(built, oracle):
     """Differential test over 16 random configurations: scene mix (box-world + tilted clutter at random densities), map
     cell size, state (pose AND LiDAR-IMU extrinsics away from identity), gates (MAX_DIST_PLANE, PLANE_THRESHOLD), both caps
