@@ -43,13 +43,12 @@ struct flimo_ctx {
   // map
   float4* d_map_raw = nullptr;     // insertion order
   float4* d_map_sorted = nullptr;  // cell order
-  float4* d_map_sorted2 = nullptr; // the other half of the double buffer of the incremental merge (lazy)
   float gbox[6] = {0, 0, 0, 0, 0, 0};   // box the grid geometry was laid out for (the map box plus slack on the sides that grew)
   bool have_gbox = false;
   bool force_full = false;         // the next index update lays the grid out afresh (cell size changed)
   bool full_rebuild = false;       // FLIMO_FULL_REBUILD=1: sort the whole map on every insert (A/B of the merge)
   uint64_t grid_merges = 0, grid_builds = 0, index_overflows = 0;
-  size_t map_n = 0, map_cap = 0;
+  size_t map_n = 0, map_cap = 0, sorted_cap = 0;
   IndexTables idx;                 // the index of the main grid (GridView, flimo_types.h): tiles, directory, escapes, xstart
   GridView grid{};
   bool grid_valid = false;
@@ -223,6 +222,7 @@ struct flimo_ctx {
   unsigned int pipe_tag = 0;
   unsigned long long pipe_published = 0, pipe_cancelled = 0;   // statistics
   unsigned long long pipe_aged = 0, pipe_left = 0;             // passes found too old to be published to / that left before the publish reached them
+  bool test_tight_array = false;          // FLIMO_TEST_TIGHT_ARRAY (tests): the cell-sorted array gets 4096 points of room instead of twice the map
   int test_publish_delay_ms = 0;         // FLIMO_TEST_PUBLISH_DELAY_MS (tests): a sleep between the age check of a waiting pass and the publish
   PrevPass prev_before{};                // `prev` as the pass in flight was given it (a pass that has to be launched a second time)
   // Which way the iterated update runs: the chain costs about 11 us per pass on top of the pass's kernels whatever the host (the
@@ -303,6 +303,8 @@ static int ensure_dev(flimo_ctx* c, T*& p, size_t& cap, size_t need, bool keep, 
 //   FLIMO_PIPELINE=0              host loop: no pass is queued ahead of the filter's algebra (default: the next one-launch pass waits on the
 //                                 GPU for its pose, which the host stores into device memory)
 //   FLIMO_NO_BAR=1                behave like a system that does not map device memory for the host (no pipelined loop, staged IMU frames)
+//   FLIMO_TEST_TIGHT_ARRAY=1      (tests) the cell-sorted point array has room for 4096 more points only: inserts find it full and the
+//                                 map is laid out afresh (the path a long drive takes when the array fills up)
 //   FLIMO_TEST_PUBLISH_DELAY_MS   (tests) a sleep between the age check of a waiting pass and the publish of its pose
 //   FLIMO_PROF_PASS / FLIMO_PROF_INSERT   host-side timing prints (stderr)
 // (csrc/host: FLIMO_REFERENCE_SOLVE=1 literal two-inverse gain, FLIMO_NO_FRONT_CTX=1 input stage on the main context,
@@ -322,6 +324,7 @@ static void load_dev_switches(flimo_ctx* c) {
   if (env_int("FLIMO_HOST_UPDATE", v)) c->update_mode = v != 0 ? 1 : 2;
   if (env_int("FLIMO_PIPELINE", v)) { c->pipeline = v != 0; c->pipeline_env = true; }
   if (env_int("FLIMO_TEST_PUBLISH_DELAY_MS", v) && v > 0) c->test_publish_delay_ms = v;
+  if (env_int("FLIMO_TEST_TIGHT_ARRAY", v)) c->test_tight_array = v != 0;
 }
 
 // Does the GPU see what the HOST stores into this allocation?  The host writes a pattern into the head's epoch word (a plain store
@@ -470,7 +473,7 @@ extern "C" void flimo_ctx_destroy(flimo_ctx* c) {
   if (!c) return;
   ctx_enter(c);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  (void)hipFree(c->d_map_raw); (void)hipFree(c->d_map_sorted); (void)hipFree(c->d_map_sorted2); index_free(c->idx); index_free(c->fine_idx);
+  (void)hipFree(c->d_map_raw); (void)hipFree(c->d_map_sorted); index_free(c->idx); index_free(c->fine_idx);
   (void)hipFree(c->d_scan_sorted); (void)hipFree(c->d_nbr); (void)hipFree(c->d_wl); (void)hipFree(c->d_wl_count);
   (void)hipFree(c->d_fit_partials); (void)hipFree(c->d_raw_sorted); (void)hipFree(c->d_t_sorted);
   (void)hipFree(c->d_scan); (void)hipFree(c->d_scan_raw); (void)hipFree(c->d_scan_world); (void)hipFree(c->d_scan_t);
@@ -638,7 +641,7 @@ static int update_fine_grid(flimo_ctx* c, bool relayout, const float4* new_pts =
     c->fine_pts_cap = cap;
   }
   HIPCHK(c, map_box_copy(c->stream, g, c0, c1, c->d_fine_tmp, c->scratch));
-  HIPCHK(c, map_build_grid(c->stream, c->d_fine_tmp, m, c->d_fine_pts, c->fine_idx, c->fine_pts_cap, of[0], of[1], of[2], inv_f, nf[0], nf[1], nf[2], 1,
+  HIPCHK(c, map_build_grid(c->stream, c->d_fine_tmp, m, c->d_fine_pts, c->fine_pts_cap, false, c->fine_idx, c->fine_pts_cap, of[0], of[1], of[2], inv_f, nf[0], nf[1], nf[2], 1,
                            c->scratch));
   if (prof) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -677,13 +680,11 @@ static int rebuild_grid(flimo_ctx* c) {
     const size_t n_old = c->grid.n_pts, k = c->map_n - n_old;
     if (k == 0) return FLIMO_OK;
     c->grid_valid = false;
-    if (!c->d_map_sorted2) HIPCHK(c, hipMalloc(&c->d_map_sorted2, c->map_cap * sizeof(float4)));
     const GridView& g = c->grid;
-    HIPCHK(c, map_merge_grid(c->stream, c->d_map_sorted, n_old, c->d_map_raw + n_old, k, c->d_map_sorted2, c->idx,
+    HIPCHK(c, map_merge_grid(c->stream, c->d_map_sorted, c->sorted_cap, c->d_map_raw + n_old, k, c->idx,
                              g.ox, g.oy, g.oz, g.inv_cell, g.nx, g.ny, g.nz, g.xs, c->scratch));
-    // (no wait here: everything that reads the index is queued behind this on the same stream; map_add_device ends synchronised)
-    std::swap(c->d_map_sorted, c->d_map_sorted2);
-    c->grid.pts = c->d_map_sorted;
+    // (no wait here: everything that reads the index is queued behind this on the same stream; map_add_device ends synchronised
+    //  and looks whether the point array or the tile pool ran out)
     c->grid.n_pts = (uint32_t)c->map_n;
     c->grid_valid = true;
     c->grid_merges++;
@@ -734,9 +735,19 @@ static int rebuild_grid(flimo_ctx* c) {
   }
   for (int a = 0; a < 6; a++) c->gbox[a] = W[a];
   c->have_gbox = true;
-  if (!c->d_map_sorted) HIPCHK(c, hipMalloc(&c->d_map_sorted, c->map_cap * sizeof(float4)));   // mirrors the raw capacity (freed whenever that grows)
-  HIPCHK(c, map_build_grid(c->stream, c->d_map_raw, c->map_n, c->d_map_sorted, c->idx, c->map_cap, ox, oy, oz, inv, nx, ny, nz, xs, c->scratch));
-  c->scratch.mail_host[MAIL_TILES + 2] = c->scratch.mail_host[MAIL_TILES + 3] = 0u;      // (the merges' words: tiles taken, "ran out")
+  if (!c->d_map_sorted) {
+    // the rows of the cell-sorted copy are not packed (a build leaves half a row's length of room behind every row, an insert
+    // moves a row that outgrows its room to the end): three times the raw capacity (freed whenever that grows); an insert that finds it full has the map laid out afresh, packed
+    c->sorted_cap = 3 * c->map_cap + 65536;
+    HIPCHK(c, hipMalloc(&c->d_map_sorted, c->sorted_cap * sizeof(float4)));
+  }
+  if (c->test_tight_array) {
+    (void)hipFree(c->d_map_sorted); c->d_map_sorted = nullptr;
+    c->sorted_cap = c->map_n + 4096;
+    HIPCHK(c, hipMalloc(&c->d_map_sorted, c->sorted_cap * sizeof(float4)));
+  }
+  HIPCHK(c, map_build_grid(c->stream, c->d_map_raw, c->map_n, c->d_map_sorted, c->sorted_cap, true, c->idx, c->map_cap, ox, oy, oz, inv, nx, ny, nz, xs, c->scratch));
+  c->scratch.mail_host[MAIL_TILES + 2] = c->scratch.mail_host[MAIL_TILES + 3] = c->scratch.mail_host[MAIL_ROWS] = 0u;      // (the merges' words: tiles taken, "ran out", "array full")
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->grid.pts = c->d_map_sorted;
   c->grid.ox = ox; c->grid.oy = oy; c->grid.oz = oz;
@@ -770,16 +781,9 @@ extern "C" int flimo_map_grid_selfcheck(flimo_ctx* c, uint64_t* mismatches, uint
   HIPCHK(c, hipMalloc(&t.pts, n * sizeof(float4)));
   HIPCHK(c, hipMalloc(&t.diff, sizeof(unsigned long long)));
   HIPCHK(c, hipMemsetAsync(t.diff, 0, sizeof(unsigned long long), c->stream));
-  HIPCHK(c, map_build_grid(c->stream, c->d_map_raw, n, t.pts, t.idx, n, g.ox, g.oy, g.oz, g.inv_cell, g.nx, g.ny, g.nz, g.xs, c->scratch));
-  // the points bit for bit; the index by meaning (every row's start, every column's count: escapes take their slots in arrival order)
-  {
-    const size_t bytes = n * sizeof(float4);
-    std::vector<unsigned char> ha(bytes), hb(bytes);
-    HIPCHK(c, hipMemcpyAsync(ha.data(), t.pts, bytes, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(hb.data(), g.pts, bytes, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (size_t i = 0; i + 4 <= bytes; i += 4) *mismatches += memcmp(&ha[i], &hb[i], 4) != 0;
-  }
+  HIPCHK(c, map_build_grid(c->stream, c->d_map_raw, n, t.pts, n, false, t.idx, n, g.ox, g.oy, g.oz, g.inv_cell, g.nx, g.ny, g.nz, g.xs, c->scratch));
+  // by meaning: every row holds the same points in the same order, every row's position at every column agrees with its own
+  // array (the rows of the maintained copy are not packed; escapes and tiles take their numbers in arrival order)
   GridView ref = g;
   ref.pts = t.pts;
   index_view(t.idx, ref);
@@ -798,7 +802,7 @@ static int map_append_host(flimo_ctx* c, const float4* pts, size_t n) {
   const size_t old_cap = c->map_cap;
   int rc = ensure_dev(c, c->d_map_raw, c->map_cap, c->map_n + n, true, c->map_n);
   if (rc) return rc;
-  if (c->map_cap != old_cap && c->d_map_sorted) { (void)hipFree(c->d_map_sorted); (void)hipFree(c->d_map_sorted2); c->d_map_sorted = c->d_map_sorted2 = nullptr; c->grid_valid = false; }
+  if (c->map_cap != old_cap && c->d_map_sorted) { (void)hipFree(c->d_map_sorted); c->d_map_sorted = nullptr; c->grid_valid = false; }
   HIPCHK(c, hipMemcpyAsync(c->d_map_raw + c->map_n, pts, n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->map_n += n;
@@ -822,7 +826,7 @@ static int map_add_device(flimo_ctx* c, const float4* d_pts, size_t m, double st
     const size_t old_cap = c->map_cap;
     int rc = ensure_dev(c, c->d_map_raw, c->map_cap, c->map_n + m, true, c->map_n);
     if (rc) return rc;
-    if (c->map_cap != old_cap && c->d_map_sorted) { (void)hipFree(c->d_map_sorted); (void)hipFree(c->d_map_sorted2); c->d_map_sorted = c->d_map_sorted2 = nullptr; c->grid_valid = false; }
+    if (c->map_cap != old_cap && c->d_map_sorted) { (void)hipFree(c->d_map_sorted); c->d_map_sorted = nullptr; c->grid_valid = false; }
     int kept = 0;
     if (!c->gbook.active)        // first batch: Octree::initialize on the device
       HIPCHK(c, c->gbook.init(c->stream, d_pts, (int)m, bb, c->d_map_raw, &kept, c->map_cfg.min_extent, c->map_cfg.downsample != 0,
@@ -901,7 +905,7 @@ extern "C" int flimo_map_points(flimo_ctx* c, float* out, size_t cap, size_t* n)
   const size_t m = std::min(cap, c->map_n);
   int rc = ensure_stage(c, m * sizeof(float4));
   if (rc) return rc;
-  HIPCHK(c, hipMemcpyAsync(c->h_stage, c->d_map_sorted, m * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_stage, c->d_map_raw, m * sizeof(float4), hipMemcpyDeviceToHost, c->stream));      // (insertion order)
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const float4* s = (const float4*)c->h_stage;
   for (size_t i = 0; i < m; i++) { out[3 * i] = s[i].x; out[3 * i + 1] = s[i].y; out[3 * i + 2] = s[i].z; }

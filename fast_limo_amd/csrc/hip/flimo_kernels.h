@@ -123,7 +123,7 @@ struct MapBuildScratch {
   unsigned long long* filt_mail_dev = nullptr;
 };
 // slots of the mail words
-enum MailSlot { MAIL_BOOK = 0 /* 6 */, MAIL_BOOK_END = 8 /* 2 */, MAIL_CROWD = 12, MAIL_BOXCOUNT = 13, MAIL_BBOX = 16 /* 6 */, MAIL_VOXEL = 24 /* 4 */, MAIL_TILES = 28 /* build: tiles, overflow; merge: tiles, overflow */,
+enum MailSlot { MAIL_BOOK = 0 /* 6 */, MAIL_BOOK_END = 8 /* 2 */, MAIL_CROWD = 12, MAIL_BOXCOUNT = 13, MAIL_BBOX = 16 /* 6 */, MAIL_VOXEL = 24 /* 4 */, MAIL_TILES = 28 /* build: tiles, overflow; merge: tiles, overflow */, MAIL_ROWS = 32 /* an insert found the point array full */,
                 MAIL_TAG = 62 /* number of the last mail_words, written behind its words */, MAIL_WORDS = 64 };
 struct MailPart { const void* src; int n; int dst; };
 // queues ONE small kernel that copies up to 6 runs of words into the mail slots; `rearm_bbox`: S.bbox is reset to the empty box
@@ -152,11 +152,16 @@ struct IndexTables {
   uint32_t* counters = nullptr;                           // [0] next free tile number, [1] a merge ran out of tiles, [2] escape slots taken
   uint32_t* ovf = nullptr; size_t ovf_cap = 0;            // words (8 per slot)
   uint32_t* xstart = nullptr; size_t xstart_cap = 0;
+  uint32_t* rowcap = nullptr; size_t rowcap_cap = 0;      // [(nz+4)(ny+4)] points that fit from a row's first one to the next row's
+  uint32_t* rowoff = nullptr; size_t rowoff_cap = 0;      // build scratch: the rows' first positions
+  uint32_t* tail = nullptr;                               // [0] first free position of the point array, [1] an insert found it full, [2] rows moved
 };
 void index_free(IndexTables& T);
-// Sorts `pts_in` by (z, y, fine x column) into `pts_out` and builds the index (ends synchronised: the pool is sized by the number
-// of tiles the points need).  pts_cap: capacity of the point buffer the index is for.
-hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4* pts_out, IndexTables& T, size_t pts_cap,
+// Sorts `pts_in` by (z, y, fine x column) into the rows of `pts_out` (room for out_cap points) and builds the index (ends with the
+// stream waited for once: the pool is sized by the number of tiles the points need).  slack: the rows keep room behind their last
+// point (a map that receives inserts) as far as out_cap allows; otherwise they are packed.  pts_cap: capacity of the point buffer
+// the index is for (sizes the escape pool).
+hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4* pts_out, size_t out_cap, bool slack, IndexTables& T, size_t pts_cap,
                           float ox, float oy, float oz, float inv_cell, int nx, int ny, int nz, int xs,
                           MapBuildScratch& S);
 // fills the table pointers and the tile shape of a GridView whose geometry (nx, ny, nz, xs, nxf) is set
@@ -165,11 +170,12 @@ void index_view(const IndexTables& T, GridView& G);
 bool index_merge_overflow(const MapBuildScratch& S);
 // debug: *diff_dev += the number of (row, column) pairs at which two indices of the same geometry differ
 hipError_t index_compare(hipStream_t st, const GridView& A, const GridView& B, unsigned long long* diff_dev);
-// Merges the k points appended since the last build into the cell-sorted array (same geometry): out_sorted and the tables
-// become what map_build_grid gives for all n_old + k points.  The index is updated in place -- the rows' starts, and the
-// entries of the rows that received points: O(rows + touched rows x row length), not O(cells); out_sorted != old_sorted.
-hipError_t map_merge_grid(hipStream_t st, const float4* old_sorted, size_t n_old, const float4* new_pts, size_t k,
-                          float4* out_sorted, IndexTables& T, float ox, float oy, float oz,
+// Puts the k points appended since the last build into the rows of the cell-sorted array IN PLACE (same geometry): a row whose
+// new points fit is merged where it is, a row that outgrows its room moves to the end of the array; the index of the rows that
+// received points is rebuilt from those rows.  O(rows + touched rows x row length): no pass over the stored points.  A full array
+// or tile pool is reported after the stream has been waited for (index_merge_overflow): the caller lays the map out afresh.
+hipError_t map_merge_grid(hipStream_t st, float4* sorted, size_t sorted_cap, const float4* new_pts, size_t k,
+                          IndexTables& T, float ox, float oy, float oz,
                           float inv_cell, int nx, int ny, int nz, int xs, MapBuildScratch& S);
 // Input filters of a raw sweep (32-byte PointType records already on the device): NaN removal, crop box, every rate-th survivor,
 // min distance; order preserved.  out[k] = (xyz, w = k), t_out[k] = stamp without the sweep offset; ext_dev[4] = {extreme ordered

@@ -1753,7 +1753,7 @@ __global__ __launch_bounds__(FIT_THREADS) void fit_kernel(GridView G, const floa
           const bool has = (flag == 1);
           cnt += has ? 1 : 0;
           d.sqd[s] = has ? sq[s] : 0.f;
-          d.nbr[s] = has ? ids[s] : -1;
+          d.nbr[s] = has ? (int32_t)__float_as_uint(G.pts[ids[s]].w) : -1;      // (insertion index: flimo_map_points' order)
         }
         d.n_nbr = cnt;
         d.cand = 0;
@@ -2239,7 +2239,8 @@ __global__ __launch_bounds__(256) void knn_tie_kernel(GridView G, BookView B, co
     (void)tied;
     const bool ok = tie_select_wave(G, B, qxyz[3 * q], qxyz[3 * q + 1], qxyz[3 * q + 2], dk, k, s_t[wave], pos, d);
     if (ok && lane == 0) {
-      for (int s = 0; s < k; s++) { idx[(size_t)q * k + s] = (int32_t)pos[s]; sqd[(size_t)q * k + s] = d[s]; }
+      // (what leaves the library: the point's insertion index -- flimo_map_points' order -- not its place in the sorted array)
+      for (int s = 0; s < k; s++) { idx[(size_t)q * k + s] = (int32_t)__float_as_uint(G.pts[pos[s]].w); sqd[(size_t)q * k + s] = d[s]; }
     }
     wave_lds_sync();
   }
@@ -2340,7 +2341,7 @@ __global__ __launch_bounds__(256) void fitk_kernel(GridView G, const float4* __r
 #pragma unroll
     for (int s = 0; s < 5; s++) {            // the debug record shows the first five neighbours
       d.sqd[s] = (has && s < K) ? sq[s < K ? s : 0] : 0.f;
-      d.nbr[s] = (has && s < K) ? nb.idx[s] : -1;
+      d.nbr[s] = (has && s < K) ? (int32_t)__float_as_uint(G.pts[nb.idx[s]].w) : -1;
     }
     d.n_nbr = has ? K : 0;
     d.cand = 0;
@@ -2415,7 +2416,7 @@ __global__ __launch_bounds__(256) void knn_kernel(GridView G, const float* __res
     for (int s = 0; s < k; s++) {
       const bool has = R.bi[s] != INT_MAX;
       c += has ? 1 : 0;
-      idx[(size_t)q * k + s] = has ? R.bi[s] : -1;
+      idx[(size_t)q * k + s] = has ? (int32_t)__float_as_uint(G.pts[R.bi[s]].w) : -1;      // (insertion index: flimo_map_points' order)
       sqd[(size_t)q * k + s] = has ? R.bd[s] : 0.f;
     }
     cnt[q] = R.exact ? c : -c - 1;

@@ -353,25 +353,53 @@ __device__ __forceinline__ void row_entries(const SegTab& T, uint32_t py, uint32
     __syncthreads();
   }
 }
-// Full build: one workgroup per row of the grid.  keys: the sorted column keys of all n points (key = row * nxs + column).
-__global__ __launch_bounds__(256) void rows_build_kernel(SegTab T, const uint32_t* __restrict__ keys, uint32_t n) {
-  __shared__ uint32_t s_cnt[SEG_WIN + 8], s_pre[513], s_scan[256], s_lo, s_hi;
+// Full build.  The rows are laid out behind each other in (z, y) order, each with ROOM behind its last point when the map is one
+// that receives inserts (`slack`: half its length, at least two points; an empty row has none and goes to the end of the array
+// with its first points) -- a packed layout would send every row the next insert touches to the end of the array at once.
+//   rows_len_kernel   : per row, where its keys begin in the sorted keys and how much room it gets
+//   (exclusive sum of the rooms: the rows' first positions)
+//   rows_place_kernel : sorted point i -> its row's first position + its rank in the row
+//   rows_build_kernel : one workgroup per row: xstart and the entries
+__global__ __launch_bounds__(256) void rows_len_kernel(const uint32_t* __restrict__ keys, uint32_t n, uint32_t nrows, int nxs, int slack,
+                                                       uint32_t* __restrict__ row_lo /*[nrows + 1]*/, uint32_t* __restrict__ room) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nrows) return;
+  const uint32_t lo = lower_bound_u32(keys, 0u, n, r * (uint32_t)nxs), hi = lower_bound_u32(keys, lo, n, (r + 1u) * (uint32_t)nxs);
+  const uint32_t len = hi - lo;
+  row_lo[r] = lo;
+  if (r + 1u == nrows) row_lo[nrows] = n;
+  room[r] = (slack && len) ? len + max(2u, len >> 1) : len;
+}
+__global__ __launch_bounds__(256) void rows_place_kernel(const float4* __restrict__ in, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ keys,
+                                                         uint32_t n, int nxs, const uint32_t* __restrict__ row_lo, const uint32_t* __restrict__ row_off,
+                                                         float4* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t r = keys[i] / (uint32_t)nxs;
+  out[row_off[r] + (i - row_lo[r])] = in[perm[i]];
+}
+__global__ __launch_bounds__(256) void rows_build_kernel(SegTab T, uint32_t* __restrict__ rowcap, uint32_t* __restrict__ tail, const uint32_t* __restrict__ keys,
+                                                         const uint32_t* __restrict__ row_lo, const uint32_t* __restrict__ room,
+                                                         const uint32_t* __restrict__ row_off, uint32_t nrows) {
+  __shared__ uint32_t s_cnt[SEG_WIN + 8], s_pre[513], s_scan[256];
   const TabGeo& g = T.g;
   const uint32_t r = blockIdx.x;
   const uint32_t first = r * (uint32_t)g.nxs;
-  if (threadIdx.x < 64) { const uint32_t v = wave_lower_bound_u32(keys, n, first); if (threadIdx.x == 0) s_lo = v; }
-  else if (threadIdx.x < 128) { const uint32_t v = wave_lower_bound_u32(keys, n, first + (uint32_t)g.nxs); if (threadIdx.x == 64) s_hi = v; }
-  __syncthreads();
-  const uint32_t lo = s_lo, hi = s_hi;
+  const uint32_t lo = row_lo[r], len = row_lo[r + 1u] - lo, cap = room[r], start = row_off[r];
   const uint32_t py = r % (uint32_t)g.ny + GRID_PAD, pz = r / (uint32_t)g.ny + GRID_PAD;
-  if (lo == hi) {
-    // an empty row: no entries (the pool was cleared), and every xstart = where its first point will go
+  if (threadIdx.x == 0) {
+    rowcap[pz * (uint32_t)(g.ny + 2 * GRID_PAD) + py] = cap;
+    if (r + 1u == nrows) tail[0] = start + cap;                    // first free position behind the last row
+  }
+  if (len == 0u) {
+    // an empty row: no entries (the pool was cleared); its xstarts say where it would begin (it has no room there: its first
+    // points take it to the end of the array)
     const uint32_t xrow = (pz * (uint32_t)g.ntx) * (uint32_t)(g.ny + 2 * GRID_PAD) + py;
-    for (int tx = (int)threadIdx.x; tx < g.ntx; tx += 256) T.xstart[xrow + (uint32_t)tx * (uint32_t)(g.ny + 2 * GRID_PAD)] = lo;
+    for (int tx = (int)threadIdx.x; tx < g.ntx; tx += 256) T.xstart[xrow + (uint32_t)tx * (uint32_t)(g.ny + 2 * GRID_PAD)] = start;
     return;
   }
   const uint32_t* rk = keys + lo;
-  row_entries(T, py, pz, lo, hi - lo, [&](uint32_t i) { return (int)(rk[i] - first); }, s_cnt, s_pre, s_scan);
+  row_entries(T, py, pz, start, len, [&](uint32_t i) { return (int)(rk[i] - first); }, s_cnt, s_pre, s_scan);
 }
 static hipError_t sort_keys(hipStream_t st, size_t n, int bits, MapBuildScratch& S) {
   size_t tmp_bytes = 0;
@@ -391,9 +419,9 @@ void index_view(const IndexTables& T, GridView& G) {
   G.tiles = T.tiles; G.dir = T.dir; G.ovf = T.ovf; G.xstart = T.xstart;
   G.ts = t.ts; G.ty = t.ty; G.tz = t.tz; G.ntx = t.ntx; G.nty = t.nty; G.ntz = t.ntz;
 }
-bool index_merge_overflow(const MapBuildScratch& S) { return S.mail_host && S.mail_host[MAIL_TILES + 3] != 0u; }
+bool index_merge_overflow(const MapBuildScratch& S) { return S.mail_host && (S.mail_host[MAIL_TILES + 3] != 0u || S.mail_host[MAIL_ROWS] != 0u); }
 void index_free(IndexTables& T) {
-  (void)hipFree(T.tiles); (void)hipFree(T.dir); (void)hipFree(T.need); (void)hipFree(T.counters); (void)hipFree(T.ovf); (void)hipFree(T.xstart);
+  (void)hipFree(T.tiles); (void)hipFree(T.dir); (void)hipFree(T.need); (void)hipFree(T.counters); (void)hipFree(T.ovf); (void)hipFree(T.xstart); (void)hipFree(T.rowcap); (void)hipFree(T.tail); (void)hipFree(T.rowoff);
   T = IndexTables{};
 }
 template <typename P>
@@ -408,7 +436,7 @@ static hipError_t grow(P*& p, size_t& cap, size_t need, size_t slack) {
 static TabGeo tab_geo(int nx, int ny, int nz, int xs, const TileShape& ts) {
   return TabGeo{nx * xs + 1, ny, nz, ts.ts, ts.ty, ts.tz, ts.ntx, ts.nty, ts.ntz};
 }
-hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4* pts_out, IndexTables& T, size_t pts_cap,
+hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4* pts_out, size_t out_cap, bool slack, IndexTables& T, size_t pts_cap,
                           float ox, float oy, float oz, float inv_cell, int nx, int ny, int nz, int xs,
                           MapBuildScratch& S) {
   const int nxf = nx * xs, nxs = nxf + 1;
@@ -416,7 +444,7 @@ hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4
   const TileShape shape = grid_tile_shape(nxf, ny, nz);
   const TabGeo g = tab_geo(nx, ny, nz, xs, shape);
   const int ndir = shape.ntx * shape.nty * shape.ntz;
-  hipError_t e = ensure_scratch(S, n);
+  hipError_t e = ensure_scratch(S, std::max(n, nrows + 1));       // (the rows' key ranges and rooms live in the sort's input buffers)
   if (e != hipSuccess) return e;
   if ((e = ensure_mail(S)) != hipSuccess) return e;
   if (!T.dir) {
@@ -436,9 +464,29 @@ hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4
                        S.keys_in, S.vals_in);
   int bits = 1;                                                    // number of key bits actually used
   while (bits < 32 && ((size_t)1 << bits) < ncols) bits++;
-  if (n > 0) {
-    if ((e = sort_keys(st, n, bits, S)) != hipSuccess) return e;
-    hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(256), 0, st, pts_in, S.vals_out, n, pts_out);
+  if (n > 0 && (e = sort_keys(st, n, bits, S)) != hipSuccess) return e;
+  // the rows' places: key range and room per row, an exclusive sum of the rooms, every point to its row's place + its rank
+  // (slack: only as far as the output array has room for it -- half a row's length and two points per row at least)
+  const bool roomy = slack && (n + n / 2 + 2 * std::min(n, nrows) + 64 <= out_cap);
+  uint32_t* row_lo = S.keys_in;                                    // [nrows + 1]
+  uint32_t* room = S.vals_in;                                      // [nrows]
+  {
+    hipLaunchKernelGGL(rows_len_kernel, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, st, S.keys_out, (uint32_t)n, (uint32_t)nrows, nxs, roomy ? 1 : 0,
+                       row_lo, room);
+    size_t off_cap = T.rowoff_cap;
+    if ((e = grow(T.rowoff, off_cap, nrows, nrows / 2)) != hipSuccess) return e;
+    T.rowoff_cap = off_cap;
+    size_t scan_bytes = 0;
+    if ((e = exclusive_sum(nullptr, scan_bytes, room, T.rowoff, nrows, st)) != hipSuccess) return e;
+    if (scan_bytes > S.cub_tmp_bytes) {
+      if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+      if (S.cub_tmp) (void)hipFree(S.cub_tmp);
+      S.cub_tmp = nullptr; S.cub_tmp_bytes = 0;
+      if ((e = hipMalloc(&S.cub_tmp, scan_bytes + 1024)) != hipSuccess) return e;
+      S.cub_tmp_bytes = scan_bytes + 1024;
+    }
+    if ((e = exclusive_sum(S.cub_tmp, scan_bytes, room, T.rowoff, nrows, st)) != hipSuccess) return e;
+    if (n > 0) hipLaunchKernelGGL(rows_place_kernel, dim3(blocks), dim3(256), 0, st, pts_in, S.vals_out, S.keys_out, (uint32_t)n, nxs, row_lo, T.rowoff, pts_out);
   }
   // which tiles exist, and their numbers (directory order); the host sizes the pool by their count
   if ((e = hipMemsetAsync(T.need, 0, GRID_DIR_MAX * sizeof(uint32_t), st)) != hipSuccess) return e;
@@ -462,7 +510,15 @@ hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4
   if ((e = hipMemsetAsync(T.tiles, 0, (size_t)T.cap_tiles * te * sizeof(uint2), st)) != hipSuccess) return e;
   if ((e = hipMemsetAsync(T.xstart, 0, grid_xstart_size(ny, nz, shape.ntx) * sizeof(uint32_t), st)) != hipSuccess) return e;
   const SegTab tab{T.tiles, T.dir, T.ovf, T.counters + 2, (uint32_t)(T.ovf_cap / 8), T.xstart, g};
-  hipLaunchKernelGGL(rows_build_kernel, dim3((unsigned)nrows), dim3(256), 0, st, tab, S.keys_out, (uint32_t)n);
+  {
+    size_t rc = T.rowcap_cap;
+    if ((e = grow(T.rowcap, rc, ((size_t)ny + 2 * GRID_PAD) * ((size_t)nz + 2 * GRID_PAD), ((size_t)ny + 2 * GRID_PAD) * ((size_t)nz + 2 * GRID_PAD) / 2)) != hipSuccess) return e;
+    T.rowcap_cap = rc;
+    if (!T.tail && (e = hipMalloc(&T.tail, 4 * sizeof(uint32_t))) != hipSuccess) return e;
+  }
+  if ((e = hipMemsetAsync(T.rowcap, 0, ((size_t)ny + 2 * GRID_PAD) * ((size_t)nz + 2 * GRID_PAD) * sizeof(uint32_t), st)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(T.tail, 0, 4 * sizeof(uint32_t), st)) != hipSuccess) return e;
+  hipLaunchKernelGGL(rows_build_kernel, dim3((unsigned)nrows), dim3(256), 0, st, tab, T.rowcap, T.tail, S.keys_out, row_lo, room, T.rowoff, (uint32_t)nrows);
   T.tiles_used = (uint32_t)ntiles;
   return hipGetLastError();
 }
@@ -475,96 +531,122 @@ hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4
 // of (stored points..., new points...) by cell gives, i.e. what map_build_grid produces for the same geometry.
 // One streaming pass over the points and one over the cell table; the binary searches over the k new keys are done
 // once per block (first / last element) and only blocks that straddle a new key search per element.
-// new point j (cell-sorted) -> behind the stored points of its cell: position = j + #stored points in cells <= key
-// stored point i (cell-sorted) -> i + #new points in cells < its cell
-// (one launch for both: the first `old_blocks` blocks move the stored points, the rest place the new ones; they write disjoint
-//  positions and read only the old index -- a tile that came into being for this batch is still all zero: "no stored point here")
-__global__ __launch_bounds__(256) void merge_points_kernel(const float4* __restrict__ old_pts, uint32_t n_old,
-                                                           const uint32_t* __restrict__ nkeys, uint32_t k, float ox, float oy, float oz,
-                                                           float inv_cell, int nx, int ny, int nz, int xs, float4* __restrict__ out,
-                                                           uint32_t old_blocks, const float4* __restrict__ new_pts,
-                                                           const uint32_t* __restrict__ nperm, SegTab T) {
-  __shared__ uint32_t s_lo, s_hi, s_c0, s_c1;
-  if (blockIdx.x >= old_blocks) {
-    const uint32_t j = (blockIdx.x - old_blocks) * blockDim.x + threadIdx.x;
-    if (j >= k) return;
-    // (behind the stored points of its column: the row's points below the NEXT column)
-    const TabGeo& g = T.g;
-    const uint32_t key = nkeys[j];
-    const uint32_t r = key / (uint32_t)g.nxs, col = key - r * (uint32_t)g.nxs + 1u, sg = col >> 3;
-    const uint32_t py = r % (uint32_t)g.ny + GRID_PAD, pz = r / (uint32_t)g.ny + GRID_PAD;
-    uint32_t pos = T.xstart[(pz * (uint32_t)g.ntx + (sg >> g.ts)) * (uint32_t)(g.ny + 2 * GRID_PAD) + py];
-    const uint32_t tile = T.dir[tab_dir_index(g, py, pz, sg)];
-    if (tile) {
-      const uint32_t TS = 1u << g.ts;
-      const uint2 e = T.tiles[(((size_t)tile << (g.ty + g.tz)) + (size_t)(((pz & ((1u << g.tz) - 1u)) << g.ty) + (py & ((1u << g.ty) - 1u)))) * (TS + 1u) + (sg & (TS - 1u))];
-      pos += seg_count(e.x, e.y, col & 7u, T.ovf);
-    }
-    out[(size_t)pos + j] = new_pts[nperm[j]];
-    return;
-  }
-  const uint32_t base = blockIdx.x * blockDim.x;
-  const uint32_t i = base + threadIdx.x;
-  const uint32_t last = min(n_old, base + blockDim.x) - 1u;
-  float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-  uint32_t cid = 0;
-  if (i < n_old) {
-    p = old_pts[i];
-    cid = column_key(p, ox, oy, oz, inv_cell, nx, ny, nz, xs);
-    if (i == base) s_c0 = cid;
-    if (i == last) s_c1 = cid + 1u;
-  }
-  __syncthreads();
-  if (threadIdx.x < 64) { const uint32_t r = wave_lower_bound_u32(nkeys, k, s_c0); if (threadIdx.x == 0) s_lo = r; }
-  else if (threadIdx.x < 128) { const uint32_t r = wave_lower_bound_u32(nkeys, k, s_c1); if (threadIdx.x == 64) s_hi = r; }
-  __syncthreads();
-  if (i >= n_old) return;
-  const uint32_t lo = s_lo, hi = s_hi;
-  const uint32_t shift = (lo == hi) ? lo : lower_bound_u32(nkeys, lo, hi, cid);
-  out[(size_t)i + shift] = p;
+// One row's points are one contiguous run of `pts`, but the rows are NOT packed behind each other (round 5): `xstart` says where a
+// row begins, `rowcap` how many points fit before the next one.  A build packs them (capacity = length); an insert touches only
+// the rows that receive points: a row whose new points fit is merged in place (old points move up inside the row, from the back),
+// a row that outgrows its room moves to the end of the array with room to double.  No pass over the stored points, no shift of
+// any other row.  What a row leaves behind is garbage until the next full build (which the insert asks for when the array is full).
+// Order inside a row: by column, stored points before new ones, new ones in their batch order -- exactly what a stable sort of
+// (stored..., new...) by column key gives, i.e. what map_build_grid produces for the same points.
+__device__ __forceinline__ int point_column(const float4* __restrict__ p, float ox, float oy, float oz, float inv_cell, int nx, int ny, int nz,
+                                            int xs, uint32_t first) {
+  // (points this workgroup has just written: read past the vector L1)
+  const unsigned* w = reinterpret_cast<const unsigned*>(p);
+  float4 q;
+  q.x = __uint_as_float(__hip_atomic_load(w + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  q.y = __uint_as_float(__hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  q.z = __uint_as_float(__hip_atomic_load(w + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  q.w = 0.f;
+  return (int)(column_key(q, ox, oy, oz, inv_cell, nx, ny, nz, xs) - first);
 }
-// The index after a merge.  Every xstart of row r += #new points in rows < r (the small table).  Entries change only inside the
-// rows that received points: one workgroup per row looks whether its row has new keys at all (a wave-wide search over the sorted
-// new keys) and leaves if not; a row that has rebuilds its entries and its xstarts from its points in the merged array.
-__global__ __launch_bounds__(256) void rows_merge_kernel(SegTab T, const uint32_t* __restrict__ nkeys, uint32_t k,
-                                                         const float4* __restrict__ merged, float ox, float oy, float oz, float inv_cell,
-                                                         int nx, int xs) {
-  __shared__ uint32_t s_cnt[SEG_WIN + 8], s_pre[513], s_scan[256], s_lo, s_hi;
+// tail[0] = first free position behind the last row, tail[1] = 1: the array is full (nothing was written for that row; the host
+// lays the map out afresh), tail[2] = rows moved (statistics)
+// the rows a batch of sorted keys touches: (row, index of its first key), one entry per run of keys of one row; tail[3] counts them
+__global__ __launch_bounds__(256) void rows_touched_kernel(const uint32_t* __restrict__ nkeys, uint32_t k, int nxs, uint32_t* __restrict__ rows,
+                                                           uint32_t* __restrict__ firsts, uint32_t* __restrict__ count) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= k) return;
+  const uint32_t r = nkeys[j] / (uint32_t)nxs;
+  if (j != 0u && nkeys[j - 1u] / (uint32_t)nxs == r) return;
+  const uint32_t slot = atomicAdd(count, 1u);
+  rows[slot] = r; firsts[slot] = j;
+}
+// (one workgroup per touched row, a fixed number of workgroups walking the list)
+__global__ __launch_bounds__(256) void rows_insert_kernel(SegTab T, uint32_t* __restrict__ rowcap, uint32_t* __restrict__ tail, uint32_t* __restrict__ full_mail, uint32_t pts_capacity,
+                                                          float4* __restrict__ pts, const uint32_t* __restrict__ nkeys, uint32_t k,
+                                                          const uint32_t* __restrict__ rows, const uint32_t* __restrict__ firsts,
+                                                          const float4* __restrict__ new_pts, const uint32_t* __restrict__ nperm,
+                                                          float ox, float oy, float oz, float inv_cell, int nx, int xs) {
+  __shared__ uint32_t s_cnt[SEG_WIN + 8], s_pre[513], s_scan[256], s_hi, s_dest;
   const TabGeo& g = T.g;
-  const uint32_t r = blockIdx.x;
+  const int t = (int)threadIdx.x;
+  const uint32_t ntouched = tail[3];
+ for (uint32_t item = blockIdx.x; item < ntouched; item += gridDim.x) {
+  __syncthreads();                                                 // (the last row's shared memory is done with)
+  const uint32_t r = rows[item], lo = firsts[item];
   const uint32_t first = r * (uint32_t)g.nxs;
-  if (threadIdx.x < 64) { const uint32_t v = wave_lower_bound_u32(nkeys, k, first); if (threadIdx.x == 0) s_lo = v; }
-  else if (threadIdx.x < 128) { const uint32_t v = wave_lower_bound_u32(nkeys, k, first + (uint32_t)g.nxs); if (threadIdx.x == 64) s_hi = v; }
+  if (t < 64) { const uint32_t v = wave_lower_bound_u32(nkeys, k, first + (uint32_t)g.nxs); if (t == 0) s_hi = v; }
   __syncthreads();
-  const uint32_t lo = s_lo, hi = s_hi;
+  const uint32_t hi = s_hi;
   const uint32_t py = r % (uint32_t)g.ny + GRID_PAD, pz = r / (uint32_t)g.ny + GRID_PAD;
   const uint32_t stride = (uint32_t)(g.ny + 2 * GRID_PAD);
+  const uint32_t prow = pz * stride + py;
   const uint32_t xrow = (pz * (uint32_t)g.ntx) * stride + py;
-  if (lo == hi) {
-    if (lo != 0u)
-      for (int tx = (int)threadIdx.x; tx < g.ntx; tx += 256) T.xstart[xrow + (uint32_t)tx * stride] += lo;
-    return;
-  }
-  // the row before the merge: its first point, and its length -- the last x-tile's xstart + the row's points in that tile
+  const uint32_t TS = 1u << g.ts;
+  // the row before the insert: first point, points below a column (from the old entries: they stay until row_entries rewrites them)
   const uint32_t start_old = T.xstart[xrow];
-  uint32_t end_old = T.xstart[xrow + (uint32_t)(g.ntx - 1) * stride];
-  {
-    const uint32_t TS = 1u << g.ts;
-    const uint32_t sg = (uint32_t)(g.nxs - 1) >> 3;                  // (column nxf lies in the last x-tile)
+  auto below_old = [&](uint32_t col) -> uint32_t {                  // stored points of the row in columns < col
+    const uint32_t sg = col >> 3;
+    uint32_t n = T.xstart[xrow + (sg >> g.ts) * stride] - start_old;
     const uint32_t tile = T.dir[tab_dir_index(g, py, pz, sg)];
-    if (tile) {
-      const uint2 e = T.tiles[(((size_t)tile << (g.ty + g.tz)) + (size_t)(((pz & ((1u << g.tz) - 1u)) << g.ty) + (py & ((1u << g.ty) - 1u)))) * (TS + 1u) + (sg & (TS - 1u))];
-      end_old += seg_count(e.x, e.y, (uint32_t)(g.nxs - 1) & 7u, T.ovf);
+    const uint2 e = T.tiles[(((size_t)tile << (g.ty + g.tz)) + (size_t)(((pz & ((1u << g.tz) - 1u)) << g.ty) + (py & ((1u << g.ty) - 1u)))) * (TS + 1u) + (sg & (TS - 1u))];
+    return n + seg_count(e.x, e.y, col & 7u, T.ovf);
+  };
+  const uint32_t len_old = below_old((uint32_t)(g.nxs - 1)), add = hi - lo, need = len_old + add;
+  if (t == 0) {
+    uint32_t dest = start_old;
+    if (need > rowcap[prow]) {                                     // the row moves behind everything, with room to double
+      const uint32_t ncap = 2u * need + 8u;
+      const uint32_t d = atomicAdd(&tail[0], ncap);
+      if (d > pts_capacity || ncap > pts_capacity - d) { atomicExch(&tail[1], 1u); *full_mail = 1u; dest = 0xffffffffu; }
+      else { dest = d; rowcap[prow] = ncap; atomicAdd(&tail[2], 1u); }
     }
+    s_dest = dest;
   }
-  __syncthreads();                                                 // (everybody has read the old index of this row)
-  const uint32_t start = start_old + lo, len = (end_old - start_old) + (hi - lo);
-  const float4* rp = merged + start;
-  row_entries(T, py, pz, start, len,
-              [&](uint32_t i) { return (int)(column_key(rp[i], ox, oy, oz, inv_cell, nx, g.ny, g.nz, xs) - first); }, s_cnt, s_pre, s_scan);
+  __syncthreads();
+  const uint32_t dest = s_dest;
+  if (dest == 0xffffffffu) continue;                               // (block-uniform)
+  const float4* src = pts + start_old;
+  float4* dst = pts + dest;
+  // stored points: point i goes to i + #new points in columns below its own.  From the back, a chunk at a time: read, barrier,
+  // write -- a point only ever moves up, by no less than the one before it, so a chunk's writes land on positions already read.
+  // (a row merged where it is: the points in columns below the first new one stay; the row's new keys, when they are few, are
+  //  searched in shared memory -- s_pre is free until row_entries)
+  const uint32_t i_stay = (dest == start_old) ? below_old(nkeys[lo] - first) : 0u;
+  const bool keys_lds = add <= 512u;
+  if (keys_lds) for (uint32_t j = (uint32_t)t; j < add; j += 256u) s_pre[j] = nkeys[lo + j];
+  __syncthreads();
+  for (int c0 = (int)((len_old + 255u) / 256u) * 256 - 256; c0 >= 0 && (uint32_t)(c0 + 256) > i_stay; c0 -= 256) {
+    const uint32_t i = (uint32_t)(c0 + t);
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t sh = 0u;
+    if (i < len_old && i >= i_stay) {
+      p = src[i];
+      const uint32_t key = column_key(p, ox, oy, oz, inv_cell, nx, g.ny, g.nz, xs);
+      if (keys_lds) {
+        uint32_t a = 0u, b = add;
+        while (a < b) { const uint32_t m = (a + b) >> 1; if (s_pre[m] < key) a = m + 1u; else b = m; }
+        sh = a;
+      } else {
+        sh = lower_bound_u32(nkeys, lo, hi, key) - lo;
+      }
+    }
+    __syncthreads();
+    if (i < len_old && i >= i_stay && (sh != 0u || dest != start_old)) dst[i + sh] = p;
+    __syncthreads();
+  }
+  // new points: the j-th of the row goes behind the stored points of its column
+  for (uint32_t j = lo + (uint32_t)t; j < hi; j += 256u) {
+    const uint32_t col = nkeys[j] - first;
+    dst[(j - lo) + below_old(col + 1u)] = new_pts[nperm[j]];
+  }
+  __syncthreads();                                                 // (everybody is done with the old entries, every point is in place)
+  row_entries(T, py, pz, dest, need,
+              [&](uint32_t i) { return point_column(dst + i, ox, oy, oz, inv_cell, nx, g.ny, g.nz, xs, first); }, s_cnt, s_pre, s_scan);
+ }
 }
-hipError_t map_merge_grid(hipStream_t st, const float4* old_sorted, size_t n_old, const float4* new_pts, size_t k,
-                          float4* out_sorted, IndexTables& T, float ox, float oy, float oz,
+hipError_t map_merge_grid(hipStream_t st, float4* sorted, size_t sorted_cap, const float4* new_pts, size_t k,
+                          IndexTables& T, float ox, float oy, float oz,
                           float inv_cell, int nx, int ny, int nz, int xs, MapBuildScratch& S) {
   if (k == 0) return hipSuccess;
   const int nxs = nx * xs + 1;
@@ -583,14 +665,12 @@ hipError_t map_merge_grid(hipStream_t st, const float4* old_sorted, size_t n_old
   hipLaunchKernelGGL(tiles_number_kernel, dim3(1), dim3(256), 0, st, T.dir, T.need, shape.ntx * shape.nty * shape.ntz, T.cap_tiles, T.counters,
                      S.mail_dev + MAIL_TILES + 2, 0);
   const SegTab tab{T.tiles, T.dir, T.ovf, T.counters + 2, (uint32_t)(T.ovf_cap / 8), T.xstart, g};
-  {
-    const unsigned old_blocks = (unsigned)((n_old + 255) / 256);
-    hipLaunchKernelGGL(merge_points_kernel, dim3(old_blocks + (unsigned)kb), dim3(256), 0, st, old_sorted, (uint32_t)n_old, S.keys_out, (uint32_t)k,
-                       ox, oy, oz, inv_cell, nx, ny, nz, xs, out_sorted, old_blocks, new_pts, S.vals_out, tab);
-  }
-  // (the points were placed with the OLD index: the index follows)
-  hipLaunchKernelGGL(rows_merge_kernel, dim3((unsigned)nrows), dim3(256), 0, st, tab, S.keys_out, (uint32_t)k, out_sorted,
-                     ox, oy, oz, inv_cell, nx, xs);
+  // the rows that receive points (the sort's input buffers are free again: they take the list)
+  if ((e = hipMemsetAsync(T.tail + 3, 0, sizeof(uint32_t), st)) != hipSuccess) return e;
+  hipLaunchKernelGGL(rows_touched_kernel, dim3(kb), dim3(256), 0, st, S.keys_out, (uint32_t)k, nxs, S.keys_in, S.vals_in, T.tail + 3);
+  const unsigned walkers = (unsigned)std::min<size_t>(std::min<size_t>(k, nrows), 8192);
+  hipLaunchKernelGGL(rows_insert_kernel, dim3(walkers), dim3(256), 0, st, tab, T.rowcap, T.tail, S.mail_dev + MAIL_ROWS, (uint32_t)std::min<size_t>(sorted_cap, 0xffffffffull),
+                     sorted, S.keys_out, (uint32_t)k, S.keys_in, S.vals_in, new_pts, S.vals_out, ox, oy, oz, inv_cell, nx, xs);
   return hipGetLastError();
 }
 
@@ -747,9 +827,26 @@ __global__ __launch_bounds__(256) void index_compare_kernel(GridView A, GridView
   if (i >= (size_t)A.ny * A.nz * per) return;
   const int row = (int)(i / per), col = (int)(i % per);
   const int y = row % A.ny, z = row / A.ny;
-  if (grid_pos(A, A.dir, y, z, col) != grid_pos(B, B.dir, y, z, col)) atomicAdd(diff, 1ull);
+  // (relative to the row's first point: the rows of a maintained map are not packed behind each other)
+  if (grid_pos(A, A.dir, y, z, col) - grid_pos(A, A.dir, y, z, 0) != grid_pos(B, B.dir, y, z, col) - grid_pos(B, B.dir, y, z, 0)) atomicAdd(diff, 1ull);
+}
+// ... and hold the same points, row by row (the rows of a maintained map are not packed behind each other)
+__global__ __launch_bounds__(64) void rows_compare_kernel(GridView A, GridView B, unsigned long long* __restrict__ diff) {
+  const int row = (int)blockIdx.x;
+  const int y = row % A.ny, z = row / A.ny;
+  const uint32_t a0 = grid_pos(A, A.dir, y, z, 0), a1 = grid_pos(A, A.dir, y, z, A.nxf);
+  const uint32_t b0 = grid_pos(B, B.dir, y, z, 0), b1 = grid_pos(B, B.dir, y, z, B.nxf);
+  if (a1 - a0 != b1 - b0) { if (threadIdx.x == 0) atomicAdd(diff, 1ull); return; }
+  unsigned bad = 0;
+  for (uint32_t i = threadIdx.x; i < a1 - a0; i += 64) {
+    const float4 p = A.pts[a0 + i], q = B.pts[b0 + i];
+    bad += (__float_as_uint(p.x) != __float_as_uint(q.x)) + (__float_as_uint(p.y) != __float_as_uint(q.y)) +
+           (__float_as_uint(p.z) != __float_as_uint(q.z)) + (__float_as_uint(p.w) != __float_as_uint(q.w));
+  }
+  if (bad) atomicAdd(diff, (unsigned long long)bad);
 }
 hipError_t index_compare(hipStream_t st, const GridView& A, const GridView& B, unsigned long long* diff_dev) {
+  hipLaunchKernelGGL(rows_compare_kernel, dim3((unsigned)((size_t)A.ny * A.nz)), dim3(64), 0, st, A, B, diff_dev);
   const size_t n = (size_t)A.ny * A.nz * ((size_t)A.nxf + 1);
   hipLaunchKernelGGL(index_compare_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, A, B, diff_dev);
   return hipGetLastError();

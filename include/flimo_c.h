@@ -63,7 +63,7 @@ typedef struct flimo_match_rec {
   float n[4];        /* plane n_ABCD */
   float p_global[3]; /* scan point in the world frame */
   float sqd[5];      /* ascending squared distances of the 5 neighbours */
-  int32_t nbr[5];    /* indices into the device map order (see flimo_map_points) or -1 */
+  int32_t nbr[5];    /* indices into the map's insertion order (see flimo_map_points) or -1 */
   int32_t n_nbr;
 } flimo_match_rec;
 
@@ -88,12 +88,12 @@ int flimo_map_add(flimo_ctx* ctx, const float* xyz, size_t n, size_t stride_byte
 int flimo_map_clear(flimo_ctx* ctx);
 size_t flimo_map_size(const flimo_ctx* ctx);
 double flimo_map_last_time(const flimo_ctx* ctx);
-/* copies the stored points (device order) as packed xyz; *n receives the total count
+/* copies the stored points (insertion order: what neighbour indices refer to) as packed xyz; *n receives the total count
  * (Octree::getData, Objects/Octree.hpp:198-215) */
 int flimo_map_points(flimo_ctx* ctx, float* xyz_out, size_t cap, size_t* n);
 
 /* ---- exact k-NN: replaces octree::Octree::knn (Objects/Octree.hpp:526-555) for a batch ----
- * q_xyz packed [nq][3] host; outputs host: idx [nq][k] (device map order, -1 padded),
+ * q_xyz packed [nq][3] host; outputs host: idx [nq][k] (the map's insertion order, -1 padded),
  * sqd [nq][k] ascending squared distances (0 padded), cnt [nq].  k <= 5. */
 int flimo_knn(flimo_ctx* ctx, const float* q_xyz, size_t nq, int k, int32_t* idx, float* sqd, int32_t* cnt);
 

@@ -899,6 +899,36 @@ def test_incremental_index_equals_full_sort(built, oracle):
 
 
 @pytest.mark.gpu
+def test_insert_that_finds_the_point_array_full_lays_the_map_out_afresh(built, oracle, monkeypatch):
+    """The rows of the cell-sorted array are not packed: a row that outgrows its room moves to the end.  When the end is reached
+    the insert says so and the map is laid out afresh, packed -- with room for 4096 points only (test switch) that happens every
+    few inserts; the index stays what a from-scratch build gives and k-NN answers like the oracle."""
+    from fast_limo_amd import _lib
+    monkeypatch.setenv("FLIMO_TEST_TIGHT_ARRAY", "1")
+    rng = np.random.default_rng(17)
+    ctx = _lib.HipCtx(0)
+    try:
+        ctx.map_config(0.2, 2, True)
+        oc = oracle.Octree(0.2, True)
+        first = synth.box_world_map(100000, 30.0, 5)
+        ctx.map_add(first); oc.update(first)
+        for k in range(12):
+            b = synth.box_world_map(6000, 25.0, 400 + k)
+            ctx.map_add(b); oc.update(b)
+            assert ctx.map_size() == oc.size(), k
+            mm, merges, builds = ctx.grid_selfcheck()
+            assert mm == 0, (k, mm, merges, builds)
+        ib = ctx.map_index_bytes()
+        print("tight array: %d merges, %d full builds, %d of them because the array or the tile pool was full" % (merges, builds, ib["tile_pool_relayouts"]))
+        assert ib["tile_pool_relayouts"] >= 2, ib
+        q = rng.uniform(-30, 30, (3000, 3)).astype(np.float32); q[:, 2] = rng.uniform(0, 5, 3000)
+        idx, sqd, cnt = ctx.knn(q, 5)
+        np.testing.assert_array_equal(sqd, oc.knn(q, 5)[1])
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
 def test_l_shaped_two_kilometre_drive_keeps_the_index_sparse(built, oracle):
     """A 2 km drive, 1 km along +x and then 1 km along +y, inserting what the sensor sees every 10 m.  The map's bounding box is
     a square kilometre of which the drive touches an L: the index holds tiles only where map points are (a table over the whole
