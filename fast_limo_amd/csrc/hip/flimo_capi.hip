@@ -47,7 +47,8 @@ struct flimo_ctx {
   bool have_gbox = false;
   bool force_full = false;         // the next index update lays the grid out afresh (cell size changed)
   bool full_rebuild = false;       // FLIMO_FULL_REBUILD=1: sort the whole map on every insert (A/B of the merge)
-  uint64_t grid_merges = 0, grid_builds = 0, index_overflows = 0;
+  uint64_t grid_merges = 0, grid_builds = 0, grid_regrids = 0, index_overflows = 0;
+  bool have_origin = false;        // the origin of the map's cells is set (GridView: it stays; a grid that grows moves its corner by whole cells)
   size_t map_n = 0, map_cap = 0, sorted_cap = 0;
   IndexTables idx;                 // the index of the main grid (GridView, flimo_types.h): tiles, directory, escapes, xstart
   GridView grid{};
@@ -222,6 +223,7 @@ struct flimo_ctx {
   unsigned int pipe_tag = 0;
   unsigned long long pipe_published = 0, pipe_cancelled = 0;   // statistics
   unsigned long long pipe_aged = 0, pipe_left = 0;             // passes found too old to be published to / that left before the publish reached them
+  bool row_slack = true;                  // FLIMO_ROW_SLACK=0: a full layout packs the rows (A/B of the room behind every row)
   bool test_tight_array = false;          // FLIMO_TEST_TIGHT_ARRAY (tests): the cell-sorted array gets 4096 points of room instead of twice the map
   int test_publish_delay_ms = 0;         // FLIMO_TEST_PUBLISH_DELAY_MS (tests): a sleep between the age check of a waiting pass and the publish
   PrevPass prev_before{};                // `prev` as the pass in flight was given it (a pass that has to be launched a second time)
@@ -303,6 +305,7 @@ static int ensure_dev(flimo_ctx* c, T*& p, size_t& cap, size_t need, bool keep, 
 //   FLIMO_PIPELINE=0              host loop: no pass is queued ahead of the filter's algebra (default: the next one-launch pass waits on the
 //                                 GPU for its pose, which the host stores into device memory)
 //   FLIMO_NO_BAR=1                behave like a system that does not map device memory for the host (no pipelined loop, staged IMU frames)
+//   FLIMO_ROW_SLACK=0             a full layout packs the rows of the cell-sorted array (default: half a row's length of room behind each)
 //   FLIMO_TEST_TIGHT_ARRAY=1      (tests) the cell-sorted point array has room for 4096 more points only: inserts find it full and the
 //                                 map is laid out afresh (the path a long drive takes when the array fills up)
 //   FLIMO_TEST_PUBLISH_DELAY_MS   (tests) a sleep between the age check of a waiting pass and the publish of its pose
@@ -325,6 +328,7 @@ static void load_dev_switches(flimo_ctx* c) {
   if (env_int("FLIMO_PIPELINE", v)) { c->pipeline = v != 0; c->pipeline_env = true; }
   if (env_int("FLIMO_TEST_PUBLISH_DELAY_MS", v) && v > 0) c->test_publish_delay_ms = v;
   if (env_int("FLIMO_TEST_TIGHT_ARRAY", v)) c->test_tight_array = v != 0;
+  if (env_int("FLIMO_ROW_SLACK", v)) c->row_slack = v != 0;
 }
 
 // Does the GPU see what the HOST stores into this allocation?  The host writes a pattern into the head's epoch word (a plain store
@@ -517,7 +521,7 @@ extern "C" int flimo_map_config(flimo_ctx* c, const flimo_map_cfg* cfg) {
   const float cell_before = c->map_cfg.cell_size;
   c->map_cfg = *cfg;
   if (!(c->map_cfg.cell_size > 0.f)) c->map_cfg.cell_size = 0.5f;
-  if (c->map_cfg.cell_size != cell_before) { c->force_full = true; c->have_gbox = false; }   // takes effect at the next index update
+  if (c->map_cfg.cell_size != cell_before) { c->force_full = true; c->have_gbox = false; c->have_origin = false; }   // takes effect at the next index update
   insert_book_config(c->book, cfg->min_extent, cfg->downsample != 0);
   return FLIMO_OK;
 }
@@ -528,6 +532,7 @@ extern "C" int flimo_map_clear(flimo_ctx* c) {
   c->grid_valid = false;
   c->fine_valid = false;
   c->have_gbox = false;
+  c->have_origin = false;
   c->map_last_time = -1.0;
   c->bb[0] = c->bb[1] = c->bb[2] = 3.4e38f; c->bb[3] = c->bb[4] = c->bb[5] = -3.4e38f;
   c->crowd_box_valid = false;
@@ -545,11 +550,11 @@ extern "C" double flimo_map_last_time(const flimo_ctx* c) { return c ? c->map_la
 // >= 0, highest <= n-2)?  Same float expressions as the kernels.
 static bool grid_covers(const GridView& g, const float* bb) {
   const float o[3] = {g.ox, g.oy, g.oz};
-  const int n[3] = {g.nx, g.ny, g.nz};
+  const int n[3] = {g.nx, g.ny, g.nz}, si[3] = {g.six, g.siy, g.siz};
   for (int a = 0; a < 3; a++) {
-    if (!(o[a] <= bb[a] - 0.5f * g.cell)) return false;
-    if ((int)floorf((bb[a] - o[a]) * g.inv_cell) < 0) return false;
-    if ((int)floorf((bb[3 + a] - o[a]) * g.inv_cell) > n[a] - 2) return false;
+    if ((int)floorf((bb[a] - 0.5f * g.cell - o[a]) * g.inv_cell) - si[a] < 0) return false;
+    if ((int)floorf((bb[a] - o[a]) * g.inv_cell) - si[a] < 0) return false;
+    if ((int)floorf((bb[3 + a] - o[a]) * g.inv_cell) - si[a] > n[a] - 2) return false;
   }
   return true;
 }
@@ -603,7 +608,7 @@ static int update_fine_grid(flimo_ctx* c, bool relayout, const float4* new_pts =
   int box[7] = {INT_MAX, INT_MAX, INT_MAX, -1, -1, -1, 0};
   {
     const float R = c->fine_radius * g.inv_cell;                // cells
-    const float scx = (c->fine_center[0] - g.ox) * g.inv_cell, scy = (c->fine_center[1] - g.oy) * g.inv_cell;
+    const float scx = (c->fine_center[0] - g.ox) * g.inv_cell - (float)g.six, scy = (c->fine_center[1] - g.oy) * g.inv_cell - (float)g.siy;
     for (const auto& q : c->crowd_cells) {
       if (c->have_fine_center) {
         const float dx = (float)q[0] + 0.5f - scx, dy = (float)q[1] + 0.5f - scy;
@@ -617,7 +622,8 @@ static int update_fine_grid(flimo_ctx* c, bool relayout, const float4* new_pts =
   // region copied completely: the crowded cells and one cell around them
   float lo[3], hi[3];
   const float o[3] = {g.ox, g.oy, g.oz};
-  for (int a = 0; a < 3; a++) { lo[a] = o[a] + (float)(box[a] - 1) * g.cell; hi[a] = o[a] + (float)(box[3 + a] + 2) * g.cell; }
+  const int si3[3] = {g.six, g.siy, g.siz};
+  for (int a = 0; a < 3; a++) { lo[a] = o[a] + (float)(box[a] - 1 + si3[a]) * g.cell; hi[a] = o[a] + (float)(box[3 + a] + 2 + si3[a]) * g.cell; }
   const float cf = g.cell / (float)c->fine_div, inv_f = 1.0f / cf;
   const float of[3] = {lo[0] - cf, lo[1] - cf, lo[2] - cf};             // one fine cell of margin below the region
   int nf[3];
@@ -641,8 +647,12 @@ static int update_fine_grid(flimo_ctx* c, bool relayout, const float4* new_pts =
     c->fine_pts_cap = cap;
   }
   HIPCHK(c, map_box_copy(c->stream, g, c0, c1, c->d_fine_tmp, c->scratch));
-  HIPCHK(c, map_build_grid(c->stream, c->d_fine_tmp, m, c->d_fine_pts, c->fine_pts_cap, false, c->fine_idx, c->fine_pts_cap, of[0], of[1], of[2], inv_f, nf[0], nf[1], nf[2], 1,
-                           c->scratch));
+  {
+    GridView fg{};
+    fg.ox = of[0]; fg.oy = of[1]; fg.oz = of[2]; fg.inv_cell = inv_f; fg.cell = cf;
+    fg.nx = nf[0]; fg.ny = nf[1]; fg.nz = nf[2]; fg.xs = 1; fg.nxf = nf[0]; fg.nxs = nf[0] + 1;
+    HIPCHK(c, map_build_grid(c->stream, c->d_fine_tmp, m, c->d_fine_pts, c->fine_pts_cap, false, c->fine_idx, c->fine_pts_cap, fg, c->scratch));
+  }
   if (prof) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     fprintf(stderr, "[flimo fine] crowded cells + count %.1f us, copy + sort + tables of %d x %d x %d cells %.1f us (%u points)\n",
@@ -650,7 +660,7 @@ static int update_fine_grid(flimo_ctx* c, bool relayout, const float4* new_pts =
   }
   GridView& f = c->fine;
   f.pts = c->d_fine_pts;
-  f.ox = of[0]; f.oy = of[1]; f.oz = of[2];
+  f.ox = of[0]; f.oy = of[1]; f.oz = of[2]; f.six = f.siy = f.siz = 0;
   f.inv_cell = inv_f; f.cell = cf;
   f.nx = nf[0]; f.ny = nf[1]; f.nz = nf[2];
   f.n_pts = m; f.xs = 1; f.nxf = nf[0]; f.nxs = nf[0] + 1;
@@ -671,52 +681,30 @@ static int update_fine_grid(flimo_ctx* c, bool relayout, const float4* new_pts =
 //    into the sorted array (one streaming pass, map_merge_grid);
 //  * build: first build, or the map outgrew the geometry -> new geometry, laid out with slack on the sides that grew so
 //    that a sensor moving through new territory triggers it rarely, and a full sort.
+// (the k points appended since the index was last brought up to date go into their rows: map_merge_grid)
+static int merge_appended(flimo_ctx* c) {
+  const size_t n_old = c->grid.n_pts, k = c->map_n - n_old;
+  if (k == 0) { c->grid_valid = true; return FLIMO_OK; }
+  c->grid_valid = false;
+  HIPCHK(c, map_merge_grid(c->stream, c->d_map_sorted, c->sorted_cap, c->d_map_raw + n_old, k, c->idx, c->grid, c->scratch));
+  // (no wait here: everything that reads the index is queued behind this on the same stream; map_add_device ends synchronised
+  //  and looks whether the point array or the tile pool ran out)
+  c->grid.n_pts = (uint32_t)c->map_n;
+  c->grid_valid = true;
+  c->grid_merges++;
+  return update_fine_grid(c, false, c->d_map_raw + n_old, k);
+}
 static int rebuild_grid(flimo_ctx* c) {
   ctx_enter(c);
   if (c->map_n == 0) { c->grid_valid = false; return FLIMO_OK; }
   const float* bb = c->bb;    // tracked on the host while points are appended (no reduction kernel)
-  if (c->grid_valid && c->d_map_sorted && !c->full_rebuild && !c->force_full && c->grid.n_pts > 0 && c->map_n >= c->grid.n_pts &&
-      (c->map_n - c->grid.n_pts) <= c->grid.n_pts && grid_covers(c->grid, bb)) {
-    const size_t n_old = c->grid.n_pts, k = c->map_n - n_old;
-    if (k == 0) return FLIMO_OK;
-    c->grid_valid = false;
-    const GridView& g = c->grid;
-    HIPCHK(c, map_merge_grid(c->stream, c->d_map_sorted, c->sorted_cap, c->d_map_raw + n_old, k, c->idx,
-                             g.ox, g.oy, g.oz, g.inv_cell, g.nx, g.ny, g.nz, g.xs, c->scratch));
-    // (no wait here: everything that reads the index is queued behind this on the same stream; map_add_device ends synchronised
-    //  and looks whether the point array or the tile pool ran out)
-    c->grid.n_pts = (uint32_t)c->map_n;
-    c->grid_valid = true;
-    c->grid_merges++;
-    return update_fine_grid(c, false, c->d_map_raw + n_old, k);
-  }
-  if (getenv("FLIMO_PROF_INSERT"))
-    fprintf(stderr, "[flimo index] full layout: valid %d sorted %p full_rebuild %d force %d n_pts %u map_n %zu covers %d  box [%g %g %g | %g %g %g] grid o (%g %g %g) n (%d %d %d)\n",
-            (int)c->grid_valid, (void*)c->d_map_sorted, (int)c->full_rebuild, (int)c->force_full, c->grid.n_pts, c->map_n,
-            c->grid_valid ? (int)grid_covers(c->grid, bb) : -1, bb[0], bb[1], bb[2], bb[3], bb[4], bb[5], c->grid.ox, c->grid.oy, c->grid.oz,
-            c->grid.nx, c->grid.ny, c->grid.nz);
+  const bool index_live = c->grid_valid && c->d_map_sorted && !c->full_rebuild && !c->force_full && c->grid.n_pts > 0 &&
+                          c->map_n >= c->grid.n_pts && (c->map_n - c->grid.n_pts) <= c->grid.n_pts;
+  if (index_live && grid_covers(c->grid, bb)) return merge_appended(c);
   c->grid_valid = false;
   float cell = c->map_cfg.cell_size > 0.f ? c->map_cfg.cell_size : 0.5f;
-  int nx = 0, ny = 0, nz = 0;
-  float ox = 0.f, oy = 0.f, oz = 0.f, inv = 1.f;
-  float W[6];
-  int xs = c->xslabs;
-  auto layout = [&](const float* box) {
-    inv = 1.0f / cell;
-    ox = box[0] - 0.5f * cell; oy = box[1] - 0.5f * cell; oz = box[2] - 0.5f * cell;
-    // same float expression as the kernels: floor((p - o) * inv)
-    nx = (int)floorf((box[3] - ox) * inv) + 2;
-    ny = (int)floorf((box[4] - oy) * inv) + 2;
-    nz = (int)floorf((box[5] - oz) * inv) + 2;
-    // both indices stay 32-bit addressable; the fine x columns are given up first (xs = preferred .. 1), then the cell grows
-    for (xs = c->xslabs; xs >= 1; xs >>= 1) {
-      const double ncols = (double)ny * (double)nz * ((double)nx * xs + 1.0);              // (32-bit column keys)
-      if (ncols < 1.9e9) return true;
-    }
-    xs = 1;
-    return false;
-  };
   // slack: a side the map has grown beyond since the last layout moves out by max(8 cells, 1/8 of the extent)
+  float W[6];
   for (int a = 0; a < 3; a++) { W[a] = bb[a]; W[3 + a] = bb[3 + a]; }
   if (!c->have_gbox) {
     // first layout: a little room on every side (8 cells horizontally, 4 vertically), so that the first scans inserted into a
@@ -729,15 +717,93 @@ static int rebuild_grid(flimo_ctx* c) {
       W[3 + a] = (bb[3 + a] > c->gbox[3 + a]) ? bb[3 + a] + pad : c->gbox[3 + a];
     }
   }
+  // ---- the map outgrew its grid, the index is up to date: the grid grows, nothing is sorted.  The origin of the cells is fixed
+  //      (GridView); the corner moves down by whole tiles, the extents follow; the rows stay where they are and new rows start
+  //      empty (index_regrid).  Not when the larger grid needs another tile shape or 32-bit column keys no longer do. ----
+  if (index_live && c->have_origin && cell == c->grid.cell) {
+    const GridView O = c->grid;
+    GridView N = O;
+    const float o[3] = {O.ox, O.oy, O.oz};
+    const int si_old[3] = {O.six, O.siy, O.siz}, n_old[3] = {O.nx, O.ny, O.nz};
+    const int T[3] = {std::max(1, (8 << O.ts) / O.xs), 1 << O.ty, 1 << O.tz};      // cells per tile
+    int si[3], n[3];
+    for (int a = 0; a < 3; a++) {
+      const int lo = (int)floorf((W[a] - 0.5f * cell - o[a]) * O.inv_cell), hi = (int)floorf((W[3 + a] - o[a]) * O.inv_cell);
+      si[a] = si_old[a];
+      if (lo < si_old[a]) si[a] = si_old[a] - ((si_old[a] - lo + T[a] - 1) / T[a]) * T[a];
+      n[a] = std::max(hi - si[a] + 2, n_old[a] + (si_old[a] - si[a]));
+    }
+    N.six = si[0]; N.siy = si[1]; N.siz = si[2];
+    N.nx = n[0]; N.ny = n[1]; N.nz = n[2];
+    N.nxf = N.nx * N.xs; N.nxs = N.nxf + 1;
+    const double ncols = (double)N.ny * (double)N.nz * ((double)N.nx * N.xs + 1.0);
+    hipError_t e = ncols < 1.9e9 ? index_regrid(c->stream, c->idx, O, N) : hipErrorInvalidValue;
+    if (e == hipSuccess) {
+      // the crowded cells listed so far (second level): the same cells under the new corner
+      const int d[3] = {si_old[0] - si[0], si_old[1] - si[1], si_old[2] - si[2]};
+      for (auto& q : c->crowd_cells) for (int a = 0; a < 3; a++) q[a] += d[a];
+      if (c->crowd_box_valid && c->d_crowd_list && c->crowd_cells.size() == c->crowd_listed) {
+        // ... and the device's bit per cell, re-made from the list (a look at every cell of a 20M-point map's grid is milliseconds)
+        const size_t words = ((size_t)N.nx * N.ny * N.nz + 31) / 32;
+        if (words > c->crowd_bits_cap) {
+          (void)hipFree(c->d_crowd_bits);
+          c->d_crowd_bits = nullptr; c->crowd_bits_cap = 0;
+          HIPCHK(c, hipMalloc(&c->d_crowd_bits, (words + words / 4 + 64) * sizeof(uint32_t)));
+          c->crowd_bits_cap = words + words / 4 + 64;
+        }
+        std::vector<int> buf(4 * c->crowd_cells.size() + 4);
+        for (size_t i = 0; i < c->crowd_cells.size(); i++) { buf[4 * i] = c->crowd_cells[i][0]; buf[4 * i + 1] = c->crowd_cells[i][1]; buf[4 * i + 2] = c->crowd_cells[i][2]; buf[4 * i + 3] = 0; }
+        if (!c->crowd_cells.empty())
+          HIPCHK(c, hipMemcpyAsync(c->d_crowd_list, buf.data(), c->crowd_cells.size() * sizeof(int4), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, crowded_relist(c->stream, (const int4*)c->d_crowd_list, (uint32_t)c->crowd_cells.size(), N.nx, N.ny, N.nz, c->d_crowd_bits, c->d_crowd_count));
+        HIPCHK(c, hipStreamSynchronize(c->stream));              // (buf goes out of scope)
+      } else {
+        c->crowd_box_valid = false;                                // (every cell is looked at again at the next index update)
+      }
+      c->grid = N;
+      for (int a = 0; a < 6; a++) c->gbox[a] = W[a];
+      c->grid_regrids++;
+      return merge_appended(c);
+    }
+    if (e != hipErrorInvalidValue) HIPCHK(c, e);
+  }
+  if (getenv("FLIMO_PROF_INSERT"))
+    fprintf(stderr, "[flimo index] full layout: sorted %p full_rebuild %d force %d n_pts %u map_n %zu  box [%g %g %g | %g %g %g] grid o (%g %g %g) n (%d %d %d)\n",
+            (void*)c->d_map_sorted, (int)c->full_rebuild, (int)c->force_full, c->grid.n_pts, c->map_n,
+            bb[0], bb[1], bb[2], bb[3], bb[4], bb[5], c->grid.ox, c->grid.oy, c->grid.oz, c->grid.nx, c->grid.ny, c->grid.nz);
+  // ---- full layout: sort everything.  The origin stays once it is set (same cell size); the corner is a cell shift. ----
+  GridView G{};
+  int xs = c->xslabs;
+  auto layout = [&](const float* box) {
+    G.cell = cell; G.inv_cell = 1.0f / cell;
+    if (c->have_origin && cell == c->grid.cell) { G.ox = c->grid.ox; G.oy = c->grid.oy; G.oz = c->grid.oz; }
+    else { G.ox = box[0] - 0.5f * cell; G.oy = box[1] - 0.5f * cell; G.oz = box[2] - 0.5f * cell; }
+    // same float expression as the kernels: floor((p - o) * inv) - shift
+    G.six = (int)floorf((box[0] - 0.5f * cell - G.ox) * G.inv_cell);
+    G.siy = (int)floorf((box[1] - 0.5f * cell - G.oy) * G.inv_cell);
+    G.siz = (int)floorf((box[2] - 0.5f * cell - G.oz) * G.inv_cell);
+    G.nx = (int)floorf((box[3] - G.ox) * G.inv_cell) - G.six + 2;
+    G.ny = (int)floorf((box[4] - G.oy) * G.inv_cell) - G.siy + 2;
+    G.nz = (int)floorf((box[5] - G.oz) * G.inv_cell) - G.siz + 2;
+    // column keys stay 32-bit; the fine x columns are given up first (xs = preferred .. 1), then the cell grows
+    for (xs = c->xslabs; xs >= 1; xs >>= 1) {
+      const double ncols = (double)G.ny * (double)G.nz * ((double)G.nx * xs + 1.0);
+      if (ncols < 1.9e9) return true;
+    }
+    xs = 1;
+    return false;
+  };
   if (!layout(W)) {
     for (int a = 0; a < 6; a++) W[a] = bb[a];
-    while (!layout(W)) cell *= 2.0f;   // keep the dense index addressable with 32 bits
+    while (!layout(W)) cell *= 2.0f;   // keep the column keys within 32 bits
   }
+  G.xs = xs; G.nxf = G.nx * xs; G.nxs = G.nxf + 1;
   for (int a = 0; a < 6; a++) c->gbox[a] = W[a];
   c->have_gbox = true;
   if (!c->d_map_sorted) {
     // the rows of the cell-sorted copy are not packed (a build leaves half a row's length of room behind every row, an insert
-    // moves a row that outgrows its room to the end): three times the raw capacity (freed whenever that grows); an insert that finds it full has the map laid out afresh, packed
+    // moves a row that outgrows its room to the end): three times the raw capacity (freed whenever that grows); an insert that
+    // finds it full has the map laid out afresh
     c->sorted_cap = 3 * c->map_cap + 65536;
     HIPCHK(c, hipMalloc(&c->d_map_sorted, c->sorted_cap * sizeof(float4)));
   }
@@ -746,18 +812,15 @@ static int rebuild_grid(flimo_ctx* c) {
     c->sorted_cap = c->map_n + 4096;
     HIPCHK(c, hipMalloc(&c->d_map_sorted, c->sorted_cap * sizeof(float4)));
   }
-  HIPCHK(c, map_build_grid(c->stream, c->d_map_raw, c->map_n, c->d_map_sorted, c->sorted_cap, true, c->idx, c->map_cap, ox, oy, oz, inv, nx, ny, nz, xs, c->scratch));
+  HIPCHK(c, map_build_grid(c->stream, c->d_map_raw, c->map_n, c->d_map_sorted, c->sorted_cap, c->row_slack, c->idx, c->map_cap, G, c->scratch));
   c->scratch.mail_host[MAIL_TILES + 2] = c->scratch.mail_host[MAIL_TILES + 3] = c->scratch.mail_host[MAIL_ROWS] = 0u;      // (the merges' words: tiles taken, "ran out", "array full")
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  c->grid.pts = c->d_map_sorted;
-  c->grid.ox = ox; c->grid.oy = oy; c->grid.oz = oz;
-  c->grid.inv_cell = inv;
-  c->grid.cell = cell;
-  c->grid.nx = nx; c->grid.ny = ny; c->grid.nz = nz;
-  c->grid.xs = xs; c->grid.nxf = nx * xs; c->grid.nxs = nx * xs + 1;
+  G.pts = c->d_map_sorted;
+  c->grid = G;
   index_view(c->idx, c->grid);
   c->grid.n_pts = (uint32_t)c->map_n;
   c->grid_valid = true;
+  c->have_origin = true;
   c->force_full = false;
   c->grid_builds++;
   return update_fine_grid(c, true);
@@ -781,7 +844,7 @@ extern "C" int flimo_map_grid_selfcheck(flimo_ctx* c, uint64_t* mismatches, uint
   HIPCHK(c, hipMalloc(&t.pts, n * sizeof(float4)));
   HIPCHK(c, hipMalloc(&t.diff, sizeof(unsigned long long)));
   HIPCHK(c, hipMemsetAsync(t.diff, 0, sizeof(unsigned long long), c->stream));
-  HIPCHK(c, map_build_grid(c->stream, c->d_map_raw, n, t.pts, n, false, t.idx, n, g.ox, g.oy, g.oz, g.inv_cell, g.nx, g.ny, g.nz, g.xs, c->scratch));
+  HIPCHK(c, map_build_grid(c->stream, c->d_map_raw, n, t.pts, n, false, t.idx, n, g, c->scratch));
   // by meaning: every row holds the same points in the same order, every row's position at every column agrees with its own
   // array (the rows of the maintained copy are not packed; escapes and tiles take their numbers in arrival order)
   GridView ref = g;

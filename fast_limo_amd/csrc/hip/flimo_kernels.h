@@ -147,6 +147,7 @@ hipError_t index_scan(hipStream_t st, const float4* in, size_t n, float4* out, c
 struct IndexTables {
   uint2* tiles = nullptr; size_t tiles_cap_entries = 0;
   uint32_t cap_tiles = 0, tiles_used = 0;                 // tiles of the current shape the pool holds / numbers taken at the last build
+  TileShape shape{5, 5, 3, 0, 0, 0};                      // the tile shape of the last layout (ts, ty, tz; the extents follow the grid)
   uint16_t* dir = nullptr;                                // GRID_DIR_MAX entries
   uint32_t* need = nullptr;                               // GRID_DIR_MAX words: tiles a batch of new points needs
   uint32_t* counters = nullptr;                           // [0] next free tile number, [1] a merge ran out of tiles, [2] escape slots taken
@@ -161,9 +162,12 @@ void index_free(IndexTables& T);
 // stream waited for once: the pool is sized by the number of tiles the points need).  slack: the rows keep room behind their last
 // point (a map that receives inserts) as far as out_cap allows; otherwise they are packed.  pts_cap: capacity of the point buffer
 // the index is for (sizes the escape pool).
+// geo: the grid's geometry (origin, cell, extents, column factor, cell shifts; its table pointers are not looked at).
 hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4* pts_out, size_t out_cap, bool slack, IndexTables& T, size_t pts_cap,
-                          float ox, float oy, float oz, float inv_cell, int nx, int ny, int nz, int xs,
-                          MapBuildScratch& S);
+                          const GridView& geo, MapBuildScratch& S);
+// A grid that grows without a re-sort: N = the new geometry (extents and cell shifts; origin, cell, column factor as O; corner moved
+// by whole tiles of O's shape).  hipErrorInvalidValue when the larger grid needs another tile shape (the caller builds afresh).
+hipError_t index_regrid(hipStream_t st, IndexTables& T, const GridView& O, GridView& N);
 // fills the table pointers and the tile shape of a GridView whose geometry (nx, ny, nz, xs, nxf) is set
 void index_view(const IndexTables& T, GridView& G);
 // after the stream has been waited for: did a merge since the last build run out of tiles (the index is then incomplete)?
@@ -175,8 +179,7 @@ hipError_t index_compare(hipStream_t st, const GridView& A, const GridView& B, u
 // received points is rebuilt from those rows.  O(rows + touched rows x row length): no pass over the stored points.  A full array
 // or tile pool is reported after the stream has been waited for (index_merge_overflow): the caller lays the map out afresh.
 hipError_t map_merge_grid(hipStream_t st, float4* sorted, size_t sorted_cap, const float4* new_pts, size_t k,
-                          IndexTables& T, float ox, float oy, float oz,
-                          float inv_cell, int nx, int ny, int nz, int xs, MapBuildScratch& S);
+                          IndexTables& T, const GridView& geo, MapBuildScratch& S);
 // Input filters of a raw sweep (32-byte PointType records already on the device): NaN removal, crop box, every rate-th survivor,
 // min distance; order preserved.  out[k] = (xyz, w = k), t_out[k] = stamp without the sweep offset; ext_dev[4] = {extreme ordered
 // stamp key (complemented when the sweep is sorted descending), kept count, "a kept stamp is NaN", "two kept stamps are equal"
@@ -199,6 +202,7 @@ hipError_t crowded_list_all(hipStream_t st, const GridView& G, uint32_t threshol
                             int4* list, uint32_t cap, uint32_t* count_dev, uint32_t* count_host, MapBuildScratch& S);
 hipError_t crowded_list_points(hipStream_t st, const float4* pts, size_t k, const GridView& G, uint32_t threshold, uint32_t* bits, int4* list,
                                uint32_t cap, uint32_t* count_dev, uint32_t* count_host, MapBuildScratch& S);
+hipError_t crowded_relist(hipStream_t st, const int4* list, uint32_t m, int nx, int ny, int nz, uint32_t* bits, uint32_t* count_dev);
 hipError_t map_box_count(hipStream_t st, const GridView& G, const int c0[3], const int c1[3],
                          uint32_t* count_dev, uint32_t* count_host, MapBuildScratch& S);
 hipError_t map_box_copy(hipStream_t st, const GridView& G, const int c0[3], const int c1[3], float4* out, MapBuildScratch& S);

@@ -164,11 +164,11 @@ FLIMO_DEV void knn_search(const GridView& G, float gx, float gy, float gz, int s
   const float flx = floorf(fminf(fmaxf(fx, -lim), lim));
   const float fly = floorf(fminf(fmaxf(fy, -lim), lim));
   const float flz = floorf(fminf(fmaxf(fz, -lim), lim));
-  const int cx = (int)flx, cy = (int)fly, cz = (int)flz;
+  const int cx = (int)flx - G.six, cy = (int)fly - G.siy, cz = (int)flz - G.siz;      // (GridView: the origin is fixed, the grid's corner is a cell shift)
   const float rx = fminf(fmaxf(fx - flx, 0.f), 1.f), ry = fminf(fmaxf(fy - fly, 0.f), 1.f),
               rz = fminf(fmaxf(fz - flz, 0.f), 1.f);
 
-  const int maxdim = max(G.nx, max(G.ny, G.nz));
+  const int maxdim = grid_maxdim(G);
   const float margin = 1.0e-3f + 4.0e-7f * (float)maxdim;   // cell units; covers the rounding of the cell map
   const float cell2 = G.cell * G.cell;
   const float edge = fminf(fminf(fminf(rx, 1.f - rx), fminf(ry, 1.f - ry)), fminf(rz, 1.f - rz));
@@ -499,7 +499,7 @@ __device__ __forceinline__ void knn5_tail(const GridView& G, const uint16_t* dir
   const int Gl = 64 / ngroups;
   const int lg = __ffs(Gl) - 1;
   const int grp = lane >> lg, sub = lane & (Gl - 1);
-  const int maxdim = max(G.nx, max(G.ny, G.nz));
+  const int maxdim = grid_maxdim(G);
   const float margin = 1.0e-3f + 4.0e-7f * (float)maxdim;
   const double none = __longlong_as_double((long long)KEY_NONE);
   int cand = 0;
@@ -514,7 +514,7 @@ __device__ __forceinline__ void knn5_tail(const GridView& G, const uint16_t* dir
     const float fx = (qx - G.ox) * G.inv_cell, fy = (qy - G.oy) * G.inv_cell, fz = (qz - G.oz) * G.inv_cell;
     const float flx = floorf(fminf(fmaxf(fx, -1.0e9f), 1.0e9f)), fly = floorf(fminf(fmaxf(fy, -1.0e9f), 1.0e9f)),
                 flz = floorf(fminf(fmaxf(fz, -1.0e9f), 1.0e9f));
-    const int cx = (int)flx, cy = (int)fly, cz = (int)flz;
+    const int cx = (int)flx - G.six, cy = (int)fly - G.siy, cz = (int)flz - G.siz;      // (GridView: the origin is fixed, the grid's corner is a cell shift)
     const float rx = fminf(fmaxf(fx - flx, 0.f), 1.f), ry = fminf(fmaxf(fy - fly, 0.f), 1.f),
                 rz = fminf(fmaxf(fz - flz, 0.f), 1.f);
     const float edge = fminf(fminf(fminf(rx, 1.f - rx), fminf(ry, 1.f - ry)), fminf(rz, 1.f - rz));
@@ -880,19 +880,20 @@ __device__ __forceinline__ void tie_repair_wave(const GridView& G, const BookVie
 // The directory of the index (GridView) in the workgroup's shared memory: at most GRID_DIR_MAX 16-bit entries = 512 x 16 bytes, two
 // 16-byte loads per thread (the host pads the directory to a multiple of 16 bytes).  Fetch and store are separate so that a launch
 // can have the loads in flight while it fetches its query; the store is followed by a barrier (every thread of the workgroup).
-struct DirRegs { uint4 a, b; };
+struct DirRegs { uint4 v[GRID_DIR_MAX / 8 / 256]; };
 __device__ __forceinline__ DirRegs grid_dir_fetch(const GridView& G) {
   const int n16 = (G.ntx * G.nty * G.ntz + 7) >> 3;
   const uint4* src = reinterpret_cast<const uint4*>(G.dir);
   DirRegs r;
-  r.a = (int)threadIdx.x < n16 ? src[threadIdx.x] : make_uint4(0u, 0u, 0u, 0u);
-  r.b = (int)threadIdx.x + 256 < n16 ? src[threadIdx.x + 256] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+  for (int k = 0; k < GRID_DIR_MAX / 8 / 256; k++)
+    r.v[k] = (int)threadIdx.x + 256 * k < n16 ? src[threadIdx.x + 256 * k] : make_uint4(0u, 0u, 0u, 0u);
   return r;
 }
 __device__ __forceinline__ void grid_dir_store(uint16_t* s_dir, const DirRegs& r) {
   uint4* dst = reinterpret_cast<uint4*>(s_dir);
-  dst[threadIdx.x] = r.a;
-  dst[threadIdx.x + 256] = r.b;
+#pragma unroll
+  for (int k = 0; k < GRID_DIR_MAX / 8 / 256; k++) dst[threadIdx.x + 256 * k] = r.v[k];
   __syncthreads();
 }
 // The pass's body, shared by the two kernels below: a host-driven pass gets its pose constants by value (kernel arguments), a
@@ -1009,7 +1010,7 @@ __device__ __forceinline__ void knn5_pass(const GridView& G, uint16_t* dir, cons
     const float lim = 1.0e9f;
     const float flx = floorf(fminf(fmaxf(fx, -lim), lim)), fly = floorf(fminf(fmaxf(fy, -lim), lim)),
                 flz = floorf(fminf(fmaxf(fz, -lim), lim));
-    const int cx = (int)flx, cy = (int)fly, cz = (int)flz;
+    const int cx = (int)flx - G.six, cy = (int)fly - G.siy, cz = (int)flz - G.siz;      // (GridView: the origin is fixed, the grid's corner is a cell shift)
     qcx = cx; qcy = cy; qcz = cz;
     const int ox_ = cx < 0 ? -cx : (cx >= G.nx ? cx - G.nx + 1 : 0);
     const int oy_ = cy < 0 ? -cy : (cy >= G.ny ? cy - G.ny + 1 : 0);
@@ -1031,14 +1032,14 @@ __device__ __forceinline__ void knn5_pass(const GridView& G, uint16_t* dir, cons
       // (32-bit table indices: the host keeps the table below 2^32 entries)
       const float rx = fminf(fmaxf(fx - flx, 0.f), 1.f), ry = fminf(fmaxf(fy - fly, 0.f), 1.f),
                   rz = fminf(fmaxf(fz - flz, 0.f), 1.f);
-      const int maxdim = max(G.nx, max(G.ny, G.nz));
+      const int maxdim = grid_maxdim(G);
       const float margin = 1.0e-3f + 4.0e-7f * (float)maxdim;
       int c0 = (cx - 1) * G.xs, c1 = (cx + 2) * G.xs;          // first column, one past the last
       if (prev_valid && b2 < 1.0e6f) {
         const float rb_ = fl_sqrt(b2) + margin;                 // reach along x in cell units (b2 is already inflated)
         const float fxs = (float)G.xs;
-        c0 = max(c0, (int)floorf((fx - rb_) * fxs));
-        c1 = min(c1, (int)floorf((fx + rb_) * fxs) + 1);
+        c0 = max(c0, (int)floorf((fx - rb_) * fxs) - G.six * G.xs);
+        c1 = min(c1, (int)floorf((fx + rb_) * fxs) - G.six * G.xs + 1);
       }
       c0 = min(max(c0, 0), G.nxf);
       c1 = min(max(c1, c0), G.nxf);
@@ -1131,7 +1132,7 @@ __device__ __forceinline__ void knn5_pass(const GridView& G, uint16_t* dir, cons
       // its own cell otherwise: in a crowded cell the column holds a fraction of the points and its 5th distance is as good.
       uint32_t lo_own = own_a, hi_own = own_b;
       if (heavy_block && G.xs > 1 && hi_own - lo_own >= 2u * PROBE_MIN_OWN) {
-        const int col = min(max((int)floorf(fx * (float)G.xs), cx * G.xs), (cx + 1) * G.xs - 1);
+        const int col = min(max((int)floorf(fx * (float)G.xs) - G.six * G.xs, cx * G.xs), (cx + 1) * G.xs - 1);
         const uint32_t ca = (col == cx * G.xs) ? lo_own : centre_pos(col);
         const uint32_t cb = (col + 1 == (cx + 1) * G.xs) ? hi_own : centre_pos(col + 1);
         if (cb - ca >= PROBE_MIN_OWN) { lo_own = ca; hi_own = cb; }
@@ -1190,8 +1191,8 @@ __device__ __forceinline__ void knn5_pass(const GridView& G, uint16_t* dir, cons
             if (bb < 1.0e6f) {
               const float rb_ = fl_sqrt(bb) + margin;
               const float fxs = (float)G.xs;
-              h0 = max(h0, (int)floorf((fx - rb_) * fxs));
-              h1 = min(h1, (int)floorf((fx + rb_) * fxs) + 1);
+              h0 = max(h0, (int)floorf((fx - rb_) * fxs) - G.six * G.xs);
+              h1 = min(h1, (int)floorf((fx + rb_) * fxs) - G.six * G.xs + 1);
             }
             h0 = min(max(h0, 0), G.nxf);
             h1 = min(max(h1, h0), G.nxf);
@@ -1479,7 +1480,7 @@ __device__ __forceinline__ void widen_body(const GridView& G, int max_ring, NbrR
                                            unsigned long long* __restrict__ cand_total, int first_ring, const TieList& tl,
                                            int blk, int nblk, uint32_t (*s_off)[65], uint32_t (*s_lo)[64]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int maxdim = max(G.nx, max(G.ny, G.nz));
+  const int maxdim = grid_maxdim(G);
   const float margin = 1.0e-3f + 4.0e-7f * (float)maxdim;
   // the first entry of this wave is fetched together with the count (one round trip); slots beyond the count hold
   // stale entries of earlier passes and are never used
@@ -1495,7 +1496,7 @@ __device__ __forceinline__ void widen_body(const GridView& G, int max_ring, NbrR
     const float fx = (gx - G.ox) * G.inv_cell, fy = (gy - G.oy) * G.inv_cell, fz = (gz - G.oz) * G.inv_cell;
     const float flx = floorf(fminf(fmaxf(fx, -1.0e9f), 1.0e9f)), fly = floorf(fminf(fmaxf(fy, -1.0e9f), 1.0e9f)),
                 flz = floorf(fminf(fmaxf(fz, -1.0e9f), 1.0e9f));
-    const int cx = (int)flx, cy = (int)fly, cz = (int)flz;
+    const int cx = (int)flx - G.six, cy = (int)fly - G.siy, cz = (int)flz - G.siz;      // (GridView: the origin is fixed, the grid's corner is a cell shift)
     const float rx = fminf(fmaxf(fx - flx, 0.f), 1.f), ry = fminf(fmaxf(fy - fly, 0.f), 1.f),
                 rz = fminf(fmaxf(fz - flz, 0.f), 1.f);
     const float edge = fminf(fminf(fminf(rx, 1.f - rx), fminf(ry, 1.f - ry)), fminf(rz, 1.f - rz));
@@ -2125,12 +2126,12 @@ struct TieLds { float4 pt[64]; float d[64]; uint32_t pos[64]; unsigned int cnt; 
 __device__ bool tie_select_wave(const GridView& G, const BookView& B, float qx, float qy, float qz, float dk, int k, TieLds& S,
                                 uint32_t (&out_pos)[8], float (&out_d)[8]) {
   const int lane = threadIdx.x & 63;
-  const int maxdim = max(G.nx, max(G.ny, G.nz));
+  const int maxdim = grid_maxdim(G);
   const float margin = 1.0e-3f + 4.0e-7f * (float)maxdim;
   const float fx = (qx - G.ox) * G.inv_cell, fy = (qy - G.oy) * G.inv_cell, fz = (qz - G.oz) * G.inv_cell;
   const float flx = floorf(fminf(fmaxf(fx, -1.0e9f), 1.0e9f)), fly = floorf(fminf(fmaxf(fy, -1.0e9f), 1.0e9f)),
               flz = floorf(fminf(fmaxf(fz, -1.0e9f), 1.0e9f));
-  const int cx = (int)flx, cy = (int)fly, cz = (int)flz;
+  const int cx = (int)flx - G.six, cy = (int)fly - G.siy, cz = (int)flz - G.siz;      // (GridView: the origin is fixed, the grid's corner is a cell shift)
   const float rx = fminf(fmaxf(fx - flx, 0.f), 1.f), ry = fminf(fmaxf(fy - fly, 0.f), 1.f), rz = fminf(fmaxf(fz - flz, 0.f), 1.f);
   const float edge = fminf(fminf(fminf(rx, 1.f - rx), fminf(ry, 1.f - ry)), fminf(rz, 1.f - rz));
   // smallest ring whose block provably holds the ball of radius sqrt(dk) (the same bound the searches use, turned around)

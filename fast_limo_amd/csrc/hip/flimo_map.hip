@@ -61,22 +61,24 @@ __global__ __launch_bounds__(256) void bbox_kernel(const float4* __restrict__ pt
 
 // column key of a point: (z, y, fine x column).  The fine column is floor(t * xs) of the SAME rounded t = (p.x - ox) * inv_cell whose
 // floor is the cell (xs is a power of two: the product is exact), so columns nest in cells exactly.
-__device__ __forceinline__ uint32_t column_key(const float4& p, float ox, float oy, float oz, float inv_cell, int nx, int ny, int nz, int xs) {
-  const float tx = (p.x - ox) * inv_cell;     // identical float expression to the query side (flimo_kernels.hip: knn_search)
-  int cx = (int)floorf(fminf(fmaxf(tx * (float)xs, -1.0e9f), 1.0e9f));
-  int cy = (int)floorf((p.y - oy) * inv_cell);
-  int cz = (int)floorf((p.z - oz) * inv_cell);
-  cx = min(max(cx, 0), nx * xs - 1);
-  cy = min(max(cy, 0), ny - 1);
-  cz = min(max(cz, 0), nz - 1);
-  return (uint32_t)(((size_t)cz * ny + cy) * ((size_t)nx * xs + 1) + cx);      // (a row of the cell table: nxf columns + its end entry)
+// (the geometry a cell computation needs: GridView's, without its tables)
+struct CellGeo { float ox, oy, oz, inv_cell; int nx, ny, nz, xs, six, siy, siz; };
+static inline CellGeo cell_geo(const GridView& G) { return CellGeo{G.ox, G.oy, G.oz, G.inv_cell, G.nx, G.ny, G.nz, G.xs, G.six, G.siy, G.siz}; }
+__device__ __forceinline__ uint32_t column_key(const float4& p, const CellGeo& c) {
+  const float tx = (p.x - c.ox) * c.inv_cell;     // identical float expression to the query side (flimo_kernels.hip: knn_search)
+  int cx = (int)floorf(fminf(fmaxf(tx * (float)c.xs, -1.0e9f), 1.0e9f)) - c.six * c.xs;      // (the grid's corner: a whole-cell shift behind the floor)
+  int cy = (int)floorf((p.y - c.oy) * c.inv_cell) - c.siy;
+  int cz = (int)floorf((p.z - c.oz) * c.inv_cell) - c.siz;
+  cx = min(max(cx, 0), c.nx * c.xs - 1);
+  cy = min(max(cy, 0), c.ny - 1);
+  cz = min(max(cz, 0), c.nz - 1);
+  return (uint32_t)(((size_t)cz * c.ny + cy) * ((size_t)c.nx * c.xs + 1) + cx);      // (a row of columns: nxf of them + its end entry)
 }
-__global__ __launch_bounds__(256) void cellkey_kernel(const float4* __restrict__ pts, size_t n, float ox, float oy,
-                                                      float oz, float inv_cell, int nx, int ny, int nz, int xs,
+__global__ __launch_bounds__(256) void cellkey_kernel(const float4* __restrict__ pts, size_t n, CellGeo c,
                                                       uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  keys[i] = column_key(pts[i], ox, oy, oz, inv_cell, nx, ny, nz, xs);
+  keys[i] = column_key(pts[i], c);
   vals[i] = (uint32_t)i;
 }
 
@@ -415,7 +417,8 @@ static hipError_t sort_keys(hipStream_t st, size_t n, int bits, MapBuildScratch&
   return sort_pairs_u32(S.cub_tmp, tmp_bytes, S.keys_in, S.keys_out, S.vals_in, S.vals_out, (int)n, 0, bits, st);
 }
 void index_view(const IndexTables& T, GridView& G) {
-  const TileShape t = grid_tile_shape(G.nxf, G.ny, G.nz);
+  TileShape t = T.shape;                                          // (the shape the index was laid out with: a grown grid keeps it)
+  grid_tile_extent(t, G.nxf, G.ny, G.nz);
   G.tiles = T.tiles; G.dir = T.dir; G.ovf = T.ovf; G.xstart = T.xstart;
   G.ts = t.ts; G.ty = t.ty; G.tz = t.tz; G.ntx = t.ntx; G.nty = t.nty; G.ntz = t.ntz;
 }
@@ -437,11 +440,12 @@ static TabGeo tab_geo(int nx, int ny, int nz, int xs, const TileShape& ts) {
   return TabGeo{nx * xs + 1, ny, nz, ts.ts, ts.ty, ts.tz, ts.ntx, ts.nty, ts.ntz};
 }
 hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4* pts_out, size_t out_cap, bool slack, IndexTables& T, size_t pts_cap,
-                          float ox, float oy, float oz, float inv_cell, int nx, int ny, int nz, int xs,
-                          MapBuildScratch& S) {
+                          const GridView& geo, MapBuildScratch& S) {
+  const int nx = geo.nx, ny = geo.ny, nz = geo.nz, xs = geo.xs;
   const int nxf = nx * xs, nxs = nxf + 1;
   const size_t nrows = (size_t)ny * nz, ncols = nrows * (size_t)nxs;
   const TileShape shape = grid_tile_shape(nxf, ny, nz);
+  T.shape = shape;
   const TabGeo g = tab_geo(nx, ny, nz, xs, shape);
   const int ndir = shape.ntx * shape.nty * shape.ntz;
   hipError_t e = ensure_scratch(S, std::max(n, nrows + 1));       // (the rows' key ranges and rooms live in the sort's input buffers)
@@ -460,8 +464,7 @@ hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4
   }
   const int blocks = (int)((n + 255) / 256);
   if (blocks > 0)
-    hipLaunchKernelGGL(cellkey_kernel, dim3(blocks), dim3(256), 0, st, pts_in, n, ox, oy, oz, inv_cell, nx, ny, nz, xs,
-                       S.keys_in, S.vals_in);
+    hipLaunchKernelGGL(cellkey_kernel, dim3(blocks), dim3(256), 0, st, pts_in, n, cell_geo(geo), S.keys_in, S.vals_in);
   int bits = 1;                                                    // number of key bits actually used
   while (bits < 32 && ((size_t)1 << bits) < ncols) bits++;
   if (n > 0 && (e = sort_keys(st, n, bits, S)) != hipSuccess) return e;
@@ -524,22 +527,18 @@ hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4
 }
 
 // ---- incremental update of the cell-sorted map ------------------------------------------------
-// The map only grows (the insert rule drops incoming points, never stored ones), so when the grid geometry still covers
-// the map the k points appended since the last build are MERGED into the sorted array instead of sorting everything
-// again: the new points are sorted by cell (k is a scan, not the map), every stored point moves up by the number of new
-// points in lower cells, every new point lands behind the stored points of its cell -- exactly the array a stable sort
-// of (stored points..., new points...) by cell gives, i.e. what map_build_grid produces for the same geometry.
-// One streaming pass over the points and one over the cell table; the binary searches over the k new keys are done
-// once per block (first / last element) and only blocks that straddle a new key search per element.
+// The map only grows (the insert rule drops incoming points, never stored ones), so while the grid geometry still covers the map
+// the k points appended since the last build are put into their rows instead of sorting everything again: the new points are
+// sorted by column key (k is a scan, not the map) and every row that receives some is rewritten -- exactly the rows a stable sort
+// of (stored points..., new points...) by column key gives.
 // One row's points are one contiguous run of `pts`, but the rows are NOT packed behind each other (round 5): `xstart` says where a
-// row begins, `rowcap` how many points fit before the next one.  A build packs them (capacity = length); an insert touches only
+// row begins, `rowcap` how many points fit before the next one.  A build leaves room behind every row's last point; an insert touches only
 // the rows that receive points: a row whose new points fit is merged in place (old points move up inside the row, from the back),
 // a row that outgrows its room moves to the end of the array with room to double.  No pass over the stored points, no shift of
 // any other row.  What a row leaves behind is garbage until the next full build (which the insert asks for when the array is full).
 // Order inside a row: by column, stored points before new ones, new ones in their batch order -- exactly what a stable sort of
 // (stored..., new...) by column key gives, i.e. what map_build_grid produces for the same points.
-__device__ __forceinline__ int point_column(const float4* __restrict__ p, float ox, float oy, float oz, float inv_cell, int nx, int ny, int nz,
-                                            int xs, uint32_t first) {
+__device__ __forceinline__ int point_column(const float4* __restrict__ p, const CellGeo& c, uint32_t first) {
   // (points this workgroup has just written: read past the vector L1)
   const unsigned* w = reinterpret_cast<const unsigned*>(p);
   float4 q;
@@ -547,7 +546,7 @@ __device__ __forceinline__ int point_column(const float4* __restrict__ p, float 
   q.y = __uint_as_float(__hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
   q.z = __uint_as_float(__hip_atomic_load(w + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
   q.w = 0.f;
-  return (int)(column_key(q, ox, oy, oz, inv_cell, nx, ny, nz, xs) - first);
+  return (int)(column_key(q, c) - first);
 }
 // tail[0] = first free position behind the last row, tail[1] = 1: the array is full (nothing was written for that row; the host
 // lays the map out afresh), tail[2] = rows moved (statistics)
@@ -565,8 +564,7 @@ __global__ __launch_bounds__(256) void rows_touched_kernel(const uint32_t* __res
 __global__ __launch_bounds__(256) void rows_insert_kernel(SegTab T, uint32_t* __restrict__ rowcap, uint32_t* __restrict__ tail, uint32_t* __restrict__ full_mail, uint32_t pts_capacity,
                                                           float4* __restrict__ pts, const uint32_t* __restrict__ nkeys, uint32_t k,
                                                           const uint32_t* __restrict__ rows, const uint32_t* __restrict__ firsts,
-                                                          const float4* __restrict__ new_pts, const uint32_t* __restrict__ nperm,
-                                                          float ox, float oy, float oz, float inv_cell, int nx, int xs) {
+                                                          const float4* __restrict__ new_pts, const uint32_t* __restrict__ nperm, CellGeo cg) {
   __shared__ uint32_t s_cnt[SEG_WIN + 8], s_pre[513], s_scan[256], s_hi, s_dest;
   const TabGeo& g = T.g;
   const int t = (int)threadIdx.x;
@@ -622,7 +620,7 @@ __global__ __launch_bounds__(256) void rows_insert_kernel(SegTab T, uint32_t* __
     uint32_t sh = 0u;
     if (i < len_old && i >= i_stay) {
       p = src[i];
-      const uint32_t key = column_key(p, ox, oy, oz, inv_cell, nx, g.ny, g.nz, xs);
+      const uint32_t key = column_key(p, cg);
       if (keys_lds) {
         uint32_t a = 0u, b = add;
         while (a < b) { const uint32_t m = (a + b) >> 1; if (s_pre[m] < key) a = m + 1u; else b = m; }
@@ -642,21 +640,22 @@ __global__ __launch_bounds__(256) void rows_insert_kernel(SegTab T, uint32_t* __
   }
   __syncthreads();                                                 // (everybody is done with the old entries, every point is in place)
   row_entries(T, py, pz, dest, need,
-              [&](uint32_t i) { return point_column(dst + i, ox, oy, oz, inv_cell, nx, g.ny, g.nz, xs, first); }, s_cnt, s_pre, s_scan);
+              [&](uint32_t i) { return point_column(dst + i, cg, first); }, s_cnt, s_pre, s_scan);
  }
 }
 hipError_t map_merge_grid(hipStream_t st, float4* sorted, size_t sorted_cap, const float4* new_pts, size_t k,
-                          IndexTables& T, float ox, float oy, float oz,
-                          float inv_cell, int nx, int ny, int nz, int xs, MapBuildScratch& S) {
+                          IndexTables& T, const GridView& geo, MapBuildScratch& S) {
   if (k == 0) return hipSuccess;
+  const int nx = geo.nx, ny = geo.ny, nz = geo.nz, xs = geo.xs;
   const int nxs = nx * xs + 1;
   const size_t nrows = (size_t)ny * nz, ncols = nrows * (size_t)nxs;
-  const TileShape shape = grid_tile_shape(nx * xs, ny, nz);
+  TileShape shape = T.shape;
+  grid_tile_extent(shape, nx * xs, ny, nz);
   const TabGeo g = tab_geo(nx, ny, nz, xs, shape);
   hipError_t e = ensure_scratch(S, k);
   if (e != hipSuccess) return e;
   const int kb = (int)((k + 255) / 256);
-  hipLaunchKernelGGL(cellkey_kernel, dim3(kb), dim3(256), 0, st, new_pts, k, ox, oy, oz, inv_cell, nx, ny, nz, xs, S.keys_in, S.vals_in);
+  hipLaunchKernelGGL(cellkey_kernel, dim3(kb), dim3(256), 0, st, new_pts, k, cell_geo(geo), S.keys_in, S.vals_in);
   int bits = 1;
   while (bits < 32 && ((size_t)1 << bits) < ncols) bits++;
   if ((e = sort_keys(st, k, bits, S)) != hipSuccess) return e;
@@ -670,7 +669,7 @@ hipError_t map_merge_grid(hipStream_t st, float4* sorted, size_t sorted_cap, con
   hipLaunchKernelGGL(rows_touched_kernel, dim3(kb), dim3(256), 0, st, S.keys_out, (uint32_t)k, nxs, S.keys_in, S.vals_in, T.tail + 3);
   const unsigned walkers = (unsigned)std::min<size_t>(std::min<size_t>(k, nrows), 8192);
   hipLaunchKernelGGL(rows_insert_kernel, dim3(walkers), dim3(256), 0, st, tab, T.rowcap, T.tail, S.mail_dev + MAIL_ROWS, (uint32_t)std::min<size_t>(sorted_cap, 0xffffffffull),
-                     sorted, S.keys_out, (uint32_t)k, S.keys_in, S.vals_in, new_pts, S.vals_out, ox, oy, oz, inv_cell, nx, xs);
+                     sorted, S.keys_out, (uint32_t)k, S.keys_in, S.vals_in, new_pts, S.vals_out, cell_geo(geo));
   return hipGetLastError();
 }
 
@@ -708,13 +707,29 @@ __global__ __launch_bounds__(256) void crowded_points_kernel(const float4* __res
                                                              uint32_t cap, uint32_t* __restrict__ count) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= k) return;
-  const uint32_t col = column_key(pts[i], G.ox, G.oy, G.oz, G.inv_cell, G.nx, G.ny, G.nz, G.xs);
+  const uint32_t col = column_key(pts[i], CellGeo{G.ox, G.oy, G.oz, G.inv_cell, G.nx, G.ny, G.nz, G.xs, G.six, G.siy, G.siz});
   const uint32_t row = col / (uint32_t)G.nxs, xf = col - row * (uint32_t)G.nxs;
   const int x = (int)(xf / (uint32_t)G.xs), y = (int)(row % (uint32_t)G.ny), z = (int)(row / (uint32_t)G.ny);
   uint32_t lo, hi;
   grid_row_range(G, G.dir, y, z, x * G.xs, (x + 1) * G.xs, lo, hi);
   if (hi - lo <= threshold) return;
   crowded_append(row * (uint32_t)G.nx + (uint32_t)x, x, y, z, bits, list, cap, count);
+}
+// the bits of a list of crowded cells under another grid geometry (a grid that grew: index_regrid), count = the list's length
+__global__ __launch_bounds__(256) void crowded_relist_kernel(const int4* __restrict__ list, uint32_t m, int nx, int ny, uint32_t* __restrict__ bits,
+                                                             uint32_t* __restrict__ count) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) *count = m;
+  if (i >= m) return;
+  const int4 q = list[i];
+  const uint32_t cell = ((uint32_t)q.z * (uint32_t)ny + (uint32_t)q.y) * (uint32_t)nx + (uint32_t)q.x;
+  atomicOr(&bits[cell >> 5], 1u << (cell & 31u));
+}
+hipError_t crowded_relist(hipStream_t st, const int4* list, uint32_t m, int nx, int ny, int nz, uint32_t* bits, uint32_t* count_dev) {
+  hipError_t e = hipMemsetAsync(bits, 0, (((size_t)nx * ny * nz + 31) / 32) * sizeof(uint32_t), st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(crowded_relist_kernel, dim3((m + 255) / 256 + 1), dim3(256), 0, st, list, m, nx, ny, bits, count_dev);
+  return hipGetLastError();
 }
 // *count_host = entries listed so far (may exceed cap: the list is then incomplete)
 hipError_t crowded_list_all(hipStream_t st, const GridView& G, uint32_t threshold, uint32_t* bits,
@@ -817,6 +832,70 @@ hipError_t atan2f_probe(hipStream_t st, const float* yx_host, int n, float* out_
   if (e == hipSuccess) e = hipStreamSynchronize(st);
   (void)hipFree(d_in); (void)hipFree(d_out);
   return e;
+}
+
+// ---- a grid that grows without a re-sort ---------------------------------------------------------------------------------------
+// The origin of the cells is fixed (GridView): a larger grid is the same lattice with another corner (six, siy, siz) and other
+// extents.  When the corner moves by whole tiles and the tile shape stays, nothing a tile holds changes -- its counts are relative
+// to its own row segments -- and the sorted rows stay where they are: only the small tables are laid out afresh.
+//   regrid_rows_kernel : xstart and rowcap of every row of the new grid (an old row: its values, its row start / end for x-tiles
+//                        the old grid did not have; a new row: empty, no room -- its first points take it to the array's end)
+//   regrid_dir_kernel  : the directory (an old tile keeps its number)
+__global__ __launch_bounds__(256) void regrid_rows_kernel(GridView O, GridView N, uint32_t* __restrict__ xstart_new, uint32_t* __restrict__ rowcap_new,
+                                                          const uint32_t* __restrict__ rowcap_old) {
+  const uint32_t sy = (uint32_t)(N.ny + 2 * GRID_PAD), sz = (uint32_t)(N.nz + 2 * GRID_PAD);
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= sy * sz) return;
+  const uint32_t py = i % sy, pz = i / sy;
+  // the same row in the old grid (cell of the origin's lattice = y + siy)
+  const int yo = (int)py - GRID_PAD + N.siy - O.siy, zo = (int)pz - GRID_PAD + N.siz - O.siz;
+  const bool had = yo >= 0 && yo < O.ny && zo >= 0 && zo < O.nz;
+  const int dtx = ((N.six - O.six) * N.xs) >> (3 + N.ts);          // x-tile of the old grid = x-tile of the new one + dtx (whole tiles)
+  uint32_t first = 0u, last = 0u;
+  if (had) { first = grid_pos(O, O.dir, yo, zo, 0); last = grid_pos(O, O.dir, yo, zo, O.nxf); }
+  rowcap_new[pz * sy + py] = had ? rowcap_old[(uint32_t)(zo + GRID_PAD) * (uint32_t)(O.ny + 2 * GRID_PAD) + (uint32_t)(yo + GRID_PAD)] : 0u;
+  for (int tx = 0; tx < N.ntx; tx++) {
+    uint32_t v = 0u;
+    if (had) {
+      const int to = tx + dtx;
+      v = to < 0 ? first : (to >= O.ntx ? last : O.xstart[grid_xstart_index(O, (uint32_t)(yo + GRID_PAD), (uint32_t)(zo + GRID_PAD), (uint32_t)to)]);
+    }
+    xstart_new[(pz * (uint32_t)N.ntx + (uint32_t)tx) * sy + py] = v;
+  }
+}
+__global__ __launch_bounds__(256) void regrid_dir_kernel(GridView O, GridView N, uint16_t* __restrict__ dir_new) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N.ntx * N.nty * N.ntz) return;
+  const int tx = i % N.ntx, ty = (i / N.ntx) % N.nty, tz = i / (N.ntx * N.nty);
+  const int to_x = tx + (((N.six - O.six) * N.xs) >> (3 + N.ts)), to_y = ty + ((N.siy - O.siy) >> N.ty), to_z = tz + ((N.siz - O.siz) >> N.tz);
+  uint16_t v = 0;
+  if (to_x >= 0 && to_x < O.ntx && to_y >= 0 && to_y < O.nty && to_z >= 0 && to_z < O.ntz) v = O.dir[(to_z * O.nty + to_y) * O.ntx + to_x];
+  dir_new[i] = v;
+}
+// N: the new geometry (extents, shifts; same origin, cell, column factor and tile shape as O, corner moved by whole tiles).  The
+// tables of T are replaced, the tiles, the escapes and the points stay; N gets its views.
+hipError_t index_regrid(hipStream_t st, IndexTables& T, const GridView& O, GridView& N) {
+  TileShape sh = T.shape;                                          // the grid keeps its tile shape while the directory has room
+  grid_tile_extent(sh, N.nxf, N.ny, N.nz);
+  if ((long long)sh.ntx * sh.nty * sh.ntz > GRID_DIR_MAX) return hipErrorInvalidValue;
+  N.ts = sh.ts; N.ty = sh.ty; N.tz = sh.tz; N.ntx = sh.ntx; N.nty = sh.nty; N.ntz = sh.ntz;
+  const size_t nrowsp = ((size_t)N.ny + 2 * GRID_PAD) * ((size_t)N.nz + 2 * GRID_PAD), nx = grid_xstart_size(N.ny, N.nz, N.ntx);
+  uint32_t *xs2 = nullptr, *rc2 = nullptr;
+  uint16_t* dir2 = nullptr;
+  hipError_t e;
+  if ((e = hipMalloc(&xs2, (nx + nx / 2) * sizeof(uint32_t))) != hipSuccess) return e;
+  if ((e = hipMalloc(&rc2, (nrowsp + nrowsp / 2) * sizeof(uint32_t))) != hipSuccess) { (void)hipFree(xs2); return e; }
+  if ((e = hipMalloc(&dir2, (GRID_DIR_MAX + 8) * sizeof(uint16_t))) != hipSuccess) { (void)hipFree(xs2); (void)hipFree(rc2); return e; }
+  if ((e = hipMemsetAsync(dir2, 0, (GRID_DIR_MAX + 8) * sizeof(uint16_t), st)) != hipSuccess) return e;
+  hipLaunchKernelGGL(regrid_rows_kernel, dim3((unsigned)((nrowsp + 255) / 256)), dim3(256), 0, st, O, N, xs2, rc2, T.rowcap);
+  hipLaunchKernelGGL(regrid_dir_kernel, dim3((unsigned)((sh.ntx * sh.nty * sh.ntz + 255) / 256)), dim3(256), 0, st, O, N, dir2);
+  if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;    // (the old tables are freed below)
+  (void)hipFree(T.xstart); (void)hipFree(T.rowcap); (void)hipFree(T.dir);
+  T.xstart = xs2; T.xstart_cap = nx + nx / 2;
+  T.rowcap = rc2; T.rowcap_cap = nrowsp + nrowsp / 2;
+  T.dir = dir2;
+  N.tiles = T.tiles; N.dir = T.dir; N.ovf = T.ovf; N.xstart = T.xstart;
+  return hipGetLastError();
 }
 
 // ---- debug: two indices of the same geometry say the same (flimo_map_grid_selfcheck) -- compared by MEANING, column by column:

@@ -20,7 +20,7 @@ namespace flimo {
 //    the eight of rounds 3-5a (a row-major and a y-fastest table of 32-bit positions).
 //  * TILES: the entries live in tiles of 2^ts segments x 2^ty rows x 2^tz layers, and only tiles that hold a point exist; `dir`
 //    maps a tile's coordinates to its number in the pool (0: the shared all-zero tile: "no points here").  The directory is at most
-//    GRID_DIR_MAX 16-bit entries (the layout doubles the tile until it is): the k-NN pass keeps it in shared memory, so the way to an
+//    GRID_DIR_MAX 16-bit entries (a layout doubles the tile until half of that is enough: room for the grid to grow): the k-NN pass keeps it in shared memory, so the way to an
 //    entry is still ONE round trip to memory.  A row of a tile has 2^ts + 1 entries: the last one continues into the first
 //    segment of the next tile along x (same prefix base), so that the 16-byte load of two neighbouring entries never leaves the
 //    tile -- a tile whose first segment holds a point makes its left neighbour exist.
@@ -34,7 +34,11 @@ struct GridView {
   const uint16_t* dir;         // [ntz][nty][ntx]
   const uint32_t* ovf;         // [..][8]  escapes: points of the segment in columns below k, k = 0..7
   const uint32_t* xstart;      // [nz + 4][ntx][ny + 4]
-  float ox, oy, oz;            // min corner of cell (0,0,0)
+  float ox, oy, oz;            // the FIXED origin of the map's cells (set at the first layout): a point p lies in cell
+                               // floor((p - o) * inv_cell) - si.  A grid that grows moves its corner by whole cells (si), never
+                               // the origin: a stored point's cell -- and with it the sorted order, the tiles, the entries --
+                               // is the same under every later geometry (an integer subtraction behind the floor, no rounding)
+  int six, siy, siz;           // cell (0, 0, 0) of the grid is cell (six, siy, siz) of the origin's lattice
   float inv_cell;              // 1 / cell edge
   float cell;                  // cell edge [m]
   int nx, ny, nz;
@@ -48,18 +52,23 @@ struct GridView {
   int ntx, nty, ntz;           // directory extent
 };
 constexpr int GRID_PAD = 2;    // empty rows around the grid in y and z
-constexpr int GRID_DIR_MAX = 4096;
+constexpr int GRID_DIR_MAX = 4096;     // entries of the directory (8 KB of the pass's shared memory; 16 KB cost 0.7 us per pass)
+constexpr int GRID_DIR_BUILD = 2048;   // ... a layout uses at most: a grid that grows keeps its tile shape until the directory is full
 struct TileShape { int ts, ty, tz, ntx, nty, ntz; };
-// tile shape of a grid of nxf columns x ny x nz rows: from 32 segments (256 columns) x 32 rows x 8 layers, doubled (z, y, x in
-// turn) until the directory fits
+// directory extent of a grid of nxf columns x ny x nz rows under a tile shape
+inline void grid_tile_extent(TileShape& t, int nxf, int ny, int nz) {
+  const int nseg = (nxf >> 3) + 1;                         // segments 0 .. nxf >> 3 (column nxf -- a row's length -- has an entry)
+  t.ntx = (nseg + (1 << t.ts) - 1) >> t.ts;
+  t.nty = (ny + 2 * GRID_PAD + (1 << t.ty) - 1) >> t.ty;
+  t.ntz = (nz + 2 * GRID_PAD + (1 << t.tz) - 1) >> t.tz;
+}
+// tile shape a LAYOUT chooses: from 32 segments (256 columns) x 32 rows x 8 layers, doubled (z, y, x in turn) until the directory
+// has at most GRID_DIR_BUILD entries
 inline TileShape grid_tile_shape(int nxf, int ny, int nz) {
   TileShape t{5, 5, 3, 0, 0, 0};
   for (int turn = 0;; turn++) {
-    const int nseg = (nxf >> 3) + 1;                       // segments 0 .. nxf >> 3 (column nxf -- a row's length -- has an entry)
-    t.ntx = (nseg + (1 << t.ts) - 1) >> t.ts;
-    t.nty = (ny + 2 * GRID_PAD + (1 << t.ty) - 1) >> t.ty;
-    t.ntz = (nz + 2 * GRID_PAD + (1 << t.tz) - 1) >> t.tz;
-    if ((long long)t.ntx * t.nty * t.ntz <= GRID_DIR_MAX) return t;
+    grid_tile_extent(t, nxf, ny, nz);
+    if ((long long)t.ntx * t.nty * t.ntz <= GRID_DIR_BUILD) return t;
     if (turn % 3 == 0) t.tz++; else if (turn % 3 == 1) t.ty++; else t.ts++;
   }
 }
@@ -67,6 +76,10 @@ constexpr size_t grid_tile_entries(int ts, int ty, int tz) { return (((size_t)1 
 constexpr size_t grid_xstart_size(int ny, int nz, int ntx) { return ((size_t)ny + 2 * GRID_PAD) * ((size_t)nz + 2 * GRID_PAD) * (size_t)ntx; }
 
 #if defined(__HIPCC__)
+// what the rounding margin of the cell map scales with: the largest cell coordinate in the origin's lattice
+__device__ __forceinline__ int grid_maxdim(const GridView& G) {
+  return max(G.nx + abs(G.six), max(G.ny + abs(G.siy), G.nz + abs(G.siz)));
+}
 // points in the columns below column k (0..7) of a segment
 __device__ __forceinline__ uint32_t seg_count(uint32_t ex, uint32_t ey, uint32_t k, const uint32_t* __restrict__ ovf) {
   if (__builtin_expect((int)ex < 0, 0)) return (ex & 0x7fffffffu) + ovf[(size_t)ey * 8u + k];
