@@ -1386,7 +1386,13 @@ __global__ __launch_bounds__(256) KNN_WPE void knn5_kernel(GridView G, const flo
                                                    FuseArgs fa) {
   __shared__ __align__(16) uint16_t s_dir[GRID_DIR_MAX];
   const DirRegs dr = grid_dir_fetch(G);
-  knn5_pass<L, SLOTS, FUSE, FINE>(G, s_dir, &dr, scan_sorted, n, P, max_ring, nbr, wl, wl_count, cand_total, prev.RT, prev.valid, prev.probe_min, tail, fa);
+  // the pose constants go through shared memory (like a chained pass's, which reads them from the filter's head): 66 scalars that
+  // would otherwise sit in registers from the first instruction to the fit -- the barrier behind the directory's store covers them
+  __shared__ PoseMats s_pose;
+  static_assert(sizeof(PoseMats) % 4 == 0 && sizeof(PoseMats) / 4 <= 256, "one word per thread");
+  if (threadIdx.x < sizeof(PoseMats) / 4)
+    reinterpret_cast<uint32_t*>(&s_pose)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&P)[threadIdx.x];
+  knn5_pass<L, SLOTS, FUSE, FINE>(G, s_dir, &dr, scan_sorted, n, s_pose, max_ring, nbr, wl, wl_count, cand_total, prev.RT, prev.valid, prev.probe_min, tail, fa);
 }
 // How a launch of a chained pass gets the filter's head: a copy in the workgroup's shared memory (one word per thread), which the pass
 // reads its constants from.  wait_epoch == 0: the head was stored by an earlier launch on this stream (the algebra as a launch of

@@ -957,7 +957,7 @@ def test_l_shaped_two_kilometre_drive_keeps_the_index_sparse(built, oracle):
         print("L-shaped drive: map %d points (%.1f MB), index %.1f MB in %d tiles (a table over the box: %.0f MB), "
               "%d merges, %d full builds, %d of them for a full tile pool"
               % (ctx.map_size(), ib["points"] / 1e6, ib["index"] / 1e6, ib["tiles"], whole_box / 1e6, merges, builds, ib["tile_pool_relayouts"]))
-        assert ib["index"] < 0.4 * whole_box, (ib, whole_box)
+        assert ib["index"] < 0.5 * whole_box, (ib, whole_box)
         assert merges >= 120, (merges, builds)
         q = []
         for c in (pos[0], pos[50], pos[100], pos[150], pos[200], np.float32([500.0, 500.0, 0.0]), np.float32([-30.0, -30.0, 0.0])):
