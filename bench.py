@@ -301,7 +301,7 @@ def hbm_regime_leg(device, steps, with_oracle, max_threads=32):
     ib = loc.hip.map_index_bytes()
     out["index_bytes"] = dict(ib, over_map_bytes=ib["index"] / max(ib["points"], 1))
     out["map_insert_ms"] = {"first": 1e3 * ins[0], "repeat": 1e3 * float(np.median(ins[1:])), "points_stored": loc.map_size() - n0,
-                            "note": "flimo_map_add_scan of the resident scan, waited for; index merged incrementally"}
+                            "note": "flimo_map_add_scan of the resident scan, waited for; first: the scan's high points grow the map's box (the grid grows in place, nothing is re-sorted); repeat: the points go into their rows in place"}
     loc.close()
     return out
 

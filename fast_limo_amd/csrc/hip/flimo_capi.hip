@@ -47,9 +47,10 @@ struct flimo_ctx {
   bool have_gbox = false;
   bool force_full = false;         // the next index update lays the grid out afresh (cell size changed)
   bool full_rebuild = false;       // FLIMO_FULL_REBUILD=1: sort the whole map on every insert (A/B of the merge)
-  uint64_t grid_merges = 0, grid_builds = 0, grid_regrids = 0, index_overflows = 0;
+  uint64_t grid_merges = 0, grid_builds = 0, grid_regrids = 0, index_overflows = 0, pool_grows = 0;
   bool have_origin = false;        // the origin of the map's cells is set (GridView: it stays; a grid that grows moves its corner by whole cells)
   size_t map_n = 0, map_cap = 0, sorted_cap = 0;
+  bool sorted_follows = false;     // the raw buffer grew: the cell-sorted copy (3x its capacity) and the escape pool have to follow
   IndexTables idx;                 // the index of the main grid (GridView, flimo_types.h): tiles, directory, escapes, xstart
   GridView grid{};
   bool grid_valid = false;
@@ -686,6 +687,17 @@ static int merge_appended(flimo_ctx* c) {
   const size_t n_old = c->grid.n_pts, k = c->map_n - n_old;
   if (k == 0) { c->grid_valid = true; return FLIMO_OK; }
   c->grid_valid = false;
+  // room in the tile pool for what this insert may need (the count of tiles in use is the last insert's, read behind its wait):
+  // a quarter of the tiles in use, 64 at least -- a pool that runs out anyway has the map laid out afresh
+  {
+    const uint32_t used = std::max(c->idx.tiles_used, c->scratch.mail_host ? c->scratch.mail_host[MAIL_TILES + 2] : 0u);
+    const uint32_t want_free = std::max(64u, used / 4);
+    if (c->idx.cap_tiles < used + want_free) {
+      HIPCHK(c, index_grow_pool(c->stream, c->idx, used + 2 * want_free));
+      index_view(c->idx, c->grid);
+      c->pool_grows++;
+    }
+  }
   HIPCHK(c, map_merge_grid(c->stream, c->d_map_sorted, c->sorted_cap, c->d_map_raw + n_old, k, c->idx, c->grid, c->scratch));
   // (no wait here: everything that reads the index is queued behind this on the same stream; map_add_device ends synchronised
   //  and looks whether the point array or the tile pool ran out)
@@ -698,6 +710,31 @@ static int rebuild_grid(flimo_ctx* c) {
   ctx_enter(c);
   if (c->map_n == 0) { c->grid_valid = false; return FLIMO_OK; }
   const float* bb = c->bb;    // tracked on the host while points are appended (no reduction kernel)
+  if (c->sorted_follows) {
+    // the raw buffer grew (by a quarter each time): the cell-sorted copy moves into a larger array as it is -- its rows stay where
+    // they are -- and the escape pool grows with it; nothing is sorted
+    c->sorted_follows = false;
+    if (c->d_map_sorted && c->grid_valid && !c->test_tight_array) {
+      const size_t ncap = 3 * c->map_cap + 65536;
+      float4* np = nullptr;
+      HIPCHK(c, hipMalloc(&np, ncap * sizeof(float4)));
+      HIPCHK(c, hipMemcpyAsync(np, c->d_map_sorted, std::min(ncap, c->sorted_cap) * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+      const size_t ovf_words = (c->map_cap / 16 + 64) * 8;
+      uint32_t* no = nullptr;
+      if (ovf_words > c->idx.ovf_cap) {
+        HIPCHK(c, hipMalloc(&no, ovf_words * sizeof(uint32_t)));
+        HIPCHK(c, hipMemcpyAsync(no, c->idx.ovf, c->idx.ovf_cap * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+      }
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      (void)hipFree(c->d_map_sorted);
+      c->d_map_sorted = np; c->sorted_cap = ncap;
+      if (no) { (void)hipFree(c->idx.ovf); c->idx.ovf = no; c->idx.ovf_cap = ovf_words; }
+      c->grid.pts = c->d_map_sorted;
+      index_view(c->idx, c->grid);
+    } else if (c->d_map_sorted) {
+      (void)hipFree(c->d_map_sorted); c->d_map_sorted = nullptr; c->grid_valid = false;
+    }
+  }
   const bool index_live = c->grid_valid && c->d_map_sorted && !c->full_rebuild && !c->force_full && c->grid.n_pts > 0 &&
                           c->map_n >= c->grid.n_pts && (c->map_n - c->grid.n_pts) <= c->grid.n_pts;
   if (index_live && grid_covers(c->grid, bb)) return merge_appended(c);
@@ -865,7 +902,7 @@ static int map_append_host(flimo_ctx* c, const float4* pts, size_t n) {
   const size_t old_cap = c->map_cap;
   int rc = ensure_dev(c, c->d_map_raw, c->map_cap, c->map_n + n, true, c->map_n);
   if (rc) return rc;
-  if (c->map_cap != old_cap && c->d_map_sorted) { (void)hipFree(c->d_map_sorted); c->d_map_sorted = nullptr; c->grid_valid = false; }
+  if (c->map_cap != old_cap && c->d_map_sorted) c->sorted_follows = true;      // (the cell-sorted copy and the escape pool follow at the next index update: rebuild_grid)
   HIPCHK(c, hipMemcpyAsync(c->d_map_raw + c->map_n, pts, n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->map_n += n;
@@ -889,7 +926,7 @@ static int map_add_device(flimo_ctx* c, const float4* d_pts, size_t m, double st
     const size_t old_cap = c->map_cap;
     int rc = ensure_dev(c, c->d_map_raw, c->map_cap, c->map_n + m, true, c->map_n);
     if (rc) return rc;
-    if (c->map_cap != old_cap && c->d_map_sorted) { (void)hipFree(c->d_map_sorted); c->d_map_sorted = nullptr; c->grid_valid = false; }
+    if (c->map_cap != old_cap && c->d_map_sorted) c->sorted_follows = true;      // (the cell-sorted copy and the escape pool follow at the next index update: rebuild_grid)
     int kept = 0;
     if (!c->gbook.active)        // first batch: Octree::initialize on the device
       HIPCHK(c, c->gbook.init(c->stream, d_pts, (int)m, bb, c->d_map_raw, &kept, c->map_cfg.min_extent, c->map_cfg.downsample != 0,

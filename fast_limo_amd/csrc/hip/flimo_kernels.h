@@ -168,6 +168,8 @@ hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4
 // A grid that grows without a re-sort: N = the new geometry (extents and cell shifts; origin, cell, column factor as O; corner moved
 // by whole tiles of O's shape).  hipErrorInvalidValue when the larger grid needs another tile shape (the caller builds afresh).
 hipError_t index_regrid(hipStream_t st, IndexTables& T, const GridView& O, GridView& N);
+// more room in the pool of tiles before an insert needs it (the tiles move; the caller refreshes its views with index_view)
+hipError_t index_grow_pool(hipStream_t st, IndexTables& T, uint32_t cap_tiles_new);
 // fills the table pointers and the tile shape of a GridView whose geometry (nx, ny, nz, xs, nxf) is set
 void index_view(const IndexTables& T, GridView& G);
 // after the stream has been waited for: did a merge since the last build run out of tiles (the index is then incomplete)?

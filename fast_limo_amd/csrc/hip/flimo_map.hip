@@ -898,6 +898,25 @@ hipError_t index_regrid(hipStream_t st, IndexTables& T, const GridView& O, GridV
   return hipGetLastError();
 }
 
+// more room in the pool of tiles (same shape): the tiles move to a larger array, the new ones are cleared.  Ends with the stream
+// waited for (the old array is freed).
+hipError_t index_grow_pool(hipStream_t st, IndexTables& T, uint32_t cap_tiles_new) {
+  const size_t te = grid_tile_entries(T.shape.ts, T.shape.ty, T.shape.tz);
+  cap_tiles_new = (uint32_t)std::min<size_t>(std::min<size_t>(cap_tiles_new, 65536), (((size_t)1 << 32) - 1) / te);
+  if (cap_tiles_new <= T.cap_tiles) return hipSuccess;
+  uint2* np = nullptr;
+  hipError_t e = hipMalloc(&np, (size_t)cap_tiles_new * te * sizeof(uint2));
+  if (e != hipSuccess) return e;
+  if ((e = hipMemcpyAsync(np, T.tiles, (size_t)T.cap_tiles * te * sizeof(uint2), hipMemcpyDeviceToDevice, st)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(np + (size_t)T.cap_tiles * te, 0, (size_t)(cap_tiles_new - T.cap_tiles) * te * sizeof(uint2), st)) != hipSuccess) return e;
+  if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+  (void)hipFree(T.tiles);
+  T.tiles = np;
+  T.tiles_cap_entries = (size_t)cap_tiles_new * te;
+  T.cap_tiles = cap_tiles_new;
+  return hipSuccess;
+}
+
 // ---- debug: two indices of the same geometry say the same (flimo_map_grid_selfcheck) -- compared by MEANING, column by column:
 //      escapes take their slots in the order the workgroups arrive ----
 __global__ __launch_bounds__(256) void index_compare_kernel(GridView A, GridView B, unsigned long long* __restrict__ diff) {

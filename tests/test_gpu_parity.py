@@ -1167,6 +1167,70 @@ def test_knn_on_a_lattice_ties_follow_the_reference(built, oracle):
 
 
 @pytest.mark.gpu
+def test_map_that_grows_downwards_after_a_region_got_crowded(built, oracle):
+    """A grid that the map outgrows moves its CORNER by whole cells (the origin of the cells is fixed) and keeps its rows: no
+    re-sort.  Here the map grows towards -x, -y and -z (the low side: the corner itself moves, by whole tiles) after raw sweeps have
+    crowded the cells under the sensor (the second level's list of crowded cells has to follow the corner).  After every insert the
+    index is what a from-scratch build gives; passes over it equal, bit for bit, those of a context that sorts the whole map on
+    every insert and has no second level; k-NN answers like the oracle octree."""
+    import os
+    from fast_limo_amd import _lib
+    L = 30.0
+    mp = synth.box_world_map(100000, L, 5)
+    x_true = np.zeros(26); x_true[6] = 1; x_true[10] = 1; x_true[25] = -9.809
+    sweeps = [np.ascontiguousarray(synth.velodyne_scan(64, 1024, L, 60 + j)[:, :3]) for j in range(4)]
+    query = np.ascontiguousarray(synth.velodyne_scan(64, 512, L, 78)[:, :3])
+    rng = np.random.default_rng(23)
+    res = {}
+    oc = oracle.Octree()
+    oc.update(mp)
+    for label in ("grown", "resorted"):
+        os.environ["FLIMO_FINE"] = "1" if label == "grown" else "0"
+        os.environ["FLIMO_FINE_THRESHOLD"] = "32"
+        os.environ["FLIMO_FINE_MIN_POINTS"] = "0"
+        if label == "resorted":
+            os.environ["FLIMO_FULL_REBUILD"] = "1"
+        ctx = _lib.HipCtx(0)
+        for v in ("FLIMO_FINE", "FLIMO_FINE_THRESHOLD", "FLIMO_FINE_MIN_POINTS", "FLIMO_FULL_REBUILD"):
+            os.environ.pop(v, None)
+        ctx.map_config()
+        ctx.map_add(mp)
+        for j, sw in enumerate(sweeps):
+            ctx.scan_set(sw)
+            if label == "grown":
+                oc.update(ctx.scan_to_world(x_true))
+            ctx.map_add_scan(x_true, 0.1 * (j + 1))
+        if label == "grown":
+            assert ctx.fine_stats()["active"]
+            builds0 = ctx.grid_selfcheck()[2]
+        for k in range(8):
+            b = synth.box_world_map(3000, 12.0, 500 + k) - np.float32([14.0 * (k + 1), 9.0 * (k + 1), 1.2 * (k + 1)])
+            ctx.map_add(b)
+            if label == "grown":
+                oc.update(b)
+                mm, merges, builds = ctx.grid_selfcheck()
+                assert mm == 0, (k, mm, merges, builds)
+        assert ctx.map_size() == oc.size()
+        cfg = _lib.default_match_cfg(**CAPS)
+        ctx.scan_set(query)
+        p1 = ctx.match_reduce(x_true, cfg)
+        p2 = ctx.match_reduce(x_true, cfg)
+        q = (rng.uniform(-20, 20, (2000, 3)) - [60.0, 40.0, 4.0]).astype(np.float32) if label == "grown" else None
+        knn = ctx.knn(q, 5) if q is not None else None
+        res[label] = (p1, p2, ctx.grid_selfcheck(), knn, q)
+        ctx.close()
+    mm, merges, builds = res["grown"][2]
+    print("downward growth: %d merges, %d full builds (%d before the growth)" % (merges, builds, builds0))
+    assert builds - builds0 <= 2, (builds, builds0)               # the grid grew in place (a re-sort only for a raw buffer that grew)
+    for k in range(2):
+        np.testing.assert_array_equal(res["grown"][k][0], res["resorted"][k][0])       # H^T H, H^T h, M: bit for bit
+        np.testing.assert_array_equal(res["grown"][k][1], res["resorted"][k][1])
+        assert res["grown"][k][2] == res["resorted"][k][2]
+    idx, sqd, cnt = res["grown"][3]
+    np.testing.assert_array_equal(sqd, oc.knn(res["grown"][4], 5)[1])
+
+
+@pytest.mark.gpu
 def test_crowded_cells_second_level_is_exact(built, oracle):
     """Raw sweeps inserted into the map leave the cells under the sensor with hundreds of points (the insert rule keeps the whole
     first batch that lands in a leaf).  Those regions get a second-level grid (a quarter of the cell edge, copies of every map
