@@ -688,12 +688,13 @@ static int merge_appended(flimo_ctx* c) {
   if (k == 0) { c->grid_valid = true; return FLIMO_OK; }
   c->grid_valid = false;
   // room in the tile pool for what this insert may need (the count of tiles in use is the last insert's, read behind its wait):
-  // a quarter of the tiles in use, 64 at least -- a pool that runs out anyway has the map laid out afresh
+  // an eighth of the tiles in use, 32 at least (a layout leaves half of them, 64 at least) -- a pool that runs out anyway has the
+  // map laid out afresh
   {
     const uint32_t used = std::max(c->idx.tiles_used, c->scratch.mail_host ? c->scratch.mail_host[MAIL_TILES + 2] : 0u);
-    const uint32_t want_free = std::max(64u, used / 4);
+    const uint32_t want_free = std::max(32u, used / 8);
     if (c->idx.cap_tiles < used + want_free) {
-      HIPCHK(c, index_grow_pool(c->stream, c->idx, used + 2 * want_free));
+      HIPCHK(c, index_grow_pool(c->stream, c->idx, used + std::max(128u, used / 2)));
       index_view(c->idx, c->grid);
       c->pool_grows++;
     }
@@ -715,7 +716,7 @@ static int rebuild_grid(flimo_ctx* c) {
     // they are -- and the escape pool grows with it; nothing is sorted
     c->sorted_follows = false;
     if (c->d_map_sorted && c->grid_valid && !c->test_tight_array) {
-      const size_t ncap = 3 * c->map_cap + 65536;
+      const size_t ncap = std::min<size_t>(3 * c->map_cap + 65536, 0x7fffffffull);
       float4* np = nullptr;
       HIPCHK(c, hipMalloc(&np, ncap * sizeof(float4)));
       HIPCHK(c, hipMemcpyAsync(np, c->d_map_sorted, std::min(ncap, c->sorted_cap) * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
@@ -841,7 +842,7 @@ static int rebuild_grid(flimo_ctx* c) {
     // the rows of the cell-sorted copy are not packed (a build leaves half a row's length of room behind every row, an insert
     // moves a row that outgrows its room to the end): three times the raw capacity (freed whenever that grows); an insert that
     // finds it full has the map laid out afresh
-    c->sorted_cap = 3 * c->map_cap + 65536;
+    c->sorted_cap = std::min<size_t>(3 * c->map_cap + 65536, 0x7fffffffull);      // (positions are 31-bit: bit 31 of an entry marks an escape)
     HIPCHK(c, hipMalloc(&c->d_map_sorted, c->sorted_cap * sizeof(float4)));
   }
   if (c->test_tight_array) {

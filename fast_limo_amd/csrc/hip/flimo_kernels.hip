@@ -1058,13 +1058,13 @@ __device__ __forceinline__ void knn5_pass(const GridView& G, uint16_t* dir, cons
       // of the true one, and the other 26 cells are then walked only as far as that ball reaches (rows and end cells it cannot
       // reach are dropped, exactly as with the bound of a previous pass).
       const bool probe_on = L == 2 && !prev_valid && prev_probe_min != 0u;          // wave-uniform
-      // (the entries count from their row's first point in the tile's x range; those positions are three 12-byte loads of
-      //  `xstart` in the same round trip -- pad rows and tiles that do not exist: an empty range)
+      // (the entries hold POSITIONS in pts: rows do not move when other rows grow -- GridView -- so nothing has to be added; pad
+      //  rows and tiles that do not exist read zeros: an empty range)
       // conservative distances (cell units) to the neighbouring rows; without a bound every row is in
       const float yd[3] = {fmaxf(ry - margin, 0.f), 0.f, fmaxf(1.f - ry - margin, 0.f)};
       const float zd[3] = {fmaxf(rz - margin, 0.f), 0.f, fmaxf(1.f - rz - margin, 0.f)};
       const float yd2[3] = {yd[0] * yd[0], 0.f, yd[2] * yd[2]}, zd2[3] = {zd[0] * zd[0], 0.f, zd[2] * zd[2]};
-      U3 rbl[3], rbh[3], rsb[3];
+      U3 rbl[3], rbh[3];
       Seg2 own_e;                       // the centre row's two entries: the probe's own cell / column is read off them
       {
         Seg2 e[9];
@@ -1074,7 +1074,6 @@ __device__ __forceinline__ void knn5_pass(const GridView& G, uint16_t* dir, cons
           for (int k = 0; k < 3; k++) {
             e[3 * dz + k] = *reinterpret_cast<const Seg2*>(G.tiles + eidx[3 * dz + k]);
           }
-          rsb[dz] = *reinterpret_cast<const U3*>(G.xstart + grid_xstart_index(G, py0, pz0 + (uint32_t)dz, tx0));
         }
         own_e = e[4];
         const uint32_t k0 = (uint32_t)c0 & 7u, k1 = (uint32_t)c1 & 7u;
@@ -1097,8 +1096,8 @@ __device__ __forceinline__ void knn5_pass(const GridView& G, uint16_t* dir, cons
         }
 #pragma unroll
         for (int dz = 0; dz < 3; dz++) {
-          rbl[dz].a = lo9[3 * dz] + rsb[dz].a; rbl[dz].b = lo9[3 * dz + 1] + rsb[dz].b; rbl[dz].c = lo9[3 * dz + 2] + rsb[dz].c;
-          rbh[dz].a = hi9[3 * dz] + rsb[dz].a; rbh[dz].b = hi9[3 * dz + 1] + rsb[dz].b; rbh[dz].c = hi9[3 * dz + 2] + rsb[dz].c;
+          rbl[dz].a = lo9[3 * dz]; rbl[dz].b = lo9[3 * dz + 1]; rbl[dz].c = lo9[3 * dz + 2];
+          rbh[dz].a = hi9[3 * dz]; rbh[dz].b = hi9[3 * dz + 1]; rbh[dz].c = hi9[3 * dz + 2];
         }
       }
       uint32_t off[10], dl[9];          // dl[t] = lo[t] - off[t]: stream position -> map position
@@ -1121,7 +1120,7 @@ __device__ __forceinline__ void knn5_pass(const GridView& G, uint16_t* dir, cons
       // position of column `col` (within the loaded range's two entries) in the centre row
       auto centre_pos = [&](int col) -> uint32_t {
         const bool nx_ = ((uint32_t)col >> 3) != sg0;
-        return rsb[1].b + seg_count(nx_ ? own_e.x1 : own_e.x0, nx_ ? own_e.y1 : own_e.y0, (uint32_t)col & 7u, G.ovf);
+        return seg_count(nx_ ? own_e.x1 : own_e.x0, nx_ ? own_e.y1 : own_e.y0, (uint32_t)col & 7u, G.ovf);
       };
       uint32_t own_a = rbl[1].b, own_b = rbh[1].b;                  // the own cell's range (heavy blocks only; no load: the entries are here)
       if (heavy_block) {
@@ -1214,8 +1213,8 @@ __device__ __forceinline__ void knn5_pass(const GridView& G, uint16_t* dir, cons
               }
 #pragma unroll
               for (int dz = 0; dz < 3; dz++) {
-                hl[dz].a = lo9[3 * dz] + rsb[dz].a; hl[dz].b = lo9[3 * dz + 1] + rsb[dz].b; hl[dz].c = lo9[3 * dz + 2] + rsb[dz].c;
-                hh[dz].a = hi9[3 * dz] + rsb[dz].a; hh[dz].b = hi9[3 * dz + 1] + rsb[dz].b; hh[dz].c = hi9[3 * dz + 2] + rsb[dz].c;
+                hl[dz].a = lo9[3 * dz]; hl[dz].b = lo9[3 * dz + 1]; hl[dz].c = lo9[3 * dz + 2];
+                hh[dz].a = hi9[3 * dz]; hh[dz].b = hi9[3 * dz + 1]; hh[dz].c = hi9[3 * dz + 2];
               }
             }
 #pragma unroll

@@ -281,9 +281,7 @@ __device__ __forceinline__ void row_entries(const SegTab& T, uint32_t py, uint32
   const int nseg = g.ntx << g.ts;                                  // segments of the directory's x extent
   const uint32_t xrow = (pz * (uint32_t)g.ntx) * (uint32_t)(g.ny + 2 * GRID_PAD) + py;      // xstart index of x-tile 0
   uint32_t carry = 0u;                                             // points in the columns below the window
-  uint32_t tbase = 0u;                                             // ... below the tile the window starts in (tiles longer than a window)
   for (int w0 = 0; w0 < nseg * 8; w0 += SEG_WIN) {
-    if ((((uint32_t)w0 >> 3) & (TS - 1u)) == 0u) tbase = carry;
     // (eight columns more than the window: the segment behind it, whose nibbles the closing entry of a tile that ends with the
     //  window carries)
     for (int i = t; i < SEG_WIN + 8; i += 256) s_cnt[i] = 0u;
@@ -315,10 +313,10 @@ __device__ __forceinline__ void row_entries(const SegTab& T, uint32_t py, uint32
     s_pre[2 * t + 1] = carry + excl + tot[0];
     if (t == 255) s_pre[512] = carry + win_total;
     __syncthreads();
-    // entry of window segment i (0 .. 512) at `slot` of tile `tile`, counted from `base` points
-    auto put = [&](int i, uint32_t tile, uint32_t slot, uint32_t base) {
+    // entry of window segment i (0 .. 512) at `slot` of tile `tile`: the position of the row's first point in its columns or beyond
+    auto put = [&](int i, uint32_t tile, uint32_t slot) {
       uint2* dst = T.tiles + ((((size_t)tile << (g.ty + g.tz)) + (size_t)(((pz & ((1u << g.tz) - 1u)) << g.ty) + (py & ((1u << g.ty) - 1u)))) * (TS + 1u) + slot);
-      const uint32_t pre = s_pre[i] - base;
+      const uint32_t pre = start + s_pre[i];
       uint32_t nib = 0u;
       bool big = false;
 #pragma unroll
@@ -345,9 +343,8 @@ __device__ __forceinline__ void row_entries(const SegTab& T, uint32_t py, uint32
         if (sl == 0u) T.xstart[xrow + (uint32_t)(sg >> g.ts) * (uint32_t)(g.ny + 2 * GRID_PAD)] = start + s_pre[i];
         const uint32_t tile = T.dir[tab_dir_index(g, py, pz, (uint32_t)sg)];
         if (tile) {
-          const uint32_t base = (TS <= 512u) ? s_pre[i - (int)sl] : tbase;      // (a window is a whole number of tiles, or a part of one)
-          put(i, tile, sl, base);
-          if (sl == TS - 1u) put(i + 1, tile, TS, base);         // the closing entry: the segment behind the tile, same base
+          put(i, tile, sl);
+          if (sl == TS - 1u) put(i + 1, tile, TS);               // the closing entry: the segment behind the tile
         }
       }
     }
@@ -378,7 +375,7 @@ __global__ __launch_bounds__(256) void rows_place_kernel(const float4* __restric
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint32_t r = keys[i] / (uint32_t)nxs;
-  out[row_off[r] + (i - row_lo[r])] = in[perm[i]];
+  out[row_off[r] + 1u + (i - row_lo[r])] = in[perm[i]];      // (+1: position 0 of the array is nobody's -- an entry that reads 0 was never written)
 }
 __global__ __launch_bounds__(256) void rows_build_kernel(SegTab T, uint32_t* __restrict__ rowcap, uint32_t* __restrict__ tail, const uint32_t* __restrict__ keys,
                                                          const uint32_t* __restrict__ row_lo, const uint32_t* __restrict__ room,
@@ -387,7 +384,7 @@ __global__ __launch_bounds__(256) void rows_build_kernel(SegTab T, uint32_t* __r
   const TabGeo& g = T.g;
   const uint32_t r = blockIdx.x;
   const uint32_t first = r * (uint32_t)g.nxs;
-  const uint32_t lo = row_lo[r], len = row_lo[r + 1u] - lo, cap = room[r], start = row_off[r];
+  const uint32_t lo = row_lo[r], len = row_lo[r + 1u] - lo, cap = room[r], start = row_off[r] + 1u;
   const uint32_t py = r % (uint32_t)g.ny + GRID_PAD, pz = r / (uint32_t)g.ny + GRID_PAD;
   if (threadIdx.x == 0) {
     rowcap[pz * (uint32_t)(g.ny + 2 * GRID_PAD) + py] = cap;
@@ -505,10 +502,10 @@ hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4
   {
     // the pool in TILES of this shape; room for the map to grow into (a merge that runs out lays the index out afresh)
     size_t cap_entries = T.tiles_cap_entries;
-    if ((e = grow(T.tiles, cap_entries, (ntiles + std::max<size_t>(8, ntiles / 4)) * te, 0)) != hipSuccess) return e;
+    if ((e = grow(T.tiles, cap_entries, (ntiles + std::max<size_t>(64, ntiles / 2)) * te, 0)) != hipSuccess) return e;
     T.tiles_cap_entries = cap_entries;
   }
-  if ((ntiles + std::max<size_t>(8, ntiles / 4)) * te >= ((size_t)1 << 32)) return hipErrorOutOfMemory;      // (32-bit entry indices)
+  if ((ntiles + std::max<size_t>(64, ntiles / 2)) * te >= ((size_t)1 << 32)) return hipErrorOutOfMemory;      // (32-bit entry indices)
   T.cap_tiles = (uint32_t)std::min<size_t>(std::min<size_t>(T.tiles_cap_entries, ((size_t)1 << 32) - 1) / te, 65536);
   if ((e = hipMemsetAsync(T.tiles, 0, (size_t)T.cap_tiles * te * sizeof(uint2), st)) != hipSuccess) return e;
   if ((e = hipMemsetAsync(T.xstart, 0, grid_xstart_size(ny, nz, shape.ntx) * sizeof(uint32_t), st)) != hipSuccess) return e;
@@ -585,10 +582,12 @@ __global__ __launch_bounds__(256) void rows_insert_kernel(SegTab T, uint32_t* __
   const uint32_t start_old = T.xstart[xrow];
   auto below_old = [&](uint32_t col) -> uint32_t {                  // stored points of the row in columns < col
     const uint32_t sg = col >> 3;
-    uint32_t n = T.xstart[xrow + (sg >> g.ts) * stride] - start_old;
     const uint32_t tile = T.dir[tab_dir_index(g, py, pz, sg)];
+    const uint32_t xs_ = T.xstart[xrow + (sg >> g.ts) * stride];
     const uint2 e = T.tiles[(((size_t)tile << (g.ty + g.tz)) + (size_t)(((pz & ((1u << g.tz) - 1u)) << g.ty) + (py & ((1u << g.ty) - 1u)))) * (TS + 1u) + (sg & (TS - 1u))];
-    return n + seg_count(e.x, e.y, col & 7u, T.ovf);
+    // (entries hold positions; no tile, or a tile that came into being for this batch and has nothing of this row yet -- an entry
+    //  that reads 0: no position is 0 -- : the row's xstart there)
+    return ((tile && e.x) ? 0u : xs_) + seg_count(e.x, e.y, col & 7u, T.ovf) - start_old;
   };
   const uint32_t len_old = below_old((uint32_t)(g.nxs - 1)), add = hi - lo, need = len_old + add;
   if (t == 0) {
@@ -668,7 +667,7 @@ hipError_t map_merge_grid(hipStream_t st, float4* sorted, size_t sorted_cap, con
   if ((e = hipMemsetAsync(T.tail + 3, 0, sizeof(uint32_t), st)) != hipSuccess) return e;
   hipLaunchKernelGGL(rows_touched_kernel, dim3(kb), dim3(256), 0, st, S.keys_out, (uint32_t)k, nxs, S.keys_in, S.vals_in, T.tail + 3);
   const unsigned walkers = (unsigned)std::min<size_t>(std::min<size_t>(k, nrows), 8192);
-  hipLaunchKernelGGL(rows_insert_kernel, dim3(walkers), dim3(256), 0, st, tab, T.rowcap, T.tail, S.mail_dev + MAIL_ROWS, (uint32_t)std::min<size_t>(sorted_cap, 0xffffffffull),
+  hipLaunchKernelGGL(rows_insert_kernel, dim3(walkers), dim3(256), 0, st, tab, T.rowcap, T.tail, S.mail_dev + MAIL_ROWS, (uint32_t)std::min<size_t>(sorted_cap, 0x7fffffffull),
                      sorted, S.keys_out, (uint32_t)k, S.keys_in, S.vals_in, new_pts, S.vals_out, cell_geo(geo));
   return hipGetLastError();
 }

@@ -12,9 +12,11 @@ namespace flimo {
 //
 // The index (round 5) has two levels.
 //  * SEGMENT ENTRIES, 8 bytes per segment of 8 fine x columns of a row (row = one (y, z) line of cells along x):
-//        entry.x = number of the row's points in the columns of its TILE below the segment's first   (bit 31: escape, below)
+//        entry.x = POSITION in pts of the row's first point in the segment's columns or beyond       (bit 31: escape, below)
 //        entry.y = eight 4-bit counts, one per column of the segment (column k in bits 4k .. 4k+3)
-//    "points in columns < c" is entry.x + the sum of the nibbles below c & 7: one v_bfe + one v_dot8_u32_u4.  A segment with a
+//    "position of the first point in columns >= c" is entry.x + the sum of the nibbles below c & 7: one v_bfe + one v_dot8_u32_u4.
+//    (Positions, not counts: a row does not move when another row grows -- "rows with room", below -- so an entry is rewritten
+//    only with its own row, and the fast path adds nothing to it.)  A segment with a
 //    column of more than 15 points (crowded maps: raw sweeps inserted under the sensor) is an ESCAPE: entry.y is the index of
 //    eight cumulative 32-bit counts in `ovf` (one more dependent load, only there).  One byte of index per fine column instead of
 //    the eight of rounds 3-5a (a row-major and a y-fastest table of 32-bit positions).
@@ -106,11 +108,12 @@ __device__ __forceinline__ uint32_t grid_xstart_index(const GridView& G, uint32_
 // position in pts of the first point of row (y, z) in column col or beyond (col in 0 .. nxf); dir: G.dir or a copy of it
 __device__ __forceinline__ uint32_t grid_pos(const GridView& G, const uint16_t* dir, int y, int z, int col) {
   const uint32_t py = (uint32_t)(y + GRID_PAD), pz = (uint32_t)(z + GRID_PAD), sg = (uint32_t)col >> 3;
-  // (no branch on "no tile": tile 0 is all zero -- no point of any row here -- so that the loads of two calls overlap)
+  // (entries hold positions; where no tile exists -- no point of any row -- the position is the row's `xstart` of that x-tile.  No
+  //  branch: tile 0 is all zero, so that the loads of two calls overlap)
   const uint32_t tile = dir[grid_dir_index(G, py, pz, sg)];
   const uint32_t base = G.xstart[grid_xstart_index(G, py, pz, sg >> G.ts)];
   const uint2 e = G.tiles[grid_entry_index(G, tile, py, pz, sg)];
-  return base + seg_count(e.x, e.y, (uint32_t)col & 7u, G.ovf);
+  return ((tile && e.x) ? 0u : base) + seg_count(e.x, e.y, (uint32_t)col & 7u, G.ovf);      // (an entry that reads 0 was never written: a tile that is new, a row that has nothing in it)
 }
 // [lo, hi) = positions in pts of the points of row (y, z) in columns [col0, col1)
 __device__ __forceinline__ void grid_row_range(const GridView& G, const uint16_t* dir, int y, int z, int col0, int col1, uint32_t& lo, uint32_t& hi) {
@@ -118,11 +121,12 @@ __device__ __forceinline__ void grid_row_range(const GridView& G, const uint16_t
   const uint32_t t0 = dir[grid_dir_index(G, py, pz, s0)], t1 = dir[grid_dir_index(G, py, pz, s1)];
   const uint32_t b0 = G.xstart[grid_xstart_index(G, py, pz, s0 >> G.ts)], b1 = G.xstart[grid_xstart_index(G, py, pz, s1 >> G.ts)];
   const uint2 e0 = G.tiles[grid_entry_index(G, t0, py, pz, s0)], e1 = G.tiles[grid_entry_index(G, t1, py, pz, s1)];
-  lo = b0 + seg_count_plain(e0.x, e0.y, (uint32_t)col0 & 7u);
-  hi = b1 + seg_count_plain(e1.x, e1.y, (uint32_t)col1 & 7u);
+  const uint32_t a0 = (t0 && e0.x) ? 0u : b0, a1 = (t1 && e1.x) ? 0u : b1;      // (positions; no tile / an entry never written: the row's xstart there)
+  lo = a0 + seg_count_plain(e0.x, e0.y, (uint32_t)col0 & 7u);
+  hi = a1 + seg_count_plain(e1.x, e1.y, (uint32_t)col1 & 7u);
   if (__builtin_expect((int)(e0.x | e1.x) < 0, 0)) {
-    lo = b0 + seg_count(e0.x, e0.y, (uint32_t)col0 & 7u, G.ovf);
-    hi = b1 + seg_count(e1.x, e1.y, (uint32_t)col1 & 7u, G.ovf);
+    lo = a0 + seg_count(e0.x, e0.y, (uint32_t)col0 & 7u, G.ovf);
+    hi = a1 + seg_count(e1.x, e1.y, (uint32_t)col1 & 7u, G.ovf);
   }
 }
 #endif
