@@ -115,18 +115,21 @@ __device__ __forceinline__ uint32_t grid_pos(const GridView& G, const uint16_t* 
   const uint2 e = G.tiles[grid_entry_index(G, tile, py, pz, sg)];
   return ((tile && e.x) ? 0u : base) + seg_count(e.x, e.y, (uint32_t)col & 7u, G.ovf);      // (an entry that reads 0 was never written: a tile that is new, a row that has nothing in it)
 }
-// [lo, hi) = positions in pts of the points of row (y, z) in columns [col0, col1)
+// [lo, hi) = positions in pts of the points of row (y, z) in columns [col0, col1).  Both ends in ONE tile (the usual case: a ring
+// search's range is a few cells): the entries' positions as they are -- a row that has nothing in the tile reads zeros at both ends,
+// an empty range -- and nothing else is loaded.  Two tiles, or an escape: the careful way (xstart where a tile is missing or has
+// nothing of the row).
 __device__ __forceinline__ void grid_row_range(const GridView& G, const uint16_t* dir, int y, int z, int col0, int col1, uint32_t& lo, uint32_t& hi) {
   const uint32_t py = (uint32_t)(y + GRID_PAD), pz = (uint32_t)(z + GRID_PAD), s0 = (uint32_t)col0 >> 3, s1 = (uint32_t)col1 >> 3;
-  const uint32_t t0 = dir[grid_dir_index(G, py, pz, s0)], t1 = dir[grid_dir_index(G, py, pz, s1)];
-  const uint32_t b0 = G.xstart[grid_xstart_index(G, py, pz, s0 >> G.ts)], b1 = G.xstart[grid_xstart_index(G, py, pz, s1 >> G.ts)];
+  const uint32_t d0 = grid_dir_index(G, py, pz, s0), d1 = grid_dir_index(G, py, pz, s1);
+  const uint32_t t0 = dir[d0], t1 = dir[d1];
   const uint2 e0 = G.tiles[grid_entry_index(G, t0, py, pz, s0)], e1 = G.tiles[grid_entry_index(G, t1, py, pz, s1)];
-  const uint32_t a0 = (t0 && e0.x) ? 0u : b0, a1 = (t1 && e1.x) ? 0u : b1;      // (positions; no tile / an entry never written: the row's xstart there)
-  lo = a0 + seg_count_plain(e0.x, e0.y, (uint32_t)col0 & 7u);
-  hi = a1 + seg_count_plain(e1.x, e1.y, (uint32_t)col1 & 7u);
-  if (__builtin_expect((int)(e0.x | e1.x) < 0, 0)) {
-    lo = a0 + seg_count(e0.x, e0.y, (uint32_t)col0 & 7u, G.ovf);
-    hi = a1 + seg_count(e1.x, e1.y, (uint32_t)col1 & 7u, G.ovf);
+  lo = seg_count_plain(e0.x, e0.y, (uint32_t)col0 & 7u);
+  hi = seg_count_plain(e1.x, e1.y, (uint32_t)col1 & 7u);
+  if (__builtin_expect(d0 != d1 || (int)(e0.x | e1.x) < 0, 0)) {
+    const uint32_t b0 = G.xstart[grid_xstart_index(G, py, pz, s0 >> G.ts)], b1 = G.xstart[grid_xstart_index(G, py, pz, s1 >> G.ts)];
+    lo = ((t0 && e0.x) ? 0u : b0) + seg_count(e0.x, e0.y, (uint32_t)col0 & 7u, G.ovf);
+    hi = ((t1 && e1.x) ? 0u : b1) + seg_count(e1.x, e1.y, (uint32_t)col1 & 7u, G.ovf);
   }
 }
 #endif
