@@ -286,9 +286,12 @@ __device__ __forceinline__ void row_entries(const SegTab& T, uint32_t py, uint32
     //  window carries)
     for (int i = t; i < SEG_WIN + 8; i += 256) s_cnt[i] = 0u;
     __syncthreads();
-    for (uint32_t i = (uint32_t)t; i < len; i += 256u) {
-      const int c = cols(i) - w0;
-      if (c >= 0 && c < SEG_WIN + 8) atomicAdd(&s_cnt[c], 1u);
+    for (uint32_t i0 = (uint32_t)t; i0 < len; i0 += 1024u) {       // (four columns per thread and round: their loads overlap)
+      int c[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { const uint32_t i = i0 + 256u * (uint32_t)u; c[u] = i < len ? cols(i) - w0 : -1; }
+#pragma unroll
+      for (int u = 0; u < 4; u++) if (c[u] >= 0 && c[u] < SEG_WIN + 8) atomicAdd(&s_cnt[c[u]], 1u);
     }
     __syncthreads();
     uint32_t tot[2];
@@ -613,23 +616,38 @@ __global__ __launch_bounds__(256) void rows_insert_kernel(SegTab T, uint32_t* __
   const bool keys_lds = add <= 512u;
   if (keys_lds) for (uint32_t j = (uint32_t)t; j < add; j += 256u) s_pre[j] = nkeys[lo + j];
   __syncthreads();
-  for (int c0 = (int)((len_old + 255u) / 256u) * 256 - 256; c0 >= 0 && (uint32_t)(c0 + 256) > i_stay; c0 -= 256) {
-    const uint32_t i = (uint32_t)(c0 + t);
-    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-    uint32_t sh = 0u;
-    if (i < len_old && i >= i_stay) {
-      p = src[i];
-      const uint32_t key = column_key(p, cg);
-      if (keys_lds) {
-        uint32_t a = 0u, b = add;
-        while (a < b) { const uint32_t m = (a + b) >> 1; if (s_pre[m] < key) a = m + 1u; else b = m; }
-        sh = a;
-      } else {
-        sh = lower_bound_u32(nkeys, lo, hi, key) - lo;
+  for (int c0 = (int)((len_old + 1023u) / 1024u) * 1024 - 1024; c0 >= 0 && (uint32_t)(c0 + 1024) > i_stay; c0 -= 1024) {
+    // (1024 points a round, four per thread: read all, barrier, write all -- a point only ever moves up, by no less than the one
+    //  before it, so a round's writes land on positions this round or an earlier one has read)
+    float4 p[4];
+    uint32_t sh[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const uint32_t i = (uint32_t)(c0 + t + 256 * u);
+      p[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < len_old && i >= i_stay) p[u] = src[i];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const uint32_t i = (uint32_t)(c0 + t + 256 * u);
+      sh[u] = 0u;
+      if (i < len_old && i >= i_stay) {
+        const uint32_t key = column_key(p[u], cg);
+        if (keys_lds) {
+          uint32_t a = 0u, b = add;
+          while (a < b) { const uint32_t m = (a + b) >> 1; if (s_pre[m] < key) a = m + 1u; else b = m; }
+          sh[u] = a;
+        } else {
+          sh[u] = lower_bound_u32(nkeys, lo, hi, key) - lo;
+        }
       }
     }
     __syncthreads();
-    if (i < len_old && i >= i_stay && (sh != 0u || dest != start_old)) dst[i + sh] = p;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const uint32_t i = (uint32_t)(c0 + t + 256 * u);
+      if (i < len_old && i >= i_stay && (sh[u] != 0u || dest != start_old)) dst[i + sh[u]] = p[u];
+    }
     __syncthreads();
   }
   // new points: the j-th of the row goes behind the stored points of its column
