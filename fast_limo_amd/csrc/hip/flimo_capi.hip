@@ -559,7 +559,7 @@ static bool grid_covers(const GridView& g, const float* bb) {
   }
   return true;
 }
-// Second level: (re)built after every index update.  Cheap when no cell is crowded (one pass over the cell table).
+// Second level: (re)built after every index update.  Cheap when no cell is crowded (a look at the cells of the new points).
 // `relayout`: the geometry is new -> every cell is looked at; otherwise only the cells of the n_new points merged since the last look.
 static int update_fine_grid(flimo_ctx* c, bool relayout, const float4* new_pts = nullptr, size_t n_new = 0) {
   c->fine_valid = false;
@@ -678,10 +678,11 @@ static int update_fine_grid(flimo_ctx* c, bool relayout, const float4* new_pts =
 }
 
 // Brings the cell-sorted copy of the map and its tables up to date with d_map_raw[0 .. map_n).
-//  * merge: the geometry still covers the map box and only points were appended since the last build -> the tail is merged
-//    into the sorted array (one streaming pass, map_merge_grid);
-//  * build: first build, or the map outgrew the geometry -> new geometry, laid out with slack on the sides that grew so
-//    that a sensor moving through new territory triggers it rarely, and a full sort.
+//  * insert in place: the geometry still covers the map box and only points were appended since the last build -> they go into
+//    their rows (map_merge_grid: only the rows that receive points are touched);
+//  * the map outgrew the geometry -> the grid grows (same cell origin, the corner moves by whole tiles: index_regrid), then the
+//    same insert -- nothing is sorted;
+//  * full layout: first build, another tile shape or cell size, a full point array or tile pool -> a sort of the whole map.
 // (the k points appended since the index was last brought up to date go into their rows: map_merge_grid)
 static int merge_appended(flimo_ctx* c) {
   const size_t n_old = c->grid.n_pts, k = c->map_n - n_old;
@@ -865,7 +866,8 @@ static int rebuild_grid(flimo_ctx* c) {
 }
 
 // Debug: sort the whole map again with the CURRENT geometry into temporary buffers and compare the result with the
-// incrementally maintained index (points, cell table, row table).  stats = {merges, full builds} so far.
+// incrementally maintained index, by meaning (every row's points in order, every row's position at every column).
+// stats = {inserts in place, full layouts} so far.
 extern "C" int flimo_map_grid_selfcheck(flimo_ctx* c, uint64_t* mismatches, uint64_t stats[2]) {
   if (!c || !mismatches) return FLIMO_ERR_INVALID;
   if (stats) { stats[0] = c->grid_merges; stats[1] = c->grid_builds; }

@@ -1114,7 +1114,7 @@ __device__ __forceinline__ void knn5_pass(const GridView& G, uint16_t* dir, cons
         }
       }
       // probing pays when the block is heavy (crowded region: every lane of the wave probes, so nobody waits for a neighbour's
-      // full walk) and the own cell can give a bound at all.  Only those queries fetch the two inner x planes of the row table:
+      // full walk) and the own cell can give a bound at all.  Its bounds are read off the centre row's entries, which are here already:
       // they hold the own cell's range and let the second walk be clipped to cells.
       const bool heavy_block = probe_on && off[9] >= prev_probe_min && cx >= 0 && cx < G.nx;
       // position of column `col` (within the loaded range's two entries) in the centre row

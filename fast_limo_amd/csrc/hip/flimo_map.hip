@@ -5,11 +5,15 @@
 // (Objects/Octree.hpp:282-338 createOctant); which points are STORED is decided by the caller
 // (flimo_capi.cpp implements the reference's insert rule).  Steps, all on the context stream:
 //   1. bbox      : min/max reduction (wave shuffles + one atomic per wave)
-//   2. cell keys : key = floor((p - o) * inv_cell) linearised with x fastest
-//   3. sort      : stable LSD radix sort of (key, index) pairs (rocPRIM through hipCUB) -- keeps
-//                  insertion order inside a cell, so the device order is deterministic
-//   4. gather    : points re-ordered into cell order (float4, w keeps the insertion index)
-//   5. segment table: one workgroup per row turns the row's columns into its entries (GridView, flimo_types.h)
+//   2. cell keys : key = (floor((p - o) * inv_cell) - corner) linearised with x fastest, at fine-column resolution along x
+//   3. sort      : stable LSD radix sort of (key, index) pairs (rocPRIM) -- keeps insertion order inside a column, so the
+//                  device order is deterministic
+//   4. rows      : per row its key range and its room, an exclusive sum of the rooms, every point to its row's place (float4,
+//                  w keeps the insertion index)
+//   5. index     : tiles marked and numbered, one workgroup per row turns the row's columns into its entries
+//                  (GridView, flimo_types.h)
+// An insert afterwards touches only the rows it adds to (rows_insert_kernel); a map that outgrows its grid has the grid grown
+// around it (index_regrid).
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <immintrin.h>
@@ -80,13 +84,6 @@ __global__ __launch_bounds__(256) void cellkey_kernel(const float4* __restrict__
   if (i >= n) return;
   keys[i] = column_key(pts[i], c);
   vals[i] = (uint32_t)i;
-}
-
-__global__ __launch_bounds__(256) void gather_kernel(const float4* __restrict__ in, const uint32_t* __restrict__ perm,
-                                                     size_t n, float4* __restrict__ out) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  out[i] = in[perm[i]];
 }
 
 struct MailArgs { const uint32_t* src[6]; int n[6]; int dst[6]; int parts; unsigned* rearm; uint32_t* zero; int zero_n; uint32_t tag; };
@@ -774,7 +771,7 @@ hipError_t crowded_list_points(hipStream_t st, const float4* pts, size_t k, cons
   return hipSuccess;
 }
 // Copy of the map points of a box of cells [c0, c1] (inclusive, already clipped to the grid), w = position in the main sorted
-// map.  The map is sorted by (z, y, x column), so the box is (y1-y0+1)(z1-z0+1) contiguous ranges read off the cell table:
+// map.  The map is sorted by (z, y, x column), so the box is (y1-y0+1)(z1-z0+1) contiguous ranges read off the index:
 // counting and copying cost what the box holds, not what the map holds.  Two steps, so that the caller can size its
 // buffers (or give up) once it knows the count.
 __global__ __launch_bounds__(256) void boxrows_count_kernel(GridView G, int x0, int x1, int y0, int nyb, int z0, int nrows,

@@ -23,8 +23,5 @@ template <class In, class Out>
 inline hipError_t exclusive_sum(void* tmp, size_t& bytes, In* in, Out* out, size_t n, hipStream_t st) {
   return rocprim::exclusive_scan(tmp, bytes, in, out, Out(0), n, rocprim::plus<Out>(), st);
 }
-inline hipError_t inclusive_max_u32(void* tmp, size_t& bytes, uint32_t* in, uint32_t* out, size_t n, hipStream_t st) {
-  return rocprim::inclusive_scan(tmp, bytes, in, out, n, rocprim::maximum<uint32_t>(), st);
-}
 
 }  // namespace flimo

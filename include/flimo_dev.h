@@ -47,10 +47,11 @@ int flimo_last_stragglers(const flimo_ctx* ctx);
 /* mean number of candidate map points examined per query in the last pass */
 double flimo_last_candidates_per_query(const flimo_ctx* ctx);
 
-/* The cell-sorted copy of the map is maintained incrementally: points appended by an insert are merged into it as long as
- * the grid geometry covers the map box; otherwise the grid is laid out again (with slack on the sides that grew) and the whole
- * map sorted.  Debug check: sorts the whole map again with the current geometry and counts the 32-bit words in which the
- * maintained index (points, cell table, row table) differs -- 0 by construction.  stats = {merges, full builds} so far. */
+/* The cell-sorted copy of the map is maintained incrementally: points appended by an insert go into their rows in place, a map
+ * that outgrows its grid has the grid grown around it; the whole map is sorted only at the first layout and when a tile shape,
+ * the point array or the tile pool no longer does.  Debug check: sorts the whole map again with the current geometry and counts
+ * where the maintained index differs (by meaning: a row's points in order, a row's position at every column) -- 0 by construction.
+ * stats = {inserts in place, full layouts} so far. */
 int flimo_map_grid_selfcheck(flimo_ctx* ctx, uint64_t* mismatches, uint64_t stats[2]);
 
 /* out[0] = GPU ms of the algebra launches timed so far (timing level 1), out[1] = their number,
