@@ -565,6 +565,7 @@ static int update_fine_grid(flimo_ctx* c, bool relayout, const float4* new_pts =
   c->fine_valid = false;
   if (!c->fine_on || !c->grid_valid || c->map_n == 0) return FLIMO_OK;
   const GridView& g = c->grid;
+  if ((double)g.nx * (double)g.ny * (double)g.nz > 2.0e9) return FLIMO_OK;      // (a bit per cell: not for a grid of many kilometres)
   constexpr uint32_t CROWD_CAP = 1u << 20;
   if (!c->d_crowd_list) {
     HIPCHK(c, hipMalloc(&c->d_crowd_list, (size_t)CROWD_CAP * sizeof(int4)));
@@ -775,8 +776,9 @@ static int rebuild_grid(flimo_ctx* c) {
     N.six = si[0]; N.siy = si[1]; N.siz = si[2];
     N.nx = n[0]; N.ny = n[1]; N.nz = n[2];
     N.nxf = N.nx * N.xs; N.nxs = N.nxf + 1;
-    const double ncols = (double)N.ny * (double)N.nz * ((double)N.nx * N.xs + 1.0);
-    hipError_t e = ncols < 1.9e9 ? index_regrid(c->stream, c->idx, O, N) : hipErrorInvalidValue;
+    // (column keys are 64-bit; what stays 32-bit: a row's number and a column's number within its row)
+    const bool fits = (double)N.ny * (double)N.nz < 4.0e9 && (double)N.nx * N.xs < 2.0e9;
+    hipError_t e = fits ? index_regrid(c->stream, c->idx, O, N) : hipErrorInvalidValue;
     if (e == hipSuccess) {
       // the crowded cells listed so far (second level): the same cells under the new corner
       const int d[3] = {si_old[0] - si[0], si_old[1] - si[1], si_old[2] - si[2]};
@@ -824,17 +826,16 @@ static int rebuild_grid(flimo_ctx* c) {
     G.nx = (int)floorf((box[3] - G.ox) * G.inv_cell) - G.six + 2;
     G.ny = (int)floorf((box[4] - G.oy) * G.inv_cell) - G.siy + 2;
     G.nz = (int)floorf((box[5] - G.oz) * G.inv_cell) - G.siz + 2;
-    // column keys stay 32-bit; the fine x columns are given up first (xs = preferred .. 1), then the cell grows
-    for (xs = c->xslabs; xs >= 1; xs >>= 1) {
-      const double ncols = (double)G.ny * (double)G.nz * ((double)G.nx * xs + 1.0);
-      if (ncols < 1.9e9) return true;
-    }
+    // column keys are 64-bit (round 5: a grid of kilometres keeps its cell); what stays 32-bit is a row's number and a column's
+    // number within its row -- beyond that (a box of thousands of kilometres) the fine x columns are given up, then the cell grows
+    for (xs = c->xslabs; xs >= 1; xs >>= 1)
+      if ((double)G.ny * (double)G.nz < 4.0e9 && (double)G.nx * xs < 2.0e9) return true;
     xs = 1;
     return false;
   };
   if (!layout(W)) {
     for (int a = 0; a < 6; a++) W[a] = bb[a];
-    while (!layout(W)) cell *= 2.0f;   // keep the column keys within 32 bits
+    while (!layout(W)) cell *= 2.0f;   // (rows and columns-per-row within 32 bits)
   }
   G.xs = xs; G.nxf = G.nx * xs; G.nxs = G.nxf + 1;
   for (int a = 0; a < 6; a++) c->gbox[a] = W[a];

@@ -109,6 +109,8 @@ struct MapBuildScratch {
   uint32_t* vals_in = nullptr;
   uint32_t* vals_out = nullptr;
   size_t cap_pts = 0;
+  unsigned long long *ck_in = nullptr, *ck_out = nullptr;      // 64-bit column keys of the index builds / inserts (flimo_map.hip)
+  size_t ck_cap = 0;
   float* bbox = nullptr;   // 6 floats on device (min xyz, max xyz) as ordered ints; armed (empty box) whenever no reduction is running
   // "mail": 64 words of pinned host memory the device writes into (mail_words); the host reads them after synchronising the
   // stream.  Replaces the 4-byte device-to-host copies (each a staged, blocking copy) of counts and boxes.
@@ -155,6 +157,9 @@ struct IndexTables {
   uint32_t* xstart = nullptr; size_t xstart_cap = 0;
   uint32_t* rowcap = nullptr; size_t rowcap_cap = 0;      // [(nz+4)(ny+4)] points that fit from a row's first one to the next row's
   uint32_t* rowoff = nullptr; size_t rowoff_cap = 0;      // build scratch: the rows' first positions
+  uint32_t* xstart_alt = nullptr; size_t xstart_alt_cap = 0;      // the second set of the small tables: a grid that grows
+  uint32_t* rowcap_alt = nullptr; size_t rowcap_alt_cap = 0;      // (index_regrid) writes it and the two sets change places
+  uint16_t* dir_alt = nullptr;
   uint32_t* tail = nullptr;                               // [0] first free position of the point array, [1] an insert found it full, [2] rows moved
 };
 void index_free(IndexTables& T);

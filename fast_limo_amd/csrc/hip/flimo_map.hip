@@ -68,7 +68,9 @@ __global__ __launch_bounds__(256) void bbox_kernel(const float4* __restrict__ pt
 // (the geometry a cell computation needs: GridView's, without its tables)
 struct CellGeo { float ox, oy, oz, inv_cell; int nx, ny, nz, xs, six, siy, siz; };
 static inline CellGeo cell_geo(const GridView& G) { return CellGeo{G.ox, G.oy, G.oz, G.inv_cell, G.nx, G.ny, G.nz, G.xs, G.six, G.siy, G.siz}; }
-__device__ __forceinline__ uint32_t column_key(const float4& p, const CellGeo& c) {
+// (64-bit: a grid of kilometres has more than 2^32 fine columns; the sort looks only at the bits the grid needs)
+typedef unsigned long long ckey_t;
+__device__ __forceinline__ ckey_t column_key(const float4& p, const CellGeo& c) {
   const float tx = (p.x - c.ox) * c.inv_cell;     // identical float expression to the query side (flimo_kernels.hip: knn_search)
   int cx = (int)floorf(fminf(fmaxf(tx * (float)c.xs, -1.0e9f), 1.0e9f)) - c.six * c.xs;      // (the grid's corner: a whole-cell shift behind the floor)
   int cy = (int)floorf((p.y - c.oy) * c.inv_cell) - c.siy;
@@ -76,10 +78,10 @@ __device__ __forceinline__ uint32_t column_key(const float4& p, const CellGeo& c
   cx = min(max(cx, 0), c.nx * c.xs - 1);
   cy = min(max(cy, 0), c.ny - 1);
   cz = min(max(cz, 0), c.nz - 1);
-  return (uint32_t)(((size_t)cz * c.ny + cy) * ((size_t)c.nx * c.xs + 1) + cx);      // (a row of columns: nxf of them + its end entry)
+  return ((ckey_t)cz * (ckey_t)c.ny + (ckey_t)cy) * ((ckey_t)c.nx * c.xs + 1ull) + (ckey_t)cx;      // (a row of columns: nxf of them + its end entry)
 }
 __global__ __launch_bounds__(256) void cellkey_kernel(const float4* __restrict__ pts, size_t n, CellGeo c,
-                                                      uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+                                                      ckey_t* __restrict__ keys, uint32_t* __restrict__ vals) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   keys[i] = column_key(pts[i], c);
@@ -204,6 +206,29 @@ __device__ __forceinline__ uint32_t wave_lower_bound_u32(const uint32_t* __restr
   return lo + (uint32_t)__popcll(__ballot(below));
 }
 
+__device__ __forceinline__ uint32_t lower_bound_k(const ckey_t* __restrict__ keys, uint32_t lo, uint32_t hi, ckey_t key) {
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (keys[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+__device__ __forceinline__ uint32_t wave_lower_bound_k(const ckey_t* __restrict__ keys, uint32_t k, ckey_t key) {
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t lo = 0u, hi = k;                            // the answer lies in [lo, hi]
+  while (hi - lo > 64u) {
+    const uint32_t step = (hi - lo + 63u) / 64u;
+    const uint32_t idx = lo + lane * step + (step - 1u);            // last element of this lane's segment
+    const bool below = idx < hi && keys[idx] < key;                  // monotone over the lanes (sorted keys)
+    const uint32_t c = (uint32_t)__popcll(__ballot(below));
+    const uint32_t nlo = min(lo + c * step, hi);
+    hi = min(nlo + (step - 1u), hi);
+    lo = nlo;
+  }
+  const uint32_t idx = lo + lane;
+  const bool below = idx < hi && keys[idx] < key;
+  return lo + (uint32_t)__popcll(__ballot(below));
+}
 // geometry of the index as the builders need it
 struct TabGeo { int nxs, ny, nz, ts, ty, tz, ntx, nty, ntz; };
 struct SegTab { uint2* tiles; const uint16_t* dir; uint32_t* ovf; uint32_t* ovf_count; uint32_t ovf_cap; uint32_t* xstart; TabGeo g; };
@@ -212,11 +237,11 @@ __device__ __forceinline__ uint32_t tab_dir_index(const TabGeo& g, uint32_t py, 
 }
 // which tiles a batch of sorted column keys needs: the tile of each key's segment, and -- for a key in the FIRST segment of a
 // tile -- the tile to its left (whose last entry continues into that segment)
-__global__ __launch_bounds__(256) void tiles_mark_kernel(const uint32_t* __restrict__ keys, uint32_t n, TabGeo g, uint32_t* __restrict__ need) {
+__global__ __launch_bounds__(256) void tiles_mark_kernel(const ckey_t* __restrict__ keys, uint32_t n, TabGeo g, uint32_t* __restrict__ need) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const uint32_t key = keys[i];
-  const uint32_t r = key / (uint32_t)g.nxs, sg = (key - r * (uint32_t)g.nxs) >> 3;
+  const ckey_t key = keys[i];
+  const uint32_t r = (uint32_t)(key / (ckey_t)g.nxs), sg = (uint32_t)(key - (ckey_t)r * (ckey_t)g.nxs) >> 3;
   const uint32_t py = r % (uint32_t)g.ny + GRID_PAD, pz = r / (uint32_t)g.ny + GRID_PAD;
   const uint32_t d = tab_dir_index(g, py, pz, sg);
   need[d] = 1u;
@@ -359,31 +384,31 @@ __device__ __forceinline__ void row_entries(const SegTab& T, uint32_t py, uint32
 //   (exclusive sum of the rooms: the rows' first positions)
 //   rows_place_kernel : sorted point i -> its row's first position + its rank in the row
 //   rows_build_kernel : one workgroup per row: xstart and the entries
-__global__ __launch_bounds__(256) void rows_len_kernel(const uint32_t* __restrict__ keys, uint32_t n, uint32_t nrows, int nxs, int slack,
+__global__ __launch_bounds__(256) void rows_len_kernel(const ckey_t* __restrict__ keys, uint32_t n, uint32_t nrows, int nxs, int slack,
                                                        uint32_t* __restrict__ row_lo /*[nrows + 1]*/, uint32_t* __restrict__ room) {
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= nrows) return;
-  const uint32_t lo = lower_bound_u32(keys, 0u, n, r * (uint32_t)nxs), hi = lower_bound_u32(keys, lo, n, (r + 1u) * (uint32_t)nxs);
+  const uint32_t lo = lower_bound_k(keys, 0u, n, (ckey_t)r * (ckey_t)nxs), hi = lower_bound_k(keys, lo, n, ((ckey_t)r + 1ull) * (ckey_t)nxs);
   const uint32_t len = hi - lo;
   row_lo[r] = lo;
   if (r + 1u == nrows) row_lo[nrows] = n;
   room[r] = (slack && len) ? len + max(2u, len >> 1) : len;
 }
-__global__ __launch_bounds__(256) void rows_place_kernel(const float4* __restrict__ in, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ keys,
+__global__ __launch_bounds__(256) void rows_place_kernel(const float4* __restrict__ in, const uint32_t* __restrict__ perm, const ckey_t* __restrict__ keys,
                                                          uint32_t n, int nxs, const uint32_t* __restrict__ row_lo, const uint32_t* __restrict__ row_off,
                                                          float4* __restrict__ out) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const uint32_t r = keys[i] / (uint32_t)nxs;
+  const uint32_t r = (uint32_t)(keys[i] / (ckey_t)nxs);
   out[row_off[r] + 1u + (i - row_lo[r])] = in[perm[i]];      // (+1: position 0 of the array is nobody's -- an entry that reads 0 was never written)
 }
-__global__ __launch_bounds__(256) void rows_build_kernel(SegTab T, uint32_t* __restrict__ rowcap, uint32_t* __restrict__ tail, const uint32_t* __restrict__ keys,
+__global__ __launch_bounds__(256) void rows_build_kernel(SegTab T, uint32_t* __restrict__ rowcap, uint32_t* __restrict__ tail, const ckey_t* __restrict__ keys,
                                                          const uint32_t* __restrict__ row_lo, const uint32_t* __restrict__ room,
                                                          const uint32_t* __restrict__ row_off, uint32_t nrows) {
   __shared__ uint32_t s_cnt[SEG_WIN + 8], s_pre[513], s_scan[256];
   const TabGeo& g = T.g;
   const uint32_t r = blockIdx.x;
-  const uint32_t first = r * (uint32_t)g.nxs;
+  const ckey_t first = (ckey_t)r * (ckey_t)g.nxs;
   const uint32_t lo = row_lo[r], len = row_lo[r + 1u] - lo, cap = room[r], start = row_off[r] + 1u;
   const uint32_t py = r % (uint32_t)g.ny + GRID_PAD, pz = r / (uint32_t)g.ny + GRID_PAD;
   if (threadIdx.x == 0) {
@@ -397,12 +422,24 @@ __global__ __launch_bounds__(256) void rows_build_kernel(SegTab T, uint32_t* __r
     for (int tx = (int)threadIdx.x; tx < g.ntx; tx += 256) T.xstart[xrow + (uint32_t)tx * (uint32_t)(g.ny + 2 * GRID_PAD)] = start;
     return;
   }
-  const uint32_t* rk = keys + lo;
+  const ckey_t* rk = keys + lo;
   row_entries(T, py, pz, start, len, [&](uint32_t i) { return (int)(rk[i] - first); }, s_cnt, s_pre, s_scan);
 }
+static hipError_t ensure_keys(MapBuildScratch& S, size_t n) {
+  if (n <= S.ck_cap) return hipSuccess;
+  if (S.ck_in) { (void)hipFree(S.ck_in); (void)hipFree(S.ck_out); }
+  S.ck_in = S.ck_out = nullptr; S.ck_cap = 0;
+  const size_t cap = n + n / 4 + 1024;
+  hipError_t e;
+  if ((e = hipMalloc(&S.ck_in, cap * sizeof(unsigned long long))) != hipSuccess) return e;
+  if ((e = hipMalloc(&S.ck_out, cap * sizeof(unsigned long long))) != hipSuccess) return e;
+  S.ck_cap = cap;
+  return hipSuccess;
+}
+// (column keys S.ck_in -> S.ck_out, their points' numbers S.vals_in -> S.vals_out; `bits`: the key bits the grid uses)
 static hipError_t sort_keys(hipStream_t st, size_t n, int bits, MapBuildScratch& S) {
   size_t tmp_bytes = 0;
-  hipError_t e = sort_pairs_u32(nullptr, tmp_bytes, S.keys_in, S.keys_out, S.vals_in, S.vals_out, (int)n, 0, bits, st);
+  hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, S.ck_in, S.ck_out, S.vals_in, S.vals_out, n, 0, (unsigned)bits, st);
   if (e != hipSuccess) return e;
   if (tmp_bytes > S.cub_tmp_bytes) {
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;   // (an earlier launch may still be using cub_tmp)
@@ -411,7 +448,7 @@ static hipError_t sort_keys(hipStream_t st, size_t n, int bits, MapBuildScratch&
     if ((e = hipMalloc(&S.cub_tmp, tmp_bytes + 1024)) != hipSuccess) return e;
     S.cub_tmp_bytes = tmp_bytes + 1024;
   }
-  return sort_pairs_u32(S.cub_tmp, tmp_bytes, S.keys_in, S.keys_out, S.vals_in, S.vals_out, (int)n, 0, bits, st);
+  return rocprim::radix_sort_pairs(S.cub_tmp, tmp_bytes, S.ck_in, S.ck_out, S.vals_in, S.vals_out, n, 0, (unsigned)bits, st);
 }
 void index_view(const IndexTables& T, GridView& G) {
   TileShape t = T.shape;                                          // (the shape the index was laid out with: a grown grid keeps it)
@@ -422,6 +459,7 @@ void index_view(const IndexTables& T, GridView& G) {
 bool index_merge_overflow(const MapBuildScratch& S) { return S.mail_host && (S.mail_host[MAIL_TILES + 3] != 0u || S.mail_host[MAIL_ROWS] != 0u); }
 void index_free(IndexTables& T) {
   (void)hipFree(T.tiles); (void)hipFree(T.dir); (void)hipFree(T.need); (void)hipFree(T.counters); (void)hipFree(T.ovf); (void)hipFree(T.xstart); (void)hipFree(T.rowcap); (void)hipFree(T.tail); (void)hipFree(T.rowoff);
+  (void)hipFree(T.xstart_alt); (void)hipFree(T.rowcap_alt); (void)hipFree(T.dir_alt);
   T = IndexTables{};
 }
 template <typename P>
@@ -448,6 +486,7 @@ hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4
   hipError_t e = ensure_scratch(S, std::max(n, nrows + 1));       // (the rows' key ranges and rooms live in the sort's input buffers)
   if (e != hipSuccess) return e;
   if ((e = ensure_mail(S)) != hipSuccess) return e;
+  if ((e = ensure_keys(S, n)) != hipSuccess) return e;
   if (!T.dir) {
     if ((e = hipMalloc(&T.dir, (GRID_DIR_MAX + 8) * sizeof(uint16_t))) != hipSuccess) return e;
     if ((e = hipMalloc(&T.need, GRID_DIR_MAX * sizeof(uint32_t))) != hipSuccess) return e;
@@ -461,9 +500,9 @@ hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4
   }
   const int blocks = (int)((n + 255) / 256);
   if (blocks > 0)
-    hipLaunchKernelGGL(cellkey_kernel, dim3(blocks), dim3(256), 0, st, pts_in, n, cell_geo(geo), S.keys_in, S.vals_in);
+    hipLaunchKernelGGL(cellkey_kernel, dim3(blocks), dim3(256), 0, st, pts_in, n, cell_geo(geo), S.ck_in, S.vals_in);
   int bits = 1;                                                    // number of key bits actually used
-  while (bits < 32 && ((size_t)1 << bits) < ncols) bits++;
+  while (bits < 64 && ((size_t)1 << bits) < ncols) bits++;
   if (n > 0 && (e = sort_keys(st, n, bits, S)) != hipSuccess) return e;
   // the rows' places: key range and room per row, an exclusive sum of the rooms, every point to its row's place + its rank
   // (slack: only as far as the output array has room for it -- half a row's length and two points per row at least)
@@ -471,7 +510,7 @@ hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4
   uint32_t* row_lo = S.keys_in;                                    // [nrows + 1]
   uint32_t* room = S.vals_in;                                      // [nrows]
   {
-    hipLaunchKernelGGL(rows_len_kernel, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, st, S.keys_out, (uint32_t)n, (uint32_t)nrows, nxs, roomy ? 1 : 0,
+    hipLaunchKernelGGL(rows_len_kernel, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, st, S.ck_out, (uint32_t)n, (uint32_t)nrows, nxs, roomy ? 1 : 0,
                        row_lo, room);
     size_t off_cap = T.rowoff_cap;
     if ((e = grow(T.rowoff, off_cap, nrows, nrows / 2)) != hipSuccess) return e;
@@ -486,13 +525,13 @@ hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4
       S.cub_tmp_bytes = scan_bytes + 1024;
     }
     if ((e = exclusive_sum(S.cub_tmp, scan_bytes, room, T.rowoff, nrows, st)) != hipSuccess) return e;
-    if (n > 0) hipLaunchKernelGGL(rows_place_kernel, dim3(blocks), dim3(256), 0, st, pts_in, S.vals_out, S.keys_out, (uint32_t)n, nxs, row_lo, T.rowoff, pts_out);
+    if (n > 0) hipLaunchKernelGGL(rows_place_kernel, dim3(blocks), dim3(256), 0, st, pts_in, S.vals_out, S.ck_out, (uint32_t)n, nxs, row_lo, T.rowoff, pts_out);
   }
   // which tiles exist, and their numbers (directory order); the host sizes the pool by their count
   if ((e = hipMemsetAsync(T.need, 0, GRID_DIR_MAX * sizeof(uint32_t), st)) != hipSuccess) return e;
   if ((e = hipMemsetAsync(T.dir, 0, (GRID_DIR_MAX + 8) * sizeof(uint16_t), st)) != hipSuccess) return e;
   if ((e = hipMemsetAsync(T.counters, 0, 4 * sizeof(uint32_t), st)) != hipSuccess) return e;
-  if (n > 0) hipLaunchKernelGGL(tiles_mark_kernel, dim3(blocks), dim3(256), 0, st, S.keys_out, (uint32_t)n, g, T.need);
+  if (n > 0) hipLaunchKernelGGL(tiles_mark_kernel, dim3(blocks), dim3(256), 0, st, S.ck_out, (uint32_t)n, g, T.need);
   S.mail_host[MAIL_TILES] = 0u; S.mail_host[MAIL_TILES + 1] = 0u;
   hipLaunchKernelGGL(tiles_number_kernel, dim3(1), dim3(256), 0, st, T.dir, T.need, ndir, 65536u, T.counters, S.mail_dev + MAIL_TILES, 1);
   if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
@@ -518,7 +557,7 @@ hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4
   }
   if ((e = hipMemsetAsync(T.rowcap, 0, ((size_t)ny + 2 * GRID_PAD) * ((size_t)nz + 2 * GRID_PAD) * sizeof(uint32_t), st)) != hipSuccess) return e;
   if ((e = hipMemsetAsync(T.tail, 0, 4 * sizeof(uint32_t), st)) != hipSuccess) return e;
-  hipLaunchKernelGGL(rows_build_kernel, dim3((unsigned)nrows), dim3(256), 0, st, tab, T.rowcap, T.tail, S.keys_out, row_lo, room, T.rowoff, (uint32_t)nrows);
+  hipLaunchKernelGGL(rows_build_kernel, dim3((unsigned)nrows), dim3(256), 0, st, tab, T.rowcap, T.tail, S.ck_out, row_lo, room, T.rowoff, (uint32_t)nrows);
   T.tiles_used = (uint32_t)ntiles;
   return hipGetLastError();
 }
@@ -535,7 +574,7 @@ hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4
 // any other row.  What a row leaves behind is garbage until the next full build (which the insert asks for when the array is full).
 // Order inside a row: by column, stored points before new ones, new ones in their batch order -- exactly what a stable sort of
 // (stored..., new...) by column key gives, i.e. what map_build_grid produces for the same points.
-__device__ __forceinline__ int point_column(const float4* __restrict__ p, const CellGeo& c, uint32_t first) {
+__device__ __forceinline__ int point_column(const float4* __restrict__ p, const CellGeo& c, ckey_t first) {
   // (points this workgroup has just written: read past the vector L1)
   const unsigned* w = reinterpret_cast<const unsigned*>(p);
   float4 q;
@@ -548,18 +587,18 @@ __device__ __forceinline__ int point_column(const float4* __restrict__ p, const 
 // tail[0] = first free position behind the last row, tail[1] = 1: the array is full (nothing was written for that row; the host
 // lays the map out afresh), tail[2] = rows moved (statistics)
 // the rows a batch of sorted keys touches: (row, index of its first key), one entry per run of keys of one row; tail[3] counts them
-__global__ __launch_bounds__(256) void rows_touched_kernel(const uint32_t* __restrict__ nkeys, uint32_t k, int nxs, uint32_t* __restrict__ rows,
+__global__ __launch_bounds__(256) void rows_touched_kernel(const ckey_t* __restrict__ nkeys, uint32_t k, int nxs, uint32_t* __restrict__ rows,
                                                            uint32_t* __restrict__ firsts, uint32_t* __restrict__ count) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= k) return;
-  const uint32_t r = nkeys[j] / (uint32_t)nxs;
-  if (j != 0u && nkeys[j - 1u] / (uint32_t)nxs == r) return;
+  const uint32_t r = (uint32_t)(nkeys[j] / (ckey_t)nxs);
+  if (j != 0u && (uint32_t)(nkeys[j - 1u] / (ckey_t)nxs) == r) return;
   const uint32_t slot = atomicAdd(count, 1u);
   rows[slot] = r; firsts[slot] = j;
 }
 // (one workgroup per touched row, a fixed number of workgroups walking the list)
 __global__ __launch_bounds__(256) void rows_insert_kernel(SegTab T, uint32_t* __restrict__ rowcap, uint32_t* __restrict__ tail, uint32_t* __restrict__ full_mail, uint32_t pts_capacity,
-                                                          float4* __restrict__ pts, const uint32_t* __restrict__ nkeys, uint32_t k,
+                                                          float4* __restrict__ pts, const ckey_t* __restrict__ nkeys, uint32_t k,
                                                           const uint32_t* __restrict__ rows, const uint32_t* __restrict__ firsts,
                                                           const float4* __restrict__ new_pts, const uint32_t* __restrict__ nperm, CellGeo cg) {
   __shared__ uint32_t s_cnt[SEG_WIN + 8], s_pre[513], s_scan[256], s_hi, s_dest;
@@ -569,8 +608,8 @@ __global__ __launch_bounds__(256) void rows_insert_kernel(SegTab T, uint32_t* __
  for (uint32_t item = blockIdx.x; item < ntouched; item += gridDim.x) {
   __syncthreads();                                                 // (the last row's shared memory is done with)
   const uint32_t r = rows[item], lo = firsts[item];
-  const uint32_t first = r * (uint32_t)g.nxs;
-  if (t < 64) { const uint32_t v = wave_lower_bound_u32(nkeys, k, first + (uint32_t)g.nxs); if (t == 0) s_hi = v; }
+  const ckey_t first = (ckey_t)r * (ckey_t)g.nxs;
+  if (t < 64) { const uint32_t v = wave_lower_bound_k(nkeys, k, first + (ckey_t)g.nxs); if (t == 0) s_hi = v; }
   __syncthreads();
   const uint32_t hi = s_hi;
   const uint32_t py = r % (uint32_t)g.ny + GRID_PAD, pz = r / (uint32_t)g.ny + GRID_PAD;
@@ -609,9 +648,9 @@ __global__ __launch_bounds__(256) void rows_insert_kernel(SegTab T, uint32_t* __
   // write -- a point only ever moves up, by no less than the one before it, so a chunk's writes land on positions already read.
   // (a row merged where it is: the points in columns below the first new one stay; the row's new keys, when they are few, are
   //  searched in shared memory -- s_pre is free until row_entries)
-  const uint32_t i_stay = (dest == start_old) ? below_old(nkeys[lo] - first) : 0u;
+  const uint32_t i_stay = (dest == start_old) ? below_old((uint32_t)(nkeys[lo] - first)) : 0u;
   const bool keys_lds = add <= 512u;
-  if (keys_lds) for (uint32_t j = (uint32_t)t; j < add; j += 256u) s_pre[j] = nkeys[lo + j];
+  if (keys_lds) for (uint32_t j = (uint32_t)t; j < add; j += 256u) s_pre[j] = (uint32_t)(nkeys[lo + j] - first);      // (the row's new COLUMNS)
   __syncthreads();
   for (int c0 = (int)((len_old + 1023u) / 1024u) * 1024 - 1024; c0 >= 0 && (uint32_t)(c0 + 1024) > i_stay; c0 -= 1024) {
     // (1024 points a round, four per thread: read all, barrier, write all -- a point only ever moves up, by no less than the one
@@ -629,13 +668,14 @@ __global__ __launch_bounds__(256) void rows_insert_kernel(SegTab T, uint32_t* __
       const uint32_t i = (uint32_t)(c0 + t + 256 * u);
       sh[u] = 0u;
       if (i < len_old && i >= i_stay) {
-        const uint32_t key = column_key(p[u], cg);
+        const ckey_t key = column_key(p[u], cg);
+        const uint32_t colk = (uint32_t)(key - first);
         if (keys_lds) {
           uint32_t a = 0u, b = add;
-          while (a < b) { const uint32_t m = (a + b) >> 1; if (s_pre[m] < key) a = m + 1u; else b = m; }
+          while (a < b) { const uint32_t m = (a + b) >> 1; if (s_pre[m] < colk) a = m + 1u; else b = m; }
           sh[u] = a;
         } else {
-          sh[u] = lower_bound_u32(nkeys, lo, hi, key) - lo;
+          sh[u] = lower_bound_k(nkeys, lo, hi, key) - lo;
         }
       }
     }
@@ -649,7 +689,7 @@ __global__ __launch_bounds__(256) void rows_insert_kernel(SegTab T, uint32_t* __
   }
   // new points: the j-th of the row goes behind the stored points of its column
   for (uint32_t j = lo + (uint32_t)t; j < hi; j += 256u) {
-    const uint32_t col = nkeys[j] - first;
+    const uint32_t col = (uint32_t)(nkeys[j] - first);
     dst[(j - lo) + below_old(col + 1u)] = new_pts[nperm[j]];
   }
   __syncthreads();                                                 // (everybody is done with the old entries, every point is in place)
@@ -668,22 +708,23 @@ hipError_t map_merge_grid(hipStream_t st, float4* sorted, size_t sorted_cap, con
   const TabGeo g = tab_geo(nx, ny, nz, xs, shape);
   hipError_t e = ensure_scratch(S, k);
   if (e != hipSuccess) return e;
+  if ((e = ensure_keys(S, k)) != hipSuccess) return e;
   const int kb = (int)((k + 255) / 256);
-  hipLaunchKernelGGL(cellkey_kernel, dim3(kb), dim3(256), 0, st, new_pts, k, cell_geo(geo), S.keys_in, S.vals_in);
+  hipLaunchKernelGGL(cellkey_kernel, dim3(kb), dim3(256), 0, st, new_pts, k, cell_geo(geo), S.ck_in, S.vals_in);
   int bits = 1;
-  while (bits < 32 && ((size_t)1 << bits) < ncols) bits++;
+  while (bits < 64 && ((size_t)1 << bits) < ncols) bits++;
   if ((e = sort_keys(st, k, bits, S)) != hipSuccess) return e;
   // tiles the new points need and the map did not have take the next numbers of the pool (cleared when it was laid out)
-  hipLaunchKernelGGL(tiles_mark_kernel, dim3(kb), dim3(256), 0, st, S.keys_out, (uint32_t)k, g, T.need);
+  hipLaunchKernelGGL(tiles_mark_kernel, dim3(kb), dim3(256), 0, st, S.ck_out, (uint32_t)k, g, T.need);
   hipLaunchKernelGGL(tiles_number_kernel, dim3(1), dim3(256), 0, st, T.dir, T.need, shape.ntx * shape.nty * shape.ntz, T.cap_tiles, T.counters,
                      S.mail_dev + MAIL_TILES + 2, 0);
   const SegTab tab{T.tiles, T.dir, T.ovf, T.counters + 2, (uint32_t)(T.ovf_cap / 8), T.xstart, g};
   // the rows that receive points (the sort's input buffers are free again: they take the list)
   if ((e = hipMemsetAsync(T.tail + 3, 0, sizeof(uint32_t), st)) != hipSuccess) return e;
-  hipLaunchKernelGGL(rows_touched_kernel, dim3(kb), dim3(256), 0, st, S.keys_out, (uint32_t)k, nxs, S.keys_in, S.vals_in, T.tail + 3);
+  hipLaunchKernelGGL(rows_touched_kernel, dim3(kb), dim3(256), 0, st, S.ck_out, (uint32_t)k, nxs, S.keys_in, S.vals_in, T.tail + 3);
   const unsigned walkers = (unsigned)std::min<size_t>(std::min<size_t>(k, nrows), 8192);
   hipLaunchKernelGGL(rows_insert_kernel, dim3(walkers), dim3(256), 0, st, tab, T.rowcap, T.tail, S.mail_dev + MAIL_ROWS, (uint32_t)std::min<size_t>(sorted_cap, 0x7fffffffull),
-                     sorted, S.keys_out, (uint32_t)k, S.keys_in, S.vals_in, new_pts, S.vals_out, cell_geo(geo));
+                     sorted, S.ck_out, (uint32_t)k, S.keys_in, S.vals_in, new_pts, S.vals_out, cell_geo(geo));
   return hipGetLastError();
 }
 
@@ -721,8 +762,8 @@ __global__ __launch_bounds__(256) void crowded_points_kernel(const float4* __res
                                                              uint32_t cap, uint32_t* __restrict__ count) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= k) return;
-  const uint32_t col = column_key(pts[i], CellGeo{G.ox, G.oy, G.oz, G.inv_cell, G.nx, G.ny, G.nz, G.xs, G.six, G.siy, G.siz});
-  const uint32_t row = col / (uint32_t)G.nxs, xf = col - row * (uint32_t)G.nxs;
+  const ckey_t col = column_key(pts[i], CellGeo{G.ox, G.oy, G.oz, G.inv_cell, G.nx, G.ny, G.nz, G.xs, G.six, G.siy, G.siz});
+  const uint32_t row = (uint32_t)(col / (ckey_t)G.nxs), xf = (uint32_t)(col - (ckey_t)row * (ckey_t)G.nxs);
   const int x = (int)(xf / (uint32_t)G.xs), y = (int)(row % (uint32_t)G.ny), z = (int)(row / (uint32_t)G.ny);
   uint32_t lo, hi;
   grid_row_range(G, G.dir, y, z, x * G.xs, (x + 1) * G.xs, lo, hi);
@@ -894,20 +935,18 @@ hipError_t index_regrid(hipStream_t st, IndexTables& T, const GridView& O, GridV
   if ((long long)sh.ntx * sh.nty * sh.ntz > GRID_DIR_MAX) return hipErrorInvalidValue;
   N.ts = sh.ts; N.ty = sh.ty; N.tz = sh.tz; N.ntx = sh.ntx; N.nty = sh.nty; N.ntz = sh.ntz;
   const size_t nrowsp = ((size_t)N.ny + 2 * GRID_PAD) * ((size_t)N.nz + 2 * GRID_PAD), nx = grid_xstart_size(N.ny, N.nz, N.ntx);
-  uint32_t *xs2 = nullptr, *rc2 = nullptr;
-  uint16_t* dir2 = nullptr;
+  // the new tables go into the index's second set of buffers (kept between calls: no allocation, no wait on the way), then the
+  // two sets change places
   hipError_t e;
-  if ((e = hipMalloc(&xs2, (nx + nx / 2) * sizeof(uint32_t))) != hipSuccess) return e;
-  if ((e = hipMalloc(&rc2, (nrowsp + nrowsp / 2) * sizeof(uint32_t))) != hipSuccess) { (void)hipFree(xs2); return e; }
-  if ((e = hipMalloc(&dir2, (GRID_DIR_MAX + 8) * sizeof(uint16_t))) != hipSuccess) { (void)hipFree(xs2); (void)hipFree(rc2); return e; }
-  if ((e = hipMemsetAsync(dir2, 0, (GRID_DIR_MAX + 8) * sizeof(uint16_t), st)) != hipSuccess) return e;
-  hipLaunchKernelGGL(regrid_rows_kernel, dim3((unsigned)((nrowsp + 255) / 256)), dim3(256), 0, st, O, N, xs2, rc2, T.rowcap);
-  hipLaunchKernelGGL(regrid_dir_kernel, dim3((unsigned)((sh.ntx * sh.nty * sh.ntz + 255) / 256)), dim3(256), 0, st, O, N, dir2);
-  if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;    // (the old tables are freed below)
-  (void)hipFree(T.xstart); (void)hipFree(T.rowcap); (void)hipFree(T.dir);
-  T.xstart = xs2; T.xstart_cap = nx + nx / 2;
-  T.rowcap = rc2; T.rowcap_cap = nrowsp + nrowsp / 2;
-  T.dir = dir2;
+  if ((e = grow(T.xstart_alt, T.xstart_alt_cap, nx, nx / 2)) != hipSuccess) return e;
+  if ((e = grow(T.rowcap_alt, T.rowcap_alt_cap, nrowsp, nrowsp / 2)) != hipSuccess) return e;
+  if (!T.dir_alt && (e = hipMalloc(&T.dir_alt, (GRID_DIR_MAX + 8) * sizeof(uint16_t))) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(T.dir_alt, 0, (GRID_DIR_MAX + 8) * sizeof(uint16_t), st)) != hipSuccess) return e;
+  hipLaunchKernelGGL(regrid_rows_kernel, dim3((unsigned)((nrowsp + 255) / 256)), dim3(256), 0, st, O, N, T.xstart_alt, T.rowcap_alt, T.rowcap);
+  hipLaunchKernelGGL(regrid_dir_kernel, dim3((unsigned)((sh.ntx * sh.nty * sh.ntz + 255) / 256)), dim3(256), 0, st, O, N, T.dir_alt);
+  std::swap(T.xstart, T.xstart_alt); std::swap(T.xstart_cap, T.xstart_alt_cap);
+  std::swap(T.rowcap, T.rowcap_alt); std::swap(T.rowcap_cap, T.rowcap_alt_cap);
+  std::swap(T.dir, T.dir_alt);
   N.tiles = T.tiles; N.dir = T.dir; N.ovf = T.ovf; N.xstart = T.xstart;
   return hipGetLastError();
 }
@@ -1536,6 +1575,7 @@ hipError_t voxel_grid(hipStream_t st, const float4* in, size_t n, float leaf, fl
 void map_scratch_free(MapBuildScratch& S) {
   if (S.cub_tmp) hipFree(S.cub_tmp);
   if (S.keys_in) { hipFree(S.keys_in); hipFree(S.keys_out); hipFree(S.vals_in); hipFree(S.vals_out); }
+  if (S.ck_in) { (void)hipFree(S.ck_in); (void)hipFree(S.ck_out); S.ck_in = S.ck_out = nullptr; S.ck_cap = 0; }
   if (S.bbox) hipFree(S.bbox);
   if (S.filt_desc) hipFree(S.filt_desc);
   if (S.filt_mail_host) hipHostFree(S.filt_mail_host);

@@ -929,6 +929,51 @@ def test_insert_that_finds_the_point_array_full_lays_the_map_out_afresh(built, o
 
 
 @pytest.mark.gpu
+def test_two_places_six_kilometres_apart_keep_the_cell(built, oracle):
+    """A map of two places 6 km apart in x and y: its bounding box at the 0.5 m cell is 1.2e10 fine columns -- more than 32-bit column
+    keys can number (rounds 1-5a doubled the cell until they could: 4 m cells here) and 90 GB in the rounds-3-4 tables.  Column
+    keys are 64-bit and the index holds tiles only around the two places: the cell stays, the index is megabytes, a pass looks
+    at as many candidates per query as on a small map, k-NN answers like the oracle, and inserts go into their rows in place."""
+    from fast_limo_amd import _lib
+    rng = np.random.default_rng(3)
+    ctx = _lib.HipCtx(0)
+    try:
+        ctx.map_config()
+        oc = oracle.Octree()
+        far = np.float32([6000.0, 6000.0, 0.0])
+        a, b = synth.box_world_map(60000, 30.0, 11), synth.box_world_map(60000, 30.0, 12) + far
+        mp = np.concatenate([a, b])
+        ctx.map_add(mp); oc.update(mp)
+        for k in range(4):
+            extra = synth.box_world_map(3000, 20.0, 20 + k) + (far if k % 2 else np.float32([0, 0, 0]))
+            ctx.map_add(extra); oc.update(extra)
+            mm, merges, builds = ctx.grid_selfcheck()
+            assert mm == 0, (k, mm, merges, builds)
+        assert ctx.map_size() == oc.size()
+        assert merges >= 4 and builds == 1, (merges, builds)
+        ib = ctx.map_index_bytes()
+        print("two places 6 km apart: map %.1f MB, index %.1f MB in %d tiles" % (ib["points"] / 1e6, ib["index"] / 1e6, ib["tiles"]))
+        assert ib["index"] < 400e6, ib
+        q = np.concatenate([(rng.uniform(-25, 25, (1500, 3)) * [1, 1, 0.1] + [0, 0, 2]).astype(np.float32),
+                            (rng.uniform(-25, 25, (1500, 3)) * [1, 1, 0.1] + [0, 0, 2]).astype(np.float32) + far])
+        idx, sqd, cnt = ctx.knn(q, 5)
+        np.testing.assert_array_equal(sqd, oc.knn(q, 5)[1])
+        # a pass over the far place: the cell is still 0.5 m (candidates per query as on a small map, not 8^3 times as many)
+        x = np.zeros(26); x[6] = 1; x[10] = 1; x[25] = -9.809; x[0:3] = far
+        scan = np.ascontiguousarray(synth.velodyne_scan(32, 512, 30.0, 5)[:, :3])
+        ctx.scan_set(scan)
+        ctx.set_debug_records(True)
+        HTH, HTh, M = ctx.match_reduce(x, _lib.default_match_cfg(**CAPS))
+        cand = ctx.last_candidates_per_query()
+        ctx.set_debug_records(False)
+        recs, H, h, _ = oracle.match_H(oc, oracle.default_cfg(num_threads=4, **CAPS), x, scan)
+        assert M == H.shape[0] and M > 1000, (M, H.shape)
+        assert 5 < cand < 400, cand
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
 def test_l_shaped_two_kilometre_drive_keeps_the_index_sparse(built, oracle):
     """A 2 km drive, 1 km along +x and then 1 km along +y, inserting what the sensor sees every 10 m.  The map's bounding box is
     a square kilometre of which the drive touches an L: the index holds tiles only where map points are (a table over the whole
