@@ -458,7 +458,7 @@ void index_view(const IndexTables& T, GridView& G) {
 }
 bool index_merge_overflow(const MapBuildScratch& S) { return S.mail_host && (S.mail_host[MAIL_TILES + 3] != 0u || S.mail_host[MAIL_ROWS] != 0u); }
 void index_free(IndexTables& T) {
-  (void)hipFree(T.tiles); (void)hipFree(T.dir); (void)hipFree(T.need); (void)hipFree(T.counters); (void)hipFree(T.ovf); (void)hipFree(T.xstart); (void)hipFree(T.rowcap); (void)hipFree(T.tail); (void)hipFree(T.rowoff);
+  (void)hipFree(T.tiles); (void)hipFree(T.dir); (void)hipFree(T.need); (void)hipFree(T.ovf); (void)hipFree(T.xstart); (void)hipFree(T.rowcap); (void)hipFree(T.rowoff);      // (counters and tail live behind `need`)
   (void)hipFree(T.xstart_alt); (void)hipFree(T.rowcap_alt); (void)hipFree(T.dir_alt);
   T = IndexTables{};
 }
@@ -489,8 +489,10 @@ hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4
   if ((e = ensure_keys(S, n)) != hipSuccess) return e;
   if (!T.dir) {
     if ((e = hipMalloc(&T.dir, (GRID_DIR_MAX + 8) * sizeof(uint16_t))) != hipSuccess) return e;
-    if ((e = hipMalloc(&T.need, GRID_DIR_MAX * sizeof(uint32_t))) != hipSuccess) return e;
-    if ((e = hipMalloc(&T.counters, 4 * sizeof(uint32_t))) != hipSuccess) return e;
+    // (need, counters and tail are one allocation: one clear per layout)
+    if ((e = hipMalloc(&T.need, (GRID_DIR_MAX + 8) * sizeof(uint32_t))) != hipSuccess) return e;
+    T.counters = T.need + GRID_DIR_MAX;
+    T.tail = T.counters + 4;
   }
   {
     size_t slots = T.ovf_cap;
@@ -528,16 +530,21 @@ hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4
     if (n > 0) hipLaunchKernelGGL(rows_place_kernel, dim3(blocks), dim3(256), 0, st, pts_in, S.vals_out, S.ck_out, (uint32_t)n, nxs, row_lo, T.rowoff, pts_out);
   }
   // which tiles exist, and their numbers (directory order); the host sizes the pool by their count
-  if ((e = hipMemsetAsync(T.need, 0, GRID_DIR_MAX * sizeof(uint32_t), st)) != hipSuccess) return e;
+  const size_t te = grid_tile_entries(shape.ts, shape.ty, shape.tz);
+  // a grid whose every tile fits in 32 MB (the second level over a crowded region) takes them all: nothing to count, no wait
+  const bool all_tiles = !slack && (size_t)(ndir + 1) * te * sizeof(uint2) <= ((size_t)32 << 20);
+  if ((e = hipMemsetAsync(T.need, 0, (GRID_DIR_MAX + 8) * sizeof(uint32_t), st)) != hipSuccess) return e;      // (need, counters, tail)
+  if (all_tiles && (e = hipMemsetAsync(T.need, 0x01, (size_t)ndir * sizeof(uint32_t), st)) != hipSuccess) return e;      // (every tile is needed)
   if ((e = hipMemsetAsync(T.dir, 0, (GRID_DIR_MAX + 8) * sizeof(uint16_t), st)) != hipSuccess) return e;
-  if ((e = hipMemsetAsync(T.counters, 0, 4 * sizeof(uint32_t), st)) != hipSuccess) return e;
-  if (n > 0) hipLaunchKernelGGL(tiles_mark_kernel, dim3(blocks), dim3(256), 0, st, S.ck_out, (uint32_t)n, g, T.need);
+  if (n > 0 && !all_tiles) hipLaunchKernelGGL(tiles_mark_kernel, dim3(blocks), dim3(256), 0, st, S.ck_out, (uint32_t)n, g, T.need);
   S.mail_host[MAIL_TILES] = 0u; S.mail_host[MAIL_TILES + 1] = 0u;
   hipLaunchKernelGGL(tiles_number_kernel, dim3(1), dim3(256), 0, st, T.dir, T.need, ndir, 65536u, T.counters, S.mail_dev + MAIL_TILES, 1);
-  if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
-  const size_t ntiles = S.mail_host[MAIL_TILES];                   // the zero tile + the tiles that exist
-  if (S.mail_host[MAIL_TILES + 1] || ntiles == 0) return hipErrorOutOfMemory;      // (more than 65535 tiles: the directory has at most 4096 entries)
-  const size_t te = grid_tile_entries(shape.ts, shape.ty, shape.tz);
+  size_t ntiles = (size_t)ndir + 1;
+  if (!all_tiles) {
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+    ntiles = S.mail_host[MAIL_TILES];                              // the zero tile + the tiles that exist
+    if (S.mail_host[MAIL_TILES + 1] || ntiles == 0) return hipErrorOutOfMemory;      // (more than 65535 tiles: the directory has at most 4096 entries)
+  }
   {
     // the pool in TILES of this shape; room for the map to grow into (a merge that runs out lays the index out afresh)
     size_t cap_entries = T.tiles_cap_entries;
@@ -553,10 +560,8 @@ hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4
     size_t rc = T.rowcap_cap;
     if ((e = grow(T.rowcap, rc, ((size_t)ny + 2 * GRID_PAD) * ((size_t)nz + 2 * GRID_PAD), ((size_t)ny + 2 * GRID_PAD) * ((size_t)nz + 2 * GRID_PAD) / 2)) != hipSuccess) return e;
     T.rowcap_cap = rc;
-    if (!T.tail && (e = hipMalloc(&T.tail, 4 * sizeof(uint32_t))) != hipSuccess) return e;
   }
   if ((e = hipMemsetAsync(T.rowcap, 0, ((size_t)ny + 2 * GRID_PAD) * ((size_t)nz + 2 * GRID_PAD) * sizeof(uint32_t), st)) != hipSuccess) return e;
-  if ((e = hipMemsetAsync(T.tail, 0, 4 * sizeof(uint32_t), st)) != hipSuccess) return e;
   hipLaunchKernelGGL(rows_build_kernel, dim3((unsigned)nrows), dim3(256), 0, st, tab, T.rowcap, T.tail, S.ck_out, row_lo, room, T.rowoff, (uint32_t)nrows);
   T.tiles_used = (uint32_t)ntiles;
   return hipGetLastError();
