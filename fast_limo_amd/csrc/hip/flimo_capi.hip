@@ -882,10 +882,10 @@ extern "C" int flimo_map_grid_selfcheck(flimo_ctx* c, uint64_t* mismatches, uint
     float4* pts = nullptr; unsigned long long* diff = nullptr; IndexTables idx;
     ~Tmp() { (void)hipFree(pts); (void)hipFree(diff); index_free(idx); }
   } t;
-  HIPCHK(c, hipMalloc(&t.pts, n * sizeof(float4)));
+  HIPCHK(c, hipMalloc(&t.pts, (n + 1) * sizeof(float4)));      // (position 0 of a cell-sorted array is nobody's)
   HIPCHK(c, hipMalloc(&t.diff, sizeof(unsigned long long)));
   HIPCHK(c, hipMemsetAsync(t.diff, 0, sizeof(unsigned long long), c->stream));
-  HIPCHK(c, map_build_grid(c->stream, c->d_map_raw, n, t.pts, n, false, t.idx, n, g, c->scratch));
+  HIPCHK(c, map_build_grid(c->stream, c->d_map_raw, n, t.pts, n + 1, false, t.idx, n, g, c->scratch));
   // by meaning: every row holds the same points in the same order, every row's position at every column agrees with its own
   // array (the rows of the maintained copy are not packed; escapes and tiles take their numbers in arrival order)
   GridView ref = g;

@@ -479,6 +479,7 @@ hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4
   const int nx = geo.nx, ny = geo.ny, nz = geo.nz, xs = geo.xs;
   const int nxf = nx * xs, nxs = nxf + 1;
   const size_t nrows = (size_t)ny * nz, ncols = nrows * (size_t)nxs;
+  if (out_cap < n + 1) return hipErrorInvalidValue;                // (position 0 is nobody's: n points take n + 1 places)
   const TileShape shape = grid_tile_shape(nxf, ny, nz);
   T.shape = shape;
   const TabGeo g = tab_geo(nx, ny, nz, xs, shape);
@@ -984,7 +985,13 @@ __global__ __launch_bounds__(256) void index_compare_kernel(GridView A, GridView
   const int row = (int)(i / per), col = (int)(i % per);
   const int y = row % A.ny, z = row / A.ny;
   // (relative to the row's first point: the rows of a maintained map are not packed behind each other)
-  if (grid_pos(A, A.dir, y, z, col) - grid_pos(A, A.dir, y, z, 0) != grid_pos(B, B.dir, y, z, col) - grid_pos(B, B.dir, y, z, 0)) atomicAdd(diff, 1ull);
+  if (grid_pos(A, A.dir, y, z, col) - grid_pos(A, A.dir, y, z, 0) != grid_pos(B, B.dir, y, z, col) - grid_pos(B, B.dir, y, z, 0)) {
+#ifdef FLIMO_SELFCHECK_DEBUG
+    printf("index_compare: row (y %d, z %d) col %d: ref %u - %u, live %u - %u\n", y, z, col, grid_pos(A, A.dir, y, z, col), grid_pos(A, A.dir, y, z, 0),
+           grid_pos(B, B.dir, y, z, col), grid_pos(B, B.dir, y, z, 0));
+#endif
+    atomicAdd(diff, 1ull);
+  }
 }
 // ... and hold the same points, row by row (the rows of a maintained map are not packed behind each other)
 __global__ __launch_bounds__(64) void rows_compare_kernel(GridView A, GridView B, unsigned long long* __restrict__ diff) {
@@ -992,12 +999,23 @@ __global__ __launch_bounds__(64) void rows_compare_kernel(GridView A, GridView B
   const int y = row % A.ny, z = row / A.ny;
   const uint32_t a0 = grid_pos(A, A.dir, y, z, 0), a1 = grid_pos(A, A.dir, y, z, A.nxf);
   const uint32_t b0 = grid_pos(B, B.dir, y, z, 0), b1 = grid_pos(B, B.dir, y, z, B.nxf);
-  if (a1 - a0 != b1 - b0) { if (threadIdx.x == 0) atomicAdd(diff, 1ull); return; }
+  if (a1 - a0 != b1 - b0) {
+#ifdef FLIMO_SELFCHECK_DEBUG
+    if (threadIdx.x == 0) printf("rows_compare: row (y %d, z %d): ref len %u live len %u\n", y, z, a1 - a0, b1 - b0);
+#endif
+    if (threadIdx.x == 0) atomicAdd(diff, 1ull);
+    return;
+  }
   unsigned bad = 0;
   for (uint32_t i = threadIdx.x; i < a1 - a0; i += 64) {
     const float4 p = A.pts[a0 + i], q = B.pts[b0 + i];
-    bad += (__float_as_uint(p.x) != __float_as_uint(q.x)) + (__float_as_uint(p.y) != __float_as_uint(q.y)) +
+    const unsigned b_ = (__float_as_uint(p.x) != __float_as_uint(q.x)) + (__float_as_uint(p.y) != __float_as_uint(q.y)) +
            (__float_as_uint(p.z) != __float_as_uint(q.z)) + (__float_as_uint(p.w) != __float_as_uint(q.w));
+#ifdef FLIMO_SELFCHECK_DEBUG
+    if (b_) printf("rows_compare: row (y %d, z %d) len %u point %u: ref (%g %g %g w %u) live (%g %g %g w %u) a0 %u b0 %u\n", y, z, a1 - a0, i, p.x, p.y, p.z,
+                   __float_as_uint(p.w), q.x, q.y, q.z, __float_as_uint(q.w), a0, b0);
+#endif
+    bad += b_;
   }
   if (bad) atomicAdd(diff, (unsigned long long)bad);
 }

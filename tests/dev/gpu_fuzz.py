@@ -2,21 +2,22 @@
 Velodyne-like or random scans, maps crowded by raw sweeps inserted through the product AND the oracle's octree (same world points),
 poor / good priors, gates, caps, extrinsics; second level and own-cell probe forced on by low thresholds in half of the trials.
 Per trial three passes (no bound, pruned, pruned after a small move): same M, the oracle's H rows and residuals bit for bit.
-usage: TRIALS=200 SEED=1 python tests/dev/gpu_fuzz.py"""
+usage: TRIALS=200 SEED=1 python tests/dev/gpu_fuzz.py      (START=<trial>: the trials before it only draw their random numbers)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 from fast_limo_amd import synth, _lib
 import oracle_py as oracle
-TRIALS = int(os.environ.get("TRIALS", 100)); SEED = int(os.environ.get("SEED", 1))
+TRIALS = int(os.environ.get("TRIALS", 100)); SEED = int(os.environ.get("SEED", 1)); START = int(os.environ.get("START", 0))
 rs = np.random.RandomState(SEED)
 t_start = time.time()
 stats = dict(M=0, fine=0, ties=0, widened=0, crowded=0)
 for trial in range(TRIALS):
     L = float(rs.choice([10.0, 25.0, 50.0]))
     n_map = int(rs.choice([30000, 100000, 300000]))
-    mp = synth.box_world_map(n_map, L, 1000 * SEED + trial)
+    live = trial >= START
+    mp = synth.box_world_map(n_map if live else 16, L, 1000 * SEED + trial)
     if trial % 3 == 1:
         parts = [mp]
         for k in range(4):
@@ -28,9 +29,10 @@ for trial in range(TRIALS):
     velo = bool(rs.randint(0, 2))
     if velo:
         rings, az = int(rs.choice([16, 32, 64])), int(rs.choice([128, 256, 512]))
-        scan = np.ascontiguousarray(synth.velodyne_scan(rings, az, L, 7000 + trial)[:, :3])
+        scan = np.ascontiguousarray(synth.velodyne_scan(rings, az, L, 7000 + trial)[:, :3]) if live else None
     else:
-        scan = np.ascontiguousarray(synth.box_world_scan_random(int(rs.choice([500, 3000, 9000])), L, 7000 + trial)[:, :3])
+        nscan = int(rs.choice([500, 3000, 9000]))
+        scan = np.ascontiguousarray(synth.box_world_scan_random(nscan, L, 7000 + trial)[:, :3]) if live else None
     force = bool(trial % 2)
     os.environ["FLIMO_FINE_THRESHOLD"] = "12" if force else "64"
     os.environ["FLIMO_FINE_MIN_POINTS"] = "0" if force else "32768"
@@ -41,10 +43,15 @@ for trial in range(TRIALS):
     r, p_, y = [np.deg2rad(v) for v in synth.T_STAR_RPY_DEG]
     cr, sr, cp, sp, cy, sy = np.cos(r / 2), np.sin(r / 2), np.cos(p_ / 2), np.sin(p_ / 2), np.cos(y / 2), np.sin(y / 2)
     xt[3:7] = [sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy, cr * cp * cy + sr * sp * sy]
+    n_ins = int(rs.choice([0, 0, 3, 8]))
+    if not live:                                                     # (the same draws as a live trial, nothing else)
+        if rs.randint(0, 2):
+            rs.normal(0, 0.2, 3); rs.normal(0, 0.01, 3)
+        rs.normal(0, 0.01, 3); rs.normal(0, 0.002, 3)
+        continue
     ctx = _lib.HipCtx(0)
     oc = oracle.Octree(); oc.update(mp)
     ctx.map_config(); ctx.map_add(mp)
-    n_ins = int(rs.choice([0, 0, 3, 8]))
     for j in range(n_ins):                                           # raw sweeps at the true pose crowd the cells near the sensor
         sw = np.ascontiguousarray(synth.velodyne_scan(32, 512, L, 9000 + 10 * trial + j)[:, :3])
         ctx.scan_set(sw); oc.update(ctx.scan_to_world(xt)); ctx.map_add_scan(xt, 0.1 * (j + 1))
