@@ -1005,7 +1005,7 @@ def test_l_shaped_two_kilometre_drive_keeps_the_index_sparse(built, oracle):
         assert ib["index"] < 0.5 * whole_box, (ib, whole_box)
         assert merges >= 120, (merges, builds)
         q = []
-        for c in (pos[0], pos[50], pos[100], pos[150], pos[200], np.float32([500.0, 500.0, 0.0]), np.float32([-30.0, -30.0, 0.0])):
+        for c in (pos[0], pos[50], pos[100], pos[150], pos[200], np.float32([420.0, 170.0, 0.0]), np.float32([-30.0, -30.0, 0.0])):      # (the sixth: 80 m off the path, over tiles that do not exist)
             q.append((rng.uniform(-40, 40, (600, 3)) * [1, 1, 0.1] + [0, 0, 2]).astype(np.float32) + c)
         q = np.concatenate(q)
         idx, sqd, cnt = ctx.knn(q, 5)
