@@ -549,12 +549,24 @@ extern "C" double flimo_map_last_time(const flimo_ctx* c) { return c ? c->map_la
 
 // Does the current grid geometry hold every point of box `bb` with the margins the kernels assume (lowest cell index
 // >= 0, highest <= n-2)?  Same float expressions as the kernels.
+// Along x the lowest cell is kept out of the FIRST SEGMENT (8 fine columns) of the row: a point in a tile's first segment makes the
+// tile to its left exist and carry the row's closing entry (GridView) -- x-tile 0 has no left neighbour, and when the corner later
+// moves down by whole tiles (index_regrid) the old x-tile 0 gets one.  With the first segment of x-tile 0 always empty, every row
+// that has points in a tile's first segment got them through tiles_mark_kernel / row_entries, which write that closing entry.
+static inline int grid_low_x_cells(int xs) { return (8 + xs - 1) / xs; }
+static bool grid_side_low_ok(const GridView& g, const float* bb, int a) {
+  const float o[3] = {g.ox, g.oy, g.oz};
+  const int si[3] = {g.six, g.siy, g.siz};
+  const int low = a == 0 ? grid_low_x_cells(g.xs) : 0;
+  if ((int)floorf((bb[a] - 0.5f * g.cell - o[a]) * g.inv_cell) - si[a] < low) return false;
+  if ((int)floorf((bb[a] - o[a]) * g.inv_cell) - si[a] < low) return false;
+  return true;
+}
 static bool grid_covers(const GridView& g, const float* bb) {
   const float o[3] = {g.ox, g.oy, g.oz};
   const int n[3] = {g.nx, g.ny, g.nz}, si[3] = {g.six, g.siy, g.siz};
   for (int a = 0; a < 3; a++) {
-    if ((int)floorf((bb[a] - 0.5f * g.cell - o[a]) * g.inv_cell) - si[a] < 0) return false;
-    if ((int)floorf((bb[a] - o[a]) * g.inv_cell) - si[a] < 0) return false;
+    if (!grid_side_low_ok(g, bb, a)) return false;
     if ((int)floorf((bb[3 + a] - o[a]) * g.inv_cell) - si[a] > n[a] - 2) return false;
   }
   return true;
@@ -746,14 +758,22 @@ static int rebuild_grid(flimo_ctx* c) {
   // slack: a side the map has grown beyond since the last layout moves out by max(8 cells, 1/8 of the extent)
   float W[6];
   for (int a = 0; a < 3; a++) { W[a] = bb[a]; W[3 + a] = bb[3 + a]; }
+  // (the low x side keeps the first segment of x-tile 0 empty: grid_covers)
+  const float low_x_pad = (float)(grid_low_x_cells(1) + 2) * cell;      // (whatever column factor the layout ends up with)
   if (!c->have_gbox) {
     // first layout: a little room on every side (8 cells horizontally, 4 vertically), so that the first scans inserted into a
     // pre-built map -- their noise alone pokes through an exact box -- are merged instead of re-sorting the whole map
-    for (int a = 0; a < 3; a++) { const float pad = (a < 2 ? 8.0f : 4.0f) * cell; W[a] = bb[a] - pad; W[3 + a] = bb[3 + a] + pad; }
+    for (int a = 0; a < 3; a++) {
+      float pad = (a < 2 ? 8.0f : 4.0f) * cell;
+      if (a == 0) pad = std::max(pad, low_x_pad);
+      W[a] = bb[a] - pad; W[3 + a] = bb[3 + a] + pad;
+    }
   } else {
     for (int a = 0; a < 3; a++) {
       const float pad = std::max(8.0f * cell, 0.125f * (bb[3 + a] - bb[a]));
-      W[a] = (bb[a] < c->gbox[a]) ? bb[a] - pad : c->gbox[a];
+      // (a low side moves when the box has passed it -- or, with the geometry it was laid out for, no longer keeps its margin)
+      const bool low_moves = bb[a] < c->gbox[a] || (cell == c->grid.cell && !grid_side_low_ok(c->grid, bb, a));
+      W[a] = low_moves ? bb[a] - (a == 0 ? std::max(pad, low_x_pad) : pad) : c->gbox[a];
       W[3 + a] = (bb[3 + a] > c->gbox[3 + a]) ? bb[3 + a] + pad : c->gbox[3 + a];
     }
   }
@@ -835,7 +855,8 @@ static int rebuild_grid(flimo_ctx* c) {
   };
   if (!layout(W)) {
     for (int a = 0; a < 6; a++) W[a] = bb[a];
-    while (!layout(W)) cell *= 2.0f;   // (rows and columns-per-row within 32 bits)
+    W[0] = bb[0] - 10.0f * cell;
+    while (!layout(W)) { cell *= 2.0f; W[0] = bb[0] - 10.0f * cell; }   // (rows and columns-per-row within 32 bits; the first segment of x-tile 0 stays empty)
   }
   G.xs = xs; G.nxf = G.nx * xs; G.nxs = G.nxf + 1;
   for (int a = 0; a < 6; a++) c->gbox[a] = W[a];

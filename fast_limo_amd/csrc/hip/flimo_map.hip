@@ -992,6 +992,30 @@ __global__ __launch_bounds__(256) void index_compare_kernel(GridView A, GridView
 #endif
     atomicAdd(diff, 1ull);
   }
+  // ... and the way the k-NN pass's fast path reads a range (flimo_kernels.hip: knn5_pass): both ends from the TWO NEIGHBOURING
+  // ENTRIES of the tile of the range's first column, no xstart -- a tile that does not exist, or a row that has nothing in it, must
+  // read as an empty range there exactly when the range IS empty.  Every range of one column and of three cells that starts here.
+  const uint32_t py = (uint32_t)(y + GRID_PAD), pz = (uint32_t)(z + GRID_PAD);
+  const int widths[2] = {1, 3 * B.xs};
+  for (int wi = 0; wi < 2; wi++) {
+    const int c0 = col, c1 = min(col + widths[wi], B.nxf);
+    if (c1 <= c0) continue;
+    const uint32_t sg0 = (uint32_t)c0 >> 3;
+    const uint32_t tile = B.dir[grid_dir_index(B, py, pz, sg0)];
+    const uint2* e = B.tiles + grid_entry_index(B, tile, py, pz, sg0);
+    const uint2 e0 = e[0], e1 = e[1];
+    const bool next = ((uint32_t)c1 >> 3) != sg0;
+    const uint32_t lo = seg_count(e0.x, e0.y, (uint32_t)c0 & 7u, B.ovf);
+    const uint32_t hi = seg_count(next ? e1.x : e0.x, next ? e1.y : e0.y, (uint32_t)c1 & 7u, B.ovf);
+    const uint32_t want = grid_pos(A, A.dir, y, z, c1) - grid_pos(A, A.dir, y, z, c0);
+    if (hi - lo != want || (want != 0u && lo != grid_pos(B, B.dir, y, z, c0))) {
+#ifdef FLIMO_SELFCHECK_DEBUG
+      printf("index_compare: row (y %d, z %d) columns [%d, %d): the pass would read %u .. %u, the range holds %u points from %u\n", y, z, c0, c1, lo, hi, want,
+             grid_pos(B, B.dir, y, z, c0));
+#endif
+      atomicAdd(diff, 1ull);
+    }
+  }
 }
 // ... and hold the same points, row by row (the rows of a maintained map are not packed behind each other)
 __global__ __launch_bounds__(64) void rows_compare_kernel(GridView A, GridView B, unsigned long long* __restrict__ diff) {

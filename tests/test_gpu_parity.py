@@ -1276,6 +1276,65 @@ def test_map_that_grows_downwards_after_a_region_got_crowded(built, oracle):
 
 
 @pytest.mark.gpu
+def test_map_that_creeps_towards_minus_x_keeps_the_closing_entries(built, oracle):
+    """The pass's fast path reads both ends of a row's x range from the two neighbouring entries of ONE tile (no xstart fallback):
+    a point in a tile's first segment must have made the tile to its left exist and carry the row's closing entry.  x-tile 0 has
+    no left neighbour -- until the grid's corner moves down by whole tiles (index_regrid) and the old x-tile 0 gets one.  The map
+    creeps towards -x in steps of less than a segment (4 cells), so that points reach the lowest cells of the grid before it
+    grows; then a scan whose points straddle the old low-x boundary is matched.  After every insert the index is what a
+    from-scratch build gives, READ THE WAY THE PASS READS IT (index_compare's two-entry ranges); the passes equal, bit for bit,
+    those of a context that sorts the whole map on every insert; k-NN answers like the oracle octree."""
+    import os
+    from fast_limo_amd import _lib
+    L = 30.0
+    mp = synth.box_world_map(100000, L, 5)
+    query = np.ascontiguousarray(synth.velodyne_scan(64, 512, 20.0, 79)[:, :3])
+    rng = np.random.default_rng(29)
+    res = {}
+    oc = oracle.Octree()
+    oc.update(mp)
+    for label in ("grown", "resorted"):
+        if label == "resorted":
+            os.environ["FLIMO_FULL_REBUILD"] = "1"
+        ctx = _lib.HipCtx(0)
+        os.environ.pop("FLIMO_FULL_REBUILD", None)
+        ctx.map_config()
+        ctx.map_add(mp)
+        builds0 = ctx.grid_selfcheck()[2]
+        passes = []
+        for k in range(14):
+            # a slab of ground and wall whose low-x face moves down by 1.5 m (three cells) per insert
+            b = synth.box_world_map(4000, 10.0, 700 + k) - np.float32([L - 8.0 + 1.5 * (k + 1), 0.0, 0.0])
+            ctx.map_add(b)
+            if label == "grown":
+                oc.update(b)
+                mm, merges, builds = ctx.grid_selfcheck()
+                assert mm == 0, (k, mm, merges, builds)
+            if k in (2, 5, 9, 13):
+                # a scan from a sensor standing on the grid's first low-x boundary (-L - padding): first pass (no bound) and second
+                x = np.zeros(26); x[6] = 1; x[10] = 1; x[25] = -9.809; x[0] = -L - 5.0 + 0.37 * k
+                ctx.scan_set(query)
+                cfg = _lib.default_match_cfg(**CAPS)
+                passes.append(ctx.match_reduce(x, cfg))
+                x[0] -= 0.05
+                passes.append(ctx.match_reduce(x, cfg))
+        assert ctx.map_size() == oc.size()
+        q = (rng.uniform(-12, 12, (3000, 3)) * [1, 1, 0.2] + [-L - 5.0, 0.0, 2.0]).astype(np.float32) if label == "grown" else None
+        knn = ctx.knn(q, 5) if q is not None else None
+        res[label] = (passes, ctx.grid_selfcheck(), knn, q, builds0)
+        ctx.close()
+    mm, merges, builds = res["grown"][1]
+    print("creeping towards -x: %d merges, %d full builds (%d before the creep)" % (merges, builds, res["grown"][4]))
+    assert mm == 0 and builds - res["grown"][4] <= 1, (mm, merges, builds)          # the grid grew in place
+    for pg, pr in zip(res["grown"][0], res["resorted"][0]):
+        np.testing.assert_array_equal(pg[0], pr[0])                                    # H^T H, H^T h, M: bit for bit
+        np.testing.assert_array_equal(pg[1], pr[1])
+        assert pg[2] == pr[2] and pg[2] > 1000, (pg[2], pr[2])
+    idx, sqd, cnt = res["grown"][2]
+    np.testing.assert_array_equal(sqd, oc.knn(res["grown"][3], 5)[1])
+
+
+@pytest.mark.gpu
 def test_crowded_cells_second_level_is_exact(built, oracle):
     """Raw sweeps inserted into the map leave the cells under the sensor with hundreds of points (the insert rule keeps the whole
     first batch that lands in a leaf).  Those regions get a second-level grid (a quarter of the cell edge, copies of every map
