@@ -1059,9 +1059,9 @@ extern "C" int flimo_knn(flimo_ctx* c, const float* q, size_t nq, int k, int32_t
   HIPCHK(c, hipMalloc(&d.sqd, nq * k * sizeof(float)));
   HIPCHK(c, hipMalloc(&d.cnt, nq * sizeof(int32_t)));
   HIPCHK(c, hipMemcpyAsync(d.q, q, nq * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
-  // (no gate like a pass's MAX_DIST_PLANE: ring after ring until the k are proven, as Octree::knn answers from anywhere.  A ring r
-  //  inside the grid costs (2r+1)^2 row lookups: a query hundreds of metres from every point of a sparse map of kilometres is a
-  //  kernel of seconds to minutes -- a test / tool entry point, not the path)
+  // (no gate like a pass's MAX_DIST_PLANE: Octree::knn answers from anywhere.  A few rings of cells near the map, then -- round 6 --
+  //  the best-first search over the tiles that exist (knn_far_kernel): a query hundreds of metres from every point of a sparse map
+  //  of kilometres costs a look at the directory and at the nearest tiles, not (2r+1)^2 row lookups per ring)
   launch_knn(c->stream, c->grid, d.q, (int)nq, k, 1 << 29, d.idx, d.sqd, d.cnt);
   if (c->ties && c->gbook.active) {    // exactly tied distances: the reference's first-met choice (device copy of its octree)
     const BookView book{c->gbook.node_c, c->gbook.node_child, c->gbook.node_cnt, c->gbook.root, c->d_tie_settled};

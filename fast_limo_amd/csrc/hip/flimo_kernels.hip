@@ -465,6 +465,7 @@ __device__ __forceinline__ bool key_has_tie(const u64 (&best)[5], u64 sixth) {
   return (d0 == d1) | (d1 == d2) | (d2 == d3) | (d3 == d4) | (d4 == d5);
 }
 constexpr int TAIL_MAX_RING = 3;
+constexpr int KNN_FAR_RING = 4;                  // flimo_knn: rings the ring search tries before the tiles' best-first search takes over
 constexpr uint32_t PROBE_MIN_OWN = 6;           // first pass: an own cell with fewer points gives no useful bound
 struct __align__(16) WaveLds {                  // one per wave of the block
   float tile[16 * 65];                          // fused pass: the wave's rows, [col][row] with stride 65
@@ -2430,6 +2431,140 @@ __global__ __launch_bounds__(256) void knn_kernel(GridView G, const float* __res
 }
 
 // ------------------------------------------------------------------------------------------
+// Octree::knn answers from ANYWHERE at bounded cost (Octree.hpp:526-555: a descent, then siblings pruned by the heap's worst
+// distance).  The ring search above does too near the map, but a query far from every point would walk (2r+1)^2 rows per ring --
+// minutes on a sparse grid of kilometres.  knn_kernel is therefore run with a bound of KNN_FAR_RING rings (flimo_knn), and what
+// it could not prove is finished here, ONE WAVE PER QUERY, over the index's own coarse level: the directory of tiles that exist
+// (at most GRID_DIR_MAX).  Tiles are visited in ascending order of their box's distance to the query -- a lower bound of the
+// distance of every point inside -- until the next tile is farther than the k-th best: best-first search, exact.  Inside a tile
+// the rows are dealt to the lanes; a row (and the cells of it) the k-th best's ball cannot reach is not looked at.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void knn_far_kernel(GridView G, const float* __restrict__ qxyz, int nq, int k,
+                                                      int32_t* __restrict__ idx, float* __restrict__ sqd, int32_t* __restrict__ cnt) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int maxdim = grid_maxdim(G);
+  const float margin = 1.0e-3f + 4.0e-7f * (float)maxdim;
+  const double none = __longlong_as_double((long long)KEY_NONE);
+  const int ndir = G.ntx * G.nty * G.ntz;
+  const int cells_per_xtile = max(1, (8 << G.ts) / G.xs);
+  for (int q = blockIdx.x * 4 + wave; q < nq; q += gridDim.x * 4) {
+    if (cnt[q] >= 0) continue;                                   // proven by the ring search (wave-uniform)
+    const float gx = qxyz[3 * q], gy = qxyz[3 * q + 1], gz = qxyz[3 * q + 2];
+    const float fx = (gx - G.ox) * G.inv_cell, fy = (gy - G.oy) * G.inv_cell, fz = (gz - G.oz) * G.inv_cell;
+    if (!(fx == fx) || !(fy == fy) || !(fz == fz)) {             // NaN query: no neighbours
+      if (lane == 0) { cnt[q] = 0; for (int s = 0; s < k; s++) { idx[(size_t)q * k + s] = -1; sqd[(size_t)q * k + s] = 0.f; } }
+      continue;
+    }
+    const float flx = floorf(fminf(fmaxf(fx, -1.0e9f), 1.0e9f)), fly = floorf(fminf(fmaxf(fy, -1.0e9f), 1.0e9f)),
+                flz = floorf(fminf(fmaxf(fz, -1.0e9f), 1.0e9f));
+    const int cx = (int)flx - G.six, cy = (int)fly - G.siy, cz = (int)flz - G.siz;
+    const float rx = fminf(fmaxf(fx - flx, 0.f), 1.f), ry = fminf(fmaxf(fy - fly, 0.f), 1.f), rz = fminf(fmaxf(fz - flz, 0.f), 1.f);
+    // the query in grid cell units
+    const float qcx = (float)cx + rx, qcy = (float)cy + ry, qcz = (float)cz + rz;
+    double k5[6] = {none, none, none, none, none, none};          // this lane's own candidates (every point is seen by one lane, once)
+    float bnd2 = INFINITY;                                        // ball of the k-th best so far, cell units squared, inflated
+    float last_d = -1.f;
+    int last_i = -1;
+    for (;;) {
+      // ---- the nearest tile not visited yet: (distance, directory index) in ascending order ----
+      float best_d = INFINITY;
+      int best_i = INT_MAX;
+      for (int i = lane; i < ndir; i += 64) {
+        if (G.dir[i] == 0) continue;
+        const int tx = i % G.ntx, tyz = i / G.ntx, ty_ = tyz % G.nty, tz_ = tyz / G.nty;
+        const float x0 = (float)(tx * cells_per_xtile), x1 = (float)((tx + 1) * cells_per_xtile);
+        const float y0 = (float)((ty_ << G.ty) - GRID_PAD), y1 = (float)(((ty_ + 1) << G.ty) - GRID_PAD);
+        const float z0 = (float)((tz_ << G.tz) - GRID_PAD), z1 = (float)(((tz_ + 1) << G.tz) - GRID_PAD);
+        const float ax = fmaxf(fmaxf(x0 - qcx, qcx - x1) - margin, 0.f), ay = fmaxf(fmaxf(y0 - qcy, qcy - y1) - margin, 0.f),
+                    az = fmaxf(fmaxf(z0 - qcz, qcz - z1) - margin, 0.f);
+        const float d = (ax * ax + ay * ay + az * az) * (1.f - 1.0e-6f);
+        const bool after = d > last_d || (d == last_d && i > last_i);
+        if (after && (d < best_d || (d == best_d && i < best_i))) { best_d = d; best_i = i; }
+      }
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const float od = __shfl_xor(best_d, o, 64);
+        const int oi = __shfl_xor(best_i, o, 64);
+        if (od < best_d || (od == best_d && oi < best_i)) { best_d = od; best_i = oi; }
+      }
+      if (best_i == INT_MAX) break;                              // every tile has been visited
+      if (best_d >= bnd2) break;                                 // no point of it -- or of any later one -- can be among the k
+      last_d = best_d; last_i = best_i;
+      // ---- its rows, one per lane and round ----
+      const int tx = best_i % G.ntx, tyz = best_i / G.ntx, ty_ = tyz % G.nty, tz_ = tyz / G.nty;
+      const int xt0 = tx * cells_per_xtile, xt1 = min((tx + 1) * cells_per_xtile, G.nx) - 1;
+      const int nrows = 1 << (G.ty + G.tz);
+      for (int jb = 0; jb < nrows; jb += 64) {
+        const int j = jb + lane;
+        const int yy = (ty_ << G.ty) + (j & ((1 << G.ty) - 1)) - GRID_PAD, zz = (tz_ << G.tz) + (j >> G.ty) - GRID_PAD;
+        if (j < nrows && yy >= 0 && yy < G.ny && zz >= 0 && zz < G.nz && xt0 <= xt1) {
+          const float a = fmaxf(fmaxf((float)yy - qcy, qcy - (float)(yy + 1)) - margin, 0.f),
+                      b = fmaxf(fmaxf((float)zz - qcz, qcz - (float)(zz + 1)) - margin, 0.f);
+          const float dyz2 = a * a + b * b;
+          if (dyz2 <= bnd2) {
+            int x0 = xt0, x1 = xt1;
+            if (bnd2 < 1.0e18f) {
+              // cells of the row the ball reaches: |x - qcx| <= xr, widened
+              const float xr = fl_sqrt(fmaxf(bnd2 - dyz2, 0.f)) * (1.f + 1.0e-6f) + margin + 1.0e-4f;
+              x0 = max(x0, (int)floorf(fmaxf(qcx - xr, -1.0e9f)));
+              x1 = min(x1, (int)floorf(fminf(qcx + xr, 1.0e9f)));
+            }
+            if (x0 <= x1) {
+              uint32_t lo, hi;
+              grid_row_range(G, G.dir, yy, zz, x0 * G.xs, (x1 + 1) * G.xs, lo, hi);
+              for (uint32_t i = lo; i < hi; i++) {
+                const float4 p = G.pts[i];
+                best6_insert(k5, key_make(sqdist3(gx, gy, gz, p.x, p.y, p.z), i));
+              }
+            }
+          }
+        }
+        // the ball shrinks as soon as ANY lane holds k candidates (its k-th is an upper bound of the true one)
+        const float mine_k = __uint_as_float((uint32_t)((u64)__double_as_longlong(k5[k - 1]) >> 32));
+        float mk = mine_k;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) mk = fminf(mk, __shfl_xor(mk, o, 64));
+        if (mk < INFINITY) {
+          const float rc = (fl_sqrt(mk) * (1.f + 1.0e-5f) + 1.0e-6f) * G.inv_cell;
+          bnd2 = fminf(bnd2, rc * rc * (1.f + 1.0e-5f));
+        }
+      }
+      // ---- the k-th best over the whole wave (the lanes keep their lists) ----
+      u64 mine[6];
+#pragma unroll
+      for (int i = 0; i < 6; i++) mine[i] = (u64)__double_as_longlong(k5[i]);
+      u64 kth = KEY_NONE;
+      for (int r = 0; r < k; r++) {
+        const u64 m = (u64)__double_as_longlong(key_group_min(__longlong_as_double((long long)mine[0]), 64, lane));
+        kth = m;
+        if (mine[0] == m) { mine[0] = mine[1]; mine[1] = mine[2]; mine[2] = mine[3]; mine[3] = mine[4]; mine[4] = mine[5]; mine[5] = KEY_NONE; }
+      }
+      const float dk = __uint_as_float((uint32_t)(kth >> 32));
+      if (dk < INFINITY) {
+        const float rc = (fl_sqrt(dk) * (1.f + 1.0e-5f) + 1.0e-6f) * G.inv_cell;
+        bnd2 = fminf(bnd2, rc * rc * (1.f + 1.0e-5f));
+      }
+    }
+    // ---- the k nearest, ascending by (distance, position) ----
+    u64 mine[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) mine[i] = (u64)__double_as_longlong(k5[i]);
+    int found = 0;
+    for (int r = 0; r < k; r++) {
+      const u64 m = (u64)__double_as_longlong(key_group_min(__longlong_as_double((long long)mine[0]), 64, lane));
+      if (mine[0] == m) { mine[0] = mine[1]; mine[1] = mine[2]; mine[2] = mine[3]; mine[3] = mine[4]; mine[4] = mine[5]; mine[5] = KEY_NONE; }
+      const bool has = m != KEY_NONE;
+      found += has ? 1 : 0;
+      if (lane == 0) {
+        idx[(size_t)q * k + r] = has ? (int32_t)__float_as_uint(G.pts[(uint32_t)m].w) : -1;      // (insertion index, as knn_kernel)
+        sqd[(size_t)q * k + r] = has ? __uint_as_float((uint32_t)(m >> 32)) : 0.f;
+      }
+    }
+    if (lane == 0) cnt[q] = found;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // MAX_NUM_MATCHES: keep only the first `cap` valid records in scan order (single block)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void cap_kernel(Rec16* __restrict__ recs, int n, int cap) {
@@ -2792,7 +2927,10 @@ void launch_knn(hipStream_t st, const GridView& G, const float* qxyz, int nq, in
   const long long threads = (long long)nq * L;
   const int blocks = (int)((threads + 255) / 256);
   if (blocks == 0) return;
-  hipLaunchKernelGGL((knn_kernel<4>), dim3(blocks), dim3(256), 0, st, G, qxyz, nq, k, max_ring, idx, sqd, cnt);
+  // no gate (Octree::knn's answer from anywhere): rings near the map, then the best-first search over the tiles for what is left
+  const bool anywhere = max_ring > KNN_FAR_RING * 1024;
+  hipLaunchKernelGGL((knn_kernel<4>), dim3(blocks), dim3(256), 0, st, G, qxyz, nq, k, anywhere ? KNN_FAR_RING : max_ring, idx, sqd, cnt);
+  if (anywhere) hipLaunchKernelGGL(knn_far_kernel, dim3(std::min(4096, (nq + 3) / 4)), dim3(256), 0, st, G, qxyz, nq, k, idx, sqd, cnt);
 }
 
 void launch_cap(hipStream_t st, Rec16* recs, int n, int cap) {

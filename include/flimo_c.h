@@ -94,8 +94,10 @@ int flimo_map_points(flimo_ctx* ctx, float* xyz_out, size_t cap, size_t* n);
 
 /* ---- exact k-NN: replaces octree::Octree::knn (Objects/Octree.hpp:526-555) for a batch ----
  * q_xyz packed [nq][3] host; outputs host: idx [nq][k] (the map's insertion order, -1 padded),
- * sqd [nq][k] ascending squared distances (0 padded), cnt [nq].  k <= 5.  (No gate: a query far from every point INSIDE a
- * sparse map of kilometres searches ring after ring -- seconds to minutes; the passes are bounded by MAX_DIST_PLANE.) */
+ * sqd [nq][k] ascending squared distances (0 padded), cnt [nq].  k <= 5.  No gate: like Octree::knn the call answers from
+ * anywhere -- rings of cells near the map, then a best-first search over the index's tiles (nearest tile first, until the next
+ * one is farther than the k-th best): a query kilometres from every point costs a look at the tile directory, not at the
+ * empty space in between. */
 int flimo_knn(flimo_ctx* ctx, const float* q_xyz, size_t nq, int k, int32_t* idx, float* sqd, int32_t* cnt);
 
 /* ---- scan: pc2match of the reference (Modules/Localizer.hpp:36) ---- */

@@ -9,6 +9,7 @@ float64 adds (rel 1e-12); the pose per scan is within 1e-4 m / 1e-4 rad (north_s
 import os
 import subprocess
 
+import time
 import numpy as np
 import pytest
 
@@ -969,6 +970,15 @@ def test_two_places_six_kilometres_apart_keep_the_cell(built, oracle):
         recs, H, h, _ = oracle.match_H(oc, oracle.default_cfg(num_threads=4, **CAPS), x, scan)
         assert M == H.shape[0] and M > 1000, (M, H.shape)
         assert 5 < cand < 400, cand
+        # Octree::knn answers from anywhere: fifty queries 5 km OUTSIDE the 6 km box, and fifty in the empty middle of it
+        qf = np.concatenate([(rng.uniform(-100, 100, (50, 3)) + [-5000.0, 3000.0, 0.0]).astype(np.float32),
+                             (rng.uniform(-100, 100, (50, 3)) + [3000.0, 3000.0, 0.0]).astype(np.float32)])
+        t0 = time.perf_counter()
+        idx, sqd, cnt = ctx.knn(qf, 5)
+        dt = time.perf_counter() - t0
+        print("100 queries kilometres from every point: %.2f ms" % (1e3 * dt))
+        np.testing.assert_array_equal(sqd, oc.knn(qf, 5)[1])
+        assert (cnt == 5).all() and dt < 0.1, (cnt.min(), dt)
     finally:
         ctx.close()
 
@@ -1005,11 +1015,16 @@ def test_l_shaped_two_kilometre_drive_keeps_the_index_sparse(built, oracle):
         assert ib["index"] < 0.5 * whole_box, (ib, whole_box)
         assert merges >= 120, (merges, builds)
         q = []
-        for c in (pos[0], pos[50], pos[100], pos[150], pos[200], np.float32([420.0, 170.0, 0.0]), np.float32([-30.0, -30.0, 0.0])):      # (the sixth: 80 m off the path, over tiles that do not exist)
+        for c in (pos[0], pos[50], pos[100], pos[150], pos[200], np.float32([500.0, 500.0, 0.0]), np.float32([-30.0, -30.0, 0.0])):      # (the sixth: half a kilometre from every point, over tiles that do not exist)
             q.append((rng.uniform(-40, 40, (600, 3)) * [1, 1, 0.1] + [0, 0, 2]).astype(np.float32) + c)
         q = np.concatenate(q)
+        t0 = time.perf_counter()
         idx, sqd, cnt = ctx.knn(q, 5)
+        dt = time.perf_counter() - t0
+        print("k-NN of %d queries on and off the path (600 of them 450 m from the nearest point): %.1f ms" % (len(q), 1e3 * dt))
         np.testing.assert_array_equal(sqd, oc.knn(q, 5)[1])
+        assert (cnt == 5).all()
+        assert dt < 0.25, dt          # (round 5: seconds -- ring after ring over empty cells; now the tiles' best-first search)
     finally:
         ctx.close()
 
