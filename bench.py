@@ -102,7 +102,25 @@ def drive_to_prior(loc, mp, scan, imu):
     return rc1
 
 
-def cpu_baseline(mp, scan, imu, caps, max_threads):
+def cpu_baseline(args):
+    """The CPU oracle's baseline in a child process: OpenMP threads pinned (OMP_PROC_BIND=close, OMP_PLACES=cores -- in the child's
+    environment only: a pinned OpenMP runtime in THIS process would bind the main thread, and with it every helper thread the
+    product starts later, to one core), thread counts swept up to the CPUs the process may run on."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("OMP_PROC_BIND", "close")
+    env.setdefault("OMP_PLACES", "cores")
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--rings", str(args.rings), "--azimuths", str(args.azimuths),
+           "--map-points", str(args.map_points), "--box", str(args.box)]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=900)
+    for line in r.stdout.decode(errors="replace").splitlines():
+        if line.startswith("CPU_BASELINE_JSON "):
+            d = json.loads(line[len("CPU_BASELINE_JSON "):])
+            return d["cb"], d["E"], np.array(d["x_o"])
+    raise RuntimeError("the CPU baseline child did not deliver (rc %d)" % r.returncode)
+
+
+def cpu_baseline_here(mp, scan, imu, caps, max_threads, ncpu=None):
     """Oracle Localizer timed on the host: deskew + iterated update of the same scan (no map insert).  3 warm-ups, then up to 20
     registrations per thread count within a time budget (about 20 s in total)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -114,7 +132,10 @@ def cpu_baseline(mp, scan, imu, caps, max_threads):
     model, phys, logical = cpu_info()
     # 1 thread and every power of two up to the machine's hardware threads (Config.num_threads is what the wrapper hands to
     # omp_set_num_threads, Localizer.cpp:46-50): the best is shown, all are reported (`by_threads`); about 25 s in total
-    ncpu = os.cpu_count() or 1
+    # (the CPUs this process may run on, not the machine's: a container or a cpuset-limited box oversubscribes otherwise --
+    #  round 5's sweep collapsed at 64 / 128 threads; OMP_PROC_BIND / OMP_PLACES come with the child's environment: cpu_baseline)
+    if ncpu is None:
+        ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     tried = sorted(set([1] + [t for t in (8, 16, 32, 64, 128) if t <= min(ncpu, max_threads)]))
     for nt in tried:
         L = O.Localizer(O.default_cfg(num_threads=nt, **caps))
@@ -146,6 +167,7 @@ def cpu_baseline(mp, scan, imu, caps, max_threads):
             best = (t, nt, len(times), [float(v) * 1e3 for v in np.median(np.array(stages), axis=0)] + [t_add * 1e3])
     t, nt, reps, stg = best
     return dict(value=1.0 / t, unit="scans/s", cores=nt, kind="port", cpu_model=model, physical_cores=phys, logical_cpus=logical,
+                cpus_allowed=ncpu, omp_proc_bind=os.environ.get("OMP_PROC_BIND"), omp_places=os.environ.get("OMP_PLACES"),
                 threads=nt, reps=reps, by_threads=per_threads,
                 stages_ms={"deskew": stg[0], "knn_plane_fit": stg[1], "H_rows": stg[2], "HtH_and_solve": stg[3],
                            "map_add_once_not_in_value": stg[4]},
@@ -299,7 +321,8 @@ def hbm_regime_leg(device, steps, with_oracle, max_threads=32):
         loc.hip.map_add_scan(loc.get_x(), 0.2 + 0.1 * k)
         ins.append(time.perf_counter() - t1)
     ib = loc.hip.map_index_bytes()
-    out["index_bytes"] = dict(ib, over_map_bytes=ib["index"] / max(ib["points"], 1))
+    out["index_bytes"] = dict(ib, over_map_bytes=ib["index"] / max(ib["points"], 1),
+                              sorted_array_allocated_over_map_bytes=ib["sorted_array_allocated"] / max(ib["points"], 1))
     out["map_insert_ms"] = {"first": 1e3 * ins[0], "repeat": 1e3 * float(np.median(ins[1:])), "points_stored": loc.map_size() - n0,
                             "note": "flimo_map_add_scan of the resident scan, waited for; first: the scan's high points grow the map's box (the grid grows in place, nothing is re-sorted); repeat: the points go into their rows in place"}
     loc.close()
@@ -359,7 +382,7 @@ def crowded_leg(device, rings, az, nmap, box, n_sweeps=50):
     return out
 
 
-def shipped_config_leg(device, with_oracle, n_sweeps=10, n_pts=120000):
+def shipped_config_leg(device, with_oracle, n_sweeps=10, n_pts=120000, tied=False):
     """The reference's shipped configuration (config/kitti.yaml: crop box +-1 m, min distance 4 m, every 4th point, voxel grid 1 m,
     MAX_NUM_PC2MATCH 1e4 / MAX_NUM_MATCHES 5000, the yaml's extrinsics and biases, debug on, clouds handed back) on raw 120k-point
     sweeps of a drive, map inserts on: what a drop-in user behind the ROS wrapper runs.  ms per sweep (call + map insert), the
@@ -374,7 +397,11 @@ def shipped_config_leg(device, with_oracle, n_sweeps=10, n_pts=120000):
                   dist_active=1, min_dist=4.0, rate_active=1, rate_value=4, time_offset=1,
                   lidar2baselink_t=lid_t, lidar2baselink_R=lid_R, accel_bias=(0.01, 0.01, 0.01), gyro_bias=(0.01, 0.01, 0.01),
                   cov_gyro=6.01e-4, cov_acc=1.53e-2, cov_bias_gyro=1.54e-5, cov_bias_acc=3.38e-4)
+    # tied: the stamps a spinning sensor's driver writes (all rings of a column share one: 1800 columns per sweep) -- what the
+    # reference's kitti.yaml configuration is actually fed; otherwise every point its own stamp, in order
     sweeps5 = [synth.corridor_scan(k, n_pts, 4321, speed=speed) for k in range(n_sweeps)]
+    if tied:
+        sweeps5 = [synth.spinning_stamps(s5, columns=1800) for s5 in sweeps5]
     sweeps = [api.make_points_velodyne(s5) for s5 in sweeps5]
 
     def drive(L, feed, sync):
@@ -406,7 +433,9 @@ def shipped_config_leg(device, with_oracle, n_sweeps=10, n_pts=120000):
         return rc
     tg = drive(G, feed_gpu, lambda L: L.sync())
     out = {"workload": "config/kitti.yaml filters / caps / voxel grid / extrinsics, debug on, clouds downloaded: %d raw sweeps of %d points, "
-                       "map inserts on" % (n_sweeps, n_pts),
+                       "map inserts on; stamps: %s" % (n_sweeps, n_pts, "a spinning sensor's (1800 columns, all rings of a column share one)" if tied
+                                                       else "one per point, in order"),
+           "sweeps_with_equal_stamps_kept_on_the_device": bool(G.last_sweep_tied()),
            "ms_per_sweep": 1e3 * float(np.median(tg[3:])), "pc2match_points": int(G.pc2match().shape[0]), "map_points": G.map_size(),
            "last_sweep_stages_ms": {kk: 1e3 * float(v) for kk, v in G.stage_times().items()}}
     xg = G.get_x()
@@ -444,7 +473,9 @@ def shipped_config_leg(device, with_oracle, n_sweeps=10, n_pts=120000):
         out["cpu_oracle_ms_per_sweep_mean"] = 1e3 * float(np.mean(to[3:]))
         out["cpu_threads"] = nt
         out["speedup_vs_cpu_oracle"] = out["cpu_oracle_ms_per_sweep"] / out["ms_per_sweep"]
-        out["speedup_vs_cpu_oracle_sustained"] = out["cpu_oracle_ms_per_sweep_mean"] / out["ms_per_sweep_sustained"]      # (sequential CPU mean vs back-to-back GPU)
+        # (like for like is the line above: median sweep, each waited for, on both sides.  This one is the GPU's back-to-back
+        #  THROUGHPUT against the CPU's sequential mean LATENCY -- two statistics, two execution modes: context, not a speed-up)
+        out["gpu_sustained_throughput_vs_cpu_mean_latency"] = out["cpu_oracle_ms_per_sweep_mean"] / out["ms_per_sweep_sustained"]
         xo = Lo.get_x()
         out["free_running_pose_difference_m"] = float(np.abs(xg[0:3] - xo[0:3]).max())
     return out
@@ -468,6 +499,28 @@ def aggregate(dist, torch, elapsed: float, world: int, steps: int):
     return elapsed, world * steps / elapsed
 
 
+def visible_gpus() -> int:
+    """GPUs this process would see, without loading the HIP runtime (the parent of `--gpus N` never does): the visibility
+    variables when set, else the KFD topology (a node with SIMDs is a GPU)."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    n = 0
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for node in os.listdir(base):
+            try:
+                props = dict(line.split()[:2] for line in open(os.path.join(base, node, "properties")) if len(line.split()) >= 2)
+            except OSError:
+                continue
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except OSError:
+        return 0
+    return n
+
+
 def self_launch(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (RANK / LOCAL_RANK / WORLD_SIZE /
     MASTER_* in their environment, the protocol torch.distributed.run uses) and wait for them.  This parent never touches the GPU
@@ -481,10 +534,8 @@ def self_launch(n: int) -> int:
     port = sock.getsockname()[1]
     sock.close()
     env0 = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    if "FLIMO_BENCH_BACKEND" not in env0:
-        import torch                                   # device_count() enumerates without creating a HIP context
-        if torch.cuda.device_count() < n:
-            env0["FLIMO_BENCH_BACKEND"] = "gloo"
+    if "FLIMO_BENCH_BACKEND" not in env0 and visible_gpus() < n:
+        env0["FLIMO_BENCH_BACKEND"] = "gloo"
     procs = []
     for r in range(n):
         env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
@@ -521,7 +572,18 @@ def main():
     ap.add_argument("--with-insert", action="store_true",
                     help="time the step WITH the path exit (transform + map insert) over six steps instead of the default two "
                          "(first insertion + one repeat), for a steadier 'repeat' figure")
+    ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.cpu_baseline_child:
+        # the CPU oracle's sweep over thread counts in a process of its own (cpu_baseline): OpenMP pinned by the environment the
+        # parent set, no GPU runtime loaded, nothing of the product in the address space
+        allowed = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)      # (before libgomp binds this thread)
+        caps = dict(MAX_NUM_PC2MATCH=10**7, MAX_NUM_MATCHES=10**7)
+        mp, scan, imu = workload(0, args.rings, args.azimuths, args.map_points, args.box)
+        cb, E, x_o = cpu_baseline_here(mp, scan, imu, caps, max_threads=128, ncpu=allowed)
+        print("CPU_BASELINE_JSON " + json.dumps({"cb": cb, "E": E, "x_o": [float(v) for v in x_o]}))
+        return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))            # plain `python bench.py --gpus N`: this process only starts the N ranks
@@ -636,6 +698,13 @@ def main():
         regs = sorted(regs + [args.steps / elapsed])
         value_regions = {"regions": len(regs), "steps_each": args.steps, "scans_per_s_min": regs[0], "scans_per_s_median": float(np.median(regs)),
                          "scans_per_s_max": regs[-1], "note": "`value` is the FIRST region (the one between the barriers); the others follow it back to back"}
+        # ... and one region of at least 100 steps beside a short timed one (the driver's 20 steps last 3 ms)
+        k100 = max(100, args.steps)
+        tr0 = time.perf_counter()
+        for _ in range(k100):
+            step()
+        value_regions["scans_per_s_region_of_%d_steps" % k100] = k100 / (time.perf_counter() - tr0)
+        value_regions["long_region_steps"] = k100
         loc.hip.set_timing(int(os.environ.get('FLIMO_BENCH_TIMING', '1')))
     # The update's two layouts on THIS host, the same K steps each (informational; `value` above is the layout the library chose by
     # its launch round-trip measurement): the chain queued at once and the host loop over single passes
@@ -863,6 +932,7 @@ def main():
                                      "last_sweep_stages_ms": {kk: 1e3 * float(v) for kk, v in stg.items()}}
         end_to_end["map_points_after"] = loc.map_size()
         end_to_end["shipped_config"] = shipped_config_leg(local_rank % n_dev, not args.no_cpu_baseline)
+        end_to_end["shipped_config_tied"] = shipped_config_leg(local_rank % n_dev, not args.no_cpu_baseline, tied=True)
 
     elapsed, value = aggregate(dist, torch, elapsed, world, args.steps)
 
@@ -901,7 +971,7 @@ def main():
         }
         cb, E, x_o = (None, None, None)
         if world == 1 and not args.no_cpu_baseline:
-            cb, E, x_o = cpu_baseline(mp, scan, imu, caps, max_threads=128)
+            cb, E, x_o = cpu_baseline(args)
             out["cpu_baseline"] = cb
             dpos = float(np.abs(x_ref[0:3] - x_o[0:3]).max())
             drot = float(2.0 * np.abs(x_ref[3:6] - x_o[3:6]).max())
@@ -969,6 +1039,35 @@ def main():
             out["roofline"]["hbm_regime"] = hbm_regime_leg(local_rank % n_dev, args.hbm_steps, with_oracle=not args.no_cpu_baseline)
         if rank == 0 and world == 1 and not args.no_crowded:
             out["roofline"]["crowded"] = crowded_leg(local_rank % n_dev, args.rings, args.azimuths, args.map_points, args.box)
+        # the figures a reader of a trimmed record wants, as plain scalars of `config` / `roofline` (nested objects may be dropped)
+        flat = out["config"]
+        if value_regions:
+            flat["scans_per_s_long_region"] = value_regions.get("scans_per_s_region_of_%d_steps" % value_regions["long_region_steps"])
+            flat["scans_per_s_median_of_regions"] = value_regions["scans_per_s_median"]
+        if end_to_end:
+            for key, src in (("tied", end_to_end.get("tied_stamps")), ("unique", end_to_end.get("unique_stamps")),
+                             ("shipped", end_to_end.get("shipped_config")), ("shipped_tied", end_to_end.get("shipped_config_tied"))):
+                if not src:
+                    continue
+                flat["pcie_inclusive_ms_per_sweep_%s" % key] = src.get("ms_per_sweep")
+                flat["pcie_inclusive_ms_per_sweep_%s_sustained" % key] = src.get("ms_per_sweep_sustained")
+                if "speedup_vs_cpu_oracle" in src:
+                    flat["speedup_vs_cpu_oracle_%s" % key] = src["speedup_vs_cpu_oracle"]
+        rf = out["roofline"]
+        ks = rf.get("knn_stage_separate_dispatches")
+        if ks and bytes_per_query:
+            rf["knn_kernel_alone_us"] = ks["knn_us"]
+            rf["knn_kernel_alone_frac"] = bytes_per_query * qpl / (ks["knn_us"] * 1e-6) / 1e9 / HBM_PEAK_GBPS
+            rf["knn_stage_frac"] = ks["frac"]
+        hb = rf.get("hbm_regime")
+        if hb:
+            rf["hbm_regime_ms_per_step"] = hb.get("ms_per_step")
+            rf["hbm_regime_frac"] = hb.get("frac")
+            rf["hbm_regime_widen_us"] = (hb.get("separate_dispatch_pass_us") or {}).get("widen")
+            rf["hbm_regime_insert_ms_repeat"] = (hb.get("map_insert_ms") or {}).get("repeat")
+            rf["hbm_regime_insert_ms_first"] = (hb.get("map_insert_ms") or {}).get("first")
+        if kernel_us_per_step:
+            rf["kernel_us_per_step"] = kernel_us_per_step["total"]
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if loc is not None:
         loc.close()

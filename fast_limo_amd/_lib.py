@@ -381,9 +381,10 @@ class HipCtx:
         return dict(passes_redone=int(o[0]), queries_settled=int(o[1]))
 
     def map_index_bytes(self):
-        o = (C.c_uint64 * 5)()
+        o = (C.c_uint64 * 6)()
         self._chk(self._L.flimo_map_index_bytes(self._h, o))
-        return dict(points=int(o[0]), index=int(o[1]), second_level=int(o[2]), tiles=int(o[3]), tile_pool_relayouts=int(o[4]))
+        return dict(points=int(o[0]), index=int(o[1]), second_level=int(o[2]), tiles=int(o[3]), tile_pool_relayouts=int(o[4]),
+                    sorted_array_allocated=int(o[5]))
 
     def fused_pass_count(self) -> int:
         return int(self._L.flimo_fused_pass_count(self._h))

@@ -41,7 +41,7 @@ class LocCfg(C.Structure):
 
 
 HOST_SYMBOLS = [
-    "flimo_loc_create", "flimo_loc_destroy", "flimo_loc_ctx", "flimo_loc_sync", "flimo_loc_set_async_insert", "flimo_loc_set_lazy_time_order", "flimo_loc_set_gpu_filters", "flimo_loc_set_propagation_wait", "flimo_loc_last_insert_seconds", "flimo_loc_update_imu", "flimo_loc_update_imu_n", "flimo_loc_replay", "flimo_loc_update_pointcloud", "flimo_loc_update_pointcloud_points",
+    "flimo_loc_create", "flimo_loc_destroy", "flimo_loc_ctx", "flimo_loc_sync", "flimo_loc_set_async_insert", "flimo_loc_set_lazy_time_order", "flimo_loc_set_gpu_filters", "flimo_loc_set_exact_tied_order", "flimo_loc_last_sweep_tied", "flimo_loc_set_propagation_wait", "flimo_loc_last_insert_seconds", "flimo_loc_update_imu", "flimo_loc_update_imu_n", "flimo_loc_replay", "flimo_loc_update_pointcloud", "flimo_loc_update_pointcloud_points",
     "flimo_loc_map_add", "flimo_loc_map_size", "flimo_loc_get_x", "flimo_loc_set_x", "flimo_loc_get_P",
     "flimo_loc_set_P", "flimo_loc_set_flags", "flimo_loc_num_passes", "flimo_loc_get_pass", "flimo_loc_get_pc2match",
     "flimo_loc_get_final_scan", "flimo_loc_get_stage_times", "flimo_loc_get_pose_cov", "flimo_loc_register_resident", "flimo_loc_host_profile",
@@ -129,6 +129,10 @@ def load_host():
     L.flimo_loc_set_lazy_time_order.argtypes = [vp, C.c_int]
     L.flimo_loc_set_gpu_filters.restype = None
     L.flimo_loc_set_gpu_filters.argtypes = [vp, C.c_int]
+    L.flimo_loc_set_exact_tied_order.restype = None
+    L.flimo_loc_set_exact_tied_order.argtypes = [vp, C.c_int]
+    L.flimo_loc_last_sweep_tied.restype = C.c_int
+    L.flimo_loc_last_sweep_tied.argtypes = [vp]
     L.flimo_loc_set_propagation_wait.restype = None
     L.flimo_loc_set_propagation_wait.argtypes = [vp, C.c_double]
     L.flimo_loc_last_insert_seconds.restype = C.c_double
@@ -292,6 +296,14 @@ class Localizer:
 
     def set_gpu_filters(self, on=True):
         self._L.flimo_loc_set_gpu_filters(self._h, int(on))
+
+    def set_exact_tied_order(self, on=True):
+        """Equal stamps in a sweep whose time order is observable: the reference's library order (host front end) instead of the
+        device's stable order (flimo_localizer_c.h)."""
+        self._L.flimo_loc_set_exact_tied_order(self._h, int(on))
+
+    def last_sweep_tied(self) -> bool:
+        return bool(self._L.flimo_loc_last_sweep_tied(self._h))
 
     def set_propagation_wait(self, seconds: float):
         """< 0: wait for the IMU stream without bound (the reference's behaviour; needs a second thread feeding update_imu)."""

@@ -734,7 +734,7 @@ static int rebuild_grid(flimo_ctx* c) {
       float4* np = nullptr;
       HIPCHK(c, hipMalloc(&np, ncap * sizeof(float4)));
       HIPCHK(c, hipMemcpyAsync(np, c->d_map_sorted, std::min(ncap, c->sorted_cap) * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
-      const size_t ovf_words = (c->map_cap / 16 + 64) * 8;
+      const size_t ovf_words = (c->map_cap / 8 + 64) * 8;
       uint32_t* no = nullptr;
       if (ovf_words > c->idx.ovf_cap) {
         HIPCHK(c, hipMalloc(&no, ovf_words * sizeof(uint32_t)));
@@ -1358,6 +1358,7 @@ extern "C" int flimo_raw_scan_filter_order_set(flimo_ctx* c, const void* points3
   }
   F.fov = cfg->fov_active ? 1 : 0; F.fov_angle = cfg->fov_angle;
   const bool keep_order = (time_order & 2) != 0;      // bit 1: no spatial order (a voxel filter follows and re-orders the scan)
+  const bool ties_as_they_come = (time_order & 8) != 0;      // bit 3: equal stamps keep their arrival order (see below)
   time_order &= 1;
   HIPCHK(c, filter_raw_scan(c->stream, c->d_raw32, n, F, c->d_scan_raw, c->d_scan_t, c->d_filt_ext, c->scratch, time_order ? c->d_tkey[0] : nullptr, (int)rec));
   HIPCHK(c, filter_raw_scan_result(c->stream, c->scratch, c->d_filt_ext, c->wait_timeout_ms, c->h_filt_ext));
@@ -1393,7 +1394,12 @@ extern "C" int flimo_raw_scan_filter_order_set(flimo_ctx* c, const void* points3
                              c->d_filt_ext, c->scratch));
     bool is_tied = false;
     HIPCHK(c, time_order_raw_tied(c->stream, c->scratch, c->d_filt_ext, c->wait_timeout_ms, &is_tied));
-    if (is_tied) { *tied = 1; return FLIMO_OK; }      // equal stamps: only the host routine reproduces the library's order among them
+    // Equal stamps (a spinning sensor: all rings of a column share one): the reference's std::partial_sort_copy leaves them in the
+    // order its heap happens to produce, which only the host routine reproduces move for move.  That order is observable only as
+    // ulp-level voxel centroids and as which of several equally stamped points a cap cuts off -- far below north_star's 1e-4 m.
+    // A caller that says so (bit 3) gets the stable order of the radix sort -- arrival order among equal stamps -- and the sweep
+    // stays on the device; without the bit the call reports `tied` and leaves the sweep to the caller's host routine.
+    if (is_tied) { *tied = 1; if (!ties_as_they_come) return FLIMO_OK; }
     std::swap(c->d_scan_raw, c->d_scan_world);
     std::swap(c->d_scan_t, c->d_t_tmp);
     c->raw_time_ordered = true;
@@ -1552,14 +1558,17 @@ extern "C" int flimo_fine_stats(const flimo_ctx* c, unsigned long long out[4]) {
   out[0] = c->fine_valid ? 1 : 0; out[1] = c->fine_valid ? c->fine.n_pts : 0; out[2] = c->fine_builds; out[3] = c->fine_passes;
   return FLIMO_OK;
 }
-extern "C" int flimo_map_index_bytes(const flimo_ctx* c, uint64_t out[5]) {
+extern "C" int flimo_map_index_bytes(const flimo_ctx* c, uint64_t out[6]) {
   if (!c || !out) return FLIMO_ERR_INVALID;
   out[0] = (uint64_t)c->map_n * sizeof(float4);
-  // (the tiles that exist + the zero tile, the directory, xstart, the escape pool as allocated)
+  // (the tiles that exist + the zero tile, the directory, xstart, the rows' room and first positions, the escape pool as allocated)
   auto tables = [](const GridView& g, const IndexTables& T) {
+    const uint64_t rows = ((uint64_t)g.ny + 2 * GRID_PAD) * ((uint64_t)g.nz + 2 * GRID_PAD);
     return (uint64_t)T.tiles_used * grid_tile_entries(g.ts, g.ty, g.tz) * 8ull + (uint64_t)GRID_DIR_MAX * 2ull +
-           (uint64_t)(grid_xstart_size(g.ny, g.nz, g.ntx) + T.ovf_cap) * 4ull;
+           (uint64_t)(grid_xstart_size(g.ny, g.nz, g.ntx) + T.ovf_cap) * 4ull + rows * 4ull + (uint64_t)g.ny * g.nz * 4ull;
   };
+  // the cell-sorted array AS ALLOCATED: three times the raw buffer's capacity, its rows keep room behind their last point
+  out[5] = c->d_map_sorted ? (uint64_t)c->sorted_cap * sizeof(float4) : 0ull;
   out[1] = c->grid_valid ? tables(c->grid, c->idx) : 0ull;
   out[2] = c->fine_valid ? (uint64_t)c->fine.n_pts * sizeof(float4) + tables(c->fine, c->fine_idx) : 0ull;
   out[3] = c->grid_valid ? c->idx.tiles_used : 0ull;

@@ -231,7 +231,7 @@ __device__ __forceinline__ uint32_t wave_lower_bound_k(const ckey_t* __restrict_
 }
 // geometry of the index as the builders need it
 struct TabGeo { int nxs, ny, nz, ts, ty, tz, ntx, nty, ntz; };
-struct SegTab { uint2* tiles; const uint16_t* dir; uint32_t* ovf; uint32_t* ovf_count; uint32_t ovf_cap; uint32_t* xstart; TabGeo g; };
+struct SegTab { uint2* tiles; const uint16_t* dir; uint32_t* ovf; uint32_t* ovf_count; uint32_t ovf_cap; uint32_t* xstart; TabGeo g; uint32_t* full_mail; };      // full_mail: word of mapped host memory that says "lay the index out afresh" (an insert), or null
 __device__ __forceinline__ uint32_t tab_dir_index(const TabGeo& g, uint32_t py, uint32_t pz, uint32_t sg) {
   return ((pz >> g.tz) * (uint32_t)g.nty + (py >> g.ty)) * (uint32_t)g.ntx + (sg >> g.ts);
 }
@@ -353,11 +353,13 @@ __device__ __forceinline__ void row_entries(const SegTab& T, uint32_t py, uint32
       if (!big) { *dst = make_uint2(pre, nib); return; }
       const uint2 old = *dst;
       const uint32_t slot_o = ((int)old.x < 0) ? old.y : atomicAdd(T.ovf_count, 1u);
-      if (slot_o < T.ovf_cap) {            // (always: the pool holds one slot per 16 points of the point buffer's capacity)
+      if (slot_o < T.ovf_cap) {            // (the pool holds two slots per 16 points of the point buffer's capacity: a segment at a tile's edge takes two -- its own entry and the left tile's closing one)
         uint32_t a = 0u;
 #pragma unroll
         for (int k = 0; k < 8; k++) { T.ovf[(size_t)slot_o * 8u + k] = a; a += s_cnt[i * 8 + k]; }
         *dst = make_uint2(pre | 0x80000000u, slot_o);
+      } else if (T.full_mail) {
+        *T.full_mail = 1u;                 // out of escape slots: the entry stays stale -- the host lays the index out afresh before anything reads it
       }
     };
 #pragma unroll
@@ -497,7 +499,7 @@ hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4
   }
   {
     size_t slots = T.ovf_cap;
-    if ((e = grow(T.ovf, slots, (pts_cap / 16 + 64) * 8, 0)) != hipSuccess) return e;
+    if ((e = grow(T.ovf, slots, (pts_cap / 8 + 64) * 8, 0)) != hipSuccess) return e;
     T.ovf_cap = slots;
     if ((e = grow(T.xstart, T.xstart_cap, grid_xstart_size(ny, nz, shape.ntx), grid_xstart_size(ny, nz, shape.ntx) / 2)) != hipSuccess) return e;
   }
@@ -556,7 +558,7 @@ hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4
   T.cap_tiles = (uint32_t)std::min<size_t>(std::min<size_t>(T.tiles_cap_entries, ((size_t)1 << 32) - 1) / te, 65536);
   if ((e = hipMemsetAsync(T.tiles, 0, (size_t)T.cap_tiles * te * sizeof(uint2), st)) != hipSuccess) return e;
   if ((e = hipMemsetAsync(T.xstart, 0, grid_xstart_size(ny, nz, shape.ntx) * sizeof(uint32_t), st)) != hipSuccess) return e;
-  const SegTab tab{T.tiles, T.dir, T.ovf, T.counters + 2, (uint32_t)(T.ovf_cap / 8), T.xstart, g};
+  const SegTab tab{T.tiles, T.dir, T.ovf, T.counters + 2, (uint32_t)(T.ovf_cap / 8), T.xstart, g, nullptr};
   {
     size_t rc = T.rowcap_cap;
     if ((e = grow(T.rowcap, rc, ((size_t)ny + 2 * GRID_PAD) * ((size_t)nz + 2 * GRID_PAD), ((size_t)ny + 2 * GRID_PAD) * ((size_t)nz + 2 * GRID_PAD) / 2)) != hipSuccess) return e;
@@ -724,7 +726,7 @@ hipError_t map_merge_grid(hipStream_t st, float4* sorted, size_t sorted_cap, con
   hipLaunchKernelGGL(tiles_mark_kernel, dim3(kb), dim3(256), 0, st, S.ck_out, (uint32_t)k, g, T.need);
   hipLaunchKernelGGL(tiles_number_kernel, dim3(1), dim3(256), 0, st, T.dir, T.need, shape.ntx * shape.nty * shape.ntz, T.cap_tiles, T.counters,
                      S.mail_dev + MAIL_TILES + 2, 0);
-  const SegTab tab{T.tiles, T.dir, T.ovf, T.counters + 2, (uint32_t)(T.ovf_cap / 8), T.xstart, g};
+  const SegTab tab{T.tiles, T.dir, T.ovf, T.counters + 2, (uint32_t)(T.ovf_cap / 8), T.xstart, g, S.mail_dev + MAIL_ROWS};
   // the rows that receive points (the sort's input buffers are free again: they take the list)
   if ((e = hipMemsetAsync(T.tail + 3, 0, sizeof(uint32_t), st)) != hipSuccess) return e;
   hipLaunchKernelGGL(rows_touched_kernel, dim3(kb), dim3(256), 0, st, S.ck_out, (uint32_t)k, nxs, S.keys_in, S.vals_in, T.tail + 3);

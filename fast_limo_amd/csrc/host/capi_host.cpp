@@ -209,6 +209,8 @@ void flimo_loc_set_flags(flimo_loc* L, int add_to_map, int download_clouds, int 
 }
 void flimo_loc_set_lazy_time_order(flimo_loc* L, int on) { if (L) L->loc->lazy_time_order = on != 0; }
 void flimo_loc_set_gpu_filters(flimo_loc* L, int on) { if (L) L->loc->gpu_filters = on != 0; }
+void flimo_loc_set_exact_tied_order(flimo_loc* L, int on) { if (L) L->loc->exact_tied_order = on != 0; }
+int flimo_loc_last_sweep_tied(const flimo_loc* L) { return (L && L->loc->last_sweep_tied()) ? 1 : 0; }
 void flimo_loc_set_propagation_wait(flimo_loc* L, double seconds) { if (L) L->loc->propagation_wait_s = seconds; }
 // the map insert that ends a scan runs on the Mapper's worker thread (Mapper::add_scan): wait for it / switch it off
 void flimo_loc_sync(flimo_loc* L) { if (L) L->map->sync(); }

@@ -1256,6 +1256,7 @@ int Localizer::deskewOnDevice(const PointType* raw_points, size_t n, double star
   const auto& fl = config.filters;
   const auto& mc = config.ikfom.mapping;
   dev_front_end_ = false;
+  dev_tied_ = false;
   order_ctx_ = nullptr;
   if (!deviceFrontEndEnabled()) return 0;
   // Upload, filters, stamps and the time order do not read the map: they run on the Mapper's second context while the main one
@@ -1341,8 +1342,12 @@ int Localizer::deskewOnDevice(const PointType* raw_points, size_t n, double star
     }
   }
   const double tf2 = prof ? now_s() : 0.0;
-  if (flimo_raw_scan_filter_order_set(c, src, n, &fc, (need_order ? 1 : 0) | (fl.voxel_active ? 2 : 0) | (rec16 ? 4 : 0), &kept, &last_stamp, &nan, &tied) != FLIMO_OK || nan || tied)
+  // (equal stamps -- every spinning sensor: all rings of a column share one -- keep their arrival order on the device unless the
+  //  caller insists on the order the reference's partial_sort_copy leaves them in: `exact_tied_order`, the host routine)
+  if (flimo_raw_scan_filter_order_set(c, src, n, &fc, (need_order ? 1 : 0) | (fl.voxel_active ? 2 : 0) | (rec16 ? 4 : 0) | (exact_tied_order ? 0 : 8),
+                                      &kept, &last_stamp, &nan, &tied) != FLIMO_OK || nan || (tied && exact_tied_order))
     return 0;
+  dev_tied_ = tied != 0;
   const double tf3 = prof ? now_s() : 0.0;
   double tf4 = tf3;
   order_ctx_ = c;

@@ -76,6 +76,12 @@ class fast_limo::Localizer {
   bool lazy_time_order = true;          // the GPU gets the sweep in arrival order whenever the time order is not observable through
                                         // caps / voxel sums (deskewPointCloud); false: always the reference's permutation first
 
+  bool exact_tied_order = false;        // equal stamps (a spinning sensor) in a sweep whose time order is observable (caps / voxel grid on):
+                                        // false: the device's stable order, arrival order among the equal ones -- the sweep never leaves the
+                                        // GPU; true: the order std::partial_sort_copy leaves them in (Localizer.cpp:789-790), reproduced move
+                                        // for move by the host front end (bit-exact centroids and cap membership, 1.5 ms per 64k sweep)
+  bool last_sweep_tied() const { return dev_tied_; }      // the last sweep of the device front end had equal stamps
+
   static Localizer& getInstance() {
     static Localizer* loc = new Localizer();
     return *loc;
@@ -127,6 +133,7 @@ class fast_limo::Localizer {
   bool dev_front_end_ = false;          // the last sweep went through the device front end (clouds materialized afterwards)
   bool device_declined_ = false;        // updatePointCloudView asked the device front end for this sweep and was turned down
   flimo_ctx* order_ctx_ = nullptr;      // the context that ran this sweep's input stage (it keeps the time order)
+  bool dev_tied_ = false;
   bool dev_time_ordered_ = false;       // ... and the device holds it in the reference's time order (stamps pairwise different)
   bool dev_voxel_ = false;
   const float* mat_body4_ = nullptr;          // the downloaded clouds (float4 records in the context's pinned memory)

@@ -165,6 +165,16 @@ def corridor_scan(k: int, n: int, seed: int, speed: float = 10.0, sweep_s: float
     return out
 
 
+def spinning_stamps(scan5: np.ndarray, columns: int = 1800, sweep_s: float = 0.1) -> np.ndarray:
+    """The stamps of a spinning sensor: the sweep is `columns` firings, and every point of a firing (all rings of a column) carries
+    that firing's stamp -- column j at j / columns * sweep_s, like a Velodyne driver writes them.  Returns a copy of the (n, 5)
+    scan with its time column quantised down to its column's stamp (the order of the points is kept: arrival order)."""
+    out = np.array(scan5, dtype=np.float32, copy=True)
+    col = np.floor(out[:, 4].astype(np.float64) / sweep_s * columns)
+    out[:, 4] = (col * (sweep_s / columns)).astype(np.float32)
+    return out
+
+
 def corridor_map(n: int, x0: float, x1: float, seed: int, half_width: float = 6.0, sensor_height: float = 1.8,
                  sigma: float = 0.01) -> np.ndarray:
     """World-frame map (n, 3) float32 of the corridor `corridor_scan` drives through, over x in [x0, x1]: the same ground,

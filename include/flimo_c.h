@@ -157,7 +157,10 @@ int flimo_upload_stage(flimo_ctx* ctx, size_t bytes, void** host_ptr);
  * flimo_scan_voxel_filter right after the deskew, which re-orders the scan anyway.
  * time_order bit 2 (value 4): points32 holds 16-byte records {float x, y, z; 32-bit time word (PointType offset 24: OUSTER's uint32 t,
  * VELODYNE's float time)} instead of PointType records: time_kind 0 or 1 only.  A caller that stages the upload itself
- * (flimo_upload_stage) packs the sweep while it copies it and halves the bytes over PCIe. */
+ * (flimo_upload_stage) packs the sweep while it copies it and halves the bytes over PCIe.
+ * time_order bit 3 (value 8): equal stamps keep their ARRIVAL order (the radix sort is stable) and the sweep is made resident all
+ * the same; *tied = 1 still says that there were some.  Among equal stamps the reference's order is whatever its heap sort leaves
+ * -- observable only as ulp-level voxel centroids and as which of several equally stamped points a cap cuts off. */
 int flimo_raw_scan_filter_order_set(flimo_ctx* ctx, const void* points32, size_t n, const flimo_filter_cfg* cfg, int time_order,
                                     size_t* n_kept, double* last_stamp, int* nan_stamp, int* tied);
 int flimo_raw_scan_order(flimo_ctx* ctx, uint32_t* order_out, size_t cap, size_t* n);

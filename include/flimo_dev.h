@@ -57,11 +57,12 @@ int flimo_map_grid_selfcheck(flimo_ctx* ctx, uint64_t* mismatches, uint64_t stat
 /* out[0] = GPU ms of the algebra launches timed so far (timing level 1), out[1] = their number,
  * out[2] = chains run, out[3] = chains that came back before the final iteration, out[4] = chains declined */
 int flimo_chain_stats(flimo_ctx* ctx, double out[5], int reset);
-/* bytes held by the map: out[0] = the cell-sorted points (16 B each), out[1] = its index (the tiles that exist, directory, row
- * starts, escape pool as allocated), out[2] = the second level over crowded regions (points + index), 0 when none is active;
- * out[3] = tiles of the index that exist (with the shared empty one), out[4] = inserts that found the tile pool too small and
- * had the index laid out afresh */
-int flimo_map_index_bytes(const flimo_ctx* ctx, uint64_t out[5]);
+/* bytes held by the map: out[0] = the stored points (16 B each), out[1] = its index (the tiles that exist, directory, row
+ * starts, the rows' room and first positions, escape pool as allocated), out[2] = the second level over crowded regions (points +
+ * index), 0 when none is active; out[3] = tiles of the index that exist (with the shared empty one), out[4] = inserts that found
+ * the tile pool too small and had the index laid out afresh, out[5] = the cell-sorted array AS ALLOCATED (three times the raw
+ * buffer's capacity: its rows keep room behind their last point, so that an insert touches only the rows it adds to) */
+int flimo_map_index_bytes(const flimo_ctx* ctx, uint64_t out[6]);
 /* pipelined host loop (flimo_set_pass_pipeline): {passes that found their launch waiting, queued passes nobody asked for, passes
  * whose waiting launch was found too old to publish to (told to leave, launched the usual way), passes whose launch had left as a
  * whole before the publish reached it (launched again)} */

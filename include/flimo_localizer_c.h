@@ -59,6 +59,13 @@ void   flimo_loc_set_lazy_time_order(flimo_loc* L, int on);
 /* default on: NaN removal, crop box, rate and min-distance filters and the per-point stamps run on the GPU
  * (flimo_raw_scan_filter_set) whenever the arrival-order path applies and no host copies of the clouds are requested */
 void   flimo_loc_set_gpu_filters(flimo_loc* L, int on);
+/* default off.  A sweep whose stamps are not pairwise different (every spinning sensor: all rings of a column share one) and whose
+ * time order is observable (MAX_NUM_PC2MATCH / MAX_NUM_MATCHES can bind, or the voxel grid is on): off = the device's stable
+ * order, arrival order among equal stamps -- observable only as ulp-level voxel centroids and as which of several equally stamped
+ * points a cap cuts off; on = the order std::partial_sort_copy leaves them in (Localizer.cpp:789-790), reproduced move for move
+ * by the host front end (bit-exact against the reference's library call, 1.5 ms per 64k-point sweep). */
+void   flimo_loc_set_exact_tied_order(flimo_loc* L, int on);
+int    flimo_loc_last_sweep_tied(const flimo_loc* L);      /* 1: the last sweep of the device front end had equal stamps */
 /* how long updatePointCloud waits for the IMU stream to reach the end of the sweep (Localizer::propagatedFromTimeRange,
  * Localizer.cpp:855-871).  The reference waits on its condition variable without bound, and so does fast_limo::Localizer used
  * through its C++ header (seconds < 0).  Handles made by flimo_loc_create start with 1 s, because their callers usually feed IMU

@@ -355,6 +355,49 @@ def test_reference_yaml_configuration_sequence(built, oracle):
     G.close()
 
 
+def test_reference_yaml_configuration_with_a_spinning_sensors_stamps_stays_on_the_device(built, oracle):
+    """What a real spinning LiDAR hands the reference's shipped configuration: all rings of a column share one stamp, the sweep is
+    time-sorted (Localizer.cpp:789-790) and then voxelised (:313-321).  The order among equal stamps is the library's heap moves';
+    the device keeps their arrival order instead (stable radix sort) and the sweep never leaves the GPU -- the difference is ulps of
+    voxel centroids.  A 12-scan drive with map inserts against the CPU oracle (which restates the library's order): same status
+    codes, pc2match sizes within 4, map sizes within 8, pose within 1e-4 m / 1e-4 rad on every scan."""
+    from fast_limo_amd import api
+    n_scans, n_pts, speed = 12, 30000, 10.0
+    st, w, a = synth.stationary_imu(0.0, 0.1 * n_scans + 0.06)
+    lid_t = (8.086759e-01, -3.195559e-01, 7.997231e-01)
+    lid_R = (9.999976e-01, -7.854027e-04, 2.024406e-03, 7.553071e-04, 9.998898e-01, 1.482454e-02,
+             -2.035826e-03, -1.482298e-02, 9.998881e-01)
+    common = dict(MAX_NUM_PC2MATCH=10000, MAX_NUM_MATCHES=5000, voxel_active=1, leaf_size=1.0, crop_active=1,
+                  dist_active=1, min_dist=4.0, rate_active=1, rate_value=4, time_offset=1,
+                  lidar2baselink_t=lid_t, lidar2baselink_R=lid_R, accel_bias=(0.01, 0.01, 0.01), gyro_bias=(0.01, 0.01, 0.01),
+                  cov_gyro=6.01e-4, cov_acc=1.53e-2, cov_bias_gyro=1.54e-5, cov_bias_acc=3.38e-4)
+    G = api.Localizer(api.default_cfg(cropBoxMin=(-1.0, -1.0, -1.0), cropBoxMax=(1.0, 1.0, 1.0), **common))
+    Lo = oracle.Localizer(oracle.default_cfg(crop_min=(-1.0, -1.0, -1.0), crop_max=(1.0, 1.0, 1.0), num_threads=4, **common))
+    x0 = G.get_x(); x0[14] = speed
+    G.set_x(x0); Lo.set_x(x0)
+    i = 0
+    worst = (0.0, 0.0)
+    sizes = []
+    for k in range(n_scans):
+        until = 0.1 * (k + 1) + 0.005
+        while i < len(st) and st[i] <= until:
+            G.update_imu(st[i], w[i], a[i]); Lo.update_imu(st[i], w[i], a[i]); i += 1
+        scan = synth.spinning_stamps(synth.corridor_scan(k, n_pts, 321, speed=speed), columns=1800)
+        rg = G.update_pointcloud(scan, 0.1 * k)
+        ro = Lo.update_pointcloud(scan, 0.1 * k)
+        assert rg == ro, (k, rg, ro)
+        assert G.last_sweep_tied(), k                                     # equal stamps, and the device front end took the sweep
+        assert abs(G.pc2match().shape[0] - Lo.pc2match().shape[0]) <= 4, (k, G.pc2match().shape, Lo.pc2match().shape)
+        assert abs(G.map_size() - Lo.map_size()) <= 8, (k, G.map_size(), Lo.map_size())
+        dpos, ang = pose_delta(G.get_x(), Lo.get_x())
+        worst = (max(worst[0], dpos), max(worst[1], ang))
+        sizes.append((G.pc2match().shape[0], G.map_size()))
+    print("kitti.yaml configuration, spinning-sensor stamps on the device: worst GPU-vs-CPU deviation", worst, "pc2match / map sizes", sizes[-1])
+    assert worst[0] <= 1e-4 and worst[1] <= 1e-4, worst
+    assert 200 < sizes[-1][0] < 10000 and sizes[-1][1] > 2 * sizes[-1][0]
+    G.close()
+
+
 def test_per_scan_parity_along_a_drive_from_identical_state(built, oracle):
     """The bar is per scan ON IDENTICAL INPUT (BASELINE.json north_star).  Free-running, two implementations of this filter
     drift apart chaotically: the reference's covariance update cancels many digits, so a 1e-16 difference in the order of
@@ -407,7 +450,10 @@ def test_device_time_order_front_end_equals_host_front_end(built):
     itself (stable radix sort of the stamp keys: the sorted order is unique), so filters, stamps, time order, deskew, voxel grid and
     caps all run on the GPU and the clouds are put together after the update; the host front end (one-pass filters, the library's
     partial_sort_copy restated, upload) must give the SAME pose, covariance, map and clouds, bit for bit.  With equal stamps
-    (columns of a spinning sensor) the device declines and both runs take the host routine."""
+    (columns of a spinning sensor) the order among them is the library's heap moves': a caller that insists on it
+    (set_exact_tied_order) gets the host routine -- bit for bit again; by default (round 6) the sweep stays on the device in the
+    radix sort's stable order -- arrival order among equal stamps --, observable only as ulp-level voxel centroids: same status
+    codes, same cloud and map sizes, pose within 1e-4 m of the host routine's."""
     from fast_limo_amd import api
     from common import sort_rows
     n_scans, n_pts, speed = 6, 40000, 10.0
@@ -415,9 +461,10 @@ def test_device_time_order_front_end_equals_host_front_end(built):
     common = dict(MAX_NUM_PC2MATCH=3000, MAX_NUM_MATCHES=2000, voxel_active=1, leaf_size=0.5, crop_active=1, dist_active=1, min_dist=2.0,
                   rate_active=1, rate_value=3, time_offset=1, cropBoxMin=(-1.0, -1.0, -1.0), cropBoxMax=(1.0, 1.0, 1.0))
 
-    def drive(gpu_front_end, tied, shuffle):
+    def drive(gpu_front_end, tied, shuffle, exact=True):
         G = api.Localizer(api.default_cfg(**common))
         G.set_gpu_filters(gpu_front_end)
+        G.set_exact_tied_order(exact)
         G.set_flags(add_to_map=True, download_clouds=True)
         x0 = G.get_x(); x0[14] = speed; G.set_x(x0)
         i = 0
@@ -433,11 +480,24 @@ def test_device_time_order_front_end_equals_host_front_end(built):
             if shuffle:
                 scan = scan[rs.permutation(n_pts)]                   # arrival order is NOT time order: the sort has work to do
             rc = G.update_pointcloud(scan, 0.1 * k)
-            out.append(dict(rc=rc, x=G.get_x(), P=G.get_P(), n=G.map_size(), pc=G.pc2match(), fs=G.final_scan() if rc == 0 else None))
+            out.append(dict(rc=rc, x=G.get_x(), P=G.get_P(), n=G.map_size(), pc=G.pc2match(), fs=G.final_scan() if rc == 0 else None,
+                            dev_tied=G.last_sweep_tied()))
         G.sync()
         pts = sort_rows(G.hip.map_points())
         G.close()
         return out, pts
+
+    # equal stamps, the device's own order (the default): every sweep stays on the device; against the host routine (the library's order)
+    dev, m_dev = drive(True, True, False, exact=False)
+    host, m_host = drive(False, True, False)
+    worst = 0.0
+    for k in range(n_scans):
+        assert dev[k]["dev_tied"], k                                       # (the device front end took the tied sweep)
+        assert dev[k]["rc"] == host[k]["rc"], k
+        assert abs(dev[k]["pc"].shape[0] - host[k]["pc"].shape[0]) <= 4 and abs(dev[k]["n"] - host[k]["n"]) <= 8, (k, dev[k]["n"], host[k]["n"])
+        worst = max(worst, float(np.abs(dev[k]["x"][0:3] - host[k]["x"][0:3]).max()))
+    print("tied stamps, device order vs the library's order: worst position difference over %d free-running scans %.2e m" % (n_scans, worst))
+    assert worst <= 1e-4, worst
 
     for tied, shuffle in ((False, False), (False, True), (True, False)):
         dev, m_dev = drive(True, tied, shuffle)
