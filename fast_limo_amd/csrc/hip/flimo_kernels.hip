@@ -1954,32 +1954,40 @@ __device__ __forceinline__ void fit_reduce_publish(const float (&v)[16], bool ow
     bool launch_last = false;
     if (threadIdx.x == 0)
       launch_last = __hip_atomic_fetch_add(ticket + FIT_GROUPS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned int)FIT_GROUPS - 1u;
-    // two halves of the group's block list x 128 columns (91 live); agent-scope loads read past this XCD's L2
-    const int t = threadIdx.x & 127, part = threadIdx.x >> 7;
-    const int per = (nb_g + 1) >> 1;
-    const int k0 = part * per, k1 = min(nb_g, k0 + per);
-    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    if (t < FIT_LIVE) {
-      const double* base = partials + (size_t)group * FIT_LIVE_PAD + t;
+    // Five slices of the group's block list x 48 column PAIRS: 16-byte loads, a slice's thirteen (at 64 blocks per group) in flight
+    // at once -- one round trip, where round 5's 32 eight-byte loads per thread went out in two to three batches behind their
+    // address arithmetic (1.5 us of the launch's tail).  Agent-scope loads (sc1) read past this XCD's L2.  Fixed slices, fixed
+    // order inside a slice and of the slices: bit-reproducible.
+    const int c2 = (int)threadIdx.x % (FIT_LIVE_PAD / 2), sl = (int)threadIdx.x / (FIT_LIVE_PAD / 2);      // (threads 240 .. 255 have no slice)
+    const int per = (nb_g + 4) / 5;
+    const int k0 = sl * per, k1 = sl < 5 ? min(nb_g, k0 + per) : 0;
+    v2d_t a0 = {0.0, 0.0}, a1 = {0.0, 0.0};
+    {
+      const double* base = partials + (size_t)group * FIT_LIVE_PAD + 2 * c2;
       const size_t stride = (size_t)FIT_GROUPS * FIT_LIVE_PAD;
-      int k = k0;
-      for (; k + 31 < k1; k += 32) {
-        double w[32];
+      for (int k = k0; k < k1; k += 16) {
+        v2d_t w[16];
 #pragma unroll
-        for (int u = 0; u < 32; u++) w[u] = __hip_atomic_load(base + (size_t)(k + u) * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int u = 0; u < 16; u++) {
+          const double* q = base + (size_t)min(k + u, k1 - 1) * stride;      // (dead slots read the slice's last partial again)
+          asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(w[u]) : "v"(q));
+        }
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]), "+v"(w[8]), "+v"(w[9]),
+                       "+v"(w[10]), "+v"(w[11]), "+v"(w[12]), "+v"(w[13]), "+v"(w[14]), "+v"(w[15]));
 #pragma unroll
-        for (int u = 0; u < 32; u += 4) { s0 += w[u]; s1 += w[u + 1]; s2 += w[u + 2]; s3 += w[u + 3]; }
+        for (int u = 0; u < 16; u += 2) {
+          if (k + u < k1) a0 += w[u];
+          if (k + u + 1 < k1) a1 += w[u + 1];
+        }
       }
-      for (; k + 3 < k1; k += 4) {
-        double w[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) w[u] = __hip_atomic_load(base + (size_t)(k + u) * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s0 += w[0]; s1 += w[1]; s2 += w[2]; s3 += w[3];
-      }
-      for (; k < k1; k++) s0 += __hip_atomic_load(base + (size_t)k * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __syncthreads();                                               // sa0 / sa1 are free (every thread read its block sums above)
-    (part == 0 ? sa0 : sa1)[t] = (s0 + s1) + (s2 + s3);
+    __syncthreads();                                               // sa0 .. sa2 are free (every thread read its block sums above)
+    if (sl < 5) {
+      double* dstb = sl < 2 ? sa0 + sl * FIT_LIVE_PAD : (sl < 4 ? sa1 + (sl - 2) * FIT_LIVE_PAD : sa2);
+      dstb[2 * c2] = a0.x + a1.x;
+      dstb[2 * c2 + 1] = a0.y + a1.y;
+    }
     __syncthreads();
     TRACE(1, 6);
     if (threadIdx.x < FIT_LIVE) {
@@ -1987,7 +1995,7 @@ __device__ __forceinline__ void fit_reduce_publish(const float (&v)[16], bool ow
       // (s_nop 1 after every such store: the two wait states of the VMEM-store-data hazard on gfx940+, which the compiler cannot
       //  insert for inline assembly -- the next VALU write of g's registers could otherwise reach the store)
       v2d_t g;
-      g.x = sa0[threadIdx.x] + sa1[threadIdx.x];
+      g.x = ((sa0[threadIdx.x] + sa0[FIT_LIVE_PAD + threadIdx.x]) + (sa1[threadIdx.x] + sa1[FIT_LIVE_PAD + threadIdx.x])) + sa2[threadIdx.x];
       g.y = __longlong_as_double((long long)seq);
       double2* o = out_granules + (size_t)group * FIT_LIVE_PAD + threadIdx.x;
       asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(o), "v"(g) : "memory");
