@@ -20,6 +20,7 @@
 #include <thread>
 
 #include "../../../include/flimo_c.h"
+#include "../../../include/flimo_dev.h"      // flimo_calculate_H_host (Localizer::calculate_H of the mirror)
 #include "fast_limo/Modules/Localizer.hpp"
 #include "fast_limo/Modules/Mapper.hpp"
 #include "flimo_ikfom.hpp"

@@ -9,6 +9,7 @@
 #include "fast_limo/Common.hpp"
 #include "fast_limo/Utils/Config.hpp"
 #include "flimo_c.h"
+#include "flimo_dev.h"      // flimo_plane_fit5_host / flimo_plane_eval5_host: the fit kernel's plane routines compiled for the host
 
 class fast_limo::Plane {
  public:

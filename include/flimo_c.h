@@ -275,24 +275,6 @@ int flimo_map_add_scan(flimo_ctx* ctx, const double x26[26], double stamp);
  * which holds the filter's mutex (Localizer.cpp:326-353). */
 int flimo_set_wait_timeout_ms(flimo_ctx* ctx, int ms);
 
-/* ---- diagnostics without a GPU ----
- * Replays the map's insert rule (Octree::initialize / update, Objects/Octree.hpp:282-432) over a
- * sequence of batches of packed NaN-free points: keep[i] = 1 if point i is stored.  Host only. */
-/* Host-side evaluation of the plane routines of the fit kernel (same source, compiled for the host): Plane::estimate_plane
- * (Objects/Plane.cpp:80-105) for exactly 5 points (xyz packed) and Plane::plane_eval (:107-114).  They back the
- * fast_limo::Plane object of the host C++ mirror; the registration path never calls them. */
-void flimo_plane_fit5_host(const float xyz[15], float n_out[4]);
-int  flimo_plane_eval5_host(const float n[4], const float xyz[15], float threshold);
-
-/* Localizer::calculate_H (Localizer.cpp:537-577) for M given matches on the host, with the fit kernel's own row routine:
- * p_global [M][3], n [M][4] (plane.get_normal()), dist [M] (Match::dist); H [M][12] row-major, h [M] = -dist.  Backs the
- * Localizer::calculate_H method of the host C++ mirror; the registration path computes the same rows on the GPU. */
-int flimo_calculate_H_host(const double x26[26], const float* p_global, const float* n, const float* dist, size_t M,
-                           int estimate_extrinsics, double* H, double* h);
-
-int flimo_insert_rule_replay(float min_extent, int downsample, const float* xyz, const size_t* batch_sizes,
-                             size_t n_batches, unsigned char* keep, size_t* stored);
-
 #ifdef __cplusplus
 }
 #endif
