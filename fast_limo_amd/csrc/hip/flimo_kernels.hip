@@ -266,17 +266,35 @@ typedef unsigned long long u64;
 // thread 0 of every block stores the 100 MHz wall clock after draining its outstanding memory operations.
 #ifdef FLIMO_TRACE
 __device__ unsigned long long g_trace[2][16384 * 8];
+#if FLIMO_TRACE == 2
+// light form (round 6): the stamps are kept in shared memory and written out once, at the launch's end (TRACE_FLUSH) -- a stamp
+// stored to global memory makes the NEXT stamp's s_waitcnt wait for that store's acknowledgement (0.4 - 1 us per phase)
+__shared__ unsigned long long s_trace_lds[2][8];
+#define TRACE(k, slot)                                                                                  \
+  do {                                                                                                  \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                         \
+    if (threadIdx.x == 0) s_trace_lds[k][slot] = wall_clock64();                                        \
+  } while (0)
+#define TRACE_FLUSH()                                                                                   \
+  do {                                                                                                  \
+    if (threadIdx.x == 0 && blockIdx.x < 16384)                                                         \
+      for (int k_ = 0; k_ < 2; k_++) for (int s_ = 0; s_ < 8; s_++) g_trace[k_][blockIdx.x * 8 + s_] = s_trace_lds[k_][s_]; \
+  } while (0)
+#else
 #define TRACE(k, slot)                                                                                  \
   do {                                                                                                  \
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                         \
     if (threadIdx.x == 0 && blockIdx.x < 16384) g_trace[k][blockIdx.x * 8 + (slot)] = wall_clock64();  \
   } while (0)
+#define TRACE_FLUSH() do {} while (0)
+#endif
 extern "C" int flimo_trace_read(int k, unsigned long long* out, size_t n) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), n * sizeof(unsigned long long), (size_t)k * 16384 * 8 * sizeof(unsigned long long),
                                   hipMemcpyDeviceToHost);
 }
 #else
 #define TRACE(k, slot) do {} while (0)
+#define TRACE_FLUSH() do {} while (0)
 #endif
 
 FLIMO_DEV u64 make_key(float d, uint32_t idx) { return ((u64)__float_as_uint(d) << 32) | (u64)idx; }
@@ -643,7 +661,7 @@ __device__ __forceinline__ void knn5_tail(const GridView& G, const uint16_t* dir
     }
   }
   if (cand_total && cand) atomicAdd(cand_total, (unsigned long long)cand);
-#ifdef FLIMO_TRACE
+#if defined(FLIMO_TRACE) && FLIMO_TRACE != 2
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   if (lane == 0 && blockIdx.x < 16384)      // developer statistics of the tail: duration (10 ns units), stragglers of the wave, ring iterations
     g_trace[0][blockIdx.x * 8 + 7] = ((wall_clock64() - tr_t0) & 0xffffull) | ((unsigned long long)F << 16) | ((unsigned long long)tr_iters << 24) | (1ull << 40);
@@ -931,6 +949,10 @@ __device__ __forceinline__ void knn5_pass(const GridView& G, uint16_t* dir, cons
   const int p = slot >> fa.spread;
   const int sub = threadIdx.x % L;
   const bool in_range = p < n && (slot & ((1 << fa.spread) - 1)) == 0;          // no early exit: the tail below is a wave-wide phase
+#if defined(FLIMO_TRACE) && FLIMO_TRACE == 2
+  if (threadIdx.x < 16) s_trace_lds[threadIdx.x >> 3][threadIdx.x & 7] = 0ull;
+  __syncthreads();
+#endif
   TRACE(0, 0);
 
   float4 sp;
@@ -1167,7 +1189,7 @@ __device__ __forceinline__ void knn5_pass(const GridView& G, uint16_t* dir, cons
       for (int i = 0; i < 5; i++) best[i] = (u64)__double_as_longlong(k5[i]);
       sixth = (u64)__double_as_longlong(k5[5]);
       TRACE(0, 3);
-#ifdef FLIMO_TRACE
+#if defined(FLIMO_TRACE) && FLIMO_TRACE != 2
       if (blockIdx.x < 16384) {   // developer statistics: accumulated block candidates (all passes), CU id
         if (sub == 0) atomicAdd(&g_trace[0][blockIdx.x * 8 + 6], (unsigned long long)total);
         if (threadIdx.x == 0) g_trace[0][blockIdx.x * 8 + 7] = __smid();
@@ -1376,6 +1398,7 @@ __device__ __forceinline__ void knn5_pass(const GridView& G, uint16_t* dir, cons
     fit_reduce_publish<64 / L>(v, sub == 0, lane / L, W.tile, s_w[0].acc, s_w[1].acc, s_w[2].acc, s_w[3].acc, &s_last, fa.idx,
                                fa.partials, fa.granules, fa.ticket, wl_count, fa.seq, tl, (int)blockIdx.x, nb);
   }
+  TRACE_FLUSH();
 }
 
 template <int L, int SLOTS, bool FUSE, bool FINE = false>
