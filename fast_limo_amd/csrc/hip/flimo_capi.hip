@@ -1772,33 +1772,62 @@ static inline void run_overlap(flimo_ctx* c) {
   fn(c->overlap_arg);
 }
 
-extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flimo_match_cfg* cfg, double HTH[144],
-                                  double HTh[12], int* M) {
-  if (!c || !x26 || !cfg || !HTH || !HTh || !M) return FLIMO_ERR_INVALID;
-  if (cfg->NUM_MATCH_POINTS < 3 || cfg->NUM_MATCH_POINTS > 8)
-    return fail(c, FLIMO_ERR_UNSUPPORTED, "NUM_MATCH_POINTS must be in 3..8 (a plane needs 3 points; the neighbour records hold 8)");
-  const bool general_k = cfg->NUM_MATCH_POINTS != 5;
+// One measurement pass = Mapper::match + calculate_H + H^T H for the scan at pose x26, in three steps (round 6: the 380-line function
+// of rounds 2-5 cut where its phases part):
+//   pass_plan    -- what this call is: which points take part, the pose constants, which layout the pass runs in (one launch /
+//                   k-NN + widening + fit / records), whether the launch that waits on the GPU is this call's;
+//   pass_launch  -- publishes the pose to the waiting launch or queues the pass's launches, then queues the NEXT pass of the
+//                   same update behind them (pipelined host loop);
+//   pass_collect -- waits for the sums (granules in mapped host memory), settles exact distance ties, decodes H^T H, H^T h, M.
+// NUM_MATCH_POINTS other than 5 takes pass_general_k (records + record reduction, synchronous).
+struct PassPlan {
+  const flimo_match_cfg* cfg = nullptr;
+  PoseMats P;
+  MatchParams mp;
+  size_t nq = 0;                   // points that take part (the first MAX_NUM_PC2MATCH of pc2match)
+  int n_all = 0;                   // resident query set (== nq, or the whole scan when no cap binds)
+  bool general_k = false;
+  bool use_pre = false, was_pre = false;      // the pass queued ahead of this call is this call's / was published to
+  uint64_t grid_version = 0;
+  const DeskewArgs* dkp = nullptr;            // a pending deskew rides on this pass's k-NN launch
+  bool cap_binds = false, want_recs = false, want_count = false, fused_cap = false, use_fit2 = false;
+  int tlev = 0;                    // timing level of THIS pass
+  int tail_max = 0;
+  bool tail = false, fused = false, after_fine = false, widen_timed = false;
+  unsigned long long seq = 0;
+  bool ties_on = false, inline_ties = false;
+  TieList tl{};
+  BookView book{};
+  const BookView* bookp = nullptr;
+  double tp0 = 0, tpa = 0, tpb = 0, tpc = 0, tp1 = 0;      // developer timing of the host side (FLIMO_PROF_PASS)
+};
+static const bool g_prof_pass = getenv("FLIMO_PROF_PASS") != nullptr;        // developer timing of the host side of a pass
+static inline double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// rc > 0: nothing to do (no map, no points): the zeroed outputs stand and the call returns FLIMO_OK
+constexpr int PASS_NOTHING = 2000;
+static int pass_plan(flimo_ctx* c, const double x26[26], const flimo_match_cfg* cfg, PassPlan& pl) {
+  pl.cfg = cfg;
+  pl.general_k = cfg->NUM_MATCH_POINTS != 5;
   // (a pass queued ahead of this call -- pipelined host loop -- is either this call's, decided below before anything is queued, or
   //  told to leave: every early way out of this function cancels it)
   struct PreGuard { flimo_ctx* c; bool decided = false; ~PreGuard() { if (!decided) cancel_prelaunch(c); } } pre_guard{c};
   { const int rca = check_abandoned(c); if (rca) return rca; }
-  for (int i = 0; i < 144; i++) HTH[i] = 0.0;
-  for (int i = 0; i < 12; i++) HTh[i] = 0.0;
-  *M = 0;
   c->last_nq = 0;
   c->last_cfg = *cfg;
   c->recs_valid = c->dbg_valid = false;
   if (!c->grid_valid && c->map_n > 0) { int rc0 = rebuild_grid(c); if (rc0) return rc0; }   // never a stored map without its index
-  if (!c->grid_valid || c->map_n == 0) return FLIMO_OK;      // Mapper::match: `if(not this->exists()) return matches;`
+  if (!c->grid_valid || c->map_n == 0) return PASS_NOTHING;      // Mapper::match: `if(not this->exists()) return matches;`
   size_t nq = c->scan_n;
   if (cfg->MAX_NUM_PC2MATCH >= 0 && nq > (size_t)cfg->MAX_NUM_PC2MATCH) nq = (size_t)cfg->MAX_NUM_PC2MATCH;
-  if (nq == 0) return FLIMO_OK;
+  if (nq == 0) return PASS_NOTHING;
+  pl.nq = nq;
   (void)hipSetDevice(c->device);            // (not ctx_enter: a waiting pass may be THIS call's)
   // Is the pass that waits on the GPU this call's?  Same scan, same settings, same map index, the next pass number, nothing else
   // to queue first (no re-sort, no pending deskew), and not so old that its workgroups may have given up (CH_POLL_MS).
-  const uint64_t grid_version = c->grid_builds * 0x100000000ull + c->grid_merges;
-  bool use_pre = c->pre.active && !general_k && c->prev.valid && c->pre.nq == nq && c->pre.seq == c->pass_seq + 1 &&
-                 same_match_cfg(c->pre.cfg, *cfg) && c->pre.grid_version == grid_version && !c->deskew_pending &&
+  pl.grid_version = c->grid_builds * 0x100000000ull + c->grid_merges;
+  bool use_pre = c->pre.active && !pl.general_k && c->prev.valid && c->pre.nq == nq && c->pre.seq == c->pass_seq + 1 &&
+                 same_match_cfg(c->pre.cfg, *cfg) && c->pre.grid_version == pl.grid_version && !c->deskew_pending &&
                  !(nq < c->sorted_n || (c->sorted_n < c->scan_n && nq > c->sorted_n)) && c->pre.n_all == (int)c->sorted_n &&
                  !c->debug_recs && !(cfg->MAX_NUM_MATCHES >= 0 && (size_t)cfg->MAX_NUM_MATCHES < nq);
   if (use_pre && !(wall_s() - c->pre.t_launch < 0.25e-3 * (double)CH_POLL_MS)) { use_pre = false; c->pipe_aged++; }      // (this call's, but too old)
@@ -1807,12 +1836,9 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   int rc = ensure_recs(c, nq);
   if (rc) { cancel_prelaunch(c); return rc; }
 
-  static const bool prof = getenv("FLIMO_PROF_PASS") != nullptr;        // developer timing of the host side of a pass
-  auto now_us = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  const double tp0 = prof ? now_us() : 0.0;
-  PoseMats P;
-  pose_from_x26(x26, P);
-  MatchParams mp;
+  pl.tp0 = g_prof_pass ? now_us() : 0.0;
+  pose_from_x26(x26, pl.P);
+  MatchParams& mp = pl.mp;
   mp.max_dist_plane_d = cfg->MAX_DIST_PLANE;          // the gate compares the float sq. distance with the DOUBLE threshold (Plane.cpp:47)
   mp.plane_threshold = (float)cfg->PLANE_THRESHOLD;
   mp.estimate_extrinsics = cfg->estimate_extrinsics ? 1 : 0;
@@ -1828,55 +1854,21 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
     c->sorted_n = want;
     c->prev.valid = 0;
   }
-  const int n_all = (int)c->sorted_n;                 // resident query set (== nq, or the whole scan when no cap binds)
+  pl.n_all = (int)c->sorted_n;
   // A pending deskew rides on this pass's k-NN launch when that launch covers the whole scan and is the first to read it
-  const bool ride = c->deskew_pending && !general_k && c->deskew_n == (size_t)n_all &&
+  const bool ride = c->deskew_pending && !pl.general_k && c->deskew_n == (size_t)pl.n_all &&
                     !(c->fine_valid && mp.max_ring >= 1);     // (a fine pre-pass reads the scan first)
   if (!ride) { const int rcf = flush_deskew(c); if (rcf) return rcf; }
-  const DeskewArgs* dkp = ride ? &c->deskew_args : nullptr;
+  pl.dkp = ride ? &c->deskew_args : nullptr;
   c->deskew_pending = false;
-  const bool cap_binds = cfg->MAX_NUM_MATCHES >= 0 && (size_t)cfg->MAX_NUM_MATCHES < nq;
-  if (general_k) {
-    // any NUM_MATCH_POINTS: exact k-NN by the ring search, M x 3 plane fit, records, record reduction (slow, general pass)
-    if ((size_t)n_all > c->nbrk_cap) {
-      (void)hipFree(c->d_nbrk);
-      c->d_nbrk = nullptr; c->nbrk_cap = 0;
-      const size_t cap = (size_t)n_all + (size_t)n_all / 4 + 1024;
-      HIPCHK(c, hipMalloc(&c->d_nbrk, cap * nbrk_rec_size()));
-      c->nbrk_cap = cap;
-    }
-    c->prev.valid = 0;                                 // the 5-NN records of this scan (pruning bound) are not maintained here
-    const BookView bookk{c->gbook.node_c, c->gbook.node_child, c->gbook.node_cnt, c->gbook.root, nullptr};
-    if (!launch_match_k(c->stream, cfg->NUM_MATCH_POINTS, c->grid, c->d_scan_sorted, n_all, P, mp, c->d_nbrk, c->d_recs, c->d_dbg,
-                        (c->ties && c->gbook.active) ? &bookk : nullptr))
-      return fail(c, FLIMO_ERR_UNSUPPORTED, "NUM_MATCH_POINTS out of range");
-    if (cap_binds) launch_cap(c->stream, c->d_recs, (int)nq, cfg->MAX_NUM_MATCHES);
-    launch_reduce(c->stream, c->d_recs, (int)nq, c->reduce_waves, c->d_partials, c->d_out256_host);
-    // the general pass settles ties for every query (tiek_kernel) and does not use the two alternating tie counters of the
-    // 5-NN passes; it keeps them armed for whichever 5-NN pass comes next
-    HIPCHK(c, hipMemsetAsync(c->d_tie_count, 0, 2 * sizeof(unsigned int), c->stream));
-    HIPCHK(c, hipGetLastError());
-    run_overlap(c);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    ++c->pass_seq;
-    for (int i = 0; i < 12; i++) {
-      for (int j = 0; j < 12; j++) HTH[i * 12 + j] = c->h_out256[c->mfma_idx[i][j]];
-      HTh[i] = c->h_out256[c->mfma_idx[i][12]];
-    }
-    *M = (int)llround(c->h_out256[c->mfma_idx[13][13]]);
-    c->last_nq = (int)nq;
-    c->last_P = P; c->last_mp = mp; c->last_n_all = n_all;
-    c->recs_valid = true; c->dbg_valid = true;
-    c->last_stragglers = -1;
-    c->async_deskews = 0;
-    return FLIMO_OK;
-  }
-  const bool want_recs = c->debug_recs || cap_binds;
+  pl.cap_binds = cfg->MAX_NUM_MATCHES >= 0 && (size_t)cfg->MAX_NUM_MATCHES < nq;
+  if (pl.general_k) return FLIMO_OK;
+  pl.want_recs = c->debug_recs || pl.cap_binds;
   if (c->debug_recs) HIPCHK(c, hipMemsetAsync(c->d_cand, 0, sizeof(unsigned long long), c->stream));
-  const bool want_count = c->debug_recs;
-  const double tpa = prof ? now_us() : 0.0;
+  pl.want_count = c->debug_recs;
+  pl.tpa = g_prof_pass ? now_us() : 0.0;
   // effective level of THIS pass (level 1 may sample every timing_stride-th pass)
-  const int tlev = (c->timing == 1 && c->timing_stride > 1 && ((c->pass_seq + 1) % (unsigned long long)c->timing_stride) != 0) ? 0 : c->timing;
+  pl.tlev = (c->timing == 1 && c->timing_stride > 1 && ((c->pass_seq + 1) % (unsigned long long)c->timing_stride) != 0) ? 0 : c->timing;
   // level 1: the two events ride on the k-NN dispatch itself (kernel begin / end, no extra packets)
   // the k-NN launch finishes its own stragglers (in-kernel tail) for gates of up to 3 rings; the worklist + widening dispatch
   // remains for wider gates and for the developer switch FLIMO_TAIL=0
@@ -1890,28 +1882,28 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   // sweeps over a 900 m map) keeps thousands of points beyond their 3x3x3 block in every pass
   // The bound grows with the scan: what hurts is a wave whose queries are ALL pending (one long chain), and a launch of n
   // queries spreads 1/64 of them over its waves a handful at a time
-  const int tail_max = std::max(1024, n_all / 64);
-  const bool tail_here = first_pass ? (c->stragglers_hist[0] <= tail_max)
-                                    : (c->stragglers_hist[c->pass_in_scan] <= tail_max);
-  const bool tail = c->tail && tail_here && mp.max_ring >= 2 && mp.max_ring <= 3;
+  pl.tail_max = std::max(1024, pl.n_all / 64);
+  const bool tail_here = first_pass ? (c->stragglers_hist[0] <= pl.tail_max)
+                                    : (c->stragglers_hist[c->pass_in_scan] <= pl.tail_max);
+  pl.tail = c->tail && tail_here && mp.max_ring >= 2 && mp.max_ring <= 3;
   c->prev.probe_min = c->probe_min;
   // One launch for the whole pass (k-NN + tail + fit + reduction) whenever the tail applies, no records are wanted and the
   // k-NN runs with its default two lanes per query
-  const bool fused = tail && c->fuse && !want_recs;
-  const unsigned long long seq = ++c->pass_seq;
+  pl.fused = pl.tail && c->fuse && !pl.want_recs;
+  pl.seq = ++c->pass_seq;
   // exact distance ties: the reference's choice needs the octree's visiting order, i.e. the device insert book
-  const bool ties_on = c->ties && c->gbook.active;
-  TieList tl{};
-  tl.count_next = c->d_tie_count + ((seq + 1) & 1);            // re-armed by this pass's reduction for the next pass
+  pl.ties_on = c->ties && c->gbook.active;
+  pl.tl = TieList{};
+  pl.tl.count_next = c->d_tie_count + ((pl.seq + 1) & 1);            // re-armed by this pass's reduction for the next pass
   // The per-pass fast paths (one launch / k-NN + widening + fit2) settle ties where they build the rows (tie_repair_wave): no list,
   // the count they publish stays 0.  The records / caps / debug path lists them for tie_kernel as before.
-  const bool inline_ties = ties_on && !want_recs;
-  if (ties_on && !inline_ties) { tl.list = c->d_tie_list; tl.count = c->d_tie_count + (seq & 1); tl.cap = (unsigned)c->tie_cap; }
-  const BookView book{c->gbook.node_c, c->gbook.node_child, c->gbook.node_cnt, c->gbook.root, c->d_tie_settled};
-  const BookView* bookp = inline_ties ? &book : nullptr;
+  pl.inline_ties = pl.ties_on && !pl.want_recs;
+  if (pl.ties_on && !pl.inline_ties) { pl.tl.list = c->d_tie_list; pl.tl.count = c->d_tie_count + (pl.seq & 1); pl.tl.cap = (unsigned)c->tie_cap; }
+  pl.book = BookView{c->gbook.node_c, c->gbook.node_child, c->gbook.node_cnt, c->gbook.root, c->d_tie_settled};
+  pl.bookp = pl.inline_ties ? &pl.book : nullptr;
   // crowded regions first: the fine pre-pass settles the queries whose five lie within centimetres (second-level grid)
-  const bool after_fine = c->fine_valid && mp.max_ring >= 1;
-  if (use_pre && !(fused && !after_fine && tlev == 0)) {
+  pl.after_fine = c->fine_valid && mp.max_ring >= 1;
+  if (use_pre && !(pl.fused && !pl.after_fine && pl.tlev == 0)) {
     // (what was queued ahead is a one-launch pass without a fine pre-pass and without timing events: anything else -- a straggler
     //  count that changed the layout, a sampled pass -- is launched the usual way)
     cancel_prelaunch(c);
@@ -1924,78 +1916,128 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
     if (wall_s() - c->pre.t_launch >= 0.25e-3 * (double)CH_POLL_MS) { cancel_prelaunch(c); use_pre = false; c->pipe_aged++; }
     else if (test_delay_ms > 0) std::this_thread::sleep_for(std::chrono::milliseconds(test_delay_ms));      // (tests: the window the decision word closes)
   }
-  const bool was_pre = use_pre;
-  if (use_pre) {
+  pl.use_pre = pl.was_pre = use_pre;
+  pl.widen_timed = !pl.tail && pl.tlev == 1 && mp.max_ring >= 2;
+  // MAX_NUM_MATCHES path: the fit kernel only writes the records (no reduction), one fused kernel ranks them in scan
+  // order, reduces the first MAX_NUM_MATCHES and publishes to slot 0
+  pl.fused_cap = pl.cap_binds && !c->debug_recs;
+  pl.use_fit2 = !pl.want_recs;                             // the per-pass fast path (granule results)
+  return FLIMO_OK;
+}
+
+// any NUM_MATCH_POINTS: exact k-NN by the ring search, M x 3 plane fit, records, record reduction (slow, general pass)
+static int pass_general_k(flimo_ctx* c, const PassPlan& pl, double HTH[144], double HTh[12], int* M) {
+  const flimo_match_cfg* cfg = pl.cfg;
+  const int n_all = pl.n_all;
+  const size_t nq = pl.nq;
+  if ((size_t)n_all > c->nbrk_cap) {
+    (void)hipFree(c->d_nbrk);
+    c->d_nbrk = nullptr; c->nbrk_cap = 0;
+    const size_t cap = (size_t)n_all + (size_t)n_all / 4 + 1024;
+    HIPCHK(c, hipMalloc(&c->d_nbrk, cap * nbrk_rec_size()));
+    c->nbrk_cap = cap;
+  }
+  c->prev.valid = 0;                                 // the 5-NN records of this scan (pruning bound) are not maintained here
+  const BookView bookk{c->gbook.node_c, c->gbook.node_child, c->gbook.node_cnt, c->gbook.root, nullptr};
+  if (!launch_match_k(c->stream, cfg->NUM_MATCH_POINTS, c->grid, c->d_scan_sorted, n_all, pl.P, pl.mp, c->d_nbrk, c->d_recs, c->d_dbg,
+                      (c->ties && c->gbook.active) ? &bookk : nullptr))
+    return fail(c, FLIMO_ERR_UNSUPPORTED, "NUM_MATCH_POINTS out of range");
+  if (pl.cap_binds) launch_cap(c->stream, c->d_recs, (int)nq, cfg->MAX_NUM_MATCHES);
+  launch_reduce(c->stream, c->d_recs, (int)nq, c->reduce_waves, c->d_partials, c->d_out256_host);
+  // the general pass settles ties for every query (tiek_kernel) and does not use the two alternating tie counters of the
+  // 5-NN passes; it keeps them armed for whichever 5-NN pass comes next
+  HIPCHK(c, hipMemsetAsync(c->d_tie_count, 0, 2 * sizeof(unsigned int), c->stream));
+  HIPCHK(c, hipGetLastError());
+  run_overlap(c);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  ++c->pass_seq;
+  for (int i = 0; i < 12; i++) {
+    for (int j = 0; j < 12; j++) HTH[i * 12 + j] = c->h_out256[c->mfma_idx[i][j]];
+    HTh[i] = c->h_out256[c->mfma_idx[i][12]];
+  }
+  *M = (int)llround(c->h_out256[c->mfma_idx[13][13]]);
+  c->last_nq = (int)nq;
+  c->last_P = pl.P; c->last_mp = pl.mp; c->last_n_all = n_all;
+  c->recs_valid = true; c->dbg_valid = true;
+  c->last_stragglers = -1;
+  c->async_deskews = 0;
+  return FLIMO_OK;
+}
+
+static int pass_launch(flimo_ctx* c, PassPlan& pl) {
+  const flimo_match_cfg* cfg = pl.cfg;
+  const PoseMats& P = pl.P;
+  const MatchParams& mp = pl.mp;
+  const int n_all = pl.n_all;
+  const size_t nq = pl.nq;
+  const unsigned long long seq = pl.seq;
+  const int tlev = pl.tlev;
+  if (pl.use_pre) {
     publish_prelaunch(c, P, c->prev.RT, seq);
     c->fused_passes++;
-  } else if (after_fine) {
-    launch_knn5_fine(c->stream, c->fine, c->d_scan_sorted, n_all, P, c->d_nbr, c->prev, c->fine_qlo, c->fine_qhi, &tl, seq);
+  } else if (pl.after_fine) {
+    launch_knn5_fine(c->stream, c->fine, c->d_scan_sorted, n_all, P, c->d_nbr, c->prev, c->fine_qlo, c->fine_qhi, &pl.tl, seq);
     c->fine_passes++;
   }
-  if (use_pre) {
+  if (pl.use_pre) {
     // its launch is on the GPU already
-  } else if (fused) {
+  } else if (pl.fused) {
     launch_match_fused(c->stream, c->grid, c->d_scan_sorted, n_all, P, mp, c->d_nbr, c->d_wl, c->d_wl_count, nullptr, c->prev,
                        c->live_idx, c->d_fit2_partials, c->d_granules_host, c->d_ticket, seq, tlev == 1 ? c->ev[0] : nullptr,
-                       tlev == 1 ? c->ev[1] : nullptr, &tl, after_fine ? 1 : 0, dkp, nullptr, nullptr, bookp);
+                       tlev == 1 ? c->ev[1] : nullptr, &pl.tl, pl.after_fine ? 1 : 0, pl.dkp, nullptr, nullptr, pl.bookp);
     c->fused_passes++;
   } else
   launch_knn5(c->stream, 2, c->grid, c->d_scan_sorted, n_all, P, mp.max_ring, c->d_nbr, c->d_wl,
-              c->d_wl_count, c->debug_recs ? c->d_cand : nullptr, c->prev, tail ? 1 : 0, tlev == 1 ? c->ev[0] : nullptr,
-              tlev == 1 ? c->ev[1] : nullptr, nullptr, &tl, after_fine ? 1 : 0, seq, dkp);
+              c->d_wl_count, c->debug_recs ? c->d_cand : nullptr, c->prev, pl.tail ? 1 : 0, tlev == 1 ? c->ev[0] : nullptr,
+              tlev == 1 ? c->ev[1] : nullptr, nullptr, &pl.tl, pl.after_fine ? 1 : 0, seq, pl.dkp);
   c->prev_before = c->prev;
   if (c->prune) { memcpy(c->prev.RT, P.RT, sizeof(c->prev.RT)); c->prev.valid = 1; }   // the records now belong to this pose
-  const double tpb = prof ? now_us() : 0.0;
+  pl.tpb = g_prof_pass ? now_us() : 0.0;
   // A separate-dispatch pass is three launches: k-NN, widening of the worklist (one wave per pending query, dealt out over the whole
   // chip), fit + reduction.  (Rounds 3's widen_fit_kernel ran the last two as one launch, its fit workgroups polling records its
   // widening workgroups were still writing: 3 us per step bought with a forward-progress assumption and relaxed cross-XCD reads --
   // retired in round 4 by design.)
-  const bool widen_timed = !tail && tlev == 1 && mp.max_ring >= 2;
-  if (!tail)
+  if (!pl.tail)
     launch_widen(c->stream, c->grid, c->d_scan_sorted, P, mp.max_ring, c->d_nbr, c->d_wl, c->d_wl_count,
-                 c->debug_recs ? c->d_cand : nullptr, widen_timed ? c->ev[4] : nullptr, widen_timed ? c->ev[5] : nullptr, &tl);
-  const double tpc = prof ? now_us() : 0.0;
-  if (want_count) HIPCHK(c, hipMemcpyAsync(c->h_wl_count, c->d_wl_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                 c->debug_recs ? c->d_cand : nullptr, pl.widen_timed ? c->ev[4] : nullptr, pl.widen_timed ? c->ev[5] : nullptr, &pl.tl);
+  pl.tpc = g_prof_pass ? now_us() : 0.0;
+  if (pl.want_count) HIPCHK(c, hipMemcpyAsync(c->h_wl_count, c->d_wl_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   // fit + reductions; the last block writes the 16x16 accumulator to mapped host memory, publishes the
   // pass number and re-arms the ticket and the worklist counter
-  // MAX_NUM_MATCHES path: the fit kernel only writes the records (no reduction), one fused kernel ranks them in scan
-  // order, reduces the first MAX_NUM_MATCHES and publishes to slot 0
-  const bool fused_cap = cap_binds && !c->debug_recs;
-  const bool use_fit2 = !want_recs;                             // the per-pass fast path (granule results)
-  if (fused) {
+  if (pl.fused) {
     // the fit and the reduction ran inside the k-NN launch
-  } else if (use_fit2)
+  } else if (pl.use_fit2)
     launch_fit2(c->stream, c->grid, c->d_scan_sorted, n_all, c->d_nbr, P, mp, c->live_idx, c->d_fit2_partials, c->d_granules_host,
-                c->d_ticket, c->d_wl_count, seq, tlev == 1 ? c->ev[2] : nullptr, tlev == 1 ? c->ev[3] : nullptr, &tl, nullptr, nullptr, bookp);
+                c->d_ticket, c->d_wl_count, seq, tlev == 1 ? c->ev[2] : nullptr, tlev == 1 ? c->ev[3] : nullptr, &pl.tl, nullptr, nullptr, pl.bookp);
   else {
     // records / caps / debug / timing level 2 (synchronous): settle the ties before the rows are built, re-arm both counters after
     HIPCHK(c, hipGetLastError());
-    if (ties_on) { launch_tie(c->stream, c->grid, book, c->d_scan_sorted, P, c->d_nbr, tl); HIPCHK(c, hipGetLastError()); }
-  launch_fit(c->stream, c->grid, c->d_scan_sorted, n_all, c->d_nbr, P, mp, fused_cap ? nullptr : c->d_fit_partials,
-             want_recs ? c->d_recs : nullptr, c->debug_recs ? c->d_dbg : nullptr, cap_binds ? c->d_out256 : c->d_out256_host,
-             c->d_ticket, c->d_wl_count, seq);
+    if (pl.ties_on) { launch_tie(c->stream, c->grid, pl.book, c->d_scan_sorted, P, c->d_nbr, pl.tl); HIPCHK(c, hipGetLastError()); }
+    launch_fit(c->stream, c->grid, c->d_scan_sorted, n_all, c->d_nbr, P, mp, pl.fused_cap ? nullptr : c->d_fit_partials,
+               pl.want_recs ? c->d_recs : nullptr, c->debug_recs ? c->d_dbg : nullptr, pl.cap_binds ? c->d_out256 : c->d_out256_host,
+               c->d_ticket, c->d_wl_count, seq);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemsetAsync(c->d_tie_count, 0, 2 * sizeof(unsigned int), c->stream));
   }
-  if (fused_cap) {
+  if (pl.fused_cap) {
     launch_capreduce(c->stream, c->d_recs, (int)nq, cfg->MAX_NUM_MATCHES, c->d_out256_host, c->d_wl_count, seq);
-  } else if (cap_binds) {
+  } else if (pl.cap_binds) {
     launch_cap(c->stream, c->d_recs, (int)nq, cfg->MAX_NUM_MATCHES);
     launch_reduce(c->stream, c->d_recs, (int)nq, c->reduce_waves, c->d_partials, c->d_out256_host);
   }
   HIPCHK(c, hipGetLastError());
-  const double tp1 = prof ? now_us() : 0.0;
+  pl.tp1 = g_prof_pass ? now_us() : 0.0;
   if (c->debug_recs) HIPCHK(c, hipMemcpyAsync(c->h_cand, c->d_cand, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
   // ---- pipelined host loop: the NEXT pass of this update is queued now, behind this one.  Its workgroups are placed when this pass
   //      ends and wait for their constants in device memory; the next call publishes them instead of launching (use_pre above).
   //      Only the usual case is queued ahead: a one-launch pass (by the straggler count its position published in the last scan),
   //      no fine pre-pass, no timing events, no records. ----
-  if (c->pipeline && c->d_pipe_head && c->prune && use_fit2 && !want_count && c->tail && c->fuse &&
-      mp.max_ring >= 2 && mp.max_ring <= 3 && !c->fine_valid && inline_ties == ties_on) {
+  if (c->pipeline && c->d_pipe_head && c->prune && pl.use_fit2 && !pl.want_count && c->tail && c->fuse &&
+      mp.max_ring >= 2 && mp.max_ring <= 3 && !c->fine_valid && pl.inline_ties == pl.ties_on) {
     const unsigned long long nseq = seq + 1;
     const int ntlev = (c->timing == 1 && c->timing_stride > 1 && (nseq % (unsigned long long)c->timing_stride) != 0) ? 0 : c->timing;
     const int npos = std::min(c->pass_in_scan + 1, 3);
-    if (ntlev == 0 && c->stragglers_hist[npos] <= tail_max) {
+    if (ntlev == 0 && c->stragglers_hist[npos] <= pl.tail_max) {
       TieList tln{};
       tln.count_next = c->d_tie_count + ((nseq + 1) & 1);
       ChainCtl pc{};
@@ -2004,14 +2046,24 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
       pv.valid = 1;                                            // (its reference pose comes from the head)
       launch_match_fused(c->stream, c->grid, c->d_scan_sorted, n_all, P, mp, c->d_nbr, c->d_wl, c->d_wl_count, nullptr, pv,
                          c->live_idx, c->d_fit2_partials, c->d_granules_host, c->d_ticket, nseq, nullptr, nullptr, &tln, 0, nullptr,
-                         c->d_pipe_head, &pc, bookp, ch_epoch_of(nseq));
+                         c->d_pipe_head, &pc, pl.bookp, ch_epoch_of(nseq));
       HIPCHK(c, hipGetLastError());
       c->pre.active = true; c->pre.seq = nseq; c->pre.nq = nq; c->pre.n_all = n_all; c->pre.pos = npos; c->pre.cfg = *cfg;
-      c->pre.grid_version = grid_version; c->pre.end_code = pc.end_code; c->pre.t_launch = wall_s();
+      c->pre.grid_version = pl.grid_version; c->pre.end_code = pc.end_code; c->pre.t_launch = wall_s();
     }
   }
+  return FLIMO_OK;
+}
+
+static int pass_collect(flimo_ctx* c, PassPlan& pl, double HTH[144], double HTh[12], int* M) {
+  const PoseMats& P = pl.P;
+  const MatchParams& mp = pl.mp;
+  const int n_all = pl.n_all;
+  const size_t nq = pl.nq;
+  const unsigned long long seq = pl.seq;
+  const int tlev = pl.tlev;
   double acc[256];
-  if (use_fit2) {
+  if (pl.use_fit2) {
     // low-latency completion: every sum arrives as a 16-byte granule {value, pass number}; a group's slot is complete when
     // all of its tags carry this pass (the last granule stored is polled, then all are checked)
     auto wait_granules = [&](unsigned long long want, int left_ms = -1) -> int {
@@ -2023,15 +2075,15 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
     };
     run_overlap(c);                                    // the caller's own work, beside the launch
     {
-      int rcw = wait_granules(seq, was_pre ? CH_POLL_MS + 25 : -1);
+      int rcw = wait_granules(seq, pl.was_pre ? CH_POLL_MS + 25 : -1);
       if (rcw == FLIMO_PASS_LEFT) {
         // the launch that waited for this pass left before the pose reached it, as a whole: nothing ran.  The pass queued behind it for
         // the NEXT iteration is told to leave too, and this pass is launched the usual way (same number, same buffers).
         cancel_prelaunch(c);
         c->pipe_left++;
         launch_match_fused(c->stream, c->grid, c->d_scan_sorted, n_all, P, mp, c->d_nbr, c->d_wl, c->d_wl_count, nullptr, c->prev_before,
-                           c->live_idx, c->d_fit2_partials, c->d_granules_host, c->d_ticket, seq, nullptr, nullptr, &tl, 0, nullptr, nullptr,
-                           nullptr, bookp);
+                           c->live_idx, c->d_fit2_partials, c->d_granules_host, c->d_ticket, seq, nullptr, nullptr, &pl.tl, 0, nullptr, nullptr,
+                           nullptr, pl.bookp);
         HIPCHK(c, hipGetLastError());
         rcw = wait_granules(seq);
       }
@@ -2040,11 +2092,11 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
     c->last_stragglers = (int)llround(c->h_granules[2 * FIT_LIVE]);
     c->stragglers_hist[c->pass_in_scan] = c->last_stragglers;
     const long n_ties = (long)llround(c->h_granules[2 * (FIT_LIVE + 1)]);
-    if (n_ties > 0 && ties_on) {
+    if (n_ties > 0 && pl.ties_on) {
       // A few queries' five hinge on an exact float32 distance tie: settle them the reference's way (tie_kernel), then build the
       // rows and the sums again (one more fit dispatch).  Roughly once per 65k-point scan on measured data.
       c->tie_redos++; c->tie_queries += (unsigned long long)n_ties;
-      launch_tie(c->stream, c->grid, book, c->d_scan_sorted, P, c->d_nbr, tl);
+      launch_tie(c->stream, c->grid, pl.book, c->d_scan_sorted, P, c->d_nbr, pl.tl);
       const unsigned long long seq2 = ++c->pass_seq;
       TieList tl2{};
       tl2.count_next = c->d_tie_count + ((seq2 + 1) & 1);      // == this pass's counter: consumed by tie_kernel just above
@@ -2072,7 +2124,7 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
     // low-latency completion: spin on the pass number every reduction group publishes to host memory (one slot on
     // the MAX_NUM_MATCHES path)
     unsigned long long spins = 0;
-    for (int g = 0; g < (cap_binds ? 1 : FIT_GROUPS); g++) {
+    for (int g = 0; g < (pl.cap_binds ? 1 : FIT_GROUPS); g++) {
       volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(c->h_out256 + (size_t)g * FIT_SLOT + 256);
       while (*flag != seq) {
         _mm_pause();
@@ -2095,12 +2147,12 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
       (void)hipEventElapsedTime(&c->last_knn_ms, c->ev[0], c->ev[1]);
     }
     c->tot_knn_ms += c->last_knn_ms;
-    if (fused) {
+    if (pl.fused) {
       c->last_fit_ms = 0.f; c->last_widen_ms = 0.f;            // one dispatch: everything is in the k-NN figure
       c->split_fused_ms += c->last_knn_ms; c->split_fused_n++;
-    } else if (use_fit2) {
+    } else if (pl.use_fit2) {
       c->last_widen_ms = 0.f;
-      if (widen_timed) {
+      if (pl.widen_timed) {
         if (hipEventElapsedTime(&c->last_widen_ms, c->ev[4], c->ev[5]) != hipSuccess) c->last_widen_ms = 0.f;
         c->tot_widen_ms += c->last_widen_ms;
       }
@@ -2115,11 +2167,11 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
     }
     c->tot_passes++; c->tot_queries += n_all;
   }
-  if (prof) {
+  if (g_prof_pass) {
     static double acc_launch = 0, acc_wait = 0, a0 = 0, a1 = 0, a2 = 0, a3 = 0; static long cnt = 0;
     const double tp2 = now_us();
-    acc_launch += tp1 - tp0; acc_wait += tp2 - tp1;
-    a0 += tpa - tp0; a1 += tpb - tpa; a2 += tpc - tpb; a3 += tp1 - tpc;
+    acc_launch += pl.tp1 - pl.tp0; acc_wait += tp2 - pl.tp1;
+    a0 += pl.tpa - pl.tp0; a1 += pl.tpb - pl.tpa; a2 += pl.tpc - pl.tpb; a3 += pl.tp1 - pl.tpc;
     if (++cnt % 200 == 0) {
       fprintf(stderr, "[flimo pass] host: pose+launches %.2f us (prep %.2f, knn launch %.2f, widen launch %.2f, fit launch %.2f), wait for result %.2f us (mean of 200)\n",
               acc_launch / 200, a0 / 200, a1 / 200, a2 / 200, a3 / 200, acc_wait / 200);
@@ -2127,12 +2179,12 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
     }
   }
   c->async_deskews = 0;            // the pass completed: the stream is idle
-  if (want_count) c->last_widen_count = *c->h_wl_count;
+  if (pl.want_count) c->last_widen_count = *c->h_wl_count;
   if (c->debug_recs) c->last_cand_per_query = (double)(*c->h_cand) / (double)nq;
   // final sum over the reduction groups in slot order (the records path delivers one slot)
-  if (!use_fit2) {
+  if (!pl.use_fit2) {
     c->last_stragglers = -1;
-    const int slots = cap_binds ? 1 : FIT_GROUPS;
+    const int slots = pl.cap_binds ? 1 : FIT_GROUPS;
     for (int t = 0; t < 256; t++) {
       double r = c->h_out256[t];
       for (int g = 1; g < slots; g++) r += c->h_out256[(size_t)g * FIT_SLOT + t];
@@ -2146,9 +2198,26 @@ extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flim
   *M = (int)llround(acc[c->mfma_idx[13][13]]);
   c->last_nq = (int)nq;
   c->last_P = P; c->last_mp = mp; c->last_n_all = n_all;
-  c->recs_valid = want_recs && !fused_cap;      // the fused path leaves the records un-capped: a fetch re-materialises them
+  c->recs_valid = pl.want_recs && !pl.fused_cap;      // the fused path leaves the records un-capped: a fetch re-materialises them
   c->dbg_valid = c->debug_recs;
   return FLIMO_OK;
+}
+
+extern "C" int flimo_match_reduce(flimo_ctx* c, const double x26[26], const flimo_match_cfg* cfg, double HTH[144],
+                                  double HTh[12], int* M) {
+  if (!c || !x26 || !cfg || !HTH || !HTh || !M) return FLIMO_ERR_INVALID;
+  if (cfg->NUM_MATCH_POINTS < 3 || cfg->NUM_MATCH_POINTS > 8)
+    return fail(c, FLIMO_ERR_UNSUPPORTED, "NUM_MATCH_POINTS must be in 3..8 (a plane needs 3 points; the neighbour records hold 8)");
+  for (int i = 0; i < 144; i++) HTH[i] = 0.0;
+  for (int i = 0; i < 12; i++) HTh[i] = 0.0;
+  *M = 0;
+  PassPlan pl;
+  int rc = pass_plan(c, x26, cfg, pl);
+  if (rc == PASS_NOTHING) return FLIMO_OK;
+  if (rc) return rc;
+  if (pl.general_k) return pass_general_k(c, pl, HTH, HTh, M);
+  if ((rc = pass_launch(c, pl)) != FLIMO_OK) return rc;
+  return pass_collect(c, pl, HTH, HTh, M);
 }
 
 // ---- the whole iterated update enqueued at once (flimo_chain.h) ---------------------------------------------------------------
