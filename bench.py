@@ -49,7 +49,7 @@ def pmc_traffic(queries_per_launch):
     in separate passes of this same command, FETCH_SIZE doubled per MI355X_MICROARCH.md).  PMC counters cannot be collected
     from inside the run; the profile carries the hash of the kernel sources it was taken with and is only reported when that is
     the hash of the sources in the tree (and the launch shape is the benchmark's)."""
-    f = os.path.join(ROOT, "profiles", "r05", "pmc_fetch_write_per_kernel.json")
+    f = os.path.join(ROOT, "profiles", "r06", "pmc_fetch_write_per_kernel.json")
     try:
         from fast_limo_amd import build as b
         d = json.load(open(f))
@@ -199,7 +199,7 @@ HBM_REGIME = dict(rings=128, azimuths=2048, map_points=20000000, box=447.0)     
 def pmc_traffic_hbm_regime():
     """HBM-side bytes per launch at 256k x 20M from the committed PMC profile (same rule as pmc_traffic): the one-launch pass and
     the k-NN kernel of the passes that run as separate dispatches."""
-    f = os.path.join(ROOT, "profiles", "r05", "pmc_hbm_regime.json")
+    f = os.path.join(ROOT, "profiles", "r06", "pmc_hbm_regime.json")
     try:
         from fast_limo_amd import build as b
         d = json.load(open(f))
@@ -1003,7 +1003,7 @@ def main():
                                                       "event duration includes the wait for the pose, so `mean_launch_us` is taken from the dense series right after the "
                                                       "region, where every pass is launched when its pose is known (knn5_kernel<2, 8, true, false>)"
                                                       if pipe_found else "knn5_kernel<2, 8, true, false> (passes launched when their pose is known)"),
-                           "reproduce": "rocprofv3 --kernel-trace --stats of `FLIMO_PIPELINE=0 python3 bench.py --streams 0`: profiles/r05/bench_r05_prof_nopipeline_kernel_stats.csv, "
+                           "reproduce": "rocprofv3 --kernel-trace --stats of `FLIMO_PIPELINE=0 python3 bench.py --streams 0`: profiles/r06/bench_r06_prof_nopipeline_kernel_stats.csv, "
                                         "row knn5_kernel<2, 8, true, false>",
                            "step": {"value_regions": value_regions, "kernel_us_per_step": kernel_us_per_step,
                                     "step_minus_kernels_us": ((1e3 * 1e3 * elapsed / args.steps) - kernel_us_per_step["total"]) if kernel_us_per_step else None,
