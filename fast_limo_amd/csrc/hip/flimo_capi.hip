@@ -734,7 +734,7 @@ static int rebuild_grid(flimo_ctx* c) {
       float4* np = nullptr;
       HIPCHK(c, hipMalloc(&np, ncap * sizeof(float4)));
       HIPCHK(c, hipMemcpyAsync(np, c->d_map_sorted, std::min(ncap, c->sorted_cap) * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
-      const size_t ovf_words = (c->map_cap / 8 + 64) * 8;
+      const size_t ovf_words = (c->map_cap / 16 + 64) * 8;
       uint32_t* no = nullptr;
       if (ovf_words > c->idx.ovf_cap) {
         HIPCHK(c, hipMalloc(&no, ovf_words * sizeof(uint32_t)));

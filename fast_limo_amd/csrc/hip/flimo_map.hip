@@ -353,7 +353,7 @@ __device__ __forceinline__ void row_entries(const SegTab& T, uint32_t py, uint32
       if (!big) { *dst = make_uint2(pre, nib); return; }
       const uint2 old = *dst;
       const uint32_t slot_o = ((int)old.x < 0) ? old.y : atomicAdd(T.ovf_count, 1u);
-      if (slot_o < T.ovf_cap) {            // (the pool holds two slots per 16 points of the point buffer's capacity: a segment at a tile's edge takes two -- its own entry and the left tile's closing one)
+      if (slot_o < T.ovf_cap) {            // (the pool holds one slot per 16 points of the point buffer's capacity -- 2 bytes per point; a segment at a tile's edge takes two, its own entry and the left tile's closing one, and moved rows never hand slots back: when it does run out, the insert says so below)
         uint32_t a = 0u;
 #pragma unroll
         for (int k = 0; k < 8; k++) { T.ovf[(size_t)slot_o * 8u + k] = a; a += s_cnt[i * 8 + k]; }
@@ -499,7 +499,7 @@ hipError_t map_build_grid(hipStream_t st, const float4* pts_in, size_t n, float4
   }
   {
     size_t slots = T.ovf_cap;
-    if ((e = grow(T.ovf, slots, (pts_cap / 8 + 64) * 8, 0)) != hipSuccess) return e;
+    if ((e = grow(T.ovf, slots, (pts_cap / 16 + 64) * 8, 0)) != hipSuccess) return e;
     T.ovf_cap = slots;
     if ((e = grow(T.xstart, T.xstart_cap, grid_xstart_size(ny, nz, shape.ntx), grid_xstart_size(ny, nz, shape.ntx) / 2)) != hipSuccess) return e;
   }
