@@ -82,7 +82,7 @@ HIP_SYMBOLS = [
     "flimo_scan_to_world", "flimo_scan_clouds", "flimo_upload_stage", "flimo_match_reduce_overlap", "flimo_map_add_scan",
     "flimo_set_timing", "flimo_set_timing_stride", "flimo_pass_count", "flimo_fused_pass_count", "flimo_tie_stats", "flimo_map_index_bytes", "flimo_fine_stats", "flimo_map_grid_selfcheck", "flimo_set_debug_records", "flimo_last_kernel_ms",
     "flimo_last_candidates_per_query", "flimo_last_widen_count", "flimo_last_stragglers", "flimo_timing_totals", "flimo_timing_split", "flimo_set_path_switches", "flimo_set_wait_timeout_ms", "flimo_insert_rule_replay", "flimo_plane_fit5_host", "flimo_plane_eval5_host", "flimo_calculate_H_host",
-    "flimo_update_chain", "flimo_chain_stats", "flimo_set_update_mode", "flimo_update_mode", "flimo_scan_adopt", "flimo_set_pass_pipeline", "flimo_pass_pipeline_end", "flimo_pass_pipeline_stats",
+    "flimo_update_chain", "flimo_chain_stats", "flimo_set_update_mode", "flimo_update_mode", "flimo_scan_adopt", "flimo_set_pass_pipeline", "flimo_pass_pipeline_end", "flimo_pass_pipeline_last", "flimo_pass_pipeline_stats",
 ]
 
 _hip = None
@@ -165,6 +165,7 @@ def load_hip():
                                                np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS"), C.c_double]
     L.flimo_set_pass_pipeline.argtypes = [vp, C.c_int]
     L.flimo_pass_pipeline_end.argtypes = [vp]
+    L.flimo_pass_pipeline_last.argtypes = [vp]
     L.flimo_pass_pipeline_stats.argtypes = [vp, C.POINTER(C.c_ulonglong)]
     L.flimo_update_mode.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_double)]
     L.flimo_last_widen_count.restype = C.c_int

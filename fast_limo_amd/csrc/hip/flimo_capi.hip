@@ -222,6 +222,7 @@ struct flimo_ctx {
   bool pipeline_env = false;
   ChainHead* d_pipe_head = nullptr;      // fine-grained device memory (host-writable); nullptr: not available on this system
   unsigned int pipe_tag = 0;
+  bool pipe_last_hint = false;           // flimo_pass_pipeline_last: the next pass is its update's last -- nothing is queued behind it
   unsigned long long pipe_published = 0, pipe_cancelled = 0;   // statistics
   unsigned long long pipe_aged = 0, pipe_left = 0;             // passes found too old to be published to / that left before the publish reached them
   bool row_slack = true;                  // FLIMO_ROW_SLACK=0: a full layout packs the rows (A/B of the room behind every row)
@@ -1788,6 +1789,7 @@ struct PassPlan {
   int n_all = 0;                   // resident query set (== nq, or the whole scan when no cap binds)
   bool general_k = false;
   bool use_pre = false, was_pre = false;      // the pass queued ahead of this call is this call's / was published to
+  bool last_of_update = false;     // the caller said so (flimo_pass_pipeline_last): no pass is queued behind this one
   uint64_t grid_version = 0;
   const DeskewArgs* dkp = nullptr;            // a pending deskew rides on this pass's k-NN launch
   bool cap_binds = false, want_recs = false, want_count = false, fused_cap = false, use_fit2 = false;
@@ -1809,6 +1811,8 @@ constexpr int PASS_NOTHING = 2000;
 static int pass_plan(flimo_ctx* c, const double x26[26], const flimo_match_cfg* cfg, PassPlan& pl) {
   pl.cfg = cfg;
   pl.general_k = cfg->NUM_MATCH_POINTS != 5;
+  pl.last_of_update = c->pipe_last_hint;
+  c->pipe_last_hint = false;
   // (a pass queued ahead of this call -- pipelined host loop -- is either this call's, decided below before anything is queued, or
   //  told to leave: every early way out of this function cancels it)
   struct PreGuard { flimo_ctx* c; bool decided = false; ~PreGuard() { if (!decided) cancel_prelaunch(c); } } pre_guard{c};
@@ -2032,7 +2036,7 @@ static int pass_launch(flimo_ctx* c, PassPlan& pl) {
   //      ends and wait for their constants in device memory; the next call publishes them instead of launching (use_pre above).
   //      Only the usual case is queued ahead: a one-launch pass (by the straggler count its position published in the last scan),
   //      no fine pre-pass, no timing events, no records. ----
-  if (c->pipeline && c->d_pipe_head && c->prune && pl.use_fit2 && !pl.want_count && c->tail && c->fuse &&
+  if (c->pipeline && !pl.last_of_update && c->d_pipe_head && c->prune && pl.use_fit2 && !pl.want_count && c->tail && c->fuse &&
       mp.max_ring >= 2 && mp.max_ring <= 3 && !c->fine_valid && pl.inline_ties == pl.ties_on) {
     const unsigned long long nseq = seq + 1;
     const int ntlev = (c->timing == 1 && c->timing_stride > 1 && (nseq % (unsigned long long)c->timing_stride) != 0) ? 0 : c->timing;
@@ -2241,6 +2245,11 @@ extern "C" int flimo_set_pass_pipeline(flimo_ctx* c, int on) {
 extern "C" int flimo_pass_pipeline_end(flimo_ctx* c) {
   if (!c) return FLIMO_ERR_INVALID;
   cancel_prelaunch(c);
+  return FLIMO_OK;
+}
+extern "C" int flimo_pass_pipeline_last(flimo_ctx* c) {
+  if (!c) return FLIMO_ERR_INVALID;
+  c->pipe_last_hint = true;                            // (consumed by the next flimo_match_reduce)
   return FLIMO_OK;
 }
 extern "C" int flimo_pass_pipeline_stats(const flimo_ctx* c, unsigned long long out[4]) {

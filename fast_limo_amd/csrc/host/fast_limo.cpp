@@ -586,6 +586,10 @@ void Localizer::init_iKFoM() {                                     // Localizer.
     flimo_ctx* c = map_->ctx();
     if (c) (void)flimo_pass_pipeline_end(c);
   };
+  ikfom_->h_last_iteration = [this]() {
+    flimo_ctx* c = map_->ctx();
+    if (c) (void)flimo_pass_pipeline_last(c);
+  };
   ikfom_->h_dense = [this](flimo_host::DenseMeas& dm) {
     flimo_ctx* c = map_->ctx();
     size_t M = 0;

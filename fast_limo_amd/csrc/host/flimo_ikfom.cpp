@@ -890,8 +890,11 @@ void Esekf::update_iterated_dyn_share_modified(double R, double D) {
     }
     };
     if (inject) inject = false;                                 // (the device's pass at this very state)
-    else if (h_reduced_overlap) h_reduced_overlap(x_, meas, pre);    // esekfom.hpp:1637
-    else h_reduced(x_, meas);
+    else {
+      if (it == maximum_iter_ - 1 && h_last_iteration) h_last_iteration();      // (no pass can follow this one)
+      if (h_reduced_overlap) h_reduced_overlap(x_, meas, pre);    // esekfom.hpp:1637
+      else h_reduced(x_, meas);
+    }
     if (failed) { x_ = x_prop; P_ = P_prop; return; }          // the pass did not happen: nothing to update with
     if (!pre_done) pre();
     const int M = meas.M;

@@ -164,6 +164,9 @@ class Esekf {
   // called once when update_iterated_dyn_share_modified leaves, whichever way: a plug-in that queued a pass ahead of the loop's
   // next iteration (pipelined host loop, flimo_c.h: flimo_pass_pipeline_end) lets it go
   std::function<void()> h_update_end;
+  // called before the measurement of the loop's last possible iteration (i == maximum_iter - 1): a plug-in that queues passes ahead
+  // (flimo_pass_pipeline_last) need not queue one behind it
+  std::function<void()> h_last_iteration;
   std::vector<PassLog> log;
   bool keep_log = false;
   // true: literal two-inverse form of esekfom.hpp:1722-1729 and unconditional eigen-decomposition;

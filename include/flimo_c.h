@@ -250,6 +250,9 @@ int flimo_update_chain(flimo_ctx* ctx, const flimo_match_cfg* cfg, flimo_chain_i
  */
 int flimo_set_pass_pipeline(flimo_ctx* ctx, int on);
 int flimo_pass_pipeline_end(flimo_ctx* ctx);
+/* Optional hint of the same loop: the NEXT flimo_match_reduce is the last pass its update can run (the loop's i == maximum_iter - 1,
+ * esekfom.hpp:1634) -- nothing is queued behind it.  Without the hint one launch per update is queued for nothing and told to leave. */
+int flimo_pass_pipeline_last(flimo_ctx* ctx);
 int flimo_set_update_mode(flimo_ctx* ctx, int mode);
 int flimo_update_mode(const flimo_ctx* ctx, int* chained, double* launch_rtt_us);
 /* per-point records of the last flimo_match_reduce (first min(N, MAX_NUM_PC2MATCH) points) */
