@@ -84,7 +84,7 @@ def workload(rank: int, rings: int, az: int, nmap: int, L: float):
     mp = synth.box_world_map(nmap, L, 1)
     scan_seed = 2 if rank == 0 else 10 + rank        # cfg 2 on rank 0, cfg 5 seeds on the others
     scan = synth.velodyne_scan(rings, az, L, scan_seed)
-    imu = synth.stationary_imu(0.0, 5.4)            # 0.35 s are used by the registration, the rest by the end-to-end sweeps
+    imu = synth.stationary_imu(0.0, 6.6)            # 0.35 s are used by the registration, the rest by the end-to-end sweeps
     return mp, scan, imu
 
 
@@ -843,6 +843,26 @@ def main():
         loc.set_flags(add_to_map=True, download_clouds=False, keep_log=False)
         end_to_end = {"points_per_sweep": int(scan.shape[0])}
         k = 2
+        # The first sweeps inserted into a map that has never seen a sweep are slower than the ones behind them (raw sweeps crowd the
+        # cells under the sensor; the second level over that region comes into being after about ten of them:
+        # tests/dev/gpu_e2e_order_probe.py -- rounds 1-5 ran the "tied" leg FIRST and read those sweeps as the cost of tied stamps).
+        # They are run and reported on their own; the two legs behind them start from the same warmed map.
+        first = []
+        for j in range(12):
+            sc = synth.velodyne_scan(args.rings, args.azimuths, args.box, 500 + j)
+            sw = api.make_points_velodyne(sc)
+            until = 0.1 * (k + 1) + 0.005
+            while i < len(st) and st[i] <= until:
+                loc.update_imu(st[i], w[i], a[i]); i += 1
+            t1 = time.perf_counter()
+            rc = loc.update_pointcloud_points(sw, 0.1 * k)
+            loc.sync()
+            first.append(time.perf_counter() - t1)
+            assert rc == 0, rc
+            k += 1
+        end_to_end["first_sweeps_into_a_static_map"] = {"sweeps": len(first), "ms_per_sweep": 1e3 * float(np.median(first[1:])),
+                                                        "ms_first": 1e3 * first[0], "ms_each": [round(1e3 * t, 3) for t in first],
+                                                        "note": "tied stamps, each sweep waited for; the legs below follow on the same map"}
         for label in ("tied", "unique"):
             sweeps = []
             for j in range(2 * args.e2e_sweeps):
@@ -1045,6 +1065,8 @@ def main():
             flat["scans_per_s_long_region"] = value_regions.get("scans_per_s_region_of_%d_steps" % value_regions["long_region_steps"])
             flat["scans_per_s_median_of_regions"] = value_regions["scans_per_s_median"]
         if end_to_end:
+            if end_to_end.get("first_sweeps_into_a_static_map"):
+                flat["pcie_inclusive_ms_per_sweep_first_sweeps_into_a_static_map"] = end_to_end["first_sweeps_into_a_static_map"]["ms_per_sweep"]
             for key, src in (("tied", end_to_end.get("tied_stamps")), ("unique", end_to_end.get("unique_stamps")),
                              ("shipped", end_to_end.get("shipped_config")), ("shipped_tied", end_to_end.get("shipped_config_tied"))):
                 if not src:
