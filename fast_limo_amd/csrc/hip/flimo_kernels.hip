@@ -2474,7 +2474,6 @@ __global__ __launch_bounds__(256) void knn_far_kernel(GridView G, const float* _
                                                       int32_t* __restrict__ idx, float* __restrict__ sqd, int32_t* __restrict__ cnt) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int maxdim = grid_maxdim(G);
-  const float margin = 1.0e-3f + 4.0e-7f * (float)maxdim;
   const double none = __longlong_as_double((long long)KEY_NONE);
   const int ndir = G.ntx * G.nty * G.ntz;
   const int cells_per_xtile = max(1, (8 << G.ts) / G.xs);
@@ -2490,8 +2489,9 @@ __global__ __launch_bounds__(256) void knn_far_kernel(GridView G, const float* _
                 flz = floorf(fminf(fmaxf(fz, -1.0e9f), 1.0e9f));
     const int cx = (int)flx - G.six, cy = (int)fly - G.siy, cz = (int)flz - G.siz;
     const float rx = fminf(fmaxf(fx - flx, 0.f), 1.f), ry = fminf(fmaxf(fy - fly, 0.f), 1.f), rz = fminf(fmaxf(fz - flz, 0.f), 1.f);
-    // the query in grid cell units
+    // the query in grid cell units (a query a million cells away: its own coordinate's rounding joins the margin)
     const float qcx = (float)cx + rx, qcy = (float)cy + ry, qcz = (float)cz + rz;
+    const float margin = 1.0e-3f + 4.0e-7f * fmaxf((float)maxdim, fmaxf(fmaxf(fabsf(qcx), fabsf(qcy)), fabsf(qcz)));
     double k5[6] = {none, none, none, none, none, none};          // this lane's own candidates (every point is seen by one lane, once)
     float bnd2 = INFINITY;                                        // ball of the k-th best so far, cell units squared, inflated
     float last_d = -1.f;

@@ -93,6 +93,16 @@ def test_knn_small_k_and_empty_map(built):
     np.testing.assert_allclose(sqd[0, :3], [0.01, 0.81, 1.01], rtol=1e-6)
     idx, sqd, cnt = c.knn(np.array([[0.1, 0, 0]], np.float32), 2)
     assert cnt[0] == 2
+    # from anywhere (the tiles' best-first search): a query 40 km away, one 2000 km away, a NaN query, every k
+    far = np.array([[40000.0, -3.0, 2.0], [2.0e6, 2.0e6, -1.0e6], [np.nan, 0, 0], [-7.5, 0.2, 0.1]], np.float32)
+    for k in (1, 2, 3, 4, 5):
+        idx, sqd, cnt = c.knn(far, k)
+        assert list(cnt) == [min(k, 3), min(k, 3), 0, min(k, 3)], (k, cnt)
+        for q in (0, 1, 3):
+            d = np.sort(((pts[[0, 1, 3]].astype(np.float32) - far[q]) ** 2).astype(np.float32).sum(1, dtype=np.float32))
+            np.testing.assert_allclose(sqd[q, :min(k, 3)], d[:min(k, 3)], rtol=1e-6)
+            assert np.all(idx[q, min(k, 3):] == -1) and np.all(idx[q, :min(k, 3)] >= 0)
+        assert np.all(idx[2] == -1)
     c.close()
 
 
