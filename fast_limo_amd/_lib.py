@@ -453,6 +453,10 @@ class HipCtx:
     def pass_pipeline_end(self):
         self._chk(self._L.flimo_pass_pipeline_end(self._h))
 
+    def pass_pipeline_last(self):
+        """The next match_reduce is the last pass its update can run: nothing is queued behind it."""
+        self._chk(self._L.flimo_pass_pipeline_last(self._h))
+
     def pass_pipeline_stats(self):
         o = (C.c_ulonglong * 4)()
         self._chk(self._L.flimo_pass_pipeline_stats(self._h, o))

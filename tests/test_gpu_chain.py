@@ -184,10 +184,15 @@ def test_pipelined_host_loop_is_bit_equal_and_lets_its_last_pass_go(built, monke
         h.map_add(np.ascontiguousarray(mp[:, :3]))
         h.scan_set(np.ascontiguousarray(scan5[:, :3]))
         h.set_pass_pipeline(on)
-        got[on] = [h.match_reduce(xk, cfg) for xk in xs]
+        got[on] = []
+        for j, xk in enumerate(xs):
+            if j == len(xs) - 1:
+                h.pass_pipeline_last()                                # (the filter's hint: no pass can follow this one)
+            got[on].append(h.match_reduce(xk, cfg))
         h.pass_pipeline_end()
         s_ = h.pass_pipeline_stats()
         assert (s_["published"] >= 1) == on, s_
+        assert s_["cancelled"] == 0, s_                               # nothing was queued behind the last pass: nothing to let go
         t0 = time.perf_counter()
         h.map_add(np.ascontiguousarray(mp[:1000, :3] + 0.01))         # other work on the context: nothing in its way
         assert time.perf_counter() - t0 < 0.15
