@@ -664,6 +664,9 @@ def main():
     loc.host_profile(reset=True)
     barrier()
     step_marks = [] if os.environ.get("FLIMO_BENCH_STEP_TIMES") else None      # developer: the region's profile, step by step
+    import gc
+    gc.collect()
+    gc.disable()                       # (a collector pause inside a 3 ms region is a fifth of it: the interpreter's, not the path's)
     t0 = time.perf_counter()
     if step_marks is None:
         for _ in range(args.steps):
@@ -674,6 +677,7 @@ def main():
             step_marks.append(time.perf_counter())
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     if step_marks:
         print("step times [us]: " + " ".join("%.0f" % (1e6 * d) for d in np.diff([t0] + step_marks)), file=sys.stderr)
     tot = loc.hip.timing_totals()
