@@ -652,9 +652,17 @@ def main():
         auto_stride = 1 << 30           # a short run (the driver's 20 steps last 3 ms) is not sampled at all: three timed passes would
                                         # cost 3 % of it; the dense series below provides the kernel statistics
     loc.hip.set_timing_stride(int(os.environ.get('FLIMO_BENCH_TIMING_STRIDE', str(auto_stride))))
+    # (setup: the first barrier of a process initialises torch's own HIP context; it belongs here, ahead of the warm-up, not between
+    #  the warm-up and the timed region)
+    barrier()
     # W untimed warm-up steps, exactly (the registration above that made the scan resident and `step()` for x_step are setup)
+    warm_marks = []
     for _ in range(args.warmup):
+        tw0 = time.perf_counter()
         step()
+        warm_marks.append(time.perf_counter() - tw0)
+    if os.environ.get("FLIMO_BENCH_STEP_TIMES"):
+        print("warm-up step times [us]: " + " ".join("%.0f" % (1e6 * d) for d in warm_marks), file=sys.stderr)
     loc.hip.timing_totals(reset=True)
     loc.hip.timing_split(reset=True)
     loc.hip.chain_stats(reset=True)
@@ -665,8 +673,8 @@ def main():
     barrier()
     step_marks = [] if os.environ.get("FLIMO_BENCH_STEP_TIMES") else None      # developer: the region's profile, step by step
     import gc
-    gc.collect()
-    gc.disable()                       # (a collector pause inside a 3 ms region is a fifth of it: the interpreter's, not the path's)
+    gc.disable()                       # (a collector pause inside a 3 ms region is a fifth of it: the interpreter's, not the path's.  No
+                                       #  gc.collect() here: a full collection right before the region costs its first step 60 us of cold caches)
     t0 = time.perf_counter()
     if step_marks is None:
         for _ in range(args.steps):
