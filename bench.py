@@ -742,7 +742,14 @@ def main():
     kernel_us_per_step = None
     if int(os.environ.get('FLIMO_BENCH_TIMING', '1')) == 1:
         loc.hip.set_timing_stride(1)
+        # (the series as rounds 3-5 ran it, each pass's events read right behind it: the host's reading leaves the GPU idle half
+        # of the time, and on some boxes its clocks follow -- kept as a second figure, never the one the roofline uses)
         loc.hip.timing_split(reset=True)
+        for _ in range(12):
+            step()
+        d0 = loc.hip.timing_split(reset=True)
+        read_behind_us = (1e3 * d0["fused_ms"] / d0["fused_n"]) if d0["fused_n"] else None
+        loc.hip.set_timing_deferred(True)          # events read after the series: the passes run back to back as they do untimed
         loc.hip.chain_stats(reset=True)
         for _ in range(12):
             step()
@@ -756,7 +763,9 @@ def main():
         dense = {"one_launch_pass_us": (1e3 * d["fused_ms"] / d["fused_n"]) if d["fused_n"] else None, "one_launch_passes_timed": d["fused_n"],
                  "separate_dispatch_pass_us": ({"knn": 1e3 * d["knn_ms"] / d["separate_n"], "widen": 1e3 * d["widen_ms"] / d["separate_n"],
                                                 "fit_reduce": 1e3 * d["fit_ms"] / d["separate_n"]} if d["separate_n"] else None),
-                 "separate_dispatch_passes_timed": d["separate_n"]}
+                 "separate_dispatch_passes_timed": d["separate_n"],
+                 "one_launch_pass_us_events_read_behind_each_pass": read_behind_us,
+                 "note": "every pass of 12 steps carries its events; they are read after the series (flimo_set_timing_deferred), so the passes run back to back as in the timed region"}
     x_end = loc.get_x()
     # Every step must land on the same state, bit for bit when every step runs the same pass layout.  The full-path registration
     # that made the scan resident (x_ref) may have used another layout for some passes (256k x 20M: its later passes ran as one
@@ -782,6 +791,7 @@ def main():
         if d["separate_n"]:
             knn_stage = {"knn_us": 1e3 * d["knn_ms"] / d["separate_n"], "widen_us": 1e3 * d["widen_ms"] / d["separate_n"],
                          "fit_us": 1e3 * d["fit_ms"] / d["separate_n"], "passes_timed": d["separate_n"]}
+    loc.hip.set_timing_deferred(False)
     loc.hip.set_timing(0)
     if knn_stage:
         step()          # back on the one-launch path: same state as at the end of the timed region
@@ -1017,7 +1027,8 @@ def main():
         in_region_us = us(split["fused_ms"], split["fused_n"])      # sparse samples inside the timed region (each perturbs the wall time)
         one_us = dense["one_launch_pass_us"] if (dense and dense.get("one_launch_pass_us")) else in_region_us
         # ^ mean duration of the one-launch pass from HIP events on its dispatch: the dense series (every pass of 12 steps timed,
-        #   right after the timed region) when it ran -- a timed dispatch issued once in 30 passes runs cold and reads ~10 % long
+        #   right after the timed region, events read after the series) when it ran -- a timed dispatch issued once in 30 passes
+        #   runs cold and reads ~10 % long
         sep = {"knn": us(split["knn_ms"], split["separate_n"]), "widen": us(split["widen_ms"], split["separate_n"]),
                "fit_reduce": us(split["fit_ms"], split["separate_n"])} if split["separate_n"] else None
         if one_us:

@@ -80,7 +80,7 @@ HIP_SYMBOLS = [
     "flimo_scan_voxel_filter", "flimo_raw_scan_set", "flimo_raw_scan_filter_set", "flimo_raw_scan_filter_order_set", "flimo_raw_scan_order", "flimo_deskew_resident", "flimo_deskew_resident_offset", "flimo_deskew",
     "flimo_match_reduce", "flimo_match_fetch", "flimo_match_fetch_H",
     "flimo_scan_to_world", "flimo_scan_clouds", "flimo_upload_stage", "flimo_match_reduce_overlap", "flimo_map_add_scan",
-    "flimo_set_timing", "flimo_set_timing_stride", "flimo_pass_count", "flimo_fused_pass_count", "flimo_tie_stats", "flimo_map_index_bytes", "flimo_fine_stats", "flimo_map_grid_selfcheck", "flimo_set_debug_records", "flimo_last_kernel_ms",
+    "flimo_set_timing", "flimo_set_timing_stride", "flimo_set_timing_deferred", "flimo_pass_count", "flimo_fused_pass_count", "flimo_tie_stats", "flimo_map_index_bytes", "flimo_fine_stats", "flimo_map_grid_selfcheck", "flimo_set_debug_records", "flimo_last_kernel_ms",
     "flimo_last_candidates_per_query", "flimo_last_widen_count", "flimo_last_stragglers", "flimo_timing_totals", "flimo_timing_split", "flimo_set_path_switches", "flimo_set_wait_timeout_ms", "flimo_insert_rule_replay", "flimo_plane_fit5_host", "flimo_plane_eval5_host", "flimo_calculate_H_host",
     "flimo_update_chain", "flimo_chain_stats", "flimo_set_update_mode", "flimo_update_mode", "flimo_scan_adopt", "flimo_set_pass_pipeline", "flimo_pass_pipeline_end", "flimo_pass_pipeline_last", "flimo_pass_pipeline_stats",
 ]
@@ -137,6 +137,7 @@ def load_hip():
     L.flimo_set_timing.argtypes = [vp, C.c_int]
     L.flimo_set_wait_timeout_ms.argtypes = [vp, C.c_int]
     L.flimo_set_timing_stride.argtypes = [vp, C.c_int]
+    L.flimo_set_timing_deferred.argtypes = [vp, C.c_int]
     L.flimo_pass_count.restype = C.c_ulonglong
     L.flimo_pass_count.argtypes = [vp]
     L.flimo_tie_stats.argtypes = [vp, C.POINTER(C.c_ulonglong)]
@@ -367,6 +368,10 @@ class HipCtx:
     def set_timing_stride(self, every=1):
         """Level 1 only: time every ``every``-th pass (sampling)."""
         self._chk(self._L.flimo_set_timing_stride(self._h, int(every)))
+
+    def set_timing_deferred(self, on=True):
+        """Read the timed passes' events when the totals are asked for, not right behind each pass (include/flimo_dev.h)."""
+        self._chk(self._L.flimo_set_timing_deferred(self._h, 1 if on else 0))
 
     def pass_count(self) -> int:
         return int(self._L.flimo_pass_count(self._h))

@@ -133,6 +133,14 @@ struct flimo_ctx {
   size_t stage_cap = 0;
   // timing
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [0,1] k-NN / fused dispatch, [2,3] fit, [4,5] widening
+  // deferred reading (flimo_set_timing_deferred): each timed pass takes the next set of a ring and nobody reads it until the totals
+  // are asked for -- reading a pass's events right behind it costs the host tens of microseconds per pass, and a GPU that idles
+  // through those lowers its clocks on some boxes (the same kernels then read 10-15 % long)
+  static constexpr int EV_RING = 64;
+  hipEvent_t ev_ring[EV_RING][6];
+  unsigned char ev_kind[EV_RING];   // bit 0: one-launch pass, bit 1: fit2 layout, bit 2: the widening was timed
+  int ev_pending = 0;
+  bool ev_ring_made = false, timing_deferred = false;
   float last_knn_ms = 0.f, last_widen_ms = 0.f, last_fit_ms = 0.f;
   int* h_wl_count = nullptr;   // pinned
   int last_widen_count = 0;
@@ -245,6 +253,7 @@ struct flimo_ctx {
 };
 
 constexpr size_t FRAMES_FG_SLOT = 8192;             // bytes per slot of flimo_ctx::d_frames_fg (about 70 IMU frames)
+static int timing_drain(flimo_ctx* c);            // reads the timed passes nobody has read yet (deferred reading)
 static inline void ctx_enter(flimo_ctx* c);       // hipSetDevice + a pass queued ahead of the filter's algebra is told to leave (see cancel_prelaunch)
 static int fail(flimo_ctx* c, int code, const char* fmt, ...) {
   char buf[512];
@@ -504,6 +513,7 @@ extern "C" void flimo_ctx_destroy(flimo_ctx* c) {
   for (int k = 0; k < 2; k++) if (c->h_frames[k]) (void)hipHostFree(c->h_frames[k]);
   map_scratch_free(c->scratch);
   for (int i = 0; i < 6; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  if (c->ev_ring_made) for (int r = 0; r < flimo_ctx::EV_RING; r++) for (int i = 0; i < 6; i++) (void)hipEventDestroy(c->ev_ring[r][i]);
   if (c->timeout_ev) (void)hipEventDestroy(c->timeout_ev);
   if (c->adopt_ev) (void)hipEventDestroy(c->adopt_ev);
   if (c->h_wl_count) (void)hipHostFree(c->h_wl_count);
@@ -1552,6 +1562,17 @@ extern "C" int flimo_set_timing(flimo_ctx* c, int level) {
   }
   return FLIMO_OK;
 }
+extern "C" int flimo_set_timing_deferred(flimo_ctx* c, int on) {
+  if (!c) return FLIMO_ERR_INVALID;
+  ctx_enter(c);
+  if (on && !c->ev_ring_made) {
+    for (int r = 0; r < flimo_ctx::EV_RING; r++) for (int i = 0; i < 6; i++) HIPCHK(c, hipEventCreate(&c->ev_ring[r][i]));
+    c->ev_ring_made = true;
+  }
+  if (!on && c->ev_pending) { const int rc = timing_drain(c); if (rc) return rc; }
+  c->timing_deferred = on != 0;
+  return FLIMO_OK;
+}
 extern "C" unsigned long long flimo_pass_count(const flimo_ctx* c) { return c ? c->pass_seq : 0ull; }
 extern "C" unsigned long long flimo_fused_pass_count(const flimo_ctx* c) { return c ? c->fused_passes : 0ull; }
 extern "C" int flimo_fine_stats(const flimo_ctx* c, unsigned long long out[4]) {
@@ -1600,6 +1621,7 @@ extern "C" int flimo_last_stragglers(const flimo_ctx* c) { return c ? c->last_st
 extern "C" int flimo_timing_totals(flimo_ctx* c, double* knn_ms, double* widen_ms, double* fit_ms, long long* passes,
                                    long long* queries, int reset) {
   if (!c) return FLIMO_ERR_INVALID;
+  if (c->ev_pending) { ctx_enter(c); const int rc = timing_drain(c); if (rc) return rc; }
   if (knn_ms) *knn_ms = c->tot_knn_ms;
   if (widen_ms) *widen_ms = c->tot_widen_ms;
   if (fit_ms) *fit_ms = c->tot_fit_ms;
@@ -1617,6 +1639,7 @@ extern "C" int flimo_set_path_switches(flimo_ctx* c, int tail, int fuse) {
 }
 extern "C" int flimo_timing_split(flimo_ctx* c, double out[6], int reset) {
   if (!c || !out) return FLIMO_ERR_INVALID;
+  if (c->ev_pending) { ctx_enter(c); const int rc = timing_drain(c); if (rc) return rc; }
   out[0] = c->split_fused_ms; out[1] = (double)c->split_fused_n;
   out[2] = c->split_knn_ms; out[3] = c->split_widen_ms; out[4] = c->split_fit_ms; out[5] = (double)c->split_sep_n;
   if (reset) { c->split_fused_ms = c->split_knn_ms = c->split_widen_ms = c->split_fit_ms = 0.0; c->split_fused_n = c->split_sep_n = 0; }
@@ -1794,6 +1817,7 @@ struct PassPlan {
   const DeskewArgs* dkp = nullptr;            // a pending deskew rides on this pass's k-NN launch
   bool cap_binds = false, want_recs = false, want_count = false, fused_cap = false, use_fit2 = false;
   int tlev = 0;                    // timing level of THIS pass
+  hipEvent_t* ev = nullptr;        // its events (the context's set, or the next of the ring when reading is deferred)
   int tail_max = 0;
   bool tail = false, fused = false, after_fine = false, widen_timed = false;
   unsigned long long seq = 0;
@@ -1873,6 +1897,7 @@ static int pass_plan(flimo_ctx* c, const double x26[26], const flimo_match_cfg* 
   pl.tpa = g_prof_pass ? now_us() : 0.0;
   // effective level of THIS pass (level 1 may sample every timing_stride-th pass)
   pl.tlev = (c->timing == 1 && c->timing_stride > 1 && ((c->pass_seq + 1) % (unsigned long long)c->timing_stride) != 0) ? 0 : c->timing;
+  pl.ev = (c->timing_deferred && c->ev_ring_made) ? c->ev_ring[c->ev_pending] : c->ev;
   // level 1: the two events ride on the k-NN dispatch itself (kernel begin / end, no extra packets)
   // the k-NN launch finishes its own stragglers (in-kernel tail) for gates of up to 3 rings; the worklist + widening dispatch
   // remains for wider gates and for the developer switch FLIMO_TAIL=0
@@ -1987,13 +2012,13 @@ static int pass_launch(flimo_ctx* c, PassPlan& pl) {
     // its launch is on the GPU already
   } else if (pl.fused) {
     launch_match_fused(c->stream, c->grid, c->d_scan_sorted, n_all, P, mp, c->d_nbr, c->d_wl, c->d_wl_count, nullptr, c->prev,
-                       c->live_idx, c->d_fit2_partials, c->d_granules_host, c->d_ticket, seq, tlev == 1 ? c->ev[0] : nullptr,
-                       tlev == 1 ? c->ev[1] : nullptr, &pl.tl, pl.after_fine ? 1 : 0, pl.dkp, nullptr, nullptr, pl.bookp);
+                       c->live_idx, c->d_fit2_partials, c->d_granules_host, c->d_ticket, seq, tlev == 1 ? pl.ev[0] : nullptr,
+                       tlev == 1 ? pl.ev[1] : nullptr, &pl.tl, pl.after_fine ? 1 : 0, pl.dkp, nullptr, nullptr, pl.bookp);
     c->fused_passes++;
   } else
   launch_knn5(c->stream, 2, c->grid, c->d_scan_sorted, n_all, P, mp.max_ring, c->d_nbr, c->d_wl,
-              c->d_wl_count, c->debug_recs ? c->d_cand : nullptr, c->prev, pl.tail ? 1 : 0, tlev == 1 ? c->ev[0] : nullptr,
-              tlev == 1 ? c->ev[1] : nullptr, nullptr, &pl.tl, pl.after_fine ? 1 : 0, seq, pl.dkp);
+              c->d_wl_count, c->debug_recs ? c->d_cand : nullptr, c->prev, pl.tail ? 1 : 0, tlev == 1 ? pl.ev[0] : nullptr,
+              tlev == 1 ? pl.ev[1] : nullptr, nullptr, &pl.tl, pl.after_fine ? 1 : 0, seq, pl.dkp);
   c->prev_before = c->prev;
   if (c->prune) { memcpy(c->prev.RT, P.RT, sizeof(c->prev.RT)); c->prev.valid = 1; }   // the records now belong to this pose
   pl.tpb = g_prof_pass ? now_us() : 0.0;
@@ -2003,7 +2028,7 @@ static int pass_launch(flimo_ctx* c, PassPlan& pl) {
   // retired in round 4 by design.)
   if (!pl.tail)
     launch_widen(c->stream, c->grid, c->d_scan_sorted, P, mp.max_ring, c->d_nbr, c->d_wl, c->d_wl_count,
-                 c->debug_recs ? c->d_cand : nullptr, pl.widen_timed ? c->ev[4] : nullptr, pl.widen_timed ? c->ev[5] : nullptr, &pl.tl);
+                 c->debug_recs ? c->d_cand : nullptr, pl.widen_timed ? pl.ev[4] : nullptr, pl.widen_timed ? pl.ev[5] : nullptr, &pl.tl);
   pl.tpc = g_prof_pass ? now_us() : 0.0;
   if (pl.want_count) HIPCHK(c, hipMemcpyAsync(c->h_wl_count, c->d_wl_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   // fit + reductions; the last block writes the 16x16 accumulator to mapped host memory, publishes the
@@ -2012,7 +2037,7 @@ static int pass_launch(flimo_ctx* c, PassPlan& pl) {
     // the fit and the reduction ran inside the k-NN launch
   } else if (pl.use_fit2)
     launch_fit2(c->stream, c->grid, c->d_scan_sorted, n_all, c->d_nbr, P, mp, c->live_idx, c->d_fit2_partials, c->d_granules_host,
-                c->d_ticket, c->d_wl_count, seq, tlev == 1 ? c->ev[2] : nullptr, tlev == 1 ? c->ev[3] : nullptr, &pl.tl, nullptr, nullptr, pl.bookp);
+                c->d_ticket, c->d_wl_count, seq, tlev == 1 ? pl.ev[2] : nullptr, tlev == 1 ? pl.ev[3] : nullptr, &pl.tl, nullptr, nullptr, pl.bookp);
   else {
     // records / caps / debug / timing level 2 (synchronous): settle the ties before the rows are built, re-arm both counters after
     HIPCHK(c, hipGetLastError());
@@ -2056,6 +2081,42 @@ static int pass_launch(flimo_ctx* c, PassPlan& pl) {
       c->pre.grid_version = pl.grid_version; c->pre.end_code = pc.end_code; c->pre.t_launch = wall_s();
     }
   }
+  return FLIMO_OK;
+}
+
+// Level-1 timing: read one timed pass's events (kernel begin / end stamps of its dispatches) into the totals.
+static int timing_read(flimo_ctx* c, hipEvent_t* ev, int kind) {
+  const bool fused = kind & 1, use_fit2 = kind & 2, widen_timed = kind & 4;
+  if (hipEventElapsedTime(&c->last_knn_ms, ev[0], ev[1]) != hipSuccess) {      // not marked complete yet: wait for it
+    HIPCHK(c, hipEventSynchronize(ev[1]));
+    (void)hipEventElapsedTime(&c->last_knn_ms, ev[0], ev[1]);
+  }
+  c->tot_knn_ms += c->last_knn_ms;
+  if (fused) {
+    c->last_fit_ms = 0.f; c->last_widen_ms = 0.f;            // one dispatch: everything is in the k-NN figure
+    c->split_fused_ms += c->last_knn_ms; c->split_fused_n++;
+  } else if (use_fit2) {
+    c->last_widen_ms = 0.f;
+    if (widen_timed) {
+      if (hipEventElapsedTime(&c->last_widen_ms, ev[4], ev[5]) != hipSuccess) c->last_widen_ms = 0.f;
+      c->tot_widen_ms += c->last_widen_ms;
+    }
+    // the fit dispatch carries its own pair of events (kernel begin / end); the host saw the granules, the kernel's
+    // end-of-dispatch signal may still be a moment away
+    if (hipEventElapsedTime(&c->last_fit_ms, ev[2], ev[3]) != hipSuccess) {
+      HIPCHK(c, hipEventSynchronize(ev[3]));
+      (void)hipEventElapsedTime(&c->last_fit_ms, ev[2], ev[3]);
+    }
+    c->tot_fit_ms += c->last_fit_ms;
+    c->split_knn_ms += c->last_knn_ms; c->split_widen_ms += c->last_widen_ms; c->split_fit_ms += c->last_fit_ms; c->split_sep_n++;
+  }
+  return FLIMO_OK;
+}
+// the passes whose events nobody has read yet (deferred reading), oldest first
+static int timing_drain(flimo_ctx* c) {
+  const int n = c->ev_pending;
+  c->ev_pending = 0;
+  for (int i = 0; i < n; i++) { const int rc = timing_read(c, c->ev_ring[i], c->ev_kind[i]); if (rc) return rc; }
   return FLIMO_OK;
 }
 
@@ -2146,28 +2207,13 @@ static int pass_collect(flimo_ctx* c, PassPlan& pl, double HTH[144], double HTh[
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
   if (tlev) {
-    if (hipEventElapsedTime(&c->last_knn_ms, c->ev[0], c->ev[1]) != hipSuccess) {      // not marked complete yet: wait for it
-      HIPCHK(c, hipEventSynchronize(c->ev[1]));
-      (void)hipEventElapsedTime(&c->last_knn_ms, c->ev[0], c->ev[1]);
-    }
-    c->tot_knn_ms += c->last_knn_ms;
-    if (pl.fused) {
-      c->last_fit_ms = 0.f; c->last_widen_ms = 0.f;            // one dispatch: everything is in the k-NN figure
-      c->split_fused_ms += c->last_knn_ms; c->split_fused_n++;
-    } else if (pl.use_fit2) {
-      c->last_widen_ms = 0.f;
-      if (pl.widen_timed) {
-        if (hipEventElapsedTime(&c->last_widen_ms, c->ev[4], c->ev[5]) != hipSuccess) c->last_widen_ms = 0.f;
-        c->tot_widen_ms += c->last_widen_ms;
-      }
-      // level 1: the fit dispatch carries its own pair of events (kernel begin / end); the host saw the granules, the
-      // kernel's end-of-dispatch signal may still be a moment away
-      if (hipEventElapsedTime(&c->last_fit_ms, c->ev[2], c->ev[3]) != hipSuccess) {
-        HIPCHK(c, hipEventSynchronize(c->ev[3]));
-        (void)hipEventElapsedTime(&c->last_fit_ms, c->ev[2], c->ev[3]);
-      }
-      c->tot_fit_ms += c->last_fit_ms;
-      c->split_knn_ms += c->last_knn_ms; c->split_widen_ms += c->last_widen_ms; c->split_fit_ms += c->last_fit_ms; c->split_sep_n++;
+    const int kind = (pl.fused ? 1 : 0) | (pl.use_fit2 ? 2 : 0) | (pl.widen_timed ? 4 : 0);
+    if (pl.ev != c->ev) {                                         // deferred: the events stay unread (timing_drain)
+      c->ev_kind[c->ev_pending++] = (unsigned char)kind;
+      if (c->ev_pending == flimo_ctx::EV_RING) { const int rc = timing_drain(c); if (rc) return rc; }
+    } else {
+      const int rc = timing_read(c, c->ev, kind);
+      if (rc) return rc;
     }
     c->tot_passes++; c->tot_queries += n_all;
   }

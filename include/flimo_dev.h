@@ -10,10 +10,15 @@ extern "C" {
 
 /* GPU time [ms] of the stages of the last flimo_match_reduce, from HIP events on the ctx stream:
  * k-NN fast path, ring widening of the worklist, fit + reductions.  flimo_set_timing level:
- * 0 off, 1 k-NN kernel only (two events per pass), 2 every stage. */
+ * 0 off, 1 on: every dispatch of a pass carries its own begin / end events (no extra packets on the stream). */
 int flimo_set_timing(flimo_ctx* ctx, int level);
 /* level 1 only: time every `every`-th pass (default 1 = all); the totals count the timed passes only. */
 int flimo_set_timing_stride(flimo_ctx* ctx, int every);
+/* on != 0: the events of flimo_match_reduce's timed passes are read when the totals are asked for (flimo_timing_totals /
+ * flimo_timing_split; at the latest after 64 timed passes) instead of right behind each pass.  Reading costs the host tens of
+ * microseconds per pass; a series in which every pass is timed then leaves the GPU idle half of the time, and on some boxes its
+ * clocks follow (the same kernels read 10-15 % long).  flimo_last_kernel_ms reports the last pass READ, not the last run. */
+int flimo_set_timing_deferred(flimo_ctx* ctx, int on);
 /* number of flimo_match_reduce passes launched on this context so far */
 unsigned long long flimo_pass_count(const flimo_ctx* ctx);
 /* ... of which ran as ONE launch (k-NN + in-kernel widening + fit + reduction); the others used separate dispatches (first pass
