@@ -81,7 +81,7 @@ HIP_SYMBOLS = [
     "flimo_match_reduce", "flimo_match_fetch", "flimo_match_fetch_H",
     "flimo_scan_to_world", "flimo_scan_clouds", "flimo_upload_stage", "flimo_match_reduce_overlap", "flimo_map_add_scan",
     "flimo_set_timing", "flimo_set_timing_stride", "flimo_set_timing_deferred", "flimo_pass_count", "flimo_fused_pass_count", "flimo_tie_stats", "flimo_map_index_bytes", "flimo_fine_stats", "flimo_map_grid_selfcheck", "flimo_set_debug_records", "flimo_last_kernel_ms",
-    "flimo_last_candidates_per_query", "flimo_last_widen_count", "flimo_last_stragglers", "flimo_timing_totals", "flimo_timing_split", "flimo_set_path_switches", "flimo_set_wait_timeout_ms", "flimo_insert_rule_replay", "flimo_plane_fit5_host", "flimo_plane_eval5_host", "flimo_calculate_H_host",
+    "flimo_last_candidates_per_query", "flimo_last_widen_count", "flimo_last_stragglers", "flimo_stragglers_by_pass", "flimo_timing_totals", "flimo_timing_split", "flimo_set_path_switches", "flimo_set_wait_timeout_ms", "flimo_insert_rule_replay", "flimo_plane_fit5_host", "flimo_plane_eval5_host", "flimo_calculate_H_host",
     "flimo_update_chain", "flimo_chain_stats", "flimo_set_update_mode", "flimo_update_mode", "flimo_scan_adopt", "flimo_set_pass_pipeline", "flimo_pass_pipeline_end", "flimo_pass_pipeline_last", "flimo_pass_pipeline_stats",
 ]
 
@@ -173,6 +173,7 @@ def load_hip():
     L.flimo_last_widen_count.argtypes = [vp]
     L.flimo_last_stragglers.restype = C.c_int
     L.flimo_last_stragglers.argtypes = [vp]
+    L.flimo_stragglers_by_pass.argtypes = [vp, C.POINTER(C.c_int)]
     L.flimo_last_candidates_per_query.restype = C.c_double
     L.flimo_last_candidates_per_query.argtypes = [vp]
     for name in HIP_SYMBOLS:
@@ -480,6 +481,11 @@ class HipCtx:
 
     def last_stragglers(self) -> int:
         return int(self._L.flimo_last_stragglers(self._h))
+
+    def stragglers_by_pass(self):
+        o = (C.c_int * 4)()
+        self._chk(self._L.flimo_stragglers_by_pass(self._h, o))
+        return [int(v) for v in o]
 
     def last_candidates_per_query(self) -> float:
         return float(self._L.flimo_last_candidates_per_query(self._h))

@@ -38,6 +38,7 @@ struct flimo_ctx {
   // config
   flimo_map_cfg map_cfg{0.2f, 2, 1, 0.5f};
   int timing = 0;                  // 0 off, 1 k-NN kernel only (events ride on its dispatch), 2 every stage
+  int tail_max_env = 0;            // developer: FLIMO_TAIL_MAX overrides the straggler count up to which a launch finishes its own
   int timing_stride = 1;           // level 1: time every n-th pass only (sampling keeps the perturbation small)
   bool debug_recs = false;
   // map
@@ -340,6 +341,7 @@ static void load_dev_switches(flimo_ctx* c) {
   if (env_int("FLIMO_TEST_PUBLISH_DELAY_MS", v) && v > 0) c->test_publish_delay_ms = v;
   if (env_int("FLIMO_TEST_TIGHT_ARRAY", v)) c->test_tight_array = v != 0;
   if (env_int("FLIMO_ROW_SLACK", v)) c->row_slack = v != 0;
+  if (env_int("FLIMO_TAIL_MAX", v) && v > 0) c->tail_max_env = v;
 }
 
 // Does the GPU see what the HOST stores into this allocation?  The host writes a pattern into the head's epoch word (a plain store
@@ -1618,6 +1620,11 @@ extern "C" int flimo_last_kernel_ms(const flimo_ctx* c, float* knn_ms, float* wi
 }
 extern "C" int flimo_last_widen_count(const flimo_ctx* c) { return c ? c->last_widen_count : 0; }
 extern "C" int flimo_last_stragglers(const flimo_ctx* c) { return c ? c->last_stragglers : -1; }
+extern "C" int flimo_stragglers_by_pass(const flimo_ctx* c, int out[4]) {
+  if (!c || !out) return FLIMO_ERR_INVALID;
+  for (int i = 0; i < 4; i++) out[i] = c->stragglers_hist[i];
+  return FLIMO_OK;
+}
 extern "C" int flimo_timing_totals(flimo_ctx* c, double* knn_ms, double* widen_ms, double* fit_ms, long long* passes,
                                    long long* queries, int reset) {
   if (!c) return FLIMO_ERR_INVALID;
@@ -1911,7 +1918,7 @@ static int pass_plan(flimo_ctx* c, const double x26[26], const flimo_match_cfg* 
   // sweeps over a 900 m map) keeps thousands of points beyond their 3x3x3 block in every pass
   // The bound grows with the scan: what hurts is a wave whose queries are ALL pending (one long chain), and a launch of n
   // queries spreads 1/64 of them over its waves a handful at a time
-  pl.tail_max = std::max(1024, pl.n_all / 64);
+  pl.tail_max = c->tail_max_env > 0 ? c->tail_max_env : std::max(1024, pl.n_all / 64);
   const bool tail_here = first_pass ? (c->stragglers_hist[0] <= pl.tail_max)
                                     : (c->stragglers_hist[c->pass_in_scan] <= pl.tail_max);
   pl.tail = c->tail && tail_here && mp.max_ring >= 2 && mp.max_ring <= 3;

@@ -49,6 +49,9 @@ int flimo_last_widen_count(const flimo_ctx* ctx);
 /* the same count as published by the pass itself with its result (fast path), -1 when the last pass took a path that does
  * not report it (records / caps / timing level 2) */
 int flimo_last_stragglers(const flimo_ctx* ctx);
+/* ... by the pass's position within its scan, as last reported: out[0] first pass .. out[3] fourth and later (what decides the
+ * layout of the pass at the same position of the next scan) */
+int flimo_stragglers_by_pass(const flimo_ctx* ctx, int out[4]);
 /* mean number of candidate map points examined per query in the last pass */
 double flimo_last_candidates_per_query(const flimo_ctx* ctx);
 
