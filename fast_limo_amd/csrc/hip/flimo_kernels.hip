@@ -985,6 +985,11 @@ __device__ __forceinline__ void knn5_pass(const GridView& G, uint16_t* dir, cons
   } else {
     sp = scan_sorted[in_range ? p : 0];
   }
+  // the query's record of the previous pass (its bound) travels with the point: issued here, it shares the point's round trip --
+  // behind the directory's barrier (where the compiler leaves it) it was a round trip of its own in every workgroup's chain
+  const bool want_rec = (prev_valid || (!FINE && fa.fine_mode == 1)) && in_range;
+  int4 rec_early = make_int4(0, 0, 0, 0);
+  if (want_rec) rec_early = reinterpret_cast<const int4*>(&nbr[p])[1];       // idx[4], flag, d5 bits, "d5 valid"
   // (the directory's loads were issued before the query's: into shared memory now, behind a barrier)
   if (dir_pending) grid_dir_store(dir, *dir_pending);
   float gx, gy, gz;
@@ -998,8 +1003,8 @@ __device__ __forceinline__ void knn5_pass(const GridView& G, uint16_t* dir, cons
   float b2 = INFINITY;                               // bound, squared, in cell units
   bool resolved = false;                             // settled by the fine pre-pass of this pass: nothing to search
   int4 pa_res = make_int4(0, 0, 0, 0), pb_res = make_int4(0, 0, 0, 0);
-  if ((prev_valid || (!FINE && fa.fine_mode == 1)) && in_range) {
-    const int4 pb = reinterpret_cast<const int4*>(&nbr[p])[1];       // idx[4], flag, d5 bits, "d5 valid"
+  if (want_rec) {
+    const int4 pb = rec_early;
     // (a record settled by the fine pre-pass of THIS pass carries flag 4 and the pass number in the upper bits of w: a stale or
     //  never-written record cannot be mistaken for one)
     if (!FINE && fa.fine_mode == 1 && pb.y == 4 && ((uint32_t)pb.w >> 8) == (uint32_t)(fa.seq & 0xffffffull)) {
