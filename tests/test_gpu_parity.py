@@ -645,6 +645,52 @@ def test_separate_dispatch_pass_is_bit_reproducible(built):
 
 
 @pytest.mark.gpu
+def test_timed_series_read_after_the_series_counts_every_pass(built):
+    """flimo_set_timing_deferred (include/flimo_dev.h): every pass of a timed series carries its own events and nobody reads them
+    until the totals are asked for.  The same poses timed both ways: equal sums (timing never touches a result), the same number of
+    passes of each layout in the totals, durations in the same range -- and more timed passes than the ring holds (64) lose none."""
+    from fast_limo_amd import _lib
+    mcfg = _lib.default_match_cfg(**CAPS)
+    mp = synth.box_world_map(200000, 25.0, 1)
+    scan = np.ascontiguousarray(synth.velodyne_scan(32, 512, 25.0, 3)[:, :3])
+    c = _lib.HipCtx(0)
+    try:
+        c.map_config(); c.map_add(mp); c.scan_set(scan)
+        x = np.zeros(26); x[6] = 1.0; x[0:3] = (0.3, -0.2, 0.05)
+        poses = []
+        for k in range(75):
+            y = x.copy(); y[0] += 1e-4 * k; poses.append(y)
+        res = {}
+        for deferred in (False, True):
+            for y in poses[:3]:                                  # the same history of bounds and straggler counts in both runs
+                c.match_reduce(y, mcfg)
+            c.set_timing(1); c.set_timing_stride(1); c.set_timing_deferred(deferred)
+            c.timing_split(reset=True); c.timing_totals(reset=True)
+            sums = [c.match_reduce(y, mcfg) for y in poses]
+            d = c.timing_split(reset=True)
+            tot = c.timing_totals(reset=True)
+            c.set_timing_deferred(False); c.set_timing(0)
+            res[deferred] = (sums, d, tot)
+        (s0, d0, t0), (s1, d1, t1) = res[False], res[True]
+        same_layouts = (d0["fused_n"], d0["separate_n"]) == (d1["fused_n"], d1["separate_n"])
+        for a, b in zip(s0, s1):
+            assert a[2] == b[2]
+            if same_layouts:                                     # (another layout partitions the sums differently: 1e-13)
+                np.testing.assert_array_equal(a[0], b[0]); np.testing.assert_array_equal(a[1], b[1])
+            else:
+                np.testing.assert_allclose(a[0], b[0], rtol=1e-11, atol=1e-9); np.testing.assert_allclose(a[1], b[1], rtol=1e-11, atol=1e-9)
+        assert d0["fused_n"] + d0["separate_n"] == len(poses) == d1["fused_n"] + d1["separate_n"]
+        assert t0["passes"] == t1["passes"] == len(poses)
+        if d0["fused_n"]:
+            m0, m1 = d0["fused_ms"] / d0["fused_n"], d1["fused_ms"] / d1["fused_n"]
+            assert 0.002 < m1 < 1.0 and 0.5 < m1 / m0 < 2.0, (m0, m1)
+        hist = c.stragglers_by_pass()
+        assert len(hist) == 4 and hist[3] == c.last_stragglers()
+    finally:
+        c.close()
+
+
+@pytest.mark.gpu
 def test_previous_pass_bound_prunes_exactly(built, oracle):
     """The k-NN fast path skips cells beyond (sqrt(d5 of the previous pass) + displacement); this must never change a
     result.  A context with the bound on and one with it off (FLIMO_PRUNE=0) walk the same pose sequence -- tiny steps
