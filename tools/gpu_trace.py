@@ -92,4 +92,20 @@ for k in (0, 1):
         for x in range(8):
             m = (np.arange(nb) % 8) == x
             print(f"  xcd {x}: median end {np.median(end[m]):6.2f}  last end {end[m].max():6.2f}  sum cand {int(tot[m].sum())}")
+# LATE=<n>: the n workgroups of the one-launch pass that took their group ticket last -- every stamp of each (what made them late?)
+if int(os.environ.get("LATE", 0)) and os.environ.get("FLIMO_FUSE", "1") != "0":
+    nb = nblk[0]
+    b0 = np.zeros(nb * 8, np.uint64); b1 = np.zeros(nb * 8, np.uint64)
+    assert lib.flimo_trace_read(0, b0.ctypes.data, b0.size) == 0 and lib.flimo_trace_read(1, b1.ctypes.data, b1.size) == 0
+    a = b0.reshape(nb, 8).astype(np.int64); f = b1.reshape(nb, 8).astype(np.int64)
+    t0 = a[:, 0].min()
+    rel = lambda v: (v - t0) / 100.0
+    order = np.argsort(-f[:, 5])
+    print("latest group tickets: block, xcd | start, query, bounds, candidates, merged, stored(tail) | fit starts, row computed, partial stored, ticket  [us]")
+    for b in order[:int(os.environ["LATE"])]:
+        print("  %4d %d | %5.2f %5.2f %5.2f %5.2f %5.2f %5.2f | %5.2f %5.2f %5.2f %5.2f" % (b, b % 8, rel(a[b, 0]), rel(a[b, 1]), rel(a[b, 2]), rel(a[b, 3]), rel(a[b, 4]),
+              rel(a[b, 5]), rel(f[b, 1]), rel(f[b, 3]), rel(f[b, 4]), rel(f[b, 5])))
+    med = lambda col: float(np.median(rel(col[col > 0])))
+    print("  median      | %5.2f %5.2f %5.2f %5.2f %5.2f %5.2f | %5.2f %5.2f %5.2f %5.2f" % (med(a[:, 0]), med(a[:, 1]), med(a[:, 2]), med(a[:, 3]), med(a[:, 4]), med(a[:, 5]),
+          med(f[:, 1]), med(f[:, 3]), med(f[:, 4]), med(f[:, 5])))
 ctx.close()
